@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""Generate golden input/output vectors from the REFERENCE's own Python.
+
+Run in the build container only (needs /root/reference; the GPU box does not
+have it):   python tests/golden/make_golden.py
+
+The reference package is not importable as a whole here (missing loguru,
+msgspec, ...), so this script loads the few pure-Python files it needs *by
+path* under stub parent packages, and lifts the torch reference functions out
+of the reference's test files with ``ast`` (source text is executed from where
+it lies; nothing is copied into this repo).  Outputs: small ``.npz`` fixtures
+under tests/golden/, committed, which pin ``oracle/`` (tests/test_oracle_golden.py).
+
+Sources exercised:
+  aphrodite/quantization/utils/quant_utils.py   quantize_weights, gptq_pack,
+      awq_pack, pack_cols, unpack_cols, sort_weights, permute_rows
+  tests/kernels/test_awq_triton.py              awq_dequantize_torch
+  tests/kernels/quant_utils.py                  ref_dynamic_per_token_quant,
+                                                ref_dynamic_per_tensor_fp8_quant
+  tests/kernels/test_cutlass.py                 baseline_scaled_mm
+  tests/kernels/test_attention.py               ref_single_query_cached_kv_attention
+  tests/kernels/test_cache.py                   (scatter reference, restated
+                                                 inline from :176-192)
+"""
+import ast
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = os.environ.get("APHRODITE_REFERENCE", "/root/reference")
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    m.__path__ = []
+    sys.modules[name] = m
+    return m
+
+
+def _load(name, relpath):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REF, relpath))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _lift(relpath, names, extra_globals):
+    """exec the named top-level functions/assignments of a reference file."""
+    src = open(os.path.join(REF, relpath)).read()
+    tree = ast.parse(src)
+    ns = dict(extra_globals)
+    for node in tree.body:
+        tgt = None
+        if isinstance(node, ast.FunctionDef) and node.name in names:
+            tgt = node
+        elif isinstance(node, ast.Assign) and any(
+                isinstance(t, ast.Name) and t.id in names for t in node.targets):
+            tgt = node
+        if tgt is not None:
+            seg = ast.get_source_segment(src, tgt).replace("'cuda'", "'cpu'")
+            exec(compile(seg, relpath, "exec"), ns)
+    return ns
+
+
+def load_reference():
+    class _Logger:
+        def __getattr__(self, _):
+            return lambda *a, **k: None
+    _stub("loguru", logger=_Logger())
+    _stub("aphrodite")
+    _stub("aphrodite.quantization")
+    _stub("aphrodite.quantization.utils")
+    _stub("aphrodite.quantization.qqq", MARLIN_QQQ_SUPPORTED_NUM_BITS=[4])
+    # The reference's pure-Python ScalarType (aphrodite/_core_ext.py:28-171) is
+    # a typing mock (min()/max() raise, uint() mis-sets the exponent); the
+    # real one is C++ (kernels/core/scalar_type.hpp:12-260), which is not built
+    # here.  Stand in a minimal integer-only type with the C++ semantics:
+    # value = stored - bias, min = (signed ? -2^(bits-1) : 0) - bias.
+    class ScalarType:
+        def __init__(self, size_bits, bias=0, signed=False):
+            self.size_bits, self.bias, self.signed = size_bits, bias, signed
+        def is_integer(self): return True
+        def is_signed(self): return self.signed
+        def has_bias(self): return self.bias != 0
+        def min(self):
+            return (-(1 << (self.size_bits - 1)) if self.signed else 0) - self.bias
+        def max(self):
+            return ((1 << (self.size_bits - (1 if self.signed else 0))) - 1) - self.bias
+        def __eq__(self, o):
+            return (self.size_bits, self.bias, self.signed) == (o.size_bits, o.bias, o.signed)
+        def __hash__(self):
+            return hash((self.size_bits, self.bias, self.signed))
+    class scalar_types:
+        uint4 = ScalarType(4)
+        uint8 = ScalarType(8)
+        uint4b8 = ScalarType(4, 8)
+        uint8b128 = ScalarType(8, 128)
+    st = _stub("aphrodite.scalar_type", ScalarType=ScalarType,
+               scalar_types=scalar_types)
+    qu = _load("aphrodite.quantization.utils.quant_utils",
+               "aphrodite/quantization/utils/quant_utils.py")
+    return st, qu
+
+
+def main():
+    st, qu = load_reference()
+    from typing import List, Optional, Tuple, Type, Union
+    g = dict(torch=torch, Optional=Optional, List=List, Tuple=Tuple,
+             Union=Union, Type=Type)
+
+    # ---------------- int4 formats --------------------------------------
+    torch.manual_seed(0)
+    K, N, G = 256, 64, 128
+    w = (torch.randn(K, N) * 0.02).half()
+    out = {}
+    w_ref, w_q, w_s, _ = qu.quantize_weights(w, st.scalar_types.uint4b8, G)
+    out.update(w=w.numpy(), sym_w_ref=w_ref.numpy(), sym_w_q=w_q.numpy(),
+               sym_w_s=w_s.numpy())
+    out["gptq_packed"] = qu.gptq_pack(w_q, 4, K, N).numpy()
+    w_ref2, w_q2, w_s2, w_zp2 = qu.quantize_weights(
+        w, st.scalar_types.uint4, G, zero_points=True)
+    out.update(zp_w_ref=w_ref2.numpy(), zp_w_q=w_q2.numpy(),
+               zp_w_s=w_s2.numpy(), zp_w_zp=w_zp2.numpy())
+    out["awq_packed"] = qu.awq_pack(w_q2, 4, K, N).numpy()
+    out["awq_zeros_packed"] = qu.awq_pack(w_zp2, 4, K // G, N).numpy()
+    out["pack_cols"] = qu.pack_cols(w_q2, 4, K, N).numpy()
+    out["unpack_cols"] = qu.unpack_cols(qu.pack_cols(w_q2, 4, K, N), 4, K, N).numpy()
+    # act-order helpers
+    torch.manual_seed(1)
+    w_ref3, w_q3, g_idx3, rand_perm3 = qu.permute_rows(w_q.clone(), w_ref.clone(), G)
+    q_sorted, g_sorted, sort_idx = qu.sort_weights(w_q3, g_idx3)
+    out.update(act_w_q=w_q3.numpy(), act_g_idx=g_idx3.numpy(),
+               act_rand_perm=rand_perm3.numpy(), act_sorted_q=q_sorted.numpy(),
+               act_sorted_g=g_sorted.numpy(), act_sort_idx=sort_idx.numpy(),
+               act_w_ref=w_ref3.numpy())
+    # AWQ dequant torch oracle of the reference test
+    ns = _lift("tests/kernels/test_awq_triton.py",
+               {"reverse_awq_order", "awq_dequantize_torch"}, g)
+    awq_dq = ns["awq_dequantize_torch"](
+        torch.from_numpy(out["awq_packed"]), w_s2,
+        torch.from_numpy(out["awq_zeros_packed"]), G)
+    out["awq_dequant"] = awq_dq.to(torch.float16).numpy()
+    np.savez_compressed(os.path.join(OUT, "int4_formats.npz"), **out)
+
+    # ---------------- fp8 quant + scaled mm -------------------------------
+    _stub("aphrodite.common")
+    _stub("aphrodite.common.utils", is_hip=lambda: False)
+    ns = _lift("tests/kernels/quant_utils.py",
+               {"ROCM_FP8_MAX", "FP8_DTYPE", "as_float32_tensor",
+                "ref_dynamic_per_token_quant",
+                "ref_dynamic_per_tensor_fp8_quant"},
+               dict(g, is_hip=lambda: False))
+    torch.manual_seed(2)
+    x = (torch.rand(7, 96) - 0.5) * 40
+    x[3] *= 1e-4                      # hits the min-scale floor
+    xh = x.half()
+    q_tok, s_tok = ns["ref_dynamic_per_token_quant"](xh, torch.float8_e4m3fn)
+    ub = torch.tensor([5.0])
+    q_ub, s_ub = ns["ref_dynamic_per_token_quant"](xh, torch.float8_e4m3fn, ub)
+    q_ten, s_ten = ns["ref_dynamic_per_tensor_fp8_quant"](xh)
+    f8 = {}
+    f8.update(x=xh.numpy(), q_tok=q_tok.view(torch.uint8).numpy(),
+              s_tok=s_tok.numpy(), q_ub=q_ub.view(torch.uint8).numpy(),
+              s_ub=s_ub.numpy(), ub=ub.numpy(),
+              q_ten=q_ten.view(torch.uint8).numpy(),
+              s_ten=np.asarray(s_ten.numpy()).reshape(1))
+    ns2 = _lift("tests/kernels/test_cutlass.py", {"baseline_scaled_mm"}, g)
+    torch.manual_seed(3)
+    a = (torch.randn(5, 64) * 2).to(torch.float8_e4m3fn)
+    b = (torch.randn(64, 48) * 2).to(torch.float8_e4m3fn)
+    sa = torch.rand(5, 1) + 0.1
+    sb = torch.rand(1, 48) + 0.1
+    bias = torch.randn(48)
+    mm = ns2["baseline_scaled_mm"](a, b, sa, sb, torch.float32, bias)
+    f8.update(mm_a=a.view(torch.uint8).numpy(), mm_b=b.view(torch.uint8).numpy(),
+              mm_sa=sa.numpy(), mm_sb=sb.numpy(), mm_bias=bias.numpy(),
+              mm_out=mm.numpy())
+    # codec KATs: every e4m3fn / e5m2 byte through torch's own decode
+    allb = torch.arange(256, dtype=torch.uint8)
+    f8["e4m3_table"] = allb.view(torch.float8_e4m3fn).float().numpy()
+    f8["e5m2_table"] = allb.view(torch.float8_e5m2).float().numpy()
+    np.savez_compressed(os.path.join(OUT, "fp8.npz"), **f8)
+
+    # ---------------- paged attention + cache write -----------------------
+    ns3 = _lift("tests/kernels/test_attention.py",
+                {"ref_masked_attention", "ref_single_query_cached_kv_attention"}, g)
+    torch.manual_seed(4)
+    S, Hq, Hkv, D, BS, NB = 4, 8, 2, 64, 16, 12
+    x_ = 4  # float32 cache -> x = 16/4
+    q = torch.randn(S, Hq, D) * 0.5
+    kc = (torch.rand(NB, Hkv, D // x_, BS, x_) - 0.5) * 2 * D ** -0.5 * 4
+    vc = (torch.rand(NB, Hkv, D, BS) - 0.5) * 2 * D ** -0.5 * 4
+    seq_lens = torch.tensor([1, 16, 37, 150], dtype=torch.int32)
+    maxb = (150 + BS - 1) // BS
+    bt = torch.stack([torch.randperm(NB)[:maxb] for _ in range(S)]).int()
+    slopes = torch.randn(Hq)
+    att = {}
+    for tag, al in (("plain", None), ("alibi", slopes)):
+        o = torch.empty(S, Hq, D)
+        ns3["ref_single_query_cached_kv_attention"](
+            o, q, Hq // Hkv, kc, vc, bt, seq_lens, 0.125, al)
+        att["out_" + tag] = o.numpy()
+    att.update(q=q.numpy(), kc=kc.numpy(), vc=vc.numpy(), bt=bt.numpy(),
+               seq_lens=seq_lens.numpy(), slopes=slopes.numpy())
+    # reshape_and_cache reference loop (tests/kernels/test_cache.py:176-192)
+    torch.manual_seed(5)
+    T = 9
+    key = torch.randn(T, Hkv, D)
+    val = torch.randn(T, Hkv, D)
+    slots = torch.tensor(np.random.RandomState(5).choice(NB * BS, T, replace=False))
+    ckc, cvc = kc.clone(), vc.clone()
+    rk = key.reshape(T, *ckc[0, :, :, 0, :].shape)
+    for i in range(T):
+        bi, bo = int(slots[i]) // BS, int(slots[i]) % BS
+        ckc[bi, :, :, bo, :] = rk[i]
+        cvc[bi, :, :, bo] = val[i]
+    att.update(rc_key=key.numpy(), rc_val=val.numpy(), rc_slots=slots.numpy(),
+               rc_kc=ckc.numpy(), rc_vc=cvc.numpy())
+    np.savez_compressed(os.path.join(OUT, "attention.npz"), **att)
+    print("golden fixtures written to", OUT)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,235 @@
+"""Pins oracle/ against golden vectors produced by the reference's own Python
+(tests/golden/make_golden.py) and against the reference's own CPU kernels
+(oracle/_ref, compiled from /root/reference/kernels/cpu)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import attention as oa
+from oracle import fp8 as of8
+from oracle import quant as oq
+
+
+@pytest.fixture(scope="module")
+def int4(golden_dir):
+    return np.load(os.path.join(golden_dir, "int4_formats.npz"))
+
+
+@pytest.fixture(scope="module")
+def f8(golden_dir):
+    return np.load(os.path.join(golden_dir, "fp8.npz"))
+
+
+@pytest.fixture(scope="module")
+def att(golden_dir):
+    return np.load(os.path.join(golden_dir, "attention.npz"))
+
+
+# ---- int4 formats -----------------------------------------------------------
+def test_quantize_weights_symmetric(int4):
+    w_ref, w_q, w_s, zp = oq.quantize_weights(int4["w"], 4, 128)
+    assert zp is None
+    np.testing.assert_array_equal(w_q, int4["sym_w_q"])
+    np.testing.assert_array_equal(w_s, int4["sym_w_s"])
+    np.testing.assert_array_equal(w_ref, int4["sym_w_ref"])
+
+
+def test_quantize_weights_zero_points(int4):
+    w_ref, w_q, w_s, zp = oq.quantize_weights(int4["w"], 4, 128, zero_points=True)
+    np.testing.assert_array_equal(w_q, int4["zp_w_q"])
+    np.testing.assert_array_equal(zp, int4["zp_w_zp"])
+    np.testing.assert_array_equal(w_s, int4["zp_w_s"])
+    np.testing.assert_array_equal(w_ref, int4["zp_w_ref"])
+
+
+def test_gptq_pack_unpack(int4):
+    packed = oq.gptq_pack(int4["sym_w_q"])
+    np.testing.assert_array_equal(packed, int4["gptq_packed"])
+    np.testing.assert_array_equal(oq.gptq_unpack(packed), int4["sym_w_q"])
+
+
+def test_awq_pack_unpack(int4):
+    np.testing.assert_array_equal(oq.awq_pack(int4["zp_w_q"]), int4["awq_packed"])
+    np.testing.assert_array_equal(oq.awq_pack(int4["zp_w_zp"]),
+                                  int4["awq_zeros_packed"])
+    np.testing.assert_array_equal(oq.awq_unpack(int4["awq_packed"]),
+                                  int4["zp_w_q"])
+    np.testing.assert_array_equal(oq.pack_cols(int4["zp_w_q"]), int4["pack_cols"])
+    np.testing.assert_array_equal(oq.unpack_cols(int4["pack_cols"]),
+                                  int4["unpack_cols"])
+
+
+def test_awq_dequantize_exact(int4):
+    """Reference test pins AWQ dequant exactly (test_awq_triton.py:96)."""
+    got = oq.awq_dequantize(int4["awq_packed"], int4["zp_w_s"],
+                            int4["awq_zeros_packed"])
+    np.testing.assert_array_equal(got, int4["awq_dequant"])
+    # and it reproduces quantize_weights' own w_ref
+    np.testing.assert_array_equal(got, int4["zp_w_ref"])
+
+
+def test_act_order_sort(int4):
+    """sort_weights (quant_utils.py:313-331): argsort(g_idx) gathers rows."""
+    perm = np.argsort(int4["act_g_idx"], kind="stable")
+    # torch.argsort is not guaranteed stable: compare the sorted results
+    np.testing.assert_array_equal(int4["act_g_idx"][int4["act_sort_idx"]],
+                                  int4["act_sorted_g"])
+    np.testing.assert_array_equal(int4["act_w_q"][int4["act_sort_idx"]],
+                                  int4["act_sorted_q"])
+    np.testing.assert_array_equal(np.sort(int4["act_g_idx"]), int4["act_g_idx"][perm])
+
+
+def test_gptq_shuffle_consistency(int4):
+    """gptq_shuffle / gptq_gemm have no reference fixture (parity unpinned,
+    SURVEY 8c): check the restatement is self-consistent -- shuffled+perm
+    dequant followed by the A-gather equals the plain act-order dequant."""
+    rng = np.random.RandomState(0)
+    q = int4["act_w_q"]                        # rows permuted by rand_perm
+    g_idx = int4["act_g_idx"]
+    scales = int4["sym_w_s"]
+    G, N = scales.shape
+    zeros = np.full((G, N), 8, np.int32)       # uint4b8: zero point 8
+    qzeros = oq.gptq_pack_zeros(zeros)
+    qweight = oq.gptq_pack(q)
+    a = rng.randn(5, q.shape[0]).astype(np.float16)
+    ref = oq.gptq_gemm(a, qweight, qzeros, scales, g_idx, use_exllama=False)
+    w = oq.gptq_dequant(qweight, qzeros, scales, g_idx)
+    # the reference rounds (q - 8) * s to fp16 (quant_utils.py:184)
+    np.testing.assert_array_equal(w.astype(np.float16), int4["act_w_ref"])
+    perm = np.argsort(g_idx, kind="stable").astype(np.int32)
+    shuf = oq.gptq_shuffle(qweight, perm)
+    got = oq.gptq_gemm(a, shuf, qzeros, scales, perm, use_exllama=True)
+    np.testing.assert_allclose(got, ref, rtol=1e-12, atol=1e-9)
+    # nibble permutation is an involution pair
+    w32 = qweight.view(np.uint32)
+    np.testing.assert_array_equal(
+        oq.unshuffle_4bit_word(oq.shuffle_4bit_word(w32)), w32)
+    # known answer: element i in nibble i -> 0x7531_6420
+    assert int(oq.shuffle_4bit_word(np.array([0x76543210], np.uint32))[0]) == 0x75316420
+
+
+# ---- fp8 -----------------------------------------------------------------
+def test_fp8_tables(f8):
+    for kind in ("e4m3", "e5m2"):
+        mine = of8.fp8_decode_table(kind)
+        ref = f8[f"{kind}_table"]
+        np.testing.assert_array_equal(np.isnan(mine), np.isnan(ref))
+        ok = ~np.isnan(ref)
+        np.testing.assert_array_equal(mine[ok], ref[ok])
+        fin = ok & np.isfinite(ref)
+        bits = np.arange(256, dtype=np.uint8)[fin]
+        enc = of8.fp8_encode(ref[fin], kind)
+        # -0 and +0 both decode to 0; compare decoded values
+        np.testing.assert_array_equal(of8.fp8_decode(enc, kind), ref[fin])
+        assert (enc == bits).mean() > 0.99
+
+
+def test_fp8_saturation():
+    assert of8.fp8_decode(of8.fp8_encode([1e6, -1e6], "e4m3"), "e4m3").tolist() == [448.0, -448.0]
+    assert of8.fp8_decode(of8.fp8_encode([1e9, -1e9], "e5m2"), "e5m2").tolist() == [57344.0, -57344.0]
+
+
+def test_fp8_per_token_quant(f8):
+    q, s = of8.dynamic_per_token_scaled_fp8_quant(f8["x"])
+    np.testing.assert_array_equal(s, f8["s_tok"])
+    np.testing.assert_array_equal(q, f8["q_tok"])
+    q, s = of8.dynamic_per_token_scaled_fp8_quant(f8["x"], f8["ub"][0])
+    np.testing.assert_array_equal(s, f8["s_ub"])
+    np.testing.assert_array_equal(q, f8["q_ub"])
+
+
+def test_fp8_per_tensor_quant(f8):
+    q, s = of8.dynamic_scaled_fp8_quant(f8["x"])
+    np.testing.assert_array_equal(s, f8["s_ten"])
+    np.testing.assert_array_equal(q, f8["q_ten"])
+
+
+def test_scaled_mm(f8):
+    got = of8.scaled_mm(f8["mm_a"], f8["mm_b"], f8["mm_sa"], f8["mm_sb"],
+                        f8["mm_bias"])
+    np.testing.assert_allclose(got, f8["mm_out"], rtol=1e-5, atol=1e-4)
+
+
+# ---- attention / cache -------------------------------------------------------
+@pytest.mark.parametrize("tag", ["plain", "alibi"])
+def test_paged_attention_golden(att, tag):
+    slopes = att["slopes"] if tag == "alibi" else None
+    got = oa.paged_attention_decode(att["q"], att["kc"], att["vc"], att["bt"],
+                                    att["seq_lens"], 0.125, slopes)
+    np.testing.assert_allclose(got, att["out_" + tag], rtol=1e-4, atol=2e-5)
+    merged, mx, es, tmp = oa.paged_attention_v2_partials(
+        att["q"], att["kc"], att["vc"], att["bt"], att["seq_lens"], 0.125,
+        partition_size=64, alibi_slopes=slopes)
+    np.testing.assert_allclose(merged, got, rtol=1e-4, atol=1e-5)
+
+
+def test_reshape_and_cache_golden(att):
+    kc, vc = att["kc"].copy(), att["vc"].copy()
+    oa.reshape_and_cache(att["rc_key"], att["rc_val"], kc, vc, att["rc_slots"])
+    np.testing.assert_array_equal(kc, att["rc_kc"])
+    np.testing.assert_array_equal(vc, att["rc_vc"])
+
+
+def _ref_lib():
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                        "oracle", "_ref", "libaphro_ref_cpu.so")
+    if not os.path.exists(path):
+        pytest.skip("oracle/_ref not built (needs /root/reference)")
+    try:
+        torch.ops.load_library(path)
+    except Exception as e:  # pragma: no cover
+        pytest.skip(f"cannot load oracle/_ref: {e}")
+    return torch.ops.aphro_ref_cpu
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("version", ["v1", "v2"])
+def test_oracle_vs_reference_cpu_kernel(dtype, version):
+    """Our restatement vs the reference's own compiled CPU paged attention
+    (kernels/cpu/attention.cpp) on seeded inputs."""
+    ops = _ref_lib()
+    torch.manual_seed(0)
+    S, Hq, Hkv, D, BS, NB = 5, 8, 2, 128, 16, 80
+    x = 16 // torch.tensor([], dtype=dtype).element_size()
+    q = (torch.randn(S, Hq, D) * 0.3).to(dtype)
+    kc = ((torch.rand(NB, Hkv, D // x, BS, x) - 0.5) * 0.4).to(dtype)
+    vc = ((torch.rand(NB, Hkv, D, BS) - 0.5) * 0.4).to(dtype)
+    seq_lens = torch.tensor([1, 15, 16, 700, 1100], dtype=torch.int32)
+    maxb = (1100 + BS - 1) // BS
+    bt = torch.stack([torch.randperm(NB)[:maxb] for _ in range(S)]).int()
+    out = torch.empty_like(q)
+    scale = D ** -0.5
+    if version == "v1":
+        ops.paged_attention_v1(out, q, kc, vc, Hkv, scale, bt, seq_lens, BS,
+                               1100, None, "auto", 1.0, 1.0, 0, 0, 0, 64, 0)
+    else:
+        parts = (1100 + 511) // 512
+        es = torch.empty(S, Hq, parts)
+        ml = torch.empty(S, Hq, parts)
+        tmp = torch.empty(S, Hq, parts, D, dtype=dtype)
+        ops.paged_attention_v2(out, es, ml, tmp, q, kc, vc, Hkv, scale, bt,
+                               seq_lens, BS, 1100, None, "auto", 1.0, 1.0, 0, 0,
+                               0, 64, 0)
+    ref = oa.paged_attention_decode(q, kc.float().numpy(), vc.float().numpy(),
+                                    bt.numpy(), seq_lens.numpy(), scale)
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    np.testing.assert_allclose(out.float().numpy(), ref, rtol=tol, atol=tol)
+
+
+def test_reshape_and_cache_vs_reference_cpu_kernel():
+    ops = _ref_lib()
+    torch.manual_seed(1)
+    T, Hkv, D, BS, NB = 11, 2, 64, 16, 6
+    x = 4
+    key = torch.randn(T, Hkv, D)
+    val = torch.randn(T, Hkv, D)
+    kc = torch.zeros(NB, Hkv, D // x, BS, x)
+    vc = torch.zeros(NB, Hkv, D, BS)
+    slots = torch.randperm(NB * BS)[:T].to(torch.int64)
+    kc2, vc2 = kc.numpy().copy(), vc.numpy().copy()
+    ops.reshape_and_cache(key, val, kc, vc, slots, "auto", 1.0, 1.0)
+    oa.reshape_and_cache(key, val, kc2, vc2, slots.numpy())
+    np.testing.assert_array_equal(kc.numpy(), kc2)
+    np.testing.assert_array_equal(vc.numpy(), vc2)
