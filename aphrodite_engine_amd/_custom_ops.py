@@ -1,0 +1,511 @@
+"""Host-side mirror of the reference's ``aphrodite/_custom_ops.py`` for the hot
+path: same function names, argument order, meaning and error behaviour, each
+bound to the MI355X HIP kernels through the C ABI (no CPU fallback).
+
+Reference: aphrodite/_custom_ops.py (paged_attention_v1 :85-115, v2 :118-151,
+paged_attention_rocm :154-178, rms_norm/fused_add_rms_norm :192-199,
+awq_dequantize/awq_gemm :223-240, gptq_gemm/gptq_shuffle :243-270,
+cutlass_scaled_mm :497-517, scaled_fp8_quant :632-685, reshape_and_cache
+:925-946, convert_fp8 :984-989).
+
+Tensors are borrowed; ``Tensor!`` outputs are caller-allocated; returned
+tensors are allocated here on the input's device.  Every launch goes to
+``torch.cuda.current_stream()`` and nothing synchronises, so the ops can be
+captured into a HIP graph exactly like the reference's.
+"""
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import check
+
+FP8_DTYPE = torch.float8_e4m3fn  # gfx950 is OCP, not e4m3fnuz
+
+_DT = {torch.float16: _lib.F16, torch.bfloat16: _lib.BF16, torch.float32: _lib.F32}
+_KV = {"auto": _lib.KV_AUTO, "fp8": _lib.KV_FP8_E4M3, "fp8_e4m3": _lib.KV_FP8_E4M3,
+       "fp8_e5m2": _lib.KV_FP8_E5M2}
+
+_WS_BYTES = 128 << 20
+_workspaces = {}
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dt(t: torch.Tensor) -> int:
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise RuntimeError(f"Unsupported dtype {t.dtype}") from None
+
+
+def _kv(kv_cache_dtype: str) -> int:
+    try:
+        return _KV[kv_cache_dtype]
+    except KeyError:
+        raise RuntimeError(
+            f"Unsupported data type of kv cache: {kv_cache_dtype}") from None
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _workspace(device: torch.device, nbytes: int) -> torch.Tensor:
+    """Persistent split-K scratch (stable address -> HIP-graph safe)."""
+    if nbytes > _WS_BYTES:
+        return torch.empty(nbytes, dtype=torch.uint8, device=device)
+    ws = _workspaces.get(device)
+    if ws is None:
+        ws = torch.empty(_WS_BYTES, dtype=torch.uint8, device=device)
+        _workspaces[device] = ws
+    return ws
+
+
+def _require_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(
+                "aphrodite_engine_amd ops run on the MI355X only (got a CPU "
+                "tensor); there is no CPU fallback")
+
+
+# --------------------------------------------------------------------------
+# paged attention
+# --------------------------------------------------------------------------
+def _paged_attention(out, exp_sums, max_logits, tmp_out, query, key_cache,
+                     value_cache, num_kv_heads, scale, block_tables, seq_lens,
+                     block_size, max_seq_len, alibi_slopes, kv_cache_dtype,
+                     k_scale, v_scale, partition_size):
+    _require_cuda(out, query, key_cache, value_cache, block_tables, seq_lens)
+    num_seqs, num_heads, head_size = query.shape
+    if query.stride(2) != 1 or query.stride(1) != head_size:
+        raise RuntimeError("query heads must be contiguous")
+    if not out.is_contiguous():
+        raise RuntimeError("out must be contiguous")
+    if block_tables.dtype != torch.int32 or seq_lens.dtype != torch.int32:
+        raise RuntimeError("block_tables / seq_lens must be int32")
+    if alibi_slopes is not None and alibi_slopes.dtype != torch.float32:
+        alibi_slopes = alibi_slopes.float()
+    check(_lib.lib().aphro_paged_attention(
+        out.data_ptr(), _ptr(exp_sums), _ptr(max_logits), _ptr(tmp_out),
+        query.data_ptr(), key_cache.data_ptr(), value_cache.data_ptr(),
+        num_seqs, num_heads, num_kv_heads, head_size, float(scale),
+        block_tables.data_ptr(), seq_lens.data_ptr(), block_tables.stride(0),
+        block_size, int(max_seq_len), _ptr(alibi_slopes), query.stride(0),
+        key_cache.stride(0), key_cache.stride(1), _dt(query), _kv(kv_cache_dtype),
+        float(k_scale), float(v_scale), partition_size, _stream()),
+        "paged_attention")
+
+
+def paged_attention_v1(out, query, key_cache, value_cache, num_kv_heads, scale,
+                       block_tables, seq_lens, block_size, max_seq_len,
+                       alibi_slopes, kv_cache_dtype, k_scale, v_scale,
+                       tp_rank: int = 0, blocksparse_local_blocks: int = 0,
+                       blocksparse_vert_stride: int = 0,
+                       blocksparse_block_size: int = 64,
+                       blocksparse_head_sliding_step: int = 0) -> None:
+    if blocksparse_vert_stride > 1:
+        raise RuntimeError("blocksparse attention is out of scope (SURVEY 2.1)")
+    _paged_attention(out, None, None, None, query, key_cache, value_cache,
+                     num_kv_heads, scale, block_tables, seq_lens, block_size,
+                     max_seq_len, alibi_slopes, kv_cache_dtype, k_scale, v_scale, 0)
+
+
+def paged_attention_v2(out, exp_sum, max_logits, tmp_out, query, key_cache,
+                       value_cache, num_kv_heads, scale, block_tables, seq_lens,
+                       block_size, max_seq_len, alibi_slopes, kv_cache_dtype,
+                       k_scale, v_scale, tp_rank: int = 0,
+                       blocksparse_local_blocks: int = 0,
+                       blocksparse_vert_stride: int = 0,
+                       blocksparse_block_size: int = 64,
+                       blocksparse_head_sliding_step: int = 0) -> None:
+    if blocksparse_vert_stride > 1:
+        raise RuntimeError("blocksparse attention is out of scope (SURVEY 2.1)")
+    part = _partition_size(tmp_out, max_seq_len)
+    _paged_attention(out, exp_sum, max_logits, tmp_out, query, key_cache,
+                     value_cache, num_kv_heads, scale, block_tables, seq_lens,
+                     block_size, max_seq_len, alibi_slopes, kv_cache_dtype,
+                     k_scale, v_scale, part)
+
+
+def paged_attention_rocm(out, exp_sum, max_logits, tmp_out, query, key_cache,
+                         value_cache, num_kv_heads, scale, block_tables,
+                         seq_lens, block_size, max_seq_len, alibi_slopes,
+                         kv_cache_dtype, k_scale, v_scale) -> None:
+    part = _partition_size(tmp_out, max_seq_len)
+    _paged_attention(out, exp_sum, max_logits, tmp_out, query, key_cache,
+                     value_cache, num_kv_heads, scale, block_tables, seq_lens,
+                     block_size, max_seq_len, alibi_slopes, kv_cache_dtype,
+                     k_scale, v_scale, part)
+
+
+def _partition_size(tmp_out: torch.Tensor, max_seq_len: int) -> int:
+    """Callers size the scratch for 512-token partitions
+    (paged_attn.py:13,118-119; rocm_flash_attn.py:23,544-546)."""
+    part = 512
+    need = (max_seq_len + part - 1) // part
+    if tmp_out.shape[2] < need:
+        raise RuntimeError(
+            f"tmp_out has {tmp_out.shape[2]} partitions, need {need} for "
+            f"max_seq_len={max_seq_len}")
+    if not (tmp_out.is_contiguous()):
+        raise RuntimeError("tmp_out must be contiguous")
+    return part
+
+
+# --------------------------------------------------------------------------
+# cache ops
+# --------------------------------------------------------------------------
+def reshape_and_cache(key, value, key_cache, value_cache, slot_mapping,
+                      kv_cache_dtype: str, k_scale: float, v_scale: float) -> None:
+    _require_cuda(key, value, key_cache, value_cache, slot_mapping)
+    num_tokens, num_kv_heads, head_size = key.shape
+    block_size, x = key_cache.shape[3], key_cache.shape[4]
+    if slot_mapping.dtype != torch.int64:
+        raise RuntimeError("slot_mapping must be int64")
+    if key.stride(1) != head_size or value.stride(1) != head_size:
+        raise RuntimeError("key/value heads must be contiguous")
+    check(_lib.lib().aphro_reshape_and_cache(
+        key.data_ptr(), value.data_ptr(), key_cache.data_ptr(),
+        value_cache.data_ptr(), slot_mapping.data_ptr(), num_tokens,
+        num_kv_heads, head_size, block_size, x, key.stride(0), value.stride(0),
+        _dt(key), _kv(kv_cache_dtype), float(k_scale), float(v_scale),
+        _stream()), "reshape_and_cache")
+
+
+def convert_fp8(output: torch.Tensor, input: torch.Tensor, scale: float = 1.0,
+                kv_dtype: str = "fp8") -> None:
+    _require_cuda(output, input)
+    kvd = _kv(kv_dtype)
+    if kvd == _lib.KV_AUTO:
+        raise RuntimeError(f"Unsupported data type of kv cache: {kv_dtype}")
+    if not (output.is_contiguous() and input.is_contiguous()):
+        raise RuntimeError("convert_fp8 needs contiguous tensors")
+    to_fp8 = output.dtype == torch.uint8
+    hp = input if to_fp8 else output
+    check(_lib.lib().aphro_convert_fp8(
+        output.data_ptr(), input.data_ptr(), input.numel(), float(scale),
+        _dt(hp), kvd, 1 if to_fp8 else 0, _stream()), "convert_fp8")
+
+
+# --------------------------------------------------------------------------
+# GPTQ
+# --------------------------------------------------------------------------
+def gptq_shuffle(q_weight: torch.Tensor, q_perm: torch.Tensor, bit: int) -> None:
+    _require_cuda(q_weight)
+    rows, n = q_weight.shape
+    perm = q_perm if (q_perm is not None and q_perm.numel() > 0) else None
+    tmp = torch.empty_like(q_weight) if perm is not None else None
+    if perm is not None and perm.dtype != torch.int32:
+        perm = perm.to(torch.int32)
+    check(_lib.lib().aphro_gptq_shuffle(
+        q_weight.data_ptr(), _ptr(perm), rows * (32 // bit), n, bit, _ptr(tmp),
+        _stream()), "gptq_shuffle")
+
+
+def gptq_dequant(b_q_weight, b_gptq_qzeros, b_gptq_scales, b_g_idx,
+                 use_exllama: bool, bit: int = 4, zero_offset: int = 1):
+    """temp_dq of q_gemm.cu:1520-1535: the fp16 weight the reference hands to
+    hipBLAS for M > 50."""
+    if bit != 4:
+        raise RuntimeError("only 4-bit GPTQ is implemented")
+    k, n = b_q_weight.shape[0] * 8, b_q_weight.shape[1]
+    out = torch.empty((k, n), dtype=b_gptq_scales.dtype, device=b_q_weight.device)
+    g_idx = None
+    if not use_exllama and b_g_idx is not None and b_g_idx.numel() > 0:
+        g_idx = b_g_idx.to(torch.int32)
+    check(_lib.lib().aphro_gptq_dequant(
+        b_q_weight.data_ptr(), b_gptq_qzeros.data_ptr(), b_gptq_scales.data_ptr(),
+        _ptr(g_idx), out.data_ptr(), k, n, b_gptq_scales.shape[0],
+        1 if use_exllama else 0, zero_offset, _dt(b_gptq_scales), _stream()),
+        "gptq_dequant")
+    return out
+
+
+def _wna16(a, qweight, qzeros, scales, perm, zero_offset):
+    m, k = a.shape
+    n = qweight.shape[1]
+    lib = _lib.lib()
+    out = torch.empty((m, n), dtype=a.dtype, device=a.device)
+    if a.stride(1) != 1:
+        a = a.contiguous()
+    ws = _workspace(a.device, lib.aphro_wna16_workspace_bytes(min(m, 64), n, k))
+    a_tmp = torch.empty((min(m, 64), k), dtype=a.dtype, device=a.device) \
+        if perm is not None else None
+    for m0 in range(0, m, 64):
+        rows = min(64, m - m0)
+        a_blk = a[m0:m0 + rows]
+        check(lib.aphro_gptq_gemm(
+            a_blk.data_ptr(), qweight.data_ptr(), qzeros.data_ptr(),
+            scales.data_ptr(), _ptr(perm), _ptr(a_tmp), out[m0:].data_ptr(),
+            ws.data_ptr(), ws.numel(), rows, n, k, scales.shape[0], a.stride(0),
+            zero_offset, _dt(a), _stream()), "gptq_gemm")
+    return out
+
+
+# M above which the weight is reconstructed once and a library GEMM is used;
+# the reference switches at 50 rows (q_gemm.cu:28,1529-1544).
+GPTQ_DEQUANT_MIN_M = 256
+
+
+def gptq_gemm(a: torch.Tensor, b_q_weight: torch.Tensor,
+              b_gptq_qzeros: torch.Tensor, b_gptq_scales: torch.Tensor,
+              b_g_idx: torch.Tensor, use_exllama: bool, bit: int) -> torch.Tensor:
+    _require_cuda(a, b_q_weight, b_gptq_qzeros, b_gptq_scales)
+    if bit != 4:
+        raise RuntimeError("gptq_gemm: only 4-bit is implemented on MI355X")
+    if a.dtype != b_gptq_scales.dtype:
+        raise RuntimeError("gptq_gemm: activations and scales must share a dtype")
+    m = a.shape[0]
+    if not use_exllama or m >= GPTQ_DEQUANT_MIN_M:
+        w = gptq_dequant(b_q_weight, b_gptq_qzeros, b_gptq_scales, b_g_idx,
+                         use_exllama, bit)
+        if use_exllama and b_g_idx is not None and b_g_idx.numel() > 0:
+            a = a[:, b_g_idx.long()]
+        return torch.matmul(a, w)
+    perm = None
+    if b_g_idx is not None and b_g_idx.numel() > 0:
+        perm = b_g_idx.to(torch.int32) if b_g_idx.dtype != torch.int32 else b_g_idx
+    return _wna16(a, b_q_weight, b_gptq_qzeros, b_gptq_scales, perm, 1)
+
+
+def gptq_marlin_repack(b_q_weight: torch.Tensor, perm: torch.Tensor, size_k: int,
+                       size_n: int, num_bits: int) -> torch.Tensor:
+    """Marlin-role load-time prepack into the CDNA4 K-packed layout (same
+    shape as the input, [K/8, N]); perm = argsort(g_idx) or empty."""
+    _require_cuda(b_q_weight)
+    out = torch.empty_like(b_q_weight)
+    p = perm.to(torch.int32) if (perm is not None and perm.numel() > 0) else None
+    check(_lib.lib().aphro_gptq_repack(b_q_weight.data_ptr(), _ptr(p),
+                                       out.data_ptr(), size_k, size_n, num_bits,
+                                       _stream()), "gptq_marlin_repack")
+    return out
+
+
+# --------------------------------------------------------------------------
+# AWQ
+# --------------------------------------------------------------------------
+def awq_dequantize(qweight: torch.Tensor, scales: torch.Tensor,
+                   zeros: torch.Tensor, split_k_iters: int = 0, thx: int = 0,
+                   thy: int = 0) -> torch.Tensor:
+    _require_cuda(qweight, scales, zeros)
+    k, n = qweight.shape[0], qweight.shape[1] * 8
+    out = torch.empty((k, n), dtype=scales.dtype, device=qweight.device)
+    check(_lib.lib().aphro_awq_dequantize(
+        qweight.data_ptr(), scales.data_ptr(), zeros.data_ptr(), out.data_ptr(),
+        k, n, scales.shape[0], _dt(scales), _stream()), "awq_dequantize")
+    return out
+
+
+def awq_gemm(input: torch.Tensor, qweight: torch.Tensor, qzeros: torch.Tensor,
+             scales: torch.Tensor, split_k_iters: int) -> torch.Tensor:
+    """NOTE the reference wrapper's parameter names are swapped relative to what
+    callers pass (SURVEY 8b gotcha): positionally it is
+    (in_feats, kernel, scaling_factors, zeros, split_k_iters) --
+    awq.py:165-166 calls awq_gemm(x, qweight, scales, qzeros, pack_factor).
+    So here ``qzeros`` receives the scales and ``scales`` the zeros."""
+    scaling_factors, zeros = qzeros, scales
+    _require_cuda(input, qweight, scaling_factors, zeros)
+    lib = _lib.lib()
+    m, k = input.shape
+    n = qweight.shape[1] * 8
+    groups = scaling_factors.shape[0]
+    if input.stride(1) != 1:
+        input = input.contiguous()
+    out = torch.empty((m, n), dtype=input.dtype, device=input.device)
+    nbytes = lib.aphro_awq_gemm_workspace_bytes(min(m, 64), n, k, groups)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=input.device)
+    for m0 in range(0, m, 64):
+        rows = min(64, m - m0)
+        check(lib.aphro_awq_gemm(
+            input[m0:].data_ptr(), qweight.data_ptr(), scaling_factors.data_ptr(),
+            zeros.data_ptr(), out[m0:].data_ptr(), ws.data_ptr(), ws.numel(),
+            rows, n, k, groups, input.stride(0), _dt(input), _stream()),
+            "awq_gemm")
+    return out
+
+
+def awq_marlin_repack(b_q_weight: torch.Tensor, size_k: int, size_n: int,
+                      num_bits: int) -> torch.Tensor:
+    """AWQ [K, N/8] -> CDNA4 K-packed [K/8, N] (load time)."""
+    _require_cuda(b_q_weight)
+    if num_bits != 4:
+        raise RuntimeError("only 4-bit AWQ is implemented")
+    out = torch.empty((size_k // 8, size_n), dtype=torch.int32,
+                      device=b_q_weight.device)
+    check(_lib.lib().aphro_awq_repack(b_q_weight.data_ptr(), out.data_ptr(),
+                                      size_k, size_n, _stream()), "awq_repack")
+    return out
+
+
+def awq_repack_zeros(qzeros: torch.Tensor, size_n: int) -> torch.Tensor:
+    out = torch.empty_like(qzeros)
+    check(_lib.lib().aphro_awq_repack_zeros(qzeros.data_ptr(), out.data_ptr(),
+                                            qzeros.shape[0], size_n, _stream()),
+          "awq_repack_zeros")
+    return out
+
+
+def wna16_gemm(a, qweight_kpacked, qzeros, scales, perm=None, zero_offset=0):
+    """The gptq_marlin_gemm role: fast W4A16 kernel on prepacked weights."""
+    _require_cuda(a, qweight_kpacked, qzeros, scales)
+    return _wna16(a, qweight_kpacked, qzeros, scales, perm, zero_offset)
+
+
+# --------------------------------------------------------------------------
+# FP8
+# --------------------------------------------------------------------------
+def scaled_fp8_quant(input: torch.Tensor, scale: Optional[torch.Tensor] = None,
+                     num_token_padding: Optional[int] = None,
+                     scale_ub: Optional[torch.Tensor] = None,
+                     use_per_token_if_dynamic: bool = False
+                     ) -> Tuple[torch.Tensor, torch.Tensor]:
+    """_custom_ops.py:632-685 with the OCP e4m3fn output dtype of gfx950."""
+    assert input.ndim == 2
+    _require_cuda(input)
+    if not input.is_contiguous():
+        input = input.contiguous()
+    lib = _lib.lib()
+    shape = input.shape
+    if num_token_padding:
+        shape = (max(num_token_padding, input.shape[0]), shape[1])
+    output = torch.empty(shape, device=input.device, dtype=FP8_DTYPE)
+    m, k = input.shape
+    if scale is None:
+        if use_per_token_if_dynamic:
+            scale = torch.empty((shape[0], 1), device=input.device,
+                                dtype=torch.float32)
+            check(lib.aphro_dynamic_per_token_scaled_fp8_quant(
+                output.data_ptr(), input.data_ptr(), scale.data_ptr(),
+                _ptr(scale_ub), m, k, _dt(input), _stream()), "scaled_fp8_quant")
+        else:
+            scale = torch.zeros(1, device=input.device, dtype=torch.float32)
+            check(lib.aphro_dynamic_scaled_fp8_quant(
+                output.data_ptr(), input.data_ptr(), scale.data_ptr(), m, k,
+                _dt(input), _stream()), "scaled_fp8_quant")
+    else:
+        assert scale.numel() == 1 or num_token_padding is None
+        check(lib.aphro_static_scaled_fp8_quant(
+            output.data_ptr(), input.data_ptr(), scale.data_ptr(), m, k,
+            _dt(input), _stream()), "scaled_fp8_quant")
+    return output, scale
+
+
+def cutlass_scaled_mm_supports_fp8(cuda_device_capability: int) -> bool:
+    return True  # gfx950 has native OCP fp8 MFMA
+
+
+def cutlass_scaled_mm(a: torch.Tensor, b: torch.Tensor, scale_a: torch.Tensor,
+                      scale_b: torch.Tensor, out_dtype: torch.dtype,
+                      bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """_custom_ops.py:497-517.  a [M,K] e4m3 row-major, b [K,N] e4m3
+    column-major (``weight.t()``)."""
+    _require_cuda(a, b, scale_a, scale_b)
+    assert b.shape[0] % 16 == 0 and b.shape[1] % 16 == 0
+    assert out_dtype in (torch.bfloat16, torch.float16)
+    assert bias is None or (bias.shape[0] == b.shape[1] and bias.dtype == out_dtype)
+    if a.dtype != FP8_DTYPE or b.dtype != FP8_DTYPE:
+        raise RuntimeError("cutlass_scaled_mm on MI355X implements fp8 (e4m3fn) "
+                           "only; int8 is out of scope (SURVEY 2.2)")
+    m, k = a.shape
+    n = b.shape[1]
+    if b.stride(0) != 1 or b.stride(1) != k:
+        raise RuntimeError("b must be column-major [K,N] (weight.t())")
+    if not a.is_contiguous():
+        a = a.contiguous()
+    lib = _lib.lib()
+    out = torch.empty((m, n), dtype=out_dtype, device=a.device)
+    odt = _lib.F16 if out_dtype == torch.float16 else _lib.BF16
+    sa = scale_a.reshape(-1).float()
+    sb = scale_b.reshape(-1).float()
+    a_tok = 1 if sa.numel() > 1 else 0
+    b_ch = 1 if sb.numel() > 1 else 0
+    ws = _workspace(a.device, lib.aphro_fp8_gemm_workspace_bytes(min(m, 64), n, k))
+    for m0 in range(0, m, 64):
+        rows = min(64, m - m0)
+        sa_blk = sa[m0:] if a_tok else sa
+        check(lib.aphro_scaled_mm_fp8(
+            out[m0:].data_ptr(), a[m0:].data_ptr(), b.data_ptr(),
+            sa_blk.data_ptr(), sb.data_ptr(), _ptr(bias), ws.data_ptr(),
+            ws.numel(), rows, n, k, a_tok, b_ch, odt, _stream()),
+            "cutlass_scaled_mm")
+    return out
+
+
+def fp8_marlin_gemm(a: torch.Tensor, b_q_weight: torch.Tensor,
+                    b_scales: torch.Tensor, workspace: Optional[torch.Tensor],
+                    num_bits: int, size_m: int, size_n: int, size_k: int,
+                    bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """W8A16 role of _C::fp8_marlin_gemm (torch_bindings.cpp:218-222).
+    b_q_weight: e4m3 [N,K] row-major (checkpoint layout, no Marlin prepack);
+    b_scales: fp32 [1] or [N].  ``workspace`` (Marlin locks) is ignored."""
+    _require_cuda(a, b_q_weight, b_scales)
+    assert num_bits == 8
+    lib = _lib.lib()
+    if a.stride(1) != 1:
+        a = a.contiguous()
+    out = torch.empty((size_m, size_n), dtype=a.dtype, device=a.device)
+    sb = b_scales.reshape(-1).float()
+    ws = _workspace(a.device,
+                    lib.aphro_fp8_gemm_workspace_bytes(min(size_m, 64), size_n, size_k))
+    for m0 in range(0, size_m, 64):
+        rows = min(64, size_m - m0)
+        check(lib.aphro_fp8_w8a16_gemm(
+            out[m0:].data_ptr(), a[m0:].data_ptr(), b_q_weight.data_ptr(),
+            sb.data_ptr(), _ptr(bias), ws.data_ptr(), ws.numel(), rows, size_n,
+            size_k, a.stride(0), 1 if sb.numel() > 1 else 0, _dt(a), _stream()),
+            "fp8_marlin_gemm")
+    return out
+
+
+# --------------------------------------------------------------------------
+# glue
+# --------------------------------------------------------------------------
+def rms_norm(out: torch.Tensor, input: torch.Tensor, weight: torch.Tensor,
+             epsilon: float) -> None:
+    _require_cuda(out, input, weight)
+    hidden = input.shape[-1]
+    x = input.reshape(-1, hidden)
+    check(_lib.lib().aphro_rms_norm(out.data_ptr(), x.data_ptr(), weight.data_ptr(),
+                                    float(epsilon), x.shape[0], hidden,
+                                    x.stride(0), _dt(input), _stream()), "rms_norm")
+
+
+def fused_add_rms_norm(input: torch.Tensor, residual: torch.Tensor,
+                       weight: torch.Tensor, epsilon: float) -> None:
+    _require_cuda(input, residual, weight)
+    hidden = input.shape[-1]
+    assert input.is_contiguous() and residual.is_contiguous()
+    check(_lib.lib().aphro_fused_add_rms_norm(
+        input.data_ptr(), residual.data_ptr(), weight.data_ptr(), float(epsilon),
+        input.numel() // hidden, hidden, _dt(input), _stream()),
+        "fused_add_rms_norm")
+
+
+def silu_and_mul(out: torch.Tensor, x: torch.Tensor) -> None:
+    _require_cuda(out, x)
+    d = x.shape[-1] // 2
+    assert x.is_contiguous() and out.is_contiguous()
+    check(_lib.lib().aphro_silu_and_mul(out.data_ptr(), x.data_ptr(),
+                                        x.numel() // (2 * d), d, _dt(x), _stream()),
+          "silu_and_mul")
+
+
+def rotary_embedding(positions: torch.Tensor, query: torch.Tensor,
+                     key: torch.Tensor, head_size: int,
+                     cos_sin_cache: torch.Tensor, is_neox: bool) -> None:
+    _require_cuda(positions, query, key, cos_sin_cache)
+    num_tokens = positions.numel()
+    q2 = query.view(num_tokens, -1) if query.dim() != 2 else query
+    k2 = key.view(num_tokens, -1) if key.dim() != 2 else key
+    if positions.dtype != torch.int64:
+        positions = positions.long()
+    check(_lib.lib().aphro_rotary_embedding(
+        positions.data_ptr(), q2.data_ptr(), k2.data_ptr(), num_tokens,
+        q2.shape[1] // head_size, k2.shape[1] // head_size, head_size,
+        cos_sin_cache.shape[1], cos_sin_cache.data_ptr(), q2.stride(0),
+        k2.stride(0), 1 if is_neox else 0, _dt(query), _stream()),
+        "rotary_embedding")

@@ -1,0 +1,80 @@
+"""ctypes binding of libaphrodite_mi355x.so (the C ABI in include/aphrodite_mi355x.h).
+
+The product path has NO CPU fallback: if the HIP library is missing or a symbol
+is absent this module raises at import/lookup time (the reference behaves the
+same way -- `aphrodite/_custom_ops.py:13-43` re-raises with a hint when
+`aphrodite._C` cannot be imported).
+"""
+import ctypes
+import os
+from ctypes import c_float, c_int, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get(
+    "APHRODITE_MI355X_LIB", os.path.join(_HERE, "lib", "libaphrodite_mi355x.so"))
+
+P, I, L, F, Z = c_void_p, c_int, c_int64, c_float, c_size_t
+
+# name -> (restype, argtypes); mirrors include/aphrodite_mi355x.h one to one
+SIGNATURES = {
+    "aphro_last_error": (ctypes.c_char_p, []),
+    "aphro_abi_version": (I, []),
+    "aphro_gptq_shuffle": (I, [P, P, L, L, I, P, P]),
+    "aphro_gptq_repack": (I, [P, P, P, L, L, I, P]),
+    "aphro_gptq_gemm": (I, [P, P, P, P, P, P, P, P, Z, L, L, L, L, L, I, I, P]),
+    "aphro_wna16_workspace_bytes": (Z, [L, L, L]),
+    "aphro_gptq_dequant": (I, [P, P, P, P, P, L, L, L, I, I, I, P]),
+    "aphro_awq_dequantize": (I, [P, P, P, P, L, L, L, I, P]),
+    "aphro_awq_gemm_workspace_bytes": (Z, [L, L, L, L]),
+    "aphro_awq_gemm": (I, [P, P, P, P, P, P, Z, L, L, L, L, L, I, P]),
+    "aphro_awq_repack": (I, [P, P, L, L, P]),
+    "aphro_awq_repack_zeros": (I, [P, P, L, L, P]),
+    "aphro_reshape_and_cache": (I, [P, P, P, P, P, L, I, I, I, I, L, L, I, I, F, F, P]),
+    "aphro_convert_fp8": (I, [P, P, L, F, I, I, I, P]),
+    "aphro_paged_attention": (I, [P, P, P, P, P, P, P, I, I, I, I, F, P, P, I, I, I, P,
+                                  L, L, L, I, I, F, F, I, P]),
+    "aphro_static_scaled_fp8_quant": (I, [P, P, P, L, L, I, P]),
+    "aphro_dynamic_scaled_fp8_quant": (I, [P, P, P, L, L, I, P]),
+    "aphro_dynamic_per_token_scaled_fp8_quant": (I, [P, P, P, P, L, L, I, P]),
+    "aphro_scaled_mm_fp8": (I, [P, P, P, P, P, P, P, Z, L, L, L, I, I, I, P]),
+    "aphro_fp8_w8a16_gemm": (I, [P, P, P, P, P, P, Z, L, L, L, L, I, I, P]),
+    "aphro_fp8_gemm_workspace_bytes": (Z, [L, L, L]),
+    "aphro_rms_norm": (I, [P, P, P, F, L, I, L, I, P]),
+    "aphro_fused_add_rms_norm": (I, [P, P, P, F, L, I, I, P]),
+    "aphro_silu_and_mul": (I, [P, P, L, I, I, P]),
+    "aphro_rotary_embedding": (I, [P, P, P, L, I, I, I, I, P, L, L, I, I, P]),
+}
+
+OK = 0
+F16, BF16, F32 = 0, 1, 2
+KV_AUTO, KV_FP8_E4M3, KV_FP8_E5M2 = 0, 1, 2
+
+_lib = None
+
+
+def lib():
+    """Load the shared library (once).  Raises ImportError with a build hint."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: the MI355X HIP library has not been built. "
+            "Run `python -c 'import __graft_entry__ as g; g.build()'` (or "
+            "`make -C aphrodite_engine_amd/csrc`). There is no CPU fallback.")
+    l = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(l, name)
+        except AttributeError as e:
+            raise ImportError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = l
+    return l
+
+
+def check(rc, what=""):
+    if rc != OK:
+        msg = lib().aphro_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{what}: {msg} (code {rc})" if what else f"{msg} (code {rc})")

@@ -1,0 +1,120 @@
+// Common device helpers for the gfx950 (CDNA4) kernels.  wave = 64 lanes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/aphrodite_mi355x.h"
+
+typedef _Float16 f16;
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint16_t u16x8 __attribute__((ext_vector_type(8)));
+typedef uint16_t u16x4 __attribute__((ext_vector_type(4)));
+
+#define WAVE 64
+
+namespace aphro {
+
+void set_error(const char* fmt, ...);
+
+#define APHRO_CHECK(cond, ...)                      \
+  do {                                              \
+    if (!(cond)) {                                  \
+      ::aphro::set_error(__VA_ARGS__);              \
+      return APHRO_ERR_INVALID;                     \
+    }                                               \
+  } while (0)
+
+#define APHRO_LAUNCH_CHECK()                                          \
+  do {                                                                \
+    hipError_t e__ = hipGetLastError();                               \
+    if (e__ != hipSuccess) {                                          \
+      ::aphro::set_error("launch failed: %s", hipGetErrorString(e__)); \
+      return APHRO_ERR_LAUNCH;                                        \
+    }                                                                 \
+  } while (0)
+
+// ---- scalar conversions -----------------------------------------------------
+__device__ __forceinline__ float bf16_bits_to_f32(uint16_t b) {
+  return __builtin_bit_cast(float, (uint32_t)b << 16);
+}
+__device__ __forceinline__ uint16_t f32_to_bf16_bits(float f) {  // RNE
+  uint32_t u = __builtin_bit_cast(uint32_t, f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ float f16_bits_to_f32(uint16_t b) {
+  return (float)__builtin_bit_cast(f16, b);
+}
+__device__ __forceinline__ uint16_t f32_to_f16_bits(float f) {
+  return __builtin_bit_cast(uint16_t, (f16)f);
+}
+
+// Storage-type traits: T is a tag for the 16-bit (or 32-bit) activation dtype.
+struct Half {
+  typedef uint16_t storage;
+  static __device__ __forceinline__ float to_f32(uint16_t b) { return f16_bits_to_f32(b); }
+  static __device__ __forceinline__ uint16_t from_f32(float f) { return f32_to_f16_bits(f); }
+};
+struct BFloat {
+  typedef uint16_t storage;
+  static __device__ __forceinline__ float to_f32(uint16_t b) { return bf16_bits_to_f32(b); }
+  static __device__ __forceinline__ uint16_t from_f32(float f) { return f32_to_bf16_bits(f); }
+};
+struct Float {
+  typedef float storage;
+  static __device__ __forceinline__ float to_f32(float b) { return b; }
+  static __device__ __forceinline__ float from_f32(float f) { return f; }
+};
+
+// ---- fp8 (OCP e4m3fn / e5m2, native on gfx950) ---------------------------------
+// word: 4 packed fp8; returns elements (2*hi_pair, 2*hi_pair+1) as f32.
+template <bool E5M2>
+__device__ __forceinline__ f32x2 fp8x2_to_f32(uint32_t word, bool hi) {
+  if constexpr (E5M2) {
+    return hi ? __builtin_amdgcn_cvt_pk_f32_bf8(word, true)
+              : __builtin_amdgcn_cvt_pk_f32_bf8(word, false);
+  } else {
+    return hi ? __builtin_amdgcn_cvt_pk_f32_fp8(word, true)
+              : __builtin_amdgcn_cvt_pk_f32_fp8(word, false);
+  }
+}
+template <bool E5M2>
+__device__ __forceinline__ float fp8_to_f32(uint8_t b) {
+  if constexpr (E5M2) return __builtin_amdgcn_cvt_f32_bf8((uint32_t)b, 0);
+  else return __builtin_amdgcn_cvt_f32_fp8((uint32_t)b, 0);
+}
+// saturating RNE encode of two floats -> low 16 bits of the result.
+template <bool E5M2>
+__device__ __forceinline__ uint32_t f32x2_to_fp8(float a, float b) {
+  if constexpr (E5M2) {
+    a = __builtin_fminf(__builtin_fmaxf(a, -57344.f), 57344.f);
+    b = __builtin_fminf(__builtin_fmaxf(b, -57344.f), 57344.f);
+    return (uint32_t)__builtin_amdgcn_cvt_pk_bf8_f32(a, b, 0, false) & 0xffffu;
+  } else {
+    a = __builtin_fminf(__builtin_fmaxf(a, -448.f), 448.f);
+    b = __builtin_fminf(__builtin_fmaxf(b, -448.f), 448.f);
+    return (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false) & 0xffffu;
+  }
+}
+
+// ---- wave reductions ------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = __builtin_fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+}  // namespace aphro

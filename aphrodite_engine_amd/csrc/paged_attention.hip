@@ -1,0 +1,565 @@
+// Paged-attention decode for gfx950: one kernel serves _C::paged_attention_v1,
+// _C::paged_attention_v2 and _rocm_C::paged_attention.
+//
+// Reference semantics: kernels/attention/attention_kernels.cu:87-669 (math),
+// kernels/rocm/attention.cu:206-1042 (the MI300 kernel whose *role* this
+// fills; nothing of its structure is reused).
+//
+// Design (DESIGN.md "paged_attention"):  HBM-bound, KV read exactly once.
+//  * one workgroup = one (sequence, kv-head, partition); all GQA query heads of
+//    the kv-head share the K/V stream (heads sit in the MFMA N dimension).
+//  * S^T[token, head] = K[token, :] . Q^T  with v_mfma_f32_16x16x32: the K cache
+//    layout [hd/x][block][x] (x = 16 B) makes the A fragment of a 16-token tile a
+//    lane-linear 1 KiB load (lane = 16*chunk + token) -- perfectly coalesced,
+//    no LDS staging, no transposes.
+//  * online softmax per head in registers; the probabilities leave the QK MFMA
+//    in exactly the lane layout the PV MFMA wants as its B operand if the
+//    "k index" of that MFMA is defined as (tile, 4g+r) -- so P never moves
+//    between lanes.  O^T[d, head] += V^T[d, token] . P^T[token, head].
+//  * fp8 (e4m3 / e5m2) KV is widened to the query dtype in registers (exact),
+//    k_scale folds into the softmax scale and v_scale into the final
+//    normalisation: dequant costs no extra memory pass.
+//  * waves of a workgroup interleave 32-token tile pairs and merge (m, l, O)
+//    through LDS; partitions merge by the reference's exp_sums/max_logits/
+//    tmp_out contract.
+#include "common.h"
+
+namespace aphro {
+
+struct PAParams {
+  void* out;
+  float* exp_sums;
+  float* max_logits;
+  void* tmp_out;
+  const void* q;
+  const void* kc;
+  const void* vc;
+  const int32_t* block_tables;
+  const int32_t* seq_lens;
+  const float* alibi;
+  int num_heads, num_kv_heads;
+  int max_blocks_per_seq;
+  int partition_size;  // tokens per grid.z slice (multiple of 32) ; 0 -> whole sequence
+  int max_parts;       // P of the scratch tensors (0 in v1 form)
+  int nh_lds;          // query heads per kv head held in the LDS merge buffer (<= 16)
+  int write_direct;    // 1: write `out` (single partition) ; 0: write scratch
+  float scale;         // softmax scale * k_scale
+  float v_scale;
+  int64_t q_stride, kv_block_stride, kv_head_stride;
+};
+
+template <typename T>
+__device__ __forceinline__ f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c);
+template <>
+__device__ __forceinline__ f32x4 mfma16<Half>(u32x4 a, u32x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ f32x4 mfma16<BFloat>(u32x4 a, u32x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// two floats (exactly representable in T) -> packed pair of T
+template <typename T>
+__device__ __forceinline__ uint32_t pack2(float a, float b) {
+  if constexpr (__is_same(T, Half)) {
+    f16x2 h = {(f16)a, (f16)b};
+    return __builtin_bit_cast(uint32_t, h);
+  } else {
+    return (uint32_t)f32_to_bf16_bits(a) | ((uint32_t)f32_to_bf16_bits(b) << 16);
+  }
+}
+// 4 packed fp8 -> 4 values of T (two dwords)
+template <typename T, bool E5M2>
+__device__ __forceinline__ u32x2 fp8x4_to_T(uint32_t w) {
+  f32x2 a = fp8x2_to_f32<E5M2>(w, false);
+  f32x2 b = fp8x2_to_f32<E5M2>(w, true);
+  u32x2 r;
+  if constexpr (__is_same(T, Half)) {
+    r[0] = pack2<Half>(a[0], a[1]);
+    r[1] = pack2<Half>(b[0], b[1]);
+  } else {  // exact in bf16: truncation
+    r[0] = (__builtin_bit_cast(uint32_t, a[0]) >> 16) | (__builtin_bit_cast(uint32_t, a[1]) & 0xffff0000u);
+    r[1] = (__builtin_bit_cast(uint32_t, b[0]) >> 16) | (__builtin_bit_cast(uint32_t, b[1]) & 0xffff0000u);
+  }
+  return r;
+}
+
+// KV: 0 = cache holds T, 1 = e4m3, 2 = e5m2.   HD: head size.  BS: block size.
+template <typename T, int KV, int HD, int BS, int NW>
+__global__ __launch_bounds__(NW * 64) void paged_attention_kernel(PAParams p) {
+  constexpr bool FP8 = KV != 0;
+  constexpr bool E5M2 = KV == 2;
+  constexpr int XB = 16;                        // bytes per K chunk
+  constexpr int XE = FP8 ? 16 : 8;              // elements per K chunk
+  constexpr int NCH = HD / XE;                  // chunks per token
+  constexpr int NLD = (NCH + 3) / 4;            // 16-B K loads per lane per tile
+  constexpr int NKS = FP8 ? 2 * NLD : (HD + 31) / 32;  // QK MFMAs per tile
+  constexpr int NDT = (HD + 15) / 16;           // PV d-tiles
+  constexpr int ESZ = FP8 ? 1 : 2;              // cache element bytes
+  static_assert(HD % XE == 0, "head size must be a multiple of the K chunk");
+
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int g = lane >> 4;
+  const int c = lane & 15;
+  const int kvh = blockIdx.x;
+  const int seq = blockIdx.y;
+  const int part = blockIdx.z;
+  const int gqa = p.num_heads / p.num_kv_heads;
+  const int seq_len = p.seq_lens[seq];
+  const int psz = p.partition_size > 0 ? p.partition_size : 0x7fffffe0;
+  const int pstart = part * psz;
+  if (pstart >= seq_len) return;
+  const int pend = min(seq_len, pstart + psz);
+  const int32_t* bt = p.block_tables + (size_t)seq * p.max_blocks_per_seq;
+  const int alloc_tokens = ((seq_len + BS - 1) / BS) * BS;  // addressable tokens
+
+  const char* kc = (const char*)p.kc + (size_t)kvh * p.kv_head_stride * ESZ;
+  const char* vc = (const char*)p.vc + (size_t)kvh * p.kv_head_stride * ESZ;
+
+  for (int hb = 0; hb < gqa; hb += 16) {  // >16 query heads per kv head: extra passes
+    const int nh = min(16, gqa - hb);
+    const int head = kvh * gqa + hb + c;  // this lane's query head (valid if c < nh)
+    // ---- Q fragments (B operand: lane (g, head) holds 8 consecutive d) --------
+    u32x4 qf[NKS];
+    {
+      const uint16_t* qp = (const uint16_t*)p.q + (size_t)seq * p.q_stride + (size_t)head * HD;
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        int d0;
+        if constexpr (FP8) d0 = 64 * (ks >> 1) + 16 * g + 8 * (ks & 1);
+        else d0 = 32 * ks + 8 * g;
+        if (c < nh && d0 < HD) qf[ks] = *reinterpret_cast<const u32x4*>(qp + d0);
+        else qf[ks] = u32x4{0, 0, 0, 0};
+      }
+    }
+    const float slope = (p.alibi != nullptr && c < nh) ? p.alibi[head] : 0.f;
+
+    f32x4 o[NDT];
+#pragma unroll
+    for (int i = 0; i < NDT; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -1e30f;
+    float l_run = 0.f;  // this lane's share (its 4g..4g+3 tokens); summed over g at the end
+
+    const int pair0 = pstart >> 5;
+    const int pair_end = (pend + 31) >> 5;
+    for (int pr = pair0 + wave; pr < pair_end; pr += NW) {
+      const int tb = pr << 5;
+      // ---- addresses -----------------------------------------------------------
+      const char* kptr[2];
+      const char* vptr[2];
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        int tk = min(tb + 16 * jj + c, seq_len - 1);
+        int blk = bt[tk / BS];
+        kptr[jj] = kc + ((size_t)blk * p.kv_block_stride + (size_t)(tk % BS) * XE) * ESZ;
+        int tv = min(tb + 16 * jj + 4 * g, alloc_tokens - 4);
+        int blv = bt[tv / BS];
+        vptr[jj] = vc + ((size_t)blv * p.kv_block_stride + (size_t)c * BS + (tv % BS)) * ESZ;
+      }
+      // ---- issue all K and V loads of the pair ----------------------------------
+      u32x4 kf[2][NLD];
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int ld = 0; ld < NLD; ++ld) {
+          int ch = 4 * ld + g;
+          if (ch < NCH)
+            kf[jj][ld] = __builtin_nontemporal_load(
+                reinterpret_cast<const u32x4*>(kptr[jj] + (size_t)ch * BS * XB));
+          else
+            kf[jj][ld] = u32x4{0, 0, 0, 0};
+        }
+      u32x2 vraw[NDT][2];  // 16-bit KV: 4 tokens = 8 B ; fp8: 4 B in [0]
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+          const char* vp = vptr[jj] + (size_t)dt * 16 * BS * ESZ;
+          if (16 * dt + c < HD) {
+            if constexpr (FP8) {
+              vraw[dt][jj][0] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(vp));
+              vraw[dt][jj][1] = 0;
+            } else {
+              vraw[dt][jj] = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(vp));
+            }
+          } else {
+            vraw[dt][jj] = u32x2{0, 0};
+          }
+        }
+      // ---- S^T = K . Q^T -----------------------------------------------------------
+      f32x4 s[2];
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        s[jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (FP8) {
+#pragma unroll
+          for (int ld = 0; ld < NLD; ++ld) {
+            u32x2 c0 = fp8x4_to_T<T, E5M2>(kf[jj][ld][0]);
+            u32x2 c1 = fp8x4_to_T<T, E5M2>(kf[jj][ld][1]);
+            u32x2 c2 = fp8x4_to_T<T, E5M2>(kf[jj][ld][2]);
+            u32x2 c3 = fp8x4_to_T<T, E5M2>(kf[jj][ld][3]);
+            u32x4 lo = {c0[0], c0[1], c1[0], c1[1]};
+            u32x4 hi = {c2[0], c2[1], c3[0], c3[1]};
+            s[jj] = mfma16<T>(lo, qf[2 * ld], s[jj]);
+            s[jj] = mfma16<T>(hi, qf[2 * ld + 1], s[jj]);
+          }
+        } else {
+#pragma unroll
+          for (int ks = 0; ks < NKS; ++ks) s[jj] = mfma16<T>(kf[jj][ks], qf[ks], s[jj]);
+        }
+      }
+      // ---- online softmax (lane = head column c, tokens tb+16jj+4g+r) ------------------
+      float pv[2][4];
+      float mx = -1e30f;
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          int tok = tb + 16 * jj + 4 * g + r;
+          float x = s[jj][r] * p.scale + slope * (float)(tok - seq_len + 1);
+          bool ok = tok >= pstart && tok < pend;
+          x = ok ? x : -1e30f;
+          pv[jj][r] = x;
+          mx = __builtin_fmaxf(mx, x);
+        }
+      mx = __builtin_fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = __builtin_fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = __builtin_fmaxf(m_run, mx);
+      const float alpha = __expf(m_run - m_new);
+      m_run = m_new;
+      float lsum = 0.f;
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float e = pv[jj][r] > -1e29f ? __expf(pv[jj][r] - m_new) : 0.f;
+          pv[jj][r] = e;
+          lsum += e;
+        }
+      l_run = l_run * alpha + lsum;
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt) o[dt] *= alpha;
+      u32x4 pf;  // B operand of the PV MFMA: k = (jj, 4g + r)
+      pf[0] = pack2<T>(pv[0][0], pv[0][1]);
+      pf[1] = pack2<T>(pv[0][2], pv[0][3]);
+      pf[2] = pack2<T>(pv[1][0], pv[1][1]);
+      pf[3] = pack2<T>(pv[1][2], pv[1][3]);
+      // ---- O^T += V^T . P^T --------------------------------------------------------
+      const bool ragged = (tb + 32 > pend);  // wave-uniform: last pair of the range
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt) {
+        u32x4 vf;
+        if constexpr (FP8) {
+          u32x2 c0 = fp8x4_to_T<T, E5M2>(vraw[dt][0][0]);
+          u32x2 c1 = fp8x4_to_T<T, E5M2>(vraw[dt][1][0]);
+          vf = u32x4{c0[0], c0[1], c1[0], c1[1]};
+        } else {
+          vf[0] = vraw[dt][0][0]; vf[1] = vraw[dt][0][1];
+          vf[2] = vraw[dt][1][0]; vf[3] = vraw[dt][1][1];
+        }
+        if (ragged) {  // zero V of tokens outside [pstart, pend): 0 * NaN must not poison O
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+              int tok = tb + 16 * jj + 4 * g + 2 * h2;
+              uint32_t msk = (tok < pend ? 0x0000ffffu : 0u) | (tok + 1 < pend ? 0xffff0000u : 0u);
+              vf[2 * jj + h2] &= msk;
+            }
+        }
+        o[dt] = mfma16<T>(vf, pf, o[dt]);
+      }
+    }
+
+    // ---- merge the NW waves through LDS ---------------------------------------------
+    // layout: ml[NW][16][2] then ov[NW][16 heads][HD]
+    l_run += __shfl_xor(l_run, 16, 64);
+    l_run += __shfl_xor(l_run, 32, 64);
+    float* ml = lds;
+    float* ov = lds + NW * 16 * 2;
+    __syncthreads();  // previous head-block pass finished reading
+    if (g == 0) {
+      ml[(wave * 16 + c) * 2 + 0] = m_run;
+      ml[(wave * 16 + c) * 2 + 1] = l_run;
+    }
+    if (c < nh) {
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt) {
+        int d = 16 * dt + 4 * g;
+        if (d < HD) *reinterpret_cast<f32x4*>(&ov[((size_t)wave * p.nh_lds + c) * HD + d]) = o[dt];
+      }
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < nh * HD; idx += NW * 64) {
+      const int h = idx / HD, d = idx - h * HD;
+      float M = -1e30f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) M = __builtin_fmaxf(M, ml[(w * 16 + h) * 2]);
+      float L = 0.f, acc = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) {
+        float wt = __expf(ml[(w * 16 + h) * 2] - M);
+        L += ml[(w * 16 + h) * 2 + 1] * wt;
+        acc += ov[((size_t)w * p.nh_lds + h) * HD + d] * wt;
+      }
+      const float res = acc * (1.f / (L + 1e-6f)) * p.v_scale;
+      const int qh = kvh * gqa + hb + h;
+      if (p.write_direct) {
+        ((typename T::storage*)p.out)[((size_t)seq * p.num_heads + qh) * HD + d] = T::from_f32(res);
+      } else {
+        const size_t pi = ((size_t)seq * p.num_heads + qh) * p.max_parts + part;
+        ((typename T::storage*)p.tmp_out)[pi * HD + d] = T::from_f32(res);
+        if (d == 0) {
+          p.exp_sums[pi] = L;
+          p.max_logits[pi] = M;
+        }
+      }
+    }
+  }
+}
+
+// attention_kernels.cu:564-669: merge partitions.  grid (heads, seqs), block HD.
+template <typename T, int HD>
+__global__ void paged_attention_reduce_kernel(typename T::storage* __restrict__ out,
+                                              const float* __restrict__ exp_sums,
+                                              const float* __restrict__ max_logits,
+                                              const typename T::storage* __restrict__ tmp_out,
+                                              const int32_t* __restrict__ seq_lens, int num_heads,
+                                              int max_parts, int partition_size) {
+  const int head = blockIdx.x, seq = blockIdx.y;
+  const int seq_len = seq_lens[seq];
+  const int parts = (seq_len + partition_size - 1) / partition_size;
+  const size_t base = ((size_t)seq * num_heads + head) * max_parts;
+  float M = -1e30f;
+  for (int j = 0; j < parts; ++j) M = __builtin_fmaxf(M, max_logits[base + j]);
+  float L = 0.f;
+  for (int j = 0; j < parts; ++j) L += exp_sums[base + j] * __expf(max_logits[base + j] - M);
+  const float inv = 1.f / (L + 1e-6f);
+  for (int d = threadIdx.x; d < HD; d += blockDim.x) {
+    float acc = 0.f;
+    for (int j = 0; j < parts; ++j)
+      acc += T::to_f32(tmp_out[(base + j) * HD + d]) * exp_sums[base + j] * __expf(max_logits[base + j] - M);
+    out[((size_t)seq * num_heads + head) * HD + d] = T::from_f32(parts > 0 ? acc * inv : 0.f);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// cache write / fp8 convert
+// ---------------------------------------------------------------------------
+template <typename T, int KV>
+__global__ void reshape_and_cache_kernel(const typename T::storage* __restrict__ key,
+                                         const typename T::storage* __restrict__ value,
+                                         void* __restrict__ key_cache, void* __restrict__ value_cache,
+                                         const int64_t* __restrict__ slot_mapping, int num_kv_heads,
+                                         int head_size, int block_size, int x, int64_t key_stride,
+                                         int64_t value_stride, float k_scale, float v_scale) {
+  const int64_t token = blockIdx.x;
+  const int64_t slot = slot_mapping[token];
+  if (slot < 0) return;  // padding (cache_kernels.cu:163-166)
+  const int64_t blk = slot / block_size, off = slot % block_size;
+  const int n = num_kv_heads * head_size;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const int h = i / head_size, d = i % head_size;
+    const int64_t kdst = (((blk * num_kv_heads + h) * (head_size / x) + d / x) * block_size + off) * x + d % x;
+    const int64_t vdst = ((blk * num_kv_heads + h) * head_size + d) * block_size + off;
+    if constexpr (KV == 0) {
+      ((typename T::storage*)key_cache)[kdst] = key[token * key_stride + i];
+      ((typename T::storage*)value_cache)[vdst] = value[token * value_stride + i];
+    } else {
+      float kf = T::to_f32(key[token * key_stride + i]) / k_scale;  // cache_kernels.cu:198-201
+      float vf = T::to_f32(value[token * value_stride + i]) / v_scale;
+      ((uint8_t*)key_cache)[kdst] = (uint8_t)f32x2_to_fp8<KV == 2>(kf, 0.f);
+      ((uint8_t*)value_cache)[vdst] = (uint8_t)f32x2_to_fp8<KV == 2>(vf, 0.f);
+    }
+  }
+}
+
+template <typename T, int KV, bool TO_FP8>
+__global__ void convert_fp8_kernel(void* __restrict__ dst, const void* __restrict__ src, int64_t n,
+                                   float scale) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    if constexpr (TO_FP8) {
+      float f = T::to_f32(((const typename T::storage*)src)[i]) / scale;
+      ((uint8_t*)dst)[i] = (uint8_t)f32x2_to_fp8<KV == 2>(f, 0.f);
+    } else {
+      float f = fp8_to_f32<KV == 2>(((const uint8_t*)src)[i]) * scale;
+      ((typename T::storage*)dst)[i] = T::from_f32(f);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+template <typename T, int KV, int HD, int BS>
+static int launch_pa(const PAParams& p, int num_seqs, int parts, int nw, hipStream_t st) {
+  dim3 grid((unsigned)p.num_kv_heads, (unsigned)num_seqs, (unsigned)parts);
+  size_t lds = ((size_t)nw * 16 * 2 + (size_t)nw * p.nh_lds * HD) * sizeof(float);
+#define APHRO_PA_LAUNCH(NWV)                                                                        \
+  {                                                                                                 \
+    auto kern = paged_attention_kernel<T, KV, HD, BS, NWV>;                                         \
+    if (lds > 64 * 1024)                                                                            \
+      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL(kern, grid, dim3(NWV * 64), lds, st, p);                                      \
+  }
+  if (nw == 4) APHRO_PA_LAUNCH(4)
+  else APHRO_PA_LAUNCH(8)
+#undef APHRO_PA_LAUNCH
+  APHRO_LAUNCH_CHECK();
+  return APHRO_OK;
+}
+
+template <typename T, int KV>
+static int dispatch_pa(const PAParams& p, int num_seqs, int parts, int nw, int head_size, int block_size,
+                       hipStream_t st) {
+#define APHRO_PA_CASE(HDV, BSV) \
+  if (head_size == HDV && block_size == BSV) return launch_pa<T, KV, HDV, BSV>(p, num_seqs, parts, nw, st);
+  APHRO_PA_CASE(128, 16)
+  APHRO_PA_CASE(128, 32)
+  APHRO_PA_CASE(64, 16)
+  APHRO_PA_CASE(64, 32)
+  APHRO_PA_CASE(96, 16)
+  APHRO_PA_CASE(80, 16)
+  APHRO_PA_CASE(112, 16)
+  APHRO_PA_CASE(192, 16)
+  APHRO_PA_CASE(256, 16)
+  APHRO_PA_CASE(128, 8)
+  APHRO_PA_CASE(64, 8)
+#undef APHRO_PA_CASE
+  set_error("paged_attention: unsupported head_size=%d / block_size=%d", head_size, block_size);
+  return APHRO_ERR_INVALID;
+}
+
+}  // namespace aphro
+
+using namespace aphro;
+
+extern "C" int aphro_paged_attention(void* out, float* exp_sums, float* max_logits, void* tmp_out,
+                                     const void* query, const void* key_cache, const void* value_cache,
+                                     int num_seqs, int num_heads, int num_kv_heads, int head_size,
+                                     float scale, const int32_t* block_tables, const int32_t* seq_lens,
+                                     int max_num_blocks_per_seq, int block_size, int max_seq_len,
+                                     const float* alibi_slopes, int64_t q_stride, int64_t kv_block_stride,
+                                     int64_t kv_head_stride, int dtype, int kv_dtype, float k_scale,
+                                     float v_scale, int partition_size, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  APHRO_CHECK(dtype == APHRO_F16 || dtype == APHRO_BF16, "paged_attention: query dtype must be f16 or bf16");
+  APHRO_CHECK(kv_dtype >= APHRO_KV_AUTO && kv_dtype <= APHRO_KV_FP8_E5M2, "Unsupported data type of kv cache: %d", kv_dtype);
+  APHRO_CHECK(num_kv_heads > 0 && num_heads % num_kv_heads == 0, "paged_attention: num_heads %% num_kv_heads != 0");
+  APHRO_CHECK(partition_size >= 0 && partition_size % 32 == 0, "paged_attention: partition size must be a multiple of 32");
+  APHRO_CHECK(q_stride % 8 == 0 && ((uintptr_t)query % 16) == 0, "paged_attention: query must be 16-byte aligned");
+  if (num_seqs == 0) return APHRO_OK;
+  PAParams p;
+  p.out = out; p.exp_sums = exp_sums; p.max_logits = max_logits; p.tmp_out = tmp_out;
+  p.q = query; p.kc = key_cache; p.vc = value_cache;
+  p.block_tables = block_tables; p.seq_lens = seq_lens; p.alibi = alibi_slopes;
+  p.num_heads = num_heads; p.num_kv_heads = num_kv_heads;
+  p.max_blocks_per_seq = max_num_blocks_per_seq;
+  p.scale = scale * (kv_dtype == APHRO_KV_AUTO ? 1.f : k_scale);
+  p.v_scale = kv_dtype == APHRO_KV_AUTO ? 1.f : v_scale;
+  p.q_stride = q_stride; p.kv_block_stride = kv_block_stride; p.kv_head_stride = kv_head_stride;
+  const int gqa = num_heads / num_kv_heads;
+  p.nh_lds = gqa < 16 ? gqa : 16;
+  int parts = 1, nw;
+  if (partition_size == 0) {
+    p.partition_size = 0; p.max_parts = 0; p.write_direct = 1;
+    // v1 form: one workgroup per (seq, kv head) walks the whole sequence
+    nw = max_seq_len > 256 ? 8 : 4;
+    while (nw > 4 && (size_t)nw * (32 + p.nh_lds * head_size) * 4 > 96 * 1024) nw >>= 1;
+  } else {
+    APHRO_CHECK(exp_sums && max_logits && tmp_out, "paged_attention: partitioned form needs scratch tensors");
+    parts = (max_seq_len + partition_size - 1) / partition_size;
+    if (parts < 1) parts = 1;
+    p.partition_size = partition_size; p.max_parts = parts;
+    p.write_direct = parts == 1;
+    nw = 4;
+  }
+  int rc;
+#define APHRO_PA_KV(TT)                                                                                 \
+  (kv_dtype == APHRO_KV_AUTO       ? dispatch_pa<TT, 0>(p, num_seqs, parts, nw, head_size, block_size, st) \
+   : kv_dtype == APHRO_KV_FP8_E4M3 ? dispatch_pa<TT, 1>(p, num_seqs, parts, nw, head_size, block_size, st) \
+                                   : dispatch_pa<TT, 2>(p, num_seqs, parts, nw, head_size, block_size, st))
+  rc = dtype == APHRO_F16 ? APHRO_PA_KV(Half) : APHRO_PA_KV(BFloat);
+#undef APHRO_PA_KV
+  if (rc != APHRO_OK) return rc;
+  if (!p.write_direct) {
+    dim3 grid((unsigned)num_heads, (unsigned)num_seqs);
+    int threads = head_size <= 64 ? 64 : 128;
+#define APHRO_RED(TT, HDV)                                                                      \
+  hipLaunchKernelGGL((paged_attention_reduce_kernel<TT, HDV>), grid, dim3(threads), 0, st,       \
+                     (typename TT::storage*)out, exp_sums, max_logits,                          \
+                     (const typename TT::storage*)tmp_out, seq_lens, num_heads, parts, partition_size)
+#define APHRO_RED_HD(TT)                                     \
+  switch (head_size) {                                       \
+    case 64: APHRO_RED(TT, 64); break;                       \
+    case 80: APHRO_RED(TT, 80); break;                       \
+    case 96: APHRO_RED(TT, 96); break;                       \
+    case 112: APHRO_RED(TT, 112); break;                     \
+    case 128: APHRO_RED(TT, 128); break;                     \
+    case 192: APHRO_RED(TT, 192); break;                     \
+    default: APHRO_RED(TT, 256); break;                      \
+  }
+    if (dtype == APHRO_F16) { APHRO_RED_HD(Half) } else { APHRO_RED_HD(BFloat) }
+#undef APHRO_RED_HD
+#undef APHRO_RED
+    APHRO_LAUNCH_CHECK();
+  }
+  return APHRO_OK;
+}
+
+extern "C" int aphro_reshape_and_cache(const void* key, const void* value, void* key_cache,
+                                       void* value_cache, const int64_t* slot_mapping, int64_t num_tokens,
+                                       int num_kv_heads, int head_size, int block_size, int x,
+                                       int64_t key_stride, int64_t value_stride, int dtype, int kv_dtype,
+                                       float k_scale, float v_scale, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  APHRO_CHECK(kv_dtype >= APHRO_KV_AUTO && kv_dtype <= APHRO_KV_FP8_E5M2, "Unsupported data type of kv cache: %d", kv_dtype);
+  APHRO_CHECK(dtype >= APHRO_F16 && dtype <= APHRO_F32, "Unsupported input type of kv cache: %d", dtype);
+  APHRO_CHECK(x > 0 && head_size % x == 0, "reshape_and_cache: head_size %% x != 0");
+  if (num_tokens == 0) return APHRO_OK;
+  int n = num_kv_heads * head_size;
+  dim3 grid((unsigned)num_tokens), block((unsigned)(n < 512 ? (n + 63) / 64 * 64 : 512));
+#define APHRO_RC(TT, KVV)                                                                           \
+  hipLaunchKernelGGL((reshape_and_cache_kernel<TT, KVV>), grid, block, 0, st,                        \
+                     (const typename TT::storage*)key, (const typename TT::storage*)value, key_cache, \
+                     value_cache, slot_mapping, num_kv_heads, head_size, block_size, x, key_stride,   \
+                     value_stride, k_scale, v_scale)
+#define APHRO_RC_T(KVV)                                  \
+  if (dtype == APHRO_F16) APHRO_RC(Half, KVV);           \
+  else if (dtype == APHRO_BF16) APHRO_RC(BFloat, KVV);   \
+  else APHRO_RC(Float, KVV);
+  if (kv_dtype == APHRO_KV_AUTO) { APHRO_RC_T(0) }
+  else if (kv_dtype == APHRO_KV_FP8_E4M3) { APHRO_RC_T(1) }
+  else { APHRO_RC_T(2) }
+#undef APHRO_RC_T
+#undef APHRO_RC
+  APHRO_LAUNCH_CHECK();
+  return APHRO_OK;
+}
+
+extern "C" int aphro_convert_fp8(void* dst, const void* src, int64_t numel, float scale, int hp_dtype,
+                                 int kv_dtype, int to_fp8, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  APHRO_CHECK(kv_dtype == APHRO_KV_FP8_E4M3 || kv_dtype == APHRO_KV_FP8_E5M2, "Unsupported data type of kv cache: %d", kv_dtype);
+  APHRO_CHECK(hp_dtype >= APHRO_F16 && hp_dtype <= APHRO_F32, "convert_fp8: unsupported dtype %d", hp_dtype);
+  if (numel == 0) return APHRO_OK;
+  unsigned blocks = (unsigned)((numel + 255) / 256 < 4096 ? (numel + 255) / 256 : 4096);
+#define APHRO_CV(TT, KVV, DIR) \
+  hipLaunchKernelGGL((convert_fp8_kernel<TT, KVV, DIR>), dim3(blocks), dim3(256), 0, st, dst, src, numel, scale)
+#define APHRO_CV_T(KVV, DIR)                                  \
+  if (hp_dtype == APHRO_F16) APHRO_CV(Half, KVV, DIR);        \
+  else if (hp_dtype == APHRO_BF16) APHRO_CV(BFloat, KVV, DIR); \
+  else APHRO_CV(Float, KVV, DIR);
+  if (kv_dtype == APHRO_KV_FP8_E4M3) {
+    if (to_fp8) { APHRO_CV_T(1, true) } else { APHRO_CV_T(1, false) }
+  } else {
+    if (to_fp8) { APHRO_CV_T(2, true) } else { APHRO_CV_T(2, false) }
+  }
+#undef APHRO_CV_T
+#undef APHRO_CV
+  APHRO_LAUNCH_CHECK();
+  return APHRO_OK;
+}

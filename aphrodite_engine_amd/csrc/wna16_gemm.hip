@@ -1,0 +1,539 @@
+// W4A16 (GPTQ / K-packed int4) small-M GEMM for gfx950 -- the decode hot kernel.
+//
+// Replaces the reference's exllama kernel gemm_half_q_half_gptq_4bit_kernel
+// (kernels/quantization/gptq/q_gemm.cu:190-326), its shuffle / reconstruct
+// kernels (:856-965, :1394-1434, :1569-1657) and fills the gptq_marlin_gemm
+// role for M <= 64.  Design (DESIGN.md "wna16_gemm"):
+//   * HBM-bound: every packed int4 word is read exactly once per call with
+//     16 B/lane coalesced loads (256 B contiguous per 16 lanes).
+//   * The exllama word layout (8 consecutive k of ONE column per dword, nibble
+//     pairs (k, k+1) in the two halves) is already the B fragment of
+//     v_mfma_f32_16x16x32_f16: lane (g = lane>>4, c = lane&15) holds
+//     k = 8g..8g+7 of one column.  A dwordx4 load gives the lane 4 adjacent
+//     columns -> 4 MFMA n-tiles whose column index is n0 + 4c + t.
+//   * int4 -> f16 in registers: (w & 0x000f000f) | 0x6400 is half2(1024 + q);
+//     subtracting half2(1024 + z) is exact.  The group scale is applied to
+//     the fp32 partial sum of each 128-k group (exact integer weights in the
+//     MFMA, fp32 everywhere after) -- strictly more accurate than the
+//     reference's fp16 dot + fp16 atomics.
+//   * A workgroup = 8 waves that split the K range of ONE column tile and
+//     reduce through LDS (deterministic, no atomics); an optional second
+//     level of split-K across workgroups goes through an fp32 workspace and
+//     a tiny reduce kernel.
+#include "common.h"
+
+namespace aphro {
+
+constexpr int NW = 8;  // waves per workgroup
+
+// ---------------------------------------------------------------------------
+// int4 -> f16x8 for one exllama-ordered word.  zh = half2(1024 + z),
+// zh16 = half2(-64 - z)  (z = effective zero point)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ f16x8 dq8_exl(uint32_t w, f16x2 zh, f16x2 zh16) {
+  const f16x2 inv16 = {(f16)0.0625f, (f16)0.0625f};
+  uint32_t q0 = (w & 0x000f000fu) | 0x64006400u;  // 1024 + (e0, e1)
+  uint32_t q1 = (w & 0x00f000f0u) | 0x64006400u;  // 1024 + 16*(e2, e3)
+  w >>= 8;
+  uint32_t q2 = (w & 0x000f000fu) | 0x64006400u;  // e4, e5
+  uint32_t q3 = (w & 0x00f000f0u) | 0x64006400u;  // e6, e7
+  f16x2 d0 = __builtin_bit_cast(f16x2, q0) - zh;
+  f16x2 d1 = __builtin_bit_cast(f16x2, q1) * inv16 + zh16;
+  f16x2 d2 = __builtin_bit_cast(f16x2, q2) - zh;
+  f16x2 d3 = __builtin_bit_cast(f16x2, q3) * inv16 + zh16;
+  f16x8 r;
+  r[0] = d0[0]; r[1] = d0[1]; r[2] = d1[0]; r[3] = d1[1];
+  r[4] = d2[0]; r[5] = d2[1]; r[6] = d3[0]; r[7] = d3[1];
+  return r;
+}
+
+template <typename T>
+__device__ __forceinline__ f16x8 load_a_frag(const uint16_t* p);
+template <>
+__device__ __forceinline__ f16x8 load_a_frag<Half>(const uint16_t* p) {
+  return *reinterpret_cast<const f16x8*>(p);
+}
+template <>
+__device__ __forceinline__ f16x8 load_a_frag<BFloat>(const uint16_t* p) {
+  // bf16 activations are converted to f16 for the MFMA (the
+  // reference's GPTQ/AWQ kernels are fp16-only, gptq.py:54-55).
+  u16x8 v = *reinterpret_cast<const u16x8*>(p);
+  f16x8 r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r[i] = (f16)bf16_bits_to_f32(v[i]);
+  return r;
+}
+
+struct Wna16Params {
+  const uint16_t* a;      // [M, lda]
+  const uint32_t* qw;     // [K/8, N] exllama order
+  const uint32_t* qz;     // [G, N/8]
+  const uint16_t* sc;     // [G, N]
+  uint16_t* c;            // [M, N]  (when ksplit == 1)
+  float* partial;         // [ksplit, M, N] (when ksplit > 1)
+  int M, N, K;
+  int lda;
+  int group_size;         // K / groups, multiple of 32
+  int ksteps_per_split;   // k-steps (32 k) per blockIdx.y
+  int ksplit;
+  int zero_offset;
+};
+
+// VEC = dwords per lane per k-step (4 -> 64-column tile, 2 -> 32, 1 -> 16)
+// MT  = 16-row m-tiles (1 or 2)
+template <typename T, int VEC, int MT>
+__global__ __launch_bounds__(NW * 64) void wna16_gemm_kernel(Wna16Params p) {
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [NW][MT*VEC][64][4]
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int g = lane >> 4;   // k sub-block (8 k each)
+  const int c = lane & 15;   // column slot / A row
+  const int n0 = blockIdx.x * (16 * VEC);
+  const int m0 = blockIdx.z * (16 * MT);
+  const int ncol = n0 + VEC * c;  // first of this lane's VEC columns
+
+  // K range of this workgroup, then of this wave (contiguous chunk of k-steps)
+  const int total_steps = p.K >> 5;
+  const int wg_begin = blockIdx.y * p.ksteps_per_split;
+  const int wg_end = min(total_steps, wg_begin + p.ksteps_per_split);
+  const int per_wave = (wg_end - wg_begin + NW - 1) / NW;
+  int s = wg_begin + wave * per_wave;
+  const int s_end = min(wg_end, s + per_wave);
+
+  f32x4 acc[MT][VEC];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int t = 0; t < VEC; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // A row pointers (rows >= M are clamped; their results are never stored)
+  const uint16_t* arow[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    int r = min(m0 + 16 * i + c, p.M - 1);
+    arow[i] = p.a + (size_t)r * p.lda + 8 * g;
+  }
+  const uint32_t* wbase = p.qw + (size_t)g * p.N + ncol;
+  const int steps_per_group = p.group_size >> 5;
+
+  while (s < s_end) {
+    const int grp = s / steps_per_group;
+    const int seg_end = min(s_end, (grp + 1) * steps_per_group);
+    // group scale / zero for this lane's VEC columns
+    float scl[VEC];
+    f16x2 zh[VEC], zh16[VEC];
+    {
+      const uint16_t* sp = p.sc + (size_t)grp * p.N + ncol;
+      uint32_t zw = p.qz[(size_t)grp * (p.N >> 3) + (ncol >> 3)] >> ((ncol & 7) * 4);
+#pragma unroll
+      for (int t = 0; t < VEC; ++t) {
+        scl[t] = T::to_f32(sp[t]);
+        int z = (int)((zw >> (4 * t)) & 0xf) + p.zero_offset;
+        f16 a = __builtin_bit_cast(f16, (uint16_t)(0x6400 | z));  // 1024 + z
+        f16 b = (f16)(float)(-64 - z);
+        zh[t] = f16x2{a, a};
+        zh16[t] = f16x2{b, b};
+      }
+    }
+    f32x4 part[MT][VEC];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int t = 0; t < VEC; ++t) part[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // 4 k-steps per trip: all loads first, then dequant + MFMA
+    for (; s + 4 <= seg_end; s += 4) {
+      uint32_t w[4][VEC];
+      f16x8 af[4][MT];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint32_t* wp = wbase + (size_t)(s + u) * 4 * p.N;
+        if constexpr (VEC == 4) {
+          u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp));
+          w[u][0] = v[0]; w[u][1] = v[1]; w[u][2] = v[2]; w[u][3] = v[3];
+        } else if constexpr (VEC == 2) {
+          u32x2 v = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(wp));
+          w[u][0] = v[0]; w[u][1] = v[1];
+        } else {
+          w[u][0] = __builtin_nontemporal_load(wp);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int i = 0; i < MT; ++i) af[u][i] = load_a_frag<T>(arow[i] + (size_t)(s + u) * 32);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int t = 0; t < VEC; ++t) {
+          f16x8 b = dq8_exl(w[u][t], zh[t], zh16[t]);
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+            part[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[u][i], b, part[i][t], 0, 0, 0);
+        }
+    }
+    for (; s < seg_end; ++s) {  // tail k-steps of a short segment
+      const uint32_t* wp = wbase + (size_t)s * 4 * p.N;
+      uint32_t w[VEC];
+#pragma unroll
+      for (int t = 0; t < VEC; ++t) w[t] = wp[t];
+#pragma unroll
+      for (int t = 0; t < VEC; ++t) {
+        f16x8 b = dq8_exl(w[t], zh[t], zh16[t]);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          f16x8 af = load_a_frag<T>(arow[i] + (size_t)s * 32);
+          part[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, b, part[i][t], 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int t = 0; t < VEC; ++t) acc[i][t] += part[i][t] * scl[t];
+  }
+
+  // ---- in-workgroup split-K reduction through LDS -------------------------
+  // red[wave][q = i*VEC + t][lane] as float4 (lane-contiguous: conflict-free)
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int t = 0; t < VEC; ++t)
+      *reinterpret_cast<f32x4*>(&red[((wave * (MT * VEC) + i * VEC + t) * 64 + lane) * 4]) = acc[i][t];
+  __syncthreads();
+  // thread -> (lane l, row slot (i, r)): sums VEC adjacent columns of one row
+  for (int idx = wave; idx < MT * 4; idx += NW) {
+    const int i = idx >> 2, r = idx & 3;
+    const int row = m0 + 16 * i + 4 * g + r;
+    float v[VEC];
+#pragma unroll
+    for (int t = 0; t < VEC; ++t) {
+      float sum = 0.f;
+#pragma unroll
+      for (int w2 = 0; w2 < NW; ++w2)
+        sum += red[((w2 * (MT * VEC) + i * VEC + t) * 64 + lane) * 4 + r];
+      v[t] = sum;
+    }
+    if (row < p.M) {
+      if (p.ksplit == 1) {
+        uint16_t* cp = p.c + (size_t)row * p.N + ncol;
+        if constexpr (VEC == 4) {
+          u16x4 o = {T::from_f32(v[0]), T::from_f32(v[1]), T::from_f32(v[2]), T::from_f32(v[3])};
+          *reinterpret_cast<u16x4*>(cp) = o;
+        } else {
+#pragma unroll
+          for (int t = 0; t < VEC; ++t) cp[t] = T::from_f32(v[t]);
+        }
+      } else {
+        float* pp = p.partial + ((size_t)blockIdx.y * p.M + row) * p.N + ncol;
+        if constexpr (VEC == 4) {
+          *reinterpret_cast<f32x4*>(pp) = f32x4{v[0], v[1], v[2], v[3]};
+        } else {
+#pragma unroll
+          for (int t = 0; t < VEC; ++t) pp[t] = v[t];
+        }
+      }
+    }
+  }
+}
+
+// partial [S][M*N] fp32 -> c [M*N] (+ bias[N])
+template <typename T>
+__global__ void splitk_reduce_kernel(const float* __restrict__ partial, uint16_t* __restrict__ c,
+                                     const uint16_t* __restrict__ bias, int64_t mn, int N, int S) {
+  int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i >= mn) return;
+  f32x4 s = *reinterpret_cast<const f32x4*>(partial + i);
+  for (int k = 1; k < S; ++k) s += *reinterpret_cast<const f32x4*>(partial + (size_t)k * mn + i);
+  if (bias) {
+    int n = (int)(i % N);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s[j] += T::to_f32(bias[n + j]);
+  }
+  u16x4 o = {T::from_f32(s[0]), T::from_f32(s[1]), T::from_f32(s[2]), T::from_f32(s[3])};
+  *reinterpret_cast<u16x4*>(c + i) = o;
+}
+
+// a_perm[m][k] = a[m][perm[k]]   (act-order column gather, q_gemm.cu:219-226)
+__global__ void permute_cols_kernel(const uint16_t* __restrict__ a, const int32_t* __restrict__ perm,
+                                    uint16_t* __restrict__ out, int M, int K, int lda) {
+  int k = blockIdx.x * blockDim.x + threadIdx.x;
+  int m = blockIdx.y;
+  if (k < K) out[(size_t)m * K + k] = a[(size_t)m * lda + perm[k]];
+}
+
+// ---- load-time repack kernels ---------------------------------------------------
+__device__ __forceinline__ uint32_t shuffle_word(uint32_t q) {
+  // elements 0,2,4,6 -> bits[15:0]; 1,3,5,7 -> bits[31:16]  (qdq_4.cuh:17-35)
+  uint32_t r = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    r |= ((q >> (8 * i)) & 0xfu) << (4 * i);
+    r |= ((q >> (8 * i + 4)) & 0xfu) << (4 * i + 16);
+  }
+  return r;
+}
+__device__ __forceinline__ uint32_t unshuffle_word(uint32_t q) {
+  uint32_t r = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r |= ((q >> ((j >> 1) * 4 + ((j & 1) ? 16 : 0))) & 0xfu) << (4 * j);
+  return r;
+}
+
+// out[r][n] = shuffle(gather rows perm[8r..8r+7] of in)  (perm may be null)
+__global__ void gptq_repack_kernel(const uint32_t* __restrict__ in, const int32_t* __restrict__ perm,
+                                   uint32_t* __restrict__ out, int rows, int N) {
+  int n = blockIdx.x * blockDim.x + threadIdx.x;
+  int r = blockIdx.y;
+  if (n >= N) return;
+  uint32_t q;
+  if (perm) {
+    q = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      int src = perm[8 * r + i];
+      uint32_t w = in[(size_t)(src >> 3) * N + n];
+      q |= ((w >> ((src & 7) * 4)) & 0xfu) << (4 * i);
+    }
+  } else {
+    q = in[(size_t)r * N + n];
+  }
+  out[(size_t)r * N + n] = shuffle_word(q);
+}
+
+// AWQ [K, N/8] (nibble p of word c = column 8c + {0,2,4,6,1,3,5,7}[p]) ->
+// exllama-ordered K-packed [K/8, N]
+__global__ void awq_repack_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, int K,
+                                  int N) {
+  int n = blockIdx.x * blockDim.x + threadIdx.x;
+  int r = blockIdx.y;  // output row: k = 8r..8r+7
+  if (n >= N) return;
+  const int j = n & 7;
+  const int shift = 4 * (((j & 1) << 2) | (j >> 1));  // column j sits at nibble [0,4,1,5,2,6,3,7][j]
+  uint32_t q = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    uint32_t w = in[(size_t)(8 * r + i) * (N >> 3) + (n >> 3)];
+    q |= ((w >> shift) & 0xfu) << (4 * i);
+  }
+  out[(size_t)r * N + n] = shuffle_word(q);
+}
+__global__ void awq_repack_zeros_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
+                                        int64_t words) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= words) return;
+  uint32_t w = in[i], r = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int shift = 4 * (((j & 1) << 2) | (j >> 1));
+    r |= ((w >> shift) & 0xfu) << (4 * j);
+  }
+  out[i] = r;
+}
+
+// W[k][n] = (q - (z + zero_offset)) * s, one thread per packed word (8 k x 1 col)
+template <typename T>
+__global__ void gptq_dequant_kernel(const uint32_t* __restrict__ qw, const uint32_t* __restrict__ qz,
+                                    const uint16_t* __restrict__ sc, const int32_t* __restrict__ g_idx,
+                                    uint16_t* __restrict__ out, int K, int N, int group_size,
+                                    int shuffled, int zero_offset) {
+  int n = blockIdx.x * blockDim.x + threadIdx.x;
+  int r = blockIdx.y;
+  if (n >= N) return;
+  uint32_t w = qw[(size_t)r * N + n];
+  if (shuffled) w = unshuffle_word(w);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    int k = 8 * r + i;
+    int grp = g_idx ? g_idx[k] : k / group_size;
+    int z = (int)((qz[(size_t)grp * (N >> 3) + (n >> 3)] >> ((n & 7) * 4)) & 0xf) + zero_offset;
+    float s = T::to_f32(sc[(size_t)grp * N + n]);
+    int q = (int)((w >> (4 * i)) & 0xf);
+    // (q - z) is exact; one rounding to the 16-bit type, as __hmul does
+    // (q_gemm.cu:1427-1431)
+    out[(size_t)k * N + n] = T::from_f32((float)(q - z) * s);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+struct Wna16Plan {
+  int vec, mt, ksplit, ksteps_per_split;
+};
+
+static int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+
+static Wna16Plan make_plan(int64_t M, int64_t N, int64_t K) {
+  Wna16Plan pl;
+  pl.vec = (N % 64 == 0) ? 4 : (N % 32 == 0) ? 2 : 1;
+  int fv = env_int("APHRO_WNA16_VEC", 0);
+  if (fv == 1 || fv == 2 || fv == 4) {
+    if (N % (16 * fv) == 0) pl.vec = fv;
+  } else if (pl.vec == 4 && N / 64 < 192 && N % 32 == 0) {
+    pl.vec = 2;  // narrow N: 32-column tiles double the workgroup count
+  }
+  pl.mt = (M > 16) ? 2 : 1;
+  const int64_t tiles = N / (16 * pl.vec);
+  const int64_t mchunks = (M + 16 * pl.mt - 1) / (16 * pl.mt);
+  const int total_steps = (int)(K / 32);
+  // aim for >= ~1.5 workgroups per CU; every extra split costs M*N*8 bytes
+  int ks = (int)((384 + tiles * mchunks - 1) / (tiles * mchunks));
+  ks = ks < 1 ? 1 : (ks > 8 ? 8 : ks);
+  int fk = env_int("APHRO_WNA16_KSPLIT", 0);
+  if (fk > 0) ks = fk;
+  // each workgroup should keep >= 8 waves x 4 k-steps
+  while (ks > 1 && total_steps / ks < NW * 4) --ks;
+  pl.ksteps_per_split = (total_steps + ks - 1) / ks;
+  pl.ksteps_per_split = (pl.ksteps_per_split + 3) / 4 * 4;
+  pl.ksplit = (total_steps + pl.ksteps_per_split - 1) / pl.ksteps_per_split;
+  return pl;
+}
+
+template <typename T, int VEC, int MT>
+static void launch_wna16(const Wna16Params& p, const Wna16Plan& pl, hipStream_t st) {
+  dim3 grid((unsigned)(p.N / (16 * VEC)), (unsigned)pl.ksplit, (unsigned)((p.M + 16 * MT - 1) / (16 * MT)));
+  size_t lds = (size_t)NW * MT * VEC * 64 * 4 * sizeof(float);
+  hipLaunchKernelGGL((wna16_gemm_kernel<T, VEC, MT>), grid, dim3(NW * 64), lds, st, p);
+}
+
+template <typename T>
+static int run_wna16(Wna16Params p, const Wna16Plan& pl, hipStream_t st) {
+  switch (pl.vec * 10 + pl.mt) {
+    case 41: launch_wna16<T, 4, 1>(p, pl, st); break;
+    case 42: launch_wna16<T, 4, 2>(p, pl, st); break;
+    case 21: launch_wna16<T, 2, 1>(p, pl, st); break;
+    case 22: launch_wna16<T, 2, 2>(p, pl, st); break;
+    case 11: launch_wna16<T, 1, 1>(p, pl, st); break;
+    case 12: launch_wna16<T, 1, 2>(p, pl, st); break;
+    default: set_error("bad wna16 plan"); return APHRO_ERR_INVALID;
+  }
+  APHRO_LAUNCH_CHECK();
+  if (pl.ksplit > 1) {
+    int64_t mn = (int64_t)p.M * p.N;
+    unsigned blocks = (unsigned)((mn / 4 + 255) / 256);
+    hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3(blocks), dim3(256), 0, st, p.partial, p.c,
+                       (const uint16_t*)nullptr, mn, p.N, pl.ksplit);
+    APHRO_LAUNCH_CHECK();
+  }
+  return APHRO_OK;
+}
+
+}  // namespace aphro
+
+using namespace aphro;
+
+extern "C" size_t aphro_wna16_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+  (void)K;
+  int64_t m = M < APHRO_WNA16_MAX_M ? M : APHRO_WNA16_MAX_M;
+  return (size_t)8 * (size_t)m * (size_t)N * sizeof(float);
+}
+
+extern "C" int aphro_gptq_gemm(const void* a, const uint32_t* q_weight, const uint32_t* qzeros,
+                               const void* scales, const int32_t* perm, void* a_perm_tmp, void* c,
+                               void* workspace, size_t workspace_bytes, int64_t M, int64_t N, int64_t K,
+                               int64_t groups, int64_t lda, int zero_offset, int dtype, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  APHRO_CHECK(dtype == APHRO_F16 || dtype == APHRO_BF16, "gptq_gemm: dtype must be f16 or bf16");
+  APHRO_CHECK(M >= 0 && M <= APHRO_WNA16_MAX_M, "gptq_gemm: M=%ld exceeds APHRO_WNA16_MAX_M", (long)M);
+  APHRO_CHECK(groups > 0 && K % groups == 0, "gptq_gemm: K=%ld not divisible by groups=%ld", (long)K, (long)groups);
+  const int64_t gs = K / groups;
+  APHRO_CHECK(K % 32 == 0 && gs % 32 == 0, "gptq_gemm: K and group size must be multiples of 32 (K=%ld, g=%ld)", (long)K, (long)gs);
+  APHRO_CHECK(N % 16 == 0, "gptq_gemm: N=%ld must be a multiple of 16", (long)N);
+  APHRO_CHECK(lda % 8 == 0 && ((uintptr_t)a % 16) == 0, "gptq_gemm: a must be 16-byte aligned with lda %% 8 == 0");
+  if (M == 0) return APHRO_OK;
+  Wna16Plan pl = make_plan(M, N, K);
+  if (pl.ksplit > 1) {
+    size_t need = (size_t)pl.ksplit * M * N * sizeof(float);
+    if (workspace == nullptr || workspace_bytes < need) {
+      set_error("gptq_gemm: workspace %zu < %zu bytes", workspace_bytes, need);
+      return APHRO_ERR_WORKSPACE;
+    }
+  }
+  const uint16_t* ap = (const uint16_t*)a;
+  int64_t ld = lda;
+  if (perm) {
+    APHRO_CHECK(a_perm_tmp != nullptr, "gptq_gemm: act-order needs a_perm_tmp");
+    hipLaunchKernelGGL(permute_cols_kernel, dim3((unsigned)((K + 255) / 256), (unsigned)M), dim3(256), 0, st,
+                       ap, perm, (uint16_t*)a_perm_tmp, (int)M, (int)K, (int)lda);
+    APHRO_LAUNCH_CHECK();
+    ap = (const uint16_t*)a_perm_tmp;
+    ld = K;
+  }
+  Wna16Params p;
+  p.a = ap; p.qw = q_weight; p.qz = qzeros; p.sc = (const uint16_t*)scales;
+  p.c = (uint16_t*)c; p.partial = (float*)workspace;
+  p.M = (int)M; p.N = (int)N; p.K = (int)K; p.lda = (int)ld;
+  p.group_size = (int)gs; p.ksteps_per_split = pl.ksteps_per_split; p.ksplit = pl.ksplit;
+  p.zero_offset = zero_offset;
+  return dtype == APHRO_F16 ? run_wna16<Half>(p, pl, st) : run_wna16<BFloat>(p, pl, st);
+}
+
+extern "C" int aphro_gptq_repack(const uint32_t* q_weight, const int32_t* q_perm, uint32_t* out,
+                                 int64_t size_k, int64_t size_n, int bit, void* stream) {
+  APHRO_CHECK(bit == 4, "gptq_shuffle/repack: only 4-bit is implemented (bit=%d)", bit);
+  APHRO_CHECK(size_k % 8 == 0, "gptq_shuffle/repack: K must be a multiple of 8");
+  APHRO_CHECK(q_weight != out || q_perm == nullptr, "gptq_repack: in-place needs no perm");
+  if (size_k == 0 || size_n == 0) return APHRO_OK;
+  dim3 grid((unsigned)((size_n + 255) / 256), (unsigned)(size_k / 8));
+  hipLaunchKernelGGL(gptq_repack_kernel, grid, dim3(256), 0, (hipStream_t)stream, q_weight, q_perm, out,
+                     (int)(size_k / 8), (int)size_n);
+  APHRO_LAUNCH_CHECK();
+  return APHRO_OK;
+}
+
+extern "C" int aphro_gptq_shuffle(uint32_t* q_weight, const int32_t* q_perm, int64_t size_k,
+                                  int64_t size_n, int bit, uint32_t* tmp, void* stream) {
+  if (q_perm == nullptr) return aphro_gptq_repack(q_weight, nullptr, q_weight, size_k, size_n, bit, stream);
+  APHRO_CHECK(tmp != nullptr, "gptq_shuffle: act-order needs a tmp buffer of K/8*N words");
+  int rc = aphro_gptq_repack(q_weight, q_perm, tmp, size_k, size_n, bit, stream);
+  if (rc != APHRO_OK) return rc;
+  hipError_t e = hipMemcpyAsync(q_weight, tmp, (size_t)(size_k / 8) * size_n * 4, hipMemcpyDeviceToDevice,
+                                (hipStream_t)stream);
+  if (e != hipSuccess) {
+    set_error("gptq_shuffle: copy back failed: %s", hipGetErrorString(e));
+    return APHRO_ERR_LAUNCH;
+  }
+  return APHRO_OK;
+}
+
+extern "C" int aphro_gptq_dequant(const uint32_t* q_weight, const uint32_t* qzeros, const void* scales,
+                                  const int32_t* g_idx, void* out, int64_t K, int64_t N, int64_t groups,
+                                  int shuffled, int zero_offset, int dtype, void* stream) {
+  APHRO_CHECK(dtype == APHRO_F16 || dtype == APHRO_BF16, "gptq_dequant: dtype must be f16 or bf16");
+  APHRO_CHECK(K % 8 == 0 && N % 8 == 0 && groups > 0, "gptq_dequant: bad shape");
+  if (K == 0 || N == 0) return APHRO_OK;
+  dim3 grid((unsigned)((N + 255) / 256), (unsigned)(K / 8));
+  int gs = (int)(K / groups);
+  if (dtype == APHRO_F16)
+    hipLaunchKernelGGL((gptq_dequant_kernel<Half>), grid, dim3(256), 0, (hipStream_t)stream, q_weight, qzeros,
+                       (const uint16_t*)scales, g_idx, (uint16_t*)out, (int)K, (int)N, gs, shuffled, zero_offset);
+  else
+    hipLaunchKernelGGL((gptq_dequant_kernel<BFloat>), grid, dim3(256), 0, (hipStream_t)stream, q_weight, qzeros,
+                       (const uint16_t*)scales, g_idx, (uint16_t*)out, (int)K, (int)N, gs, shuffled, zero_offset);
+  APHRO_LAUNCH_CHECK();
+  return APHRO_OK;
+}
+
+extern "C" int aphro_awq_repack(const uint32_t* qweight, uint32_t* out, int64_t K, int64_t N, void* stream) {
+  APHRO_CHECK(K % 8 == 0 && N % 8 == 0, "awq_repack: K and N must be multiples of 8");
+  if (K == 0 || N == 0) return APHRO_OK;
+  dim3 grid((unsigned)((N + 255) / 256), (unsigned)(K / 8));
+  hipLaunchKernelGGL(awq_repack_kernel, grid, dim3(256), 0, (hipStream_t)stream, qweight, out, (int)K, (int)N);
+  APHRO_LAUNCH_CHECK();
+  return APHRO_OK;
+}
+
+extern "C" int aphro_awq_repack_zeros(const uint32_t* qzeros, uint32_t* out, int64_t groups, int64_t N,
+                                      void* stream) {
+  APHRO_CHECK(N % 8 == 0, "awq_repack_zeros: N must be a multiple of 8");
+  int64_t words = groups * (N / 8);
+  if (words == 0) return APHRO_OK;
+  hipLaunchKernelGGL(awq_repack_zeros_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, qzeros, out, words);
+  APHRO_LAUNCH_CHECK();
+  return APHRO_OK;
+}

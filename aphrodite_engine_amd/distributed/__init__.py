@@ -1,0 +1,76 @@
+"""Tensor-parallel state + collectives for the hot path -- the slice of
+aphrodite/distributed/{parallel_state,communication_op}.py the layers call
+(tensor_model_parallel_all_reduce :9-12, all_gather :15-18; GroupCoordinator
+.all_reduce parallel_state.py:321-379).
+
+One process per GPU; the TP group is a torch.distributed group whose "nccl"
+backend IS RCCL over xGMI on ROCm ("gloo" in the CPU tests).  The all-reduce
+is issued on the current stream so it is captured into the decode HIP graph
+like the reference's pynccl path (pynccl.py:102-118)."""
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+_TP_GROUP: Optional[dist.ProcessGroup] = None
+_TP_RANK = 0
+_TP_SIZE = 1
+
+
+def init_tensor_parallel(tp_size: int, backend: Optional[str] = None) -> None:
+    """initialize_model_parallel (parallel_state.py:968-1040) for TP only:
+    consecutive ranks form a TP group."""
+    global _TP_GROUP, _TP_RANK, _TP_SIZE
+    if tp_size <= 1:
+        _TP_GROUP, _TP_RANK, _TP_SIZE = None, 0, 1
+        return
+    assert dist.is_initialized(), "torch.distributed must be initialised first"
+    world = dist.get_world_size()
+    assert world % tp_size == 0
+    rank = dist.get_rank()
+    for start in range(0, world, tp_size):
+        ranks = list(range(start, start + tp_size))
+        grp = dist.new_group(ranks, backend=backend)
+        if rank in ranks:
+            _TP_GROUP = grp
+            _TP_RANK = rank - start
+            _TP_SIZE = tp_size
+
+
+def destroy_tensor_parallel() -> None:
+    global _TP_GROUP, _TP_RANK, _TP_SIZE
+    _TP_GROUP, _TP_RANK, _TP_SIZE = None, 0, 1
+
+
+def get_tensor_model_parallel_world_size() -> int:
+    return _TP_SIZE
+
+
+def get_tensor_model_parallel_rank() -> int:
+    return _TP_RANK
+
+
+def tensor_model_parallel_all_reduce(input_: torch.Tensor) -> torch.Tensor:
+    """Sum over the TP group, in place (communication_op.py:9-12)."""
+    if _TP_SIZE == 1:
+        return input_
+    dist.all_reduce(input_, group=_TP_GROUP)
+    return input_
+
+
+def tensor_model_parallel_all_gather(input_: torch.Tensor, dim: int = -1) -> torch.Tensor:
+    """communication_op.py:15-18 / parallel_state.py:381-416."""
+    if _TP_SIZE == 1:
+        return input_
+    if dim < 0:
+        dim += input_.dim()
+    inp = input_.contiguous()
+    if inp.dim() == 0:
+        inp = inp.reshape(1)
+    out = torch.empty((_TP_SIZE * inp.shape[0], ) + tuple(inp.shape[1:]),
+                      dtype=inp.dtype, device=inp.device)
+    dist.all_gather_into_tensor(out, inp, group=_TP_GROUP)
+    out = out.view((_TP_SIZE, ) + tuple(inp.shape)).movedim(0, dim)
+    shape = list(input_.shape)
+    shape[dim] *= _TP_SIZE
+    return out.reshape(shape)

@@ -1,0 +1,311 @@
+"""Llama decoder wired exactly like the reference's hot loop
+(aphrodite/modeling/models/llama.py: LlamaMLP :58-103, LlamaAttention :106-190,
+LlamaDecoderLayer :193-270, LlamaModel :273-357; call stack SURVEY 3.2), with
+every layer op going through the MI355X ``_custom_ops`` / quant-method /
+attention-backend surface.  Used by bench.py, smoke() and the GPU tests; weights
+are synthetic but in the real on-disk formats (GPTQ v1 int4 g128, FP8 e4m3
+per-tensor/per-channel), created directly on the device.
+
+Tensor parallelism follows the reference: QKV / gate_up column
+parallel, o_proj / down_proj row parallel + all-reduce
+(modeling/layers/linear.py:1139-1143).
+"""
+import math
+from dataclasses import dataclass
+from typing import List, Optional
+
+import torch
+from torch import nn
+
+from . import _custom_ops as ops
+from .attention.backend import MI355XAttentionImpl, MI355XAttentionMetadata
+from .distributed import (get_tensor_model_parallel_rank,
+                          get_tensor_model_parallel_world_size,
+                          tensor_model_parallel_all_reduce)
+from .quantization.awq import AWQConfig
+from .quantization.base_config import QuantizationConfig
+from .quantization.fp8 import Fp8Config
+from .quantization.gptq import GPTQConfig
+
+
+@dataclass
+class LlamaConfig:
+    hidden_size: int = 4096
+    intermediate_size: int = 14336
+    num_hidden_layers: int = 32
+    num_attention_heads: int = 32
+    num_key_value_heads: int = 8
+    vocab_size: int = 128256
+    rms_norm_eps: float = 1e-5
+    rope_theta: float = 500000.0
+    max_position_embeddings: int = 8192
+
+    @property
+    def head_dim(self) -> int:
+        return self.hidden_size // self.num_attention_heads
+
+
+LLAMA3_8B = LlamaConfig()
+LLAMA3_70B = LlamaConfig(hidden_size=8192, intermediate_size=28672,
+                         num_hidden_layers=80, num_attention_heads=64,
+                         num_key_value_heads=8)
+TINY = LlamaConfig(hidden_size=512, intermediate_size=1024, num_hidden_layers=2,
+                   num_attention_heads=4, num_key_value_heads=2, vocab_size=1024,
+                   max_position_embeddings=2048)
+
+
+class QuantLinear(nn.Module):
+    """LinearBase (modeling/layers/linear.py:150-190) reduced to what the hot
+    path needs: holds the quant method and its parameters."""
+
+    def __init__(self, in_features: int, out_partition_sizes: List[int],
+                 quant_config: Optional[QuantizationConfig], dtype: torch.dtype,
+                 full_in_features: Optional[int] = None, prefix: str = ""):
+        super().__init__()
+        self.in_features = in_features
+        self.out_features = sum(out_partition_sizes)
+        self.quant_config = quant_config
+        if quant_config is None:
+            self.quant_method = None
+            self.weight = nn.Parameter(
+                torch.empty(self.out_features, in_features, dtype=dtype),
+                requires_grad=False)
+        else:
+            self.quant_method = quant_config.get_quant_method(self, prefix)
+            self.quant_method.create_weights(
+                self, in_features, out_partition_sizes,
+                full_in_features or in_features, self.out_features, dtype)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if self.quant_method is None:
+            return torch.nn.functional.linear(x, self.weight)
+        return self.quant_method.apply(self, x)
+
+
+def _rope_cache(head_dim: int, max_pos: int, theta: float, dtype, device):
+    """modeling/layers/rotary_embedding.py:_compute_cos_sin_cache."""
+    inv_freq = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.float,
+                                             device=device) / head_dim))
+    t = torch.arange(max_pos, dtype=torch.float, device=device)
+    freqs = torch.einsum("i,j->ij", t, inv_freq)
+    return torch.cat((freqs.cos(), freqs.sin()), dim=-1).to(dtype)
+
+
+class LlamaDecoderLayer(nn.Module):
+    def __init__(self, cfg: LlamaConfig, quant_config, dtype, kv_cache_dtype: str):
+        super().__init__()
+        tp = get_tensor_model_parallel_world_size()
+        self.cfg = cfg
+        self.num_heads = cfg.num_attention_heads // tp
+        self.num_kv_heads = max(1, cfg.num_key_value_heads // tp)
+        self.head_dim = cfg.head_dim
+        self.q_size = self.num_heads * self.head_dim
+        self.kv_size = self.num_kv_heads * self.head_dim
+        h = cfg.hidden_size
+        self.input_layernorm = nn.Parameter(torch.ones(h, dtype=dtype), requires_grad=False)
+        self.post_attention_layernorm = nn.Parameter(torch.ones(h, dtype=dtype),
+                                                     requires_grad=False)
+        self.qkv_proj = QuantLinear(h, [self.q_size, self.kv_size, self.kv_size],
+                                    quant_config, dtype)
+        self.o_proj = QuantLinear(self.q_size, [h], quant_config, dtype,
+                                  full_in_features=cfg.num_attention_heads * self.head_dim)
+        inter = cfg.intermediate_size // tp
+        self.gate_up_proj = QuantLinear(h, [inter, inter], quant_config, dtype)
+        self.down_proj = QuantLinear(inter, [h], quant_config, dtype,
+                                     full_in_features=cfg.intermediate_size)
+        self.attn = MI355XAttentionImpl(self.num_heads, self.head_dim,
+                                        self.head_dim ** -0.5, self.num_kv_heads,
+                                        kv_cache_dtype=kv_cache_dtype)
+        self.k_scale = 1.0
+        self.v_scale = 1.0
+        self.tp = tp
+
+    def forward(self, positions, hidden, residual, kv_cache, attn_metadata, cos_sin):
+        eps = self.cfg.rms_norm_eps
+        if residual is None:
+            residual = hidden
+            normed = torch.empty_like(hidden)
+            ops.rms_norm(normed, hidden, self.input_layernorm, eps)
+            hidden = normed
+        else:
+            ops.fused_add_rms_norm(hidden, residual, self.input_layernorm, eps)
+        qkv = self.qkv_proj(hidden)
+        q, k, v = qkv.split([self.q_size, self.kv_size, self.kv_size], dim=-1)
+        ops.rotary_embedding(positions, q, k, self.head_dim, cos_sin, True)
+        attn_out = self.attn.forward(q, k, v, kv_cache, attn_metadata,
+                                     self.k_scale, self.v_scale)
+        hidden = self.o_proj(attn_out)
+        if self.tp > 1:
+            hidden = tensor_model_parallel_all_reduce(hidden)
+        ops.fused_add_rms_norm(hidden, residual, self.post_attention_layernorm, eps)
+        gate_up = self.gate_up_proj(hidden)
+        act = torch.empty(gate_up.shape[0], gate_up.shape[1] // 2, dtype=gate_up.dtype,
+                          device=gate_up.device)
+        ops.silu_and_mul(act, gate_up)
+        hidden = self.down_proj(act)
+        if self.tp > 1:
+            hidden = tensor_model_parallel_all_reduce(hidden)
+        return hidden, residual
+
+
+class LlamaForCausalLM(nn.Module):
+    def __init__(self, cfg: LlamaConfig, quant_config: Optional[QuantizationConfig],
+                 dtype: torch.dtype = torch.float16, kv_cache_dtype: str = "auto"):
+        super().__init__()
+        self.cfg = cfg
+        self.dtype = dtype
+        self.kv_cache_dtype = kv_cache_dtype
+        self.embed_tokens = nn.Parameter(
+            torch.empty(cfg.vocab_size, cfg.hidden_size, dtype=dtype), requires_grad=False)
+        self.layers = nn.ModuleList([
+            LlamaDecoderLayer(cfg, quant_config, dtype, kv_cache_dtype)
+            for _ in range(cfg.num_hidden_layers)])
+        self.norm = nn.Parameter(torch.ones(cfg.hidden_size, dtype=dtype),
+                                 requires_grad=False)
+        tp = get_tensor_model_parallel_world_size()
+        self.lm_head = nn.Parameter(
+            torch.empty(cfg.vocab_size // tp, cfg.hidden_size, dtype=dtype),
+            requires_grad=False)
+        self.cos_sin = None
+
+    # -- synthetic weights in the real formats -----------------------------------
+    @torch.no_grad()
+    def init_synthetic(self, device, seed: int = 0):
+        g = torch.Generator(device=device)
+        g.manual_seed(seed + 1000 * get_tensor_model_parallel_rank())
+        self.to(device)
+        cfg = self.cfg
+
+        def randn_(p, std):
+            p.copy_((torch.randn(p.shape, generator=g, device=device,
+                                 dtype=torch.float32) * std).to(p.dtype))
+
+        randn_(self.embed_tokens, 1.0)
+        randn_(self.lm_head, 1.0 / math.sqrt(cfg.hidden_size))
+        for layer in self.layers:
+            for lin in (layer.qkv_proj, layer.o_proj, layer.gate_up_proj, layer.down_proj):
+                _init_linear(lin, g, device)
+        self.cos_sin = _rope_cache(cfg.head_dim, cfg.max_position_embeddings,
+                                   cfg.rope_theta, self.dtype, device)
+        for layer in self.layers:
+            for lin in (layer.qkv_proj, layer.o_proj, layer.gate_up_proj, layer.down_proj):
+                if lin.quant_method is not None:
+                    lin.quant_method.process_weights_after_loading(lin)
+        return self
+
+    def weight_bytes_per_layer(self) -> int:
+        """Algorithmic bytes of the four linears of one layer."""
+        layer = self.layers[0]
+        n = 0
+        for lin in (layer.qkv_proj, layer.o_proj, layer.gate_up_proj, layer.down_proj):
+            for name, p in lin.named_parameters():
+                if name in ("g_idx", "input_scale"):
+                    continue
+                n += p.numel() * p.element_size()
+        return n
+
+    def forward(self, input_ids, positions, kv_caches, attn_metadata):
+        hidden = self.embed_tokens[input_ids]
+        residual = None
+        for i, layer in enumerate(self.layers):
+            hidden, residual = layer(positions, hidden, residual, kv_caches[i],
+                                     attn_metadata, self.cos_sin)
+        ops.fused_add_rms_norm(hidden, residual, self.norm, self.cfg.rms_norm_eps)
+        return hidden
+
+    def compute_logits(self, hidden):
+        logits = torch.matmul(hidden, self.lm_head.t())
+        if get_tensor_model_parallel_world_size() > 1:
+            from .distributed import tensor_model_parallel_all_gather
+            logits = tensor_model_parallel_all_gather(logits, dim=-1)
+        return logits
+
+    def sample_greedy(self, logits):
+        return torch.argmax(logits, dim=-1)
+
+
+@torch.no_grad()
+def _init_linear(lin: QuantLinear, g, device):
+    k = lin.in_features
+    qc = lin.quant_config
+    if qc is None:
+        lin.weight.copy_((torch.randn(lin.weight.shape, generator=g, device=device)
+                          / math.sqrt(k)).to(lin.weight.dtype))
+        return
+    if isinstance(qc, (GPTQConfig, AWQConfig)):
+        # random nibbles are a valid quantised weight; (q - z) ~ U[-8, 7]
+        for name in ("qweight", "qzeros"):
+            p = getattr(lin, name)
+            p.copy_(torch.randint(-2 ** 31, 2 ** 31 - 1, p.shape, generator=g,
+                                  device=device, dtype=torch.int64).to(torch.int32))
+        s = lin.scales
+        s.copy_(((torch.rand(s.shape, generator=g, device=device) * 0.5 + 0.75)
+                 * (1.0 / (4.6 * math.sqrt(k)))).to(s.dtype))
+        return
+    if isinstance(qc, Fp8Config):
+        w = torch.randn(lin.weight.shape, generator=g, device=device) / math.sqrt(k)
+        amax = w.abs().max()
+        scale = (amax / 448.0).float()
+        lin.weight.copy_((w / scale).clamp(-448, 448).to(torch.float8_e4m3fn))
+        lin.weight_scale.fill_(scale.item())
+        if getattr(lin, "input_scale", None) is not None:
+            lin.input_scale.fill_(8.0 / 448.0)
+        return
+    raise ValueError(f"no synthetic init for {type(qc).__name__}")
+
+
+def make_decode_metadata(batch: int, ctx_len, block_size: int, device,
+                         blocks_per_seq: Optional[int] = None, seed: int = 0):
+    """Decode-step metadata as CommonMetadataBuilder.build produces it
+    (attention/backends/utils.py:191-274): every sequence has ``ctx_len``
+    tokens *including* the one being generated; block tables are a random
+    permutation of the block pool, slot = last token's slot."""
+    if isinstance(ctx_len, int):
+        seq_lens = [ctx_len] * batch
+    else:
+        seq_lens = list(ctx_len)
+    max_len = max(seq_lens)
+    bps = blocks_per_seq or (max_len + block_size - 1) // block_size
+    total_blocks = batch * bps
+    gen = torch.Generator().manual_seed(seed)
+    perm = torch.randperm(total_blocks, generator=gen).to(torch.int32)
+    block_tables = perm.view(batch, bps)
+    slots = []
+    for i, L in enumerate(seq_lens):
+        last = L - 1
+        slots.append(int(block_tables[i, last // block_size]) * block_size + last % block_size)
+    meta = MI355XAttentionMetadata(
+        num_prefills=0, num_prefill_tokens=0, num_decode_tokens=batch,
+        slot_mapping=torch.tensor(slots, dtype=torch.int64, device=device),
+        seq_lens=None,
+        seq_lens_tensor=torch.tensor(seq_lens, dtype=torch.int32, device=device),
+        max_query_len=None, max_prefill_seq_len=0, max_decode_seq_len=max_len,
+        query_start_loc=None, seq_start_loc=None, context_lens_tensor=None,
+        block_tables=block_tables.to(device), use_cuda_graph=False)
+    positions = torch.tensor([L - 1 for L in seq_lens], dtype=torch.int64, device=device)
+    return meta, positions, total_blocks
+
+
+def make_kv_caches(cfg: LlamaConfig, num_blocks: int, block_size: int, dtype,
+                   kv_cache_dtype: str, device, num_layers: Optional[int] = None,
+                   fill: bool = True, seed: int = 0):
+    """worker/cache_engine.py:66-86 + common/utils.py:686-740 (uniform fill)."""
+    tp = get_tensor_model_parallel_world_size()
+    hkv = max(1, cfg.num_key_value_heads // tp)
+    cache_dtype = dtype if kv_cache_dtype == "auto" else torch.uint8
+    shape = (2, num_blocks, block_size * hkv * cfg.head_dim)
+    caches = []
+    g = torch.Generator(device=device).manual_seed(seed)
+    for _ in range(num_layers or cfg.num_hidden_layers):
+        if not fill:
+            caches.append(torch.zeros(shape, dtype=cache_dtype, device=device))
+        elif cache_dtype == torch.uint8:
+            # random e4m3 bytes without NaN patterns (0x7f / 0xff)
+            # (|x| <= 3.75 as e4m3, finite as e5m2)
+            c = torch.randint(0, 0x48, shape, generator=g, device=device, dtype=torch.int16)
+            sign = torch.randint(0, 2, shape, generator=g, device=device, dtype=torch.int16) << 7
+            caches.append((c | sign).to(torch.uint8))
+        else:
+            c = torch.rand(shape, generator=g, device=device, dtype=torch.float32)
+            caches.append(((c * 2 - 1) * cfg.head_dim ** -0.5).to(cache_dtype))
+    return caches

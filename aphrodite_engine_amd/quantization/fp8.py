@@ -1,0 +1,167 @@
+"""FP8 linear on MI355X -- mirror of aphrodite/quantization/fp8.py (Fp8Config
+:31-93, Fp8LinearMethod :96-270) and quantization/utils/w8a8_utils.py
+(apply_fp8_linear :83-183, requantize_with_max_scale :54-80).
+
+gfx950 implements OCP e4m3fn natively, so -- unlike the reference's MI300
+branch (fp8.py:225-234, w8a8_utils.py:207-228) -- checkpoints are used as
+stored: no e4m3fnuz re-labelling, no scale doubling, and the fused
+cutlass_scaled_mm role is available (per-token x per-channel included)."""
+from typing import Any, Dict, List, Optional
+
+import torch
+from torch import nn
+
+from .. import _custom_ops as ops
+from .base_config import LinearMethodBase, QuantizationConfig, _param
+
+ACTIVATION_SCHEMES = ["static", "dynamic"]
+
+
+def apply_fp8_linear(input: torch.Tensor, weight: torch.Tensor,
+                     weight_scale: torch.Tensor,
+                     input_scale: Optional[torch.Tensor] = None,
+                     input_scale_ub: Optional[torch.Tensor] = None,
+                     bias: Optional[torch.Tensor] = None,
+                     cutlass_fp8_supported: bool = True,
+                     use_per_token_if_dynamic: bool = False) -> torch.Tensor:
+    """w8a8_utils.py:83-183, fused branch (:99-113)."""
+    x2 = input.reshape(-1, input.shape[-1])
+    qinput, x_scale = ops.scaled_fp8_quant(
+        x2, input_scale, scale_ub=input_scale_ub,
+        use_per_token_if_dynamic=use_per_token_if_dynamic)
+    out = ops.cutlass_scaled_mm(qinput, weight, out_dtype=input.dtype,
+                                scale_a=x_scale, scale_b=weight_scale, bias=bias)
+    return out.reshape(input.shape[:-1] + (weight.shape[1], ))
+
+
+def requantize_with_max_scale(weight: torch.Tensor, weight_scale: torch.Tensor,
+                              logical_widths: List[int]):
+    """w8a8_utils.py:54-80: fused shards with per-shard scales -> one scale."""
+    max_w_scale = weight_scale.max()
+    unfused = (weight_scale[-1] > torch.finfo(torch.float8_e4m3fn).min)
+    if unfused:
+        start = 0
+        for idx, width in enumerate(logical_widths):
+            end = start + width
+            w_dq = weight[start:end, :].to(torch.float32) * weight_scale[idx]
+            q = (w_dq / max_w_scale).clamp(-448.0, 448.0).to(torch.float8_e4m3fn)
+            weight[start:end, :] = q
+            start = end
+    return max_w_scale, weight
+
+
+class Fp8Config(QuantizationConfig):
+    def __init__(self, is_checkpoint_fp8_serialized: bool = False,
+                 activation_scheme: str = "dynamic",
+                 ignored_layers: Optional[List[str]] = None,
+                 weight_only: bool = False) -> None:
+        self.is_checkpoint_fp8_serialized = is_checkpoint_fp8_serialized
+        if activation_scheme not in ACTIVATION_SCHEMES:
+            raise ValueError(f"Unsupported activation scheme {activation_scheme}")
+        self.activation_scheme = activation_scheme
+        self.ignored_layers = ignored_layers or []
+        self.weight_only = weight_only  # W8A16: the fp8_marlin role (fp8.py:125-127)
+
+    @classmethod
+    def get_name(cls) -> str:
+        return "fp8"
+
+    @classmethod
+    def get_supported_act_dtypes(cls) -> List[torch.dtype]:
+        return [torch.bfloat16, torch.half]
+
+    @classmethod
+    def get_min_capability(cls) -> int:
+        return 80
+
+    @classmethod
+    def get_config_filenames(cls) -> List[str]:
+        return []
+
+    @classmethod
+    def from_config(cls, config: Dict[str, Any]) -> "Fp8Config":
+        quant_method = cls.get_from_keys(config, ["quant_method"])
+        is_checkpoint_fp8_serialized = ("fp8" in quant_method)
+        activation_scheme = cls.get_from_keys(config, ["activation_scheme"])
+        ignored_layers = cls.get_from_keys_or(config, ["ignored_layers"], None)
+        return cls(is_checkpoint_fp8_serialized, activation_scheme, ignored_layers)
+
+    def get_quant_method(self, layer: nn.Module, prefix: str) -> Optional["Fp8LinearMethod"]:
+        if any(prefix == i or prefix.startswith(i + ".") for i in self.ignored_layers):
+            return None
+        return Fp8LinearMethod(self)
+
+    def get_scaled_act_names(self) -> List[str]:
+        return []
+
+
+class Fp8LinearMethod(LinearMethodBase):
+    def __init__(self, quant_config: Fp8Config):
+        self.quant_config = quant_config
+        self.use_marlin = quant_config.weight_only
+
+    def create_weights(self, layer: nn.Module, input_size_per_partition: int,
+                       output_partition_sizes: List[int], input_size: int,
+                       output_size: int, params_dtype: torch.dtype,
+                       **extra_weight_attrs):
+        del input_size, output_size
+        output_size_per_partition = sum(output_partition_sizes)
+        weight_loader = extra_weight_attrs.get("weight_loader")
+        layer.logical_widths = output_partition_sizes
+        layer.input_size_per_partition = input_size_per_partition
+        layer.output_size_per_partition = output_size_per_partition
+        layer.orig_dtype = params_dtype
+        weight_dtype = (torch.float8_e4m3fn
+                        if self.quant_config.is_checkpoint_fp8_serialized else params_dtype)
+        layer.register_parameter("weight", _param(
+            torch.empty(output_size_per_partition, input_size_per_partition,
+                        dtype=weight_dtype),
+            input_dim=1, output_dim=0, weight_loader=weight_loader))
+        if self.quant_config.is_checkpoint_fp8_serialized:
+            scale = _param(torch.empty(len(output_partition_sizes), dtype=torch.float32),
+                           weight_loader=weight_loader)
+            scale[:] = torch.finfo(torch.float32).min
+            layer.register_parameter("weight_scale", scale)
+            if self.quant_config.activation_scheme == "static":
+                iscale = _param(torch.empty(len(output_partition_sizes),
+                                            dtype=torch.float32),
+                                weight_loader=weight_loader)
+                iscale[:] = torch.finfo(torch.float32).min
+                layer.register_parameter("input_scale", iscale)
+            else:
+                layer.register_parameter("input_scale", None)
+
+    def process_weights_after_loading(self, layer: nn.Module) -> None:
+        if not self.quant_config.is_checkpoint_fp8_serialized:
+            # fp8.py:185-199: quantise a 16-bit checkpoint per tensor
+            qweight, weight_scale = ops.scaled_fp8_quant(
+                layer.weight.data.reshape(-1, layer.weight.shape[-1]), scale=None)
+            layer.weight = nn.Parameter(qweight.t(), requires_grad=False)
+            layer.weight_scale = nn.Parameter(weight_scale, requires_grad=False)
+            layer.input_scale = None
+            return
+        weight, weight_scale = layer.weight.data, layer.weight_scale.data
+        if weight_scale.numel() > 1 and weight_scale.dim() == 1 and \
+                weight_scale.numel() == len(layer.logical_widths):
+            weight_scale, weight = requantize_with_max_scale(
+                weight, weight_scale, layer.logical_widths)
+        layer.weight = nn.Parameter(weight.t(), requires_grad=False)
+        layer.weight_scale = nn.Parameter(weight_scale.reshape(-1).float(),
+                                          requires_grad=False)
+        if self.quant_config.activation_scheme == "static":
+            layer.input_scale = nn.Parameter(layer.input_scale.max().reshape(1),
+                                             requires_grad=False)
+
+    def apply(self, layer: nn.Module, x: torch.Tensor,
+              bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if self.use_marlin:
+            x2 = x.reshape(-1, x.shape[-1])
+            w = layer.weight.t()  # back to the [N,K] row-major checkpoint layout
+            out = ops.fp8_marlin_gemm(x2, w, layer.weight_scale, None, 8,
+                                      x2.shape[0], w.shape[0], w.shape[1], bias)
+            return out.reshape(x.shape[:-1] + (w.shape[0], ))
+        return apply_fp8_linear(input=x, weight=layer.weight,
+                                weight_scale=layer.weight_scale,
+                                input_scale=layer.input_scale, bias=bias,
+                                cutlass_fp8_supported=True,
+                                use_per_token_if_dynamic=False)

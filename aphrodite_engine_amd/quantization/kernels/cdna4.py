@@ -1,0 +1,78 @@
+"""CDNA4LinearKernel -- the MPLinearKernel the MI355X registers where Machete /
+Marlin sit on NVIDIA (reference: quantization/kernels/marlin.py:18-132 is the
+contract being honoured: can_implement / process_weights_after_loading /
+apply_weights).  Weight layout after loading is our own K-packed exllama
+order [K/8, N] -- no Marlin tile layout, no workspace locks.
+
+Accepted checkpoint parameter layouts (those ``gptq_marlin.py`` and
+``compressed_tensors_wNa16.py`` hand to an MPLinearKernel):
+  w_q   int32 [K/8, N] packed along K (GPTQ order), uint4b8 or uint4+zp
+  w_s   [G, N]
+  w_zp  int32 [G, N/8] packed along N, plain column order (optional)
+  g_idx int32 [K] (optional, act-order)
+"""
+from typing import Optional, Tuple
+
+import torch
+
+from ... import _custom_ops as ops
+from ...scalar_type import scalar_types
+from .MPLinearKernel import MPLinearKernel, MPLinearLayerConfig
+
+
+class CDNA4LinearKernel(MPLinearKernel):
+    SUPPORTED_TYPES = (scalar_types.uint4b8, scalar_types.uint4)
+
+    @classmethod
+    def get_min_capability(cls) -> int:
+        return 95  # gfx950
+
+    @classmethod
+    def can_implement(cls, c: MPLinearLayerConfig) -> Tuple[bool, Optional[str]]:
+        if c.weight_type not in cls.SUPPORTED_TYPES:
+            return False, f"Quant type ({c.weight_type}) not supported by CDNA4 kernel"
+        if c.zero_points != (c.weight_type == scalar_types.uint4):
+            return False, "zero points must accompany uint4 (and only uint4)"
+        k, n = c.partition_weight_shape
+        gs = c.group_size if c.group_size != -1 else c.full_weight_shape[0]
+        if gs % 32 != 0 or k % gs != 0:
+            return False, f"group size {gs} must be a multiple of 32 dividing K={k}"
+        if k % 32 != 0 or n % 16 != 0:
+            return False, f"K={k} must be a multiple of 32 and N={n} of 16"
+        if c.act_type not in (torch.float16, torch.bfloat16):
+            return False, f"activation dtype {c.act_type} not supported"
+        return True, None
+
+    def process_weights_after_loading(self, layer: torch.nn.Module) -> None:
+        c = self.config
+        w_q, w_s, w_zp, w_gidx = self._get_weight_params(layer)
+        device = w_q.device
+        k, n = c.partition_weight_shape
+        perm = torch.empty(0, dtype=torch.int32, device=device)
+        if c.has_g_idx and w_gidx is not None and w_gidx.numel() > 0:
+            perm = torch.argsort(w_gidx).to(torch.int32)
+        self._transform_param(
+            layer, self.w_q_name,
+            lambda x: ops.gptq_marlin_repack(x.data.contiguous(), perm, k, n, 4))
+        self._transform_param(layer, self.w_s_name, lambda x: x.data.contiguous())
+        if c.zero_points:
+            self._transform_param(layer, self.w_zp_name, lambda x: x.data.contiguous())
+        else:
+            # symmetric uint4b8: zero point 8 for every column, stored once
+            groups = getattr(layer, self.w_s_name).shape[0]
+            zp = torch.full((groups, n // 8), 0x88888888 - (1 << 32), dtype=torch.int64,
+                            device=device).to(torch.int32)
+            layer.register_buffer("_cdna4_zp", zp, persistent=False)
+        layer._cdna4_perm = perm if perm.numel() > 0 else None
+
+    def apply_weights(self, layer: torch.nn.Module, x: torch.Tensor,
+                      bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+        c = self.config
+        w_q, w_s, w_zp, _ = self._get_weight_params(layer)
+        if not c.zero_points:
+            w_zp = layer._cdna4_zp
+        x2 = x.reshape(-1, x.shape[-1])
+        out = ops.wna16_gemm(x2, w_q, w_zp, w_s, layer._cdna4_perm, 0)
+        if bias is not None:
+            out.add_(bias)
+        return out.reshape(x.shape[:-1] + (c.partition_weight_shape[1], ))

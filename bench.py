@@ -1,0 +1,374 @@
+#!/usr/bin/env python3
+"""bench.py -- decode throughput of the MI355X quantized-inference hot path.
+
+Metric (BASELINE.json): output tokens/s + HBM-roofline fraction, Llama-3-8B
+GPTQ-int4 g128 (configs[1]: TP=1, bs=32) on 1/2/4/8 MI355X.
+
+A "step" is one full greedy decode step of the whole model over a batch of
+synthetic sequences: embedding gather -> 32 x [rms_norm, qkv GPTQ GEMM, RoPE,
+KV-cache write, paged-attention decode, o_proj GEMM, fused add+rms_norm,
+gate_up GEMM, silu*mul, down GEMM] -> final norm -> fp16 lm_head -> argmax ->
+advance (positions, seq_lens, slot mapping, next input ids).  Nothing is
+skipped or cached inside the timed region; the sampled tokens feed the next
+step.  The step is captured once into a HIP graph (as the reference captures
+decode, worker/model_runner.py:1360-1507) and replayed K times.
+
+Launch:  python bench.py --gpus N --steps K --warmup W
+ N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
+             --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+   default parallelism "dp": N independent replicas (the 8B model fits one GPU;
+   SURVEY 8e) -> weak scaling, value = total tokens/s of all replicas.
+   --parallelism tp: Megatron TP over RCCL (strong scaling), for reference.
+
+Prints ONE JSON line on rank 0 (contract in the task statement), extended with
+"roofline" (dominant kernel, live HIP-event timing) and "cpu_baseline".
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (guides: 8 TB/s; ~6.3 TB/s achievable)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--quant", default="gptq", choices=["gptq", "fp8", "awq"])
+    ap.add_argument("--kv-cache-dtype", default="auto", choices=["auto", "fp8", "fp8_e5m2"])
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--ctx", type=int, default=1024, help="context length at the first timed step")
+    ap.add_argument("--parallelism", default="dp", choices=["dp", "tp"])
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--layers", type=int, default=0, help="debug only: fewer layers (marks the line invalid)")
+    return ap.parse_args()
+
+
+def build(args, device):
+    from aphrodite_engine_amd import model as M
+    from aphrodite_engine_amd.quantization.awq import AWQConfig
+    from aphrodite_engine_amd.quantization.fp8 import Fp8Config
+    from aphrodite_engine_amd.quantization.gptq import GPTQConfig
+    cfg = M.LLAMA3_8B
+    if args.layers:
+        cfg = M.LlamaConfig(num_hidden_layers=args.layers)
+    if args.quant == "gptq":
+        qc = GPTQConfig(4, 128, False)
+    elif args.quant == "awq":
+        qc = AWQConfig(4, 128, True, prepack=True)
+    else:
+        qc = Fp8Config(is_checkpoint_fp8_serialized=True, activation_scheme="dynamic")
+    dtype = torch.float16
+    model = M.LlamaForCausalLM(cfg, qc, dtype, args.kv_cache_dtype)
+    model.init_synthetic(device, seed=0)
+    return model, cfg, dtype
+
+
+class DecodeLoop:
+    """Persistent device state of a greedy decode loop (what the reference's
+    CUDAGraphRunner keeps in its input buffers, model_runner.py:1682-1790)."""
+
+    def __init__(self, model, cfg, dtype, args, device, total_steps):
+        from aphrodite_engine_amd import model as M
+        self.model, self.cfg, self.bs = model, cfg, 16
+        self.block_size = 16
+        max_len = args.ctx + total_steps + 1
+        self.meta, self.positions, nblocks = M.make_decode_metadata(
+            args.batch, args.ctx, self.block_size, device,
+            blocks_per_seq=(max_len + self.block_size - 1) // self.block_size)
+        self.meta.max_decode_seq_len = max_len      # capture-time maximum
+        self.kv_caches = M.make_kv_caches(cfg, nblocks, self.block_size, dtype,
+                                          args.kv_cache_dtype, device)
+        g = torch.Generator(device=device).manual_seed(1)
+        self.input_ids = torch.randint(0, cfg.vocab_size, (args.batch, ), generator=g,
+                                       device=device)
+        self.next_ids = torch.zeros_like(self.input_ids)
+
+    def step(self):
+        m = self.meta
+        hidden = self.model(self.input_ids, self.positions, self.kv_caches, m)
+        logits = self.model.compute_logits(hidden)
+        self.next_ids.copy_(self.model.sample_greedy(logits))
+        # advance: the generated token becomes the next input, context grows by one
+        self.input_ids.copy_(self.next_ids)
+        self.positions.add_(1)
+        m.seq_lens_tensor.add_(1)
+        blk = m.block_tables.gather(1, (self.positions // self.block_size).unsqueeze(1)).squeeze(1)
+        m.slot_mapping.copy_(blk.long() * self.block_size + self.positions % self.block_size)
+
+
+def gemm_bytes(lin, M_rows):
+    n = 0
+    for name, p in lin.named_parameters():
+        if name in ("g_idx", "input_scale"):
+            continue
+        n += p.numel() * p.element_size()
+    return n + M_rows * lin.in_features * 2 + M_rows * lin.out_features * 2
+
+
+def measure_kernel(fn, launches_per_call, iters=5):
+    """Average duration of one launch, HIP events on the launching stream."""
+    stream = torch.cuda.current_stream()
+    fn()
+    torch.cuda.synchronize()
+    start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    start.record(stream)
+    for _ in range(iters):
+        fn()
+    end.record(stream)
+    end.synchronize()
+    return start.elapsed_time(end) * 1e-3 / (iters * launches_per_call)
+
+
+def roofline_section(model, loop, args):
+    """Live per-kernel timing of the two HBM-heavy kernels, cycling over all
+    layers so the 256 MiB Infinity Cache cannot serve the weights / KV."""
+    from aphrodite_engine_amd import _custom_ops as ops
+    bs = args.batch
+    layers = list(model.layers)
+    x = torch.randn(bs, model.cfg.hidden_size, device="cuda", dtype=model.dtype)
+    out = {}
+
+    def run_gate_up():
+        for layer in layers:
+            layer.gate_up_proj(x)
+    t = measure_kernel(run_gate_up, len(layers))
+    b = gemm_bytes(layers[0].gate_up_proj, bs)
+    out["gate_up_gemm"] = dict(kernel="wna16_gemm_kernel" if args.quant != "fp8" else "fp8_gemm_kernel",
+                               shape=[bs, layers[0].gate_up_proj.in_features,
+                                      layers[0].gate_up_proj.out_features],
+                               bytes=b, seconds=t)
+    # decode attention over the real caches / metadata of the loop
+    l0 = layers[0]
+    q = torch.randn(bs, l0.q_size + 2 * l0.kv_size, device="cuda", dtype=model.dtype)[:, :l0.q_size]
+    meta = loop.meta
+    from aphrodite_engine_amd.attention.paged_attn import PagedAttention
+    P = (meta.max_decode_seq_len + 511) // 512
+    tmp = torch.empty(bs, l0.num_heads, P, l0.head_dim, device="cuda", dtype=model.dtype)
+    es = torch.empty(bs, l0.num_heads, P, device="cuda", dtype=torch.float32)
+    ml = torch.empty_like(es)
+    o = torch.empty(bs, l0.num_heads, l0.head_dim, device="cuda", dtype=model.dtype)
+    caches = [PagedAttention.split_kv_cache(c, l0.num_kv_heads, l0.head_dim) for c in loop.kv_caches]
+
+    def run_attn():
+        for kc, vc in caches:
+            ops.paged_attention_rocm(o, es, ml, tmp, q.view(bs, l0.num_heads, l0.head_dim), kc, vc,
+                                     l0.num_kv_heads, l0.attn.scale, meta.block_tables,
+                                     meta.seq_lens_tensor, 16, meta.max_decode_seq_len, None,
+                                     args.kv_cache_dtype, 1.0, 1.0)
+    launches = len(caches) * (2 if P > 1 else 1)
+    t2 = measure_kernel(run_attn, len(caches))
+    esz = 1 if args.kv_cache_dtype != "auto" else 2
+    tokens = int(meta.seq_lens_tensor.sum().item())
+    ab = 2 * tokens * l0.num_kv_heads * l0.head_dim * esz + 2 * bs * l0.q_size * 2
+    out["paged_attention"] = dict(kernel="paged_attention_kernel(+reduce)", bytes=ab, seconds=t2,
+                                  launches_per_call=launches // len(caches))
+    return out
+
+
+def cpu_baseline(args, cfg):
+    """The oracle ("port": restated int4 dequant + matmul; paged attention by the
+    REFERENCE's own CPU kernel from oracle/_ref when present) timed on the host
+    cores for ONE decoder layer of the same workload, scaled to a full step."""
+    import numpy as np
+    from oracle import attention as oa
+    from oracle import quant as oq
+    torch.set_num_threads(os.cpu_count() or 1)
+    rng = np.random.default_rng(0)
+    bs, hid, inter = args.batch, cfg.hidden_size, cfg.intermediate_size
+    hq, hkv, hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+    shapes = [(hid, (hq + 2 * hkv) * hd), (hq * hd, hid), (hid, 2 * inter), (inter, hid)]
+    weights = []
+    for k, n in shapes:
+        qw = rng.integers(-2 ** 31, 2 ** 31 - 1, size=(k // 8, n), dtype=np.int64).astype(np.int32)
+        qz = rng.integers(-2 ** 31, 2 ** 31 - 1, size=(k // 128, n // 8), dtype=np.int64).astype(np.int32)
+        sc = (rng.random((k // 128, n)) * 0.01).astype(np.float16)
+        weights.append((qw, qz, sc))
+    ctx = args.ctx
+    nb = bs * ((ctx + 15) // 16)
+    kc = torch.rand(nb, hkv, hd // 8, 16, 8).to(torch.bfloat16)
+    vc = torch.rand(nb, hkv, hd, 16).to(torch.bfloat16)
+    bt = torch.randperm(nb).view(bs, -1).int()
+    sl = torch.full((bs, ), ctx, dtype=torch.int32)
+    q = torch.randn(bs, hq, hd).to(torch.bfloat16)
+    ref_ops = None
+    so = os.path.join(ROOT, "oracle", "_ref", "libaphro_ref_cpu.so")
+    if os.path.exists(so):
+        try:
+            torch.ops.load_library(so)
+            ref_ops = torch.ops.aphro_ref_cpu
+        except Exception:
+            ref_ops = None
+    x = torch.randn(bs, hid).to(torch.bfloat16)
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        h = x
+        for i, (qw, qz, sc) in enumerate(weights):
+            w = torch.from_numpy(oq.gptq_dequant(qw, qz, sc, None, shuffled=False)).to(torch.bfloat16)
+            a = h if h.shape[1] == w.shape[0] else torch.randn(bs, w.shape[0]).to(torch.bfloat16)
+            h = a @ w
+            if i == 0:
+                out = torch.empty_like(q)
+                if ref_ops is not None:
+                    ref_ops.paged_attention_v1(out, q, kc, vc, hkv, hd ** -0.5, bt, sl, 16, ctx,
+                                               None, "auto", 1.0, 1.0, 0, 0, 0, 64, 0)
+                else:
+                    oa.paged_attention_decode(q, kc.float().numpy(), vc.float().numpy(),
+                                              bt.numpy(), sl.numpy(), hd ** -0.5)
+        reps += 1
+        if time.perf_counter() - t0 > 10.0 or reps >= 3:
+            break
+    per_layer = (time.perf_counter() - t0) / reps
+    step = per_layer * cfg.num_hidden_layers
+    return dict(value=bs / step, unit="tokens/s", cores=os.cpu_count() or 1,
+                kind="port",
+                sample=(f"{reps} x one decoder layer (4 int4->bf16 dequant+matmul via oracle.quant, "
+                        f"paged attention bs={bs} ctx={ctx} via "
+                        f"{'oracle/_ref reference CPU kernel' if ref_ops is not None else 'oracle.attention'}), "
+                        f"scaled x{cfg.num_hidden_layers} layers; lm_head/glue excluded"))
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        print("bench.py needs a GPU (torch.cuda.is_available() is False)", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=device)
+    from aphrodite_engine_amd import _lib
+    from aphrodite_engine_amd import distributed as D
+    _lib.lib()  # fail loudly if the HIP library is missing
+    tp = world if (args.parallelism == "tp" and world > 1) else 1
+    D.init_tensor_parallel(tp)
+
+    model, cfg, dtype = build(args, device)
+    total = args.warmup + args.steps + 4
+    loop = DecodeLoop(model, cfg, dtype, args, device, total)
+
+    with torch.no_grad():
+        # eager warm-up (allocates workspaces, loads code objects)
+        for _ in range(2):
+            loop.step()
+        torch.cuda.synchronize()
+        graph = None
+        if not args.no_graph:
+            graph = torch.cuda.CUDAGraph()
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                loop.step()
+            torch.cuda.current_stream().wait_stream(s)
+            with torch.cuda.graph(graph):
+                loop.step()
+        run = graph.replay if graph is not None else loop.step
+        for _ in range(args.warmup):
+            run()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            run()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed = float(tmax.item())
+        ctx_end = int(loop.meta.seq_lens_tensor[0].item())
+        roof = roofline_section(model, loop, args) if rank == 0 else None
+
+    if rank != 0:
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+    replicas = world if tp == 1 else 1
+    tokens = args.batch * args.steps * replicas
+    ms_per_step = elapsed / args.steps * 1e3
+    # step-level algorithmic bytes
+    w_bytes = model.weight_bytes_per_layer() * cfg.num_hidden_layers
+    lm_head = model.lm_head.numel() * 2
+    esz = 1 if args.kv_cache_dtype != "auto" else 2
+    ctx_mid = (args.ctx + args.warmup + 2 + ctx_end) / 2.0
+    kv_bytes = args.batch * ctx_mid * 2 * (cfg.num_key_value_heads // tp) * cfg.head_dim * esz * cfg.num_hidden_layers
+    step_bytes = w_bytes + lm_head + kv_bytes
+    dom_name = max(roof, key=lambda k: roof[k]["seconds"])   # dominant kernel by time
+    dom = roof[dom_name]
+    achieved = dom["bytes"] / dom["seconds"] / 1e9
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if os.path.exists(tfile):
+        try:
+            traffic = json.load(open(tfile)).get(dom_name)
+        except Exception:
+            traffic = None
+    line = {
+        "metric": "output tokens/sec + HBM-roofline %, Llama-3-8B int4/fp8 @ 1/2/4/8 MI355X",
+        "value": tokens / elapsed,
+        "unit": "tokens/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "weak" if tp == 1 else "strong",
+        "vs_baseline": None,
+        "dtype": {"gptq": "int4 weights x f16 (fp32 accumulate)", "awq": "int4 weights x f16 (fp32 accumulate)",
+                  "fp8": "fp8-e4m3 x fp8-e4m3 (fp32 accumulate)"}[args.quant],
+        "data": "synthetic (random-init weights in the real GPTQ/FP8 formats, random token ids, random-permutation block tables)",
+        "config": {
+            "workload": f"Llama-3-8B {args.quant.upper()} {'4-bit g128' if args.quant != 'fp8' else 'W8A8'}, greedy decode, "
+                        f"bs={args.batch}/GPU, context {args.ctx}->{ctx_end}, kv_cache={args.kv_cache_dtype}, "
+                        f"block_size=16, HIP-graph={'off' if args.no_graph else 'on'}",
+            "global_batch": args.batch * replicas,
+            "seq_len": args.ctx,
+            "parallelism": f"{args.parallelism}{world}",
+            "layers": cfg.num_hidden_layers,
+        },
+        "step_hbm": {"algorithmic_bytes": step_bytes, "achieved_GBps": step_bytes / (elapsed / args.steps) / 1e9,
+                     "frac_of_peak": step_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS},
+        "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "bytes_per_launch": dom["bytes"], "avg_launch_us": dom["seconds"] * 1e6},
+        "roofline_all": {k: {"GBps": v["bytes"] / v["seconds"] / 1e9, "frac": v["bytes"] / v["seconds"] / 1e9 / HBM_PEAK_GBS,
+                             "bytes": v["bytes"], "avg_us": v["seconds"] * 1e6} for k, v in roof.items()},
+    }
+    if args.layers:
+        line["config"]["INVALID"] = "debug run with fewer layers"
+    if world == 1 and not args.no_cpu_baseline:
+        try:
+            line["cpu_baseline"] = cpu_baseline(args, cfg)
+        except Exception as e:  # never lose the GPU number to a CPU-side problem
+            line["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": os.cpu_count(),
+                                    "kind": "port", "sample": f"failed: {e!r}"}
+    print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

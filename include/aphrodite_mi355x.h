@@ -1,0 +1,233 @@
+/*
+ * aphrodite_mi355x.h -- C ABI of libaphrodite_mi355x.so
+ *
+ * MI355X (gfx950 / CDNA4) native kernels for the quantized-inference hot path
+ * of PygmalionAI/aphrodite-engine.  Plain pointers (device memory unless
+ * noted), sizes and a hipStream_t (passed as void*) -- no torch types.  Every
+ * entry point is asynchronous on `stream`, allocates nothing, never
+ * synchronises (HIP-graph capturable) and returns APHRO_OK or a negative
+ * error code; aphro_last_error() describes the failure (thread-local).
+ *
+ * Each function names the reference interface it replaces
+ * (file:line relative to the reference tree, kernels/torch_bindings.cpp = the
+ * op schema, kernels/...cu = the launcher).
+ */
+#ifndef APHRODITE_MI355X_H_
+#define APHRODITE_MI355X_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define APHRO_OK 0
+#define APHRO_ERR_INVALID (-1)  /* unsupported shape / dtype / argument     */
+#define APHRO_ERR_LAUNCH (-2)   /* hipLaunch failure                        */
+#define APHRO_ERR_WORKSPACE (-3) /* caller workspace too small              */
+
+/* activation / output dtypes */
+#define APHRO_F16 0
+#define APHRO_BF16 1
+#define APHRO_F32 2
+/* KV-cache dtypes ("auto" | "fp8"=="fp8_e4m3" | "fp8_e5m2"), OCP encodings */
+#define APHRO_KV_AUTO 0
+#define APHRO_KV_FP8_E4M3 1
+#define APHRO_KV_FP8_E5M2 2
+
+const char* aphro_last_error(void);
+int aphro_abi_version(void);
+
+/* ------------------------------------------------------------------------
+ * GPTQ 4-bit
+ * ---------------------------------------------------------------------- */
+
+/* _C::gptq_shuffle(Tensor! q_weight, Tensor q_perm, int bit)
+ *   kernels/torch_bindings.cpp:364-365, quantization/gptq/q_gemm.cu:2263-2277.
+ * In-place exllama repack of q_weight int32 [K/8, N]: optional row gather by
+ * q_perm (int32 [K], act-order) then the per-word nibble permutation of
+ * qdq_4.cuh:17-35.  `tmp` (K/8*N words) is required only when q_perm != NULL
+ * (the reference cudaMallocs it; we take it from the caller).  bit must be 4. */
+int aphro_gptq_shuffle(uint32_t* q_weight, const int32_t* q_perm, int64_t size_k,
+                       int64_t size_n, int bit, uint32_t* tmp, void* stream);
+
+/* Out-of-place variant of the above: the gptq_marlin_repack role
+ * (kernels/torch_bindings.cpp:204-208) for our CDNA4 K-packed layout. */
+int aphro_gptq_repack(const uint32_t* q_weight, const int32_t* q_perm,
+                      uint32_t* out, int64_t size_k, int64_t size_n, int bit,
+                      void* stream);
+
+/* _C::gptq_gemm(Tensor a, Tensor b_q_weight, Tensor b_gptq_qzeros,
+ *               Tensor b_gptq_scales, Tensor b_g_idx, bool use_exllama, int bit)
+ *   kernels/torch_bindings.cpp:357-361, q_gemm.cu:2238-2261  (exllama path).
+ * c[M,N] = a[M,K] . dequant(W), W = (q - (qzero+1)) * scale, group = k/(K/groups)
+ * a: [M,K] row stride lda (elements), dtype f16|bf16; q_weight: exllama-shuffled
+ * int32 [K/8,N]; qzeros int32 [groups, N/8]; scales dtype [groups,N];
+ * perm: int32 [K] or NULL (act-order: column gather of a, q_gemm.cu:219-226),
+ * needs a_perm_tmp [M,K] dtype.  workspace: fp32 split-K partials, size from
+ * aphro_wna16_workspace_bytes().  zero_offset: 1 for GPTQ v1 checkpoints
+ * (stored zero - 1), 0 for AWQ-style zero points in the same K-packed layout.
+ * M <= APHRO_WNA16_MAX_M rows per call (larger M: caller loops or uses
+ * aphro_gptq_dequant + a library GEMM, as the reference does for M > 50,
+ * q_gemm.cu:1529-1544). */
+#define APHRO_WNA16_MAX_M 64
+int aphro_gptq_gemm(const void* a, const uint32_t* q_weight, const uint32_t* qzeros,
+                    const void* scales, const int32_t* perm, void* a_perm_tmp,
+                    void* c, void* workspace, size_t workspace_bytes, int64_t M,
+                    int64_t N, int64_t K, int64_t groups, int64_t lda,
+                    int zero_offset, int dtype, void* stream);
+size_t aphro_wna16_workspace_bytes(int64_t M, int64_t N, int64_t K);
+
+/* Reconstruct W[K,N] (dtype f16|bf16) from a GPTQ tensor set
+ *   q_gemm.cu:1394-1434 (reconstruct_gptq, shuffled=0, g_idx int32 [K] or NULL)
+ *   q_gemm.cu:856-965   (reconstruct_exllama, shuffled=1, perm ignored: rows are
+ *                        in the permuted order, exactly as the reference). */
+int aphro_gptq_dequant(const uint32_t* q_weight, const uint32_t* qzeros,
+                       const void* scales, const int32_t* g_idx, void* out,
+                       int64_t K, int64_t N, int64_t groups, int shuffled,
+                       int zero_offset, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------
+ * AWQ 4-bit (row a8)
+ * ---------------------------------------------------------------------- */
+
+/* _C::awq_dequantize(Tensor _kernel, Tensor _scaling_factors, Tensor _zeros,
+ *                    int split_k_iters, int thx, int thy)
+ *   kernels/torch_bindings.cpp:148-151, awq/gemm_kernels.cu:720-776.
+ * out[K,N] f16 = (q - z) * s; qweight int32 [K,N/8] (AWQ nibble order),
+ * qzeros int32 [groups,N/8], scales f16 [groups,N]. */
+int aphro_awq_dequantize(const uint32_t* qweight, const void* scales,
+                         const uint32_t* qzeros, void* out, int64_t K, int64_t N,
+                         int64_t groups, int dtype, void* stream);
+
+/* _C::awq_gemm(Tensor _in_feats, Tensor _kernel, Tensor _scaling_factors,
+ *              Tensor _zeros, int split_k_iters)
+ *   kernels/torch_bindings.cpp:142-145, awq/gemm_kernels.cu:784-841.
+ * c[M,N] = a[M,K] . ((q - z) * s).  Positional order as the C++ op. */
+size_t aphro_awq_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K, int64_t groups);
+int aphro_awq_gemm(const void* a, const uint32_t* qweight, const void* scales,
+                   const uint32_t* qzeros, void* c, void* workspace,
+                   size_t workspace_bytes, int64_t M, int64_t N, int64_t K,
+                   int64_t groups, int64_t lda, int dtype, void* stream);
+
+/* awq_marlin_repack role (kernels/torch_bindings.cpp:211-215): AWQ [K,N/8]
+ * qweight -> CDNA4 K-packed exllama-order [K/8,N]; AWQ qzeros [G,N/8] ->
+ * plain column order [G,N/8] (nibble j of word c = column 8c+j). */
+int aphro_awq_repack(const uint32_t* qweight, uint32_t* out, int64_t K, int64_t N,
+                     void* stream);
+int aphro_awq_repack_zeros(const uint32_t* qzeros, uint32_t* out, int64_t groups,
+                           int64_t N, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Paged KV cache + decode attention (rows a1-a4)
+ * ---------------------------------------------------------------------- */
+
+/* _C_cache_ops::reshape_and_cache(Tensor key, Tensor value, Tensor! key_cache,
+ *     Tensor! value_cache, Tensor slot_mapping, str kv_cache_dtype,
+ *     float k_scale, float v_scale)
+ *   kernels/torch_bindings.cpp:467-473, kernels/cache_kernels.cu:263-289.
+ * key/value [T,Hkv,hd] with token strides (elements); key_cache
+ * [NB,Hkv,hd/x,block,x], value_cache [NB,Hkv,hd,block]; slot_mapping int64 [T]
+ * (-1 = padding). */
+int aphro_reshape_and_cache(const void* key, const void* value, void* key_cache,
+                            void* value_cache, const int64_t* slot_mapping,
+                            int64_t num_tokens, int num_kv_heads, int head_size,
+                            int block_size, int x, int64_t key_stride,
+                            int64_t value_stride, int dtype, int kv_dtype,
+                            float k_scale, float v_scale, void* stream);
+
+/* _C_cache_ops::convert_fp8(Tensor! dst_cache, Tensor src_cache, float scale,
+ *                           str kv_cache_dtype)
+ *   kernels/torch_bindings.cpp:487-490, cache_kernels.cu:356-409.
+ * to_fp8 != 0: dst uint8 = fp8(src / scale); else dst = float(src fp8) * scale. */
+int aphro_convert_fp8(void* dst, const void* src, int64_t numel, float scale,
+                      int hp_dtype, int kv_dtype, int to_fp8, void* stream);
+
+/* _C::paged_attention_v1 / _C::paged_attention_v2 / _rocm_C::paged_attention
+ *   kernels/torch_bindings.cpp:25-49, kernels/rocm/torch_bindings.cpp:17-28,
+ *   launchers attention/attention_kernels.cu:809-830, 974-998,
+ *   rocm/attention.cu:1077-1117.
+ * out [S,Hq,hd] (row stride = Hq*hd); query [S,Hq,hd] with seq stride q_stride;
+ * caches as above with block stride kv_block_stride and head stride
+ * kv_head_stride (elements of the cache dtype).  partition_size == 0 selects
+ * the v1 form (no scratch); otherwise exp_sums/max_logits [S,Hq,P] fp32 and
+ * tmp_out [S,Hq,P,hd] (dtype) with P = ceil(max_seq_len/partition_size) are
+ * written exactly as the reference defines them (attention_kernels.cu:350-358)
+ * and merged into out.  alibi_slopes fp32 [Hq] or NULL. */
+int aphro_paged_attention(void* out, float* exp_sums, float* max_logits,
+                          void* tmp_out, const void* query, const void* key_cache,
+                          const void* value_cache, int num_seqs, int num_heads,
+                          int num_kv_heads, int head_size, float scale,
+                          const int32_t* block_tables, const int32_t* seq_lens,
+                          int max_num_blocks_per_seq, int block_size,
+                          int max_seq_len, const float* alibi_slopes,
+                          int64_t q_stride, int64_t kv_block_stride,
+                          int64_t kv_head_stride, int dtype, int kv_dtype,
+                          float k_scale, float v_scale, int partition_size,
+                          void* stream);
+
+/* ------------------------------------------------------------------------
+ * FP8 activations + GEMMs (rows a9-a11)
+ * ---------------------------------------------------------------------- */
+
+/* _C::static_scaled_fp8_quant / dynamic_scaled_fp8_quant /
+ * dynamic_per_token_scaled_fp8_quant
+ *   kernels/torch_bindings.cpp:374-390, quantization/fp8/common.cu:258-321.
+ * out uint8 (OCP e4m3fn) [M,K]; input dtype f16|bf16|f32 [M,K] contiguous. */
+int aphro_static_scaled_fp8_quant(void* out, const void* input, const float* scale,
+                                  int64_t M, int64_t K, int dtype, void* stream);
+/* scale must be zero-initialised by the caller (as _custom_ops.py:676 does). */
+int aphro_dynamic_scaled_fp8_quant(void* out, const void* input, float* scale,
+                                   int64_t M, int64_t K, int dtype, void* stream);
+int aphro_dynamic_per_token_scaled_fp8_quant(void* out, const void* input,
+                                             float* scales, const float* scale_ub,
+                                             int64_t M, int64_t K, int dtype,
+                                             void* stream);
+
+/* _C::cutlass_scaled_mm(Tensor! out, Tensor a, Tensor b, Tensor a_scales,
+ *                       Tensor b_scales, Tensor? bias)
+ *   kernels/torch_bindings.cpp:235-239, cutlass_w8a8/scaled_mm_entry.cu:92-137.
+ * out[M,N] (f16|bf16) = a_scales * (a[M,K] . b[K,N]) * b_scales + bias.
+ * a: e4m3 [M,K] row-major; b: e4m3 column-major [K,N] == row-major [N,K];
+ * a_scales fp32 [1] or [M]; b_scales fp32 [1] or [N]; bias (out dtype) [N]|NULL. */
+int aphro_scaled_mm_fp8(void* out, const void* a, const void* b,
+                        const float* a_scales, const float* b_scales,
+                        const void* bias, void* workspace, size_t workspace_bytes,
+                        int64_t M, int64_t N, int64_t K, int a_scale_per_token,
+                        int b_scale_per_channel, int out_dtype, void* stream);
+
+/* _C::fp8_marlin_gemm role (kernels/torch_bindings.cpp:218-222,
+ * quantization/fp8/fp8_marlin.cu:1212): W8A16, c = a . (fp8->hp(W) * s_n).
+ * a f16|bf16 [M,K]; w e4m3 row-major [N,K]; w_scales fp32 [1] or [N]. */
+int aphro_fp8_w8a16_gemm(void* out, const void* a, const void* w,
+                         const float* w_scales, const void* bias, void* workspace,
+                         size_t workspace_bytes, int64_t M, int64_t N, int64_t K,
+                         int64_t lda, int w_scale_per_channel, int dtype,
+                         void* stream);
+size_t aphro_fp8_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K);
+
+/* ------------------------------------------------------------------------
+ * Glue between the hot kernels
+ * ---------------------------------------------------------------------- */
+/* _C::rms_norm / fused_add_rms_norm  kernels/layernorm_kernels.cu:282-352 */
+int aphro_rms_norm(void* out, const void* input, const void* weight, float eps,
+                   int64_t num_tokens, int hidden, int64_t in_stride, int dtype,
+                   void* stream);
+int aphro_fused_add_rms_norm(void* input, void* residual, const void* weight,
+                             float eps, int64_t num_tokens, int hidden, int dtype,
+                             void* stream);
+/* _C::silu_and_mul  kernels/activation_kernels.cu:55-75 : out[T,d] from in[T,2d] */
+int aphro_silu_and_mul(void* out, const void* input, int64_t num_tokens, int d,
+                       int dtype, void* stream);
+/* _C::rotary_embedding  kernels/pos_encoding_kernels.cu:120-160 (in place) */
+int aphro_rotary_embedding(const int64_t* positions, void* query, void* key,
+                           int64_t num_tokens, int num_heads, int num_kv_heads,
+                           int head_size, int rot_dim, const void* cos_sin_cache,
+                           int64_t query_stride, int64_t key_stride, int is_neox,
+                           int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* APHRODITE_MI355X_H_ */

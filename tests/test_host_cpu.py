@@ -1,0 +1,182 @@
+"""CPU-side tests: the C-ABI library loads and exports every declared symbol
+(no compute calls without a GPU), the host-side mirror of the reference's
+plugin surface behaves like the reference, and the TP collectives work over
+gloo with world_size 2."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "aphrodite_mi355x.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(aphro_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_library_exports_every_declared_symbol():
+    import ctypes
+    from aphrodite_engine_amd import _lib
+    assert os.path.exists(_lib.LIB_PATH), "build the HIP library first (__graft_entry__.build())"
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    syms = _declared_symbols()
+    assert len(syms) >= 25
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/aphrodite_mi355x.h but not exported"
+    # the ctypes table binds exactly the declared ABI
+    assert sorted(_lib.SIGNATURES) == syms
+    assert _lib.lib().aphro_abi_version() == 1
+
+
+def test_no_cpu_fallback():
+    from aphrodite_engine_amd import _custom_ops as ops
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.gptq_gemm(torch.zeros(1, 64, dtype=torch.half),
+                      torch.zeros(8, 16, dtype=torch.int32),
+                      torch.zeros(1, 2, dtype=torch.int32),
+                      torch.zeros(1, 16, dtype=torch.half), torch.empty(0), True, 4)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.scaled_fp8_quant(torch.zeros(2, 8))
+    # nothing under the product package imports the oracle
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "aphrodite_engine_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from aphrodite_engine_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(ImportError, match="no CPU fallback"):
+        _lib.lib()
+
+
+def test_gptq_config_and_weights():
+    from aphrodite_engine_amd.quantization import get_quantization_config
+    from aphrodite_engine_amd.quantization.gptq import ExllamaState, GPTQLinearMethod
+    cfg = get_quantization_config("gptq").from_config(
+        {"bits": 4, "group_size": 128, "desc_act": False})
+    assert cfg.get_name() == "gptq" and int(cfg.pack_factor) == 8
+    layer = torch.nn.Module()
+    m = cfg.get_quant_method(layer, "")
+    assert isinstance(m, GPTQLinearMethod)
+    m.create_weights(layer, 4096, [4096, 1024, 1024], 4096, 6144, torch.float16)
+    assert layer.qweight.shape == (512, 6144) and layer.qweight.dtype == torch.int32
+    assert layer.qzeros.shape == (32, 768) and layer.scales.shape == (32, 6144)
+    assert layer.g_idx.shape == (4096, ) and layer.exllama_state == ExllamaState.UNINITIALIZED
+    # row-parallel + act-order disables exllama (gptq.py:137-139)
+    cfg2 = type(cfg)(4, 128, True)
+    layer2 = torch.nn.Module()
+    cfg2.get_quant_method(layer2, "").create_weights(layer2, 2048, [4096], 4096, 4096, torch.float16)
+    assert layer2.exllama_state == ExllamaState.UNUSED
+    with pytest.raises(ValueError):
+        cfg.get_quant_method(layer, "").create_weights(torch.nn.Module(), 100, [64], 100, 64,
+                                                      torch.float16)
+    with pytest.raises(ValueError):
+        get_quantization_config("nope")
+
+
+def test_awq_and_fp8_configs():
+    from aphrodite_engine_amd.quantization.awq import AWQConfig
+    from aphrodite_engine_amd.quantization.fp8 import Fp8Config, requantize_with_max_scale
+    a = AWQConfig.from_config({"w_bit": 4, "q_group_size": 128, "zero_point": True})
+    layer = torch.nn.Module()
+    a.get_quant_method(layer, "").create_weights(layer, 8192, [1280], 8192, 1280, torch.float16)
+    assert layer.qweight.shape == (8192, 160) and layer.qzeros.shape == (64, 160)
+    with pytest.raises(ValueError):
+        AWQConfig(3, 128, True)
+    f = Fp8Config.from_config({"quant_method": "fp8", "activation_scheme": "static",
+                               "ignored_layers": ["lm_head"]})
+    assert f.is_checkpoint_fp8_serialized and f.get_quant_method(layer, "lm_head") is None
+    layer = torch.nn.Module()
+    f.get_quant_method(layer, "x").create_weights(layer, 64, [32, 16], 64, 48, torch.bfloat16)
+    assert layer.weight.dtype == torch.float8_e4m3fn and layer.weight_scale.shape == (2, )
+    # requantize_with_max_scale (w8a8_utils.py:54-80) on CPU tensors
+    w = (torch.randn(48, 64)).to(torch.float8_e4m3fn)
+    s = torch.tensor([0.5, 2.0])
+    w2 = w.clone()
+    mx, w2 = requantize_with_max_scale(w2, s, [32, 16])
+    assert float(mx) == 2.0
+    ref0 = (w[:32].float() * 0.5 / 2.0).clamp(-448, 448).to(torch.float8_e4m3fn)
+    assert torch.equal(w2[:32].view(torch.uint8), ref0.view(torch.uint8))
+    assert torch.equal(w2[32:].view(torch.uint8), w[32:].view(torch.uint8))
+
+
+def test_mp_linear_kernel_selection():
+    from aphrodite_engine_amd.quantization.kernels import (MPLinearLayerConfig,
+                                                           choose_mp_linear_kernel,
+                                                           register_with_reference)
+    from aphrodite_engine_amd.quantization.kernels.cdna4 import CDNA4LinearKernel
+    from aphrodite_engine_amd.scalar_type import scalar_types
+    c = MPLinearLayerConfig((4096, 4096), (4096, 4096), scalar_types.uint4b8, torch.float16,
+                            128, False, False)
+    assert choose_mp_linear_kernel(c) is CDNA4LinearKernel
+    bad = MPLinearLayerConfig((4096, 4096), (4096, 4096), scalar_types.uint8b128,
+                              torch.float16, 128, False, False)
+    with pytest.raises(ValueError):
+        choose_mp_linear_kernel(bad)
+    with pytest.raises(ValueError):
+        choose_mp_linear_kernel(c, compute_capability=90)   # not gfx950
+    lst = ["Machete", "Marlin"]
+    register_with_reference(lst)
+    register_with_reference(lst)                             # idempotent
+    assert lst[0] is CDNA4LinearKernel and len(lst) == 3
+    assert scalar_types.uint4b8.min() == -8 and scalar_types.uint4b8.max() == 7
+
+
+def test_attention_host_logic():
+    from aphrodite_engine_amd.attention import MI355XAttentionBackend, PagedAttention
+    from aphrodite_engine_amd.model import make_decode_metadata
+    shape = MI355XAttentionBackend.get_kv_cache_shape(10, 16, 8, 128)
+    assert shape == (2, 10, 16 * 8 * 128)
+    kv = torch.zeros(shape, dtype=torch.float16)
+    k, v = PagedAttention.split_kv_cache(kv, 8, 128)
+    assert k.shape == (10, 8, 16, 16, 8) and v.shape == (10, 8, 128, 16)
+    kv8 = torch.zeros(shape, dtype=torch.uint8)
+    k8, _ = PagedAttention.split_kv_cache(kv8, 8, 128)
+    assert k8.shape == (10, 8, 8, 16, 16)
+    meta, pos, nblocks = make_decode_metadata(4, [5, 16, 17, 40], 16, "cpu")
+    assert meta.decode_metadata.num_decode_tokens == 4 and meta.prefill_metadata is None
+    assert pos.tolist() == [4, 15, 16, 39] and nblocks == 12
+    bt = meta.block_tables
+    assert sorted(bt.flatten().tolist()) == list(range(12))        # random permutation
+    for i, L in enumerate([5, 16, 17, 40]):
+        assert int(meta.slot_mapping[i]) == int(bt[i, (L - 1) // 16]) * 16 + (L - 1) % 16
+    with pytest.raises(ValueError):
+        MI355XAttentionBackend.get_impl_cls()(8, 72, 1.0, 2)          # unsupported head size
+
+
+def _tp_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from aphrodite_engine_amd import distributed as d
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank,
+                            world_size=world)
+    d.init_tensor_parallel(world, backend="gloo")
+    x = torch.full((3, 4), float(rank + 1))
+    y = d.tensor_model_parallel_all_reduce(x.clone())
+    g = d.tensor_model_parallel_all_gather(torch.full((2, 3), float(rank)), dim=-1)
+    q.put((rank, d.get_tensor_model_parallel_rank(), y.tolist(), g.tolist()))
+    dist.destroy_process_group()
+
+
+def test_tensor_parallel_collectives_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_tp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+    for rank, tp_rank, y, g in res:
+        assert rank == tp_rank
+        assert y == [[3.0] * 4] * 3                               # 1 + 2
+        assert g == [[0.0, 0.0, 0.0, 1.0, 1.0, 1.0]] * 2          # concatenated on dim -1

@@ -1,0 +1,492 @@
+"""GPU parity tests: every op of the hot path, called through the C ABI
+(aphrodite_engine_amd._custom_ops -> libaphrodite_mi355x.so), against the CPU
+oracle on the same seeded inputs.  Bars:
+  * integer / byte / index work (shuffle, repack, fp8 quant, cache write,
+    AWQ dequant): bit-exact;
+  * GEMMs: mean|d|/mean|ref| < 0.04 (the reference's Marlin-family bar,
+    tests/kernels/test_marlin_gemm.py:57-59) AND a much tighter max-error
+    bound of ours against the fp64 oracle;
+  * paged attention: atol 1e-3 (fp8 KV 1e-2), tests/kernels/test_attention.py:318-326;
+  * scaled_mm: rtol 1e-2 atol 5e-2 (tests/kernels/test_cutlass.py:78).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import attention as oa
+from oracle import fp8 as of8
+from oracle import quant as oq
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a visible MI355X (torch.cuda.is_available() is False)")
+    from aphrodite_engine_amd import _custom_ops
+    from aphrodite_engine_amd import _lib
+    _lib.lib()  # fail loudly if the HIP library is missing
+    return _custom_ops
+
+
+def t(x, dtype=None):
+    out = torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
+    return out.to(dtype) if dtype is not None else out
+
+
+def rel_mean_err(got, ref):
+    return float(np.abs(got - ref).mean() / max(np.abs(ref).mean(), 1e-12))
+
+
+def make_gptq(rng, K, N, G, act_order=False, dtype=np.float16):
+    w = (rng.standard_normal((K, N)) * 0.02).astype(np.float16)
+    _, q, s, zp = oq.quantize_weights(w, 4, G, zero_points=True)
+    s = s.astype(np.float32)
+    g_idx = (np.arange(K) // G).astype(np.int32)
+    if act_order:
+        perm = rng.permutation(K)
+        q = q[perm]
+        g_idx = g_idx[perm]
+    qweight = oq.gptq_pack(q)
+    qzeros = oq.gptq_pack_zeros(zp)
+    return qweight, qzeros, s, g_idx
+
+
+# ---------------------------------------------------------------------------
+# GPTQ
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("K,N", [(256, 64), (512, 192), (128, 16)])
+@pytest.mark.parametrize("act_order", [False, True])
+def test_gptq_shuffle_bit_exact(ops, K, N, act_order):
+    rng = np.random.default_rng(0)
+    qweight = rng.integers(-2 ** 31, 2 ** 31 - 1, size=(K // 8, N), dtype=np.int64).astype(np.int32)
+    perm = rng.permutation(K).astype(np.int32) if act_order else np.empty(0, np.int32)
+    ref = oq.gptq_shuffle(qweight, perm if act_order else None)
+    q = t(qweight)
+    ops.gptq_shuffle(q, t(perm), 4)
+    np.testing.assert_array_equal(q.cpu().numpy(), ref)
+    # marlin-role out-of-place repack is the same transform
+    out = ops.gptq_marlin_repack(t(qweight), t(perm), K, N, 4)
+    np.testing.assert_array_equal(out.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("M", [1, 7, 16, 32, 33, 64, 100])
+@pytest.mark.parametrize("K,N,G", [(512, 256, 128), (1024, 64, 128), (256, 32, 32),
+                                   (2048, 16, 64), (4096, 512, 128)])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_gptq_gemm_exllama(ops, M, K, N, G, dtype):
+    if dtype == torch.bfloat16 and (M not in (1, 32) or K > 1024):
+        pytest.skip("bf16 covered on a subset")
+    rng = np.random.default_rng(M * 131 + K + N)
+    qweight, qzeros, s, _ = make_gptq(rng, K, N, G)
+    a = rng.standard_normal((M, K)).astype(np.float32)
+    a_t = t(a, dtype)
+    s_t = t(s, dtype)
+    shuf = t(oq.gptq_shuffle(qweight))
+    got = ops.gptq_gemm(a_t, shuf, t(qzeros), s_t, torch.empty(0, dtype=torch.int32, device=DEV),
+                        True, 4).float().cpu().numpy()
+    ref = oq.gptq_gemm(a_t.float().cpu().numpy(), shuf.cpu().numpy(), qzeros,
+                       s_t.float().cpu().numpy(), None, True)
+    assert got.shape == (M, N)
+    assert rel_mean_err(got, ref) < 0.04
+    tol = 2e-3 if dtype == torch.float16 else 1.6e-2  # output rounding dominates
+    np.testing.assert_allclose(got, ref, rtol=tol, atol=tol * np.abs(ref).max())
+
+
+@pytest.mark.parametrize("M", [3, 32])
+def test_gptq_gemm_act_order(ops, M):
+    """act-order: exllama path gathers A by the permutation (q_gemm.cu:219-226);
+    the non-exllama path honours g_idx per row (q_gemm.cu:1394-1434)."""
+    rng = np.random.default_rng(5)
+    K, N, G = 512, 128, 128
+    qweight, qzeros, s, g_idx = make_gptq(rng, K, N, G, act_order=True)
+    a = rng.standard_normal((M, K)).astype(np.float16)
+    ref = oq.gptq_gemm(a, qweight, qzeros, s, g_idx, False)
+    got_plain = ops.gptq_gemm(t(a), t(qweight), t(qzeros), t(s, torch.float16), t(g_idx),
+                              False, 4).float().cpu().numpy()
+    np.testing.assert_allclose(got_plain, ref, rtol=3e-3, atol=3e-3 * np.abs(ref).max())
+    perm = np.argsort(g_idx, kind="stable").astype(np.int32)
+    q = t(qweight)
+    ops.gptq_shuffle(q, t(perm), 4)
+    got = ops.gptq_gemm(t(a), q, t(qzeros), t(s, torch.float16), t(perm), True,
+                        4).float().cpu().numpy()
+    np.testing.assert_allclose(got, ref, rtol=2e-3, atol=2e-3 * np.abs(ref).max())
+
+
+def test_gptq_dequant_bit_exact(ops):
+    rng = np.random.default_rng(6)
+    K, N, G = 256, 64, 64
+    qweight, qzeros, s, g_idx = make_gptq(rng, K, N, G, act_order=True)
+    ref = oq.gptq_dequant(qweight, qzeros, s, g_idx).astype(np.float16)
+    got = ops.gptq_dequant(t(qweight), t(qzeros), t(s, torch.float16), t(g_idx), False)
+    np.testing.assert_array_equal(got.cpu().numpy(), ref)
+
+
+def test_gptq_gemm_large_m_path(ops):
+    rng = np.random.default_rng(7)
+    K, N, G, M = 512, 128, 128, 300
+    qweight, qzeros, s, _ = make_gptq(rng, K, N, G)
+    a = rng.standard_normal((M, K)).astype(np.float16)
+    shuf = oq.gptq_shuffle(qweight)
+    ref = oq.gptq_gemm(a, shuf, qzeros, s, None, True)
+    got = ops.gptq_gemm(t(a), t(shuf), t(qzeros), t(s, torch.float16),
+                        torch.empty(0, dtype=torch.int32, device=DEV), True, 4)
+    assert rel_mean_err(got.float().cpu().numpy(), ref) < 0.04
+
+
+# ---------------------------------------------------------------------------
+# AWQ
+# ---------------------------------------------------------------------------
+def make_awq(rng, K, N, G):
+    w = (rng.standard_normal((K, N)) * 0.02).astype(np.float16)
+    _, q, s, zp = oq.quantize_weights(w, 4, G, zero_points=True)
+    return oq.awq_pack(q), oq.awq_pack(zp), s
+
+
+@pytest.mark.parametrize("K,N,G", [(256, 64, 128), (128, 8, 32), (1024, 256, 128)])
+def test_awq_dequantize_bit_exact(ops, K, N, G):
+    rng = np.random.default_rng(8)
+    qw, qz, s = make_awq(rng, K, N, G)
+    ref = oq.awq_dequantize(qw, s, qz)
+    got = ops.awq_dequantize(t(qw), t(s), t(qz), 0, 0, 0)
+    np.testing.assert_array_equal(got.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("M", [1, 16, 64, 70])
+@pytest.mark.parametrize("K,N,G", [(512, 128, 128), (1024, 64, 64)])
+def test_awq_gemm(ops, M, K, N, G):
+    rng = np.random.default_rng(9 + M)
+    qw, qz, s = make_awq(rng, K, N, G)
+    a = rng.standard_normal((M, K)).astype(np.float16)
+    ref = oq.awq_gemm(a, qw, s, qz)
+    # positional order of awq.py:165-166: (x, qweight, scales, qzeros, pack_factor)
+    got = ops.awq_gemm(t(a), t(qw), t(s), t(qz), 8).float().cpu().numpy()
+    assert rel_mean_err(got, ref) < 0.04  # reference bar (atol=rtol=1e-1 in test_awq_triton.py:170)
+    np.testing.assert_allclose(got, ref, rtol=2e-3, atol=2e-3 * np.abs(ref).max())
+    # load-time repack (awq_marlin role) + fast kernel gives the same numbers
+    rq = ops.awq_marlin_repack(t(qw), K, N, 4)
+    rz = ops.awq_repack_zeros(t(qz), N)
+    np.testing.assert_array_equal(rq.cpu().numpy(), oq.gptq_shuffle(oq.gptq_pack(oq.awq_unpack(qw))))
+    np.testing.assert_array_equal(rz.cpu().numpy(), oq.pack_cols(oq.awq_unpack(qz)))
+    got2 = ops.wna16_gemm(t(a), rq, rz, t(s), None, 0).float().cpu().numpy()
+    np.testing.assert_array_equal(got2, got)
+
+
+# ---------------------------------------------------------------------------
+# FP8 quant + GEMMs
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("M,K", [(1, 64), (7, 96), (33, 1026), (64, 4096)])
+def test_scaled_fp8_quant_bit_exact(ops, dtype, M, K):
+    rng = np.random.default_rng(10)
+    x = ((rng.random((M, K)) - 0.5) * 60).astype(np.float32)
+    x[0] *= 1e-4
+    xt = t(x, dtype)
+    xr = xt.float().cpu().numpy()
+    q, s = ops.scaled_fp8_quant(xt, use_per_token_if_dynamic=True)
+    rq, rs = of8.dynamic_per_token_scaled_fp8_quant(xr)
+    np.testing.assert_array_equal(s.cpu().numpy(), rs)
+    np.testing.assert_array_equal(q.view(torch.uint8).cpu().numpy(), rq)
+    ub = torch.tensor([3.0], device=DEV)
+    q, s = ops.scaled_fp8_quant(xt, scale_ub=ub, use_per_token_if_dynamic=True)
+    rq, rs = of8.dynamic_per_token_scaled_fp8_quant(xr, 3.0)
+    np.testing.assert_array_equal(s.cpu().numpy(), rs)
+    np.testing.assert_array_equal(q.view(torch.uint8).cpu().numpy(), rq)
+    q, s = ops.scaled_fp8_quant(xt)
+    rq, rs = of8.dynamic_scaled_fp8_quant(xr)
+    np.testing.assert_array_equal(s.cpu().numpy(), rs)
+    np.testing.assert_array_equal(q.view(torch.uint8).cpu().numpy(), rq)
+    sc = torch.tensor([0.37], device=DEV)
+    q, _ = ops.scaled_fp8_quant(xt, sc)
+    np.testing.assert_array_equal(q.view(torch.uint8).cpu().numpy(),
+                                  of8.static_scaled_fp8_quant(xr, np.float32(0.37)))
+    q, _ = ops.scaled_fp8_quant(xt, num_token_padding=M + 5, use_per_token_if_dynamic=True)
+    assert q.shape == (M + 5, K)
+
+
+@pytest.mark.parametrize("M", [1, 16, 33, 64, 90])
+@pytest.mark.parametrize("K,N", [(256, 64), (1024, 256), (4096, 32)])
+@pytest.mark.parametrize("per_token,per_channel", [(False, False), (True, True)])
+@pytest.mark.parametrize("out_dtype", [torch.float16, torch.bfloat16])
+def test_cutlass_scaled_mm(ops, M, K, N, per_token, per_channel, out_dtype):
+    rng = np.random.default_rng(M + K + N)
+    a = t((rng.standard_normal((M, K)) * 2).astype(np.float32)).to(torch.float8_e4m3fn)
+    w = t((rng.standard_normal((N, K)) * 2).astype(np.float32)).to(torch.float8_e4m3fn)
+    sa = t((rng.random((M, 1) if per_token else (1, )) * 0.1 + 0.01).astype(np.float32))
+    sb = t((rng.random((N, 1) if per_channel else (1, )) * 0.1 + 0.01).astype(np.float32))
+    bias = t(rng.standard_normal(N).astype(np.float32), out_dtype)
+    got = ops.cutlass_scaled_mm(a, w.t(), sa, sb, out_dtype, bias).float().cpu().numpy()
+    ref = of8.scaled_mm(a.view(torch.uint8).cpu().numpy(), w.view(torch.uint8).cpu().numpy().T,
+                        sa.cpu().numpy(), sb.cpu().numpy().reshape(-1),
+                        bias.float().cpu().numpy())
+    np.testing.assert_allclose(got, ref, rtol=1e-2, atol=5e-2)
+
+
+@pytest.mark.parametrize("M", [1, 32, 64])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_fp8_w8a16(ops, M, dtype):
+    rng = np.random.default_rng(M)
+    K, N = 512, 128
+    a = t(rng.standard_normal((M, K)).astype(np.float32), dtype)
+    w = t((rng.standard_normal((N, K)) * 2).astype(np.float32)).to(torch.float8_e4m3fn)
+    sb = t((rng.random(N) * 0.1 + 0.01).astype(np.float32))
+    got = ops.fp8_marlin_gemm(a, w, sb, None, 8, M, N, K).float().cpu().numpy()
+    ref = of8.fp8_w8a16_gemm(a.float().cpu().numpy(), w.view(torch.uint8).cpu().numpy().T,
+                             sb.cpu().numpy())
+    assert rel_mean_err(got, ref) < 0.04
+    tol = 2e-3 if dtype == torch.float16 else 1.6e-2
+    np.testing.assert_allclose(got, ref, rtol=tol, atol=tol * np.abs(ref).max())
+
+
+# ---------------------------------------------------------------------------
+# cache ops + paged attention
+# ---------------------------------------------------------------------------
+def make_cache(rng, NB, Hkv, D, BS, dtype, kv_cache_dtype):
+    if kv_cache_dtype == "auto":
+        x = 16 // torch.tensor([], dtype=dtype).element_size()
+        kc = t(((rng.random((NB, Hkv, D // x, BS, x)) - 0.5) * 2 * D ** -0.5).astype(np.float32), dtype)
+        vc = t(((rng.random((NB, Hkv, D, BS)) - 0.5) * 2 * D ** -0.5).astype(np.float32), dtype)
+    else:
+        x = 16
+        kf = ((rng.random((NB, Hkv, D // x, BS, x)) - 0.5) * 2).astype(np.float32)
+        vf = ((rng.random((NB, Hkv, D, BS)) - 0.5) * 2).astype(np.float32)
+        kc = t(of8.kv_quant(kf, 1.0, kv_cache_dtype))
+        vc = t(of8.kv_quant(vf, 1.0, kv_cache_dtype))
+    return kc, vc
+
+
+@pytest.mark.parametrize("kv_cache_dtype", ["auto", "fp8", "fp8_e5m2"])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32])
+def test_reshape_and_cache(ops, kv_cache_dtype, dtype):
+    if dtype == torch.float32 and kv_cache_dtype == "auto":
+        x = 4
+    rng = np.random.default_rng(11)
+    T, Hkv, D, BS, NB = 13, 2, 64, 16, 5
+    cdt = dtype if kv_cache_dtype == "auto" else torch.uint8
+    x = 16 // torch.tensor([], dtype=cdt).element_size()
+    kc = torch.zeros(NB, Hkv, D // x, BS, x, dtype=cdt, device=DEV)
+    vc = torch.zeros(NB, Hkv, D, BS, dtype=cdt, device=DEV)
+    qkv = t(rng.standard_normal((T, 3 * Hkv * D)).astype(np.float32), dtype)
+    key = qkv[:, Hkv * D:2 * Hkv * D].view(T, Hkv, D)      # strided views like the model's
+    val = qkv[:, 2 * Hkv * D:].view(T, Hkv, D)
+    slots = rng.permutation(NB * BS)[:T].astype(np.int64)
+    slots[3] = -1                                            # padding token is skipped
+    ks, vs = (1.0, 1.0) if kv_cache_dtype == "auto" else (0.37, 0.5)
+    ops.reshape_and_cache(key, val, kc, vc, t(slots), kv_cache_dtype, ks, vs)
+    kc_ref = np.zeros(kc.shape, dtype=np.float32 if kv_cache_dtype == "auto" else np.uint8)
+    vc_ref = np.zeros(vc.shape, dtype=kc_ref.dtype)
+    oa.reshape_and_cache(key.float().cpu().numpy(), val.float().cpu().numpy(), kc_ref, vc_ref,
+                         slots, kv_cache_dtype, ks, vs)
+    got_k = kc.float().cpu().numpy() if kv_cache_dtype == "auto" else kc.cpu().numpy()
+    got_v = vc.float().cpu().numpy() if kv_cache_dtype == "auto" else vc.cpu().numpy()
+    np.testing.assert_array_equal(got_k, kc_ref)
+    np.testing.assert_array_equal(got_v, vc_ref)
+
+
+@pytest.mark.parametrize("kind", ["fp8", "fp8_e5m2"])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_convert_fp8_round_trip(ops, kind, dtype):
+    rng = np.random.default_rng(12)
+    src = t(((rng.random((4, 2, 8, 16, 8)) - 0.5) * 6).astype(np.float32), dtype)
+    q = torch.empty(src.shape, dtype=torch.uint8, device=DEV)
+    ops.convert_fp8(q, src, 0.5, kind)
+    np.testing.assert_array_equal(q.cpu().numpy(),
+                                  of8.kv_quant(src.float().cpu().numpy(), 0.5, kind))
+    back = torch.empty_like(src)
+    ops.convert_fp8(back, q, 0.5, kind)
+    ref = torch.from_numpy(of8.kv_dequant(q.cpu().numpy(), 0.5, kind)).to(dtype)
+    assert torch.equal(back.cpu(), ref)
+    # the reference's own (loose) pin: tests/kernels/test_cache.py:408-433
+    torch.testing.assert_close(back.float(), src.float(), atol=1e-3 if kind == "fp8" else 1e-3, rtol=0.26)
+
+
+ATT_CASES = [
+    # (num_seqs, Hq, Hkv, D, BS, max_len)
+    (7, 8, 2, 128, 16, 700),
+    (3, 40, 40, 64, 16, 300),
+    (5, 64, 8, 128, 32, 1100),
+    (2, 32, 8, 128, 16, 2500),
+    (4, 16, 2, 96, 16, 400),
+    (3, 8, 8, 80, 16, 200),
+    (2, 32, 1, 128, 16, 600),     # gqa 32 > 16: two head passes
+    (3, 8, 2, 128, 8, 500),
+]
+
+
+@pytest.mark.parametrize("case", ATT_CASES)
+@pytest.mark.parametrize("version", ["v1", "v2", "rocm"])
+@pytest.mark.parametrize("kv_cache_dtype", ["auto", "fp8", "fp8_e5m2"])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("use_alibi", [False, True])
+def test_paged_attention(ops, case, version, kv_cache_dtype, dtype, use_alibi):
+    num_seqs, Hq, Hkv, D, BS, max_len = case
+    if use_alibi and (dtype == torch.bfloat16 or kv_cache_dtype != "auto"):
+        pytest.skip("alibi covered with fp16/auto")
+    if dtype == torch.bfloat16 and case not in ATT_CASES[:3]:
+        pytest.skip("bf16 covered on a subset")
+    rng = np.random.default_rng(hash((case, version)) % 2 ** 31)
+    seq_lens = rng.integers(1, max_len + 1, size=num_seqs).astype(np.int32)
+    seq_lens[-1] = max_len
+    if num_seqs > 2:
+        seq_lens[0] = 1
+        seq_lens[1] = min(max_len, 513)
+    bps = (max_len + BS - 1) // BS
+    NB = num_seqs * bps + 3
+    kc, vc = make_cache(rng, NB, Hkv, D, BS, dtype, kv_cache_dtype)
+    # poison unused cache space with NaN / garbage: masked tokens must not leak
+    bt = rng.permutation(NB)[:num_seqs * bps].reshape(num_seqs, bps).astype(np.int32)
+    qkv = t(rng.standard_normal((num_seqs, Hq * D + 64)).astype(np.float32), dtype)
+    query = qkv[:, :Hq * D].view(num_seqs, Hq, D)            # strided like q of qkv
+    scale = float(D ** -0.5)
+    ks, vs = (1.0, 1.0) if kv_cache_dtype == "auto" else (0.7, 1.3)
+    slopes = t(rng.standard_normal(Hq).astype(np.float32)) if use_alibi else None
+    out = torch.empty(num_seqs, Hq, D, dtype=dtype, device=DEV)
+    args = (query, kc, vc, Hkv, scale, t(bt), t(seq_lens), BS, int(max_len), slopes,
+            kv_cache_dtype, ks, vs)
+    P = (max_len + 511) // 512
+    es = torch.full((num_seqs, Hq, P), float("nan"), device=DEV)
+    ml = torch.full((num_seqs, Hq, P), float("nan"), device=DEV)
+    tmp = torch.full((num_seqs, Hq, P, D), float("nan"), dtype=dtype, device=DEV)
+    if version == "v1":
+        ops.paged_attention_v1(out, *args)
+    elif version == "v2":
+        ops.paged_attention_v2(out, es, ml, tmp, *args)
+    else:
+        ops.paged_attention_rocm(out, es, ml, tmp, *args)
+    kc_np = kc.float().cpu().numpy() if kv_cache_dtype == "auto" else kc.cpu().numpy()
+    vc_np = vc.float().cpu().numpy() if kv_cache_dtype == "auto" else vc.cpu().numpy()
+    ref = oa.paged_attention_decode(query.float().cpu().numpy(), kc_np, vc_np, bt, seq_lens,
+                                    scale, slopes.cpu().numpy() if use_alibi else None,
+                                    kv_cache_dtype, ks, vs)
+    atol = 1e-3 if kv_cache_dtype == "auto" else 1e-2
+    if dtype == torch.bfloat16:
+        atol = max(atol, 8e-3)  # bf16 output rounding (|out| <~ 1)
+    np.testing.assert_allclose(out.float().cpu().numpy(), ref, atol=atol, rtol=1e-2)
+    if version != "v1" and P > 1:
+        # scratch tensors carry the reference's meaning (attention_kernels.cu:350-358)
+        _, mx_ref, es_ref, _ = oa.paged_attention_v2_partials(
+            query.float().cpu().numpy(), kc_np, vc_np, bt, seq_lens, scale, 512,
+            slopes.cpu().numpy() if use_alibi else None, kv_cache_dtype, ks, vs)
+        ok = ~np.isnan(mx_ref)
+        ks_eff = 1.0
+        np.testing.assert_allclose(ml.cpu().numpy()[ok], mx_ref[ok] * ks_eff, atol=2e-2, rtol=1e-2)
+        np.testing.assert_allclose(es.cpu().numpy()[ok], es_ref[ok], rtol=3e-2, atol=1e-3)
+
+
+def test_paged_attention_garbage_beyond_seq_len(ops):
+    """Unwritten slots of the last block may hold NaN: they must not leak
+    (attention_kernels.cu:421-430 zeroes V for out-of-range tokens)."""
+    rng = np.random.default_rng(13)
+    S, Hq, Hkv, D, BS = 2, 8, 2, 128, 16
+    seq_lens = np.array([5, 37], np.int32)
+    NB = 8
+    kc, vc = make_cache(rng, NB, Hkv, D, BS, torch.float16, "auto")
+    bt = np.array([[0, 1, 2], [3, 4, 5]], np.int32)
+    kc_np, vc_np = kc.float().cpu().numpy(), vc.float().cpu().numpy()
+    for i, L in enumerate(seq_lens):
+        b, off = divmod(int(L), BS)
+        kc[bt[i, b], :, :, off:, :] = float("nan")
+        vc[bt[i, b], :, :, off:] = float("nan")
+    q = t(rng.standard_normal((S, Hq, D)).astype(np.float32), torch.float16)
+    out = torch.empty_like(q)
+    ops.paged_attention_v1(out, q, kc, vc, Hkv, 0.1, t(bt), t(seq_lens), BS, 37, None,
+                           "auto", 1.0, 1.0)
+    ref = oa.paged_attention_decode(q.float().cpu().numpy(), kc_np, vc_np, bt, seq_lens, 0.1)
+    assert not torch.isnan(out).any()
+    np.testing.assert_allclose(out.float().cpu().numpy(), ref, atol=1e-3, rtol=1e-2)
+
+
+def test_ops_reject_bad_arguments(ops):
+    q = torch.zeros(1, 4, 72, dtype=torch.float16, device=DEV)   # head size 72 unsupported
+    kc = torch.zeros(2, 1, 9, 16, 8, dtype=torch.float16, device=DEV)
+    vc = torch.zeros(2, 1, 72, 16, dtype=torch.float16, device=DEV)
+    bt = torch.zeros(1, 1, dtype=torch.int32, device=DEV)
+    sl = torch.ones(1, dtype=torch.int32, device=DEV)
+    with pytest.raises(RuntimeError):
+        ops.paged_attention_v1(torch.empty_like(q), q, kc, vc, 1, 1.0, bt, sl, 16, 1, None,
+                               "auto", 1.0, 1.0)
+    with pytest.raises(RuntimeError):
+        ops.reshape_and_cache(q, q, kc, vc, torch.zeros(1, dtype=torch.int64, device=DEV),
+                              "int3", 1.0, 1.0)
+    with pytest.raises(RuntimeError):
+        ops.gptq_gemm(torch.zeros(1, 64), torch.zeros(8, 16, dtype=torch.int32),
+                      torch.zeros(1, 2, dtype=torch.int32), torch.zeros(1, 16),
+                      torch.empty(0), True, 4)   # CPU tensors: no CPU fallback
+
+
+# ---------------------------------------------------------------------------
+# glue
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("hidden", [512, 4096, 8192])
+def test_rms_norm_and_fused_add(ops, dtype, hidden):
+    rng = np.random.default_rng(14)
+    T = 9
+    x = t(rng.standard_normal((T, hidden)).astype(np.float32), dtype)
+    res = t(rng.standard_normal((T, hidden)).astype(np.float32), dtype)
+    w = t((rng.standard_normal(hidden) * 0.1 + 1).astype(np.float32), dtype)
+    out = torch.empty_like(x)
+    ops.rms_norm(out, x, w, 1e-5)
+    ref = oa.rms_norm(x, w, 1e-5)
+    tol = 4e-3 if dtype == torch.float16 else 3e-2
+    np.testing.assert_allclose(out.float().cpu().numpy(), ref, atol=tol, rtol=tol)
+    x2, r2 = x.clone(), res.clone()
+    ops.fused_add_rms_norm(x2, r2, w, 1e-5)
+    r_ref = (x.float() + res.float()).to(dtype)
+    assert torch.equal(r2, r_ref)
+    ref2 = oa.rms_norm(r_ref, w, 1e-5)
+    np.testing.assert_allclose(x2.float().cpu().numpy(), ref2, atol=tol, rtol=tol)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_silu_and_mul_and_rope(ops, dtype):
+    rng = np.random.default_rng(15)
+    T, d = 11, 1024
+    x = t(rng.standard_normal((T, 2 * d)).astype(np.float32), dtype)
+    out = torch.empty(T, d, dtype=dtype, device=DEV)
+    ops.silu_and_mul(out, x)
+    tol = 4e-3 if dtype == torch.float16 else 3e-2
+    np.testing.assert_allclose(out.float().cpu().numpy(), oa.silu_and_mul(x), atol=tol, rtol=tol)
+    Hq, Hkv, hd = 8, 2, 128
+    qkv = t(rng.standard_normal((T, (Hq + 2 * Hkv) * hd)).astype(np.float32), dtype)
+    q, k, _ = qkv.split([Hq * hd, Hkv * hd, Hkv * hd], dim=-1)
+    from aphrodite_engine_amd.model import _rope_cache
+    cs = _rope_cache(hd, 256, 10000.0, dtype, DEV)
+    pos = t(rng.integers(0, 256, size=T).astype(np.int64))
+    q_ref, k_ref = oa.rotary_embedding_neox(pos.cpu().numpy(), q, k, hd, cs)
+    ops.rotary_embedding(pos, q, k, hd, cs, True)
+    np.testing.assert_allclose(q.float().cpu().numpy(), q_ref, atol=tol, rtol=tol)
+    np.testing.assert_allclose(k.float().cpu().numpy(), k_ref, atol=tol, rtol=tol)
+
+
+# ---------------------------------------------------------------------------
+# full-size property checks (BASELINE configs[1] shapes)
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("K,N", [(4096, 6144), (4096, 4096), (4096, 28672), (14336, 4096)])
+def test_gptq_gemm_full_size_linearity(ops, K, N):
+    """Llama-3-8B shapes, M=32: linearity (gemm(a+b) = gemm(a)+gemm(b)) and
+    agreement with dequant + fp32 matmul on the device (size-independent
+    properties; the fp64 oracle is too slow at this size)."""
+    g = torch.Generator(device=DEV).manual_seed(K + N)
+    G = K // 128
+    qw = torch.randint(-2 ** 31, 2 ** 31 - 1, (K // 8, N), generator=g, device=DEV,
+                       dtype=torch.int64).to(torch.int32)
+    qz = torch.randint(-2 ** 31, 2 ** 31 - 1, (G, N // 8), generator=g, device=DEV,
+                       dtype=torch.int64).to(torch.int32)
+    s = (torch.rand(G, N, generator=g, device=DEV) * 0.01 + 0.005).half()
+    a = torch.randn(32, K, generator=g, device=DEV).half()
+    b = torch.randn(32, K, generator=g, device=DEV).half()
+    empty = torch.empty(0, dtype=torch.int32, device=DEV)
+    ya = ops.gptq_gemm(a, qw, qz, s, empty, True, 4).float()
+    yb = ops.gptq_gemm(b, qw, qz, s, empty, True, 4).float()
+    yab = ops.gptq_gemm((a.float() + b.float()).half(), qw, qz, s, empty, True, 4).float()
+    w = ops.gptq_dequant(qw, qz, s, None, True).float()
+    ref = a.float() @ w
+    scale_ = ref.abs().max().item()
+    assert (ya - ref).abs().max().item() < 3e-3 * scale_
+    assert (yab - (ya + yb)).abs().max().item() < 6e-3 * scale_
+    # determinism: no atomics anywhere in the path
+    assert torch.equal(ya, ops.gptq_gemm(a, qw, qz, s, empty, True, 4).float())
