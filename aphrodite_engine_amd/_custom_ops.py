@@ -156,6 +156,34 @@ def _partition_size(tmp_out: torch.Tensor, max_seq_len: int) -> int:
     return part
 
 
+def flash_attn_varlen(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor,
+                      cu_seqlens: torch.Tensor, max_seqlen: int, softmax_scale: float,
+                      causal: bool = True,
+                      alibi_slopes: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Prefill self-attention over packed sequences: the role of
+    triton_attention / flash_attn_varlen_func in ROCmFlashAttentionImpl
+    (rocm_flash_attn.py:455-508).  q [T,Hq,hd], k/v [T,Hkv,hd] (token-strided
+    views allowed), cu_seqlens int32 [B+1]; returns [T,Hq,hd]."""
+    _require_cuda(q, k, v, cu_seqlens)
+    t, hq, hd = q.shape
+    hkv = k.shape[1]
+    for x in (q, k, v):
+        if x.stride(2) != 1 or x.stride(1) != hd:
+            raise RuntimeError("flash_attn_varlen: heads must be contiguous")
+    if cu_seqlens.dtype != torch.int32:
+        cu_seqlens = cu_seqlens.to(torch.int32)
+    out = torch.empty((t, hq, hd), dtype=q.dtype, device=q.device)
+    if alibi_slopes is not None and alibi_slopes.dtype != torch.float32:
+        alibi_slopes = alibi_slopes.float()
+    check(_lib.lib().aphro_flash_attn_varlen(
+        out.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(),
+        cu_seqlens.data_ptr(), cu_seqlens.numel() - 1, int(max_seqlen), hq, hkv, hd,
+        q.stride(0), k.stride(0), v.stride(0), float(softmax_scale),
+        1 if causal else 0, _ptr(alibi_slopes), _dt(q), _stream()),
+        "flash_attn_varlen")
+    return out
+
+
 # --------------------------------------------------------------------------
 # cache ops
 # --------------------------------------------------------------------------

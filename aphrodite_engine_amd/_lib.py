@@ -43,6 +43,7 @@ SIGNATURES = {
     "aphro_fused_add_rms_norm": (I, [P, P, P, F, L, I, I, P]),
     "aphro_silu_and_mul": (I, [P, P, L, I, I, P]),
     "aphro_rotary_embedding": (I, [P, P, P, L, I, I, I, I, P, L, L, I, I, P]),
+    "aphro_flash_attn_varlen": (I, [P, P, P, P, P, I, I, I, I, I, L, L, L, F, I, P, I, P]),
 }
 
 OK = 0

@@ -95,14 +95,29 @@ __device__ __forceinline__ float fp8_to_f32(uint8_t b) {
 template <bool E5M2>
 __device__ __forceinline__ uint32_t f32x2_to_fp8(float a, float b) {
   if constexpr (E5M2) {
-    a = __builtin_fminf(__builtin_fmaxf(a, -57344.f), 57344.f);
-    b = __builtin_fminf(__builtin_fmaxf(b, -57344.f), 57344.f);
+    a = __builtin_fmaxf(-57344.f, __builtin_fminf(a, 57344.f));
+    b = __builtin_fmaxf(-57344.f, __builtin_fminf(b, 57344.f));
     return (uint32_t)__builtin_amdgcn_cvt_pk_bf8_f32(a, b, 0, false) & 0xffffu;
   } else {
-    a = __builtin_fminf(__builtin_fmaxf(a, -448.f), 448.f);
-    b = __builtin_fminf(__builtin_fmaxf(b, -448.f), 448.f);
+    a = __builtin_fmaxf(-448.f, __builtin_fminf(a, 448.f));
+    b = __builtin_fmaxf(-448.f, __builtin_fminf(b, 448.f));
     return (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false) & 0xffffu;
   }
+}
+
+template <bool E5M2, int BYTE>
+__device__ __forceinline__ float fp8_byte_to_f32(uint32_t word) {
+  if constexpr (E5M2) return __builtin_amdgcn_cvt_f32_bf8(word, BYTE);
+  else return __builtin_amdgcn_cvt_f32_fp8(word, BYTE);
+}
+
+// (hi16(lo) | hi16(hi) << 16): two f32 that are exactly representable in bf16 ->
+// packed bf16 pair.  One v_perm_b32.  NOTE (hipcc 7.2, gfx950): bit-casting
+// element [1] of a __builtin_amdgcn_cvt_pk_f32_fp8/bf8 result to an integer is
+// MISCOMPILED (element [0]'s register is read instead; float uses of [1] are
+// fine) -- feed this helper from the per-byte converts (fp8_byte_to_f32) only.
+__device__ __forceinline__ uint32_t f32x2_hi16(float lo, float hi) {
+  return __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, hi), __builtin_bit_cast(uint32_t, lo), 0x07060302u);
 }
 
 // ---- wave reductions ------------------------------------------------------------

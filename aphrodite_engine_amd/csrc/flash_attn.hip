@@ -1,0 +1,226 @@
+// Prefill attention for gfx950: causal var-len flash attention on MFMA
+// (SURVEY 8a row a5).  Fills the role of the Triton / CK kernels the reference
+// calls at aphrodite/attention/backends/rocm_flash_attn.py:455-508
+// (attention/ops/triton_flash_attn.py:700-820): q [T,Hq,hd], k/v [T,Hkv,hd]
+// packed sequences delimited by cu_seqlens, GQA by head / (Hq/Hkv).
+//
+// Design: one workgroup = 4 waves = 64 query rows of one (sequence, head); each
+// wave owns 16 rows.  K/V tiles of 32 tokens are staged through LDS once per
+// workgroup (K row-major with a 16-byte XOR swizzle so the ds_read_b128 fragment
+// reads are conflict-free, V transposed on the way in so the PV operand is a
+// contiguous 8-byte read).  As in the decode kernel the score tile is computed
+// transposed, S^T[token, q] = K . Q^T, which leaves the probabilities in
+// exactly the lane layout the PV MFMA consumes as its B operand:
+// O^T[d, q] += V^T[d, token] . P^T[token, q].  Online softmax in registers,
+// fp32 accumulation.  MFMA-bound regime; this first version is single-buffered
+// (two barriers per K/V tile) -- see DESIGN.md for the planned pipeline.
+#include "common.h"
+
+namespace aphro {
+
+struct FAParams {
+  void* out;
+  const void* q;
+  const void* k;
+  const void* v;
+  const int32_t* cu_seqlens;
+  const float* alibi;
+  int num_heads, num_kv_heads;
+  int64_t q_stride, k_stride, v_stride;
+  float scale;
+  int causal;
+};
+
+template <typename T>
+__device__ __forceinline__ f32x4 fa_mfma(u32x4 a, u32x4 b, f32x4 c) {
+  if constexpr (__is_same(T, Half))
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+template <typename T>
+__device__ __forceinline__ uint32_t fa_pack2(float a, float b) {
+  if constexpr (__is_same(T, Half)) {
+    f16x2 h = {(f16)a, (f16)b};
+    return __builtin_bit_cast(uint32_t, h);
+  } else {
+    return (uint32_t)f32_to_bf16_bits(a) | ((uint32_t)f32_to_bf16_bits(b) << 16);
+  }
+}
+
+constexpr int FA_BM = 64;   // query rows per workgroup
+constexpr int FA_BN = 32;   // kv tokens per tile
+constexpr int FA_VT_STRIDE = 36;  // halfs per V^T row (32 + 4 pad)
+
+template <typename T, int HD>
+__global__ __launch_bounds__(256) void flash_attn_varlen_kernel(FAParams p) {
+  constexpr int NCH = HD / 8;    // 16-byte chunks per row
+  constexpr int SWZ = (NCH & -NCH) - 1;  // XOR mask: largest power of two dividing NCH, minus 1
+  constexpr int NKS = HD / 32;
+  constexpr int NDT = HD / 16;
+  __shared__ __attribute__((aligned(16))) uint16_t k_lds[FA_BN * HD];
+  __shared__ __attribute__((aligned(16))) uint16_t vt_lds[HD * FA_VT_STRIDE];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int g = lane >> 4;
+  const int c = lane & 15;
+  const int head = blockIdx.y;
+  const int seq = blockIdx.z;
+  const int kvh = head / (p.num_heads / p.num_kv_heads);
+  const int s0 = p.cu_seqlens[seq];
+  const int len = p.cu_seqlens[seq + 1] - s0;
+  // heavy (late) tiles first: better tail balance under the causal triangle
+  const int ntiles = (len + FA_BM - 1) / FA_BM;
+  const int tile = ntiles - 1 - (int)blockIdx.x;
+  if (tile < 0) return;
+  const int q0 = tile * FA_BM;
+  const int qrow = q0 + 16 * wave + c;           // this lane's query row (B-operand column)
+  const bool qvalid = qrow < len;
+
+  // ---- Q fragments ---------------------------------------------------------------
+  u32x4 qf[NKS];
+  {
+    const uint16_t* qp = (const uint16_t*)p.q + (size_t)(s0 + min(qrow, len - 1)) * p.q_stride + (size_t)head * HD;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) qf[ks] = *reinterpret_cast<const u32x4*>(qp + 32 * ks + 8 * g);
+  }
+  const float slope = p.alibi ? p.alibi[head] : 0.f;
+
+  f32x4 o[NDT];
+#pragma unroll
+  for (int i = 0; i < NDT; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_run = -1e30f, l_run = 0.f;
+
+  const int kv_end = p.causal ? min(len, q0 + FA_BM) : len;
+  const uint16_t* kbase = (const uint16_t*)p.k + (size_t)s0 * p.k_stride + (size_t)kvh * HD;
+  const uint16_t* vbase = (const uint16_t*)p.v + (size_t)s0 * p.v_stride + (size_t)kvh * HD;
+
+  for (int t0 = 0; t0 < kv_end; t0 += FA_BN) {
+    // ---- stage K (swizzled) and V^T into LDS -------------------------------------
+    __syncthreads();  // previous tile's readers are done
+    for (int i = threadIdx.x; i < FA_BN * NCH; i += 256) {
+      const int tok = i / NCH, ch = i % NCH;
+      const int ta = min(t0 + tok, len - 1);
+      u32x4 kv4 = *reinterpret_cast<const u32x4*>(kbase + (size_t)ta * p.k_stride + 8 * ch);
+      *reinterpret_cast<u32x4*>(&k_lds[tok * HD + 8 * (ch ^ (tok & SWZ))]) = kv4;
+      u16x8 vv = *reinterpret_cast<const u16x8*>(vbase + (size_t)ta * p.v_stride + 8 * ch);
+      if (t0 + tok >= len) vv = u16x8{0, 0, 0, 0, 0, 0, 0, 0};  // 0 * garbage must stay 0
+#pragma unroll
+      for (int j = 0; j < 8; ++j) vt_lds[(8 * ch + j) * FA_VT_STRIDE + tok] = vv[j];
+    }
+    __syncthreads();
+    // a wave whose rows all precede this tile (causal) has nothing to add
+    const bool wave_active = !p.causal || (t0 <= q0 + 16 * wave + 15);
+    if (wave_active) {
+      // ---- S^T = K . Q^T ------------------------------------------------------------
+      f32x4 s[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        s[h] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int tok = 16 * h + c;  // A-operand row of this lane
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+          const int ch = (4 * ks + g) ^ (tok & SWZ);
+          u32x4 kf = *reinterpret_cast<const u32x4*>(&k_lds[tok * HD + 8 * ch]);
+          s[h] = fa_mfma<T>(kf, qf[ks], s[h]);
+        }
+      }
+      // ---- online softmax (lane column = query row) ----------------------------------
+      float pv[2][4];
+      float mx = -1e30f;
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int tok = t0 + 16 * h + 4 * g + r;
+          float x = s[h][r] * p.scale + slope * (float)(tok - qrow);
+          const bool ok = tok < len && (!p.causal || tok <= qrow);
+          x = ok ? x : -1e30f;
+          pv[h][r] = x;
+          mx = __builtin_fmaxf(mx, x);
+        }
+      mx = __builtin_fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = __builtin_fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = __builtin_fmaxf(m_run, mx);
+      const float alpha = __expf(m_run - m_new);
+      m_run = m_new;
+      float lsum = 0.f;
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float e = pv[h][r] > -1e29f ? __expf(pv[h][r] - m_new) : 0.f;
+          pv[h][r] = e;
+          lsum += e;
+        }
+      l_run = l_run * alpha + lsum;
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt) o[dt] *= alpha;
+      u32x4 pf;
+      pf[0] = fa_pack2<T>(pv[0][0], pv[0][1]);
+      pf[1] = fa_pack2<T>(pv[0][2], pv[0][3]);
+      pf[2] = fa_pack2<T>(pv[1][0], pv[1][1]);
+      pf[3] = fa_pack2<T>(pv[1][2], pv[1][3]);
+      // ---- O^T += V^T . P^T ------------------------------------------------------------
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt) {
+        const uint16_t* vr = &vt_lds[(16 * dt + c) * FA_VT_STRIDE + 4 * g];
+        u32x2 lo = *reinterpret_cast<const u32x2*>(vr);
+        u32x2 hi = *reinterpret_cast<const u32x2*>(vr + 16);
+        u32x4 vf = {lo[0], lo[1], hi[0], hi[1]};
+        o[dt] = fa_mfma<T>(vf, pf, o[dt]);
+      }
+    }
+  }
+
+  l_run += __shfl_xor(l_run, 16, 64);
+  l_run += __shfl_xor(l_run, 32, 64);
+  if (qvalid) {
+    const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+    typename T::storage* op = (typename T::storage*)p.out + ((size_t)(s0 + qrow) * p.num_heads + head) * HD;
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) {
+      u16x4 r = {T::from_f32(o[dt][0] * inv), T::from_f32(o[dt][1] * inv), T::from_f32(o[dt][2] * inv),
+                 T::from_f32(o[dt][3] * inv)};
+      *reinterpret_cast<u16x4*>(op + 16 * dt + 4 * g) = r;
+    }
+  }
+}
+
+}  // namespace aphro
+
+using namespace aphro;
+
+extern "C" int aphro_flash_attn_varlen(void* out, const void* q, const void* k, const void* v,
+                                       const int32_t* cu_seqlens, int batch, int max_seqlen, int num_heads,
+                                       int num_kv_heads, int head_size, int64_t q_stride, int64_t k_stride,
+                                       int64_t v_stride, float scale, int causal, const float* alibi_slopes,
+                                       int dtype, void* stream) {
+  APHRO_CHECK(dtype == APHRO_F16 || dtype == APHRO_BF16, "flash_attn_varlen: dtype must be f16 or bf16");
+  APHRO_CHECK(num_kv_heads > 0 && num_heads % num_kv_heads == 0, "flash_attn_varlen: bad head counts");
+  APHRO_CHECK(q_stride % 8 == 0 && k_stride % 8 == 0 && v_stride % 8 == 0, "flash_attn_varlen: strides must be multiples of 8");
+  APHRO_CHECK(((uintptr_t)q % 16) == 0 && ((uintptr_t)k % 16) == 0 && ((uintptr_t)v % 16) == 0, "flash_attn_varlen: 16-byte alignment");
+  if (batch == 0 || max_seqlen == 0) return APHRO_OK;
+  FAParams p;
+  p.out = out; p.q = q; p.k = k; p.v = v; p.cu_seqlens = cu_seqlens; p.alibi = alibi_slopes;
+  p.num_heads = num_heads; p.num_kv_heads = num_kv_heads;
+  p.q_stride = q_stride; p.k_stride = k_stride; p.v_stride = v_stride;
+  p.scale = scale; p.causal = causal;
+  dim3 grid((unsigned)((max_seqlen + FA_BM - 1) / FA_BM), (unsigned)num_heads, (unsigned)batch);
+#define FA_L(TT, HDV) hipLaunchKernelGGL((flash_attn_varlen_kernel<TT, HDV>), grid, dim3(256), 0, (hipStream_t)stream, p)
+#define FA_T(HDV) if (dtype == APHRO_F16) FA_L(Half, HDV); else FA_L(BFloat, HDV);
+  switch (head_size) {
+    case 64: FA_T(64) break;
+    case 96: FA_T(96) break;
+    case 128: FA_T(128) break;
+    case 256: FA_T(256) break;
+    default:
+      set_error("flash_attn_varlen: unsupported head_size=%d", head_size);
+      return APHRO_ERR_INVALID;
+  }
+#undef FA_T
+#undef FA_L
+  APHRO_LAUNCH_CHECK();
+  return APHRO_OK;
+}

@@ -116,14 +116,21 @@ def gemm_bytes(lin, M_rows):
 
 
 def measure_kernel(fn, launches_per_call, iters=5):
-    """Average duration of one launch, HIP events on the launching stream."""
-    stream = torch.cuda.current_stream()
+    """Average duration of one launch: the launches are captured into a HIP graph
+    (no host launch overhead between them, exactly like the timed decode step)
+    and the replays are bracketed by HIP events on the replaying stream."""
     fn()
     torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        fn()
+    g.replay()
+    torch.cuda.synchronize()
+    stream = torch.cuda.current_stream()
     start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     start.record(stream)
     for _ in range(iters):
-        fn()
+        g.replay()
     end.record(stream)
     end.synchronize()
     return start.elapsed_time(end) * 1e-3 / (iters * launches_per_call)
@@ -135,18 +142,19 @@ def roofline_section(model, loop, args):
     from aphrodite_engine_amd import _custom_ops as ops
     bs = args.batch
     layers = list(model.layers)
-    x = torch.randn(bs, model.cfg.hidden_size, device="cuda", dtype=model.dtype)
     out = {}
 
-    def run_gate_up():
-        for layer in layers:
-            layer.gate_up_proj(x)
-    t = measure_kernel(run_gate_up, len(layers))
-    b = gemm_bytes(layers[0].gate_up_proj, bs)
-    out["gate_up_gemm"] = dict(kernel="wna16_gemm_kernel" if args.quant != "fp8" else "fp8_gemm_kernel",
-                               shape=[bs, layers[0].gate_up_proj.in_features,
-                                      layers[0].gate_up_proj.out_features],
-                               bytes=b, seconds=t)
+    for name in ("gate_up_proj", "down_proj", "qkv_proj", "o_proj"):
+        lin0 = getattr(layers[0], name)
+        xin = torch.randn(bs, lin0.in_features, device="cuda", dtype=model.dtype)
+
+        def run_lin(name=name, xin=xin):
+            for layer in layers:
+                getattr(layer, name)(xin)
+        t = measure_kernel(run_lin, len(layers))
+        out[name] = dict(kernel=("wna16_gemm_kernel" if args.quant != "fp8" else "fp8_gemm_kernel")
+                         + " (+splitk_reduce)", shape=[bs, lin0.in_features, lin0.out_features],
+                         bytes=gemm_bytes(lin0, bs), seconds=t)
     # decode attention over the real caches / metadata of the loop
     l0 = layers[0]
     q = torch.randn(bs, l0.q_size + 2 * l0.kv_size, device="cuda", dtype=model.dtype)[:, :l0.q_size]

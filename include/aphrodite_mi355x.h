@@ -227,6 +227,20 @@ int aphro_rotary_embedding(const int64_t* positions, void* query, void* key,
                            int64_t query_stride, int64_t key_stride, int is_neox,
                            int dtype, void* stream);
 
+/* ------------------------------------------------------------------------
+ * Prefill attention (row a5): causal varlen flash attention on MFMA.
+ *   replaces attention/ops/triton_flash_attn.py:700-820 / CK
+ *   flash_attn_varlen_func as called at backends/rocm_flash_attn.py:455-508.
+ * q [T,Hq,hd], k/v [T,Hkv,hd] with token strides (elements), out [T,Hq,hd]
+ * contiguous; cu_seqlens int32 [B+1] (same for q and k: self-attention);
+ * alibi_slopes fp32 [Hq] or NULL (bias = slope * (key_pos - query_pos)). */
+int aphro_flash_attn_varlen(void* out, const void* q, const void* k, const void* v,
+                            const int32_t* cu_seqlens, int batch, int max_seqlen,
+                            int num_heads, int num_kv_heads, int head_size,
+                            int64_t q_stride, int64_t k_stride, int64_t v_stride,
+                            float scale, int causal, const float* alibi_slopes,
+                            int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -399,6 +399,87 @@ def test_paged_attention_garbage_beyond_seq_len(ops):
     np.testing.assert_allclose(out.float().cpu().numpy(), ref, atol=1e-3, rtol=1e-2)
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("Hq,Hkv,D", [(8, 2, 128), (4, 4, 64), (6, 2, 96)])
+@pytest.mark.parametrize("causal", [True, False])
+def test_flash_attn_varlen(ops, dtype, Hq, Hkv, D, causal):
+    """Prefill: vs the fp64 oracle; the reference's bar for this op is the
+    prefix-prefill test's atol 1e-3 (fp16) on O(1) outputs -- we use 2e-3/1.6e-2
+    (fp16/bf16 output rounding)."""
+    rng = np.random.default_rng(Hq * 7 + D)
+    lens = [1, 63, 64, 65, 200, 33]
+    cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    T = int(cu[-1])
+    qkv = t(rng.standard_normal((T, (Hq + 2 * Hkv) * D)).astype(np.float32), dtype)
+    q, k, v = qkv.split([Hq * D, Hkv * D, Hkv * D], dim=-1)
+    q, k, v = q.view(T, Hq, D), k.view(T, Hkv, D), v.view(T, Hkv, D)
+    scale = float(D ** -0.5)
+    got = ops.flash_attn_varlen(q, k, v, t(cu), max(lens), scale, causal=causal)
+    ref = oa.varlen_causal_attention(q, k, v, cu, scale, causal=causal)
+    tol = 2e-3 if dtype == torch.float16 else 1.6e-2
+    np.testing.assert_allclose(got.float().cpu().numpy(), ref, atol=tol, rtol=tol)
+
+
+def test_attention_backend_prefill_then_decode(ops):
+    """AttentionImpl.forward on a mixed (chunked-prefill style) batch: prefill
+    tokens attend causally within their sequence and are written to the paged
+    cache; decode tokens read the cache (rocm_flash_attn.py:373-595)."""
+    from aphrodite_engine_amd.attention import MI355XAttentionImpl, MI355XAttentionMetadata
+    rng = np.random.default_rng(21)
+    Hq, Hkv, D, BS = 8, 2, 128, 16
+    plens = [40, 17]
+    dlens = [23, 70]          # decode sequences (length incl. the new token)
+    NB = 20
+    kv_cache = torch.zeros(2, NB, BS * Hkv * D, dtype=torch.float16, device=DEV)
+    impl = MI355XAttentionImpl(Hq, D, D ** -0.5, Hkv)
+    # block tables: seq i uses a disjoint set of 5 blocks
+    bt = np.random.default_rng(3).permutation(NB).reshape(4, 5).astype(np.int32)
+    # pre-fill the decode sequences' history through the cache-write op
+    hist_k, hist_v = [], []
+    for si, L in zip((2, 3), dlens):
+        kk = rng.standard_normal((L - 1, Hkv, D)).astype(np.float16)
+        vv = rng.standard_normal((L - 1, Hkv, D)).astype(np.float16)
+        slots = np.array([bt[si, p // BS] * BS + p % BS for p in range(L - 1)], np.int64)
+        kc, vc = ops_split(kv_cache, Hkv, D)
+        ops.reshape_and_cache(t(kk), t(vv), kc, vc, t(slots), "auto", 1.0, 1.0)
+        hist_k.append(kk); hist_v.append(vv)
+    T = sum(plens) + len(dlens)
+    q = rng.standard_normal((T, Hq * D)).astype(np.float16)
+    k = rng.standard_normal((T, Hkv * D)).astype(np.float16)
+    v = rng.standard_normal((T, Hkv * D)).astype(np.float16)
+    slots = []
+    for si, L in enumerate(plens):
+        slots += [bt[si, p // BS] * BS + p % BS for p in range(L)]
+    for si, L in zip((2, 3), dlens):
+        slots.append(bt[si, (L - 1) // BS] * BS + (L - 1) % BS)
+    cu = np.concatenate([[0], np.cumsum(plens)]).astype(np.int32)
+    meta = MI355XAttentionMetadata(
+        num_prefills=2, num_prefill_tokens=sum(plens), num_decode_tokens=2,
+        slot_mapping=t(np.array(slots, np.int64)), seq_lens=plens + dlens,
+        seq_lens_tensor=t(np.array(plens + dlens, np.int32)), max_query_len=max(plens),
+        max_prefill_seq_len=max(plens), max_decode_seq_len=max(dlens),
+        query_start_loc=t(cu), seq_start_loc=t(cu), context_lens_tensor=t(np.zeros(2, np.int32)),
+        block_tables=t(bt))
+    out = impl.forward(t(q), t(k), t(v), kv_cache, meta).float().cpu().numpy()
+    npf = sum(plens)
+    ref_p = oa.varlen_causal_attention(q[:npf].reshape(npf, Hq, D), k[:npf].reshape(npf, Hkv, D),
+                                       v[:npf].reshape(npf, Hkv, D), cu, D ** -0.5)
+    np.testing.assert_allclose(out[:npf].reshape(npf, Hq, D), ref_p, atol=2e-3, rtol=2e-3)
+    for j, (L, hk, hv) in enumerate(zip(dlens, hist_k, hist_v)):
+        kk = np.concatenate([hk, k[npf + j].reshape(1, Hkv, D)], 0).astype(np.float64)
+        vv = np.concatenate([hv, v[npf + j].reshape(1, Hkv, D)], 0).astype(np.float64)
+        kk, vv = np.repeat(kk, Hq // Hkv, 1), np.repeat(vv, Hq // Hkv, 1)
+        lg = D ** -0.5 * np.einsum("hd,lhd->hl", q[npf + j].reshape(Hq, D).astype(np.float64), kk)
+        p_ = np.exp(lg - lg.max(1, keepdims=True)); p_ /= p_.sum(1, keepdims=True)
+        ref_d = np.einsum("hl,lhd->hd", p_, vv)
+        np.testing.assert_allclose(out[npf + j].reshape(Hq, D), ref_d, atol=2e-3, rtol=2e-3)
+
+
+def ops_split(kv_cache, Hkv, D):
+    from aphrodite_engine_amd.attention import PagedAttention
+    return PagedAttention.split_kv_cache(kv_cache, Hkv, D)
+
+
 def test_ops_reject_bad_arguments(ops):
     q = torch.zeros(1, 4, 72, dtype=torch.float16, device=DEV)   # head size 72 unsupported
     kc = torch.zeros(2, 1, 9, 16, 8, dtype=torch.float16, device=DEV)
