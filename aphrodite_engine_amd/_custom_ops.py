@@ -377,6 +377,133 @@ def awq_repack_zeros(qzeros: torch.Tensor, size_n: int) -> torch.Tensor:
     return out
 
 
+# -- decode fast path: fragment-major activations + fused glue --------------------
+def wna16_ksplit(m: int, n: int, k: int, groups: int) -> int:
+    """fp32 split-K slabs the fast kernel produces for this shape (0: not served)."""
+    return _lib.lib().aphro_wna16_ksplit(m, n, k, groups)
+
+
+def wna16_pack_a(a: torch.Tensor, perm: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """[M,K] f16/bf16 -> fragment-major f16 buffer (see include/aphrodite_mi355x.h)."""
+    _require_cuda(a)
+    m, k = a.shape
+    lib = _lib.lib()
+    out = torch.empty(lib.aphro_wna16_packed_a_bytes(m, k) // 2, dtype=torch.float16, device=a.device)
+    if a.stride(1) != 1:
+        a = a.contiguous()
+    check(lib.aphro_wna16_pack_a(a.data_ptr(), _ptr(perm), out.data_ptr(), m, k, a.stride(0),
+                                 _dt(a), _stream()), "wna16_pack_a")
+    return out
+
+
+def wna16_gemm_packed(a_packed: torch.Tensor, m: int, k: int, qweight: torch.Tensor,
+                      qzeros: torch.Tensor, scales: torch.Tensor, zero_offset: int,
+                      partials: bool = False):
+    """GEMM on packed activations.  partials=False -> [M,N] tensor in scales.dtype;
+    partials=True -> (fp32 slabs [S,M,N], S) left for a fused consumer."""
+    lib = _lib.lib()
+    n = qweight.shape[1]
+    groups = scales.shape[0]
+    ks = lib.aphro_wna16_ksplit(m, n, k, groups)
+    if ks <= 0:
+        raise RuntimeError(f"wna16_gemm_packed: shape M={m} N={n} K={k} not served by the fast kernel")
+    dt = _dt(scales)
+    if partials:
+        slabs = torch.empty((ks, m, n), dtype=torch.float32, device=qweight.device)
+        check(lib.aphro_wna16_gemm_packed(a_packed.data_ptr(), qweight.data_ptr(), qzeros.data_ptr(),
+                                          scales.data_ptr(), None, slabs.data_ptr(), slabs.numel() * 4,
+                                          m, n, k, groups, zero_offset, dt, _stream()), "wna16_gemm_packed")
+        return slabs, ks
+    out = torch.empty((m, n), dtype=scales.dtype, device=qweight.device)
+    slabs = torch.empty((ks, m, n), dtype=torch.float32, device=qweight.device) if ks > 1 else None
+    check(lib.aphro_wna16_gemm_packed(a_packed.data_ptr(), qweight.data_ptr(), qzeros.data_ptr(),
+                                      scales.data_ptr(), out.data_ptr(), _ptr(slabs),
+                                      slabs.numel() * 4 if slabs is not None else 0, m, n, k, groups,
+                                      zero_offset, dt, _stream()), "wna16_gemm_packed")
+    return out
+
+
+def fused_add_rms_norm_pack(x: Optional[torch.Tensor], slabs: Optional[torch.Tensor],
+                            residual: Optional[torch.Tensor], has_residual: bool,
+                            weight: torch.Tensor, epsilon: float, pack: bool = True,
+                            want_out: bool = False):
+    """[slab reduce] + fused_add_rms_norm + [pack]; returns (packed or None, out or None)."""
+    lib = _lib.lib()
+    if slabs is not None:
+        nslab, tokens, hidden = slabs.shape
+        dev = slabs.device
+    else:
+        tokens, hidden = x.shape
+        nslab, dev = 0, x.device
+        assert x.is_contiguous()
+    packed = torch.empty(lib.aphro_wna16_packed_a_bytes(tokens, hidden) // 2, dtype=torch.float16,
+                         device=dev) if pack else None
+    out = torch.empty((tokens, hidden), dtype=weight.dtype, device=dev) if want_out else None
+    check(lib.aphro_fused_add_rms_norm_pack(_ptr(x), _ptr(slabs), nslab, _ptr(residual),
+                                            1 if has_residual else 0, weight.data_ptr(), float(epsilon),
+                                            _ptr(packed), _ptr(out), tokens, hidden, _dt(weight), _stream()),
+          "fused_add_rms_norm_pack")
+    return packed, out
+
+
+def silu_and_mul_pack(x: torch.Tensor) -> torch.Tensor:
+    lib = _lib.lib()
+    tokens, d2 = x.shape
+    d = d2 // 2
+    assert x.is_contiguous()
+    packed = torch.empty(lib.aphro_wna16_packed_a_bytes(tokens, d) // 2, dtype=torch.float16, device=x.device)
+    check(lib.aphro_silu_and_mul_pack(x.data_ptr(), packed.data_ptr(), None, tokens, d, _dt(x), _stream()),
+          "silu_and_mul_pack")
+    return packed
+
+
+def rope_cache(qkv: Optional[torch.Tensor], slabs: Optional[torch.Tensor], positions: torch.Tensor,
+               cos_sin_cache: torch.Tensor, is_neox: bool, key_cache: torch.Tensor,
+               value_cache: torch.Tensor, slot_mapping: torch.Tensor, num_heads: int,
+               num_kv_heads: int, head_size: int, kv_cache_dtype: str, k_scale: float,
+               v_scale: float) -> torch.Tensor:
+    """[slab reduce] + rotary_embedding(q, k) + reshape_and_cache(k, v); returns q [T, Hq*hd]."""
+    lib = _lib.lib()
+    if slabs is not None:
+        nslab, tokens, _ = slabs.shape
+        dev, stride = slabs.device, 0
+    else:
+        tokens = qkv.shape[0]
+        nslab, dev, stride = 0, qkv.device, qkv.stride(0)
+    dtype = cos_sin_cache.dtype
+    q_out = torch.empty((tokens, num_heads * head_size), dtype=dtype, device=dev)
+    if positions.dtype != torch.int64:
+        positions = positions.long()
+    check(lib.aphro_rope_cache(_ptr(qkv), stride, _ptr(slabs), nslab, positions.data_ptr(),
+                               cos_sin_cache.data_ptr(), cos_sin_cache.shape[1], 1 if is_neox else 0,
+                               q_out.data_ptr(), key_cache.data_ptr(), value_cache.data_ptr(),
+                               slot_mapping.data_ptr(), tokens, num_heads, num_kv_heads, head_size,
+                               key_cache.shape[3], key_cache.shape[4], _dt(cos_sin_cache),
+                               _kv(kv_cache_dtype), float(k_scale), float(v_scale), _stream()), "rope_cache")
+    return q_out
+
+
+def paged_attention_packed(query: torch.Tensor, key_cache: torch.Tensor, value_cache: torch.Tensor,
+                           num_kv_heads: int, scale: float, block_tables: torch.Tensor,
+                           seq_lens: torch.Tensor, block_size: int, max_seq_len: int,
+                           alibi_slopes: Optional[torch.Tensor], kv_cache_dtype: str, k_scale: float,
+                           v_scale: float, want_out: bool = False):
+    """Single-launch decode attention writing its output fragment-major for o_proj."""
+    lib = _lib.lib()
+    num_seqs, num_heads, head_size = query.shape
+    packed = torch.empty(lib.aphro_wna16_packed_a_bytes(num_seqs, num_heads * head_size) // 2,
+                         dtype=torch.float16, device=query.device)
+    out = torch.empty((num_seqs, num_heads, head_size), dtype=query.dtype, device=query.device) \
+        if want_out else None
+    check(lib.aphro_paged_attention_packed(
+        _ptr(out), packed.data_ptr(), query.data_ptr(), key_cache.data_ptr(), value_cache.data_ptr(),
+        num_seqs, num_heads, num_kv_heads, head_size, float(scale), block_tables.data_ptr(),
+        seq_lens.data_ptr(), block_tables.stride(0), block_size, int(max_seq_len), _ptr(alibi_slopes),
+        query.stride(0), key_cache.stride(0), key_cache.stride(1), _dt(query), _kv(kv_cache_dtype),
+        float(k_scale), float(v_scale), _stream()), "paged_attention_packed")
+    return packed, out
+
+
 def wna16_gemm(a, qweight_kpacked, qzeros, scales, perm=None, zero_offset=0):
     """The gptq_marlin_gemm role: fast W4A16 kernel on prepacked weights."""
     _require_cuda(a, qweight_kpacked, qzeros, scales)

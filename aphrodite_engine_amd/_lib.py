@@ -23,6 +23,15 @@ SIGNATURES = {
     "aphro_gptq_repack": (I, [P, P, P, L, L, I, P]),
     "aphro_gptq_gemm": (I, [P, P, P, P, P, P, P, P, Z, L, L, L, L, L, I, I, P]),
     "aphro_wna16_workspace_bytes": (Z, [L, L, L]),
+    "aphro_wna16_packed_a_bytes": (Z, [L, L]),
+    "aphro_wna16_pack_a": (I, [P, P, P, L, L, L, I, P]),
+    "aphro_wna16_ksplit": (I, [L, L, L, L]),
+    "aphro_wna16_gemm_packed": (I, [P, P, P, P, P, P, Z, L, L, L, L, I, I, P]),
+    "aphro_paged_attention_packed": (I, [P, P, P, P, P, I, I, I, I, F, P, P, I, I, I, P,
+                                         L, L, L, I, I, F, F, P]),
+    "aphro_fused_add_rms_norm_pack": (I, [P, P, I, P, I, P, F, P, P, L, I, I, P]),
+    "aphro_silu_and_mul_pack": (I, [P, P, P, L, I, I, P]),
+    "aphro_rope_cache": (I, [P, L, P, I, P, P, I, I, P, P, P, P, L, I, I, I, I, I, I, I, F, F, P]),
     "aphro_gptq_dequant": (I, [P, P, P, P, P, L, L, L, I, I, I, P]),
     "aphro_awq_dequantize": (I, [P, P, P, P, L, L, L, I, P]),
     "aphro_awq_gemm_workspace_bytes": (Z, [L, L, L, L]),

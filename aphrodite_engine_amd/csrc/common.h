@@ -120,6 +120,16 @@ __device__ __forceinline__ uint32_t f32x2_hi16(float lo, float hi) {
   return __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, hi), __builtin_bit_cast(uint32_t, lo), 0x07060302u);
 }
 
+// One rotary pair in fp32 with a FIXED operation order (no fp contraction), shared by
+// rotary_kernel and rope_cache_kernel so the fused and unfused paths agree bit
+// for bit (left to the compiler, fp contraction differs between kernels).
+__device__ __forceinline__ void rope_pair(float x, float y, float c, float s, float& xo, float& yo) {
+#pragma clang fp contract(off)
+  const float xc = x * c, ys = y * s, yc = y * c, xs = x * s;
+  xo = xc - ys;
+  yo = yc + xs;
+}
+
 // ---- wave reductions ------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -1,0 +1,286 @@
+// Fused glue kernels of the decode fast path ("fusing them into
+// GEMM prologues/epilogues ... they are ~all remaining HBM traffic per layer").
+// On MI355X the small ops between the GEMMs are latency bound (~4.5 us each at
+// batch 32: two dependent memory round trips), and the unfused layer spends as
+// long in them as in the GEMMs.  These kernels merge
+//   [split-K slab reduce] + fused_add_rms_norm + [activation pack]      (K1/K6)
+//   [split-K slab reduce] + rotary_embedding + reshape_and_cache        (K3)
+//   silu_and_mul + [activation pack]                                    (K8)
+// while reproducing the unfused op sequence bit for bit (every intermediate is
+// rounded to the activation dtype exactly where the separate ops would).
+// Reference semantics: kernels/layernorm_kernels.cu:200-240,
+// kernels/pos_encoding_kernels.cu:10-160, kernels/cache_kernels.cu:152-204,
+// kernels/activation_kernels.cu:12-75.
+#include "common.h"
+
+namespace aphro {
+
+__device__ __forceinline__ float block_sum_f(float v, float* red) {
+  v = wave_sum(v);
+  const int nw = blockDim.x >> 6;
+  if (nw == 1) return v;
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int w = 0; w < nw; ++w) t += red[w];
+  __syncthreads();
+  return t;
+}
+
+// fragment-major offset (in halfs) of the 8-element chunk holding A[row][k..k+7], k % 8 == 0
+__device__ __forceinline__ size_t packed_chunk(int row, int k, int mtiles) {
+  const int seg = k >> 7, g = (k & 127) >> 5, u = (k & 31) >> 3;
+  const int mt = row >> 4;
+  return ((((size_t)seg * 4 + u) * mtiles + mt) * 64 + g * 16 + (row & 15)) * 8;
+}
+
+template <typename T>
+__device__ __forceinline__ uint16_t to_f16_bits(uint16_t tbits) {
+  if constexpr (__is_same(T, Half)) return tbits;
+  else return f32_to_f16_bits(bf16_bits_to_f32(tbits));
+}
+
+// x = input (T) or sum of `nslab` fp32 slabs (rounded to T like the GEMM's own
+// reduce would); residual' = round(x + residual) (or x when residual_in is null);
+// y = round(round(residual' * rstd) * w).  y goes to the packed buffer (f16) and/or
+// row-major `out`.
+template <typename T>
+__global__ void add_rms_norm_pack_kernel(const uint16_t* __restrict__ input, const float* __restrict__ slabs,
+                                         int nslab, uint16_t* __restrict__ residual, int has_residual,
+                                         const uint16_t* __restrict__ weight, float eps,
+                                         uint16_t* __restrict__ packed, uint16_t* __restrict__ out, int tokens,
+                                         int hidden) {
+  __shared__ float red[16];
+  const int tok = blockIdx.x;
+  const int nv = hidden >> 3;
+  const int mtiles = (tokens + 15) >> 4;
+  const size_t slab_stride = (size_t)tokens * hidden;
+  float v[2][8];
+  float ss = 0.f;
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int i = threadIdx.x + it * blockDim.x;
+    if (i < nv) {
+      const size_t off = (size_t)tok * hidden + 8 * i;
+      float x[8];
+      if (slabs) {
+        f32x4 a = *reinterpret_cast<const f32x4*>(slabs + off);
+        f32x4 b = *reinterpret_cast<const f32x4*>(slabs + off + 4);
+        for (int s = 1; s < nslab; ++s) {
+          a += *reinterpret_cast<const f32x4*>(slabs + s * slab_stride + off);
+          b += *reinterpret_cast<const f32x4*>(slabs + s * slab_stride + off + 4);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          x[j] = T::to_f32(T::from_f32(a[j]));
+          x[4 + j] = T::to_f32(T::from_f32(b[j]));
+        }
+      } else {
+        u16x8 a = *reinterpret_cast<const u16x8*>(input + off);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = T::to_f32(a[j]);
+      }
+      u16x8 rs;
+      if (has_residual) {
+        u16x8 r = *reinterpret_cast<const u16x8*>(residual + off);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          rs[j] = T::from_f32(x[j] + T::to_f32(r[j]));
+          v[it][j] = T::to_f32(rs[j]);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          rs[j] = T::from_f32(x[j]);
+          v[it][j] = x[j];
+        }
+      }
+      if (residual) *reinterpret_cast<u16x8*>(residual + off) = rs;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ss += v[it][j] * v[it][j];
+    }
+  }
+  ss = block_sum_f(ss, red);
+  const float inv = __frsqrt_rn(ss / (float)hidden + eps);
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int i = threadIdx.x + it * blockDim.x;
+    if (i < nv) {
+      u16x8 w = *reinterpret_cast<const u16x8*>(weight + 8 * i);
+      u16x8 y, yh;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        y[j] = T::from_f32(T::to_f32(T::from_f32(v[it][j] * inv)) * T::to_f32(w[j]));
+        yh[j] = to_f16_bits<T>(y[j]);
+      }
+      if (out) *reinterpret_cast<u16x8*>(out + (size_t)tok * hidden + 8 * i) = y;
+      if (packed) *reinterpret_cast<u16x8*>(packed + packed_chunk(tok, 8 * i, mtiles)) = yh;
+    }
+  }
+}
+
+// act = round(round(silu(gate)) * up) -> packed f16 (and/or row-major)
+template <typename T>
+__global__ void silu_mul_pack_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ packed,
+                                     uint16_t* __restrict__ out, int tokens, int d) {
+  const int tok = blockIdx.x;
+  const int mtiles = (tokens + 15) >> 4;
+  const uint16_t* a = in + (size_t)tok * 2 * d;
+  const uint16_t* b = a + d;
+  for (int i = threadIdx.x; i < (d >> 3); i += blockDim.x) {
+    u16x8 x = *reinterpret_cast<const u16x8*>(a + 8 * i);
+    u16x8 y = *reinterpret_cast<const u16x8*>(b + 8 * i);
+    u16x8 r, rh;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float xf = T::to_f32(x[j]);
+      float s = T::to_f32(T::from_f32(xf / (1.0f + __expf(-xf))));
+      r[j] = T::from_f32(s * T::to_f32(y[j]));
+      rh[j] = to_f16_bits<T>(r[j]);
+    }
+    if (out) *reinterpret_cast<u16x8*>(out + (size_t)tok * d + 8 * i) = r;
+    if (packed) *reinterpret_cast<u16x8*>(packed + packed_chunk(tok, 8 * i, mtiles)) = rh;
+  }
+}
+
+// qkv row (T, or fp32 slabs) -> RoPE(q) to q_out, RoPE(k) and v into the paged cache.
+template <typename T, int KV, bool NEOX>
+__global__ void rope_cache_kernel(const uint16_t* __restrict__ qkv, int64_t qkv_stride,
+                                  const float* __restrict__ slabs, int nslab, int tokens,
+                                  const int64_t* __restrict__ positions, const uint16_t* __restrict__ cos_sin,
+                                  int rot_dim, uint16_t* __restrict__ q_out, void* __restrict__ key_cache,
+                                  void* __restrict__ value_cache, const int64_t* __restrict__ slot_mapping,
+                                  int num_heads, int num_kv_heads, int head_size, int block_size, int x,
+                                  float k_scale, float v_scale) {
+  const int tok = blockIdx.x;
+  const int nq = num_heads * head_size, nkv = num_kv_heads * head_size;
+  const int ntot = nq + 2 * nkv;
+  const size_t slab_stride = (size_t)tokens * ntot;
+  auto val = [&](int j) -> float {  // element j of the token's qkv row, rounded to T
+    if (slabs) {
+      float s = slabs[(size_t)tok * ntot + j];
+      for (int k = 1; k < nslab; ++k) s += slabs[k * slab_stride + (size_t)tok * ntot + j];
+      return T::to_f32(T::from_f32(s));
+    }
+    return T::to_f32(qkv[(size_t)tok * qkv_stride + j]);
+  };
+  const int64_t pos = positions[tok];
+  const uint16_t* cs = cos_sin + pos * rot_dim;
+  const int embed = rot_dim >> 1;
+  const int64_t slot = slot_mapping[tok];
+  const int64_t blk = slot >= 0 ? slot / block_size : 0, off = slot >= 0 ? slot % block_size : 0;
+  auto kstore = [&](int h, int d, float f) {
+    if (slot < 0) return;
+    const int64_t dst = (((blk * num_kv_heads + h) * (head_size / x) + d / x) * block_size + off) * x + d % x;
+    if constexpr (KV == 0) ((uint16_t*)key_cache)[dst] = T::from_f32(f);
+    else ((uint8_t*)key_cache)[dst] = (uint8_t)f32x2_to_fp8<KV == 2>(T::to_f32(T::from_f32(f)) / k_scale, 0.f);
+  };
+  // rotary pairs of q and k heads
+  const int npairs = (num_heads + num_kv_heads) * embed;
+  for (int i = threadIdx.x; i < npairs; i += blockDim.x) {
+    const int h = i / embed, r = i % embed;
+    const bool is_k = h >= num_heads;
+    const int base = is_k ? nq + (h - num_heads) * head_size : h * head_size;
+    const int xi = NEOX ? r : 2 * r, yi = NEOX ? embed + r : 2 * r + 1;
+    const float c = T::to_f32(cs[r]), s = T::to_f32(cs[embed + r]);
+    const float xv = val(base + xi), yv = val(base + yi);
+    float xo, yo;
+    rope_pair(xv, yv, c, s, xo, yo);
+    if (!is_k) {
+      q_out[(size_t)tok * nq + base + xi] = T::from_f32(xo);
+      q_out[(size_t)tok * nq + base + yi] = T::from_f32(yo);
+    } else {
+      kstore(h - num_heads, xi, xo);
+      kstore(h - num_heads, yi, yo);
+    }
+  }
+  // pass-through dims beyond rot_dim
+  if (rot_dim < head_size) {
+    const int rest = head_size - rot_dim;
+    for (int i = threadIdx.x; i < (num_heads + num_kv_heads) * rest; i += blockDim.x) {
+      const int h = i / rest, d = rot_dim + i % rest;
+      if (h < num_heads) q_out[(size_t)tok * nq + h * head_size + d] = T::from_f32(val(h * head_size + d));
+      else kstore(h - num_heads, d, val(nq + (h - num_heads) * head_size + d));
+    }
+  }
+  // v
+  if (slot >= 0) {
+    for (int i = threadIdx.x; i < nkv; i += blockDim.x) {
+      const int h = i / head_size, d = i % head_size;
+      const float f = val(nq + nkv + i);
+      const int64_t dst = ((blk * num_kv_heads + h) * head_size + d) * block_size + off;
+      if constexpr (KV == 0) ((uint16_t*)value_cache)[dst] = T::from_f32(f);
+      else ((uint8_t*)value_cache)[dst] = (uint8_t)f32x2_to_fp8<KV == 2>(f / v_scale, 0.f);
+    }
+  }
+}
+
+}  // namespace aphro
+
+using namespace aphro;
+
+extern "C" int aphro_fused_add_rms_norm_pack(const void* input, const float* slabs, int nslab, void* residual,
+                                             int has_residual, const void* weight, float eps, void* packed,
+                                             void* out, int64_t tokens, int hidden, int dtype, void* stream) {
+  APHRO_CHECK(dtype == APHRO_F16 || dtype == APHRO_BF16, "fused_add_rms_norm_pack: dtype must be f16 or bf16");
+  APHRO_CHECK((input != nullptr) != (slabs != nullptr), "fused_add_rms_norm_pack: exactly one of input / slabs");
+  APHRO_CHECK(hidden % 8 == 0 && hidden <= 16384, "fused_add_rms_norm_pack: hidden=%d unsupported", hidden);
+  APHRO_CHECK(packed == nullptr || hidden % 128 == 0, "fused_add_rms_norm_pack: packing needs hidden %% 128 == 0");
+  APHRO_CHECK(!has_residual || residual != nullptr, "fused_add_rms_norm_pack: residual missing");
+  if (tokens == 0) return APHRO_OK;
+  int nv = hidden / 8, t = (nv + 1) / 2;
+  t = (t + 63) / 64 * 64;
+  t = t < 64 ? 64 : (t > 1024 ? 1024 : t);
+  dim3 grid((unsigned)tokens), block(t);
+#define L(TT)                                                                                                   \
+  hipLaunchKernelGGL((add_rms_norm_pack_kernel<TT>), grid, block, 0, (hipStream_t)stream, (const uint16_t*)input, \
+                     slabs, nslab, (uint16_t*)residual, has_residual, (const uint16_t*)weight, eps,             \
+                     (uint16_t*)packed, (uint16_t*)out, (int)tokens, hidden)
+  if (dtype == APHRO_F16) L(Half); else L(BFloat);
+#undef L
+  APHRO_LAUNCH_CHECK();
+  return APHRO_OK;
+}
+
+extern "C" int aphro_silu_and_mul_pack(const void* input, void* packed, void* out, int64_t tokens, int d,
+                                       int dtype, void* stream) {
+  APHRO_CHECK(dtype == APHRO_F16 || dtype == APHRO_BF16, "silu_and_mul_pack: dtype must be f16 or bf16");
+  APHRO_CHECK(d % 8 == 0 && (packed == nullptr || d % 128 == 0), "silu_and_mul_pack: d=%d unsupported", d);
+  if (tokens == 0) return APHRO_OK;
+  int threads = d / 8 >= 1024 ? 1024 : ((d / 8 + 63) / 64 * 64);
+  dim3 grid((unsigned)tokens), block(threads);
+  if (dtype == APHRO_F16)
+    hipLaunchKernelGGL((silu_mul_pack_kernel<Half>), grid, block, 0, (hipStream_t)stream, (const uint16_t*)input,
+                       (uint16_t*)packed, (uint16_t*)out, (int)tokens, d);
+  else
+    hipLaunchKernelGGL((silu_mul_pack_kernel<BFloat>), grid, block, 0, (hipStream_t)stream, (const uint16_t*)input,
+                       (uint16_t*)packed, (uint16_t*)out, (int)tokens, d);
+  APHRO_LAUNCH_CHECK();
+  return APHRO_OK;
+}
+
+extern "C" int aphro_rope_cache(const void* qkv, int64_t qkv_stride, const float* slabs, int nslab,
+                                const int64_t* positions, const void* cos_sin_cache, int rot_dim, int is_neox,
+                                void* q_out, void* key_cache, void* value_cache, const int64_t* slot_mapping,
+                                int64_t tokens, int num_heads, int num_kv_heads, int head_size, int block_size,
+                                int x, int dtype, int kv_dtype, float k_scale, float v_scale, void* stream) {
+  APHRO_CHECK(dtype == APHRO_F16 || dtype == APHRO_BF16, "rope_cache: dtype must be f16 or bf16");
+  APHRO_CHECK(kv_dtype >= APHRO_KV_AUTO && kv_dtype <= APHRO_KV_FP8_E5M2, "Unsupported data type of kv cache: %d", kv_dtype);
+  APHRO_CHECK((qkv != nullptr) != (slabs != nullptr), "rope_cache: exactly one of qkv / slabs");
+  APHRO_CHECK(rot_dim % 2 == 0 && rot_dim <= head_size && head_size % x == 0, "rope_cache: bad rot_dim / x");
+  if (tokens == 0) return APHRO_OK;
+  dim3 grid((unsigned)tokens), block(512);
+#define L(TT, KVV, NX)                                                                                          \
+  hipLaunchKernelGGL((rope_cache_kernel<TT, KVV, NX>), grid, block, 0, (hipStream_t)stream, (const uint16_t*)qkv, \
+                     qkv_stride, slabs, nslab, (int)tokens, positions, (const uint16_t*)cos_sin_cache, rot_dim,  \
+                     (uint16_t*)q_out, key_cache, value_cache, slot_mapping, num_heads, num_kv_heads, head_size, \
+                     block_size, x, k_scale, v_scale)
+#define LN(TT, KVV) { if (is_neox) L(TT, KVV, true); else L(TT, KVV, false); }
+#define LK(TT) { if (kv_dtype == APHRO_KV_AUTO) LN(TT, 0) else if (kv_dtype == APHRO_KV_FP8_E4M3) LN(TT, 1) else LN(TT, 2) }
+  if (dtype == APHRO_F16) LK(Half) else LK(BFloat)
+#undef LK
+#undef LN
+#undef L
+  APHRO_LAUNCH_CHECK();
+  return APHRO_OK;
+}

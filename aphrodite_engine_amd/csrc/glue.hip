@@ -118,8 +118,10 @@ __global__ void rotary_kernel(const int64_t* __restrict__ positions, uint16_t* _
     const float s = T::to_f32(cs[embed + r]);
     const float x = T::to_f32(arr[xi]);
     const float y = T::to_f32(arr[yi]);
-    arr[xi] = T::from_f32(x * c - y * s);
-    arr[yi] = T::from_f32(y * c + x * s);
+    float xo, yo;
+    rope_pair(x, y, c, s, xo, yo);
+    arr[xi] = T::from_f32(xo);
+    arr[yi] = T::from_f32(yo);
   }
 }
 

@@ -43,6 +43,8 @@ struct PAParams {
   int max_parts;       // P of the scratch tensors (0 in v1 form)
   int nh_lds;          // query heads per kv head held in the LDS merge buffer (<= 16)
   int write_direct;    // 1: write `out` (single partition) ; 0: write scratch
+  void* out_packed;    // optional fragment-major f16 copy of out for the o_proj GEMM (see wna16_gemm.hip)
+  int pack_mtiles;     // ceil(num_seqs / 16)
   float scale;         // softmax scale * k_scale
   float v_scale;
   int64_t q_stride, kv_block_stride, kv_head_stride;
@@ -309,7 +311,17 @@ __global__ __launch_bounds__(NW * 64) void paged_attention_kernel(PAParams p) {
       const float res = acc * (1.f / (L + 1e-6f)) * p.v_scale;
       const int qh = kvh * gqa + hb + h;
       if (p.write_direct) {
-        ((typename T::storage*)p.out)[((size_t)seq * p.num_heads + qh) * HD + d] = T::from_f32(res);
+        const typename T::storage r16 = T::from_f32(res);
+        if (p.out) ((typename T::storage*)p.out)[((size_t)seq * p.num_heads + qh) * HD + d] = r16;
+        if (p.out_packed) {
+          const int k = qh * HD + d;  // column of the [num_seqs, Hq*hd] activation matrix
+          const size_t chunk = ((((size_t)(k >> 7) * 4 + ((k & 31) >> 3)) * p.pack_mtiles + (seq >> 4)) * 64 +
+                                ((k & 127) >> 5) * 16 + (seq & 15)) * 8;
+          uint16_t h16;
+          if constexpr (__is_same(T, Half)) h16 = r16;
+          else h16 = f32_to_f16_bits(bf16_bits_to_f32(r16));
+          ((uint16_t*)p.out_packed)[chunk + (k & 7)] = h16;
+        }
       } else {
         const size_t pi = ((size_t)seq * p.num_heads + qh) * p.max_parts + part;
         ((typename T::storage*)p.tmp_out)[pi * HD + d] = T::from_f32(res);
@@ -437,7 +449,7 @@ static int dispatch_pa(const PAParams& p, int num_seqs, int parts, int nw, int h
 
 using namespace aphro;
 
-extern "C" int aphro_paged_attention(void* out, float* exp_sums, float* max_logits, void* tmp_out,
+static int paged_attention_impl(void* out, void* out_packed, float* exp_sums, float* max_logits, void* tmp_out,
                                      const void* query, const void* key_cache, const void* value_cache,
                                      int num_seqs, int num_heads, int num_kv_heads, int head_size,
                                      float scale, const int32_t* block_tables, const int32_t* seq_lens,
@@ -453,6 +465,9 @@ extern "C" int aphro_paged_attention(void* out, float* exp_sums, float* max_logi
   APHRO_CHECK(q_stride % 8 == 0 && ((uintptr_t)query % 16) == 0, "paged_attention: query must be 16-byte aligned");
   if (num_seqs == 0) return APHRO_OK;
   PAParams p;
+  p.out_packed = out_packed; p.pack_mtiles = (num_seqs + 15) / 16;
+  APHRO_CHECK(out_packed == nullptr || (partition_size == 0 && ((int64_t)num_heads * head_size) % 128 == 0),
+              "paged_attention: packed output needs the single-kernel (v1) form and Hq*hd %% 128 == 0");
   p.out = out; p.exp_sums = exp_sums; p.max_logits = max_logits; p.tmp_out = tmp_out;
   p.q = query; p.kc = key_cache; p.vc = value_cache;
   p.block_tables = block_tables; p.seq_lens = seq_lens; p.alibi = alibi_slopes;
@@ -508,6 +523,37 @@ extern "C" int aphro_paged_attention(void* out, float* exp_sums, float* max_logi
     APHRO_LAUNCH_CHECK();
   }
   return APHRO_OK;
+}
+
+extern "C" int aphro_paged_attention(void* out, float* exp_sums, float* max_logits, void* tmp_out,
+                                     const void* query, const void* key_cache, const void* value_cache,
+                                     int num_seqs, int num_heads, int num_kv_heads, int head_size,
+                                     float scale, const int32_t* block_tables, const int32_t* seq_lens,
+                                     int max_num_blocks_per_seq, int block_size, int max_seq_len,
+                                     const float* alibi_slopes, int64_t q_stride, int64_t kv_block_stride,
+                                     int64_t kv_head_stride, int dtype, int kv_dtype, float k_scale,
+                                     float v_scale, int partition_size, void* stream) {
+  return paged_attention_impl(out, nullptr, exp_sums, max_logits, tmp_out, query, key_cache, value_cache, num_seqs,
+                              num_heads, num_kv_heads, head_size, scale, block_tables, seq_lens,
+                              max_num_blocks_per_seq, block_size, max_seq_len, alibi_slopes, q_stride,
+                              kv_block_stride, kv_head_stride, dtype, kv_dtype, k_scale, v_scale, partition_size,
+                              stream);
+}
+
+// v1-form decode attention whose output is (also) written fragment-major for the
+// o_proj GEMM of the decode fast path; `out` may be NULL.
+extern "C" int aphro_paged_attention_packed(void* out, void* out_packed, const void* query, const void* key_cache,
+                                            const void* value_cache, int num_seqs, int num_heads,
+                                            int num_kv_heads, int head_size, float scale,
+                                            const int32_t* block_tables, const int32_t* seq_lens,
+                                            int max_num_blocks_per_seq, int block_size, int max_seq_len,
+                                            const float* alibi_slopes, int64_t q_stride, int64_t kv_block_stride,
+                                            int64_t kv_head_stride, int dtype, int kv_dtype, float k_scale,
+                                            float v_scale, void* stream) {
+  return paged_attention_impl(out, out_packed, nullptr, nullptr, nullptr, query, key_cache, value_cache, num_seqs,
+                              num_heads, num_kv_heads, head_size, scale, block_tables, seq_lens,
+                              max_num_blocks_per_seq, block_size, max_seq_len, alibi_slopes, q_stride,
+                              kv_block_stride, kv_head_stride, dtype, kv_dtype, k_scale, v_scale, 0, stream);
 }
 
 extern "C" int aphro_reshape_and_cache(const void* key, const void* value, void* key_cache,

@@ -68,7 +68,6 @@ __device__ __forceinline__ f16x8 load_a_frag<BFloat>(const uint16_t* p) {
 struct Wna16Params {
   const uint16_t* a;      // [M, lda]
   const uint16_t* apk;    // fragment-major f16 copy of a (fast path), see pack_a_kernel
-  const float* asum;      // [K/128][mtiles][16] row sums of the f16 activations per segment
   const uint32_t* qw;     // [K/8, N] exllama order
   const uint32_t* qz;     // [G, N/8]
   const uint16_t* sc;     // [G, N]
@@ -80,7 +79,8 @@ struct Wna16Params {
   int ksteps_per_split;   // k-steps (32 k) per blockIdx.y
   int ksplit;
   int zero_offset;
-  int dbg;                // perf experiments only (APHRO_WNA16_DBG), 0 in production
+  int dbg;                // unused
+  int force_partial;      // 1: write the fp32 slab even when ksplit == 1 (fused consumer)
 };
 
 // ---- in-workgroup split-K reduction through LDS + store ---------------------
@@ -109,7 +109,7 @@ __device__ __forceinline__ void wna16_epilogue(const Wna16Params& p, float* red,
       v[t] = sum;
     }
     if (row < p.M) {
-      if (p.ksplit == 1) {
+      if (p.ksplit == 1 && !p.force_partial) {
         uint16_t* cp = p.c + (size_t)row * p.N + ncol;
         if constexpr (VEC == 4) {
           u16x4 o = {T::from_f32(v[0]), T::from_f32(v[1]), T::from_f32(v[2]), T::from_f32(v[3])};
@@ -133,17 +133,21 @@ __device__ __forceinline__ void wna16_epilogue(const Wna16Params& p, float* red,
 
 // ---------------------------------------------------------------------------
 // Fast path (group size a multiple of 128).  A "segment" is 128 consecutive k
-// (16 packed rows, one group scale).  Per wave: weight segments are double
-// buffered in registers (the loads of segment s+1 / s+2 are in flight while s is
-// consumed), the L2-resident activation fragments are refilled for s+1 as soon
-// as s has used them, scales / zeros are fetched one segment ahead.  The group
-// scale is folded into the f16 B fragment ((q - z) exact, one rounding in the
-// multiply -- the numerics of the reference's own reconstruct kernels,
-// q_gemm.cu:1427-1431), which keeps the kernel at <= 128 VGPRs so that two
-// 8-wave workgroups are resident per CU and overlap each other's memory and
-// MFMA phases.  Inside a segment lane group g owns k = 32g..32g+31 (MFMA u takes
-// 8u..8u+7 of them): A fragment loads are 64 contiguous bytes per lane and the
-// weight row for (u, g) is 16*seg + 4g + u.
+// (16 packed rows, one group scale).
+//  * activations arrive FRAGMENT-MAJOR (pack_a_kernel or a fused producer):
+//    block (seg, u, mtile) = 1 KiB, lane (g, m) holds A[16*mtile+m][128*seg +
+//    32*g + 8*u .. +7] as f16.  A row-major A makes every MFMA A-fragment a
+//    16-row gather (64 sectors per wave instruction, measured 2.4x slower).
+//  * the weight row for (u, g) is 16*seg + 4g + u (same k as the A fragment).
+//  * NSEG segments per wave is a compile-time constant: straight-line code
+//    (hipcc's waitcnt insertion degrades to vmcnt(0) around runtime-conditional
+//    loads); W loads run DEPTH segments ahead of their use and the issue points
+//    are pinned with sched_barrier (the scheduler otherwise sinks loads next to
+//    their first use, serialising HBM latency and compute).
+//  * the group scale is folded into the f16 B fragment ((q - z) exact, one
+//    rounding in the multiply -- the numerics of the reference's own
+//    reconstruct kernels, q_gemm.cu:1427-1431) so no second accumulator set is
+//    needed: ~165 VGPRs, three 4-wave workgroups resident per CU.
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t v_and_or(uint32_t a, uint32_t mask, uint32_t orv) {
   uint32_t r;  // gfx9 VOP3 takes one SGPR: the mask goes in an SGPR, the magic in a VGPR
@@ -168,198 +172,127 @@ __device__ __forceinline__ f16x8 dq8_exl_scaled(uint32_t w, f16x2 zh, f16x2 zh16
   return __builtin_bit_cast(f16x8, r);
 }
 
-// int4 word -> 8 exact integer-valued f16 (q - z)
-__device__ __forceinline__ f16x8 dq8_exl_int(uint32_t w, f16x2 zh, f16x2 zh16, uint32_t magic) {
-  const f16x2 inv16 = {(f16)0.0625f, (f16)0.0625f};
-  uint32_t q0 = v_and_or(w, 0x000f000fu, magic);
-  uint32_t q1 = v_and_or(w, 0x00f000f0u, magic);
-  uint32_t w8 = w >> 8;
-  uint32_t q2 = v_and_or(w8, 0x000f000fu, magic);
-  uint32_t q3 = v_and_or(w8, 0x00f000f0u, magic);
-  f16x2 d0 = __builtin_bit_cast(f16x2, q0) - zh;
-  f16x2 d1 = __builtin_bit_cast(f16x2, q1) * inv16 + zh16;
-  f16x2 d2 = __builtin_bit_cast(f16x2, q2) - zh;
-  f16x2 d3 = __builtin_bit_cast(f16x2, q3) * inv16 + zh16;
-  u32x4 r = {__builtin_bit_cast(uint32_t, d0), __builtin_bit_cast(uint32_t, d1),
-             __builtin_bit_cast(uint32_t, d2), __builtin_bit_cast(uint32_t, d3)};
-  return __builtin_bit_cast(f16x8, r);
-}
-
 template <int VEC>
 struct SegMeta {          // RAW group scale / zero words of one segment: no ALU op may touch
   uint32_t sc[(VEC + 1) / 2];  // them before the segment is consumed, or the compiler has to
   uint32_t zw;                 // wait for the load -- and with it for every older weight load
 };
 
-// Fast kernel, final form (DESIGN.md "wna16_gemm"):
-//  * NSEG segments per wave is a compile-time constant: straight-line code
-//    (hipcc's waitcnt insertion degrades to vmcnt(0) around runtime-conditional
-//    loads); W loads run DEPTH segments ahead, issue points pinned by
-//    sched_barrier (the scheduler otherwise sinks loads next to their use).
-//  * a workgroup = NWV waves = MW m-tiles x (NWV/MW) K-slices of ONE column tile:
-//    every wave works on a single 16-row m-tile (16 + 16 accumulator VGPRs), so
-//    ~100 VGPRs/wave and 3-4 waves per SIMD -- a wave issues one VALU op per
-//    ~5 cycles, the SIMD needs several waves to fill its VALU and MFMA pipes.
-//    The m-tile waves of a K-slice load the same weight words (L1 merges them).
-//  * int4 -> MFMA operand without any f16 arithmetic: (w >> 4i) & 0x000f000f IS
-//    a pair of f16 SUBNORMALS q * 2^-24, which v_mfma_f32_16x16x32_f16 consumes
-//    exactly (verified on gfx950, tools/valu_probe.hip).  7 integer ops per
-//    packed word.  Zero point and scale are applied to the fp32 group sum:
-//        acc += (s * 2^24) * part - (s * z) * rowsum(A)
-//    with rowsum(A) per (segment, row) precomputed by pack_a_kernel.  All
-//    products are exact in fp32: the result is exact integer-weight arithmetic.
-template <typename T, int VEC, int NSEG, int NWV, int MW>
-__global__ __launch_bounds__(NWV * 64, 4) void wna16_gemm_kernel(Wna16Params p) {
-  constexpr int DEPTH = NSEG < 2 ? NSEG : 2;
+template <typename T, int VEC, int MT, int NSEG>
+__global__ __launch_bounds__(FNW * 64, 3) void wna16_gemm_kernel(Wna16Params p) {
+  constexpr int DEPTH = NSEG < 2 ? NSEG : 2;  // weight segments in flight ahead of the consumer
   constexpr int NBUF = DEPTH + 1;
-  constexpr int KW = NWV / MW;  // K-slices per workgroup
   extern __shared__ __attribute__((aligned(16))) float red[];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int g = lane >> 4;
   const int c = lane & 15;
   const int n0 = blockIdx.x * (16 * VEC);
-  const int mt = wave % MW;                 // this wave's m-tile within the workgroup
-  const int kslice = wave / MW;
-  const int mtile = blockIdx.z * MW + mt;   // global m-tile
+  const int m0 = blockIdx.z * (16 * MT);
   const int ncol = n0 + VEC * c;
-  const int seg0 = (blockIdx.y * KW + kslice) * NSEG;  // host: K == ksplit*KW*NSEG*128
+  const int seg0 = (blockIdx.y * FNW + wave) * NSEG;  // host guarantees K == ksplit*FNW*NSEG*128
+
+  f32x4 acc[MT][VEC];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int t = 0; t < VEC; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
   const int mtiles = (p.M + 15) >> 4;
-  const bool live = mtile < mtiles;         // surplus m-tile waves only join the barrier
-
-  f32x4 acc[VEC];
+  // surplus m-tiles of the last z-block read tile mtiles-1 again (never stored)
+  const uint16_t* apk = p.apk + ((size_t)seg0 * 4 * mtiles * 64 + lane) * 8;
+  int mt_idx[MT];
 #pragma unroll
-  for (int t = 0; t < VEC; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < MT; ++i) mt_idx[i] = min((m0 >> 4) + i, mtiles - 1);
+  auto a_frag = [&](int s, int u, int i) {
+    return *reinterpret_cast<const f16x8*>(apk + ((size_t)(s * 4 + u) * mtiles + mt_idx[i]) * 512);
+  };
+  const uint32_t* wbase = p.qw + ((size_t)seg0 * 16 + 4 * g) * p.N + ncol;
+  const int segs_per_group = p.group_size >> 7;
+  const int zshift = (ncol & 7) * 4;
+  uint32_t magic = 0x64006400u;
+  asm volatile("" : "+v"(magic));  // keep the f16 magic in a VGPR (see v_and_or)
 
-  if (live) {
-    // packed A: block (seg, u, mtile) is 1 KiB, lane-linear (16 B per lane)
-    const uint16_t* apk = p.apk + (((size_t)seg0 * 4 * mtiles + mtile) * 64 + lane) * 8;
-    auto a_frag = [&](int s, int u) {
-      return *reinterpret_cast<const f16x8*>(apk + (size_t)(s * 4 + u) * mtiles * 512);
-    };
-    // row sums of A for rows 4g..4g+3 of this m-tile, per segment
-    const float* asum = p.asum + ((size_t)seg0 * mtiles + mtile) * 16 + 4 * g;
-    const uint32_t* wbase = p.qw + ((size_t)seg0 * 16 + 4 * g) * p.N + ncol;
-    const int segs_per_group = p.group_size >> 7;
-    const int zshift = (ncol & 7) * 4;
+  SegMeta<VEC> meta[2];
+  uint32_t w[NBUF][4][VEC];
+  f16x8 af[4][MT];
 
-    SegMeta<VEC> meta[2];
-    f32x4 rs[2];
-    uint32_t w[NBUF][4][VEC];
-    f16x8 af[4];
-
-    auto load_meta = [&](int slot, int s) {
-      const int grp = (seg0 + s) / segs_per_group;
-      const uint16_t* sp = p.sc + (size_t)grp * p.N + ncol;
-      meta[slot].zw = p.qz[(size_t)grp * (p.N >> 3) + (ncol >> 3)];
+  auto load_meta = [&](SegMeta<VEC>& m, int s) {
+    const int grp = (seg0 + s) / segs_per_group;
+    const uint16_t* sp = p.sc + (size_t)grp * p.N + ncol;
+    m.zw = p.qz[(size_t)grp * (p.N >> 3) + (ncol >> 3)];
+    if constexpr (VEC == 4) {
+      u32x2 v = *reinterpret_cast<const u32x2*>(sp);
+      m.sc[0] = v[0]; m.sc[1] = v[1];
+    } else if constexpr (VEC == 2) {
+      m.sc[0] = *reinterpret_cast<const uint32_t*>(sp);
+    } else {
+      m.sc[0] = *sp;
+    }
+  };
+  auto load_w = [&](uint32_t (&wd)[4][VEC], int s) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint32_t* wp = wbase + ((size_t)s * 16 + u) * p.N;
       if constexpr (VEC == 4) {
-        u32x2 v = *reinterpret_cast<const u32x2*>(sp);
-        meta[slot].sc[0] = v[0]; meta[slot].sc[1] = v[1];
+        u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp));
+        wd[u][0] = v[0]; wd[u][1] = v[1]; wd[u][2] = v[2]; wd[u][3] = v[3];
       } else if constexpr (VEC == 2) {
-        meta[slot].sc[0] = *reinterpret_cast<const uint32_t*>(sp);
+        u32x2 v = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(wp));
+        wd[u][0] = v[0]; wd[u][1] = v[1];
       } else {
-        meta[slot].sc[0] = *sp;
-      }
-      rs[slot] = *reinterpret_cast<const f32x4*>(asum + (size_t)s * mtiles * 16);
-    };
-    auto load_w = [&](uint32_t (&wd)[4][VEC], int s) {
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const uint32_t* wp = wbase + ((size_t)s * 16 + u) * p.N;
-        if constexpr (VEC == 4) {
-          u32x4 v = (MW == 1) ? __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp))
-                              : *reinterpret_cast<const u32x4*>(wp);
-          wd[u][0] = v[0]; wd[u][1] = v[1]; wd[u][2] = v[2]; wd[u][3] = v[3];
-        } else if constexpr (VEC == 2) {
-          u32x2 v = (MW == 1) ? __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(wp))
-                              : *reinterpret_cast<const u32x2*>(wp);
-          wd[u][0] = v[0]; wd[u][1] = v[1];
-        } else {
-          wd[u][0] = *wp;
-        }
-      }
-    };
-
-    load_meta(0, 0);
-#pragma unroll
-    for (int u = 0; u < 4; ++u) af[u] = a_frag(0, u);
-#pragma unroll
-    for (int d = 0; d < DEPTH; ++d) load_w(w[d], d);
-    __builtin_amdgcn_sched_barrier(0);
-
-#pragma unroll
-    for (int s = 0; s < NSEG; ++s) {
-      if (s + DEPTH < NSEG) load_w(w[(s + DEPTH) % NBUF], s + DEPTH);
-      if (s + 1 < NSEG) load_meta((s + 1) & 1, s + 1);
-      __builtin_amdgcn_sched_barrier(0);
-      f32x4 part[VEC];
-#pragma unroll
-      for (int t = 0; t < VEC; ++t) part[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-#pragma unroll
-        for (int t = 0; t < VEC; ++t) {
-          const uint32_t wv = w[s % NBUF][u][t];
-          u32x4 b = {wv & 0x000f000fu, (wv >> 4) & 0x000f000fu, (wv >> 8) & 0x000f000fu,
-                     (wv >> 12) & 0x000f000fu};  // f16 subnormals q * 2^-24
-          part[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[u], __builtin_bit_cast(f16x8, b), part[t], 0, 0, 0);
-        }
-        if (s + 1 < NSEG) {  // slot u is free: refill it for the next segment
-          af[u] = a_frag(s + 1, u);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-      const SegMeta<VEC>& m = meta[s & 1];
-      const f32x4 rsum = rs[s & 1];
-#pragma unroll
-      for (int t = 0; t < VEC; ++t) {
-        const float z = (float)((int)((m.zw >> (zshift + 4 * t)) & 0xf) + p.zero_offset);
-        const float sf = T::to_f32((uint16_t)(m.sc[t >> 1] >> (16 * (t & 1))));
-        acc[t] += part[t] * (sf * 16777216.0f);
-        acc[t] -= rsum * (sf * z);
+        wd[u][0] = __builtin_nontemporal_load(wp);
       }
     }
-  }
+  };
 
-  // ---- reduce the KW K-slices of each m-tile through LDS, then store -------------
-  // red[wave][t][lane] as float4 (lane-contiguous: conflict-free)
+  // ---- prologue: meta(0), A(0), W(0..DEPTH-1) ---------------------------------------
+  load_meta(meta[0], 0);
 #pragma unroll
-  for (int t = 0; t < VEC; ++t)
-    *reinterpret_cast<f32x4*>(&red[((wave * VEC + t) * 64 + lane) * 4]) = acc[t];
-  __syncthreads();
-  // thread -> (m-tile i, row r, lane): sums the K-slices for VEC adjacent columns of one row
-  for (int idx = wave; idx < MW * 4; idx += NWV) {
-    const int i = idx >> 2, r = idx & 3;
-    const int row = (blockIdx.z * MW + i) * 16 + 4 * g + r;
-    float v[VEC];
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int i = 0; i < MT; ++i) af[u][i] = a_frag(0, u, i);
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) load_w(w[d], d);
+  __builtin_amdgcn_sched_barrier(0);
+
+#pragma unroll
+  for (int s = 0; s < NSEG; ++s) {
+    if (s + DEPTH < NSEG) load_w(w[(s + DEPTH) % NBUF], s + DEPTH);
+    if (s + 1 < NSEG) load_meta(meta[(s + 1) & 1], s + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    const SegMeta<VEC>& m = meta[s & 1];
+    f16x2 zh[VEC], zh16[VEC], sc[VEC];
 #pragma unroll
     for (int t = 0; t < VEC; ++t) {
-      float sum = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < KW; ++ks) sum += red[(((ks * MW + i) * VEC + t) * 64 + lane) * 4 + r];
-      v[t] = sum;
+      int z = (int)((m.zw >> (zshift + 4 * t)) & 0xf) + p.zero_offset;
+      f16 a = __builtin_bit_cast(f16, (uint16_t)(0x6400 | z));  // 1024 + z
+      f16 b = (f16)(float)(-64 - z);
+      const uint16_t sraw = (uint16_t)(m.sc[t >> 1] >> (16 * (t & 1)));
+      f16 s16;
+      if constexpr (__is_same(T, Half)) s16 = __builtin_bit_cast(f16, sraw);
+      else s16 = (f16)bf16_bits_to_f32(sraw);
+      zh[t] = f16x2{a, a};
+      zh16[t] = f16x2{b, b};
+      sc[t] = f16x2{s16, s16};
     }
-    if (row < p.M) {
-      if (p.ksplit == 1) {
-        uint16_t* cp = p.c + (size_t)row * p.N + ncol;
-        if constexpr (VEC == 4) {
-          u16x4 o = {T::from_f32(v[0]), T::from_f32(v[1]), T::from_f32(v[2]), T::from_f32(v[3])};
-          *reinterpret_cast<u16x4*>(cp) = o;
-        } else {
 #pragma unroll
-          for (int t = 0; t < VEC; ++t) cp[t] = T::from_f32(v[t]);
-        }
-      } else {
-        float* pp = p.partial + ((size_t)blockIdx.y * p.M + row) * p.N + ncol;
-        if constexpr (VEC == 4) {
-          *reinterpret_cast<f32x4*>(pp) = f32x4{v[0], v[1], v[2], v[3]};
-        } else {
+    for (int u = 0; u < 4; ++u) {
 #pragma unroll
-          for (int t = 0; t < VEC; ++t) pp[t] = v[t];
-        }
+      for (int t = 0; t < VEC; ++t) {
+        f16x8 b = dq8_exl_scaled(w[s % NBUF][u][t], zh[t], zh16[t], sc[t], magic);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+          acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[u][i], b, acc[i][t], 0, 0, 0);
+      }
+      if (s + 1 < NSEG) {  // slot u is free: refill it for the next segment
+#pragma unroll
+        for (int i = 0; i < MT; ++i) af[u][i] = a_frag(s + 1, u, i);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   }
+  wna16_epilogue<T, VEC, MT, FNW>(p, red, acc, lane, wave, g, m0, ncol);
 }
 
 // Generic path (any group size that is a multiple of 32): per-segment loads.
@@ -505,39 +438,32 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ partial, uint16_t
 // would repeat; packing once turns them into 1 KiB coalesced loads.
 template <typename T>
 __global__ void pack_a_kernel(const uint16_t* __restrict__ a, const int32_t* __restrict__ perm,
-                              uint16_t* __restrict__ out, float* __restrict__ asum, int M, int K, int lda) {
-  // one wave per (segment, m-tile); lane = (g, m)
+                              uint16_t* __restrict__ out, int M, int K, int lda) {
   const int mtiles = (M + 15) >> 4;
-  const int wave_global = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-  if (wave_global >= (K >> 7) * mtiles) return;
-  const int lane = threadIdx.x & 63;
-  const int mt = wave_global % mtiles;
-  const int seg = wave_global / mtiles;
+  const int64_t total = (int64_t)(K >> 7) * 4 * mtiles * 64;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int lane = (int)(idx & 63);
+  int64_t blk = idx >> 6;
+  const int mt = (int)(blk % mtiles); blk /= mtiles;
+  const int u = (int)(blk & 3);
+  const int seg = (int)(blk >> 2);
   const int row = 16 * mt + (lane & 15);
-  float rsum = 0.f;
+  const int k0 = 128 * seg + 32 * (lane >> 4) + 8 * u;
+  u16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (row < M) {
+    if (perm) {
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const int k0 = 128 * seg + 32 * (lane >> 4) + 8 * u;
-    u16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (row < M) {
-      if (perm) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = a[(size_t)row * lda + perm[k0 + j]];
-      } else {
-        v = *reinterpret_cast<const u16x8*>(a + (size_t)row * lda + k0);
-      }
-      if constexpr (!__is_same(T, Half)) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = f32_to_f16_bits(bf16_bits_to_f32(v[j]));
-      }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) rsum += f16_bits_to_f32(v[j]);
+      for (int j = 0; j < 8; ++j) v[j] = a[(size_t)row * lda + perm[k0 + j]];
+    } else {
+      v = *reinterpret_cast<const u16x8*>(a + (size_t)row * lda + k0);
     }
-    *reinterpret_cast<u16x8*>(out + ((((size_t)seg * 4 + u) * mtiles + mt) * 64 + lane) * 8) = v;
+    if constexpr (!__is_same(T, Half)) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = f32_to_f16_bits(bf16_bits_to_f32(v[j]));
+    }
   }
-  rsum += __shfl_xor(rsum, 16, 64);
-  rsum += __shfl_xor(rsum, 32, 64);
-  if (lane < 16) asum[((size_t)seg * mtiles + mt) * 16 + lane] = rsum;
+  *reinterpret_cast<u16x8*>(out + idx * 8) = v;
 }
 
 // a_perm[m][k] = a[m][perm[k]]   (act-order column gather, q_gemm.cu:219-226)
@@ -645,7 +571,7 @@ __global__ void gptq_dequant_kernel(const uint32_t* __restrict__ qw, const uint3
 // host side
 // ---------------------------------------------------------------------------
 struct Wna16Plan {
-  int vec, mt, ksplit, ksteps_per_split, nseg, nwv, mw;
+  int vec, mt, ksplit, ksteps_per_split, nseg;
   bool fast;
 };
 
@@ -656,7 +582,7 @@ static int env_int(const char* name, int dflt) {
 
 static Wna16Plan make_plan(int64_t M, int64_t N, int64_t K, int64_t gs) {
   Wna16Plan pl;
-  pl.nseg = 0; pl.nwv = NW; pl.mw = 1;
+  pl.nseg = 0;
   pl.vec = (N % 64 == 0) ? 4 : (N % 32 == 0) ? 2 : 1;
   int fv = env_int("APHRO_WNA16_VEC", 0);
   if (fv == 1 || fv == 2 || fv == 4) {
@@ -665,35 +591,30 @@ static Wna16Plan make_plan(int64_t M, int64_t N, int64_t K, int64_t gs) {
     pl.vec = 2;  // narrow N: 32-column tiles double the workgroup count
   }
   pl.mt = (M > 16) ? 2 : 1;
+  const int64_t tiles = N / (16 * pl.vec) * ((M + 16 * pl.mt - 1) / (16 * pl.mt));
   const int total_segs = (int)((K + 127) / 128);
   pl.fast = (K % 128 == 0 && gs % 128 == 0 && pl.vec >= 2) && !env_int("APHRO_WNA16_GENERIC", 0);
   if (pl.fast) {
-    // 8-wave workgroups = MW m-tiles x KW K-slices; each wave owns NSEG segments;
-    // ksplit (cross-workgroup, fp32 slabs) only when the grid would otherwise be small.
-    pl.nwv = 8;
-    pl.mw = M <= 16 ? 1 : (M <= 32 ? 2 : 4);
-    const int kw = pl.nwv / pl.mw;
-    const int64_t tiles = N / (16 * pl.vec) * ((M + 16 * pl.mw - 1) / (16 * pl.mw));
+    // every wave owns exactly NSEG segments; ksplit = total_segs / (FNW * NSEG) fp32 slabs.
     const int fk = env_int("APHRO_WNA16_KSPLIT", 0);
     int best_ns = 0, best_split = 0;
     for (int split = 1; split <= 8; ++split) {
-      if (total_segs % (split * kw) != 0) continue;
-      const int ns = total_segs / (split * kw);
+      if (total_segs % (split * FNW) != 0) continue;
+      const int ns = total_segs / (split * FNW);
       if (!(ns == 1 || ns == 2 || ns == 4 || ns == 7 || ns == 8)) continue;
       if (fk > 0) { if (split == fk) { best_ns = ns; best_split = split; } continue; }
       if (best_ns == 0) { best_ns = ns; best_split = split; }
-      else if (tiles * best_split < 320 && tiles * split <= 1100) { best_ns = ns; best_split = split; }
+      // a deeper split only while the grid is small (< ~1.5 workgroups per CU)
+      else if (tiles * best_split < 400 && tiles * split <= 1100) { best_ns = ns; best_split = split; }
     }
     if (best_ns) {
       pl.nseg = best_ns;
       pl.ksplit = best_split;
-      pl.ksteps_per_split = kw * best_ns * 4;
+      pl.ksteps_per_split = FNW * best_ns * 4;
       return pl;
     }
     pl.fast = false;
-    pl.nwv = NW; pl.mw = 1;
   }
-  const int64_t tiles = N / (16 * pl.vec) * ((M + 16 * pl.mt - 1) / (16 * pl.mt));
   int target = (int)((256 + tiles / 2) / tiles);
   target = target < 1 ? 1 : (target > 8 ? 8 : target);
   int fk = env_int("APHRO_WNA16_KSPLIT", 0);
@@ -707,25 +628,21 @@ static Wna16Plan make_plan(int64_t M, int64_t N, int64_t K, int64_t gs) {
 
 template <typename T, int VEC, int MT>
 static void launch_wna16(const Wna16Params& p, const Wna16Plan& pl, hipStream_t st) {
+  dim3 grid((unsigned)(p.N / (16 * VEC)), (unsigned)pl.ksplit, (unsigned)((p.M + 16 * MT - 1) / (16 * MT)));
   if (pl.fast) {
-    if constexpr (VEC >= 2 && MT == 1) {  // MT is unused by the fast kernel (one m-tile per wave)
-      dim3 grid((unsigned)(p.N / (16 * VEC)), (unsigned)pl.ksplit,
-                (unsigned)((p.M + 16 * pl.mw - 1) / (16 * pl.mw)));
-      size_t lds = (size_t)8 * VEC * 64 * 4 * sizeof(float);
-#define APHRO_FAST(NS, MWV) hipLaunchKernelGGL((wna16_gemm_kernel<T, VEC, NS, 8, MWV>), grid, dim3(512), lds, st, p)
-#define APHRO_FAST_MW(NS) { if (pl.mw == 1) APHRO_FAST(NS, 1); else if (pl.mw == 2) APHRO_FAST(NS, 2); else APHRO_FAST(NS, 4); }
+    if constexpr (VEC >= 2) {
+      size_t lds = (size_t)FNW * MT * VEC * 64 * 4 * sizeof(float);
+#define APHRO_FAST(NS) hipLaunchKernelGGL((wna16_gemm_kernel<T, VEC, MT, NS>), grid, dim3(FNW * 64), lds, st, p)
       switch (pl.nseg) {
-        case 8: APHRO_FAST_MW(8) break;
-        case 7: APHRO_FAST_MW(7) break;
-        case 4: APHRO_FAST_MW(4) break;
-        case 2: APHRO_FAST_MW(2) break;
-        default: APHRO_FAST_MW(1) break;
+        case 8: APHRO_FAST(8); break;
+        case 7: APHRO_FAST(7); break;
+        case 4: APHRO_FAST(4); break;
+        case 2: APHRO_FAST(2); break;
+        default: APHRO_FAST(1); break;
       }
-#undef APHRO_FAST_MW
 #undef APHRO_FAST
     }
   } else {
-    dim3 grid((unsigned)(p.N / (16 * VEC)), (unsigned)pl.ksplit, (unsigned)((p.M + 16 * MT - 1) / (16 * MT)));
     size_t lds = (size_t)NW * MT * VEC * 64 * 4 * sizeof(float);
     hipLaunchKernelGGL((wna16_gemm_generic_kernel<T, VEC, MT>), grid, dim3(NW * 64), lds, st, p);
   }
@@ -733,7 +650,7 @@ static void launch_wna16(const Wna16Params& p, const Wna16Plan& pl, hipStream_t 
 
 template <typename T>
 static int run_wna16(Wna16Params p, const Wna16Plan& pl, hipStream_t st) {
-  switch (pl.vec * 10 + (pl.fast ? 1 : pl.mt)) {
+  switch (pl.vec * 10 + pl.mt) {
     case 41: launch_wna16<T, 4, 1>(p, pl, st); break;
     case 42: launch_wna16<T, 4, 2>(p, pl, st); break;
     case 21: launch_wna16<T, 2, 1>(p, pl, st); break;
@@ -743,7 +660,7 @@ static int run_wna16(Wna16Params p, const Wna16Plan& pl, hipStream_t st) {
     default: set_error("bad wna16 plan"); return APHRO_ERR_INVALID;
   }
   APHRO_LAUNCH_CHECK();
-  if (pl.ksplit > 1) {
+  if (pl.ksplit > 1 && p.c != nullptr) {
     int64_t mn = (int64_t)p.M * p.N;
     unsigned blocks = (unsigned)((mn / 4 + 255) / 256);
     hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3(blocks), dim3(256), 0, st, p.partial, p.c,
@@ -757,14 +674,7 @@ static int run_wna16(Wna16Params p, const Wna16Plan& pl, hipStream_t st) {
 
 using namespace aphro;
 
-static size_t packed_a_bytes(int64_t M, int64_t K) {  // fragment-major A + per-segment row sums
-  const size_t mtiles = (size_t)((M + 15) / 16);
-  size_t b = mtiles * 16 * (size_t)K * 2;
-  b = (b + 255) / 256 * 256;
-  b += (size_t)((K + 127) / 128) * mtiles * 16 * sizeof(float);
-  return (b + 255) / 256 * 256;
-}
-static size_t packed_a_sum_offset(int64_t M, int64_t K) {
+static size_t packed_a_bytes(int64_t M, int64_t K) {  // fragment-major f16 copy of A
   size_t b = (size_t)((M + 15) / 16) * 16 * (size_t)K * 2;
   return (b + 255) / 256 * 256;
 }
@@ -800,20 +710,18 @@ extern "C" int aphro_gptq_gemm(const void* a, const uint32_t* q_weight, const ui
   const uint16_t* ap = (const uint16_t*)a;
   int64_t ld = lda;
   Wna16Params p;
-  p.apk = nullptr; p.asum = nullptr;
+  p.apk = nullptr;
   if (pl.fast) {
-    const int64_t threads = (K / 128) * ((M + 15) / 16) * 64;
-    dim3 grid((unsigned)((threads + 255) / 256));
-    float* asum = (float*)((char*)workspace + packed_a_sum_offset(M, K));
+    const int64_t total = (K / 128) * 4 * ((M + 15) / 16) * 64;
+    dim3 grid((unsigned)((total + 255) / 256));
     if (dtype == APHRO_F16)
-      hipLaunchKernelGGL((pack_a_kernel<Half>), grid, dim3(256), 0, st, ap, perm, (uint16_t*)workspace, asum,
-                         (int)M, (int)K, (int)lda);
+      hipLaunchKernelGGL((pack_a_kernel<Half>), grid, dim3(256), 0, st, ap, perm, (uint16_t*)workspace, (int)M,
+                         (int)K, (int)lda);
     else
-      hipLaunchKernelGGL((pack_a_kernel<BFloat>), grid, dim3(256), 0, st, ap, perm, (uint16_t*)workspace, asum,
-                         (int)M, (int)K, (int)lda);
+      hipLaunchKernelGGL((pack_a_kernel<BFloat>), grid, dim3(256), 0, st, ap, perm, (uint16_t*)workspace, (int)M,
+                         (int)K, (int)lda);
     APHRO_LAUNCH_CHECK();
     p.apk = (const uint16_t*)workspace;
-    p.asum = asum;
   } else if (perm) {
     APHRO_CHECK(a_perm_tmp != nullptr, "gptq_gemm: act-order needs a_perm_tmp");
     hipLaunchKernelGGL(permute_cols_kernel, dim3((unsigned)((K + 255) / 256), (unsigned)M), dim3(256), 0, st,
@@ -828,6 +736,68 @@ extern "C" int aphro_gptq_gemm(const void* a, const uint32_t* q_weight, const ui
   p.group_size = (int)gs; p.ksteps_per_split = pl.ksteps_per_split; p.ksplit = pl.ksplit;
   p.zero_offset = zero_offset;
   p.dbg = 0;
+  p.force_partial = 0;
+  return dtype == APHRO_F16 ? run_wna16<Half>(p, pl, st) : run_wna16<BFloat>(p, pl, st);
+}
+
+// Fragment-major activation packing, exposed so that producers / callers can pack
+// once and feed several GEMMs (qkv and gate_up share their input).
+extern "C" size_t aphro_wna16_packed_a_bytes(int64_t M, int64_t K) { return packed_a_bytes(M, K); }
+
+extern "C" int aphro_wna16_pack_a(const void* a, const int32_t* perm, void* packed, int64_t M, int64_t K,
+                                  int64_t lda, int dtype, void* stream) {
+  APHRO_CHECK(dtype == APHRO_F16 || dtype == APHRO_BF16, "pack_a: dtype must be f16 or bf16");
+  APHRO_CHECK(K % 128 == 0 && lda % 8 == 0 && ((uintptr_t)a % 16) == 0, "pack_a: K %% 128 and 16-byte alignment required");
+  if (M == 0) return APHRO_OK;
+  const int64_t total = (K / 128) * 4 * ((M + 15) / 16) * 64;
+  dim3 grid((unsigned)((total + 255) / 256));
+  if (dtype == APHRO_F16)
+    hipLaunchKernelGGL((pack_a_kernel<Half>), grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)a, perm,
+                       (uint16_t*)packed, (int)M, (int)K, (int)lda);
+  else
+    hipLaunchKernelGGL((pack_a_kernel<BFloat>), grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)a, perm,
+                       (uint16_t*)packed, (int)M, (int)K, (int)lda);
+  APHRO_LAUNCH_CHECK();
+  return APHRO_OK;
+}
+
+// Number of fp32 K-split slabs the fast kernel will produce for this shape (1 = none),
+// or 0 if the shape is not served by the fast (packed-A) kernel.
+extern "C" int aphro_wna16_ksplit(int64_t M, int64_t N, int64_t K, int64_t groups) {
+  if (groups <= 0 || K % groups != 0 || M <= 0 || M > APHRO_WNA16_MAX_M || N % 16 != 0) return 0;
+  Wna16Plan pl = make_plan(M, N, K, K / groups);
+  return pl.fast ? pl.ksplit : 0;
+}
+
+// GEMM on pre-packed activations.  c != NULL: result [M,N] in `dtype` (a reduce kernel
+// runs when ksplit > 1).  c == NULL: the fp32 slabs [ksplit][M][N] are left in `partials`
+// for a fused consumer (aphro_fused_add_rms_norm_pack / aphro_rope_cache) to sum.
+extern "C" int aphro_wna16_gemm_packed(const void* a_packed, const uint32_t* q_weight, const uint32_t* qzeros,
+                                       const void* scales, void* c, float* partials, size_t partial_bytes,
+                                       int64_t M, int64_t N, int64_t K, int64_t groups, int zero_offset,
+                                       int dtype, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  APHRO_CHECK(dtype == APHRO_F16 || dtype == APHRO_BF16, "wna16_gemm_packed: dtype must be f16 or bf16");
+  APHRO_CHECK(M > 0 && M <= APHRO_WNA16_MAX_M, "wna16_gemm_packed: M=%ld out of range", (long)M);
+  APHRO_CHECK(groups > 0 && K % groups == 0, "wna16_gemm_packed: bad groups");
+  Wna16Plan pl = make_plan(M, N, K, K / groups);
+  APHRO_CHECK(pl.fast, "wna16_gemm_packed: shape K=%ld N=%ld g=%ld is not served by the fast kernel", (long)K,
+              (long)N, (long)(K / groups));
+  if (pl.ksplit > 1 || c == nullptr) {
+    size_t need = (size_t)pl.ksplit * M * N * sizeof(float);
+    if (partials == nullptr || partial_bytes < need) {
+      set_error("wna16_gemm_packed: partial buffer %zu < %zu bytes", partial_bytes, need);
+      return APHRO_ERR_WORKSPACE;
+    }
+  }
+  Wna16Params p;
+  p.a = nullptr; p.apk = (const uint16_t*)a_packed; p.qw = q_weight; p.qz = qzeros;
+  p.sc = (const uint16_t*)scales; p.c = (uint16_t*)c; p.partial = partials;
+  p.M = (int)M; p.N = (int)N; p.K = (int)K; p.lda = 0;
+  p.group_size = (int)(K / groups); p.ksteps_per_split = pl.ksteps_per_split;
+  p.ksplit = (c == nullptr && pl.ksplit == 1) ? 1 : pl.ksplit;
+  p.zero_offset = zero_offset; p.dbg = 0;
+  p.force_partial = (c == nullptr) ? 1 : 0;
   return dtype == APHRO_F16 ? run_wna16<Half>(p, pl, st) : run_wna16<BFloat>(p, pl, st);
 }
 

@@ -81,6 +81,17 @@ class QuantLinear(nn.Module):
             return torch.nn.functional.linear(x, self.weight)
         return self.quant_method.apply(self, x)
 
+    def fast_params(self):
+        """(qweight, qzeros, scales, zero_offset) if this layer's weights are in the
+        CDNA4 K-packed layout served by the packed-activation W4A16 kernel."""
+        from .quantization.gptq import ExllamaState
+        if isinstance(self.quant_config, GPTQConfig):
+            if getattr(self, "exllama_state", None) == ExllamaState.READY and self.g_idx.numel() == 0:
+                return self.qweight, self.qzeros, self.scales, 1
+        elif isinstance(self.quant_config, AWQConfig) and getattr(self, "awq_prepacked", False):
+            return self.qweight, self.qzeros, self.scales, 0
+        return None
+
 
 def _rope_cache(head_dim: int, max_pos: int, theta: float, dtype, device):
     """modeling/layers/rotary_embedding.py:_compute_cos_sin_cache."""
@@ -119,6 +130,49 @@ class LlamaDecoderLayer(nn.Module):
         self.k_scale = 1.0
         self.v_scale = 1.0
         self.tp = tp
+
+    def fused_decode_ok(self, m: int) -> bool:
+        """Decode fast path (8 launches per layer instead of 17): W4A16 linears in the
+        K-packed layout, shapes served by the packed-activation kernel, TP == 1."""
+        if self.tp != 1 or m > 64:
+            return False
+        for lin in (self.qkv_proj, self.o_proj, self.gate_up_proj, self.down_proj):
+            fp = lin.fast_params()
+            if fp is None or ops.wna16_ksplit(m, lin.out_features, lin.in_features, fp[2].shape[0]) <= 0:
+                return False
+        return True
+
+    def forward_decode_fused(self, positions, x, slabs, residual, first, kv_cache, attn_metadata, cos_sin):
+        """x: row-major input (first layer) or None; slabs: fp32 split-K slabs of the
+        previous down_proj.  Returns the fp32 slabs of this layer's down_proj."""
+        eps = self.cfg.rms_norm_eps
+        m = positions.shape[0]
+        h = self.cfg.hidden_size
+        packed, _ = ops.fused_add_rms_norm_pack(x if first else None, None if first else slabs, residual,
+                                                not first, self.input_layernorm, eps)
+        qw, qz, sc, zo = self.qkv_proj.fast_params()
+        qkv_slabs, _ = ops.wna16_gemm_packed(packed, m, h, qw, qz, sc, zo, partials=True)
+        from .attention.paged_attn import PagedAttention
+        key_cache, value_cache = PagedAttention.split_kv_cache(kv_cache, self.num_kv_heads, self.head_dim)
+        q = ops.rope_cache(None, qkv_slabs, positions, cos_sin, True, key_cache, value_cache,
+                           attn_metadata.slot_mapping, self.num_heads, self.num_kv_heads, self.head_dim,
+                           self.attn.kv_cache_dtype, self.k_scale, self.v_scale)
+        attn_packed, _ = ops.paged_attention_packed(
+            q.view(m, self.num_heads, self.head_dim), key_cache, value_cache, self.num_kv_heads,
+            self.attn.scale, attn_metadata.block_tables, attn_metadata.seq_lens_tensor,
+            value_cache.shape[3], attn_metadata.max_decode_seq_len, None, self.attn.kv_cache_dtype,
+            self.k_scale, self.v_scale)
+        qw, qz, sc, zo = self.o_proj.fast_params()
+        o_slabs, _ = ops.wna16_gemm_packed(attn_packed, m, self.q_size, qw, qz, sc, zo, partials=True)
+        packed2, _ = ops.fused_add_rms_norm_pack(None, o_slabs, residual, True,
+                                                 self.post_attention_layernorm, eps)
+        qw, qz, sc, zo = self.gate_up_proj.fast_params()
+        gate_up = ops.wna16_gemm_packed(packed2, m, h, qw, qz, sc, zo, partials=False)
+        act_packed = ops.silu_and_mul_pack(gate_up)
+        qw, qz, sc, zo = self.down_proj.fast_params()
+        down_slabs, _ = ops.wna16_gemm_packed(act_packed, m, self.down_proj.in_features, qw, qz, sc, zo,
+                                              partials=True)
+        return down_slabs
 
     def forward(self, positions, hidden, residual, kv_cache, attn_metadata, cos_sin):
         eps = self.cfg.rms_norm_eps
@@ -167,6 +221,7 @@ class LlamaForCausalLM(nn.Module):
             torch.empty(cfg.vocab_size // tp, cfg.hidden_size, dtype=dtype),
             requires_grad=False)
         self.cos_sin = None
+        self.use_fused_decode = True
 
     # -- synthetic weights in the real formats -----------------------------------
     @torch.no_grad()
@@ -206,6 +261,17 @@ class LlamaForCausalLM(nn.Module):
 
     def forward(self, input_ids, positions, kv_caches, attn_metadata):
         hidden = self.embed_tokens[input_ids]
+        if (self.use_fused_decode and attn_metadata.num_prefill_tokens == 0
+                and attn_metadata.num_decode_tokens > 0
+                and all(l.fused_decode_ok(hidden.shape[0]) for l in self.layers)):
+            residual = torch.empty_like(hidden)
+            slabs = None
+            for i, layer in enumerate(self.layers):
+                slabs = layer.forward_decode_fused(positions, hidden, slabs, residual, i == 0,
+                                                   kv_caches[i], attn_metadata, self.cos_sin)
+            _, out = ops.fused_add_rms_norm_pack(None, slabs, residual, True, self.norm,
+                                                 self.cfg.rms_norm_eps, pack=False, want_out=True)
+            return out
         residual = None
         for i, layer in enumerate(self.layers):
             hidden, residual = layer(positions, hidden, residual, kv_caches[i],

@@ -79,6 +79,24 @@ int aphro_gptq_gemm(const void* a, const uint32_t* q_weight, const uint32_t* qze
                     int zero_offset, int dtype, void* stream);
 size_t aphro_wna16_workspace_bytes(int64_t M, int64_t N, int64_t K);
 
+/* The fast W4A16 kernel consumes the activations FRAGMENT-MAJOR (f16): block
+ * (seg = k/128, u = (k%32)/8, mtile = m/16) is 1 KiB, lane (g = (k%128)/32, m%16)
+ * holds the 8 halfs A[m][k..k+7].  aphro_gptq_gemm packs internally; the decode
+ * fast path packs once in the producer (fused norm / activation / attention
+ * epilogue) and calls aphro_wna16_gemm_packed.  With c == NULL the fp32 split-K
+ * slabs [ksplit][M][N] are left in `partials` for a fused consumer
+ * (aphro_fused_add_rms_norm_pack, aphro_rope_cache) -- the gptq_marlin_gemm role
+ * (kernels/torch_bindings.cpp:195-201) with use_fp32_reduce, re-designed. */
+size_t aphro_wna16_packed_a_bytes(int64_t M, int64_t K);
+int aphro_wna16_pack_a(const void* a, const int32_t* perm, void* packed, int64_t M,
+                       int64_t K, int64_t lda, int dtype, void* stream);
+int aphro_wna16_ksplit(int64_t M, int64_t N, int64_t K, int64_t groups);
+int aphro_wna16_gemm_packed(const void* a_packed, const uint32_t* q_weight,
+                            const uint32_t* qzeros, const void* scales, void* c,
+                            float* partials, size_t partial_bytes, int64_t M, int64_t N,
+                            int64_t K, int64_t groups, int zero_offset, int dtype,
+                            void* stream);
+
 /* Reconstruct W[K,N] (dtype f16|bf16) from a GPTQ tensor set
  *   q_gemm.cu:1394-1434 (reconstruct_gptq, shuffled=0, g_idx int32 [K] or NULL)
  *   q_gemm.cu:856-965   (reconstruct_exllama, shuffled=1, perm ignored: rows are
@@ -167,6 +185,19 @@ int aphro_paged_attention(void* out, float* exp_sums, float* max_logits,
                           float k_scale, float v_scale, int partition_size,
                           void* stream);
 
+/* Same kernel in its single-launch (v1) form, additionally writing the output
+ * fragment-major (f16) for the o_proj GEMM of the decode fast path; `out` may be
+ * NULL. */
+int aphro_paged_attention_packed(void* out, void* out_packed, const void* query,
+                                 const void* key_cache, const void* value_cache,
+                                 int num_seqs, int num_heads, int num_kv_heads,
+                                 int head_size, float scale, const int32_t* block_tables,
+                                 const int32_t* seq_lens, int max_num_blocks_per_seq,
+                                 int block_size, int max_seq_len, const float* alibi_slopes,
+                                 int64_t q_stride, int64_t kv_block_stride,
+                                 int64_t kv_head_stride, int dtype, int kv_dtype,
+                                 float k_scale, float v_scale, void* stream);
+
 /* ------------------------------------------------------------------------
  * FP8 activations + GEMMs (rows a9-a11)
  * ---------------------------------------------------------------------- */
@@ -226,6 +257,29 @@ int aphro_rotary_embedding(const int64_t* positions, void* query, void* key,
                            int head_size, int rot_dim, const void* cos_sin_cache,
                            int64_t query_stride, int64_t key_stride, int is_neox,
                            int dtype, void* stream);
+
+/* Fused glue of the decode fast path.  Each reproduces the
+ * unfused op sequence bit for bit:
+ *  fused_add_rms_norm_pack: x = input (dtype) or the sum of `nslab` fp32 slabs
+ *    [nslab][T][hidden] rounded to dtype; residual' = x + residual (in place;
+ *    has_residual == 0: residual' = x, stored if residual != NULL);
+ *    y = rms_norm(residual') * weight -> `packed` (fragment-major f16) and/or `out`.
+ *    (_C::fused_add_rms_norm, kernels/layernorm_kernels.cu:200-240)
+ *  silu_and_mul_pack: _C::silu_and_mul -> packed and/or row-major.
+ *  rope_cache: qkv row (dtype, or fp32 slabs) -> _C::rotary_embedding on q,k then
+ *    _C_cache_ops::reshape_and_cache; q_out [T, Hq*hd] (dtype). */
+int aphro_fused_add_rms_norm_pack(const void* input, const float* slabs, int nslab,
+                                  void* residual, int has_residual, const void* weight,
+                                  float eps, void* packed, void* out, int64_t tokens,
+                                  int hidden, int dtype, void* stream);
+int aphro_silu_and_mul_pack(const void* input, void* packed, void* out, int64_t tokens,
+                            int d, int dtype, void* stream);
+int aphro_rope_cache(const void* qkv, int64_t qkv_stride, const float* slabs, int nslab,
+                     const int64_t* positions, const void* cos_sin_cache, int rot_dim,
+                     int is_neox, void* q_out, void* key_cache, void* value_cache,
+                     const int64_t* slot_mapping, int64_t tokens, int num_heads,
+                     int num_kv_heads, int head_size, int block_size, int x, int dtype,
+                     int kv_dtype, float k_scale, float v_scale, void* stream);
 
 /* ------------------------------------------------------------------------
  * Prefill attention (row a5): causal varlen flash attention on MFMA.

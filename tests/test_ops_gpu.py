@@ -571,3 +571,167 @@ def test_gptq_gemm_full_size_linearity(ops, K, N):
     assert (yab - (ya + yb)).abs().max().item() < 6e-3 * scale_
     # determinism: no atomics anywhere in the path
     assert torch.equal(ya, ops.gptq_gemm(a, qw, qz, s, empty, True, 4).float())
+
+
+# ---------------------------------------------------------------------------
+# decode fast path: fragment-major activations + fused glue (bit-exact vs the
+# unfused op sequence)
+# ---------------------------------------------------------------------------
+def unpack_a(packed, M, K):
+    """numpy inverse of the fragment-major layout (include/aphrodite_mi355x.h)."""
+    mt = (M + 15) // 16
+    p = packed.cpu().numpy().view(np.uint16)[: (K // 128) * 4 * mt * 64 * 8].reshape(K // 128, 4, mt, 4, 16, 8)
+    # dims: seg, u, mtile, g, m, j  ->  row = 16*mtile + m, k = 128*seg + 32*g + 8*u + j
+    a = p.transpose(2, 4, 0, 3, 1, 5).reshape(mt * 16, K)
+    return a[:M]
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,K", [(1, 128), (32, 512), (33, 256), (64, 1024)])
+def test_pack_a(ops, dtype, M, K):
+    rng = np.random.default_rng(M + K)
+    a = t(rng.standard_normal((M, K + 64)).astype(np.float32), dtype)[:, :K]      # strided rows
+    got = unpack_a(ops.wna16_pack_a(a), M, K)
+    ref = a.to(torch.float16).cpu().numpy().view(np.uint16)
+    np.testing.assert_array_equal(got, ref)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("nslab", [0, 1, 3])
+@pytest.mark.parametrize("has_res", [True, False])
+def test_fused_add_rms_norm_pack(ops, dtype, nslab, has_res):
+    rng = np.random.default_rng(nslab * 7 + has_res)
+    T_, H = 19, 1024
+    w = t((rng.standard_normal(H) * 0.1 + 1).astype(np.float32), dtype)
+    res = t(rng.standard_normal((T_, H)).astype(np.float32), dtype)
+    if nslab:
+        slabs = t(rng.standard_normal((nslab, T_, H)).astype(np.float32))
+        x = slabs.sum(0) if nslab == 1 else (slabs[0] + slabs[1] + slabs[2])
+        x = x.to(dtype)
+        xin = None
+    else:
+        slabs = None
+        x = t(rng.standard_normal((T_, H)).astype(np.float32), dtype)
+        xin = x.clone()
+    # unfused reference sequence on the device ops
+    r_ref = res.clone()
+    x_ref = x.clone()
+    if has_res:
+        ops.fused_add_rms_norm(x_ref, r_ref, w, 1e-5)
+    else:
+        r_ref = x.clone()
+        out = torch.empty_like(x_ref)
+        ops.rms_norm(out, x_ref, w, 1e-5)
+        x_ref = out
+    r_got = res.clone()
+    packed, out = ops.fused_add_rms_norm_pack(xin, slabs, r_got, has_res, w, 1e-5, pack=True, want_out=True)
+    assert torch.equal(out, x_ref)
+    assert torch.equal(r_got, r_ref)
+    np.testing.assert_array_equal(unpack_a(packed, T_, H), x_ref.to(torch.float16).cpu().numpy().view(np.uint16))
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_silu_and_mul_pack(ops, dtype):
+    rng = np.random.default_rng(31)
+    T_, d = 21, 1024
+    x = t(rng.standard_normal((T_, 2 * d)).astype(np.float32), dtype)
+    ref = torch.empty(T_, d, dtype=dtype, device=DEV)
+    ops.silu_and_mul(ref, x)
+    got = unpack_a(ops.silu_and_mul_pack(x), T_, d)
+    np.testing.assert_array_equal(got, ref.to(torch.float16).cpu().numpy().view(np.uint16))
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("kv_cache_dtype", ["auto", "fp8", "fp8_e5m2"])
+@pytest.mark.parametrize("nslab", [0, 2])
+def test_rope_cache_fused(ops, dtype, kv_cache_dtype, nslab):
+    from aphrodite_engine_amd.model import _rope_cache
+    rng = np.random.default_rng(33)
+    T_, Hq, Hkv, hd, BS, NB = 9, 8, 2, 128, 16, 6
+    ntot = (Hq + 2 * Hkv) * hd
+    cdt = dtype if kv_cache_dtype == "auto" else torch.uint8
+    x = 16 // torch.tensor([], dtype=cdt).element_size()
+    cs = _rope_cache(hd, 512, 10000.0, dtype, DEV)
+    pos = t(rng.integers(0, 512, size=T_).astype(np.int64))
+    slots = rng.permutation(NB * BS)[:T_].astype(np.int64)
+    slots[2] = -1
+    if nslab:
+        slabs = t(rng.standard_normal((nslab, T_, ntot)).astype(np.float32))
+        qkv = (slabs[0] + slabs[1]).to(dtype)
+        qin = None
+    else:
+        slabs = None
+        qkv = t(rng.standard_normal((T_, ntot)).astype(np.float32), dtype)
+        qin = qkv.clone()
+    ks, vs = (1.0, 1.0) if kv_cache_dtype == "auto" else (0.5, 0.25)
+    # unfused
+    ref = qkv.clone()
+    q, k, v = ref.split([Hq * hd, Hkv * hd, Hkv * hd], dim=-1)
+    ops.rotary_embedding(pos, q, k, hd, cs, True)
+    kc1 = torch.zeros(NB, Hkv, hd // x, BS, x, dtype=cdt, device=DEV)
+    vc1 = torch.zeros(NB, Hkv, hd, BS, dtype=cdt, device=DEV)
+    ops.reshape_and_cache(k.view(T_, Hkv, hd), v.view(T_, Hkv, hd), kc1, vc1, t(slots), kv_cache_dtype, ks, vs)
+    # fused
+    kc2, vc2 = torch.zeros_like(kc1), torch.zeros_like(vc1)
+    q2 = ops.rope_cache(qin, slabs, pos, cs, True, kc2, vc2, t(slots), Hq, Hkv, hd, kv_cache_dtype, ks, vs)
+    assert torch.equal(q2, q.contiguous())
+    assert torch.equal(kc2, kc1) and torch.equal(vc2, vc1)
+
+
+def test_paged_attention_packed_matches_v1(ops):
+    rng = np.random.default_rng(35)
+    S, Hq, Hkv, D, BS = 19, 8, 2, 128, 16
+    seq_lens = rng.integers(1, 300, size=S).astype(np.int32)
+    bps = 19
+    NB = S * bps
+    kc, vc = make_cache(rng, NB, Hkv, D, BS, torch.float16, "auto")
+    bt = rng.permutation(NB).reshape(S, bps).astype(np.int32)
+    q = t(rng.standard_normal((S, Hq, D)).astype(np.float32), torch.float16)
+    out = torch.empty_like(q)
+    ops.paged_attention_v1(out, q, kc, vc, Hkv, 0.09, t(bt), t(seq_lens), BS, 300, None, "auto", 1.0, 1.0)
+    packed, out2 = ops.paged_attention_packed(q, kc, vc, Hkv, 0.09, t(bt), t(seq_lens), BS, 300, None,
+                                              "auto", 1.0, 1.0, want_out=True)
+    assert torch.equal(out, out2)
+    np.testing.assert_array_equal(unpack_a(packed, S, Hq * D),
+                                  out.view(S, Hq * D).cpu().numpy().view(np.uint16))
+
+
+@pytest.mark.parametrize("M", [1, 16, 32, 64])
+@pytest.mark.parametrize("K,N", [(512, 256), (1024, 64), (3584, 128), (4096, 192)])
+def test_wna16_gemm_packed_paths(ops, M, K, N):
+    """packed-A entry point: direct output and fp32-slab output agree with the op."""
+    rng = np.random.default_rng(M + K + N)
+    qweight, qzeros, s, _ = make_gptq(rng, K, N, 128)
+    a = t(rng.standard_normal((M, K)).astype(np.float16))
+    shuf = t(oq.gptq_shuffle(qweight))
+    empty = torch.empty(0, dtype=torch.int32, device=DEV)
+    ref = ops.gptq_gemm(a, shuf, t(qzeros), t(s, torch.float16), empty, True, 4)
+    ap = ops.wna16_pack_a(a)
+    got = ops.wna16_gemm_packed(ap, M, K, shuf, t(qzeros), t(s, torch.float16), 1, partials=False)
+    assert torch.equal(got, ref)
+    slabs, ks = ops.wna16_gemm_packed(ap, M, K, shuf, t(qzeros), t(s, torch.float16), 1, partials=True)
+    acc = slabs[0].clone()
+    for i in range(1, ks):
+        acc += slabs[i]
+    assert torch.equal(acc.to(torch.float16), ref)
+
+
+def test_fused_decode_model_matches_unfused(ops):
+    """Whole decode step: fused fast path vs the op-by-op path of the same model."""
+    from aphrodite_engine_amd import model as M
+    from aphrodite_engine_amd.quantization.gptq import GPTQConfig
+    with torch.no_grad():
+        m = M.LlamaForCausalLM(M.TINY, GPTQConfig(4, 128, False), torch.float16)
+        m.init_synthetic(torch.device(DEV))
+        meta, pos, nblocks = M.make_decode_metadata(5, [3, 17, 64, 200, 129], 16, DEV)
+        ids = torch.randint(0, M.TINY.vocab_size, (5, ), device=DEV)
+        outs, caches_all = [], []
+        for fused in (False, True):
+            caches = M.make_kv_caches(M.TINY, nblocks, 16, torch.float16, "auto", DEV, seed=3)
+            m.use_fused_decode = fused
+            assert all(l.fused_decode_ok(5) for l in m.layers)
+            outs.append(m(ids, pos, caches, meta).float())
+            caches_all.append(caches)
+        torch.testing.assert_close(outs[0], outs[1], atol=2e-2, rtol=2e-2)
+        # layer-0 cache writes are identical (same rounded q/k/v, same slots)
+        assert torch.equal(caches_all[0][0], caches_all[1][0])
