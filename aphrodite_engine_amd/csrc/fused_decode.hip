@@ -215,6 +215,104 @@ __global__ void rope_cache_kernel(const uint16_t* __restrict__ qkv, int64_t qkv_
   }
 }
 
+// Vectorised form of rope_cache_kernel for the common case (NeoX rotary over the
+// whole head, head_size % 16 == 0): one thread = 8 consecutive dims of the first
+// half of a head and their 8 partners in the second half; 16-byte loads/stores.
+template <typename T, int KV>
+__global__ void rope_cache_vec_kernel(const uint16_t* __restrict__ qkv, int64_t qkv_stride,
+                                      const float* __restrict__ slabs, int nslab, int tokens,
+                                      const int64_t* __restrict__ positions, const uint16_t* __restrict__ cos_sin,
+                                      uint16_t* __restrict__ q_out, void* __restrict__ key_cache,
+                                      void* __restrict__ value_cache, const int64_t* __restrict__ slot_mapping,
+                                      int num_heads, int num_kv_heads, int head_size, int block_size, int x,
+                                      float k_scale, float v_scale) {
+  const int tok = blockIdx.x;
+  const int nq = num_heads * head_size, nkv = num_kv_heads * head_size;
+  const int ntot = nq + 2 * nkv;
+  const size_t slab_stride = (size_t)tokens * ntot;
+  auto val8 = [&](int j, float (&o)[8]) {  // 8 consecutive elements from j (j % 8 == 0), rounded to T
+    if (slabs) {
+      const float* p0 = slabs + (size_t)tok * ntot + j;
+      f32x4 a = *reinterpret_cast<const f32x4*>(p0), b = *reinterpret_cast<const f32x4*>(p0 + 4);
+      for (int k = 1; k < nslab; ++k) {
+        a += *reinterpret_cast<const f32x4*>(p0 + k * slab_stride);
+        b += *reinterpret_cast<const f32x4*>(p0 + k * slab_stride + 4);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        o[i] = T::to_f32(T::from_f32(a[i]));
+        o[4 + i] = T::to_f32(T::from_f32(b[i]));
+      }
+    } else {
+      u16x8 v = *reinterpret_cast<const u16x8*>(qkv + (size_t)tok * qkv_stride + j);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[i] = T::to_f32(v[i]);
+    }
+  };
+  const int64_t pos = positions[tok];
+  const int half = head_size >> 1;
+  const uint16_t* cs = cos_sin + pos * head_size;
+  const int64_t slot = slot_mapping[tok];
+  const int64_t blk = slot >= 0 ? slot / block_size : 0, off = slot >= 0 ? slot % block_size : 0;
+  const int cph = half >> 3;  // chunks per head (first half)
+  const int nrope = (num_heads + num_kv_heads) * cph;
+  const int nv = nkv >> 3;
+  for (int i = threadIdx.x; i < nrope + nv; i += blockDim.x) {
+    if (i < nrope) {
+      const int h = i / cph, d0 = (i % cph) * 8;
+      const bool is_k = h >= num_heads;
+      const int base = is_k ? nq + (h - num_heads) * head_size : h * head_size;
+      float xv[8], yv[8];
+      val8(base + d0, xv);
+      val8(base + half + d0, yv);
+      u16x8 c8 = *reinterpret_cast<const u16x8*>(cs + d0);
+      u16x8 s8 = *reinterpret_cast<const u16x8*>(cs + half + d0);
+      u16x8 xo8, yo8;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float xo, yo;
+        rope_pair(xv[j], yv[j], T::to_f32(c8[j]), T::to_f32(s8[j]), xo, yo);
+        xo8[j] = T::from_f32(xo);
+        yo8[j] = T::from_f32(yo);
+      }
+      if (!is_k) {
+        *reinterpret_cast<u16x8*>(q_out + (size_t)tok * nq + base + d0) = xo8;
+        *reinterpret_cast<u16x8*>(q_out + (size_t)tok * nq + base + half + d0) = yo8;
+      } else if (slot >= 0) {
+        const int hk = h - num_heads;
+#pragma unroll
+        for (int part = 0; part < 2; ++part) {
+          const int d = part ? half + d0 : d0;
+          const u16x8& o8 = part ? yo8 : xo8;
+          const int64_t dst = (((blk * num_kv_heads + hk) * (head_size / x) + d / x) * block_size + off) * x + d % x;
+          if constexpr (KV == 0) {
+            *reinterpret_cast<u16x8*>((uint16_t*)key_cache + dst) = o8;
+          } else {
+            uint32_t w0 = 0, w1 = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j += 2) {
+              w0 |= f32x2_to_fp8<KV == 2>(T::to_f32(o8[j]) / k_scale, T::to_f32(o8[j + 1]) / k_scale) << (8 * j);
+              w1 |= f32x2_to_fp8<KV == 2>(T::to_f32(o8[4 + j]) / k_scale, T::to_f32(o8[5 + j]) / k_scale) << (8 * j);
+            }
+            *reinterpret_cast<u32x2*>((uint8_t*)key_cache + dst) = u32x2{w0, w1};
+          }
+        }
+      }
+    } else if (slot >= 0) {
+      const int e = (i - nrope) * 8;
+      const int h = e / head_size, d = e % head_size;
+      float v[8];
+      val8(nq + nkv + e, v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int64_t dst = ((blk * num_kv_heads + h) * head_size + d + j) * block_size + off;
+        if constexpr (KV == 0) ((uint16_t*)value_cache)[dst] = T::from_f32(v[j]);
+        else ((uint8_t*)value_cache)[dst] = (uint8_t)f32x2_to_fp8<KV == 2>(v[j] / v_scale, 0.f);
+      }
+    }
+  }
+}
+
 }  // namespace aphro
 
 using namespace aphro;
@@ -270,6 +368,22 @@ extern "C" int aphro_rope_cache(const void* qkv, int64_t qkv_stride, const float
   APHRO_CHECK(rot_dim % 2 == 0 && rot_dim <= head_size && head_size % x == 0, "rope_cache: bad rot_dim / x");
   if (tokens == 0) return APHRO_OK;
   dim3 grid((unsigned)tokens), block(512);
+  if (is_neox && rot_dim == head_size && head_size % 16 == 0 && (x == 8 || x == 16) &&
+      (qkv == nullptr || (qkv_stride % 8 == 0 && ((uintptr_t)qkv % 16) == 0))) {
+    const int work = (num_heads + num_kv_heads) * (head_size / 16) + num_kv_heads * head_size / 8;
+    dim3 vblock((unsigned)(work >= 512 ? 512 : (work + 63) / 64 * 64));
+#define LV(TT, KVV)                                                                                             \
+  hipLaunchKernelGGL((rope_cache_vec_kernel<TT, KVV>), grid, vblock, 0, (hipStream_t)stream, (const uint16_t*)qkv, \
+                     qkv_stride, slabs, nslab, (int)tokens, positions, (const uint16_t*)cos_sin_cache,           \
+                     (uint16_t*)q_out, key_cache, value_cache, slot_mapping, num_heads, num_kv_heads, head_size, \
+                     block_size, x, k_scale, v_scale)
+#define LVK(TT) { if (kv_dtype == APHRO_KV_AUTO) LV(TT, 0); else if (kv_dtype == APHRO_KV_FP8_E4M3) LV(TT, 1); else LV(TT, 2); }
+    if (dtype == APHRO_F16) LVK(Half) else LVK(BFloat)
+#undef LVK
+#undef LV
+    APHRO_LAUNCH_CHECK();
+    return APHRO_OK;
+  }
 #define L(TT, KVV, NX)                                                                                          \
   hipLaunchKernelGGL((rope_cache_kernel<TT, KVV, NX>), grid, block, 0, (hipStream_t)stream, (const uint16_t*)qkv, \
                      qkv_stride, slabs, nslab, (int)tokens, positions, (const uint16_t*)cos_sin_cache, rot_dim,  \

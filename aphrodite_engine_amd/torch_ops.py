@@ -1,0 +1,110 @@
+"""Registers the MI355X kernels as the torch.library ops the reference binds
+(`kernels/torch_bindings.cpp`, `kernels/rocm/torch_bindings.cpp`): after
+``import aphrodite_engine_amd.torch_ops`` (or the ``aphrodite.general_plugins``
+entry point in ``plugin.py``) the reference's own ``aphrodite/_custom_ops.py``
+resolves ``torch.ops._C.*`` / ``_C_cache_ops.*`` / ``_rocm_C.*`` to this library
+without any change.  Schemas are the reference's, verbatim (file:line in the
+table below); implementations are registered for the CUDA(HIP) dispatch key and
+forward to ``aphrodite_engine_amd._custom_ops``.
+"""
+from typing import Optional
+
+import torch
+
+from . import _custom_ops as ops
+
+_LIBS = []
+_REGISTERED = False
+
+# (namespace, schema, python impl)            reference torch_bindings.cpp line
+_C_OPS = [
+    ("paged_attention_v1(Tensor! out, Tensor query, Tensor key_cache, Tensor value_cache, int num_kv_heads, "
+     "float scale, Tensor block_tables, Tensor seq_lens, int block_size, int max_seq_len, Tensor? alibi_slopes, "
+     "str kv_cache_dtype, float k_scale, float v_scale, int tp_rank, int blocksparse_local_blocks, "
+     "int blocksparse_vert_stride, int blocksparse_block_size, int blocksparse_head_sliding_step) -> ()",
+     ops.paged_attention_v1),                                                              # :25-35
+    ("paged_attention_v2(Tensor! out, Tensor! exp_sums, Tensor! max_logits, Tensor! tmp_out, Tensor query, "
+     "Tensor key_cache, Tensor value_cache, int num_kv_heads, float scale, Tensor block_tables, Tensor seq_lens, "
+     "int block_size, int max_seq_len, Tensor? alibi_slopes, str kv_cache_dtype, float k_scale, float v_scale, "
+     "int tp_rank, int blocksparse_local_blocks, int blocksparse_vert_stride, int blocksparse_block_size, "
+     "int blocksparse_head_sliding_step) -> ()", ops.paged_attention_v2),                  # :38-49
+    ("gptq_gemm(Tensor a, Tensor b_q_weight, Tensor b_gptq_qzeros, Tensor b_gptq_scales, Tensor b_g_idx, "
+     "bool use_exllama, int bit) -> Tensor", ops.gptq_gemm),                               # :357-361
+    ("gptq_shuffle(Tensor! q_weight, Tensor q_perm, int bit) -> ()", ops.gptq_shuffle),    # :364-365
+    ("awq_gemm(Tensor _in_feats, Tensor _kernel, Tensor _scaling_factors, Tensor _zeros, int split_k_iters) "
+     "-> Tensor", ops.awq_gemm),                                                           # :142-145
+    ("awq_dequantize(Tensor _kernel, Tensor _scaling_factors, Tensor _zeros, int split_k_iters, int thx, "
+     "int thy) -> Tensor", ops.awq_dequantize),                                            # :148-151
+    ("rms_norm(Tensor! out, Tensor input, Tensor weight, float epsilon) -> ()", ops.rms_norm),          # :101-105
+    ("fused_add_rms_norm(Tensor! input, Tensor! residual, Tensor weight, float epsilon) -> ()",
+     ops.fused_add_rms_norm),                                                              # :108-111
+    ("silu_and_mul(Tensor! out, Tensor input) -> ()", ops.silu_and_mul),                   # :56-57
+    ("rotary_embedding(Tensor positions, Tensor! query, Tensor! key, int head_size, Tensor cos_sin_cache, "
+     "bool is_neox) -> ()", ops.rotary_embedding),                                         # :117-121
+]
+
+
+def _static_scaled_fp8_quant(out, input, scale):
+    q, _ = ops.scaled_fp8_quant(input, scale)
+    out.view(torch.uint8).copy_(q.view(torch.uint8))
+
+
+def _dynamic_scaled_fp8_quant(out, input, scale):
+    q, s = ops.scaled_fp8_quant(input)
+    out.view(torch.uint8).copy_(q.view(torch.uint8))
+    scale.copy_(s)
+
+
+def _dynamic_per_token_scaled_fp8_quant(out, input, scale, scale_ub: Optional[torch.Tensor]):
+    q, s = ops.scaled_fp8_quant(input, scale_ub=scale_ub, use_per_token_if_dynamic=True)
+    out.view(torch.uint8)[:q.shape[0]].copy_(q.view(torch.uint8))
+    scale[:s.shape[0]].copy_(s)
+
+
+def _cutlass_scaled_mm(out, a, b, a_scales, b_scales, bias: Optional[torch.Tensor]):
+    out.copy_(ops.cutlass_scaled_mm(a, b, a_scales, b_scales, out.dtype, bias))
+
+
+_C_OPS += [
+    ("static_scaled_fp8_quant(Tensor! out, Tensor input, Tensor scale) -> ()", _static_scaled_fp8_quant),   # :374-376
+    ("dynamic_scaled_fp8_quant(Tensor! out, Tensor input, Tensor! scale) -> ()", _dynamic_scaled_fp8_quant),  # :379-382
+    ("dynamic_per_token_scaled_fp8_quant(Tensor! out, Tensor input, Tensor! scale, Tensor? scale_ub) -> ()",
+     _dynamic_per_token_scaled_fp8_quant),                                                 # :385-390
+    ("cutlass_scaled_mm(Tensor! out, Tensor a, Tensor b, Tensor a_scales, Tensor b_scales, Tensor? bias) -> ()",
+     _cutlass_scaled_mm),                                                                  # :235-239
+    ("cutlass_scaled_mm_supports_fp8(int cuda_device_capability) -> bool",
+     ops.cutlass_scaled_mm_supports_fp8),                                                  # :242-244
+]
+
+_CACHE_OPS = [
+    ("reshape_and_cache(Tensor key, Tensor value, Tensor! key_cache, Tensor! value_cache, Tensor slot_mapping, "
+     "str kv_cache_dtype, float k_scale, float v_scale) -> ()", ops.reshape_and_cache),    # :467-473
+    ("convert_fp8(Tensor! dst_cache, Tensor src_cache, float scale, str kv_cache_dtype) -> ()",
+     ops.convert_fp8),                                                                     # :487-490
+]
+
+_ROCM_OPS = [
+    ("paged_attention(Tensor! out, Tensor exp_sums, Tensor max_logits, Tensor tmp_out, Tensor query, "
+     "Tensor key_cache, Tensor value_cache, int num_kv_heads, float scale, Tensor block_tables, "
+     "Tensor context_lens, int block_size, int max_context_len, Tensor? alibi_slopes, str kv_cache_dtype, "
+     "float k_scale, float v_scale) -> ()", ops.paged_attention_rocm),   # kernels/rocm/torch_bindings.cpp:17-28
+]
+
+
+def register(ns_c: str = "_C", ns_cache: str = "_C_cache_ops", ns_rocm: str = "_rocm_C") -> None:
+    """Idempotent.  Pass other namespaces to avoid clashing with an already
+    loaded ``aphrodite._C`` (e.g. in A/B comparisons)."""
+    global _REGISTERED
+    if _REGISTERED:
+        return
+    for ns, table in ((ns_c, _C_OPS), (ns_cache, _CACHE_OPS), (ns_rocm, _ROCM_OPS)):
+        lib = torch.library.Library(ns, "FRAGMENT")
+        for schema, fn in table:
+            name = schema.split("(", 1)[0]
+            lib.define(schema)
+            if name == "cutlass_scaled_mm_supports_fp8":
+                lib.impl(name, fn, "CompositeExplicitAutograd")
+            else:
+                lib.impl(name, fn, "CUDA")
+        _LIBS.append(lib)
+    _REGISTERED = True

@@ -180,3 +180,27 @@ def test_tensor_parallel_collectives_gloo():
         assert rank == tp_rank
         assert y == [[3.0] * 4] * 3                               # 1 + 2
         assert g == [[0.0, 0.0, 0.0, 1.0, 1.0, 1.0]] * 2          # concatenated on dim -1
+
+
+def test_torch_library_registration():
+    """The reference's op schemas resolve to our implementations
+    (aphrodite_engine_amd/torch_ops.py); registered under private namespaces here
+    so the test cannot clash with a real aphrodite._C."""
+    from aphrodite_engine_amd import torch_ops
+    torch_ops._REGISTERED = False
+    torch_ops.register("_aphro_t_C", "_aphro_t_cache", "_aphro_t_rocm")
+    for name in ("paged_attention_v1", "paged_attention_v2", "gptq_gemm", "gptq_shuffle", "awq_gemm",
+                 "awq_dequantize", "static_scaled_fp8_quant", "dynamic_scaled_fp8_quant",
+                 "dynamic_per_token_scaled_fp8_quant", "cutlass_scaled_mm", "rms_norm",
+                 "fused_add_rms_norm", "silu_and_mul", "rotary_embedding"):
+        assert hasattr(torch.ops._aphro_t_C, name), name
+    assert hasattr(torch.ops._aphro_t_cache, "reshape_and_cache")
+    assert hasattr(torch.ops._aphro_t_rocm, "paged_attention")
+    assert torch.ops._aphro_t_C.cutlass_scaled_mm_supports_fp8(95) is True
+    # CPU tensors have no kernel registered: dispatch fails loudly, no fallback
+    with pytest.raises((RuntimeError, NotImplementedError)):
+        torch.ops._aphro_t_C.gptq_gemm(torch.zeros(1, 64, dtype=torch.half),
+                                       torch.zeros(8, 16, dtype=torch.int32),
+                                       torch.zeros(1, 2, dtype=torch.int32),
+                                       torch.zeros(1, 16, dtype=torch.half),
+                                       torch.empty(0, dtype=torch.int32), True, 4)
