@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""Runs the decode attention kernel a few times (for rocprofv3 --pmc / --kernel-trace)."""
+import os
+import sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from aphrodite_engine_amd import _custom_ops as ops  # noqa: E402
+ctx = int(sys.argv[1]) if len(sys.argv) > 1 else 1040
+kvd = sys.argv[2] if len(sys.argv) > 2 else "auto"
+bs, Hq, Hkv, D, BS = 32, 32, 8, 128, 16
+bps = (ctx + BS - 1) // BS
+nb = bs * bps
+caches = []
+for _ in range(6):
+    if kvd == "auto":
+        caches.append((torch.randn(nb, Hkv, D // 8, BS, 8, device="cuda", dtype=torch.float16) * 0.1,
+                       torch.randn(nb, Hkv, D, BS, device="cuda", dtype=torch.float16) * 0.1))
+    else:
+        caches.append((torch.randint(0, 0x48, (nb, Hkv, D // 16, BS, 16), device="cuda", dtype=torch.uint8),
+                       torch.randint(0, 0x48, (nb, Hkv, D, BS), device="cuda", dtype=torch.uint8)))
+bt = torch.randperm(nb, device="cuda").view(bs, bps).int()
+sl = torch.full((bs, ), ctx, dtype=torch.int32, device="cuda")
+q = torch.randn(bs, Hq, D, device="cuda", dtype=torch.float16)
+o = torch.empty_like(q)
+for _ in range(5):
+    for kc, vc in caches:
+        ops.paged_attention_v1(o, q, kc, vc, Hkv, D ** -0.5, bt, sl, BS, ctx, None, kvd, 1.0, 1.0)
+torch.cuda.synchronize()
