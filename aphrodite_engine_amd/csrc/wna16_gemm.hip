@@ -79,7 +79,7 @@ struct Wna16Params {
   int ksteps_per_split;   // k-steps (32 k) per blockIdx.y
   int ksplit;
   int zero_offset;
-  int dbg;                // unused
+  int gshift;             // log2(group_size / 128) (fast path)
   int force_partial;      // 1: write the fp32 slab even when ksplit == 1 (fused consumer)
 };
 
@@ -178,13 +178,23 @@ struct SegMeta {          // RAW group scale / zero words of one segment: no ALU
   uint32_t zw;                 // wait for the load -- and with it for every older weight load
 };
 
+// gfx950 buffer resource: base, no stride, byte count, DATA_FORMAT=32 (raw dword access)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+
 template <typename T, int VEC, int MT, int NSEG>
-__global__ __launch_bounds__(FNW * 64, 3) void wna16_gemm_kernel(Wna16Params p) {
+__global__ __launch_bounds__(FNW * 64, (VEC * MT >= 8) ? 2 : 3) void wna16_gemm_kernel(Wna16Params p) {
+#ifdef ABL_DEPTH
+  constexpr int DEPTH = NSEG < ABL_DEPTH ? NSEG : ABL_DEPTH;
+#else
   constexpr int DEPTH = NSEG < 2 ? NSEG : 2;  // weight segments in flight ahead of the consumer
+#endif
   constexpr int NBUF = DEPTH + 1;
+  constexpr int AUX_NT = 2;  // nontemporal: weights are read exactly once
   extern __shared__ __attribute__((aligned(16))) float red[];
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4;
   const int c = lane & 15;
   const int n0 = blockIdx.x * (16 * VEC);
@@ -192,107 +202,134 @@ __global__ __launch_bounds__(FNW * 64, 3) void wna16_gemm_kernel(Wna16Params p) 
   const int ncol = n0 + VEC * c;
   const int seg0 = (blockIdx.y * FNW + wave) * NSEG;  // host guarantees K == ksplit*FNW*NSEG*128
 
-  f32x4 acc[MT][VEC];
+  // All global reads are buffer loads: the per-lane part of every address is a loop-invariant
+  // VGPR offset, the (segment, k-step) part an SGPR offset -- no vector address arithmetic in
+  // the loop (the kernel is instruction-issue bound on the CUs that host two workgroups).
+  const int mtiles = (p.M + 15) >> 4;
+  const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.qw, (uint32_t)((size_t)(p.K >> 3) * p.N * 4));
+  const __amdgpu_buffer_rsrc_t ra = make_rsrc(p.apk, (uint32_t)((size_t)(p.K >> 7) * 4 * mtiles * 1024));
+  const int ngroups = p.K / p.group_size;
+  const __amdgpu_buffer_rsrc_t rs_ = make_rsrc(p.sc, (uint32_t)((size_t)ngroups * p.N * 2));
+  const __amdgpu_buffer_rsrc_t rz = make_rsrc(p.qz, (uint32_t)((size_t)ngroups * (p.N >> 3) * 4));
+  const int roww = p.N * 4;                       // bytes per packed weight row
+  const int voff_w = (4 * g * p.N + ncol) * 4;    // row 4g (+u via the SGPR offset), this lane's columns
+  int voff_a[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)  // surplus m-tiles of the last z-block read tile mtiles-1 again (never stored)
+    voff_a[i] = (min((m0 >> 4) + i, mtiles - 1) * 64 + lane) * 16;
+  const int abytes = mtiles * 1024;               // bytes per (segment, u) block row of the packed A
+  const int voff_s = ncol * 2;
+  const int voff_z = (ncol >> 3) * 4;
+  const int zshift = (ncol & 7) * 4;
+  const float zoff = (float)p.zero_offset;
+  // weights of the 8 fragment positions after the A pre-scale (see below)
+  const f16x8 ones = {(f16)1.f, (f16)1.f, (f16)16.f, (f16)16.f, (f16)1.f, (f16)1.f, (f16)16.f, (f16)16.f};
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+  f32x4 cacc[MT][VEC];
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll
-    for (int t = 0; t < VEC; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int mtiles = (p.M + 15) >> 4;
-  // surplus m-tiles of the last z-block read tile mtiles-1 again (never stored)
-  const uint16_t* apk = p.apk + ((size_t)seg0 * 4 * mtiles * 64 + lane) * 8;
-  int mt_idx[MT];
-#pragma unroll
-  for (int i = 0; i < MT; ++i) mt_idx[i] = min((m0 >> 4) + i, mtiles - 1);
-  auto a_frag = [&](int s, int u, int i) {
-    return *reinterpret_cast<const f16x8*>(apk + ((size_t)(s * 4 + u) * mtiles + mt_idx[i]) * 512);
-  };
-  const uint32_t* wbase = p.qw + ((size_t)seg0 * 16 + 4 * g) * p.N + ncol;
-  const int segs_per_group = p.group_size >> 7;
-  const int zshift = (ncol & 7) * 4;
-  uint32_t magic = 0x64006400u;
-  asm volatile("" : "+v"(magic));  // keep the f16 magic in a VGPR (see v_and_or)
+    for (int t = 0; t < VEC; ++t) cacc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   SegMeta<VEC> meta[2];
   uint32_t w[NBUF][4][VEC];
-  f16x8 af[4][MT];
+  u32x4 af[2][4][MT];
 
   auto load_meta = [&](SegMeta<VEC>& m, int s) {
-    const int grp = (seg0 + s) / segs_per_group;
-    const uint16_t* sp = p.sc + (size_t)grp * p.N + ncol;
-    m.zw = p.qz[(size_t)grp * (p.N >> 3) + (ncol >> 3)];
+    const int grp = (seg0 + s) >> p.gshift;  // group_size / 128 is a power of two on this path
+    m.zw = __builtin_amdgcn_raw_buffer_load_b32(rz, voff_z, grp * (p.N >> 3) * 4, 0);
     if constexpr (VEC == 4) {
-      u32x2 v = *reinterpret_cast<const u32x2*>(sp);
+      u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs_, voff_s, grp * p.N * 2, 0);
       m.sc[0] = v[0]; m.sc[1] = v[1];
-    } else if constexpr (VEC == 2) {
-      m.sc[0] = *reinterpret_cast<const uint32_t*>(sp);
     } else {
-      m.sc[0] = *sp;
+      m.sc[0] = __builtin_amdgcn_raw_buffer_load_b32(rs_, voff_s, grp * p.N * 2, 0);
     }
   };
   auto load_w = [&](uint32_t (&wd)[4][VEC], int s) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const uint32_t* wp = wbase + ((size_t)s * 16 + u) * p.N;
+      const int soff = ((seg0 + s) * 16 + u) * roww;
       if constexpr (VEC == 4) {
-        u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp));
+        u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rw, voff_w, soff, AUX_NT);
         wd[u][0] = v[0]; wd[u][1] = v[1]; wd[u][2] = v[2]; wd[u][3] = v[3];
-      } else if constexpr (VEC == 2) {
-        u32x2 v = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(wp));
-        wd[u][0] = v[0]; wd[u][1] = v[1];
       } else {
-        wd[u][0] = __builtin_nontemporal_load(wp);
+        u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rw, voff_w, soff, AUX_NT);
+        wd[u][0] = v[0]; wd[u][1] = v[1];
       }
     }
+  };
+  auto load_a = [&](u32x4 (&ad)[4][MT], int s) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+        ad[u][i] = __builtin_amdgcn_raw_buffer_load_b128(ra, voff_a[i], ((seg0 + s) * 4 + u) * abytes, 0);
   };
 
   // ---- prologue: meta(0), A(0), W(0..DEPTH-1) ---------------------------------------
   load_meta(meta[0], 0);
-#pragma unroll
-  for (int u = 0; u < 4; ++u)
-#pragma unroll
-    for (int i = 0; i < MT; ++i) af[u][i] = a_frag(0, u, i);
+  load_a(af[0], 0);
 #pragma unroll
   for (int d = 0; d < DEPTH; ++d) load_w(w[d], d);
   __builtin_amdgcn_sched_barrier(0);
 
 #pragma unroll
   for (int s = 0; s < NSEG; ++s) {
+    // straight-line code (NSEG is a template constant): hipcc's waitcnt insertion degrades to
+    // vmcnt(0) around runtime-conditional loads, and the issue points are pinned with
+    // sched_barrier (the scheduler otherwise sinks loads next to their first use).
+#ifndef ABL_NO_A
+    if (s + 1 < NSEG) load_a(af[(s + 1) & 1], s + 1);
+#endif
     if (s + DEPTH < NSEG) load_w(w[(s + DEPTH) % NBUF], s + DEPTH);
     if (s + 1 < NSEG) load_meta(meta[(s + 1) & 1], s + 1);
     __builtin_amdgcn_sched_barrier(0);
-    const SegMeta<VEC>& m = meta[s & 1];
-    f16x2 zh[VEC], zh16[VEC], sc[VEC];
-#pragma unroll
-    for (int t = 0; t < VEC; ++t) {
-      int z = (int)((m.zw >> (zshift + 4 * t)) & 0xf) + p.zero_offset;
-      f16 a = __builtin_bit_cast(f16, (uint16_t)(0x6400 | z));  // 1024 + z
-      f16 b = (f16)(float)(-64 - z);
-      const uint16_t sraw = (uint16_t)(m.sc[t >> 1] >> (16 * (t & 1)));
-      f16 s16;
-      if constexpr (__is_same(T, Half)) s16 = __builtin_bit_cast(f16, sraw);
-      else s16 = (f16)bf16_bits_to_f32(sraw);
-      zh[t] = f16x2{a, a};
-      zh16[t] = f16x2{b, b};
-      sc[t] = f16x2{s16, s16};
-    }
+    f32x4 acc[MT][VEC];  // sum_k a'[m][k] * q[k][n] * 2^-24 over this 128-k group
+    f32x4 rs[MT];        // sum_k a[m][k] (all 16 columns of the tile hold the same row sums)
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
+      f16x8 a[MT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        // nibbles 2,3,6,7 of a word are extracted in place (bits 4-7 of each half):
+        // they weigh 16x, so those four k of the A fragment are scaled by 1/16
+        // (inline asm on the integer lanes: hipcc miscompiles a bitcast of one vector element)
+        u32x4 av = af[s & 1][u][i];
+        asm("v_pk_mul_f16 %0, %1, %2" : "=v"(av[1]) : "v"(av[1]), "s"(0x2c002c00u));
+        asm("v_pk_mul_f16 %0, %1, %2" : "=v"(av[3]) : "v"(av[3]), "s"(0x2c002c00u));
+        a[i] = __builtin_bit_cast(f16x8, av);
+        rs[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], ones, u == 0 ? zero4 : rs[i], 0, 0, 0);
+      }
 #pragma unroll
       for (int t = 0; t < VEC; ++t) {
-        f16x8 b = dq8_exl_scaled(w[s % NBUF][u][t], zh[t], zh16[t], sc[t], magic);
+        // a nibble in the low mantissa bits of an f16 IS the subnormal q * 2^-24 -- the
+        // MFMA consumes subnormals exactly, so the unpack is four ANDs and one shift
+        const uint32_t wv = w[s % NBUF][u][t];
+        const uint32_t w8 = wv >> 8;
+        u32x4 bq = {wv & 0x000f000fu, wv & 0x00f000f0u, w8 & 0x000f000fu, w8 & 0x00f000f0u};
+        const f16x8 b = __builtin_bit_cast(f16x8, bq);
 #pragma unroll
         for (int i = 0; i < MT; ++i)
-          acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[u][i], b, acc[i][t], 0, 0, 0);
+          acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b, u == 0 ? zero4 : acc[i][t], 0, 0, 0);
       }
-      if (s + 1 < NSEG) {  // slot u is free: refill it for the next segment
+    }
+    // group epilogue (fp32): c += s * (2^24 * acc - z * rowsum)
+    const SegMeta<VEC>& m = meta[s & 1];
 #pragma unroll
-        for (int i = 0; i < MT; ++i) af[u][i] = a_frag(s + 1, u, i);
-        __builtin_amdgcn_sched_barrier(0);
+    for (int t = 0; t < VEC; ++t) {
+      const float z = (float)((m.zw >> (zshift + 4 * t)) & 0xf) + zoff;
+      const float sf = T::to_f32((uint16_t)(m.sc[t >> 1] >> (16 * (t & 1))));
+      const float s24 = sf * 16777216.f;
+      const float nzs = -z * sf;
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        cacc[i][t] = __builtin_elementwise_fma(acc[i][t], f32x4{s24, s24, s24, s24}, cacc[i][t]);
+        cacc[i][t] = __builtin_elementwise_fma(rs[i], f32x4{nzs, nzs, nzs, nzs}, cacc[i][t]);
       }
     }
   }
-  wna16_epilogue<T, VEC, MT, FNW>(p, red, acc, lane, wave, g, m0, ncol);
+  wna16_epilogue<T, VEC, MT, FNW>(p, red, cacc, lane, wave, g, m0, ncol);
 }
 
 // Generic path (any group size that is a multiple of 32): per-segment loads.
@@ -587,13 +624,16 @@ static Wna16Plan make_plan(int64_t M, int64_t N, int64_t K, int64_t gs) {
   int fv = env_int("APHRO_WNA16_VEC", 0);
   if (fv == 1 || fv == 2 || fv == 4) {
     if (N % (16 * fv) == 0) pl.vec = fv;
-  } else if (pl.vec == 4 && N / 64 < 192 && N % 32 == 0) {
-    pl.vec = 2;  // narrow N: 32-column tiles double the workgroup count
   }
+  // (64-column tiles even for narrow N: a 32-column tile doubles the A-fragment traffic per
+  //  weight byte, which costs more than the extra workgroups gain -- measured 10.3 vs 12.8 us
+  //  on the 14336x4096 down projection)
   pl.mt = (M > 16) ? 2 : 1;
   const int64_t tiles = N / (16 * pl.vec) * ((M + 16 * pl.mt - 1) / (16 * pl.mt));
   const int total_segs = (int)((K + 127) / 128);
-  pl.fast = (K % 128 == 0 && gs % 128 == 0 && pl.vec >= 2) && !env_int("APHRO_WNA16_GENERIC", 0);
+  const int64_t gq = gs >> 7;
+  pl.fast = (K % 128 == 0 && gs % 128 == 0 && (gq & (gq - 1)) == 0 && pl.vec >= 2 &&
+             (K / 8) * N * 4 < (int64_t)0xffffffff) && !env_int("APHRO_WNA16_GENERIC", 0);
   if (pl.fast) {
     // every wave owns exactly NSEG segments; ksplit = total_segs / (FNW * NSEG) fp32 slabs.
     const int fk = env_int("APHRO_WNA16_KSPLIT", 0);
@@ -604,8 +644,8 @@ static Wna16Plan make_plan(int64_t M, int64_t N, int64_t K, int64_t gs) {
       if (!(ns == 1 || ns == 2 || ns == 4 || ns == 7 || ns == 8)) continue;
       if (fk > 0) { if (split == fk) { best_ns = ns; best_split = split; } continue; }
       if (best_ns == 0) { best_ns = ns; best_split = split; }
-      // a deeper split only while the grid is small (< ~1.5 workgroups per CU)
-      else if (tiles * best_split < 400 && tiles * split <= 1100) { best_ns = ns; best_split = split; }
+      // a deeper split only while the grid leaves CUs idle (< ~0.75 workgroups per CU)
+      else if (tiles * best_split < 192 && tiles * split <= 1100) { best_ns = ns; best_split = split; }
     }
     if (best_ns) {
       pl.nseg = best_ns;
@@ -735,7 +775,8 @@ extern "C" int aphro_gptq_gemm(const void* a, const uint32_t* q_weight, const ui
   p.M = (int)M; p.N = (int)N; p.K = (int)K; p.lda = (int)ld;
   p.group_size = (int)gs; p.ksteps_per_split = pl.ksteps_per_split; p.ksplit = pl.ksplit;
   p.zero_offset = zero_offset;
-  p.dbg = 0;
+  p.gshift = 0;
+  for (int64_t q = gs >> 7; q > 1; q >>= 1) ++p.gshift;
   p.force_partial = 0;
   return dtype == APHRO_F16 ? run_wna16<Half>(p, pl, st) : run_wna16<BFloat>(p, pl, st);
 }
@@ -796,7 +837,9 @@ extern "C" int aphro_wna16_gemm_packed(const void* a_packed, const uint32_t* q_w
   p.M = (int)M; p.N = (int)N; p.K = (int)K; p.lda = 0;
   p.group_size = (int)(K / groups); p.ksteps_per_split = pl.ksteps_per_split;
   p.ksplit = (c == nullptr && pl.ksplit == 1) ? 1 : pl.ksplit;
-  p.zero_offset = zero_offset; p.dbg = 0;
+  p.zero_offset = zero_offset;
+  p.gshift = 0;
+  for (int64_t q = (K / groups) >> 7; q > 1; q >>= 1) ++p.gshift;
   p.force_partial = (c == nullptr) ? 1 : 0;
   return dtype == APHRO_F16 ? run_wna16<Half>(p, pl, st) : run_wna16<BFloat>(p, pl, st);
 }
