@@ -423,6 +423,42 @@ def wna16_gemm_packed(a_packed: torch.Tensor, m: int, k: int, qweight: torch.Ten
     return out
 
 
+def interleave_gate_up(qweight: torch.Tensor, qzeros: torch.Tensor, scales: torch.Tensor):
+    """Load-time column permutation of a merged [gate | up] K-packed int4 tensor set so that
+    column 2j = gate_j and 2j+1 = up_j (the layout wna16_gemm_silu_pack consumes).
+    qweight int32 [K/8, 2I] (any row order: the shuffle is per word along K), qzeros int32
+    [G, 2I/8] (8 nibbles per word along N), scales [G, 2I]."""
+    n = qweight.shape[1]
+    half = n // 2
+    idx = torch.arange(n, device=qweight.device)
+    src = torch.where(idx % 2 == 0, idx // 2, half + idx // 2)
+    qw = qweight[:, src].contiguous()
+    sc = scales[:, src].contiguous()
+    shifts = torch.arange(0, 32, 4, device=qzeros.device, dtype=torch.int32)
+    z = ((qzeros.unsqueeze(-1) >> shifts) & 0xF).reshape(qzeros.shape[0], n)[:, src]
+    z = z.reshape(qzeros.shape[0], n // 8, 8).to(torch.int64)
+    packed = torch.zeros(qzeros.shape[0], n // 8, dtype=torch.int64, device=qzeros.device)
+    for i in range(8):
+        packed |= z[:, :, i] << (4 * i)
+    packed = torch.where(packed >= 2 ** 31, packed - 2 ** 32, packed).to(torch.int32)
+    return qw, packed.contiguous(), sc
+
+
+def wna16_gemm_silu_pack(a_packed: torch.Tensor, m: int, k: int, qweight: torch.Tensor,
+                         qzeros: torch.Tensor, scales: torch.Tensor, zero_offset: int) -> torch.Tensor:
+    """gate_up GEMM (interleaved columns, see interleave_gate_up) + SiluAndMul + pack:
+    returns the fragment-major f16 activations [M, N/2] for the down projection."""
+    lib = _lib.lib()
+    n = qweight.shape[1]
+    groups = scales.shape[0]
+    out = torch.empty(lib.aphro_wna16_packed_a_bytes(m, n // 2) // 2, dtype=torch.float16,
+                      device=qweight.device)
+    check(lib.aphro_wna16_gemm_silu_pack(a_packed.data_ptr(), qweight.data_ptr(), qzeros.data_ptr(),
+                                         scales.data_ptr(), out.data_ptr(), m, n, k, groups, zero_offset,
+                                         _dt(scales), _stream()), "wna16_gemm_silu_pack")
+    return out
+
+
 def fused_add_rms_norm_pack(x: Optional[torch.Tensor], slabs: Optional[torch.Tensor],
                             residual: Optional[torch.Tensor], has_residual: bool,
                             weight: torch.Tensor, epsilon: float, pack: bool = True,

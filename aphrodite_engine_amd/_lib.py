@@ -27,6 +27,7 @@ SIGNATURES = {
     "aphro_wna16_pack_a": (I, [P, P, P, L, L, L, I, P]),
     "aphro_wna16_ksplit": (I, [L, L, L, L]),
     "aphro_wna16_gemm_packed": (I, [P, P, P, P, P, P, Z, L, L, L, L, I, I, P]),
+    "aphro_wna16_gemm_silu_pack": (I, [P, P, P, P, P, L, L, L, L, I, I, P]),
     "aphro_paged_attention_packed": (I, [P, P, P, P, P, I, I, I, I, F, P, P, I, I, I, P,
                                          L, L, L, I, I, F, F, P]),
     "aphro_fused_add_rms_norm_pack": (I, [P, P, I, P, I, P, F, P, P, L, I, I, P]),

@@ -143,4 +143,13 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// round(round(silu(gate)) * up) in the activation type T, on T-rounded inputs
+// (activation_kernels.cu:14-17, 25-28).  Shared by silu_and_mul, silu_and_mul_pack and the
+// fused GEMM epilogue so that the three paths are bit-identical.
+template <typename T>
+__device__ __forceinline__ uint16_t silu_mul_bits(float gate, float up) {
+  const float s = T::to_f32(T::from_f32(gate / (1.0f + __expf(-gate))));
+  return T::from_f32(s * up);
+}
+
 }  // namespace aphro

@@ -81,6 +81,8 @@ struct Wna16Params {
   int zero_offset;
   int gshift;             // log2(group_size / 128) (fast path)
   int force_partial;      // 1: write the fp32 slab even when ksplit == 1 (fused consumer)
+  uint16_t* act_packed;   // != NULL (ksplit == 1 only): columns are (gate_j, up_j) pairs; the epilogue
+                          // writes silu(gate) * up as fragment-major f16 [M, N/2] for the next GEMM
 };
 
 // ---- in-workgroup split-K reduction through LDS + store ---------------------
@@ -109,7 +111,28 @@ __device__ __forceinline__ void wna16_epilogue(const Wna16Params& p, float* red,
       v[t] = sum;
     }
     if (row < p.M) {
-      if (p.ksplit == 1 && !p.force_partial) {
+      if (p.act_packed) {
+        // fused SiLU-and-mul + activation pack (same roundings as the separate ops: the GEMM
+        // result is rounded to T first).  Output feature j = column / 2.
+        if constexpr (VEC >= 2) {
+          const int mtiles = (p.M + 15) >> 4;
+          const int j = ncol >> 1;
+          const int seg = j >> 7, gg = (j & 127) >> 5, u = (j & 31) >> 3;
+          uint16_t* dst = p.act_packed +
+                          ((((size_t)seg * 4 + u) * mtiles + (row >> 4)) * 64 + gg * 16 + (row & 15)) * 8 + (j & 7);
+          uint16_t o[VEC / 2];
+#pragma unroll
+          for (int q = 0; q < VEC / 2; ++q) {
+            const float gate = T::to_f32(T::from_f32(v[2 * q]));
+            const float up = T::to_f32(T::from_f32(v[2 * q + 1]));
+            uint16_t r = silu_mul_bits<T>(gate, up);
+            if constexpr (!__is_same(T, Half)) r = f32_to_f16_bits(bf16_bits_to_f32(r));
+            o[q] = r;
+          }
+          if constexpr (VEC == 4) *reinterpret_cast<uint32_t*>(dst) = (uint32_t)o[0] | ((uint32_t)o[1] << 16);
+          else dst[0] = o[0];
+        }
+      } else if (p.ksplit == 1 && !p.force_partial) {
         uint16_t* cp = p.c + (size_t)row * p.N + ncol;
         if constexpr (VEC == 4) {
           u16x4 o = {T::from_f32(v[0]), T::from_f32(v[1]), T::from_f32(v[2]), T::from_f32(v[3])};
@@ -778,6 +801,7 @@ extern "C" int aphro_gptq_gemm(const void* a, const uint32_t* q_weight, const ui
   p.gshift = 0;
   for (int64_t q = gs >> 7; q > 1; q >>= 1) ++p.gshift;
   p.force_partial = 0;
+  p.act_packed = nullptr;
   return dtype == APHRO_F16 ? run_wna16<Half>(p, pl, st) : run_wna16<BFloat>(p, pl, st);
 }
 
@@ -841,6 +865,38 @@ extern "C" int aphro_wna16_gemm_packed(const void* a_packed, const uint32_t* q_w
   p.gshift = 0;
   for (int64_t q = (K / groups) >> 7; q > 1; q >>= 1) ++p.gshift;
   p.force_partial = (c == nullptr) ? 1 : 0;
+  p.act_packed = nullptr;
+  return dtype == APHRO_F16 ? run_wna16<Half>(p, pl, st) : run_wna16<BFloat>(p, pl, st);
+}
+
+// gate_up GEMM with the SiLU-and-mul + activation pack fused into its epilogue.  The weight
+// columns must be INTERLEAVED (column 2j = gate_j, 2j+1 = up_j; qzeros / scales likewise) --
+// a load-time permutation of the merged [gate | up] tensor.  Output: fragment-major f16
+// [M, N/2] ready for aphro_wna16_gemm_packed.  Only shapes whose plan keeps the whole K inside
+// one workgroup (aphro_wna16_ksplit == 1) are served.
+extern "C" int aphro_wna16_gemm_silu_pack(const void* a_packed, const uint32_t* q_weight, const uint32_t* qzeros,
+                                          const void* scales, void* act_packed, int64_t M, int64_t N, int64_t K,
+                                          int64_t groups, int zero_offset, int dtype, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  APHRO_CHECK(dtype == APHRO_F16 || dtype == APHRO_BF16, "wna16_gemm_silu_pack: dtype must be f16 or bf16");
+  APHRO_CHECK(M > 0 && M <= APHRO_WNA16_MAX_M, "wna16_gemm_silu_pack: M=%ld out of range", (long)M);
+  APHRO_CHECK(groups > 0 && K % groups == 0, "wna16_gemm_silu_pack: bad groups");
+  APHRO_CHECK(N % 256 == 0, "wna16_gemm_silu_pack: N/2 must be a multiple of 128 (packed K of the next GEMM)");
+  Wna16Plan pl = make_plan(M, N, K, K / groups);
+  APHRO_CHECK(pl.fast && pl.ksplit == 1 && pl.vec >= 2,
+              "wna16_gemm_silu_pack: shape K=%ld N=%ld is split across workgroups; use the unfused ops", (long)K,
+              (long)N);
+  Wna16Params p;
+  p.a = nullptr; p.apk = (const uint16_t*)a_packed; p.qw = q_weight; p.qz = qzeros;
+  p.sc = (const uint16_t*)scales; p.c = nullptr; p.partial = nullptr;
+  p.M = (int)M; p.N = (int)N; p.K = (int)K; p.lda = 0;
+  p.group_size = (int)(K / groups); p.ksteps_per_split = pl.ksteps_per_split;
+  p.ksplit = 1;
+  p.zero_offset = zero_offset;
+  p.gshift = 0;
+  for (int64_t q = (K / groups) >> 7; q > 1; q >>= 1) ++p.gshift;
+  p.force_partial = 0;
+  p.act_packed = (uint16_t*)act_packed;
   return dtype == APHRO_F16 ? run_wna16<Half>(p, pl, st) : run_wna16<BFloat>(p, pl, st);
 }
 

@@ -130,6 +130,24 @@ class LlamaDecoderLayer(nn.Module):
         self.k_scale = 1.0
         self.v_scale = 1.0
         self.tp = tp
+        self.gate_up_interleaved = None
+
+    def enable_fused_silu(self, m: int = 32, keep_original: bool = True) -> bool:
+        """Re-lay the gate_up weights with interleaved (gate_j, up_j) columns so that the
+        decode fast path runs SiluAndMul inside the GEMM epilogue.  With
+        keep_original=False the [gate | up] copy is dropped (the unfused forward then
+        de-interleaves the GEMM output instead)."""
+        fp = self.gate_up_proj.fast_params()
+        lin = self.gate_up_proj
+        if fp is None or ops.wna16_ksplit(m, lin.out_features, lin.in_features, fp[2].shape[0]) != 1 \
+                or lin.out_features % 256 != 0:
+            return False
+        qw, qz, sc = ops.interleave_gate_up(fp[0], fp[1], fp[2])
+        self.gate_up_interleaved = (qw, qz, sc, fp[3])
+        self.gate_up_keep_original = keep_original
+        if not keep_original:
+            lin.qweight.data, lin.qzeros.data, lin.scales.data = qw, qz, sc
+        return True
 
     def fused_decode_ok(self, m: int) -> bool:
         """Decode fast path (8 launches per layer instead of 17): W4A16 linears in the
@@ -166,9 +184,14 @@ class LlamaDecoderLayer(nn.Module):
         o_slabs, _ = ops.wna16_gemm_packed(attn_packed, m, self.q_size, qw, qz, sc, zo, partials=True)
         packed2, _ = ops.fused_add_rms_norm_pack(None, o_slabs, residual, True,
                                                  self.post_attention_layernorm, eps)
-        qw, qz, sc, zo = self.gate_up_proj.fast_params()
-        gate_up = ops.wna16_gemm_packed(packed2, m, h, qw, qz, sc, zo, partials=False)
-        act_packed = ops.silu_and_mul_pack(gate_up)
+        if self.gate_up_interleaved is not None:
+            # SiluAndMul + pack run in the GEMM epilogue (interleaved gate/up columns)
+            qw, qz, sc, zo = self.gate_up_interleaved
+            act_packed = ops.wna16_gemm_silu_pack(packed2, m, h, qw, qz, sc, zo)
+        else:
+            qw, qz, sc, zo = self.gate_up_proj.fast_params()
+            gate_up = ops.wna16_gemm_packed(packed2, m, h, qw, qz, sc, zo, partials=False)
+            act_packed = ops.silu_and_mul_pack(gate_up)
         qw, qz, sc, zo = self.down_proj.fast_params()
         down_slabs, _ = ops.wna16_gemm_packed(act_packed, m, self.down_proj.in_features, qw, qz, sc, zo,
                                               partials=True)
@@ -193,6 +216,8 @@ class LlamaDecoderLayer(nn.Module):
             hidden = tensor_model_parallel_all_reduce(hidden)
         ops.fused_add_rms_norm(hidden, residual, self.post_attention_layernorm, eps)
         gate_up = self.gate_up_proj(hidden)
+        if self.gate_up_interleaved is not None and not self.gate_up_keep_original:
+            gate_up = gate_up.view(gate_up.shape[0], -1, 2).transpose(1, 2).reshape(gate_up.shape[0], -1)
         act = torch.empty(gate_up.shape[0], gate_up.shape[1] // 2, dtype=gate_up.dtype,
                           device=gate_up.device)
         ops.silu_and_mul(act, gate_up)

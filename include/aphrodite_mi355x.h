@@ -96,6 +96,17 @@ int aphro_wna16_gemm_packed(const void* a_packed, const uint32_t* q_weight,
                             float* partials, size_t partial_bytes, int64_t M, int64_t N,
                             int64_t K, int64_t groups, int zero_offset, int dtype,
                             void* stream);
+/* gate_up projection with SiluAndMul (modeling/layers/activation.py SiluAndMul ->
+ * kernels/activation_kernels.cu:12-75) and the activation pack fused into the GEMM
+ * epilogue.  Weight columns are INTERLEAVED at load time (column 2j = gate_j,
+ * 2j+1 = up_j; qzeros and scales permuted alike) so both halves of an output
+ * feature meet in one lane.  act_packed: fragment-major f16 [M, N/2].  Served only
+ * when aphro_wna16_ksplit(M,N,K,groups) == 1; roundings identical to gptq_gemm ->
+ * silu_and_mul. */
+int aphro_wna16_gemm_silu_pack(const void* a_packed, const uint32_t* q_weight,
+                               const uint32_t* qzeros, const void* scales,
+                               void* act_packed, int64_t M, int64_t N, int64_t K,
+                               int64_t groups, int zero_offset, int dtype, void* stream);
 
 /* Reconstruct W[K,N] (dtype f16|bf16) from a GPTQ tensor set
  *   q_gemm.cu:1394-1434 (reconstruct_gptq, shuffled=0, g_idx int32 [K] or NULL)

@@ -716,6 +716,60 @@ def test_wna16_gemm_packed_paths(ops, M, K, N):
     assert torch.equal(acc.to(torch.float16), ref)
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M", [1, 16, 19, 32])
+@pytest.mark.parametrize("K,I", [(512, 128), (1024, 256), (4096, 384)])
+def test_wna16_gemm_silu_pack(ops, dtype, M, K, I):
+    """gate_up GEMM with SiluAndMul + pack in its epilogue (interleaved columns) is
+    bit-identical to gptq_gemm -> silu_and_mul -> pack on the [gate | up] layout."""
+    rng = np.random.default_rng(M + K + I)
+    N = 2 * I
+    qweight, qzeros, s, _ = make_gptq(rng, K, N, 128)
+    a = t(rng.standard_normal((M, K)).astype(np.float32), dtype)
+    shuf, qz, sc = t(oq.gptq_shuffle(qweight)), t(qzeros), t(s, dtype)
+    empty = torch.empty(0, dtype=torch.int32, device=DEV)
+    gate_up = ops.gptq_gemm(a, shuf, qz, sc, empty, True, 4)
+    act = torch.empty(M, I, dtype=dtype, device=DEV)
+    ops.silu_and_mul(act, gate_up)
+    ref = act.to(torch.float16).cpu().numpy().view(np.uint16)
+    qw_i, qz_i, sc_i = ops.interleave_gate_up(shuf, qz, sc)
+    # the permutation itself: dequantised interleaved weights == permuted dequantised weights
+    w_ref = ops.gptq_dequant(shuf, qz, sc, empty, True, 4)
+    w_int = ops.gptq_dequant(qw_i, qz_i, sc_i, empty, True, 4)
+    assert torch.equal(w_int[:, 0::2], w_ref[:, :I]) and torch.equal(w_int[:, 1::2], w_ref[:, I:])
+    if ops.wna16_ksplit(M, N, K, K // 128) != 1:
+        with pytest.raises(RuntimeError):
+            ops.wna16_gemm_silu_pack(ops.wna16_pack_a(a), M, K, qw_i, qz_i, sc_i, 1)
+        return
+    packed = ops.wna16_gemm_silu_pack(ops.wna16_pack_a(a), M, K, qw_i, qz_i, sc_i, 1)
+    np.testing.assert_array_equal(unpack_a(packed, M, I), ref)
+
+
+@pytest.mark.parametrize("keep_original", [True, False])
+def test_fused_silu_model_matches_unfused(ops, keep_original):
+    """Decode step with the SiluAndMul-in-epilogue gate_up vs the op-by-op path."""
+    from aphrodite_engine_amd import model as M
+    from aphrodite_engine_amd.quantization.gptq import GPTQConfig
+    with torch.no_grad():
+        m = M.LlamaForCausalLM(M.TINY, GPTQConfig(4, 128, False), torch.float16)
+        m.init_synthetic(torch.device(DEV))
+        meta, pos, nblocks = M.make_decode_metadata(5, [3, 17, 64, 200, 129], 16, DEV)
+        ids = torch.randint(0, M.TINY.vocab_size, (5, ), device=DEV)
+        caches = M.make_kv_caches(M.TINY, nblocks, 16, torch.float16, "auto", DEV, seed=3)
+        m.use_fused_decode = False
+        ref = m(ids, pos, caches, meta).float()
+        enabled = [l.enable_fused_silu(5, keep_original) for l in m.layers]
+        if not all(enabled):
+            pytest.skip("TINY gate_up is split across workgroups at this shape")
+        outs = []
+        for fused in (False, True):
+            caches = M.make_kv_caches(M.TINY, nblocks, 16, torch.float16, "auto", DEV, seed=3)
+            m.use_fused_decode = fused
+            outs.append(m(ids, pos, caches, meta).float())
+        assert torch.equal(outs[0], ref)            # interleaving changes no number on the unfused path
+        torch.testing.assert_close(outs[1], ref, atol=2e-2, rtol=2e-2)
+
+
 def test_fused_decode_model_matches_unfused(ops):
     """Whole decode step: fused fast path vs the op-by-op path of the same model."""
     from aphrodite_engine_amd import model as M
