@@ -13,7 +13,7 @@ tensors are allocated here on the input's device.  Every launch goes to
 ``torch.cuda.current_stream()`` and nothing synchronises, so the ops can be
 captured into a HIP graph exactly like the reference's.
 """
-from typing import Optional, Tuple
+from typing import List, Optional, Tuple
 
 import torch
 
@@ -184,6 +184,39 @@ def flash_attn_varlen(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor,
     return out
 
 
+def context_attention_fwd(q, k, v, o, kv_cache_dtype: str, k_cache, v_cache, b_loc, b_start_loc,
+                          b_seq_len, b_ctx_len, max_input_len: int, k_scale: float = 1.0,
+                          v_scale: float = 1.0, alibi_slopes: Optional[torch.Tensor] = None,
+                          sliding_window: Optional[int] = None) -> None:
+    """attention/ops/prefix_prefill.py:696-711 (same argument order).  q/k/v/o [T,H,hd]
+    views of the new tokens; k_cache [NB,Hkv,hd/x,block,x], v_cache [NB,Hkv,hd,block];
+    b_loc = block tables, b_start_loc = query_start_loc [B+1], b_seq_len = context + new,
+    b_ctx_len = cached context.  Like the reference the softmax scale is 1/sqrt(hd)
+    (prefix_prefill.py:745)."""
+    _require_cuda(q, k, v, o, k_cache, v_cache, b_loc, b_start_loc, b_seq_len, b_ctx_len)
+    if q.dtype not in (torch.float16, torch.bfloat16):
+        raise RuntimeError("context_attention_fwd: query must be fp16 or bf16")
+    head_size = q.shape[-1]
+    if q.stride(1) != head_size or k.stride(1) != head_size or v.stride(1) != head_size \
+            or o.stride(1) != head_size:
+        raise RuntimeError("context_attention_fwd: heads must be contiguous")
+    batch = b_seq_len.shape[0]
+    i32 = lambda t_: t_ if t_.dtype == torch.int32 else t_.to(torch.int32)
+    b_loc, b_start_loc, b_seq_len, b_ctx_len = map(i32, (b_loc, b_start_loc, b_seq_len, b_ctx_len))
+    b_loc = b_loc.contiguous()
+    slopes = None
+    if alibi_slopes is not None:
+        slopes = alibi_slopes.to(device=q.device, dtype=torch.float32).contiguous()
+    win = int(sliding_window) if sliding_window is not None and sliding_window > 0 else 0
+    check(_lib.lib().aphro_context_attention(
+        o.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(),
+        b_loc.data_ptr(), b_start_loc.data_ptr(), b_seq_len.data_ptr(), b_ctx_len.data_ptr(), batch,
+        int(max_input_len), b_loc.shape[1], q.shape[1], k.shape[1], head_size, v_cache.shape[3],
+        k_cache.shape[4], q.stride(0), k.stride(0), v.stride(0), o.stride(0), head_size ** -0.5,
+        float(k_scale), float(v_scale), _ptr(slopes), win, _dt(q), _kv(kv_cache_dtype), _stream()),
+        "context_attention_fwd")
+
+
 # --------------------------------------------------------------------------
 # cache ops
 # --------------------------------------------------------------------------
@@ -202,6 +235,69 @@ def reshape_and_cache(key, value, key_cache, value_cache, slot_mapping,
         num_kv_heads, head_size, block_size, x, key.stride(0), value.stride(0),
         _dt(key), _kv(kv_cache_dtype), float(k_scale), float(v_scale),
         _stream()), "reshape_and_cache")
+
+
+def reshape_and_cache_flash(key, value, key_cache, value_cache, slot_mapping,
+                            kv_cache_dtype: str, k_scale: float, v_scale: float) -> None:
+    """_custom_ops.py reshape_and_cache_flash: caches in the [NB, block, H, hd] layout."""
+    _require_cuda(key, value, key_cache, value_cache, slot_mapping)
+    num_tokens, num_heads, head_size = key.shape
+    block_size = key_cache.shape[1]
+    if slot_mapping.dtype != torch.int64:
+        raise RuntimeError("slot_mapping must be int64")
+    if key_cache.stride(0) != value_cache.stride(0):
+        raise RuntimeError("key_cache and value_cache must have the same block stride")
+    if key.stride(1) != head_size or value.stride(1) != head_size:
+        raise RuntimeError("key/value heads must be contiguous")
+    check(_lib.lib().aphro_reshape_and_cache_flash(
+        key.data_ptr(), value.data_ptr(), key_cache.data_ptr(), value_cache.data_ptr(),
+        slot_mapping.data_ptr(), num_tokens, num_heads, head_size, block_size,
+        key_cache.stride(0), key.stride(0), value.stride(0), _dt(key), _kv(kv_cache_dtype),
+        float(k_scale), float(v_scale), _stream()), "reshape_and_cache_flash")
+
+
+def copy_blocks(key_caches: List[torch.Tensor], value_caches: List[torch.Tensor],
+                block_mapping: torch.Tensor) -> None:
+    """_C_cache_ops::copy_blocks (cache_kernels.cu:103-148): for every layer copy block
+    src -> dst for each (src, dst) row of block_mapping (int64 [num_pairs, 2], device)."""
+    num_layers = len(key_caches)
+    if num_layers != len(value_caches):
+        raise RuntimeError("copy_blocks: key_caches and value_caches differ in length")
+    if num_layers == 0 or block_mapping.numel() == 0:
+        return
+    _require_cuda(key_caches[0], value_caches[0], block_mapping)
+    dev = key_caches[0].device
+    kp = torch.tensor([t.data_ptr() for t in key_caches], dtype=torch.int64, device=dev)
+    vp = torch.tensor([t.data_ptr() for t in value_caches], dtype=torch.int64, device=dev)
+    bm = block_mapping.to(torch.int64).contiguous()
+    block_bytes = key_caches[0][0].numel() * key_caches[0].element_size()
+    check(_lib.lib().aphro_copy_blocks(kp.data_ptr(), vp.data_ptr(), num_layers, bm.data_ptr(),
+                                       bm.shape[0], block_bytes, _stream()), "copy_blocks")
+
+
+def swap_blocks(src: torch.Tensor, dst: torch.Tensor, block_mapping: torch.Tensor) -> None:
+    """_C_cache_ops::swap_blocks (cache_kernels.cu:24-63); block_mapping is a CPU int64
+    [num_pairs, 2] tensor, src/dst are whole caches indexed by block along dim 0."""
+    if block_mapping.device.type != "cpu":
+        raise RuntimeError("block_mapping must be on CPU")
+    sd, dd = src.device.type, dst.device.type
+    if sd == "cuda" and dd == "cuda":
+        if src.device.index != dst.device.index:
+            raise RuntimeError("src and dst must be on the same GPU")
+        kind = 0
+    elif sd == "cuda" and dd == "cpu":
+        kind = 1
+    elif sd == "cpu" and dd == "cuda":
+        kind = 2
+    else:
+        raise RuntimeError("Invalid device combination")
+    bm = block_mapping.to(torch.int64).contiguous()
+    block_bytes = src[0].numel() * src.element_size()
+    if bm.numel() == 0:
+        return
+    with torch.cuda.device(src.device if sd == "cuda" else dst.device):
+        check(_lib.lib().aphro_swap_blocks(src.data_ptr(), dst.data_ptr(), bm.data_ptr(),
+                                           bm.shape[0], block_bytes, kind, _stream()), "swap_blocks")
 
 
 def convert_fp8(output: torch.Tensor, input: torch.Tensor, scale: float = 1.0,
@@ -316,6 +412,36 @@ def gptq_marlin_repack(b_q_weight: torch.Tensor, perm: torch.Tensor, size_k: int
 # --------------------------------------------------------------------------
 # AWQ
 # --------------------------------------------------------------------------
+def gptq_marlin_gemm(a: torch.Tensor, b_q_weight: torch.Tensor, b_scales: torch.Tensor,
+                     b_zeros: torch.Tensor, g_idx: torch.Tensor, perm: torch.Tensor,
+                     workspace: Optional[torch.Tensor], b_q_type, size_m: int, size_n: int,
+                     size_k: int, is_k_full: bool = True, has_zp: bool = False,
+                     use_fp32_reduce: bool = False, is_zp_float: bool = False) -> torch.Tensor:
+    """W4A16 "Marlin role" (torch_bindings.cpp:195-201) on the CDNA4 layout:
+    b_q_weight = gptq_marlin_repack / awq_marlin_repack output ([K/8, N] K-packed, exllama
+    nibble order; act-order rows already sorted), b_scales [G, N], b_zeros int32 [G, N/8]
+    plain column order (awq_repack_zeros output) when has_zp, ignored for the symmetric
+    uint4b8 type (zero point 8).  perm = argsort(g_idx) or empty; g_idx / workspace /
+    is_k_full / use_fp32_reduce are accepted for signature parity (the kernel always
+    reduces in fp32 and needs no lock workspace)."""
+    if is_zp_float:
+        raise RuntimeError("gptq_marlin_gemm: float zero points are not supported")
+    bits = getattr(b_q_type, "size_bits", 4)
+    if bits != 4:
+        raise RuntimeError("gptq_marlin_gemm on MI355X serves 4-bit weights only")
+    x = a.reshape(-1, a.shape[-1])
+    if x.shape[0] != size_m or x.shape[1] != size_k or b_q_weight.shape != (size_k // 8, size_n):
+        raise RuntimeError("gptq_marlin_gemm: shape mismatch")
+    groups = b_scales.shape[0]
+    if has_zp:
+        zp = b_zeros
+    else:
+        zp = torch.full((groups, size_n // 8), 0x88888888 - (1 << 32), dtype=torch.int64,
+                        device=a.device).to(torch.int32)
+    p = perm if perm is not None and perm.numel() > 0 else None
+    return wna16_gemm(x, b_q_weight, zp, b_scales, p, 0)
+
+
 def awq_dequantize(qweight: torch.Tensor, scales: torch.Tensor,
                    zeros: torch.Tensor, split_k_iters: int = 0, thx: int = 0,
                    thy: int = 0) -> torch.Tensor:

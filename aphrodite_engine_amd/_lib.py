@@ -40,6 +40,9 @@ SIGNATURES = {
     "aphro_awq_repack": (I, [P, P, L, L, P]),
     "aphro_awq_repack_zeros": (I, [P, P, L, L, P]),
     "aphro_reshape_and_cache": (I, [P, P, P, P, P, L, I, I, I, I, L, L, I, I, F, F, P]),
+    "aphro_reshape_and_cache_flash": (I, [P, P, P, P, P, L, I, I, I, L, L, L, I, I, F, F, P]),
+    "aphro_copy_blocks": (I, [P, P, I, P, L, L, P]),
+    "aphro_swap_blocks": (I, [P, P, P, L, L, I, P]),
     "aphro_convert_fp8": (I, [P, P, L, F, I, I, I, P]),
     "aphro_paged_attention": (I, [P, P, P, P, P, P, P, I, I, I, I, F, P, P, I, I, I, P,
                                   L, L, L, I, I, F, F, I, P]),
@@ -54,6 +57,8 @@ SIGNATURES = {
     "aphro_silu_and_mul": (I, [P, P, L, I, I, P]),
     "aphro_rotary_embedding": (I, [P, P, P, L, I, I, I, I, P, L, L, I, I, P]),
     "aphro_flash_attn_varlen": (I, [P, P, P, P, P, I, I, I, I, I, L, L, L, F, I, P, I, P]),
+    "aphro_context_attention": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, L, L, L, L,
+                                    F, F, F, P, I, I, I, P]),
 }
 
 OK = 0

@@ -95,11 +95,11 @@ class MI355XAttentionBackend:
 
     @staticmethod
     def swap_blocks(src_kv_cache, dst_kv_cache, src_to_dst) -> None:
-        raise NotImplementedError("swap_blocks is next-tier (SURVEY 8f row 4)")
+        PagedAttention.swap_blocks(src_kv_cache, dst_kv_cache, src_to_dst)
 
     @staticmethod
     def copy_blocks(kv_caches, src_to_dists) -> None:
-        raise NotImplementedError("copy_blocks is next-tier (SURVEY 8f row 4)")
+        PagedAttention.copy_blocks(kv_caches, src_to_dists)
 
 
 class MI355XAttentionImpl:
@@ -123,6 +123,7 @@ class MI355XAttentionImpl:
         self.alibi_slopes = (torch.tensor(alibi_slopes, dtype=torch.float32)
                              if alibi_slopes is not None else None)
         self.kv_cache_dtype = kv_cache_dtype
+        self.sliding_window = None
         assert self.num_heads % self.num_kv_heads == 0
         self.num_queries_per_kv = self.num_heads // self.num_kv_heads
         supported = PagedAttention.get_supported_head_sizes()
@@ -163,14 +164,20 @@ class MI355XAttentionImpl:
                        and prefill_meta.block_tables.numel() > 0
                        and bool((prefill_meta.context_lens_tensor > 0).any()))
             if has_ctx:
-                raise NotImplementedError(
-                    "prefix-cached prefill (context_attention_fwd role) is not "
-                    "implemented yet on MI355X (SURVEY 8a row a5)")
-            out = ops.flash_attn_varlen(
-                query, key, value, prefill_meta.seq_start_loc,
-                prefill_meta.max_prefill_seq_len, self.scale, causal=True,
-                alibi_slopes=self.alibi_slopes)
-            output[:num_prefill_tokens] = out
+                # prefix-enabled attention (rocm_flash_attn.py:509-527)
+                assert key_cache is not None
+                output[:num_prefill_tokens] = PagedAttention.forward_prefix(
+                    query, key, value, self.kv_cache_dtype, key_cache, value_cache,
+                    prefill_meta.block_tables, prefill_meta.query_start_loc,
+                    prefill_meta.seq_lens_tensor, prefill_meta.context_lens_tensor,
+                    prefill_meta.max_query_len, self.alibi_slopes, self.sliding_window,
+                    k_scale, v_scale)
+            else:
+                out = ops.flash_attn_varlen(
+                    query, key, value, prefill_meta.seq_start_loc,
+                    prefill_meta.max_prefill_seq_len, self.scale, causal=True,
+                    alibi_slopes=self.alibi_slopes)
+                output[:num_prefill_tokens] = out
 
         if decode_meta := attn_metadata.decode_metadata:
             assert key_cache is not None

@@ -74,3 +74,30 @@ class PagedAttention:
                                    blocksparse_vert_stride, blocksparse_block_size,
                                    blocksparse_head_sliding_step)
         return output
+
+    @staticmethod
+    def forward_prefix(query, key, value, kv_cache_dtype: str, key_cache, value_cache,
+                       block_tables, query_start_loc, seq_lens_tensor, context_lens,
+                       max_query_len: int, alibi_slopes, sliding_window, k_scale: float,
+                       v_scale: float) -> torch.Tensor:
+        """ops/paged_attn.py:192-231."""
+        output = torch.empty_like(query)
+        ops.context_attention_fwd(query, key, value, output, kv_cache_dtype, key_cache,
+                                  value_cache, block_tables, query_start_loc, seq_lens_tensor,
+                                  context_lens, max_query_len, k_scale, v_scale, alibi_slopes,
+                                  sliding_window)
+        return output
+
+    @staticmethod
+    def swap_blocks(src_kv_cache: torch.Tensor, dst_kv_cache: torch.Tensor,
+                    src_to_dst: torch.Tensor) -> None:
+        """ops/paged_attn.py:233-244: kv cache [2, NB, ...]; keys then values."""
+        ops.swap_blocks(src_kv_cache[0], dst_kv_cache[0], src_to_dst)
+        ops.swap_blocks(src_kv_cache[1], dst_kv_cache[1], src_to_dst)
+
+    @staticmethod
+    def copy_blocks(kv_caches: List[torch.Tensor], src_to_dists: torch.Tensor) -> None:
+        """ops/paged_attn.py:246-253."""
+        key_caches = [kv_cache[0] for kv_cache in kv_caches]
+        value_caches = [kv_cache[1] for kv_cache in kv_caches]
+        ops.copy_blocks(key_caches, value_caches, src_to_dists)

@@ -188,9 +188,240 @@ __global__ __launch_bounds__(256) void flash_attn_varlen_kernel(FAParams p) {
   }
 }
 
+// ---------------------------------------------------------------------------
+// Prefill WITH cached context (the context_attention_fwd role,
+// aphrodite/attention/ops/prefix_prefill.py:696-858, kernel :58-255): every new
+// token attends to the sequence's cached context, read from the PAGED KV cache
+// (K [NB,Hkv,hd/x,block,x], V [NB,Hkv,hd,block]; fp8 caches are dequantised as
+// float(fp8) * scale and rounded to the query dtype, :131-134,178-181), plus the
+// causal part of the new tokens.  Same tile machine as the kernel above; only the
+// K/V staging differs between the two phases.
+// ---------------------------------------------------------------------------
+struct CAParams {
+  void* out;
+  const void* q;
+  const void* k;
+  const void* v;
+  const void* k_cache;
+  const void* v_cache;
+  const int32_t* block_tables;   // [B, max_blocks]
+  const int32_t* q_start_loc;    // [B+1] (only [b] is read: start row of sequence b)
+  const int32_t* seq_lens;       // [B] context + new
+  const int32_t* ctx_lens;       // [B]
+  const float* alibi;
+  int num_heads, num_kv_heads, max_blocks, block_size, x;
+  int64_t q_stride, k_stride, v_stride, o_stride;
+  float scale, k_scale, v_scale;
+  int window;                    // sliding window (0 = off): keys with qpos - kpos >= window are masked
+};
+
+template <typename T, int KV>
+__device__ __forceinline__ uint16_t cache_elem_to_t(const void* base, int64_t idx, float scale) {
+  if constexpr (KV == 0) return ((const uint16_t*)base)[idx];
+  else return T::from_f32(fp8_to_f32<KV == 2>(((const uint8_t*)base)[idx]) * scale);
+}
+
+template <typename T, int KV, int HD>
+__global__ __launch_bounds__(256) void context_attn_kernel(CAParams p) {
+  constexpr int NCH = HD / 8;
+  constexpr int SWZ = (NCH & -NCH) - 1;
+  constexpr int NKS = HD / 32;
+  constexpr int NDT = HD / 16;
+  __shared__ __attribute__((aligned(16))) uint16_t k_lds[FA_BN * HD];
+  __shared__ __attribute__((aligned(16))) uint16_t vt_lds[HD * FA_VT_STRIDE];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int g = lane >> 4;
+  const int c = lane & 15;
+  const int head = blockIdx.y;
+  const int seq = blockIdx.z;
+  const int kvh = head / (p.num_heads / p.num_kv_heads);
+  const int s0 = p.q_start_loc[seq];
+  const int ctx = p.ctx_lens[seq];
+  const int len = p.seq_lens[seq] - ctx;        // new tokens
+  if (len <= 0) return;
+  const int ntiles = (len + FA_BM - 1) / FA_BM;
+  const int tile = ntiles - 1 - (int)blockIdx.x;
+  if (tile < 0) return;
+  const int q0 = tile * FA_BM;
+  const int qrow = q0 + 16 * wave + c;
+  const bool qvalid = qrow < len;
+  const int qpos = ctx + qrow;                  // absolute position of this lane's query
+
+  u32x4 qf[NKS];
+  {
+    const uint16_t* qp = (const uint16_t*)p.q + (size_t)(s0 + min(qrow, len - 1)) * p.q_stride + (size_t)head * HD;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) qf[ks] = *reinterpret_cast<const u32x4*>(qp + 32 * ks + 8 * g);
+  }
+  const float slope = p.alibi ? p.alibi[head] : 0.f;
+
+  f32x4 o[NDT];
+#pragma unroll
+  for (int i = 0; i < NDT; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_run = -1e30f, l_run = 0.f;
+
+  const uint16_t* kbase = (const uint16_t*)p.k + (size_t)s0 * p.k_stride + (size_t)kvh * HD;
+  const uint16_t* vbase = (const uint16_t*)p.v + (size_t)s0 * p.v_stride + (size_t)kvh * HD;
+  const int32_t* bt = p.block_tables + (size_t)seq * p.max_blocks;
+  const int new_end = min(len, q0 + FA_BM);     // causal bound within the new tokens
+  const int nctx_tiles = (ctx + FA_BN - 1) / FA_BN;
+  const int nnew_tiles = (new_end + FA_BN - 1) / FA_BN;
+
+  for (int it = 0; it < nctx_tiles + nnew_tiles; ++it) {
+    const bool paged = it < nctx_tiles;
+    const int t0 = paged ? it * FA_BN : (it - nctx_tiles) * FA_BN;   // first key of the tile within its phase
+    const int phase_len = paged ? ctx : len;
+    __syncthreads();
+    for (int i = threadIdx.x; i < FA_BN * NCH; i += 256) {
+      const int tok = i / NCH, ch = i % NCH;
+      const int ta = min(t0 + tok, phase_len - 1);
+      const bool live = t0 + tok < phase_len;
+      u16x8 kk, vv;
+      if (paged) {
+        const int64_t blk = bt[ta / p.block_size];
+        const int off = ta % p.block_size;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int d = 8 * ch + j;
+          const int64_t kidx = (((blk * p.num_kv_heads + kvh) * (HD / p.x) + d / p.x) * p.block_size + off) * p.x + d % p.x;
+          const int64_t vidx = ((blk * p.num_kv_heads + kvh) * HD + d) * p.block_size + off;
+          kk[j] = cache_elem_to_t<T, KV>(p.k_cache, kidx, p.k_scale);
+          vv[j] = cache_elem_to_t<T, KV>(p.v_cache, vidx, p.v_scale);
+        }
+      } else {
+        kk = *reinterpret_cast<const u16x8*>(kbase + (size_t)ta * p.k_stride + 8 * ch);
+        vv = *reinterpret_cast<const u16x8*>(vbase + (size_t)ta * p.v_stride + 8 * ch);
+      }
+      if (!live) vv = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      *reinterpret_cast<u16x8*>(&k_lds[tok * HD + 8 * (ch ^ (tok & SWZ))]) = kk;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) vt_lds[(8 * ch + j) * FA_VT_STRIDE + tok] = vv[j];
+    }
+    __syncthreads();
+    const bool wave_active = paged || (t0 <= q0 + 16 * wave + 15);
+    if (wave_active) {
+      f32x4 s[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        s[h] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int tok = 16 * h + c;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+          const int ch = (4 * ks + g) ^ (tok & SWZ);
+          u32x4 kf = *reinterpret_cast<const u32x4*>(&k_lds[tok * HD + 8 * ch]);
+          s[h] = fa_mfma<T>(kf, qf[ks], s[h]);
+        }
+      }
+      float pv[2][4];
+      float mx = -1e30f;
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int tok = t0 + 16 * h + 4 * g + r;          // key index within the phase
+          const int kpos = paged ? tok : ctx + tok;         // absolute key position
+          float xv = s[h][r] * p.scale + slope * (float)(kpos - qpos);
+          bool ok = tok < phase_len && kpos <= qpos;
+          if (p.window > 0 && qpos - kpos >= p.window) ok = false;
+          xv = ok ? xv : -1e30f;
+          pv[h][r] = xv;
+          mx = __builtin_fmaxf(mx, xv);
+        }
+      mx = __builtin_fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = __builtin_fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = __builtin_fmaxf(m_run, mx);
+      const float alpha = __expf(m_run - m_new);
+      m_run = m_new;
+      float lsum = 0.f;
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float e = pv[h][r] > -1e29f ? __expf(pv[h][r] - m_new) : 0.f;
+          pv[h][r] = e;
+          lsum += e;
+        }
+      l_run = l_run * alpha + lsum;
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt) o[dt] *= alpha;
+      u32x4 pf;
+      pf[0] = fa_pack2<T>(pv[0][0], pv[0][1]);
+      pf[1] = fa_pack2<T>(pv[0][2], pv[0][3]);
+      pf[2] = fa_pack2<T>(pv[1][0], pv[1][1]);
+      pf[3] = fa_pack2<T>(pv[1][2], pv[1][3]);
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt) {
+        const uint16_t* vr = &vt_lds[(16 * dt + c) * FA_VT_STRIDE + 4 * g];
+        u32x2 lo = *reinterpret_cast<const u32x2*>(vr);
+        u32x2 hi = *reinterpret_cast<const u32x2*>(vr + 16);
+        u32x4 vf = {lo[0], lo[1], hi[0], hi[1]};
+        o[dt] = fa_mfma<T>(vf, pf, o[dt]);
+      }
+    }
+  }
+
+  l_run += __shfl_xor(l_run, 16, 64);
+  l_run += __shfl_xor(l_run, 32, 64);
+  if (qvalid) {
+    const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+    typename T::storage* op = (typename T::storage*)p.out + (size_t)(s0 + qrow) * p.o_stride + (size_t)head * HD;
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) {
+      u16x4 r = {T::from_f32(o[dt][0] * inv), T::from_f32(o[dt][1] * inv), T::from_f32(o[dt][2] * inv),
+                 T::from_f32(o[dt][3] * inv)};
+      *reinterpret_cast<u16x4*>(op + 16 * dt + 4 * g) = r;
+    }
+  }
+}
+
 }  // namespace aphro
 
 using namespace aphro;
+
+extern "C" int aphro_context_attention(void* out, const void* q, const void* k, const void* v, const void* k_cache,
+                                       const void* v_cache, const int32_t* block_tables,
+                                       const int32_t* q_start_loc, const int32_t* seq_lens,
+                                       const int32_t* ctx_lens, int batch, int max_query_len, int max_blocks,
+                                       int num_heads, int num_kv_heads, int head_size, int block_size, int x,
+                                       int64_t q_stride, int64_t k_stride, int64_t v_stride, int64_t o_stride,
+                                       float scale, float k_scale, float v_scale, const float* alibi_slopes,
+                                       int sliding_window, int dtype, int kv_dtype, void* stream) {
+  APHRO_CHECK(dtype == APHRO_F16 || dtype == APHRO_BF16, "context_attention: dtype must be f16 or bf16");
+  APHRO_CHECK(kv_dtype >= APHRO_KV_AUTO && kv_dtype <= APHRO_KV_FP8_E5M2, "Unsupported data type of kv cache: %d", kv_dtype);
+  APHRO_CHECK(num_kv_heads > 0 && num_heads % num_kv_heads == 0, "context_attention: bad head counts");
+  APHRO_CHECK(q_stride % 8 == 0 && k_stride % 8 == 0 && v_stride % 8 == 0 && o_stride % 4 == 0,
+              "context_attention: strides must be multiples of 8");
+  APHRO_CHECK(((uintptr_t)q % 16) == 0 && ((uintptr_t)k % 16) == 0 && ((uintptr_t)v % 16) == 0, "context_attention: 16-byte alignment");
+  APHRO_CHECK(block_size > 0 && x > 0 && head_size % x == 0, "context_attention: bad cache geometry");
+  if (batch == 0 || max_query_len == 0) return APHRO_OK;
+  CAParams p;
+  p.out = out; p.q = q; p.k = k; p.v = v; p.k_cache = k_cache; p.v_cache = v_cache;
+  p.block_tables = block_tables; p.q_start_loc = q_start_loc; p.seq_lens = seq_lens; p.ctx_lens = ctx_lens;
+  p.alibi = alibi_slopes; p.num_heads = num_heads; p.num_kv_heads = num_kv_heads; p.max_blocks = max_blocks;
+  p.block_size = block_size; p.x = x; p.q_stride = q_stride; p.k_stride = k_stride; p.v_stride = v_stride;
+  p.o_stride = o_stride; p.scale = scale; p.k_scale = k_scale; p.v_scale = v_scale; p.window = sliding_window;
+  dim3 grid((unsigned)((max_query_len + FA_BM - 1) / FA_BM), (unsigned)num_heads, (unsigned)batch);
+#define CA_L(TT, KVV, HDV) hipLaunchKernelGGL((context_attn_kernel<TT, KVV, HDV>), grid, dim3(256), 0, (hipStream_t)stream, p)
+#define CA_K(TT, HDV) { if (kv_dtype == APHRO_KV_AUTO) CA_L(TT, 0, HDV); else if (kv_dtype == APHRO_KV_FP8_E4M3) CA_L(TT, 1, HDV); else CA_L(TT, 2, HDV); }
+#define CA_T(HDV) { if (dtype == APHRO_F16) CA_K(Half, HDV) else CA_K(BFloat, HDV) }
+  switch (head_size) {
+    case 64: CA_T(64) break;
+    case 96: CA_T(96) break;
+    case 128: CA_T(128) break;
+    case 256: CA_T(256) break;
+    default:
+      set_error("context_attention: unsupported head_size=%d", head_size);
+      return APHRO_ERR_INVALID;
+  }
+#undef CA_T
+#undef CA_K
+#undef CA_L
+  APHRO_LAUNCH_CHECK();
+  return APHRO_OK;
+}
+
 
 extern "C" int aphro_flash_attn_varlen(void* out, const void* q, const void* k, const void* v,
                                        const int32_t* cu_seqlens, int batch, int max_seqlen, int num_heads,

@@ -76,11 +76,30 @@ _C_OPS += [
      ops.cutlass_scaled_mm_supports_fp8),                                                  # :242-244
 ]
 
+def _fp8_marlin_gemm(a, b_q_weight, b_scales, workspace, num_bits, size_m, size_n, size_k):
+    return ops.fp8_marlin_gemm(a, b_q_weight, b_scales, workspace, num_bits, size_m, size_n, size_k)
+
+
+_C_OPS += [
+    ("gptq_marlin_repack(Tensor b_q_weight, Tensor perm, SymInt size_k, SymInt size_n, int num_bits) -> Tensor",
+     ops.gptq_marlin_repack),                                                              # :204-208
+    ("awq_marlin_repack(Tensor b_q_weight, SymInt size_k, SymInt size_n, int num_bits) -> Tensor",
+     ops.awq_marlin_repack),                                                               # :211-215
+    ("fp8_marlin_gemm(Tensor a, Tensor b_q_weight, Tensor b_scales, Tensor! workspace, int num_bits, "
+     "int size_m, int size_n, int size_k) -> Tensor", _fp8_marlin_gemm),                   # :218-222
+]
+
 _CACHE_OPS = [
     ("reshape_and_cache(Tensor key, Tensor value, Tensor! key_cache, Tensor! value_cache, Tensor slot_mapping, "
      "str kv_cache_dtype, float k_scale, float v_scale) -> ()", ops.reshape_and_cache),    # :467-473
     ("convert_fp8(Tensor! dst_cache, Tensor src_cache, float scale, str kv_cache_dtype) -> ()",
      ops.convert_fp8),                                                                     # :487-490
+    ("reshape_and_cache_flash(Tensor key, Tensor value, Tensor! key_cache, Tensor! value_cache, "
+     "Tensor slot_mapping, str kv_cache_dtype, float k_scale, float v_scale) -> ()",
+     ops.reshape_and_cache_flash),                                                         # :476-484
+    ("copy_blocks(Tensor(a!)[] key_caches, Tensor[](b!) value_caches, Tensor block_mapping) -> ()",
+     ops.copy_blocks),                                                                     # :461-464
+    ("swap_blocks(Tensor src, Tensor! dst, Tensor block_mapping) -> ()", ops.swap_blocks),  # :456-458
 ]
 
 _ROCM_OPS = [

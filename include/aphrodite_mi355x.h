@@ -166,6 +166,34 @@ int aphro_reshape_and_cache(const void* key, const void* value, void* key_cache,
                             int64_t value_stride, int dtype, int kv_dtype,
                             float k_scale, float v_scale, void* stream);
 
+/* _C_cache_ops::reshape_and_cache_flash(Tensor key, Tensor value, Tensor! key_cache,
+ *     Tensor! value_cache, Tensor slot_mapping, str kv_cache_dtype, float k_scale,
+ *     float v_scale)   kernels/torch_bindings.cpp:476-484, cache_kernels.cu:207-330.
+ * Caches in the flash layout [NB, block, H, hd]; block_stride = key_cache.stride(0)
+ * in elements. */
+int aphro_reshape_and_cache_flash(const void* key, const void* value, void* key_cache,
+                                  void* value_cache, const int64_t* slot_mapping,
+                                  int64_t num_tokens, int num_heads, int head_size,
+                                  int block_size, int64_t block_stride,
+                                  int64_t key_stride, int64_t value_stride, int dtype,
+                                  int kv_dtype, float k_scale, float v_scale,
+                                  void* stream);
+
+/* _C_cache_ops::copy_blocks(Tensor(a!)[] key_caches, Tensor[](b!) value_caches,
+ *     Tensor block_mapping)   kernels/torch_bindings.cpp:461-464, cache_kernels.cu:66-148.
+ * key/value_cache_ptrs: DEVICE arrays of num_layers base addresses; block_mapping:
+ * device int64 [num_pairs, 2] (src, dst); block_bytes = bytes of one cache block. */
+int aphro_copy_blocks(const int64_t* key_cache_ptrs, const int64_t* value_cache_ptrs,
+                      int num_layers, const int64_t* block_mapping, int64_t num_pairs,
+                      int64_t block_bytes, void* stream);
+
+/* _C_cache_ops::swap_blocks(Tensor src, Tensor! dst, Tensor block_mapping)
+ *   kernels/torch_bindings.cpp:456-458, cache_kernels.cu:24-63.
+ * block_mapping_host: HOST int64 [num_pairs, 2]; kind 0 = device->device,
+ * 1 = device->host, 2 = host->device; async copies on `stream`. */
+int aphro_swap_blocks(const void* src, void* dst, const int64_t* block_mapping_host,
+                      int64_t num_pairs, int64_t block_bytes, int kind, void* stream);
+
 /* _C_cache_ops::convert_fp8(Tensor! dst_cache, Tensor src_cache, float scale,
  *                           str kv_cache_dtype)
  *   kernels/torch_bindings.cpp:487-490, cache_kernels.cu:356-409.
@@ -305,6 +333,28 @@ int aphro_flash_attn_varlen(void* out, const void* q, const void* k, const void*
                             int64_t q_stride, int64_t k_stride, int64_t v_stride,
                             float scale, int causal, const float* alibi_slopes,
                             int dtype, void* stream);
+
+/* Prefill with cached context -- the context_attention_fwd role
+ *   attention/ops/prefix_prefill.py:696-858 (kernel :58-255), called through
+ *   PagedAttention.forward_prefix (ops/paged_attn.py:192-231) from
+ *   backends/rocm_flash_attn.py:509-527.
+ * q/k/v: the NEW tokens [T,H,hd] with token strides (elements); k_cache
+ * [NB,Hkv,hd/x,block,x], v_cache [NB,Hkv,hd,block] (uint8 for fp8: dequantised
+ * as float(fp8) * scale, rounded to the query dtype); block_tables int32
+ * [B,max_blocks]; q_start_loc int32 [B+1]; seq_lens (context + new) and ctx_lens
+ * int32 [B].  sliding_window 0 = off.  NOTE: the reference kernel ignores the
+ * layer's scale and uses 1/sqrt(hd) (prefix_prefill.py:745); `scale` here is
+ * explicit and the Python mirror passes 1/sqrt(hd). */
+int aphro_context_attention(void* out, const void* q, const void* k, const void* v,
+                            const void* k_cache, const void* v_cache,
+                            const int32_t* block_tables, const int32_t* q_start_loc,
+                            const int32_t* seq_lens, const int32_t* ctx_lens, int batch,
+                            int max_query_len, int max_blocks, int num_heads,
+                            int num_kv_heads, int head_size, int block_size, int x,
+                            int64_t q_stride, int64_t k_stride, int64_t v_stride,
+                            int64_t o_stride, float scale, float k_scale, float v_scale,
+                            const float* alibi_slopes, int sliding_window, int dtype,
+                            int kv_dtype, void* stream);
 
 #ifdef __cplusplus
 }

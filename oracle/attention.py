@@ -60,6 +60,42 @@ def reshape_and_cache(key, value, key_cache, value_cache, slot_mapping,
             value_cache[b, :, :, off] = _fp8.kv_quant(v, v_scale, kv_cache_dtype)
 
 
+def reshape_and_cache_flash(key, value, key_cache, value_cache, slot_mapping,
+                            kv_cache_dtype="auto", k_scale=1.0, v_scale=1.0):
+    """Flash-layout cache write: caches [NB, block, H, hd] (cache_kernels.cu:207-250,
+    tests/kernels/test_cache.py:268-292)."""
+    key = _f32(key)
+    value = _f32(value)
+    bs = key_cache.shape[1]
+    for t, slot in enumerate(np.asarray(slot_mapping).tolist()):
+        if slot < 0:
+            continue
+        b, off = divmod(int(slot), bs)
+        if kv_cache_dtype == "auto":
+            key_cache[b, off] = key[t].astype(key_cache.dtype)
+            value_cache[b, off] = value[t].astype(value_cache.dtype)
+        else:
+            key_cache[b, off] = _fp8.kv_quant(key[t], k_scale, kv_cache_dtype)
+            value_cache[b, off] = _fp8.kv_quant(value[t], v_scale, kv_cache_dtype)
+
+
+def copy_blocks(key_caches, value_caches, block_mapping):
+    """Per layer: cache[dst] = cache[src] for every (src, dst) pair, in order
+    (cache_kernels.cu:66-100; tests/kernels/test_cache.py:84-90)."""
+    for src, dst in np.asarray(block_mapping).reshape(-1, 2).tolist():
+        for kc in key_caches:
+            kc[dst] = kc[src]
+        for vc in value_caches:
+            vc[dst] = vc[src]
+
+
+def swap_blocks(src, dst, block_mapping):
+    """dst[d] = src[s] for every (s, d) pair (cache_kernels.cu:24-63;
+    tests/kernels/test_cache.py:383-388)."""
+    for s_, d_ in np.asarray(block_mapping).reshape(-1, 2).tolist():
+        dst[d_] = src[s_]
+
+
 def gather_kv(key_cache, value_cache, block_table, seq_len,
               kv_cache_dtype="auto", k_scale=1.0, v_scale=1.0):
     """-> K,V float32 [L,Hkv,hd] for one sequence (test_attention.py:81-93)."""
@@ -181,10 +217,15 @@ def varlen_causal_attention(q, k, v, cu_seqlens, scale, causal=True):
 
 def context_attention(q, k, v, key_cache, value_cache, block_tables,
                       query_start_loc, seq_lens, ctx_lens, scale,
-                      kv_cache_dtype="auto", k_scale=1.0, v_scale=1.0):
+                      kv_cache_dtype="auto", k_scale=1.0, v_scale=1.0,
+                      alibi_slopes=None, sliding_window=0, cache_round=None):
     """Prefill with cached context (prefix_prefill.py:58-255): each query token
     attends to the sequence's cached context (paged) plus the causal part of
-    the new tokens.  seq_lens = ctx_len + query_len."""
+    the new tokens.  seq_lens = ctx_len + query_len.  alibi bias =
+    slope * (key_pos - query_pos) (_fwd_kernel_alibi, :460-690); sliding window
+    masks keys with query_pos - key_pos >= window (:137-150).  cache_round:
+    optional callable rounding the dequantised cache values to the query dtype
+    (the kernel's `.to(q.dtype)`, :131-134)."""
     q = _f32(q).astype(np.float64)
     kn = _f32(k).astype(np.float64)
     vn = _f32(v).astype(np.float64)
@@ -200,6 +241,8 @@ def context_attention(q, k, v, key_cache, value_cache, block_tables,
         if c > 0:
             kc, vc = gather_kv(key_cache, value_cache, block_tables[b], c,
                                kv_cache_dtype, k_scale, v_scale)
+            if cache_round is not None:
+                kc, vc = cache_round(kc), cache_round(vc)
             kk = np.concatenate([kc.astype(np.float64), kn[s:s + n]], 0)
             vv = np.concatenate([vc.astype(np.float64), vn[s:s + n]], 0)
         else:
@@ -209,7 +252,12 @@ def context_attention(q, k, v, key_cache, value_cache, block_tables,
         lg = scale * np.einsum("qhd,khd->hqk", q[s:s + n], kk)
         qpos = c + np.arange(n)[:, None]
         kpos = np.arange(c + n)[None, :]
-        lg = np.where((kpos > qpos)[None], -np.inf, lg)
+        if alibi_slopes is not None:
+            lg = lg + np.asarray(alibi_slopes, np.float64)[:, None, None] * (kpos - qpos)[None]
+        mask = kpos > qpos
+        if sliding_window and sliding_window > 0:
+            mask = mask | ((qpos - kpos) >= sliding_window)
+        lg = np.where(mask[None], -np.inf, lg)
         lg -= lg.max(axis=2, keepdims=True)
         p = np.exp(lg)
         p /= p.sum(axis=2, keepdims=True)

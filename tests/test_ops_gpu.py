@@ -286,6 +286,196 @@ def test_reshape_and_cache(ops, kv_cache_dtype, dtype):
     np.testing.assert_array_equal(got_v, vc_ref)
 
 
+@pytest.mark.parametrize("kv_cache_dtype", ["auto", "fp8", "fp8_e5m2"])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_reshape_and_cache_flash(ops, kv_cache_dtype, dtype):
+    rng = np.random.default_rng(21)
+    T, H, D, BS, NB = 11, 3, 64, 16, 4
+    cdt = dtype if kv_cache_dtype == "auto" else torch.uint8
+    kc = torch.zeros(NB, BS, H, D, dtype=cdt, device=DEV)
+    vc = torch.zeros(NB, BS, H, D, dtype=cdt, device=DEV)
+    qkv = t(rng.standard_normal((T, 3 * H * D)).astype(np.float32), dtype)
+    key = qkv[:, H * D:2 * H * D].view(T, H, D)
+    val = qkv[:, 2 * H * D:].view(T, H, D)
+    slots = rng.permutation(NB * BS)[:T].astype(np.int64)
+    slots[5] = -1
+    ks, vs = (1.0, 1.0) if kv_cache_dtype == "auto" else (0.37, 0.5)
+    ops.reshape_and_cache_flash(key, val, kc, vc, t(slots), kv_cache_dtype, ks, vs)
+    kc_ref = np.zeros(kc.shape, dtype=np.float32 if kv_cache_dtype == "auto" else np.uint8)
+    vc_ref = np.zeros(vc.shape, dtype=kc_ref.dtype)
+    oa.reshape_and_cache_flash(key.float().cpu().numpy(), val.float().cpu().numpy(), kc_ref, vc_ref,
+                               slots, kv_cache_dtype, ks, vs)
+    got_k = kc.float().cpu().numpy() if kv_cache_dtype == "auto" else kc.cpu().numpy()
+    got_v = vc.float().cpu().numpy() if kv_cache_dtype == "auto" else vc.cpu().numpy()
+    np.testing.assert_array_equal(got_k, kc_ref)
+    np.testing.assert_array_equal(got_v, vc_ref)
+
+
+@pytest.mark.parametrize("kv_cache_dtype", ["auto", "fp8", "fp8_e5m2"])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("Hq,Hkv,D", [(8, 2, 128), (4, 4, 64), (6, 3, 96)])
+@pytest.mark.parametrize("variant", ["plain", "alibi", "window"])
+def test_context_attention_fwd(ops, kv_cache_dtype, dtype, Hq, Hkv, D, variant):
+    """Prefill with cached context vs the oracle (tests/kernels/test_prefix_prefill.py recipe:
+    ragged query / context lengths, shuffled block table, GQA)."""
+    if variant != "plain" and (kv_cache_dtype == "fp8_e5m2" or D == 96):
+        pytest.skip("variants covered on a subset")
+    rng = np.random.default_rng(Hq * 7 + D)
+    BS = 16
+    ctx_lens = np.array([0, 37, 128, 5, 300], np.int32)
+    qry_lens = np.array([70, 1, 65, 130, 17], np.int32)
+    B = len(ctx_lens)
+    seq_lens = ctx_lens + qry_lens
+    T = int(qry_lens.sum())
+    start = np.concatenate([[0], np.cumsum(qry_lens)]).astype(np.int32)
+    max_blocks = int((seq_lens.max() + BS - 1) // BS)
+    NB = B * max_blocks + 3
+    bt = rng.permutation(NB)[:B * max_blocks].reshape(B, max_blocks).astype(np.int32)
+    cdt = dtype if kv_cache_dtype == "auto" else torch.uint8
+    x = 16 // torch.tensor([], dtype=cdt).element_size()
+    qkv = t(rng.standard_normal((T, (Hq + 2 * Hkv) * D)).astype(np.float32) * 0.5, dtype)
+    q = qkv[:, :Hq * D].view(T, Hq, D)
+    k = qkv[:, Hq * D:(Hq + Hkv) * D].view(T, Hkv, D)
+    v = qkv[:, (Hq + Hkv) * D:].view(T, Hkv, D)
+    ks, vs = (1.0, 1.0) if kv_cache_dtype == "auto" else (0.37, 0.5)
+    if kv_cache_dtype == "auto":
+        kc = t(rng.standard_normal((NB, Hkv, D // x, BS, x)).astype(np.float32) * 0.5, dtype)
+        vc = t(rng.standard_normal((NB, Hkv, D, BS)).astype(np.float32) * 0.5, dtype)
+        kc_np, vc_np = kc.float().cpu().numpy(), vc.float().cpu().numpy()
+    else:
+        kc = torch.from_numpy(rng.integers(0, 0x70, (NB, Hkv, D // x, BS, x), dtype=np.uint8)).to(DEV)
+        vc = torch.from_numpy(rng.integers(0, 0x70, (NB, Hkv, D, BS), dtype=np.uint8)).to(DEV)
+        kc_np, vc_np = kc.cpu().numpy(), vc.cpu().numpy()
+    slopes = (rng.random(Hq).astype(np.float32) * 0.2) if variant == "alibi" else None
+    window = 48 if variant == "window" else None
+    out = torch.empty(T, Hq, D, dtype=dtype, device=DEV)
+    ops.context_attention_fwd(q, k, v, out, kv_cache_dtype, kc, vc, t(bt), t(start), t(seq_lens),
+                              t(ctx_lens), int(qry_lens.max()), ks, vs,
+                              t(slopes) if slopes is not None else None, window)
+    rnd = lambda a: torch.from_numpy(a.astype(np.float32)).to(dtype).float().numpy()
+    ref = oa.context_attention(q.float().cpu().numpy(), k.float().cpu().numpy(), v.float().cpu().numpy(),
+                               kc_np, vc_np, bt, start, seq_lens, ctx_lens, D ** -0.5, kv_cache_dtype,
+                               ks, vs, slopes, window or 0, rnd)
+    tol = 2e-3 if dtype == torch.float16 else 1.6e-2
+    np.testing.assert_allclose(out.float().cpu().numpy(), ref, atol=tol, rtol=tol)
+
+
+def test_backend_prefix_prefill_matches_full_prefill(ops):
+    """AttentionImpl.forward with cached context == prefill of the whole sequence
+    (chunked-prefill / prefix-caching consistency through the backend seam)."""
+    from aphrodite_engine_amd.attention.backend import MI355XAttentionBackend as BK
+    from aphrodite_engine_amd.attention.backend import MI355XAttentionImpl, MI355XAttentionMetadata
+    rng = np.random.default_rng(3)
+    Hq, Hkv, D, BS = 8, 2, 128, 16
+    lens = [100, 33]
+    cut = [64, 16]                     # tokens already cached
+    T = sum(lens)
+    NB = 20
+    impl = MI355XAttentionImpl(Hq, D, D ** -0.5, Hkv)
+    kv_cache = torch.zeros(BK.get_kv_cache_shape(NB, BS, Hkv, D), dtype=torch.float16, device=DEV)
+    q = t(rng.standard_normal((T, Hq * D)).astype(np.float32) * 0.5, torch.float16)
+    k = t(rng.standard_normal((T, Hkv * D)).astype(np.float32) * 0.5, torch.float16)
+    v = t(rng.standard_normal((T, Hkv * D)).astype(np.float32) * 0.5, torch.float16)
+    bt = rng.permutation(NB)[:2 * 8].reshape(2, 8).astype(np.int32)
+    starts = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+
+    def slots(b, lo, hi):
+        pos = np.arange(lo, hi)
+        return bt[b][pos // BS].astype(np.int64) * BS + pos % BS
+
+    def meta(qlens, ctx, slot_list):
+        qs = np.concatenate([[0], np.cumsum(qlens)]).astype(np.int32)
+        sl = [c + n for c, n in zip(ctx, qlens)]
+        return MI355XAttentionMetadata(
+            num_prefills=2, num_prefill_tokens=int(sum(qlens)), num_decode_tokens=0,
+            slot_mapping=t(np.concatenate(slot_list)), seq_lens=sl,
+            seq_lens_tensor=t(np.array(sl, np.int32)), max_query_len=max(qlens),
+            max_prefill_seq_len=max(sl), max_decode_seq_len=0, query_start_loc=t(qs),
+            seq_start_loc=t(np.concatenate([[0], np.cumsum(sl)]).astype(np.int32)),
+            context_lens_tensor=t(np.array(ctx, np.int32)), block_tables=t(bt))
+
+    # full prefill (no context)
+    full = impl.forward(q, k, v, kv_cache, meta(lens, [0, 0], [slots(0, 0, lens[0]), slots(1, 0, lens[1])]))
+    # second chunk only, first chunk already in the cache (written by the full pass)
+    rows = np.concatenate([np.arange(starts[b] + cut[b], starts[b + 1]) for b in range(2)])
+    rows_t = torch.from_numpy(rows).to(DEV)
+    qlens = [lens[b] - cut[b] for b in range(2)]
+    part = impl.forward(q[rows_t], k[rows_t], v[rows_t], kv_cache,
+                        meta(qlens, cut, [slots(0, cut[0], lens[0]), slots(1, cut[1], lens[1])]))
+    torch.testing.assert_close(part.float(), full[rows_t].float(), atol=2e-3, rtol=2e-3)
+
+
+@pytest.mark.parametrize("cdt", [torch.float16, torch.uint8])
+@pytest.mark.parametrize("num_layers,num_pairs", [(1, 1), (3, 7), (5, 40)])
+def test_copy_blocks(ops, cdt, num_layers, num_pairs):
+    """tests/kernels/test_cache.py:42-113: forked blocks are copied in every layer."""
+    rng = np.random.default_rng(num_layers * 100 + num_pairs)
+    NB, Hkv, D, BS = 64, 2, 32, 16
+    x = 16 // torch.tensor([], dtype=cdt).element_size()
+    mk = (lambda shape: torch.randint(0, 255, shape, dtype=torch.uint8, device=DEV)) if cdt == torch.uint8 \
+        else (lambda shape: torch.randn(shape, device=DEV).to(cdt))
+    kcs = [mk((NB, Hkv, D // x, BS, x)) for _ in range(num_layers)]
+    vcs = [mk((NB, Hkv, D, BS)) for _ in range(num_layers)]
+    # distinct destinations, sources never also a destination (the reference test's recipe)
+    perm = rng.permutation(NB)
+    src = perm[:num_pairs // 2 + 1]
+    dsts = perm[num_pairs // 2 + 1:num_pairs // 2 + 1 + num_pairs]
+    mapping = np.stack([rng.choice(src, size=len(dsts)), dsts], axis=1).astype(np.int64)
+    k_ref = [k.cpu().numpy().copy() for k in kcs]
+    v_ref = [v.cpu().numpy().copy() for v in vcs]
+    oa.copy_blocks(k_ref, v_ref, mapping)
+    ops.copy_blocks(kcs, vcs, t(mapping))
+    for got, ref in zip(kcs + vcs, k_ref + v_ref):
+        np.testing.assert_array_equal(got.cpu().numpy(), ref)
+    ops.copy_blocks([], [], t(mapping))   # no layers: no-op
+
+
+@pytest.mark.parametrize("direction", [("cuda", "cuda"), ("cuda", "cpu"), ("cpu", "cuda")])
+def test_swap_blocks(ops, direction):
+    """tests/kernels/test_cache.py:319-390."""
+    rng = np.random.default_rng(5)
+    NB, Hkv, D, BS = 32, 2, 64, 16
+    sdev, ddev = direction
+    src = torch.randn(NB, Hkv, D, BS).half().to(sdev)
+    dst = torch.randn(NB, Hkv, D, BS).half().to(ddev)
+    if sdev == "cpu":
+        src = src.pin_memory()
+    if ddev == "cpu":
+        dst = dst.pin_memory()
+    pairs = np.stack([rng.permutation(NB)[:9], rng.permutation(NB)[:9]], axis=1).astype(np.int64)
+    ref = dst.cpu().numpy().copy()
+    oa.swap_blocks(src.cpu().numpy(), ref, pairs)
+    ops.swap_blocks(src, dst, torch.from_numpy(pairs))
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(dst.cpu().numpy(), ref)
+    with pytest.raises(RuntimeError):
+        ops.swap_blocks(src, dst, t(pairs))            # block_mapping must be on the CPU
+    with pytest.raises(RuntimeError):
+        ops.swap_blocks(src.cpu(), dst.cpu(), torch.from_numpy(pairs))
+
+
+@pytest.mark.parametrize("has_zp", [False, True])
+@pytest.mark.parametrize("M", [1, 32, 48])
+def test_gptq_marlin_gemm_role(ops, has_zp, M):
+    """The Marlin-role op (torch_bindings.cpp:195-201) over the CDNA4 repack."""
+    from aphrodite_engine_amd.scalar_type import scalar_types
+    rng = np.random.default_rng(M + has_zp)
+    K, N, G = 512, 256, 128
+    w = (rng.standard_normal((K, N)) * 0.05).astype(np.float32)
+    w_ref, q, s, zp = oq.quantize_weights(w, 4, G, zero_points=has_zp)
+    qweight = oq.gptq_pack(q, 4)
+    a = t(rng.standard_normal((M, K)).astype(np.float16))
+    empty = torch.empty(0, dtype=torch.int32, device=DEV)
+    b = ops.gptq_marlin_repack(t(qweight), empty, K, N, 4)
+    zeros = t(oq.pack_cols(zp.astype(np.int32), 4)) if has_zp else empty
+    got = ops.gptq_marlin_gemm(a, b, t(s, torch.float16), zeros, empty, empty, None,
+                               scalar_types.uint4 if has_zp else scalar_types.uint4b8,
+                               M, N, K, True, has_zp, True, False).float().cpu().numpy()
+    ref = a.float().cpu().numpy() @ w_ref.astype(np.float16).astype(np.float32)
+    assert rel_mean_err(got, ref) < 0.04          # tests/kernels/test_marlin_gemm.py:30-32
+    np.testing.assert_allclose(got, ref, rtol=2e-3, atol=2e-3 * np.abs(ref).max())
+
+
 @pytest.mark.parametrize("kind", ["fp8", "fp8_e5m2"])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_convert_fp8_round_trip(ops, kind, dtype):
