@@ -666,6 +666,36 @@ def paged_attention_packed(query: torch.Tensor, key_cache: torch.Tensor, value_c
     return packed, out
 
 
+def paged_attention_rope_packed(qkv_slabs: torch.Tensor, positions: torch.Tensor,
+                                cos_sin_cache: torch.Tensor, slot_mapping: torch.Tensor,
+                                key_cache: torch.Tensor, value_cache: torch.Tensor, num_heads: int,
+                                num_kv_heads: int, scale: float, block_tables: torch.Tensor,
+                                seq_lens: torch.Tensor, block_size: int, max_seq_len: int,
+                                alibi_slopes: Optional[torch.Tensor], kv_cache_dtype: str, k_scale: float,
+                                v_scale: float, want_out: bool = False):
+    """[qkv slab reduce] + rotary_embedding + reshape_and_cache + decode attention + pack in one
+    launch (head_size 128, NeoX, v1 form).  Mutates key_cache / value_cache.  positions=None:
+    cos_sin_cache is the per-sequence gather cos_sin[positions] (done once per step)."""
+    lib = _lib.lib()
+    nslab, num_seqs, ntot = qkv_slabs.shape
+    head_size = ntot // (num_heads + 2 * num_kv_heads)
+    dtype = cos_sin_cache.dtype
+    packed = torch.empty(lib.aphro_wna16_packed_a_bytes(num_seqs, num_heads * head_size) // 2,
+                         dtype=torch.float16, device=qkv_slabs.device)
+    out = torch.empty((num_seqs, num_heads, head_size), dtype=dtype, device=qkv_slabs.device) \
+        if want_out else None
+    if positions is not None and positions.dtype != torch.int64:
+        positions = positions.long()
+    check(lib.aphro_paged_attention_rope_packed(
+        _ptr(out), packed.data_ptr(), qkv_slabs.data_ptr(), nslab, _ptr(positions),
+        cos_sin_cache.data_ptr(), slot_mapping.data_ptr(), key_cache.data_ptr(), value_cache.data_ptr(),
+        num_seqs, num_heads, num_kv_heads, head_size, float(scale), block_tables.data_ptr(),
+        seq_lens.data_ptr(), block_tables.stride(0), block_size, int(max_seq_len), _ptr(alibi_slopes),
+        key_cache.stride(0), key_cache.stride(1), _dt(cos_sin_cache), _kv(kv_cache_dtype),
+        float(k_scale), float(v_scale), _stream()), "paged_attention_rope_packed")
+    return packed, out
+
+
 def wna16_gemm(a, qweight_kpacked, qzeros, scales, perm=None, zero_offset=0):
     """The gptq_marlin_gemm role: fast W4A16 kernel on prepacked weights."""
     _require_cuda(a, qweight_kpacked, qzeros, scales)

@@ -30,6 +30,8 @@ SIGNATURES = {
     "aphro_wna16_gemm_silu_pack": (I, [P, P, P, P, P, L, L, L, L, I, I, P]),
     "aphro_paged_attention_packed": (I, [P, P, P, P, P, I, I, I, I, F, P, P, I, I, I, P,
                                          L, L, L, I, I, F, F, P]),
+    "aphro_paged_attention_rope_packed": (I, [P, P, P, I, P, P, P, P, P, I, I, I, I, F, P, P, I, I, I, P,
+                                              L, L, I, I, F, F, P]),
     "aphro_fused_add_rms_norm_pack": (I, [P, P, I, P, I, P, F, P, P, L, I, I, P]),
     "aphro_silu_and_mul_pack": (I, [P, P, P, L, I, I, P]),
     "aphro_rope_cache": (I, [P, L, P, I, P, P, I, I, P, P, P, P, L, I, I, I, I, I, I, I, F, F, P]),

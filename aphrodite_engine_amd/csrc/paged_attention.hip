@@ -48,6 +48,19 @@ struct PAParams {
   float scale;         // softmax scale * k_scale
   float v_scale;
   int64_t q_stride, kv_block_stride, kv_head_stride;
+  // ---- fused QKV-slab reduce + rotary embedding + cache write (decode fast path) ----
+  // When qkv_slabs != NULL the kernel takes q/k/v of the NEW token of every sequence from the
+  // fp32 split-K slabs of the qkv GEMM ([nslab][num_seqs][(Hq+2Hkv)*hd]), applies NeoX rotary
+  // embedding (rot_dim == hd) and writes K/V to the cache slot before attending -- the work of
+  // rotary_embedding + reshape_and_cache (pos_encoding_kernels.cu:10-160, cache_kernels.cu:
+  // 152-204) with identical roundings.  v1 form, hd == 128 only.
+  const float* qkv_slabs;
+  int nslab;
+  int64_t slab_stride;           // num_seqs * (Hq + 2 Hkv) * hd
+  const int64_t* positions;      // [num_seqs]
+  const uint16_t* cos_sin;       // T [max_pos, hd]: cos | sin
+  const int64_t* slot_mapping;   // [num_seqs]
+  float k_scale_raw, v_scale_raw;
 };
 
 template <typename T>
@@ -88,7 +101,9 @@ __device__ __forceinline__ u32x2 fp8x4_to_T(uint32_t w) {
 }
 
 // KV: 0 = cache holds T, 1 = e4m3, 2 = e5m2.   HD: head size.  BS: block size.
-template <typename T, int KV, int HD, int BS, int NW>
+// ROPE: the fused rotary + cache-write form (a separate instantiation: the plain kernel must not
+// pay for the extra live state -- measured +1.4 us per launch when it was a runtime branch)
+template <typename T, int KV, int HD, int BS, int NW, bool ROPE>
 __global__ __launch_bounds__(NW * 64) void paged_attention_kernel(PAParams p) {
   constexpr bool FP8 = KV != 0;
   constexpr bool E5M2 = KV == 2;
@@ -122,33 +137,106 @@ __global__ __launch_bounds__(NW * 64) void paged_attention_kernel(PAParams p) {
   const char* kc = (const char*)p.kc + (size_t)kvh * p.kv_head_stride * ESZ;
   const char* vc = (const char*)p.vc + (size_t)kvh * p.kv_head_stride * ESZ;
 
+  // ---- fused rope + cache write of the new token (see PAParams) ---------------------------
+  constexpr bool fused_rope = ROPE && HD == 128;
+  const int ntot = (p.num_heads + 2 * p.num_kv_heads) * HD;
+  const uint16_t* cs_row = nullptr;
+  auto slab8 = [&](int col, float (&o8)[8]) {  // 8 consecutive qkv columns of this sequence, rounded to T
+    const float* p0 = p.qkv_slabs + (size_t)seq * ntot + col;
+    f32x4 a = *reinterpret_cast<const f32x4*>(p0), b = *reinterpret_cast<const f32x4*>(p0 + 4);
+    for (int k = 1; k < p.nslab; ++k) {
+      a += *reinterpret_cast<const f32x4*>(p0 + k * p.slab_stride);
+      b += *reinterpret_cast<const f32x4*>(p0 + k * p.slab_stride + 4);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      o8[i] = T::to_f32(T::from_f32(a[i]));
+      o8[4 + i] = T::to_f32(T::from_f32(b[i]));
+    }
+  };
+  auto rope8 = [&](int col, int d0, u16x8& xo8, u16x8& yo8) {  // dims d0..d0+7 and their partners d0+HD/2
+    float xv[8], yv[8];
+    slab8(col + d0, xv);
+    slab8(col + HD / 2 + d0, yv);
+    const u16x8 c8 = *reinterpret_cast<const u16x8*>(cs_row + d0);
+    const u16x8 s8 = *reinterpret_cast<const u16x8*>(cs_row + HD / 2 + d0);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float xo, yo;
+      rope_pair(xv[j], yv[j], T::to_f32(c8[j]), T::to_f32(s8[j]), xo, yo);
+      xo8[j] = T::from_f32(xo);
+      yo8[j] = T::from_f32(yo);
+    }
+  };
+  // positions == NULL: cos_sin already holds one gathered row per sequence (no dependent load)
+  if (fused_rope) cs_row = p.cos_sin + (p.positions ? p.positions[seq] : (int64_t)seq) * HD;
+  // The wave that owns the LAST tile pair writes the new token's K/V before it loads that pair:
+  // the cache lines of one 16-token block are only ever read by the wave that owns its tile, so
+  // a wave-local release/acquire fence is enough (no workgroup barrier).
+  auto write_new_kv = [&]() __attribute__((always_inline)) {
+    {
+      const int64_t slot = p.slot_mapping[seq];
+      if (slot >= 0) {
+        const int64_t blk = slot / BS;
+        const int off = (int)(slot % BS);
+        const int nq = p.num_heads * HD;
+        if (lane < HD / 16) {  // K: rotary, then [hd/x][block][x] chunks
+          const int d0 = 8 * lane;
+          u16x8 xo8, yo8;
+          rope8(nq + kvh * HD, d0, xo8, yo8);
+#pragma unroll
+          for (int part2 = 0; part2 < 2; ++part2) {
+            const int d = part2 ? HD / 2 + d0 : d0;
+            const u16x8& o8 = part2 ? yo8 : xo8;
+            char* dst = const_cast<char*>(kc) + ((size_t)blk * p.kv_block_stride + (size_t)(d / XE) * BS * XE +
+                                                 (size_t)off * XE + d % XE) * ESZ;
+            if constexpr (!FP8) {
+              *reinterpret_cast<u16x8*>(dst) = o8;
+            } else {
+              uint32_t w0 = 0, w1 = 0;
+#pragma unroll
+              for (int j = 0; j < 4; j += 2) {
+                w0 |= f32x2_to_fp8<E5M2>(T::to_f32(o8[j]) / p.k_scale_raw, T::to_f32(o8[j + 1]) / p.k_scale_raw) << (8 * j);
+                w1 |= f32x2_to_fp8<E5M2>(T::to_f32(o8[4 + j]) / p.k_scale_raw, T::to_f32(o8[5 + j]) / p.k_scale_raw) << (8 * j);
+              }
+              *reinterpret_cast<u32x2*>(dst) = u32x2{w0, w1};
+            }
+          }
+        } else if (lane < HD / 16 + HD / 8) {  // V: [hd][block]
+          const int d0 = 8 * (lane - HD / 16);
+          float vv[8];
+          slab8(nq + p.num_kv_heads * HD + kvh * HD + d0, vv);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            char* dst = const_cast<char*>(vc) + ((size_t)blk * p.kv_block_stride + (size_t)(d0 + j) * BS + off) * ESZ;
+            if constexpr (!FP8) *reinterpret_cast<uint16_t*>(dst) = T::from_f32(vv[j]);
+            else *reinterpret_cast<uint8_t*>(dst) = (uint8_t)f32x2_to_fp8<E5M2>(vv[j] / p.v_scale_raw, 0.f);
+          }
+        }
+      }
+      // wave-local visibility only: the stores must have been performed (write-through L1) before
+      // this wave's loads of the same lines.  NOT __threadfence(): an agent-scope fence writes back
+      // and invalidates the whole L2 (measured +16 us per launch).
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    }
+  };
+
   for (int hb = 0; hb < gqa; hb += 16) {  // >16 query heads per kv head: extra passes
     const int nh = min(16, gqa - hb);
     const int head = kvh * gqa + hb + c;  // this lane's query head (valid if c < nh)
-    // ---- Q fragments (B operand: lane (g, head) holds 8 consecutive d) --------
-    u32x4 qf[NKS];
-    {
-      const uint16_t* qp = (const uint16_t*)p.q + (size_t)seq * p.q_stride + (size_t)head * HD;
-#pragma unroll
-      for (int ks = 0; ks < NKS; ++ks) {
-        int d0;
-        if constexpr (FP8) d0 = 64 * (ks >> 1) + 16 * g + 8 * (ks & 1);
-        else d0 = 32 * ks + 8 * g;
-        if (c < nh && d0 < HD) qf[ks] = *reinterpret_cast<const u32x4*>(qp + d0);
-        else qf[ks] = u32x4{0, 0, 0, 0};
-      }
-    }
     const float slope = (p.alibi != nullptr && c < nh) ? p.alibi[head] : 0.f;
-
     f32x4 o[NDT];
 #pragma unroll
     for (int i = 0; i < NDT; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     float m_run = -1e30f;
     float l_run = 0.f;  // this lane's share (its 4g..4g+3 tokens); summed over g at the end
-
+    u32x4 qf[NKS];
     const int pair0 = pstart >> 5;
     const int pair_end = (pend + 31) >> 5;
-    for (int pr = pair0 + wave; pr < pair_end; pr += NW) {
+    // K/V registers of one 32-token tile pair: kf = K fragments, vraw = 4 tokens x 16 d-rows per
+    // lane (16-bit KV: 8 B, fp8: 4 B in [0]).  Two sets: the next pair's loads are in flight while
+    // the current pair is computed (and, in the fused-rope form, while q is being rotated).
+    auto load_pair = [&](int pr, u32x4 (&kf)[2][NLD], u32x2 (&vraw)[NDT][2]) __attribute__((always_inline)) {
       const int tb = pr << 5;
       // ---- addresses -----------------------------------------------------------
       const char* kptr[2];
@@ -163,7 +251,6 @@ __global__ __launch_bounds__(NW * 64) void paged_attention_kernel(PAParams p) {
         vptr[jj] = vc + ((size_t)blv * p.kv_block_stride + (size_t)c * BS + (tv % BS)) * ESZ;
       }
       // ---- issue all K and V loads of the pair ----------------------------------
-      u32x4 kf[2][NLD];
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
@@ -175,7 +262,6 @@ __global__ __launch_bounds__(NW * 64) void paged_attention_kernel(PAParams p) {
           else
             kf[jj][ld] = u32x4{0, 0, 0, 0};
         }
-      u32x2 vraw[NDT][2];  // 16-bit KV: 4 tokens = 8 B ; fp8: 4 B in [0]
 #pragma unroll
       for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
@@ -192,6 +278,9 @@ __global__ __launch_bounds__(NW * 64) void paged_attention_kernel(PAParams p) {
             vraw[dt][jj] = u32x2{0, 0};
           }
         }
+    };
+    auto compute_pair = [&](int pr, u32x4 (&kf)[2][NLD], u32x2 (&vraw)[NDT][2]) __attribute__((always_inline)) {
+      const int tb = pr << 5;
       // ---- S^T = K . Q^T -----------------------------------------------------------
       f32x4 s[2];
 #pragma unroll
@@ -275,6 +364,61 @@ __global__ __launch_bounds__(NW * 64) void paged_attention_kernel(PAParams p) {
         }
         o[dt] = mfma16<T>(vf, pf, o[dt]);
       }
+    };
+    u32x4 kfa[2][NLD];
+    u32x2 vra[NDT][2];
+    int pr = pair0 + wave;
+    const bool kv_owner = fused_rope && hb == 0 && wave == ((pair_end - 1 - pair0) % NW);
+    const bool first_is_last = pr + NW >= pair_end;
+#ifndef APHRO_PA_PEEL
+#define APHRO_PA_PEEL 0
+#endif
+    constexpr bool PEEL = APHRO_PA_PEEL && HD <= 128;
+    if (kv_owner && (first_is_last || !PEEL)) write_new_kv();  // must be visible before this wave loads the last pair
+    if constexpr (PEEL) {
+      if (pr < pair_end) load_pair(pr, kfa, vra);   // in flight while the q fragments are prepared
+    }
+    // ---- Q fragments (B operand: lane (g, head) holds 8 consecutive d) --------
+    if (fused_rope) {
+      if constexpr (HD == 128) {
+#pragma unroll
+        for (int ks = 0; ks < NKS / 2; ++ks) {
+          int d0;
+          if constexpr (FP8) d0 = 64 * (ks >> 1) + 16 * g + 8 * (ks & 1);
+          else d0 = 32 * ks + 8 * g;
+          if (c < nh) {
+            u16x8 xo8, yo8;
+            rope8(head * HD, d0, xo8, yo8);      // partner chunk d0 + 64 is fragment ks + NKS/2 of this lane
+            qf[ks] = __builtin_bit_cast(u32x4, xo8);
+            qf[ks + NKS / 2] = __builtin_bit_cast(u32x4, yo8);
+          } else {
+            qf[ks] = u32x4{0, 0, 0, 0};
+            qf[ks + NKS / 2] = u32x4{0, 0, 0, 0};
+          }
+        }
+      }
+    } else {
+      const uint16_t* qp = (const uint16_t*)p.q + (size_t)seq * p.q_stride + (size_t)head * HD;
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        int d0;
+        if constexpr (FP8) d0 = 64 * (ks >> 1) + 16 * g + 8 * (ks & 1);
+        else d0 = 32 * ks + 8 * g;
+        if (c < nh && d0 < HD) qf[ks] = *reinterpret_cast<const u32x4*>(qp + d0);
+        else qf[ks] = u32x4{0, 0, 0, 0};
+      }
+    }
+
+    if constexpr (PEEL) {
+      if (kv_owner && !first_is_last) write_new_kv();  // overlaps with the first pair's loads
+      if (pr < pair_end) {
+        compute_pair(pr, kfa, vra);
+        pr += NW;
+      }
+    }
+    for (; pr < pair_end; pr += NW) {
+      load_pair(pr, kfa, vra);
+      compute_pair(pr, kfa, vra);
     }
 
     // ---- merge the NW waves through LDS ---------------------------------------------
@@ -406,13 +550,13 @@ __global__ void convert_fp8_kernel(void* __restrict__ dst, const void* __restric
 }
 
 // ---------------------------------------------------------------------------
-template <typename T, int KV, int HD, int BS>
+template <typename T, int KV, int HD, int BS, bool ROPE = false>
 static int launch_pa(const PAParams& p, int num_seqs, int parts, int nw, hipStream_t st) {
   dim3 grid((unsigned)p.num_kv_heads, (unsigned)num_seqs, (unsigned)parts);
   size_t lds = ((size_t)nw * 16 * 2 + (size_t)nw * p.nh_lds * HD) * sizeof(float);
 #define APHRO_PA_LAUNCH(NWV)                                                                        \
   {                                                                                                 \
-    auto kern = paged_attention_kernel<T, KV, HD, BS, NWV>;                                         \
+    auto kern = paged_attention_kernel<T, KV, HD, BS, NWV, ROPE>;                                   \
     if (lds > 64 * 1024)                                                                            \
       (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     hipLaunchKernelGGL(kern, grid, dim3(NWV * 64), lds, st, p);                                      \
@@ -427,6 +571,12 @@ static int launch_pa(const PAParams& p, int num_seqs, int parts, int nw, hipStre
 template <typename T, int KV>
 static int dispatch_pa(const PAParams& p, int num_seqs, int parts, int nw, int head_size, int block_size,
                        hipStream_t st) {
+  if (p.qkv_slabs != nullptr) {  // fused rotary + cache write: head_size 128 only (checked by the caller)
+    if (block_size == 16) return launch_pa<T, KV, 128, 16, true>(p, num_seqs, parts, nw, st);
+    if (block_size == 32) return launch_pa<T, KV, 128, 32, true>(p, num_seqs, parts, nw, st);
+    set_error("paged_attention: the fused rotary form supports block_size 16 / 32");
+    return APHRO_ERR_INVALID;
+  }
 #define APHRO_PA_CASE(HDV, BSV) \
   if (head_size == HDV && block_size == BSV) return launch_pa<T, KV, HDV, BSV>(p, num_seqs, parts, nw, st);
   APHRO_PA_CASE(128, 16)
@@ -456,15 +606,29 @@ static int paged_attention_impl(void* out, void* out_packed, float* exp_sums, fl
                                      int max_num_blocks_per_seq, int block_size, int max_seq_len,
                                      const float* alibi_slopes, int64_t q_stride, int64_t kv_block_stride,
                                      int64_t kv_head_stride, int dtype, int kv_dtype, float k_scale,
-                                     float v_scale, int partition_size, void* stream) {
+                                     float v_scale, int partition_size, void* stream,
+                                     const float* qkv_slabs = nullptr, int nslab = 0,
+                                     const int64_t* positions = nullptr, const void* cos_sin = nullptr,
+                                     const int64_t* slot_mapping = nullptr) {
   hipStream_t st = (hipStream_t)stream;
   APHRO_CHECK(dtype == APHRO_F16 || dtype == APHRO_BF16, "paged_attention: query dtype must be f16 or bf16");
   APHRO_CHECK(kv_dtype >= APHRO_KV_AUTO && kv_dtype <= APHRO_KV_FP8_E5M2, "Unsupported data type of kv cache: %d", kv_dtype);
   APHRO_CHECK(num_kv_heads > 0 && num_heads % num_kv_heads == 0, "paged_attention: num_heads %% num_kv_heads != 0");
   APHRO_CHECK(partition_size >= 0 && partition_size % 32 == 0, "paged_attention: partition size must be a multiple of 32");
-  APHRO_CHECK(q_stride % 8 == 0 && ((uintptr_t)query % 16) == 0, "paged_attention: query must be 16-byte aligned");
+  APHRO_CHECK(qkv_slabs != nullptr || (q_stride % 8 == 0 && ((uintptr_t)query % 16) == 0),
+              "paged_attention: query must be 16-byte aligned");
   if (num_seqs == 0) return APHRO_OK;
   PAParams p;
+  p.qkv_slabs = qkv_slabs; p.nslab = nslab; p.positions = positions; p.cos_sin = (const uint16_t*)cos_sin;
+  p.slot_mapping = slot_mapping;
+  p.slab_stride = (int64_t)num_seqs * (num_heads + 2 * num_kv_heads) * head_size;
+  p.k_scale_raw = k_scale; p.v_scale_raw = v_scale;
+  if (qkv_slabs != nullptr) {
+    APHRO_CHECK(partition_size == 0 && head_size == 128 && nslab >= 1 && cos_sin && slot_mapping &&
+                    num_heads / num_kv_heads <= 16,
+                "paged_attention: the fused rotary + cache-write form needs the v1 form, head_size 128 and GQA <= 16");
+    APHRO_CHECK(kv_head_stride == (int64_t)head_size * block_size, "paged_attention: fused form needs contiguous caches");
+  }
   p.out_packed = out_packed; p.pack_mtiles = (num_seqs + 15) / 16;
   APHRO_CHECK(out_packed == nullptr || (partition_size == 0 && ((int64_t)num_heads * head_size) % 128 == 0),
               "paged_attention: packed output needs the single-kernel (v1) form and Hq*hd %% 128 == 0");
@@ -554,6 +718,26 @@ extern "C" int aphro_paged_attention_packed(void* out, void* out_packed, const v
                               num_heads, num_kv_heads, head_size, scale, block_tables, seq_lens,
                               max_num_blocks_per_seq, block_size, max_seq_len, alibi_slopes, q_stride,
                               kv_block_stride, kv_head_stride, dtype, kv_dtype, k_scale, v_scale, 0, stream);
+}
+
+// Decode fast path: [qkv split-K slab reduce] + rotary_embedding (NeoX, rot_dim == head_size) +
+// reshape_and_cache + paged attention (v1 form) + fragment-major output, one kernel.
+// key_cache / value_cache are WRITTEN (slot_mapping) before they are read.
+extern "C" int aphro_paged_attention_rope_packed(void* out, void* out_packed, const float* qkv_slabs, int nslab,
+                                                 const int64_t* positions, const void* cos_sin_cache,
+                                                 const int64_t* slot_mapping, void* key_cache, void* value_cache,
+                                                 int num_seqs, int num_heads, int num_kv_heads, int head_size,
+                                                 float scale, const int32_t* block_tables,
+                                                 const int32_t* seq_lens, int max_num_blocks_per_seq,
+                                                 int block_size, int max_seq_len, const float* alibi_slopes,
+                                                 int64_t kv_block_stride, int64_t kv_head_stride, int dtype,
+                                                 int kv_dtype, float k_scale, float v_scale, void* stream) {
+  APHRO_CHECK(qkv_slabs != nullptr, "paged_attention_rope_packed: qkv_slabs is NULL");
+  return paged_attention_impl(out, out_packed, nullptr, nullptr, nullptr, nullptr, key_cache, value_cache,
+                              num_seqs, num_heads, num_kv_heads, head_size, scale, block_tables, seq_lens,
+                              max_num_blocks_per_seq, block_size, max_seq_len, alibi_slopes, 0, kv_block_stride,
+                              kv_head_stride, dtype, kv_dtype, k_scale, v_scale, 0, stream, qkv_slabs, nslab,
+                              positions, cos_sin_cache, slot_mapping);
 }
 
 extern "C" int aphro_reshape_and_cache(const void* key, const void* value, void* key_cache,

@@ -131,6 +131,7 @@ class LlamaDecoderLayer(nn.Module):
         self.v_scale = 1.0
         self.tp = tp
         self.gate_up_interleaved = None
+        self.fuse_rope_attention = True
 
     def enable_fused_silu(self, m: int = 32, keep_original: bool = True) -> bool:
         """Re-lay the gate_up weights with interleaved (gate_j, up_j) columns so that the
@@ -160,7 +161,8 @@ class LlamaDecoderLayer(nn.Module):
                 return False
         return True
 
-    def forward_decode_fused(self, positions, x, slabs, residual, first, kv_cache, attn_metadata, cos_sin):
+    def forward_decode_fused(self, positions, x, slabs, residual, first, kv_cache, attn_metadata, cos_sin,
+                             cos_sin_tok=None):
         """x: row-major input (first layer) or None; slabs: fp32 split-K slabs of the
         previous down_proj.  Returns the fp32 slabs of this layer's down_proj."""
         eps = self.cfg.rms_norm_eps
@@ -172,14 +174,24 @@ class LlamaDecoderLayer(nn.Module):
         qkv_slabs, _ = ops.wna16_gemm_packed(packed, m, h, qw, qz, sc, zo, partials=True)
         from .attention.paged_attn import PagedAttention
         key_cache, value_cache = PagedAttention.split_kv_cache(kv_cache, self.num_kv_heads, self.head_dim)
-        q = ops.rope_cache(None, qkv_slabs, positions, cos_sin, True, key_cache, value_cache,
-                           attn_metadata.slot_mapping, self.num_heads, self.num_kv_heads, self.head_dim,
-                           self.attn.kv_cache_dtype, self.k_scale, self.v_scale)
-        attn_packed, _ = ops.paged_attention_packed(
-            q.view(m, self.num_heads, self.head_dim), key_cache, value_cache, self.num_kv_heads,
-            self.attn.scale, attn_metadata.block_tables, attn_metadata.seq_lens_tensor,
-            value_cache.shape[3], attn_metadata.max_decode_seq_len, None, self.attn.kv_cache_dtype,
-            self.k_scale, self.v_scale)
+        if self.head_dim == 128 and self.fuse_rope_attention:
+            # rotary embedding + cache write run inside the attention kernel
+            attn_packed, _ = ops.paged_attention_rope_packed(
+                qkv_slabs, None if cos_sin_tok is not None else positions,
+                cos_sin_tok if cos_sin_tok is not None else cos_sin, attn_metadata.slot_mapping,
+                key_cache, value_cache,
+                self.num_heads, self.num_kv_heads, self.attn.scale, attn_metadata.block_tables,
+                attn_metadata.seq_lens_tensor, value_cache.shape[3], attn_metadata.max_decode_seq_len,
+                None, self.attn.kv_cache_dtype, self.k_scale, self.v_scale)
+        else:
+            q = ops.rope_cache(None, qkv_slabs, positions, cos_sin, True, key_cache, value_cache,
+                               attn_metadata.slot_mapping, self.num_heads, self.num_kv_heads, self.head_dim,
+                               self.attn.kv_cache_dtype, self.k_scale, self.v_scale)
+            attn_packed, _ = ops.paged_attention_packed(
+                q.view(m, self.num_heads, self.head_dim), key_cache, value_cache, self.num_kv_heads,
+                self.attn.scale, attn_metadata.block_tables, attn_metadata.seq_lens_tensor,
+                value_cache.shape[3], attn_metadata.max_decode_seq_len, None, self.attn.kv_cache_dtype,
+                self.k_scale, self.v_scale)
         qw, qz, sc, zo = self.o_proj.fast_params()
         o_slabs, _ = ops.wna16_gemm_packed(attn_packed, m, self.q_size, qw, qz, sc, zo, partials=True)
         packed2, _ = ops.fused_add_rms_norm_pack(None, o_slabs, residual, True,
@@ -291,9 +303,11 @@ class LlamaForCausalLM(nn.Module):
                 and all(l.fused_decode_ok(hidden.shape[0]) for l in self.layers)):
             residual = torch.empty_like(hidden)
             slabs = None
+            # rotary table rows of this step's positions, gathered once for all layers
+            cos_sin_tok = self.cos_sin.index_select(0, positions)
             for i, layer in enumerate(self.layers):
                 slabs = layer.forward_decode_fused(positions, hidden, slabs, residual, i == 0,
-                                                   kv_caches[i], attn_metadata, self.cos_sin)
+                                                   kv_caches[i], attn_metadata, self.cos_sin, cos_sin_tok)
             _, out = ops.fused_add_rms_norm_pack(None, slabs, residual, True, self.norm,
                                                  self.cfg.rms_norm_eps, pack=False, want_out=True)
             return out

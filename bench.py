@@ -70,6 +70,9 @@ def build(args, device):
     dtype = torch.float16
     model = M.LlamaForCausalLM(cfg, qc, dtype, args.kv_cache_dtype)
     model.init_synthetic(device, seed=0)
+    if os.environ.get("APHRO_NO_FUSED_ROPE"):
+        for layer in model.layers:
+            layer.fuse_rope_attention = False
     if not os.environ.get("APHRO_NO_FUSED_SILU"):
         # load-time relayout: SiluAndMul + pack run in the gate_up GEMM epilogue
         for layer in model.layers:

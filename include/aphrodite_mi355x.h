@@ -237,6 +237,26 @@ int aphro_paged_attention_packed(void* out, void* out_packed, const void* query,
                                  int64_t kv_head_stride, int dtype, int kv_dtype,
                                  float k_scale, float v_scale, void* stream);
 
+/* Decode fast path, one launch: [qkv GEMM split-K slab reduce] + rotary_embedding
+ * (NeoX, rot_dim == head_size == 128; pos_encoding_kernels.cu:10-160) +
+ * reshape_and_cache (cache_kernels.cu:152-204) + paged attention (v1 form) +
+ * fragment-major output.  qkv_slabs fp32 [nslab][num_seqs][(Hq+2Hkv)*hd] as left by
+ * aphro_wna16_gemm_packed(c = NULL); positions / slot_mapping int64 [num_seqs];
+ * cos_sin_cache [max_pos, hd] in the activation dtype (positions == NULL: cos_sin_cache
+ * is already gathered, row i belongs to sequence i).  The new token's K/V are
+ * WRITTEN to the caches (same roundings as the separate ops) before being read. */
+int aphro_paged_attention_rope_packed(void* out, void* out_packed, const float* qkv_slabs,
+                                      int nslab, const int64_t* positions,
+                                      const void* cos_sin_cache, const int64_t* slot_mapping,
+                                      void* key_cache, void* value_cache, int num_seqs,
+                                      int num_heads, int num_kv_heads, int head_size,
+                                      float scale, const int32_t* block_tables,
+                                      const int32_t* seq_lens, int max_num_blocks_per_seq,
+                                      int block_size, int max_seq_len,
+                                      const float* alibi_slopes, int64_t kv_block_stride,
+                                      int64_t kv_head_stride, int dtype, int kv_dtype,
+                                      float k_scale, float v_scale, void* stream);
+
 /* ------------------------------------------------------------------------
  * FP8 activations + GEMMs (rows a9-a11)
  * ---------------------------------------------------------------------- */

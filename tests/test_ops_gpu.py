@@ -886,6 +886,48 @@ def test_paged_attention_packed_matches_v1(ops):
                                   out.view(S, Hq * D).cpu().numpy().view(np.uint16))
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("kv_cache_dtype", ["auto", "fp8", "fp8_e5m2"])
+@pytest.mark.parametrize("nslab", [1, 3])
+def test_paged_attention_rope_packed(ops, dtype, kv_cache_dtype, nslab):
+    """rope + cache write + attention in one launch == rope_cache -> paged_attention_packed
+    (bit for bit: attention output and both caches)."""
+    rng = np.random.default_rng(nslab + len(kv_cache_dtype))
+    S, Hq, Hkv, D, BS = 7, 8, 2, 128, 16
+    seq_lens = np.array([1, 16, 17, 32, 33, 200, 515], np.int32)
+    maxb = int((seq_lens.max() + BS - 1) // BS)
+    NB = S * maxb + 2
+    bt = rng.permutation(NB)[:S * maxb].reshape(S, maxb).astype(np.int32)
+    slots = np.array([bt[i][(l - 1) // BS] * BS + (l - 1) % BS for i, l in enumerate(seq_lens)], np.int64)
+    slots[1] = -1                                        # a padded row writes nothing
+    cdt = dtype if kv_cache_dtype == "auto" else torch.uint8
+    x = 16 // torch.tensor([], dtype=cdt).element_size()
+    if kv_cache_dtype == "auto":
+        kc0 = t(rng.standard_normal((NB, Hkv, D // x, BS, x)).astype(np.float32) * 0.3, dtype)
+        vc0 = t(rng.standard_normal((NB, Hkv, D, BS)).astype(np.float32) * 0.3, dtype)
+    else:
+        kc0 = torch.from_numpy(rng.integers(0, 0x60, (NB, Hkv, D // x, BS, x), dtype=np.uint8)).to(DEV)
+        vc0 = torch.from_numpy(rng.integers(0, 0x60, (NB, Hkv, D, BS), dtype=np.uint8)).to(DEV)
+    ks, vs = (1.0, 1.0) if kv_cache_dtype == "auto" else (0.37, 0.5)
+    slabs = t(rng.standard_normal((nslab, S, (Hq + 2 * Hkv) * D)).astype(np.float32) * 0.4)
+    pos = t((seq_lens - 1).astype(np.int64))
+    cos_sin = t(rng.standard_normal((600, D)).astype(np.float32), dtype)
+    kc_a, vc_a, kc_b, vc_b = kc0.clone(), vc0.clone(), kc0.clone(), vc0.clone()
+    q = ops.rope_cache(None, slabs, pos, cos_sin, True, kc_a, vc_a, t(slots), Hq, Hkv, D,
+                       kv_cache_dtype, ks, vs)
+    ref_packed, ref_out = ops.paged_attention_packed(q.view(S, Hq, D), kc_a, vc_a, Hkv, 0.09, t(bt),
+                                                     t(seq_lens), BS, 515, None, kv_cache_dtype, ks, vs,
+                                                     want_out=True)
+    got_packed, got_out = ops.paged_attention_rope_packed(slabs, pos, cos_sin, t(slots), kc_b, vc_b, Hq, Hkv,
+                                                          0.09, t(bt), t(seq_lens), BS, 515, None,
+                                                          kv_cache_dtype, ks, vs, want_out=True)
+    assert torch.equal(kc_a, kc_b) and torch.equal(vc_a, vc_b)
+    live = torch.from_numpy(slots >= 0).to(DEV)
+    assert torch.equal(got_out[live].view(torch.int16), ref_out[live].view(torch.int16))
+    np.testing.assert_array_equal(unpack_a(got_packed, S, Hq * D)[slots >= 0],
+                                  unpack_a(ref_packed, S, Hq * D)[slots >= 0])
+
+
 @pytest.mark.parametrize("M", [1, 16, 32, 64])
 @pytest.mark.parametrize("K,N", [(512, 256), (1024, 64), (3584, 128), (4096, 192)])
 def test_wna16_gemm_packed_paths(ops, M, K, N):

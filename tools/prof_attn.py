@@ -22,7 +22,18 @@ bt = torch.randperm(nb, device="cuda").view(bs, bps).int()
 sl = torch.full((bs, ), ctx, dtype=torch.int32, device="cuda")
 q = torch.randn(bs, Hq, D, device="cuda", dtype=torch.float16)
 o = torch.empty_like(q)
+mode = sys.argv[3] if len(sys.argv) > 3 else "v1"
+slabs = torch.randn(2, bs, (Hq + 2 * Hkv) * D, device="cuda") * 0.3
+pos = torch.full((bs, ), ctx - 1, dtype=torch.int64, device="cuda")
+cos_sin = torch.randn(ctx + 8, D, device="cuda").half()
+slots = (bt[:, (ctx - 1) // BS].long() * BS + (ctx - 1) % BS)
 for _ in range(5):
     for kc, vc in caches:
-        ops.paged_attention_v1(o, q, kc, vc, Hkv, D ** -0.5, bt, sl, BS, ctx, None, kvd, 1.0, 1.0)
+        if mode == "v1":
+            ops.paged_attention_v1(o, q, kc, vc, Hkv, D ** -0.5, bt, sl, BS, ctx, None, kvd, 1.0, 1.0)
+        elif mode == "packed":
+            ops.paged_attention_packed(q, kc, vc, Hkv, D ** -0.5, bt, sl, BS, ctx, None, kvd, 1.0, 1.0)
+        else:
+            ops.paged_attention_rope_packed(slabs, pos, cos_sin, slots, kc, vc, Hq, Hkv, D ** -0.5, bt, sl, BS,
+                                            ctx, None, kvd, 1.0, 1.0)
 torch.cuda.synchronize()
