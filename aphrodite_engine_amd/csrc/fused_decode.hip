@@ -56,12 +56,14 @@ __global__ void add_rms_norm_pack_kernel(const uint16_t* __restrict__ input, con
   const int mtiles = (tokens + 15) >> 4;
   const size_t slab_stride = (size_t)tokens * hidden;
   float v[2][8];
+  u16x8 wv[2];  // norm weights: fetched with the inputs, not after the reduction barrier
   float ss = 0.f;
 #pragma unroll
   for (int it = 0; it < 2; ++it) {
     const int i = threadIdx.x + it * blockDim.x;
     if (i < nv) {
       const size_t off = (size_t)tok * hidden + 8 * i;
+      wv[it] = *reinterpret_cast<const u16x8*>(weight + 8 * i);
       float x[8];
       if (slabs) {
         f32x4 a = *reinterpret_cast<const f32x4*>(slabs + off);
@@ -106,7 +108,7 @@ __global__ void add_rms_norm_pack_kernel(const uint16_t* __restrict__ input, con
   for (int it = 0; it < 2; ++it) {
     const int i = threadIdx.x + it * blockDim.x;
     if (i < nv) {
-      u16x8 w = *reinterpret_cast<const u16x8*>(weight + 8 * i);
+      const u16x8 w = wv[it];
       u16x8 y, yh;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -326,7 +328,8 @@ extern "C" int aphro_fused_add_rms_norm_pack(const void* input, const float* sla
   APHRO_CHECK(packed == nullptr || hidden % 128 == 0, "fused_add_rms_norm_pack: packing needs hidden %% 128 == 0");
   APHRO_CHECK(!has_residual || residual != nullptr, "fused_add_rms_norm_pack: residual missing");
   if (tokens == 0) return APHRO_OK;
-  int nv = hidden / 8, t = (nv + 1) / 2;
+  // latency bound (one workgroup per token): one 8-element vector per thread while that fits
+  int nv = hidden / 8, t = nv <= 1024 ? nv : (nv + 1) / 2;
   t = (t + 63) / 64 * 64;
   t = t < 64 ? 64 : (t > 1024 ? 1024 : t);
   dim3 grid((unsigned)tokens), block(t);

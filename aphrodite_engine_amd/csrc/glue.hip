@@ -130,8 +130,10 @@ __global__ void rotary_kernel(const int64_t* __restrict__ positions, uint16_t* _
 using namespace aphro;
 
 static int norm_threads(int hidden) {
+  // same thread -> element mapping as add_rms_norm_pack_kernel (fused_decode.hip): the
+  // sum-of-squares reduction order, hence every output bit, is shared by the two paths
   int nv = hidden / 8;
-  int t = (nv + 1) / 2;
+  int t = nv <= 1024 ? nv : (nv + 1) / 2;
   t = (t + 63) / 64 * 64;
   return t < 64 ? 64 : (t > 1024 ? 1024 : t);
 }
