@@ -634,9 +634,9 @@ def rope_cache(qkv: Optional[torch.Tensor], slabs: Optional[torch.Tensor], posit
         nslab, dev, stride = 0, qkv.device, qkv.stride(0)
     dtype = cos_sin_cache.dtype
     q_out = torch.empty((tokens, num_heads * head_size), dtype=dtype, device=dev)
-    if positions.dtype != torch.int64:
+    if positions is not None and positions.dtype != torch.int64:
         positions = positions.long()
-    check(lib.aphro_rope_cache(_ptr(qkv), stride, _ptr(slabs), nslab, positions.data_ptr(),
+    check(lib.aphro_rope_cache(_ptr(qkv), stride, _ptr(slabs), nslab, _ptr(positions),
                                cos_sin_cache.data_ptr(), cos_sin_cache.shape[1], 1 if is_neox else 0,
                                q_out.data_ptr(), key_cache.data_ptr(), value_cache.data_ptr(),
                                slot_mapping.data_ptr(), tokens, num_heads, num_kv_heads, head_size,

@@ -166,7 +166,7 @@ __global__ void rope_cache_kernel(const uint16_t* __restrict__ qkv, int64_t qkv_
     }
     return T::to_f32(qkv[(size_t)tok * qkv_stride + j]);
   };
-  const int64_t pos = positions[tok];
+  const int64_t pos = positions ? positions[tok] : (int64_t)tok;  // NULL: cos_sin rows pre-gathered per token
   const uint16_t* cs = cos_sin + pos * rot_dim;
   const int embed = rot_dim >> 1;
   const int64_t slot = slot_mapping[tok];
@@ -251,7 +251,7 @@ __global__ void rope_cache_vec_kernel(const uint16_t* __restrict__ qkv, int64_t 
       for (int i = 0; i < 8; ++i) o[i] = T::to_f32(v[i]);
     }
   };
-  const int64_t pos = positions[tok];
+  const int64_t pos = positions ? positions[tok] : (int64_t)tok;  // NULL: cos_sin rows pre-gathered per token
   const int half = head_size >> 1;
   const uint16_t* cs = cos_sin + pos * head_size;
   const int64_t slot = slot_mapping[tok];

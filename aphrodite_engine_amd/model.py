@@ -184,7 +184,8 @@ class LlamaDecoderLayer(nn.Module):
                 attn_metadata.seq_lens_tensor, value_cache.shape[3], attn_metadata.max_decode_seq_len,
                 None, self.attn.kv_cache_dtype, self.k_scale, self.v_scale)
         else:
-            q = ops.rope_cache(None, qkv_slabs, positions, cos_sin, True, key_cache, value_cache,
+            q = ops.rope_cache(None, qkv_slabs, None if cos_sin_tok is not None else positions,
+                               cos_sin_tok if cos_sin_tok is not None else cos_sin, True, key_cache, value_cache,
                                attn_metadata.slot_mapping, self.num_heads, self.num_kv_heads, self.head_dim,
                                self.attn.kv_cache_dtype, self.k_scale, self.v_scale)
             attn_packed, _ = ops.paged_attention_packed(

@@ -151,42 +151,66 @@ def roofline_section(model, loop, args):
     layers = list(model.layers)
     out = {}
 
+    fast = all(l.fused_decode_ok(bs) for l in layers) and getattr(model, "use_fused_decode", False)
     for name in ("gate_up_proj", "down_proj", "qkv_proj", "o_proj"):
         lin0 = getattr(layers[0], name)
         xin = torch.randn(bs, lin0.in_features, device="cuda", dtype=model.dtype)
+        if fast:
+            # exactly what the decode step launches: packed activations in, fp32 slabs (or, for
+            # gate_up with the fused epilogue, packed activations) out -- one kernel per call
+            packed = ops.wna16_pack_a(xin)
+            silu = name == "gate_up_proj" and layers[0].gate_up_interleaved is not None
 
-        def run_lin(name=name, xin=xin):
-            for layer in layers:
-                getattr(layer, name)(xin)
+            def run_lin(name=name, packed=packed, silu=silu, k=lin0.in_features):
+                for layer in layers:
+                    if silu:
+                        qw, qz, sc, zo = layer.gate_up_interleaved
+                        ops.wna16_gemm_silu_pack(packed, bs, k, qw, qz, sc, zo)
+                    else:
+                        qw, qz, sc, zo = getattr(layer, name).fast_params()
+                        ops.wna16_gemm_packed(packed, bs, k, qw, qz, sc, zo, partials=True)
+            kname = "wna16_gemm_kernel" + (" (+SiluAndMul epilogue)" if silu else "")
+        else:
+            def run_lin(name=name, xin=xin):
+                for layer in layers:
+                    getattr(layer, name)(xin)
+            kname = ("wna16_gemm_kernel" if args.quant != "fp8" else "fp8_gemm_kernel") + " (+pack/splitk_reduce)"
         t = measure_kernel(run_lin, len(layers))
-        out[name] = dict(kernel=("wna16_gemm_kernel" if args.quant != "fp8" else "fp8_gemm_kernel")
-                         + " (+splitk_reduce)", shape=[bs, lin0.in_features, lin0.out_features],
+        out[name] = dict(kernel=kname, shape=[bs, lin0.in_features, lin0.out_features],
                          bytes=gemm_bytes(lin0, bs), seconds=t)
-    # decode attention over the real caches / metadata of the loop
+    # decode attention over the real caches / metadata of the loop, in the form the step launches
     l0 = layers[0]
-    q = torch.randn(bs, l0.q_size + 2 * l0.kv_size, device="cuda", dtype=model.dtype)[:, :l0.q_size]
     meta = loop.meta
     from aphrodite_engine_amd.attention.paged_attn import PagedAttention
-    P = (meta.max_decode_seq_len + 511) // 512
-    tmp = torch.empty(bs, l0.num_heads, P, l0.head_dim, device="cuda", dtype=model.dtype)
-    es = torch.empty(bs, l0.num_heads, P, device="cuda", dtype=torch.float32)
-    ml = torch.empty_like(es)
-    o = torch.empty(bs, l0.num_heads, l0.head_dim, device="cuda", dtype=model.dtype)
     caches = [PagedAttention.split_kv_cache(c, l0.num_kv_heads, l0.head_dim) for c in loop.kv_caches]
-
-    def run_attn():
-        for kc, vc in caches:
-            ops.paged_attention_rocm(o, es, ml, tmp, q.view(bs, l0.num_heads, l0.head_dim), kc, vc,
-                                     l0.num_kv_heads, l0.attn.scale, meta.block_tables,
-                                     meta.seq_lens_tensor, 16, meta.max_decode_seq_len, None,
-                                     args.kv_cache_dtype, 1.0, 1.0)
-    launches = len(caches) * (2 if P > 1 else 1)
-    t2 = measure_kernel(run_attn, len(caches))
     esz = 1 if args.kv_cache_dtype != "auto" else 2
     tokens = int(meta.seq_lens_tensor.sum().item())
     ab = 2 * tokens * l0.num_kv_heads * l0.head_dim * esz + 2 * bs * l0.q_size * 2
-    out["paged_attention"] = dict(kernel="paged_attention_kernel(+reduce)", bytes=ab, seconds=t2,
-                                  launches_per_call=launches // len(caches))
+    ntot = l0.q_size + 2 * l0.kv_size
+    if fast and l0.head_dim == 128 and l0.fuse_rope_attention:
+        slabs = torch.randn(2, bs, ntot, device="cuda", dtype=torch.float32) * 0.1
+        cs_tok = model.cos_sin.index_select(0, loop.positions if hasattr(loop, "positions")
+                                            else (meta.seq_lens_tensor.long() - 1))
+
+        def run_attn():
+            for kc, vc in caches:
+                ops.paged_attention_rope_packed(slabs, None, cs_tok, meta.slot_mapping, kc, vc, l0.num_heads,
+                                                l0.num_kv_heads, l0.attn.scale, meta.block_tables,
+                                                meta.seq_lens_tensor, 16, meta.max_decode_seq_len, None,
+                                                args.kv_cache_dtype, 1.0, 1.0)
+        kname = "paged_attention_kernel<ROPE> (qkv slab reduce + rotary + cache write + attention)"
+        ab += slabs.numel() * 4
+    else:
+        q = torch.randn(bs, ntot, device="cuda", dtype=model.dtype)[:, :l0.q_size]
+
+        def run_attn():
+            for kc, vc in caches:
+                ops.paged_attention_packed(q.view(bs, l0.num_heads, l0.head_dim), kc, vc, l0.num_kv_heads,
+                                           l0.attn.scale, meta.block_tables, meta.seq_lens_tensor, 16,
+                                           meta.max_decode_seq_len, None, args.kv_cache_dtype, 1.0, 1.0)
+        kname = "paged_attention_kernel (v1 form)"
+    t2 = measure_kernel(run_attn, len(caches))
+    out["paged_attention"] = dict(kernel=kname, bytes=ab, seconds=t2, launches_per_call=1)
     return out
 
 
