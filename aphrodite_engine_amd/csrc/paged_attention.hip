@@ -117,6 +117,7 @@ __global__ __launch_bounds__(NW * 64) void paged_attention_kernel(PAParams p) {
   static_assert(HD % XE == 0, "head size must be a multiple of the K chunk");
 
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  __shared__ int kv_flag;  // fused form: "the new token's K/V are in the cache" (see below)
 
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -139,6 +140,10 @@ __global__ __launch_bounds__(NW * 64) void paged_attention_kernel(PAParams p) {
 
   // ---- fused rope + cache write of the new token (see PAParams) ---------------------------
   constexpr bool fused_rope = ROPE && HD == 128;
+  if constexpr (fused_rope) {
+    if (threadIdx.x == 0) kv_flag = 0;
+    __syncthreads();
+  }
   const int ntot = (p.num_heads + 2 * p.num_kv_heads) * HD;
   const uint16_t* cs_row = nullptr;
   auto slab8 = [&](int col, float (&o8)[8]) {  // 8 consecutive qkv columns of this sequence, rounded to T
@@ -368,18 +373,20 @@ __global__ __launch_bounds__(NW * 64) void paged_attention_kernel(PAParams p) {
     u32x4 kfa[2][NLD];
     u32x2 vra[NDT][2];
     int pr = pair0 + wave;
-    const bool kv_owner = fused_rope && hb == 0 && wave == ((pair_end - 1 - pair0) % NW);
-    const bool first_is_last = pr + NW >= pair_end;
-#ifndef APHRO_PA_PEEL
-#define APHRO_PA_PEEL 0
-#endif
-    constexpr bool PEEL = APHRO_PA_PEEL && HD <= 128;
-    if (kv_owner && (first_is_last || !PEEL)) write_new_kv();  // must be visible before this wave loads the last pair
-    if constexpr (PEEL) {
-      if (pr < pair_end) load_pair(pr, kfa, vra);   // in flight while the q fragments are prepared
+    // Fused form: the wave AFTER the owner of the last tile pair (the one with the fewest pairs in
+    // the round-robin) writes the new token's K/V and raises an LDS flag; the owner polls the flag
+    // right before it loads the last pair -- normally several tiles later, so it never waits.
+    const int owner_wave = (pair_end - 1 - pair0) % NW;
+    const bool kv_owner = fused_rope && hb == 0 && wave == owner_wave;
+    const bool kv_writer = fused_rope && hb == 0 && wave == (owner_wave + 1) % NW;
+    if (kv_writer) {
+      write_new_kv();
+      __hip_atomic_store(&kv_flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     // ---- Q fragments (B operand: lane (g, head) holds 8 consecutive d) --------
-    if (fused_rope) {
+    // fused form: rotated from the qkv slabs INSIDE the first loop iteration, after that
+    // iteration's K/V loads have been issued (their HBM latency covers the slab round trip)
+    auto prepare_q_rope = [&]() __attribute__((always_inline)) {
       if constexpr (HD == 128) {
 #pragma unroll
         for (int ks = 0; ks < NKS / 2; ++ks) {
@@ -397,7 +404,8 @@ __global__ __launch_bounds__(NW * 64) void paged_attention_kernel(PAParams p) {
           }
         }
       }
-    } else {
+    };
+    if constexpr (!fused_rope) {
       const uint16_t* qp = (const uint16_t*)p.q + (size_t)seq * p.q_stride + (size_t)head * HD;
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks) {
@@ -409,15 +417,21 @@ __global__ __launch_bounds__(NW * 64) void paged_attention_kernel(PAParams p) {
       }
     }
 
-    if constexpr (PEEL) {
-      if (kv_owner && !first_is_last) write_new_kv();  // overlaps with the first pair's loads
-      if (pr < pair_end) {
-        compute_pair(pr, kfa, vra);
-        pr += NW;
-      }
-    }
+    bool q_ready = !fused_rope;
     for (; pr < pair_end; pr += NW) {
+      if constexpr (fused_rope) {
+        if (kv_owner && pr + NW >= pair_end) {  // the last pair holds the new token: wait for its writer
+          while (__hip_atomic_load(&kv_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0)
+            __builtin_amdgcn_s_sleep(1);
+        }
+      }
       load_pair(pr, kfa, vra);
+      if constexpr (fused_rope) {
+        if (!q_ready) {  // wave-uniform, first iteration only
+          prepare_q_rope();
+          q_ready = true;
+        }
+      }
       compute_pair(pr, kfa, vra);
     }
 
