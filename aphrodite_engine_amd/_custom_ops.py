@@ -64,6 +64,19 @@ def _workspace(device: torch.device, nbytes: int) -> torch.Tensor:
     return ws
 
 
+_QUANT_SCRATCH = {}
+
+
+def _quant_scratch(device: torch.device) -> torch.Tensor:
+    """Per-device scratch of the atomic-free dynamic fp8 quantisation (2048 partial maxima)."""
+    key = (device.type, device.index)
+    t = _QUANT_SCRATCH.get(key)
+    if t is None:
+        t = torch.empty(2048, dtype=torch.float32, device=device)
+        _QUANT_SCRATCH[key] = t
+    return t
+
+
 def _require_cuda(*ts):
     for t in ts:
         if t is not None and not t.is_cuda:
@@ -729,10 +742,11 @@ def scaled_fp8_quant(input: torch.Tensor, scale: Optional[torch.Tensor] = None,
                 output.data_ptr(), input.data_ptr(), scale.data_ptr(),
                 _ptr(scale_ub), m, k, _dt(input), _stream()), "scaled_fp8_quant")
         else:
-            scale = torch.zeros(1, device=input.device, dtype=torch.float32)
-            check(lib.aphro_dynamic_scaled_fp8_quant(
-                output.data_ptr(), input.data_ptr(), scale.data_ptr(), m, k,
-                _dt(input), _stream()), "scaled_fp8_quant")
+            scale = torch.empty(1, device=input.device, dtype=torch.float32)
+            ws = _quant_scratch(input.device)
+            check(lib.aphro_dynamic_scaled_fp8_quant_ws(
+                output.data_ptr(), input.data_ptr(), scale.data_ptr(), ws.data_ptr(), ws.numel() * 4,
+                m, k, _dt(input), _stream()), "scaled_fp8_quant")
     else:
         assert scale.numel() == 1 or num_token_padding is None
         check(lib.aphro_static_scaled_fp8_quant(

@@ -50,6 +50,7 @@ SIGNATURES = {
                                   L, L, L, I, I, F, F, I, P]),
     "aphro_static_scaled_fp8_quant": (I, [P, P, P, L, L, I, P]),
     "aphro_dynamic_scaled_fp8_quant": (I, [P, P, P, L, L, I, P]),
+    "aphro_dynamic_scaled_fp8_quant_ws": (I, [P, P, P, P, Z, L, L, I, P]),
     "aphro_dynamic_per_token_scaled_fp8_quant": (I, [P, P, P, P, L, L, I, P]),
     "aphro_scaled_mm_fp8": (I, [P, P, P, P, P, P, P, Z, L, L, L, I, I, I, P]),
     "aphro_fp8_w8a16_gemm": (I, [P, P, P, P, P, P, Z, L, L, L, L, I, I, P]),

@@ -184,6 +184,131 @@ __global__ __launch_bounds__(FNW * 64) void fp8_gemm_kernel(Fp8GemmParams p) {
   }
 }
 
+// ---------------------------------------------------------------------------
+// W8A8 fast path (decode shapes): the structure that the int4 kernel converged on
+// (wna16_gemm.hip) -- 4 waves split K of one 64-column tile, a wave owns exactly
+// NSEG macro steps of 128 k (template parameter -> straight-line code), weight
+// loads run two macro steps ahead in registers, every global read is a buffer load
+// whose per-lane address part is loop invariant and whose k part is an SGPR offset.
+// No unpack at all: the 32 contiguous bytes a lane reads of one weight row are four
+// fp8 MFMA B fragments as they are.
+// ---------------------------------------------------------------------------
+constexpr int F8W = 4;  // waves per workgroup, fast kernel
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t fp8_rsrc(const void* base, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+
+template <typename T, int NT, int MT, int NSEG>
+__global__ __launch_bounds__(F8W * 64, 2) void fp8_gemm_fast_kernel(Fp8GemmParams p) {
+  constexpr int DEPTH = NSEG < 2 ? NSEG : 2;
+  constexpr int NBUF = DEPTH + 1;
+  extern __shared__ __attribute__((aligned(16))) float red[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4;
+  const int c = lane & 15;
+  const int n0 = blockIdx.x * (16 * NT);
+  const int m0 = blockIdx.z * (16 * MT);
+  const int ncol = n0 + NT * c;
+  const int seg0 = (blockIdx.y * F8W + wave) * NSEG;  // host guarantees K == ksplit * F8W * NSEG * 128
+
+  const __amdgpu_buffer_rsrc_t rw = fp8_rsrc(p.w, (uint32_t)((size_t)p.N * p.K));
+  const __amdgpu_buffer_rsrc_t ra = fp8_rsrc(p.a, (uint32_t)((size_t)p.M * p.lda));
+  int voff_w[NT], voff_a[MT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) voff_w[t] = (ncol + t) * p.K + 16 * g;   // lane g: bytes [16g,16g+16) and [64+16g, ..) of the 128-B step
+#pragma unroll
+  for (int i = 0; i < MT; ++i) voff_a[i] = min(m0 + 16 * i + c, p.M - 1) * p.lda + 16 * g;  // same k mapping as the weights
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  u32x4 wq[NBUF][NT][2];
+  u32x4 aq[2][MT][2];
+  auto load_w = [&](u32x4 (&wd)[NT][2], int s) {
+    const int soff = (seg0 + s) * 128;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      wd[t][0] = __builtin_amdgcn_raw_buffer_load_b128(rw, voff_w[t], soff, 2);
+      wd[t][1] = __builtin_amdgcn_raw_buffer_load_b128(rw, voff_w[t] + 64, soff, 2);
+    }
+  };
+  auto load_a = [&](u32x4 (&ad)[MT][2], int s) {
+    const int soff = (seg0 + s) * 128;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      ad[i][0] = __builtin_amdgcn_raw_buffer_load_b128(ra, voff_a[i], soff, 0);
+      ad[i][1] = __builtin_amdgcn_raw_buffer_load_b128(ra, voff_a[i] + 64, soff, 0);
+    }
+  };
+
+  load_a(aq[0], 0);
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) load_w(wq[d], d);
+  __builtin_amdgcn_sched_barrier(0);
+
+#pragma unroll
+  for (int s = 0; s < NSEG; ++s) {
+    if (s + 1 < NSEG) load_a(aq[(s + 1) & 1], s + 1);
+    if (s + DEPTH < NSEG) load_w(wq[(s + DEPTH) % NBUF], s + DEPTH);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const u32x4 wv = wq[s % NBUF][t][j >> 1];
+        const long b = (long)(((uint64_t)wv[2 * (j & 1) + 1] << 32) | wv[2 * (j & 1)]);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          const u32x4 av = aq[s & 1][i][j >> 1];
+          const long a = (long)(((uint64_t)av[2 * (j & 1) + 1] << 32) | av[2 * (j & 1)]);
+          acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a, b, acc[i][t], 0, 0, 0);
+        }
+      }
+  }
+
+  // ---- in-workgroup split-K reduction through LDS, dequant epilogue -----------------
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+      *reinterpret_cast<f32x4*>(&red[((wave * (MT * NT) + i * NT + t) * 64 + lane) * 4]) = acc[i][t];
+  __syncthreads();
+  for (int idx = wave; idx < MT * 4; idx += F8W) {
+    const int i = idx >> 2, r = idx & 3;
+    const int row = m0 + 16 * i + 4 * g + r;
+    float v[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      float sum = 0.f;
+#pragma unroll
+      for (int w2 = 0; w2 < F8W; ++w2) sum += red[((w2 * (MT * NT) + i * NT + t) * 64 + lane) * 4 + r];
+      v[t] = sum;
+    }
+    if (row < p.M) {
+      if (p.ksplit == 1) {
+        const float sa = p.a_scales ? p.a_scales[p.a_per_token ? row : 0] : 1.f;
+        typename T::storage* cp = (typename T::storage*)p.c + (size_t)row * p.N + ncol;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const float sb = p.b_scales ? p.b_scales[p.b_per_channel ? ncol + t : 0] : 1.f;
+          float o = sa * (sb * v[t]);  // order of test_cutlass.py:43
+          if (p.bias) o += T::to_f32(((const typename T::storage*)p.bias)[ncol + t]);
+          cp[t] = T::from_f32(o);
+        }
+      } else {
+        float* pp = p.partial + ((size_t)blockIdx.y * p.M + row) * p.N + ncol;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) pp[t] = v[t];
+      }
+    }
+  }
+}
+
 template <typename T>
 __global__ void fp8_splitk_reduce_kernel(Fp8GemmParams p) {
   const int64_t mn = (int64_t)p.M * p.N;
@@ -199,10 +324,30 @@ __global__ void fp8_splitk_reduce_kernel(Fp8GemmParams p) {
   ((typename T::storage*)p.c)[i] = T::from_f32(o);
 }
 
-struct Fp8Plan { int nt, mt, ksplit, msteps_per_split; };
+struct Fp8Plan { int nt, mt, ksplit, msteps_per_split, nseg; };
 
-static Fp8Plan make_fp8_plan(int64_t M, int64_t N, int64_t K) {
+static Fp8Plan make_fp8_plan(int64_t M, int64_t N, int64_t K, bool a8) {
   Fp8Plan pl;
+  pl.nseg = 0;
+  if (a8 && N % 64 == 0 && K % 128 == 0 && N * K < (int64_t)0xffffffff && !getenv("APHRO_FP8_GENERIC")) {
+    // fast W8A8 kernel: every wave owns exactly NSEG macro steps; split across workgroups only
+    // while the grid leaves CUs idle
+    const int total = (int)(K / 128);
+    const int64_t tiles = N / 64 * ((M + 31) / 32);
+    int best_ns = 0, best_split = 0;
+    for (int split = 1; split <= 8; ++split) {
+      if (total % (split * F8W) != 0) continue;
+      const int ns = total / (split * F8W);
+      if (!(ns == 1 || ns == 2 || ns == 4 || ns == 7 || ns == 8)) continue;
+      if (best_ns == 0) { best_ns = ns; best_split = split; }
+      else if (tiles * best_split < 192 && tiles * split <= 1100) { best_ns = ns; best_split = split; }
+    }
+    if (best_ns) {
+      pl.nt = 4; pl.mt = M > 16 ? 2 : 1; pl.nseg = best_ns; pl.ksplit = best_split;
+      pl.msteps_per_split = F8W * best_ns;
+      return pl;
+    }
+  }
   pl.nt = (N % 64 == 0 && N / 64 >= 192) ? 4 : (N % 32 == 0 ? 2 : 1);
   const char* e = getenv("APHRO_FP8_NT");
   if (e) { int v = atoi(e); if ((v == 1 || v == 2 || v == 4) && N % (16 * v) == 0) pl.nt = v; }
@@ -228,6 +373,29 @@ static Fp8Plan make_fp8_plan(int64_t M, int64_t N, int64_t K) {
 template <typename T, bool A8>
 static int run_fp8(Fp8GemmParams p, const Fp8Plan& pl, hipStream_t st) {
   dim3 grid((unsigned)(p.N / (16 * pl.nt)), (unsigned)pl.ksplit, (unsigned)((p.M + 16 * pl.mt - 1) / (16 * pl.mt)));
+  if (pl.nseg > 0) {
+    if constexpr (A8) {
+      size_t flds = (size_t)F8W * pl.mt * 4 * 64 * 4 * sizeof(float);
+#define LF(MTV, NS) hipLaunchKernelGGL((fp8_gemm_fast_kernel<T, 4, MTV, NS>), grid, dim3(F8W * 64), flds, st, p)
+#define LFM(NS) { if (pl.mt == 2) LF(2, NS); else LF(1, NS); }
+      switch (pl.nseg) {
+        case 8: LFM(8) break;
+        case 7: LFM(7) break;
+        case 4: LFM(4) break;
+        case 2: LFM(2) break;
+        default: LFM(1) break;
+      }
+#undef LFM
+#undef LF
+      APHRO_LAUNCH_CHECK();
+      if (pl.ksplit > 1) {
+        int64_t mn = (int64_t)p.M * p.N;
+        hipLaunchKernelGGL((fp8_splitk_reduce_kernel<T>), dim3((unsigned)((mn + 255) / 256)), dim3(256), 0, st, p);
+        APHRO_LAUNCH_CHECK();
+      }
+      return APHRO_OK;
+    }
+  }
   size_t lds = (size_t)FNW * pl.mt * pl.nt * 64 * 4 * sizeof(float);
 #define L(NTV, MTV) hipLaunchKernelGGL((fp8_gemm_kernel<T, A8, NTV, MTV>), grid, dim3(FNW * 64), lds, st, p)
   switch (pl.nt * 10 + pl.mt) {
@@ -255,7 +423,7 @@ static int fp8_gemm_common(Fp8GemmParams p, bool a8, int dtype, void* workspace,
   APHRO_CHECK(p.N % 16 == 0, "fp8 gemm: N=%d must be a multiple of 16", p.N);
   APHRO_CHECK(p.M <= 64, "fp8 gemm: M=%d exceeds 64 rows per call", p.M);
   if (p.M == 0) return APHRO_OK;
-  Fp8Plan pl = make_fp8_plan(p.M, p.N, p.K);
+  Fp8Plan pl = make_fp8_plan(p.M, p.N, p.K, a8);
   if (pl.ksplit > 1) {
     size_t need = (size_t)pl.ksplit * p.M * p.N * sizeof(float);
     if (!workspace || workspace_bytes < need) {

@@ -81,6 +81,60 @@ __global__ void absmax_scale_kernel(float* __restrict__ scale, const typename T:
   }
 }
 
+// Atomic-free dynamic per-tensor scale: every workgroup leaves its |x| maximum in partials[blockIdx.x]
+// (no zero-initialised scale, no atomicMax, hence no fill launch) ...
+template <typename T>
+__global__ void absmax_partial_kernel(float* __restrict__ partials, const typename T::storage* __restrict__ in,
+                                      int64_t n) {
+  __shared__ float red[16];
+  float m = 0.f;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t nvec = n >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+    float v[4];
+    load4<T>(in + 4 * i, v);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) m = __builtin_fmaxf(m, __builtin_fabsf(v[j]));
+  }
+  for (int64_t i = nvec * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    m = __builtin_fmaxf(m, __builtin_fabsf(T::to_f32(in[i])));
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) m = __builtin_fmaxf(m, red[w]);
+    partials[blockIdx.x] = m;
+  }
+}
+
+// ... and every workgroup of the quantisation pass reduces the (<= 2048) partials itself:
+// scale = max|x| / 448 exactly as absmax_scale_kernel computes it (max is order independent).
+template <typename T>
+__global__ void dynamic_quant_kernel(uint8_t* __restrict__ out, float* __restrict__ scale,
+                                     const float* __restrict__ partials, int nparts,
+                                     const typename T::storage* __restrict__ in, int64_t n) {
+  __shared__ float red[16];
+  float m = 0.f;
+  for (int i = threadIdx.x; i < nparts; i += blockDim.x) m = __builtin_fmaxf(m, partials[i]);
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  m = red[0];
+  for (int w = 1; w < (int)(blockDim.x >> 6); ++w) m = __builtin_fmaxf(m, red[w]);
+  const float s = m / FP8_MAX;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *scale = s;
+  const float inv = 1.0f / s;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t nvec = n >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+    float v[4];
+    load4<T>(in + 4 * i, v);
+    reinterpret_cast<uint32_t*>(out)[i] = pack4_e4m3(v, inv, true);
+  }
+  for (int64_t i = nvec * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    out[i] = to_e4m3(T::to_f32(in[i]) * inv);
+}
+
 // one workgroup per token (common.cu:201-256)
 template <typename T>
 __global__ void per_token_quant_kernel(uint8_t* __restrict__ out, float* __restrict__ scales,
@@ -167,6 +221,30 @@ extern "C" int aphro_dynamic_scaled_fp8_quant(void* out, const void* input, floa
 #undef CALL
   APHRO_LAUNCH_CHECK();
   return aphro_static_scaled_fp8_quant(out, input, scale, M, K, dtype, stream);
+}
+
+// Same result as aphro_dynamic_scaled_fp8_quant with caller scratch (>= 2048 floats) instead of a
+// zero-initialised scale + atomics: two launches instead of fill + absmax + quant.
+extern "C" int aphro_dynamic_scaled_fp8_quant_ws(void* out, const void* input, float* scale, float* partials,
+                                                 size_t partials_bytes, int64_t M, int64_t K, int dtype,
+                                                 void* stream) {
+  APHRO_CHECK(dtype >= APHRO_F16 && dtype <= APHRO_F32, "scaled_fp8_quant: unsupported dtype %d", dtype);
+  int64_t n = M * K;
+  if (n == 0) return APHRO_OK;
+  const unsigned nb = blocks_for(n);
+  if (partials == nullptr || partials_bytes < nb * sizeof(float)) {
+    set_error("scaled_fp8_quant: scratch %zu < %zu bytes", partials_bytes, (size_t)nb * sizeof(float));
+    return APHRO_ERR_WORKSPACE;
+  }
+#define CALL(TT)                                                                                          \
+  hipLaunchKernelGGL((absmax_partial_kernel<TT>), dim3(nb), dim3(256), 0, (hipStream_t)stream, partials,   \
+                     (const typename TT::storage*)input, n);                                              \
+  hipLaunchKernelGGL((dynamic_quant_kernel<TT>), dim3(nb), dim3(256), 0, (hipStream_t)stream,              \
+                     (uint8_t*)out, scale, (const float*)partials, (int)nb, (const typename TT::storage*)input, n)
+  DISPATCH_IN(dtype, CALL)
+#undef CALL
+  APHRO_LAUNCH_CHECK();
+  return APHRO_OK;
 }
 
 extern "C" int aphro_dynamic_per_token_scaled_fp8_quant(void* out, const void* input, float* scales,

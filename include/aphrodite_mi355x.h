@@ -267,6 +267,13 @@ int aphro_paged_attention_rope_packed(void* out, void* out_packed, const float* 
  * out uint8 (OCP e4m3fn) [M,K]; input dtype f16|bf16|f32 [M,K] contiguous. */
 int aphro_static_scaled_fp8_quant(void* out, const void* input, const float* scale,
                                   int64_t M, int64_t K, int dtype, void* stream);
+/* aphro_dynamic_scaled_fp8_quant with caller scratch (>= 8 KiB) instead of a zero-initialised
+ * scale and atomics: identical scale and bytes (max is order independent), two launches instead
+ * of fill + absmax + quant.  Used by ops.scaled_fp8_quant(scale=None). */
+int aphro_dynamic_scaled_fp8_quant_ws(void* out, const void* input, float* scale,
+                                      float* partials, size_t partials_bytes, int64_t M,
+                                      int64_t K, int dtype, void* stream);
+
 /* scale must be zero-initialised by the caller (as _custom_ops.py:676 does). */
 int aphro_dynamic_scaled_fp8_quant(void* out, const void* input, float* scale,
                                    int64_t M, int64_t K, int dtype, void* stream);
