@@ -176,6 +176,87 @@ def test_awq_gemm(ops, M, K, N, G):
 
 
 # ---------------------------------------------------------------------------
+# BASELINE.json configs[2..4] at their real shapes (parity-test cases, not bench lines)
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("K,N", [(8192, 1280), (1024, 8192), (8192, 7168), (3584, 8192)])
+def test_config3_llama70b_awq_tp8_shapes(ops, K, N):
+    """configs[3]: Llama-3-70B AWQ g128, TP=8 per-GPU shapes at M = 64:
+    AWQ op vs the oracle, and the load-time repack + fast kernel give the same numbers."""
+    rng = np.random.default_rng(K + N)
+    M, G = 64, 128
+    qw, qz, s = make_awq(rng, K, N, G)
+    a = (rng.standard_normal((M, K)) * 0.5).astype(np.float16)
+    ref = oq.awq_gemm(a, qw, s, qz)
+    got = ops.awq_gemm(t(a), t(qw), t(s), t(qz), 8).float().cpu().numpy()
+    assert rel_mean_err(got, ref) < 0.04
+    np.testing.assert_allclose(got, ref, rtol=2e-3, atol=2e-3 * np.abs(ref).max())
+    rq, rz = ops.awq_marlin_repack(t(qw), K, N, 4), ops.awq_repack_zeros(t(qz), N)
+    got2 = ops.wna16_gemm(t(a), rq, rz, t(s), None, 0).float().cpu().numpy()
+    np.testing.assert_array_equal(got2, got)
+
+
+@pytest.mark.parametrize("K,N", [(4096, 6144), (4096, 4096), (4096, 28672), (14336, 4096)])
+def test_config2_llama8b_fp8_per_token_shapes(ops, K, N):
+    """configs[2]: llm-compressor FP8 (per-channel weight scale, dynamic per-token activation scale,
+    w8a8_utils.py:143-183) at the Llama-3-8B shapes, M = 32."""
+    rng = np.random.default_rng(K + N)
+    M = 32
+    x = t((rng.standard_normal((M, K)) * 1.5).astype(np.float32), torch.bfloat16)
+    w = t((rng.standard_normal((N, K)) * 2).astype(np.float32)).to(torch.float8_e4m3fn)
+    sb = t((rng.random((N, 1)) * 0.02 + 0.001).astype(np.float32))
+    aq, sa = ops.scaled_fp8_quant(x, use_per_token_if_dynamic=True)
+    rq, rs = of8.dynamic_per_token_scaled_fp8_quant(x.float().cpu().numpy())
+    np.testing.assert_array_equal(aq.view(torch.uint8).cpu().numpy(), rq)
+    np.testing.assert_array_equal(sa.cpu().numpy(), rs)
+    got = ops.cutlass_scaled_mm(aq, w.t(), sa, sb, torch.bfloat16, None).float().cpu().numpy()
+    ref = of8.scaled_mm(rq, w.view(torch.uint8).cpu().numpy().T, rs, sb.cpu().numpy().reshape(-1), None)
+    np.testing.assert_allclose(got, ref, rtol=1.6e-2, atol=1.6e-2 * np.abs(ref).max())
+
+
+def test_config2_fp8_kv_decode_ctx8192(ops):
+    """configs[2]: FP8-E4M3 KV cache decode at seq = 8192 (v2 / partitioned form, as the reference
+    routes > 8192-token contexts, ops/paged_attn.py:127-128)."""
+    rng = np.random.default_rng(82)
+    S, Hq, Hkv, D, BS = 2, 32, 8, 128, 16
+    seq_lens = np.array([8192, 5000], np.int32)
+    bps = 8192 // BS
+    NB = S * bps + 1
+    kc, vc = make_cache(rng, NB, Hkv, D, BS, torch.float16, "fp8")
+    bt = rng.permutation(NB)[:S * bps].reshape(S, bps).astype(np.int32)
+    q = t(rng.standard_normal((S, Hq, D)).astype(np.float32) * 0.5, torch.float16)
+    out = torch.empty_like(q)
+    P = (8192 + 511) // 512
+    tmp = torch.empty(S, Hq, P, D, dtype=torch.float16, device=DEV)
+    es = torch.empty(S, Hq, P, dtype=torch.float32, device=DEV)
+    ml = torch.empty_like(es)
+    ops.paged_attention_v2(out, es, ml, tmp, q, kc, vc, Hkv, D ** -0.5, t(bt), t(seq_lens), BS, 8192, None,
+                           "fp8", 0.37, 0.5)
+    ref = oa.paged_attention_decode(q.float().cpu().numpy(), kc.cpu().numpy(), vc.cpu().numpy(), bt, seq_lens,
+                                    D ** -0.5, None, "fp8", 0.37, 0.5)
+    np.testing.assert_allclose(out.float().cpu().numpy(), ref, atol=1e-2, rtol=1e-2)
+    out1 = torch.empty_like(q)
+    ops.paged_attention_v1(out1, q, kc, vc, Hkv, D ** -0.5, t(bt), t(seq_lens), BS, 8192, None, "fp8", 0.37, 0.5)
+    np.testing.assert_allclose(out1.float().cpu().numpy(), ref, atol=1e-2, rtol=1e-2)
+
+
+@pytest.mark.parametrize("K,N", [(4096, 7168), (3584, 4096)])
+def test_config4_mixtral_gptq_tp4_expert_shapes(ops, K, N):
+    """configs[4]: one Mixtral-8x7B GPTQ expert at TP=4 (w1|w3 merged 4096 x 2*3584, w2 3584 x 4096)
+    at the handful of tokens an expert sees in decode."""
+    rng = np.random.default_rng(K + N)
+    M = 8
+    qweight, qzeros, s, _ = make_gptq(rng, K, N, 128)
+    a = t(rng.standard_normal((M, K)).astype(np.float16))
+    shuf = t(oq.gptq_shuffle(qweight))
+    got = ops.gptq_gemm(a, shuf, t(qzeros), t(s, torch.float16), torch.empty(0, dtype=torch.int32, device=DEV),
+                        True, 4).float().cpu().numpy()
+    ref = oq.gptq_gemm(a.float().cpu().numpy(), shuf.cpu().numpy(), qzeros, s.astype(np.float16).astype(np.float32),
+                       None, True)
+    assert rel_mean_err(got, ref) < 0.04
+    np.testing.assert_allclose(got, ref, rtol=2e-3, atol=2e-3 * np.abs(ref).max())
+
+
+# ---------------------------------------------------------------------------
 # FP8 quant + GEMMs
 # ---------------------------------------------------------------------------
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32])
