@@ -709,6 +709,107 @@ def paged_attention_rope_packed(qkv_slabs: torch.Tensor, positions: torch.Tensor
     return packed, out
 
 
+# --------------------------------------------------------------------------
+# mixture of experts
+# --------------------------------------------------------------------------
+def topk_softmax(topk_weights: torch.Tensor, topk_ids: torch.Tensor,
+                 token_expert_indicies: Optional[torch.Tensor], gating_output: torch.Tensor) -> None:
+    """_custom_ops.py topk_softmax -> _moe_C::topk_softmax (kernels/moe/torch_bindings.cpp:11-14)."""
+    _require_cuda(topk_weights, topk_ids, gating_output)
+    if gating_output.dtype != torch.float32 or not gating_output.is_contiguous():
+        raise RuntimeError("topk_softmax: gating_output must be contiguous float32")
+    if topk_ids.dtype != torch.int32 or topk_weights.dtype != torch.float32:
+        raise RuntimeError("topk_softmax: topk_weights must be float32 and topk_ids int32")
+    t_, e = gating_output.shape
+    check(_lib.lib().aphro_topk_softmax(topk_weights.data_ptr(), topk_ids.data_ptr(),
+                                        _ptr(token_expert_indicies), gating_output.data_ptr(), t_, e,
+                                        topk_ids.shape[1], _stream()), "topk_softmax")
+
+
+def moe_align_block_size(topk_ids: torch.Tensor, num_experts: int, block_size: int,
+                         sorted_token_ids: torch.Tensor, experts_ids: torch.Tensor,
+                         num_tokens_post_pad: torch.Tensor, inv_pos: Optional[torch.Tensor] = None) -> None:
+    """_custom_ops.py moe_align_block_size (kernels/torch_bindings.cpp:394-399); inv_pos is an
+    optional extra output of ours (position of every (token, k) slot in the sorted order)."""
+    _require_cuda(topk_ids, sorted_token_ids, experts_ids, num_tokens_post_pad)
+    if topk_ids.dtype != torch.int32 or not topk_ids.is_contiguous():
+        raise RuntimeError("moe_align_block_size: topk_ids must be contiguous int32")
+    numel = topk_ids.numel()
+    need = numel + num_experts * (block_size - 1)
+    if sorted_token_ids.numel() < need or experts_ids.numel() < (need + block_size - 1) // block_size:
+        raise RuntimeError("moe_align_block_size: output tensors too small")
+    check(_lib.lib().aphro_moe_align_block_size(topk_ids.data_ptr(), num_experts, block_size,
+                                                sorted_token_ids.data_ptr(), experts_ids.data_ptr(),
+                                                num_tokens_post_pad.data_ptr(), _ptr(inv_pos), numel,
+                                                _stream()), "moe_align_block_size")
+
+
+def moe_gather_pack(a: torch.Tensor, sorted_token_ids: torch.Tensor, num_tokens_post_pad: torch.Tensor,
+                    m_pad: int, topk: int) -> torch.Tensor:
+    """Packed (fragment-major f16) activations of the expert GEMMs: row r = a[sorted[r] // topk]."""
+    lib = _lib.lib()
+    k = a.shape[1]
+    if a.stride(1) != 1:
+        a = a.contiguous()
+    out = torch.empty(lib.aphro_wna16_packed_a_bytes(m_pad, k) // 2, dtype=torch.float16, device=a.device)
+    check(lib.aphro_moe_gather_pack(a.data_ptr(), sorted_token_ids.data_ptr(), num_tokens_post_pad.data_ptr(),
+                                    out.data_ptr(), m_pad, k, a.stride(0), a.shape[0] * topk, topk, _dt(a),
+                                    _stream()), "moe_gather_pack")
+    return out
+
+
+def wna16_grouped_ksplit(m_pad: int, n: int, k: int, groups: int) -> int:
+    return _lib.lib().aphro_wna16_grouped_ksplit(m_pad, n, k, groups)
+
+
+def wna16_gemm_grouped(a_packed: torch.Tensor, m_pad: int, k: int, qweight: torch.Tensor,
+                       qzeros: torch.Tensor, scales: torch.Tensor, expert_ids: torch.Tensor,
+                       num_tokens_post_pad: torch.Tensor, zero_offset: int, mode: str):
+    """Grouped expert GEMM (marlin_gemm_moe role).  qweight [E, K/8, N], qzeros [E, G, N/8],
+    scales [E, G, N].  mode "silu_pack" -> packed activations [m_pad, N/2]; "slabs" -> (fp32
+    [S, m_pad, N], S); "out" -> [m_pad, N] in scales.dtype."""
+    lib = _lib.lib()
+    n = qweight.shape[2]
+    groups = scales.shape[1]
+    ks = lib.aphro_wna16_grouped_ksplit(m_pad, n, k, groups)
+    if ks <= 0:
+        raise RuntimeError(f"wna16_gemm_grouped: shape N={n} K={k} not served by the fast kernel")
+    dt = _dt(scales)
+    dev = qweight.device
+    common = (a_packed.data_ptr(), qweight.data_ptr(), qzeros.data_ptr(), scales.data_ptr(),
+              expert_ids.data_ptr(), num_tokens_post_pad.data_ptr())
+    if mode == "silu_pack":
+        if ks != 1 or n % 256 != 0:
+            raise RuntimeError("wna16_gemm_grouped: SiluAndMul epilogue unavailable for this shape")
+        out = torch.empty(lib.aphro_wna16_packed_a_bytes(m_pad, n // 2) // 2, dtype=torch.float16, device=dev)
+        check(lib.aphro_wna16_gemm_grouped(*common, None, None, 0, out.data_ptr(), m_pad, n, k, groups,
+                                           zero_offset, dt, _stream()), "wna16_gemm_grouped")
+        return out
+    if mode == "slabs":
+        slabs = torch.empty((ks, m_pad, n), dtype=torch.float32, device=dev)
+        check(lib.aphro_wna16_gemm_grouped(*common, None, slabs.data_ptr(), slabs.numel() * 4, None, m_pad, n, k,
+                                           groups, zero_offset, dt, _stream()), "wna16_gemm_grouped")
+        return slabs, ks
+    out = torch.zeros((m_pad, n), dtype=scales.dtype, device=dev)
+    slabs = torch.empty((ks, m_pad, n), dtype=torch.float32, device=dev) if ks > 1 else None
+    check(lib.aphro_wna16_gemm_grouped(*common, out.data_ptr(), _ptr(slabs),
+                                       slabs.numel() * 4 if slabs is not None else 0, None, m_pad, n, k, groups,
+                                       zero_offset, dt, _stream()), "wna16_gemm_grouped")
+    return out
+
+
+def moe_combine(slabs: torch.Tensor, inv_pos: torch.Tensor, topk_weights: torch.Tensor,
+                out_dtype: torch.dtype) -> torch.Tensor:
+    """out[t] = sum_k round(w[t,k] * y[inv_pos[t,k]]), y = sum of the split-K slabs."""
+    nslab, m_pad, n = slabs.shape
+    t_, topk = topk_weights.shape
+    out = torch.empty((t_, n), dtype=out_dtype, device=slabs.device)
+    odt = _lib.F16 if out_dtype == torch.float16 else _lib.BF16
+    check(_lib.lib().aphro_moe_combine(out.data_ptr(), slabs.data_ptr(), nslab, m_pad, inv_pos.data_ptr(),
+                                       topk_weights.data_ptr(), t_, topk, n, odt, _stream()), "moe_combine")
+    return out
+
+
 def wna16_gemm(a, qweight_kpacked, qzeros, scales, perm=None, zero_offset=0):
     """The gptq_marlin_gemm role: fast W4A16 kernel on prepacked weights."""
     _require_cuda(a, qweight_kpacked, qzeros, scales)

@@ -32,6 +32,12 @@ SIGNATURES = {
                                          L, L, L, I, I, F, F, P]),
     "aphro_paged_attention_rope_packed": (I, [P, P, P, I, P, P, P, P, P, I, I, I, I, F, P, P, I, I, I, P,
                                               L, L, I, I, F, F, P]),
+    "aphro_topk_softmax": (I, [P, P, P, P, L, I, I, P]),
+    "aphro_moe_align_block_size": (I, [P, I, I, P, P, P, P, L, P]),
+    "aphro_moe_gather_pack": (I, [P, P, P, P, L, L, L, L, I, I, P]),
+    "aphro_wna16_grouped_ksplit": (I, [L, L, L, L]),
+    "aphro_wna16_gemm_grouped": (I, [P, P, P, P, P, P, P, P, Z, P, L, L, L, L, I, I, P]),
+    "aphro_moe_combine": (I, [P, P, I, L, P, P, L, I, L, I, P]),
     "aphro_fused_add_rms_norm_pack": (I, [P, P, I, P, I, P, F, P, P, L, I, I, P]),
     "aphro_silu_and_mul_pack": (I, [P, P, P, L, I, I, P]),
     "aphro_rope_cache": (I, [P, L, P, I, P, P, I, I, P, P, P, P, L, I, I, I, I, I, I, I, F, F, P]),

@@ -1,0 +1,233 @@
+// Mixture-of-experts routing + dispatch for the W4A16 expert GEMMs:
+//   topk_softmax           kernels/moe/softmax.cu:17-520 (schema kernels/moe/torch_bindings.cpp:11-14)
+//   moe_align_block_size   kernels/moe/align_block_size_kernel.cu:17-126 (kernels/torch_bindings.cpp:394-399)
+//   moe_gather_pack        the "replicate_input / sorted_ids" addressing of marlin_gemm_moe
+//                          (kernels/moe/marlin_moe_ops.cu) as a fragment-major activation pack
+//   moe_combine            routed-weight multiply + sum over top-k (fused_moe.py:520-542)
+// The expert GEMMs themselves are wna16_gemm_kernel with a per-m-tile expert index
+// (aphro_wna16_gemm_grouped, wna16_gemm.hip): one 16-row m-tile = one block of moe_align.
+#include "common.h"
+
+namespace aphro {
+
+// one wave per token: softmax over the experts (fp32), then k rounds of arg-max
+// (ties -> lowest expert index, like cub::ArgMax).  Weights are NOT renormalised.
+__global__ void topk_softmax_kernel(float* __restrict__ topk_weights, int32_t* __restrict__ topk_ids,
+                                    int32_t* __restrict__ token_expert_indices, const float* __restrict__ gating,
+                                    int num_tokens, int num_experts, int k) {
+  const int lane = threadIdx.x & 63;
+  const int tok = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (tok >= num_tokens) return;
+  const float* row = gating + (size_t)tok * num_experts;
+  // softmax (softmax.cu:60-103): max, sum of exp, exp(x - max) * (1 / sum)
+  float mx = -INFINITY;
+  for (int e = lane; e < num_experts; e += 64) mx = __builtin_fmaxf(mx, row[e]);
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int e = lane; e < num_experts; e += 64) sum += expf(row[e] - mx);
+  sum = wave_sum(sum);
+  const float norm = 1.f / sum;
+  // lane-resident probabilities for up to 256 experts
+  float prob[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int e = lane + 64 * j;
+    prob[j] = e < num_experts ? expf(row[e] - mx) * norm : -1.f;
+  }
+  for (int kk = 0; kk < k; ++kk) {
+    float best = -1.f;
+    int best_e = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int e = lane + 64 * j;
+      if (prob[j] > best) { best = prob[j]; best_e = e; }   // ascending e within a lane: ties keep the lower
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ob = __shfl_xor(best, o, 64);
+      const int oe = __shfl_xor(best_e, o, 64);
+      if (ob > best || (ob == best && oe < best_e)) { best = ob; best_e = oe; }
+    }
+    if (lane == 0) {
+      topk_weights[(size_t)tok * k + kk] = best;
+      topk_ids[(size_t)tok * k + kk] = best_e;
+      if (token_expert_indices) token_expert_indices[(size_t)tok * k + kk] = kk * num_tokens + tok;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (lane + 64 * j == best_e) prob[j] = -1.f;  // winner leaves the pool
+  }
+}
+
+// Stable counting sort of the flattened (token, k) slots by expert, every expert's segment padded
+// to a multiple of block_size (padding entries hold `numel`).  One wave; thread t owns a contiguous
+// shard like the reference, so the order inside an expert is ascending slot index.
+// inv_pos (optional): position of slot i in sorted_token_ids.
+__global__ void moe_align_kernel(const int32_t* __restrict__ topk_ids, int32_t* __restrict__ sorted_token_ids,
+                                 int32_t* __restrict__ expert_ids, int32_t* __restrict__ num_tokens_post_pad,
+                                 int32_t* __restrict__ inv_pos, int num_experts, int block_size, int numel,
+                                 int max_padded, int max_blocks) {
+  extern __shared__ int32_t sm[];
+  int32_t* cnt = sm;                                  // [65][E]
+  int32_t* cumsum = sm + 65 * num_experts;            // [E + 1]
+  const int t = threadIdx.x;                          // 0..63
+  const int per = (numel + 63) / 64;
+  const int lo = t * per, hi = min(numel, lo + per);
+  for (int e = 0; e < num_experts; ++e) cnt[(t + 1) * num_experts + e] = 0;
+  for (int i = lo; i < hi; ++i) ++cnt[(t + 1) * num_experts + topk_ids[i]];
+  for (int i = t; i < max_padded; i += 64) sorted_token_ids[i] = numel;
+  for (int i = t; i < max_blocks; i += 64) expert_ids[i] = -1;
+  __syncthreads();
+  for (int e = t; e < num_experts; e += 64) {         // prefix over the shards, per expert
+    cnt[e] = 0;
+    for (int s = 1; s <= 64; ++s) cnt[s * num_experts + e] += cnt[(s - 1) * num_experts + e];
+  }
+  __syncthreads();
+  if (t == 0) {
+    cumsum[0] = 0;
+    for (int e = 1; e <= num_experts; ++e)
+      cumsum[e] = cumsum[e - 1] + (cnt[64 * num_experts + e - 1] + block_size - 1) / block_size * block_size;
+    *num_tokens_post_pad = cumsum[num_experts];
+  }
+  __syncthreads();
+  for (int e = t; e < num_experts; e += 64)
+    for (int i = cumsum[e]; i < cumsum[e + 1]; i += block_size) expert_ids[i / block_size] = e;
+  for (int i = lo; i < hi; ++i) {
+    const int e = topk_ids[i];
+    const int pos = cnt[t * num_experts + e] + cumsum[e];
+    sorted_token_ids[pos] = i;
+    if (inv_pos) inv_pos[i] = pos;
+    ++cnt[t * num_experts + e];
+  }
+}
+
+// Fragment-major pack (see pack_a_kernel, wna16_gemm.hip) of the rows selected by sorted_token_ids:
+// packed row r <- a[sorted[r] / topk] (a zero row for padding entries and for rows beyond
+// *num_tokens_post_pad).
+template <typename T>
+__global__ void moe_gather_pack_kernel(const uint16_t* __restrict__ a, const int32_t* __restrict__ sorted_token_ids,
+                                       const int32_t* __restrict__ num_tokens_post_pad,
+                                       uint16_t* __restrict__ out, int m_pad, int K, int lda, int numel,
+                                       int topk) {
+  const int mtiles = m_pad >> 4;
+  const int64_t total = (int64_t)(K >> 7) * 4 * mtiles * 64;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int lane = (int)(idx & 63);
+  int64_t blk = idx >> 6;
+  const int mt = (int)(blk % mtiles); blk /= mtiles;
+  const int u = (int)(blk & 3);
+  const int seg = (int)(blk >> 2);
+  const int row = 16 * mt + (lane & 15);
+  const int k0 = 128 * seg + 32 * (lane >> 4) + 8 * u;
+  u16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (row < *num_tokens_post_pad) {
+    const int slot = sorted_token_ids[row];
+    if (slot < numel) {
+      v = *reinterpret_cast<const u16x8*>(a + (size_t)(slot / topk) * lda + k0);
+      if constexpr (!__is_same(T, Half)) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = f32_to_f16_bits(bf16_bits_to_f32(v[j]));
+      }
+    }
+  }
+  *reinterpret_cast<u16x8*>(out + idx * 8) = v;
+}
+
+// out[t][:] = sum_k round_T(w[t][k] * y[pos(t, k)][:])   (fused_moe.py:520-542: routed weight applied to
+// the second GEMM's fp32 result, cast, then summed over top-k).  y = sum of `nslab` fp32 slabs
+// [nslab][m_pad][N] (split-K partials of the expert GEMM) -- rounded once, after the weight.
+template <typename T>
+__global__ void moe_combine_kernel(typename T::storage* __restrict__ out, const float* __restrict__ slabs,
+                                   int nslab, int64_t slab_stride, const int32_t* __restrict__ inv_pos,
+                                   const float* __restrict__ topk_weights, int topk, int N) {
+  const int tok = blockIdx.x;
+  for (int c0 = threadIdx.x * 4; c0 < N; c0 += blockDim.x * 4) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int kk = 0; kk < topk; ++kk) {
+      const int pos = inv_pos[tok * topk + kk];
+      const float w = topk_weights[tok * topk + kk];
+      const float* p0 = slabs + (size_t)pos * N + c0;
+      f32x4 y = *reinterpret_cast<const f32x4*>(p0);
+      for (int s = 1; s < nslab; ++s) y += *reinterpret_cast<const f32x4*>(p0 + s * slab_stride);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] += T::to_f32(T::from_f32(y[j] * w));
+    }
+    typename T::storage* o = out + (size_t)tok * N + c0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = T::from_f32(acc[j]);
+  }
+}
+
+}  // namespace aphro
+
+using namespace aphro;
+
+extern "C" int aphro_topk_softmax(float* topk_weights, int32_t* topk_ids, int32_t* token_expert_indices,
+                                  const float* gating_output, int64_t num_tokens, int num_experts, int topk,
+                                  void* stream) {
+  APHRO_CHECK(num_experts >= 1 && num_experts <= 256, "topk_softmax: num_experts=%d (1..256 supported)", num_experts);
+  APHRO_CHECK(topk >= 1 && topk <= num_experts, "topk_softmax: bad topk=%d", topk);
+  if (num_tokens == 0) return APHRO_OK;
+  const int wpb = 4;
+  hipLaunchKernelGGL(topk_softmax_kernel, dim3((unsigned)((num_tokens + wpb - 1) / wpb)), dim3(wpb * 64), 0,
+                     (hipStream_t)stream, topk_weights, topk_ids, token_expert_indices, gating_output,
+                     (int)num_tokens, num_experts, topk);
+  APHRO_LAUNCH_CHECK();
+  return APHRO_OK;
+}
+
+extern "C" int aphro_moe_align_block_size(const int32_t* topk_ids, int num_experts, int block_size,
+                                          int32_t* sorted_token_ids, int32_t* expert_ids,
+                                          int32_t* num_tokens_post_pad, int32_t* inv_pos, int64_t numel,
+                                          void* stream) {
+  APHRO_CHECK(num_experts >= 1 && num_experts <= 256 && block_size >= 1, "moe_align_block_size: bad arguments");
+  APHRO_CHECK(numel >= 0 && numel < (1 << 24), "moe_align_block_size: numel out of range");
+  const int max_padded = (int)numel + num_experts * (block_size - 1);
+  const int max_blocks = (max_padded + block_size - 1) / block_size;
+  const size_t lds = (size_t)(65 * num_experts + num_experts + 1) * sizeof(int32_t);
+  hipLaunchKernelGGL(moe_align_kernel, dim3(1), dim3(64), lds, (hipStream_t)stream, topk_ids, sorted_token_ids,
+                     expert_ids, num_tokens_post_pad, inv_pos, num_experts, block_size, (int)numel, max_padded,
+                     max_blocks);
+  APHRO_LAUNCH_CHECK();
+  return APHRO_OK;
+}
+
+extern "C" int aphro_moe_gather_pack(const void* a, const int32_t* sorted_token_ids,
+                                     const int32_t* num_tokens_post_pad, void* packed, int64_t m_pad, int64_t K,
+                                     int64_t lda, int64_t numel, int topk, int dtype, void* stream) {
+  APHRO_CHECK(dtype == APHRO_F16 || dtype == APHRO_BF16, "moe_gather_pack: dtype must be f16 or bf16");
+  APHRO_CHECK(m_pad % 16 == 0 && K % 128 == 0 && lda % 8 == 0 && topk >= 1, "moe_gather_pack: bad shape");
+  if (m_pad == 0) return APHRO_OK;
+  const int64_t total = (K / 128) * 4 * (m_pad / 16) * 64;
+  dim3 grid((unsigned)((total + 255) / 256));
+  if (dtype == APHRO_F16)
+    hipLaunchKernelGGL((moe_gather_pack_kernel<Half>), grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)a,
+                       sorted_token_ids, num_tokens_post_pad, (uint16_t*)packed, (int)m_pad, (int)K, (int)lda,
+                       (int)numel, topk);
+  else
+    hipLaunchKernelGGL((moe_gather_pack_kernel<BFloat>), grid, dim3(256), 0, (hipStream_t)stream,
+                       (const uint16_t*)a, sorted_token_ids, num_tokens_post_pad, (uint16_t*)packed, (int)m_pad,
+                       (int)K, (int)lda, (int)numel, topk);
+  APHRO_LAUNCH_CHECK();
+  return APHRO_OK;
+}
+
+extern "C" int aphro_moe_combine(void* out, const float* slabs, int nslab, int64_t m_pad, const int32_t* inv_pos,
+                                 const float* topk_weights, int64_t num_tokens, int topk, int64_t N, int dtype,
+                                 void* stream) {
+  APHRO_CHECK(dtype == APHRO_F16 || dtype == APHRO_BF16, "moe_combine: dtype must be f16 or bf16");
+  APHRO_CHECK(N % 4 == 0 && nslab >= 1, "moe_combine: bad shape");
+  if (num_tokens == 0) return APHRO_OK;
+  const int threads = N / 4 >= 256 ? 256 : (int)((N / 4 + 63) / 64 * 64);
+  if (dtype == APHRO_F16)
+    hipLaunchKernelGGL((moe_combine_kernel<Half>), dim3((unsigned)num_tokens), dim3(threads), 0,
+                       (hipStream_t)stream, (uint16_t*)out, slabs, nslab, m_pad * N, inv_pos, topk_weights, topk,
+                       (int)N);
+  else
+    hipLaunchKernelGGL((moe_combine_kernel<BFloat>), dim3((unsigned)num_tokens), dim3(threads), 0,
+                       (hipStream_t)stream, (uint16_t*)out, slabs, nslab, m_pad * N, inv_pos, topk_weights, topk,
+                       (int)N);
+  APHRO_LAUNCH_CHECK();
+  return APHRO_OK;
+}

@@ -83,6 +83,10 @@ struct Wna16Params {
   int force_partial;      // 1: write the fp32 slab even when ksplit == 1 (fused consumer)
   uint16_t* act_packed;   // != NULL (ksplit == 1 only): columns are (gate_j, up_j) pairs; the epilogue
                           // writes silu(gate) * up as fragment-major f16 [M, N/2] for the next GEMM
+  // ---- grouped (mixture-of-experts) form: every 16-row m-tile uses the weights of ONE expert ----
+  const int32_t* expert_ids;     // [M / 16] expert of each m-tile (moe_align_block_size), < 0: skip; NULL: dense
+  const int32_t* num_post_pad;   // device scalar: rows >= *num_post_pad are not computed
+  int64_t w_estride, z_estride, s_estride;  // per-expert strides of qw / qz (words) and sc (elements)
 };
 
 // ---- in-workgroup split-K reduction through LDS + store ---------------------
@@ -229,11 +233,22 @@ __global__ __launch_bounds__(FNW * 64, (VEC * MT >= 8) ? 2 : 3) void wna16_gemm_
   // VGPR offset, the (segment, k-step) part an SGPR offset -- no vector address arithmetic in
   // the loop (the kernel is instruction-issue bound on the CUs that host two workgroups).
   const int mtiles = (p.M + 15) >> 4;
-  const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.qw, (uint32_t)((size_t)(p.K >> 3) * p.N * 4));
+  const uint32_t* qw_base = p.qw;
+  const uint32_t* qz_base = p.qz;
+  const uint16_t* sc_base = p.sc;
+  if (p.expert_ids != nullptr) {  // grouped form (MT == 1): this m-tile's expert; uniform for the workgroup
+    if (m0 >= *p.num_post_pad) return;
+    const int e = p.expert_ids[m0 >> 4];
+    if (e < 0) return;
+    qw_base += (size_t)e * p.w_estride;
+    qz_base += (size_t)e * p.z_estride;
+    sc_base += (size_t)e * p.s_estride;
+  }
+  const __amdgpu_buffer_rsrc_t rw = make_rsrc(qw_base, (uint32_t)((size_t)(p.K >> 3) * p.N * 4));
   const __amdgpu_buffer_rsrc_t ra = make_rsrc(p.apk, (uint32_t)((size_t)(p.K >> 7) * 4 * mtiles * 1024));
   const int ngroups = p.K / p.group_size;
-  const __amdgpu_buffer_rsrc_t rs_ = make_rsrc(p.sc, (uint32_t)((size_t)ngroups * p.N * 2));
-  const __amdgpu_buffer_rsrc_t rz = make_rsrc(p.qz, (uint32_t)((size_t)ngroups * (p.N >> 3) * 4));
+  const __amdgpu_buffer_rsrc_t rs_ = make_rsrc(sc_base, (uint32_t)((size_t)ngroups * p.N * 2));
+  const __amdgpu_buffer_rsrc_t rz = make_rsrc(qz_base, (uint32_t)((size_t)ngroups * (p.N >> 3) * 4));
   const int roww = p.N * 4;                       // bytes per packed weight row
   const int voff_w = (4 * g * p.N + ncol) * 4;    // row 4g (+u via the SGPR offset), this lane's columns
   int voff_a[MT];
@@ -640,7 +655,7 @@ static int env_int(const char* name, int dflt) {
   return v ? atoi(v) : dflt;
 }
 
-static Wna16Plan make_plan(int64_t M, int64_t N, int64_t K, int64_t gs) {
+static Wna16Plan make_plan(int64_t M, int64_t N, int64_t K, int64_t gs, int64_t ztiles = 0) {
   Wna16Plan pl;
   pl.nseg = 0;
   pl.vec = (N % 64 == 0) ? 4 : (N % 32 == 0) ? 2 : 1;
@@ -652,7 +667,7 @@ static Wna16Plan make_plan(int64_t M, int64_t N, int64_t K, int64_t gs) {
   //  weight byte, which costs more than the extra workgroups gain -- measured 10.3 vs 12.8 us
   //  on the 14336x4096 down projection)
   pl.mt = (M > 16) ? 2 : 1;
-  const int64_t tiles = N / (16 * pl.vec) * ((M + 16 * pl.mt - 1) / (16 * pl.mt));
+  const int64_t tiles = N / (16 * pl.vec) * (ztiles > 0 ? ztiles : (M + 16 * pl.mt - 1) / (16 * pl.mt));
   const int total_segs = (int)((K + 127) / 128);
   const int64_t gq = gs >> 7;
   pl.fast = (K % 128 == 0 && gs % 128 == 0 && (gq & (gq - 1)) == 0 && pl.vec >= 2 &&
@@ -802,6 +817,7 @@ extern "C" int aphro_gptq_gemm(const void* a, const uint32_t* q_weight, const ui
   for (int64_t q = gs >> 7; q > 1; q >>= 1) ++p.gshift;
   p.force_partial = 0;
   p.act_packed = nullptr;
+  p.expert_ids = nullptr; p.num_post_pad = nullptr; p.w_estride = p.z_estride = p.s_estride = 0;
   return dtype == APHRO_F16 ? run_wna16<Half>(p, pl, st) : run_wna16<BFloat>(p, pl, st);
 }
 
@@ -866,6 +882,7 @@ extern "C" int aphro_wna16_gemm_packed(const void* a_packed, const uint32_t* q_w
   for (int64_t q = (K / groups) >> 7; q > 1; q >>= 1) ++p.gshift;
   p.force_partial = (c == nullptr) ? 1 : 0;
   p.act_packed = nullptr;
+  p.expert_ids = nullptr; p.num_post_pad = nullptr; p.w_estride = p.z_estride = p.s_estride = 0;
   return dtype == APHRO_F16 ? run_wna16<Half>(p, pl, st) : run_wna16<BFloat>(p, pl, st);
 }
 
@@ -897,6 +914,58 @@ extern "C" int aphro_wna16_gemm_silu_pack(const void* a_packed, const uint32_t* 
   for (int64_t q = (K / groups) >> 7; q > 1; q >>= 1) ++p.gshift;
   p.force_partial = 0;
   p.act_packed = (uint16_t*)act_packed;
+  p.expert_ids = nullptr; p.num_post_pad = nullptr; p.w_estride = p.z_estride = p.s_estride = 0;
+  return dtype == APHRO_F16 ? run_wna16<Half>(p, pl, st) : run_wna16<BFloat>(p, pl, st);
+}
+
+// Expert GEMMs of a mixture-of-experts layer in ONE launch (the marlin_gemm_moe role,
+// kernels/moe/marlin_moe_ops.cu, re-designed): activations arrive packed and sorted by expert
+// (aphro_moe_gather_pack over moe_align_block_size's order, block_size 16), so every 16-row m-tile
+// belongs to one expert and the dense kernel only needs that expert's weight base.  Weights:
+// [E][K/8][N] K-packed (exllama order per expert), qzeros [E][G][N/8], scales [E][G][N].
+// Exactly one output: act_packed (w1|w3 GEMM with interleaved gate/up columns: SiluAndMul + pack
+// epilogue, needs aphro_wna16_grouped_ksplit == 1), c (T [m_pad, N]) or partials (fp32 slabs).
+extern "C" int aphro_wna16_grouped_ksplit(int64_t m_pad, int64_t N, int64_t K, int64_t groups) {
+  if (groups <= 0 || K % groups != 0 || m_pad <= 0 || m_pad % 16 != 0) return -1;
+  Wna16Plan pl = make_plan(16, N, K, K / groups, m_pad / 16);
+  return pl.fast ? pl.ksplit : -1;
+}
+
+extern "C" int aphro_wna16_gemm_grouped(const void* a_packed, const uint32_t* q_weight, const uint32_t* qzeros,
+                                        const void* scales, const int32_t* expert_ids,
+                                        const int32_t* num_tokens_post_pad, void* c, float* partials,
+                                        size_t partial_bytes, void* act_packed, int64_t m_pad, int64_t N,
+                                        int64_t K, int64_t groups, int zero_offset, int dtype, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  APHRO_CHECK(dtype == APHRO_F16 || dtype == APHRO_BF16, "wna16_gemm_grouped: dtype must be f16 or bf16");
+  APHRO_CHECK(m_pad > 0 && m_pad % 16 == 0, "wna16_gemm_grouped: m_pad=%ld must be a positive multiple of 16", (long)m_pad);
+  APHRO_CHECK(groups > 0 && K % groups == 0 && expert_ids && num_tokens_post_pad, "wna16_gemm_grouped: bad arguments");
+  Wna16Plan pl = make_plan(16, N, K, K / groups, m_pad / 16);
+  APHRO_CHECK(pl.fast, "wna16_gemm_grouped: shape K=%ld N=%ld g=%ld is not served by the fast kernel", (long)K,
+              (long)N, (long)(K / groups));
+  pl.mt = 1;
+  APHRO_CHECK(act_packed == nullptr || (pl.ksplit == 1 && N % 256 == 0),
+              "wna16_gemm_grouped: the SiluAndMul epilogue needs ksplit == 1 and N %% 256 == 0");
+  if (act_packed == nullptr && (pl.ksplit > 1 || c == nullptr)) {
+    size_t need = (size_t)pl.ksplit * m_pad * N * sizeof(float);
+    if (partials == nullptr || partial_bytes < need) {
+      set_error("wna16_gemm_grouped: partial buffer %zu < %zu bytes", partial_bytes, need);
+      return APHRO_ERR_WORKSPACE;
+    }
+  }
+  Wna16Params p;
+  p.a = nullptr; p.apk = (const uint16_t*)a_packed; p.qw = q_weight; p.qz = qzeros;
+  p.sc = (const uint16_t*)scales; p.c = (uint16_t*)c; p.partial = partials;
+  p.M = (int)m_pad; p.N = (int)N; p.K = (int)K; p.lda = 0;
+  p.group_size = (int)(K / groups); p.ksteps_per_split = pl.ksteps_per_split;
+  p.ksplit = pl.ksplit;
+  p.zero_offset = zero_offset;
+  p.gshift = 0;
+  for (int64_t q = (K / groups) >> 7; q > 1; q >>= 1) ++p.gshift;
+  p.force_partial = (c == nullptr && act_packed == nullptr) ? 1 : 0;
+  p.act_packed = (uint16_t*)act_packed;
+  p.expert_ids = expert_ids; p.num_post_pad = num_tokens_post_pad;
+  p.w_estride = (K / 8) * N; p.z_estride = groups * (N / 8); p.s_estride = groups * N;
   return dtype == APHRO_F16 ? run_wna16<Half>(p, pl, st) : run_wna16<BFloat>(p, pl, st);
 }
 

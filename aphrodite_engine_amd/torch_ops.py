@@ -89,6 +89,20 @@ _C_OPS += [
      "int size_m, int size_n, int size_k) -> Tensor", _fp8_marlin_gemm),                   # :218-222
 ]
 
+def _moe_align_block_size(topk_ids, num_experts, block_size, sorted_token_ids, experts_ids, num_tokens_post_pad):
+    ops.moe_align_block_size(topk_ids, num_experts, block_size, sorted_token_ids, experts_ids, num_tokens_post_pad)
+
+
+_C_OPS += [
+    ("moe_align_block_size(Tensor topk_ids, int num_experts, int block_size, Tensor! sorted_token_ids, "
+     "Tensor! experts_ids, Tensor! num_tokens_post_pad) -> ()", _moe_align_block_size),     # :394-399
+]
+
+_MOE_OPS = [
+    ("topk_softmax(Tensor! topk_weights, Tensor! topk_indices, Tensor! token_expert_indices, "
+     "Tensor gating_output) -> ()", ops.topk_softmax),                 # kernels/moe/torch_bindings.cpp:11-14
+]
+
 _CACHE_OPS = [
     ("reshape_and_cache(Tensor key, Tensor value, Tensor! key_cache, Tensor! value_cache, Tensor slot_mapping, "
      "str kv_cache_dtype, float k_scale, float v_scale) -> ()", ops.reshape_and_cache),    # :467-473
@@ -110,13 +124,14 @@ _ROCM_OPS = [
 ]
 
 
-def register(ns_c: str = "_C", ns_cache: str = "_C_cache_ops", ns_rocm: str = "_rocm_C") -> None:
+def register(ns_c: str = "_C", ns_cache: str = "_C_cache_ops", ns_rocm: str = "_rocm_C",
+             ns_moe: str = "_moe_C") -> None:
     """Idempotent.  Pass other namespaces to avoid clashing with an already
     loaded ``aphrodite._C`` (e.g. in A/B comparisons)."""
     global _REGISTERED
     if _REGISTERED:
         return
-    for ns, table in ((ns_c, _C_OPS), (ns_cache, _CACHE_OPS), (ns_rocm, _ROCM_OPS)):
+    for ns, table in ((ns_c, _C_OPS), (ns_cache, _CACHE_OPS), (ns_rocm, _ROCM_OPS), (ns_moe, _MOE_OPS)):
         lib = torch.library.Library(ns, "FRAGMENT")
         for schema, fn in table:
             name = schema.split("(", 1)[0]

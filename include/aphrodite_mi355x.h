@@ -383,6 +383,57 @@ int aphro_context_attention(void* out, const void* q, const void* k, const void*
                             const float* alibi_slopes, int sliding_window, int dtype,
                             int kv_dtype, void* stream);
 
+/* ------------------------------------------------------------------------
+ * Mixture of experts: routing, dispatch and the grouped W4A16 GEMM
+ * ---------------------------------------------------------------------- */
+
+/* _moe_C::topk_softmax(Tensor! topk_weights, Tensor! topk_indices,
+ *     Tensor! token_expert_indices, Tensor gating_output)
+ *   kernels/moe/torch_bindings.cpp:11-14, kernels/moe/softmax.cu:17-520.
+ * gating fp32 [T, E] (E <= 256); weights = softmax probabilities of the k winners
+ * (not renormalised), ids int32, token_expert_indices[t][k] = k * T + t (may be NULL). */
+int aphro_topk_softmax(float* topk_weights, int32_t* topk_ids, int32_t* token_expert_indices,
+                       const float* gating_output, int64_t num_tokens, int num_experts,
+                       int topk, void* stream);
+
+/* _C::moe_align_block_size(Tensor topk_ids, int num_experts, int block_size,
+ *     Tensor! sorted_token_ids, Tensor! experts_ids, Tensor! num_tokens_post_pad)
+ *   kernels/torch_bindings.cpp:394-399, kernels/moe/align_block_size_kernel.cu:17-126.
+ * sorted_token_ids int32 [numel + E*(block-1)] (padding entries = numel; filled here),
+ * expert_ids int32 [ceil(that / block)] (-1 beyond the used blocks), inv_pos (optional,
+ * ours) int32 [numel]: position of slot i in sorted_token_ids. */
+int aphro_moe_align_block_size(const int32_t* topk_ids, int num_experts, int block_size,
+                               int32_t* sorted_token_ids, int32_t* expert_ids,
+                               int32_t* num_tokens_post_pad, int32_t* inv_pos,
+                               int64_t numel, void* stream);
+
+/* Fragment-major activation pack of the rows a[sorted_token_ids[r] / topk] (zero rows for
+ * padding) -- the sorted_ids / replicate_input addressing of marlin_gemm_moe
+ * (kernels/moe/marlin_moe_ops.cu) done once, ahead of the GEMM. */
+int aphro_moe_gather_pack(const void* a, const int32_t* sorted_token_ids,
+                          const int32_t* num_tokens_post_pad, void* packed, int64_t m_pad,
+                          int64_t K, int64_t lda, int64_t numel, int topk, int dtype,
+                          void* stream);
+
+/* Grouped expert GEMM, the marlin_gemm_moe role (kernels/moe/torch_bindings.cpp:17-24):
+ * one launch, m-tile z uses expert expert_ids[z].  Weights [E][K/8][N] K-packed,
+ * qzeros [E][G][N/8], scales [E][G][N].  Exactly one of act_packed (SiluAndMul + pack
+ * epilogue over interleaved gate/up columns; needs aphro_wna16_grouped_ksplit == 1),
+ * c (T [m_pad, N]) or partials (fp32 [ksplit][m_pad][N], c == act_packed == NULL). */
+int aphro_wna16_grouped_ksplit(int64_t m_pad, int64_t N, int64_t K, int64_t groups);
+int aphro_wna16_gemm_grouped(const void* a_packed, const uint32_t* q_weight,
+                             const uint32_t* qzeros, const void* scales,
+                             const int32_t* expert_ids, const int32_t* num_tokens_post_pad,
+                             void* c, float* partials, size_t partial_bytes,
+                             void* act_packed, int64_t m_pad, int64_t N, int64_t K,
+                             int64_t groups, int zero_offset, int dtype, void* stream);
+
+/* out[t] = sum_k round(w[t][k] * y[inv_pos[t*topk+k]]) with y = sum of the nslab fp32 slabs
+ * [nslab][m_pad][N] of the second expert GEMM (fused_moe.py:520-542). */
+int aphro_moe_combine(void* out, const float* slabs, int nslab, int64_t m_pad,
+                      const int32_t* inv_pos, const float* topk_weights, int64_t num_tokens,
+                      int topk, int64_t N, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

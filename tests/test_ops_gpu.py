@@ -1102,3 +1102,107 @@ def test_fused_decode_model_matches_unfused(ops):
         torch.testing.assert_close(outs[0], outs[1], atol=2e-2, rtol=2e-2)
         # layer-0 cache writes are identical (same rounded q/k/v, same slots)
         assert torch.equal(caches_all[0][0], caches_all[1][0])
+
+
+# ---------------------------------------------------------------------------
+# mixture of experts
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("T,E,topk", [(1, 8, 2), (33, 8, 2), (64, 64, 6), (5, 60, 4), (17, 256, 8)])
+def test_topk_softmax(ops, T, E, topk):
+    from oracle import moe as om
+    rng = np.random.default_rng(T + E)
+    g = rng.standard_normal((T, E)).astype(np.float32) * 2
+    g[0, :min(E, 4)] = 1.25                      # ties: the lowest expert index wins
+    w = torch.empty(T, topk, dtype=torch.float32, device=DEV)
+    ids = torch.empty(T, topk, dtype=torch.int32, device=DEV)
+    src = torch.empty(T, topk, dtype=torch.int32, device=DEV)
+    ops.topk_softmax(w, ids, src, t(g))
+    rw, rids, rsrc = om.topk_softmax(g, topk)
+    np.testing.assert_array_equal(ids.cpu().numpy(), rids)
+    np.testing.assert_array_equal(src.cpu().numpy(), rsrc)
+    np.testing.assert_allclose(w.cpu().numpy(), rw, rtol=2e-6, atol=1e-9)
+
+
+@pytest.mark.parametrize("T,E,topk,block", [(1, 8, 2, 16), (32, 8, 2, 16), (77, 64, 6, 16), (4, 4, 3, 4),
+                                            (300, 8, 2, 16), (9, 256, 8, 16)])
+def test_moe_align_block_size(ops, T, E, topk, block):
+    from oracle import moe as om
+    from aphrodite_engine_amd import moe as M
+    rng = np.random.default_rng(T * 3 + E)
+    if (T, E, topk, block) == (4, 4, 3, 4):      # the reference's docstring example (fused_moe.py:199-212)
+        ids = np.array([[2, 3, 4], [1, 2, 4], [1, 3, 4], [1, 2, 3]], np.int32) - 1
+    else:
+        ids = np.stack([rng.permutation(E)[:topk] for _ in range(T)]).astype(np.int32)
+    sorted_ids, expert_ids, post, inv = M.moe_align_block_size(t(ids), block, E, want_inverse=True)
+    rs, re_, rp = om.moe_align_block_size(ids, E, block)
+    assert int(post.item()) == rp
+    np.testing.assert_array_equal(sorted_ids.cpu().numpy(), rs)
+    np.testing.assert_array_equal(expert_ids.cpu().numpy(), re_)
+    np.testing.assert_array_equal(rs[inv.cpu().numpy()], np.arange(T * topk))
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("T", [1, 7, 64])
+@pytest.mark.parametrize("E,topk,H,I", [(8, 2, 512, 512), (4, 2, 1024, 512)])
+def test_fused_wna16_moe(ops, dtype, T, E, topk, H, I):
+    """Routing + grouped int4 expert GEMMs + combine vs the dense per-expert loop of the reference
+    (tests/kernels/test_moe.py torch_moe, mixtral_quant.py:130-156) on the dequantised weights."""
+    from oracle import moe as om
+    from aphrodite_engine_amd import moe as M
+    if dtype == torch.bfloat16 and T != 7:
+        pytest.skip("bf16 covered on a subset")
+    rng = np.random.default_rng(T + E + H)
+    w13_sets, w2_sets, w13_f, w2_f = [], [], [], []
+    for _ in range(E):
+        qw, qz, s, _ = make_gptq(rng, H, 2 * I, 128)
+        w13_sets.append((t(qw), t(qz), t(s, dtype)))
+        w13_f.append(oq.gptq_dequant(qw, qz, t(s, dtype).float().cpu().numpy(), None, False))
+        qw, qz, s, _ = make_gptq(rng, I, H, 128)
+        w2_sets.append((t(qw), t(qz), t(s, dtype)))
+        w2_f.append(oq.gptq_dequant(qw, qz, t(s, dtype).float().cpu().numpy(), None, False))
+    experts = M.Wna16Experts(w13_sets, w2_sets)
+    x = t(rng.standard_normal((T, H)).astype(np.float32) * 0.5, dtype)
+    gating = t(rng.standard_normal((T, E)).astype(np.float32))
+    got = M.fused_wna16_moe(x, experts, gating, topk, renormalize=True).float().cpu().numpy()
+    rw, rids, _ = om.topk_softmax(gating.cpu().numpy(), topk)
+    rw = rw / rw.sum(axis=1, keepdims=True)
+    ref = om.moe_layer(x.float().cpu().numpy(), np.stack(w13_f), np.stack(w2_f), rw, rids)
+    assert got.shape == (T, H)
+    assert rel_mean_err(got, ref) < 0.04
+    tol = 4e-3 if dtype == torch.float16 else 3e-2
+    np.testing.assert_allclose(got, ref, rtol=tol, atol=tol * np.abs(ref).max())
+
+
+def test_fused_wna16_moe_mixtral_tp4_shape(ops):
+    """configs[4]: Mixtral-8x7B GPTQ, TP=4 expert slices (hidden 4096, intermediate 14336 / 4), bs 32."""
+    from oracle import moe as om
+    from aphrodite_engine_amd import moe as M
+    rng = np.random.default_rng(4)
+    T, E, topk, H, I = 32, 8, 2, 4096, 3584
+    w13_sets, w2_sets = [], []
+    for _ in range(E):
+        qw, qz, s, _ = make_gptq(rng, H, 2 * I, 128)
+        w13_sets.append((t(qw), t(qz), t(s, torch.float16)))
+        qw, qz, s, _ = make_gptq(rng, I, H, 128)
+        w2_sets.append((t(qw), t(qz), t(s, torch.float16)))
+    experts = M.Wna16Experts(w13_sets, w2_sets)
+    x = t(rng.standard_normal((T, H)).astype(np.float32) * 0.5, torch.float16)
+    gating = t(rng.standard_normal((T, E)).astype(np.float32))
+    got = M.fused_wna16_moe(x, experts, gating, topk, renormalize=True)
+    # reference: the dense loop of mixtral_quant.py over the SAME device GEMM ops (gptq_gemm per expert)
+    rw, rids = M.fused_topk(x, gating, topk, True)
+    empty = torch.empty(0, dtype=torch.int32, device=DEV)
+    ref = torch.zeros(T, H, dtype=torch.float32, device=DEV)
+    for e in range(E):
+        qw, qz, s = w13_sets[e]
+        shuf = qw.clone(); ops.gptq_shuffle(shuf, empty, 4)
+        h = ops.gptq_gemm(x, shuf, qz, s, empty, True, 4)
+        act = torch.empty(T, I, dtype=torch.float16, device=DEV)
+        ops.silu_and_mul(act, h)
+        qw, qz, s = w2_sets[e]
+        shuf = qw.clone(); ops.gptq_shuffle(shuf, empty, 4)
+        y = ops.gptq_gemm(act, shuf, qz, s, empty, True, 4).float()
+        wgt = (rw * (rids == e)).sum(dim=-1, keepdim=True)
+        ref += y * wgt
+    torch.testing.assert_close(got.float(), ref, atol=2e-2, rtol=2e-2)
+

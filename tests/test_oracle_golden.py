@@ -233,3 +233,23 @@ def test_reshape_and_cache_vs_reference_cpu_kernel():
     oa.reshape_and_cache(key, val, kc2, vc2, slots.numpy())
     np.testing.assert_array_equal(kc.numpy(), kc2)
     np.testing.assert_array_equal(vc.numpy(), vc2)
+
+
+def test_moe_routing_oracle_known_answers():
+    """moe_align_block_size: the worked example in the reference's own docstring
+    (modeling/layers/fused_moe/fused_moe.py:199-212; experts 1..4 there are 0..3 here);
+    topk_softmax: torch softmax + topk (tests/kernels/test_moe.py:19-26)."""
+    import torch
+    from oracle import moe
+    ids = np.array([[2, 3, 4], [1, 2, 4], [1, 3, 4], [1, 2, 3]]) - 1
+    sorted_ids, expert_ids, post = moe.moe_align_block_size(ids, 4, 4)
+    assert sorted_ids[:16].tolist() == [3, 6, 9, 12, 0, 4, 10, 12, 1, 7, 11, 12, 2, 5, 8, 12]
+    assert expert_ids[:4].tolist() == [0, 1, 2, 3] and post == 16
+    rng = np.random.default_rng(0)
+    g = rng.standard_normal((9, 8)).astype(np.float32)
+    w, idx, src = moe.topk_softmax(g, 2)
+    tw, ti = torch.topk(torch.softmax(torch.from_numpy(g), dim=-1), 2, dim=-1)
+    np.testing.assert_array_equal(idx, ti.numpy())
+    np.testing.assert_allclose(w, tw.numpy(), rtol=1e-6)
+    assert src[3, 1] == 1 * 9 + 3
+
