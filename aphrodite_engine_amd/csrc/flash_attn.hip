@@ -48,16 +48,19 @@ __device__ __forceinline__ uint32_t fa_pack2(float a, float b) {
   }
 }
 
-constexpr int FA_BM = 64;   // query rows per workgroup
+constexpr int FA_BM = 64;   // query rows per workgroup (context kernel; QT * 64 in the varlen kernel)
 constexpr int FA_BN = 32;   // kv tokens per tile
 constexpr int FA_VT_STRIDE = 36;  // halfs per V^T row (32 + 4 pad)
 
-template <typename T, int HD>
+// QT = 16-row query tiles per wave: every K / V^T fragment read from LDS (and every byte staged
+// into it) is used by QT MFMAs -- the staging path, not the MFMA pipe, bounds this kernel.
+template <typename T, int HD, int QT>
 __global__ __launch_bounds__(256) void flash_attn_varlen_kernel(FAParams p) {
   constexpr int NCH = HD / 8;    // 16-byte chunks per row
   constexpr int SWZ = (NCH & -NCH) - 1;  // XOR mask: largest power of two dividing NCH, minus 1
   constexpr int NKS = HD / 32;
   constexpr int NDT = HD / 16;
+  constexpr int BM = 64 * QT;
   __shared__ __attribute__((aligned(16))) uint16_t k_lds[FA_BN * HD];
   __shared__ __attribute__((aligned(16))) uint16_t vt_lds[HD * FA_VT_STRIDE];
 
@@ -71,33 +74,45 @@ __global__ __launch_bounds__(256) void flash_attn_varlen_kernel(FAParams p) {
   const int s0 = p.cu_seqlens[seq];
   const int len = p.cu_seqlens[seq + 1] - s0;
   // heavy (late) tiles first: better tail balance under the causal triangle
-  const int ntiles = (len + FA_BM - 1) / FA_BM;
+  const int ntiles = (len + BM - 1) / BM;
   const int tile = ntiles - 1 - (int)blockIdx.x;
   if (tile < 0) return;
-  const int q0 = tile * FA_BM;
-  const int qrow = q0 + 16 * wave + c;           // this lane's query row (B-operand column)
-  const bool qvalid = qrow < len;
+  const int q0 = tile * BM;
+  const int wq0 = q0 + 16 * QT * wave;           // first query row of this wave
+  int qrow[QT];                                  // this lane's query rows (B-operand columns)
+#pragma unroll
+  for (int t = 0; t < QT; ++t) qrow[t] = wq0 + 16 * t + c;
 
   // ---- Q fragments ---------------------------------------------------------------
-  u32x4 qf[NKS];
-  {
-    const uint16_t* qp = (const uint16_t*)p.q + (size_t)(s0 + min(qrow, len - 1)) * p.q_stride + (size_t)head * HD;
+  u32x4 qf[QT][NKS];
 #pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) qf[ks] = *reinterpret_cast<const u32x4*>(qp + 32 * ks + 8 * g);
+  for (int t = 0; t < QT; ++t) {
+    const uint16_t* qp = (const uint16_t*)p.q + (size_t)(s0 + min(qrow[t], len - 1)) * p.q_stride + (size_t)head * HD;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) qf[t][ks] = *reinterpret_cast<const u32x4*>(qp + 32 * ks + 8 * g);
   }
   const float slope = p.alibi ? p.alibi[head] : 0.f;
+  const float sc2 = p.scale * 1.44269504088896f;     // softmax in the log2 domain
+  const float slope2 = slope * 1.44269504088896f;
 
-  f32x4 o[NDT];
+  f32x4 o[QT][NDT];
+  float m_run[QT], l_run[QT];
 #pragma unroll
-  for (int i = 0; i < NDT; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float m_run = -1e30f, l_run = 0.f;
+  for (int t = 0; t < QT; ++t) {
+#pragma unroll
+    for (int i = 0; i < NDT; ++i) o[t][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    m_run[t] = -1e30f;
+    l_run[t] = 0.f;
+  }
 
-  const int kv_end = p.causal ? min(len, q0 + FA_BM) : len;
+  const int kv_end = p.causal ? min(len, q0 + BM) : len;
   const uint16_t* kbase = (const uint16_t*)p.k + (size_t)s0 * p.k_stride + (size_t)kvh * HD;
   const uint16_t* vbase = (const uint16_t*)p.v + (size_t)s0 * p.v_stride + (size_t)kvh * HD;
 
   for (int t0 = 0; t0 < kv_end; t0 += FA_BN) {
     // ---- stage K (swizzled) and V^T into LDS -------------------------------------
+    // (prefetching the next tile into registers across the compute phase was measured SLOWER:
+    //  247 -> 181 TFLOP/s at T = 8192 -- the extra live registers cost more than the latency)
     __syncthreads();  // previous tile's readers are done
     for (int i = threadIdx.x; i < FA_BN * NCH; i += 256) {
       const int tok = i / NCH, ch = i % NCH;
@@ -111,79 +126,109 @@ __global__ __launch_bounds__(256) void flash_attn_varlen_kernel(FAParams p) {
     }
     __syncthreads();
     // a wave whose rows all precede this tile (causal) has nothing to add
-    const bool wave_active = !p.causal || (t0 <= q0 + 16 * wave + 15);
+    const bool wave_active = !p.causal || (t0 <= wq0 + 16 * QT - 1);
     if (wave_active) {
-      // ---- S^T = K . Q^T ------------------------------------------------------------
-      f32x4 s[2];
+      // ---- S^T = K . Q^T : one K fragment read feeds the QT query tiles --------------
+      f32x4 s[QT][2];
+#pragma unroll
+      for (int t = 0; t < QT; ++t) { s[t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; s[t][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        s[h] = f32x4{0.f, 0.f, 0.f, 0.f};
         const int tok = 16 * h + c;  // A-operand row of this lane
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
           const int ch = (4 * ks + g) ^ (tok & SWZ);
           u32x4 kf = *reinterpret_cast<const u32x4*>(&k_lds[tok * HD + 8 * ch]);
-          s[h] = fa_mfma<T>(kf, qf[ks], s[h]);
+#pragma unroll
+          for (int t = 0; t < QT; ++t) s[t][h] = fa_mfma<T>(kf, qf[t][ks], s[t][h]);
         }
       }
-      // ---- online softmax (lane column = query row) ----------------------------------
-      float pv[2][4];
-      float mx = -1e30f;
+      // ---- online softmax (lane column = query row), log2 domain ----------------------
+      // x2 = s * scale * log2(e) (+ alibi); p = exp2(x2 - m).  Interior tiles (every key visible to
+      // every row of the wave, no ALiBi) skip the mask and bias arithmetic; the O rescale is skipped
+      // when no lane's running maximum moved (alpha == 1 everywhere).
+      u32x4 pf[QT];
+      const bool edge = (t0 + FA_BN > len) || (p.causal && t0 + FA_BN - 1 > wq0) || slope != 0.f;
 #pragma unroll
-      for (int h = 0; h < 2; ++h)
+      for (int t = 0; t < QT; ++t) {
+        float pv[2][4];
+        float mx = -1e30f;
+        if (edge) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int tok = t0 + 16 * h + 4 * g + r;
-          float x = s[h][r] * p.scale + slope * (float)(tok - qrow);
-          const bool ok = tok < len && (!p.causal || tok <= qrow);
-          x = ok ? x : -1e30f;
-          pv[h][r] = x;
-          mx = __builtin_fmaxf(mx, x);
+          for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int tok = t0 + 16 * h + 4 * g + r;
+              float x = s[t][h][r] * sc2 + slope2 * (float)(tok - qrow[t]);
+              const bool ok = tok < len && (!p.causal || tok <= qrow[t]);
+              x = ok ? x : -1e30f;
+              pv[h][r] = x;
+              mx = __builtin_fmaxf(mx, x);
+            }
+        } else {
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              pv[h][r] = s[t][h][r] * sc2;
+              mx = __builtin_fmaxf(mx, pv[h][r]);
+            }
         }
-      mx = __builtin_fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = __builtin_fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float m_new = __builtin_fmaxf(m_run, mx);
-      const float alpha = __expf(m_run - m_new);
-      m_run = m_new;
-      float lsum = 0.f;
+        mx = __builtin_fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = __builtin_fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = __builtin_fmaxf(m_run[t], mx);
+        const bool moved = m_new != m_run[t];
+        const float alpha = __builtin_amdgcn_exp2f(m_run[t] - m_new);
+        m_run[t] = m_new;
+        float lsum = 0.f;
 #pragma unroll
-      for (int h = 0; h < 2; ++h)
+        for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float e = pv[h][r] > -1e29f ? __expf(pv[h][r] - m_new) : 0.f;
-          pv[h][r] = e;
-          lsum += e;
+          for (int r = 0; r < 4; ++r) {
+            // masked entries sit at -1e30: exp2 underflows to exactly 0 unless the whole row is still
+            // masked (m_new == -1e30), which the select handles
+            float e = __builtin_amdgcn_exp2f(pv[h][r] - m_new);
+            if (edge) e = pv[h][r] > -1e29f ? e : 0.f;
+            pv[h][r] = e;
+            lsum += e;
+          }
+        l_run[t] = l_run[t] * alpha + lsum;
+        if (__builtin_amdgcn_ballot_w64(moved) != 0) {
+#pragma unroll
+          for (int dt = 0; dt < NDT; ++dt) o[t][dt] *= alpha;
         }
-      l_run = l_run * alpha + lsum;
-#pragma unroll
-      for (int dt = 0; dt < NDT; ++dt) o[dt] *= alpha;
-      u32x4 pf;
-      pf[0] = fa_pack2<T>(pv[0][0], pv[0][1]);
-      pf[1] = fa_pack2<T>(pv[0][2], pv[0][3]);
-      pf[2] = fa_pack2<T>(pv[1][0], pv[1][1]);
-      pf[3] = fa_pack2<T>(pv[1][2], pv[1][3]);
-      // ---- O^T += V^T . P^T ------------------------------------------------------------
+        pf[t][0] = fa_pack2<T>(pv[0][0], pv[0][1]);
+        pf[t][1] = fa_pack2<T>(pv[0][2], pv[0][3]);
+        pf[t][2] = fa_pack2<T>(pv[1][0], pv[1][1]);
+        pf[t][3] = fa_pack2<T>(pv[1][2], pv[1][3]);
+      }
+      // ---- O^T += V^T . P^T : one V^T fragment read feeds the QT query tiles ----------
 #pragma unroll
       for (int dt = 0; dt < NDT; ++dt) {
         const uint16_t* vr = &vt_lds[(16 * dt + c) * FA_VT_STRIDE + 4 * g];
         u32x2 lo = *reinterpret_cast<const u32x2*>(vr);
         u32x2 hi = *reinterpret_cast<const u32x2*>(vr + 16);
         u32x4 vf = {lo[0], lo[1], hi[0], hi[1]};
-        o[dt] = fa_mfma<T>(vf, pf, o[dt]);
+#pragma unroll
+        for (int t = 0; t < QT; ++t) o[t][dt] = fa_mfma<T>(vf, pf[t], o[t][dt]);
       }
     }
   }
 
-  l_run += __shfl_xor(l_run, 16, 64);
-  l_run += __shfl_xor(l_run, 32, 64);
-  if (qvalid) {
-    const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
-    typename T::storage* op = (typename T::storage*)p.out + ((size_t)(s0 + qrow) * p.num_heads + head) * HD;
 #pragma unroll
-    for (int dt = 0; dt < NDT; ++dt) {
-      u16x4 r = {T::from_f32(o[dt][0] * inv), T::from_f32(o[dt][1] * inv), T::from_f32(o[dt][2] * inv),
-                 T::from_f32(o[dt][3] * inv)};
-      *reinterpret_cast<u16x4*>(op + 16 * dt + 4 * g) = r;
+  for (int t = 0; t < QT; ++t) {
+    float l = l_run[t];
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    if (qrow[t] < len) {
+      const float inv = l > 0.f ? 1.f / l : 0.f;
+      typename T::storage* op = (typename T::storage*)p.out + ((size_t)(s0 + qrow[t]) * p.num_heads + head) * HD;
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt) {
+        u16x4 r = {T::from_f32(o[t][dt][0] * inv), T::from_f32(o[t][dt][1] * inv), T::from_f32(o[t][dt][2] * inv),
+                   T::from_f32(o[t][dt][3] * inv)};
+        *reinterpret_cast<u16x4*>(op + 16 * dt + 4 * g) = r;
+      }
     }
   }
 }
@@ -438,9 +483,13 @@ extern "C" int aphro_flash_attn_varlen(void* out, const void* q, const void* k, 
   p.num_heads = num_heads; p.num_kv_heads = num_kv_heads;
   p.q_stride = q_stride; p.k_stride = k_stride; p.v_stride = v_stride;
   p.scale = scale; p.causal = causal;
-  dim3 grid((unsigned)((max_seqlen + FA_BM - 1) / FA_BM), (unsigned)num_heads, (unsigned)batch);
-#define FA_L(TT, HDV) hipLaunchKernelGGL((flash_attn_varlen_kernel<TT, HDV>), grid, dim3(256), 0, (hipStream_t)stream, p)
-#define FA_T(HDV) if (dtype == APHRO_F16) FA_L(Half, HDV); else FA_L(BFloat, HDV);
+  // two 16-row query tiles per wave (128-row workgroups) once the sequences are long enough to
+  // fill the chip with them; head 256 keeps one tile (registers)
+  const int qt = (max_seqlen >= 512 && head_size <= 128 && !getenv("APHRO_FA_QT1")) ? 2 : 1;
+  dim3 grid((unsigned)((max_seqlen + 64 * qt - 1) / (64 * qt)), (unsigned)num_heads, (unsigned)batch);
+#define FA_L(TT, HDV) { if (qt == 2) hipLaunchKernelGGL((flash_attn_varlen_kernel<TT, HDV, (HDV <= 128 ? 2 : 1)>), grid, dim3(256), 0, (hipStream_t)stream, p); \
+                        else hipLaunchKernelGGL((flash_attn_varlen_kernel<TT, HDV, 1>), grid, dim3(256), 0, (hipStream_t)stream, p); }
+#define FA_T(HDV) if (dtype == APHRO_F16) FA_L(Half, HDV) else FA_L(BFloat, HDV)
   switch (head_size) {
     case 64: FA_T(64) break;
     case 96: FA_T(96) break;
