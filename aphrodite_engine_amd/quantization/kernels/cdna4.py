@@ -10,6 +10,11 @@ Accepted checkpoint parameter layouts (those ``gptq_marlin.py`` and
   w_s   [G, N]
   w_zp  int32 [G, N/8] packed along N, plain column order (optional)
   g_idx int32 [K] (optional, act-order)
+or the compressed-tensors ``pack_quantized`` orientation (``compressed_tensors_wNa16.py:97-135``:
+``weight_packed`` int32 [N, K/8] with ``input_dim=1, output_dim=0, packed_dim=1``, ``weight_scale``
+[N, G]): parameters that carry ``input_dim`` / ``output_dim`` attributes are brought to the
+[K.., N] orientation first, as ``permute_param_layout_`` does for Marlin
+(``quantization/kernels/marlin.py:90-109``).
 """
 from typing import Optional, Tuple
 
@@ -51,12 +56,17 @@ class CDNA4LinearKernel(MPLinearKernel):
         perm = torch.empty(0, dtype=torch.int32, device=device)
         if c.has_g_idx and w_gidx is not None and w_gidx.numel() > 0:
             perm = torch.argsort(w_gidx).to(torch.int32)
+        def kn(x):  # [out, in..] (compressed-tensors) -> [in.., out]
+            if getattr(x, "input_dim", 0) == 1 and getattr(x, "output_dim", 1) == 0:
+                return x.data.t().contiguous()
+            return x.data.contiguous()
+
         self._transform_param(
             layer, self.w_q_name,
-            lambda x: ops.gptq_marlin_repack(x.data.contiguous(), perm, k, n, 4))
-        self._transform_param(layer, self.w_s_name, lambda x: x.data.contiguous())
+            lambda x: ops.gptq_marlin_repack(kn(x), perm, k, n, 4))
+        self._transform_param(layer, self.w_s_name, kn)
         if c.zero_points:
-            self._transform_param(layer, self.w_zp_name, lambda x: x.data.contiguous())
+            self._transform_param(layer, self.w_zp_name, kn)
         else:
             # symmetric uint4b8: zero point 8 for every column, stored once
             groups = getattr(layer, self.w_s_name).shape[0]

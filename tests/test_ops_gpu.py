@@ -1206,3 +1206,34 @@ def test_fused_wna16_moe_mixtral_tp4_shape(ops):
         ref += y * wgt
     torch.testing.assert_close(got.float(), ref, atol=2e-2, rtol=2e-2)
 
+
+def test_cdna4_kernel_ingests_compressed_tensors_layout(ops):
+    """compressed-tensors pack_quantized orientation (weight_packed [N, K/8], weight_scale [N, G],
+    input_dim=1 / output_dim=0; compressed_tensors_wNa16.py:97-135) through the MPLinearKernel seam."""
+    from aphrodite_engine_amd.quantization.kernels import choose_mp_linear_kernel
+    from aphrodite_engine_amd.quantization.kernels.MPLinearKernel import MPLinearLayerConfig
+    from aphrodite_engine_amd.scalar_type import scalar_types
+    rng = np.random.default_rng(12)
+    K, N, G = 512, 256, 128
+    w = (rng.standard_normal((K, N)) * 0.05).astype(np.float32)
+    w_ref, q, s, _ = oq.quantize_weights(w, 4, G, zero_points=False)
+    packed_kn = oq.gptq_pack(q, 4)                         # [K/8, N]
+    cfg = MPLinearLayerConfig(full_weight_shape=(K, N), partition_weight_shape=(K, N),
+                              weight_type=scalar_types.uint4b8, act_type=torch.float16, group_size=G,
+                              zero_points=False, has_g_idx=False)
+    kern = choose_mp_linear_kernel(cfg)(cfg, "weight_packed", "weight_scale")
+    layer = torch.nn.Module()
+    wp = torch.nn.Parameter(t(np.ascontiguousarray(packed_kn.T)), requires_grad=False)   # [N, K/8]
+    ws = torch.nn.Parameter(t(np.ascontiguousarray(s.T), torch.float16), requires_grad=False)  # [N, G]
+    for prm in (wp, ws):
+        prm.input_dim, prm.output_dim = 1, 0
+    wp.packed_dim = 1
+    layer.register_parameter("weight_packed", wp)
+    layer.register_parameter("weight_scale", ws)
+    kern.process_weights_after_loading(layer)
+    a = t(rng.standard_normal((9, K)).astype(np.float16))
+    got = kern.apply_weights(layer, a).float().cpu().numpy()
+    ref = a.float().cpu().numpy() @ w_ref.astype(np.float16).astype(np.float32)
+    assert rel_mean_err(got, ref) < 0.04
+    np.testing.assert_allclose(got, ref, rtol=2e-3, atol=2e-3 * np.abs(ref).max())
+
