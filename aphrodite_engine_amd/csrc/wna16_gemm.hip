@@ -218,7 +218,17 @@ __global__ __launch_bounds__(FNW * 64, (VEC * MT >= 8) ? 2 : 3) void wna16_gemm_
   constexpr int DEPTH = NSEG < 2 ? NSEG : 2;  // weight segments in flight ahead of the consumer
 #endif
   constexpr int NBUF = DEPTH + 1;
+#ifdef ABL_ADEPTH
+  constexpr int ADEPTH = NSEG < ABL_ADEPTH ? NSEG : ABL_ADEPTH;   // experiment: A fragments this many segments ahead
+#else
+  constexpr int ADEPTH = 1;
+#endif
+  constexpr int NA = ADEPTH + 1;
+#ifdef ABL_WAUX
+  constexpr int AUX_NT = ABL_WAUX;
+#else
   constexpr int AUX_NT = 2;  // nontemporal: weights are read exactly once
+#endif
   extern __shared__ __attribute__((aligned(16))) float red[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -272,7 +282,7 @@ __global__ __launch_bounds__(FNW * 64, (VEC * MT >= 8) ? 2 : 3) void wna16_gemm_
 
   SegMeta<VEC> meta[2];
   uint32_t w[NBUF][4][VEC];
-  u32x4 af[2][4][MT];
+  u32x4 af[NA][4][MT];
 
   auto load_meta = [&](SegMeta<VEC>& m, int s) {
     const int grp = (seg0 + s) >> p.gshift;  // group_size / 128 is a power of two on this path
@@ -302,12 +312,17 @@ __global__ __launch_bounds__(FNW * 64, (VEC * MT >= 8) ? 2 : 3) void wna16_gemm_
     for (int u = 0; u < 4; ++u)
 #pragma unroll
       for (int i = 0; i < MT; ++i)
+#ifdef ABL_AAUX
+        ad[u][i] = __builtin_amdgcn_raw_buffer_load_b128(ra, voff_a[i], ((seg0 + s) * 4 + u) * abytes, ABL_AAUX);
+#else
         ad[u][i] = __builtin_amdgcn_raw_buffer_load_b128(ra, voff_a[i], ((seg0 + s) * 4 + u) * abytes, 0);
+#endif
   };
 
   // ---- prologue: meta(0), A(0), W(0..DEPTH-1) ---------------------------------------
   load_meta(meta[0], 0);
-  load_a(af[0], 0);
+#pragma unroll
+  for (int d = 0; d < ADEPTH; ++d) load_a(af[d], d);
 #pragma unroll
   for (int d = 0; d < DEPTH; ++d) load_w(w[d], d);
   __builtin_amdgcn_sched_barrier(0);
@@ -318,7 +333,7 @@ __global__ __launch_bounds__(FNW * 64, (VEC * MT >= 8) ? 2 : 3) void wna16_gemm_
     // vmcnt(0) around runtime-conditional loads, and the issue points are pinned with
     // sched_barrier (the scheduler otherwise sinks loads next to their first use).
 #ifndef ABL_NO_A
-    if (s + 1 < NSEG) load_a(af[(s + 1) & 1], s + 1);
+    if (s + ADEPTH < NSEG) load_a(af[(s + ADEPTH) % NA], s + ADEPTH);
 #endif
     if (s + DEPTH < NSEG) load_w(w[(s + DEPTH) % NBUF], s + DEPTH);
     if (s + 1 < NSEG) load_meta(meta[(s + 1) & 1], s + 1);
@@ -333,7 +348,7 @@ __global__ __launch_bounds__(FNW * 64, (VEC * MT >= 8) ? 2 : 3) void wna16_gemm_
         // nibbles 2,3,6,7 of a word are extracted in place (bits 4-7 of each half):
         // they weigh 16x, so those four k of the A fragment are scaled by 1/16
         // (inline asm on the integer lanes: hipcc miscompiles a bitcast of one vector element)
-        u32x4 av = af[s & 1][u][i];
+        u32x4 av = af[s % NA][u][i];
         asm("v_pk_mul_f16 %0, %1, %2" : "=v"(av[1]) : "v"(av[1]), "s"(0x2c002c00u));
         asm("v_pk_mul_f16 %0, %1, %2" : "=v"(av[3]) : "v"(av[3]), "s"(0x2c002c00u));
         a[i] = __builtin_bit_cast(f16x8, av);

@@ -1,6 +1,9 @@
-"""aphrodite/quantization/kernels/MPLinearKernel.py:11-83 (interface mirror)."""
-from abc import ABC, abstractmethod
-from dataclasses import dataclass
+"""Mixed-precision linear kernel seam: the object a ``*LinearMethod`` delegates weight
+post-processing and the GEMM to, selected per layer from ``_POSSIBLE_KERNELS``.  Interface restated
+from aphrodite/quantization/kernels/MPLinearKernel.py:11-83 (field and method names are the
+reference's -- ``gptq_marlin.py`` / ``compressed_tensors_wNa16.py`` construct these objects)."""
+import abc
+import dataclasses
 from typing import Callable, Optional, Tuple
 
 import torch
@@ -8,9 +11,10 @@ import torch
 from ...scalar_type import ScalarType
 
 
-@dataclass
+@dataclasses.dataclass
 class MPLinearLayerConfig:
-    full_weight_shape: Tuple[int, int]  # [in, out]
+    """Static description of one quantised linear layer (shapes are [in, out])."""
+    full_weight_shape: Tuple[int, int]
     partition_weight_shape: Tuple[int, int]
     weight_type: ScalarType
     act_type: torch.dtype
@@ -19,46 +23,51 @@ class MPLinearLayerConfig:
     has_g_idx: bool
 
 
-class MPLinearKernel(ABC):
+class MPLinearKernel(abc.ABC):
+    # ---- class-level capability questions (asked before an instance exists) ------------------------
     @classmethod
-    @abstractmethod
+    @abc.abstractmethod
     def get_min_capability(cls) -> int:
-        raise NotImplementedError
+        ...
 
     @classmethod
-    @abstractmethod
+    @abc.abstractmethod
     def can_implement(cls, c: MPLinearLayerConfig) -> Tuple[bool, Optional[str]]:
-        raise NotImplementedError
+        """(True, None) or (False, reason)."""
+        ...
 
-    def __init__(self, c: MPLinearLayerConfig, w_q_param_name: str,
-                 w_s_param_name: str, w_zp_param_name: Optional[str] = None,
+    # ---- instance: remembers which layer attributes hold the tensors ------------------------------
+    def __init__(self, c: MPLinearLayerConfig, w_q_param_name: str, w_s_param_name: str,
+                 w_zp_param_name: Optional[str] = None,
                  w_gidx_param_name: Optional[str] = None) -> None:
-        assert self.can_implement(c)
+        ok, why = self.can_implement(c)
+        if not ok:
+            raise AssertionError(f"{type(self).__name__} cannot implement this layer: {why}")
         self.config = c
-        self.w_q_name = w_q_param_name
-        self.w_s_name = w_s_param_name
-        self.w_zp_name = w_zp_param_name
-        self.w_gidx_name = w_gidx_param_name
+        self.w_q_name, self.w_s_name = w_q_param_name, w_s_param_name
+        self.w_zp_name, self.w_gidx_name = w_zp_param_name, w_gidx_param_name
 
-    @abstractmethod
+    @abc.abstractmethod
     def process_weights_after_loading(self, layer: torch.nn.Module) -> None:
-        raise NotImplementedError
+        ...
 
-    @abstractmethod
+    @abc.abstractmethod
     def apply_weights(self, layer: torch.nn.Module, x: torch.Tensor,
                       bias: Optional[torch.Tensor] = None) -> torch.Tensor:
-        raise NotImplementedError
+        ...
 
-    def _transform_param(self, layer: torch.nn.Module, name: Optional[str],
-                         fn: Callable) -> None:
-        if name is not None and getattr(layer, name, None) is not None:
-            old_param = getattr(layer, name)
-            new_param = fn(old_param)
-            delattr(layer, name)
-            layer.register_parameter(
-                name, torch.nn.Parameter(new_param.data, requires_grad=False))
+    # ---- helpers for subclasses ------------------------------------------------------------------
+    def _transform_param(self, layer: torch.nn.Module, name: Optional[str], fn: Callable) -> None:
+        """Replace layer.<name> by fn(layer.<name>) as a frozen parameter (no-op if absent)."""
+        current = getattr(layer, name, None) if name is not None else None
+        if current is None:
+            return
+        replacement = fn(current)
+        delattr(layer, name)
+        layer.register_parameter(name, torch.nn.Parameter(replacement.data, requires_grad=False))
 
     def _get_weight_params(self, layer: torch.nn.Module):
-        return (getattr(layer, self.w_q_name), getattr(layer, self.w_s_name),
-                getattr(layer, self.w_zp_name or "", None),
-                getattr(layer, self.w_gidx_name or "", None))
+        """(w_q, w_s, w_zp or None, g_idx or None)."""
+        opt = lambda n: getattr(layer, n, None) if n else None  # noqa: E731
+        return getattr(layer, self.w_q_name), getattr(layer, self.w_s_name), opt(self.w_zp_name), \
+            opt(self.w_gidx_name)
