@@ -118,6 +118,7 @@ __global__ __launch_bounds__(NW * 64) void paged_attention_kernel(PAParams p) {
 
   extern __shared__ __attribute__((aligned(16))) float lds[];
   __shared__ int kv_flag;  // fused form: "the new token's K/V are in the cache" (see below)
+  __shared__ __attribute__((aligned(16))) uint16_t q_lds[ROPE ? 16 * HD : 8];  // fused form: rotated q, [head][d]
 
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -379,32 +380,35 @@ __global__ __launch_bounds__(NW * 64) void paged_attention_kernel(PAParams p) {
     const int owner_wave = (pair_end - 1 - pair0) % NW;
     const bool kv_owner = fused_rope && hb == 0 && wave == owner_wave;
     const bool kv_writer = fused_rope && hb == 0 && wave == (owner_wave + 1) % NW;
-    if (kv_writer) {
-      write_new_kv();
-      __hip_atomic_store(&kv_flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    // q of the fused form: issue the slab / cos-sin loads now (one rotary pair per thread)
+    constexpr int QIT = (16 * (HD / 2) + NW * 64 - 1) / (NW * 64);   // pairs per thread for up to 16 heads
+    float q_x[QIT], q_y[QIT];
+    uint16_t q_c[QIT], q_s[QIT];
+    if constexpr (fused_rope) {
+      if (hb == 0) {
+#pragma unroll
+        for (int it = 0; it < QIT; ++it) {
+          const int i = (int)threadIdx.x + it * NW * 64;
+          q_x[it] = q_y[it] = 0.f;
+          q_c[it] = q_s[it] = 0;
+          if (i < nh * (HD / 2)) {
+            const int h = i / (HD / 2), d = i % (HD / 2);
+            const float* p0 = p.qkv_slabs + (size_t)seq * ntot + (kvh * gqa + h) * HD + d;
+            float x = p0[0], y = p0[HD / 2];
+            for (int k = 1; k < p.nslab; ++k) {
+              x += p0[k * p.slab_stride];
+              y += p0[k * p.slab_stride + HD / 2];
+            }
+            q_x[it] = x; q_y[it] = y;
+            q_c[it] = cs_row[d];
+            q_s[it] = cs_row[HD / 2 + d];
+          }
+        }
+      }
     }
     // ---- Q fragments (B operand: lane (g, head) holds 8 consecutive d) --------
     // fused form: rotated from the qkv slabs INSIDE the first loop iteration, after that
     // iteration's K/V loads have been issued (their HBM latency covers the slab round trip)
-    auto prepare_q_rope = [&]() __attribute__((always_inline)) {
-      if constexpr (HD == 128) {
-#pragma unroll
-        for (int ks = 0; ks < NKS / 2; ++ks) {
-          int d0;
-          if constexpr (FP8) d0 = 64 * (ks >> 1) + 16 * g + 8 * (ks & 1);
-          else d0 = 32 * ks + 8 * g;
-          if (c < nh) {
-            u16x8 xo8, yo8;
-            rope8(head * HD, d0, xo8, yo8);      // partner chunk d0 + 64 is fragment ks + NKS/2 of this lane
-            qf[ks] = __builtin_bit_cast(u32x4, xo8);
-            qf[ks + NKS / 2] = __builtin_bit_cast(u32x4, yo8);
-          } else {
-            qf[ks] = u32x4{0, 0, 0, 0};
-            qf[ks + NKS / 2] = u32x4{0, 0, 0, 0};
-          }
-        }
-      }
-    };
     if constexpr (!fused_rope) {
       const uint16_t* qp = (const uint16_t*)p.q + (size_t)seq * p.q_stride + (size_t)head * HD;
 #pragma unroll
@@ -417,22 +421,68 @@ __global__ __launch_bounds__(NW * 64) void paged_attention_kernel(PAParams p) {
       }
     }
 
-    bool q_ready = !fused_rope;
-    for (; pr < pair_end; pr += NW) {
-      if constexpr (fused_rope) {
-        if (kv_owner && pr + NW >= pair_end) {  // the last pair holds the new token: wait for its writer
-          while (__hip_atomic_load(&kv_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0)
-            __builtin_amdgcn_s_sleep(1);
+    // Rotated loop: the first pair's K/V loads are issued BEFORE the q phase of the fused form, so
+    // their HBM latency covers it; afterwards load -> compute per pair as in the plain form.
+    if constexpr (!fused_rope) {
+      for (; pr < pair_end; pr += NW) {
+        load_pair(pr, kfa, vra);
+        compute_pair(pr, kfa, vra);
+      }
+    }
+    bool have = fused_rope && pr < pair_end;
+    // (the owner of the last pair must not read it before the writer has stored the new token)
+    const bool defer_first = kv_owner && have && pr + NW >= pair_end;
+    if (have && !defer_first) load_pair(pr, kfa, vra);
+    if constexpr (fused_rope) {
+      // ---- q of the new token: slab reduce + rotary, ONCE per workgroup, one (d, d + hd/2) pair per
+      // thread, through LDS.  The slab / cos-sin loads were issued above (before the K/V loads: the
+      // vector L1 returns in order) -- see q_x / q_y.
+      if (hb == 0) {
+#pragma unroll
+        for (int it = 0; it < QIT; ++it) {
+          const int i = (int)threadIdx.x + it * NW * 64;
+          if (i < nh * (HD / 2)) {
+            const int h = i / (HD / 2), d = i % (HD / 2);
+            float xo, yo;
+            rope_pair(T::to_f32(T::from_f32(q_x[it])), T::to_f32(T::from_f32(q_y[it])), T::to_f32(q_c[it]),
+                      T::to_f32(q_s[it]), xo, yo);
+            q_lds[h * HD + d] = T::from_f32(xo);
+            q_lds[h * HD + HD / 2 + d] = T::from_f32(yo);
+          }
         }
       }
-      load_pair(pr, kfa, vra);
-      if constexpr (fused_rope) {
-        if (!q_ready) {  // wave-uniform, first iteration only
-          prepare_q_rope();
-          q_ready = true;
-        }
+      __syncthreads();
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        int d0;
+        if constexpr (FP8) d0 = 64 * (ks >> 1) + 16 * g + 8 * (ks & 1);
+        else d0 = 32 * ks + 8 * g;
+        if (c < nh && d0 < HD) qf[ks] = *reinterpret_cast<const u32x4*>(&q_lds[c * HD + d0]);
+        else qf[ks] = u32x4{0, 0, 0, 0};
       }
+      if (kv_writer) {  // after the barrier: nobody waits for this wave's extra round trip
+        write_new_kv();
+        __hip_atomic_store(&kv_flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      if (defer_first) {
+        while (__hip_atomic_load(&kv_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0)
+          __builtin_amdgcn_s_sleep(1);
+        load_pair(pr, kfa, vra);
+      }
+    }
+    while (have) {
       compute_pair(pr, kfa, vra);
+      pr += NW;
+      have = pr < pair_end;
+      if (have) {
+        if constexpr (fused_rope) {
+          if (kv_owner && pr + NW >= pair_end) {  // the last pair holds the new token: wait for its writer
+            while (__hip_atomic_load(&kv_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0)
+              __builtin_amdgcn_s_sleep(1);
+          }
+        }
+        load_pair(pr, kfa, vra);
+      }
     }
 
     // ---- merge the NW waves through LDS ---------------------------------------------
