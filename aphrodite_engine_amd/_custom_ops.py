@@ -710,6 +710,39 @@ def paged_attention_rope_packed(qkv_slabs: torch.Tensor, positions: torch.Tensor
 
 
 # --------------------------------------------------------------------------
+# per-step bookkeeping
+# --------------------------------------------------------------------------
+def advance_step_flashattn(num_seqs: int, num_queries: int, block_size: int, input_tokens: torch.Tensor,
+                           sampled_token_ids: torch.Tensor, input_positions: torch.Tensor,
+                           seq_lens: torch.Tensor, slot_mapping: torch.Tensor,
+                           block_tables: torch.Tensor) -> None:
+    """_custom_ops.py advance_step_flashattn (kernels/torch_bindings.cpp:77-82)."""
+    _require_cuda(input_tokens, sampled_token_ids, input_positions, seq_lens, slot_mapping, block_tables)
+    for name, t_, dt in (("input_tokens", input_tokens, torch.int64), ("sampled_token_ids", sampled_token_ids, torch.int64),
+                         ("input_positions", input_positions, torch.int64), ("seq_lens", seq_lens, torch.int32),
+                         ("slot_mapping", slot_mapping, torch.int64), ("block_tables", block_tables, torch.int32)):
+        if t_.dtype != dt or not t_.is_contiguous():
+            raise RuntimeError(f"tensor: name = {name}, shape = {tuple(t_.shape)} is_cont = {t_.is_contiguous()}, "
+                               f"type = {t_.dtype} is not as expected: type = {dt}")
+    check(_lib.lib().aphro_advance_step_flashattn(
+        num_seqs, num_queries, block_size, input_tokens.data_ptr(), sampled_token_ids.data_ptr(),
+        input_positions.data_ptr(), seq_lens.data_ptr(), slot_mapping.data_ptr(), block_tables.data_ptr(),
+        block_tables.stride(0), _stream()), "advance_step_flashattn")
+
+
+def argmax_rows(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Greedy sampling: int64 argmax over the last dim of a 2-D logits tensor (lowest index on ties)."""
+    _require_cuda(x)
+    if x.dim() != 2 or x.stride(1) != 1:
+        raise RuntimeError("argmax_rows: expected a 2-D tensor with contiguous rows")
+    if out is None:
+        out = torch.empty(x.shape[0], dtype=torch.int64, device=x.device)
+    check(_lib.lib().aphro_argmax_rows(out.data_ptr(), x.data_ptr(), x.shape[0], x.shape[1], x.stride(0),
+                                       _dt(x), _stream()), "argmax_rows")
+    return out
+
+
+# --------------------------------------------------------------------------
 # mixture of experts
 # --------------------------------------------------------------------------
 def topk_softmax(topk_weights: torch.Tensor, topk_ids: torch.Tensor,

@@ -32,6 +32,8 @@ SIGNATURES = {
                                          L, L, L, I, I, F, F, P]),
     "aphro_paged_attention_rope_packed": (I, [P, P, P, I, P, P, P, P, P, I, I, I, I, F, P, P, I, I, I, P,
                                               L, L, I, I, F, F, P]),
+    "aphro_advance_step_flashattn": (I, [I, I, I, P, P, P, P, P, P, L, P]),
+    "aphro_argmax_rows": (I, [P, P, L, L, L, I, P]),
     "aphro_topk_softmax": (I, [P, P, P, P, L, I, I, P]),
     "aphro_moe_align_block_size": (I, [P, I, I, P, P, P, P, L, P]),
     "aphro_moe_gather_pack": (I, [P, P, P, P, L, L, L, L, I, I, P]),

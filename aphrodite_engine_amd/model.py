@@ -326,7 +326,9 @@ class LlamaForCausalLM(nn.Module):
             logits = tensor_model_parallel_all_gather(logits, dim=-1)
         return logits
 
-    def sample_greedy(self, logits):
+    def sample_greedy(self, logits, out=None):
+        if logits.is_cuda and logits.dim() == 2 and logits.stride(1) == 1:
+            return ops.argmax_rows(logits, out)
         return torch.argmax(logits, dim=-1)
 
 

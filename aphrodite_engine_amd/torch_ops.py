@@ -98,6 +98,12 @@ _C_OPS += [
      "Tensor! experts_ids, Tensor! num_tokens_post_pad) -> ()", _moe_align_block_size),     # :394-399
 ]
 
+_C_OPS += [
+    ("advance_step_flashattn(int num_seqs, int num_queries, int block_size, Tensor! input_tokens, "
+     "Tensor sampled_token_ids, Tensor! input_positions, Tensor! seq_lens, Tensor! slot_mapping, "
+     "Tensor block_tables) -> ()", ops.advance_step_flashattn),                             # :77-82
+]
+
 _MOE_OPS = [
     ("topk_softmax(Tensor! topk_weights, Tensor! topk_indices, Tensor! token_expert_indices, "
      "Tensor gating_output) -> ()", ops.topk_softmax),                 # kernels/moe/torch_bindings.cpp:11-14

@@ -104,13 +104,13 @@ class DecodeLoop:
         m = self.meta
         hidden = self.model(self.input_ids, self.positions, self.kv_caches, m)
         logits = self.model.compute_logits(hidden)
-        self.next_ids.copy_(self.model.sample_greedy(logits))
+        self.model.sample_greedy(logits, self.next_ids)
         # advance: the generated token becomes the next input, context grows by one
-        self.input_ids.copy_(self.next_ids)
-        self.positions.add_(1)
-        m.seq_lens_tensor.add_(1)
-        blk = m.block_tables.gather(1, (self.positions // self.block_size).unsqueeze(1)).squeeze(1)
-        m.slot_mapping.copy_(blk.long() * self.block_size + self.positions % self.block_size)
+        # (advance_step_flashattn, prepare_inputs/advance_step.cu: one launch instead of six)
+        from aphrodite_engine_amd import _custom_ops as ops
+        ops.advance_step_flashattn(self.input_ids.shape[0], self.input_ids.shape[0], self.block_size,
+                                   self.input_ids, self.next_ids, self.positions, m.seq_lens_tensor,
+                                   m.slot_mapping, m.block_tables)
 
 
 def gemm_bytes(lin, M_rows):

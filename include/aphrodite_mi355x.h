@@ -434,6 +434,26 @@ int aphro_moe_combine(void* out, const float* slabs, int nslab, int64_t m_pad,
                       const int32_t* inv_pos, const float* topk_weights, int64_t num_tokens,
                       int topk, int64_t N, int dtype, void* stream);
 
+/* ------------------------------------------------------------------------
+ * Per-step bookkeeping inside the HIP graph
+ * ---------------------------------------------------------------------- */
+
+/* _C::advance_step_flashattn(int num_seqs, int num_queries, int block_size,
+ *     Tensor! input_tokens, Tensor sampled_token_ids, Tensor! input_positions,
+ *     Tensor! seq_lens, Tensor! slot_mapping, Tensor block_tables)
+ *   kernels/torch_bindings.cpp:77-82, kernels/prepare_inputs/advance_step.cu:13-51.
+ * int64 tokens / positions / slots, int32 seq_lens and block_tables (row stride in elements). */
+int aphro_advance_step_flashattn(int num_seqs, int num_queries, int block_size,
+                                 int64_t* input_tokens, const int64_t* sampled_token_ids,
+                                 int64_t* input_positions, int32_t* seq_lens,
+                                 int64_t* slot_mapping, const int32_t* block_tables,
+                                 int64_t block_tables_stride, void* stream);
+
+/* Greedy sampling: out[r] = argmax_c x[r][c] (lowest index on ties) -- the torch.argmax of
+ * modeling/layers/sampler.py:_greedy_sample as one pass over each logits row. */
+int aphro_argmax_rows(int64_t* out, const void* x, int64_t rows, int64_t cols,
+                      int64_t row_stride, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

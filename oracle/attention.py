@@ -96,6 +96,18 @@ def swap_blocks(src, dst, block_mapping):
         dst[d_] = src[s_]
 
 
+def advance_step(input_tokens, sampled_token_ids, input_positions, seq_lens, slot_mapping,
+                 block_tables, block_size, num_queries):
+    """prepare_inputs/advance_step.cu:13-51: in place, for the first num_queries rows."""
+    for q in range(num_queries):
+        input_tokens[q] = sampled_token_ids[q]
+        nxt = int(seq_lens[q]) + 1
+        pos = nxt - 1
+        seq_lens[q] = nxt
+        input_positions[q] = pos
+        slot_mapping[q] = int(block_tables[q][pos // block_size]) * block_size + pos % block_size
+
+
 def gather_kv(key_cache, value_cache, block_table, seq_len,
               kv_cache_dtype="auto", k_scale=1.0, v_scale=1.0):
     """-> K,V float32 [L,Hkv,hd] for one sequence (test_attention.py:81-93)."""

@@ -1237,3 +1237,42 @@ def test_cdna4_kernel_ingests_compressed_tensors_layout(ops):
     assert rel_mean_err(got, ref) < 0.04
     np.testing.assert_allclose(got, ref, rtol=2e-3, atol=2e-3 * np.abs(ref).max())
 
+
+# ---------------------------------------------------------------------------
+# per-step bookkeeping
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("rows,cols", [(1, 7), (32, 128256), (5, 1000), (3, 8191)])
+def test_argmax_rows(ops, dtype, rows, cols):
+    rng = np.random.default_rng(rows + cols)
+    x = t(rng.standard_normal((rows, cols + 3)).astype(np.float32), dtype)[:, 1:cols + 1]   # unaligned strided rows
+    got = ops.argmax_rows(x)
+    xf = x.float().cpu().numpy()
+    ref = np.array([int(np.flatnonzero(r == r.max())[0]) for r in xf])   # lowest index on ties
+    np.testing.assert_array_equal(got.cpu().numpy(), ref)
+    y = torch.zeros(4, 4096, dtype=dtype, device=DEV)                       # all ties -> index 0
+    y[2, 77] = 1.0
+    y[3, 4095] = 2.0
+    np.testing.assert_array_equal(ops.argmax_rows(y).cpu().numpy(), [0, 0, 77, 4095])
+
+
+def test_advance_step_flashattn(ops):
+    rng = np.random.default_rng(6)
+    S, BS, maxb = 9, 16, 12
+    seq_lens = rng.integers(1, BS * (maxb - 1), size=S).astype(np.int32)
+    seq_lens[0] = 15                                        # crosses into the next block
+    bt = rng.permutation(S * maxb).reshape(S, maxb).astype(np.int32)
+    tokens = rng.integers(0, 1000, size=S).astype(np.int64)
+    sampled = rng.integers(0, 1000, size=S).astype(np.int64)
+    pos = (seq_lens - 1).astype(np.int64)
+    slots = np.full(S, -7, np.int64)
+    nq = 7                                                  # the last two rows stay untouched
+    d = [t(a.copy()) for a in (tokens, sampled, pos, seq_lens, slots, bt)]
+    ops.advance_step_flashattn(S, nq, BS, d[0], d[1], d[2], d[3], d[4], d[5])
+    ref = [a.copy() for a in (tokens, sampled, pos, seq_lens, slots)]
+    oa.advance_step(ref[0], ref[1], ref[2], ref[3], ref[4], bt, BS, nq)
+    for got, r in zip(d[:5], ref):
+        np.testing.assert_array_equal(got.cpu().numpy(), r)
+    with pytest.raises(RuntimeError):
+        ops.advance_step_flashattn(S, nq, BS, d[0], d[1], d[2], d[3].long(), d[4], d[5])
+
