@@ -10,6 +10,139 @@ namespace aphro { void set_error(const char*, ...) {} }
 #ifndef ABL_VEC
 #define ABL_VEC 4
 #endif
+#ifndef ABL_NWV
+#define ABL_NWV 4
+#endif
+
+// ---- experiment: one wave owns TWO adjacent 64-column tiles of the same K range and reuses its A
+// fragments for both (halves the A-fragment requests per weight byte); tile-outer / k-step-inner so
+// one accumulator set serves both tiles.  Timing only (epilogue reduced to one tile's worth).
+namespace aphro {
+template <typename T, int MT, int NSEG, int NWV>
+__global__ __launch_bounds__(NWV * 64, 1) void wna16_gemm2_kernel(Wna16Params p) {
+  constexpr int VEC = 4;
+  constexpr int DEPTH = 1, NBUF = 2;
+  extern __shared__ __attribute__((aligned(16))) float red[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, c = lane & 15;
+  const int n0 = blockIdx.x * 128;
+  const int m0 = blockIdx.z * (16 * MT);
+  const int seg0 = (blockIdx.y * NWV + wave) * NSEG;
+  const int mtiles = (p.M + 15) >> 4;
+  const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.qw, (uint32_t)((size_t)(p.K >> 3) * p.N * 4));
+  const __amdgpu_buffer_rsrc_t ra = make_rsrc(p.apk, (uint32_t)((size_t)(p.K >> 7) * 4 * mtiles * 1024));
+  const int ngroups = p.K / p.group_size;
+  const __amdgpu_buffer_rsrc_t rs_ = make_rsrc(p.sc, (uint32_t)((size_t)ngroups * p.N * 2));
+  const __amdgpu_buffer_rsrc_t rz = make_rsrc(p.qz, (uint32_t)((size_t)ngroups * (p.N >> 3) * 4));
+  const int roww = p.N * 4;
+  int voff_w[2], voff_s[2], voff_z[2], zshift[2];
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt) {
+    const int ncol = n0 + 64 * tt + VEC * c;
+    voff_w[tt] = (4 * g * p.N + ncol) * 4;
+    voff_s[tt] = ncol * 2;
+    voff_z[tt] = (ncol >> 3) * 4;
+    zshift[tt] = (ncol & 7) * 4;
+  }
+  int voff_a[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) voff_a[i] = (min((m0 >> 4) + i, mtiles - 1) * 64 + lane) * 16;
+  const int abytes = mtiles * 1024;
+  const float zoff = (float)p.zero_offset;
+  const f16x8 ones = {(f16)1.f, (f16)1.f, (f16)16.f, (f16)16.f, (f16)1.f, (f16)1.f, (f16)16.f, (f16)16.f};
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 cacc[2][MT][VEC];
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int t = 0; t < VEC; ++t) cacc[tt][i][t] = zero4;
+  SegMeta<VEC> meta[2][2];
+  uint32_t w[NBUF][2][4][VEC];
+  u32x4 af[2][4][MT];
+  auto load_meta = [&](SegMeta<VEC> (&m)[2], int s) {
+    const int grp = (seg0 + s) >> p.gshift;
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+      m[tt].zw = __builtin_amdgcn_raw_buffer_load_b32(rz, voff_z[tt], grp * (p.N >> 3) * 4, 0);
+      u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs_, voff_s[tt], grp * p.N * 2, 0);
+      m[tt].sc[0] = v[0]; m[tt].sc[1] = v[1];
+    }
+  };
+  auto load_w = [&](uint32_t (&wd)[2][4][VEC], int s) {
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rw, voff_w[tt], ((seg0 + s) * 16 + u) * roww, 2);
+        wd[tt][u][0] = v[0]; wd[tt][u][1] = v[1]; wd[tt][u][2] = v[2]; wd[tt][u][3] = v[3];
+      }
+  };
+  auto load_a = [&](u32x4 (&ad)[4][MT], int s) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+        ad[u][i] = __builtin_amdgcn_raw_buffer_load_b128(ra, voff_a[i], ((seg0 + s) * 4 + u) * abytes, 0);
+  };
+  load_meta(meta[0], 0);
+  load_a(af[0], 0);
+  load_w(w[0], 0);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int s = 0; s < NSEG; ++s) {
+    if (s + 1 < NSEG) load_a(af[(s + 1) & 1], s + 1);
+    if (s + DEPTH < NSEG) load_w(w[(s + DEPTH) % NBUF], s + DEPTH);
+    if (s + 1 < NSEG) load_meta(meta[(s + 1) & 1], s + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 rs[MT];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+      f32x4 acc[MT][VEC];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        f16x8 a[MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          u32x4 av = af[s & 1][u][i];
+          asm("v_pk_mul_f16 %0, %1, %2" : "=v"(av[1]) : "v"(av[1]), "s"(0x2c002c00u));
+          asm("v_pk_mul_f16 %0, %1, %2" : "=v"(av[3]) : "v"(av[3]), "s"(0x2c002c00u));
+          a[i] = __builtin_bit_cast(f16x8, av);
+          if (tt == 0) rs[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], ones, u == 0 ? zero4 : rs[i], 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < VEC; ++t) {
+          const uint32_t wv = w[s % NBUF][tt][u][t];
+          const uint32_t w8 = wv >> 8;
+          u32x4 bq = {wv & 0x000f000fu, wv & 0x00f000f0u, w8 & 0x000f000fu, w8 & 0x00f000f0u};
+          const f16x8 b = __builtin_bit_cast(f16x8, bq);
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+            acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b, u == 0 ? zero4 : acc[i][t], 0, 0, 0);
+        }
+      }
+      const SegMeta<VEC>& m = meta[s & 1][tt];
+#pragma unroll
+      for (int t = 0; t < VEC; ++t) {
+        const float z = (float)((m.zw >> (zshift[tt] + 4 * t)) & 0xf) + zoff;
+        const float sf = T::to_f32((uint16_t)(m.sc[t >> 1] >> (16 * (t & 1))));
+        const float s24 = sf * 16777216.f, nzs = -z * sf;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          cacc[tt][i][t] = __builtin_elementwise_fma(acc[i][t], f32x4{s24, s24, s24, s24}, cacc[tt][i][t]);
+          cacc[tt][i][t] = __builtin_elementwise_fma(rs[i], f32x4{nzs, nzs, nzs, nzs}, cacc[tt][i][t]);
+        }
+      }
+    }
+  }
+  Wna16Params p2 = p;
+  wna16_epilogue<T, VEC, MT, NWV>(p2, red, cacc[0], lane, wave, g, m0, n0 + VEC * c);
+  __syncthreads();
+  wna16_epilogue<T, VEC, MT, NWV>(p2, red, cacc[1], lane, wave, g, m0, n0 + 64 + VEC * c);
+}
+}  // namespace aphro
 #ifndef ABL_NSEG
 #define ABL_NSEG 8
 #endif
@@ -41,10 +174,20 @@ int main(int argc, char** argv) {
   uint64_t* tb; CK(hipMalloc(&tb, (size_t)grid.x * grid.y * aphro::FNW * 16 * 8)); CK(hipMemset(tb, 0, (size_t)grid.x * grid.y * aphro::FNW * 16 * 8));
   p.a = (const uint16_t*)tb;
 #endif
+#ifdef ABL_TWO
+  CK(hipFuncSetAttribute((const void*)aphro::wna16_gemm2_kernel<aphro::Half, MT, ABL_NSEG, ABL_NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)ABL_NWV * MT * 4 * 64 * 16)));
+#endif
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   auto run = [&](int i) {
     p.qw = qw[i % copies];
+#ifdef ABL_TWO
+#ifndef ABL_NWV
+#define ABL_NWV 4
+#endif
+    hipLaunchKernelGGL((aphro::wna16_gemm2_kernel<aphro::Half, MT, ABL_NSEG, ABL_NWV>), dim3(grid.x / 2, K / (128 * ABL_NWV * ABL_NSEG), grid.z), dim3(ABL_NWV * 64), (size_t)ABL_NWV * MT * 4 * 64 * 16, 0, p);
+#else
     hipLaunchKernelGGL((aphro::wna16_gemm_kernel<aphro::Half, ABL_VEC, MT, ABL_NSEG>), grid, dim3(aphro::FNW * 64), lds, 0, p);
+#endif
   };
   for (int i = 0; i < 8; ++i) run(i);
   CK(hipDeviceSynchronize());
