@@ -151,9 +151,11 @@ class LlamaDecoderLayer(nn.Module):
         return True
 
     def fused_decode_ok(self, m: int) -> bool:
-        """Decode fast path (8 launches per layer instead of 17): W4A16 linears in the
-        K-packed layout, shapes served by the packed-activation kernel, TP == 1."""
-        if self.tp != 1 or m > 64:
+        """Decode fast path (7 launches per layer instead of 17): W4A16 linears in the
+        K-packed layout, shapes (per TP shard) served by the packed-activation kernel.  With
+        TP > 1 the two row-parallel projections reduce their split-K slabs locally, all-reduce
+        the [M, hidden] result over the TP group and hand it to the fused norm as a tensor."""
+        if m > 64:
             return False
         for lin in (self.qkv_proj, self.o_proj, self.gate_up_proj, self.down_proj):
             fp = lin.fast_params()
@@ -163,12 +165,13 @@ class LlamaDecoderLayer(nn.Module):
 
     def forward_decode_fused(self, positions, x, slabs, residual, first, kv_cache, attn_metadata, cos_sin,
                              cos_sin_tok=None):
-        """x: row-major input (first layer) or None; slabs: fp32 split-K slabs of the
-        previous down_proj.  Returns the fp32 slabs of this layer's down_proj."""
+        """x: row-major input (first layer, or the all-reduced down_proj output of the previous
+        layer when TP > 1) or None; slabs: fp32 split-K slabs of the previous down_proj (TP == 1).
+        Returns (x, slabs) of this layer's down_proj in the same convention."""
         eps = self.cfg.rms_norm_eps
         m = positions.shape[0]
         h = self.cfg.hidden_size
-        packed, _ = ops.fused_add_rms_norm_pack(x if first else None, None if first else slabs, residual,
+        packed, _ = ops.fused_add_rms_norm_pack(x if slabs is None else None, slabs, residual,
                                                 not first, self.input_layernorm, eps)
         qw, qz, sc, zo = self.qkv_proj.fast_params()
         qkv_slabs, _ = ops.wna16_gemm_packed(packed, m, h, qw, qz, sc, zo, partials=True)
@@ -194,9 +197,15 @@ class LlamaDecoderLayer(nn.Module):
                 value_cache.shape[3], attn_metadata.max_decode_seq_len, None, self.attn.kv_cache_dtype,
                 self.k_scale, self.v_scale)
         qw, qz, sc, zo = self.o_proj.fast_params()
-        o_slabs, _ = ops.wna16_gemm_packed(attn_packed, m, self.q_size, qw, qz, sc, zo, partials=True)
-        packed2, _ = ops.fused_add_rms_norm_pack(None, o_slabs, residual, True,
-                                                 self.post_attention_layernorm, eps)
+        if self.tp > 1:   # row-parallel: local reduce, all-reduce over the TP group, then the norm
+            o = ops.wna16_gemm_packed(attn_packed, m, self.q_size, qw, qz, sc, zo, partials=False)
+            o = tensor_model_parallel_all_reduce(o)
+            packed2, _ = ops.fused_add_rms_norm_pack(o, None, residual, True,
+                                                     self.post_attention_layernorm, eps)
+        else:
+            o_slabs, _ = ops.wna16_gemm_packed(attn_packed, m, self.q_size, qw, qz, sc, zo, partials=True)
+            packed2, _ = ops.fused_add_rms_norm_pack(None, o_slabs, residual, True,
+                                                     self.post_attention_layernorm, eps)
         if self.gate_up_interleaved is not None:
             # SiluAndMul + pack run in the GEMM epilogue (interleaved gate/up columns)
             qw, qz, sc, zo = self.gate_up_interleaved
@@ -206,9 +215,12 @@ class LlamaDecoderLayer(nn.Module):
             gate_up = ops.wna16_gemm_packed(packed2, m, h, qw, qz, sc, zo, partials=False)
             act_packed = ops.silu_and_mul_pack(gate_up)
         qw, qz, sc, zo = self.down_proj.fast_params()
+        if self.tp > 1:
+            d = ops.wna16_gemm_packed(act_packed, m, self.down_proj.in_features, qw, qz, sc, zo, partials=False)
+            return tensor_model_parallel_all_reduce(d), None
         down_slabs, _ = ops.wna16_gemm_packed(act_packed, m, self.down_proj.in_features, qw, qz, sc, zo,
                                               partials=True)
-        return down_slabs
+        return None, down_slabs
 
     def forward(self, positions, hidden, residual, kv_cache, attn_metadata, cos_sin):
         eps = self.cfg.rms_norm_eps
@@ -273,7 +285,11 @@ class LlamaForCausalLM(nn.Module):
             p.copy_((torch.randn(p.shape, generator=g, device=device,
                                  dtype=torch.float32) * std).to(p.dtype))
 
-        randn_(self.embed_tokens, 1.0)
+        # replicated parameters are identical on every TP rank; sharded ones draw from the rank's stream
+        g_rep = torch.Generator(device=device)
+        g_rep.manual_seed(seed)
+        self.embed_tokens.copy_((torch.randn(self.embed_tokens.shape, generator=g_rep, device=device,
+                                             dtype=torch.float32)).to(self.embed_tokens.dtype))
         randn_(self.lm_head, 1.0 / math.sqrt(cfg.hidden_size))
         for layer in self.layers:
             for lin in (layer.qkv_proj, layer.o_proj, layer.gate_up_proj, layer.down_proj):
@@ -303,13 +319,13 @@ class LlamaForCausalLM(nn.Module):
                 and attn_metadata.num_decode_tokens > 0
                 and all(l.fused_decode_ok(hidden.shape[0]) for l in self.layers)):
             residual = torch.empty_like(hidden)
-            slabs = None
+            x, slabs = hidden, None
             # rotary table rows of this step's positions, gathered once for all layers
             cos_sin_tok = self.cos_sin.index_select(0, positions)
             for i, layer in enumerate(self.layers):
-                slabs = layer.forward_decode_fused(positions, hidden, slabs, residual, i == 0,
-                                                   kv_caches[i], attn_metadata, self.cos_sin, cos_sin_tok)
-            _, out = ops.fused_add_rms_norm_pack(None, slabs, residual, True, self.norm,
+                x, slabs = layer.forward_decode_fused(positions, x, slabs, residual, i == 0,
+                                                      kv_caches[i], attn_metadata, self.cos_sin, cos_sin_tok)
+            _, out = ops.fused_add_rms_norm_pack(x if slabs is None else None, slabs, residual, True, self.norm,
                                                  self.cfg.rms_norm_eps, pack=False, want_out=True)
             return out
         residual = None
