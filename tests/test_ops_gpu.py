@@ -306,6 +306,23 @@ def test_cutlass_scaled_mm(ops, M, K, N, per_token, per_channel, out_dtype):
     np.testing.assert_allclose(got, ref, rtol=1e-2, atol=5e-2)
 
 
+@pytest.mark.parametrize("per_token,per_channel", [(False, False), (True, True), (True, False)])
+def test_cutlass_scaled_mm_large_m(ops, per_token, per_channel):
+    """configs[2] prefill (seq 8192 would take the oracle minutes: 1024 rows here): above 64 rows the op
+    goes to the library GEMM, same contract."""
+    rng = np.random.default_rng(5)
+    M, K, N = 1024, 1024, 512
+    a = t((rng.standard_normal((M, K)) * 2).astype(np.float32)).to(torch.float8_e4m3fn)
+    w = t((rng.standard_normal((N, K)) * 2).astype(np.float32)).to(torch.float8_e4m3fn)
+    sa = t((rng.random((M, 1) if per_token else (1, )) * 0.1 + 0.01).astype(np.float32))
+    sb = t((rng.random((N, 1) if per_channel else (1, )) * 0.1 + 0.01).astype(np.float32))
+    bias = t(rng.standard_normal(N).astype(np.float32), torch.bfloat16)
+    got = ops.cutlass_scaled_mm(a, w.t(), sa, sb, torch.bfloat16, bias).float().cpu().numpy()
+    ref = of8.scaled_mm(a.view(torch.uint8).cpu().numpy(), w.view(torch.uint8).cpu().numpy().T,
+                        sa.cpu().numpy(), sb.cpu().numpy().reshape(-1), bias.float().cpu().numpy())
+    np.testing.assert_allclose(got, ref, rtol=1.6e-2, atol=1.6e-2 * np.abs(ref).max())
+
+
 @pytest.mark.parametrize("M", [1, 32, 64])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_fp8_w8a16(ops, M, dtype):
