@@ -234,6 +234,193 @@ __global__ __launch_bounds__(256) void flash_attn_varlen_kernel(FAParams p) {
 }
 
 // ---------------------------------------------------------------------------
+// Second-generation prefill kernel (hd 64 / 128): 64-key tiles, V staged ROW-major with 16-byte
+// LDS writes and consumed through ds_read_b64_tr_b16 -- the gfx950 transposing LDS read (probe:
+// tools/tr_probe.hip: within a 16-lane group, lane i supplies &blk[i/4][4*(i%4)] of a [4 keys][16
+// cols] block and lane c receives column c = {blk[0..3][c]}), which is exactly the 4-token slice of
+// the PV A-operand.  Removes the 2-byte V^T scatter (16-way bank conflicts, 239 M conflict cycles
+// per launch at T = 8192) and halves the barriers per key.
+// ---------------------------------------------------------------------------
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+constexpr int FA2_BN = 64;
+
+template <typename T, int HD, int QT>
+__global__ __launch_bounds__(256) void flash_attn_varlen_v2_kernel(FAParams p) {
+  constexpr int NCH = HD / 8;
+  constexpr int SWZ = (NCH & -NCH) - 1;
+  constexpr int NKS = HD / 32;
+  constexpr int NDT = HD / 16;
+  constexpr int BM = 64 * QT;
+  constexpr int VS = HD + 16;   // halfs per V row: 8 dwords of skew per row keeps the tr reads conflict free
+  __shared__ __attribute__((aligned(16))) uint16_t k_lds[FA2_BN * HD];
+  __shared__ __attribute__((aligned(16))) uint16_t v_lds[FA2_BN * VS];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int g = lane >> 4;
+  const int c = lane & 15;
+  const int head = blockIdx.y;
+  const int seq = blockIdx.z;
+  const int kvh = head / (p.num_heads / p.num_kv_heads);
+  const int s0 = p.cu_seqlens[seq];
+  const int len = p.cu_seqlens[seq + 1] - s0;
+  const int ntiles = (len + BM - 1) / BM;
+  const int tile = ntiles - 1 - (int)blockIdx.x;   // heavy (late) tiles first
+  if (tile < 0) return;
+  const int q0 = tile * BM;
+  const int wq0 = q0 + 16 * QT * wave;
+  int qrow[QT];
+#pragma unroll
+  for (int t = 0; t < QT; ++t) qrow[t] = wq0 + 16 * t + c;
+
+  u32x4 qf[QT][NKS];
+#pragma unroll
+  for (int t = 0; t < QT; ++t) {
+    const uint16_t* qp = (const uint16_t*)p.q + (size_t)(s0 + min(qrow[t], len - 1)) * p.q_stride + (size_t)head * HD;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) qf[t][ks] = *reinterpret_cast<const u32x4*>(qp + 32 * ks + 8 * g);
+  }
+  const float slope = p.alibi ? p.alibi[head] : 0.f;
+  const float sc2 = p.scale * 1.44269504088896f;
+  const float slope2 = slope * 1.44269504088896f;
+
+  f32x4 o[QT][NDT];
+  float m_run[QT], l_run[QT];
+#pragma unroll
+  for (int t = 0; t < QT; ++t) {
+#pragma unroll
+    for (int i = 0; i < NDT; ++i) o[t][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    m_run[t] = -1e30f;
+    l_run[t] = 0.f;
+  }
+
+  const int kv_end = p.causal ? min(len, q0 + BM) : len;
+  const uint16_t* kbase = (const uint16_t*)p.k + (size_t)s0 * p.k_stride + (size_t)kvh * HD;
+  const uint16_t* vbase = (const uint16_t*)p.v + (size_t)s0 * p.v_stride + (size_t)kvh * HD;
+  // per-lane part of the transposing V read: row (i / 4), 4 columns at 4 * (i % 4)
+  const int vtr_off = (4 * g + (c >> 2)) * VS + 4 * (c & 3);
+
+  for (int t0 = 0; t0 < kv_end; t0 += FA2_BN) {
+    __syncthreads();  // previous tile's readers are done
+    for (int i = threadIdx.x; i < FA2_BN * NCH; i += 256) {
+      const int tok = i / NCH, ch = i % NCH;
+      const int ta = min(t0 + tok, len - 1);
+      u32x4 kv4 = *reinterpret_cast<const u32x4*>(kbase + (size_t)ta * p.k_stride + 8 * ch);
+      u32x4 vv4 = *reinterpret_cast<const u32x4*>(vbase + (size_t)ta * p.v_stride + 8 * ch);
+      if (t0 + tok >= len) vv4 = u32x4{0, 0, 0, 0};  // 0 * garbage must stay 0
+      *reinterpret_cast<u32x4*>(&k_lds[tok * HD + 8 * (ch ^ (tok & SWZ))]) = kv4;
+      *reinterpret_cast<u32x4*>(&v_lds[tok * VS + 8 * ch]) = vv4;
+    }
+    __syncthreads();
+    const bool wave_active = !p.causal || (t0 <= wq0 + 16 * QT - 1);
+    if (wave_active) {
+      const bool edge = (t0 + FA2_BN > len) || (p.causal && t0 + FA2_BN - 1 > wq0) || slope != 0.f;
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr) {          // two 32-key halves of the tile
+        const int tb = t0 + 32 * pr;
+        if (p.causal && tb > wq0 + 16 * QT - 1) break;   // wave-uniform: this half is entirely masked
+        // ---- S^T = K . Q^T ------------------------------------------------------------
+        f32x4 s[QT][2];
+#pragma unroll
+        for (int t = 0; t < QT; ++t) { s[t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; s[t][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int tok = 32 * pr + 16 * h + c;
+#pragma unroll
+          for (int ks = 0; ks < NKS; ++ks) {
+            const int ch = (4 * ks + g) ^ (tok & SWZ);
+            u32x4 kf = *reinterpret_cast<const u32x4*>(&k_lds[tok * HD + 8 * ch]);
+#pragma unroll
+            for (int t = 0; t < QT; ++t) s[t][h] = fa_mfma<T>(kf, qf[t][ks], s[t][h]);
+          }
+        }
+        // ---- online softmax, log2 domain (see the first-generation kernel) ---------------
+        u32x4 pf[QT];
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+          float pv[2][4];
+          float mx = -1e30f;
+          if (edge) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int tok = tb + 16 * h + 4 * g + r;
+                float x = s[t][h][r] * sc2 + slope2 * (float)(tok - qrow[t]);
+                const bool ok = tok < len && (!p.causal || tok <= qrow[t]);
+                x = ok ? x : -1e30f;
+                pv[h][r] = x;
+                mx = __builtin_fmaxf(mx, x);
+              }
+          } else {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                pv[h][r] = s[t][h][r] * sc2;
+                mx = __builtin_fmaxf(mx, pv[h][r]);
+              }
+          }
+          mx = __builtin_fmaxf(mx, __shfl_xor(mx, 16, 64));
+          mx = __builtin_fmaxf(mx, __shfl_xor(mx, 32, 64));
+          const float m_new = __builtin_fmaxf(m_run[t], mx);
+          const bool moved = m_new != m_run[t];
+          const float alpha = __builtin_amdgcn_exp2f(m_run[t] - m_new);
+          m_run[t] = m_new;
+          float lsum = 0.f;
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float e = __builtin_amdgcn_exp2f(pv[h][r] - m_new);
+              if (edge) e = pv[h][r] > -1e29f ? e : 0.f;
+              pv[h][r] = e;
+              lsum += e;
+            }
+          l_run[t] = l_run[t] * alpha + lsum;
+          if (__builtin_amdgcn_ballot_w64(moved) != 0) {
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) o[t][dt] *= alpha;
+          }
+          pf[t][0] = fa_pack2<T>(pv[0][0], pv[0][1]);
+          pf[t][1] = fa_pack2<T>(pv[0][2], pv[0][3]);
+          pf[t][2] = fa_pack2<T>(pv[1][0], pv[1][1]);
+          pf[t][3] = fa_pack2<T>(pv[1][2], pv[1][3]);
+        }
+        // ---- O^T += V^T . P^T : A fragment = two transposing reads (tokens 16h + 4g .. +3) -----
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) {
+          const uint16_t* vb = &v_lds[(32 * pr) * VS + 16 * dt + vtr_off];
+          s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)vb);
+          s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(vb + 16 * VS));
+          u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+          u32x4 vf = {l2[0], l2[1], h2[0], h2[1]};
+#pragma unroll
+          for (int t = 0; t < QT; ++t) o[t][dt] = fa_mfma<T>(vf, pf[t], o[t][dt]);
+        }
+      }
+    }
+  }
+
+#pragma unroll
+  for (int t = 0; t < QT; ++t) {
+    float l = l_run[t];
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    if (qrow[t] < len) {
+      const float inv = l > 0.f ? 1.f / l : 0.f;
+      typename T::storage* op = (typename T::storage*)p.out + ((size_t)(s0 + qrow[t]) * p.num_heads + head) * HD;
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt) {
+        u16x4 r = {T::from_f32(o[t][dt][0] * inv), T::from_f32(o[t][dt][1] * inv), T::from_f32(o[t][dt][2] * inv),
+                   T::from_f32(o[t][dt][3] * inv)};
+        *reinterpret_cast<u16x4*>(op + 16 * dt + 4 * g) = r;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // Prefill WITH cached context (the context_attention_fwd role,
 // aphrodite/attention/ops/prefix_prefill.py:696-858, kernel :58-255): every new
 // token attends to the sequence's cached context, read from the PAGED KV cache
@@ -487,7 +674,9 @@ extern "C" int aphro_flash_attn_varlen(void* out, const void* q, const void* k, 
   // fill the chip with them; head 256 keeps one tile (registers)
   const int qt = (max_seqlen >= 512 && head_size <= 128 && !getenv("APHRO_FA_QT1")) ? 2 : 1;
   dim3 grid((unsigned)((max_seqlen + 64 * qt - 1) / (64 * qt)), (unsigned)num_heads, (unsigned)batch);
-#define FA_L(TT, HDV) { if (qt == 2) hipLaunchKernelGGL((flash_attn_varlen_kernel<TT, HDV, (HDV <= 128 ? 2 : 1)>), grid, dim3(256), 0, (hipStream_t)stream, p); \
+  const bool v2 = qt == 2 && (head_size == 64 || head_size == 128) && !getenv("APHRO_FA_V1");
+#define FA_L(TT, HDV) { if (v2) hipLaunchKernelGGL((flash_attn_varlen_v2_kernel<TT, (HDV == 64 ? 64 : 128), 2>), grid, dim3(256), 0, (hipStream_t)stream, p); \
+                        else if (qt == 2) hipLaunchKernelGGL((flash_attn_varlen_kernel<TT, HDV, (HDV <= 128 ? 2 : 1)>), grid, dim3(256), 0, (hipStream_t)stream, p); \
                         else hipLaunchKernelGGL((flash_attn_varlen_kernel<TT, HDV, 1>), grid, dim3(256), 0, (hipStream_t)stream, p); }
 #define FA_T(HDV) if (dtype == APHRO_F16) FA_L(Half, HDV) else FA_L(BFloat, HDV)
   switch (head_size) {

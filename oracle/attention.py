@@ -199,9 +199,10 @@ def paged_attention_v2_partials(query, key_cache, value_cache, block_tables,
     return out, mx, es, tmp
 
 
-def varlen_causal_attention(q, k, v, cu_seqlens, scale, causal=True):
+def varlen_causal_attention(q, k, v, cu_seqlens, scale, causal=True, alibi_slopes=None):
     """Prefill self-attention over packed sequences (rocm_flash_attn.py:598-630).
-    q [T,Hq,hd], k/v [T,Hkv,hd]; float64 math."""
+    q [T,Hq,hd], k/v [T,Hkv,hd]; float64 math.  alibi bias = slope_h * (key_pos - query_pos)
+    (_make_alibi_bias, rocm_flash_attn.py:238-263)."""
     q = _f32(q).astype(np.float64)
     k = _f32(k).astype(np.float64)
     v = _f32(v).astype(np.float64)
@@ -217,6 +218,9 @@ def varlen_causal_attention(q, k, v, cu_seqlens, scale, causal=True):
         kk = np.repeat(k[s:e], rep, axis=1)
         vv = np.repeat(v[s:e], rep, axis=1)
         lg = scale * np.einsum("qhd,khd->hqk", q[s:e], kk)
+        if alibi_slopes is not None:
+            rel = np.arange(n)[None, :] - np.arange(n)[:, None]        # key_pos - query_pos
+            lg = lg + np.asarray(alibi_slopes, np.float64)[:, None, None] * rel[None]
         if causal:
             mask = np.triu(np.ones((n, n), dtype=bool), 1)
             lg = np.where(mask[None], -np.inf, lg)

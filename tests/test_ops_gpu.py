@@ -708,6 +708,30 @@ def test_flash_attn_varlen(ops, dtype, Hq, Hkv, D, causal):
     np.testing.assert_allclose(got.float().cpu().numpy(), ref, atol=tol, rtol=tol)
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("Hq,Hkv,D", [(8, 2, 128), (4, 4, 64), (6, 2, 96)])
+@pytest.mark.parametrize("causal,alibi", [(True, False), (False, False), (True, True)])
+def test_flash_attn_varlen_long(ops, dtype, Hq, Hkv, D, causal, alibi):
+    """Sequences >= 512 tokens take the 128-row / 64-key-tile kernels (transposing LDS reads for
+    hd 64 / 128): ragged lengths around the tile boundaries, GQA, ALiBi."""
+    if dtype == torch.bfloat16 and (alibi or not causal):
+        pytest.skip("bf16 covered on the causal case")
+    rng = np.random.default_rng(Hq * 3 + D)
+    lens = [700, 1, 513, 64, 1025, 127]
+    cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    T = int(cu[-1])
+    qkv = t(rng.standard_normal((T, (Hq + 2 * Hkv) * D)).astype(np.float32) * 0.7, dtype)
+    q, k, v = qkv.split([Hq * D, Hkv * D, Hkv * D], dim=-1)
+    q, k, v = q.view(T, Hq, D), k.view(T, Hkv, D), v.view(T, Hkv, D)
+    scale = float(D ** -0.5)
+    slopes = (rng.random(Hq).astype(np.float32) * 0.05) if alibi else None
+    got = ops.flash_attn_varlen(q, k, v, t(cu), max(lens), scale, causal=causal,
+                                alibi_slopes=t(slopes) if alibi else None)
+    ref = oa.varlen_causal_attention(q, k, v, cu, scale, causal=causal, alibi_slopes=slopes)
+    tol = 2e-3 if dtype == torch.float16 else 1.6e-2
+    np.testing.assert_allclose(got.float().cpu().numpy(), ref, atol=tol, rtol=tol)
+
+
 def test_attention_backend_prefill_then_decode(ops):
     """AttentionImpl.forward on a mixed (chunked-prefill style) batch: prefill
     tokens attend causally within their sequence and are written to the paged
