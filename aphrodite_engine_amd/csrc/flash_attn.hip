@@ -244,13 +244,14 @@ __global__ __launch_bounds__(256) void flash_attn_varlen_kernel(FAParams p) {
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 constexpr int FA2_BN = 64;
 
-template <typename T, int HD, int QT>
-__global__ __launch_bounds__(256) void flash_attn_varlen_v2_kernel(FAParams p) {
+template <typename T, int HD, int QT, int NWV>
+__global__ __launch_bounds__(NWV * 64) void flash_attn_varlen_v2_kernel(FAParams p) {
   constexpr int NCH = HD / 8;
   constexpr int SWZ = (NCH & -NCH) - 1;
   constexpr int NKS = HD / 32;
   constexpr int NDT = HD / 16;
-  constexpr int BM = 64 * QT;
+  constexpr int BM = 16 * QT * NWV;
+  constexpr int NTHR = NWV * 64;
   constexpr int VS = HD + 16;   // halfs per V row: 8 dwords of skew per row keeps the tr reads conflict free
   __shared__ __attribute__((aligned(16))) uint16_t k_lds[FA2_BN * HD];
   __shared__ __attribute__((aligned(16))) uint16_t v_lds[FA2_BN * VS];
@@ -304,13 +305,13 @@ __global__ __launch_bounds__(256) void flash_attn_varlen_v2_kernel(FAParams p) {
   // right after tile i became visible in LDS and land while tile i is computed (329 -> 420 TFLOP/s
   // at T = 8192; a second LDS buffer that would save one of the two barriers per tile measured
   // slower: it halves the workgroups per CU).
-  constexpr int CPT = FA2_BN * NCH / 256;   // 16-byte chunks per thread per tile (K and V each)
-  static_assert(FA2_BN * NCH % 256 == 0, "hd 64 / 128 only");
+  constexpr int CPT = FA2_BN * NCH / NTHR;   // 16-byte chunks per thread per tile (K and V each)
+  static_assert(FA2_BN * NCH % NTHR == 0, "hd 64 / 128 only");
   u32x4 kreg[CPT], vreg[CPT];
   auto fetch = [&](int t0) {
 #pragma unroll
     for (int q = 0; q < CPT; ++q) {
-      const int i = threadIdx.x + 256 * q;
+      const int i = threadIdx.x + NTHR * q;
       const int tok = i / NCH, ch = i % NCH;
       const int ta = min(t0 + tok, len - 1);
       kreg[q] = *reinterpret_cast<const u32x4*>(kbase + (size_t)ta * p.k_stride + 8 * ch);
@@ -322,7 +323,7 @@ __global__ __launch_bounds__(256) void flash_attn_varlen_v2_kernel(FAParams p) {
     __syncthreads();  // previous tile's readers are done
 #pragma unroll
     for (int q = 0; q < CPT; ++q) {
-      const int i = threadIdx.x + 256 * q;
+      const int i = threadIdx.x + NTHR * q;
       const int tok = i / NCH, ch = i % NCH;
       u32x4 vv4 = vreg[q];
       if (t0 + tok >= len) vv4 = u32x4{0, 0, 0, 0};  // 0 * garbage must stay 0
@@ -694,7 +695,11 @@ extern "C" int aphro_flash_attn_varlen(void* out, const void* q, const void* k, 
   const int qt = (max_seqlen >= 512 && head_size <= 128 && !getenv("APHRO_FA_QT1")) ? 2 : 1;
   dim3 grid((unsigned)((max_seqlen + 64 * qt - 1) / (64 * qt)), (unsigned)num_heads, (unsigned)batch);
   const bool v2 = qt == 2 && (head_size == 64 || head_size == 128) && !getenv("APHRO_FA_V1");
-#define FA_L(TT, HDV) { if (v2) hipLaunchKernelGGL((flash_attn_varlen_v2_kernel<TT, (HDV == 64 ? 64 : 128), 2>), grid, dim3(256), 0, (hipStream_t)stream, p); \
+  // 256-row (8-wave) workgroups measured slower at T = 8192 (376 vs 413 TFLOP/s): opt-in only
+  const bool v2w8 = v2 && head_size == 128 && getenv("APHRO_FA_W8") != nullptr;
+  if (v2w8) grid.x = (unsigned)((max_seqlen + 255) / 256);
+#define FA_L(TT, HDV) { if (v2w8) hipLaunchKernelGGL((flash_attn_varlen_v2_kernel<TT, 128, 2, 8>), grid, dim3(512), 0, (hipStream_t)stream, p); \
+                        else if (v2) hipLaunchKernelGGL((flash_attn_varlen_v2_kernel<TT, (HDV == 64 ? 64 : 128), 2, 4>), grid, dim3(256), 0, (hipStream_t)stream, p); \
                         else if (qt == 2) hipLaunchKernelGGL((flash_attn_varlen_kernel<TT, HDV, (HDV <= 128 ? 2 : 1)>), grid, dim3(256), 0, (hipStream_t)stream, p); \
                         else hipLaunchKernelGGL((flash_attn_varlen_kernel<TT, HDV, 1>), grid, dim3(256), 0, (hipStream_t)stream, p); }
 #define FA_T(HDV) if (dtype == APHRO_F16) FA_L(Half, HDV) else FA_L(BFloat, HDV)
