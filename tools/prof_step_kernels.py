@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Launches each decode-step kernel a few times at the bench shapes (for rocprofv3 --pmc)."""
+import os
+import sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from aphrodite_engine_amd import _custom_ops as ops  # noqa: E402
+dev = "cuda"
+g = torch.Generator(device=dev).manual_seed(0)
+bs = 32
+
+
+def gptq(k, n):
+    qw = torch.randint(-2 ** 31, 2 ** 31 - 1, (k // 8, n), generator=g, device=dev, dtype=torch.int64).to(torch.int32)
+    qz = torch.randint(-2 ** 31, 2 ** 31 - 1, (k // 128, n // 8), generator=g, device=dev, dtype=torch.int64).to(torch.int32)
+    sc = (torch.rand(k // 128, n, generator=g, device=dev) * 0.01).half()
+    return qw, qz, sc
+
+
+shapes = {"qkv": (4096, 6144), "o": (4096, 4096), "gate_up": (4096, 28672), "down": (14336, 4096)}
+ws = {n: [gptq(*s) for _ in range(6)] for n, s in shapes.items()}
+for name, (k, n) in shapes.items():
+    a = ops.wna16_pack_a(torch.randn(bs, k, device=dev, dtype=torch.float16))
+    for qw, qz, sc in ws[name]:
+        if name == "gate_up":
+            ops.wna16_gemm_silu_pack(a, bs, k, qw, qz, sc, 1)
+        else:
+            ops.wna16_gemm_packed(a, bs, k, qw, qz, sc, 1, partials=True)
+# fused attention + norms
+ctx, Hq, Hkv, D, BS = 1100, 32, 8, 128, 16
+bps = (ctx + BS - 1) // BS
+nb = bs * bps
+bt = torch.randperm(nb, device=dev).view(bs, bps).int()
+sl = torch.full((bs, ), ctx, dtype=torch.int32, device=dev)
+slabs = torch.randn(2, bs, (Hq + 2 * Hkv) * D, device=dev) * 0.3
+cs = torch.randn(bs, D, device=dev).half()
+slots = (bt[:, (ctx - 1) // BS].long() * BS + (ctx - 1) % BS)
+for _ in range(6):
+    kc = torch.randn(nb, Hkv, D // 8, BS, 8, device=dev, dtype=torch.float16) * 0.1
+    vc = torch.randn(nb, Hkv, D, BS, device=dev, dtype=torch.float16) * 0.1
+    ops.paged_attention_rope_packed(slabs, None, cs, slots, kc, vc, Hq, Hkv, D ** -0.5, bt, sl, BS, ctx, None,
+                                    "auto", 1.0, 1.0)
+res = torch.randn(bs, 4096, device=dev).half()
+w = torch.ones(4096, device=dev).half()
+s4 = torch.randn(4, bs, 4096, device=dev)
+for _ in range(6):
+    ops.fused_add_rms_norm_pack(None, s4, res, True, w, 1e-5)
+torch.cuda.synchronize()
