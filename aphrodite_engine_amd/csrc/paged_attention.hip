@@ -242,7 +242,18 @@ __global__ __launch_bounds__(NW * 64) void paged_attention_kernel(PAParams p) {
     // K/V registers of one 32-token tile pair: kf = K fragments, vraw = 4 tokens x 16 d-rows per
     // lane (16-bit KV: 8 B, fp8: 4 B in [0]).  Two sets: the next pair's loads are in flight while
     // the current pair is computed (and, in the fused-rope form, while q is being rotated).
-    auto load_pair = [&](int pr, u32x4 (&kf)[2][NLD], u32x2 (&vraw)[NDT][2]) __attribute__((always_inline)) {
+    // Block-table entries of a pair ([jj] K block, [2 + jj] V block): fetched ONE PAIR AHEAD so that
+    // the K/V loads never wait behind a dependent table lookup.
+    auto load_ids = [&](int pr, int (&ids)[4]) __attribute__((always_inline)) {
+      const int tb = pr << 5;
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        ids[jj] = bt[min(tb + 16 * jj + c, seq_len - 1) / BS];
+        ids[2 + jj] = bt[min(tb + 16 * jj + 4 * g, alloc_tokens - 4) / BS];
+      }
+    };
+    auto load_pair = [&](int pr, const int (&ids)[4], u32x4 (&kf)[2][NLD], u32x2 (&vraw)[NDT][2])
+        __attribute__((always_inline)) {
       const int tb = pr << 5;
       // ---- addresses -----------------------------------------------------------
       const char* kptr[2];
@@ -250,11 +261,9 @@ __global__ __launch_bounds__(NW * 64) void paged_attention_kernel(PAParams p) {
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj) {
         int tk = min(tb + 16 * jj + c, seq_len - 1);
-        int blk = bt[tk / BS];
-        kptr[jj] = kc + ((size_t)blk * p.kv_block_stride + (size_t)(tk % BS) * XE) * ESZ;
+        kptr[jj] = kc + ((size_t)ids[jj] * p.kv_block_stride + (size_t)(tk % BS) * XE) * ESZ;
         int tv = min(tb + 16 * jj + 4 * g, alloc_tokens - 4);
-        int blv = bt[tv / BS];
-        vptr[jj] = vc + ((size_t)blv * p.kv_block_stride + (size_t)c * BS + (tv % BS)) * ESZ;
+        vptr[jj] = vc + ((size_t)ids[2 + jj] * p.kv_block_stride + (size_t)c * BS + (tv % BS)) * ESZ;
       }
       // ---- issue all K and V loads of the pair ----------------------------------
 #pragma unroll
@@ -423,16 +432,22 @@ __global__ __launch_bounds__(NW * 64) void paged_attention_kernel(PAParams p) {
 
     // Rotated loop: the first pair's K/V loads are issued BEFORE the q phase of the fused form, so
     // their HBM latency covers it; afterwards load -> compute per pair as in the plain form.
+    int ids[4] = {0, 0, 0, 0}, ids_next[4] = {0, 0, 0, 0};
+    if (pr < pair_end) load_ids(pr, ids);
     if constexpr (!fused_rope) {
       for (; pr < pair_end; pr += NW) {
-        load_pair(pr, kfa, vra);
+        load_pair(pr, ids, kfa, vra);
+        if (pr + NW < pair_end) load_ids(pr + NW, ids_next);
         compute_pair(pr, kfa, vra);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ids[e] = ids_next[e];
       }
     }
     bool have = fused_rope && pr < pair_end;
     // (the owner of the last pair must not read it before the writer has stored the new token)
     const bool defer_first = kv_owner && have && pr + NW >= pair_end;
-    if (have && !defer_first) load_pair(pr, kfa, vra);
+    if (have && !defer_first) load_pair(pr, ids, kfa, vra);
+    if (have && pr + NW < pair_end) load_ids(pr + NW, ids_next);
     if constexpr (fused_rope) {
       // ---- q of the new token: slab reduce + rotary, ONCE per workgroup, one (d, d + hd/2) pair per
       // thread, through LDS.  The slab / cos-sin loads were issued above (before the K/V loads: the
@@ -467,7 +482,7 @@ __global__ __launch_bounds__(NW * 64) void paged_attention_kernel(PAParams p) {
       if (defer_first) {
         while (__hip_atomic_load(&kv_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0)
           __builtin_amdgcn_s_sleep(1);
-        load_pair(pr, kfa, vra);
+        load_pair(pr, ids, kfa, vra);
       }
     }
     while (have) {
@@ -481,7 +496,10 @@ __global__ __launch_bounds__(NW * 64) void paged_attention_kernel(PAParams p) {
               __builtin_amdgcn_s_sleep(1);
           }
         }
-        load_pair(pr, kfa, vra);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ids[e] = ids_next[e];
+        load_pair(pr, ids, kfa, vra);
+        if (pr + NW < pair_end) load_ids(pr + NW, ids_next);
       }
     }
 
