@@ -711,6 +711,96 @@ def paged_attention_rope_packed(qkv_slabs: torch.Tensor, positions: torch.Tensor
 
 
 # --------------------------------------------------------------------------
+# FP8 (W8A8, per-token dynamic) decode fast path
+# --------------------------------------------------------------------------
+def fp8_gemm_ksplit(m: int, n: int, k: int) -> int:
+    """Split-K factor scaled_mm_fp8_slabs uses for this shape (<= 0: shape not served)."""
+    return int(_lib.lib().aphro_fp8_gemm_ksplit(m, n, k))
+
+
+def scaled_mm_fp8_slabs(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """a fp8 [M,K], b fp8 [K,N] column-major (weight.t()); returns the raw fp32 accumulators as
+    split-K slabs [S, M, N] -- the consumer applies a_scale * (b_scale * sum)."""
+    lib = _lib.lib()
+    m, k = a.shape
+    n = b.shape[1]
+    if b.stride(0) != 1 or b.stride(1) != k:
+        raise RuntimeError("b must be column-major [K,N] (weight.t())")
+    ks = lib.aphro_fp8_gemm_ksplit(m, n, k)
+    if ks <= 0:
+        raise RuntimeError(f"scaled_mm_fp8_slabs: shape M={m} N={n} K={k} not served")
+    slabs = torch.empty((ks, m, n), dtype=torch.float32, device=a.device)
+    check(lib.aphro_scaled_mm_fp8_slabs(a.data_ptr(), b.data_ptr(), slabs.data_ptr(), slabs.numel() * 4,
+                                        m, n, k, _stream()), "scaled_mm_fp8_slabs")
+    return slabs
+
+
+def fused_add_rms_norm_quant_fp8(x: Optional[torch.Tensor], slabs: Optional[torch.Tensor],
+                                 slab_a_scales: Optional[torch.Tensor], slab_b_scales: Optional[torch.Tensor],
+                                 residual: torch.Tensor, has_residual: bool, weight: torch.Tensor,
+                                 epsilon: float, want_out: bool = False):
+    """[slab reduce + dequant] + fused_add_rms_norm + per-token fp8 quant.
+    Returns (q fp8 [M, H], scales fp32 [M, 1], out or None)."""
+    lib = _lib.lib()
+    if slabs is not None:
+        nslab, tokens, hidden = slabs.shape
+        dev = slabs.device
+    else:
+        tokens, hidden = x.shape
+        nslab, dev = 0, x.device
+        assert x.is_contiguous()
+    q = torch.empty((tokens, hidden), dtype=FP8_DTYPE, device=dev)
+    sc = torch.empty((tokens, 1), dtype=torch.float32, device=dev)
+    out = torch.empty((tokens, hidden), dtype=weight.dtype, device=dev) if want_out else None
+    a_tok = 1 if slab_a_scales is not None and slab_a_scales.numel() > 1 else 0
+    b_ch = 1 if slab_b_scales is not None and slab_b_scales.numel() > 1 else 0
+    check(lib.aphro_fused_add_rms_norm_quant_fp8(
+        _ptr(x), _ptr(slabs), nslab, _ptr(slab_a_scales), _ptr(slab_b_scales), a_tok, b_ch, residual.data_ptr(),
+        1 if has_residual else 0, weight.data_ptr(), float(epsilon), q.data_ptr(), sc.data_ptr(), _ptr(out),
+        tokens, hidden, _dt(weight), _stream()), "fused_add_rms_norm_quant_fp8")
+    return q, sc, out
+
+
+def silu_and_mul_quant_fp8(x: torch.Tensor, want_out: bool = False):
+    """silu_and_mul + per-token fp8 quant over x [M, 2d]; returns (q [M, d], scales [M, 1], out or None)."""
+    lib = _lib.lib()
+    tokens, d2 = x.shape
+    d = d2 // 2
+    assert x.is_contiguous()
+    q = torch.empty((tokens, d), dtype=FP8_DTYPE, device=x.device)
+    sc = torch.empty((tokens, 1), dtype=torch.float32, device=x.device)
+    out = torch.empty((tokens, d), dtype=x.dtype, device=x.device) if want_out else None
+    check(lib.aphro_silu_and_mul_quant_fp8(x.data_ptr(), q.data_ptr(), sc.data_ptr(), _ptr(out), tokens, d,
+                                           _dt(x), _stream()), "silu_and_mul_quant_fp8")
+    return q, sc, out
+
+
+def paged_attention_rope_scaled(qkv_slabs: torch.Tensor, slab_row_scale: Optional[torch.Tensor],
+                                slab_col_scale: torch.Tensor, positions: Optional[torch.Tensor],
+                                cos_sin_cache: torch.Tensor, slot_mapping: torch.Tensor, key_cache: torch.Tensor,
+                                value_cache: torch.Tensor, num_heads: int, num_kv_heads: int, scale: float,
+                                block_tables: torch.Tensor, seq_lens: torch.Tensor, block_size: int,
+                                max_seq_len: int, alibi_slopes: Optional[torch.Tensor], kv_cache_dtype: str,
+                                k_scale: float, v_scale: float) -> torch.Tensor:
+    """paged_attention_rope_packed over the raw slabs of an FP8 qkv projection (dequantised on the
+    fly); returns the attention output [S, Hq, hd] row-major in the activation dtype."""
+    lib = _lib.lib()
+    nslab, num_seqs, ntot = qkv_slabs.shape
+    head_size = ntot // (num_heads + 2 * num_kv_heads)
+    out = torch.empty((num_seqs, num_heads, head_size), dtype=cos_sin_cache.dtype, device=qkv_slabs.device)
+    if positions is not None and positions.dtype != torch.int64:
+        positions = positions.long()
+    check(lib.aphro_paged_attention_rope_packed_scaled(
+        out.data_ptr(), None, qkv_slabs.data_ptr(), nslab, _ptr(slab_row_scale), slab_col_scale.data_ptr(),
+        _ptr(positions), cos_sin_cache.data_ptr(), slot_mapping.data_ptr(), key_cache.data_ptr(),
+        value_cache.data_ptr(), num_seqs, num_heads, num_kv_heads, head_size, float(scale),
+        block_tables.data_ptr(), seq_lens.data_ptr(), block_tables.stride(0), block_size, int(max_seq_len),
+        _ptr(alibi_slopes), key_cache.stride(0), key_cache.stride(1), _dt(cos_sin_cache), _kv(kv_cache_dtype),
+        float(k_scale), float(v_scale), _stream()), "paged_attention_rope_packed_scaled")
+    return out
+
+
+# --------------------------------------------------------------------------
 # per-step bookkeeping
 # --------------------------------------------------------------------------
 def advance_step_flashattn(num_seqs: int, num_queries: int, block_size: int, input_tokens: torch.Tensor,

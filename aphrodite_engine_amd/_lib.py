@@ -32,6 +32,12 @@ SIGNATURES = {
                                          L, L, L, I, I, F, F, P]),
     "aphro_paged_attention_rope_packed": (I, [P, P, P, I, P, P, P, P, P, I, I, I, I, F, P, P, I, I, I, P,
                                               L, L, I, I, F, F, P]),
+    "aphro_fp8_gemm_ksplit": (I, [L, L, L]),
+    "aphro_scaled_mm_fp8_slabs": (I, [P, P, P, Z, L, L, L, P]),
+    "aphro_fused_add_rms_norm_quant_fp8": (I, [P, P, I, P, P, I, I, P, I, P, F, P, P, P, L, I, I, P]),
+    "aphro_silu_and_mul_quant_fp8": (I, [P, P, P, P, L, I, I, P]),
+    "aphro_paged_attention_rope_packed_scaled": (I, [P, P, P, I, P, P, P, P, P, P, P, I, I, I, I, F, P, P,
+                                                     I, I, I, P, L, L, I, I, F, F, P]),
     "aphro_advance_step_flashattn": (I, [I, I, I, P, P, P, P, P, P, L, P]),
     "aphro_argmax_rows": (I, [P, P, L, L, L, I, P]),
     "aphro_topk_softmax": (I, [P, P, P, P, L, I, I, P]),

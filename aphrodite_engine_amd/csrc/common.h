@@ -75,6 +75,16 @@ struct Float {
   static __device__ __forceinline__ float from_f32(float f) { return f; }
 };
 
+// hipcc selects fptrunc(fmul a, b) as v_fma_mixlo_f16: ONE rounding of the exact product, where the
+// reference rounds the fp32 product first and converts second (they differ when the fp32 product
+// lands on an f16 tie, ~2^-13 of the elements).  Kernels that promise bit-exactness against an op
+// sequence round through this: the asm makes the fp32 value opaque to that selection.
+template <typename T>
+__device__ __forceinline__ typename T::storage from_f32_exact(float f) {
+  asm("" : "+v"(f));
+  return T::from_f32(f);
+}
+
 // ---- fp8 (OCP e4m3fn / e5m2, native on gfx950) ---------------------------------
 // word: 4 packed fp8; returns elements (2*hi_pair, 2*hi_pair+1) as f32.
 template <bool E5M2>
@@ -149,7 +159,7 @@ __device__ __forceinline__ float wave_max(float v) {
 template <typename T>
 __device__ __forceinline__ uint16_t silu_mul_bits(float gate, float up) {
   const float s = T::to_f32(T::from_f32(gate / (1.0f + __expf(-gate))));
-  return T::from_f32(s * up);
+  return from_f32_exact<T>(s * up);
 }
 
 }  // namespace aphro

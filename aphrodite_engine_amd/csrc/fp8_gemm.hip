@@ -35,6 +35,7 @@ struct Fp8GemmParams {
   int msteps_per_split;  // macro steps (128 k) per blockIdx.y
   int ksplit;
   int a_per_token, b_per_channel;
+  int force_partial;     // 1: leave the raw fp32 accumulators in `partial` even when ksplit == 1 (fused consumer)
 };
 
 template <typename T>
@@ -165,7 +166,7 @@ __global__ __launch_bounds__(FNW * 64) void fp8_gemm_kernel(Fp8GemmParams p) {
       v[t] = sum;
     }
     if (row < p.M) {
-      if (p.ksplit == 1) {
+      if (p.ksplit == 1 && !p.force_partial) {
         const float sa = p.a_scales ? p.a_scales[p.a_per_token ? row : 0] : 1.f;
         typename T::storage* cp = (typename T::storage*)p.c + (size_t)row * p.N + ncol;
 #pragma unroll
@@ -290,7 +291,7 @@ __global__ __launch_bounds__(F8W * 64, 2) void fp8_gemm_fast_kernel(Fp8GemmParam
       v[t] = sum;
     }
     if (row < p.M) {
-      if (p.ksplit == 1) {
+      if (p.ksplit == 1 && !p.force_partial) {
         const float sa = p.a_scales ? p.a_scales[p.a_per_token ? row : 0] : 1.f;
         typename T::storage* cp = (typename T::storage*)p.c + (size_t)row * p.N + ncol;
 #pragma unroll
@@ -388,7 +389,7 @@ static int run_fp8(Fp8GemmParams p, const Fp8Plan& pl, hipStream_t st) {
 #undef LFM
 #undef LF
       APHRO_LAUNCH_CHECK();
-      if (pl.ksplit > 1) {
+      if (pl.ksplit > 1 && !p.force_partial) {
         int64_t mn = (int64_t)p.M * p.N;
         hipLaunchKernelGGL((fp8_splitk_reduce_kernel<T>), dim3((unsigned)((mn + 255) / 256)), dim3(256), 0, st, p);
         APHRO_LAUNCH_CHECK();
@@ -408,7 +409,7 @@ static int run_fp8(Fp8GemmParams p, const Fp8Plan& pl, hipStream_t st) {
   }
 #undef L
   APHRO_LAUNCH_CHECK();
-  if (pl.ksplit > 1) {
+  if (pl.ksplit > 1 && !p.force_partial) {
     int64_t mn = (int64_t)p.M * p.N;
     hipLaunchKernelGGL((fp8_splitk_reduce_kernel<T>), dim3((unsigned)((mn + 255) / 256)), dim3(256), 0, st, p);
     APHRO_LAUNCH_CHECK();
@@ -424,7 +425,7 @@ static int fp8_gemm_common(Fp8GemmParams p, bool a8, int dtype, void* workspace,
   APHRO_CHECK(p.M <= 64, "fp8 gemm: M=%d exceeds 64 rows per call", p.M);
   if (p.M == 0) return APHRO_OK;
   Fp8Plan pl = make_fp8_plan(p.M, p.N, p.K, a8);
-  if (pl.ksplit > 1) {
+  if (pl.ksplit > 1 || p.force_partial) {
     size_t need = (size_t)pl.ksplit * p.M * p.N * sizeof(float);
     if (!workspace || workspace_bytes < need) {
       set_error("fp8 gemm: workspace %zu < %zu bytes", workspace_bytes, need);
@@ -457,8 +458,26 @@ extern "C" int aphro_scaled_mm_fp8(void* out, const void* a, const void* b, cons
   Fp8GemmParams p;
   p.a = a; p.w = (const uint8_t*)b; p.a_scales = a_scales; p.b_scales = b_scales; p.bias = bias; p.c = out;
   p.M = (int)M; p.N = (int)N; p.K = (int)K; p.lda = (int)K;
-  p.a_per_token = a_scale_per_token; p.b_per_channel = b_scale_per_channel;
+  p.a_per_token = a_scale_per_token; p.b_per_channel = b_scale_per_channel; p.force_partial = 0;
   return fp8_gemm_common(p, true, out_dtype, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+// W8A8 GEMM that leaves the raw fp32 accumulators as split-K slabs [ksplit][M][N] for a fused
+// consumer (aphro_fused_add_rms_norm_quant_fp8, the rotary/attention kernel) which sums them and
+// applies a_scale * (b_scale * acc) itself -- no reduce launch, no fp16 round trip.
+extern "C" int aphro_fp8_gemm_ksplit(int64_t M, int64_t N, int64_t K) {
+  if (M <= 0 || M > 64 || K % 128 != 0 || N % 16 != 0) return -1;
+  return make_fp8_plan(M, N, K, true).ksplit;
+}
+
+extern "C" int aphro_scaled_mm_fp8_slabs(const void* a, const void* b, float* partials, size_t partial_bytes,
+                                         int64_t M, int64_t N, int64_t K, void* stream) {
+  APHRO_CHECK(((uintptr_t)a % 16) == 0 && ((uintptr_t)b % 16) == 0, "scaled_mm: operands must be 16-byte aligned");
+  Fp8GemmParams p;
+  p.a = a; p.w = (const uint8_t*)b; p.a_scales = nullptr; p.b_scales = nullptr; p.bias = nullptr; p.c = nullptr;
+  p.M = (int)M; p.N = (int)N; p.K = (int)K; p.lda = (int)K;
+  p.a_per_token = 0; p.b_per_channel = 0; p.force_partial = 1;
+  return fp8_gemm_common(p, true, APHRO_F16, partials, partial_bytes, (hipStream_t)stream);
 }
 
 extern "C" int aphro_fp8_w8a16_gemm(void* out, const void* a, const void* w, const float* w_scales,
@@ -469,6 +488,6 @@ extern "C" int aphro_fp8_w8a16_gemm(void* out, const void* a, const void* w, con
   Fp8GemmParams p;
   p.a = a; p.w = (const uint8_t*)w; p.a_scales = nullptr; p.b_scales = w_scales; p.bias = bias; p.c = out;
   p.M = (int)M; p.N = (int)N; p.K = (int)K; p.lda = (int)lda;
-  p.a_per_token = 0; p.b_per_channel = w_scale_per_channel;
+  p.a_per_token = 0; p.b_per_channel = w_scale_per_channel; p.force_partial = 0;
   return fp8_gemm_common(p, false, dtype, workspace, workspace_bytes, (hipStream_t)stream);
 }

@@ -151,7 +151,7 @@ __global__ void moe_combine_kernel(typename T::storage* __restrict__ out, const 
       f32x4 y = *reinterpret_cast<const f32x4*>(p0);
       for (int s = 1; s < nslab; ++s) y += *reinterpret_cast<const f32x4*>(p0 + s * slab_stride);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[j] += T::to_f32(T::from_f32(y[j] * w));
+      for (int j = 0; j < 4; ++j) acc[j] += T::to_f32(from_f32_exact<T>(y[j] * w));
     }
     typename T::storage* o = out + (size_t)tok * N + c0;
 #pragma unroll

@@ -61,6 +61,9 @@ struct PAParams {
   const uint16_t* cos_sin;       // T [max_pos, hd]: cos | sin
   const int64_t* slot_mapping;   // [num_seqs]
   float k_scale_raw, v_scale_raw;
+  // optional dequantisation of the slabs (FP8 W8A8 qkv GEMM): value = row[seq] * (col[c] * sum)
+  const float* slab_row_scale;   // [num_seqs] or NULL
+  const float* slab_col_scale;   // [(Hq + 2 Hkv) * hd] or NULL
 };
 
 template <typename T>
@@ -103,7 +106,7 @@ __device__ __forceinline__ u32x2 fp8x4_to_T(uint32_t w) {
 // KV: 0 = cache holds T, 1 = e4m3, 2 = e5m2.   HD: head size.  BS: block size.
 // ROPE: the fused rotary + cache-write form (a separate instantiation: the plain kernel must not
 // pay for the extra live state -- measured +1.4 us per launch when it was a runtime branch)
-template <typename T, int KV, int HD, int BS, int NW, bool ROPE>
+template <typename T, int KV, int HD, int BS, int NW, int ROPE>
 __global__ __launch_bounds__(NW * 64) void paged_attention_kernel(PAParams p) {
   constexpr bool FP8 = KV != 0;
   constexpr bool E5M2 = KV == 2;
@@ -140,7 +143,8 @@ __global__ __launch_bounds__(NW * 64) void paged_attention_kernel(PAParams p) {
   const char* vc = (const char*)p.vc + (size_t)kvh * p.kv_head_stride * ESZ;
 
   // ---- fused rope + cache write of the new token (see PAParams) ---------------------------
-  constexpr bool fused_rope = ROPE && HD == 128;
+  constexpr bool fused_rope = ROPE != 0 && HD == 128;
+  constexpr bool scaled_slabs = ROPE == 2;  // slabs of a quantised projection: dequantised on the fly
   if constexpr (fused_rope) {
     if (threadIdx.x == 0) kv_flag = 0;
     __syncthreads();
@@ -153,6 +157,18 @@ __global__ __launch_bounds__(NW * 64) void paged_attention_kernel(PAParams p) {
     for (int k = 1; k < p.nslab; ++k) {
       a += *reinterpret_cast<const f32x4*>(p0 + k * p.slab_stride);
       b += *reinterpret_cast<const f32x4*>(p0 + k * p.slab_stride + 4);
+    }
+    if constexpr (scaled_slabs) {   // a_scale * (b_scale * acc), the scaled-mm epilogue order
+      const float rsc = p.slab_row_scale ? p.slab_row_scale[seq] : 1.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        // fp32 product first, rounding to T second (kept apart: see from_f32_exact, common.h)
+        float ta = rsc * (p.slab_col_scale[col + i] * a[i]);
+        float tb = rsc * (p.slab_col_scale[col + 4 + i] * b[i]);
+        asm("" : "+v"(ta), "+v"(tb));
+        a[i] = ta;
+        b[i] = tb;
+      }
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -408,6 +424,13 @@ __global__ __launch_bounds__(NW * 64) void paged_attention_kernel(PAParams p) {
               x += p0[k * p.slab_stride];
               y += p0[k * p.slab_stride + HD / 2];
             }
+            if constexpr (scaled_slabs) {
+              const float rsc = p.slab_row_scale ? p.slab_row_scale[seq] : 1.f;
+              const int col = (kvh * gqa + h) * HD + d;
+              x = rsc * (p.slab_col_scale[col] * x);
+              y = rsc * (p.slab_col_scale[col + HD / 2] * y);
+              asm("" : "+v"(x), "+v"(y));
+            }
             q_x[it] = x; q_y[it] = y;
             q_c[it] = cs_row[d];
             q_s[it] = cs_row[HD / 2 + d];
@@ -632,7 +655,7 @@ __global__ void convert_fp8_kernel(void* __restrict__ dst, const void* __restric
 }
 
 // ---------------------------------------------------------------------------
-template <typename T, int KV, int HD, int BS, bool ROPE = false>
+template <typename T, int KV, int HD, int BS, int ROPE = 0>
 static int launch_pa(const PAParams& p, int num_seqs, int parts, int nw, hipStream_t st) {
   dim3 grid((unsigned)p.num_kv_heads, (unsigned)num_seqs, (unsigned)parts);
   size_t lds = ((size_t)nw * 16 * 2 + (size_t)nw * p.nh_lds * HD) * sizeof(float);
@@ -654,8 +677,13 @@ template <typename T, int KV>
 static int dispatch_pa(const PAParams& p, int num_seqs, int parts, int nw, int head_size, int block_size,
                        hipStream_t st) {
   if (p.qkv_slabs != nullptr) {  // fused rotary + cache write: head_size 128 only (checked by the caller)
-    if (block_size == 16) return launch_pa<T, KV, 128, 16, true>(p, num_seqs, parts, nw, st);
-    if (block_size == 32) return launch_pa<T, KV, 128, 32, true>(p, num_seqs, parts, nw, st);
+    if (p.slab_col_scale != nullptr) {
+      if (block_size == 16) return launch_pa<T, KV, 128, 16, 2>(p, num_seqs, parts, nw, st);
+      if (block_size == 32) return launch_pa<T, KV, 128, 32, 2>(p, num_seqs, parts, nw, st);
+    } else {
+      if (block_size == 16) return launch_pa<T, KV, 128, 16, 1>(p, num_seqs, parts, nw, st);
+      if (block_size == 32) return launch_pa<T, KV, 128, 32, 1>(p, num_seqs, parts, nw, st);
+    }
     set_error("paged_attention: the fused rotary form supports block_size 16 / 32");
     return APHRO_ERR_INVALID;
   }
@@ -691,7 +719,8 @@ static int paged_attention_impl(void* out, void* out_packed, float* exp_sums, fl
                                      float v_scale, int partition_size, void* stream,
                                      const float* qkv_slabs = nullptr, int nslab = 0,
                                      const int64_t* positions = nullptr, const void* cos_sin = nullptr,
-                                     const int64_t* slot_mapping = nullptr) {
+                                     const int64_t* slot_mapping = nullptr, const float* slab_row_scale = nullptr,
+                                     const float* slab_col_scale = nullptr) {
   hipStream_t st = (hipStream_t)stream;
   APHRO_CHECK(dtype == APHRO_F16 || dtype == APHRO_BF16, "paged_attention: query dtype must be f16 or bf16");
   APHRO_CHECK(kv_dtype >= APHRO_KV_AUTO && kv_dtype <= APHRO_KV_FP8_E5M2, "Unsupported data type of kv cache: %d", kv_dtype);
@@ -705,6 +734,7 @@ static int paged_attention_impl(void* out, void* out_packed, float* exp_sums, fl
   p.slot_mapping = slot_mapping;
   p.slab_stride = (int64_t)num_seqs * (num_heads + 2 * num_kv_heads) * head_size;
   p.k_scale_raw = k_scale; p.v_scale_raw = v_scale;
+  p.slab_row_scale = slab_row_scale; p.slab_col_scale = slab_col_scale;
   if (qkv_slabs != nullptr) {
     APHRO_CHECK(partition_size == 0 && head_size == 128 && nslab >= 1 && cos_sin && slot_mapping &&
                     num_heads / num_kv_heads <= 16,
@@ -820,6 +850,28 @@ extern "C" int aphro_paged_attention_rope_packed(void* out, void* out_packed, co
                               max_num_blocks_per_seq, block_size, max_seq_len, alibi_slopes, 0, kv_block_stride,
                               kv_head_stride, dtype, kv_dtype, k_scale, v_scale, 0, stream, qkv_slabs, nslab,
                               positions, cos_sin_cache, slot_mapping);
+}
+
+// Same, for a quantised (FP8 W8A8) qkv projection: the slabs hold raw accumulators and are
+// dequantised on the fly, value = row_scale[seq] * (col_scale[c] * sum) (cutlass_scaled_mm epilogue
+// order), before the rounding to the activation dtype.
+extern "C" int aphro_paged_attention_rope_packed_scaled(void* out, void* out_packed, const float* qkv_slabs,
+                                                        int nslab, const float* slab_row_scale,
+                                                        const float* slab_col_scale, const int64_t* positions,
+                                                        const void* cos_sin_cache, const int64_t* slot_mapping,
+                                                        void* key_cache, void* value_cache, int num_seqs,
+                                                        int num_heads, int num_kv_heads, int head_size, float scale,
+                                                        const int32_t* block_tables, const int32_t* seq_lens,
+                                                        int max_num_blocks_per_seq, int block_size,
+                                                        int max_seq_len, const float* alibi_slopes,
+                                                        int64_t kv_block_stride, int64_t kv_head_stride, int dtype,
+                                                        int kv_dtype, float k_scale, float v_scale, void* stream) {
+  APHRO_CHECK(qkv_slabs != nullptr && slab_col_scale != nullptr, "paged_attention_rope_packed_scaled: NULL slabs / scales");
+  return paged_attention_impl(out, out_packed, nullptr, nullptr, nullptr, nullptr, key_cache, value_cache,
+                              num_seqs, num_heads, num_kv_heads, head_size, scale, block_tables, seq_lens,
+                              max_num_blocks_per_seq, block_size, max_seq_len, alibi_slopes, 0, kv_block_stride,
+                              kv_head_stride, dtype, kv_dtype, k_scale, v_scale, 0, stream, qkv_slabs, nslab,
+                              positions, cos_sin_cache, slot_mapping, slab_row_scale, slab_col_scale);
 }
 
 extern "C" int aphro_reshape_and_cache(const void* key, const void* value, void* key_cache,

@@ -24,7 +24,7 @@ from .distributed import (get_tensor_model_parallel_rank,
                           tensor_model_parallel_all_reduce)
 from .quantization.awq import AWQConfig
 from .quantization.base_config import QuantizationConfig
-from .quantization.fp8 import Fp8Config
+from .quantization.fp8 import CompressedTensorsW8A8Fp8Config, Fp8Config
 from .quantization.gptq import GPTQConfig
 
 
@@ -222,6 +222,74 @@ class LlamaDecoderLayer(nn.Module):
                                               partials=True)
         return None, down_slabs
 
+    # -- FP8 W8A8 (per-token dynamic activations) decode fast path -------------------------------
+    def fused_decode_fp8_ok(self, m: int) -> bool:
+        """9 launches per layer instead of 15+: every activation quantisation rides in the kernel
+        that produces the activations, the GEMMs hand their raw fp32 split-K slabs to the consumer
+        (which dequantises with the per-token x per-channel scales), rotary + cache write run
+        inside the attention kernel."""
+        from .quantization.fp8 import CompressedTensorsW8A8Fp8Method
+        if m > 64 or self.head_dim != 128 or not self.fuse_rope_attention:
+            return False
+        for lin in (self.qkv_proj, self.o_proj, self.gate_up_proj, self.down_proj):
+            if not isinstance(lin.quant_method, CompressedTensorsW8A8Fp8Method) or lin.input_scale is not None:
+                return False
+            if ops.fp8_gemm_ksplit(m, lin.out_features, lin.in_features) <= 0:
+                return False
+        return True
+
+    def _channel_scale(self, lin) -> torch.Tensor:
+        ws = lin.weight_scale
+        if ws.numel() == lin.out_features:
+            return ws
+        cached = getattr(lin, "_weight_scale_channel", None)
+        if cached is None:
+            cached = ws.reshape(1).expand(lin.out_features).contiguous()
+            lin._weight_scale_channel = cached
+        return cached
+
+    def forward_decode_fused_fp8(self, positions, x, prev, residual, first, kv_cache, attn_metadata, cos_sin,
+                                 cos_sin_tok=None):
+        """x: row-major input or None; prev = (slabs, a_scales, b_scales) of the previous layer's
+        down_proj (TP == 1).  Returns (x, prev) of this layer's down_proj in the same convention."""
+        eps = self.cfg.rms_norm_eps
+        m = positions.shape[0]
+        if prev is None:
+            qx, sx, _ = ops.fused_add_rms_norm_quant_fp8(x, None, None, None, residual, not first,
+                                                         self.input_layernorm, eps)
+        else:
+            qx, sx, _ = ops.fused_add_rms_norm_quant_fp8(None, prev[0], prev[1], prev[2], residual, True,
+                                                         self.input_layernorm, eps)
+        qkv_slabs = ops.scaled_mm_fp8_slabs(qx, self.qkv_proj.weight)
+        from .attention.paged_attn import PagedAttention
+        key_cache, value_cache = PagedAttention.split_kv_cache(kv_cache, self.num_kv_heads, self.head_dim)
+        attn_out = ops.paged_attention_rope_scaled(
+            qkv_slabs, sx, self._channel_scale(self.qkv_proj),
+            None if cos_sin_tok is not None else positions,
+            cos_sin_tok if cos_sin_tok is not None else cos_sin, attn_metadata.slot_mapping,
+            key_cache, value_cache, self.num_heads, self.num_kv_heads, self.attn.scale,
+            attn_metadata.block_tables, attn_metadata.seq_lens_tensor, value_cache.shape[3],
+            attn_metadata.max_decode_seq_len, None, self.attn.kv_cache_dtype, self.k_scale, self.v_scale)
+        qa, sa = ops.scaled_fp8_quant(attn_out.view(m, self.q_size), None, use_per_token_if_dynamic=True)
+        if self.tp > 1:
+            o = ops.cutlass_scaled_mm(qa, self.o_proj.weight, out_dtype=attn_out.dtype, scale_a=sa,
+                                      scale_b=self.o_proj.weight_scale)
+            o = tensor_model_parallel_all_reduce(o)
+            qh, sh, _ = ops.fused_add_rms_norm_quant_fp8(o, None, None, None, residual, True,
+                                                         self.post_attention_layernorm, eps)
+        else:
+            o_slabs = ops.scaled_mm_fp8_slabs(qa, self.o_proj.weight)
+            qh, sh, _ = ops.fused_add_rms_norm_quant_fp8(None, o_slabs, sa, self.o_proj.weight_scale, residual,
+                                                         True, self.post_attention_layernorm, eps)
+        gate_up = ops.cutlass_scaled_mm(qh, self.gate_up_proj.weight, out_dtype=attn_out.dtype, scale_a=sh,
+                                        scale_b=self.gate_up_proj.weight_scale)
+        qd, sd, _ = ops.silu_and_mul_quant_fp8(gate_up)
+        if self.tp > 1:
+            d = ops.cutlass_scaled_mm(qd, self.down_proj.weight, out_dtype=attn_out.dtype, scale_a=sd,
+                                      scale_b=self.down_proj.weight_scale)
+            return tensor_model_parallel_all_reduce(d), None
+        return None, (ops.scaled_mm_fp8_slabs(qd, self.down_proj.weight), sd, self.down_proj.weight_scale)
+
     def forward(self, positions, hidden, residual, kv_cache, attn_metadata, cos_sin):
         eps = self.cfg.rms_norm_eps
         if residual is None:
@@ -328,6 +396,22 @@ class LlamaForCausalLM(nn.Module):
             _, out = ops.fused_add_rms_norm_pack(x if slabs is None else None, slabs, residual, True, self.norm,
                                                  self.cfg.rms_norm_eps, pack=False, want_out=True)
             return out
+        if (self.use_fused_decode and attn_metadata.num_prefill_tokens == 0
+                and attn_metadata.num_decode_tokens > 0
+                and all(l.fused_decode_fp8_ok(hidden.shape[0]) for l in self.layers)):
+            residual = torch.empty_like(hidden)
+            x, prev = hidden, None
+            cos_sin_tok = self.cos_sin.index_select(0, positions)
+            for i, layer in enumerate(self.layers):
+                x, prev = layer.forward_decode_fused_fp8(positions, x, prev, residual, i == 0, kv_caches[i],
+                                                         attn_metadata, self.cos_sin, cos_sin_tok)
+            if prev is None:
+                _, _, out = ops.fused_add_rms_norm_quant_fp8(x, None, None, None, residual, True, self.norm,
+                                                             self.cfg.rms_norm_eps, want_out=True)
+            else:
+                _, _, out = ops.fused_add_rms_norm_quant_fp8(None, prev[0], prev[1], prev[2], residual, True,
+                                                             self.norm, self.cfg.rms_norm_eps, want_out=True)
+            return out
         residual = None
         for i, layer in enumerate(self.layers):
             hidden, residual = layer(positions, hidden, residual, kv_caches[i],
@@ -372,6 +456,19 @@ def _init_linear(lin: QuantLinear, g, device):
         scale = (amax / 448.0).float()
         lin.weight.copy_((w / scale).clamp(-448, 448).to(torch.float8_e4m3fn))
         lin.weight_scale.fill_(scale.item())
+        if getattr(lin, "input_scale", None) is not None:
+            lin.input_scale.fill_(8.0 / 448.0)
+        return
+    if isinstance(qc, CompressedTensorsW8A8Fp8Config):
+        w = torch.randn(lin.weight.shape, generator=g, device=device) / math.sqrt(k)
+        if qc.strategy == "channel":
+            scale = (w.abs().amax(dim=1, keepdim=True) / 448.0).float()
+            lin.weight.copy_((w / scale).clamp(-448, 448).to(torch.float8_e4m3fn))
+            lin.weight_scale.copy_(scale)
+        else:
+            scale = (w.abs().max() / 448.0).float()
+            lin.weight.copy_((w / scale).clamp(-448, 448).to(torch.float8_e4m3fn))
+            lin.weight_scale.fill_(scale.item())
         if getattr(lin, "input_scale", None) is not None:
             lin.input_scale.fill_(8.0 / 448.0)
         return

@@ -5,13 +5,14 @@ from typing import Dict, Type
 
 from .awq import AWQConfig
 from .base_config import QuantizationConfig
-from .fp8 import Fp8Config
+from .fp8 import CompressedTensorsW8A8Fp8Config, Fp8Config
 from .gptq import GPTQConfig
 
 QUANTIZATION_METHODS: Dict[str, Type[QuantizationConfig]] = {
     "awq": AWQConfig,
     "gptq": GPTQConfig,
     "fp8": Fp8Config,
+    "compressed-tensors": CompressedTensorsW8A8Fp8Config,   # its W8A8-FP8 scheme only
 }
 
 

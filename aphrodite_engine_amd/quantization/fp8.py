@@ -165,3 +165,95 @@ class Fp8LinearMethod(LinearMethodBase):
                                 input_scale=layer.input_scale, bias=bias,
                                 cutlass_fp8_supported=True,
                                 use_per_token_if_dynamic=False)
+
+
+# --------------------------------------------------------------------------------------------------
+# llm-compressor / compressed-tensors "float-quantized" W8A8 checkpoints (BASELINE configs[2]):
+# per-channel (or per-tensor) weight scales, dynamic PER-TOKEN activation scales.  Scheme restated
+# from quantization/compressed_tensors/schemes/compressed_tensors_w8a8_fp8.py:19-148 as a
+# LinearMethodBase (the reference wraps schemes in CompressedTensorsLinearMethod; the tensors,
+# their names and the forward are the scheme's).  On gfx950 the checkpoint's OCP e4m3fn bytes are
+# used as stored (no fnuz normalisation, :38-43, :52-60).
+# --------------------------------------------------------------------------------------------------
+class CompressedTensorsW8A8Fp8Config(QuantizationConfig):
+    def __init__(self, strategy: str = "channel", is_static_input_scheme: bool = False) -> None:
+        if strategy not in ("channel", "tensor"):
+            raise ValueError(f"Unknown quantization strategy {strategy}")
+        self.strategy = strategy
+        self.is_static_input_scheme = is_static_input_scheme
+
+    def get_name(self) -> str:
+        return "compressed-tensors"
+
+    def get_supported_act_dtypes(self) -> List[torch.dtype]:
+        return [torch.float16, torch.bfloat16]
+
+    @classmethod
+    def get_min_capability(cls) -> int:
+        return 89
+
+    @staticmethod
+    def get_config_filenames() -> List[str]:
+        return []
+
+    @classmethod
+    def from_config(cls, config: Dict[str, Any]) -> "CompressedTensorsW8A8Fp8Config":
+        groups = config.get("config_groups", {})
+        first = next(iter(groups.values()), {})
+        w = first.get("weights", {}) or {}
+        a = first.get("input_activations", {}) or {}
+        return cls(strategy=w.get("strategy", "channel"), is_static_input_scheme=not a.get("dynamic", True))
+
+    def get_quant_method(self, layer: nn.Module, prefix: str) -> Optional["CompressedTensorsW8A8Fp8Method"]:
+        return CompressedTensorsW8A8Fp8Method(self)
+
+    def get_scaled_act_names(self) -> List[str]:
+        return []
+
+
+class CompressedTensorsW8A8Fp8Method(LinearMethodBase):
+    def __init__(self, quant_config: CompressedTensorsW8A8Fp8Config):
+        self.quant_config = quant_config
+
+    def create_weights(self, layer: nn.Module, input_size_per_partition: int,
+                       output_partition_sizes: List[int], input_size: int, output_size: int,
+                       params_dtype: torch.dtype, **extra_weight_attrs):
+        del input_size, output_size, params_dtype
+        n = sum(output_partition_sizes)
+        loader = extra_weight_attrs.get("weight_loader")
+        layer.logical_widths = output_partition_sizes
+        layer.register_parameter("weight", _param(
+            torch.empty(n, input_size_per_partition, dtype=torch.float8_e4m3fn),
+            input_dim=1, output_dim=0, weight_loader=loader))
+        if self.quant_config.strategy == "channel":
+            scale = _param(torch.empty((n, 1), dtype=torch.float32), output_dim=0, weight_loader=loader)
+        else:
+            scale = _param(torch.empty(len(output_partition_sizes), dtype=torch.float32), weight_loader=loader)
+        scale[:] = torch.finfo(torch.float32).min
+        layer.register_parameter("weight_scale", scale)
+        if self.quant_config.is_static_input_scheme:
+            iscale = _param(torch.empty(len(output_partition_sizes), dtype=torch.float32), weight_loader=loader)
+            iscale[:] = torch.finfo(torch.float32).min
+            layer.register_parameter("input_scale", iscale)
+        else:
+            layer.register_parameter("input_scale", None)
+
+    def process_weights_after_loading(self, layer: nn.Module) -> None:
+        if self.quant_config.strategy == "tensor":
+            scale, weight = requantize_with_max_scale(layer.weight.data, layer.weight_scale.data,
+                                                      layer.logical_widths)
+            scale = scale.reshape(1).float()
+        else:
+            weight, scale = layer.weight.data, layer.weight_scale.data.reshape(-1).float()
+        layer.weight = nn.Parameter(weight.t(), requires_grad=False)
+        layer.weight_scale = nn.Parameter(scale.contiguous(), requires_grad=False)
+        if self.quant_config.is_static_input_scheme:
+            layer.input_scale = nn.Parameter(layer.input_scale.max().reshape(1), requires_grad=False)
+        else:
+            layer.input_scale = None
+
+    def apply(self, layer: nn.Module, x: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+        return apply_fp8_linear(input=x, weight=layer.weight, weight_scale=layer.weight_scale,
+                                input_scale=layer.input_scale, bias=bias, cutlass_fp8_supported=True,
+                                use_per_token_if_dynamic=True)
+

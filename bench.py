@@ -42,7 +42,8 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=8)
-    ap.add_argument("--quant", default="gptq", choices=["gptq", "fp8", "awq"])
+    ap.add_argument("--quant", default="gptq", choices=["gptq", "fp8", "awq", "fp8ct"],
+                    help="fp8: per-tensor W8A8 (Fp8Config); fp8ct: compressed-tensors W8A8, per-token x per-channel")
     ap.add_argument("--kv-cache-dtype", default="auto", choices=["auto", "fp8", "fp8_e5m2"])
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--ctx", type=int, default=1024, help="context length at the first timed step")
@@ -65,6 +66,9 @@ def build(args, device):
         qc = GPTQConfig(4, 128, False)
     elif args.quant == "awq":
         qc = AWQConfig(4, 128, True, prepack=True)
+    elif args.quant == "fp8ct":
+        from aphrodite_engine_amd.quantization.fp8 import CompressedTensorsW8A8Fp8Config
+        qc = CompressedTensorsW8A8Fp8Config(strategy="channel", is_static_input_scheme=False)
     else:
         qc = Fp8Config(is_checkpoint_fp8_serialized=True, activation_scheme="dynamic")
     dtype = torch.float16
@@ -174,7 +178,7 @@ def roofline_section(model, loop, args):
             def run_lin(name=name, xin=xin):
                 for layer in layers:
                     getattr(layer, name)(xin)
-            kname = ("wna16_gemm_kernel" if args.quant != "fp8" else "fp8_gemm_kernel") + " (+pack/splitk_reduce)"
+            kname = ("fp8_gemm_kernel" if args.quant.startswith("fp8") else "wna16_gemm_kernel") + " (+pack/splitk_reduce)"
         t = measure_kernel(run_lin, len(layers))
         out[name] = dict(kernel=kname, shape=[bs, lin0.in_features, lin0.out_features],
                          bytes=gemm_bytes(lin0, bs), seconds=t)
@@ -376,10 +380,11 @@ def main():
         "scaling": "weak" if tp == 1 else "strong",
         "vs_baseline": None,
         "dtype": {"gptq": "int4 weights x f16 (fp32 accumulate)", "awq": "int4 weights x f16 (fp32 accumulate)",
-                  "fp8": "fp8-e4m3 x fp8-e4m3 (fp32 accumulate)"}[args.quant],
+                  "fp8": "fp8-e4m3 x fp8-e4m3 (fp32 accumulate)",
+                  "fp8ct": "fp8-e4m3 x fp8-e4m3 (fp32 accumulate)"}[args.quant],
         "data": "synthetic (random-init weights in the real GPTQ/FP8 formats, random token ids, random-permutation block tables)",
         "config": {
-            "workload": f"Llama-3-8B {args.quant.upper()} {'4-bit g128' if args.quant != 'fp8' else 'W8A8'}, greedy decode, "
+            "workload": f"Llama-3-8B {args.quant.upper()} {'W8A8' if args.quant.startswith('fp8') else '4-bit g128'}, greedy decode, "
                         f"bs={args.batch}/GPU, context {args.ctx}->{ctx_end}, kv_cache={args.kv_cache_dtype}, "
                         f"block_size=16, HIP-graph={'off' if args.no_graph else 'on'}",
             "global_batch": args.batch * replicas,

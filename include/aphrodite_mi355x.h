@@ -384,6 +384,51 @@ int aphro_context_attention(void* out, const void* q, const void* k, const void*
                             int kv_dtype, void* stream);
 
 /* ------------------------------------------------------------------------
+ * FP8 (W8A8, per-token dynamic activation scale) decode fast path -- configs[2],
+ * compressed_tensors_w8a8_fp8.py:139-148.  Bit-identical to the op sequences they replace.
+ * ---------------------------------------------------------------------- */
+
+/* W8A8 GEMM leaving raw fp32 accumulators as split-K slabs [ksplit][M][N]
+ * (ksplit = aphro_fp8_gemm_ksplit) for a fused consumer that applies
+ * a_scale * (b_scale * acc) -- cutlass_scaled_mm without its epilogue. */
+int aphro_fp8_gemm_ksplit(int64_t M, int64_t N, int64_t K);
+int aphro_scaled_mm_fp8_slabs(const void* a, const void* b, float* partials,
+                              size_t partial_bytes, int64_t M, int64_t N, int64_t K,
+                              void* stream);
+
+/* [slab reduce + dequant] + fused_add_rms_norm (layernorm_kernels.cu:200-240) +
+ * dynamic_per_token_scaled_fp8_quant (fp8/common.cu:201-256).  input (T) XOR slabs
+ * (+ slab scales: a per token or [1], b per channel or [1]); residual updated in place
+ * (has_residual == 0: residual = x); q_out fp8 [tokens, hidden], scale_out fp32 [tokens];
+ * out (optional) = the normalised activations in T. */
+int aphro_fused_add_rms_norm_quant_fp8(const void* input, const float* slabs, int nslab,
+                                       const float* slab_a_scales, const float* slab_b_scales,
+                                       int a_scale_per_token, int b_scale_per_channel,
+                                       void* residual, int has_residual, const void* weight,
+                                       float eps, void* q_out, float* scale_out, void* out,
+                                       int64_t tokens, int hidden, int dtype, void* stream);
+
+/* silu_and_mul (activation_kernels.cu:12-75) + dynamic_per_token_scaled_fp8_quant over
+ * input T [tokens, 2d]; out (optional) = the activations in T. */
+int aphro_silu_and_mul_quant_fp8(const void* input, void* q_out, float* scale_out, void* out,
+                                 int64_t tokens, int d, int dtype, void* stream);
+
+/* aphro_paged_attention_rope_packed over the slabs of a QUANTISED qkv projection:
+ * value = slab_row_scale[seq] * (slab_col_scale[c] * sum of slabs) before the rounding. */
+int aphro_paged_attention_rope_packed_scaled(void* out, void* out_packed, const float* qkv_slabs,
+                                             int nslab, const float* slab_row_scale,
+                                             const float* slab_col_scale, const int64_t* positions,
+                                             const void* cos_sin_cache, const int64_t* slot_mapping,
+                                             void* key_cache, void* value_cache, int num_seqs,
+                                             int num_heads, int num_kv_heads, int head_size,
+                                             float scale, const int32_t* block_tables,
+                                             const int32_t* seq_lens, int max_num_blocks_per_seq,
+                                             int block_size, int max_seq_len,
+                                             const float* alibi_slopes, int64_t kv_block_stride,
+                                             int64_t kv_head_stride, int dtype, int kv_dtype,
+                                             float k_scale, float v_scale, void* stream);
+
+/* ------------------------------------------------------------------------
  * Mixture of experts: routing, dispatch and the grouped W4A16 GEMM
  * ---------------------------------------------------------------------- */
 

@@ -1146,6 +1146,115 @@ def test_fused_decode_model_matches_unfused(ops):
 
 
 # ---------------------------------------------------------------------------
+# FP8 W8A8 (per-token dynamic) decode fast path: every fused kernel equals the op sequence it replaces
+# ---------------------------------------------------------------------------
+def _fp8_operands(rng, M, K, N):
+    a = t((rng.standard_normal((M, K)) * 2).astype(np.float32)).to(torch.float8_e4m3fn)
+    w = t((rng.standard_normal((N, K)) * 2).astype(np.float32)).to(torch.float8_e4m3fn)
+    sa = t((rng.random((M, 1)) * 0.02 + 0.002).astype(np.float32))
+    sb = t((rng.random(N) * 0.02 + 0.002).astype(np.float32))
+    return a, w, sa, sb
+
+
+@pytest.mark.parametrize("M", [1, 7, 32, 64])
+@pytest.mark.parametrize("K,N", [(512, 512), (4096, 6144), (14336, 4096), (1024, 1024)])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_scaled_mm_fp8_slabs(ops, M, K, N, dtype):
+    rng = np.random.default_rng(M + K + N)
+    a, w, sa, sb = _fp8_operands(rng, M, K, N)
+    ref = ops.cutlass_scaled_mm(a, w.t(), sa, sb, dtype)
+    slabs = ops.scaled_mm_fp8_slabs(a, w.t())
+    assert slabs.shape[0] == ops.fp8_gemm_ksplit(M, N, K)
+    acc = slabs[0].clone()
+    for k in range(1, slabs.shape[0]):
+        acc += slabs[k]
+    got = (sa * (sb.view(1, -1) * acc)).to(dtype)
+    assert torch.equal(got, ref)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("tokens,hidden", [(1, 512), (32, 4096), (5, 8192), (3, 11008), (64, 1024)])
+@pytest.mark.parametrize("mode", ["input", "input_first", "slabs", "slabs_tensor_scales"])
+def test_fused_add_rms_norm_quant_fp8(ops, dtype, tokens, hidden, mode):
+    rng = np.random.default_rng(tokens + hidden)
+    w = t(rng.standard_normal(hidden).astype(np.float32) * 0.5 + 1.0, dtype)
+    res0 = t(rng.standard_normal((tokens, hidden)).astype(np.float32), dtype)
+    if mode.startswith("slabs"):
+        K = 512
+        a, wq, sa, sb = _fp8_operands(rng, tokens, K, hidden)
+        if mode == "slabs_tensor_scales":
+            sa, sb = sa[:1].reshape(1).contiguous(), sb[:1].contiguous()
+        x = ops.cutlass_scaled_mm(a, wq.t(), sa, sb, dtype)
+        slabs = ops.scaled_mm_fp8_slabs(a, wq.t())
+        if slabs.shape[0] == 1:       # exercise the reduction as well
+            slabs = torch.cat([slabs * 0.25, slabs * 0.5, slabs * 0.25])
+            acc = (slabs[0] + slabs[1]) + slabs[2]
+            x = (sa * (sb.view(1, -1) * acc)).to(dtype)
+    else:
+        x = t(rng.standard_normal((tokens, hidden)).astype(np.float32), dtype)
+    # reference: the op sequence of the unfused path
+    ref_x, ref_res = x.clone(), res0.clone()
+    if mode == "input_first":
+        ref_res = x.clone()
+        ref_y = torch.empty_like(x)
+        ops.rms_norm(ref_y, x, w, 1e-5)
+    else:
+        ops.fused_add_rms_norm(ref_x, ref_res, w, 1e-5)
+        ref_y = ref_x
+    ref_q, ref_s = ops.scaled_fp8_quant(ref_y, None, use_per_token_if_dynamic=True)
+    res = res0.clone()
+    if mode.startswith("slabs"):
+        q, s, out = ops.fused_add_rms_norm_quant_fp8(None, slabs, sa, sb, res, True, w, 1e-5, want_out=True)
+    else:
+        q, s, out = ops.fused_add_rms_norm_quant_fp8(x, None, None, None, res, mode != "input_first", w, 1e-5,
+                                                     want_out=True)
+    assert torch.equal(res, ref_res)
+    assert torch.equal(out, ref_y)
+    assert torch.equal(s, ref_s)
+    assert torch.equal(q.view(torch.uint8), ref_q.view(torch.uint8))
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("tokens,d", [(1, 512), (32, 14336), (7, 28672), (64, 1024), (3, 8)])
+def test_silu_and_mul_quant_fp8(ops, dtype, tokens, d):
+    rng = np.random.default_rng(tokens + d)
+    x = t(rng.standard_normal((tokens, 2 * d)).astype(np.float32) * 2, dtype)
+    act = torch.empty(tokens, d, dtype=dtype, device=DEV)
+    ops.silu_and_mul(act, x)
+    ref_q, ref_s = ops.scaled_fp8_quant(act, None, use_per_token_if_dynamic=True)
+    q, s, out = ops.silu_and_mul_quant_fp8(x, want_out=True)
+    assert torch.equal(out, act)
+    assert torch.equal(s, ref_s)
+    assert torch.equal(q.view(torch.uint8), ref_q.view(torch.uint8))
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("strategy", ["channel", "tensor"])
+@pytest.mark.parametrize("kv_cache_dtype", ["auto", "fp8"])
+def test_fused_decode_fp8_model_matches_unfused(ops, dtype, strategy, kv_cache_dtype):
+    """Whole decode step of the compressed-tensors W8A8-FP8 model: the fused path reproduces the
+    op-by-op path bit for bit (hidden states and every layer's KV-cache writes)."""
+    from aphrodite_engine_amd import model as M
+    from aphrodite_engine_amd.quantization.fp8 import CompressedTensorsW8A8Fp8Config
+    with torch.no_grad():
+        m = M.LlamaForCausalLM(M.TINY, CompressedTensorsW8A8Fp8Config(strategy), dtype, kv_cache_dtype)
+        m.init_synthetic(torch.device(DEV))
+        meta, pos, nblocks = M.make_decode_metadata(5, [3, 17, 64, 200, 129], 16, DEV)
+        ids = torch.randint(0, M.TINY.vocab_size, (5, ), device=DEV)
+        outs, caches_all = [], []
+        for fused in (False, True):
+            caches = M.make_kv_caches(M.TINY, nblocks, 16, dtype, kv_cache_dtype, DEV, seed=3)
+            m.use_fused_decode = fused
+            assert all(l.fused_decode_fp8_ok(5) for l in m.layers)
+            outs.append(m(ids, pos, caches, meta))
+            caches_all.append(caches)
+        assert torch.isfinite(outs[0].float()).all()
+        assert torch.equal(outs[0], outs[1])
+        for a, b in zip(caches_all[0], caches_all[1]):
+            assert torch.equal(a.view(torch.uint8), b.view(torch.uint8))
+
+
+# ---------------------------------------------------------------------------
 # mixture of experts (SURVEY 8f row 2)
 # ---------------------------------------------------------------------------
 @pytest.mark.parametrize("T,E,topk", [(1, 8, 2), (33, 8, 2), (64, 64, 6), (5, 60, 4), (17, 256, 8)])
