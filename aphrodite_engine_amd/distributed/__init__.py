@@ -7,6 +7,7 @@ One process per GPU; the TP group is a torch.distributed group whose "nccl"
 backend IS RCCL over xGMI on ROCm ("gloo" in the CPU tests).  The all-reduce
 is issued on the current stream so it is captured into the decode HIP graph
 like the reference's pynccl path (pynccl.py:102-118)."""
+import contextlib
 from typing import Optional
 
 import torch
@@ -40,6 +41,19 @@ def init_tensor_parallel(tp_size: int, backend: Optional[str] = None) -> None:
 def destroy_tensor_parallel() -> None:
     global _TP_GROUP, _TP_RANK, _TP_SIZE
     _TP_GROUP, _TP_RANK, _TP_SIZE = None, 0, 1
+
+
+@contextlib.contextmanager
+def simulated_tensor_parallel(rank: int, size: int):
+    """Pretend to be TP rank ``rank`` of ``size`` with no process group: for building one rank's
+    parameter shards offline (checkpoint resharding, loader tests).  Collectives are not available."""
+    global _TP_GROUP, _TP_RANK, _TP_SIZE
+    saved = (_TP_GROUP, _TP_RANK, _TP_SIZE)
+    _TP_GROUP, _TP_RANK, _TP_SIZE = None, rank, size
+    try:
+        yield
+    finally:
+        _TP_GROUP, _TP_RANK, _TP_SIZE = saved
 
 
 def get_tensor_model_parallel_world_size() -> int:

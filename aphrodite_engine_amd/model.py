@@ -60,21 +60,28 @@ class QuantLinear(nn.Module):
 
     def __init__(self, in_features: int, out_partition_sizes: List[int],
                  quant_config: Optional[QuantizationConfig], dtype: torch.dtype,
-                 full_in_features: Optional[int] = None, prefix: str = ""):
+                 full_in_features: Optional[int] = None, prefix: str = "", plan=None,
+                 full_out_features: Optional[int] = None):
         super().__init__()
+        from .loader import make_weight_loader, merged_plan
         self.in_features = in_features
         self.out_features = sum(out_partition_sizes)
         self.quant_config = quant_config
-        if quant_config is None:
-            self.quant_method = None
-            self.weight = nn.Parameter(
+        # how checkpoint tensors are cut into this rank's parameters (loader.py)
+        self.plan = plan if plan is not None else merged_plan(
+            [n * get_tensor_model_parallel_world_size() for n in out_partition_sizes])
+        self.weight_loader = make_weight_loader(self.plan)
+        self.quant_method = None if quant_config is None else quant_config.get_quant_method(self, prefix)
+        if self.quant_method is None:   # unquantised checkpoint, or a layer the config ignores
+            from .quantization.base_config import _param
+            self.register_parameter("weight", _param(
                 torch.empty(self.out_features, in_features, dtype=dtype),
-                requires_grad=False)
+                input_dim=1, output_dim=0, weight_loader=self.weight_loader))
         else:
-            self.quant_method = quant_config.get_quant_method(self, prefix)
             self.quant_method.create_weights(
                 self, in_features, out_partition_sizes,
-                full_in_features or in_features, self.out_features, dtype)
+                full_in_features or in_features, full_out_features or self.out_features, dtype,
+                weight_loader=self.weight_loader)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if self.quant_method is None:
@@ -90,6 +97,10 @@ class QuantLinear(nn.Module):
                 return self.qweight, self.qzeros, self.scales, 1
         elif isinstance(self.quant_config, AWQConfig) and getattr(self, "awq_prepacked", False):
             return self.qweight, self.qzeros, self.scales, 0
+        kernel = getattr(self, "kernel", None)   # compressed-tensors pack-quantized via the MPLinearKernel seam
+        if kernel is not None and type(kernel).__name__ == "CDNA4LinearKernel" \
+                and getattr(self, "_cdna4_perm", None) is None and hasattr(self, "_cdna4_zp"):
+            return self.weight_packed, self._cdna4_zp, self.weight_scale, 0
         return None
 
 
@@ -103,7 +114,7 @@ def _rope_cache(head_dim: int, max_pos: int, theta: float, dtype, device):
 
 
 class LlamaDecoderLayer(nn.Module):
-    def __init__(self, cfg: LlamaConfig, quant_config, dtype, kv_cache_dtype: str):
+    def __init__(self, cfg: LlamaConfig, quant_config, dtype, kv_cache_dtype: str, layer_idx: int = 0):
         super().__init__()
         tp = get_tensor_model_parallel_world_size()
         self.cfg = cfg
@@ -116,14 +127,23 @@ class LlamaDecoderLayer(nn.Module):
         self.input_layernorm = nn.Parameter(torch.ones(h, dtype=dtype), requires_grad=False)
         self.post_attention_layernorm = nn.Parameter(torch.ones(h, dtype=dtype),
                                                      requires_grad=False)
+        from .loader import merged_plan, qkv_plan, row_plan
+        pfx = f"model.layers.{layer_idx}."
         self.qkv_proj = QuantLinear(h, [self.q_size, self.kv_size, self.kv_size],
-                                    quant_config, dtype)
+                                    quant_config, dtype, prefix=pfx + "self_attn.qkv_proj",
+                                    plan=qkv_plan(cfg.num_attention_heads, cfg.num_key_value_heads, self.head_dim),
+                                    full_out_features=(cfg.num_attention_heads + 2 * cfg.num_key_value_heads)
+                                    * self.head_dim)
         self.o_proj = QuantLinear(self.q_size, [h], quant_config, dtype,
-                                  full_in_features=cfg.num_attention_heads * self.head_dim)
+                                  full_in_features=cfg.num_attention_heads * self.head_dim,
+                                  prefix=pfx + "self_attn.o_proj", plan=row_plan())
         inter = cfg.intermediate_size // tp
-        self.gate_up_proj = QuantLinear(h, [inter, inter], quant_config, dtype)
+        self.gate_up_proj = QuantLinear(h, [inter, inter], quant_config, dtype, prefix=pfx + "mlp.gate_up_proj",
+                                        plan=merged_plan([cfg.intermediate_size] * 2),
+                                        full_out_features=2 * cfg.intermediate_size)
         self.down_proj = QuantLinear(inter, [h], quant_config, dtype,
-                                     full_in_features=cfg.intermediate_size)
+                                     full_in_features=cfg.intermediate_size, prefix=pfx + "mlp.down_proj",
+                                     plan=row_plan())
         self.attn = MI355XAttentionImpl(self.num_heads, self.head_dim,
                                         self.head_dim ** -0.5, self.num_kv_heads,
                                         kv_cache_dtype=kv_cache_dtype)
@@ -330,8 +350,8 @@ class LlamaForCausalLM(nn.Module):
         self.embed_tokens = nn.Parameter(
             torch.empty(cfg.vocab_size, cfg.hidden_size, dtype=dtype), requires_grad=False)
         self.layers = nn.ModuleList([
-            LlamaDecoderLayer(cfg, quant_config, dtype, kv_cache_dtype)
-            for _ in range(cfg.num_hidden_layers)])
+            LlamaDecoderLayer(cfg, quant_config, dtype, kv_cache_dtype, i)
+            for i in range(cfg.num_hidden_layers)])
         self.norm = nn.Parameter(torch.ones(cfg.hidden_size, dtype=dtype),
                                  requires_grad=False)
         tp = get_tensor_model_parallel_world_size()
@@ -364,6 +384,12 @@ class LlamaForCausalLM(nn.Module):
                 _init_linear(lin, g, device)
         self.cos_sin = _rope_cache(cfg.head_dim, cfg.max_position_embeddings,
                                    cfg.rope_theta, self.dtype, device)
+        self.process_weights_after_loading()
+        return self
+
+    def process_weights_after_loading(self):
+        """Every quant method's post-load hook (repack / requantise), once the parameters are on
+        the device (model_loader/loader.py:396-408)."""
         for layer in self.layers:
             for lin in (layer.qkv_proj, layer.o_proj, layer.gate_up_proj, layer.down_proj):
                 if lin.quant_method is not None:

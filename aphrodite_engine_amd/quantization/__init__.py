@@ -5,14 +5,15 @@ from typing import Dict, Type
 
 from .awq import AWQConfig
 from .base_config import QuantizationConfig
-from .fp8 import CompressedTensorsW8A8Fp8Config, Fp8Config
+from .compressed_tensors import CompressedTensorsConfig
+from .fp8 import Fp8Config
 from .gptq import GPTQConfig
 
 QUANTIZATION_METHODS: Dict[str, Type[QuantizationConfig]] = {
     "awq": AWQConfig,
     "gptq": GPTQConfig,
     "fp8": Fp8Config,
-    "compressed-tensors": CompressedTensorsW8A8Fp8Config,   # its W8A8-FP8 scheme only
+    "compressed-tensors": CompressedTensorsConfig,   # W8A8-FP8, W8A16-FP8 and pack-quantized int4 schemes
 }
 
 

@@ -4,6 +4,7 @@ AWQLinearMethod :81-169).  ``apply`` keeps the reference's op calls
 ``prepack=True`` (the awq_marlin role, quantization/awq_marlin.py) weights are
 transposed once at load time into the CDNA4 K-packed layout and the fast
 W4A16 kernel is used directly."""
+import os
 from typing import Any, Dict, List, Optional
 
 import torch
@@ -48,7 +49,10 @@ class AWQConfig(QuantizationConfig):
         weight_bits = cls.get_from_keys(config, ["w_bit", "bits"])
         group_size = cls.get_from_keys(config, ["q_group_size", "group_size"])
         zero_point = cls.get_from_keys(config, ["zero_point"])
-        return cls(weight_bits, group_size, zero_point)
+        # checkpoints are re-laid into the CDNA4 K-packed order at load time (the decode fast path
+        # needs it); APHRODITE_AWQ_NO_PREPACK=1 keeps the on-disk layout and the awq_gemm op
+        return cls(weight_bits, group_size, zero_point,
+                   prepack=os.environ.get("APHRODITE_AWQ_NO_PREPACK", "0") != "1")
 
     def get_quant_method(self, layer: nn.Module, prefix: str) -> Optional["AWQLinearMethod"]:
         return AWQLinearMethod(self)

@@ -13,6 +13,7 @@ from torch import nn
 
 from .. import _custom_ops as ops
 from .base_config import LinearMethodBase, QuantizationConfig, _param
+from .utils import layer_is_ignored
 
 ACTIVATION_SCHEMES = ["static", "dynamic"]
 
@@ -87,7 +88,7 @@ class Fp8Config(QuantizationConfig):
         return cls(is_checkpoint_fp8_serialized, activation_scheme, ignored_layers)
 
     def get_quant_method(self, layer: nn.Module, prefix: str) -> Optional["Fp8LinearMethod"]:
-        if any(prefix == i or prefix.startswith(i + ".") for i in self.ignored_layers):
+        if layer_is_ignored(prefix, self.ignored_layers):   # fp8.py:84-86 is_layer_skipped
             return None
         return Fp8LinearMethod(self)
 
@@ -118,14 +119,15 @@ class Fp8LinearMethod(LinearMethodBase):
                         dtype=weight_dtype),
             input_dim=1, output_dim=0, weight_loader=weight_loader))
         if self.quant_config.is_checkpoint_fp8_serialized:
+            # one scale per logical matrix of a fused layer (fp8.py:150-170: PerTensorScaleParameter)
             scale = _param(torch.empty(len(output_partition_sizes), dtype=torch.float32),
-                           weight_loader=weight_loader)
+                           needs_scalar_to_array=True, weight_loader=weight_loader)
             scale[:] = torch.finfo(torch.float32).min
             layer.register_parameter("weight_scale", scale)
             if self.quant_config.activation_scheme == "static":
                 iscale = _param(torch.empty(len(output_partition_sizes),
                                             dtype=torch.float32),
-                                weight_loader=weight_loader)
+                                needs_scalar_to_array=True, weight_loader=weight_loader)
                 iscale[:] = torch.finfo(torch.float32).min
                 layer.register_parameter("input_scale", iscale)
             else:
@@ -228,11 +230,13 @@ class CompressedTensorsW8A8Fp8Method(LinearMethodBase):
         if self.quant_config.strategy == "channel":
             scale = _param(torch.empty((n, 1), dtype=torch.float32), output_dim=0, weight_loader=loader)
         else:
-            scale = _param(torch.empty(len(output_partition_sizes), dtype=torch.float32), weight_loader=loader)
+            scale = _param(torch.empty(len(output_partition_sizes), dtype=torch.float32),
+                           needs_scalar_to_array=True, weight_loader=loader)
         scale[:] = torch.finfo(torch.float32).min
         layer.register_parameter("weight_scale", scale)
         if self.quant_config.is_static_input_scheme:
-            iscale = _param(torch.empty(len(output_partition_sizes), dtype=torch.float32), weight_loader=loader)
+            iscale = _param(torch.empty(len(output_partition_sizes), dtype=torch.float32),
+                            needs_scalar_to_array=True, weight_loader=loader)
             iscale[:] = torch.finfo(torch.float32).min
             layer.register_parameter("input_scale", iscale)
         else:

@@ -44,6 +44,9 @@ class CDNA4LinearKernel(MPLinearKernel):
             return False, f"group size {gs} must be a multiple of 32 dividing K={k}"
         if k % 32 != 0 or n % 16 != 0:
             return False, f"K={k} must be a multiple of 32 and N={n} of 16"
+        if c.has_g_idx and k != c.full_weight_shape[0]:
+            # act-order rows of one K shard reference groups of the whole matrix in uneven numbers
+            return False, "act-order (g_idx) with a K-sharded (row-parallel) weight is not supported"
         if c.act_type not in (torch.float16, torch.bfloat16):
             return False, f"activation dtype {c.act_type} not supported"
         return True, None
@@ -57,7 +60,7 @@ class CDNA4LinearKernel(MPLinearKernel):
         if c.has_g_idx and w_gidx is not None and w_gidx.numel() > 0:
             perm = torch.argsort(w_gidx).to(torch.int32)
         def kn(x):  # [out, in..] (compressed-tensors) -> [in.., out]
-            if getattr(x, "input_dim", 0) == 1 and getattr(x, "output_dim", 1) == 0:
+            if getattr(x, "output_dim", 1) == 0:
                 return x.data.t().contiguous()
             return x.data.contiguous()
 

@@ -1,0 +1,337 @@
+"""On-disk format ingestion on CPU: synthetic Hugging Face checkpoints in every
+supported format are loaded for tensor-parallel sizes 1, 2 and 4 (TINY has 2 KV heads, so 4 ranks
+exercise KV-head replication) and every parameter is compared with the shard derived here by plain
+index arithmetic on the LOGICAL matrices -- no code shared with the loader.  No post-processing
+(repack / requantise) is run: those are GPU ops and are covered by the -m gpu tests."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from aphrodite_engine_amd import loader as L
+from aphrodite_engine_amd import model as M
+from aphrodite_engine_amd.distributed import simulated_tensor_parallel
+from oracle import quant as oq
+from tests import ckpt_util as CU
+
+CFG = M.TINY   # hidden 512, 4 heads x 128, 2 KV heads, intermediate 1024, 2 layers
+HD = CFG.hidden_size // CFG.num_attention_heads
+
+
+# ----------------------------------------------------------------------------------------------
+# expected shards, by index sets over the logical [K, N] matrices
+# ----------------------------------------------------------------------------------------------
+def col_sets(rank, world):
+    """Logical output columns this rank holds, per fused layer, in parameter order."""
+    hq, hkv, inter = CFG.num_attention_heads, CFG.num_key_value_heads, CFG.intermediate_size
+    q_heads = list(range(rank * hq // world, (rank + 1) * hq // world))
+    if world >= hkv:
+        kv_heads = [rank // (world // hkv)]
+    else:
+        kv_heads = list(range(rank * hkv // world, (rank + 1) * hkv // world))
+
+    def cols(heads):
+        return np.concatenate([np.arange(h * HD, (h + 1) * HD) for h in heads])
+    i0, i1 = rank * inter // world, (rank + 1) * inter // world
+    return {"qkv": [("self_attn.q_proj", cols(q_heads)), ("self_attn.k_proj", cols(kv_heads)),
+                    ("self_attn.v_proj", cols(kv_heads))],
+            "gate_up": [("mlp.gate_proj", np.arange(i0, i1)), ("mlp.up_proj", np.arange(i0, i1))]}
+
+
+def row_set(k, rank, world):
+    return np.arange(rank * k // world, (rank + 1) * k // world)
+
+
+def expected_logical(truth, layer, rank, world, key):
+    """{module: logical matrix [K_local, N_local]} for qkv_proj, o_proj, gate_up_proj, down_proj."""
+    base = f"model.layers.{layer}."
+    lg = truth["logical"]
+    sets = col_sets(rank, world)
+    out = {}
+    out["qkv_proj"] = np.concatenate([lg[base + p][key][:, c] for p, c in sets["qkv"]], axis=1)
+    out["gate_up_proj"] = np.concatenate([lg[base + p][key][:, c] for p, c in sets["gate_up"]], axis=1)
+    for mod, proj in (("o_proj", "self_attn.o_proj"), ("down_proj", "mlp.down_proj")):
+        full = lg[base + proj][key]
+        out[mod] = full[row_set(full.shape[0], rank, world), :]
+    return out
+
+
+def expected_groups(truth, layer, rank, world, key, group):
+    """Group-wise metadata (scales / zero points, [K/g, N]): columns as above; rows follow K."""
+    base = f"model.layers.{layer}."
+    lg = truth["logical"]
+    sets = col_sets(rank, world)
+    out = {}
+    out["qkv_proj"] = np.concatenate([lg[base + p][key][:, c] for p, c in sets["qkv"]], axis=1)
+    out["gate_up_proj"] = np.concatenate([lg[base + p][key][:, c] for p, c in sets["gate_up"]], axis=1)
+    for mod, proj in (("o_proj", "self_attn.o_proj"), ("down_proj", "mlp.down_proj")):
+        full = lg[base + proj][key]
+        k = full.shape[0] * group
+        rows = row_set(k, rank, world)
+        out[mod] = full[rows[0] // group:(rows[-1] + 1) // group, :]
+    return out
+
+
+def build(tmp, fmt, rank, world, dtype=torch.float16, kv_cache_dtype="auto", **kw):
+    with simulated_tensor_parallel(rank, world):
+        return L.load_model(str(tmp), dtype=dtype, kv_cache_dtype=kv_cache_dtype, device="cpu",
+                            process_weights=False, **kw)
+
+
+MODS = ("qkv_proj", "o_proj", "gate_up_proj", "down_proj")
+WORLDS = [(0, 1), (0, 2), (1, 2), (0, 4), (3, 4)]
+
+
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("embedded", [True, False])
+def test_gptq_checkpoint(tmp_path, embedded):
+    truth = CU.write_checkpoint(str(tmp_path), CFG, "gptq", seed=1, embedded_config=embedded)
+    for rank, world in WORLDS:
+        m = build(tmp_path, "gptq", rank, world, quantization=None if embedded else "gptq")
+        for li, layer in enumerate(m.layers):
+            eq = expected_logical(truth, li, rank, world, "q")
+            es = expected_groups(truth, li, rank, world, "s", 128)
+            ez = expected_groups(truth, li, rank, world, "zp", 128)
+            for mod in MODS:
+                lin = getattr(layer, mod)
+                np.testing.assert_array_equal(oq.gptq_unpack(lin.qweight.numpy()), eq[mod], err_msg=f"{mod} q")
+                np.testing.assert_array_equal(lin.scales.numpy(), es[mod], err_msg=f"{mod} scales")
+                np.testing.assert_array_equal(oq.unpack_cols(lin.qzeros.numpy()), (ez[mod] - 1) & 15,
+                                              err_msg=f"{mod} zeros (stored = zero - 1)")
+                k_local = eq[mod].shape[0]
+                k0 = row_set(k_local * world, rank, world)[0] if mod in ("o_proj", "down_proj") else 0
+                np.testing.assert_array_equal(lin.g_idx.numpy(), (k0 + np.arange(k_local)) // 128)
+        check_replicated(m, truth, rank, world)
+
+
+def check_replicated(m, truth, rank, world):
+    t = {k: v.to(m.dtype) if v.dtype == torch.float16 else v for k, v in truth["tensors"].items()}
+    assert torch.equal(m.embed_tokens.data, t["model.embed_tokens.weight"])
+    assert torch.equal(m.norm.data, t["model.norm.weight"])
+    rows = CFG.vocab_size // world
+    assert torch.equal(m.lm_head.data, t["lm_head.weight"][rank * rows:(rank + 1) * rows])
+    for li, layer in enumerate(m.layers):
+        assert torch.equal(layer.input_layernorm.data, t[f"model.layers.{li}.input_layernorm.weight"])
+        assert torch.equal(layer.post_attention_layernorm.data,
+                           t[f"model.layers.{li}.post_attention_layernorm.weight"])
+
+
+def test_awq_checkpoint(tmp_path):
+    truth = CU.write_checkpoint(str(tmp_path), CFG, "awq", seed=2)
+    for rank, world in WORLDS:
+        m = build(tmp_path, "awq", rank, world)
+        assert type(m.layers[0].qkv_proj.quant_method).__name__ == "AWQLinearMethod"
+        for li, layer in enumerate(m.layers):
+            eq = expected_logical(truth, li, rank, world, "q")
+            es = expected_groups(truth, li, rank, world, "s", 128)
+            ez = expected_groups(truth, li, rank, world, "zp", 128)
+            for mod in MODS:
+                lin = getattr(layer, mod)
+                np.testing.assert_array_equal(oq.awq_unpack(lin.qweight.numpy()), eq[mod], err_msg=mod)
+                np.testing.assert_array_equal(oq.awq_unpack(lin.qzeros.numpy()), ez[mod], err_msg=mod)
+                np.testing.assert_array_equal(lin.scales.numpy(), es[mod], err_msg=mod)
+
+
+@pytest.mark.parametrize("fmt,static", [("fp8", False), ("fp8", True), ("ct-fp8-channel", False),
+                                        ("ct-fp8-tensor", False), ("ct-fp8-tensor", True), ("ct-w8a16", False)])
+def test_fp8_checkpoints(tmp_path, fmt, static):
+    truth = CU.write_checkpoint(str(tmp_path), CFG, fmt, seed=3, fp8_static=static)
+    lg, t = truth["logical"], truth["tensors"]
+    for rank, world in WORLDS:
+        m = build(tmp_path, fmt, rank, world, dtype=torch.bfloat16)
+        sets = col_sets(rank, world)
+        expect_method = {"fp8": "Fp8LinearMethod", "ct-fp8-channel": "CompressedTensorsW8A8Fp8Method",
+                         "ct-fp8-tensor": "CompressedTensorsW8A8Fp8Method",
+                         "ct-w8a16": "CompressedTensorsW8A16Fp8Method"}[fmt]
+        for li, layer in enumerate(m.layers):
+            base = f"model.layers.{li}."
+            for mod, group in (("qkv_proj", sets["qkv"]), ("gate_up_proj", sets["gate_up"])):
+                lin = getattr(layer, mod)
+                assert type(lin.quant_method).__name__ == expect_method
+                w = torch.cat([lg[base + p]["wq"][torch.from_numpy(c)] for p, c in group], 0)
+                assert torch.equal(lin.weight.data.view(torch.uint8), w.view(torch.uint8))
+                if fmt in ("ct-fp8-channel", "ct-w8a16"):
+                    s = torch.cat([lg[base + p]["s"][torch.from_numpy(c)] for p, c in group], 0)
+                    assert torch.equal(lin.weight_scale.data, s)
+                else:   # one scalar per logical matrix, in shard order
+                    s = torch.stack([lg[base + p]["s"].reshape(()) for p, _ in group])
+                    assert torch.equal(lin.weight_scale.data, s)
+                if static:
+                    i = torch.stack([t[base + p + ".input_scale"].reshape(()) for p, _ in group])
+                    assert torch.equal(lin.input_scale.data, i)
+                else:
+                    assert getattr(lin, "input_scale", None) is None
+            for mod, proj in (("o_proj", "self_attn.o_proj"), ("down_proj", "mlp.down_proj")):
+                lin = getattr(layer, mod)
+                full = lg[base + proj]["wq"]
+                cols = torch.from_numpy(row_set(full.shape[1], rank, world))
+                assert torch.equal(lin.weight.data.view(torch.uint8), full[:, cols].view(torch.uint8))
+                assert torch.equal(lin.weight_scale.data.reshape(-1), lg[base + proj]["s"].reshape(-1))
+        check_replicated(m, truth, rank, world)
+
+
+def test_compressed_tensors_pack_quantized(tmp_path):
+    truth = CU.write_checkpoint(str(tmp_path), CFG, "ct-w4a16", seed=4)
+    for rank, world in WORLDS:
+        m = build(tmp_path, "ct-w4a16", rank, world)
+        for li, layer in enumerate(m.layers):
+            eq = expected_logical(truth, li, rank, world, "q")
+            es = expected_groups(truth, li, rank, world, "s", 128)
+            for mod in MODS:
+                lin = getattr(layer, mod)
+                assert type(lin.quant_method).__name__ == "CompressedTensorsWNA16Method"
+                assert type(lin.kernel).__name__ == "CDNA4LinearKernel"
+                # weight_packed is [N, K/8] packed along K
+                got = oq.gptq_unpack(np.ascontiguousarray(lin.weight_packed.numpy().T))
+                np.testing.assert_array_equal(got, eq[mod], err_msg=mod)
+                np.testing.assert_array_equal(lin.weight_scale.numpy().T, es[mod], err_msg=mod)
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_unquantised_checkpoint_and_fused_on_disk(tmp_path, fused):
+    truth = CU.write_checkpoint(str(tmp_path), CFG, "fp16", seed=5, fused_on_disk=fused)
+    for rank, world in WORLDS:
+        m = build(tmp_path, "fp16", rank, world)
+        for li, layer in enumerate(m.layers):
+            ew = expected_logical(truth, li, rank, world, "w")
+            for mod in MODS:
+                lin = getattr(layer, mod)
+                assert lin.quant_method is None
+                np.testing.assert_array_equal(lin.weight.numpy().T, ew[mod], err_msg=mod)
+
+
+# ----------------------------------------------------------------------------------------------
+def test_kv_cache_scales(tmp_path):
+    n = CFG.num_hidden_layers
+    CU.write_checkpoint(str(tmp_path / "a"), CFG, "fp8", seed=6, kv_scales="kv")
+    m = build(tmp_path / "a", "fp8", 0, 1, kv_cache_dtype="fp8")
+    assert [(l.k_scale, l.v_scale) for l in m.layers] == [
+        (pytest.approx(0.02 + 0.001 * i), pytest.approx(0.03 + 0.001 * i)) for i in range(n)]
+    # a 16-bit cache ignores them
+    m = build(tmp_path / "a", "fp8", 0, 1, kv_cache_dtype="auto")
+    assert all((l.k_scale, l.v_scale) == (1.0, 1.0) for l in m.layers)
+    # deprecated single kv_scale: used for both
+    CU.write_checkpoint(str(tmp_path / "b"), CFG, "fp8", seed=6, kv_scales="legacy")
+    m = build(tmp_path / "b", "fp8", 0, 1, kv_cache_dtype="fp8")
+    assert [(l.k_scale, l.v_scale) for l in m.layers] == [
+        (pytest.approx(0.05 + 0.001 * i), pytest.approx(0.05 + 0.001 * i)) for i in range(n)]
+    # compressed-tensors spelling
+    CU.write_checkpoint(str(tmp_path / "c"), CFG, "ct-fp8-channel", seed=6, kv_scales="ct")
+    m = build(tmp_path / "c", "ct", 0, 1, kv_cache_dtype="fp8")
+    assert m.layers[1].k_scale == pytest.approx(0.021) and m.layers[1].v_scale == pytest.approx(0.031)
+    # none in the checkpoint: 1.0
+    CU.write_checkpoint(str(tmp_path / "d"), CFG, "fp8", seed=6)
+    m = build(tmp_path / "d", "fp8", 0, 1, kv_cache_dtype="fp8")
+    assert all((l.k_scale, l.v_scale) == (1.0, 1.0) for l in m.layers)
+
+
+def test_quantization_param_path(tmp_path):
+    CU.write_checkpoint(str(tmp_path / "m"), CFG, "fp8", seed=7)
+    n = CFG.num_hidden_layers
+    doc = {"model_type": "llama", "kv_cache": {"dtype": "float8_e4m3fn", "scaling_factor": {
+        "0": {str(i): 0.1 + i for i in range(n)}, "1": {str(i): 0.2 + i for i in range(n)}}}}
+    path = tmp_path / "kv.json"
+    path.write_text(json.dumps(doc))
+    m = build(tmp_path / "m", "fp8", 1, 2, kv_cache_dtype="fp8", quantization_param_path=str(path))
+    assert [(l.k_scale, l.v_scale) for l in m.layers] == [(pytest.approx(0.2 + i), ) * 2 for i in range(n)]
+    with pytest.raises(ValueError, match="TP size 2"):
+        build(tmp_path / "m", "fp8", 0, 1, kv_cache_dtype="fp8", quantization_param_path=str(path))
+    with pytest.raises(ValueError, match="fp8 KV cache"):
+        build(tmp_path / "m", "fp8", 0, 2, kv_cache_dtype="auto", quantization_param_path=str(path))
+    doc["kv_cache"]["dtype"] = "float8_e5m2"
+    path.write_text(json.dumps(doc))
+    with pytest.raises(ValueError, match="float8_e4m3fn"):
+        build(tmp_path / "m", "fp8", 0, 2, kv_cache_dtype="fp8", quantization_param_path=str(path))
+    doc["kv_cache"]["dtype"] = "float8_e4m3fn"
+    del doc["kv_cache"]["scaling_factor"]["1"][str(n - 1)]
+    path.write_text(json.dumps(doc))
+    with pytest.raises(ValueError, match="malformed"):
+        build(tmp_path / "m", "fp8", 1, 2, kv_cache_dtype="fp8", quantization_param_path=str(path))
+
+
+def test_config_resolution_and_gates(tmp_path):
+    CU.write_checkpoint(str(tmp_path / "g"), CFG, "gptq", seed=8)
+    hf = L.read_hf_config(str(tmp_path / "g"))
+    assert type(L.resolve_quant_config(str(tmp_path / "g"), hf)).__name__ == "GPTQConfig"
+    with pytest.raises(ValueError, match="does not match"):
+        L.resolve_quant_config(str(tmp_path / "g"), hf, quantization="awq")
+    with pytest.raises(ValueError, match="not supported for quantization method"):
+        L.resolve_quant_config(str(tmp_path / "g"), hf, dtype=torch.float32)
+    # GPTQ without any config json
+    CU.write_checkpoint(str(tmp_path / "n"), CFG, "fp16", seed=8)
+    hf = L.read_hf_config(str(tmp_path / "n"))
+    assert L.resolve_quant_config(str(tmp_path / "n"), hf) is None
+    with pytest.raises(ValueError, match="Cannot find the config file"):
+        L.resolve_quant_config(str(tmp_path / "n"), hf, quantization="gptq")
+    with pytest.raises(ValueError, match="Invalid quantization method"):
+        L.resolve_quant_config(str(tmp_path / "n"), hf, quantization="gguf")
+    # schemes outside the hot path are refused, not mis-loaded
+    from aphrodite_engine_amd.quantization.compressed_tensors import CompressedTensorsConfig
+    int8 = CompressedTensorsConfig.from_config({"format": "int-quantized", "config_groups": {"g": {
+        "targets": ["Linear"], "weights": {"num_bits": 8, "type": "int", "strategy": "channel"},
+        "input_activations": {"num_bits": 8, "type": "int", "strategy": "token", "dynamic": True}}}})
+    with pytest.raises(NotImplementedError):
+        int8.get_quant_method(torch.nn.Module(), "model.layers.0.mlp.down_proj")
+    mixed = CompressedTensorsConfig.from_config({"format": "float-quantized", "config_groups": {},
+                                                 "ignore": ["model.layers.0.self_attn.q_proj"]})
+    with pytest.raises(ValueError, match="same scheme"):
+        mixed.get_quant_method(torch.nn.Module(), "model.layers.0.self_attn.qkv_proj")
+
+
+def test_shard_plan_rules():
+    p = L.qkv_plan(32, 8, 128, rank=5, world=16)            # 2 ranks per KV head
+    assert [(o.local, o.src_index) for o in p.outs] == [(256, 5), (128, 2), (128, 2)]
+    p = L.qkv_plan(32, 8, 128, rank=3, world=4)
+    assert [(o.local, o.src_index) for o in p.outs] == [(1024, 3), (256, 3), (256, 3)]
+    with pytest.raises(ValueError):
+        L.qkv_plan(32, 8, 128, rank=0, world=3)
+    with pytest.raises(ValueError):
+        L.qkv_plan(32, 8, 128, rank=0, world=12)
+    with pytest.raises(ValueError):
+        L.merged_plan([14336, 14336], rank=0, world=3)
+    # shape mismatches are errors, never silent truncation
+    plan = L.merged_plan([16, 16], rank=0, world=1)
+    from aphrodite_engine_amd.quantization.base_config import _param
+    prm = _param(torch.zeros(32, 8), input_dim=1, output_dim=0)
+    with pytest.raises(ValueError, match="does not fit"):
+        L.load_sharded(plan, prm, torch.zeros(16, 9), 0)
+    with pytest.raises(ValueError, match="Unknown shard id"):
+        L.load_sharded(plan, prm, torch.zeros(16, 8), "q")
+    with pytest.raises(KeyError):
+        L.map_llama_name("model.layers.0.self_attn.unknown_proj.weight")
+
+
+# ----------------------------------------------------------------------------------------------
+def _tp_load_worker(rank, world, port, path, q):
+    import torch.distributed as dist
+    from aphrodite_engine_amd import distributed as d
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    d.init_tensor_parallel(world, backend="gloo")
+    m = L.load_model(path, device="cpu", process_weights=False)
+    lin = m.layers[1].qkv_proj
+    # the ranks' lm_head shards gathered over the TP group give back the full matrix
+    full = d.tensor_model_parallel_all_gather(m.lm_head.data.float(), dim=0)
+    q.put((rank, oq.gptq_unpack(lin.qweight.numpy()).tolist(), full.shape[0], float(full.sum())))
+    dist.destroy_process_group()
+
+
+def test_load_under_real_tensor_parallel_gloo(tmp_path):
+    """world_size 2 over gloo: each rank loads its own shard from the same directory."""
+    truth = CU.write_checkpoint(str(tmp_path), CFG, "gptq", seed=9)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_tp_load_worker, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=180) for _ in range(2)), key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+    for rank, qkv, rows, total in res:
+        exp = expected_logical(truth, 1, rank, 2, "q")["qkv_proj"]
+        np.testing.assert_array_equal(np.array(qkv), exp)
+        assert rows == CFG.vocab_size
+        assert total == pytest.approx(float(truth["tensors"]["lm_head.weight"].float().sum()), rel=1e-6)

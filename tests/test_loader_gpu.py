@@ -1,0 +1,113 @@
+"""On-disk format ingestion, GPU half: a synthetic checkpoint of every supported format is loaded
+onto the MI355X (post-load repack / requantisation included) and each linear of the loaded model is
+checked against x @ W with W dequantised from the LOGICAL matrices the writer kept; then a decode
+step runs through the loaded model (fused fast path where the format has one)."""
+import numpy as np
+import pytest
+import torch
+
+from aphrodite_engine_amd import loader as L
+from aphrodite_engine_amd import model as M
+from tests import ckpt_util as CU
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+CFG = M.TINY
+PROJ_OF = {"qkv_proj": ["self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj"], "o_proj": ["self_attn.o_proj"],
+           "gate_up_proj": ["mlp.gate_proj", "mlp.up_proj"], "down_proj": ["mlp.down_proj"]}
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from aphrodite_engine_amd import _custom_ops
+    return _custom_ops
+
+
+def dense_weight(fmt, lg):
+    """Logical matrices -> float32 [K, N]."""
+    if fmt == "fp16":
+        return lg["w"].astype(np.float32)
+    if fmt in ("gptq", "awq"):
+        g = np.arange(lg["q"].shape[0]) // 128
+        return (lg["q"] - lg["zp"][g]).astype(np.float32) * lg["s"].astype(np.float32)[g]
+    if fmt == "ct-w4a16":
+        g = np.arange(lg["q"].shape[0]) // 128
+        return (lg["q"] - 8).astype(np.float32) * lg["s"].astype(np.float32)[g]
+    w = lg["wq"].float() * lg["s"].float().reshape(-1, 1) if lg["s"].numel() > 1 else lg["wq"].float() * lg["s"]
+    return w.numpy().T      # stored [N, K]
+
+
+@pytest.mark.parametrize("fmt", ["fp16", "gptq", "awq", "fp8", "ct-fp8-channel", "ct-fp8-tensor", "ct-w8a16",
+                                 "ct-w4a16"])
+def test_loaded_checkpoint_linears_and_decode(ops, tmp_path, fmt):
+    truth = CU.write_checkpoint(str(tmp_path), CFG, fmt, seed=11,
+                                kv_scales="kv" if fmt == "fp8" else None)
+    kv_dtype = "fp8" if fmt == "fp8" else "auto"
+    with torch.no_grad():
+        m = L.load_model(str(tmp_path), dtype=torch.float16, kv_cache_dtype=kv_dtype, device=DEV)
+        rng = np.random.default_rng(5)
+        for li, layer in enumerate(m.layers):
+            for mod, projs in PROJ_OF.items():
+                lin = getattr(layer, mod)
+                w = np.concatenate([dense_weight(fmt, truth["logical"][f"model.layers.{li}.{p}"]) for p in projs], 1)
+                x = torch.from_numpy(rng.standard_normal((7, w.shape[0])).astype(np.float32)).half().to(DEV)
+                got = lin(x).float().cpu().numpy()
+                ref = x.float().cpu().numpy() @ w
+                err = np.abs(got - ref).mean() / np.abs(ref).mean()
+                # W8A8 adds the activation quantisation (e4m3: 2^-4 relative steps) on top of fp16 rounding
+                assert err < (0.04 if fmt in ("fp8", "ct-fp8-channel", "ct-fp8-tensor") else 4e-3), (fmt, mod, err)
+        if fmt == "fp8":
+            assert m.layers[1].k_scale == pytest.approx(0.021) and m.layers[1].v_scale == pytest.approx(0.031)
+        # one decode step through the loaded model: fused fast path == op-by-op path
+        meta, pos, nblocks = M.make_decode_metadata(5, [3, 17, 64, 200, 129], 16, DEV)
+        ids = torch.randint(0, CFG.vocab_size, (5, ), device=DEV)
+        outs = []
+        for fused in (False, True):
+            caches = M.make_kv_caches(CFG, nblocks, 16, torch.float16, kv_dtype, DEV, seed=3)
+            m.use_fused_decode = fused
+            outs.append(m(ids, pos, caches, meta).float())
+        assert torch.isfinite(outs[0]).all()
+        if fmt in ("gptq", "awq", "ct-w4a16"):
+            assert all(l.fused_decode_ok(5) for l in m.layers)
+            torch.testing.assert_close(outs[0], outs[1], atol=2e-2, rtol=2e-2)
+        elif fmt in ("ct-fp8-channel", "ct-fp8-tensor"):
+            assert all(l.fused_decode_fp8_ok(5) for l in m.layers)
+            assert torch.equal(outs[0], outs[1])
+        else:
+            assert torch.equal(outs[0], outs[1])      # no fast path for this format: same code twice
+        logits = m.compute_logits(outs[1].half())
+        assert logits.shape == (5, CFG.vocab_size) and torch.isfinite(logits.float()).all()
+
+
+def test_loaded_gptq_matches_directly_built_model(ops, tmp_path):
+    """The loader path and direct parameter assignment give the same model, bit for bit."""
+    from aphrodite_engine_amd.quantization.gptq import GPTQConfig
+    truth = CU.write_checkpoint(str(tmp_path), CFG, "gptq", seed=12)
+    t = truth["tensors"]
+    with torch.no_grad():
+        a = L.load_model(str(tmp_path), device=DEV)
+        b = M.LlamaForCausalLM(CFG, GPTQConfig(4, 128, False), torch.float16)
+        b.embed_tokens.copy_(t["model.embed_tokens.weight"])
+        b.norm.copy_(t["model.norm.weight"])
+        b.lm_head.copy_(t["lm_head.weight"])
+        for li, layer in enumerate(b.layers):
+            base = f"model.layers.{li}."
+            layer.input_layernorm.copy_(t[base + "input_layernorm.weight"])
+            layer.post_attention_layernorm.copy_(t[base + "post_attention_layernorm.weight"])
+            for mod, projs in PROJ_OF.items():
+                lin = getattr(layer, mod)
+                for attr, dim in (("qweight", 1), ("qzeros", 1), ("scales", 1)):
+                    getattr(lin, attr).copy_(torch.cat([t[base + p + "." + attr] for p in projs], dim))
+                lin.g_idx.copy_(t[base + projs[0] + ".g_idx"])
+        b.to(DEV)
+        b.cos_sin = a.cos_sin
+        b.process_weights_after_loading()
+        meta, pos, nblocks = M.make_decode_metadata(4, [5, 33, 100, 64], 16, DEV)
+        ids = torch.randint(0, CFG.vocab_size, (4, ), device=DEV)
+        outs = []
+        for m in (a, b):
+            caches = M.make_kv_caches(CFG, nblocks, 16, torch.float16, "auto", DEV, seed=3)
+            outs.append(m(ids, pos, caches, meta))
+        assert torch.equal(outs[0], outs[1])
