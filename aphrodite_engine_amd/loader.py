@@ -216,7 +216,9 @@ def llama_config_from_hf(hf: Dict[str, Any]):
                        num_hidden_layers=hf["num_hidden_layers"], num_attention_heads=heads,
                        num_key_value_heads=hf.get("num_key_value_heads", heads), vocab_size=hf["vocab_size"],
                        rms_norm_eps=hf.get("rms_norm_eps", 1e-6), rope_theta=hf.get("rope_theta", 10000.0),
-                       max_position_embeddings=hf.get("max_position_embeddings", 8192))
+                       max_position_embeddings=hf.get("max_position_embeddings", 8192),
+                       num_local_experts=hf.get("num_local_experts", 0) or 0,
+                       num_experts_per_tok=hf.get("num_experts_per_tok", 2))
 
 
 def resolve_quant_config(model_dir: str, hf: Dict[str, Any], quantization: Optional[str] = None,
@@ -289,11 +291,12 @@ _LAYER_RE = re.compile(r"^(?:model\.)?layers\.(\d+)\.(.+)$")
 
 @dataclass(frozen=True)
 class Target:
-    kind: str                       # "linear" | "param" | "kv_scale" | "skip"
+    kind: str                       # "linear" | "expert" | "param" | "kv_scale" | "skip"
     path: str = ""                  # attribute path inside LlamaForCausalLM
     attr: str = ""                  # parameter name inside the linear / "k" or "v" or "kv" for scales
     shard: ShardId = None
     layer: int = -1
+    expert: int = -1
 
 
 def map_llama_name(name: str, tie_word_embeddings: bool = False) -> Target:
@@ -320,6 +323,12 @@ def map_llama_name(name: str, tie_word_embeddings: bool = False) -> Target:
     if rest in ("self_attn.kv_scale", "self_attn.attn.kv_scale"):   # deprecated spelling: one scale for both
         return Target("kv_scale", attr="kv", layer=layer)
     parts = rest.split(".")
+    # Mixtral (modeling/models/mixtral.py:400-470): replicated router + experts.{e}.w{1,2,3}.<tensor>
+    if rest == "block_sparse_moe.gate.weight":
+        return Target("param", f"layers.{layer}.moe_gate", layer=layer)
+    if len(parts) == 5 and parts[:2] == ["block_sparse_moe", "experts"] and parts[3] in ("w1", "w2", "w3"):
+        fused = "w13_" if parts[3] in ("w1", "w3") else "w2_"
+        return Target("expert", f"layers.{layer}.experts", fused + parts[4], parts[3], layer, int(parts[2]))
     if len(parts) == 3 and parts[0] in ("self_attn", "mlp"):
         _, proj, attr = parts
         if proj in _FUSED:
@@ -377,6 +386,15 @@ def load_llama_weights(model, weights: Iterable[Tuple[str, torch.Tensor]], tie_w
                 tensor = tensor.narrow(0, rank * rows, rows)
                 seen_lm_head = True
             default_weight_loader(param, tensor.to(param.dtype))
+            continue
+        if tgt.kind == "expert":
+            moe = _get_path(model, tgt.path)
+            param = getattr(moe, tgt.attr, None)
+            if not isinstance(param, torch.nn.Parameter):
+                if tgt.attr.endswith("bias"):
+                    continue
+                raise KeyError(f"{name}: the expert layer has no parameter {tgt.attr!r}")
+            moe.weight_loader(param, tensor, name, tgt.shard, tgt.expert)
             continue
         linear = _get_path(model, tgt.path)
         param = getattr(linear, tgt.attr, None)

@@ -39,6 +39,8 @@ class LlamaConfig:
     rms_norm_eps: float = 1e-5
     rope_theta: float = 500000.0
     max_position_embeddings: int = 8192
+    num_local_experts: int = 0        # > 0: Mixtral-style sparse MLP (block_sparse_moe), SURVEY 8f row 2
+    num_experts_per_tok: int = 2
 
     @property
     def head_dim(self) -> int:
@@ -49,6 +51,13 @@ LLAMA3_8B = LlamaConfig()
 LLAMA3_70B = LlamaConfig(hidden_size=8192, intermediate_size=28672,
                          num_hidden_layers=80, num_attention_heads=64,
                          num_key_value_heads=8)
+MIXTRAL_8X7B = LlamaConfig(hidden_size=4096, intermediate_size=14336, num_hidden_layers=32,
+                          num_attention_heads=32, num_key_value_heads=8, vocab_size=32000,
+                          rope_theta=1e6, max_position_embeddings=32768, num_local_experts=8,
+                          num_experts_per_tok=2)
+TINY_MOE = LlamaConfig(hidden_size=512, intermediate_size=1024, num_hidden_layers=2,
+                       num_attention_heads=4, num_key_value_heads=2, vocab_size=1024,
+                       max_position_embeddings=2048, num_local_experts=8, num_experts_per_tok=2)
 TINY = LlamaConfig(hidden_size=512, intermediate_size=1024, num_hidden_layers=2,
                    num_attention_heads=4, num_key_value_heads=2, vocab_size=1024,
                    max_position_embeddings=2048)
@@ -138,12 +147,22 @@ class LlamaDecoderLayer(nn.Module):
                                   full_in_features=cfg.num_attention_heads * self.head_dim,
                                   prefix=pfx + "self_attn.o_proj", plan=row_plan())
         inter = cfg.intermediate_size // tp
-        self.gate_up_proj = QuantLinear(h, [inter, inter], quant_config, dtype, prefix=pfx + "mlp.gate_up_proj",
-                                        plan=merged_plan([cfg.intermediate_size] * 2),
-                                        full_out_features=2 * cfg.intermediate_size)
-        self.down_proj = QuantLinear(inter, [h], quant_config, dtype,
-                                     full_in_features=cfg.intermediate_size, prefix=pfx + "mlp.down_proj",
-                                     plan=row_plan())
+        self.is_moe = cfg.num_local_experts > 0
+        if self.is_moe:
+            # MixtralMoE (modeling/models/mixtral.py:60-110): replicated fp16 router + quantised experts
+            from .moe import FusedMoE
+            self.moe_gate = nn.Parameter(torch.empty(cfg.num_local_experts, h, dtype=dtype), requires_grad=False)
+            self.experts = FusedMoE(cfg.num_local_experts, cfg.num_experts_per_tok, h, cfg.intermediate_size,
+                                    params_dtype=dtype, reduce_results=True, renormalize=True,
+                                    quant_config=quant_config, prefix=pfx + "block_sparse_moe.experts")
+            self.gate_up_proj = self.down_proj = None
+        else:
+            self.gate_up_proj = QuantLinear(h, [inter, inter], quant_config, dtype, prefix=pfx + "mlp.gate_up_proj",
+                                            plan=merged_plan([cfg.intermediate_size] * 2),
+                                            full_out_features=2 * cfg.intermediate_size)
+            self.down_proj = QuantLinear(inter, [h], quant_config, dtype,
+                                         full_in_features=cfg.intermediate_size, prefix=pfx + "mlp.down_proj",
+                                         plan=row_plan())
         self.attn = MI355XAttentionImpl(self.num_heads, self.head_dim,
                                         self.head_dim ** -0.5, self.num_kv_heads,
                                         kv_cache_dtype=kv_cache_dtype)
@@ -158,6 +177,8 @@ class LlamaDecoderLayer(nn.Module):
         decode fast path runs SiluAndMul inside the GEMM epilogue.  With
         keep_original=False the [gate | up] copy is dropped (the unfused forward then
         de-interleaves the GEMM output instead)."""
+        if self.is_moe:
+            return False
         fp = self.gate_up_proj.fast_params()
         lin = self.gate_up_proj
         if fp is None or ops.wna16_ksplit(m, lin.out_features, lin.in_features, fp[2].shape[0]) != 1 \
@@ -177,11 +198,21 @@ class LlamaDecoderLayer(nn.Module):
         the [M, hidden] result over the TP group and hand it to the fused norm as a tensor."""
         if m > 64:
             return False
-        for lin in (self.qkv_proj, self.o_proj, self.gate_up_proj, self.down_proj):
+        for lin in self.linears():
             fp = lin.fast_params()
             if fp is None or ops.wna16_ksplit(m, lin.out_features, lin.in_features, fp[2].shape[0]) <= 0:
                 return False
         return True
+
+    def linears(self):
+        """The dense quantised projections of this layer (a sparse MLP's experts live in ``experts``)."""
+        return (self.qkv_proj, self.o_proj) if self.is_moe else \
+            (self.qkv_proj, self.o_proj, self.gate_up_proj, self.down_proj)
+
+    def moe_block(self, normed: torch.Tensor) -> torch.Tensor:
+        """router (fp16 library GEMM, [M, E]) + fused experts (+ TP all-reduce inside FusedMoE)."""
+        router_logits = torch.matmul(normed, self.moe_gate.t())
+        return self.experts(normed, router_logits)
 
     def forward_decode_fused(self, positions, x, slabs, residual, first, kv_cache, attn_metadata, cos_sin,
                              cos_sin_tok=None):
@@ -217,6 +248,19 @@ class LlamaDecoderLayer(nn.Module):
                 value_cache.shape[3], attn_metadata.max_decode_seq_len, None, self.attn.kv_cache_dtype,
                 self.k_scale, self.v_scale)
         qw, qz, sc, zo = self.o_proj.fast_params()
+        if self.is_moe:
+            # sparse MLP: the norm hands row-major activations to the router and the expert gather
+            if self.tp > 1:
+                o = ops.wna16_gemm_packed(attn_packed, m, self.q_size, qw, qz, sc, zo, partials=False)
+                o = tensor_model_parallel_all_reduce(o)
+                _, normed = ops.fused_add_rms_norm_pack(o, None, residual, True, self.post_attention_layernorm,
+                                                        eps, pack=False, want_out=True)
+            else:
+                o_slabs, _ = ops.wna16_gemm_packed(attn_packed, m, self.q_size, qw, qz, sc, zo, partials=True)
+                _, normed = ops.fused_add_rms_norm_pack(None, o_slabs, residual, True,
+                                                        self.post_attention_layernorm, eps, pack=False,
+                                                        want_out=True)
+            return self.moe_block(normed), None
         if self.tp > 1:   # row-parallel: local reduce, all-reduce over the TP group, then the norm
             o = ops.wna16_gemm_packed(attn_packed, m, self.q_size, qw, qz, sc, zo, partials=False)
             o = tensor_model_parallel_all_reduce(o)
@@ -249,9 +293,9 @@ class LlamaDecoderLayer(nn.Module):
         (which dequantises with the per-token x per-channel scales), rotary + cache write run
         inside the attention kernel."""
         from .quantization.fp8 import CompressedTensorsW8A8Fp8Method
-        if m > 64 or self.head_dim != 128 or not self.fuse_rope_attention:
+        if m > 64 or self.head_dim != 128 or not self.fuse_rope_attention or self.is_moe:
             return False
-        for lin in (self.qkv_proj, self.o_proj, self.gate_up_proj, self.down_proj):
+        for lin in self.linears():
             if not isinstance(lin.quant_method, CompressedTensorsW8A8Fp8Method) or lin.input_scale is not None:
                 return False
             if ops.fp8_gemm_ksplit(m, lin.out_features, lin.in_features) <= 0:
@@ -328,6 +372,8 @@ class LlamaDecoderLayer(nn.Module):
         if self.tp > 1:
             hidden = tensor_model_parallel_all_reduce(hidden)
         ops.fused_add_rms_norm(hidden, residual, self.post_attention_layernorm, eps)
+        if self.is_moe:
+            return self.moe_block(hidden), residual
         gate_up = self.gate_up_proj(hidden)
         if self.gate_up_interleaved is not None and not self.gate_up_keep_original:
             gate_up = gate_up.view(gate_up.shape[0], -1, 2).transpose(1, 2).reshape(gate_up.shape[0], -1)
@@ -380,8 +426,12 @@ class LlamaForCausalLM(nn.Module):
                                              dtype=torch.float32)).to(self.embed_tokens.dtype))
         randn_(self.lm_head, 1.0 / math.sqrt(cfg.hidden_size))
         for layer in self.layers:
-            for lin in (layer.qkv_proj, layer.o_proj, layer.gate_up_proj, layer.down_proj):
+            for lin in layer.linears():
                 _init_linear(lin, g, device)
+            if layer.is_moe:
+                layer.moe_gate.copy_((torch.randn(layer.moe_gate.shape, generator=g_rep, device=device)
+                                      / math.sqrt(cfg.hidden_size)).to(layer.moe_gate.dtype))
+                _init_experts(layer.experts, g, device)
         self.cos_sin = _rope_cache(cfg.head_dim, cfg.max_position_embeddings,
                                    cfg.rope_theta, self.dtype, device)
         self.process_weights_after_loading()
@@ -391,20 +441,27 @@ class LlamaForCausalLM(nn.Module):
         """Every quant method's post-load hook (repack / requantise), once the parameters are on
         the device (model_loader/loader.py:396-408)."""
         for layer in self.layers:
-            for lin in (layer.qkv_proj, layer.o_proj, layer.gate_up_proj, layer.down_proj):
+            for lin in layer.linears():
                 if lin.quant_method is not None:
                     lin.quant_method.process_weights_after_loading(lin)
+            if layer.is_moe:
+                layer.experts.quant_method.process_weights_after_loading(layer.experts)
         return self
 
-    def weight_bytes_per_layer(self) -> int:
-        """Algorithmic bytes of the four linears of one layer."""
+    def weight_bytes_per_layer(self, active_expert_fraction: float = 1.0) -> int:
+        """Algorithmic bytes of the linears of one layer; for a sparse MLP the experts'
+        weights count in proportion to the experts a step actually routes to."""
         layer = self.layers[0]
         n = 0
-        for lin in (layer.qkv_proj, layer.o_proj, layer.gate_up_proj, layer.down_proj):
+        for lin in layer.linears():
             for name, p in lin.named_parameters():
                 if name in ("g_idx", "input_scale"):
                     continue
                 n += p.numel() * p.element_size()
+        if layer.is_moe:   # every expert's weights (at batch 32, top-2 of 8 touches all of them) + the router
+            ex = layer.experts.experts_packed
+            n += int(sum(t.numel() * t.element_size() for t in ex.w13 + ex.w2) * active_expert_fraction)
+            n += layer.moe_gate.numel() * layer.moe_gate.element_size()
         return n
 
     def forward(self, input_ids, positions, kv_caches, attn_metadata):
@@ -459,6 +516,23 @@ class LlamaForCausalLM(nn.Module):
 
 
 @torch.no_grad()
+def _init_experts(moe, g, device):
+    """Random int4 experts in the checkpoint layout of the method (GPTQ / AWQ)."""
+    gs = moe.quant_method.group_size
+    for name, p in list(moe.named_parameters()):
+        if name.endswith(("qweight", "qzeros")):
+            for e in range(p.shape[0]):      # per expert: bounded temporaries at Mixtral size
+                p[e].copy_(torch.randint(-2 ** 31, 2 ** 31 - 1, p.shape[1:], generator=g, device=device,
+                                         dtype=torch.int64).to(torch.int32))
+        elif name.endswith("scales"):
+            k = moe.hidden_size if name.startswith("w13") else moe.intermediate_size_per_partition * moe.tp_size
+            p.copy_(((torch.rand(p.shape, generator=g, device=device) * 0.5 + 0.75)
+                     * (1.0 / (4.6 * math.sqrt(k)))).to(p.dtype))
+        elif name.endswith("g_idx"):
+            k0 = moe.tp_rank * p.shape[1] if name.startswith("w2") else 0
+            p.copy_(((torch.arange(p.shape[1], device=device) + k0) // gs).to(p.dtype).expand_as(p))
+
+
 def _init_linear(lin: QuantLinear, g, device):
     k = lin.in_features
     qc = lin.quant_config

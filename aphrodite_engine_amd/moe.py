@@ -12,11 +12,14 @@ weights read once):
     wna16_gemm_grouped(w2, slabs)       fp32 split-K slabs
     moe_combine                         routed weight, sum over top-k
 """
-from typing import Optional, Tuple
+import abc
+from typing import List, Optional, Tuple
 
 import torch
+from torch import nn
 
 from . import _custom_ops as ops
+from .quantization.base_config import QuantizeMethodBase, _param
 
 MOE_BLOCK_M = 16   # one MFMA m-tile = one block of moe_align_block_size
 
@@ -57,12 +60,19 @@ class Wna16Experts:
     columns INTERLEAVED (``ops.interleave_gate_up``) ; w2: [E, I/8, H].  Built from per-expert GPTQ
     tensor sets (qweight [K/8, N] plain GPTQ order, qzeros [G, N/8] stored zero-1, scales [G, N])."""
 
-    def __init__(self, w13_sets, w2_sets, zero_offset: int = 1):
+    def __init__(self, w13_sets, w2_sets, zero_offset: int = 1, layout: str = "gptq"):
+        """layout "gptq": tensors as above; "awq": qweight [K, N/8] / qzeros [G, N/8] in the AWQ
+        nibble order (zeros stored as-is: zero_offset 0)."""
         empty = torch.empty(0, dtype=torch.int32, device=w13_sets[0][0].device)
 
         def prep(qw, qz, sc, interleave):
-            k8, n = qw.shape
-            qw = ops.gptq_marlin_repack(qw.contiguous(), empty, k8 * 8, n, 4)
+            if layout == "awq":
+                k, n = qw.shape[0], qw.shape[1] * 8
+                qw = ops.awq_marlin_repack(qw.contiguous(), k, n, 4)
+                qz = ops.awq_repack_zeros(qz.contiguous(), n)
+            else:
+                k8, n = qw.shape
+                qw = ops.gptq_marlin_repack(qw.contiguous(), empty, k8 * 8, n, 4)
             if interleave:
                 qw, qz, sc = ops.interleave_gate_up(qw, qz, sc)
             return qw, qz.contiguous(), sc.contiguous()
@@ -107,3 +117,177 @@ def fused_wna16_moe(hidden_states: torch.Tensor, experts: Wna16Experts, gating_o
     slabs, _ = ops.wna16_gemm_grouped(act, m_pad, experts.inter, qw, qz, sc, expert_ids, post_pad,
                                       experts.zero_offset, "slabs")
     return ops.moe_combine(slabs, inv, topk_weights.contiguous(), hidden_states.dtype)
+
+
+# --------------------------------------------------------------------------------------------------
+# the layer + quant-method seam (modeling/layers/fused_moe/layer.py:22-35, 146-300)
+# --------------------------------------------------------------------------------------------------
+class FusedMoEMethodBase(QuantizeMethodBase):
+    """What a FusedMoE layer delegates to (layer.py:22-35): same two entry points as the reference."""
+
+    @abc.abstractmethod
+    def create_weights(self, layer: nn.Module, num_experts: int, hidden_size: int, intermediate_size: int,
+                       params_dtype: torch.dtype, **extra_weight_attrs):
+        raise NotImplementedError
+
+    @abc.abstractmethod
+    def apply(self, layer: nn.Module, x: torch.Tensor, router_logits: torch.Tensor, top_k: int,
+              renormalize: bool, use_grouped_topk: bool = False) -> torch.Tensor:
+        raise NotImplementedError
+
+
+class Wna16MoEMethod(FusedMoEMethodBase):
+    """GPTQ / AWQ int4 experts through the grouped CDNA4 GEMM -- the FusedMoEMethodBase the reference
+    lacks for these formats (it runs ``mixtral_quant.py``'s per-expert loop).  Parameters are the
+    checkpoint tensors stacked over experts, [w1 | w3] merged along N:
+
+        gptq   w13_qweight [E, H/8, 2I]   w13_qzeros [E, H/g, 2I/8]   w13_scales [E, H/g, 2I]
+               w2_qweight  [E, I/8, H]    w2_qzeros  [E, I/g, H/8]    w2_scales  [E, I/g, H]
+        awq    w13_qweight [E, H, 2I/8]   ... (N packed)              w2_qweight [E, I, H/8]
+
+    with I the per-rank intermediate size (w1/w3 column-parallel, w2 row-parallel: every rank streams
+    1/TP of every active expert -- balanced at decode, unlike expert-parallel placement).  After loading
+    they are re-laid once into ``Wna16Experts`` (K-packed, gate/up interleaved) and dropped."""
+
+    def __init__(self, layout: str, group_size: int, desc_act: bool = False):
+        if layout not in ("gptq", "awq"):
+            raise ValueError(f"unknown int4 expert layout {layout}")
+        if desc_act:
+            raise NotImplementedError("act-order (desc_act) GPTQ experts are not supported by the grouped kernel")
+        self.layout, self.group_size = layout, group_size
+
+    def create_weights(self, layer: nn.Module, num_experts: int, hidden_size: int, intermediate_size: int,
+                       params_dtype: torch.dtype, **extra_weight_attrs):
+        loader = extra_weight_attrs.get("weight_loader")
+        g = self.group_size if self.group_size != -1 else None
+        e, h, i = num_experts, hidden_size, intermediate_size
+        if g is None or h % g or i % g or i % 8 or h % 8:
+            raise ValueError(f"group size {self.group_size} must divide hidden {h} and the per-rank intermediate "
+                             f"size {i} (too large a tensor-parallel size?)")
+
+        def reg(name, shape, dtype, in_dim, out_dim, packed_dim=None):
+            layer.register_parameter(name, _param(torch.empty(shape, dtype=dtype), input_dim=in_dim,
+                                                  output_dim=out_dim, packed_dim=packed_dim,
+                                                  pack_factor=8 if packed_dim is not None else None,
+                                                  weight_loader=loader))
+        # dims are those of ONE expert's [K.., N..] tensor (the expert axis is indexed away first)
+        if self.layout == "gptq":
+            reg("w13_qweight", (e, h // 8, 2 * i), torch.int32, 0, 1, 0)
+            reg("w2_qweight", (e, i // 8, h), torch.int32, 0, 1, 0)
+            reg("w13_g_idx", (e, h), torch.int32, 0, None)
+            reg("w2_g_idx", (e, i), torch.int32, 0, None)
+        else:
+            reg("w13_qweight", (e, h, 2 * i // 8), torch.int32, 0, 1, 1)
+            reg("w2_qweight", (e, i, h // 8), torch.int32, 0, 1, 1)
+        reg("w13_qzeros", (e, h // g, 2 * i // 8), torch.int32, 0, 1, 1)
+        reg("w13_scales", (e, h // g, 2 * i), params_dtype, 0, 1)
+        reg("w2_qzeros", (e, i // g, h // 8), torch.int32, 0, 1, 1)
+        reg("w2_scales", (e, i // g, h), params_dtype, 0, 1)
+        layer.experts_packed = None
+
+    def process_weights_after_loading(self, layer: nn.Module) -> None:
+        e = layer.w13_qweight.shape[0]
+        if self.layout == "gptq":
+            for name in ("w13_g_idx", "w2_g_idx"):      # desc_act = False: rows must be in group order
+                gi = getattr(layer, name).data
+                k = gi.shape[1]
+                k0 = layer.tp_rank * k if name == "w2_g_idx" else 0
+                want = ((torch.arange(k, device=gi.device) + k0) // self.group_size).to(gi.dtype)
+                if not torch.equal(gi, want.expand_as(gi)):
+                    raise ValueError(f"{name}: act-order g_idx found in a checkpoint declared desc_act=false")
+        sets13 = [(layer.w13_qweight.data[x], layer.w13_qzeros.data[x], layer.w13_scales.data[x]) for x in range(e)]
+        sets2 = [(layer.w2_qweight.data[x], layer.w2_qzeros.data[x], layer.w2_scales.data[x]) for x in range(e)]
+        layer.experts_packed = Wna16Experts(sets13, sets2, zero_offset=1 if self.layout == "gptq" else 0,
+                                            layout=self.layout)
+        for name in ("w13_qweight", "w13_qzeros", "w13_scales", "w2_qweight", "w2_qzeros", "w2_scales",
+                     "w13_g_idx", "w2_g_idx"):
+            if hasattr(layer, name):
+                delattr(layer, name)
+
+    def apply(self, layer: nn.Module, x: torch.Tensor, router_logits: torch.Tensor, top_k: int,
+              renormalize: bool, use_grouped_topk: bool = False) -> torch.Tensor:
+        if use_grouped_topk:
+            raise NotImplementedError("grouped top-k routing (DeepSeek-V2) is outside the hot path")
+        if layer.experts_packed is None:
+            raise RuntimeError("FusedMoE: process_weights_after_loading has not run")
+        topk_weights, topk_ids = fused_topk(x, router_logits, top_k, renormalize)
+        if getattr(layer, "record_routing", False):     # measurement aid: which experts a step touched
+            layer.last_topk_ids = topk_ids
+        return fused_wna16_moe(x, layer.experts_packed, router_logits, top_k, renormalize,
+                               topk_weights=topk_weights, topk_ids=topk_ids)
+
+
+class FusedMoE(nn.Module):
+    """modeling/layers/fused_moe/layer.py:146-300 for quantised experts: owns the stacked expert
+    parameters, shards them over the TP group (intermediate dimension) and optionally all-reduces."""
+
+    SHARDS = ("w1", "w2", "w3")
+
+    def __init__(self, num_experts: int, top_k: int, hidden_size: int, intermediate_size: int,
+                 params_dtype: torch.dtype = torch.float16, reduce_results: bool = False, renormalize: bool = True,
+                 quant_config=None, tp_size: Optional[int] = None, prefix: str = ""):
+        super().__init__()
+        from .distributed import get_tensor_model_parallel_rank, get_tensor_model_parallel_world_size
+        self.tp_size = tp_size if tp_size is not None else get_tensor_model_parallel_world_size()
+        self.tp_rank = get_tensor_model_parallel_rank() if self.tp_size > 1 else 0
+        if intermediate_size % self.tp_size != 0:
+            raise ValueError(f"intermediate size {intermediate_size} is not divisible by tensor parallel size "
+                             f"{self.tp_size}")
+        self.num_experts, self.top_k = num_experts, top_k
+        self.hidden_size = hidden_size
+        self.intermediate_size_per_partition = intermediate_size // self.tp_size
+        self.reduce_results, self.renormalize = reduce_results, renormalize
+        if quant_config is None:
+            raise NotImplementedError("unquantised experts are outside the hot path (SURVEY 8f row 2: quantised MoE)")
+        self.quant_method = quant_config.get_quant_method(self, prefix)
+        if not isinstance(self.quant_method, FusedMoEMethodBase):
+            raise NotImplementedError(f"{type(quant_config).__name__} has no FusedMoE method")
+        self.quant_method.create_weights(layer=self, num_experts=num_experts, hidden_size=hidden_size,
+                                         intermediate_size=self.intermediate_size_per_partition,
+                                         params_dtype=params_dtype, weight_loader=self.weight_loader)
+
+    def weight_loader(self, param: nn.Parameter, loaded_weight: torch.Tensor, weight_name: str, shard_id: str,
+                      expert_id: int) -> None:
+        """One checkpoint tensor of one expert -> its slot.  w1 / w3 are cut along their output
+        dimension (this rank's slice lands in the first / second half of the merged w13 parameter),
+        w2 along its input dimension; packing follows the parameter's ``packed_dim``."""
+        if shard_id not in self.SHARDS:
+            raise ValueError(f"shard_id must be ['w1','w2','w3'] but got {shard_id}.")
+        if not 0 <= expert_id < self.num_experts:
+            raise ValueError(f"{weight_name}: expert {expert_id} out of range")
+        data = param.data[expert_id]
+        in_dim, out_dim = getattr(param, "input_dim", None), getattr(param, "output_dim", None)
+        if shard_id == "w2":
+            if in_dim is not None and self.tp_size > 1:
+                size = data.shape[in_dim]
+                loaded_weight = loaded_weight.narrow(in_dim, self.tp_rank * size, size)
+            dst = data
+        elif out_dim is None:                      # replicated per-expert metadata (g_idx of w1 / w3)
+            dst = data
+        else:
+            half = data.shape[out_dim] // 2
+            loaded_weight = loaded_weight.narrow(out_dim, self.tp_rank * half, half)
+            dst = data.narrow(out_dim, 0 if shard_id == "w1" else half, half)
+        if dst.shape != loaded_weight.shape:
+            raise ValueError(f"{weight_name}: checkpoint tensor {tuple(loaded_weight.shape)} does not fit "
+                             f"parameter slice {tuple(dst.shape)}")
+        dst.copy_(loaded_weight)
+
+    @classmethod
+    def make_expert_params_mapping(cls, ckpt_gate_proj_name: str, ckpt_down_proj_name: str,
+                                   ckpt_up_proj_name: str, num_experts: int) -> List[Tuple[str, str, int, str]]:
+        """(param_name_prefix, checkpoint_name_prefix, expert_id, shard_id) rows (layer.py:449-468)."""
+        rows = []
+        for expert in range(num_experts):
+            for shard, ckpt in (("w1", ckpt_gate_proj_name), ("w2", ckpt_down_proj_name),
+                                ("w3", ckpt_up_proj_name)):
+                fused = "experts.w13_" if shard in ("w1", "w3") else "experts.w2_"
+                rows.append((fused, f"experts.{expert}.{ckpt}.", expert, shard))
+        return rows
+
+    def forward(self, hidden_states: torch.Tensor, router_logits: torch.Tensor) -> torch.Tensor:
+        out = self.quant_method.apply(self, hidden_states, router_logits, self.top_k, self.renormalize)
+        if self.reduce_results and self.tp_size > 1:
+            from .distributed import tensor_model_parallel_all_reduce
+            out = tensor_model_parallel_all_reduce(out)
+        return out

@@ -54,7 +54,10 @@ class AWQConfig(QuantizationConfig):
         return cls(weight_bits, group_size, zero_point,
                    prepack=os.environ.get("APHRODITE_AWQ_NO_PREPACK", "0") != "1")
 
-    def get_quant_method(self, layer: nn.Module, prefix: str) -> Optional["AWQLinearMethod"]:
+    def get_quant_method(self, layer: nn.Module, prefix: str):
+        if type(layer).__name__ == "FusedMoE":     # int4 experts: grouped CDNA4 GEMM (moe.py)
+            from ..moe import Wna16MoEMethod
+            return Wna16MoEMethod("awq", self.group_size)
         return AWQLinearMethod(self)
 
     def get_scaled_act_names(self) -> List[str]:

@@ -56,7 +56,10 @@ class GPTQConfig(QuantizationConfig):
         lm_head_quantized = cls.get_from_keys_or(config, ["lm_head"], default=False)
         return cls(weight_bits, group_size, desc_act, lm_head_quantized)
 
-    def get_quant_method(self, layer: nn.Module, prefix: str) -> Optional["GPTQLinearMethod"]:
+    def get_quant_method(self, layer: nn.Module, prefix: str):
+        if type(layer).__name__ == "FusedMoE":     # int4 experts: grouped CDNA4 GEMM (moe.py)
+            from ..moe import Wna16MoEMethod
+            return Wna16MoEMethod("gptq", self.group_size, self.desc_act)
         return GPTQLinearMethod(self)
 
     def get_scaled_act_names(self) -> List[str]:

@@ -42,6 +42,8 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--model", default="llama3-8b", choices=["llama3-8b", "mixtral-8x7b"],
+                    help="mixtral-8x7b: BASELINE configs[4] (int4 experts through the grouped GEMM); gptq / awq only")
     ap.add_argument("--quant", default="gptq", choices=["gptq", "fp8", "awq", "fp8ct"],
                     help="fp8: per-tensor W8A8 (Fp8Config); fp8ct: compressed-tensors W8A8, per-token x per-channel")
     ap.add_argument("--kv-cache-dtype", default="auto", choices=["auto", "fp8", "fp8_e5m2"])
@@ -59,9 +61,12 @@ def build(args, device):
     from aphrodite_engine_amd.quantization.awq import AWQConfig
     from aphrodite_engine_amd.quantization.fp8 import Fp8Config
     from aphrodite_engine_amd.quantization.gptq import GPTQConfig
-    cfg = M.LLAMA3_8B
+    import dataclasses
+    cfg = M.LLAMA3_8B if args.model == "llama3-8b" else M.MIXTRAL_8X7B
+    if args.model == "mixtral-8x7b" and args.quant not in ("gptq", "awq"):
+        raise SystemExit("--model mixtral-8x7b runs int4 experts: --quant gptq or awq")
     if args.layers:
-        cfg = M.LlamaConfig(num_hidden_layers=args.layers)
+        cfg = dataclasses.replace(cfg, num_hidden_layers=args.layers)
     if args.quant == "gptq":
         qc = GPTQConfig(4, 128, False)
     elif args.quant == "awq":
@@ -156,7 +161,32 @@ def roofline_section(model, loop, args):
     out = {}
 
     fast = all(l.fused_decode_ok(bs) for l in layers) and getattr(model, "use_fused_decode", False)
-    for name in ("gate_up_proj", "down_proj", "qkv_proj", "o_proj"):
+    dense_names = ("gate_up_proj", "down_proj", "qkv_proj", "o_proj")
+    if layers[0].is_moe:
+        # the sparse MLP as the decode step runs it: router GEMM, top-k softmax, align, gather-pack, the two
+        # grouped int4 GEMMs, combine.  Real routing of random activations: at bs 32, top-2 of 8 every expert
+        # is active, so the algorithmic bytes are all experts' weights (+ router, + activations).
+        dense_names = ("qkv_proj", "o_proj")
+        xin = torch.randn(bs, model.cfg.hidden_size, device="cuda", dtype=model.dtype)
+
+        def run_moe():
+            for layer in layers:
+                layer.moe_block(xin)
+        ex = layers[0].experts.experts_packed
+        for layer in layers:
+            layer.experts.record_routing = True
+        run_moe()
+        torch.cuda.synchronize()
+        active = sum(int(torch.unique(l.experts.last_topk_ids).numel()) for l in layers) / len(layers)
+        for layer in layers:
+            layer.experts.record_routing = False
+        eb = sum(t.numel() * t.element_size() for t in ex.w13 + ex.w2) * active / ex.num_experts \
+            + layers[0].moe_gate.numel() * 2 + 2 * bs * model.cfg.hidden_size * 2
+        t = measure_kernel(run_moe, len(layers))
+        out["moe_block"] = dict(kernel="sparse MLP block: router + topk_softmax + moe_align + gather_pack + "
+                                       "wna16 grouped GEMM x2 + combine (seconds = whole block, not one launch)",
+                                bytes=eb, seconds=t, active_experts=active)
+    for name in dense_names:
         lin0 = getattr(layers[0], name)
         xin = torch.randn(bs, lin0.in_features, device="cuda", dtype=model.dtype)
         if fast:
@@ -341,6 +371,17 @@ def main():
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             elapsed = float(tmax.item())
         ctx_end = int(loop.meta.seq_lens_tensor[0].item())
+        active_frac = 1.0
+        if cfg.num_local_experts:
+            # experts the decode step really routes to (one more eager step with the routing recorded)
+            for layer in model.layers:
+                layer.experts.record_routing = True
+            loop.step()
+            torch.cuda.synchronize()
+            active_frac = sum(int(torch.unique(l.experts.last_topk_ids).numel()) for l in model.layers) \
+                / (len(model.layers) * cfg.num_local_experts)
+            for layer in model.layers:
+                layer.experts.record_routing = False
         roof = roofline_section(model, loop, args) if rank == 0 else None
 
     if rank != 0:
@@ -352,7 +393,7 @@ def main():
     tokens = args.batch * args.steps * replicas
     ms_per_step = elapsed / args.steps * 1e3
     # step-level algorithmic bytes
-    w_bytes = model.weight_bytes_per_layer() * cfg.num_hidden_layers
+    w_bytes = model.weight_bytes_per_layer(active_frac) * cfg.num_hidden_layers
     lm_head = model.lm_head.numel() * 2
     esz = 1 if args.kv_cache_dtype != "auto" else 2
     ctx_mid = (args.ctx + args.warmup + 2 + ctx_end) / 2.0
@@ -384,7 +425,8 @@ def main():
                   "fp8ct": "fp8-e4m3 x fp8-e4m3 (fp32 accumulate)"}[args.quant],
         "data": "synthetic (random-init weights in the real GPTQ/FP8 formats, random token ids, random-permutation block tables)",
         "config": {
-            "workload": f"Llama-3-8B {args.quant.upper()} {'W8A8' if args.quant.startswith('fp8') else '4-bit g128'}, greedy decode, "
+            "workload": f"{'Llama-3-8B' if args.model == 'llama3-8b' else 'Mixtral-8x7B (top-2 of 8 experts)'} "
+                        f"{args.quant.upper()} {'W8A8' if args.quant.startswith('fp8') else '4-bit g128'}, greedy decode, "
                         f"bs={args.batch}/GPU, context {args.ctx}->{ctx_end}, kv_cache={args.kv_cache_dtype}, "
                         f"block_size=16, HIP-graph={'off' if args.no_graph else 'on'}",
             "global_batch": args.batch * replicas,
@@ -392,17 +434,19 @@ def main():
             "parallelism": f"{args.parallelism}{world}",
             "layers": cfg.num_hidden_layers,
         },
-        "step_hbm": {"algorithmic_bytes": step_bytes, "achieved_GBps": step_bytes / (elapsed / args.steps) / 1e9,
+        "step_hbm": {"active_expert_fraction": active_frac, "algorithmic_bytes": step_bytes, "achieved_GBps": step_bytes / (elapsed / args.steps) / 1e9,
                      "frac_of_peak": step_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS},
         "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "bytes_per_launch": dom["bytes"], "avg_launch_us": dom["seconds"] * 1e6},
         "roofline_all": {k: {"GBps": v["bytes"] / v["seconds"] / 1e9, "frac": v["bytes"] / v["seconds"] / 1e9 / HBM_PEAK_GBS,
-                             "bytes": v["bytes"], "avg_us": v["seconds"] * 1e6} for k, v in roof.items()},
+                             "bytes": v["bytes"], "avg_us": v["seconds"] * 1e6,
+                             **({"active_experts": v["active_experts"]} if "active_experts" in v else {})}
+                         for k, v in roof.items()},
     }
     if args.layers:
         line["config"]["INVALID"] = "debug run with fewer layers"
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline and args.model == "llama3-8b":
         try:
             line["cpu_baseline"] = cpu_baseline(args, cfg)
         except Exception as e:  # never lose the GPU number to a CPU-side problem

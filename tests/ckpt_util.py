@@ -30,6 +30,9 @@ def hf_config(cfg, extra=None):
          "num_attention_heads": cfg.num_attention_heads, "num_key_value_heads": cfg.num_key_value_heads,
          "vocab_size": cfg.vocab_size, "rms_norm_eps": cfg.rms_norm_eps, "rope_theta": cfg.rope_theta,
          "max_position_embeddings": cfg.max_position_embeddings, "tie_word_embeddings": False}
+    if cfg.num_local_experts:
+        d.update({"architectures": ["MixtralForCausalLM"], "model_type": "mixtral",
+                  "num_local_experts": cfg.num_local_experts, "num_experts_per_tok": cfg.num_experts_per_tok})
     d.update(extra or {})
     return d
 
@@ -65,7 +68,17 @@ def write_checkpoint(path, cfg, fmt, seed=0, group_size=128, kv_scales=None, fp8
             tensors[base + nm + ".weight"] = torch.from_numpy(
                 rng.random(cfg.hidden_size).astype(np.float32) + 0.5).half()
         tensors[base + "self_attn.rotary_emb.inv_freq"] = torch.zeros(4)      # must be skipped
-        for proj, (ki, ni) in PROJS.items():
+        projs = dict(PROJS)
+        if cfg.num_local_experts:     # Mixtral: sparse MLP -- router + experts.{e}.w1 (gate) / w3 (up) / w2 (down)
+            for p in ("mlp.gate_proj", "mlp.up_proj", "mlp.down_proj"):
+                del projs[p]
+            for e in range(cfg.num_local_experts):
+                projs[f"block_sparse_moe.experts.{e}.w1"] = ("h", "i")
+                projs[f"block_sparse_moe.experts.{e}.w3"] = ("h", "i")
+                projs[f"block_sparse_moe.experts.{e}.w2"] = ("i", "h")
+            tensors[base + "block_sparse_moe.gate.weight"] = torch.from_numpy(
+                (rng.standard_normal((cfg.num_local_experts, cfg.hidden_size)) * 0.1).astype(np.float32)).half()
+        for proj, (ki, ni) in projs.items():
             K, N = dims[ki], dims[ni]
             w = (rng.standard_normal((K, N)) * 0.05).astype(np.float32)        # [K, N] = weight.T
             name = base + proj

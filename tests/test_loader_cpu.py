@@ -190,6 +190,48 @@ def test_compressed_tensors_pack_quantized(tmp_path):
                 np.testing.assert_array_equal(lin.weight_scale.numpy().T, es[mod], err_msg=mod)
 
 
+@pytest.mark.parametrize("fmt", ["gptq", "awq"])
+def test_mixtral_int4_experts(tmp_path, fmt):
+    """Mixtral-style checkpoint: router replicated, experts.{e}.w1/w3 column-cut into the two halves of
+    the stacked w13 parameters, w2 row-cut (FusedMoE.weight_loader)."""
+    cfg = M.TINY_MOE
+    truth = CU.write_checkpoint(str(tmp_path), cfg, fmt, seed=21)
+    lg, t = truth["logical"], truth["tensors"]
+    inter = cfg.intermediate_size
+    unpack = oq.gptq_unpack if fmt == "gptq" else oq.awq_unpack
+    for rank, world in [(0, 1), (0, 2), (1, 2), (3, 4)]:
+        m = build(tmp_path, fmt, rank, world)
+        cols = np.arange(rank * inter // world, (rank + 1) * inter // world)
+        for li, layer in enumerate(m.layers):
+            assert layer.is_moe and layer.gate_up_proj is None
+            assert torch.equal(layer.moe_gate.data, t[f"model.layers.{li}.block_sparse_moe.gate.weight"])
+            ex = layer.experts
+            for e in range(cfg.num_local_experts):
+                base = f"model.layers.{li}.block_sparse_moe.experts.{e}."
+                w1, w3, w2 = lg[base + "w1"], lg[base + "w3"], lg[base + "w2"]
+                np.testing.assert_array_equal(unpack(ex.w13_qweight[e].numpy()),
+                                              np.concatenate([w1["q"][:, cols], w3["q"][:, cols]], 1))
+                np.testing.assert_array_equal(ex.w13_scales[e].numpy(),
+                                              np.concatenate([w1["s"][:, cols], w3["s"][:, cols]], 1))
+                np.testing.assert_array_equal(unpack(ex.w2_qweight[e].numpy()), w2["q"][cols, :])
+                g0, g1 = cols[0] // 128, (cols[-1] + 1) // 128
+                np.testing.assert_array_equal(ex.w2_scales[e].numpy(), w2["s"][g0:g1])
+                z13 = np.concatenate([w1["zp"][:, cols], w3["zp"][:, cols]], 1)
+                if fmt == "gptq":
+                    np.testing.assert_array_equal(oq.unpack_cols(ex.w13_qzeros[e].numpy()), (z13 - 1) & 15)
+                    np.testing.assert_array_equal(oq.unpack_cols(ex.w2_qzeros[e].numpy()),
+                                                  (w2["zp"][g0:g1] - 1) & 15)
+                    np.testing.assert_array_equal(ex.w2_g_idx[e].numpy(), cols // 128)
+                else:
+                    np.testing.assert_array_equal(oq.awq_unpack(ex.w13_qzeros[e].numpy()), z13)
+                    np.testing.assert_array_equal(oq.awq_unpack(ex.w2_qzeros[e].numpy()), w2["zp"][g0:g1])
+        # attention projections of the same checkpoint go through the dense plans
+        eq = col_sets(rank, world)["qkv"]
+        got = unpack(m.layers[0].qkv_proj.qweight.numpy())
+        exp = np.concatenate([lg["model.layers.0." + p]["q"][:, c] for p, c in eq], 1)
+        np.testing.assert_array_equal(got, exp)
+
+
 @pytest.mark.parametrize("fused", [False, True])
 def test_unquantised_checkpoint_and_fused_on_disk(tmp_path, fused):
     truth = CU.write_checkpoint(str(tmp_path), CFG, "fp16", seed=5, fused_on_disk=fused)
