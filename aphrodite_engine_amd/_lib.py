@@ -38,6 +38,19 @@ SIGNATURES = {
     "aphro_silu_and_mul_quant_fp8": (I, [P, P, P, P, L, I, I, P]),
     "aphro_paged_attention_rope_packed_scaled": (I, [P, P, P, I, P, P, P, P, P, P, P, I, I, I, I, F, P, P,
                                                      I, I, I, P, L, L, I, I, F, F, P]),
+    "aphro_custom_ar_meta_size": (L, []),
+    "aphro_ipc_handle_bytes": (I, []),
+    "aphro_custom_ar_alloc_shared": (I, [P, Z]),
+    "aphro_custom_ar_free_shared": (I, [P]),
+    "aphro_ipc_get_mem_handle": (I, [P, P, P]),
+    "aphro_custom_ar_init": (I, [P, P, P, P, P, Z, P, P, P, Z, I, I]),
+    "aphro_custom_ar_dispose": (I, [P]),
+    "aphro_custom_ar_register_buffer": (I, [P, P, P, P]),
+    "aphro_custom_ar_should_one_shot": (I, [I, Z]),
+    "aphro_custom_ar_all_reduce": (I, [P, P, P, L, I, P, Z, P]),
+    "aphro_custom_ar_get_graph_buffer_ipc_meta": (I, [P, P, P, I, P]),
+    "aphro_custom_ar_register_graph_buffers": (I, [P, P, P, I]),
+    "aphro_custom_ar_error": (I, [P]),
     "aphro_advance_step_flashattn": (I, [I, I, I, P, P, P, P, P, P, L, P]),
     "aphro_argmax_rows": (I, [P, P, L, L, L, I, P]),
     "aphro_topk_softmax": (I, [P, P, P, P, L, I, I, P]),

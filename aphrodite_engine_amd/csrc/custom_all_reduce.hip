@@ -1,0 +1,520 @@
+// Tensor-parallel sum all-reduce over xGMI peer access -- the `_C_custom_ar::*` role (SURVEY a14;
+// reference: kernels/custom_all_reduce.cu + custom_all_reduce.cuh, compiled OUT of its ROCm build,
+// torch_bindings.cpp:506-536).  One process per GPU; every rank maps every peer's buffers through
+// HIP IPC and reads them directly over the point-to-point xGMI links.
+//
+// Shapes on the hot path: [M, hidden] f16/bf16 after o_proj and down_proj -- 256 KiB (8B, bs 32) to
+// 1 MiB (70B, bs 64), twice per layer.  At these sizes a ring is latency bound (2(N-1) hops); here
+//   one-shot  : every rank reads all N inputs and sums them itself      (1 hop,  N x bytes per rank)
+//   two-shot  : reduce-scatter then all-gather through peer reads       (2 hops, 2 x bytes per rank)
+// xGMI is point to point (one link per peer pair), so in one-shot every link carries `bytes` once in
+// each direction concurrently -- the cost is one link transfer, not N.
+//
+// MI355X-specific decisions (none of this is in the reference's CUDA design):
+//  * flags live in UNCACHED fine-grained device memory (hipDeviceMallocUncached) and are accessed
+//    with system-scope relaxed atomics: no release/acquire fences, because a system-scope release on
+//    gfx9 writes back the whole L2 (measured: +16 us per launch for an agent-scope fence);
+//    ordering comes from `s_waitcnt vmcnt(0)` between the data accesses and the flag store;
+//  * peer data is read with `sc0 sc1` (system-coherent) loads so that a line cached by an earlier
+//    call can never be served stale; two-shot partial sums go to an uncached (MTYPE UC) region, whose
+//    stores bypass the L2, and are complete once `s_waitcnt vmcnt(0)` returns;
+//  * the sum runs over ranks 0..N-1 in the same order on every rank (fp32 accumulate): all ranks
+//    hold bit-identical results, which the greedy-decode parity tests rely on;
+//  * barriers spin a bounded number of times and then raise an error word the host can read
+//    (aphro_custom_ar_error) instead of hanging the GPU;
+//  * per-block call counters live on the device, so a captured launch replays correctly in a HIP graph.
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+namespace aphro {
+
+constexpr int AR_MAX_RANKS = 8;
+constexpr int AR_MAX_BLOCKS = 64;
+constexpr int AR_THREADS = 512;
+constexpr int64_t AR_TICKS_PER_MS = 100000;   // wall_clock64(): 100 MHz constant clock
+
+struct ArSignal {                       // one per rank, IPC-mapped by every peer
+  uint32_t start[AR_MAX_BLOCKS][AR_MAX_RANKS];   // start[b][r] written by rank r's block b
+  uint32_t mid[AR_MAX_BLOCKS][AR_MAX_RANKS];
+  uint32_t end[AR_MAX_BLOCKS][AR_MAX_RANKS];
+  uint32_t counter[AR_MAX_BLOCKS];      // local: calls so far, per block
+  uint32_t error;                       // local: a barrier timed out
+  uint32_t pad[63];
+};
+
+struct ArPeers {                        // one logical buffer as seen from this rank (device memory)
+  const void* ptr[AR_MAX_RANKS];
+};
+
+struct ArParams {
+  ArSignal* sig[AR_MAX_RANKS];          // every rank's signal area (own one included)
+  const ArPeers* in;                    // inputs of all ranks
+  ArPeers scratch;                      // two-shot partial sums of all ranks (uncached)
+  void* out;
+  int64_t nvec;                         // 16-byte vectors
+  int64_t timeout_ticks;                // a barrier waits this long for a peer, then raises `error`
+  int rank, world;
+};
+
+__device__ __forceinline__ void st_sys(uint32_t* p, uint32_t v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ uint32_t ld_sys(const uint32_t* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// System-coherent (sc0 sc1) 16-byte loads.  The wait for the data sits INSIDE the asm statement: an
+// asm output counts as available the moment the statement ends, so with a separate `s_waitcnt` the
+// compiler is free to move the destination registers before the data has arrived (seen: address
+// arithmetic left in the low half of element 0).
+__device__ __forceinline__ u32x4 ld_peer(const void* p) {
+  u32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
+  return v;
+}
+// one input vector from every rank, all loads in flight together (one per xGMI link), one wait
+template <int W>
+__device__ __forceinline__ void ld_peers(u32x4 (&v)[W], const struct ArPeers& in, int64_t i);
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// All ranks' block `b` meet.  which: 0 start, 1 mid, 2 end.  `val` is this call's ticket.
+__device__ __forceinline__ void ar_barrier(const ArParams& p, int which, uint32_t val) {
+  wait_vm();                     // my earlier loads / stores have completed before I tell anyone
+  __syncthreads();
+  const int b = blockIdx.x;
+  if ((int)threadIdx.x < p.world) {
+    const int r = threadIdx.x;
+    ArSignal* peer = p.sig[r];
+    ArSignal* self = p.sig[p.rank];
+    uint32_t* dst = which == 0 ? &peer->start[b][p.rank] : which == 1 ? &peer->mid[b][p.rank] : &peer->end[b][p.rank];
+    const uint32_t* src = which == 0 ? &self->start[b][r] : which == 1 ? &self->mid[b][r] : &self->end[b][r];
+    st_sys(dst, val);
+    const int64_t t0 = (int64_t)wall_clock64();
+    while ((int32_t)(ld_sys(src) - val) < 0) {            // wrap-safe "not yet"
+      __builtin_amdgcn_s_sleep(2);
+      if ((int64_t)wall_clock64() - t0 > p.timeout_ticks) {   // bounded: an absent peer is an error, not a hang
+        st_sys(&self->error, 1u);
+        break;
+      }
+    }
+  }
+  __syncthreads();
+}
+
+template <typename T>
+__device__ __forceinline__ void acc8(float (&a)[8], u32x4 v) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    a[2 * i] += T::to_f32((uint16_t)(v[i] & 0xffffu));
+    a[2 * i + 1] += T::to_f32((uint16_t)(v[i] >> 16));
+  }
+}
+template <>
+__device__ __forceinline__ void acc8<Float>(float (&a)[8], u32x4 v) {
+  // whole-vector bit cast: casting ONE element of an ext-vector reads element [0] (hipcc bug)
+  const f32x4 f = __builtin_bit_cast(f32x4, v);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) a[i] += f[i];
+}
+template <typename T>
+__device__ __forceinline__ u32x4 pack8(const float (&a)[8]) {
+  u32x4 r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    r[i] = (uint32_t)T::from_f32(a[2 * i]) | ((uint32_t)T::from_f32(a[2 * i + 1]) << 16);
+  return r;
+}
+template <>
+__device__ __forceinline__ u32x4 pack8<Float>(const float (&a)[8]) {
+  const f32x4 f = {a[0], a[1], a[2], a[3]};
+  return __builtin_bit_cast(u32x4, f);
+}
+
+template <>
+__device__ __forceinline__ void ld_peers<2>(u32x4 (&v)[2], const ArPeers& in, int64_t i) {
+    asm volatile("global_load_dwordx4 %0, %2, off sc0 sc1\n\tglobal_load_dwordx4 %1, %3, off sc0 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1])
+                 : "v"((const u32x4*)in.ptr[0] + i), "v"((const u32x4*)in.ptr[1] + i)
+                 : "memory");
+}
+template <>
+__device__ __forceinline__ void ld_peers<4>(u32x4 (&v)[4], const ArPeers& in, int64_t i) {
+    asm volatile("global_load_dwordx4 %0, %4, off sc0 sc1\n\tglobal_load_dwordx4 %1, %5, off sc0 sc1\n\tglobal_load_dwordx4 %2, %6, off sc0 sc1\n\tglobal_load_dwordx4 %3, %7, off sc0 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])
+                 : "v"((const u32x4*)in.ptr[0] + i), "v"((const u32x4*)in.ptr[1] + i), "v"((const u32x4*)in.ptr[2] + i), "v"((const u32x4*)in.ptr[3] + i)
+                 : "memory");
+}
+template <>
+__device__ __forceinline__ void ld_peers<6>(u32x4 (&v)[6], const ArPeers& in, int64_t i) {
+    asm volatile("global_load_dwordx4 %0, %6, off sc0 sc1\n\tglobal_load_dwordx4 %1, %7, off sc0 sc1\n\tglobal_load_dwordx4 %2, %8, off sc0 sc1\n\tglobal_load_dwordx4 %3, %9, off sc0 sc1\n\tglobal_load_dwordx4 %4, %10, off sc0 sc1\n\tglobal_load_dwordx4 %5, %11, off sc0 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5])
+                 : "v"((const u32x4*)in.ptr[0] + i), "v"((const u32x4*)in.ptr[1] + i), "v"((const u32x4*)in.ptr[2] + i), "v"((const u32x4*)in.ptr[3] + i), "v"((const u32x4*)in.ptr[4] + i), "v"((const u32x4*)in.ptr[5] + i)
+                 : "memory");
+}
+template <>
+__device__ __forceinline__ void ld_peers<8>(u32x4 (&v)[8], const ArPeers& in, int64_t i) {
+    asm volatile("global_load_dwordx4 %0, %8, off sc0 sc1\n\tglobal_load_dwordx4 %1, %9, off sc0 sc1\n\tglobal_load_dwordx4 %2, %10, off sc0 sc1\n\tglobal_load_dwordx4 %3, %11, off sc0 sc1\n\tglobal_load_dwordx4 %4, %12, off sc0 sc1\n\tglobal_load_dwordx4 %5, %13, off sc0 sc1\n\tglobal_load_dwordx4 %6, %14, off sc0 sc1\n\tglobal_load_dwordx4 %7, %15, off sc0 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+                 : "v"((const u32x4*)in.ptr[0] + i), "v"((const u32x4*)in.ptr[1] + i), "v"((const u32x4*)in.ptr[2] + i), "v"((const u32x4*)in.ptr[3] + i), "v"((const u32x4*)in.ptr[4] + i), "v"((const u32x4*)in.ptr[5] + i), "v"((const u32x4*)in.ptr[6] + i), "v"((const u32x4*)in.ptr[7] + i)
+                 : "memory");
+}
+
+template <typename T, int WORLD>
+__device__ __forceinline__ u32x4 reduce_vec(const ArPeers& in, int64_t i) {
+  u32x4 v[WORLD];
+  ld_peers<WORLD>(v, in, i);
+  float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int r = 0; r < WORLD; ++r) acc8<T>(a, v[r]);    // rank order: identical bits on every rank
+  return pack8<T>(a);
+}
+
+template <typename T, int WORLD>
+__global__ __launch_bounds__(AR_THREADS) void ar_one_shot_kernel(ArParams p) {
+  __shared__ uint32_t ticket;
+  if (threadIdx.x == 0) {
+    ArSignal* self = p.sig[p.rank];
+    ticket = self->counter[blockIdx.x] + 1;
+    self->counter[blockIdx.x] = ticket;
+  }
+  __syncthreads();
+  const uint32_t val = ticket;
+  ar_barrier(p, 0, val);                                  // every peer's input is in place
+  const ArPeers in = *p.in;
+  for (int64_t i = (int64_t)blockIdx.x * AR_THREADS + threadIdx.x; i < p.nvec; i += (int64_t)gridDim.x * AR_THREADS)
+    ((u32x4*)p.out)[i] = reduce_vec<T, WORLD>(in, i);
+  ar_barrier(p, 2, val);                                  // nobody still reads my input when I return
+}
+
+template <typename T, int WORLD>
+__global__ __launch_bounds__(AR_THREADS) void ar_two_shot_kernel(ArParams p) {
+  __shared__ uint32_t ticket;
+  if (threadIdx.x == 0) {
+    ArSignal* self = p.sig[p.rank];
+    ticket = self->counter[blockIdx.x] + 1;
+    self->counter[blockIdx.x] = ticket;
+  }
+  __syncthreads();
+  const uint32_t val = ticket;
+  const int64_t part = (p.nvec + WORLD - 1) / WORLD;
+  const int64_t lo = part * p.rank, hi = lo + part < p.nvec ? lo + part : p.nvec;
+  ar_barrier(p, 0, val);
+  const ArPeers in = *p.in;
+  u32x4* mine = (u32x4*)p.scratch.ptr[p.rank];
+  for (int64_t i = lo + (int64_t)blockIdx.x * AR_THREADS + threadIdx.x; i < hi; i += (int64_t)gridDim.x * AR_THREADS) {
+    const u32x4 s = reduce_vec<T, WORLD>(in, i);
+    ((u32x4*)p.out)[i] = s;
+    mine[i] = s;        // uncached (MTYPE UC) memory: the store goes through to HBM; peers gather it in shot 2
+  }
+  ar_barrier(p, 1, val);                                  // (waits for the write-through stores first)
+#pragma unroll
+  for (int rr = 1; rr < WORLD; ++rr) {
+    const int r = (p.rank + rr) % WORLD;                  // start with a different peer on every rank
+    const int64_t rlo = part * r, rhi = rlo + part < p.nvec ? rlo + part : p.nvec;
+    const u32x4* theirs = (const u32x4*)p.scratch.ptr[r];
+    for (int64_t i = rlo + (int64_t)blockIdx.x * AR_THREADS + threadIdx.x; i < rhi; i += (int64_t)gridDim.x * AR_THREADS) {
+      ((u32x4*)p.out)[i] = ld_peer(theirs + i);
+    }
+  }
+  ar_barrier(p, 2, val);
+}
+
+// ---------------------------------------------------------------------------------------------------
+struct IpcKey {
+  char b[sizeof(hipIpcMemHandle_t)];
+  bool operator<(const IpcKey& o) const { return memcmp(b, o.b, sizeof(b)) < 0; }
+};
+
+struct CustomAr {
+  int rank = 0, world = 0;
+  ArSignal* sig[AR_MAX_RANKS] = {};
+  ArPeers scratch = {};
+  size_t scratch_bytes = 0;
+  ArPeers* d_slots = nullptr;           // device array of registered buffers' peer pointers
+  int slot_cap = 0, slot_used = 0;
+  std::map<const void*, int> registered;            // local base pointer -> slot
+  std::vector<const void*> graph_unreg;             // inputs seen while capturing, slots reserved in order
+  std::map<IpcKey, void*> opened;
+  void* own_signal = nullptr;
+  void* own_scratch = nullptr;
+  int64_t timeout_ticks = 10000 * AR_TICKS_PER_MS;   // APHRODITE_CUSTOM_AR_TIMEOUT_MS, default 10 s
+
+  void* open_peer(const char* handle) {
+    IpcKey k;
+    memcpy(k.b, handle, sizeof(k.b));
+    auto it = opened.find(k);
+    if (it != opened.end()) return it->second;
+    hipIpcMemHandle_t h;
+    memcpy(&h, handle, sizeof(h));
+    void* p = nullptr;
+    if (hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) {
+      (void)hipGetLastError();
+      return nullptr;
+    }
+    opened[k] = p;
+    return p;
+  }
+};
+
+static int fill_peers(CustomAr* fa, const void* local, const char* handles, const int64_t* offsets, ArPeers* out) {
+  for (int r = 0; r < fa->world; ++r) {
+    if (r == fa->rank) {
+      out->ptr[r] = local;
+    } else {
+      char* base = (char*)fa->open_peer(handles + (size_t)r * sizeof(hipIpcMemHandle_t));
+      if (!base) {
+        set_error("custom_ar: cannot open the IPC handle of rank %d", r);
+        return APHRO_ERR_INVALID;
+      }
+      out->ptr[r] = base + offsets[r];
+    }
+  }
+  return APHRO_OK;
+}
+
+}  // namespace aphro
+
+using namespace aphro;
+
+extern "C" int64_t aphro_custom_ar_meta_size() { return (int64_t)sizeof(ArSignal); }
+
+extern "C" int aphro_ipc_handle_bytes() { return (int)sizeof(hipIpcMemHandle_t); }
+
+// Peer-visible, uncached device memory (signals, two-shot scratch): zero-filled.
+extern "C" int aphro_custom_ar_alloc_shared(void** ptr, size_t bytes) {
+  APHRO_CHECK(ptr != nullptr && bytes > 0, "custom_ar: bad allocation request");
+  void* p = nullptr;
+  hipError_t e = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    set_error("custom_ar: hipExtMallocWithFlags(%zu, uncached) failed: %s", bytes, hipGetErrorString(e));
+    return APHRO_ERR_LAUNCH;
+  }
+  e = hipMemset(p, 0, bytes);
+  if (e != hipSuccess) {
+    (void)hipFree(p);
+    set_error("custom_ar: hipMemset failed: %s", hipGetErrorString(e));
+    return APHRO_ERR_LAUNCH;
+  }
+  (void)hipDeviceSynchronize();
+  *ptr = p;
+  return APHRO_OK;
+}
+
+extern "C" int aphro_custom_ar_free_shared(void* ptr) {
+  if (ptr) (void)hipFree(ptr);
+  return APHRO_OK;
+}
+
+// IPC handle of the allocation that contains `ptr` + the offset of `ptr` inside it
+// (what torch's storage._share_cuda_() hands the reference: custom_all_reduce.py:193-199).
+extern "C" int aphro_ipc_get_mem_handle(const void* ptr, char* handle_out, int64_t* offset_out) {
+  APHRO_CHECK(ptr && handle_out && offset_out, "ipc_get_mem_handle: NULL argument");
+  hipDeviceptr_t base = nullptr;
+  size_t size = 0;
+  hipError_t e = hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)ptr);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    set_error("ipc_get_mem_handle: hipMemGetAddressRange failed: %s", hipGetErrorString(e));
+    return APHRO_ERR_LAUNCH;
+  }
+  hipIpcMemHandle_t h;
+  e = hipIpcGetMemHandle(&h, (void*)base);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    set_error("ipc_get_mem_handle: hipIpcGetMemHandle failed: %s", hipGetErrorString(e));
+    return APHRO_ERR_LAUNCH;
+  }
+  memcpy(handle_out, &h, sizeof(h));
+  *offset_out = (int64_t)((const char*)ptr - (const char*)base);
+  return APHRO_OK;
+}
+
+// init_custom_ar: `signal` / `scratch` are this rank's aphro_custom_ar_alloc_shared areas (meta_size
+// and scratch_bytes big), `*_handles` = world x aphro_ipc_handle_bytes() bytes in rank order with
+// their offsets, `rank_data` = device memory for `rank_data_bytes / 64` registered-buffer slots.
+extern "C" int aphro_custom_ar_init(void** fa_out, void* signal, const char* signal_handles,
+                                    const int64_t* signal_offsets, void* scratch, size_t scratch_bytes,
+                                    const char* scratch_handles, const int64_t* scratch_offsets, void* rank_data,
+                                    size_t rank_data_bytes, int rank, int world) {
+  APHRO_CHECK(fa_out && signal && scratch && rank_data, "custom_ar_init: NULL argument");
+  APHRO_CHECK(world >= 2 && world <= AR_MAX_RANKS && world % 2 == 0, "custom_ar: world size %d not in {2,4,6,8}", world);
+  APHRO_CHECK(rank >= 0 && rank < world, "custom_ar: invalid rank %d", rank);
+  APHRO_CHECK(rank_data_bytes >= sizeof(ArPeers) && scratch_bytes % 16 == 0, "custom_ar: bad buffer sizes");
+  CustomAr* fa = new CustomAr();
+  fa->rank = rank; fa->world = world;
+  fa->own_signal = signal; fa->own_scratch = scratch; fa->scratch_bytes = scratch_bytes;
+  if (const char* ms = getenv("APHRODITE_CUSTOM_AR_TIMEOUT_MS")) {
+    long v = atol(ms);
+    if (v > 0) fa->timeout_ticks = (int64_t)v * AR_TICKS_PER_MS;
+  }
+  fa->d_slots = (ArPeers*)rank_data;
+  fa->slot_cap = (int)(rank_data_bytes / sizeof(ArPeers));
+  ArPeers sp;
+  int rc = fill_peers(fa, signal, signal_handles, signal_offsets, &sp);
+  if (rc == APHRO_OK) rc = fill_peers(fa, scratch, scratch_handles, scratch_offsets, &fa->scratch);
+  if (rc != APHRO_OK) {
+    delete fa;
+    return rc;
+  }
+  for (int r = 0; r < world; ++r) fa->sig[r] = (ArSignal*)sp.ptr[r];
+  *fa_out = fa;
+  return APHRO_OK;
+}
+
+extern "C" int aphro_custom_ar_dispose(void* fa_) {
+  CustomAr* fa = (CustomAr*)fa_;
+  if (!fa) return APHRO_OK;
+  for (auto& kv : fa->opened) (void)hipIpcCloseMemHandle(kv.second);
+  delete fa;
+  return APHRO_OK;
+}
+
+// register_buffer: a user buffer every rank allocated at the same point (handles of all ranks).
+extern "C" int aphro_custom_ar_register_buffer(void* fa_, const void* local_ptr, const char* handles,
+                                               const int64_t* offsets) {
+  CustomAr* fa = (CustomAr*)fa_;
+  APHRO_CHECK(fa && local_ptr && handles && offsets, "custom_ar_register_buffer: NULL argument");
+  APHRO_CHECK(fa->slot_used < fa->slot_cap, "custom_ar: rank_data is full (%d buffers)", fa->slot_cap);
+  ArPeers pe = {};
+  int rc = fill_peers(fa, local_ptr, handles, offsets, &pe);
+  if (rc != APHRO_OK) return rc;
+  APHRO_CHECK(hipMemcpy(fa->d_slots + fa->slot_used, &pe, sizeof(pe), hipMemcpyHostToDevice) == hipSuccess,
+              "custom_ar: hipMemcpy of the peer table failed");
+  fa->registered[local_ptr] = fa->slot_used++;
+  return APHRO_OK;
+}
+
+extern "C" int aphro_custom_ar_should_one_shot(int world, size_t bytes) {
+  // one link transfer of `bytes` vs two transfers of bytes / world plus a second flag round trip
+  if (world <= 2) return 1;
+  return bytes <= (world <= 4 ? 512u * 1024u : 256u * 1024u);
+}
+
+// all_reduce_reg (reg_buffer == NULL: `inp` itself is registered, or -- while the stream is capturing
+// -- gets a slot that aphro_custom_ar_register_graph_buffers fills after the capture) and
+// all_reduce_unreg (reg_buffer = a registered staging buffer: copy, then reduce).
+extern "C" int aphro_custom_ar_all_reduce(void* fa_, const void* inp, void* out, int64_t numel, int dtype,
+                                          void* reg_buffer, size_t reg_buffer_bytes, void* stream) {
+  CustomAr* fa = (CustomAr*)fa_;
+  hipStream_t st = (hipStream_t)stream;
+  APHRO_CHECK(fa && inp && out, "custom_ar_all_reduce: NULL argument");
+  APHRO_CHECK(dtype == APHRO_F16 || dtype == APHRO_BF16 || dtype == APHRO_F32, "custom_ar: unsupported dtype %d", dtype);
+  const size_t esz = dtype == APHRO_F32 ? 4 : 2;
+  const size_t bytes = (size_t)numel * esz;
+  APHRO_CHECK(bytes % 16 == 0 && ((uintptr_t)inp % 16) == 0 && ((uintptr_t)out % 16) == 0,
+              "custom all reduce currently requires input length to be multiple of 16 bytes");
+  if (numel == 0) return APHRO_OK;
+  const void* src = inp;
+  if (reg_buffer != nullptr) {
+    APHRO_CHECK(bytes <= reg_buffer_bytes, "custom_ar: registered buffer is too small (%zu > %zu)", bytes, reg_buffer_bytes);
+    APHRO_CHECK(hipMemcpyAsync(reg_buffer, inp, bytes, hipMemcpyDeviceToDevice, st) == hipSuccess,
+                "custom_ar: staging copy failed");
+    src = reg_buffer;
+  }
+  int slot = -1;
+  auto it = fa->registered.find(src);
+  if (it != fa->registered.end()) {
+    slot = it->second;
+  } else {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(st, &cs);
+    if (cs != hipStreamCaptureStatusActive) {
+      set_error("custom_ar: buffer address %p is not registered!", src);
+      return APHRO_ERR_INVALID;
+    }
+    APHRO_CHECK(fa->slot_used + (int)fa->graph_unreg.size() < fa->slot_cap, "custom_ar: rank_data is full");
+    slot = fa->slot_used + (int)fa->graph_unreg.size();    // filled by register_graph_buffers
+    fa->graph_unreg.push_back(src);
+  }
+  const bool one_shot = aphro_custom_ar_should_one_shot(fa->world, bytes) != 0;
+  APHRO_CHECK(one_shot || bytes <= fa->scratch_bytes, "custom_ar: %zu bytes exceed the two-shot scratch", bytes);
+  ArParams p;
+  for (int r = 0; r < AR_MAX_RANKS; ++r) p.sig[r] = fa->sig[r];
+  p.in = fa->d_slots + slot; p.scratch = fa->scratch; p.out = out;
+  p.nvec = (int64_t)(bytes / 16); p.rank = fa->rank; p.world = fa->world;
+  p.timeout_ticks = fa->timeout_ticks;
+  int64_t work = one_shot ? p.nvec : (p.nvec + fa->world - 1) / fa->world;
+  int blocks = (int)((work + AR_THREADS - 1) / AR_THREADS);
+  blocks = blocks < 1 ? 1 : (blocks > AR_MAX_BLOCKS ? AR_MAX_BLOCKS : blocks);
+#define AR_LAUNCH(TT, W)                                                                                     \
+  {                                                                                                          \
+    if (one_shot) hipLaunchKernelGGL((ar_one_shot_kernel<TT, W>), dim3(blocks), dim3(AR_THREADS), 0, st, p);   \
+    else hipLaunchKernelGGL((ar_two_shot_kernel<TT, W>), dim3(blocks), dim3(AR_THREADS), 0, st, p);           \
+  }
+#define AR_WORLD(TT)                                                                  \
+  switch (fa->world) {                                                               \
+    case 2: AR_LAUNCH(TT, 2) break;                                                   \
+    case 4: AR_LAUNCH(TT, 4) break;                                                   \
+    case 6: AR_LAUNCH(TT, 6) break;                                                   \
+    default: AR_LAUNCH(TT, 8) break;                                                  \
+  }
+  if (dtype == APHRO_F16) AR_WORLD(Half)
+  else if (dtype == APHRO_BF16) AR_WORLD(BFloat)
+  else AR_WORLD(Float)
+#undef AR_WORLD
+#undef AR_LAUNCH
+  APHRO_LAUNCH_CHECK();
+  return APHRO_OK;
+}
+
+// get_graph_buffer_ipc_meta: handles + offsets of the inputs recorded while capturing (count of them
+// in *count; cap = room in the output arrays, in buffers).
+extern "C" int aphro_custom_ar_get_graph_buffer_ipc_meta(void* fa_, char* handles_out, int64_t* offsets_out, int cap,
+                                                         int* count) {
+  CustomAr* fa = (CustomAr*)fa_;
+  APHRO_CHECK(fa && count, "custom_ar_get_graph_buffer_ipc_meta: NULL argument");
+  const int n = (int)fa->graph_unreg.size();
+  *count = n;
+  if (handles_out == nullptr) return APHRO_OK;          // size query
+  APHRO_CHECK(cap >= n, "custom_ar: %d graph buffers, room for %d", n, cap);
+  for (int i = 0; i < n; ++i) {
+    int rc = aphro_ipc_get_mem_handle(fa->graph_unreg[i], handles_out + (size_t)i * sizeof(hipIpcMemHandle_t),
+                                      offsets_out + i);
+    if (rc != APHRO_OK) return rc;
+  }
+  return APHRO_OK;
+}
+
+// register_graph_buffers: handles[r][i], offsets[r][i] (rank-major) for the `count` recorded inputs.
+extern "C" int aphro_custom_ar_register_graph_buffers(void* fa_, const char* handles, const int64_t* offsets, int count) {
+  CustomAr* fa = (CustomAr*)fa_;
+  APHRO_CHECK(fa, "custom_ar_register_graph_buffers: NULL handle");
+  APHRO_CHECK(count == (int)fa->graph_unreg.size(), "custom_ar: %d graph buffers recorded, %d registered",
+              (int)fa->graph_unreg.size(), count);
+  const size_t hb = sizeof(hipIpcMemHandle_t);
+  std::vector<char> hrow((size_t)fa->world * hb);
+  std::vector<int64_t> orow(fa->world);
+  for (int i = 0; i < count; ++i) {
+    for (int r = 0; r < fa->world; ++r) {
+      memcpy(hrow.data() + r * hb, handles + ((size_t)r * count + i) * hb, hb);
+      orow[r] = offsets[(size_t)r * count + i];
+    }
+    ArPeers pe = {};
+    int rc = fill_peers(fa, fa->graph_unreg[i], hrow.data(), orow.data(), &pe);
+    if (rc != APHRO_OK) return rc;
+    APHRO_CHECK(hipMemcpy(fa->d_slots + fa->slot_used, &pe, sizeof(pe), hipMemcpyHostToDevice) == hipSuccess,
+                "custom_ar: hipMemcpy of the peer table failed");
+    fa->registered[fa->graph_unreg[i]] = fa->slot_used++;
+  }
+  fa->graph_unreg.clear();
+  return APHRO_OK;
+}
+
+// 1 if a barrier of this rank ever timed out (the results of that call are garbage); clears it.
+extern "C" int aphro_custom_ar_error(void* fa_) {
+  CustomAr* fa = (CustomAr*)fa_;
+  if (!fa) return 0;
+  ArSignal* s = (ArSignal*)fa->own_signal;
+  uint32_t e = 0;
+  if (hipMemcpy(&e, &s->error, sizeof(e), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  if (e) {
+    uint32_t z = 0;
+    (void)hipMemcpy(&s->error, &z, sizeof(z), hipMemcpyHostToDevice);
+  }
+  return (int)e;
+}

@@ -16,6 +16,7 @@ import torch.distributed as dist
 _TP_GROUP: Optional[dist.ProcessGroup] = None
 _TP_RANK = 0
 _TP_SIZE = 1
+_CUSTOM_AR = None      # CustomAllreduce of the TP group (enable_custom_all_reduce)
 
 
 def init_tensor_parallel(tp_size: int, backend: Optional[str] = None) -> None:
@@ -39,8 +40,34 @@ def init_tensor_parallel(tp_size: int, backend: Optional[str] = None) -> None:
 
 
 def destroy_tensor_parallel() -> None:
-    global _TP_GROUP, _TP_RANK, _TP_SIZE
-    _TP_GROUP, _TP_RANK, _TP_SIZE = None, 0, 1
+    global _TP_GROUP, _TP_RANK, _TP_SIZE, _CUSTOM_AR
+    if _CUSTOM_AR is not None:
+        _CUSTOM_AR.close()
+    _TP_GROUP, _TP_RANK, _TP_SIZE, _CUSTOM_AR = None, 0, 1, None
+
+
+def enable_custom_all_reduce(device, cpu_group: Optional[dist.ProcessGroup] = None, max_size: int = 8192 * 1024):
+    """Attach the xGMI peer-access all-reduce to the TP group (GroupCoordinator.__init__,
+    parallel_state.py:186-196: ``ca_comm``).  ``cpu_group``: a non-NCCL group over the same ranks for
+    the one-off handle exchange (the reference's ``cpu_group``); made here (gloo) if omitted."""
+    global _CUSTOM_AR
+    if _TP_SIZE == 1:
+        return None
+    from .custom_all_reduce import CustomAllreduce
+    if cpu_group is None:
+        world = dist.get_world_size()
+        rank = dist.get_rank()
+        for start in range(0, world, _TP_SIZE):
+            ranks = list(range(start, start + _TP_SIZE))
+            grp = dist.new_group(ranks, backend="gloo")
+            if rank in ranks:
+                cpu_group = grp
+    _CUSTOM_AR = CustomAllreduce(cpu_group, device, max_size)
+    return _CUSTOM_AR
+
+
+def get_custom_all_reduce():
+    return _CUSTOM_AR
 
 
 @contextlib.contextmanager
@@ -68,6 +95,12 @@ def tensor_model_parallel_all_reduce(input_: torch.Tensor) -> torch.Tensor:
     """Sum over the TP group, in place (communication_op.py:9-12)."""
     if _TP_SIZE == 1:
         return input_
+    # GroupCoordinator.all_reduce (parallel_state.py:321-379): the peer-access kernel when eligible
+    # (out of place), else RCCL in place
+    if _CUSTOM_AR is not None and input_.is_cuda:
+        out = _CUSTOM_AR.custom_all_reduce(input_)
+        if out is not None:
+            return out
     dist.all_reduce(input_, group=_TP_GROUP)
     return input_
 

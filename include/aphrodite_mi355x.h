@@ -429,6 +429,49 @@ int aphro_paged_attention_rope_packed_scaled(void* out, void* out_packed, const 
                                              float k_scale, float v_scale, void* stream);
 
 /* ------------------------------------------------------------------------
+ * Tensor-parallel sum all-reduce through xGMI peer access -- the `_C_custom_ar::*` ops
+ * (kernels/torch_bindings.cpp:506-536, kernels/custom_all_reduce.cu; compiled out of the reference's
+ * ROCm build).  One process per GPU; buffers are exchanged as HIP IPC handles (64 opaque bytes each,
+ * aphro_ipc_handle_bytes()) gathered over any host-side channel.  Calls on one communicator must be
+ * issued in the same order with the same sizes on every rank.
+ * ---------------------------------------------------------------------- */
+int64_t aphro_custom_ar_meta_size(void);                       /* meta_size(): bytes of one signal area */
+int aphro_ipc_handle_bytes(void);
+/* zero-filled, peer-visible UNCACHED device memory for the signal area and the two-shot scratch */
+int aphro_custom_ar_alloc_shared(void** ptr, size_t bytes);
+int aphro_custom_ar_free_shared(void* ptr);
+/* IPC handle of the allocation containing ptr + ptr's offset in it (storage._share_cuda_() role) */
+int aphro_ipc_get_mem_handle(const void* ptr, char* handle_out, int64_t* offset_out);
+/* init_custom_ar(meta, rank_data, handles, offsets, rank, full_nvlink) -> fa.  *_handles: world
+ * handles in rank order (the entry of `rank` itself is ignored); rank_data: device memory holding
+ * one 64-byte peer table per registered buffer. */
+int aphro_custom_ar_init(void** fa_out, void* signal, const char* signal_handles,
+                         const int64_t* signal_offsets, void* scratch, size_t scratch_bytes,
+                         const char* scratch_handles, const int64_t* scratch_offsets, void* rank_data,
+                         size_t rank_data_bytes, int rank, int world);
+int aphro_custom_ar_dispose(void* fa);
+/* register_buffer(fa, t, handles, offsets) */
+int aphro_custom_ar_register_buffer(void* fa, const void* local_ptr, const char* handles,
+                                    const int64_t* offsets);
+/* 1: one-shot (every rank sums all inputs), 0: two-shot (reduce-scatter + all-gather) */
+int aphro_custom_ar_should_one_shot(int world, size_t bytes);
+/* all_reduce_reg(fa, inp, out) when reg_buffer == NULL (inp registered, or the stream is capturing
+ * and inp gets registered by register_graph_buffers afterwards); all_reduce_unreg(fa, inp,
+ * reg_buffer, out) otherwise.  dtype APHRO_F16 / BF16 / F32; bytes % 16 == 0.  Sum in rank order,
+ * fp32 accumulate: bit-identical on every rank. */
+int aphro_custom_ar_all_reduce(void* fa, const void* inp, void* out, int64_t numel, int dtype,
+                               void* reg_buffer, size_t reg_buffer_bytes, void* stream);
+/* get_graph_buffer_ipc_meta(fa) -> (handles, offsets); handles_out == NULL: only *count */
+int aphro_custom_ar_get_graph_buffer_ipc_meta(void* fa, char* handles_out, int64_t* offsets_out,
+                                              int cap, int* count);
+/* register_graph_buffers(fa, handles, offsets): rank-major [world][count] */
+int aphro_custom_ar_register_graph_buffers(void* fa, const char* handles, const int64_t* offsets,
+                                           int count);
+/* 1 if one of this rank's barriers timed out since the last query (bounded spin: a lost peer raises
+ * this instead of hanging the GPU) */
+int aphro_custom_ar_error(void* fa);
+
+/* ------------------------------------------------------------------------
  * Mixture of experts: routing, dispatch and the grouped W4A16 GEMM
  * ---------------------------------------------------------------------- */
 

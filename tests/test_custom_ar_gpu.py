@@ -1,0 +1,161 @@
+"""The xGMI peer-access all-reduce (`_C_custom_ar::*` role) on the one-GPU box: 2 and 4
+ranks share cuda:0, map each other's buffers through HIP IPC exactly as they would across GPUs, and
+the result is checked against the sum computed on the host (fp32 accumulate in rank order, the
+kernel's contract: bit-exact).  One-shot and two-shot sizes, repeated calls (barrier tickets),
+HIP-graph capture + replay with buffers registered after the capture, and the decode model end to end.
+Every wait in the kernel is bounded, every process is spawned with a join timeout."""
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def _spawn(fn, world, *args, timeout=150):
+    import os
+    import torch.multiprocessing as mp
+    os.environ["APHRODITE_CUSTOM_AR_TIMEOUT_MS"] = "3000"     # inherited by the workers: fail fast, never hang
+    import time
+    ctx = mp.spawn(fn, args=(world, _free_port()) + args, nprocs=world, join=False)
+    deadline = time.monotonic() + timeout
+    # ProcessContext.join returns once ONE more process has ended (True when all have; raises if one failed)
+    while not ctx.join(max(0.1, deadline - time.monotonic())):
+        if time.monotonic() > deadline:
+            for p in ctx.processes:          # exact children we started
+                if p.is_alive():
+                    p.kill()
+            pytest.fail("custom all-reduce workers did not finish in time")
+
+
+def _expected(parts, dtype):
+    acc = torch.zeros_like(parts[0], dtype=torch.float32)
+    for p in parts:                      # rank order, fp32 accumulate, one rounding
+        acc += p.float()
+    return acc.to(dtype)
+
+
+def _ar_worker(rank, world, port):
+    import torch.distributed as dist
+    from aphrodite_engine_amd.distributed.custom_all_reduce import CustomAllreduce
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    ca = CustomAllreduce(dist.group.WORLD, dev, max_size=4 * 1024 * 1024)
+    assert not ca.disabled
+    gen = torch.Generator(device="cpu")
+    try:
+        # numel chosen to hit one-shot (small), two-shot (large), ragged two-shot slices and fp32
+        for dtype, numel in [(torch.float16, 32 * 4096), (torch.bfloat16, 64 * 8192), (torch.float16, 8),
+                             (torch.float32, 3 * 1000 * 8), (torch.float16, 1024 * 1024), (torch.bfloat16, 7 * 8 * 123)]:
+            parts = []
+            for r in range(world):
+                gen.manual_seed(1000 * r + numel % 997)
+                parts.append((torch.randn(numel, generator=gen) * 3).to(dtype))
+            want = _expected(parts, dtype)
+            x = parts[rank].to(dev)
+            assert ca.should_custom_ar(x)
+            for it in range(6):          # same buffers again and again: tickets, stale-cache hazards
+                out = ca.custom_all_reduce(x)
+                assert out is not None and out.data_ptr() != x.data_ptr()
+                torch.cuda.synchronize()
+                ca.check()
+                got = out.cpu()
+                if not torch.equal(got, want):
+                    bad = (got != want).nonzero().flatten()
+                    raise AssertionError(f"{dtype} numel={numel} call {it} rank {rank}: {bad.numel()} wrong, first at "
+                                         f"{bad[:4].tolist()}: got {got[bad[:4]].tolist()} want {want[bad[:4]].tolist()} "
+                                         f"parts {[p[bad[:4]].tolist() for p in parts]}")
+                assert torch.equal(x.cpu(), parts[rank])            # input untouched
+        # changing contents between calls (what decode does)
+        x = torch.zeros(32 * 4096, dtype=torch.float16, device=dev)
+        for it in range(20):
+            x.fill_(float(rank + 1 + it))
+            out = ca.custom_all_reduce(x)
+            torch.cuda.synchronize()
+            assert float(out[0]) == sum(r + 1 + it for r in range(world)) and float(out[-1]) == float(out[0])
+        # ineligible inputs fall through to the caller's RCCL path
+        assert ca.custom_all_reduce(torch.zeros(7, dtype=torch.float16, device=dev)) is None
+        assert ca.custom_all_reduce(torch.zeros(8 * 1024 * 1024, dtype=torch.float16, device=dev)) is None
+        assert ca.custom_all_reduce(torch.zeros(64, dtype=torch.int32, device=dev)) is None
+        # HIP graph: inputs seen while capturing are registered after the capture, then replayed
+        a = torch.empty(32 * 4096, dtype=torch.float16, device=dev)
+        b = torch.empty(64 * 8192, dtype=torch.float16, device=dev)      # two-shot
+        g = torch.cuda.CUDAGraph()
+        with ca.capture():
+            for t_ in (a, b):
+                assert ca.custom_all_reduce(t_) is not None              # warm-up outside the capture: shape only
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s), torch.cuda.graph(g, stream=s):
+                oa = ca.custom_all_reduce(a)
+                ob = ca.custom_all_reduce(b * 2)                         # a graph-private temporary as input
+        for it in range(5):
+            a.fill_(rank + it)
+            b.fill_(0.5 * rank + it)
+            torch.cuda.synchronize()
+            dist.barrier()               # replay only once every rank has written its inputs
+            g.replay()
+            torch.cuda.synchronize()
+            ca.check()
+            assert float(oa[5]) == sum(r + it for r in range(world))
+            assert float(ob[-1]) == sum(2 * (0.5 * r + it) for r in range(world))
+            dist.barrier()
+    finally:
+        ca.close()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_custom_all_reduce_ranks_on_one_gpu(world):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    _spawn(_ar_worker, world)
+
+
+def _tp_model_worker(rank, world, port):
+    """TP = 2 decode with the peer-access all-reduce in the loop == the same model over gloo."""
+    import torch.distributed as dist
+    from aphrodite_engine_amd import distributed as D
+    from aphrodite_engine_amd import model as M
+    from aphrodite_engine_amd.quantization.gptq import GPTQConfig
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    D.init_tensor_parallel(world, backend="gloo")
+    cfg = M.LlamaConfig(hidden_size=1024, intermediate_size=4096, num_hidden_layers=2, num_attention_heads=8,
+                        num_key_value_heads=4, vocab_size=512, max_position_embeddings=1024)
+    with torch.no_grad():
+        m = M.LlamaForCausalLM(cfg, GPTQConfig(4, 128, False), torch.float16).init_synthetic(torch.device("cuda:0"))
+        meta, pos, nblocks = M.make_decode_metadata(8, [3, 17, 64, 200, 129, 5, 77, 31], 16, "cuda:0")
+        ids = torch.randint(0, cfg.vocab_size, (8, ), device="cuda:0",
+                            generator=torch.Generator(device="cuda:0").manual_seed(1))
+        outs = []
+        for custom in (False, True):
+            if custom:
+                ca = D.enable_custom_all_reduce(torch.device("cuda:0"))
+                assert ca is not None and not ca.disabled
+            caches = M.make_kv_caches(cfg, nblocks, 16, torch.float16, "auto", "cuda:0", seed=3)
+            outs.append(m(ids, pos, caches, meta).float())
+            torch.cuda.synchronize()
+        D.get_custom_all_reduce().check()
+        # gloo sums in its own order: the two paths agree to rounding, and with the custom kernel every
+        # rank holds the same bits
+        torch.testing.assert_close(outs[0], outs[1], atol=2e-2, rtol=2e-2)
+        gathered = [torch.empty_like(outs[1]) for _ in range(world)]
+        dist.all_gather(gathered, outs[1])
+        assert torch.equal(gathered[0], gathered[1])
+    D.destroy_tensor_parallel()
+    dist.destroy_process_group()
+
+
+def test_tp2_decode_with_custom_all_reduce():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    _spawn(_tp_model_worker, 2)
