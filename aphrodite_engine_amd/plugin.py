@@ -9,7 +9,11 @@ It (1) registers the torch.library ops so ``aphrodite._custom_ops`` resolves to 
 MI355X kernels, (2) swaps the quantization methods and prepends the CDNA4 mixed
 precision kernel, (3) leaves attention to the op level: the reference's
 ``ROCM_FLASH`` backend (selector.py:210-220) calls ``ops.paged_attention_rocm`` /
-``reshape_and_cache``, which are now ours.
+``reshape_and_cache``, which are now ours, and (4) puts the xGMI peer-access
+all-reduce where the reference's ROCm build has none: ``CustomAllreduce`` is swapped at the class
+level (distributed/device_communicators/custom_all_reduce.py:41 -- the ``_C_custom_ar`` ops are
+compiled out on ROCm, torch_bindings.cpp:506, so ``custom_ar`` is False there and the class
+disables itself), because its signal memory must be an uncached allocation a torch tensor cannot be.
 """
 
 
@@ -25,3 +29,9 @@ def register() -> None:
     from .quantization.kernels import register_with_reference as reg_kernels
     reg_methods(ref_q.QUANTIZATION_METHODS)
     reg_kernels(ref_k._POSSIBLE_KERNELS)
+    try:   # GroupCoordinator builds ``ca_comm = CustomAllreduce(group=cpu_group, device=...)`` (parallel_state.py:186-196)
+        import aphrodite.distributed.device_communicators.custom_all_reduce as ref_ca
+        from .distributed.custom_all_reduce import CustomAllreduce
+        ref_ca.CustomAllreduce = CustomAllreduce
+    except Exception:
+        pass
