@@ -331,6 +331,10 @@ def main():
     _lib.lib()  # fail loudly if the HIP library is missing
     tp = world if (args.parallelism == "tp" and world > 1) else 1
     D.init_tensor_parallel(tp)
+    ca = None
+    if tp > 1 and not os.environ.get("APHRO_NO_CUSTOM_AR"):
+        # xGMI peer-access all-reduce for the [M, hidden] sums (RCCL stays the fallback for ineligible sizes)
+        ca = D.enable_custom_all_reduce(device)
 
     model, cfg, dtype = build(args, device)
     total = args.warmup + args.steps + 4
@@ -343,14 +347,17 @@ def main():
         torch.cuda.synchronize()
         graph = None
         if not args.no_graph:
+            import contextlib
             graph = torch.cuda.CUDAGraph()
             s = torch.cuda.Stream()
             s.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(s):
-                loop.step()
-            torch.cuda.current_stream().wait_stream(s)
-            with torch.cuda.graph(graph):
-                loop.step()
+            # inputs of the all-reduces seen while capturing are registered with the peers afterwards
+            with (ca.capture() if ca is not None and not ca.disabled else contextlib.nullcontext()):
+                with torch.cuda.stream(s):
+                    loop.step()
+                torch.cuda.current_stream().wait_stream(s)
+                with torch.cuda.graph(graph):
+                    loop.step()
         run = graph.replay if graph is not None else loop.step
         for _ in range(args.warmup):
             run()
@@ -370,6 +377,8 @@ def main():
             tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             elapsed = float(tmax.item())
+        if ca is not None:
+            ca.check()      # a timed-out barrier would have produced garbage: fail loudly
         ctx_end = int(loop.meta.seq_lens_tensor[0].item())
         active_frac = 1.0
         if cfg.num_local_experts:
@@ -432,6 +441,7 @@ def main():
             "global_batch": args.batch * replicas,
             "seq_len": args.ctx,
             "parallelism": f"{args.parallelism}{world}",
+            "all_reduce": ("xGMI peer-access kernel" if ca is not None and not ca.disabled else "RCCL") if tp > 1 else None,
             "layers": cfg.num_hidden_layers,
         },
         "step_hbm": {"active_expert_fraction": active_frac, "algorithmic_bytes": step_bytes, "achieved_GBps": step_bytes / (elapsed / args.steps) / 1e9,
