@@ -97,6 +97,20 @@ __device__ __forceinline__ f32x2 fp8x2_to_f32(uint32_t word, bool hi) {
               : __builtin_amdgcn_cvt_pk_f32_fp8(word, false);
   }
 }
+// Two packed fp8 (low or high half of a dword) -> a packed pair of T in ONE instruction: gfx950's
+// v_cvt_scalef32_pk_{f16,bf16}_{fp8,bf8} with scale 1.0.  Exact (every e4m3 / e5m2 value, subnormals
+// included, is representable in f16 and in bf16), and 3-4x fewer VALU than fp8 -> f32 -> T.
+template <typename T, bool E5M2, bool HI>
+__device__ __forceinline__ uint32_t fp8x2_to_T(uint32_t w) {
+  if constexpr (__is_same(T, Half)) {
+    if constexpr (E5M2) return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_bf8(w, 1.0f, HI));
+    else return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w, 1.0f, HI));
+  } else {
+    if constexpr (E5M2) return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_bf8(w, 1.0f, HI));
+    else return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w, 1.0f, HI));
+  }
+}
+
 template <bool E5M2>
 __device__ __forceinline__ float fp8_to_f32(uint8_t b) {
   if constexpr (E5M2) return __builtin_amdgcn_cvt_f32_bf8((uint32_t)b, 0);

@@ -41,21 +41,10 @@ struct Fp8GemmParams {
 template <typename T>
 __device__ __forceinline__ u32x4 fp8x8_to_T(uint32_t w0, uint32_t w1) {
   u32x4 r;
-  if constexpr (__is_same(T, Half)) {
-    f32x2 a = __builtin_amdgcn_cvt_pk_f32_fp8(w0, false);
-    f32x2 b = __builtin_amdgcn_cvt_pk_f32_fp8(w0, true);
-    f32x2 c = __builtin_amdgcn_cvt_pk_f32_fp8(w1, false);
-    f32x2 d = __builtin_amdgcn_cvt_pk_f32_fp8(w1, true);
-    f16x2 h0 = {(f16)a[0], (f16)a[1]}, h1 = {(f16)b[0], (f16)b[1]};
-    f16x2 h2 = {(f16)c[0], (f16)c[1]}, h3 = {(f16)d[0], (f16)d[1]};
-    r[0] = __builtin_bit_cast(uint32_t, h0); r[1] = __builtin_bit_cast(uint32_t, h1);
-    r[2] = __builtin_bit_cast(uint32_t, h2); r[3] = __builtin_bit_cast(uint32_t, h3);
-  } else {
-    r[0] = f32x2_hi16(fp8_byte_to_f32<false, 0>(w0), fp8_byte_to_f32<false, 1>(w0));
-    r[1] = f32x2_hi16(fp8_byte_to_f32<false, 2>(w0), fp8_byte_to_f32<false, 3>(w0));
-    r[2] = f32x2_hi16(fp8_byte_to_f32<false, 0>(w1), fp8_byte_to_f32<false, 1>(w1));
-    r[3] = f32x2_hi16(fp8_byte_to_f32<false, 2>(w1), fp8_byte_to_f32<false, 3>(w1));
-  }
+  r[0] = fp8x2_to_T<T, false, false>(w0);
+  r[1] = fp8x2_to_T<T, false, true>(w0);
+  r[2] = fp8x2_to_T<T, false, false>(w1);
+  r[3] = fp8x2_to_T<T, false, true>(w1);
   return r;
 }
 

@@ -91,15 +91,8 @@ __device__ __forceinline__ uint32_t pack2(float a, float b) {
 template <typename T, bool E5M2>
 __device__ __forceinline__ u32x2 fp8x4_to_T(uint32_t w) {
   u32x2 r;
-  if constexpr (__is_same(T, Half)) {
-    f32x2 a = fp8x2_to_f32<E5M2>(w, false);
-    f32x2 b = fp8x2_to_f32<E5M2>(w, true);
-    r[0] = pack2<Half>(a[0], a[1]);
-    r[1] = pack2<Half>(b[0], b[1]);
-  } else {  // exact in bf16: keep the high 16 bits (per-byte converts, see f32x2_hi16)
-    r[0] = f32x2_hi16(fp8_byte_to_f32<E5M2, 0>(w), fp8_byte_to_f32<E5M2, 1>(w));
-    r[1] = f32x2_hi16(fp8_byte_to_f32<E5M2, 2>(w), fp8_byte_to_f32<E5M2, 3>(w));
-  }
+  r[0] = fp8x2_to_T<T, E5M2, false>(w);
+  r[1] = fp8x2_to_T<T, E5M2, true>(w);
   return r;
 }
 
