@@ -711,6 +711,46 @@ def paged_attention_rope_packed(qkv_slabs: torch.Tensor, positions: torch.Tensor
 
 
 # --------------------------------------------------------------------------
+# random sampling
+# --------------------------------------------------------------------------
+def sample_top_k_top_p(logits: torch.Tensor, temperature: Optional[torch.Tensor] = None,
+                       top_k: Optional[torch.Tensor] = None, top_p: Optional[torch.Tensor] = None,
+                       q: Optional[torch.Tensor] = None, seeds: Optional[torch.Tensor] = None,
+                       out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """temperature -> top-k -> top-p -> softmax -> argmax(probs / q) in one launch (sampler.py:256-262,
+    865-891, 1273-1292).  logits [B, V] f16 / bf16 / f32 (rows may be strided); per-row fp32
+    temperature / int32 top_k / fp32 top_p or None; q: Exp(1) draws [B, V] fp32 (``torch.empty_like
+    (...).exponential_()`` like the reference), or None with int64 ``seeds`` [B] to draw in the kernel.
+    Returns int64 [B]."""
+    _require_cuda(logits)
+    if logits.dim() != 2 or logits.stride(1) != 1:
+        raise RuntimeError("sample_top_k_top_p: logits must be [rows, vocab] with unit column stride")
+    rows, vocab = logits.shape
+    dev = logits.device
+
+    def prep(t_, dtype):
+        if t_ is None:
+            return None
+        if t_.dtype != dtype or not t_.is_contiguous() or t_.device != dev:
+            t_ = t_.to(device=dev, dtype=dtype).contiguous()
+        if t_.numel() != rows:
+            raise RuntimeError("sample_top_k_top_p: per-row parameters must have one entry per row")
+        return t_
+    temperature, top_k, top_p = prep(temperature, torch.float32), prep(top_k, torch.int32), prep(top_p, torch.float32)
+    seeds = prep(seeds, torch.int64)
+    if q is not None and (q.dtype != torch.float32 or q.shape != logits.shape or q.stride(1) != 1):
+        raise RuntimeError("sample_top_k_top_p: q must be float32 [rows, vocab]")
+    if q is None and seeds is None:
+        raise RuntimeError("sample_top_k_top_p: pass the Exp(1) noise q or per-row seeds")
+    if out is None:
+        out = torch.empty(rows, dtype=torch.int64, device=dev)
+    check(_lib.lib().aphro_sample_top_k_top_p(
+        out.data_ptr(), logits.data_ptr(), logits.stride(0), _ptr(temperature), _ptr(top_k), _ptr(top_p), _ptr(q),
+        q.stride(0) if q is not None else 0, _ptr(seeds), rows, vocab, _dt(logits), _stream()), "sample_top_k_top_p")
+    return out
+
+
+# --------------------------------------------------------------------------
 # FP8 (W8A8, per-token dynamic) decode fast path
 # --------------------------------------------------------------------------
 def fp8_gemm_ksplit(m: int, n: int, k: int) -> int:

@@ -50,6 +50,9 @@ def parse_args():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--ctx", type=int, default=1024, help="context length at the first timed step")
     ap.add_argument("--parallelism", default="dp", choices=["dp", "tp"])
+    ap.add_argument("--sampling", default="greedy", choices=["greedy", "random"],
+                    help="random: temperature 0.8, top-k 50, top-p 0.95 through the fused sampling kernel "
+                         "(in-kernel noise, per-row seeds advanced on the device) instead of argmax")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--layers", type=int, default=0, help="debug only: fewer layers (marks the line invalid)")
@@ -108,12 +111,24 @@ class DecodeLoop:
         self.input_ids = torch.randint(0, cfg.vocab_size, (args.batch, ), generator=g,
                                        device=device)
         self.next_ids = torch.zeros_like(self.input_ids)
+        self.sampling = args.sampling
+        if self.sampling == "random":
+            self.temperature = torch.full((args.batch, ), 0.8, device=device)
+            self.top_k = torch.full((args.batch, ), 50, dtype=torch.int32, device=device)
+            self.top_p = torch.full((args.batch, ), 0.95, device=device)
+            self.seeds = torch.arange(args.batch, dtype=torch.int64, device=device) * 1000003 + 17
 
     def step(self):
         m = self.meta
         hidden = self.model(self.input_ids, self.positions, self.kv_caches, m)
         logits = self.model.compute_logits(hidden)
-        self.model.sample_greedy(logits, self.next_ids)
+        if self.sampling == "random":
+            from aphrodite_engine_amd import _custom_ops as ops_
+            ops_.sample_top_k_top_p(logits, self.temperature, self.top_k, self.top_p, seeds=self.seeds,
+                                    out=self.next_ids)
+            self.seeds.add_(1)           # a fresh stream every step, also under graph replay
+        else:
+            self.model.sample_greedy(logits, self.next_ids)
         # advance: the generated token becomes the next input, context grows by one
         # (advance_step_flashattn, prepare_inputs/advance_step.cu: one launch instead of six)
         from aphrodite_engine_amd import _custom_ops as ops
@@ -435,7 +450,8 @@ def main():
         "data": "synthetic (random-init weights in the real GPTQ/FP8 formats, random token ids, random-permutation block tables)",
         "config": {
             "workload": f"{'Llama-3-8B' if args.model == 'llama3-8b' else 'Mixtral-8x7B (top-2 of 8 experts)'} "
-                        f"{args.quant.upper()} {'W8A8' if args.quant.startswith('fp8') else '4-bit g128'}, greedy decode, "
+                        f"{args.quant.upper()} {'W8A8' if args.quant.startswith('fp8') else '4-bit g128'}, decode, "
+                        f"{'greedy' if args.sampling == 'greedy' else 'random sampling (T 0.8, top-k 50, top-p 0.95)'}, "
                         f"bs={args.batch}/GPU, context {args.ctx}->{ctx_end}, kv_cache={args.kv_cache_dtype}, "
                         f"block_size=16, HIP-graph={'off' if args.no_graph else 'on'}",
             "global_batch": args.batch * replicas,

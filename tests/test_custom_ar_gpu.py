@@ -6,7 +6,6 @@ HIP-graph capture + replay with buffers registered after the capture, and the de
 Every wait in the kernel is bounded, every process is spawned with a join timeout."""
 import socket
 
-import numpy as np
 import pytest
 import torch
 

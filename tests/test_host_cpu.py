@@ -5,7 +5,6 @@ gloo with world_size 2."""
 import os
 import re
 
-import numpy as np
 import pytest
 import torch
 import torch.multiprocessing as mp
