@@ -43,6 +43,53 @@ __device__ __forceinline__ float load_logit(const void* base, int64_t i) {
   else return T::to_f32(((const uint16_t*)base)[i]);
 }
 
+// Visit every logit of the row as (index, logit / t).  VEC: 16-byte loads, four in flight per thread
+// before any is consumed (the scalar loop is latency bound: one dependent L2 round trip per element,
+// measured 630 us per launch at 32 x 128256); indices ascend within a thread.
+template <typename T, bool VEC, typename F>
+__device__ __forceinline__ void for_each_logit(const void* lrow, int V, float t, F&& f) {
+  const int tid = threadIdx.x;
+  const bool unit = t == 1.0f;                    // x / 1 == x: skip the IEEE division
+  if constexpr (VEC) {
+    constexpr int E = __is_same(T, Float) ? 4 : 8;   // elements per 16-byte vector
+    constexpr int UN = 4;
+    const int nvec = V / E;
+    for (int c0 = tid; c0 < nvec; c0 += SP_THREADS * UN) {
+      u32x4 v[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int c = c0 + u * SP_THREADS;
+        v[u] = c < nvec ? ((const u32x4*)lrow)[c] : u32x4{0u, 0u, 0u, 0u};
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int c = c0 + u * SP_THREADS;
+        if (c >= nvec) break;
+        if constexpr (__is_same(T, Float)) {
+          const f32x4 fv = __builtin_bit_cast(f32x4, v[u]);   // whole-vector cast (element casts are miscompiled)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) f(c * 4 + j, unit ? fv[j] : fv[j] / t);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float x = T::to_f32((uint16_t)(v[u][j >> 1] >> (16 * (j & 1))));
+            f(c * 8 + j, unit ? x : x / t);
+          }
+        }
+      }
+    }
+    for (int i = nvec * E + tid; i < V; i += SP_THREADS) {
+      const float x = load_logit<T>(lrow, i);
+      f(i, unit ? x : x / t);
+    }
+  } else {
+    for (int i = tid; i < V; i += SP_THREADS) {
+      const float x = load_logit<T>(lrow, i);
+      f(i, unit ? x : x / t);
+    }
+  }
+}
+
 // Exp(1) noise from a counter hash when the caller supplies none (splitmix64 finaliser, 24-bit uniform)
 __device__ __forceinline__ float exp_noise(int64_t seed, int i) {
   uint64_t z = (uint64_t)seed + 0x9E3779B97F4A7C15ull * (uint64_t)(i + 1);
@@ -55,8 +102,23 @@ __device__ __forceinline__ float exp_noise(int64_t seed, int i) {
 
 // wave 0: which digit does the running sum (from the top, or from the bottom) cross `target` in?
 // returns the digit and the sum accumulated BEFORE it.  W = u32 counts or u64 masses.
+// `hist` holds SP_SUB interleaved copies of every bin (lanes spread over them to cut same-address
+// serialisation of the LDS atomics: random-model logits share a handful of exponents); a bin's value
+// is the sum of its copies.
+constexpr int SP_SUB = 4;
+template <typename W>
+struct SubHist {
+  const W* h;
+  __device__ __forceinline__ W operator[](int b) const {
+    W s = 0;
+#pragma unroll
+    for (int j = 0; j < SP_SUB; ++j) s += h[b * SP_SUB + j];
+    return s;
+  }
+};
+
 template <typename W, bool FROM_TOP>
-__device__ __forceinline__ void pick_digit(const W* hist, int nbins, W before, W target, int* digit_out, W* before_out) {
+__device__ __forceinline__ void pick_digit(const SubHist<W> hist, int nbins, W before, W target, int* digit_out, W* before_out) {
   const int lane = threadIdx.x;                 // called by wave 0 only
   const int per = nbins / 64;                   // bins per lane, contiguous; lane 0 owns the FIRST bins walked
   W mine = 0;
@@ -122,10 +184,12 @@ __device__ __forceinline__ void pick_digit(const W* hist, int nbins, W before, W
   }
 }
 
-template <typename T>
+template <typename T, bool VEC>
 __global__ __launch_bounds__(SP_THREADS) void sample_kernel(SampleParams p) {
-  __shared__ uint32_t cnt[SP_BINS];
-  __shared__ unsigned long long mass[SP_BINS];
+  extern __shared__ __attribute__((aligned(16))) unsigned long long hist_raw[];   // SP_BINS * SP_SUB u64 (64 KiB)
+  unsigned long long* mass = hist_raw;
+  uint32_t* cnt = (uint32_t*)hist_raw;          // the count histogram reuses the same storage (top-k runs first)
+  const int sub = threadIdx.x & (SP_SUB - 1);
   __shared__ float redf[SP_THREADS / 64];
   __shared__ int redi[SP_THREADS / 64];
   __shared__ int sh_digit;
@@ -135,11 +199,10 @@ __global__ __launch_bounds__(SP_THREADS) void sample_kernel(SampleParams p) {
   const void* lrow = (const char*)p.logits + (size_t)row * p.row_stride * (__is_same(T, Float) ? 4 : 2);
   float t = p.temperature ? p.temperature[row] : 1.0f;
   if (t < 1e-5f) t = 1.0f;
-  auto xval = [&](int i) { return load_logit<T>(lrow, i) / t; };   // the same fp32 value in every pass
 
   // ---- pass 1: row maximum (it always survives both filters: the softmax shift) ------------------
   float mx = -INFINITY;
-  for (int i = tid; i < V; i += SP_THREADS) mx = __builtin_fmaxf(mx, xval(i));
+  for_each_logit<T, VEC>(lrow, V, t, [&](int, float x) { mx = __builtin_fmaxf(mx, x); });
   mx = wave_max(mx);
   if ((tid & 63) == 0) redf[tid >> 6] = mx;
   __syncthreads();
@@ -157,15 +220,16 @@ __global__ __launch_bounds__(SP_THREADS) void sample_kernel(SampleParams p) {
     for (int pass = 0; pass < 3; ++pass) {
       const int bits = pass == 2 ? 10 : 11;
       shift -= bits;
-      for (int b = tid; b < SP_BINS; b += SP_THREADS) cnt[b] = 0;
+      for (int b = tid; b < SP_BINS * SP_SUB; b += SP_THREADS) cnt[b] = 0;
       __syncthreads();
       const uint32_t hi_mask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + bits));
-      for (int i = tid; i < V; i += SP_THREADS) {
-        const uint32_t key = key_of(xval(i));
-        if ((key & hi_mask) == prefix) atomicAdd(&cnt[(key >> shift) & ((1u << bits) - 1)], 1u);
-      }
+      for_each_logit<T, VEC>(lrow, V, t, [&](int, float x) {
+        const uint32_t key = key_of(x);
+        if ((key & hi_mask) == prefix) atomicAdd(&cnt[((key >> shift) & ((1u << bits) - 1)) * SP_SUB + sub], 1u);
+      });
       __syncthreads();
-      if (tid < 64) pick_digit<uint32_t, true>(cnt, 1 << bits, before, (uint32_t)k, &sh_digit, &sh_cbefore);
+      if (tid < 64)
+        pick_digit<uint32_t, true>(SubHist<uint32_t>{cnt}, 1 << bits, before, (uint32_t)k, &sh_digit, &sh_cbefore);
       __syncthreads();
       prefix |= (uint32_t)sh_digit << shift;
       before = sh_cbefore;
@@ -183,22 +247,21 @@ __global__ __launch_bounds__(SP_THREADS) void sample_kernel(SampleParams p) {
     for (int pass = 0; pass < 3; ++pass) {
       const int bits = pass == 2 ? 10 : 11;
       shift -= bits;
-      for (int b = tid; b < SP_BINS; b += SP_THREADS) mass[b] = 0;
+      for (int b = tid; b < SP_BINS * SP_SUB; b += SP_THREADS) mass[b] = 0;
       __syncthreads();
       const uint32_t hi_mask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + bits));
-      for (int i = tid; i < V; i += SP_THREADS) {
-        const float x = xval(i);
+      for_each_logit<T, VEC>(lrow, V, t, [&](int, float x) {
         const uint32_t key = key_of(x);
         if (key >= kmin && (key & hi_mask) == prefix) {
           const unsigned long long f = (unsigned long long)((double)expf(x - mx) * 4294967296.0);
-          atomicAdd(&mass[(key >> shift) & ((1u << bits) - 1)], f);
+          atomicAdd(&mass[((key >> shift) & ((1u << bits) - 1)) * SP_SUB + sub], f);
         }
-      }
+      });
       __syncthreads();
       if (pass == 0) {                              // total mass of the top-k survivors -> the target
         if (tid < 64) {
           unsigned long long s = 0;
-          for (int b = tid; b < SP_BINS; b += 64) s += mass[b];
+          for (int b = tid; b < SP_BINS * SP_SUB; b += 64) s += mass[b];
 #pragma unroll
           for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d);
           if (tid == 0) sh_target = (unsigned long long)((1.0 - (double)pp) * (double)s);
@@ -206,7 +269,8 @@ __global__ __launch_bounds__(SP_THREADS) void sample_kernel(SampleParams p) {
         __syncthreads();
       }
       if (tid < 64)
-        pick_digit<unsigned long long, false>(mass, 1 << bits, before, sh_target, &sh_digit, &sh_mbefore);
+        pick_digit<unsigned long long, false>(SubHist<unsigned long long>{mass}, 1 << bits, before, sh_target, &sh_digit,
+                                              &sh_mbefore);
       __syncthreads();
       prefix |= (uint32_t)sh_digit << shift;
       before = sh_mbefore;
@@ -220,15 +284,14 @@ __global__ __launch_bounds__(SP_THREADS) void sample_kernel(SampleParams p) {
   int best_i = 0x7fffffff;
   const float* qrow = p.q ? p.q + (size_t)row * p.q_stride : nullptr;
   const int64_t seed = p.seeds ? p.seeds[row] : 0;
-  for (int i = tid; i < V; i += SP_THREADS) {
-    const float x = xval(i);
+  for_each_logit<T, VEC>(lrow, V, t, [&](int i, float x) {
     if (key_of(x) >= kmin) {
       const float e = expf(x - mx);
       const float qq = qrow ? qrow[i] : exp_noise(seed, i);
       const float s = e / qq;
       if (s > best) { best = s; best_i = i; }        // ascending i: first maximum wins inside the thread
     }
-  }
+  });
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) {
     const float ob = __shfl_xor(best, d);
@@ -260,9 +323,21 @@ extern "C" int aphro_sample_top_k_top_p(int64_t* out, const void* logits, int64_
   p.out = out; p.logits = logits; p.row_stride = row_stride; p.temperature = temperature; p.top_k = top_k;
   p.top_p = top_p; p.q = q; p.q_stride = q_stride; p.seeds = seeds; p.vocab = (int)vocab;
   dim3 grid((unsigned)rows), block(SP_THREADS);
-  if (dtype == APHRO_F16) hipLaunchKernelGGL((sample_kernel<Half>), grid, block, 0, (hipStream_t)stream, p);
-  else if (dtype == APHRO_BF16) hipLaunchKernelGGL((sample_kernel<BFloat>), grid, block, 0, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL((sample_kernel<Float>), grid, block, 0, (hipStream_t)stream, p);
+  const size_t esz = dtype == APHRO_F32 ? 4 : 2;
+  const bool vec = ((uintptr_t)logits % 16) == 0 && ((size_t)row_stride * esz) % 16 == 0;   // every row 16-byte aligned
+  const size_t lds = (size_t)SP_BINS * SP_SUB * sizeof(unsigned long long);
+#define SP_LAUNCH1(TT, VV)                                                                                  \
+  {                                                                                                         \
+    auto kern = sample_kernel<TT, VV>;                                                                      \
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);     \
+    hipLaunchKernelGGL(kern, grid, block, lds, (hipStream_t)stream, p);                                      \
+  }
+#define SP_LAUNCH(TT) { if (vec) SP_LAUNCH1(TT, true) else SP_LAUNCH1(TT, false) }
+  if (dtype == APHRO_F16) SP_LAUNCH(Half)
+  else if (dtype == APHRO_BF16) SP_LAUNCH(BFloat)
+  else SP_LAUNCH(Float)
+#undef SP_LAUNCH
+#undef SP_LAUNCH1
   APHRO_LAUNCH_CHECK();
   return APHRO_OK;
 }

@@ -20,7 +20,7 @@ def ops():
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("v", [1000, 32000, 128256])
+@pytest.mark.parametrize("v", [1000, 1003, 32000, 128256])      # 1003: rows not 16-byte aligned (scalar loads)
 def test_sample_matches_reference_restatement(ops, dtype, v):
     rng = np.random.default_rng(v)
     b = 12
