@@ -4,9 +4,11 @@ never imports this).  Follows aphrodite/modeling/layers/sampler.py:
   _apply_top_k_top_p  ascending sort, k-th largest as threshold (`<` masks, ties at the threshold
                    stay), softmax of the masked row, ascending cumsum <= 1 - p masks, last stays  (:865-891)
   _multinomial     q ~ Exp(1); argmax(probs / q)                                                 (:1273-1292)
-all in float32 like the reference (logits are cast to float first, :232).  Parity is pinned by the
-reference's own definition (a sort-based algorithm, restated line by line); the reference holds no
-golden vectors for the sampler."""
+all in float32 like the reference (logits are cast to float first, :232).  PINNED: the reference
+holds no golden vectors for the sampler, so tests/golden/make_golden.py lifts `_apply_top_k_top_p` and
+`_multinomial` out of the reference file with ``ast`` and runs them here; tests/golden/sampler.npz
+holds their outputs and tests/test_oracle_golden.py::test_sampler_golden checks this restatement
+against them (masked logits exact, sampled ids exact)."""
 import numpy as np
 
 

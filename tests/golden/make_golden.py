@@ -21,6 +21,8 @@ Sources exercised:
   tests/kernels/test_attention.py               ref_single_query_cached_kv_attention
   tests/kernels/test_cache.py                   (scatter reference, restated
                                                  inline from :176-192)
+  aphrodite/modeling/layers/sampler.py          _apply_top_k_top_p, _multinomial
+  aphrodite/quantization/compressed_tensors/utils.py   should_ignore_layer
 """
 import ast
 import importlib.util
@@ -224,6 +226,50 @@ def main():
     att.update(rc_key=key.numpy(), rc_val=val.numpy(), rc_slots=slots.numpy(),
                rc_kc=ckc.numpy(), rc_vc=cvc.numpy())
     np.savez_compressed(os.path.join(OUT, "attention.npz"), **att)
+
+    # ---------------- sampler: top-k / top-p masking and the multinomial draw --------------------
+    # aphrodite/modeling/layers/sampler.py:865-891 and :1273-1292, lifted as they lie
+    ns4 = _lift("aphrodite/modeling/layers/sampler.py", {"_apply_top_k_top_p", "_multinomial"},
+                dict(g, SequenceGroupToSample=object))
+    torch.manual_seed(11)
+    B, V = 7, 4096
+    logits = torch.randn(B, V) * 3
+    logits[6] = torch.round(logits[6] * 4) / 4                 # a row with ties (kept set may differ in ties)
+    top_k = torch.tensor([50, V, 1, 40, V, 7, 25])
+    top_p = torch.tensor([0.9, 0.8, 1.0, 0.95, 0.5, 1.0, 0.7])
+    masked = ns4["_apply_top_k_top_p"](logits.clone(), top_p, top_k)
+    probs = torch.softmax(masked, dim=-1, dtype=torch.float)
+    torch.manual_seed(12)
+    q = torch.empty_like(probs).exponential_()                 # the draws _multinomial makes with this seed
+    torch.manual_seed(12)
+    ids = ns4["_multinomial"](probs.clone(), 1).reshape(-1)
+    np.savez_compressed(os.path.join(OUT, "sampler.npz"), logits=logits.numpy(), top_k=top_k.numpy(),
+                        top_p=top_p.numpy(), masked=masked.numpy(), probs=probs.numpy(), q=q.numpy(),
+                        ids=ids.numpy())
+
+    # ---------------- compressed-tensors: which layers a checkpoint left unquantised ----------------
+    # compressed_tensors/utils.py:113-171, 242-260 (should_ignore_layer and helpers)
+    import json
+    import re
+    ns5 = _lift("aphrodite/quantization/compressed_tensors/utils.py",
+                {"should_ignore_layer", "check_equal_or_regex_match", "_is_equal_or_regex_match"},
+                dict(g, re=re, Iterable=__import__("typing").Iterable,
+                     FUSED_LAYER_NAME_MAPPING=qu.FUSED_LAYER_NAME_MAPPING))
+    cases = []
+    ignores = [["lm_head"], ["re:.*self_attn.*"], ["model.layers.0.mlp.gate_proj", "model.layers.0.mlp.up_proj"],
+               ["model.layers.1.self_attn.q_proj"], ["re:model\\.layers\\.[01]\\.mlp\\..*"], []]
+    names = ["lm_head", "model.layers.0.self_attn.qkv_proj", "model.layers.0.self_attn.o_proj",
+             "model.layers.0.mlp.gate_up_proj", "model.layers.1.mlp.down_proj", "model.layers.1.self_attn.qkv_proj",
+             "model.layers.2.mlp.gate_up_proj"]
+    for ig in ignores:
+        for n in names:
+            try:
+                res = bool(ns5["should_ignore_layer"](n, ignore=ig))
+            except ValueError:
+                res = "ValueError"
+            cases.append({"layer": n, "ignore": ig, "result": res})
+    with open(os.path.join(OUT, "ct_ignore.json"), "w") as f:
+        json.dump(cases, f, indent=0)
     print("golden fixtures written to", OUT)
 
 

@@ -253,3 +253,42 @@ def test_moe_routing_oracle_known_answers():
     np.testing.assert_allclose(w, tw.numpy(), rtol=1e-6)
     assert src[3, 1] == 1 * 9 + 3
 
+
+
+# ---------------------------------------------------------------------------
+# sampler restatement vs the reference's own functions (tests/golden/sampler.npz)
+# ---------------------------------------------------------------------------
+def test_sampler_golden(golden_dir):
+    from oracle import sampling as osamp
+    g = np.load(os.path.join(golden_dir, "sampler.npz"))
+    logits, top_k, top_p = g["logits"], g["top_k"], g["top_p"]
+    masked = osamp.apply_top_k_top_p(logits, top_p, top_k)
+    tie_row = 6
+    for r in range(logits.shape[0]):
+        if r == tie_row:
+            # torch.sort and numpy's stable sort order equal values differently: same kept VALUES
+            np.testing.assert_array_equal(np.sort(masked[r][np.isfinite(masked[r])]),
+                                          np.sort(g["masked"][r][np.isfinite(g["masked"][r])]))
+        else:
+            np.testing.assert_array_equal(masked[r], g["masked"][r], err_msg=f"row {r}")
+    np.testing.assert_allclose(osamp.softmax32(g["masked"]), g["probs"], rtol=2e-6, atol=1e-12)
+    # the draw itself, on the reference's probabilities and its Exp(1) variates
+    np.testing.assert_array_equal(osamp.multinomial(g["probs"], g["q"]), g["ids"])
+    # and the whole chain from logits
+    ids, _ = osamp.sample(logits, np.ones(logits.shape[0], np.float32), top_k, top_p, g["q"])
+    keep = np.arange(logits.shape[0]) != tie_row
+    np.testing.assert_array_equal(ids[keep], g["ids"][keep])
+
+
+def test_compressed_tensors_ignore_list_golden(golden_dir):
+    """Host logic, not oracle: layer_is_ignored vs the reference's should_ignore_layer."""
+    import json
+    from aphrodite_engine_amd.quantization.utils import layer_is_ignored
+    cases = json.load(open(os.path.join(golden_dir, "ct_ignore.json")))
+    assert len(cases) >= 40
+    for c in cases:
+        if c["result"] == "ValueError":
+            with pytest.raises(ValueError):
+                layer_is_ignored(c["layer"], c["ignore"])
+        else:
+            assert layer_is_ignored(c["layer"], c["ignore"]) == c["result"], c
