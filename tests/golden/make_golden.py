@@ -23,6 +23,9 @@ Sources exercised:
                                                  inline from :176-192)
   aphrodite/modeling/layers/sampler.py          _apply_top_k_top_p, _multinomial
   aphrodite/quantization/compressed_tensors/utils.py   should_ignore_layer
+  aphrodite/modeling/layers/linear.py           MergedColumnParallelLinear / QKVParallelLinear /
+                                                RowParallelLinear .weight_loader (methods lifted out of
+                                                their classes, run with a stand-in self)
 """
 import ast
 import importlib.util
@@ -270,6 +273,112 @@ def main():
             cases.append({"layer": n, "ignore": ig, "result": res})
     with open(os.path.join(OUT, "ct_ignore.json"), "w") as f:
         json.dump(cases, f, indent=0)
+    # ---------------- tensor-parallel weight loaders: the reference's own methods on small tensors ----
+    # modeling/layers/linear.py: MergedColumnParallelLinear.weight_loader (:452-595),
+    # QKVParallelLinear.weight_loader (:815-988), RowParallelLinear.weight_loader (:1072-1112), lifted out
+    # of their classes and run with a stand-in ``self`` for every (world, rank) below.
+    import textwrap
+    from torch.nn.parameter import Parameter, UninitializedParameter
+    tp = {"rank": 0, "world": 1}
+    lg = dict(g, Parameter=Parameter, UninitializedParameter=UninitializedParameter, Dict=__import__("typing").Dict,
+              get_tensor_model_parallel_rank=lambda: tp["rank"],
+              get_tensor_model_parallel_world_size=lambda: tp["world"], logger=type("L", (), {
+                  "warning": staticmethod(lambda *a, **k: None)})())
+    lg.update(_lift("aphrodite/modeling/layers/linear.py",
+                    {"adjust_marlin_shard", "adjust_bitsandbytes_4bit_shard", "adjust_scalar_to_fused_array"}, lg))
+
+    def lift_method(cls, name):
+        src = open(os.path.join(REF, "aphrodite/modeling/layers/linear.py")).read()
+        for node in ast.parse(src).body:
+            if isinstance(node, ast.ClassDef) and node.name == cls:
+                for sub in node.body:
+                    if isinstance(sub, ast.FunctionDef) and sub.name == name:
+                        seg = textwrap.dedent(ast.get_source_segment(src, sub, padded=True))
+                        ns = dict(lg)
+                        exec(compile(seg, "linear.py", "exec"), ns)
+                        return ns[name]
+        raise KeyError((cls, name))
+
+    def holder(cls, **attrs):
+        k = type("Ref" + cls, (), {"weight_loader": lift_method(cls, "weight_loader")})
+        o = k()
+        o.__dict__.update(attrs)
+        return o
+
+    HQ, HKV, HD, HID, INTER, GS = 4, 2, 16, 64, 96, 32
+    rs = np.random.RandomState(7)
+    ld = {}
+
+    def rnd(shape, dtype):
+        if dtype == torch.int32:
+            return torch.from_numpy(rs.randint(-2 ** 31, 2 ** 31 - 1, size=shape, dtype=np.int64).astype(np.int32))
+        return torch.from_numpy(rs.standard_normal(shape).astype(np.float32)).to(dtype)
+
+    def mk(shape, dtype, **attrs):
+        prm = Parameter(torch.zeros(shape, dtype=dtype), requires_grad=False)
+        for k_, v_ in attrs.items():
+            setattr(prm, k_, v_)
+        return prm
+
+    def param_table(k_loc, n_loc, nshards, row):
+        """name -> (shape on this rank, dtype, loader attributes, checkpoint shape given the full (K, N))"""
+        kin = 0 if row else None     # group metadata follows K only when K is cut
+        return {
+            "gptq.qweight": ((k_loc // 8, n_loc), torch.int32, dict(input_dim=0, output_dim=1, packed_dim=0, pack_factor=8)),
+            "gptq.qzeros": ((k_loc // GS, n_loc // 8), torch.int32,
+                            dict(output_dim=1, packed_dim=1, pack_factor=8, **({"input_dim": 0} if row else {}))),
+            "gptq.scales": ((k_loc // GS, n_loc), torch.float16, dict(output_dim=1, **({"input_dim": 0} if row else {}))),
+            "gptq.g_idx": ((k_loc, ), torch.int32, dict(input_dim=0)),
+            "awq.qweight": ((k_loc, n_loc // 8), torch.int32, dict(input_dim=0, output_dim=1, packed_dim=1, pack_factor=8)),
+            "fp8.weight": ((n_loc, k_loc), torch.float16, dict(input_dim=1, output_dim=0)),
+            "fp8.weight_scale": ((nshards, ), torch.float32, dict(needs_scalar_to_array=True)),
+            "ct.weight_scale": ((n_loc, 1), torch.float32, dict(output_dim=0)),
+        }
+
+    def full_shape(name, k, n):
+        return {"gptq.qweight": (k // 8, n), "gptq.qzeros": (k // GS, n // 8), "gptq.scales": (k // GS, n),
+                "gptq.g_idx": (k, ), "awq.qweight": (k, n // 8), "fp8.weight": (n, k), "fp8.weight_scale": (),
+                "ct.weight_scale": (n, 1)}[name]
+
+    for world, rank in ((1, 0), (2, 1), (4, 3)):
+        tp["rank"], tp["world"] = rank, world
+        nh = HQ // world
+        nkv, rep = (1, world // HKV) if world >= HKV else (HKV // world, 1)
+        qkv = holder("QKVParallelLinear", quant_config=object(), num_heads=nh, num_kv_heads=nkv, head_size=HD,
+                     num_kv_head_replicas=rep, total_num_heads=HQ, total_num_kv_heads=HKV,
+                     output_sizes=[nh * HD * world, nkv * HD * world, nkv * HD * world])
+        merged = holder("MergedColumnParallelLinear", quant_config=object(), output_sizes=[INTER, INTER])
+        row = holder("RowParallelLinear", quant_config=object(), tp_rank=rank, tp_size=world, input_size=INTER)
+        layers = {
+            "qkv": (qkv, HID, (nh + 2 * nkv) * HD, [("q", HQ * HD), ("k", HKV * HD), ("v", HKV * HD)], False),
+            "merged": (merged, HID, 2 * INTER // world, [(0, INTER), (1, INTER)], False),
+            "row": (row, INTER // world, HID, [(None, HID)], True),
+        }
+        for lname, (obj, k_loc, n_loc, shards, is_row) in layers.items():
+            k_full = INTER if is_row else HID
+            for pname, (shape, dtype, attrs) in param_table(k_loc, n_loc, len(shards), is_row).items():
+                if is_row and pname == "ct.weight_scale":
+                    continue
+                prm = mk(shape, dtype, **attrs)
+                for sid, n_full in shards:
+                    key_in = f"in.{lname}.{pname}.{sid}"
+                    if key_in not in ld:
+                        ld[key_in] = rnd(full_shape(pname, k_full, n_full), dtype).numpy()
+                    t_in = torch.from_numpy(np.asarray(ld[key_in]))
+                    if is_row:
+                        obj.weight_loader(prm, t_in)
+                    else:
+                        obj.weight_loader(prm, t_in, sid)
+                ld[f"out.{lname}.{pname}.w{world}r{rank}"] = prm.data.numpy().copy()
+                # the same tensors stored fused on disk (Phi-3 style), through loaded_shard_id = None
+                if not is_row and pname in ("fp8.weight", "gptq.qweight", "gptq.scales", "ct.weight_scale"):
+                    odim = attrs["output_dim"]
+                    fused = torch.cat([torch.from_numpy(np.asarray(ld[f"in.{lname}.{pname}.{sid}"]))
+                                       for sid, _ in shards], dim=odim)
+                    prm2 = mk(shape, dtype, **attrs)
+                    obj.weight_loader(prm2, fused, None)
+                    assert torch.equal(prm2.data, prm.data)
+    np.savez_compressed(os.path.join(OUT, "loader_shards.npz"), **ld)
     print("golden fixtures written to", OUT)
 
 

@@ -377,3 +377,53 @@ def test_load_under_real_tensor_parallel_gloo(tmp_path):
         np.testing.assert_array_equal(np.array(qkv), exp)
         assert rows == CFG.vocab_size
         assert total == pytest.approx(float(truth["tensors"]["lm_head.weight"].float().sum()), rel=1e-6)
+
+
+# ----------------------------------------------------------------------------------------------
+def test_shard_arithmetic_matches_the_reference_weight_loaders(golden_dir):
+    """tests/golden/loader_shards.npz holds what the reference's OWN MergedColumnParallelLinear /
+    QKVParallelLinear / RowParallelLinear.weight_loader methods (lifted out of linear.py and run in the
+    build container) leave in GPTQ / AWQ / FP8 / compressed-tensors parameters for (world, rank) =
+    (1,0), (2,1), (4,3): the single copy routine of loader.py must produce the same bytes."""
+    from aphrodite_engine_amd.quantization.base_config import _param
+    g = np.load(os.path.join(golden_dir, "loader_shards.npz"))
+    HQ, HKV, HD, INTER = 4, 2, 16, 96
+    row_attrs = {"gptq.qzeros": dict(input_dim=0), "gptq.scales": dict(input_dim=0)}
+    attrs = {
+        "gptq.qweight": dict(input_dim=0, output_dim=1, packed_dim=0, pack_factor=8),
+        "gptq.qzeros": dict(output_dim=1, packed_dim=1, pack_factor=8),
+        "gptq.scales": dict(output_dim=1),
+        "gptq.g_idx": dict(input_dim=0),
+        "awq.qweight": dict(input_dim=0, output_dim=1, packed_dim=1, pack_factor=8),
+        "fp8.weight": dict(input_dim=1, output_dim=0),
+        "fp8.weight_scale": dict(needs_scalar_to_array=True),
+        "ct.weight_scale": dict(output_dim=0),
+    }
+    shard_ids = {"qkv": ["q", "k", "v"], "merged": [0, 1], "row": [None]}
+    checked = 0
+    for key in g.files:
+        if not key.startswith("out."):
+            continue
+        _, lname, fmt, pname, tag = key.split(".")
+        name = f"{fmt}.{pname}"
+        world, rank = int(tag[1:tag.index("r")]), int(tag[tag.index("r") + 1:])
+        plan = {"qkv": lambda: L.qkv_plan(HQ, HKV, HD, rank, world),
+                "merged": lambda: L.merged_plan([INTER, INTER], rank, world),
+                "row": lambda: L.row_plan(rank, world)}[lname]()
+        want = torch.from_numpy(g[key])
+        a = dict(attrs[name])
+        if lname == "row":
+            a.update(row_attrs.get(name, {}))
+        prm = _param(torch.zeros_like(want), **a)
+        for sid in shard_ids[lname]:
+            L.load_sharded(plan, prm, torch.from_numpy(g[f"in.{lname}.{name}.{sid}"]), sid)
+        assert torch.equal(prm.data, want), key
+        # fused on disk: one tensor, shard id None
+        if lname != "row" and "output_dim" in a:
+            fused = torch.cat([torch.from_numpy(g[f"in.{lname}.{name}.{sid}"]) for sid in shard_ids[lname]],
+                              dim=a["output_dim"])
+            prm2 = _param(torch.zeros_like(want), **a)
+            L.load_sharded(plan, prm2, fused, None)
+            assert torch.equal(prm2.data, want), key + " (fused)"
+        checked += 1
+    assert checked >= 60
