@@ -1,5 +1,6 @@
 """CPU restatement of the mixture-of-experts routing ops and of the reference's MoE layer.
-TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  PINNED by tests/golden/moe.npz (the reference's
+torch_moe run in the build container) and by the worked example in fused_moe.py:199-212.
 
   topk_softmax            kernels/moe/softmax.cu:17-520 (softmax in fp32, k rounds of arg-max,
                           ties -> lowest index; weights not renormalised; source row k*T + t)

@@ -26,6 +26,9 @@ Sources exercised:
   aphrodite/modeling/layers/linear.py           MergedColumnParallelLinear / QKVParallelLinear /
                                                 RowParallelLinear .weight_loader (methods lifted out of
                                                 their classes, run with a stand-in self)
+  tests/kernels/test_moe.py                     torch_moe (+ SiluAndMul.forward_native)
+  aphrodite/quantization/kv_cache.py            BaseKVCacheMethod.process_weights_after_loading
+  aphrodite/modeling/model_loader/weight_utils.py  kv_cache_scales_loader (+ quantization/schema.py)
 """
 import ast
 import importlib.util
@@ -379,6 +382,67 @@ def main():
                     obj.weight_loader(prm2, fused, None)
                     assert torch.equal(prm2.data, prm.data)
     np.savez_compressed(os.path.join(OUT, "loader_shards.npz"), **ld)
+
+    # ---------------- mixture of experts: the reference's torch_moe (tests/kernels/test_moe.py:15-29) ----
+    def lift_class_method(relpath, cls, name, glb):
+        src = open(os.path.join(REF, relpath)).read()
+        for node in ast.parse(src).body:
+            if isinstance(node, ast.ClassDef) and node.name == cls:
+                for sub in node.body:
+                    if isinstance(sub, ast.FunctionDef) and sub.name == name:
+                        ns_ = dict(glb)
+                        exec(compile(textwrap.dedent(ast.get_source_segment(src, sub, padded=True)), relpath, "exec"),
+                             ns_)
+                        return ns_[name]
+        raise KeyError((cls, name))
+    silu_native = lift_class_method("aphrodite/modeling/layers/activation.py", "SiluAndMul", "forward_native",
+                                    dict(g, F=torch.nn.functional))
+    SiluAndMul = type("SiluAndMul", (), {"__call__": lambda self, x: silu_native(self, x)})
+    ns6 = _lift("tests/kernels/test_moe.py", {"torch_moe"}, dict(g, SiluAndMul=SiluAndMul))
+    torch.manual_seed(21)
+    Bm, Dm, Nm, Em, Tk = 9, 64, 32, 8, 2
+    a_m = torch.randn(Bm, Dm) / 4
+    w1_m = torch.randn(Em, 2 * Nm, Dm) / 8         # [E, 2N, K] as fused_moe holds them (gate | up rows)
+    w2_m = torch.randn(Em, Dm, Nm) / 8
+    score = torch.randn(Bm, Em)
+    moe_out = ns6["torch_moe"](a_m, w1_m, w2_m, score, Tk)
+    np.savez_compressed(os.path.join(OUT, "moe.npz"), a=a_m.numpy(), w1=w1_m.numpy(), w2=w2_m.numpy(),
+                        score=score.numpy(), out=moe_out.numpy(), topk=np.int64(Tk))
+
+    # ---------------- FP8 KV-cache scales: checkpoint rule and the quantization_param_path json ---------
+    kv_rule = lift_class_method("aphrodite/quantization/kv_cache.py", "BaseKVCacheMethod",
+                                "process_weights_after_loading", dict(g, print_warning_once=lambda *a, **k: None))
+    kv_cases = []
+    for kvd in ("auto", "fp8", "fp8_e5m2"):
+        for ks, vs in ((-1.0, -1.0), (0.02, 0.03), (0.05, -1.0), (1.0, 1.0)):
+            layer = types.SimpleNamespace(kv_cache_dtype=kvd, k_scale=torch.tensor(ks), v_scale=torch.tensor(vs))
+            kv_rule(None, layer)
+            kv_cases.append({"kv_cache_dtype": kvd, "k_scale": ks, "v_scale": vs,
+                             "out": [getattr(layer, "_k_scale", None), getattr(layer, "_v_scale", None)]})
+    _stub("aphrodite.quantization.schema")
+    schema = _load("aphrodite.quantization.schema", "aphrodite/quantization/schema.py")
+    ns7 = _lift("aphrodite/modeling/model_loader/weight_utils.py", {"kv_cache_scales_loader"},
+                dict(g, json=json, Iterable=__import__("typing").Iterable, QuantParamSchema=schema.QuantParamSchema,
+                     logger=type("L", (), {"error": staticmethod(lambda *a, **k: None),
+                                           "warning": staticmethod(lambda *a, **k: None)})()))
+    import tempfile
+    doc = {"model_type": "llama", "kv_cache": {"dtype": "float8_e4m3fn", "scaling_factor": {
+        "0": {"0": 0.1, "1": 0.2, "2": 0.3}, "1": {"0": 0.4, "1": 0.5, "2": 0.6}}}}
+    json_cases = []
+    variants = [("ok", doc, dict(tp_rank=1, tp_size=2, layers=3, model_type="llama")),
+                ("wrong_tp", doc, dict(tp_rank=0, tp_size=1, layers=3, model_type="llama")),
+                ("wrong_layers", doc, dict(tp_rank=0, tp_size=2, layers=4, model_type="llama")),
+                ("wrong_model", doc, dict(tp_rank=0, tp_size=2, layers=3, model_type="mixtral")),
+                ("wrong_dtype", {**doc, "kv_cache": {**doc["kv_cache"], "dtype": "float8_e5m2"}},
+                 dict(tp_rank=0, tp_size=2, layers=3, model_type="llama"))]
+    for tag, d_, kw in variants:
+        with tempfile.NamedTemporaryFile("w", suffix=".json", delete=False) as tf:
+            json.dump(d_, tf)
+        res = list(ns7["kv_cache_scales_loader"](tf.name, kw["tp_rank"], kw["tp_size"], kw["layers"], kw["model_type"]))
+        os.unlink(tf.name)
+        json_cases.append({"tag": tag, "doc": d_, "args": kw, "result": [[int(a_), float(b_)] for a_, b_ in res]})
+    with open(os.path.join(OUT, "kv_scales.json"), "w") as f:
+        json.dump({"rule": kv_cases, "param_path": json_cases}, f, indent=0)
     print("golden fixtures written to", OUT)
 
 

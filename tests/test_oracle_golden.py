@@ -292,3 +292,45 @@ def test_compressed_tensors_ignore_list_golden(golden_dir):
                 layer_is_ignored(c["layer"], c["ignore"])
         else:
             assert layer_is_ignored(c["layer"], c["ignore"]) == c["result"], c
+
+
+def test_moe_layer_golden(golden_dir):
+    """oracle/moe.py (routing + dense per-expert MLP) vs the reference's torch_moe."""
+    from oracle import moe as om
+    g = np.load(os.path.join(golden_dir, "moe.npz"))
+    w, ids, _ = om.topk_softmax(g["score"], int(g["topk"]))
+    # torch_moe: softmax -> topk, weights NOT renormalised; w1 is [E, 2N, K] (gate rows | up rows)
+    out = om.moe_layer(g["a"], np.transpose(g["w1"], (0, 2, 1)), np.transpose(g["w2"], (0, 2, 1)), w, ids)
+    np.testing.assert_allclose(out, g["out"], rtol=2e-4, atol=2e-5)
+
+
+def test_kv_scale_rules_golden(golden_dir):
+    """Host logic vs the reference: BaseKVCacheMethod.process_weights_after_loading (checkpoint scales) and
+    kv_cache_scales_loader (quantization_param_path json)."""
+    import json
+    import tempfile
+    from aphrodite_engine_amd import loader as L
+    doc = json.load(open(os.path.join(golden_dir, "kv_scales.json")))
+    for c in doc["rule"]:
+        found = {0: {}}
+        if c["k_scale"] > 0:
+            found[0]["k"] = c["k_scale"]
+        if c["v_scale"] > 0:
+            found[0]["v"] = c["v_scale"]
+        k, v = L.finalize_kv_scales(found, 1, c["kv_cache_dtype"])[0]
+        want = c["out"] if c["out"][0] is not None else [1.0, 1.0]      # "auto": the reference leaves the default 1.0
+        assert (k, v) == (pytest.approx(want[0], rel=1e-6), pytest.approx(want[1], rel=1e-6)), c
+    for c in doc["param_path"]:
+        with tempfile.NamedTemporaryFile("w", suffix=".json", delete=False) as tf:
+            json.dump(c["doc"], tf)
+        a = c["args"]
+        try:
+            if c["result"]:
+                got = L.read_kv_cache_scales(tf.name, a["tp_rank"], a["tp_size"], a["layers"], a["model_type"])
+                assert sorted(got.items()) == [(i, pytest.approx(s)) for i, s in c["result"]]
+            else:
+                # the reference logs and silently falls back to 1.0 for every layer; here a malformed file is an error
+                with pytest.raises(ValueError):
+                    L.read_kv_cache_scales(tf.name, a["tp_rank"], a["tp_size"], a["layers"], a["model_type"])
+        finally:
+            os.unlink(tf.name)
