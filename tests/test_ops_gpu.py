@@ -1465,6 +1465,48 @@ def _tp2_worker(rank, world, port, fused_silu):
     dist.destroy_process_group()
 
 
+def _tp2_fp8_worker(rank, world, port):
+    """TP = 2 with the compressed-tensors W8A8-FP8 scheme: fused fast path (row-parallel GEMMs write f16,
+    all-reduce, fused norm+quant) == op-by-op path, bit for bit per rank; replicated hidden state."""
+    import torch.distributed as dist
+    from aphrodite_engine_amd import distributed as D
+    from aphrodite_engine_amd import model as M
+    from aphrodite_engine_amd.quantization.fp8 import CompressedTensorsW8A8Fp8Config
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    D.init_tensor_parallel(world, backend="gloo")
+    cfg = M.LlamaConfig(hidden_size=1024, intermediate_size=4096, num_hidden_layers=2, num_attention_heads=8,
+                        num_key_value_heads=4, vocab_size=512, max_position_embeddings=1024)
+    with torch.no_grad():
+        m = M.LlamaForCausalLM(cfg, CompressedTensorsW8A8Fp8Config("channel"), torch.float16)
+        m.init_synthetic(torch.device("cuda:0"))
+        meta, pos, nblocks = M.make_decode_metadata(5, [3, 17, 64, 200, 129], 16, "cuda:0")
+        ids = torch.randint(0, cfg.vocab_size, (5, ), device="cuda:0",
+                            generator=torch.Generator(device="cuda:0").manual_seed(1))
+        outs = []
+        for fused in (False, True):
+            caches = M.make_kv_caches(cfg, nblocks, 16, torch.float16, "auto", "cuda:0", seed=3)
+            m.use_fused_decode = fused
+            assert all(l.fused_decode_fp8_ok(5) for l in m.layers) and m.layers[0].tp == world
+            outs.append(m(ids, pos, caches, meta))
+        assert torch.isfinite(outs[0].float()).all()
+        assert torch.equal(outs[0], outs[1])
+        gathered = [torch.empty_like(outs[1]) for _ in range(world)]
+        dist.all_gather(gathered, outs[1])
+        assert torch.equal(gathered[0], gathered[1])
+    D.destroy_tensor_parallel()
+    dist.destroy_process_group()
+
+
+def test_tp2_fused_fp8_decode_matches_unfused(ops):
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    mp.spawn(_tp2_fp8_worker, args=(2, port), nprocs=2, join=True)
+
+
 @pytest.mark.parametrize("fused_silu", [False, True])
 def test_tp2_fused_decode_matches_unfused(ops, fused_silu):
     """TP = 2 (column-parallel qkv / gate_up, row-parallel o / down + all-reduce, heads split):
