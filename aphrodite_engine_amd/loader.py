@@ -208,6 +208,15 @@ def read_hf_config(model_dir: str) -> Dict[str, Any]:
 
 def llama_config_from_hf(hf: Dict[str, Any]):
     from .model import LlamaConfig
+    # what this skeleton does not model is refused, never loaded approximately
+    if hf.get("rope_scaling"):
+        raise NotImplementedError(f"rope_scaling={hf['rope_scaling']!r} (scaled rotary tables) is not implemented")
+    if hf.get("sliding_window"):
+        raise NotImplementedError("sliding-window attention in decode is not implemented")
+    if hf.get("attention_bias") or hf.get("mlp_bias"):
+        raise NotImplementedError("projection biases are not implemented")
+    if hf.get("hidden_act", "silu") != "silu":
+        raise NotImplementedError(f"hidden_act={hf['hidden_act']!r}: only SiluAndMul MLPs are implemented")
     heads = hf["num_attention_heads"]
     head_dim = hf.get("head_dim") or hf["hidden_size"] // heads
     if head_dim * heads != hf["hidden_size"]:

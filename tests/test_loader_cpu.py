@@ -323,6 +323,56 @@ def test_config_resolution_and_gates(tmp_path):
         mixed.get_quant_method(torch.nn.Module(), "model.layers.0.self_attn.qkv_proj")
 
 
+def test_unsupported_architectures_are_refused(tmp_path):
+    import json as _json
+    CU.write_checkpoint(str(tmp_path), CFG, "fp16", seed=13)
+    cfg_path = tmp_path / "config.json"
+    base = _json.loads(cfg_path.read_text())
+    for extra in ({"rope_scaling": {"rope_type": "llama3", "factor": 8.0}}, {"sliding_window": 4096},
+                  {"attention_bias": True}, {"hidden_act": "gelu"}):
+        cfg_path.write_text(_json.dumps({**base, **extra}))
+        with pytest.raises(NotImplementedError):
+            build(tmp_path, "fp16", 0, 1)
+    cfg_path.write_text(_json.dumps({**base, "sliding_window": None, "rope_scaling": None}))
+    build(tmp_path, "fp16", 0, 1)
+
+
+def test_gptq_act_order_checkpoint(tmp_path):
+    """desc_act = true: g_idx is a real permutation-derived map; column-parallel layers take it whole,
+    row-parallel layers their K slice, and with TP > 1 the row-parallel group metadata is NOT cut
+    (gptq.py:133-143: exllama is disabled there and every group must be reachable)."""
+    import json as _json
+    truth = CU.write_checkpoint(str(tmp_path), CFG, "gptq", seed=14)
+    t = truth["tensors"]
+    # turn the checkpoint into an act-order one: shuffle every g_idx (the loader must carry it through)
+    from safetensors.torch import load_file, save_file
+    rng = np.random.default_rng(0)
+    for f in sorted(tmp_path.glob("*.safetensors")):
+        d = load_file(str(f))
+        for name in list(d):
+            if name.endswith(".g_idx"):
+                k = d[name].numel()
+                d[name] = torch.from_numpy((rng.permutation(k) // 128).astype(np.int32))
+                t[name] = d[name]
+        save_file(d, str(f))
+    cfgp = tmp_path / "config.json"
+    c = _json.loads(cfgp.read_text())
+    c["quantization_config"]["desc_act"] = True
+    cfgp.write_text(_json.dumps(c))
+    for rank, world in [(0, 1), (1, 2)]:
+        m = build(tmp_path, "gptq", rank, world)
+        for li, layer in enumerate(m.layers):
+            base = f"model.layers.{li}."
+            assert torch.equal(layer.qkv_proj.g_idx.data, t[base + "self_attn.v_proj.g_idx"])   # last shard written
+            k = t[base + "mlp.down_proj.g_idx"].numel() // world
+            assert torch.equal(layer.down_proj.g_idx.data, t[base + "mlp.down_proj.g_idx"][rank * k:(rank + 1) * k])
+            full_groups = t[base + "mlp.down_proj.scales"].shape[0]
+            assert layer.down_proj.scales.shape[0] == full_groups          # all groups on every rank
+            assert torch.equal(layer.down_proj.scales.data, t[base + "mlp.down_proj.scales"])
+            from aphrodite_engine_amd.quantization.gptq import ExllamaState
+            assert layer.down_proj.exllama_state == (ExllamaState.UNUSED if world > 1 else ExllamaState.UNINITIALIZED)
+
+
 def test_shard_plan_rules():
     p = L.qkv_plan(32, 8, 128, rank=5, world=16)            # 2 ranks per KV head
     assert [(o.local, o.src_index) for o in p.outs] == [(256, 5), (128, 2), (128, 2)]
