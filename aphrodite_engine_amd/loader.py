@@ -209,8 +209,9 @@ def read_hf_config(model_dir: str) -> Dict[str, Any]:
 def llama_config_from_hf(hf: Dict[str, Any]):
     from .model import LlamaConfig
     # what this skeleton does not model is refused, never loaded approximately
-    if hf.get("rope_scaling"):
-        raise NotImplementedError(f"rope_scaling={hf['rope_scaling']!r} (scaled rotary tables) is not implemented")
+    rs = hf.get("rope_scaling")
+    if rs and rs.get("rope_type", rs.get("type")) != "llama3":
+        raise NotImplementedError(f"rope_scaling={rs!r}: only the llama3 scheme is implemented")
     if hf.get("sliding_window"):
         raise NotImplementedError("sliding-window attention in decode is not implemented")
     if hf.get("attention_bias") or hf.get("mlp_bias"):
@@ -226,6 +227,7 @@ def llama_config_from_hf(hf: Dict[str, Any]):
                        num_key_value_heads=hf.get("num_key_value_heads", heads), vocab_size=hf["vocab_size"],
                        rms_norm_eps=hf.get("rms_norm_eps", 1e-6), rope_theta=hf.get("rope_theta", 10000.0),
                        max_position_embeddings=hf.get("max_position_embeddings", 8192),
+                       rope_scaling=rs or None,
                        num_local_experts=hf.get("num_local_experts", 0) or 0,
                        num_experts_per_tok=hf.get("num_experts_per_tok", 2))
 
@@ -474,7 +476,8 @@ def load_model(model_dir: str, dtype: torch.dtype = torch.float16, kv_cache_dtyp
     for layer, (k, v) in zip(model.layers, finalize_kv_scales(kv, cfg.num_hidden_layers, kv_cache_dtype)):
         layer.k_scale, layer.v_scale = k, v
     model.to(device)
-    model.cos_sin = _rope_cache(cfg.head_dim, cfg.max_position_embeddings, cfg.rope_theta, dtype, device)
+    model.cos_sin = _rope_cache(cfg.head_dim, cfg.max_position_embeddings, cfg.rope_theta, dtype, device,
+                                cfg.rope_scaling)
     if process_weights:
         model.process_weights_after_loading()
     return model

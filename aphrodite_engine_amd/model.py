@@ -39,6 +39,7 @@ class LlamaConfig:
     rms_norm_eps: float = 1e-5
     rope_theta: float = 500000.0
     max_position_embeddings: int = 8192
+    rope_scaling: Optional[dict] = None   # {"rope_type": "llama3", factor, low_freq_factor, high_freq_factor, original_max_position_embeddings}
     num_local_experts: int = 0        # > 0: Mixtral-style sparse MLP (block_sparse_moe), SURVEY 8f row 2
     num_experts_per_tok: int = 2
 
@@ -113,10 +114,24 @@ class QuantLinear(nn.Module):
         return None
 
 
-def _rope_cache(head_dim: int, max_pos: int, theta: float, dtype, device):
-    """modeling/layers/rotary_embedding.py:_compute_cos_sin_cache."""
+def _rope_cache(head_dim: int, max_pos: int, theta: float, dtype, device, rope_scaling: Optional[dict] = None):
+    """cos | sin table [max_pos, head_dim] (modeling/layers/rotary_embedding.py:101-120).  ``rope_scaling``
+    of type "llama3" (Llama-3.1 checkpoints) stretches the long wavelengths: a frequency whose wavelength
+    exceeds orig_max / low_freq_factor is divided by ``factor``, one below orig_max / high_freq_factor is
+    kept, and the band in between is blended linearly in orig_max / wavelength (:680-723)."""
     inv_freq = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.float,
                                              device=device) / head_dim))
+    if rope_scaling:
+        kind = rope_scaling.get("rope_type", rope_scaling.get("type"))
+        if kind != "llama3":
+            raise NotImplementedError(f"rope_scaling type {kind!r} is not implemented (llama3 only)")
+        factor = float(rope_scaling["factor"])
+        lo, hi = float(rope_scaling["low_freq_factor"]), float(rope_scaling["high_freq_factor"])
+        orig = float(rope_scaling["original_max_position_embeddings"])
+        wavelen = 2 * math.pi / inv_freq
+        blend = (orig / wavelen - lo) / (hi - lo) if lo != hi else torch.zeros_like(inv_freq)
+        mid = (1 - blend) * inv_freq / factor + blend * inv_freq
+        inv_freq = torch.where(wavelen < orig / hi, inv_freq, torch.where(wavelen > orig / lo, inv_freq / factor, mid))
     t = torch.arange(max_pos, dtype=torch.float, device=device)
     freqs = torch.einsum("i,j->ij", t, inv_freq)
     return torch.cat((freqs.cos(), freqs.sin()), dim=-1).to(dtype)
@@ -433,7 +448,7 @@ class LlamaForCausalLM(nn.Module):
                                       / math.sqrt(cfg.hidden_size)).to(layer.moe_gate.dtype))
                 _init_experts(layer.experts, g, device)
         self.cos_sin = _rope_cache(cfg.head_dim, cfg.max_position_embeddings,
-                                   cfg.rope_theta, self.dtype, device)
+                                   cfg.rope_theta, self.dtype, device, cfg.rope_scaling)
         self.process_weights_after_loading()
         return self
 

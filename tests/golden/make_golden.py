@@ -27,6 +27,7 @@ Sources exercised:
                                                 RowParallelLinear .weight_loader (methods lifted out of
                                                 their classes, run with a stand-in self)
   tests/kernels/test_moe.py                     torch_moe (+ SiluAndMul.forward_native)
+  aphrodite/modeling/layers/rotary_embedding.py RotaryEmbedding._compute_cos_sin_cache, Llama3RotaryEmbedding
   aphrodite/quantization/kv_cache.py            BaseKVCacheMethod.process_weights_after_loading
   aphrodite/modeling/model_loader/weight_utils.py  kv_cache_scales_loader (+ quantization/schema.py)
 """
@@ -408,6 +409,31 @@ def main():
     moe_out = ns6["torch_moe"](a_m, w1_m, w2_m, score, Tk)
     np.savez_compressed(os.path.join(OUT, "moe.npz"), a=a_m.numpy(), w1=w1_m.numpy(), w2=w2_m.numpy(),
                         score=score.numpy(), out=moe_out.numpy(), topk=np.int64(Tk))
+
+    # ---------------- rotary tables, plain and Llama-3.1 scaled (rotary_embedding.py:101-120, 680-723) -----
+    import math
+    rsrc = "aphrodite/modeling/layers/rotary_embedding.py"
+    base_inv = lift_class_method(rsrc, "RotaryEmbedding", "_compute_inv_freq", dict(g, math=math))
+    base_cache = lift_class_method(rsrc, "RotaryEmbedding", "_compute_cos_sin_cache", dict(g, math=math))
+    # the subclass method calls super()._compute_inv_freq(base): bind that one call to the lifted base method
+    src_r = open(os.path.join(REF, rsrc)).read()
+    l3 = None
+    for node in ast.parse(src_r).body:
+        if isinstance(node, ast.ClassDef) and node.name == "Llama3RotaryEmbedding":
+            for sub in node.body:
+                if isinstance(sub, ast.FunctionDef) and sub.name == "_compute_inv_freq":
+                    seg = textwrap.dedent(ast.get_source_segment(src_r, sub, padded=True))
+                    seg = seg.replace("super()._compute_inv_freq(base)", "_base_inv(self, base)")
+                    ns_r = dict(g, math=math, _base_inv=base_inv)
+                    exec(compile(seg, rsrc, "exec"), ns_r)
+                    l3 = ns_r["_compute_inv_freq"]
+    plain = types.SimpleNamespace(rotary_dim=128, base=500000.0, max_position_embeddings=640)
+    plain._compute_inv_freq = lambda b: base_inv(plain, b)
+    scaled = types.SimpleNamespace(rotary_dim=128, base=500000.0, max_position_embeddings=640, scaling_factor=8.0,
+                                   low_freq_factor=1.0, high_freq_factor=4.0, orig_max_position=8192)
+    scaled._compute_inv_freq = lambda b: l3(scaled, b)
+    np.savez_compressed(os.path.join(OUT, "rope.npz"), plain=base_cache(plain).numpy(),
+                        llama3=base_cache(scaled).numpy())
 
     # ---------------- FP8 KV-cache scales: checkpoint rule and the quantization_param_path json ---------
     kv_rule = lift_class_method("aphrodite/quantization/kv_cache.py", "BaseKVCacheMethod",

@@ -328,7 +328,7 @@ def test_unsupported_architectures_are_refused(tmp_path):
     CU.write_checkpoint(str(tmp_path), CFG, "fp16", seed=13)
     cfg_path = tmp_path / "config.json"
     base = _json.loads(cfg_path.read_text())
-    for extra in ({"rope_scaling": {"rope_type": "llama3", "factor": 8.0}}, {"sliding_window": 4096},
+    for extra in ({"rope_scaling": {"rope_type": "yarn", "factor": 8.0}}, {"sliding_window": 4096},
                   {"attention_bias": True}, {"hidden_act": "gelu"}):
         cfg_path.write_text(_json.dumps({**base, **extra}))
         with pytest.raises(NotImplementedError):

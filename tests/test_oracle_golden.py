@@ -334,3 +334,19 @@ def test_kv_scale_rules_golden(golden_dir):
                     L.read_kv_cache_scales(tf.name, a["tp_rank"], a["tp_size"], a["layers"], a["model_type"])
         finally:
             os.unlink(tf.name)
+
+
+def test_rotary_tables_golden(golden_dir):
+    """Host logic: the cos|sin table, plain and with Llama-3.1 (llama3) frequency scaling, vs the reference's
+    RotaryEmbedding / Llama3RotaryEmbedding."""
+    from aphrodite_engine_amd.model import _rope_cache
+    g = np.load(os.path.join(golden_dir, "rope.npz"))
+    plain = _rope_cache(128, 640, 500000.0, torch.float32, "cpu")
+    np.testing.assert_array_equal(plain.numpy(), g["plain"])
+    scaled = _rope_cache(128, 640, 500000.0, torch.float32, "cpu",
+                         {"rope_type": "llama3", "factor": 8.0, "low_freq_factor": 1.0, "high_freq_factor": 4.0,
+                          "original_max_position_embeddings": 8192})
+    np.testing.assert_array_equal(scaled.numpy(), g["llama3"])
+    assert not np.array_equal(g["plain"], g["llama3"])
+    with pytest.raises(NotImplementedError):
+        _rope_cache(128, 16, 10000.0, torch.float32, "cpu", {"rope_type": "yarn", "factor": 4.0})
