@@ -22,7 +22,8 @@ Sources exercised:
   tests/kernels/test_cache.py                   (scatter reference, restated
                                                  inline from :176-192)
   aphrodite/modeling/layers/sampler.py          _apply_top_k_top_p, _multinomial
-  aphrodite/quantization/compressed_tensors/utils.py   should_ignore_layer
+  aphrodite/quantization/compressed_tensors/utils.py   should_ignore_layer, QuantizationArgs
+  aphrodite/quantization/compressed_tensors/compressed_tensors.py   _get_scheme_from_parts + predicates
   aphrodite/modeling/layers/linear.py           MergedColumnParallelLinear / QKVParallelLinear /
                                                 RowParallelLinear .weight_loader (methods lifted out of
                                                 their classes, run with a stand-in self)
@@ -409,6 +410,64 @@ def main():
     moe_out = ns6["torch_moe"](a_m, w1_m, w2_m, score, Tk)
     np.savez_compressed(os.path.join(OUT, "moe.npz"), a=a_m.numpy(), w1=w1_m.numpy(), w2=w2_m.numpy(),
                         score=score.numpy(), out=moe_out.numpy(), topk=np.int64(Tk))
+
+    # ---------------- compressed-tensors: which scheme a config group selects ----------------------------
+    # compressed_tensors.py:133-253 (_is_* predicates + _get_scheme_from_parts) on the reference's own pydantic
+    # QuantizationArgs; the scheme classes are recorded, not constructed.
+    _stub("aphrodite.quantization.compressed_tensors")
+    ctu = _load("aphrodite.quantization.compressed_tensors.utils", "aphrodite/quantization/compressed_tensors/utils.py")
+
+    def recorder(name):
+        def make(**kw):
+            return {"scheme": name, **{k_: (v_.value if hasattr(v_, "value") else v_) for k_, v_ in kw.items()}}
+        make.get_min_capability = staticmethod(lambda: 89)
+        return make
+    ct_glb = dict(g, BaseModel=object, QuantizationStrategy=ctu.QuantizationStrategy, QuantizationType=ctu.QuantizationType,
+                  CompressionFormat=ctu.CompressionFormat,
+                  is_activation_quantization_format=ctu.is_activation_quantization_format,
+                  W4A16SPARSE24_SUPPORTED_BITS=[4], WNA16_SUPPORTED_BITS=[4, 8],
+                  CompressedTensorsW4A16Sparse24=recorder("W4A16Sparse24"), CompressedTensorsWNA16=recorder("WNA16"),
+                  CompressedTensorsW8A8Fp8=recorder("W8A8Fp8"), CompressedTensorsW8A16Fp8=recorder("W8A16Fp8"),
+                  CompressedTensorsW8A8Int8=recorder("W8A8Int8"))
+    csrc = "aphrodite/quantization/compressed_tensors/compressed_tensors.py"
+    meths = {n: lift_class_method(csrc, "CompressedTensorsConfig", n, ct_glb) for n in
+             ("_is_static_tensor_w8a8", "_is_dynamic_token_w8a8", "_is_fp8_w8a8", "_is_fp8_w8a16",
+              "_is_wNa16_group_channel", "_get_scheme_from_parts")}
+    f8w = {"num_bits": 8, "type": "float", "symmetric": True, "dynamic": False}
+    i4w = {"num_bits": 4, "type": "int", "symmetric": True, "dynamic": False}
+    groups = [
+        ("float-quantized", {**f8w, "strategy": "channel"}, {"num_bits": 8, "type": "float", "strategy": "token", "dynamic": True}),
+        ("float-quantized", {**f8w, "strategy": "tensor"}, {"num_bits": 8, "type": "float", "strategy": "tensor", "dynamic": False}),
+        ("float-quantized", {**f8w, "strategy": "tensor"}, {"num_bits": 8, "type": "float", "strategy": "token", "dynamic": True}),
+        ("float-quantized", {**f8w, "strategy": "channel"}, None),
+        ("naive-quantized", {**f8w, "strategy": "tensor"}, None),
+        ("pack-quantized", {**i4w, "strategy": "group", "group_size": 128}, None),
+        ("pack-quantized", {**i4w, "strategy": "channel"}, None),
+        ("pack-quantized", {**i4w, "strategy": "group", "group_size": 128, "actorder": "group"}, None),
+        ("pack-quantized", {**i4w, "strategy": "group", "group_size": 128, "actorder": "weight"}, None),
+        ("pack-quantized", {**i4w, "num_bits": 8, "strategy": "group", "group_size": 128}, None),
+        ("marlin-24", {**i4w, "strategy": "group", "group_size": 128}, None),
+        ("int-quantized", {"num_bits": 8, "type": "int", "symmetric": True, "strategy": "channel", "dynamic": False},
+         {"num_bits": 8, "type": "int", "symmetric": True, "strategy": "token", "dynamic": True}),
+        ("int-quantized", {"num_bits": 8, "type": "int", "symmetric": True, "strategy": "tensor", "dynamic": False},
+         {"num_bits": 8, "type": "int", "symmetric": True, "strategy": "tensor", "dynamic": False}),
+        ("pack-quantized", {**i4w, "symmetric": False, "strategy": "group", "group_size": 128}, None),
+        ("float-quantized", {**f8w, "strategy": "group", "group_size": 128}, {"num_bits": 8, "type": "float", "strategy": "token", "dynamic": True}),
+    ]
+    scheme_cases = []
+    for fmt_, w_, a_ in groups:
+        cfg_ = types.SimpleNamespace(quant_format=fmt_, _check_scheme_supported=lambda *x, **k: True)
+        for n_, f_ in meths.items():
+            setattr(cfg_, n_, types.MethodType(f_, cfg_))
+        wq = ctu.QuantizationArgs.parse_obj(w_)
+        aq = ctu.QuantizationArgs.parse_obj(a_) if a_ is not None else None
+        try:
+            res = cfg_._get_scheme_from_parts(wq, aq)
+        except NotImplementedError:
+            res = "NotImplementedError"
+        scheme_cases.append({"format": fmt_, "weights": w_, "input_activations": a_, "result": res})
+    with open(os.path.join(OUT, "ct_schemes.json"), "w") as f:
+        json.dump(scheme_cases, f, indent=0, default=str)
 
     # ---------------- rotary tables, plain and Llama-3.1 scaled (rotary_embedding.py:101-120, 680-723) -----
     import math
