@@ -29,6 +29,8 @@ Sources exercised:
                                                 their classes, run with a stand-in self)
   tests/kernels/test_moe.py                     torch_moe (+ SiluAndMul.forward_native)
   aphrodite/modeling/layers/rotary_embedding.py RotaryEmbedding._compute_cos_sin_cache, Llama3RotaryEmbedding
+  aphrodite/quantization/{gptq,awq,fp8}.py, compressed_tensors/schemes/compressed_tensors_w8a8_fp8.py
+                                                *.create_weights (parameter shapes, dtypes, loader metadata)
   aphrodite/quantization/kv_cache.py            BaseKVCacheMethod.process_weights_after_loading
   aphrodite/modeling/model_loader/weight_utils.py  kv_cache_scales_loader (+ quantization/schema.py)
 """
@@ -468,6 +470,79 @@ def main():
         scheme_cases.append({"format": fmt_, "weights": w_, "input_activations": a_, "result": res})
     with open(os.path.join(OUT, "ct_schemes.json"), "w") as f:
         json.dump(scheme_cases, f, indent=0, default=str)
+
+    # ---------------- parameter contracts: what each quant method registers on a layer ---------------------
+    # create_weights of GPTQLinearMethod (gptq.py:102-213), AWQLinearMethod (awq.py:81-139), Fp8LinearMethod
+    # (fp8.py:128-180) and the CompressedTensorsW8A8Fp8 scheme (:62-107), run with recording parameter classes.
+    from fractions import Fraction
+
+    def rec_param(kind):
+        def make(data, weight_loader=None, **kw):
+            data._rec = {"kind": kind, **{k_: (int(v_) if isinstance(v_, Fraction) else v_) for k_, v_ in kw.items()}}
+            return data
+        return make
+    pkinds = ("PackedAphroditeParameter", "RowAphroditeParameter", "ChannelQuantScaleParameter",
+              "GroupQuantScaleParameter", "PackedColumnParameter", "ModelWeightParameter", "PerTensorScaleParameter",
+              "BaseAphroditeParameter")
+    pg = dict(g, Callable=__import__("typing").Callable, **{k_: rec_param(k_) for k_ in pkinds})
+
+    class FakeLayer:
+        def __init__(self):
+            self.params = {}
+        def register_parameter(self, name, prm):
+            self.params[name] = None if prm is None else {"shape": list(prm.shape), "dtype": str(prm.dtype),
+                                                          **prm._rec}
+
+    def lift_class(relpath, cls, glb):
+        src = open(os.path.join(REF, relpath)).read()
+        for node in ast.parse(src).body:
+            if isinstance(node, ast.ClassDef) and node.name == cls:
+                ns_ = dict(glb)
+                exec(compile(ast.get_source_segment(src, node), relpath, "exec"), ns_)
+                return ns_[cls]
+        raise KeyError(cls)
+    import enum
+    ExllamaState = lift_class("aphrodite/quantization/gptq.py", "ExllamaState", dict(g, Enum=enum.Enum, enum=enum))
+    gptq_cw = lift_class_method("aphrodite/quantization/gptq.py", "GPTQLinearMethod", "create_weights",
+                                dict(pg, ExllamaState=ExllamaState))
+    awq_cw = lift_class_method("aphrodite/quantization/awq.py", "AWQLinearMethod", "create_weights", pg)
+    fp8_cw = lift_class_method("aphrodite/quantization/fp8.py", "Fp8LinearMethod", "create_weights", pg)
+    ctf_cw = lift_class_method("aphrodite/quantization/compressed_tensors/schemes/compressed_tensors_w8a8_fp8.py",
+                               "CompressedTensorsW8A8Fp8", "create_weights",
+                               dict(pg, QuantizationStrategy=ctu.QuantizationStrategy))
+    # (in_per_partition, out_partition_sizes, in_full, out_full)
+    geoms = {"column_tp1": (256, [256, 64, 64], 256, 384), "column_tp2": (256, [128, 32, 32], 256, 384),
+             "row_tp1": (512, [256], 512, 256), "row_tp2": (256, [256], 512, 256)}
+    contracts = []
+    for gname, (kin, outs, kfull, nfull) in geoms.items():
+        for gs_, desc in ((128, False), (128, True), (-1, False)):
+            qc_ = types.SimpleNamespace(group_size=gs_, desc_act=desc, pack_factor=Fraction(32, 4), weight_bits=4)
+            lay = FakeLayer()
+            gptq_cw(types.SimpleNamespace(quant_config=qc_), lay, kin, outs, kfull, nfull, torch.float16)
+            contracts.append({"method": "gptq", "geom": gname, "args": [kin, outs, kfull, nfull],
+                              "config": {"group_size": gs_, "desc_act": desc}, "params": lay.params,
+                              "exllama_state": lay.exllama_state.name})
+        qc_ = types.SimpleNamespace(group_size=128, pack_factor=8, weight_bits=4)
+        lay = FakeLayer()
+        awq_cw(types.SimpleNamespace(quant_config=qc_), lay, kin, outs, kfull, nfull, torch.float16)
+        contracts.append({"method": "awq", "geom": gname, "args": [kin, outs, kfull, nfull],
+                          "config": {"group_size": 128}, "params": lay.params})
+        for ser, scheme in ((True, "dynamic"), (True, "static"), (False, "dynamic")):
+            qc_ = types.SimpleNamespace(is_checkpoint_fp8_serialized=ser, activation_scheme=scheme)
+            lay = FakeLayer()
+            fp8_cw(types.SimpleNamespace(quant_config=qc_), lay, kin, outs, kfull, nfull, torch.bfloat16)
+            contracts.append({"method": "fp8", "geom": gname, "args": [kin, outs, kfull, nfull],
+                              "config": {"serialized": ser, "activation_scheme": scheme}, "params": lay.params})
+        for strat in ("channel", "tensor"):
+            for static in (False, True):
+                lay = FakeLayer()
+                ctf_cw(types.SimpleNamespace(strategy=ctu.QuantizationStrategy(strat), is_static_input_scheme=static),
+                       lay, output_partition_sizes=outs, input_size_per_partition=kin, params_dtype=torch.bfloat16,
+                       weight_loader=None)
+                contracts.append({"method": "ct-w8a8-fp8", "geom": gname, "args": [kin, outs, kfull, nfull],
+                                  "config": {"strategy": strat, "static": static}, "params": lay.params})
+    with open(os.path.join(OUT, "param_contracts.json"), "w") as f:
+        json.dump(contracts, f, indent=0)
 
     # ---------------- rotary tables, plain and Llama-3.1 scaled (rotary_embedding.py:101-120, 680-723) -----
     import math

@@ -388,3 +388,49 @@ def test_compressed_tensors_scheme_selection_golden(golden_dir):
             assert m.group_size == (-1 if want["group_size"] is None else want["group_size"])
             assert m.has_g_idx == (want["actorder"] == "group")
     assert seen == {"W8A8Fp8", "W8A16Fp8", "WNA16"}
+
+
+def test_parameter_contracts_golden(golden_dir):
+    """Host logic: the parameters every quant method registers (names, shapes, dtypes and the loader metadata
+    input_dim / output_dim / packed_dim / pack factor / one-scalar-per-shard) vs what the reference's own
+    create_weights registers, over column/row-parallel geometries at TP 1 and 2 (44 cases)."""
+    import json
+    from aphrodite_engine_amd.quantization.awq import AWQConfig
+    from aphrodite_engine_amd.quantization.fp8 import (CompressedTensorsW8A8Fp8Config, CompressedTensorsW8A8Fp8Method,
+                                                       Fp8Config)
+    from aphrodite_engine_amd.quantization.gptq import GPTQConfig
+    cases = json.load(open(os.path.join(golden_dir, "param_contracts.json")))
+    assert len(cases) == 44
+    for c in cases:
+        kin, outs, kfull, nfull = c["args"]
+        cfg = c["config"]
+        layer = torch.nn.Module()
+        if c["method"] == "gptq":
+            method = GPTQConfig(4, cfg["group_size"], cfg["desc_act"]).get_quant_method(layer, "")
+            dtype = torch.float16
+        elif c["method"] == "awq":
+            method = AWQConfig(4, cfg["group_size"], True).get_quant_method(layer, "")
+            dtype = torch.float16
+        elif c["method"] == "fp8":
+            method = Fp8Config(cfg["serialized"], cfg["activation_scheme"]).get_quant_method(layer, "")
+            dtype = torch.bfloat16
+        else:
+            method = CompressedTensorsW8A8Fp8Method(CompressedTensorsW8A8Fp8Config(cfg["strategy"], cfg["static"]))
+            dtype = torch.bfloat16
+        method.create_weights(layer, kin, outs, kfull, nfull, dtype, weight_loader=None)
+        mine = dict(layer.named_parameters())
+        for name, want in c["params"].items():
+            if want is None:
+                assert getattr(layer, name, None) is None, (c["method"], c["geom"], name)
+                continue
+            prm = mine.pop(name)
+            tag = (c["method"], c["geom"], cfg, name)
+            assert list(prm.shape) == want["shape"], tag
+            assert str(prm.dtype) == want["dtype"], tag
+            for key in ("input_dim", "output_dim", "packed_dim"):
+                assert getattr(prm, key, None) == want.get(key), tag + (key, )
+            assert getattr(prm, "pack_factor", None) == want.get("packed_factor"), tag
+            assert bool(getattr(prm, "needs_scalar_to_array", False)) == (want["kind"] == "PerTensorScaleParameter"), tag
+        assert not mine, f"extra parameters {list(mine)} in {c['method']} {c['geom']}"
+        if "exllama_state" in c:
+            assert layer.exllama_state.name == c["exllama_state"]
