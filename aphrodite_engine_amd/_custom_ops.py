@@ -716,9 +716,9 @@ def paged_attention_rope_packed(qkv_slabs: torch.Tensor, positions: torch.Tensor
 def sample_top_k_top_p(logits: torch.Tensor, temperature: Optional[torch.Tensor] = None,
                        top_k: Optional[torch.Tensor] = None, top_p: Optional[torch.Tensor] = None,
                        q: Optional[torch.Tensor] = None, seeds: Optional[torch.Tensor] = None,
-                       out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """temperature -> top-k -> top-p -> softmax -> argmax(probs / q) in one launch (sampler.py:256-262,
-    865-891, 1273-1292).  logits [B, V] f16 / bf16 / f32 (rows may be strided); per-row fp32
+                       out: Optional[torch.Tensor] = None, min_p: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """temperature -> top-k -> top-p -> min-p -> softmax -> argmax(probs / q) in one launch (sampler.py:256-262,
+    865-891, 894-908, 1273-1292).  logits [B, V] f16 / bf16 / f32 (rows may be strided); per-row fp32
     temperature / int32 top_k / fp32 top_p or None; q: Exp(1) draws [B, V] fp32 (``torch.empty_like
     (...).exponential_()`` like the reference), or None with int64 ``seeds`` [B] to draw in the kernel.
     Returns int64 [B]."""
@@ -737,6 +737,7 @@ def sample_top_k_top_p(logits: torch.Tensor, temperature: Optional[torch.Tensor]
             raise RuntimeError("sample_top_k_top_p: per-row parameters must have one entry per row")
         return t_
     temperature, top_k, top_p = prep(temperature, torch.float32), prep(top_k, torch.int32), prep(top_p, torch.float32)
+    min_p = prep(min_p, torch.float32)
     seeds = prep(seeds, torch.int64)
     if q is not None and (q.dtype != torch.float32 or q.shape != logits.shape or q.stride(1) != 1):
         raise RuntimeError("sample_top_k_top_p: q must be float32 [rows, vocab]")
@@ -745,7 +746,8 @@ def sample_top_k_top_p(logits: torch.Tensor, temperature: Optional[torch.Tensor]
     if out is None:
         out = torch.empty(rows, dtype=torch.int64, device=dev)
     check(_lib.lib().aphro_sample_top_k_top_p(
-        out.data_ptr(), logits.data_ptr(), logits.stride(0), _ptr(temperature), _ptr(top_k), _ptr(top_p), _ptr(q),
+        out.data_ptr(), logits.data_ptr(), logits.stride(0), _ptr(temperature), _ptr(top_k), _ptr(top_p), _ptr(min_p),
+        _ptr(q),
         q.stride(0) if q is not None else 0, _ptr(seeds), rows, vocab, _dt(logits), _stream()), "sample_top_k_top_p")
     return out
 

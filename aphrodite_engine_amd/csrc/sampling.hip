@@ -1,7 +1,8 @@
 // Fused random sampling for the decode step (sampling inside the HIP graph):
-//   temperature -> top-k -> top-p -> softmax -> multinomial (argmax(probs / q), q ~ Exp(1))
+//   temperature -> top-k -> top-p -> min-p -> softmax -> multinomial (argmax(probs / q), q ~ Exp(1))
 // one launch, one workgroup per row, no sort.  Semantics of aphrodite/modeling/layers/sampler.py:
-// logits.div_(t) (:256-262), _apply_top_k_top_p (:865-891), _multinomial (:1273-1292), in fp32.
+// logits.div_(t) (:256-262), _apply_top_k_top_p (:865-891), _apply_min_p (:894-908), _multinomial
+// (:1273-1292), in fp32.
 //
 // The reference sorts every row (128k logits) and scatters back; here the two thresholds are found by
 // a 3-pass radix select (11 + 11 + 10 bits) over order-preserving integer keys with histograms in LDS:
@@ -26,6 +27,7 @@ struct SampleParams {
   const float* temperature;  // [rows] or NULL (1.0)
   const int32_t* top_k;      // [rows] or NULL (disabled); <= 0 or >= vocab: disabled
   const float* top_p;        // [rows] or NULL (disabled)
+  const float* min_p;        // [rows] or NULL (disabled): drop tokens with prob < min_p * max prob (:894-908)
   const float* q;            // [rows, vocab] Exp(1) noise, or NULL: drawn in the kernel from `seeds`
   int64_t q_stride;
   const int64_t* seeds;      // [rows], used when q == NULL
@@ -284,9 +286,12 @@ __global__ __launch_bounds__(SP_THREADS) void sample_kernel(SampleParams p) {
   int best_i = 0x7fffffff;
   const float* qrow = p.q ? p.q + (size_t)row * p.q_stride : nullptr;
   const int64_t seed = p.seeds ? p.seeds[row] : 0;
+  // min-p acts on the probabilities of the row as masked so far: p_i < min_p * p_max  <=>  exp(x_i - max) < min_p
+  const float mp = p.min_p ? p.min_p[row] : 0.0f;
   for_each_logit<T, VEC>(lrow, V, t, [&](int i, float x) {
     if (key_of(x) >= kmin) {
       const float e = expf(x - mx);
+      if (e < mp && x != mx) return;
       const float qq = qrow ? qrow[i] : exp_noise(seed, i);
       const float s = e / qq;
       if (s > best) { best = s; best_i = i; }        // ascending i: first maximum wins inside the thread
@@ -312,7 +317,8 @@ __global__ __launch_bounds__(SP_THREADS) void sample_kernel(SampleParams p) {
 using namespace aphro;
 
 extern "C" int aphro_sample_top_k_top_p(int64_t* out, const void* logits, int64_t row_stride, const float* temperature,
-                                        const int32_t* top_k, const float* top_p, const float* q, int64_t q_stride,
+                                        const int32_t* top_k, const float* top_p, const float* min_p, const float* q,
+                                        int64_t q_stride,
                                         const int64_t* seeds, int64_t rows, int64_t vocab, int dtype, void* stream) {
   APHRO_CHECK(out && logits, "sample_top_k_top_p: NULL argument");
   APHRO_CHECK(dtype == APHRO_F16 || dtype == APHRO_BF16 || dtype == APHRO_F32, "sample_top_k_top_p: unsupported dtype %d", dtype);
@@ -321,7 +327,7 @@ extern "C" int aphro_sample_top_k_top_p(int64_t* out, const void* logits, int64_
   if (rows == 0) return APHRO_OK;
   SampleParams p;
   p.out = out; p.logits = logits; p.row_stride = row_stride; p.temperature = temperature; p.top_k = top_k;
-  p.top_p = top_p; p.q = q; p.q_stride = q_stride; p.seeds = seeds; p.vocab = (int)vocab;
+  p.top_p = top_p; p.min_p = min_p; p.q = q; p.q_stride = q_stride; p.seeds = seeds; p.vocab = (int)vocab;
   dim3 grid((unsigned)rows), block(SP_THREADS);
   const size_t esz = dtype == APHRO_F32 ? 4 : 2;
   const bool vec = ((uintptr_t)logits % 16) == 0 && ((size_t)row_stride * esz) % 16 == 0;   // every row 16-byte aligned

@@ -432,15 +432,17 @@ int aphro_paged_attention_rope_packed_scaled(void* out, void* out_packed, const 
  * Random sampling inside the decode graph: temperature -> top-k -> top-p -> softmax
  * -> multinomial in one launch.  Semantics of modeling/layers/sampler.py: logits / t (:256-262, t <
  * 1e-5 -> 1), _apply_top_k_top_p (:865-891; values tied with a threshold are kept as a group),
- * _multinomial = argmax(probs / q), q ~ Exp(1) (:1273-1292).  logits [rows, vocab] f16 / bf16 / f32
- * with row_stride elements between rows; temperature / top_k / top_p per row or NULL (disabled;
+ * _apply_min_p (:894-908: prob < min_p * max prob dropped), _multinomial = argmax(probs / q), q ~ Exp(1)
+ * (:1273-1292).  logits [rows, vocab] f16 / bf16 / f32
+ * with row_stride elements between rows; temperature / top_k / top_p / min_p per row or NULL (disabled;
  * top_k <= 0 or >= vocab disables); q: the caller's Exp(1) draws [rows, vocab] (q_stride), or NULL
  * to draw them in the kernel from seeds[rows].  out: int64 [rows].
  * ---------------------------------------------------------------------- */
 int aphro_sample_top_k_top_p(int64_t* out, const void* logits, int64_t row_stride,
                              const float* temperature, const int32_t* top_k, const float* top_p,
-                             const float* q, int64_t q_stride, const int64_t* seeds, int64_t rows,
-                             int64_t vocab, int dtype, void* stream);
+                             const float* min_p, const float* q, int64_t q_stride,
+                             const int64_t* seeds, int64_t rows, int64_t vocab, int dtype,
+                             void* stream);
 
 /* ------------------------------------------------------------------------
  * Tensor-parallel sum all-reduce through xGMI peer access -- the `_C_custom_ar::*` ops

@@ -239,7 +239,7 @@ def main():
 
     # ---------------- sampler: top-k / top-p masking and the multinomial draw --------------------
     # aphrodite/modeling/layers/sampler.py:865-891 and :1273-1292, lifted as they lie
-    ns4 = _lift("aphrodite/modeling/layers/sampler.py", {"_apply_top_k_top_p", "_multinomial"},
+    ns4 = _lift("aphrodite/modeling/layers/sampler.py", {"_apply_top_k_top_p", "_multinomial", "_apply_min_p"},
                 dict(g, SequenceGroupToSample=object))
     torch.manual_seed(11)
     B, V = 7, 4096
@@ -253,9 +253,11 @@ def main():
     q = torch.empty_like(probs).exponential_()                 # the draws _multinomial makes with this seed
     torch.manual_seed(12)
     ids = ns4["_multinomial"](probs.clone(), 1).reshape(-1)
+    min_p = torch.tensor([0.05, 0.0, 0.2, 0.01, 0.5, 0.1, 0.02])
+    masked_minp = ns4["_apply_min_p"](masked.clone(), min_p.clone())
     np.savez_compressed(os.path.join(OUT, "sampler.npz"), logits=logits.numpy(), top_k=top_k.numpy(),
                         top_p=top_p.numpy(), masked=masked.numpy(), probs=probs.numpy(), q=q.numpy(),
-                        ids=ids.numpy())
+                        ids=ids.numpy(), min_p=min_p.numpy(), masked_minp=masked_minp.numpy())
 
     # ---------------- compressed-tensors: which layers a checkpoint left unquantised ----------------
     # compressed_tensors/utils.py:113-171, 242-260 (should_ignore_layer and helpers)

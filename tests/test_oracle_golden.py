@@ -272,6 +272,8 @@ def test_sampler_golden(golden_dir):
         else:
             np.testing.assert_array_equal(masked[r], g["masked"][r], err_msg=f"row {r}")
     np.testing.assert_allclose(osamp.softmax32(g["masked"]), g["probs"], rtol=2e-6, atol=1e-12)
+    # min-p on the reference's masked logits
+    np.testing.assert_array_equal(osamp.apply_min_p(g["masked"], g["min_p"]), g["masked_minp"])
     # the draw itself, on the reference's probabilities and its Exp(1) variates
     np.testing.assert_array_equal(osamp.multinomial(g["probs"], g["q"]), g["ids"])
     # and the whole chain from logits

@@ -57,6 +57,23 @@ def test_sample_matches_reference_restatement(ops, dtype, v):
             assert (g == tok) == expect_in
 
 
+def test_sample_min_p(ops):
+    rng = np.random.default_rng(9)
+    b, v = 8, 32000
+    logits = (rng.standard_normal((b, v)) * 3).astype(np.float32)
+    temperature = np.array([1.0, 0.7, 1.3, 1.0, 2.0, 0.5, 1.0, 1.0], np.float32)
+    top_k = np.array([0, 50, 0, 40, 0, 0, 200, 0], np.int32)
+    top_p = np.array([1.0, 1.0, 0.9, 0.95, 1.0, 0.8, 1.0, 1.0], np.float32)
+    min_p = np.array([0.05, 0.1, 0.02, 0.3, 0.01, 0.0, 0.9, 1.0], np.float32)
+    q = rng.exponential(size=(b, v)).astype(np.float32)
+    want, masked = osamp.sample(logits, temperature, top_k, top_p, q, min_p=min_p)
+    got = ops.sample_top_k_top_p(torch.from_numpy(logits).to(DEV), torch.from_numpy(temperature),
+                                 torch.from_numpy(top_k), torch.from_numpy(top_p), torch.from_numpy(q).to(DEV),
+                                 min_p=torch.from_numpy(min_p)).cpu().numpy()
+    assert np.isfinite(masked)[np.arange(b), got].all()
+    np.testing.assert_array_equal(got, want)
+
+
 def test_sample_disabled_filters_and_errors(ops):
     rng = np.random.default_rng(3)
     logits = torch.from_numpy(rng.standard_normal((4, 5000)).astype(np.float32))
