@@ -96,7 +96,7 @@ class Fp8Config(QuantizationConfig):
         return []
 
 
-class Fp8LinearMethod(LinearMethodBase):
+class CDNA4Fp8LinearMethod(LinearMethodBase):
     def __init__(self, quant_config: Fp8Config):
         self.quant_config = quant_config
         self.use_marlin = quant_config.weight_only
@@ -167,6 +167,9 @@ class Fp8LinearMethod(LinearMethodBase):
                                 input_scale=layer.input_scale, bias=bias,
                                 cutlass_fp8_supported=True,
                                 use_per_token_if_dynamic=False)
+
+
+Fp8LinearMethod = CDNA4Fp8LinearMethod   # the reference's name (see the note in gptq.py on weight_loader_v2)
 
 
 # --------------------------------------------------------------------------------------------------

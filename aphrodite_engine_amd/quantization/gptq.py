@@ -72,7 +72,7 @@ class ExllamaState(Enum):
     READY = enum.auto()
 
 
-class GPTQLinearMethod(LinearMethodBase):
+class CDNA4GPTQLinearMethod(LinearMethodBase):
     def __init__(self, quant_config: GPTQConfig):
         self.quant_config = quant_config
 
@@ -149,3 +149,12 @@ class GPTQLinearMethod(LinearMethodBase):
         if bias is not None:
             output.add_(bias)
         return output.reshape(out_shape)
+
+
+# The reference picks its parameter-object loader (``weight_loader_v2``: ``param.load_qkv_weight(...)`` on
+# BaseAphroditeParameter subclasses) for methods whose CLASS NAME is in WEIGHT_LOADER_V2_SUPPORTED
+# (modeling/layers/linear.py:28-44, 330-332).  Our parameters are plain nn.Parameters carrying the
+# v1 metadata (input_dim / output_dim / packed_dim / pack_factor), which the reference's v1
+# ``weight_loader`` methods consume -- so the class carries a name of its own and the reference's
+# name stays available as an alias for imports.
+GPTQLinearMethod = CDNA4GPTQLinearMethod

@@ -66,6 +66,15 @@ def test_gptq_config_and_weights():
     layer = torch.nn.Module()
     m = cfg.get_quant_method(layer, "")
     assert isinstance(m, GPTQLinearMethod)
+    # the reference routes classes NAMED like its own v2-loader methods to param.load_*_weight(); ours use
+    # plain Parameters + v1 metadata, so the class name must not collide (linear.py:28-44, 330-332)
+    from aphrodite_engine_amd.quantization.awq import AWQLinearMethod
+    from aphrodite_engine_amd.quantization.fp8 import Fp8LinearMethod
+    v2_names = {"AWQLinearMethod", "AWQMarlinLinearMethod", "CompressedTensorsLinearMethod", "FBGEMMFp8LinearMethod",
+                "Fp8LinearMethod", "GPTQLinearMethod", "GPTQMarlin24LinearMethod", "GPTQMarlinLinearMethod",
+                "HQQMarlinMethod", "MarlinLinearMethod", "ModelOptFp8LinearMethod", "QQQLinearMethod"}
+    for cls in (GPTQLinearMethod, AWQLinearMethod, Fp8LinearMethod):
+        assert cls.__name__ not in v2_names
     m.create_weights(layer, 4096, [4096, 1024, 1024], 4096, 6144, torch.float16)
     assert layer.qweight.shape == (512, 6144) and layer.qweight.dtype == torch.int32
     assert layer.qzeros.shape == (32, 768) and layer.scales.shape == (32, 6144)

@@ -123,7 +123,7 @@ def test_awq_checkpoint(tmp_path):
     truth = CU.write_checkpoint(str(tmp_path), CFG, "awq", seed=2)
     for rank, world in WORLDS:
         m = build(tmp_path, "awq", rank, world)
-        assert type(m.layers[0].qkv_proj.quant_method).__name__ == "AWQLinearMethod"
+        assert type(m.layers[0].qkv_proj.quant_method).__name__ == "CDNA4AWQLinearMethod"
         for li, layer in enumerate(m.layers):
             eq = expected_logical(truth, li, rank, world, "q")
             es = expected_groups(truth, li, rank, world, "s", 128)
@@ -143,7 +143,7 @@ def test_fp8_checkpoints(tmp_path, fmt, static):
     for rank, world in WORLDS:
         m = build(tmp_path, fmt, rank, world, dtype=torch.bfloat16)
         sets = col_sets(rank, world)
-        expect_method = {"fp8": "Fp8LinearMethod", "ct-fp8-channel": "CompressedTensorsW8A8Fp8Method",
+        expect_method = {"fp8": "CDNA4Fp8LinearMethod", "ct-fp8-channel": "CompressedTensorsW8A8Fp8Method",
                          "ct-fp8-tensor": "CompressedTensorsW8A8Fp8Method",
                          "ct-w8a16": "CompressedTensorsW8A16Fp8Method"}[fmt]
         for li, layer in enumerate(m.layers):
