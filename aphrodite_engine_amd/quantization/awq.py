@@ -12,6 +12,7 @@ from torch import nn
 
 from .. import _custom_ops as ops
 from .base_config import LinearMethodBase, QuantizationConfig, _param
+from .utils import layer_kind
 
 
 class AWQConfig(QuantizationConfig):
@@ -55,10 +56,13 @@ class AWQConfig(QuantizationConfig):
                    prepack=os.environ.get("APHRODITE_AWQ_NO_PREPACK", "0") != "1")
 
     def get_quant_method(self, layer: nn.Module, prefix: str):
-        if type(layer).__name__ == "FusedMoE":     # int4 experts: grouped CDNA4 GEMM (moe.py)
+        kind = layer_kind(layer)
+        if kind == "moe":                 # int4 experts: grouped CDNA4 GEMM (moe.py)
             from ..moe import Wna16MoEMethod
             return Wna16MoEMethod("awq", self.group_size)
-        return AWQLinearMethod(self)
+        if kind == "linear":
+            return AWQLinearMethod(self)
+        return None                       # awq.py:63-67
 
     def get_scaled_act_names(self) -> List[str]:
         return ["gelu", "gelu_fast", "gelu_new", "gelu_pytorch_tanh"]

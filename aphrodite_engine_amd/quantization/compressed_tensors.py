@@ -25,7 +25,8 @@ from ..scalar_type import scalar_types
 from .base_config import LinearMethodBase, QuantizationConfig, _param
 from .fp8 import CompressedTensorsW8A8Fp8Config, CompressedTensorsW8A8Fp8Method
 from .kernels import choose_mp_linear_kernel
-from .utils import FUSED_LAYER_SHARDS, layer_is_ignored, name_matches as _matches
+from .utils import (FUSED_LAYER_SHARDS, layer_is_ignored, layer_kind, name_matches as _matches,
+                    unquantized_linear_method)
 from .kernels.MPLinearKernel import MPLinearLayerConfig
 
 ACTIVATION_QUANT_FORMATS = ("naive-quantized", "int-quantized", "float-quantized")
@@ -109,8 +110,17 @@ class CompressedTensorsConfig(QuantizationConfig):
         return found[0]
 
     def get_quant_method(self, layer: nn.Module, prefix: str) -> Optional[LinearMethodBase]:
+        kind = layer_kind(layer)             # compressed_tensors.py:60-79
+        if kind == "attention":
+            from .kv_cache import BaseKVCacheMethod
+            return BaseKVCacheMethod(self)
+        if kind == "moe":
+            raise NotImplementedError("compressed-tensors experts (CompressedTensorsMoEMethod) are not built for "
+                                      "MI355X yet")
+        if kind != "linear":
+            return None
         if layer_is_ignored(prefix, self.ignore):
-            return None                      # the layer keeps its 16-bit weight (UnquantizedLinearMethod role)
+            return unquantized_linear_method()   # the layer keeps its 16-bit weight
         scheme = self._scheme_for(prefix)
         w, a = scheme["weights"], scheme["input_activations"]
         if w is None:

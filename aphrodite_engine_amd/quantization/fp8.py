@@ -13,7 +13,7 @@ from torch import nn
 
 from .. import _custom_ops as ops
 from .base_config import LinearMethodBase, QuantizationConfig, _param
-from .utils import layer_is_ignored
+from .utils import layer_is_ignored, layer_kind, unquantized_linear_method
 
 ACTIVATION_SCHEMES = ["static", "dynamic"]
 
@@ -88,9 +88,17 @@ class Fp8Config(QuantizationConfig):
         return cls(is_checkpoint_fp8_serialized, activation_scheme, ignored_layers)
 
     def get_quant_method(self, layer: nn.Module, prefix: str) -> Optional["Fp8LinearMethod"]:
-        if layer_is_ignored(prefix, self.ignored_layers):   # fp8.py:84-86 is_layer_skipped
-            return None
-        return Fp8LinearMethod(self)
+        kind = layer_kind(layer)        # fp8.py:79-92
+        if kind == "linear":
+            if layer_is_ignored(prefix, self.ignored_layers):   # is_layer_skipped
+                return unquantized_linear_method()
+            return Fp8LinearMethod(self)
+        if kind == "attention":           # k_scale / v_scale of an FP8 KV cache come with the checkpoint
+            from .kv_cache import BaseKVCacheMethod
+            return BaseKVCacheMethod(self)
+        if kind == "moe":
+            raise NotImplementedError("FP8 experts (Fp8MoEMethod) are not built for MI355X yet")
+        return None
 
     def get_scaled_act_names(self) -> List[str]:
         return []
@@ -210,7 +218,7 @@ class CompressedTensorsW8A8Fp8Config(QuantizationConfig):
         return cls(strategy=w.get("strategy", "channel"), is_static_input_scheme=not a.get("dynamic", True))
 
     def get_quant_method(self, layer: nn.Module, prefix: str) -> Optional["CompressedTensorsW8A8Fp8Method"]:
-        return CompressedTensorsW8A8Fp8Method(self)
+        return CompressedTensorsW8A8Fp8Method(self) if layer_kind(layer) == "linear" else None
 
     def get_scaled_act_names(self) -> List[str]:
         return []

@@ -12,6 +12,7 @@ from torch import nn
 
 from .. import _custom_ops as ops
 from .base_config import LinearMethodBase, QuantizationConfig, _param
+from .utils import layer_kind
 
 
 class GPTQConfig(QuantizationConfig):
@@ -57,10 +58,14 @@ class GPTQConfig(QuantizationConfig):
         return cls(weight_bits, group_size, desc_act, lm_head_quantized)
 
     def get_quant_method(self, layer: nn.Module, prefix: str):
-        if type(layer).__name__ == "FusedMoE":     # int4 experts: grouped CDNA4 GEMM (moe.py)
+        kind = layer_kind(layer)
+        if kind == "moe":                 # int4 experts: grouped CDNA4 GEMM (moe.py)
             from ..moe import Wna16MoEMethod
             return Wna16MoEMethod("gptq", self.group_size, self.desc_act)
-        return GPTQLinearMethod(self)
+        if kind == "linear" or (kind == "embedding" and self.lm_head_quantized
+                                and "ParallelLMHead" in {c.__name__ for c in type(layer).__mro__}):
+            return GPTQLinearMethod(self)
+        return None                       # attention, embeddings: nothing to quantise (gptq.py:75-80)
 
     def get_scaled_act_names(self) -> List[str]:
         return []

@@ -25,3 +25,28 @@ def layer_is_ignored(prefix: Optional[str], ignore: List[str]) -> bool:
         raise ValueError(f"Found a different quantization schemes for {FUSED_LAYER_SHARDS[proj]} in {prefix}. "
                          "All shards of a fused layer must use the same scheme.")
     return verdicts.pop()
+
+
+def layer_kind(layer) -> str:
+    """Which family a layer asking for its quant method belongs to, by class NAME along the MRO (the
+    reference dispatches with isinstance on LinearBase / FusedMoE / Attention / ParallelLMHead --
+    fp8.py:79-92, gptq.py:75-80 -- which must work here without importing the reference):
+    "moe", "attention", "embedding" (vocab embedding / lm_head), else "linear"."""
+    names = {c.__name__ for c in type(layer).__mro__}
+    if "FusedMoE" in names:
+        return "moe"
+    if "Attention" in names:
+        return "attention"
+    if names & {"VocabParallelEmbedding", "ParallelLMHead"}:
+        return "embedding"
+    return "linear"
+
+
+def unquantized_linear_method():
+    """What an ignored linear layer gets: the reference's UnquantizedLinearMethod when the reference is
+    importable (its LinearBase needs a method object), else None (our QuantLinear keeps a 16-bit weight)."""
+    try:
+        from aphrodite.modeling.layers.linear import UnquantizedLinearMethod
+        return UnquantizedLinearMethod()
+    except Exception:
+        return None

@@ -212,3 +212,42 @@ def test_torch_library_registration():
                                        torch.zeros(1, 2, dtype=torch.int32),
                                        torch.zeros(1, 16, dtype=torch.half),
                                        torch.empty(0, dtype=torch.int32), True, 4)
+
+
+def test_quant_configs_dispatch_on_layer_family():
+    """The reference asks every Attention / FusedMoE / embedding layer for a quant method too (attention/
+    layer.py:60-75 asserts a BaseKVCacheMethod): a config must answer by layer family, not always with a
+    linear method."""
+    from aphrodite_engine_amd.quantization.awq import AWQConfig
+    from aphrodite_engine_amd.quantization.compressed_tensors import CompressedTensorsConfig
+    from aphrodite_engine_amd.quantization.fp8 import Fp8Config
+    from aphrodite_engine_amd.quantization.gptq import GPTQConfig
+    from aphrodite_engine_amd.quantization.kv_cache import BaseKVCacheMethod
+    mk = lambda name: type(name, (torch.nn.Module, ), {})()        # noqa: E731
+    attn, lin, emb, head = mk("Attention"), mk("ColumnParallelLinear"), mk("VocabParallelEmbedding"), mk("ParallelLMHead")
+    gptq, awq = GPTQConfig(4, 128, False), AWQConfig(4, 128, True)
+    fp8 = Fp8Config(True, "dynamic", ignored_layers=["lm_head"])
+    ct = CompressedTensorsConfig.from_config({"format": "float-quantized", "ignore": ["lm_head"], "config_groups": {
+        "g": {"targets": ["Linear"], "weights": {"num_bits": 8, "type": "float", "strategy": "channel"},
+              "input_activations": {"num_bits": 8, "type": "float", "strategy": "token", "dynamic": True}}}})
+    for cfg in (gptq, awq):
+        assert cfg.get_quant_method(attn, "model.layers.0.self_attn.attn") is None
+        assert cfg.get_quant_method(emb, "model.embed_tokens") is None
+        assert cfg.get_quant_method(head, "lm_head") is None
+        assert cfg.get_quant_method(lin, "model.layers.0.mlp.down_proj") is not None
+    assert GPTQConfig(4, 128, False, lm_head_quantized=True).get_quant_method(head, "lm_head") is not None
+    for cfg in (fp8, ct):
+        assert isinstance(cfg.get_quant_method(attn, "model.layers.0.self_attn.attn"), BaseKVCacheMethod)
+        assert cfg.get_quant_method(emb, "model.embed_tokens") is None
+        assert cfg.get_quant_method(lin, "model.layers.0.mlp.down_proj") is not None
+        assert cfg.get_quant_method(lin, "lm_head") is None          # ignored layer, reference not installed here
+        with pytest.raises(NotImplementedError):
+            cfg.get_quant_method(mk("FusedMoE"), "model.layers.0.block_sparse_moe.experts")
+    # the KV-cache method registers k_scale / v_scale and resolves them after loading
+    attn.kv_cache_dtype = "fp8"
+    m = fp8.get_quant_method(attn, "x")
+    m.create_weights(attn)
+    attn.k_scale.data.fill_(0.02)
+    attn.v_scale.data.fill_(0.03)
+    m.process_weights_after_loading(attn)
+    assert (attn._k_scale, attn._v_scale) == (pytest.approx(0.02), pytest.approx(0.03)) and not hasattr(attn, "k_scale")
