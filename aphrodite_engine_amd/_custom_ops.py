@@ -716,12 +716,14 @@ def paged_attention_rope_packed(qkv_slabs: torch.Tensor, positions: torch.Tensor
 def sample_top_k_top_p(logits: torch.Tensor, temperature: Optional[torch.Tensor] = None,
                        top_k: Optional[torch.Tensor] = None, top_p: Optional[torch.Tensor] = None,
                        q: Optional[torch.Tensor] = None, seeds: Optional[torch.Tensor] = None,
-                       out: Optional[torch.Tensor] = None, min_p: Optional[torch.Tensor] = None) -> torch.Tensor:
+                       out: Optional[torch.Tensor] = None, min_p: Optional[torch.Tensor] = None,
+                       logprobs_out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """temperature -> top-k -> top-p -> min-p -> softmax -> argmax(probs / q) in one launch (sampler.py:256-262,
     865-891, 894-908, 1273-1292).  logits [B, V] f16 / bf16 / f32 (rows may be strided); per-row fp32
     temperature / int32 top_k / fp32 top_p or None; q: Exp(1) draws [B, V] fp32 (``torch.empty_like
     (...).exponential_()`` like the reference), or None with int64 ``seeds`` [B] to draw in the kernel.
-    Returns int64 [B]."""
+    ``logprobs_out`` (fp32 [B], optional) receives log_softmax of the row after temperature and masks -- what
+    the reference calls logprobs (sampler.py:545) -- at the sampled token.  Returns int64 [B]."""
     _require_cuda(logits)
     if logits.dim() != 2 or logits.stride(1) != 1:
         raise RuntimeError("sample_top_k_top_p: logits must be [rows, vocab] with unit column stride")
@@ -745,10 +747,14 @@ def sample_top_k_top_p(logits: torch.Tensor, temperature: Optional[torch.Tensor]
         raise RuntimeError("sample_top_k_top_p: pass the Exp(1) noise q or per-row seeds")
     if out is None:
         out = torch.empty(rows, dtype=torch.int64, device=dev)
+    if logprobs_out is not None and (logprobs_out.dtype != torch.float32 or logprobs_out.numel() != rows
+                                     or not logprobs_out.is_contiguous() or logprobs_out.device != dev):
+        raise RuntimeError("sample_top_k_top_p: logprobs_out must be a contiguous float32 [rows] tensor on the device")
     check(_lib.lib().aphro_sample_top_k_top_p(
         out.data_ptr(), logits.data_ptr(), logits.stride(0), _ptr(temperature), _ptr(top_k), _ptr(top_p), _ptr(min_p),
         _ptr(q),
-        q.stride(0) if q is not None else 0, _ptr(seeds), rows, vocab, _dt(logits), _stream()), "sample_top_k_top_p")
+        q.stride(0) if q is not None else 0, _ptr(seeds), _ptr(logprobs_out), rows, vocab, _dt(logits), _stream()),
+        "sample_top_k_top_p")
     return out
 
 

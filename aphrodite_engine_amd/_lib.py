@@ -38,7 +38,7 @@ SIGNATURES = {
     "aphro_silu_and_mul_quant_fp8": (I, [P, P, P, P, L, I, I, P]),
     "aphro_paged_attention_rope_packed_scaled": (I, [P, P, P, I, P, P, P, P, P, P, P, I, I, I, I, F, P, P,
                                                      I, I, I, P, L, L, I, I, F, F, P]),
-    "aphro_sample_top_k_top_p": (I, [P, P, L, P, P, P, P, P, L, P, L, L, I, P]),
+    "aphro_sample_top_k_top_p": (I, [P, P, L, P, P, P, P, P, L, P, P, L, L, I, P]),
     "aphro_custom_ar_meta_size": (L, []),
     "aphro_ipc_handle_bytes": (I, []),
     "aphro_custom_ar_alloc_shared": (I, [P, Z]),

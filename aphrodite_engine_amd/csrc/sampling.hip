@@ -31,6 +31,7 @@ struct SampleParams {
   const float* q;            // [rows, vocab] Exp(1) noise, or NULL: drawn in the kernel from `seeds`
   int64_t q_stride;
   const int64_t* seeds;      // [rows], used when q == NULL
+  float* logprobs;           // [rows] or NULL: log-softmax of the masked, temperature-scaled row at the sampled token
   int vocab;
 };
 
@@ -288,10 +289,14 @@ __global__ __launch_bounds__(SP_THREADS) void sample_kernel(SampleParams p) {
   const int64_t seed = p.seeds ? p.seeds[row] : 0;
   // min-p acts on the probabilities of the row as masked so far: p_i < min_p * p_max  <=>  exp(x_i - max) < min_p
   const float mp = p.min_p ? p.min_p[row] : 0.0f;
+  // logprobs: the reference takes log_softmax of the row AFTER the masks (sampler.py:545): normaliser = the survivors
+  const bool want_lp = p.logprobs != nullptr;
+  float zsum = 0.f;
   for_each_logit<T, VEC>(lrow, V, t, [&](int i, float x) {
     if (key_of(x) >= kmin) {
       const float e = expf(x - mx);
       if (e < mp && x != mx) return;
+      zsum += e;
       const float qq = qrow ? qrow[i] : exp_noise(seed, i);
       const float s = e / qq;
       if (s > best) { best = s; best_i = i; }        // ascending i: first maximum wins inside the thread
@@ -308,7 +313,21 @@ __global__ __launch_bounds__(SP_THREADS) void sample_kernel(SampleParams p) {
   if (tid == 0) {
     for (int w = 1; w < SP_THREADS / 64; ++w)
       if (redf[w] > best || (redf[w] == best && redi[w] < best_i)) { best = redf[w]; best_i = redi[w]; }
-    p.out[row] = best_i == 0x7fffffff ? 0 : best_i;
+    best_i = best_i == 0x7fffffff ? 0 : best_i;
+    p.out[row] = best_i;
+    redi[0] = best_i;
+  }
+  if (want_lp) {                                  // fixed reduction order: thread, wave tree, waves in sequence
+    __syncthreads();
+    zsum = wave_sum(zsum);
+    if ((tid & 63) == 0) redf[tid >> 6] = zsum;
+    __syncthreads();
+    if (tid == 0) {
+      float z = 0.f;
+      for (int w = 0; w < SP_THREADS / 64; ++w) z += redf[w];
+      const float xs = load_logit<T>(lrow, redi[0]);
+      p.logprobs[row] = ((t == 1.0f ? xs : xs / t) - mx) - logf(z);
+    }
   }
 }
 
@@ -318,8 +337,8 @@ using namespace aphro;
 
 extern "C" int aphro_sample_top_k_top_p(int64_t* out, const void* logits, int64_t row_stride, const float* temperature,
                                         const int32_t* top_k, const float* top_p, const float* min_p, const float* q,
-                                        int64_t q_stride,
-                                        const int64_t* seeds, int64_t rows, int64_t vocab, int dtype, void* stream) {
+                                        int64_t q_stride, const int64_t* seeds, float* logprobs_out, int64_t rows,
+                                        int64_t vocab, int dtype, void* stream) {
   APHRO_CHECK(out && logits, "sample_top_k_top_p: NULL argument");
   APHRO_CHECK(dtype == APHRO_F16 || dtype == APHRO_BF16 || dtype == APHRO_F32, "sample_top_k_top_p: unsupported dtype %d", dtype);
   APHRO_CHECK(vocab > 0 && vocab < (1ll << 31), "sample_top_k_top_p: vocab=%lld unsupported", (long long)vocab);
@@ -327,7 +346,7 @@ extern "C" int aphro_sample_top_k_top_p(int64_t* out, const void* logits, int64_
   if (rows == 0) return APHRO_OK;
   SampleParams p;
   p.out = out; p.logits = logits; p.row_stride = row_stride; p.temperature = temperature; p.top_k = top_k;
-  p.top_p = top_p; p.min_p = min_p; p.q = q; p.q_stride = q_stride; p.seeds = seeds; p.vocab = (int)vocab;
+  p.top_p = top_p; p.min_p = min_p; p.q = q; p.q_stride = q_stride; p.seeds = seeds; p.logprobs = logprobs_out; p.vocab = (int)vocab;
   dim3 grid((unsigned)rows), block(SP_THREADS);
   const size_t esz = dtype == APHRO_F32 ? 4 : 2;
   const bool vec = ((uintptr_t)logits % 16) == 0 && ((size_t)row_stride * esz) % 16 == 0;   // every row 16-byte aligned

@@ -436,13 +436,14 @@ int aphro_paged_attention_rope_packed_scaled(void* out, void* out_packed, const 
  * (:1273-1292).  logits [rows, vocab] f16 / bf16 / f32
  * with row_stride elements between rows; temperature / top_k / top_p / min_p per row or NULL (disabled;
  * top_k <= 0 or >= vocab disables); q: the caller's Exp(1) draws [rows, vocab] (q_stride), or NULL
- * to draw them in the kernel from seeds[rows].  out: int64 [rows].
+ * to draw them in the kernel from seeds[rows].  out: int64 [rows]; logprobs_out (optional, fp32 [rows]):
+ * log_softmax of the temperature-scaled row AFTER the masks, at the sampled token (sampler.py:545).
  * ---------------------------------------------------------------------- */
 int aphro_sample_top_k_top_p(int64_t* out, const void* logits, int64_t row_stride,
                              const float* temperature, const int32_t* top_k, const float* top_p,
                              const float* min_p, const float* q, int64_t q_stride,
-                             const int64_t* seeds, int64_t rows, int64_t vocab, int dtype,
-                             void* stream);
+                             const int64_t* seeds, float* logprobs_out, int64_t rows, int64_t vocab,
+                             int dtype, void* stream);
 
 /* ------------------------------------------------------------------------
  * Tensor-parallel sum all-reduce through xGMI peer access -- the `_C_custom_ar::*` ops

@@ -72,6 +72,15 @@ def test_sample_min_p(ops):
                                  min_p=torch.from_numpy(min_p)).cpu().numpy()
     assert np.isfinite(masked)[np.arange(b), got].all()
     np.testing.assert_array_equal(got, want)
+    # logprob of the sampled token: log_softmax of the masked row (sampler.py:545)
+    lp = torch.empty(b, dtype=torch.float32, device=DEV)
+    got2 = ops.sample_top_k_top_p(torch.from_numpy(logits).to(DEV), torch.from_numpy(temperature),
+                                  torch.from_numpy(top_k), torch.from_numpy(top_p), torch.from_numpy(q).to(DEV),
+                                  min_p=torch.from_numpy(min_p), logprobs_out=lp).cpu().numpy()
+    np.testing.assert_array_equal(got2, want)
+    x = masked.astype(np.float64)          # after temperature, top-k, top-p, min-p (-inf = masked)
+    ref_lp = x[np.arange(b), want] - (np.log(np.exp(x - x.max(1, keepdims=True)).sum(1)) + x.max(1))
+    np.testing.assert_allclose(lp.cpu().numpy(), ref_lp, atol=2e-5, rtol=1e-5)
 
 
 def test_sample_disabled_filters_and_errors(ops):
