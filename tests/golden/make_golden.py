@@ -387,6 +387,27 @@ def main():
                     prm2 = mk(shape, dtype, **attrs)
                     obj.weight_loader(prm2, fused, None)
                     assert torch.equal(prm2.data, prm.data)
+    # more head layouts for the qkv loader alone: MHA (8/8), MQA (4/1: the KV head replicated on every rank),
+    # GQA with fewer KV heads than ranks (8/2 at world 4 and 8)
+    for hq, hkv, worlds in ((8, 8, ((2, 0), (4, 2))), (4, 1, ((2, 1), (4, 3))), (8, 2, ((4, 1), (8, 5)))):
+        for world, rank in worlds:
+            tp["rank"], tp["world"] = rank, world
+            nh = hq // world
+            nkv, rep = (1, world // hkv) if world >= hkv else (hkv // world, 1)
+            qkv = holder("QKVParallelLinear", quant_config=object(), num_heads=nh, num_kv_heads=nkv, head_size=HD,
+                         num_kv_head_replicas=rep, total_num_heads=hq, total_num_kv_heads=hkv,
+                         output_sizes=[nh * HD * world, nkv * HD * world, nkv * HD * world])
+            n_loc = (nh + 2 * nkv) * HD
+            tag = f"h{hq}kv{hkv}"
+            for pname in ("gptq.qweight", "gptq.qzeros", "gptq.scales", "fp8.weight", "fp8.weight_scale"):
+                shape, dtype, attrs = param_table(HID, n_loc, 3, False)[pname]
+                prm = mk(shape, dtype, **attrs)
+                for sid, n_full in (("q", hq * HD), ("k", hkv * HD), ("v", hkv * HD)):
+                    key_in = f"in.qkv_{tag}.{pname}.{sid}"
+                    if key_in not in ld:
+                        ld[key_in] = rnd(full_shape(pname, HID, n_full), dtype).numpy()
+                    qkv.weight_loader(prm, torch.from_numpy(np.asarray(ld[key_in])), sid)
+                ld[f"out.qkv_{tag}.{pname}.w{world}r{rank}"] = prm.data.numpy().copy()
     np.savez_compressed(os.path.join(OUT, "loader_shards.npz"), **ld)
 
     # ---------------- mixture of experts: the reference's torch_moe (tests/kernels/test_moe.py:15-29) ----

@@ -457,23 +457,27 @@ def test_shard_arithmetic_matches_the_reference_weight_loaders(golden_dir):
         _, lname, fmt, pname, tag = key.split(".")
         name = f"{fmt}.{pname}"
         world, rank = int(tag[1:tag.index("r")]), int(tag[tag.index("r") + 1:])
-        plan = {"qkv": lambda: L.qkv_plan(HQ, HKV, HD, rank, world),
-                "merged": lambda: L.merged_plan([INTER, INTER], rank, world),
-                "row": lambda: L.row_plan(rank, world)}[lname]()
+        if lname.startswith("qkv_h"):             # extra head layouts: qkv_h8kv8, qkv_h4kv1, qkv_h8kv2
+            hq, hkv = (int(v) for v in lname[len("qkv_h"):].split("kv"))
+            plan, sids = L.qkv_plan(hq, hkv, HD, rank, world), shard_ids["qkv"]
+        else:
+            plan = {"qkv": lambda: L.qkv_plan(HQ, HKV, HD, rank, world),
+                    "merged": lambda: L.merged_plan([INTER, INTER], rank, world),
+                    "row": lambda: L.row_plan(rank, world)}[lname]()
+            sids = shard_ids[lname]
         want = torch.from_numpy(g[key])
         a = dict(attrs[name])
         if lname == "row":
             a.update(row_attrs.get(name, {}))
         prm = _param(torch.zeros_like(want), **a)
-        for sid in shard_ids[lname]:
+        for sid in sids:
             L.load_sharded(plan, prm, torch.from_numpy(g[f"in.{lname}.{name}.{sid}"]), sid)
         assert torch.equal(prm.data, want), key
         # fused on disk: one tensor, shard id None
         if lname != "row" and "output_dim" in a:
-            fused = torch.cat([torch.from_numpy(g[f"in.{lname}.{name}.{sid}"]) for sid in shard_ids[lname]],
-                              dim=a["output_dim"])
+            fused = torch.cat([torch.from_numpy(g[f"in.{lname}.{name}.{sid}"]) for sid in sids], dim=a["output_dim"])
             prm2 = _param(torch.zeros_like(want), **a)
             L.load_sharded(plan, prm2, fused, None)
             assert torch.equal(prm2.data, want), key + " (fused)"
         checked += 1
-    assert checked >= 60
+    assert checked >= 90
