@@ -435,6 +435,11 @@ def main():
     moe_out = ns6["torch_moe"](a_m, w1_m, w2_m, score, Tk)
     np.savez_compressed(os.path.join(OUT, "moe.npz"), a=a_m.numpy(), w1=w1_m.numpy(), w2=w2_m.numpy(),
                         score=score.numpy(), out=moe_out.numpy(), topk=np.int64(Tk))
+    # FusedMoE.make_expert_params_mapping (fused_moe/layer.py:455-471): the rows a model's load_weights walks
+    mapping = lift_class_method("aphrodite/modeling/layers/fused_moe/layer.py", "FusedMoE", "make_expert_params_mapping", g)
+    with open(os.path.join(OUT, "moe_mapping.json"), "w") as f:
+        json.dump([list(r) for r in mapping(None, "w1", "w2", "w3", 3)] +
+                  [list(r) for r in mapping(None, "gate_proj", "down_proj", "up_proj", 2)], f)
 
     # ---------------- compressed-tensors: which scheme a config group selects ----------------------------
     # compressed_tensors.py:133-253 (_is_* predicates + _get_scheme_from_parts) on the reference's own pydantic

@@ -306,6 +306,15 @@ def test_moe_layer_golden(golden_dir):
     np.testing.assert_allclose(out, g["out"], rtol=2e-4, atol=2e-5)
 
 
+def test_expert_params_mapping_golden(golden_dir):
+    import json
+    from aphrodite_engine_amd.moe import FusedMoE
+    want = json.load(open(os.path.join(golden_dir, "moe_mapping.json")))
+    got = [list(r) for r in FusedMoE.make_expert_params_mapping("w1", "w2", "w3", 3)] + \
+        [list(r) for r in FusedMoE.make_expert_params_mapping("gate_proj", "down_proj", "up_proj", 2)]
+    assert got == want
+
+
 def test_kv_scale_rules_golden(golden_dir):
     """Host logic vs the reference: BaseKVCacheMethod.process_weights_after_loading (checkpoint scales) and
     kv_cache_scales_loader (quantization_param_path json)."""
