@@ -44,8 +44,10 @@ def requantize_with_max_scale(weight: torch.Tensor, weight_scale: torch.Tensor,
         start = 0
         for idx, width in enumerate(logical_widths):
             end = start + width
-            w_dq = weight[start:end, :].to(torch.float32) * weight_scale[idx]
-            q = (w_dq / max_w_scale).clamp(-448.0, 448.0).to(torch.float8_e4m3fn)
+            # per_tensor_dequantize (:23-28): through fp16 -- a 0-dim fp32 scale does not promote an fp16 tensor --
+            # then the static scaled_fp8_quant arithmetic, x * (1 / scale) (fp8/common.cu:187-199)
+            w_dq = weight[start:end, :].to(torch.float16) * weight_scale[idx]
+            q = (w_dq.float() * (1.0 / max_w_scale.float())).clamp(-448.0, 448.0).to(torch.float8_e4m3fn)
             weight[start:end, :] = q
             start = end
     return max_w_scale, weight

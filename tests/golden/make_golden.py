@@ -572,6 +572,29 @@ def main():
     with open(os.path.join(OUT, "param_contracts.json"), "w") as f:
         json.dump(contracts, f, indent=0)
 
+    # ---------------- FP8: fused shards with their own scales -> one scale (w8a8_utils.py:23-28, 54-80) --------
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    from oracle import fp8 as of8_
+
+    class _Ops:      # the one custom op the function calls, served by the restatement the fp8 goldens above pin
+        @staticmethod
+        def scaled_fp8_quant(x, scale):
+            bits = of8_.static_scaled_fp8_quant(x.float().numpy(), float(scale))
+            return torch.from_numpy(bits).view(torch.float8_e4m3fn), scale
+    ns8 = _lift("aphrodite/quantization/utils/w8a8_utils.py", {"per_tensor_dequantize", "requantize_with_max_scale"},
+                dict(g, ops=_Ops))
+    torch.manual_seed(33)
+    widths = [48, 16, 16]
+    wq_ = (torch.randn(sum(widths), 64) * 60).clamp(-448, 448).to(torch.float8_e4m3fn)
+    ws_ = torch.tensor([0.011, 0.0042, 0.0087])
+    mx_, wq_out = ns8["requantize_with_max_scale"](wq_.clone(), ws_.clone(), widths)
+    fused_ws = torch.tensor([0.011, torch.finfo(torch.float32).min, torch.finfo(torch.float32).min])   # fused on disk
+    mx2_, wq_out2 = ns8["requantize_with_max_scale"](wq_.clone(), fused_ws, widths)
+    np.savez_compressed(os.path.join(OUT, "fp8_requant.npz"), w=wq_.view(torch.uint8).numpy(), scales=ws_.numpy(),
+                        widths=np.array(widths), out=wq_out.view(torch.uint8).numpy(), max_scale=mx_.numpy(),
+                        fused_scales=fused_ws.numpy(), out_fused=wq_out2.view(torch.uint8).numpy(),
+                        max_scale_fused=mx2_.numpy())
+
     # ---------------- rotary tables, plain and Llama-3.1 scaled (rotary_embedding.py:101-120, 680-723) -----
     import math
     rsrc = "aphrodite/modeling/layers/rotary_embedding.py"

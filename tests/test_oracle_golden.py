@@ -306,6 +306,23 @@ def test_moe_layer_golden(golden_dir):
     np.testing.assert_allclose(out, g["out"], rtol=2e-4, atol=2e-5)
 
 
+def test_fp8_requantize_with_max_scale_golden(golden_dir):
+    """Host logic: fused shards quantised with their own scales are requantised to the largest one exactly as
+    the reference does it (through fp16, multiplying by 1 / scale) -- same bytes."""
+    from aphrodite_engine_amd.quantization.fp8 import requantize_with_max_scale
+    g = np.load(os.path.join(golden_dir, "fp8_requant.npz"))
+    w = torch.from_numpy(g["w"]).view(torch.float8_e4m3fn)
+    mx, out = requantize_with_max_scale(w.clone(), torch.from_numpy(g["scales"]), [int(x) for x in g["widths"]])
+    assert float(mx) == float(g["max_scale"])
+    np.testing.assert_array_equal(out.view(torch.uint8).numpy(), g["out"])
+    assert (g["out"] != g["w"]).any()
+    # a module stored fused on disk carries one real scale: nothing is requantised
+    mx2, out2 = requantize_with_max_scale(w.clone(), torch.from_numpy(g["fused_scales"]), [int(x) for x in g["widths"]])
+    assert float(mx2) == float(g["max_scale_fused"])
+    np.testing.assert_array_equal(out2.view(torch.uint8).numpy(), g["out_fused"])
+    np.testing.assert_array_equal(g["out_fused"], g["w"])
+
+
 def test_expert_params_mapping_golden(golden_dir):
     import json
     from aphrodite_engine_amd.moe import FusedMoE
