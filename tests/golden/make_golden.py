@@ -27,6 +27,7 @@ Sources exercised:
   aphrodite/modeling/layers/linear.py           MergedColumnParallelLinear / QKVParallelLinear /
                                                 RowParallelLinear .weight_loader (methods lifted out of
                                                 their classes, run with a stand-in self)
+  tests/kernels/test_flash_attn.py              ref_paged_attn (prefill over a paged cache, sliding window)
   tests/kernels/test_moe.py                     torch_moe (+ SiluAndMul.forward_native)
   aphrodite/modeling/layers/rotary_embedding.py RotaryEmbedding._compute_cos_sin_cache, Llama3RotaryEmbedding
   aphrodite/quantization/{gptq,awq,fp8}.py, compressed_tensors/schemes/compressed_tensors_w8a8_fp8.py
@@ -236,6 +237,22 @@ def main():
     att.update(rc_key=key.numpy(), rc_val=val.numpy(), rc_slots=slots.numpy(),
                rc_kc=ckc.numpy(), rc_vc=cvc.numpy())
     np.savez_compressed(os.path.join(OUT, "attention.npz"), **att)
+
+    # ---------------- prefill over a paged cache: tests/kernels/test_flash_attn.py ref_paged_attn (:17-70) -------
+    ns_fa = _lift("tests/kernels/test_flash_attn.py", {"ref_paged_attn"}, g)
+    torch.manual_seed(17)
+    fa_hq, fa_hkv, fa_hd, fa_bs, fa_nb = 4, 2, 32, 16, 12
+    q_lens, kv_lens = [5, 1, 17, 9], [13, 40, 17, 9]          # the last two: no cached context (plain causal prefill)
+    fq = torch.randn(sum(q_lens), fa_hq, fa_hd)
+    fkc = torch.randn(fa_nb, fa_bs, fa_hkv, fa_hd)            # flash layout [blocks, block, heads, dim]
+    fvc = torch.randn(fa_nb, fa_bs, fa_hkv, fa_hd)
+    fbt = torch.stack([torch.randperm(fa_nb)[:3] for _ in q_lens]).int()
+    fa = dict(q=fq.numpy(), kc=fkc.numpy(), vc=fvc.numpy(), bt=fbt.numpy(), q_lens=np.array(q_lens),
+              kv_lens=np.array(kv_lens), scale=np.float32(fa_hd ** -0.5))
+    for tag, win in (("full", None), ("win8", 8)):
+        fa["out_" + tag] = ns_fa["ref_paged_attn"](fq.clone(), fkc, fvc, q_lens, kv_lens, fbt, fa_hd ** -0.5,
+                                                   sliding_window=win).numpy()
+    np.savez_compressed(os.path.join(OUT, "prefill_paged.npz"), **fa)
 
     # ---------------- sampler: top-k / top-p masking and the multinomial draw --------------------
     # aphrodite/modeling/layers/sampler.py:865-891 and :1273-1292, lifted as they lie

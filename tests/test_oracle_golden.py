@@ -296,6 +296,35 @@ def test_compressed_tensors_ignore_list_golden(golden_dir):
             assert layer_is_ignored(c["layer"], c["ignore"]) == c["result"], c
 
 
+@pytest.mark.parametrize("tag,window", [("full", 0), ("win8", 8)])
+def test_prefill_over_paged_cache_golden(golden_dir, tag, window):
+    """oracle.attention.context_attention / varlen_causal_attention vs the reference's ref_paged_attn (flash-attn
+    tests): cached context + causal new tokens, GQA, shuffled block tables, sliding window."""
+    g = np.load(os.path.join(golden_dir, "prefill_paged.npz"))
+    q, kc, vc, bt = g["q"], g["kc"], g["vc"], g["bt"]
+    q_lens, kv_lens, scale = g["q_lens"], g["kv_lens"], float(g["scale"])
+    nb, bs, hkv, hd = kc.shape
+    # logical K/V of every sequence from the flash-layout cache [blocks, block, heads, dim]
+    seqs_k = [kc[bt[i]].reshape(-1, hkv, hd)[:kv_lens[i]] for i in range(len(q_lens))]
+    seqs_v = [vc[bt[i]].reshape(-1, hkv, hd)[:kv_lens[i]] for i in range(len(q_lens))]
+    k_new = np.concatenate([seqs_k[i][kv_lens[i] - q_lens[i]:] for i in range(len(q_lens))], 0)
+    v_new = np.concatenate([seqs_v[i][kv_lens[i] - q_lens[i]:] for i in range(len(q_lens))], 0)
+    # the same context in the paged layout of the decode kernels: K [blocks, heads, dim/x, block, x], V [blocks, heads, dim, block]
+    x = 4      # float32 cache
+    pk = np.ascontiguousarray(kc.transpose(0, 2, 3, 1).reshape(nb, hkv, hd // x, x, bs).transpose(0, 1, 2, 4, 3))
+    pv = np.ascontiguousarray(vc.transpose(0, 2, 3, 1))
+    start = np.concatenate([[0], np.cumsum(q_lens)])[:-1]
+    out = oa.context_attention(q, k_new, v_new, pk, pv, bt, start, kv_lens, kv_lens - q_lens, scale,
+                               sliding_window=window)
+    np.testing.assert_allclose(out, g["out_" + tag], rtol=2e-5, atol=2e-6)
+    if window == 0:   # sequences without cached context are plain causal prefill
+        sel = [i for i in range(len(q_lens)) if q_lens[i] == kv_lens[i]]
+        rows = np.concatenate([np.arange(start[i], start[i] + q_lens[i]) for i in sel])
+        cu = np.concatenate([[0], np.cumsum([q_lens[i] for i in sel])])
+        out2 = oa.varlen_causal_attention(q[rows], k_new[rows], v_new[rows], cu, scale)
+        np.testing.assert_allclose(out2, g["out_full"][rows], rtol=2e-5, atol=2e-6)
+
+
 def test_moe_layer_golden(golden_dir):
     """oracle/moe.py (routing + dense per-expert MLP) vs the reference's torch_moe."""
     from oracle import moe as om
