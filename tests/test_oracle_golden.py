@@ -491,3 +491,41 @@ def test_parameter_contracts_golden(golden_dir):
         assert not mine, f"extra parameters {list(mine)} in {c['method']} {c['geom']}"
         if "exllama_state" in c:
             assert layer.exllama_state.name == c["exllama_state"]
+
+
+# ---------------------------------------------------------------------------
+# glue restatements vs the reference's own compiled CPU kernels (oracle/_ref)
+# ---------------------------------------------------------------------------
+def test_glue_ops_vs_reference_cpu_kernels():
+    """oracle rms_norm / fused_add_rms_norm / silu_and_mul / rotary_embedding (fp64 math) vs kernels/cpu/
+    {layernorm,activation,pos_encoding}.cpp compiled where they lie, on fp32 inputs."""
+    ops = _ref_lib()
+    torch.manual_seed(3)
+    T, H = 7, 256
+    x = torch.randn(T, H)
+    w = torch.rand(H) + 0.5
+    out = torch.empty_like(x)
+    ops.rms_norm(out, x, w, 1e-5)
+    np.testing.assert_allclose(out.numpy(), oa.rms_norm(x.numpy(), w.numpy(), 1e-5), rtol=2e-6, atol=2e-6)
+    xi, res = torch.randn(T, H), torch.randn(T, H)
+    x2, r2 = xi.clone(), res.clone()
+    ops.fused_add_rms_norm(x2, r2, w, 1e-5)
+    o_ref, r_ref = oa.fused_add_rms_norm(xi.numpy(), res.numpy(), w.numpy(), 1e-5)
+    np.testing.assert_allclose(r2.numpy(), r_ref, rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(x2.numpy(), o_ref, rtol=2e-6, atol=2e-6)
+    gu = torch.randn(T, 2 * 96) * 2
+    act = torch.empty(T, 96)
+    ops.silu_and_mul(act, gu)
+    np.testing.assert_allclose(act.numpy(), oa.silu_and_mul(gu.numpy()), rtol=2e-6, atol=2e-6)
+    # NeoX rotary on q [T, 4 heads x 64] and k [T, 2 heads x 64]
+    hd, max_pos = 64, 97
+    inv = 1.0 / (10000.0 ** (torch.arange(0, hd, 2).float() / hd))
+    fr = torch.einsum("i,j->ij", torch.arange(max_pos).float(), inv)
+    cs = torch.cat((fr.cos(), fr.sin()), dim=-1)
+    pos = torch.tensor([0, 5, 96, 17, 1, 33, 64])
+    q, k = torch.randn(T, 4 * hd), torch.randn(T, 2 * hd)
+    q2, k2 = q.clone(), k.clone()
+    ops.rotary_embedding(pos, q2, k2, hd, cs, True)
+    qr, kr = oa.rotary_embedding_neox(pos.numpy(), q.numpy(), k.numpy(), hd, cs.numpy())
+    np.testing.assert_allclose(q2.numpy(), qr, rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(k2.numpy(), kr, rtol=2e-6, atol=2e-6)
