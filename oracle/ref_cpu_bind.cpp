@@ -7,6 +7,7 @@
 // call the reference implementation itself:
 //   paged_attention_v1 / v2   kernels/cpu/attention.cpp:421-441, 739-758
 //   reshape_and_cache         kernels/cpu/cache.cpp:107-132
+//   copy_blocks               kernels/cpu/cache.cpp:88-105
 //   silu_and_mul              kernels/cpu/activation.cpp:87
 //   rms_norm/fused_add_rms_norm  kernels/cpu/layernorm.cpp:90,104
 //   rotary_embedding          kernels/cpu/pos_encoding.cpp:170
@@ -43,6 +44,9 @@ void reshape_and_cache(torch::Tensor& key, torch::Tensor& value,
                        const std::string& kv_cache_dtype, double k_scale,
                        double v_scale);
 
+void copy_blocks(std::vector<torch::Tensor> const& key_caches, std::vector<torch::Tensor> const& value_caches,
+                 const torch::Tensor& block_mapping);
+
 void silu_and_mul(torch::Tensor& out, torch::Tensor& input);
 void rms_norm(torch::Tensor& out, torch::Tensor& input, torch::Tensor& weight,
               double epsilon);
@@ -75,6 +79,8 @@ TORCH_LIBRARY(aphro_ref_cpu, ops) {
       "value_cache, Tensor slot_mapping, str kv_cache_dtype, float k_scale, "
       "float v_scale) -> ()");
   ops.impl("reshape_and_cache", torch::kCPU, &reshape_and_cache);
+  ops.def("copy_blocks(Tensor(a!)[] key_caches, Tensor[](b!) value_caches, Tensor block_mapping) -> ()");
+  ops.impl("copy_blocks", torch::kCPU, &copy_blocks);
   ops.def("silu_and_mul(Tensor! out, Tensor input) -> ()");
   ops.impl("silu_and_mul", torch::kCPU, &silu_and_mul);
   ops.def(

@@ -529,3 +529,18 @@ def test_glue_ops_vs_reference_cpu_kernels():
     qr, kr = oa.rotary_embedding_neox(pos.numpy(), q.numpy(), k.numpy(), hd, cs.numpy())
     np.testing.assert_allclose(q2.numpy(), qr, rtol=2e-6, atol=2e-6)
     np.testing.assert_allclose(k2.numpy(), kr, rtol=2e-6, atol=2e-6)
+
+
+def test_copy_blocks_vs_reference_cpu_kernel():
+    ops = _ref_lib()
+    torch.manual_seed(4)
+    layers, NB = 3, 10
+    kcs = [torch.randn(NB, 2, 8, 16, 4) for _ in range(layers)]
+    vcs = [torch.randn(NB, 2, 32, 16) for _ in range(layers)]
+    mapping = torch.tensor([[0, 5], [0, 7], [3, 9], [8, 1]], dtype=torch.int64)
+    k2 = [k.numpy().copy() for k in kcs]
+    v2 = [v.numpy().copy() for v in vcs]
+    ops.copy_blocks(kcs, vcs, mapping)
+    oa.copy_blocks(k2, v2, mapping.numpy())
+    for a, b in zip(kcs + vcs, k2 + v2):
+        np.testing.assert_array_equal(a.numpy(), b)
