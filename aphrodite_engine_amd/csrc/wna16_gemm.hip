@@ -349,10 +349,16 @@ __global__ __launch_bounds__(FNW * 64, (VEC * MT >= 8) ? 2 : 3) void wna16_gemm_
         // they weigh 16x, so those four k of the A fragment are scaled by 1/16
         // (inline asm on the integer lanes: hipcc miscompiles a bitcast of one vector element)
         u32x4 av = af[s % NA][u][i];
+#ifndef ABL_NO_PKMUL   // (timing experiments only: tools/gemm_ablate.hip)
         asm("v_pk_mul_f16 %0, %1, %2" : "=v"(av[1]) : "v"(av[1]), "s"(0x2c002c00u));
         asm("v_pk_mul_f16 %0, %1, %2" : "=v"(av[3]) : "v"(av[3]), "s"(0x2c002c00u));
+#endif
         a[i] = __builtin_bit_cast(f16x8, av);
+#ifndef ABL_NO_RS
         rs[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], ones, u == 0 ? zero4 : rs[i], 0, 0, 0);
+#else
+        rs[i] = zero4;
+#endif
       }
 #pragma unroll
       for (int t = 0; t < VEC; ++t) {
