@@ -275,6 +275,152 @@ __global__ __launch_bounds__(512, 1) void wna16_gemm_cs_kernel(Wna16Params p) {
   wna16_epilogue<T, VEC, MT, KQ>(p, red + cg * (KQ * MT * VEC * 64 * 4), cacc, lane, kq, g, m0, ncol);
 }
 }  // namespace aphro
+// ---- experiment ABL_LDSW ("weights through LDS"): same workgroup shape as the shipped kernel (4 waves =
+// 4 K-quarters, 64 columns), but the weight fragments are fetched with direct-to-LDS 16-byte buffer loads
+// (buffer_load_dwordx4 ... lds: lane l's bytes land at slot + 16*l, tools/lds_direct_probe.hip) R segments ahead
+// into a per-wave ring of R + 1 slots and read back with ds_read_b128 when their segment is computed: bytes in
+// flight no longer cost VGPRs.  VMEM operations complete in issue order, so "segment s has landed" is an
+// s_waitcnt vmcnt(n) with n = the operations issued after W(s) -- a compile-time constant per unrolled iteration.
+// NOT measured yet (written without GPU access at the end of round 1); the driver checks it against the shipped
+// kernel before timing it.
+#include <type_traits>
+#include <utility>
+namespace aphro {
+template <int NSEG, int R, int MT>
+struct LdswCount {   // VMEM ops issued in the issue phase of iteration j: A(j+1), W(j+R), meta(j+1)
+  static constexpr int a(int j) { return j + 1 < NSEG ? 4 * MT : 0; }
+  static constexpr int w(int j) { return j + R < NSEG ? 4 : 0; }
+  static constexpr int m(int j) { return j + 1 < NSEG ? 2 : 0; }
+  static constexpr int after(int s) {   // ops issued after the last load of W(s), up to the wait in iteration s
+    int n = 0;
+    if (s < R) {
+      n += 4 * ((R < NSEG ? R : NSEG) - 1 - s);
+      for (int j = 0; j <= s; ++j) n += a(j) + w(j) + m(j);
+    } else {
+      n += m(s - R);
+      for (int j = s - R + 1; j <= s; ++j) n += a(j) + w(j) + m(j);
+    }
+    return n > 63 ? 63 : n;
+  }
+};
+template <typename F, int... S>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, S...>) {
+  (f(std::integral_constant<int, S>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+template <typename T, int MT, int NSEG, int R>
+__global__ __launch_bounds__(FNW * 64, 2) void wna16_gemm_ldsw_kernel(Wna16Params p) {
+  constexpr int VEC = 4, RING = R + 1;
+  using Cnt = LdswCount<NSEG, R, MT>;
+  extern __shared__ __attribute__((aligned(16))) float red[];
+  uint32_t* ring = reinterpret_cast<uint32_t*>(red);        // [FNW][RING][4 u][64 lanes][4 dwords]
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, c = lane & 15;
+  const int n0 = blockIdx.x * 64, m0 = blockIdx.z * (16 * MT), ncol = n0 + VEC * c;
+  const int seg0 = (blockIdx.y * FNW + wave) * NSEG;
+  const int mtiles = (p.M + 15) >> 4;
+  const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.qw, (uint32_t)((size_t)(p.K >> 3) * p.N * 4));
+  const __amdgpu_buffer_rsrc_t ra = make_rsrc(p.apk, (uint32_t)((size_t)(p.K >> 7) * 4 * mtiles * 1024));
+  const int ngroups = p.K / p.group_size;
+  const __amdgpu_buffer_rsrc_t rs_ = make_rsrc(p.sc, (uint32_t)((size_t)ngroups * p.N * 2));
+  const __amdgpu_buffer_rsrc_t rz = make_rsrc(p.qz, (uint32_t)((size_t)ngroups * (p.N >> 3) * 4));
+  const int roww = p.N * 4;
+  const int voff_w = (4 * g * p.N + ncol) * 4;
+  int voff_a[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) voff_a[i] = (min((m0 >> 4) + i, mtiles - 1) * 64 + lane) * 16;
+  const int abytes = mtiles * 1024;
+  const int voff_s = ncol * 2, voff_z = (ncol >> 3) * 4, zshift = (ncol & 7) * 4;
+  const float zoff = (float)p.zero_offset;
+  const f16x8 ones = {(f16)1.f, (f16)1.f, (f16)16.f, (f16)16.f, (f16)1.f, (f16)1.f, (f16)16.f, (f16)16.f};
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 cacc[MT][VEC];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int t = 0; t < VEC; ++t) cacc[i][t] = zero4;
+  SegMeta<VEC> meta[2];
+  u32x4 af[2][4][MT];
+  uint32_t* wring = ring + wave * (RING * 4 * 256);          // this wave's slots, 1 KiB per (slot, u)
+  auto load_meta = [&](SegMeta<VEC>& m, int s) {
+    const int grp = (seg0 + s) >> p.gshift;
+    m.zw = __builtin_amdgcn_raw_buffer_load_b32(rz, voff_z, grp * (p.N >> 3) * 4, 0);
+    u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs_, voff_s, grp * p.N * 2, 0);
+    m.sc[0] = v[0]; m.sc[1] = v[1];
+  };
+  auto load_w_lds = [&](int s) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(wring + ((s % RING) * 4 + u) * 256),
+                                               16, voff_w, ((seg0 + s) * 16 + u) * roww, 0, 2);
+  };
+  auto load_a = [&](u32x4 (&ad)[4][MT], int s) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+        ad[u][i] = __builtin_amdgcn_raw_buffer_load_b128(ra, voff_a[i], ((seg0 + s) * 4 + u) * abytes, 0);
+  };
+  load_meta(meta[0], 0);
+  load_a(af[0], 0);
+#pragma unroll
+  for (int d = 0; d < (R < NSEG ? R : NSEG); ++d) load_w_lds(d);
+  __builtin_amdgcn_sched_barrier(0);
+  static_for<NSEG>([&](auto sc) {
+    constexpr int s = decltype(sc)::value;
+    if (s + 1 < NSEG) load_a(af[(s + 1) & 1], s + 1);
+    if (s + R < NSEG) load_w_lds(s + R);                 // slot (s + R) % (R + 1) != s % (R + 1): never the one being read
+    if (s + 1 < NSEG) load_meta(meta[(s + 1) & 1], s + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Cnt::after(s)) : "memory");   // W(s) has landed in this wave's slot
+    f32x4 acc[MT][VEC];
+    f32x4 rs[MT];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const u32x4 wq = *reinterpret_cast<const u32x4*>(wring + ((s % RING) * 4 + u) * 256 + lane * 4);
+      f16x8 a[MT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        u32x4 av = af[s & 1][u][i];
+        asm("v_pk_mul_f16 %0, %1, %2" : "=v"(av[1]) : "v"(av[1]), "s"(0x2c002c00u));
+        asm("v_pk_mul_f16 %0, %1, %2" : "=v"(av[3]) : "v"(av[3]), "s"(0x2c002c00u));
+        a[i] = __builtin_bit_cast(f16x8, av);
+        rs[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], ones, u == 0 ? zero4 : rs[i], 0, 0, 0);
+      }
+#pragma unroll
+      for (int t = 0; t < VEC; ++t) {
+        const uint32_t wv = wq[t];
+        const uint32_t w8 = wv >> 8;
+        u32x4 bq = {wv & 0x000f000fu, wv & 0x00f000f0u, w8 & 0x000f000fu, w8 & 0x00f000f0u};
+        const f16x8 b = __builtin_bit_cast(f16x8, bq);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+          acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b, u == 0 ? zero4 : acc[i][t], 0, 0, 0);
+      }
+    }
+    const SegMeta<VEC>& m = meta[s & 1];
+#pragma unroll
+    for (int t = 0; t < VEC; ++t) {
+      const float z = (float)((m.zw >> (zshift + 4 * t)) & 0xf) + zoff;
+      const float sf = T::to_f32((uint16_t)(m.sc[t >> 1] >> (16 * (t & 1))));
+      const float s24 = sf * 16777216.f, nzs = -z * sf;
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        cacc[i][t] = __builtin_elementwise_fma(acc[i][t], f32x4{s24, s24, s24, s24}, cacc[i][t]);
+        cacc[i][t] = __builtin_elementwise_fma(rs[i], f32x4{nzs, nzs, nzs, nzs}, cacc[i][t]);
+      }
+    }
+  });
+  __syncthreads();                       // every wave is done with its ring: the reduction reuses the LDS
+  wna16_epilogue<T, VEC, MT, FNW>(p, red, cacc, lane, wave, g, m0, ncol);
+}
+}  // namespace aphro
+#ifndef ABL_LDSW_R
+#define ABL_LDSW_R 3
+#endif
 #ifndef ABL_NSEG
 #define ABL_NSEG 8
 #endif
@@ -314,6 +460,10 @@ int main(int argc, char** argv) {
 #ifdef ABL_TWO
   CK(hipFuncSetAttribute((const void*)aphro::wna16_gemm2_kernel<aphro::Half, MT, ABL_NSEG, ABL_NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)ABL_NWV * MT * 4 * 64 * 16)));
 #endif
+#ifdef ABL_LDSW
+  CK(hipFuncSetAttribute((const void*)aphro::wna16_gemm_ldsw_kernel<aphro::Half, MT, ABL_NSEG, ABL_LDSW_R>,
+                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)aphro::FNW * (ABL_LDSW_R + 1) * 4096)));
+#endif
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   auto run = [&](int i) {
     p.qw = qw[i % copies];
@@ -325,11 +475,14 @@ int main(int argc, char** argv) {
 #elif defined(ABL_CS)
     hipLaunchKernelGGL((aphro::wna16_gemm_cs_kernel<aphro::Half, MT, ABL_NSEG>), dim3(grid.x / 2, grid.y, grid.z), dim3(512),
                        (size_t)64 * 1024, 0, p);
+#elif defined(ABL_LDSW)
+    hipLaunchKernelGGL((aphro::wna16_gemm_ldsw_kernel<aphro::Half, MT, ABL_NSEG, ABL_LDSW_R>), grid, dim3(aphro::FNW * 64),
+                       (size_t)aphro::FNW * (ABL_LDSW_R + 1) * 4096, 0, p);
 #else
     hipLaunchKernelGGL((aphro::wna16_gemm_kernel<aphro::Half, ABL_VEC, MT, ABL_NSEG>), grid, dim3(aphro::FNW * 64), lds, 0, p);
 #endif
   };
-#ifdef ABL_CS
+#if defined(ABL_CS) || defined(ABL_LDSW)
   {  // correctness first: the shipped kernel and the experiment on the same inputs (fp32 sums in a different order)
     const size_t outn = ksplit == 1 ? (size_t)M * N : (size_t)ksplit * M * N;
     std::vector<float> ref(outn), got(outn);
@@ -349,7 +502,7 @@ int main(int argc, char** argv) {
     run(0); CK(hipDeviceSynchronize()); fetch(got);
     double maxd = 0, maxr = 0;
     for (size_t i = 0; i < outn; ++i) { maxd = fmax(maxd, fabs((double)ref[i] - got[i])); maxr = fmax(maxr, fabs((double)ref[i])); }
-    printf("ABL_CS check: max |diff| %.3e vs max |ref| %.3e -> %s\n", maxd, maxr, maxd <= 2e-3 * maxr + 1e-6 ? "OK" : "MISMATCH");
+    printf("experiment check: max |diff| %.3e vs max |ref| %.3e -> %s\n", maxd, maxr, maxd <= 2e-3 * maxr + 1e-6 ? "OK" : "MISMATCH");
   }
 #endif
   for (int i = 0; i < 8; ++i) run(i);
