@@ -1,0 +1,386 @@
+// Round-2 prototype bench: the "strip" int4 decode GEMM (not part of the product build).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/strip_lab.hip -o /tmp/strip_lab && /tmp/strip_lab
+// Why (gemm_lab results): the shipped kernel moves 8 KiB of A fragments through the CU's
+// vector-memory path for every 4 KiB of weights and A + W loads ADD UP (17.5 us with the MFMAs removed, 12.7 us
+// with W only): the texture path of the CU, not HBM, is what saturates.  Here ONE workgroup per CU owns NS strips
+// of 16 columns over the whole K range of its k-split; a loader wave streams the A fragments (and their row sums)
+// into an LDS ring ONCE per CU with direct-to-LDS loads, NS consumer waves read them from LDS, stream their own
+// weight strip straight into registers (dword loads, DW segments ahead) and keep full-K sums in registers -- no
+// cross-wave reduction, A through the texture path once per CU instead of once per 64 columns.
+#include "../aphrodite_engine_amd/csrc/wna16_gemm.hip"
+#include <vector>
+#include <string>
+#include <algorithm>
+#include <stdio.h>
+#include <stdlib.h>
+#include <math.h>
+namespace aphro { void set_error(const char*, ...) {} }
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
+
+enum { SM_PRESC = 1, SM_NOMFMA = 2, SM_NOA = 4, SM_NOW = 8, SM_NOPOLL = 16, SM_LOOP = 32 };
+
+namespace aphro {
+struct StripParams {
+  const uint16_t* apk;   // fragment-major A [K/128][4][mtiles][64 lanes][8 halfs]
+  const float* rs;       // row sums [K/128][64]  (rows >= M: 0)
+  const uint32_t* qw; const uint32_t* qz; const uint16_t* sc;
+  uint16_t* c; float* partial;
+  int M, N, K, zero_offset;
+  unsigned* dbg;
+};
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+__device__ __forceinline__ uint32_t lds_read_u32_volatile(uint32_t addr) {
+  uint32_t r;
+  asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(r) : "v"(addr) : "memory");
+  return r;
+}
+__device__ __forceinline__ void lds_write_u32_volatile(uint32_t addr, uint32_t v) {
+  asm volatile("ds_write_b32 %0, %1" :: "v"(addr), "v"(v) : "memory");
+}
+
+// NS strips (consumer waves) + 1 loader wave; S segments of 128 k per workgroup; W DW segments ahead in registers;
+// LDS ring of R stages, loader PD stages ahead.
+template <int NS, int S, int DW, int R, int PD, int MODE>
+__global__ __launch_bounds__((NS + 1) * 64) void strip_gemm_kernel(StripParams p) {
+  constexpr int MT = 2;
+  constexpr int STAGE = 8192 + 256;            // A fragments (8 KiB) + row sums (64 floats)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* ring = smem;
+  uint16_t* meta_sc = reinterpret_cast<uint16_t*>(smem + R * STAGE);              // [S][NS*16]
+  uint32_t* meta_z = reinterpret_cast<uint32_t*>(smem + R * STAGE + S * NS * 32); // [S][NS*2]
+  uint32_t* flags = reinterpret_cast<uint32_t*>(smem + R * STAGE + S * NS * 32 + S * NS * 8);  // [0]=ready, [8..15]=progress
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n0 = blockIdx.x * (NS * 16);
+  const int seg0 = blockIdx.y * S;
+  const int mtiles = (p.M + 15) >> 4;
+
+  // ---- prologue: this workgroup's group scales / zeros -> LDS; flags ------------------------------------------
+  {
+    const uint32_t* sc32 = reinterpret_cast<const uint32_t*>(p.sc);
+    for (int i = threadIdx.x; i < S * NS * 8; i += (NS + 1) * 64) {
+      const int grp = i / (NS * 8), j = i % (NS * 8);
+      reinterpret_cast<uint32_t*>(meta_sc)[i] = sc32[((size_t)(seg0 + grp) * p.N + n0) / 2 + j];
+    }
+    for (int i = threadIdx.x; i < S * NS * 2; i += (NS + 1) * 64) {
+      const int grp = i / (NS * 2), j = i % (NS * 2);
+      meta_z[i] = p.qz[(size_t)(seg0 + grp) * (p.N >> 3) + (n0 >> 3) + j];
+    }
+    if (threadIdx.x < 16) flags[threadIdx.x] = (threadIdx.x >= 8 + NS) ? 0x7fffffffu : 0u;
+  }
+  __syncthreads();
+  const uint32_t flags_addr = (uint32_t)(size_t)(lds_ptr_t)flags;   // LDS byte offset
+
+  if (wave == NS) {
+    if constexpr (MODE & SM_NOPOLL) return;
+    // ================= loader wave =================
+    const __amdgpu_buffer_rsrc_t ra = make_rsrc(p.apk, (uint32_t)((size_t)(p.K >> 7) * 4 * mtiles * 1024));
+    const __amdgpu_buffer_rsrc_t rr = make_rsrc(p.rs, (uint32_t)((size_t)(p.K >> 7) * 256));
+    const int abytes = mtiles * 1024;
+    int done_min = 0;   // all consumers have finished reading segments < done_min
+#pragma unroll 1
+    for (int s = -PD; s < S; ++s) {
+      const int sp = s + PD;
+      if (sp < S) {
+        if (sp >= R) {   // stage (sp % R) still holds segment sp - R: wait until every consumer is past it
+          while (done_min < sp - R + 1) {
+            u32x4 a, b;
+            asm volatile("ds_read_b128 %0, %2 offset:32\n\tds_read_b128 %1, %2 offset:48\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(a), "=&v"(b) : "v"(flags_addr) : "memory");
+            uint32_t m = min(min(min(a[0], a[1]), min(a[2], a[3])), min(min(b[0], b[1]), min(b[2], b[3])));
+            done_min = __builtin_amdgcn_readfirstlane((int)m);
+            if (done_min < sp - R + 1) __builtin_amdgcn_s_sleep(1);
+          }
+        }
+        unsigned char* st = ring + (sp % R) * STAGE;
+        const int sg = seg0 + sp;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr_t)(st + (u * MT + i) * 1024), 16,
+                                                     (min(i, mtiles - 1) * 64 + lane) * 16, (sg * 4 + u) * abytes, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rr, (lds_ptr_t)(st + 8192), 4, lane * 4, sg * 256, 0, 0);
+      }
+      if (s >= 0) {
+        // segment s has landed once at most 9 * (segments issued after it) loads are outstanding
+        const int after = min(PD, S - 1 - s);
+        if (after >= 4) asm volatile("s_waitcnt vmcnt(36)" ::: "memory");
+        else if (after == 3) asm volatile("s_waitcnt vmcnt(27)" ::: "memory");
+        else if (after == 2) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+        else if (after == 1) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) lds_write_u32_volatile(flags_addr, (uint32_t)(s + 1));
+      }
+    }
+    return;
+  }
+
+  // ================= consumer wave: strip `wave` =================
+  const int g = lane >> 4, c = lane & 15;
+  const int ncol = n0 + 16 * wave + c;
+  const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.qw, (uint32_t)((size_t)(p.K >> 3) * p.N * 4));
+  const int roww = p.N * 4;
+  const int voff_w = (4 * g * p.N + ncol) * 4;
+  const float zoff = (float)p.zero_offset;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 cacc[MT] = {zero4, zero4};
+  uint32_t w[DW][4];
+  auto load_w = [&](uint32_t (&wd)[4], int s) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) wd[u] = __builtin_amdgcn_raw_buffer_load_b32(rw, voff_w, ((seg0 + s) * 16 + u) * roww, 2);
+  };
+#pragma unroll
+  for (int d = 0; d < DW; ++d) if (d < S) { if constexpr (MODE & SM_NOW) { for (int u = 0; u < 4; ++u) w[d][u] = lane * 2654435761u + d + u; } else load_w(w[d], d); }
+  int ready_seen = (MODE & SM_NOPOLL) ? S : 0;
+  const uint32_t prog_addr = flags_addr + 32 + 4 * wave;
+
+  constexpr int UB = (MODE & SM_LOOP) ? 8 : S;   // segments per unrolled block
+  static_assert(S % UB == 0 && UB % DW == 0 && UB % R == 0 || !(MODE & SM_LOOP), "loop form needs 8 % DW == 0 and 8 % R == 0");
+#pragma unroll 1
+  for (int sb = 0; sb < S; sb += UB)
+#pragma unroll
+  for (int si = 0; si < UB; ++si) {
+    const int s = sb + si;
+    while (ready_seen < s + 1) {
+      ready_seen = __builtin_amdgcn_readfirstlane((int)lds_read_u32_volatile(flags_addr));
+      if (ready_seen < s + 1) __builtin_amdgcn_s_sleep(1);
+    }
+    const unsigned char* st = ring + (si % R) * STAGE;
+    u32x4 af[4][MT];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        if constexpr (MODE & SM_NOA) { af[u][i] = u32x4{0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u}; asm volatile("" : "+v"(af[u][i])); }
+        else af[u][i] = *reinterpret_cast<const u32x4*>(st + ((u * MT + i) * 64 + lane) * 16);
+      }
+    f32x4 rs[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) rs[i] = *reinterpret_cast<const f32x4*>(st + 8192 + (16 * i + 4 * g) * 4);
+    const uint32_t scw = meta_sc[(s * NS + wave) * 16 + c];
+    const uint32_t zw = meta_z[(s * NS + wave) * 2 + (c >> 3)];
+    if (lane == 0) lds_write_u32_volatile(prog_addr, (uint32_t)(s + 1));   // LDS is in order: executes after the reads above
+    f32x4 acc[MT] = {zero4, zero4};
+    uint32_t wv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) wv[u] = w[si % DW][u];
+    if constexpr (!(MODE & SM_NOW)) { if constexpr (MODE & SM_LOOP) load_w(w[si % DW], min(s + DW, S - 1)); else if (s + DW < S) load_w(w[si % DW], s + DW); } else { for (int u = 0; u < 4; ++u) asm volatile("" : "+v"(wv[u])); }
+    __builtin_amdgcn_sched_barrier(0);    // pin the prefetch distance (the scheduler otherwise hoists every later load)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint32_t w8 = wv[u] >> 8;
+      u32x4 bq = {wv[u] & 0x000f000fu, wv[u] & 0x00f000f0u, w8 & 0x000f000fu, w8 & 0x00f000f0u};
+      const f16x8 b = __builtin_bit_cast(f16x8, bq);
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        u32x4 av = af[u][i];
+        if constexpr (!(MODE & SM_PRESC)) {
+          asm("v_pk_mul_f16 %0, %1, %2" : "=v"(av[1]) : "v"(av[1]), "s"(0x2c002c00u));
+          asm("v_pk_mul_f16 %0, %1, %2" : "=v"(av[3]) : "v"(av[3]), "s"(0x2c002c00u));
+        }
+        if constexpr (MODE & SM_NOMFMA) { asm volatile("" :: "v"(av), "v"(b)); }
+        else acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, av), b, acc[i], 0, 0, 0);
+      }
+    }
+    const float z = (float)((zw >> ((c & 7) * 4)) & 0xf) + zoff;
+    const float sf = Half::to_f32((uint16_t)scw);
+    const float s24 = sf * 16777216.f;
+    const float nzs = -z * sf;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      cacc[i] = __builtin_elementwise_fma(acc[i], f32x4{s24, s24, s24, s24}, cacc[i]);
+      cacc[i] = __builtin_elementwise_fma(rs[i], f32x4{nzs, nzs, nzs, nzs}, cacc[i]);
+      asm volatile("" : "+v"(cacc[i]));   // the group epilogue happens HERE (the compiler otherwise sinks all S of them to the end)
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // ---- store: lane (g, c) holds rows 16 i + 4 g + r of column ncol ------------------------------------------------
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * i + 4 * g + r;
+      if (row < p.M) {
+        if (gridDim.y == 1) p.c[(size_t)row * p.N + ncol] = Half::from_f32(cacc[i][r]);
+        else p.partial[((size_t)blockIdx.y * p.M + row) * p.N + ncol] = cacc[i][r];
+      }
+    }
+}
+}  // namespace aphro
+
+struct Ctx {
+  int K, N, M, G, mtiles;
+  std::vector<uint32_t*> qw;
+  uint32_t* qz; uint16_t *sc, *apk, *apk_pre, *c; float *part, *rs;
+  std::vector<float> ref;
+};
+
+template <typename F>
+static double time_us(F&& launch, int iters = 30) {
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int i = 0; i < 6; ++i) launch(i);
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(e0));
+  for (int i = 0; i < iters; ++i) launch(i);
+  CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+  float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+  CK(hipEventDestroy(e0)); CK(hipEventDestroy(e1));
+  return ms * 1e3 / iters;
+}
+
+static void fetch_sum(Ctx& cx, int ksplit, std::vector<float>& dst) {
+  const size_t mn = (size_t)cx.M * cx.N;
+  dst.assign(mn, 0.f);
+  if (ksplit == 1) {
+    std::vector<uint16_t> h(mn);
+    CK(hipMemcpy(h.data(), cx.c, mn * 2, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < mn; ++i) dst[i] = (float)__builtin_bit_cast(_Float16, h[i]);
+  } else {
+    std::vector<float> h(mn * ksplit);
+    CK(hipMemcpy(h.data(), cx.part, mn * ksplit * 4, hipMemcpyDeviceToHost));
+    for (int k = 0; k < ksplit; ++k) for (size_t i = 0; i < mn; ++i) dst[i] += h[(size_t)k * mn + i];
+  }
+}
+
+static void run_shipped(Ctx& cx, int nseg, int ksplit) {
+  aphro::Wna16Params p{};
+  p.a = nullptr; p.apk = cx.apk; p.qz = cx.qz; p.sc = cx.sc; p.c = cx.c; p.partial = cx.part;
+  p.M = cx.M; p.N = cx.N; p.K = cx.K; p.lda = cx.K; p.group_size = 128; p.ksteps_per_split = 4 * aphro::FNW * nseg;
+  p.ksplit = ksplit; p.zero_offset = 1; p.gshift = 0; p.force_partial = 0;
+  dim3 grid(cx.N / 64, ksplit, (cx.M + 31) / 32);
+  const size_t lds = (size_t)aphro::FNW * 2 * 4 * 64 * 4 * sizeof(float);
+  auto launch = [&](int i) {
+    p.qw = cx.qw[i % cx.qw.size()];
+    switch (nseg) {
+      case 8: hipLaunchKernelGGL((aphro::wna16_gemm_kernel<aphro::Half, 4, 2, 8>), grid, dim3(256), lds, 0, p); break;
+      case 7: hipLaunchKernelGGL((aphro::wna16_gemm_kernel<aphro::Half, 4, 2, 7>), grid, dim3(256), lds, 0, p); break;
+      case 4: hipLaunchKernelGGL((aphro::wna16_gemm_kernel<aphro::Half, 4, 2, 4>), grid, dim3(256), lds, 0, p); break;
+      default: hipLaunchKernelGGL((aphro::wna16_gemm_kernel<aphro::Half, 4, 2, 2>), grid, dim3(256), lds, 0, p); break;
+    }
+  };
+  CK(hipMemset(cx.c, 0, (size_t)cx.M * cx.N * 2)); CK(hipMemset(cx.part, 0, (size_t)8 * cx.M * cx.N * 4));
+  launch(0); CK(hipDeviceSynchronize());
+  fetch_sum(cx, ksplit, cx.ref);
+  const double us = time_us(launch);
+  printf("  %-40s wg=%4d : %7.2f us  %6.0f GB/s (weights)\n", "SHIPPED", grid.x * grid.y, us, (double)cx.K / 8 * cx.N * 4 / us / 1e3);
+  fflush(stdout);
+}
+
+template <int NS, int S, int DW, int R, int PD, int MODE>
+static void run_strip(Ctx& cx, const char* name) {
+  if (cx.N % (NS * 16) != 0 || (cx.K / 128) % S != 0) return;
+  const int ksplit = cx.K / 128 / S;
+  aphro::StripParams p{};
+  p.apk = (MODE & SM_PRESC) ? cx.apk_pre : cx.apk; p.rs = cx.rs; p.qz = cx.qz; p.sc = cx.sc; p.c = cx.c; p.partial = cx.part;
+  p.M = cx.M; p.N = cx.N; p.K = cx.K; p.zero_offset = 1;
+  dim3 grid(cx.N / (NS * 16), ksplit);
+  const size_t lds = (size_t)R * (8192 + 256) + (size_t)S * NS * 32 + (size_t)S * NS * 8 + 64;
+  auto kern = aphro::strip_gemm_kernel<NS, S, DW, R, PD, MODE>;
+  CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  auto launch = [&](int i) { p.qw = cx.qw[i % cx.qw.size()]; hipLaunchKernelGGL(kern, grid, dim3((NS + 1) * 64), lds, 0, p); };
+  CK(hipMemset(cx.c, 0, (size_t)cx.M * cx.N * 2)); CK(hipMemset(cx.part, 0, (size_t)8 * cx.M * cx.N * 4));
+  launch(0);
+  hipError_t le = hipDeviceSynchronize();
+  if (le != hipSuccess) { printf("  %-40s FAILED: %s\n", name, hipGetErrorString(le)); exit(1); }
+  std::vector<float> got; fetch_sum(cx, ksplit, got);
+  double maxd = 0, maxr = 0; size_t bad = 0;
+  for (size_t i = 0; i < got.size(); ++i) {
+    const double d = fabs((double)cx.ref[i] - got[i]);
+    if (d > 2e-3 * fabs((double)cx.ref[i]) + 2e-2) ++bad;
+    maxd = fmax(maxd, d); maxr = fmax(maxr, fabs((double)cx.ref[i]));
+  }
+  const double us = time_us(launch);
+  printf("  %-40s wg=%4d x %dw lds=%zuK : %7.2f us  %6.0f GB/s  maxdiff %.3g (max|ref| %.3g) %s\n", name, grid.x * grid.y, NS + 1, lds / 1024, us,
+         (double)cx.K / 8 * cx.N * 4 / us / 1e3, maxd, maxr, bad == 0 ? "ok" : "MISMATCH");
+  fflush(stdout);
+}
+
+static void shape(int K, int N, int M, int ship_nseg, int ship_ksplit) {
+  Ctx cx; cx.K = K; cx.N = N; cx.M = M; cx.G = K / 128; cx.mtiles = (M + 15) / 16;
+  const size_t wbytes = (size_t)K / 8 * N * 4;
+  const int copies = (int)std::max<size_t>(2, (600u << 20) / wbytes + 1);
+  std::vector<uint32_t> h(wbytes / 4);
+  for (auto& x : h) x = (uint32_t)rand() * 2654435761u;
+  cx.qw.resize(std::min(copies, 48));
+  for (auto& q : cx.qw) { CK(hipMalloc(&q, wbytes)); CK(hipMemcpy(q, h.data(), wbytes, hipMemcpyHostToDevice)); }
+  {
+    std::vector<uint32_t> hz((size_t)cx.G * N / 8); for (auto& x : hz) x = (uint32_t)rand() * 2654435761u;
+    CK(hipMalloc(&cx.qz, hz.size() * 4)); CK(hipMemcpy(cx.qz, hz.data(), hz.size() * 4, hipMemcpyHostToDevice));
+    std::vector<uint16_t> hs((size_t)cx.G * N);
+    for (auto& x : hs) { _Float16 v = (_Float16)(0.002f + (rand() % 1000) * 1e-5f); x = __builtin_bit_cast(uint16_t, v); }
+    CK(hipMalloc(&cx.sc, hs.size() * 2)); CK(hipMemcpy(cx.sc, hs.data(), hs.size() * 2, hipMemcpyHostToDevice));
+  }
+  {
+    // row-major random activations -> fragment-major packed (plain and pre-scaled) + row sums per 128-k group
+    std::vector<_Float16> a((size_t)cx.mtiles * 16 * K, (_Float16)0.f);
+    for (int m = 0; m < M; ++m) for (int k = 0; k < K; ++k) a[(size_t)m * K + k] = (_Float16)((rand() % 2048) / 1024.0f - 1.0f);
+    std::vector<uint16_t> pk(a.size()), pkp(a.size());
+    std::vector<float> rs((size_t)cx.G * 64, 0.f);
+    for (int seg = 0; seg < cx.G; ++seg)
+      for (int u = 0; u < 4; ++u)
+        for (int mt = 0; mt < cx.mtiles; ++mt)
+          for (int lane = 0; lane < 64; ++lane)
+            for (int j = 0; j < 8; ++j) {
+              const int row = 16 * mt + (lane & 15), k = 128 * seg + 32 * (lane >> 4) + 8 * u + j;
+              const _Float16 v = a[(size_t)row * K + k];
+              const size_t idx = ((((size_t)seg * 4 + u) * cx.mtiles + mt) * 64 + lane) * 8 + j;
+              pk[idx] = __builtin_bit_cast(uint16_t, v);
+              const _Float16 vp = ((j & 2) ? (_Float16)((float)v * 0.0625f) : v);
+              pkp[idx] = __builtin_bit_cast(uint16_t, vp);
+              rs[(size_t)seg * 64 + row] += (float)v;
+            }
+    CK(hipMalloc(&cx.apk, pk.size() * 2)); CK(hipMemcpy(cx.apk, pk.data(), pk.size() * 2, hipMemcpyHostToDevice));
+    CK(hipMalloc(&cx.apk_pre, pk.size() * 2)); CK(hipMemcpy(cx.apk_pre, pkp.data(), pk.size() * 2, hipMemcpyHostToDevice));
+    CK(hipMalloc(&cx.rs, rs.size() * 4)); CK(hipMemcpy(cx.rs, rs.data(), rs.size() * 4, hipMemcpyHostToDevice));
+  }
+  CK(hipMalloc(&cx.c, (size_t)M * N * 2));
+  CK(hipMalloc(&cx.part, (size_t)8 * M * N * 4 + 4096));
+  printf("== K=%d N=%d M=%d  (%.1f MB of packed weights, %zu copies cycled)\n", K, N, M, wbytes / 1e6, cx.qw.size());
+  run_shipped(cx, ship_nseg, ship_ksplit);
+#define V(NS, S, DW, R, PD, MODE) run_strip<NS, S, DW, R, PD, MODE>(cx, "strip NS=" #NS " S=" #S " DW=" #DW " R=" #R " PD=" #PD " m=" #MODE)
+  if (K == 4096 && N == 28672) {
+    V(7, 32, 4, 8, 4, SM_PRESC);
+    V(7, 32, 4, 8, 4, SM_PRESC | SM_LOOP);
+    V(7, 32, 8, 8, 4, SM_PRESC | SM_LOOP);
+    V(7, 32, 4, 8, 4, SM_PRESC | SM_LOOP | SM_NOA | SM_NOPOLL | SM_NOW);
+    V(7, 32, 4, 8, 4, SM_PRESC | SM_LOOP | SM_NOA | SM_NOPOLL | SM_NOMFMA);
+    V(7, 32, 4, 8, 4, SM_PRESC | SM_LOOP | SM_NOW);
+    V(7, 32, 4, 8, 4, SM_PRESC | SM_NOMFMA);
+    V(7, 32, 4, 8, 4, SM_PRESC | SM_NOA);
+    V(7, 32, 4, 8, 4, SM_PRESC | SM_NOA | SM_NOMFMA);
+    V(7, 32, 4, 8, 4, SM_PRESC | SM_NOW);
+    V(7, 32, 4, 8, 4, SM_PRESC | SM_NOA | SM_NOPOLL);
+    V(7, 32, 4, 8, 4, SM_PRESC | SM_NOA | SM_NOPOLL | SM_NOMFMA);
+    V(7, 32, 8, 8, 4, SM_PRESC | SM_NOA | SM_NOPOLL | SM_NOMFMA);
+    V(7, 32, 4, 8, 4, SM_PRESC | SM_NOA | SM_NOPOLL | SM_NOW);
+  } else if (K == 4096 && N == 6144) {
+    V(6, 8, 8, 6, 3, SM_PRESC);      // 64 x ksplit 4
+    V(3, 16, 8, 6, 3, SM_PRESC);     // 128 x ksplit 2
+    V(6, 16, 8, 6, 3, SM_PRESC);     // 64 x ksplit 2 (half the chip)
+  } else if (K == 4096 && N == 4096) {
+    V(4, 8, 8, 6, 3, SM_PRESC);      // 64 x 4
+    V(2, 16, 8, 6, 3, SM_PRESC);     // 128 x 2
+    V(4, 16, 8, 6, 3, SM_PRESC);     // 64 x 2
+  } else if (K == 14336) {
+    V(4, 28, 8, 6, 3, SM_PRESC);     // 64 x 4
+    V(2, 56, 8, 6, 3, SM_PRESC);     // 128 x 2
+    V(4, 14, 8, 6, 3, SM_PRESC);     // 64 x 8
+  }
+#undef V
+  for (auto q : cx.qw) CK(hipFree(q));
+  CK(hipFree(cx.qz)); CK(hipFree(cx.sc)); CK(hipFree(cx.apk)); CK(hipFree(cx.apk_pre)); CK(hipFree(cx.rs)); CK(hipFree(cx.c)); CK(hipFree(cx.part));
+}
+
+int main(int argc, char** argv) {
+  std::vector<std::string> which;
+  for (int i = 1; i < argc; ++i) which.push_back(argv[i]);
+  auto want = [&](const char* s) { return which.empty() || std::find(which.begin(), which.end(), std::string(s)) != which.end(); };
+  if (want("gate_up")) shape(4096, 28672, 32, 8, 1);
+  if (want("down")) shape(14336, 4096, 32, 7, 4);
+  if (want("qkv")) shape(4096, 6144, 32, 4, 2);
+  if (want("o")) shape(4096, 4096, 32, 2, 4);
+  return 0;
+}
