@@ -14,9 +14,14 @@ follows.  Pinning status (see DESIGN.md "Oracle pinning"):
   are pinned against golden vectors generated from the reference's own Python
   (``tests/golden/make_golden.py``), and paged attention / cache write also
   against the reference's own CPU kernels compiled into ``oracle/_ref``.
-* ``gptq_shuffle`` / ``gptq_gemm`` / CUDA ``awq_gemm``: the reference holds no
-  kernel-level test or fixture for them -- **parity
-  unpinned** at kernel level; the restatement follows the CUDA source
-  (q_gemm.cu, qdq_4.cuh) line by line and is cross-checked for internal
-  consistency (shuffle o dequant == dequant).
+* ``gptq_shuffle`` / ``gptq_dequant`` / ``gptq_gemm``: pinned by the reference's OWN CUDA kernels
+  (q_gemm.cu shuffle_4bit_kernel, make_sequential_4bit_kernel, reconstruct_exllama_4bit_kernel,
+  reconstruct_gptq_kernel, gemm_half_q_half_gptq_4bit_kernel + qdq_4.cuh, matrix_view.cuh) compiled
+  unmodified for the HOST against ``oracle/cuda_host_shim/`` (``oracle/Makefile`` ->
+  ``oracle/_ref/libaphro_ref_gptq.so``; fixtures ``tests/golden/gptq_ref.npz`` from
+  ``tests/golden/make_golden_gptq.py``): shuffle / act-order repack and both fp16 dequant kernels agree
+  bit for bit, the M <= 50 exllama GEMM within its own fp16-accumulation noise (mean rel 5e-4).
+* ``awq_gemm``: on ROCm the reference's op IS ``awq_gemm_triton``, which its own test pins against
+  ``matmul(x, awq_dequantize_torch(...))`` (tests/kernels/test_awq_triton.py) -- the golden-pinned
+  dequant + a matmul, as restated here.  (The CUDA PTX kernel is not compilable on a host.)
 """

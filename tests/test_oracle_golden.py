@@ -82,8 +82,8 @@ def test_act_order_sort(int4):
 
 
 def test_gptq_shuffle_consistency(int4):
-    """gptq_shuffle / gptq_gemm have no reference fixture (parity unpinned,
-    SURVEY 8c): check the restatement is self-consistent -- shuffled+perm
+    """Self-consistency of the restatement (the pin against the reference's own kernels is
+    test_gptq_*_reference_kernels below): shuffled+perm
     dequant followed by the A-gather equals the plain act-order dequant."""
     rng = np.random.RandomState(0)
     q = int4["act_w_q"]                        # rows permuted by rand_perm
@@ -544,3 +544,83 @@ def test_copy_blocks_vs_reference_cpu_kernel():
     oa.copy_blocks(k2, v2, mapping.numpy())
     for a, b in zip(kcs + vcs, k2 + v2):
         np.testing.assert_array_equal(a.numpy(), b)
+
+
+# ---- GPTQ exllama path: pinned by the REFERENCE's own CUDA kernels run on the host -----------------------------
+# tests/golden/gptq_ref.npz holds what kernels/quantization/gptq/q_gemm.cu's shuffle_4bit_kernel /
+# make_sequential_4bit_kernel / reconstruct_exllama_4bit_kernel / reconstruct_gptq_kernel /
+# gemm_half_q_half_gptq_4bit_kernel return when compiled for the CPU (oracle/Makefile, oracle/ref_gptq_bind.cpp);
+# generated by tests/golden/make_golden_gptq.py.  Integer work and the fp16 dequant are bit-exact; the GEMM is
+# compared within the reference kernel's own fp16-dot / fp16-atomics noise.
+@pytest.fixture(scope="module")
+def gref(golden_dir):
+    return np.load(os.path.join(golden_dir, "gptq_ref.npz"))
+
+
+def _gref_case(gref, name):
+    perm = gref[f"{name}_perm"]
+    return (gref[f"{name}_qweight"], gref[f"{name}_qzeros"], gref[f"{name}_scales"], gref[f"{name}_g_idx"],
+            perm if len(perm) else None)
+
+
+@pytest.mark.parametrize("name", ["a", "b", "c", "d"])
+def test_gptq_shuffle_reference_kernels(gref, name):
+    qw, qz, sc, g_idx, perm = _gref_case(gref, name)
+    got = oq.gptq_shuffle(qw, perm)
+    np.testing.assert_array_equal(got.view(np.uint32), gref[f"{name}_shuffle"].view(np.uint32))
+
+
+@pytest.mark.parametrize("name", ["a", "b", "c", "d"])
+def test_gptq_dequant_reference_kernels(gref, name):
+    qw, qz, sc, g_idx, perm = _gref_case(gref, name)
+    # (q - (z + 1)) * s from checkpoint order + g_idx: reconstruct_gptq_kernel, q_gemm.cu:1394-1434
+    w = oq.gptq_dequant(qw, qz, sc, g_idx, shuffled=False).astype(np.float16)
+    np.testing.assert_array_equal(w.view(np.uint16), gref[f"{name}_recon_gptq"].view(np.uint16))
+    # the same weights through the exllama layout: reconstruct_exllama_4bit_kernel writes row perm[k] (:937-960)
+    shuf = gref[f"{name}_shuffle"]
+    w_seq = oq.gptq_dequant(shuf, qz, sc, None, shuffled=True).astype(np.float16)
+    full = np.zeros_like(w_seq)
+    if perm is not None:
+        full[perm, :] = w_seq
+    else:
+        full = w_seq
+    np.testing.assert_array_equal(full.view(np.uint16), gref[f"{name}_recon_exl"].view(np.uint16))
+    np.testing.assert_array_equal(full.view(np.uint16), w.view(np.uint16))   # both reference kernels agree, too
+
+
+@pytest.mark.parametrize("name", ["c", "d"])
+@pytest.mark.parametrize("m", [1, 5, 8, 13])
+def test_gptq_gemm_reference_kernel(gref, name, m):
+    qw, qz, sc, g_idx, perm = _gref_case(gref, name)
+    a = gref[f"{name}_gemm_a{m}"]
+    ref = gref[f"{name}_gemm_c{m}"].astype(np.float64)
+    got = oq.gptq_gemm(a, gref[f"{name}_shuffle"], qz, sc, perm, True)
+    # the reference kernel: fp16 hfma2 dot over 8 k, fp32 per 128-k block, fp16 atomics across blocks
+    assert np.isfinite(ref).all()
+    assert np.abs(ref - got).max() <= 2e-2
+    assert np.abs(ref - got).mean() / np.abs(got).mean() < 2e-3
+
+
+def test_gptq_reference_library_live(gref):
+    """When oracle/_ref/libaphro_ref_gptq.so is present (build container, GPU box), run the reference kernels NOW on
+    fresh random inputs -- the fixtures above were not cherry-picked."""
+    import ctypes
+    import importlib.util
+    lib_path = os.path.join(os.path.dirname(__file__), "..", "oracle", "_ref", "libaphro_ref_gptq.so")
+    if not os.path.exists(lib_path):
+        pytest.skip("oracle/_ref/libaphro_ref_gptq.so not built")
+    spec = importlib.util.spec_from_file_location("make_golden_gptq", os.path.join(os.path.dirname(__file__), "golden",
+                                                                                   "make_golden_gptq.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    lib = ctypes.CDLL(lib_path)
+    rng = np.random.default_rng(7)
+    for k, n, gs, ao in [(128, 64, 32, True), (384, 128, 128, False), (256, 32, 64, True)]:
+        qw, qz, sc, g_idx, perm = mg.make_case(rng, k, n, gs, ao)
+        shuf = mg.ref_shuffle(lib, qw, perm)
+        np.testing.assert_array_equal(oq.gptq_shuffle(qw, perm).view(np.uint32), shuf.view(np.uint32))
+        w = oq.gptq_dequant(qw, qz, sc, g_idx, shuffled=False).astype(np.float16)
+        np.testing.assert_array_equal(w.view(np.uint16), mg.ref_recon_gptq(lib, qw, qz, sc, g_idx).view(np.uint16))
+        a = rng.standard_normal((3, k)).astype(np.float16)
+        c = mg.ref_gemm(lib, a, shuf, qz, sc, perm).astype(np.float64)
+        assert np.abs(c - oq.gptq_gemm(a, shuf, qz, sc, perm, True)).max() <= 2e-2
