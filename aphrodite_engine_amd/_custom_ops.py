@@ -426,6 +426,20 @@ def gptq_marlin_repack(b_q_weight: torch.Tensor, perm: torch.Tensor, size_k: int
 # --------------------------------------------------------------------------
 # AWQ
 # --------------------------------------------------------------------------
+_ZP8 = {}
+
+
+def _uint4b8_zeros(device: torch.device, groups: int, n: int) -> torch.Tensor:
+    """Packed zero points of the symmetric uint4b8 type (8 in every nibble), made once per shape: no allocation
+    or fill launch inside the op (it runs under HIP-graph capture)."""
+    key = (device.type, device.index, groups, n)
+    z = _ZP8.get(key)
+    if z is None:
+        z = torch.full((groups, n // 8), 0x88888888 - (1 << 32), dtype=torch.int64, device=device).to(torch.int32)
+        _ZP8[key] = z
+    return z
+
+
 def gptq_marlin_gemm(a: torch.Tensor, b_q_weight: torch.Tensor, b_scales: torch.Tensor,
                      b_zeros: torch.Tensor, g_idx: torch.Tensor, perm: torch.Tensor,
                      workspace: Optional[torch.Tensor], b_q_type, size_m: int, size_n: int,
@@ -450,8 +464,7 @@ def gptq_marlin_gemm(a: torch.Tensor, b_q_weight: torch.Tensor, b_scales: torch.
     if has_zp:
         zp = b_zeros
     else:
-        zp = torch.full((groups, size_n // 8), 0x88888888 - (1 << 32), dtype=torch.int64,
-                        device=a.device).to(torch.int32)
+        zp = _uint4b8_zeros(a.device, groups, size_n)
     p = perm if perm is not None and perm.numel() > 0 else None
     return wna16_gemm(x, b_q_weight, zp, b_scales, p, 0)
 
@@ -991,12 +1004,28 @@ def wna16_gemm(a, qweight_kpacked, qzeros, scales, perm=None, zero_offset=0):
 # --------------------------------------------------------------------------
 # FP8
 # --------------------------------------------------------------------------
+def check_fp8_buffer(t: torch.Tensor, what: str) -> None:
+    """gfx950 computes in OCP e4m3fn.  The reference's ROCm branch allocates MI300's e4m3fnuz (``_custom_ops.py:663-665``,
+    ``w8a8_utils.py:207-228``): the same bytes mean HALF the value there and 0x80 is NaN, so writing OCP bits into an
+    fnuz-typed tensor (or multiplying fnuz-typed operands) would be silently wrong by 2x.  Refuse it."""
+    fnuz = getattr(torch, "float8_e4m3fnuz", None)
+    if fnuz is not None and t.dtype == fnuz:
+        raise RuntimeError(f"{what}: tensor is float8_e4m3fnuz (MI300 encoding); the MI355X kernels produce / consume "
+                           "OCP float8_e4m3fn -- allocate torch.float8_e4m3fn (plugin.register() patches the reference's "
+                           "ROCm fp8 dtype selection)")
+    if t.dtype not in (FP8_DTYPE, torch.uint8):
+        raise RuntimeError(f"{what}: expected a float8_e4m3fn (or uint8) buffer, got {t.dtype}")
+
+
 def scaled_fp8_quant(input: torch.Tensor, scale: Optional[torch.Tensor] = None,
                      num_token_padding: Optional[int] = None,
                      scale_ub: Optional[torch.Tensor] = None,
-                     use_per_token_if_dynamic: bool = False
+                     use_per_token_if_dynamic: bool = False,
+                     out: Optional[torch.Tensor] = None,
+                     scale_out: Optional[torch.Tensor] = None
                      ) -> Tuple[torch.Tensor, torch.Tensor]:
-    """_custom_ops.py:632-685 with the OCP e4m3fn output dtype of gfx950."""
+    """_custom_ops.py:632-685 with the OCP e4m3fn output dtype of gfx950.  ``out`` / ``scale_out``: caller-owned
+    buffers (the ``Tensor!`` arguments of the schema-level ops, torch_bindings.cpp:374-390) written in place."""
     assert input.ndim == 2
     _require_cuda(input)
     if not input.is_contiguous():
@@ -1005,17 +1034,23 @@ def scaled_fp8_quant(input: torch.Tensor, scale: Optional[torch.Tensor] = None,
     shape = input.shape
     if num_token_padding:
         shape = (max(num_token_padding, input.shape[0]), shape[1])
-    output = torch.empty(shape, device=input.device, dtype=FP8_DTYPE)
+    if out is not None:
+        check_fp8_buffer(out, "scaled_fp8_quant")
+        if not out.is_contiguous() or out.shape[1] != shape[1] or out.shape[0] < input.shape[0]:
+            raise RuntimeError("scaled_fp8_quant: out must be a contiguous [>= M, K] buffer")
+        output = out
+    else:
+        output = torch.empty(shape, device=input.device, dtype=FP8_DTYPE)
     m, k = input.shape
     if scale is None:
         if use_per_token_if_dynamic:
-            scale = torch.empty((shape[0], 1), device=input.device,
-                                dtype=torch.float32)
+            scale = scale_out if scale_out is not None else \
+                torch.empty((shape[0], 1), device=input.device, dtype=torch.float32)
             check(lib.aphro_dynamic_per_token_scaled_fp8_quant(
                 output.data_ptr(), input.data_ptr(), scale.data_ptr(),
                 _ptr(scale_ub), m, k, _dt(input), _stream()), "scaled_fp8_quant")
         else:
-            scale = torch.empty(1, device=input.device, dtype=torch.float32)
+            scale = scale_out if scale_out is not None else torch.empty(1, device=input.device, dtype=torch.float32)
             ws = _quant_scratch(input.device)
             check(lib.aphro_dynamic_scaled_fp8_quant_ws(
                 output.data_ptr(), input.data_ptr(), scale.data_ptr(), ws.data_ptr(), ws.numel() * 4,
@@ -1034,10 +1069,15 @@ def cutlass_scaled_mm_supports_fp8(cuda_device_capability: int) -> bool:
 
 def cutlass_scaled_mm(a: torch.Tensor, b: torch.Tensor, scale_a: torch.Tensor,
                       scale_b: torch.Tensor, out_dtype: torch.dtype,
-                      bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+                      bias: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """_custom_ops.py:497-517.  a [M,K] e4m3 row-major, b [K,N] e4m3
-    column-major (``weight.t()``)."""
+    column-major (``weight.t()``).  ``out``: caller-owned [M,N] result buffer (the ``Tensor! out`` of the
+    schema-level op, torch_bindings.cpp:235-239)."""
     _require_cuda(a, b, scale_a, scale_b)
+    for x_ in (a, b):
+        fnuz = getattr(torch, "float8_e4m3fnuz", None)
+        if fnuz is not None and x_.dtype == fnuz:
+            check_fp8_buffer(x_, "cutlass_scaled_mm")
     assert b.shape[0] % 16 == 0 and b.shape[1] % 16 == 0
     assert out_dtype in (torch.bfloat16, torch.float16)
     assert bias is None or (bias.shape[0] == b.shape[1] and bias.dtype == out_dtype)
@@ -1065,16 +1105,26 @@ def cutlass_scaled_mm(a: torch.Tensor, b: torch.Tensor, scale_a: torch.Tensor,
                 one = torch.ones((), dtype=torch.float32, device=a.device)
                 acc = torch._scaled_mm(a, b, scale_a=one, scale_b=one, out_dtype=torch.float32)
                 acc = acc[0] if isinstance(acc, tuple) else acc
-                out = (acc * sb_ * sa_)
+                res = (acc * sb_ * sa_)
                 if bias is not None:
-                    out = out + bias
-                return out.to(out_dtype)
+                    res = res + bias
+                if out is not None:
+                    out.copy_(res)
+                    return out
+                return res.to(out_dtype)
         else:
             sa_, sb_ = sa_.reshape(()), sb_.reshape(())
-        out = torch._scaled_mm(a, b, scale_a=sa_, scale_b=sb_, bias=bias, out_dtype=out_dtype)
-        return out[0] if isinstance(out, tuple) else out
+        res = torch._scaled_mm(a, b, scale_a=sa_, scale_b=sb_, bias=bias, out_dtype=out_dtype)
+        res = res[0] if isinstance(res, tuple) else res
+        if out is not None:
+            out.copy_(res)
+            return out
+        return res
     lib = _lib.lib()
-    out = torch.empty((m, n), dtype=out_dtype, device=a.device)
+    if out is None:
+        out = torch.empty((m, n), dtype=out_dtype, device=a.device)
+    elif out.shape != (m, n) or out.dtype != out_dtype or not out.is_contiguous():
+        raise RuntimeError("cutlass_scaled_mm: out must be a contiguous [M, N] tensor of out_dtype")
     odt = _lib.F16 if out_dtype == torch.float16 else _lib.BF16
     sa = scale_a.reshape(-1).float()
     sb = scale_b.reshape(-1).float()

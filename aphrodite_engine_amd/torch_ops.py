@@ -45,24 +45,19 @@ _C_OPS = [
 
 
 def _static_scaled_fp8_quant(out, input, scale):
-    q, _ = ops.scaled_fp8_quant(input, scale)
-    out.view(torch.uint8).copy_(q.view(torch.uint8))
+    ops.scaled_fp8_quant(input, scale, out=out)                       # written in place: no staging copy
 
 
 def _dynamic_scaled_fp8_quant(out, input, scale):
-    q, s = ops.scaled_fp8_quant(input)
-    out.view(torch.uint8).copy_(q.view(torch.uint8))
-    scale.copy_(s)
+    ops.scaled_fp8_quant(input, out=out, scale_out=scale)
 
 
 def _dynamic_per_token_scaled_fp8_quant(out, input, scale, scale_ub: Optional[torch.Tensor]):
-    q, s = ops.scaled_fp8_quant(input, scale_ub=scale_ub, use_per_token_if_dynamic=True)
-    out.view(torch.uint8)[:q.shape[0]].copy_(q.view(torch.uint8))
-    scale[:s.shape[0]].copy_(s)
+    ops.scaled_fp8_quant(input, scale_ub=scale_ub, use_per_token_if_dynamic=True, out=out, scale_out=scale)
 
 
 def _cutlass_scaled_mm(out, a, b, a_scales, b_scales, bias: Optional[torch.Tensor]):
-    out.copy_(ops.cutlass_scaled_mm(a, b, a_scales, b_scales, out.dtype, bias))
+    ops.cutlass_scaled_mm(a, b, a_scales, b_scales, out.dtype, bias, out=out)
 
 
 _C_OPS += [
@@ -79,6 +74,26 @@ _C_OPS += [
 def _fp8_marlin_gemm(a, b_q_weight, b_scales, workspace, num_bits, size_m, size_n, size_k):
     return ops.fp8_marlin_gemm(a, b_q_weight, b_scales, workspace, num_bits, size_m, size_n, size_k)
 
+
+def _gptq_marlin_gemm(a, b_q_weight, b_scales, b_zeros, g_idx, perm, workspace, b_q_type, size_m, size_n, size_k,
+                      is_k_full, has_zp, use_fp32_reduce, is_zp_float):
+    if isinstance(b_q_type, int):          # standalone schema: the type travels as its size in bits
+        from .scalar_type import ScalarType
+        b_q_type = ScalarType.uint(b_q_type, 0 if has_zp else 8)
+    return ops.gptq_marlin_gemm(a, b_q_weight, b_scales, b_zeros, g_idx, perm, workspace, b_q_type, size_m, size_n,
+                                size_k, is_k_full, has_zp, use_fp32_reduce, is_zp_float)
+
+
+# torch_bindings.cpp:195-201.  The verbatim schema names the torchbind class ``_core_C.ScalarType``
+# (kernels/core/torch_bindings.cpp:13), which exists once the reference's ``_core_C`` extension is loaded -- inside
+# the reference that is always the case.  Standalone (tests, bench) the class is absent and the schema cannot be
+# parsed: the same op is then defined with ``int b_q_type`` (size in bits) in that position.
+_MARLIN_GEMM_TAIL = ("int size_m, int size_n, int size_k, bool is_k_full, bool has_zp, bool use_fp32_reduce, "
+                     "bool is_zp_float) -> Tensor")
+_MARLIN_GEMM_HEAD = ("gptq_marlin_gemm(Tensor a, Tensor b_q_weight, Tensor b_scales, Tensor b_zeros, Tensor g_idx, "
+                     "Tensor perm, Tensor workspace, ")
+GPTQ_MARLIN_GEMM_SCHEMAS = (_MARLIN_GEMM_HEAD + "__torch__.torch.classes._core_C.ScalarType b_q_type, " + _MARLIN_GEMM_TAIL,
+                            _MARLIN_GEMM_HEAD + "int b_q_type, " + _MARLIN_GEMM_TAIL)
 
 _C_OPS += [
     ("gptq_marlin_repack(Tensor b_q_weight, Tensor perm, SymInt size_k, SymInt size_n, int num_bits) -> Tensor",
@@ -146,5 +161,11 @@ def register(ns_c: str = "_C", ns_cache: str = "_C_cache_ops", ns_rocm: str = "_
                 lib.impl(name, fn, "CompositeExplicitAutograd")
             else:
                 lib.impl(name, fn, "CUDA")
+        if ns == ns_c:
+            try:
+                lib.define(GPTQ_MARLIN_GEMM_SCHEMAS[0])
+            except Exception:          # _core_C.ScalarType is not registered: standalone form
+                lib.define(GPTQ_MARLIN_GEMM_SCHEMAS[1])
+            lib.impl("gptq_marlin_gemm", _gptq_marlin_gemm, "CUDA")
         _LIBS.append(lib)
     _REGISTERED = True

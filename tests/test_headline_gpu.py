@@ -1,0 +1,190 @@
+"""BASELINE.json configs[1] (Llama-3-8B GPTQ 4-bit g128, bs 32) at its REAL shapes against the ORACLE.
+
+VERDICT r1 ("What's weak" #1): the kernel instantiations the bench times -- wna16_gemm_kernel<Half,4,2,{8,7,4,2}>,
+the packed-activation / split-K-slab / SiluAndMul-epilogue entry points, the fused decode layer -- were checked at
+full size only against this repo's own dequant kernel.  Here every one of them is compared with oracle.quant (pinned
+by the reference's own CUDA kernels, tests/test_oracle_golden.py::test_gptq_*reference*) on the four projection
+shapes at M = 1 and M = 32, and a 2-layer Llama-3-8B-geometry decode step through forward_decode_fused is compared
+with a layer composed from oracle functions only."""
+import dataclasses
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import attention as oa
+from oracle import quant as oq
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+SHAPES = [(4096, 6144), (4096, 4096), (4096, 28672), (14336, 4096)]     # qkv, o, gate_up, down (tests/benchmarks/kernels/weight_shapes.py:11-48)
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a visible MI355X (torch.cuda.is_available() is False)")
+    from aphrodite_engine_amd import _custom_ops, _lib
+    _lib.lib()
+    return _custom_ops
+
+
+def t(x, dtype=None):
+    out = torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
+    return out.to(dtype) if dtype is not None else out
+
+
+def unpack_a(packed, M, K):
+    """numpy inverse of the fragment-major layout (include/aphrodite_mi355x.h)."""
+    mt = (M + 15) // 16
+    p = packed.cpu().numpy().view(np.uint16)[: (K // 128) * 4 * mt * 64 * 8].reshape(K // 128, 4, mt, 4, 16, 8)
+    return p.transpose(2, 4, 0, 3, 1, 5).reshape(mt * 16, K)[:M]
+
+
+_CASES = {}
+
+
+def case(K, N):
+    """Random AutoGPTQ-v1 tensors of the shape, their exllama-shuffled form, activations and the fp64 oracle result."""
+    if (K, N) not in _CASES:
+        rng = np.random.default_rng(K * 7 + N)
+        G = K // 128
+        qweight = rng.integers(0, 2 ** 32, size=(K // 8, N), dtype=np.uint32).view(np.int32)
+        qzeros = rng.integers(0, 2 ** 32, size=(G, N // 8), dtype=np.uint32).view(np.int32)
+        scales = (rng.uniform(0.75, 1.25, size=(G, N)) / (4.6 * np.sqrt(K))).astype(np.float16)
+        a = rng.standard_normal((32, K)).astype(np.float16)
+        shuf = oq.gptq_shuffle(qweight)
+        ref = oq.gptq_gemm(a, shuf, qzeros, scales, None, True)           # fp64 [32, N]
+        _CASES[(K, N)] = (shuf, qzeros, scales, a, ref)
+    return _CASES[(K, N)]
+
+
+@pytest.mark.parametrize("M", [1, 32])
+@pytest.mark.parametrize("K,N", SHAPES)
+def test_config1_gptq_gemm_vs_oracle(ops, K, N, M):
+    """ops.gptq_gemm (the schema-level op: pack + fast kernel + split-K reduce) at the bench's shapes."""
+    shuf, qzeros, scales, a, ref = case(K, N)
+    ref = ref[:M]
+    empty = torch.empty(0, dtype=torch.int32, device=DEV)
+    got = ops.gptq_gemm(t(a[:M]), t(shuf), t(qzeros), t(scales), empty, True, 4)
+    g = got.float().cpu().numpy()
+    assert np.abs(g - ref).mean() / np.abs(ref).mean() < 0.04            # the reference's Marlin-family bar
+    np.testing.assert_allclose(g, ref, rtol=2e-3, atol=2e-3 * np.abs(ref).max())
+    assert torch.equal(got, ops.gptq_gemm(t(a[:M]), t(shuf), t(qzeros), t(scales), empty, True, 4))   # no atomics
+
+
+@pytest.mark.parametrize("M", [1, 32])
+@pytest.mark.parametrize("K,N", SHAPES)
+def test_config1_packed_and_slab_entry_points_vs_oracle(ops, K, N, M):
+    """The entry points the decode fast path (and bench.py's roofline leg) launches: fragment-major activations,
+    f16 output and raw fp32 split-K slabs for a fused consumer."""
+    shuf, qzeros, scales, a, ref = case(K, N)
+    ref = ref[:M]
+    pk = ops.wna16_pack_a(t(a[:M]))
+    np.testing.assert_array_equal(unpack_a(pk, M, K), a[:M].view(np.uint16))
+    y = ops.wna16_gemm_packed(pk, M, K, t(shuf), t(qzeros), t(scales), 1, partials=False)
+    np.testing.assert_allclose(y.float().cpu().numpy(), ref, rtol=2e-3, atol=2e-3 * np.abs(ref).max())
+    slabs, ks = ops.wna16_gemm_packed(pk, M, K, t(shuf), t(qzeros), t(scales), 1, partials=True)
+    assert slabs.shape == (ks, M, N) and ks == ops.wna16_ksplit(M, N, K, K // 128) and ks >= 1
+    s = slabs.double().sum(0).cpu().numpy()
+    np.testing.assert_allclose(s, ref, rtol=1e-4, atol=2e-5 * np.abs(ref).max())     # fp32 accumulate vs fp64
+    # the f16 output is the rounded slab sum (same kernel, same order)
+    assert torch.equal(y, slabs.sum(0).to(torch.float16)) or ks > 2   # (a + b) + c order of torch.sum may differ beyond 2 slabs
+
+
+@pytest.mark.parametrize("M", [1, 32])
+def test_config1_gate_up_silu_epilogue_vs_oracle(ops, M):
+    """gate_up with interleaved (gate_j, up_j) columns + SiluAndMul + pack in the GEMM epilogue, against
+    silu_and_mul(round16(oracle GEMM)) (activation_kernels.cu:12-60 on the fp16-rounded projection)."""
+    K, N = 4096, 28672
+    shuf, qzeros, scales, a, ref = case(K, N)
+    qw_i, qz_i, sc_i = ops.interleave_gate_up(t(shuf), t(qzeros), t(scales))
+    act = ops.wna16_gemm_silu_pack(ops.wna16_pack_a(t(a[:M])), M, K, qw_i, qz_i, sc_i, 1)
+    got = unpack_a(act, M, N // 2).view(np.float16).astype(np.float64)
+    gu = ref[:M].astype(np.float16)                                       # the kernel rounds the projection first
+    d = N // 2
+    gate = gu[:, :d].astype(np.float64)
+    silu = (gate / (1.0 + np.exp(-gate))).astype(np.float16).astype(np.float64)   # silu is rounded, then multiplied
+    want = (silu * gu[:, d:].astype(np.float64)).astype(np.float16).astype(np.float64)
+    np.testing.assert_allclose(got, want, rtol=4e-3, atol=4e-3 * np.abs(want).max())
+    # and the oracle's own (unrounded) silu_and_mul is within fp16 rounding of it
+    np.testing.assert_allclose(got, oa.silu_and_mul(ref[:M]), rtol=6e-3, atol=6e-3 * np.abs(want).max())
+
+
+def _lin_np(lin):
+    fp = lin.fast_params()
+    assert fp is not None and fp[3] == 1
+    return tuple(x.cpu().numpy() for x in fp[:3])
+
+
+def test_config1_fused_decode_layers_vs_oracle(ops):
+    """A decode step through TWO decoder layers of Llama-3-8B geometry (hidden 4096, 32/8 heads, inter 14336, GPTQ
+    g128) on the fused fast path -- norm+pack, qkv slabs, rope+cache+attention in one launch, o_proj slabs,
+    norm+pack, gate_up with the SiluAndMul epilogue, down slabs -- against the same step composed from ORACLE
+    functions only (fp64 math, rounded to fp16 where the reference's kernels store fp16)."""
+    from aphrodite_engine_amd import model as M
+    from aphrodite_engine_amd.quantization.gptq import GPTQConfig
+    cfg = dataclasses.replace(M.LLAMA3_8B, num_hidden_layers=2, vocab_size=2048, max_position_embeddings=512)
+    bs, lens, block = 4, [5, 17, 33, 64], 16
+    f16 = lambda x: np.asarray(x).astype(np.float16)
+    with torch.no_grad():
+        m = M.LlamaForCausalLM(cfg, GPTQConfig(4, 128, False), torch.float16)
+        m.init_synthetic(torch.device(DEV))
+        assert all(l.enable_fused_silu(bs) for l in m.layers)
+        meta, pos, nblocks = M.make_decode_metadata(bs, lens, block, DEV)
+        ids = torch.randint(0, cfg.vocab_size, (bs, ), device=DEV, generator=torch.Generator(device=DEV).manual_seed(5))
+        caches = M.make_kv_caches(cfg, nblocks, block, torch.float16, "auto", DEV, seed=3)
+        caches0 = [c.cpu().numpy().copy() for c in caches]
+        m.use_fused_decode = True
+        assert all(l.fused_decode_ok(bs) for l in m.layers)
+        got = m(ids, pos, caches, meta).float().cpu().numpy()
+
+        # ---- the same step from oracle functions ---------------------------------------------------------------
+        hkv, hd, hq = cfg.num_key_value_heads, cfg.head_dim, cfg.num_attention_heads
+        positions = pos.cpu().numpy()
+        slots = meta.slot_mapping.cpu().numpy()
+        bt = meta.block_tables.cpu().numpy()
+        cos_sin = m.cos_sin.cpu().numpy()
+        hidden = f16(m.embed_tokens[ids].cpu().numpy())
+        residual = None
+        for li, layer in enumerate(m.layers):
+            ln1 = layer.input_layernorm.cpu().numpy()
+            ln2 = layer.post_attention_layernorm.cpu().numpy()
+            if residual is None:
+                residual = hidden
+                x = f16(oa.rms_norm(hidden, ln1, cfg.rms_norm_eps))
+            else:
+                x, r = oa.fused_add_rms_norm(hidden, residual, ln1, cfg.rms_norm_eps)
+                residual = f16(r)
+                x = f16(oa.rms_norm(residual, ln1, cfg.rms_norm_eps))
+            qw, qz, sc = _lin_np(layer.qkv_proj)
+            qkv = f16(oq.gptq_gemm(x, qw, qz, sc, None, True))
+            q, k, v = qkv[:, :hq * hd], qkv[:, hq * hd:(hq + hkv) * hd], qkv[:, (hq + hkv) * hd:]
+            q, k = oa.rotary_embedding_neox(positions, q, k, hd, cos_sin)
+            q, k = f16(q), f16(k)
+            kc_shape, vc_shape = oa.split_kv_cache_shapes(nblocks, hkv, hd, block, 2)
+            kc = caches0[li][0].reshape(kc_shape)
+            vc = caches0[li][1].reshape(vc_shape)
+            oa.reshape_and_cache(k.reshape(bs, hkv, hd), v.reshape(bs, hkv, hd), kc, vc, slots)
+            attn = f16(oa.paged_attention_decode(q.reshape(bs, hq, hd), kc, vc, bt, lens, hd ** -0.5)).reshape(bs, hq * hd)
+            # the device wrote the same K / V bits into the same slots
+            dev_cache = caches[li].cpu().numpy()
+            # (rotary differences cancel: the error is a few fp16 ulps of the INPUT magnitude, not of the result)
+            kmax = float(np.abs(k.astype(np.float32)).max())
+            np.testing.assert_allclose(dev_cache[0].reshape(kc_shape).astype(np.float32), kc.astype(np.float32), atol=4e-3 * kmax, rtol=2e-3)
+            np.testing.assert_allclose(dev_cache[1].reshape(vc_shape).astype(np.float32), vc.astype(np.float32), atol=4e-3 * kmax, rtol=2e-3)
+            qw, qz, sc = _lin_np(layer.o_proj)
+            o = f16(oq.gptq_gemm(attn, qw, qz, sc, None, True))
+            x2, r = oa.fused_add_rms_norm(o, residual, ln2, cfg.rms_norm_eps)
+            residual = f16(r)
+            x2 = f16(oa.rms_norm(residual, ln2, cfg.rms_norm_eps))
+            qw, qz, sc = _lin_np(layer.gate_up_proj)
+            gu = f16(oq.gptq_gemm(x2, qw, qz, sc, None, True))
+            act = f16(oa.silu_and_mul(gu))
+            qw, qz, sc = _lin_np(layer.down_proj)
+            hidden = f16(oq.gptq_gemm(act, qw, qz, sc, None, True))
+        _, r = oa.fused_add_rms_norm(hidden, residual, m.norm.cpu().numpy(), cfg.rms_norm_eps)
+        want = oa.rms_norm(f16(r), m.norm.cpu().numpy(), cfg.rms_norm_eps)
+    np.testing.assert_allclose(got, want, atol=2e-2, rtol=2e-2)
+    assert np.abs(got - want).mean() / np.abs(want).mean() < 4e-3

@@ -5,6 +5,7 @@ gloo with world_size 2."""
 import os
 import re
 
+import numpy as np
 import pytest
 import torch
 import torch.multiprocessing as mp
@@ -200,7 +201,8 @@ def test_torch_library_registration():
     for name in ("paged_attention_v1", "paged_attention_v2", "gptq_gemm", "gptq_shuffle", "awq_gemm",
                  "awq_dequantize", "static_scaled_fp8_quant", "dynamic_scaled_fp8_quant",
                  "dynamic_per_token_scaled_fp8_quant", "cutlass_scaled_mm", "rms_norm",
-                 "fused_add_rms_norm", "silu_and_mul", "rotary_embedding"):
+                 "fused_add_rms_norm", "silu_and_mul", "rotary_embedding", "gptq_marlin_gemm", "gptq_marlin_repack",
+                 "awq_marlin_repack", "fp8_marlin_gemm"):
         assert hasattr(torch.ops._aphro_t_C, name), name
     assert hasattr(torch.ops._aphro_t_cache, "reshape_and_cache")
     assert hasattr(torch.ops._aphro_t_rocm, "paged_attention")
@@ -251,3 +253,59 @@ def test_quant_configs_dispatch_on_layer_family():
     attn.v_scale.data.fill_(0.03)
     m.process_weights_after_loading(attn)
     assert (attn._k_scale, attn._v_scale) == (pytest.approx(0.02), pytest.approx(0.03)) and not hasattr(attn, "k_scale")
+
+
+# ---- AttentionState / AttentionMetadataBuilder (a13): pinned by the reference's own CommonMetadataBuilder /
+# CommonAttentionState run on the same scenarios (tests/golden/make_golden_attn_builder.py) ---------------------------
+def _attn_golden():
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(__file__), "golden", "attn_builder.json")) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("name", ["decode_eager", "decode_graph_pad", "prefill_only", "chunked_mixed",
+                                  "prefix_cache_hit", "sliding_window", "profile_run"])
+def test_attention_metadata_builder_matches_reference(name):
+    import attn_builder_cases as cases
+    from aphrodite_engine_amd.attention.backend import MI355XAttentionBackend
+    sc = cases.scenarios()[name]
+    ib = cases.make_input_builder(sc)
+    builder = MI355XAttentionBackend.make_metadata_builder(ib)
+    assert isinstance(builder, MI355XAttentionBackend.get_builder_cls())
+    meta = builder.build(sc["seq_lens"], sc["query_lens"], sc["pad"], sc["batch"])
+    assert cases.to_plain(meta) == _attn_golden()[name]
+    # dtypes of the tensors the kernels read (utils.py:229-247)
+    assert meta.slot_mapping.dtype == torch.long and meta.seq_lens_tensor.dtype == torch.int32
+    assert meta.block_tables.dtype == torch.int32 and meta.query_start_loc.dtype == torch.int32
+    # host-side context knowledge for the sync-free prefill dispatch
+    prefill_ctx = [c for g in sc["groups"] if g.is_prompt for c in g.context_lens]
+    assert meta.max_context_len == max(prefill_ctx, default=0)
+
+
+def test_attention_state_matches_reference():
+    import attn_builder_cases as cases
+    from types import SimpleNamespace
+    from aphrodite_engine_amd.attention.backend import MI355XAttentionBackend
+    runner = SimpleNamespace(device="cpu", graph_block_tables=np.arange(48, dtype=np.int32).reshape(8, 6),
+                             max_seq_len_to_capture=96, attn_backend=MI355XAttentionBackend)
+    st = MI355XAttentionBackend.get_state_cls()(runner)
+    golden = _attn_golden()
+    with st.graph_capture(8):
+        clone = st.graph_clone(4)
+        assert type(clone) is type(st) and clone.runner is runner
+        m = st.graph_capture_get_metadata_for_batch(4)
+        assert cases.to_plain(m) == golden["state_capture_batch4"]
+        bufs = st.get_graph_input_buffers(m)
+        assert sorted(bufs) == golden["state_buffer_keys"]
+        # the buffers ARE the persistent capture tensors: refreshing them is what a replay reads
+        assert bufs["seq_lens_tensor"].data_ptr() == m.seq_lens_tensor.data_ptr()
+        live = MI355XAttentionBackend.make_metadata(
+            num_prefills=0, num_prefill_tokens=0, num_decode_tokens=4, slot_mapping=torch.tensor([5, 6, 7, -1]),
+            seq_lens=None, seq_lens_tensor=torch.tensor([9, 17, 33, 1], dtype=torch.int32), max_query_len=None,
+            max_prefill_seq_len=0, max_decode_seq_len=33, query_start_loc=None, seq_start_loc=None,
+            context_lens_tensor=None, block_tables=torch.ones(4, 6, dtype=torch.int32), use_cuda_graph=True)
+        st.prepare_graph_input_buffers(bufs, live)
+        assert m.seq_lens_tensor.tolist() == [9, 17, 33, 1] and int(m.block_tables.sum()) == 24
+    assert not st._is_graph_capturing and not hasattr(st, "_graph_seq_lens")
+    st.begin_forward(None)

@@ -78,8 +78,6 @@ def test_gptq_shuffle_bit_exact(ops, K, N, act_order):
                                    (2048, 16, 64), (4096, 512, 128)])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_gptq_gemm_exllama(ops, M, K, N, G, dtype):
-    if dtype == torch.bfloat16 and (M not in (1, 32) or K > 1024):
-        pytest.skip("bf16 covered on a subset")
     rng = np.random.default_rng(M * 131 + K + N)
     qweight, qzeros, s, _ = make_gptq(rng, K, N, G)
     a = rng.standard_normal((M, K)).astype(np.float32)
@@ -416,8 +414,6 @@ def test_reshape_and_cache_flash(ops, kv_cache_dtype, dtype):
 def test_context_attention_fwd(ops, kv_cache_dtype, dtype, Hq, Hkv, D, variant):
     """Prefill with cached context vs the oracle (tests/kernels/test_prefix_prefill.py recipe:
     ragged query / context lengths, shuffled block table, GQA)."""
-    if variant != "plain" and (kv_cache_dtype == "fp8_e5m2" or D == 96):
-        pytest.skip("variants covered on a subset")
     rng = np.random.default_rng(Hq * 7 + D)
     BS = 16
     ctx_lens = np.array([0, 37, 128, 5, 300], np.int32)
@@ -611,10 +607,6 @@ ATT_CASES = [
 @pytest.mark.parametrize("use_alibi", [False, True])
 def test_paged_attention(ops, case, version, kv_cache_dtype, dtype, use_alibi):
     num_seqs, Hq, Hkv, D, BS, max_len = case
-    if use_alibi and (dtype == torch.bfloat16 or kv_cache_dtype != "auto"):
-        pytest.skip("alibi covered with fp16/auto")
-    if dtype == torch.bfloat16 and case not in ATT_CASES[:3]:
-        pytest.skip("bf16 covered on a subset")
     rng = np.random.default_rng(hash((case, version)) % 2 ** 31)
     seq_lens = rng.integers(1, max_len + 1, size=num_seqs).astype(np.int32)
     seq_lens[-1] = max_len
@@ -714,8 +706,6 @@ def test_flash_attn_varlen(ops, dtype, Hq, Hkv, D, causal):
 def test_flash_attn_varlen_long(ops, dtype, Hq, Hkv, D, causal, alibi):
     """Sequences >= 512 tokens take the 128-row / 64-key-tile kernels (transposing LDS reads for
     hd 64 / 128): ragged lengths around the tile boundaries, GQA, ALiBi."""
-    if dtype == torch.bfloat16 and (alibi or not causal):
-        pytest.skip("bf16 covered on the causal case")
     rng = np.random.default_rng(Hq * 3 + D)
     lens = [700, 1, 513, 64, 1025, 127]
     cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
@@ -1299,8 +1289,6 @@ def test_fused_wna16_moe(ops, dtype, T, E, topk, H, I):
     (tests/kernels/test_moe.py torch_moe, mixtral_quant.py:130-156) on the dequantised weights."""
     from oracle import moe as om
     from aphrodite_engine_amd import moe as M
-    if dtype == torch.bfloat16 and T != 7:
-        pytest.skip("bf16 covered on a subset")
     rng = np.random.default_rng(T + E + H)
     w13_sets, w2_sets, w13_f, w2_f = [], [], [], []
     for _ in range(E):

@@ -1,0 +1,221 @@
+"""The drop-in boundary AS THE REFERENCE SEES IT: torch.library ops with the reference's schemas
+(kernels/torch_bindings.cpp, kernels/rocm/torch_bindings.cpp -- SURVEY.md 8b "the contract is the schema"), dispatched
+with device tensors, eagerly and under HIP-graph capture + replay (decode runs captured: worker/model_runner.py:1360-1507),
+against the oracle.  Registered under private namespaces so that a real ``aphrodite._C`` could be loaded beside them."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import attention as oa
+from oracle import fp8 as of8
+from oracle import quant as oq
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def T():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a visible MI355X (torch.cuda.is_available() is False)")
+    from aphrodite_engine_amd import _lib, torch_ops
+    _lib.lib()
+    torch_ops._REGISTERED = False
+    torch_ops.register("_aphro_g_C", "_aphro_g_cache", "_aphro_g_rocm", "_aphro_g_moe")
+
+    class NS:
+        C = torch.ops._aphro_g_C
+        cache = torch.ops._aphro_g_cache
+        rocm = torch.ops._aphro_g_rocm
+    return NS
+
+
+def t(x, dtype=None):
+    out = torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
+    return out.to(dtype) if dtype is not None else out
+
+
+def captured(fn):
+    """Run fn() once eagerly (warm-up on a side stream, as torch requires), capture it into a HIP graph, replay it
+    and return (graph, result of the captured call)."""
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        fn()
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = fn()
+    g.replay()
+    torch.cuda.synchronize()
+    return g, out
+
+
+def make_gptq(rng, K, N, G):
+    w = (rng.standard_normal((K, N)) * 0.02).astype(np.float16)
+    _, q, s, zp = oq.quantize_weights(w, 4, G, zero_points=True)
+    return oq.gptq_pack(q), oq.gptq_pack_zeros(zp), s.astype(np.float16)
+
+
+def test_schema_gptq_gemm_and_shuffle(T):
+    rng = np.random.default_rng(0)
+    K, N, G, M = 1024, 256, 128, 32
+    qweight, qzeros, scales = make_gptq(rng, K, N, G)
+    qw = t(qweight)
+    T.C.gptq_shuffle(qw, torch.empty(0, dtype=torch.int32, device=DEV), 4)            # Tensor! q_weight, in place
+    np.testing.assert_array_equal(qw.cpu().numpy(), oq.gptq_shuffle(qweight))
+    a = t(rng.standard_normal((M, K)).astype(np.float16))
+    empty = torch.empty(0, dtype=torch.int32, device=DEV)
+    args = (a, qw, t(qzeros), t(scales), empty, True, 4)
+    ref = oq.gptq_gemm(a.cpu().numpy(), qw.cpu().numpy(), qzeros, scales, None, True)
+    eager = T.C.gptq_gemm(*args)
+    np.testing.assert_allclose(eager.float().cpu().numpy(), ref, rtol=2e-3, atol=2e-3 * np.abs(ref).max())
+    g, out = captured(lambda: T.C.gptq_gemm(*args))
+    assert torch.equal(out, eager)
+    # replay reads the CURRENT contents of the captured input buffer
+    a2 = rng.standard_normal((M, K)).astype(np.float16)
+    a.copy_(t(a2))
+    g.replay()
+    torch.cuda.synchronize()
+    ref2 = oq.gptq_gemm(a2, qw.cpu().numpy(), qzeros, scales, None, True)
+    np.testing.assert_allclose(out.float().cpu().numpy(), ref2, rtol=2e-3, atol=2e-3 * np.abs(ref2).max())
+
+
+def test_schema_awq_gemm_and_dequantize(T):
+    rng = np.random.default_rng(1)
+    K, N, G, M = 512, 128, 128, 16
+    w = (rng.standard_normal((K, N)) * 0.02).astype(np.float16)
+    _, q, s, zp = oq.quantize_weights(w, 4, G, zero_points=True)
+    qw, qz = oq.awq_pack(q), oq.awq_pack(zp)
+    a = rng.standard_normal((M, K)).astype(np.float16)
+    # positional order of the C++ schema: (_in_feats, _kernel, _scaling_factors, _zeros, split_k_iters)
+    args = (t(a), t(qw), t(s), t(qz), 8)
+    ref = oq.awq_gemm(a, qw, s, qz)
+    _, out = captured(lambda: T.C.awq_gemm(*args))
+    np.testing.assert_allclose(out.float().cpu().numpy(), ref, rtol=2e-3, atol=2e-3 * np.abs(ref).max())
+    deq = T.C.awq_dequantize(t(qw), t(s), t(qz), 0, 0, 0)
+    np.testing.assert_array_equal(deq.cpu().numpy(), oq.awq_dequantize(qw, s, qz))
+
+
+@pytest.mark.parametrize("kv_cache_dtype", ["auto", "fp8"])
+def test_schema_paged_attention_and_cache_write(T, kv_cache_dtype):
+    rng = np.random.default_rng(2)
+    S, Hq, Hkv, D, BS = 4, 8, 2, 128, 16
+    dtype = torch.float16
+    seq_lens = np.array([1, 40, 513, 700], np.int32)
+    max_len = int(seq_lens.max())
+    bps = (max_len + BS - 1) // BS
+    NB = S * bps + 2
+    x = 8 if kv_cache_dtype == "auto" else 16
+    cdt = dtype if kv_cache_dtype == "auto" else torch.uint8
+    kc = torch.zeros((NB, Hkv, D // x, BS, x), dtype=cdt, device=DEV)
+    vc = torch.zeros((NB, Hkv, D, BS), dtype=cdt, device=DEV)
+    kc_ref, vc_ref = kc.cpu().numpy().copy(), vc.cpu().numpy().copy()
+    bt = rng.permutation(NB)[:S * bps].reshape(S, bps).astype(np.int32)
+    ks, vs = (1.0, 1.0) if kv_cache_dtype == "auto" else (0.5, 2.0)
+    # fill the caches through the schema-level cache write, token by token batch (slots of every position)
+    for pos in range(max_len):
+        live = [i for i in range(S) if pos < seq_lens[i]]
+        if pos % 97 and pos > 3 and pos < max_len - 2:      # keep the oracle loop short: write most positions in bulk below
+            continue
+        k = (rng.standard_normal((len(live), Hkv, D)) * 0.3).astype(np.float16)
+        v = (rng.standard_normal((len(live), Hkv, D)) * 0.3).astype(np.float16)
+        slots = np.array([bt[i, pos // BS] * BS + pos % BS for i in live], np.int64)
+        T.cache.reshape_and_cache(t(k), t(v), kc, vc, t(slots), kv_cache_dtype, ks, vs)
+        oa.reshape_and_cache(k, v, kc_ref, vc_ref, slots, kv_cache_dtype, ks, vs)
+    np.testing.assert_array_equal(kc.cpu().numpy().view(np.uint8), kc_ref.view(np.uint8))
+    np.testing.assert_array_equal(vc.cpu().numpy().view(np.uint8), vc_ref.view(np.uint8))
+    q = t(rng.standard_normal((S, Hq, D)).astype(np.float32), dtype)
+    scale = float(D ** -0.5)
+    ref = oa.paged_attention_decode(q.float().cpu().numpy(), kc_ref if kv_cache_dtype != "auto" else kc_ref.astype(np.float32),
+                                    vc_ref if kv_cache_dtype != "auto" else vc_ref.astype(np.float32), bt, seq_lens, scale,
+                                    None, kv_cache_dtype, ks, vs)
+    atol = 1e-3 if kv_cache_dtype == "auto" else 1e-2
+    common = (q, kc, vc, Hkv, scale, t(bt), t(seq_lens), BS, max_len, None, kv_cache_dtype, ks, vs)
+    out1 = torch.empty(S, Hq, D, dtype=dtype, device=DEV)
+    captured(lambda: T.C.paged_attention_v1(out1, *common, 0, 0, 0, 64, 0))
+    np.testing.assert_allclose(out1.float().cpu().numpy(), ref, atol=atol, rtol=1e-2)
+    P = (max_len + 511) // 512
+    es = torch.empty(S, Hq, P, device=DEV)
+    ml = torch.empty(S, Hq, P, device=DEV)
+    tmp = torch.empty(S, Hq, P, D, dtype=dtype, device=DEV)
+    out2 = torch.empty_like(out1)
+    captured(lambda: T.C.paged_attention_v2(out2, es, ml, tmp, *common, 0, 0, 0, 64, 0))
+    np.testing.assert_allclose(out2.float().cpu().numpy(), ref, atol=atol, rtol=1e-2)
+    out3 = torch.empty_like(out1)
+    captured(lambda: T.rocm.paged_attention(out3, es, ml, tmp, *common))
+    np.testing.assert_allclose(out3.float().cpu().numpy(), ref, atol=atol, rtol=1e-2)
+
+
+def test_schema_fp8_quant_ops_write_in_place(T):
+    rng = np.random.default_rng(3)
+    M, K = 33, 1024
+    x = t(((rng.random((M, K)) - 0.5) * 60).astype(np.float32), torch.bfloat16)
+    xr = x.float().cpu().numpy()
+    # static
+    out = torch.empty(M, K, dtype=torch.float8_e4m3fn, device=DEV)
+    ptr = out.data_ptr()
+    sc = torch.tensor([0.37], device=DEV)
+    captured(lambda: T.C.static_scaled_fp8_quant(out, x, sc))
+    assert out.data_ptr() == ptr
+    np.testing.assert_array_equal(out.view(torch.uint8).cpu().numpy(), of8.static_scaled_fp8_quant(xr, np.float32(0.37)))
+    # dynamic per tensor (Tensor! scale)
+    out.zero_()
+    scale = torch.zeros(1, device=DEV)
+    captured(lambda: T.C.dynamic_scaled_fp8_quant(out, x, scale))
+    rq, rs = of8.dynamic_scaled_fp8_quant(xr)
+    np.testing.assert_array_equal(scale.cpu().numpy(), rs)
+    np.testing.assert_array_equal(out.view(torch.uint8).cpu().numpy(), rq)
+    # dynamic per token, out padded to max(M, 17) rows like the reference allocates it (_custom_ops.py:661-664)
+    outp = torch.zeros(M + 4, K, dtype=torch.float8_e4m3fn, device=DEV)
+    scales = torch.zeros(M + 4, 1, device=DEV)
+    captured(lambda: T.C.dynamic_per_token_scaled_fp8_quant(outp, x, scales, None))
+    rq, rs = of8.dynamic_per_token_scaled_fp8_quant(xr)
+    np.testing.assert_array_equal(outp.view(torch.uint8).cpu().numpy()[:M], rq)
+    np.testing.assert_array_equal(scales.cpu().numpy()[:M], rs)
+    assert (outp.view(torch.uint8)[M:] == 0).all()
+    # MI300's fnuz encoding is refused, not silently mis-scaled by 2x
+    if hasattr(torch, "float8_e4m3fnuz"):
+        bad = torch.empty(M, K, dtype=torch.float8_e4m3fnuz, device=DEV)
+        with pytest.raises(RuntimeError, match="fnuz"):
+            T.C.static_scaled_fp8_quant(bad, x, sc)
+
+
+@pytest.mark.parametrize("M", [8, 200])
+def test_schema_cutlass_scaled_mm(T, M):
+    rng = np.random.default_rng(4 + M)
+    K, N = 1024, 256
+    a = t((rng.standard_normal((M, K)) * 2).astype(np.float32)).to(torch.float8_e4m3fn)
+    w = t((rng.standard_normal((N, K)) * 2).astype(np.float32)).to(torch.float8_e4m3fn)
+    sa = t((rng.random((M, 1)) * 0.02 + 0.002).astype(np.float32))
+    sb = t((rng.random((N, 1)) * 0.02 + 0.002).astype(np.float32))
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    ptr = out.data_ptr()
+    if M <= 64:
+        captured(lambda: T.C.cutlass_scaled_mm(out, a, w.t(), sa, sb, None))
+    else:
+        T.C.cutlass_scaled_mm(out, a, w.t(), sa, sb, None)
+    assert out.data_ptr() == ptr
+    ref = of8.scaled_mm(a.view(torch.uint8).cpu().numpy(), w.view(torch.uint8).cpu().numpy().T, sa.cpu().numpy(),
+                        sb.cpu().numpy().reshape(-1), None)
+    np.testing.assert_allclose(out.float().cpu().numpy(), ref, rtol=1.6e-2, atol=1.6e-2 * np.abs(ref).max())
+    assert T.C.cutlass_scaled_mm_supports_fp8(95) is True
+
+
+def test_schema_gptq_marlin_gemm(T):
+    """_C::gptq_marlin_gemm (torch_bindings.cpp:195-201).  Standalone the ScalarType argument travels as its size in
+    bits (torch_ops.GPTQ_MARLIN_GEMM_SCHEMAS); symmetric uint4b8 weights, no per-call allocation under capture."""
+    rng = np.random.default_rng(5)
+    K, N, G, M = 1024, 256, 128, 16
+    w = (rng.standard_normal((K, N)) * 0.02).astype(np.float16)
+    w_ref, q, s, _ = oq.quantize_weights(w, 4, G)                       # symmetric: stored q in [0, 15], zero point 8
+    qw = T.C.gptq_marlin_repack(t(oq.gptq_pack(q)), torch.empty(0, dtype=torch.int32, device=DEV), K, N, 4)
+    a = rng.standard_normal((M, K)).astype(np.float16)
+    empty = torch.empty(0, dtype=torch.int32, device=DEV)
+    ws = torch.zeros(N // 64 * 16, dtype=torch.int32, device=DEV)
+    args = (t(a), qw, t(s.astype(np.float16)), empty, empty, empty, ws, 4, M, N, K, True, False, True, False)
+    _, out = captured(lambda: T.C.gptq_marlin_gemm(*args))
+    ref = a.astype(np.float64) @ w_ref.astype(np.float64)
+    got = out.float().cpu().numpy()
+    assert np.abs(got - ref).mean() / np.abs(ref).mean() < 0.04            # tests/kernels/test_marlin_gemm.py:57-59
+    np.testing.assert_allclose(got, ref, rtol=2e-3, atol=2e-3 * np.abs(ref).max())
