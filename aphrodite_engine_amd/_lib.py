@@ -73,6 +73,7 @@ SIGNATURES = {
     "aphro_reshape_and_cache_flash": (I, [P, P, P, P, P, L, I, I, I, L, L, L, I, I, F, F, P]),
     "aphro_copy_blocks": (I, [P, P, I, P, L, L, P]),
     "aphro_swap_blocks": (I, [P, P, P, L, L, I, P]),
+    "aphro_prefetch": (I, [P, Z, P]),
     "aphro_convert_fp8": (I, [P, P, L, F, I, I, I, P]),
     "aphro_paged_attention": (I, [P, P, P, P, P, P, P, I, I, I, I, F, P, P, I, I, I, P,
                                   L, L, L, I, I, F, F, I, P]),

@@ -124,3 +124,28 @@ extern "C" int aphro_reshape_and_cache_flash(const void* key, const void* value,
   APHRO_LAUNCH_CHECK();
   return APHRO_OK;
 }
+
+
+// ---- weight prefetch (tensor-parallel overlap) -------------------------------------------------------------------
+// While a row-parallel projection's all-reduce crosses the xGMI links (latency bound, no HBM traffic) the compute
+// stream pulls the NEXT projection's packed weights through the memory-side Infinity Cache (256 MiB), so that the
+// GEMM that follows the all-reduce finds them on die.  Plain 16-byte loads, nothing is written.
+namespace aphro {
+__global__ __launch_bounds__(256) void prefetch_kernel(const u32x4* __restrict__ p, size_t n16, uint32_t* __restrict__ sink) {
+  u32x4 acc = {0, 0, 0, 0};
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) acc ^= p[i];
+  if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x9e3779b9u && sink != nullptr) *sink = 1;   // keeps the loads alive
+}
+}  // namespace aphro
+
+extern "C" int aphro_prefetch(const void* ptr, size_t bytes, void* stream) {
+  APHRO_CHECK(((uintptr_t)ptr % 16) == 0, "prefetch: pointer must be 16-byte aligned");
+  const size_t n16 = bytes / 16;
+  if (n16 == 0) return APHRO_OK;
+  unsigned blocks = (unsigned)((n16 + 256 * 8 - 1) / (256 * 8));
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(aphro::prefetch_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const u32x4*)ptr, n16,
+                     (uint32_t*)nullptr);
+  APHRO_LAUNCH_CHECK();
+  return APHRO_OK;
+}

@@ -17,6 +17,7 @@ _TP_GROUP: Optional[dist.ProcessGroup] = None
 _TP_RANK = 0
 _TP_SIZE = 1
 _CUSTOM_AR = None      # CustomAllreduce of the TP group (enable_custom_all_reduce)
+_OVERLAP = None        # AllReduceOverlap (enable_all_reduce_overlap): all-reduce on a side stream + weight prefetch
 
 
 def init_tensor_parallel(tp_size: int, backend: Optional[str] = None) -> None:
@@ -40,10 +41,10 @@ def init_tensor_parallel(tp_size: int, backend: Optional[str] = None) -> None:
 
 
 def destroy_tensor_parallel() -> None:
-    global _TP_GROUP, _TP_RANK, _TP_SIZE, _CUSTOM_AR
+    global _TP_GROUP, _TP_RANK, _TP_SIZE, _CUSTOM_AR, _OVERLAP
     if _CUSTOM_AR is not None:
         _CUSTOM_AR.close()
-    _TP_GROUP, _TP_RANK, _TP_SIZE, _CUSTOM_AR = None, 0, 1, None
+    _TP_GROUP, _TP_RANK, _TP_SIZE, _CUSTOM_AR, _OVERLAP = None, 0, 1, None, None
 
 
 def enable_custom_all_reduce(device, cpu_group: Optional[dist.ProcessGroup] = None, max_size: int = 8192 * 1024):
@@ -70,6 +71,22 @@ def get_custom_all_reduce():
     return _CUSTOM_AR
 
 
+def enable_all_reduce_overlap(device, enabled: bool = True):
+    """Run the TP all-reduces on a side stream, overlapped with a prefetch of the next projection's weights
+    (distributed/overlap.py).  Graph-capturable; results are bit-identical to the serial path."""
+    global _OVERLAP
+    if not enabled or _TP_SIZE == 1:
+        _OVERLAP = None
+        return None
+    from .overlap import AllReduceOverlap
+    _OVERLAP = AllReduceOverlap(torch.device(device))
+    return _OVERLAP
+
+
+def get_all_reduce_overlap():
+    return _OVERLAP
+
+
 @contextlib.contextmanager
 def simulated_tensor_parallel(rank: int, size: int):
     """Pretend to be TP rank ``rank`` of ``size`` with no process group: for building one rank's
@@ -91,10 +108,7 @@ def get_tensor_model_parallel_rank() -> int:
     return _TP_RANK
 
 
-def tensor_model_parallel_all_reduce(input_: torch.Tensor) -> torch.Tensor:
-    """Sum over the TP group, in place (communication_op.py:9-12)."""
-    if _TP_SIZE == 1:
-        return input_
+def _all_reduce_serial(input_: torch.Tensor) -> torch.Tensor:
     # GroupCoordinator.all_reduce (parallel_state.py:321-379): the peer-access kernel when eligible
     # (out of place), else RCCL in place
     if _CUSTOM_AR is not None and input_.is_cuda:
@@ -103,6 +117,17 @@ def tensor_model_parallel_all_reduce(input_: torch.Tensor) -> torch.Tensor:
             return out
     dist.all_reduce(input_, group=_TP_GROUP)
     return input_
+
+
+def tensor_model_parallel_all_reduce(input_: torch.Tensor, prefetch=None) -> torch.Tensor:
+    """Sum over the TP group (communication_op.py:9-12).  ``prefetch``: tensors (the next projection's packed
+    weights) to stream through the Infinity Cache while the all-reduce is in flight -- used only when
+    enable_all_reduce_overlap() is on; otherwise ignored and the all-reduce runs on the current stream."""
+    if _TP_SIZE == 1:
+        return input_
+    if _OVERLAP is not None and input_.is_cuda:
+        return _OVERLAP.all_reduce(_all_reduce_serial, input_, prefetch)
+    return _all_reduce_serial(input_)
 
 
 def tensor_model_parallel_all_gather(input_: torch.Tensor, dim: int = -1) -> torch.Tensor:

@@ -9,10 +9,17 @@ Differences that are MI355X decisions, not omissions:
     device memory (a torch tensor cannot be); IPC handles are taken with hipIpcGetMemHandle through
     the C ABI, not through ``storage._share_cuda_()``;
   * every node pair of an MI355X box is one xGMI hop, so the reference's NVLink-topology probe
-    (``is_full_nvlink``) reduces to "same node" -- PCIe-only peers would still work through IPC;
+    (``is_full_nvlink``) reduces to "same node + peer access": the constructor all-gathers (hostname, boot id,
+    physical device) over the CPU group and asks the runtime ``can_device_access_peer`` for every pair; if any
+    rank is on another node or a pair lacks peer access the communicator stays ``disabled`` and the caller falls
+    back to RCCL, exactly as the reference does (custom_all_reduce.py:73-77, 133-146);
   * a peer that never arrives raises ``RuntimeError`` from ``check()`` (bounded spin in the
-    kernel) instead of hanging the GPU."""
+    kernel) instead of hanging the GPU; eager calls poll the error word every
+    ``APHRODITE_CUSTOM_AR_CHECK_EVERY`` calls (default 256; the poll is a blocking 4-byte read), graph
+    replays are checked by whoever replays (bench.py, the tests)."""
 import ctypes
+import os
+import socket
 from contextlib import contextmanager
 from typing import List, Optional, Tuple, Union
 
@@ -52,7 +59,15 @@ class CustomAllreduce:
             device = torch.device(device)
         self.device = device
         self.rank, self.world_size, self.max_size = rank, world_size, max_size
-        self.full_nvlink = True            # one xGMI hop between any two GPUs of the node
+        self._calls = 0
+        self._check_every = int(os.environ.get("APHRODITE_CUSTOM_AR_CHECK_EVERY", "256"))
+        ok, why = self._peers_eligible(device)
+        self.full_nvlink = ok              # one xGMI hop between any two GPUs of the node
+        if not ok:
+            if rank == 0:
+                import warnings
+                warnings.warn(f"custom all-reduce is disabled ({why}); tensor parallelism falls back to RCCL")
+            return
         lib = _lib.lib()
         self._hb = lib.aphro_ipc_handle_bytes()
         with torch.cuda.device(device):
@@ -74,6 +89,31 @@ class CustomAllreduce:
             self._ptr = fa
             self.disabled = False
             self.register_buffer(self.buffer)
+
+    # -- eligibility (custom_all_reduce.py:73-77, 112-146; in_the_same_node_as, _can_p2p) ------------
+    def _peers_eligible(self, device: torch.device):
+        try:
+            boot = open("/proc/sys/kernel/random/boot_id").read().strip()
+        except OSError:
+            boot = ""
+        visible = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("CUDA_VISIBLE_DEVICES")
+        ids = [int(v) for v in visible.split(",")] if visible else None
+        phys = ids[device.index] if ids is not None and device.index < len(ids) else device.index
+        mine = (socket.gethostname(), boot, int(phys), int(device.index))
+        everyone: List[Optional[tuple]] = [None] * self.world_size
+        dist.all_gather_object(everyone, mine, group=self.group)
+        if any((e[0], e[1]) != (mine[0], mine[1]) for e in everyone):
+            return False, "the process group spans several nodes"
+        local_ok = True
+        if ids is None:            # peers' local indices are meaningful in this process only without a device mask
+            for e in everyone:
+                if e[3] != device.index and e[3] < torch.cuda.device_count():
+                    local_ok &= bool(torch.cuda.can_device_access_peer(device.index, e[3]))
+        verdicts: List[Optional[bool]] = [None] * self.world_size
+        dist.all_gather_object(verdicts, local_ok, group=self.group)
+        if not all(verdicts):
+            return False, "a GPU pair lacks peer access"
+        return True, ""
 
     # -- IPC plumbing ------------------------------------------------------------------------------
     def _ipc_meta(self, ptr: int) -> Tuple[bytes, int]:
@@ -160,7 +200,11 @@ class CustomAllreduce:
             if torch.cuda.is_current_stream_capturing():
                 return self.all_reduce_reg(input)
             return torch.empty_like(input)          # warm-up run before the capture: shape only
-        return self.all_reduce_unreg(input)
+        out = self.all_reduce_unreg(input)
+        self._calls += 1
+        if self._check_every > 0 and self._calls % self._check_every == 0:
+            self.check()                            # a timed-out barrier must not return garbage silently for long
+        return out
 
     def check(self) -> None:
         """Raise if one of this rank's barriers timed out since the last call."""

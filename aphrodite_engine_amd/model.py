@@ -230,7 +230,7 @@ class LlamaDecoderLayer(nn.Module):
         return self.experts(normed, router_logits)
 
     def forward_decode_fused(self, positions, x, slabs, residual, first, kv_cache, attn_metadata, cos_sin,
-                             cos_sin_tok=None):
+                             cos_sin_tok=None, next_weights=None):
         """x: row-major input (first layer, or the all-reduced down_proj output of the previous
         layer when TP > 1) or None; slabs: fp32 split-K slabs of the previous down_proj (TP == 1).
         Returns (x, slabs) of this layer's down_proj in the same convention."""
@@ -278,7 +278,10 @@ class LlamaDecoderLayer(nn.Module):
             return self.moe_block(normed), None
         if self.tp > 1:   # row-parallel: local reduce, all-reduce over the TP group, then the norm
             o = ops.wna16_gemm_packed(attn_packed, m, self.q_size, qw, qz, sc, zo, partials=False)
-            o = tensor_model_parallel_all_reduce(o)
+            # (with enable_all_reduce_overlap: the all-reduce runs on a side stream while this stream pulls the
+            #  gate_up weights through the Infinity Cache -- distributed/overlap.py)
+            gu = self.gate_up_interleaved if self.gate_up_interleaved is not None else self.gate_up_proj.fast_params()
+            o = tensor_model_parallel_all_reduce(o, prefetch=gu[:3])
             packed2, _ = ops.fused_add_rms_norm_pack(o, None, residual, True,
                                                      self.post_attention_layernorm, eps)
         else:
@@ -296,7 +299,7 @@ class LlamaDecoderLayer(nn.Module):
         qw, qz, sc, zo = self.down_proj.fast_params()
         if self.tp > 1:
             d = ops.wna16_gemm_packed(act_packed, m, self.down_proj.in_features, qw, qz, sc, zo, partials=False)
-            return tensor_model_parallel_all_reduce(d), None
+            return tensor_model_parallel_all_reduce(d, prefetch=next_weights), None
         down_slabs, _ = ops.wna16_gemm_packed(act_packed, m, self.down_proj.in_features, qw, qz, sc, zo,
                                               partials=True)
         return None, down_slabs
@@ -488,9 +491,15 @@ class LlamaForCausalLM(nn.Module):
             x, slabs = hidden, None
             # rotary table rows of this step's positions, gathered once for all layers
             cos_sin_tok = self.cos_sin.index_select(0, positions)
+            tp = get_tensor_model_parallel_world_size()
             for i, layer in enumerate(self.layers):
+                # TP: the down_proj all-reduce of this layer overlaps with a prefetch of the NEXT layer's qkv weights
+                nxt = None
+                if tp > 1 and i + 1 < len(self.layers):
+                    fp = self.layers[i + 1].qkv_proj.fast_params()
+                    nxt = fp[:3] if fp is not None else None
                 x, slabs = layer.forward_decode_fused(positions, x, slabs, residual, i == 0,
-                                                      kv_caches[i], attn_metadata, self.cos_sin, cos_sin_tok)
+                                                      kv_caches[i], attn_metadata, self.cos_sin, cos_sin_tok, nxt)
             _, out = ops.fused_add_rms_norm_pack(x if slabs is None else None, slabs, residual, True, self.norm,
                                                  self.cfg.rms_norm_eps, pack=False, want_out=True)
             return out

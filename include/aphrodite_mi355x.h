@@ -488,6 +488,13 @@ int aphro_custom_ar_register_graph_buffers(void* fa, const char* handles, const 
  * this instead of hanging the GPU) */
 int aphro_custom_ar_error(void* fa);
 
+/* Overlap helper for tensor parallelism (north_star: "all-reduce overlapped with the quantized GEMMs on HIP
+ * streams"): streams `bytes` at `ptr` through the memory-side Infinity Cache on `stream` while the all-reduce of the
+ * previous row-parallel projection runs on a side stream -- see aphrodite_engine_amd/distributed/overlap.py.  Reads
+ * only; ptr 16-byte aligned.  No reference counterpart (the reference serialises its all-reduce with the GEMMs,
+ * parallel_state.py:321-379). */
+int aphro_prefetch(const void* ptr, size_t bytes, void* stream);
+
 /* ------------------------------------------------------------------------
  * Mixture of experts: routing, dispatch and the grouped W4A16 GEMM
  * ---------------------------------------------------------------------- */

@@ -158,3 +158,73 @@ def test_tp2_decode_with_custom_all_reduce():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     _spawn(_tp_model_worker, 2)
+
+
+def _tp_overlap_worker(rank, world, port):
+    """x1: the TP all-reduces on a side stream, overlapped with a prefetch of the next projection's weights
+    (distributed/overlap.py) -- eager and inside a captured HIP graph -- give the bits of the serial path."""
+    import torch.distributed as dist
+    from aphrodite_engine_amd import distributed as D
+    from aphrodite_engine_amd import model as M
+    from aphrodite_engine_amd.quantization.gptq import GPTQConfig
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    D.init_tensor_parallel(world, backend="gloo")
+    cfg = M.LlamaConfig(hidden_size=1024, intermediate_size=4096, num_hidden_layers=3, num_attention_heads=8,
+                        num_key_value_heads=4, vocab_size=512, max_position_embeddings=1024)
+    try:
+        with torch.no_grad():
+            m = M.LlamaForCausalLM(cfg, GPTQConfig(4, 128, False), torch.float16).init_synthetic(dev)
+            lens = [3, 17, 64, 200, 129, 5, 77, 31]
+            meta, pos, nblocks = M.make_decode_metadata(8, lens, 16, "cuda:0")
+            ids = torch.randint(0, cfg.vocab_size, (8, ), device=dev, generator=torch.Generator(device=dev).manual_seed(1))
+            ca = D.enable_custom_all_reduce(dev)
+            assert ca is not None and not ca.disabled
+
+            def step():
+                caches = M.make_kv_caches(cfg, nblocks, 16, torch.float16, "auto", "cuda:0", seed=3)
+                out = m(ids, pos, caches, meta)
+                torch.cuda.synchronize()
+                ca.check()
+                return out.clone()
+            serial = step()
+            ov = D.enable_all_reduce_overlap(dev)
+            assert ov is not None and D.get_all_reduce_overlap() is ov
+            overlapped = step()
+            assert torch.equal(serial, overlapped)
+            assert ov.stats["all_reduces"] == 2 * cfg.num_hidden_layers            # o_proj + down_proj per layer
+            # gate_up of every layer + qkv of layers 1.. were prefetched under an all-reduce
+            per_layer = sum(t_.numel() * t_.element_size() for t_ in m.layers[0].gate_up_proj.fast_params()[:3])
+            assert ov.stats["prefetched_bytes"] >= cfg.num_hidden_layers * per_layer
+            # the same step captured: fork / join through events inside the graph, buffers registered after capture
+            caches = M.make_kv_caches(cfg, nblocks, 16, torch.float16, "auto", "cuda:0", seed=3)
+            g = torch.cuda.CUDAGraph()
+            with ca.capture():
+                m(ids, pos, caches, meta)                       # warm-up outside the capture
+                s = torch.cuda.Stream()
+                s.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(s), torch.cuda.graph(g, stream=s):
+                    out_g = m(ids, pos, caches, meta)
+            for _ in range(3):
+                caches_fresh = M.make_kv_caches(cfg, nblocks, 16, torch.float16, "auto", "cuda:0", seed=3)
+                for c, f in zip(caches, caches_fresh):
+                    c.copy_(f)
+                torch.cuda.synchronize()
+                dist.barrier()
+                g.replay()
+                torch.cuda.synchronize()
+                ca.check()
+                assert torch.equal(out_g, serial)
+                dist.barrier()
+            D.enable_all_reduce_overlap(dev, enabled=False)
+            assert D.get_all_reduce_overlap() is None
+    finally:
+        D.destroy_tensor_parallel()
+        dist.destroy_process_group()
+
+
+def test_tp2_all_reduce_overlap_is_bit_identical():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    _spawn(_tp_overlap_worker, 2)
