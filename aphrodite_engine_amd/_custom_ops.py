@@ -13,6 +13,7 @@ tensors are allocated here on the input's device.  Every launch goes to
 ``torch.cuda.current_stream()`` and nothing synchronises, so the ops can be
 captured into a HIP graph exactly like the reference's.
 """
+import os
 from typing import List, Optional, Tuple
 
 import torch
@@ -362,9 +363,39 @@ def gptq_dequant(b_q_weight, b_gptq_qzeros, b_gptq_scales, b_g_idx,
     return out
 
 
+# M above which the MFMA-bound prefill kernel (csrc/wna16_gemm_large.hip: dequant in registers, 32x32x16 MFMA,
+# activations through direct-to-LDS loads) takes over from the HBM-bound decode kernel
+WNA16_LARGE_MIN_M = 64
+
+
+def wna16_large_ok(m: int, n: int, k: int, groups: int) -> bool:
+    gs = k // max(groups, 1)
+    return m > WNA16_LARGE_MIN_M and n % 128 == 0 and k % 64 == 0 and groups > 0 and k % groups == 0 and gs % 64 == 0 \
+        and (k // 8) * n * 4 < 2 ** 32 and m * k * 2 < 2 ** 32
+
+
+def _wna16_large(a, qweight, qzeros, scales, perm, zero_offset):
+    m, k = a.shape
+    n = qweight.shape[1]
+    lib = _lib.lib()
+    if perm is not None:
+        a = a[:, perm.long()]                       # act-order: gather once (q_gemm.cu:219-226)
+    if a.stride(1) != 1 or a.stride(0) % 8 != 0 or a.data_ptr() % 16 != 0:
+        a = a.contiguous()
+    out = torch.empty((m, n), dtype=a.dtype, device=a.device)
+    nbytes = lib.aphro_wna16_gemm_large_workspace_bytes(m, n, k, scales.shape[0], _dt(a))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=a.device) if nbytes else None
+    check(lib.aphro_wna16_gemm_large(a.data_ptr(), qweight.data_ptr(), qzeros.data_ptr(), scales.data_ptr(),
+                                     out.data_ptr(), _ptr(ws), nbytes, m, n, k, scales.shape[0], a.stride(0),
+                                     zero_offset, _dt(a), _stream()), "wna16_gemm_large")
+    return out
+
+
 def _wna16(a, qweight, qzeros, scales, perm, zero_offset):
     m, k = a.shape
     n = qweight.shape[1]
+    if wna16_large_ok(m, n, k, scales.shape[0]) and not os.environ.get("APHRO_WNA16_NO_LARGE"):
+        return _wna16_large(a, qweight, qzeros, scales, perm, zero_offset)
     lib = _lib.lib()
     out = torch.empty((m, n), dtype=a.dtype, device=a.device)
     if a.stride(1) != 1:
@@ -398,7 +429,9 @@ def gptq_gemm(a: torch.Tensor, b_q_weight: torch.Tensor,
     if a.dtype != b_gptq_scales.dtype:
         raise RuntimeError("gptq_gemm: activations and scales must share a dtype")
     m = a.shape[0]
-    if not use_exllama or m >= GPTQ_DEQUANT_MIN_M:
+    large = use_exllama and wna16_large_ok(m, b_q_weight.shape[1], a.shape[1], b_gptq_scales.shape[0]) \
+        and not os.environ.get("APHRO_WNA16_NO_LARGE")
+    if not use_exllama or (m >= GPTQ_DEQUANT_MIN_M and not large):
         w = gptq_dequant(b_q_weight, b_gptq_qzeros, b_gptq_scales, b_g_idx,
                          use_exllama, bit)
         if use_exllama and b_g_idx is not None and b_g_idx.numel() > 0:

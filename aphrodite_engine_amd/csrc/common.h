@@ -58,6 +58,15 @@ __device__ __forceinline__ uint16_t f32_to_f16_bits(float f) {
   return __builtin_bit_cast(uint16_t, (f16)f);
 }
 
+// bf16 -> f16 for the int4 kernels' MFMA operands (the reference's GPTQ / AWQ kernels are fp16-only, gptq.py:54-55;
+// we accept bf16 activations by widening them).  SATURATING: a bf16 activation beyond the f16 range (|x| > 65504)
+// becomes +-65504 instead of inf -- an inf would turn into NaN in the MFMA and poison the whole output row, a clamped
+// outlier costs accuracy on that one element only.  (Values below 2^-24 flush to zero: f16 subnormal range.)
+__device__ __forceinline__ uint16_t bf16_bits_to_f16_bits_sat(uint16_t b) {
+  const float f = bf16_bits_to_f32(b);
+  return f32_to_f16_bits(__builtin_fminf(__builtin_fmaxf(f, -65504.f), 65504.f));
+}
+
 // Storage-type traits: T is a tag for the 16-bit (or 32-bit) activation dtype.
 struct Half {
   typedef uint16_t storage;

@@ -37,7 +37,7 @@ __device__ __forceinline__ size_t packed_chunk(int row, int k, int mtiles) {
 template <typename T>
 __device__ __forceinline__ uint16_t to_f16_bits(uint16_t tbits) {
   if constexpr (__is_same(T, Half)) return tbits;
-  else return f32_to_f16_bits(bf16_bits_to_f32(tbits));
+  else return bf16_bits_to_f16_bits_sat(tbits);
 }
 
 // x = input (T) or sum of `nslab` fp32 slabs (rounded to T like the GEMM's own

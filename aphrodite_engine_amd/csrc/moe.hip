@@ -127,7 +127,7 @@ __global__ void moe_gather_pack_kernel(const uint16_t* __restrict__ a, const int
       v = *reinterpret_cast<const u16x8*>(a + (size_t)(slot / topk) * lda + k0);
       if constexpr (!__is_same(T, Half)) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = f32_to_f16_bits(bf16_bits_to_f32(v[j]));
+        for (int j = 0; j < 8; ++j) v[j] = bf16_bits_to_f16_bits_sat(v[j]);
       }
     }
   }

@@ -561,7 +561,7 @@ __global__ __launch_bounds__(NW * 64) void paged_attention_kernel(PAParams p) {
                                 ((k & 127) >> 5) * 16 + (seq & 15)) * 8;
           uint16_t h16;
           if constexpr (__is_same(T, Half)) h16 = r16;
-          else h16 = f32_to_f16_bits(bf16_bits_to_f32(r16));
+          else h16 = bf16_bits_to_f16_bits_sat(r16);
           ((uint16_t*)p.out_packed)[chunk + (k & 7)] = h16;
         }
       } else {

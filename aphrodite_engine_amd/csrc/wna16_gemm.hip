@@ -61,7 +61,7 @@ __device__ __forceinline__ f16x8 load_a_frag<BFloat>(const uint16_t* p) {
   u16x8 v = *reinterpret_cast<const u16x8*>(p);
   f16x8 r;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) r[i] = (f16)bf16_bits_to_f32(v[i]);
+  for (int i = 0; i < 8; ++i) r[i] = __builtin_bit_cast(f16, bf16_bits_to_f16_bits_sat(v[i]));
   return r;
 }
 
@@ -130,7 +130,7 @@ __device__ __forceinline__ void wna16_epilogue(const Wna16Params& p, float* red,
             const float gate = T::to_f32(T::from_f32(v[2 * q]));
             const float up = T::to_f32(T::from_f32(v[2 * q + 1]));
             uint16_t r = silu_mul_bits<T>(gate, up);
-            if constexpr (!__is_same(T, Half)) r = f32_to_f16_bits(bf16_bits_to_f32(r));
+            if constexpr (!__is_same(T, Half)) r = bf16_bits_to_f16_bits_sat(r);
             o[q] = r;
           }
           if constexpr (VEC == 4) *reinterpret_cast<uint32_t*>(dst) = (uint32_t)o[0] | ((uint32_t)o[1] << 16);
@@ -556,7 +556,7 @@ __global__ void pack_a_kernel(const uint16_t* __restrict__ a, const int32_t* __r
     }
     if constexpr (!__is_same(T, Half)) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = f32_to_f16_bits(bf16_bits_to_f32(v[j]));
+      for (int j = 0; j < 8; ++j) v[j] = bf16_bits_to_f16_bits_sat(v[j]);
     }
   }
   *reinterpret_cast<u16x8*>(out + idx * 8) = v;

@@ -1,0 +1,407 @@
+// W4A16 (GPTQ / AWQ-repacked int4) GEMM for PREFILL-sized M on gfx950 -- the Marlin role at large M.
+//
+// Replaces the reference's "reconstruct to fp16 [K, N] + cuBLAS/hipBLAS" fallback above 50 rows
+// (kernels/quantization/gptq/q_gemm.cu:1529-1544: temp_dq written + read = 4x the int4 bytes) and fills the
+// gptq_marlin_gemm slot (kernels/quantization/gptq_marlin/gptq_marlin.cu:544, 2247) for M > 64.  MFMA bound:
+//   * D^T[n][m] = W^T[n][k] . A^T[k][m] with v_mfma_f32_32x32x16_f16: the packed exllama dword (8 consecutive k of
+//     ONE column) is exactly one lane's A-operand fragment (lane: row n = lane & 31, k = 8 (lane >> 5) .. +7), so the
+//     weights never need a transposing LDS layout; the activations are the B operand (lane: column m = lane & 31).
+//     One dequantised weight fragment feeds 4 MFMAs (4 m-blocks of 32 rows), one activation fragment 2.
+//   * int4 -> f16 in registers, the reference's own numerics (q_gemm.cu:1394-1434, qdq_4.cuh:38-63): (q - z) exactly
+//     through the 1024 + q trick, one rounding in the multiply by the group scale.  13 VALU per dword against 128
+//     MFMA cycles: the dequant hides in the MFMA shadow.
+//   * activations: global -> LDS with direct-to-LDS loads (no VGPR round trip), 128-byte rows XOR-swizzled on the
+//     SOURCE address (the LDS image of such a load is lane-linear), read back with conflict-free ds_read_b128;
+//     weights: the tile's 8 packed rows go through LDS too (4-8 KiB) so the K loop has only LDS-DMA in flight;
+//     group scales / zeros of the workgroup's columns are staged once for the whole K range.
+//   * 2 LDS stages: the next K tile's loads are issued before the current tile's MFMAs, one barrier per tile.
+//   * XCD-aware tile order: consecutive workgroups of one XCD share the A row panel (2 MiB, L2 resident) and walk
+//     the column tiles.
+// Workgroup = WN x WM waves (WM in the M direction), wave tile = 128 rows x 64 columns, K tile 64.
+#include "common.h"
+
+namespace aphro {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+
+struct Wna16LargeParams {
+  const uint16_t* a;      // [M, lda] f16
+  const uint32_t* qw;     // [K/8, N] exllama order
+  const uint32_t* qz;     // [G, N/8]
+  const uint16_t* sc;     // [G, N] f16 (or bf16: see scale_is_bf16)
+  uint16_t* c;            // [M, N]
+  int M, N, K, lda;
+  int group_size;         // multiple of 64
+  int zero_offset;
+  int out_bf16;           // round the result to bf16 instead of f16
+  int scale_bf16;         // scales are stored as bf16
+  int tiles_m, tiles_n;
+  int ksplit;             // > 1: blockIdx.y owns K / ksplit consecutive k and writes an fp32 slab of `partial`
+  float* partial;         // [ksplit][M][N]
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t lg_rsrc(const void* base, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+
+__device__ __forceinline__ uint32_t vlg_and_or(uint32_t a, uint32_t mask, uint32_t orv) {
+  uint32_t r;
+  asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(mask), "v"(orv));
+  return r;
+}
+
+// one exllama dword -> 8 scaled f16: ((1024 + q) - (1024 + z)) * s  (exact difference, one rounding)
+__device__ __forceinline__ f16x8 dq8_scaled(uint32_t w, f16x2 zh, f16x2 zh16, f16x2 sc) {
+  const f16x2 inv16 = {(f16)0.0625f, (f16)0.0625f};
+  const uint32_t magic = 0x64006400u;
+  const uint32_t q0 = vlg_and_or(w, 0x000f000fu, magic);
+  const uint32_t q1 = vlg_and_or(w, 0x00f000f0u, magic);
+  const uint32_t w8 = w >> 8;
+  const uint32_t q2 = vlg_and_or(w8, 0x000f000fu, magic);
+  const uint32_t q3 = vlg_and_or(w8, 0x00f000f0u, magic);
+  const f16x2 d0 = (__builtin_bit_cast(f16x2, q0) - zh) * sc;
+  const f16x2 d1 = (__builtin_bit_cast(f16x2, q1) * inv16 + zh16) * sc;
+  const f16x2 d2 = (__builtin_bit_cast(f16x2, q2) - zh) * sc;
+  const f16x2 d3 = (__builtin_bit_cast(f16x2, q3) * inv16 + zh16) * sc;
+  u32x4 r = {__builtin_bit_cast(uint32_t, d0), __builtin_bit_cast(uint32_t, d1), __builtin_bit_cast(uint32_t, d2),
+             __builtin_bit_cast(uint32_t, d3)};
+  return __builtin_bit_cast(f16x8, r);
+}
+
+template <int WM, int WN, int STAGES>
+__global__ __launch_bounds__(WM * WN * 64) void wna16_gemm_large_kernel(Wna16LargeParams p) {
+  constexpr int NWAVE = WM * WN;
+  constexpr int BM = 128 * WM, BN = 64 * WN, BK = 64;
+  constexpr int A_STAGE = BM * BK * 2;              // bytes
+  constexpr int B_STAGE = (BK / 8) * BN * 4;
+  constexpr int STAGE = A_STAGE + B_STAGE;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // [STAGES][A tile | B tile] [scales: G x BN f16] [zeros: G x BN/8 words]
+  const int klen = p.K / p.ksplit;                  // this workgroup's K range: [k_begin, k_begin + klen)
+  const int k_begin = blockIdx.y * klen;
+  const int g_begin = k_begin / p.group_size;
+  const int G = klen / p.group_size;                // groups in the range (the host makes klen a multiple of the group)
+  uint16_t* meta_sc = reinterpret_cast<uint16_t*>(smem + STAGES * STAGE);
+  uint32_t* meta_z = reinterpret_cast<uint32_t*>(smem + STAGES * STAGE + G * BN * 2);
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave % WM, wn = wave / WM;
+  // ---- XCD-aware tile order: XCD x gets a contiguous range of tile ids; within it the column tiles are the fast
+  // index (neighbours share the A row panel) ------------------------------------------------------------------------
+  const int ntiles = p.tiles_m * p.tiles_n;
+  int tid;
+  {
+    const int bid = blockIdx.x, q = ntiles / 8, r = ntiles % 8, xcd = bid % 8, k = bid / 8;
+    tid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;    // bijective for any ntiles
+  }
+  const int tm = tid / p.tiles_n, tn = tid % p.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  // ---- prologue: group scales / zeros of this workgroup's BN columns for the whole K range -> LDS ------------------
+  for (int i = threadIdx.x; i < G * (BN / 2); i += NWAVE * 64) {
+    const int g = i / (BN / 2), j = i % (BN / 2);
+    reinterpret_cast<uint32_t*>(meta_sc)[i] = reinterpret_cast<const uint32_t*>(p.sc)[((size_t)(g_begin + g) * p.N + n0) / 2 + j];
+  }
+  for (int i = threadIdx.x; i < G * (BN / 8); i += NWAVE * 64) {
+    const int g = i / (BN / 8), j = i % (BN / 8);
+    meta_z[i] = p.qz[(size_t)(g_begin + g) * (p.N >> 3) + (n0 >> 3) + j];
+  }
+
+  // ---- staging (direct-to-LDS) ---------------------------------------------------------------------------------------
+  const __amdgpu_buffer_rsrc_t ra = lg_rsrc(p.a, (uint32_t)((size_t)p.M * p.lda * 2));
+  const __amdgpu_buffer_rsrc_t rb = lg_rsrc(p.qw, (uint32_t)((size_t)(p.K >> 3) * p.N * 4));
+  // A tile: BM rows x 128 B; one DMA instruction = 8 rows (lane -> row l/8, 16-byte slot l%8).  LDS slot s' of row r
+  // holds global slot s' ^ f(r), f(r) = (r >> 1) & 7  (conflict-free ds_read_b128 below).
+  constexpr int A_INSTR = BM / 8;                   // DMA instructions per A tile
+  constexpr int A_PER_WAVE = A_INSTR / NWAVE;
+  int a_voff[A_PER_WAVE];
+#pragma unroll
+  for (int i = 0; i < A_PER_WAVE; ++i) {
+    const int row = (wave * A_PER_WAVE + i) * 8 + (lane >> 3);
+    const int slot = (lane & 7) ^ ((row >> 1) & 7);
+    a_voff[i] = (min(m0 + row, p.M - 1) * p.lda + slot * 8) * 2;
+  }
+  // B tile: 8 packed rows x BN dwords = BN * 32 bytes; one DMA instruction = 1 KiB = 256 dwords
+  constexpr int B_INSTR = B_STAGE / 1024;
+  const int b_row_bytes = p.N * 4;
+  auto stage = [&](int st, int kt) {
+    unsigned char* sa = smem + st * STAGE;
+#pragma unroll
+    for (int i = 0; i < A_PER_WAVE; ++i) {
+      // (a local copy: with the captured array element `a_voff[i]` spelled in the builtin call itself, hipcc 7.2
+      //  silently drops the HOST-side launch stub of every instantiation of this kernel template -- the library then
+      //  fails to load with an undefined kernel symbol)
+      const int voff = a_voff[i];
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_ptr)(sa + (wave * A_PER_WAVE + i) * 1024), 16, voff,
+                                               (k_begin + kt * BK) * 2, 0, 0);
+    }
+    for (int i = wave; i < B_INSTR; i += NWAVE) {
+      // dword index d = i * 256 + 4 * lane .. +3 of the [8][BN] tile
+      const int d = i * 256 + lane * 4;
+      const int row = d / BN, col = d % BN;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void_ptr)(sa + A_STAGE + i * 1024), 16,
+                                               (n0 + col) * 4 + row * b_row_bytes, (k_begin / 8 + kt * 8) * b_row_bytes, 0, 0);
+    }
+  };
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[nb][mb][r] = 0.f;
+
+  const int kh = lane >> 5, l31 = lane & 31;
+  const int ktiles = klen / BK;
+  // DMA instructions one wave issues per K tile (uniform over the waves: the counted waits below rely on it)
+  constexpr int DMA_PER_TILE = A_PER_WAVE + B_INSTR / NWAVE;
+  static_assert(B_INSTR % NWAVE == 0, "every wave must issue the same number of B-tile loads");
+  stage(0, 0);
+  if constexpr (STAGES == 3) { if (ktiles > 1) stage(1, 1); }
+  __syncthreads();                                     // (also publishes the group scales / zeros staged above)
+
+  f16x2 zh[2], zh16[2], scv[2];
+  int cur_group = -1;
+  for (int kt = 0; kt < ktiles; ++kt) {
+    const int st = kt % STAGES;
+    if constexpr (STAGES == 3) {
+      // tile kt has landed once at most the loads of tile kt+1 are outstanding; a RAW barrier (no vmcnt(0) drain:
+      // __syncthreads() would wait for the tile in flight) publishes it to every wave and tells everyone that
+      // stage (kt + 2) % 3 -- read during tile kt - 1 -- is free, so tile kt + 2 can be issued under this tile's MFMAs
+      if (kt + 1 < ktiles) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(DMA_PER_TILE) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (kt + 2 < ktiles) stage((kt + 2) % 3, kt + 2);
+    } else {
+      if (kt + 1 < ktiles) stage(st ^ 1, kt + 1);     // next tile's DMA in flight under this tile's MFMAs
+    }
+    const int grp = (kt * BK) / p.group_size;
+    if (grp != cur_group) {                           // wave-uniform: new quantisation group
+      cur_group = grp;
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        const int col = wn * 64 + nb * 32 + l31;      // column inside the workgroup tile
+        const uint16_t sb = meta_sc[grp * BN + col];
+        const float sf = p.scale_bf16 ? bf16_bits_to_f32(sb) : f16_bits_to_f32(sb);
+        const int z = (int)((meta_z[grp * (BN / 8) + (col >> 3)] >> ((col & 7) * 4)) & 0xf) + p.zero_offset;
+        const f16 s16 = (f16)sf;
+        const f16 a16 = __builtin_bit_cast(f16, (uint16_t)(0x6400 | z));   // 1024 + z
+        const f16 b16 = (f16)(float)(-64 - z);
+        scv[nb] = f16x2{s16, s16};
+        zh[nb] = f16x2{a16, a16};
+        zh16[nb] = f16x2{b16, b16};
+      }
+    }
+    const unsigned char* sa = smem + st * STAGE;
+    const uint32_t* sb = reinterpret_cast<const uint32_t*>(sa + A_STAGE);
+    // Fragments of k-step j + 1 are read from LDS while the MFMAs of step j run (two register sets; hipcc left to
+    // itself reuses ONE fragment register and waits lgkmcnt(0) in front of every MFMA pair: 0.40 -> see DESIGN.md).
+    u32x4 af[2][4];
+    uint32_t wraw[2][2];
+    auto read_frags = [&](int j, u32x4 (&a4)[4], uint32_t (&w2)[2]) {
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) w2[nb] = sb[(2 * j + kh) * BN + wn * 64 + nb * 32 + l31];
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb) {
+        const int row = wm * 128 + mb * 32 + l31;
+        const int slot = (2 * j + kh) ^ ((row >> 1) & 7);
+        a4[mb] = *reinterpret_cast<const u32x4*>(sa + row * 128 + slot * 16);
+      }
+    };
+    read_frags(0, af[0], wraw[0]);
+#pragma unroll
+    for (int j = 0; j < BK / 16; ++j) {
+      if (j + 1 < BK / 16) read_frags(j + 1, af[(j + 1) & 1], wraw[(j + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);            // keep the next step's LDS reads ABOVE this step's MFMAs
+      f16x8 wf[2];
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) wf[nb] = dq8_scaled(wraw[j & 1][nb], zh[nb], zh16[nb], scv[nb]);
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+          acc[nb][mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[nb], __builtin_bit_cast(f16x8, af[j & 1][mb]), acc[nb][mb], 0, 0, 0);
+    }
+    if constexpr (STAGES == 2) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next tile landed (this wave's share)
+      __syncthreads();                                   // ... everyone's; and everyone is done reading `st`
+    }
+  }
+
+  // ---- epilogue: lane holds, for row m = mb*32 + l31, columns nb*32 + 8 q + 4 kh + (0..3), q = reg >> 2 --------------
+#pragma unroll
+  for (int mb = 0; mb < 4; ++mb) {
+    const int row = m0 + wm * 128 + mb * 32 + l31;
+    if (row >= p.M) continue;
+    if (p.ksplit > 1) {        // fp32 slab of this K range; summed by splitk_reduce_large_kernel
+      float* prow = p.partial + ((size_t)blockIdx.y * p.M + row) * p.N + n0 + wn * 64;
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<f32x4*>(prow + nb * 32 + 8 * q + 4 * kh) =
+              f32x4{acc[nb][mb][4 * q], acc[nb][mb][4 * q + 1], acc[nb][mb][4 * q + 2], acc[nb][mb][4 * q + 3]};
+      continue;
+    }
+    uint16_t* crow = p.c + (size_t)row * p.N + n0 + wn * 64;
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        u16x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = acc[nb][mb][4 * q + r];
+          o[r] = p.out_bf16 ? f32_to_bf16_bits(v) : f32_to_f16_bits(v);
+        }
+        *reinterpret_cast<u16x4*>(crow + nb * 32 + 8 * q + 4 * kh) = o;
+      }
+  }
+}
+
+// partial [S][M*N] fp32 -> c [M*N] f16 / bf16 (fixed summation order: deterministic)
+__global__ void splitk_reduce_large_kernel(const float* __restrict__ partial, uint16_t* __restrict__ c, int64_t mn, int S,
+                                           int out_bf16) {
+  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i >= mn) return;
+  f32x4 s = *reinterpret_cast<const f32x4*>(partial + i);
+  for (int k = 1; k < S; ++k) s += *reinterpret_cast<const f32x4*>(partial + (size_t)k * mn + i);
+  u16x4 o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) o[j] = out_bf16 ? f32_to_bf16_bits(s[j]) : f32_to_f16_bits(s[j]);
+  *reinterpret_cast<u16x4*>(c + i) = o;
+}
+
+// bf16 [M, K] (row stride lda) -> f16 [M, K] contiguous, saturating (see bf16_bits_to_f16_bits_sat)
+__global__ void bf16_to_f16_rows_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, int M, int K, int lda) {
+  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+  if (i >= (int64_t)M * K) return;
+  const int row = (int)(i / K), col = (int)(i % K);
+  u16x8 v = *reinterpret_cast<const u16x8*>(in + (size_t)row * lda + col);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = bf16_bits_to_f16_bits_sat(v[j]);
+  *reinterpret_cast<u16x8*>(out + i) = v;
+}
+
+template <int WM, int WN, int STAGES>
+static int launch_large_s(const Wna16LargeParams& p, hipStream_t st) {
+  constexpr int BM = 128 * WM, BN = 64 * WN;
+  Wna16LargeParams q = p;
+  q.tiles_m = (p.M + BM - 1) / BM;
+  q.tiles_n = p.N / BN;
+  const int G = p.K / p.ksplit / p.group_size;
+  const size_t lds = STAGES * ((size_t)BM * 64 * 2 + 8 * BN * 4) + (size_t)G * BN * 2 + (size_t)G * (BN / 8) * 4;
+  if (lds > 160 * 1024) {
+    set_error("wna16_gemm_large: %zu bytes of LDS needed (K=%d, group %d)", lds, p.K, p.group_size);
+    return APHRO_ERR_INVALID;
+  }
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)wna16_gemm_large_kernel<WM, WN, STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024) != hipSuccess) {
+      set_error("wna16_gemm_large: cannot raise the dynamic LDS limit");
+      return APHRO_ERR_LAUNCH;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((wna16_gemm_large_kernel<WM, WN, STAGES>), dim3(q.tiles_m * q.tiles_n, q.ksplit), dim3(WM * WN * 64), lds, st, q);
+  APHRO_LAUNCH_CHECK();
+  return APHRO_OK;
+}
+
+// three LDS stages (loads two K tiles ahead, one raw barrier per tile) when the group metadata leaves room for them
+template <int WM, int WN>
+static int launch_large(const Wna16LargeParams& p, hipStream_t st) {
+  constexpr int BM = 128 * WM, BN = 64 * WN;
+  const int G = p.K / p.ksplit / p.group_size;
+  const size_t lds3 = 3 * ((size_t)BM * 64 * 2 + 8 * BN * 4) + (size_t)G * BN * 2 + (size_t)G * (BN / 8) * 4;
+  static const int force = getenv("APHRO_WNA16_LARGE_STAGES") ? atoi(getenv("APHRO_WNA16_LARGE_STAGES")) : 0;
+  if ((lds3 <= 160 * 1024 && force != 2) || force == 3) return launch_large_s<WM, WN, 3>(p, st);
+  return launch_large_s<WM, WN, 2>(p, st);
+}
+
+}  // namespace aphro
+
+using namespace aphro;
+
+struct LargePlan { int wm, wn, ksplit; };
+
+// Tile shape and K split: 256 x 256 tiles when they still cover the chip; for small grids narrower tiles and a split of
+// K into up to 8 fp32 slabs (summed in fixed order by splitk_reduce_large_kernel) so that ~256+ workgroups exist.
+static LargePlan large_plan(int64_t M, int64_t N, int64_t K, int64_t gs) {
+  LargePlan pl;
+  pl.wm = M > 128 ? 2 : 1;
+  const int64_t rows = (M + 128 * pl.wm - 1) / (128 * pl.wm);
+  pl.wn = (N % 256 == 0 && rows * (N / 256) >= 200) ? 4 : 2;
+  const int64_t tiles = rows * (N / (64 * pl.wn));
+  pl.ksplit = 1;
+  const int64_t unit = gs > 64 ? gs : 64;           // a K range holds whole groups and whole K tiles
+  for (int s = 2; s <= 8; ++s) {
+    if (tiles * pl.ksplit >= 200) break;
+    if (K % (s * unit) == 0 && K / s >= 512) pl.ksplit = s;
+  }
+  if (const char* e = getenv("APHRO_WNA16_LARGE_KSPLIT")) { const int s = atoi(e); if (s >= 1 && K % (s * unit) == 0) pl.ksplit = s; }
+  return pl;
+}
+
+// Bytes of scratch aphro_wna16_gemm_large needs: the f16 copy of bf16 activations + the fp32 split-K slabs.
+extern "C" size_t aphro_wna16_gemm_large_workspace_bytes(int64_t M, int64_t N, int64_t K, int64_t groups, int dtype) {
+  if (groups <= 0 || K % groups != 0) return 0;
+  const LargePlan pl = large_plan(M, N, K, K / groups);
+  size_t b = dtype == APHRO_BF16 ? ((size_t)M * K * 2 + 255) / 256 * 256 : 0;
+  if (pl.ksplit > 1) b += (size_t)pl.ksplit * M * N * sizeof(float);
+  return b;
+}
+
+// c[M, N] = a[M, K] . dequant(q_weight[K/8, N] exllama order, qzeros[G, N/8], scales[G, N]); any M, meant for M > 64.
+// N % 128 == 0, K % 64 == 0, group size a multiple of 64.  dtype f16 / bf16 (bf16 activations are widened to f16
+// with saturation, scales and output stay bf16).  Act-order: pass the activations already gathered (a[:, perm]).
+extern "C" int aphro_wna16_gemm_large(const void* a, const uint32_t* q_weight, const uint32_t* qzeros, const void* scales,
+                                      void* c, void* workspace, size_t workspace_bytes, int64_t M, int64_t N, int64_t K,
+                                      int64_t groups, int64_t lda, int zero_offset, int dtype, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  APHRO_CHECK(dtype == APHRO_F16 || dtype == APHRO_BF16, "wna16_gemm_large: dtype must be f16 or bf16");
+  APHRO_CHECK(groups > 0 && K % groups == 0, "wna16_gemm_large: K=%ld not divisible by groups=%ld", (long)K, (long)groups);
+  const int64_t gs = K / groups;
+  APHRO_CHECK(K % 64 == 0 && gs % 64 == 0, "wna16_gemm_large: K and the group size must be multiples of 64 (K=%ld, g=%ld)", (long)K, (long)gs);
+  APHRO_CHECK(N % 128 == 0, "wna16_gemm_large: N=%ld must be a multiple of 128", (long)N);
+  APHRO_CHECK(lda % 8 == 0 && ((uintptr_t)a % 16) == 0, "wna16_gemm_large: a must be 16-byte aligned with lda %% 8 == 0");
+  APHRO_CHECK((size_t)M * lda * 2 < 0xffffffffull && (size_t)(K / 8) * N * 4 < 0xffffffffull, "wna16_gemm_large: operand exceeds 4 GiB");
+  if (M == 0) return APHRO_OK;
+  const LargePlan pl = large_plan(M, N, K, gs);
+  const size_t need = aphro_wna16_gemm_large_workspace_bytes(M, N, K, groups, dtype);
+  if (need > 0 && (workspace == nullptr || workspace_bytes < need)) {
+    set_error("wna16_gemm_large: workspace %zu < %zu bytes", workspace_bytes, need);
+    return APHRO_ERR_WORKSPACE;
+  }
+  Wna16LargeParams p;
+  p.a = (const uint16_t*)a; p.lda = (int)lda;
+  char* ws = (char*)workspace;
+  if (dtype == APHRO_BF16) {
+    const int64_t n8 = M * K / 8;
+    hipLaunchKernelGGL(bf16_to_f16_rows_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, st, (const uint16_t*)a,
+                       (uint16_t*)ws, (int)M, (int)K, (int)lda);
+    APHRO_LAUNCH_CHECK();
+    p.a = (const uint16_t*)ws; p.lda = (int)K;
+    ws += ((size_t)M * K * 2 + 255) / 256 * 256;
+  }
+  p.qw = q_weight; p.qz = qzeros; p.sc = (const uint16_t*)scales; p.c = (uint16_t*)c;
+  p.M = (int)M; p.N = (int)N; p.K = (int)K; p.group_size = (int)gs; p.zero_offset = zero_offset;
+  p.out_bf16 = dtype == APHRO_BF16; p.scale_bf16 = dtype == APHRO_BF16;
+  p.tiles_m = p.tiles_n = 0;
+  p.ksplit = pl.ksplit; p.partial = (float*)ws;
+  int rc;
+  if (pl.wm == 2) rc = pl.wn == 4 ? launch_large<2, 4>(p, st) : launch_large<2, 2>(p, st);
+  else rc = pl.wn == 4 ? launch_large<1, 4>(p, st) : launch_large<1, 2>(p, st);
+  if (rc != APHRO_OK) return rc;
+  if (pl.ksplit > 1) {
+    const int64_t mn = M * N;
+    hipLaunchKernelGGL(splitk_reduce_large_kernel, dim3((unsigned)((mn / 4 + 255) / 256)), dim3(256), 0, st, p.partial,
+                       (uint16_t*)c, mn, pl.ksplit, p.out_bf16);
+    APHRO_LAUNCH_CHECK();
+  }
+  return APHRO_OK;
+}

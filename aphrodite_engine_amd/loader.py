@@ -392,10 +392,10 @@ def load_llama_weights(model, weights: Iterable[Tuple[str, torch.Tensor]], tie_w
             continue
         if tgt.kind == "param":
             param = _get_path(model, tgt.path)
-            if tgt.path == "lm_head":       # vocab-parallel rows (ParallelLMHead)
-                rows = param.shape[0]
-                tensor = tensor.narrow(0, rank * rows, rows)
+            if tgt.path == "lm_head":       # vocab-parallel rows of the PADDED vocabulary (ParallelLMHead)
+                _load_vocab_rows(param, tensor, rank)
                 seen_lm_head = True
+                continue
             default_weight_loader(param, tensor.to(param.dtype))
             continue
         if tgt.kind == "expert":
@@ -422,9 +422,19 @@ def load_llama_weights(model, weights: Iterable[Tuple[str, torch.Tensor]], tie_w
             except ValueError as e:
                 raise ValueError(f"{name}: {e}") from None
     if tie_word_embeddings or not seen_lm_head:
-        rows = model.lm_head.shape[0]
-        model.lm_head.data.copy_(model.embed_tokens.data.narrow(0, rank * rows, rows))
+        _load_vocab_rows(model.lm_head, model.embed_tokens.data, rank)
     return kv
+
+
+def _load_vocab_rows(param: torch.nn.Parameter, full: torch.Tensor, rank: int) -> None:
+    """This rank's rows [rank * rows, (rank + 1) * rows) of the vocabulary padded to a multiple of 64 (and of tp):
+    the rows the checkpoint holds are copied, the padding stays zero (VocabParallelEmbedding.weight_loader)."""
+    rows = param.shape[0]
+    start = rank * rows
+    valid = max(0, min(rows, full.shape[0] - start))
+    param.data.zero_()
+    if valid:
+        param.data[:valid].copy_(full.narrow(0, start, valid).to(param.dtype))
 
 
 def read_kv_cache_scales(path: str, tp_rank: int, tp_size: int, num_hidden_layers: int,

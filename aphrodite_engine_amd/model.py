@@ -48,6 +48,15 @@ class LlamaConfig:
         return self.hidden_size // self.num_attention_heads
 
 
+def padded_vocab_size(vocab_size: int, tp: int = 1, pad_to: int = 64) -> int:
+    """pad_vocab_size (modeling/layers/vocab_parallel_embedding.py): next multiple of 64, made divisible by tp."""
+    v = (vocab_size + pad_to - 1) // pad_to * pad_to
+    if v % tp:
+        step = pad_to * tp
+        v = (vocab_size + step - 1) // step * step
+    return v
+
+
 LLAMA3_8B = LlamaConfig()
 LLAMA3_70B = LlamaConfig(hidden_size=8192, intermediate_size=28672,
                          num_hidden_layers=80, num_attention_heads=64,
@@ -419,8 +428,12 @@ class LlamaForCausalLM(nn.Module):
         self.norm = nn.Parameter(torch.ones(cfg.hidden_size, dtype=dtype),
                                  requires_grad=False)
         tp = get_tensor_model_parallel_world_size()
+        # ParallelLMHead (vocab_parallel_embedding.py: DEFAULT_VOCAB_PADDING_SIZE = 64): the vocabulary is padded to a
+        # multiple of 64 (and of the TP size) and the PADDED size is sharded; padding rows are zero and their logits
+        # are sliced away after the gather, so a checkpoint with added tokens (vocab % tp != 0) loses no token.
+        self.vocab_padded = padded_vocab_size(cfg.vocab_size, tp)
         self.lm_head = nn.Parameter(
-            torch.empty(cfg.vocab_size // tp, cfg.hidden_size, dtype=dtype),
+            torch.zeros(self.vocab_padded // tp, cfg.hidden_size, dtype=dtype),
             requires_grad=False)
         self.cos_sin = None
         self.use_fused_decode = True
@@ -443,6 +456,10 @@ class LlamaForCausalLM(nn.Module):
         self.embed_tokens.copy_((torch.randn(self.embed_tokens.shape, generator=g_rep, device=device,
                                              dtype=torch.float32)).to(self.embed_tokens.dtype))
         randn_(self.lm_head, 1.0 / math.sqrt(cfg.hidden_size))
+        rows = self.lm_head.shape[0]
+        valid = max(0, min(rows, cfg.vocab_size - get_tensor_model_parallel_rank() * rows))
+        if valid < rows:
+            self.lm_head[valid:].zero_()
         for layer in self.layers:
             for lin in layer.linears():
                 _init_linear(lin, g, device)
@@ -531,6 +548,8 @@ class LlamaForCausalLM(nn.Module):
         if get_tensor_model_parallel_world_size() > 1:
             from .distributed import tensor_model_parallel_all_gather
             logits = tensor_model_parallel_all_gather(logits, dim=-1)
+        if logits.shape[-1] != self.cfg.vocab_size:
+            logits = logits[..., :self.cfg.vocab_size]          # drop the padding columns (a strided view)
         return logits
 
     def sample_greedy(self, logits, out=None):

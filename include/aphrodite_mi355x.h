@@ -488,6 +488,19 @@ int aphro_custom_ar_register_graph_buffers(void* fa, const char* handles, const 
  * this instead of hanging the GPU) */
 int aphro_custom_ar_error(void* fa);
 
+/* W4A16 GEMM for prefill-sized M (M > 64) -- the role of `_C::gptq_marlin_gemm` at large M
+ * (kernels/torch_bindings.cpp:195-201, kernels/quantization/gptq_marlin/gptq_marlin.cu:544,2247) and of the reference's
+ * `reconstruct + hipBLAS` fallback above 50 rows (kernels/quantization/gptq/q_gemm.cu:1529-1544), which this replaces
+ * with ONE MFMA kernel that dequantises in registers (csrc/wna16_gemm_large.hip).  Same tensors as aphro_gptq_gemm:
+ * q_weight [K/8, N] in the exllama-shuffled order, qzeros [G, N/8], scales [G, N] in `dtype`; c [M, N] in `dtype`.
+ * N % 128 == 0, K % 64 == 0, group size % 64 == 0.  Act-order: pass activations already gathered (a[:, perm]).
+ * workspace: aphro_wna16_gemm_large_workspace_bytes (f16 copy of bf16 activations, saturating; fp32 split-K slabs when
+ * the tile grid alone would not cover the chip). */
+size_t aphro_wna16_gemm_large_workspace_bytes(int64_t M, int64_t N, int64_t K, int64_t groups, int dtype);
+int aphro_wna16_gemm_large(const void* a, const uint32_t* q_weight, const uint32_t* qzeros, const void* scales,
+                           void* c, void* workspace, size_t workspace_bytes, int64_t M, int64_t N, int64_t K,
+                           int64_t groups, int64_t lda, int zero_offset, int dtype, void* stream);
+
 /* Overlap helper for tensor parallelism (north_star: "all-reduce overlapped with the quantized GEMMs on HIP
  * streams"): streams `bytes` at `ptr` through the memory-side Infinity Cache on `stream` while the all-reduce of the
  * previous row-parallel projection runs on a side stream -- see aphrodite_engine_amd/distributed/overlap.py.  Reads

@@ -481,3 +481,29 @@ def test_shard_arithmetic_matches_the_reference_weight_loaders(golden_dir):
             assert torch.equal(prm2.data, want), key + " (fused)"
         checked += 1
     assert checked >= 90
+
+
+def test_vocab_not_divisible_by_tp_is_padded_not_truncated(tmp_path):
+    """A checkpoint with added tokens (vocab 1000: not a multiple of 64, nor of tp 4): the lm_head is the vocabulary
+    padded to 1024 and sharded like ParallelLMHead (vocab_parallel_embedding.py); the last rank holds the 232 real tail
+    rows + 24 zero rows -- no token is dropped."""
+    import dataclasses
+    from aphrodite_engine_amd.model import padded_vocab_size
+    cfg = dataclasses.replace(CFG, vocab_size=1000)
+    truth = CU.write_checkpoint(str(tmp_path), cfg, "fp16", seed=9)
+    full = truth["tensors"]["lm_head.weight"]
+    assert padded_vocab_size(1000, 4) == 1024 and padded_vocab_size(128256, 8) == 128256 and padded_vocab_size(1000, 3) == 1152
+    seen = []
+    for rank in range(4):
+        m = build(tmp_path, "fp16", rank, 4)
+        assert m.lm_head.shape[0] == 256 and m.vocab_padded == 1024
+        lo = rank * 256
+        valid = max(0, min(256, 1000 - lo))
+        assert torch.equal(m.lm_head.data[:valid], full[lo:lo + valid])
+        assert not m.lm_head.data[valid:].any()
+        seen.append(m.lm_head.data[:valid])
+    assert torch.equal(torch.cat(seen), full)
+    m1 = build(tmp_path, "fp16", 0, 1)
+    assert m1.lm_head.shape[0] == 1024 and torch.equal(m1.lm_head.data[:1000], full)
+    hidden = torch.randn(3, cfg.hidden_size).half()
+    assert m1.compute_logits(hidden).shape == (3, 1000)

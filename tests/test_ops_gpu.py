@@ -898,6 +898,25 @@ def test_pack_a(ops, dtype, M, K):
     np.testing.assert_array_equal(got, ref)
 
 
+def test_bf16_activations_beyond_f16_range_saturate(ops):
+    """bf16 activations are widened to f16 for the int4 MFMA (the reference's GPTQ kernels are fp16-only): a value
+    beyond +-65504 saturates instead of becoming inf -> NaN in every output of its row."""
+    rng = np.random.default_rng(5)
+    M, K, N, G = 4, 256, 64, 128
+    a = rng.standard_normal((M, K)).astype(np.float32)
+    a[1, 7], a[2, 100] = 3.0e5, -1.0e6
+    at = t(a, torch.bfloat16)
+    got = unpack_a(ops.wna16_pack_a(at), M, K).view(np.float16)
+    assert got[1, 7] == np.float16(65504) and got[2, 100] == np.float16(-65504) and np.isfinite(got.astype(np.float32)).all()
+    qweight, qzeros, s_, _ = make_gptq(rng, K, N, G)
+    y = ops.gptq_gemm(at, t(oq.gptq_shuffle(qweight)), t(qzeros), t(s_, torch.bfloat16),
+                      torch.empty(0, dtype=torch.int32, device=DEV), True, 4)
+    assert torch.isfinite(y.float()).all()
+    # rows without an outlier are unaffected
+    ref = oq.gptq_gemm(at.float().cpu().numpy(), oq.gptq_shuffle(qweight), qzeros, t(s_, torch.bfloat16).float().cpu().numpy(), None, True)
+    np.testing.assert_allclose(y.float().cpu().numpy()[[0, 3]], ref[[0, 3]], rtol=1.6e-2, atol=1.6e-2 * np.abs(ref[[0, 3]]).max())
+
+
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("nslab", [0, 1, 3])
 @pytest.mark.parametrize("has_res", [True, False])
