@@ -170,7 +170,10 @@ def test_awq_gemm(ops, M, K, N, G):
     np.testing.assert_array_equal(rq.cpu().numpy(), oq.gptq_shuffle(oq.gptq_pack(oq.awq_unpack(qw))))
     np.testing.assert_array_equal(rz.cpu().numpy(), oq.pack_cols(oq.awq_unpack(qz)))
     got2 = ops.wna16_gemm(t(a), rq, rz, t(s), None, 0).float().cpu().numpy()
-    np.testing.assert_array_equal(got2, got)
+    if M <= 64:
+        np.testing.assert_array_equal(got2, got)
+    else:   # M > 64: the prefill-sized MFMA kernel (scale folded into the f16 weight: one extra rounding)
+        np.testing.assert_allclose(got2, ref, rtol=2e-3, atol=2e-3 * np.abs(ref).max())
 
 
 # ---------------------------------------------------------------------------
@@ -190,7 +193,10 @@ def test_config3_llama70b_awq_tp8_shapes(ops, K, N):
     np.testing.assert_allclose(got, ref, rtol=2e-3, atol=2e-3 * np.abs(ref).max())
     rq, rz = ops.awq_marlin_repack(t(qw), K, N, 4), ops.awq_repack_zeros(t(qz), N)
     got2 = ops.wna16_gemm(t(a), rq, rz, t(s), None, 0).float().cpu().numpy()
-    np.testing.assert_array_equal(got2, got)
+    if M <= 64:
+        np.testing.assert_array_equal(got2, got)
+    else:   # M > 64: the prefill-sized MFMA kernel (scale folded into the f16 weight: one extra rounding)
+        np.testing.assert_allclose(got2, ref, rtol=2e-3, atol=2e-3 * np.abs(ref).max())
 
 
 @pytest.mark.parametrize("K,N", [(4096, 6144), (4096, 4096), (4096, 28672), (14336, 4096)])
