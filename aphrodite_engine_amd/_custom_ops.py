@@ -1123,8 +1123,25 @@ def cutlass_scaled_mm(a: torch.Tensor, b: torch.Tensor, scale_a: torch.Tensor,
         raise RuntimeError("b must be column-major [K,N] (weight.t())")
     if not a.is_contiguous():
         a = a.contiguous()
+    if m > SCALED_MM_LIBRARY_MIN_M and n % 128 == 0 and k % 128 == 0 and not os.environ.get("APHRO_FP8_NO_LARGE"):
+        # prefill-sized M: the MFMA-bound kernel of fp8_gemm_large.hip (scales + bias in its epilogue, f16 or bf16)
+        lib = _lib.lib()
+        if out is None:
+            out = torch.empty((m, n), dtype=out_dtype, device=a.device)
+        elif out.shape != (m, n) or out.dtype != out_dtype or not out.is_contiguous():
+            raise RuntimeError("cutlass_scaled_mm: out must be a contiguous [M, N] tensor of out_dtype")
+        sa = scale_a.reshape(-1).float()
+        sb = scale_b.reshape(-1).float()
+        if sa.numel() not in (1, m) or sb.numel() not in (1, n):
+            raise RuntimeError("cutlass_scaled_mm: scale_a must have 1 or M elements, scale_b 1 or N")
+        ws = _workspace(a.device, lib.aphro_scaled_mm_fp8_large_workspace_bytes(m, n, k))
+        check(lib.aphro_scaled_mm_fp8_large(
+            out.data_ptr(), a.data_ptr(), b.data_ptr(), sa.data_ptr(), sb.data_ptr(), _ptr(bias),
+            ws.data_ptr(), ws.numel(), m, n, k, 1 if sa.numel() > 1 else 0, 1 if sb.numel() > 1 else 0,
+            _lib.F16 if out_dtype == torch.float16 else _lib.BF16, _stream()), "cutlass_scaled_mm")
+        return out
     if m > SCALED_MM_LIBRARY_MIN_M:
-        # prefill-sized M is MFMA-bound: a plain library GEMM (hipBLASLt through torch._scaled_mm --
+        # shapes the hand-written kernel does not tile (N or K not a multiple of 128): library GEMM: a plain library GEMM (hipBLASLt through torch._scaled_mm --
         # what the reference itself calls on ROCm, w8a8_utils.py:130,165; measured 1.9 PFLOP/s fp8 at
         # M = 8192).  Row-wise scaling needs both scale vectors; a scalar one is broadcast.
         sa_, sb_ = scale_a.reshape(-1).float(), scale_b.reshape(-1).float()

@@ -84,6 +84,8 @@ SIGNATURES = {
     "aphro_dynamic_scaled_fp8_quant_ws": (I, [P, P, P, P, Z, L, L, I, P]),
     "aphro_dynamic_per_token_scaled_fp8_quant": (I, [P, P, P, P, L, L, I, P]),
     "aphro_scaled_mm_fp8": (I, [P, P, P, P, P, P, P, Z, L, L, L, I, I, I, P]),
+    "aphro_scaled_mm_fp8_large_workspace_bytes": (Z, [L, L, L]),
+    "aphro_scaled_mm_fp8_large": (I, [P, P, P, P, P, P, P, Z, L, L, L, I, I, I, P]),
     "aphro_fp8_w8a16_gemm": (I, [P, P, P, P, P, P, Z, L, L, L, L, I, I, P]),
     "aphro_fp8_gemm_workspace_bytes": (Z, [L, L, L]),
     "aphro_rms_norm": (I, [P, P, P, F, L, I, L, I, P]),

@@ -185,4 +185,35 @@ __device__ __forceinline__ uint16_t silu_mul_bits(float gate, float up) {
   return from_f32_exact<T>(s * up);
 }
 
+// two fp32 -> packed pair of 16-bit floats with the hardware converters (v_cvt_pk_bf16_f32 is RNE like f32_to_bf16_bits;
+// it differs only in the NaN payload it produces)
+typedef __bf16 bf16x2_hw __attribute__((ext_vector_type(2)));
+template <bool BF16>
+__device__ __forceinline__ uint32_t pack2_16(float a, float b) {
+  if constexpr (BF16) {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{a, b}, bf16x2_hw));
+  } else {
+    return __builtin_bit_cast(uint32_t, f16x2{(f16)a, (f16)b});
+  }
+}
+
+// ---- epilogue of the prefill-sized GEMMs (wna16_gemm_large.hip, fp8_gemm_large.hip) ------------------------------
+// A wave owns a 128 (m) x 64 (n) tile of 16-bit results, one output ROW per lane (32x32 MFMA C layout: lane = row
+// l & 31, 4 consecutive columns 8 q + 4 (l >> 5) per accumulator quad).  Stored straight from that layout every
+// instruction scatters 8-byte pieces over 32 rows: measured 1.7 TB/s, a quarter of the kernel at K = 4096.  Instead
+// the tile goes through a wave-private 16 KiB LDS region (XOR-swizzled 8-byte slots, conflict-free both ways) and
+// leaves as full 128-byte row segments, 16 bytes per lane.
+__device__ __forceinline__ void epi_put(unsigned char* region, int row, int c8, u32x2 v) {
+  // row: 0..127 inside the wave tile; c8: 8-byte column chunk 0..15
+  *reinterpret_cast<u32x2*>(region + row * 128 + ((c8 ^ (((row >> 1) & 7) << 1)) << 3)) = v;
+}
+__device__ __forceinline__ void epi_flush(const unsigned char* region, uint16_t* c, int64_t ldc, int rows_valid, int lane) {
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int row = i * 8 + (lane >> 3), c16 = lane & 7;
+    const u32x4 v = *reinterpret_cast<const u32x4*>(region + row * 128 + ((c16 ^ ((row >> 1) & 7)) << 4));
+    if (row < rows_valid) *reinterpret_cast<u32x4*>(c + (int64_t)row * ldc + c16 * 8) = v;
+  }
+}
+
 }  // namespace aphro

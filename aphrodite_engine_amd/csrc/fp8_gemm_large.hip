@@ -1,0 +1,470 @@
+// W8A8 FP8 (OCP e4m3 x e4m3) scaled GEMM for PREFILL-sized M on gfx950 -- the cutlass_scaled_mm role above 64 rows
+// (kernels/quantization/cutlass_w8a8/scaled_mm_entry.cu:32-81; on ROCm the reference falls back to
+// torch._scaled_mm, modeling/layers/quantization/utils/w8a8_utils.py:130-183).  MFMA bound:
+//   * out[m][n] = a_scale[m] * (b_scale[n] * sum_k A[m][k] W[n][k]) + bias[n], both operands K-contiguous in HBM
+//     ([M, K] activations, [N, K] = the column-major [K, N] weight the op receives), so neither needs a transpose:
+//     v_mfma_scale_f32_32x32x64_f8f6f4 (unit E8M0 scales: the double-rate fp8 path of CDNA4) takes 32 consecutive
+//     k bytes of one row per lane for BOTH operands.  D^T[n][m] = W[n][k] . A^T[k][m]: the weights are the A operand,
+//     the activations the B operand, like wna16_gemm_large.hip (a lane then owns 4 consecutive n of one output row).
+//   * both tiles go global -> LDS with direct-to-LDS loads (no VGPR round trip), 128-byte rows XOR-swizzled on the
+//     SOURCE address, read back with conflict-free ds_read_b128 (two per operand fragment).
+//   * 2 LDS stages of 64 KiB (256 x 256 x 128 tile) or 3 stages of 48 KiB (narrower tiles): the next K tile's loads
+//     are in flight under the current tile's 16 MFMAs per wave.
+//   * STREAM-K: one persistent workgroup per CU; the (tile, K tile) units are dealt out in equal contiguous ranges, so
+//     (a) there is no last partial round of tiles, and (b) the workgroups reach their tile boundaries at different
+//     times -- measured on the one-workgroup-per-tile form, all 256 CUs storing their 128 KiB of C at the same moment
+//     ran at 1.7 TB/s with every MFMA idle: a quarter of the kernel at K = 4096.  A tile whose K range is cut between
+//     workgroups is finished by the one that owns its k = 0 end: the others publish their fp32 accumulators
+//     (write-through stores + one flag word each, no fences) and the owner adds them in workgroup order
+//     (deterministic).  Small grids (< 128 tiles) keep the one-workgroup-per-(tile, K slice) form with fp32 slabs.
+//   * results leave through a wave-private LDS transpose as full 128-byte row segments (epi_put / epi_flush, common.h).
+// Workgroup = WN x WM waves, wave tile = 128 rows (m) x 64 columns (n), K tile = 128.
+#include "common.h"
+
+namespace aphro {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+
+struct Fp8LargeParams {
+  const uint8_t* a;        // [M, K] e4m3
+  const uint8_t* w;        // [N, K] e4m3
+  const float* a_scales;   // [M] or [1] or null
+  const float* b_scales;   // [N] or [1] or null
+  const uint16_t* bias;    // [N] (output type) or null
+  uint16_t* c;             // [M, N]
+  int M, N, K;
+  int a_per_token, b_per_channel, out_bf16;
+  int tiles_m, tiles_n;
+  int streamk;             // 1: persistent grid, equal unit ranges; 0: one workgroup per (tile, K slice)
+  int ksplit;              // streamk == 0: K slices (blockIdx.y), fp32 slabs + reduce kernel when > 1
+  float* partial;          // streamk == 0: [ksplit][M][N];  streamk == 1: [grid] accumulator images (see publish)
+  unsigned* flags;         // streamk == 1: [grid] "image published", zeroed by the host before the launch
+  int debug;               // lab only (APHRO_FP8_LARGE_DEBUG): 1 = no output stores, 2 = one K tile per segment
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t f8_rsrc(const void* base, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+
+// XCD x (workgroup ids x, x + 8, ...) gets a contiguous range of logical ids; bijective on [0, n) for any n
+__device__ __forceinline__ int xcd_contiguous(int bid, int n) {
+  const int q = n / 8, r = n % 8, xcd = bid % 8, k = bid / 8;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+
+// lab (debug == 4): workgroups 0..7 record s_memtime stamps of their 2nd and 3rd segments at flags[512 + w*32 + ...]
+#define F8_STAMP(slot)                                                                                         \
+  if (p.debug == 4 && w < 8 && threadIdx.x == 0 && seg >= 1 && seg <= 2)                                       \
+    reinterpret_cast<unsigned long long*>(p.flags + 512)[w * 16 + (seg - 1) * 8 + (slot)] = __builtin_amdgcn_s_memtime();
+
+constexpr int SC_COHERENT = 17;   // buffer aux bits sc0 | sc1: write-through stores / loads that do not trust this XCD's L2
+
+template <int WM, int WN, int STAGES, bool BF16OUT>
+__global__ __launch_bounds__(WM * WN * 64) void fp8_gemm_large_kernel(Fp8LargeParams p) {
+  constexpr int NWAVE = WM * WN;
+  constexpr int BM = 128 * WM, BN = 64 * WN, BK = 128;
+  constexpr int A_STAGE = BM * BK;                  // bytes
+  constexpr int B_STAGE = BN * BK;
+  constexpr int STAGE = A_STAGE + B_STAGE;
+  constexpr int IMAGE = NWAVE * 32 * 1024;          // bytes of one workgroup's accumulator image
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave % WM, wn = wave / WM;
+  const int kh = lane >> 5, l31 = lane & 31;
+  const int ktiles_total = p.K / BK;
+  const int ntiles = p.tiles_m * p.tiles_n;
+  const int G = gridDim.x;
+  const int64_t U = (int64_t)ntiles * ktiles_total;
+
+  // ---- this workgroup's units [u, u_end): unit = tile * ktiles_total + K tile; neighbouring ids share the A row panel
+  // Stream-K boundaries are SKEWED: workgroup j starts (j mod 8) * skew units late, so that the tile boundaries -- where
+  // a workgroup stores 128 KiB of C -- are spread over the tile period instead of hitting HBM from all 256 CUs at once
+  // (equal unskewed ranges are whole tiles whenever 256 divides the tile count: measured 12.6k of 108k cycles per tile in
+  // the store burst).  Sizes differ by at most 7 * skew units (< 1 % of a range).
+  const int skew = (p.streamk && p.debug == 8) ? (int)min((int64_t)max(ktiles_total / 8, 1), U / G / 16) : 0;   // lab: measured slower (L2 sharing lost)
+  auto unit_begin = [&](int j) -> int64_t { return j >= G ? U : j * U / G + (int64_t)(j & 7) * skew; };
+  int u, u_end, w = 0;
+  if (p.streamk) {
+    w = xcd_contiguous(blockIdx.x, G);
+    u = (int)unit_begin(w);
+    u_end = (int)unit_begin(w + 1);
+  } else {
+    const int per = ktiles_total / p.ksplit;
+    u = xcd_contiguous(blockIdx.x, ntiles) * ktiles_total + blockIdx.y * per;
+    u_end = u + per;
+  }
+
+  const __amdgpu_buffer_rsrc_t ra = f8_rsrc(p.a, (uint32_t)((size_t)p.M * p.K));
+  const __amdgpu_buffer_rsrc_t rb = f8_rsrc(p.w, (uint32_t)((size_t)p.N * p.K));
+  const __amdgpu_buffer_rsrc_t rp = f8_rsrc(p.partial, p.streamk ? (uint32_t)((size_t)G * IMAGE) : 0u);
+  constexpr int A_PER_WAVE = BM / 8 / NWAVE, B_PER_WAVE = BN / 8 / NWAVE;
+  static_assert((BM / 8) % NWAVE == 0 && (BN / 8) % NWAVE == 0, "every wave issues the same number of loads");
+  constexpr int DMA_PER_TILE = A_PER_WAVE + B_PER_WAVE;
+
+  // fragment addresses inside a stage: 32 consecutive k bytes = 16-byte slots 4 j + 2 kh and + 1.  Physical slot P of
+  // row r holds logical slot P ^ f(r), f(r) = (r >> 1) & 7: the logical pair (2x, 2x + 1) sits at (2x ^ f, 2x ^ f ^ 1).
+  // f(row) depends on l31 only (rows of one lane differ by multiples of 32), j toggles bit 2 of the slot: one base
+  // register per operand, the rest are immediates / one XOR.
+  const int a_base = (wm * 128 + l31) * 128 + (((2 * kh) ^ ((l31 >> 1) & 7)) << 4);
+  const int b_base = A_STAGE + (wn * 64 + l31) * 128 + (((2 * kh) ^ ((l31 >> 1) & 7)) << 4);
+  auto read_frag = [&](const unsigned char* sa, int off) {
+    const u32x4 lo = *reinterpret_cast<const u32x4*>(sa + off);
+    const u32x4 hi = *reinterpret_cast<const u32x4*>(sa + (off ^ 16));
+    return i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+  };
+
+  bool first_segment = true;
+  int seg = -1;
+  while (u < u_end) {
+    ++seg;
+    const int tile = u / ktiles_total;
+    const int k0 = u - tile * ktiles_total;
+    int k1 = min(ktiles_total, k0 + (u_end - u));
+    u += k1 - k0;
+    const bool head = k0 == 0, tail = k1 == ktiles_total;
+    if (p.debug == 2) k1 = k0 + 1;
+    const int tm = tile / p.tiles_n, tn = tile % p.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    if (!first_segment) __syncthreads();            // the previous segment's epilogue is done with the LDS
+    first_segment = false;
+    F8_STAMP(0)
+
+    // ---- staging (direct-to-LDS): one DMA instruction = 8 rows x 128 B (lane -> row l / 8, 16-byte slot l % 8) ------
+    int a_voff[A_PER_WAVE], b_voff[B_PER_WAVE];
+#pragma unroll
+    for (int i = 0; i < A_PER_WAVE; ++i) {
+      const int row = (wave * A_PER_WAVE + i) * 8 + (lane >> 3);
+      const int slot = (lane & 7) ^ ((row >> 1) & 7);
+      a_voff[i] = min(m0 + row, p.M - 1) * p.K + slot * 16;
+    }
+#pragma unroll
+    for (int i = 0; i < B_PER_WAVE; ++i) {
+      const int row = (wave * B_PER_WAVE + i) * 8 + (lane >> 3);
+      const int slot = (lane & 7) ^ ((row >> 1) & 7);
+      b_voff[i] = (n0 + row) * p.K + slot * 16;
+    }
+    auto stage = [&](int st, int kt) {
+      unsigned char* sa = smem + st * STAGE;
+      const int soff = kt * BK;
+#pragma unroll
+      for (int i = 0; i < A_PER_WAVE; ++i) {
+        const int voff = a_voff[i];   // (local copy: see wna16_gemm_large.hip on the hipcc host-stub bug)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_ptr)(sa + (wave * A_PER_WAVE + i) * 1024), 16, voff, soff, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < B_PER_WAVE; ++i) {
+        const int voff = b_voff[i];
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void_ptr)(sa + A_STAGE + (wave * B_PER_WAVE + i) * 1024), 16, voff, soff, 0, 0);
+      }
+    };
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nb][mb][r] = 0.f;
+
+    const int nk = k1 - k0;
+    stage(0, k0);
+    if constexpr (STAGES == 3) { if (nk > 1) stage(1, k0 + 1); }
+    else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
+    F8_STAMP(1)
+
+    for (int i = 0; i < nk; ++i) {
+      const int st = i % STAGES;
+      if constexpr (STAGES == 3) {
+        // tile i has landed once at most the loads of tile i + 1 are outstanding; the raw barrier (no vmcnt(0) drain)
+        // publishes it and frees stage (i + 2) % 3, read during tile i - 1
+        if (i + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(DMA_PER_TILE) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (i + 2 < nk) stage((i + 2) % 3, k0 + i + 2);
+      } else {
+        // the two waves of a SIMD (w, w + NWAVE/2) issue their loads at different points of the tile: while one is
+        // busy issuing 8 direct-to-LDS loads the other one's MFMAs keep the matrix pipe fed
+        if (i + 1 < nk && (wave < NWAVE / 2 || p.debug == 16)) stage(st ^ 1, k0 + i + 1);
+      }
+      const unsigned char* sa = smem + st * STAGE;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if constexpr (STAGES == 2) {
+          if (j == 1) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (i + 1 < nk && wave >= NWAVE / 2 && p.debug != 16) stage(st ^ 1, k0 + i + 1);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        i32x8 wf[2], af[4];
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) wf[nb] = read_frag(sa + nb * 4096, b_base ^ (j << 6));
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) af[mb] = read_frag(sa + mb * 4096, a_base ^ (j << 6));
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb)
+            acc[nb][mb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wf[nb], af[mb], acc[nb][mb], 0, 0, 0, 127, 0, 127);
+      }
+      if constexpr (STAGES == 2) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+      }
+    }
+    if constexpr (STAGES == 3) __syncthreads();      // every wave is done with the stage buffers
+    F8_STAMP(2)
+
+    // ---- what happens to the accumulators ---------------------------------------------------------------------------
+    // lane holds, for row m = mb*32 + l31, columns nb*32 + 8 q + 4 kh + (0..3), q = reg >> 2
+    if (p.streamk && !head) {
+      // not the owner of this tile (always a workgroup's FIRST segment): publish the accumulators as they sit in the
+      // registers -- image [wave][quad = (nb*4 + mb)*4 + q][lane] f32x4, 1 KiB per store instruction, write-through
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 v = {acc[nb][mb][4 * q], acc[nb][mb][4 * q + 1], acc[nb][mb][4 * q + 2], acc[nb][mb][4 * q + 3]};
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rp,
+                                                   ((w * NWAVE + wave) * 32 + (nb * 4 + mb) * 4 + q) * 1024 + lane * 16, 0, SC_COHERENT);
+          }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every storing wave drains ...
+      __syncthreads();                                     // ... before ONE lane raises the flag
+      if (threadIdx.x == 0) __hip_atomic_store(p.flags + w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      continue;
+    }
+    if (p.streamk && !tail) {
+      // owner of a tile whose K range continues in the following workgroups (always the LAST segment): add their images
+      // in workgroup order.  They were published long ago unless the whole tile is being computed right now.
+      const int64_t tile_end = (int64_t)(tile + 1) * ktiles_total;
+      for (int j = w + 1; j < G && unit_begin(j) < tile_end; ++j) {
+        if (threadIdx.x == 0)
+          while (__hip_atomic_load(p.flags + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(4);
+        __syncthreads();
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+          for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(
+                  rp, ((j * NWAVE + wave) * 32 + (nb * 4 + mb) * 4 + q) * 1024 + lane * 16, 0, SC_COHERENT);
+              const f32x4 v = __builtin_bit_cast(f32x4, raw);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) acc[nb][mb][4 * q + r] += v[r];
+            }
+      }
+    }
+    if (!p.streamk && p.ksplit > 1) {      // fp32 slab of this K slice; summed by fp8_splitk_reduce_large_kernel
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb) {
+        const int row = m0 + wm * 128 + mb * 32 + l31;
+        if (row >= p.M) continue;
+        float* prow = p.partial + ((size_t)blockIdx.y * p.M + row) * p.N + n0 + wn * 64;
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<f32x4*>(prow + nb * 32 + 8 * q + 4 * kh) =
+                f32x4{acc[nb][mb][4 * q], acc[nb][mb][4 * q + 1], acc[nb][mb][4 * q + 2], acc[nb][mb][4 * q + 3]};
+      }
+      continue;
+    }
+    // ---- scaled-mm epilogue -> wave-private LDS transpose -> full-row stores ----------------------------------------------
+    unsigned char* region = smem + wave * 16384;
+    const int colbase = n0 + wn * 64;
+    // every scale / bias value this lane needs, fetched up front (one wait): issued one by one next to their use the 32
+    // dependent L2 round trips cost 28k cycles per tile -- a fifth of the kernel at K = 4096
+    f32x4 sbv[2][4];
+    u16x4 bbv[2][4];
+    float sav[4];
+    {
+      const float s0 = (p.b_scales && !p.b_per_channel) ? p.b_scales[0] : 1.f;
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int col = colbase + nb * 32 + 8 * q + 4 * kh;
+          sbv[nb][q] = (p.b_scales && p.b_per_channel) ? *reinterpret_cast<const f32x4*>(p.b_scales + col) : f32x4{s0, s0, s0, s0};
+          bbv[nb][q] = p.bias ? *reinterpret_cast<const u16x4*>(p.bias + col) : u16x4{0, 0, 0, 0};
+        }
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb)
+        sav[mb] = p.a_scales ? p.a_scales[p.a_per_token ? min(m0 + wm * 128 + mb * 32 + l31, p.M - 1) : 0] : 1.f;
+    }
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+      const float sa_ = sav[mb];
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 sb = sbv[nb][q];
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            // order of test_cutlass.py:43; the bias vector is zeros when there is none (one code path: with a branch
+            // per output type / bias hipcc spills 200 registers here)
+            v[r] = sa_ * (sb[r] * acc[nb][mb][4 * q + r]) + (BF16OUT ? bf16_bits_to_f32(bbv[nb][q][r]) : f16_bits_to_f32(bbv[nb][q][r]));
+            asm("" : "+v"(v[r]));                            // fp32 result first, ONE rounding to 16 bits second
+          }
+          epi_put(region, mb * 32 + l31, nb * 8 + 2 * q + kh, u32x2{pack2_16<BF16OUT>(v[0], v[1]), pack2_16<BF16OUT>(v[2], v[3])});
+        }
+    }
+    F8_STAMP(3)
+    if (p.debug != 1)
+      epi_flush(region, p.c + (size_t)(m0 + wm * 128) * p.N + colbase, p.N, p.M - (m0 + wm * 128), lane);
+    F8_STAMP(4)
+    if (p.debug == 4) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); F8_STAMP(5) }
+  }
+}
+
+// partial [S][M*N] fp32 -> c: sum in fixed order, then the scaled-mm epilogue
+__global__ void fp8_splitk_reduce_large_kernel(const float* __restrict__ partial, Fp8LargeParams p, int S) {
+  const int64_t mn = (int64_t)p.M * p.N;
+  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i >= mn) return;
+  f32x4 s = *reinterpret_cast<const f32x4*>(partial + i);
+  for (int k = 1; k < S; ++k) s += *reinterpret_cast<const f32x4*>(partial + (size_t)k * mn + i);
+  const int row = (int)(i / p.N), col = (int)(i % p.N);
+  const float sa_ = p.a_scales ? p.a_scales[p.a_per_token ? row : 0] : 1.f;
+  u16x4 o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float sb = p.b_scales ? p.b_scales[p.b_per_channel ? col + j : 0] : 1.f;
+    float v = sa_ * (sb * s[j]);
+    if (p.bias) v += p.out_bf16 ? bf16_bits_to_f32(p.bias[col + j]) : f16_bits_to_f32(p.bias[col + j]);
+    asm("" : "+v"(v));
+    o[j] = p.out_bf16 ? f32_to_bf16_bits(v) : f32_to_f16_bits(v);
+  }
+  *reinterpret_cast<u16x4*>(p.c + i) = o;
+}
+
+template <int WM, int WN, int STAGES, bool BF16OUT>
+static int launch_fp8_large_t(const Fp8LargeParams& p, int grid_x, hipStream_t st) {
+  constexpr size_t lds = (size_t)STAGES * (128 * WM + 64 * WN) * 128;
+  static_assert(lds <= 160 * 1024 && lds >= (size_t)WM * WN * 16384, "stage buffers must fit and cover the epilogue regions");
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)fp8_gemm_large_kernel<WM, WN, STAGES, BF16OUT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024) != hipSuccess) {
+      set_error("fp8_gemm_large: cannot raise the dynamic LDS limit");
+      return APHRO_ERR_LAUNCH;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((fp8_gemm_large_kernel<WM, WN, STAGES, BF16OUT>), dim3(grid_x, p.streamk ? 1 : p.ksplit), dim3(WM * WN * 64), lds, st, p);
+  APHRO_LAUNCH_CHECK();
+  return APHRO_OK;
+}
+
+template <int WM, int WN, int STAGES>
+static int launch_fp8_large(const Fp8LargeParams& p, int grid_x, hipStream_t st) {
+  return p.out_bf16 ? launch_fp8_large_t<WM, WN, STAGES, true>(p, grid_x, st) : launch_fp8_large_t<WM, WN, STAGES, false>(p, grid_x, st);
+}
+
+}  // namespace aphro
+
+using namespace aphro;
+
+struct Fp8LargePlan { int wm, wn, tiles_m, tiles_n, streamk, grid, ksplit; };
+
+static int cu_count() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+  }
+  return n;
+}
+
+// Stream-K (one persistent workgroup per CU) when the biggest tile the shape allows still gives >= 128 tiles: then
+// every workgroup gets at least half a tile's K loop and a tile is cut between at most 3 workgroups.  Below that: one
+// workgroup per tile, narrower tiles and up to 8 K slices (fp32 slabs) so that ~200+ workgroups exist.
+static Fp8LargePlan fp8_large_plan(int64_t M, int64_t N, int64_t K) {
+  Fp8LargePlan pl;
+  pl.wm = M > 128 ? 2 : 1;
+  const int64_t rows = (M + 128 * pl.wm - 1) / (128 * pl.wm);
+  static const int mode = getenv("APHRO_FP8_LARGE_STREAMK") ? atoi(getenv("APHRO_FP8_LARGE_STREAMK")) : -1;
+  const int64_t big_tiles = N % 256 == 0 ? rows * (N / 256) : rows * (N / 128);
+  pl.streamk = mode >= 0 ? mode : (big_tiles >= 128);
+  pl.ksplit = 1;
+  if (pl.streamk) {
+    pl.wn = N % 256 == 0 ? 4 : 2;
+    pl.grid = cu_count();
+  } else {
+    pl.wn = (N % 256 == 0 && rows * (N / 256) >= 200) ? 4 : 2;
+    const int64_t tiles = rows * (N / (64 * pl.wn));
+    for (int s = 2; s <= 8; ++s) {
+      if (tiles * pl.ksplit >= 200) break;
+      if (K % (s * 128) == 0 && K / s >= 1024) pl.ksplit = s;
+    }
+    if (const char* e = getenv("APHRO_FP8_LARGE_KSPLIT")) { const int s = atoi(e); if (s >= 1 && K % (s * 128) == 0) pl.ksplit = s; }
+    pl.grid = (int)tiles;
+  }
+  pl.tiles_m = (int)rows;
+  pl.tiles_n = (int)(N / (64 * pl.wn));
+  return pl;
+}
+
+constexpr size_t FP8_LARGE_FLAG_BYTES = 4096;
+
+// Bytes of scratch aphro_scaled_mm_fp8_large needs: stream-K flags + accumulator images, or the fp32 split-K slabs.
+extern "C" size_t aphro_scaled_mm_fp8_large_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+  const Fp8LargePlan pl = fp8_large_plan(M, N, K);
+  if (pl.streamk) return FP8_LARGE_FLAG_BYTES + (size_t)pl.grid * pl.wm * pl.wn * 32 * 1024;
+  return pl.ksplit > 1 ? (size_t)pl.ksplit * M * N * sizeof(float) : 0;
+}
+
+// out[M, N] = a_scales (.) (a[M, K] . b[N, K]^T) (.) b_scales + bias; e4m3 operands, any M (meant for M > 64).
+// N % 128 == 0, K % 128 == 0.  Same argument meaning as aphro_scaled_mm_fp8.
+extern "C" int aphro_scaled_mm_fp8_large(void* out, const void* a, const void* b, const float* a_scales,
+                                         const float* b_scales, const void* bias, void* workspace,
+                                         size_t workspace_bytes, int64_t M, int64_t N, int64_t K,
+                                         int a_scale_per_token, int b_scale_per_channel, int out_dtype, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  APHRO_CHECK(out_dtype == APHRO_F16 || out_dtype == APHRO_BF16, "scaled_mm_fp8_large: out dtype must be f16 or bf16");
+  APHRO_CHECK(N % 128 == 0 && K % 128 == 0, "scaled_mm_fp8_large: N=%ld and K=%ld must be multiples of 128", (long)N, (long)K);
+  APHRO_CHECK(((uintptr_t)a % 16) == 0 && ((uintptr_t)b % 16) == 0, "scaled_mm_fp8_large: operands must be 16-byte aligned");
+  APHRO_CHECK((size_t)M * K < 0xffffffffull && (size_t)N * K < 0xffffffffull, "scaled_mm_fp8_large: operand exceeds 4 GiB");
+  if (M == 0) return APHRO_OK;
+  const Fp8LargePlan pl = fp8_large_plan(M, N, K);
+  APHRO_CHECK((int64_t)pl.tiles_m * pl.tiles_n * (K / 128) < 0x7fffffff, "scaled_mm_fp8_large: too many work units");
+  const size_t need = aphro_scaled_mm_fp8_large_workspace_bytes(M, N, K);
+  if (need > 0 && (workspace == nullptr || workspace_bytes < need)) {
+    set_error("scaled_mm_fp8_large: workspace %zu < %zu bytes", workspace_bytes, need);
+    return APHRO_ERR_WORKSPACE;
+  }
+  Fp8LargeParams p;
+  p.a = (const uint8_t*)a; p.w = (const uint8_t*)b; p.a_scales = a_scales; p.b_scales = b_scales;
+  p.bias = (const uint16_t*)bias; p.c = (uint16_t*)out;
+  p.M = (int)M; p.N = (int)N; p.K = (int)K;
+  p.a_per_token = a_scale_per_token; p.b_per_channel = b_scale_per_channel; p.out_bf16 = out_dtype == APHRO_BF16;
+  p.tiles_m = pl.tiles_m; p.tiles_n = pl.tiles_n; p.streamk = pl.streamk; p.ksplit = pl.ksplit;
+  p.flags = nullptr; p.partial = (float*)workspace;
+  p.debug = getenv("APHRO_FP8_LARGE_DEBUG") ? atoi(getenv("APHRO_FP8_LARGE_DEBUG")) : 0;
+  if (pl.streamk) {
+    p.flags = (unsigned*)workspace;
+    p.partial = (float*)((char*)workspace + FP8_LARGE_FLAG_BYTES);
+    if (hipMemsetAsync(p.flags, 0, FP8_LARGE_FLAG_BYTES, st) != hipSuccess) {
+      set_error("scaled_mm_fp8_large: cannot clear the stream-K flags");
+      return APHRO_ERR_LAUNCH;
+    }
+  }
+  int rc;
+  if (pl.wm == 2) rc = pl.wn == 4 ? launch_fp8_large<2, 4, 2>(p, pl.grid, st) : launch_fp8_large<2, 2, 3>(p, pl.grid, st);
+  else rc = pl.wn == 4 ? launch_fp8_large<1, 4, 3>(p, pl.grid, st) : launch_fp8_large<1, 2, 3>(p, pl.grid, st);
+  if (rc != APHRO_OK) return rc;
+  if (!pl.streamk && pl.ksplit > 1) {
+    const int64_t mn = M * N;
+    hipLaunchKernelGGL(fp8_splitk_reduce_large_kernel, dim3((unsigned)((mn / 4 + 255) / 256)), dim3(256), 0, st, p.partial, p, pl.ksplit);
+    APHRO_LAUNCH_CHECK();
+  }
+  return APHRO_OK;
+}

@@ -232,11 +232,11 @@ __global__ __launch_bounds__(WM * WN * 64) void wna16_gemm_large_kernel(Wna16Lar
   }
 
   // ---- epilogue: lane holds, for row m = mb*32 + l31, columns nb*32 + 8 q + 4 kh + (0..3), q = reg >> 2 --------------
+  if (p.ksplit > 1) {          // fp32 slab of this K range; summed by splitk_reduce_large_kernel
 #pragma unroll
-  for (int mb = 0; mb < 4; ++mb) {
-    const int row = m0 + wm * 128 + mb * 32 + l31;
-    if (row >= p.M) continue;
-    if (p.ksplit > 1) {        // fp32 slab of this K range; summed by splitk_reduce_large_kernel
+    for (int mb = 0; mb < 4; ++mb) {
+      const int row = m0 + wm * 128 + mb * 32 + l31;
+      if (row >= p.M) continue;
       float* prow = p.partial + ((size_t)blockIdx.y * p.M + row) * p.N + n0 + wn * 64;
 #pragma unroll
       for (int nb = 0; nb < 2; ++nb)
@@ -244,22 +244,22 @@ __global__ __launch_bounds__(WM * WN * 64) void wna16_gemm_large_kernel(Wna16Lar
         for (int q = 0; q < 4; ++q)
           *reinterpret_cast<f32x4*>(prow + nb * 32 + 8 * q + 4 * kh) =
               f32x4{acc[nb][mb][4 * q], acc[nb][mb][4 * q + 1], acc[nb][mb][4 * q + 2], acc[nb][mb][4 * q + 3]};
-      continue;
     }
-    uint16_t* crow = p.c + (size_t)row * p.N + n0 + wn * 64;
+    return;
+  }
+  if constexpr (STAGES == 3) __syncthreads();      // every wave is done with the stage buffers: reuse them (epi_put)
+  unsigned char* region = smem + wave * 16384;
+#pragma unroll
+  for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        u16x4 o;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float v = acc[nb][mb][4 * q + r];
-          o[r] = p.out_bf16 ? f32_to_bf16_bits(v) : f32_to_f16_bits(v);
-        }
-        *reinterpret_cast<u16x4*>(crow + nb * 32 + 8 * q + 4 * kh) = o;
+        const float v0 = acc[nb][mb][4 * q], v1 = acc[nb][mb][4 * q + 1], v2 = acc[nb][mb][4 * q + 2], v3 = acc[nb][mb][4 * q + 3];
+        epi_put(region, mb * 32 + l31, nb * 8 + 2 * q + kh,
+                p.out_bf16 ? u32x2{pack2_16<true>(v0, v1), pack2_16<true>(v2, v3)} : u32x2{pack2_16<false>(v0, v1), pack2_16<false>(v2, v3)});
       }
-  }
+  epi_flush(region, p.c + (size_t)(m0 + wm * 128) * p.N + n0 + wn * 64, p.N, p.M - (m0 + wm * 128), lane);
 }
 
 // partial [S][M*N] fp32 -> c [M*N] f16 / bf16 (fixed summation order: deterministic)
@@ -293,7 +293,8 @@ static int launch_large_s(const Wna16LargeParams& p, hipStream_t st) {
   q.tiles_m = (p.M + BM - 1) / BM;
   q.tiles_n = p.N / BN;
   const int G = p.K / p.ksplit / p.group_size;
-  const size_t lds = STAGES * ((size_t)BM * 64 * 2 + 8 * BN * 4) + (size_t)G * BN * 2 + (size_t)G * (BN / 8) * 4;
+  size_t lds = STAGES * ((size_t)BM * 64 * 2 + 8 * BN * 4) + (size_t)G * BN * 2 + (size_t)G * (BN / 8) * 4;
+  if (lds < (size_t)WM * WN * 16384) lds = (size_t)WM * WN * 16384;   // the epilogue's wave-private transpose regions
   if (lds > 160 * 1024) {
     set_error("wna16_gemm_large: %zu bytes of LDS needed (K=%d, group %d)", lds, p.K, p.group_size);
     return APHRO_ERR_INVALID;

@@ -72,6 +72,11 @@ def build(args, device):
         raise SystemExit("--model mixtral-8x7b runs int4 experts: --quant gptq or awq")
     if args.layers:
         cfg = dataclasses.replace(cfg, num_hidden_layers=args.layers)
+    # the rotary table must cover every position the loop reaches (--ctx 8192 ends past Llama-3-8B's 8192 window:
+    # the long-context variants of the same geometry ship a longer table)
+    last_pos = args.ctx + args.steps + args.warmup + 8
+    if last_pos > cfg.max_position_embeddings:
+        cfg = dataclasses.replace(cfg, max_position_embeddings=(last_pos + 1023) // 1024 * 1024)
     if args.quant == "gptq":
         qc = GPTQConfig(4, 128, False)
     elif args.quant == "awq":

@@ -294,6 +294,19 @@ int aphro_scaled_mm_fp8(void* out, const void* a, const void* b,
                         int64_t M, int64_t N, int64_t K, int a_scale_per_token,
                         int b_scale_per_channel, int out_dtype, void* stream);
 
+/* The same op for prefill-sized M (meant for M > 64; any M): MFMA-bound kernel on
+ * v_mfma_scale_f32_32x32x64_f8f6f4, both tiles through LDS (fp8_gemm_large.hip) -- the
+ * cutlass sm89/sm90 kernels' role (cutlass_w8a8/scaled_mm_c3x.cu, scaled_mm_c2x.cu), which
+ * on ROCm the reference hands to torch._scaled_mm (w8a8_utils.py:130-183).
+ * N % 128 == 0, K % 128 == 0.  workspace: aphro_scaled_mm_fp8_large_workspace_bytes (split-K
+ * slabs for small grids; may be 0). */
+size_t aphro_scaled_mm_fp8_large_workspace_bytes(int64_t M, int64_t N, int64_t K);
+int aphro_scaled_mm_fp8_large(void* out, const void* a, const void* b,
+                              const float* a_scales, const float* b_scales,
+                              const void* bias, void* workspace, size_t workspace_bytes,
+                              int64_t M, int64_t N, int64_t K, int a_scale_per_token,
+                              int b_scale_per_channel, int out_dtype, void* stream);
+
 /* _C::fp8_marlin_gemm role (kernels/torch_bindings.cpp:218-222,
  * quantization/fp8/fp8_marlin.cu:1212): W8A16, c = a . (fp8->hp(W) * s_n).
  * a f16|bf16 [M,K]; w e4m3 row-major [N,K]; w_scales fp32 [1] or [N]. */
