@@ -1276,3 +1276,196 @@ def rotary_embedding(positions: torch.Tensor, query: torch.Tensor,
         cos_sin_cache.shape[1], cos_sin_cache.data_ptr(), q2.stride(0),
         k2.stride(0), 1 if is_neox else 0, _dt(query), _stream()),
         "rotary_embedding")
+
+
+# ---------------------------------------------------------------------------
+# _C_custom_ar::* (kernels/torch_bindings.cpp:506-536; aphrodite/_custom_ops.py:906-941) over
+# csrc/custom_all_reduce.hip.  Same names, argument order and meaning as the reference wrappers, so that
+# aphrodite/distributed/device_communicators/custom_all_reduce.py runs unchanged on top of them.
+# IPC handles are the 64 opaque bytes of hipIpcMemHandle_t -- what ``storage._share_cuda_()[1]`` holds on
+# ROCm -- passed as ``bytes`` (the reference passes ``bytes`` where its schema says ``str[]``); a ``str`` is
+# taken as latin-1 or, when it is 128 hex digits, as hex (the only forms that survive the dispatcher's
+# UTF-8 round trip: see torch_ops.CUSTOM_AR_SCHEMAS).
+# ---------------------------------------------------------------------------
+_CUSTOM_AR_DT = {torch.float16: _lib.F16, torch.bfloat16: _lib.BF16, torch.float32: 2}
+_custom_ar_live = {}       # fa -> objects the communicator borrows (meta / rank_data tensors)
+
+
+def _ipc_handle_bytes(h) -> bytes:
+    n = _lib.lib().aphro_ipc_handle_bytes()
+    if isinstance(h, (bytes, bytearray, memoryview)):
+        b = bytes(h)
+    elif isinstance(h, str):
+        b = bytes.fromhex(h) if len(h) == 2 * n else h.encode("latin-1")
+    else:
+        raise TypeError(f"IPC handle must be bytes or str, not {type(h).__name__}")
+    if len(b) != n:
+        raise ValueError(f"IPC handle has {len(b)} bytes, expected {n}")
+    return b
+
+
+def _ipc_pack(handles, offsets):
+    import ctypes
+    raw = b"".join(_ipc_handle_bytes(h) for h in handles)
+    return ctypes.create_string_buffer(raw, len(raw)), (ctypes.c_int64 * len(offsets))(*[int(o) for o in offsets])
+
+
+def meta_size() -> int:
+    """Bytes of one rank's signal area (the ``Signal`` struct, custom_all_reduce.cuh:30-42)."""
+    return int(_lib.lib().aphro_custom_ar_meta_size())
+
+
+class _SharedDeviceBuffer:
+    """Peer-visible UNCACHED device memory exposed through __cuda_array_interface__ (freed with the object)."""
+
+    def __init__(self, nbytes: int):
+        import ctypes
+        self.ptr = ctypes.c_void_p()
+        check(_lib.lib().aphro_custom_ar_alloc_shared(ctypes.byref(self.ptr), nbytes), "custom_ar_alloc_shared")
+        self.nbytes = nbytes
+        self.__cuda_array_interface__ = {"shape": (nbytes, ), "typestr": "|u1", "data": (self.ptr.value, False),
+                                         "version": 2, "strides": None}
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                _lib.lib().aphro_custom_ar_free_shared(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+
+def custom_ar_alloc_meta(nbytes: int, device) -> torch.Tensor:
+    """The ``meta`` buffer of init_custom_ar (``torch.zeros(meta_size() + max_size, uint8)`` in the reference,
+    custom_all_reduce.py:101-104) as zero-filled fine-grained memory: the signal words are polled by the peer GPUs
+    while kernels run, which ordinary (coarse-grained, L2-cached) allocations do not guarantee to be visible."""
+    with torch.cuda.device(device):
+        owner = _SharedDeviceBuffer(nbytes)
+        t = torch.as_tensor(owner, device=torch.device(device))
+    t._aphro_owner = owner
+    return t
+
+
+def ipc_handle_of(t: torch.Tensor) -> Tuple[bytes, int]:
+    """(handle, offset) of the allocation holding ``t`` -- ``t.untyped_storage()._share_cuda_()`` (data[1], data[3])
+    in the reference (custom_all_reduce.py:210-214), taken with hipIpcGetMemHandle so that it also works for the
+    fine-grained buffers above."""
+    import ctypes
+    lib = _lib.lib()
+    h = ctypes.create_string_buffer(lib.aphro_ipc_handle_bytes())
+    off = ctypes.c_int64()
+    check(lib.aphro_ipc_get_mem_handle(ctypes.c_void_p(t.data_ptr()), h, ctypes.byref(off)), "ipc_get_mem_handle")
+    return bytes(h.raw), int(off.value)
+
+
+def init_custom_ar(meta: torch.Tensor, rank_data: torch.Tensor, handles: List, offsets: List[int], rank: int,
+                   full_nvlink: bool) -> int:
+    """custom_all_reduce.cu:13-41.  ``meta``: this rank's signal area followed by the two-shot scratch
+    (meta_size() + max_size bytes); ``handles`` / ``offsets``: every rank's meta, in rank order; ``rank_data``: device
+    memory for the registered-buffer table.  ``full_nvlink`` is accepted for signature parity: every GPU pair of an
+    MI355X node is one xGMI hop, the one-shot / two-shot choice depends on the size only."""
+    import ctypes
+    _require_cuda(meta, rank_data)
+    world = len(handles)
+    if len(offsets) != world:
+        raise ValueError("handles length should equal to offsets length")
+    if not 0 <= rank < world:
+        raise ValueError("invalid rank passed in")
+    ms = meta_size()
+    if meta.numel() * meta.element_size() <= ms:
+        raise ValueError("meta must hold the signal area and the two-shot scratch (meta_size() + max_size bytes)")
+    scratch_bytes = (meta.numel() * meta.element_size() - ms) // 16 * 16
+    hbuf, obuf = _ipc_pack(handles, offsets)
+    sbuf = (ctypes.c_int64 * world)(*[int(o) + ms for o in offsets])
+    fa = ctypes.c_void_p()
+    check(_lib.lib().aphro_custom_ar_init(
+        ctypes.byref(fa), meta.data_ptr(), hbuf, obuf, meta.data_ptr() + ms, scratch_bytes, hbuf, sbuf,
+        rank_data.data_ptr(), rank_data.numel() * rank_data.element_size(), rank, world), "init_custom_ar")
+    _custom_ar_live[fa.value] = (meta, rank_data)
+    return fa.value
+
+
+def _ar_check_io(inp: torch.Tensor, out: torch.Tensor):
+    _require_cuda(inp, out)
+    if inp.dtype != out.dtype or inp.numel() != out.numel():
+        raise RuntimeError("all_reduce: inp and out must have the same dtype and number of elements")
+    if inp.dtype not in _CUSTOM_AR_DT:
+        raise RuntimeError("custom allreduce only supports float32, float16 and bfloat16")
+
+
+def all_reduce_reg(fa: int, inp: torch.Tensor, out: torch.Tensor) -> None:
+    """custom_all_reduce.cu:84-92: ``inp`` is a registered buffer (or is being captured into a graph)."""
+    _ar_check_io(inp, out)
+    check(_lib.lib().aphro_custom_ar_all_reduce(fa, inp.data_ptr(), out.data_ptr(), inp.numel(), _CUSTOM_AR_DT[inp.dtype],
+                                                None, 0, _stream()), "all_reduce_reg")
+
+
+def all_reduce_unreg(fa: int, inp: torch.Tensor, reg_buffer: torch.Tensor, out: torch.Tensor) -> None:
+    """custom_all_reduce.cu:94-109: copy ``inp`` into the registered ``reg_buffer``, then reduce from there."""
+    _ar_check_io(inp, out)
+    nbytes = inp.numel() * inp.element_size()
+    if nbytes > reg_buffer.numel() * reg_buffer.element_size():
+        raise RuntimeError("registered buffer is too small to contain the input")
+    check(_lib.lib().aphro_custom_ar_all_reduce(fa, inp.data_ptr(), out.data_ptr(), inp.numel(), _CUSTOM_AR_DT[inp.dtype],
+                                                reg_buffer.data_ptr(), reg_buffer.numel() * reg_buffer.element_size(),
+                                                _stream()), "all_reduce_unreg")
+
+
+def dispose(fa: int) -> None:
+    _lib.lib().aphro_custom_ar_dispose(fa)
+    _custom_ar_live.pop(fa, None)
+
+
+def register_buffer(fa: int, t: torch.Tensor, handles: List, offsets: List[int]) -> None:
+    hbuf, obuf = _ipc_pack(handles, offsets)
+    check(_lib.lib().aphro_custom_ar_register_buffer(fa, t.data_ptr(), hbuf, obuf), "register_buffer")
+
+
+def get_graph_buffer_ipc_meta(fa: int) -> Tuple[bytes, List[int]]:
+    """(handle blob, offsets) of the buffers all-reduced while the last graph was captured: the blob is the buffers'
+    IPC handles back to back -- ``std::vector<uint8_t>`` in the reference (custom_all_reduce.cu:120-128), which its
+    caller turns into ``bytes(handle)`` (custom_all_reduce.py:232-233)."""
+    import ctypes
+    lib = _lib.lib()
+    hb = lib.aphro_ipc_handle_bytes()
+    n = ctypes.c_int()
+    check(lib.aphro_custom_ar_get_graph_buffer_ipc_meta(fa, None, None, 0, ctypes.byref(n)), "get_graph_buffer_ipc_meta")
+    count = n.value
+    if count == 0:
+        return b"", []
+    hbuf = ctypes.create_string_buffer(count * hb)
+    obuf = (ctypes.c_int64 * count)()
+    check(lib.aphro_custom_ar_get_graph_buffer_ipc_meta(fa, hbuf, obuf, count, ctypes.byref(n)), "get_graph_buffer_ipc_meta")
+    return bytes(hbuf.raw[:count * hb]), [int(o) for o in obuf]
+
+
+def register_graph_buffers(fa: int, handles: List, offsets: List[List[int]]) -> None:
+    """``handles[r]`` / ``offsets[r]``: rank r's get_graph_buffer_ipc_meta -- the handle blob (bytes; a str is taken as
+    hex or latin-1) or a list of single handles (custom_all_reduce.cu:130-137)."""
+    import ctypes
+    hb = _lib.lib().aphro_ipc_handle_bytes()
+    world = len(handles)
+    if len(offsets) != world:
+        raise RuntimeError("register_graph_buffers: handles and offsets must have one entry per rank")
+    count = len(offsets[0]) if world else 0
+    blobs = []
+    for hr, orow in zip(handles, offsets):
+        if isinstance(hr, (list, tuple)):
+            blob = b"".join(_ipc_handle_bytes(h) for h in hr)
+        elif isinstance(hr, str):
+            blob = bytes.fromhex(hr) if len(hr) == 2 * hb * len(orow) else hr.encode("latin-1")
+        else:
+            blob = bytes(hr)
+        if len(orow) != count or len(blob) != count * hb:
+            raise RuntimeError("register_graph_buffers: every rank must contribute the same number of buffers")
+        blobs.append(blob)
+    raw = b"".join(blobs)                                                        # rank-major [world][count]
+    flat = [int(o) for orow in offsets for o in orow]
+    check(_lib.lib().aphro_custom_ar_register_graph_buffers(
+        fa, ctypes.create_string_buffer(raw, max(1, len(raw))), (ctypes.c_int64 * max(1, len(flat)))(*flat), count),
+        "register_graph_buffers")
+
+
+def custom_ar_error(fa: int) -> bool:
+    """True if one of this rank's barriers timed out since the last query (bounded spin instead of a hung GPU)."""
+    return _lib.lib().aphro_custom_ar_error(fa) != 0

@@ -5,9 +5,11 @@ aphrodite/distributed/device_communicators/custom_all_reduce.py:41-300 (same con
 ``csrc/custom_all_reduce.hip`` instead of the ``_C_custom_ar`` ops the reference compiles out on ROCm.
 
 Differences that are MI355X decisions, not omissions:
-  * the signal area and the two-shot scratch are allocated by the library as uncached fine-grained
-    device memory (a torch tensor cannot be); IPC handles are taken with hipIpcGetMemHandle through
-    the C ABI, not through ``storage._share_cuda_()``;
+  * the ``meta`` buffer (signal area + two-shot scratch) is fine-grained uncached device memory wrapped in a tensor
+    (``ops.custom_ar_alloc_meta``; ``torch.zeros`` memory is coarse-grained); IPC handles are taken with
+    hipIpcGetMemHandle (``ops.ipc_handle_of``), which also works for that memory, instead of ``storage._share_cuda_()``;
+    everything else goes through the ``_C_custom_ar`` op surface of ``_custom_ops.py`` (init_custom_ar, register_buffer,
+    all_reduce_reg / _unreg, get_graph_buffer_ipc_meta, register_graph_buffers, dispose, meta_size);
   * every node pair of an MI355X box is one xGMI hop, so the reference's NVLink-topology probe
     (``is_full_nvlink``) reduces to "same node + peer access": the constructor all-gathers (hostname, boot id,
     physical device) over the CPU group and asks the runtime ``can_device_access_peer`` for every pair; if any
@@ -68,25 +70,16 @@ class CustomAllreduce:
                 import warnings
                 warnings.warn(f"custom all-reduce is disabled ({why}); tensor parallelism falls back to RCCL")
             return
-        lib = _lib.lib()
-        self._hb = lib.aphro_ipc_handle_bytes()
+        from .. import _custom_ops as ops
+        self._ops = ops
         with torch.cuda.device(device):
-            self._signal = ctypes.c_void_p()
-            check(lib.aphro_custom_ar_alloc_shared(ctypes.byref(self._signal), lib.aphro_custom_ar_meta_size()),
-                  "custom_ar_alloc_shared")
-            self._scratch = ctypes.c_void_p()
-            check(lib.aphro_custom_ar_alloc_shared(ctypes.byref(self._scratch), max_size), "custom_ar_alloc_shared")
-            # staging buffer for unregistered inputs + the table of registered buffers (device memory
-            # owned here and handed to the library, like self.buffer / self.rank_data in the reference)
+            # custom_all_reduce.py:101-120: meta = signal area + two-shot scratch, a staging buffer for unregistered
+            # inputs, the table of registered buffers -- all through the _C_custom_ar op surface (_custom_ops.py)
+            self.meta = ops.custom_ar_alloc_meta(ops.meta_size() + max_size, device)
             self.buffer = torch.empty(max_size, dtype=torch.uint8, device=device)
             self.rank_data = torch.empty(8 * 1024 * 1024, dtype=torch.uint8, device=device)
-            sh, so = self._gather_ipc_meta(self._ipc_meta(self._signal.value))
-            ch, co = self._gather_ipc_meta(self._ipc_meta(self._scratch.value))
-            fa = ctypes.c_void_p()
-            check(lib.aphro_custom_ar_init(ctypes.byref(fa), self._signal, sh, so, self._scratch, max_size, ch, co,
-                                           self.rank_data.data_ptr(), self.rank_data.numel(), rank, world_size),
-                  "custom_ar_init")
-            self._ptr = fa
+            handles, offsets = self._get_ipc_meta(self.meta)
+            self._ptr = ops.init_custom_ar(self.meta, self.rank_data, handles, offsets, rank, self.full_nvlink)
             self.disabled = False
             self.register_buffer(self.buffer)
 
@@ -115,45 +108,26 @@ class CustomAllreduce:
             return False, "a GPU pair lacks peer access"
         return True, ""
 
-    # -- IPC plumbing ------------------------------------------------------------------------------
-    def _ipc_meta(self, ptr: int) -> Tuple[bytes, int]:
-        h = ctypes.create_string_buffer(self._hb)
-        off = ctypes.c_int64()
-        check(_lib.lib().aphro_ipc_get_mem_handle(ctypes.c_void_p(ptr), h, ctypes.byref(off)), "ipc_get_mem_handle")
-        return bytes(h.raw), int(off.value)
+    # -- IPC plumbing (custom_all_reduce.py:206-245) -----------------------------------------------------
+    def _get_ipc_meta(self, inp: torch.Tensor):
+        return self._gather_ipc_meta(self._ops.ipc_handle_of(inp))
 
-    def _gather_ipc_meta(self, mine):
-        """Every rank's (handles, offsets) in group-rank order, as C arrays."""
+    def _gather_ipc_meta(self, shard_data):
+        """Every rank's (handle, offset) in group-rank order."""
         everyone: List[Optional[tuple]] = [None] * self.world_size
-        dist.all_gather_object(everyone, mine, group=self.group)
-        handles = b"".join(e[0] for e in everyone)
-        offsets = (ctypes.c_int64 * self.world_size)(*[e[1] for e in everyone])
-        return ctypes.create_string_buffer(handles, len(handles)), offsets
+        dist.all_gather_object(everyone, shard_data, group=self.group)
+        return [e[0] for e in everyone], [e[1] for e in everyone]
 
     def register_buffer(self, inp: torch.Tensor) -> None:
-        h, o = self._gather_ipc_meta(self._ipc_meta(inp.data_ptr()))
-        check(_lib.lib().aphro_custom_ar_register_buffer(self._ptr, inp.data_ptr(), h, o), "custom_ar_register_buffer")
+        handles, offsets = self._get_ipc_meta(inp)
+        self._ops.register_buffer(self._ptr, inp, handles, offsets)
 
     def register_graph_buffers(self) -> None:
-        lib = _lib.lib()
-        n = ctypes.c_int()
-        check(lib.aphro_custom_ar_get_graph_buffer_ipc_meta(self._ptr, None, None, 0, ctypes.byref(n)),
-              "custom_ar_get_graph_buffer_ipc_meta")
-        count = n.value
-        hbuf = ctypes.create_string_buffer(max(1, count * self._hb))
-        obuf = (ctypes.c_int64 * max(1, count))()
-        if count:
-            check(lib.aphro_custom_ar_get_graph_buffer_ipc_meta(self._ptr, hbuf, obuf, count, ctypes.byref(n)),
-                  "custom_ar_get_graph_buffer_ipc_meta")
-        everyone: List[Optional[tuple]] = [None] * self.world_size
-        dist.all_gather_object(everyone, (bytes(hbuf.raw[:count * self._hb]), list(obuf[:count])), group=self.group)
-        if any(len(e[1]) != count for e in everyone):
+        handle, offset = self._ops.get_graph_buffer_ipc_meta(self._ptr)
+        handles, offsets = self._gather_ipc_meta((bytes(handle), offset))
+        if any(len(o) != len(offset) for o in offsets):
             raise RuntimeError("custom all-reduce: ranks captured different numbers of graph buffers")
-        handles = b"".join(e[0] for e in everyone)                    # rank-major [world][count]
-        offsets = (ctypes.c_int64 * max(1, self.world_size * count))(*[o for e in everyone for o in e[1]])
-        check(lib.aphro_custom_ar_register_graph_buffers(
-            self._ptr, ctypes.create_string_buffer(handles, max(1, len(handles))), offsets, count),
-            "custom_ar_register_graph_buffers")
+        self._ops.register_graph_buffers(self._ptr, handles, offsets)
 
     @contextmanager
     def capture(self):
@@ -177,20 +151,17 @@ class CustomAllreduce:
             return False
         return inp_size < self.max_size
 
-    def _run(self, inp: torch.Tensor, out: Optional[torch.Tensor], staged: bool) -> torch.Tensor:
+    def all_reduce_reg(self, inp: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         if out is None:
             out = torch.empty_like(inp)
-        check(_lib.lib().aphro_custom_ar_all_reduce(
-            self._ptr, inp.data_ptr(), out.data_ptr(), inp.numel(), _DT[inp.dtype],
-            self.buffer.data_ptr() if staged else None, self.buffer.numel() if staged else 0,
-            torch.cuda.current_stream().cuda_stream), "custom_ar_all_reduce")
+        self._ops.all_reduce_reg(self._ptr, inp, out)
         return out
 
-    def all_reduce_reg(self, inp: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        return self._run(inp, out, staged=False)
-
     def all_reduce_unreg(self, inp: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        return self._run(inp, out, staged=True)
+        if out is None:
+            out = torch.empty_like(inp)
+        self._ops.all_reduce_unreg(self._ptr, inp, self.buffer, out)
+        return out
 
     def custom_all_reduce(self, input: torch.Tensor) -> Optional[torch.Tensor]:
         """None = not eligible, the caller falls back to RCCL (custom_all_reduce.py:268-289)."""
@@ -208,17 +179,15 @@ class CustomAllreduce:
 
     def check(self) -> None:
         """Raise if one of this rank's barriers timed out since the last call."""
-        if not self.disabled and _lib.lib().aphro_custom_ar_error(self._ptr) != 0:
+        if not self.disabled and self._ops.custom_ar_error(self._ptr):
             raise RuntimeError("custom all-reduce: a peer did not arrive at a barrier (results are invalid)")
 
     def close(self) -> None:
         if self._ptr:
-            lib = _lib.lib()
             torch.cuda.synchronize(self.device)
-            lib.aphro_custom_ar_dispose(self._ptr)
-            lib.aphro_custom_ar_free_shared(self._signal)
-            lib.aphro_custom_ar_free_shared(self._scratch)
+            self._ops.dispose(self._ptr)
             self._ptr = None
+            self.meta = None
             self.disabled = True
 
     def __del__(self):

@@ -145,8 +145,34 @@ _ROCM_OPS = [
 ]
 
 
+# _C_custom_ar (kernels/torch_bindings.cpp:506-536), schemas verbatim.  The tensor ops dispatch on the CUDA(HIP) key; the
+# ops without tensor arguments (dispose, meta_size, get_graph_buffer_ipc_meta, register_graph_buffers -- bound from C++
+# function signatures in the reference, :524-535) are CompositeExplicitAutograd.  IPC handles travel as ``str``: a
+# Python-implemented op receives them UTF-8 DECODED, so the only forms that survive the dispatcher are hex (128 digits)
+# and latin-1 text; callers that hold raw ``bytes`` (the reference's CustomAllreduce) call
+# ``aphrodite_engine_amd._custom_ops`` directly, exactly as they call ``aphrodite._custom_ops`` today.
+def _car_get_graph_buffer_ipc_meta(fa: int):
+    blob, offsets = ops.get_graph_buffer_ipc_meta(fa)
+    return list(blob), offsets          # std::vector<uint8_t> -> int[] (custom_all_reduce.cu:120-128)
+
+
+CUSTOM_AR_SCHEMAS = [
+    ("init_custom_ar(Tensor meta, Tensor rank_data, str[] handles, int[] offsets, int rank, bool full_nvlink) -> int",
+     ops.init_custom_ar, "CUDA"),                                                          # :510-514
+    ("all_reduce_reg(int fa, Tensor inp, Tensor! out) -> ()", ops.all_reduce_reg, "CUDA"),  # :516-517
+    ("all_reduce_unreg(int fa, Tensor inp, Tensor reg_buffer, Tensor! out) -> ()", ops.all_reduce_unreg, "CUDA"),  # :519-522
+    ("dispose(int fa) -> ()", ops.dispose, "CompositeExplicitAutograd"),                   # :524
+    ("meta_size() -> int", ops.meta_size, "CompositeExplicitAutograd"),                    # :526
+    ("register_buffer(int fa, Tensor t, str[] handles, int[] offsets) -> ()", ops.register_buffer, "CUDA"),  # :528-531
+    ("get_graph_buffer_ipc_meta(int fa) -> (int[], int[])", _car_get_graph_buffer_ipc_meta,
+     "CompositeExplicitAutograd"),                                                         # :533
+    ("register_graph_buffers(int fa, str[] handles, int[][] offsets) -> ()", ops.register_graph_buffers,
+     "CompositeExplicitAutograd"),                                                         # :535
+]
+
+
 def register(ns_c: str = "_C", ns_cache: str = "_C_cache_ops", ns_rocm: str = "_rocm_C",
-             ns_moe: str = "_moe_C") -> None:
+             ns_moe: str = "_moe_C", ns_custom_ar: Optional[str] = None) -> None:
     """Idempotent.  Pass other namespaces to avoid clashing with an already
     loaded ``aphrodite._C`` (e.g. in A/B comparisons)."""
     global _REGISTERED
@@ -168,4 +194,9 @@ def register(ns_c: str = "_C", ns_cache: str = "_C_cache_ops", ns_rocm: str = "_
                 lib.define(GPTQ_MARLIN_GEMM_SCHEMAS[1])
             lib.impl("gptq_marlin_gemm", _gptq_marlin_gemm, "CUDA")
         _LIBS.append(lib)
+    lib = torch.library.Library(ns_custom_ar or ns_c + "_custom_ar", "FRAGMENT")
+    for schema, fn, key in CUSTOM_AR_SCHEMAS:
+        lib.define(schema)
+        lib.impl(schema.split("(", 1)[0], fn, key)
+    _LIBS.append(lib)
     _REGISTERED = True

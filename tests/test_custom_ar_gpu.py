@@ -119,6 +119,89 @@ def test_custom_all_reduce_ranks_on_one_gpu(world):
     _spawn(_ar_worker, world)
 
 
+def _schema_worker(rank, world, port):
+    """The `_C_custom_ar::*` ops as torch.library ops (kernels/torch_bindings.cpp:506-536), driven the way the
+    reference's CustomAllreduce drives them (custom_all_reduce.py:101-120, 206-289); IPC handles travel as hex str."""
+    import torch.distributed as dist
+    from aphrodite_engine_amd import _custom_ops as ops
+    from aphrodite_engine_amd import torch_ops
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    torch_ops.register("_sC", "_sC_cache_ops", "_s_rocm_C", "_s_moe_C")
+    car = torch.ops._sC_custom_ar
+
+    def gather(shard):
+        everyone = [None] * world
+        dist.all_gather_object(everyone, shard)
+        return [e[0] for e in everyone], [e[1] for e in everyone]
+
+    max_size = 2 * 1024 * 1024
+    assert car.meta_size() == ops.meta_size() > 0
+    meta = ops.custom_ar_alloc_meta(car.meta_size() + max_size, dev)
+    assert meta.dtype == torch.uint8 and int(meta.sum()) == 0
+    rank_data = torch.empty(1024 * 1024, dtype=torch.uint8, device=dev)
+    buffer = torch.empty(max_size, dtype=torch.uint8, device=dev)
+    h, o = ops.ipc_handle_of(meta)
+    handles, offsets = gather((h.hex(), o))
+    fa = car.init_custom_ar(meta, rank_data, handles, offsets, rank, True)
+    try:
+        h, o = ops.ipc_handle_of(buffer)
+        handles, offsets = gather((h.hex(), o))
+        car.register_buffer(fa, buffer, handles, offsets)
+        gen = torch.Generator(device="cpu")
+        for dtype, numel in [(torch.float16, 32 * 4096), (torch.bfloat16, 64 * 8192), (torch.float32, 4096)]:
+            parts = []
+            for r in range(world):
+                gen.manual_seed(77 * r + numel)
+                parts.append((torch.randn(numel, generator=gen) * 3).to(dtype))
+            want = _expected(parts, dtype)
+            x = parts[rank].to(dev)
+            out = torch.empty_like(x)
+            for _ in range(3):
+                car.all_reduce_unreg(fa, x, buffer, out)          # staged through the registered buffer
+                torch.cuda.synchronize()
+                assert not ops.custom_ar_error(fa)
+                assert torch.equal(out.cpu(), want)
+            # the registered buffer itself as the input
+            view = buffer[:numel * x.element_size()].view(dtype)
+            view.copy_(x)
+            out.zero_()
+            car.all_reduce_reg(fa, view, out)
+            torch.cuda.synchronize()
+            assert torch.equal(out.cpu(), want)
+        # graph capture: the captured input is registered afterwards through the two meta ops
+        a = torch.empty(16 * 4096, dtype=torch.float16, device=dev)
+        oa = torch.empty_like(a)
+        g = torch.cuda.CUDAGraph()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s), torch.cuda.graph(g, stream=s):
+            car.all_reduce_reg(fa, a, oa)
+        blob, offs = car.get_graph_buffer_ipc_meta(fa)
+        assert len(offs) == 1 and len(blob) == len(h)
+        hs, os_ = gather((bytes(blob).hex(), offs))
+        car.register_graph_buffers(fa, hs, os_)
+        for it in range(3):
+            a.fill_(rank + it)
+            torch.cuda.synchronize()
+            dist.barrier()
+            g.replay()
+            torch.cuda.synchronize()
+            assert float(oa[7]) == sum(r + it for r in range(world))
+            dist.barrier()
+    finally:
+        torch.cuda.synchronize()
+        car.dispose(fa)
+        dist.destroy_process_group()
+
+
+def test_custom_ar_schema_ops_two_ranks():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    _spawn(_schema_worker, 2)
+
+
 def _tp_model_worker(rank, world, port):
     """TP = 2 decode with the peer-access all-reduce in the loop == the same model over gloo."""
     import torch.distributed as dist
