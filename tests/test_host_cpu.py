@@ -216,6 +216,25 @@ def test_torch_library_registration():
                                        torch.empty(0, dtype=torch.int32), True, 4)
 
 
+def test_cpp_torch_library_registration():
+    """INTEGRATION.md option 3 as real code: csrc_torch/torch_bindings.cpp registers ops from C++ (TORCH_LIBRARY_FRAGMENT)
+    with the same schemas as the Python registration; it loads without a GPU and has no CPU kernels."""
+    from aphrodite_engine_amd import torch_cpp, torch_ops
+    torch_cpp.load()
+    torch_ops.register("_aphro_t_C", "_aphro_t_cache", "_aphro_t_rocm")         # idempotent (registered above)
+    py_ns = [ns for ns in ("_aphro_t_C", "_aphro_g_C", "_C") if hasattr(torch.ops, ns) and hasattr(getattr(torch.ops, ns), "gptq_gemm")]
+    strip = lambda sch: str(sch).split("::", 1)[1]
+    for name in ("gptq_gemm", "paged_attention_v1", "cutlass_scaled_mm"):
+        cpp = getattr(torch.ops._C_mi355x, name).default._schema
+        assert py_ns, "python registration missing"
+        assert strip(cpp) == strip(getattr(getattr(torch.ops, py_ns[0]), name).default._schema), name
+    assert "reshape_and_cache(Tensor key, Tensor value" in str(torch.ops._C_mi355x_cache_ops.reshape_and_cache.default._schema)
+    with pytest.raises((RuntimeError, NotImplementedError)):
+        torch.ops._C_mi355x.gptq_gemm(torch.zeros(1, 64, dtype=torch.half), torch.zeros(8, 16, dtype=torch.int32),
+                                      torch.zeros(1, 2, dtype=torch.int32), torch.zeros(1, 16, dtype=torch.half),
+                                      torch.empty(0, dtype=torch.int32), True, 4)
+
+
 def test_quant_configs_dispatch_on_layer_family():
     """The reference asks every Attention / FusedMoE / embedding layer for a quant method too (attention/
     layer.py:60-75 asserts a BaseKVCacheMethod): a config must answer by layer family, not always with a

@@ -219,3 +219,59 @@ def test_schema_gptq_marlin_gemm(T):
     got = out.float().cpu().numpy()
     assert np.abs(got - ref).mean() / np.abs(ref).mean() < 0.04            # tests/kernels/test_marlin_gemm.py:57-59
     np.testing.assert_allclose(got, ref, rtol=2e-3, atol=2e-3 * np.abs(ref).max())
+
+
+def test_cpp_registered_ops_match_the_python_registration(T):
+    """The ops registered from C++ (csrc_torch/torch_bindings.cpp, INTEGRATION.md option 3) give the same bits as the
+    Python-registered ones (same C ABI underneath), decode- and prefill-sized, also under HIP-graph capture."""
+    from aphrodite_engine_amd import torch_cpp
+    torch_cpp.load()
+    C, cache = torch.ops._C_mi355x, torch.ops._C_mi355x_cache_ops
+    rng = np.random.default_rng(11)
+    # gptq_gemm: M = 32 (decode kernel), 300 (prefill-sized MFMA kernel), act-order at 300
+    K, N, G = 1024, 512, 128
+    qw, qz, s_ = make_gptq(rng, K, N, G)
+    shuf = t(qw.copy())
+    empty = torch.empty(0, dtype=torch.int32, device=DEV)
+    T.C.gptq_shuffle(shuf, empty, 4)
+    qz_d, s_d = t(qz), t(s_)
+    for M in (32, 300):
+        a = t(rng.standard_normal((M, K)).astype(np.float16))
+        want = T.C.gptq_gemm(a, shuf, qz_d, s_d, empty, True, 4)
+        _, got = captured(lambda: C.gptq_gemm(a, shuf, qz_d, s_d, empty, True, 4))
+        assert torch.equal(got, want)
+    # cutlass_scaled_mm: M = 40 and 200
+    for M in (40, 200):
+        K2, N2 = 512, 256
+        a8 = t((rng.standard_normal((M, K2)) * 2).astype(np.float32)).to(torch.float8_e4m3fn)
+        w8 = t((rng.standard_normal((N2, K2)) * 2).astype(np.float32)).to(torch.float8_e4m3fn)
+        sa = t((rng.random((M, 1)) * 0.1 + 0.01).astype(np.float32))
+        sb = t((rng.random((N2, 1)) * 0.1 + 0.01).astype(np.float32))
+        bias = t(rng.standard_normal(N2).astype(np.float32), torch.bfloat16)
+        want = torch.empty(M, N2, dtype=torch.bfloat16, device=DEV)
+        got = torch.empty_like(want)
+        T.C.cutlass_scaled_mm(want, a8, w8.t(), sa, sb, bias)
+        C.cutlass_scaled_mm(got, a8, w8.t(), sa, sb, bias)
+        assert torch.equal(got, want)
+    # cache write + decode attention
+    S, Hq, Hkv, D, BS = 3, 8, 2, 128, 16
+    seq_lens = np.array([5, 130, 600], np.int32)
+    bps = (int(seq_lens.max()) + BS - 1) // BS
+    NB = S * bps
+    kc = (torch.randn(NB, Hkv, D // 8, BS, 8, device=DEV) * 0.3).half()
+    vc = (torch.randn(NB, Hkv, D, BS, device=DEV) * 0.3).half()
+    kc2, vc2 = kc.clone(), vc.clone()
+    bt = rng.permutation(NB).reshape(S, bps).astype(np.int32)
+    k = t((rng.standard_normal((S, Hkv, D)) * 0.3).astype(np.float16))
+    v = t((rng.standard_normal((S, Hkv, D)) * 0.3).astype(np.float16))
+    slots = t(np.array([bt[i, (seq_lens[i] - 1) // BS] * BS + (seq_lens[i] - 1) % BS for i in range(S)], np.int64))
+    T.cache.reshape_and_cache(k, v, kc, vc, slots, "auto", 1.0, 1.0)
+    cache.reshape_and_cache(k, v, kc2, vc2, slots, "auto", 1.0, 1.0)
+    assert torch.equal(kc, kc2) and torch.equal(vc, vc2)
+    q = t(rng.standard_normal((S, Hq, D)).astype(np.float32), torch.float16)
+    common = (q, kc, vc, Hkv, float(D ** -0.5), t(bt), t(seq_lens), BS, int(seq_lens.max()), None, "auto", 1.0, 1.0, 0, 0, 0, 64, 0)
+    want = torch.empty(S, Hq, D, dtype=torch.float16, device=DEV)
+    got = torch.empty_like(want)
+    T.C.paged_attention_v1(want, *common)
+    captured(lambda: C.paged_attention_v1(got, *common))
+    assert torch.equal(got, want)
