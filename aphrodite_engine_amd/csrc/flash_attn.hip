@@ -29,6 +29,7 @@ struct FAParams {
   int64_t q_stride, k_stride, v_stride;
   float scale;
   int causal;
+  int debug;
 };
 
 template <typename T>
@@ -441,6 +442,305 @@ __global__ __launch_bounds__(NWV * 64) void flash_attn_varlen_v2_kernel(FAParams
 }
 
 // ---------------------------------------------------------------------------
+// Third-generation prefill kernel (hd 128, sequences >= 1024): 8 waves x 32 query rows = 256 rows per workgroup,
+// 64-key tiles, 32x32x16 MFMA.  VERDICT r1 #6: the second-generation kernel is VALU-issue bound at 7.4 VALU per
+// 16x16x32 MFMA; this one spends ~150 VALU per 32 MFMAs of 32 cycles:
+//   * swapped QK^T on 32x32 tiles (S^T = K . Q^T): a lane holds 32 of the 64 scores of ONE query row, so the row
+//     maximum / sum are 31 lane-local ops + one half-wave exchange (v_permlane32_swap), no LDS;
+//   * softmax in the log2 domain straight off the accumulators: p = exp2(fma(s, scale*log2e, -m)), 2 VALU per score;
+//   * P -> 16-bit with packed hardware converts, redistributed into PV B-operand fragments by 8 permlane32_swap per
+//     32 keys (the MFMA C layout interleaves the two half-waves' keys in groups of 4);
+//   * K and V tiles go global -> LDS with direct-to-LDS loads (no VGPR round trip, no address VALU in the loop),
+//     a 4-deep ring, one barrier per tile.  The LDS image is chosen on the SOURCE side (lane L of a 1 KiB piece
+//     fetches whatever must live at byte 16 L): K rows XOR-swizzled by key & 15 for conflict-free ds_read_b128
+//     fragments; V in [16-byte d-chunk][4 keys] order inside each 4-key piece, which makes every
+//     ds_read_b64_tr_b16 (transposing read: 4 keys of one d per lane) of a PV A-operand hit 64 distinct banks;
+//   * O leaves through a wave-private LDS transpose as full 256-byte rows.
+// Keys beyond the sequence are fetched as zeros by the buffer descriptor's bounds check.
+// ---------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) void* fa_lds_ptr;
+// lab (APHRO_FA_DEBUG=1): s_memtime stamps of the heaviest workgroup's waves, read back with aphro_fa_debug_dump
+__device__ unsigned long long fa_dbg[8 * 64];
+#define FA_STAMP(slot) if ((p.debug & 1) && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) fa_dbg[wave * 64 + (slot)] = __builtin_amdgcn_s_memtime();
+
+template <typename T>
+__device__ __forceinline__ f32x16 fa_mfma32(u32x4 a, u32x4 b, f32x16 c) {
+  if constexpr (__is_same(T, Half))
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+template <typename T>
+__global__ __launch_bounds__(512) void flash_attn_varlen_v3_kernel(FAParams p) {
+  constexpr int HD = 128, BM = 256, BN = 64;
+  constexpr bool BF = __is_same(T, BFloat);
+  constexpr int KT = BN * HD * 2;           // bytes of one K (or V) tile: 16 KiB
+  constexpr int STAGE = 2 * KT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char fa_smem[];   // ring of 4 x [K tile | V tile]
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int kh = lane >> 5, l31 = lane & 31;
+  const int head = blockIdx.y, seq = blockIdx.z;
+  const int kvh = head / (p.num_heads / p.num_kv_heads);
+  const int s0 = p.cu_seqlens[seq];
+  const int len = p.cu_seqlens[seq + 1] - s0;
+  const int nqt = (len + BM - 1) / BM;
+  const int qt = nqt - 1 - (int)blockIdx.x;   // heavy (late) tiles first
+  if (qt < 0) return;
+  const int q0 = qt * BM;
+  const int wq0 = q0 + 32 * wave;
+  const int qrow = wq0 + l31;
+
+  // ---- Q fragments (B operand of S^T = K . Q^T): lane (q = l31, kh) holds d = 16 ks + 8 kh .. + 7 ----------------------
+  u32x4 qf[8];
+  {
+    const uint16_t* qp = (const uint16_t*)p.q + (size_t)(s0 + min(qrow, len - 1)) * p.q_stride + (size_t)head * HD + 8 * kh;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const u32x4*>(qp + 16 * ks);
+  }
+  const float slope2 = (p.alibi ? p.alibi[head] : 0.f) * 1.44269504088896f;
+  const float c2 = p.scale * 1.44269504088896f;
+
+  // ---- K / V staging: buffer descriptors over this sequence's rows of this kv head (reads past the end return 0) -------
+  const uint16_t* kbase = (const uint16_t*)p.k + (size_t)s0 * p.k_stride + (size_t)kvh * HD;
+  const uint16_t* vbase = (const uint16_t*)p.v + (size_t)s0 * p.v_stride + (size_t)kvh * HD;
+  const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(kbase), 0,
+      (uint32_t)(((size_t)(len - 1) * p.k_stride + HD) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(vbase), 0,
+      (uint32_t)(((size_t)(len - 1) * p.v_stride + HD) * 2), 0x00020000);
+  // a wave stages pieces 2 wave, 2 wave + 1 (4 keys = 1 KiB each) of both tiles.
+  // K piece: lane L -> key 4 c + (L >> 4), LDS slot L & 15 holds d-chunk slot ^ (key & 15)
+  // V piece: lane L -> key 4 c + (L & 3), d-chunk L >> 2  (image [d-chunk][key] inside the piece)
+  int k_voff[2], v_voff[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int c = 2 * wave + j;
+    const int kk = 4 * c + (lane >> 4);
+    k_voff[j] = (int)(kk * p.k_stride * 2) + (((lane & 15) ^ (kk & 15)) << 4);
+    const int vk = 4 * c + (lane & 3);
+    v_voff[j] = (int)(vk * p.v_stride * 2) + ((lane >> 2) << 4);
+  }
+  auto stage = [&](int buf, int t0) {
+    unsigned char* sk = fa_smem + buf * STAGE;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int kv = k_voff[j], vv = v_voff[j];     // (local copies: see wna16_gemm_large.hip on the hipcc host-stub bug)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (fa_lds_ptr)(sk + (2 * wave + j) * 1024), 16, kv, (int)(t0 * p.k_stride * 2), 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (fa_lds_ptr)(sk + KT + (2 * wave + j) * 1024), 16, vv, (int)(t0 * p.v_stride * 2), 0, 0);
+    }
+  };
+  // fragment read addresses (lane-invariant parts)
+  //  K: key = 32 b + l31, d-chunk 2 ks + kh -> l31 * 256 + (((2 ks + kh) ^ (l31 & 15)) << 4) = kaddr ^ (ks << 5)
+  const int kaddr = l31 * 256 + ((kh ^ (l31 & 15)) << 4);
+  //  V (transposing read; 16-lane group g, lane i of it): piece 4 ks + 2 kh + h, key i >> 2 of it,
+  //  d = 32 db + 16 (g & 1) + 4 (i & 3)
+  const int vaddr = KT + (2 * kh) * 1024 + ((((2 * ((lane >> 4) & 1) + ((lane & 3) >> 1)) * 4 + ((lane & 15) >> 2)) << 4)) + ((lane & 1) << 3);
+
+  f32x16 o[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+  float m_run = -1e30f, l_run = 0.f;          // log2-domain running maximum; this lane's share of the row sum
+
+  const int kv_end = p.causal ? min(len, q0 + BM) : len;
+  const int ntile = (kv_end + BN - 1) / BN;
+  f32x16 sacc[2];
+
+  // ---- the two halves of a tile ------------------------------------------------------------------------------------------
+  // S^T = K . Q^T : lane (q = l31) gets keys 32 b + 8 (r >> 2) + 4 kh + (r & 3)
+  auto do_qk = [&](int it) __attribute__((always_inline)) {
+    const int t0 = it * BN;
+    if (p.causal && t0 > wq0 + 31) return;               // wave-uniform: the whole tile is masked for these rows
+    const int nb = (p.causal && t0 + 32 > wq0 + 31) ? 1 : 2;   // 32-key blocks with at least one live key
+    const unsigned char* sk = fa_smem + (it & 3) * STAGE;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[b][r] = 0.f;
+      if (b < nb) {
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+          const u32x4 kf = *reinterpret_cast<const u32x4*>(sk + b * 8192 + (kaddr ^ (ks << 5)));
+          sacc[b] = fa_mfma32<T>(kf, qf[ks], sacc[b]);
+        }
+      }
+    }
+  };
+  // online softmax (log2 domain) on sacc, then O^T += V^T . P^T
+  auto do_sm_pv = [&](int it) __attribute__((always_inline)) {
+    const int t0 = it * BN;
+    if (p.causal && t0 > wq0 + 31) return;
+    const int nb = (p.causal && t0 + 32 > wq0 + 31) ? 1 : 2;
+    const unsigned char* sk = fa_smem + (it & 3) * STAGE;
+    const bool edge = (t0 + BN > len) || (p.causal && t0 + BN - 1 > wq0) || slope2 != 0.f;
+    float mx = -1e30f;
+    if (edge) {
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = t0 + 32 * b + 8 * (r >> 2) + 4 * kh + (r & 3);
+          float x = sacc[b][r] * c2 + slope2 * (float)(key - qrow);
+          const bool ok = b < nb && key < len && (!p.causal || key <= qrow);
+          x = ok ? x : -1e30f;
+          sacc[b][r] = x;
+          mx = __builtin_fmaxf(mx, x);
+        }
+    } else {
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = __builtin_fmaxf(mx, sacc[b][r]);
+      mx *= c2;                                    // scale > 0: the maximum commutes with it
+    }
+    {
+      const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, mx), __builtin_bit_cast(unsigned, mx), false, false);
+      mx = __builtin_fmaxf(__builtin_bit_cast(float, (unsigned)sw[0]), __builtin_bit_cast(float, (unsigned)sw[1]));
+    }
+    const float m_new = __builtin_fmaxf(m_run, mx);
+    const bool moved = m_new != m_run;
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    m_run = m_new;
+    float lsum = 0.f;
+    if (edge) {
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float e = __builtin_amdgcn_exp2f(sacc[b][r] - m_new);
+          e = sacc[b][r] > -1e29f ? e : 0.f;
+          sacc[b][r] = e;
+          lsum += e;
+        }
+    } else {
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[b][r], c2, -m_new));
+          sacc[b][r] = e;
+          lsum += e;
+        }
+    }
+    l_run = l_run * alpha + lsum;
+    if (__builtin_amdgcn_ballot_w64(moved) != 0) {
+#pragma unroll
+      for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+    }
+    // P^T fragments: k-slot 2 b + j holds tile keys 32 b + 16 j + 8 kh .. + 7 of row q = l31
+    u32x4 pf[4];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int g0 = 8 * j, g1 = 8 * j + 4;       // accumulator quads 2 j and 2 j + 1
+        uint32_t lo0 = pack2_16<BF>(sacc[b][g0], sacc[b][g0 + 1]), hi0 = pack2_16<BF>(sacc[b][g0 + 2], sacc[b][g0 + 3]);
+        uint32_t lo1 = pack2_16<BF>(sacc[b][g1], sacc[b][g1 + 1]), hi1 = pack2_16<BF>(sacc[b][g1 + 2], sacc[b][g1 + 3]);
+        const auto s_lo = __builtin_amdgcn_permlane32_swap(lo0, lo1, false, false);
+        const auto s_hi = __builtin_amdgcn_permlane32_swap(hi0, hi1, false, false);
+        pf[2 * b + j] = u32x4{(uint32_t)s_lo[0], (uint32_t)s_hi[0], (uint32_t)s_lo[1], (uint32_t)s_hi[1]};
+      }
+    // O^T += V^T . P^T : A fragment of (d block db, k-slot ks) = two transposing reads
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      if (ks < 2 * nb) {
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+          const unsigned char* vb = sk + vaddr + (4 * ks) * 1024 + db * 256;
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)vb);
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(vb + 1024));
+          const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+          o[db] = fa_mfma32<T>(u32x4{l2[0], l2[1], h2[0], h2[1]}, pf[ks], o[db]);
+        }
+      }
+    }
+  };
+  // top of iteration `it`: this wave's pieces of tile `it` have landed (the pieces of tile it + 1 may still be in flight);
+  // the barrier publishes everyone's and frees ring slot (it + 2) & 3 -- tile it - 2, which even the trailing half of the
+  // workgroup (below) finished before it arrived here
+  auto tile_top = [&](int it) __attribute__((always_inline)) {
+    if (it == 40) { FA_STAMP(8) }
+    if (it + 1 < ntile) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (it == 40) { FA_STAMP(9) }
+    __builtin_amdgcn_s_barrier();
+    if (it == 40) { FA_STAMP(10) }
+    if (it + 2 < ntile) stage((it + 2) & 3, (it + 2) * BN);
+    if (it == 40) { FA_STAMP(11) }
+  };
+
+  stage(0, 0);
+  if (ntile > 1) stage(1, BN);
+  FA_STAMP(0)
+  // The two waves of a SIMD (w and w + 4) run half a tile apart: waves 0-3 do QK^T, softmax, PV between two barriers,
+  // waves 4-7 do softmax, PV of the PREVIOUS tile and then QK^T of this one -- so one wave's softmax (VALU) runs beside
+  // the other's MFMAs instead of both fighting for the matrix pipe and then both for the VALU (measured in lockstep:
+  // QK^T 1280 + softmax 1224 + PV 1032 cycles per tile, no overlap at all).  A 4-deep ring makes it legal: the trailing
+  // half still reads tile it - 1 while tile it + 2 is being written.
+  const bool trail = (p.debug & 2) ? (wave & 1) : (p.debug & 4) ? ((wave >> 1) & 1) : (wave >= 4);
+  if (!trail) {
+    for (int it = 0; it < ntile; ++it) {
+      if (it == 32) { FA_STAMP(1) }
+      if (it == 64) { FA_STAMP(2) }
+      tile_top(it);
+      if (it == 40) { FA_STAMP(3) }
+      do_qk(it);
+      if (it == 40) { FA_STAMP(4) }
+      do_sm_pv(it);
+      if (it == 40) { FA_STAMP(6) }
+    }
+  } else {
+    tile_top(0);
+    do_qk(0);
+    for (int it = 1; it < ntile; ++it) {
+      if (it == 32) { FA_STAMP(1) }
+      if (it == 64) { FA_STAMP(2) }
+      tile_top(it);
+      if (it == 40) { FA_STAMP(3) }
+      do_sm_pv(it - 1);
+      if (it == 40) { FA_STAMP(4) }
+      do_qk(it);
+      if (it == 40) { FA_STAMP(6) }
+    }
+    do_sm_pv(ntile - 1);
+  }
+  FA_STAMP(7)
+  __syncthreads();                                         // every wave is done with the K / V buffers
+
+  // ---- normalise, transpose through LDS (wave-private 8 KiB: 32 rows x 256 B), store whole rows -----------------------------
+  float l = l_run;
+  {
+    const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, l), __builtin_bit_cast(unsigned, l), false, false);
+    l = __builtin_bit_cast(float, (unsigned)sw[0]) + __builtin_bit_cast(float, (unsigned)sw[1]);
+  }
+  const float inv = l > 0.f ? 1.f / l : 0.f;
+  unsigned char* region = fa_smem + wave * 8192;
+#pragma unroll
+  for (int db = 0; db < 4; ++db)
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      // d = 32 db + 8 g4 + 4 kh .. + 3  ->  8-byte chunk c8 = 8 db + 2 g4 + kh of row l31; 16-byte chunk XOR (row & 15)
+      const int c8 = 8 * db + 2 * g4 + kh;
+      const u32x2 v = {pack2_16<BF>(o[db][4 * g4] * inv, o[db][4 * g4 + 1] * inv),
+                       pack2_16<BF>(o[db][4 * g4 + 2] * inv, o[db][4 * g4 + 3] * inv)};
+      *reinterpret_cast<u32x2*>(region + l31 * 256 + ((c8 ^ ((l31 & 15) << 1)) << 3)) = v;
+    }
+  uint16_t* obase = (uint16_t*)p.out + ((size_t)(s0 + wq0) * p.num_heads + head) * HD;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int row = i * 4 + (lane >> 4), c16 = lane & 15;
+    const u32x4 v = *reinterpret_cast<const u32x4*>(region + row * 256 + ((c16 ^ (row & 15)) << 4));
+    if (wq0 + row < len) *reinterpret_cast<u32x4*>(obase + (size_t)row * p.num_heads * HD + c16 * 8) = v;
+  }
+}
+
+// ---------------------------------------------------------------------------
 // Prefill WITH cached context (the context_attention_fwd role,
 // aphrodite/attention/ops/prefix_prefill.py:696-858, kernel :58-255): every new
 // token attends to the sequence's cached context, read from the PAGED KV cache
@@ -689,7 +989,24 @@ extern "C" int aphro_flash_attn_varlen(void* out, const void* q, const void* k, 
   p.out = out; p.q = q; p.k = k; p.v = v; p.cu_seqlens = cu_seqlens; p.alibi = alibi_slopes;
   p.num_heads = num_heads; p.num_kv_heads = num_kv_heads;
   p.q_stride = q_stride; p.k_stride = k_stride; p.v_stride = v_stride;
-  p.scale = scale; p.causal = causal;
+  p.scale = scale; p.causal = causal; p.debug = getenv("APHRO_FA_DEBUG") ? atoi(getenv("APHRO_FA_DEBUG")) : 0;
+  // third-generation kernel (256-row workgroups on 32x32 MFMA tiles): head 128, long sequences
+  if (head_size == 128 && max_seqlen >= 1024 && !getenv("APHRO_FA_NO_V3")) {
+    dim3 grid3((unsigned)((max_seqlen + 255) / 256), (unsigned)num_heads, (unsigned)batch);
+    static bool attr_set = false;
+    if (!attr_set) {
+      if (hipFuncSetAttribute((const void*)flash_attn_varlen_v3_kernel<Half>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072) != hipSuccess ||
+          hipFuncSetAttribute((const void*)flash_attn_varlen_v3_kernel<BFloat>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072) != hipSuccess) {
+        set_error("flash_attn_varlen: cannot raise the dynamic LDS limit");
+        return APHRO_ERR_LAUNCH;
+      }
+      attr_set = true;
+    }
+    if (dtype == APHRO_F16) hipLaunchKernelGGL((flash_attn_varlen_v3_kernel<Half>), grid3, dim3(512), 131072, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((flash_attn_varlen_v3_kernel<BFloat>), grid3, dim3(512), 131072, (hipStream_t)stream, p);
+    APHRO_LAUNCH_CHECK();
+    return APHRO_OK;
+  }
   // two 16-row query tiles per wave (128-row workgroups) once the sequences are long enough to
   // fill the chip with them; head 256 keeps one tile (registers)
   const int qt = (max_seqlen >= 512 && head_size <= 128 && !getenv("APHRO_FA_QT1")) ? 2 : 1;
@@ -716,4 +1033,10 @@ extern "C" int aphro_flash_attn_varlen(void* out, const void* q, const void* k, 
 #undef FA_L
   APHRO_LAUNCH_CHECK();
   return APHRO_OK;
+}
+
+// lab: copy the stamp buffer of the third-generation prefill kernel to the host
+extern "C" int aphro_fa_debug_dump(unsigned long long* host_out, int n) {
+  if (n > 8 * 64) n = 8 * 64;
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(aphro::fa_dbg), (size_t)n * 8) == hipSuccess ? APHRO_OK : APHRO_ERR_LAUNCH;
 }
