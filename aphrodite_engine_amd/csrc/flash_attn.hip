@@ -30,6 +30,7 @@ struct FAParams {
   float scale;
   int causal;
   int debug;
+  int nqt_max, xcd_remap;   // third-generation kernel: query tiles per sequence in the grid; kv-head -> XCD placement
 };
 
 template <typename T>
@@ -451,7 +452,7 @@ __global__ __launch_bounds__(NWV * 64) void flash_attn_varlen_v2_kernel(FAParams
 //   * P -> 16-bit with packed hardware converts, redistributed into PV B-operand fragments by 8 permlane32_swap per
 //     32 keys (the MFMA C layout interleaves the two half-waves' keys in groups of 4);
 //   * K and V tiles go global -> LDS with direct-to-LDS loads (no VGPR round trip, no address VALU in the loop),
-//     a 4-deep ring, one barrier per tile.  The LDS image is chosen on the SOURCE side (lane L of a 1 KiB piece
+//     a 3-deep ring, one barrier per tile; the next tile's QK^T shares a straight-line block with this tile's softmax.  The LDS image is chosen on the SOURCE side (lane L of a 1 KiB piece
 //     fetches whatever must live at byte 16 L): K rows XOR-swizzled by key & 15 for conflict-free ds_read_b128
 //     fragments; V in [16-byte d-chunk][4 keys] order inside each 4-key piece, which makes every
 //     ds_read_b64_tr_b16 (transposing read: 4 keys of one d per lane) of a PV A-operand hit 64 distinct banks;
@@ -462,7 +463,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) void* fa_lds_ptr;
 // lab (APHRO_FA_DEBUG=1): s_memtime stamps of the heaviest workgroup's waves, read back with aphro_fa_debug_dump
 __device__ unsigned long long fa_dbg[8 * 64];
-#define FA_STAMP(slot) if ((p.debug & 1) && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) fa_dbg[wave * 64 + (slot)] = __builtin_amdgcn_s_memtime();
+#define FA_STAMP(slot) if ((p.debug & 1) && blockIdx.x == 0 && lane == 0) fa_dbg[wave * 64 + (slot)] = __builtin_amdgcn_s_memtime();
 
 template <typename T>
 __device__ __forceinline__ f32x16 fa_mfma32(u32x4 a, u32x4 b, f32x16 c) {
@@ -478,28 +479,49 @@ __global__ __launch_bounds__(512) void flash_attn_varlen_v3_kernel(FAParams p) {
   constexpr bool BF = __is_same(T, BFloat);
   constexpr int KT = BN * HD * 2;           // bytes of one K (or V) tile: 16 KiB
   constexpr int STAGE = 2 * KT;
-  extern __shared__ __attribute__((aligned(16))) unsigned char fa_smem[];   // ring of 4 x [K tile | V tile]
+  extern __shared__ __attribute__((aligned(16))) unsigned char fa_smem[];   // ring of 3 x [K tile | V tile], then 8 x 8 KiB of Q fragments
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int kh = lane >> 5, l31 = lane & 31;
-  const int head = blockIdx.y, seq = blockIdx.z;
+  // ---- which (sequence, head, 256-row query tile) is this workgroup -------------------------------------------------------
+  // Workgroup b runs on XCD b % 8 (round-robin dispatch).  All query heads of ONE kv head, and all their query tiles, go
+  // to the same XCD and walk the K/V tiles from key 0 upwards roughly in step: a K/V tile is pulled into that XCD's
+  // 4 MiB L2 once and the other workgroups hit it (K + V of one kv head at 8192 tokens = 4 MiB).  With the plain
+  // (tile, head, sequence) grid every XCD streamed every kv head: the staging alone ran at the 6 TB/s MALL/HBM rate and
+  // cost 0.37 of 1.06 ms at T = 8192 (tools/fa_lab.hip).  Within an XCD: heavy (late) query tiles first.
+  int head, seq, qt_rev;
+  {
+    const int G = p.num_heads / p.num_kv_heads;
+    const int per_group = G * p.nqt_max;                  // workgroups of one (sequence, kv head)
+    const int b = blockIdx.x;
+    int group, r;
+    if (p.xcd_remap) { group = (b % 8) + 8 * ((b / 8) / per_group); r = (b / 8) % per_group; }
+    else { group = b / per_group; r = b % per_group; }
+    seq = group / p.num_kv_heads;
+    head = (group % p.num_kv_heads) * G + r % G;
+    qt_rev = r / G;
+  }
   const int kvh = head / (p.num_heads / p.num_kv_heads);
   const int s0 = p.cu_seqlens[seq];
   const int len = p.cu_seqlens[seq + 1] - s0;
   const int nqt = (len + BM - 1) / BM;
-  const int qt = nqt - 1 - (int)blockIdx.x;   // heavy (late) tiles first
+  const int qt = nqt - 1 - qt_rev;            // heavy (late) tiles first
   if (qt < 0) return;
   const int q0 = qt * BM;
   const int wq0 = q0 + 32 * wave;
   const int qrow = wq0 + l31;
 
-  // ---- Q fragments (B operand of S^T = K . Q^T): lane (q = l31, kh) holds d = 16 ks + 8 kh .. + 7 ----------------------
-  u32x4 qf[8];
+  // ---- Q fragments (B operand of S^T = K . Q^T): lane (q = l31, kh) holds d = 16 ks + 8 kh .. + 7.  They live in LDS, not
+  // in 32 VGPRs: the lane that wrote a fragment is the one that reads it back (8 ds_read_b128 per tile), which is what
+  // lets two score tiles + the output accumulators + the P fragments fit in 256 registers without spills.
+  unsigned char* qlds = fa_smem + 3 * STAGE + wave * 8192;
+  const int qaddr = l31 * 256 + ((kh ^ (l31 & 15)) << 4);          // chunk 2 ks + kh of row l31, XOR-swizzled like K
   {
     const uint16_t* qp = (const uint16_t*)p.q + (size_t)(s0 + min(qrow, len - 1)) * p.q_stride + (size_t)head * HD + 8 * kh;
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const u32x4*>(qp + 16 * ks);
+    for (int ks = 0; ks < 8; ++ks)
+      *reinterpret_cast<u32x4*>(qlds + (qaddr ^ (ks << 5))) = *reinterpret_cast<const u32x4*>(qp + 16 * ks);
   }
   const float slope2 = (p.alibi ? p.alibi[head] : 0.f) * 1.44269504088896f;
   const float c2 = p.scale * 1.44269504088896f;
@@ -548,167 +570,171 @@ __global__ __launch_bounds__(512) void flash_attn_varlen_v3_kernel(FAParams p) {
 
   const int kv_end = p.causal ? min(len, q0 + BM) : len;
   const int ntile = (kv_end + BN - 1) / BN;
-  f32x16 sacc[2];
+  // tiles this wave computes (causal: up to its diagonal), and how many of them need no masking for its 32 rows
+  const int L = p.causal ? min(ntile, (wq0 + 31) / BN + 1) : ntile;
+  const int F = slope2 != 0.f ? 0 : min(L, p.causal ? min((wq0 + 1) / BN, len / BN) : len / BN);
 
-  // ---- the two halves of a tile ------------------------------------------------------------------------------------------
-  // S^T = K . Q^T : lane (q = l31) gets keys 32 b + 8 (r >> 2) + 4 kh + (r & 3)
-  auto do_qk = [&](int it) __attribute__((always_inline)) {
-    const int t0 = it * BN;
-    if (p.causal && t0 > wq0 + 31) return;               // wave-uniform: the whole tile is masked for these rows
-    const int nb = (p.causal && t0 + 32 > wq0 + 31) ? 1 : 2;   // 32-key blocks with at least one live key
-    const unsigned char* sk = fa_smem + (it & 3) * STAGE;
+  // ---- pieces of a tile ------------------------------------------------------------------------------------------------------
+  // S^T = K . Q^T of tile `it` into dst: lane (q = l31) gets keys 32 b + 8 (r >> 2) + 4 kh + (r & 3).  The two 32-key
+  // blocks are two independent accumulation chains, interleaved so that no MFMA waits for its predecessor.
+  auto do_qk = [&](int it, f32x16 (&dst)[2]) __attribute__((always_inline)) {
+    const unsigned char* sk = fa_smem + (it % 3) * STAGE;
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // (the addresses are made opaque per tile: otherwise hipcc hoists the 16 XOR-ed fragment addresses x 3 ring slots
+    //  out of the tile loop and SPILLS them -- one v_xor per read is cheaper than a scratch reload)
+    int ka = kaddr, qa = qaddr;
+    asm volatile("" : "+v"(ka), "+v"(qa));
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sacc[b][r] = 0.f;
-      if (b < nb) {
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-          const u32x4 kf = *reinterpret_cast<const u32x4*>(sk + b * 8192 + (kaddr ^ (ks << 5)));
-          sacc[b] = fa_mfma32<T>(kf, qf[ks], sacc[b]);
-        }
-      }
+    for (int ks = 0; ks < 8; ++ks) {
+      const u32x4 qq = *reinterpret_cast<const u32x4*>(qlds + (qa ^ (ks << 5)));
+      const u32x4 k0 = *reinterpret_cast<const u32x4*>(sk + (ka ^ (ks << 5)));
+      const u32x4 k1 = *reinterpret_cast<const u32x4*>(sk + 8192 + (ka ^ (ks << 5)));
+      dst[0] = fa_mfma32<T>(k0, qq, ks == 0 ? zero : dst[0]);
+      dst[1] = fa_mfma32<T>(k1, qq, ks == 0 ? zero : dst[1]);
     }
   };
-  // online softmax (log2 domain) on sacc, then O^T += V^T . P^T
-  auto do_sm_pv = [&](int it) __attribute__((always_inline)) {
-    const int t0 = it * BN;
-    if (p.causal && t0 > wq0 + 31) return;
-    const int nb = (p.causal && t0 + 32 > wq0 + 31) ? 1 : 2;
-    const unsigned char* sk = fa_smem + (it & 3) * STAGE;
-    const bool edge = (t0 + BN > len) || (p.causal && t0 + BN - 1 > wq0) || slope2 != 0.f;
-    float mx = -1e30f;
-    if (edge) {
-#pragma unroll
-      for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = t0 + 32 * b + 8 * (r >> 2) + 4 * kh + (r & 3);
-          float x = sacc[b][r] * c2 + slope2 * (float)(key - qrow);
-          const bool ok = b < nb && key < len && (!p.causal || key <= qrow);
-          x = ok ? x : -1e30f;
-          sacc[b][r] = x;
-          mx = __builtin_fmaxf(mx, x);
-        }
-    } else {
-#pragma unroll
-      for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) mx = __builtin_fmaxf(mx, sacc[b][r]);
-      mx *= c2;                                    // scale > 0: the maximum commutes with it
-    }
-    {
-      const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, mx), __builtin_bit_cast(unsigned, mx), false, false);
-      mx = __builtin_fmaxf(__builtin_bit_cast(float, (unsigned)sw[0]), __builtin_bit_cast(float, (unsigned)sw[1]));
-    }
-    const float m_new = __builtin_fmaxf(m_run, mx);
-    const bool moved = m_new != m_run;
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    m_run = m_new;
-    float lsum = 0.f;
-    if (edge) {
-#pragma unroll
-      for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float e = __builtin_amdgcn_exp2f(sacc[b][r] - m_new);
-          e = sacc[b][r] > -1e29f ? e : 0.f;
-          sacc[b][r] = e;
-          lsum += e;
-        }
-    } else {
-#pragma unroll
-      for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[b][r], c2, -m_new));
-          sacc[b][r] = e;
-          lsum += e;
-        }
-    }
-    l_run = l_run * alpha + lsum;
-    if (__builtin_amdgcn_ballot_w64(moved) != 0) {
-#pragma unroll
-      for (int db = 0; db < 4; ++db)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
-    }
-    // P^T fragments: k-slot 2 b + j holds tile keys 32 b + 16 j + 8 kh .. + 7 of row q = l31
-    u32x4 pf[4];
+  // exchange a value with the lane holding the other 32 keys of the same row
+  auto other_half = [&](float x) __attribute__((always_inline)) {
+    const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, x), false, false);
+    return kh ? __builtin_bit_cast(float, (unsigned)sw[0]) : __builtin_bit_cast(float, (unsigned)sw[1]);
+  };
+  // probabilities (in src) -> PV B-operand fragments: k-slot 2 b + j holds tile keys 32 b + 16 j + 8 kh .. + 7 of row l31
+  auto make_pf = [&](const f32x16 (&src)[2], u32x4 (&pf)[4]) __attribute__((always_inline)) {
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int g0 = 8 * j, g1 = 8 * j + 4;       // accumulator quads 2 j and 2 j + 1
-        uint32_t lo0 = pack2_16<BF>(sacc[b][g0], sacc[b][g0 + 1]), hi0 = pack2_16<BF>(sacc[b][g0 + 2], sacc[b][g0 + 3]);
-        uint32_t lo1 = pack2_16<BF>(sacc[b][g1], sacc[b][g1 + 1]), hi1 = pack2_16<BF>(sacc[b][g1 + 2], sacc[b][g1 + 3]);
+        const uint32_t lo0 = pack2_16<BF>(src[b][g0], src[b][g0 + 1]), hi0 = pack2_16<BF>(src[b][g0 + 2], src[b][g0 + 3]);
+        const uint32_t lo1 = pack2_16<BF>(src[b][g1], src[b][g1 + 1]), hi1 = pack2_16<BF>(src[b][g1 + 2], src[b][g1 + 3]);
         const auto s_lo = __builtin_amdgcn_permlane32_swap(lo0, lo1, false, false);
         const auto s_hi = __builtin_amdgcn_permlane32_swap(hi0, hi1, false, false);
         pf[2 * b + j] = u32x4{(uint32_t)s_lo[0], (uint32_t)s_hi[0], (uint32_t)s_lo[1], (uint32_t)s_hi[1]};
       }
-    // O^T += V^T . P^T : A fragment of (d block db, k-slot ks) = two transposing reads
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      if (ks < 2 * nb) {
-#pragma unroll
-        for (int db = 0; db < 4; ++db) {
-          const unsigned char* vb = sk + vaddr + (4 * ks) * 1024 + db * 256;
-          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)vb);
-          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(vb + 1024));
-          const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
-          o[db] = fa_mfma32<T>(u32x4{l2[0], l2[1], h2[0], h2[1]}, pf[ks], o[db]);
-        }
-      }
-    }
   };
-  // top of iteration `it`: this wave's pieces of tile `it` have landed (the pieces of tile it + 1 may still be in flight);
-  // the barrier publishes everyone's and frees ring slot (it + 2) & 3 -- tile it - 2, which even the trailing half of the
-  // workgroup (below) finished before it arrived here
-  auto tile_top = [&](int it) __attribute__((always_inline)) {
-    if (it == 40) { FA_STAMP(8) }
-    if (it + 1 < ntile) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (it == 40) { FA_STAMP(9) }
-    __builtin_amdgcn_s_barrier();
-    if (it == 40) { FA_STAMP(10) }
-    if (it + 2 < ntile) stage((it + 2) & 3, (it + 2) * BN);
-    if (it == 40) { FA_STAMP(11) }
+  // online softmax of an UNMASKED tile, straight-line (no branches: it is scheduled together with the next tile's QK^T).
+  // Returns the factor the running output must be scaled with.
+  auto softmax_fast = [&](f32x16 (&src)[2], u32x4 (&pf)[4]) __attribute__((always_inline)) -> float {
+    float mx = __builtin_fmaxf(src[0][0], src[1][0]);
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = __builtin_fmaxf(mx, __builtin_fmaxf(src[0][r], src[1][r]));   // -> v_max3_f32
+    mx *= c2;                                      // scale > 0: the maximum commutes with it
+    mx = __builtin_fmaxf(mx, other_half(mx));
+    const float m_new = __builtin_fmaxf(m_run, mx);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    m_run = m_new;
+    float lsum0 = 0.f, lsum1 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      src[0][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(src[0][r], c2, -m_new));
+      src[1][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(src[1][r], c2, -m_new));
+      lsum0 += src[0][r];
+      lsum1 += src[1][r];
+    }
+    l_run = l_run * alpha + (lsum0 + lsum1);
+    make_pf(src, pf);
+    return alpha;
+  };
+  // the general form: key >= len, key > q (causal), ALiBi
+  auto softmax_edge = [&](int it, f32x16 (&src)[2], u32x4 (&pf)[4]) __attribute__((always_inline)) -> float {
+    const int t0 = it * BN;
+    float mx = -1e30f;
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = t0 + 32 * b + 8 * (r >> 2) + 4 * kh + (r & 3);
+        float x = src[b][r] * c2 + slope2 * (float)(key - qrow);
+        const int lim = p.causal ? min(qrow, len - 1) : len - 1;
+        x = key <= lim ? x : -1e30f;
+        src[b][r] = x;
+        mx = __builtin_fmaxf(mx, x);
+      }
+    mx = __builtin_fmaxf(mx, other_half(mx));
+    const float m_new = __builtin_fmaxf(m_run, mx);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    m_run = m_new;
+    float lsum = 0.f;
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float e = __builtin_amdgcn_exp2f(src[b][r] - m_new);
+        e = src[b][r] > -1e29f ? e : 0.f;
+        src[b][r] = e;
+        lsum += e;
+      }
+    l_run = l_run * alpha + lsum;
+    make_pf(src, pf);
+    return alpha;
+  };
+  // O^T += V^T . P^T : A fragment of (d block db, k-slot ks) = two transposing reads
+  auto do_pv = [&](int it, const u32x4 (&pf)[4]) __attribute__((always_inline)) {
+    int va = vaddr + (it % 3) * STAGE;
+    asm volatile("" : "+v"(va));
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        const unsigned char* vb = fa_smem + va + (4 * ks) * 1024 + db * 256;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)vb);
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(vb + 1024));
+        const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+        o[db] = fa_mfma32<T>(u32x4{l2[0], l2[1], h2[0], h2[1]}, pf[ks], o[db]);
+      }
   };
 
+  // ---- the tile loop ---------------------------------------------------------------------------------------------------------
+  // Iteration `it` (one barrier): QK^T of tile it + 1 || softmax of tile it, then PV of tile it.  The next tile's MFMAs are
+  // independent of this tile's softmax VALU, so one straight-line block holds both (measured on the phase-by-phase form:
+  // QK^T 1280 + softmax 1224 + PV 1032 cycles per tile with NOTHING overlapping, whatever the pairing of waves).
+  // Ring of 3 tile buffers: at the top of iteration it every wave has finished tile it - 1 (the barrier), tiles it and
+  // it + 1 are being read, tile it + 2 is written.
+  f32x16 s_a[2], s_b[2];
   stage(0, 0);
   if (ntile > 1) stage(1, BN);
+  if (ntile > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
   FA_STAMP(0)
-  // The two waves of a SIMD (w and w + 4) run half a tile apart: waves 0-3 do QK^T, softmax, PV between two barriers,
-  // waves 4-7 do softmax, PV of the PREVIOUS tile and then QK^T of this one -- so one wave's softmax (VALU) runs beside
-  // the other's MFMAs instead of both fighting for the matrix pipe and then both for the VALU (measured in lockstep:
-  // QK^T 1280 + softmax 1224 + PV 1032 cycles per tile, no overlap at all).  A 4-deep ring makes it legal: the trailing
-  // half still reads tile it - 1 while tile it + 2 is being written.
-  const bool trail = (p.debug & 2) ? (wave & 1) : (p.debug & 4) ? ((wave >> 1) & 1) : (wave >= 4);
-  if (!trail) {
-    for (int it = 0; it < ntile; ++it) {
-      if (it == 32) { FA_STAMP(1) }
-      if (it == 64) { FA_STAMP(2) }
-      tile_top(it);
-      if (it == 40) { FA_STAMP(3) }
-      do_qk(it);
-      if (it == 40) { FA_STAMP(4) }
-      do_sm_pv(it);
-      if (it == 40) { FA_STAMP(6) }
+  if (L > 0) do_qk(0, s_a);
+  auto step = [&](int it, f32x16 (&s_cur)[2], f32x16 (&s_nxt)[2]) __attribute__((always_inline)) {
+    if (it == 32) { FA_STAMP(1) }
+    if (it == 64) { FA_STAMP(2) }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of tile it + 1 (issued one iteration ago)
+    __builtin_amdgcn_s_barrier();
+#if defined(FA_LAB) && (FA_LAB & 64)
+    if (it + 2 < ntile && it < 2) stage((it + 2) % 3, (it + 2) * BN);
+#else
+    if (it + 2 < ntile) stage((it + 2) % 3, (it + 2) * BN);
+#endif
+    if (it >= L) return;                                   // causal: this wave's rows are done (it still stages its pieces)
+    u32x4 pf[4];
+    float alpha;
+#ifdef FA_LAB     // tools/fa_lab.hip: timing floors with pieces compiled out (results are garbage)
+    {
+      if (!(FA_LAB & 16) && it + 1 < L) do_qk(it + 1, s_nxt);
+      if (!(FA_LAB & 8)) alpha = softmax_fast(s_cur, pf);
+      else { alpha = 1.f; make_pf(s_cur, pf); }
+      if (!(FA_LAB & 32)) do_pv(it, pf);
+      else { o[0][0] += __builtin_bit_cast(float, pf[0][0] ^ pf[1][1] ^ pf[2][2] ^ pf[3][3]); }
+      return;
     }
-  } else {
-    tile_top(0);
-    do_qk(0);
-    for (int it = 1; it < ntile; ++it) {
-      if (it == 32) { FA_STAMP(1) }
-      if (it == 64) { FA_STAMP(2) }
-      tile_top(it);
-      if (it == 40) { FA_STAMP(3) }
-      do_sm_pv(it - 1);
-      if (it == 40) { FA_STAMP(4) }
-      do_qk(it);
-      if (it == 40) { FA_STAMP(6) }
+#endif
+    // QK^T of the NEXT tile is issued ahead of this tile's softmax: its MFMAs are independent of the softmax VALU
+    if (it + 1 < L) do_qk(it + 1, s_nxt);
+    alpha = it < F ? softmax_fast(s_cur, pf) : softmax_edge(it, s_cur, pf);
+    if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
+#pragma unroll
+      for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
     }
-    do_sm_pv(ntile - 1);
+    do_pv(it, pf);
+  };
+  for (int it = 0; it < ntile; it += 2) {
+    step(it, s_a, s_b);
+    if (it + 1 < ntile) step(it + 1, s_b, s_a);
   }
   FA_STAMP(7)
   __syncthreads();                                         // every wave is done with the K / V buffers
@@ -992,18 +1018,21 @@ extern "C" int aphro_flash_attn_varlen(void* out, const void* q, const void* k, 
   p.scale = scale; p.causal = causal; p.debug = getenv("APHRO_FA_DEBUG") ? atoi(getenv("APHRO_FA_DEBUG")) : 0;
   // third-generation kernel (256-row workgroups on 32x32 MFMA tiles): head 128, long sequences
   if (head_size == 128 && max_seqlen >= 1024 && !getenv("APHRO_FA_NO_V3")) {
-    dim3 grid3((unsigned)((max_seqlen + 255) / 256), (unsigned)num_heads, (unsigned)batch);
+    p.nqt_max = (max_seqlen + 255) / 256;
+    const int groups = batch * num_kv_heads;
+    p.xcd_remap = groups % 8 == 0 && !getenv("APHRO_FA_NO_XCD");
+    dim3 grid3((unsigned)(p.nqt_max * num_heads * batch));
     static bool attr_set = false;
     if (!attr_set) {
-      if (hipFuncSetAttribute((const void*)flash_attn_varlen_v3_kernel<Half>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072) != hipSuccess ||
-          hipFuncSetAttribute((const void*)flash_attn_varlen_v3_kernel<BFloat>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072) != hipSuccess) {
+      if (hipFuncSetAttribute((const void*)flash_attn_varlen_v3_kernel<Half>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840) != hipSuccess ||
+          hipFuncSetAttribute((const void*)flash_attn_varlen_v3_kernel<BFloat>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840) != hipSuccess) {
         set_error("flash_attn_varlen: cannot raise the dynamic LDS limit");
         return APHRO_ERR_LAUNCH;
       }
       attr_set = true;
     }
-    if (dtype == APHRO_F16) hipLaunchKernelGGL((flash_attn_varlen_v3_kernel<Half>), grid3, dim3(512), 131072, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL((flash_attn_varlen_v3_kernel<BFloat>), grid3, dim3(512), 131072, (hipStream_t)stream, p);
+    if (dtype == APHRO_F16) hipLaunchKernelGGL((flash_attn_varlen_v3_kernel<Half>), grid3, dim3(512), 163840, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((flash_attn_varlen_v3_kernel<BFloat>), grid3, dim3(512), 163840, (hipStream_t)stream, p);
     APHRO_LAUNCH_CHECK();
     return APHRO_OK;
   }
