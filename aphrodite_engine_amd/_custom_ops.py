@@ -198,11 +198,17 @@ def flash_attn_varlen(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor,
     return out
 
 
+# sequences (context + new tokens) at least this long take the gathered-context path of context_attention_fwd
+CONTEXT_ATTN_GATHER_MIN_LEN = 1024
+
+
 def context_attention_fwd(q, k, v, o, kv_cache_dtype: str, k_cache, v_cache, b_loc, b_start_loc,
                           b_seq_len, b_ctx_len, max_input_len: int, k_scale: float = 1.0,
                           v_scale: float = 1.0, alibi_slopes: Optional[torch.Tensor] = None,
-                          sliding_window: Optional[int] = None) -> None:
-    """attention/ops/prefix_prefill.py:696-711 (same argument order).  q/k/v/o [T,H,hd]
+                          sliding_window: Optional[int] = None, max_seq_len: Optional[int] = None,
+                          total_kv_tokens: Optional[int] = None) -> None:
+    """attention/ops/prefix_prefill.py:696-711 (same argument order; ``max_seq_len`` / ``total_kv_tokens`` are optional
+    host-side hints -- max and sum of ``b_seq_len`` -- that save a device sync on the long-prompt path).  q/k/v/o [T,H,hd]
     views of the new tokens; k_cache [NB,Hkv,hd/x,block,x], v_cache [NB,Hkv,hd,block];
     b_loc = block tables, b_start_loc = query_start_loc [B+1], b_seq_len = context + new,
     b_ctx_len = cached context.  Like the reference the softmax scale is 1/sqrt(hd)
@@ -222,7 +228,25 @@ def context_attention_fwd(q, k, v, o, kv_cache_dtype: str, k_cache, v_cache, b_l
     if alibi_slopes is not None:
         slopes = alibi_slopes.to(device=q.device, dtype=torch.float32).contiguous()
     win = int(sliding_window) if sliding_window is not None and sliding_window > 0 else 0
-    check(_lib.lib().aphro_context_attention(
+    lib = _lib.lib()
+    if head_size == 128 and win == 0 and not os.environ.get("APHRO_CA_NO_GATHER"):
+        # long prompts: gather the cached context once, then the third-generation prefill kernel over context + new
+        # tokens.  The caller may pass the host-side maxima (the attention metadata has them); otherwise one sync.
+        if max_seq_len is None or total_kv_tokens is None:
+            msl, tot = int(b_seq_len.max().item()), int(b_seq_len.sum().item())
+        else:
+            msl, tot = int(max_seq_len), int(total_kv_tokens)
+        if msl >= CONTEXT_ATTN_GATHER_MIN_LEN:
+            ws = _workspace(q.device, lib.aphro_context_attention_workspace_bytes(tot, batch, k.shape[1], head_size))
+            check(lib.aphro_context_attention_gathered(
+                o.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(),
+                b_loc.data_ptr(), b_start_loc.data_ptr(), b_seq_len.data_ptr(), b_ctx_len.data_ptr(), batch,
+                int(max_input_len), msl, tot, b_loc.shape[1], q.shape[1], k.shape[1], head_size, v_cache.shape[3],
+                k_cache.shape[4], q.stride(0), k.stride(0), v.stride(0), o.stride(0), head_size ** -0.5,
+                float(k_scale), float(v_scale), _ptr(slopes), _dt(q), _kv(kv_cache_dtype), ws.data_ptr(), ws.numel(),
+                _stream()), "context_attention_fwd")
+            return
+    check(lib.aphro_context_attention(
         o.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(),
         b_loc.data_ptr(), b_start_loc.data_ptr(), b_seq_len.data_ptr(), b_ctx_len.data_ptr(), batch,
         int(max_input_len), b_loc.shape[1], q.shape[1], k.shape[1], head_size, v_cache.shape[3],

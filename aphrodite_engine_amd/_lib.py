@@ -95,6 +95,12 @@ SIGNATURES = {
     "aphro_flash_attn_varlen": (I, [P, P, P, P, P, I, I, I, I, I, L, L, L, F, I, P, I, P]),
     "aphro_context_attention": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, L, L, L, L,
                                     F, F, F, P, I, I, I, P]),
+    "aphro_context_attention_workspace_bytes": (Z, [L, I, I, I]),
+    # out q k v k_cache v_cache block_tables q_start_loc seq_lens ctx_lens | batch max_query_len max_seq_len | total_kv_tokens |
+    # max_blocks num_heads num_kv_heads head_size block_size x | 4 strides | scale k_scale v_scale | alibi | dtype kv_dtype |
+    # workspace bytes stream
+    "aphro_context_attention_gathered": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, L, I, I, I, I, I, I, L, L, L, L,
+                                             F, F, F, P, I, I, P, Z, P]),
 }
 
 OK = 0

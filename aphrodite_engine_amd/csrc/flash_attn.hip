@@ -31,6 +31,8 @@ struct FAParams {
   int causal;
   int debug;
   int nqt_max, xcd_remap;   // third-generation kernel: query tiles per sequence in the grid; kv-head -> XCD placement
+  const int32_t* cu_seqlens_k;   // third-generation kernel: key rows per sequence when they differ from the query rows
+  int64_t o_stride;              // ... and the output row stride (elements)
 };
 
 template <typename T>
@@ -461,6 +463,9 @@ __global__ __launch_bounds__(NWV * 64) void flash_attn_varlen_v2_kernel(FAParams
 // ---------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) void* fa_lds_ptr;
+#ifndef FA_QK_SCHED
+#define FA_QK_SCHED 1
+#endif
 // lab (APHRO_FA_DEBUG=1): s_memtime stamps of the heaviest workgroup's waves, read back with aphro_fa_debug_dump
 __device__ unsigned long long fa_dbg[8 * 64];
 #define FA_STAMP(slot) if ((p.debug & 1) && blockIdx.x == 0 && lane == 0) fa_dbg[wave * 64 + (slot)] = __builtin_amdgcn_s_memtime();
@@ -503,9 +508,14 @@ __global__ __launch_bounds__(512) void flash_attn_varlen_v3_kernel(FAParams p) {
     qt_rev = r / G;
   }
   const int kvh = head / (p.num_heads / p.num_kv_heads);
-  const int s0 = p.cu_seqlens[seq];
-  const int len = p.cu_seqlens[seq + 1] - s0;
-  const int nqt = (len + BM - 1) / BM;
+  // queries [s0q, s0q + qlen) and keys [s0, s0 + len): the same rows for plain prefill; with a cached context in front
+  // (cu_seqlens_k given) the keys are context + new tokens and query row i sits at key position i + off, off = len - qlen
+  const int s0q = p.cu_seqlens[seq];
+  const int qlen = p.cu_seqlens[seq + 1] - s0q;
+  const int s0 = p.cu_seqlens_k ? p.cu_seqlens_k[seq] : s0q;
+  const int len = p.cu_seqlens_k ? p.cu_seqlens_k[seq + 1] - s0 : qlen;
+  const int off = len - qlen;
+  const int nqt = (qlen + BM - 1) / BM;
   const int qt = nqt - 1 - qt_rev;            // heavy (late) tiles first
   if (qt < 0) return;
   const int q0 = qt * BM;
@@ -518,7 +528,7 @@ __global__ __launch_bounds__(512) void flash_attn_varlen_v3_kernel(FAParams p) {
   unsigned char* qlds = fa_smem + 3 * STAGE + wave * 8192;
   const int qaddr = l31 * 256 + ((kh ^ (l31 & 15)) << 4);          // chunk 2 ks + kh of row l31, XOR-swizzled like K
   {
-    const uint16_t* qp = (const uint16_t*)p.q + (size_t)(s0 + min(qrow, len - 1)) * p.q_stride + (size_t)head * HD + 8 * kh;
+    const uint16_t* qp = (const uint16_t*)p.q + (size_t)(s0q + min(qrow, qlen - 1)) * p.q_stride + (size_t)head * HD + 8 * kh;
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks)
       *reinterpret_cast<u32x4*>(qlds + (qaddr ^ (ks << 5))) = *reinterpret_cast<const u32x4*>(qp + 16 * ks);
@@ -568,11 +578,11 @@ __global__ __launch_bounds__(512) void flash_attn_varlen_v3_kernel(FAParams p) {
     for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
   float m_run = -1e30f, l_run = 0.f;          // log2-domain running maximum; this lane's share of the row sum
 
-  const int kv_end = p.causal ? min(len, q0 + BM) : len;
+  const int kv_end = p.causal ? min(len, q0 + BM + off) : len;
   const int ntile = (kv_end + BN - 1) / BN;
   // tiles this wave computes (causal: up to its diagonal), and how many of them need no masking for its 32 rows
-  const int L = p.causal ? min(ntile, (wq0 + 31) / BN + 1) : ntile;
-  const int F = slope2 != 0.f ? 0 : min(L, p.causal ? min((wq0 + 1) / BN, len / BN) : len / BN);
+  const int L = p.causal ? min(ntile, (wq0 + off + 31) / BN + 1) : ntile;
+  const int F = slope2 != 0.f ? 0 : min(L, p.causal ? min((wq0 + off + 1) / BN, len / BN) : len / BN);
 
   // ---- pieces of a tile ------------------------------------------------------------------------------------------------------
   // S^T = K . Q^T of tile `it` into dst: lane (q = l31) gets keys 32 b + 8 (r >> 2) + 4 kh + (r & 3).  The two 32-key
@@ -584,13 +594,23 @@ __global__ __launch_bounds__(512) void flash_attn_varlen_v3_kernel(FAParams p) {
     //  out of the tile loop and SPILLS them -- one v_xor per read is cheaper than a scratch reload)
     int ka = kaddr, qa = qaddr;
     asm volatile("" : "+v"(ka), "+v"(qa));
+    // fragments of k-step ks + 1 are read while the two MFMAs of step ks run (left alone hipcc issues each read right in
+    // front of its MFMA and waits lgkmcnt(0): ~100 exposed cycles per pair)
+    u32x4 fr[2][3];
+    auto rd = [&](int ks, u32x4 (&f)[3]) __attribute__((always_inline)) {
+      f[0] = *reinterpret_cast<const u32x4*>(qlds + (qa ^ (ks << 5)));
+      f[1] = *reinterpret_cast<const u32x4*>(sk + (ka ^ (ks << 5)));
+      f[2] = *reinterpret_cast<const u32x4*>(sk + 8192 + (ka ^ (ks << 5)));
+    };
+    rd(0, fr[0]);
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
-      const u32x4 qq = *reinterpret_cast<const u32x4*>(qlds + (qa ^ (ks << 5)));
-      const u32x4 k0 = *reinterpret_cast<const u32x4*>(sk + (ka ^ (ks << 5)));
-      const u32x4 k1 = *reinterpret_cast<const u32x4*>(sk + 8192 + (ka ^ (ks << 5)));
-      dst[0] = fa_mfma32<T>(k0, qq, ks == 0 ? zero : dst[0]);
-      dst[1] = fa_mfma32<T>(k1, qq, ks == 0 ? zero : dst[1]);
+      if (ks < 7) rd(ks + 1, fr[(ks + 1) & 1]);
+#if FA_QK_SCHED == 1
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+      dst[0] = fa_mfma32<T>(fr[ks & 1][1], fr[ks & 1][0], ks == 0 ? zero : dst[0]);
+      dst[1] = fa_mfma32<T>(fr[ks & 1][2], fr[ks & 1][0], ks == 0 ? zero : dst[1]);
     }
   };
   // exchange a value with the lane holding the other 32 keys of the same row
@@ -644,8 +664,8 @@ __global__ __launch_bounds__(512) void flash_attn_varlen_v3_kernel(FAParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int key = t0 + 32 * b + 8 * (r >> 2) + 4 * kh + (r & 3);
-        float x = src[b][r] * c2 + slope2 * (float)(key - qrow);
-        const int lim = p.causal ? min(qrow, len - 1) : len - 1;
+        float x = src[b][r] * c2 + slope2 * (float)(key - (qrow + off));
+        const int lim = p.causal ? min(qrow + off, len - 1) : len - 1;
         x = key <= lim ? x : -1e30f;
         src[b][r] = x;
         mx = __builtin_fmaxf(mx, x);
@@ -690,6 +710,14 @@ __global__ __launch_bounds__(512) void flash_attn_varlen_v3_kernel(FAParams p) {
   // QK^T 1280 + softmax 1224 + PV 1032 cycles per tile with NOTHING overlapping, whatever the pairing of waves).
   // Ring of 3 tile buffers: at the top of iteration it every wave has finished tile it - 1 (the barrier), tiles it and
   // it + 1 are being read, tile it + 2 is written.
+  // Lab knob (FA_TRAIL = 1 / 2): the two waves of a SIMD rotate the three phases of a tile against each other (waves 0-3
+  // QK^T(next) | softmax | PV, the others softmax | PV | QK^T(next)) so that one wave's softmax VALU runs beside the
+  // other's MFMAs.  Measured at T = 8192: 0.794 ms unrotated, 0.852 (w >= 4) / 0.837 (odd waves) rotated -- no gain, like
+  // the half-tile stagger of the first version; off.
+#ifndef FA_TRAIL
+#define FA_TRAIL 0
+#endif
+  const bool trail = FA_TRAIL == 1 ? wave >= 4 : FA_TRAIL == 2 ? (wave & 1) : false;
   f32x16 s_a[2], s_b[2];
   stage(0, 0);
   if (ntile > 1) stage(1, BN);
@@ -697,6 +725,7 @@ __global__ __launch_bounds__(512) void flash_attn_varlen_v3_kernel(FAParams p) {
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   FA_STAMP(0)
+  if ((p.debug & 1) && blockIdx.x == 0 && lane == 0) fa_dbg[wave * 64 + 12] = wall_clock64();
   if (L > 0) do_qk(0, s_a);
   auto step = [&](int it, f32x16 (&s_cur)[2], f32x16 (&s_nxt)[2]) __attribute__((always_inline)) {
     if (it == 32) { FA_STAMP(1) }
@@ -722,7 +751,9 @@ __global__ __launch_bounds__(512) void flash_attn_varlen_v3_kernel(FAParams p) {
     }
 #endif
     // QK^T of the NEXT tile is issued ahead of this tile's softmax: its MFMAs are independent of the softmax VALU
-    if (it + 1 < L) do_qk(it + 1, s_nxt);
+    // (unconditional: past this wave's last tile it multiplies stale ring data into a buffer nobody reads -- keeping the
+    //  branch out puts these MFMAs and the softmax VALU in ONE scheduling region)
+    if (!trail) do_qk(it + 1, s_nxt);
     alpha = it < F ? softmax_fast(s_cur, pf) : softmax_edge(it, s_cur, pf);
     if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
 #pragma unroll
@@ -731,12 +762,14 @@ __global__ __launch_bounds__(512) void flash_attn_varlen_v3_kernel(FAParams p) {
         for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
     }
     do_pv(it, pf);
+    if (trail) do_qk(it + 1, s_nxt);
   };
   for (int it = 0; it < ntile; it += 2) {
     step(it, s_a, s_b);
     if (it + 1 < ntile) step(it + 1, s_b, s_a);
   }
   FA_STAMP(7)
+  if ((p.debug & 1) && blockIdx.x == 0 && lane == 0) fa_dbg[wave * 64 + 13] = wall_clock64();
   __syncthreads();                                         // every wave is done with the K / V buffers
 
   // ---- normalise, transpose through LDS (wave-private 8 KiB: 32 rows x 256 B), store whole rows -----------------------------
@@ -757,12 +790,12 @@ __global__ __launch_bounds__(512) void flash_attn_varlen_v3_kernel(FAParams p) {
                        pack2_16<BF>(o[db][4 * g4 + 2] * inv, o[db][4 * g4 + 3] * inv)};
       *reinterpret_cast<u32x2*>(region + l31 * 256 + ((c8 ^ ((l31 & 15) << 1)) << 3)) = v;
     }
-  uint16_t* obase = (uint16_t*)p.out + ((size_t)(s0 + wq0) * p.num_heads + head) * HD;
+  uint16_t* obase = (uint16_t*)p.out + (size_t)(s0q + wq0) * p.o_stride + (size_t)head * HD;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int row = i * 4 + (lane >> 4), c16 = lane & 15;
     const u32x4 v = *reinterpret_cast<const u32x4*>(region + row * 256 + ((c16 ^ (row & 15)) << 4));
-    if (wq0 + row < len) *reinterpret_cast<u32x4*>(obase + (size_t)row * p.num_heads * HD + c16 * 8) = v;
+    if (wq0 + row < qlen) *reinterpret_cast<u32x4*>(obase + (size_t)row * p.o_stride + c16 * 8) = v;
   }
 }
 
@@ -958,6 +991,54 @@ __global__ __launch_bounds__(256) void context_attn_kernel(CAParams p) {
 
 using namespace aphro;
 
+// ---------------------------------------------------------------------------
+// Prefill with cached context on the third-generation tile machine: the context of every sequence is
+// gathered ONCE from the paged cache into contiguous [token][kv head][hd] rows (dequantised like
+// prefix_prefill.py:131-134,178-181: float(fp8) * scale rounded to the query type), the new tokens' k / v are appended,
+// and flash_attn_varlen_v3_kernel runs over keys = context + new with the query rows offset by the context length.
+// The gather is a streaming copy (2 x the context bytes); the attention then reads K/V tiles with direct-to-LDS loads
+// instead of per-element cache gathers.  hd 128, no sliding window; everything else stays on context_attn_kernel.
+// ---------------------------------------------------------------------------
+__global__ void ca_prefix_kernel(const int32_t* __restrict__ seq_lens, int32_t* __restrict__ cu_k, int batch) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    int acc = 0;
+    for (int b = 0; b < batch; ++b) { cu_k[b] = acc; acc += seq_lens[b]; }
+    cu_k[batch] = acc;
+  }
+}
+
+// grid (32-token tiles, kv heads, sequences), 512 threads: thread -> token (fast index), 8-wide d chunk
+template <typename T, int KV>
+__global__ __launch_bounds__(512) void ca_gather_kernel(CAParams p, const int32_t* __restrict__ cu_k,
+                                                        uint16_t* __restrict__ kc_out, uint16_t* __restrict__ vc_out, int hd) {
+  const int seq = blockIdx.z, h = blockIdx.y;
+  const int tok = blockIdx.x * 32 + (threadIdx.x & 31);
+  const int chunk = threadIdx.x >> 5;                 // d = 8 chunk .. + 7
+  const int total = p.seq_lens[seq];
+  if (tok >= total || chunk * 8 >= hd) return;
+  const int ctx = p.ctx_lens[seq];
+  const size_t orow = ((size_t)(cu_k[seq] + tok) * p.num_kv_heads + h) * hd + chunk * 8;
+  u16x8 kk, vv;
+  if (tok < ctx) {
+    const int64_t blk = p.block_tables[(size_t)seq * p.max_blocks + tok / p.block_size];
+    const int boff = tok % p.block_size;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int d = chunk * 8 + j;
+      const int64_t ki = (((blk * p.num_kv_heads + h) * (hd / p.x) + d / p.x) * p.block_size + boff) * p.x + d % p.x;
+      const int64_t vi = ((blk * p.num_kv_heads + h) * hd + d) * p.block_size + boff;
+      kk[j] = cache_elem_to_t<T, KV>(p.k_cache, ki, p.k_scale);
+      vv[j] = cache_elem_to_t<T, KV>(p.v_cache, vi, p.v_scale);
+    }
+  } else {
+    const size_t row = (size_t)(p.q_start_loc[seq] + tok - ctx);
+    kk = *reinterpret_cast<const u16x8*>((const uint16_t*)p.k + row * p.k_stride + (size_t)h * hd + chunk * 8);
+    vv = *reinterpret_cast<const u16x8*>((const uint16_t*)p.v + row * p.v_stride + (size_t)h * hd + chunk * 8);
+  }
+  *reinterpret_cast<u16x8*>(kc_out + orow) = kk;
+  *reinterpret_cast<u16x8*>(vc_out + orow) = vv;
+}
+
 extern "C" int aphro_context_attention(void* out, const void* q, const void* k, const void* v, const void* k_cache,
                                        const void* v_cache, const int32_t* block_tables,
                                        const int32_t* q_start_loc, const int32_t* seq_lens,
@@ -1001,6 +1082,79 @@ extern "C" int aphro_context_attention(void* out, const void* q, const void* k, 
 }
 
 
+// Scratch of aphro_context_attention_gathered: the gathered K and V rows of every sequence (context + new tokens) in
+// the query type, plus the key-row offsets.
+extern "C" size_t aphro_context_attention_workspace_bytes(int64_t total_kv_tokens, int batch, int num_kv_heads, int head_size) {
+  return 2 * (size_t)total_kv_tokens * num_kv_heads * head_size * 2 + ((size_t)(batch + 1) * 4 + 255) / 256 * 256;
+}
+
+// Same arguments as aphro_context_attention plus: max_seq_len = max(seq_lens) (context + new), total_kv_tokens >=
+// sum(seq_lens), workspace.  head_size 128, no sliding window (the caller falls back to aphro_context_attention).
+extern "C" int aphro_context_attention_gathered(void* out, const void* q, const void* k, const void* v, const void* k_cache,
+                                                const void* v_cache, const int32_t* block_tables, const int32_t* q_start_loc,
+                                                const int32_t* seq_lens, const int32_t* ctx_lens, int batch, int max_query_len,
+                                                int max_seq_len, int64_t total_kv_tokens, int max_blocks, int num_heads,
+                                                int num_kv_heads, int head_size, int block_size, int x, int64_t q_stride,
+                                                int64_t k_stride, int64_t v_stride, int64_t o_stride, float scale, float k_scale,
+                                                float v_scale, const float* alibi_slopes, int dtype, int kv_dtype,
+                                                void* workspace, size_t workspace_bytes, void* stream) {
+  APHRO_CHECK(dtype == APHRO_F16 || dtype == APHRO_BF16, "context_attention: dtype must be f16 or bf16");
+  APHRO_CHECK(kv_dtype >= APHRO_KV_AUTO && kv_dtype <= APHRO_KV_FP8_E5M2, "Unsupported data type of kv cache: %d", kv_dtype);
+  APHRO_CHECK(head_size == 128, "context_attention_gathered: head_size 128 only");
+  APHRO_CHECK(num_kv_heads > 0 && num_heads % num_kv_heads == 0, "context_attention: bad head counts");
+  APHRO_CHECK(q_stride % 8 == 0 && k_stride % 8 == 0 && v_stride % 8 == 0 && o_stride % 8 == 0, "context_attention: strides must be multiples of 8");
+  APHRO_CHECK(((uintptr_t)q % 16) == 0 && ((uintptr_t)k % 16) == 0 && ((uintptr_t)v % 16) == 0 && ((uintptr_t)out % 16) == 0,
+              "context_attention: 16-byte alignment");
+  APHRO_CHECK(block_size > 0 && x > 0 && head_size % x == 0, "context_attention: bad cache geometry");
+  if (batch == 0 || max_query_len == 0) return APHRO_OK;
+  const size_t need = aphro_context_attention_workspace_bytes(total_kv_tokens, batch, num_kv_heads, head_size);
+  if (workspace == nullptr || workspace_bytes < need) {
+    set_error("context_attention_gathered: workspace %zu < %zu bytes", workspace_bytes, need);
+    return APHRO_ERR_WORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const size_t kv_bytes = (size_t)total_kv_tokens * num_kv_heads * head_size * 2;
+  uint16_t* kc = (uint16_t*)workspace;
+  uint16_t* vc = (uint16_t*)((char*)workspace + kv_bytes);
+  int32_t* cu_k = (int32_t*)((char*)workspace + 2 * kv_bytes);
+  CAParams g;
+  g.out = nullptr; g.q = nullptr; g.k = k; g.v = v; g.k_cache = k_cache; g.v_cache = v_cache;
+  g.block_tables = block_tables; g.q_start_loc = q_start_loc; g.seq_lens = seq_lens; g.ctx_lens = ctx_lens;
+  g.alibi = nullptr; g.num_heads = num_heads; g.num_kv_heads = num_kv_heads; g.max_blocks = max_blocks;
+  g.block_size = block_size; g.x = x; g.q_stride = q_stride; g.k_stride = k_stride; g.v_stride = v_stride;
+  g.o_stride = o_stride; g.scale = scale; g.k_scale = k_scale; g.v_scale = v_scale; g.window = 0;
+  hipLaunchKernelGGL(ca_prefix_kernel, dim3(1), dim3(64), 0, st, seq_lens, cu_k, batch);
+  dim3 ggrid((unsigned)((max_seq_len + 31) / 32), (unsigned)num_kv_heads, (unsigned)batch);
+#define CG_L(TT, KVV) hipLaunchKernelGGL((ca_gather_kernel<TT, KVV>), ggrid, dim3(512), 0, st, g, cu_k, kc, vc, head_size)
+#define CG_K(TT) { if (kv_dtype == APHRO_KV_AUTO) CG_L(TT, 0); else if (kv_dtype == APHRO_KV_FP8_E4M3) CG_L(TT, 1); else CG_L(TT, 2); }
+  if (dtype == APHRO_F16) CG_K(Half) else CG_K(BFloat)
+#undef CG_K
+#undef CG_L
+  APHRO_LAUNCH_CHECK();
+  FAParams p;
+  p.out = out; p.q = q; p.k = kc; p.v = vc; p.cu_seqlens = q_start_loc; p.cu_seqlens_k = cu_k; p.alibi = alibi_slopes;
+  p.num_heads = num_heads; p.num_kv_heads = num_kv_heads;
+  p.q_stride = q_stride; p.k_stride = (int64_t)num_kv_heads * head_size; p.v_stride = p.k_stride; p.o_stride = o_stride;
+  p.scale = scale; p.causal = 1; p.debug = 0;
+  p.nqt_max = (max_query_len + 255) / 256;
+  p.xcd_remap = (batch * num_kv_heads) % 8 == 0 && !getenv("APHRO_FA_NO_XCD");
+  dim3 grid3((unsigned)(p.nqt_max * num_heads * batch));
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)flash_attn_varlen_v3_kernel<Half>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840) != hipSuccess ||
+        hipFuncSetAttribute((const void*)flash_attn_varlen_v3_kernel<BFloat>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840) != hipSuccess) {
+      set_error("context_attention_gathered: cannot raise the dynamic LDS limit");
+      return APHRO_ERR_LAUNCH;
+    }
+    attr_set = true;
+  }
+  if (dtype == APHRO_F16) hipLaunchKernelGGL((flash_attn_varlen_v3_kernel<Half>), grid3, dim3(512), 163840, st, p);
+  else hipLaunchKernelGGL((flash_attn_varlen_v3_kernel<BFloat>), grid3, dim3(512), 163840, st, p);
+  APHRO_LAUNCH_CHECK();
+  return APHRO_OK;
+}
+
+
 extern "C" int aphro_flash_attn_varlen(void* out, const void* q, const void* k, const void* v,
                                        const int32_t* cu_seqlens, int batch, int max_seqlen, int num_heads,
                                        int num_kv_heads, int head_size, int64_t q_stride, int64_t k_stride,
@@ -1016,6 +1170,7 @@ extern "C" int aphro_flash_attn_varlen(void* out, const void* q, const void* k, 
   p.num_heads = num_heads; p.num_kv_heads = num_kv_heads;
   p.q_stride = q_stride; p.k_stride = k_stride; p.v_stride = v_stride;
   p.scale = scale; p.causal = causal; p.debug = getenv("APHRO_FA_DEBUG") ? atoi(getenv("APHRO_FA_DEBUG")) : 0;
+  p.cu_seqlens_k = nullptr; p.o_stride = (int64_t)num_heads * head_size; p.nqt_max = 0; p.xcd_remap = 0;
   // third-generation kernel (256-row workgroups on 32x32 MFMA tiles): head 128, long sequences
   if (head_size == 128 && max_seqlen >= 1024 && !getenv("APHRO_FA_NO_V3")) {
     p.nqt_max = (max_seqlen + 255) / 256;

@@ -460,6 +460,65 @@ def test_context_attention_fwd(ops, kv_cache_dtype, dtype, Hq, Hkv, D, variant):
     np.testing.assert_allclose(out.float().cpu().numpy(), ref, atol=tol, rtol=tol)
 
 
+@pytest.mark.parametrize("kv_cache_dtype", ["auto", "fp8"])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("variant", ["plain", "alibi"])
+def test_context_attention_fwd_long(ops, kv_cache_dtype, dtype, variant):
+    """Long prompts (context + new >= 1024 tokens, hd 128) take the gathered-context path: the cached context is copied
+    once out of the paged cache and the 256-row / 32x32-MFMA prefill kernel runs over context + new tokens with the query
+    rows offset by the context length.  Ragged context / query lengths around the 64-key and 256-row tile edges, one
+    sequence without context, one with a single new token; must agree with the oracle AND with the per-element-gather
+    kernel (APHRO_CA_NO_GATHER)."""
+    import os
+    rng = np.random.default_rng(17)
+    Hq, Hkv, D, BS = 8, 2, 128, 16
+    ctx_lens = np.array([1000, 0, 257, 1500, 63], np.int32)
+    qry_lens = np.array([300, 1100, 1, 129, 513], np.int32)
+    B = len(ctx_lens)
+    seq_lens = ctx_lens + qry_lens
+    T = int(qry_lens.sum())
+    start = np.concatenate([[0], np.cumsum(qry_lens)]).astype(np.int32)
+    max_blocks = int((seq_lens.max() + BS - 1) // BS)
+    NB = B * max_blocks + 3
+    bt = rng.permutation(NB)[:B * max_blocks].reshape(B, max_blocks).astype(np.int32)
+    cdt = dtype if kv_cache_dtype == "auto" else torch.uint8
+    x = 16 // torch.tensor([], dtype=cdt).element_size()
+    qkv = t(rng.standard_normal((T, (Hq + 2 * Hkv) * D)).astype(np.float32) * 0.5, dtype)
+    q = qkv[:, :Hq * D].view(T, Hq, D)
+    k = qkv[:, Hq * D:(Hq + Hkv) * D].view(T, Hkv, D)
+    v = qkv[:, (Hq + Hkv) * D:].view(T, Hkv, D)
+    ks, vs = (1.0, 1.0) if kv_cache_dtype == "auto" else (0.37, 0.5)
+    if kv_cache_dtype == "auto":
+        kc = t(rng.standard_normal((NB, Hkv, D // x, BS, x)).astype(np.float32) * 0.5, dtype)
+        vc = t(rng.standard_normal((NB, Hkv, D, BS)).astype(np.float32) * 0.5, dtype)
+        kc_np, vc_np = kc.float().cpu().numpy(), vc.float().cpu().numpy()
+    else:
+        kc = torch.from_numpy(rng.integers(0, 0x70, (NB, Hkv, D // x, BS, x), dtype=np.uint8)).to(DEV)
+        vc = torch.from_numpy(rng.integers(0, 0x70, (NB, Hkv, D, BS), dtype=np.uint8)).to(DEV)
+        kc_np, vc_np = kc.cpu().numpy(), vc.cpu().numpy()
+    slopes = (rng.random(Hq).astype(np.float32) * 0.02) if variant == "alibi" else None
+    args = (kv_cache_dtype, kc, vc, t(bt), t(start), t(seq_lens), t(ctx_lens), int(qry_lens.max()), ks, vs,
+            t(slopes) if slopes is not None else None, None)
+    out = torch.empty(T, Hq, D, dtype=dtype, device=DEV)
+    ops.context_attention_fwd(q, k, v, out, *args)                                   # gathered path (one device sync)
+    out_h = torch.empty_like(out)
+    ops.context_attention_fwd(q, k, v, out_h, *args, max_seq_len=int(seq_lens.max()), total_kv_tokens=int(seq_lens.sum()))
+    assert torch.equal(out, out_h)                                                   # host-side hints: same result
+    os.environ["APHRO_CA_NO_GATHER"] = "1"
+    try:
+        out_old = torch.empty_like(out)
+        ops.context_attention_fwd(q, k, v, out_old, *args)
+    finally:
+        del os.environ["APHRO_CA_NO_GATHER"]
+    rnd = lambda a: torch.from_numpy(a.astype(np.float32)).to(dtype).float().numpy()
+    ref = oa.context_attention(q.float().cpu().numpy(), k.float().cpu().numpy(), v.float().cpu().numpy(),
+                               kc_np, vc_np, bt, start, seq_lens, ctx_lens, D ** -0.5, kv_cache_dtype,
+                               ks, vs, slopes, 0, rnd)
+    tol = 2e-3 if dtype == torch.float16 else 1.6e-2
+    np.testing.assert_allclose(out.float().cpu().numpy(), ref, atol=tol, rtol=tol)
+    np.testing.assert_allclose(out_old.float().cpu().numpy(), ref, atol=tol, rtol=tol)
+
+
 def test_backend_prefix_prefill_matches_full_prefill(ops):
     """AttentionImpl.forward with cached context == prefill of the whole sequence
     (chunked-prefill / prefix-caching consistency through the backend seam)."""
