@@ -538,6 +538,9 @@ def awq_dequantize(qweight: torch.Tensor, scales: torch.Tensor,
     return out
 
 
+AWQ_REPACK_MIN_M = 256    # awq_gemm rows from which the per-call nibble transpose + prefill-sized kernel pays
+
+
 def awq_gemm(input: torch.Tensor, qweight: torch.Tensor, qzeros: torch.Tensor,
              scales: torch.Tensor, split_k_iters: int) -> torch.Tensor:
     """NOTE the reference wrapper's parameter names are swapped relative to what
@@ -553,6 +556,12 @@ def awq_gemm(input: torch.Tensor, qweight: torch.Tensor, qzeros: torch.Tensor,
     groups = scaling_factors.shape[0]
     if input.stride(1) != 1:
         input = input.contiguous()
+    if m >= AWQ_REPACK_MIN_M and wna16_large_ok(m, n, k, groups) and not os.environ.get("APHRO_WNA16_NO_LARGE"):
+        # prefill-sized M on checkpoint-layout AWQ tensors: transpose the nibbles once per call (2 x the weight bytes,
+        # a few % of the GEMM at this M) and run the MFMA-bound kernel -- the reference dequantises + matmuls above 256
+        # tokens (awq.py:160-164).  Load-time repack (AWQConfig(prepack=True)) skips this step entirely.
+        return _wna16_large(input, awq_marlin_repack(qweight, k, n, 4), awq_repack_zeros(zeros, n), scaling_factors,
+                            None, 0)
     out = torch.empty((m, n), dtype=input.dtype, device=input.device)
     nbytes = lib.aphro_awq_gemm_workspace_bytes(min(m, 64), n, k, groups)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=input.device)

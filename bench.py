@@ -57,6 +57,7 @@ def parse_args():
                     help="tp only: keep the all-reduces on the compute stream (default: side stream + weight prefetch)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prefill-info", action="store_true", help="skip the MFMA-bound prefill kernels' info section")
     ap.add_argument("--layers", type=int, default=0, help="debug only: fewer layers (marks the line invalid)")
     return ap.parse_args()
 
@@ -288,6 +289,66 @@ def cpu_baseline(args, cfg):
     return out
 
 
+def prefill_section(cfg):
+    """The MFMA-bound side of the same path (configs[2]'s prefill: seq 8192), timed live with HIP events: causal prefill
+    attention, prefill with cached context, and the prefill-sized W4A16 / W8A8 GEMMs on the model's gate_up shape.
+    Reported as information next to the decode roofline (same JSON line, key ``prefill_kernels``); frac = TFLOP/s over the
+    dense MFMA peak of the type (2.5 PFLOP/s f16, 5 PFLOP/s fp8: MI355X_MICROARCH.md)."""
+    from aphrodite_engine_amd import _custom_ops as ops
+    dev = "cuda"
+    Hq, Hkv, D = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+
+    def timeit(fn, iters=5):
+        fn()
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(iters):
+            fn()
+        e.record()
+        e.synchronize()
+        return s.elapsed_time(e) * 1e-3 / iters
+
+    out = {}
+    g = torch.Generator(device=dev).manual_seed(7)
+    T = 8192
+    qkv = torch.randn(T, (Hq + 2 * Hkv) * D, device=dev, dtype=torch.float16, generator=g) * 0.5
+    q, k, v = qkv[:, :Hq * D].view(T, Hq, D), qkv[:, Hq * D:(Hq + Hkv) * D].view(T, Hkv, D), qkv[:, (Hq + Hkv) * D:].view(T, Hkv, D)
+    cu = torch.tensor([0, T], dtype=torch.int32, device=dev)
+    t = timeit(lambda: ops.flash_attn_varlen(q, k, v, cu, T, D ** -0.5, causal=True))
+    fl = 4.0 * T * T * D * Hq / 2
+    out["flash_attn_varlen causal T=8192"] = dict(ms=t * 1e3, TFLOPs=fl / t / 1e12, frac=fl / t / 2.5e15, bound="mfma f16")
+    ctx, new, BS = 6144, 2048, 16
+    nblk = (ctx + new) // BS
+    kc = (torch.randn(nblk, Hkv, D // 8, BS, 8, device=dev, generator=g) * 0.5).half()
+    vc = (torch.randn(nblk, Hkv, D, BS, device=dev, generator=g) * 0.5).half()
+    bt = torch.randperm(nblk, device=dev, generator=g).to(torch.int32).view(1, nblk)
+    o = torch.empty(new, Hq, D, device=dev, dtype=torch.float16)
+    i32 = lambda *a: torch.tensor(a, dtype=torch.int32, device=dev)
+    args_ = ("auto", kc, vc, bt, i32(0, new), i32(ctx + new), i32(ctx), new, 1.0, 1.0, None, None)
+    t = timeit(lambda: ops.context_attention_fwd(q[:new], k[:new], v[:new], o, *args_, max_seq_len=ctx + new, total_kv_tokens=ctx + new))
+    fl = 4.0 * D * Hq * (new * ctx + new * new / 2)
+    out["context_attention_fwd 6144 cached + 2048 new"] = dict(ms=t * 1e3, TFLOPs=fl / t / 1e12, frac=fl / t / 2.5e15, bound="mfma f16")
+    M, K, N = 8192, cfg.hidden_size, 2 * cfg.intermediate_size
+    qw = torch.randint(-2 ** 31, 2 ** 31 - 1, (K // 8, N), generator=g, device=dev, dtype=torch.int64).to(torch.int32)
+    qz = torch.randint(-2 ** 31, 2 ** 31 - 1, (K // 128, N // 8), generator=g, device=dev, dtype=torch.int64).to(torch.int32)
+    sc = (torch.rand(K // 128, N, generator=g, device=dev) * 0.01 + 0.005).half()
+    a = torch.randn(M, K, device=dev, dtype=torch.float16, generator=g)
+    empty = torch.empty(0, dtype=torch.int32, device=dev)
+    t = timeit(lambda: ops.gptq_gemm(a, qw, qz, sc, empty, True, 4), 3)
+    fl = 2.0 * M * N * K
+    out[f"gptq_gemm W4A16 {M}x{K}x{N}"] = dict(ms=t * 1e3, TFLOPs=fl / t / 1e12, frac=fl / t / 2.5e15, bound="mfma f16")
+    del qw, qz, sc
+    w8 = (torch.randn(N, K, device=dev, generator=g) * 0.5).to(torch.float8_e4m3fn)
+    a8 = a.to(torch.float8_e4m3fn)
+    sa = torch.rand(M, 1, device=dev, generator=g) * 0.1 + 0.05
+    sb = torch.rand(N, device=dev, generator=g) * 0.01 + 0.005
+    ob = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    t = timeit(lambda: ops.cutlass_scaled_mm(a8, w8.t(), sa, sb, torch.bfloat16, out=ob), 3)
+    out[f"cutlass_scaled_mm W8A8 fp8 {M}x{K}x{N}"] = dict(ms=t * 1e3, TFLOPs=fl / t / 1e12, frac=fl / t / 5.0e15, bound="mfma fp8")
+    return out
+
+
 def all_reduce_section(args, model, device, ca):
     """TP only (every rank calls it): latency of the [bs, hidden] sum the decode layer issues twice, as the decode
     graph runs it -- 32 back-to-back all-reduces captured into one HIP graph -- for the xGMI peer-access kernel
@@ -505,6 +566,13 @@ def main():
     }
     if ar_info is not None:
         line["all_reduce_info"] = ar_info
+    if world == 1 and not args.no_prefill_info and args.model == "llama3-8b":
+        try:
+            del loop, model               # the decode state is no longer needed: give its memory back first
+            torch.cuda.empty_cache()
+            line["prefill_kernels"] = prefill_section(cfg)
+        except Exception as e:
+            line["prefill_kernels"] = {"error": repr(e)}
     if args.layers:
         line["config"]["INVALID"] = "debug run with fewer layers"
     if world == 1 and not args.no_cpu_baseline and args.model == "llama3-8b":

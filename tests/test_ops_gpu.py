@@ -176,6 +176,18 @@ def test_awq_gemm(ops, M, K, N, G):
         np.testing.assert_allclose(got2, ref, rtol=2e-3, atol=2e-3 * np.abs(ref).max())
 
 
+def test_awq_gemm_prefill_sized(ops):
+    """awq_gemm on checkpoint-layout tensors at prefill-sized M: per-call nibble transpose + the MFMA-bound kernel, same
+    answer as the oracle (reference bar atol = rtol = 1e-1, test_awq_triton.py:170; ours 2e-3)."""
+    rng = np.random.default_rng(21)
+    M, K, N, G = 600, 1024, 512, 128
+    qw, qz, s_ = make_awq(rng, K, N, G)
+    a = rng.standard_normal((M, K)).astype(np.float16)
+    ref = oq.awq_gemm(a, qw, s_, qz)
+    got = ops.awq_gemm(t(a), t(qw), t(s_), t(qz), 8).float().cpu().numpy()
+    np.testing.assert_allclose(got, ref, rtol=2e-3, atol=2e-3 * np.abs(ref).max())
+
+
 # ---------------------------------------------------------------------------
 # BASELINE.json configs[2..4] at their real shapes (parity-test cases, not bench lines)
 # ---------------------------------------------------------------------------
