@@ -466,6 +466,9 @@ typedef __attribute__((address_space(3))) void* fa_lds_ptr;
 #ifndef FA_QK_SCHED
 #define FA_QK_SCHED 1
 #endif
+#ifndef FA_FUSED_QKSM
+#define FA_FUSED_QKSM 1
+#endif
 // lab (APHRO_FA_DEBUG=1): s_memtime stamps of the heaviest workgroup's waves, read back with aphro_fa_debug_dump
 __device__ unsigned long long fa_dbg[8 * 64];
 #define FA_STAMP(slot) if ((p.debug & 1) && blockIdx.x == 0 && lane == 0) fa_dbg[wave * 64 + (slot)] = __builtin_amdgcn_s_memtime();
@@ -655,6 +658,63 @@ __global__ __launch_bounds__(512) void flash_attn_varlen_v3_kernel(FAParams p) {
     make_pf(src, pf);
     return alpha;
   };
+  // QK^T of tile it + 1 (into nxt) and the softmax of an unmasked tile (cur -> pf) as ONE hand-interleaved stream: per
+  // k-step two MFMAs, then a slice of the softmax VALU that runs in their shadow; sched_barrier keeps hipcc from
+  // regrouping them into an MFMA block and a VALU block (which is what every compiler-driven attempt produced).
+  auto qk_softmax_fast = [&](int it_next, f32x16 (&nxt)[2], f32x16 (&cur)[2], u32x4 (&pf)[4]) __attribute__((always_inline)) -> float {
+    const unsigned char* sk = fa_smem + (it_next % 3) * STAGE;
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int ka = kaddr, qa = qaddr;
+    asm volatile("" : "+v"(ka), "+v"(qa));
+    u32x4 fr[2][3];
+    auto rd = [&](int ks, u32x4 (&f)[3]) __attribute__((always_inline)) {
+      f[0] = *reinterpret_cast<const u32x4*>(qlds + (qa ^ (ks << 5)));
+      f[1] = *reinterpret_cast<const u32x4*>(sk + (ka ^ (ks << 5)));
+      f[2] = *reinterpret_cast<const u32x4*>(sk + 8192 + (ka ^ (ks << 5)));
+    };
+    float mx = 0.f, m_new = 0.f, alpha = 1.f, lsum = 0.f;
+    rd(0, fr[0]);
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      if (ks < 7) rd(ks + 1, fr[(ks + 1) & 1]);
+      nxt[0] = fa_mfma32<T>(fr[ks & 1][1], fr[ks & 1][0], ks == 0 ? zero : nxt[0]);
+      nxt[1] = fa_mfma32<T>(fr[ks & 1][2], fr[ks & 1][0], ks == 0 ? zero : nxt[1]);
+      if (ks == 0) {
+        mx = __builtin_fmaxf(cur[0][0], cur[1][0]);
+#pragma unroll
+        for (int r = 1; r < 8; ++r) mx = __builtin_fmaxf(mx, __builtin_fmaxf(cur[0][r], cur[1][r]));
+      } else if (ks == 1) {
+#pragma unroll
+        for (int r = 8; r < 16; ++r) mx = __builtin_fmaxf(mx, __builtin_fmaxf(cur[0][r], cur[1][r]));
+        mx *= c2;
+        mx = __builtin_fmaxf(mx, other_half(mx));
+        m_new = __builtin_fmaxf(m_run, mx);
+        alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        m_run = m_new;
+      } else if (ks < 6) {
+        const int b = (ks - 2) >> 1, r0 = ((ks - 2) & 1) * 8;
+#pragma unroll
+        for (int r = r0; r < r0 + 8; ++r) {
+          cur[b][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(cur[b][r], c2, -m_new));
+          lsum += cur[b][r];
+        }
+      } else {
+        const int b = ks - 6;
+        if (b == 0) l_run = l_run * alpha + lsum;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int g0 = 8 * j, g1 = 8 * j + 4;
+          const uint32_t lo0 = pack2_16<BF>(cur[b][g0], cur[b][g0 + 1]), hi0 = pack2_16<BF>(cur[b][g0 + 2], cur[b][g0 + 3]);
+          const uint32_t lo1 = pack2_16<BF>(cur[b][g1], cur[b][g1 + 1]), hi1 = pack2_16<BF>(cur[b][g1 + 2], cur[b][g1 + 3]);
+          const auto s_lo = __builtin_amdgcn_permlane32_swap(lo0, lo1, false, false);
+          const auto s_hi = __builtin_amdgcn_permlane32_swap(hi0, hi1, false, false);
+          pf[2 * b + j] = u32x4{(uint32_t)s_lo[0], (uint32_t)s_hi[0], (uint32_t)s_lo[1], (uint32_t)s_hi[1]};
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    return alpha;
+  };
   // the general form: key >= len, key > q (causal), ALiBi
   auto softmax_edge = [&](int it, f32x16 (&src)[2], u32x4 (&pf)[4]) __attribute__((always_inline)) -> float {
     const int t0 = it * BN;
@@ -753,8 +813,17 @@ __global__ __launch_bounds__(512) void flash_attn_varlen_v3_kernel(FAParams p) {
     // QK^T of the NEXT tile is issued ahead of this tile's softmax: its MFMAs are independent of the softmax VALU
     // (unconditional: past this wave's last tile it multiplies stale ring data into a buffer nobody reads -- keeping the
     //  branch out puts these MFMAs and the softmax VALU in ONE scheduling region)
+#if FA_FUSED_QKSM
+    if (it < F && !trail) {
+      alpha = qk_softmax_fast(it + 1, s_nxt, s_cur, pf);
+    } else {
+      if (!trail) do_qk(it + 1, s_nxt);
+      alpha = it < F ? softmax_fast(s_cur, pf) : softmax_edge(it, s_cur, pf);
+    }
+#else
     if (!trail) do_qk(it + 1, s_nxt);
     alpha = it < F ? softmax_fast(s_cur, pf) : softmax_edge(it, s_cur, pf);
+#endif
     if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
 #pragma unroll
       for (int db = 0; db < 4; ++db)
