@@ -1237,9 +1237,21 @@ def fp8_marlin_gemm(a: torch.Tensor, b_q_weight: torch.Tensor,
     lib = _lib.lib()
     if a.stride(1) != 1:
         a = a.contiguous()
+    if size_m > WNA16_LARGE_MIN_M and size_n % 128 == 0 and size_k % 64 == 0 and not os.environ.get("APHRO_WNA16_NO_LARGE"):
+        # prefill-sized M: the int4 kernel's tile machine with e4m3 weights widened in registers (wna16_gemm_large.hip)
+        a_ = a[:size_m]
+        if a_.stride(0) % 8 != 0 or a_.data_ptr() % 16 != 0:
+            a_ = a_.contiguous()
+        out = torch.empty((size_m, size_n), dtype=a.dtype, device=a.device)
+        sb = b_scales.reshape(-1).float()
+        nbytes = lib.aphro_fp8_w8a16_gemm_large_workspace_bytes(size_m, size_n, size_k, _dt(a))
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=a.device) if nbytes else None
+        check(lib.aphro_fp8_w8a16_gemm_large(
+            out.data_ptr(), a_.data_ptr(), b_q_weight.data_ptr(), sb.data_ptr(), _ptr(bias), _ptr(ws), nbytes,
+            size_m, size_n, size_k, a_.stride(0), 1 if sb.numel() > 1 else 0, _dt(a), _stream()), "fp8_marlin_gemm")
+        return out
     if size_m >= GPTQ_DEQUANT_MIN_M:
-        # prefill-sized M: widen the weight once (exact) and run a library GEMM, the same strategy as
-        # the int4 path above 256 rows
+        # shapes the hand-written kernel does not tile: widen the weight once (exact) and run a library GEMM
         w = b_q_weight.to(a.dtype)
         sb_ = b_scales.reshape(-1).to(a.dtype)
         w = w * (sb_.reshape(-1, 1) if sb_.numel() > 1 else sb_)

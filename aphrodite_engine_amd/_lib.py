@@ -85,6 +85,8 @@ SIGNATURES = {
     "aphro_dynamic_per_token_scaled_fp8_quant": (I, [P, P, P, P, L, L, I, P]),
     "aphro_scaled_mm_fp8": (I, [P, P, P, P, P, P, P, Z, L, L, L, I, I, I, P]),
     "aphro_scaled_mm_fp8_large_workspace_bytes": (Z, [L, L, L]),
+    "aphro_fp8_w8a16_gemm_large_workspace_bytes": (Z, [L, L, L, I]),
+    "aphro_fp8_w8a16_gemm_large": (I, [P, P, P, P, P, P, Z, L, L, L, L, I, I, P]),
     "aphro_scaled_mm_fp8_large": (I, [P, P, P, P, P, P, P, Z, L, L, L, I, I, I, P]),
     "aphro_fp8_w8a16_gemm": (I, [P, P, P, P, P, P, Z, L, L, L, L, I, I, P]),
     "aphro_fp8_gemm_workspace_bytes": (Z, [L, L, L]),

@@ -39,6 +39,12 @@ struct Wna16LargeParams {
   int tiles_m, tiles_n;
   int ksplit;             // > 1: blockIdx.y owns K / ksplit consecutive k and writes an fp32 slab of `partial`
   float* partial;         // [ksplit][M][N]
+  // W8A16 form (template WFP8): e4m3 weights [N, K] (K-contiguous), per-tensor / per-channel fp32 scales applied in the
+  // epilogue, optional bias in the output type.  qw / qz / sc / group_size / zero_offset are unused then.
+  const uint8_t* w8;
+  const float* w_scales;
+  int w_per_channel;
+  const uint16_t* bias;
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t lg_rsrc(const void* base, uint32_t bytes) {
@@ -69,19 +75,19 @@ __device__ __forceinline__ f16x8 dq8_scaled(uint32_t w, f16x2 zh, f16x2 zh16, f1
   return __builtin_bit_cast(f16x8, r);
 }
 
-template <int WM, int WN, int STAGES>
+template <int WM, int WN, int STAGES, bool WFP8>
 __global__ __launch_bounds__(WM * WN * 64) void wna16_gemm_large_kernel(Wna16LargeParams p) {
   constexpr int NWAVE = WM * WN;
   constexpr int BM = 128 * WM, BN = 64 * WN, BK = 64;
   constexpr int A_STAGE = BM * BK * 2;              // bytes
-  constexpr int B_STAGE = (BK / 8) * BN * 4;
+  constexpr int B_STAGE = WFP8 ? BN * BK : (BK / 8) * BN * 4;   // W8A16: BN rows of 64 e4m3
   constexpr int STAGE = A_STAGE + B_STAGE;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // [STAGES][A tile | B tile] [scales: G x BN f16] [zeros: G x BN/8 words]
   const int klen = p.K / p.ksplit;                  // this workgroup's K range: [k_begin, k_begin + klen)
   const int k_begin = blockIdx.y * klen;
-  const int g_begin = k_begin / p.group_size;
-  const int G = klen / p.group_size;                // groups in the range (the host makes klen a multiple of the group)
+  const int g_begin = WFP8 ? 0 : k_begin / p.group_size;
+  const int G = WFP8 ? 0 : klen / p.group_size;     // groups in the range (the host makes klen a multiple of the group)
   uint16_t* meta_sc = reinterpret_cast<uint16_t*>(smem + STAGES * STAGE);
   uint32_t* meta_z = reinterpret_cast<uint32_t*>(smem + STAGES * STAGE + G * BN * 2);
 
@@ -100,10 +106,12 @@ __global__ __launch_bounds__(WM * WN * 64) void wna16_gemm_large_kernel(Wna16Lar
   const int m0 = tm * BM, n0 = tn * BN;
 
   // ---- prologue: group scales / zeros of this workgroup's BN columns for the whole K range -> LDS ------------------
+  if constexpr (!WFP8)
   for (int i = threadIdx.x; i < G * (BN / 2); i += NWAVE * 64) {
     const int g = i / (BN / 2), j = i % (BN / 2);
     reinterpret_cast<uint32_t*>(meta_sc)[i] = reinterpret_cast<const uint32_t*>(p.sc)[((size_t)(g_begin + g) * p.N + n0) / 2 + j];
   }
+  if constexpr (!WFP8)
   for (int i = threadIdx.x; i < G * (BN / 8); i += NWAVE * 64) {
     const int g = i / (BN / 8), j = i % (BN / 8);
     meta_z[i] = p.qz[(size_t)(g_begin + g) * (p.N >> 3) + (n0 >> 3) + j];
@@ -111,7 +119,8 @@ __global__ __launch_bounds__(WM * WN * 64) void wna16_gemm_large_kernel(Wna16Lar
 
   // ---- staging (direct-to-LDS) ---------------------------------------------------------------------------------------
   const __amdgpu_buffer_rsrc_t ra = lg_rsrc(p.a, (uint32_t)((size_t)p.M * p.lda * 2));
-  const __amdgpu_buffer_rsrc_t rb = lg_rsrc(p.qw, (uint32_t)((size_t)(p.K >> 3) * p.N * 4));
+  const __amdgpu_buffer_rsrc_t rb = WFP8 ? lg_rsrc(p.w8, (uint32_t)((size_t)p.N * p.K))
+                                         : lg_rsrc(p.qw, (uint32_t)((size_t)(p.K >> 3) * p.N * 4));
   // A tile: BM rows x 128 B; one DMA instruction = 8 rows (lane -> row l/8, 16-byte slot l%8).  LDS slot s' of row r
   // holds global slot s' ^ f(r), f(r) = (r >> 1) & 7  (conflict-free ds_read_b128 below).
   constexpr int A_INSTR = BM / 8;                   // DMA instructions per A tile
@@ -138,11 +147,20 @@ __global__ __launch_bounds__(WM * WN * 64) void wna16_gemm_large_kernel(Wna16Lar
                                                (k_begin + kt * BK) * 2, 0, 0);
     }
     for (int i = wave; i < B_INSTR; i += NWAVE) {
-      // dword index d = i * 256 + 4 * lane .. +3 of the [8][BN] tile
-      const int d = i * 256 + lane * 4;
-      const int row = d / BN, col = d % BN;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void_ptr)(sa + A_STAGE + i * 1024), 16,
-                                               (n0 + col) * 4 + row * b_row_bytes, (k_begin / 8 + kt * 8) * b_row_bytes, 0, 0);
+      if constexpr (WFP8) {
+        // 16 weight rows x 64 B per instruction (lane -> row i * 16 + l / 4, 16-byte slot l % 4); LDS slot s' of row r
+        // holds global slot s' ^ ((r >> 2) & 3): the 8-byte fragment reads below are then at most 2-way conflicted
+        const int row = i * 16 + (lane >> 2);
+        const int slot = (lane & 3) ^ ((row >> 2) & 3);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void_ptr)(sa + A_STAGE + i * 1024), 16,
+                                                 (n0 + row) * p.K + slot * 16, k_begin + kt * BK, 0, 0);
+      } else {
+        // dword index d = i * 256 + 4 * lane .. +3 of the [8][BN] tile
+        const int d = i * 256 + lane * 4;
+        const int row = d / BN, col = d % BN;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void_ptr)(sa + A_STAGE + i * 1024), 16,
+                                                 (n0 + col) * 4 + row * b_row_bytes, (k_begin / 8 + kt * 8) * b_row_bytes, 0, 0);
+      }
     }
   };
 
@@ -178,8 +196,8 @@ __global__ __launch_bounds__(WM * WN * 64) void wna16_gemm_large_kernel(Wna16Lar
     } else {
       if (kt + 1 < ktiles) stage(st ^ 1, kt + 1);     // next tile's DMA in flight under this tile's MFMAs
     }
-    const int grp = (kt * BK) / p.group_size;
-    if (grp != cur_group) {                           // wave-uniform: new quantisation group
+    const int grp = WFP8 ? 0 : (kt * BK) / p.group_size;
+    if (!WFP8 && grp != cur_group) {                  // wave-uniform: new quantisation group
       cur_group = grp;
 #pragma unroll
       for (int nb = 0; nb < 2; ++nb) {
@@ -200,10 +218,20 @@ __global__ __launch_bounds__(WM * WN * 64) void wna16_gemm_large_kernel(Wna16Lar
     // Fragments of k-step j + 1 are read from LDS while the MFMAs of step j run (two register sets; hipcc left to
     // itself reuses ONE fragment register and waits lgkmcnt(0) in front of every MFMA pair: 0.40 -> see DESIGN.md).
     u32x4 af[2][4];
-    uint32_t wraw[2][2];
-    auto read_frags = [&](int j, u32x4 (&a4)[4], uint32_t (&w2)[2]) {
+    uint32_t wraw[2][2], wrawh[2][2];   // (wrawh: second dword of the 8 e4m3 of the W8A16 form)
+    auto read_frags = [&](int j, u32x4 (&a4)[4], uint32_t (&w2)[2], uint32_t (&w2h)[2]) {
 #pragma unroll
-      for (int nb = 0; nb < 2; ++nb) w2[nb] = sb[(2 * j + kh) * BN + wn * 64 + nb * 32 + l31];
+      for (int nb = 0; nb < 2; ++nb) {
+        if constexpr (WFP8) {   // 8 e4m3 = k 16 j + 8 kh .. + 7 of weight row n: 8-byte piece q = 2 j + kh of the row
+          const int row = wn * 64 + nb * 32 + l31;
+          const int q = 2 * j + kh;
+          const u32x2 w8v = *reinterpret_cast<const u32x2*>(sa + A_STAGE + row * 64 + ((((q >> 1) ^ ((row >> 2) & 3)) << 4) | ((q & 1) << 3)));
+          w2[nb] = w8v[0];
+          w2h[nb] = w8v[1];
+        } else {
+          w2[nb] = sb[(2 * j + kh) * BN + wn * 64 + nb * 32 + l31];
+        }
+      }
 #pragma unroll
       for (int mb = 0; mb < 4; ++mb) {
         const int row = wm * 128 + mb * 32 + l31;
@@ -211,14 +239,23 @@ __global__ __launch_bounds__(WM * WN * 64) void wna16_gemm_large_kernel(Wna16Lar
         a4[mb] = *reinterpret_cast<const u32x4*>(sa + row * 128 + slot * 16);
       }
     };
-    read_frags(0, af[0], wraw[0]);
+    read_frags(0, af[0], wraw[0], wrawh[0]);
 #pragma unroll
     for (int j = 0; j < BK / 16; ++j) {
-      if (j + 1 < BK / 16) read_frags(j + 1, af[(j + 1) & 1], wraw[(j + 1) & 1]);
+      if (j + 1 < BK / 16) read_frags(j + 1, af[(j + 1) & 1], wraw[(j + 1) & 1], wrawh[(j + 1) & 1]);
       __builtin_amdgcn_sched_barrier(0);            // keep the next step's LDS reads ABOVE this step's MFMAs
       f16x8 wf[2];
 #pragma unroll
-      for (int nb = 0; nb < 2; ++nb) wf[nb] = dq8_scaled(wraw[j & 1][nb], zh[nb], zh16[nb], scv[nb]);
+      for (int nb = 0; nb < 2; ++nb) {
+        if constexpr (WFP8) {   // e4m3 -> f16 is exact: 4 packed hardware converts, the scale waits for the epilogue
+          const uint32_t lo = wraw[j & 1][nb], hi = wrawh[j & 1][nb];
+          const u32x4 r = {fp8x2_to_T<Half, false, false>(lo), fp8x2_to_T<Half, false, true>(lo),
+                           fp8x2_to_T<Half, false, false>(hi), fp8x2_to_T<Half, false, true>(hi)};
+          wf[nb] = __builtin_bit_cast(f16x8, r);
+        } else {
+          wf[nb] = dq8_scaled(wraw[j & 1][nb], zh[nb], zh16[nb], scv[nb]);
+        }
+      }
 #pragma unroll
       for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
@@ -249,13 +286,34 @@ __global__ __launch_bounds__(WM * WN * 64) void wna16_gemm_large_kernel(Wna16Lar
   }
   if constexpr (STAGES == 3) __syncthreads();      // every wave is done with the stage buffers: reuse them (epi_put)
   unsigned char* region = smem + wave * 16384;
+  f32x4 wsv[2][4], bsv[2][4];     // W8A16: per-channel scale and bias of this lane's 4-column groups, fetched up front
+  if constexpr (WFP8) {
+    const float s0 = p.w_per_channel ? 1.f : p.w_scales[0];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int col = n0 + wn * 64 + nb * 32 + 8 * q + 4 * kh;
+        wsv[nb][q] = p.w_per_channel ? *reinterpret_cast<const f32x4*>(p.w_scales + col) : f32x4{s0, s0, s0, s0};
+        bsv[nb][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (p.bias) {
+          const u16x4 b4 = *reinterpret_cast<const u16x4*>(p.bias + col);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) bsv[nb][q][r] = p.out_bf16 ? bf16_bits_to_f32(b4[r]) : f16_bits_to_f32(b4[r]);
+        }
+      }
+  }
 #pragma unroll
   for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const float v0 = acc[nb][mb][4 * q], v1 = acc[nb][mb][4 * q + 1], v2 = acc[nb][mb][4 * q + 2], v3 = acc[nb][mb][4 * q + 3];
+        float v0 = acc[nb][mb][4 * q], v1 = acc[nb][mb][4 * q + 1], v2 = acc[nb][mb][4 * q + 2], v3 = acc[nb][mb][4 * q + 3];
+        if constexpr (WFP8) {
+          v0 = v0 * wsv[nb][q][0] + bsv[nb][q][0]; v1 = v1 * wsv[nb][q][1] + bsv[nb][q][1];
+          v2 = v2 * wsv[nb][q][2] + bsv[nb][q][2]; v3 = v3 * wsv[nb][q][3] + bsv[nb][q][3];
+        }
         epi_put(region, mb * 32 + l31, nb * 8 + 2 * q + kh,
                 p.out_bf16 ? u32x2{pack2_16<true>(v0, v1), pack2_16<true>(v2, v3)} : u32x2{pack2_16<false>(v0, v1), pack2_16<false>(v2, v3)});
       }
@@ -264,11 +322,20 @@ __global__ __launch_bounds__(WM * WN * 64) void wna16_gemm_large_kernel(Wna16Lar
 
 // partial [S][M*N] fp32 -> c [M*N] f16 / bf16 (fixed summation order: deterministic)
 __global__ void splitk_reduce_large_kernel(const float* __restrict__ partial, uint16_t* __restrict__ c, int64_t mn, int S,
-                                           int out_bf16) {
+                                           int out_bf16, const float* __restrict__ w_scales = nullptr, int w_per_channel = 0,
+                                           const uint16_t* __restrict__ bias = nullptr, int N = 1) {
   const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (i >= mn) return;
   f32x4 s = *reinterpret_cast<const f32x4*>(partial + i);
   for (int k = 1; k < S; ++k) s += *reinterpret_cast<const f32x4*>(partial + (size_t)k * mn + i);
+  if (w_scales) {            // W8A16 form: the epilogue the single-slice kernel applies itself
+    const int col = (int)(i % N);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      s[j] *= w_scales[w_per_channel ? col + j : 0];
+      if (bias) s[j] += out_bf16 ? bf16_bits_to_f32(bias[col + j]) : f16_bits_to_f32(bias[col + j]);
+    }
+  }
   u16x4 o;
 #pragma unroll
   for (int j = 0; j < 4; ++j) o[j] = out_bf16 ? f32_to_bf16_bits(s[j]) : f32_to_f16_bits(s[j]);
@@ -286,14 +353,14 @@ __global__ void bf16_to_f16_rows_kernel(const uint16_t* __restrict__ in, uint16_
   *reinterpret_cast<u16x8*>(out + i) = v;
 }
 
-template <int WM, int WN, int STAGES>
+template <int WM, int WN, int STAGES, bool WFP8>
 static int launch_large_s(const Wna16LargeParams& p, hipStream_t st) {
   constexpr int BM = 128 * WM, BN = 64 * WN;
   Wna16LargeParams q = p;
   q.tiles_m = (p.M + BM - 1) / BM;
   q.tiles_n = p.N / BN;
-  const int G = p.K / p.ksplit / p.group_size;
-  size_t lds = STAGES * ((size_t)BM * 64 * 2 + 8 * BN * 4) + (size_t)G * BN * 2 + (size_t)G * (BN / 8) * 4;
+  const int G = WFP8 ? 0 : p.K / p.ksplit / p.group_size;
+  size_t lds = STAGES * ((size_t)BM * 64 * 2 + (WFP8 ? (size_t)BN * 64 : (size_t)8 * BN * 4)) + (size_t)G * BN * 2 + (size_t)G * (BN / 8) * 4;
   if (lds < (size_t)WM * WN * 16384) lds = (size_t)WM * WN * 16384;   // the epilogue's wave-private transpose regions
   if (lds > 160 * 1024) {
     set_error("wna16_gemm_large: %zu bytes of LDS needed (K=%d, group %d)", lds, p.K, p.group_size);
@@ -301,27 +368,27 @@ static int launch_large_s(const Wna16LargeParams& p, hipStream_t st) {
   }
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)wna16_gemm_large_kernel<WM, WN, STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute((const void*)wna16_gemm_large_kernel<WM, WN, STAGES, WFP8>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024) != hipSuccess) {
       set_error("wna16_gemm_large: cannot raise the dynamic LDS limit");
       return APHRO_ERR_LAUNCH;
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL((wna16_gemm_large_kernel<WM, WN, STAGES>), dim3(q.tiles_m * q.tiles_n, q.ksplit), dim3(WM * WN * 64), lds, st, q);
+  hipLaunchKernelGGL((wna16_gemm_large_kernel<WM, WN, STAGES, WFP8>), dim3(q.tiles_m * q.tiles_n, q.ksplit), dim3(WM * WN * 64), lds, st, q);
   APHRO_LAUNCH_CHECK();
   return APHRO_OK;
 }
 
 // three LDS stages (loads two K tiles ahead, one raw barrier per tile) when the group metadata leaves room for them
-template <int WM, int WN>
+template <int WM, int WN, bool WFP8 = false>
 static int launch_large(const Wna16LargeParams& p, hipStream_t st) {
   constexpr int BM = 128 * WM, BN = 64 * WN;
-  const int G = p.K / p.ksplit / p.group_size;
-  const size_t lds3 = 3 * ((size_t)BM * 64 * 2 + 8 * BN * 4) + (size_t)G * BN * 2 + (size_t)G * (BN / 8) * 4;
+  const int G = WFP8 ? 0 : p.K / p.ksplit / p.group_size;
+  const size_t lds3 = 3 * ((size_t)BM * 64 * 2 + (WFP8 ? (size_t)BN * 64 : (size_t)8 * BN * 4)) + (size_t)G * BN * 2 + (size_t)G * (BN / 8) * 4;
   static const int force = getenv("APHRO_WNA16_LARGE_STAGES") ? atoi(getenv("APHRO_WNA16_LARGE_STAGES")) : 0;
-  if ((lds3 <= 160 * 1024 && force != 2) || force == 3) return launch_large_s<WM, WN, 3>(p, st);
-  return launch_large_s<WM, WN, 2>(p, st);
+  if ((lds3 <= 160 * 1024 && force != 2) || force == 3) return launch_large_s<WM, WN, 3, WFP8>(p, st);
+  return launch_large_s<WM, WN, 2, WFP8>(p, st);
 }
 
 }  // namespace aphro
@@ -394,6 +461,7 @@ extern "C" int aphro_wna16_gemm_large(const void* a, const uint32_t* q_weight, c
   p.out_bf16 = dtype == APHRO_BF16; p.scale_bf16 = dtype == APHRO_BF16;
   p.tiles_m = p.tiles_n = 0;
   p.ksplit = pl.ksplit; p.partial = (float*)ws;
+  p.w8 = nullptr; p.w_scales = nullptr; p.w_per_channel = 0; p.bias = nullptr;
   int rc;
   if (pl.wm == 2) rc = pl.wn == 4 ? launch_large<2, 4>(p, st) : launch_large<2, 2>(p, st);
   else rc = pl.wn == 4 ? launch_large<1, 4>(p, st) : launch_large<1, 2>(p, st);
@@ -402,6 +470,61 @@ extern "C" int aphro_wna16_gemm_large(const void* a, const uint32_t* q_weight, c
     const int64_t mn = M * N;
     hipLaunchKernelGGL(splitk_reduce_large_kernel, dim3((unsigned)((mn / 4 + 255) / 256)), dim3(256), 0, st, p.partial,
                        (uint16_t*)c, mn, pl.ksplit, p.out_bf16);
+    APHRO_LAUNCH_CHECK();
+  }
+  return APHRO_OK;
+}
+
+// W8A16 for prefill-sized M -- the role of `_C::fp8_marlin_gemm` (kernels/torch_bindings.cpp:218-222,
+// quantization/fp8/fp8_marlin.cu:1212) above 64 rows: c[M, N] = a[M, K] . (f16(w[N, K]) * w_scales[n]) + bias.  The same tile
+// machine as the int4 kernel: e4m3 weights [N, K] go direct-to-LDS, are widened to f16 in registers (exact) and the scale
+// is applied once per output in the epilogue.  N % 128 == 0, K % 64 == 0.  workspace: the f16 copy of bf16 activations
+// + the fp32 split-K slabs of small grids.
+extern "C" size_t aphro_fp8_w8a16_gemm_large_workspace_bytes(int64_t M, int64_t N, int64_t K, int dtype) {
+  const LargePlan pl = large_plan(M, N, K, 64);
+  size_t b = dtype == APHRO_BF16 ? ((size_t)M * K * 2 + 255) / 256 * 256 : 0;
+  if (pl.ksplit > 1) b += (size_t)pl.ksplit * M * N * sizeof(float);
+  return b;
+}
+
+extern "C" int aphro_fp8_w8a16_gemm_large(void* out, const void* a, const void* w, const float* w_scales, const void* bias,
+                                          void* workspace, size_t workspace_bytes, int64_t M, int64_t N, int64_t K, int64_t lda,
+                                          int w_scale_per_channel, int dtype, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  APHRO_CHECK(dtype == APHRO_F16 || dtype == APHRO_BF16, "fp8_w8a16_gemm_large: dtype must be f16 or bf16");
+  APHRO_CHECK(N % 128 == 0 && K % 64 == 0, "fp8_w8a16_gemm_large: N=%ld must be a multiple of 128, K=%ld of 64", (long)N, (long)K);
+  APHRO_CHECK(lda % 8 == 0 && ((uintptr_t)a % 16) == 0 && ((uintptr_t)w % 16) == 0, "fp8_w8a16_gemm_large: 16-byte alignment");
+  APHRO_CHECK((size_t)M * lda * 2 < 0xffffffffull && (size_t)N * K < 0xffffffffull, "fp8_w8a16_gemm_large: operand exceeds 4 GiB");
+  if (M == 0) return APHRO_OK;
+  const size_t need = aphro_fp8_w8a16_gemm_large_workspace_bytes(M, N, K, dtype);
+  if (need > 0 && (workspace == nullptr || workspace_bytes < need)) {
+    set_error("fp8_w8a16_gemm_large: workspace %zu < %zu bytes", workspace_bytes, need);
+    return APHRO_ERR_WORKSPACE;
+  }
+  Wna16LargeParams p;
+  p.a = (const uint16_t*)a; p.lda = (int)lda;
+  if (dtype == APHRO_BF16) {
+    const int64_t n8 = M * K / 8;
+    hipLaunchKernelGGL(bf16_to_f16_rows_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, st, (const uint16_t*)a,
+                       (uint16_t*)workspace, (int)M, (int)K, (int)lda);
+    APHRO_LAUNCH_CHECK();
+    p.a = (const uint16_t*)workspace; p.lda = (int)K;
+  }
+  p.qw = nullptr; p.qz = nullptr; p.sc = nullptr; p.c = (uint16_t*)out;
+  p.M = (int)M; p.N = (int)N; p.K = (int)K; p.group_size = 64; p.zero_offset = 0;
+  p.out_bf16 = dtype == APHRO_BF16; p.scale_bf16 = 0;
+  const LargePlan pl = large_plan(M, N, K, 64);
+  p.tiles_m = p.tiles_n = 0; p.ksplit = pl.ksplit;
+  p.partial = (float*)((char*)workspace + (dtype == APHRO_BF16 ? ((size_t)M * K * 2 + 255) / 256 * 256 : 0));
+  p.w8 = (const uint8_t*)w; p.w_scales = w_scales; p.w_per_channel = w_scale_per_channel; p.bias = (const uint16_t*)bias;
+  int rc;
+  if (pl.wm == 2) rc = pl.wn == 4 ? launch_large<2, 4, true>(p, st) : launch_large<2, 2, true>(p, st);
+  else rc = pl.wn == 4 ? launch_large<1, 4, true>(p, st) : launch_large<1, 2, true>(p, st);
+  if (rc != APHRO_OK) return rc;
+  if (pl.ksplit > 1) {
+    const int64_t mn = M * N;
+    hipLaunchKernelGGL(splitk_reduce_large_kernel, dim3((unsigned)((mn / 4 + 255) / 256)), dim3(256), 0, st, p.partial,
+                       (uint16_t*)out, mn, pl.ksplit, p.out_bf16, w_scales, w_scale_per_channel, (const uint16_t*)bias, (int)N);
     APHRO_LAUNCH_CHECK();
   }
   return APHRO_OK;

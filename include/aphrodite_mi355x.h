@@ -315,6 +315,14 @@ int aphro_fp8_w8a16_gemm(void* out, const void* a, const void* w,
                          size_t workspace_bytes, int64_t M, int64_t N, int64_t K,
                          int64_t lda, int w_scale_per_channel, int dtype,
                          void* stream);
+
+/* The same op for prefill-sized M (meant for M > 64): the tile machine of aphro_wna16_gemm_large with e4m3 weights widened
+ * to f16 in registers and the scale applied in the epilogue (wna16_gemm_large.hip).  N % 128 == 0, K % 64 == 0.
+ * workspace: the saturating f16 copy of bf16 activations + fp32 split-K slabs for small grids (may be 0). */
+size_t aphro_fp8_w8a16_gemm_large_workspace_bytes(int64_t M, int64_t N, int64_t K, int dtype);
+int aphro_fp8_w8a16_gemm_large(void* out, const void* a, const void* w, const float* w_scales, const void* bias,
+                               void* workspace, size_t workspace_bytes, int64_t M, int64_t N, int64_t K, int64_t lda,
+                               int w_scale_per_channel, int dtype, void* stream);
 size_t aphro_fp8_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K);
 
 /* ------------------------------------------------------------------------

@@ -226,6 +226,31 @@ def test_prefill_sized_fp8_scaled_mm_under_graph_capture(ops):
         assert torch.equal(out, eager)
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,K,N,per_channel,with_bias", [(65, 4096, 6144, True, False), (1000, 14336, 4096, True, True),
+                                                          (2100, 4096, 6144, False, False), (8192, 4096, 4096, True, False)])
+def test_prefill_sized_fp8_w8a16_vs_oracle(ops, dtype, M, K, N, per_channel, with_bias):
+    """W8A16 (fp8_marlin_gemm role) at prefill-sized M: e4m3 weights widened to f16 in registers on the int4 kernel's tile
+    machine, scale + bias in the epilogue; 160 rows vs the oracle, whole output finite, bit-identical across calls."""
+    from oracle import fp8 as of8
+    rng = np.random.default_rng(M + K + N)
+    a = t(rng.standard_normal((M, K)).astype(np.float32), dtype)
+    w = t((rng.standard_normal((N, K)) * 2).astype(np.float32)).to(torch.float8_e4m3fn)
+    sb = t((rng.random(N if per_channel else 1) * 0.1 + 0.01).astype(np.float32))
+    bias = t(rng.standard_normal(N).astype(np.float32), dtype) if with_bias else None
+    got = ops.fp8_marlin_gemm(a, w, sb, None, 8, M, N, K, bias)
+    assert got.shape == (M, N) and got.dtype == dtype and torch.isfinite(got.float()).all()
+    rows = sorted(set([0, 1, 31, 32, 63, 64, 127, 128, 255, 256, 257, M // 2, M - 2, M - 1]) & set(range(M))
+                  | set(rng.integers(0, M, size=146).tolist()))
+    ridx = torch.tensor(rows, device=DEV)
+    ref = of8.fp8_w8a16_gemm(a[ridx].float().cpu().numpy(), w.view(torch.uint8).cpu().numpy().T, sb.cpu().numpy())
+    if bias is not None:
+        ref = ref + bias.float().cpu().numpy()
+    tol = 2e-3 if dtype == torch.float16 else 1.6e-2
+    np.testing.assert_allclose(got[ridx].float().cpu().numpy(), ref, rtol=tol, atol=tol * np.abs(ref).max())
+    assert torch.equal(got, ops.fp8_marlin_gemm(a, w, sb, None, 8, M, N, K, bias))
+
+
 def _lin_np(lin):
     fp = lin.fast_params()
     assert fp is not None and fp[3] == 1
