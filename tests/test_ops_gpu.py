@@ -799,6 +799,34 @@ def test_flash_attn_varlen_long(ops, dtype, Hq, Hkv, D, causal, alibi):
     np.testing.assert_allclose(got.float().cpu().numpy(), ref, atol=tol, rtol=tol)
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("causal", [True, False])
+def test_flash_attn_varlen_v3_kv_head_placement(ops, dtype, causal):
+    """Third-generation prefill kernel with (sequences x kv heads) a multiple of 8: the kv-head -> XCD placement of the
+    workgroups is active (all query heads / query tiles of one kv head on one XCD).  Ragged lengths around the 256-row and
+    64-key tile edges, GQA 2:1, vs the oracle; the unplaced grid (APHRO_FA_NO_XCD) must give the same bits."""
+    import os
+    rng = np.random.default_rng(5)
+    Hq, Hkv, D = 16, 8, 128
+    lens = [1300, 257, 1024, 65]
+    cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    T = int(cu[-1])
+    qkv = t(rng.standard_normal((T, (Hq + 2 * Hkv) * D)).astype(np.float32) * 0.7, dtype)
+    q, k, v = qkv.split([Hq * D, Hkv * D, Hkv * D], dim=-1)
+    q, k, v = q.view(T, Hq, D), k.view(T, Hkv, D), v.view(T, Hkv, D)
+    scale = float(D ** -0.5)
+    got = ops.flash_attn_varlen(q, k, v, t(cu), max(lens), scale, causal=causal)
+    os.environ["APHRO_FA_NO_XCD"] = "1"
+    try:
+        plain = ops.flash_attn_varlen(q, k, v, t(cu), max(lens), scale, causal=causal)
+    finally:
+        del os.environ["APHRO_FA_NO_XCD"]
+    assert torch.equal(got, plain)
+    ref = oa.varlen_causal_attention(q, k, v, cu, scale, causal=causal)
+    tol = 2e-3 if dtype == torch.float16 else 1.6e-2
+    np.testing.assert_allclose(got.float().cpu().numpy(), ref, atol=tol, rtol=tol)
+
+
 def test_attention_backend_prefill_then_decode(ops):
     """AttentionImpl.forward on a mixed (chunked-prefill style) batch: prefill
     tokens attend causally within their sequence and are written to the paged
