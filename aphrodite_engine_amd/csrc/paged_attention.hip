@@ -251,7 +251,9 @@ __global__ __launch_bounds__(NW * 64) void paged_attention_kernel(PAParams p) {
     // K/V registers of one 32-token tile pair: kf = K fragments, vraw = 4 tokens x 16 d-rows per
     // lane (16-bit KV: 8 B, fp8: 4 B in [0]).  ONE set: a pair is loaded, then computed; the other 7 waves hide the
     // latency.  (A second set -- the next pair's loads issued before this pair's compute -- was measured in round 2:
-    // 256 VGPRs with 74 spills in the fused-rope form, 44 us instead of 29.7; fp8 KV 26.6 instead of 20 us.)
+    // 256 VGPRs with 74 spills in the fused-rope form, 44 us instead of 29.7; fp8 KV 26.6 instead of 20 us.  An L2
+    // warm-up of the next pair instead -- one dword per 128-byte line, issued when this pair's compute starts -- also
+    // lost: 36.1 / 24.0 us.)
     // Block-table entries of a pair ([jj] K block, [2 + jj] V block): fetched ONE PAIR AHEAD so that
     // the K/V loads never wait behind a dependent table lookup.
     auto load_ids = [&](int pr, int (&ids)[4]) __attribute__((always_inline)) {
