@@ -17,6 +17,8 @@
 //     workgroups is finished by the one that owns its k = 0 end: the others publish their fp32 accumulators
 //     (write-through stores + one flag word each, no fences) and the owner adds them in workgroup order
 //     (deterministic).  Small grids (< 128 tiles) keep the one-workgroup-per-(tile, K slice) form with fp32 slabs.
+//     Co-residency: an owner only waits for its successor, which publishes as soon as it has started -- progress is
+//     guaranteed while more than half of the CUs are available to this launch; the wait is bounded (5 s, then trap).
 //   * results leave through a wave-private LDS transpose as full 128-byte row segments (epi_put / epi_flush, common.h).
 // Workgroup = WN x WM waves, wave tile = 128 rows (m) x 64 columns (n), K tile = 128.
 #include "common.h"
@@ -244,8 +246,16 @@ __global__ __launch_bounds__(WM * WN * 64) void fp8_gemm_large_kernel(Fp8LargePa
       // in workgroup order.  They were published long ago unless the whole tile is being computed right now.
       const int64_t tile_end = (int64_t)(tile + 1) * ktiles_total;
       for (int j = w + 1; j < G && unit_begin(j) < tile_end; ++j) {
-        if (threadIdx.x == 0)
-          while (__hip_atomic_load(p.flags + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(4);
+        if (threadIdx.x == 0) {
+          // Bounded: workgroup j publishes its first segment right after it starts, so this only waits long if j is not
+          // resident yet.  Progress needs two consecutive logical workgroups resident at some point, i.e. more than half
+          // of the CUs available to this kernel; if something else pins the chip for 5 s, abort instead of hanging.
+          const unsigned long long t0 = wall_clock64();
+          while (__hip_atomic_load(p.flags + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+            __builtin_amdgcn_s_sleep(4);
+            if (wall_clock64() - t0 > 500000000ull) __builtin_trap();      // 100 MHz ticks
+          }
+        }
         __syncthreads();
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb)
