@@ -39,6 +39,10 @@ struct Wna16LargeParams {
   int tiles_m, tiles_n;
   int ksplit;             // > 1: blockIdx.y owns K / ksplit consecutive k and writes an fp32 slab of `partial`
   float* partial;         // [ksplit][M][N]
+  // stream-K form (see fp8_gemm_large.hip): one persistent workgroup per CU, equal (tile, K tile) unit ranges; `partial`
+  // then holds the accumulator images [grid][NWAVE * 32 KiB] and `flags` one "image published" word per workgroup
+  int streamk, grid;      // grid: persistent workgroups (= CUs)
+  unsigned* flags;
   // W8A16 form (template WFP8): e4m3 weights [N, K] (K-contiguous), per-tensor / per-channel fp32 scales applied in the
   // epilogue, optional bias in the output type.  qw / qz / sc / group_size / zero_offset are unused then.
   const uint8_t* w8;
@@ -84,26 +88,51 @@ __global__ __launch_bounds__(WM * WN * 64) void wna16_gemm_large_kernel(Wna16Lar
   constexpr int STAGE = A_STAGE + B_STAGE;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // [STAGES][A tile | B tile] [scales: G x BN f16] [zeros: G x BN/8 words]
-  const int klen = p.K / p.ksplit;                  // this workgroup's K range: [k_begin, k_begin + klen)
-  const int k_begin = blockIdx.y * klen;
-  const int g_begin = WFP8 ? 0 : k_begin / p.group_size;
-  const int G = WFP8 ? 0 : klen / p.group_size;     // groups in the range (the host makes klen a multiple of the group)
-  uint16_t* meta_sc = reinterpret_cast<uint16_t*>(smem + STAGES * STAGE);
-  uint32_t* meta_z = reinterpret_cast<uint32_t*>(smem + STAGES * STAGE + G * BN * 2);
-
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave % WM, wn = wave / WM;
-  // ---- XCD-aware tile order: XCD x gets a contiguous range of tile ids; within it the column tiles are the fast
-  // index (neighbours share the A row panel) ------------------------------------------------------------------------
+  const int kh = lane >> 5, l31 = lane & 31;
+  constexpr int IMAGE = NWAVE * 32 * 1024;          // bytes of one workgroup's accumulator image (stream-K)
+  // ---- this workgroup's units [u, u_end): unit = tile * (K / 64) + K tile.  XCD x gets a contiguous range of logical
+  // ids; within it the column tiles are the fast index (neighbours share the A row panel) --------------------------------
+  const int ktiles_total = p.K / BK;
   const int ntiles = p.tiles_m * p.tiles_n;
-  int tid;
-  {
-    const int bid = blockIdx.x, q = ntiles / 8, r = ntiles % 8, xcd = bid % 8, k = bid / 8;
-    tid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;    // bijective for any ntiles
+  const int GW = gridDim.x;
+  const int64_t U = (int64_t)ntiles * ktiles_total;
+  auto xcd_contiguous = [](int bid, int n) {
+    const int q = n / 8, r = n % 8, xcd = bid % 8, k = bid / 8;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;    // bijective for any n
+  };
+  int u, u_end, w = 0;
+  if (p.streamk) {
+    w = xcd_contiguous(blockIdx.x, GW);
+    u = (int)(w * U / GW);
+    u_end = (int)((w + 1) * U / GW);
+  } else {
+    const int per = ktiles_total / p.ksplit;
+    u = xcd_contiguous(blockIdx.x, ntiles) * ktiles_total + blockIdx.y * per;
+    u_end = u + per;
   }
-  const int tm = tid / p.tiles_n, tn = tid % p.tiles_n;
+  const __amdgpu_buffer_rsrc_t ra = lg_rsrc(p.a, (uint32_t)((size_t)p.M * p.lda * 2));
+  const __amdgpu_buffer_rsrc_t rb = WFP8 ? lg_rsrc(p.w8, (uint32_t)((size_t)p.N * p.K))
+                                         : lg_rsrc(p.qw, (uint32_t)((size_t)(p.K >> 3) * p.N * 4));
+  const __amdgpu_buffer_rsrc_t rp = lg_rsrc(p.partial, p.streamk ? (uint32_t)((size_t)GW * IMAGE) : 0u);
+  bool first_segment = true;
+  while (u < u_end) {
+  const int tile = u / ktiles_total;
+  const int k0t = u - tile * ktiles_total;
+  const int k1t = min(ktiles_total, k0t + (u_end - u));
+  u += k1t - k0t;
+  const bool head = k0t == 0, tail = k1t == ktiles_total;
+  const int k_begin = k0t * BK, klen = (k1t - k0t) * BK;   // this segment's K range: [k_begin, k_begin + klen)
+  const int g_begin = WFP8 ? 0 : k_begin / p.group_size;
+  const int G = WFP8 ? 0 : (k_begin + klen - 1) / p.group_size - g_begin + 1;   // quantisation groups it touches
+  uint16_t* meta_sc = reinterpret_cast<uint16_t*>(smem + STAGES * STAGE);
+  uint32_t* meta_z = reinterpret_cast<uint32_t*>(smem + STAGES * STAGE + G * BN * 2);
+  const int tm = tile / p.tiles_n, tn = tile % p.tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
+  if (!first_segment) __syncthreads();                // the previous segment's epilogue is done with the LDS
+  first_segment = false;
 
   // ---- prologue: group scales / zeros of this workgroup's BN columns for the whole K range -> LDS ------------------
   if constexpr (!WFP8)
@@ -118,9 +147,6 @@ __global__ __launch_bounds__(WM * WN * 64) void wna16_gemm_large_kernel(Wna16Lar
   }
 
   // ---- staging (direct-to-LDS) ---------------------------------------------------------------------------------------
-  const __amdgpu_buffer_rsrc_t ra = lg_rsrc(p.a, (uint32_t)((size_t)p.M * p.lda * 2));
-  const __amdgpu_buffer_rsrc_t rb = WFP8 ? lg_rsrc(p.w8, (uint32_t)((size_t)p.N * p.K))
-                                         : lg_rsrc(p.qw, (uint32_t)((size_t)(p.K >> 3) * p.N * 4));
   // A tile: BM rows x 128 B; one DMA instruction = 8 rows (lane -> row l/8, 16-byte slot l%8).  LDS slot s' of row r
   // holds global slot s' ^ f(r), f(r) = (r >> 1) & 7  (conflict-free ds_read_b128 below).
   constexpr int A_INSTR = BM / 8;                   // DMA instructions per A tile
@@ -172,7 +198,6 @@ __global__ __launch_bounds__(WM * WN * 64) void wna16_gemm_large_kernel(Wna16Lar
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[nb][mb][r] = 0.f;
 
-  const int kh = lane >> 5, l31 = lane & 31;
   const int ktiles = klen / BK;
   // DMA instructions one wave issues per K tile (uniform over the waves: the counted waits below rely on it)
   constexpr int DMA_PER_TILE = A_PER_WAVE + B_INSTR / NWAVE;
@@ -196,7 +221,7 @@ __global__ __launch_bounds__(WM * WN * 64) void wna16_gemm_large_kernel(Wna16Lar
     } else {
       if (kt + 1 < ktiles) stage(st ^ 1, kt + 1);     // next tile's DMA in flight under this tile's MFMAs
     }
-    const int grp = WFP8 ? 0 : (kt * BK) / p.group_size;
+    const int grp = WFP8 ? 0 : (k_begin + kt * BK) / p.group_size - g_begin;
     if (!WFP8 && grp != cur_group) {                  // wave-uniform: new quantisation group
       cur_group = grp;
 #pragma unroll
@@ -268,8 +293,54 @@ __global__ __launch_bounds__(WM * WN * 64) void wna16_gemm_large_kernel(Wna16Lar
     }
   }
 
-  // ---- epilogue: lane holds, for row m = mb*32 + l31, columns nb*32 + 8 q + 4 kh + (0..3), q = reg >> 2 --------------
-  if (p.ksplit > 1) {          // fp32 slab of this K range; summed by splitk_reduce_large_kernel
+  if constexpr (STAGES == 3) __syncthreads();      // every wave is done with the stage buffers
+  // ---- what happens to the accumulators: lane holds, for row m = mb*32 + l31, columns nb*32 + 8 q + 4 kh + (0..3) ----------
+  if (p.streamk && !head) {
+    // not the owner of this tile (always a workgroup's FIRST segment): publish the accumulators as they sit in the
+    // registers -- image [wave][quad = (nb*4 + mb)*4 + q][lane] f32x4, 1 KiB per store instruction, write-through
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 v = {acc[nb][mb][4 * q], acc[nb][mb][4 * q + 1], acc[nb][mb][4 * q + 2], acc[nb][mb][4 * q + 3]};
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rp,
+                                                 ((w * NWAVE + wave) * 32 + (nb * 4 + mb) * 4 + q) * 1024 + lane * 16, 0, 17);
+        }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every storing wave drains ...
+    __syncthreads();                                     // ... before ONE lane raises the flag
+    if (threadIdx.x == 0) __hip_atomic_store(p.flags + w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    continue;
+  }
+  if (p.streamk && !tail) {
+    // owner of a tile whose K range continues in the following workgroups (always the LAST segment): add their images in
+    // workgroup order (deterministic).  Bounded wait, see fp8_gemm_large.hip.
+    const int64_t tile_end = (int64_t)(tile + 1) * ktiles_total;
+    for (int j = w + 1; j < GW && j * U / GW < tile_end; ++j) {
+      if (threadIdx.x == 0) {
+        const unsigned long long t0 = wall_clock64();
+        while (__hip_atomic_load(p.flags + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+          __builtin_amdgcn_s_sleep(4);
+          if (wall_clock64() - t0 > 500000000ull) __builtin_trap();
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(
+                rp, ((j * NWAVE + wave) * 32 + (nb * 4 + mb) * 4 + q) * 1024 + lane * 16, 0, 17);
+            const f32x4 v = __builtin_bit_cast(f32x4, raw);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[nb][mb][4 * q + r] += v[r];
+          }
+    }
+  }
+  if (!p.streamk && p.ksplit > 1) {          // fp32 slab of this K range; summed by splitk_reduce_large_kernel
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) {
       const int row = m0 + wm * 128 + mb * 32 + l31;
@@ -282,9 +353,8 @@ __global__ __launch_bounds__(WM * WN * 64) void wna16_gemm_large_kernel(Wna16Lar
           *reinterpret_cast<f32x4*>(prow + nb * 32 + 8 * q + 4 * kh) =
               f32x4{acc[nb][mb][4 * q], acc[nb][mb][4 * q + 1], acc[nb][mb][4 * q + 2], acc[nb][mb][4 * q + 3]};
     }
-    return;
+    continue;
   }
-  if constexpr (STAGES == 3) __syncthreads();      // every wave is done with the stage buffers: reuse them (epi_put)
   unsigned char* region = smem + wave * 16384;
   f32x4 wsv[2][4], bsv[2][4];     // W8A16: per-channel scale and bias of this lane's 4-column groups, fetched up front
   if constexpr (WFP8) {
@@ -318,6 +388,7 @@ __global__ __launch_bounds__(WM * WN * 64) void wna16_gemm_large_kernel(Wna16Lar
                 p.out_bf16 ? u32x2{pack2_16<true>(v0, v1), pack2_16<true>(v2, v3)} : u32x2{pack2_16<false>(v0, v1), pack2_16<false>(v2, v3)});
       }
   epi_flush(region, p.c + (size_t)(m0 + wm * 128) * p.N + n0 + wn * 64, p.N, p.M - (m0 + wm * 128), lane);
+  }   // segments
 }
 
 // partial [S][M*N] fp32 -> c [M*N] f16 / bf16 (fixed summation order: deterministic)
@@ -359,7 +430,7 @@ static int launch_large_s(const Wna16LargeParams& p, hipStream_t st) {
   Wna16LargeParams q = p;
   q.tiles_m = (p.M + BM - 1) / BM;
   q.tiles_n = p.N / BN;
-  const int G = WFP8 ? 0 : p.K / p.ksplit / p.group_size;
+  const int G = WFP8 ? 0 : (p.streamk ? p.K / p.group_size : p.K / p.ksplit / p.group_size);   // groups a segment can touch
   size_t lds = STAGES * ((size_t)BM * 64 * 2 + (WFP8 ? (size_t)BN * 64 : (size_t)8 * BN * 4)) + (size_t)G * BN * 2 + (size_t)G * (BN / 8) * 4;
   if (lds < (size_t)WM * WN * 16384) lds = (size_t)WM * WN * 16384;   // the epilogue's wave-private transpose regions
   if (lds > 160 * 1024) {
@@ -375,7 +446,7 @@ static int launch_large_s(const Wna16LargeParams& p, hipStream_t st) {
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL((wna16_gemm_large_kernel<WM, WN, STAGES, WFP8>), dim3(q.tiles_m * q.tiles_n, q.ksplit), dim3(WM * WN * 64), lds, st, q);
+  hipLaunchKernelGGL((wna16_gemm_large_kernel<WM, WN, STAGES, WFP8>), p.streamk ? dim3(p.grid) : dim3(q.tiles_m * q.tiles_n, q.ksplit), dim3(WM * WN * 64), lds, st, q);
   APHRO_LAUNCH_CHECK();
   return APHRO_OK;
 }
@@ -384,7 +455,7 @@ static int launch_large_s(const Wna16LargeParams& p, hipStream_t st) {
 template <int WM, int WN, bool WFP8 = false>
 static int launch_large(const Wna16LargeParams& p, hipStream_t st) {
   constexpr int BM = 128 * WM, BN = 64 * WN;
-  const int G = WFP8 ? 0 : p.K / p.ksplit / p.group_size;
+  const int G = WFP8 ? 0 : (p.streamk ? p.K / p.group_size : p.K / p.ksplit / p.group_size);
   const size_t lds3 = 3 * ((size_t)BM * 64 * 2 + (WFP8 ? (size_t)BN * 64 : (size_t)8 * BN * 4)) + (size_t)G * BN * 2 + (size_t)G * (BN / 8) * 4;
   static const int force = getenv("APHRO_WNA16_LARGE_STAGES") ? atoi(getenv("APHRO_WNA16_LARGE_STAGES")) : 0;
   if ((lds3 <= 160 * 1024 && force != 2) || force == 3) return launch_large_s<WM, WN, 3, WFP8>(p, st);
@@ -395,17 +466,38 @@ static int launch_large(const Wna16LargeParams& p, hipStream_t st) {
 
 using namespace aphro;
 
-struct LargePlan { int wm, wn, ksplit; };
+struct LargePlan { int wm, wn, ksplit, streamk, grid; };
 
-// Tile shape and K split: 256 x 256 tiles when they still cover the chip; for small grids narrower tiles and a split of
-// K into up to 8 fp32 slabs (summed in fixed order by splitk_reduce_large_kernel) so that ~256+ workgroups exist.
+static int large_cu_count() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+  }
+  return n;
+}
+
+constexpr size_t LARGE_FLAG_BYTES = 4096;
+
+// Stream-K (one persistent workgroup per CU, see fp8_gemm_large.hip) when the biggest tile the shape allows still gives
+// >= 128 tiles.  Below that: one workgroup per tile, narrower tiles and a split of K into up to 8 fp32 slabs (summed in
+// fixed order by splitk_reduce_large_kernel) so that ~256+ workgroups exist.
 static LargePlan large_plan(int64_t M, int64_t N, int64_t K, int64_t gs) {
   LargePlan pl;
   pl.wm = M > 128 ? 2 : 1;
   const int64_t rows = (M + 128 * pl.wm - 1) / (128 * pl.wm);
+  static const int mode = getenv("APHRO_WNA16_LARGE_STREAMK") ? atoi(getenv("APHRO_WNA16_LARGE_STREAMK")) : -1;
+  const int64_t big_tiles = N % 256 == 0 ? rows * (N / 256) : rows * (N / 128);
+  pl.streamk = mode >= 0 ? mode : (big_tiles >= 128);
+  pl.ksplit = 1;
+  pl.grid = 0;
+  if (pl.streamk) {
+    pl.wn = N % 256 == 0 ? 4 : 2;
+    pl.grid = large_cu_count();
+    return pl;
+  }
   pl.wn = (N % 256 == 0 && rows * (N / 256) >= 200) ? 4 : 2;
   const int64_t tiles = rows * (N / (64 * pl.wn));
-  pl.ksplit = 1;
   const int64_t unit = gs > 64 ? gs : 64;           // a K range holds whole groups and whole K tiles
   for (int s = 2; s <= 8; ++s) {
     if (tiles * pl.ksplit >= 200) break;
@@ -415,13 +507,31 @@ static LargePlan large_plan(int64_t M, int64_t N, int64_t K, int64_t gs) {
   return pl;
 }
 
+static size_t large_scratch_bytes(const LargePlan& pl, int64_t M, int64_t N) {
+  if (pl.streamk) return LARGE_FLAG_BYTES + (size_t)pl.grid * pl.wm * pl.wn * 32 * 1024;
+  return pl.ksplit > 1 ? (size_t)pl.ksplit * M * N * sizeof(float) : 0;
+}
+
+// stream-K: clear the flag words (a memset node in front of the kernel: replays in HIP graphs), point the kernel at them
+static int large_bind_scratch(Wna16LargeParams& p, const LargePlan& pl, char* ws, hipStream_t st) {
+  p.streamk = pl.streamk; p.grid = pl.grid; p.ksplit = pl.ksplit; p.flags = nullptr; p.partial = (float*)ws;
+  if (pl.streamk) {
+    p.flags = (unsigned*)ws;
+    p.partial = (float*)(ws + LARGE_FLAG_BYTES);
+    if (hipMemsetAsync(p.flags, 0, LARGE_FLAG_BYTES, st) != hipSuccess) {
+      set_error("wna16_gemm_large: cannot clear the stream-K flags");
+      return APHRO_ERR_LAUNCH;
+    }
+  }
+  return APHRO_OK;
+}
+
 // Bytes of scratch aphro_wna16_gemm_large needs: the f16 copy of bf16 activations + the fp32 split-K slabs.
 extern "C" size_t aphro_wna16_gemm_large_workspace_bytes(int64_t M, int64_t N, int64_t K, int64_t groups, int dtype) {
   if (groups <= 0 || K % groups != 0) return 0;
   const LargePlan pl = large_plan(M, N, K, K / groups);
   size_t b = dtype == APHRO_BF16 ? ((size_t)M * K * 2 + 255) / 256 * 256 : 0;
-  if (pl.ksplit > 1) b += (size_t)pl.ksplit * M * N * sizeof(float);
-  return b;
+  return b + large_scratch_bytes(pl, M, N);
 }
 
 // c[M, N] = a[M, K] . dequant(q_weight[K/8, N] exllama order, qzeros[G, N/8], scales[G, N]); any M, meant for M > 64.
@@ -460,13 +570,13 @@ extern "C" int aphro_wna16_gemm_large(const void* a, const uint32_t* q_weight, c
   p.M = (int)M; p.N = (int)N; p.K = (int)K; p.group_size = (int)gs; p.zero_offset = zero_offset;
   p.out_bf16 = dtype == APHRO_BF16; p.scale_bf16 = dtype == APHRO_BF16;
   p.tiles_m = p.tiles_n = 0;
-  p.ksplit = pl.ksplit; p.partial = (float*)ws;
   p.w8 = nullptr; p.w_scales = nullptr; p.w_per_channel = 0; p.bias = nullptr;
+  if (int rcb = large_bind_scratch(p, pl, ws, st)) return rcb;
   int rc;
   if (pl.wm == 2) rc = pl.wn == 4 ? launch_large<2, 4>(p, st) : launch_large<2, 2>(p, st);
   else rc = pl.wn == 4 ? launch_large<1, 4>(p, st) : launch_large<1, 2>(p, st);
   if (rc != APHRO_OK) return rc;
-  if (pl.ksplit > 1) {
+  if (!pl.streamk && pl.ksplit > 1) {
     const int64_t mn = M * N;
     hipLaunchKernelGGL(splitk_reduce_large_kernel, dim3((unsigned)((mn / 4 + 255) / 256)), dim3(256), 0, st, p.partial,
                        (uint16_t*)c, mn, pl.ksplit, p.out_bf16);
@@ -483,8 +593,7 @@ extern "C" int aphro_wna16_gemm_large(const void* a, const uint32_t* q_weight, c
 extern "C" size_t aphro_fp8_w8a16_gemm_large_workspace_bytes(int64_t M, int64_t N, int64_t K, int dtype) {
   const LargePlan pl = large_plan(M, N, K, 64);
   size_t b = dtype == APHRO_BF16 ? ((size_t)M * K * 2 + 255) / 256 * 256 : 0;
-  if (pl.ksplit > 1) b += (size_t)pl.ksplit * M * N * sizeof(float);
-  return b;
+  return b + large_scratch_bytes(pl, M, N);
 }
 
 extern "C" int aphro_fp8_w8a16_gemm_large(void* out, const void* a, const void* w, const float* w_scales, const void* bias,
@@ -514,14 +623,14 @@ extern "C" int aphro_fp8_w8a16_gemm_large(void* out, const void* a, const void* 
   p.M = (int)M; p.N = (int)N; p.K = (int)K; p.group_size = 64; p.zero_offset = 0;
   p.out_bf16 = dtype == APHRO_BF16; p.scale_bf16 = 0;
   const LargePlan pl = large_plan(M, N, K, 64);
-  p.tiles_m = p.tiles_n = 0; p.ksplit = pl.ksplit;
-  p.partial = (float*)((char*)workspace + (dtype == APHRO_BF16 ? ((size_t)M * K * 2 + 255) / 256 * 256 : 0));
+  p.tiles_m = p.tiles_n = 0;
+  if (int rcb = large_bind_scratch(p, pl, (char*)workspace + (dtype == APHRO_BF16 ? ((size_t)M * K * 2 + 255) / 256 * 256 : 0), st)) return rcb;
   p.w8 = (const uint8_t*)w; p.w_scales = w_scales; p.w_per_channel = w_scale_per_channel; p.bias = (const uint16_t*)bias;
   int rc;
   if (pl.wm == 2) rc = pl.wn == 4 ? launch_large<2, 4, true>(p, st) : launch_large<2, 2, true>(p, st);
   else rc = pl.wn == 4 ? launch_large<1, 4, true>(p, st) : launch_large<1, 2, true>(p, st);
   if (rc != APHRO_OK) return rc;
-  if (pl.ksplit > 1) {
+  if (!pl.streamk && pl.ksplit > 1) {
     const int64_t mn = M * N;
     hipLaunchKernelGGL(splitk_reduce_large_kernel, dim3((unsigned)((mn / 4 + 255) / 256)), dim3(256), 0, st, p.partial,
                        (uint16_t*)out, mn, pl.ksplit, p.out_bf16, w_scales, w_scale_per_channel, (const uint16_t*)bias, (int)N);
