@@ -227,11 +227,26 @@ def roofline_section(model, loop, args):
                         qw, qz, sc, zo = getattr(layer, name).fast_params()
                         ops.wna16_gemm_packed(packed, bs, k, qw, qz, sc, zo, partials=True)
             kname = "wna16_gemm_kernel" + (" (+SiluAndMul epilogue)" if silu else "")
+        elif args.quant == "fp8ct" and getattr(model, "use_fused_decode", False):
+            # the FP8 decode fast path hands every GEMM pre-quantised activations (the quantisation is fused into the norm /
+            # SiluAndMul kernels): time the GEMM launch alone, in the form the step uses (fp32 slabs for qkv / o / down,
+            # the scaled epilogue for gate_up)
+            qx, sx = ops.scaled_fp8_quant(xin, None, use_per_token_if_dynamic=True)
+            slab_form = name != "gate_up_proj"
+
+            def run_lin(name=name, qx=qx, sx=sx, slab_form=slab_form):
+                for layer in layers:
+                    lin = getattr(layer, name)
+                    if slab_form:
+                        ops.scaled_mm_fp8_slabs(qx, lin.weight)
+                    else:
+                        ops.cutlass_scaled_mm(qx, lin.weight, out_dtype=model.dtype, scale_a=sx, scale_b=lin.weight_scale)
+            kname = "fp8_gemm_fast_kernel" + (" (fp32 slabs)" if slab_form else " (scaled epilogue)")
         else:
             def run_lin(name=name, xin=xin):
                 for layer in layers:
                     getattr(layer, name)(xin)
-            kname = ("fp8_gemm_kernel" if args.quant.startswith("fp8") else "wna16_gemm_kernel") + " (+pack/splitk_reduce)"
+            kname = ("fp8_gemm_kernel" if args.quant.startswith("fp8") else "wna16_gemm_kernel") + " (+quant/pack/splitk_reduce)"
         t = measure_kernel(run_lin, len(layers))
         out[name] = dict(kernel=kname, shape=[bs, lin0.in_features, lin0.out_features],
                          bytes=gemm_bytes(lin0, bs), seconds=t)
