@@ -55,7 +55,10 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
 
 
 def _workspace(device: torch.device, nbytes: int) -> torch.Tensor:
-    """Persistent split-K scratch (stable address -> HIP-graph safe)."""
+    """Persistent split-K / stream-K scratch (stable address -> HIP-graph safe).  ONE buffer per device: ops that use it
+    are ordered by the stream they are issued on -- the package issues all of them on the current stream (the side stream
+    of distributed/overlap.py carries only the all-reduce).  A caller that runs these ops concurrently on several streams
+    must give each stream its own scratch through the C ABI (every entry point takes workspace pointers)."""
     if nbytes > _WS_BYTES:
         return torch.empty(nbytes, dtype=torch.uint8, device=device)
     ws = _workspaces.get(device)
