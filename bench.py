@@ -380,6 +380,22 @@ def all_reduce_section(args, model, device, ca):
             sizes.append(extra)
     lib = _lib.lib()
 
+    def timed_eager(fn, x, n=32, iters=5):
+        """32 chained calls issued eagerly between two events (no capture: a failed capture of a collective would leave
+        the CUDA generator in capture state and break every later torch.randn of this process)."""
+        fn(x)
+        torch.cuda.synchronize()
+        dist.barrier()
+        start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        start.record()
+        for _ in range(iters):
+            y = x
+            for _ in range(n):
+                y = fn(y)
+        end.record()
+        end.synchronize()
+        return start.elapsed_time(end) * 1e3 / (iters * n)
+
     def timed(fn, x, n=32, iters=5):
         fn(x)
         torch.cuda.synchronize()
@@ -415,13 +431,13 @@ def all_reduce_section(args, model, device, ca):
             dist.all_reduce(t_, group=D._TP_GROUP)
             return t_
         try:
-            row["rccl_us"] = timed(rccl, x)
-        except Exception as e:       # RCCL capture can be unavailable on some stacks: report, do not fail the bench
+            row["rccl_us"] = timed_eager(rccl, x)      # eager issue: includes the host launch of each collective
+        except Exception as e:       # report, do not fail the bench
             row["rccl_us"] = None
             row["rccl_error"] = repr(e)[:120]
         info[str(nbytes)] = row
     return {"world": world, "decode_all_reduce_bytes": sizes[0], "per_size": info,
-            "note": "us per all-reduce, 32 chained calls per HIP-graph replay, MAX over ranks not taken (rank 0's clock)"}
+            "note": "us per all-reduce on rank 0's clock: the peer-access kernel as 32 chained calls per HIP-graph replay, RCCL as 32 chained eager calls (host launch included)"}
 
 
 def main():
@@ -432,13 +448,20 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py needs a GPU (torch.cuda.is_available() is False)", file=sys.stderr)
         sys.exit(2)
+    # APHRO_BENCH_ONE_GPU=1 (test rig only): every rank runs on cuda:0 and the process group is gloo -- exercises the
+    # multi-rank control flow (barriers, max over ranks, rank-0 line) on a one-GPU box; the numbers are meaningless.
+    one_gpu = os.environ.get("APHRO_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=device)
+        if one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     from aphrodite_engine_amd import _lib
     from aphrodite_engine_amd import distributed as D
     _lib.lib()  # fail loudly if the HIP library is missing
@@ -490,7 +513,7 @@ def main():
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         if world > 1:
-            tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
+            tmax = torch.tensor([elapsed], device="cpu" if one_gpu else device, dtype=torch.float64)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             elapsed = float(tmax.item())
         if ca is not None:
