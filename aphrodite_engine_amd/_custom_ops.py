@@ -401,6 +401,13 @@ def wna16_large_ok(m: int, n: int, k: int, groups: int) -> bool:
         and (k // 8) * n * 4 < 2 ** 32 and m * k * 2 < 2 ** 32
 
 
+def wna16_prefers_large(m: int, n: int, k: int) -> bool:
+    """Between 65 and 128 rows the decode kernel (two 64-row passes over the weights) still beats the tile machine on
+    the small projections (weights < 16 MiB: qkv 21.6 vs 27.4 us, o 20.0 vs 23.8 us at M = 96), not on the large ones
+    (gate_up 59 vs 52 us, down 43 vs 35 us) -- tools/mid_gemm_bench.py, profiles/r2_mid_gemm.txt."""
+    return m > 128 or n * k >= 2 ** 25
+
+
 def _wna16_large(a, qweight, qzeros, scales, perm, zero_offset):
     m, k = a.shape
     n = qweight.shape[1]
@@ -418,11 +425,44 @@ def _wna16_large(a, qweight, qzeros, scales, perm, zero_offset):
     return out
 
 
+def wna16_mid_ok(m: int, n: int, k: int, groups: int) -> bool:
+    return bool(_lib.lib().aphro_wna16_gemm_mid_supported(m, n, k, groups)) and m * k * 2 < 2 ** 32
+
+
+def wna16_prefers_mid(m: int, n: int, k: int) -> bool:
+    """33..64 rows: one pass of the 32x32x16 MFMA kernel over the weights against two passes of the decode kernel.
+    Measured (tools/mid_gemm_bench.py, profiles/r2_mid_gemm.txt, whole op incl. pack / slab reduce): a win only where
+    the weight stream dominates the fixed costs -- gate_up 34.4 vs 37.8 us at M = 64; down 28.1 vs 24.9, qkv 21.2 vs
+    11.4 the other way."""
+    return 32 < m <= 64 and n * k >= 2 ** 26
+
+
+def _wna16_mid(a, qweight, qzeros, scales, perm, zero_offset):
+    """Decode batches of 33..64 rows in ONE pass over the weights (csrc/wna16_gemm_mid.hip)."""
+    m, k = a.shape
+    n = qweight.shape[1]
+    lib = _lib.lib()
+    if perm is not None:
+        a = a[:, perm.long()]                       # act-order: gather once (q_gemm.cu:219-226)
+    if a.stride(1) != 1 or a.stride(0) % 8 != 0 or a.data_ptr() % 16 != 0:
+        a = a.contiguous()
+    out = torch.empty((m, n), dtype=a.dtype, device=a.device)
+    nbytes = lib.aphro_wna16_gemm_mid_workspace_bytes(m, n, k, scales.shape[0])
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=a.device)
+    check(lib.aphro_wna16_gemm_mid(a.data_ptr(), qweight.data_ptr(), qzeros.data_ptr(), scales.data_ptr(),
+                                   out.data_ptr(), ws.data_ptr(), nbytes, m, n, k, scales.shape[0], a.stride(0),
+                                   zero_offset, _dt(a), _stream()), "wna16_gemm_mid")
+    return out
+
+
 def _wna16(a, qweight, qzeros, scales, perm, zero_offset):
     m, k = a.shape
     n = qweight.shape[1]
-    if wna16_large_ok(m, n, k, scales.shape[0]) and not os.environ.get("APHRO_WNA16_NO_LARGE"):
+    if wna16_large_ok(m, n, k, scales.shape[0]) and wna16_prefers_large(m, n, k) \
+            and not os.environ.get("APHRO_WNA16_NO_LARGE"):
         return _wna16_large(a, qweight, qzeros, scales, perm, zero_offset)
+    if wna16_prefers_mid(m, n, k) and wna16_mid_ok(m, n, k, scales.shape[0]) and not os.environ.get("APHRO_WNA16_NO_MID"):
+        return _wna16_mid(a, qweight, qzeros, scales, perm, zero_offset)
     lib = _lib.lib()
     out = torch.empty((m, n), dtype=a.dtype, device=a.device)
     if a.stride(1) != 1:
@@ -457,7 +497,7 @@ def gptq_gemm(a: torch.Tensor, b_q_weight: torch.Tensor,
         raise RuntimeError("gptq_gemm: activations and scales must share a dtype")
     m = a.shape[0]
     large = use_exllama and wna16_large_ok(m, b_q_weight.shape[1], a.shape[1], b_gptq_scales.shape[0]) \
-        and not os.environ.get("APHRO_WNA16_NO_LARGE")
+        and wna16_prefers_large(m, b_q_weight.shape[1], a.shape[1]) and not os.environ.get("APHRO_WNA16_NO_LARGE")
     if not use_exllama or (m >= GPTQ_DEQUANT_MIN_M and not large):
         w = gptq_dequant(b_q_weight, b_gptq_qzeros, b_gptq_scales, b_g_idx,
                          use_exllama, bit)

@@ -497,11 +497,17 @@ static LargePlan large_plan(int64_t M, int64_t N, int64_t K, int64_t gs) {
     return pl;
   }
   pl.wn = (N % 256 == 0 && rows * (N / 256) >= 200) ? 4 : 2;
+  if (const char* e = getenv("APHRO_WNA16_LARGE_WN")) { const int v = atoi(e); if (v == 2 || (v == 4 && N % 256 == 0)) pl.wn = v; }
   const int64_t tiles = rows * (N / (64 * pl.wn));
   const int64_t unit = gs > 64 ? gs : 64;           // a K range holds whole groups and whole K tiles
-  for (int s = 2; s <= 8; ++s) {
-    if (tiles * pl.ksplit >= 200) break;
-    if (K % (s * unit) == 0 && K / s >= 512) pl.ksplit = s;
+  // K slices until ~800 waves exist (a 2-wave workgroup fills half a CU's SIMDs: 400 of those), as long as the fp32
+  // slabs stay small beside the weights (measured, tools/mid_gemm_sweep.py: past ~36 MB the reduce pass costs more than
+  // the extra workgroups buy)
+  const int64_t want = pl.wm * pl.wn <= 2 ? 400 : 200;
+  const int64_t slab = M * N * 4;
+  for (int s = 2; s <= 16; ++s) {
+    if (tiles * pl.ksplit >= want) break;
+    if (K % (s * unit) == 0 && K / s >= 512 && s * slab <= (36ll << 20)) pl.ksplit = s;
   }
   if (const char* e = getenv("APHRO_WNA16_LARGE_KSPLIT")) { const int s = atoi(e); if (s >= 1 && K % (s * unit) == 0) pl.ksplit = s; }
   return pl;

@@ -535,6 +535,18 @@ int aphro_wna16_gemm_large(const void* a, const uint32_t* q_weight, const uint32
                            void* c, void* workspace, size_t workspace_bytes, int64_t M, int64_t N, int64_t K,
                            int64_t groups, int64_t lda, int zero_offset, int dtype, void* stream);
 
+/* W4A16 GEMM for decode batches of 33..64 rows (any M in 1..64 is accepted) -- the reference runs its exllama kernel
+ * up to 50 rows and reconstruct + hipBLAS above (kernels/quantization/gptq/q_gemm.cu:1529-1544); Marlin covers the range
+ * with one kernel (gptq_marlin.cu:2247).  csrc/wna16_gemm_mid.hip: weights global -> VGPR -> 32x32x16 MFMA (the exllama
+ * dword is the fragment), activations fragment-major from L2, 4 waves split K and meet in an LDS butterfly, fp32 slabs
+ * for more K slices.  Same tensors as aphro_wna16_gemm_large.  N % 128 == 0, group size % 128 == 0, K % (4 groups) == 0.
+ * workspace: aphro_wna16_gemm_mid_workspace_bytes (packed activations + slabs). */
+int aphro_wna16_gemm_mid_supported(int64_t M, int64_t N, int64_t K, int64_t groups);
+size_t aphro_wna16_gemm_mid_workspace_bytes(int64_t M, int64_t N, int64_t K, int64_t groups);
+int aphro_wna16_gemm_mid(const void* a, const uint32_t* q_weight, const uint32_t* qzeros, const void* scales,
+                         void* c, void* workspace, size_t workspace_bytes, int64_t M, int64_t N, int64_t K,
+                         int64_t groups, int64_t lda, int zero_offset, int dtype, void* stream);
+
 /* Overlap helper for tensor parallelism (north_star: "all-reduce overlapped with the quantized GEMMs on HIP
  * streams"): streams `bytes` at `ptr` through the memory-side Infinity Cache on `stream` while the all-reduce of the
  * previous row-parallel projection runs on a side stream -- see aphrodite_engine_amd/distributed/overlap.py.  Reads

@@ -135,6 +135,47 @@ def test_gptq_gemm_large_m_path(ops):
     assert rel_mean_err(got.float().cpu().numpy(), ref) < 0.04
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M", [1, 31, 32, 33, 48, 64])
+@pytest.mark.parametrize("K,N,G", [(512, 128, 128), (2048, 384, 128), (1024, 256, 256)])
+def test_wna16_gemm_mid_vs_oracle(ops, K, N, G, M, dtype):
+    """csrc/wna16_gemm_mid.hip (one pass of 32x32x16 MFMAs for decode batches up to 64 rows, 4 waves split K and meet
+    in an LDS butterfly, fp32 slabs for more K slices) against the oracle's gptq_gemm, every row and column; and
+    bit-equal to itself run twice (fixed summation order)."""
+    rng = np.random.default_rng(100 + M + K)
+    qweight, qzeros, s, _ = make_gptq(rng, K, N, G)
+    a = rng.standard_normal((M, K)).astype(np.float16)
+    shuf = oq.gptq_shuffle(qweight)
+    ref = oq.gptq_gemm(a, shuf, qzeros, s, None, True)
+    assert ops.wna16_mid_ok(M, N, K, K // G)
+    ta, ts = t(a).to(dtype), t(s, torch.float16).to(dtype)
+    if dtype == torch.bfloat16:
+        ref = oq.gptq_gemm(ta.float().cpu().numpy().astype(np.float16), shuf, qzeros,
+                           ts.float().cpu().numpy().astype(np.float16), None, True)
+    got = ops._wna16_mid(ta, t(shuf), t(qzeros), ts, None, 1)
+    assert got.shape == (M, N) and got.dtype == dtype
+    tol = 2e-3 if dtype == torch.float16 else 1.2e-2
+    np.testing.assert_allclose(got.float().cpu().numpy(), ref, rtol=tol, atol=tol * np.abs(ref).max())
+    again = ops._wna16_mid(ta, t(shuf), t(qzeros), ts, None, 1)
+    assert torch.equal(got, again)
+
+
+def test_wna16_gemm_mid_dispatch_and_act_order(ops):
+    """gptq_gemm routes 33..64 rows of a gate_up-sized weight to the mid kernel (and nothing else there); act-order
+    (g_idx) goes through the same gather as the other paths."""
+    assert ops.wna16_prefers_mid(64, 28672, 4096) and not ops.wna16_prefers_mid(32, 28672, 4096)
+    assert not ops.wna16_prefers_mid(64, 4096, 14336) and not ops.wna16_prefers_mid(65, 28672, 4096)
+    rng = np.random.default_rng(5)
+    K, N, G, M = 1024, 256, 128, 40
+    qweight, qzeros, s, g_idx = make_gptq(rng, K, N, G, act_order=True)
+    perm = np.argsort(g_idx, kind="stable").astype(np.int32)
+    shuf = oq.gptq_shuffle(qweight, perm)
+    a = rng.standard_normal((M, K)).astype(np.float16)
+    ref = oq.gptq_gemm(a, shuf, qzeros, s, perm, True)
+    got = ops._wna16_mid(t(a), t(shuf), t(qzeros), t(s, torch.float16), t(perm), 1)
+    np.testing.assert_allclose(got.float().cpu().numpy(), ref, rtol=2e-3, atol=2e-3 * np.abs(ref).max())
+
+
 # ---------------------------------------------------------------------------
 # AWQ
 # ---------------------------------------------------------------------------
