@@ -431,10 +431,10 @@ def wna16_mid_ok(m: int, n: int, k: int, groups: int) -> bool:
 
 def wna16_prefers_mid(m: int, n: int, k: int) -> bool:
     """33..64 rows: one pass of the 32x32x16 MFMA kernel over the weights against two passes of the decode kernel.
-    Measured (tools/mid_gemm_bench.py, profiles/r2_mid_gemm.txt, whole op incl. pack / slab reduce): a win only where
-    the weight stream dominates the fixed costs -- gate_up 34.4 vs 37.8 us at M = 64; down 28.1 vs 24.9, qkv 21.2 vs
-    11.4 the other way."""
-    return 32 < m <= 64 and n * k >= 2 ** 26
+    Measured (tools/mid_gemm_bench.py, profiles/r2_mid_gemm.txt, whole op incl. activation pack / slab reduce): a win
+    where the weight stream dominates the fixed costs -- gate_up 27.0 vs 37.7 us at M = 64 (25.1 vs 32.8 at 33), down
+    23.7 vs 25.3; the small projections go the other way (qkv 21.5 vs 11.4, o 16.1 vs 11.7)."""
+    return 32 < m <= 64 and n * k >= 2 ** 25
 
 
 def _wna16_mid(a, qweight, qzeros, scales, perm, zero_offset):

@@ -12,7 +12,7 @@
 //     holds A[m][8 k8 .. + 7]: every activation fragment is one lane-linear 1 KiB load that hits in L2.
 //   * weights run DW steps ahead of their use in a register ring, activations DA steps; loads past a wave's K range are
 //     issued anyway (buffer loads: in range of the next slice or zero) so the loop is straight-line code.
-//   * the 4 waves of a workgroup split K; their accumulators meet in a two-round butterfly through 64 KiB of LDS after
+//   * the 4 (or 8) waves of a workgroup split K; their accumulators meet in a butterfly through LDS (64 / 128 KiB) after
 //     which wave w owns accumulator quad q = w; the 64 x 128 tile is put together in LDS and leaves as whole rows.  More K slices
 //     (grid.y) write fp32 slabs summed by mid_splitk_reduce_kernel in fixed order -- no atomics, deterministic.
 //   * int4 -> f16 in registers with the reference's numerics (q_gemm.cu:1394-1434): (q - z) exact through the 1024 + q
@@ -71,49 +71,55 @@ __device__ __forceinline__ f16x8 mid_dq8(uint32_t w, f16x2 zh, f16x2 zh16, f16x2
 }
 
 // ---- butterfly pieces: static register indices only (a runtime quad index would put the accumulators in scratch) -----
-template <int MB, int NQ, int QSEND>
+// send / receive quads [Q0, Q0 + NQ) of n-blocks [NB0, NB0 + NNB)
+template <int MB, int NQ, int Q0, int NB0 = 0, int NNB = 4>
 __device__ __forceinline__ void mid_send(const f32x16 (&acc)[4][MB], float* red, int wave, int lane) {
 #pragma unroll
-  for (int nb = 0; nb < 4; ++nb)
+  for (int nbi = 0; nbi < NNB; ++nbi)
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
       for (int qi = 0; qi < NQ; ++qi) {
-        const int q = QSEND + qi;
+        const int q = Q0 + qi, nb = NB0 + nbi;
         const f32x4 v = {acc[nb][mb][4 * q], acc[nb][mb][4 * q + 1], acc[nb][mb][4 * q + 2], acc[nb][mb][4 * q + 3]};
-        *reinterpret_cast<f32x4*>(&red[(((wave * (4 * MB * NQ)) + (nb * MB + mb) * NQ + qi) * 64 + lane) * 4]) = v;
+        *reinterpret_cast<f32x4*>(&red[(((wave * (NNB * MB * NQ)) + (nbi * MB + mb) * NQ + qi) * 64 + lane) * 4]) = v;
       }
 }
-template <int MB, int NQ, int QKEEP>
+template <int MB, int NQ, int Q0, int NB0 = 0, int NNB = 4>
 __device__ __forceinline__ void mid_recv(f32x16 (&acc)[4][MB], const float* red, int partner, int lane) {
 #pragma unroll
-  for (int nb = 0; nb < 4; ++nb)
+  for (int nbi = 0; nbi < NNB; ++nbi)
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
       for (int qi = 0; qi < NQ; ++qi) {
-        const int q = QKEEP + qi;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(&red[(((partner * (4 * MB * NQ)) + (nb * MB + mb) * NQ + qi) * 64 + lane) * 4]);
+        const int q = Q0 + qi, nb = NB0 + nbi;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(&red[(((partner * (NNB * MB * NQ)) + (nbi * MB + mb) * NQ + qi) * 64 + lane) * 4]);
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[nb][mb][4 * q + r] += v[r];
       }
 }
-// wave owns quad Q: row m = mb * 32 + l31, columns 32 Q + 16 kh + (4 r + nb) of the workgroup's 128.  Stored straight
-// from the registers every instruction would scatter 16-byte pieces over 32 rows (measured: 10 us of a 28 us kernel);
-// the tile goes through LDS ([32 MB][128 + 4] fp32, conflict-free both ways) and leaves as whole 512-byte rows.
+// wave owns quad Q (of n-blocks NB0 .. NB0 + NNB - 1): row m = mb * 32 + l31, columns 32 Q + 16 kh + (4 r + nb) of the
+// workgroup's 128.  Stored straight from the registers every instruction would scatter 16-byte pieces over 32 rows
+// (measured: 10 us of a 28 us kernel); the tile goes through LDS ([32 MB][128 + 4] fp32, conflict-free both ways) and
+// leaves as whole 512-byte rows.
 constexpr int MID_LDT = 132;
-template <int MB, int Q>
+template <int MB, int Q, int NB0 = 0, int NNB = 4>
 __device__ __forceinline__ void mid_put(const f32x16 (&acc)[4][MB], float* tile, int l31, int kh) {
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-      *reinterpret_cast<f32x4*>(&tile[(mb * 32 + l31) * MID_LDT + 32 * Q + 16 * kh + 4 * r]) =
-          f32x4{acc[0][mb][4 * Q + r], acc[1][mb][4 * Q + r], acc[2][mb][4 * Q + r], acc[3][mb][4 * Q + r]};
+    for (int r = 0; r < 4; ++r) {
+      float* dst = &tile[(mb * 32 + l31) * MID_LDT + 32 * Q + 16 * kh + 4 * r + NB0];
+      if constexpr (NNB == 4)
+        *reinterpret_cast<f32x4*>(dst) = f32x4{acc[0][mb][4 * Q + r], acc[1][mb][4 * Q + r], acc[2][mb][4 * Q + r], acc[3][mb][4 * Q + r]};
+      else
+        *reinterpret_cast<f32x2*>(dst) = f32x2{acc[NB0][mb][4 * Q + r], acc[NB0 + 1][mb][4 * Q + r]};
+    }
 }
-template <int MB>
+template <int MB, int NWK>
 __device__ __forceinline__ void mid_flush(const float* tile, const Wna16MidParams& p, int n0, int wave, int lane) {
-  constexpr int ROWS = 8 * MB;                  // rows per wave
+  constexpr int ROWS = 32 * MB / NWK;           // rows per wave
   if (p.ksplit > 1) {                           // fp32 slab: 2 rows x 512 B per instruction
 #pragma unroll
     for (int i = 0; i < ROWS / 2; ++i) {
@@ -134,8 +140,9 @@ __device__ __forceinline__ void mid_flush(const float* tile, const Wna16MidParam
   }
 }
 
-template <int MB>
-__global__ __launch_bounds__(256, 2) void wna16_gemm_mid_kernel(Wna16MidParams p) {
+// NWK waves split K: 4 (two workgroups per CU, more K slices go to slabs) or 8 (one workgroup per CU, 128 KiB butterfly)
+template <int MB, int NWK>
+__global__ __launch_bounds__(64 * NWK, 2) void wna16_gemm_mid_kernel(Wna16MidParams p) {
   constexpr int NB = 4;
   constexpr int DW = 8;   // weight steps in flight (one 16-byte load each)
   constexpr int DA = 4;   // activation steps in flight (MB loads each)
@@ -144,8 +151,8 @@ __global__ __launch_bounds__(256, 2) void wna16_gemm_mid_kernel(Wna16MidParams p
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int kh = lane >> 5, l31 = lane & 31;
   const int n0 = blockIdx.x * (32 * NB);
-  const int steps = p.K / 16 / (4 * p.ksplit);          // 16-k steps of this wave; host: a multiple of group_size / 16
-  const int s0 = (blockIdx.y * 4 + wave) * steps;
+  const int steps = p.K / 16 / (NWK * p.ksplit);        // 16-k steps of this wave; host: a multiple of group_size / 16
+  const int s0 = (blockIdx.y * NWK + wave) * steps;
   const int gsteps = p.group_size >> 4;
 
   const __amdgpu_buffer_rsrc_t rw = mid_rsrc(p.qw, (uint32_t)((size_t)(p.K >> 3) * p.N * 4));
@@ -252,30 +259,64 @@ __global__ __launch_bounds__(256, 2) void wna16_gemm_mid_kernel(Wna16MidParams p
 #pragma unroll
         for (int r = 0; r < 16; ++r) t += acc[nb][mb][r];
     t += __builtin_bit_cast(float, wr[0][0] ^ wr[1][1] ^ wr[2][2] ^ wr[3][3] ^ wr[4][0] ^ wr[5][1] ^ wr[6][2] ^ wr[7][3] ^ ar[0][0][0] ^ ar[1][0][1] ^ ar[2][0][2] ^ ar[3][0][3]);
-    p.partial[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x] = t;
+    p.partial[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (64 * NWK) + threadIdx.x] = t;
     return;
   }
-  // ---- K reduction across the 4 waves: round 1 with wave ^ 2 (two quads each way), round 2 with wave ^ 1 (one quad) ------
-  if (wave & 2) mid_send<MB, 2, 0>(acc, red, wave, lane); else mid_send<MB, 2, 2>(acc, red, wave, lane);
+  // ---- K reduction: butterfly over the wave index.  Quad rounds on bits SH+1 and SH (two quads each way, then one);
+  // with 8 waves a last round on bit 0 splits the n-blocks.  Fixed pairing -> fixed summation order. ---------------------
+  constexpr int SH = NWK == 8 ? 1 : 0;
+  const int wq = wave >> SH;                     // the quad this wave ends up owning
+  if (wq & 2) mid_send<MB, 2, 0>(acc, red, wave, lane); else mid_send<MB, 2, 2>(acc, red, wave, lane);
   __syncthreads();
-  if (wave & 2) mid_recv<MB, 2, 2>(acc, red, wave ^ 2, lane); else mid_recv<MB, 2, 0>(acc, red, wave ^ 2, lane);
+  if (wq & 2) mid_recv<MB, 2, 2>(acc, red, wave ^ (2 << SH), lane); else mid_recv<MB, 2, 0>(acc, red, wave ^ (2 << SH), lane);
   __syncthreads();
-  switch (wave) {
+  switch (wq) {
     case 0: mid_send<MB, 1, 1>(acc, red, wave, lane); break;
     case 1: mid_send<MB, 1, 0>(acc, red, wave, lane); break;
     case 2: mid_send<MB, 1, 3>(acc, red, wave, lane); break;
     default: mid_send<MB, 1, 2>(acc, red, wave, lane); break;
   }
   __syncthreads();
-  float* tile = red + 4096 * MB;                 // behind the round-2 buffers (16 MB KiB): no barrier between recv and put
-  switch (wave) {
-    case 0: mid_recv<MB, 1, 0>(acc, red, 1, lane); mid_put<MB, 0>(acc, tile, l31, kh); break;
-    case 1: mid_recv<MB, 1, 1>(acc, red, 0, lane); mid_put<MB, 1>(acc, tile, l31, kh); break;
-    case 2: mid_recv<MB, 1, 2>(acc, red, 3, lane); mid_put<MB, 2>(acc, tile, l31, kh); break;
-    default: mid_recv<MB, 1, 3>(acc, red, 2, lane); mid_put<MB, 3>(acc, tile, l31, kh); break;
+  float* tile = red + 4096 * MB;                 // behind the last round's buffers (16 MB KiB): no barrier between recv and put
+  if constexpr (NWK == 4) {
+    switch (wq) {
+      case 0: mid_recv<MB, 1, 0>(acc, red, wave ^ 1, lane); mid_put<MB, 0>(acc, tile, l31, kh); break;
+      case 1: mid_recv<MB, 1, 1>(acc, red, wave ^ 1, lane); mid_put<MB, 1>(acc, tile, l31, kh); break;
+      case 2: mid_recv<MB, 1, 2>(acc, red, wave ^ 1, lane); mid_put<MB, 2>(acc, tile, l31, kh); break;
+      default: mid_recv<MB, 1, 3>(acc, red, wave ^ 1, lane); mid_put<MB, 3>(acc, tile, l31, kh); break;
+    }
+  } else {
+    switch (wq) {
+      case 0: mid_recv<MB, 1, 0>(acc, red, wave ^ 2, lane); break;
+      case 1: mid_recv<MB, 1, 1>(acc, red, wave ^ 2, lane); break;
+      case 2: mid_recv<MB, 1, 2>(acc, red, wave ^ 2, lane); break;
+      default: mid_recv<MB, 1, 3>(acc, red, wave ^ 2, lane); break;
+    }
+    __syncthreads();
+    switch (wave) {       // quad wq: the even wave keeps n-blocks 0, 1, the odd one 2, 3
+      case 0: mid_send<MB, 1, 0, 2, 2>(acc, red, wave, lane); break;
+      case 1: mid_send<MB, 1, 0, 0, 2>(acc, red, wave, lane); break;
+      case 2: mid_send<MB, 1, 1, 2, 2>(acc, red, wave, lane); break;
+      case 3: mid_send<MB, 1, 1, 0, 2>(acc, red, wave, lane); break;
+      case 4: mid_send<MB, 1, 2, 2, 2>(acc, red, wave, lane); break;
+      case 5: mid_send<MB, 1, 2, 0, 2>(acc, red, wave, lane); break;
+      case 6: mid_send<MB, 1, 3, 2, 2>(acc, red, wave, lane); break;
+      default: mid_send<MB, 1, 3, 0, 2>(acc, red, wave, lane); break;
+    }
+    __syncthreads();
+    switch (wave) {
+      case 0: mid_recv<MB, 1, 0, 0, 2>(acc, red, 1, lane); mid_put<MB, 0, 0, 2>(acc, tile, l31, kh); break;
+      case 1: mid_recv<MB, 1, 0, 2, 2>(acc, red, 0, lane); mid_put<MB, 0, 2, 2>(acc, tile, l31, kh); break;
+      case 2: mid_recv<MB, 1, 1, 0, 2>(acc, red, 3, lane); mid_put<MB, 1, 0, 2>(acc, tile, l31, kh); break;
+      case 3: mid_recv<MB, 1, 1, 2, 2>(acc, red, 2, lane); mid_put<MB, 1, 2, 2>(acc, tile, l31, kh); break;
+      case 4: mid_recv<MB, 1, 2, 0, 2>(acc, red, 5, lane); mid_put<MB, 2, 0, 2>(acc, tile, l31, kh); break;
+      case 5: mid_recv<MB, 1, 2, 2, 2>(acc, red, 4, lane); mid_put<MB, 2, 2, 2>(acc, tile, l31, kh); break;
+      case 6: mid_recv<MB, 1, 3, 0, 2>(acc, red, 7, lane); mid_put<MB, 3, 0, 2>(acc, tile, l31, kh); break;
+      default: mid_recv<MB, 1, 3, 2, 2>(acc, red, 6, lane); mid_put<MB, 3, 2, 2>(acc, tile, l31, kh); break;
+    }
   }
   __syncthreads();
-  mid_flush<MB>(tile, p, n0, wave, lane);
+  mid_flush<MB, NWK>(tile, p, n0, wave, lane);
 }
 
 // partial [S][M*N] fp32 -> c [M*N] f16 / bf16, fixed summation order
@@ -314,20 +355,47 @@ __global__ void mid_pack_a_kernel(const uint16_t* __restrict__ a, int lda, int M
 
 using namespace aphro;
 
-struct MidPlan { int mb, ksplit; };
+struct MidPlan { int mb, nwk, ksplit; };
 
-// K slices (grid.y): every wave's K range holds whole groups; ~2 workgroups per CU wanted, >= 8 steps per wave
+// Waves per workgroup (all of them split K) and K slices (grid.y); every wave's K range holds whole groups.  8 waves when
+// the column tiles alone (almost) cover the chip: one workgroup per CU, no slabs, no reduce launch.  Otherwise 4 waves
+// (two workgroups fit a CU) and as many K slices as it takes to have ~1 workgroup per CU, >= 8 steps per wave: the
+// fp32 slabs and their reduce pass cost more than a second resident workgroup buys.
 static MidPlan mid_plan(int64_t M, int64_t N, int64_t K, int64_t gs) {
   MidPlan pl;
   pl.mb = M <= 32 ? 1 : 2;
   pl.ksplit = 1;
   const int64_t tiles = N / 128;
-  for (int s = 2; s <= 32; ++s) {
-    if (tiles * pl.ksplit >= 400) break;
-    if (K % (4 * s * gs) == 0 && K / (4 * s) >= 128) pl.ksplit = s;
-  }
-  if (const char* e = getenv("APHRO_WNA16_MID_KSPLIT")) { const int s = atoi(e); if (s >= 1 && K % (4 * s * gs) == 0) pl.ksplit = s; }
+  pl.nwk = (tiles >= 200 && K % (8 * gs) == 0) ? 8 : 4;
+  if (const char* e = getenv("APHRO_WNA16_MID_WAVES")) { const int v = atoi(e); if (v == 4 || (v == 8 && K % (8 * gs) == 0)) pl.nwk = v; }
+  if (pl.nwk == 4)
+    for (int s = 2; s <= 32; ++s) {
+      if (tiles * pl.ksplit >= 200) break;      // (down_proj at M = 64: 7 slices 23.7 us, 14 slices 28.9 us)
+      if (K % (4 * s * gs) == 0 && K / (4 * s) >= 128) pl.ksplit = s;
+    }
+  if (const char* e = getenv("APHRO_WNA16_MID_KSPLIT")) { const int s = atoi(e); if (s >= 1 && K % (pl.nwk * s * gs) == 0) pl.ksplit = s; }
   return pl;
+}
+
+static size_t mid_lds_bytes(int mb, int nwk) {   // round 1 of the butterfly, or the last round + the output tile behind it
+  const size_t r1 = (size_t)nwk * mb * 8192, r2 = (size_t)mb * 16384 + (size_t)mb * 32 * MID_LDT * 4;
+  return r1 > r2 ? r1 : r2;
+}
+
+template <int MB, int NWK>
+static int mid_launch(const Wna16MidParams& p, dim3 grid, hipStream_t st) {
+  const size_t lds = mid_lds_bytes(MB, NWK);
+  static bool attr_set = false;                  // up to 128 KiB of dynamic LDS: above the default 64 KiB limit
+  if (!attr_set && lds > 64 * 1024) {
+    if (hipFuncSetAttribute((const void*)wna16_gemm_mid_kernel<MB, NWK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+      set_error("wna16_gemm_mid: cannot raise the dynamic LDS limit");
+      return APHRO_ERR_LAUNCH;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((wna16_gemm_mid_kernel<MB, NWK>), grid, dim3(64 * NWK), lds, st, p);
+  APHRO_LAUNCH_CHECK();
+  return APHRO_OK;
 }
 
 extern "C" int aphro_wna16_gemm_mid_supported(int64_t M, int64_t N, int64_t K, int64_t groups) {
@@ -375,20 +443,10 @@ extern "C" int aphro_wna16_gemm_mid(const void* a, const uint32_t* q_weight, con
   p.M = (int)M; p.N = (int)N; p.K = (int)K; p.group_size = (int)gs; p.zero_offset = zero_offset;
   p.out_bf16 = dtype == APHRO_BF16; p.scale_bf16 = dtype == APHRO_BF16; p.ksplit = pl.ksplit;
   const dim3 grid((unsigned)(N / 128), (unsigned)pl.ksplit);
-  auto lds_bytes = [](int mb) { const size_t r1 = (size_t)mb * 32768, r2 = (size_t)mb * 16384 + (size_t)mb * 32 * MID_LDT * 4; return r1 > r2 ? r1 : r2; };
-  if (pl.mb == 1) hipLaunchKernelGGL((wna16_gemm_mid_kernel<1>), grid, dim3(256), lds_bytes(1), st, p);
-  else {
-    static bool attr_set = false;    // 65 KiB of dynamic LDS: above the default 64 KiB limit
-    if (!attr_set) {
-      if (hipFuncSetAttribute((const void*)wna16_gemm_mid_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess) {
-        set_error("wna16_gemm_mid: cannot raise the dynamic LDS limit");
-        return APHRO_ERR_LAUNCH;
-      }
-      attr_set = true;
-    }
-    hipLaunchKernelGGL((wna16_gemm_mid_kernel<2>), grid, dim3(256), lds_bytes(2), st, p);
-  }
-  APHRO_LAUNCH_CHECK();
+  int rc;
+  if (pl.mb == 1) rc = pl.nwk == 8 ? mid_launch<1, 8>(p, grid, st) : mid_launch<1, 4>(p, grid, st);
+  else rc = pl.nwk == 8 ? mid_launch<2, 8>(p, grid, st) : mid_launch<2, 4>(p, grid, st);
+  if (rc != APHRO_OK) return rc;
   if (pl.ksplit > 1) {
     const int64_t mn = M * N;
     hipLaunchKernelGGL(mid_splitk_reduce_kernel, dim3((unsigned)((mn / 4 + 255) / 256)), dim3(256), 0, st, p.partial, (uint16_t*)c,

@@ -135,13 +135,16 @@ def test_gptq_gemm_large_m_path(ops):
     assert rel_mean_err(got.float().cpu().numpy(), ref) < 0.04
 
 
+@pytest.mark.parametrize("waves", [4, 8])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("M", [1, 31, 32, 33, 48, 64])
-@pytest.mark.parametrize("K,N,G", [(512, 128, 128), (2048, 384, 128), (1024, 256, 256)])
-def test_wna16_gemm_mid_vs_oracle(ops, K, N, G, M, dtype):
+@pytest.mark.parametrize("K,N,G", [(512, 128, 128), (2048, 384, 128), (1024, 256, 256), (2048, 128, 256)])
+def test_wna16_gemm_mid_vs_oracle(ops, monkeypatch, K, N, G, M, dtype, waves):
     """csrc/wna16_gemm_mid.hip (one pass of 32x32x16 MFMAs for decode batches up to 64 rows, 4 waves split K and meet
     in an LDS butterfly, fp32 slabs for more K slices) against the oracle's gptq_gemm, every row and column; and
-    bit-equal to itself run twice (fixed summation order)."""
+    bit-equal to itself run twice (fixed summation order).  waves: K-splitting waves per workgroup (8 = the form
+    gate_up-sized weights run, one more butterfly round; shapes whose K does not hold 8 groups fall back to 4)."""
+    monkeypatch.setenv("APHRO_WNA16_MID_WAVES", str(waves))
     rng = np.random.default_rng(100 + M + K)
     qweight, qzeros, s, _ = make_gptq(rng, K, N, G)
     a = rng.standard_normal((M, K)).astype(np.float16)
@@ -164,7 +167,8 @@ def test_wna16_gemm_mid_dispatch_and_act_order(ops):
     """gptq_gemm routes 33..64 rows of a gate_up-sized weight to the mid kernel (and nothing else there); act-order
     (g_idx) goes through the same gather as the other paths."""
     assert ops.wna16_prefers_mid(64, 28672, 4096) and not ops.wna16_prefers_mid(32, 28672, 4096)
-    assert not ops.wna16_prefers_mid(64, 4096, 14336) and not ops.wna16_prefers_mid(65, 28672, 4096)
+    assert ops.wna16_prefers_mid(64, 4096, 14336) and not ops.wna16_prefers_mid(65, 28672, 4096)
+    assert not ops.wna16_prefers_mid(64, 6144, 4096)
     rng = np.random.default_rng(5)
     K, N, G, M = 1024, 256, 128, 40
     qweight, qzeros, s, g_idx = make_gptq(rng, K, N, G, act_order=True)
@@ -211,9 +215,10 @@ def test_awq_gemm(ops, M, K, N, G):
     np.testing.assert_array_equal(rq.cpu().numpy(), oq.gptq_shuffle(oq.gptq_pack(oq.awq_unpack(qw))))
     np.testing.assert_array_equal(rz.cpu().numpy(), oq.pack_cols(oq.awq_unpack(qz)))
     got2 = ops.wna16_gemm(t(a), rq, rz, t(s), None, 0).float().cpu().numpy()
-    if M <= 64:
+    if M <= 64 and not ops.wna16_prefers_mid(M, N, K):
         np.testing.assert_array_equal(got2, got)
-    else:   # M > 64: the prefill-sized MFMA kernel (scale folded into the f16 weight: one extra rounding)
+    else:   # the 32x32x16 MFMA kernels (33..64 rows of a large weight, or M > 64): scale folded into the f16 weight
+        # -- one extra rounding, the numerics of the reference's reconstruct kernels
         np.testing.assert_allclose(got2, ref, rtol=2e-3, atol=2e-3 * np.abs(ref).max())
 
 
@@ -246,9 +251,10 @@ def test_config3_llama70b_awq_tp8_shapes(ops, K, N):
     np.testing.assert_allclose(got, ref, rtol=2e-3, atol=2e-3 * np.abs(ref).max())
     rq, rz = ops.awq_marlin_repack(t(qw), K, N, 4), ops.awq_repack_zeros(t(qz), N)
     got2 = ops.wna16_gemm(t(a), rq, rz, t(s), None, 0).float().cpu().numpy()
-    if M <= 64:
+    if M <= 64 and not ops.wna16_prefers_mid(M, N, K):
         np.testing.assert_array_equal(got2, got)
-    else:   # M > 64: the prefill-sized MFMA kernel (scale folded into the f16 weight: one extra rounding)
+    else:   # the 32x32x16 MFMA kernels (33..64 rows of a large weight, or M > 64): scale folded into the f16 weight
+        # -- one extra rounding, the numerics of the reference's reconstruct kernels
         np.testing.assert_allclose(got2, ref, rtol=2e-3, atol=2e-3 * np.abs(ref).max())
 
 
