@@ -33,6 +33,30 @@ def test_library_exports_every_declared_symbol():
     assert _lib.lib().aphro_abi_version() == 1
 
 
+def test_int4_gemm_plans_through_their_workspace_sizes():
+    """The launch plans of the prefill-sized and the 33..64-row int4 GEMMs are host logic (no device call): their
+    workspace queries say which plan a shape gets -- K slices by waves and slab bytes (wna16_gemm_large.hip), 8
+    K-splitting waves without slabs when the column tiles cover the chip (wna16_gemm_mid.hip)."""
+    from aphrodite_engine_amd import _lib
+    L = _lib.lib()
+    slab = lambda m, n: m * n * 4
+    large = lambda m, n, k: L.aphro_wna16_gemm_large_workspace_bytes(m, n, k, k // 128, 0)
+    assert large(128, 28672, 4096) == 2 * slab(128, 28672)        # 224 two-wave workgroups -> 2 K slices
+    assert large(256, 6144, 4096) == 4 * slab(256, 6144)          # 8 slices would be 50 MB of slabs: capped
+    assert large(1024, 6144, 4096) == 0                           # one slab pair already 50 MB: no split
+    assert large(96, 4096, 14336) == 14 * slab(96, 4096)
+    assert large(8192, 28672, 4096) == 4096 + 256 * 8 * 32 * 1024  # stream-K: flags + one image per workgroup
+    assert large(256, 28672, 4096, ) % 256 == 0
+    mid_ok = lambda m, n, k: L.aphro_wna16_gemm_mid_supported(m, n, k, k // 128)
+    mid = lambda m, n, k: L.aphro_wna16_gemm_mid_workspace_bytes(m, n, k, k // 128)
+    assert mid_ok(64, 28672, 4096) and mid_ok(1, 128, 512) and not mid_ok(65, 28672, 4096)
+    assert not mid_ok(64, 28672, 4096 + 128) and not mid_ok(64, 28672 + 64, 4096)
+    assert mid(64, 28672, 4096) == 64 * 4096 * 2                  # packed activations only: 8 waves split K, no slabs
+    assert mid(32, 28672, 4096) == 32 * 4096 * 2
+    assert mid(64, 4096, 14336) == 64 * 14336 * 2 + 7 * slab(64, 4096)
+    assert mid(65, 28672, 4096) == 0
+
+
 def test_no_cpu_fallback():
     from aphrodite_engine_amd import _custom_ops as ops
     with pytest.raises(RuntimeError, match="no CPU fallback"):
