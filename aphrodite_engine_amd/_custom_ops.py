@@ -721,6 +721,49 @@ def wna16_gemm_silu_pack(a_packed: torch.Tensor, m: int, k: int, qweight: torch.
     return out
 
 
+def wna16_gemm_mid_ksplit(m: int, n: int, k: int, groups: int) -> int:
+    """K slices the 33..64-row kernel would use on the decode fast path; 0: shape not served."""
+    return int(_lib.lib().aphro_wna16_gemm_mid_ksplit(m, n, k, groups))
+
+
+def wna16_gemm_mid_packed(a_packed: torch.Tensor, m: int, k: int, qweight: torch.Tensor, qzeros: torch.Tensor,
+                          scales: torch.Tensor, zero_offset: int, partials: bool = False):
+    """wna16_gemm_packed for 33..64 rows on the one-pass MFMA kernel (csrc/wna16_gemm_mid.hip) -- same packed
+    activations in, same conventions out: partials=True -> (fp32 slabs [S, M, N], S) for a fused consumer."""
+    lib = _lib.lib()
+    n = qweight.shape[1]
+    groups = scales.shape[0]
+    ks = lib.aphro_wna16_gemm_mid_ksplit(m, n, k, groups)
+    if ks <= 0:
+        raise RuntimeError(f"wna16_gemm_mid_packed: shape M={m} N={n} K={k} not served")
+    if partials:
+        slabs = torch.empty((ks, m, n), dtype=torch.float32, device=qweight.device)
+        check(lib.aphro_wna16_gemm_mid_packed(a_packed.data_ptr(), qweight.data_ptr(), qzeros.data_ptr(), scales.data_ptr(),
+                                              None, slabs.data_ptr(), slabs.numel() * 4, None, m, n, k, groups,
+                                              zero_offset, _dt(scales), _stream()), "wna16_gemm_mid_packed")
+        return slabs, ks
+    if ks > 1:
+        slabs, _ = wna16_gemm_mid_packed(a_packed, m, k, qweight, qzeros, scales, zero_offset, partials=True)
+        return slabs.sum(0).to(scales.dtype)
+    out = torch.empty((m, n), dtype=scales.dtype, device=qweight.device)
+    check(lib.aphro_wna16_gemm_mid_packed(a_packed.data_ptr(), qweight.data_ptr(), qzeros.data_ptr(), scales.data_ptr(),
+                                          out.data_ptr(), None, 0, None, m, n, k, groups, zero_offset, _dt(scales),
+                                          _stream()), "wna16_gemm_mid_packed")
+    return out
+
+
+def wna16_gemm_mid_silu_pack(a_packed: torch.Tensor, m: int, k: int, qweight: torch.Tensor, qzeros: torch.Tensor,
+                             scales: torch.Tensor, zero_offset: int) -> torch.Tensor:
+    """wna16_gemm_silu_pack for 33..64 rows: gate_up GEMM (interleaved columns) + SiluAndMul + pack in one launch."""
+    lib = _lib.lib()
+    n = qweight.shape[1]
+    out = torch.empty(lib.aphro_wna16_packed_a_bytes(m, n // 2) // 2, dtype=torch.float16, device=qweight.device)
+    check(lib.aphro_wna16_gemm_mid_packed(a_packed.data_ptr(), qweight.data_ptr(), qzeros.data_ptr(), scales.data_ptr(),
+                                          None, None, 0, out.data_ptr(), m, n, k, scales.shape[0], zero_offset,
+                                          _dt(scales), _stream()), "wna16_gemm_mid_silu_pack")
+    return out
+
+
 def fused_add_rms_norm_pack(x: Optional[torch.Tensor], slabs: Optional[torch.Tensor],
                             residual: Optional[torch.Tensor], has_residual: bool,
                             weight: torch.Tensor, epsilon: float, pack: bool = True,

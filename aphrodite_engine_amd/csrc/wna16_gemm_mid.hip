@@ -40,6 +40,11 @@ struct Wna16MidParams {
   int zero_offset;
   int out_bf16, scale_bf16;
   int ksplit;             // grid.y
+  // ---- decode fast path (template ADEC): activations in the DECODE kernel's fragment-major format (wna16_gemm.hip:
+  // block (k/128, (k%32)/8, m/16) = 1 KiB, lane ((k%128)/32, m%16)), written by the fused producers --------------------
+  int mtiles;             // 16-row m-tiles of that buffer = ceil(M / 16)
+  int force_partial;      // write the fp32 slab(s) even with one K slice (the consumer kernel sums them)
+  uint16_t* act_packed;   // != NULL: SiluAndMul + pack epilogue (interleaved gate / up columns) into the same format
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t mid_rsrc(const void* base, uint32_t bytes) {
@@ -120,7 +125,30 @@ __device__ __forceinline__ void mid_put(const f32x16 (&acc)[4][MB], float* tile,
 template <int MB, int NWK>
 __device__ __forceinline__ void mid_flush(const float* tile, const Wna16MidParams& p, int n0, int wave, int lane) {
   constexpr int ROWS = 32 * MB / NWK;           // rows per wave
-  if (p.ksplit > 1) {                           // fp32 slab: 2 rows x 512 B per instruction
+  if (p.act_packed != nullptr) {
+    // SiluAndMul + activation pack (the epilogue of wna16_gemm.hip's gate_up form, same roundings: the GEMM result is
+    // rounded to T first, silu_mul_bits is shared with the separate op).  Columns 2j / 2j+1 = gate_j / up_j: a lane's 8
+    // columns are output features j0 .. j0 + 3 = one 8-byte piece of the consumer's fragment.
+#pragma unroll
+    for (int i = 0; i < ROWS / 4; ++i) {
+      const int m = wave * ROWS + 4 * i + (lane >> 4);
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(&tile[m * MID_LDT + 8 * (lane & 15)]);
+      const f32x4 v1 = *reinterpret_cast<const f32x4*>(&tile[m * MID_LDT + 8 * (lane & 15) + 4]);
+      const float g4[4] = {v0[0], v0[2], v1[0], v1[2]}, u4[4] = {v0[1], v0[3], v1[1], v1[3]};
+      uint16_t o[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (p.out_bf16) {
+          o[q] = bf16_bits_to_f16_bits_sat(silu_mul_bits<BFloat>(BFloat::to_f32(BFloat::from_f32(g4[q])), BFloat::to_f32(BFloat::from_f32(u4[q]))));
+        } else {
+          o[q] = silu_mul_bits<Half>(Half::to_f32(Half::from_f32(g4[q])), Half::to_f32(Half::from_f32(u4[q])));
+        }
+      }
+      const int j0 = (n0 >> 1) + 4 * (lane & 15);
+      uint16_t* dst = p.act_packed + ((((size_t)(j0 >> 7) * 4 + ((j0 & 31) >> 3)) * p.mtiles + (m >> 4)) * 64 + ((j0 & 127) >> 5) * 16 + (m & 15)) * 8 + (j0 & 7);
+      if (m < p.M) *reinterpret_cast<u32x2*>(dst) = u32x2{(uint32_t)o[0] | ((uint32_t)o[1] << 16), (uint32_t)o[2] | ((uint32_t)o[3] << 16)};
+    }
+  } else if (p.ksplit > 1 || p.force_partial) {   // fp32 slab: 2 rows x 512 B per instruction
 #pragma unroll
     for (int i = 0; i < ROWS / 2; ++i) {
       const int m = wave * ROWS + 2 * i + (lane >> 5);
@@ -141,7 +169,7 @@ __device__ __forceinline__ void mid_flush(const float* tile, const Wna16MidParam
 }
 
 // NWK waves split K: 4 (two workgroups per CU, more K slices go to slabs) or 8 (one workgroup per CU, 128 KiB butterfly)
-template <int MB, int NWK>
+template <int MB, int NWK, bool ADEC = false>
 __global__ __launch_bounds__(64 * NWK, 2) void wna16_gemm_mid_kernel(Wna16MidParams p) {
   constexpr int NB = 4;
   constexpr int DW = 8;   // weight steps in flight (one 16-byte load each)
@@ -156,13 +184,14 @@ __global__ __launch_bounds__(64 * NWK, 2) void wna16_gemm_mid_kernel(Wna16MidPar
   const int gsteps = p.group_size >> 4;
 
   const __amdgpu_buffer_rsrc_t rw = mid_rsrc(p.qw, (uint32_t)((size_t)(p.K >> 3) * p.N * 4));
-  const __amdgpu_buffer_rsrc_t ra = mid_rsrc(p.apk, (uint32_t)((size_t)(p.K >> 4) * MB * 1024));
+  const __amdgpu_buffer_rsrc_t ra = mid_rsrc(p.apk, ADEC ? (uint32_t)((size_t)(p.K >> 7) * 4 * p.mtiles * 1024) : (uint32_t)((size_t)(p.K >> 4) * MB * 1024));
   const int ngroups = p.K / p.group_size;
   const __amdgpu_buffer_rsrc_t rs = mid_rsrc(p.sc, (uint32_t)((size_t)ngroups * p.N * 2));
   const __amdgpu_buffer_rsrc_t rz = mid_rsrc(p.qz, (uint32_t)((size_t)ngroups * (p.N >> 3) * 4));
   const int voff_w = (kh * p.N + n0 + 4 * l31) * 4;     // packed row 2 s + kh, this lane's 4 columns
   const int wstep = 2 * p.N * 4;
-  const int voff_a = lane * 16;
+  // ADEC: chunk (m, k8 = 2 s + kh) sits in block ((s / 8) * 4 + 2 (s % 2) + kh, m / 16), lane ((s % 8) / 2, m % 16)
+  const int voff_a = ADEC ? (kh * p.mtiles + (l31 >> 4)) * 1024 + (l31 & 15) * 16 : lane * 16;
   constexpr int astep = MB * 1024;
   const int voff_s = (n0 + 4 * l31) * 2;
   const int voff_z = ((n0 + 4 * l31) >> 3) * 4;
@@ -186,7 +215,12 @@ __global__ __launch_bounds__(64 * NWK, 2) void wna16_gemm_mid_kernel(Wna16MidPar
     zraw = __builtin_amdgcn_raw_buffer_load_b32(rz, voff_z, grp * (p.N >> 3) * 4, 0);
   };
   auto load_w = [&](int s) { return __builtin_amdgcn_raw_buffer_load_b128(rw, voff_w, s * wstep, 2); };
-  auto load_a = [&](int s, int mb) { return __builtin_amdgcn_raw_buffer_load_b128(ra, voff_a + mb * 1024, s * astep, 0); };
+  auto load_a = [&](int s, int mb) {
+    if constexpr (ADEC)
+      return __builtin_amdgcn_raw_buffer_load_b128(ra, voff_a + mb * 2048, (((s >> 3) * 4 + 2 * (s & 1)) * p.mtiles) * 1024 + ((s & 7) >> 1) * 256, 0);
+    else
+      return __builtin_amdgcn_raw_buffer_load_b128(ra, voff_a + mb * 1024, s * astep, 0);
+  };
 
   if constexpr (MID_ABL & 64) {
     sraw = u32x2{0x3c003c00u, 0x3c003c00u}; zraw = 0x88888888u;
@@ -382,18 +416,18 @@ static size_t mid_lds_bytes(int mb, int nwk) {   // round 1 of the butterfly, or
   return r1 > r2 ? r1 : r2;
 }
 
-template <int MB, int NWK>
+template <int MB, int NWK, bool ADEC = false>
 static int mid_launch(const Wna16MidParams& p, dim3 grid, hipStream_t st) {
   const size_t lds = mid_lds_bytes(MB, NWK);
   static bool attr_set = false;                  // up to 128 KiB of dynamic LDS: above the default 64 KiB limit
   if (!attr_set && lds > 64 * 1024) {
-    if (hipFuncSetAttribute((const void*)wna16_gemm_mid_kernel<MB, NWK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+    if (hipFuncSetAttribute((const void*)wna16_gemm_mid_kernel<MB, NWK, ADEC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
       set_error("wna16_gemm_mid: cannot raise the dynamic LDS limit");
       return APHRO_ERR_LAUNCH;
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL((wna16_gemm_mid_kernel<MB, NWK>), grid, dim3(64 * NWK), lds, st, p);
+  hipLaunchKernelGGL((wna16_gemm_mid_kernel<MB, NWK, ADEC>), grid, dim3(64 * NWK), lds, st, p);
   APHRO_LAUNCH_CHECK();
   return APHRO_OK;
 }
@@ -442,6 +476,7 @@ extern "C" int aphro_wna16_gemm_mid(const void* a, const uint32_t* q_weight, con
   p.partial = (float*)((char*)workspace + apk_bytes);
   p.M = (int)M; p.N = (int)N; p.K = (int)K; p.group_size = (int)gs; p.zero_offset = zero_offset;
   p.out_bf16 = dtype == APHRO_BF16; p.scale_bf16 = dtype == APHRO_BF16; p.ksplit = pl.ksplit;
+  p.mtiles = 0; p.force_partial = 0; p.act_packed = nullptr;
   const dim3 grid((unsigned)(N / 128), (unsigned)pl.ksplit);
   int rc;
   if (pl.mb == 1) rc = pl.nwk == 8 ? mid_launch<1, 8>(p, grid, st) : mid_launch<1, 4>(p, grid, st);
@@ -454,4 +489,46 @@ extern "C" int aphro_wna16_gemm_mid(const void* a, const uint32_t* q_weight, con
     APHRO_LAUNCH_CHECK();
   }
   return APHRO_OK;
+}
+
+// ---- decode fast path: 33..64 rows, activations already in the decode kernel's fragment-major format ------------------
+// (aphro_wna16_pack_a / the fused producers of the decode step), results handed to the next fused kernel:
+//   act_packed != NULL : gate_up form -- columns interleaved (2j = gate_j, 2j+1 = up_j, ops.interleave_gate_up), SiluAndMul
+//                        + pack in the epilogue, output = the fragment-major f16 activations [M, N/2] of the down GEMM
+//                        (the role of aphro_wna16_gemm_silu_pack); needs a plan without K slices (N >= 25600)
+//   slabs != NULL      : fp32 slabs [aphro_wna16_gemm_mid_ksplit][M][N] for a consumer that sums them (the norm kernel)
+//   else               : c [M, N] in `dtype` (one K slice only)
+extern "C" int aphro_wna16_gemm_mid_ksplit(int64_t M, int64_t N, int64_t K, int64_t groups) {
+  if (M <= 32 || !aphro_wna16_gemm_mid_supported(M, N, K, groups)) return 0;
+  return mid_plan(M, N, K, K / groups).ksplit;
+}
+
+extern "C" int aphro_wna16_gemm_mid_packed(const void* a_packed, const uint32_t* q_weight, const uint32_t* qzeros,
+                                           const void* scales, void* c, void* slabs, size_t slabs_bytes, void* act_packed,
+                                           int64_t M, int64_t N, int64_t K, int64_t groups, int zero_offset, int dtype,
+                                           void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  APHRO_CHECK(dtype == APHRO_F16 || dtype == APHRO_BF16, "wna16_gemm_mid_packed: dtype must be f16 or bf16");
+  APHRO_CHECK(M > 32 && aphro_wna16_gemm_mid_supported(M, N, K, groups), "wna16_gemm_mid_packed: unsupported shape M=%ld N=%ld K=%ld groups=%ld",
+              (long)M, (long)N, (long)K, (long)groups);
+  APHRO_CHECK(((uintptr_t)a_packed % 16) == 0, "wna16_gemm_mid_packed: packed activations must be 16-byte aligned");
+  const int64_t gs = K / groups;
+  const MidPlan pl = mid_plan(M, N, K, gs);
+  Wna16MidParams p;
+  p.apk = (const uint32_t*)a_packed; p.qw = q_weight; p.qz = qzeros; p.sc = (const uint16_t*)scales; p.c = (uint16_t*)c;
+  p.partial = (float*)slabs;
+  p.M = (int)M; p.N = (int)N; p.K = (int)K; p.group_size = (int)gs; p.zero_offset = zero_offset;
+  p.out_bf16 = dtype == APHRO_BF16; p.scale_bf16 = dtype == APHRO_BF16; p.ksplit = pl.ksplit;
+  p.mtiles = (int)((M + 15) / 16); p.force_partial = 0; p.act_packed = nullptr;
+  if (act_packed != nullptr) {
+    APHRO_CHECK(pl.ksplit == 1 && N % 256 == 0, "wna16_gemm_mid_packed: the SiluAndMul form needs one K slice and N/2 %% 128 == 0 (N=%ld)", (long)N);
+    p.act_packed = (uint16_t*)act_packed;
+  } else if (slabs != nullptr) {
+    APHRO_CHECK(slabs_bytes >= (size_t)pl.ksplit * M * N * sizeof(float), "wna16_gemm_mid_packed: slabs too small");
+    p.force_partial = 1;
+  } else {
+    APHRO_CHECK(c != nullptr && pl.ksplit == 1, "wna16_gemm_mid_packed: this shape needs the slab form (%d K slices)", pl.ksplit);
+  }
+  const dim3 grid((unsigned)(N / 128), (unsigned)pl.ksplit);
+  return pl.nwk == 8 ? mid_launch<2, 8, true>(p, grid, st) : mid_launch<2, 4, true>(p, grid, st);
 }

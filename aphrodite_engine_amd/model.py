@@ -10,6 +10,7 @@ Tensor parallelism follows the reference: QKV / gate_up column
 parallel, o_proj / down_proj row parallel + all-reduce
 (modeling/layers/linear.py:1139-1143).
 """
+import os
 import math
 from dataclasses import dataclass
 from typing import List, Optional
@@ -297,10 +298,16 @@ class LlamaDecoderLayer(nn.Module):
             o_slabs, _ = ops.wna16_gemm_packed(attn_packed, m, self.q_size, qw, qz, sc, zo, partials=True)
             packed2, _ = ops.fused_add_rms_norm_pack(None, o_slabs, residual, True,
                                                      self.post_attention_layernorm, eps)
+        # 33..64 rows: the MLP weights go through the one-pass 32x32x16 MFMA kernel (wna16_gemm_mid.hip: 26.6 vs 37.6 us on
+        # gate_up at 64 rows) -- same packed activations in, same packed activations / fp32 slabs out
+        mid = 32 < m <= 64 and not os.environ.get("APHRO_DECODE_NO_MID")
         if self.gate_up_interleaved is not None:
             # SiluAndMul + pack run in the GEMM epilogue (interleaved gate/up columns)
             qw, qz, sc, zo = self.gate_up_interleaved
-            act_packed = ops.wna16_gemm_silu_pack(packed2, m, h, qw, qz, sc, zo)
+            if mid and ops.wna16_gemm_mid_ksplit(m, qw.shape[1], h, sc.shape[0]) == 1 and qw.shape[1] % 256 == 0:
+                act_packed = ops.wna16_gemm_mid_silu_pack(packed2, m, h, qw, qz, sc, zo)
+            else:
+                act_packed = ops.wna16_gemm_silu_pack(packed2, m, h, qw, qz, sc, zo)
         else:
             qw, qz, sc, zo = self.gate_up_proj.fast_params()
             gate_up = ops.wna16_gemm_packed(packed2, m, h, qw, qz, sc, zo, partials=False)
@@ -309,8 +316,11 @@ class LlamaDecoderLayer(nn.Module):
         if self.tp > 1:
             d = ops.wna16_gemm_packed(act_packed, m, self.down_proj.in_features, qw, qz, sc, zo, partials=False)
             return tensor_model_parallel_all_reduce(d, prefetch=next_weights), None
-        down_slabs, _ = ops.wna16_gemm_packed(act_packed, m, self.down_proj.in_features, qw, qz, sc, zo,
-                                              partials=True)
+        kd = self.down_proj.in_features
+        if mid and qw.shape[1] * kd >= 2 ** 25 and ops.wna16_gemm_mid_ksplit(m, qw.shape[1], kd, sc.shape[0]) > 0:
+            down_slabs, _ = ops.wna16_gemm_mid_packed(act_packed, m, kd, qw, qz, sc, zo, partials=True)
+        else:
+            down_slabs, _ = ops.wna16_gemm_packed(act_packed, m, kd, qw, qz, sc, zo, partials=True)
         return None, down_slabs
 
     # -- FP8 W8A8 (per-token dynamic activations) decode fast path -------------------------------

@@ -218,15 +218,22 @@ def roofline_section(model, loop, args):
             packed = ops.wna16_pack_a(xin)
             silu = name == "gate_up_proj" and layers[0].gate_up_interleaved is not None
 
-            def run_lin(name=name, packed=packed, silu=silu, k=lin0.in_features):
+            # 33..64 rows: the MLP weights run the one-pass kernel (model.py forward_decode_fused picks it the same way)
+            n_out, groups = lin0.out_features, lin0.in_features // 128
+            mid = 32 < bs <= 64 and not os.environ.get("APHRO_DECODE_NO_MID") and (
+                (silu and ops.wna16_gemm_mid_ksplit(bs, n_out, lin0.in_features, groups) == 1) or
+                (name == "down_proj" and n_out * lin0.in_features >= 2 ** 25
+                 and ops.wna16_gemm_mid_ksplit(bs, n_out, lin0.in_features, groups) > 0))
+
+            def run_lin(name=name, packed=packed, silu=silu, k=lin0.in_features, mid=mid):
                 for layer in layers:
                     if silu:
                         qw, qz, sc, zo = layer.gate_up_interleaved
-                        ops.wna16_gemm_silu_pack(packed, bs, k, qw, qz, sc, zo)
+                        (ops.wna16_gemm_mid_silu_pack if mid else ops.wna16_gemm_silu_pack)(packed, bs, k, qw, qz, sc, zo)
                     else:
                         qw, qz, sc, zo = getattr(layer, name).fast_params()
-                        ops.wna16_gemm_packed(packed, bs, k, qw, qz, sc, zo, partials=True)
-            kname = "wna16_gemm_kernel" + (" (+SiluAndMul epilogue)" if silu else "")
+                        (ops.wna16_gemm_mid_packed if mid else ops.wna16_gemm_packed)(packed, bs, k, qw, qz, sc, zo, partials=True)
+            kname = ("wna16_gemm_mid_kernel" if mid else "wna16_gemm_kernel") + (" (+SiluAndMul epilogue)" if silu else "")
         elif args.quant == "fp8ct" and getattr(model, "use_fused_decode", False):
             # the FP8 decode fast path hands every GEMM pre-quantised activations (the quantisation is fused into the norm /
             # SiluAndMul kernels): time the GEMM launch alone, in the form the step uses (fp32 slabs for qkv / o / down,

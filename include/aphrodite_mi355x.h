@@ -547,6 +547,18 @@ int aphro_wna16_gemm_mid(const void* a, const uint32_t* q_weight, const uint32_t
                          void* c, void* workspace, size_t workspace_bytes, int64_t M, int64_t N, int64_t K,
                          int64_t groups, int64_t lda, int zero_offset, int dtype, void* stream);
 
+/* The same kernel on the decode fast path (33..64 rows): activations already in the decode kernel's fragment-major
+ * format (aphro_wna16_pack_a / the fused producers), results handed to the next fused kernel -- act_packed != NULL:
+ * gate_up form (interleaved gate / up columns, SiluAndMul + pack epilogue = the role of aphro_wna16_gemm_silu_pack,
+ * `_C::silu_and_mul` fused, activation_kernels.cu:14-28); slabs != NULL: fp32 slabs [aphro_wna16_gemm_mid_ksplit][M][N]
+ * summed by the consumer (aphro_fused_add_rms_norm_pack); else c [M, N].  aphro_wna16_gemm_mid_ksplit: K slices of the
+ * plan, 0 if the shape is not served. */
+int aphro_wna16_gemm_mid_ksplit(int64_t M, int64_t N, int64_t K, int64_t groups);
+int aphro_wna16_gemm_mid_packed(const void* a_packed, const uint32_t* q_weight, const uint32_t* qzeros,
+                                const void* scales, void* c, void* slabs, size_t slabs_bytes, void* act_packed,
+                                int64_t M, int64_t N, int64_t K, int64_t groups, int zero_offset, int dtype,
+                                void* stream);
+
 /* Overlap helper for tensor parallelism (north_star: "all-reduce overlapped with the quantized GEMMs on HIP
  * streams"): streams `bytes` at `ptr` through the memory-side Infinity Cache on `stream` while the all-reduce of the
  * previous row-parallel projection runs on a side stream -- see aphrodite_engine_amd/distributed/overlap.py.  Reads

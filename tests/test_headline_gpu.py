@@ -327,3 +327,46 @@ def test_config1_fused_decode_layers_vs_oracle(ops):
         want = oa.rms_norm(f16(r), m.norm.cpu().numpy(), cfg.rms_norm_eps)
     np.testing.assert_allclose(got, want, atol=2e-2, rtol=2e-2)
     assert np.abs(got - want).mean() / np.abs(want).mean() < 4e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M", [33, 48, 64])
+def test_decode_fast_path_mid_kernel_forms(ops, M, dtype):
+    """33..64 rows on the decode fast path (csrc/wna16_gemm_mid.hip reading the decode kernel's fragment-major
+    activations): the gate_up form (SiluAndMul + pack in the epilogue) against the decode kernel's own fused epilogue --
+    same packed layout, compared element by element over the valid rows -- and the slab form on the down_proj shape
+    against the decode kernel's slabs.  Tolerance: the two kernels round the dequantised weight differently (f16
+    (q - z) * s vs exact integers + fp32 scale), ~3e-4 relative."""
+    g = torch.Generator(device=DEV).manual_seed(1000 + M)
+
+    def weights(K, N):
+        qw = torch.randint(-2 ** 31, 2 ** 31 - 1, (K // 8, N), generator=g, device=DEV, dtype=torch.int64).to(torch.int32)
+        qz = torch.randint(-2 ** 31, 2 ** 31 - 1, (K // 128, N // 8), generator=g, device=DEV, dtype=torch.int64).to(torch.int32)
+        sc = (torch.rand(K // 128, N, generator=g, device=DEV) * 0.01 + 0.005).to(dtype)
+        return qw, qz, sc
+
+    K, N = 4096, 28672
+    qw, qz, sc = weights(K, N)
+    a = (torch.randn(M, K, generator=g, device=DEV) * 0.5).to(dtype)
+    packed = ops.wna16_pack_a(a)
+    assert ops.wna16_gemm_mid_ksplit(M, N, K, K // 128) == 1
+    ref = ops.wna16_gemm_silu_pack(packed, M, K, qw, qz, sc, 1).float()
+    got = ops.wna16_gemm_mid_silu_pack(packed, M, K, qw, qz, sc, 1).float()
+    valid = ops.wna16_pack_a(torch.ones(M, N // 2, device=DEV, dtype=torch.float16)) != 0   # rows < M of the packed layout
+    assert valid.sum().item() == M * (N // 2)
+    scale = ref[valid].abs().max().item()
+    assert scale > 1.0
+    assert (got - ref)[valid].abs().max().item() <= (6e-3 if dtype == torch.float16 else 2.5e-2) * scale
+    assert (got - ref)[valid].abs().mean().item() <= 4e-4 * scale if dtype == torch.float16 else True
+
+    K2, N2 = 14336, 4096
+    qw2, qz2, sc2 = weights(K2, N2)
+    a2 = (torch.randn(M, K2, generator=g, device=DEV) * 0.5).to(dtype)
+    packed2 = ops.wna16_pack_a(a2)
+    ref2 = ops.wna16_gemm_packed(packed2, M, K2, qw2, qz2, sc2, 1, partials=True)[0].sum(0)
+    slabs, ks = ops.wna16_gemm_mid_packed(packed2, M, K2, qw2, qz2, sc2, 1, partials=True)
+    assert ks == slabs.shape[0] == ops.wna16_gemm_mid_ksplit(M, N2, K2, K2 // 128) and slabs.shape[1:] == (M, N2)
+    got2 = slabs.sum(0)
+    torch.testing.assert_close(got2, ref2, rtol=0, atol=2e-3 * ref2.abs().max().item())
+    again, _ = ops.wna16_gemm_mid_packed(packed2, M, K2, qw2, qz2, sc2, 1, partials=True)
+    assert torch.equal(again, slabs)
