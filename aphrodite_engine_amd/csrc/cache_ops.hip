@@ -131,20 +131,34 @@ extern "C" int aphro_reshape_and_cache_flash(const void* key, const void* value,
 // stream pulls the NEXT projection's packed weights through the memory-side Infinity Cache (256 MiB), so that the
 // GEMM that follows the all-reduce finds them on die.  Plain 16-byte loads, nothing is written.
 namespace aphro {
+// 4 independent 16-byte loads per thread and trip (64 bytes in flight per lane): a small grid (one or two workgroups per CU,
+// APHRO_PREFETCH_BLOCKS) streams at the HBM rate and leaves the wave slots to the kernels it runs beside.
 __global__ __launch_bounds__(256) void prefetch_kernel(const u32x4* __restrict__ p, size_t n16, uint32_t* __restrict__ sink) {
   u32x4 acc = {0, 0, 0, 0};
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) acc ^= p[i];
+  const size_t stride = (size_t)gridDim.x * 256;
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  for (; i + 3 * stride < n16; i += 4 * stride) {
+    const u32x4 a = p[i], b = p[i + stride], c = p[i + 2 * stride], d = p[i + 3 * stride];
+    acc ^= a ^ b ^ c ^ d;
+  }
+  for (; i < n16; i += stride) acc ^= p[i];
   if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x9e3779b9u && sink != nullptr) *sink = 1;   // keeps the loads alive
 }
 }  // namespace aphro
 
+// Streams [ptr, ptr + bytes) through the memory-side cache.  A pointer that is not 16-byte aligned is rounded up (the
+// first bytes are skipped: a prefetch is a hint, it must never fail a decode step).
 extern "C" int aphro_prefetch(const void* ptr, size_t bytes, void* stream) {
-  APHRO_CHECK(((uintptr_t)ptr % 16) == 0, "prefetch: pointer must be 16-byte aligned");
-  const size_t n16 = bytes / 16;
+  const uintptr_t a = ((uintptr_t)ptr + 15) & ~(uintptr_t)15;
+  const size_t skip = (size_t)(a - (uintptr_t)ptr);
+  if (bytes <= skip) return APHRO_OK;
+  const size_t n16 = (bytes - skip) / 16;
   if (n16 == 0) return APHRO_OK;
-  unsigned blocks = (unsigned)((n16 + 256 * 8 - 1) / (256 * 8));
-  if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(aphro::prefetch_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const u32x4*)ptr, n16,
+  int max_blocks = 512;                  // (read per call: calls happen at capture time only, replays never get here)
+  if (const char* e = getenv("APHRO_PREFETCH_BLOCKS")) { const int v = atoi(e); if (v >= 1) max_blocks = v; }
+  unsigned blocks = (unsigned)((n16 + 256 * 4 - 1) / (256 * 4));
+  if (blocks > (unsigned)max_blocks) blocks = (unsigned)max_blocks;
+  hipLaunchKernelGGL(aphro::prefetch_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const u32x4*)a, n16,
                      (uint32_t*)nullptr);
   APHRO_LAUNCH_CHECK();
   return APHRO_OK;

@@ -1,0 +1,534 @@
+// W4A16 (GPTQ / AWQ-repacked int4) decode GEMM for M <= 32 on gfx950 with the ACTIVATIONS RESIDENT IN REGISTERS -- round 3.
+//
+// Same role as wna16_gemm.hip's fast kernel (the reference's exllama kernel gemm_half_q_half_gptq_4bit_kernel,
+// kernels/quantization/gptq/q_gemm.cu:190-326, and the gptq_marlin_gemm role at small M), same arithmetic -- and, for a
+// configuration with the same K partition (4 waves x NSEG segments, same K slices), the same BITS: per 128-k group
+// acc = sum a'.q.2^-24 through v_mfma_f32_16x16x32_f16 on subnormal operands, c += s.(2^24 acc - z.rowsum) in fp32, the
+// waves' partial sums added in wave order.  What changes is the shape of the work ("resident" kernel):
+//
+//   * ONE workgroup per CU, every workgroup the same amount of work: the grid is (N / CW) column STRIPS x K slices = 256
+//     for the Llama-3-8B projections (gate_up: 256 strips of 112 columns; down: 64 strips of 64 x 4 slices).  The 64-column
+//     tile grid of wna16_gemm.hip puts 448 workgroups on 256 CUs for gate_up: 192 CUs do two, 64 do one.
+//   * a wave keeps the A fragments of its whole K range in registers (NSEG x 32 VGPRs at 32 rows; up to 256 of the 512 a
+//     wave owns at one wave per SIMD) and walks over the strip's column PASSES (64 columns = one 16-byte load per lane and
+//     k-step; a last pass of 16/32/48 columns): the activations go through the vector L1 ONCE per workgroup instead of
+//     once per 64 columns.  Measured on the round-2 kernel: without its A loads 14.0 us instead of 19.3 (gate_up) -- a
+//     CU's miss path carries ~50 GB/s whatever the source, and A (L2 hits) was taking 2/3 of the bytes.
+//   * the pre-scale of the A fragments (x 1/16 on the k that meet in-place nibbles) and the row sums are done once, in
+//     the first pass, and kept.
+//   * the weight stream of a wave is ONE long sequence of loads over all its passes, DEPTH k-steps ahead in a register
+//     ring (16 KiB in flight per wave at DEPTH 16); straight-line code (every index is a template constant) so that hipcc
+//     counts vmcnt exactly.
+//   * optional STRIP-MAJOR weight layout (strip_layout = 1, aphro_wna16_strip_relayout): the 16-byte pieces a wave reads
+//     are stored in the order it reads them, so every load instruction is one lane-linear 1 KiB (or 256 REM bytes) piece
+//     and a workgroup's share of the matrix is one contiguous range.  The [K/8, N] exllama layout (strip_layout = 0) is
+//     read as 256-byte row pieces, exactly like the round-2 kernel.
+//   * K reduction over the waves through LDS as a [wave][row][column] tile; the output leaves as whole rows: 16 bytes per
+//     thread for the fp32 slabs / the 16-bit result, one 16-byte fragment piece per thread for the SiluAndMul + pack form.
+#include <utility>
+
+#include "common.h"
+
+namespace aphro {
+
+struct Wna16ResParams {
+  const uint16_t* apk;    // fragment-major f16 activations (pack_a_kernel / the fused producers)
+  const uint32_t* qw;     // [K/8, N] exllama order, or strip-major (strip_layout)
+  const uint32_t* qz;     // [G, N/8]
+  const uint16_t* sc;     // [G, N]
+  uint16_t* c;            // [M, N] when ksplit == 1 and neither of the two below
+  float* partial;         // [ksplit][M][N] fp32 slabs (ksplit > 1 or force_partial)
+  uint16_t* act_packed;   // SiluAndMul + pack epilogue (interleaved gate / up columns), ksplit == 1 only
+  int M, N, K;
+  int gshift;             // log2(group_size / 128)
+  int zero_offset;
+  int ksplit;             // grid.y
+  int force_partial;
+  int strip_layout;
+  int is_bf16;            // scales / output in bf16 (the activations were widened to f16 when packed)
+};
+
+template <int B, int E, typename F>
+__device__ __forceinline__ void res_static_for(F&& f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    res_static_for<B + 1, E>(f);
+  }
+}
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t res_rsrc(const void* base, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+
+struct ResMeta {          // RAW scale / zero words of one (pass, segment): untouched until the segment is consumed
+  uint32_t sc[3];
+  uint32_t z0, z1;
+};
+
+// Columns of a strip: CW = 64 NP4 + 16 REM.  Pass p < NP4: lane (g, c) owns columns 64 p + 4 c + t (t < 4); the last pass
+// (REM > 0): columns 64 NP4 + REM c + t (t < REM).  Wave w of K slice y owns segments [(y NWV + w) NSEG, + NSEG).
+template <int MT, int NWV, int NSEG, int NP4, int REM, int DEPTH, int ADEPTH, bool KEEP_RS>
+__global__ __launch_bounds__(NWV * 64, NWV <= 4 ? 1 : 2) void wna16_gemm_resident_kernel(Wna16ResParams p) {
+  constexpr int NPASS = NP4 + (REM > 0 ? 1 : 0);
+  constexpr int NST = NPASS * NSEG * 4;             // k-steps of a wave over all passes
+  constexpr int CW = 64 * NP4 + 16 * REM;
+  constexpr int CWP = CW + 4;                       // LDS row pitch (floats): 16-byte aligned rows, conflict-free reads
+  constexpr int ROWS = 16 * MT;
+  constexpr int RING = DEPTH + 1;
+  constexpr int AD = ADEPTH < NSEG ? ADEPTH : NSEG;
+  extern __shared__ __attribute__((aligned(16))) float red[];   // [NWV][ROWS][CWP]
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4;
+  const int c = lane & 15;
+  // workgroups are dealt round-robin to the 8 XCDs: give every XCD one contiguous run of strips (neighbouring strips
+  // share cache lines at their edges when a strip's row piece is not a multiple of 128 bytes)
+  const int S = gridDim.x;
+  const int strip = (S & 7) == 0 ? (int)(blockIdx.x & 7) * (S >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  const int ky = blockIdx.y;
+  const int seg0 = (ky * NWV + wave) * NSEG;
+  const int cb = strip * CW;
+  const int mtiles = (p.M + 15) >> 4;
+
+  const __amdgpu_buffer_rsrc_t rw = res_rsrc(p.qw, (uint32_t)((size_t)(p.K >> 3) * p.N * 4));
+  const __amdgpu_buffer_rsrc_t ra = res_rsrc(p.apk, (uint32_t)((size_t)(p.K >> 7) * 4 * mtiles * 1024));
+  const int ngroups = (p.K >> 7) >> p.gshift;
+  const __amdgpu_buffer_rsrc_t rs_ = res_rsrc(p.sc, (uint32_t)((size_t)ngroups * p.N * 2));
+  const __amdgpu_buffer_rsrc_t rz = res_rsrc(p.qz, (uint32_t)((size_t)ngroups * (p.N >> 3) * 4));
+
+  // weight addressing: voffset per lane (one for the 64-column passes, one for the last pass), SGPR offset
+  // sbase + pass offset + s * SS + u * SU
+  int voff_w4, voff_wr, sbase, ss4, su4, ssr, sur, poff4, poffr;
+  if (p.strip_layout) {
+    constexpr int WAVE_BYTES = NSEG * 4 * 64 * (16 * NP4 + 4 * REM);
+    sbase = ((ky * S + strip) * NWV + wave) * WAVE_BYTES;
+    voff_w4 = lane * 16; voff_wr = lane * 4 * REM;
+    ss4 = 4096; su4 = 1024; ssr = 1024 * REM; sur = 256 * REM;
+    poff4 = NSEG * 4096; poffr = NP4 * NSEG * 4096;
+  } else {
+    sbase = seg0 * 16 * p.N * 4;
+    voff_w4 = (4 * g * p.N + cb + 4 * c) * 4; voff_wr = (4 * g * p.N + cb + 64 * NP4 + REM * c) * 4;
+    ss4 = ssr = 16 * p.N * 4; su4 = sur = p.N * 4;
+    poff4 = 256; poffr = 0;
+  }
+  int voff_a[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) voff_a[i] = (min(i, mtiles - 1) * 64 + lane) * 16;
+  const int abytes = mtiles * 1024;
+  // metadata addressing
+  const int col4 = cb + 4 * c;                      // first column of the lane in pass 0 (pass p: + 64 p)
+  const int colr = cb + 64 * NP4 + REM * c;         // first column of the lane in the last pass
+  const int voff_s4 = col4 * 2, voff_z4 = (col4 >> 3) * 4, zshift4 = (col4 & 7) * 4;
+  const int voff_sr = colr * 2, voff_zr0 = (colr >> 3) * 4, voff_zr1 = ((colr + (REM > 0 ? REM - 1 : 0)) >> 3) * 4;
+  const int zshiftr = (colr & 7) * 4;
+  const float zoff = (float)p.zero_offset;
+  const f16x8 ones = {(f16)1.f, (f16)1.f, (f16)16.f, (f16)16.f, (f16)1.f, (f16)1.f, (f16)16.f, (f16)16.f};
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+  u32x4 af[NSEG][4][MT];
+  f32x4 rsk[KEEP_RS ? NSEG : 1][MT];
+  f32x4 cacc[MT][4], acc[MT][4], rs[MT];
+  u32x4 wr[RING];
+  ResMeta meta[2];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    rs[i] = zero4;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { cacc[i][t] = zero4; acc[i][t] = zero4; }
+  }
+
+  auto load_w = [&](auto I_) -> u32x4 {
+    constexpr int I = decltype(I_)::value;
+    constexpr int pass = I / (NSEG * 4), s = (I / 4) % NSEG, u = I % 4;
+    if constexpr (pass < NP4) {
+      return __builtin_amdgcn_raw_buffer_load_b128(rw, voff_w4, sbase + pass * poff4 + s * ss4 + u * su4, 2);
+    } else {
+      const int so = sbase + poffr + s * ssr + u * sur;
+      if constexpr (REM == 3) {
+        typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+        const u32x3 v = __builtin_amdgcn_raw_buffer_load_b96(rw, voff_wr, so, 2);
+        return u32x4{v[0], v[1], v[2], 0u};
+      } else if constexpr (REM == 2) {
+        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rw, voff_wr, so, 2);
+        return u32x4{v[0], v[1], 0u, 0u};
+      } else {
+        return u32x4{__builtin_amdgcn_raw_buffer_load_b32(rw, voff_wr, so, 2), 0u, 0u, 0u};
+      }
+    }
+  };
+  auto load_a = [&](auto S_) {
+    constexpr int s = decltype(S_)::value;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const int vo = voff_a[i];
+        af[s][u][i] = __builtin_amdgcn_raw_buffer_load_b128(ra, vo, ((seg0 + s) * 4 + u) * abytes, 0);
+      }
+  };
+  auto load_meta = [&](auto Q_) {   // Q = pass * NSEG + s
+    constexpr int Q = decltype(Q_)::value;
+    constexpr int pass = Q / NSEG, s = Q % NSEG;
+    ResMeta& m = meta[Q & 1];
+    const int grp = (seg0 + s) >> p.gshift;
+    const int so_s = grp * p.N * 2, so_z = grp * (p.N >> 3) * 4;
+    if constexpr (pass < NP4) {
+      const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs_, voff_s4, so_s + pass * 128, 0);
+      m.sc[0] = v[0]; m.sc[1] = v[1];
+      m.z0 = __builtin_amdgcn_raw_buffer_load_b32(rz, voff_z4, so_z + pass * 32, 0);
+    } else {
+      if constexpr (REM == 2) {
+        m.sc[0] = __builtin_amdgcn_raw_buffer_load_b32(rs_, voff_sr, so_s, 0);
+      } else {
+#pragma unroll
+        for (int t = 0; t < REM; ++t) m.sc[t] = (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rs_, voff_sr, so_s + 2 * t, 0);
+      }
+      m.z0 = __builtin_amdgcn_raw_buffer_load_b32(rz, voff_zr0, so_z, 0);
+      if constexpr (REM == 3) m.z1 = __builtin_amdgcn_raw_buffer_load_b32(rz, voff_zr1, so_z, 0);
+    }
+  };
+
+  // ---- prologue: metadata of the first group, the first AD segments of A, the first DEPTH weight steps --------------
+  load_meta(std::integral_constant<int, 0>{});
+  res_static_for<0, AD>([&](auto S_) { load_a(S_); });
+  res_static_for<0, (DEPTH < NST ? DEPTH : NST)>([&](auto I_) { wr[decltype(I_)::value % RING] = load_w(I_); });
+  __builtin_amdgcn_sched_barrier(0);
+
+  res_static_for<0, NST>([&](auto I_) {
+    constexpr int I = decltype(I_)::value;
+    constexpr int pass = I / (NSEG * 4), s = (I / 4) % NSEG, u = I % 4;
+    constexpr bool LAST = pass >= NP4;
+    constexpr int VEC = LAST ? REM : 4;
+    constexpr int Q = pass * NSEG + s;
+    // ---- issue: weights DEPTH steps ahead, A AD segments ahead (first pass only), metadata one segment ahead ---------
+    if constexpr (I + DEPTH < NST) wr[(I + DEPTH) % RING] = load_w(std::integral_constant<int, I + DEPTH>{});
+    if constexpr (pass == 0 && u == 0 && s + AD < NSEG) load_a(std::integral_constant<int, (s + AD < NSEG ? s + AD : 0)>{});
+    if constexpr (u == 0 && Q + 1 < NPASS * NSEG) load_meta(std::integral_constant<int, (Q + 1 < NPASS * NSEG ? Q + 1 : 0)>{});
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- A fragments: nibbles 2,3,6,7 of a word are taken in place (bits 4-7 of each half) and weigh 16x, so those k
+    // of the fragment carry 1/16 (once: the scaled fragment is what stays resident) ------------------------------------
+    f16x8 a[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      u32x4 av = af[s][u][i];
+      if constexpr (pass == 0) {
+        asm("v_pk_mul_f16 %0, %1, %2" : "=v"(av[1]) : "v"(av[1]), "s"(0x2c002c00u));
+        asm("v_pk_mul_f16 %0, %1, %2" : "=v"(av[3]) : "v"(av[3]), "s"(0x2c002c00u));
+        af[s][u][i] = av;
+      }
+      a[i] = __builtin_bit_cast(f16x8, av);
+      if constexpr (pass == 0 || !KEEP_RS)
+        rs[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], ones, u == 0 ? zero4 : rs[i], 0, 0, 0);
+    }
+    const u32x4 wq = wr[I % RING];
+#pragma unroll
+    for (int t = 0; t < VEC; ++t) {
+      const uint32_t wv = wq[t];
+      const uint32_t w8 = wv >> 8;
+      const u32x4 bq = {wv & 0x000f000fu, wv & 0x00f000f0u, w8 & 0x000f000fu, w8 & 0x00f000f0u};
+      const f16x8 b = __builtin_bit_cast(f16x8, bq);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+        acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b, u == 0 ? zero4 : acc[i][t], 0, 0, 0);
+    }
+    if constexpr (u == 3) {
+      if constexpr (KEEP_RS) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          if constexpr (pass == 0) rsk[s][i] = rs[i]; else rs[i] = rsk[s][i];
+        }
+      }
+      // ---- group epilogue (fp32): c += s * (2^24 * acc - z * rowsum) ---------------------------------------------------
+      const ResMeta& m = meta[Q & 1];
+      uint32_t zbits;
+      if constexpr (!LAST) zbits = m.z0 >> zshift4;
+      else if constexpr (REM == 3) zbits = __builtin_amdgcn_alignbit(m.z1, m.z0, zshiftr);
+      else zbits = m.z0 >> zshiftr;
+#pragma unroll
+      for (int t = 0; t < VEC; ++t) {
+        const float z = (float)((zbits >> (4 * t)) & 0xf) + zoff;
+        uint16_t sb;
+        if constexpr (!LAST) sb = (uint16_t)(m.sc[t >> 1] >> (16 * (t & 1)));
+        else if constexpr (REM == 2) sb = (uint16_t)(m.sc[0] >> (16 * t));
+        else sb = (uint16_t)m.sc[t];
+        const float sf = p.is_bf16 ? bf16_bits_to_f32(sb) : f16_bits_to_f32(sb);
+        const float s24 = sf * 16777216.f;
+        const float nzs = -z * sf;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          cacc[i][t] = __builtin_elementwise_fma(acc[i][t], f32x4{s24, s24, s24, s24}, cacc[i][t]);
+          cacc[i][t] = __builtin_elementwise_fma(rs[i], f32x4{nzs, nzs, nzs, nzs}, cacc[i][t]);
+        }
+      }
+      if constexpr (s == NSEG - 1) {
+        // ---- the pass is complete: this wave's partial sums go to its LDS tile, the accumulators start over ------------
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float* dst = &red[(wave * ROWS + 16 * i + 4 * g + r) * CWP + (LAST ? 64 * NP4 + REM * c : 64 * pass + 4 * c)];
+            if constexpr (!LAST) {
+              *reinterpret_cast<f32x4*>(dst) = f32x4{cacc[i][0][r], cacc[i][1][r], cacc[i][2][r], cacc[i][3][r]};
+            } else {
+#pragma unroll
+              for (int t = 0; t < REM; ++t) dst[t] = cacc[i][t][r];
+            }
+          }
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) cacc[i][t] = zero4;
+      }
+    }
+  });
+  __syncthreads();
+
+  // ---- K reduction over the waves (wave order: the summation order of wna16_gemm.hip) + store ---------------------------
+  const int tid = threadIdx.x;
+  if (p.act_packed != nullptr) {
+    // SiluAndMul + pack (columns 2j / 2j+1 = gate_j / up_j): a unit = 16 columns of one row = 8 output features = one
+    // 16-byte piece of the consumer's fragment-major buffer; consecutive threads take consecutive rows (256 B runs)
+    constexpr int UNITS = ROWS * (CW / 16);
+    for (int unit = tid; unit < UNITS; unit += NWV * 64) {
+      const int ch = unit / ROWS, row = unit % ROWS;
+      float v[16];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 sum = zero4;
+#pragma unroll
+        for (int w2 = 0; w2 < NWV; ++w2) sum += *reinterpret_cast<const f32x4*>(&red[(w2 * ROWS + row) * CWP + 16 * ch + 4 * q]);
+        v[4 * q] = sum[0]; v[4 * q + 1] = sum[1]; v[4 * q + 2] = sum[2]; v[4 * q + 3] = sum[3];
+      }
+      uint16_t o[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        if (p.is_bf16) {
+          o[q] = bf16_bits_to_f16_bits_sat(silu_mul_bits<BFloat>(BFloat::to_f32(BFloat::from_f32(v[2 * q])), BFloat::to_f32(BFloat::from_f32(v[2 * q + 1]))));
+        } else {
+          o[q] = silu_mul_bits<Half>(Half::to_f32(Half::from_f32(v[2 * q])), Half::to_f32(Half::from_f32(v[2 * q + 1])));
+        }
+      }
+      const int j0 = (cb + 16 * ch) >> 1;
+      uint16_t* dst = p.act_packed + ((((size_t)(j0 >> 7) * 4 + ((j0 & 31) >> 3)) * mtiles + (row >> 4)) * 64 + ((j0 & 127) >> 5) * 16 + (row & 15)) * 8;
+      if (row < p.M)
+        *reinterpret_cast<u32x4*>(dst) = u32x4{(uint32_t)o[0] | ((uint32_t)o[1] << 16), (uint32_t)o[2] | ((uint32_t)o[3] << 16),
+                                               (uint32_t)o[4] | ((uint32_t)o[5] << 16), (uint32_t)o[6] | ((uint32_t)o[7] << 16)};
+    }
+  } else if (p.ksplit > 1 || p.force_partial) {
+    constexpr int UNITS = ROWS * (CW / 4);          // 4 columns of one row: 16 bytes of fp32
+    for (int unit = tid; unit < UNITS; unit += NWV * 64) {
+      const int row = unit / (CW / 4), c4 = unit % (CW / 4);
+      f32x4 sum = zero4;
+#pragma unroll
+      for (int w2 = 0; w2 < NWV; ++w2) sum += *reinterpret_cast<const f32x4*>(&red[(w2 * ROWS + row) * CWP + 4 * c4]);
+      if (row < p.M) *reinterpret_cast<f32x4*>(p.partial + ((size_t)ky * p.M + row) * p.N + cb + 4 * c4) = sum;
+    }
+  } else {
+    constexpr int UNITS = ROWS * (CW / 8);          // 8 columns of one row: 16 bytes of f16 / bf16
+    for (int unit = tid; unit < UNITS; unit += NWV * 64) {
+      const int row = unit / (CW / 8), c8 = unit % (CW / 8);
+      f32x4 s0 = zero4, s1 = zero4;
+#pragma unroll
+      for (int w2 = 0; w2 < NWV; ++w2) {
+        s0 += *reinterpret_cast<const f32x4*>(&red[(w2 * ROWS + row) * CWP + 8 * c8]);
+        s1 += *reinterpret_cast<const f32x4*>(&red[(w2 * ROWS + row) * CWP + 8 * c8 + 4]);
+      }
+      uint16_t o[8];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        o[q] = p.is_bf16 ? BFloat::from_f32(s0[q]) : Half::from_f32(s0[q]);
+        o[4 + q] = p.is_bf16 ? BFloat::from_f32(s1[q]) : Half::from_f32(s1[q]);
+      }
+      if (row < p.M)
+        *reinterpret_cast<u32x4*>(p.c + (size_t)row * p.N + cb + 8 * c8) =
+            u32x4{(uint32_t)o[0] | ((uint32_t)o[1] << 16), (uint32_t)o[2] | ((uint32_t)o[3] << 16),
+                  (uint32_t)o[4] | ((uint32_t)o[5] << 16), (uint32_t)o[6] | ((uint32_t)o[7] << 16)};
+    }
+  }
+}
+
+// [K/8, N] exllama order -> strip-major: the 16-byte (last pass: 4 REM-byte) pieces in the order the waves read them.
+// One thread per destination dword.
+__global__ void wna16_strip_relayout_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, int N, int K,
+                                            int nwv, int nseg, int np4, int rem, int ksplit) {
+  const int64_t total = (int64_t)(K >> 3) * N;
+  const int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >= total) return;
+  const int cw = 64 * np4 + 16 * rem;
+  const int S = N / cw;
+  const int lane_dw = 4 * np4 + rem;                 // dwords per lane per (s, u) over all passes
+  const int64_t wave_dw = (int64_t)nseg * 4 * 64 * lane_dw;
+  int64_t r = d;
+  const int64_t widx = r / wave_dw; r -= widx * wave_dw;       // ((ky * S + strip) * nwv + wave)
+  const int wave = (int)(widx % nwv);
+  const int strip = (int)((widx / nwv) % S);
+  const int ky = (int)(widx / nwv / S);
+  int pass, s, u, lane, t;
+  const int64_t p4_dw = (int64_t)np4 * nseg * 4 * 256;
+  if (r < p4_dw) {
+    pass = (int)(r / (nseg * 1024)); r %= nseg * 1024;
+    s = (int)(r / 1024); r %= 1024;
+    u = (int)(r / 256); r %= 256;
+    lane = (int)(r / 4); t = (int)(r % 4);
+  } else {
+    r -= p4_dw;
+    pass = np4;
+    s = (int)(r / (256 * rem)); r %= 256 * rem;
+    u = (int)(r / (64 * rem)); r %= 64 * rem;
+    lane = (int)(r / rem); t = (int)(r % rem);
+  }
+  const int g = lane >> 4, c = lane & 15;
+  const int seg = (ky * nwv + wave) * nseg + s;
+  const int row = seg * 16 + 4 * g + u;
+  const int col = strip * cw + (pass < np4 ? 64 * pass + 4 * c + t : 64 * np4 + rem * c + t);
+  out[d] = in[(size_t)row * N + col];
+}
+
+}  // namespace aphro
+
+using namespace aphro;
+
+struct ResConfig { int nwv, nseg, np4, rem, ksplit; };
+
+// The configuration serving (M, N, K, group size), or nwv == 0.  One workgroup per CU with equal work where the shape
+// allows it: strips x K slices as close to the CU count as the divisibility permits.
+//   APHRO_WNA16_RES_CFG="nwv,nseg,np4,rem" picks an instantiated configuration by hand (lab / tests).
+static bool res_instantiated(int nwv, int nseg, int np4, int rem);
+static ResConfig res_plan(int64_t M, int64_t N, int64_t K, int64_t gs) {
+  ResConfig none = {0, 0, 0, 0, 0};
+  if (M < 1 || M > 32 || K % 128 != 0 || gs % 128 != 0 || N % 16 != 0) return none;
+  const int64_t gq = gs >> 7;
+  if ((gq & (gq - 1)) != 0 || (K / 8) * N * 4 >= (int64_t)0xffffffff) return none;
+  const int segs = (int)(K / 128);
+  auto fits = [&](int nwv, int nseg, int np4, int rem) -> int {   // K slices, or 0
+    const int cw = 64 * np4 + 16 * rem;
+    if (!res_instantiated(nwv, nseg, np4, rem) || N % cw != 0 || segs % (nwv * nseg) != 0) return 0;
+    return segs / (nwv * nseg);
+  };
+  if (const char* e = getenv("APHRO_WNA16_RES_CFG")) {
+    int a = 0, b = 0, c2 = 0, d = 0;
+    if (sscanf(e, "%d,%d,%d,%d", &a, &b, &c2, &d) == 4) {
+      const int ks = fits(a, b, c2, d);
+      if (ks > 0 && ks <= 16) return ResConfig{a, b, c2, d, ks};
+    }
+    return none;
+  }
+  // candidates in order of preference per shape class; the first that fits and fills >= 3/4 of the CUs wins
+  static const int cand[][4] = {{4, 8, 1, 3}, {4, 7, 1, 0}, {4, 8, 1, 0}, {4, 4, 1, 0}, {4, 2, 1, 0}, {4, 4, 0, 3}};
+  for (const auto& cd : cand) {
+    const int ks = fits(cd[0], cd[1], cd[2], cd[3]);
+    if (ks <= 0 || ks > 8) continue;
+    const int64_t wgs = N / (64 * cd[2] + 16 * cd[3]) * ks;
+    if (wgs >= 192 && wgs <= 256) return ResConfig{cd[0], cd[1], cd[2], cd[3], ks};
+  }
+  return none;
+}
+
+template <int MT, int NWV, int NSEG, int NP4, int REM, int DEPTH, int ADEPTH, bool KEEP_RS>
+static int res_launch(const Wna16ResParams& p, hipStream_t st) {
+  constexpr int CW = 64 * NP4 + 16 * REM;
+  const size_t lds = (size_t)NWV * 16 * MT * (CW + 4) * sizeof(float);
+  auto kern = wna16_gemm_resident_kernel<MT, NWV, NSEG, NP4, REM, DEPTH, ADEPTH, KEEP_RS>;
+  if (lds > 64 * 1024) {   // per device and cheap: set every time (a process-wide flag misses a second GPU)
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      set_error("wna16_gemm_resident: cannot raise the dynamic LDS limit to %zu", lds);
+      return APHRO_ERR_LAUNCH;
+    }
+  }
+  const dim3 grid((unsigned)(p.N / CW), (unsigned)p.ksplit);
+  hipLaunchKernelGGL(kern, grid, dim3(NWV * 64), lds, st, p);
+  APHRO_LAUNCH_CHECK();
+  return APHRO_OK;
+}
+
+// ---- the instantiated configurations ------------------------------------------------------------------------------------
+#ifndef RES_DEPTH
+#define RES_DEPTH 12
+#endif
+#ifndef RES_ADEPTH
+#define RES_ADEPTH 2
+#endif
+#define RES_CONFIGS(X) \
+  X(4, 8, 1, 3)        \
+  X(4, 7, 1, 0)        \
+  X(4, 8, 1, 0)        \
+  X(4, 4, 1, 0)        \
+  X(4, 2, 1, 0)        \
+  X(4, 4, 0, 3)        \
+  X(4, 2, 1, 2)        \
+  X(4, 1, 2, 0)        \
+  X(7, 2, 2, 0)
+
+static bool res_instantiated(int nwv, int nseg, int np4, int rem) {
+#define X(a, b, c, d) if (nwv == a && nseg == b && np4 == c && rem == d) return true;
+  RES_CONFIGS(X)
+#undef X
+  return false;
+}
+
+static int res_dispatch(const Wna16ResParams& p, const ResConfig& cf, hipStream_t st) {
+  const int mt = p.M > 16 ? 2 : 1;
+#define X(a, b, c, d)                                                                       \
+  if (cf.nwv == a && cf.nseg == b && cf.np4 == c && cf.rem == d) {                          \
+    constexpr bool KR = (c + (d > 0 ? 1 : 0)) > 1;                                          \
+    return mt == 2 ? res_launch<2, a, b, c, d, RES_DEPTH, RES_ADEPTH, KR>(p, st)            \
+                   : res_launch<1, a, b, c, d, RES_DEPTH, RES_ADEPTH, KR>(p, st);           \
+  }
+  RES_CONFIGS(X)
+#undef X
+  set_error("wna16_gemm_resident: configuration %d,%d,%d,%d is not instantiated", cf.nwv, cf.nseg, cf.np4, cf.rem);
+  return APHRO_ERR_INVALID;
+}
+
+// K slices the resident kernel produces for this shape (fp32 slabs when > 1), 0: shape not served.
+extern "C" int aphro_wna16_resident_ksplit(int64_t M, int64_t N, int64_t K, int64_t groups) {
+  if (groups <= 0 || K % groups != 0) return 0;
+  const ResConfig cf = res_plan(M, N, K, K / groups);
+  return cf.nwv ? cf.ksplit : 0;
+}
+
+// Decode GEMM on packed activations with the resident kernel.  Exactly one output: act_packed (gate_up form: interleaved
+// gate / up columns, SiluAndMul + pack epilogue, one K slice), slabs (fp32 [ksplit][M][N] for a fused consumer) or c
+// ([M, N] in `dtype`, one K slice).  strip_layout: q_weight was re-laid by aphro_wna16_strip_relayout for THIS shape.
+extern "C" int aphro_wna16_gemm_resident(const void* a_packed, const uint32_t* q_weight, const uint32_t* qzeros,
+                                         const void* scales, void* c, float* slabs, size_t slabs_bytes, void* act_packed,
+                                         int64_t M, int64_t N, int64_t K, int64_t groups, int zero_offset, int dtype,
+                                         int strip_layout, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  APHRO_CHECK(dtype == APHRO_F16 || dtype == APHRO_BF16, "wna16_gemm_resident: dtype must be f16 or bf16");
+  APHRO_CHECK(groups > 0 && K % groups == 0, "wna16_gemm_resident: bad groups");
+  const ResConfig cf = res_plan(M, N, K, K / groups);
+  APHRO_CHECK(cf.nwv != 0, "wna16_gemm_resident: shape M=%ld N=%ld K=%ld groups=%ld is not served", (long)M, (long)N, (long)K, (long)groups);
+  APHRO_CHECK(((uintptr_t)a_packed % 16) == 0 && ((uintptr_t)q_weight % 16) == 0, "wna16_gemm_resident: 16-byte alignment required");
+  Wna16ResParams p;
+  p.apk = (const uint16_t*)a_packed; p.qw = q_weight; p.qz = qzeros; p.sc = (const uint16_t*)scales;
+  p.c = (uint16_t*)c; p.partial = slabs; p.act_packed = (uint16_t*)act_packed;
+  p.M = (int)M; p.N = (int)N; p.K = (int)K; p.zero_offset = zero_offset; p.ksplit = cf.ksplit;
+  p.gshift = 0;
+  for (int64_t q = (K / groups) >> 7; q > 1; q >>= 1) ++p.gshift;
+  p.force_partial = 0; p.strip_layout = strip_layout ? 1 : 0; p.is_bf16 = dtype == APHRO_BF16;
+  if (act_packed != nullptr) {
+    APHRO_CHECK(cf.ksplit == 1 && N % 256 == 0, "wna16_gemm_resident: the SiluAndMul form needs one K slice and N/2 %% 128 == 0 (N=%ld)", (long)N);
+    p.c = nullptr; p.partial = nullptr;
+  } else if (slabs != nullptr) {
+    APHRO_CHECK(slabs_bytes >= (size_t)cf.ksplit * M * N * sizeof(float), "wna16_gemm_resident: slabs too small");
+    p.force_partial = 1; p.c = nullptr;
+  } else {
+    APHRO_CHECK(c != nullptr && cf.ksplit == 1, "wna16_gemm_resident: this shape needs the slab form (%d K slices)", cf.ksplit);
+  }
+  return res_dispatch(p, cf, st);
+}
+
+// Load-time relayout of a [K/8, N] exllama-ordered int4 matrix into the strip-major order of the configuration
+// res_plan picks for (M, N, K, groups).  out != in.
+extern "C" int aphro_wna16_strip_relayout(const uint32_t* q_weight, uint32_t* out, int64_t M, int64_t N, int64_t K,
+                                          int64_t groups, void* stream) {
+  APHRO_CHECK(groups > 0 && K % groups == 0 && q_weight != out, "wna16_strip_relayout: bad arguments");
+  const ResConfig cf = res_plan(M, N, K, K / groups);
+  APHRO_CHECK(cf.nwv != 0, "wna16_strip_relayout: shape M=%ld N=%ld K=%ld is not served by the resident kernel", (long)M, (long)N, (long)K);
+  const int64_t total = (K / 8) * N;
+  hipLaunchKernelGGL(wna16_strip_relayout_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     q_weight, out, (int)N, (int)K, cf.nwv, cf.nseg, cf.np4, cf.rem, cf.ksplit);
+  APHRO_LAUNCH_CHECK();
+  return APHRO_OK;
+}
