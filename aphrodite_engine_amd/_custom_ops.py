@@ -235,10 +235,12 @@ def context_attention_fwd(q, k, v, o, kv_cache_dtype: str, k_cache, v_cache, b_l
     if head_size == 128 and win == 0 and not os.environ.get("APHRO_CA_NO_GATHER"):
         # long prompts: gather the cached context once, then the third-generation prefill kernel over context + new
         # tokens.  The caller may pass the host-side maxima (the attention metadata has them); otherwise one sync.
-        if max_seq_len is None or total_kv_tokens is None:
-            msl, tot = int(b_seq_len.max().item()), int(b_seq_len.sum().item())
-        else:
+        if max_seq_len is not None and total_kv_tokens is not None:
             msl, tot = int(max_seq_len), int(total_kv_tokens)
+        elif int(max_input_len) + b_loc.shape[1] * v_cache.shape[3] < CONTEXT_ATTN_GATHER_MIN_LEN:
+            msl = tot = 0     # host-side bound (new tokens + block-table capacity): cannot reach the long path, no sync
+        else:
+            msl, tot = int(b_seq_len.max().item()), int(b_seq_len.sum().item())
         if msl >= CONTEXT_ATTN_GATHER_MIN_LEN:
             ws = _workspace(q.device, lib.aphro_context_attention_workspace_bytes(tot, batch, k.shape[1], head_size))
             check(lib.aphro_context_attention_gathered(
@@ -762,6 +764,50 @@ def wna16_gemm_mid_silu_pack(a_packed: torch.Tensor, m: int, k: int, qweight: to
                                           None, None, 0, out.data_ptr(), m, n, k, scales.shape[0], zero_offset,
                                           _dt(scales), _stream()), "wna16_gemm_mid_silu_pack")
     return out
+
+
+def wna16_resident_ksplit(m: int, n: int, k: int, groups: int) -> int:
+    """K slices of the resident-activation decode kernel (csrc/wna16_gemm_resident.hip) for this shape; 0: not served."""
+    return int(_lib.lib().aphro_wna16_resident_ksplit(m, n, k, groups))
+
+
+def wna16_strip_relayout(qweight: torch.Tensor, m: int, groups: int) -> torch.Tensor:
+    """Load-time: [K/8, N] exllama-ordered words -> the strip-major order the resident kernel streams (a permutation)."""
+    _require_cuda(qweight)
+    out = torch.empty_like(qweight)
+    check(_lib.lib().aphro_wna16_strip_relayout(qweight.data_ptr(), out.data_ptr(), m, qweight.shape[1],
+                                                qweight.shape[0] * 8, groups, _stream()), "wna16_strip_relayout")
+    return out
+
+
+def wna16_gemm_resident(a_packed: torch.Tensor, m: int, k: int, qweight: torch.Tensor, qzeros: torch.Tensor,
+                        scales: torch.Tensor, zero_offset: int, mode: str = "out", strip_layout: bool = False):
+    """Decode GEMM (M <= 32) on packed activations with the resident kernel.  mode "out": [M, N] tensor (one K slice
+    only); "slabs": (fp32 [S, M, N], S) for a fused consumer; "silu": SiluAndMul + pack epilogue over interleaved
+    gate / up columns -> fragment-major f16 [M, N/2]."""
+    lib = _lib.lib()
+    n = scales.shape[1]
+    groups = scales.shape[0]
+    ks = lib.aphro_wna16_resident_ksplit(m, n, k, groups)
+    if ks <= 0:
+        raise RuntimeError(f"wna16_gemm_resident: shape M={m} N={n} K={k} not served")
+    dev = qweight.device
+    c = slabs = act = None
+    if mode == "silu":
+        act = torch.empty(lib.aphro_wna16_packed_a_bytes(m, n // 2) // 2, dtype=torch.float16, device=dev)
+    elif mode == "slabs":
+        slabs = torch.empty((ks, m, n), dtype=torch.float32, device=dev)
+    else:
+        c = torch.empty((m, n), dtype=scales.dtype, device=dev)
+    check(lib.aphro_wna16_gemm_resident(a_packed.data_ptr(), qweight.data_ptr(), qzeros.data_ptr(), scales.data_ptr(),
+                                        _ptr(c), _ptr(slabs), slabs.numel() * 4 if slabs is not None else 0, _ptr(act),
+                                        m, n, k, groups, zero_offset, _dt(scales), 1 if strip_layout else 0, _stream()),
+          "wna16_gemm_resident")
+    if mode == "silu":
+        return act
+    if mode == "slabs":
+        return slabs, ks
+    return c
 
 
 def fused_add_rms_norm_pack(x: Optional[torch.Tensor], slabs: Optional[torch.Tensor],

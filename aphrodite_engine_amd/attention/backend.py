@@ -193,7 +193,9 @@ class MI355XAttentionImpl:
                     prefill_meta.block_tables, prefill_meta.query_start_loc,
                     prefill_meta.seq_lens_tensor, prefill_meta.context_lens_tensor,
                     prefill_meta.max_query_len, self.alibi_slopes, self.sliding_window,
-                    k_scale, v_scale)
+                    k_scale, v_scale,
+                    # host-side maxima of the prefill sequences (seq_lens is a Python list): no .item() per layer
+                    max_seq_len=max(prefill_meta.seq_lens), total_kv_tokens=sum(prefill_meta.seq_lens))
             else:
                 out = ops.flash_attn_varlen(
                     query, key, value, prefill_meta.seq_start_loc,

@@ -79,13 +79,16 @@ class PagedAttention:
     def forward_prefix(query, key, value, kv_cache_dtype: str, key_cache, value_cache,
                        block_tables, query_start_loc, seq_lens_tensor, context_lens,
                        max_query_len: int, alibi_slopes, sliding_window, k_scale: float,
-                       v_scale: float) -> torch.Tensor:
-        """ops/paged_attn.py:192-231."""
+                       v_scale: float, max_seq_len: Optional[int] = None,
+                       total_kv_tokens: Optional[int] = None) -> torch.Tensor:
+        """ops/paged_attn.py:192-231.  ``max_seq_len`` / ``total_kv_tokens``: host-side max / sum of the prefill
+        sequences' lengths (the metadata holds them as a Python list): with them the long-prompt path of
+        context_attention_fwd needs no device-to-host sync."""
         output = torch.empty_like(query)
         ops.context_attention_fwd(query, key, value, output, kv_cache_dtype, key_cache,
                                   value_cache, block_tables, query_start_loc, seq_lens_tensor,
                                   context_lens, max_query_len, k_scale, v_scale, alibi_slopes,
-                                  sliding_window)
+                                  sliding_window, max_seq_len=max_seq_len, total_kv_tokens=total_kv_tokens)
         return output
 
     @staticmethod

@@ -41,6 +41,25 @@ void set_error(const char* fmt, ...);
     }                                                                 \
   } while (0)
 
+// Host-side per-device state (function attributes, CU counts) is indexed by the current HIP device: a process that
+// drives a second GPU must not inherit the first one's "already set" flag.
+constexpr int APHRO_MAX_DEVICES = 64;
+inline int device_slot() {
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= APHRO_MAX_DEVICES) d = 0;
+  return d;
+}
+inline int device_cu_count() {
+  static int n[APHRO_MAX_DEVICES] = {};
+  const int d = device_slot();
+  if (n[d] == 0) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || v <= 0) v = 256;
+    n[d] = v;
+  }
+  return n[d];
+}
+
 // ---- scalar conversions -----------------------------------------------------
 __device__ __forceinline__ float bf16_bits_to_f32(uint16_t b) {
   return __builtin_bit_cast(float, (uint32_t)b << 16);
@@ -62,9 +81,12 @@ __device__ __forceinline__ uint16_t f32_to_f16_bits(float f) {
 // we accept bf16 activations by widening them).  SATURATING: a bf16 activation beyond the f16 range (|x| > 65504)
 // becomes +-65504 instead of inf -- an inf would turn into NaN in the MFMA and poison the whole output row, a clamped
 // outlier costs accuracy on that one element only.  (Values below 2^-24 flush to zero: f16 subnormal range.)
+// NaN stays NaN (fminf / fmaxf return the non-NaN operand: without the test an upstream NaN would silently become a finite
+// -65504 and the fault would surface as garbage logits instead of NaN -- ADVICE r2).
 __device__ __forceinline__ uint16_t bf16_bits_to_f16_bits_sat(uint16_t b) {
   const float f = bf16_bits_to_f32(b);
-  return f32_to_f16_bits(__builtin_fminf(__builtin_fmaxf(f, -65504.f), 65504.f));
+  const uint16_t h = f32_to_f16_bits(__builtin_fminf(__builtin_fmaxf(f, -65504.f), 65504.f));
+  return (f != f) ? (uint16_t)0x7e00 : h;
 }
 
 // Storage-type traits: T is a tag for the 16-bit (or 32-bit) activation dtype.

@@ -1208,7 +1208,7 @@ extern "C" int aphro_context_attention_gathered(void* out, const void* q, const 
   p.nqt_max = (max_query_len + 255) / 256;
   p.xcd_remap = (batch * num_kv_heads) % 8 == 0 && !getenv("APHRO_FA_NO_XCD");
   dim3 grid3((unsigned)(p.nqt_max * num_heads * batch));
-  static bool attr_set = false;
+  static bool attr_set_dev[APHRO_MAX_DEVICES] = {}; bool& attr_set = attr_set_dev[device_slot()];
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)flash_attn_varlen_v3_kernel<Half>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840) != hipSuccess ||
         hipFuncSetAttribute((const void*)flash_attn_varlen_v3_kernel<BFloat>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840) != hipSuccess) {
@@ -1246,7 +1246,7 @@ extern "C" int aphro_flash_attn_varlen(void* out, const void* q, const void* k, 
     const int groups = batch * num_kv_heads;
     p.xcd_remap = groups % 8 == 0 && !getenv("APHRO_FA_NO_XCD");
     dim3 grid3((unsigned)(p.nqt_max * num_heads * batch));
-    static bool attr_set = false;
+    static bool attr_set_dev[APHRO_MAX_DEVICES] = {}; bool& attr_set = attr_set_dev[device_slot()];
     if (!attr_set) {
       if (hipFuncSetAttribute((const void*)flash_attn_varlen_v3_kernel<Half>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840) != hipSuccess ||
           hipFuncSetAttribute((const void*)flash_attn_varlen_v3_kernel<BFloat>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840) != hipSuccess) {

@@ -360,7 +360,7 @@ template <int WM, int WN, int STAGES, bool BF16OUT>
 static int launch_fp8_large_t(const Fp8LargeParams& p, int grid_x, hipStream_t st) {
   constexpr size_t lds = (size_t)STAGES * (128 * WM + 64 * WN) * 128;
   static_assert(lds <= 160 * 1024 && lds >= (size_t)WM * WN * 16384, "stage buffers must fit and cover the epilogue regions");
-  static bool attr_set = false;
+  static bool attr_set_dev[APHRO_MAX_DEVICES] = {}; bool& attr_set = attr_set_dev[device_slot()];
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)fp8_gemm_large_kernel<WM, WN, STAGES, BF16OUT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024) != hipSuccess) {
@@ -385,14 +385,7 @@ using namespace aphro;
 
 struct Fp8LargePlan { int wm, wn, tiles_m, tiles_n, streamk, grid, ksplit; };
 
-static int cu_count() {
-  static int n = 0;
-  if (n == 0) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-  }
-  return n;
-}
+static int cu_count() { return device_cu_count(); }
 
 // Stream-K (one persistent workgroup per CU) when the biggest tile the shape allows still gives >= 128 tiles: then
 // every workgroup gets at least half a tile's K loop and a tile is cut between at most 3 workgroups.  Below that: one

@@ -437,7 +437,7 @@ static int launch_large_s(const Wna16LargeParams& p, hipStream_t st) {
     set_error("wna16_gemm_large: %zu bytes of LDS needed (K=%d, group %d)", lds, p.K, p.group_size);
     return APHRO_ERR_INVALID;
   }
-  static bool attr_set = false;
+  static bool attr_set_dev[APHRO_MAX_DEVICES] = {}; bool& attr_set = attr_set_dev[device_slot()];
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)wna16_gemm_large_kernel<WM, WN, STAGES, WFP8>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024) != hipSuccess) {
@@ -468,14 +468,7 @@ using namespace aphro;
 
 struct LargePlan { int wm, wn, ksplit, streamk, grid; };
 
-static int large_cu_count() {
-  static int n = 0;
-  if (n == 0) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-  }
-  return n;
-}
+static int large_cu_count() { return device_cu_count(); }
 
 constexpr size_t LARGE_FLAG_BYTES = 4096;
 

@@ -419,7 +419,7 @@ static size_t mid_lds_bytes(int mb, int nwk) {   // round 1 of the butterfly, or
 template <int MB, int NWK, bool ADEC = false>
 static int mid_launch(const Wna16MidParams& p, dim3 grid, hipStream_t st) {
   const size_t lds = mid_lds_bytes(MB, NWK);
-  static bool attr_set = false;                  // up to 128 KiB of dynamic LDS: above the default 64 KiB limit
+  static bool attr_set_dev[APHRO_MAX_DEVICES] = {}; bool& attr_set = attr_set_dev[device_slot()];                  // up to 128 KiB of dynamic LDS: above the default 64 KiB limit
   if (!attr_set && lds > 64 * 1024) {
     if (hipFuncSetAttribute((const void*)wna16_gemm_mid_kernel<MB, NWK, ADEC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
       set_error("wna16_gemm_mid: cannot raise the dynamic LDS limit");

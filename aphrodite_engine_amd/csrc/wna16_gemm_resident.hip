@@ -46,7 +46,10 @@ struct Wna16ResParams {
   int force_partial;
   int strip_layout;
   int is_bf16;            // scales / output in bf16 (the activations were widened to f16 when packed)
+  unsigned long long* trace;   // TRACE instantiations (RES_LAB builds, tools/resident_trace.py): per-wave timeline stamps
 };
+
+#define RES_STAMP(i) do { if constexpr (TRACE) stamp[i] = __builtin_readcyclecounter(); } while (0)
 
 template <int B, int E, typename F>
 __device__ __forceinline__ void res_static_for(F&& f) {
@@ -67,7 +70,7 @@ struct ResMeta {          // RAW scale / zero words of one (pass, segment): unto
 
 // Columns of a strip: CW = 64 NP4 + 16 REM.  Pass p < NP4: lane (g, c) owns columns 64 p + 4 c + t (t < 4); the last pass
 // (REM > 0): columns 64 NP4 + REM c + t (t < REM).  Wave w of K slice y owns segments [(y NWV + w) NSEG, + NSEG).
-template <int MT, int NWV, int NSEG, int NP4, int REM, int DEPTH, int ADEPTH, bool KEEP_RS>
+template <int MT, int NWV, int NSEG, int NP4, int REM, int DEPTH, int ADEPTH, bool KEEP_RS, bool TRACE = false>
 __global__ __launch_bounds__(NWV * 64, NWV <= 4 ? 1 : 2) void wna16_gemm_resident_kernel(Wna16ResParams p) {
   constexpr int NPASS = NP4 + (REM > 0 ? 1 : 0);
   constexpr int NST = NPASS * NSEG * 4;             // k-steps of a wave over all passes
@@ -81,6 +84,10 @@ __global__ __launch_bounds__(NWV * 64, NWV <= 4 ? 1 : 2) void wna16_gemm_residen
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4;
   const int c = lane & 15;
+  unsigned long long stamp[TRACE ? 16 : 1] = {};
+  unsigned long long wall0 = 0;
+  if constexpr (TRACE) wall0 = __builtin_amdgcn_s_memrealtime();
+  RES_STAMP(0);
   // workgroups are dealt round-robin to the 8 XCDs: give every XCD one contiguous run of strips (neighbouring strips
   // share cache lines at their edges when a strip's row piece is not a multiple of 128 bytes)
   const int S = gridDim.x;
@@ -193,6 +200,7 @@ __global__ __launch_bounds__(NWV * 64, NWV <= 4 ? 1 : 2) void wna16_gemm_residen
   res_static_for<0, AD>([&](auto S_) { load_a(S_); });
   res_static_for<0, (DEPTH < NST ? DEPTH : NST)>([&](auto I_) { wr[decltype(I_)::value % RING] = load_w(I_); });
   __builtin_amdgcn_sched_barrier(0);
+  RES_STAMP(1);
 
   res_static_for<0, NST>([&](auto I_) {
     constexpr int I = decltype(I_)::value;
@@ -230,6 +238,13 @@ __global__ __launch_bounds__(NWV * 64, NWV <= 4 ? 1 : 2) void wna16_gemm_residen
 #pragma unroll
       for (int i = 0; i < MT; ++i)
         acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b, u == 0 ? zero4 : acc[i][t], 0, 0, 0);
+    }
+    if constexpr (TRACE) {
+      // 2: first k-step issued; 3 .. 10: MFMAs of the last k-step of segment s of the first pass issued (s < 8);
+      // 11: same for the last segment of the last pass
+      if constexpr (I == 0) { __builtin_amdgcn_sched_barrier(0); RES_STAMP(2); }
+      if constexpr (pass == 0 && u == 3 && s < 8) { __builtin_amdgcn_sched_barrier(0); RES_STAMP(3 + s); }
+      if constexpr (I == NST - 1 && NPASS > 1) { __builtin_amdgcn_sched_barrier(0); RES_STAMP(11); }
     }
     if constexpr (u == 3) {
       if constexpr (KEEP_RS) {
@@ -281,7 +296,9 @@ __global__ __launch_bounds__(NWV * 64, NWV <= 4 ? 1 : 2) void wna16_gemm_residen
       }
     }
   });
+  RES_STAMP(12);
   __syncthreads();
+  RES_STAMP(13);
 
   // ---- K reduction over the waves (wave order: the summation order of wna16_gemm.hip) + store ---------------------------
   const int tid = threadIdx.x;
@@ -343,6 +360,19 @@ __global__ __launch_bounds__(NWV * 64, NWV <= 4 ? 1 : 2) void wna16_gemm_residen
         *reinterpret_cast<u32x4*>(p.c + (size_t)row * p.N + cb + 8 * c8) =
             u32x4{(uint32_t)o[0] | ((uint32_t)o[1] << 16), (uint32_t)o[2] | ((uint32_t)o[3] << 16),
                   (uint32_t)o[4] | ((uint32_t)o[5] << 16), (uint32_t)o[6] | ((uint32_t)o[7] << 16)};
+    }
+  }
+  if constexpr (TRACE) {
+    RES_STAMP(14);
+    if (p.trace && lane == 0) {
+      // [workgroup][wave][20]: 16 cycle stamps, wall clock (100 MHz) at entry / exit, HW_ID, XCC_ID
+      unsigned long long* t = p.trace + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * NWV + wave) * 20;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) t[i] = stamp[i];
+      t[16] = wall0;
+      t[17] = __builtin_amdgcn_s_memrealtime();
+      t[18] = __builtin_amdgcn_s_getreg(((32 - 1) << 11) | 4);     // HW_REG_HW_ID
+      t[19] = __builtin_amdgcn_s_getreg(((32 - 1) << 11) | 20);    // HW_REG_XCC_ID
     }
   }
 }
@@ -424,11 +454,11 @@ static ResConfig res_plan(int64_t M, int64_t N, int64_t K, int64_t gs) {
   return none;
 }
 
-template <int MT, int NWV, int NSEG, int NP4, int REM, int DEPTH, int ADEPTH, bool KEEP_RS>
+template <int MT, int NWV, int NSEG, int NP4, int REM, int DEPTH, int ADEPTH, bool KEEP_RS, bool TRACE = false>
 static int res_launch(const Wna16ResParams& p, hipStream_t st) {
   constexpr int CW = 64 * NP4 + 16 * REM;
   const size_t lds = (size_t)NWV * 16 * MT * (CW + 4) * sizeof(float);
-  auto kern = wna16_gemm_resident_kernel<MT, NWV, NSEG, NP4, REM, DEPTH, ADEPTH, KEEP_RS>;
+  auto kern = wna16_gemm_resident_kernel<MT, NWV, NSEG, NP4, REM, DEPTH, ADEPTH, KEEP_RS, TRACE>;
   if (lds > 64 * 1024) {   // per device and cheap: set every time (a process-wide flag misses a second GPU)
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
       set_error("wna16_gemm_resident: cannot raise the dynamic LDS limit to %zu", lds);
@@ -443,7 +473,7 @@ static int res_launch(const Wna16ResParams& p, hipStream_t st) {
 
 // ---- the instantiated configurations ------------------------------------------------------------------------------------
 #ifndef RES_DEPTH
-#define RES_DEPTH 12
+#define RES_DEPTH 8
 #endif
 #ifndef RES_ADEPTH
 #define RES_ADEPTH 2
@@ -468,6 +498,23 @@ static bool res_instantiated(int nwv, int nseg, int np4, int rem) {
 
 static int res_dispatch(const Wna16ResParams& p, const ResConfig& cf, hipStream_t st) {
   const int mt = p.M > 16 ? 2 : 1;
+#ifdef RES_LAB   // prefetch-depth sweep / per-wave timeline of the two big shapes (tools/resident_bench.py, resident_trace.py):
+                 // APHRO_WNA16_RES_DEPTH="depth,adepth"; with a trace buffer set the TRACE instantiation runs
+  if (const char* e = getenv("APHRO_WNA16_RES_DEPTH")) {
+    int d = 0, ad = 0;
+    if (sscanf(e, "%d,%d", &d, &ad) == 2 && mt == 2) {
+#define L(D, AD)                                                                                                   \
+      if (d == D && ad == AD) {                                                                                    \
+        if (cf.nwv == 4 && cf.nseg == 8 && cf.np4 == 1 && cf.rem == 3)                                             \
+          return p.trace ? res_launch<2, 4, 8, 1, 3, D, AD, true, true>(p, st) : res_launch<2, 4, 8, 1, 3, D, AD, true>(p, st);  \
+        if (cf.nwv == 4 && cf.nseg == 7 && cf.np4 == 1 && cf.rem == 0)                                             \
+          return p.trace ? res_launch<2, 4, 7, 1, 0, D, AD, false, true>(p, st) : res_launch<2, 4, 7, 1, 0, D, AD, false>(p, st); \
+      }
+      L(4, 1) L(8, 2) L(12, 2)
+#undef L
+    }
+  }
+#endif
 #define X(a, b, c, d)                                                                       \
   if (cf.nwv == a && cf.nseg == b && cf.np4 == c && cf.rem == d) {                          \
     constexpr bool KR = (c + (d > 0 ? 1 : 0)) > 1;                                          \
@@ -479,6 +526,10 @@ static int res_dispatch(const Wna16ResParams& p, const ResConfig& cf, hipStream_
   set_error("wna16_gemm_resident: configuration %d,%d,%d,%d is not instantiated", cf.nwv, cf.nseg, cf.np4, cf.rem);
   return APHRO_ERR_INVALID;
 }
+
+static unsigned long long* g_res_trace = nullptr;
+// RES_LAB builds: device buffer of [workgroups][waves][20] u64 the next launches stamp their timeline into (NULL: off).
+extern "C" void aphro_wna16_resident_set_trace(void* buf) { g_res_trace = (unsigned long long*)buf; }
 
 // K slices the resident kernel produces for this shape (fp32 slabs when > 1), 0: shape not served.
 extern "C" int aphro_wna16_resident_ksplit(int64_t M, int64_t N, int64_t K, int64_t groups) {
@@ -507,6 +558,7 @@ extern "C" int aphro_wna16_gemm_resident(const void* a_packed, const uint32_t* q
   p.gshift = 0;
   for (int64_t q = (K / groups) >> 7; q > 1; q >>= 1) ++p.gshift;
   p.force_partial = 0; p.strip_layout = strip_layout ? 1 : 0; p.is_bf16 = dtype == APHRO_BF16;
+  p.trace = g_res_trace;
   if (act_packed != nullptr) {
     APHRO_CHECK(cf.ksplit == 1 && N % 256 == 0, "wna16_gemm_resident: the SiluAndMul form needs one K slice and N/2 %% 128 == 0 (N=%ld)", (long)N);
     p.c = nullptr; p.partial = nullptr;

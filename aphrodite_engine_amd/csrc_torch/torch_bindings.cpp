@@ -45,6 +45,7 @@ torch::Tensor gptq_gemm(torch::Tensor a, torch::Tensor b_q_weight, torch::Tensor
   auto out = torch::empty({m, n}, a.options());
   const bool act_order = b_g_idx.numel() > 0 && b_g_idx.device().is_cuda();
   const int64_t groups = b_gptq_scales.size(0);
+  TORCH_CHECK(groups > 0 && k % groups == 0, "gptq_gemm: scales [groups, N] with groups dividing K (groups=", groups, ", K=", k, ")");
   if (m > 64 && n % 128 == 0 && k % 64 == 0 && k % groups == 0 && (k / groups) % 64 == 0) {
     // prefill-sized M: one MFMA kernel that dequantises in registers (the reference reconstructs + calls hipBLAS,
     // q_gemm.cu:1529-1544); act-order = gather the activation columns once
@@ -111,6 +112,18 @@ void cutlass_scaled_mm(torch::Tensor out, torch::Tensor a, torch::Tensor b, torc
   const int64_t m = a.size(0), k = a.size(1), n = b.size(1);
   TORCH_CHECK(a_scales.numel() == 1 || a_scales.numel() == m, "a_scales: 1 or M elements");
   TORCH_CHECK(b_scales.numel() == 1 || b_scales.numel() == n, "b_scales: 1 or N elements");
+  if (bias) TORCH_CHECK(bias->scalar_type() == out.scalar_type() && bias->numel() == n && bias->is_contiguous(),
+                        "cutlass_scaled_mm: bias must be a contiguous [N] tensor of the output dtype");
+  // The kernels index rows as base + row * K / N.  The reference admits row-strided a / out (stride(0) % 16 == 0,
+  // scaled_mm_entry.cu:104-110): serve those through a contiguous copy instead of reading the wrong rows.
+  if (a.stride(0) != k) a = a.contiguous();
+  TORCH_CHECK(b.stride(1) == k || n == 1, "cutlass_scaled_mm: b must be a dense column-major [K, N] matrix");
+  if (out.stride(0) != n) {
+    auto tmp = torch::empty({m, n}, out.options());
+    cutlass_scaled_mm(tmp, a, b, a_scales, b_scales, bias);
+    out.copy_(tmp);
+    return;
+  }
   const int odt = act_dtype(out);
   const void* bp = bias ? bias->data_ptr() : nullptr;
   const int a_tok = a_scales.numel() > 1, b_ch = b_scales.numel() > 1;

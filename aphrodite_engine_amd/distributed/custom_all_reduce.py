@@ -90,7 +90,11 @@ class CustomAllreduce:
         except OSError:
             boot = ""
         visible = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("CUDA_VISIBLE_DEVICES")
-        ids = [int(v) for v in visible.split(",")] if visible else None
+        try:
+            ids = [int(v) for v in visible.split(",")] if visible else None
+        except ValueError:
+            # UUID-style entries ("GPU-..."): physical ordinals unknown, peers cannot be matched -> RCCL
+            return False, f"device mask {visible!r} is not a list of ordinals"
         phys = ids[device.index] if ids is not None and device.index < len(ids) else device.index
         mine = (socket.gethostname(), boot, int(phys), int(device.index))
         everyone: List[Optional[tuple]] = [None] * self.world_size

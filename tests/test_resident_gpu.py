@@ -1,0 +1,139 @@
+"""The resident-activation decode GEMM (csrc/wna16_gemm_resident.hip, round 3) at the BASELINE configs[1] shapes
+against the ORACLE (oracle.quant, pinned by the reference's own CUDA kernels run on a host shim --
+tests/test_oracle_golden.py::test_gptq_*reference*), in every output form the decode step launches, both weight layouts,
+f16 and bf16, M = 1 .. 32; plus bit-equality with the round-2 kernel where the K partition is the same (that kernel is
+itself oracle-checked in tests/test_headline_gpu.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import attention as oa
+from oracle import quant as oq
+from tests.test_headline_gpu import SHAPES, case, t, unpack_a
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a visible MI355X (torch.cuda.is_available() is False)")
+    from aphrodite_engine_amd import _custom_ops, _lib
+    _lib.lib()
+    return _custom_ops
+
+
+@pytest.fixture(autouse=True)
+def _no_cfg_env():
+    os.environ.pop("APHRO_WNA16_RES_CFG", None)
+    yield
+    os.environ.pop("APHRO_WNA16_RES_CFG", None)
+
+
+@pytest.mark.parametrize("M", [1, 8, 16, 17, 32])
+@pytest.mark.parametrize("K,N", SHAPES)
+def test_resident_slabs_and_out_vs_oracle(ops, K, N, M):
+    shuf, qzeros, scales, a, ref = case(K, N)
+    ref = ref[:M]
+    G = K // 128
+    ks = ops.wna16_resident_ksplit(M, N, K, G)
+    assert ks >= 1, "every configs[1] projection is served by the resident kernel"
+    pk = ops.wna16_pack_a(t(a[:M]))
+    slabs, ks2 = ops.wna16_gemm_resident(pk, M, K, t(shuf), t(qzeros), t(scales), 1, mode="slabs")
+    assert ks2 == ks and slabs.shape == (ks, M, N)
+    s = slabs.double().sum(0).cpu().numpy()
+    np.testing.assert_allclose(s, ref, rtol=1e-4, atol=2e-5 * np.abs(ref).max())     # fp32 accumulate vs fp64 oracle
+    # deterministic (no atomics)
+    slabs_b, _ = ops.wna16_gemm_resident(pk, M, K, t(shuf), t(qzeros), t(scales), 1, mode="slabs")
+    assert torch.equal(slabs, slabs_b)
+    if ks == 1:
+        y = ops.wna16_gemm_resident(pk, M, K, t(shuf), t(qzeros), t(scales), 1, mode="out")
+        np.testing.assert_allclose(y.float().cpu().numpy(), ref, rtol=2e-3, atol=2e-3 * np.abs(ref).max())
+        assert torch.equal(y, slabs[0].to(torch.float16))
+    # same K slices as the round-2 kernel: the slabs agree to fp32 rounding (bit for bit when the plan also splits K over
+    # the waves the same way -- 4 waves x the same segments)
+    if ops.wna16_ksplit(M, N, K, G) == ks:
+        old, _ = ops.wna16_gemm_packed(pk, M, K, t(shuf), t(qzeros), t(scales), 1, partials=True)
+        torch.testing.assert_close(slabs, old, rtol=2e-5, atol=2e-6 * float(np.abs(ref).max()))
+
+
+@pytest.mark.parametrize("M", [1, 16, 32])
+@pytest.mark.parametrize("K,N", SHAPES)
+def test_resident_strip_layout_is_bit_identical(ops, K, N, M):
+    shuf, qzeros, scales, a, _ = case(K, N)
+    pk = ops.wna16_pack_a(t(a[:M]))
+    qw = t(shuf)
+    strip = ops.wna16_strip_relayout(qw, M, K // 128)
+    assert strip.shape == qw.shape and not torch.equal(strip, qw)
+    assert torch.equal(torch.sort(strip.flatten())[0], torch.sort(qw.flatten())[0])      # a permutation of the words
+    s0, _ = ops.wna16_gemm_resident(pk, M, K, qw, t(qzeros), t(scales), 1, mode="slabs")
+    s1, _ = ops.wna16_gemm_resident(pk, M, K, strip, t(qzeros), t(scales), 1, mode="slabs", strip_layout=True)
+    assert torch.equal(s0, s1)
+
+
+@pytest.mark.parametrize("strip", [False, True])
+@pytest.mark.parametrize("M", [1, 17, 32])
+def test_resident_gate_up_silu_epilogue_vs_oracle(ops, M, strip):
+    """gate_up with interleaved (gate_j, up_j) columns + SiluAndMul + pack in the epilogue, against
+    silu_and_mul(round16(oracle GEMM)) (activation_kernels.cu:12-60 on the fp16-rounded projection)."""
+    K, N = 4096, 28672
+    shuf, qzeros, scales, a, ref = case(K, N)
+    qw_i, qz_i, sc_i = ops.interleave_gate_up(t(shuf), t(qzeros), t(scales))
+    pk = ops.wna16_pack_a(t(a[:M]))
+    qw_k = ops.wna16_strip_relayout(qw_i, M, K // 128) if strip else qw_i
+    act = ops.wna16_gemm_resident(pk, M, K, qw_k, qz_i, sc_i, 1, mode="silu", strip_layout=strip)
+    got = unpack_a(act, M, N // 2).view(np.float16).astype(np.float64)
+    gu = ref[:M].astype(np.float16)
+    d = N // 2
+    gate = gu[:, :d].astype(np.float64)
+    silu = (gate / (1.0 + np.exp(-gate))).astype(np.float16).astype(np.float64)
+    want = (silu * gu[:, d:].astype(np.float64)).astype(np.float16).astype(np.float64)
+    np.testing.assert_allclose(got, want, rtol=4e-3, atol=4e-3 * np.abs(want).max())
+    np.testing.assert_allclose(got, oa.silu_and_mul(ref[:M]), rtol=6e-3, atol=6e-3 * np.abs(want).max())
+    # same partition as the round-2 kernel's fused form -> same bits
+    # the round-2 kernel's fused form: same roundings, fp32 sums in a different order -> f16 results one ulp apart at most
+    old = ops.wna16_gemm_silu_pack(pk, M, K, qw_i, qz_i, sc_i, 1)
+    a_new = unpack_a(act, M, N // 2).view(np.float16).astype(np.float64)     # (rows >= M of a tile are not written)
+    a_old = unpack_a(old, M, N // 2).view(np.float16).astype(np.float64)
+    np.testing.assert_allclose(a_new, a_old, rtol=2e-3, atol=2e-3 * np.abs(want).max())
+
+
+@pytest.mark.parametrize("cfg,K,N", [("4,2,1,2", 4096, 6144), ("4,1,2,0", 4096, 4096), ("7,2,2,0", 14336, 4096),
+                                     ("4,4,0,3", 4096, 6144), ("4,8,1,0", 4096, 4096), ("4,2,1,0", 4096, 4096)])
+def test_resident_alternative_configs_vs_oracle(ops, cfg, K, N):
+    """The other instantiated (waves, segments per wave, 64-column passes, last-pass blocks) plans, picked by hand."""
+    shuf, qzeros, scales, a, ref = case(K, N)
+    os.environ["APHRO_WNA16_RES_CFG"] = cfg
+    for M in (5, 32):
+        ks = ops.wna16_resident_ksplit(M, N, K, K // 128)
+        assert ks >= 1
+        pk = ops.wna16_pack_a(t(a[:M]))
+        for strip in (False, True):
+            qw = ops.wna16_strip_relayout(t(shuf), M, K // 128) if strip else t(shuf)
+            slabs, _ = ops.wna16_gemm_resident(pk, M, K, qw, t(qzeros), t(scales), 1, mode="slabs", strip_layout=strip)
+            s = slabs.double().sum(0).cpu().numpy()
+            np.testing.assert_allclose(s, ref[:M], rtol=1e-4, atol=2e-5 * np.abs(ref).max())
+
+
+@pytest.mark.parametrize("K,N", [(4096, 28672), (14336, 4096)])
+def test_resident_bf16_vs_oracle(ops, K, N):
+    """bf16 activations / scales / output: activations widened to f16 (saturating) when packed, scales read as bf16."""
+    rng = np.random.default_rng(5)
+    shuf, qzeros, _, _, _ = case(K, N)
+    G = K // 128
+    M = 32
+    sc = torch.from_numpy((rng.uniform(0.75, 1.25, size=(G, N)) / (4.6 * np.sqrt(K))).astype(np.float32)).to(DEV).to(torch.bfloat16)
+    a = torch.from_numpy(rng.standard_normal((M, K)).astype(np.float32)).to(DEV).to(torch.bfloat16)
+    a16 = a.float().cpu().numpy().astype(np.float16)          # what the packed buffer holds (|a| << 65504: exact widening? no: rounded)
+    ref = oq.gptq_gemm(a.float().cpu().numpy(), shuf, qzeros, sc.float().cpu().numpy(), None, True)
+    pk = ops.wna16_pack_a(a)
+    slabs, ks = ops.wna16_gemm_resident(pk, M, K, t(shuf), t(qzeros), sc, 1, mode="slabs")
+    s = slabs.double().sum(0).cpu().numpy()
+    # bf16 -> f16 widening of the activations is exact for |a| in the f16 normal range (8 mantissa bits fit 11)
+    np.testing.assert_allclose(s, ref, rtol=1e-4, atol=3e-5 * np.abs(ref).max())
+    old, _ = ops.wna16_gemm_packed(pk, M, K, t(shuf), t(qzeros), sc, 1, partials=True)
+    if old.shape == slabs.shape:
+        torch.testing.assert_close(slabs, old, rtol=2e-5, atol=2e-6 * float(np.abs(ref).max()))

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Round-3 lab: (A) the decode GEMMs / attention with their operands WARM in the 256 MiB Infinity Cache vs cold
-(cycling over > 600 MB), (B) the whole configs[1] decode step (HIP graph) with weight-prefetch plans on a side stream
-(model.WeightPrefetcher).  Prints one JSON line per measurement; everything lands in gpurun_out/prefetch_lab.jsonl."""
+(cycling over > 600 MB), (B) the whole configs[1] decode step (HIP graph) with weight-prefetch plans on a side stream.
+Part B needs model.WeightPrefetcher, which exists at commit 4299031 only (measured: every plan made the step SLOWER, 3.10 ->
+4.27 .. 4.99 ms, profiles/r3_prefetch_lab.txt; the hooks were removed from the product model again) -- `--parts A` runs here.
+Prints one JSON line per measurement; everything lands in gpurun_out/prefetch_lab.jsonl."""
 import argparse
 import json
 import os
@@ -68,9 +70,13 @@ def part_a(M=32):
                 else:
                     ops.wna16_gemm_packed(packed, M, K, qw, qz, sc, 1, partials=True)
         nb = wbytes + G * N * 2 + G * N // 2 + M * K * 2
+        # the SAME number of launches per graph in every state (a graph replay has a fixed cost of a few us: comparing a
+        # 1-launch graph with an 11-launch graph charges it to the wrong side -- the first version of this lab did)
+        L = max(24, ncold)
         for tag, wl in (("cold", ws), ("mall_warm", ws[:nwarm]), ("one_copy", ws[:1])):
-            t = timeit(lambda: run(wl), len(wl))
-            emit(part="A", kernel=name, M=M, state=tag, copies=len(wl), us=round(t * 1e6, 2),
+            seq = [wl[i % len(wl)] for i in range(L)]
+            t = timeit(lambda: run(seq), L)
+            emit(part="A", kernel=name, M=M, state=tag, copies=len(wl), launches_per_graph=L, us=round(t * 1e6, 2),
                  TBps=round(nb / t / 1e12, 3))
         del ws
         torch.cuda.empty_cache()
@@ -92,8 +98,9 @@ def part_a(M=32):
             ops.paged_attention_packed(q, kc, vc, Hkv, D ** -0.5, bt, sl, BS, ctx, None, "auto", 1.0, 1.0)
     nbytes = 2 * bs * ctx * Hkv * D * 2
     for tag, cl in (("cold", caches), ("one_copy", caches[:1])):
-        t = timeit(lambda: run_attn(cl), len(cl))
-        emit(part="A", kernel="paged_attention_packed", state=tag, copies=len(cl), us=round(t * 1e6, 2),
+        seq = [cl[i % len(cl)] for i in range(12)]
+        t = timeit(lambda: run_attn(seq), 12)
+        emit(part="A", kernel="paged_attention_packed", state=tag, copies=len(cl), launches_per_graph=12, us=round(t * 1e6, 2),
              TBps=round(nbytes / t / 1e12, 3))
 
 
@@ -144,7 +151,7 @@ def part_b(plans, steps=40, blocks=(512, )):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--parts", default="AB")
+    ap.add_argument("--parts", default="A")
     ap.add_argument("--plans", default="")
     args = ap.parse_args()
     if "A" in args.parts:
