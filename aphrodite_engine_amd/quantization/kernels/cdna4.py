@@ -32,11 +32,24 @@ class CDNA4LinearKernel(MPLinearKernel):
     def get_min_capability(cls) -> int:
         return 95  # gfx950
 
+    @staticmethod
+    def _type_key(t):
+        """(bits, bias, signed, integer) of a ScalarType -- ours (scalar_type.py) or the reference's (the C++ class of
+        aphrodite._core_ext / its Python mock, _core_ext.py:28-171: no common base class, so compare by value; through the
+        plugin the reference's own MPLinearLayerConfig arrives here with ITS scalar_types.uint4b8)."""
+        try:
+            is_int = bool(t.is_integer()) if hasattr(t, "is_integer") else True
+            signed = bool(t.is_signed()) if hasattr(t, "is_signed") else bool(getattr(t, "signed", False))
+            return int(t.size_bits), int(getattr(t, "bias", 0) or 0), signed, is_int
+        except Exception:
+            return None
+
     @classmethod
     def can_implement(cls, c: MPLinearLayerConfig) -> Tuple[bool, Optional[str]]:
-        if c.weight_type not in cls.SUPPORTED_TYPES:
+        wt = cls._type_key(c.weight_type)
+        if wt not in tuple(cls._type_key(x) for x in cls.SUPPORTED_TYPES):
             return False, f"Quant type ({c.weight_type}) not supported by CDNA4 kernel"
-        if c.zero_points != (c.weight_type == scalar_types.uint4):
+        if c.zero_points != (wt == cls._type_key(scalar_types.uint4)):
             return False, "zero points must accompany uint4 (and only uint4)"
         k, n = c.partition_weight_shape
         gs = c.group_size if c.group_size != -1 else c.full_weight_shape[0]

@@ -200,3 +200,18 @@ def register(ns_c: str = "_C", ns_cache: str = "_C_cache_ops", ns_rocm: str = "_
         lib.impl(schema.split("(", 1)[0], fn, key)
     _LIBS.append(lib)
     _REGISTERED = True
+
+
+def schema_arity(ns_c: str = "_C", ns_cache: str = "_C_cache_ops", ns_rocm: str = "_rocm_C", ns_moe: str = "_moe_C") -> dict:
+    """{(namespace, op): number of schema arguments} of everything ``register`` defines -- what a caller that passes its
+    arguments positionally (the reference's ``aphrodite/_custom_ops.py`` wrappers) must match
+    (tests/test_reference_binding_cpu.py)."""
+    out = {}
+    for ns, table in ((ns_c, _C_OPS), (ns_cache, _CACHE_OPS), (ns_rocm, _ROCM_OPS), (ns_moe, _MOE_OPS)):
+        for schema, _ in table:
+            out[(ns, schema.split("(", 1)[0])] = len(torch._C.parse_schema(ns + "::" + schema).arguments)
+    for schema in GPTQ_MARLIN_GEMM_SCHEMAS[1:2]:
+        out[(ns_c, "gptq_marlin_gemm")] = len(torch._C.parse_schema(ns_c + "::" + schema).arguments)
+    for schema, _, _ in CUSTOM_AR_SCHEMAS:
+        out[(ns_c + "_custom_ar", schema.split("(", 1)[0])] = len(torch._C.parse_schema(ns_c + "_custom_ar::" + schema).arguments)
+    return out

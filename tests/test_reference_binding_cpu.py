@@ -1,0 +1,251 @@
+"""The REFERENCE-side half of ``plugin.register()`` executed against the reference's own modules (VERDICT r2 missing #2 /
+next-round 5): ``aphrodite/quantization/__init__.py`` (QUANTIZATION_METHODS, get_quantization_config),
+``aphrodite/quantization/kernels/__init__.py`` (_POSSIBLE_KERNELS, choose_mp_linear_kernel), ``MPLinearKernel.py`` and
+``scalar_type.py`` + ``_core_ext.py`` (its own ScalarType), and ``distributed/device_communicators/custom_all_reduce.py`` are
+loaded BY PATH from /root/reference under stub parent packages (the package as a whole is not importable here: loguru,
+msgspec ... are missing -- the technique of tests/golden/make_golden.py); every sibling module they import is replaced by a
+stub that defines only the imported names.  Then the plugin entry point runs, twice.
+
+Also: the reference's ``_custom_ops.py`` wrappers of the SURVEY 8a ops are parsed (ast) and every ``torch.ops.<ns>.<op>(...)``
+call they make is checked against the schemas ``torch_ops.register`` defines (op exists, positional arity matches); the
+call list is committed as tests/golden/ref_custom_ops_calls.json so the GPU box (no /root/reference there) checks the same
+list against the registered ops (tests/test_schema_gpu.py).
+
+Needs /root/reference (this container); skipped where it is absent."""
+import ast
+import importlib.util
+import json
+import os
+import sys
+import types
+
+import pytest
+import torch
+
+REF = os.environ.get("APHRODITE_REFERENCE", "/root/reference")
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_custom_ops_calls.json")
+HOT_OPS = ["paged_attention_v1", "paged_attention_v2", "paged_attention_rocm", "reshape_and_cache", "reshape_and_cache_flash",
+           "copy_blocks", "swap_blocks", "convert_fp8", "gptq_gemm", "gptq_shuffle", "awq_gemm", "awq_dequantize",
+           "scaled_fp8_quant", "cutlass_scaled_mm", "cutlass_scaled_mm_supports_fp8", "fp8_marlin_gemm", "gptq_marlin_gemm",
+           "gptq_marlin_repack", "rms_norm", "fused_add_rms_norm", "silu_and_mul", "rotary_embedding",
+           "advance_step_flashattn", "topk_softmax", "moe_align_block_size"]
+
+needs_ref = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "aphrodite")), reason="reference checkout not present")
+
+
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    m.__path__ = []
+    sys.modules[name] = m
+    return m
+
+
+def _load(name, relpath):
+    pkg = relpath.endswith("__init__.py")
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REF, relpath),
+                                                  submodule_search_locations=[] if pkg else None)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _stub_imports_of(relpath, keep=()):
+    """A stub module for every ``from aphrodite.x.y import A, B`` of the file (unless already loaded / in keep), defining
+    A and B as empty classes."""
+    tree = ast.parse(open(os.path.join(REF, relpath)).read())
+    for node in tree.body:
+        if isinstance(node, ast.ImportFrom) and node.module and node.module.startswith("aphrodite") \
+                and node.module not in keep and node.module not in sys.modules:
+            _stub(node.module, **{a.name: type(a.name, (), {}) for a in node.names})
+
+
+@pytest.fixture()
+def reference_modules():
+    saved = {k: v for k, v in sys.modules.items() if k == "aphrodite" or k.startswith("aphrodite.") or k == "loguru"}
+    for k in list(saved):
+        del sys.modules[k]
+
+    class _Log:
+        def __getattr__(self, _):
+            return lambda *a, **k: None
+    _stub("loguru", logger=_Log())
+    _stub("aphrodite")
+    _stub("aphrodite.common")
+    _stub("aphrodite.common.envs", APHRODITE_PLUGINS=None)
+    _stub("aphrodite.common.utils", cuda_device_count_stateless=lambda: 0, is_hip=lambda: True)
+
+    class _Platform:           # gfx950 reports (9, 5)
+        @staticmethod
+        def get_device_capability(device_id=0):
+            return (9, 5)
+        is_rocm = staticmethod(lambda: True)
+        is_tpu = staticmethod(lambda: False)
+        is_cuda_alike = staticmethod(lambda: True)
+    _stub("aphrodite.platforms", current_platform=_Platform())
+    # The reference's ScalarType is the C++ class of aphrodite._core_C (kernels/core/scalar_type.hpp:12-260, bound in
+    # kernels/core/torch_bindings.cpp); its Python fallback in _core_ext.py is a typing mock (min / max / __str__ raise,
+    # is_signed() returns None).  A stand-in with the C++ class's fields and methods takes its place -- NOT our own
+    # aphrodite_engine_amd.scalar_type class, so that the kernel's by-value type check is what gets exercised -- and the
+    # reference's real aphrodite/scalar_type.py builds ``scalar_types`` out of it.
+    import enum
+
+    class NanRepr(enum.Enum):
+        NONE, IEEE_754, EXTD_RANGE_MAX_MIN = 0, 1, 2
+
+    class RefScalarType:
+        def __init__(self, exponent, mantissa, bias, signed, finite_values_only=False, nan_repr=1):
+            self.exponent, self.mantissa, self.bias, self.signed = exponent, mantissa, bias, signed
+            self._finite_values_only, self.nan_repr = finite_values_only, nan_repr
+        size_bits = property(lambda self: self.exponent + self.mantissa + int(self.signed))     # scalar_type.hpp:88-90
+        is_signed = lambda self: self.signed
+        is_integer = lambda self: self.exponent == 0
+        is_floating_point = lambda self: self.exponent > 0
+        has_bias = lambda self: self.bias != 0
+        int_ = classmethod(lambda cls, size_bits, bias: cls(0, size_bits - 1, bias or 0, True))   # :32-36
+        uint = classmethod(lambda cls, size_bits, bias: cls(0, size_bits, bias or 0, False))      # :38-41
+        float_IEEE754 = classmethod(lambda cls, e, m: cls(e, m, 0, True))
+        float_ = classmethod(lambda cls, e, m, finite_values_only, nan_repr: cls(e, m, 0, True, finite_values_only, nan_repr))
+
+        def __str__(self):                                                                        # :171-208
+            if self.is_integer():
+                return ("int" if self.signed else "uint") + str(self.size_bits) + (f"b{self.bias}" if self.bias else "")
+            return f"float{self.size_bits}_e{self.exponent}m{self.mantissa}"
+        __repr__ = __str__
+    core = _stub("aphrodite._core_ext", ScalarType=RefScalarType, NanRepr=NanRepr)
+    st = _load("aphrodite.scalar_type", "aphrodite/scalar_type.py")
+    # quantization package: the real __init__ over stub method modules
+    _stub_imports_of("aphrodite/quantization/__init__.py")
+    ref_q = _load("aphrodite.quantization", "aphrodite/quantization/__init__.py")
+    _stub("aphrodite.quantization.utils", replace_parameter=lambda *a, **k: None)
+    _load("aphrodite.quantization.kernels.MPLinearKernel", "aphrodite/quantization/kernels/MPLinearKernel.py")
+    mpk = sys.modules["aphrodite.quantization.kernels.MPLinearKernel"]
+
+    def _other(name):          # Machete / Marlin stand-ins: present in the list, unable to implement anything here
+        return type(name, (mpk.MPLinearKernel, ), {
+            "get_min_capability": classmethod(lambda cls: 80),
+            "can_implement": classmethod(lambda cls, c: (False, "stub")),
+            "process_weights_after_loading": lambda self, layer: None,
+            "apply_weights": lambda self, layer, x, bias=None: None})
+    _stub("aphrodite.quantization.kernels.machete", MacheteLinearKernel=_other("MacheteLinearKernel"))
+    _stub("aphrodite.quantization.kernels.marlin", MarlinLinearKernel=_other("MarlinLinearKernel"))
+    ref_k = _load("aphrodite.quantization.kernels", "aphrodite/quantization/kernels/__init__.py")
+    # custom all-reduce: the real class file over stubs of what it imports
+
+    class _NoOps:
+        def __getattr__(self, name):
+            raise AttributeError(name)         # `ops.meta_size()` fails -> custom_ar = False, as on the reference's ROCm build
+    sys.modules["aphrodite"]._custom_ops = _NoOps()
+    sys.modules["aphrodite._custom_ops"] = sys.modules["aphrodite"]._custom_ops
+    _stub("aphrodite.distributed")
+    _stub("aphrodite.distributed.device_communicators")
+    _stub("aphrodite.distributed.device_communicators.custom_all_reduce_utils", gpu_p2p_access_check=lambda a, b: True)
+    _stub("aphrodite.distributed.parallel_state", in_the_same_node_as=lambda pg, source_rank=0: [True])
+    ref_ca = _load("aphrodite.distributed.device_communicators.custom_all_reduce",
+                   "aphrodite/distributed/device_communicators/custom_all_reduce.py")
+    try:
+        yield types.SimpleNamespace(q=ref_q, k=ref_k, ca=ref_ca, scalar_types=st.scalar_types, mpk=mpk, core=core)
+    finally:
+        for k in [k for k in sys.modules if k == "aphrodite" or k.startswith("aphrodite.") or k == "loguru"]:
+            del sys.modules[k]
+        sys.modules.update(saved)
+
+
+@needs_ref
+def test_plugin_register_against_the_reference_modules(reference_modules):
+    ref = reference_modules
+    from aphrodite_engine_amd import plugin
+    from aphrodite_engine_amd import quantization as ours_q
+    from aphrodite_engine_amd.distributed.custom_all_reduce import CustomAllreduce
+    from aphrodite_engine_amd.quantization.kernels import CDNA4LinearKernel
+    before = dict(ref.q.QUANTIZATION_METHODS)
+    assert ref.ca.custom_ar is False                    # the ROCm build's state: the reference class disables itself
+    assert not issubclass(before["gptq"], ours_q.QUANTIZATION_METHODS["gptq"])
+    plugin.register()
+    plugin.register()                                   # every worker process loads plugins again: idempotent
+    # (1) quantization methods: ours under the reference's names, the reference's own lookup function returns them, the
+    # methods we do not implement are untouched, the iteration order of the dict (config.py walks it) is unchanged
+    for name, cls in ours_q.QUANTIZATION_METHODS.items():
+        assert ref.q.QUANTIZATION_METHODS[name] is cls
+        assert ref.q.get_quantization_config(name) is cls
+    assert list(ref.q.QUANTIZATION_METHODS)[:len(before)] == list(before)
+    for name in ("aqlm", "gguf", "bitsandbytes", "marlin"):
+        assert ref.q.QUANTIZATION_METHODS[name] is before[name]
+    with pytest.raises(ValueError):
+        ref.q.get_quantization_config("no-such-method")
+    # (2) mixed-precision kernels: first in the reference's list, exactly once; the reference's own chooser picks it for a
+    # GPTQ uint4b8 g128 layer described with the REFERENCE's MPLinearLayerConfig and ScalarType, at capability 95 and at
+    # the platform's (stubbed: (9, 5)) capability
+    assert ref.k._POSSIBLE_KERNELS[0] is CDNA4LinearKernel and ref.k._POSSIBLE_KERNELS.count(CDNA4LinearKernel) == 1
+    assert len(ref.k._POSSIBLE_KERNELS) == 3
+    cfg = ref.mpk.MPLinearLayerConfig(full_weight_shape=(4096, 28672), partition_weight_shape=(4096, 28672),
+                                      weight_type=ref.scalar_types.uint4b8, act_type=torch.float16, group_size=128,
+                                      zero_points=False, has_g_idx=False)
+    assert ref.k.choose_mp_linear_kernel(cfg, 95) is CDNA4LinearKernel
+    assert ref.k.choose_mp_linear_kernel(cfg) is CDNA4LinearKernel
+    awq_cfg = ref.mpk.MPLinearLayerConfig(full_weight_shape=(8192, 7168), partition_weight_shape=(8192, 7168),
+                                          weight_type=ref.scalar_types.uint4, act_type=torch.bfloat16, group_size=128,
+                                          zero_points=True, has_g_idx=False)
+    assert ref.k.choose_mp_linear_kernel(awq_cfg, 95) is CDNA4LinearKernel
+    # what we do not serve falls through to the reference's kernels (stubs here: "cannot implement") with its own error
+    cfg8 = ref.mpk.MPLinearLayerConfig(full_weight_shape=(4096, 4096), partition_weight_shape=(4096, 4096),
+                                       weight_type=ref.scalar_types.uint8b128, act_type=torch.float16, group_size=128,
+                                       zero_points=False, has_g_idx=False)
+    with pytest.raises(ValueError, match="CDNA4LinearKernel cannot implement"):
+        ref.k.choose_mp_linear_kernel(cfg8, 95)
+    with pytest.raises(ValueError, match="requires capability 95"):
+        ref.k.choose_mp_linear_kernel(cfg, 90)          # an MI300 (9, 4) keeps the reference's kernels
+    os.environ["APHRODITE_DISABLED_KERNELS"] = "CDNA4LinearKernel"
+    try:
+        with pytest.raises(ValueError, match="disabled by environment variable"):
+            ref.k.choose_mp_linear_kernel(cfg, 95)
+    finally:
+        del os.environ["APHRODITE_DISABLED_KERNELS"]
+    # (3) the all-reduce class symbol GroupCoordinator instantiates (parallel_state.py:186-196)
+    assert ref.ca.CustomAllreduce is CustomAllreduce
+
+
+def _wrapper_calls():
+    """{wrapper name: [[namespace, op, n_positional_args], ...]} for the hot-path wrappers of the reference's _custom_ops.py."""
+    src = open(os.path.join(REF, "aphrodite/_custom_ops.py")).read()
+    tree = ast.parse(src)
+    out = {}
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and node.name in HOT_OPS:
+            calls = []
+            for sub in ast.walk(node):
+                if isinstance(sub, ast.Call) and isinstance(sub.func, ast.Attribute) and isinstance(sub.func.value, ast.Attribute) \
+                        and isinstance(sub.func.value.value, ast.Attribute) and isinstance(sub.func.value.value.value, ast.Name) \
+                        and sub.func.value.value.value.id == "torch" and sub.func.value.value.attr == "ops":
+                    assert not sub.keywords, f"{node.name}: keyword arguments in a torch.ops call"
+                    calls.append([sub.func.value.attr, sub.func.attr, len(sub.args)])
+            out[node.name] = calls
+    return out
+
+
+@needs_ref
+def test_reference_custom_ops_wrappers_bind_to_our_schemas():
+    """Every torch.ops call the reference's own wrappers make for the SURVEY 8a ops lands on a registered op whose schema
+    takes exactly that many arguments; the call list is what tests/golden/ref_custom_ops_calls.json holds."""
+    from aphrodite_engine_amd import torch_ops
+    calls = _wrapper_calls()
+    assert set(calls) >= {"paged_attention_v1", "paged_attention_rocm", "reshape_and_cache", "gptq_gemm", "gptq_shuffle",
+                          "awq_gemm", "scaled_fp8_quant", "cutlass_scaled_mm"}
+    committed = json.load(open(GOLDEN))
+    assert committed == calls, "tests/golden/ref_custom_ops_calls.json is stale: regenerate with `python tests/test_reference_binding_cpu.py`"
+    schemas = torch_ops.schema_arity()
+    missing = []
+    for wrapper, cl in calls.items():
+        for ns, op, nargs in cl:
+            key = (ns, op)
+            if key not in schemas:
+                missing.append(f"{wrapper}: torch.ops.{ns}.{op} is not registered")
+            elif schemas[key] != nargs:
+                missing.append(f"{wrapper}: torch.ops.{ns}.{op} takes {schemas[key]} arguments, the wrapper passes {nargs}")
+    assert not missing, "\n".join(missing)
+
+
+if __name__ == "__main__":   # regenerate the committed call list (build container only)
+    json.dump(_wrapper_calls(), open(GOLDEN, "w"), indent=1, sort_keys=True)
+    print("wrote", GOLDEN)

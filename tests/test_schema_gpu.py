@@ -275,3 +275,21 @@ def test_cpp_registered_ops_match_the_python_registration(T):
     T.C.paged_attention_v1(want, *common)
     captured(lambda: C.paged_attention_v1(got, *common))
     assert torch.equal(got, want)
+
+
+def test_reference_wrapper_call_list_resolves_on_the_device_box(T):
+    """tests/golden/ref_custom_ops_calls.json = every ``torch.ops.<ns>.<op>(...)`` call the reference's own
+    ``aphrodite/_custom_ops.py`` wrappers make for the hot-path ops, with the number of positional arguments they pass
+    (generated here from /root/reference by tests/test_reference_binding_cpu.py, which also checks it is current).  On
+    the GPU box the reference is absent: check the committed list against the ops actually registered -- the op exists
+    in the mirrored namespace and its schema takes exactly that many arguments."""
+    import json
+    import os
+    calls = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_custom_ops_calls.json")))
+    ns_map = {"_C": "_aphro_g_C", "_C_cache_ops": "_aphro_g_cache", "_rocm_C": "_aphro_g_rocm", "_moe_C": "_aphro_g_moe"}
+    assert len(calls) >= 20
+    for wrapper, cl in calls.items():
+        for ns, op, nargs in cl:
+            packet = getattr(getattr(torch.ops, ns_map[ns]), op)        # AttributeError = the reference's hint_on_error case
+            schema = packet.default._schema
+            assert len(schema.arguments) == nargs, (wrapper, op, str(schema))
