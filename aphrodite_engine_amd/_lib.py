@@ -74,6 +74,7 @@ SIGNATURES = {
     "aphro_copy_blocks": (I, [P, P, I, P, L, L, P]),
     "aphro_swap_blocks": (I, [P, P, P, L, L, I, P]),
     "aphro_prefetch": (I, [P, Z, P]),
+    "aphro_spin_us": (I, [ctypes.c_double, P]),
     "aphro_wna16_gemm_large_workspace_bytes": (Z, [L, L, L, L, I]),
     "aphro_wna16_gemm_large": (I, [P, P, P, P, P, P, Z, L, L, L, L, L, I, I, P]),
     "aphro_wna16_gemm_mid_supported": (I, [L, L, L, L]),

@@ -84,6 +84,7 @@ struct Wna16Params {
   uint16_t* act_packed;   // != NULL (ksplit == 1 only): columns are (gate_j, up_j) pairs; the epilogue
                           // writes silu(gate) * up as fragment-major f16 [M, N/2] for the next GEMM
   // ---- grouped (mixture-of-experts) form: every 16-row m-tile uses the weights of ONE expert ----
+  int xcd_remap;          // fast kernel, ksplit in {2, 4, 8}: K slice y runs on 8 / ksplit XCDs (see the kernel)
   const int32_t* expert_ids;     // [M / 16] expert of each m-tile (moe_align_block_size), < 0: skip; NULL: dense
   const int32_t* num_post_pad;   // device scalar: rows >= *num_post_pad are not computed
   int64_t w_estride, z_estride, s_estride;  // per-expert strides of qw / qz (words) and sc (elements)
@@ -92,7 +93,7 @@ struct Wna16Params {
 // ---- in-workgroup split-K reduction through LDS + store ---------------------
 template <typename T, int VEC, int MT, int NWV>
 __device__ __forceinline__ void wna16_epilogue(const Wna16Params& p, float* red, f32x4 (&acc)[MT][VEC],
-                                               int lane, int wave, int g, int m0, int ncol) {
+                                               int lane, int wave, int g, int m0, int ncol, int ky) {
   // ---- in-workgroup split-K reduction through LDS -------------------------
   // red[wave][q = i*VEC + t][lane] as float4 (lane-contiguous: conflict-free)
 #pragma unroll
@@ -146,7 +147,7 @@ __device__ __forceinline__ void wna16_epilogue(const Wna16Params& p, float* red,
           for (int t = 0; t < VEC; ++t) cp[t] = T::from_f32(v[t]);
         }
       } else {
-        float* pp = p.partial + ((size_t)blockIdx.y * p.M + row) * p.N + ncol;
+        float* pp = p.partial + ((size_t)ky * p.M + row) * p.N + ncol;
         if constexpr (VEC == 4) {
           *reinterpret_cast<f32x4*>(pp) = f32x4{v[0], v[1], v[2], v[3]};
         } else {
@@ -234,10 +235,21 @@ __global__ __launch_bounds__(FNW * 64, (VEC * MT >= 8) ? 2 : 3) void wna16_gemm_
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4;
   const int c = lane & 15;
-  const int n0 = blockIdx.x * (16 * VEC);
+  // K slices across workgroups: all column tiles of slice y read the SAME activation rows.  Workgroups are dealt
+  // round-robin to the 8 XCDs (each with its own L2), so with the plain (x, y) order every XCD fetches every slice of the
+  // activations: 8 x M x K x 2 bytes through the fabric (PMC: 38.8 MB read for the 31.4 MB down projection, profiles/
+  // r3_pmc_traffic.txt).  xcd_remap gives slice y to 8 / ksplit XCDs only.
+  int bx = blockIdx.x, by = blockIdx.y;
+  if (p.xcd_remap) {
+    const int L = blockIdx.y * gridDim.x + blockIdx.x, xcd = L & 7, idx = L >> 3;
+    const int per = 8 / gridDim.y;                  // XCDs per K slice (host: 8 % ksplit == 0, grid.x % per == 0)
+    by = xcd / per;
+    bx = (xcd % per) * (gridDim.x / per) + idx;
+  }
+  const int n0 = bx * (16 * VEC);
   const int m0 = blockIdx.z * (16 * MT);
   const int ncol = n0 + VEC * c;
-  const int seg0 = (blockIdx.y * FNW + wave) * NSEG;  // host guarantees K == ksplit*FNW*NSEG*128
+  const int seg0 = (by * FNW + wave) * NSEG;  // host guarantees K == ksplit*FNW*NSEG*128
 
   // All global reads are buffer loads: the per-lane part of every address is a loop-invariant
   // VGPR offset, the (segment, k-step) part an SGPR offset -- no vector address arithmetic in
@@ -388,7 +400,7 @@ __global__ __launch_bounds__(FNW * 64, (VEC * MT >= 8) ? 2 : 3) void wna16_gemm_
       }
     }
   }
-  wna16_epilogue<T, VEC, MT, FNW>(p, red, cacc, lane, wave, g, m0, ncol);
+  wna16_epilogue<T, VEC, MT, FNW>(p, red, cacc, lane, wave, g, m0, ncol, by);
 }
 
 // Generic path (any group size that is a multiple of 32): per-segment loads.
@@ -506,7 +518,7 @@ __global__ __launch_bounds__(NW * 64) void wna16_gemm_generic_kernel(Wna16Params
       for (int t = 0; t < VEC; ++t) acc[i][t] += part[i][t] * scl[t];
   }
 
-  wna16_epilogue<T, VEC, MT, NW>(p, red, acc, lane, wave, g, m0, ncol);
+  wna16_epilogue<T, VEC, MT, NW>(p, red, acc, lane, wave, g, m0, ncol, (int)blockIdx.y);
 }
 
 // partial [S][M*N] fp32 -> c [M*N] (+ bias[N])
@@ -726,10 +738,14 @@ static Wna16Plan make_plan(int64_t M, int64_t N, int64_t K, int64_t gs, int64_t 
 }
 
 template <typename T, int VEC, int MT>
-static void launch_wna16(const Wna16Params& p, const Wna16Plan& pl, hipStream_t st) {
+static void launch_wna16(const Wna16Params& p_in, const Wna16Plan& pl, hipStream_t st) {
+  const Wna16Params& p = p_in;
   dim3 grid((unsigned)(p.N / (16 * VEC)), (unsigned)pl.ksplit, (unsigned)((p.M + 16 * MT - 1) / (16 * MT)));
   if (pl.fast) {
     if constexpr (VEC >= 2) {
+      Wna16Params p = p_in;
+      const unsigned per = pl.ksplit > 1 && 8 % pl.ksplit == 0 ? 8u / (unsigned)pl.ksplit : 0u;
+      p.xcd_remap = (per > 0 && grid.z == 1 && p.expert_ids == nullptr && grid.x % per == 0 && !env_int("APHRO_WNA16_NO_XCD_REMAP", 0)) ? 1 : 0;
       size_t lds = (size_t)FNW * MT * VEC * 64 * 4 * sizeof(float);
 #define APHRO_FAST(NS) hipLaunchKernelGGL((wna16_gemm_kernel<T, VEC, MT, NS>), grid, dim3(FNW * 64), lds, st, p)
       switch (pl.nseg) {

@@ -18,6 +18,7 @@ _TP_RANK = 0
 _TP_SIZE = 1
 _CUSTOM_AR = None      # CustomAllreduce of the TP group (enable_custom_all_reduce)
 _OVERLAP = None        # AllReduceOverlap (enable_all_reduce_overlap): all-reduce on a side stream + weight prefetch
+_SIM_AR_US = None      # simulated TP (init_simulated_tensor_parallel): {bytes threshold: microseconds} of the stubbed all-reduce
 
 
 def init_tensor_parallel(tp_size: int, backend: Optional[str] = None) -> None:
@@ -40,11 +41,23 @@ def init_tensor_parallel(tp_size: int, backend: Optional[str] = None) -> None:
             _TP_SIZE = tp_size
 
 
+def init_simulated_tensor_parallel(tp_size: int, all_reduce_us, rank: int = 0) -> None:
+    """ONE rank of a TP group of ``tp_size`` on a one-GPU box (bench.py --sim-tp): every layer
+    shards exactly as it would in the group (column / row parallel, heads, vocabulary), the rank runs its real per-GPU
+    kernels on its real shard shapes, and each all-reduce is replaced by a launch that holds the stream for the latency
+    measured for that message size (``all_reduce_us``: float, or {max bytes: us} picked by size) -- the data is left as
+    this rank's partial sum, so the OUTPUT is meaningless, only the timing is.  The logits gather returns the local
+    shard."""
+    global _TP_GROUP, _TP_RANK, _TP_SIZE, _SIM_AR_US
+    _TP_GROUP, _TP_RANK, _TP_SIZE = None, rank, tp_size
+    _SIM_AR_US = all_reduce_us if isinstance(all_reduce_us, dict) else {1 << 62: float(all_reduce_us)}
+
+
 def destroy_tensor_parallel() -> None:
-    global _TP_GROUP, _TP_RANK, _TP_SIZE, _CUSTOM_AR, _OVERLAP
+    global _TP_GROUP, _TP_RANK, _TP_SIZE, _CUSTOM_AR, _OVERLAP, _SIM_AR_US
     if _CUSTOM_AR is not None:
         _CUSTOM_AR.close()
-    _TP_GROUP, _TP_RANK, _TP_SIZE, _CUSTOM_AR, _OVERLAP = None, 0, 1, None, None
+    _TP_GROUP, _TP_RANK, _TP_SIZE, _CUSTOM_AR, _OVERLAP, _SIM_AR_US = None, 0, 1, None, None, None
 
 
 def enable_custom_all_reduce(device, cpu_group: Optional[dist.ProcessGroup] = None, max_size: int = 8192 * 1024):
@@ -125,6 +138,12 @@ def tensor_model_parallel_all_reduce(input_: torch.Tensor, prefetch=None) -> tor
     enable_all_reduce_overlap() is on; otherwise ignored and the all-reduce runs on the current stream."""
     if _TP_SIZE == 1:
         return input_
+    if _SIM_AR_US is not None:
+        from .. import _lib
+        nbytes = input_.numel() * input_.element_size()
+        us = next(v for k, v in sorted(_SIM_AR_US.items()) if nbytes <= k)
+        _lib.check(_lib.lib().aphro_spin_us(float(us), torch.cuda.current_stream(input_.device).cuda_stream), "spin_us")
+        return input_
     if _OVERLAP is not None and input_.is_cuda:
         return _OVERLAP.all_reduce(_all_reduce_serial, input_, prefetch)
     return _all_reduce_serial(input_)
@@ -132,7 +151,7 @@ def tensor_model_parallel_all_reduce(input_: torch.Tensor, prefetch=None) -> tor
 
 def tensor_model_parallel_all_gather(input_: torch.Tensor, dim: int = -1) -> torch.Tensor:
     """communication_op.py:15-18 / parallel_state.py:381-416."""
-    if _TP_SIZE == 1:
+    if _TP_SIZE == 1 or _SIM_AR_US is not None:
         return input_
     if dim < 0:
         dim += input_.dim()

@@ -42,7 +42,14 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=8)
-    ap.add_argument("--model", default="llama3-8b", choices=["llama3-8b", "mixtral-8x7b"],
+    ap.add_argument("--sim-tp", type=int, default=0,
+                    help="one-GPU shard bench: time ONE rank of a TP group of this size (real per-GPU shard shapes, every "
+                         "all-reduce replaced by a launch that holds the stream for --sim-ar-us); configs[3]: --model "
+                         "llama3-70b --quant awq --batch 64 --sim-tp 8, configs[4]: --model mixtral-8x7b --sim-tp 4")
+    ap.add_argument("--sim-ar-us", type=float, default=0.0,
+                    help="latency of the stubbed all-reduce (default: the one-GPU lower bound of the peer-access kernel for "
+                         "the message size, profiles/r1_custom_ar_one_gpu.txt)")
+    ap.add_argument("--model", default="llama3-8b", choices=["llama3-8b", "llama3-70b", "mixtral-8x7b"],
                     help="mixtral-8x7b: BASELINE configs[4] (int4 experts through the grouped GEMM); gptq / awq only")
     ap.add_argument("--quant", default="gptq", choices=["gptq", "fp8", "awq", "fp8ct"],
                     help="fp8: per-tensor W8A8 (Fp8Config); fp8ct: compressed-tensors W8A8, per-token x per-channel")
@@ -58,6 +65,9 @@ def parse_args():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prefill-info", action="store_true", help="skip the MFMA-bound prefill kernels' info section")
+    ap.add_argument("--no-ops-path", action="store_true", help="skip the second measurement on the op-by-op (drop-in) path")
+    ap.add_argument("--no-tp-section", action="store_true",
+                    help="N > 1, replicas: skip the tensor-parallel section (TP = N timing, overlap A/B, all-reduce latencies)")
     ap.add_argument("--layers", type=int, default=0, help="debug only: fewer layers (marks the line invalid)")
     return ap.parse_args()
 
@@ -68,7 +78,7 @@ def build(args, device):
     from aphrodite_engine_amd.quantization.fp8 import Fp8Config
     from aphrodite_engine_amd.quantization.gptq import GPTQConfig
     import dataclasses
-    cfg = M.LLAMA3_8B if args.model == "llama3-8b" else M.MIXTRAL_8X7B
+    cfg = {"llama3-8b": M.LLAMA3_8B, "llama3-70b": M.LLAMA3_70B, "mixtral-8x7b": M.MIXTRAL_8X7B}[args.model]
     if args.model == "mixtral-8x7b" and args.quant not in ("gptq", "awq"):
         raise SystemExit("--model mixtral-8x7b runs int4 experts: --quant gptq or awq")
     if args.layers:
@@ -454,6 +464,94 @@ def all_reduce_section(args, model, device, ca):
             "note": "us per all-reduce on rank 0's clock: the peer-access kernel as 32 chained calls per HIP-graph replay, RCCL as 32 chained eager calls (host launch included)"}
 
 
+def timed_decode(loop, args, world, one_gpu, device, ca=None):
+    """Capture loop.step into a HIP graph (the all-reduce inputs seen while capturing are registered with the peers
+    afterwards) and time args.steps replays: barrier + synchronize on both sides, max over ranks."""
+    import contextlib
+    import torch.distributed as dist
+    for _ in range(2):
+        loop.step()
+    torch.cuda.synchronize()
+    run = loop.step
+    if not args.no_graph:
+        graph = torch.cuda.CUDAGraph()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with (ca.capture() if ca is not None and not ca.disabled else contextlib.nullcontext()):
+            with torch.cuda.stream(s):
+                loop.step()
+            torch.cuda.current_stream().wait_stream(s)
+            with torch.cuda.graph(graph):
+                loop.step()
+        run = graph.replay
+    for _ in range(args.warmup):
+        run()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], device="cpu" if one_gpu else device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    if ca is not None:
+        ca.check()
+    return elapsed
+
+
+def tp_section(args, device, world, rank, one_gpu):
+    """After the replica ("dp") timing of an N > 1 run: the SAME model sharded Megatron-style over the N ranks
+    (north_star: RCCL all-reduce over xGMI overlapped with the quantized GEMMs), so that ONE `bench.py --gpus N` run
+    yields both points of the scaling story: tokens/s of TP = N with the all-reduce overlapped with the next weights'
+    prefetch and without, which all-reduce served the [M, hidden] sums (peer-access kernel vs RCCL, one- / two-shot),
+    their latencies per size, and how many ranks RCCL really spans.  Never executed on real links before the driver's
+    first 8-GPU run: every failure is reported in the dict instead of raised."""
+    import torch.distributed as dist
+    from aphrodite_engine_amd import distributed as D
+    out = {"tp": world}
+    ones = torch.ones(1, device="cpu" if one_gpu else device)
+    dist.all_reduce(ones)
+    out["ranks_seen_by_collective"] = int(ones.item())
+    out["backend"] = dist.get_backend()
+    D.init_tensor_parallel(world)
+    ca = None
+    if not os.environ.get("APHRO_NO_CUSTOM_AR"):
+        try:
+            ca = D.enable_custom_all_reduce(device)
+            out["custom_all_reduce"] = "enabled" if (ca is not None and not ca.disabled) else \
+                f"disabled: {getattr(ca, 'disabled_reason', 'ineligible')}"
+        except Exception as e:
+            out["custom_all_reduce"] = f"failed: {e!r}"[:200]
+            ca = None
+    model, cfg, dtype = build(args, device)
+    total = 2 * (args.warmup + args.steps + 8)
+    loop = DecodeLoop(model, cfg, dtype, args, device, total)
+    with torch.no_grad():
+        for name, on in (("overlap", True), ("no_overlap", False)):
+            D.enable_all_reduce_overlap(device, enabled=on)
+            try:
+                el = timed_decode(loop, args, world, one_gpu, device, ca)
+                out[name] = {"tokens_per_s": args.batch * args.steps / el, "ms_per_step": el / args.steps * 1e3}
+            except Exception as e:
+                out[name] = {"error": repr(e)[:200]}
+        D.enable_all_reduce_overlap(device, enabled=False)
+        try:
+            out["all_reduce_info"] = all_reduce_section(args, model, device, ca)
+        except Exception as e:
+            out["all_reduce_info"] = {"error": repr(e)[:200]}
+    del loop, model
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -481,6 +579,14 @@ def main():
     _lib.lib()  # fail loudly if the HIP library is missing
     tp = world if (args.parallelism == "tp" and world > 1) else 1
     D.init_tensor_parallel(tp)
+    sim_ar_us = None
+    if args.sim_tp > 1:
+        assert world == 1, "--sim-tp times one rank of the group on one GPU"
+        # [M, hidden] f16 message of this workload; stub latency = the peer-access kernel + flag protocol measured with
+        # the ranks on one GPU (no link time): <= 256 KiB one-shot 6.7 us, above two-shot 11.4 us (4 ranks)
+        msg = args.batch * {"llama3-8b": 4096, "llama3-70b": 8192, "mixtral-8x7b": 4096}[args.model] * 2
+        sim_ar_us = args.sim_ar_us if args.sim_ar_us > 0 else (6.7 if msg <= 256 * 1024 else 11.4)
+        D.init_simulated_tensor_parallel(args.sim_tp, sim_ar_us)
     ca = None
     if tp > 1 and not os.environ.get("APHRO_NO_CUSTOM_AR"):
         # xGMI peer-access all-reduce for the [M, hidden] sums (RCCL stays the fallback for ineligible sizes)
@@ -490,7 +596,8 @@ def main():
         overlap = D.enable_all_reduce_overlap(device)
 
     model, cfg, dtype = build(args, device)
-    total = args.warmup + args.steps + 4
+    ops_path = world == 1 and not args.no_ops_path and args.model == "llama3-8b" and args.sim_tp <= 1
+    total = (args.warmup + args.steps + 4) * (2 if ops_path else 1)
     loop = DecodeLoop(model, cfg, dtype, args, device, total)
 
     with torch.no_grad():
@@ -533,6 +640,31 @@ def main():
         if ca is not None:
             ca.check()      # a timed-out barrier would have produced garbage: fail loudly
         ctx_end = int(loop.meta.seq_lens_tensor[0].item())
+        # ---- the same workload on the OP-BY-OP path: what a reference LlamaDecoderLayer (modeling/models/llama.py:234,
+        # quant_method.apply -> ops.gptq_gemm, quantization/gptq.py:230-243; Attention.forward -> ops.reshape_and_cache +
+        # ops.paged_attention_*) gets through the plugin without adopting forward_decode_fused: one launch per reference op
+        # (17 per layer instead of 7), row-major activations between them.  Captured and timed exactly like the headline.
+        elapsed_ops = None
+        if ops_path:
+            model.use_fused_decode = False
+            for _ in range(2):
+                loop.step()
+            torch.cuda.synchronize()
+            run_ops = loop.step
+            if not args.no_graph:
+                g_ops = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g_ops):
+                    loop.step()
+                run_ops = g_ops.replay
+            for _ in range(args.warmup):
+                run_ops()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                run_ops()
+            torch.cuda.synchronize()
+            elapsed_ops = time.perf_counter() - t1
+            model.use_fused_decode = True
         active_frac = 1.0
         if cfg.num_local_experts:
             # experts the decode step really routes to (one more eager step with the routing recorded)
@@ -554,70 +686,140 @@ def main():
                 ar_info = {"error": repr(e)[:200]}
         roof = roofline_section(model, loop, args) if rank == 0 else None
 
+    line = None
+    if rank == 0:
+        replicas = world if tp == 1 else 1
+        tokens = args.batch * args.steps * replicas
+        ms_per_step = elapsed / args.steps * 1e3
+        # step-level algorithmic bytes
+        w_bytes = model.weight_bytes_per_layer(active_frac) * cfg.num_hidden_layers
+        lm_head = model.lm_head.numel() * 2
+        esz = 1 if args.kv_cache_dtype != "auto" else 2
+        ctx_mid = (args.ctx + args.warmup + 2 + ctx_end) / 2.0
+        tp_eff = max(tp, args.sim_tp, 1)
+        kv_bytes = args.batch * ctx_mid * 2 * max(1, cfg.num_key_value_heads // tp_eff) * cfg.head_dim * esz * cfg.num_hidden_layers
+        step_bytes = w_bytes + lm_head + kv_bytes
+        # dominant kernel = the kernel TEMPLATE with the largest total time per step: several
+        # projections may run one template (qkv / o / down on wna16_gemm_kernel); its roofline point is their summed
+        # algorithmic bytes over their summed launch time, per launch the average.
+        groups = {}
+        for k, v in roof.items():
+            tmpl = v.get("kernel", k).split(" ")[0].split("<")[0]
+            gsum = groups.setdefault(tmpl, {"bytes": 0.0, "seconds": 0.0, "members": []})
+            gsum["bytes"] += v["bytes"]
+            gsum["seconds"] += v["seconds"]
+            gsum["members"].append(k)
+        dom_name = max(groups, key=lambda k: groups[k]["seconds"])
+        dom = groups[dom_name]
+        achieved = dom["bytes"] / dom["seconds"] / 1e9
+        n_members = len(dom["members"])
+        # HBM bytes per launch: PMC counters cannot be collected from inside this process (rocprofv3 wraps it).  The
+        # committed same-round passes (profiles/r3_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE,
+        # separate runs of tools/prof_step_kernels.py at THESE shapes, gfx950 x2 correction on FETCH_SIZE) are attached
+        # with their provenance; null when the file has no entry for the dominant template.
+        traffic = None
+        traffic_src = None
+        try:
+            pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r3_pmc_traffic.json")))
+            ent = [pmc["kernels"][m] for m in dom["members"] if m in pmc.get("kernels", {})]
+            if len(ent) == n_members and args.quant == "gptq" and args.batch == 32 and args.kv_cache_dtype == "auto":
+                traffic = sum(e["hbm_bytes_per_launch"] for e in ent) / n_members
+                traffic_src = pmc.get("source")
+        except Exception:
+            pass
+        line = {
+            "metric": "output tokens/sec + HBM-roofline %, Llama-3-8B int4/fp8 @ 1/2/4/8 MI355X",
+            "value": tokens / elapsed,
+            "unit": "tokens/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak" if tp == 1 else "strong",
+            "vs_baseline": None,
+            "dtype": {"gptq": "int4 weights x f16 (fp32 accumulate)", "awq": "int4 weights x f16 (fp32 accumulate)",
+                      "fp8": "fp8-e4m3 x fp8-e4m3 (fp32 accumulate)",
+                      "fp8ct": "fp8-e4m3 x fp8-e4m3 (fp32 accumulate)"}[args.quant],
+            "data": "synthetic (random-init weights in the real GPTQ/FP8 formats, random token ids, random-permutation block tables)",
+            "config": {
+                "workload": f"{ {'llama3-8b': 'Llama-3-8B', 'llama3-70b': 'Llama-3-70B', 'mixtral-8x7b': 'Mixtral-8x7B (top-2 of 8 experts)'}[args.model]} "
+                            f"{args.quant.upper()} {'W8A8' if args.quant.startswith('fp8') else '4-bit g128'}, decode, "
+                            f"{'greedy' if args.sampling == 'greedy' else 'random sampling (T 0.8, top-k 50, top-p 0.95)'}, "
+                            f"bs={args.batch}/GPU, context {args.ctx}->{ctx_end}, kv_cache={args.kv_cache_dtype}, "
+                            f"block_size=16, HIP-graph={'off' if args.no_graph else 'on'}",
+                "global_batch": args.batch * replicas,
+                "seq_len": args.ctx,
+                "parallelism": f"{args.parallelism}{world}",
+                "all_reduce": ("xGMI peer-access kernel" if ca is not None and not ca.disabled else "RCCL") if tp > 1 else None,
+                "all_reduce_overlap": (overlap is not None) if tp > 1 else None,
+                "layers": cfg.num_hidden_layers,
+            },
+            "step_hbm": {"active_expert_fraction": active_frac, "algorithmic_bytes": step_bytes, "achieved_GBps": step_bytes / (elapsed / args.steps) / 1e9,
+                         "frac_of_peak": step_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS},
+            "roofline": {"bound": "hbm", "kernel": dom_name, "members": dom["members"], "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "bytes_per_launch": dom["bytes"] / n_members, "avg_launch_us": dom["seconds"] / n_members * 1e6,
+                         "total_us_per_layer": dom["seconds"] * 1e6,
+                         # the whole step against the same peak (the headline fraction; `frac` is the dominant kernel's)
+                         "step_frac": step_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS},
+            "roofline_all": {k: {"GBps": v["bytes"] / v["seconds"] / 1e9, "frac": v["bytes"] / v["seconds"] / 1e9 / HBM_PEAK_GBS,
+                                 "bytes": v["bytes"], "avg_us": v["seconds"] * 1e6,
+                                 **({"active_experts": v["active_experts"]} if "active_experts" in v else {})}
+                             for k, v in roof.items()},
+        }
+        if elapsed_ops is not None:
+            line["value_ops_path"] = args.batch * args.steps / elapsed_ops
+            line["ops_path"] = {"ms_per_step": elapsed_ops / args.steps * 1e3,
+                                "what": "same workload, one launch per reference op (LlamaDecoderLayer.forward -> quant_method.apply / "
+                                        "ops.* through the plugin surface), HIP graph; `value` is the fused fast path (forward_decode_fused)"}
+        if ar_info is not None:
+            line["all_reduce_info"] = ar_info
+        if args.layers:
+            line["config"]["INVALID"] = "debug run with fewer layers"
+        if args.sim_tp > 1:
+            line["config"]["parallelism"] = f"ONE rank of tp{args.sim_tp}, simulated on one GPU"
+            line["config"]["simulated_all_reduce_us"] = sim_ar_us
+            line["config"]["NOTE"] = ("per-GPU shard timing: real shard shapes and kernels of one rank; every all-reduce replaced by a "
+                                      "launch holding the stream for simulated_all_reduce_us (one-GPU lower bound of the peer-access "
+                                      "kernel, no link time); tokens/s is what the TP group would deliver at that all-reduce latency; "
+                                      "outputs are not meaningful (partial sums are not reduced)")
+
+    def emit_line(tp_result=None):
+        if tp_result is not None:
+            line["tp_section"] = tp_result
+        print(json.dumps(line), flush=True)
+
+    tp_info = None
+    if world > 1 and tp == 1 and not args.no_tp_section and args.model == "llama3-8b":
+        # free the replica first, then run the sharded model under a watchdog: a hung collective must not cost the line
+        loop = model = None
+        torch.cuda.empty_cache()
+        import threading
+        done = threading.Event()
+        result = {}
+
+        def guard():
+            if not done.wait(float(os.environ.get("APHRO_BENCH_TP_TIMEOUT_S", "240"))):
+                result["tp"] = {"error": "tensor-parallel section timed out (watchdog): replica numbers above are unaffected"}
+                result["timeout"] = True
+                if rank == 0:
+                    emit_line(result["tp"])
+                os._exit(0)
+        threading.Thread(target=guard, daemon=True).start()
+        try:
+            tp_info = tp_section(args, device, world, rank, one_gpu)
+        except Exception as e:
+            tp_info = {"error": repr(e)[:300]}
+        done.set()
+        if rank == 0:
+            line["tp_section"] = tp_info
+
     if rank != 0:
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
         return
-    replicas = world if tp == 1 else 1
-    tokens = args.batch * args.steps * replicas
-    ms_per_step = elapsed / args.steps * 1e3
-    # step-level algorithmic bytes
-    w_bytes = model.weight_bytes_per_layer(active_frac) * cfg.num_hidden_layers
-    lm_head = model.lm_head.numel() * 2
-    esz = 1 if args.kv_cache_dtype != "auto" else 2
-    ctx_mid = (args.ctx + args.warmup + 2 + ctx_end) / 2.0
-    kv_bytes = args.batch * ctx_mid * 2 * (cfg.num_key_value_heads // tp) * cfg.head_dim * esz * cfg.num_hidden_layers
-    step_bytes = w_bytes + lm_head + kv_bytes
-    dom_name = max(roof, key=lambda k: roof[k]["seconds"])   # dominant kernel by time
-    dom = roof[dom_name]
-    achieved = dom["bytes"] / dom["seconds"] / 1e9
-    # HBM bytes per launch from PMC counters cannot be collected from inside this process; the figure measured for
-    # THIS kernel under rocprofv3 --pmc FETCH_SIZE (own pass, x2 gfx950 correction) lives in profiles/ and DESIGN.md
-    # (1.003-1.005 x algorithmic).  Not attached to a run it was not measured in.
-    traffic = None
-    line = {
-        "metric": "output tokens/sec + HBM-roofline %, Llama-3-8B int4/fp8 @ 1/2/4/8 MI355X",
-        "value": tokens / elapsed,
-        "unit": "tokens/s",
-        "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": ms_per_step,
-        "higher_is_better": True,
-        "scaling": "weak" if tp == 1 else "strong",
-        "vs_baseline": None,
-        "dtype": {"gptq": "int4 weights x f16 (fp32 accumulate)", "awq": "int4 weights x f16 (fp32 accumulate)",
-                  "fp8": "fp8-e4m3 x fp8-e4m3 (fp32 accumulate)",
-                  "fp8ct": "fp8-e4m3 x fp8-e4m3 (fp32 accumulate)"}[args.quant],
-        "data": "synthetic (random-init weights in the real GPTQ/FP8 formats, random token ids, random-permutation block tables)",
-        "config": {
-            "workload": f"{'Llama-3-8B' if args.model == 'llama3-8b' else 'Mixtral-8x7B (top-2 of 8 experts)'} "
-                        f"{args.quant.upper()} {'W8A8' if args.quant.startswith('fp8') else '4-bit g128'}, decode, "
-                        f"{'greedy' if args.sampling == 'greedy' else 'random sampling (T 0.8, top-k 50, top-p 0.95)'}, "
-                        f"bs={args.batch}/GPU, context {args.ctx}->{ctx_end}, kv_cache={args.kv_cache_dtype}, "
-                        f"block_size=16, HIP-graph={'off' if args.no_graph else 'on'}",
-            "global_batch": args.batch * replicas,
-            "seq_len": args.ctx,
-            "parallelism": f"{args.parallelism}{world}",
-            "all_reduce": ("xGMI peer-access kernel" if ca is not None and not ca.disabled else "RCCL") if tp > 1 else None,
-            "all_reduce_overlap": (overlap is not None) if tp > 1 else None,
-            "layers": cfg.num_hidden_layers,
-        },
-        "step_hbm": {"active_expert_fraction": active_frac, "algorithmic_bytes": step_bytes, "achieved_GBps": step_bytes / (elapsed / args.steps) / 1e9,
-                     "frac_of_peak": step_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS},
-        "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "bytes_per_launch": dom["bytes"], "avg_launch_us": dom["seconds"] * 1e6,
-                     # the whole step against the same peak (the headline fraction; `frac` is the dominant kernel's)
-                     "step_frac": step_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS},
-        "roofline_all": {k: {"GBps": v["bytes"] / v["seconds"] / 1e9, "frac": v["bytes"] / v["seconds"] / 1e9 / HBM_PEAK_GBS,
-                             "bytes": v["bytes"], "avg_us": v["seconds"] * 1e6,
-                             **({"active_experts": v["active_experts"]} if "active_experts" in v else {})}
-                         for k, v in roof.items()},
-    }
-    if ar_info is not None:
-        line["all_reduce_info"] = ar_info
     if world == 1 and not args.no_prefill_info and args.model == "llama3-8b":
         try:
             del loop, model               # the decode state is no longer needed: give its memory back first
@@ -625,8 +827,6 @@ def main():
             line["prefill_kernels"] = prefill_section(cfg)
         except Exception as e:
             line["prefill_kernels"] = {"error": repr(e)}
-    if args.layers:
-        line["config"]["INVALID"] = "debug run with fewer layers"
     if world == 1 and not args.no_cpu_baseline and args.model == "llama3-8b":
         try:
             line["cpu_baseline"] = cpu_baseline(args, cfg)

@@ -577,6 +577,10 @@ int aphro_wna16_gemm_resident(const void* a_packed, const uint32_t* q_weight, co
 int aphro_wna16_strip_relayout(const uint32_t* q_weight, uint32_t* out, int64_t M, int64_t N, int64_t K,
                                int64_t groups, void* stream);
 
+/* Test-rig helper: a launch that holds `stream` for `us` microseconds without touching memory -- the stand-in for an
+ * all-reduce when one rank of a tensor-parallel group is timed alone (bench.py --sim-tp).  No reference counterpart. */
+int aphro_spin_us(double us, void* stream);
+
 /* Overlap helper for tensor parallelism (north_star: "all-reduce overlapped with the quantized GEMMs on HIP
  * streams"): streams `bytes` at `ptr` through the memory-side Infinity Cache on `stream` while the all-reduce of the
  * previous row-parallel projection runs on a side stream -- see aphrodite_engine_amd/distributed/overlap.py.  Reads

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Launches each decode-step kernel a few times at the bench shapes (for rocprofv3 --pmc)."""
+"""Launches each decode-step kernel a few times at the bench shapes (for rocprofv3 --pmc).  Round 3: gate_up runs the
+resident kernel on strip-major weights, as the decode step does; the 33..64-row forms run at M = 64."""
 import os
 import sys
 import torch
@@ -21,11 +22,17 @@ shapes = {"qkv": (4096, 6144), "o": (4096, 4096), "gate_up": (4096, 28672), "dow
 ws = {n: [gptq(*s) for _ in range(6)] for n, s in shapes.items()}
 for name, (k, n) in shapes.items():
     a = ops.wna16_pack_a(torch.randn(bs, k, device=dev, dtype=torch.float16))
+    a64 = ops.wna16_pack_a(torch.randn(64, k, device=dev, dtype=torch.float16))
     for qw, qz, sc in ws[name]:
         if name == "gate_up":
-            ops.wna16_gemm_silu_pack(a, bs, k, qw, qz, sc, 1)
+            ops.wna16_gemm_silu_pack(a, bs, k, qw, qz, sc, 1)                     # round-2 kernel (M <= 32 fallback)
+            strip = ops.wna16_strip_relayout(qw, bs, k // 128)
+            ops.wna16_gemm_resident(a, bs, k, strip, qz, sc, 1, mode="silu", strip_layout=True)   # what the step launches
+            ops.wna16_gemm_mid_silu_pack(a64, 64, k, qw, qz, sc, 1)               # bs 64
         else:
             ops.wna16_gemm_packed(a, bs, k, qw, qz, sc, 1, partials=True)
+            if name == "down":
+                ops.wna16_gemm_mid_packed(a64, 64, k, qw, qz, sc, 1, partials=True)
 # fused attention + norms
 ctx, Hq, Hkv, D, BS = 1100, 32, 8, 128, 16
 bps = (ctx + BS - 1) // BS
