@@ -183,7 +183,7 @@ class MI355XAttentionImpl:
             # handles ctx_len == 0 per sequence.
             has_ctx = (key_cache is not None and prefill_meta.context_lens_tensor is not None
                        and prefill_meta.block_tables is not None and prefill_meta.block_tables.numel() > 0)
-            if has_ctx and prefill_meta.max_context_len is not None:
+            if has_ctx and getattr(prefill_meta, "max_context_len", None) is not None:   # (ours; the reference's has no such field)
                 has_ctx = prefill_meta.max_context_len > 0
             if has_ctx:
                 # prefix-enabled attention (rocm_flash_attn.py:509-527)

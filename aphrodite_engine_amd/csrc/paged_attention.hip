@@ -64,7 +64,41 @@ struct PAParams {
   // optional dequantisation of the slabs (FP8 W8A8 qkv GEMM): value = row[seq] * (col[c] * sum)
   const float* slab_row_scale;   // [num_seqs] or NULL
   const float* slab_col_scale;   // [(Hq + 2 Hkv) * hd] or NULL
+  // ---- split-KV inside ONE launch (v1 / packed / fused forms; GQA <= 16) -----------------------------------------
+  // grid.z = nsplit workgroups share one (sequence, kv-head): each attends over an equal run of 32-token pairs, leaves
+  // its unnormalised (O, m, l) in split_scratch with write-through stores and takes a ticket from split_counter; the
+  // LAST arriver merges all runs with the reference's partition-merge math (attention_kernels.cu:637-668) and writes the
+  // output -- no second launch, nobody waits.  Fills the chip when num_seqs x num_kv_heads << CUs (a TP8 shard of
+  // Llama-3-70B has ONE kv head per GPU: 64 workgroups at bs 64).
+  int nsplit;                    // 0 / 1: off
+  float* split_scratch;          // [num_seqs * Hkv][nsplit][16 * HD + 32]
+  unsigned* split_counter;       // [num_seqs * Hkv], zero between launches (the merging workgroup resets it)
 };
+
+// write-through (system-scope) store / coherent loads: partial results cross XCDs (separate L2s) inside one launch.  No
+// release / acquire FENCES: at agent scope those write back / invalidate the whole L2 (+16 us per launch).
+__device__ __forceinline__ void st_wt_f32x4(float* p, f32x4 v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void st_wt_f32x2(float* p, f32x2 v) {
+  asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+}
+// (m, l) of four runs and one O element of each, all twelve loads in flight together; the wait sits INSIDE the statement
+// (with a separate s_waitcnt the compiler may move a destination register before its data has arrived -- seen in
+// custom_all_reduce.hip)
+__device__ __forceinline__ void ld_coh_runs4(float (&m)[4], float (&l)[4], float (&a)[4], const float* const (&pm)[4],
+                                             const float* const (&pa)[4]) {
+  asm volatile(
+      "global_load_dword %0, %12, off sc0 sc1\n\tglobal_load_dword %4, %12, off offset:4 sc0 sc1\n\tglobal_load_dword %8, %16, off sc0 sc1\n\t"
+      "global_load_dword %1, %13, off sc0 sc1\n\tglobal_load_dword %5, %13, off offset:4 sc0 sc1\n\tglobal_load_dword %9, %17, off sc0 sc1\n\t"
+      "global_load_dword %2, %14, off sc0 sc1\n\tglobal_load_dword %6, %14, off offset:4 sc0 sc1\n\tglobal_load_dword %10, %18, off sc0 sc1\n\t"
+      "global_load_dword %3, %15, off sc0 sc1\n\tglobal_load_dword %7, %15, off offset:4 sc0 sc1\n\tglobal_load_dword %11, %19, off sc0 sc1\n\t"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(m[0]), "=&v"(m[1]), "=&v"(m[2]), "=&v"(m[3]), "=&v"(l[0]), "=&v"(l[1]), "=&v"(l[2]), "=&v"(l[3]),
+        "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3])
+      : "v"(pm[0]), "v"(pm[1]), "v"(pm[2]), "v"(pm[3]), "v"(pa[0]), "v"(pa[1]), "v"(pa[2]), "v"(pa[3])
+      : "memory");
+}
 
 template <typename T>
 __device__ __forceinline__ f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c);
@@ -99,7 +133,7 @@ __device__ __forceinline__ u32x2 fp8x4_to_T(uint32_t w) {
 // KV: 0 = cache holds T, 1 = e4m3, 2 = e5m2.   HD: head size.  BS: block size.
 // ROPE: the fused rotary + cache-write form (a separate instantiation: the plain kernel must not
 // pay for the extra live state -- measured +1.4 us per launch when it was a runtime branch)
-template <typename T, int KV, int HD, int BS, int NW, int ROPE>
+template <typename T, int KV, int HD, int BS, int NW, int ROPE, bool SPLIT = false>
 __global__ __launch_bounds__(NW * 64) void paged_attention_kernel(PAParams p) {
   constexpr bool FP8 = KV != 0;
   constexpr bool E5M2 = KV == 2;
@@ -125,10 +159,14 @@ __global__ __launch_bounds__(NW * 64) void paged_attention_kernel(PAParams p) {
   const int part = blockIdx.z;
   const int gqa = p.num_heads / p.num_kv_heads;
   const int seq_len = p.seq_lens[seq];
-  const int psz = p.partition_size > 0 ? p.partition_size : 0x7fffffe0;
+  constexpr bool split = SPLIT;       // (a template parameter: the unsplit instantiations keep their register budget)
+  // split form: equal runs of 32-token pairs per workgroup of the (sequence, kv-head) group
+  const int split_pp = split ? (((seq_len + 31) >> 5) + p.nsplit - 1) / p.nsplit : 0;
+  const int psz = split ? max(split_pp, 1) * 32 : (p.partition_size > 0 ? p.partition_size : 0x7fffffe0);
   const int pstart = part * psz;
-  if (pstart >= seq_len) return;
-  const int pend = min(seq_len, pstart + psz);
+  const bool empty_run = pstart >= seq_len;
+  if (empty_run && !split) return;       // (split form: an empty run still takes its ticket -- it may be the last arriver)
+  const int pend = empty_run ? pstart : min(seq_len, pstart + psz);
   const int32_t* bt = p.block_tables + (size_t)seq * p.max_blocks_per_seq;
   const int alloc_tokens = ((seq_len + BS - 1) / BS) * BS;  // addressable tokens
 
@@ -398,9 +436,10 @@ __global__ __launch_bounds__(NW * 64) void paged_attention_kernel(PAParams p) {
     // Fused form: the wave AFTER the owner of the last tile pair (the one with the fewest pairs in
     // the round-robin) writes the new token's K/V and raises an LDS flag; the owner polls the flag
     // right before it loads the last pair -- normally several tiles later, so it never waits.
-    const int owner_wave = (pair_end - 1 - pair0) % NW;
-    const bool kv_owner = fused_rope && hb == 0 && wave == owner_wave;
-    const bool kv_writer = fused_rope && hb == 0 && wave == (owner_wave + 1) % NW;
+    const bool has_last = !empty_run && pend == seq_len;       // this run holds the new token's pair
+    const int owner_wave = has_last ? (pair_end - 1 - pair0) % NW : 0;
+    const bool kv_owner = fused_rope && hb == 0 && has_last && wave == owner_wave;
+    const bool kv_writer = fused_rope && hb == 0 && has_last && wave == (owner_wave + 1) % NW;
     // q of the fused form: issue the slab / cos-sin loads now (one rotary pair per thread)
     constexpr int QIT = (16 * (HD / 2) + NW * 64 - 1) / (NW * 64);   // pairs per thread for up to 16 heads
     float q_x[QIT], q_y[QIT];
@@ -541,17 +580,88 @@ __global__ __launch_bounds__(NW * 64) void paged_attention_kernel(PAParams p) {
       }
     }
     __syncthreads();
+    constexpr int SLOT = 16 * HD + 32;      // floats per (group, run) slot of split_scratch: O [16][HD], then (m, l) [16]
+    float* const grp_scratch = split ? p.split_scratch + ((size_t)seq * p.num_kv_heads + kvh) * p.nsplit * SLOT : nullptr;
+    if (split) {
+      // ---- this run's unnormalised (O, m, l) -> scratch (write-through), ticket, and only the last arriver goes on -----
+      if (!empty_run) {
+        float* slot = grp_scratch + (size_t)part * SLOT;
+        for (int idx = threadIdx.x; idx < nh * (HD / 4); idx += NW * 64) {      // 16 bytes per store
+          const int h = idx / (HD / 4), d = 4 * (idx - h * (HD / 4));
+          float M = -1e30f;
+#pragma unroll
+          for (int w = 0; w < NW; ++w) M = __builtin_fmaxf(M, ml[(w * 16 + h) * 2]);
+          float L = 0.f;
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int w = 0; w < NW; ++w) {
+            float wt = __expf(ml[(w * 16 + h) * 2] - M);
+            L += ml[(w * 16 + h) * 2 + 1] * wt;
+            acc += *reinterpret_cast<const f32x4*>(&ov[((size_t)w * p.nh_lds + h) * HD + d]) * wt;
+          }
+          st_wt_f32x4(slot + h * HD + d, acc);
+          if (d == 0) st_wt_f32x2(slot + 16 * HD + 2 * h, f32x2{M, L});
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // my stores have been performed before the ticket is taken
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        const unsigned old = __hip_atomic_fetch_add(p.split_counter + (size_t)seq * p.num_kv_heads + kvh, 1u, __ATOMIC_RELAXED,
+                                                    __HIP_MEMORY_SCOPE_AGENT);
+        kv_flag = (old == (unsigned)p.nsplit - 1u) ? 2 : 3;
+      }
+      __syncthreads();
+      if (kv_flag != 2) return;
+      if (threadIdx.x == 0)   // everybody has arrived: ready for the next launch
+        __hip_atomic_store(p.split_counter + (size_t)seq * p.num_kv_heads + kvh, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     for (int idx = threadIdx.x; idx < nh * HD; idx += NW * 64) {
       const int h = idx / HD, d = idx - h * HD;
-      float M = -1e30f;
+      float M = -1e30f, L = 0.f, acc = 0.f;
+      if (split) {
+        // merge the runs (all loads of a thread in flight together, one wait): out = sum_z O_z e^(m_z - M) / (sum_z l_z e^(m_z - M) + 1e-6)
+        float mz[8], lz[8], az[8];
 #pragma unroll
-      for (int w = 0; w < NW; ++w) M = __builtin_fmaxf(M, ml[(w * 16 + h) * 2]);
-      float L = 0.f, acc = 0.f;
+        for (int q4 = 0; q4 < 2; ++q4) {
+          float m4[4] = {-1e30f, -1e30f, -1e30f, -1e30f}, l4[4] = {0.f, 0.f, 0.f, 0.f}, a4[4] = {0.f, 0.f, 0.f, 0.f};
+          if (4 * q4 < p.nsplit) {            // (uniform) runs 4 q4 .. 4 q4 + 3; a run that does not exist reads run 0's slot
+            const float* pm[4];
+            const float* pa[4];
 #pragma unroll
-      for (int w = 0; w < NW; ++w) {
-        float wt = __expf(ml[(w * 16 + h) * 2] - M);
-        L += ml[(w * 16 + h) * 2 + 1] * wt;
-        acc += ov[((size_t)w * p.nh_lds + h) * HD + d] * wt;
+            for (int j = 0; j < 4; ++j) {
+              const int z = 4 * q4 + j;
+              const bool ok = z < p.nsplit && z * psz < seq_len;
+              const float* slot = grp_scratch + (size_t)(ok ? z : 0) * SLOT;
+              pm[j] = slot + 16 * HD + 2 * h;
+              pa[j] = slot + h * HD + d;
+            }
+            ld_coh_runs4(m4, l4, a4, pm, pa);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int z = 4 * q4 + j;
+              if (!(z < p.nsplit && z * psz < seq_len)) { m4[j] = -1e30f; l4[j] = 0.f; a4[j] = 0.f; }
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { mz[4 * q4 + j] = m4[j]; lz[4 * q4 + j] = l4[j]; az[4 * q4 + j] = a4[j]; }
+        }
+#pragma unroll
+        for (int z = 0; z < 8; ++z) M = __builtin_fmaxf(M, mz[z]);
+#pragma unroll
+        for (int z = 0; z < 8; ++z) {
+          const float wt = __expf(mz[z] - M);
+          L += lz[z] * wt;
+          acc += az[z] * wt;
+        }
+      } else {
+#pragma unroll
+        for (int w = 0; w < NW; ++w) M = __builtin_fmaxf(M, ml[(w * 16 + h) * 2]);
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+          float wt = __expf(ml[(w * 16 + h) * 2] - M);
+          L += ml[(w * 16 + h) * 2 + 1] * wt;
+          acc += ov[((size_t)w * p.nh_lds + h) * HD + d] * wt;
+        }
       }
       const float res = acc * (1.f / (L + 1e-6f)) * p.v_scale;
       const int qh = kvh * gqa + hb + h;
@@ -655,15 +765,23 @@ template <typename T, int KV, int HD, int BS, int ROPE = 0>
 static int launch_pa(const PAParams& p, int num_seqs, int parts, int nw, hipStream_t st) {
   dim3 grid((unsigned)p.num_kv_heads, (unsigned)num_seqs, (unsigned)parts);
   size_t lds = ((size_t)nw * 16 * 2 + (size_t)nw * p.nh_lds * HD) * sizeof(float);
-#define APHRO_PA_LAUNCH(NWV)                                                                        \
+#define APHRO_PA_LAUNCH(NWV, SPL)                                                                   \
   {                                                                                                 \
-    auto kern = paged_attention_kernel<T, KV, HD, BS, NWV, ROPE>;                                   \
+    auto kern = paged_attention_kernel<T, KV, HD, BS, NWV, ROPE, SPL>;                              \
     if (lds > 64 * 1024)                                                                            \
       (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     hipLaunchKernelGGL(kern, grid, dim3(NWV * 64), lds, st, p);                                      \
   }
-  if (nw == 4) APHRO_PA_LAUNCH(4)
-  else APHRO_PA_LAUNCH(8)
+  if constexpr (HD == 128 && (BS == 16 || BS == 32)) {   // the split form is instantiated for the serving geometry only
+    if (p.nsplit > 1) {
+      if (nw == 4) APHRO_PA_LAUNCH(4, true)
+      else APHRO_PA_LAUNCH(8, true)
+      APHRO_LAUNCH_CHECK();
+      return APHRO_OK;
+    }
+  }
+  if (nw == 4) APHRO_PA_LAUNCH(4, false)
+  else APHRO_PA_LAUNCH(8, false)
 #undef APHRO_PA_LAUNCH
   APHRO_LAUNCH_CHECK();
   return APHRO_OK;
@@ -704,6 +822,36 @@ static int dispatch_pa(const PAParams& p, int num_seqs, int parts, int nw, int h
 }  // namespace aphro
 
 using namespace aphro;
+
+// Per-device workspace of the split form: tickets (zero between launches) + the runs' partial results.  Owned by the
+// library (hipMalloc on first use / growth, never during a stream capture: a capturing call that finds it too small runs
+// unsplit).  The decode attention launches of a process are stream-ordered (one compute stream per worker, as in the
+// reference), so one workspace per device suffices.
+struct SplitWs { unsigned* counter = nullptr; size_t groups = 0; float* scratch = nullptr; size_t floats = 0; };
+static SplitWs g_split_ws[APHRO_MAX_DEVICES];
+
+static bool split_workspace(size_t groups, size_t floats, hipStream_t st, SplitWs** ws_out) {
+  SplitWs& ws = g_split_ws[device_slot()];
+  if (ws.groups < groups || ws.floats < floats) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return false;
+    if (hipStreamSynchronize(st) != hipSuccess) return false;         // nobody is using the old buffers
+    if (ws.groups < groups) {
+      if (ws.counter) (void)hipFree(ws.counter);
+      const size_t g2 = groups < 4096 ? 4096 : groups * 2;
+      if (hipMalloc((void**)&ws.counter, g2 * sizeof(unsigned)) != hipSuccess) { ws.counter = nullptr; ws.groups = 0; return false; }
+      if (hipMemset(ws.counter, 0, g2 * sizeof(unsigned)) != hipSuccess) return false;
+      ws.groups = g2;
+    }
+    if (ws.floats < floats) {
+      if (ws.scratch) (void)hipFree(ws.scratch);
+      if (hipMalloc((void**)&ws.scratch, floats * sizeof(float)) != hipSuccess) { ws.scratch = nullptr; ws.floats = 0; return false; }
+      ws.floats = floats;
+    }
+  }
+  *ws_out = &ws;
+  return true;
+}
 
 static int paged_attention_impl(void* out, void* out_packed, float* exp_sums, float* max_logits, void* tmp_out,
                                      const void* query, const void* key_cache, const void* value_cache,
@@ -751,11 +899,30 @@ static int paged_attention_impl(void* out, void* out_packed, float* exp_sums, fl
   const int gqa = num_heads / num_kv_heads;
   p.nh_lds = gqa < 16 ? gqa : 16;
   int parts = 1, nw;
+  p.nsplit = 0; p.split_scratch = nullptr; p.split_counter = nullptr;
   if (partition_size == 0) {
     p.partition_size = 0; p.max_parts = 0; p.write_direct = 1;
     // v1 form: one workgroup per (seq, kv head) walks the whole sequence
     nw = max_seq_len > 256 ? 8 : 4;
     while (nw > 4 && (size_t)nw * (32 + p.nh_lds * head_size) * 4 > 96 * 1024) nw >>= 1;
+    // ... or nsplit workgroups share it (split-KV inside the launch) when (seq, kv head) groups alone leave CUs idle:
+    // aim at ~2 workgroups per CU, at least 8 pairs (256 tokens) per run.  APHRO_PA_SPLITS=n forces n (1 = off).
+    if (gqa <= 16 && head_size == 128 && (block_size == 16 || block_size == 32)) {
+      const int64_t groups = (int64_t)num_seqs * num_kv_heads;
+      const int cus = device_cu_count();
+      int want = groups >= cus ? 1 : (int)((2 * cus + groups - 1) / groups);
+      const int max_pairs = (max_seq_len + 31) / 32;
+      if (want > max_pairs / 8) want = max_pairs / 8;
+      if (const char* e = getenv("APHRO_PA_SPLITS")) want = atoi(e);
+      want = want > 8 ? 8 : want;
+      if (want > 1) {
+        SplitWs* ws = nullptr;
+        if (split_workspace((size_t)groups, (size_t)groups * want * (16 * head_size + 32), st, &ws)) {
+          p.nsplit = want; p.split_scratch = ws->scratch; p.split_counter = ws->counter;
+          parts = want;
+        }
+      }
+    }
   } else {
     APHRO_CHECK(exp_sums && max_logits && tmp_out, "paged_attention: partitioned form needs scratch tensors");
     parts = (max_seq_len + partition_size - 1) / partition_size;

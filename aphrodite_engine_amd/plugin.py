@@ -13,7 +13,9 @@ precision kernel, (3) leaves attention to the op level: the reference's
 all-reduce where the reference's ROCm build has none: ``CustomAllreduce`` is swapped at the class
 level (distributed/device_communicators/custom_all_reduce.py:41 -- the ``_C_custom_ar`` ops are
 compiled out on ROCm, torch_bindings.cpp:506, so ``custom_ar`` is False there and the class
-disables itself), because its signal memory must be an uncached allocation a torch tensor cannot be.
+disables itself), because its signal memory must be an uncached allocation a torch tensor cannot be, and (5) with
+``APHRODITE_MI355X_FUSED_MODEL=1`` registers ``MI355XLlamaForCausalLM`` through ``ModelRegistry.register_model`` so that
+the decode step runs the fused fast path (reference_model.py; modeling/models/__init__.py:193-199).
 """
 
 
@@ -29,6 +31,15 @@ def register() -> None:
     from .quantization.kernels import register_with_reference as reg_kernels
     reg_methods(ref_q.QUANTIZATION_METHODS)
     reg_kernels(ref_k._POSSIBLE_KERNELS)
+    import os
+    if os.environ.get("APHRODITE_MI355X_FUSED_MODEL") == "1":
+        # model-level adoption of the fused decode step: the reference's out-of-tree model hook (reference_model.py)
+        try:
+            from aphrodite.modeling.models import ModelRegistry
+            from .reference_model import register_with_reference as reg_model
+            reg_model(ModelRegistry)
+        except Exception:
+            pass
     try:   # GroupCoordinator builds ``ca_comm = CustomAllreduce(group=cpu_group, device=...)`` (parallel_state.py:186-196)
         import aphrodite.distributed.device_communicators.custom_all_reduce as ref_ca
         from .distributed.custom_all_reduce import CustomAllreduce

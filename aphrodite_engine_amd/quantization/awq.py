@@ -127,6 +127,8 @@ class CDNA4AWQLinearMethod(LinearMethodBase):
             out_shape = x.shape[:-1] + (qweight.shape[-1] * pack_factor, )
             # num_tokens >= threshold (awq.py:159-163)
             if x.shape[:-1].numel() >= 256:
+                # (the reference's own rule for the unprepacked AWQ layout; prepack=True runs the hand-written kernels)
+                ops._library_fallback("awq linear", "unprepacked AWQ layout at >= 256 tokens: awq_dequantize + matmul (awq.py:159-163)")
                 out = ops.awq_dequantize(qweight, scales, qzeros, 0, 0, 0)
                 out = torch.matmul(reshaped_x, out)
             else:

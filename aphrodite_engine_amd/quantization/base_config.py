@@ -6,6 +6,7 @@ method names, argument order and defaults are the reference's so the concrete GP
 methods in this package can be registered in ``QUANTIZATION_METHODS`` unchanged; the bodies are
 ours (a small ``_abstract`` helper instead of one ``raise`` per method)."""
 import abc
+import functools
 from typing import Any, Dict, List, Optional
 
 import torch
@@ -31,6 +32,26 @@ class QuantizeMethodBase(abc.ABC):
 
     def process_weights_after_loading(self, layer: nn.Module) -> None:
         """Optional hook (repack / requantise); the default keeps the checkpoint layout."""
+
+    def __init_subclass__(cls, **kwargs):
+        """Every subclass's ``process_weights_after_loading`` runs ONCE per layer: the hook repacks / transposes in place,
+        and a layer can meet it twice -- from the reference's loader pass over the modules (model_loader/loader.py:402-408)
+        and from this package's own model code (reference_model.py, LlamaForCausalLM.process_weights_after_loading)."""
+        super().__init_subclass__(**kwargs)
+        fn = cls.__dict__.get("process_weights_after_loading")
+        if fn is None or getattr(fn, "_runs_once", False):
+            return
+
+        @functools.wraps(fn)
+        def once(self, layer, _fn=fn):
+            done = layer.__dict__.setdefault("_pwal_done", set())
+            if _fn.__qualname__ in done:
+                return None
+            out = _fn(self, layer)
+            done.add(_fn.__qualname__)
+            return out
+        once._runs_once = True
+        cls.process_weights_after_loading = once
 
     def embedding(self, layer: nn.Module, *args, **kwargs) -> torch.Tensor:
         """Only embedding-capable methods override this."""

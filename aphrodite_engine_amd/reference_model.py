@@ -1,0 +1,113 @@
+"""Model-level adoption of the decode fast path inside the REFERENCE engine.
+
+Through the op / quant-method seams alone a reference ``LlamaDecoderLayer`` (modeling/models/llama.py:193-270) gets one
+launch per reference op -- ``bench.py``'s ``value_ops_path``.  The fused step (``forward_decode_fused``: 7 launches per
+layer, fragment-major activations threaded between the kernels) needs the MODEL to call it, and the reference has a seam
+for exactly that: ``ModelRegistry.register_model(arch, cls)`` (modeling/models/__init__.py:193-199) -- the out-of-tree
+model hook, consulted before the built-in table (``_try_load_model_cls`` :158-160).  ``MI355XLlamaForCausalLM`` is such
+a class: constructed the way ``build_model`` constructs every model (model_loader/loader.py:144-157:
+``model_class(config=hf_config, cache_config=..., quant_config=..., **extra)``), fed by ``load_weights`` with the
+checkpoint's (name, tensor) pairs (llama.py:480-542), called by the model runner as
+``model(input_ids, positions, kv_caches, attn_metadata, intermediate_tensors)`` (worker/model_runner.py:1497-1507) and
+then ``compute_logits`` / ``sample`` (llama.py:433-450).  Inside, it is this package's ``LlamaForCausalLM``: prefill runs
+op by op (prefill kernels), decode batches of <= 64 rows take the fused path, both under the reference's own HIP-graph
+capture (everything is launched on the current stream).
+
+Opt in:  ``APHRODITE_MI355X_FUSED_MODEL=1`` makes ``plugin.register()`` register it for ``LlamaForCausalLM`` (and
+``MistralForCausalLM``: same decoder, llama.py:548).  What this class cannot do is listed where it raises: LoRA, pipeline
+parallelism, sliding-window / biased projections / non-llama3 rope scaling (``loader.llama_config_from_hf``).
+
+The attention metadata it receives is the reference's ``ROCmFlashAttentionMetadata`` (or ``MI355XAttentionMetadata``): the
+fields read -- ``num_prefill_tokens``, ``num_decode_tokens``, ``slot_mapping``, ``prefill_metadata`` /
+``decode_metadata``, ``seq_lens``, ``seq_lens_tensor``, ``block_tables``, ``max_decode_seq_len``, ``query_start_loc``,
+``seq_start_loc``, ``context_lens_tensor``, ``max_query_len``, ``max_prefill_seq_len`` -- carry the same names and meaning
+in both (attention/backends/rocm_flash_attn.py:62-152; pinned by tests/golden/attn_builder_cases)."""
+from typing import Iterable, List, Optional, Tuple
+
+import torch
+from torch import nn
+
+from . import loader as L
+from .model import LlamaForCausalLM, _rope_cache
+
+
+class MI355XLlamaForCausalLM(nn.Module):
+    # the reference's loader and LoRA manager look these up on the class (llama.py:338-366)
+    packed_modules_mapping = {"qkv_proj": ["q_proj", "k_proj", "v_proj"], "gate_up_proj": ["gate_proj", "up_proj"]}
+    supported_lora_modules: List[str] = []
+    embedding_modules = {}
+    embedding_padding_modules: List[str] = []
+
+    def __init__(self, config, cache_config=None, quant_config=None, lora_config=None, **extra) -> None:
+        super().__init__()
+        if lora_config is not None:
+            raise NotImplementedError("MI355XLlamaForCausalLM: LoRA is outside the hot path (SURVEY 8 out of scope)")
+        hf = config.to_dict() if hasattr(config, "to_dict") else dict(vars(config))
+        self.config = config
+        self.cfg = L.llama_config_from_hf(hf)
+        dtype = hf.get("torch_dtype") or getattr(config, "torch_dtype", None) or torch.get_default_dtype()
+        if isinstance(dtype, str):
+            dtype = getattr(torch, dtype)
+        kv_cache_dtype = getattr(cache_config, "cache_dtype", "auto") if cache_config is not None else "auto"
+        self.tie_word_embeddings = bool(hf.get("tie_word_embeddings", False))
+        self.kv_cache_dtype = kv_cache_dtype
+        # (quant_config is OUR config class: the plugin has swapped QUANTIZATION_METHODS before the loader resolves it)
+        self.inner = LlamaForCausalLM(self.cfg, quant_config, dtype, kv_cache_dtype)
+        self._kv_scales = {}
+        self._ready = False
+        self._sampler = None
+
+    # -- checkpoint ingestion (DefaultModelLoader calls model.load_weights(iterator), loader.py:396-408) --------------
+    def load_weights(self, weights: Iterable[Tuple[str, torch.Tensor]]) -> None:
+        self._kv_scales = L.load_llama_weights(self.inner, weights, self.tie_word_embeddings)
+
+    def _finish(self, device: torch.device) -> None:
+        """After the loader's ``process_weights_after_loading`` pass over the modules (loader.py:402-408: every module
+        with a ``quant_method`` -- our linears have one): rotary table, KV scales, the load-time relayouts of the fused
+        step.  Lazily at the first forward: that is the first point where the parameters are on the device AND
+        post-processed."""
+        inner, cfg = self.inner, self.cfg
+        for layer, (k, v) in zip(inner.layers, L.finalize_kv_scales(self._kv_scales, cfg.num_hidden_layers, self.kv_cache_dtype)):
+            layer.k_scale, layer.v_scale = k, v
+        if inner.cos_sin is None or inner.cos_sin.device != device:
+            inner.cos_sin = _rope_cache(cfg.head_dim, cfg.max_position_embeddings, cfg.rope_theta, inner.dtype, device,
+                                        cfg.rope_scaling)
+        inner.process_weights_after_loading()       # no-op for the layers the loader's own pass has already processed
+        for layer in inner.layers:
+            layer.enable_fused_silu(32, keep_original=True)                    # SiluAndMul in the gate_up epilogue
+        inner.use_fused_decode = True
+        self._ready = True
+
+    # -- the model runner's calls -----------------------------------------------------------------------------------
+    def forward(self, input_ids: torch.Tensor, positions: torch.Tensor, kv_caches: List[torch.Tensor], attn_metadata,
+                intermediate_tensors=None) -> torch.Tensor:
+        if intermediate_tensors is not None:
+            raise NotImplementedError("MI355XLlamaForCausalLM: pipeline parallelism is not implemented")
+        if not self._ready:
+            self._finish(input_ids.device)
+        return self.inner(input_ids, positions, kv_caches, attn_metadata)
+
+    def compute_logits(self, hidden_states: torch.Tensor, sampling_metadata) -> Optional[torch.Tensor]:
+        """LogitsProcessor.forward (modeling/layers/logits_processor.py:46-77): keep the rows that are sampled from, lm_head,
+        gather over TP, drop the vocabulary padding."""
+        idx = getattr(sampling_metadata, "selected_token_indices", None)
+        if idx is not None:
+            hidden_states = hidden_states.index_select(0, idx)
+        logits = self.inner.compute_logits(hidden_states)
+        scale = getattr(self.config, "logit_scale", 1.0)
+        return logits if scale == 1.0 else logits * scale
+
+    def sample(self, logits: torch.Tensor, sampling_metadata):
+        if self._sampler is None:
+            from aphrodite.modeling.layers.sampler import Sampler      # the reference's own sampler (llama.py:430, 444-450)
+            self._sampler = Sampler()
+        return self._sampler(logits, sampling_metadata)
+
+    def make_empty_intermediate_tensors(self, batch_size: int, dtype: torch.dtype, device: torch.device):
+        raise NotImplementedError("MI355XLlamaForCausalLM: pipeline parallelism is not implemented")
+
+
+def register_with_reference(model_registry, archs=("LlamaForCausalLM", "MistralForCausalLM")) -> None:
+    """ModelRegistry.register_model for the dense Llama-family architectures (idempotent: a dict assignment)."""
+    for arch in archs:
+        model_registry.register_model(arch, MI355XLlamaForCausalLM)

@@ -514,9 +514,15 @@ def tp_section(args, device, world, rank, one_gpu):
     prefetch and without, which all-reduce served the [M, hidden] sums (peer-access kernel vs RCCL, one- / two-shot),
     their latencies per size, and how many ranks RCCL really spans.  Never executed on real links before the driver's
     first 8-GPU run: every failure is reported in the dict instead of raised."""
+    import copy
     import torch.distributed as dist
     from aphrodite_engine_amd import distributed as D
     out = {"tp": world}
+    if one_gpu and not args.no_graph:
+        # test rig (gloo on one GPU): the host-side collectives of gloo cannot be captured; RCCL's can (tests/test_custom_ar_gpu.py)
+        args = copy.copy(args)
+        args.no_graph = True
+        out["graph"] = "off (gloo test rig)"
     ones = torch.ones(1, device="cpu" if one_gpu else device)
     dist.all_reduce(ones)
     out["ranks_seen_by_collective"] = int(ones.item())

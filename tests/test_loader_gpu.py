@@ -166,3 +166,53 @@ def test_synthetic_mixtral_decode_runs(ops):
         out = m(ids, pos, caches, meta)
         assert out.shape == (32, M.TINY_MOE.hidden_size) and torch.isfinite(out.float()).all()
         assert m.weight_bytes_per_layer() > 0
+
+
+def test_reference_model_adapter_matches_load_model(ops, tmp_path):
+    """reference_model.MI355XLlamaForCausalLM -- the class the plugin hands to the reference's ModelRegistry -- driven the
+    way the reference drives a model: constructed from a HF-style config + cache config + quant config
+    (model_loader/loader.py:144-157), ``load_weights`` with the checkpoint's (name, tensor) pairs, the loader's post-load
+    pass over modules with a ``quant_method`` (:402-408), then ``forward(input_ids, positions, kv_caches, attn_metadata)``
+    for a prefill and for a decode step (the fused fast path), ``compute_logits`` on the selected rows.  Same results as
+    this package's own load_model on the same checkpoint (whose linears are oracle-checked above)."""
+    import types
+    from aphrodite_engine_amd.reference_model import MI355XLlamaForCausalLM
+    CU.write_checkpoint(str(tmp_path), CFG, "gptq", seed=21)
+    hf_dict = L.read_hf_config(str(tmp_path))
+    hf = types.SimpleNamespace(**hf_dict)
+    hf.to_dict = lambda: dict(hf_dict)
+    hf.torch_dtype = torch.float16
+    qc = L.resolve_quant_config(str(tmp_path), hf_dict, None, torch.float16)
+    with torch.no_grad():
+        ref = L.load_model(str(tmp_path), dtype=torch.float16, device=DEV)
+        m = MI355XLlamaForCausalLM(config=hf, cache_config=types.SimpleNamespace(cache_dtype="auto"), quant_config=qc)
+        m.load_weights(L.iter_safetensors(str(tmp_path)))
+        m.to(DEV)
+        for _, module in m.named_modules():                   # DefaultModelLoader.load_model's post-load pass
+            qm = getattr(module, "quant_method", None)
+            if qm is not None:
+                qm.process_weights_after_loading(module)
+        # prefill of 3 prompts, then one decode step, through both models
+        from aphrodite_engine_amd.attention.backend import MI355XAttentionMetadata   # noqa: F401  (the metadata both accept)
+        lens = [5, 17, 33]
+        bs, block = len(lens), 16
+        meta_d, pos_d, nblocks = M.make_decode_metadata(bs, lens, block, DEV)
+        ids = torch.randint(0, CFG.vocab_size, (bs, ), device=DEV, generator=torch.Generator(device=DEV).manual_seed(3))
+        outs = []
+        for model in (ref, m):
+            caches = M.make_kv_caches(CFG, nblocks, block, torch.float16, "auto", DEV, seed=9)
+            hidden = model(ids, pos_d, caches, meta_d) if model is ref else model.forward(ids, pos_d, caches, meta_d, None)
+            outs.append(hidden)
+        assert m.inner.use_fused_decode and all(l.fused_decode_ok(bs) for l in m.inner.layers)
+        assert torch.isfinite(outs[1].float()).all()
+        torch.testing.assert_close(outs[1].float(), outs[0].float(), rtol=2e-3, atol=2e-3)
+        sm = types.SimpleNamespace(selected_token_indices=torch.tensor([0, 2], device=DEV))
+        logits = m.compute_logits(outs[1], sm)
+        assert logits.shape == (2, CFG.vocab_size)
+        torch.testing.assert_close(logits.float(), ref.compute_logits(outs[0][[0, 2]]).float(), rtol=2e-3, atol=2e-3)
+        # a second post-load pass (the adapter's own _finish already ran one) must not repack again
+        before = m.inner.layers[0].qkv_proj.qweight.clone()
+        m.inner.process_weights_after_loading()
+        assert torch.equal(before, m.inner.layers[0].qkv_proj.qweight)
+        with pytest.raises(NotImplementedError):
+            m.forward(ids, pos_d, caches, meta_d, intermediate_tensors=object())

@@ -1692,3 +1692,104 @@ def test_tp2_fused_decode_matches_unfused(ops, fused_silu):
         port = sk.getsockname()[1]
     mp.spawn(_tp2_worker, args=(2, port, fused_silu), nprocs=2, join=True)
 
+
+
+@pytest.mark.parametrize("splits", [2, 3, 5, 8])
+@pytest.mark.parametrize("dtype,kv_cache_dtype", [(torch.float16, "auto"), (torch.bfloat16, "auto"), (torch.float16, "fp8")])
+def test_paged_attention_split_kv_inside_the_launch(ops, splits, dtype, kv_cache_dtype):
+    """Split-KV in ONE launch (round 3): `splits` workgroups share a (sequence, kv-head) group, the last arriver merges
+    their unnormalised (O, m, l) with the reference's partition-merge math (attention_kernels.cu:637-668).  Ragged
+    lengths -- sequences shorter than one run (empty runs that still take their ticket), exactly on run boundaries, one
+    token -- against the ORACLE, in the v1 form and in the packed form; a second call on the same workspace (tickets were
+    reset by the merging workgroup) must give the same bits."""
+    import os
+    rng = np.random.default_rng(splits * 11 + len(kv_cache_dtype))
+    S, Hq, Hkv, D, BS = 9, 16, 2, 128, 16
+    seq_lens = np.array([1, 31, 32, 33, 64 * splits, 64 * splits + 1, 700, 1023, 1500], np.int32)
+    max_len = int(seq_lens.max())
+    bps = (max_len + BS - 1) // BS
+    NB = S * bps + 3
+    kc, vc = make_cache(rng, NB, Hkv, D, BS, dtype, kv_cache_dtype)
+    bt = rng.permutation(NB)[:S * bps].reshape(S, bps).astype(np.int32)
+    q = t(rng.standard_normal((S, Hq, D)).astype(np.float32), dtype)
+    ks, vs = (1.0, 1.0) if kv_cache_dtype == "auto" else (0.7, 1.3)
+    kc_np = kc.float().cpu().numpy() if kv_cache_dtype == "auto" else kc.cpu().numpy()
+    vc_np = vc.float().cpu().numpy() if kv_cache_dtype == "auto" else vc.cpu().numpy()
+    ref = oa.paged_attention_decode(q.float().cpu().numpy(), kc_np, vc_np, bt, seq_lens, D ** -0.5, None, kv_cache_dtype, ks, vs)
+    atol = 1e-3 if kv_cache_dtype == "auto" else 1e-2
+    if dtype == torch.bfloat16:
+        atol += 2.0 ** -8 * float(np.abs(ref).max())
+    args = (q, kc, vc, Hkv, D ** -0.5, t(bt), t(seq_lens), BS, max_len, None, kv_cache_dtype, ks, vs)
+    old = os.environ.get("APHRO_PA_SPLITS")
+    try:
+        os.environ["APHRO_PA_SPLITS"] = "1"
+        plain = torch.empty_like(q)
+        ops.paged_attention_v1(plain, *args)
+        os.environ["APHRO_PA_SPLITS"] = str(splits)
+        out = torch.full_like(q, float("nan"))
+        ops.paged_attention_v1(out, *args)
+        np.testing.assert_allclose(out.float().cpu().numpy(), ref, atol=atol, rtol=1e-5)
+        # same math as the unsplit kernel up to the order of the fp32 merge
+        np.testing.assert_allclose(out.float().cpu().numpy(), plain.float().cpu().numpy(), atol=atol, rtol=1e-5)
+        out2 = torch.full_like(q, float("nan"))
+        ops.paged_attention_v1(out2, *args)
+        assert torch.equal(out, out2)                       # tickets back at zero, no dependence on arrival order
+        packed, out3 = ops.paged_attention_packed(q, kc, vc, Hkv, D ** -0.5, t(bt), t(seq_lens), BS, max_len, None,
+                                                  kv_cache_dtype, ks, vs, want_out=True)
+        assert torch.equal(out3, out)
+        want_packed = ops.wna16_pack_a(out.view(S, Hq * D))
+        np.testing.assert_array_equal(unpack_a(packed, S, Hq * D), unpack_a(want_packed, S, Hq * D))
+        # under HIP-graph capture + replays (the decode step's regime)
+        g_out = torch.empty_like(q)
+        s_ = torch.cuda.Stream()
+        s_.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s_):
+            ops.paged_attention_v1(g_out, *args)
+        torch.cuda.current_stream().wait_stream(s_)
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            ops.paged_attention_v1(g_out, *args)
+        for _ in range(3):
+            g_out.fill_(float("nan"))
+            gr.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(g_out, out)
+    finally:
+        if old is None:
+            os.environ.pop("APHRO_PA_SPLITS", None)
+        else:
+            os.environ["APHRO_PA_SPLITS"] = old
+
+
+def test_paged_attention_rope_packed_split_matches_unsplit(ops):
+    """The fused rotary + cache-write form with split-KV: the run that holds the new token writes its K / V, every run
+    rotates q itself; caches bit-identical to the unsplit launch, output within the merge's fp32 rounding."""
+    import os
+    rng = np.random.default_rng(77)
+    S, Hq, Hkv, D, BS = 6, 8, 2, 128, 16
+    seq_lens = np.array([1, 33, 200, 515, 640, 1290], np.int32)
+    maxb = int((seq_lens.max() + BS - 1) // BS)
+    NB = S * maxb + 2
+    bt = rng.permutation(NB)[:S * maxb].reshape(S, maxb).astype(np.int32)
+    slots = np.array([bt[i][(l - 1) // BS] * BS + (l - 1) % BS for i, l in enumerate(seq_lens)], np.int64)
+    kc0 = t(rng.standard_normal((NB, Hkv, D // 8, BS, 8)).astype(np.float32) * 0.3, torch.float16)
+    vc0 = t(rng.standard_normal((NB, Hkv, D, BS)).astype(np.float32) * 0.3, torch.float16)
+    slabs = t(rng.standard_normal((2, S, (Hq + 2 * Hkv) * D)).astype(np.float32) * 0.4)
+    pos = t((seq_lens - 1).astype(np.int64))
+    cos_sin = t(rng.standard_normal((1400, D)).astype(np.float32), torch.float16)
+    res = {}
+    old = os.environ.get("APHRO_PA_SPLITS")
+    try:
+        for sp in (1, 4):
+            os.environ["APHRO_PA_SPLITS"] = str(sp)
+            kc, vc = kc0.clone(), vc0.clone()
+            packed, out = ops.paged_attention_rope_packed(slabs, pos, cos_sin, t(slots), kc, vc, Hq, Hkv, 0.09, t(bt),
+                                                          t(seq_lens), BS, int(seq_lens.max()), None, "auto", 1.0, 1.0, want_out=True)
+            res[sp] = (kc, vc, out)
+    finally:
+        if old is None:
+            os.environ.pop("APHRO_PA_SPLITS", None)
+        else:
+            os.environ["APHRO_PA_SPLITS"] = old
+    assert torch.equal(res[1][0], res[4][0]) and torch.equal(res[1][1], res[4][1])
+    np.testing.assert_allclose(res[4][2].float().cpu().numpy(), res[1][2].float().cpu().numpy(), atol=1e-3, rtol=1e-5)

@@ -249,3 +249,53 @@ def test_reference_custom_ops_wrappers_bind_to_our_schemas():
 if __name__ == "__main__":   # regenerate the committed call list (build container only)
     json.dump(_wrapper_calls(), open(GOLDEN, "w"), indent=1, sort_keys=True)
     print("wrote", GOLDEN)
+
+
+@needs_ref
+def test_fused_model_registers_through_the_reference_model_registry(monkeypatch):
+    """APHRODITE_MI355X_FUSED_MODEL=1: plugin.register() hands MI355XLlamaForCausalLM to the reference's OWN ModelRegistry
+    (modeling/models/__init__.py loaded by path), whose lookup then resolves the Llama architectures to it; the class is
+    constructed with the keyword arguments ``build_model`` passes (model_loader/loader.py:144-157) and exposes the methods
+    the model runner calls."""
+    saved = {k: v for k, v in sys.modules.items() if k == "aphrodite" or k.startswith("aphrodite.") or k == "loguru"}
+    for k in list(saved):
+        del sys.modules[k]
+    try:
+        class _Log:
+            def __getattr__(self, _):
+                return lambda *a, **k: None
+        _stub("loguru", logger=_Log())
+        _stub("aphrodite")
+        _stub("aphrodite.common")
+        _stub("aphrodite.common.utils", is_hip=lambda: True)
+        _stub("aphrodite.modeling")
+        # quantization seams must exist for register() to get as far as the model hook
+        _stub("aphrodite.quantization", QUANTIZATION_METHODS={})
+        _stub("aphrodite.quantization.kernels", _POSSIBLE_KERNELS=[])
+        reg = _load("aphrodite.modeling.models", "aphrodite/modeling/models/__init__.py")
+        from aphrodite_engine_amd import plugin
+        from aphrodite_engine_amd.reference_model import MI355XLlamaForCausalLM
+        monkeypatch.setenv("APHRODITE_MI355X_FUSED_MODEL", "1")
+        builtin = reg._MODELS["LlamaForCausalLM"]
+        plugin.register()
+        plugin.register()
+        assert reg.ModelRegistry._try_load_model_cls("LlamaForCausalLM") is MI355XLlamaForCausalLM
+        assert reg.ModelRegistry._try_load_model_cls("MistralForCausalLM") is MI355XLlamaForCausalLM
+        assert reg._MODELS["LlamaForCausalLM"] == builtin                   # the built-in table is untouched
+        assert "LlamaForCausalLM" in reg.ModelRegistry.get_supported_archs()
+        # constructed the way build_model does, from a HF-style config object
+        from aphrodite_engine_amd.quantization.gptq import GPTQConfig
+        hf = types.SimpleNamespace(hidden_size=512, intermediate_size=1024, num_hidden_layers=2, num_attention_heads=4,
+                                   num_key_value_heads=2, vocab_size=1024, rms_norm_eps=1e-5, rope_theta=10000.0,
+                                   max_position_embeddings=2048, torch_dtype=torch.float16, tie_word_embeddings=False)
+        cache = types.SimpleNamespace(cache_dtype="auto")
+        m = MI355XLlamaForCausalLM(config=hf, cache_config=cache, quant_config=GPTQConfig(4, 128, False))
+        for name in ("forward", "load_weights", "compute_logits", "sample"):
+            assert callable(getattr(m, name))
+        assert m.inner.layers[0].qkv_proj.qweight.shape == (512 // 8, (4 + 2 * 2) * 128)
+        with pytest.raises(NotImplementedError):
+            MI355XLlamaForCausalLM(config=hf, cache_config=cache, quant_config=None, lora_config=object())
+    finally:
+        for k in [k for k in sys.modules if k == "aphrodite" or k.startswith("aphrodite.") or k == "loguru"]:
+            del sys.modules[k]
+        sys.modules.update(saved)
