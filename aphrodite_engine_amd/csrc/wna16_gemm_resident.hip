@@ -90,9 +90,18 @@ __global__ __launch_bounds__(NWV * 64, NWV <= 4 ? 1 : 2) void wna16_gemm_residen
   RES_STAMP(0);
   // workgroups are dealt round-robin to the 8 XCDs: give every XCD one contiguous run of strips (neighbouring strips
   // share cache lines at their edges when a strip's row piece is not a multiple of 128 bytes)
+  // With K slices (grid.y > 1) all strips of slice y read the same activation rows: slice y goes to 8 / grid.y XCDs, so
+  // that each XCD's L2 fetches only its slice of A (same placement as wna16_gemm.hip's xcd_remap).
   const int S = gridDim.x;
-  const int strip = (S & 7) == 0 ? (int)(blockIdx.x & 7) * (S >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-  const int ky = blockIdx.y;
+  int strip, ky;
+  if (gridDim.y > 1 && 8 % gridDim.y == 0 && S % (8 / gridDim.y) == 0) {
+    const int L = blockIdx.y * S + blockIdx.x, xcd = L & 7, idx = L >> 3, per = 8 / gridDim.y;
+    ky = xcd / per;
+    strip = (xcd % per) * (S / per) + idx;
+  } else {
+    strip = (S & 7) == 0 ? (int)(blockIdx.x & 7) * (S >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    ky = blockIdx.y;
+  }
   const int seg0 = (ky * NWV + wave) * NSEG;
   const int cb = strip * CW;
   const int mtiles = (p.M + 15) >> 4;

@@ -196,6 +196,7 @@ class LlamaDecoderLayer(nn.Module):
         self.tp = tp
         self.gate_up_interleaved = None
         self.gate_up_strip = None
+        self.strip = {}
         self.fuse_rope_attention = True
 
     def enable_fused_silu(self, m: int = 32, keep_original: bool = True) -> bool:
@@ -220,9 +221,37 @@ class LlamaDecoderLayer(nn.Module):
         if m <= 32 and not os.environ.get("APHRO_DECODE_NO_RESIDENT") \
                 and ops.wna16_resident_ksplit(m, lin.out_features, lin.in_features, sc.shape[0]) == 1:
             self.gate_up_strip = ops.wna16_strip_relayout(qw, m, sc.shape[0])
+        self.enable_resident_layouts(m)
         if not keep_original:
             lin.qweight.data, lin.qzeros.data, lin.scales.data = qw, qz, sc
         return True
+
+    def enable_resident_layouts(self, m: int = 32) -> None:
+        """Strip-major copies of the qkv and down weights for the resident kernel at <= 32 rows (same K partition as the
+        round-2 kernel, so the fp32 slabs -- and everything downstream -- are bit-identical; measured 8.2 -> 7.1 us and
+        11.4 -> 10.5 us, profiles/r3_resident_bench.txt).  o_proj stays on the round-2 kernel (5.7 vs 6.0 us)."""
+        self.strip = {}
+        if m > 32 or os.environ.get("APHRO_DECODE_NO_RESIDENT"):
+            return
+        for name in ("qkv_proj", "down_proj"):
+            lin = getattr(self, name, None)
+            fp = lin.fast_params() if lin is not None else None
+            if fp is None:
+                continue
+            qw, qz, sc, zo = fp
+            n, k, g = lin.out_features, lin.in_features, sc.shape[0]
+            # only where the resident plan keeps the round-2 kernel's K slices (the consumers were tuned to those slab counts)
+            if ops.wna16_resident_ksplit(m, n, k, g) == ops.wna16_ksplit(m, n, k, g) and (k // 8) * n * 4 >= 2 ** 23:
+                self.strip[name] = ops.wna16_strip_relayout(qw, m, g)
+
+    def _gemm_slabs(self, name, packed, m, k):
+        """fp32 split-K slabs of projection ``name`` on packed activations: the resident kernel on its strip-major copy at
+        <= 32 rows, else the round-2 kernel."""
+        qw, qz, sc, zo = getattr(self, name).fast_params()
+        st = self.strip.get(name) if m <= 32 else None
+        if st is not None:
+            return ops.wna16_gemm_resident(packed, m, k, st, qz, sc, zo, mode="slabs", strip_layout=True)
+        return ops.wna16_gemm_packed(packed, m, k, qw, qz, sc, zo, partials=True)
 
     def fused_decode_ok(self, m: int) -> bool:
         """Decode fast path (7 launches per layer instead of 17): W4A16 linears in the
@@ -257,8 +286,7 @@ class LlamaDecoderLayer(nn.Module):
         h = self.cfg.hidden_size
         packed, _ = ops.fused_add_rms_norm_pack(x if slabs is None else None, slabs, residual,
                                                 not first, self.input_layernorm, eps)
-        qw, qz, sc, zo = self.qkv_proj.fast_params()
-        qkv_slabs, _ = ops.wna16_gemm_packed(packed, m, h, qw, qz, sc, zo, partials=True)
+        qkv_slabs, _ = self._gemm_slabs("qkv_proj", packed, m, h)
         from .attention.paged_attn import PagedAttention
         key_cache, value_cache = PagedAttention.split_kv_cache(kv_cache, self.num_kv_heads, self.head_dim)
         if self.head_dim == 128 and self.fuse_rope_attention:
@@ -331,7 +359,7 @@ class LlamaDecoderLayer(nn.Module):
         if mid and qw.shape[1] * kd >= 2 ** 25 and ops.wna16_gemm_mid_ksplit(m, qw.shape[1], kd, sc.shape[0]) > 0:
             down_slabs, _ = ops.wna16_gemm_mid_packed(act_packed, m, kd, qw, qz, sc, zo, partials=True)
         else:
-            down_slabs, _ = ops.wna16_gemm_packed(act_packed, m, kd, qw, qz, sc, zo, partials=True)
+            down_slabs, _ = self._gemm_slabs("down_proj", act_packed, m, kd)
         return None, down_slabs
 
     # -- FP8 W8A8 (per-token dynamic activations) decode fast path -------------------------------

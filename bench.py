@@ -246,10 +246,13 @@ def roofline_section(model, loop, args):
                             ops.wna16_gemm_resident(packed, bs, k, layer.gate_up_strip, qz, sc, zo, mode="silu", strip_layout=True)
                         else:
                             (ops.wna16_gemm_mid_silu_pack if mid else ops.wna16_gemm_silu_pack)(packed, bs, k, qw, qz, sc, zo)
-                    else:
+                    elif mid:
                         qw, qz, sc, zo = getattr(layer, name).fast_params()
-                        (ops.wna16_gemm_mid_packed if mid else ops.wna16_gemm_packed)(packed, bs, k, qw, qz, sc, zo, partials=True)
-            kname = ("wna16_gemm_mid_kernel" if mid else "wna16_gemm_resident_kernel (strip-major weights)" if resident
+                        ops.wna16_gemm_mid_packed(packed, bs, k, qw, qz, sc, zo, partials=True)
+                    else:
+                        layer._gemm_slabs(name, packed, bs, k)      # resident kernel on the strip-major copy where the layer has one
+            res_slabs = (not silu) and (not mid) and bs <= 32 and name in getattr(layers[0], "strip", {})
+            kname = ("wna16_gemm_mid_kernel" if mid else "wna16_gemm_resident_kernel (strip-major weights)" if (resident or res_slabs)
                      else "wna16_gemm_kernel") + (" (+SiluAndMul epilogue)" if silu else "")
         elif args.quant == "fp8ct" and getattr(model, "use_fused_decode", False):
             # the FP8 decode fast path hands every GEMM pre-quantised activations (the quantisation is fused into the norm /

@@ -30,7 +30,10 @@ for name, (k, n) in shapes.items():
             ops.wna16_gemm_resident(a, bs, k, strip, qz, sc, 1, mode="silu", strip_layout=True)   # what the step launches
             ops.wna16_gemm_mid_silu_pack(a64, 64, k, qw, qz, sc, 1)               # bs 64
         else:
-            ops.wna16_gemm_packed(a, bs, k, qw, qz, sc, 1, partials=True)
+            ops.wna16_gemm_packed(a, bs, k, qw, qz, sc, 1, partials=True)       # round-2 kernel (o_proj in the step; fallback elsewhere)
+            if name in ("down", "qkv"):                                          # what the step launches at <= 32 rows
+                strip = ops.wna16_strip_relayout(qw, bs, k // 128)
+                ops.wna16_gemm_resident(a, bs, k, strip, qz, sc, 1, mode="slabs", strip_layout=True)
             if name == "down":
                 ops.wna16_gemm_mid_packed(a64, 64, k, qw, qz, sc, 1, partials=True)
 # fused attention + norms
