@@ -51,7 +51,7 @@ def main():
         ("qkv_proj", r"wna16_gemm_resident_kernel<2, 4, 4, 1, 0", *gemm_alg(4096, 6144, out_bytes=2 * M * 6144 * 4)),
         ("qkv_proj (round-2 kernel)", r"wna16_gemm_kernel<aphro::Half, 4, 2, 4>", *gemm_alg(4096, 6144, out_bytes=2 * M * 6144 * 4)),
         ("o_proj", r"wna16_gemm_kernel<aphro::Half, 4, 2, 2>", *gemm_alg(4096, 4096, out_bytes=4 * M * 4096 * 4)),
-        ("paged_attention", r"paged_attention_kernel<aphro::Half, 0, 128, 16, 8, 1>", kv + 2 * bs * 6144 * 4, bs * 4096 * 2 + bs * 2 * 8 * 128 * 2),
+        ("paged_attention", r"paged_attention_kernel<aphro::Half, 0, 128, 16, 8, 1", kv + 2 * bs * 6144 * 4, bs * 4096 * 2 + bs * 2 * 8 * 128 * 2),
         ("add_rms_norm_pack", r"add_rms_norm_pack_kernel", 4 * M * 4096 * 4 + M * 4096 * 2, 2 * M * 4096 * 2),
         ("gate_up_proj bs64 (mid kernel)", r"wna16_gemm_mid_kernel<2, 8, true>", *gemm_alg(4096, 28672, m=64, out_bytes=64 * 14336 * 2)),
         ("down_proj bs64 (mid kernel)", r"wna16_gemm_mid_kernel<2, 4, true>", *gemm_alg(14336, 4096, m=64, out_bytes=0)),
