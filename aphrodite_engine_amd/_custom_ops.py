@@ -215,8 +215,10 @@ def flash_attn_varlen(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor,
     return out
 
 
-# sequences (context + new tokens) at least this long take the gathered-context path of context_attention_fwd
-CONTEXT_ATTN_GATHER_MIN_LEN = 1024
+# context_attention_fwd without host-side length hints: a workspace bound of new tokens + block-table capacity per sequence
+# is used without a device sync while it stays below this many bytes
+CONTEXT_ATTN_NOSYNC_WS_BYTES = 256 << 20
+CONTEXT_ATTN_GATHER_MIN_LEN = 1024     # (kept for callers that imported it: the third-generation kernel's threshold)
 
 
 def context_attention_fwd(q, k, v, o, kv_cache_dtype: str, k_cache, v_cache, b_loc, b_start_loc,
@@ -246,25 +248,29 @@ def context_attention_fwd(q, k, v, o, kv_cache_dtype: str, k_cache, v_cache, b_l
         slopes = alibi_slopes.to(device=q.device, dtype=torch.float32).contiguous()
     win = int(sliding_window) if sliding_window is not None and sliding_window > 0 else 0
     lib = _lib.lib()
-    if head_size == 128 and win == 0 and not os.environ.get("APHRO_CA_NO_GATHER"):
-        # long prompts: gather the cached context once, then the third-generation prefill kernel over context + new
-        # tokens.  The caller may pass the host-side maxima (the attention metadata has them); otherwise one sync.
+    if head_size in (64, 96, 128, 256) and not os.environ.get("APHRO_CA_NO_GATHER"):
+        # gather the cached context once, then the prefill tile machines over context + new tokens (every head size, ALiBi,
+        # sliding window: round 3).  The caller passes the host-side maxima when it has them (the attention metadata does);
+        # without them a host-side bound -- new tokens + block-table capacity per sequence -- sizes the workspace when that
+        # stays small, else one sync.
         if max_seq_len is not None and total_kv_tokens is not None:
             msl, tot = int(max_seq_len), int(total_kv_tokens)
-        elif int(max_input_len) + b_loc.shape[1] * v_cache.shape[3] < CONTEXT_ATTN_GATHER_MIN_LEN:
-            msl = tot = 0     # host-side bound (new tokens + block-table capacity): cannot reach the long path, no sync
         else:
-            msl, tot = int(b_seq_len.max().item()), int(b_seq_len.sum().item())
-        if msl >= CONTEXT_ATTN_GATHER_MIN_LEN:
-            ws = _workspace(q.device, lib.aphro_context_attention_workspace_bytes(tot, batch, k.shape[1], head_size))
-            check(lib.aphro_context_attention_gathered(
-                o.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(),
-                b_loc.data_ptr(), b_start_loc.data_ptr(), b_seq_len.data_ptr(), b_ctx_len.data_ptr(), batch,
-                int(max_input_len), msl, tot, b_loc.shape[1], q.shape[1], k.shape[1], head_size, v_cache.shape[3],
-                k_cache.shape[4], q.stride(0), k.stride(0), v.stride(0), o.stride(0), head_size ** -0.5,
-                float(k_scale), float(v_scale), _ptr(slopes), _dt(q), _kv(kv_cache_dtype), ws.data_ptr(), ws.numel(),
-                _stream()), "context_attention_fwd")
-            return
+            cap = int(max_input_len) + b_loc.shape[1] * v_cache.shape[3]
+            if batch * cap * k.shape[1] * head_size * 4 <= CONTEXT_ATTN_NOSYNC_WS_BYTES:
+                msl, tot = cap, batch * cap
+            else:
+                msl, tot = int(b_seq_len.max().item()), int(b_seq_len.sum().item())
+        ws = _workspace(q.device, lib.aphro_context_attention_workspace_bytes(tot, batch, k.shape[1], head_size))
+        check(lib.aphro_context_attention_gathered(
+            o.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(),
+            b_loc.data_ptr(), b_start_loc.data_ptr(), b_seq_len.data_ptr(), b_ctx_len.data_ptr(), batch,
+            int(max_input_len), msl, tot, b_loc.shape[1], q.shape[1], k.shape[1], head_size, v_cache.shape[3],
+            k_cache.shape[4], q.stride(0), k.stride(0), v.stride(0), o.stride(0), head_size ** -0.5,
+            float(k_scale), float(v_scale), _ptr(slopes), win, _dt(q), _kv(kv_cache_dtype), ws.data_ptr(), ws.numel(),
+            _stream()), "context_attention_fwd")
+        return
+    # first-round kernel (scalar cache gathers): kept for head sizes the tile machines do not serve and for A/B runs
     check(lib.aphro_context_attention(
         o.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(),
         b_loc.data_ptr(), b_start_loc.data_ptr(), b_seq_len.data_ptr(), b_ctx_len.data_ptr(), batch,

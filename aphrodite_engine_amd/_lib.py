@@ -109,9 +109,9 @@ SIGNATURES = {
     "aphro_context_attention_workspace_bytes": (Z, [L, I, I, I]),
     # out q k v k_cache v_cache block_tables q_start_loc seq_lens ctx_lens | batch max_query_len max_seq_len | total_kv_tokens |
     # max_blocks num_heads num_kv_heads head_size block_size x | 4 strides | scale k_scale v_scale | alibi | dtype kv_dtype |
-    # workspace bytes stream
+    # workspace bytes stream   (round 3: sliding_window before dtype)
     "aphro_context_attention_gathered": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, L, I, I, I, I, I, I, L, L, L, L,
-                                             F, F, F, P, I, I, P, Z, P]),
+                                             F, F, F, P, I, I, I, P, Z, P]),
 }
 
 OK = 0

@@ -33,6 +33,7 @@ struct FAParams {
   int nqt_max, xcd_remap;   // third-generation kernel: query tiles per sequence in the grid; kv-head -> XCD placement
   const int32_t* cu_seqlens_k;   // third-generation kernel: key rows per sequence when they differ from the query rows
   int64_t o_stride;              // ... and the output row stride (elements)
+  int window;                    // first / second generation kernels: sliding window (keys > query position - window), 0 = off
 };
 
 template <typename T>
@@ -75,10 +76,16 @@ __global__ __launch_bounds__(256) void flash_attn_varlen_kernel(FAParams p) {
   const int head = blockIdx.y;
   const int seq = blockIdx.z;
   const int kvh = head / (p.num_heads / p.num_kv_heads);
+  // query rows [s0, s0 + qlen) of q / out; key rows [k0, k0 + len) of k / v.  With cu_seqlens_k (prefill over a cached
+  // context, gathered into contiguous rows) the keys are context + new tokens and query row i sits at key position i + off.
   const int s0 = p.cu_seqlens[seq];
-  const int len = p.cu_seqlens[seq + 1] - s0;
+  const int qlen = p.cu_seqlens[seq + 1] - s0;
+  const int k0 = p.cu_seqlens_k ? p.cu_seqlens_k[seq] : s0;
+  const int len = p.cu_seqlens_k ? p.cu_seqlens_k[seq + 1] - k0 : qlen;
+  const int off = len - qlen;
+  const int win = p.window;
   // heavy (late) tiles first: better tail balance under the causal triangle
-  const int ntiles = (len + BM - 1) / BM;
+  const int ntiles = (qlen + BM - 1) / BM;
   const int tile = ntiles - 1 - (int)blockIdx.x;
   if (tile < 0) return;
   const int q0 = tile * BM;
@@ -91,7 +98,7 @@ __global__ __launch_bounds__(256) void flash_attn_varlen_kernel(FAParams p) {
   u32x4 qf[QT][NKS];
 #pragma unroll
   for (int t = 0; t < QT; ++t) {
-    const uint16_t* qp = (const uint16_t*)p.q + (size_t)(s0 + min(qrow[t], len - 1)) * p.q_stride + (size_t)head * HD;
+    const uint16_t* qp = (const uint16_t*)p.q + (size_t)(s0 + min(qrow[t], qlen - 1)) * p.q_stride + (size_t)head * HD;
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) qf[t][ks] = *reinterpret_cast<const u32x4*>(qp + 32 * ks + 8 * g);
   }
@@ -109,11 +116,13 @@ __global__ __launch_bounds__(256) void flash_attn_varlen_kernel(FAParams p) {
     l_run[t] = 0.f;
   }
 
-  const int kv_end = p.causal ? min(len, q0 + BM) : len;
-  const uint16_t* kbase = (const uint16_t*)p.k + (size_t)s0 * p.k_stride + (size_t)kvh * HD;
-  const uint16_t* vbase = (const uint16_t*)p.v + (size_t)s0 * p.v_stride + (size_t)kvh * HD;
+  const int kv_end = p.causal ? min(len, q0 + BM + off) : len;
+  // sliding window: the first key any row of this workgroup can see
+  const int kv_begin = win > 0 ? max(0, q0 + off - win + 1) / FA_BN * FA_BN : 0;
+  const uint16_t* kbase = (const uint16_t*)p.k + (size_t)k0 * p.k_stride + (size_t)kvh * HD;
+  const uint16_t* vbase = (const uint16_t*)p.v + (size_t)k0 * p.v_stride + (size_t)kvh * HD;
 
-  for (int t0 = 0; t0 < kv_end; t0 += FA_BN) {
+  for (int t0 = kv_begin; t0 < kv_end; t0 += FA_BN) {
     // ---- stage K (swizzled) and V^T into LDS -------------------------------------
     // (prefetching the next tile into registers across the compute phase was measured SLOWER:
     //  247 -> 181 TFLOP/s at T = 8192 -- the extra live registers cost more than the latency)
@@ -130,7 +139,7 @@ __global__ __launch_bounds__(256) void flash_attn_varlen_kernel(FAParams p) {
     }
     __syncthreads();
     // a wave whose rows all precede this tile (causal) has nothing to add
-    const bool wave_active = !p.causal || (t0 <= wq0 + 16 * QT - 1);
+    const bool wave_active = !p.causal || (t0 <= wq0 + 16 * QT - 1 + off);
     if (wave_active) {
       // ---- S^T = K . Q^T : one K fragment read feeds the QT query tiles --------------
       f32x4 s[QT][2];
@@ -152,7 +161,7 @@ __global__ __launch_bounds__(256) void flash_attn_varlen_kernel(FAParams p) {
       // every row of the wave, no ALiBi) skip the mask and bias arithmetic; the O rescale is skipped
       // when no lane's running maximum moved (alpha == 1 everywhere).
       u32x4 pf[QT];
-      const bool edge = (t0 + FA_BN > len) || (p.causal && t0 + FA_BN - 1 > wq0) || slope != 0.f;
+      const bool edge = (t0 + FA_BN > len) || (p.causal && t0 + FA_BN - 1 > wq0 + off) || slope != 0.f || win > 0;
 #pragma unroll
       for (int t = 0; t < QT; ++t) {
         float pv[2][4];
@@ -163,8 +172,8 @@ __global__ __launch_bounds__(256) void flash_attn_varlen_kernel(FAParams p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const int tok = t0 + 16 * h + 4 * g + r;
-              float x = s[t][h][r] * sc2 + slope2 * (float)(tok - qrow[t]);
-              const bool ok = tok < len && (!p.causal || tok <= qrow[t]);
+              float x = s[t][h][r] * sc2 + slope2 * (float)(tok - qrow[t] - off);
+              const bool ok = tok < len && (!p.causal || tok <= qrow[t] + off) && (win <= 0 || tok > qrow[t] + off - win);
               x = ok ? x : -1e30f;
               pv[h][r] = x;
               mx = __builtin_fmaxf(mx, x);
@@ -224,9 +233,9 @@ __global__ __launch_bounds__(256) void flash_attn_varlen_kernel(FAParams p) {
     float l = l_run[t];
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
-    if (qrow[t] < len) {
+    if (qrow[t] < qlen) {
       const float inv = l > 0.f ? 1.f / l : 0.f;
-      typename T::storage* op = (typename T::storage*)p.out + ((size_t)(s0 + qrow[t]) * p.num_heads + head) * HD;
+      typename T::storage* op = (typename T::storage*)p.out + (size_t)(s0 + qrow[t]) * p.o_stride + (size_t)head * HD;
 #pragma unroll
       for (int dt = 0; dt < NDT; ++dt) {
         u16x4 r = {T::from_f32(o[t][dt][0] * inv), T::from_f32(o[t][dt][1] * inv), T::from_f32(o[t][dt][2] * inv),
@@ -267,9 +276,15 @@ __global__ __launch_bounds__(NWV * 64) void flash_attn_varlen_v2_kernel(FAParams
   const int head = blockIdx.y;
   const int seq = blockIdx.z;
   const int kvh = head / (p.num_heads / p.num_kv_heads);
+  // query rows [s0, s0 + qlen) of q / out; key rows [k0, k0 + len) of k / v.  With cu_seqlens_k (prefill over a cached
+  // context, gathered into contiguous rows) the keys are context + new tokens and query row i sits at key position i + off.
   const int s0 = p.cu_seqlens[seq];
-  const int len = p.cu_seqlens[seq + 1] - s0;
-  const int ntiles = (len + BM - 1) / BM;
+  const int qlen = p.cu_seqlens[seq + 1] - s0;
+  const int k0 = p.cu_seqlens_k ? p.cu_seqlens_k[seq] : s0;
+  const int len = p.cu_seqlens_k ? p.cu_seqlens_k[seq + 1] - k0 : qlen;
+  const int off = len - qlen;
+  const int win = p.window;
+  const int ntiles = (qlen + BM - 1) / BM;
   const int tile = ntiles - 1 - (int)blockIdx.x;   // heavy (late) tiles first
   if (tile < 0) return;
   const int q0 = tile * BM;
@@ -281,7 +296,7 @@ __global__ __launch_bounds__(NWV * 64) void flash_attn_varlen_v2_kernel(FAParams
   u32x4 qf[QT][NKS];
 #pragma unroll
   for (int t = 0; t < QT; ++t) {
-    const uint16_t* qp = (const uint16_t*)p.q + (size_t)(s0 + min(qrow[t], len - 1)) * p.q_stride + (size_t)head * HD;
+    const uint16_t* qp = (const uint16_t*)p.q + (size_t)(s0 + min(qrow[t], qlen - 1)) * p.q_stride + (size_t)head * HD;
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) qf[t][ks] = *reinterpret_cast<const u32x4*>(qp + 32 * ks + 8 * g);
   }
@@ -299,9 +314,11 @@ __global__ __launch_bounds__(NWV * 64) void flash_attn_varlen_v2_kernel(FAParams
     l_run[t] = 0.f;
   }
 
-  const int kv_end = p.causal ? min(len, q0 + BM) : len;
-  const uint16_t* kbase = (const uint16_t*)p.k + (size_t)s0 * p.k_stride + (size_t)kvh * HD;
-  const uint16_t* vbase = (const uint16_t*)p.v + (size_t)s0 * p.v_stride + (size_t)kvh * HD;
+  const int kv_end = p.causal ? min(len, q0 + BM + off) : len;
+  // sliding window: the first key any row of this workgroup can see
+  const int kv_begin = win > 0 ? max(0, q0 + off - win + 1) / FA2_BN * FA2_BN : 0;
+  const uint16_t* kbase = (const uint16_t*)p.k + (size_t)k0 * p.k_stride + (size_t)kvh * HD;
+  const uint16_t* vbase = (const uint16_t*)p.v + (size_t)k0 * p.v_stride + (size_t)kvh * HD;
   // per-lane part of the transposing V read: row (i / 4), 4 columns at 4 * (i % 4)
   const int vtr_off = (4 * g + (c >> 2)) * VS + 4 * (c & 3);
 
@@ -322,8 +339,8 @@ __global__ __launch_bounds__(NWV * 64) void flash_attn_varlen_v2_kernel(FAParams
       vreg[q] = *reinterpret_cast<const u32x4*>(vbase + (size_t)ta * p.v_stride + 8 * ch);
     }
   };
-  fetch(0);
-  for (int t0 = 0; t0 < kv_end; t0 += FA2_BN) {
+  fetch(kv_begin);
+  for (int t0 = kv_begin; t0 < kv_end; t0 += FA2_BN) {
     __syncthreads();  // previous tile's readers are done
 #pragma unroll
     for (int q = 0; q < CPT; ++q) {
@@ -336,13 +353,13 @@ __global__ __launch_bounds__(NWV * 64) void flash_attn_varlen_v2_kernel(FAParams
     }
     __syncthreads();
     if (t0 + FA2_BN < kv_end) fetch(t0 + FA2_BN);
-    const bool wave_active = !p.causal || (t0 <= wq0 + 16 * QT - 1);
+    const bool wave_active = !p.causal || (t0 <= wq0 + 16 * QT - 1 + off);
     if (wave_active) {
-      const bool edge = (t0 + FA2_BN > len) || (p.causal && t0 + FA2_BN - 1 > wq0) || slope != 0.f;
+      const bool edge = (t0 + FA2_BN > len) || (p.causal && t0 + FA2_BN - 1 > wq0 + off) || slope != 0.f || win > 0;
 #pragma unroll
       for (int pr = 0; pr < 2; ++pr) {          // two 32-key halves of the tile
         const int tb = t0 + 32 * pr;
-        if (p.causal && tb > wq0 + 16 * QT - 1) break;   // wave-uniform: this half is entirely masked
+        if (p.causal && tb > wq0 + 16 * QT - 1 + off) break;   // wave-uniform: this half is entirely masked
         // ---- S^T = K . Q^T ------------------------------------------------------------
         f32x4 s[QT][2];
 #pragma unroll
@@ -370,8 +387,8 @@ __global__ __launch_bounds__(NWV * 64) void flash_attn_varlen_v2_kernel(FAParams
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
                 const int tok = tb + 16 * h + 4 * g + r;
-                float x = s[t][h][r] * sc2 + slope2 * (float)(tok - qrow[t]);
-                const bool ok = tok < len && (!p.causal || tok <= qrow[t]);
+                float x = s[t][h][r] * sc2 + slope2 * (float)(tok - qrow[t] - off);
+                const bool ok = tok < len && (!p.causal || tok <= qrow[t] + off) && (win <= 0 || tok > qrow[t] + off - win);
                 x = ok ? x : -1e30f;
                 pv[h][r] = x;
                 mx = __builtin_fmaxf(mx, x);
@@ -431,9 +448,9 @@ __global__ __launch_bounds__(NWV * 64) void flash_attn_varlen_v2_kernel(FAParams
     float l = l_run[t];
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
-    if (qrow[t] < len) {
+    if (qrow[t] < qlen) {
       const float inv = l > 0.f ? 1.f / l : 0.f;
-      typename T::storage* op = (typename T::storage*)p.out + ((size_t)(s0 + qrow[t]) * p.num_heads + head) * HD;
+      typename T::storage* op = (typename T::storage*)p.out + (size_t)(s0 + qrow[t]) * p.o_stride + (size_t)head * HD;
 #pragma unroll
       for (int dt = 0; dt < NDT; ++dt) {
         u16x4 r = {T::from_f32(o[t][dt][0] * inv), T::from_f32(o[t][dt][1] * inv), T::from_f32(o[t][dt][2] * inv),
@@ -1082,30 +1099,31 @@ __global__ __launch_bounds__(512) void ca_gather_kernel(CAParams p, const int32_
                                                         uint16_t* __restrict__ kc_out, uint16_t* __restrict__ vc_out, int hd) {
   const int seq = blockIdx.z, h = blockIdx.y;
   const int tok = blockIdx.x * 32 + (threadIdx.x & 31);
-  const int chunk = threadIdx.x >> 5;                 // d = 8 chunk .. + 7
   const int total = p.seq_lens[seq];
-  if (tok >= total || chunk * 8 >= hd) return;
+  if (tok >= total) return;
   const int ctx = p.ctx_lens[seq];
-  const size_t orow = ((size_t)(cu_k[seq] + tok) * p.num_kv_heads + h) * hd + chunk * 8;
-  u16x8 kk, vv;
-  if (tok < ctx) {
-    const int64_t blk = p.block_tables[(size_t)seq * p.max_blocks + tok / p.block_size];
-    const int boff = tok % p.block_size;
+  for (int chunk = threadIdx.x >> 5; chunk * 8 < hd; chunk += 16) {      // d = 8 chunk .. + 7 (head 256: two trips)
+    const size_t orow = ((size_t)(cu_k[seq] + tok) * p.num_kv_heads + h) * hd + chunk * 8;
+    u16x8 kk, vv;
+    if (tok < ctx) {
+      const int64_t blk = p.block_tables[(size_t)seq * p.max_blocks + tok / p.block_size];
+      const int boff = tok % p.block_size;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int d = chunk * 8 + j;
-      const int64_t ki = (((blk * p.num_kv_heads + h) * (hd / p.x) + d / p.x) * p.block_size + boff) * p.x + d % p.x;
-      const int64_t vi = ((blk * p.num_kv_heads + h) * hd + d) * p.block_size + boff;
-      kk[j] = cache_elem_to_t<T, KV>(p.k_cache, ki, p.k_scale);
-      vv[j] = cache_elem_to_t<T, KV>(p.v_cache, vi, p.v_scale);
+      for (int j = 0; j < 8; ++j) {
+        const int d = chunk * 8 + j;
+        const int64_t ki = (((blk * p.num_kv_heads + h) * (hd / p.x) + d / p.x) * p.block_size + boff) * p.x + d % p.x;
+        const int64_t vi = ((blk * p.num_kv_heads + h) * hd + d) * p.block_size + boff;
+        kk[j] = cache_elem_to_t<T, KV>(p.k_cache, ki, p.k_scale);
+        vv[j] = cache_elem_to_t<T, KV>(p.v_cache, vi, p.v_scale);
+      }
+    } else {
+      const size_t row = (size_t)(p.q_start_loc[seq] + tok - ctx);
+      kk = *reinterpret_cast<const u16x8*>((const uint16_t*)p.k + row * p.k_stride + (size_t)h * hd + chunk * 8);
+      vv = *reinterpret_cast<const u16x8*>((const uint16_t*)p.v + row * p.v_stride + (size_t)h * hd + chunk * 8);
     }
-  } else {
-    const size_t row = (size_t)(p.q_start_loc[seq] + tok - ctx);
-    kk = *reinterpret_cast<const u16x8*>((const uint16_t*)p.k + row * p.k_stride + (size_t)h * hd + chunk * 8);
-    vv = *reinterpret_cast<const u16x8*>((const uint16_t*)p.v + row * p.v_stride + (size_t)h * hd + chunk * 8);
+    *reinterpret_cast<u16x8*>(kc_out + orow) = kk;
+    *reinterpret_cast<u16x8*>(vc_out + orow) = vv;
   }
-  *reinterpret_cast<u16x8*>(kc_out + orow) = kk;
-  *reinterpret_cast<u16x8*>(vc_out + orow) = vv;
 }
 
 extern "C" int aphro_context_attention(void* out, const void* q, const void* k, const void* v, const void* k_cache,
@@ -1151,6 +1169,58 @@ extern "C" int aphro_context_attention(void* out, const void* q, const void* k, 
 }
 
 
+// One dispatcher for the three prefill kernel generations (p fully set up except nqt_max / xcd_remap): third generation
+// for head 128, sequences >= 1024, no sliding window; second for head 64 / 128 (always when the keys carry a context
+// offset: its 64-key tiles are what the gathered-context path wants); first generation for the rest.
+static int fa_dispatch(FAParams p, int head_size, int dtype, int batch, int max_query_len, int max_key_len, hipStream_t st) {
+  if (head_size == 128 && max_key_len >= 1024 && p.window <= 0 && !getenv("APHRO_FA_NO_V3")) {
+    p.nqt_max = (max_query_len + 255) / 256;
+    p.xcd_remap = (batch * p.num_kv_heads) % 8 == 0 && !getenv("APHRO_FA_NO_XCD");
+    dim3 grid3((unsigned)(p.nqt_max * p.num_heads * batch));
+    static bool attr_set_dev[APHRO_MAX_DEVICES] = {}; bool& attr_set = attr_set_dev[device_slot()];
+    if (!attr_set) {
+      if (hipFuncSetAttribute((const void*)flash_attn_varlen_v3_kernel<Half>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840) != hipSuccess ||
+          hipFuncSetAttribute((const void*)flash_attn_varlen_v3_kernel<BFloat>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840) != hipSuccess) {
+        set_error("flash attention: cannot raise the dynamic LDS limit");
+        return APHRO_ERR_LAUNCH;
+      }
+      attr_set = true;
+    }
+    if (dtype == APHRO_F16) hipLaunchKernelGGL((flash_attn_varlen_v3_kernel<Half>), grid3, dim3(512), 163840, st, p);
+    else hipLaunchKernelGGL((flash_attn_varlen_v3_kernel<BFloat>), grid3, dim3(512), 163840, st, p);
+    APHRO_LAUNCH_CHECK();
+    return APHRO_OK;
+  }
+  p.nqt_max = 0; p.xcd_remap = 0;
+  // two 16-row query tiles per wave (128-row workgroups) once the sequences are long enough to
+  // fill the chip with them; head 256 keeps one tile (registers)
+  const bool offset_keys = p.cu_seqlens_k != nullptr;
+  const int qt = ((max_query_len >= 512 || (offset_keys && max_query_len >= 128)) && head_size <= 128 && !getenv("APHRO_FA_QT1")) ? 2 : 1;
+  dim3 grid((unsigned)((max_query_len + 64 * qt - 1) / (64 * qt)), (unsigned)p.num_heads, (unsigned)batch);
+  const bool v2 = qt == 2 && (head_size == 64 || head_size == 128) && !getenv("APHRO_FA_V1");
+  // 256-row (8-wave) workgroups measured slower at T = 8192 (376 vs 413 TFLOP/s): opt-in only
+  const bool v2w8 = v2 && head_size == 128 && getenv("APHRO_FA_W8") != nullptr;
+  if (v2w8) grid.x = (unsigned)((max_query_len + 255) / 256);
+#define FA_L(TT, HDV) { if (v2w8) hipLaunchKernelGGL((flash_attn_varlen_v2_kernel<TT, 128, 2, 8>), grid, dim3(512), 0, st, p); \
+                        else if (v2) hipLaunchKernelGGL((flash_attn_varlen_v2_kernel<TT, (HDV == 64 ? 64 : 128), 2, 4>), grid, dim3(256), 0, st, p); \
+                        else if (qt == 2) hipLaunchKernelGGL((flash_attn_varlen_kernel<TT, HDV, (HDV <= 128 ? 2 : 1)>), grid, dim3(256), 0, st, p); \
+                        else hipLaunchKernelGGL((flash_attn_varlen_kernel<TT, HDV, 1>), grid, dim3(256), 0, st, p); }
+#define FA_T(HDV) if (dtype == APHRO_F16) FA_L(Half, HDV) else FA_L(BFloat, HDV)
+  switch (head_size) {
+    case 64: FA_T(64) break;
+    case 96: FA_T(96) break;
+    case 128: FA_T(128) break;
+    case 256: FA_T(256) break;
+    default:
+      set_error("flash attention: unsupported head_size=%d", head_size);
+      return APHRO_ERR_INVALID;
+  }
+#undef FA_T
+#undef FA_L
+  APHRO_LAUNCH_CHECK();
+  return APHRO_OK;
+}
+
 // Scratch of aphro_context_attention_gathered: the gathered K and V rows of every sequence (context + new tokens) in
 // the query type, plus the key-row offsets.
 extern "C" size_t aphro_context_attention_workspace_bytes(int64_t total_kv_tokens, int batch, int num_kv_heads, int head_size) {
@@ -1158,18 +1228,22 @@ extern "C" size_t aphro_context_attention_workspace_bytes(int64_t total_kv_token
 }
 
 // Same arguments as aphro_context_attention plus: max_seq_len = max(seq_lens) (context + new), total_kv_tokens >=
-// sum(seq_lens), workspace.  head_size 128, no sliding window (the caller falls back to aphro_context_attention).
+// sum(seq_lens), workspace.  Head sizes 64 / 96 / 128 / 256, ALiBi, sliding window: the context is gathered once and the
+// prefill tile machines run over context + new tokens (third generation for head 128 / >= 1024 keys / no window, second
+// for head 64 / 128, first for the rest) -- round 3: the scalar-gather aphro_context_attention kernel is no longer on any
+// path the Python op takes.
 extern "C" int aphro_context_attention_gathered(void* out, const void* q, const void* k, const void* v, const void* k_cache,
                                                 const void* v_cache, const int32_t* block_tables, const int32_t* q_start_loc,
                                                 const int32_t* seq_lens, const int32_t* ctx_lens, int batch, int max_query_len,
                                                 int max_seq_len, int64_t total_kv_tokens, int max_blocks, int num_heads,
                                                 int num_kv_heads, int head_size, int block_size, int x, int64_t q_stride,
                                                 int64_t k_stride, int64_t v_stride, int64_t o_stride, float scale, float k_scale,
-                                                float v_scale, const float* alibi_slopes, int dtype, int kv_dtype,
-                                                void* workspace, size_t workspace_bytes, void* stream) {
+                                                float v_scale, const float* alibi_slopes, int sliding_window, int dtype,
+                                                int kv_dtype, void* workspace, size_t workspace_bytes, void* stream) {
   APHRO_CHECK(dtype == APHRO_F16 || dtype == APHRO_BF16, "context_attention: dtype must be f16 or bf16");
   APHRO_CHECK(kv_dtype >= APHRO_KV_AUTO && kv_dtype <= APHRO_KV_FP8_E5M2, "Unsupported data type of kv cache: %d", kv_dtype);
-  APHRO_CHECK(head_size == 128, "context_attention_gathered: head_size 128 only");
+  APHRO_CHECK(head_size == 64 || head_size == 96 || head_size == 128 || head_size == 256,
+              "context_attention_gathered: head_size %d (64 / 96 / 128 / 256)", head_size);
   APHRO_CHECK(num_kv_heads > 0 && num_heads % num_kv_heads == 0, "context_attention: bad head counts");
   APHRO_CHECK(q_stride % 8 == 0 && k_stride % 8 == 0 && v_stride % 8 == 0 && o_stride % 8 == 0, "context_attention: strides must be multiples of 8");
   APHRO_CHECK(((uintptr_t)q % 16) == 0 && ((uintptr_t)k % 16) == 0 && ((uintptr_t)v % 16) == 0 && ((uintptr_t)out % 16) == 0,
@@ -1204,23 +1278,8 @@ extern "C" int aphro_context_attention_gathered(void* out, const void* q, const 
   p.out = out; p.q = q; p.k = kc; p.v = vc; p.cu_seqlens = q_start_loc; p.cu_seqlens_k = cu_k; p.alibi = alibi_slopes;
   p.num_heads = num_heads; p.num_kv_heads = num_kv_heads;
   p.q_stride = q_stride; p.k_stride = (int64_t)num_kv_heads * head_size; p.v_stride = p.k_stride; p.o_stride = o_stride;
-  p.scale = scale; p.causal = 1; p.debug = 0;
-  p.nqt_max = (max_query_len + 255) / 256;
-  p.xcd_remap = (batch * num_kv_heads) % 8 == 0 && !getenv("APHRO_FA_NO_XCD");
-  dim3 grid3((unsigned)(p.nqt_max * num_heads * batch));
-  static bool attr_set_dev[APHRO_MAX_DEVICES] = {}; bool& attr_set = attr_set_dev[device_slot()];
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)flash_attn_varlen_v3_kernel<Half>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840) != hipSuccess ||
-        hipFuncSetAttribute((const void*)flash_attn_varlen_v3_kernel<BFloat>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840) != hipSuccess) {
-      set_error("context_attention_gathered: cannot raise the dynamic LDS limit");
-      return APHRO_ERR_LAUNCH;
-    }
-    attr_set = true;
-  }
-  if (dtype == APHRO_F16) hipLaunchKernelGGL((flash_attn_varlen_v3_kernel<Half>), grid3, dim3(512), 163840, st, p);
-  else hipLaunchKernelGGL((flash_attn_varlen_v3_kernel<BFloat>), grid3, dim3(512), 163840, st, p);
-  APHRO_LAUNCH_CHECK();
-  return APHRO_OK;
+  p.scale = scale; p.causal = 1; p.debug = 0; p.window = sliding_window > 0 ? sliding_window : 0;
+  return fa_dispatch(p, head_size, dtype, batch, max_query_len, max_seq_len, st);
 }
 
 
@@ -1239,53 +1298,8 @@ extern "C" int aphro_flash_attn_varlen(void* out, const void* q, const void* k, 
   p.num_heads = num_heads; p.num_kv_heads = num_kv_heads;
   p.q_stride = q_stride; p.k_stride = k_stride; p.v_stride = v_stride;
   p.scale = scale; p.causal = causal; p.debug = getenv("APHRO_FA_DEBUG") ? atoi(getenv("APHRO_FA_DEBUG")) : 0;
-  p.cu_seqlens_k = nullptr; p.o_stride = (int64_t)num_heads * head_size; p.nqt_max = 0; p.xcd_remap = 0;
-  // third-generation kernel (256-row workgroups on 32x32 MFMA tiles): head 128, long sequences
-  if (head_size == 128 && max_seqlen >= 1024 && !getenv("APHRO_FA_NO_V3")) {
-    p.nqt_max = (max_seqlen + 255) / 256;
-    const int groups = batch * num_kv_heads;
-    p.xcd_remap = groups % 8 == 0 && !getenv("APHRO_FA_NO_XCD");
-    dim3 grid3((unsigned)(p.nqt_max * num_heads * batch));
-    static bool attr_set_dev[APHRO_MAX_DEVICES] = {}; bool& attr_set = attr_set_dev[device_slot()];
-    if (!attr_set) {
-      if (hipFuncSetAttribute((const void*)flash_attn_varlen_v3_kernel<Half>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840) != hipSuccess ||
-          hipFuncSetAttribute((const void*)flash_attn_varlen_v3_kernel<BFloat>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840) != hipSuccess) {
-        set_error("flash_attn_varlen: cannot raise the dynamic LDS limit");
-        return APHRO_ERR_LAUNCH;
-      }
-      attr_set = true;
-    }
-    if (dtype == APHRO_F16) hipLaunchKernelGGL((flash_attn_varlen_v3_kernel<Half>), grid3, dim3(512), 163840, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL((flash_attn_varlen_v3_kernel<BFloat>), grid3, dim3(512), 163840, (hipStream_t)stream, p);
-    APHRO_LAUNCH_CHECK();
-    return APHRO_OK;
-  }
-  // two 16-row query tiles per wave (128-row workgroups) once the sequences are long enough to
-  // fill the chip with them; head 256 keeps one tile (registers)
-  const int qt = (max_seqlen >= 512 && head_size <= 128 && !getenv("APHRO_FA_QT1")) ? 2 : 1;
-  dim3 grid((unsigned)((max_seqlen + 64 * qt - 1) / (64 * qt)), (unsigned)num_heads, (unsigned)batch);
-  const bool v2 = qt == 2 && (head_size == 64 || head_size == 128) && !getenv("APHRO_FA_V1");
-  // 256-row (8-wave) workgroups measured slower at T = 8192 (376 vs 413 TFLOP/s): opt-in only
-  const bool v2w8 = v2 && head_size == 128 && getenv("APHRO_FA_W8") != nullptr;
-  if (v2w8) grid.x = (unsigned)((max_seqlen + 255) / 256);
-#define FA_L(TT, HDV) { if (v2w8) hipLaunchKernelGGL((flash_attn_varlen_v2_kernel<TT, 128, 2, 8>), grid, dim3(512), 0, (hipStream_t)stream, p); \
-                        else if (v2) hipLaunchKernelGGL((flash_attn_varlen_v2_kernel<TT, (HDV == 64 ? 64 : 128), 2, 4>), grid, dim3(256), 0, (hipStream_t)stream, p); \
-                        else if (qt == 2) hipLaunchKernelGGL((flash_attn_varlen_kernel<TT, HDV, (HDV <= 128 ? 2 : 1)>), grid, dim3(256), 0, (hipStream_t)stream, p); \
-                        else hipLaunchKernelGGL((flash_attn_varlen_kernel<TT, HDV, 1>), grid, dim3(256), 0, (hipStream_t)stream, p); }
-#define FA_T(HDV) if (dtype == APHRO_F16) FA_L(Half, HDV) else FA_L(BFloat, HDV)
-  switch (head_size) {
-    case 64: FA_T(64) break;
-    case 96: FA_T(96) break;
-    case 128: FA_T(128) break;
-    case 256: FA_T(256) break;
-    default:
-      set_error("flash_attn_varlen: unsupported head_size=%d", head_size);
-      return APHRO_ERR_INVALID;
-  }
-#undef FA_T
-#undef FA_L
-  APHRO_LAUNCH_CHECK();
-  return APHRO_OK;
+  p.cu_seqlens_k = nullptr; p.o_stride = (int64_t)num_heads * head_size; p.nqt_max = 0; p.xcd_remap = 0; p.window = 0;
+  return fa_dispatch(p, head_size, dtype, batch, max_seqlen, max_seqlen, (hipStream_t)stream);
 }
 
 // lab: copy the stamp buffer of the third-generation prefill kernel to the host

@@ -406,7 +406,9 @@ int aphro_context_attention(void* out, const void* q, const void* k, const void*
 
 /* The same op for long prompts (head_size 128, no sliding window): the cached context is gathered once into contiguous
  * rows (workspace) and the third-generation prefill kernel (256-row workgroups, 32x32 MFMA, direct-to-LDS K/V) runs over
- * context + new tokens.  max_seq_len = max(seq_lens), total_kv_tokens >= sum(seq_lens). */
+ * context + new tokens.  max_seq_len = max(seq_lens), total_kv_tokens >= sum(seq_lens).  Round 3: every head size of
+ * aphro_context_attention (64 / 96 / 128 / 256), ALiBi and sliding_window (> 0: keys within the window, prefix_prefill.py:
+ * 756-760) -- the second / first generation tile machines take the shapes the third does not. */
 size_t aphro_context_attention_workspace_bytes(int64_t total_kv_tokens, int batch, int num_kv_heads, int head_size);
 int aphro_context_attention_gathered(void* out, const void* q, const void* k, const void* v, const void* k_cache,
                                      const void* v_cache, const int32_t* block_tables, const int32_t* q_start_loc,
@@ -414,8 +416,8 @@ int aphro_context_attention_gathered(void* out, const void* q, const void* k, co
                                      int max_seq_len, int64_t total_kv_tokens, int max_blocks, int num_heads,
                                      int num_kv_heads, int head_size, int block_size, int x, int64_t q_stride,
                                      int64_t k_stride, int64_t v_stride, int64_t o_stride, float scale, float k_scale,
-                                     float v_scale, const float* alibi_slopes, int dtype, int kv_dtype,
-                                     void* workspace, size_t workspace_bytes, void* stream);
+                                     float v_scale, const float* alibi_slopes, int sliding_window, int dtype,
+                                     int kv_dtype, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------
  * FP8 (W8A8, per-token dynamic activation scale) decode fast path -- configs[2],

@@ -1793,3 +1793,43 @@ def test_paged_attention_rope_packed_split_matches_unsplit(ops):
             os.environ["APHRO_PA_SPLITS"] = old
     assert torch.equal(res[1][0], res[4][0]) and torch.equal(res[1][1], res[4][1])
     np.testing.assert_allclose(res[4][2].float().cpu().numpy(), res[1][2].float().cpu().numpy(), atol=1e-3, rtol=1e-5)
+
+
+@pytest.mark.parametrize("hints", [True, False])
+@pytest.mark.parametrize("Hq,Hkv,D,variant", [(8, 2, 64, "window"), (8, 2, 128, "window"), (4, 2, 256, "plain"),
+                                              (6, 3, 96, "alibi"), (8, 4, 64, "plain"), (4, 1, 256, "window")])
+def test_context_attention_fwd_every_shape_on_the_tile_machines(ops, Hq, Hkv, D, variant, hints):
+    """Round 3: prefill with cached context for every head size of the reference's kernel (prefix_prefill.py:696-858 is one
+    kernel for all of them), sliding window and ALiBi runs gather-once + the prefill tile machines (second generation for
+    head 64 / 128, first for 96 / 256; keys = context + new tokens, query rows offset by the context length, window =
+    keys within `sliding_window` of the query position) instead of the scalar-gather kernel -- against the oracle, at
+    lengths around the 64-key / 128-row tile edges, with and without the host-side length hints."""
+    rng = np.random.default_rng(Hq * 13 + D)
+    BS = 16
+    ctx_lens = np.array([0, 700, 63, 1, 513, 130], np.int32)
+    qry_lens = np.array([200, 129, 64, 257, 1, 640], np.int32)
+    B = len(ctx_lens)
+    seq_lens = ctx_lens + qry_lens
+    T = int(qry_lens.sum())
+    start = np.concatenate([[0], np.cumsum(qry_lens)]).astype(np.int32)
+    max_blocks = int((seq_lens.max() + BS - 1) // BS)
+    NB = B * max_blocks + 3
+    bt = rng.permutation(NB)[:B * max_blocks].reshape(B, max_blocks).astype(np.int32)
+    dtype = torch.float16
+    qkv = t(rng.standard_normal((T, (Hq + 2 * Hkv) * D)).astype(np.float32) * 0.5, dtype)
+    q = qkv[:, :Hq * D].view(T, Hq, D)
+    k = qkv[:, Hq * D:(Hq + Hkv) * D].view(T, Hkv, D)
+    v = qkv[:, (Hq + Hkv) * D:].view(T, Hkv, D)
+    kc = t(rng.standard_normal((NB, Hkv, D // 8, BS, 8)).astype(np.float32) * 0.5, dtype)
+    vc = t(rng.standard_normal((NB, Hkv, D, BS)).astype(np.float32) * 0.5, dtype)
+    slopes = (rng.random(Hq).astype(np.float32) * 0.05) if variant == "alibi" else None
+    window = 100 if variant == "window" else None
+    out = torch.full((T, Hq, D), float("nan"), dtype=dtype, device=DEV)
+    kw = dict(max_seq_len=int(seq_lens.max()), total_kv_tokens=int(seq_lens.sum())) if hints else {}
+    ops.context_attention_fwd(q, k, v, out, "auto", kc, vc, t(bt), t(start), t(seq_lens), t(ctx_lens), int(qry_lens.max()),
+                              1.0, 1.0, t(slopes) if slopes is not None else None, window, **kw)
+    rnd = lambda a: torch.from_numpy(a.astype(np.float32)).to(dtype).float().numpy()
+    ref = oa.context_attention(q.float().cpu().numpy(), k.float().cpu().numpy(), v.float().cpu().numpy(),
+                               kc.float().cpu().numpy(), vc.float().cpu().numpy(), bt, start, seq_lens, ctx_lens, D ** -0.5,
+                               "auto", 1.0, 1.0, slopes, window or 0, rnd)
+    np.testing.assert_allclose(out.float().cpu().numpy(), ref, atol=2e-3, rtol=2e-3)
