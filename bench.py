@@ -341,8 +341,16 @@ def prefill_section(cfg):
     Hq, Hkv, D = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
 
     def timeit(fn, iters=5):
+        # steady state: these kernels follow a light decode section, and the first ~50 ms of MFMA-heavy work run below
+        # the clocks the chip then holds (tools/prefill_section_alone.py: the same section three times back to back gives
+        # 882 -> 1037 -> 1066 TFLOP/s on the W4A16 GEMM, 696 -> 815 -> 859 on the attention) -- warm up for >= 60 ms first
         fn()
         torch.cuda.synchronize()
+        t_w = time.perf_counter()
+        while time.perf_counter() - t_w < 0.06:
+            fn()
+            torch.cuda.synchronize()
+        iters = max(iters, 8)
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
         for _ in range(iters):
