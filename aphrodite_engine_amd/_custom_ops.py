@@ -832,6 +832,56 @@ def wna16_gemm_resident(a_packed: torch.Tensor, m: int, k: int, qweight: torch.T
     return c
 
 
+def wna16_gemm_rowmajor_supported(m: int, n: int, k: int, groups: int, dtype: torch.dtype) -> bool:
+    return dtype == torch.float16 and bool(_lib.lib().aphro_wna16_gemm_rowmajor_supported(m, n, k, groups, _DT[dtype]))
+
+
+def wna16_gemm_rowmajor(a: torch.Tensor, qweight: torch.Tensor, qzeros: torch.Tensor, scales: torch.Tensor,
+                        zero_offset: int, strip_layout: bool = False) -> torch.Tensor:
+    """The op-level decode GEMM (M <= 32, f16) in ONE launch: row-major ``a`` read in place, K slices reduced inside the
+    kernel (csrc/wna16_gemm_resident.hip).  ``gptq_gemm`` / ``awq_gemm`` take this path by themselves; this entry exists
+    for the strip-major weight copy and the tests."""
+    lib = _lib.lib()
+    m, k = a.shape
+    n, groups = scales.shape[1], scales.shape[0]
+    if a.stride(1) != 1 or a.stride(0) % 8 != 0 or a.data_ptr() % 16 != 0:
+        a = a.contiguous()
+    out = torch.empty((m, n), dtype=a.dtype, device=a.device)
+    nbytes = lib.aphro_wna16_workspace_bytes(m, n, k)
+    ws = _workspace(a.device, nbytes)
+    check(lib.aphro_wna16_gemm_rowmajor(a.data_ptr(), a.stride(0), qweight.data_ptr(), qzeros.data_ptr(), scales.data_ptr(),
+                                        out.data_ptr(), ws.data_ptr(), ws.numel(), m, n, k, groups, zero_offset, _dt(a),
+                                        1 if strip_layout else 0, _stream()), "wna16_gemm_rowmajor")
+    return out
+
+
+STRIP_COPY_MIN_BYTES = 32 << 20
+
+
+def wna16_decode_strip_copy(qweight: torch.Tensor, scales: torch.Tensor) -> Optional[torch.Tensor]:
+    """Load-time: the strip-major copy of a [K/8, N] int4 matrix for the one-launch decode GEMM, or None where it does
+    not pay.  Measured (tools/op_gemm_bench.py, profiles/r3_op_gemm.txt): 21.2 -> 18.8 us on the 4096 x 28672 gate_up
+    matrix at 32 rows (two column passes per workgroup), nothing on the one-pass shapes (down / qkv / o) -- so only
+    matrices of >= 32 MiB get one (it doubles their footprint: the [K/8, N] original still serves M > 32).
+    APHRODITE_MI355X_NO_STRIP_COPY=1 turns it off."""
+    if os.environ.get("APHRODITE_MI355X_NO_STRIP_COPY") == "1" or scales.dtype != torch.float16:
+        return None
+    k, n, groups = qweight.shape[0] * 8, qweight.shape[1], scales.shape[0]
+    if qweight.numel() * 4 < STRIP_COPY_MIN_BYTES or not wna16_gemm_rowmajor_supported(32, n, k, groups, torch.float16):
+        return None
+    return wna16_strip_relayout(qweight, 32, groups)
+
+
+def wna16_decode_linear(x: torch.Tensor, qweight: torch.Tensor, qzeros: torch.Tensor, scales: torch.Tensor,
+                        zero_offset: int, strip: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    """The strip-major one-launch GEMM when the call is a decode batch it serves, else None (caller: the generic op)."""
+    if strip is None or x.shape[0] > 32 or x.dtype != torch.float16 or x.shape[0] == 0:
+        return None
+    if not wna16_gemm_rowmajor_supported(x.shape[0], scales.shape[1], x.shape[1], scales.shape[0], x.dtype):
+        return None
+    return wna16_gemm_rowmajor(x, strip, qzeros, scales, zero_offset, strip_layout=True)
+
+
 def fused_add_rms_norm_pack(x: Optional[torch.Tensor], slabs: Optional[torch.Tensor],
                             residual: Optional[torch.Tensor], has_residual: bool,
                             weight: torch.Tensor, epsilon: float, pack: bool = True,

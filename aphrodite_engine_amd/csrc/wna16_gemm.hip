@@ -813,6 +813,12 @@ extern "C" int aphro_gptq_gemm(const void* a, const uint32_t* q_weight, const ui
   APHRO_CHECK(N % 16 == 0, "gptq_gemm: N=%ld must be a multiple of 16", (long)N);
   APHRO_CHECK(lda % 8 == 0 && ((uintptr_t)a % 16) == 0, "gptq_gemm: a must be 16-byte aligned with lda %% 8 == 0");
   if (M == 0) return APHRO_OK;
+  // one launch instead of pack + GEMM (+ reduce) where the resident kernel serves the shape (wna16_gemm_resident.hip)
+  if (perm == nullptr && lda >= K && ((uintptr_t)c % 16) == 0 && aphro_wna16_gemm_rowmajor_supported(M, N, K, groups, dtype)) {
+    const int rc = aphro_wna16_gemm_rowmajor(a, lda, q_weight, qzeros, scales, c, workspace, workspace_bytes, M, N, K,
+                                             groups, zero_offset, dtype, 0, stream);
+    if (rc != APHRO_ERR_WORKSPACE) return rc;
+  }
   Wna16Plan pl = make_plan(M, N, K, gs);
   const size_t apk_bytes = pl.fast ? packed_a_bytes(M, K) : 0;
   {

@@ -46,6 +46,9 @@ struct Wna16ResParams {
   int force_partial;
   int strip_layout;
   int is_bf16;            // scales / output in bf16 (the activations were widened to f16 when packed)
+  const uint16_t* a;      // AROW instantiations: row-major f16 activations [M, lda] read in place (no pack launch)
+  int lda;
+  unsigned* counter;      // one launch for [M, N] with K slices: tickets per strip (zero between launches), see the epilogue
   unsigned long long* trace;   // TRACE instantiations (RES_LAB builds, tools/resident_trace.py): per-wave timeline stamps
 };
 
@@ -63,6 +66,52 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t res_rsrc(const void* base, uin
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
 }
 
+// write-through (system-scope) store and coherent loads for the in-launch K-slice reduce (same primitives as the split
+// form of paged_attention.hip).  Eight 16-byte loads in flight, the wait INSIDE the statement.
+__device__ __forceinline__ void res_st_wt(float* p, f32x4 v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void res_ld_coh8(f32x4 (&v)[8], const float* const (&p)[8]) {
+  asm volatile(
+      "global_load_dwordx4 %0, %8, off sc0 sc1\n\tglobal_load_dwordx4 %1, %9, off sc0 sc1\n\t"
+      "global_load_dwordx4 %2, %10, off sc0 sc1\n\tglobal_load_dwordx4 %3, %11, off sc0 sc1\n\t"
+      "global_load_dwordx4 %4, %12, off sc0 sc1\n\tglobal_load_dwordx4 %5, %13, off sc0 sc1\n\t"
+      "global_load_dwordx4 %6, %14, off sc0 sc1\n\tglobal_load_dwordx4 %7, %15, off sc0 sc1\n\t"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+      : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7])
+      : "memory");
+}
+
+typedef __attribute__((address_space(3))) void* res_lds_ptr;
+
+// AROW: hipcc does not order a ds_read after the `buffer_load ... lds` that fills its source, so the wait is written by
+// hand: the number of vector-memory instructions issued after the last staging load of segment s and before its
+// fragments are read (loads return in order: vmcnt(that number) = "segment s has landed", everything younger stays in
+// flight).  Mirrors the issue order of the kernel below exactly -- straight-line code, every term a constant.
+template <int MT, int NSEG, int NP4, int REM, int DEPTH, int AD>
+constexpr int res_vm_after_stage(int s) {
+  constexpr int NPASS = NP4 + (REM > 0 ? 1 : 0), NST = NPASS * NSEG * 4;
+  auto nmeta = [](int q) { return (q / NSEG < NP4) ? 2 : (REM == 3 ? 5 : 2); };
+  auto block = [&](int I, bool w, bool a, bool m) {      // the issue block of k-step I (which of its three parts)
+    const int pass = I / (NSEG * 4), sg = (I / 4) % NSEG, u = I % 4, q = pass * NSEG + sg;
+    int n = 0;
+    if (w && I + DEPTH < NST) n += 1;
+    if (a && pass == 0 && u == 0 && sg + AD < NSEG) n += 4 * MT;
+    if (m && u == 0 && q + 1 < NPASS * NSEG) n += nmeta(q + 1);
+    return n;
+  };
+  int n = 0;
+  if (s < AD) {       // staged in the prologue: the later prologue stages, the first weights, the blocks of steps 0 .. 4 s
+    n += (AD - 1 - s) * 4 * MT + (DEPTH < NST ? DEPTH : NST);
+    for (int I = 0; I <= 4 * s; ++I) n += block(I, true, true, true);
+  } else {            // staged in the block of step 4 (s - AD): its metadata, then the blocks up to step 4 s
+    n += block(4 * (s - AD), false, false, true);
+    for (int I = 4 * (s - AD) + 1; I <= 4 * s; ++I) n += block(I, true, true, true);
+  }
+  return n > 63 ? 63 : n;
+}
+
 struct ResMeta {          // RAW scale / zero words of one (pass, segment): untouched until the segment is consumed
   uint32_t sc[3];
   uint32_t z0, z1;
@@ -70,7 +119,7 @@ struct ResMeta {          // RAW scale / zero words of one (pass, segment): unto
 
 // Columns of a strip: CW = 64 NP4 + 16 REM.  Pass p < NP4: lane (g, c) owns columns 64 p + 4 c + t (t < 4); the last pass
 // (REM > 0): columns 64 NP4 + REM c + t (t < REM).  Wave w of K slice y owns segments [(y NWV + w) NSEG, + NSEG).
-template <int MT, int NWV, int NSEG, int NP4, int REM, int DEPTH, int ADEPTH, bool KEEP_RS, bool TRACE = false>
+template <int MT, int NWV, int NSEG, int NP4, int REM, int DEPTH, int ADEPTH, bool KEEP_RS, bool TRACE = false, bool AROW = false>
 __global__ __launch_bounds__(NWV * 64, NWV <= 4 ? 1 : 2) void wna16_gemm_resident_kernel(Wna16ResParams p) {
   constexpr int NPASS = NP4 + (REM > 0 ? 1 : 0);
   constexpr int NST = NPASS * NSEG * 4;             // k-steps of a wave over all passes
@@ -79,7 +128,15 @@ __global__ __launch_bounds__(NWV * 64, NWV <= 4 ? 1 : 2) void wna16_gemm_residen
   constexpr int ROWS = 16 * MT;
   constexpr int RING = DEPTH + 1;
   constexpr int AD = ADEPTH < NSEG ? ADEPTH : NSEG;
-  extern __shared__ __attribute__((aligned(16))) float red[];   // [NWV][ROWS][CWP]
+  // AROW (row-major activations, the op-level form): a wave stages its A segments through LDS -- coalesced
+  // `buffer_load ... lds` of 4 rows x 256 bytes per instruction (8 full cache lines; the 16-row fragment gather straight
+  // from the rows touches 32 lines per instruction and cost +7 us at 32 rows), slots XOR-swizzled by the row so that the
+  // fragment reads (16 rows, one 16-byte chunk each, per 16 lanes) are bank-conflict free.  NBUF segments per wave, in
+  // the wave's own slice of `red` (its reduction tile is written after its last staged segment has been read).
+  constexpr int NBUF = AD + 1;
+  constexpr int SEGB = ROWS * 256;                  // bytes of one staged segment: [row][16 chunks of 8 k]
+  constexpr int WP = (AROW && NBUF * SEGB / 4 > ROWS * CWP) ? NBUF * SEGB / 4 : ROWS * CWP;   // floats per wave
+  extern __shared__ __attribute__((aligned(16))) float red[];   // [NWV][WP]: [ROWS][CWP] tiles
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4;
@@ -107,7 +164,8 @@ __global__ __launch_bounds__(NWV * 64, NWV <= 4 ? 1 : 2) void wna16_gemm_residen
   const int mtiles = (p.M + 15) >> 4;
 
   const __amdgpu_buffer_rsrc_t rw = res_rsrc(p.qw, (uint32_t)((size_t)(p.K >> 3) * p.N * 4));
-  const __amdgpu_buffer_rsrc_t ra = res_rsrc(p.apk, (uint32_t)((size_t)(p.K >> 7) * 4 * mtiles * 1024));
+  const __amdgpu_buffer_rsrc_t ra = AROW ? res_rsrc(p.a, (uint32_t)(((size_t)(p.M - 1) * p.lda + p.K) * 2))
+                                         : res_rsrc(p.apk, (uint32_t)((size_t)(p.K >> 7) * 4 * mtiles * 1024));
   const int ngroups = (p.K >> 7) >> p.gshift;
   const __amdgpu_buffer_rsrc_t rs_ = res_rsrc(p.sc, (uint32_t)((size_t)ngroups * p.N * 2));
   const __amdgpu_buffer_rsrc_t rz = res_rsrc(p.qz, (uint32_t)((size_t)ngroups * (p.N >> 3) * 4));
@@ -127,9 +185,20 @@ __global__ __launch_bounds__(NWV * 64, NWV <= 4 ? 1 : 2) void wna16_gemm_residen
     ss4 = ssr = 16 * p.N * 4; su4 = sur = p.N * 4;
     poff4 = 256; poffr = 0;
   }
-  int voff_a[MT];
+  int voff_a[AROW ? 4 * MT : MT];
+  if constexpr (AROW) {
+    // staging instruction `it`: lane -> slot row 4 it + lane / 16 (rows past M read row M - 1: never stored), chunk
+    // (lane % 16) ^ (slot row % 16); lands lane-linear in LDS = [slot row][swizzled chunk]
 #pragma unroll
-  for (int i = 0; i < MT; ++i) voff_a[i] = (min(i, mtiles - 1) * 64 + lane) * 16;
+    for (int it = 0; it < 4 * MT; ++it) {
+      const int srow = 4 * it + (lane >> 4);
+      voff_a[it] = min(srow, p.M - 1) * p.lda * 2 + (((lane & 15) ^ (srow & 15)) << 4);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < MT; ++i) voff_a[i] = (min(i, mtiles - 1) * 64 + lane) * 16;
+  }
+  unsigned char* const astage = reinterpret_cast<unsigned char*>(red) + (size_t)wave * WP * 4;
   const int abytes = mtiles * 1024;
   // metadata addressing
   const int col4 = cb + 4 * c;                      // first column of the lane in pass 0 (pass p: + 64 p)
@@ -174,13 +243,30 @@ __global__ __launch_bounds__(NWV * 64, NWV <= 4 ? 1 : 2) void wna16_gemm_residen
   };
   auto load_a = [&](auto S_) {
     constexpr int s = decltype(S_)::value;
+    if constexpr (AROW) {
+#pragma unroll
+      for (int it = 0; it < 4 * MT; ++it) {
+        const int vo = voff_a[it];    // (local copy: see wna16_gemm_large.hip on the hipcc host-stub bug)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (res_lds_ptr)(astage + (s % NBUF) * SEGB + it * 1024), 16, vo,
+                                                 (seg0 + s) * 256, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          const int vo = voff_a[i];
+          af[s][u][i] = __builtin_amdgcn_raw_buffer_load_b128(ra, vo, ((seg0 + s) * 4 + u) * abytes, 0);
+        }
+    }
+  };
+  auto fetch_a = [&](auto S_) {     // AROW: the staged segment -> fragments (lane (g, c): row 16 i + c, chunk 4 g + u)
+    constexpr int s = decltype(S_)::value;
 #pragma unroll
     for (int u = 0; u < 4; ++u)
 #pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        const int vo = voff_a[i];
-        af[s][u][i] = __builtin_amdgcn_raw_buffer_load_b128(ra, vo, ((seg0 + s) * 4 + u) * abytes, 0);
-      }
+      for (int i = 0; i < MT; ++i)
+        af[s][u][i] = *reinterpret_cast<const u32x4*>(astage + (s % NBUF) * SEGB + (16 * i + c) * 256 + (((4 * g + u) ^ c) << 4));
   };
   auto load_meta = [&](auto Q_) {   // Q = pass * NSEG + s
     constexpr int Q = decltype(Q_)::value;
@@ -206,7 +292,9 @@ __global__ __launch_bounds__(NWV * 64, NWV <= 4 ? 1 : 2) void wna16_gemm_residen
 
   // ---- prologue: metadata of the first group, the first AD segments of A, the first DEPTH weight steps --------------
   load_meta(std::integral_constant<int, 0>{});
+  if constexpr (AROW) __builtin_amdgcn_sched_barrier(0);      // (AROW: the issue ORDER is what res_vm_after_stage counts)
   res_static_for<0, AD>([&](auto S_) { load_a(S_); });
+  if constexpr (AROW) __builtin_amdgcn_sched_barrier(0);
   res_static_for<0, (DEPTH < NST ? DEPTH : NST)>([&](auto I_) { wr[decltype(I_)::value % RING] = load_w(I_); });
   __builtin_amdgcn_sched_barrier(0);
   RES_STAMP(1);
@@ -219,9 +307,15 @@ __global__ __launch_bounds__(NWV * 64, NWV <= 4 ? 1 : 2) void wna16_gemm_residen
     constexpr int Q = pass * NSEG + s;
     // ---- issue: weights DEPTH steps ahead, A AD segments ahead (first pass only), metadata one segment ahead ---------
     if constexpr (I + DEPTH < NST) wr[(I + DEPTH) % RING] = load_w(std::integral_constant<int, I + DEPTH>{});
+    if constexpr (AROW && pass == 0 && u == 0) __builtin_amdgcn_sched_barrier(0);
     if constexpr (pass == 0 && u == 0 && s + AD < NSEG) load_a(std::integral_constant<int, (s + AD < NSEG ? s + AD : 0)>{});
+    if constexpr (AROW && pass == 0 && u == 0) __builtin_amdgcn_sched_barrier(0);
     if constexpr (u == 0 && Q + 1 < NPASS * NSEG) load_meta(std::integral_constant<int, (Q + 1 < NPASS * NSEG ? Q + 1 : 0)>{});
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (AROW && pass == 0 && u == 0) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(res_vm_after_stage<MT, NSEG, NP4, REM, DEPTH, AD>(s)) : "memory");
+      fetch_a(std::integral_constant<int, s>{});
+    }
     // ---- A fragments: nibbles 2,3,6,7 of a word are taken in place (bits 4-7 of each half) and weigh 16x, so those k
     // of the fragment carry 1/16 (once: the scaled fragment is what stays resident) ------------------------------------
     f16x8 a[MT];
@@ -290,7 +384,7 @@ __global__ __launch_bounds__(NWV * 64, NWV <= 4 ? 1 : 2) void wna16_gemm_residen
         for (int i = 0; i < MT; ++i)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            float* dst = &red[(wave * ROWS + 16 * i + 4 * g + r) * CWP + (LAST ? 64 * NP4 + REM * c : 64 * pass + 4 * c)];
+            float* dst = &red[wave * WP + (16 * i + 4 * g + r) * CWP + (LAST ? 64 * NP4 + REM * c : 64 * pass + 4 * c)];
             if constexpr (!LAST) {
               *reinterpret_cast<f32x4*>(dst) = f32x4{cacc[i][0][r], cacc[i][1][r], cacc[i][2][r], cacc[i][3][r]};
             } else {
@@ -322,7 +416,7 @@ __global__ __launch_bounds__(NWV * 64, NWV <= 4 ? 1 : 2) void wna16_gemm_residen
       for (int q = 0; q < 4; ++q) {
         f32x4 sum = zero4;
 #pragma unroll
-        for (int w2 = 0; w2 < NWV; ++w2) sum += *reinterpret_cast<const f32x4*>(&red[(w2 * ROWS + row) * CWP + 16 * ch + 4 * q]);
+        for (int w2 = 0; w2 < NWV; ++w2) sum += *reinterpret_cast<const f32x4*>(&red[w2 * WP + row * CWP + 16 * ch + 4 * q]);
         v[4 * q] = sum[0]; v[4 * q + 1] = sum[1]; v[4 * q + 2] = sum[2]; v[4 * q + 3] = sum[3];
       }
       uint16_t o[8];
@@ -340,13 +434,72 @@ __global__ __launch_bounds__(NWV * 64, NWV <= 4 ? 1 : 2) void wna16_gemm_residen
         *reinterpret_cast<u32x4*>(dst) = u32x4{(uint32_t)o[0] | ((uint32_t)o[1] << 16), (uint32_t)o[2] | ((uint32_t)o[3] << 16),
                                                (uint32_t)o[4] | ((uint32_t)o[5] << 16), (uint32_t)o[6] | ((uint32_t)o[7] << 16)};
     }
+  } else if (p.counter != nullptr) {
+    // ---- [M, N] out of ONE launch although K is sliced over workgroups (the op-level form: no reduce launch).  Each slice
+    // stores its fp32 tile write-through (the slices of a strip sit on different XCDs = different L2s), takes a ticket;
+    // the last arriver adds the slices IN SLICE ORDER (= splitk_reduce_kernel's order: the bits do not depend on who
+    // arrives last), rounds and stores.  No fences (an agent-scope release / acquire writes back / invalidates the whole
+    // L2): write-through stores, a wait for their completion, a relaxed ticket, coherent loads.
+    constexpr int UNITS = ROWS * (CW / 4);
+    constexpr int NT = NWV * 64;
+    for (int unit = tid; unit < UNITS; unit += NT) {
+      const int row = unit / (CW / 4), c4 = unit % (CW / 4);
+      f32x4 sum = zero4;
+#pragma unroll
+      for (int w2 = 0; w2 < NWV; ++w2) sum += *reinterpret_cast<const f32x4*>(&red[w2 * WP + row * CWP + 4 * c4]);
+      if (row < p.M) res_st_wt(p.partial + ((size_t)ky * p.M + row) * p.N + cb + 4 * c4, sum);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int* flag = reinterpret_cast<int*>(red);          // (every wave is past its reads of the tile)
+    if (tid == 0) {
+      const unsigned old = __hip_atomic_fetch_add(p.counter + strip, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      *flag = old == (unsigned)p.ksplit - 1u;
+    }
+    __syncthreads();
+    if (*flag == 0) return;
+    if (tid == 0) __hip_atomic_store(p.counter + strip, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    constexpr int PER = (UNITS + NT - 1) / NT;      // units per thread
+    auto reduce_batches = [&](auto SPU_) {            // SPU slices per unit (ksplit rounded up), 8 / SPU units per 8-load batch
+      constexpr int SPU = decltype(SPU_)::value, UPC = 8 / SPU;
+      for (int u0 = 0; u0 < PER; u0 += UPC) {
+        const float* ptr[8];
+        f32x4 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int unit = tid + (u0 + j / SPU) * NT, z = j % SPU;
+          const bool ok = unit < UNITS && z < p.ksplit;
+          const int row = ok ? min(unit / (CW / 4), p.M - 1) : 0, c4 = ok ? unit % (CW / 4) : 0;
+          ptr[j] = p.partial + ((size_t)(ok ? z : 0) * p.M + row) * p.N + cb + 4 * c4;
+        }
+        res_ld_coh8(v, ptr);
+#pragma unroll
+        for (int q = 0; q < UPC; ++q) {
+          const int unit = tid + (u0 + q) * NT;
+          const int row = unit / (CW / 4), c4 = unit % (CW / 4);
+          f32x4 sum = v[q * SPU];
+#pragma unroll
+          for (int z = 1; z < SPU; ++z)
+            if (z < p.ksplit) sum += v[q * SPU + z];
+          uint16_t o[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = p.is_bf16 ? BFloat::from_f32(sum[e]) : Half::from_f32(sum[e]);
+          if (unit < UNITS && row < p.M)
+            *reinterpret_cast<u32x2*>(p.c + (size_t)row * p.N + cb + 4 * c4) =
+                u32x2{(uint32_t)o[0] | ((uint32_t)o[1] << 16), (uint32_t)o[2] | ((uint32_t)o[3] << 16)};
+        }
+      }
+    };
+    if (p.ksplit <= 2) reduce_batches(std::integral_constant<int, 2>{});
+    else if (p.ksplit <= 4) reduce_batches(std::integral_constant<int, 4>{});
+    else reduce_batches(std::integral_constant<int, 8>{});
   } else if (p.ksplit > 1 || p.force_partial) {
     constexpr int UNITS = ROWS * (CW / 4);          // 4 columns of one row: 16 bytes of fp32
     for (int unit = tid; unit < UNITS; unit += NWV * 64) {
       const int row = unit / (CW / 4), c4 = unit % (CW / 4);
       f32x4 sum = zero4;
 #pragma unroll
-      for (int w2 = 0; w2 < NWV; ++w2) sum += *reinterpret_cast<const f32x4*>(&red[(w2 * ROWS + row) * CWP + 4 * c4]);
+      for (int w2 = 0; w2 < NWV; ++w2) sum += *reinterpret_cast<const f32x4*>(&red[w2 * WP + row * CWP + 4 * c4]);
       if (row < p.M) *reinterpret_cast<f32x4*>(p.partial + ((size_t)ky * p.M + row) * p.N + cb + 4 * c4) = sum;
     }
   } else {
@@ -356,8 +509,8 @@ __global__ __launch_bounds__(NWV * 64, NWV <= 4 ? 1 : 2) void wna16_gemm_residen
       f32x4 s0 = zero4, s1 = zero4;
 #pragma unroll
       for (int w2 = 0; w2 < NWV; ++w2) {
-        s0 += *reinterpret_cast<const f32x4*>(&red[(w2 * ROWS + row) * CWP + 8 * c8]);
-        s1 += *reinterpret_cast<const f32x4*>(&red[(w2 * ROWS + row) * CWP + 8 * c8 + 4]);
+        s0 += *reinterpret_cast<const f32x4*>(&red[w2 * WP + row * CWP + 8 * c8]);
+        s1 += *reinterpret_cast<const f32x4*>(&red[w2 * WP + row * CWP + 8 * c8 + 4]);
       }
       uint16_t o[8];
 #pragma unroll
@@ -463,11 +616,13 @@ static ResConfig res_plan(int64_t M, int64_t N, int64_t K, int64_t gs) {
   return none;
 }
 
-template <int MT, int NWV, int NSEG, int NP4, int REM, int DEPTH, int ADEPTH, bool KEEP_RS, bool TRACE = false>
+template <int MT, int NWV, int NSEG, int NP4, int REM, int DEPTH, int ADEPTH, bool KEEP_RS, bool TRACE = false, bool AROW = false>
 static int res_launch(const Wna16ResParams& p, hipStream_t st) {
   constexpr int CW = 64 * NP4 + 16 * REM;
-  const size_t lds = (size_t)NWV * 16 * MT * (CW + 4) * sizeof(float);
-  auto kern = wna16_gemm_resident_kernel<MT, NWV, NSEG, NP4, REM, DEPTH, ADEPTH, KEEP_RS, TRACE>;
+  constexpr int AD = ADEPTH < NSEG ? ADEPTH : NSEG;
+  constexpr size_t TILE = (size_t)16 * MT * (CW + 4) * sizeof(float), STAGE = (size_t)(AD + 1) * 16 * MT * 256;
+  const size_t lds = (size_t)NWV * (AROW && STAGE > TILE ? STAGE : TILE);
+  auto kern = wna16_gemm_resident_kernel<MT, NWV, NSEG, NP4, REM, DEPTH, ADEPTH, KEEP_RS, TRACE, AROW>;
   if (lds > 64 * 1024) {   // per device and cheap: set every time (a process-wide flag misses a second GPU)
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
       set_error("wna16_gemm_resident: cannot raise the dynamic LDS limit to %zu", lds);
@@ -498,6 +653,15 @@ static int res_launch(const Wna16ResParams& p, hipStream_t st) {
   X(4, 1, 2, 0)        \
   X(7, 2, 2, 0)
 
+// (the candidates of res_plan: what a call without APHRO_WNA16_RES_CFG can get)
+#define RES_AROW_CONFIGS(X) \
+  X(4, 8, 1, 3)             \
+  X(4, 7, 1, 0)             \
+  X(4, 8, 1, 0)             \
+  X(4, 4, 1, 0)             \
+  X(4, 2, 1, 0)             \
+  X(4, 4, 0, 3)
+
 static bool res_instantiated(int nwv, int nseg, int np4, int rem) {
 #define X(a, b, c, d) if (nwv == a && nseg == b && np4 == c && rem == d) return true;
   RES_CONFIGS(X)
@@ -524,6 +688,18 @@ static int res_dispatch(const Wna16ResParams& p, const ResConfig& cf, hipStream_
     }
   }
 #endif
+  if (p.a != nullptr) {   // row-major activations read in place: the configurations res_plan picks by itself
+#define X(a, b, c, d)                                                                                    \
+    if (cf.nwv == a && cf.nseg == b && cf.np4 == c && cf.rem == d) {                                     \
+      constexpr bool KR = (c + (d > 0 ? 1 : 0)) > 1;                                                     \
+      return mt == 2 ? res_launch<2, a, b, c, d, RES_DEPTH, RES_ADEPTH, KR, false, true>(p, st)          \
+                     : res_launch<1, a, b, c, d, RES_DEPTH, RES_ADEPTH, KR, false, true>(p, st);         \
+    }
+    RES_AROW_CONFIGS(X)
+#undef X
+    set_error("wna16_gemm_resident: configuration %d,%d,%d,%d has no row-major instantiation", cf.nwv, cf.nseg, cf.np4, cf.rem);
+    return APHRO_ERR_INVALID;
+  }
 #define X(a, b, c, d)                                                                       \
   if (cf.nwv == a && cf.nseg == b && cf.np4 == c && cf.rem == d) {                          \
     constexpr bool KR = (c + (d > 0 ? 1 : 0)) > 1;                                          \
@@ -568,6 +744,7 @@ extern "C" int aphro_wna16_gemm_resident(const void* a_packed, const uint32_t* q
   for (int64_t q = (K / groups) >> 7; q > 1; q >>= 1) ++p.gshift;
   p.force_partial = 0; p.strip_layout = strip_layout ? 1 : 0; p.is_bf16 = dtype == APHRO_BF16;
   p.trace = g_res_trace;
+  p.a = nullptr; p.lda = 0; p.counter = nullptr;
   if (act_packed != nullptr) {
     APHRO_CHECK(cf.ksplit == 1 && N % 256 == 0, "wna16_gemm_resident: the SiluAndMul form needs one K slice and N/2 %% 128 == 0 (N=%ld)", (long)N);
     p.c = nullptr; p.partial = nullptr;
@@ -576,6 +753,75 @@ extern "C" int aphro_wna16_gemm_resident(const void* a_packed, const uint32_t* q
     p.force_partial = 1; p.c = nullptr;
   } else {
     APHRO_CHECK(c != nullptr && cf.ksplit == 1, "wna16_gemm_resident: this shape needs the slab form (%d K slices)", cf.ksplit);
+  }
+  return res_dispatch(p, cf, st);
+}
+
+// Tickets of the one-launch K-slice reduce, per device: zero between launches (the last arriver of a strip resets its
+// ticket).  hipMalloc'ed on first use, never during a stream capture.  The op-level GEMMs of a process are stream-ordered
+// (one compute stream per worker, as in the reference): two of them running CONCURRENTLY on one device would share tickets.
+static unsigned* g_res_counter[APHRO_MAX_DEVICES];
+static constexpr int RES_COUNTERS = 4096;
+
+static unsigned* res_counters(hipStream_t st) {
+  unsigned*& cnt = g_res_counter[device_slot()];
+  if (cnt == nullptr) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
+    if (hipMalloc((void**)&cnt, RES_COUNTERS * sizeof(unsigned)) != hipSuccess) { cnt = nullptr; return nullptr; }
+    if (hipMemset(cnt, 0, RES_COUNTERS * sizeof(unsigned)) != hipSuccess) { (void)hipFree(cnt); cnt = nullptr; return nullptr; }
+  }
+  return cnt;
+}
+
+// 1: aphro_wna16_gemm_rowmajor serves this call (f16 activations, M <= 32, a shape the resident kernel tiles).
+extern "C" int aphro_wna16_gemm_rowmajor_supported(int64_t M, int64_t N, int64_t K, int64_t groups, int dtype) {
+  if (dtype != APHRO_F16 || groups <= 0 || K % groups != 0 || getenv("APHRO_WNA16_OP_NO_RESIDENT")) return 0;
+  const ResConfig cf = res_plan(M, N, K, K / groups);
+  if (cf.nwv == 0 || N / (64 * cf.np4 + 16 * cf.rem) > RES_COUNTERS) return 0;
+#define X(a, b, c, d) if (cf.nwv == a && cf.nseg == b && cf.np4 == c && cf.rem == d) return 1;
+  RES_AROW_CONFIGS(X)
+#undef X
+  return 0;
+}
+
+// The op-level decode GEMM in ONE launch: c[M, N] = a[M, K] (row-major f16, row pitch lda) x int4 weights -- no activation
+// pack launch (the kernel gathers its A fragments from the rows), no split-K reduce launch (last-arriver reduce inside the
+// kernel).  workspace: ksplit x M x N floats when the shape is K-sliced (aphro_wna16_workspace_bytes covers it).
+// Returns APHRO_ERR_WORKSPACE without launching anything when the tickets cannot be allocated (first call under a stream
+// capture) or the workspace is too small: the caller takes the three-launch path (aphro_gptq_gemm does).
+extern "C" int aphro_wna16_gemm_rowmajor(const void* a, int64_t lda, const uint32_t* q_weight, const uint32_t* qzeros,
+                                         const void* scales, void* c, void* workspace, size_t workspace_bytes, int64_t M,
+                                         int64_t N, int64_t K, int64_t groups, int zero_offset, int dtype,
+                                         int strip_layout, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  APHRO_CHECK(aphro_wna16_gemm_rowmajor_supported(M, N, K, groups, dtype), "wna16_gemm_rowmajor: M=%ld N=%ld K=%ld groups=%ld dtype=%d is not served",
+              (long)M, (long)N, (long)K, (long)groups, dtype);
+  APHRO_CHECK(((uintptr_t)a % 16) == 0 && lda % 8 == 0 && lda >= K && ((uintptr_t)q_weight % 16) == 0 && ((uintptr_t)c % 16) == 0,
+              "wna16_gemm_rowmajor: 16-byte alignment required (lda %% 8 == 0)");
+  APHRO_CHECK(((size_t)(M - 1) * lda + K) * 2 < 0xffffffffull, "wna16_gemm_rowmajor: activations exceed one buffer descriptor");
+  const ResConfig cf = res_plan(M, N, K, K / groups);
+  Wna16ResParams p;
+  p.apk = nullptr; p.qw = q_weight; p.qz = qzeros; p.sc = (const uint16_t*)scales;
+  p.c = (uint16_t*)c; p.partial = nullptr; p.act_packed = nullptr;
+  p.M = (int)M; p.N = (int)N; p.K = (int)K; p.zero_offset = zero_offset; p.ksplit = cf.ksplit;
+  p.gshift = 0;
+  for (int64_t q = (K / groups) >> 7; q > 1; q >>= 1) ++p.gshift;
+  p.force_partial = 0; p.strip_layout = strip_layout ? 1 : 0; p.is_bf16 = 0;
+  p.trace = nullptr;
+  p.a = (const uint16_t*)a; p.lda = (int)lda; p.counter = nullptr;
+  if (cf.ksplit > 1) {
+    const size_t need = (size_t)cf.ksplit * M * N * sizeof(float);
+    if (workspace == nullptr || workspace_bytes < need || ((uintptr_t)workspace % 16) != 0) {
+      set_error("wna16_gemm_rowmajor: workspace %zu < %zu bytes", workspace_bytes, need);
+      return APHRO_ERR_WORKSPACE;
+    }
+    p.counter = res_counters(st);
+    if (p.counter == nullptr) {
+      set_error("wna16_gemm_rowmajor: tickets not allocated (first call under a stream capture)");
+      return APHRO_ERR_WORKSPACE;
+    }
+    p.partial = (float*)workspace;
   }
   return res_dispatch(p, cf, st);
 }

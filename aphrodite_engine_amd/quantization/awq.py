@@ -114,6 +114,7 @@ class CDNA4AWQLinearMethod(LinearMethodBase):
             layer.qzeros = nn.Parameter(
                 ops.awq_repack_zeros(layer.qzeros.data, n), requires_grad=False)
             layer.awq_prepacked = True
+            layer.qweight_strip = ops.wna16_decode_strip_copy(layer.qweight.data, layer.scales.data)
 
     def apply(self, layer: nn.Module, x: torch.Tensor,
               bias: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -122,7 +123,9 @@ class CDNA4AWQLinearMethod(LinearMethodBase):
         reshaped_x = x.reshape(-1, x.shape[-1])
         if getattr(layer, "awq_prepacked", False):
             out_shape = x.shape[:-1] + (qweight.shape[-1], )
-            out = ops.wna16_gemm(reshaped_x, qweight, qzeros, scales, None, 0)
+            out = ops.wna16_decode_linear(reshaped_x, qweight, qzeros, scales, 0, getattr(layer, "qweight_strip", None))
+            if out is None:
+                out = ops.wna16_gemm(reshaped_x, qweight, qzeros, scales, None, 0)
         else:
             out_shape = x.shape[:-1] + (qweight.shape[-1] * pack_factor, )
             # num_tokens >= threshold (awq.py:159-163)

@@ -142,11 +142,19 @@ class CDNA4GPTQLinearMethod(LinearMethodBase):
                                                device=layer.g_idx.device)
             layer.exllama_state = ExllamaState.READY
             ops.gptq_shuffle(layer.qweight, layer.g_idx, self.quant_config.weight_bits)
+            # big matrices also get the strip-major copy the one-launch decode GEMM reads fastest (ops.wna16_decode_strip_copy)
+            layer.qweight_strip = None if self.quant_config.desc_act else ops.wna16_decode_strip_copy(layer.qweight.data, layer.scales.data)
 
     def apply(self, layer: nn.Module, x: torch.Tensor,
               bias: Optional[torch.Tensor] = None) -> torch.Tensor:
         out_shape = x.shape[:-1] + (layer.qweight.shape[-1], )
         reshaped_x = x.reshape(-1, x.shape[-1])
+        output = ops.wna16_decode_linear(reshaped_x, layer.qweight, layer.qzeros, layer.scales, 1,
+                                         getattr(layer, "qweight_strip", None))
+        if output is not None:
+            if bias is not None:
+                output.add_(bias)
+            return output.reshape(out_shape)
         output = ops.gptq_gemm(reshaped_x, layer.qweight, layer.qzeros,
                                layer.scales, layer.g_idx,
                                layer.exllama_state == ExllamaState.READY,

@@ -579,6 +579,21 @@ int aphro_wna16_gemm_resident(const void* a_packed, const uint32_t* q_weight, co
 int aphro_wna16_strip_relayout(const uint32_t* q_weight, uint32_t* out, int64_t M, int64_t N, int64_t K,
                                int64_t groups, void* stream);
 
+/* The op-level decode GEMM (`_C::gptq_gemm` / `_C::awq_gemm` at M <= 32, torch_bindings.cpp:229-243; the role of
+ * gemm_half_q_half_gptq_4bit_kernel, q_gemm.cu:190-326, which also reads row-major `a` and writes [M, N] in one launch) in
+ * ONE launch of the resident kernel: the A fragments are gathered from the row-major f16 rows in place (no
+ * aphro_wna16_pack_a launch) and a K-sliced shape is reduced by the last-arriving slice of each strip inside the kernel
+ * (write-through partials, one ticket per strip, slices added in slice order: bits independent of arrival order) instead
+ * of a reduce launch.  workspace: K-slices x M x N floats (aphro_wna16_workspace_bytes covers it).  aphro_gptq_gemm takes
+ * this path by itself when `aphro_wna16_gemm_rowmajor_supported` (f16, no act-order permutation, a shape the resident
+ * kernel tiles; APHRO_WNA16_OP_NO_RESIDENT=1 turns it off).  APHRO_ERR_WORKSPACE without any launch when the ticket array
+ * cannot be allocated (first call under a stream capture). */
+int aphro_wna16_gemm_rowmajor_supported(int64_t M, int64_t N, int64_t K, int64_t groups, int dtype);
+int aphro_wna16_gemm_rowmajor(const void* a, int64_t lda, const uint32_t* q_weight, const uint32_t* qzeros,
+                              const void* scales, void* c, void* workspace, size_t workspace_bytes, int64_t M,
+                              int64_t N, int64_t K, int64_t groups, int zero_offset, int dtype, int strip_layout,
+                              void* stream);
+
 /* Test-rig helper: a launch that holds `stream` for `us` microseconds without touching memory -- the stand-in for an
  * all-reduce when one rank of a tensor-parallel group is timed alone (bench.py --sim-tp).  No reference counterpart. */
 int aphro_spin_us(double us, void* stream);

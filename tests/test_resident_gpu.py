@@ -137,3 +137,79 @@ def test_resident_bf16_vs_oracle(ops, K, N):
     old, _ = ops.wna16_gemm_packed(pk, M, K, t(shuf), t(qzeros), sc, 1, partials=True)
     if old.shape == slabs.shape:
         torch.testing.assert_close(slabs, old, rtol=2e-5, atol=2e-6 * float(np.abs(ref).max()))
+
+
+# ---- the op-level form: row-major activations, [M, N] out of ONE launch (aphro_wna16_gemm_rowmajor) ----------------------
+@pytest.mark.parametrize("M", [1, 7, 16, 17, 32])
+@pytest.mark.parametrize("K,N", SHAPES)
+def test_rowmajor_one_launch_vs_oracle(ops, K, N, M):
+    """What ``ops.gptq_gemm`` launches at M <= 32 for f16: the oracle bounds it; it is bit-identical to the slab form of the
+    same kernel summed in slice order (the in-kernel reduce is arrival-order independent) and to itself over 20 runs (the
+    tickets return to zero); a row pitch wider than K is read in place."""
+    shuf, qzeros, scales, a, ref = case(K, N)
+    ref = ref[:M]
+    G = K // 128
+    assert ops.wna16_gemm_rowmajor_supported(M, N, K, G, torch.float16)
+    x = t(a[:M])
+    y = ops.wna16_gemm_rowmajor(x, t(shuf), t(qzeros), t(scales), 1)
+    np.testing.assert_allclose(y.float().cpu().numpy(), ref, rtol=2e-3, atol=2e-3 * np.abs(ref).max())
+    slabs, ks = ops.wna16_gemm_resident(ops.wna16_pack_a(x), M, K, t(shuf), t(qzeros), t(scales), 1, mode="slabs")
+    s = slabs[0].clone()
+    for z in range(1, ks):
+        s += slabs[z]
+    assert torch.equal(y, s.to(torch.float16))
+    for _ in range(20):
+        assert torch.equal(ops.wna16_gemm_rowmajor(x, t(shuf), t(qzeros), t(scales), 1), y)
+    wide = torch.zeros((M, K + 72), dtype=torch.float16, device=DEV)
+    wide[:, 8:8 + K] = x
+    assert torch.equal(ops.wna16_gemm_rowmajor(wide[:, 8:8 + K], t(shuf), t(qzeros), t(scales), 1), y)
+    # the op itself takes this path ...
+    g_idx = torch.empty(0, dtype=torch.int32, device=DEV)
+    assert torch.equal(ops.gptq_gemm(x, t(shuf), t(qzeros), t(scales), g_idx, True, 4), y)
+    # ... and agrees with the three-launch path it replaces (another K partition: fp32 rounding apart)
+    os.environ["APHRO_WNA16_OP_NO_RESIDENT"] = "1"
+    try:
+        old = ops.gptq_gemm(x, t(shuf), t(qzeros), t(scales), g_idx, True, 4)
+    finally:
+        os.environ.pop("APHRO_WNA16_OP_NO_RESIDENT")
+    torch.testing.assert_close(y.float(), old.float(), rtol=2e-3, atol=2e-3 * float(np.abs(ref).max()))
+
+
+def test_rowmajor_one_launch_strip_layout_and_graph(ops):
+    """Strip-major weights give the same bits; the launch is capturable (tickets allocated by the eager call before)."""
+    K, N = 14336, 4096
+    M = 32
+    shuf, qzeros, scales, a, _ = case(K, N)
+    x = t(a[:M])
+    qw = t(shuf)
+    y = ops.wna16_gemm_rowmajor(x, qw, t(qzeros), t(scales), 1)
+    strip = ops.wna16_strip_relayout(qw, M, K // 128)
+    assert torch.equal(ops.wna16_gemm_rowmajor(x, strip, t(qzeros), t(scales), 1, strip_layout=True), y)
+    g_idx = torch.empty(0, dtype=torch.int32, device=DEV)
+    qz, sc = t(qzeros), t(scales)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = ops.gptq_gemm(x, qw, qz, sc, g_idx, True, 4)
+    for _ in range(5):
+        out.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, y)
+
+
+def test_rowmajor_awq_and_bf16_routes(ops):
+    """awq_gemm (zero offset 0) takes the same one-launch path; bf16 keeps the pack + GEMM path (the resident kernel
+    computes on f16 fragments and has no in-register bf16 widening) -- both against the oracle."""
+    rng = np.random.default_rng(5)
+    K, N, M, G = 4096, 4096, 24, 32
+    w = rng.integers(0, 16, size=(K, N), dtype=np.int32)
+    zeros = rng.integers(0, 16, size=(G, N), dtype=np.int32)
+    scales = (rng.random((G, N), dtype=np.float32) * 0.01 + 0.002).astype(np.float16)
+    a = (rng.standard_normal((M, K)) * 0.5).astype(np.float16)
+    qw = oq.awq_pack(w)
+    qz = oq.awq_pack(zeros)
+    ref = a.astype(np.float64) @ oq.awq_dequantize(qw, scales, qz).astype(np.float64)
+    y = ops.awq_gemm(t(a), t(qw), t(scales), t(qz), 8)
+    np.testing.assert_allclose(y.float().cpu().numpy(), ref, rtol=2e-3, atol=2e-3 * np.abs(ref).max())
+    assert not ops.wna16_gemm_rowmajor_supported(M, N, K, G, torch.bfloat16)
