@@ -73,7 +73,16 @@ struct PAParams {
   int nsplit;                    // 0 / 1: off
   float* split_scratch;          // [num_seqs * Hkv][nsplit][16 * HD + 32]
   unsigned* split_counter;       // [num_seqs * Hkv], zero between launches (the merging workgroup resets it)
+  unsigned long long* trace;     // PA_LAB builds (tools/attn_trace.py): [workgroup][wave][16] timeline stamps, or NULL
 };
+
+#ifdef PA_LAB
+#define PA_STAMP(i) do { if (p.trace) { __builtin_amdgcn_sched_barrier(0); stamp[i] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#define PA_WAIT_DATA() do { if (p.trace) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); } while (0)
+#else
+#define PA_STAMP(i) do { } while (0)
+#define PA_WAIT_DATA() do { } while (0)
+#endif
 
 // write-through (system-scope) store / coherent loads: partial results cross XCDs (separate L2s) inside one launch.  No
 // release / acquire FENCES: at agent scope those write back / invalidate the whole L2 (+16 us per launch).
@@ -154,12 +163,18 @@ __global__ __launch_bounds__(NW * 64) void paged_attention_kernel(PAParams p) {
   const int wave = threadIdx.x >> 6;
   const int g = lane >> 4;
   const int c = lane & 15;
+#ifdef PA_LAB
+  unsigned long long stamp[16] = {};
+  const unsigned long long wall0 = __builtin_amdgcn_s_memrealtime();
+  int it_count = 0;
+#endif
+  PA_STAMP(0);
   const int kvh = blockIdx.x;
   const int seq = blockIdx.y;
   const int part = blockIdx.z;
   const int gqa = p.num_heads / p.num_kv_heads;
-  const int seq_len = p.seq_lens[seq];
-  constexpr bool split = SPLIT;       // (a template parameter: the unsplit instantiations keep their register budget)
+  constexpr bool split = SPLIT;
+  const int seq_len = p.seq_lens[seq];       // (a template parameter: the unsplit instantiations keep their register budget)
   // split form: equal runs of 32-token pairs per workgroup of the (sequence, kv-head) group
   const int split_pp = split ? (((seq_len + 31) >> 5) + p.nsplit - 1) / p.nsplit : 0;
   const int psz = split ? max(split_pp, 1) * 32 : (p.partition_size > 0 ? p.partition_size : 0x7fffffe0);
@@ -496,7 +511,16 @@ __global__ __launch_bounds__(NW * 64) void paged_attention_kernel(PAParams p) {
       for (; pr < pair_end; pr += NW) {
         load_pair(pr, ids, kfa, vra);
         if (pr + NW < pair_end) load_ids(pr + NW, ids_next);
+#ifdef PA_LAB
+        if (it_count == 0) PA_STAMP(1);                 // first pair's loads issued
+        PA_WAIT_DATA();
+        if (it_count < 6) PA_STAMP(2 + 2 * it_count);   // pair i: data has arrived
+#endif
         compute_pair(pr, kfa, vra);
+#ifdef PA_LAB
+        if (it_count < 6) PA_STAMP(3 + 2 * it_count);   // pair i: compute issued
+        ++it_count;
+#endif
 #pragma unroll
         for (int e = 0; e < 4; ++e) ids[e] = ids_next[e];
       }
@@ -544,7 +568,16 @@ __global__ __launch_bounds__(NW * 64) void paged_attention_kernel(PAParams p) {
       }
     }
     while (have) {
+#ifdef PA_LAB
+      if (it_count == 0) PA_STAMP(1);                   // (fused form: q phase done, first pair's loads long issued)
+      PA_WAIT_DATA();
+      if (it_count < 6) PA_STAMP(2 + 2 * it_count);
+#endif
       compute_pair(pr, kfa, vra);
+#ifdef PA_LAB
+      if (it_count < 6) PA_STAMP(3 + 2 * it_count);
+      ++it_count;
+#endif
       pr += NW;
       have = pr < pair_end;
       if (have) {
@@ -563,6 +596,7 @@ __global__ __launch_bounds__(NW * 64) void paged_attention_kernel(PAParams p) {
 
     // ---- merge the NW waves through LDS ---------------------------------------------
     // layout: ml[NW][16][2] then ov[NW][16 heads][HD]
+    PA_STAMP(14);
     l_run += __shfl_xor(l_run, 16, 64);
     l_run += __shfl_xor(l_run, 32, 64);
     float* ml = lds;
@@ -686,6 +720,20 @@ __global__ __launch_bounds__(NW * 64) void paged_attention_kernel(PAParams p) {
         }
       }
     }
+#ifdef PA_LAB
+    if (p.trace && hb == 0) {
+      PA_STAMP(15);
+      if (lane == 0) {
+        unsigned long long* t = p.trace + ((((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * NW + wave) * 20;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t[i] = stamp[i];
+        t[16] = wall0;
+        t[17] = __builtin_amdgcn_s_memrealtime();
+        t[18] = __builtin_amdgcn_s_getreg(((32 - 1) << 11) | 20);    // HW_REG_XCC_ID
+        t[19] = (unsigned long long)it_count;
+      }
+    }
+#endif
   }
 }
 
@@ -853,6 +901,10 @@ static bool split_workspace(size_t groups, size_t floats, hipStream_t st, SplitW
   return true;
 }
 
+static unsigned long long* g_pa_trace = nullptr;
+// PA_LAB builds: device buffer of [workgroups][waves][20] u64 the next launches stamp their timeline into (NULL: off).
+extern "C" void aphro_paged_attention_set_trace(void* buf) { g_pa_trace = (unsigned long long*)buf; }
+
 static int paged_attention_impl(void* out, void* out_packed, float* exp_sums, float* max_logits, void* tmp_out,
                                      const void* query, const void* key_cache, const void* value_cache,
                                      int num_seqs, int num_heads, int num_kv_heads, int head_size,
@@ -900,6 +952,7 @@ static int paged_attention_impl(void* out, void* out_packed, float* exp_sums, fl
   p.nh_lds = gqa < 16 ? gqa : 16;
   int parts = 1, nw;
   p.nsplit = 0; p.split_scratch = nullptr; p.split_counter = nullptr;
+  p.trace = g_pa_trace;
   if (partition_size == 0) {
     p.partition_size = 0; p.max_parts = 0; p.write_direct = 1;
     // v1 form: one workgroup per (seq, kv head) walks the whole sequence
