@@ -1164,6 +1164,35 @@ def argmax_rows(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Te
     return out
 
 
+def lm_head_argmax_supported(m: int, k: int, v: int, ldw: int, dtype: torch.dtype) -> bool:
+    return dtype in (torch.float16, torch.bfloat16) and \
+        bool(_lib.lib().aphro_lm_head_argmax_supported(m, k, v, ldw, _DT[dtype]))
+
+
+def lm_head_argmax(hidden: torch.Tensor, weight: torch.Tensor, vocab_size: Optional[int] = None,
+                   out: Optional[torch.Tensor] = None, logits_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Greedy decode of M <= 32 rows in one launch: int64 argmax over ``hidden @ weight[:vocab_size].T`` rounded to the
+    activation dtype (LogitsProcessor._get_logits + Sampler._greedy_sample, logits_processor.py:78-96 / sampler.py);
+    ``logits_out`` [M, >= vocab_size] also receives the logits."""
+    _require_cuda(hidden, weight)
+    if hidden.dim() != 2 or weight.dim() != 2 or hidden.dtype != weight.dtype or hidden.shape[1] != weight.shape[1]:
+        raise RuntimeError("lm_head_argmax: hidden [M, K] and weight [V, K] of one dtype expected")
+    if hidden.stride(1) != 1 or weight.stride(1) != 1:
+        raise RuntimeError("lm_head_argmax: rows must be contiguous")
+    v = weight.shape[0] if vocab_size is None else int(vocab_size)
+    if v > weight.shape[0]:
+        raise RuntimeError("lm_head_argmax: vocab_size exceeds the weight rows")
+    m, k = hidden.shape
+    if out is None:
+        out = torch.empty(m, dtype=torch.int64, device=hidden.device)
+    if logits_out is not None and (logits_out.dtype != hidden.dtype or logits_out.stride(1) != 1 or logits_out.shape[0] < m):
+        raise RuntimeError("lm_head_argmax: logits_out must be [M, >= V] of the activation dtype with contiguous rows")
+    check(_lib.lib().aphro_lm_head_argmax(hidden.data_ptr(), hidden.stride(0), weight.data_ptr(), weight.stride(0),
+                                          _ptr(logits_out), logits_out.stride(0) if logits_out is not None else 0,
+                                          out.data_ptr(), m, k, v, _dt(hidden), _stream()), "lm_head_argmax")
+    return out
+
+
 # --------------------------------------------------------------------------
 # mixture of experts
 # --------------------------------------------------------------------------

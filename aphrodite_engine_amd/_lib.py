@@ -86,6 +86,8 @@ SIGNATURES = {
     "aphro_wna16_gemm_resident": (I, [P, P, P, P, P, P, Z, P, L, L, L, L, I, I, I, P]),
     "aphro_wna16_strip_relayout": (I, [P, P, L, L, L, L, P]),
     "aphro_wna16_gemm_rowmajor_supported": (I, [L, L, L, L, I]),
+    "aphro_lm_head_argmax_supported": (I, [L, L, L, L, I]),
+    "aphro_lm_head_argmax": (I, [P, L, P, L, P, L, P, L, L, L, I, P]),
     "aphro_wna16_gemm_rowmajor": (I, [P, L, P, P, P, P, P, Z, L, L, L, L, I, I, I, P]),
     "aphro_convert_fp8": (I, [P, P, L, F, I, I, I, P]),
     "aphro_paged_attention": (I, [P, P, P, P, P, P, P, I, I, I, I, F, P, P, I, I, I, P,

@@ -601,6 +601,18 @@ class LlamaForCausalLM(nn.Module):
             logits = logits[..., :self.cfg.vocab_size]          # drop the padding columns (a strided view)
         return logits
 
+    def greedy_tokens(self, hidden, out=None):
+        """Greedy next tokens straight from the final hidden states: the LM head GEMM with the argmax folded in
+        (csrc/lm_head.hip) where it is served -- one rank, <= 32 rows, 16-bit, K <= 4096 --, else logits + argmax.
+        APHRO_NO_LM_HEAD_ARGMAX=1 keeps the two-step path."""
+        import os
+        if (hidden.is_cuda and hidden.dim() == 2 and get_tensor_model_parallel_world_size() == 1
+                and not os.environ.get("APHRO_NO_LM_HEAD_ARGMAX") and hidden.stride(1) == 1
+                and ops.lm_head_argmax_supported(hidden.shape[0], hidden.shape[1], self.cfg.vocab_size,
+                                                 self.lm_head.stride(0), hidden.dtype)):
+            return ops.lm_head_argmax(hidden, self.lm_head, self.cfg.vocab_size, out)
+        return self.sample_greedy(self.compute_logits(hidden), out)
+
     def sample_greedy(self, logits, out=None):
         if logits.is_cuda and logits.dim() == 2 and logits.stride(1) == 1:
             return ops.argmax_rows(logits, out)

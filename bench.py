@@ -139,14 +139,18 @@ class DecodeLoop:
     def step(self):
         m = self.meta
         hidden = self.model(self.input_ids, self.positions, self.kv_caches, m)
-        logits = self.model.compute_logits(hidden)
         if self.sampling == "random":
             from aphrodite_engine_amd import _custom_ops as ops_
+            logits = self.model.compute_logits(hidden)
             ops_.sample_top_k_top_p(logits, self.temperature, self.top_k, self.top_p, seeds=self.seeds,
                                     out=self.next_ids)
             self.seeds.add_(1)           # a fresh stream every step, also under graph replay
+        elif self.model.use_fused_decode:
+            # greedy: LM head GEMM + argmax in one launch where served (model.greedy_tokens, csrc/lm_head.hip)
+            self.model.greedy_tokens(hidden, self.next_ids)
         else:
-            self.model.sample_greedy(logits, self.next_ids)
+            # the op-by-op path keeps the reference's two steps (LogitsProcessor, then Sampler._greedy_sample)
+            self.model.sample_greedy(self.model.compute_logits(hidden), self.next_ids)
         # advance: the generated token becomes the next input, context grows by one
         # (advance_step_flashattn, prepare_inputs/advance_step.cu: one launch instead of six)
         from aphrodite_engine_amd import _custom_ops as ops

@@ -671,6 +671,20 @@ int aphro_advance_step_flashattn(int num_seqs, int num_queries, int block_size,
                                  int64_t* slot_mapping, const int32_t* block_tables,
                                  int64_t block_tables_stride, void* stream);
 
+/* Decode-time LM head with the greedy argmax folded in: out_ids[m] = argmax_v round_T(hidden[m, :] . weight[v, :]) for
+ * M <= 32 rows, one launch.  The reference computes the logits with a library GEMM (LogitsProcessor._get_logits,
+ * modeling/layers/logits_processor.py:78-96: lm_head.linear_method.apply) and Sampler._greedy_sample takes torch.argmax
+ * (modeling/layers/sampler.py); this entry is what a greedy-only decode batch needs of the two: the fp32 sums are rounded
+ * to the activation dtype before they are compared (the values the reference's argmax sees), ties go to the lowest index,
+ * NaN never wins (= aphro_argmax_rows).  logits != NULL also stores them ([M, ldl], columns < V).  weight: [V, ldw]
+ * row-major 16-bit (K contiguous), V >= 16; K in {1024, 2048, 3072, 4096}.  HBM-bound (every weight byte read once).
+ * APHRO_ERR_WORKSPACE without a launch when the library-owned scratch cannot be allocated (first call under a stream
+ * capture).  TP: a vocabulary-parallel head needs the (value, index) pairs of all ranks -- callers with tp > 1 keep the
+ * GEMM + all-gather + argmax path. */
+int aphro_lm_head_argmax_supported(int64_t M, int64_t K, int64_t V, int64_t ldw, int dtype);
+int aphro_lm_head_argmax(const void* hidden, int64_t lda, const void* weight, int64_t ldw, void* logits, int64_t ldl,
+                         int64_t* out_ids, int64_t M, int64_t K, int64_t V, int dtype, void* stream);
+
 /* Greedy sampling: out[r] = argmax_c x[r][c] (lowest index on ties) -- the torch.argmax of
  * modeling/layers/sampler.py:_greedy_sample as one pass over each logits row. */
 int aphro_argmax_rows(int64_t* out, const void* x, int64_t rows, int64_t cols,

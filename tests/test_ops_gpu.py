@@ -1833,3 +1833,67 @@ def test_context_attention_fwd_every_shape_on_the_tile_machines(ops, Hq, Hkv, D,
                                kc.float().cpu().numpy(), vc.float().cpu().numpy(), bt, start, seq_lens, ctx_lens, D ** -0.5,
                                "auto", 1.0, 1.0, slopes, window or 0, rnd)
     np.testing.assert_allclose(out.float().cpu().numpy(), ref, atol=2e-3, rtol=2e-3)
+
+
+# ---- LM head with the greedy argmax folded in (csrc/lm_head.hip) ---------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,K,V", [(32, 4096, 128256), (1, 4096, 128256), (17, 2048, 32000), (8, 1024, 50), (32, 3072, 1000),
+                                   (16, 4096, 151936 // 8 + 3)])
+def test_lm_head_argmax_vs_oracle(ops, M, K, V, dtype):
+    """out_ids = argmax over round_T(hidden . W^T): the kernel's logits agree with an fp64 product to accumulation
+    rounding, the chosen index is the argmax of the kernel's OWN logits exactly (ties -> lowest index), and the oracle's
+    argmax is within one rounding step of the chosen logit (the two may differ only on near-ties)."""
+    g = torch.Generator(device="cpu").manual_seed(M * 131 + K + V)
+    h = (torch.randn(M, K, generator=g) * 0.7).to(dtype)
+    w = (torch.randn(V, K, generator=g) * 0.05).to(dtype)
+    ref = h.double() @ w.double().T                                        # oracle: exact products, fp64 sums
+    hd, wd = h.to(DEV), w.to(DEV)
+    logits = torch.full((M, V + 5), float("nan"), dtype=dtype, device=DEV)
+    ids = ops.lm_head_argmax(hd, wd, V, logits_out=logits)
+    got = logits[:, :V].double().cpu()
+    assert torch.isnan(logits[:, V:].float()).all()                        # nothing written past V
+    eps = 2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7
+    tol = eps * ref.abs().max().item() + 1e-3
+    assert (got - ref).abs().max().item() <= tol
+    # the index is the argmax of the stored logits, lowest index on ties
+    mx = logits[:, :V].float().max(dim=1, keepdim=True).values
+    first = (logits[:, :V].float() == mx).float().argmax(dim=1)
+    assert torch.equal(ids.cpu(), first.cpu())
+    # and the oracle's choice is no better than one rounding step
+    chosen = ref.gather(1, ids.cpu().view(-1, 1)).squeeze(1)
+    assert (ref.max(dim=1).values - chosen).max().item() <= 2 * tol
+    # without the logits output: same ids; deterministic over repeated launches (the ticket returns to zero)
+    for _ in range(5):
+        assert torch.equal(ops.lm_head_argmax(hd, wd, V), ids)
+
+
+def test_lm_head_argmax_ties_padding_and_graph(ops):
+    """Ties go to the lowest index; rows of the weight past vocab_size (padding) never win; a strided hidden / a padded
+    weight pitch are read in place; the launch is capturable."""
+    M, K, V = 12, 2048, 777
+    g = torch.Generator(device="cpu").manual_seed(3)
+    w_full = torch.zeros(V + 23, K + 64, dtype=torch.float16)
+    w_full[:V, :K] = (torch.randn(V, K, generator=g) * 0.05).half()
+    w_full[V:, :K] = 50.0                                                   # padding rows would win every row
+    w_full[300, :K] = w_full[100, :K]                                       # an exact tie between two rows
+    h_full = torch.zeros(M, K + 8, dtype=torch.float16)
+    h_full[:, :K] = (torch.randn(M, K, generator=g) * 0.7).half()
+    h_full[0, :K] = w_full[100, :K] * 40                                    # row 0 is maximised by rows 100 == 300
+    wd, hd = w_full.to(DEV), h_full.to(DEV)
+    ids = ops.lm_head_argmax(hd[:, :K], wd[:, :K], V)
+    ref = (h_full[:, :K].double() @ w_full[:V, :K].double().T).half()
+    mx = ref.float().max(dim=1, keepdim=True).values
+    assert int(ids[0]) == 100
+    chosen = ref.float().gather(1, ids.cpu().view(-1, 1))
+    assert ((mx - chosen).abs() <= 2.0 ** -9 * mx.abs() + 1e-3).all()
+    assert (ids.cpu() < V).all()
+    out = torch.zeros(M, dtype=torch.int64, device=DEV)
+    torch.cuda.synchronize()
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        ops.lm_head_argmax(hd[:, :K], wd[:, :K], V, out=out)
+    for _ in range(3):
+        out.zero_()
+        gr.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, ids)
