@@ -385,6 +385,16 @@ def gptq_shuffle(q_weight: torch.Tensor, q_perm: torch.Tensor, bit: int) -> None
     _require_cuda(q_weight)
     rows, n = q_weight.shape
     perm = q_perm if (q_perm is not None and q_perm.numel() > 0) else None
+    if bit in (2, 3, 8):
+        # the layout after the shuffle is private to the kernels that read it: these widths keep the checkpoint's
+        # sequential bitstring, act-order rows made sequential (csrc/wnx_gemm.hip)
+        if perm is not None:
+            tmp = torch.empty_like(q_weight)
+            check(_lib.lib().aphro_gptq_make_sequential_bits(q_weight.data_ptr(), tmp.data_ptr(),
+                                                             perm.to(torch.int32).data_ptr(), rows * 32 // bit, n, bit,
+                                                             _stream()), "gptq_shuffle")
+            q_weight.copy_(tmp)
+        return
     tmp = torch.empty_like(q_weight) if perm is not None else None
     if perm is not None and perm.dtype != torch.int32:
         perm = perm.to(torch.int32)
@@ -397,8 +407,16 @@ def gptq_dequant(b_q_weight, b_gptq_qzeros, b_gptq_scales, b_g_idx,
                  use_exllama: bool, bit: int = 4, zero_offset: int = 1):
     """temp_dq of q_gemm.cu:1520-1535: the fp16 weight the reference hands to
     hipBLAS for M > 50."""
+    if bit in (2, 3, 8):
+        k, n = b_q_weight.shape[0] * 32 // bit, b_q_weight.shape[1]
+        out = torch.empty((k, n), dtype=b_gptq_scales.dtype, device=b_q_weight.device)
+        g_idx = b_g_idx.to(torch.int32) if (not use_exllama and b_g_idx is not None and b_g_idx.numel() > 0) else None
+        check(_lib.lib().aphro_gptq_dequant_bits(b_q_weight.data_ptr(), b_gptq_qzeros.data_ptr(), b_gptq_scales.data_ptr(),
+                                                 _ptr(g_idx), out.data_ptr(), k, n, b_gptq_scales.shape[0], bit,
+                                                 _dt(b_gptq_scales), _stream()), "gptq_dequant")
+        return out
     if bit != 4:
-        raise RuntimeError("only 4-bit GPTQ is implemented")
+        raise RuntimeError(f"GPTQ weight width {bit} is not one of 2, 3, 4, 8")
     k, n = b_q_weight.shape[0] * 8, b_q_weight.shape[1]
     out = torch.empty((k, n), dtype=b_gptq_scales.dtype, device=b_q_weight.device)
     g_idx = None
@@ -513,10 +531,12 @@ def gptq_gemm(a: torch.Tensor, b_q_weight: torch.Tensor,
               b_gptq_qzeros: torch.Tensor, b_gptq_scales: torch.Tensor,
               b_g_idx: torch.Tensor, use_exllama: bool, bit: int) -> torch.Tensor:
     _require_cuda(a, b_q_weight, b_gptq_qzeros, b_gptq_scales)
-    if bit != 4:
-        raise RuntimeError("gptq_gemm: only 4-bit is implemented on MI355X")
     if a.dtype != b_gptq_scales.dtype:
         raise RuntimeError("gptq_gemm: activations and scales must share a dtype")
+    if bit in (2, 3, 8):
+        return _gptq_gemm_bits(a, b_q_weight, b_gptq_qzeros, b_gptq_scales, b_g_idx, use_exllama, bit)
+    if bit != 4:
+        raise RuntimeError(f"gptq_gemm: weight width {bit} is not one of 2, 3, 4, 8")
     m = a.shape[0]
     large = use_exllama and wna16_large_ok(m, b_q_weight.shape[1], a.shape[1], b_gptq_scales.shape[0]) \
         and wna16_prefers_large(m, b_q_weight.shape[1], a.shape[1]) and not os.environ.get("APHRO_WNA16_NO_LARGE")
@@ -532,6 +552,32 @@ def gptq_gemm(a: torch.Tensor, b_q_weight: torch.Tensor,
     if b_g_idx is not None and b_g_idx.numel() > 0:
         perm = b_g_idx.to(torch.int32) if b_g_idx.dtype != torch.int32 else b_g_idx
     return _wna16(a, b_q_weight, b_gptq_qzeros, b_gptq_scales, perm, 1)
+
+
+def _gptq_gemm_bits(a, qweight, qzeros, scales, g_idx, use_exllama: bool, bit: int) -> torch.Tensor:
+    """2 / 3 / 8-bit GPTQ (q_gemm.cu:329-700, 1526-1560): the MFMA small-M kernel on the sequential layout at <= 32 rows
+    (64 in two passes), else the weight reconstructed once (bit for bit the reference's reconstruct kernels) + a library
+    GEMM -- the reference's own rule above 50 (8-bit: 24) rows."""
+    lib = _lib.lib()
+    m, k = a.shape
+    n, groups = qweight.shape[1], scales.shape[0]
+    has_perm = g_idx is not None and g_idx.numel() > 0
+    if use_exllama and 0 < m <= 64 and lib.aphro_gptq_gemm_bits_supported(min(m, 32), n, k, groups, bit):
+        x = a[:, g_idx.long()] if has_perm else a           # act-order: gather once (q_gemm.cu:219-226)
+        if x.stride(1) != 1 or x.stride(0) % 8 != 0 or x.data_ptr() % 16 != 0:
+            x = x.contiguous()
+        out = torch.empty((m, n), dtype=a.dtype, device=a.device)
+        for m0 in range(0, m, 32):
+            rows = min(32, m - m0)
+            check(lib.aphro_gptq_gemm_bits(x[m0:].data_ptr(), x.stride(0), qweight.data_ptr(), qzeros.data_ptr(),
+                                           scales.data_ptr(), out[m0:].data_ptr(), rows, n, k, groups, bit, _dt(a),
+                                           _stream()), "gptq_gemm")
+        return out
+    w = gptq_dequant(qweight, qzeros, scales, g_idx, use_exllama, bit)
+    if use_exllama and has_perm:
+        a = a[:, g_idx.long()]
+    _library_fallback("gptq_gemm", f"{bit}-bit weights at M={m}: gptq_dequant + matmul")
+    return torch.matmul(a, w)
 
 
 def gptq_marlin_repack(b_q_weight: torch.Tensor, perm: torch.Tensor, size_k: int,

@@ -39,13 +39,30 @@ void ok(int rc, const char* op) { TORCH_CHECK(rc == APHRO_OK, op, ": ", aphro_la
 // gptq_gemm (q_gemm.cu:1824-1859): c [M, N] in a's dtype
 torch::Tensor gptq_gemm(torch::Tensor a, torch::Tensor b_q_weight, torch::Tensor b_gptq_qzeros, torch::Tensor b_gptq_scales,
                         torch::Tensor b_g_idx, bool use_exllama, int64_t bit) {
-  TORCH_CHECK(use_exllama && bit == 4, "gptq_gemm on MI355X: 4-bit exllama-shuffled weights only");
+  TORCH_CHECK(use_exllama && (bit == 2 || bit == 3 || bit == 4 || bit == 8),
+              "gptq_gemm on MI355X: exllama-shuffled 2 / 3 / 4 / 8-bit weights (the non-exllama form is served by the Python op)");
   TORCH_CHECK(a.is_cuda() && a.dim() == 2 && a.stride(1) == 1, "gptq_gemm: a must be a row-major device matrix");
   const int64_t m = a.size(0), k = a.size(1), n = b_q_weight.size(1);
   auto out = torch::empty({m, n}, a.options());
   const bool act_order = b_g_idx.numel() > 0 && b_g_idx.device().is_cuda();
   const int64_t groups = b_gptq_scales.size(0);
   TORCH_CHECK(groups > 0 && k % groups == 0, "gptq_gemm: scales [groups, N] with groups dividing K (groups=", groups, ", K=", k, ")");
+  if (bit != 4) {   // csrc/wnx_gemm.hip: MFMA small-M kernel on the sequential layout, else reconstruct + library GEMM
+    torch::Tensor ag = act_order ? a.index_select(1, b_g_idx.to(torch::kLong)) : a;
+    if (ag.stride(1) != 1 || ag.stride(0) % 8 != 0) ag = ag.contiguous();
+    if (m >= 1 && m <= 32 && aphro_gptq_gemm_bits_supported(m, n, k, groups, (int)bit)) {
+      ok(aphro_gptq_gemm_bits(ag.data_ptr(), ag.stride(0), (const uint32_t*)b_q_weight.data_ptr(),
+                              (const uint32_t*)b_gptq_qzeros.data_ptr(), b_gptq_scales.data_ptr(), out.data_ptr(), m, n, k,
+                              groups, (int)bit, act_dtype(a), cur_stream()),
+         "gptq_gemm");
+      return out;
+    }
+    auto w = torch::empty({k, n}, a.options());
+    ok(aphro_gptq_dequant_bits((const uint32_t*)b_q_weight.data_ptr(), (const uint32_t*)b_gptq_qzeros.data_ptr(),
+                               b_gptq_scales.data_ptr(), nullptr, w.data_ptr(), k, n, groups, (int)bit, act_dtype(a), cur_stream()),
+       "gptq_gemm");
+    return torch::matmul(ag, w);
+  }
   if (m > 64 && n % 128 == 0 && k % 64 == 0 && k % groups == 0 && (k / groups) % 64 == 0) {
     // prefill-sized M: one MFMA kernel that dequantises in registers (the reference reconstructs + calls hipBLAS,
     // q_gemm.cu:1529-1544); act-order = gather the activation columns once

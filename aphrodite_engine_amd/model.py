@@ -113,7 +113,8 @@ class QuantLinear(nn.Module):
         CDNA4 K-packed layout served by the packed-activation W4A16 kernel."""
         from .quantization.gptq import ExllamaState
         if isinstance(self.quant_config, GPTQConfig):
-            if getattr(self, "exllama_state", None) == ExllamaState.READY and self.g_idx.numel() == 0:
+            if getattr(self, "exllama_state", None) == ExllamaState.READY and self.g_idx.numel() == 0 \
+                    and self.quant_config.weight_bits == 4:
                 return self.qweight, self.qzeros, self.scales, 1
         elif isinstance(self.quant_config, AWQConfig) and getattr(self, "awq_prepacked", False):
             return self.qweight, self.qzeros, self.scales, 0

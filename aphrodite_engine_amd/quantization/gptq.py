@@ -23,10 +23,10 @@ class GPTQConfig(QuantizationConfig):
         self.desc_act = desc_act
         self.lm_head_quantized = lm_head_quantized
         self.pack_factor = Fraction(32, self.weight_bits)
-        if self.weight_bits != 4:
-            raise ValueError("MI355X GPTQ path implements 4-bit weights only "
-                             f"(got {self.weight_bits}); 2/3/8-bit are optional "
-                             "in the scope table (SURVEY 2.2)")
+        if self.weight_bits not in [2, 3, 4, 8]:
+            raise ValueError(
+                "Currently, only 2/3/4/8-bit weight quantization is "
+                f"supported for GPTQ, but got {self.weight_bits} bits.")
 
     def __repr__(self) -> str:
         return (f"GPTQConfig(weight_bits={self.weight_bits}, "
@@ -60,6 +60,8 @@ class GPTQConfig(QuantizationConfig):
     def get_quant_method(self, layer: nn.Module, prefix: str):
         kind = layer_kind(layer)
         if kind == "moe":                 # int4 experts: grouped CDNA4 GEMM (moe.py)
+            if self.weight_bits != 4:
+                raise ValueError(f"GPTQ experts are served at 4 bits only (got {self.weight_bits})")
             from ..moe import Wna16MoEMethod
             return Wna16MoEMethod("gptq", self.group_size, self.desc_act)
         if kind == "linear" or (kind == "embedding" and self.lm_head_quantized
@@ -107,7 +109,8 @@ class CDNA4GPTQLinearMethod(LinearMethodBase):
             else:
                 scale_and_zero_size = input_size_per_partition // group_size
                 scale_and_zero_input_dim = 0
-        pf = int(cfg.pack_factor)
+        # 3-bit: 32 values per 3 words -- a Fraction, as in the reference (gptq.py:37); `n // pf` / `n % pf` stay exact
+        pf = int(cfg.pack_factor) if cfg.pack_factor.denominator == 1 else cfg.pack_factor
         layer.register_parameter("qweight", _param(
             torch.empty(input_size_per_partition // pf, output_size_per_partition,
                         dtype=torch.int32),
@@ -143,7 +146,8 @@ class CDNA4GPTQLinearMethod(LinearMethodBase):
             layer.exllama_state = ExllamaState.READY
             ops.gptq_shuffle(layer.qweight, layer.g_idx, self.quant_config.weight_bits)
             # big matrices also get the strip-major copy the one-launch decode GEMM reads fastest (ops.wna16_decode_strip_copy)
-            layer.qweight_strip = None if self.quant_config.desc_act else ops.wna16_decode_strip_copy(layer.qweight.data, layer.scales.data)
+            layer.qweight_strip = None if (self.quant_config.desc_act or self.quant_config.weight_bits != 4) \
+                else ops.wna16_decode_strip_copy(layer.qweight.data, layer.scales.data)
 
     def apply(self, layer: nn.Module, x: torch.Tensor,
               bias: Optional[torch.Tensor] = None) -> torch.Tensor:

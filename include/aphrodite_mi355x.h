@@ -671,6 +671,24 @@ int aphro_advance_step_flashattn(int num_seqs, int num_queries, int block_size,
                                  int64_t* slot_mapping, const int32_t* block_tables,
                                  int64_t block_tables_stride, void* stream);
 
+/* GPTQ 2 / 3 / 8-bit weights (`_C::gptq_gemm` / `_C::gptq_shuffle` with bit != 4, torch_bindings.cpp:229-243;
+ * gemm_half_q_half_gptq_{2,3,8}bit_kernel q_gemm.cu:329-700, reconstruct_gptq q_gemm.cu:1394-1505, make_sequential /
+ * shuffle q_gemm.cu:1659-1872; csrc/wnx_gemm.hip).  Layout: the checkpoint's -- values (zero points: along N) laid end to
+ * end in uint32 words, 32 values per `bits` words; after gptq_shuffle the SAME words with act-order rows made sequential
+ * (the post-shuffle layout is private to the library that reads it).
+ *   aphro_gptq_dequant_bits   [K, N] 16-bit = (q - (z + 1)) * s, one rounding: the reference's reconstruct kernels bit for
+ *                             bit (g_idx: row -> group, or NULL = k / group_size).
+ *   aphro_gptq_gemm_bits      M <= 32 rows on the sequential layout, MFMA on the integers, fp32 group sums; act-order:
+ *                             pass a[:, perm].  aphro_gptq_gemm_bits_supported: 1 if the shape is served.
+ *   aphro_gptq_make_sequential_bits   new row k = source row perm[k]; out != q_weight. */
+int aphro_gptq_dequant_bits(const uint32_t* q_weight, const uint32_t* qzeros, const void* scales, const int32_t* g_idx,
+                            void* out, int64_t K, int64_t N, int64_t groups, int bits, int dtype, void* stream);
+int aphro_gptq_gemm_bits_supported(int64_t M, int64_t N, int64_t K, int64_t groups, int bits);
+int aphro_gptq_gemm_bits(const void* a, int64_t lda, const uint32_t* q_weight, const uint32_t* qzeros, const void* scales,
+                         void* c, int64_t M, int64_t N, int64_t K, int64_t groups, int bits, int dtype, void* stream);
+int aphro_gptq_make_sequential_bits(const uint32_t* q_weight, uint32_t* out, const int32_t* perm, int64_t K, int64_t N,
+                                    int bits, void* stream);
+
 /* Decode-time LM head with the greedy argmax folded in: out_ids[m] = argmax_v round_T(hidden[m, :] . weight[v, :]) for
  * M <= 32 rows, one launch.  The reference computes the logits with a library GEMM (LogitsProcessor._get_logits,
  * modeling/layers/logits_processor.py:78-96: lm_head.linear_method.apply) and Sampler._greedy_sample takes torch.argmax

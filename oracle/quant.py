@@ -79,8 +79,32 @@ def quantize_weights(w, num_bits=4, group_size=128, zero_points=False,
 # --------------------------------------------------------------------------
 # GPTQ (AutoGPTQ v1) tensors
 # --------------------------------------------------------------------------
+def _pack_bitstring(q, num_bits, axis):
+    """Values laid end to end, little-endian, into uint32 words along `axis` -- what AutoGPTQ does for every width; for
+    3 bits 32 values fill 3 words and values 10 / 21 straddle a word boundary (the reference reads them back exactly so:
+    reconstruct_gptq_3bit_kernel, q_gemm.cu:1437-1478; MatrixView_q3_row, matrix_view.cuh:185-212)."""
+    q = np.moveaxis(np.asarray(q).astype(np.uint64), axis, 0)
+    n = q.shape[0]
+    assert (n * num_bits) % 32 == 0
+    bits = ((q[:, None, ...] >> np.arange(num_bits, dtype=np.uint64).reshape((1, num_bits) + (1, ) * (q.ndim - 1))) & 1)
+    bits = bits.reshape((n * num_bits // 32, 32) + q.shape[1:]).astype(np.uint64)
+    words = (bits << np.arange(32, dtype=np.uint64).reshape((1, 32) + (1, ) * (q.ndim - 1))).sum(axis=1)
+    return np.moveaxis(words.astype(np.uint32), 0, axis)
+
+
+def _unpack_bitstring(words, num_bits, axis):
+    w = np.moveaxis(np.asarray(words).view(np.uint32).astype(np.uint64), axis, 0)
+    nw = w.shape[0]
+    bits = (w[:, None, ...] >> np.arange(32, dtype=np.uint64).reshape((1, 32) + (1, ) * (w.ndim - 1))) & 1
+    bits = bits.reshape((nw * 32 // num_bits, num_bits) + w.shape[1:])
+    vals = (bits << np.arange(num_bits, dtype=np.uint64).reshape((1, num_bits) + (1, ) * (w.ndim - 1))).sum(axis=1)
+    return np.moveaxis(vals.astype(np.int32), 0, axis)
+
+
 def gptq_pack(q_w, num_bits=4):
     """pack_rows, quant_utils.py:334-355: nibble i of word r = element 8r+i."""
+    if 32 % num_bits != 0:
+        return _pack_bitstring(q_w, num_bits, 0).view(np.int32)
     q_w = np.asarray(q_w).astype(np.uint32)
     pf = 32 // num_bits
     size_k, size_n = q_w.shape
@@ -93,6 +117,8 @@ def gptq_pack(q_w, num_bits=4):
 
 def gptq_unpack(qweight, num_bits=4):
     """Inverse of gptq_pack -> int32 [K,N]."""
+    if 32 % num_bits != 0:
+        return _unpack_bitstring(qweight, num_bits, 0)
     qw = np.asarray(qweight).view(np.uint32)
     pf = 32 // num_bits
     rows, size_n = qw.shape
@@ -104,6 +130,12 @@ def gptq_unpack(qweight, num_bits=4):
 
 
 def pack_cols(q_w, num_bits=4):
+    if 32 % num_bits != 0:
+        return _pack_bitstring(q_w, num_bits, 1).view(np.int32)
+    return _pack_cols_pow2(q_w, num_bits)
+
+
+def _pack_cols_pow2(q_w, num_bits=4):
     """quant_utils.py:358-380: nibble i of word c = column 8c+i."""
     q_w = np.asarray(q_w).astype(np.uint32)
     pf = 32 // num_bits
@@ -116,6 +148,12 @@ def pack_cols(q_w, num_bits=4):
 
 
 def unpack_cols(packed, num_bits=4):
+    if 32 % num_bits != 0:
+        return _unpack_bitstring(packed, num_bits, 1)
+    return _unpack_cols_pow2(packed, num_bits)
+
+
+def _unpack_cols_pow2(packed, num_bits=4):
     """quant_utils.py:383-411."""
     p = np.asarray(packed).view(np.uint32)
     pf = 32 // num_bits
@@ -171,10 +209,21 @@ def make_sequential_4bit(qweight, q_perm):
     return gptq_pack(w[q_perm, :])
 
 
-def gptq_shuffle(qweight, q_perm=None):
+def gptq_shuffle(qweight, q_perm=None, bits=4):
     """ops.gptq_shuffle (q_gemm.cu:1826-1860, 4-bit): optional row permutation
     (act-order) followed by the per-word nibble shuffle.  Returns a new int32
-    array (the op mutates in place)."""
+    array (the op mutates in place).
+
+    bits 2 / 3 / 8: the layout AFTER the shuffle is private to the kernels that
+    consume it (the reference's shuffle_{2,3,8}bit_kernel reorder the fields inside
+    a word for ITS dequant routines); this package keeps the checkpoint's
+    sequential bitstring and only makes act-order rows sequential
+    (make_sequential_{2,3,8}bit_kernel's role, q_gemm.cu:1659-1820)."""
+    if bits != 4:
+        qw = np.asarray(qweight)
+        if q_perm is not None and len(q_perm) > 0:
+            return gptq_pack(gptq_unpack(qw, bits)[np.asarray(q_perm).astype(np.int64), :], bits)
+        return qw.copy()
     qw = np.asarray(qweight)
     if q_perm is not None and len(q_perm) > 0:
         qw = make_sequential_4bit(qw, q_perm)
@@ -182,7 +231,7 @@ def gptq_shuffle(qweight, q_perm=None):
 
 
 def gptq_dequant(qweight, qzeros, scales, g_idx=None, shuffled=False,
-                 group_size=None):
+                 group_size=None, bits=4):
     """W[K,N] float32 = (q - (z_stored + 1)) * s   (q_gemm.cu:1394-1434).
 
     qweight int32 [K/8,N] (AutoGPTQ order, or exllama order when shuffled),
@@ -191,10 +240,11 @@ def gptq_dequant(qweight, qzeros, scales, g_idx=None, shuffled=False,
     in [-16,15] with an fp16 scale is exact in fp32.
     """
     qw = np.asarray(qweight).view(np.uint32)
-    if shuffled:
+    if shuffled and bits == 4:
         qw = unshuffle_4bit_word(qw)
-    q = gptq_unpack(qw.view(np.int32))                     # [K,N]
-    z = gptq_unpack_zeros(qzeros)                          # [G,N]
+    q = gptq_unpack(qw.view(np.int32), bits)               # [K,N]
+    z = gptq_unpack_zeros(qzeros, bits)                    # [G,N]  (stored + 1, NOT masked: 8-bit 255 -> 256, as the
+    #                                                        reference's uint32 `item + 1`, q_gemm.cu:1427)
     s = np.asarray(scales).astype(np.float32)              # [G,N]
     size_k = q.shape[0]
     groups = s.shape[0]
@@ -214,14 +264,14 @@ def gptq_gemm(a, qweight, qzeros, scales, g_idx, use_exllama, bit=4):
     k // group_size in the permuted order.
     use_exllama=False: qweight is in AutoGPTQ order and g_idx maps row->group.
     """
-    assert bit == 4
+    assert bit in (2, 3, 4, 8)
     a = np.asarray(a).astype(np.float64)
     if use_exllama:
-        w = gptq_dequant(qweight, qzeros, scales, None, shuffled=True)
+        w = gptq_dequant(qweight, qzeros, scales, None, shuffled=True, bits=bit)
         if g_idx is not None and len(g_idx) > 0:
             a = a[:, np.asarray(g_idx).astype(np.int64)]
     else:
-        w = gptq_dequant(qweight, qzeros, scales, g_idx, shuffled=False)
+        w = gptq_dequant(qweight, qzeros, scales, g_idx, shuffled=False, bits=bit)
     return a @ w.astype(np.float64)
 
 

@@ -143,6 +143,25 @@ void ref_gptq_reconstruct(const uint32_t* b_q_weight, const uint32_t* b_gptq_qze
   });
 }
 
+// reconstruct_gptq (q_gemm.cu:1480-1505) for the other widths: <MatrixView_q2_row, 2>, reconstruct_gptq_3bit_kernel,
+// <MatrixView_q8_row, 8> -- the DEFINITION of the 2 / 3 / 8-bit checkpoint layout (values and zero points laid end to end,
+// 3-bit values 10 and 21 straddling words) that oracle/quant.py's bitstring pack / unpack restates.
+int ref_gptq_reconstruct_bits(const uint32_t* b_q_weight, const uint32_t* b_gptq_qzeros, const uint16_t* b_gptq_scales,
+                              const int* b_g_idx, int height, int width, int groups, int bit, uint16_t* out) {
+  const half* sc = reinterpret_cast<const half*>(b_gptq_scales);
+  half* o = reinterpret_cast<half*>(out);
+  dim3 block(BLOCK_KN_SIZE, 1, 1), grid(DIVIDE(width, BLOCK_KN_SIZE), bit == 3 ? DIVIDE(height, 32) : DIVIDE(height, 32 / bit), 1);
+  if (bit == 2)
+    cuemu::launch(grid, block, [&] { reconstruct_gptq_kernel<MatrixView_q2_row, 2>(b_q_weight, sc, b_gptq_qzeros, b_g_idx, height, width, groups, o); });
+  else if (bit == 3)
+    cuemu::launch(grid, block, [&] { reconstruct_gptq_3bit_kernel(b_q_weight, sc, b_gptq_qzeros, b_g_idx, height, width, groups, o); });
+  else if (bit == 8)
+    cuemu::launch(grid, block, [&] { reconstruct_gptq_kernel<MatrixView_q8_row, 8>(b_q_weight, sc, b_gptq_qzeros, b_g_idx, height, width, groups, o); });
+  else
+    return -1;
+  return 0;
+}
+
 // fp32 -> binary16 bits with the shim's RNE conversion (so that fixtures can be made without torch)
 uint16_t ref_f32_to_f16(float f) { return cuemu::d2h((double)f); }
 float ref_f16_to_f32(uint16_t h) { return cuemu::h2f(h); }

@@ -48,7 +48,7 @@ def fp8_quant(w, per_channel):
 
 
 def write_checkpoint(path, cfg, fmt, seed=0, group_size=128, kv_scales=None, fp8_static=False,
-                     embedded_config=True, fused_on_disk=False, extra_bias=True):
+                     embedded_config=True, fused_on_disk=False, extra_bias=True, bits=4):
     """fmt: fp16 | gptq | awq | fp8 | ct-fp8-channel | ct-fp8-tensor | ct-w8a16 | ct-w4a16.
     kv_scales: None | "kv" (per-layer k_scale + v_scale) | "legacy" (kv_scale) | "ct" ({k,v}_proj.output_scale).
     Returns {"tensors": {hf name: tensor}, "logical": {hf module name: dict of logical matrices}}."""
@@ -86,11 +86,11 @@ def write_checkpoint(path, cfg, fmt, seed=0, group_size=128, kv_scales=None, fp8
                 tensors[name + ".weight"] = torch.from_numpy(np.ascontiguousarray(w.T)).half()
                 logical[name] = {"w": w.astype(np.float16)}
             elif fmt in ("gptq", "awq"):
-                _, q, s, zp = oq.quantize_weights(w, 4, group_size, zero_points=True)
+                _, q, s, zp = oq.quantize_weights(w, bits if fmt == "gptq" else 4, group_size, zero_points=True)
                 logical[name] = {"q": q, "s": s.astype(np.float16), "zp": zp}
                 if fmt == "gptq":
-                    tensors[name + ".qweight"] = torch.from_numpy(oq.gptq_pack(q, 4).astype(np.int32))
-                    tensors[name + ".qzeros"] = torch.from_numpy(oq.gptq_pack_zeros(zp, 4).astype(np.int32))
+                    tensors[name + ".qweight"] = torch.from_numpy(oq.gptq_pack(q, bits).astype(np.int32))
+                    tensors[name + ".qzeros"] = torch.from_numpy(oq.gptq_pack_zeros(zp, bits).astype(np.int32))
                     tensors[name + ".g_idx"] = torch.from_numpy((np.arange(K) // group_size).astype(np.int32))
                     if extra_bias:
                         tensors[name + ".bias"] = torch.zeros(N, dtype=torch.float16)   # AutoGPTQ exports these
@@ -138,7 +138,7 @@ def write_checkpoint(path, cfg, fmt, seed=0, group_size=128, kv_scales=None, fp8
             gu = [tensors.pop(base + f"mlp.{p}_proj.weight") for p in ("gate", "up")]
             tensors[base + "mlp.gate_up_proj.weight"] = torch.cat(gu, 0)
     if fmt == "gptq":
-        qcfg = {"bits": 4, "group_size": group_size, "desc_act": False, "quant_method": "gptq"}
+        qcfg = {"bits": bits, "group_size": group_size, "desc_act": False, "quant_method": "gptq"}
         if not embedded_config:
             extra_files["quantize_config.json"] = {k: v for k, v in qcfg.items() if k != "quant_method"}
     elif fmt == "awq":

@@ -63,6 +63,31 @@ def ref_recon_gptq(lib, qweight, qzeros, scales, g_idx):
     return out
 
 
+def ref_recon_gptq_bits(lib, qweight, qzeros, scales, g_idx, bits):
+    """reconstruct_gptq for 2 / 3 / 8-bit checkpoints (q_gemm.cu:1394-1505)."""
+    rows, n = qweight.shape
+    k = rows * 32 // bits
+    g = scales.shape[0]
+    out = np.zeros((k, n), dtype=np.float16)
+    rc = lib.ref_gptq_reconstruct_bits(_p(np.ascontiguousarray(qweight)), _p(np.ascontiguousarray(qzeros)),
+                                       _p(np.ascontiguousarray(scales)), _p(np.ascontiguousarray(g_idx, dtype=np.int32)),
+                                       ctypes.c_int(k), ctypes.c_int(n), ctypes.c_int(g), ctypes.c_int(bits), _p(out))
+    assert rc == 0
+    return out
+
+
+def make_case_bits(rng, k, n, group_size, act_order, bits):
+    g = k // group_size
+    qweight = rng.integers(0, 2**32, size=(k * bits // 32, n), dtype=np.uint32).view(np.int32)
+    qzeros = rng.integers(0, 2**32, size=(g, n * bits // 32), dtype=np.uint32).view(np.int32)
+    scales = (rng.uniform(0.002, 0.02, size=(g, n))).astype(np.float16)
+    if act_order:
+        g_idx = rng.permutation(np.arange(k) // group_size).astype(np.int32)
+    else:
+        g_idx = (np.arange(k) // group_size).astype(np.int32)
+    return qweight, qzeros, scales, g_idx
+
+
 def ref_gemm(lib, a, qw_shuf, qzeros, scales, perm):
     m, k = a.shape
     n = qw_shuf.shape[1]
@@ -109,6 +134,15 @@ def main():
                 a = rng.standard_normal((m, k)).astype(np.float16)
                 out[f"{name}_gemm_a{m}"] = a
                 out[f"{name}_gemm_c{m}"] = ref_gemm(lib, a, shuf, qzeros, scales, perm)
+    # 2 / 3 / 8-bit checkpoints: the layout definition (reconstruct_gptq) -> gptq_ref_bits.npz
+    outb = {}
+    for bits in (2, 3, 8):
+        for name, (k, n, gs, ao) in {"p": (128, 64, 32, False), "q": (256, 96, 128, True)}.items():
+            qweight, qzeros, scales, g_idx = make_case_bits(rng, k, n, gs, ao, bits)
+            key = f"b{bits}{name}"
+            outb[f"{key}_qweight"], outb[f"{key}_qzeros"], outb[f"{key}_scales"], outb[f"{key}_g_idx"] = qweight, qzeros, scales, g_idx
+            outb[f"{key}_recon_gptq"] = ref_recon_gptq_bits(lib, qweight, qzeros, scales, g_idx, bits)
+    np.savez_compressed(os.path.join(HERE, "gptq_ref_bits.npz"), **outb)
     np.savez_compressed(os.path.join(HERE, "gptq_ref.npz"), **out)
     print("wrote gptq_ref.npz:", {k: v.shape for k, v in out.items() if k.endswith("shuffle") or "gemm_c" in k})
 

@@ -107,6 +107,25 @@ def test_gptq_checkpoint(tmp_path, embedded):
         check_replicated(m, truth, rank, world)
 
 
+@pytest.mark.parametrize("bits", [3, 8])
+def test_gptq_3_and_8_bit_checkpoints_shard_like_4_bit(tmp_path, bits):
+    """GPTQ 3-bit (32 values per 3 words: the pack factor is the Fraction 32/3, gptq.py:37) and 8-bit checkpoints through
+    the same loader under TP 1 / 2 / 4: every rank's slice unpacks to the logical values."""
+    truth = CU.write_checkpoint(str(tmp_path), CFG, "gptq", seed=4, bits=bits)
+    mask = (1 << bits) - 1
+    for rank, world in [(0, 1), (1, 2), (3, 4)]:
+        m = build(tmp_path, "gptq", rank, world)
+        for li, layer in enumerate(m.layers):
+            eq = expected_logical(truth, li, rank, world, "q")
+            ez = expected_groups(truth, li, rank, world, "zp", 128)
+            for mod in MODS:
+                lin = getattr(layer, mod)
+                assert lin.quant_config.weight_bits == bits
+                np.testing.assert_array_equal(oq.gptq_unpack(lin.qweight.numpy(), bits), eq[mod], err_msg=f"{mod} q")
+                np.testing.assert_array_equal(oq.unpack_cols(lin.qzeros.numpy(), bits), (ez[mod] - 1) & mask,
+                                              err_msg=f"{mod} zeros")
+
+
 def check_replicated(m, truth, rank, world):
     t = {k: v.to(m.dtype) if v.dtype == torch.float16 else v for k, v in truth["tensors"].items()}
     assert torch.equal(m.embed_tokens.data, t["model.embed_tokens.weight"])

@@ -1897,3 +1897,93 @@ def test_lm_head_argmax_ties_padding_and_graph(ops):
         gr.replay()
         torch.cuda.synchronize()
         assert torch.equal(out, ids)
+
+
+# ---- GPTQ 2 / 3 / 8-bit (csrc/wnx_gemm.hip) --------------------------------------------------------------------------
+def _gptq_bits_case(bits, k, n, gs, act_order, seed):
+    rng = np.random.default_rng(seed)
+    q = rng.integers(0, 1 << bits, size=(k, n))
+    z = rng.integers(0, 1 << bits, size=(k // gs, n))
+    qw, qz = oq.gptq_pack(q, bits), oq.pack_cols(z, bits)
+    sc = rng.uniform(0.002, 0.02, size=(k // gs, n)).astype(np.float16)
+    if act_order:
+        g_idx = rng.permutation(np.arange(k) // gs).astype(np.int32)
+        perm = np.argsort(g_idx, kind="stable").astype(np.int32)
+    else:
+        g_idx = (np.arange(k) // gs).astype(np.int32)
+        perm = np.zeros((0, ), np.int32)
+    return qw, qz, sc, g_idx, perm
+
+
+@pytest.mark.parametrize("bits", [2, 3, 8])
+@pytest.mark.parametrize("act_order", [False, True])
+def test_gptq_bits_dequant_and_shuffle_bit_exact(ops, bits, act_order):
+    """gptq_dequant on the checkpoint order == the oracle (itself == the reference's reconstruct kernels, bit for bit);
+    gptq_shuffle makes act-order rows sequential exactly as the oracle does."""
+    k, n, gs = 512, 256, 64
+    qw, qz, sc, g_idx, perm = _gptq_bits_case(bits, k, n, gs, act_order, 11 * bits + act_order)
+    ref = oq.gptq_dequant(qw, qz, sc, g_idx, shuffled=False, bits=bits).astype(np.float16)
+    got = ops.gptq_dequant(t(qw), t(qz), t(sc), t(g_idx), False, bits)
+    np.testing.assert_array_equal(got.cpu().numpy().view(np.uint16), ref.view(np.uint16))
+    shuf = t(qw).clone()
+    ops.gptq_shuffle(shuf, t(perm), bits)
+    np.testing.assert_array_equal(shuf.cpu().numpy().view(np.uint32), oq.gptq_shuffle(qw, perm, bits).view(np.uint32))
+    # bf16 output: one rounding of the same exact product
+    got_bf = ops.gptq_dequant(t(qw), t(qz), t(sc).to(torch.bfloat16), t(g_idx), False, bits)
+    exact = oq.gptq_dequant(qw, qz, sc.astype(np.float32).astype(np.float16), g_idx, shuffled=False, bits=bits)
+    sc_bf = torch.from_numpy(sc).to(torch.bfloat16).float().numpy()
+    exact_bf = (exact / sc.astype(np.float32)[g_idx, :]) * sc_bf[g_idx, :]
+    assert torch.equal(got_bf.cpu(), torch.from_numpy(exact_bf).to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("bits", [2, 3, 8])
+@pytest.mark.parametrize("M", [1, 16, 17, 32, 50])
+@pytest.mark.parametrize("act_order", [False, True])
+def test_gptq_bits_gemm_vs_oracle(ops, bits, M, act_order):
+    """ops.gptq_gemm with bit in {2, 3, 8}: the exllama (shuffled) form through the MFMA small-M kernel and, above its
+    rows, through dequant + GEMM; the non-exllama form (g_idx = row -> group) through dequant + GEMM."""
+    k, n, gs = 1024, 384, 128
+    qw, qz, sc, g_idx, perm = _gptq_bits_case(bits, k, n, gs, act_order, 5 * bits + M)
+    rng = np.random.default_rng(M)
+    a = (rng.standard_normal((M, k)) * 0.5).astype(np.float16)
+    ref = oq.gptq_gemm(a, qw, qz, sc, g_idx, False, bits)
+    tol = dict(rtol=2e-3, atol=2e-3 * np.abs(ref).max())
+    y0 = ops.gptq_gemm(t(a), t(qw), t(qz), t(sc), t(g_idx), False, bits)
+    np.testing.assert_allclose(y0.float().cpu().numpy(), ref, **tol)
+    shuf = t(qw).clone()
+    ops.gptq_shuffle(shuf, t(perm), bits)
+    y1 = ops.gptq_gemm(t(a), shuf, t(qz), t(sc), t(perm), True, bits)
+    np.testing.assert_allclose(y1.float().cpu().numpy(), ref, **tol)
+    if M <= 32:       # the MFMA kernel: exact products, fp32 sums -- much tighter than the bound above
+        np.testing.assert_allclose(y1.float().cpu().numpy(), ref, rtol=1e-3, atol=6e-4 * np.abs(ref).max())
+        yb = ops.gptq_gemm(t(a).to(torch.bfloat16), shuf, t(qz), t(sc).to(torch.bfloat16), t(perm), True, bits)
+        refb = oq.gptq_gemm(torch.from_numpy(a).to(torch.bfloat16).float().numpy(), oq.gptq_shuffle(qw, perm, bits), qz,
+                            torch.from_numpy(sc).to(torch.bfloat16).float().numpy(), perm, True, bits)
+        np.testing.assert_allclose(yb.float().cpu().numpy(), refb, rtol=1e-2, atol=8e-3 * np.abs(refb).max())
+
+
+def test_gptq_8bit_linear_method_end_to_end(ops):
+    """GPTQConfig(bits = 8) through create_weights -> load -> process_weights_after_loading -> apply (decode and prefill
+    sized), the path a reference engine takes with an 8-bit checkpoint (quantization/gptq.py)."""
+    from aphrodite_engine_amd.quantization.gptq import GPTQConfig
+    import torch.nn as nn
+    bits, k, n, gs = 8, 1024, 512, 128
+    qw, qz, sc, g_idx, _ = _gptq_bits_case(bits, k, n, gs, False, 3)
+    cfg = GPTQConfig(bits, gs, False)
+    layer = nn.Module()
+    method = cfg.get_quant_method(nn.Linear(1, 1), "")
+    assert method is not None
+    method.create_weights(layer, k, [n], k, n, torch.float16, weight_loader=None)
+    assert tuple(layer.qweight.shape) == qw.shape and tuple(layer.qzeros.shape) == qz.shape
+    layer.to(DEV)
+    layer.qweight.data.copy_(t(qw))
+    layer.qzeros.data.copy_(t(qz))
+    layer.scales.data.copy_(t(sc))
+    layer.g_idx.data.copy_(t(g_idx))
+    method.process_weights_after_loading(layer)
+    rng = np.random.default_rng(1)
+    for m in (4, 300):
+        a = (rng.standard_normal((m, k)) * 0.5).astype(np.float16)
+        ref = oq.gptq_gemm(a, qw, qz, sc, g_idx, False, bits)
+        y = method.apply(layer, t(a))
+        np.testing.assert_allclose(y.float().cpu().numpy(), ref, rtol=2e-3, atol=2e-3 * np.abs(ref).max())

@@ -624,3 +624,36 @@ def test_gptq_reference_library_live(gref):
         a = rng.standard_normal((3, k)).astype(np.float16)
         c = mg.ref_gemm(lib, a, shuf, qz, sc, perm).astype(np.float64)
         assert np.abs(c - oq.gptq_gemm(a, shuf, qz, sc, perm, True)).max() <= 2e-2
+
+
+# ---- GPTQ 2 / 3 / 8-bit: the checkpoint layout pinned by the reference's reconstruct_gptq kernels run on the host ------
+@pytest.mark.parametrize("bits", [2, 3, 8])
+@pytest.mark.parametrize("name", ["p", "q"])
+def test_gptq_dequant_bits_reference_kernels(golden_dir, bits, name):
+    """reconstruct_gptq_kernel<MatrixView_q{2,8}_row> / reconstruct_gptq_3bit_kernel (q_gemm.cu:1394-1505): bit-exact,
+    including the 3-bit values / zero points that straddle a word and the unmasked `zero + 1` (8-bit 255 -> 256)."""
+    g = np.load(os.path.join(golden_dir, "gptq_ref_bits.npz"))
+    k = f"b{bits}{name}"
+    w = oq.gptq_dequant(g[k + "_qweight"], g[k + "_qzeros"], g[k + "_scales"], g[k + "_g_idx"], shuffled=False,
+                        bits=bits).astype(np.float16)
+    np.testing.assert_array_equal(w.view(np.uint16), g[k + "_recon_gptq"].view(np.uint16))
+
+
+@pytest.mark.parametrize("bits", [2, 3, 8])
+def test_gptq_bits_pack_roundtrip_and_shuffle(bits):
+    rng = np.random.default_rng(bits)
+    k, n, gs = 128, 64, 32
+    q = rng.integers(0, 1 << bits, size=(k, n))
+    z = rng.integers(0, 1 << bits, size=(k // gs, n))
+    qw, qz = oq.gptq_pack(q, bits), oq.pack_cols(z, bits)
+    assert qw.shape == (k * bits // 32, n) and qz.shape == (k // gs, n * bits // 32)
+    np.testing.assert_array_equal(oq.gptq_unpack(qw, bits), q)
+    np.testing.assert_array_equal(oq.unpack_cols(qz, bits), z)
+    # act-order: W through (shuffle with perm, gather a[:, perm]) == W through g_idx on the checkpoint order
+    g_idx = rng.permutation(np.arange(k) // gs).astype(np.int32)
+    perm = np.argsort(g_idx, kind="stable").astype(np.int32)
+    sc = rng.uniform(0.002, 0.02, size=(k // gs, n)).astype(np.float16)
+    a = rng.standard_normal((3, k)).astype(np.float16)
+    y0 = oq.gptq_gemm(a, qw, qz, sc, g_idx, False, bits)
+    y1 = oq.gptq_gemm(a, oq.gptq_shuffle(qw, perm, bits), qz, sc, perm, True, bits)
+    np.testing.assert_allclose(y0, y1, rtol=1e-12, atol=1e-12)

@@ -240,6 +240,16 @@ def test_cpp_registered_ops_match_the_python_registration(T):
         want = T.C.gptq_gemm(a, shuf, qz_d, s_d, empty, True, 4)
         _, got = captured(lambda: C.gptq_gemm(a, shuf, qz_d, s_d, empty, True, 4))
         assert torch.equal(got, want)
+    # 8-bit weights through the same op (csrc/wnx_gemm.hip): the small-M kernel and the reconstruct + GEMM rule
+    from oracle import quant as oq
+    q8 = rng.integers(0, 256, size=(K, N))
+    z8 = rng.integers(0, 256, size=(K // G, N))
+    qw8, qz8 = t(oq.gptq_pack(q8, 8)), t(oq.pack_cols(z8, 8))
+    for M in (8, 100):
+        a = t(rng.standard_normal((M, K)).astype(np.float16))
+        want = T.C.gptq_gemm(a, qw8, qz8, s_d, empty, True, 8)
+        got = C.gptq_gemm(a, qw8, qz8, s_d, empty, True, 8)
+        assert torch.equal(got, want)
     # cutlass_scaled_mm: M = 40 and 200
     for M in (40, 200):
         K2, N2 = 512, 256
