@@ -1242,6 +1242,31 @@ def lm_head_argmax(hidden: torch.Tensor, weight: torch.Tensor, vocab_size: Optio
 # --------------------------------------------------------------------------
 # mixture of experts
 # --------------------------------------------------------------------------
+def fp8_moe_gemm(a_q: torch.Tensor, w: torch.Tensor, a_scale: torch.Tensor, w_scales: torch.Tensor,
+                 topk_weights: Optional[torch.Tensor], sorted_ids: torch.Tensor, expert_ids: torch.Tensor,
+                 num_post_pad: torch.Tensor, out: torch.Tensor, top_k_div: int) -> None:
+    """One grouped FP8 W8A8 GEMM of an MoE layer (fused_moe_kernel with use_fp8_w8a8, fused_moe.py:20-170): for every
+    valid slot of the expert-sorted list, out[slot] = T(((a_q[slot // top_k_div] . w[expert]^T) * w_routed[slot]) *
+    a_scale * w_scales[expert])."""
+    _require_cuda(a_q, w, out)
+    check_fp8_buffer(a_q, "fp8_moe_gemm")
+    check_fp8_buffer(w, "fp8_moe_gemm")
+    e, n, k = w.shape
+    if a_q.dim() != 2 or a_q.shape[1] != k or not a_q.is_contiguous() or not w.is_contiguous() or not out.is_contiguous():
+        raise RuntimeError("fp8_moe_gemm: contiguous a_q [rows, K], w [E, N, K], out [slots, N] expected")
+    if out.shape[1] != n or w_scales.numel() != e or a_scale.numel() != 1:
+        raise RuntimeError("fp8_moe_gemm: shape mismatch")
+    tw = None
+    if topk_weights is not None:
+        tw = topk_weights.to(torch.float32).contiguous()
+        if tw.numel() != out.shape[0]:
+            raise RuntimeError("fp8_moe_gemm: one routed weight per slot expected")
+    check(_lib.lib().aphro_fp8_moe_gemm(a_q.data_ptr(), w.data_ptr(), a_scale.to(torch.float32).data_ptr(),
+                                        w_scales.to(torch.float32).contiguous().data_ptr(), _ptr(tw), sorted_ids.data_ptr(),
+                                        expert_ids.data_ptr(), num_post_pad.data_ptr(), out.data_ptr(), out.shape[0], n, k,
+                                        expert_ids.numel(), int(top_k_div), _dt(out), _stream()), "fp8_moe_gemm")
+
+
 def topk_softmax(topk_weights: torch.Tensor, topk_ids: torch.Tensor,
                  token_expert_indicies: Optional[torch.Tensor], gating_output: torch.Tensor) -> None:
     """_custom_ops.py topk_softmax -> _moe_C::topk_softmax (kernels/moe/torch_bindings.cpp:11-14)."""

@@ -544,8 +544,9 @@ class LlamaForCausalLM(nn.Module):
                     continue
                 n += p.numel() * p.element_size()
         if layer.is_moe:   # every expert's weights (at batch 32, top-2 of 8 touches all of them) + the router
-            ex = layer.experts.experts_packed
-            n += int(sum(t.numel() * t.element_size() for t in ex.w13 + ex.w2) * active_expert_fraction)
+            ex = getattr(layer.experts, "experts_packed", None)
+            tensors = (ex.w13 + ex.w2) if ex is not None else (layer.experts.w13_weight, layer.experts.w2_weight)
+            n += int(sum(t.numel() * t.element_size() for t in tensors) * active_expert_fraction)
             n += layer.moe_gate.numel() * layer.moe_gate.element_size()
         return n
 
@@ -622,7 +623,19 @@ class LlamaForCausalLM(nn.Module):
 
 @torch.no_grad()
 def _init_experts(moe, g, device):
-    """Random int4 experts in the checkpoint layout of the method (GPTQ / AWQ)."""
+    """Random experts in the checkpoint layout of the method (GPTQ / AWQ int4, or FP8 with per-tensor scales)."""
+    if type(moe.quant_method).__name__ == "Fp8MoEMethod":
+        for name, p in list(moe.named_parameters()):
+            if name.endswith("_weight"):
+                k = p.shape[2]
+                for e in range(p.shape[0]):      # unit-variance values in e4m3, scale 1 / sqrt(K)-ish below
+                    p[e].copy_((torch.randn(p.shape[1:], generator=g, device=device) * 64.0).clamp(-448, 448).to(p.dtype))
+            elif name.endswith("weight_scale"):
+                k = moe.hidden_size if name.startswith("w13") else moe.intermediate_size_per_partition * moe.tp_size
+                p.copy_(((torch.rand(p.shape, generator=g, device=device) * 0.1 + 0.95) / (64.0 * math.sqrt(k))).to(p.dtype))
+            elif name.endswith("input_scale"):
+                p.fill_(0.02)
+        return
     gs = moe.quant_method.group_size
     for name, p in list(moe.named_parameters()):
         if name.endswith(("qweight", "qzeros")):

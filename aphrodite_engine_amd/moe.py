@@ -217,6 +217,121 @@ class Wna16MoEMethod(FusedMoEMethodBase):
                                topk_weights=topk_weights, topk_ids=topk_ids)
 
 
+def fused_fp8_moe(hidden_states: torch.Tensor, w13: torch.Tensor, w2: torch.Tensor, w13_scale: torch.Tensor,
+                  w2_scale: torch.Tensor, topk_weights: torch.Tensor, topk_ids: torch.Tensor,
+                  a1_scale: Optional[torch.Tensor] = None, a2_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``fused_experts(..., use_fp8_w8a8=True)`` (fused_moe.py:566-690) on the grouped FP8 kernel (csrc/fp8_moe.hip).
+    w13 [E, 2I, H] / w2 [E, H, I] e4m3, one weight scale per expert, per-tensor activation scales (static, or dynamic
+    over the whole tensor: ``scaled_fp8_quant``), the reference's intermediate layouts and roundings:
+
+        A1_q, s1 = scaled_fp8_quant(hidden)            cache1[slot] = T(acc * s1 * w13_scale[e])      slot = token * k + j
+        cache2   = silu_and_mul(cache1)                A2_q, s2 = scaled_fp8_quant(cache2)
+        cache3[slot] = T((acc * w_routed[slot]) * s2 * w2_scale[e])                out = sum_j cache3[token, j]"""
+    m, h = hidden_states.shape
+    e, n13, _ = w13.shape
+    k = topk_ids.shape[1]
+    dev, dt = hidden_states.device, hidden_states.dtype
+    sorted_ids, expert_ids, post_pad = moe_align_block_size(topk_ids, MOE_BLOCK_M, e)
+    xq, s1 = ops.scaled_fp8_quant(hidden_states, a1_scale)
+    cache1 = torch.empty((m * k, n13), dtype=dt, device=dev)
+    ops.fp8_moe_gemm(xq, w13, s1, w13_scale, None, sorted_ids, expert_ids, post_pad, cache1, k)
+    cache2 = torch.empty((m * k, n13 // 2), dtype=dt, device=dev)
+    ops.silu_and_mul(cache2, cache1)
+    aq, s2 = ops.scaled_fp8_quant(cache2, a2_scale)
+    cache3 = torch.empty((m * k, h), dtype=dt, device=dev)
+    ops.fp8_moe_gemm(aq, w2, s2, w2_scale, topk_weights.reshape(-1).contiguous(), sorted_ids, expert_ids, post_pad,
+                     cache3, 1)
+    return cache3.view(m, k, h).sum(dim=1)
+
+
+class Fp8MoEMethod(FusedMoEMethodBase):
+    """quantization/fp8.py:279-503 (Fp8MoEMethod): FP8 checkpoints with one weight scale per expert matrix and static or
+    dynamic per-tensor activation scales, or 16-bit checkpoints quantised at load.  Same parameters, same
+    post-processing (a single w13 scale per expert: max of the w1 / w3 scales, both halves requantised to it; static input
+    scales reduced to their maximum over the experts).  gfx950 computes in OCP e4m3fn: no fnuz renormalisation."""
+
+    def __init__(self, quant_config):
+        self.quant_config = quant_config
+
+    def create_weights(self, layer: nn.Module, num_experts: int, hidden_size: int, intermediate_size: int,
+                       params_dtype: torch.dtype, **extra_weight_attrs):
+        loader = extra_weight_attrs.get("weight_loader")
+        cfg = self.quant_config
+        wdt = torch.float8_e4m3fn if cfg.is_checkpoint_fp8_serialized else params_dtype
+        e, h, i = num_experts, hidden_size, intermediate_size
+        if h % 128 or i % 128:
+            raise ValueError(f"FP8 experts need hidden ({h}) and per-rank intermediate ({i}) sizes that are multiples of 128")
+        layer.register_parameter("w13_weight", _param(torch.empty(e, 2 * i, h, dtype=wdt), input_dim=1, output_dim=0,
+                                                      weight_loader=loader))
+        layer.register_parameter("w2_weight", _param(torch.empty(e, h, i, dtype=wdt), input_dim=1, output_dim=0,
+                                                     weight_loader=loader))
+        # two scales for w1 and w3, combined after loading (fp8.py:319-331)
+        ser = cfg.is_checkpoint_fp8_serialized
+        layer.register_parameter("w13_weight_scale", _param(torch.ones(e, 2, dtype=torch.float32),
+                                                            weight_loader=loader if ser else None))
+        layer.register_parameter("w2_weight_scale", _param(torch.ones(e, dtype=torch.float32),
+                                                           weight_loader=loader if ser else None))
+        if cfg.activation_scheme == "static":
+            if not ser:
+                raise ValueError("Found static activation scheme for checkpoint that was not serialized fp8.")
+            layer.register_parameter("w13_input_scale", _param(torch.ones(e, dtype=torch.float32), weight_loader=loader))
+            layer.register_parameter("w2_input_scale", _param(torch.ones(e, dtype=torch.float32), weight_loader=loader))
+        else:
+            layer.w13_input_scale = None
+            layer.w2_input_scale = None
+
+    def process_weights_after_loading(self, layer: nn.Module) -> None:
+        cfg = self.quant_config
+        e = layer.w13_weight.shape[0]
+        if not cfg.is_checkpoint_fp8_serialized:        # 16-bit checkpoint: one scale per merged w13 / per w2 (fp8.py:370-396)
+            w13 = torch.empty_like(layer.w13_weight.data, dtype=torch.float8_e4m3fn)
+            w2 = torch.empty_like(layer.w2_weight.data, dtype=torch.float8_e4m3fn)
+            s13 = torch.ones(e, dtype=torch.float32, device=w13.device)
+            s2 = torch.ones(e, dtype=torch.float32, device=w13.device)
+            for x in range(e):
+                q, sc = ops.scaled_fp8_quant(layer.w13_weight.data[x])
+                w13[x].copy_(q)
+                s13[x] = sc.reshape(())
+                q, sc = ops.scaled_fp8_quant(layer.w2_weight.data[x])
+                w2[x].copy_(q)
+                s2[x] = sc.reshape(())
+            layer.w13_weight = nn.Parameter(w13, requires_grad=False)
+            layer.w2_weight = nn.Parameter(w2, requires_grad=False)
+            layer.w13_weight_scale = nn.Parameter(s13, requires_grad=False)
+            layer.w2_weight_scale = nn.Parameter(s2, requires_grad=False)
+            return
+        if cfg.activation_scheme == "static":            # a single activation scale: the maximum (fp8.py:404-419)
+            if layer.w13_input_scale is None or layer.w2_input_scale is None:
+                raise ValueError("QuantConfig has static quantization, but found activation scales are None.")
+            layer.w13_input_scale = nn.Parameter(layer.w13_input_scale.data.max().reshape(1), requires_grad=False)
+            layer.w2_input_scale = nn.Parameter(layer.w2_input_scale.data.max().reshape(1), requires_grad=False)
+        # a single weight scale for w13 per expert: take the max, dequantise each half with its own scale and requantise
+        # (fp8.py:447-465)
+        shard = layer.intermediate_size_per_partition
+        mx = layer.w13_weight_scale.data.max(dim=1).values
+        w13 = layer.w13_weight.data
+        for x in range(e):
+            for sh in range(2):
+                rows = w13[x, sh * shard:(sh + 1) * shard, :]
+                dq = rows.to(torch.float32) * layer.w13_weight_scale.data[x, sh]       # per_tensor_dequantize
+                q, _ = ops.scaled_fp8_quant(dq.to(layer.orig_dtype), mx[x].reshape(1))
+                rows.copy_(q)
+        layer.w13_weight_scale = nn.Parameter(mx.contiguous(), requires_grad=False)
+        layer.w13_weight = nn.Parameter(w13, requires_grad=False)
+        layer.w2_weight = nn.Parameter(layer.w2_weight.data, requires_grad=False)
+        layer.w2_weight_scale = nn.Parameter(layer.w2_weight_scale.data, requires_grad=False)
+
+    def apply(self, layer: nn.Module, x: torch.Tensor, router_logits: torch.Tensor, top_k: int,
+              renormalize: bool, use_grouped_topk: bool = False) -> torch.Tensor:
+        if use_grouped_topk:
+            raise NotImplementedError("grouped top-k routing (DeepSeek-V2) is outside the hot path")
+        topk_weights, topk_ids = fused_topk(x, router_logits, top_k, renormalize)
+        if getattr(layer, "record_routing", False):
+            layer.last_topk_ids = topk_ids
+        return fused_fp8_moe(x, layer.w13_weight, layer.w2_weight, layer.w13_weight_scale, layer.w2_weight_scale,
+                             topk_weights, topk_ids, layer.w13_input_scale, layer.w2_input_scale)
+
+
 class FusedMoE(nn.Module):
     """modeling/layers/fused_moe/layer.py:146-300 for quantised experts: owns the stacked expert
     parameters, shards them over the TP group (intermediate dimension) and optionally all-reduces."""
@@ -242,6 +357,7 @@ class FusedMoE(nn.Module):
         self.quant_method = quant_config.get_quant_method(self, prefix)
         if not isinstance(self.quant_method, FusedMoEMethodBase):
             raise NotImplementedError(f"{type(quant_config).__name__} has no FusedMoE method")
+        self.orig_dtype = params_dtype
         self.quant_method.create_weights(layer=self, num_experts=num_experts, hidden_size=hidden_size,
                                          intermediate_size=self.intermediate_size_per_partition,
                                          params_dtype=params_dtype, weight_loader=self.weight_loader)
@@ -255,6 +371,21 @@ class FusedMoE(nn.Module):
             raise ValueError(f"shard_id must be ['w1','w2','w3'] but got {shard_id}.")
         if not 0 <= expert_id < self.num_experts:
             raise ValueError(f"{weight_name}: expert {expert_id} out of range")
+        if "weight_scale" in weight_name:              # per-tensor scales (layer.py:219-232): w1 / w3 kept apart
+            if param.data.dim() == 2:
+                if shard_id == "w2":
+                    raise ValueError(f"{weight_name}: a [E, 2] scale parameter belongs to w1 / w3")
+                param.data[expert_id][0 if shard_id == "w1" else 1] = loaded_weight.reshape(())
+            else:
+                param.data[expert_id] = loaded_weight.reshape(())
+            return
+        if "input_scale" in weight_name:               # (layer.py:299-304; w1 and w3 of a layer must agree)
+            if shard_id == "w3" and param.data[expert_id] != 1 and \
+                    (param.data[expert_id] - loaded_weight.reshape(())).abs() > 1e-5:
+                raise ValueError("input_scales of w1 and w3 of a layer must be equal. But got "
+                                 f"{param.data[expert_id]} vs. {loaded_weight}")
+            param.data[expert_id] = loaded_weight.reshape(())
+            return
         data = param.data[expert_id]
         in_dim, out_dim = getattr(param, "input_dim", None), getattr(param, "output_dim", None)
         if shard_id == "w2":

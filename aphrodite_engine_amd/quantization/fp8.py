@@ -98,8 +98,9 @@ class Fp8Config(QuantizationConfig):
         if kind == "attention":           # k_scale / v_scale of an FP8 KV cache come with the checkpoint
             from .kv_cache import BaseKVCacheMethod
             return BaseKVCacheMethod(self)
-        if kind == "moe":
-            raise NotImplementedError("FP8 experts (Fp8MoEMethod) are not built for MI355X yet")
+        if kind == "moe":                 # fp8.py:86-87
+            from ..moe import Fp8MoEMethod
+            return Fp8MoEMethod(self)
         return None
 
     def get_scaled_act_names(self) -> List[str]:

@@ -79,8 +79,8 @@ def build(args, device):
     from aphrodite_engine_amd.quantization.gptq import GPTQConfig
     import dataclasses
     cfg = {"llama3-8b": M.LLAMA3_8B, "llama3-70b": M.LLAMA3_70B, "mixtral-8x7b": M.MIXTRAL_8X7B}[args.model]
-    if args.model == "mixtral-8x7b" and args.quant not in ("gptq", "awq"):
-        raise SystemExit("--model mixtral-8x7b runs int4 experts: --quant gptq or awq")
+    if args.model == "mixtral-8x7b" and args.quant not in ("gptq", "awq", "fp8"):
+        raise SystemExit("--model mixtral-8x7b runs int4 (--quant gptq / awq) or FP8 (--quant fp8) experts")
     if args.layers:
         cfg = dataclasses.replace(cfg, num_hidden_layers=args.layers)
     # the rotary table must cover every position the loop reaches (--ctx 8192 ends past Llama-3-8B's 8192 window:
@@ -209,7 +209,8 @@ def roofline_section(model, loop, args):
         def run_moe():
             for layer in layers:
                 layer.moe_block(xin)
-        ex = layers[0].experts.experts_packed
+        ex = getattr(layers[0].experts, "experts_packed", None)
+        ex_tensors = (ex.w13 + ex.w2) if ex is not None else (layers[0].experts.w13_weight, layers[0].experts.w2_weight)
         for layer in layers:
             layer.experts.record_routing = True
         run_moe()
@@ -217,11 +218,13 @@ def roofline_section(model, loop, args):
         active = sum(int(torch.unique(l.experts.last_topk_ids).numel()) for l in layers) / len(layers)
         for layer in layers:
             layer.experts.record_routing = False
-        eb = sum(t.numel() * t.element_size() for t in ex.w13 + ex.w2) * active / ex.num_experts \
+        eb = sum(t.numel() * t.element_size() for t in ex_tensors) * active / layers[0].experts.num_experts \
             + layers[0].moe_gate.numel() * 2 + 2 * bs * model.cfg.hidden_size * 2
         t = measure_kernel(run_moe, len(layers))
-        out["moe_block"] = dict(kernel="sparse MLP block: router + topk_softmax + moe_align + gather_pack + "
-                                       "wna16 grouped GEMM x2 + combine (seconds = whole block, not one launch)",
+        out["moe_block"] = dict(kernel=("sparse MLP block: router + topk_softmax + moe_align + gather_pack + "
+                                        "wna16 grouped GEMM x2 + combine (seconds = whole block, not one launch)") if ex is not None else
+                                ("sparse MLP block, FP8 experts: router + topk_softmax + moe_align + scaled_fp8_quant x2 + "
+                                 "fp8_moe_gemm x2 + silu_and_mul + sum (seconds = whole block, not one launch)"),
                                 bytes=eb, seconds=t, active_experts=active)
     for name in dense_names:
         lin0 = getattr(layers[0], name)

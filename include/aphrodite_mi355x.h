@@ -689,6 +689,16 @@ int aphro_gptq_gemm_bits(const void* a, int64_t lda, const uint32_t* q_weight, c
 int aphro_gptq_make_sequential_bits(const uint32_t* q_weight, uint32_t* out, const int32_t* perm, int64_t K, int64_t N,
                                     int bits, void* stream);
 
+/* One grouped FP8 W8A8 GEMM of a mixture-of-experts layer: the reference's Triton fused_moe_kernel with use_fp8_w8a8
+ * (aphrodite/modeling/layers/fused_moe/fused_moe.py:20-170; called twice by fused_experts :566-690 for
+ * Fp8MoEMethod.apply, quantization/fp8.py:468-503).  For every valid slot s of the expert-sorted list
+ * (moe_align_block_size with block 16): c[s, :] = T(((a[s / top_k_div, :] . w[expert]^T) * topk_weights[s]) * a_scale *
+ * b_scales[expert]).  a e4m3 [rows, K]; w e4m3 [E, N, K]; a_scale [1]; b_scales [E]; topk_weights [num_valid] or NULL;
+ * c [num_valid, N] f16 / bf16; max_blocks = length of expert_ids.  K % 128 == 0, N % 16 == 0.  csrc/fp8_moe.hip. */
+int aphro_fp8_moe_gemm(const void* a, const void* w, const float* a_scale, const float* b_scales, const float* topk_weights,
+                       const int32_t* sorted_ids, const int32_t* expert_ids, const int32_t* num_post_pad, void* c,
+                       int64_t num_valid, int64_t N, int64_t K, int64_t max_blocks, int top_k_div, int dtype, void* stream);
+
 /* Decode-time LM head with the greedy argmax folded in: out_ids[m] = argmax_v round_T(hidden[m, :] . weight[v, :]) for
  * M <= 32 rows, one launch.  The reference computes the logits with a library GEMM (LogitsProcessor._get_logits,
  * modeling/layers/logits_processor.py:78-96: lm_head.linear_method.apply) and Sampler._greedy_sample takes torch.argmax

@@ -60,3 +60,52 @@ def moe_layer(x, w13, w2, topk_weights, topk_ids):
             a = g / (1.0 + np.exp(-g)) * u
             out[i] += float(topk_weights[i, k]) * (a @ np.asarray(w2[e], np.float64))
     return out
+
+
+def fused_experts_fp8(x, w13_bits, w2_bits, w13_scale, w2_scale, topk_weights, topk_ids, a1_scale=None, a2_scale=None,
+                      dtype="float16"):
+    """fused_experts(use_fp8_w8a8=True), aphrodite/modeling/layers/fused_moe/fused_moe.py:566-690 with the kernel
+    epilogue of :150-163, restated with the reference's tensor layouts and roundings:
+
+      A1_q, s1 = scaled_fp8_quant(x, a1_scale)            per tensor (dynamic: absmax over the whole tensor)
+      cache1[t, j] = T(acc * s1 * w13_scale[e])            acc = A1_q[t] . W13_q[e]^T (exact products, fp64 sums here)
+      cache2 = silu_and_mul(cache1)                        in T (activation_kernels.cu:14-28: fp32 math, one rounding)
+      A2_q, s2 = scaled_fp8_quant(cache2, a2_scale)
+      cache3[t, j] = T((acc * w[t, j]) * s2 * w2_scale[e])
+      out[t] = T(sum_j cache3[t, j])                        torch.sum: fp32 accumulate, one rounding
+
+    x [M, H] in T; w13_bits [E, 2I, H] / w2_bits [E, H, I] uint8 e4m3; scales float32.  Returns (out, cache1, cache3)."""
+    import torch
+    from . import fp8 as ofp8
+    tdt = getattr(torch, dtype)
+
+    def rnd(a):        # one rounding of fp32 values to T, back as float32
+        return torch.from_numpy(np.asarray(a, np.float32)).to(tdt).float().numpy()
+    x = np.asarray(x, np.float32)
+    m, h = x.shape
+    k = topk_ids.shape[1]
+    inter = w2_bits.shape[2]
+    a1q, s1 = ofp8.scaled_fp8_quant(x, a1_scale)
+    s1 = np.float32(np.asarray(s1).reshape(-1)[0])
+    a1 = ofp8.fp8_decode(a1q, "e4m3").astype(np.float64)
+    w13 = ofp8.fp8_decode(np.asarray(w13_bits), "e4m3").astype(np.float64)
+    w2 = ofp8.fp8_decode(np.asarray(w2_bits), "e4m3").astype(np.float64)
+    cache1 = np.zeros((m * k, 2 * inter), np.float32)
+    for t in range(m):
+        for j in range(k):
+            e = int(topk_ids[t, j])
+            acc = (a1[t] @ w13[e].T).astype(np.float32)
+            cache1[t * k + j] = rnd((acc * s1) * np.float32(w13_scale[e]))
+    g, u = cache1[:, :inter], cache1[:, inter:]
+    cache2 = rnd((g / (np.float32(1.0) + np.exp(-g, dtype=np.float32))).astype(np.float32) * u)
+    a2q, s2 = ofp8.scaled_fp8_quant(cache2, a2_scale)
+    s2 = np.float32(np.asarray(s2).reshape(-1)[0])
+    a2 = ofp8.fp8_decode(a2q, "e4m3").astype(np.float64)
+    cache3 = np.zeros((m * k, h), np.float32)
+    for t in range(m):
+        for j in range(k):
+            e = int(topk_ids[t, j])
+            acc = (a2[t * k + j] @ w2[e].T).astype(np.float32)
+            cache3[t * k + j] = rnd(((acc * np.float32(topk_weights[t, j])) * s2) * np.float32(w2_scale[e]))
+    out = rnd(cache3.reshape(m, k, h).sum(axis=1, dtype=np.float32))
+    return out, cache1, cache3

@@ -1987,3 +1987,107 @@ def test_gptq_8bit_linear_method_end_to_end(ops):
         ref = oq.gptq_gemm(a, qw, qz, sc, g_idx, False, bits)
         y = method.apply(layer, t(a))
         np.testing.assert_allclose(y.float().cpu().numpy(), ref, rtol=2e-3, atol=2e-3 * np.abs(ref).max())
+
+
+# ---- FP8 mixture-of-experts (csrc/fp8_moe.hip, moe.Fp8MoEMethod) -------------------------------------------------------
+def _fp8_moe_case(rng, m, h, inter, e, k, dtype):
+    from oracle import fp8 as ofp8
+    x = (rng.standard_normal((m, h)) * 0.8).astype(np.float32)
+    x = torch.from_numpy(x).to(dtype).float().numpy()
+    w13 = rng.standard_normal((e, 2 * inter, h)).astype(np.float32) * 0.05
+    w2 = rng.standard_normal((e, h, inter)).astype(np.float32) * 0.05
+    s13 = (np.abs(w13).reshape(e, -1).max(1) / 448).astype(np.float32)
+    s2 = (np.abs(w2).reshape(e, -1).max(1) / 448).astype(np.float32)
+    w13q = np.stack([ofp8.static_scaled_fp8_quant(w13[i], s13[i]) for i in range(e)])
+    w2q = np.stack([ofp8.static_scaled_fp8_quant(w2[i], s2[i]) for i in range(e)])
+    gating = rng.standard_normal((m, e)).astype(np.float32)
+    return x, w13q, w2q, s13, s2, gating
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("m,e,k,static", [(1, 8, 2, False), (7, 8, 2, True), (33, 8, 2, False), (64, 4, 1, False), (5, 16, 4, True)])
+def test_fused_fp8_moe_vs_oracle(ops, m, e, k, static, dtype):
+    """fused_experts(use_fp8_w8a8=True) on the grouped FP8 kernel: the first GEMM's output against the oracle to one
+    rounding step of T (same fp8 operands, exact products), the layer output within the noise the 1-ulp differences of
+    cache1 put on the requantised intermediate."""
+    from aphrodite_engine_amd import moe as moe_mod
+    from oracle import fp8 as ofp8, moe as omoe
+    rng = np.random.default_rng(m * 7 + e + k)
+    h, inter = 512, 384
+    x, w13q, w2q, s13, s2, gating = _fp8_moe_case(rng, m, h, inter, e, k, dtype)
+    tw, ids, _ = omoe.topk_softmax(gating, k)
+    tw = (tw / tw.sum(1, keepdims=True)).astype(np.float32)
+    a1 = np.array([np.abs(x).max() / 448 * 1.25], np.float32) if static else None
+    a2 = np.array([0.02], np.float32) if static else None
+    ref, c1_ref, _ = omoe.fused_experts_fp8(x, w13q, w2q, s13, s2, tw, ids, a1, a2, dtype=str(dtype).split(".")[1])
+    xd = t(x).to(dtype)
+    w13d, w2d = t(w13q).view(torch.float8_e4m3fn), t(w2q).view(torch.float8_e4m3fn)
+    out = moe_mod.fused_fp8_moe(xd, w13d, w2d, t(s13), t(s2), t(tw), t(ids.astype(np.int32)),
+                                t(a1) if static else None, t(a2) if static else None)
+    eps = 2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7
+    # Bound: rounding steps of T, plus ONE flipped e4m3 code of the requantised intermediate per output element -- a
+    # 1-ulp difference in cache1 (fp32 vs fp64 sums) can move a cache2 value across an fp8 rounding boundary, a step of
+    # up to 2^-4 of the value, which reaches an output through one weight
+    g_, u_ = c1_ref[:, :inter], c1_ref[:, inter:]
+    x2max = np.abs(g_ / (1 + np.exp(-g_)) * u_).max()
+    w2max = (np.abs(ofp8.fp8_decode(w2q, "e4m3")).reshape(e, -1).max(1) * s2).max()
+    flip = 2.0 ** -4 * x2max * w2max
+    got = out.float().cpu().numpy()
+    np.testing.assert_allclose(got, ref, rtol=0, atol=6 * eps * np.abs(ref).max() + flip + 1e-4)
+    assert np.abs(got - ref).mean() <= 2 * eps * np.abs(ref).max() + 0.05 * flip
+    # first grouped GEMM alone: one rounding step
+    sorted_ids, expert_ids, post_pad = moe_mod.moe_align_block_size(t(ids.astype(np.int32)), 16, e)
+    xq, s1 = ops.scaled_fp8_quant(xd, t(a1) if static else None)
+    c1 = torch.empty(m * k, 2 * inter, dtype=dtype, device=DEV)
+    ops.fp8_moe_gemm(xq, w13d, s1, t(s13), None, sorted_ids, expert_ids, post_pad, c1, k)
+    d = np.abs(c1.float().cpu().numpy() - c1_ref)
+    assert d.max() <= 2 * eps * np.abs(c1_ref).max() + 1e-6
+    # (the fp8 MFMA sums the 32 products of an instruction with its own internal alignment: against exact fp64 sums a few
+    #  per cent of the outputs land one step of T away -- 6.7 % measured in f16 -- never more than a step)
+    assert (d > 0).mean() < 0.15
+
+
+def test_fp8_moe_method_end_to_end_and_graph(ops):
+    """Fp8MoEMethod through FusedMoE: FP8-serialised checkpoint tensors with separate w1 / w3 scales loaded per expert
+    (merged to one scale per expert by requantisation, fp8.py:447-465), static activation scales reduced to their maximum,
+    the layer against the oracle fed with the POST-processed tensors; replayable under HIP-graph capture."""
+    from aphrodite_engine_amd import moe as moe_mod
+    from aphrodite_engine_amd.quantization.fp8 import Fp8Config
+    from oracle import fp8 as ofp8, moe as omoe
+    rng = np.random.default_rng(9)
+    m, h, inter, e, k = 12, 256, 256, 4, 2
+    cfg = Fp8Config(True, "static", None)
+    layer = moe_mod.FusedMoE(e, k, h, inter, params_dtype=torch.float16, quant_config=cfg, tp_size=1).to(DEV)
+    assert isinstance(layer.quant_method, moe_mod.Fp8MoEMethod)
+    w = {s_: rng.standard_normal((e, inter, h) if s_ != "w2" else (e, h, inter)).astype(np.float32) * 0.05 for s_ in ("w1", "w2", "w3")}
+    for x_ in range(e):
+        for s_ in ("w1", "w2", "w3"):
+            sc = np.float32(np.abs(w[s_][x_]).max() / 448 * (1.0 + 0.3 * (s_ == "w3")))
+            q = ofp8.static_scaled_fp8_quant(w[s_][x_], sc)
+            pre = "w13_" if s_ != "w2" else "w2_"
+            name = f"experts.{x_}.{s_}."
+            layer.weight_loader(getattr(layer, pre + "weight"), t(q).view(torch.float8_e4m3fn), name + "weight", s_, x_)
+            layer.weight_loader(getattr(layer, pre + "weight_scale"), t(np.array(sc)), name + "weight_scale", s_, x_)
+            layer.weight_loader(getattr(layer, pre + "input_scale"), t(np.array(np.float32(0.01 + 0.001 * x_))),
+                                name + "input_scale", s_, x_)
+    layer.quant_method.process_weights_after_loading(layer)
+    assert layer.w13_weight_scale.shape == (e, ) and layer.w13_input_scale.numel() == 1
+    assert abs(float(layer.w13_input_scale) - (0.01 + 0.001 * (e - 1))) < 1e-7
+    x = (rng.standard_normal((m, h)) * 0.5).astype(np.float16)
+    gating = rng.standard_normal((m, e)).astype(np.float32)
+    xd, gd = t(x), t(gating)
+    out = layer(xd, gd)
+    tw, ids, _ = omoe.topk_softmax(gating, k)
+    tw = (tw / tw.sum(1, keepdims=True)).astype(np.float32)
+    ref, _, _ = omoe.fused_experts_fp8(x.astype(np.float32), layer.w13_weight.data.view(torch.uint8).cpu().numpy(),
+                                       layer.w2_weight.data.view(torch.uint8).cpu().numpy(),
+                                       layer.w13_weight_scale.data.cpu().numpy(), layer.w2_weight_scale.data.cpu().numpy(),
+                                       tw, ids, layer.w13_input_scale.data.cpu().numpy(), layer.w2_input_scale.data.cpu().numpy())
+    np.testing.assert_allclose(out.float().cpu().numpy(), ref, rtol=0, atol=6 * 2.0 ** -10 * np.abs(ref).max() + 4e-3)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out2 = layer(xd, gd)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out2, out)
