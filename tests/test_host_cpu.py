@@ -286,8 +286,11 @@ def test_quant_configs_dispatch_on_layer_family():
         assert cfg.get_quant_method(emb, "model.embed_tokens") is None
         assert cfg.get_quant_method(lin, "model.layers.0.mlp.down_proj") is not None
         assert cfg.get_quant_method(lin, "lm_head") is None          # ignored layer, reference not installed here
-        with pytest.raises(NotImplementedError):
-            cfg.get_quant_method(mk("FusedMoE"), "model.layers.0.block_sparse_moe.experts")
+    # experts: FP8 checkpoints get Fp8MoEMethod (fp8.py:86-87); compressed-tensors experts are not built
+    from aphrodite_engine_amd.moe import Fp8MoEMethod
+    assert isinstance(fp8.get_quant_method(mk("FusedMoE"), "model.layers.0.block_sparse_moe.experts"), Fp8MoEMethod)
+    with pytest.raises(NotImplementedError):
+        ct.get_quant_method(mk("FusedMoE"), "model.layers.0.block_sparse_moe.experts")
     # the KV-cache method registers k_scale / v_scale and resolves them after loading
     attn.kv_cache_dtype = "fp8"
     m = fp8.get_quant_method(attn, "x")
