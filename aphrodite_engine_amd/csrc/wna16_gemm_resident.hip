@@ -434,7 +434,9 @@ __global__ __launch_bounds__(NWV * 64, NWV <= 4 ? 1 : 2) void wna16_gemm_residen
         *reinterpret_cast<u32x4*>(dst) = u32x4{(uint32_t)o[0] | ((uint32_t)o[1] << 16), (uint32_t)o[2] | ((uint32_t)o[3] << 16),
                                                (uint32_t)o[4] | ((uint32_t)o[5] << 16), (uint32_t)o[6] | ((uint32_t)o[7] << 16)};
     }
-  } else if (p.counter != nullptr) {
+  } else if (AROW && p.counter != nullptr) {      // (AROW instantiations only: the packed forms keep their code as it was.
+    // An epilogue-specialised instantiation per output form was tried on top: same box, gate_up 19.9-20.3 us against 19.5
+    // for this generic kernel in tools/resident_bench.py -- smaller code is not faster here, the schedule hipcc finds is)
     // ---- [M, N] out of ONE launch although K is sliced over workgroups (the op-level form: no reduce launch).  Each slice
     // stores its fp32 tile write-through (the slices of a strip sit on different XCDs = different L2s), takes a ticket;
     // the last arriver adds the slices IN SLICE ORDER (= splitk_reduce_kernel's order: the bits do not depend on who
