@@ -488,6 +488,9 @@ __global__ __launch_bounds__(NW * 64) void paged_attention_kernel(PAParams p) {
         }
       }
     }
+#ifdef PA_LAB
+    if constexpr (fused_rope) PA_STAMP(11);             // fused: q slab / cos-sin loads issued
+#endif
     // ---- Q fragments (B operand: lane (g, head) holds 8 consecutive d) --------
     // fused form: rotated from the qkv slabs INSIDE the first loop iteration, after that
     // iteration's K/V loads have been issued (their HBM latency covers the slab round trip)
@@ -530,6 +533,9 @@ __global__ __launch_bounds__(NW * 64) void paged_attention_kernel(PAParams p) {
     const bool defer_first = kv_owner && have && pr + NW >= pair_end;
     if (have && !defer_first) load_pair(pr, ids, kfa, vra);
     if (have && pr + NW < pair_end) load_ids(pr + NW, ids_next);
+#ifdef PA_LAB
+    if constexpr (fused_rope) PA_STAMP(12);             // fused: first pair's K/V loads issued
+#endif
     if constexpr (fused_rope) {
       // ---- q of the new token: slab reduce + rotary, ONCE per workgroup, one (d, d + hd/2) pair per
       // thread, through LDS.  The slab / cos-sin loads were issued above (before the K/V loads: the
@@ -548,6 +554,9 @@ __global__ __launch_bounds__(NW * 64) void paged_attention_kernel(PAParams p) {
           }
         }
       }
+#ifdef PA_LAB
+      PA_STAMP(13);                                     // fused: this wave's share of q rotated and in LDS (slab data arrived)
+#endif
       __syncthreads();
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks) {
@@ -571,11 +580,11 @@ __global__ __launch_bounds__(NW * 64) void paged_attention_kernel(PAParams p) {
 #ifdef PA_LAB
       if (it_count == 0) PA_STAMP(1);                   // (fused form: q phase done, first pair's loads long issued)
       PA_WAIT_DATA();
-      if (it_count < 6) PA_STAMP(2 + 2 * it_count);
+      if (it_count < 4) PA_STAMP(2 + 2 * it_count);     // (stamps 11..13 belong to the fused prologue)
 #endif
       compute_pair(pr, kfa, vra);
 #ifdef PA_LAB
-      if (it_count < 6) PA_STAMP(3 + 2 * it_count);
+      if (it_count < 4) PA_STAMP(3 + 2 * it_count);
       ++it_count;
 #endif
       pr += NW;

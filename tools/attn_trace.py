@@ -97,7 +97,8 @@ def main():
             names = ["entry", "first loads issued"]
             for i in range(6):
                 names += [f"pair {i} data arrived", f"pair {i} compute issued"]
-            names += ["loop done", "end"]
+            names = names[:11] + ["fused: q slab loads issued", "fused: first K/V loads issued", "fused: own q share in LDS", "loop done", "end"]
+            names[1] = "plain: first loads issued / fused: q-phase barrier passed"
             row = {"kv": kv, "form": form, "us_per_launch_in_graph": round(us, 2), "waves": int(len(t)),
                    "wave start us (p50/p90/max)": [round(float(np.percentile(start, q_)), 2) for q_ in (50, 90, 100)],
                    "wave end us (p10/p50/max)": [round(float(np.percentile(end, q_)), 2) for q_ in (10, 50, 100)],
