@@ -88,6 +88,8 @@ SIGNATURES = {
     "aphro_wna16_gemm_rowmajor_supported": (I, [L, L, L, L, I]),
     "aphro_lm_head_argmax_supported": (I, [L, L, L, L, I]),
     "aphro_fp8_moe_gemm": (I, [P, P, P, P, P, P, P, P, P, L, L, L, L, I, I, P]),
+    "aphro_fp8_gemm_stream_ksplit": (I, [L, L, L]),
+    "aphro_fp8_gemm_stream": (I, [P, L, P, P, P, P, P, P, Z, L, L, L, I, I, I, P]),
     "aphro_gptq_dequant_bits": (I, [P, P, P, P, P, L, L, L, I, I, P]),
     "aphro_gptq_gemm_bits_supported": (I, [L, L, L, L, I]),
     "aphro_gptq_gemm_bits": (I, [P, L, P, P, P, P, L, L, L, L, I, I, P]),

@@ -413,6 +413,23 @@ static int fp8_gemm_common(Fp8GemmParams p, bool a8, int dtype, void* workspace,
   APHRO_CHECK(p.N % 16 == 0, "fp8 gemm: N=%d must be a multiple of 16", p.N);
   APHRO_CHECK(p.M <= 64, "fp8 gemm: M=%d exceeds 64 rows per call", p.M);
   if (p.M == 0) return APHRO_OK;
+  // W8A8 at <= 32 rows: the LDS-DMA streaming kernel (fp8_gemm_stream.hip) where it tiles the shape -- directly to `c` when
+  // K fits one workgroup, raw slabs for a fused consumer otherwise
+  if (a8 && p.lda == p.K) {
+    const int split = aphro_fp8_gemm_stream_ksplit(p.M, p.N, p.K);
+    if (split > 0 && (p.force_partial || split == 1)) {
+      if (p.force_partial) {
+        const size_t need = (size_t)split * p.M * p.N * sizeof(float);
+        if (!workspace || workspace_bytes < need) {
+          set_error("fp8 gemm: workspace %zu < %zu bytes", workspace_bytes, need);
+          return APHRO_ERR_WORKSPACE;
+        }
+      }
+      return aphro_fp8_gemm_stream(p.a, p.lda, p.w, p.a_scales, p.b_scales, p.bias, p.force_partial ? nullptr : p.c,
+                                   p.force_partial ? (float*)workspace : nullptr, workspace_bytes, p.M, p.N, p.K,
+                                   p.a_per_token, p.b_per_channel, dtype, (void*)st);
+    }
+  }
   Fp8Plan pl = make_fp8_plan(p.M, p.N, p.K, a8);
   if (pl.ksplit > 1 || p.force_partial) {
     size_t need = (size_t)pl.ksplit * p.M * p.N * sizeof(float);
@@ -456,6 +473,8 @@ extern "C" int aphro_scaled_mm_fp8(void* out, const void* a, const void* b, cons
 // applies a_scale * (b_scale * acc) itself -- no reduce launch, no fp16 round trip.
 extern "C" int aphro_fp8_gemm_ksplit(int64_t M, int64_t N, int64_t K) {
   if (M <= 0 || M > 64 || K % 128 != 0 || N % 16 != 0) return -1;
+  const int split = aphro_fp8_gemm_stream_ksplit(M, N, K);     // (what fp8_gemm_common will run)
+  if (split > 0) return split;
   return make_fp8_plan(M, N, K, true).ksplit;
 }
 

@@ -689,6 +689,16 @@ int aphro_gptq_gemm_bits(const void* a, int64_t lda, const uint32_t* q_weight, c
 int aphro_gptq_make_sequential_bits(const uint32_t* q_weight, uint32_t* out, const int32_t* perm, int64_t K, int64_t N,
                                     int bits, void* stream);
 
+/* FP8 W8A8 decode GEMM for M <= 32 on the LDS-DMA streaming structure (round 3, csrc/fp8_gemm_stream.hip): same role and
+ * arithmetic as aphro_scaled_mm_fp8 / aphro_scaled_mm_fp8_slabs (cutlass_scaled_mm, scaled_mm_entry.cu:92-137), which route
+ * to it by themselves.  a e4m3 [M, lda], w e4m3 [N, K] row-major; exactly one of out ([M, N] in `dtype`, shapes whose K fits
+ * one workgroup: aphro_fp8_gemm_stream_ksplit == 1) / slabs (fp32 [ksplit][M][N] raw accumulators).
+ * aphro_fp8_gemm_stream_ksplit: K slices, 0 = shape not served (APHRO_FP8_NO_STREAM=1 turns the kernel off). */
+int aphro_fp8_gemm_stream_ksplit(int64_t M, int64_t N, int64_t K);
+int aphro_fp8_gemm_stream(const void* a, int64_t lda, const void* w, const float* a_scales, const float* b_scales,
+                          const void* bias, void* out, float* slabs, size_t slabs_bytes, int64_t M, int64_t N, int64_t K,
+                          int a_scale_per_token, int b_scale_per_channel, int dtype, void* stream);
+
 /* One grouped FP8 W8A8 GEMM of a mixture-of-experts layer: the reference's Triton fused_moe_kernel with use_fp8_w8a8
  * (aphrodite/modeling/layers/fused_moe/fused_moe.py:20-170; called twice by fused_experts :566-690 for
  * Fp8MoEMethod.apply, quantization/fp8.py:468-503).  For every valid slot s of the expert-sorted list

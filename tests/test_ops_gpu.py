@@ -2091,3 +2091,46 @@ def test_fp8_moe_method_end_to_end_and_graph(ops):
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(out2, out)
+
+
+# ---- FP8 W8A8 decode GEMM on the LDS-DMA streaming structure (csrc/fp8_gemm_stream.hip) ---------------------------------
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [(32, 28672, 4096), (1, 28672, 4096), (17, 512, 1024), (32, 256, 14336), (9, 1024, 8192)])
+def test_fp8_gemm_stream_vs_oracle(ops, M, N, K, dtype):
+    import os
+    """The streaming kernel in both output forms against oracle.fp8.scaled_mm (exact fp8 products, fp64 sums): [M, N] with
+    per-token x per-channel scales + bias where K fits one workgroup, raw fp32 slabs otherwise.  APHRO_FP8_STREAM_ALL
+    lifts the "wide matrices only" routing rule so that every shape class is exercised."""
+    from aphrodite_engine_amd import _lib
+    from oracle import fp8 as ofp8
+    lib = _lib.lib()
+    rng = np.random.default_rng(M + N + K)
+    os.environ["APHRO_FP8_STREAM_ALL"] = "1"
+    try:
+        split = lib.aphro_fp8_gemm_stream_ksplit(M, N, K)
+        assert split >= 1
+        a = ofp8.fp8_encode((rng.standard_normal((M, K)) * 1.5).astype(np.float32), "e4m3")
+        w = ofp8.fp8_encode((rng.standard_normal((N, K)) * 1.5).astype(np.float32), "e4m3")
+        sa = (rng.random((M, 1)) * 0.05 + 0.01).astype(np.float32)
+        sb = (rng.random((N, )) * 0.05 + 0.01).astype(np.float32)
+        bias = rng.standard_normal(N).astype(np.float32)
+        ad, wd = t(a).view(torch.float8_e4m3fn), t(w).view(torch.float8_e4m3fn)
+        stream = torch.cuda.current_stream().cuda_stream
+        raw = ofp8.scaled_mm(a, w.T, 1.0, 1.0)                                       # exact products, fp64 sums
+        slabs = torch.empty((split, M, N), dtype=torch.float32, device=DEV)
+        rc = lib.aphro_fp8_gemm_stream(ad.data_ptr(), K, wd.data_ptr(), None, None, None, None, slabs.data_ptr(), slabs.numel() * 4,
+                                       M, N, K, 0, 0, 0 if dtype == torch.float16 else 1, stream)
+        assert rc == 0
+        np.testing.assert_allclose(slabs.double().sum(0).cpu().numpy(), raw, rtol=1e-5, atol=1e-3 * np.abs(raw).max())
+        if split == 1:
+            out = torch.empty((M, N), dtype=dtype, device=DEV)
+            bd = t(bias).to(dtype)
+            sad, sbd = t(sa), t(sb)                  # (kept alive across the launch)
+            rc = lib.aphro_fp8_gemm_stream(ad.data_ptr(), K, wd.data_ptr(), sad.data_ptr(), sbd.data_ptr(), bd.data_ptr(),
+                                           out.data_ptr(), None, 0, M, N, K, 1, 1, 0 if dtype == torch.float16 else 1, stream)
+            assert rc == 0
+            ref = ofp8.scaled_mm(a, w.T, sa, sb, bd.float().cpu().numpy())
+            eps = 2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7
+            np.testing.assert_allclose(out.float().cpu().numpy(), ref, rtol=2 * eps, atol=2 * eps * np.abs(ref).max())
+    finally:
+        os.environ.pop("APHRO_FP8_STREAM_ALL")
