@@ -1299,6 +1299,34 @@ def moe_align_block_size(topk_ids: torch.Tensor, num_experts: int, block_size: i
                                                 _stream()), "moe_align_block_size")
 
 
+def moe_route_align(gating_output: torch.Tensor, topk: int, renormalize: bool, num_experts: int, block_size: int,
+                    want_inverse: bool = False):
+    """fused_topk + moe_align_block_size in one launch (decode-sized batches; csrc/moe.hip moe_route_align_kernel):
+    returns (topk_weights fp32 [T, k], topk_ids int32 [T, k], sorted_ids, expert_ids, num_tokens_post_pad, inv or None) --
+    bit-identical to topk_softmax (+ the fp32 renormalisation) followed by moe_align_block_size."""
+    _require_cuda(gating_output)
+    t_, e = gating_output.shape
+    if e != num_experts or gating_output.stride(1) != 1:
+        raise RuntimeError("moe_route_align: gating_output must be [tokens, num_experts] with contiguous rows")
+    dev = gating_output.device
+    numel = t_ * topk
+    max_padded = numel + num_experts * (block_size - 1)
+    topk_weights = torch.empty((t_, topk), dtype=torch.float32, device=dev)
+    topk_ids = torch.empty((t_, topk), dtype=torch.int32, device=dev)
+    sorted_ids = torch.empty((max_padded, ), dtype=torch.int32, device=dev)
+    expert_ids = torch.empty(((max_padded + block_size - 1) // block_size, ), dtype=torch.int32, device=dev)
+    post_pad = torch.empty((1, ), dtype=torch.int32, device=dev)
+    inv = torch.empty(numel, dtype=torch.int32, device=dev) if want_inverse else None
+    check(_lib.lib().aphro_moe_route_align(topk_weights.data_ptr(), topk_ids.data_ptr(), gating_output.data_ptr(),
+                                           gating_output.stride(0), sorted_ids.data_ptr(), expert_ids.data_ptr(),
+                                           post_pad.data_ptr(), _ptr(inv), t_, num_experts, topk, 1 if renormalize else 0,
+                                           block_size, _dt(gating_output), _stream()), "moe_route_align")
+    return topk_weights, topk_ids, sorted_ids, expert_ids, post_pad, inv
+
+
+MOE_ROUTE_ALIGN_MAX_SLOTS = 8192
+
+
 def moe_gather_pack(a: torch.Tensor, sorted_token_ids: torch.Tensor, num_tokens_post_pad: torch.Tensor,
                     m_pad: int, topk: int) -> torch.Tensor:
     """Packed (fragment-major f16) activations of the expert GEMMs: row r = a[sorted[r] // topk]."""

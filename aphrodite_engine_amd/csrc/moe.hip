@@ -101,6 +101,110 @@ __global__ void moe_align_kernel(const int32_t* __restrict__ topk_ids, int32_t* 
   }
 }
 
+// fused_topk (fused_moe.py:369-402: gating.float() -> topk_softmax -> optional renormalise) + moe_align_block_size
+// (:174-228) in ONE launch for decode-sized batches: the two ops, the fp32 cast and the renormalisation (sum + divide) are
+// five launches of a few microseconds each in front of every sparse MLP -- at ~5 us of fixed cost per launch that is a
+// tenth of a Mixtral decode step.  One workgroup of 16 waves: wave w routes tokens w, w + 16, ... with exactly the
+// arithmetic of topk_softmax_kernel (bit-identical weights and ids), the ids stay in LDS, and after a barrier wave 0 runs
+// moe_align_kernel's counting sort on them.  Renormalisation: w / (w_0 + w_1 + ...) in fp32, in slot order.
+template <typename T>
+__global__ __launch_bounds__(1024) void moe_route_align_kernel(
+    float* __restrict__ topk_weights, int32_t* __restrict__ topk_ids_out, const typename T::storage* __restrict__ gating,
+    int64_t gating_stride, int32_t* __restrict__ sorted_token_ids, int32_t* __restrict__ expert_ids,
+    int32_t* __restrict__ num_tokens_post_pad, int32_t* __restrict__ inv_pos, int num_tokens, int num_experts, int k,
+    int renormalize, int block_size, int max_padded, int max_blocks) {
+  extern __shared__ int32_t sm[];
+  const int numel = num_tokens * k;
+  int32_t* ids = sm;                                  // [numel]
+  int32_t* cnt = sm + numel;                          // [65][E]
+  int32_t* cumsum = cnt + 65 * num_experts;           // [E + 1]
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int nwave = blockDim.x >> 6;
+  for (int tok = wave; tok < num_tokens; tok += nwave) {
+    const typename T::storage* row = gating + (size_t)tok * gating_stride;
+    float mx = -INFINITY;
+    for (int e = lane; e < num_experts; e += 64) mx = __builtin_fmaxf(mx, T::to_f32(row[e]));
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int e = lane; e < num_experts; e += 64) sum += expf(T::to_f32(row[e]) - mx);
+    sum = wave_sum(sum);
+    const float norm = 1.f / sum;
+    float prob[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int e = lane + 64 * j;
+      prob[j] = e < num_experts ? expf(T::to_f32(row[e]) - mx) * norm : -1.f;
+    }
+    float wsum = 0.f;
+    float wk[8];
+    for (int kk = 0; kk < k; ++kk) {
+      float best = -1.f;
+      int best_e = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int e = lane + 64 * j;
+        if (prob[j] > best) { best = prob[j]; best_e = e; }
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o, 64);
+        const int oe = __shfl_xor(best_e, o, 64);
+        if (ob > best || (ob == best && oe < best_e)) { best = ob; best_e = oe; }
+      }
+      if (kk < 8) wk[kk] = best;
+      wsum += best;
+      if (lane == 0) {
+        ids[tok * k + kk] = best_e;
+        topk_ids_out[(size_t)tok * k + kk] = best_e;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (lane + 64 * j == best_e) prob[j] = -1.f;
+    }
+    if (lane == 0)
+      for (int kk = 0; kk < k; ++kk) topk_weights[(size_t)tok * k + kk] = renormalize ? wk[kk] / wsum : wk[kk];
+  }
+  __syncthreads();
+  if (wave != 0) return;
+  // ---- moe_align_kernel on the ids in LDS (same shards, same order) -------------------------------------------------
+  const int t = lane;
+  const int per = (numel + 63) / 64;
+  const int lo = t * per, hi = min(numel, lo + per);
+  for (int e = 0; e < num_experts; ++e) cnt[(t + 1) * num_experts + e] = 0;
+  for (int i = lo; i < hi; ++i) ++cnt[(t + 1) * num_experts + ids[i]];
+  for (int i = t; i < max_padded; i += 64) sorted_token_ids[i] = numel;
+  for (int i = t; i < max_blocks; i += 64) expert_ids[i] = -1;
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  for (int e = t; e < num_experts; e += 64) {
+    cnt[e] = 0;
+    for (int s2 = 1; s2 <= 64; ++s2) cnt[s2 * num_experts + e] += cnt[(s2 - 1) * num_experts + e];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  if (t == 0) {
+    cumsum[0] = 0;
+    for (int e = 1; e <= num_experts; ++e)
+      cumsum[e] = cumsum[e - 1] + (cnt[64 * num_experts + e - 1] + block_size - 1) / block_size * block_size;
+    *num_tokens_post_pad = cumsum[num_experts];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  // (the global stores of expert_ids = -1 above and of the real ids below come from the same wave in program order, but
+  //  from DIFFERENT lanes: make the fill visible first)
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+  for (int e = t; e < num_experts; e += 64)
+    for (int i = cumsum[e]; i < cumsum[e + 1]; i += block_size) expert_ids[i / block_size] = e;
+  for (int i = lo; i < hi; ++i) {
+    const int e = ids[i];
+    const int pos = cnt[t * num_experts + e] + cumsum[e];
+    sorted_token_ids[pos] = i;
+    if (inv_pos) inv_pos[i] = pos;
+    ++cnt[t * num_experts + e];
+  }
+}
+
 // Fragment-major pack (see pack_a_kernel, wna16_gemm.hip) of the rows selected by sorted_token_ids:
 // packed row r <- a[sorted[r] / topk] (a zero row for padding entries and for rows beyond
 // *num_tokens_post_pad).
@@ -189,6 +293,32 @@ extern "C" int aphro_moe_align_block_size(const int32_t* topk_ids, int num_exper
   hipLaunchKernelGGL(moe_align_kernel, dim3(1), dim3(64), lds, (hipStream_t)stream, topk_ids, sorted_token_ids,
                      expert_ids, num_tokens_post_pad, inv_pos, num_experts, block_size, (int)numel, max_padded,
                      max_blocks);
+  APHRO_LAUNCH_CHECK();
+  return APHRO_OK;
+}
+
+// fused_topk + moe_align_block_size in one launch (decode-sized batches: num_tokens * topk <= 8192, topk <= 8).
+// gating: [num_tokens, gating_stride] f16 / bf16 / f32 router logits.  Outputs as aphro_topk_softmax (+ renormalised
+// weights when `renormalize`) and aphro_moe_align_block_size.
+extern "C" int aphro_moe_route_align(float* topk_weights, int32_t* topk_ids, const void* gating, int64_t gating_stride,
+                                     int32_t* sorted_token_ids, int32_t* expert_ids, int32_t* num_tokens_post_pad,
+                                     int32_t* inv_pos, int64_t num_tokens, int num_experts, int topk, int renormalize,
+                                     int block_size, int dtype, void* stream) {
+  APHRO_CHECK(num_experts >= 1 && num_experts <= 256 && block_size >= 1, "moe_route_align: bad arguments");
+  APHRO_CHECK(topk >= 1 && topk <= 8 && topk <= num_experts, "moe_route_align: topk=%d (1..8 supported)", topk);
+  APHRO_CHECK(num_tokens >= 0 && num_tokens * topk <= 8192, "moe_route_align: %ld slots exceed the one-workgroup form", (long)(num_tokens * topk));
+  APHRO_CHECK(dtype >= APHRO_F16 && dtype <= APHRO_F32, "moe_route_align: unsupported gating dtype %d", dtype);
+  const int numel = (int)num_tokens * topk;
+  const int max_padded = numel + num_experts * (block_size - 1);
+  const int max_blocks = (max_padded + block_size - 1) / block_size;
+  const size_t lds = (size_t)(numel + 65 * num_experts + num_experts + 1) * sizeof(int32_t);
+  APHRO_CHECK(lds <= 64 * 1024, "moe_route_align: %zu bytes of LDS", lds);
+#define L(TT)                                                                                                       \
+  hipLaunchKernelGGL((moe_route_align_kernel<TT>), dim3(1), dim3(1024), lds, (hipStream_t)stream, topk_weights, topk_ids, \
+                     (const typename TT::storage*)gating, gating_stride, sorted_token_ids, expert_ids, num_tokens_post_pad, \
+                     inv_pos, (int)num_tokens, num_experts, topk, renormalize, block_size, max_padded, max_blocks)
+  if (dtype == APHRO_F16) L(Half); else if (dtype == APHRO_BF16) L(BFloat); else L(Float);
+#undef L
   APHRO_LAUNCH_CHECK();
   return APHRO_OK;
 }

@@ -53,6 +53,22 @@ def moe_align_block_size(topk_ids: torch.Tensor, block_size: int, num_experts: i
     return sorted_ids, expert_ids, num_tokens_post_pad
 
 
+def route_and_align(hidden_states: torch.Tensor, gating_output: torch.Tensor, topk: int, renormalize: bool,
+                    num_experts: int, want_inverse: bool = False):
+    """fused_topk + moe_align_block_size(MOE_BLOCK_M): ONE launch for decode-sized batches (ops.moe_route_align), the
+    separate ops above otherwise -- same results either way.  Returns (topk_weights, topk_ids, sorted_ids, expert_ids,
+    num_tokens_post_pad, inv or None)."""
+    import os
+    t_ = hidden_states.shape[0]
+    if (0 < t_ * topk <= ops.MOE_ROUTE_ALIGN_MAX_SLOTS and topk <= 8 and gating_output.stride(1) == 1
+            and gating_output.dtype in (torch.float16, torch.bfloat16, torch.float32)
+            and not os.environ.get("APHRO_MOE_NO_ROUTE_ALIGN")):
+        return ops.moe_route_align(gating_output, topk, renormalize, num_experts, MOE_BLOCK_M, want_inverse)
+    topk_weights, topk_ids = fused_topk(hidden_states, gating_output, topk, renormalize)
+    out = moe_align_block_size(topk_ids, MOE_BLOCK_M, num_experts, want_inverse=want_inverse)
+    return (topk_weights, topk_ids) + tuple(out) + (() if want_inverse else (None, ))
+
+
 class Wna16Experts:
     """Stacked int4 expert weights in the layouts the grouped kernel consumes.
 
@@ -90,15 +106,20 @@ class Wna16Experts:
 def fused_wna16_moe(hidden_states: torch.Tensor, experts: Wna16Experts, gating_output: torch.Tensor,
                     topk: int, renormalize: bool = True,
                     topk_weights: Optional[torch.Tensor] = None,
-                    topk_ids: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """The fused_marlin_moe role (fused_moe.py:438-542) for GPTQ/AWQ int4 experts."""
+                    topk_ids: Optional[torch.Tensor] = None, aligned=None) -> torch.Tensor:
+    """The fused_marlin_moe role (fused_moe.py:438-542) for GPTQ/AWQ int4 experts.  aligned: (sorted_ids, expert_ids,
+    post_pad, inv) when the caller has routed and aligned already (route_and_align)."""
     assert hidden_states.shape[1] == experts.hidden, "Hidden size mismatch"
     assert gating_output.shape[1] == experts.num_experts, "Number of experts mismatch"
     m = hidden_states.shape[0]
-    if topk_ids is None:
-        topk_weights, topk_ids = fused_topk(hidden_states, gating_output, topk, renormalize)
     e = experts.num_experts
-    sorted_ids, expert_ids, post_pad, inv = moe_align_block_size(topk_ids, MOE_BLOCK_M, e, want_inverse=True)
+    if aligned is not None:
+        sorted_ids, expert_ids, post_pad, inv = aligned
+    elif topk_ids is None:
+        topk_weights, topk_ids, sorted_ids, expert_ids, post_pad, inv = route_and_align(
+            hidden_states, gating_output, topk, renormalize, e, want_inverse=True)
+    else:
+        sorted_ids, expert_ids, post_pad, inv = moe_align_block_size(topk_ids, MOE_BLOCK_M, e, want_inverse=True)
     m_pad = (sorted_ids.numel() + MOE_BLOCK_M - 1) // MOE_BLOCK_M * MOE_BLOCK_M
     packed = ops.moe_gather_pack(hidden_states, sorted_ids, post_pad, m_pad, topk)
     qw, qz, sc = experts.w13
@@ -210,16 +231,19 @@ class Wna16MoEMethod(FusedMoEMethodBase):
             raise NotImplementedError("grouped top-k routing (DeepSeek-V2) is outside the hot path")
         if layer.experts_packed is None:
             raise RuntimeError("FusedMoE: process_weights_after_loading has not run")
-        topk_weights, topk_ids = fused_topk(x, router_logits, top_k, renormalize)
+        topk_weights, topk_ids, sorted_ids, expert_ids, post_pad, inv = route_and_align(
+            x, router_logits, top_k, renormalize, layer.experts_packed.num_experts, want_inverse=True)
         if getattr(layer, "record_routing", False):     # measurement aid: which experts a step touched
             layer.last_topk_ids = topk_ids
         return fused_wna16_moe(x, layer.experts_packed, router_logits, top_k, renormalize,
-                               topk_weights=topk_weights, topk_ids=topk_ids)
+                               topk_weights=topk_weights, topk_ids=topk_ids,
+                               aligned=(sorted_ids, expert_ids, post_pad, inv))
 
 
 def fused_fp8_moe(hidden_states: torch.Tensor, w13: torch.Tensor, w2: torch.Tensor, w13_scale: torch.Tensor,
                   w2_scale: torch.Tensor, topk_weights: torch.Tensor, topk_ids: torch.Tensor,
-                  a1_scale: Optional[torch.Tensor] = None, a2_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+                  a1_scale: Optional[torch.Tensor] = None, a2_scale: Optional[torch.Tensor] = None,
+                  aligned=None) -> torch.Tensor:
     """``fused_experts(..., use_fp8_w8a8=True)`` (fused_moe.py:566-690) on the grouped FP8 kernel (csrc/fp8_moe.hip).
     w13 [E, 2I, H] / w2 [E, H, I] e4m3, one weight scale per expert, per-tensor activation scales (static, or dynamic
     over the whole tensor: ``scaled_fp8_quant``), the reference's intermediate layouts and roundings:
@@ -231,7 +255,10 @@ def fused_fp8_moe(hidden_states: torch.Tensor, w13: torch.Tensor, w2: torch.Tens
     e, n13, _ = w13.shape
     k = topk_ids.shape[1]
     dev, dt = hidden_states.device, hidden_states.dtype
-    sorted_ids, expert_ids, post_pad = moe_align_block_size(topk_ids, MOE_BLOCK_M, e)
+    if aligned is not None:
+        sorted_ids, expert_ids, post_pad = aligned
+    else:
+        sorted_ids, expert_ids, post_pad = moe_align_block_size(topk_ids, MOE_BLOCK_M, e)
     xq, s1 = ops.scaled_fp8_quant(hidden_states, a1_scale)
     cache1 = torch.empty((m * k, n13), dtype=dt, device=dev)
     ops.fp8_moe_gemm(xq, w13, s1, w13_scale, None, sorted_ids, expert_ids, post_pad, cache1, k)
@@ -325,11 +352,13 @@ class Fp8MoEMethod(FusedMoEMethodBase):
               renormalize: bool, use_grouped_topk: bool = False) -> torch.Tensor:
         if use_grouped_topk:
             raise NotImplementedError("grouped top-k routing (DeepSeek-V2) is outside the hot path")
-        topk_weights, topk_ids = fused_topk(x, router_logits, top_k, renormalize)
+        topk_weights, topk_ids, sorted_ids, expert_ids, post_pad, _ = route_and_align(
+            x, router_logits, top_k, renormalize, layer.w13_weight.shape[0])
         if getattr(layer, "record_routing", False):
             layer.last_topk_ids = topk_ids
         return fused_fp8_moe(x, layer.w13_weight, layer.w2_weight, layer.w13_weight_scale, layer.w2_weight_scale,
-                             topk_weights, topk_ids, layer.w13_input_scale, layer.w2_input_scale)
+                             topk_weights, topk_ids, layer.w13_input_scale, layer.w2_input_scale,
+                             aligned=(sorted_ids, expert_ids, post_pad))
 
 
 class FusedMoE(nn.Module):

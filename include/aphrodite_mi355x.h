@@ -629,6 +629,16 @@ int aphro_moe_align_block_size(const int32_t* topk_ids, int num_experts, int blo
                                int32_t* num_tokens_post_pad, int32_t* inv_pos,
                                int64_t numel, void* stream);
 
+/* fused_topk (fused_moe.py:369-402: gating.float() -> topk_softmax -> optional renormalise, w / sum_k w in fp32) +
+ * moe_align_block_size (:174-228) in ONE launch for decode-sized batches (num_tokens * topk <= 8192, topk <= 8): same
+ * outputs as the separate ops (the same routing arithmetic and counting sort: ids and lists identical, weights identical up
+ * to the order of the renormalising sum for topk > 2).  gating:
+ * [num_tokens, gating_stride] f16 / bf16 / f32 router logits.  csrc/moe.hip. */
+int aphro_moe_route_align(float* topk_weights, int32_t* topk_ids, const void* gating, int64_t gating_stride,
+                          int32_t* sorted_token_ids, int32_t* expert_ids, int32_t* num_tokens_post_pad, int32_t* inv_pos,
+                          int64_t num_tokens, int num_experts, int topk, int renormalize, int block_size, int dtype,
+                          void* stream);
+
 /* Fragment-major activation pack of the rows a[sorted_token_ids[r] / topk] (zero rows for
  * padding) -- the sorted_ids / replicate_input addressing of marlin_gemm_moe
  * (kernels/moe/marlin_moe_ops.cu) done once, ahead of the GEMM. */

@@ -2134,3 +2134,41 @@ def test_fp8_gemm_stream_vs_oracle(ops, M, N, K, dtype):
             np.testing.assert_allclose(out.float().cpu().numpy(), ref, rtol=2 * eps, atol=2 * eps * np.abs(ref).max())
     finally:
         os.environ.pop("APHRO_FP8_STREAM_ALL")
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("T,E,k,renorm", [(1, 8, 2, True), (32, 8, 2, True), (64, 8, 2, False), (33, 16, 4, True), (200, 64, 6, True),
+                                          (7, 4, 1, False)])
+def test_moe_route_align_matches_the_separate_ops(ops, T, E, k, renorm, dtype):
+    """fused_topk + moe_align_block_size in one launch == gating.float() -> topk_softmax -> renormalise ->
+    moe_align_block_size launched separately: weights and ids bit for bit, the same sorted / expert / inverse lists
+    (those ops are themselves oracle-checked above); also against the oracle's routing."""
+    from aphrodite_engine_amd import moe as moe_mod
+    from oracle import moe as omoe
+    rng = np.random.default_rng(T * 31 + E + k)
+    gating = t((rng.standard_normal((T, E)) * 2).astype(np.float32)).to(dtype)
+    hidden = torch.empty(T, 8, device=DEV, dtype=torch.float16)
+    tw0, ids0 = moe_mod.fused_topk(hidden, gating, k, renorm)
+    s0, e0, p0, inv0 = moe_mod.moe_align_block_size(ids0, 16, E, want_inverse=True)
+    tw1, ids1, s1, e1, p1, inv1 = ops.moe_route_align(gating, k, renorm, E, 16, want_inverse=True)
+    assert torch.equal(ids1, ids0)
+    if k <= 2 or not renorm:
+        assert torch.equal(tw1, tw0)
+    else:   # the renormalising sum runs in slot order here, in torch's reduction order there: one fp32 rounding apart
+        torch.testing.assert_close(tw1, tw0, rtol=3e-7, atol=0)
+    npad = int(p0.item())
+    assert int(p1.item()) == npad
+    assert torch.equal(s1, s0) and torch.equal(e1, e0) and torch.equal(inv1, inv0)
+    w_ref, ids_ref, _ = omoe.topk_softmax(gating.float().cpu().numpy(), k)
+    assert np.array_equal(ids1.cpu().numpy(), ids_ref)
+    if renorm:
+        w_ref = w_ref / w_ref.sum(1, keepdims=True)
+    np.testing.assert_allclose(tw1.cpu().numpy(), w_ref, rtol=2e-6, atol=1e-7)
+    # capturable, and repeatable
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = ops.moe_route_align(gating, k, renorm, E, 16, want_inverse=True)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out[2], s0) and torch.equal(out[0], tw1)
