@@ -951,6 +951,30 @@ def fused_add_rms_norm_pack(x: Optional[torch.Tensor], slabs: Optional[torch.Ten
     return packed, out
 
 
+def fused_add_rms_norm_router(x: Optional[torch.Tensor], slabs: Optional[torch.Tensor], residual: Optional[torch.Tensor],
+                              has_residual: bool, weight: torch.Tensor, epsilon: float, router_weight: torch.Tensor):
+    """[slab reduce] + fused_add_rms_norm + the router's logits of a sparse-MLP layer (the replicated ``gate`` linear of
+    MixtralMoE, mixtral.py:60-110) in one launch; returns (out [tokens, hidden], router_logits [tokens, E]), E <= 16."""
+    lib = _lib.lib()
+    if slabs is not None:
+        nslab, tokens, hidden = slabs.shape
+        dev = slabs.device
+    else:
+        tokens, hidden = x.shape
+        nslab, dev = 0, x.device
+        assert x.is_contiguous()
+    e = router_weight.shape[0]
+    if router_weight.shape[1] != hidden or not router_weight.is_contiguous() or router_weight.dtype != weight.dtype:
+        raise RuntimeError("fused_add_rms_norm_router: router_weight must be a contiguous [E, hidden] tensor of the norm's dtype")
+    out = torch.empty((tokens, hidden), dtype=weight.dtype, device=dev)
+    logits = torch.empty((tokens, e), dtype=weight.dtype, device=dev)
+    check(lib.aphro_fused_add_rms_norm_router(_ptr(x), _ptr(slabs), nslab, _ptr(residual), 1 if has_residual else 0,
+                                              weight.data_ptr(), float(epsilon), out.data_ptr(), router_weight.data_ptr(),
+                                              logits.data_ptr(), e, tokens, hidden, _dt(weight), _stream()),
+          "fused_add_rms_norm_router")
+    return out, logits
+
+
 def silu_and_mul_pack(x: torch.Tensor) -> torch.Tensor:
     lib = _lib.lib()
     tokens, d2 = x.shape

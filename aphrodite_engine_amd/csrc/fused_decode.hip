@@ -44,13 +44,24 @@ __device__ __forceinline__ uint16_t to_f16_bits(uint16_t tbits) {
 // reduce would); residual' = round(x + residual) (or x when residual_in is null);
 // y = round(round(residual' * rstd) * w).  y goes to the packed buffer (f16) and/or
 // row-major `out`.
-template <typename T>
+// ROUTER (sparse-MLP layers): the router's logits of the token, round_T(y . Wg[e]) for e < num_experts <= 16 (the
+// replicated `gate` linear of MixtralMoE, modeling/models/mixtral.py:60-110, a [M, E] library GEMM launch of its own
+// otherwise), from the normalised values the thread already holds.  A separate instantiation: the dense model's norm kernel
+// is not touched.
+template <typename T, bool ROUTER = false>
 __global__ void add_rms_norm_pack_kernel(const uint16_t* __restrict__ input, const float* __restrict__ slabs,
                                          int nslab, uint16_t* __restrict__ residual, int has_residual,
                                          const uint16_t* __restrict__ weight, float eps,
                                          uint16_t* __restrict__ packed, uint16_t* __restrict__ out, int tokens,
-                                         int hidden) {
+                                         int hidden, const uint16_t* __restrict__ router_w = nullptr,
+                                         uint16_t* __restrict__ router_out = nullptr, int num_experts = 0) {
   __shared__ float red[16];
+  __shared__ float rred[ROUTER ? 16 * 16 : 1];
+  float rpart[ROUTER ? 16 : 1];
+  if constexpr (ROUTER) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) rpart[e] = 0.f;
+  }
   const int tok = blockIdx.x;
   const int nv = hidden >> 3;
   const int mtiles = (tokens + 15) >> 4;
@@ -117,6 +128,31 @@ __global__ void add_rms_norm_pack_kernel(const uint16_t* __restrict__ input, con
       }
       if (out) *reinterpret_cast<u16x8*>(out + (size_t)tok * hidden + 8 * i) = y;
       if (packed) *reinterpret_cast<u16x8*>(packed + packed_chunk(tok, 8 * i, mtiles)) = yh;
+      if constexpr (ROUTER) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          if (e < num_experts) {
+            const u16x8 g8 = *reinterpret_cast<const u16x8*>(router_w + (size_t)e * hidden + 8 * i);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) rpart[e] += T::to_f32(y[j]) * T::to_f32(g8[j]);
+          }
+      }
+    }
+  }
+  if constexpr (ROUTER) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = (blockDim.x + 63) >> 6;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      float v2 = rpart[e];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v2 += __shfl_xor(v2, o, 64);
+      if (lane == 0) rred[wave * 16 + e] = v2;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < num_experts) {
+      float sum = 0.f;
+      for (int w2 = 0; w2 < nwave; ++w2) sum += rred[w2 * 16 + threadIdx.x];
+      router_out[(size_t)tok * num_experts + threadIdx.x] = T::from_f32(sum);
     }
   }
 }
@@ -337,6 +373,34 @@ extern "C" int aphro_fused_add_rms_norm_pack(const void* input, const float* sla
   hipLaunchKernelGGL((add_rms_norm_pack_kernel<TT>), grid, block, 0, (hipStream_t)stream, (const uint16_t*)input, \
                      slabs, nslab, (uint16_t*)residual, has_residual, (const uint16_t*)weight, eps,             \
                      (uint16_t*)packed, (uint16_t*)out, (int)tokens, hidden)
+  if (dtype == APHRO_F16) L(Half); else L(BFloat);
+#undef L
+  APHRO_LAUNCH_CHECK();
+  return APHRO_OK;
+}
+
+// The same kernel for a sparse-MLP layer: also writes router_out[tokens, num_experts] = round_T(y . router_w[e]) (the
+// replicated gate linear of MixtralMoE; num_experts <= 16).  `out` (the row-major normalised activations the expert
+// gather reads) is required.
+extern "C" int aphro_fused_add_rms_norm_router(const void* input, const float* slabs, int nslab, void* residual,
+                                               int has_residual, const void* weight, float eps, void* out,
+                                               const void* router_w, void* router_out, int num_experts, int64_t tokens,
+                                               int hidden, int dtype, void* stream) {
+  APHRO_CHECK(dtype == APHRO_F16 || dtype == APHRO_BF16, "fused_add_rms_norm_router: dtype must be f16 or bf16");
+  APHRO_CHECK((input != nullptr) != (slabs != nullptr), "fused_add_rms_norm_router: exactly one of input / slabs");
+  APHRO_CHECK(hidden % 8 == 0 && hidden <= 16384 && out != nullptr, "fused_add_rms_norm_router: hidden=%d unsupported", hidden);
+  APHRO_CHECK(num_experts >= 1 && num_experts <= 16 && router_w != nullptr && router_out != nullptr,
+              "fused_add_rms_norm_router: 1..16 experts (got %d)", num_experts);
+  APHRO_CHECK(!has_residual || residual != nullptr, "fused_add_rms_norm_router: residual missing");
+  if (tokens == 0) return APHRO_OK;
+  int nv = hidden / 8, t = nv <= 1024 ? nv : (nv + 1) / 2;
+  t = (t + 63) / 64 * 64;
+  t = t < 64 ? 64 : (t > 1024 ? 1024 : t);
+  dim3 grid((unsigned)tokens), block(t);
+#define L(TT)                                                                                                      \
+  hipLaunchKernelGGL((add_rms_norm_pack_kernel<TT, true>), grid, block, 0, (hipStream_t)stream, (const uint16_t*)input, \
+                     slabs, nslab, (uint16_t*)residual, has_residual, (const uint16_t*)weight, eps, (uint16_t*)nullptr, \
+                     (uint16_t*)out, (int)tokens, hidden, (const uint16_t*)router_w, (uint16_t*)router_out, num_experts)
   if (dtype == APHRO_F16) L(Half); else L(BFloat);
 #undef L
   APHRO_LAUNCH_CHECK();

@@ -272,9 +272,11 @@ class LlamaDecoderLayer(nn.Module):
         return (self.qkv_proj, self.o_proj) if self.is_moe else \
             (self.qkv_proj, self.o_proj, self.gate_up_proj, self.down_proj)
 
-    def moe_block(self, normed: torch.Tensor) -> torch.Tensor:
-        """router (fp16 library GEMM, [M, E]) + fused experts (+ TP all-reduce inside FusedMoE)."""
-        router_logits = torch.matmul(normed, self.moe_gate.t())
+    def moe_block(self, normed: torch.Tensor, router_logits: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """router (fp16 library GEMM, [M, E], unless the norm kernel already produced the logits) + fused experts
+        (+ TP all-reduce inside FusedMoE)."""
+        if router_logits is None:
+            router_logits = torch.matmul(normed, self.moe_gate.t())
         return self.experts(normed, router_logits)
 
     def forward_decode_fused(self, positions, x, slabs, residual, first, kv_cache, attn_metadata, cos_sin,
@@ -315,10 +317,19 @@ class LlamaDecoderLayer(nn.Module):
             if self.tp > 1:
                 o = ops.wna16_gemm_packed(attn_packed, m, self.q_size, qw, qz, sc, zo, partials=False)
                 o = tensor_model_parallel_all_reduce(o)
+                if self.moe_gate.shape[0] <= 16 and not os.environ.get("APHRO_MOE_NO_NORM_ROUTER"):
+                    normed, logits = ops.fused_add_rms_norm_router(o, None, residual, True,
+                                                                   self.post_attention_layernorm, eps, self.moe_gate)
+                    return self.moe_block(normed, logits), None
                 _, normed = ops.fused_add_rms_norm_pack(o, None, residual, True, self.post_attention_layernorm,
                                                         eps, pack=False, want_out=True)
             else:
                 o_slabs, _ = ops.wna16_gemm_packed(attn_packed, m, self.q_size, qw, qz, sc, zo, partials=True)
+                if self.moe_gate.shape[0] <= 16 and not os.environ.get("APHRO_MOE_NO_NORM_ROUTER"):
+                    # the router's logits come out of the norm launch (no [M, E] library GEMM launch)
+                    normed, logits = ops.fused_add_rms_norm_router(None, o_slabs, residual, True,
+                                                                   self.post_attention_layernorm, eps, self.moe_gate)
+                    return self.moe_block(normed, logits), None
                 _, normed = ops.fused_add_rms_norm_pack(None, o_slabs, residual, True,
                                                         self.post_attention_layernorm, eps, pack=False,
                                                         want_out=True)

@@ -629,6 +629,14 @@ int aphro_moe_align_block_size(const int32_t* topk_ids, int num_experts, int blo
                                int32_t* num_tokens_post_pad, int32_t* inv_pos,
                                int64_t numel, void* stream);
 
+/* aphro_fused_add_rms_norm_pack for a sparse-MLP layer: [slab reduce] + fused_add_rms_norm + the router's logits
+ * router_out[tokens, num_experts] = round_T(y . router_w[e]) -- the replicated `gate` linear of MixtralMoE
+ * (modeling/models/mixtral.py:60-110), a [M, E] library GEMM launch of its own otherwise.  num_experts <= 16; `out` =
+ * the row-major normalised activations.  csrc/fused_decode.hip. */
+int aphro_fused_add_rms_norm_router(const void* input, const float* slabs, int nslab, void* residual, int has_residual,
+                                    const void* weight, float eps, void* out, const void* router_w, void* router_out,
+                                    int num_experts, int64_t tokens, int hidden, int dtype, void* stream);
+
 /* fused_topk (fused_moe.py:369-402: gating.float() -> topk_softmax -> optional renormalise, w / sum_k w in fp32) +
  * moe_align_block_size (:174-228) in ONE launch for decode-sized batches (num_tokens * topk <= 8192, topk <= 8): same
  * outputs as the separate ops (the same routing arithmetic and counting sort: ids and lists identical, weights identical up

@@ -2172,3 +2172,28 @@ def test_moe_route_align_matches_the_separate_ops(ops, T, E, k, renorm, dtype):
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(out[2], s0) and torch.equal(out[0], tw1)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("tokens,hidden,E,nslab", [(32, 4096, 8, 4), (1, 4096, 8, 2), (5, 1024, 16, 0), (64, 2048, 3, 1)])
+def test_fused_add_rms_norm_router(ops, tokens, hidden, E, nslab, dtype):
+    """The norm launch of a sparse-MLP layer that also emits the router logits: `out` and the residual are bit-identical
+    to fused_add_rms_norm_pack's, the logits are round_T(out . Wg^T) with fp32 accumulation (fp64 reference: one rounding
+    step of T)."""
+    rng = np.random.default_rng(tokens + hidden + E)
+    w = t((rng.random(hidden) + 0.5).astype(np.float32)).to(dtype)
+    wg = t((rng.standard_normal((E, hidden)) * 0.05).astype(np.float32)).to(dtype)
+    res = t((rng.standard_normal((tokens, hidden))).astype(np.float32)).to(dtype)
+    if nslab:
+        slabs = t((rng.standard_normal((nslab, tokens, hidden)) * 0.5).astype(np.float32))
+        x = None
+    else:
+        slabs = None
+        x = t((rng.standard_normal((tokens, hidden))).astype(np.float32)).to(dtype)
+    r0, r1 = res.clone(), res.clone()
+    _, want = ops.fused_add_rms_norm_pack(x, slabs, r0, True, w, 1e-5, pack=False, want_out=True)
+    out, logits = ops.fused_add_rms_norm_router(x, slabs, r1, True, w, 1e-5, wg)
+    assert torch.equal(out, want) and torch.equal(r0, r1)
+    ref = out.double() @ wg.double().T
+    eps = 2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7
+    torch.testing.assert_close(logits.double(), ref, rtol=eps, atol=eps * float(ref.abs().max()))
