@@ -975,6 +975,24 @@ def fused_add_rms_norm_router(x: Optional[torch.Tensor], slabs: Optional[torch.T
     return out, logits
 
 
+def fused_add_rms_norm_pack_combine(slabs: torch.Tensor, inv_pos: torch.Tensor, topk_weights: torch.Tensor,
+                                    residual: Optional[torch.Tensor], has_residual: bool, weight: torch.Tensor,
+                                    epsilon: float, pack: bool = True, want_out: bool = False):
+    """moe_combine + fused_add_rms_norm (+ pack) in one launch: the norm that follows a sparse MLP reads the second expert
+    GEMM's slabs through inv_pos / topk_weights itself.  Returns (packed or None, out or None)."""
+    lib = _lib.lib()
+    nslab, m_pad, hidden = slabs.shape
+    tokens, topk = topk_weights.shape
+    dev = slabs.device
+    packed = torch.empty(lib.aphro_wna16_packed_a_bytes(tokens, hidden) // 2, dtype=torch.float16, device=dev) if pack else None
+    out = torch.empty((tokens, hidden), dtype=weight.dtype, device=dev) if want_out else None
+    check(lib.aphro_fused_add_rms_norm_pack_combine(slabs.data_ptr(), nslab, m_pad, inv_pos.data_ptr(),
+                                                    topk_weights.data_ptr(), topk, _ptr(residual), 1 if has_residual else 0,
+                                                    weight.data_ptr(), float(epsilon), _ptr(packed), _ptr(out), tokens,
+                                                    hidden, _dt(weight), _stream()), "fused_add_rms_norm_pack_combine")
+    return packed, out
+
+
 def silu_and_mul_pack(x: torch.Tensor) -> torch.Tensor:
     lib = _lib.lib()
     tokens, d2 = x.shape

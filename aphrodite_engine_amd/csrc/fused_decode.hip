@@ -48,13 +48,19 @@ __device__ __forceinline__ uint16_t to_f16_bits(uint16_t tbits) {
 // replicated `gate` linear of MixtralMoE, modeling/models/mixtral.py:60-110, a [M, E] library GEMM launch of its own
 // otherwise), from the normalised values the thread already holds.  A separate instantiation: the dense model's norm kernel
 // is not touched.
-template <typename T, bool ROUTER = false>
+// COMBINE (the norm that follows a sparse MLP): x = moe_combine of the expert GEMM's fp32 slabs, sum_k round_T(w[t, k] *
+// sum_s slab[s][inv_pos[t k + kk]]) rounded to T -- moe_combine_kernel's arithmetic (moe.hip), without its launch and its
+// [T, hidden] round trip.
+template <typename T, bool ROUTER = false, bool COMBINE = false>
 __global__ void add_rms_norm_pack_kernel(const uint16_t* __restrict__ input, const float* __restrict__ slabs,
                                          int nslab, uint16_t* __restrict__ residual, int has_residual,
                                          const uint16_t* __restrict__ weight, float eps,
                                          uint16_t* __restrict__ packed, uint16_t* __restrict__ out, int tokens,
                                          int hidden, const uint16_t* __restrict__ router_w = nullptr,
-                                         uint16_t* __restrict__ router_out = nullptr, int num_experts = 0) {
+                                         uint16_t* __restrict__ router_out = nullptr, int num_experts = 0,
+                                         const int32_t* __restrict__ inv_pos = nullptr,
+                                         const float* __restrict__ topk_w = nullptr, int topk = 0,
+                                         int64_t comb_stride = 0) {
   __shared__ float red[16];
   __shared__ float rred[ROUTER ? 16 * 16 : 1];
   float rpart[ROUTER ? 16 : 1];
@@ -76,7 +82,27 @@ __global__ void add_rms_norm_pack_kernel(const uint16_t* __restrict__ input, con
       const size_t off = (size_t)tok * hidden + 8 * i;
       wv[it] = *reinterpret_cast<const u16x8*>(weight + 8 * i);
       float x[8];
-      if (slabs) {
+      if constexpr (COMBINE) {
+        float acc8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int kk = 0; kk < topk; ++kk) {
+          const int pos = inv_pos[tok * topk + kk];
+          const float w = topk_w[tok * topk + kk];
+          const float* p0 = slabs + (size_t)pos * hidden + 8 * i;
+          f32x4 a = *reinterpret_cast<const f32x4*>(p0);
+          f32x4 b = *reinterpret_cast<const f32x4*>(p0 + 4);
+          for (int s2 = 1; s2 < nslab; ++s2) {
+            a += *reinterpret_cast<const f32x4*>(p0 + s2 * comb_stride);
+            b += *reinterpret_cast<const f32x4*>(p0 + s2 * comb_stride + 4);
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            acc8[j] += T::to_f32(from_f32_exact<T>(a[j] * w));
+            acc8[4 + j] += T::to_f32(from_f32_exact<T>(b[j] * w));
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = T::to_f32(T::from_f32(acc8[j]));
+      } else if (slabs) {
         f32x4 a = *reinterpret_cast<const f32x4*>(slabs + off);
         f32x4 b = *reinterpret_cast<const f32x4*>(slabs + off + 4);
         for (int s = 1; s < nslab; ++s) {
@@ -401,6 +427,34 @@ extern "C" int aphro_fused_add_rms_norm_router(const void* input, const float* s
   hipLaunchKernelGGL((add_rms_norm_pack_kernel<TT, true>), grid, block, 0, (hipStream_t)stream, (const uint16_t*)input, \
                      slabs, nslab, (uint16_t*)residual, has_residual, (const uint16_t*)weight, eps, (uint16_t*)nullptr, \
                      (uint16_t*)out, (int)tokens, hidden, (const uint16_t*)router_w, (uint16_t*)router_out, num_experts)
+  if (dtype == APHRO_F16) L(Half); else L(BFloat);
+#undef L
+  APHRO_LAUNCH_CHECK();
+  return APHRO_OK;
+}
+
+// The norm after a sparse MLP: x = moe_combine(slabs [nslab][m_pad][hidden], inv_pos [tokens * topk], topk_weights) folded
+// into the kernel's input stage (same bits as aphro_moe_combine followed by aphro_fused_add_rms_norm_pack).
+extern "C" int aphro_fused_add_rms_norm_pack_combine(const float* slabs, int nslab, int64_t m_pad, const int32_t* inv_pos,
+                                                     const float* topk_weights, int topk, void* residual, int has_residual,
+                                                     const void* weight, float eps, void* packed, void* out, int64_t tokens,
+                                                     int hidden, int dtype, void* stream) {
+  APHRO_CHECK(dtype == APHRO_F16 || dtype == APHRO_BF16, "fused_add_rms_norm_pack_combine: dtype must be f16 or bf16");
+  APHRO_CHECK(slabs != nullptr && inv_pos != nullptr && topk_weights != nullptr && nslab >= 1 && topk >= 1,
+              "fused_add_rms_norm_pack_combine: slabs / inv_pos / topk_weights required");
+  APHRO_CHECK(hidden % 8 == 0 && hidden <= 16384, "fused_add_rms_norm_pack_combine: hidden=%d unsupported", hidden);
+  APHRO_CHECK(packed == nullptr || hidden % 128 == 0, "fused_add_rms_norm_pack_combine: packing needs hidden %% 128 == 0");
+  APHRO_CHECK(!has_residual || residual != nullptr, "fused_add_rms_norm_pack_combine: residual missing");
+  if (tokens == 0) return APHRO_OK;
+  int nv = hidden / 8, t = nv <= 1024 ? nv : (nv + 1) / 2;
+  t = (t + 63) / 64 * 64;
+  t = t < 64 ? 64 : (t > 1024 ? 1024 : t);
+  dim3 grid((unsigned)tokens), block(t);
+#define L(TT)                                                                                                      \
+  hipLaunchKernelGGL((add_rms_norm_pack_kernel<TT, false, true>), grid, block, 0, (hipStream_t)stream,             \
+                     (const uint16_t*)nullptr, slabs, nslab, (uint16_t*)residual, has_residual, (const uint16_t*)weight, \
+                     eps, (uint16_t*)packed, (uint16_t*)out, (int)tokens, hidden, (const uint16_t*)nullptr,         \
+                     (uint16_t*)nullptr, 0, inv_pos, topk_weights, topk, (int64_t)m_pad * hidden)
   if (dtype == APHRO_F16) L(Half); else L(BFloat);
 #undef L
   APHRO_LAUNCH_CHECK();

@@ -20,6 +20,7 @@ from torch import nn
 
 from . import _custom_ops as ops
 from .attention.backend import MI355XAttentionImpl, MI355XAttentionMetadata
+from .moe import DeferredCombine
 from .distributed import (get_tensor_model_parallel_rank,
                           get_tensor_model_parallel_world_size,
                           tensor_model_parallel_all_reduce)
@@ -272,12 +273,13 @@ class LlamaDecoderLayer(nn.Module):
         return (self.qkv_proj, self.o_proj) if self.is_moe else \
             (self.qkv_proj, self.o_proj, self.gate_up_proj, self.down_proj)
 
-    def moe_block(self, normed: torch.Tensor, router_logits: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def moe_block(self, normed: torch.Tensor, router_logits: Optional[torch.Tensor] = None,
+                  defer_combine: bool = False):
         """router (fp16 library GEMM, [M, E], unless the norm kernel already produced the logits) + fused experts
         (+ TP all-reduce inside FusedMoE)."""
         if router_logits is None:
             router_logits = torch.matmul(normed, self.moe_gate.t())
-        return self.experts(normed, router_logits)
+        return self.experts(normed, router_logits, defer_combine=defer_combine)
 
     def forward_decode_fused(self, positions, x, slabs, residual, first, kv_cache, attn_metadata, cos_sin,
                              cos_sin_tok=None, next_weights=None):
@@ -287,8 +289,12 @@ class LlamaDecoderLayer(nn.Module):
         eps = self.cfg.rms_norm_eps
         m = positions.shape[0]
         h = self.cfg.hidden_size
-        packed, _ = ops.fused_add_rms_norm_pack(x if slabs is None else None, slabs, residual,
-                                                not first, self.input_layernorm, eps)
+        if isinstance(x, DeferredCombine):        # the previous layer's sparse MLP: combine inside this norm launch
+            packed, _ = ops.fused_add_rms_norm_pack_combine(x.slabs, x.inv, x.topk_weights, residual, not first,
+                                                            self.input_layernorm, eps)
+        else:
+            packed, _ = ops.fused_add_rms_norm_pack(x if slabs is None else None, slabs, residual,
+                                                    not first, self.input_layernorm, eps)
         qkv_slabs, _ = self._gemm_slabs("qkv_proj", packed, m, h)
         from .attention.paged_attn import PagedAttention
         key_cache, value_cache = PagedAttention.split_kv_cache(kv_cache, self.num_kv_heads, self.head_dim)
@@ -329,7 +335,8 @@ class LlamaDecoderLayer(nn.Module):
                     # the router's logits come out of the norm launch (no [M, E] library GEMM launch)
                     normed, logits = ops.fused_add_rms_norm_router(None, o_slabs, residual, True,
                                                                    self.post_attention_layernorm, eps, self.moe_gate)
-                    return self.moe_block(normed, logits), None
+                    return self.moe_block(normed, logits,
+                                          defer_combine=not os.environ.get("APHRO_MOE_NO_DEFERRED_COMBINE")), None
                 _, normed = ops.fused_add_rms_norm_pack(None, o_slabs, residual, True,
                                                         self.post_attention_layernorm, eps, pack=False,
                                                         want_out=True)
@@ -579,6 +586,10 @@ class LlamaForCausalLM(nn.Module):
                     nxt = fp[:3] if fp is not None else None
                 x, slabs = layer.forward_decode_fused(positions, x, slabs, residual, i == 0,
                                                       kv_caches[i], attn_metadata, self.cos_sin, cos_sin_tok, nxt)
+            if isinstance(x, DeferredCombine):
+                _, out = ops.fused_add_rms_norm_pack_combine(x.slabs, x.inv, x.topk_weights, residual, True, self.norm,
+                                                             self.cfg.rms_norm_eps, pack=False, want_out=True)
+                return out
             _, out = ops.fused_add_rms_norm_pack(x if slabs is None else None, slabs, residual, True, self.norm,
                                                  self.cfg.rms_norm_eps, pack=False, want_out=True)
             return out

@@ -53,6 +53,17 @@ def moe_align_block_size(topk_ids: torch.Tensor, block_size: int, num_experts: i
     return sorted_ids, expert_ids, num_tokens_post_pad
 
 
+class DeferredCombine:
+    """The second expert GEMM's fp32 slabs + what moe_combine needs, handed to the NEXT norm launch instead of a combine
+    launch of its own (ops.fused_add_rms_norm_pack_combine folds it into its input stage: same bits)."""
+
+    def __init__(self, slabs: torch.Tensor, inv: torch.Tensor, topk_weights: torch.Tensor, dtype: torch.dtype):
+        self.slabs, self.inv, self.topk_weights, self.dtype = slabs, inv, topk_weights, dtype
+
+    def combine(self) -> torch.Tensor:
+        return ops.moe_combine(self.slabs, self.inv, self.topk_weights, self.dtype)
+
+
 def route_and_align(hidden_states: torch.Tensor, gating_output: torch.Tensor, topk: int, renormalize: bool,
                     num_experts: int, want_inverse: bool = False):
     """fused_topk + moe_align_block_size(MOE_BLOCK_M): ONE launch for decode-sized batches (ops.moe_route_align), the
@@ -106,7 +117,7 @@ class Wna16Experts:
 def fused_wna16_moe(hidden_states: torch.Tensor, experts: Wna16Experts, gating_output: torch.Tensor,
                     topk: int, renormalize: bool = True,
                     topk_weights: Optional[torch.Tensor] = None,
-                    topk_ids: Optional[torch.Tensor] = None, aligned=None) -> torch.Tensor:
+                    topk_ids: Optional[torch.Tensor] = None, aligned=None, defer_combine: bool = False):
     """The fused_marlin_moe role (fused_moe.py:438-542) for GPTQ/AWQ int4 experts.  aligned: (sorted_ids, expert_ids,
     post_pad, inv) when the caller has routed and aligned already (route_and_align)."""
     assert hidden_states.shape[1] == experts.hidden, "Hidden size mismatch"
@@ -137,6 +148,8 @@ def fused_wna16_moe(hidden_states: torch.Tensor, experts: Wna16Experts, gating_o
     qw, qz, sc = experts.w2
     slabs, _ = ops.wna16_gemm_grouped(act, m_pad, experts.inter, qw, qz, sc, expert_ids, post_pad,
                                       experts.zero_offset, "slabs")
+    if defer_combine:
+        return DeferredCombine(slabs, inv, topk_weights.contiguous(), hidden_states.dtype)
     return ops.moe_combine(slabs, inv, topk_weights.contiguous(), hidden_states.dtype)
 
 
@@ -226,7 +239,7 @@ class Wna16MoEMethod(FusedMoEMethodBase):
                 delattr(layer, name)
 
     def apply(self, layer: nn.Module, x: torch.Tensor, router_logits: torch.Tensor, top_k: int,
-              renormalize: bool, use_grouped_topk: bool = False) -> torch.Tensor:
+              renormalize: bool, use_grouped_topk: bool = False, defer_combine: bool = False) -> torch.Tensor:
         if use_grouped_topk:
             raise NotImplementedError("grouped top-k routing (DeepSeek-V2) is outside the hot path")
         if layer.experts_packed is None:
@@ -237,7 +250,7 @@ class Wna16MoEMethod(FusedMoEMethodBase):
             layer.last_topk_ids = topk_ids
         return fused_wna16_moe(x, layer.experts_packed, router_logits, top_k, renormalize,
                                topk_weights=topk_weights, topk_ids=topk_ids,
-                               aligned=(sorted_ids, expert_ids, post_pad, inv))
+                               aligned=(sorted_ids, expert_ids, post_pad, inv), defer_combine=defer_combine)
 
 
 def fused_fp8_moe(hidden_states: torch.Tensor, w13: torch.Tensor, w2: torch.Tensor, w13_scale: torch.Tensor,
@@ -445,7 +458,11 @@ class FusedMoE(nn.Module):
                 rows.append((fused, f"experts.{expert}.{ckpt}.", expert, shard))
         return rows
 
-    def forward(self, hidden_states: torch.Tensor, router_logits: torch.Tensor) -> torch.Tensor:
+    def forward(self, hidden_states: torch.Tensor, router_logits: torch.Tensor, defer_combine: bool = False):
+        """defer_combine: return a DeferredCombine for the next norm launch to consume (int4 experts on one rank only)."""
+        if defer_combine and isinstance(self.quant_method, Wna16MoEMethod) and not (self.reduce_results and self.tp_size > 1):
+            return self.quant_method.apply(self, hidden_states, router_logits, self.top_k, self.renormalize,
+                                           defer_combine=True)
         out = self.quant_method.apply(self, hidden_states, router_logits, self.top_k, self.renormalize)
         if self.reduce_results and self.tp_size > 1:
             from .distributed import tensor_model_parallel_all_reduce

@@ -637,6 +637,14 @@ int aphro_fused_add_rms_norm_router(const void* input, const float* slabs, int n
                                     const void* weight, float eps, void* out, const void* router_w, void* router_out,
                                     int num_experts, int64_t tokens, int hidden, int dtype, void* stream);
 
+/* The norm that follows a sparse MLP with moe_combine folded into its input stage: x[t] = sum_k round_T(w[t, k] * sum_s
+ * slab[s][inv_pos[t k + kk]]) (fused_moe.py:520-542; = aphro_moe_combine), then fused_add_rms_norm (+ pack) as
+ * aphro_fused_add_rms_norm_pack.  slabs fp32 [nslab][m_pad][hidden].  csrc/fused_decode.hip. */
+int aphro_fused_add_rms_norm_pack_combine(const float* slabs, int nslab, int64_t m_pad, const int32_t* inv_pos,
+                                          const float* topk_weights, int topk, void* residual, int has_residual,
+                                          const void* weight, float eps, void* packed, void* out, int64_t tokens, int hidden,
+                                          int dtype, void* stream);
+
 /* fused_topk (fused_moe.py:369-402: gating.float() -> topk_softmax -> optional renormalise, w / sum_k w in fp32) +
  * moe_align_block_size (:174-228) in ONE launch for decode-sized batches (num_tokens * topk <= 8192, topk <= 8): same
  * outputs as the separate ops (the same routing arithmetic and counting sort: ids and lists identical, weights identical up

@@ -2197,3 +2197,24 @@ def test_fused_add_rms_norm_router(ops, tokens, hidden, E, nslab, dtype):
     ref = out.double() @ wg.double().T
     eps = 2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7
     torch.testing.assert_close(logits.double(), ref, rtol=eps, atol=eps * float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("tokens,hidden,topk,nslab", [(32, 4096, 2, 4), (1, 4096, 2, 1), (7, 1024, 4, 2)])
+def test_fused_add_rms_norm_pack_combine(ops, tokens, hidden, topk, nslab, dtype):
+    """moe_combine folded into the next norm launch: residual, row-major output and the packed activations are
+    bit-identical to aphro_moe_combine followed by aphro_fused_add_rms_norm_pack."""
+    rng = np.random.default_rng(tokens + hidden + topk)
+    m_pad = ((tokens * topk + 15) // 16 + 3) * 16
+    slabs = t((rng.standard_normal((nslab, m_pad, hidden)) * 0.5).astype(np.float32))
+    inv = t(rng.permutation(m_pad)[:tokens * topk].astype(np.int32))
+    tw = t(rng.random((tokens, topk)).astype(np.float32))
+    w = t((rng.random(hidden) + 0.5).astype(np.float32)).to(dtype)
+    res = t(rng.standard_normal((tokens, hidden)).astype(np.float32)).to(dtype)
+    r0, r1 = res.clone(), res.clone()
+    x = ops.moe_combine(slabs, inv, tw, dtype)
+    pk0, out0 = ops.fused_add_rms_norm_pack(x, None, r0, True, w, 1e-5, pack=True, want_out=True)
+    pk1, out1 = ops.fused_add_rms_norm_pack_combine(slabs, inv, tw, r1, True, w, 1e-5, pack=True, want_out=True)
+    assert torch.equal(out0, out1) and torch.equal(r0, r1)
+    a0, a1 = unpack_a(pk0, tokens, hidden), unpack_a(pk1, tokens, hidden)
+    assert np.array_equal(a0, a1)
