@@ -166,7 +166,17 @@ def paged_attention_rocm(out, exp_sum, max_logits, tmp_out, query, key_cache,
                          value_cache, num_kv_heads, scale, block_tables,
                          seq_lens, block_size, max_seq_len, alibi_slopes,
                          kv_cache_dtype, k_scale, v_scale) -> None:
+    """`_rocm_C::paged_attention` (kernels/rocm/torch_bindings.cpp): the reference's ROCm backend calls it for every decode
+    batch on gfx9 (rocm_flash_attn.py:539-560, 633-641) with scratch for 512-token partitions.  Only ``out`` is read back by
+    the caller; where one launch over whole sequences is the faster form -- the reference's own v1 / v2 rule,
+    paged_attn.py:112-121: max_seq_len <= 8192 and (one partition or num_seqs * num_heads > 512) -- the op runs that form and
+    leaves the scratch untouched (25.4 against 26.4 + 5.0 us for the partition kernel + its reduce launch at configs[1]).
+    APHRO_PA_ROCM_PARTITIONED=1 keeps the partitioned form (and the exp_sums / max_logits / tmp_out contract)."""
     part = _partition_size(tmp_out, max_seq_len)
+    num_seqs, num_heads = query.shape[0], query.shape[1]
+    if (max_seq_len <= 8192 and ((max_seq_len + part - 1) // part == 1 or num_seqs * num_heads > 512)
+            and not os.environ.get("APHRO_PA_ROCM_PARTITIONED")):
+        part, exp_sum, max_logits, tmp_out = 0, None, None, None
     _paged_attention(out, exp_sum, max_logits, tmp_out, query, key_cache,
                      value_cache, num_kv_heads, scale, block_tables, seq_lens,
                      block_size, max_seq_len, alibi_slopes, kv_cache_dtype,

@@ -759,7 +759,17 @@ def test_paged_attention(ops, case, version, kv_cache_dtype, dtype, use_alibi):
     elif version == "v2":
         ops.paged_attention_v2(out, es, ml, tmp, *args)
     else:
+        # the rocm op takes the single-launch form where the reference's v1 / v2 rule says v1 (scratch untouched: only
+        # `out` is the caller's); check that output first, then the partitioned form and its scratch contract
         ops.paged_attention_rocm(out, es, ml, tmp, *args)
+        first = out.clone()
+        out.fill_(float("nan"))
+        import os
+        os.environ["APHRO_PA_ROCM_PARTITIONED"] = "1"
+        try:
+            ops.paged_attention_rocm(out, es, ml, tmp, *args)
+        finally:
+            os.environ.pop("APHRO_PA_ROCM_PARTITIONED")
     kc_np = kc.float().cpu().numpy() if kv_cache_dtype == "auto" else kc.cpu().numpy()
     vc_np = vc.float().cpu().numpy() if kv_cache_dtype == "auto" else vc.cpu().numpy()
     ref = oa.paged_attention_decode(query.float().cpu().numpy(), kc_np, vc_np, bt, seq_lens,
@@ -773,6 +783,8 @@ def test_paged_attention(ops, case, version, kv_cache_dtype, dtype, use_alibi):
     if dtype == torch.bfloat16:
         atol += 2.0 ** -8 * float(np.abs(ref).max())
     np.testing.assert_allclose(out.float().cpu().numpy(), ref, atol=atol, rtol=1e-5)
+    if version == "rocm":
+        np.testing.assert_allclose(first.float().cpu().numpy(), ref, atol=atol, rtol=1e-5)
     if version != "v1" and P > 1:
         # scratch tensors carry the reference's meaning (attention_kernels.cu:350-358)
         _, mx_ref, es_ref, _ = oa.paged_attention_v2_partials(
