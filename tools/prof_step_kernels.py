@@ -56,3 +56,15 @@ s4 = torch.randn(4, bs, 4096, device=dev)
 for _ in range(6):
     ops.fused_add_rms_norm_pack(None, s4, res, True, w, 1e-5)
 torch.cuda.synchronize()
+# round 3, late: the LM head with the argmax folded in, and the op-level one-launch GEMMs (row-major activations)
+V = 128256
+lmw = [(torch.randn(V, 4096, device=dev, generator=g) * 0.02).half() for _ in range(2)]
+hid = (torch.randn(bs, 4096, device=dev, generator=g) * 0.5).half()
+for i in range(6):
+    ops.lm_head_argmax(hid, lmw[i % 2], V)
+gi = torch.empty(0, dtype=torch.int32, device=dev)
+for name, (k, n) in shapes.items():
+    x = torch.randn(bs, k, device=dev, dtype=torch.float16)
+    for qw, qz, sc in ws[name]:
+        ops.gptq_gemm(x, qw, qz, sc, gi, True, 4)
+torch.cuda.synchronize()
