@@ -16,6 +16,7 @@
 //     to the activation dtype (the value the reference's argmax sees), optionally stores it, and keeps a running
 //     (max, index); at the end the workgroup's best per token goes to a partial buffer (write-through), a ticket is taken,
 //     and the LAST workgroup reduces the partials: ties -> the lowest index, NaN never wins (= argmax_rows, step_ops.hip).
+#include <mutex>
 #include <utility>
 
 #include "common.h"
@@ -249,6 +250,8 @@ static LmHeadWs g_lmh_ws[APHRO_MAX_DEVICES];
 static constexpr int LMH_MAX_GRID = 1024;
 
 static LmHeadWs* lmh_workspace(hipStream_t st) {
+  static std::mutex mu;                        // host threads racing on the first call allocate once
+  std::lock_guard<std::mutex> lock(mu);
   LmHeadWs& ws = g_lmh_ws[device_slot()];
   if (ws.counter == nullptr) {
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;

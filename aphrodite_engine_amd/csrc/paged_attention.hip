@@ -22,6 +22,8 @@
 //  * waves of a workgroup interleave 32-token tile pairs and merge (m, l, O)
 //    through LDS; partitions merge by the reference's exp_sums/max_logits/
 //    tmp_out contract.
+#include <mutex>
+
 #include "common.h"
 
 namespace aphro {
@@ -888,6 +890,8 @@ struct SplitWs { unsigned* counter = nullptr; size_t groups = 0; float* scratch 
 static SplitWs g_split_ws[APHRO_MAX_DEVICES];
 
 static bool split_workspace(size_t groups, size_t floats, hipStream_t st, SplitWs** ws_out) {
+  static std::mutex mu;                        // host threads racing on first use / growth
+  std::lock_guard<std::mutex> lock(mu);
   SplitWs& ws = g_split_ws[device_slot()];
   if (ws.groups < groups || ws.floats < floats) {
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;

@@ -25,6 +25,7 @@
 //     read as 256-byte row pieces, exactly like the round-2 kernel.
 //   * K reduction over the waves through LDS as a [wave][row][column] tile; the output leaves as whole rows: 16 bytes per
 //     thread for the fp32 slabs / the 16-bit result, one 16-byte fragment piece per thread for the SiluAndMul + pack form.
+#include <mutex>
 #include <utility>
 
 #include "common.h"
@@ -766,6 +767,8 @@ static unsigned* g_res_counter[APHRO_MAX_DEVICES];
 static constexpr int RES_COUNTERS = 4096;
 
 static unsigned* res_counters(hipStream_t st) {
+  static std::mutex mu;                        // host threads racing on the first call allocate once
+  std::lock_guard<std::mutex> lock(mu);
   unsigned*& cnt = g_res_counter[device_slot()];
   if (cnt == nullptr) {
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
