@@ -27,9 +27,10 @@ struct Fp8MoeParams {
   int N, K, num_valid, top_k_div;
 };
 
-constexpr int MOE8_NW = 8;
-
-template <typename T, int NT>
+// MOE8_NW waves split K.  4, not 8: a wave's two-step pipeline needs a few steps to reach its steady state (K = 4096 over 8
+// waves is 4 steps each) and the LDS reduce is half as long -- Mixtral-8x7B shapes, 8 active experts, tools/fp8_moe_bench.py:
+// w13 196 -> 191 us, w2 112 -> 98 us (4.2 -> 4.8 TB/s)
+template <typename T, int NT, int MOE8_NW>
 __global__ __launch_bounds__(MOE8_NW * 64) void fp8_moe_gemm_kernel(Fp8MoeParams p) {
   __shared__ __attribute__((aligned(16))) float red[MOE8_NW * NT * 64 * 4];
   const int blk = blockIdx.z;
@@ -141,17 +142,22 @@ extern "C" int aphro_fp8_moe_gemm(const void* a, const void* w, const float* a_s
   APHRO_CHECK(K % 128 == 0 && N % 16 == 0 && top_k_div >= 1, "fp8_moe_gemm: K %% 128 == 0 and N %% 16 == 0 required (K=%ld N=%ld)", (long)K, (long)N);
   APHRO_CHECK(((uintptr_t)a % 16) == 0 && ((uintptr_t)w % 16) == 0, "fp8_moe_gemm: operands must be 16-byte aligned");
   if (num_valid == 0 || max_blocks == 0) return APHRO_OK;
-  const int nt = (N % 64 == 0) ? 4 : (N % 32 == 0) ? 2 : 1;
+  int nt = (N % 64 == 0) ? 4 : (N % 32 == 0) ? 2 : 1;
+  int nw = 4;
+  if (const char* e = getenv("APHRO_FP8_MOE_NT")) { const int v = atoi(e); if ((v == 1 || v == 2 || v == 4) && N % (16 * v) == 0) nt = v; }
+  if (const char* e = getenv("APHRO_FP8_MOE_NW")) { const int v = atoi(e); if (v == 4 || v == 8) nw = v; }
   Fp8MoeParams p;
   p.a = (const uint8_t*)a; p.w = (const uint8_t*)w; p.a_scale = a_scale; p.b_scales = b_scales; p.topk_weights = topk_weights;
   p.sorted_ids = sorted_ids; p.expert_ids = expert_ids; p.num_post_pad = num_post_pad; p.c = c;
   p.N = (int)N; p.K = (int)K; p.num_valid = (int)num_valid; p.top_k_div = top_k_div;
   dim3 grid((unsigned)(N / (16 * nt)), 1, (unsigned)max_blocks);
-#define L(TT, NTV) hipLaunchKernelGGL((fp8_moe_gemm_kernel<TT, NTV>), grid, dim3(MOE8_NW * 64), 0, (hipStream_t)stream, p)
-#define LN(TT) { if (nt == 4) L(TT, 4); else if (nt == 2) L(TT, 2); else L(TT, 1); }
+#define L2(TT, NTV, NWV) hipLaunchKernelGGL((fp8_moe_gemm_kernel<TT, NTV, NWV>), grid, dim3(NWV * 64), 0, (hipStream_t)stream, p)
+#define L(TT, NTV) { if (nw == 8) L2(TT, NTV, 8); else L2(TT, NTV, 4); }
+#define LN(TT) { if (nt == 4) L(TT, 4) else if (nt == 2) L(TT, 2) else L(TT, 1) }
   if (dtype == APHRO_F16) LN(Half) else LN(BFloat)
 #undef LN
 #undef L
+#undef L2
   APHRO_LAUNCH_CHECK();
   return APHRO_OK;
 }
