@@ -1164,11 +1164,19 @@ def scaled_mm_fp8_slabs(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     return slabs
 
 
+def _check_static_scale(static_scale: Optional[torch.Tensor], dev) -> None:
+    if static_scale is not None and (static_scale.dtype != torch.float32 or static_scale.numel() != 1
+                                     or static_scale.device.type != torch.device(dev).type):
+        raise RuntimeError("static_scale must be one float32 on the activations' device")
+
+
 def fused_add_rms_norm_quant_fp8(x: Optional[torch.Tensor], slabs: Optional[torch.Tensor],
                                  slab_a_scales: Optional[torch.Tensor], slab_b_scales: Optional[torch.Tensor],
                                  residual: torch.Tensor, has_residual: bool, weight: torch.Tensor,
-                                 epsilon: float, want_out: bool = False):
-    """[slab reduce + dequant] + fused_add_rms_norm + per-token fp8 quant.
+                                 epsilon: float, want_out: bool = False,
+                                 static_scale: Optional[torch.Tensor] = None):
+    """[slab reduce + dequant] + fused_add_rms_norm + per-token fp8 quant (``static_scale``: the layer's per-tensor
+    input_scale, fp32 [1] -- quantises as static_scaled_fp8_quant and returns that scale for every token).
     Returns (q fp8 [M, H], scales fp32 [M, 1], out or None)."""
     lib = _lib.lib()
     if slabs is not None:
@@ -1183,15 +1191,17 @@ def fused_add_rms_norm_quant_fp8(x: Optional[torch.Tensor], slabs: Optional[torc
     out = torch.empty((tokens, hidden), dtype=weight.dtype, device=dev) if want_out else None
     a_tok = 1 if slab_a_scales is not None and slab_a_scales.numel() > 1 else 0
     b_ch = 1 if slab_b_scales is not None and slab_b_scales.numel() > 1 else 0
-    check(lib.aphro_fused_add_rms_norm_quant_fp8(
+    _check_static_scale(static_scale, dev)
+    check(lib.aphro_fused_add_rms_norm_quant_fp8_static(
         _ptr(x), _ptr(slabs), nslab, _ptr(slab_a_scales), _ptr(slab_b_scales), a_tok, b_ch, residual.data_ptr(),
         1 if has_residual else 0, weight.data_ptr(), float(epsilon), q.data_ptr(), sc.data_ptr(), _ptr(out),
-        tokens, hidden, _dt(weight), _stream()), "fused_add_rms_norm_quant_fp8")
+        tokens, hidden, _dt(weight), _ptr(static_scale), _stream()), "fused_add_rms_norm_quant_fp8")
     return q, sc, out
 
 
-def silu_and_mul_quant_fp8(x: torch.Tensor, want_out: bool = False):
-    """silu_and_mul + per-token fp8 quant over x [M, 2d]; returns (q [M, d], scales [M, 1], out or None)."""
+def silu_and_mul_quant_fp8(x: torch.Tensor, want_out: bool = False, static_scale: Optional[torch.Tensor] = None):
+    """silu_and_mul + per-token fp8 quant over x [M, 2d] (``static_scale``: as in fused_add_rms_norm_quant_fp8);
+    returns (q [M, d], scales [M, 1], out or None)."""
     lib = _lib.lib()
     tokens, d2 = x.shape
     d = d2 // 2
@@ -1199,8 +1209,9 @@ def silu_and_mul_quant_fp8(x: torch.Tensor, want_out: bool = False):
     q = torch.empty((tokens, d), dtype=FP8_DTYPE, device=x.device)
     sc = torch.empty((tokens, 1), dtype=torch.float32, device=x.device)
     out = torch.empty((tokens, d), dtype=x.dtype, device=x.device) if want_out else None
-    check(lib.aphro_silu_and_mul_quant_fp8(x.data_ptr(), q.data_ptr(), sc.data_ptr(), _ptr(out), tokens, d,
-                                           _dt(x), _stream()), "silu_and_mul_quant_fp8")
+    _check_static_scale(static_scale, x.device)
+    check(lib.aphro_silu_and_mul_quant_fp8_static(x.data_ptr(), q.data_ptr(), sc.data_ptr(), _ptr(out), tokens, d,
+                                                  _dt(x), _ptr(static_scale), _stream()), "silu_and_mul_quant_fp8")
     return q, sc, out
 
 

@@ -36,6 +36,8 @@ SIGNATURES = {
     "aphro_scaled_mm_fp8_slabs": (I, [P, P, P, Z, L, L, L, P]),
     "aphro_fused_add_rms_norm_quant_fp8": (I, [P, P, I, P, P, I, I, P, I, P, F, P, P, P, L, I, I, P]),
     "aphro_silu_and_mul_quant_fp8": (I, [P, P, P, P, L, I, I, P]),
+    "aphro_fused_add_rms_norm_quant_fp8_static": (I, [P, P, I, P, P, I, I, P, I, P, F, P, P, P, L, I, I, P, P]),
+    "aphro_silu_and_mul_quant_fp8_static": (I, [P, P, P, P, L, I, I, P, P]),
     "aphro_paged_attention_rope_packed_scaled": (I, [P, P, P, I, P, P, P, P, P, P, P, I, I, I, I, F, P, P,
                                                      I, I, I, P, L, L, I, I, F, F, P]),
     "aphro_sample_top_k_top_p": (I, [P, P, L, P, P, P, P, P, L, P, P, L, L, I, P]),

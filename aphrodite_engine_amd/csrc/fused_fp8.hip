@@ -6,6 +6,9 @@
 // Reference semantics: kernels/layernorm_kernels.cu:200-240, kernels/activation_kernels.cu:12-75,
 // kernels/quantization/fp8/common.cu:201-256 (scale = max(absmax / 448, 1 / (448 * 512)), x / scale),
 // cutlass_scaled_mm epilogue a_scale * (b_scale * acc) (tests/kernels/test_cutlass.py:43).
+// STATIC activation scheme (input_scale in the checkpoint: compressed_tensors_w8a8_fp8.py:98-113, fp8.py static
+// activation_scheme): the same kernels with `static_scale` given quantise as static_scaled_fp8_quant does -- x * (1 / scale),
+// common.cu:187-199 -- skip the absmax reduction, and still fill scale_out[token] so that every consumer is unchanged.
 #include "common.h"
 
 namespace aphro {
@@ -35,6 +38,15 @@ __device__ __forceinline__ uint32_t fq_pack4(const float (&v)[4], float s) {
   return (uint32_t)w;
 }
 
+__device__ __forceinline__ uint32_t fq_pack4_inv(const float (&v)[4], float inv) {   // static scheme: x * (1 / scale)
+  float a[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) a[i] = __builtin_fmaxf(-FQ_MAX, __builtin_fminf(v[i] * inv, FQ_MAX));
+  int w = __builtin_amdgcn_cvt_pk_fp8_f32(a[0], a[1], 0, false);
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(a[2], a[3], w, true);
+  return (uint32_t)w;
+}
+
 // x = input (T) or T(sa[tok] * (sb[col] * sum_k slabs[k])); residual' = T(x + residual) (or x);
 // y = T(T(residual' * rstd) * w); q = fp8(y / scale), scale = max(absmax(y) / 448, 1/(448*512)).
 // Same thread -> element mapping and reduction order as rms_norm_kernel / add_rms_norm_pack_kernel.
@@ -44,7 +56,8 @@ __global__ void add_rms_norm_quant_kernel(const uint16_t* __restrict__ input, co
                                           int sa_per_token, int sb_per_channel, uint16_t* __restrict__ residual,
                                           int has_residual, const uint16_t* __restrict__ weight, float eps,
                                           uint8_t* __restrict__ q_out, float* __restrict__ scale_out,
-                                          uint16_t* __restrict__ out, int tokens, int hidden) {
+                                          uint16_t* __restrict__ out, int tokens, int hidden,
+                                          const float* __restrict__ static_scale) {
   __shared__ float red[16];
   const int tok = blockIdx.x;
   const int nv = hidden >> 3;
@@ -115,8 +128,14 @@ __global__ void add_rms_norm_quant_kernel(const uint16_t* __restrict__ input, co
       if (out) *reinterpret_cast<u16x8*>(out + (size_t)tok * hidden + 8 * i) = y;
     }
   }
-  amax = fq_block_reduce(amax, red, true);
-  const float scale = __builtin_fmaxf(amax / FQ_MAX, 1.0f / (FQ_MAX * 512.f));
+  float scale, inv_static = 0.f;
+  if (static_scale) {
+    scale = *static_scale;
+    inv_static = 1.0f / scale;
+  } else {
+    amax = fq_block_reduce(amax, red, true);
+    scale = __builtin_fmaxf(amax / FQ_MAX, 1.0f / (FQ_MAX * 512.f));
+  }
   if (threadIdx.x == 0) scale_out[tok] = scale;
 #pragma unroll
   for (int it = 0; it < 2; ++it) {
@@ -124,7 +143,8 @@ __global__ void add_rms_norm_quant_kernel(const uint16_t* __restrict__ input, co
     if (i < nv) {
       const float lo[4] = {v[it][0], v[it][1], v[it][2], v[it][3]};
       const float hi[4] = {v[it][4], v[it][5], v[it][6], v[it][7]};
-      u32x2 q = {fq_pack4(lo, scale), fq_pack4(hi, scale)};
+      u32x2 q = static_scale ? u32x2{fq_pack4_inv(lo, inv_static), fq_pack4_inv(hi, inv_static)}
+                             : u32x2{fq_pack4(lo, scale), fq_pack4(hi, scale)};
       *reinterpret_cast<u32x2*>(q_out + (size_t)tok * hidden + 8 * i) = q;
     }
   }
@@ -133,7 +153,8 @@ __global__ void add_rms_norm_quant_kernel(const uint16_t* __restrict__ input, co
 // act = T(T(silu(gate)) * up) over x = [gate | up] (T [tokens, 2d]); q = fp8(act / scale) per token
 template <typename T, int VPT>
 __global__ void silu_mul_quant_kernel(const uint16_t* __restrict__ in, uint8_t* __restrict__ q_out,
-                                      float* __restrict__ scale_out, uint16_t* __restrict__ out, int d) {
+                                      float* __restrict__ scale_out, uint16_t* __restrict__ out, int d,
+                                      const float* __restrict__ static_scale) {
   __shared__ float red[16];
   const int tok = blockIdx.x;
   const uint16_t* a = in + (size_t)tok * 2 * d;
@@ -157,8 +178,14 @@ __global__ void silu_mul_quant_kernel(const uint16_t* __restrict__ in, uint8_t* 
       if (out) *reinterpret_cast<u16x8*>(out + (size_t)tok * d + 8 * i) = r;
     }
   }
-  amax = fq_block_reduce(amax, red, true);
-  const float scale = __builtin_fmaxf(amax / FQ_MAX, 1.0f / (FQ_MAX * 512.f));
+  float scale, inv_static = 0.f;
+  if (static_scale) {
+    scale = *static_scale;
+    inv_static = 1.0f / scale;
+  } else {
+    amax = fq_block_reduce(amax, red, true);
+    scale = __builtin_fmaxf(amax / FQ_MAX, 1.0f / (FQ_MAX * 512.f));
+  }
   if (threadIdx.x == 0) scale_out[tok] = scale;
 #pragma unroll
   for (int it = 0; it < VPT; ++it) {
@@ -166,7 +193,8 @@ __global__ void silu_mul_quant_kernel(const uint16_t* __restrict__ in, uint8_t* 
     if (i < nv) {
       const float lo[4] = {v[it][0], v[it][1], v[it][2], v[it][3]};
       const float hi[4] = {v[it][4], v[it][5], v[it][6], v[it][7]};
-      u32x2 q = {fq_pack4(lo, scale), fq_pack4(hi, scale)};
+      u32x2 q = static_scale ? u32x2{fq_pack4_inv(lo, inv_static), fq_pack4_inv(hi, inv_static)}
+                             : u32x2{fq_pack4(lo, scale), fq_pack4(hi, scale)};
       *reinterpret_cast<u32x2*>(q_out + (size_t)tok * d + 8 * i) = q;
     }
   }
@@ -176,12 +204,13 @@ __global__ void silu_mul_quant_kernel(const uint16_t* __restrict__ in, uint8_t* 
 
 using namespace aphro;
 
-extern "C" int aphro_fused_add_rms_norm_quant_fp8(const void* input, const float* slabs, int nslab,
-                                                  const float* slab_a_scales, const float* slab_b_scales,
-                                                  int a_scale_per_token, int b_scale_per_channel, void* residual,
-                                                  int has_residual, const void* weight, float eps, void* q_out,
-                                                  float* scale_out, void* out, int64_t tokens, int hidden,
-                                                  int dtype, void* stream) {
+// static_scale: NULL = dynamic per-token scales; else the layer's per-tensor input scale ([1], device)
+extern "C" int aphro_fused_add_rms_norm_quant_fp8_static(const void* input, const float* slabs, int nslab,
+                                                         const float* slab_a_scales, const float* slab_b_scales,
+                                                         int a_scale_per_token, int b_scale_per_channel, void* residual,
+                                                         int has_residual, const void* weight, float eps, void* q_out,
+                                                         float* scale_out, void* out, int64_t tokens, int hidden,
+                                                         int dtype, const float* static_scale, void* stream) {
   APHRO_CHECK(dtype == APHRO_F16 || dtype == APHRO_BF16, "fused_add_rms_norm_quant: dtype must be f16 or bf16");
   APHRO_CHECK((input != nullptr) != (slabs != nullptr), "fused_add_rms_norm_quant: exactly one of input / slabs");
   APHRO_CHECK(hidden % 8 == 0 && hidden <= 16384, "fused_add_rms_norm_quant: hidden=%d unsupported", hidden);
@@ -195,15 +224,27 @@ extern "C" int aphro_fused_add_rms_norm_quant_fp8(const void* input, const float
   hipLaunchKernelGGL((add_rms_norm_quant_kernel<TT>), dim3((unsigned)tokens), dim3(t), 0, (hipStream_t)stream,    \
                      (const uint16_t*)input, slabs, nslab, slab_a_scales, slab_b_scales, a_scale_per_token,      \
                      b_scale_per_channel, (uint16_t*)residual, has_residual, (const uint16_t*)weight, eps,       \
-                     (uint8_t*)q_out, scale_out, (uint16_t*)out, (int)tokens, hidden)
+                     (uint8_t*)q_out, scale_out, (uint16_t*)out, (int)tokens, hidden, static_scale)
   if (dtype == APHRO_F16) L(Half); else L(BFloat);
 #undef L
   APHRO_LAUNCH_CHECK();
   return APHRO_OK;
 }
 
-extern "C" int aphro_silu_and_mul_quant_fp8(const void* input, void* q_out, float* scale_out, void* out,
-                                            int64_t tokens, int d, int dtype, void* stream) {
+extern "C" int aphro_fused_add_rms_norm_quant_fp8(const void* input, const float* slabs, int nslab,
+                                                  const float* slab_a_scales, const float* slab_b_scales,
+                                                  int a_scale_per_token, int b_scale_per_channel, void* residual,
+                                                  int has_residual, const void* weight, float eps, void* q_out,
+                                                  float* scale_out, void* out, int64_t tokens, int hidden,
+                                                  int dtype, void* stream) {
+  return aphro_fused_add_rms_norm_quant_fp8_static(input, slabs, nslab, slab_a_scales, slab_b_scales, a_scale_per_token,
+                                                   b_scale_per_channel, residual, has_residual, weight, eps, q_out,
+                                                   scale_out, out, tokens, hidden, dtype, nullptr, stream);
+}
+
+extern "C" int aphro_silu_and_mul_quant_fp8_static(const void* input, void* q_out, float* scale_out, void* out,
+                                                   int64_t tokens, int d, int dtype, const float* static_scale,
+                                                   void* stream) {
   APHRO_CHECK(dtype == APHRO_F16 || dtype == APHRO_BF16, "silu_and_mul_quant: dtype must be f16 or bf16");
   APHRO_CHECK(d % 8 == 0 && d <= 4 * 1024 * 8, "silu_and_mul_quant: d=%d unsupported", d);
   if (tokens == 0) return APHRO_OK;
@@ -213,11 +254,16 @@ extern "C" int aphro_silu_and_mul_quant_fp8(const void* input, void* q_out, floa
   dim3 grid((unsigned)tokens), block(threads);
 #define L(TT, V)                                                                                              \
   hipLaunchKernelGGL((silu_mul_quant_kernel<TT, V>), grid, block, 0, (hipStream_t)stream, (const uint16_t*)input, \
-                     (uint8_t*)q_out, scale_out, (uint16_t*)out, d)
+                     (uint8_t*)q_out, scale_out, (uint16_t*)out, d, static_scale)
 #define LV(TT) { if (vpt == 1) L(TT, 1); else if (vpt == 2) L(TT, 2); else L(TT, 4); }
   if (dtype == APHRO_F16) LV(Half) else LV(BFloat)
 #undef LV
 #undef L
   APHRO_LAUNCH_CHECK();
   return APHRO_OK;
+}
+
+extern "C" int aphro_silu_and_mul_quant_fp8(const void* input, void* q_out, float* scale_out, void* out,
+                                            int64_t tokens, int d, int dtype, void* stream) {
+  return aphro_silu_and_mul_quant_fp8_static(input, q_out, scale_out, out, tokens, d, dtype, nullptr, stream);
 }

@@ -381,17 +381,24 @@ class LlamaDecoderLayer(nn.Module):
             down_slabs, _ = self._gemm_slabs("down_proj", act_packed, m, kd)
         return None, down_slabs
 
-    # -- FP8 W8A8 (per-token dynamic activations) decode fast path -------------------------------
+    # -- FP8 W8A8 (per-token dynamic or static per-tensor activations) decode fast path ----------
     def fused_decode_fp8_ok(self, m: int) -> bool:
         """9 launches per layer instead of 15+: every activation quantisation rides in the kernel
         that produces the activations, the GEMMs hand their raw fp32 split-K slabs to the consumer
         (which dequantises with the per-token x per-channel scales), rotary + cache write run
-        inside the attention kernel."""
+        inside the attention kernel.  The activation scheme -- dynamic per token, or the checkpoint's
+        static per-tensor input_scale -- must be the same for the four projections of the layer."""
         from .quantization.fp8 import CompressedTensorsW8A8Fp8Method
         if m > 64 or self.head_dim != 128 or not self.fuse_rope_attention or self.is_moe:
             return False
-        for lin in self.linears():
-            if not isinstance(lin.quant_method, CompressedTensorsW8A8Fp8Method) or lin.input_scale is not None:
+        lins = self.linears()
+        static = [lin.input_scale is not None for lin in lins]
+        if any(static) != all(static):
+            return False
+        for lin in lins:
+            if not isinstance(lin.quant_method, CompressedTensorsW8A8Fp8Method):
+                return False
+            if lin.input_scale is not None and (lin.input_scale.numel() != 1 or lin.input_scale.dtype != torch.float32):
                 return False
             if ops.fp8_gemm_ksplit(m, lin.out_features, lin.in_features) <= 0:
                 return False
@@ -413,12 +420,15 @@ class LlamaDecoderLayer(nn.Module):
         down_proj (TP == 1).  Returns (x, prev) of this layer's down_proj in the same convention."""
         eps = self.cfg.rms_norm_eps
         m = positions.shape[0]
+        # static scheme: each projection's input_scale ([1]) goes to the kernel that quantises its input
+        s_qkv, s_o = self.qkv_proj.input_scale, self.o_proj.input_scale
+        s_gu, s_dn = self.gate_up_proj.input_scale, self.down_proj.input_scale
         if prev is None:
             qx, sx, _ = ops.fused_add_rms_norm_quant_fp8(x, None, None, None, residual, not first,
-                                                         self.input_layernorm, eps)
+                                                         self.input_layernorm, eps, static_scale=s_qkv)
         else:
             qx, sx, _ = ops.fused_add_rms_norm_quant_fp8(None, prev[0], prev[1], prev[2], residual, True,
-                                                         self.input_layernorm, eps)
+                                                         self.input_layernorm, eps, static_scale=s_qkv)
         qkv_slabs = ops.scaled_mm_fp8_slabs(qx, self.qkv_proj.weight)
         from .attention.paged_attn import PagedAttention
         key_cache, value_cache = PagedAttention.split_kv_cache(kv_cache, self.num_kv_heads, self.head_dim)
@@ -429,20 +439,20 @@ class LlamaDecoderLayer(nn.Module):
             key_cache, value_cache, self.num_heads, self.num_kv_heads, self.attn.scale,
             attn_metadata.block_tables, attn_metadata.seq_lens_tensor, value_cache.shape[3],
             attn_metadata.max_decode_seq_len, None, self.attn.kv_cache_dtype, self.k_scale, self.v_scale)
-        qa, sa = ops.scaled_fp8_quant(attn_out.view(m, self.q_size), None, use_per_token_if_dynamic=True)
+        qa, sa = ops.scaled_fp8_quant(attn_out.view(m, self.q_size), s_o, use_per_token_if_dynamic=True)
         if self.tp > 1:
             o = ops.cutlass_scaled_mm(qa, self.o_proj.weight, out_dtype=attn_out.dtype, scale_a=sa,
                                       scale_b=self.o_proj.weight_scale)
             o = tensor_model_parallel_all_reduce(o)
             qh, sh, _ = ops.fused_add_rms_norm_quant_fp8(o, None, None, None, residual, True,
-                                                         self.post_attention_layernorm, eps)
+                                                         self.post_attention_layernorm, eps, static_scale=s_gu)
         else:
             o_slabs = ops.scaled_mm_fp8_slabs(qa, self.o_proj.weight)
             qh, sh, _ = ops.fused_add_rms_norm_quant_fp8(None, o_slabs, sa, self.o_proj.weight_scale, residual,
-                                                         True, self.post_attention_layernorm, eps)
+                                                         True, self.post_attention_layernorm, eps, static_scale=s_gu)
         gate_up = ops.cutlass_scaled_mm(qh, self.gate_up_proj.weight, out_dtype=attn_out.dtype, scale_a=sh,
                                         scale_b=self.gate_up_proj.weight_scale)
-        qd, sd, _ = ops.silu_and_mul_quant_fp8(gate_up)
+        qd, sd, _ = ops.silu_and_mul_quant_fp8(gate_up, static_scale=s_dn)
         if self.tp > 1:
             d = ops.cutlass_scaled_mm(qd, self.down_proj.weight, out_dtype=attn_out.dtype, scale_a=sd,
                                       scale_b=self.down_proj.weight_scale)

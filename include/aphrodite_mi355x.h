@@ -443,11 +443,25 @@ int aphro_fused_add_rms_norm_quant_fp8(const void* input, const float* slabs, in
                                        void* residual, int has_residual, const void* weight,
                                        float eps, void* q_out, float* scale_out, void* out,
                                        int64_t tokens, int hidden, int dtype, void* stream);
+/* The same with a STATIC per-tensor activation scale (static_scale: fp32 [1] on the device, the layer's input_scale;
+ * NULL = the dynamic form): q = fp8(y * (1 / scale)) as static_scaled_fp8_quant (fp8/common.cu:187-199),
+ * scale_out[token] = scale. */
+int aphro_fused_add_rms_norm_quant_fp8_static(const void* input, const float* slabs, int nslab,
+                                              const float* slab_a_scales, const float* slab_b_scales,
+                                              int a_scale_per_token, int b_scale_per_channel,
+                                              void* residual, int has_residual, const void* weight,
+                                              float eps, void* q_out, float* scale_out, void* out,
+                                              int64_t tokens, int hidden, int dtype,
+                                              const float* static_scale, void* stream);
 
 /* silu_and_mul (activation_kernels.cu:12-75) + dynamic_per_token_scaled_fp8_quant over
  * input T [tokens, 2d]; out (optional) = the activations in T. */
 int aphro_silu_and_mul_quant_fp8(const void* input, void* q_out, float* scale_out, void* out,
                                  int64_t tokens, int d, int dtype, void* stream);
+/* ... + static_scaled_fp8_quant (static_scale fp32 [1]; NULL = the dynamic form). */
+int aphro_silu_and_mul_quant_fp8_static(const void* input, void* q_out, float* scale_out, void* out,
+                                        int64_t tokens, int d, int dtype, const float* static_scale,
+                                        void* stream);
 
 /* aphro_paged_attention_rope_packed over the slabs of a QUANTISED qkv projection:
  * value = slab_row_scale[seq] * (slab_col_scale[c] * sum of slabs) before the rounding. */

@@ -502,8 +502,9 @@ def test_config3_batch64_fused_decode_layers_vs_oracle(ops):
     assert np.abs(got - want).mean() / np.abs(want).mean() < 4e-3
 
 
+@pytest.mark.parametrize("scheme", ["dynamic", "static"])
 @pytest.mark.parametrize("kv_cache_dtype", ["fp8", "auto"])
-def test_config2_fused_fp8_decode_layers_vs_oracle(ops, kv_cache_dtype):
+def test_config2_fused_fp8_decode_layers_vs_oracle(ops, kv_cache_dtype, scheme):
     """configs[2] (compressed-tensors FP8 W8A8, per-token dynamic activations x per-channel weights, FP8-E4M3 KV cache)
     through TWO decoder layers of Llama-3-8B geometry on forward_decode_fused_fp8 -- every activation quantisation fused
     into its producer, raw fp32 slabs between the GEMMs and their consumers, rotary + cache write inside the attention
@@ -511,7 +512,9 @@ def test_config2_fused_fp8_decode_layers_vs_oracle(ops, kv_cache_dtype):
     w8a8_utils.py:104-183; attention/layer.py) composed from ORACLE functions.  Activation quantisation is a step
     function: a half-ulp difference upstream moves a token's scale and with it many elements by one fp8 step (6 %), which the
     K-long dot products only average out -- hence a bound on the MEAN error, calibrated in the test itself against the
-    oracle's own sensitivity to one omitted bf16 rounding, plus a loose element-wise one."""
+    oracle's own sensitivity to one omitted bf16 rounding, plus a loose element-wise one.
+    scheme "static": the checkpoint carries one input_scale per projection (compressed_tensors_w8a8_fp8.py:98-113) and
+    every quantisation is static_scaled_fp8_quant (x * (1 / scale)) -- the same fused launches with the scale handed in."""
     from oracle import fp8 as of8
     from aphrodite_engine_amd import model as M
     from aphrodite_engine_amd.quantization.fp8 import CompressedTensorsW8A8Fp8Config
@@ -521,8 +524,13 @@ def test_config2_fused_fp8_decode_layers_vs_oracle(ops, kv_cache_dtype):
     to_dt = lambda x: torch.from_numpy(np.asarray(x, dtype=np.float32)).to(dtype).float().numpy()     # round to bf16
     kind = "fp8_e4m3" if kv_cache_dtype == "fp8" else "auto"
     with torch.no_grad():
-        m = M.LlamaForCausalLM(cfg, CompressedTensorsW8A8Fp8Config("channel"), dtype, kv_cache_dtype)
+        m = M.LlamaForCausalLM(cfg, CompressedTensorsW8A8Fp8Config("channel", is_static_input_scheme=scheme == "static"),
+                               dtype, kv_cache_dtype)
         m.init_synthetic(torch.device(DEV))
+        if scheme == "static":          # distinct scales per projection, some rows saturating
+            for li, layer in enumerate(m.layers):
+                for j, lin_ in enumerate(layer.linears()):
+                    lin_.input_scale.fill_((3.0 + j + 0.5 * li) / 448.0)
         meta, pos, nblocks = M.make_decode_metadata(bs, lens, block, DEV)
         ids = torch.randint(0, cfg.vocab_size, (bs, ), device=DEV, generator=torch.Generator(device=DEV).manual_seed(7))
         caches = M.make_kv_caches(cfg, nblocks, block, dtype, kv_cache_dtype, DEV, seed=5)
@@ -534,7 +542,11 @@ def test_config2_fused_fp8_decode_layers_vs_oracle(ops, kv_cache_dtype):
 
         def linear(lin_, x):
             """dynamic per-token quant + scaled_mm, output rounded to the activation dtype (w8a8_utils.py:143-183)."""
-            qx, sx = of8.dynamic_per_token_scaled_fp8_quant(x)
+            if lin_.input_scale is not None:
+                sx = np.float32(lin_.input_scale.item())
+                qx = of8.static_scaled_fp8_quant(x, sx)
+            else:
+                qx, sx = of8.dynamic_per_token_scaled_fp8_quant(x)
             w = lin_.weight.view(torch.uint8).cpu().numpy()                 # [K, N] view of the [N, K] checkpoint tensor
             return to_dt(of8.scaled_mm(qx, w, sx, lin_.weight_scale.float().cpu().numpy()))
 

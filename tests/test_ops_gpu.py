@@ -1363,8 +1363,12 @@ def test_scaled_mm_fp8_slabs(ops, M, K, N, dtype):
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("tokens,hidden", [(1, 512), (32, 4096), (5, 8192), (3, 11008), (64, 1024)])
 @pytest.mark.parametrize("mode", ["input", "input_first", "slabs", "slabs_tensor_scales"])
-def test_fused_add_rms_norm_quant_fp8(ops, dtype, tokens, hidden, mode):
+@pytest.mark.parametrize("scheme", ["dynamic", "static"])
+def test_fused_add_rms_norm_quant_fp8(ops, dtype, tokens, hidden, mode, scheme):
+    """scheme "static": the layer's per-tensor input_scale handed in -- static_scaled_fp8_quant's bits, the scale returned
+    for every token."""
     rng = np.random.default_rng(tokens + hidden)
+    st = t(np.array([1.7 / 448.0], np.float32)) if scheme == "static" else None     # |y| > 1.7 saturates
     w = t(rng.standard_normal(hidden).astype(np.float32) * 0.5 + 1.0, dtype)
     res0 = t(rng.standard_normal((tokens, hidden)).astype(np.float32), dtype)
     if mode.startswith("slabs"):
@@ -1389,13 +1393,16 @@ def test_fused_add_rms_norm_quant_fp8(ops, dtype, tokens, hidden, mode):
     else:
         ops.fused_add_rms_norm(ref_x, ref_res, w, 1e-5)
         ref_y = ref_x
-    ref_q, ref_s = ops.scaled_fp8_quant(ref_y, None, use_per_token_if_dynamic=True)
+    ref_q, ref_s = ops.scaled_fp8_quant(ref_y, st, use_per_token_if_dynamic=True)
+    if st is not None:
+        ref_s = st.reshape(1, 1).expand(tokens, 1)
     res = res0.clone()
     if mode.startswith("slabs"):
-        q, s, out = ops.fused_add_rms_norm_quant_fp8(None, slabs, sa, sb, res, True, w, 1e-5, want_out=True)
+        q, s, out = ops.fused_add_rms_norm_quant_fp8(None, slabs, sa, sb, res, True, w, 1e-5, want_out=True,
+                                                     static_scale=st)
     else:
         q, s, out = ops.fused_add_rms_norm_quant_fp8(x, None, None, None, res, mode != "input_first", w, 1e-5,
-                                                     want_out=True)
+                                                     want_out=True, static_scale=st)
     assert torch.equal(res, ref_res)
     assert torch.equal(out, ref_y)
     assert torch.equal(s, ref_s)
@@ -1404,13 +1411,17 @@ def test_fused_add_rms_norm_quant_fp8(ops, dtype, tokens, hidden, mode):
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("tokens,d", [(1, 512), (32, 14336), (7, 28672), (64, 1024), (3, 8)])
-def test_silu_and_mul_quant_fp8(ops, dtype, tokens, d):
+@pytest.mark.parametrize("scheme", ["dynamic", "static"])
+def test_silu_and_mul_quant_fp8(ops, dtype, tokens, d, scheme):
     rng = np.random.default_rng(tokens + d)
     x = t(rng.standard_normal((tokens, 2 * d)).astype(np.float32) * 2, dtype)
+    st = t(np.array([2.5 / 448.0], np.float32)) if scheme == "static" else None
     act = torch.empty(tokens, d, dtype=dtype, device=DEV)
     ops.silu_and_mul(act, x)
-    ref_q, ref_s = ops.scaled_fp8_quant(act, None, use_per_token_if_dynamic=True)
-    q, s, out = ops.silu_and_mul_quant_fp8(x, want_out=True)
+    ref_q, ref_s = ops.scaled_fp8_quant(act, st, use_per_token_if_dynamic=True)
+    if st is not None:
+        ref_s = st.reshape(1, 1).expand(tokens, 1)
+    q, s, out = ops.silu_and_mul_quant_fp8(x, want_out=True, static_scale=st)
     assert torch.equal(out, act)
     assert torch.equal(s, ref_s)
     assert torch.equal(q.view(torch.uint8), ref_q.view(torch.uint8))
@@ -1419,14 +1430,21 @@ def test_silu_and_mul_quant_fp8(ops, dtype, tokens, d):
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("strategy", ["channel", "tensor"])
 @pytest.mark.parametrize("kv_cache_dtype", ["auto", "fp8"])
-def test_fused_decode_fp8_model_matches_unfused(ops, dtype, strategy, kv_cache_dtype):
+@pytest.mark.parametrize("scheme", ["dynamic", "static"])
+def test_fused_decode_fp8_model_matches_unfused(ops, dtype, strategy, kv_cache_dtype, scheme):
     """Whole decode step of the compressed-tensors W8A8-FP8 model: the fused path reproduces the
-    op-by-op path bit for bit (hidden states and every layer's KV-cache writes)."""
+    op-by-op path bit for bit (hidden states and every layer's KV-cache writes) -- dynamic per-token activation
+    scales, or the checkpoint's static per-tensor input_scale."""
     from aphrodite_engine_amd import model as M
     from aphrodite_engine_amd.quantization.fp8 import CompressedTensorsW8A8Fp8Config
     with torch.no_grad():
-        m = M.LlamaForCausalLM(M.TINY, CompressedTensorsW8A8Fp8Config(strategy), dtype, kv_cache_dtype)
+        m = M.LlamaForCausalLM(M.TINY, CompressedTensorsW8A8Fp8Config(strategy, is_static_input_scheme=scheme == "static"),
+                               dtype, kv_cache_dtype)
         m.init_synthetic(torch.device(DEV))
+        if scheme == "static":
+            for li, layer in enumerate(m.layers):
+                for j, lin_ in enumerate(layer.linears()):
+                    lin_.input_scale.fill_((3.0 + j + 0.5 * li) / 448.0)
         meta, pos, nblocks = M.make_decode_metadata(5, [3, 17, 64, 200, 129], 16, DEV)
         ids = torch.randint(0, M.TINY.vocab_size, (5, ), device=DEV)
         outs, caches_all = [], []
