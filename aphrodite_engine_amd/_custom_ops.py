@@ -42,6 +42,13 @@ def _dt(t: torch.Tensor) -> int:
         raise RuntimeError(f"Unsupported dtype {t.dtype}") from None
 
 
+def _dt_of(dtype: torch.dtype) -> int:
+    try:
+        return _DT[dtype]
+    except KeyError:
+        raise RuntimeError(f"Unsupported dtype {dtype}") from None
+
+
 def _kv(kv_cache_dtype: str) -> int:
     try:
         return _KV[kv_cache_dtype]
@@ -1164,6 +1171,33 @@ def scaled_mm_fp8_slabs(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     return slabs
 
 
+def fp8_gemm_silu_quant_supported(m: int, n: int, k: int) -> bool:
+    return bool(_lib.lib().aphro_fp8_gemm_stream_silu_supported(m, n, k))
+
+
+def fp8_gemm_silu_quant(a: torch.Tensor, b: torch.Tensor, scale_a: torch.Tensor, scale_b: torch.Tensor,
+                        static_scale: torch.Tensor, dtype: torch.dtype, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """gate_up GEMM + SiluAndMul + static fp8 quant in one launch: a fp8 [M, K], b fp8 [K, N] column-major
+    (gate_up weight.t()); returns e4m3 [M, N / 2] = static_scaled_fp8_quant(silu_and_mul(cutlass_scaled_mm(a, b, ...)),
+    static_scale), bit for bit, with ``dtype`` the dtype the two intermediate tensors would have had."""
+    m, k = a.shape
+    n = b.shape[1]
+    if b.stride(0) != 1 or b.stride(1) != k or not a.is_contiguous():
+        raise RuntimeError("fp8_gemm_silu_quant: a [M, K] contiguous and b column-major [K, N] (weight.t()) expected")
+    check_fp8_buffer(a, "fp8_gemm_silu_quant")
+    check_fp8_buffer(b, "fp8_gemm_silu_quant")
+    _check_static_scale(static_scale, a.device)
+    q = torch.empty((m, n // 2), dtype=FP8_DTYPE, device=a.device)
+    sa = scale_a.to(torch.float32).contiguous()
+    sb = scale_b.to(torch.float32).contiguous()
+    if bias is not None and (bias.dtype != dtype or bias.numel() != n):
+        raise RuntimeError("fp8_gemm_silu_quant: bias must be [N] in the activation dtype")
+    check(_lib.lib().aphro_fp8_gemm_stream_silu_quant(
+        a.data_ptr(), k, b.data_ptr(), sa.data_ptr(), sb.data_ptr(), _ptr(bias), q.data_ptr(), static_scale.data_ptr(),
+        m, n, k, 1 if sa.numel() > 1 else 0, 1 if sb.numel() > 1 else 0, _dt_of(dtype), _stream()), "fp8_gemm_silu_quant")
+    return q
+
+
 def _check_static_scale(static_scale: Optional[torch.Tensor], dev) -> None:
     if static_scale is not None and (static_scale.dtype != torch.float32 or static_scale.numel() != 1
                                      or static_scale.device.type != torch.device(dev).type):
@@ -1221,15 +1255,31 @@ def paged_attention_rope_scaled(qkv_slabs: torch.Tensor, slab_row_scale: Optiona
                                 value_cache: torch.Tensor, num_heads: int, num_kv_heads: int, scale: float,
                                 block_tables: torch.Tensor, seq_lens: torch.Tensor, block_size: int,
                                 max_seq_len: int, alibi_slopes: Optional[torch.Tensor], kv_cache_dtype: str,
-                                k_scale: float, v_scale: float) -> torch.Tensor:
+                                k_scale: float, v_scale: float,
+                                out_q8_scale: Optional[torch.Tensor] = None, want_out: bool = True):
     """paged_attention_rope_packed over the raw slabs of an FP8 qkv projection (dequantised on the
-    fly); returns the attention output [S, Hq, hd] row-major in the activation dtype."""
+    fly); returns the attention output [S, Hq, hd] row-major in the activation dtype.
+    ``out_q8_scale`` (fp32 [1]: the static input_scale of an FP8 o_proj): returns (out or None, out_q8) with out_q8 the
+    e4m3 [S, Hq * hd] static_scaled_fp8_quant would produce from out -- written by the attention launch itself."""
     lib = _lib.lib()
     nslab, num_seqs, ntot = qkv_slabs.shape
     head_size = ntot // (num_heads + 2 * num_kv_heads)
-    out = torch.empty((num_seqs, num_heads, head_size), dtype=cos_sin_cache.dtype, device=qkv_slabs.device)
     if positions is not None and positions.dtype != torch.int64:
         positions = positions.long()
+    if out_q8_scale is not None:
+        _check_static_scale(out_q8_scale, qkv_slabs.device)
+        out = torch.empty((num_seqs, num_heads, head_size), dtype=cos_sin_cache.dtype, device=qkv_slabs.device) \
+            if want_out else None
+        out_q8 = torch.empty((num_seqs, num_heads * head_size), dtype=FP8_DTYPE, device=qkv_slabs.device)
+        check(lib.aphro_paged_attention_rope_scaled_q8(
+            _ptr(out), out_q8.data_ptr(), out_q8_scale.data_ptr(), qkv_slabs.data_ptr(), nslab, _ptr(slab_row_scale),
+            slab_col_scale.data_ptr(), _ptr(positions), cos_sin_cache.data_ptr(), slot_mapping.data_ptr(),
+            key_cache.data_ptr(), value_cache.data_ptr(), num_seqs, num_heads, num_kv_heads, head_size, float(scale),
+            block_tables.data_ptr(), seq_lens.data_ptr(), block_tables.stride(0), block_size, int(max_seq_len),
+            _ptr(alibi_slopes), key_cache.stride(0), key_cache.stride(1), _dt(cos_sin_cache), _kv(kv_cache_dtype),
+            float(k_scale), float(v_scale), _stream()), "paged_attention_rope_scaled_q8")
+        return out, out_q8
+    out = torch.empty((num_seqs, num_heads, head_size), dtype=cos_sin_cache.dtype, device=qkv_slabs.device)
     check(lib.aphro_paged_attention_rope_packed_scaled(
         out.data_ptr(), None, qkv_slabs.data_ptr(), nslab, _ptr(slab_row_scale), slab_col_scale.data_ptr(),
         _ptr(positions), cos_sin_cache.data_ptr(), slot_mapping.data_ptr(), key_cache.data_ptr(),

@@ -40,6 +40,8 @@ SIGNATURES = {
     "aphro_silu_and_mul_quant_fp8_static": (I, [P, P, P, P, L, I, I, P, P]),
     "aphro_paged_attention_rope_packed_scaled": (I, [P, P, P, I, P, P, P, P, P, P, P, I, I, I, I, F, P, P,
                                                      I, I, I, P, L, L, I, I, F, F, P]),
+    "aphro_paged_attention_rope_scaled_q8": (I, [P, P, P, P, I, P, P, P, P, P, P, P, I, I, I, I, F, P, P,
+                                                 I, I, I, P, L, L, I, I, F, F, P]),
     "aphro_sample_top_k_top_p": (I, [P, P, L, P, P, P, P, P, L, P, P, L, L, I, P]),
     "aphro_custom_ar_meta_size": (L, []),
     "aphro_ipc_handle_bytes": (I, []),
@@ -95,6 +97,8 @@ SIGNATURES = {
     "aphro_fused_add_rms_norm_pack_combine": (I, [P, I, L, P, P, I, P, I, P, F, P, P, L, I, I, P]),
     "aphro_fp8_gemm_stream_ksplit": (I, [L, L, L]),
     "aphro_fp8_gemm_stream": (I, [P, L, P, P, P, P, P, P, Z, L, L, L, I, I, I, P]),
+    "aphro_fp8_gemm_stream_silu_supported": (I, [L, L, L]),
+    "aphro_fp8_gemm_stream_silu_quant": (I, [P, L, P, P, P, P, P, P, L, L, L, I, I, I, P]),
     "aphro_gptq_dequant_bits": (I, [P, P, P, P, P, L, L, L, I, I, P]),
     "aphro_gptq_gemm_bits_supported": (I, [L, L, L, L, I]),
     "aphro_gptq_gemm_bits": (I, [P, L, P, P, P, P, L, L, L, L, I, I, P]),

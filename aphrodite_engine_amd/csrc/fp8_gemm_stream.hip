@@ -14,6 +14,12 @@
 //     asm, an LDS-only workgroup barrier per tile (see lm_head.hip);
 //   * K reduction over the waves through LDS once per tile, epilogue in the reference's order sa * (sb * acc) (+ bias).
 //     Shapes whose K does not fit one workgroup's 8 x 8 segments are K-sliced over grid.y: raw slabs only.
+//   * SILU form (gate_up of an FP8 MLP whose down_proj has a STATIC input scale): a 16-row tile is 8 gate rows and the 8 up
+//     rows of the same features (the two 8-row staging instructions of a segment simply start N/2 rows apart), so the
+//     finishing threads of a tile hold gate and up of a feature 8 lanes apart: out = T(sa (sb acc)) per half as the GEMM
+//     would store it, SiluAndMul in T, fp8(x * (1 / scale)) -- the bits of cutlass_scaled_mm + silu_and_mul +
+//     static_scaled_fp8_quant (activation_kernels.cu:12-75, fp8/common.cu:187-199) without the [M, N] round trip and
+//     two launches.
 #include <utility>
 
 #include "common.h"
@@ -31,6 +37,8 @@ struct Fp8StreamParams {
   int M, N, K, lda;
   int a_per_token, b_per_channel;
   int tiles;              // N / 16
+  uint8_t* q_out;         // SILU form: e4m3 [M, N / 2]
+  const float* q_scale;   // SILU form: the static scale of q_out ([1])
 };
 
 typedef __attribute__((address_space(3))) void* f8s_lds_ptr;
@@ -46,7 +54,7 @@ __device__ __forceinline__ void f8s_static_for(F&& f) {
 __device__ __forceinline__ void f8s_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // KS: 128-k segments per wave and K slice (K = gridDim.y x 8 waves x KS x 128).  MT: 16-token tiles.
-template <typename T, int MT, int KS>
+template <typename T, int MT, int KS, bool SILU = false>
 __global__ __launch_bounds__(512, 1) void fp8_gemm_stream_kernel(Fp8StreamParams p) {
   constexpr int NWV = 8;
   constexpr int SEGB = 16 * 128;                    // one staged segment: [16 rows][8 chunks of 16 k]
@@ -83,7 +91,9 @@ __global__ __launch_bounds__(512, 1) void fp8_gemm_stream_kernel(Fp8StreamParams
 #pragma unroll
   for (int it = 0; it < 2; ++it) {
     const int srow = 8 * it + (lane >> 3);
-    voff_w[it] = srow * p.K + (((lane & 7) ^ ((srow >> 1) & 7)) << 4);
+    // global row of slot row srow: tile * 16 + srow, or (SILU) tile * 8 + lane / 8 of the gate (it 0) / up (it 1) half
+    const int grow = SILU ? (it == 1 ? (p.N >> 1) : 0) + (lane >> 3) : srow;
+    voff_w[it] = grow * p.K + (((lane & 7) ^ ((srow >> 1) & 7)) << 4);
   }
   // B fragment of k-step u: row c, bytes 32 u + 8 g .. + 8 of the segment = chunk 2 u + g / 2, half g % 2
   uint32_t rd[4];
@@ -96,7 +106,7 @@ __global__ __launch_bounds__(512, 1) void fp8_gemm_stream_kernel(Fp8StreamParams
   const int Q = ntile * KS;
   auto stage = [&](int q) {                         // segment q -> its slot (q < Q)
     const int tile = (int)blockIdx.x + (q / KS) * G, s = q % KS;
-    const int so = tile * 16 * p.K + kseg(s);
+    const int so = tile * (SILU ? 8 : 16) * p.K + kseg(s);
     unsigned char* dst = ring + (q % R) * SEGB;
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
@@ -105,6 +115,11 @@ __global__ __launch_bounds__(512, 1) void fp8_gemm_stream_kernel(Fp8StreamParams
     }
   };
   const int tok = tid >> 4, col = tid & 15;
+  float q_inv = 0.f;                                // SILU form: fetched once, ahead of the ring (byte stores may alias it)
+  if constexpr (SILU) {
+    q_inv = 1.0f / *(const volatile float*)p.q_scale;
+    asm volatile("" : "+v"(q_inv));                 // (computed here: not sunk into the first tile's epilogue)
+  }
 
   __builtin_amdgcn_sched_barrier(0);
   for (int q = 0; q < R && q < Q; ++q) stage(q);
@@ -158,6 +173,20 @@ __global__ __launch_bounds__(512, 1) void fp8_gemm_stream_kernel(Fp8StreamParams
       float sum = red[tok * RP + col];
 #pragma unroll
       for (int w2 = 1; w2 < NWV; ++w2) sum += red[(w2 * 16 * MT + tok) * RP + col];
+      if constexpr (SILU) {
+        const int n = (col < 8 ? 0 : (p.N >> 1)) + tile * 8 + (col & 7);
+        const float sa = p.a_scales ? p.a_scales[p.a_per_token ? tok : 0] : 1.f;
+        const float sb = p.b_scales ? p.b_scales[p.b_per_channel ? n : 0] : 1.f;
+        float o = sa * (sb * sum);
+        if (p.bias) o += T::to_f32(((const typename T::storage*)p.bias)[n]);
+        const float mine = T::to_f32(T::from_f32(o));           // what the GEMM would have stored
+        const float other = __shfl_xor(mine, 8, 64);            // col < 8: up of the same feature
+        if (col < 8) {
+          const float act = T::to_f32(silu_mul_bits<T>(mine, other));
+          const float qv = __builtin_fmaxf(-448.f, __builtin_fminf(act * q_inv, 448.f));
+          p.q_out[(size_t)tok * (p.N >> 1) + tile * 8 + col] = (uint8_t)(__builtin_amdgcn_cvt_pk_fp8_f32(qv, qv, 0, false) & 0xff);
+        }
+      } else {
       const int n = tile * 16 + col;
       if (p.slab) {
         p.slab[((size_t)ky * p.M + tok) * p.N + n] = sum;
@@ -167,6 +196,7 @@ __global__ __launch_bounds__(512, 1) void fp8_gemm_stream_kernel(Fp8StreamParams
         float o = sa * (sb * sum);                  // order of test_cutlass.py:43
         if (p.bias) o += T::to_f32(((const typename T::storage*)p.bias)[n]);
         ((typename T::storage*)p.c)[(size_t)tok * p.N + n] = T::from_f32(o);
+      }
       }
     }
     f8s_lds_barrier();
@@ -211,6 +241,7 @@ extern "C" int aphro_fp8_gemm_stream(const void* a, int64_t lda, const void* w, 
   p.a = (const uint8_t*)a; p.w = (const uint8_t*)w; p.a_scales = a_scales; p.b_scales = b_scales; p.bias = bias;
   p.c = out; p.slab = slabs; p.M = (int)M; p.N = (int)N; p.K = (int)K; p.lda = (int)lda;
   p.a_per_token = a_scale_per_token; p.b_per_channel = b_scale_per_channel; p.tiles = (int)(N / 16);
+  p.q_out = nullptr; p.q_scale = nullptr;
   const int ks = (int)(K / 128) / 8 / split, mt = M > 16 ? 2 : 1;
   int gx = device_cu_count() / split;
   if (gx < 1) gx = 1;
@@ -222,6 +253,61 @@ extern "C" int aphro_fp8_gemm_stream(const void* a, int64_t lda, const void* w, 
     auto kern = fp8_gemm_stream_kernel<TT, MTV, KSV>;                                                              \
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { \
       set_error("fp8_gemm_stream: cannot raise the dynamic LDS limit to %zu", lds);                                \
+      return APHRO_ERR_LAUNCH;                                                                                     \
+    }                                                                                                              \
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, (hipStream_t)stream, p);                                        \
+  }
+#define LK(TT, MTV)                                   \
+  switch (ks) {                                       \
+    case 1: L(TT, MTV, 1) break;                      \
+    case 2: L(TT, MTV, 2) break;                      \
+    case 3: L(TT, MTV, 3) break;                      \
+    case 4: L(TT, MTV, 4) break;                      \
+    case 5: L(TT, MTV, 5) break;                      \
+    case 6: L(TT, MTV, 6) break;                      \
+    case 7: L(TT, MTV, 7) break;                      \
+    default: L(TT, MTV, 8) break;                     \
+  }
+  if (dtype == APHRO_F16) { if (mt == 2) LK(Half, 2) else LK(Half, 1) }
+  else { if (mt == 2) LK(BFloat, 2) else LK(BFloat, 1) }
+#undef LK
+#undef L
+  APHRO_LAUNCH_CHECK();
+  return APHRO_OK;
+}
+
+// gate_up + SiluAndMul + static fp8 quantisation in ONE launch: w = [gate rows | up rows] ([N, K], N even halves),
+// q_out e4m3 [M, N / 2] = fp8(T(silu(T(gate)) * T(up)) * (1 / *q_scale)), T = `dtype` (the model's activation dtype).
+// Served when aphro_fp8_gemm_stream_silu_supported: K fits one workgroup, N % 32 == 0, N / 16 >= 4 x CUs.
+extern "C" int aphro_fp8_gemm_stream_silu_supported(int64_t M, int64_t N, int64_t K) {
+  return N % 32 == 0 && aphro_fp8_gemm_stream_ksplit(M, N, K) == 1;
+}
+
+extern "C" int aphro_fp8_gemm_stream_silu_quant(const void* a, int64_t lda, const void* w, const float* a_scales,
+                                                const float* b_scales, const void* bias, void* q_out,
+                                                const float* q_scale, int64_t M, int64_t N, int64_t K,
+                                                int a_scale_per_token, int b_scale_per_channel, int dtype,
+                                                void* stream) {
+  APHRO_CHECK(aphro_fp8_gemm_stream_silu_supported(M, N, K), "fp8_gemm_stream_silu_quant: M=%ld N=%ld K=%ld is not served",
+              (long)M, (long)N, (long)K);
+  APHRO_CHECK(dtype == APHRO_F16 || dtype == APHRO_BF16, "fp8_gemm_stream_silu_quant: dtype must be f16 or bf16");
+  APHRO_CHECK(q_out != nullptr && q_scale != nullptr, "fp8_gemm_stream_silu_quant: output / scale missing");
+  APHRO_CHECK(((uintptr_t)a % 8) == 0 && ((uintptr_t)w % 16) == 0 && lda % 8 == 0 && lda >= K, "fp8_gemm_stream_silu_quant: alignment");
+  Fp8StreamParams p;
+  p.a = (const uint8_t*)a; p.w = (const uint8_t*)w; p.a_scales = a_scales; p.b_scales = b_scales; p.bias = bias;
+  p.c = nullptr; p.slab = nullptr; p.M = (int)M; p.N = (int)N; p.K = (int)K; p.lda = (int)lda;
+  p.a_per_token = a_scale_per_token; p.b_per_channel = b_scale_per_channel; p.tiles = (int)(N / 16);
+  p.q_out = (uint8_t*)q_out; p.q_scale = q_scale;
+  const int ks = (int)(K / 128) / 8, mt = M > 16 ? 2 : 1;
+  int gx = device_cu_count();
+  if (gx > p.tiles) gx = p.tiles;
+  const size_t lds = (size_t)8 * 8 * 2048 + (size_t)8 * 16 * mt * 17 * sizeof(float);
+  dim3 grid((unsigned)gx, 1);
+#define L(TT, MTV, KSV)                                                                                            \
+  {                                                                                                                \
+    auto kern = fp8_gemm_stream_kernel<TT, MTV, KSV, true>;                                                        \
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { \
+      set_error("fp8_gemm_stream_silu_quant: cannot raise the dynamic LDS limit to %zu", lds);                     \
       return APHRO_ERR_LAUNCH;                                                                                     \
     }                                                                                                              \
     hipLaunchKernelGGL(kern, grid, dim3(512), lds, (hipStream_t)stream, p);                                        \

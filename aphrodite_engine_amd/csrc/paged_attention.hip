@@ -47,6 +47,10 @@ struct PAParams {
   int write_direct;    // 1: write `out` (single partition) ; 0: write scratch
   void* out_packed;    // optional fragment-major f16 copy of out for the o_proj GEMM (see wna16_gemm.hip)
   int pack_mtiles;     // ceil(num_seqs / 16)
+  // optional e4m3 copy of out for an FP8 o_proj with a STATIC input scale: fp8(T(out) * (1 / *out_q8_scale)), the bits
+  // static_scaled_fp8_quant (fp8/common.cu:187-199) produces from `out`
+  uint8_t* out_q8;
+  const float* out_q8_scale;
   float scale;         // softmax scale * k_scale
   float v_scale;
   int64_t q_stride, kv_block_stride, kv_head_stride;
@@ -177,6 +181,13 @@ __global__ __launch_bounds__(NW * 64) void paged_attention_kernel(PAParams p) {
   const int gqa = p.num_heads / p.num_kv_heads;
   constexpr bool split = SPLIT;
   const int seq_len = p.seq_lens[seq];       // (a template parameter: the unsplit instantiations keep their register budget)
+  // fp8 copy of the output (scaled-slab form only): the scale is fetched HERE, a whole kernel ahead of its use -- at the
+  // store it would be a serial global load (and a reload after every byte store, which may alias it)
+  float q8_inv = 0.f;
+  if constexpr (ROPE == 2) {
+    if (p.out_q8) q8_inv = 1.0f / *(const volatile float*)p.out_q8_scale;
+    asm volatile("" : "+v"(q8_inv));
+  }
   // split form: equal runs of 32-token pairs per workgroup of the (sequence, kv-head) group
   const int split_pp = split ? (((seq_len + 31) >> 5) + p.nsplit - 1) / p.nsplit : 0;
   const int psz = split ? max(split_pp, 1) * 32 : (p.partition_size > 0 ? p.partition_size : 0x7fffffe0);
@@ -722,6 +733,12 @@ __global__ __launch_bounds__(NW * 64) void paged_attention_kernel(PAParams p) {
           else h16 = bf16_bits_to_f16_bits_sat(r16);
           ((uint16_t*)p.out_packed)[chunk + (k & 7)] = h16;
         }
+        if constexpr (ROPE == 2) {
+          if (p.out_q8) {
+            const float qv = __builtin_fmaxf(-448.f, __builtin_fminf(T::to_f32(r16) * q8_inv, 448.f));
+            p.out_q8[((size_t)seq * p.num_heads + qh) * HD + d] = (uint8_t)(__builtin_amdgcn_cvt_pk_fp8_f32(qv, qv, 0, false) & 0xff);
+          }
+        }
       } else {
         const size_t pi = ((size_t)seq * p.num_heads + qh) * p.max_parts + part;
         ((typename T::storage*)p.tmp_out)[pi * HD + d] = T::from_f32(res);
@@ -929,7 +946,8 @@ static int paged_attention_impl(void* out, void* out_packed, float* exp_sums, fl
                                      const float* qkv_slabs = nullptr, int nslab = 0,
                                      const int64_t* positions = nullptr, const void* cos_sin = nullptr,
                                      const int64_t* slot_mapping = nullptr, const float* slab_row_scale = nullptr,
-                                     const float* slab_col_scale = nullptr) {
+                                     const float* slab_col_scale = nullptr, void* out_q8 = nullptr,
+                                     const float* out_q8_scale = nullptr) {
   hipStream_t st = (hipStream_t)stream;
   APHRO_CHECK(dtype == APHRO_F16 || dtype == APHRO_BF16, "paged_attention: query dtype must be f16 or bf16");
   APHRO_CHECK(kv_dtype >= APHRO_KV_AUTO && kv_dtype <= APHRO_KV_FP8_E5M2, "Unsupported data type of kv cache: %d", kv_dtype);
@@ -953,6 +971,9 @@ static int paged_attention_impl(void* out, void* out_packed, float* exp_sums, fl
   p.out_packed = out_packed; p.pack_mtiles = (num_seqs + 15) / 16;
   APHRO_CHECK(out_packed == nullptr || (partition_size == 0 && ((int64_t)num_heads * head_size) % 128 == 0),
               "paged_attention: packed output needs the single-kernel (v1) form and Hq*hd %% 128 == 0");
+  p.out_q8 = (uint8_t*)out_q8; p.out_q8_scale = out_q8_scale;
+  APHRO_CHECK(out_q8 == nullptr || (partition_size == 0 && out_q8_scale != nullptr && qkv_slabs != nullptr && slab_col_scale != nullptr),
+              "paged_attention: the fp8 output needs the fused scaled-slab form and its scale");
   p.out = out; p.exp_sums = exp_sums; p.max_logits = max_logits; p.tmp_out = tmp_out;
   p.q = query; p.kc = key_cache; p.vc = value_cache;
   p.block_tables = block_tables; p.seq_lens = seq_lens; p.alibi = alibi_slopes;
@@ -1101,6 +1122,29 @@ extern "C" int aphro_paged_attention_rope_packed_scaled(void* out, void* out_pac
                               max_num_blocks_per_seq, block_size, max_seq_len, alibi_slopes, 0, kv_block_stride,
                               kv_head_stride, dtype, kv_dtype, k_scale, v_scale, 0, stream, qkv_slabs, nslab,
                               positions, cos_sin_cache, slot_mapping, slab_row_scale, slab_col_scale);
+}
+
+// ... and the output ALSO (or only: out may be NULL) as e4m3 with a static per-tensor scale for an FP8 o_proj whose
+// checkpoint carries input_scale: out_q8[seq, head, d] = fp8(T(out) * (1 / *out_q8_scale)) -- static_scaled_fp8_quant's
+// bits, without its launch.
+extern "C" int aphro_paged_attention_rope_scaled_q8(void* out, void* out_q8, const float* out_q8_scale,
+                                                    const float* qkv_slabs, int nslab, const float* slab_row_scale,
+                                                    const float* slab_col_scale, const int64_t* positions,
+                                                    const void* cos_sin_cache, const int64_t* slot_mapping,
+                                                    void* key_cache, void* value_cache, int num_seqs, int num_heads,
+                                                    int num_kv_heads, int head_size, float scale,
+                                                    const int32_t* block_tables, const int32_t* seq_lens,
+                                                    int max_num_blocks_per_seq, int block_size, int max_seq_len,
+                                                    const float* alibi_slopes, int64_t kv_block_stride,
+                                                    int64_t kv_head_stride, int dtype, int kv_dtype, float k_scale,
+                                                    float v_scale, void* stream) {
+  APHRO_CHECK(qkv_slabs != nullptr && slab_col_scale != nullptr && out_q8 != nullptr && out_q8_scale != nullptr,
+              "paged_attention_rope_scaled_q8: NULL slabs / scales / output");
+  return paged_attention_impl(out, nullptr, nullptr, nullptr, nullptr, nullptr, key_cache, value_cache, num_seqs,
+                              num_heads, num_kv_heads, head_size, scale, block_tables, seq_lens,
+                              max_num_blocks_per_seq, block_size, max_seq_len, alibi_slopes, 0, kv_block_stride,
+                              kv_head_stride, dtype, kv_dtype, k_scale, v_scale, 0, stream, qkv_slabs, nslab, positions,
+                              cos_sin_cache, slot_mapping, slab_row_scale, slab_col_scale, out_q8, out_q8_scale);
 }
 
 extern "C" int aphro_reshape_and_cache(const void* key, const void* value, void* key_cache,

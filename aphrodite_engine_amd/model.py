@@ -432,16 +432,26 @@ class LlamaDecoderLayer(nn.Module):
         qkv_slabs = ops.scaled_mm_fp8_slabs(qx, self.qkv_proj.weight)
         from .attention.paged_attn import PagedAttention
         key_cache, value_cache = PagedAttention.split_kv_cache(kv_cache, self.num_kv_heads, self.head_dim)
-        attn_out = ops.paged_attention_rope_scaled(
+        # static scheme: the attention launch writes the o_proj input as e4m3 itself, and gate_up + SiluAndMul + the
+        # down_proj input quantisation are one launch where the streaming kernel tiles the shape (7 launches per layer)
+        fuse_static = s_o is not None and not os.environ.get("APHRO_FP8_NO_STATIC_FUSION")
+        attn_res = ops.paged_attention_rope_scaled(
             qkv_slabs, sx, self._channel_scale(self.qkv_proj),
             None if cos_sin_tok is not None else positions,
             cos_sin_tok if cos_sin_tok is not None else cos_sin, attn_metadata.slot_mapping,
             key_cache, value_cache, self.num_heads, self.num_kv_heads, self.attn.scale,
             attn_metadata.block_tables, attn_metadata.seq_lens_tensor, value_cache.shape[3],
-            attn_metadata.max_decode_seq_len, None, self.attn.kv_cache_dtype, self.k_scale, self.v_scale)
-        qa, sa = ops.scaled_fp8_quant(attn_out.view(m, self.q_size), s_o, use_per_token_if_dynamic=True)
+            attn_metadata.max_decode_seq_len, None, self.attn.kv_cache_dtype, self.k_scale, self.v_scale,
+            out_q8_scale=s_o if fuse_static else None, want_out=False)
+        if fuse_static:
+            qa, sa = attn_res[1], s_o
+            act_dtype = cos_sin.dtype if cos_sin_tok is None else cos_sin_tok.dtype
+        else:
+            attn_out = attn_res
+            act_dtype = attn_out.dtype
+            qa, sa = ops.scaled_fp8_quant(attn_out.view(m, self.q_size), s_o, use_per_token_if_dynamic=True)
         if self.tp > 1:
-            o = ops.cutlass_scaled_mm(qa, self.o_proj.weight, out_dtype=attn_out.dtype, scale_a=sa,
+            o = ops.cutlass_scaled_mm(qa, self.o_proj.weight, out_dtype=act_dtype, scale_a=sa,
                                       scale_b=self.o_proj.weight_scale)
             o = tensor_model_parallel_all_reduce(o)
             qh, sh, _ = ops.fused_add_rms_norm_quant_fp8(o, None, None, None, residual, True,
@@ -450,11 +460,16 @@ class LlamaDecoderLayer(nn.Module):
             o_slabs = ops.scaled_mm_fp8_slabs(qa, self.o_proj.weight)
             qh, sh, _ = ops.fused_add_rms_norm_quant_fp8(None, o_slabs, sa, self.o_proj.weight_scale, residual,
                                                          True, self.post_attention_layernorm, eps, static_scale=s_gu)
-        gate_up = ops.cutlass_scaled_mm(qh, self.gate_up_proj.weight, out_dtype=attn_out.dtype, scale_a=sh,
-                                        scale_b=self.gate_up_proj.weight_scale)
-        qd, sd, _ = ops.silu_and_mul_quant_fp8(gate_up, static_scale=s_dn)
+        if fuse_static and ops.fp8_gemm_silu_quant_supported(m, self.gate_up_proj.out_features,
+                                                             self.gate_up_proj.in_features):
+            qd = ops.fp8_gemm_silu_quant(qh, self.gate_up_proj.weight, sh, self.gate_up_proj.weight_scale, s_dn, act_dtype)
+            sd = s_dn
+        else:
+            gate_up = ops.cutlass_scaled_mm(qh, self.gate_up_proj.weight, out_dtype=act_dtype, scale_a=sh,
+                                            scale_b=self.gate_up_proj.weight_scale)
+            qd, sd, _ = ops.silu_and_mul_quant_fp8(gate_up, static_scale=s_dn)
         if self.tp > 1:
-            d = ops.cutlass_scaled_mm(qd, self.down_proj.weight, out_dtype=attn_out.dtype, scale_a=sd,
+            d = ops.cutlass_scaled_mm(qd, self.down_proj.weight, out_dtype=act_dtype, scale_a=sd,
                                       scale_b=self.down_proj.weight_scale)
             return tensor_model_parallel_all_reduce(d), None
         return None, (ops.scaled_mm_fp8_slabs(qd, self.down_proj.weight), sd, self.down_proj.weight_scale)

@@ -477,6 +477,20 @@ int aphro_paged_attention_rope_packed_scaled(void* out, void* out_packed, const 
                                              const float* alibi_slopes, int64_t kv_block_stride,
                                              int64_t kv_head_stride, int dtype, int kv_dtype,
                                              float k_scale, float v_scale, void* stream);
+/* ... with the output ALSO (or only: out may be NULL) as e4m3 under a static per-tensor scale, for an FP8 o_proj whose
+ * checkpoint carries input_scale: out_q8[seq, head, d] = fp8(T(out) * (1 / *out_q8_scale)) -- the bits of
+ * static_scaled_fp8_quant (fp8/common.cu:187-199) over `out`, without its launch. */
+int aphro_paged_attention_rope_scaled_q8(void* out, void* out_q8, const float* out_q8_scale,
+                                         const float* qkv_slabs, int nslab, const float* slab_row_scale,
+                                         const float* slab_col_scale, const int64_t* positions,
+                                         const void* cos_sin_cache, const int64_t* slot_mapping,
+                                         void* key_cache, void* value_cache, int num_seqs, int num_heads,
+                                         int num_kv_heads, int head_size, float scale,
+                                         const int32_t* block_tables, const int32_t* seq_lens,
+                                         int max_num_blocks_per_seq, int block_size, int max_seq_len,
+                                         const float* alibi_slopes, int64_t kv_block_stride,
+                                         int64_t kv_head_stride, int dtype, int kv_dtype, float k_scale,
+                                         float v_scale, void* stream);
 
 /* ------------------------------------------------------------------------
  * Random sampling inside the decode graph: temperature -> top-k -> top-p -> softmax
@@ -738,6 +752,15 @@ int aphro_fp8_gemm_stream_ksplit(int64_t M, int64_t N, int64_t K);
 int aphro_fp8_gemm_stream(const void* a, int64_t lda, const void* w, const float* a_scales, const float* b_scales,
                           const void* bias, void* out, float* slabs, size_t slabs_bytes, int64_t M, int64_t N, int64_t K,
                           int a_scale_per_token, int b_scale_per_channel, int dtype, void* stream);
+/* gate_up of an FP8 MLP + SiluAndMul + static fp8 quantisation in ONE launch: w = [gate rows | up rows] ([N, K]);
+ * q_out e4m3 [M, N / 2] = fp8(T(silu(T(gate)) * T(up)) * (1 / *q_scale)) with T = dtype -- the bits of cutlass_scaled_mm
+ * -> silu_and_mul (activation_kernels.cu:12-75) -> static_scaled_fp8_quant (fp8/common.cu:187-199).
+ * aphro_fp8_gemm_stream_silu_supported: 1 when the shape is served (N % 32 == 0 and aphro_fp8_gemm_stream_ksplit == 1). */
+int aphro_fp8_gemm_stream_silu_supported(int64_t M, int64_t N, int64_t K);
+int aphro_fp8_gemm_stream_silu_quant(const void* a, int64_t lda, const void* w, const float* a_scales,
+                                     const float* b_scales, const void* bias, void* q_out, const float* q_scale,
+                                     int64_t M, int64_t N, int64_t K, int a_scale_per_token, int b_scale_per_channel,
+                                     int dtype, void* stream);
 
 /* One grouped FP8 W8A8 GEMM of a mixture-of-experts layer: the reference's Triton fused_moe_kernel with use_fp8_w8a8
  * (aphrodite/modeling/layers/fused_moe/fused_moe.py:20-170; called twice by fused_experts :566-690 for

@@ -2166,6 +2166,47 @@ def test_fp8_gemm_stream_vs_oracle(ops, M, N, K, dtype):
         os.environ.pop("APHRO_FP8_STREAM_ALL")
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [(32, 28672, 4096), (1, 28672, 4096), (19, 28672, 4096), (17, 512, 1024), (32, 1024, 8192)])
+@pytest.mark.parametrize("per_token", [True, False])
+def test_fp8_gemm_silu_quant_matches_op_sequence(ops, M, N, K, dtype, per_token):
+    """gate_up GEMM + SiluAndMul + static fp8 quant in one launch (the streaming kernel's SILU form: 16-row tiles of 8 gate
+    + 8 up rows) against the three ops it replaces -- cutlass_scaled_mm -> silu_and_mul -> scaled_fp8_quant(static): bit
+    for bit (same kernel structure, hence the same sums), and against the oracle's composition within one fp8 step on a
+    bounded fraction of the elements (a half-ulp difference of the T-rounded GEMM output can move a code)."""
+    import os
+    from oracle import fp8 as ofp8
+    from oracle import attention as oa
+    rng = np.random.default_rng(M + N + K)
+    os.environ["APHRO_FP8_STREAM_ALL"] = "1"
+    try:
+        assert ops.fp8_gemm_silu_quant_supported(M, N, K)
+        a = ofp8.fp8_encode((rng.standard_normal((M, K)) * 1.5).astype(np.float32), "e4m3")
+        w = ofp8.fp8_encode((rng.standard_normal((N, K)) * 1.5).astype(np.float32), "e4m3")
+        sa = (rng.random((M, 1)) * 0.02 + 0.01).astype(np.float32) if per_token else np.array([0.017], np.float32)
+        sb = (rng.random((N, )) * 0.02 + 0.01).astype(np.float32)
+        st = t(np.array([1.5 / 448.0], np.float32))                                  # a good part of the rows saturates
+        ad, wd = t(a).view(torch.float8_e4m3fn), t(w).view(torch.float8_e4m3fn)
+        sad, sbd = t(sa), t(sb)
+        gu = ops.cutlass_scaled_mm(ad, wd.t(), sad, sbd, dtype)
+        act = torch.empty(M, N // 2, dtype=dtype, device=DEV)
+        ops.silu_and_mul(act, gu)
+        ref_q, _ = ops.scaled_fp8_quant(act, st)
+        q = ops.fp8_gemm_silu_quant(ad, wd.t(), sad, sbd, st, dtype)
+        assert torch.equal(q.view(torch.uint8), ref_q.view(torch.uint8))
+        # oracle composition
+        to_dt = lambda x: torch.from_numpy(np.asarray(x, dtype=np.float32)).to(dtype).float().numpy()
+        ogu = to_dt(ofp8.scaled_mm(a, w.T, sa, sb))
+        oq = ofp8.static_scaled_fp8_quant(to_dt(oa.silu_and_mul(ogu)), st.item())
+        got = ofp8.fp8_decode(q.view(torch.uint8).cpu().numpy(), "e4m3")
+        want = ofp8.fp8_decode(oq, "e4m3")
+        diff = got != want
+        assert diff.mean() < 0.02, diff.mean()
+        np.testing.assert_allclose(got, want, rtol=0.13, atol=2.0 ** -6)             # one e4m3 step (mantissa 3 bits)
+    finally:
+        os.environ.pop("APHRO_FP8_STREAM_ALL")
+
+
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("T,E,k,renorm", [(1, 8, 2, True), (32, 8, 2, True), (64, 8, 2, False), (33, 16, 4, True), (200, 64, 6, True),
                                           (7, 4, 1, False)])

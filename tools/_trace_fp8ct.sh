@@ -1,8 +1,13 @@
-mkdir -p gpurun_out/fp8ct_trace
-cd /tmp && export TMPDIR=/tmp
-cd $GRAFT_REPO_ROOT
-timeout 280 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/fp8ct_trace/prof -o t -- python bench.py --gpus 1 --steps 20 --warmup 5 --quant fp8ct --kv-cache-dtype fp8 --ctx 8192 --no-cpu-baseline --no-prefill-info --no-ops-path > gpurun_out/fp8ct_trace/line.json 2> gpurun_out/fp8ct_trace/err.txt
-find gpurun_out/fp8ct_trace/prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/fp8ct_trace/kernel_stats.csv
-rm -rf gpurun_out/fp8ct_trace/prof
-head -30 gpurun_out/fp8ct_trace/kernel_stats.csv | cut -c1-200
-tail -3 gpurun_out/fp8ct_trace/err.txt
+# kernel trace of one bench configuration: bash tools/_trace_fp8ct.sh <outdir> <bench args...>
+out=gpurun_out/$1; shift
+mkdir -p $out
+export TMPDIR=/tmp
+timeout 280 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -o t -- python bench.py --gpus 1 --steps 20 --warmup 5 --no-prefill-info --no-ops-path --no-cpu-baseline "$@" > $out/line.json 2> $out/err.txt
+find $out/prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $out/kernel_stats.csv
+rm -rf $out/prof
+python - $out/kernel_stats.csv <<'P'
+import csv, sys
+for r in csv.DictReader(open(sys.argv[1])):
+    if 'aphro' in r['Name']:
+        print(r['Name'][:90].ljust(90), r['Calls'], round(float(r['AverageNs']) / 1e3, 2), r['MinNs'])
+P
