@@ -1,4 +1,4 @@
-# kernel trace of one bench configuration: bash tools/_trace_fp8ct.sh <outdir> <bench args...>
+# kernel trace of one bench configuration: bash tools/trace_bench_kernels.sh <outdir> <bench args...>
 out=gpurun_out/$1; shift
 mkdir -p $out
 export TMPDIR=/tmp
