@@ -388,15 +388,22 @@ class LlamaDecoderLayer(nn.Module):
         (which dequantises with the per-token x per-channel scales), rotary + cache write run
         inside the attention kernel.  The activation scheme -- dynamic per token, or the checkpoint's
         static per-tensor input_scale -- must be the same for the four projections of the layer."""
-        from .quantization.fp8 import CompressedTensorsW8A8Fp8Method
+        from .quantization.fp8 import CompressedTensorsW8A8Fp8Method, CDNA4Fp8LinearMethod
         if m > 64 or self.head_dim != 128 or not self.fuse_rope_attention or self.is_moe:
             return False
         lins = self.linears()
-        static = [lin.input_scale is not None for lin in lins]
+        static = [getattr(lin, "input_scale", None) is not None for lin in lins]
         if any(static) != all(static):
             return False
         for lin in lins:
-            if not isinstance(lin.quant_method, CompressedTensorsW8A8Fp8Method):
+            qm = lin.quant_method
+            if isinstance(qm, CDNA4Fp8LinearMethod):
+                # Fp8Config checkpoints (per-tensor weight scale): the static activation scheme only -- the dynamic one
+                # is ONE scale over the whole tensor (a cross-workgroup absmax: the op-by-op path)
+                if qm.use_marlin or lin.input_scale is None or lin.weight.dtype != torch.float8_e4m3fn \
+                        or lin.weight_scale.numel() != 1:
+                    return False
+            elif not isinstance(qm, CompressedTensorsW8A8Fp8Method):
                 return False
             if lin.input_scale is not None and (lin.input_scale.numel() != 1 or lin.input_scale.dtype != torch.float32):
                 return False

@@ -54,8 +54,8 @@ def parse_args():
     ap.add_argument("--quant", default="gptq", choices=["gptq", "fp8", "awq", "fp8ct"],
                     help="fp8: per-tensor W8A8 (Fp8Config); fp8ct: compressed-tensors W8A8, per-token x per-channel")
     ap.add_argument("--act-scheme", default="dynamic", choices=["dynamic", "static"],
-                    help="fp8ct only: per-token dynamic activation scales (llm-compressor FP8_DYNAMIC, configs[2]) or the "
-                         "checkpoint's static per-tensor input_scale")
+                    help="fp8ct: per-token dynamic activation scales (llm-compressor FP8_DYNAMIC, configs[2]) or the "
+                         "checkpoint's static per-tensor input_scale; fp8 (Fp8Config): dynamic per-tensor or static")
     ap.add_argument("--kv-cache-dtype", default="auto", choices=["auto", "fp8", "fp8_e5m2"])
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--ctx", type=int, default=1024, help="context length at the first timed step")
@@ -99,7 +99,7 @@ def build(args, device):
         from aphrodite_engine_amd.quantization.fp8 import CompressedTensorsW8A8Fp8Config
         qc = CompressedTensorsW8A8Fp8Config(strategy="channel", is_static_input_scheme=args.act_scheme == "static")
     else:
-        qc = Fp8Config(is_checkpoint_fp8_serialized=True, activation_scheme="dynamic")
+        qc = Fp8Config(is_checkpoint_fp8_serialized=True, activation_scheme=args.act_scheme)
     dtype = torch.float16
     model = M.LlamaForCausalLM(cfg, qc, dtype, args.kv_cache_dtype)
     model.init_synthetic(device, seed=0)
@@ -771,7 +771,7 @@ def main():
             "data": "synthetic (random-init weights in the real GPTQ/FP8 formats, random token ids, random-permutation block tables)",
             "config": {
                 "workload": f"{ {'llama3-8b': 'Llama-3-8B', 'llama3-70b': 'Llama-3-70B', 'mixtral-8x7b': 'Mixtral-8x7B (top-2 of 8 experts)'}[args.model]} "
-                            f"{args.quant.upper()} {('W8A8' + (' static input scales' if args.quant == 'fp8ct' and args.act_scheme == 'static' else '')) if args.quant.startswith('fp8') else '4-bit g128'}, decode, "
+                            f"{args.quant.upper()} {('W8A8' + (' static input scales' if args.act_scheme == 'static' else '')) if args.quant.startswith('fp8') else '4-bit g128'}, decode, "
                             f"{'greedy' if args.sampling == 'greedy' else 'random sampling (T 0.8, top-k 50, top-p 0.95)'}, "
                             f"bs={args.batch}/GPU, context {args.ctx}->{ctx_end}, kv_cache={args.kv_cache_dtype}, "
                             f"block_size=16, HIP-graph={'off' if args.no_graph else 'on'}",

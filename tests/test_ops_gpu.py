@@ -1430,18 +1430,23 @@ def test_silu_and_mul_quant_fp8(ops, dtype, tokens, d, scheme):
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("strategy", ["channel", "tensor"])
 @pytest.mark.parametrize("kv_cache_dtype", ["auto", "fp8"])
-@pytest.mark.parametrize("scheme", ["dynamic", "static"])
+@pytest.mark.parametrize("scheme", ["dynamic", "static", "fp8config-static"])
 def test_fused_decode_fp8_model_matches_unfused(ops, dtype, strategy, kv_cache_dtype, scheme):
     """Whole decode step of the compressed-tensors W8A8-FP8 model: the fused path reproduces the
     op-by-op path bit for bit (hidden states and every layer's KV-cache writes) -- dynamic per-token activation
     scales, or the checkpoint's static per-tensor input_scale."""
     from aphrodite_engine_amd import model as M
-    from aphrodite_engine_amd.quantization.fp8 import CompressedTensorsW8A8Fp8Config
+    from aphrodite_engine_amd.quantization.fp8 import CompressedTensorsW8A8Fp8Config, Fp8Config
+    if scheme == "fp8config-static":     # AutoFP8-style checkpoints (Fp8Config, per-tensor weight scales, static input_scale)
+        if strategy != "tensor":
+            pytest.skip("Fp8Config has per-tensor weight scales only")
+        qc = Fp8Config(is_checkpoint_fp8_serialized=True, activation_scheme="static")
+    else:
+        qc = CompressedTensorsW8A8Fp8Config(strategy, is_static_input_scheme=scheme == "static")
     with torch.no_grad():
-        m = M.LlamaForCausalLM(M.TINY, CompressedTensorsW8A8Fp8Config(strategy, is_static_input_scheme=scheme == "static"),
-                               dtype, kv_cache_dtype)
+        m = M.LlamaForCausalLM(M.TINY, qc, dtype, kv_cache_dtype)
         m.init_synthetic(torch.device(DEV))
-        if scheme == "static":
+        if scheme != "dynamic":
             for li, layer in enumerate(m.layers):
                 for j, lin_ in enumerate(layer.linears()):
                     lin_.input_scale.fill_((3.0 + j + 0.5 * li) / 448.0)
