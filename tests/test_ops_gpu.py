@@ -1428,9 +1428,9 @@ def test_silu_and_mul_quant_fp8(ops, dtype, tokens, d, scheme):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("strategy", ["channel", "tensor"])
+@pytest.mark.parametrize("strategy,scheme", [("channel", "dynamic"), ("tensor", "dynamic"), ("channel", "static"),
+                                             ("tensor", "static"), ("tensor", "fp8config-static")])
 @pytest.mark.parametrize("kv_cache_dtype", ["auto", "fp8"])
-@pytest.mark.parametrize("scheme", ["dynamic", "static", "fp8config-static"])
 def test_fused_decode_fp8_model_matches_unfused(ops, dtype, strategy, kv_cache_dtype, scheme):
     """Whole decode step of the compressed-tensors W8A8-FP8 model: the fused path reproduces the
     op-by-op path bit for bit (hidden states and every layer's KV-cache writes) -- dynamic per-token activation
@@ -1438,8 +1438,6 @@ def test_fused_decode_fp8_model_matches_unfused(ops, dtype, strategy, kv_cache_d
     from aphrodite_engine_amd import model as M
     from aphrodite_engine_amd.quantization.fp8 import CompressedTensorsW8A8Fp8Config, Fp8Config
     if scheme == "fp8config-static":     # AutoFP8-style checkpoints (Fp8Config, per-tensor weight scales, static input_scale)
-        if strategy != "tensor":
-            pytest.skip("Fp8Config has per-tensor weight scales only")
         qc = Fp8Config(is_checkpoint_fp8_serialized=True, activation_scheme="static")
     else:
         qc = CompressedTensorsW8A8Fp8Config(strategy, is_static_input_scheme=scheme == "static")
