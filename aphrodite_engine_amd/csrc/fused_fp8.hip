@@ -80,9 +80,18 @@ __global__ void add_rms_norm_quant_kernel(const uint16_t* __restrict__ input, co
           b += *reinterpret_cast<const f32x4*>(slabs + s * slab_stride + off + 4);
         }
         const float sav = sa ? sa[sa_per_token ? tok : 0] : 1.f;
+        f32x4 sb0, sb1;                                   // the 8 column scales: two 16-byte loads, not 8 conditional ones
+        if (sb && sb_per_channel) {
+          sb0 = *reinterpret_cast<const f32x4*>(sb + 8 * i);
+          sb1 = *reinterpret_cast<const f32x4*>(sb + 8 * i + 4);
+        } else {
+          const float s1 = sb ? sb[0] : 1.f;
+          sb0 = f32x4{s1, s1, s1, s1};
+          sb1 = sb0;
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const float sbv = sb ? sb[sb_per_channel ? 8 * i + j : 0] : 1.f;
+          const float sbv = j < 4 ? sb0[j] : sb1[j - 4];
           const float acc = j < 4 ? a[j] : b[j - 4];
           x[j] = T::to_f32(from_f32_exact<T>(sav * (sbv * acc)));
         }
@@ -216,6 +225,8 @@ extern "C" int aphro_fused_add_rms_norm_quant_fp8_static(const void* input, cons
   APHRO_CHECK(hidden % 8 == 0 && hidden <= 16384, "fused_add_rms_norm_quant: hidden=%d unsupported", hidden);
   APHRO_CHECK(!has_residual || residual != nullptr, "fused_add_rms_norm_quant: residual missing");
   APHRO_CHECK(q_out && scale_out, "fused_add_rms_norm_quant: outputs missing");
+  APHRO_CHECK(!(slabs && slab_b_scales && b_scale_per_channel) || ((uintptr_t)slab_b_scales % 16) == 0,
+              "fused_add_rms_norm_quant: per-channel scales must be 16-byte aligned");
   if (tokens == 0) return APHRO_OK;
   int nv = hidden / 8, t = nv <= 1024 ? nv : (nv + 1) / 2;   // same mapping as the norm kernels (glue.hip)
   t = (t + 63) / 64 * 64;
