@@ -121,20 +121,86 @@ __global__ __launch_bounds__(1024) void moe_route_align_kernel(
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int nwave = blockDim.x >> 6;
+  if (num_experts <= 16) {
+    // <= 16 experts (Mixtral: 8): a token's whole row lives in ONE thread -- no cross-lane step at all.  Bit-identical to
+    // the wave form below: max is exact in any order; the sum of exps replays wave_sum's butterfly (offsets 8, 4, 2, 1 over
+    // 16 slots, the idle lanes' zeros left out: x + 0 = x); arg-max scans ascending, so ties keep the lower expert.
+    for (int tok = threadIdx.x; tok < num_tokens; tok += blockDim.x) {
+      const typename T::storage* row = gating + (size_t)tok * gating_stride;
+      float ex[16];
+      float mx = -INFINITY;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        ex[j] = j < num_experts ? T::to_f32(row[j]) : 0.f;
+        if (j < num_experts) mx = __builtin_fmaxf(mx, ex[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < 16; ++j) ex[j] = j < num_experts ? expf(ex[j] - mx) : 0.f;
+      float a[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) a[j] = ex[j];
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) {
+        float nx[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) nx[j] = a[j] + a[j ^ o];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) a[j] = nx[j];
+      }
+      const float norm = 1.f / a[0];
+      float prob[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) prob[j] = j < num_experts ? ex[j] * norm : -1.f;
+      float wsum = 0.f;
+      float wk[8];
+      int we[8];
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) {
+        if (kk < k) {
+          float best = -1.f;
+          int best_e = 0;
+#pragma unroll
+          for (int j = 0; j < 16; ++j)
+            if (prob[j] > best) { best = prob[j]; best_e = j; }
+          wk[kk] = best;
+          we[kk] = best_e;
+          wsum += best;
+#pragma unroll
+          for (int j = 0; j < 16; ++j)
+            if (j == best_e) prob[j] = -1.f;
+        }
+      }
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) {
+        if (kk < k) {
+          ids[tok * k + kk] = we[kk];
+          topk_ids_out[(size_t)tok * k + kk] = we[kk];
+          topk_weights[(size_t)tok * k + kk] = renormalize ? wk[kk] / wsum : wk[kk];
+        }
+      }
+    }
+  } else
   for (int tok = wave; tok < num_tokens; tok += nwave) {
     const typename T::storage* row = gating + (size_t)tok * gating_stride;
+    float gv[4];                                      // the row once (num_experts <= 256): one global round trip, not three
+#pragma unroll
+    for (int j = 0; j < 4; ++j) gv[j] = lane + 64 * j < num_experts ? T::to_f32(row[lane + 64 * j]) : 0.f;
     float mx = -INFINITY;
-    for (int e = lane; e < num_experts; e += 64) mx = __builtin_fmaxf(mx, T::to_f32(row[e]));
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (lane + 64 * j < num_experts) mx = __builtin_fmaxf(mx, gv[j]);
     mx = wave_max(mx);
     float sum = 0.f;
-    for (int e = lane; e < num_experts; e += 64) sum += expf(T::to_f32(row[e]) - mx);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (lane + 64 * j < num_experts) sum += expf(gv[j] - mx);
     sum = wave_sum(sum);
     const float norm = 1.f / sum;
     float prob[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int e = lane + 64 * j;
-      prob[j] = e < num_experts ? expf(T::to_f32(row[e]) - mx) * norm : -1.f;
+      prob[j] = e < num_experts ? expf(gv[j] - mx) * norm : -1.f;
     }
     float wsum = 0.f;
     float wk[8];
@@ -167,6 +233,52 @@ __global__ __launch_bounds__(1024) void moe_route_align_kernel(
   }
   __syncthreads();
   if (wave != 0) return;
+  if (num_experts <= 64) {
+    // ---- moe_align_kernel's result by wave-wide ranking (the decode case: a few dozen slots, <= 64 experts): lane e owns
+    // expert e.  Within an expert the slots stay in ascending order, as the counting sort below leaves them (its shards are
+    // ascending slot ranges) -- the 65-deep serial prefix of that sort was 2/3 of this launch's 12 us.
+    const int t = lane;
+    int my_cnt = 0;
+    for (int c0 = 0; c0 < numel; c0 += 64) {
+      const int my_e = c0 + t < numel ? ids[c0 + t] : -1;
+      for (int e = 0; e < num_experts; ++e) {
+        const unsigned long long mask = __ballot(my_e == e);
+        if (t == e) my_cnt += __popcll(mask);
+      }
+    }
+    const int padded = t < num_experts ? (my_cnt + block_size - 1) / block_size * block_size : 0;
+    int incl = padded;                                // inclusive scan over the lanes
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int up = __shfl_up(incl, o, 64);
+      if (t >= o) incl += up;
+    }
+    const int start = incl - padded;                  // cumsum[e]
+    const int total = __shfl(incl, 63, 64);
+    if (t == 0) *num_tokens_post_pad = total;
+    for (int i = t; i < max_padded; i += 64) sorted_token_ids[i] = numel;
+    for (int i = t; i < max_blocks; i += 64) expert_ids[i] = -1;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // the fills above come from other lanes than the real entries below
+    if (t < num_experts)
+      for (int i = start; i < start + padded; i += block_size) expert_ids[i / block_size] = t;
+    int base = start;                                 // lane e: next free position of expert e
+    for (int c0 = 0; c0 < numel; c0 += 64) {
+      const int i = c0 + t;
+      const int my_e = i < numel ? ids[i] : -1;
+      int pos = -1;
+      for (int e = 0; e < num_experts; ++e) {
+        const unsigned long long mask = __ballot(my_e == e);
+        const int b = __shfl(base, e, 64);
+        if (my_e == e) pos = b + __popcll(mask & ((1ull << t) - 1ull));
+        if (t == e) base += __popcll(mask);
+      }
+      if (pos >= 0) {
+        sorted_token_ids[pos] = i;
+        if (inv_pos) inv_pos[i] = pos;
+      }
+    }
+    return;
+  }
   // ---- moe_align_kernel on the ids in LDS (same shards, same order) -------------------------------------------------
   const int t = lane;
   const int per = (numel + 63) / 64;

@@ -2211,7 +2211,7 @@ def test_fp8_gemm_silu_quant_matches_op_sequence(ops, M, N, K, dtype, per_token)
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32])
-@pytest.mark.parametrize("T,E,k,renorm", [(1, 8, 2, True), (32, 8, 2, True), (64, 8, 2, False), (33, 16, 4, True), (200, 64, 6, True),
+@pytest.mark.parametrize("T,E,k,renorm", [(1, 8, 2, True), (32, 8, 2, True), (64, 8, 2, False), (33, 16, 4, True), (200, 64, 6, True), (9, 128, 4, True), (40, 12, 3, True),
                                           (7, 4, 1, False)])
 def test_moe_route_align_matches_the_separate_ops(ops, T, E, k, renorm, dtype):
     """fused_topk + moe_align_block_size in one launch == gating.float() -> topk_softmax -> renormalise ->
