@@ -74,6 +74,7 @@ __global__ void add_rms_norm_pack_kernel(const uint16_t* __restrict__ input, con
   const size_t slab_stride = (size_t)tokens * hidden;
   float v[2][8];
   u16x8 wv[2];  // norm weights: fetched with the inputs, not after the reduction barrier
+  u16x8 g8v[ROUTER ? 2 : 1][ROUTER ? 8 : 1];   // ... and so are the first 8 router rows (a serial L2 round trip otherwise)
   float ss = 0.f;
 #pragma unroll
   for (int it = 0; it < 2; ++it) {
@@ -81,6 +82,11 @@ __global__ void add_rms_norm_pack_kernel(const uint16_t* __restrict__ input, con
     if (i < nv) {
       const size_t off = (size_t)tok * hidden + 8 * i;
       wv[it] = *reinterpret_cast<const u16x8*>(weight + 8 * i);
+      if constexpr (ROUTER) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (e < num_experts) g8v[it][e] = *reinterpret_cast<const u16x8*>(router_w + (size_t)e * hidden + 8 * i);
+      }
       float x[8];
       if constexpr (COMBINE) {
         float acc8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -158,7 +164,9 @@ __global__ void add_rms_norm_pack_kernel(const uint16_t* __restrict__ input, con
 #pragma unroll
         for (int e = 0; e < 16; ++e)
           if (e < num_experts) {
-            const u16x8 g8 = *reinterpret_cast<const u16x8*>(router_w + (size_t)e * hidden + 8 * i);
+            u16x8 g8;
+            if (e < 8) g8 = g8v[it][e < 8 ? e : 0];
+            else g8 = *reinterpret_cast<const u16x8*>(router_w + (size_t)e * hidden + 8 * i);
 #pragma unroll
             for (int j = 0; j < 8; ++j) rpart[e] += T::to_f32(y[j]) * T::to_f32(g8[j]);
           }
@@ -167,13 +175,27 @@ __global__ void add_rms_norm_pack_kernel(const uint16_t* __restrict__ input, con
   }
   if constexpr (ROUTER) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = (blockDim.x + 63) >> 6;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      float v2 = rpart[e];
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) v2 += __shfl_xor(v2, o, 64);
-      if (lane == 0) rred[wave * 16 + e] = v2;
+    // 16 wave sums in 17 shuffles instead of 96: a reduce-scatter butterfly -- at offset 32 a lane keeps one half of the
+    // experts and hands the other half to its partner, at 16 a quarter, ... after offset 4 it holds ONE expert's partial
+    // (expert = lane bits 5..2), two plain steps finish it
+#define APHRO_RS_STEP(O, HALF)                                        \
+    {                                                                 \
+      const bool up = (lane & O) != 0;                                \
+      _Pragma("unroll") for (int j = 0; j < HALF; ++j) {              \
+        const float send = up ? rpart[j] : rpart[j + HALF];           \
+        const float keep = up ? rpart[j + HALF] : rpart[j];           \
+        rpart[j] = keep + __shfl_xor(send, O, 64);                    \
+      }                                                               \
     }
+    APHRO_RS_STEP(32, 8)
+    APHRO_RS_STEP(16, 4)
+    APHRO_RS_STEP(8, 2)
+    APHRO_RS_STEP(4, 1)
+#undef APHRO_RS_STEP
+    float v2 = rpart[0];
+    v2 += __shfl_xor(v2, 2, 64);
+    v2 += __shfl_xor(v2, 1, 64);
+    if ((lane & 3) == 0) rred[wave * 16 + ((lane >> 2) & 15)] = v2;
     __syncthreads();
     if ((int)threadIdx.x < num_experts) {
       float sum = 0.f;
