@@ -355,3 +355,40 @@ def test_attention_state_matches_reference():
         assert m.seq_lens_tensor.tolist() == [9, 17, 33, 1] and int(m.block_tables.sum()) == 24
     assert not st._is_graph_capturing and not hasattr(st, "_graph_seq_lens")
     st.begin_forward(None)
+
+
+def test_fused_fp8_decode_path_selection():
+    """Which FP8 checkpoints take the fused decode path (model.fused_decode_fp8_ok, host logic only): compressed-tensors
+    W8A8 with per-token dynamic OR static per-tensor activation scales (compressed_tensors_w8a8_fp8.py:98-148), Fp8Config
+    with the static scheme (fp8.py:150-199) -- not its dynamic one (ONE scale over the whole tensor needs a cross-workgroup
+    absmax), not weight-only (Marlin role), not a layer whose projections disagree on the scheme."""
+    from aphrodite_engine_amd import model as M
+    from aphrodite_engine_amd.quantization.fp8 import CompressedTensorsW8A8Fp8Config, Fp8Config
+
+    def build(qc):
+        m = M.LlamaForCausalLM(M.TINY, qc, torch.float16, "auto")
+        for layer in m.layers:
+            for lin in layer.linears():
+                lin.quant_method.process_weights_after_loading(lin)
+        return m
+
+    for qc, want in ((CompressedTensorsW8A8Fp8Config("channel", False), True),
+                     (CompressedTensorsW8A8Fp8Config("channel", True), True),
+                     (CompressedTensorsW8A8Fp8Config("tensor", True), True),
+                     (Fp8Config(True, "static"), True),
+                     (Fp8Config(True, "dynamic"), False)):
+        m = build(qc)
+        assert [layer.fused_decode_fp8_ok(5) for layer in m.layers] == [want] * len(m.layers), type(qc).__name__
+        assert not any(layer.fused_decode_fp8_ok(65) for layer in m.layers)          # decode-sized batches only
+    m = build(CompressedTensorsW8A8Fp8Config("channel", True))
+    assert all(lin.input_scale.shape == (1, ) and lin.input_scale.dtype == torch.float32
+               for layer in m.layers for lin in layer.linears())
+    m.layers[0].o_proj.input_scale = None                                             # schemes disagree inside a layer
+    assert [layer.fused_decode_fp8_ok(5) for layer in m.layers] == [False] + [True] * (len(m.layers) - 1)
+    # the library-side shape rules behind it are host logic too
+    from aphrodite_engine_amd import _lib
+    lib = _lib.lib()
+    assert lib.aphro_fp8_gemm_stream_silu_supported(32, 28672, 4096) == 1
+    assert lib.aphro_fp8_gemm_stream_silu_supported(33, 28672, 4096) == 0            # M <= 32
+    assert lib.aphro_fp8_gemm_stream_silu_supported(32, 28672 + 16, 4096) == 0       # halves of 8-row groups
+    assert lib.aphro_fp8_gemm_stream_silu_supported(32, 4096, 14336) == 0            # K beyond one workgroup's 8 x 8 segments
