@@ -253,6 +253,83 @@ class Wna16MoEMethod(FusedMoEMethodBase):
                                aligned=(sorted_ids, expert_ids, post_pad, inv), defer_combine=defer_combine)
 
 
+class CompressedTensorsMoEMethod(Wna16MoEMethod):
+    """compressed-tensors ``pack-quantized`` int4 experts (llm-compressor W4A16 Mixtral checkpoints): the role of
+    quantization/compressed_tensors/compressed_tensors_moe.py:23-286, which repacks for ``fused_marlin_moe`` (CUDA only).
+    Same parameters and names as the reference (:48-157) -- the loader transposes the on-disk [N, K / 8] / [N, G]
+    tensors (``is_transposed``, fused_moe/layer.py:324-331), so that
+
+        w13_weight_packed [E, H/8, 2I] int32     w13_weight_scale [E, H/g, 2I]     w13_weight_shape [E, 2]
+        w2_weight_packed  [E, I/8, H]  int32     w2_weight_scale  [E, I/g, H]      w2_weight_shape  [E, 2]
+
+    -- and a transposed ``weight_packed`` IS AutoGPTQ's qweight (nibble i of word r = element k = 8 r + i, stored q + 8:
+    compressed_tensors_wNA16.py:97-135, uint4b8).  Symmetric weights have the zero point 8 in every group, i.e. 7 in
+    GPTQ's stored-minus-one convention: after loading the tensors go through ``Wna16Experts`` unchanged and the grouped
+    CDNA4 GEMM serves them like GPTQ experts.  ``channel`` strategy: one scale row per expert matrix, expanded to groups
+    of 128 (the grouped kernel's group sizes are 128 x 2^n and K = 14336 is not one).  8-bit and act-order are refused."""
+
+    def __init__(self, quant_config):
+        scheme = quant_config.target_scheme_map.get("Linear")
+        w = scheme.get("weights") if scheme else None
+        if w is None:
+            raise ValueError("compressed-tensors experts: no `Linear` target with a weights block in the config")
+        if not w.symmetric:
+            raise ValueError("Only symmetric quantization is supported for MoE")             # (:37-38)
+        if quant_config.quant_format != "pack-quantized" or w.num_bits not in (4, 8) or w.type != "int":
+            raise ValueError("For Fused MoE layers, only pack-quantized is supported for the following bits: [4, 8]")
+        if w.num_bits != 4:
+            raise NotImplementedError("pack-quantized 8-bit experts: only 4-bit is built for MI355X")
+        if w.actorder is not None:
+            raise NotImplementedError("act-order compressed-tensors experts are not supported by the grouped kernel")
+        if w.strategy not in ("group", "channel"):
+            raise ValueError(f"compressed-tensors experts: unsupported weight strategy {w.strategy}")
+        self.strategy = w.strategy
+        self.ckpt_group_size = w.group_size if w.strategy == "group" else -1
+        super().__init__("gptq", w.group_size if w.strategy == "group" else 128, False)
+
+    def create_weights(self, layer: nn.Module, num_experts: int, hidden_size: int, intermediate_size: int,
+                       params_dtype: torch.dtype, **extra_weight_attrs):
+        loader = extra_weight_attrs.get("weight_loader")
+        e, h, i = num_experts, hidden_size, intermediate_size
+        g = self.ckpt_group_size
+        if i % 8 or h % 8 or (g != -1 and (g <= 0 or h % g or i % g)) or (g == -1 and (h % 128 or i % 128)):
+            raise ValueError(f"group size {g} must divide hidden {h} and the per-rank intermediate size {i} "
+                             f"(too large a tensor-parallel size?)")
+        g13, g2 = (1, 1) if g == -1 else (h // g, i // g)
+
+        def reg(name, shape, dtype, in_dim, out_dim, packed_dim=None):
+            layer.register_parameter(name, _param(torch.empty(shape, dtype=dtype), input_dim=in_dim,
+                                                  output_dim=out_dim, packed_dim=packed_dim,
+                                                  pack_factor=8 if packed_dim is not None else None,
+                                                  weight_loader=loader, is_transposed=True,
+                                                  quant_method=self.strategy))
+        reg("w13_weight_packed", (e, h // 8, 2 * i), torch.int32, 0, 1, 0)
+        reg("w2_weight_packed", (e, i // 8, h), torch.int32, 0, 1, 0)
+        # channel strategy: ONE scale row; w2's is not cut by tensor parallelism (layer.py:252-265)
+        reg("w13_weight_scale", (e, g13, 2 * i), params_dtype, 0 if g != -1 else None, 1)
+        reg("w2_weight_scale", (e, g2, h), params_dtype, 0 if g != -1 else None, 1)
+        for name in ("w13_weight_shape", "w2_weight_shape"):
+            layer.register_parameter(name, _param(torch.zeros((e, 2), dtype=torch.int64), weight_loader=loader))
+        layer.experts_packed = None
+
+    def process_weights_after_loading(self, layer: nn.Module) -> None:
+        e = layer.w13_weight_packed.shape[0]
+
+        def tensors(packed, scale):
+            k8, n = packed.shape
+            groups = k8 * 8 // self.group_size
+            if scale.shape[0] != groups:                                   # channel strategy: one row -> groups of 128
+                scale = scale.expand(groups, n)
+            zeros = torch.full((groups, n // 8), 0x77777777, dtype=torch.int32, device=packed.device)
+            return packed, zeros, scale.contiguous()
+        sets13 = [tensors(layer.w13_weight_packed.data[x], layer.w13_weight_scale.data[x]) for x in range(e)]
+        sets2 = [tensors(layer.w2_weight_packed.data[x], layer.w2_weight_scale.data[x]) for x in range(e)]
+        layer.experts_packed = Wna16Experts(sets13, sets2, zero_offset=1, layout="gptq")
+        for name in ("w13_weight_packed", "w13_weight_scale", "w13_weight_shape", "w2_weight_packed", "w2_weight_scale",
+                     "w2_weight_shape"):
+            delattr(layer, name)
+
+
 def fused_fp8_moe(hidden_states: torch.Tensor, w13: torch.Tensor, w2: torch.Tensor, w13_scale: torch.Tensor,
                   w2_scale: torch.Tensor, topk_weights: torch.Tensor, topk_ids: torch.Tensor,
                   a1_scale: Optional[torch.Tensor] = None, a2_scale: Optional[torch.Tensor] = None,
@@ -413,7 +490,13 @@ class FusedMoE(nn.Module):
             raise ValueError(f"shard_id must be ['w1','w2','w3'] but got {shard_id}.")
         if not 0 <= expert_id < self.num_experts:
             raise ValueError(f"{weight_name}: expert {expert_id} out of range")
-        if "weight_scale" in weight_name:              # per-tensor scales (layer.py:219-232): w1 / w3 kept apart
+        if getattr(param, "is_transposed", False):     # compressed-tensors experts: [N, ...] on disk (layer.py:324-331)
+            loaded_weight = loaded_weight.t().contiguous()
+        elif "weight_shape" in weight_name:            # (layer.py:365-369)
+            param.data[expert_id] = loaded_weight.reshape(-1).to(param.data.dtype)
+            return
+        if "weight_scale" in weight_name and not getattr(param, "is_transposed", False):
+            # per-tensor scales (layer.py:219-232): w1 / w3 kept apart
             if param.data.dim() == 2:
                 if shard_id == "w2":
                     raise ValueError(f"{weight_name}: a [E, 2] scale parameter belongs to w1 / w3")

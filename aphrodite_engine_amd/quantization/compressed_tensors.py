@@ -8,6 +8,8 @@ hot path serves, each bound to a CDNA4 kernel:
   float-quantized   fp8, tensor / channel      none                    CompressedTensorsW8A16Fp8Method
   pack-quantized    int4 symmetric,            none                    CompressedTensorsWNA16Method ->
                     group / channel (+actorder)                        MPLinearKernel (kernels/cdna4.py)
+  pack-quantized    int4 symmetric experts     none                    CompressedTensorsMoEMethod (moe.py) ->
+                    (FusedMoE), group / channel                        the grouped int4 GEMM
 
 The reference wraps "schemes" in one CompressedTensorsLinearMethod; here every scheme IS a
 LinearMethodBase (same tensors, names and forward), and scheme selection is a table of predicates
@@ -114,9 +116,9 @@ class CompressedTensorsConfig(QuantizationConfig):
         if kind == "attention":
             from .kv_cache import BaseKVCacheMethod
             return BaseKVCacheMethod(self)
-        if kind == "moe":
-            raise NotImplementedError("compressed-tensors experts (CompressedTensorsMoEMethod) are not built for "
-                                      "MI355X yet")
+        if kind == "moe":                    # compressed_tensors.py:77-78
+            from ..moe import CompressedTensorsMoEMethod
+            return CompressedTensorsMoEMethod(self)
         if kind != "linear":
             return None
         if layer_is_ignored(prefix, self.ignore):

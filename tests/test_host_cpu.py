@@ -286,11 +286,28 @@ def test_quant_configs_dispatch_on_layer_family():
         assert cfg.get_quant_method(emb, "model.embed_tokens") is None
         assert cfg.get_quant_method(lin, "model.layers.0.mlp.down_proj") is not None
         assert cfg.get_quant_method(lin, "lm_head") is None          # ignored layer, reference not installed here
-    # experts: FP8 checkpoints get Fp8MoEMethod (fp8.py:86-87); compressed-tensors experts are not built
-    from aphrodite_engine_amd.moe import Fp8MoEMethod
+    # experts: FP8 checkpoints get Fp8MoEMethod (fp8.py:86-87); compressed-tensors experts CompressedTensorsMoEMethod
+    # (compressed_tensors.py:77-78), which serves pack-quantized symmetric int4 like the reference's (and refuses the rest)
+    from aphrodite_engine_amd.moe import CompressedTensorsMoEMethod, Fp8MoEMethod
     assert isinstance(fp8.get_quant_method(mk("FusedMoE"), "model.layers.0.block_sparse_moe.experts"), Fp8MoEMethod)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError, match="only pack-quantized is supported"):        # the float-quantized config above
         ct.get_quant_method(mk("FusedMoE"), "model.layers.0.block_sparse_moe.experts")
+
+    def ct_w(bits=4, strategy="group", symmetric=True, actorder=None):
+        w = {"num_bits": bits, "type": "int", "symmetric": symmetric, "strategy": strategy, "actorder": actorder}
+        if strategy == "group":
+            w["group_size"] = 128
+        return CompressedTensorsConfig.from_config({"format": "pack-quantized", "config_groups": {
+            "g": {"targets": ["Linear"], "weights": w, "input_activations": None}}})
+    for kw in ({}, {"strategy": "channel"}):
+        mth = ct_w(**kw).get_quant_method(mk("FusedMoE"), "model.layers.0.block_sparse_moe.experts")
+        assert isinstance(mth, CompressedTensorsMoEMethod) and mth.layout == "gptq" and mth.group_size == 128
+    with pytest.raises(ValueError, match="Only symmetric quantization is supported for MoE"):
+        ct_w(symmetric=False).get_quant_method(mk("FusedMoE"), "x.experts")
+    with pytest.raises(NotImplementedError):
+        ct_w(bits=8).get_quant_method(mk("FusedMoE"), "x.experts")
+    with pytest.raises(NotImplementedError):
+        ct_w(actorder="group").get_quant_method(mk("FusedMoE"), "x.experts")
     # the KV-cache method registers k_scale / v_scale and resolves them after loading
     attn.kv_cache_dtype = "fp8"
     m = fp8.get_quant_method(attn, "x")

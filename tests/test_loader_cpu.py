@@ -251,6 +251,67 @@ def test_mixtral_int4_experts(tmp_path, fmt):
         np.testing.assert_array_equal(got, exp)
 
 
+def test_mixtral_compressed_tensors_experts(tmp_path):
+    """llm-compressor W4A16 Mixtral checkpoint (pack-quantized, symmetric, group 128): experts.{e}.w{1,2,3}.weight_packed
+    [N, K/8] / weight_scale [N, K/g] / weight_shape are transposed on their way into CompressedTensorsMoEMethod's
+    parameters (is_transposed, fused_moe/layer.py:324-331) and cut like the GPTQ experts; the transposed weight_packed IS
+    a GPTQ qweight."""
+    cfg = M.TINY_MOE
+    truth = CU.write_checkpoint(str(tmp_path), cfg, "ct-w4a16", seed=23)
+    lg = truth["logical"]
+    inter = cfg.intermediate_size
+    for rank, world in [(0, 1), (1, 2), (3, 4)]:
+        m = build(tmp_path, "ct-w4a16", rank, world)
+        cols = np.arange(rank * inter // world, (rank + 1) * inter // world)
+        for li, layer in enumerate(m.layers):
+            ex = layer.experts
+            assert type(ex.quant_method).__name__ == "CompressedTensorsMoEMethod"
+            assert ex.w13_weight_packed.shape == (cfg.num_local_experts, cfg.hidden_size // 8, 2 * len(cols))
+            for e in range(cfg.num_local_experts):
+                base = f"model.layers.{li}.block_sparse_moe.experts.{e}."
+                w1, w3, w2 = lg[base + "w1"], lg[base + "w3"], lg[base + "w2"]
+                np.testing.assert_array_equal(oq.gptq_unpack(ex.w13_weight_packed[e].numpy()),
+                                              np.concatenate([w1["q"][:, cols], w3["q"][:, cols]], 1))
+                np.testing.assert_array_equal(ex.w13_weight_scale[e].numpy(),
+                                              np.concatenate([w1["s"][:, cols], w3["s"][:, cols]], 1))
+                np.testing.assert_array_equal(oq.gptq_unpack(ex.w2_weight_packed[e].numpy()), w2["q"][cols, :])
+                g0, g1 = cols[0] // 128, (cols[-1] + 1) // 128
+                np.testing.assert_array_equal(ex.w2_weight_scale[e].numpy(), w2["s"][g0:g1])
+                assert ex.w13_weight_shape[e].tolist() == [inter, cfg.hidden_size]
+                assert ex.w2_weight_shape[e].tolist() == [cfg.hidden_size, inter]
+
+
+def test_compressed_tensors_experts_channel_strategy():
+    """``channel`` strategy: ONE scale row per expert matrix; w1 / w3 rows are cut along N, w2's is NOT cut by tensor
+    parallelism (fused_moe/layer.py:252-265)."""
+    from aphrodite_engine_amd.moe import FusedMoE
+    from aphrodite_engine_amd.quantization.compressed_tensors import CompressedTensorsConfig
+    qc = CompressedTensorsConfig.from_config({"format": "pack-quantized", "config_groups": {"g": {
+        "targets": ["Linear"], "weights": {"num_bits": 4, "type": "int", "symmetric": True, "strategy": "channel"},
+        "input_activations": None}}})
+    e, h, inter = 2, 256, 512
+    rng = np.random.default_rng(0)
+    for rank, world in [(0, 1), (1, 2)]:
+        with simulated_tensor_parallel(rank, world):
+            moe = FusedMoE(e, 2, h, inter, params_dtype=torch.float16, quant_config=qc, prefix="x.experts")
+        assert moe.w13_weight_scale.shape == (e, 1, 2 * inter // world) and moe.w2_weight_scale.shape == (e, 1, h)
+        cols = slice(rank * inter // world, (rank + 1) * inter // world)
+        for x in range(e):
+            for shard, n, k in (("w1", inter, h), ("w3", inter, h), ("w2", h, inter)):
+                s = torch.from_numpy(rng.random((n, 1)).astype(np.float16))
+                wp = torch.from_numpy(rng.integers(-2 ** 31, 2 ** 31 - 1, (n, k // 8)).astype(np.int32))
+                fused = "w13_" if shard != "w2" else "w2_"
+                moe.weight_loader(getattr(moe, fused + "weight_scale"), s, f"x.experts.{x}.{shard}.weight_scale", shard, x)
+                moe.weight_loader(getattr(moe, fused + "weight_packed"), wp, f"x.experts.{x}.{shard}.weight_packed", shard, x)
+                if shard == "w2":
+                    assert torch.equal(moe.w2_weight_scale[x], s.t())
+                    assert torch.equal(moe.w2_weight_packed[x], wp.t()[cols.start // 8:cols.stop // 8])
+                else:
+                    off = 0 if shard == "w1" else inter // world
+                    assert torch.equal(moe.w13_weight_scale[x][:, off:off + inter // world], s.t()[:, cols])
+                    assert torch.equal(moe.w13_weight_packed[x][:, off:off + inter // world], wp.t()[:, cols])
+
+
 @pytest.mark.parametrize("fused", [False, True])
 def test_unquantised_checkpoint_and_fused_on_disk(tmp_path, fused):
     truth = CU.write_checkpoint(str(tmp_path), CFG, "fp16", seed=5, fused_on_disk=fused)
