@@ -121,7 +121,8 @@ class QuantLinear(nn.Module):
             return self.qweight, self.qzeros, self.scales, 0
         kernel = getattr(self, "kernel", None)   # compressed-tensors pack-quantized via the MPLinearKernel seam
         if kernel is not None and type(kernel).__name__ == "CDNA4LinearKernel" \
-                and getattr(self, "_cdna4_perm", None) is None and hasattr(self, "_cdna4_zp"):
+                and getattr(self, "_cdna4_perm", None) is None and hasattr(self, "_cdna4_zp") \
+                and getattr(self, "_cdna4_bits", 4) == 4:
             return self.weight_packed, self._cdna4_zp, self.weight_scale, 0
         return None
 

@@ -6,7 +6,7 @@ hot path serves, each bound to a CDNA4 kernel:
   float-quantized   fp8, tensor / channel      fp8 dynamic per token   CompressedTensorsW8A8Fp8Method (fp8.py)
                                                or static per tensor
   float-quantized   fp8, tensor / channel      none                    CompressedTensorsW8A16Fp8Method
-  pack-quantized    int4 symmetric,            none                    CompressedTensorsWNA16Method ->
+  pack-quantized    int4 / int8 symmetric,     none                    CompressedTensorsWNA16Method ->
                     group / channel (+actorder)                        MPLinearKernel (kernels/cdna4.py)
   pack-quantized    int4 symmetric experts     none                    CompressedTensorsMoEMethod (moe.py) ->
                     (FusedMoE), group / channel                        the grouped int4 GEMM
@@ -14,7 +14,7 @@ hot path serves, each bound to a CDNA4 kernel:
 The reference wraps "schemes" in one CompressedTensorsLinearMethod; here every scheme IS a
 LinearMethodBase (same tensors, names and forward), and scheme selection is a table of predicates
 over the parsed ``weights`` / ``input_activations`` blocks instead of an if-chain.  Anything else
-(int8 W8A8, 2:4 sparse, 8-bit WNA16) raises NotImplementedError like the reference does for unknown
+(int8 W8A8, 2:4 sparse) raises NotImplementedError like the reference does for unknown
 combinations (:252-253)."""
 from dataclasses import dataclass
 from typing import Any, Dict, List, Optional
@@ -130,8 +130,8 @@ class CompressedTensorsConfig(QuantizationConfig):
         static_w = not w.dynamic and w.symmetric
         if (a is None and static_w and w.type == "int" and w.strategy in ("channel", "group")
                 and self.quant_format == "pack-quantized"):
-            if w.num_bits != 4:
-                raise NotImplementedError(f"pack-quantized {w.num_bits}-bit weights: only 4-bit is built for MI355X")
+            if w.num_bits not in (4, 8):           # WNA16_SUPPORTED_BITS (compressed_tensors_wNa16.py:16-20)
+                raise ValueError(f"Unsupported num_bits = {w.num_bits}. Supported num_bits = [4, 8]")
             return CompressedTensorsWNA16Method(w.num_bits, w.strategy, w.group_size, w.actorder)
         if self.quant_format in ACTIVATION_QUANT_FORMATS and w.type == "float" and w.num_bits == 8 and static_w \
                 and w.strategy in ("tensor", "channel"):
@@ -159,7 +159,7 @@ class CompressedTensorsWNA16Method(LinearMethodBase):
         if self.group_size == -1 and strategy != "channel":
             raise ValueError("Marlin kernels require group quantization or channelwise quantization, but found no "
                              "group size and strategy is not channelwise.")
-        self.quant_type = scalar_types.uint4b8
+        self.quant_type = {4: scalar_types.uint4b8, 8: scalar_types.uint8b128}[num_bits]    # (wNa16.py:16-20)
 
     def create_weights(self, layer: nn.Module, input_size_per_partition: int, output_partition_sizes: List[int],
                        input_size: int, output_size: int, params_dtype: torch.dtype, **extra_weight_attrs):

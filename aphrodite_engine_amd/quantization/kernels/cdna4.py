@@ -6,7 +6,8 @@ order [K/8, N] -- no Marlin tile layout, no workspace locks.
 
 Accepted checkpoint parameter layouts (those ``gptq_marlin.py`` and
 ``compressed_tensors_wNa16.py`` hand to an MPLinearKernel):
-  w_q   int32 [K/8, N] packed along K (GPTQ order), uint4b8 or uint4+zp
+  w_q   int32 [K/8, N] packed along K (GPTQ order), uint4b8 or uint4+zp -- or [K/4, N], uint8b128 (round 3: the 8-bit
+        GPTQ kernels of csrc/wnx_gemm.hip behind the same seam, as Marlin serves both widths: kernels/marlin.py:27-31)
   w_s   [G, N]
   w_zp  int32 [G, N/8] packed along N, plain column order (optional)
   g_idx int32 [K] (optional, act-order)
@@ -26,7 +27,7 @@ from .MPLinearKernel import MPLinearKernel, MPLinearLayerConfig
 
 
 class CDNA4LinearKernel(MPLinearKernel):
-    SUPPORTED_TYPES = (scalar_types.uint4b8, scalar_types.uint4)
+    SUPPORTED_TYPES = (scalar_types.uint4b8, scalar_types.uint4, scalar_types.uint8b128)
 
     @classmethod
     def get_min_capability(cls) -> int:
@@ -52,6 +53,8 @@ class CDNA4LinearKernel(MPLinearKernel):
         if c.zero_points != (wt == cls._type_key(scalar_types.uint4)):
             return False, "zero points must accompany uint4 (and only uint4)"
         k, n = c.partition_weight_shape
+        if wt[0] == 8 and c.group_size != -1 and c.group_size % 4 != 0:
+            return False, f"group size {c.group_size} must be a multiple of 4 for 8-bit weights"
         gs = c.group_size if c.group_size != -1 else c.full_weight_shape[0]
         if gs % 32 != 0 or k % gs != 0:
             return False, f"group size {gs} must be a multiple of 32 dividing K={k}"
@@ -77,6 +80,24 @@ class CDNA4LinearKernel(MPLinearKernel):
                 return x.data.t().contiguous()
             return x.data.contiguous()
 
+        layer._cdna4_bits = self._type_key(c.weight_type)[0]
+        if layer._cdna4_bits == 8:
+            # uint8b128: the checkpoint's sequential [K/4, N] words are what gptq_gemm(bit=8) reads (act-order rows made
+            # sequential by gptq_shuffle, as GPTQLinearMethod does); the zero point 128 of every group in GPTQ's
+            # stored-minus-one convention is 127 per byte
+            def seq8(x):
+                w = kn(x)
+                if perm.numel() > 0:
+                    ops.gptq_shuffle(w, perm, 8)
+                return w
+            self._transform_param(layer, self.w_q_name, seq8)
+            self._transform_param(layer, self.w_s_name, kn)
+            groups = getattr(layer, self.w_s_name).shape[0]
+            layer.register_buffer("_cdna4_zp", torch.full((groups, n // 4), 0x7f7f7f7f, dtype=torch.int32, device=device),
+                                  persistent=False)
+            layer._cdna4_perm = perm if perm.numel() > 0 else None
+            return
+
         self._transform_param(
             layer, self.w_q_name,
             lambda x: ops.gptq_marlin_repack(kn(x), perm, k, n, 4))
@@ -98,6 +119,13 @@ class CDNA4LinearKernel(MPLinearKernel):
         if not c.zero_points:
             w_zp = layer._cdna4_zp
         x2 = x.reshape(-1, x.shape[-1])
+        if getattr(layer, "_cdna4_bits", 4) == 8:
+            perm = layer._cdna4_perm
+            out = ops.gptq_gemm(x2, w_q, w_zp, w_s, perm if perm is not None else torch.empty(0, dtype=torch.int32, device=x.device),
+                                True, 8)
+            if bias is not None:
+                out.add_(bias)
+            return out.reshape(x.shape[:-1] + (c.partition_weight_shape[1], ))
         out = ops.wna16_gemm(x2, w_q, w_zp, w_s, layer._cdna4_perm, 0)
         if bias is not None:
             out.add_(bias)

@@ -49,7 +49,7 @@ def fp8_quant(w, per_channel):
 
 def write_checkpoint(path, cfg, fmt, seed=0, group_size=128, kv_scales=None, fp8_static=False,
                      embedded_config=True, fused_on_disk=False, extra_bias=True, bits=4):
-    """fmt: fp16 | gptq | awq | fp8 | ct-fp8-channel | ct-fp8-tensor | ct-w8a16 | ct-w4a16.
+    """fmt: fp16 | gptq | awq | fp8 | ct-fp8-channel | ct-fp8-tensor | ct-w8a16 | ct-w4a16 | ct-w8a16i (int8 pack-quantized).
     kv_scales: None | "kv" (per-layer k_scale + v_scale) | "legacy" (kv_scale) | "ct" ({k,v}_proj.output_scale).
     Returns {"tensors": {hf name: tensor}, "logical": {hf module name: dict of logical matrices}}."""
     os.makedirs(path, exist_ok=True)
@@ -112,11 +112,12 @@ def write_checkpoint(path, cfg, fmt, seed=0, group_size=128, kv_scales=None, fp8
                     iscale = torch.tensor(0.01 + 0.001 * rng.random(), dtype=torch.float32)
                     tensors[name + ".input_scale"] = iscale.reshape(()) if fmt == "fp8" else iscale.reshape(1)
                 logical[name] = {"wq": wq, "s": s, "input_scale": tensors.get(name + ".input_scale")}
-            elif fmt == "ct-w4a16":
-                _, q, s, _ = oq.quantize_weights(w, 4, group_size, zero_points=False)
+            elif fmt in ("ct-w4a16", "ct-w8a16i"):
+                wbits = 4 if fmt == "ct-w4a16" else 8
+                _, q, s, _ = oq.quantize_weights(w, wbits, group_size, zero_points=False)
                 logical[name] = {"q": q, "s": s.astype(np.float16)}
                 tensors[name + ".weight_packed"] = torch.from_numpy(
-                    np.ascontiguousarray(oq.gptq_pack(q, 4).T).astype(np.int32))               # [N, K/8]
+                    np.ascontiguousarray(oq.gptq_pack(q, wbits).T).astype(np.int32))           # [N, K/8] ([N, K/4])
                 tensors[name + ".weight_scale"] = torch.from_numpy(np.ascontiguousarray(s.T).astype(np.float16))
                 tensors[name + ".weight_shape"] = torch.tensor([N, K], dtype=torch.int64)
             else:
@@ -154,14 +155,16 @@ def write_checkpoint(path, cfg, fmt, seed=0, group_size=128, kv_scales=None, fp8
                    "ct-w8a16": {"num_bits": 8, "type": "float", "symmetric": True, "strategy": "channel",
                                 "dynamic": False},
                    "ct-w4a16": {"num_bits": 4, "type": "int", "symmetric": True, "strategy": "group",
-                                "group_size": group_size, "dynamic": False}}[fmt]
+                                "group_size": group_size, "dynamic": False},
+                   "ct-w8a16i": {"num_bits": 8, "type": "int", "symmetric": True, "strategy": "group",
+                                 "group_size": group_size, "dynamic": False}}[fmt]
         acts = None
         if fmt in ("ct-fp8-channel", "ct-fp8-tensor"):
             acts = ({"num_bits": 8, "type": "float", "symmetric": True, "strategy": "tensor", "dynamic": False}
                     if fp8_static else
                     {"num_bits": 8, "type": "float", "symmetric": True, "strategy": "token", "dynamic": True})
         qcfg = {"quant_method": "compressed-tensors",
-                "format": "pack-quantized" if fmt == "ct-w4a16" else "float-quantized",
+                "format": "pack-quantized" if fmt in ("ct-w4a16", "ct-w8a16i") else "float-quantized",
                 "config_groups": {"group_0": {"targets": ["Linear"], "weights": weights,
                                               "input_activations": acts}},
                 "ignore": ["lm_head"]}

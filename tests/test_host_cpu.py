@@ -151,10 +151,13 @@ def test_mp_linear_kernel_selection():
     c = MPLinearLayerConfig((4096, 4096), (4096, 4096), scalar_types.uint4b8, torch.float16,
                             128, False, False)
     assert choose_mp_linear_kernel(c) is CDNA4LinearKernel
-    bad = MPLinearLayerConfig((4096, 4096), (4096, 4096), scalar_types.uint8b128,
-                              torch.float16, 128, False, False)
-    with pytest.raises(ValueError):
-        choose_mp_linear_kernel(bad)
+    c8 = MPLinearLayerConfig((4096, 4096), (4096, 4096), scalar_types.uint8b128, torch.float16, 128, False, False)
+    assert choose_mp_linear_kernel(c8) is CDNA4LinearKernel       # 8-bit symmetric: the wnx kernels behind the same seam
+    for bad in (MPLinearLayerConfig((4096, 4096), (4096, 4096), scalar_types.uint4b8, torch.float16, 48, False, False),
+                MPLinearLayerConfig((4096, 4096), (4096, 4096), scalar_types.uint8b128, torch.float16, 128, True, False),
+                MPLinearLayerConfig((4096, 4096), (4096, 4096), scalar_types.uint4b8, torch.float32, 128, False, False)):
+        with pytest.raises(ValueError):
+            choose_mp_linear_kernel(bad)
     with pytest.raises(ValueError):
         choose_mp_linear_kernel(c, compute_capability=90)   # not gfx950
     lst = ["Machete", "Marlin"]

@@ -192,10 +192,12 @@ def test_fp8_checkpoints(tmp_path, fmt, static):
         check_replicated(m, truth, rank, world)
 
 
-def test_compressed_tensors_pack_quantized(tmp_path):
-    truth = CU.write_checkpoint(str(tmp_path), CFG, "ct-w4a16", seed=4)
+@pytest.mark.parametrize("fmt,bits", [("ct-w4a16", 4), ("ct-w8a16i", 8)])
+def test_compressed_tensors_pack_quantized(tmp_path, fmt, bits):
+    """pack-quantized int4 (uint4b8) and int8 (uint8b128) weights (compressed_tensors_wNa16.py:16-20, 97-135)."""
+    truth = CU.write_checkpoint(str(tmp_path), CFG, fmt, seed=4)
     for rank, world in WORLDS:
-        m = build(tmp_path, "ct-w4a16", rank, world)
+        m = build(tmp_path, fmt, rank, world)
         for li, layer in enumerate(m.layers):
             eq = expected_logical(truth, li, rank, world, "q")
             es = expected_groups(truth, li, rank, world, "s", 128)
@@ -203,10 +205,11 @@ def test_compressed_tensors_pack_quantized(tmp_path):
                 lin = getattr(layer, mod)
                 assert type(lin.quant_method).__name__ == "CompressedTensorsWNA16Method"
                 assert type(lin.kernel).__name__ == "CDNA4LinearKernel"
-                # weight_packed is [N, K/8] packed along K
-                got = oq.gptq_unpack(np.ascontiguousarray(lin.weight_packed.numpy().T))
+                # weight_packed is [N, K/8] ([N, K/4]) packed along K
+                got = oq.gptq_unpack(np.ascontiguousarray(lin.weight_packed.numpy().T), bits)
                 np.testing.assert_array_equal(got, eq[mod], err_msg=mod)
                 np.testing.assert_array_equal(lin.weight_scale.numpy().T, es[mod], err_msg=mod)
+                assert lin.kernel.config.weight_type.size_bits == bits
 
 
 @pytest.mark.parametrize("fmt", ["gptq", "awq"])

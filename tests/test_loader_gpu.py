@@ -32,15 +32,15 @@ def dense_weight(fmt, lg):
     if fmt in ("gptq", "awq"):
         g = np.arange(lg["q"].shape[0]) // 128
         return (lg["q"] - lg["zp"][g]).astype(np.float32) * lg["s"].astype(np.float32)[g]
-    if fmt == "ct-w4a16":
+    if fmt in ("ct-w4a16", "ct-w8a16i"):
         g = np.arange(lg["q"].shape[0]) // 128
-        return (lg["q"] - 8).astype(np.float32) * lg["s"].astype(np.float32)[g]
+        return (lg["q"] - (8 if fmt == "ct-w4a16" else 128)).astype(np.float32) * lg["s"].astype(np.float32)[g]
     w = lg["wq"].float() * lg["s"].float().reshape(-1, 1) if lg["s"].numel() > 1 else lg["wq"].float() * lg["s"]
     return w.numpy().T      # stored [N, K]
 
 
 @pytest.mark.parametrize("fmt", ["fp16", "gptq", "awq", "fp8", "ct-fp8-channel", "ct-fp8-tensor", "ct-w8a16",
-                                 "ct-w4a16"])
+                                 "ct-w4a16", "ct-w8a16i"])
 def test_loaded_checkpoint_linears_and_decode(ops, tmp_path, fmt):
     truth = CU.write_checkpoint(str(tmp_path), CFG, fmt, seed=11,
                                 kv_scales="kv" if fmt == "fp8" else None)

@@ -411,8 +411,8 @@ def test_rotary_tables_golden(golden_dir):
 
 def test_compressed_tensors_scheme_selection_golden(golden_dir):
     """Host logic: CompressedTensorsConfig.get_quant_method vs the reference's _get_scheme_from_parts on its own
-    pydantic QuantizationArgs.  Schemes outside the hot path (int8 W8A8, 2:4 sparse, 8-bit WNA16) must be
-    refused, everything else must select the same scheme with the same arguments."""
+    pydantic QuantizationArgs.  Schemes outside the hot path (int8 W8A8, 2:4 sparse) must be
+    refused, everything else (FP8 W8A8 / W8A16, 4- and 8-bit WNA16) must select the same scheme with the same arguments."""
     import json
     from aphrodite_engine_amd.quantization.compressed_tensors import (CompressedTensorsConfig,
                                                                       CompressedTensorsW8A16Fp8Method,
@@ -420,13 +420,12 @@ def test_compressed_tensors_scheme_selection_golden(golden_dir):
     from aphrodite_engine_amd.quantization.fp8 import CompressedTensorsW8A8Fp8Method
     cases = json.load(open(os.path.join(golden_dir, "ct_schemes.json")))
     assert len(cases) >= 15
-    seen = set()
+    seen, bits_seen = set(), set()
     for c in cases:
         cfg = CompressedTensorsConfig.from_config({"format": c["format"], "config_groups": {"group_0": {
             "targets": ["Linear"], "weights": c["weights"], "input_activations": c["input_activations"]}}})
         want = c["result"]
-        outside = want == "NotImplementedError" or want["scheme"] in ("W4A16Sparse24", "W8A8Int8") or \
-            (want["scheme"] == "WNA16" and want["num_bits"] != 4)
+        outside = want == "NotImplementedError" or want["scheme"] in ("W4A16Sparse24", "W8A8Int8")
         if outside:
             with pytest.raises(NotImplementedError):
                 cfg.get_quant_method(torch.nn.Module(), "model.layers.0.mlp.down_proj")
@@ -441,10 +440,12 @@ def test_compressed_tensors_scheme_selection_golden(golden_dir):
             assert isinstance(m, CompressedTensorsW8A16Fp8Method) and m.strategy == want["strategy"]
         else:
             assert isinstance(m, CompressedTensorsWNA16Method)
+            assert m.pack_factor == 32 // want["num_bits"] and m.quant_type.size_bits == want["num_bits"]
+            bits_seen.add(want["num_bits"])
             assert m.strategy == want["strategy"]
             assert m.group_size == (-1 if want["group_size"] is None else want["group_size"])
             assert m.has_g_idx == (want["actorder"] == "group")
-    assert seen == {"W8A8Fp8", "W8A16Fp8", "WNA16"}
+    assert seen == {"W8A8Fp8", "W8A16Fp8", "WNA16"} and bits_seen == {4, 8}
 
 
 def test_parameter_contracts_golden(golden_dir):

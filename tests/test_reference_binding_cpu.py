@@ -192,8 +192,12 @@ def test_plugin_register_against_the_reference_modules(reference_modules):
     cfg8 = ref.mpk.MPLinearLayerConfig(full_weight_shape=(4096, 4096), partition_weight_shape=(4096, 4096),
                                        weight_type=ref.scalar_types.uint8b128, act_type=torch.float16, group_size=128,
                                        zero_points=False, has_g_idx=False)
+    assert ref.k.choose_mp_linear_kernel(cfg8, 95) is CDNA4LinearKernel       # 8-bit symmetric (GPTQ-Marlin / wNa16 8-bit)
+    cfg48 = ref.mpk.MPLinearLayerConfig(full_weight_shape=(4096, 4096), partition_weight_shape=(4096, 4096),
+                                        weight_type=ref.scalar_types.uint4b8, act_type=torch.float16, group_size=48,
+                                        zero_points=False, has_g_idx=False)
     with pytest.raises(ValueError, match="CDNA4LinearKernel cannot implement"):
-        ref.k.choose_mp_linear_kernel(cfg8, 95)
+        ref.k.choose_mp_linear_kernel(cfg48, 95)
     with pytest.raises(ValueError, match="requires capability 95"):
         ref.k.choose_mp_linear_kernel(cfg, 90)          # an MI300 (9, 4) keeps the reference's kernels
     os.environ["APHRODITE_DISABLED_KERNELS"] = "CDNA4LinearKernel"
