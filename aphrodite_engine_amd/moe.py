@@ -13,7 +13,7 @@ weights read once):
     moe_combine                         routed weight, sum over top-k
 """
 import abc
-from typing import List, Optional, Tuple
+from typing import Callable, List, Optional, Tuple
 
 import torch
 from torch import nn
@@ -65,12 +65,19 @@ class DeferredCombine:
 
 
 def route_and_align(hidden_states: torch.Tensor, gating_output: torch.Tensor, topk: int, renormalize: bool,
-                    num_experts: int, want_inverse: bool = False):
+                    num_experts: int, want_inverse: bool = False, custom_routing_function: Optional[Callable] = None):
     """fused_topk + moe_align_block_size(MOE_BLOCK_M): ONE launch for decode-sized batches (ops.moe_route_align), the
     separate ops above otherwise -- same results either way.  Returns (topk_weights, topk_ids, sorted_ids, expert_ids,
-    num_tokens_post_pad, inv or None)."""
+    num_tokens_post_pad, inv or None).  ``custom_routing_function`` (FusedMoE.select_experts, layer.py:400-430): the
+    model's own routing, called as the reference calls it, then aligned."""
     import os
     t_ = hidden_states.shape[0]
+    if custom_routing_function is not None:
+        topk_weights, topk_ids = custom_routing_function(hidden_states=hidden_states, gating_output=gating_output,
+                                                         topk=topk, renormalize=renormalize)
+        topk_weights, topk_ids = topk_weights.float().contiguous(), topk_ids.to(torch.int32).contiguous()
+        out = moe_align_block_size(topk_ids, MOE_BLOCK_M, num_experts, want_inverse=want_inverse)
+        return (topk_weights, topk_ids) + tuple(out) + (() if want_inverse else (None, ))
     if (0 < t_ * topk <= ops.MOE_ROUTE_ALIGN_MAX_SLOTS and topk <= 8 and gating_output.stride(1) == 1
             and gating_output.dtype in (torch.float16, torch.bfloat16, torch.float32)
             and not os.environ.get("APHRO_MOE_NO_ROUTE_ALIGN")):
@@ -166,7 +173,10 @@ class FusedMoEMethodBase(QuantizeMethodBase):
 
     @abc.abstractmethod
     def apply(self, layer: nn.Module, x: torch.Tensor, router_logits: torch.Tensor, top_k: int,
-              renormalize: bool, use_grouped_topk: bool = False) -> torch.Tensor:
+              renormalize: bool, use_grouped_topk: bool = False, topk_group: Optional[int] = None,
+              num_expert_group: Optional[int] = None,
+              custom_routing_function: Optional[Callable] = None) -> torch.Tensor:
+        """The keyword set FusedMoE.forward passes (layer.py:437-446)."""
         raise NotImplementedError
 
 
@@ -225,7 +235,11 @@ class Wna16MoEMethod(FusedMoEMethodBase):
             for name in ("w13_g_idx", "w2_g_idx"):      # desc_act = False: rows must be in group order
                 gi = getattr(layer, name).data
                 k = gi.shape[1]
-                k0 = layer.tp_rank * k if name == "w2_g_idx" else 0
+                tp_rank = getattr(layer, "tp_rank", None)       # (the reference's FusedMoE keeps only tp_size)
+                if tp_rank is None:
+                    from .distributed import get_tensor_model_parallel_rank
+                    tp_rank = get_tensor_model_parallel_rank() if getattr(layer, "tp_size", 1) > 1 else 0
+                k0 = tp_rank * k if name == "w2_g_idx" else 0
                 want = ((torch.arange(k, device=gi.device) + k0) // self.group_size).to(gi.dtype)
                 if not torch.equal(gi, want.expand_as(gi)):
                     raise ValueError(f"{name}: act-order g_idx found in a checkpoint declared desc_act=false")
@@ -239,13 +253,16 @@ class Wna16MoEMethod(FusedMoEMethodBase):
                 delattr(layer, name)
 
     def apply(self, layer: nn.Module, x: torch.Tensor, router_logits: torch.Tensor, top_k: int,
-              renormalize: bool, use_grouped_topk: bool = False, defer_combine: bool = False) -> torch.Tensor:
+              renormalize: bool, use_grouped_topk: bool = False, topk_group: Optional[int] = None,
+              num_expert_group: Optional[int] = None, custom_routing_function: Optional[Callable] = None,
+              defer_combine: bool = False) -> torch.Tensor:
         if use_grouped_topk:
             raise NotImplementedError("grouped top-k routing (DeepSeek-V2) is outside the hot path")
         if layer.experts_packed is None:
             raise RuntimeError("FusedMoE: process_weights_after_loading has not run")
         topk_weights, topk_ids, sorted_ids, expert_ids, post_pad, inv = route_and_align(
-            x, router_logits, top_k, renormalize, layer.experts_packed.num_experts, want_inverse=True)
+            x, router_logits, top_k, renormalize, layer.experts_packed.num_experts, want_inverse=True,
+            custom_routing_function=custom_routing_function)
         if getattr(layer, "record_routing", False):     # measurement aid: which experts a step touched
             layer.last_topk_ids = topk_ids
         return fused_wna16_moe(x, layer.experts_packed, router_logits, top_k, renormalize,
@@ -374,6 +391,7 @@ class Fp8MoEMethod(FusedMoEMethodBase):
                        params_dtype: torch.dtype, **extra_weight_attrs):
         loader = extra_weight_attrs.get("weight_loader")
         cfg = self.quant_config
+        layer.orig_dtype = params_dtype           # (our FusedMoE sets it too; the reference's layer does not)
         wdt = torch.float8_e4m3fn if cfg.is_checkpoint_fp8_serialized else params_dtype
         e, h, i = num_experts, hidden_size, intermediate_size
         if h % 128 or i % 128:
@@ -439,11 +457,14 @@ class Fp8MoEMethod(FusedMoEMethodBase):
         layer.w2_weight_scale = nn.Parameter(layer.w2_weight_scale.data, requires_grad=False)
 
     def apply(self, layer: nn.Module, x: torch.Tensor, router_logits: torch.Tensor, top_k: int,
-              renormalize: bool, use_grouped_topk: bool = False) -> torch.Tensor:
+              renormalize: bool, use_grouped_topk: bool = False, topk_group: Optional[int] = None,
+              num_expert_group: Optional[int] = None,
+              custom_routing_function: Optional[Callable] = None) -> torch.Tensor:
         if use_grouped_topk:
             raise NotImplementedError("grouped top-k routing (DeepSeek-V2) is outside the hot path")
         topk_weights, topk_ids, sorted_ids, expert_ids, post_pad, _ = route_and_align(
-            x, router_logits, top_k, renormalize, layer.w13_weight.shape[0])
+            x, router_logits, top_k, renormalize, layer.w13_weight.shape[0],
+            custom_routing_function=custom_routing_function)
         if getattr(layer, "record_routing", False):
             layer.last_topk_ids = topk_ids
         return fused_fp8_moe(x, layer.w13_weight, layer.w2_weight, layer.w13_weight_scale, layer.w2_weight_scale,

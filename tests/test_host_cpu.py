@@ -224,7 +224,7 @@ def test_torch_library_registration():
     so the test cannot clash with a real aphrodite._C."""
     from aphrodite_engine_amd import torch_ops
     torch_ops._REGISTERED = False
-    torch_ops.register("_aphro_t_C", "_aphro_t_cache", "_aphro_t_rocm")
+    torch_ops.register("_aphro_t_C", "_aphro_t_cache", "_aphro_t_rocm", "_aphro_t_moe")
     for name in ("paged_attention_v1", "paged_attention_v2", "gptq_gemm", "gptq_shuffle", "awq_gemm",
                  "awq_dequantize", "static_scaled_fp8_quant", "dynamic_scaled_fp8_quant",
                  "dynamic_per_token_scaled_fp8_quant", "cutlass_scaled_mm", "rms_norm",
@@ -248,7 +248,7 @@ def test_cpp_torch_library_registration():
     with the same schemas as the Python registration; it loads without a GPU and has no CPU kernels."""
     from aphrodite_engine_amd import torch_cpp, torch_ops
     torch_cpp.load()
-    torch_ops.register("_aphro_t_C", "_aphro_t_cache", "_aphro_t_rocm")         # idempotent (registered above)
+    torch_ops.register("_aphro_t_C", "_aphro_t_cache", "_aphro_t_rocm", "_aphro_t_moe")         # idempotent (registered above)
     py_ns = [ns for ns in ("_aphro_t_C", "_aphro_g_C", "_C") if hasattr(torch.ops, ns) and hasattr(getattr(torch.ops, ns), "gptq_gemm")]
     strip = lambda sch: str(sch).split("::", 1)[1]
     for name in ("gptq_gemm", "paged_attention_v1", "cutlass_scaled_mm"):

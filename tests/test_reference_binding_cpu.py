@@ -303,3 +303,32 @@ def test_fused_model_registers_through_the_reference_model_registry(monkeypatch)
         for k in [k for k in sys.modules if k == "aphrodite" or k.startswith("aphrodite.") or k == "loguru"]:
             del sys.modules[k]
         sys.modules.update(saved)
+
+
+def test_fused_moe_methods_accept_the_reference_layers_calls():
+    """The reference's FusedMoE drives its quant method with these keywords (modeling/layers/fused_moe/layer.py:211-217
+    create_weights, :437-446 apply) and owns no ``tp_rank`` / ``orig_dtype``: every MoE method the plugin's configs return
+    must accept exactly that -- a TypeError here is a broken drop-in."""
+    import inspect
+    from aphrodite_engine_amd.moe import CompressedTensorsMoEMethod, Fp8MoEMethod, Wna16MoEMethod
+    apply_kw = ("layer", "x", "router_logits", "top_k", "renormalize", "use_grouped_topk", "topk_group", "num_expert_group",
+                "custom_routing_function")
+    create_kw = ("layer", "num_experts", "hidden_size", "intermediate_size", "params_dtype", "weight_loader")
+    for cls in (Wna16MoEMethod, Fp8MoEMethod, CompressedTensorsMoEMethod):
+        sig = inspect.signature(cls.apply)
+        assert all(k in sig.parameters for k in apply_kw), (cls.__name__, list(sig.parameters))
+        sig = inspect.signature(cls.create_weights)
+        has_var_kw = any(p.kind is inspect.Parameter.VAR_KEYWORD for p in sig.parameters.values())
+        assert all(k in sig.parameters or has_var_kw for k in create_kw), cls.__name__
+    # a bare module standing in for the reference's layer: no tp_rank, no orig_dtype
+    import torch
+    from aphrodite_engine_amd.quantization.fp8 import Fp8Config
+
+    class Layer(torch.nn.Module):
+        tp_size = 1
+        intermediate_size_per_partition = 256
+    layer = Layer()
+    m = Fp8Config(True, "dynamic").get_quant_method(type("FusedMoE", (torch.nn.Module, ), {})(), "x.experts")
+    m.create_weights(layer=layer, num_experts=2, hidden_size=256, intermediate_size=256, params_dtype=torch.float16,
+                     weight_loader=lambda *a, **k: None)
+    assert layer.orig_dtype == torch.float16 and layer.w13_weight.shape == (2, 512, 256)
