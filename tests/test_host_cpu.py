@@ -412,3 +412,26 @@ def test_fused_fp8_decode_path_selection():
     assert lib.aphro_fp8_gemm_stream_silu_supported(33, 28672, 4096) == 0            # M <= 32
     assert lib.aphro_fp8_gemm_stream_silu_supported(32, 28672 + 16, 4096) == 0       # halves of 8-row groups
     assert lib.aphro_fp8_gemm_stream_silu_supported(32, 4096, 14336) == 0            # K beyond one workgroup's 8 x 8 segments
+
+
+def test_custom_routing_function_is_called_like_the_reference(monkeypatch):
+    """FusedMoE.select_experts (fused_moe/layer.py:400-430): a model's own routing function is called with
+    hidden_states / gating_output / topk / renormalize keywords and its (weights, ids) go to moe_align_block_size --
+    host wiring, checked with the alignment op stubbed out."""
+    from aphrodite_engine_amd import moe
+    seen = {}
+
+    def routing(hidden_states, gating_output, topk, renormalize):
+        seen.update(h=hidden_states.shape, g=gating_output.shape, k=topk, r=renormalize)
+        w, ids = torch.topk(torch.softmax(gating_output.float(), -1), topk, dim=-1)
+        return w.double(), ids                                  # (wrong dtypes on purpose: int64 ids, f64 weights)
+
+    def fake_align(topk_ids, block_size, num_experts, want_inverse=False):
+        assert topk_ids.dtype == torch.int32 and topk_ids.is_contiguous() and block_size == moe.MOE_BLOCK_M
+        return ("sorted", "experts", "post") + (("inv", ) if want_inverse else ())
+    monkeypatch.setattr(moe, "moe_align_block_size", fake_align)
+    x, g = torch.randn(5, 64), torch.randn(5, 8)
+    w, ids, s, e, p, inv = moe.route_and_align(x, g, 2, True, 8, want_inverse=True, custom_routing_function=routing)
+    assert seen == {"h": x.shape, "g": g.shape, "k": 2, "r": True}
+    assert w.dtype == torch.float32 and ids.dtype == torch.int32 and (s, e, p, inv) == ("sorted", "experts", "post", "inv")
+    assert moe.route_and_align(x, g, 2, False, 8, custom_routing_function=routing)[5] is None
