@@ -114,8 +114,8 @@ class CompressedTensorsConfig(QuantizationConfig):
     def get_quant_method(self, layer: nn.Module, prefix: str) -> Optional[LinearMethodBase]:
         kind = layer_kind(layer)             # compressed_tensors.py:60-79
         if kind == "attention":
-            from .kv_cache import BaseKVCacheMethod
-            return BaseKVCacheMethod(self)
+            from .kv_cache import make_kv_cache_method
+            return make_kv_cache_method(self)
         if kind == "moe":                    # compressed_tensors.py:77-78
             from ..moe import CompressedTensorsMoEMethod
             return CompressedTensorsMoEMethod(self)

@@ -96,8 +96,8 @@ class Fp8Config(QuantizationConfig):
                 return unquantized_linear_method()
             return Fp8LinearMethod(self)
         if kind == "attention":           # k_scale / v_scale of an FP8 KV cache come with the checkpoint
-            from .kv_cache import BaseKVCacheMethod
-            return BaseKVCacheMethod(self)
+            from .kv_cache import make_kv_cache_method
+            return make_kv_cache_method(self)
         if kind == "moe":                 # fp8.py:86-87
             from ..moe import Fp8MoEMethod
             return Fp8MoEMethod(self)

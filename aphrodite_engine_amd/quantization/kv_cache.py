@@ -35,3 +35,22 @@ class BaseKVCacheMethod(QuantizeMethodBase):
             layer._v_scale = v_scale
         del layer.k_scale
         del layer.v_scale
+
+
+_REF_SUBCLASS = {}
+
+
+def make_kv_cache_method(quant_config) -> BaseKVCacheMethod:
+    """What a config's ``get_quant_method`` returns for an Attention layer.  Under the plugin the caller is the
+    REFERENCE's ``Attention.__init__``, which asserts ``isinstance(quant_method, BaseKVCacheMethod)`` against ITS class
+    (attention/layer.py:61-64): when ``aphrodite.quantization.kv_cache`` is importable the instance derives from both
+    (ours first in the MRO: same behaviour, and the assertion holds); standalone it is plainly ours."""
+    try:
+        from aphrodite.quantization.kv_cache import BaseKVCacheMethod as ref_cls
+    except Exception:                # the reference package is not installed / not importable here
+        return BaseKVCacheMethod(quant_config)
+    cls = _REF_SUBCLASS.get(ref_cls)
+    if cls is None:
+        cls = type("BaseKVCacheMethod", (BaseKVCacheMethod, ref_cls), {})
+        _REF_SUBCLASS[ref_cls] = cls
+    return cls(quant_config)

@@ -332,3 +332,32 @@ def test_fused_moe_methods_accept_the_reference_layers_calls():
     m.create_weights(layer=layer, num_experts=2, hidden_size=256, intermediate_size=256, params_dtype=torch.float16,
                      weight_loader=lambda *a, **k: None)
     assert layer.orig_dtype == torch.float16 and layer.w13_weight.shape == (2, 512, 256)
+
+
+@needs_ref
+def test_kv_cache_method_satisfies_the_reference_attention_layer(reference_modules):
+    """attention/layer.py:61-64: the reference's Attention asserts ``isinstance(quant_method, BaseKVCacheMethod)`` against
+    ITS OWN class for whatever the (plugin-registered) config returns.  With the reference's real kv_cache.py /
+    base_config.py loaded, our FP8 and compressed-tensors configs must return something that passes, and behaves like
+    ours (k_scale / v_scale parameters -> python floats)."""
+    import torch
+    sys.modules["aphrodite.common.utils"].print_warning_once = lambda *a, **k: None
+    _load("aphrodite.quantization.base_config", "aphrodite/quantization/base_config.py")
+    ref_kv = _load("aphrodite.quantization.kv_cache", "aphrodite/quantization/kv_cache.py")
+    from aphrodite_engine_amd.quantization.compressed_tensors import CompressedTensorsConfig
+    from aphrodite_engine_amd.quantization.fp8 import Fp8Config
+    from aphrodite_engine_amd.quantization.kv_cache import BaseKVCacheMethod as OursKV
+    ct = CompressedTensorsConfig.from_config({"format": "float-quantized", "config_groups": {
+        "g": {"targets": ["Linear"], "weights": {"num_bits": 8, "type": "float", "strategy": "channel"},
+              "input_activations": {"num_bits": 8, "type": "float", "strategy": "token", "dynamic": True}}}})
+    for cfg in (Fp8Config(True, "dynamic"), ct):
+        attn = type("Attention", (torch.nn.Module, ), {})()
+        attn.kv_cache_dtype = "fp8"
+        m = cfg.get_quant_method(attn, prefix="model.layers.0.self_attn.attn")
+        assert isinstance(m, ref_kv.BaseKVCacheMethod) and isinstance(m, OursKV)
+        assert type(m).create_weights is OursKV.create_weights            # ours first in the MRO
+        m.create_weights(attn)
+        attn.k_scale.data.fill_(0.5)
+        attn.v_scale.data.fill_(0.25)
+        m.process_weights_after_loading(attn)
+        assert (attn._k_scale, attn._v_scale) == (0.5, 0.25) and not hasattr(attn, "k_scale")
