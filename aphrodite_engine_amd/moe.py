@@ -402,10 +402,14 @@ class Fp8MoEMethod(FusedMoEMethodBase):
                                                      weight_loader=loader))
         # two scales for w1 and w3, combined after loading (fp8.py:319-331)
         ser = cfg.is_checkpoint_fp8_serialized
+        # (quant_method = "tensor": how the reference's FusedMoE.weight_loader recognises per-tensor scales, fp8.py:333-336,
+        #  fused_moe/layer.py:340-361)
         layer.register_parameter("w13_weight_scale", _param(torch.ones(e, 2, dtype=torch.float32),
-                                                            weight_loader=loader if ser else None))
+                                                            weight_loader=loader if ser else None,
+                                                            quant_method="tensor" if ser else None))
         layer.register_parameter("w2_weight_scale", _param(torch.ones(e, dtype=torch.float32),
-                                                           weight_loader=loader if ser else None))
+                                                           weight_loader=loader if ser else None,
+                                                           quant_method="tensor" if ser else None))
         if cfg.activation_scheme == "static":
             if not ser:
                 raise ValueError("Found static activation scheme for checkpoint that was not serialized fp8.")

@@ -332,6 +332,8 @@ def test_fused_moe_methods_accept_the_reference_layers_calls():
     m.create_weights(layer=layer, num_experts=2, hidden_size=256, intermediate_size=256, params_dtype=torch.float16,
                      weight_loader=lambda *a, **k: None)
     assert layer.orig_dtype == torch.float16 and layer.w13_weight.shape == (2, 512, 256)
+    # per-tensor scales are recognised by the reference's loader through this attribute (fused_moe/layer.py:340-361)
+    assert layer.w13_weight_scale.quant_method == "tensor" and layer.w2_weight_scale.quant_method == "tensor"
 
 
 @needs_ref
@@ -361,3 +363,67 @@ def test_kv_cache_method_satisfies_the_reference_attention_layer(reference_modul
         attn.v_scale.data.fill_(0.25)
         m.process_weights_after_loading(attn)
         assert (attn._k_scale, attn._v_scale) == (0.5, 0.25) and not hasattr(attn, "k_scale")
+
+
+@needs_ref
+@pytest.mark.parametrize("fmt", ["ct-w4a16-group", "ct-w4a16-channel", "fp8"])
+def test_reference_fused_moe_layer_loads_through_our_expert_methods(reference_modules, fmt):
+    """The reference's REAL FusedMoE (modeling/layers/fused_moe/layer.py, loaded by path) built with OUR config: its
+    __init__ asks our config for the method and calls create_weights with its keywords, its weight_loader (is_transposed,
+    quant_method = group / channel / tensor, weight_shape, TP cut of rank 1 of 2) fills our parameters.  The same tensors
+    through our own FusedMoE must give identical parameters -- the two loaders are independent implementations."""
+    import numpy as np
+    import torch
+    rank, world = 1, 2
+    sys.modules["aphrodite.distributed"].get_tensor_model_parallel_rank = lambda: rank
+    sys.modules["aphrodite.distributed"].get_tensor_model_parallel_world_size = lambda: world
+    sys.modules["aphrodite.distributed"].tensor_model_parallel_all_reduce = lambda x: x
+    _load("aphrodite.quantization.base_config", "aphrodite/quantization/base_config.py")
+    _stub("aphrodite.modeling")
+    _stub("aphrodite.modeling._custom_op", CustomOp=type("CustomOp", (torch.nn.Module, ), {}))
+    from aphrodite_engine_amd.quantization.base_config import set_weight_attrs
+    _stub("aphrodite.modeling.utils", set_weight_attrs=set_weight_attrs)
+    _stub("aphrodite.modeling.layers")
+    _stub("aphrodite.modeling.layers.fused_moe")
+    ref_layer = _load("aphrodite.modeling.layers.fused_moe.layer", "aphrodite/modeling/layers/fused_moe/layer.py")
+    from aphrodite_engine_amd.distributed import simulated_tensor_parallel
+    from aphrodite_engine_amd.moe import FusedMoE as OurFusedMoE
+    from aphrodite_engine_amd.quantization.compressed_tensors import CompressedTensorsConfig
+    from aphrodite_engine_amd.quantization.fp8 import Fp8Config
+    e, h, inter = 2, 256, 512
+    rng = np.random.default_rng(3)
+    if fmt == "fp8":
+        qc = Fp8Config(True, "static")
+    else:
+        w = {"num_bits": 4, "type": "int", "symmetric": True, "strategy": fmt.rsplit("-", 1)[1]}
+        if w["strategy"] == "group":
+            w["group_size"] = 128
+        qc = CompressedTensorsConfig.from_config({"format": "pack-quantized", "config_groups": {
+            "g": {"targets": ["Linear"], "weights": w, "input_activations": None}}})
+    ref_moe = ref_layer.FusedMoE(e, 2, h, inter, params_dtype=torch.float16, quant_config=qc, prefix="m.experts")
+    with simulated_tensor_parallel(rank, world):
+        our_moe = OurFusedMoE(e, 2, h, inter, params_dtype=torch.float16, quant_config=qc, prefix="m.experts")
+    assert type(ref_moe.quant_method) is type(our_moe.quant_method)
+    for x in range(e):
+        for shard, n, k in (("w1", inter, h), ("w3", inter, h), ("w2", h, inter)):
+            fused = "w13_" if shard != "w2" else "w2_"
+            if fmt == "fp8":
+                tensors = {"weight": torch.from_numpy(rng.integers(0, 120, (n, k)).astype(np.uint8)).view(torch.float8_e4m3fn),
+                           "weight_scale": torch.tensor(0.01 * (1 + x) + 0.001 * len(shard)),
+                           "input_scale": torch.tensor(0.5 + 0.1 * x)}
+            else:
+                g = 1 if fmt.endswith("channel") else k // 128
+                tensors = {"weight_packed": torch.from_numpy(rng.integers(-2 ** 31, 2 ** 31 - 1, (n, k // 8)).astype(np.int32)),
+                           "weight_scale": torch.from_numpy(rng.random((n, g)).astype(np.float16)),
+                           "weight_shape": torch.tensor([n, k])}
+            for suffix, t_ in tensors.items():
+                name = f"m.experts.{x}.{shard}.{suffix}"
+                for moe_ in (ref_moe, our_moe):
+                    moe_.weight_loader(getattr(moe_, fused + suffix), t_.clone(), name, shard, x)
+    names = [n for n, _ in our_moe.named_parameters()]
+    assert sorted(names) == sorted(n for n, _ in ref_moe.named_parameters())
+    for n in names:
+        a, b = getattr(ref_moe, n).data, getattr(our_moe, n).data
+        assert a.shape == b.shape and a.dtype == b.dtype, n
+        assert torch.equal(a.view(torch.uint8) if a.dtype == torch.float8_e4m3fn else a,
+                           b.view(torch.uint8) if b.dtype == torch.float8_e4m3fn else b), n
