@@ -75,6 +75,31 @@ class MI355XAttentionMetadata:
             block_tables=self.block_tables[self.num_prefills:],
             use_cuda_graph=self.use_cuda_graph)
 
+    def advance_step(self, model_input, sampled_token_ids: Optional[torch.Tensor], block_size: int, num_seqs: int,
+                     num_queries: int) -> None:
+        """Multi-step decoding (rocm_flash_attn.py:185-229): move a decode-only batch one token ahead IN PLACE -- the host
+        list of sequence lengths for the real queries (a graph-padded batch has num_seqs > num_queries), and on the device
+        input_tokens / input_positions / seq_lens / slot_mapping through ``advance_step_flashattn``
+        (prepare_inputs/advance_step.cu), so that the next step needs no host-side input preparation."""
+        if num_seqs != num_queries:
+            if num_seqs < num_queries or not self.use_cuda_graph:
+                raise ValueError("advance_step: a padded batch (num_seqs > num_queries) is a graph-captured one")
+        ok = (self.num_prefills == 0 and self.num_prefill_tokens == 0 and self.num_decode_tokens == num_seqs
+              and self.slot_mapping.shape == (num_seqs, ) and self.seq_lens is not None and len(self.seq_lens) == num_seqs
+              and self.seq_lens_tensor is not None and self.seq_lens_tensor.shape == (num_seqs, )
+              and self.max_query_len == 1 and self.max_prefill_seq_len == 0
+              and self.max_decode_seq_len == max(self.seq_lens)
+              and self.block_tables is not None and self.block_tables.shape[0] == num_seqs)
+        if not ok:
+            raise ValueError("advance_step: the metadata is not that of a decode-only batch of num_seqs sequences")
+        for i in range(num_queries):
+            self.seq_lens[i] += 1
+        self.max_decode_seq_len = max(self.seq_lens)
+        ops.advance_step_flashattn(num_seqs=num_seqs, num_queries=num_queries, block_size=block_size,
+                                   input_tokens=model_input.input_tokens, sampled_token_ids=sampled_token_ids,
+                                   input_positions=model_input.input_positions, seq_lens=self.seq_lens_tensor,
+                                   slot_mapping=self.slot_mapping, block_tables=self.block_tables)
+
 
 class MI355XAttentionBackend:
     @staticmethod
@@ -151,7 +176,12 @@ class MI355XAttentionImpl:
 
     def forward(self, query: torch.Tensor, key: torch.Tensor, value: torch.Tensor,
                 kv_cache: Optional[torch.Tensor], attn_metadata: MI355XAttentionMetadata,
-                k_scale: float = 1.0, v_scale: float = 1.0) -> torch.Tensor:
+                k_scale: float = 1.0, v_scale: float = 1.0, attn_type=None) -> torch.Tensor:
+        """``attn_type``: the reference's Attention layer passes it by keyword (attention/layer.py:99-106); anything but
+        AttentionType.DECODER is refused as by ROCmFlashAttentionImpl (rocm_flash_attn.py:395-399)."""
+        if attn_type is not None and getattr(attn_type, "name", str(attn_type)) != "DECODER":
+            raise NotImplementedError("Encoder self-attention and encoder/decoder cross-attention are not implemented for "
+                                      "MI355XAttentionImpl")
         num_tokens, hidden_size = query.shape
         query = query.view(-1, self.num_heads, self.head_size)
         key = key.view(-1, self.num_kv_heads, self.head_size)

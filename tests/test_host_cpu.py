@@ -435,3 +435,42 @@ def test_custom_routing_function_is_called_like_the_reference(monkeypatch):
     assert seen == {"h": x.shape, "g": g.shape, "k": 2, "r": True}
     assert w.dtype == torch.float32 and ids.dtype == torch.int32 and (s, e, p, inv) == ("sorted", "experts", "post", "inv")
     assert moe.route_and_align(x, g, 2, False, 8, custom_routing_function=routing)[5] is None
+
+
+def test_attention_impl_and_metadata_take_the_reference_layers_calls(monkeypatch):
+    """What the reference's Attention layer and multi-step runner call on a backend: ``impl.forward(..., attn_type=)``
+    (attention/layer.py:99-106; non-decoder types refused as rocm_flash_attn.py:395-399) and
+    ``attn_metadata.advance_step(model_input, sampled_token_ids, block_size, num_seqs, num_queries)``
+    (rocm_flash_attn.py:185-229): host bookkeeping here, the device update through advance_step_flashattn (stubbed)."""
+    import enum
+    import inspect
+    import types
+    from aphrodite_engine_amd.attention import backend as B
+    assert "attn_type" in inspect.signature(B.MI355XAttentionImpl.forward).parameters
+    AttentionType = enum.Enum("AttentionType", ["DECODER", "ENCODER", "ENCODER_DECODER"])
+    impl = B.MI355XAttentionImpl(4, 128, 0.1, 2)
+    with pytest.raises(NotImplementedError):
+        impl.forward(torch.zeros(1, 512), torch.zeros(1, 256), torch.zeros(1, 256), None, None, attn_type=AttentionType.ENCODER)
+    calls = {}
+    monkeypatch.setattr(B.ops, "advance_step_flashattn", lambda **kw: calls.update(kw))
+    n_seqs, n_q = 4, 3                                        # a graph-padded batch: one padding row
+    md = B.MI355XAttentionMetadata(
+        num_prefills=0, num_prefill_tokens=0, num_decode_tokens=n_seqs, slot_mapping=torch.zeros(n_seqs, dtype=torch.int64),
+        seq_lens=[5, 9, 2, 1], seq_lens_tensor=torch.tensor([5, 9, 2, 1], dtype=torch.int32), max_query_len=1,
+        max_prefill_seq_len=0, max_decode_seq_len=9, query_start_loc=None, seq_start_loc=None, context_lens_tensor=None,
+        block_tables=torch.zeros(n_seqs, 2, dtype=torch.int32), use_cuda_graph=True)
+    mi = types.SimpleNamespace(input_tokens=torch.zeros(n_seqs, dtype=torch.int64),
+                               input_positions=torch.zeros(n_seqs, dtype=torch.int64))
+    sampled = torch.tensor([[7], [8], [9]])
+    md.advance_step(mi, sampled, 16, n_seqs, n_q)
+    assert md.seq_lens == [6, 10, 3, 1] and md.max_decode_seq_len == 10          # only the real queries move
+    assert calls["num_seqs"] == n_seqs and calls["num_queries"] == n_q and calls["block_size"] == 16
+    assert calls["sampled_token_ids"] is sampled and calls["seq_lens"] is md.seq_lens_tensor
+    assert calls["input_tokens"] is mi.input_tokens and calls["slot_mapping"] is md.slot_mapping
+    assert md.decode_metadata.max_decode_seq_len == 10
+    md.use_cuda_graph = False
+    with pytest.raises(ValueError):
+        md.advance_step(mi, sampled, 16, n_seqs, n_q)                            # padding without a captured graph
+    md2 = B.MI355XAttentionMetadata(**{**md.__dict__, "num_prefills": 1})
+    with pytest.raises(ValueError):
+        md2.advance_step(mi, sampled, 16, n_seqs, n_seqs)                        # not a decode-only batch
