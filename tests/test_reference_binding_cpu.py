@@ -515,3 +515,34 @@ def test_reference_linear_layers_load_through_our_linear_methods(reference_modul
                 av = a.data.view(torch.uint8) if a.dtype == torch.float8_e4m3fn else a.data
                 bv = b.data.view(torch.uint8) if b.dtype == torch.float8_e4m3fn else b.data
                 assert torch.equal(av, bv), (fmt, mod, n)
+
+
+def test_moe_apply_runs_with_the_reference_layers_keywords(monkeypatch):
+    """FusedMoE.forward's call (fused_moe/layer.py:437-446), keyword for keyword, through both apply bodies with the GPU
+    pieces stubbed: the routing helper must receive the model's custom routing function, the expert kernels the aligned
+    lists."""
+    import types
+    import torch
+    from aphrodite_engine_amd import moe
+    seen = {}
+
+    def fake_route(x, logits, top_k, renorm, num_experts, want_inverse=False, custom_routing_function=None):
+        seen["route"] = (top_k, renorm, num_experts, want_inverse, custom_routing_function)
+        return ("w", "ids", "sorted", "experts", "post", "inv" if want_inverse else None)
+    monkeypatch.setattr(moe, "route_and_align", fake_route)
+    monkeypatch.setattr(moe, "fused_wna16_moe", lambda *a, **k: seen.update(int4=(a, k)) or "int4-out")
+    monkeypatch.setattr(moe, "fused_fp8_moe", lambda *a, **k: seen.update(fp8=(a, k)) or "fp8-out")
+    routing = lambda **k: None                                                    # noqa: E731
+    x, logits = torch.zeros(3, 8), torch.zeros(3, 4)
+    kw = dict(x=x, router_logits=logits, top_k=2, renormalize=True, use_grouped_topk=False, topk_group=None,
+              num_expert_group=None, custom_routing_function=routing)
+    layer = types.SimpleNamespace(experts_packed=types.SimpleNamespace(num_experts=4))
+    assert moe.Wna16MoEMethod("gptq", 128).apply(layer=layer, **kw) == "int4-out"
+    assert seen["route"] == (2, True, 4, True, routing)
+    assert seen["int4"][1]["aligned"] == ("sorted", "experts", "post", "inv") and seen["int4"][1]["topk_ids"] == "ids"
+    layer = types.SimpleNamespace(w13_weight=torch.zeros(4, 2, 2), w2_weight=torch.zeros(4, 2, 2), w13_weight_scale=None,
+                                  w2_weight_scale=None, w13_input_scale=None, w2_input_scale=None)
+    assert moe.Fp8MoEMethod(types.SimpleNamespace()).apply(layer=layer, **kw) == "fp8-out"
+    assert seen["route"] == (2, True, 4, False, routing) and seen["fp8"][1]["aligned"] == ("sorted", "experts", "post")
+    with pytest.raises(NotImplementedError):
+        moe.Wna16MoEMethod("gptq", 128).apply(layer=layer, **{**kw, "use_grouped_topk": True})
