@@ -546,3 +546,53 @@ def test_moe_apply_runs_with_the_reference_layers_keywords(monkeypatch):
     assert seen["route"] == (2, True, 4, False, routing) and seen["fp8"][1]["aligned"] == ("sorted", "experts", "post")
     with pytest.raises(NotImplementedError):
         moe.Wna16MoEMethod("gptq", 128).apply(layer=layer, **{**kw, "use_grouped_topk": True})
+
+
+@needs_ref
+@pytest.mark.parametrize("kv_cache_dtype", ["auto", "fp8"])
+def test_reference_attention_layer_over_our_backend_and_kv_method(reference_modules, kv_cache_dtype):
+    """The reference's REAL Attention layer (attention/layer.py, loaded by path): built with our FP8 config and with
+    ``get_attn_backend`` handing out MI355XAttentionBackend (what the selector's ROCm branch is pointed at, INTEGRATION
+    §1.4).  Its __init__ asserts the KV method's type, lets it register k_scale / v_scale, and constructs our impl with
+    its nine positional arguments; after "loading" the scales our method turns them into the floats the layer passes to
+    ``impl.forward(..., k_scale, v_scale, attn_type=)``."""
+    import enum
+    import types
+    import torch
+    from aphrodite_engine_amd.attention.backend import MI355XAttentionBackend, MI355XAttentionImpl
+    from aphrodite_engine_amd.quantization.fp8 import Fp8Config
+    sys.modules["aphrodite.common.utils"].print_warning_once = lambda *a, **k: None
+    _load("aphrodite.quantization.base_config", "aphrodite/quantization/base_config.py")
+    _load("aphrodite.quantization.kv_cache", "aphrodite/quantization/kv_cache.py")
+    AttentionType = enum.Enum("AttentionType", ["DECODER", "ENCODER", "ENCODER_DECODER"])
+    _stub("aphrodite.attention", AttentionMetadata=object, AttentionType=AttentionType)
+    picked = {}
+
+    def get_attn_backend(head_size, sliding_window, dtype, kv_dtype, block_size, is_attention_free, is_blocksparse=False):
+        picked.update(head_size=head_size, kv=kv_dtype, block=block_size)
+        return MI355XAttentionBackend
+    _stub("aphrodite.attention.selector", get_attn_backend=get_attn_backend)
+    _stub("aphrodite.common.config", CacheConfig=object)
+    ref_attn = _load("aphrodite.attention.layer", "aphrodite/attention/layer.py")
+    cache_config = types.SimpleNamespace(cache_dtype=kv_cache_dtype, block_size=16, sliding_window=None,
+                                         is_attention_free=False)
+    layer = ref_attn.Attention(32, 128, 128 ** -0.5, num_kv_heads=8, cache_config=cache_config,
+                               quant_config=Fp8Config(True, "dynamic"), prefix="model.layers.0.self_attn.attn")
+    assert picked == {"head_size": 128, "kv": kv_cache_dtype, "block": 16}
+    assert isinstance(layer.impl, MI355XAttentionImpl) and (layer.impl.num_heads, layer.impl.num_kv_heads) == (32, 8)
+    assert layer.impl.kv_cache_dtype == kv_cache_dtype
+    assert isinstance(layer.k_scale, torch.nn.Parameter) and isinstance(layer.v_scale, torch.nn.Parameter)
+    layer.k_scale.data.fill_(0.02)                    # what default_weight_loader leaves from self_attn.k_scale
+    layer.v_scale.data.fill_(0.03)
+    layer.quant_method.process_weights_after_loading(layer)
+    if kv_cache_dtype == "fp8":
+        assert (layer._k_scale, layer._v_scale) == (pytest.approx(0.02), pytest.approx(0.03))
+    else:
+        assert (layer._k_scale, layer._v_scale) == (1.0, 1.0)      # ignored without an fp8 cache (kv_cache.py:37-75)
+    assert not hasattr(layer, "k_scale")
+    # the layer's forward hands everything to impl.forward, attn_type by keyword
+    got = {}
+    layer.impl.forward = lambda *a, **k: got.update(a=a, k=k) or "out"
+    q = torch.zeros(1, 32 * 128)
+    assert layer.forward(q, q[:, :1024], q[:, :1024], None, None) == "out"
+    assert got["a"][5:] == (layer._k_scale, layer._v_scale) and got["k"] == {"attn_type": AttentionType.DECODER}
