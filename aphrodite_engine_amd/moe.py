@@ -198,6 +198,9 @@ class Wna16MoEMethod(FusedMoEMethodBase):
             raise ValueError(f"unknown int4 expert layout {layout}")
         if desc_act:
             raise NotImplementedError("act-order (desc_act) GPTQ experts are not supported by the grouped kernel")
+        if group_size != -1 and (group_size <= 0 or group_size % 128 or (group_size // 128) & (group_size // 128 - 1)):
+            # (refused here, at construction, not by the kernel's plan at the first forward)
+            raise NotImplementedError(f"int4 experts with group size {group_size}: the grouped kernel serves 128 x 2^n")
         self.layout, self.group_size = layout, group_size
 
     def create_weights(self, layer: nn.Module, num_experts: int, hidden_size: int, intermediate_size: int,

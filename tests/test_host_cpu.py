@@ -474,3 +474,12 @@ def test_attention_impl_and_metadata_take_the_reference_layers_calls(monkeypatch
     md2 = B.MI355XAttentionMetadata(**{**md.__dict__, "num_prefills": 1})
     with pytest.raises(ValueError):
         md2.advance_step(mi, sampled, 16, n_seqs, n_seqs)                        # not a decode-only batch
+
+
+def test_int4_expert_methods_refuse_group_sizes_the_grouped_kernel_does_not_serve():
+    from aphrodite_engine_amd.moe import Wna16MoEMethod
+    for ok in (128, 256, 512):
+        assert Wna16MoEMethod("gptq", ok).group_size == ok
+    for bad in (32, 64, 192, 0):
+        with pytest.raises(NotImplementedError):
+            Wna16MoEMethod("gptq", bad)
