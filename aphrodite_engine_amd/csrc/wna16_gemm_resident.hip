@@ -542,6 +542,431 @@ __global__ __launch_bounds__(NWV * 64, NWV <= 4 ? 1 : 2) void wna16_gemm_residen
   }
 }
 
+// ---- round 4: the same GEMM with BOTH streams through an LDS ring ("ring" kernel) ---------------------------------------
+// What the round-3 kernel above loses against the pure data-movement floor of its own launch shape (tools/inbound_probe.hip:
+// 256 KB of weights + 256 KB of A per CU move in 12.9-13.1 us through `buffer_load ... lds`, 14.2 us through registers; the
+// kernel needs 16.2-17.3 us on gate_up), and what this form changes:
+//   * two column passes with the activations kept in registers put ALL the A traffic into the first pass (the first pass
+//     runs at the ~47 GB/s a CU's vector-memory path carries, the second at the HBM share of ~21 GB/s: profiles/
+//     r3_resident_trace.txt).  Here every k-step covers ALL the strip's columns: A is used once, streams at the same depth
+//     as the weights, and the mix is uniform over the whole kernel;
+//   * neither stream touches a VGPR on its way in: `buffer_load ... lds` into a per-wave ring of R k-step slots
+//     (slot = MT A pieces + NP4 16-byte weight pieces + one 4 REM-byte piece, lane-linear), so the depth in flight is a
+//     matter of LDS (R = 8: 30 KB per wave on gate_up), not of registers and not of what the compiler can keep apart;
+//   * the waits are written by hand (loads return in order: vmcnt(n) = "everything but the n youngest has landed"), the
+//     fragment reads are inline asm (a ds_read hipcc can see gets a conservative vmcnt(0)-style wait against every LDS-DMA
+//     in flight, see lm_head.hip) and run one k-step ahead of the MFMAs into a second register set.
+// Same arithmetic, same K partition over waves and slices as the kernel above for the same (NWV, NSEG): the slabs / packed
+// results are bit-identical to it.
+template <int MT, int NWV, int NP4, int REM>
+__device__ __forceinline__ void res_reduce_store(const Wna16ResParams& p, float* red, int WP, int ky, int cb, int mtiles) {
+  constexpr int CW = 64 * NP4 + 16 * REM;
+  constexpr int CWP = CW + 4;
+  constexpr int ROWS = 16 * MT;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  const int tid = threadIdx.x;
+  if (p.act_packed != nullptr) {
+    constexpr int UNITS = ROWS * (CW / 16);
+    for (int unit = tid; unit < UNITS; unit += NWV * 64) {
+      const int ch = unit / ROWS, row = unit % ROWS;
+      float v[16];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 sum = zero4;
+#pragma unroll
+        for (int w2 = 0; w2 < NWV; ++w2) sum += *reinterpret_cast<const f32x4*>(&red[w2 * WP + row * CWP + 16 * ch + 4 * q]);
+        v[4 * q] = sum[0]; v[4 * q + 1] = sum[1]; v[4 * q + 2] = sum[2]; v[4 * q + 3] = sum[3];
+      }
+      uint16_t o[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        if (p.is_bf16) {
+          o[q] = bf16_bits_to_f16_bits_sat(silu_mul_bits<BFloat>(BFloat::to_f32(BFloat::from_f32(v[2 * q])), BFloat::to_f32(BFloat::from_f32(v[2 * q + 1]))));
+        } else {
+          o[q] = silu_mul_bits<Half>(Half::to_f32(Half::from_f32(v[2 * q])), Half::to_f32(Half::from_f32(v[2 * q + 1])));
+        }
+      }
+      const int j0 = (cb + 16 * ch) >> 1;
+      uint16_t* dst = p.act_packed + ((((size_t)(j0 >> 7) * 4 + ((j0 & 31) >> 3)) * mtiles + (row >> 4)) * 64 + ((j0 & 127) >> 5) * 16 + (row & 15)) * 8;
+      if (row < p.M)
+        *reinterpret_cast<u32x4*>(dst) = u32x4{(uint32_t)o[0] | ((uint32_t)o[1] << 16), (uint32_t)o[2] | ((uint32_t)o[3] << 16),
+                                               (uint32_t)o[4] | ((uint32_t)o[5] << 16), (uint32_t)o[6] | ((uint32_t)o[7] << 16)};
+    }
+  } else if (p.ksplit > 1 || p.force_partial) {
+    constexpr int UNITS = ROWS * (CW / 4);
+    for (int unit = tid; unit < UNITS; unit += NWV * 64) {
+      const int row = unit / (CW / 4), c4 = unit % (CW / 4);
+      f32x4 sum = zero4;
+#pragma unroll
+      for (int w2 = 0; w2 < NWV; ++w2) sum += *reinterpret_cast<const f32x4*>(&red[w2 * WP + row * CWP + 4 * c4]);
+      if (row < p.M) *reinterpret_cast<f32x4*>(p.partial + ((size_t)ky * p.M + row) * p.N + cb + 4 * c4) = sum;
+    }
+  } else {
+    constexpr int UNITS = ROWS * (CW / 8);
+    for (int unit = tid; unit < UNITS; unit += NWV * 64) {
+      const int row = unit / (CW / 8), c8 = unit % (CW / 8);
+      f32x4 s0 = zero4, s1 = zero4;
+#pragma unroll
+      for (int w2 = 0; w2 < NWV; ++w2) {
+        s0 += *reinterpret_cast<const f32x4*>(&red[w2 * WP + row * CWP + 8 * c8]);
+        s1 += *reinterpret_cast<const f32x4*>(&red[w2 * WP + row * CWP + 8 * c8 + 4]);
+      }
+      uint16_t o[8];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        o[q] = p.is_bf16 ? BFloat::from_f32(s0[q]) : Half::from_f32(s0[q]);
+        o[4 + q] = p.is_bf16 ? BFloat::from_f32(s1[q]) : Half::from_f32(s1[q]);
+      }
+      if (row < p.M)
+        *reinterpret_cast<u32x4*>(p.c + (size_t)row * p.N + cb + 8 * c8) =
+            u32x4{(uint32_t)o[0] | ((uint32_t)o[1] << 16), (uint32_t)o[2] | ((uint32_t)o[3] << 16),
+                  (uint32_t)o[4] | ((uint32_t)o[5] << 16), (uint32_t)o[6] | ((uint32_t)o[7] << 16)};
+    }
+  }
+}
+
+// (free functions: hipcc does not capture a variable that a nested generic lambda names in an asm operand only)
+template <int OFF>
+__device__ __forceinline__ void ring_read128(u32x4& dst, uint32_t addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
+}
+template <typename T>
+__device__ __forceinline__ void ring_touch(T& x) { asm volatile("" : "+v"(x)); }
+template <int OFF>
+__device__ __forceinline__ void ring_read32(uint32_t& dst, uint32_t addr) {
+  asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
+}
+
+// vector-memory instructions of one k-step's ring refill / of one segment's scale + zero loads
+template <int MT, int NP4, int REM>
+constexpr int ring_per_step() { return MT + NP4 + (REM == 2 ? 2 : (REM > 0 ? 1 : 0)); }
+template <int NP4, int REM>
+constexpr int ring_meta_ops() { return 2 * NP4 + (REM == 0 ? 0 : (REM == 1 ? 2 : (REM == 2 ? 2 : 5))); }
+
+// DMA = false: the same single-pass schedule with both streams in REGISTER rings of R k-steps (plain buffer loads, hipcc's
+// own vmcnt accounting, no LDS on the way in): an LDS-DMA instruction costs its wave 60-185 cycles of issue
+// (MI355X_MICROARCH.md), 4 per k-step here against ~330 cycles of MFMA + unpack issue.
+template <int MT, int NWV, int NSEG, int NP4, int REM, int R, bool DMA = true, bool TRACE = false>
+__global__ __launch_bounds__(NWV * 64, NWV <= 4 ? 1 : 2) void wna16_gemm_ring_kernel(Wna16ResParams p) {
+  constexpr int NST = NSEG * 4;                     // k-steps of a wave
+  constexpr int CW = 64 * NP4 + 16 * REM;
+  constexpr int CWP = CW + 4;
+  constexpr int ROWS = 16 * MT;
+  constexpr int NT = 4 * NP4 + REM;                 // 16-column MFMA tiles of the strip
+  constexpr int PER = ring_per_step<MT, NP4, REM>();
+  constexpr int NMETA = ring_meta_ops<NP4, REM>();
+  constexpr int REMB = REM == 3 ? 1024 : 256 * REM;   // a 12-byte `buffer_load ... lds` lands at 16 bytes per lane (probed: 12 data + 4 skipped)
+  constexpr int SLOT = 1024 * (MT + NP4) + REMB;
+  constexpr int RR = R < NST ? R : NST;
+  constexpr int WPB = (DMA && RR * SLOT > ROWS * CWP * 4 ? RR * SLOT : ROWS * CWP * 4);   // bytes per wave: ring, later the reduction tile
+  constexpr int WP = WPB / 4;
+  extern __shared__ __attribute__((aligned(16))) float red[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4;
+  const int c = lane & 15;
+  unsigned long long stamp[TRACE ? 16 : 1] = {};
+  unsigned long long wall0 = 0;
+  if constexpr (TRACE) wall0 = __builtin_amdgcn_s_memrealtime();
+  RES_STAMP(0);
+  const int S = gridDim.x;
+  int strip, ky;
+  if (gridDim.y > 1 && 8 % gridDim.y == 0 && S % (8 / gridDim.y) == 0) {
+    const int L = blockIdx.y * S + blockIdx.x, xcd = L & 7, idx = L >> 3, per = 8 / gridDim.y;
+    ky = xcd / per;
+    strip = (xcd % per) * (S / per) + idx;
+  } else {
+    strip = (S & 7) == 0 ? (int)(blockIdx.x & 7) * (S >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    ky = blockIdx.y;
+  }
+  const int seg0 = (ky * NWV + wave) * NSEG;
+  const int cb = strip * CW;
+  const int mtiles = (p.M + 15) >> 4;
+
+  const __amdgpu_buffer_rsrc_t rw = res_rsrc(p.qw, (uint32_t)((size_t)(p.K >> 3) * p.N * 4));
+  const __amdgpu_buffer_rsrc_t ra = res_rsrc(p.apk, (uint32_t)((size_t)(p.K >> 7) * 4 * mtiles * 1024));
+  const int ngroups = (p.K >> 7) >> p.gshift;
+  const __amdgpu_buffer_rsrc_t rs_ = res_rsrc(p.sc, (uint32_t)((size_t)ngroups * p.N * 2));
+  const __amdgpu_buffer_rsrc_t rz = res_rsrc(p.qz, (uint32_t)((size_t)ngroups * (p.N >> 3) * 4));
+
+  int voff_w4, voff_wr, sbase, ss4, su4, ssr, sur, poff4, poffr;
+  if (p.strip_layout) {
+    constexpr int WAVE_BYTES = NSEG * 4 * 64 * (16 * NP4 + 4 * REM);
+    sbase = ((ky * S + strip) * NWV + wave) * WAVE_BYTES;
+    voff_w4 = lane * 16; voff_wr = lane * 4 * REM;
+    ss4 = 4096; su4 = 1024; ssr = 1024 * REM; sur = 256 * REM;
+    poff4 = NSEG * 4096; poffr = NP4 * NSEG * 4096;
+  } else {
+    sbase = seg0 * 16 * p.N * 4;
+    voff_w4 = (4 * g * p.N + cb + 4 * c) * 4; voff_wr = (4 * g * p.N + cb + 64 * NP4 + REM * c) * 4;
+    ss4 = ssr = 16 * p.N * 4; su4 = sur = p.N * 4;
+    poff4 = 256; poffr = 0;
+  }
+  int voff_a[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) voff_a[i] = (min(i, mtiles - 1) * 64 + lane) * 16;
+  const int abytes = mtiles * 1024;
+  const int col4 = cb + 4 * c;
+  const int colr = cb + 64 * NP4 + REM * c;
+  const int voff_s4 = col4 * 2, voff_z4 = (col4 >> 3) * 4, zshift4 = (col4 & 7) * 4;
+  const int voff_sr = colr * 2, voff_zr0 = (colr >> 3) * 4, voff_zr1 = ((colr + (REM > 0 ? REM - 1 : 0)) >> 3) * 4;
+  const int zshiftr = (colr & 7) * 4;
+  const float zoff = (float)p.zero_offset;
+  const f16x8 ones = {(f16)1.f, (f16)1.f, (f16)16.f, (f16)16.f, (f16)1.f, (f16)1.f, (f16)16.f, (f16)16.f};
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+  unsigned char* const ring = reinterpret_cast<unsigned char*>(red) + (size_t)wave * WPB;
+  const uint32_t rd16 = (uint32_t)(uintptr_t)(res_lds_ptr)(ring + lane * 16);              // 16-byte pieces
+  const uint32_t rdr = (uint32_t)(uintptr_t)(res_lds_ptr)(ring + lane * 4);                // the 4-byte REM piece(s)
+
+  struct RingMeta { uint32_t sc[NP4 > 0 ? 2 * NP4 : 1], z[NP4 > 0 ? NP4 : 1], scr[3], zr0, zr1; };
+  RingMeta meta[2];
+  f32x4 cacc[MT][NT], acc[MT][NT], rs[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    rs[i] = zero4;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { cacc[i][t] = zero4; acc[i][t] = zero4; }
+  }
+
+  // fragment registers of two k-steps: [I & 1]
+  constexpr int NSET = DMA ? 2 : RR + 1;    // (registers: one more set than k-steps in flight, the refill of step I + RR
+                                            //  must not land on the set step I is computing from)
+  u32x4 fa[NSET][MT], fw[NSET][NP4 > 0 ? NP4 : 1];
+  uint32_t fr[NSET][REM > 0 ? REM : 1];
+  u32x4 fr4[NSET];                             // REM == 3: the 12-byte piece, read as 16
+  auto refill = [&](auto I_) {            // k-step I -> slot I % RR: PER instructions
+    constexpr int I = decltype(I_)::value;
+    constexpr int s = I / 4, u = I % 4;
+    if constexpr (!DMA) {
+      constexpr int B = I % NSET;
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const int vo = voff_a[i];
+        fa[B][i] = __builtin_amdgcn_raw_buffer_load_b128(ra, vo, ((seg0 + s) * 4 + u) * abytes, 0);
+      }
+#pragma unroll
+      for (int pp = 0; pp < NP4; ++pp) fw[B][pp] = __builtin_amdgcn_raw_buffer_load_b128(rw, voff_w4, sbase + pp * poff4 + s * ss4 + u * su4, 2);
+      const int so = sbase + poffr + s * ssr + u * sur;
+      if constexpr (REM == 3) {
+        typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+        const u32x3 v = __builtin_amdgcn_raw_buffer_load_b96(rw, voff_wr, so, 2);
+        fr4[B] = u32x4{v[0], v[1], v[2], 0u};
+      } else if constexpr (REM == 2) {
+        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rw, voff_wr, so, 2);
+        fr[B][0] = v[0]; fr[B][1] = v[1];
+      } else if constexpr (REM == 1) {
+        fr[B][0] = __builtin_amdgcn_raw_buffer_load_b32(rw, voff_wr, so, 2);
+      }
+      return;
+    }
+    unsigned char* const slot = ring + (I % RR) * SLOT;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int vo = voff_a[i];
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (res_lds_ptr)(slot + i * 1024), 16, vo, ((seg0 + s) * 4 + u) * abytes, 0, 0);
+    }
+#pragma unroll
+    for (int pp = 0; pp < NP4; ++pp)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (res_lds_ptr)(slot + (MT + pp) * 1024), 16, voff_w4,
+                                               sbase + pp * poff4 + s * ss4 + u * su4, 0, 2);
+    if constexpr (REM == 3) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (res_lds_ptr)(slot + (MT + NP4) * 1024), 12, voff_wr, sbase + poffr + s * ssr + u * sur, 0, 2);
+    } else if constexpr (REM == 2) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (res_lds_ptr)(slot + (MT + NP4) * 1024), 4, voff_wr, sbase + poffr + s * ssr + u * sur, 0, 2);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (res_lds_ptr)(slot + (MT + NP4) * 1024 + 256), 4, voff_wr, sbase + poffr + s * ssr + u * sur, 4, 2);
+    } else if constexpr (REM == 1) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (res_lds_ptr)(slot + (MT + NP4) * 1024), 4, voff_wr, sbase + poffr + s * ssr + u * sur, 0, 2);
+    }
+  };
+  auto load_meta = [&](auto Q_) {         // segment Q: NMETA instructions
+    constexpr int Q = decltype(Q_)::value;
+    RingMeta& m = meta[Q & 1];
+    const int grp = (seg0 + Q) >> p.gshift;
+    const int so_s = grp * p.N * 2, so_z = grp * (p.N >> 3) * 4;
+#pragma unroll
+    for (int pp = 0; pp < NP4; ++pp) {
+      const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs_, voff_s4, so_s + pp * 128, 0);
+      m.sc[2 * pp] = v[0]; m.sc[2 * pp + 1] = v[1];
+      m.z[pp] = __builtin_amdgcn_raw_buffer_load_b32(rz, voff_z4, so_z + pp * 32, 0);
+    }
+    if constexpr (REM == 2) {
+      m.scr[0] = __builtin_amdgcn_raw_buffer_load_b32(rs_, voff_sr, so_s, 0);
+    } else if constexpr (REM > 0) {
+#pragma unroll
+      for (int t = 0; t < REM; ++t) m.scr[t] = (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rs_, voff_sr, so_s + 2 * t, 0);
+    }
+    if constexpr (REM > 0) m.zr0 = __builtin_amdgcn_raw_buffer_load_b32(rz, voff_zr0, so_z, 0);
+    if constexpr (REM == 3) m.zr1 = __builtin_amdgcn_raw_buffer_load_b32(rz, voff_zr1, so_z, 0);
+  };
+  // Issue order (straight-line code): meta(0); refill(0 .. RR-1); then k-step I: [wait slot I+1, read it] refill(I + RR),
+  // meta(I / 4 + 1) when I % 4 == 0.  Instructions issued after the last one of slot J and before the wait for it (which
+  // sits in k-step J - 1, ahead of that step's own refill): the refills of slots J + 1 .. J - 1 + RR - 1 ... counted here.
+  auto after_slot = [](int J) constexpr {   // J >= 1
+    int n = 0;
+    // slot J was issued in the prologue (J < RR) or by k-step J - RR; everything issued later, up to k-step J - 2 inclusive
+    // (k-step J - 1 waits before it issues)
+    if (J < RR) {
+      n += (RR - 1 - J) * PER;                              // the rest of the prologue
+      for (int I = 0; I <= J - 2; ++I) {
+        if (I + RR < NST) n += PER;
+        if (I % 4 == 0 && I / 4 + 1 < NSEG) n += NMETA;
+      }
+    } else {
+      const int I0 = J - RR;
+      if (I0 % 4 == 0 && I0 / 4 + 1 < NSEG) n += NMETA;     // the metadata loads that followed it in its own k-step
+      for (int I = I0 + 1; I <= J - 2; ++I) {
+        if (I + RR < NST) n += PER;
+        if (I % 4 == 0 && I / 4 + 1 < NSEG) n += NMETA;
+      }
+    }
+    return n > 63 ? 63 : n;
+  };
+
+  auto read_slot = [&](auto I_) {
+    constexpr int I = decltype(I_)::value;
+    if constexpr (!DMA) return;
+    constexpr int B = I & 1, off = (I % RR) * SLOT;
+    res_static_for<0, MT>([&](auto J_) {
+      constexpr int i = decltype(J_)::value;
+      ring_read128<off + i * 1024>(fa[B][i], rd16);
+    });
+    res_static_for<0, NP4>([&](auto J_) {
+      constexpr int pp = decltype(J_)::value;
+      ring_read128<off + (MT + pp) * 1024>(fw[B][pp], rd16);
+    });
+    if constexpr (REM == 3) {
+      ring_read128<off + (MT + NP4) * 1024>(fr4[B], rd16);
+    } else {
+      res_static_for<0, REM>([&](auto J_) {
+        constexpr int t = decltype(J_)::value;
+        ring_read32<off + (MT + NP4) * 1024 + 256 * t>(fr[B][t], rdr);
+      });
+    }
+  };
+  auto land = [&](auto I_) {                // the reads of k-step I have returned: make that visible to the compiler
+    if constexpr (!DMA) return;
+    constexpr int B = decltype(I_)::value & 1;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < MT; ++i) ring_touch(fa[B][i]);
+#pragma unroll
+    for (int pp = 0; pp < NP4; ++pp) ring_touch(fw[B][pp]);
+#pragma unroll
+    for (int t = 0; t < (REM == 3 ? 0 : REM); ++t) ring_touch(fr[B][t]);
+    if constexpr (REM == 3) ring_touch(fr4[B]);
+  };
+
+  // ---- prologue ---------------------------------------------------------------------------------------------------------
+  load_meta(std::integral_constant<int, 0>{});
+  __builtin_amdgcn_sched_barrier(0);
+  res_static_for<0, RR>([&](auto I_) { refill(I_); });
+  __builtin_amdgcn_sched_barrier(0);
+  RES_STAMP(1);
+  if constexpr (DMA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RR - 1) * PER > 63 ? 63 : (RR - 1) * PER) : "memory");
+  read_slot(std::integral_constant<int, 0>{});
+  RES_STAMP(2);
+
+  res_static_for<0, NST>([&](auto I_) {
+    constexpr int I = decltype(I_)::value;
+    constexpr int s = I / 4, u = I % 4, B = DMA ? (I & 1) : (I % NSET);
+    land(I_);
+    if constexpr (DMA && I + 1 < NST) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(after_slot(I + 1)) : "memory");
+      read_slot(std::integral_constant<int, (I + 1 < NST ? I + 1 : 0)>{});
+    }
+    if constexpr (DMA) __builtin_amdgcn_sched_barrier(0);
+    if constexpr (I + RR < NST) refill(std::integral_constant<int, (I + RR < NST ? I + RR : 0)>{});
+    if constexpr (u == 0 && s + 1 < NSEG) load_meta(std::integral_constant<int, (s + 1 < NSEG ? s + 1 : 0)>{});
+    if constexpr (DMA) __builtin_amdgcn_sched_barrier(0);
+    // ---- A fragments: pre-scale (see the kernel above), row sums ------------------------------------------------------------
+    f16x8 a[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      u32x4 av = fa[B][i];
+      asm("v_pk_mul_f16 %0, %1, %2" : "=v"(av[1]) : "v"(av[1]), "s"(0x2c002c00u));
+      asm("v_pk_mul_f16 %0, %1, %2" : "=v"(av[3]) : "v"(av[3]), "s"(0x2c002c00u));
+      a[i] = __builtin_bit_cast(f16x8, av);
+      rs[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], ones, u == 0 ? zero4 : rs[i], 0, 0, 0);
+    }
+    res_static_for<0, NT>([&](auto T_) {
+      constexpr int t = decltype(T_)::value;
+      uint32_t wv;
+      if constexpr (t < 4 * NP4) wv = fw[B][t / 4][t % 4];
+      else if constexpr (REM == 3) wv = fr4[B][t - 4 * NP4];
+      else wv = fr[B][t - 4 * NP4];
+      const uint32_t w8 = wv >> 8;
+      const u32x4 bq = {wv & 0x000f000fu, wv & 0x00f000f0u, w8 & 0x000f000fu, w8 & 0x00f000f0u};
+      const f16x8 b = __builtin_bit_cast(f16x8, bq);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+        acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b, u == 0 ? zero4 : acc[i][t], 0, 0, 0);
+    });
+    if constexpr (TRACE) {
+      if constexpr (u == 3 && s < 8) { __builtin_amdgcn_sched_barrier(0); RES_STAMP(3 + s); }
+    }
+    if constexpr (u == 3) {
+      // ---- group epilogue (fp32): c += s * (2^24 * acc - z * rowsum) ---------------------------------------------------
+      const RingMeta& m = meta[s & 1];
+      res_static_for<0, NT>([&](auto T_) {
+        constexpr int t = decltype(T_)::value;
+        uint32_t zb;
+        uint16_t sb;
+        if constexpr (t < 4 * NP4) {
+          zb = (m.z[t / 4] >> zshift4) >> (4 * (t % 4));
+          sb = (uint16_t)(m.sc[2 * (t / 4) + ((t % 4) >> 1)] >> (16 * (t & 1)));
+        } else {
+          constexpr int tr = t - 4 * NP4;
+          uint32_t zbits;
+          if constexpr (REM == 3) zbits = __builtin_amdgcn_alignbit(m.zr1, m.zr0, zshiftr);
+          else zbits = m.zr0 >> zshiftr;
+          zb = zbits >> (4 * tr);
+          if constexpr (REM == 2) sb = (uint16_t)(m.scr[0] >> (16 * tr));
+          else sb = (uint16_t)m.scr[tr];
+        }
+        const float z = (float)(zb & 0xf) + zoff;
+        const float sf = p.is_bf16 ? bf16_bits_to_f32(sb) : f16_bits_to_f32(sb);
+        const float s24 = sf * 16777216.f;
+        const float nzs = -z * sf;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          cacc[i][t] = __builtin_elementwise_fma(acc[i][t], f32x4{s24, s24, s24, s24}, cacc[i][t]);
+          cacc[i][t] = __builtin_elementwise_fma(rs[i], f32x4{nzs, nzs, nzs, nzs}, cacc[i][t]);
+        }
+      });
+    }
+  });
+  RES_STAMP(11);
+  // ---- this wave's partial sums -> its LDS tile (its own ring space: every DMA of the wave has landed and been read) ----
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float* row = &red[wave * WP + (16 * i + 4 * g + r) * CWP];
+#pragma unroll
+      for (int pp = 0; pp < NP4; ++pp)
+        *reinterpret_cast<f32x4*>(row + 64 * pp + 4 * c) = f32x4{cacc[i][4 * pp][r], cacc[i][4 * pp + 1][r], cacc[i][4 * pp + 2][r], cacc[i][4 * pp + 3][r]};
+#pragma unroll
+      for (int t = 0; t < REM; ++t) row[64 * NP4 + REM * c + t] = cacc[i][4 * NP4 + t][r];
+    }
+  RES_STAMP(12);
+  __syncthreads();
+  RES_STAMP(13);
+  res_reduce_store<MT, NWV, NP4, REM>(p, red, WP, ky, cb, mtiles);
+  if constexpr (TRACE) {
+    RES_STAMP(14);
+    if (p.trace && lane == 0) {
+      unsigned long long* t = p.trace + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * NWV + wave) * 20;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) t[i] = stamp[i];
+      t[16] = wall0;
+      t[17] = __builtin_amdgcn_s_memrealtime();
+      t[18] = __builtin_amdgcn_s_getreg(((32 - 1) << 11) | 4);
+      t[19] = __builtin_amdgcn_s_getreg(((32 - 1) << 11) | 20);
+    }
+  }
+}
+
 // [K/8, N] exllama order -> strip-major: the 16-byte (last pass: 4 REM-byte) pieces in the order the waves read them.
 // One thread per destination dword.
 __global__ void wna16_strip_relayout_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, int N, int K,
@@ -638,6 +1063,27 @@ static int res_launch(const Wna16ResParams& p, hipStream_t st) {
   return APHRO_OK;
 }
 
+template <int MT, int NWV, int NSEG, int NP4, int REM, int R, bool DMA = true, bool TRACE = false>
+static int res_launch_ring(const Wna16ResParams& p, hipStream_t st) {
+  constexpr int CW = 64 * NP4 + 16 * REM;
+  constexpr int NST = NSEG * 4, RR = R < NST ? R : NST;
+  constexpr size_t TILE = (size_t)16 * MT * (CW + 4) * sizeof(float), RING = DMA ? (size_t)RR * (1024 * (MT + NP4) + (REM == 3 ? 1024 : 256 * REM)) : 0;
+  // (the kernel lays its per-wave region out for the larger of ring and tile in both modes)
+  const size_t lds = (size_t)NWV * (RING > TILE ? RING : TILE);
+  static_assert((size_t)NWV * (RING > TILE ? RING : TILE) <= 160 * 1024, "ring + tiles exceed the LDS");
+  auto kern = wna16_gemm_ring_kernel<MT, NWV, NSEG, NP4, REM, R, DMA, TRACE>;
+  if (lds > 64 * 1024) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      set_error("wna16_gemm_ring: cannot raise the dynamic LDS limit to %zu", lds);
+      return APHRO_ERR_LAUNCH;
+    }
+  }
+  const dim3 grid((unsigned)(p.N / CW), (unsigned)p.ksplit);
+  hipLaunchKernelGGL(kern, grid, dim3(NWV * 64), lds, st, p);
+  APHRO_LAUNCH_CHECK();
+  return APHRO_OK;
+}
+
 // ---- the instantiated configurations ------------------------------------------------------------------------------------
 #ifndef RES_DEPTH
 #define RES_DEPTH 8
@@ -645,6 +1091,43 @@ static int res_launch(const Wna16ResParams& p, hipStream_t st) {
 #ifndef RES_ADEPTH
 #define RES_ADEPTH 2
 #endif
+// ring kernel: (nwv, nseg, np4, rem, ring depth in k-steps); RES_RING_DEFAULT: the depth a call gets without APHRO_WNA16_RING
+#ifndef RES_RING_DEFAULT
+#define RES_RING_DEFAULT 0
+#endif
+#define RES_RING_CONFIGS(X) \
+  X(4, 8, 1, 3, 8)          \
+  X(4, 8, 1, 3, 6)          \
+  X(4, 7, 1, 0, 8)          \
+  X(4, 7, 1, 0, 12)         \
+  X(4, 4, 1, 0, 8)          \
+  X(4, 4, 1, 0, 12)         \
+  X(8, 4, 1, 3, 4)          \
+  X(7, 4, 1, 0, 6)          \
+  X(8, 2, 0, 3, 6)
+#define RES_STREAM_CONFIGS(X) \
+  X(4, 8, 1, 3, 8)            \
+  X(4, 8, 1, 3, 12)           \
+  X(4, 7, 1, 0, 8)            \
+  X(4, 7, 1, 0, 12)           \
+  X(4, 4, 1, 0, 8)            \
+  X(4, 4, 1, 0, 12)
+#ifdef RES_NO_KEEP_RS   // lab: the row sums of pass 0 are recomputed in the later passes instead of kept (registers)
+#define RES_KEEP_RS(x) false
+#else
+#define RES_KEEP_RS(x) (x)
+#endif
+#ifdef RES_LAB_SET   // lab builds (tools/reslab.hip): the round-3 plans of the four configs[1] shapes + 2-waves-per-SIMD forms
+#define RES_CONFIGS(X) \
+  X(4, 8, 1, 3)        \
+  X(4, 7, 1, 0)        \
+  X(4, 4, 1, 0)        \
+  X(8, 4, 1, 3)        \
+  X(7, 4, 1, 0)        \
+  X(8, 2, 0, 3)        \
+  X(8, 2, 0, 2)
+#define RES_AROW_CONFIGS(X) X(4, 8, 1, 3)
+#else
 #define RES_CONFIGS(X) \
   X(4, 8, 1, 3)        \
   X(4, 7, 1, 0)        \
@@ -664,6 +1147,7 @@ static int res_launch(const Wna16ResParams& p, hipStream_t st) {
   X(4, 4, 1, 0)             \
   X(4, 2, 1, 0)             \
   X(4, 4, 0, 3)
+#endif
 
 static bool res_instantiated(int nwv, int nseg, int np4, int rem) {
 #define X(a, b, c, d) if (nwv == a && nseg == b && np4 == c && rem == d) return true;
@@ -691,10 +1175,31 @@ static int res_dispatch(const Wna16ResParams& p, const ResConfig& cf, hipStream_
     }
   }
 #endif
+  if (p.a == nullptr) {   // packed activations: the ring kernel where it is instantiated (APHRO_WNA16_RING=0: the round-3 kernel)
+#ifdef RES_LAB_SET     // (lab: one process times several settings)
+    const char* ring_e = getenv("APHRO_WNA16_RING");     // R: the LDS-ring form; -R: the register-ring form
+    const int ring_env = ring_e ? atoi(ring_e) : 0;
+#else
+    static const int ring_env = [] { const char* e = getenv("APHRO_WNA16_RING"); return e ? atoi(e) : 0; }();
+#endif
+    const int ring = ring_env != 0 ? ring_env : RES_RING_DEFAULT;
+#define X(a, b, c, d, r)                                                                       \
+    if (ring == r && cf.nwv == a && cf.nseg == b && cf.np4 == c && cf.rem == d)                \
+      return mt == 2 ? (p.trace ? res_launch_ring<2, a, b, c, d, r, true, true>(p, st) : res_launch_ring<2, a, b, c, d, r, true>(p, st)) \
+                     : res_launch_ring<1, a, b, c, d, r, true>(p, st);
+    RES_RING_CONFIGS(X)
+#undef X
+#define X(a, b, c, d, r)                                                                       \
+    if (ring == -r && cf.nwv == a && cf.nseg == b && cf.np4 == c && cf.rem == d)               \
+      return mt == 2 ? (p.trace ? res_launch_ring<2, a, b, c, d, r, false, true>(p, st) : res_launch_ring<2, a, b, c, d, r, false>(p, st)) \
+                     : res_launch_ring<1, a, b, c, d, r, false>(p, st);
+    RES_STREAM_CONFIGS(X)
+#undef X
+  }
   if (p.a != nullptr) {   // row-major activations read in place: the configurations res_plan picks by itself
 #define X(a, b, c, d)                                                                                    \
     if (cf.nwv == a && cf.nseg == b && cf.np4 == c && cf.rem == d) {                                     \
-      constexpr bool KR = (c + (d > 0 ? 1 : 0)) > 1;                                                     \
+      constexpr bool KR = RES_KEEP_RS((c + (d > 0 ? 1 : 0)) > 1);                                                   \
       return mt == 2 ? res_launch<2, a, b, c, d, RES_DEPTH, RES_ADEPTH, KR, false, true>(p, st)          \
                      : res_launch<1, a, b, c, d, RES_DEPTH, RES_ADEPTH, KR, false, true>(p, st);         \
     }
@@ -705,7 +1210,7 @@ static int res_dispatch(const Wna16ResParams& p, const ResConfig& cf, hipStream_
   }
 #define X(a, b, c, d)                                                                       \
   if (cf.nwv == a && cf.nseg == b && cf.np4 == c && cf.rem == d) {                          \
-    constexpr bool KR = (c + (d > 0 ? 1 : 0)) > 1;                                          \
+    constexpr bool KR = RES_KEEP_RS((c + (d > 0 ? 1 : 0)) > 1);                                        \
     return mt == 2 ? res_launch<2, a, b, c, d, RES_DEPTH, RES_ADEPTH, KR>(p, st)            \
                    : res_launch<1, a, b, c, d, RES_DEPTH, RES_ADEPTH, KR>(p, st);           \
   }
