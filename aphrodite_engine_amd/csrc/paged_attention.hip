@@ -906,6 +906,11 @@ using namespace aphro;
 struct SplitWs { unsigned* counter = nullptr; size_t groups = 0; float* scratch = nullptr; size_t floats = 0; };
 static SplitWs g_split_ws[APHRO_MAX_DEVICES];
 
+// Buffers are NEVER freed or moved once handed out: a HIP graph captured earlier has their raw pointers baked into its
+// kernel nodes, and the reference's model runner captures many batch sizes and keeps running eager decode beside them
+// (growth after capture used to hipFree what a captured graph still writes to).  The first use allocates for
+// the largest plan the launcher makes by itself (groups x want < 3 CUs, want <= 8); a forced APHRO_PA_SPLITS plan that
+// needs more gets NEW, larger buffers and the old ones stay alive for the life of the process.
 static bool split_workspace(size_t groups, size_t floats, hipStream_t st, SplitWs** ws_out) {
   static std::mutex mu;                        // host threads racing on first use / growth
   std::lock_guard<std::mutex> lock(mu);
@@ -913,18 +918,21 @@ static bool split_workspace(size_t groups, size_t floats, hipStream_t st, SplitW
   if (ws.groups < groups || ws.floats < floats) {
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return false;
-    if (hipStreamSynchronize(st) != hipSuccess) return false;         // nobody is using the old buffers
     if (ws.groups < groups) {
-      if (ws.counter) (void)hipFree(ws.counter);
       const size_t g2 = groups < 4096 ? 4096 : groups * 2;
-      if (hipMalloc((void**)&ws.counter, g2 * sizeof(unsigned)) != hipSuccess) { ws.counter = nullptr; ws.groups = 0; return false; }
-      if (hipMemset(ws.counter, 0, g2 * sizeof(unsigned)) != hipSuccess) return false;
+      unsigned* fresh = nullptr;
+      if (hipMalloc((void**)&fresh, g2 * sizeof(unsigned)) != hipSuccess) return false;
+      if (hipMemset(fresh, 0, g2 * sizeof(unsigned)) != hipSuccess) { (void)hipFree(fresh); return false; }
+      ws.counter = fresh;                      // (the previous array, if any, is retired, not freed)
       ws.groups = g2;
     }
     if (ws.floats < floats) {
-      if (ws.scratch) (void)hipFree(ws.scratch);
-      if (hipMalloc((void**)&ws.scratch, floats * sizeof(float)) != hipSuccess) { ws.scratch = nullptr; ws.floats = 0; return false; }
-      ws.floats = floats;
+      const size_t bound = (size_t)3 * device_cu_count() * (16 * 128 + 32);
+      const size_t f2 = floats < bound ? bound : floats * 2;
+      float* fresh = nullptr;
+      if (hipMalloc((void**)&fresh, f2 * sizeof(float)) != hipSuccess) return false;
+      ws.scratch = fresh;
+      ws.floats = f2;
     }
   }
   *ws_out = &ws;

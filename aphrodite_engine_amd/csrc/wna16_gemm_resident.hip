@@ -558,7 +558,7 @@ __global__ __launch_bounds__(NWV * 64, NWV <= 4 ? 1 : 2) void wna16_gemm_residen
 //     in flight, see lm_head.hip) and run one k-step ahead of the MFMAs into a second register set.
 // Same arithmetic, same K partition over waves and slices as the kernel above for the same (NWV, NSEG): the slabs / packed
 // results are bit-identical to it.
-template <int MT, int NWV, int NP4, int REM>
+template <int MT, int NWV, int NP4, int REM, int NTHREADS = NWV * 64>
 __device__ __forceinline__ void res_reduce_store(const Wna16ResParams& p, float* red, int WP, int ky, int cb, int mtiles) {
   constexpr int CW = 64 * NP4 + 16 * REM;
   constexpr int CWP = CW + 4;
@@ -567,7 +567,7 @@ __device__ __forceinline__ void res_reduce_store(const Wna16ResParams& p, float*
   const int tid = threadIdx.x;
   if (p.act_packed != nullptr) {
     constexpr int UNITS = ROWS * (CW / 16);
-    for (int unit = tid; unit < UNITS; unit += NWV * 64) {
+    for (int unit = tid; unit < UNITS; unit += NTHREADS) {
       const int ch = unit / ROWS, row = unit % ROWS;
       float v[16];
 #pragma unroll
@@ -594,7 +594,7 @@ __device__ __forceinline__ void res_reduce_store(const Wna16ResParams& p, float*
     }
   } else if (p.ksplit > 1 || p.force_partial) {
     constexpr int UNITS = ROWS * (CW / 4);
-    for (int unit = tid; unit < UNITS; unit += NWV * 64) {
+    for (int unit = tid; unit < UNITS; unit += NTHREADS) {
       const int row = unit / (CW / 4), c4 = unit % (CW / 4);
       f32x4 sum = zero4;
 #pragma unroll
@@ -603,7 +603,7 @@ __device__ __forceinline__ void res_reduce_store(const Wna16ResParams& p, float*
     }
   } else {
     constexpr int UNITS = ROWS * (CW / 8);
-    for (int unit = tid; unit < UNITS; unit += NWV * 64) {
+    for (int unit = tid; unit < UNITS; unit += NTHREADS) {
       const int row = unit / (CW / 8), c8 = unit % (CW / 8);
       f32x4 s0 = zero4, s1 = zero4;
 #pragma unroll
@@ -643,11 +643,49 @@ constexpr int ring_per_step() { return MT + NP4 + (REM == 2 ? 2 : (REM > 0 ? 1 :
 template <int NP4, int REM>
 constexpr int ring_meta_ops() { return 2 * NP4 + (REM == 0 ? 0 : (REM == 1 ? 2 : (REM == 2 ? 2 : 5))); }
 
-// DMA = false: the same single-pass schedule with both streams in REGISTER rings of R k-steps (plain buffer loads, hipcc's
-// own vmcnt accounting, no LDS on the way in): an LDS-DMA instruction costs its wave 60-185 cycles of issue
-// (MI355X_MICROARCH.md), 4 per k-step here against ~330 cycles of MFMA + unpack issue.
-template <int MT, int NWV, int NSEG, int NP4, int REM, int R, bool DMA = true, bool TRACE = false>
-__global__ __launch_bounds__(NWV * 64, NWV <= 4 ? 1 : 2) void wna16_gemm_ring_kernel(Wna16ResParams p) {
+// LC (loader / consumer): the workgroup has 2 NWV waves; wave NWV + w only ISSUES -- it fills consumer w's ring -- and
+// wave w only computes.  With the refills in the computing wave's own instruction stream (LC = false) an LDS-DMA costs it
+// 60-185 cycles of issue (MI355X_MICROARCH.md; measured here: 645 cycles per k-step with 4 refills against 470 without),
+// and while the memory pipeline pushes back the wave that issues cannot compute: the round-4 traces show the prologue
+// (8 slots) taking 5.5 k cycles, the rate at which a CU's vector-memory path accepts 128 KB.  Hand-over through two
+// monotonic counters per ring in LDS: ready (k-steps landed: the loader writes it after its own vmcnt wait; LDS serves
+// requests in order, so the counter is behind the data) and consumed (k-steps whose fragments are in the consumer's
+// registers: the slot may be refilled).  Both sides cache the other's counter and poll only when they catch up with it.
+__device__ __forceinline__ int lc_flag_read(uint32_t addr) {
+  int v;
+  asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(addr) : "memory");
+  return v;
+}
+template <int UPTO>
+__device__ __forceinline__ void lc_need(int& seen, uint32_t addr) {      // returns once seen >= UPTO
+  // (bounded: 2^20 re-reads ~ 0.1 s, then it gives up and the result is wrong -- a protocol bug must not hang the GPU)
+  uint32_t spin;
+  asm volatile(
+      "v_cmp_gt_i32_e32 vcc, %3, %0\n\t"
+      "s_cbranch_vccz 2f\n\t"
+      "s_mov_b32 %1, 0x100000\n"
+      "1:\n\t"
+      "ds_read_b32 %0, %2\n\t"
+      "s_waitcnt lgkmcnt(0)\n\t"
+      "v_cmp_gt_i32_e32 vcc, %3, %0\n\t"
+      "s_cbranch_vccz 2f\n\t"
+      "s_sub_u32 %1, %1, 1\n\t"
+      "s_cmp_lg_u32 %1, 0\n\t"
+      "s_cbranch_scc1 1b\n"
+      "2:"
+      : "+v"(seen), "=&s"(spin)
+      : "v"(addr), "n"(UPTO)
+      : "vcc", "scc", "memory");
+}
+__device__ __forceinline__ void lc_flag_prefetch(int& seen, uint32_t addr) {   // value valid after the next lgkmcnt(0)
+  asm volatile("ds_read_b32 %0, %1" : "=v"(seen) : "v"(addr) : "memory");
+}
+__device__ __forceinline__ void lc_flag_write(uint32_t addr, int v) {
+  asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+
+template <int MT, int NWV, int NSEG, int NP4, int REM, int R, bool LC = false, bool TRACE = false>
+__global__ __launch_bounds__((LC ? 2 : 1) * NWV * 64, (LC ? 2 : 1) * NWV <= 4 ? 1 : 2) void wna16_gemm_ring_kernel(Wna16ResParams p) {
   constexpr int NST = NSEG * 4;                     // k-steps of a wave
   constexpr int CW = 64 * NP4 + 16 * REM;
   constexpr int CWP = CW + 4;
@@ -658,11 +696,14 @@ __global__ __launch_bounds__(NWV * 64, NWV <= 4 ? 1 : 2) void wna16_gemm_ring_ke
   constexpr int REMB = REM == 3 ? 1024 : 256 * REM;   // a 12-byte `buffer_load ... lds` lands at 16 bytes per lane (probed: 12 data + 4 skipped)
   constexpr int SLOT = 1024 * (MT + NP4) + REMB;
   constexpr int RR = R < NST ? R : NST;
-  constexpr int WPB = (DMA && RR * SLOT > ROWS * CWP * 4 ? RR * SLOT : ROWS * CWP * 4);   // bytes per wave: ring, later the reduction tile
+  constexpr int WPB = (RR * SLOT > ROWS * CWP * 4 ? RR * SLOT : ROWS * CWP * 4);   // bytes per wave: ring, later the reduction tile
   constexpr int WP = WPB / 4;
-  extern __shared__ __attribute__((aligned(16))) float red[];
+  constexpr int NTHREADS = (LC ? 2 : 1) * NWV * 64;
+  extern __shared__ __attribute__((aligned(16))) float red[];     // [NWV][WP] | LC: flags [NWV][2] ints
   const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const bool loader = LC && wid >= NWV;
+  const int wave = loader ? wid - NWV : wid;        // the ring this wave fills / computes from
   const int g = lane >> 4;
   const int c = lane & 15;
   unsigned long long stamp[TRACE ? 16 : 1] = {};
@@ -706,60 +747,13 @@ __global__ __launch_bounds__(NWV * 64, NWV <= 4 ? 1 : 2) void wna16_gemm_ring_ke
 #pragma unroll
   for (int i = 0; i < MT; ++i) voff_a[i] = (min(i, mtiles - 1) * 64 + lane) * 16;
   const int abytes = mtiles * 1024;
-  const int col4 = cb + 4 * c;
-  const int colr = cb + 64 * NP4 + REM * c;
-  const int voff_s4 = col4 * 2, voff_z4 = (col4 >> 3) * 4, zshift4 = (col4 & 7) * 4;
-  const int voff_sr = colr * 2, voff_zr0 = (colr >> 3) * 4, voff_zr1 = ((colr + (REM > 0 ? REM - 1 : 0)) >> 3) * 4;
-  const int zshiftr = (colr & 7) * 4;
-  const float zoff = (float)p.zero_offset;
-  const f16x8 ones = {(f16)1.f, (f16)1.f, (f16)16.f, (f16)16.f, (f16)1.f, (f16)1.f, (f16)16.f, (f16)16.f};
-  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
   unsigned char* const ring = reinterpret_cast<unsigned char*>(red) + (size_t)wave * WPB;
-  const uint32_t rd16 = (uint32_t)(uintptr_t)(res_lds_ptr)(ring + lane * 16);              // 16-byte pieces
-  const uint32_t rdr = (uint32_t)(uintptr_t)(res_lds_ptr)(ring + lane * 4);                // the 4-byte REM piece(s)
+  const uint32_t flag_ready = (uint32_t)(uintptr_t)(res_lds_ptr)(reinterpret_cast<unsigned char*>(red) + (size_t)NWV * WPB + wave * 8);
+  const uint32_t flag_consumed = flag_ready + 4;
 
-  struct RingMeta { uint32_t sc[NP4 > 0 ? 2 * NP4 : 1], z[NP4 > 0 ? NP4 : 1], scr[3], zr0, zr1; };
-  RingMeta meta[2];
-  f32x4 cacc[MT][NT], acc[MT][NT], rs[MT];
-#pragma unroll
-  for (int i = 0; i < MT; ++i) {
-    rs[i] = zero4;
-#pragma unroll
-    for (int t = 0; t < NT; ++t) { cacc[i][t] = zero4; acc[i][t] = zero4; }
-  }
-
-  // fragment registers of two k-steps: [I & 1]
-  constexpr int NSET = DMA ? 2 : RR + 1;    // (registers: one more set than k-steps in flight, the refill of step I + RR
-                                            //  must not land on the set step I is computing from)
-  u32x4 fa[NSET][MT], fw[NSET][NP4 > 0 ? NP4 : 1];
-  uint32_t fr[NSET][REM > 0 ? REM : 1];
-  u32x4 fr4[NSET];                             // REM == 3: the 12-byte piece, read as 16
-  auto refill = [&](auto I_) {            // k-step I -> slot I % RR: PER instructions
-    constexpr int I = decltype(I_)::value;
-    constexpr int s = I / 4, u = I % 4;
-    if constexpr (!DMA) {
-      constexpr int B = I % NSET;
-#pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        const int vo = voff_a[i];
-        fa[B][i] = __builtin_amdgcn_raw_buffer_load_b128(ra, vo, ((seg0 + s) * 4 + u) * abytes, 0);
-      }
-#pragma unroll
-      for (int pp = 0; pp < NP4; ++pp) fw[B][pp] = __builtin_amdgcn_raw_buffer_load_b128(rw, voff_w4, sbase + pp * poff4 + s * ss4 + u * su4, 2);
-      const int so = sbase + poffr + s * ssr + u * sur;
-      if constexpr (REM == 3) {
-        typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
-        const u32x3 v = __builtin_amdgcn_raw_buffer_load_b96(rw, voff_wr, so, 2);
-        fr4[B] = u32x4{v[0], v[1], v[2], 0u};
-      } else if constexpr (REM == 2) {
-        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rw, voff_wr, so, 2);
-        fr[B][0] = v[0]; fr[B][1] = v[1];
-      } else if constexpr (REM == 1) {
-        fr[B][0] = __builtin_amdgcn_raw_buffer_load_b32(rw, voff_wr, so, 2);
-      }
-      return;
-    }
+  auto refill_rt = [&](int I) {           // k-step I -> slot I % RR: PER instructions (runtime indices: loader / prologue)
+    const int s = I >> 2, u = I & 3;
     unsigned char* const slot = ring + (I % RR) * SLOT;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
@@ -779,6 +773,67 @@ __global__ __launch_bounds__(NWV * 64, NWV <= 4 ? 1 : 2) void wna16_gemm_ring_ke
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (res_lds_ptr)(slot + (MT + NP4) * 1024), 4, voff_wr, sbase + poffr + s * ssr + u * sur, 0, 2);
     }
   };
+
+  if constexpr (LC) {
+    if (threadIdx.x < 2 * NWV) reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(red) + (size_t)NWV * WPB)[threadIdx.x] = 0;
+    __syncthreads();
+    if (loader) {
+      // ---- loader: keep up to RR slots issued, DL k-steps unpublished (in flight) -----------------------------------------
+      // DL k-steps in flight and not yet published; the other RR - DL slots hold landed k-steps the consumer has not taken
+      // yet (DL = RR - 1 leaves no such slot: loader and consumer then hand every k-step over in lock step, each exposed to
+      // the other's polling latency -- measured 21.4 us on gate_up against 16.4)
+#ifndef RES_LC_NUM
+#define RES_LC_NUM 2
+#endif
+      constexpr int DL0 = RR * RES_LC_NUM / 4 < 1 ? 1 : RR * RES_LC_NUM / 4;     // quarters of the ring
+      constexpr int DL = DL0 * PER > 60 ? 60 / PER : DL0;
+      int consumed_seen = 0;
+      for (int I = 0; I < NST; ++I) {
+        if (I >= RR) {
+          for (int spin = 0; consumed_seen <= I - RR && spin < (1 << 20); ++spin) {
+            consumed_seen = lc_flag_read(flag_consumed);
+            if (consumed_seen <= I - RR) __builtin_amdgcn_s_sleep(1);
+          }
+        }
+        refill_rt(I);
+        if (I >= DL) {
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DL * PER) : "memory");
+          lc_flag_write(flag_ready, I - DL + 1);
+        }
+      }
+      res_static_for<0, DL>([&](auto J_) {          // drain: k-steps NST - DL .. NST - 1
+        constexpr int j = DL - 1 - decltype(J_)::value;
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(j * PER) : "memory");
+        if (NST - j > 0) lc_flag_write(flag_ready, NST - j);
+      });
+      __syncthreads();                              // (the consumers' tiles are written before this barrier)
+      res_reduce_store<MT, NWV, NP4, REM, NTHREADS>(p, red, WP, ky, cb, mtiles);
+      return;
+    }
+  }
+
+  // ---- consumer (LC) / the whole kernel (!LC) ----------------------------------------------------------------------------
+  const int col4 = cb + 4 * c;
+  const int colr = cb + 64 * NP4 + REM * c;
+  const int voff_s4 = col4 * 2, voff_z4 = (col4 >> 3) * 4, zshift4 = (col4 & 7) * 4;
+  const int voff_sr = colr * 2, voff_zr0 = (colr >> 3) * 4, voff_zr1 = ((colr + (REM > 0 ? REM - 1 : 0)) >> 3) * 4;
+  const int zshiftr = (colr & 7) * 4;
+  const float zoff = (float)p.zero_offset;
+  const f16x8 ones = {(f16)1.f, (f16)1.f, (f16)16.f, (f16)16.f, (f16)1.f, (f16)1.f, (f16)16.f, (f16)16.f};
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  const uint32_t rd16 = (uint32_t)(uintptr_t)(res_lds_ptr)(ring + lane * 16);              // 16-byte pieces
+  const uint32_t rdr = (uint32_t)(uintptr_t)(res_lds_ptr)(ring + lane * 4);                // the 4-byte REM piece(s)
+
+  struct RingMeta { uint32_t sc[NP4 > 0 ? 2 * NP4 : 1], z[NP4 > 0 ? NP4 : 1], scr[3], zr0, zr1; };
+  RingMeta meta[2];
+  f32x4 cacc[MT][NT], acc[MT][NT], rs[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    rs[i] = zero4;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { cacc[i][t] = zero4; acc[i][t] = zero4; }
+  }
+
   auto load_meta = [&](auto Q_) {         // segment Q: NMETA instructions
     constexpr int Q = decltype(Q_)::value;
     RingMeta& m = meta[Q & 1];
@@ -799,13 +854,11 @@ __global__ __launch_bounds__(NWV * 64, NWV <= 4 ? 1 : 2) void wna16_gemm_ring_ke
     if constexpr (REM > 0) m.zr0 = __builtin_amdgcn_raw_buffer_load_b32(rz, voff_zr0, so_z, 0);
     if constexpr (REM == 3) m.zr1 = __builtin_amdgcn_raw_buffer_load_b32(rz, voff_zr1, so_z, 0);
   };
-  // Issue order (straight-line code): meta(0); refill(0 .. RR-1); then k-step I: [wait slot I+1, read it] refill(I + RR),
-  // meta(I / 4 + 1) when I % 4 == 0.  Instructions issued after the last one of slot J and before the wait for it (which
-  // sits in k-step J - 1, ahead of that step's own refill): the refills of slots J + 1 .. J - 1 + RR - 1 ... counted here.
+  // !LC issue order (straight-line code): meta(0); refill(0 .. RR-1); then k-step I: [wait slot I+1, read it] refill(I + RR),
+  // meta(I / 4 + 1) when I % 4 == 0.  after_slot(J): instructions issued after the last one of slot J and before the wait
+  // for it (which sits in k-step J - 1, ahead of that step's own refill).
   auto after_slot = [](int J) constexpr {   // J >= 1
     int n = 0;
-    // slot J was issued in the prologue (J < RR) or by k-step J - RR; everything issued later, up to k-step J - 2 inclusive
-    // (k-step J - 1 waits before it issues)
     if (J < RR) {
       n += (RR - 1 - J) * PER;                              // the rest of the prologue
       for (int I = 0; I <= J - 2; ++I) {
@@ -823,9 +876,12 @@ __global__ __launch_bounds__(NWV * 64, NWV <= 4 ? 1 : 2) void wna16_gemm_ring_ke
     return n > 63 ? 63 : n;
   };
 
+  // fragment registers of two k-steps: [I & 1]
+  u32x4 fa[2][MT], fw[2][NP4 > 0 ? NP4 : 1];
+  uint32_t fr[2][REM > 0 ? REM : 1];
+  u32x4 fr4[2];                             // REM == 3: the 12-byte piece, read as 16
   auto read_slot = [&](auto I_) {
     constexpr int I = decltype(I_)::value;
-    if constexpr (!DMA) return;
     constexpr int B = I & 1, off = (I % RR) * SLOT;
     res_static_for<0, MT>([&](auto J_) {
       constexpr int i = decltype(J_)::value;
@@ -844,8 +900,12 @@ __global__ __launch_bounds__(NWV * 64, NWV <= 4 ? 1 : 2) void wna16_gemm_ring_ke
       });
     }
   };
+  // LC: `ready_seen` is fetched (ds_read, no wait) next to the fragment reads of one k-step and looked at in the next one,
+  // behind the same lgkmcnt wait: a consumer that is not data-bound never waits for a counter.  The slow path (re-read until
+  // k-steps < UPTO have landed) is a loop INSIDE one asm statement: the consumer stays straight-line code for hipcc (with
+  // C++ poll loops in each of the 32 unrolled k-steps it spilled 427 registers).
+  int ready_seen = 0;
   auto land = [&](auto I_) {                // the reads of k-step I have returned: make that visible to the compiler
-    if constexpr (!DMA) return;
     constexpr int B = decltype(I_)::value & 1;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
@@ -855,30 +915,39 @@ __global__ __launch_bounds__(NWV * 64, NWV <= 4 ? 1 : 2) void wna16_gemm_ring_ke
 #pragma unroll
     for (int t = 0; t < (REM == 3 ? 0 : REM); ++t) ring_touch(fr[B][t]);
     if constexpr (REM == 3) ring_touch(fr4[B]);
+    if constexpr (LC) ring_touch(ready_seen);
   };
-
   // ---- prologue ---------------------------------------------------------------------------------------------------------
   load_meta(std::integral_constant<int, 0>{});
   __builtin_amdgcn_sched_barrier(0);
-  res_static_for<0, RR>([&](auto I_) { refill(I_); });
-  __builtin_amdgcn_sched_barrier(0);
-  RES_STAMP(1);
-  if constexpr (DMA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RR - 1) * PER > 63 ? 63 : (RR - 1) * PER) : "memory");
+  if constexpr (!LC) {
+    for (int I = 0; I < RR; ++I) refill_rt(I);
+    __builtin_amdgcn_sched_barrier(0);
+    RES_STAMP(1);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RR - 1) * PER > 63 ? 63 : (RR - 1) * PER) : "memory");
+  } else {
+    RES_STAMP(1);
+    lc_need<1>(ready_seen, flag_ready);
+  }
   read_slot(std::integral_constant<int, 0>{});
+  if constexpr (LC) lc_flag_prefetch(ready_seen, flag_ready);
   RES_STAMP(2);
 
   res_static_for<0, NST>([&](auto I_) {
     constexpr int I = decltype(I_)::value;
-    constexpr int s = I / 4, u = I % 4, B = DMA ? (I & 1) : (I % NSET);
+    constexpr int s = I / 4, u = I % 4, B = I & 1;
     land(I_);
-    if constexpr (DMA && I + 1 < NST) {
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(after_slot(I + 1)) : "memory");
+    if constexpr (LC) lc_flag_write(flag_consumed, I + 1);        // slot I is in registers
+    if constexpr (I + 1 < NST) {
+      if constexpr (LC) lc_need<I + 2>(ready_seen, flag_ready);
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(after_slot(I + 1)) : "memory");
       read_slot(std::integral_constant<int, (I + 1 < NST ? I + 1 : 0)>{});
+      if constexpr (LC && I + 2 < NST) lc_flag_prefetch(ready_seen, flag_ready);
     }
-    if constexpr (DMA) __builtin_amdgcn_sched_barrier(0);
-    if constexpr (I + RR < NST) refill(std::integral_constant<int, (I + RR < NST ? I + RR : 0)>{});
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (!LC && I + RR < NST) refill_rt(I + RR);
     if constexpr (u == 0 && s + 1 < NSEG) load_meta(std::integral_constant<int, (s + 1 < NSEG ? s + 1 : 0)>{});
-    if constexpr (DMA) __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_sched_barrier(0);
     // ---- A fragments: pre-scale (see the kernel above), row sums ------------------------------------------------------------
     f16x8 a[MT];
 #pragma unroll
@@ -937,7 +1006,7 @@ __global__ __launch_bounds__(NWV * 64, NWV <= 4 ? 1 : 2) void wna16_gemm_ring_ke
     }
   });
   RES_STAMP(11);
-  // ---- this wave's partial sums -> its LDS tile (its own ring space: every DMA of the wave has landed and been read) ----
+  // ---- this wave's partial sums -> its LDS tile (its own ring space: every DMA of the ring has landed and been read) ----
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -952,7 +1021,7 @@ __global__ __launch_bounds__(NWV * 64, NWV <= 4 ? 1 : 2) void wna16_gemm_ring_ke
   RES_STAMP(12);
   __syncthreads();
   RES_STAMP(13);
-  res_reduce_store<MT, NWV, NP4, REM>(p, red, WP, ky, cb, mtiles);
+  res_reduce_store<MT, NWV, NP4, REM, NTHREADS>(p, red, WP, ky, cb, mtiles);
   if constexpr (TRACE) {
     RES_STAMP(14);
     if (p.trace && lane == 0) {
@@ -1063,23 +1132,22 @@ static int res_launch(const Wna16ResParams& p, hipStream_t st) {
   return APHRO_OK;
 }
 
-template <int MT, int NWV, int NSEG, int NP4, int REM, int R, bool DMA = true, bool TRACE = false>
+template <int MT, int NWV, int NSEG, int NP4, int REM, int R, bool LC = false, bool TRACE = false>
 static int res_launch_ring(const Wna16ResParams& p, hipStream_t st) {
   constexpr int CW = 64 * NP4 + 16 * REM;
   constexpr int NST = NSEG * 4, RR = R < NST ? R : NST;
-  constexpr size_t TILE = (size_t)16 * MT * (CW + 4) * sizeof(float), RING = DMA ? (size_t)RR * (1024 * (MT + NP4) + (REM == 3 ? 1024 : 256 * REM)) : 0;
-  // (the kernel lays its per-wave region out for the larger of ring and tile in both modes)
-  const size_t lds = (size_t)NWV * (RING > TILE ? RING : TILE);
-  static_assert((size_t)NWV * (RING > TILE ? RING : TILE) <= 160 * 1024, "ring + tiles exceed the LDS");
-  auto kern = wna16_gemm_ring_kernel<MT, NWV, NSEG, NP4, REM, R, DMA, TRACE>;
-  if (lds > 64 * 1024) {
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-      set_error("wna16_gemm_ring: cannot raise the dynamic LDS limit to %zu", lds);
+  constexpr size_t TILE = (size_t)16 * MT * (CW + 4) * sizeof(float), RING = (size_t)RR * (1024 * (MT + NP4) + (REM == 3 ? 1024 : 256 * REM));
+  constexpr size_t LDS = (size_t)NWV * (RING > TILE ? RING : TILE) + (LC ? 64 : 0);
+  static_assert(LDS <= 160 * 1024, "ring + tiles exceed the LDS");
+  auto kern = wna16_gemm_ring_kernel<MT, NWV, NSEG, NP4, REM, R, LC, TRACE>;
+  if (LDS > 64 * 1024) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS) != hipSuccess) {
+      set_error("wna16_gemm_ring: cannot raise the dynamic LDS limit to %zu", LDS);
       return APHRO_ERR_LAUNCH;
     }
   }
   const dim3 grid((unsigned)(p.N / CW), (unsigned)p.ksplit);
-  hipLaunchKernelGGL(kern, grid, dim3(NWV * 64), lds, st, p);
+  hipLaunchKernelGGL(kern, grid, dim3((LC ? 2 : 1) * NWV * 64), LDS, st, p);
   APHRO_LAUNCH_CHECK();
   return APHRO_OK;
 }
@@ -1097,20 +1165,14 @@ static int res_launch_ring(const Wna16ResParams& p, hipStream_t st) {
 #endif
 #define RES_RING_CONFIGS(X) \
   X(4, 8, 1, 3, 8)          \
-  X(4, 8, 1, 3, 6)          \
-  X(4, 7, 1, 0, 8)          \
-  X(4, 7, 1, 0, 12)         \
-  X(4, 4, 1, 0, 8)          \
-  X(4, 4, 1, 0, 12)         \
-  X(8, 4, 1, 3, 4)          \
-  X(7, 4, 1, 0, 6)          \
-  X(8, 2, 0, 3, 6)
-#define RES_STREAM_CONFIGS(X) \
-  X(4, 8, 1, 3, 8)            \
-  X(4, 8, 1, 3, 12)           \
-  X(4, 7, 1, 0, 8)            \
-  X(4, 7, 1, 0, 12)           \
-  X(4, 4, 1, 0, 8)            \
+  X(4, 7, 1, 0, 8)
+// loader / consumer form (APHRO_WNA16_RING=-R)
+#define RES_LC_CONFIGS(X) \
+  X(4, 8, 1, 3, 8)        \
+  X(4, 8, 1, 3, 9)        \
+  X(4, 7, 1, 0, 8)        \
+  X(4, 7, 1, 0, 12)       \
+  X(4, 4, 1, 0, 8)        \
   X(4, 4, 1, 0, 12)
 #ifdef RES_NO_KEEP_RS   // lab: the row sums of pass 0 are recomputed in the later passes instead of kept (registers)
 #define RES_KEEP_RS(x) false
@@ -1177,7 +1239,7 @@ static int res_dispatch(const Wna16ResParams& p, const ResConfig& cf, hipStream_
 #endif
   if (p.a == nullptr) {   // packed activations: the ring kernel where it is instantiated (APHRO_WNA16_RING=0: the round-3 kernel)
 #ifdef RES_LAB_SET     // (lab: one process times several settings)
-    const char* ring_e = getenv("APHRO_WNA16_RING");     // R: the LDS-ring form; -R: the register-ring form
+    const char* ring_e = getenv("APHRO_WNA16_RING");     // R: the LDS-ring form; -R: with loader waves
     const int ring_env = ring_e ? atoi(ring_e) : 0;
 #else
     static const int ring_env = [] { const char* e = getenv("APHRO_WNA16_RING"); return e ? atoi(e) : 0; }();
@@ -1185,15 +1247,15 @@ static int res_dispatch(const Wna16ResParams& p, const ResConfig& cf, hipStream_
     const int ring = ring_env != 0 ? ring_env : RES_RING_DEFAULT;
 #define X(a, b, c, d, r)                                                                       \
     if (ring == r && cf.nwv == a && cf.nseg == b && cf.np4 == c && cf.rem == d)                \
-      return mt == 2 ? (p.trace ? res_launch_ring<2, a, b, c, d, r, true, true>(p, st) : res_launch_ring<2, a, b, c, d, r, true>(p, st)) \
-                     : res_launch_ring<1, a, b, c, d, r, true>(p, st);
+      return mt == 2 ? (p.trace ? res_launch_ring<2, a, b, c, d, r, false, true>(p, st) : res_launch_ring<2, a, b, c, d, r, false>(p, st)) \
+                     : res_launch_ring<1, a, b, c, d, r, false>(p, st);
     RES_RING_CONFIGS(X)
 #undef X
 #define X(a, b, c, d, r)                                                                       \
     if (ring == -r && cf.nwv == a && cf.nseg == b && cf.np4 == c && cf.rem == d)               \
-      return mt == 2 ? (p.trace ? res_launch_ring<2, a, b, c, d, r, false, true>(p, st) : res_launch_ring<2, a, b, c, d, r, false>(p, st)) \
-                     : res_launch_ring<1, a, b, c, d, r, false>(p, st);
-    RES_STREAM_CONFIGS(X)
+      return mt == 2 ? (p.trace ? res_launch_ring<2, a, b, c, d, r, true, true>(p, st) : res_launch_ring<2, a, b, c, d, r, true>(p, st)) \
+                     : res_launch_ring<1, a, b, c, d, r, true>(p, st);
+    RES_LC_CONFIGS(X)
 #undef X
   }
   if (p.a != nullptr) {   // row-major activations read in place: the configurations res_plan picks by itself

@@ -225,6 +225,12 @@ class LlamaDecoderLayer(nn.Module):
                 and ops.wna16_resident_ksplit(m, lin.out_features, lin.in_features, sc.shape[0]) == 1:
             self.gate_up_strip = ops.wna16_strip_relayout(qw, m, sc.shape[0])
         self.enable_resident_layouts(m)
+        # The op-level strip-major copy the quant method made at load time (gptq.py / awq.py process_weights_after_loading,
+        # 59 MB per layer on Llama-3-8B) is never read by the fused decode step, and with keep_original=False it would be
+        # a copy of the WRONG column order: release it (ADVICE r3 -- gate_up used to live four times in HBM).  The
+        # op-by-op forward of this layer then takes the generic op for gate_up, as it does for M > 32.
+        if getattr(lin, "qweight_strip", None) is not None:
+            lin.qweight_strip = None
         if not keep_original:
             lin.qweight.data, lin.qzeros.data, lin.scales.data = qw, qz, sc
         return True

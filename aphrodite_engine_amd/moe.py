@@ -78,7 +78,12 @@ def route_and_align(hidden_states: torch.Tensor, gating_output: torch.Tensor, to
         topk_weights, topk_ids = topk_weights.float().contiguous(), topk_ids.to(torch.int32).contiguous()
         out = moe_align_block_size(topk_ids, MOE_BLOCK_M, num_experts, want_inverse=want_inverse)
         return (topk_weights, topk_ids) + tuple(out) + (() if want_inverse else (None, ))
-    if (0 < t_ * topk <= ops.MOE_ROUTE_ALIGN_MAX_SLOTS and topk <= 8 and gating_output.stride(1) == 1
+    # the one-workgroup launcher's own limits (csrc/moe.hip aphro_moe_route_align): <= 256 experts, topk <= experts, and
+    # (slots + 66 E + 1) int32 of LDS <= 64 KB -- e.g. E = 128 with top-8 stops at 991 tokens, E >= 249 is never served.
+    # Outside them the separate ops below handle the call (the launcher's check used to surface as a RuntimeError)
+    if (0 < t_ * topk <= ops.MOE_ROUTE_ALIGN_MAX_SLOTS and topk <= 8 and topk <= num_experts <= 256
+            and (t_ * topk + 66 * num_experts + 1) * 4 <= 64 * 1024
+            and gating_output.stride(1) == 1
             and gating_output.dtype in (torch.float16, torch.bfloat16, torch.float32)
             and not os.environ.get("APHRO_MOE_NO_ROUTE_ALIGN")):
         return ops.moe_route_align(gating_output, topk, renormalize, num_experts, MOE_BLOCK_M, want_inverse)
@@ -455,8 +460,10 @@ class Fp8MoEMethod(FusedMoEMethodBase):
         for x in range(e):
             for sh in range(2):
                 rows = w13[x, sh * shard:(sh + 1) * shard, :]
-                dq = rows.to(torch.float32) * layer.w13_weight_scale.data[x, sh]       # per_tensor_dequantize
-                q, _ = ops.scaled_fp8_quant(dq.to(layer.orig_dtype), mx[x].reshape(1))
+                # per_tensor_dequantize (w8a8_utils.py:23-28) widens to FLOAT16 whatever the model dtype and multiplies
+                # there; the requantisation reads that f16 tensor (rounding through bf16 changed some e4m3 words)
+                dq = rows.to(torch.float16) * layer.w13_weight_scale.data[x, sh]
+                q, _ = ops.scaled_fp8_quant(dq, mx[x].reshape(1))
                 rows.copy_(q)
         layer.w13_weight_scale = nn.Parameter(mx.contiguous(), requires_grad=False)
         layer.w13_weight = nn.Parameter(w13, requires_grad=False)
@@ -533,7 +540,8 @@ class FusedMoE(nn.Module):
                 param.data[expert_id] = loaded_weight.reshape(())
             return
         if "input_scale" in weight_name:               # (layer.py:299-304; w1 and w3 of a layer must agree)
-            if shard_id == "w3" and param.data[expert_id] != 1 and \
+            # (checked whichever of w1 / w3 arrives second, as the reference does: 1 is the "nothing loaded yet" value)
+            if shard_id in ("w1", "w3") and param.data[expert_id] != 1 and \
                     (param.data[expert_id] - loaded_weight.reshape(())).abs() > 1e-5:
                 raise ValueError("input_scales of w1 and w3 of a layer must be equal. But got "
                                  f"{param.data[expert_id]} vs. {loaded_weight}")

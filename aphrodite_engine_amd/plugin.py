@@ -38,11 +38,13 @@ def register() -> None:
             from aphrodite.modeling.models import ModelRegistry
             from .reference_model import register_with_reference as reg_model
             reg_model(ModelRegistry)
-        except Exception:
-            pass
+        except Exception as exc:    # opted in and did not happen: say so, the op-level path still works
+            import logging
+            logging.getLogger(__name__).warning("APHRODITE_MI355X_FUSED_MODEL=1 but the fused model was not registered: %r", exc)
     try:   # GroupCoordinator builds ``ca_comm = CustomAllreduce(group=cpu_group, device=...)`` (parallel_state.py:186-196)
         import aphrodite.distributed.device_communicators.custom_all_reduce as ref_ca
         from .distributed.custom_all_reduce import CustomAllreduce
         ref_ca.CustomAllreduce = CustomAllreduce
-    except Exception:
-        pass
+    except Exception as exc:
+        import logging
+        logging.getLogger(__name__).warning("custom all-reduce not swapped in (%r): the reference's own communicator stays", exc)

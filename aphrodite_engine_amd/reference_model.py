@@ -45,7 +45,13 @@ class MI355XLlamaForCausalLM(nn.Module):
         hf = config.to_dict() if hasattr(config, "to_dict") else dict(vars(config))
         self.config = config
         self.cfg = L.llama_config_from_hf(hf)
-        dtype = hf.get("torch_dtype") or getattr(config, "torch_dtype", None) or torch.get_default_dtype()
+        # The engine's RESOLVED dtype wins over the checkpoint's: the reference's loader builds the model under
+        # set_default_torch_dtype(model_config.dtype) (modeling/model_loader/loader.py:384-390), and that dtype -- e.g.
+        # --dtype half for a GPTQ checkpoint whose config says bfloat16 -- is what the KV cache and the model runner use.
+        # hf.torch_dtype only decides when the default is still torch's own float32 (standalone construction).
+        dtype = extra.get("dtype") or torch.get_default_dtype()
+        if dtype == torch.float32:
+            dtype = hf.get("torch_dtype") or getattr(config, "torch_dtype", None) or dtype
         if isinstance(dtype, str):
             dtype = getattr(torch, dtype)
         kv_cache_dtype = getattr(cache_config, "cache_dtype", "auto") if cache_config is not None else "auto"

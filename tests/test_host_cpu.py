@@ -437,6 +437,29 @@ def test_custom_routing_function_is_called_like_the_reference(monkeypatch):
     assert moe.route_and_align(x, g, 2, False, 8, custom_routing_function=routing)[5] is None
 
 
+def test_route_and_align_falls_back_outside_the_one_launch_forms_limits(monkeypatch):
+    """the one-workgroup route + align launcher serves <= 256 experts and (slots + 66 E + 1) int32 of LDS
+    <= 64 KB; the Python guard must send every other call to fused_topk + moe_align_block_size instead of letting the
+    launcher's check surface as a RuntimeError (E = 128 with top-8 stops at 991 tokens; E >= 249 is never served)."""
+    from aphrodite_engine_amd import moe
+    calls = []
+    monkeypatch.setattr(moe.ops, "moe_route_align", lambda *a, **k: calls.append("fused") or ("w", "i", "s", "e", "p", None))
+    monkeypatch.setattr(moe, "fused_topk", lambda h, g, k, r: calls.append("topk") or ("w", torch.zeros(1, dtype=torch.int32)))
+    monkeypatch.setattr(moe, "moe_align_block_size", lambda ids, b, e, want_inverse=False: ("s", "e", "p"))
+
+    def served(tokens, experts, topk):
+        calls.clear()
+        moe.route_and_align(torch.zeros(tokens, 8), torch.zeros(tokens, experts), topk, True, experts)
+        return calls == ["fused"]
+    assert served(32, 8, 2) and served(991, 128, 8) and served(1, 248, 8)
+    assert not served(4, 248, 8)          # LDS: 66 x 248 + slots + 1 words
+    assert not served(992, 128, 8)        # LDS
+    assert not served(1024, 128, 8)
+    assert not served(4, 249, 8)          # LDS at any token count
+    assert not served(4, 300, 8)          # more than 256 experts
+    assert not served(4, 4, 8)            # topk > experts
+
+
 def test_attention_impl_and_metadata_take_the_reference_layers_calls(monkeypatch):
     """What the reference's Attention layer and multi-step runner call on a backend: ``impl.forward(..., attn_type=)``
     (attention/layer.py:99-106; non-decoder types refused as rocm_flash_attn.py:395-399) and

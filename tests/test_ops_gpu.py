@@ -1794,6 +1794,62 @@ def test_paged_attention_split_kv_inside_the_launch(ops, splits, dtype, kv_cache
             os.environ["APHRO_PA_SPLITS"] = old
 
 
+def test_paged_attention_split_workspace_growth_keeps_captured_graphs_valid(ops):
+    """the split-KV scratch / ticket buffers have their raw pointers baked into captured graphs, so a
+    later call that needs MORE (the model runner captures many batch sizes and also runs eager decode) must never free or
+    move what an earlier capture points to.  Capture a small split launch, force a much larger workspace with an eager
+    call, scribble over freshly allocated memory, then replay the captured graph: same bits as before the growth."""
+    import os
+    rng = np.random.default_rng(77)
+    Hq, Hkv, D, BS = 16, 2, 128, 16
+    old = os.environ.get("APHRO_PA_SPLITS")
+
+    def problem(S, L):
+        seq_lens = np.full(S, L, np.int32)
+        bps = (L + BS - 1) // BS
+        NB = S * bps + 1
+        kc, vc = make_cache(rng, NB, Hkv, D, BS, torch.float16, "auto")
+        bt = rng.permutation(NB)[:S * bps].reshape(S, bps).astype(np.int32)
+        q = t(rng.standard_normal((S, Hq, D)).astype(np.float32), torch.float16)
+        return q, (q, kc, vc, Hkv, D ** -0.5, t(bt), t(seq_lens), BS, L, None, "auto", 1.0, 1.0)
+    try:
+        os.environ["APHRO_PA_SPLITS"] = "4"
+        q, args = problem(3, 1024)
+        want = torch.empty_like(q)
+        ops.paged_attention_v1(want, *args)            # (allocates the workspace outside any capture)
+        g_out = torch.empty_like(q)
+        gr = torch.cuda.CUDAGraph()
+        s_ = torch.cuda.Stream()
+        s_.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s_):
+            ops.paged_attention_v1(g_out, *args)
+        torch.cuda.current_stream().wait_stream(s_)
+        with torch.cuda.graph(gr):
+            ops.paged_attention_v1(g_out, *args)
+        gr.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(g_out, want)
+        # growth: far more (sequence, kv-head) groups x splits than any plan the launcher makes by itself
+        os.environ["APHRO_PA_SPLITS"] = "8"
+        q2, args2 = problem(1400, 256)
+        big = torch.empty_like(q2)
+        ops.paged_attention_v1(big, *args2)
+        torch.cuda.synchronize()
+        junk = [torch.full((1 << 22,), float("nan"), device="cuda") for _ in range(8)]   # reuse whatever was freed
+        torch.cuda.synchronize()
+        for _ in range(3):
+            g_out.fill_(float("nan"))
+            gr.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(g_out, want)
+        del junk
+    finally:
+        if old is None:
+            os.environ.pop("APHRO_PA_SPLITS", None)
+        else:
+            os.environ["APHRO_PA_SPLITS"] = old
+
+
 def test_paged_attention_rope_packed_split_matches_unsplit(ops):
     """The fused rotary + cache-write form with split-KV: the run that holds the new token writes its K / V, every run
     rotates q itself; caches bit-identical to the unsplit launch, output within the merge's fp32 rounding."""
