@@ -1163,6 +1163,7 @@ static int res_launch_ring(const Wna16ResParams& p, hipStream_t st) {
 #ifndef RES_RING_DEFAULT
 #define RES_RING_DEFAULT 0
 #endif
+#ifdef RES_LAB_SET
 #define RES_RING_CONFIGS(X) \
   X(4, 8, 1, 3, 8)          \
   X(4, 7, 1, 0, 8)
@@ -1174,6 +1175,11 @@ static int res_launch_ring(const Wna16ResParams& p, hipStream_t st) {
   X(4, 7, 1, 0, 12)       \
   X(4, 4, 1, 0, 8)        \
   X(4, 4, 1, 0, 12)
+#else    // product builds: the round-4 ring forms are lab material (tools/reslab.hip; DESIGN.md 5 "ring kernel": they match
+         // the register-ring kernel within noise on every configs[1] shape) and are not instantiated
+#define RES_RING_CONFIGS(X)
+#define RES_LC_CONFIGS(X)
+#endif
 #ifdef RES_NO_KEEP_RS   // lab: the row sums of pass 0 are recomputed in the later passes instead of kept (registers)
 #define RES_KEEP_RS(x) false
 #else

@@ -63,12 +63,22 @@ def parse_args():
     ap.add_argument("--sampling", default="greedy", choices=["greedy", "random"],
                     help="random: temperature 0.8, top-k 50, top-p 0.95 through the fused sampling kernel "
                          "(in-kernel noise, per-row seeds advanced on the device) instead of argmax")
-    ap.add_argument("--no-overlap", action="store_true",
-                    help="tp only: keep the all-reduces on the compute stream (default: side stream + weight prefetch)")
+    ap.add_argument("--overlap", action="store_true",
+                    help="tp only: all-reduces on a side stream + a prefetch of the next projection's weights through the "
+                         "Infinity Cache on the compute stream.  OFF by default since round 4: the same side-stream prefetch "
+                         "made the one-GPU step 38-61 %% slower (profiles/r3_prefetch_lab.txt) and no multi-GPU box has shown "
+                         "the all-reduce side of the trade; the TP section of a multi-GPU run still reports both arms")
+    ap.add_argument("--no-overlap", action="store_true", help="(accepted for older command lines: overlap is off by default)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prefill-info", action="store_true", help="skip the MFMA-bound prefill kernels' info section")
     ap.add_argument("--no-ops-path", action="store_true", help="skip the second measurement on the op-by-op (drop-in) path")
+    ap.add_argument("--ragged", action="store_true",
+                    help="ragged context lengths randint(1, ctx) (seed 0; SURVEY 8d, the reference's "
+                         "tests/benchmarks/kernels/paged_attention.py) instead of one length for every sequence")
+    ap.add_argument("--no-extra-legs", action="store_true",
+                    help="skip the extra legs of the default run (FP8 configs, ragged batch, TP shards: each a child "
+                         "process of this script, summarised under `legs` in the line)")
     ap.add_argument("--no-tp-section", action="store_true",
                     help="N > 1, replicas: skip the tensor-parallel section (TP = N timing, overlap A/B, all-reduce latencies)")
     ap.add_argument("--layers", type=int, default=0, help="debug only: fewer layers (marks the line invalid)")
@@ -122,8 +132,14 @@ class DecodeLoop:
         self.model, self.cfg, self.bs = model, cfg, 16
         self.block_size = 16
         max_len = args.ctx + total_steps + 1
+        ctx = args.ctx
+        if getattr(args, "ragged", False):
+            import random
+            rnd = random.Random(0)
+            ctx = [rnd.randint(1, args.ctx) for _ in range(args.batch)]
+        self.ctx_sum0 = float(sum(ctx)) if not isinstance(ctx, int) else float(ctx * args.batch)
         self.meta, self.positions, nblocks = M.make_decode_metadata(
-            args.batch, args.ctx, self.block_size, device,
+            args.batch, ctx, self.block_size, device,
             blocks_per_seq=(max_len + self.block_size - 1) // self.block_size)
         self.meta.max_decode_seq_len = max_len      # capture-time maximum
         self.kv_caches = M.make_kv_caches(cfg, nblocks, self.block_size, dtype,
@@ -562,7 +578,7 @@ def tp_section(args, device, world, rank, one_gpu):
     total = 2 * (args.warmup + args.steps + 8)
     loop = DecodeLoop(model, cfg, dtype, args, device, total)
     with torch.no_grad():
-        for name, on in (("overlap", True), ("no_overlap", False)):
+        for name, on in (("no_overlap", False), ("overlap", True)):     # (the default arm first: it is the one that counts)
             D.enable_all_reduce_overlap(device, enabled=on)
             try:
                 el = timed_decode(loop, args, world, one_gpu, device, ca)
@@ -619,7 +635,7 @@ def main():
         # xGMI peer-access all-reduce for the [M, hidden] sums (RCCL stays the fallback for ineligible sizes)
         ca = D.enable_custom_all_reduce(device)
     overlap = None
-    if tp > 1 and not args.no_overlap:
+    if tp > 1 and args.overlap and not args.no_overlap:
         overlap = D.enable_all_reduce_overlap(device)
 
     model, cfg, dtype = build(args, device)
@@ -667,6 +683,8 @@ def main():
         if ca is not None:
             ca.check()      # a timed-out barrier would have produced garbage: fail loudly
         ctx_end = int(loop.meta.seq_lens_tensor[0].item())
+        ctx_mean_end = float(loop.meta.seq_lens_tensor.float().mean().item())
+        ctx_mean_start = loop.ctx_sum0 / args.batch
         # ---- the same workload on the OP-BY-OP path: what a reference LlamaDecoderLayer (modeling/models/llama.py:234,
         # quant_method.apply -> ops.gptq_gemm, quantization/gptq.py:230-243; Attention.forward -> ops.reshape_and_cache +
         # ops.paged_attention_*) gets through the plugin without adopting forward_decode_fused: one launch per reference op
@@ -722,7 +740,8 @@ def main():
         w_bytes = model.weight_bytes_per_layer(active_frac) * cfg.num_hidden_layers
         lm_head = model.lm_head.numel() * 2
         esz = 1 if args.kv_cache_dtype != "auto" else 2
-        ctx_mid = (args.ctx + args.warmup + 2 + ctx_end) / 2.0
+        # mean context over the timed steps (uniform lengths: the first sequence's; --ragged: the batch mean)
+        ctx_mid = (ctx_mean_start + args.warmup + 2 + ctx_mean_end) / 2.0
         tp_eff = max(tp, args.sim_tp, 1)
         kv_bytes = args.batch * ctx_mid * 2 * max(1, cfg.num_key_value_heads // tp_eff) * cfg.head_dim * esz * cfg.num_hidden_layers
         step_bytes = w_bytes + lm_head + kv_bytes
@@ -773,7 +792,10 @@ def main():
                 "workload": f"{ {'llama3-8b': 'Llama-3-8B', 'llama3-70b': 'Llama-3-70B', 'mixtral-8x7b': 'Mixtral-8x7B (top-2 of 8 experts)'}[args.model]} "
                             f"{args.quant.upper()} {('W8A8' + (' static input scales' if args.act_scheme == 'static' else '')) if args.quant.startswith('fp8') else '4-bit g128'}, decode, "
                             f"{'greedy' if args.sampling == 'greedy' else 'random sampling (T 0.8, top-k 50, top-p 0.95)'}, "
-                            f"bs={args.batch}/GPU, context {args.ctx}->{ctx_end}, kv_cache={args.kv_cache_dtype}, "
+                            f"bs={args.batch}/GPU, "
+                            + (f"ragged contexts randint(1, {args.ctx}) (seed 0; mean {ctx_mean_start:.0f}->{ctx_mean_end:.0f}), "
+                               if args.ragged else f"context {args.ctx}->{ctx_end}, ")
+                            + f"kv_cache={args.kv_cache_dtype}, "
                             f"block_size=16, HIP-graph={'off' if args.no_graph else 'on'}",
                 "global_batch": args.batch * replicas,
                 "seq_len": args.ctx,
@@ -860,10 +882,64 @@ def main():
         except Exception as e:  # never lose the GPU number to a CPU-side problem
             line["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": os.cpu_count(),
                                     "kind": "port", "sample": f"failed: {e!r}"}
+    if world == 1 and default_workload(args) and not args.no_extra_legs and not os.environ.get("APHRO_BENCH_LEG"):
+        line["legs"] = extra_legs(args)
+        # the FP8 half of the metric next to the int4 headline
+        line["fp8"] = {k: line["legs"][k] for k in ("fp8_w8a8_fp8kv_ctx8192", "fp8_w8a8_ctx1024") if k in line["legs"]}
     print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def default_workload(args) -> bool:
+    """True for the driver's command (`bench.py --gpus 1 --steps K --warmup W`): the extra legs ride on that line only."""
+    return (args.model == "llama3-8b" and args.quant == "gptq" and args.kv_cache_dtype == "auto" and args.batch == 32
+            and args.ctx == 1024 and args.sim_tp <= 1 and not args.ragged and not args.layers and not args.no_graph
+            and args.sampling == "greedy")
+
+
+# The legs of the default run: BASELINE.json configs[2] (FP8 weights + FP8 KV at 8192 tokens), the FP8 model at the
+# headline's context, a ragged batch of the headline workload, and ONE rank of configs[3] / configs[4] (real shard shapes,
+# all-reduces replaced by a stream-holding stub -- no multi-GPU box has been available to this project).  Each leg is this
+# script again in a child process (own HIP context, the parent's model already freed), timed exactly like the headline.
+LEGS = {
+    "fp8_w8a8_fp8kv_ctx8192": ["--quant", "fp8ct", "--kv-cache-dtype", "fp8", "--ctx", "8192"],
+    "fp8_w8a8_ctx1024": ["--quant", "fp8ct"],
+    "int4_ragged": ["--ragged"],
+    "cfg3_llama70b_awq_tp8_one_rank": ["--model", "llama3-70b", "--quant", "awq", "--batch", "64", "--sim-tp", "8"],
+    "cfg4_mixtral_gptq_tp4_one_rank": ["--model", "mixtral-8x7b", "--sim-tp", "4"],
+}
+
+
+def extra_legs(args):
+    import subprocess
+    out = {}
+    env = dict(os.environ, APHRO_BENCH_LEG="1")
+    budget_s = float(os.environ.get("APHRO_BENCH_LEG_TIMEOUT_S", "150"))
+    for name, extra in LEGS.items():
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(args.steps), "--warmup", str(args.warmup),
+               "--no-cpu-baseline", "--no-prefill-info", "--no-ops-path"] + extra
+        try:
+            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=budget_s)
+            rec = None
+            for ln in r.stdout.splitlines():
+                if ln.startswith("{") and '"metric"' in ln:
+                    rec = json.loads(ln)
+            if rec is None:
+                out[name] = {"error": (r.stderr or r.stdout)[-300:]}
+                continue
+            roof = rec.get("roofline", {})
+            out[name] = {"value": rec["value"], "unit": rec["unit"], "ms_per_step": rec["ms_per_step"],
+                         "workload": rec["config"]["workload"], "parallelism": rec["config"].get("parallelism"),
+                         "roofline": {"kernel": roof.get("kernel"), "frac": roof.get("frac"), "step_frac": roof.get("step_frac"),
+                                      "avg_launch_us": roof.get("avg_launch_us")},
+                         "per_kernel_us": {k: round(v["avg_us"], 2) for k, v in rec.get("roofline_all", {}).items()}}
+            if "simulated_all_reduce_us" in rec["config"]:
+                out[name]["simulated_all_reduce_us"] = rec["config"]["simulated_all_reduce_us"]
+        except Exception as e:
+            out[name] = {"error": repr(e)[:300]}
+    return out
 
 
 if __name__ == "__main__":

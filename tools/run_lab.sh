@@ -1,12 +1,15 @@
 cd $GRAFT_REPO_ROOT
-B=tools/bin
-L=aphrodite_engine_amd/lib/libaphrodite_mi355x.so
 mkdir -p gpurun_out
-V=$B/lab_vf.so
-timeout 200 $B/reslab --shapes gate_up,down,qkv $L "$V" "$V@APHRO_WNA16_RING=-8;RESLAB_TRACE=1" "$V@APHRO_WNA16_RING=-9" "$V@APHRO_WNA16_RING=-12;RESLAB_TRACE=1" \
-  "$B/lab_vfq.so@APHRO_WNA16_RING=-8" "$B/lab_vfq.so@APHRO_WNA16_RING=-9" "$B/lab_vfq.so@APHRO_WNA16_RING=-12" \
-  "$B/lab_vf3.so@APHRO_WNA16_RING=-8" "$B/lab_vf3.so@APHRO_WNA16_RING=-9" "$B/lab_vf3.so@APHRO_WNA16_RING=-12" "$V" \
-  > gpurun_out/reslab7.jsonl 2> gpurun_out/reslab7.err
-echo rc=$?
-grep -v skipped gpurun_out/reslab7.jsonl | cut -c1-420
-tail -5 gpurun_out/reslab7.err
+python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r4_bench_default.json 2> gpurun_out/r4_bench_default.err
+echo bench rc=$?
+python3 - <<'PY'
+import json
+d=json.loads(open('gpurun_out/r4_bench_default.json').read().strip().splitlines()[-1])
+print("value", d["value"], "ms", d["ms_per_step"], "step_frac", d["roofline"]["step_frac"], "dom", d["roofline"]["kernel"], d["roofline"]["frac"])
+print({k: round(v["avg_us"],2) for k,v in d["roofline_all"].items()})
+print("ops_path", d.get("value_ops_path"))
+for k,v in d.get("legs",{}).items():
+    print(k, {kk: vv for kk,vv in v.items() if kk in ("value","ms_per_step","error")})
+PY
+python bench.py --gpus 1 --steps 20 --warmup 5 --no-extra-legs --no-cpu-baseline --no-prefill-info 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('again', d['value'], d['ms_per_step'], d.get('value_ops_path'))"
+python bench.py --gpus 1 --steps 64 --warmup 8 --no-extra-legs --no-cpu-baseline --no-prefill-info --no-ops-path 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('again64', d['value'], d['ms_per_step'], d.get('value_ops_path'))"
