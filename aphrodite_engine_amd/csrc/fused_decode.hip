@@ -51,7 +51,11 @@ __device__ __forceinline__ uint16_t to_f16_bits(uint16_t tbits) {
 // COMBINE (the norm that follows a sparse MLP): x = moe_combine of the expert GEMM's fp32 slabs, sum_k round_T(w[t, k] *
 // sum_s slab[s][inv_pos[t k + kk]]) rounded to T -- moe_combine_kernel's arithmetic (moe.hip), without its launch and its
 // [T, hidden] round trip.
-template <typename T, bool ROUTER = false, bool COMBINE = false>
+// NS > 0 (dense decode layers, round 4): x = the sum of exactly NS slabs, every load of a thread -- the NS slab pieces, the
+// residual, the norm weights -- issued BEFORE the first wait.  With the runtime `nslab` loop hipcc emits load, wait, add
+// per slab and the residual load behind them: five dependent L2 / Infinity-Cache round trips in a 4.9 us launch.  Same
+// additions in the same order: bit-identical.
+template <typename T, bool ROUTER = false, bool COMBINE = false, int NS = 0>
 __global__ void add_rms_norm_pack_kernel(const uint16_t* __restrict__ input, const float* __restrict__ slabs,
                                          int nslab, uint16_t* __restrict__ residual, int has_residual,
                                          const uint16_t* __restrict__ weight, float eps,
@@ -108,6 +112,42 @@ __global__ void add_rms_norm_pack_kernel(const uint16_t* __restrict__ input, con
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) x[j] = T::to_f32(T::from_f32(acc8[j]));
+      } else if constexpr (NS > 0) {
+        f32x4 sa[NS], sb[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+          sa[s] = *reinterpret_cast<const f32x4*>(slabs + s * slab_stride + off);
+          sb[s] = *reinterpret_cast<const f32x4*>(slabs + s * slab_stride + off + 4);
+        }
+        // (the residual rides along: a pointer select, not a branch -- when there is none the weights are re-read, unused)
+        u16x8 r_early = *reinterpret_cast<const u16x8*>(has_residual ? residual + off : weight + 8 * i);
+        asm volatile("" : "+v"(r_early));    // (used HERE as far as hipcc can tell: it would sink the load into the branch below)
+        f32x4 a = sa[0], b = sb[0];
+#pragma unroll
+        for (int s = 1; s < NS; ++s) { a += sa[s]; b += sb[s]; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          x[j] = T::to_f32(T::from_f32(a[j]));
+          x[4 + j] = T::to_f32(T::from_f32(b[j]));
+        }
+        u16x8 rs2;
+        if (has_residual) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            rs2[j] = T::from_f32(x[j] + T::to_f32(r_early[j]));
+            v[it][j] = T::to_f32(rs2[j]);
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            rs2[j] = T::from_f32(x[j]);
+            v[it][j] = x[j];
+          }
+        }
+        if (residual) *reinterpret_cast<u16x8*>(residual + off) = rs2;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ss += v[it][j] * v[it][j];
+        continue;
       } else if (slabs) {
         f32x4 a = *reinterpret_cast<const f32x4*>(slabs + off);
         f32x4 b = *reinterpret_cast<const f32x4*>(slabs + off + 4);
@@ -417,11 +457,16 @@ extern "C" int aphro_fused_add_rms_norm_pack(const void* input, const float* sla
   t = (t + 63) / 64 * 64;
   t = t < 64 ? 64 : (t > 1024 ? 1024 : t);
   dim3 grid((unsigned)tokens), block(t);
-#define L(TT)                                                                                                   \
-  hipLaunchKernelGGL((add_rms_norm_pack_kernel<TT>), grid, block, 0, (hipStream_t)stream, (const uint16_t*)input, \
-                     slabs, nslab, (uint16_t*)residual, has_residual, (const uint16_t*)weight, eps,             \
+#define L(TT, NSV)                                                                                                        \
+  hipLaunchKernelGGL((add_rms_norm_pack_kernel<TT, false, false, NSV>), grid, block, 0, (hipStream_t)stream, (const uint16_t*)input, \
+                     slabs, nslab, (uint16_t*)residual, has_residual, (const uint16_t*)weight, eps,                         \
                      (uint16_t*)packed, (uint16_t*)out, (int)tokens, hidden)
-  if (dtype == APHRO_F16) L(Half); else L(BFloat);
+#define LS(NSV) do { if (dtype == APHRO_F16) L(Half, NSV); else L(BFloat, NSV); } while (0)
+  if (slabs != nullptr && nslab == 4 && !getenv("APHRO_NORM_GENERIC")) LS(4);
+  else if (slabs != nullptr && nslab == 2 && !getenv("APHRO_NORM_GENERIC")) LS(2);
+  else if (slabs != nullptr && nslab == 8 && !getenv("APHRO_NORM_GENERIC")) LS(8);
+  else LS(0);
+#undef LS
 #undef L
   APHRO_LAUNCH_CHECK();
   return APHRO_OK;
