@@ -1171,6 +1171,57 @@ def scaled_mm_fp8_slabs(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     return slabs
 
 
+def fp8_gemm_resident_ksplit(m: int, n: int, k: int) -> int:
+    """K slices of the resident FP8 decode GEMM's plan for [m, k] x [n, k]^T (0: shape not served; m <= 32)."""
+    return int(_lib.lib().aphro_fp8_gemm_resident_ksplit(m, n, k))
+
+
+def fp8_strip_relayout(weight: torch.Tensor, m: int = 32) -> torch.Tensor:
+    """Load time: the [N, K] e4m3 checkpoint tensor -> the strip-major copy ops.fp8_gemm_resident streams (every wave's
+    1 KiB pieces in the order it reads them; csrc/fp8_gemm_resident.hip).  Same bytes, permuted."""
+    check_fp8_buffer(weight, "fp8_strip_relayout")
+    if weight.dim() != 2 or not weight.is_contiguous():
+        raise RuntimeError("fp8_strip_relayout: weight must be a contiguous [N, K] tensor")
+    n, k = weight.shape
+    out = torch.empty_like(weight)
+    check(_lib.lib().aphro_fp8_strip_relayout(weight.data_ptr(), out.data_ptr(), m, n, k, _stream()), "fp8_strip_relayout")
+    return out
+
+
+def fp8_gemm_resident(a: torch.Tensor, w_strip: torch.Tensor, scale_a: Optional[torch.Tensor] = None,
+                      scale_b: Optional[torch.Tensor] = None, out_dtype: Optional[torch.dtype] = None,
+                      bias: Optional[torch.Tensor] = None, slabs: bool = False) -> torch.Tensor:
+    """FP8 W8A8 decode GEMM (<= 32 rows) on the strip-major copy of a [N, K] weight: ``slabs=True`` returns the raw fp32
+    accumulators [ksplit, M, N] (the role of scaled_mm_fp8_slabs), else ``scale_a * (scale_b * acc) (+ bias)`` in
+    ``out_dtype`` (the role of cutlass_scaled_mm; plans with one K slice only)."""
+    m, k = a.shape
+    n = w_strip.shape[0]
+    if w_strip.shape[1] != k or not a.is_contiguous() or not w_strip.is_contiguous():
+        raise RuntimeError("fp8_gemm_resident: a [M, K] and the strip-major copy of a [N, K] weight expected")
+    check_fp8_buffer(a, "fp8_gemm_resident")
+    check_fp8_buffer(w_strip, "fp8_gemm_resident")
+    lib = _lib.lib()
+    ks = lib.aphro_fp8_gemm_resident_ksplit(m, n, k)
+    if ks <= 0:
+        raise RuntimeError(f"fp8_gemm_resident: shape M={m} N={n} K={k} not served")
+    if slabs:
+        out = torch.empty((ks, m, n), dtype=torch.float32, device=a.device)
+        check(lib.aphro_fp8_gemm_resident(a.data_ptr(), k, w_strip.data_ptr(), None, None, None, None, out.data_ptr(),
+                                          out.numel() * 4, m, n, k, 0, 0, _dt_of(torch.float16), _stream()), "fp8_gemm_resident")
+        return out
+    if ks != 1:
+        raise RuntimeError(f"fp8_gemm_resident: M={m} N={n} K={k} is K-sliced ({ks}): slabs only")
+    sa = scale_a.to(torch.float32).contiguous()
+    sb = scale_b.to(torch.float32).contiguous()
+    if bias is not None and (bias.dtype != out_dtype or bias.numel() != n):
+        raise RuntimeError("fp8_gemm_resident: bias must be [N] in the output dtype")
+    out = torch.empty((m, n), dtype=out_dtype, device=a.device)
+    check(lib.aphro_fp8_gemm_resident(a.data_ptr(), k, w_strip.data_ptr(), sa.data_ptr(), sb.data_ptr(), _ptr(bias),
+                                      out.data_ptr(), None, 0, m, n, k, 1 if sa.numel() > 1 else 0,
+                                      1 if sb.numel() > 1 else 0, _dt_of(out_dtype), _stream()), "fp8_gemm_resident")
+    return out
+
+
 def fp8_gemm_silu_quant_supported(m: int, n: int, k: int) -> bool:
     return bool(_lib.lib().aphro_fp8_gemm_stream_silu_supported(m, n, k))
 

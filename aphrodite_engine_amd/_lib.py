@@ -98,6 +98,9 @@ SIGNATURES = {
     "aphro_fp8_gemm_stream_ksplit": (I, [L, L, L]),
     "aphro_fp8_gemm_stream": (I, [P, L, P, P, P, P, P, P, Z, L, L, L, I, I, I, P]),
     "aphro_fp8_gemm_stream_silu_supported": (I, [L, L, L]),
+    "aphro_fp8_gemm_resident_ksplit": (I, [L, L, L]),
+    "aphro_fp8_strip_relayout": (I, [P, P, L, L, L, P]),
+    "aphro_fp8_gemm_resident": (I, [P, L, P, P, P, P, P, P, Z, L, L, L, I, I, I, P]),
     "aphro_fp8_gemm_stream_silu_quant": (I, [P, L, P, P, P, P, P, P, L, L, L, I, I, I, P]),
     "aphro_gptq_dequant_bits": (I, [P, P, P, P, P, L, L, L, I, I, P]),
     "aphro_gptq_gemm_bits_supported": (I, [L, L, L, L, I]),

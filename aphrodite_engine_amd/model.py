@@ -200,6 +200,7 @@ class LlamaDecoderLayer(nn.Module):
         self.gate_up_interleaved = None
         self.gate_up_strip = None
         self.strip = {}
+        self.fp8_strip = {}
         self.fuse_rope_attention = True
 
     def enable_fused_silu(self, m: int = 32, keep_original: bool = True) -> bool:
@@ -234,6 +235,29 @@ class LlamaDecoderLayer(nn.Module):
         if not keep_original:
             lin.qweight.data, lin.qzeros.data, lin.scales.data = qw, qz, sc
         return True
+
+    def enable_fp8_strips(self, m: int = 32) -> None:
+        """Strip-major copies of the FP8 projections for the resident W8A8 decode GEMM at <= 32 rows
+        (csrc/fp8_gemm_resident.hip: one workgroup per CU, a wave's weights as one stream of lane-linear 1 KiB pieces).
+        A second copy of every matrix it serves (7 GB on Llama-3-8B: the [N, K] originals keep serving > 32 rows and
+        prefill); APHRO_DECODE_NO_FP8_RESIDENT=1 keeps the round-3 kernels."""
+        self.fp8_strip = {}
+        if os.environ.get("APHRO_DECODE_NO_FP8_RESIDENT") or self.is_moe:
+            return
+        for name in ("qkv_proj", "o_proj", "gate_up_proj", "down_proj"):
+            w = getattr(getattr(self, name), "weight", None)
+            if w is None or w.dtype != torch.float8_e4m3fn or w.dim() != 2:
+                continue
+            wt = w.t()                                   # the [N, K] checkpoint tensor behind the column-major [K, N] view
+            if wt.is_contiguous() and ops.fp8_gemm_resident_ksplit(m, wt.shape[0], wt.shape[1]) > 0:
+                self.fp8_strip[name] = ops.fp8_strip_relayout(wt, m)
+
+    def _fp8_slabs(self, name: str, qx: torch.Tensor) -> torch.Tensor:
+        """Raw fp32 split-K slabs of FP8 projection ``name``: the resident kernel on its strip-major copy at <= 32 rows."""
+        st = self.fp8_strip.get(name) if qx.shape[0] <= 32 else None
+        if st is not None:
+            return ops.fp8_gemm_resident(qx, st, slabs=True)
+        return ops.scaled_mm_fp8_slabs(qx, getattr(self, name).weight)
 
     def enable_resident_layouts(self, m: int = 32) -> None:
         """Strip-major copies of the qkv and down weights for the resident kernel at <= 32 rows (same K partition as the
@@ -443,7 +467,7 @@ class LlamaDecoderLayer(nn.Module):
         else:
             qx, sx, _ = ops.fused_add_rms_norm_quant_fp8(None, prev[0], prev[1], prev[2], residual, True,
                                                          self.input_layernorm, eps, static_scale=s_qkv)
-        qkv_slabs = ops.scaled_mm_fp8_slabs(qx, self.qkv_proj.weight)
+        qkv_slabs = self._fp8_slabs("qkv_proj", qx)
         from .attention.paged_attn import PagedAttention
         key_cache, value_cache = PagedAttention.split_kv_cache(kv_cache, self.num_kv_heads, self.head_dim)
         # static scheme: the attention launch writes the o_proj input as e4m3 itself, and gate_up + SiluAndMul + the
@@ -471,7 +495,7 @@ class LlamaDecoderLayer(nn.Module):
             qh, sh, _ = ops.fused_add_rms_norm_quant_fp8(o, None, None, None, residual, True,
                                                          self.post_attention_layernorm, eps, static_scale=s_gu)
         else:
-            o_slabs = ops.scaled_mm_fp8_slabs(qa, self.o_proj.weight)
+            o_slabs = self._fp8_slabs("o_proj", qa)
             qh, sh, _ = ops.fused_add_rms_norm_quant_fp8(None, o_slabs, sa, self.o_proj.weight_scale, residual,
                                                          True, self.post_attention_layernorm, eps, static_scale=s_gu)
         if fuse_static and ops.fp8_gemm_silu_quant_supported(m, self.gate_up_proj.out_features,
@@ -479,14 +503,18 @@ class LlamaDecoderLayer(nn.Module):
             qd = ops.fp8_gemm_silu_quant(qh, self.gate_up_proj.weight, sh, self.gate_up_proj.weight_scale, s_dn, act_dtype)
             sd = s_dn
         else:
-            gate_up = ops.cutlass_scaled_mm(qh, self.gate_up_proj.weight, out_dtype=act_dtype, scale_a=sh,
-                                            scale_b=self.gate_up_proj.weight_scale)
+            gu_strip = self.fp8_strip.get("gate_up_proj") if m <= 32 else None
+            if gu_strip is not None and ops.fp8_gemm_resident_ksplit(m, gu_strip.shape[0], gu_strip.shape[1]) == 1:
+                gate_up = ops.fp8_gemm_resident(qh, gu_strip, sh, self.gate_up_proj.weight_scale, out_dtype=act_dtype)
+            else:
+                gate_up = ops.cutlass_scaled_mm(qh, self.gate_up_proj.weight, out_dtype=act_dtype, scale_a=sh,
+                                                scale_b=self.gate_up_proj.weight_scale)
             qd, sd, _ = ops.silu_and_mul_quant_fp8(gate_up, static_scale=s_dn)
         if self.tp > 1:
             d = ops.cutlass_scaled_mm(qd, self.down_proj.weight, out_dtype=act_dtype, scale_a=sd,
                                       scale_b=self.down_proj.weight_scale)
             return tensor_model_parallel_all_reduce(d), None
-        return None, (ops.scaled_mm_fp8_slabs(qd, self.down_proj.weight), sd, self.down_proj.weight_scale)
+        return None, (self._fp8_slabs("down_proj", qd), sd, self.down_proj.weight_scale)
 
     def forward(self, positions, hidden, residual, kv_cache, attn_metadata, cos_sin):
         eps = self.cfg.rms_norm_eps

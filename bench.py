@@ -120,6 +120,9 @@ def build(args, device):
         # load-time relayout: SiluAndMul + pack run in the gate_up GEMM epilogue
         for layer in model.layers:
             layer.enable_fused_silu(args.batch, keep_original=False)
+    if args.quant.startswith("fp8") and args.batch <= 32:
+        for layer in model.layers:
+            layer.enable_fp8_strips(args.batch)     # load-time relayout for the resident W8A8 decode GEMM
     return model, cfg, dtype
 
 
@@ -287,14 +290,20 @@ def roofline_section(model, loop, args):
             qx, sx = ops.scaled_fp8_quant(xin, None, use_per_token_if_dynamic=True)
             slab_form = name != "gate_up_proj"
 
-            def run_lin(name=name, qx=qx, sx=sx, slab_form=slab_form):
+            res8 = bs <= 32 and name in getattr(layers[0], "fp8_strip", {}) and (
+                slab_form or ops.fp8_gemm_resident_ksplit(bs, lin0.out_features, lin0.in_features) == 1)
+
+            def run_lin(name=name, qx=qx, sx=sx, slab_form=slab_form, res8=res8):
                 for layer in layers:
                     lin = getattr(layer, name)
                     if slab_form:
-                        ops.scaled_mm_fp8_slabs(qx, lin.weight)
+                        layer._fp8_slabs(name, qx)              # the resident kernel on the strip-major copy where the layer has one
+                    elif res8:
+                        ops.fp8_gemm_resident(qx, layer.fp8_strip[name], sx, lin.weight_scale, out_dtype=model.dtype)
                     else:
                         ops.cutlass_scaled_mm(qx, lin.weight, out_dtype=model.dtype, scale_a=sx, scale_b=lin.weight_scale)
-            kname = "fp8_gemm_fast_kernel" + (" (fp32 slabs)" if slab_form else " (scaled epilogue)")
+            kname = ("fp8_gemm_resident_kernel (strip-major weights)" if res8 else "fp8_gemm_fast_kernel") + \
+                (" (fp32 slabs)" if slab_form else " (scaled epilogue)")
         else:
             def run_lin(name=name, xin=xin):
                 for layer in layers:

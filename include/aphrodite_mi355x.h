@@ -743,6 +743,21 @@ int aphro_gptq_gemm_bits(const void* a, int64_t lda, const uint32_t* q_weight, c
 int aphro_gptq_make_sequential_bits(const uint32_t* q_weight, uint32_t* out, const int32_t* perm, int64_t K, int64_t N,
                                     int bits, void* stream);
 
+/* FP8 W8A8 decode GEMM for M <= 32, one workgroup per CU on a strip-major copy of the weight (round 4,
+ * csrc/fp8_gemm_resident.hip): same role and arithmetic as aphro_scaled_mm_fp8 / aphro_scaled_mm_fp8_slabs
+ * (cutlass_scaled_mm, kernels/quantization/cutlass_w8a8/scaled_mm_entry.cu:92-137; torch._scaled_mm on ROCm,
+ * quantization/utils/w8a8_utils.py:83-183).  aphro_fp8_gemm_resident_ksplit: K slices of the plan for (M, N, K), 0 =
+ * shape not served.  aphro_fp8_strip_relayout: load time, [N, K] row-major e4m3 -> the strip-major order of that plan
+ * (a permutation of 16-byte pieces; out != w).  aphro_fp8_gemm_resident: a e4m3 [M, lda] (lda % 16 == 0), exactly one
+ * of out ([M, N] in `dtype` = a_scales * (b_scales * acc) + bias, plans with one K slice) / slabs (fp32
+ * [ksplit][M][N] raw accumulators for a fused consumer). */
+int aphro_fp8_gemm_resident_ksplit(int64_t M, int64_t N, int64_t K);
+int aphro_fp8_strip_relayout(const void* w, void* out, int64_t M, int64_t N, int64_t K, void* stream);
+int aphro_fp8_gemm_resident(const void* a, int64_t lda, const void* w_strip, const float* a_scales,
+                            const float* b_scales, const void* bias, void* out, float* slabs, size_t slabs_bytes,
+                            int64_t M, int64_t N, int64_t K, int a_scale_per_token, int b_scale_per_channel,
+                            int dtype, void* stream);
+
 /* FP8 W8A8 decode GEMM for M <= 32 on the LDS-DMA streaming structure (round 3, csrc/fp8_gemm_stream.hip): same role and
  * arithmetic as aphro_scaled_mm_fp8 / aphro_scaled_mm_fp8_slabs (cutlass_scaled_mm, scaled_mm_entry.cu:92-137), which route
  * to it by themselves.  a e4m3 [M, lda], w e4m3 [N, K] row-major; exactly one of out ([M, N] in `dtype`, shapes whose K fits

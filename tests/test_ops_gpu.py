@@ -2225,6 +2225,70 @@ def test_fp8_gemm_stream_vs_oracle(ops, M, N, K, dtype):
         os.environ.pop("APHRO_FP8_STREAM_ALL")
 
 
+# ---- FP8 W8A8 decode GEMM, one workgroup per CU on a strip-major weight copy (csrc/fp8_gemm_resident.hip, round 4) -----
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [(32, 28672, 4096), (1, 28672, 4096), (17, 28672, 4096),     # gate_up: 112-column strips, one K slice
+                                   (32, 4096, 14336), (5, 4096, 14336),                        # down: 64 columns x K / 4
+                                   (32, 6144, 4096), (16, 6144, 4096),                         # qkv: 48 columns x K / 2
+                                   (32, 4096, 4096), (31, 4096, 4096),                         # o: 64 columns x K / 4
+                                   (32, 8192, 8192), (24, 7168, 8192)])                        # other plans
+def test_fp8_gemm_resident_vs_oracle(ops, M, N, K, dtype):
+    """The resident kernel in both output forms against oracle.fp8.scaled_mm (exact fp8 products, fp64 sums): raw fp32
+    slabs [ksplit, M, N] for every served shape (summed over the slices), and [M, N] with per-token x per-channel scales +
+    bias where the plan has one K slice (rows 16 .. 31 absent, a partial second tile, one row).  The strip relayout is a
+    permutation: same byte histogram, and a wrong piece order would not survive the comparison.  The slabs must also agree with scaled_mm_fp8_slabs' (same products, another order of fp32 sums)."""
+    from oracle import fp8 as ofp8
+    rng = np.random.default_rng(M * 7 + N + K)
+    ks = ops.fp8_gemm_resident_ksplit(M, N, K)
+    assert ks >= 1
+    a = ofp8.fp8_encode((rng.standard_normal((M, K)) * 1.5).astype(np.float32), "e4m3")
+    w = ofp8.fp8_encode((rng.standard_normal((N, K)) * 1.5).astype(np.float32), "e4m3")
+    ad, wd = t(a).view(torch.float8_e4m3fn), t(w).view(torch.float8_e4m3fn)
+    strip = ops.fp8_strip_relayout(wd, M)
+    assert strip.shape == wd.shape and strip.dtype == wd.dtype
+    assert torch.equal(torch.bincount(strip.view(torch.uint8).flatten().int(), minlength=256),
+                       torch.bincount(wd.view(torch.uint8).flatten().int(), minlength=256))
+    raw = ofp8.scaled_mm(a, w.T, 1.0, 1.0)
+    slabs = ops.fp8_gemm_resident(ad, strip, slabs=True)
+    assert slabs.shape == (ks, M, N)
+    got = slabs.double().sum(0).cpu().numpy()
+    np.testing.assert_allclose(got, raw, rtol=1e-5, atol=1e-3 * np.abs(raw).max())
+    if ops.fp8_gemm_ksplit(M, N, K) > 0:
+        other = ops.scaled_mm_fp8_slabs(ad, wd.t()).double().sum(0).cpu().numpy()
+        np.testing.assert_allclose(got, other, rtol=1e-5, atol=1e-4 * np.abs(raw).max())
+    if ks == 1:
+        sa = (rng.random((M, 1)) * 0.05 + 0.01).astype(np.float32)
+        sb = (rng.random((N, )) * 0.05 + 0.01).astype(np.float32)
+        bias = t(rng.standard_normal(N).astype(np.float32)).to(dtype)
+        out = ops.fp8_gemm_resident(ad, strip, t(sa), t(sb), out_dtype=dtype, bias=bias)
+        ref = ofp8.scaled_mm(a, w.T, sa, sb, bias.float().cpu().numpy())
+        eps = 2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7
+        np.testing.assert_allclose(out.float().cpu().numpy(), ref, rtol=2 * eps, atol=2 * eps * np.abs(ref).max())
+        # per-tensor scales, no bias; under graph capture + replay
+        out2 = ops.fp8_gemm_resident(ad, strip, t(np.array([0.02], np.float32)), t(np.array([0.03], np.float32)), out_dtype=dtype)
+        ref2 = ofp8.scaled_mm(a, w.T, np.float32(0.02), np.float32(0.03))
+        np.testing.assert_allclose(out2.float().cpu().numpy(), ref2, rtol=2 * eps, atol=2 * eps * np.abs(ref2).max())
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        s2 = ops.fp8_gemm_resident(ad, strip, slabs=True)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(s2, slabs)
+
+
+def test_fp8_gemm_resident_refuses_what_it_does_not_serve(ops):
+    assert ops.fp8_gemm_resident_ksplit(33, 4096, 4096) == 0         # <= 32 rows
+    assert ops.fp8_gemm_resident_ksplit(32, 4096, 4096 + 64) == 0    # K % 128
+    assert ops.fp8_gemm_resident_ksplit(32, 1024, 1024) == 0         # no plan near one workgroup per CU
+    a = torch.zeros((32, 1024), dtype=torch.uint8, device=DEV).view(torch.float8_e4m3fn)
+    w = torch.zeros((1024, 1024), dtype=torch.uint8, device=DEV).view(torch.float8_e4m3fn)
+    with pytest.raises(RuntimeError):
+        ops.fp8_strip_relayout(w, 32)
+    with pytest.raises(RuntimeError):
+        ops.fp8_gemm_resident(a, w, slabs=True)
+
+
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("M,N,K", [(32, 28672, 4096), (1, 28672, 4096), (19, 28672, 4096), (17, 512, 1024), (32, 1024, 8192)])
 @pytest.mark.parametrize("per_token", [True, False])
