@@ -14,7 +14,8 @@
 //   * a k-PAIR (64 k) is the unit: lane (g, c) of a wave holds 16 bytes = k0 + 16 g .. + 16 of row c -- the low 8 bytes feed
 //     one v_mfma_f32_16x16x32_fp8_fp8, the high 8 the next (any bijection between (lane group, byte) and k is a valid MFMA
 //     k order as long as A and W use the same one).  So both operands are plain 16-byte loads; no LDS, no swizzle.
-//   * A (row-major e4m3 [M, lda], as the quantising producers leave it) stays resident: 2 NSEG k-pairs x MT x 4 registers.
+//   * A (row-major e4m3 [M, lda], as the quantising producers leave it) is used once per wave (a k-pair covers all the
+//     strip's columns): it streams in the same register ring as the weights.
 //   * W is read from a STRIP-MAJOR copy (aphro_fp8_strip_relayout, load time): for (K slice, strip, wave) the pieces
 //     [k-pair][16-column tile] of 1 KiB in the order the wave reads them, DEPTH k-pairs ahead in a register ring.
 //   * K reduction over the waves through an LDS [wave][row][column] tile; epilogue sa * (sb * acc) (+ bias) in the reference's
@@ -85,40 +86,43 @@ __global__ __launch_bounds__(256, 1) void fp8_gemm_resident_kernel(Fp8ResParams 
   const int sbase = ((ky * S + strip) * NWV + wave) * WAVE_BYTES;
   const int voff_w = lane * 16;
 
-  // ---- activations of this wave's K range: lane (g, c) = token 16 i + c, bytes k + 16 g .. + 16 of k-pair kp ----------------
-  u32x4 af[NKP][MT];
+  // ---- one stream per wave: the activations of k-pair kp (lane (g, c) = token 16 i + c, bytes k + 16 g .. + 16: used ONCE, every
+  // k-pair covers all the strip's columns) ride in the same register ring as its weights, DD k-pairs ahead.  (First version:
+  // all of A loaded up front -- 32 gathers of 16 x 64 bytes in front of the first weight byte of every wave.)
+  int voff_a[MT];
 #pragma unroll
-  for (int i = 0; i < MT; ++i) {
-    const int vo = min(16 * i + c, p.M - 1) * p.lda + 16 * g;
-#pragma unroll
-    for (int kp = 0; kp < NKP; ++kp) af[kp][i] = __builtin_amdgcn_raw_buffer_load_b128(ra, vo, (kp0 + kp) * 64, 0);
-  }
+  for (int i = 0; i < MT; ++i) voff_a[i] = min(16 * i + c, p.M - 1) * p.lda + 16 * g;
   f32x4 acc[MT][NT];
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  u32x4 wr[RING][NT];
-  auto load_w = [&](auto KP_) {
+  u32x4 wr[RING][NT], ar[RING][MT];
+  auto load_kp = [&](auto KP_) {
     constexpr int kp = decltype(KP_)::value;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int vo = voff_a[i];
+      ar[kp % RING][i] = __builtin_amdgcn_raw_buffer_load_b128(ra, vo, (kp0 + kp) * 64, 0);
+    }
 #pragma unroll
     for (int t = 0; t < NT; ++t)
       wr[kp % RING][t] = __builtin_amdgcn_raw_buffer_load_b128(rw, voff_w, sbase + (kp * NT + t) * 1024, 2);
   };
-  f8r_static_for<0, DD>([&](auto KP_) { load_w(KP_); });
+  f8r_static_for<0, DD>([&](auto KP_) { load_kp(KP_); });
   __builtin_amdgcn_sched_barrier(0);
 
   f8r_static_for<0, NKP>([&](auto KP_) {
     constexpr int kp = decltype(KP_)::value;
-    if constexpr (kp + DD < NKP) load_w(std::integral_constant<int, (kp + DD < NKP ? kp + DD : 0)>{});
+    if constexpr (kp + DD < NKP) load_kp(std::integral_constant<int, (kp + DD < NKP ? kp + DD : 0)>{});
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const u32x4 b = wr[kp % RING][t];
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
-        acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(f8r_lo(af[kp][i]), f8r_lo(b), acc[i][t], 0, 0, 0);
-        acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(f8r_hi(af[kp][i]), f8r_hi(b), acc[i][t], 0, 0, 0);
+        acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(f8r_lo(ar[kp % RING][i]), f8r_lo(b), acc[i][t], 0, 0, 0);
+        acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(f8r_hi(ar[kp % RING][i]), f8r_hi(b), acc[i][t], 0, 0, 0);
       }
     }
   });
@@ -249,12 +253,14 @@ extern "C" int aphro_fp8_gemm_resident(const void* a, int64_t lda, const void* w
   p.a_per_token = a_scale_per_token; p.b_per_channel = b_scale_per_channel; p.ksplit = cf.ksplit;
   const int mt = M > 16 ? 2 : 1;
   const dim3 grid((unsigned)(N / (16 * cf.nt)), (unsigned)cf.ksplit);
+  // k-pairs in flight per wave (bench.py --quant fp8ct, per-kernel, depth 4 / 6 / 8: gate_up 22.8 / 23.3 / 23.8 us, down 12.6 /
+  // 12.5 / 12.4, qkv 7.3 / 7.1 / 6.8, o 5.6 / 5.6 / 5.7): 4 for the wide strips, 8 for the narrow ones
 #ifndef F8R_DEPTH
-#define F8R_DEPTH 4
+#define F8R_DEPTH(nt) ((nt) >= 6 ? 4 : 8)
 #endif
 #define L(TT, MTV, NSEGV, NTV)                                                                                          \
   {                                                                                                                     \
-    auto kern = fp8_gemm_resident_kernel<TT, MTV, NSEGV, NTV, F8R_DEPTH>;                                               \
+    auto kern = fp8_gemm_resident_kernel<TT, MTV, NSEGV, NTV, F8R_DEPTH(NTV)>;                                          \
     const size_t lds = (size_t)4 * 16 * MTV * (16 * NTV + 4) * sizeof(float);                                           \
     if (lds > 64 * 1024 &&                                                                                              \
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {  \
