@@ -1036,6 +1036,194 @@ __global__ __launch_bounds__((LC ? 2 : 1) * NWV * 64, (LC ? 2 : 1) * NWV <= 4 ? 
   }
 }
 
+// ---- round 4: single pass, BOTH streams in one register ring ("stream" kernel) ----------------------------------------
+// The structure that took the FP8 decode GEMM from 29.6 to 22.7 us on gate_up (fp8_gemm_resident.hip), with this file's int4
+// arithmetic: every k-step covers ALL the strip's columns, so a wave uses each A fragment once -- nothing is resident;
+// the A fragments of k-step I ride in the same ring as its weights, D k-steps ahead, as plain buffer loads that hipcc counts
+// by itself (no LDS on the way in, no hand-written waits).  Same K partition and arithmetic as the kernels above for the
+// same (NWV, NSEG): bit-identical results.
+template <int MT, int NWV, int NSEG, int NP4, int REM, int D>
+__global__ __launch_bounds__(NWV * 64, 1) void wna16_gemm_stream_kernel(Wna16ResParams p) {
+  constexpr int NST = NSEG * 4;
+  constexpr int CW = 64 * NP4 + 16 * REM;
+  constexpr int CWP = CW + 4;
+  constexpr int ROWS = 16 * MT;
+  constexpr int NT = 4 * NP4 + REM;
+  constexpr int DD = D < NST ? D : NST;
+  constexpr int RING = DD + 1;
+  constexpr int WP = ROWS * CWP;
+  extern __shared__ __attribute__((aligned(16))) float red[];     // [NWV][ROWS][CWP]
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4;
+  const int c = lane & 15;
+  const int S = gridDim.x;
+  int strip, ky;
+  if (gridDim.y > 1 && 8 % gridDim.y == 0 && S % (8 / gridDim.y) == 0) {
+    const int L = blockIdx.y * S + blockIdx.x, xcd = L & 7, idx = L >> 3, per = 8 / gridDim.y;
+    ky = xcd / per;
+    strip = (xcd % per) * (S / per) + idx;
+  } else {
+    strip = (S & 7) == 0 ? (int)(blockIdx.x & 7) * (S >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    ky = blockIdx.y;
+  }
+  const int seg0 = (ky * NWV + wave) * NSEG;
+  const int cb = strip * CW;
+  const int mtiles = (p.M + 15) >> 4;
+  const __amdgpu_buffer_rsrc_t rw = res_rsrc(p.qw, (uint32_t)((size_t)(p.K >> 3) * p.N * 4));
+  const __amdgpu_buffer_rsrc_t ra = res_rsrc(p.apk, (uint32_t)((size_t)(p.K >> 7) * 4 * mtiles * 1024));
+  const int ngroups = (p.K >> 7) >> p.gshift;
+  const __amdgpu_buffer_rsrc_t rs_ = res_rsrc(p.sc, (uint32_t)((size_t)ngroups * p.N * 2));
+  const __amdgpu_buffer_rsrc_t rz = res_rsrc(p.qz, (uint32_t)((size_t)ngroups * (p.N >> 3) * 4));
+  // strip-major weights only (this kernel is reached through the fused decode path, which re-lays its weights)
+  constexpr int WAVE_BYTES = NSEG * 4 * 64 * (16 * NP4 + 4 * REM);
+  const int sbase = ((ky * S + strip) * NWV + wave) * WAVE_BYTES;
+  const int voff_w4 = lane * 16, voff_wr = lane * 4 * REM;
+  constexpr int poff4 = NSEG * 4096, poffr = NP4 * NSEG * 4096;
+  int voff_a[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) voff_a[i] = (min(i, mtiles - 1) * 64 + lane) * 16;
+  const int abytes = mtiles * 1024;
+  const int col4 = cb + 4 * c;
+  const int colr = cb + 64 * NP4 + REM * c;
+  const int voff_s4 = col4 * 2, voff_z4 = (col4 >> 3) * 4, zshift4 = (col4 & 7) * 4;
+  const int voff_sr = colr * 2, voff_zr0 = (colr >> 3) * 4, voff_zr1 = ((colr + (REM > 0 ? REM - 1 : 0)) >> 3) * 4;
+  const int zshiftr = (colr & 7) * 4;
+  const float zoff = (float)p.zero_offset;
+  const f16x8 ones = {(f16)1.f, (f16)1.f, (f16)16.f, (f16)16.f, (f16)1.f, (f16)1.f, (f16)16.f, (f16)16.f};
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+  struct Meta { uint32_t sc[NP4 > 0 ? 2 * NP4 : 1], z[NP4 > 0 ? NP4 : 1], scr[3], zr0, zr1; };
+  Meta meta[2];
+  f32x4 cacc[MT][NT], acc[MT][NT], rs[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    rs[i] = zero4;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { cacc[i][t] = zero4; acc[i][t] = zero4; }
+  }
+  u32x4 ar[RING][MT], wr4[RING][NP4 > 0 ? NP4 : 1], wrr[RING];
+  auto load_step = [&](auto I_) {
+    constexpr int I = decltype(I_)::value;
+    constexpr int s = I / 4, u = I % 4, B = I % RING;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int vo = voff_a[i];
+      ar[B][i] = __builtin_amdgcn_raw_buffer_load_b128(ra, vo, ((seg0 + s) * 4 + u) * abytes, 0);
+    }
+#pragma unroll
+    for (int pp = 0; pp < NP4; ++pp)
+      wr4[B][pp] = __builtin_amdgcn_raw_buffer_load_b128(rw, voff_w4, sbase + pp * poff4 + s * 4096 + u * 1024, 2);
+    const int so = sbase + poffr + s * 1024 * REM + u * 256 * REM;
+    if constexpr (REM == 3) {
+      typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+      const u32x3 v = __builtin_amdgcn_raw_buffer_load_b96(rw, voff_wr, so, 2);
+      wrr[B] = u32x4{v[0], v[1], v[2], 0u};
+    } else if constexpr (REM == 2) {
+      const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rw, voff_wr, so, 2);
+      wrr[B] = u32x4{v[0], v[1], 0u, 0u};
+    } else if constexpr (REM == 1) {
+      wrr[B] = u32x4{__builtin_amdgcn_raw_buffer_load_b32(rw, voff_wr, so, 2), 0u, 0u, 0u};
+    }
+  };
+  auto load_meta = [&](auto Q_) {
+    constexpr int Q = decltype(Q_)::value;
+    Meta& m = meta[Q & 1];
+    const int grp = (seg0 + Q) >> p.gshift;
+    const int so_s = grp * p.N * 2, so_z = grp * (p.N >> 3) * 4;
+#pragma unroll
+    for (int pp = 0; pp < NP4; ++pp) {
+      const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs_, voff_s4, so_s + pp * 128, 0);
+      m.sc[2 * pp] = v[0]; m.sc[2 * pp + 1] = v[1];
+      m.z[pp] = __builtin_amdgcn_raw_buffer_load_b32(rz, voff_z4, so_z + pp * 32, 0);
+    }
+    if constexpr (REM == 2) {
+      m.scr[0] = __builtin_amdgcn_raw_buffer_load_b32(rs_, voff_sr, so_s, 0);
+    } else if constexpr (REM > 0) {
+#pragma unroll
+      for (int t = 0; t < REM; ++t) m.scr[t] = (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rs_, voff_sr, so_s + 2 * t, 0);
+    }
+    if constexpr (REM > 0) m.zr0 = __builtin_amdgcn_raw_buffer_load_b32(rz, voff_zr0, so_z, 0);
+    if constexpr (REM == 3) m.zr1 = __builtin_amdgcn_raw_buffer_load_b32(rz, voff_zr1, so_z, 0);
+  };
+
+  load_meta(std::integral_constant<int, 0>{});
+  res_static_for<0, DD>([&](auto I_) { load_step(I_); });
+  __builtin_amdgcn_sched_barrier(0);
+
+  res_static_for<0, NST>([&](auto I_) {
+    constexpr int I = decltype(I_)::value;
+    constexpr int s = I / 4, u = I % 4, B = I % RING;
+    if constexpr (I + DD < NST) load_step(std::integral_constant<int, (I + DD < NST ? I + DD : 0)>{});
+    if constexpr (u == 0 && s + 1 < NSEG) load_meta(std::integral_constant<int, (s + 1 < NSEG ? s + 1 : 0)>{});
+    __builtin_amdgcn_sched_barrier(0);
+    f16x8 a[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      u32x4 av = ar[B][i];
+      asm("v_pk_mul_f16 %0, %1, %2" : "=v"(av[1]) : "v"(av[1]), "s"(0x2c002c00u));
+      asm("v_pk_mul_f16 %0, %1, %2" : "=v"(av[3]) : "v"(av[3]), "s"(0x2c002c00u));
+      a[i] = __builtin_bit_cast(f16x8, av);
+      rs[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], ones, u == 0 ? zero4 : rs[i], 0, 0, 0);
+    }
+    res_static_for<0, NT>([&](auto T_) {
+      constexpr int t = decltype(T_)::value;
+      uint32_t wv;
+      if constexpr (t < 4 * NP4) wv = wr4[B][t / 4][t % 4];
+      else wv = wrr[B][t - 4 * NP4];
+      const uint32_t w8 = wv >> 8;
+      const u32x4 bq = {wv & 0x000f000fu, wv & 0x00f000f0u, w8 & 0x000f000fu, w8 & 0x00f000f0u};
+      const f16x8 b = __builtin_bit_cast(f16x8, bq);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+        acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b, u == 0 ? zero4 : acc[i][t], 0, 0, 0);
+    });
+    if constexpr (u == 3) {
+      const Meta& m = meta[s & 1];
+      res_static_for<0, NT>([&](auto T_) {
+        constexpr int t = decltype(T_)::value;
+        uint32_t zb;
+        uint16_t sb;
+        if constexpr (t < 4 * NP4) {
+          zb = (m.z[t / 4] >> zshift4) >> (4 * (t % 4));
+          sb = (uint16_t)(m.sc[2 * (t / 4) + ((t % 4) >> 1)] >> (16 * (t & 1)));
+        } else {
+          constexpr int tr = t - 4 * NP4;
+          uint32_t zbits;
+          if constexpr (REM == 3) zbits = __builtin_amdgcn_alignbit(m.zr1, m.zr0, zshiftr);
+          else zbits = m.zr0 >> zshiftr;
+          zb = zbits >> (4 * tr);
+          if constexpr (REM == 2) sb = (uint16_t)(m.scr[0] >> (16 * tr));
+          else sb = (uint16_t)m.scr[tr];
+        }
+        const float z = (float)(zb & 0xf) + zoff;
+        const float sf = p.is_bf16 ? bf16_bits_to_f32(sb) : f16_bits_to_f32(sb);
+        const float s24 = sf * 16777216.f;
+        const float nzs = -z * sf;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          cacc[i][t] = __builtin_elementwise_fma(acc[i][t], f32x4{s24, s24, s24, s24}, cacc[i][t]);
+          cacc[i][t] = __builtin_elementwise_fma(rs[i], f32x4{nzs, nzs, nzs, nzs}, cacc[i][t]);
+        }
+      });
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  });
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float* row = &red[wave * WP + (16 * i + 4 * g + r) * CWP];
+#pragma unroll
+      for (int pp = 0; pp < NP4; ++pp)
+        *reinterpret_cast<f32x4*>(row + 64 * pp + 4 * c) = f32x4{cacc[i][4 * pp][r], cacc[i][4 * pp + 1][r], cacc[i][4 * pp + 2][r], cacc[i][4 * pp + 3][r]};
+#pragma unroll
+      for (int t = 0; t < REM; ++t) row[64 * NP4 + REM * c + t] = cacc[i][4 * NP4 + t][r];
+    }
+  __syncthreads();
+  res_reduce_store<MT, NWV, NP4, REM>(p, red, WP, ky, cb, mtiles);
+}
+
 // [K/8, N] exllama order -> strip-major: the 16-byte (last pass: 4 REM-byte) pieces in the order the waves read them.
 // One thread per destination dword.
 __global__ void wna16_strip_relayout_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, int N, int K,
@@ -1152,6 +1340,21 @@ static int res_launch_ring(const Wna16ResParams& p, hipStream_t st) {
   return APHRO_OK;
 }
 
+template <int MT, int NWV, int NSEG, int NP4, int REM, int D>
+static int res_launch_stream(const Wna16ResParams& p, hipStream_t st) {
+  constexpr int CW = 64 * NP4 + 16 * REM;
+  constexpr size_t LDS = (size_t)NWV * 16 * MT * (CW + 4) * sizeof(float);
+  auto kern = wna16_gemm_stream_kernel<MT, NWV, NSEG, NP4, REM, D>;
+  if (LDS > 64 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS) != hipSuccess) {
+    set_error("wna16_gemm_stream: cannot raise the dynamic LDS limit to %zu", LDS);
+    return APHRO_ERR_LAUNCH;
+  }
+  const dim3 grid((unsigned)(p.N / CW), (unsigned)p.ksplit);
+  hipLaunchKernelGGL(kern, grid, dim3(NWV * 64), LDS, st, p);
+  APHRO_LAUNCH_CHECK();
+  return APHRO_OK;
+}
+
 // ---- the instantiated configurations ------------------------------------------------------------------------------------
 #ifndef RES_DEPTH
 #define RES_DEPTH 8
@@ -1175,11 +1378,32 @@ static int res_launch_ring(const Wna16ResParams& p, hipStream_t st) {
   X(4, 7, 1, 0, 12)       \
   X(4, 4, 1, 0, 8)        \
   X(4, 4, 1, 0, 12)
+#define RES_STREAM_SWEEP(X) \
+  X(4, 8, 1, 3, 3)          \
+  X(4, 8, 1, 3, 5)          \
+  X(4, 7, 1, 0, 5)          \
+  X(4, 7, 1, 0, 7)          \
+  X(4, 7, 1, 0, 8)          \
+  X(4, 4, 1, 0, 5)          \
+  X(4, 4, 1, 0, 7)          \
+  X(4, 4, 1, 0, 8)          \
+  X(4, 2, 1, 0, 6)          \
+  X(4, 2, 1, 0, 8)
 #else    // product builds: the round-4 ring forms are lab material (tools/reslab.hip; DESIGN.md 5 "ring kernel": they match
          // the register-ring kernel within noise on every configs[1] shape) and are not instantiated
 #define RES_RING_CONFIGS(X)
 #define RES_LC_CONFIGS(X)
+#define RES_STREAM_SWEEP(X)
 #endif
+// stream kernel (nwv, nseg, np4, rem, k-steps in flight): the plans of the configs[1] projections, each at the depth that
+// measured best (tools/reslab.hip, profiles/r4_gemm_lab.txt (8): gate_up 3 / 4 / 5 / 6 -> 14.9 / 15.2 / 15.3 / 16.1 us against
+// 15.5-16.0 for the two-pass kernel; down 5 / 6 / 7 -> 9.92 / 9.84 / 10.12 against 10.2; qkv 5 / 6 / 7 -> 6.62 / 6.65 / 6.94
+// against 7.0; o 4 / 6 / 8 -> 4.98 / 5.09 / 5.20 against 5.58 for wna16_gemm_kernel)
+#define RES_STREAM_CONFIGS(X) \
+  X(4, 8, 1, 3, 4)            \
+  X(4, 7, 1, 0, 6)            \
+  X(4, 4, 1, 0, 6)            \
+  X(4, 2, 1, 0, 4)
 #ifdef RES_NO_KEEP_RS   // lab: the row sums of pass 0 are recomputed in the later passes instead of kept (registers)
 #define RES_KEEP_RS(x) false
 #else
@@ -1190,6 +1414,7 @@ static int res_launch_ring(const Wna16ResParams& p, hipStream_t st) {
   X(4, 8, 1, 3)        \
   X(4, 7, 1, 0)        \
   X(4, 4, 1, 0)        \
+  X(4, 2, 1, 0)        \
   X(8, 4, 1, 3)        \
   X(7, 4, 1, 0)        \
   X(8, 2, 0, 3)        \
@@ -1262,6 +1487,26 @@ static int res_dispatch(const Wna16ResParams& p, const ResConfig& cf, hipStream_
       return mt == 2 ? (p.trace ? res_launch_ring<2, a, b, c, d, r, true, true>(p, st) : res_launch_ring<2, a, b, c, d, r, true>(p, st)) \
                      : res_launch_ring<1, a, b, c, d, r, true>(p, st);
     RES_LC_CONFIGS(X)
+#undef X
+  }
+  if (p.a == nullptr && p.strip_layout) {
+    // packed activations on strip-major weights: the single-pass stream kernel where it is instantiated
+    // (APHRO_WNA16_STREAM=0: the two-pass resident kernel; lab builds: =D picks a swept depth)
+#ifdef RES_LAB_SET
+    const char* se = getenv("APHRO_WNA16_STREAM");
+    const int sd = se ? atoi(se) : -1;
+#else
+    static const int sd = [] { const char* e = getenv("APHRO_WNA16_STREAM"); return e ? atoi(e) : -1; }();
+#endif
+#define X(a, b, c, d, r)                                                                 \
+    if ((sd == r || sd < 0) && cf.nwv == a && cf.nseg == b && cf.np4 == c && cf.rem == d)  \
+      return mt == 2 ? res_launch_stream<2, a, b, c, d, r>(p, st) : res_launch_stream<1, a, b, c, d, r>(p, st);
+    RES_STREAM_CONFIGS(X)
+#undef X
+#define X(a, b, c, d, r)                                                                 \
+    if (sd == r && cf.nwv == a && cf.nseg == b && cf.np4 == c && cf.rem == d)            \
+      return mt == 2 ? res_launch_stream<2, a, b, c, d, r>(p, st) : res_launch_stream<1, a, b, c, d, r>(p, st);
+    RES_STREAM_SWEEP(X)
 #undef X
   }
   if (p.a != nullptr) {   // row-major activations read in place: the configurations res_plan picks by itself

@@ -260,13 +260,14 @@ class LlamaDecoderLayer(nn.Module):
         return ops.scaled_mm_fp8_slabs(qx, getattr(self, name).weight)
 
     def enable_resident_layouts(self, m: int = 32) -> None:
-        """Strip-major copies of the qkv and down weights for the resident kernel at <= 32 rows (same K partition as the
-        round-2 kernel, so the fp32 slabs -- and everything downstream -- are bit-identical; measured 8.2 -> 7.1 us and
-        11.4 -> 10.5 us, profiles/r3_resident_bench.txt).  o_proj stays on the round-2 kernel (5.7 vs 6.0 us)."""
+        """Strip-major copies of the qkv, o and down weights for the resident / stream kernels at <= 32 rows (same K
+        partition as the round-2 kernel, so the fp32 slabs -- and everything downstream -- are bit-identical; round 3:
+        8.2 -> 7.1 us and 11.4 -> 10.5 us, profiles/r3_resident_bench.txt; round 4, single-pass stream kernel: qkv 6.65,
+        down 9.84, o_proj 5.58 -> 4.98 us, profiles/r4_gemm_lab.txt)."""
         self.strip = {}
         if m > 32 or os.environ.get("APHRO_DECODE_NO_RESIDENT"):
             return
-        for name in ("qkv_proj", "down_proj"):
+        for name in ("qkv_proj", "o_proj", "down_proj"):
             lin = getattr(self, name, None)
             fp = lin.fast_params() if lin is not None else None
             if fp is None:
@@ -381,7 +382,7 @@ class LlamaDecoderLayer(nn.Module):
             packed2, _ = ops.fused_add_rms_norm_pack(o, None, residual, True,
                                                      self.post_attention_layernorm, eps)
         else:
-            o_slabs, _ = ops.wna16_gemm_packed(attn_packed, m, self.q_size, qw, qz, sc, zo, partials=True)
+            o_slabs, _ = self._gemm_slabs("o_proj", attn_packed, m, self.q_size)
             packed2, _ = ops.fused_add_rms_norm_pack(None, o_slabs, residual, True,
                                                      self.post_attention_layernorm, eps)
         # 33..64 rows: the MLP weights go through the one-pass 32x32x16 MFMA kernel (wna16_gemm_mid.hip: 26.6 vs 37.6 us on
