@@ -281,7 +281,10 @@ def roofline_section(model, loop, args):
                     else:
                         layer._gemm_slabs(name, packed, bs, k)      # resident kernel on the strip-major copy where the layer has one
             res_slabs = (not silu) and (not mid) and bs <= 32 and name in getattr(layers[0], "strip", {})
-            kname = ("wna16_gemm_mid_kernel" if mid else "wna16_gemm_resident_kernel (strip-major weights)" if (resident or res_slabs)
+            stream = not os.environ.get("APHRO_WNA16_STREAM") == "0"     # (the four configs[1] plans dispatch to the stream kernel)
+            kname = ("wna16_gemm_mid_kernel" if mid else
+                     ("wna16_gemm_stream_kernel" if stream and (bs, model.cfg.hidden_size) == (bs, 4096) and bs <= 32 and args.model == "llama3-8b"
+                      else "wna16_gemm_resident_kernel") + " (strip-major weights)" if (resident or res_slabs)
                      else "wna16_gemm_kernel") + (" (+SiluAndMul epilogue)" if silu else "")
         elif args.quant == "fp8ct" and getattr(model, "use_fused_decode", False):
             # the FP8 decode fast path hands every GEMM pre-quantised activations (the quantisation is fused into the norm /
@@ -769,13 +772,13 @@ def main():
         achieved = dom["bytes"] / dom["seconds"] / 1e9
         n_members = len(dom["members"])
         # HBM bytes per launch: PMC counters cannot be collected from inside this process (rocprofv3 wraps it).  The
-        # committed same-round passes (profiles/r3_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE,
+        # committed same-round passes (profiles/r4_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE,
         # separate runs of tools/prof_step_kernels.py at THESE shapes, gfx950 x2 correction on FETCH_SIZE) are attached
         # with their provenance; null when the file has no entry for the dominant template.
         traffic = None
         traffic_src = None
         try:
-            pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r3_pmc_traffic.json")))
+            pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r4_pmc_traffic.json")))
             ent = [pmc["kernels"][m] for m in dom["members"] if m in pmc.get("kernels", {})]
             if len(ent) == n_members and args.quant == "gptq" and args.batch == 32 and args.kv_cache_dtype == "auto":
                 traffic = sum(e["hbm_bytes_per_launch"] for e in ent) / n_members

@@ -3,8 +3,8 @@
 never together: 3 + 2 TCC slots of 4, MI355X_MICROARCH.md "rocprofv3 PMC slots") into HBM bytes per launch of every
 decode-step kernel, next to the algorithmic bytes of bench.py's roofline section.
 
-    python tools/pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> > profiles/r3_pmc_traffic.txt
-    (also writes profiles/r3_pmc_traffic.json, which bench.py attaches as roofline.traffic with its provenance)
+    python tools/pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> > profiles/r4_pmc_traffic.txt
+    (also writes profiles/r4_pmc_traffic.json, which bench.py attaches as roofline.traffic with its provenance)
 
 Units / corrections (guide, HBM section): FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports one half of
 the bytes of wide coalesced streaming reads (128-byte requests tallied at 64): bytes = FETCH_SIZE * 1024 * 2.  WRITE_SIZE
@@ -44,13 +44,19 @@ def main():
     ctx, bs = 1100, 32
     kv = 2 * bs * ctx * 8 * 128 * 2
     table = [
-        ("gate_up_proj", r"wna16_gemm_resident_kernel<2, 4, 8, 1, 3", *gemm_alg(4096, 28672, out_bytes=M * 14336 * 2)),
+        ("gate_up_proj", r"wna16_gemm_stream_kernel<2, 4, 8, 1, 3", *gemm_alg(4096, 28672, out_bytes=M * 14336 * 2)),
+        ("gate_up_proj (two-pass resident kernel)", r"wna16_gemm_resident_kernel<2, 4, 8, 1, 3", *gemm_alg(4096, 28672, out_bytes=M * 14336 * 2)),
         ("gate_up_proj (round-2 kernel)", r"wna16_gemm_kernel<aphro::Half, 4, 2, 8>", *gemm_alg(4096, 28672, out_bytes=M * 14336 * 2)),
-        ("down_proj", r"wna16_gemm_resident_kernel<2, 4, 7, 1, 0", *gemm_alg(14336, 4096, out_bytes=4 * M * 4096 * 4)),
+        ("down_proj", r"wna16_gemm_stream_kernel<2, 4, 7, 1, 0", *gemm_alg(14336, 4096, out_bytes=4 * M * 4096 * 4)),
         ("down_proj (round-2 kernel)", r"wna16_gemm_kernel<aphro::Half, 4, 2, 7>", *gemm_alg(14336, 4096, out_bytes=4 * M * 4096 * 4)),
-        ("qkv_proj", r"wna16_gemm_resident_kernel<2, 4, 4, 1, 0", *gemm_alg(4096, 6144, out_bytes=2 * M * 6144 * 4)),
+        ("qkv_proj", r"wna16_gemm_stream_kernel<2, 4, 4, 1, 0", *gemm_alg(4096, 6144, out_bytes=2 * M * 6144 * 4)),
         ("qkv_proj (round-2 kernel)", r"wna16_gemm_kernel<aphro::Half, 4, 2, 4>", *gemm_alg(4096, 6144, out_bytes=2 * M * 6144 * 4)),
-        ("o_proj", r"wna16_gemm_kernel<aphro::Half, 4, 2, 2>", *gemm_alg(4096, 4096, out_bytes=4 * M * 4096 * 4)),
+        ("o_proj", r"wna16_gemm_stream_kernel<2, 4, 2, 1, 0", *gemm_alg(4096, 4096, out_bytes=4 * M * 4096 * 4)),
+        ("o_proj (round-2 kernel)", r"wna16_gemm_kernel<aphro::Half, 4, 2, 2>", *gemm_alg(4096, 4096, out_bytes=4 * M * 4096 * 4)),
+        ("fp8_gate_up_proj", r"fp8_gemm_resident_kernel<aphro::Half, 2, 8, 7", 4096 * 28672 + M * 4096, M * 28672 * 4),
+        ("fp8_down_proj", r"fp8_gemm_resident_kernel<aphro::Half, 2, 7, 4", 14336 * 4096 + M * 14336, 4 * M * 4096 * 4),
+        ("fp8_qkv_proj", r"fp8_gemm_resident_kernel<aphro::Half, 2, 4, 3", 4096 * 6144 + M * 4096, 2 * M * 6144 * 4),
+        ("fp8_o_proj", r"fp8_gemm_resident_kernel<aphro::Half, 2, 2, 4", 4096 * 4096 + M * 4096, 4 * M * 4096 * 4),
         ("paged_attention", r"paged_attention_kernel<aphro::Half, 0, 128, 16, 8, 1", kv + 2 * bs * 6144 * 4, bs * 4096 * 2 + bs * 2 * 8 * 128 * 2),
         ("add_rms_norm_pack", r"add_rms_norm_pack_kernel", 4 * M * 4096 * 4 + M * 4096 * 2, 2 * M * 4096 * 2),
         ("gate_up_proj bs64 (mid kernel)", r"wna16_gemm_mid_kernel<2, 8, true>", *gemm_alg(4096, 28672, m=64, out_bytes=64 * 14336 * 2)),
@@ -67,14 +73,14 @@ def main():
     wd = find(write, r"wna16_gemm_kernel<aphro::Half, 4, 2, 7>")
     if wd:
         wcal = (4 * M * 4096 * 4) / (wd[0] * 1024)
-    print("HBM traffic per launch of the decode-step kernels (round 3; rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes of")
+    print("HBM traffic per launch of the decode-step kernels (round 4; rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes of")
     print("tools/prof_step_kernels.py: bs 32, ctx 1100, configs[1] shapes; no trace domains in the same run)")
     print("bytes read = FETCH_SIZE [KiB] x 1024 x 2 (gfx950: wide coalesced reads are tallied at half their size -- MI355X_MICROARCH.md, HBM);")
     print(f"bytes written = WRITE_SIZE [KiB] x 1024 x {wcal:.3f} (calibrated on the down projection's 4 x 32 x 4096 fp32 slabs = 2 097 152 B)" if wcal else "WRITE_SIZE uncalibrated")
     print()
     print(f"{'role':34s} {'launches':>8s} {'read MB':>9s} {'alg read MB':>11s} {'ratio':>6s} {'write MB':>9s} {'alg write MB':>12s}")
-    out = {"source": "profiles/r3_pmc_traffic.txt: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of tools/prof_step_kernels.py "
-                     "(round 3, bs 32, ctx 1100); read bytes = FETCH_SIZE KiB x 1024 x 2 (gfx950 correction), write bytes calibrated on "
+    out = {"source": "profiles/r4_pmc_traffic.txt: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of tools/prof_step_kernels.py "
+                     "(round 4, bs 32, ctx 1100); read bytes = FETCH_SIZE KiB x 1024 x 2 (gfx950 correction), write bytes calibrated on "
                      "the down projection's slabs", "kernels": {}}
     for role, pat, alg_r, alg_w in table:
         f, w = find(fetch, pat), find(write, pat)
@@ -93,7 +99,7 @@ def main():
     for k, v in sorted(fetch.items(), key=lambda kv: -kv[1][0]):
         if "aphro::" in k:
             print(f"  {short(k):70s} {v[0]:12.1f} {v[1]:4d}")
-    json.dump(out, open(os.path.join(ROOT, "profiles", "r3_pmc_traffic.json"), "w"), indent=1)
+    json.dump(out, open(os.path.join(ROOT, "profiles", "r4_pmc_traffic.json"), "w"), indent=1)
 
 
 if __name__ == "__main__":

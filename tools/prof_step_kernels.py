@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Launches each decode-step kernel a few times at the bench shapes (for rocprofv3 --pmc).  Round 3: gate_up runs the
-resident kernel on strip-major weights, as the decode step does; the 33..64-row forms run at M = 64."""
+resident kernel on strip-major weights, as the decode step does; the 33..64-row forms run at M = 64.  Round 4: the resident
+entry point dispatches to the single-pass stream kernel for the four configs[1] plans (o_proj included); the FP8 W8A8
+resident kernel runs on the same shapes at the end."""
 import os
 import sys
 import torch
@@ -31,7 +33,7 @@ for name, (k, n) in shapes.items():
             ops.wna16_gemm_mid_silu_pack(a64, 64, k, qw, qz, sc, 1)               # bs 64
         else:
             ops.wna16_gemm_packed(a, bs, k, qw, qz, sc, 1, partials=True)       # round-2 kernel (o_proj in the step; fallback elsewhere)
-            if name in ("down", "qkv"):                                          # what the step launches at <= 32 rows
+            if name in ("down", "qkv", "o"):                                     # what the step launches at <= 32 rows (round 4: o too)
                 strip = ops.wna16_strip_relayout(qw, bs, k // 128)
                 ops.wna16_gemm_resident(a, bs, k, strip, qz, sc, 1, mode="slabs", strip_layout=True)
             if name == "down":
@@ -67,4 +69,13 @@ for name, (k, n) in shapes.items():
     x = torch.randn(bs, k, device=dev, dtype=torch.float16)
     for qw, qz, sc in ws[name]:
         ops.gptq_gemm(x, qw, qz, sc, gi, True, 4)
+torch.cuda.synchronize()
+
+# round 4: FP8 W8A8 resident decode GEMM (csrc/fp8_gemm_resident.hip) on the four projection shapes, slab form
+for name, (k, n) in shapes.items():
+    qa = torch.randint(0, 0x48, (bs, k), generator=g, device=dev, dtype=torch.int16).to(torch.uint8).view(torch.float8_e4m3fn)
+    for _ in range(4):
+        w8 = torch.randint(0, 0x48, (n, k), generator=g, device=dev, dtype=torch.int16).to(torch.uint8).view(torch.float8_e4m3fn)
+        st8 = ops.fp8_strip_relayout(w8, bs)
+        ops.fp8_gemm_resident(qa, st8, slabs=True)
 torch.cuda.synchronize()
