@@ -779,8 +779,10 @@ def main():
         traffic_src = None
         try:
             pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r4_pmc_traffic.json")))
-            ent = [pmc["kernels"][m] for m in dom["members"] if m in pmc.get("kernels", {})]
-            if len(ent) == n_members and args.quant == "gptq" and args.batch == 32 and args.kv_cache_dtype == "auto":
+            pref = "fp8_" if args.quant.startswith("fp8") else ""     # (the FP8 resident kernels have their own entries)
+            ent = [pmc["kernels"][pref + m] for m in dom["members"] if pref + m in pmc.get("kernels", {})]
+            if len(ent) == n_members and args.quant in ("gptq", "awq", "fp8ct", "fp8") and args.batch == 32 \
+                    and (args.kv_cache_dtype == "auto" or pref):
                 traffic = sum(e["hbm_bytes_per_launch"] for e in ent) / n_members
                 traffic_src = pmc.get("source")
         except Exception:
