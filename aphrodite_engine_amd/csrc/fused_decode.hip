@@ -145,8 +145,13 @@ __global__ void add_rms_norm_pack_kernel(const uint16_t* __restrict__ input, con
           }
         }
         if (residual) *reinterpret_cast<u16x8*>(residual + off) = rs2;
+        {
+          // squares rounded, then added -- pinned: the norm-in-consumer GEMM launch (wna16_gemm_resident.hip, res_norm_finish)
+          // reproduces this row bit for bit and must not depend on which of the two loops hipcc contracts into FMAs
+#pragma clang fp contract(off)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) ss += v[it][j] * v[it][j];
+          for (int j = 0; j < 8; ++j) ss += v[it][j] * v[it][j];
+        }
         continue;
       } else if (slabs) {
         f32x4 a = *reinterpret_cast<const f32x4*>(slabs + off);
@@ -195,7 +200,9 @@ __global__ void add_rms_norm_pack_kernel(const uint16_t* __restrict__ input, con
       u16x8 y, yh;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        y[j] = T::from_f32(T::to_f32(T::from_f32(v[it][j] * inv)) * T::to_f32(w[j]));
+        // (from_f32_exact: product rounded to fp32, THEN converted -- (scalar_t)(x * s_variance), layernorm_kernels.cu:228;
+        //  pinned so that the norm-in-consumer GEMM launch can promise the same bits)
+        y[j] = T::from_f32(T::to_f32(from_f32_exact<T>(v[it][j] * inv)) * T::to_f32(w[j]));
         yh[j] = to_f16_bits<T>(y[j]);
       }
       if (out) *reinterpret_cast<u16x8*>(out + (size_t)tok * hidden + 8 * i) = y;

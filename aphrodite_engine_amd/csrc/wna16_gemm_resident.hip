@@ -51,6 +51,14 @@ struct Wna16ResParams {
   int lda;
   unsigned* counter;      // one launch for [M, N] with K slices: tickets per strip (zero between launches), see the epilogue
   unsigned long long* trace;   // TRACE instantiations (RES_LAB builds, tools/resident_trace.py): per-wave timeline stamps
+  // norm-in-consumer form of the stream kernel (round 4, aphro_wna16_gemm_norm_fused): the first M workgroups produce apk
+  // (one token row each: 4-slab reduce + residual add + RMSNorm + pack, add_rms_norm_pack_kernel<T, .., 4>'s arithmetic)
+  // while every workgroup's first weights are already in flight
+  const float* n_slabs;   // [4][M][K] fp32 slabs of the previous projection, or NULL: apk is an input
+  uint16_t* n_residual;   // [M, K] in / out
+  const uint16_t* n_weight;
+  float n_eps;
+  unsigned* n_sync;       // arrival ticket of THIS launch: zero when it starts, M when it is done (the caller re-zeroes it)
 };
 
 #define RES_STAMP(i) do { if constexpr (TRACE) stamp[i] = __builtin_readcyclecounter(); } while (0)
@@ -1042,8 +1050,112 @@ __global__ __launch_bounds__((LC ? 2 : 1) * NWV * 64, (LC ? 2 : 1) * NWV <= 4 ? 
 // the A fragments of k-step I ride in the same ring as its weights, D k-steps ahead, as plain buffer loads that hipcc counts
 // by itself (no LDS on the way in, no hand-written waits).  Same K partition and arithmetic as the kernels above for the
 // same (NWV, NSEG): bit-identical results.
-template <int MT, int NWV, int NSEG, int NP4, int REM, int D>
+// ---- norm-in-consumer (round 4) ---------------------------------------------------------------------------------------
+// One token row of add_rms_norm_pack_kernel<T, false, false, 4> (fused_decode.hip) by the 256 threads of a stream-kernel
+// workgroup: thread t holds the 8-element vectors t + 256 it (the 512- or 1024-thread norm launch holds ONE vector per thread,
+// wave w = vectors [64 w, 64 w + 64)), the sum of squares is reduced per such "virtual wave" and the wave sums are added in
+// wave order -- the same additions in the same order as the launch: bit-identical residual and packed rows.
+__device__ __forceinline__ size_t res_packed_chunk(int row, int k, int mtiles) {     // = packed_chunk (fused_decode.hip)
+  const int seg = k >> 7, g = (k & 127) >> 5, u = (k & 31) >> 3;
+  return ((((size_t)seg * 4 + u) * mtiles + (row >> 4)) * 64 + g * 16 + (row & 15)) * 8;
+}
+template <int NIT>
+struct ResNormRegs { f32x4 sa[NIT][4], sb[NIT][4]; u16x8 wv[NIT], rv[NIT]; };
+
+template <int NIT>
+__device__ __forceinline__ void res_norm_load(const Wna16ResParams& p, int tok, ResNormRegs<NIT>& r) {
+  const size_t slab_stride = (size_t)p.M * p.K;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int i = threadIdx.x + it * 256;
+    const size_t off = (size_t)tok * p.K + 8 * i;
+    r.wv[it] = *reinterpret_cast<const u16x8*>(p.n_weight + 8 * i);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      r.sa[it][s] = *reinterpret_cast<const f32x4*>(p.n_slabs + s * slab_stride + off);
+      r.sb[it][s] = *reinterpret_cast<const f32x4*>(p.n_slabs + s * slab_stride + off + 4);
+    }
+    r.rv[it] = *reinterpret_cast<const u16x8*>(p.n_residual + off);
+  }
+}
+
+template <typename T, int NIT>
+__device__ __forceinline__ void res_norm_finish(const Wna16ResParams& p, int tok, const ResNormRegs<NIT>& r, float* red) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int mtiles = (p.M + 15) >> 4;
+  float v[NIT][8];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int i = threadIdx.x + it * 256;
+    const size_t off = (size_t)tok * p.K + 8 * i;
+    f32x4 a = r.sa[it][0], b = r.sb[it][0];
+#pragma unroll
+    for (int s = 1; s < 4; ++s) { a += r.sa[it][s]; b += r.sb[it][s]; }
+    float x[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      x[j] = T::to_f32(T::from_f32(a[j]));
+      x[4 + j] = T::to_f32(T::from_f32(b[j]));
+    }
+    u16x8 rs2;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      rs2[j] = T::from_f32(x[j] + T::to_f32(r.rv[it][j]));
+      v[it][j] = T::to_f32(rs2[j]);
+    }
+    *reinterpret_cast<u16x8*>(p.n_residual + off) = rs2;
+    float ss = 0.f;
+    {
+#pragma clang fp contract(off)      // (squares rounded, then added: what add_rms_norm_pack_kernel's loop is pinned to)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ss += v[it][j] * v[it][j];
+    }
+    ss = wave_sum(ss);
+    if (lane == 0) red[it * 4 + wave] = ss;        // virtual wave it * 4 + wave
+  }
+  __syncthreads();
+  float t = 0.f;
+  for (int w = 0; w < 4 * NIT; ++w) t += red[w];
+  const float inv = __frsqrt_rn(t / (float)p.K + p.n_eps);
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int i = threadIdx.x + it * 256;
+    u32x4 yh;
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+      // (from_f32_exact: the fp32 product is rounded, THEN converted -- the reference's (scalar_t)(x * s_variance),
+      //  layernorm_kernels.cu:228; hipcc would fold product + conversion into one v_fma_mixlo_f16 rounding here)
+      uint16_t y0 = T::from_f32(T::to_f32(from_f32_exact<T>(v[it][j] * inv)) * T::to_f32(r.wv[it][j]));
+      uint16_t y1 = T::from_f32(T::to_f32(from_f32_exact<T>(v[it][j + 1] * inv)) * T::to_f32(r.wv[it][j + 1]));
+      if constexpr (!__is_same(T, Half)) { y0 = bf16_bits_to_f16_bits_sat(y0); y1 = bf16_bits_to_f16_bits_sat(y1); }
+      yh[j >> 1] = (uint32_t)y0 | ((uint32_t)y1 << 16);
+    }
+    // write-through: the consumers sit on all eight XCDs (the L2s are not coherent with each other)
+    uint16_t* dst = const_cast<uint16_t*>(p.apk) + res_packed_chunk(tok, 8 * i, mtiles);
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(yh) : "memory");
+  }
+}
+
+// NORM_T = Half / BFloat: the norm-in-consumer form (p.n_slabs set).  The order of a workgroup's life:
+//   producers (the first M workgroups in dispatch order, one token row each) issue their norm loads; EVERY workgroup issues
+//   its scale / zero words and the weights of its first D k-steps (they depend on nothing this launch produces); producers
+//   finish their row, store it write-through, wait for the stores and take an arrival ticket; every workgroup polls the
+//   arrivals (one lane, relaxed agent-scope loads, bounded) and only then requests its A fragments.  The hand-over (store
+//   acknowledgement + ticket + poll + first A fetch, ~3 us) runs under the weights' HBM latency and the first D k-steps'
+//   worth of stream instead of behind a launch boundary.  Producers are dispatched first and wait for nobody: no deadlock
+//   whatever the residency.  The ticket word is the caller's: zero at launch, left at M (a returning atomic that finds the last
+//   workgroup past the poll would sit in front of that wave's A fragments in its in-order return queue).
+//   STAGE > 0 (norm-in-consumer only): the hand-over takes ~8 us from the wave's entry (slab read, row, store acknowledgement,
+//   ticket, poll, first A fetch: five memory round trips) -- long enough to pull in far more weights than a register ring
+//   holds.  The weights of the first STAGE k-steps are requested in ONE batch (STAGE x (NP4 + 1) loads per lane, landing in
+//   registers the accumulators do not need yet), parked in LDS (a wave's own STAGE x SLOT bytes: 4 x 19 x 2 KiB = 152 KiB on
+//   gate_up; the K-reduce tile reuses the space after a barrier), and the ring's D k-steps follow them: 23 of gate_up's 32
+//   k-steps are on the CU when its A fragments arrive, and the loop runs at the activations' rate, not at A + W.
+template <int MT, int NWV, int NSEG, int NP4, int REM, int D, typename NORM_T = void, int STAGE = 0>
 __global__ __launch_bounds__(NWV * 64, 1) void wna16_gemm_stream_kernel(Wna16ResParams p) {
+  constexpr bool NORM = !__is_same(NORM_T, void);
+  static_assert((STAGE > 0) == NORM, "the norm-in-consumer form stages its first weights in LDS (and only it does)");
+  constexpr int SLOT = (NP4 + (REM > 0 ? 1 : 0)) * 1024;      // one k-step of one wave's weights, 16 bytes per lane and piece
   constexpr int NST = NSEG * 4;
   constexpr int CW = 64 * NP4 + 16 * REM;
   constexpr int CWP = CW + 4;
@@ -1103,14 +1215,22 @@ __global__ __launch_bounds__(NWV * 64, 1) void wna16_gemm_stream_kernel(Wna16Res
     for (int t = 0; t < NT; ++t) { cacc[i][t] = zero4; acc[i][t] = zero4; }
   }
   u32x4 ar[RING][MT], wr4[RING][NP4 > 0 ? NP4 : 1], wrr[RING];
-  auto load_step = [&](auto I_) {
+  auto load_a = [&](auto I_) {
     constexpr int I = decltype(I_)::value;
     constexpr int s = I / 4, u = I % 4, B = I % RING;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       const int vo = voff_a[i];
-      ar[B][i] = __builtin_amdgcn_raw_buffer_load_b128(ra, vo, ((seg0 + s) * 4 + u) * abytes, 0);
+      // norm-in-consumer: sc0 sc1 -- the rows were stored write-through by producers on all eight XCDs, 16 bytes per row
+      // and 128-byte line; a producer's own L2 (and L1) fills the REST of such a line from memory when its 16 bytes arrive,
+      // i.e. before the other seven rows exist: a plain load of that XCD then hits a stale line (seen on the qkv shape:
+      // NaNs from the uninitialised buffer; on gate_up the weight stream happens to evict those lines first)
+      ar[B][i] = __builtin_amdgcn_raw_buffer_load_b128(ra, vo, ((seg0 + s) * 4 + u) * abytes, NORM ? 17 : 0);
     }
+  };
+  auto load_w = [&](auto I_) {
+    constexpr int I = decltype(I_)::value;
+    constexpr int s = I / 4, u = I % 4, B = I % RING;
 #pragma unroll
     for (int pp = 0; pp < NP4; ++pp)
       wr4[B][pp] = __builtin_amdgcn_raw_buffer_load_b128(rw, voff_w4, sbase + pp * poff4 + s * 4096 + u * 1024, 2);
@@ -1147,14 +1267,101 @@ __global__ __launch_bounds__(NWV * 64, 1) void wna16_gemm_stream_kernel(Wna16Res
     if constexpr (REM == 3) m.zr1 = __builtin_amdgcn_raw_buffer_load_b32(rz, voff_zr1, so_z, 0);
   };
 
-  load_meta(std::integral_constant<int, 0>{});
-  res_static_for<0, DD>([&](auto I_) { load_step(I_); });
+  auto load_step = [&](auto I_) { load_a(I_); load_w(I_); };
+  static_assert(STAGE == 0 || STAGE + DD <= NST, "staged + ring k-steps exceed the wave's K range");
+  unsigned char* const stg = reinterpret_cast<unsigned char*>(red) + (size_t)wave * STAGE * SLOT + lane * 16;
+  u32x4 lw4[2][NP4 > 0 ? NP4 : 1], lwr[2];        // STAGE > 0: the LDS-fed k-steps, read one step ahead
+  auto lds_read = [&](auto I_) {
+    constexpr int I = decltype(I_)::value;
+#pragma unroll
+    for (int pp = 0; pp < NP4; ++pp) lw4[I & 1][pp] = *reinterpret_cast<const u32x4*>(stg + I * SLOT + pp * 1024);
+    if constexpr (REM > 0) lwr[I & 1] = *reinterpret_cast<const u32x4*>(stg + I * SLOT + NP4 * 1024);
+  };
+
+#ifdef RES_NORM_TRACE      // lab builds: wall-clock (100 MHz) stamps of every wave, kept in SGPRs, written to p.trace
+                           // [workgroup][wave][8] at the end
+  unsigned long long nfst[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define NF_STAMP(i) do { nfst[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define NF_STAMP(i) do { } while (0)
+#endif
+  if constexpr (NORM) {
+    NF_STAMP(0);
+    constexpr int NIT = 2;                          // K = 4096 (the host checks): two 8-element vectors per thread
+    const int wgid = blockIdx.y * gridDim.x + blockIdx.x;
+    const bool producer = wgid < p.M;
+    {
+      // producers: the row first, then the weight batch (the store acknowledgement would wait behind the batch otherwise)
+      if (producer) {
+        ResNormRegs<NIT> nr;
+        res_norm_load<NIT>(p, wgid, nr);
+        res_norm_finish<NORM_T, NIT>(p, wgid, nr, red);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        NF_STAMP(1);
+        __builtin_amdgcn_s_barrier();
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(p.n_sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      load_meta(std::integral_constant<int, 0>{});
+      u32x4 tb4[STAGE][NP4 > 0 ? NP4 : 1], tbr[STAGE];
+      res_static_for<0, STAGE>([&](auto I_) {
+        constexpr int I = decltype(I_)::value;
+        constexpr int s = I / 4, u = I % 4;
+#pragma unroll
+        for (int pp = 0; pp < NP4; ++pp)
+          tb4[I][pp] = __builtin_amdgcn_raw_buffer_load_b128(rw, voff_w4, sbase + pp * poff4 + s * 4096 + u * 1024, 2);
+        const int so = sbase + poffr + s * 1024 * REM + u * 256 * REM;
+        if constexpr (REM == 3) {
+          typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+          const u32x3 v = __builtin_amdgcn_raw_buffer_load_b96(rw, voff_wr, so, 2);
+          tbr[I] = u32x4{v[0], v[1], v[2], 0u};
+        } else if constexpr (REM == 2) {
+          const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rw, voff_wr, so, 2);
+          tbr[I] = u32x4{v[0], v[1], 0u, 0u};
+        } else if constexpr (REM == 1) {
+          tbr[I] = u32x4{__builtin_amdgcn_raw_buffer_load_b32(rw, voff_wr, so, 2), 0u, 0u, 0u};
+        }
+      });
+      __builtin_amdgcn_sched_barrier(0);
+      res_static_for<0, STAGE>([&](auto I_) {
+        constexpr int I = decltype(I_)::value;
+#pragma unroll
+        for (int pp = 0; pp < NP4; ++pp) *reinterpret_cast<u32x4*>(stg + I * SLOT + pp * 1024) = tb4[I][pp];
+        if constexpr (REM > 0) *reinterpret_cast<u32x4*>(stg + I * SLOT + NP4 * 1024) = tbr[I];
+      });
+#ifdef RES_NORM_TRACE
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      NF_STAMP(2);
+#endif
+      res_static_for<STAGE, STAGE + DD>([&](auto I_) { load_w(I_); });
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (threadIdx.x == 0) {
+      int spins = 0;
+      while (__hip_atomic_load(p.n_sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)p.M && ++spins < (1 << 16))
+        __builtin_amdgcn_s_sleep(2);
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    NF_STAMP(3);
+    res_static_for<0, DD>([&](auto I_) { load_a(I_); });
+    if constexpr (STAGE > 0) lds_read(std::integral_constant<int, 0>{});
+  } else {
+    load_meta(std::integral_constant<int, 0>{});
+    res_static_for<0, DD>([&](auto I_) { load_step(I_); });
+  }
   __builtin_amdgcn_sched_barrier(0);
 
   res_static_for<0, NST>([&](auto I_) {
     constexpr int I = decltype(I_)::value;
     constexpr int s = I / 4, u = I % 4, B = I % RING;
-    if constexpr (I + DD < NST) load_step(std::integral_constant<int, (I + DD < NST ? I + DD : 0)>{});
+    if constexpr (I + DD < NST) {
+      load_a(std::integral_constant<int, (I + DD < NST ? I + DD : 0)>{});
+      // (the weights of k-steps < STAGE sit in LDS, those of STAGE .. STAGE + DD - 1 were requested in the prologue)
+      if constexpr (I + DD >= STAGE + DD || STAGE == 0) load_w(std::integral_constant<int, (I + DD < NST ? I + DD : 0)>{});
+    }
+    if constexpr (I + 1 < STAGE) lds_read(std::integral_constant<int, (I + 1 < STAGE ? I + 1 : 0)>{});
     if constexpr (u == 0 && s + 1 < NSEG) load_meta(std::integral_constant<int, (s + 1 < NSEG ? s + 1 : 0)>{});
     __builtin_amdgcn_sched_barrier(0);
     f16x8 a[MT];
@@ -1169,8 +1376,13 @@ __global__ __launch_bounds__(NWV * 64, 1) void wna16_gemm_stream_kernel(Wna16Res
     res_static_for<0, NT>([&](auto T_) {
       constexpr int t = decltype(T_)::value;
       uint32_t wv;
-      if constexpr (t < 4 * NP4) wv = wr4[B][t / 4][t % 4];
-      else wv = wrr[B][t - 4 * NP4];
+      if constexpr (I < STAGE) {
+        if constexpr (t < 4 * NP4) wv = lw4[I & 1][t / 4][t % 4];
+        else wv = lwr[I & 1][t - 4 * NP4];
+      } else {
+        if constexpr (t < 4 * NP4) wv = wr4[B][t / 4][t % 4];
+        else wv = wrr[B][t - 4 * NP4];
+      }
       const uint32_t w8 = wv >> 8;
       const u32x4 bq = {wv & 0x000f000fu, wv & 0x00f000f0u, w8 & 0x000f000fu, w8 & 0x00f000f0u};
       const f16x8 b = __builtin_bit_cast(f16x8, bq);
@@ -1178,6 +1390,13 @@ __global__ __launch_bounds__(NWV * 64, 1) void wna16_gemm_stream_kernel(Wna16Res
       for (int i = 0; i < MT; ++i)
         acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b, u == 0 ? zero4 : acc[i][t], 0, 0, 0);
     });
+#ifdef RES_NORM_TRACE
+    if constexpr (NORM) {
+      if constexpr (I == 0) NF_STAMP(4);
+      if constexpr (STAGE > 0 && I == STAGE - 1) NF_STAMP(5);
+      if constexpr (I == NST - 1) NF_STAMP(6);
+    }
+#endif
     if constexpr (u == 3) {
       const Meta& m = meta[s & 1];
       res_static_for<0, NT>([&](auto T_) {
@@ -1209,6 +1428,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void wna16_gemm_stream_kernel(Wna16Res
       __builtin_amdgcn_sched_barrier(0);
     }
   });
+  if constexpr (STAGE > 0) __syncthreads();       // the K-reduce tile reuses the staging space: every wave is done reading its weights
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -1222,6 +1442,17 @@ __global__ __launch_bounds__(NWV * 64, 1) void wna16_gemm_stream_kernel(Wna16Res
     }
   __syncthreads();
   res_reduce_store<MT, NWV, NP4, REM>(p, red, WP, ky, cb, mtiles);
+#ifdef RES_NORM_TRACE
+  if constexpr (NORM) {
+    NF_STAMP(7);
+    if (p.trace != nullptr && lane == 0) {
+      unsigned long long* t = p.trace + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * NWV + wave) * 8;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) t[i] = nfst[i];
+    }
+  }
+#endif
+#undef NF_STAMP
 }
 
 // [K/8, N] exllama order -> strip-major: the 16-byte (last pass: 4 REM-byte) pieces in the order the waves read them.
@@ -1340,11 +1571,14 @@ static int res_launch_ring(const Wna16ResParams& p, hipStream_t st) {
   return APHRO_OK;
 }
 
-template <int MT, int NWV, int NSEG, int NP4, int REM, int D>
+template <int MT, int NWV, int NSEG, int NP4, int REM, int D, typename NORM_T = void, int STAGE = 0>
 static int res_launch_stream(const Wna16ResParams& p, hipStream_t st) {
   constexpr int CW = 64 * NP4 + 16 * REM;
-  constexpr size_t LDS = (size_t)NWV * 16 * MT * (CW + 4) * sizeof(float);
-  auto kern = wna16_gemm_stream_kernel<MT, NWV, NSEG, NP4, REM, D>;
+  constexpr size_t TILE = (size_t)NWV * 16 * MT * (CW + 4) * sizeof(float);
+  constexpr size_t STG = (size_t)NWV * STAGE * (NP4 + (REM > 0 ? 1 : 0)) * 1024;
+  constexpr size_t LDS = STG > TILE ? STG : TILE;
+  static_assert(LDS <= 160 * 1024, "tile / staging exceed the LDS");
+  auto kern = wna16_gemm_stream_kernel<MT, NWV, NSEG, NP4, REM, D, NORM_T, STAGE>;
   if (LDS > 64 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS) != hipSuccess) {
     set_error("wna16_gemm_stream: cannot raise the dynamic LDS limit to %zu", LDS);
     return APHRO_ERR_LAUNCH;
@@ -1404,6 +1638,14 @@ static int res_launch_stream(const Wna16ResParams& p, hipStream_t st) {
   X(4, 7, 1, 0, 6)            \
   X(4, 4, 1, 0, 6)            \
   X(4, 2, 1, 0, 4)
+// norm-in-consumer form (aphro_wna16_gemm_norm_fused): the gate_up plan of configs[1].  (A qkv form without staging was
+// measured too -- 12.1 us against 4.8 + 6.8 for the two launches: its hand-over chain alone is 6.0 us and 64 KB of weights per
+// CU leave nothing to hide it under; profiles/r4_norm_in_consumer.txt)
+//   (.., k-steps in the register ring, k-steps staged in LDS)
+#ifndef RES_NORM_STAGE
+#define RES_NORM_STAGE 19
+#endif
+#define RES_NORM_CONFIGS(X) X(4, 8, 1, 3, 4, RES_NORM_STAGE)
 #ifdef RES_NO_KEEP_RS   // lab: the row sums of pass 0 are recomputed in the later passes instead of kept (registers)
 #define RES_KEEP_RS(x) false
 #else
@@ -1489,6 +1731,16 @@ static int res_dispatch(const Wna16ResParams& p, const ResConfig& cf, hipStream_
     RES_LC_CONFIGS(X)
 #undef X
   }
+  if (p.n_slabs != nullptr) {     // norm-in-consumer: stream kernel only
+#define X(a, b, c, d, r, g)                                                                                      \
+    if (cf.nwv == a && cf.nseg == b && cf.np4 == c && cf.rem == d)                                               \
+      return p.is_bf16 ? (mt == 2 ? res_launch_stream<2, a, b, c, d, r, BFloat, g>(p, st) : res_launch_stream<1, a, b, c, d, r, BFloat, g>(p, st)) \
+                       : (mt == 2 ? res_launch_stream<2, a, b, c, d, r, Half, g>(p, st) : res_launch_stream<1, a, b, c, d, r, Half, g>(p, st));
+    RES_NORM_CONFIGS(X)
+#undef X
+    set_error("wna16_gemm_norm_fused: configuration %d,%d,%d,%d has no norm-in-consumer instantiation", cf.nwv, cf.nseg, cf.np4, cf.rem);
+    return APHRO_ERR_INVALID;
+  }
   if (p.a == nullptr && p.strip_layout) {
     // packed activations on strip-major weights: the single-pass stream kernel where it is instantiated
     // (APHRO_WNA16_STREAM=0: the two-pass resident kernel; lab builds: =D picks a swept depth)
@@ -1566,6 +1818,7 @@ extern "C" int aphro_wna16_gemm_resident(const void* a_packed, const uint32_t* q
   p.force_partial = 0; p.strip_layout = strip_layout ? 1 : 0; p.is_bf16 = dtype == APHRO_BF16;
   p.trace = g_res_trace;
   p.a = nullptr; p.lda = 0; p.counter = nullptr;
+  p.n_slabs = nullptr; p.n_residual = nullptr; p.n_weight = nullptr; p.n_eps = 0.f; p.n_sync = nullptr;
   if (act_packed != nullptr) {
     APHRO_CHECK(cf.ksplit == 1 && N % 256 == 0, "wna16_gemm_resident: the SiluAndMul form needs one K slice and N/2 %% 128 == 0 (N=%ld)", (long)N);
     p.c = nullptr; p.partial = nullptr;
@@ -1574,6 +1827,55 @@ extern "C" int aphro_wna16_gemm_resident(const void* a_packed, const uint32_t* q
     p.force_partial = 1; p.c = nullptr;
   } else {
     APHRO_CHECK(c != nullptr && cf.ksplit == 1, "wna16_gemm_resident: this shape needs the slab form (%d K slices)", cf.ksplit);
+  }
+  return res_dispatch(p, cf, st);
+}
+
+// 1: aphro_wna16_gemm_norm_fused serves this call.
+extern "C" int aphro_wna16_gemm_norm_fused_supported(int64_t M, int64_t N, int64_t K, int64_t groups, int nslab, int dtype) {
+  if ((dtype != APHRO_F16 && dtype != APHRO_BF16) || groups <= 0 || K % groups != 0 || K != 4096 || nslab != 4 || M < 1 || M > 32) return 0;
+  const ResConfig cf = res_plan(M, N, K, K / groups);
+  if (cf.nwv == 0 || (int64_t)(N / (64 * cf.np4 + 16 * cf.rem)) * cf.ksplit < M) return 0;
+#define X(a, b, c, d, r, g) if (cf.nwv == a && cf.nseg == b && cf.np4 == c && cf.rem == d) return 1;
+  RES_NORM_CONFIGS(X)
+#undef X
+  return 0;
+}
+
+// fused_add_rms_norm (+ split-K slab reduce + pack) and the decode GEMM that consumes it in ONE launch ("norm-in-consumer",
+// DESIGN.md 5): x = sum of the 4 fp32 slabs in_slabs [4][M][K] rounded to dtype, residual' = round(x + residual) (in
+// place), y = round(round(residual' rstd) w) -- bit for bit aphro_fused_add_rms_norm_pack -- produced by the first M
+// workgroups into a_packed (scratch, aphro_wna16_packed_a_bytes(M, K)) while every workgroup's first weights are in flight,
+// then aphro_wna16_gemm_resident's GEMM on it (strip-major q_weight; outputs: act_packed = SiluAndMul form, or fp32 slabs),
+// bit for bit again.  sync: one zeroed 32-bit word in device memory, left at M by the launch -- the caller zeroes it before
+// the next launch that uses it (one fill per decode step over all the words of a model).
+extern "C" int aphro_wna16_gemm_norm_fused(const float* in_slabs, int nslab, void* residual, const void* norm_weight, float eps,
+                                           void* a_packed, const uint32_t* q_weight, const uint32_t* qzeros, const void* scales,
+                                           float* slabs, size_t slabs_bytes, void* act_packed, int64_t M, int64_t N, int64_t K,
+                                           int64_t groups, int zero_offset, int dtype, void* sync, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  APHRO_CHECK(aphro_wna16_gemm_norm_fused_supported(M, N, K, groups, nslab, dtype),
+              "wna16_gemm_norm_fused: M=%ld N=%ld K=%ld groups=%ld nslab=%d dtype=%d is not served", (long)M, (long)N, (long)K, (long)groups, nslab, dtype);
+  APHRO_CHECK(in_slabs && residual && norm_weight && a_packed && sync, "wna16_gemm_norm_fused: null argument");
+  APHRO_CHECK(((uintptr_t)a_packed % 16) == 0 && ((uintptr_t)q_weight % 16) == 0 && ((uintptr_t)in_slabs % 16) == 0 &&
+              ((uintptr_t)residual % 16) == 0 && ((uintptr_t)norm_weight % 16) == 0 && ((uintptr_t)sync % 4) == 0,
+              "wna16_gemm_norm_fused: 16-byte alignment required");
+  APHRO_CHECK((act_packed != nullptr) != (slabs != nullptr), "wna16_gemm_norm_fused: exactly one of act_packed / slabs");
+  const ResConfig cf = res_plan(M, N, K, K / groups);
+  Wna16ResParams p;
+  p.apk = (const uint16_t*)a_packed; p.qw = q_weight; p.qz = qzeros; p.sc = (const uint16_t*)scales;
+  p.c = nullptr; p.partial = slabs; p.act_packed = (uint16_t*)act_packed;
+  p.M = (int)M; p.N = (int)N; p.K = (int)K; p.zero_offset = zero_offset; p.ksplit = cf.ksplit;
+  p.gshift = 0;
+  for (int64_t q = (K / groups) >> 7; q > 1; q >>= 1) ++p.gshift;
+  p.force_partial = slabs != nullptr; p.strip_layout = 1; p.is_bf16 = dtype == APHRO_BF16;
+  p.trace = g_res_trace; p.a = nullptr; p.lda = 0; p.counter = nullptr;
+  p.n_slabs = in_slabs; p.n_residual = (uint16_t*)residual; p.n_weight = (const uint16_t*)norm_weight; p.n_eps = eps;
+  p.n_sync = (unsigned*)sync;
+  if (act_packed != nullptr) {
+    APHRO_CHECK(cf.ksplit == 1 && N % 256 == 0, "wna16_gemm_norm_fused: the SiluAndMul form needs one K slice and N/2 %% 128 == 0 (N=%ld)", (long)N);
+  } else {
+    APHRO_CHECK(slabs_bytes >= (size_t)cf.ksplit * M * N * sizeof(float), "wna16_gemm_norm_fused: slabs too small");
   }
   return res_dispatch(p, cf, st);
 }
@@ -1633,6 +1935,7 @@ extern "C" int aphro_wna16_gemm_rowmajor(const void* a, int64_t lda, const uint3
   p.force_partial = 0; p.strip_layout = strip_layout ? 1 : 0; p.is_bf16 = 0;
   p.trace = nullptr;
   p.a = (const uint16_t*)a; p.lda = (int)lda; p.counter = nullptr;
+  p.n_slabs = nullptr; p.n_residual = nullptr; p.n_weight = nullptr; p.n_eps = 0.f; p.n_sync = nullptr;
   if (cf.ksplit > 1) {
     const size_t need = (size_t)cf.ksplit * M * N * sizeof(float);
     if (workspace == nullptr || workspace_bytes < need || ((uintptr_t)workspace % 16) != 0) {

@@ -313,8 +313,21 @@ class LlamaDecoderLayer(nn.Module):
             router_logits = torch.matmul(normed, self.moe_gate.t())
         return self.experts(normed, router_logits, defer_combine=defer_combine)
 
+    def _norm_fused_ok(self, name: str, in_slabs, m: int, sync) -> bool:
+        """The norm in front of projection ``name`` rides inside its GEMM launch (ops.wna16_gemm_norm_fused): dense layer,
+        one rank, the previous projection's 4 fp32 slabs as input, a strip-major copy served by the stream kernel."""
+        if sync is None or in_slabs is None or self.tp > 1 or self.is_moe or m > 32:
+            return False
+        if name != "gate_up_proj":      # (qkv: measured 12.1 us against 4.8 + 6.8 for the two launches; not instantiated)
+            return False
+        st = self.gate_up_strip if name == "gate_up_proj" else self.strip.get(name)
+        if st is None:
+            return False
+        sc = self.gate_up_interleaved[2] if name == "gate_up_proj" else getattr(self, name).fast_params()[2]
+        return ops.wna16_gemm_norm_fused_supported(m, sc.shape[1], in_slabs.shape[2], sc.shape[0], in_slabs.shape[0], sc.dtype)
+
     def forward_decode_fused(self, positions, x, slabs, residual, first, kv_cache, attn_metadata, cos_sin,
-                             cos_sin_tok=None, next_weights=None):
+                             cos_sin_tok=None, next_weights=None, norm_sync=None):
         """x: row-major input (first layer, or the all-reduced down_proj output of the previous
         layer when TP > 1) or None; slabs: fp32 split-K slabs of the previous down_proj (TP == 1).
         Returns (x, slabs) of this layer's down_proj in the same convention."""
@@ -324,10 +337,11 @@ class LlamaDecoderLayer(nn.Module):
         if isinstance(x, DeferredCombine):        # the previous layer's sparse MLP: combine inside this norm launch
             packed, _ = ops.fused_add_rms_norm_pack_combine(x.slabs, x.inv, x.topk_weights, residual, not first,
                                                             self.input_layernorm, eps)
+            qkv_slabs, _ = self._gemm_slabs("qkv_proj", packed, m, h)
         else:
             packed, _ = ops.fused_add_rms_norm_pack(x if slabs is None else None, slabs, residual,
                                                     not first, self.input_layernorm, eps)
-        qkv_slabs, _ = self._gemm_slabs("qkv_proj", packed, m, h)
+            qkv_slabs, _ = self._gemm_slabs("qkv_proj", packed, m, h)
         from .attention.paged_attn import PagedAttention
         key_cache, value_cache = PagedAttention.split_kv_cache(kv_cache, self.num_kv_heads, self.head_dim)
         if self.head_dim == 128 and self.fuse_rope_attention:
@@ -383,6 +397,13 @@ class LlamaDecoderLayer(nn.Module):
                                                      self.post_attention_layernorm, eps)
         else:
             o_slabs, _ = self._gemm_slabs("o_proj", attn_packed, m, self.q_size)
+            if self.gate_up_interleaved is not None and self._norm_fused_ok("gate_up_proj", o_slabs, m, norm_sync):
+                # norm-in-consumer: post-attention norm + gate_up + SiluAndMul + pack in one launch
+                _, qz_, sc_, zo_ = self.gate_up_interleaved
+                act_packed = ops.wna16_gemm_norm_fused(o_slabs, residual, self.post_attention_layernorm, eps,
+                                                       self.gate_up_strip, qz_, sc_, zo_, norm_sync, mode="silu")
+                down_slabs, _ = self._gemm_slabs("down_proj", act_packed, m, self.down_proj.in_features)
+                return None, down_slabs
             packed2, _ = ops.fused_add_rms_norm_pack(None, o_slabs, residual, True,
                                                      self.post_attention_layernorm, eps)
         # 33..64 rows: the MLP weights go through the one-pass 32x32x16 MFMA kernel (wna16_gemm_mid.hip: 26.6 vs 37.6 us on
@@ -573,6 +594,11 @@ class LlamaForCausalLM(nn.Module):
             requires_grad=False)
         self.cos_sin = None
         self.use_fused_decode = True
+        # norm-in-consumer gate_up launch on the fused decode path (ops.wna16_gemm_norm_fused).  OFF by default: bit-identical,
+        # but measured 21.6-22.8 us against 4.8 + 15.5-16.9 for the two launches (step 2.69-2.70 ms against 2.60-2.64; the
+        # per-wave timeline that says why: profiles/r4_norm_in_consumer.txt).  APHRO_DECODE_NORM_FUSED=1 turns it on.
+        self.norm_fused = os.environ.get("APHRO_DECODE_NORM_FUSED", "0") == "1"
+        self._norm_sync = None
 
     # -- synthetic weights in the real formats -----------------------------------
     @torch.no_grad()
@@ -646,6 +672,14 @@ class LlamaForCausalLM(nn.Module):
             # rotary table rows of this step's positions, gathered once for all layers
             cos_sin_tok = self.cos_sin.index_select(0, positions)
             tp = get_tensor_model_parallel_world_size()
+            # norm-in-consumer launches (ops.wna16_gemm_norm_fused, opt-in): one arrival ticket per launch, all zeroed by ONE
+            # fill per step
+            sync = None
+            if self.norm_fused and tp == 1 and hidden.shape[0] <= 32:
+                if self._norm_sync is None or self._norm_sync.device != hidden.device:
+                    self._norm_sync = torch.zeros(len(self.layers), dtype=torch.int32, device=hidden.device)
+                sync = self._norm_sync
+                sync.zero_()
             for i, layer in enumerate(self.layers):
                 # TP: the down_proj all-reduce of this layer overlaps with a prefetch of the NEXT layer's qkv weights
                 nxt = None
@@ -653,7 +687,8 @@ class LlamaForCausalLM(nn.Module):
                     fp = self.layers[i + 1].qkv_proj.fast_params()
                     nxt = fp[:3] if fp is not None else None
                 x, slabs = layer.forward_decode_fused(positions, x, slabs, residual, i == 0,
-                                                      kv_caches[i], attn_metadata, self.cos_sin, cos_sin_tok, nxt)
+                                                      kv_caches[i], attn_metadata, self.cos_sin, cos_sin_tok, nxt,
+                                                      norm_sync=None if sync is None else sync[i:i + 1])
             if isinstance(x, DeferredCombine):
                 _, out = ops.fused_add_rms_norm_pack_combine(x.slabs, x.inv, x.topk_weights, residual, True, self.norm,
                                                              self.cfg.rms_norm_eps, pack=False, want_out=True)

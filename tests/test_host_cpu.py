@@ -57,6 +57,19 @@ def test_int4_gemm_plans_through_their_workspace_sizes():
     assert mid(65, 28672, 4096) == 0
 
 
+def test_norm_in_consumer_plan_is_host_logic():
+    """aphro_wna16_gemm_norm_fused_supported (no device call): the gate_up plan of configs[1] only -- hidden 4096, <= 32 rows,
+    four input slabs, f16 / bf16; everything else keeps the two launches."""
+    from aphrodite_engine_amd import _lib
+    L = _lib.lib()
+    ok = L.aphro_wna16_gemm_norm_fused_supported
+    assert ok(32, 28672, 4096, 32, 4, _lib.F16) and ok(1, 28672, 4096, 32, 4, _lib.BF16)
+    assert not ok(32, 6144, 4096, 32, 4, _lib.F16)            # qkv: measured slower than its two launches, not instantiated
+    assert not ok(33, 28672, 4096, 32, 4, _lib.F16) and not ok(0, 28672, 4096, 32, 4, _lib.F16)
+    assert not ok(32, 28672, 4096, 32, 2, _lib.F16) and not ok(32, 28672, 4096, 32, 4, _lib.F32)
+    assert not ok(32, 28672, 8192, 64, 4, _lib.F16) and not ok(32, 28672, 4096, 0, 4, _lib.F16)
+
+
 def test_no_cpu_fallback():
     from aphrodite_engine_amd import _custom_ops as ops
     with pytest.raises(RuntimeError, match="no CPU fallback"):
