@@ -1045,8 +1045,19 @@ def fused_add_rms_norm_pack_combine(slabs: torch.Tensor, inv_pos: torch.Tensor, 
     return packed, out
 
 
-def silu_and_mul_pack(x: torch.Tensor) -> torch.Tensor:
+def silu_and_mul_pack(x: Optional[torch.Tensor], slabs: Optional[torch.Tensor] = None,
+                      dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    """SiluAndMul + pack of [gate | up] rows; with ``slabs`` (fp32 [S, tokens, 2 d], ``dtype`` = the activation dtype) the
+    split-K reduce of the gate_up GEMM rides in the same launch (same bits as reduce, then this op)."""
     lib = _lib.lib()
+    if slabs is not None:
+        nslab, tokens, d2 = slabs.shape
+        d = d2 // 2
+        assert slabs.is_contiguous() and slabs.dtype == torch.float32 and dtype in _DT
+        packed = torch.empty(lib.aphro_wna16_packed_a_bytes(tokens, d) // 2, dtype=torch.float16, device=slabs.device)
+        check(lib.aphro_silu_and_mul_pack_slabs(slabs.data_ptr(), nslab, packed.data_ptr(), None, tokens, d, _DT[dtype],
+                                                _stream()), "silu_and_mul_pack_slabs")
+        return packed
     tokens, d2 = x.shape
     d = d2 // 2
     assert x.is_contiguous()

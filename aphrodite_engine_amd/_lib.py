@@ -65,6 +65,7 @@ SIGNATURES = {
     "aphro_wna16_gemm_grouped": (I, [P, P, P, P, P, P, P, P, Z, P, L, L, L, L, I, I, P]),
     "aphro_moe_combine": (I, [P, P, I, L, P, P, L, I, L, I, P]),
     "aphro_fused_add_rms_norm_pack": (I, [P, P, I, P, I, P, F, P, P, L, I, I, P]),
+    "aphro_silu_and_mul_pack_slabs": (I, [P, I, P, P, L, I, I, P]),
     "aphro_silu_and_mul_pack": (I, [P, P, P, L, I, I, P]),
     "aphro_rope_cache": (I, [P, L, P, I, P, P, I, I, P, P, P, P, L, I, I, I, I, I, I, I, F, F, P]),
     "aphro_gptq_dequant": (I, [P, P, P, P, P, L, L, L, I, I, I, P]),

@@ -252,17 +252,40 @@ __global__ void add_rms_norm_pack_kernel(const uint16_t* __restrict__ input, con
   }
 }
 
-// act = round(round(silu(gate)) * up) -> packed f16 (and/or row-major)
-template <typename T>
+// act = round(round(silu(gate)) * up) -> packed f16 (and/or row-major).
+// SLABS: [gate | up] = the sum of `nslab` fp32 split-K slabs [nslab][tokens][2 d] rounded to T -- splitk_reduce_kernel's
+// arithmetic (wna16_gemm.hip: slab order, one rounding) without its launch and its [tokens, 2 d] round trip (round 4: the
+// K-sliced gate_up of a TP shard, e.g. 8192 x 7168 at 64 rows, used to be GEMM + splitk_reduce + silu_and_mul_pack).
+template <typename T, bool SLABS = false>
 __global__ void silu_mul_pack_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ packed,
-                                     uint16_t* __restrict__ out, int tokens, int d) {
+                                     uint16_t* __restrict__ out, int tokens, int d,
+                                     const float* __restrict__ slabs = nullptr, int nslab = 0) {
   const int tok = blockIdx.x;
   const int mtiles = (tokens + 15) >> 4;
   const uint16_t* a = in + (size_t)tok * 2 * d;
   const uint16_t* b = a + d;
+  const size_t slab_stride = (size_t)tokens * 2 * d;
   for (int i = threadIdx.x; i < (d >> 3); i += blockDim.x) {
-    u16x8 x = *reinterpret_cast<const u16x8*>(a + 8 * i);
-    u16x8 y = *reinterpret_cast<const u16x8*>(b + 8 * i);
+    u16x8 x, y;
+    if constexpr (SLABS) {
+      const float* pg = slabs + (size_t)tok * 2 * d + 8 * i;
+      f32x4 g0 = *reinterpret_cast<const f32x4*>(pg), g1 = *reinterpret_cast<const f32x4*>(pg + 4);
+      f32x4 u0 = *reinterpret_cast<const f32x4*>(pg + d), u1 = *reinterpret_cast<const f32x4*>(pg + d + 4);
+      for (int s = 1; s < nslab; ++s) {
+        g0 += *reinterpret_cast<const f32x4*>(pg + s * slab_stride);
+        g1 += *reinterpret_cast<const f32x4*>(pg + s * slab_stride + 4);
+        u0 += *reinterpret_cast<const f32x4*>(pg + s * slab_stride + d);
+        u1 += *reinterpret_cast<const f32x4*>(pg + s * slab_stride + d + 4);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        x[j] = T::from_f32(g0[j]); x[4 + j] = T::from_f32(g1[j]);
+        y[j] = T::from_f32(u0[j]); y[4 + j] = T::from_f32(u1[j]);
+      }
+    } else {
+      x = *reinterpret_cast<const u16x8*>(a + 8 * i);
+      y = *reinterpret_cast<const u16x8*>(b + 8 * i);
+    }
     u16x8 r, rh;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -548,6 +571,25 @@ extern "C" int aphro_silu_and_mul_pack(const void* input, void* packed, void* ou
   else
     hipLaunchKernelGGL((silu_mul_pack_kernel<BFloat>), grid, block, 0, (hipStream_t)stream, (const uint16_t*)input,
                        (uint16_t*)packed, (uint16_t*)out, (int)tokens, d);
+  APHRO_LAUNCH_CHECK();
+  return APHRO_OK;
+}
+
+// silu_and_mul_pack on the split-K slabs of the gate_up GEMM (the slab reduce rides in this launch).
+extern "C" int aphro_silu_and_mul_pack_slabs(const float* slabs, int nslab, void* packed, void* out, int64_t tokens, int d,
+                                             int dtype, void* stream) {
+  APHRO_CHECK(dtype == APHRO_F16 || dtype == APHRO_BF16, "silu_and_mul_pack_slabs: dtype must be f16 or bf16");
+  APHRO_CHECK(d % 8 == 0 && (packed == nullptr || d % 128 == 0), "silu_and_mul_pack_slabs: d=%d unsupported", d);
+  APHRO_CHECK(slabs != nullptr && nslab >= 1 && ((uintptr_t)slabs % 16) == 0, "silu_and_mul_pack_slabs: slabs missing / misaligned");
+  if (tokens == 0) return APHRO_OK;
+  int threads = d / 8 >= 1024 ? 1024 : ((d / 8 + 63) / 64 * 64);
+  dim3 grid((unsigned)tokens), block(threads);
+  if (dtype == APHRO_F16)
+    hipLaunchKernelGGL((silu_mul_pack_kernel<Half, true>), grid, block, 0, (hipStream_t)stream, (const uint16_t*)nullptr,
+                       (uint16_t*)packed, (uint16_t*)out, (int)tokens, d, slabs, nslab);
+  else
+    hipLaunchKernelGGL((silu_mul_pack_kernel<BFloat, true>), grid, block, 0, (hipStream_t)stream, (const uint16_t*)nullptr,
+                       (uint16_t*)packed, (uint16_t*)out, (int)tokens, d, slabs, nslab);
   APHRO_LAUNCH_CHECK();
   return APHRO_OK;
 }

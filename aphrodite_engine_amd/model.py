@@ -421,8 +421,14 @@ class LlamaDecoderLayer(nn.Module):
                 act_packed = ops.wna16_gemm_silu_pack(packed2, m, h, qw, qz, sc, zo)
         else:
             qw, qz, sc, zo = self.gate_up_proj.fast_params()
-            gate_up = ops.wna16_gemm_packed(packed2, m, h, qw, qz, sc, zo, partials=False)
-            act_packed = ops.silu_and_mul_pack(gate_up)
+            if ops.wna16_ksplit(m, qw.shape[1], h, sc.shape[0]) > 1 and not os.environ.get("APHRO_DECODE_NO_SILU_SLABS"):
+                # K-sliced gate_up (TP shards: 8192 x 7168 at 64 rows): the slab reduce rides in the SiluAndMul + pack launch
+                # (GEMM + splitk_reduce + silu_and_mul_pack -> GEMM + one consumer, same bits)
+                gu_slabs, _ = ops.wna16_gemm_packed(packed2, m, h, qw, qz, sc, zo, partials=True)
+                act_packed = ops.silu_and_mul_pack(None, slabs=gu_slabs, dtype=sc.dtype)
+            else:
+                gate_up = ops.wna16_gemm_packed(packed2, m, h, qw, qz, sc, zo, partials=False)
+                act_packed = ops.silu_and_mul_pack(gate_up)
         qw, qz, sc, zo = self.down_proj.fast_params()
         if self.tp > 1:
             d = ops.wna16_gemm_packed(act_packed, m, self.down_proj.in_features, qw, qz, sc, zo, partials=False)

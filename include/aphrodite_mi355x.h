@@ -361,6 +361,10 @@ int aphro_fused_add_rms_norm_pack(const void* input, const float* slabs, int nsl
                                   int hidden, int dtype, void* stream);
 int aphro_silu_and_mul_pack(const void* input, void* packed, void* out, int64_t tokens,
                             int d, int dtype, void* stream);
+/* the same on the gate_up GEMM's fp32 split-K slabs [nslab][tokens][2 d] (slab order, one rounding to dtype: the
+ * splitk reduce rides in this launch) */
+int aphro_silu_and_mul_pack_slabs(const float* slabs, int nslab, void* packed, void* out, int64_t tokens,
+                                  int d, int dtype, void* stream);
 int aphro_rope_cache(const void* qkv, int64_t qkv_stride, const float* slabs, int nslab,
                      const int64_t* positions, const void* cos_sin_cache, int rot_dim,
                      int is_neox, void* q_out, void* key_cache, void* value_cache,

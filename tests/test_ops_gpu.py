@@ -1142,6 +1142,27 @@ def test_silu_and_mul_pack(ops, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("nslab,T_,d", [(2, 64, 3584), (1, 21, 1024), (4, 5, 14336)])
+def test_silu_and_mul_pack_on_split_k_slabs(ops, dtype, nslab, T_, d):
+    """The K-sliced gate_up of a TP shard (8192 x 7168 at 64 rows: two slabs): slab reduce + SiluAndMul + pack in ONE
+    launch == splitk reduce (slab order, one rounding), then _C::silu_and_mul (activation_kernels.cu:12-60), bit for bit;
+    and the oracle's silu_and_mul on the rounded sums."""
+    from oracle import attention as oa
+    rng = np.random.default_rng(35 + nslab)
+    slabs = t(rng.standard_normal((nslab, T_, 2 * d)).astype(np.float32))
+    acc = slabs[0].clone()
+    for s_ in range(1, nslab):
+        acc += slabs[s_]
+    x = acc.to(dtype)
+    ref = torch.empty(T_, d, dtype=dtype, device=DEV)
+    ops.silu_and_mul(ref, x)
+    got = unpack_a(ops.silu_and_mul_pack(None, slabs=slabs, dtype=dtype), T_, d)
+    np.testing.assert_array_equal(got, ref.to(torch.float16).cpu().numpy().view(np.uint16))
+    want = oa.silu_and_mul(x.float().cpu().numpy())
+    np.testing.assert_allclose(got.view(np.float16).astype(np.float64), want, rtol=2e-2 if dtype == torch.bfloat16 else 3e-3, atol=1e-3)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("kv_cache_dtype", ["auto", "fp8", "fp8_e5m2"])
 @pytest.mark.parametrize("nslab", [0, 2])
 def test_rope_cache_fused(ops, dtype, kv_cache_dtype, nslab):
