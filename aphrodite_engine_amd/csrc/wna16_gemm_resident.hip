@@ -566,8 +566,10 @@ __global__ __launch_bounds__(NWV * 64, NWV <= 4 ? 1 : 2) void wna16_gemm_residen
 //     in flight, see lm_head.hip) and run one k-step ahead of the MFMAs into a second register set.
 // Same arithmetic, same K partition over waves and slices as the kernel above for the same (NWV, NSEG): the slabs / packed
 // results are bit-identical to it.
+// row0: first row of this workgroup's tiles (33..64-row launches: blockIdx.z picks a 32-row half)
 template <int MT, int NWV, int NP4, int REM, int NTHREADS = NWV * 64>
-__device__ __forceinline__ void res_reduce_store(const Wna16ResParams& p, float* red, int WP, int ky, int cb, int mtiles) {
+__device__ __forceinline__ void res_reduce_store(const Wna16ResParams& p, float* red, int WP, int ky, int cb, int mtiles,
+                                                 int row0 = 0) {
   constexpr int CW = 64 * NP4 + 16 * REM;
   constexpr int CWP = CW + 4;
   constexpr int ROWS = 16 * MT;
@@ -595,8 +597,8 @@ __device__ __forceinline__ void res_reduce_store(const Wna16ResParams& p, float*
         }
       }
       const int j0 = (cb + 16 * ch) >> 1;
-      uint16_t* dst = p.act_packed + ((((size_t)(j0 >> 7) * 4 + ((j0 & 31) >> 3)) * mtiles + (row >> 4)) * 64 + ((j0 & 127) >> 5) * 16 + (row & 15)) * 8;
-      if (row < p.M)
+      uint16_t* dst = p.act_packed + ((((size_t)(j0 >> 7) * 4 + ((j0 & 31) >> 3)) * mtiles + ((row0 + row) >> 4)) * 64 + ((j0 & 127) >> 5) * 16 + (row & 15)) * 8;
+      if (row0 + row < p.M)
         *reinterpret_cast<u32x4*>(dst) = u32x4{(uint32_t)o[0] | ((uint32_t)o[1] << 16), (uint32_t)o[2] | ((uint32_t)o[3] << 16),
                                                (uint32_t)o[4] | ((uint32_t)o[5] << 16), (uint32_t)o[6] | ((uint32_t)o[7] << 16)};
     }
@@ -607,7 +609,7 @@ __device__ __forceinline__ void res_reduce_store(const Wna16ResParams& p, float*
       f32x4 sum = zero4;
 #pragma unroll
       for (int w2 = 0; w2 < NWV; ++w2) sum += *reinterpret_cast<const f32x4*>(&red[w2 * WP + row * CWP + 4 * c4]);
-      if (row < p.M) *reinterpret_cast<f32x4*>(p.partial + ((size_t)ky * p.M + row) * p.N + cb + 4 * c4) = sum;
+      if (row0 + row < p.M) *reinterpret_cast<f32x4*>(p.partial + ((size_t)ky * p.M + row0 + row) * p.N + cb + 4 * c4) = sum;
     }
   } else {
     constexpr int UNITS = ROWS * (CW / 8);
@@ -625,8 +627,8 @@ __device__ __forceinline__ void res_reduce_store(const Wna16ResParams& p, float*
         o[q] = p.is_bf16 ? BFloat::from_f32(s0[q]) : Half::from_f32(s0[q]);
         o[4 + q] = p.is_bf16 ? BFloat::from_f32(s1[q]) : Half::from_f32(s1[q]);
       }
-      if (row < p.M)
-        *reinterpret_cast<u32x4*>(p.c + (size_t)row * p.N + cb + 8 * c8) =
+      if (row0 + row < p.M)
+        *reinterpret_cast<u32x4*>(p.c + (size_t)(row0 + row) * p.N + cb + 8 * c8) =
             u32x4{(uint32_t)o[0] | ((uint32_t)o[1] << 16), (uint32_t)o[2] | ((uint32_t)o[3] << 16),
                   (uint32_t)o[4] | ((uint32_t)o[5] << 16), (uint32_t)o[6] | ((uint32_t)o[7] << 16)};
     }
@@ -1192,9 +1194,13 @@ __global__ __launch_bounds__(NWV * 64, 1) void wna16_gemm_stream_kernel(Wna16Res
   const int sbase = ((ky * S + strip) * NWV + wave) * WAVE_BYTES;
   const int voff_w4 = lane * 16, voff_wr = lane * 4 * REM;
   constexpr int poff4 = NSEG * 4096, poffr = NP4 * NSEG * 4096;
+  // 33..64 rows: gridDim.z = 2 -- blockIdx.z picks a 32-row half; the two workgroups of a strip are the 32-row kernel twice,
+  // co-resident on a CU (<= 256 VGPRs each: two waves per SIMD, what one workgroup cannot afford), the second reader of a
+  // weight line finds it in the XCD's L2 (x + S (y + ksplit z): same XCD for both halves)
+  const int mt0 = (int)blockIdx.z * MT;
   int voff_a[MT];
 #pragma unroll
-  for (int i = 0; i < MT; ++i) voff_a[i] = (min(i, mtiles - 1) * 64 + lane) * 16;
+  for (int i = 0; i < MT; ++i) voff_a[i] = (min(mt0 + i, mtiles - 1) * 64 + lane) * 16;
   const int abytes = mtiles * 1024;
   const int col4 = cb + 4 * c;
   const int colr = cb + 64 * NP4 + REM * c;
@@ -1441,7 +1447,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void wna16_gemm_stream_kernel(Wna16Res
       for (int t = 0; t < REM; ++t) row[64 * NP4 + REM * c + t] = cacc[i][4 * NP4 + t][r];
     }
   __syncthreads();
-  res_reduce_store<MT, NWV, NP4, REM>(p, red, WP, ky, cb, mtiles);
+  res_reduce_store<MT, NWV, NP4, REM>(p, red, WP, ky, cb, mtiles, 16 * mt0);
 #ifdef RES_NORM_TRACE
   if constexpr (NORM) {
     NF_STAMP(7);
@@ -1502,7 +1508,17 @@ struct ResConfig { int nwv, nseg, np4, rem, ksplit; };
 // allows it: strips x K slices as close to the CU count as the divisibility permits.
 //   APHRO_WNA16_RES_CFG="nwv,nseg,np4,rem" picks an instantiated configuration by hand (lab / tests).
 static bool res_instantiated(int nwv, int nseg, int np4, int rem);
+static bool res_stream_instantiated(int nwv, int nseg, int np4, int rem);
+static ResConfig res_plan32(int64_t M, int64_t N, int64_t K, int64_t gs);
+// 33..64 rows (round 4): the plan of the 32-row class, launched with gridDim.z = 2 -- stream-kernel plans only
 static ResConfig res_plan(int64_t M, int64_t N, int64_t K, int64_t gs) {
+  if (M <= 32) return res_plan32(M, N, K, gs);
+  ResConfig none = {0, 0, 0, 0, 0};
+  if (M > 64 || getenv("APHRO_WNA16_NO_ROW_HALVES")) return none;
+  const ResConfig cf = res_plan32(32, N, K, gs);
+  return cf.nwv != 0 && res_stream_instantiated(cf.nwv, cf.nseg, cf.np4, cf.rem) ? cf : none;
+}
+static ResConfig res_plan32(int64_t M, int64_t N, int64_t K, int64_t gs) {
   ResConfig none = {0, 0, 0, 0, 0};
   if (M < 1 || M > 32 || K % 128 != 0 || gs % 128 != 0 || N % 16 != 0) return none;
   const int64_t gq = gs >> 7;
@@ -1522,7 +1538,8 @@ static ResConfig res_plan(int64_t M, int64_t N, int64_t K, int64_t gs) {
     return none;
   }
   // candidates in order of preference per shape class; the first that fits and fills >= 3/4 of the CUs wins
-  static const int cand[][4] = {{4, 8, 1, 3}, {4, 7, 1, 0}, {4, 8, 1, 0}, {4, 4, 1, 0}, {4, 2, 1, 0}, {4, 4, 0, 3}};
+  // ({4, 4, 1, 3}: round 4, the 8192 x 7168 gate_up of a 70B TP-8 shard -- 64 strips of 112 columns x 4 K slices)
+  static const int cand[][4] = {{4, 8, 1, 3}, {4, 4, 1, 3}, {4, 7, 1, 0}, {4, 8, 1, 0}, {4, 4, 1, 0}, {4, 2, 1, 0}, {4, 4, 0, 3}};
   for (const auto& cd : cand) {
     const int ks = fits(cd[0], cd[1], cd[2], cd[3]);
     if (ks <= 0 || ks > 8) continue;
@@ -1583,7 +1600,7 @@ static int res_launch_stream(const Wna16ResParams& p, hipStream_t st) {
     set_error("wna16_gemm_stream: cannot raise the dynamic LDS limit to %zu", LDS);
     return APHRO_ERR_LAUNCH;
   }
-  const dim3 grid((unsigned)(p.N / CW), (unsigned)p.ksplit);
+  const dim3 grid((unsigned)(p.N / CW), (unsigned)p.ksplit, (unsigned)(p.M > 32 ? 2 : 1));
   hipLaunchKernelGGL(kern, grid, dim3(NWV * 64), LDS, st, p);
   APHRO_LAUNCH_CHECK();
   return APHRO_OK;
@@ -1637,7 +1654,8 @@ static int res_launch_stream(const Wna16ResParams& p, hipStream_t st) {
   X(4, 8, 1, 3, 4)            \
   X(4, 7, 1, 0, 6)            \
   X(4, 4, 1, 0, 6)            \
-  X(4, 2, 1, 0, 4)
+  X(4, 2, 1, 0, 4)            \
+  X(4, 4, 1, 3, 4)
 // norm-in-consumer form (aphro_wna16_gemm_norm_fused): the gate_up plan of configs[1].  (A qkv form without staging was
 // measured too -- 12.1 us against 4.8 + 6.8 for the two launches: its hand-over chain alone is 6.0 us and 64 KB of weights per
 // CU leave nothing to hide it under; profiles/r4_norm_in_consumer.txt)
@@ -1672,7 +1690,8 @@ static int res_launch_stream(const Wna16ResParams& p, hipStream_t st) {
   X(4, 4, 0, 3)        \
   X(4, 2, 1, 2)        \
   X(4, 1, 2, 0)        \
-  X(7, 2, 2, 0)
+  X(7, 2, 2, 0)        \
+  X(4, 4, 1, 3)
 
 // (the candidates of res_plan: what a call without APHRO_WNA16_RES_CFG can get)
 #define RES_AROW_CONFIGS(X) \
@@ -1681,7 +1700,8 @@ static int res_launch_stream(const Wna16ResParams& p, hipStream_t st) {
   X(4, 8, 1, 0)             \
   X(4, 4, 1, 0)             \
   X(4, 2, 1, 0)             \
-  X(4, 4, 0, 3)
+  X(4, 4, 0, 3)             \
+  X(4, 4, 1, 3)
 #endif
 
 static bool res_instantiated(int nwv, int nseg, int np4, int rem) {
@@ -1691,8 +1711,19 @@ static bool res_instantiated(int nwv, int nseg, int np4, int rem) {
   return false;
 }
 
+static bool res_stream_instantiated(int nwv, int nseg, int np4, int rem) {
+#define X(a, b, c, d, r) if (nwv == a && nseg == b && np4 == c && rem == d) return true;
+  RES_STREAM_CONFIGS(X)
+#undef X
+  return false;
+}
+
 static int res_dispatch(const Wna16ResParams& p, const ResConfig& cf, hipStream_t st) {
   const int mt = p.M > 16 ? 2 : 1;
+  if (p.M > 32 && !(p.a == nullptr && p.strip_layout && p.n_slabs == nullptr)) {
+    set_error("wna16_gemm_resident: %d rows are served on packed activations and strip-major weights only", p.M);
+    return APHRO_ERR_INVALID;
+  }
 #ifdef RES_LAB   // prefetch-depth sweep / per-wave timeline of the two big shapes (tools/resident_bench.py, resident_trace.py):
                  // APHRO_WNA16_RES_DEPTH="depth,adepth"; with a trace buffer set the TRACE instantiation runs
   if (const char* e = getenv("APHRO_WNA16_RES_DEPTH")) {
@@ -1901,7 +1932,7 @@ static unsigned* res_counters(hipStream_t st) {
 
 // 1: aphro_wna16_gemm_rowmajor serves this call (f16 activations, M <= 32, a shape the resident kernel tiles).
 extern "C" int aphro_wna16_gemm_rowmajor_supported(int64_t M, int64_t N, int64_t K, int64_t groups, int dtype) {
-  if (dtype != APHRO_F16 || groups <= 0 || K % groups != 0 || getenv("APHRO_WNA16_OP_NO_RESIDENT")) return 0;
+  if (dtype != APHRO_F16 || M > 32 || groups <= 0 || K % groups != 0 || getenv("APHRO_WNA16_OP_NO_RESIDENT")) return 0;
   const ResConfig cf = res_plan(M, N, K, K / groups);
   if (cf.nwv == 0 || N / (64 * cf.np4 + 16 * cf.rem) > RES_COUNTERS) return 0;
 #define X(a, b, c, d) if (cf.nwv == a && cf.nseg == b && cf.np4 == c && cf.rem == d) return 1;

@@ -208,6 +208,7 @@ class LlamaDecoderLayer(nn.Module):
         decode fast path runs SiluAndMul inside the GEMM epilogue.  With
         keep_original=False the [gate | up] copy is dropped (the unfused forward then
         de-interleaves the GEMM output instead)."""
+        self.enable_resident_layouts(m)       # (also where SiluAndMul cannot ride in the epilogue: TP shards, sparse layers)
         if self.is_moe:
             return False
         fp = self.gate_up_proj.fast_params()
@@ -221,11 +222,13 @@ class LlamaDecoderLayer(nn.Module):
         # <= 32 rows: the resident-activation kernel (one workgroup per CU, csrc/wna16_gemm_resident.hip) streams a
         # STRIP-MAJOR copy of the interleaved words (every wave's pieces in the order it reads them: 20.7 -> 17.8 us at
         # 4096 x 28672); the [K/8, N] copy stays for the 33..64-row and prefill kernels (2 x 59 MB per layer of 288 GB)
+        # (33..64 rows, round 4: the same kernel can run on two 32-row halves, two workgroups per CU -- measured SLOWER than
+        #  the 33..64-row kernel on the one-GPU shapes: gate_up 29.6-30.7 us against 26.8, down 17.3 against 14.2 at batch 64,
+        #  a CU takes in both halves' activations AND the weights twice; APHRO_DECODE_ROW_HALVES=1 builds the copies anyway)
         self.gate_up_strip = None
-        if m <= 32 and not os.environ.get("APHRO_DECODE_NO_RESIDENT") \
+        if m <= (64 if os.environ.get("APHRO_DECODE_ROW_HALVES") == "1" else 32) and not os.environ.get("APHRO_DECODE_NO_RESIDENT") \
                 and ops.wna16_resident_ksplit(m, lin.out_features, lin.in_features, sc.shape[0]) == 1:
             self.gate_up_strip = ops.wna16_strip_relayout(qw, m, sc.shape[0])
-        self.enable_resident_layouts(m)
         # The op-level strip-major copy the quant method made at load time (gptq.py / awq.py process_weights_after_loading,
         # 59 MB per layer on Llama-3-8B) is never read by the fused decode step, and with keep_original=False it would be
         # a copy of the WRONG column order: release it (ADVICE r3 -- gate_up used to live four times in HBM).  The
@@ -265,24 +268,34 @@ class LlamaDecoderLayer(nn.Module):
         8.2 -> 7.1 us and 11.4 -> 10.5 us, profiles/r3_resident_bench.txt; round 4, single-pass stream kernel: qkv 6.65,
         down 9.84, o_proj 5.58 -> 4.98 us, profiles/r4_gemm_lab.txt)."""
         self.strip = {}
-        if m > 32 or os.environ.get("APHRO_DECODE_NO_RESIDENT"):
+        if m > 64 or os.environ.get("APHRO_DECODE_NO_RESIDENT"):
             return
-        for name in ("qkv_proj", "o_proj", "down_proj"):
+        # gate_up_proj: the NON-interleaved [gate | up] matrix, for layers whose SiluAndMul does not ride in the GEMM epilogue
+        # (K-sliced gate_up of a TP shard: slabs -> silu_and_mul_pack(slabs=...))
+        for name in ("qkv_proj", "o_proj", "down_proj", "gate_up_proj"):
             lin = getattr(self, name, None)
             fp = lin.fast_params() if lin is not None else None
             if fp is None:
                 continue
             qw, qz, sc, zo = fp
             n, k, g = lin.out_features, lin.in_features, sc.shape[0]
-            # only where the resident plan keeps the round-2 kernel's K slices (the consumers were tuned to those slab counts)
-            if ops.wna16_resident_ksplit(m, n, k, g) == ops.wna16_ksplit(m, n, k, g) and (k // 8) * n * 4 >= 2 ** 23:
+            rks = ops.wna16_resident_ksplit(m, n, k, g)
+            if name == "gate_up_proj":
+                if self.tp > 1 and rks > 1:
+                    self.strip[name] = ops.wna16_strip_relayout(qw, m, g)
+                continue
+            # <= 32 rows: only where the resident plan keeps the round-2 kernel's K slices (the consumers were tuned to those
+            # slab counts); 33..64 rows (two 32-row halves): opt-in, see enable_fused_silu
+            if m > 32 and os.environ.get("APHRO_DECODE_ROW_HALVES") != "1":
+                continue
+            if rks > 0 and (m > 32 or rks == ops.wna16_ksplit(m, n, k, g)) and (k // 8) * n * 4 >= 2 ** 23:
                 self.strip[name] = ops.wna16_strip_relayout(qw, m, g)
 
     def _gemm_slabs(self, name, packed, m, k):
         """fp32 split-K slabs of projection ``name`` on packed activations: the resident kernel on its strip-major copy at
         <= 32 rows, else the round-2 kernel."""
         qw, qz, sc, zo = getattr(self, name).fast_params()
-        st = self.strip.get(name) if m <= 32 else None
+        st = self.strip.get(name) if m <= 64 else None
         if st is not None:
             return ops.wna16_gemm_resident(packed, m, k, st, qz, sc, zo, mode="slabs", strip_layout=True)
         return ops.wna16_gemm_packed(packed, m, k, qw, qz, sc, zo, partials=True)
@@ -409,10 +422,16 @@ class LlamaDecoderLayer(nn.Module):
         # 33..64 rows: the MLP weights go through the one-pass 32x32x16 MFMA kernel (wna16_gemm_mid.hip: 26.6 vs 37.6 us on
         # gate_up at 64 rows) -- same packed activations in, same packed activations / fp32 slabs out
         mid = 32 < m <= 64 and not os.environ.get("APHRO_DECODE_NO_MID")
+        # 33..64 rows: the one-pass 32x32x16 MFMA kernel; APHRO_DECODE_ROW_HALVES=1: the stream kernel on two 32-row halves
+        # where the layer has the strip-major copies (measured slower on the one-GPU shapes, see enable_fused_silu)
+        halves = 32 < m <= 64 and os.environ.get("APHRO_DECODE_ROW_HALVES") == "1"
         if self.gate_up_interleaved is not None:
             # SiluAndMul + pack run in the GEMM epilogue (interleaved gate/up columns)
             qw, qz, sc, zo = self.gate_up_interleaved
-            if mid and ops.wna16_gemm_mid_ksplit(m, qw.shape[1], h, sc.shape[0]) == 1 and qw.shape[1] % 256 == 0:
+            if halves and self.gate_up_strip is not None and ops.wna16_resident_ksplit(m, qw.shape[1], h, sc.shape[0]) == 1:
+                act_packed = ops.wna16_gemm_resident(packed2, m, h, self.gate_up_strip, qz, sc, zo, mode="silu",
+                                                     strip_layout=True)
+            elif mid and ops.wna16_gemm_mid_ksplit(m, qw.shape[1], h, sc.shape[0]) == 1 and qw.shape[1] % 256 == 0:
                 act_packed = ops.wna16_gemm_mid_silu_pack(packed2, m, h, qw, qz, sc, zo)
             elif self.gate_up_strip is not None and m <= 32 and ops.wna16_resident_ksplit(m, qw.shape[1], h, sc.shape[0]) == 1:
                 act_packed = ops.wna16_gemm_resident(packed2, m, h, self.gate_up_strip, qz, sc, zo, mode="silu",
@@ -421,10 +440,12 @@ class LlamaDecoderLayer(nn.Module):
                 act_packed = ops.wna16_gemm_silu_pack(packed2, m, h, qw, qz, sc, zo)
         else:
             qw, qz, sc, zo = self.gate_up_proj.fast_params()
-            if ops.wna16_ksplit(m, qw.shape[1], h, sc.shape[0]) > 1 and not os.environ.get("APHRO_DECODE_NO_SILU_SLABS"):
+            if (ops.wna16_ksplit(m, qw.shape[1], h, sc.shape[0]) > 1 or "gate_up_proj" in self.strip) \
+                    and not os.environ.get("APHRO_DECODE_NO_SILU_SLABS"):
                 # K-sliced gate_up (TP shards: 8192 x 7168 at 64 rows): the slab reduce rides in the SiluAndMul + pack launch
-                # (GEMM + splitk_reduce + silu_and_mul_pack -> GEMM + one consumer, same bits)
-                gu_slabs, _ = ops.wna16_gemm_packed(packed2, m, h, qw, qz, sc, zo, partials=True)
+                # (GEMM + splitk_reduce + silu_and_mul_pack -> GEMM + one consumer, same bits); the GEMM is the stream kernel
+                # on a strip-major copy where the layer has one
+                gu_slabs, _ = self._gemm_slabs("gate_up_proj", packed2, m, h)
                 act_packed = ops.silu_and_mul_pack(None, slabs=gu_slabs, dtype=sc.dtype)
             else:
                 gate_up = ops.wna16_gemm_packed(packed2, m, h, qw, qz, sc, zo, partials=False)
@@ -434,7 +455,8 @@ class LlamaDecoderLayer(nn.Module):
             d = ops.wna16_gemm_packed(act_packed, m, self.down_proj.in_features, qw, qz, sc, zo, partials=False)
             return tensor_model_parallel_all_reduce(d, prefetch=next_weights), None
         kd = self.down_proj.in_features
-        if mid and qw.shape[1] * kd >= 2 ** 25 and ops.wna16_gemm_mid_ksplit(m, qw.shape[1], kd, sc.shape[0]) > 0:
+        if mid and not (halves and "down_proj" in self.strip) and qw.shape[1] * kd >= 2 ** 25 \
+                and ops.wna16_gemm_mid_ksplit(m, qw.shape[1], kd, sc.shape[0]) > 0:
             down_slabs, _ = ops.wna16_gemm_mid_packed(act_packed, m, kd, qw, qz, sc, zo, partials=True)
         else:
             down_slabs, _ = self._gemm_slabs("down_proj", act_packed, m, kd)

@@ -264,8 +264,12 @@ def roofline_section(model, loop, args):
                 (name == "down_proj" and n_out * lin0.in_features >= 2 ** 25
                  and ops.wna16_gemm_mid_ksplit(bs, n_out, lin0.in_features, groups) > 0))
 
-            resident = silu and not mid and layers[0].gate_up_strip is not None and bs <= 32 \
+            # 33..64 rows (round 4): the stream kernel on two 32-row halves where the layer has its strip-major copies
+            halves = 32 < bs <= 64 and os.environ.get("APHRO_DECODE_ROW_HALVES") == "1"
+            resident = silu and layers[0].gate_up_strip is not None and (bs <= 32 or halves) \
                 and ops.wna16_resident_ksplit(bs, n_out, lin0.in_features, groups) == 1
+            if resident or (halves and name in getattr(layers[0], "strip", {})):
+                mid = False
 
             # norm-in-consumer (round 4): the step's qkv / gate_up launch carries the norm in front of it -- time THAT launch
             # (4 fp32 slabs + residual in, residual out on top of the GEMM's bytes)
@@ -301,10 +305,11 @@ def roofline_section(model, loop, args):
                         ops.wna16_gemm_mid_packed(packed, bs, k, qw, qz, sc, zo, partials=True)
                     else:
                         layer._gemm_slabs(name, packed, bs, k)      # resident kernel on the strip-major copy where the layer has one
-            res_slabs = (not silu) and (not mid) and bs <= 32 and name in getattr(layers[0], "strip", {})
+            res_slabs = (not silu) and (not mid) and bs <= 64 and name in getattr(layers[0], "strip", {})
             stream = not os.environ.get("APHRO_WNA16_STREAM") == "0"     # (the four configs[1] plans dispatch to the stream kernel)
             kname = ("wna16_gemm_mid_kernel" if mid else
-                     ("wna16_gemm_stream_kernel" if stream and (bs, model.cfg.hidden_size) == (bs, 4096) and bs <= 32 and args.model == "llama3-8b"
+                     ("wna16_gemm_stream_kernel" + (" (two 32-row halves)" if bs > 32 else "")
+                      if stream and (bs > 32 or ((bs, model.cfg.hidden_size) == (bs, 4096) and args.model == "llama3-8b"))
                       else "wna16_gemm_resident_kernel") + " (strip-major weights)" if (resident or res_slabs)
                      else "wna16_gemm_kernel") + (" (+SiluAndMul epilogue)" if silu else "") + \
                 (" (+ slab reduce + fused_add_rms_norm + pack in the first M workgroups)" if norm_fused else "")

@@ -213,3 +213,91 @@ def test_rowmajor_awq_and_bf16_routes(ops):
     y = ops.awq_gemm(t(a), t(qw), t(scales), t(qz), 8)
     np.testing.assert_allclose(y.float().cpu().numpy(), ref, rtol=2e-3, atol=2e-3 * np.abs(ref).max())
     assert not ops.wna16_gemm_rowmajor_supported(M, N, K, G, torch.bfloat16)
+
+
+# ---- 33..64 rows: the stream kernel on two 32-row halves (round 4; gridDim.z = 2, two workgroups per CU) -----------------
+@pytest.mark.parametrize("M", [33, 48, 64])
+@pytest.mark.parametrize("K,N", SHAPES + [(8192, 7168)])          # + the gate_up of one rank of Llama-3-70B at TP 8 (configs[3])
+def test_row_halves_slabs_vs_oracle_and_vs_the_32_row_launches(ops, K, N, M):
+    """M in 33..64 on strip-major weights: against the fp64 oracle (same bars as the 32-row test above), and bit for bit the
+    32-row launch on rows 0..31 and the (M - 32)-row launch on the rest -- the halves ARE that kernel."""
+    rng = np.random.default_rng(K + N + M)
+    shuf, qzeros, scales, _, _ = case(K, N) if (K, N) in SHAPES else _case_shard(K, N)
+    a = rng.standard_normal((M, K)).astype(np.float16)
+    G = K // 128
+    ks = ops.wna16_resident_ksplit(M, N, K, G)
+    assert ks >= 1 and ks == ops.wna16_resident_ksplit(32, N, K, G)
+    strip = ops.wna16_strip_relayout(t(shuf), M, G)
+    assert torch.equal(strip, ops.wna16_strip_relayout(t(shuf), 32, G))         # one strip-major copy serves 1..64 rows
+    pk = ops.wna16_pack_a(t(a))
+    slabs, ks2 = ops.wna16_gemm_resident(pk, M, K, strip, t(qzeros), t(scales), 1, mode="slabs", strip_layout=True)
+    assert ks2 == ks and slabs.shape == (ks, M, N)
+    ref = oq.gptq_gemm(a, shuf, qzeros, scales, None, True)
+    np.testing.assert_allclose(slabs.double().sum(0).cpu().numpy(), ref, rtol=1e-4, atol=2e-5 * np.abs(ref).max())
+    lo, _ = ops.wna16_gemm_resident(ops.wna16_pack_a(t(a[:32])), 32, K, strip, t(qzeros), t(scales), 1, mode="slabs", strip_layout=True)
+    hi, _ = ops.wna16_gemm_resident(ops.wna16_pack_a(t(a[32:])), M - 32, K, strip, t(qzeros), t(scales), 1, mode="slabs", strip_layout=True)
+    assert torch.equal(slabs[:, :32], lo) and torch.equal(slabs[:, 32:], hi)
+
+
+_SHARD_CASES = {}
+
+
+def _case_shard(K, N):
+    if (K, N) not in _SHARD_CASES:
+        rng = np.random.default_rng(K * 7 + N)
+        G = K // 128
+        qweight = rng.integers(0, 2 ** 32, size=(K // 8, N), dtype=np.uint32).view(np.int32)
+        qzeros = rng.integers(0, 2 ** 32, size=(G, N // 8), dtype=np.uint32).view(np.int32)
+        scales = (rng.uniform(0.75, 1.25, size=(G, N)) / (4.6 * np.sqrt(K))).astype(np.float16)
+        _SHARD_CASES[(K, N)] = (oq.gptq_shuffle(qweight), qzeros, scales, None, None)
+    return _SHARD_CASES[(K, N)]
+
+
+@pytest.mark.parametrize("M", [33, 64])
+def test_row_halves_gate_up_silu_epilogue(ops, M):
+    """gate_up + SiluAndMul + pack at 33..64 rows: the 32-row launches' packed rows bit for bit, the oracle at its bar."""
+    K, N = 4096, 28672
+    rng = np.random.default_rng(90 + M)
+    shuf, qzeros, scales, _, _ = case(K, N)
+    a = rng.standard_normal((M, K)).astype(np.float16)
+    qw_i, qz_i, sc_i = ops.interleave_gate_up(t(shuf), t(qzeros), t(scales))
+    strip = ops.wna16_strip_relayout(qw_i, M, K // 128)
+    act = ops.wna16_gemm_resident(ops.wna16_pack_a(t(a)), M, K, strip, qz_i, sc_i, 1, mode="silu", strip_layout=True)
+    got = unpack_a(act, M, N // 2)
+    lo = unpack_a(ops.wna16_gemm_resident(ops.wna16_pack_a(t(a[:32])), 32, K, strip, qz_i, sc_i, 1, mode="silu", strip_layout=True), 32, N // 2)
+    hi = unpack_a(ops.wna16_gemm_resident(ops.wna16_pack_a(t(a[32:])), M - 32, K, strip, qz_i, sc_i, 1, mode="silu", strip_layout=True),
+                  M - 32, N // 2)
+    assert np.array_equal(got[:32], lo) and np.array_equal(got[32:], hi)
+    ref = oq.gptq_gemm(a, shuf, qzeros, scales, None, True)
+    want = oa.silu_and_mul(ref)
+    np.testing.assert_allclose(got.view(np.float16).astype(np.float64), want, rtol=6e-3, atol=6e-3 * np.abs(want).max())
+
+
+def test_row_halves_decode_step_vs_the_mid_kernels(ops):
+    """The fused decode step at batch 64 (3 layers of Llama-3-8B geometry): row halves on == off (the 33..64-row kernels) to the
+    GEMMs' own rounding -- different K partitions, same arithmetic -- and the same greedy tokens."""
+    from aphrodite_engine_amd import model as Mo
+    from aphrodite_engine_amd.quantization.gptq import GPTQConfig
+    cfg = Mo.LlamaConfig(hidden_size=4096, intermediate_size=14336, num_hidden_layers=3, num_attention_heads=32,
+                         num_key_value_heads=8, vocab_size=1024, max_position_embeddings=2048)
+    m = Mo.LlamaForCausalLM(cfg, GPTQConfig(4, 128, False), torch.float16, "auto").init_synthetic(DEV, seed=2)
+    bs, ctx = 64, 90
+    os.environ["APHRO_DECODE_ROW_HALVES"] = "1"          # (opt-in: the strip-major copies for 33..64 rows)
+    try:
+        for layer in m.layers:
+            assert layer.enable_fused_silu(bs)
+            assert layer.gate_up_strip is not None and {"qkv_proj", "o_proj", "down_proj"} <= set(layer.strip)
+    finally:
+        os.environ.pop("APHRO_DECODE_ROW_HALVES", None)
+    meta, pos, nblocks = Mo.make_decode_metadata(bs, ctx, 16, DEV)
+    kv0 = Mo.make_kv_caches(cfg, nblocks, 16, torch.float16, "auto", DEV)
+    ids = torch.arange(bs, device=DEV) % cfg.vocab_size
+    outs = []
+    for on in ("1", "0"):
+        os.environ["APHRO_DECODE_ROW_HALVES"] = on
+        try:
+            with torch.no_grad():
+                outs.append(m(ids, pos, [c.clone() for c in kv0], meta).float())
+        finally:
+            os.environ.pop("APHRO_DECODE_ROW_HALVES", None)
+    torch.testing.assert_close(outs[0], outs[1], rtol=2e-2, atol=2e-2 * float(outs[1].abs().max()))
