@@ -70,6 +70,33 @@ def test_norm_in_consumer_plan_is_host_logic():
     assert not ok(32, 28672, 8192, 64, 4, _lib.F16) and not ok(32, 28672, 4096, 0, 4, _lib.F16)
 
 
+def test_new_entry_points_refuse_bad_arguments_before_touching_a_device():
+    """Argument checks run on the host, before any device call: error code + message, nothing launched (no GPU here)."""
+    import ctypes
+    from aphrodite_engine_amd import _lib
+    L = _lib.lib()
+    L.aphro_last_error.restype = ctypes.c_char_p
+    # norm-in-consumer: a shape it does not serve (qkv), then null arguments on a served shape
+    rc = L.aphro_wna16_gemm_norm_fused(None, 4, None, None, 1e-5, None, None, None, None, None, 0, None, 32, 6144, 4096, 32, 1,
+                                       _lib.F16, None, None)
+    assert rc != 0 and b"not served" in L.aphro_last_error()
+    rc = L.aphro_wna16_gemm_norm_fused(None, 4, None, None, 1e-5, None, None, None, None, None, 0, None, 32, 28672, 4096, 32, 1,
+                                       _lib.F16, None, None)
+    assert rc != 0 and b"null argument" in L.aphro_last_error()
+    # SiluAndMul on slabs: missing slabs, unsupported width, unsupported dtype
+    assert L.aphro_silu_and_mul_pack_slabs(None, 2, None, None, 4, 1024, _lib.F16, None) != 0
+    assert b"slabs" in L.aphro_last_error()
+    assert L.aphro_silu_and_mul_pack_slabs(ctypes.c_void_p(256), 2, ctypes.c_void_p(256), None, 4, 1000, _lib.F16, None) != 0
+    assert L.aphro_silu_and_mul_pack_slabs(ctypes.c_void_p(256), 2, None, None, 4, 1024, _lib.F32, None) != 0
+    # 33..64 rows: the plan query answers without a device, > 64 rows is refused, the row-major one-launch op stays <= 32
+    assert L.aphro_wna16_resident_ksplit(64, 28672, 4096, 32) == 1 and L.aphro_wna16_resident_ksplit(33, 7168, 8192, 64) == 4
+    assert L.aphro_wna16_resident_ksplit(65, 28672, 4096, 32) == 0
+    assert L.aphro_wna16_gemm_rowmajor_supported(32, 28672, 4096, 32, _lib.F16) == 1
+    assert L.aphro_wna16_gemm_rowmajor_supported(33, 28672, 4096, 32, _lib.F16) == 0
+    # zero tokens: nothing to do, no device call
+    assert L.aphro_silu_and_mul_pack_slabs(ctypes.c_void_p(256), 2, ctypes.c_void_p(256), None, 0, 1024, _lib.F16, None) == 0
+
+
 def test_no_cpu_fallback():
     from aphrodite_engine_amd import _custom_ops as ops
     with pytest.raises(RuntimeError, match="no CPU fallback"):
