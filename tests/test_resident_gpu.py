@@ -301,3 +301,36 @@ def test_row_halves_decode_step_vs_the_mid_kernels(ops):
         finally:
             os.environ.pop("APHRO_DECODE_ROW_HALVES", None)
     torch.testing.assert_close(outs[0], outs[1], rtol=2e-2, atol=2e-2 * float(outs[1].abs().max()))
+
+
+def test_tp8_shard_layer_of_config3_takes_the_row_halves_and_slab_silu_path(ops):
+    """ONE rank of Llama-3-70B at TP 8 (BASELINE configs[3]: AWQ shapes, batch 64), simulated on this GPU (all-reduces are
+    identity: the rank's partial sums flow on): the fused decode layer -- K-sliced gate_up on the strip-major copy, two
+    32-row halves, slabs into silu_and_mul_pack -- against the op-by-op path of the same rank at the tp2 test's bar."""
+    import dataclasses
+    from aphrodite_engine_amd import distributed as D
+    from aphrodite_engine_amd import model as Mo
+    from aphrodite_engine_amd.quantization.gptq import GPTQConfig
+    D.init_simulated_tensor_parallel(8, 1.0)
+    try:
+        cfg = dataclasses.replace(Mo.LLAMA3_70B, num_hidden_layers=1, vocab_size=1024, max_position_embeddings=2048)
+        with torch.no_grad():
+            m = Mo.LlamaForCausalLM(cfg, GPTQConfig(4, 128, False), torch.float16, "auto").init_synthetic(DEV, seed=4)
+            bs, ctx = 64, 70
+            layer = m.layers[0]
+            assert layer.tp == 8 and not layer.enable_fused_silu(bs)          # K-sliced gate_up: no SiluAndMul epilogue ...
+            assert "gate_up_proj" in layer.strip                               # ... but a strip-major copy for the stream kernel
+            assert ops.wna16_resident_ksplit(bs, layer.gate_up_proj.out_features, cfg.hidden_size, cfg.hidden_size // 128) == 4
+            meta, pos, nblocks = Mo.make_decode_metadata(bs, ctx, 16, DEV)
+            ids = torch.arange(bs, device=DEV) % cfg.vocab_size
+            outs = []
+            for fused in (False, True):
+                kv = Mo.make_kv_caches(cfg, nblocks, 16, torch.float16, "auto", DEV, seed=3)
+                m.use_fused_decode = fused
+                if fused:
+                    assert layer.fused_decode_ok(bs)
+                outs.append(m(ids, pos, kv, meta).float())
+        assert torch.isfinite(outs[1]).all()
+        torch.testing.assert_close(outs[0], outs[1], atol=2e-2, rtol=2e-2)
+    finally:
+        D.destroy_tensor_parallel()
