@@ -781,6 +781,21 @@ def interleave_gate_up(qweight: torch.Tensor, qzeros: torch.Tensor, scales: torc
     half = n // 2
     idx = torch.arange(n, device=qweight.device)
     src = torch.where(idx % 2 == 0, idx // 2, half + idx // 2)
+    return _permute_columns(qweight, qzeros, scales, src)
+
+
+def deinterleave_gate_up(qweight: torch.Tensor, qzeros: torch.Tensor, scales: torch.Tensor):
+    """The inverse of interleave_gate_up: [gate | up] column order back from (gate_j, up_j) pairs."""
+    n = qweight.shape[1]
+    half = n // 2
+    idx = torch.arange(n, device=qweight.device)
+    src = torch.where(idx < half, 2 * idx, 2 * (idx - half) + 1)
+    return _permute_columns(qweight, qzeros, scales, src)
+
+
+def _permute_columns(qweight: torch.Tensor, qzeros: torch.Tensor, scales: torch.Tensor, src: torch.Tensor):
+    """Column j of the result = column src[j] of a K-packed int4 tensor set (zero points: 8 nibbles per word along N)."""
+    n = qweight.shape[1]
     qw = qweight[:, src].contiguous()
     sc = scales[:, src].contiguous()
     shifts = torch.arange(0, 32, 4, device=qzeros.device, dtype=torch.int32)

@@ -239,6 +239,21 @@ class LlamaDecoderLayer(nn.Module):
             lin.qweight.data, lin.qzeros.data, lin.scales.data = qw, qz, sc
         return True
 
+    def restore_op_level_layouts(self) -> None:
+        """Undo enable_fused_silu / enable_resident_layouts: the parameters and the op-level strip-major copy as the quant
+        method's process_weights_after_loading leaves them (what the reference's own LlamaDecoderLayer runs on through the
+        plugin).  bench.py measures its op-by-op leg on this state."""
+        self.strip = {}
+        self.gate_up_strip = None
+        if self.gate_up_interleaved is not None:
+            lin = self.gate_up_proj
+            if not getattr(self, "gate_up_keep_original", True):
+                qw, qz, sc = ops.deinterleave_gate_up(*self.gate_up_interleaved[:3])
+                lin.qweight.data, lin.qzeros.data, lin.scales.data = qw, qz, sc
+            self.gate_up_interleaved = None
+            if hasattr(lin, "qweight_strip") and lin.fast_params() is not None:
+                lin.qweight_strip = ops.wna16_decode_strip_copy(lin.qweight.data, lin.scales.data)
+
     def enable_fp8_strips(self, m: int = 32) -> None:
         """Strip-major copies of the FP8 projections for the resident W8A8 decode GEMM at <= 32 rows
         (csrc/fp8_gemm_resident.hip: one workgroup per CU, a wave's weights as one stream of lane-linear 1 KiB pieces).

@@ -734,6 +734,10 @@ def main():
         # (17 per layer instead of 7), row-major activations between them.  Captured and timed exactly like the headline.
         elapsed_ops = None
         if ops_path:
+            # (on the layouts the loader leaves behind -- no interleaved gate_up to undo per step, the op-level strip-major
+            #  copy of the big matrices in place; the fused layouts are rebuilt afterwards for the per-kernel section)
+            for layer in model.layers:
+                layer.restore_op_level_layouts()
             model.use_fused_decode = False
             for _ in range(2):
                 loop.step()
@@ -753,6 +757,9 @@ def main():
             torch.cuda.synchronize()
             elapsed_ops = time.perf_counter() - t1
             model.use_fused_decode = True
+            if not os.environ.get("APHRO_NO_FUSED_SILU"):
+                for layer in model.layers:
+                    layer.enable_fused_silu(args.batch, keep_original=False)
         active_frac = 1.0
         if cfg.num_local_experts:
             # experts the decode step really routes to (one more eager step with the routing recorded)

@@ -97,6 +97,25 @@ def test_new_entry_points_refuse_bad_arguments_before_touching_a_device():
     assert L.aphro_silu_and_mul_pack_slabs(ctypes.c_void_p(256), 2, ctypes.c_void_p(256), None, 0, 1024, _lib.F16, None) == 0
 
 
+def test_gate_up_interleave_round_trip():
+    """interleave_gate_up (load-time column permutation for the SiluAndMul epilogue) and its inverse are pure tensor ops:
+    column 2j = gate_j, 2j + 1 = up_j; zero-point nibbles follow their columns; the inverse restores every bit."""
+    import torch
+    from aphrodite_engine_amd import _custom_ops as ops
+    g = torch.Generator().manual_seed(0)
+    K, N, G = 256, 64, 2
+    qw = torch.randint(-2 ** 31, 2 ** 31 - 1, (K // 8, N), generator=g, dtype=torch.int64).to(torch.int32)
+    qz = torch.randint(-2 ** 31, 2 ** 31 - 1, (G, N // 8), generator=g, dtype=torch.int64).to(torch.int32)
+    sc = torch.rand(G, N, generator=g).half()
+    qi, zi, si = ops.interleave_gate_up(qw, qz, sc)
+    assert torch.equal(qi[:, 0::2], qw[:, :N // 2]) and torch.equal(qi[:, 1::2], qw[:, N // 2:])
+    assert torch.equal(si[:, 0::2], sc[:, :N // 2]) and torch.equal(si[:, 1::2], sc[:, N // 2:])
+    nib = lambda z: ((z.unsqueeze(-1) >> torch.arange(0, 32, 4, dtype=torch.int32)) & 0xF).reshape(G, N)
+    assert torch.equal(nib(zi)[:, 0::2], nib(qz)[:, :N // 2]) and torch.equal(nib(zi)[:, 1::2], nib(qz)[:, N // 2:])
+    qb, zb, sb = ops.deinterleave_gate_up(qi, zi, si)
+    assert torch.equal(qb, qw) and torch.equal(zb, qz) and torch.equal(sb, sc)
+
+
 def test_no_cpu_fallback():
     from aphrodite_engine_amd import _custom_ops as ops
     with pytest.raises(RuntimeError, match="no CPU fallback"):
