@@ -1343,8 +1343,11 @@ __global__ __launch_bounds__(NWV * 64, 1) void wna16_gemm_stream_kernel(Wna16Res
     }
     if (threadIdx.x == 0) {
       int spins = 0;
-      while (__hip_atomic_load(p.n_sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)p.M && ++spins < (1 << 16))
+      while ((__hip_atomic_load(p.n_sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0x7fffffffu) < (unsigned)p.M && ++spins < (1 << 16))
         __builtin_amdgcn_s_sleep(2);
+      // bounded: a producer that never arrives (a ticket word that was not zero at launch, a device with fewer CUs than
+      // workgroups AND out-of-order dispatch) must not hang the GPU -- the launch finishes on garbage and says so: bit 31
+      if (spins >= (1 << 16)) __hip_atomic_fetch_or(p.n_sync, 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_barrier();

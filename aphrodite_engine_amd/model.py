@@ -237,6 +237,7 @@ class LlamaDecoderLayer(nn.Module):
             lin.qweight_strip = None
         if not keep_original:
             lin.qweight.data, lin.qzeros.data, lin.scales.data = qw, qz, sc
+        self.strip.pop("gate_up_proj", None)      # (the [gate | up] copy serves layers WITHOUT the SiluAndMul epilogue only)
         return True
 
     def restore_op_level_layouts(self) -> None:

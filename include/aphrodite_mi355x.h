@@ -614,7 +614,9 @@ int aphro_wna16_gemm_resident(const void* a_packed, const uint32_t* q_weight, co
  * a_packed (scratch, aphro_wna16_packed_a_bytes(M, K)) -- bit for bit aphro_fused_add_rms_norm_pack -- from the first M
  * workgroups while every workgroup's first weights are in flight; then aphro_wna16_gemm_resident on strip-major q_weight
  * (exactly one of act_packed / slabs).  sync: one 32-bit word of device memory that is ZERO at launch; the launch leaves M
- * in it and the caller zeroes it before its next use (stream-ordered).  K == 4096, M <= 32: _supported() answers. */
+ * in it (bit 31 set: a workgroup gave up waiting for the rows -- the outputs are garbage; cannot happen with a zeroed word
+ * on a device that runs the grid's 256 workgroups at once) and the caller zeroes it before its next use (stream-ordered).
+ * K == 4096, M <= 32, the gate_up plan of Llama-3-8B: _supported() answers. */
 int aphro_wna16_gemm_norm_fused_supported(int64_t M, int64_t N, int64_t K, int64_t groups, int nslab, int dtype);
 int aphro_wna16_gemm_norm_fused(const float* in_slabs, int nslab, void* residual, const void* norm_weight, float eps,
                                 void* a_packed, const uint32_t* q_weight, const uint32_t* qzeros, const void* scales,
