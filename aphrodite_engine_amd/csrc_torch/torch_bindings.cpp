@@ -161,7 +161,199 @@ void cutlass_scaled_mm(torch::Tensor out, torch::Tensor a, torch::Tensor b, torc
   }
 }
 
+// ---- round 4: the memory-bound ops and the remaining cache / quantisation ops (one C-ABI call each) --------------------------
+int64_t rows_of(const torch::Tensor& t) { return t.numel() / t.size(-1); }
+
+// rms_norm (layernorm_kernels.cu:17-45, 160-198)
+void rms_norm(torch::Tensor out, torch::Tensor input, torch::Tensor weight, double epsilon) {
+  const int64_t hidden = input.size(-1);
+  auto x = input.reshape({-1, hidden});
+  TORCH_CHECK(out.is_contiguous() && x.stride(1) == 1, "rms_norm: contiguous rows expected");
+  ok(aphro_rms_norm(out.data_ptr(), x.data_ptr(), weight.data_ptr(), (float)epsilon, x.size(0), (int)hidden, x.stride(0),
+                    act_dtype(input), cur_stream()),
+     "rms_norm");
+}
+
+// fused_add_rms_norm (layernorm_kernels.cu:200-240)
+void fused_add_rms_norm(torch::Tensor input, torch::Tensor residual, torch::Tensor weight, double epsilon) {
+  TORCH_CHECK(input.is_contiguous() && residual.is_contiguous(), "fused_add_rms_norm: contiguous input / residual expected");
+  ok(aphro_fused_add_rms_norm(input.data_ptr(), residual.data_ptr(), weight.data_ptr(), (float)epsilon, rows_of(input),
+                              (int)input.size(-1), act_dtype(input), cur_stream()),
+     "fused_add_rms_norm");
+}
+
+// silu_and_mul (activation_kernels.cu:55-75)
+void silu_and_mul(torch::Tensor out, torch::Tensor input) {
+  TORCH_CHECK(input.is_contiguous() && out.is_contiguous() && input.size(-1) % 2 == 0, "silu_and_mul: contiguous [.., 2 d] expected");
+  const int64_t d = input.size(-1) / 2;
+  ok(aphro_silu_and_mul(out.data_ptr(), input.data_ptr(), input.numel() / (2 * d), (int)d, act_dtype(input), cur_stream()),
+     "silu_and_mul");
+}
+
+// rotary_embedding (pos_encoding_kernels.cu:120-160), in place on query / key
+void rotary_embedding(torch::Tensor positions, torch::Tensor query, torch::Tensor key, int64_t head_size,
+                      torch::Tensor cos_sin_cache, bool is_neox) {
+  const int64_t num_tokens = positions.numel();
+  auto q2 = query.dim() == 2 ? query : query.view({num_tokens, -1});
+  auto k2 = key.dim() == 2 ? key : key.view({num_tokens, -1});
+  auto pos = positions.scalar_type() == torch::kLong ? positions : positions.to(torch::kLong);
+  ok(aphro_rotary_embedding(pos.data_ptr<int64_t>(), q2.data_ptr(), k2.data_ptr(), num_tokens, (int)(q2.size(1) / head_size),
+                            (int)(k2.size(1) / head_size), (int)head_size, (int)cos_sin_cache.size(1), cos_sin_cache.data_ptr(),
+                            q2.stride(0), k2.stride(0), is_neox ? 1 : 0, act_dtype(query), cur_stream()),
+     "rotary_embedding");
+}
+
+// paged_attention_v2 (attention_kernels.cu:833-998): scratch sized for 512-token partitions (paged_attn.py:13, 118-119)
+void paged_attention_v2(torch::Tensor out, torch::Tensor exp_sums, torch::Tensor max_logits, torch::Tensor tmp_out,
+                        torch::Tensor query, torch::Tensor key_cache, torch::Tensor value_cache, int64_t num_kv_heads, double scale,
+                        torch::Tensor block_tables, torch::Tensor seq_lens, int64_t block_size, int64_t max_seq_len,
+                        const c10::optional<torch::Tensor>& alibi_slopes, std::string kv_cache_dtype, double k_scale,
+                        double v_scale, int64_t tp_rank, int64_t blocksparse_local_blocks, int64_t blocksparse_vert_stride,
+                        int64_t blocksparse_block_size, int64_t blocksparse_head_sliding_step) {
+  TORCH_CHECK(blocksparse_vert_stride <= 1, "blocksparse attention is not implemented on MI355X");
+  const int64_t part = 512, need = (max_seq_len + part - 1) / part;
+  TORCH_CHECK(tmp_out.is_contiguous() && tmp_out.size(2) >= need, "tmp_out has ", tmp_out.size(2), " partitions, need ", need,
+              " for max_seq_len=", max_seq_len);
+  const int64_t num_seqs = query.size(0), num_heads = query.size(1), head_size = query.size(2);
+  ok(aphro_paged_attention(out.data_ptr(), exp_sums.data_ptr<float>(), max_logits.data_ptr<float>(), tmp_out.data_ptr(),
+                           query.data_ptr(), key_cache.data_ptr(), value_cache.data_ptr(), (int)num_seqs, (int)num_heads,
+                           (int)num_kv_heads, (int)head_size, (float)scale, block_tables.data_ptr<int>(), seq_lens.data_ptr<int>(),
+                           (int)block_tables.size(1), (int)block_size, (int)max_seq_len,
+                           alibi_slopes ? alibi_slopes->data_ptr<float>() : nullptr, query.stride(0), key_cache.stride(0),
+                           key_cache.stride(1), act_dtype(query), kv_dtype(kv_cache_dtype), (float)k_scale, (float)v_scale, (int)part,
+                           cur_stream()),
+     "paged_attention_v2");
+}
+
+// gptq_shuffle (q_gemm.cu:1862-1872): 4-bit in C++; the 2 / 3 / 8-bit widths keep their sequential layout (Python op)
+void gptq_shuffle(torch::Tensor q_weight, torch::Tensor q_perm, int64_t bit) {
+  TORCH_CHECK(bit == 4, "gptq_shuffle (C++ registration): 4-bit weights; 2 / 3 / 8-bit go through the Python op");
+  const bool act_order = q_perm.numel() > 0 && q_perm.device().is_cuda();
+  torch::Tensor perm = act_order ? q_perm.to(torch::kInt) : q_perm;
+  torch::Tensor tmp = act_order ? torch::empty_like(q_weight) : torch::Tensor();
+  ok(aphro_gptq_shuffle((uint32_t*)q_weight.data_ptr(), act_order ? (const int32_t*)perm.data_ptr() : nullptr,
+                        q_weight.size(0) * 8, q_weight.size(1), 4, act_order ? (uint32_t*)tmp.data_ptr() : nullptr, cur_stream()),
+     "gptq_shuffle");
+}
+
+// awq_dequantize (awq/gemm_kernels.cu:694-781): [K, N] in the scales' dtype
+torch::Tensor awq_dequantize(torch::Tensor kernel, torch::Tensor scaling_factors, torch::Tensor zeros, int64_t split_k_iters,
+                             int64_t thx, int64_t thy) {
+  const int64_t k = kernel.size(0), n = kernel.size(1) * 8;
+  auto out = torch::empty({k, n}, scaling_factors.options());
+  ok(aphro_awq_dequantize((const uint32_t*)kernel.data_ptr(), scaling_factors.data_ptr(), (const uint32_t*)zeros.data_ptr(),
+                          out.data_ptr(), k, n, scaling_factors.size(0), act_dtype(scaling_factors), cur_stream()),
+     "awq_dequantize");
+  return out;
+}
+
+int quant_in_dtype(const torch::Tensor& t) {
+  if (t.scalar_type() == torch::kFloat) return APHRO_F32;
+  return act_dtype(t);
+}
+
+// static_scaled_fp8_quant (fp8/common.cu:187-199)
+void static_scaled_fp8_quant(torch::Tensor out, torch::Tensor input, torch::Tensor scale) {
+  TORCH_CHECK(input.is_contiguous() && out.is_contiguous() && scale.numel() == 1 && scale.scalar_type() == torch::kFloat,
+              "static_scaled_fp8_quant: contiguous tensors and one fp32 scale expected");
+  ok(aphro_static_scaled_fp8_quant(out.data_ptr(), input.data_ptr(), scale.data_ptr<float>(), rows_of(input), input.size(-1),
+                                   quant_in_dtype(input), cur_stream()),
+     "static_scaled_fp8_quant");
+}
+
+// dynamic_per_token_scaled_fp8_quant (fp8/common.cu:201-256)
+void dynamic_per_token_scaled_fp8_quant(torch::Tensor out, torch::Tensor input, torch::Tensor scale,
+                                        const c10::optional<torch::Tensor>& scale_ub) {
+  TORCH_CHECK(input.is_contiguous() && out.is_contiguous() && scale.scalar_type() == torch::kFloat && scale.numel() >= rows_of(input),
+              "dynamic_per_token_scaled_fp8_quant: contiguous tensors and one fp32 scale per token expected");
+  ok(aphro_dynamic_per_token_scaled_fp8_quant(out.data_ptr(), input.data_ptr(), scale.data_ptr<float>(),
+                                              scale_ub ? scale_ub->data_ptr<float>() : nullptr, rows_of(input), input.size(-1),
+                                              quant_in_dtype(input), cur_stream()),
+     "dynamic_per_token_scaled_fp8_quant");
+}
+
+// advance_step_flashattn (prepare_inputs/advance_step.cu)
+void advance_step_flashattn(int64_t num_seqs, int64_t num_queries, int64_t block_size, torch::Tensor input_tokens,
+                            torch::Tensor sampled_token_ids, torch::Tensor input_positions, torch::Tensor seq_lens,
+                            torch::Tensor slot_mapping, torch::Tensor block_tables) {
+  TORCH_CHECK(input_tokens.scalar_type() == torch::kLong && sampled_token_ids.scalar_type() == torch::kLong &&
+              input_positions.scalar_type() == torch::kLong && seq_lens.scalar_type() == torch::kInt &&
+              slot_mapping.scalar_type() == torch::kLong && block_tables.scalar_type() == torch::kInt,
+              "advance_step_flashattn: int64 tokens / positions / slots, int32 seq_lens / block_tables expected");
+  TORCH_CHECK(input_tokens.is_contiguous() && sampled_token_ids.is_contiguous() && input_positions.is_contiguous() &&
+              seq_lens.is_contiguous() && slot_mapping.is_contiguous() && block_tables.stride(1) == 1,
+              "advance_step_flashattn: contiguous tensors expected");
+  ok(aphro_advance_step_flashattn((int)num_seqs, (int)num_queries, (int)block_size, input_tokens.data_ptr<int64_t>(),
+                                  sampled_token_ids.data_ptr<int64_t>(), input_positions.data_ptr<int64_t>(), seq_lens.data_ptr<int>(),
+                                  slot_mapping.data_ptr<int64_t>(), block_tables.data_ptr<int>(), block_tables.stride(0), cur_stream()),
+     "advance_step_flashattn");
+}
+
+// reshape_and_cache_flash (cache_kernels.cu:265-309): caches [NB, block, H, hd]
+void reshape_and_cache_flash(torch::Tensor key, torch::Tensor value, torch::Tensor key_cache, torch::Tensor value_cache,
+                             torch::Tensor slot_mapping, std::string kv_cache_dtype, double k_scale, double v_scale) {
+  TORCH_CHECK(slot_mapping.scalar_type() == torch::kLong, "slot_mapping must be int64");
+  TORCH_CHECK(key_cache.stride(0) == value_cache.stride(0), "key_cache and value_cache must have the same block stride");
+  TORCH_CHECK(key.stride(1) == key.size(2) && value.stride(1) == value.size(2), "key/value heads must be contiguous");
+  ok(aphro_reshape_and_cache_flash(key.data_ptr(), value.data_ptr(), key_cache.data_ptr(), value_cache.data_ptr(),
+                                   slot_mapping.data_ptr<int64_t>(), key.size(0), (int)key.size(1), (int)key.size(2),
+                                   (int)key_cache.size(1), key_cache.stride(0), key.stride(0), value.stride(0), act_dtype(key),
+                                   kv_dtype(kv_cache_dtype), (float)k_scale, (float)v_scale, cur_stream()),
+     "reshape_and_cache_flash");
+}
+
+// convert_fp8 (cache_kernels.cu:330-380)
+void convert_fp8(torch::Tensor dst_cache, torch::Tensor src_cache, double scale, std::string kv_cache_dtype) {
+  const int kvd = kv_dtype(kv_cache_dtype);
+  TORCH_CHECK(kvd != APHRO_KV_AUTO, "Unsupported data type of kv cache: ", kv_cache_dtype);
+  TORCH_CHECK(dst_cache.is_contiguous() && src_cache.is_contiguous(), "convert_fp8 needs contiguous tensors");
+  const bool to_fp8 = dst_cache.scalar_type() == torch::kByte;
+  const torch::Tensor& hp = to_fp8 ? src_cache : dst_cache;
+  ok(aphro_convert_fp8(dst_cache.data_ptr(), src_cache.data_ptr(), src_cache.numel(), (float)scale, quant_in_dtype(hp), kvd,
+                       to_fp8 ? 1 : 0, cur_stream()),
+     "convert_fp8");
+}
+
 }  // namespace
+
+TORCH_LIBRARY_FRAGMENT(APHRO_TORCH_NS, m) {
+  m.def("paged_attention_v2(Tensor! out, Tensor! exp_sums, Tensor! max_logits, Tensor! tmp_out, Tensor query, "
+        "Tensor key_cache, Tensor value_cache, int num_kv_heads, float scale, Tensor block_tables, Tensor seq_lens, "
+        "int block_size, int max_seq_len, Tensor? alibi_slopes, str kv_cache_dtype, float k_scale, float v_scale, "
+        "int tp_rank, int blocksparse_local_blocks, int blocksparse_vert_stride, int blocksparse_block_size, "
+        "int blocksparse_head_sliding_step) -> ()");                                                    // :38-49
+  m.impl("paged_attention_v2", torch::kCUDA, &paged_attention_v2);
+  m.def("gptq_shuffle(Tensor! q_weight, Tensor q_perm, int bit) -> ()");                                // :364-365
+  m.impl("gptq_shuffle", torch::kCUDA, &gptq_shuffle);
+  m.def("awq_dequantize(Tensor _kernel, Tensor _scaling_factors, Tensor _zeros, int split_k_iters, int thx, "
+        "int thy) -> Tensor");                                                                          // :148-151
+  m.impl("awq_dequantize", torch::kCUDA, &awq_dequantize);
+  m.def("rms_norm(Tensor! out, Tensor input, Tensor weight, float epsilon) -> ()");                     // :101-105
+  m.impl("rms_norm", torch::kCUDA, &rms_norm);
+  m.def("fused_add_rms_norm(Tensor! input, Tensor! residual, Tensor weight, float epsilon) -> ()");     // :108-111
+  m.impl("fused_add_rms_norm", torch::kCUDA, &fused_add_rms_norm);
+  m.def("silu_and_mul(Tensor! out, Tensor input) -> ()");                                               // :56-57
+  m.impl("silu_and_mul", torch::kCUDA, &silu_and_mul);
+  m.def("rotary_embedding(Tensor positions, Tensor! query, Tensor! key, int head_size, Tensor cos_sin_cache, "
+        "bool is_neox) -> ()");                                                                         // :117-121
+  m.impl("rotary_embedding", torch::kCUDA, &rotary_embedding);
+  m.def("static_scaled_fp8_quant(Tensor! out, Tensor input, Tensor scale) -> ()");                      // :374-376
+  m.impl("static_scaled_fp8_quant", torch::kCUDA, &static_scaled_fp8_quant);
+  m.def("dynamic_per_token_scaled_fp8_quant(Tensor! out, Tensor input, Tensor! scale, Tensor? scale_ub) -> ()");   // :385-390
+  m.impl("dynamic_per_token_scaled_fp8_quant", torch::kCUDA, &dynamic_per_token_scaled_fp8_quant);
+  m.def("advance_step_flashattn(int num_seqs, int num_queries, int block_size, Tensor! input_tokens, "
+        "Tensor sampled_token_ids, Tensor! input_positions, Tensor! seq_lens, Tensor! slot_mapping, "
+        "Tensor block_tables) -> ()");                                                                  // :77-82
+  m.impl("advance_step_flashattn", torch::kCUDA, &advance_step_flashattn);
+}
+
+TORCH_LIBRARY_FRAGMENT(APHRO_CONCAT(APHRO_TORCH_NS, _cache_ops), m) {
+  m.def("convert_fp8(Tensor! dst_cache, Tensor src_cache, float scale, str kv_cache_dtype) -> ()");     // :487-490
+  m.impl("convert_fp8", torch::kCUDA, &convert_fp8);
+  m.def("reshape_and_cache_flash(Tensor key, Tensor value, Tensor! key_cache, Tensor! value_cache, "
+        "Tensor slot_mapping, str kv_cache_dtype, float k_scale, float v_scale) -> ()");                // :476-484
+  m.impl("reshape_and_cache_flash", torch::kCUDA, &reshape_and_cache_flash);
+}
 
 TORCH_LIBRARY_FRAGMENT(APHRO_TORCH_NS, m) {
   m.def("paged_attention_v1(Tensor! out, Tensor query, Tensor key_cache, Tensor value_cache, int num_kv_heads, float scale, "

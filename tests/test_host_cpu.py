@@ -310,11 +310,19 @@ def test_cpp_torch_library_registration():
     torch_ops.register("_aphro_t_C", "_aphro_t_cache", "_aphro_t_rocm", "_aphro_t_moe")         # idempotent (registered above)
     py_ns = [ns for ns in ("_aphro_t_C", "_aphro_g_C", "_C") if hasattr(torch.ops, ns) and hasattr(getattr(torch.ops, ns), "gptq_gemm")]
     strip = lambda sch: str(sch).split("::", 1)[1]
-    for name in ("gptq_gemm", "paged_attention_v1", "cutlass_scaled_mm"):
+    for name in ("gptq_gemm", "paged_attention_v1", "cutlass_scaled_mm",
+                 # round 4: the memory-bound ops, the partitioned attention, shuffles / dequant, FP8 quantisers, advance_step
+                 "paged_attention_v2", "gptq_shuffle", "awq_dequantize", "rms_norm", "fused_add_rms_norm", "silu_and_mul",
+                 "rotary_embedding", "static_scaled_fp8_quant", "dynamic_per_token_scaled_fp8_quant", "advance_step_flashattn"):
         cpp = getattr(torch.ops._C_mi355x, name).default._schema
         assert py_ns, "python registration missing"
         assert strip(cpp) == strip(getattr(getattr(torch.ops, py_ns[0]), name).default._schema), name
     assert "reshape_and_cache(Tensor key, Tensor value" in str(torch.ops._C_mi355x_cache_ops.reshape_and_cache.default._schema)
+    cache_ns = [ns for ns in ("_aphro_t_cache", "_aphro_g_cache", "_C_cache_ops") if hasattr(torch.ops, ns)
+                and hasattr(getattr(torch.ops, ns), "convert_fp8")]
+    for name in ("reshape_and_cache", "reshape_and_cache_flash", "convert_fp8"):
+        cpp = getattr(torch.ops._C_mi355x_cache_ops, name).default._schema
+        assert cache_ns and strip(cpp) == strip(getattr(getattr(torch.ops, cache_ns[0]), name).default._schema), name
     with pytest.raises((RuntimeError, NotImplementedError)):
         torch.ops._C_mi355x.gptq_gemm(torch.zeros(1, 64, dtype=torch.half), torch.zeros(8, 16, dtype=torch.int32),
                                       torch.zeros(1, 2, dtype=torch.int32), torch.zeros(1, 16, dtype=torch.half),

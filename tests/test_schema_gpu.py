@@ -287,6 +287,114 @@ def test_cpp_registered_ops_match_the_python_registration(T):
     assert torch.equal(got, want)
 
 
+def test_cpp_registered_memory_bound_and_cache_ops_match_the_python_registration(T):
+    """Round 4: twelve more ops registered from C++ (norms, SiluAndMul, rotary, partitioned attention, gptq_shuffle,
+    awq_dequantize, two FP8 quantisers, advance_step, reshape_and_cache_flash, convert_fp8) -- same C ABI underneath, so the
+    same bits as the Python-registered ops (which the oracle tests check)."""
+    from aphrodite_engine_amd import torch_cpp
+    torch_cpp.load()
+    C, cache = torch.ops._C_mi355x, torch.ops._C_mi355x_cache_ops
+    rng = np.random.default_rng(12)
+    for dtype in (torch.float16, torch.bfloat16):
+        x = t(rng.standard_normal((7, 1024)).astype(np.float32), dtype)
+        w = t((1 + 0.1 * rng.standard_normal(1024)).astype(np.float32), dtype)
+        a, b = torch.empty_like(x), torch.empty_like(x)
+        T.C.rms_norm(a, x, w, 1e-5)
+        C.rms_norm(b, x, w, 1e-5)
+        assert torch.equal(a, b)
+        r = t(rng.standard_normal((7, 1024)).astype(np.float32), dtype)
+        x1, r1, x2, r2 = x.clone(), r.clone(), x.clone(), r.clone()
+        T.C.fused_add_rms_norm(x1, r1, w, 1e-5)
+        C.fused_add_rms_norm(x2, r2, w, 1e-5)
+        assert torch.equal(x1, x2) and torch.equal(r1, r2)
+        g = t(rng.standard_normal((7, 2048)).astype(np.float32), dtype)
+        a, b = torch.empty(7, 1024, dtype=dtype, device=DEV), torch.empty(7, 1024, dtype=dtype, device=DEV)
+        T.C.silu_and_mul(a, g)
+        C.silu_and_mul(b, g)
+        assert torch.equal(a, b)
+        # rotary (neox and gptj), in place
+        from aphrodite_engine_amd.model import _rope_cache
+        cs = _rope_cache(128, 256, 10000.0, dtype, DEV)
+        pos = t(rng.integers(0, 256, size=7).astype(np.int64))
+        for neox in (True, False):
+            q = t(rng.standard_normal((7, 8 * 128)).astype(np.float32), dtype)
+            k = t(rng.standard_normal((7, 2 * 128)).astype(np.float32), dtype)
+            q2, k2 = q.clone(), k.clone()
+            T.C.rotary_embedding(pos, q, k, 128, cs, neox)
+            C.rotary_embedding(pos, q2, k2, 128, cs, neox)
+            assert torch.equal(q, q2) and torch.equal(k, k2)
+        # FP8 quantisers
+        xq = t(rng.standard_normal((9, 512)).astype(np.float32), dtype)
+        sc = t(np.array([0.07], np.float32))
+        a, b = (torch.empty(9, 512, dtype=torch.float8_e4m3fn, device=DEV) for _ in range(2))
+        T.C.static_scaled_fp8_quant(a, xq, sc)
+        C.static_scaled_fp8_quant(b, xq, sc)
+        assert torch.equal(a.view(torch.uint8), b.view(torch.uint8))
+        s1, s2 = (torch.empty(9, 1, dtype=torch.float32, device=DEV) for _ in range(2))
+        T.C.dynamic_per_token_scaled_fp8_quant(a, xq, s1, None)
+        C.dynamic_per_token_scaled_fp8_quant(b, xq, s2, None)
+        assert torch.equal(a.view(torch.uint8), b.view(torch.uint8)) and torch.equal(s1, s2)
+    # gptq_shuffle (with and without act-order) and awq_dequantize
+    K, N, G = 1024, 256, 128
+    qw, qz, s_ = make_gptq(rng, K, N, G)
+    perm = t(rng.permutation(K).astype(np.int32))
+    empty = torch.empty(0, dtype=torch.int32, device=DEV)
+    for p_ in (empty, perm):
+        a, b = t(qw.copy()), t(qw.copy())
+        T.C.gptq_shuffle(a, p_, 4)
+        C.gptq_shuffle(b, p_, 4)
+        assert torch.equal(a, b)
+    aw = t(rng.integers(-2 ** 31, 2 ** 31 - 1, size=(K, N // 8), dtype=np.int64).astype(np.int32))
+    az = t(rng.integers(-2 ** 31, 2 ** 31 - 1, size=(K // G, N // 8), dtype=np.int64).astype(np.int32))
+    asc = t((rng.random((K // G, N)) * 0.01).astype(np.float16))
+    assert torch.equal(T.C.awq_dequantize(aw, asc, az, 0, 0, 0), C.awq_dequantize(aw, asc, az, 0, 0, 0))
+    # partitioned decode attention (v2) and the flash-layout cache write, convert_fp8
+    S, Hq, Hkv, D, BS = 3, 8, 2, 128, 16
+    seq_lens = np.array([5, 700, 1300], np.int32)
+    bps = (int(seq_lens.max()) + BS - 1) // BS
+    NB = S * bps
+    kc = (torch.randn(NB, Hkv, D // 8, BS, 8, device=DEV) * 0.3).half()
+    vc = (torch.randn(NB, Hkv, D, BS, device=DEV) * 0.3).half()
+    bt = rng.permutation(NB).reshape(S, bps).astype(np.int32)
+    q = t(rng.standard_normal((S, Hq, D)).astype(np.float32), torch.float16)
+    nparts = (int(seq_lens.max()) + 511) // 512
+    outs = []
+    for ns in (T.C, C):
+        out = torch.empty(S, Hq, D, dtype=torch.float16, device=DEV)
+        es = torch.empty(S, Hq, nparts, dtype=torch.float32, device=DEV)
+        ml = torch.empty_like(es)
+        tmp = torch.empty(S, Hq, nparts, D, dtype=torch.float16, device=DEV)
+        ns.paged_attention_v2(out, es, ml, tmp, q, kc, vc, Hkv, float(D ** -0.5), t(bt), t(seq_lens), BS, int(seq_lens.max()), None,
+                              "auto", 1.0, 1.0, 0, 0, 0, 64, 0)
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1])
+    kf = torch.zeros(NB, BS, Hkv, D, dtype=torch.float16, device=DEV)
+    vf = torch.zeros_like(kf)
+    kf2, vf2 = kf.clone(), vf.clone()
+    k = t((rng.standard_normal((S, Hkv, D)) * 0.3).astype(np.float16))
+    v = t((rng.standard_normal((S, Hkv, D)) * 0.3).astype(np.float16))
+    slots = t(np.array([3, 77, 200], np.int64))
+    T.cache.reshape_and_cache_flash(k, v, kf, vf, slots, "auto", 1.0, 1.0)
+    cache.reshape_and_cache_flash(k, v, kf2, vf2, slots, "auto", 1.0, 1.0)
+    assert torch.equal(kf, kf2) and torch.equal(vf, vf2) and float(kf.abs().sum()) > 0
+    src = t((rng.standard_normal((64, 128)) * 0.5).astype(np.float16))
+    d1, d2 = (torch.empty(64, 128, dtype=torch.uint8, device=DEV) for _ in range(2))
+    T.cache.convert_fp8(d1, src, 0.5, "fp8")
+    cache.convert_fp8(d2, src, 0.5, "fp8")
+    assert torch.equal(d1, d2)
+    # advance_step
+    nq = 4
+    mk = lambda: (t(np.arange(nq, dtype=np.int64)), t(np.array([11, 12, 13, 14], np.int64)), t(np.array([5, 130, 600, 15], np.int64)),
+                  t(np.array([6, 131, 601, 16], np.int32)), t(np.zeros(nq, np.int64)),
+                  t(rng.permutation(nq * 40).reshape(nq, 40).astype(np.int32)))
+    a_, b_ = mk(), mk()
+    b_ = tuple(x.clone() for x in a_)
+    T.C.advance_step_flashattn(nq, nq, BS, *a_)
+    C.advance_step_flashattn(nq, nq, BS, *b_)
+    for x, y in zip(a_, b_):
+        assert torch.equal(x, y)
+
+
 def test_reference_wrapper_call_list_resolves_on_the_device_box(T):
     """tests/golden/ref_custom_ops_calls.json = every ``torch.ops.<ns>.<op>(...)`` call the reference's own
     ``aphrodite/_custom_ops.py`` wrappers make for the hot-path ops, with the number of positional arguments they pass
