@@ -1138,21 +1138,26 @@ __device__ __forceinline__ void res_norm_finish(const Wna16ResParams& p, int tok
   }
 }
 
-// NORM_T = Half / BFloat: the norm-in-consumer form (p.n_slabs set).  The order of a workgroup's life:
-//   producers (the first M workgroups in dispatch order, one token row each) issue their norm loads; EVERY workgroup issues
-//   its scale / zero words and the weights of its first D k-steps (they depend on nothing this launch produces); producers
-//   finish their row, store it write-through, wait for the stores and take an arrival ticket; every workgroup polls the
-//   arrivals (one lane, relaxed agent-scope loads, bounded) and only then requests its A fragments.  The hand-over (store
-//   acknowledgement + ticket + poll + first A fetch, ~3 us) runs under the weights' HBM latency and the first D k-steps'
-//   worth of stream instead of behind a launch boundary.  Producers are dispatched first and wait for nobody: no deadlock
-//   whatever the residency.  The ticket word is the caller's: zero at launch, left at M (a returning atomic that finds the last
-//   workgroup past the poll would sit in front of that wave's A fragments in its in-order return queue).
-//   STAGE > 0 (norm-in-consumer only): the hand-over takes ~8 us from the wave's entry (slab read, row, store acknowledgement,
-//   ticket, poll, first A fetch: five memory round trips) -- long enough to pull in far more weights than a register ring
-//   holds.  The weights of the first STAGE k-steps are requested in ONE batch (STAGE x (NP4 + 1) loads per lane, landing in
-//   registers the accumulators do not need yet), parked in LDS (a wave's own STAGE x SLOT bytes: 4 x 19 x 2 KiB = 152 KiB on
-//   gate_up; the K-reduce tile reuses the space after a barrier), and the ring's D k-steps follow them: 23 of gate_up's 32
-//   k-steps are on the CU when its A fragments arrive, and the loop runs at the activations' rate, not at A + W.
+// NORM_T = Half / BFloat, STAGE > 0: the norm-in-consumer form (p.n_slabs set; aphro_wna16_gemm_norm_fused).  A workgroup's life:
+//   * producers (the first M workgroups in dispatch order, one token row each): norm loads, the row, write-through stores,
+//     s_waitcnt vmcnt(0) (the acknowledgement), one relaxed agent-scope ticket.  Nothing else of theirs is in flight
+//     meanwhile: the acknowledgement would wait behind a weight batch issued first, and a row computed NEXT TO buffer_load..nt
+//     requests was seen consuming a norm weight before it had landed (profiles/r4_norm_in_consumer.txt (3));
+//   * EVERY workgroup: scale / zero words, then the weights of its first STAGE k-steps in ONE batch (STAGE x (NP4 + 1) loads
+//     per lane, into registers the accumulators do not need yet), parked in LDS (a wave's own STAGE x SLOT bytes: 4 x 19 x
+//     2 KiB = 152 KiB on gate_up; the K-reduce tile reuses the space after a barrier), then D more k-steps into the register
+//     ring -- none of it depends on what this launch produces;
+//   * one lane polls the ticket (relaxed agent-scope loads, bounded: bit 31 of the word flags a give-up), a raw s_barrier
+//     releases the other waves, and only then are the A fragments requested -- with sc0 sc1: an XCD's L2 fills the rest of a
+//     128-byte line when a producer's 16-byte store passes through it, i.e. before the other seven rows of the line exist;
+//   * the K loop takes k-steps < STAGE from LDS (read one k-step ahead), the rest from the ring.
+//   Producers are dispatched first and wait for nobody: no deadlock whatever the residency.  The ticket word is the caller's:
+//   zero at launch, left at M (a returning atomic that finds the last workgroup past the poll would sit in front of that
+//   wave's A fragments in its in-order return queue).
+//   MEASURED (same file, (1) and (2)): bit-identical to the two launches and 0.7-1.5 us SLOWER than them -- the hand-over is
+//   five dependent memory round trips (6.0-8.5 us from entry to "poll passed"), the weights do arrive 3 us before the
+//   activations, and the K loop then runs at its issue rate (0.27 us per k-step from LDS, 0.28 from the ring, 0.32 in the
+//   plain kernel) -- the stream the prefetch hides is not what the loop waits for.  Kept as an opt-in form.
 template <int MT, int NWV, int NSEG, int NP4, int REM, int D, typename NORM_T = void, int STAGE = 0>
 __global__ __launch_bounds__(NWV * 64, 1) void wna16_gemm_stream_kernel(Wna16ResParams p) {
   constexpr bool NORM = !__is_same(NORM_T, void);
