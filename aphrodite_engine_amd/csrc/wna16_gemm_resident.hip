@@ -1200,8 +1200,10 @@ __global__ __launch_bounds__(NWV * 64, 1) void wna16_gemm_stream_kernel(Wna16Res
   const int voff_w4 = lane * 16, voff_wr = lane * 4 * REM;
   constexpr int poff4 = NSEG * 4096, poffr = NP4 * NSEG * 4096;
   // 33..64 rows: gridDim.z = 2 -- blockIdx.z picks a 32-row half; the two workgroups of a strip are the 32-row kernel twice,
-  // co-resident on a CU (<= 256 VGPRs each: two waves per SIMD, what one workgroup cannot afford), the second reader of a
-  // weight line finds it in the XCD's L2 (x + S (y + ksplit z): same XCD for both halves)
+  // co-resident on a CU (<= 256 VGPRs each: two waves per SIMD, what one workgroup cannot afford).  Both halves of a strip
+  // land on the same XCD (x + S (y + ksplit z)), but the second reader of a weight line finds it in that L2 only part of
+  // the time: FETCH_SIZE says 97.6 MB per launch on the 4096 x 28672 gate_up (61.5 MB algorithmic: 1.6 x) and 33.7 MB on
+  // the 8192 x 7168 shard (1.1 x) -- profiles/r4_norm_in_consumer.txt (6)
   const int mt0 = (int)blockIdx.z * MT;
   int voff_a[MT];
 #pragma unroll
