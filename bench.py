@@ -35,6 +35,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (guides: 8 TB/s; ~6.3 TB/s achievable)
+# Every capture in this script: thread-local error mode.  With a process group up (N > 1) the RCCL watchdog thread polls the
+# events of earlier collectives (the barriers); under the default "global" mode such a query from ANOTHER thread while this
+# thread captures is "operation not permitted when stream is capturing" and takes the process down (seen once in
+# tests/test_custom_ar_gpu.py on one box, never on two others: a race with the watchdog's polling interval).
+GRAPH_KW = {"capture_error_mode": "thread_local"}
 
 
 def parse_args():
@@ -197,7 +202,7 @@ def measure_kernel(fn, launches_per_call, iters=5):
     fn()
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
+    with torch.cuda.graph(g, **GRAPH_KW):
         fn()
     g.replay()
     torch.cuda.synchronize()
@@ -507,7 +512,7 @@ def all_reduce_section(args, model, device, ca):
         st = torch.cuda.Stream()
         st.wait_stream(torch.cuda.current_stream())
         with (ca.capture() if ca is not None and not ca.disabled else contextlib.nullcontext()):
-            with torch.cuda.stream(st), torch.cuda.graph(g, stream=st):
+            with torch.cuda.stream(st), torch.cuda.graph(g, stream=st, **GRAPH_KW):
                 y = x
                 for _ in range(n):
                     y = fn(y)
@@ -561,7 +566,7 @@ def timed_decode(loop, args, world, one_gpu, device, ca=None):
             with torch.cuda.stream(s):
                 loop.step()
             torch.cuda.current_stream().wait_stream(s)
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, **GRAPH_KW):
                 loop.step()
         run = graph.replay
     for _ in range(args.warmup):
@@ -702,7 +707,7 @@ def main():
                 with torch.cuda.stream(s):
                     loop.step()
                 torch.cuda.current_stream().wait_stream(s)
-                with torch.cuda.graph(graph):
+                with torch.cuda.graph(graph, **GRAPH_KW):
                     loop.step()
         run = graph.replay if graph is not None else loop.step
         for _ in range(args.warmup):
@@ -745,7 +750,7 @@ def main():
             run_ops = loop.step
             if not args.no_graph:
                 g_ops = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g_ops):
+                with torch.cuda.graph(g_ops, **GRAPH_KW):
                     loop.step()
                 run_ops = g_ops.replay
             for _ in range(args.warmup):

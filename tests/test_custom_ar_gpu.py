@@ -343,8 +343,11 @@ def _rccl_capture_worker(rank, world, port):
             tmp = buf * 2
             dist.all_reduce(tmp)
         torch.cuda.current_stream().wait_stream(s)
+        # thread-local capture errors: the RCCL watchdog thread may still be polling the warm-up collective's event when the
+        # capture starts -- under the default "global" mode that query kills the process (a race: seen on one box in three)
+        torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
             tmp = buf * 2                                    # a producer kernel, the collective, a consumer kernel
             dist.all_reduce(tmp)
             out.copy_(tmp + 1)
@@ -359,7 +362,8 @@ def _rccl_capture_worker(rank, world, port):
         with torch.cuda.stream(s):
             dist.all_gather_into_tensor(gathered, buf)
         torch.cuda.current_stream().wait_stream(s)
-        with torch.cuda.graph(g2):
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g2, capture_error_mode="thread_local"):
             dist.all_gather_into_tensor(gathered, buf)
         buf.fill_(7.0)
         g2.replay()
