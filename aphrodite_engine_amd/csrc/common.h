@@ -238,4 +238,25 @@ __device__ __forceinline__ void epi_flush(const unsigned char* region, uint16_t*
   }
 }
 
+// The same flush through a buffer descriptor: 32-bit offsets (no 64-bit address per row to keep alive -- with those hipcc
+// spilled the row pointers and reloaded them from scratch in front of every store, and a scratch reload is a VMEM load:
+// its vmcnt(0) drained the PREVIOUS store, so the 16 stores of a wave went out one acknowledged round trip at a time,
+// 16.5k of 93k cycles per 256 x 256 x 4096 tile), rows past the end of C dropped by the descriptor's bounds check instead of
+// a branch per store.  c_tile: the wave tile's origin; bytes_left: from there to the end of C.
+__device__ __forceinline__ void epi_flush_buf(const unsigned char* region, uint16_t* c_tile, int64_t ldc, int64_t bytes_left, int lane) {
+  const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(
+      c_tile, 0, (uint32_t)(bytes_left > 0xffffffffll ? 0xffffffffll : (bytes_left < 0 ? 0 : bytes_left)), 0x00020000);
+  const int r8 = lane >> 3, c16 = lane & 7;
+  const uint32_t voff = (uint32_t)r8 * (uint32_t)ldc * 2u + (uint32_t)c16 * 16u;
+  const uint32_t step = 8u * (uint32_t)ldc * 2u;
+  u32x4 v[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int row = i * 8 + r8;
+    v[i] = *reinterpret_cast<const u32x4*>(region + row * 128 + ((c16 ^ ((row >> 1) & 7)) << 4));
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) __builtin_amdgcn_raw_buffer_store_b128(v[i], rc, voff, (uint32_t)i * step, 0);
+}
+
 }  // namespace aphro

@@ -386,6 +386,33 @@ def test_cutlass_scaled_mm_large_m(ops, per_token, per_channel):
     np.testing.assert_allclose(got, ref, rtol=1.6e-2, atol=1.6e-2 * np.abs(ref).max())
 
 
+@pytest.mark.parametrize("M,N,K", [(2048, 4096, 2048), (2000, 4096, 2304), (4096, 2048, 4096)])
+@pytest.mark.parametrize("per_token,per_channel,out_dtype,with_bias",
+                         [(True, True, torch.bfloat16, True), (False, False, torch.float16, False), (True, False, torch.float16, True)])
+def test_cutlass_scaled_mm_eight_phase(ops, M, N, K, per_token, per_channel, out_dtype, with_bias):
+    """Prefill-sized W8A8 on the 256 x 256 stream-K tile (>= 128 tiles, K >= 2048: the eight-phase kernel of
+    fp8_gemm_large.hip) against the oracle on sampled rows (all columns) and sampled columns (all rows): the tile edges,
+    the ragged last row tile (M = 2000) and an odd number of K tiles per stream-K segment (K = 2304: 18 K tiles)."""
+    rng = np.random.default_rng(M + N + K)
+    a = t((rng.standard_normal((M, K)) * 2).astype(np.float32)).to(torch.float8_e4m3fn)
+    w = t((rng.standard_normal((N, K)) * 2).astype(np.float32)).to(torch.float8_e4m3fn)
+    sa = t((rng.random((M, 1) if per_token else (1, )) * 0.1 + 0.01).astype(np.float32))
+    sb = t((rng.random((N, 1) if per_channel else (1, )) * 0.1 + 0.01).astype(np.float32))
+    bias = t(rng.standard_normal(N).astype(np.float32), out_dtype) if with_bias else None
+    got = ops.cutlass_scaled_mm(a, w.t(), sa, sb, out_dtype, bias).float().cpu().numpy()
+    ab, wb = a.view(torch.uint8).cpu().numpy(), w.view(torch.uint8).cpu().numpy()
+    san, sbn = sa.cpu().numpy(), sb.cpu().numpy().reshape(-1)
+    bn = bias.float().cpu().numpy() if with_bias else None
+    rows = sorted({r for r in (0, 1, 31, 32, 63, 64, 127, 128, 129, 255, 256, 257, 511, 512, M // 2 + 3, M - 257, M - 256,
+                               M - 129, M - 128, M - 2, M - 1) if 0 <= r < M})
+    cols = sorted({0, 3, 4, 31, 32, 33, 63, 64, 65, 127, 128, 255, 256, 257, N // 2 + 5, N - 257, N - 65, N - 33, N - 2, N - 1})
+    tol = 2e-3 if out_dtype == torch.float16 else 1.6e-2
+    ref_r = of8.scaled_mm(ab[rows], wb.T, san[rows] if per_token else san, sbn, bn)
+    np.testing.assert_allclose(got[rows], ref_r, rtol=tol, atol=tol * np.abs(ref_r).max())
+    ref_c = of8.scaled_mm(ab, wb[cols].T, san, sbn[cols] if per_channel else sbn, bn[cols] if with_bias else None)
+    np.testing.assert_allclose(got[:, cols], ref_c, rtol=tol, atol=tol * np.abs(ref_c).max())
+
+
 @pytest.mark.parametrize("M", [1, 32, 64])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_fp8_w8a16(ops, M, dtype):
