@@ -18,6 +18,8 @@
 //   * XCD-aware tile order: consecutive workgroups of one XCD share the A row panel (2 MiB, L2 resident) and walk
 //     the column tiles.
 // Workgroup = WN x WM waves (WM in the M direction), wave tile = 128 rows x 64 columns, K tile 64.
+#include <type_traits>
+
 #include "common.h"
 
 namespace aphro {
@@ -77,6 +79,112 @@ __device__ __forceinline__ f16x8 dq8_scaled(uint32_t w, f16x2 zh, f16x2 zh16, f1
   u32x4 r = {__builtin_bit_cast(uint32_t, d0), __builtin_bit_cast(uint32_t, d1), __builtin_bit_cast(uint32_t, d2),
              __builtin_bit_cast(uint32_t, d3)};
   return __builtin_bit_cast(f16x8, r);
+}
+
+// What happens to a wave's accumulators once the K range of a segment is done: published (stream-K, not the owner), merged
+// + converted + stored (owner), or written as an fp32 slab (split-K form).  Shared by both kernels.
+template <int NWAVE, bool WFP8>
+__device__ __forceinline__ void wna16_large_finish(const Wna16LargeParams& p, f32x16 (&acc)[2][4], unsigned char* smem,
+                                                   const __amdgpu_buffer_rsrc_t rp, bool head, bool tail, int w, int GW, int64_t U,
+                                                   int tile, int ktiles_total, int m0, int n0, int wave, int wm, int wn, int lane) {
+  const int kh = lane >> 5, l31 = lane & 31;
+  // ---- what happens to the accumulators: lane holds, for row m = mb*32 + l31, columns nb*32 + 8 q + 4 kh + (0..3) ----------
+  if (p.streamk && !head) {
+    // not the owner of this tile (always a workgroup's FIRST segment): publish the accumulators as they sit in the
+    // registers -- image [wave][quad = (nb*4 + mb)*4 + q][lane] f32x4, 1 KiB per store instruction, write-through
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 v = {acc[nb][mb][4 * q], acc[nb][mb][4 * q + 1], acc[nb][mb][4 * q + 2], acc[nb][mb][4 * q + 3]};
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rp,
+                                                 ((w * NWAVE + wave) * 32 + (nb * 4 + mb) * 4 + q) * 1024 + lane * 16, 0, 17);
+        }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every storing wave drains ...
+    __syncthreads();                                     // ... before ONE lane raises the flag
+    if (threadIdx.x == 0) __hip_atomic_store(p.flags + w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
+  if (p.streamk && !tail) {
+    // owner of a tile whose K range continues in the following workgroups (always the LAST segment): add their images in
+    // workgroup order (deterministic).  Bounded wait, see fp8_gemm_large.hip.
+    const int64_t tile_end = (int64_t)(tile + 1) * ktiles_total;
+    for (int j = w + 1; j < GW && j * U / GW < tile_end; ++j) {
+      if (threadIdx.x == 0) {
+        const unsigned long long t0 = wall_clock64();
+        while (__hip_atomic_load(p.flags + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+          __builtin_amdgcn_s_sleep(4);
+          if (wall_clock64() - t0 > 500000000ull) __builtin_trap();
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(
+                rp, ((j * NWAVE + wave) * 32 + (nb * 4 + mb) * 4 + q) * 1024 + lane * 16, 0, 17);
+            const f32x4 v = __builtin_bit_cast(f32x4, raw);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[nb][mb][4 * q + r] += v[r];
+          }
+    }
+  }
+  if (!p.streamk && p.ksplit > 1) {          // fp32 slab of this K range; summed by splitk_reduce_large_kernel
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+      const int row = m0 + wm * 128 + mb * 32 + l31;
+      if (row >= p.M) continue;
+      float* prow = p.partial + ((size_t)blockIdx.y * p.M + row) * p.N + n0 + wn * 64;
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<f32x4*>(prow + nb * 32 + 8 * q + 4 * kh) =
+              f32x4{acc[nb][mb][4 * q], acc[nb][mb][4 * q + 1], acc[nb][mb][4 * q + 2], acc[nb][mb][4 * q + 3]};
+    }
+    return;
+  }
+  unsigned char* region = smem + wave * 16384;
+  f32x4 wsv[2][4], bsv[2][4];     // W8A16: per-channel scale and bias of this lane's 4-column groups, fetched up front
+  if constexpr (WFP8) {
+    const float s0 = p.w_per_channel ? 1.f : p.w_scales[0];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int col = n0 + wn * 64 + nb * 32 + 8 * q + 4 * kh;
+        wsv[nb][q] = p.w_per_channel ? *reinterpret_cast<const f32x4*>(p.w_scales + col) : f32x4{s0, s0, s0, s0};
+        bsv[nb][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (p.bias) {
+          const u16x4 b4 = *reinterpret_cast<const u16x4*>(p.bias + col);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) bsv[nb][q][r] = p.out_bf16 ? bf16_bits_to_f32(b4[r]) : f16_bits_to_f32(b4[r]);
+        }
+      }
+  }
+#pragma unroll
+  for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float v0 = acc[nb][mb][4 * q], v1 = acc[nb][mb][4 * q + 1], v2 = acc[nb][mb][4 * q + 2], v3 = acc[nb][mb][4 * q + 3];
+        if constexpr (WFP8) {
+          v0 = v0 * wsv[nb][q][0] + bsv[nb][q][0]; v1 = v1 * wsv[nb][q][1] + bsv[nb][q][1];
+          v2 = v2 * wsv[nb][q][2] + bsv[nb][q][2]; v3 = v3 * wsv[nb][q][3] + bsv[nb][q][3];
+        }
+        epi_put(region, mb * 32 + l31, nb * 8 + 2 * q + kh,
+                p.out_bf16 ? u32x2{pack2_16<true>(v0, v1), pack2_16<true>(v2, v3)} : u32x2{pack2_16<false>(v0, v1), pack2_16<false>(v2, v3)});
+      }
+  {
+    const int64_t origin = (int64_t)(m0 + wm * 128) * p.N + n0 + wn * 64;      // (elements)
+    epi_flush_buf(region, p.c + origin, p.N, ((int64_t)p.M * p.N - origin) * 2, lane);
+  }
 }
 
 template <int WM, int WN, int STAGES, bool WFP8>
@@ -294,101 +402,290 @@ __global__ __launch_bounds__(WM * WN * 64) void wna16_gemm_large_kernel(Wna16Lar
   }
 
   if constexpr (STAGES == 3) __syncthreads();      // every wave is done with the stage buffers
-  // ---- what happens to the accumulators: lane holds, for row m = mb*32 + l31, columns nb*32 + 8 q + 4 kh + (0..3) ----------
-  if (p.streamk && !head) {
-    // not the owner of this tile (always a workgroup's FIRST segment): publish the accumulators as they sit in the
-    // registers -- image [wave][quad = (nb*4 + mb)*4 + q][lane] f32x4, 1 KiB per store instruction, write-through
+  wna16_large_finish<NWAVE, WFP8>(p, acc, smem, rp, head, tail, w, GW, U, tile, ktiles_total, m0, n0, wave, wm, wn, lane);
+  }   // segments
+}
+
+// ---- the eight-phase kernel (round 5): 256 x 256 x 64 tile, 8 waves = 2 groups (wm = wave >> 2; waves w and w + 4 share a
+// SIMD) x 4 column strips (wn = wave & 3), the schedule of fp8_gemm_large8_kernel (fp8_gemm_large.hip; read its header for
+// the phase table and the RAW / WAR argument) ------------------------------------------------------------------------------
+// What differs from the FP8 form: the WEIGHT tile is not copied, it is built.  Every thread owns four neighbouring columns
+// (n = 4 lane .. + 3 of the tile) at one packed row (r = wave: k = 8 r .. + 7 of the K tile), so a K tile's int4 weights are
+// ONE 16-byte load per thread (a wave reads 1 KiB of one q_weight row), its group scales one 8-byte and its zero points one
+// 4-byte load.  They are requested in the shadow of phase 4's MFMAs, one whole K tile before phase 4 of the next tile turns
+// them into f16 -- (q - z) * s, the reference's own numerics (q_gemm.cu:1394-1434, qdq_4.cuh:38-63) -- and writes them as
+// [n][64 k] rows (128 B, the activations' XOR swizzle) into the LDS buffer that the tile after reads with ds_read_b128
+// like the activations.  Dequantised ONCE per workgroup (the kernel above converts every dword in both waves that share
+// its columns), 52 VALU + 4 ds_write_b128 per thread per K tile, in the one phase that has no fragment reads.
+// All loads of the K loop are inline asm or LDS-DMA: nothing hipcc would wait vmcnt(0) for (cdna_hip_programming.md,
+// "Three .s-level traps" (b)); counts by hand:
+//   per wave and K tile t:  P1 shadow: 2 LDS-DMA Ah1(t+1)   P3 shadow: 2 LDS-DMA Ah0(t+2)   P4 shadow: W / scale / zero loads of t+2
+//   P2 read block: vmcnt(2) -> the packed weights of tile t+1 (requested in P4 of tile t-1) sit in registers; dword 0 is
+//   dequantised + written there, dword 1 in P3's read block, dwords 2, 3 in P4's (which has no fragment reads).
+//   (profiles/r5_w4_large_lab.txt: all four in P4's read block = 100 VALU between two barriers while the partner's MFMA cluster
+//   is 256 cycles long: 3260 cycles per K tile against 2048 of MFMA time; interleaved with the wave's OWN MFMAs: 3520.)
+//   P4 read block: vmcnt(2) -> the activations of tile t+1 are whole; lgkmcnt(0): this wave's weight rows are written;
+//   barrier; first reader: P1 of tile t+1.
+template <int OFF>
+__device__ __forceinline__ void lg_lds_read128(u32x4& dst, uint32_t addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void lg_lds_write128(uint32_t addr, const u32x4& v) {
+  asm volatile("ds_write_b128 %0, %1 offset:%2" :: "v"(addr), "v"(v), "n"(OFF) : "memory");
+}
+__device__ __forceinline__ void lg_touch(u32x4& x) { asm volatile("" : "+v"(x)); }
+
+template <bool BF16OUT>
+__global__ __launch_bounds__(512) void wna16_gemm_large8_kernel(Wna16LargeParams p) {
+  constexpr int NWAVE = 8, BM = 256, BN = 256, BK = 64;
+  constexpr int A_REGION = BM * BK * 2;             // 32 KiB
+  constexpr int BUF = 2 * A_REGION;                 // 64 KiB per K tile: [activations | f16 weights]
+  constexpr int IMAGE = NWAVE * 32 * 1024;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int kh = lane >> 5, l31 = lane & 31;
+  const int ktiles_total = p.K / BK;
+  const int ntiles = p.tiles_m * p.tiles_n;
+  const int GW = gridDim.x;
+  const int64_t U = (int64_t)ntiles * ktiles_total;
+  auto xcd_contiguous = [](int bid, int n) {
+    const int q = n / 8, r = n % 8, xcd = bid % 8, k = bid / 8;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+  };
+  const int w = xcd_contiguous(blockIdx.x, GW);
+  int u = (int)(w * U / GW);
+  const int u_end = (int)((w + 1) * U / GW);
+
+  const __amdgpu_buffer_rsrc_t ra = lg_rsrc(p.a, (uint32_t)((size_t)p.M * p.lda * 2));
+  const __amdgpu_buffer_rsrc_t rb = lg_rsrc(p.qw, (uint32_t)((size_t)(p.K >> 3) * p.N * 4));
+  const __amdgpu_buffer_rsrc_t rs = lg_rsrc(p.sc, (uint32_t)((size_t)(p.K / p.group_size) * p.N * 2));
+  const __amdgpu_buffer_rsrc_t rz = lg_rsrc(p.qz, (uint32_t)((size_t)(p.K / p.group_size) * (p.N >> 3) * 4));
+  const __amdgpu_buffer_rsrc_t rp = lg_rsrc(p.partial, (uint32_t)((size_t)GW * IMAGE));
+
+  // fragment read addresses (LDS byte offsets): k step j of the K tile = 16-byte slot 2 j + kh, XOR f(row), f = (l31 >> 1) & 7
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  const int fsw = (l31 >> 1) & 7;
+  uint32_t a_addr[4], w_addr[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int slot = ((2 * j + kh) ^ fsw) << 4;
+    a_addr[j] = lds0 + (wm * 128 + l31) * 128 + slot;
+    w_addr[j] = lds0 + A_REGION + (wn * 64 + l31) * 128 + slot;
+  }
+  // where this thread writes its dequantised weights: rows n = 4 lane + q (q = 0..3), slot r = wave; f(n) = (2 lane + (q >> 1)) & 7
+  uint32_t ww_addr[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) ww_addr[h] = lds0 + A_REGION + (4 * lane) * 128 + ((wave ^ ((2 * lane + h) & 7)) << 4);
+  const int zshift = (lane & 1) * 16;               // this thread's four zero-point nibbles inside its qzeros dword
+
+  bool first_segment = true;
+  int seg_no = -1;
+  while (u < u_end) {
+    const int tile = u / ktiles_total;
+    const int k0 = u - tile * ktiles_total;
+    const int k1 = min(ktiles_total, k0 + (u_end - u));
+    u += k1 - k0;
+    const bool head = k0 == 0, tail = k1 == ktiles_total;
+    const int tm = tile / p.tiles_n, tn = tile % p.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    if (!first_segment) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
+    first_segment = false;
+#ifdef LG_LAB
+    // lab: workgroups 0..3, waves 0 and 4 stamp s_memtime at four points of their first four segments:
+    // flags[512 ...] as u64 [w][wave >> 2][seg][point]; points 6 / 7 = s_memrealtime at segment start / end
+    ++seg_no;
+    unsigned long long* stamp = (w < 4 && (wave & 3) == 0 && lane == 0 && seg_no < 4)
+                                    ? reinterpret_cast<unsigned long long*>(p.flags + 512) + ((w * 2 + (wave >> 2)) * 4 + seg_no) * 8 : nullptr;
+#define LG_STAMP(i) if (stamp) stamp[i] = __builtin_amdgcn_s_memtime();
+    if (stamp) stamp[6] = __builtin_amdgcn_s_memrealtime();
+#else
+#define LG_STAMP(i)
+#endif
+    LG_STAMP(0)
+
+    // ---- activations: this wave's two LDS-DMA instructions (8 rows x 128 B each) of the half-tiles Ah(h): rows
+    // (i >> 3) * 128 + h * 64 + (i & 7) * 8 .. + 8 for instruction i = 2 wave + t ----------------------------------------
+    int a_voff[2][2], a_row0[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int i = 2 * wave + t;
+        a_row0[h][t] = (i >> 3) * 128 + h * 64 + (i & 7) * 8;
+        const int ar = a_row0[h][t] + (lane >> 3);
+        a_voff[h][t] = min(m0 + ar, p.M - 1) * p.lda * 2 + (((lane & 7) ^ ((ar >> 1) & 7)) << 4);
+      }
+    auto stage_a1 = [&](int h, int t, int buf, int kt) {
+      const int voff = a_voff[h][t];                // (local copy: see the kernel above on the hipcc host-stub bug)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_ptr)(smem + buf * BUF + a_row0[h][t] * 128), 16, voff, kt * (BK * 2), 0, 0);
+    };
+    // ---- weights: one packed row piece, its scales and zero points per thread and K tile (inline asm: counted by hand) ---
+    const uint32_t w_voff = (uint32_t)((wave * p.N + n0 + 4 * lane) * 4);
+    const uint32_t s_voff = (uint32_t)((n0 + 4 * lane) * 2);
+    const uint32_t z_voff = (uint32_t)(((n0 + 4 * lane) >> 3) * 4);
+    u32x4 wq = {0, 0, 0, 0};                         // (read-write asm operands: one register set across the loop's back edge)
+    u32x2 sq = {0, 0};
+    uint32_t zq = 0;
+    auto load_w = [&](int kt) {
+      const uint32_t so_w = (uint32_t)kt * 8u * (uint32_t)p.N * 4u;
+      const uint32_t g = (uint32_t)(kt * BK) / (uint32_t)p.group_size;
+      const uint32_t so_s = g * (uint32_t)p.N * 2u, so_z = g * (uint32_t)(p.N >> 3) * 4u;
+      asm volatile("buffer_load_dwordx4 %0, %3, %4, %7 offen\n\t"
+                   "buffer_load_dwordx2 %1, %5, %6, %8 offen\n\t"
+                   "buffer_load_dword %2, %9, %10, %11 offen"
+                   : "+v"(wq), "+v"(sq), "+v"(zq)
+                   : "v"(w_voff), "s"(rb), "v"(s_voff), "s"(rs), "s"(so_w), "s"(so_s), "v"(z_voff), "s"(rz), "s"(so_z)
+                   : "memory");
+    };
+    // (q - z) * s of dword q (0..3) of the thread's packed row piece -> f16 -> row 4 lane + q of the weight region of buffer
+    // `buf` (slot = wave)
+    auto dequant_write1 = [&](auto Q, int buf) {
+      constexpr int q = decltype(Q)::value;
+      const uint16_t sb = (uint16_t)(sq[q >> 1] >> ((q & 1) * 16));
+      const float sf = p.scale_bf16 ? bf16_bits_to_f32(sb) : f16_bits_to_f32(sb);
+      const int z = (int)((zq >> (zshift + 4 * q)) & 0xf) + p.zero_offset;
+      const f16 s16 = (f16)sf;
+      const f16 a16 = __builtin_bit_cast(f16, (uint16_t)(0x6400 | z));   // 1024 + z
+      const f16 b16 = (f16)(float)(-64 - z);
+      const u32x4 dv = __builtin_bit_cast(u32x4, dq8_scaled(wq[q], f16x2{a16, a16}, f16x2{b16, b16}, f16x2{s16, s16}));
+      lg_lds_write128<(q & 1) * 128 + (q >> 1) * 256>(ww_addr[q >> 1] + buf * BUF, dv);
+    };
+    using Q0 = std::integral_constant<int, 0>; using Q1 = std::integral_constant<int, 1>;
+    using Q2 = std::integral_constant<int, 2>; using Q3 = std::integral_constant<int, 3>;
+    auto landed_wq = [&]() { asm volatile("" : "+v"(wq), "+v"(sq), "+v"(zq)); };
+
+    f32x16 acc[2][4];
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
       for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const f32x4 v = {acc[nb][mb][4 * q], acc[nb][mb][4 * q + 1], acc[nb][mb][4 * q + 2], acc[nb][mb][4 * q + 3]};
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rp,
-                                                 ((w * NWAVE + wave) * 32 + (nb * 4 + mb) * 4 + q) * 1024 + lane * 16, 0, 17);
-        }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every storing wave drains ...
-    __syncthreads();                                     // ... before ONE lane raises the flag
-    if (threadIdx.x == 0) __hip_atomic_store(p.flags + w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    continue;
-  }
-  if (p.streamk && !tail) {
-    // owner of a tile whose K range continues in the following workgroups (always the LAST segment): add their images in
-    // workgroup order (deterministic).  Bounded wait, see fp8_gemm_large.hip.
-    const int64_t tile_end = (int64_t)(tile + 1) * ktiles_total;
-    for (int j = w + 1; j < GW && j * U / GW < tile_end; ++j) {
-      if (threadIdx.x == 0) {
-        const unsigned long long t0 = wall_clock64();
-        while (__hip_atomic_load(p.flags + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
-          __builtin_amdgcn_s_sleep(4);
-          if (wall_clock64() - t0 > 500000000ull) __builtin_trap();
+        for (int r = 0; r < 16; ++r) acc[nb][mb][r] = 0.f;
+
+    const int nk = k1 - k0;
+    const int klast = k0 + nk - 1;
+    // ---- prologue: K tile 0 complete in buffer 0 (activations by DMA, weights dequantised), Ah0(1) and the packed weights of
+    // tile 1 in flight.  Past the segment's last K tile every slot keeps loading a clamped tile nobody reads (one basic
+    // block, one vmcnt count: see fp8_gemm_large8_kernel) ---------------------------------------------------------------------
+    load_w(k0);
+    stage_a1(0, 0, 0, k0); stage_a1(0, 1, 0, k0); stage_a1(1, 0, 0, k0); stage_a1(1, 1, 0, k0);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    landed_wq();
+    dequant_write1(Q0{}, 0); dequant_write1(Q1{}, 0); dequant_write1(Q2{}, 0); dequant_write1(Q3{}, 0);
+    { const int kt1 = min(k0 + 1, klast); load_w(kt1); stage_a1(0, 0, 1, kt1); stage_a1(0, 1, 1, kt1); }
+    asm volatile("s_waitcnt vmcnt(5)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wm == 1) __builtin_amdgcn_s_barrier();       // group 1 runs one barrier behind
+    __builtin_amdgcn_sched_barrier(0);
+    LG_STAMP(1)
+
+    u32x4 wf[2][4], af[2][4];                        // [n block][k step] / [m block of the current half][k step]
+    auto read_w = [&](auto NB) {
+      constexpr int nb = decltype(NB)::value;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) lg_lds_read128<nb * 4096>(wf[nb][j], w_addr[j]);
+    };
+    auto read_a = [&](auto MH) {
+      constexpr int mh = decltype(MH)::value;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) lg_lds_read128<mh * 8192>(af[0][j], a_addr[j]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) lg_lds_read128<mh * 8192 + 4096>(af[1][j], a_addr[j]);
+    };
+    // the phase's 8 MFMAs; `piece(i)` issues the phase's i-th vector-memory instruction(s) behind the (i + 1)-th MFMA pair
+    auto mma = [&](int nb, int mh, auto piece) {
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+          acc[nb][mh * 2 + mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wf[nb][j]), __builtin_bit_cast(f16x8, af[mb][j]),
+                                                                        acc[nb][mh * 2 + mb], 0, 0, 0);
+        if (j < 3) {
+          __builtin_amdgcn_sched_barrier(0);
+          piece(j);
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
-      __syncthreads();
+      __builtin_amdgcn_s_setprio(0);
+    };
+    auto landed_w = [&](int nb) {
 #pragma unroll
-      for (int nb = 0; nb < 2; ++nb)
+      for (int j = 0; j < 4; ++j) lg_touch(wf[nb][j]);
+    };
+    auto landed_a = [&]() {
 #pragma unroll
-        for (int mb = 0; mb < 4; ++mb)
+      for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(
-                rp, ((j * NWAVE + wave) * 32 + (nb * 4 + mb) * 4 + q) * 1024 + lane * 16, 0, 17);
-            const f32x4 v = __builtin_bit_cast(f32x4, raw);
+        for (int j = 0; j < 4; ++j) lg_touch(af[mb][j]);
+    };
+#define LG_BAR()  do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define LG_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+    for (int t = 0; t < nk; ++t) {
+      const int cur = t & 1;
+      const int kt1 = min(k0 + t + 1, klast), kt2 = min(k0 + t + 2, klast);
+      // ---- P1 -------------------------------------------------------------------------------------------------------
+      read_w(std::integral_constant<int, 0>{});
+      read_a(std::integral_constant<int, 0>{});
+      LG_BAR();
+      LG_LGKM0(); landed_w(0); landed_a();
+      mma(0, 0, [&](int i) { if (i < 2) stage_a1(1, i, cur ^ 1, kt1); });
+      LG_BAR();
+      // ---- P2: the packed weights of tile t + 1 (requested behind P3 of the previous tile) have landed; its weight tile is
+      // built in the read blocks of P2 (1 dword), P3 (1) and P4 (2, no fragment reads there) while the SIMD's other wave is
+      // in its MFMA cluster ------------------------------------------------------------------------------------------------
+      read_w(std::integral_constant<int, 1>{});
+      asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      landed_wq();
+      dequant_write1(Q0{}, cur ^ 1);
+      LG_BAR();
+      LG_LGKM0(); landed_w(1);
+      mma(1, 0, [&](int) {});
+      LG_BAR();
+      // ---- P3 -------------------------------------------------------------------------------------------------------
+      read_a(std::integral_constant<int, 1>{});
+      dequant_write1(Q1{}, cur ^ 1);
+      LG_BAR();
+      LG_LGKM0(); landed_a();
+      mma(1, 1, [&](int i) { if (i < 2) stage_a1(0, i, cur, kt2); });
+      LG_BAR();
+      // ---- P4 -------------------------------------------------------------------------------------------------------
+      // everything older than P3's two DMAs has landed (the activations of tile t + 1 are whole); this wave's weight rows of
+      // tile t + 1 are in the LDS before the barrier: the first reader is P1 of tile t + 1.  The request for tile t + 2's
+      // packed weights follows in the MFMA shadow (wq is free again).
+      dequant_write1(Q2{}, cur ^ 1);
+      dequant_write1(Q3{}, cur ^ 1);
+      asm volatile("s_waitcnt vmcnt(2)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+      LG_BAR();
+      mma(0, 1, [&](int i) { if (i == 0) load_w(kt2); });
+      LG_BAR();
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[nb][mb][4 * q + r] += v[r];
-          }
+      for (int j = 0; j < 4; ++j) { a_addr[j] += cur ? -BUF : BUF; w_addr[j] += cur ? -BUF : BUF; }
     }
-  }
-  if (!p.streamk && p.ksplit > 1) {          // fp32 slab of this K range; summed by splitk_reduce_large_kernel
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the over-run loads have landed before anything else uses the LDS
+    asm volatile("" : "+v"(wq), "+v"(sq), "+v"(zq));
+    if (wm == 0) __builtin_amdgcn_s_barrier();       // catch up with group 1: every wave is done with the stage buffers
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (nk & 1) {
 #pragma unroll
-    for (int mb = 0; mb < 4; ++mb) {
-      const int row = m0 + wm * 128 + mb * 32 + l31;
-      if (row >= p.M) continue;
-      float* prow = p.partial + ((size_t)blockIdx.y * p.M + row) * p.N + n0 + wn * 64;
-#pragma unroll
-      for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          *reinterpret_cast<f32x4*>(prow + nb * 32 + 8 * q + 4 * kh) =
-              f32x4{acc[nb][mb][4 * q], acc[nb][mb][4 * q + 1], acc[nb][mb][4 * q + 2], acc[nb][mb][4 * q + 3]};
+      for (int j = 0; j < 4; ++j) { a_addr[j] -= BUF; w_addr[j] -= BUF; }
     }
-    continue;
+#undef LG_BAR
+#undef LG_LGKM0
+    LG_STAMP(2)
+    wna16_large_finish<NWAVE, false>(p, acc, smem, rp, head, tail, w, GW, U, tile, ktiles_total, m0, n0, wave, wm, wn, lane);
+    LG_STAMP(4)
+#ifdef LG_LAB
+    if (stamp) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp[5] = __builtin_amdgcn_s_memtime(); stamp[7] = __builtin_amdgcn_s_memrealtime(); }
+#endif
+#undef LG_STAMP
   }
-  unsigned char* region = smem + wave * 16384;
-  f32x4 wsv[2][4], bsv[2][4];     // W8A16: per-channel scale and bias of this lane's 4-column groups, fetched up front
-  if constexpr (WFP8) {
-    const float s0 = p.w_per_channel ? 1.f : p.w_scales[0];
-#pragma unroll
-    for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int col = n0 + wn * 64 + nb * 32 + 8 * q + 4 * kh;
-        wsv[nb][q] = p.w_per_channel ? *reinterpret_cast<const f32x4*>(p.w_scales + col) : f32x4{s0, s0, s0, s0};
-        bsv[nb][q] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (p.bias) {
-          const u16x4 b4 = *reinterpret_cast<const u16x4*>(p.bias + col);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) bsv[nb][q][r] = p.out_bf16 ? bf16_bits_to_f32(b4[r]) : f16_bits_to_f32(b4[r]);
-        }
-      }
-  }
-#pragma unroll
-  for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-    for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        float v0 = acc[nb][mb][4 * q], v1 = acc[nb][mb][4 * q + 1], v2 = acc[nb][mb][4 * q + 2], v3 = acc[nb][mb][4 * q + 3];
-        if constexpr (WFP8) {
-          v0 = v0 * wsv[nb][q][0] + bsv[nb][q][0]; v1 = v1 * wsv[nb][q][1] + bsv[nb][q][1];
-          v2 = v2 * wsv[nb][q][2] + bsv[nb][q][2]; v3 = v3 * wsv[nb][q][3] + bsv[nb][q][3];
-        }
-        epi_put(region, mb * 32 + l31, nb * 8 + 2 * q + kh,
-                p.out_bf16 ? u32x2{pack2_16<true>(v0, v1), pack2_16<true>(v2, v3)} : u32x2{pack2_16<false>(v0, v1), pack2_16<false>(v2, v3)});
-      }
-  epi_flush(region, p.c + (size_t)(m0 + wm * 128) * p.N + n0 + wn * 64, p.N, p.M - (m0 + wm * 128), lane);
-  }   // segments
 }
 
 // partial [S][M*N] fp32 -> c [M*N] f16 / bf16 (fixed summation order: deterministic)
@@ -447,6 +744,27 @@ static int launch_large_s(const Wna16LargeParams& p, hipStream_t st) {
     attr_set = true;
   }
   hipLaunchKernelGGL((wna16_gemm_large_kernel<WM, WN, STAGES, WFP8>), p.streamk ? dim3(p.grid) : dim3(q.tiles_m * q.tiles_n, q.ksplit), dim3(WM * WN * 64), lds, st, q);
+  APHRO_LAUNCH_CHECK();
+  return APHRO_OK;
+}
+
+static int launch_large8(const Wna16LargeParams& p, hipStream_t st) {
+  Wna16LargeParams q = p;
+  q.tiles_m = (p.M + 255) / 256;
+  q.tiles_n = p.N / 256;
+  constexpr size_t lds = 128 * 1024;
+  static bool attr_set_dev[APHRO_MAX_DEVICES][2] = {};
+  bool& attr_set = attr_set_dev[device_slot()][p.out_bf16 ? 1 : 0];
+  const void* fn = p.out_bf16 ? (const void*)wna16_gemm_large8_kernel<true> : (const void*)wna16_gemm_large8_kernel<false>;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+      set_error("wna16_gemm_large: cannot raise the dynamic LDS limit");
+      return APHRO_ERR_LAUNCH;
+    }
+    attr_set = true;
+  }
+  if (p.out_bf16) hipLaunchKernelGGL((wna16_gemm_large8_kernel<true>), dim3(p.grid), dim3(512), lds, st, q);
+  else hipLaunchKernelGGL((wna16_gemm_large8_kernel<false>), dim3(p.grid), dim3(512), lds, st, q);
   APHRO_LAUNCH_CHECK();
   return APHRO_OK;
 }
@@ -572,7 +890,10 @@ extern "C" int aphro_wna16_gemm_large(const void* a, const uint32_t* q_weight, c
   p.w8 = nullptr; p.w_scales = nullptr; p.w_per_channel = 0; p.bias = nullptr;
   if (int rcb = large_bind_scratch(p, pl, ws, st)) return rcb;
   int rc;
-  if (pl.wm == 2) rc = pl.wn == 4 ? launch_large<2, 4>(p, st) : launch_large<2, 2>(p, st);
+  // eight-phase schedule on the 256 x 256 stream-K tile from 32 K tiles per output tile up (lab switch: read per call)
+  const int eight = getenv("APHRO_WNA16_LARGE_8PHASE") ? atoi(getenv("APHRO_WNA16_LARGE_8PHASE")) : (K >= 2048 ? 1 : 0);
+  if (pl.wm == 2 && pl.wn == 4 && pl.streamk && eight) rc = launch_large8(p, st);
+  else if (pl.wm == 2) rc = pl.wn == 4 ? launch_large<2, 4>(p, st) : launch_large<2, 2>(p, st);
   else rc = pl.wn == 4 ? launch_large<1, 4>(p, st) : launch_large<1, 2>(p, st);
   if (rc != APHRO_OK) return rc;
   if (!pl.streamk && pl.ksplit > 1) {

@@ -135,6 +135,37 @@ def test_gptq_gemm_large_m_path(ops):
     assert rel_mean_err(got.float().cpu().numpy(), ref) < 0.04
 
 
+@pytest.mark.parametrize("M,N,K,G", [(2048, 4096, 2048, 128), (2000, 4096, 2304, 128), (4096, 2048, 4096, 64)])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_wna16_large_eight_phase(ops, monkeypatch, M, N, K, G, dtype):
+    """Prefill-sized W4A16 on the 256 x 256 stream-K tile (>= 128 tiles, K >= 2048: wna16_gemm_large8_kernel, weights built
+    in the LDS from one packed row piece per thread) against the oracle's gptq_gemm on sampled rows (all columns) and sampled
+    columns (all rows), and bit-equal to the staged kernel it replaces (same K order, same dequantisation)."""
+    rng = np.random.default_rng(M + N + K)
+    qweight, qzeros, s, _ = make_gptq(rng, K, N, G)
+    shuf = oq.gptq_shuffle(qweight)
+    a = rng.standard_normal((M, K)).astype(np.float16)
+    ta, ts = t(a).to(dtype), t(s, torch.float16).to(dtype)
+    got_t = ops._wna16_large(ta, t(shuf), t(qzeros), ts, None, 1)
+    assert got_t.shape == (M, N) and got_t.dtype == dtype
+    monkeypatch.setenv("APHRO_WNA16_LARGE_8PHASE", "0")
+    old_t = ops._wna16_large(ta, t(shuf), t(qzeros), ts, None, 1)
+    monkeypatch.delenv("APHRO_WNA16_LARGE_8PHASE")
+    assert torch.equal(got_t, old_t)
+    got = got_t.float().cpu().numpy()
+    a16 = ta.float().cpu().numpy().astype(np.float16)
+    s16 = ts.float().cpu().numpy().astype(np.float16)
+    rows = sorted({r for r in (0, 1, 31, 32, 63, 64, 127, 128, 129, 255, 256, 257, 511, 512, M // 2 + 3, M - 257, M - 256,
+                               M - 129, M - 128, M - 2, M - 1) if 0 <= r < M})
+    cols = sorted({0, 3, 4, 7, 8, 31, 32, 33, 63, 64, 65, 127, 128, 255, 256, 257, N // 2 + 5, N - 257, N - 65, N - 33, N - 2, N - 1})
+    tol = 2e-3 if dtype == torch.float16 else 1.2e-2
+    ref_r = oq.gptq_gemm(a16[rows], shuf, qzeros, s16, None, True)
+    np.testing.assert_allclose(got[rows], ref_r, rtol=tol, atol=tol * np.abs(ref_r).max())
+    w = oq.gptq_dequant(qweight, qzeros, s16, None).astype(np.float64)          # [K, N]
+    ref_c = a16.astype(np.float64) @ w[:, cols]
+    np.testing.assert_allclose(got[:, cols], ref_c, rtol=tol, atol=tol * np.abs(ref_c).max())
+
+
 @pytest.mark.parametrize("waves", [4, 8])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("M", [1, 31, 32, 33, 48, 64])

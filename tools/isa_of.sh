@@ -3,7 +3,7 @@
 set -e
 cd /root/repo/aphrodite_engine_amd/csrc
 f=$1; k=$2; shift 2
-mkdir -p /tmp/isa && cd /tmp/isa
+rm -rf /tmp/isa && mkdir -p /tmp/isa && cd /tmp/isa
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -Wno-unused-variable -Wno-pass-failed -I/root/repo/aphrodite_engine_amd/csrc "$@" -save-temps -c /root/repo/aphrodite_engine_amd/csrc/$f -o /tmp/isa/x.o 2>&1 | grep -E "error" || true
 S=$(ls /tmp/isa/*gfx950.s | head -1)
 name=$(grep -o "^_Z[A-Za-z0-9_]*${k}[A-Za-z0-9_]*:" $S | head -1 | tr -d ':')
