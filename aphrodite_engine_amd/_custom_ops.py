@@ -383,9 +383,10 @@ def swap_blocks(src: torch.Tensor, dst: torch.Tensor, block_mapping: torch.Tenso
 def convert_fp8(output: torch.Tensor, input: torch.Tensor, scale: float = 1.0,
                 kv_dtype: str = "fp8") -> None:
     _require_cuda(output, input)
-    kvd = _kv(kv_dtype)
-    if kvd == _lib.KV_AUTO:
-        raise RuntimeError(f"Unsupported data type of kv cache: {kv_dtype}")
+    # cache_kernels.cu:373-409 accepts "auto", "fp8" and "fp8_e4m3"; "auto" between a 16 / 32-bit tensor and a uint8 cache
+    # can only mean the platform's fp8 format (the reference instantiates kAuto there, whose scaled_convert is an assert):
+    # e4m3.  fp8_e5m2 is accepted as an extension.
+    kvd = _kv("fp8_e4m3" if kv_dtype == "auto" else kv_dtype)
     if not (output.is_contiguous() and input.is_contiguous()):
         raise RuntimeError("convert_fp8 needs contiguous tensors")
     to_fp8 = output.dtype == torch.uint8
@@ -908,41 +909,6 @@ def wna16_gemm_resident(a_packed: torch.Tensor, m: int, k: int, qweight: torch.T
     if mode == "slabs":
         return slabs, ks
     return c
-
-
-def wna16_gemm_norm_fused_supported(m: int, n: int, k: int, groups: int, nslab: int, dtype: torch.dtype) -> bool:
-    return dtype in _DT and bool(_lib.lib().aphro_wna16_gemm_norm_fused_supported(m, n, k, groups, nslab, _DT[dtype]))
-
-
-def wna16_gemm_norm_fused(in_slabs: torch.Tensor, residual: torch.Tensor, weight: torch.Tensor, eps: float,
-                          qweight_strip: torch.Tensor, qzeros: torch.Tensor, scales: torch.Tensor, zero_offset: int,
-                          sync: torch.Tensor, mode: str = "slabs"):
-    """``fused_add_rms_norm_pack(None, in_slabs, residual, True, weight, eps)`` and the decode GEMM on its packed output
-    in ONE launch (csrc/wna16_gemm_resident.hip, norm-in-consumer form of the stream kernel): the first M workgroups
-    produce the normalised rows while every workgroup's first weights are in flight.  ``residual`` is updated in place.
-    ``sync``: ONE zeroed int32 element on the device (a view into a per-model tensor); the launch leaves M in it -- the
-    owner zeroes it before the next launch that uses it.  mode "slabs": (fp32 [S, M, N], S); "silu": fragment-major f16
-    [M, N/2] (interleaved gate / up columns).  Same bits as the two launches."""
-    lib = _lib.lib()
-    nslab, m, k = in_slabs.shape
-    n, groups = scales.shape[1], scales.shape[0]
-    dev = in_slabs.device
-    assert sync.dtype == torch.int32 and sync.numel() >= 1 and sync.device == dev
-    packed = torch.empty(lib.aphro_wna16_packed_a_bytes(m, k) // 2, dtype=torch.float16, device=dev)
-    slabs = act = None
-    if mode == "silu":
-        act = torch.empty(lib.aphro_wna16_packed_a_bytes(m, n // 2) // 2, dtype=torch.float16, device=dev)
-    else:
-        ks = lib.aphro_wna16_resident_ksplit(m, n, k, groups)
-        slabs = torch.empty((max(ks, 1), m, n), dtype=torch.float32, device=dev)
-    check(lib.aphro_wna16_gemm_norm_fused(in_slabs.data_ptr(), nslab, residual.data_ptr(), weight.data_ptr(), float(eps),
-                                          packed.data_ptr(), qweight_strip.data_ptr(), qzeros.data_ptr(),
-                                          scales.data_ptr(), _ptr(slabs), slabs.numel() * 4 if slabs is not None else 0,
-                                          _ptr(act), m, n, k, groups, zero_offset, _dt(scales), sync.data_ptr(), _stream()),
-          "wna16_gemm_norm_fused")
-    if mode == "silu":
-        return act
-    return slabs, slabs.shape[0]
 
 
 def wna16_gemm_rowmajor_supported(m: int, n: int, k: int, groups: int, dtype: torch.dtype) -> bool:

@@ -50,18 +50,7 @@ struct Wna16ResParams {
   const uint16_t* a;      // AROW instantiations: row-major f16 activations [M, lda] read in place (no pack launch)
   int lda;
   unsigned* counter;      // one launch for [M, N] with K slices: tickets per strip (zero between launches), see the epilogue
-  unsigned long long* trace;   // TRACE instantiations (RES_LAB builds, tools/resident_trace.py): per-wave timeline stamps
-  // norm-in-consumer form of the stream kernel (round 4, aphro_wna16_gemm_norm_fused): the first M workgroups produce apk
-  // (one token row each: 4-slab reduce + residual add + RMSNorm + pack, add_rms_norm_pack_kernel<T, .., 4>'s arithmetic)
-  // while every workgroup's first weights are already in flight
-  const float* n_slabs;   // [4][M][K] fp32 slabs of the previous projection, or NULL: apk is an input
-  uint16_t* n_residual;   // [M, K] in / out
-  const uint16_t* n_weight;
-  float n_eps;
-  unsigned* n_sync;       // arrival ticket of THIS launch: zero when it starts, M when it is done (the caller re-zeroes it)
 };
-
-#define RES_STAMP(i) do { if constexpr (TRACE) stamp[i] = __builtin_readcyclecounter(); } while (0)
 
 template <int B, int E, typename F>
 __device__ __forceinline__ void res_static_for(F&& f) {
@@ -128,7 +117,7 @@ struct ResMeta {          // RAW scale / zero words of one (pass, segment): unto
 
 // Columns of a strip: CW = 64 NP4 + 16 REM.  Pass p < NP4: lane (g, c) owns columns 64 p + 4 c + t (t < 4); the last pass
 // (REM > 0): columns 64 NP4 + REM c + t (t < REM).  Wave w of K slice y owns segments [(y NWV + w) NSEG, + NSEG).
-template <int MT, int NWV, int NSEG, int NP4, int REM, int DEPTH, int ADEPTH, bool KEEP_RS, bool TRACE = false, bool AROW = false>
+template <int MT, int NWV, int NSEG, int NP4, int REM, int DEPTH, int ADEPTH, bool KEEP_RS, bool AROW = false>
 __global__ __launch_bounds__(NWV * 64, NWV <= 4 ? 1 : 2) void wna16_gemm_resident_kernel(Wna16ResParams p) {
   constexpr int NPASS = NP4 + (REM > 0 ? 1 : 0);
   constexpr int NST = NPASS * NSEG * 4;             // k-steps of a wave over all passes
@@ -150,10 +139,6 @@ __global__ __launch_bounds__(NWV * 64, NWV <= 4 ? 1 : 2) void wna16_gemm_residen
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4;
   const int c = lane & 15;
-  unsigned long long stamp[TRACE ? 16 : 1] = {};
-  unsigned long long wall0 = 0;
-  if constexpr (TRACE) wall0 = __builtin_amdgcn_s_memrealtime();
-  RES_STAMP(0);
   // workgroups are dealt round-robin to the 8 XCDs: give every XCD one contiguous run of strips (neighbouring strips
   // share cache lines at their edges when a strip's row piece is not a multiple of 128 bytes)
   // With K slices (grid.y > 1) all strips of slice y read the same activation rows: slice y goes to 8 / grid.y XCDs, so
@@ -306,7 +291,6 @@ __global__ __launch_bounds__(NWV * 64, NWV <= 4 ? 1 : 2) void wna16_gemm_residen
   if constexpr (AROW) __builtin_amdgcn_sched_barrier(0);
   res_static_for<0, (DEPTH < NST ? DEPTH : NST)>([&](auto I_) { wr[decltype(I_)::value % RING] = load_w(I_); });
   __builtin_amdgcn_sched_barrier(0);
-  RES_STAMP(1);
 
   res_static_for<0, NST>([&](auto I_) {
     constexpr int I = decltype(I_)::value;
@@ -351,13 +335,6 @@ __global__ __launch_bounds__(NWV * 64, NWV <= 4 ? 1 : 2) void wna16_gemm_residen
       for (int i = 0; i < MT; ++i)
         acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b, u == 0 ? zero4 : acc[i][t], 0, 0, 0);
     }
-    if constexpr (TRACE) {
-      // 2: first k-step issued; 3 .. 10: MFMAs of the last k-step of segment s of the first pass issued (s < 8);
-      // 11: same for the last segment of the last pass
-      if constexpr (I == 0) { __builtin_amdgcn_sched_barrier(0); RES_STAMP(2); }
-      if constexpr (pass == 0 && u == 3 && s < 8) { __builtin_amdgcn_sched_barrier(0); RES_STAMP(3 + s); }
-      if constexpr (I == NST - 1 && NPASS > 1) { __builtin_amdgcn_sched_barrier(0); RES_STAMP(11); }
-    }
     if constexpr (u == 3) {
       if constexpr (KEEP_RS) {
 #pragma unroll
@@ -383,6 +360,8 @@ __global__ __launch_bounds__(NWV * 64, NWV <= 4 ? 1 : 2) void wna16_gemm_residen
         const float nzs = -z * sf;
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
+          // (packed f32 FMAs: the scalar-FMA form VERDICT r4 asked about -- 945 v_fma_f32 instead of 437 v_pk_fma_f32 in the
+          //  gate_up instantiation -- measured the same to +-0.1 us on all four projections, profiles/r5_decode_experiments.txt)
           cacc[i][t] = __builtin_elementwise_fma(acc[i][t], f32x4{s24, s24, s24, s24}, cacc[i][t]);
           cacc[i][t] = __builtin_elementwise_fma(rs[i], f32x4{nzs, nzs, nzs, nzs}, cacc[i][t]);
         }
@@ -408,9 +387,7 @@ __global__ __launch_bounds__(NWV * 64, NWV <= 4 ? 1 : 2) void wna16_gemm_residen
       }
     }
   });
-  RES_STAMP(12);
   __syncthreads();
-  RES_STAMP(13);
 
   // ---- K reduction over the waves (wave order: the summation order of wna16_gemm.hip) + store ---------------------------
   const int tid = threadIdx.x;
@@ -535,38 +512,9 @@ __global__ __launch_bounds__(NWV * 64, NWV <= 4 ? 1 : 2) void wna16_gemm_residen
                   (uint32_t)o[4] | ((uint32_t)o[5] << 16), (uint32_t)o[6] | ((uint32_t)o[7] << 16)};
     }
   }
-  if constexpr (TRACE) {
-    RES_STAMP(14);
-    if (p.trace && lane == 0) {
-      // [workgroup][wave][20]: 16 cycle stamps, wall clock (100 MHz) at entry / exit, HW_ID, XCC_ID
-      unsigned long long* t = p.trace + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * NWV + wave) * 20;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) t[i] = stamp[i];
-      t[16] = wall0;
-      t[17] = __builtin_amdgcn_s_memrealtime();
-      t[18] = __builtin_amdgcn_s_getreg(((32 - 1) << 11) | 4);     // HW_REG_HW_ID
-      t[19] = __builtin_amdgcn_s_getreg(((32 - 1) << 11) | 20);    // HW_REG_XCC_ID
-    }
-  }
 }
 
-// ---- round 4: the same GEMM with BOTH streams through an LDS ring ("ring" kernel) ---------------------------------------
-// What the round-3 kernel above loses against the pure data-movement floor of its own launch shape (tools/inbound_probe.hip:
-// 256 KB of weights + 256 KB of A per CU move in 12.9-13.1 us through `buffer_load ... lds`, 14.2 us through registers; the
-// kernel needs 16.2-17.3 us on gate_up), and what this form changes:
-//   * two column passes with the activations kept in registers put ALL the A traffic into the first pass (the first pass
-//     runs at the ~47 GB/s a CU's vector-memory path carries, the second at the HBM share of ~21 GB/s: profiles/
-//     r3_resident_trace.txt).  Here every k-step covers ALL the strip's columns: A is used once, streams at the same depth
-//     as the weights, and the mix is uniform over the whole kernel;
-//   * neither stream touches a VGPR on its way in: `buffer_load ... lds` into a per-wave ring of R k-step slots
-//     (slot = MT A pieces + NP4 16-byte weight pieces + one 4 REM-byte piece, lane-linear), so the depth in flight is a
-//     matter of LDS (R = 8: 30 KB per wave on gate_up), not of registers and not of what the compiler can keep apart;
-//   * the waits are written by hand (loads return in order: vmcnt(n) = "everything but the n youngest has landed"), the
-//     fragment reads are inline asm (a ds_read hipcc can see gets a conservative vmcnt(0)-style wait against every LDS-DMA
-//     in flight, see lm_head.hip) and run one k-step ahead of the MFMAs into a second register set.
-// Same arithmetic, same K partition over waves and slices as the kernel above for the same (NWV, NSEG): the slabs / packed
-// results are bit-identical to it.
-// row0: first row of this workgroup's tiles (33..64-row launches: blockIdx.z picks a 32-row half)
+// K reduction over the waves (LDS tile [wave][row][column]) + the three output forms; shared by the two kernels.
 template <int MT, int NWV, int NP4, int REM, int NTHREADS = NWV * 64>
 __device__ __forceinline__ void res_reduce_store(const Wna16ResParams& p, float* red, int WP, int ky, int cb, int mtiles,
                                                  int row0 = 0) {
@@ -635,534 +583,14 @@ __device__ __forceinline__ void res_reduce_store(const Wna16ResParams& p, float*
   }
 }
 
-// (free functions: hipcc does not capture a variable that a nested generic lambda names in an asm operand only)
-template <int OFF>
-__device__ __forceinline__ void ring_read128(u32x4& dst, uint32_t addr) {
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
-}
-template <typename T>
-__device__ __forceinline__ void ring_touch(T& x) { asm volatile("" : "+v"(x)); }
-template <int OFF>
-__device__ __forceinline__ void ring_read32(uint32_t& dst, uint32_t addr) {
-  asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
-}
-
-// vector-memory instructions of one k-step's ring refill / of one segment's scale + zero loads
-template <int MT, int NP4, int REM>
-constexpr int ring_per_step() { return MT + NP4 + (REM == 2 ? 2 : (REM > 0 ? 1 : 0)); }
-template <int NP4, int REM>
-constexpr int ring_meta_ops() { return 2 * NP4 + (REM == 0 ? 0 : (REM == 1 ? 2 : (REM == 2 ? 2 : 5))); }
-
-// LC (loader / consumer): the workgroup has 2 NWV waves; wave NWV + w only ISSUES -- it fills consumer w's ring -- and
-// wave w only computes.  With the refills in the computing wave's own instruction stream (LC = false) an LDS-DMA costs it
-// 60-185 cycles of issue (MI355X_MICROARCH.md; measured here: 645 cycles per k-step with 4 refills against 470 without),
-// and while the memory pipeline pushes back the wave that issues cannot compute: the round-4 traces show the prologue
-// (8 slots) taking 5.5 k cycles, the rate at which a CU's vector-memory path accepts 128 KB.  Hand-over through two
-// monotonic counters per ring in LDS: ready (k-steps landed: the loader writes it after its own vmcnt wait; LDS serves
-// requests in order, so the counter is behind the data) and consumed (k-steps whose fragments are in the consumer's
-// registers: the slot may be refilled).  Both sides cache the other's counter and poll only when they catch up with it.
-__device__ __forceinline__ int lc_flag_read(uint32_t addr) {
-  int v;
-  asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(addr) : "memory");
-  return v;
-}
-template <int UPTO>
-__device__ __forceinline__ void lc_need(int& seen, uint32_t addr) {      // returns once seen >= UPTO
-  // (bounded: 2^20 re-reads ~ 0.1 s, then it gives up and the result is wrong -- a protocol bug must not hang the GPU)
-  uint32_t spin;
-  asm volatile(
-      "v_cmp_gt_i32_e32 vcc, %3, %0\n\t"
-      "s_cbranch_vccz 2f\n\t"
-      "s_mov_b32 %1, 0x100000\n"
-      "1:\n\t"
-      "ds_read_b32 %0, %2\n\t"
-      "s_waitcnt lgkmcnt(0)\n\t"
-      "v_cmp_gt_i32_e32 vcc, %3, %0\n\t"
-      "s_cbranch_vccz 2f\n\t"
-      "s_sub_u32 %1, %1, 1\n\t"
-      "s_cmp_lg_u32 %1, 0\n\t"
-      "s_cbranch_scc1 1b\n"
-      "2:"
-      : "+v"(seen), "=&s"(spin)
-      : "v"(addr), "n"(UPTO)
-      : "vcc", "scc", "memory");
-}
-__device__ __forceinline__ void lc_flag_prefetch(int& seen, uint32_t addr) {   // value valid after the next lgkmcnt(0)
-  asm volatile("ds_read_b32 %0, %1" : "=v"(seen) : "v"(addr) : "memory");
-}
-__device__ __forceinline__ void lc_flag_write(uint32_t addr, int v) {
-  asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory");
-}
-
-template <int MT, int NWV, int NSEG, int NP4, int REM, int R, bool LC = false, bool TRACE = false>
-__global__ __launch_bounds__((LC ? 2 : 1) * NWV * 64, (LC ? 2 : 1) * NWV <= 4 ? 1 : 2) void wna16_gemm_ring_kernel(Wna16ResParams p) {
-  constexpr int NST = NSEG * 4;                     // k-steps of a wave
-  constexpr int CW = 64 * NP4 + 16 * REM;
-  constexpr int CWP = CW + 4;
-  constexpr int ROWS = 16 * MT;
-  constexpr int NT = 4 * NP4 + REM;                 // 16-column MFMA tiles of the strip
-  constexpr int PER = ring_per_step<MT, NP4, REM>();
-  constexpr int NMETA = ring_meta_ops<NP4, REM>();
-  constexpr int REMB = REM == 3 ? 1024 : 256 * REM;   // a 12-byte `buffer_load ... lds` lands at 16 bytes per lane (probed: 12 data + 4 skipped)
-  constexpr int SLOT = 1024 * (MT + NP4) + REMB;
-  constexpr int RR = R < NST ? R : NST;
-  constexpr int WPB = (RR * SLOT > ROWS * CWP * 4 ? RR * SLOT : ROWS * CWP * 4);   // bytes per wave: ring, later the reduction tile
-  constexpr int WP = WPB / 4;
-  constexpr int NTHREADS = (LC ? 2 : 1) * NWV * 64;
-  extern __shared__ __attribute__((aligned(16))) float red[];     // [NWV][WP] | LC: flags [NWV][2] ints
-  const int lane = threadIdx.x & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const bool loader = LC && wid >= NWV;
-  const int wave = loader ? wid - NWV : wid;        // the ring this wave fills / computes from
-  const int g = lane >> 4;
-  const int c = lane & 15;
-  unsigned long long stamp[TRACE ? 16 : 1] = {};
-  unsigned long long wall0 = 0;
-  if constexpr (TRACE) wall0 = __builtin_amdgcn_s_memrealtime();
-  RES_STAMP(0);
-  const int S = gridDim.x;
-  int strip, ky;
-  if (gridDim.y > 1 && 8 % gridDim.y == 0 && S % (8 / gridDim.y) == 0) {
-    const int L = blockIdx.y * S + blockIdx.x, xcd = L & 7, idx = L >> 3, per = 8 / gridDim.y;
-    ky = xcd / per;
-    strip = (xcd % per) * (S / per) + idx;
-  } else {
-    strip = (S & 7) == 0 ? (int)(blockIdx.x & 7) * (S >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-    ky = blockIdx.y;
-  }
-  const int seg0 = (ky * NWV + wave) * NSEG;
-  const int cb = strip * CW;
-  const int mtiles = (p.M + 15) >> 4;
-
-  const __amdgpu_buffer_rsrc_t rw = res_rsrc(p.qw, (uint32_t)((size_t)(p.K >> 3) * p.N * 4));
-  const __amdgpu_buffer_rsrc_t ra = res_rsrc(p.apk, (uint32_t)((size_t)(p.K >> 7) * 4 * mtiles * 1024));
-  const int ngroups = (p.K >> 7) >> p.gshift;
-  const __amdgpu_buffer_rsrc_t rs_ = res_rsrc(p.sc, (uint32_t)((size_t)ngroups * p.N * 2));
-  const __amdgpu_buffer_rsrc_t rz = res_rsrc(p.qz, (uint32_t)((size_t)ngroups * (p.N >> 3) * 4));
-
-  int voff_w4, voff_wr, sbase, ss4, su4, ssr, sur, poff4, poffr;
-  if (p.strip_layout) {
-    constexpr int WAVE_BYTES = NSEG * 4 * 64 * (16 * NP4 + 4 * REM);
-    sbase = ((ky * S + strip) * NWV + wave) * WAVE_BYTES;
-    voff_w4 = lane * 16; voff_wr = lane * 4 * REM;
-    ss4 = 4096; su4 = 1024; ssr = 1024 * REM; sur = 256 * REM;
-    poff4 = NSEG * 4096; poffr = NP4 * NSEG * 4096;
-  } else {
-    sbase = seg0 * 16 * p.N * 4;
-    voff_w4 = (4 * g * p.N + cb + 4 * c) * 4; voff_wr = (4 * g * p.N + cb + 64 * NP4 + REM * c) * 4;
-    ss4 = ssr = 16 * p.N * 4; su4 = sur = p.N * 4;
-    poff4 = 256; poffr = 0;
-  }
-  int voff_a[MT];
-#pragma unroll
-  for (int i = 0; i < MT; ++i) voff_a[i] = (min(i, mtiles - 1) * 64 + lane) * 16;
-  const int abytes = mtiles * 1024;
-
-  unsigned char* const ring = reinterpret_cast<unsigned char*>(red) + (size_t)wave * WPB;
-  const uint32_t flag_ready = (uint32_t)(uintptr_t)(res_lds_ptr)(reinterpret_cast<unsigned char*>(red) + (size_t)NWV * WPB + wave * 8);
-  const uint32_t flag_consumed = flag_ready + 4;
-
-  auto refill_rt = [&](int I) {           // k-step I -> slot I % RR: PER instructions (runtime indices: loader / prologue)
-    const int s = I >> 2, u = I & 3;
-    unsigned char* const slot = ring + (I % RR) * SLOT;
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      const int vo = voff_a[i];
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (res_lds_ptr)(slot + i * 1024), 16, vo, ((seg0 + s) * 4 + u) * abytes, 0, 0);
-    }
-#pragma unroll
-    for (int pp = 0; pp < NP4; ++pp)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (res_lds_ptr)(slot + (MT + pp) * 1024), 16, voff_w4,
-                                               sbase + pp * poff4 + s * ss4 + u * su4, 0, 2);
-    if constexpr (REM == 3) {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (res_lds_ptr)(slot + (MT + NP4) * 1024), 12, voff_wr, sbase + poffr + s * ssr + u * sur, 0, 2);
-    } else if constexpr (REM == 2) {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (res_lds_ptr)(slot + (MT + NP4) * 1024), 4, voff_wr, sbase + poffr + s * ssr + u * sur, 0, 2);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (res_lds_ptr)(slot + (MT + NP4) * 1024 + 256), 4, voff_wr, sbase + poffr + s * ssr + u * sur, 4, 2);
-    } else if constexpr (REM == 1) {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (res_lds_ptr)(slot + (MT + NP4) * 1024), 4, voff_wr, sbase + poffr + s * ssr + u * sur, 0, 2);
-    }
-  };
-
-  if constexpr (LC) {
-    if (threadIdx.x < 2 * NWV) reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(red) + (size_t)NWV * WPB)[threadIdx.x] = 0;
-    __syncthreads();
-    if (loader) {
-      // ---- loader: keep up to RR slots issued, DL k-steps unpublished (in flight) -----------------------------------------
-      // DL k-steps in flight and not yet published; the other RR - DL slots hold landed k-steps the consumer has not taken
-      // yet (DL = RR - 1 leaves no such slot: loader and consumer then hand every k-step over in lock step, each exposed to
-      // the other's polling latency -- measured 21.4 us on gate_up against 16.4)
-#ifndef RES_LC_NUM
-#define RES_LC_NUM 2
-#endif
-      constexpr int DL0 = RR * RES_LC_NUM / 4 < 1 ? 1 : RR * RES_LC_NUM / 4;     // quarters of the ring
-      constexpr int DL = DL0 * PER > 60 ? 60 / PER : DL0;
-      int consumed_seen = 0;
-      for (int I = 0; I < NST; ++I) {
-        if (I >= RR) {
-          for (int spin = 0; consumed_seen <= I - RR && spin < (1 << 20); ++spin) {
-            consumed_seen = lc_flag_read(flag_consumed);
-            if (consumed_seen <= I - RR) __builtin_amdgcn_s_sleep(1);
-          }
-        }
-        refill_rt(I);
-        if (I >= DL) {
-          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DL * PER) : "memory");
-          lc_flag_write(flag_ready, I - DL + 1);
-        }
-      }
-      res_static_for<0, DL>([&](auto J_) {          // drain: k-steps NST - DL .. NST - 1
-        constexpr int j = DL - 1 - decltype(J_)::value;
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(j * PER) : "memory");
-        if (NST - j > 0) lc_flag_write(flag_ready, NST - j);
-      });
-      __syncthreads();                              // (the consumers' tiles are written before this barrier)
-      res_reduce_store<MT, NWV, NP4, REM, NTHREADS>(p, red, WP, ky, cb, mtiles);
-      return;
-    }
-  }
-
-  // ---- consumer (LC) / the whole kernel (!LC) ----------------------------------------------------------------------------
-  const int col4 = cb + 4 * c;
-  const int colr = cb + 64 * NP4 + REM * c;
-  const int voff_s4 = col4 * 2, voff_z4 = (col4 >> 3) * 4, zshift4 = (col4 & 7) * 4;
-  const int voff_sr = colr * 2, voff_zr0 = (colr >> 3) * 4, voff_zr1 = ((colr + (REM > 0 ? REM - 1 : 0)) >> 3) * 4;
-  const int zshiftr = (colr & 7) * 4;
-  const float zoff = (float)p.zero_offset;
-  const f16x8 ones = {(f16)1.f, (f16)1.f, (f16)16.f, (f16)16.f, (f16)1.f, (f16)1.f, (f16)16.f, (f16)16.f};
-  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-  const uint32_t rd16 = (uint32_t)(uintptr_t)(res_lds_ptr)(ring + lane * 16);              // 16-byte pieces
-  const uint32_t rdr = (uint32_t)(uintptr_t)(res_lds_ptr)(ring + lane * 4);                // the 4-byte REM piece(s)
-
-  struct RingMeta { uint32_t sc[NP4 > 0 ? 2 * NP4 : 1], z[NP4 > 0 ? NP4 : 1], scr[3], zr0, zr1; };
-  RingMeta meta[2];
-  f32x4 cacc[MT][NT], acc[MT][NT], rs[MT];
-#pragma unroll
-  for (int i = 0; i < MT; ++i) {
-    rs[i] = zero4;
-#pragma unroll
-    for (int t = 0; t < NT; ++t) { cacc[i][t] = zero4; acc[i][t] = zero4; }
-  }
-
-  auto load_meta = [&](auto Q_) {         // segment Q: NMETA instructions
-    constexpr int Q = decltype(Q_)::value;
-    RingMeta& m = meta[Q & 1];
-    const int grp = (seg0 + Q) >> p.gshift;
-    const int so_s = grp * p.N * 2, so_z = grp * (p.N >> 3) * 4;
-#pragma unroll
-    for (int pp = 0; pp < NP4; ++pp) {
-      const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs_, voff_s4, so_s + pp * 128, 0);
-      m.sc[2 * pp] = v[0]; m.sc[2 * pp + 1] = v[1];
-      m.z[pp] = __builtin_amdgcn_raw_buffer_load_b32(rz, voff_z4, so_z + pp * 32, 0);
-    }
-    if constexpr (REM == 2) {
-      m.scr[0] = __builtin_amdgcn_raw_buffer_load_b32(rs_, voff_sr, so_s, 0);
-    } else if constexpr (REM > 0) {
-#pragma unroll
-      for (int t = 0; t < REM; ++t) m.scr[t] = (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rs_, voff_sr, so_s + 2 * t, 0);
-    }
-    if constexpr (REM > 0) m.zr0 = __builtin_amdgcn_raw_buffer_load_b32(rz, voff_zr0, so_z, 0);
-    if constexpr (REM == 3) m.zr1 = __builtin_amdgcn_raw_buffer_load_b32(rz, voff_zr1, so_z, 0);
-  };
-  // !LC issue order (straight-line code): meta(0); refill(0 .. RR-1); then k-step I: [wait slot I+1, read it] refill(I + RR),
-  // meta(I / 4 + 1) when I % 4 == 0.  after_slot(J): instructions issued after the last one of slot J and before the wait
-  // for it (which sits in k-step J - 1, ahead of that step's own refill).
-  auto after_slot = [](int J) constexpr {   // J >= 1
-    int n = 0;
-    if (J < RR) {
-      n += (RR - 1 - J) * PER;                              // the rest of the prologue
-      for (int I = 0; I <= J - 2; ++I) {
-        if (I + RR < NST) n += PER;
-        if (I % 4 == 0 && I / 4 + 1 < NSEG) n += NMETA;
-      }
-    } else {
-      const int I0 = J - RR;
-      if (I0 % 4 == 0 && I0 / 4 + 1 < NSEG) n += NMETA;     // the metadata loads that followed it in its own k-step
-      for (int I = I0 + 1; I <= J - 2; ++I) {
-        if (I + RR < NST) n += PER;
-        if (I % 4 == 0 && I / 4 + 1 < NSEG) n += NMETA;
-      }
-    }
-    return n > 63 ? 63 : n;
-  };
-
-  // fragment registers of two k-steps: [I & 1]
-  u32x4 fa[2][MT], fw[2][NP4 > 0 ? NP4 : 1];
-  uint32_t fr[2][REM > 0 ? REM : 1];
-  u32x4 fr4[2];                             // REM == 3: the 12-byte piece, read as 16
-  auto read_slot = [&](auto I_) {
-    constexpr int I = decltype(I_)::value;
-    constexpr int B = I & 1, off = (I % RR) * SLOT;
-    res_static_for<0, MT>([&](auto J_) {
-      constexpr int i = decltype(J_)::value;
-      ring_read128<off + i * 1024>(fa[B][i], rd16);
-    });
-    res_static_for<0, NP4>([&](auto J_) {
-      constexpr int pp = decltype(J_)::value;
-      ring_read128<off + (MT + pp) * 1024>(fw[B][pp], rd16);
-    });
-    if constexpr (REM == 3) {
-      ring_read128<off + (MT + NP4) * 1024>(fr4[B], rd16);
-    } else {
-      res_static_for<0, REM>([&](auto J_) {
-        constexpr int t = decltype(J_)::value;
-        ring_read32<off + (MT + NP4) * 1024 + 256 * t>(fr[B][t], rdr);
-      });
-    }
-  };
-  // LC: `ready_seen` is fetched (ds_read, no wait) next to the fragment reads of one k-step and looked at in the next one,
-  // behind the same lgkmcnt wait: a consumer that is not data-bound never waits for a counter.  The slow path (re-read until
-  // k-steps < UPTO have landed) is a loop INSIDE one asm statement: the consumer stays straight-line code for hipcc (with
-  // C++ poll loops in each of the 32 unrolled k-steps it spilled 427 registers).
-  int ready_seen = 0;
-  auto land = [&](auto I_) {                // the reads of k-step I have returned: make that visible to the compiler
-    constexpr int B = decltype(I_)::value & 1;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int i = 0; i < MT; ++i) ring_touch(fa[B][i]);
-#pragma unroll
-    for (int pp = 0; pp < NP4; ++pp) ring_touch(fw[B][pp]);
-#pragma unroll
-    for (int t = 0; t < (REM == 3 ? 0 : REM); ++t) ring_touch(fr[B][t]);
-    if constexpr (REM == 3) ring_touch(fr4[B]);
-    if constexpr (LC) ring_touch(ready_seen);
-  };
-  // ---- prologue ---------------------------------------------------------------------------------------------------------
-  load_meta(std::integral_constant<int, 0>{});
-  __builtin_amdgcn_sched_barrier(0);
-  if constexpr (!LC) {
-    for (int I = 0; I < RR; ++I) refill_rt(I);
-    __builtin_amdgcn_sched_barrier(0);
-    RES_STAMP(1);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RR - 1) * PER > 63 ? 63 : (RR - 1) * PER) : "memory");
-  } else {
-    RES_STAMP(1);
-    lc_need<1>(ready_seen, flag_ready);
-  }
-  read_slot(std::integral_constant<int, 0>{});
-  if constexpr (LC) lc_flag_prefetch(ready_seen, flag_ready);
-  RES_STAMP(2);
-
-  res_static_for<0, NST>([&](auto I_) {
-    constexpr int I = decltype(I_)::value;
-    constexpr int s = I / 4, u = I % 4, B = I & 1;
-    land(I_);
-    if constexpr (LC) lc_flag_write(flag_consumed, I + 1);        // slot I is in registers
-    if constexpr (I + 1 < NST) {
-      if constexpr (LC) lc_need<I + 2>(ready_seen, flag_ready);
-      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(after_slot(I + 1)) : "memory");
-      read_slot(std::integral_constant<int, (I + 1 < NST ? I + 1 : 0)>{});
-      if constexpr (LC && I + 2 < NST) lc_flag_prefetch(ready_seen, flag_ready);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (!LC && I + RR < NST) refill_rt(I + RR);
-    if constexpr (u == 0 && s + 1 < NSEG) load_meta(std::integral_constant<int, (s + 1 < NSEG ? s + 1 : 0)>{});
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- A fragments: pre-scale (see the kernel above), row sums ------------------------------------------------------------
-    f16x8 a[MT];
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      u32x4 av = fa[B][i];
-      asm("v_pk_mul_f16 %0, %1, %2" : "=v"(av[1]) : "v"(av[1]), "s"(0x2c002c00u));
-      asm("v_pk_mul_f16 %0, %1, %2" : "=v"(av[3]) : "v"(av[3]), "s"(0x2c002c00u));
-      a[i] = __builtin_bit_cast(f16x8, av);
-      rs[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], ones, u == 0 ? zero4 : rs[i], 0, 0, 0);
-    }
-    res_static_for<0, NT>([&](auto T_) {
-      constexpr int t = decltype(T_)::value;
-      uint32_t wv;
-      if constexpr (t < 4 * NP4) wv = fw[B][t / 4][t % 4];
-      else if constexpr (REM == 3) wv = fr4[B][t - 4 * NP4];
-      else wv = fr[B][t - 4 * NP4];
-      const uint32_t w8 = wv >> 8;
-      const u32x4 bq = {wv & 0x000f000fu, wv & 0x00f000f0u, w8 & 0x000f000fu, w8 & 0x00f000f0u};
-      const f16x8 b = __builtin_bit_cast(f16x8, bq);
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-        acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b, u == 0 ? zero4 : acc[i][t], 0, 0, 0);
-    });
-    if constexpr (TRACE) {
-      if constexpr (u == 3 && s < 8) { __builtin_amdgcn_sched_barrier(0); RES_STAMP(3 + s); }
-    }
-    if constexpr (u == 3) {
-      // ---- group epilogue (fp32): c += s * (2^24 * acc - z * rowsum) ---------------------------------------------------
-      const RingMeta& m = meta[s & 1];
-      res_static_for<0, NT>([&](auto T_) {
-        constexpr int t = decltype(T_)::value;
-        uint32_t zb;
-        uint16_t sb;
-        if constexpr (t < 4 * NP4) {
-          zb = (m.z[t / 4] >> zshift4) >> (4 * (t % 4));
-          sb = (uint16_t)(m.sc[2 * (t / 4) + ((t % 4) >> 1)] >> (16 * (t & 1)));
-        } else {
-          constexpr int tr = t - 4 * NP4;
-          uint32_t zbits;
-          if constexpr (REM == 3) zbits = __builtin_amdgcn_alignbit(m.zr1, m.zr0, zshiftr);
-          else zbits = m.zr0 >> zshiftr;
-          zb = zbits >> (4 * tr);
-          if constexpr (REM == 2) sb = (uint16_t)(m.scr[0] >> (16 * tr));
-          else sb = (uint16_t)m.scr[tr];
-        }
-        const float z = (float)(zb & 0xf) + zoff;
-        const float sf = p.is_bf16 ? bf16_bits_to_f32(sb) : f16_bits_to_f32(sb);
-        const float s24 = sf * 16777216.f;
-        const float nzs = -z * sf;
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-          cacc[i][t] = __builtin_elementwise_fma(acc[i][t], f32x4{s24, s24, s24, s24}, cacc[i][t]);
-          cacc[i][t] = __builtin_elementwise_fma(rs[i], f32x4{nzs, nzs, nzs, nzs}, cacc[i][t]);
-        }
-      });
-    }
-  });
-  RES_STAMP(11);
-  // ---- this wave's partial sums -> its LDS tile (its own ring space: every DMA of the ring has landed and been read) ----
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float* row = &red[wave * WP + (16 * i + 4 * g + r) * CWP];
-#pragma unroll
-      for (int pp = 0; pp < NP4; ++pp)
-        *reinterpret_cast<f32x4*>(row + 64 * pp + 4 * c) = f32x4{cacc[i][4 * pp][r], cacc[i][4 * pp + 1][r], cacc[i][4 * pp + 2][r], cacc[i][4 * pp + 3][r]};
-#pragma unroll
-      for (int t = 0; t < REM; ++t) row[64 * NP4 + REM * c + t] = cacc[i][4 * NP4 + t][r];
-    }
-  RES_STAMP(12);
-  __syncthreads();
-  RES_STAMP(13);
-  res_reduce_store<MT, NWV, NP4, REM, NTHREADS>(p, red, WP, ky, cb, mtiles);
-  if constexpr (TRACE) {
-    RES_STAMP(14);
-    if (p.trace && lane == 0) {
-      unsigned long long* t = p.trace + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * NWV + wave) * 20;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) t[i] = stamp[i];
-      t[16] = wall0;
-      t[17] = __builtin_amdgcn_s_memrealtime();
-      t[18] = __builtin_amdgcn_s_getreg(((32 - 1) << 11) | 4);
-      t[19] = __builtin_amdgcn_s_getreg(((32 - 1) << 11) | 20);
-    }
-  }
-}
-
-// ---- round 4: single pass, BOTH streams in one register ring ("stream" kernel) ----------------------------------------
-// The structure that took the FP8 decode GEMM from 29.6 to 22.7 us on gate_up (fp8_gemm_resident.hip), with this file's int4
-// arithmetic: every k-step covers ALL the strip's columns, so a wave uses each A fragment once -- nothing is resident;
-// the A fragments of k-step I ride in the same ring as its weights, D k-steps ahead, as plain buffer loads that hipcc counts
-// by itself (no LDS on the way in, no hand-written waits).  Same K partition and arithmetic as the kernels above for the
-// same (NWV, NSEG): bit-identical results.
-// ---- norm-in-consumer (round 4) ---------------------------------------------------------------------------------------
-// One token row of add_rms_norm_pack_kernel<T, false, false, 4> (fused_decode.hip) by the 256 threads of a stream-kernel
-// workgroup: thread t holds the 8-element vectors t + 256 it (the 512- or 1024-thread norm launch holds ONE vector per thread,
-// wave w = vectors [64 w, 64 w + 64)), the sum of squares is reduced per such "virtual wave" and the wave sums are added in
-// wave order -- the same additions in the same order as the launch: bit-identical residual and packed rows.
-__device__ __forceinline__ size_t res_packed_chunk(int row, int k, int mtiles) {     // = packed_chunk (fused_decode.hip)
-  const int seg = k >> 7, g = (k & 127) >> 5, u = (k & 31) >> 3;
-  return ((((size_t)seg * 4 + u) * mtiles + (row >> 4)) * 64 + g * 16 + (row & 15)) * 8;
-}
-template <int NIT>
-struct ResNormRegs { f32x4 sa[NIT][4], sb[NIT][4]; u16x8 wv[NIT], rv[NIT]; };
-
-template <int NIT>
-__device__ __forceinline__ void res_norm_load(const Wna16ResParams& p, int tok, ResNormRegs<NIT>& r) {
-  const size_t slab_stride = (size_t)p.M * p.K;
-#pragma unroll
-  for (int it = 0; it < NIT; ++it) {
-    const int i = threadIdx.x + it * 256;
-    const size_t off = (size_t)tok * p.K + 8 * i;
-    r.wv[it] = *reinterpret_cast<const u16x8*>(p.n_weight + 8 * i);
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      r.sa[it][s] = *reinterpret_cast<const f32x4*>(p.n_slabs + s * slab_stride + off);
-      r.sb[it][s] = *reinterpret_cast<const f32x4*>(p.n_slabs + s * slab_stride + off + 4);
-    }
-    r.rv[it] = *reinterpret_cast<const u16x8*>(p.n_residual + off);
-  }
-}
-
-template <typename T, int NIT>
-__device__ __forceinline__ void res_norm_finish(const Wna16ResParams& p, int tok, const ResNormRegs<NIT>& r, float* red) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int mtiles = (p.M + 15) >> 4;
-  float v[NIT][8];
-#pragma unroll
-  for (int it = 0; it < NIT; ++it) {
-    const int i = threadIdx.x + it * 256;
-    const size_t off = (size_t)tok * p.K + 8 * i;
-    f32x4 a = r.sa[it][0], b = r.sb[it][0];
-#pragma unroll
-    for (int s = 1; s < 4; ++s) { a += r.sa[it][s]; b += r.sb[it][s]; }
-    float x[8];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      x[j] = T::to_f32(T::from_f32(a[j]));
-      x[4 + j] = T::to_f32(T::from_f32(b[j]));
-    }
-    u16x8 rs2;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      rs2[j] = T::from_f32(x[j] + T::to_f32(r.rv[it][j]));
-      v[it][j] = T::to_f32(rs2[j]);
-    }
-    *reinterpret_cast<u16x8*>(p.n_residual + off) = rs2;
-    float ss = 0.f;
-    {
-#pragma clang fp contract(off)      // (squares rounded, then added: what add_rms_norm_pack_kernel's loop is pinned to)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) ss += v[it][j] * v[it][j];
-    }
-    ss = wave_sum(ss);
-    if (lane == 0) red[it * 4 + wave] = ss;        // virtual wave it * 4 + wave
-  }
-  __syncthreads();
-  float t = 0.f;
-  for (int w = 0; w < 4 * NIT; ++w) t += red[w];
-  const float inv = __frsqrt_rn(t / (float)p.K + p.n_eps);
-#pragma unroll
-  for (int it = 0; it < NIT; ++it) {
-    const int i = threadIdx.x + it * 256;
-    u32x4 yh;
-#pragma unroll
-    for (int j = 0; j < 8; j += 2) {
-      // (from_f32_exact: the fp32 product is rounded, THEN converted -- the reference's (scalar_t)(x * s_variance),
-      //  layernorm_kernels.cu:228; hipcc would fold product + conversion into one v_fma_mixlo_f16 rounding here)
-      uint16_t y0 = T::from_f32(T::to_f32(from_f32_exact<T>(v[it][j] * inv)) * T::to_f32(r.wv[it][j]));
-      uint16_t y1 = T::from_f32(T::to_f32(from_f32_exact<T>(v[it][j + 1] * inv)) * T::to_f32(r.wv[it][j + 1]));
-      if constexpr (!__is_same(T, Half)) { y0 = bf16_bits_to_f16_bits_sat(y0); y1 = bf16_bits_to_f16_bits_sat(y1); }
-      yh[j >> 1] = (uint32_t)y0 | ((uint32_t)y1 << 16);
-    }
-    // write-through: the consumers sit on all eight XCDs (the L2s are not coherent with each other)
-    uint16_t* dst = const_cast<uint16_t*>(p.apk) + res_packed_chunk(tok, 8 * i, mtiles);
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(yh) : "memory");
-  }
-}
-
-// NORM_T = Half / BFloat, STAGE > 0: the norm-in-consumer form (p.n_slabs set; aphro_wna16_gemm_norm_fused).  A workgroup's life:
-//   * producers (the first M workgroups in dispatch order, one token row each): norm loads, the row, write-through stores,
-//     s_waitcnt vmcnt(0) (the acknowledgement), one relaxed agent-scope ticket.  Nothing else of theirs is in flight
-//     meanwhile: the acknowledgement would wait behind a weight batch issued first, and a row computed NEXT TO buffer_load..nt
-//     requests was seen consuming a norm weight before it had landed (profiles/r4_norm_in_consumer.txt (3));
-//   * EVERY workgroup: scale / zero words, then the weights of its first STAGE k-steps in ONE batch (STAGE x (NP4 + 1) loads
-//     per lane, into registers the accumulators do not need yet), parked in LDS (a wave's own STAGE x SLOT bytes: 4 x 19 x
-//     2 KiB = 152 KiB on gate_up; the K-reduce tile reuses the space after a barrier), then D more k-steps into the register
-//     ring -- none of it depends on what this launch produces;
-//   * one lane polls the ticket (relaxed agent-scope loads, bounded: bit 31 of the word flags a give-up), a raw s_barrier
-//     releases the other waves, and only then are the A fragments requested -- with sc0 sc1: an XCD's L2 fills the rest of a
-//     128-byte line when a producer's 16-byte store passes through it, i.e. before the other seven rows of the line exist;
-//   * the K loop takes k-steps < STAGE from LDS (read one k-step ahead), the rest from the ring.
-//   Producers are dispatched first and wait for nobody: no deadlock whatever the residency.  The ticket word is the caller's:
-//   zero at launch, left at M (a returning atomic that finds the last workgroup past the poll would sit in front of that
-//   wave's A fragments in its in-order return queue).
-//   MEASURED (same file, (1) and (2)): bit-identical to the two launches and 0.7-1.5 us SLOWER than them -- the hand-over is
-//   five dependent memory round trips (6.0-8.5 us from entry to "poll passed"), the weights do arrive 3 us before the
-//   activations, and the K loop then runs at its issue rate (0.27 us per k-step from LDS, 0.28 from the ring, 0.32 in the
-//   plain kernel) -- the stream the prefetch hides is not what the loop waits for.  Kept as an opt-in form.
-template <int MT, int NWV, int NSEG, int NP4, int REM, int D, typename NORM_T = void, int STAGE = 0>
+// The single-pass STREAM kernel (round 4): same grid, K partition and arithmetic as the resident kernel above (bit-identical
+// slabs / packed results), but every k-step covers ALL the strip's columns, so a wave uses each A fragment exactly once:
+// nothing is resident, the A fragments of k-step I ride in the same register ring as its weights (D k-steps ahead).
+// Strip-major weights and packed activations only.  (The round-4 norm-in-consumer and LDS-ring forms of this kernel were lab
+// material -- measured slower, profiles/r4_norm_in_consumer.txt, r4_gemm_lab.txt -- and left the tree in round 5; git
+// history: commit 9b85643.)
+template <int MT, int NWV, int NSEG, int NP4, int REM, int D>
 __global__ __launch_bounds__(NWV * 64, 1) void wna16_gemm_stream_kernel(Wna16ResParams p) {
-  constexpr bool NORM = !__is_same(NORM_T, void);
-  static_assert((STAGE > 0) == NORM, "the norm-in-consumer form stages its first weights in LDS (and only it does)");
-  constexpr int SLOT = (NP4 + (REM > 0 ? 1 : 0)) * 1024;      // one k-step of one wave's weights, 16 bytes per lane and piece
   constexpr int NST = NSEG * 4;
   constexpr int CW = 64 * NP4 + 16 * REM;
   constexpr int CWP = CW + 4;
@@ -1234,11 +662,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void wna16_gemm_stream_kernel(Wna16Res
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       const int vo = voff_a[i];
-      // norm-in-consumer: sc0 sc1 -- the rows were stored write-through by producers on all eight XCDs, 16 bytes per row
-      // and 128-byte line; a producer's own L2 (and L1) fills the REST of such a line from memory when its 16 bytes arrive,
-      // i.e. before the other seven rows exist: a plain load of that XCD then hits a stale line (seen on the qkv shape:
-      // NaNs from the uninitialised buffer; on gate_up the weight stream happens to evict those lines first)
-      ar[B][i] = __builtin_amdgcn_raw_buffer_load_b128(ra, vo, ((seg0 + s) * 4 + u) * abytes, NORM ? 17 : 0);
+      ar[B][i] = __builtin_amdgcn_raw_buffer_load_b128(ra, vo, ((seg0 + s) * 4 + u) * abytes, 0);
     }
   };
   auto load_w = [&](auto I_) {
@@ -1281,103 +705,16 @@ __global__ __launch_bounds__(NWV * 64, 1) void wna16_gemm_stream_kernel(Wna16Res
   };
 
   auto load_step = [&](auto I_) { load_a(I_); load_w(I_); };
-  static_assert(STAGE == 0 || STAGE + DD <= NST, "staged + ring k-steps exceed the wave's K range");
-  unsigned char* const stg = reinterpret_cast<unsigned char*>(red) + (size_t)wave * STAGE * SLOT + lane * 16;
-  u32x4 lw4[2][NP4 > 0 ? NP4 : 1], lwr[2];        // STAGE > 0: the LDS-fed k-steps, read one step ahead
-  auto lds_read = [&](auto I_) {
-    constexpr int I = decltype(I_)::value;
-#pragma unroll
-    for (int pp = 0; pp < NP4; ++pp) lw4[I & 1][pp] = *reinterpret_cast<const u32x4*>(stg + I * SLOT + pp * 1024);
-    if constexpr (REM > 0) lwr[I & 1] = *reinterpret_cast<const u32x4*>(stg + I * SLOT + NP4 * 1024);
-  };
-
-#ifdef RES_NORM_TRACE      // lab builds: wall-clock (100 MHz) stamps of every wave, kept in SGPRs, written to p.trace
-                           // [workgroup][wave][8] at the end
-  unsigned long long nfst[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#define NF_STAMP(i) do { nfst[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#else
-#define NF_STAMP(i) do { } while (0)
-#endif
-  if constexpr (NORM) {
-    NF_STAMP(0);
-    constexpr int NIT = 2;                          // K = 4096 (the host checks): two 8-element vectors per thread
-    const int wgid = blockIdx.y * gridDim.x + blockIdx.x;
-    const bool producer = wgid < p.M;
-    {
-      // producers: the row first, then the weight batch (the store acknowledgement would wait behind the batch otherwise)
-      if (producer) {
-        ResNormRegs<NIT> nr;
-        res_norm_load<NIT>(p, wgid, nr);
-        res_norm_finish<NORM_T, NIT>(p, wgid, nr, red);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        NF_STAMP(1);
-        __builtin_amdgcn_s_barrier();
-        if (threadIdx.x == 0) __hip_atomic_fetch_add(p.n_sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      load_meta(std::integral_constant<int, 0>{});
-      u32x4 tb4[STAGE][NP4 > 0 ? NP4 : 1], tbr[STAGE];
-      res_static_for<0, STAGE>([&](auto I_) {
-        constexpr int I = decltype(I_)::value;
-        constexpr int s = I / 4, u = I % 4;
-#pragma unroll
-        for (int pp = 0; pp < NP4; ++pp)
-          tb4[I][pp] = __builtin_amdgcn_raw_buffer_load_b128(rw, voff_w4, sbase + pp * poff4 + s * 4096 + u * 1024, 2);
-        const int so = sbase + poffr + s * 1024 * REM + u * 256 * REM;
-        if constexpr (REM == 3) {
-          typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
-          const u32x3 v = __builtin_amdgcn_raw_buffer_load_b96(rw, voff_wr, so, 2);
-          tbr[I] = u32x4{v[0], v[1], v[2], 0u};
-        } else if constexpr (REM == 2) {
-          const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rw, voff_wr, so, 2);
-          tbr[I] = u32x4{v[0], v[1], 0u, 0u};
-        } else if constexpr (REM == 1) {
-          tbr[I] = u32x4{__builtin_amdgcn_raw_buffer_load_b32(rw, voff_wr, so, 2), 0u, 0u, 0u};
-        }
-      });
-      __builtin_amdgcn_sched_barrier(0);
-      res_static_for<0, STAGE>([&](auto I_) {
-        constexpr int I = decltype(I_)::value;
-#pragma unroll
-        for (int pp = 0; pp < NP4; ++pp) *reinterpret_cast<u32x4*>(stg + I * SLOT + pp * 1024) = tb4[I][pp];
-        if constexpr (REM > 0) *reinterpret_cast<u32x4*>(stg + I * SLOT + NP4 * 1024) = tbr[I];
-      });
-#ifdef RES_NORM_TRACE
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      NF_STAMP(2);
-#endif
-      res_static_for<STAGE, STAGE + DD>([&](auto I_) { load_w(I_); });
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if (threadIdx.x == 0) {
-      int spins = 0;
-      while ((__hip_atomic_load(p.n_sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0x7fffffffu) < (unsigned)p.M && ++spins < (1 << 16))
-        __builtin_amdgcn_s_sleep(2);
-      // bounded: a producer that never arrives (a ticket word that was not zero at launch, a device with fewer CUs than
-      // workgroups AND out-of-order dispatch) must not hang the GPU -- the launch finishes on garbage and says so: bit 31
-      if (spins >= (1 << 16)) __hip_atomic_fetch_or(p.n_sync, 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    NF_STAMP(3);
-    res_static_for<0, DD>([&](auto I_) { load_a(I_); });
-    if constexpr (STAGE > 0) lds_read(std::integral_constant<int, 0>{});
-  } else {
-    load_meta(std::integral_constant<int, 0>{});
-    res_static_for<0, DD>([&](auto I_) { load_step(I_); });
-  }
+  load_meta(std::integral_constant<int, 0>{});
+  res_static_for<0, DD>([&](auto I_) { load_step(I_); });
   __builtin_amdgcn_sched_barrier(0);
 
   res_static_for<0, NST>([&](auto I_) {
     constexpr int I = decltype(I_)::value;
     constexpr int s = I / 4, u = I % 4, B = I % RING;
     if constexpr (I + DD < NST) {
-      load_a(std::integral_constant<int, (I + DD < NST ? I + DD : 0)>{});
-      // (the weights of k-steps < STAGE sit in LDS, those of STAGE .. STAGE + DD - 1 were requested in the prologue)
-      if constexpr (I + DD >= STAGE + DD || STAGE == 0) load_w(std::integral_constant<int, (I + DD < NST ? I + DD : 0)>{});
+      load_step(std::integral_constant<int, (I + DD < NST ? I + DD : 0)>{});
     }
-    if constexpr (I + 1 < STAGE) lds_read(std::integral_constant<int, (I + 1 < STAGE ? I + 1 : 0)>{});
     if constexpr (u == 0 && s + 1 < NSEG) load_meta(std::integral_constant<int, (s + 1 < NSEG ? s + 1 : 0)>{});
     __builtin_amdgcn_sched_barrier(0);
     f16x8 a[MT];
@@ -1392,13 +729,8 @@ __global__ __launch_bounds__(NWV * 64, 1) void wna16_gemm_stream_kernel(Wna16Res
     res_static_for<0, NT>([&](auto T_) {
       constexpr int t = decltype(T_)::value;
       uint32_t wv;
-      if constexpr (I < STAGE) {
-        if constexpr (t < 4 * NP4) wv = lw4[I & 1][t / 4][t % 4];
-        else wv = lwr[I & 1][t - 4 * NP4];
-      } else {
-        if constexpr (t < 4 * NP4) wv = wr4[B][t / 4][t % 4];
-        else wv = wrr[B][t - 4 * NP4];
-      }
+      if constexpr (t < 4 * NP4) wv = wr4[B][t / 4][t % 4];
+      else wv = wrr[B][t - 4 * NP4];
       const uint32_t w8 = wv >> 8;
       const u32x4 bq = {wv & 0x000f000fu, wv & 0x00f000f0u, w8 & 0x000f000fu, w8 & 0x00f000f0u};
       const f16x8 b = __builtin_bit_cast(f16x8, bq);
@@ -1406,13 +738,6 @@ __global__ __launch_bounds__(NWV * 64, 1) void wna16_gemm_stream_kernel(Wna16Res
       for (int i = 0; i < MT; ++i)
         acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b, u == 0 ? zero4 : acc[i][t], 0, 0, 0);
     });
-#ifdef RES_NORM_TRACE
-    if constexpr (NORM) {
-      if constexpr (I == 0) NF_STAMP(4);
-      if constexpr (STAGE > 0 && I == STAGE - 1) NF_STAMP(5);
-      if constexpr (I == NST - 1) NF_STAMP(6);
-    }
-#endif
     if constexpr (u == 3) {
       const Meta& m = meta[s & 1];
       res_static_for<0, NT>([&](auto T_) {
@@ -1444,7 +769,6 @@ __global__ __launch_bounds__(NWV * 64, 1) void wna16_gemm_stream_kernel(Wna16Res
       __builtin_amdgcn_sched_barrier(0);
     }
   });
-  if constexpr (STAGE > 0) __syncthreads();       // the K-reduce tile reuses the staging space: every wave is done reading its weights
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -1458,17 +782,6 @@ __global__ __launch_bounds__(NWV * 64, 1) void wna16_gemm_stream_kernel(Wna16Res
     }
   __syncthreads();
   res_reduce_store<MT, NWV, NP4, REM>(p, red, WP, ky, cb, mtiles, 16 * mt0);
-#ifdef RES_NORM_TRACE
-  if constexpr (NORM) {
-    NF_STAMP(7);
-    if (p.trace != nullptr && lane == 0) {
-      unsigned long long* t = p.trace + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * NWV + wave) * 8;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) t[i] = nfst[i];
-    }
-  }
-#endif
-#undef NF_STAMP
 }
 
 // [K/8, N] exllama order -> strip-major: the 16-byte (last pass: 4 REM-byte) pieces in the order the waves read them.
@@ -1559,13 +872,13 @@ static ResConfig res_plan32(int64_t M, int64_t N, int64_t K, int64_t gs) {
   return none;
 }
 
-template <int MT, int NWV, int NSEG, int NP4, int REM, int DEPTH, int ADEPTH, bool KEEP_RS, bool TRACE = false, bool AROW = false>
+template <int MT, int NWV, int NSEG, int NP4, int REM, int DEPTH, int ADEPTH, bool KEEP_RS, bool AROW = false>
 static int res_launch(const Wna16ResParams& p, hipStream_t st) {
   constexpr int CW = 64 * NP4 + 16 * REM;
   constexpr int AD = ADEPTH < NSEG ? ADEPTH : NSEG;
   constexpr size_t TILE = (size_t)16 * MT * (CW + 4) * sizeof(float), STAGE = (size_t)(AD + 1) * 16 * MT * 256;
   const size_t lds = (size_t)NWV * (AROW && STAGE > TILE ? STAGE : TILE);
-  auto kern = wna16_gemm_resident_kernel<MT, NWV, NSEG, NP4, REM, DEPTH, ADEPTH, KEEP_RS, TRACE, AROW>;
+  auto kern = wna16_gemm_resident_kernel<MT, NWV, NSEG, NP4, REM, DEPTH, ADEPTH, KEEP_RS, AROW>;
   if (lds > 64 * 1024) {   // per device and cheap: set every time (a process-wide flag misses a second GPU)
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
       set_error("wna16_gemm_resident: cannot raise the dynamic LDS limit to %zu", lds);
@@ -1578,34 +891,12 @@ static int res_launch(const Wna16ResParams& p, hipStream_t st) {
   return APHRO_OK;
 }
 
-template <int MT, int NWV, int NSEG, int NP4, int REM, int R, bool LC = false, bool TRACE = false>
-static int res_launch_ring(const Wna16ResParams& p, hipStream_t st) {
-  constexpr int CW = 64 * NP4 + 16 * REM;
-  constexpr int NST = NSEG * 4, RR = R < NST ? R : NST;
-  constexpr size_t TILE = (size_t)16 * MT * (CW + 4) * sizeof(float), RING = (size_t)RR * (1024 * (MT + NP4) + (REM == 3 ? 1024 : 256 * REM));
-  constexpr size_t LDS = (size_t)NWV * (RING > TILE ? RING : TILE) + (LC ? 64 : 0);
-  static_assert(LDS <= 160 * 1024, "ring + tiles exceed the LDS");
-  auto kern = wna16_gemm_ring_kernel<MT, NWV, NSEG, NP4, REM, R, LC, TRACE>;
-  if (LDS > 64 * 1024) {
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS) != hipSuccess) {
-      set_error("wna16_gemm_ring: cannot raise the dynamic LDS limit to %zu", LDS);
-      return APHRO_ERR_LAUNCH;
-    }
-  }
-  const dim3 grid((unsigned)(p.N / CW), (unsigned)p.ksplit);
-  hipLaunchKernelGGL(kern, grid, dim3((LC ? 2 : 1) * NWV * 64), LDS, st, p);
-  APHRO_LAUNCH_CHECK();
-  return APHRO_OK;
-}
-
-template <int MT, int NWV, int NSEG, int NP4, int REM, int D, typename NORM_T = void, int STAGE = 0>
+template <int MT, int NWV, int NSEG, int NP4, int REM, int D>
 static int res_launch_stream(const Wna16ResParams& p, hipStream_t st) {
   constexpr int CW = 64 * NP4 + 16 * REM;
-  constexpr size_t TILE = (size_t)NWV * 16 * MT * (CW + 4) * sizeof(float);
-  constexpr size_t STG = (size_t)NWV * STAGE * (NP4 + (REM > 0 ? 1 : 0)) * 1024;
-  constexpr size_t LDS = STG > TILE ? STG : TILE;
-  static_assert(LDS <= 160 * 1024, "tile / staging exceed the LDS");
-  auto kern = wna16_gemm_stream_kernel<MT, NWV, NSEG, NP4, REM, D, NORM_T, STAGE>;
+  constexpr size_t LDS = (size_t)NWV * 16 * MT * (CW + 4) * sizeof(float);
+  static_assert(LDS <= 160 * 1024, "the K-reduce tile exceeds the LDS");
+  auto kern = wna16_gemm_stream_kernel<MT, NWV, NSEG, NP4, REM, D>;
   if (LDS > 64 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS) != hipSuccess) {
     set_error("wna16_gemm_stream: cannot raise the dynamic LDS limit to %zu", LDS);
     return APHRO_ERR_LAUNCH;
@@ -1623,39 +914,6 @@ static int res_launch_stream(const Wna16ResParams& p, hipStream_t st) {
 #ifndef RES_ADEPTH
 #define RES_ADEPTH 2
 #endif
-// ring kernel: (nwv, nseg, np4, rem, ring depth in k-steps); RES_RING_DEFAULT: the depth a call gets without APHRO_WNA16_RING
-#ifndef RES_RING_DEFAULT
-#define RES_RING_DEFAULT 0
-#endif
-#ifdef RES_LAB_SET
-#define RES_RING_CONFIGS(X) \
-  X(4, 8, 1, 3, 8)          \
-  X(4, 7, 1, 0, 8)
-// loader / consumer form (APHRO_WNA16_RING=-R)
-#define RES_LC_CONFIGS(X) \
-  X(4, 8, 1, 3, 8)        \
-  X(4, 8, 1, 3, 9)        \
-  X(4, 7, 1, 0, 8)        \
-  X(4, 7, 1, 0, 12)       \
-  X(4, 4, 1, 0, 8)        \
-  X(4, 4, 1, 0, 12)
-#define RES_STREAM_SWEEP(X) \
-  X(4, 8, 1, 3, 3)          \
-  X(4, 8, 1, 3, 5)          \
-  X(4, 7, 1, 0, 5)          \
-  X(4, 7, 1, 0, 7)          \
-  X(4, 7, 1, 0, 8)          \
-  X(4, 4, 1, 0, 5)          \
-  X(4, 4, 1, 0, 7)          \
-  X(4, 4, 1, 0, 8)          \
-  X(4, 2, 1, 0, 6)          \
-  X(4, 2, 1, 0, 8)
-#else    // product builds: the round-4 ring forms are lab material (tools/reslab.hip; DESIGN.md 5 "ring kernel": they match
-         // the register-ring kernel within noise on every configs[1] shape) and are not instantiated
-#define RES_RING_CONFIGS(X)
-#define RES_LC_CONFIGS(X)
-#define RES_STREAM_SWEEP(X)
-#endif
 // stream kernel (nwv, nseg, np4, rem, k-steps in flight): the plans of the configs[1] projections, each at the depth that
 // measured best (tools/reslab.hip, profiles/r4_gemm_lab.txt (8): gate_up 3 / 4 / 5 / 6 -> 14.9 / 15.2 / 15.3 / 16.1 us against
 // 15.5-16.0 for the two-pass kernel; down 5 / 6 / 7 -> 9.92 / 9.84 / 10.12 against 10.2; qkv 5 / 6 / 7 -> 6.62 / 6.65 / 6.94
@@ -1666,31 +924,7 @@ static int res_launch_stream(const Wna16ResParams& p, hipStream_t st) {
   X(4, 4, 1, 0, 6)            \
   X(4, 2, 1, 0, 4)            \
   X(4, 4, 1, 3, 4)
-// norm-in-consumer form (aphro_wna16_gemm_norm_fused): the gate_up plan of configs[1].  (A qkv form without staging was
-// measured too -- 12.1 us against 4.8 + 6.8 for the two launches: its hand-over chain alone is 6.0 us and 64 KB of weights per
-// CU leave nothing to hide it under; profiles/r4_norm_in_consumer.txt)
-//   (.., k-steps in the register ring, k-steps staged in LDS)
-#ifndef RES_NORM_STAGE
-#define RES_NORM_STAGE 19
-#endif
-#define RES_NORM_CONFIGS(X) X(4, 8, 1, 3, 4, RES_NORM_STAGE)
-#ifdef RES_NO_KEEP_RS   // lab: the row sums of pass 0 are recomputed in the later passes instead of kept (registers)
-#define RES_KEEP_RS(x) false
-#else
 #define RES_KEEP_RS(x) (x)
-#endif
-#ifdef RES_LAB_SET   // lab builds (tools/reslab.hip): the round-3 plans of the four configs[1] shapes + 2-waves-per-SIMD forms
-#define RES_CONFIGS(X) \
-  X(4, 8, 1, 3)        \
-  X(4, 7, 1, 0)        \
-  X(4, 4, 1, 0)        \
-  X(4, 2, 1, 0)        \
-  X(8, 4, 1, 3)        \
-  X(7, 4, 1, 0)        \
-  X(8, 2, 0, 3)        \
-  X(8, 2, 0, 2)
-#define RES_AROW_CONFIGS(X) X(4, 8, 1, 3)
-#else
 #define RES_CONFIGS(X) \
   X(4, 8, 1, 3)        \
   X(4, 7, 1, 0)        \
@@ -1698,12 +932,9 @@ static int res_launch_stream(const Wna16ResParams& p, hipStream_t st) {
   X(4, 4, 1, 0)        \
   X(4, 2, 1, 0)        \
   X(4, 4, 0, 3)        \
-  X(4, 2, 1, 2)        \
-  X(4, 1, 2, 0)        \
-  X(7, 2, 2, 0)        \
   X(4, 4, 1, 3)
 
-// (the candidates of res_plan: what a call without APHRO_WNA16_RES_CFG can get)
+// row-major activations read in place (the op-level gptq_gemm in one launch): the same plans
 #define RES_AROW_CONFIGS(X) \
   X(4, 8, 1, 3)             \
   X(4, 7, 1, 0)             \
@@ -1712,7 +943,6 @@ static int res_launch_stream(const Wna16ResParams& p, hipStream_t st) {
   X(4, 2, 1, 0)             \
   X(4, 4, 0, 3)             \
   X(4, 4, 1, 3)
-#endif
 
 static bool res_instantiated(int nwv, int nseg, int np4, int rem) {
 #define X(a, b, c, d) if (nwv == a && nseg == b && np4 == c && rem == d) return true;
@@ -1730,84 +960,31 @@ static bool res_stream_instantiated(int nwv, int nseg, int np4, int rem) {
 
 static int res_dispatch(const Wna16ResParams& p, const ResConfig& cf, hipStream_t st) {
   const int mt = p.M > 16 ? 2 : 1;
-  if (p.M > 32 && !(p.a == nullptr && p.strip_layout && p.n_slabs == nullptr)) {
+  if (p.M > 32 && !(p.a == nullptr && p.strip_layout)) {
     set_error("wna16_gemm_resident: %d rows are served on packed activations and strip-major weights only", p.M);
-    return APHRO_ERR_INVALID;
-  }
-#ifdef RES_LAB   // prefetch-depth sweep / per-wave timeline of the two big shapes (tools/resident_bench.py, resident_trace.py):
-                 // APHRO_WNA16_RES_DEPTH="depth,adepth"; with a trace buffer set the TRACE instantiation runs
-  if (const char* e = getenv("APHRO_WNA16_RES_DEPTH")) {
-    int d = 0, ad = 0;
-    if (sscanf(e, "%d,%d", &d, &ad) == 2 && mt == 2) {
-#define L(D, AD)                                                                                                   \
-      if (d == D && ad == AD) {                                                                                    \
-        if (cf.nwv == 4 && cf.nseg == 8 && cf.np4 == 1 && cf.rem == 3)                                             \
-          return p.trace ? res_launch<2, 4, 8, 1, 3, D, AD, true, true>(p, st) : res_launch<2, 4, 8, 1, 3, D, AD, true>(p, st);  \
-        if (cf.nwv == 4 && cf.nseg == 7 && cf.np4 == 1 && cf.rem == 0)                                             \
-          return p.trace ? res_launch<2, 4, 7, 1, 0, D, AD, false, true>(p, st) : res_launch<2, 4, 7, 1, 0, D, AD, false>(p, st); \
-      }
-      L(4, 1) L(8, 2) L(12, 2)
-#undef L
-    }
-  }
-#endif
-  if (p.a == nullptr) {   // packed activations: the ring kernel where it is instantiated (APHRO_WNA16_RING=0: the round-3 kernel)
-#ifdef RES_LAB_SET     // (lab: one process times several settings)
-    const char* ring_e = getenv("APHRO_WNA16_RING");     // R: the LDS-ring form; -R: with loader waves
-    const int ring_env = ring_e ? atoi(ring_e) : 0;
-#else
-    static const int ring_env = [] { const char* e = getenv("APHRO_WNA16_RING"); return e ? atoi(e) : 0; }();
-#endif
-    const int ring = ring_env != 0 ? ring_env : RES_RING_DEFAULT;
-#define X(a, b, c, d, r)                                                                       \
-    if (ring == r && cf.nwv == a && cf.nseg == b && cf.np4 == c && cf.rem == d)                \
-      return mt == 2 ? (p.trace ? res_launch_ring<2, a, b, c, d, r, false, true>(p, st) : res_launch_ring<2, a, b, c, d, r, false>(p, st)) \
-                     : res_launch_ring<1, a, b, c, d, r, false>(p, st);
-    RES_RING_CONFIGS(X)
-#undef X
-#define X(a, b, c, d, r)                                                                       \
-    if (ring == -r && cf.nwv == a && cf.nseg == b && cf.np4 == c && cf.rem == d)               \
-      return mt == 2 ? (p.trace ? res_launch_ring<2, a, b, c, d, r, true, true>(p, st) : res_launch_ring<2, a, b, c, d, r, true>(p, st)) \
-                     : res_launch_ring<1, a, b, c, d, r, true>(p, st);
-    RES_LC_CONFIGS(X)
-#undef X
-  }
-  if (p.n_slabs != nullptr) {     // norm-in-consumer: stream kernel only
-#define X(a, b, c, d, r, g)                                                                                      \
-    if (cf.nwv == a && cf.nseg == b && cf.np4 == c && cf.rem == d)                                               \
-      return p.is_bf16 ? (mt == 2 ? res_launch_stream<2, a, b, c, d, r, BFloat, g>(p, st) : res_launch_stream<1, a, b, c, d, r, BFloat, g>(p, st)) \
-                       : (mt == 2 ? res_launch_stream<2, a, b, c, d, r, Half, g>(p, st) : res_launch_stream<1, a, b, c, d, r, Half, g>(p, st));
-    RES_NORM_CONFIGS(X)
-#undef X
-    set_error("wna16_gemm_norm_fused: configuration %d,%d,%d,%d has no norm-in-consumer instantiation", cf.nwv, cf.nseg, cf.np4, cf.rem);
     return APHRO_ERR_INVALID;
   }
   if (p.a == nullptr && p.strip_layout) {
     // packed activations on strip-major weights: the single-pass stream kernel where it is instantiated
-    // (APHRO_WNA16_STREAM=0: the two-pass resident kernel; lab builds: =D picks a swept depth)
-#ifdef RES_LAB_SET
-    const char* se = getenv("APHRO_WNA16_STREAM");
-    const int sd = se ? atoi(se) : -1;
-#else
-    static const int sd = [] { const char* e = getenv("APHRO_WNA16_STREAM"); return e ? atoi(e) : -1; }();
-#endif
+    // (APHRO_WNA16_STREAM=0: the two-pass resident kernel, 32 rows at most)
+    static const bool stream = [] { const char* e = getenv("APHRO_WNA16_STREAM"); return !e || atoi(e) != 0; }();
 #define X(a, b, c, d, r)                                                                 \
-    if ((sd == r || sd < 0) && cf.nwv == a && cf.nseg == b && cf.np4 == c && cf.rem == d)  \
+    if (stream && cf.nwv == a && cf.nseg == b && cf.np4 == c && cf.rem == d)             \
       return mt == 2 ? res_launch_stream<2, a, b, c, d, r>(p, st) : res_launch_stream<1, a, b, c, d, r>(p, st);
     RES_STREAM_CONFIGS(X)
 #undef X
-#define X(a, b, c, d, r)                                                                 \
-    if (sd == r && cf.nwv == a && cf.nseg == b && cf.np4 == c && cf.rem == d)            \
-      return mt == 2 ? res_launch_stream<2, a, b, c, d, r>(p, st) : res_launch_stream<1, a, b, c, d, r>(p, st);
-    RES_STREAM_SWEEP(X)
-#undef X
+  }
+  if (p.M > 32) {    // (the two-pass kernel has no second row half -- rows 32.. would stay unwritten)
+    set_error("wna16_gemm_resident: %d rows need a stream-kernel plan (configuration %d,%d,%d,%d, APHRO_WNA16_STREAM=0?)", p.M,
+              cf.nwv, cf.nseg, cf.np4, cf.rem);
+    return APHRO_ERR_INVALID;
   }
   if (p.a != nullptr) {   // row-major activations read in place: the configurations res_plan picks by itself
 #define X(a, b, c, d)                                                                                    \
     if (cf.nwv == a && cf.nseg == b && cf.np4 == c && cf.rem == d) {                                     \
       constexpr bool KR = RES_KEEP_RS((c + (d > 0 ? 1 : 0)) > 1);                                                   \
-      return mt == 2 ? res_launch<2, a, b, c, d, RES_DEPTH, RES_ADEPTH, KR, false, true>(p, st)          \
-                     : res_launch<1, a, b, c, d, RES_DEPTH, RES_ADEPTH, KR, false, true>(p, st);         \
+      return mt == 2 ? res_launch<2, a, b, c, d, RES_DEPTH, RES_ADEPTH, KR, true>(p, st)          \
+                     : res_launch<1, a, b, c, d, RES_DEPTH, RES_ADEPTH, KR, true>(p, st);         \
     }
     RES_AROW_CONFIGS(X)
 #undef X
@@ -1825,10 +1002,6 @@ static int res_dispatch(const Wna16ResParams& p, const ResConfig& cf, hipStream_
   set_error("wna16_gemm_resident: configuration %d,%d,%d,%d is not instantiated", cf.nwv, cf.nseg, cf.np4, cf.rem);
   return APHRO_ERR_INVALID;
 }
-
-static unsigned long long* g_res_trace = nullptr;
-// RES_LAB builds: device buffer of [workgroups][waves][20] u64 the next launches stamp their timeline into (NULL: off).
-extern "C" void aphro_wna16_resident_set_trace(void* buf) { g_res_trace = (unsigned long long*)buf; }
 
 // K slices the resident kernel produces for this shape (fp32 slabs when > 1), 0: shape not served.
 extern "C" int aphro_wna16_resident_ksplit(int64_t M, int64_t N, int64_t K, int64_t groups) {
@@ -1857,9 +1030,7 @@ extern "C" int aphro_wna16_gemm_resident(const void* a_packed, const uint32_t* q
   p.gshift = 0;
   for (int64_t q = (K / groups) >> 7; q > 1; q >>= 1) ++p.gshift;
   p.force_partial = 0; p.strip_layout = strip_layout ? 1 : 0; p.is_bf16 = dtype == APHRO_BF16;
-  p.trace = g_res_trace;
   p.a = nullptr; p.lda = 0; p.counter = nullptr;
-  p.n_slabs = nullptr; p.n_residual = nullptr; p.n_weight = nullptr; p.n_eps = 0.f; p.n_sync = nullptr;
   if (act_packed != nullptr) {
     APHRO_CHECK(cf.ksplit == 1 && N % 256 == 0, "wna16_gemm_resident: the SiluAndMul form needs one K slice and N/2 %% 128 == 0 (N=%ld)", (long)N);
     p.c = nullptr; p.partial = nullptr;
@@ -1868,55 +1039,6 @@ extern "C" int aphro_wna16_gemm_resident(const void* a_packed, const uint32_t* q
     p.force_partial = 1; p.c = nullptr;
   } else {
     APHRO_CHECK(c != nullptr && cf.ksplit == 1, "wna16_gemm_resident: this shape needs the slab form (%d K slices)", cf.ksplit);
-  }
-  return res_dispatch(p, cf, st);
-}
-
-// 1: aphro_wna16_gemm_norm_fused serves this call.
-extern "C" int aphro_wna16_gemm_norm_fused_supported(int64_t M, int64_t N, int64_t K, int64_t groups, int nslab, int dtype) {
-  if ((dtype != APHRO_F16 && dtype != APHRO_BF16) || groups <= 0 || K % groups != 0 || K != 4096 || nslab != 4 || M < 1 || M > 32) return 0;
-  const ResConfig cf = res_plan(M, N, K, K / groups);
-  if (cf.nwv == 0 || (int64_t)(N / (64 * cf.np4 + 16 * cf.rem)) * cf.ksplit < M) return 0;
-#define X(a, b, c, d, r, g) if (cf.nwv == a && cf.nseg == b && cf.np4 == c && cf.rem == d) return 1;
-  RES_NORM_CONFIGS(X)
-#undef X
-  return 0;
-}
-
-// fused_add_rms_norm (+ split-K slab reduce + pack) and the decode GEMM that consumes it in ONE launch ("norm-in-consumer",
-// DESIGN.md 5): x = sum of the 4 fp32 slabs in_slabs [4][M][K] rounded to dtype, residual' = round(x + residual) (in
-// place), y = round(round(residual' rstd) w) -- bit for bit aphro_fused_add_rms_norm_pack -- produced by the first M
-// workgroups into a_packed (scratch, aphro_wna16_packed_a_bytes(M, K)) while every workgroup's first weights are in flight,
-// then aphro_wna16_gemm_resident's GEMM on it (strip-major q_weight; outputs: act_packed = SiluAndMul form, or fp32 slabs),
-// bit for bit again.  sync: one zeroed 32-bit word in device memory, left at M by the launch -- the caller zeroes it before
-// the next launch that uses it (one fill per decode step over all the words of a model).
-extern "C" int aphro_wna16_gemm_norm_fused(const float* in_slabs, int nslab, void* residual, const void* norm_weight, float eps,
-                                           void* a_packed, const uint32_t* q_weight, const uint32_t* qzeros, const void* scales,
-                                           float* slabs, size_t slabs_bytes, void* act_packed, int64_t M, int64_t N, int64_t K,
-                                           int64_t groups, int zero_offset, int dtype, void* sync, void* stream) {
-  hipStream_t st = (hipStream_t)stream;
-  APHRO_CHECK(aphro_wna16_gemm_norm_fused_supported(M, N, K, groups, nslab, dtype),
-              "wna16_gemm_norm_fused: M=%ld N=%ld K=%ld groups=%ld nslab=%d dtype=%d is not served", (long)M, (long)N, (long)K, (long)groups, nslab, dtype);
-  APHRO_CHECK(in_slabs && residual && norm_weight && a_packed && sync, "wna16_gemm_norm_fused: null argument");
-  APHRO_CHECK(((uintptr_t)a_packed % 16) == 0 && ((uintptr_t)q_weight % 16) == 0 && ((uintptr_t)in_slabs % 16) == 0 &&
-              ((uintptr_t)residual % 16) == 0 && ((uintptr_t)norm_weight % 16) == 0 && ((uintptr_t)sync % 4) == 0,
-              "wna16_gemm_norm_fused: 16-byte alignment required");
-  APHRO_CHECK((act_packed != nullptr) != (slabs != nullptr), "wna16_gemm_norm_fused: exactly one of act_packed / slabs");
-  const ResConfig cf = res_plan(M, N, K, K / groups);
-  Wna16ResParams p;
-  p.apk = (const uint16_t*)a_packed; p.qw = q_weight; p.qz = qzeros; p.sc = (const uint16_t*)scales;
-  p.c = nullptr; p.partial = slabs; p.act_packed = (uint16_t*)act_packed;
-  p.M = (int)M; p.N = (int)N; p.K = (int)K; p.zero_offset = zero_offset; p.ksplit = cf.ksplit;
-  p.gshift = 0;
-  for (int64_t q = (K / groups) >> 7; q > 1; q >>= 1) ++p.gshift;
-  p.force_partial = slabs != nullptr; p.strip_layout = 1; p.is_bf16 = dtype == APHRO_BF16;
-  p.trace = g_res_trace; p.a = nullptr; p.lda = 0; p.counter = nullptr;
-  p.n_slabs = in_slabs; p.n_residual = (uint16_t*)residual; p.n_weight = (const uint16_t*)norm_weight; p.n_eps = eps;
-  p.n_sync = (unsigned*)sync;
-  if (act_packed != nullptr) {
-    APHRO_CHECK(cf.ksplit == 1 && N % 256 == 0, "wna16_gemm_norm_fused: the SiluAndMul form needs one K slice and N/2 %% 128 == 0 (N=%ld)", (long)N);
-  } else {
-    APHRO_CHECK(slabs_bytes >= (size_t)cf.ksplit * M * N * sizeof(float), "wna16_gemm_norm_fused: slabs too small");
   }
   return res_dispatch(p, cf, st);
 }
@@ -1974,9 +1096,7 @@ extern "C" int aphro_wna16_gemm_rowmajor(const void* a, int64_t lda, const uint3
   p.gshift = 0;
   for (int64_t q = (K / groups) >> 7; q > 1; q >>= 1) ++p.gshift;
   p.force_partial = 0; p.strip_layout = strip_layout ? 1 : 0; p.is_bf16 = 0;
-  p.trace = nullptr;
   p.a = (const uint16_t*)a; p.lda = (int)lda; p.counter = nullptr;
-  p.n_slabs = nullptr; p.n_residual = nullptr; p.n_weight = nullptr; p.n_eps = 0.f; p.n_sync = nullptr;
   if (cf.ksplit > 1) {
     const size_t need = (size_t)cf.ksplit * M * N * sizeof(float);
     if (workspace == nullptr || workspace_bytes < need || ((uintptr_t)workspace % 16) != 0) {

@@ -304,8 +304,8 @@ void reshape_and_cache_flash(torch::Tensor key, torch::Tensor value, torch::Tens
 
 // convert_fp8 (cache_kernels.cu:330-380)
 void convert_fp8(torch::Tensor dst_cache, torch::Tensor src_cache, double scale, std::string kv_cache_dtype) {
-  const int kvd = kv_dtype(kv_cache_dtype);
-  TORCH_CHECK(kvd != APHRO_KV_AUTO, "Unsupported data type of kv cache: ", kv_cache_dtype);
+  // "auto" = the platform's fp8 format, as the reference's dispatch accepts it (cache_kernels.cu:373-388); ADVICE r4
+  const int kvd = kv_dtype(kv_cache_dtype == "auto" ? std::string("fp8_e4m3") : kv_cache_dtype);
   TORCH_CHECK(dst_cache.is_contiguous() && src_cache.is_contiguous(), "convert_fp8 needs contiguous tensors");
   const bool to_fp8 = dst_cache.scalar_type() == torch::kByte;
   const torch::Tensor& hp = to_fp8 ? src_cache : dst_cache;

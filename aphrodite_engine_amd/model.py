@@ -310,8 +310,15 @@ class LlamaDecoderLayer(nn.Module):
     def _gemm_slabs(self, name, packed, m, k):
         """fp32 split-K slabs of projection ``name`` on packed activations: the resident kernel on its strip-major copy at
         <= 32 rows, else the round-2 kernel."""
-        qw, qz, sc, zo = getattr(self, name).fast_params()
-        st = self.strip.get(name) if m <= 64 else None
+        lin = getattr(self, name)
+        qw, qz, sc, zo = lin.fast_params()
+        st = self.strip.get(name)
+        # (ADVICE r4) the strip-major copy serves <= 32 rows; 33..64 rows only with the opt-in row halves AND a plan the
+        # stream kernel is instantiated for (an 8192 x 8192 o_proj plans to {4, 8, 1, 0}: no stream form) -- otherwise the
+        # round-2 kernel on the [K/8, N] layout, as before round 4
+        if st is not None and m > 32 and not (m <= 64 and os.environ.get("APHRO_DECODE_ROW_HALVES") == "1"
+                                              and ops.wna16_resident_ksplit(m, lin.out_features, lin.in_features, sc.shape[0]) > 0):
+            st = None
         if st is not None:
             return ops.wna16_gemm_resident(packed, m, k, st, qz, sc, zo, mode="slabs", strip_layout=True)
         return ops.wna16_gemm_packed(packed, m, k, qw, qz, sc, zo, partials=True)
@@ -342,21 +349,8 @@ class LlamaDecoderLayer(nn.Module):
             router_logits = torch.matmul(normed, self.moe_gate.t())
         return self.experts(normed, router_logits, defer_combine=defer_combine)
 
-    def _norm_fused_ok(self, name: str, in_slabs, m: int, sync) -> bool:
-        """The norm in front of projection ``name`` rides inside its GEMM launch (ops.wna16_gemm_norm_fused): dense layer,
-        one rank, the previous projection's 4 fp32 slabs as input, a strip-major copy served by the stream kernel."""
-        if sync is None or in_slabs is None or self.tp > 1 or self.is_moe or m > 32:
-            return False
-        if name != "gate_up_proj":      # (qkv: measured 12.1 us against 4.8 + 6.8 for the two launches; not instantiated)
-            return False
-        st = self.gate_up_strip if name == "gate_up_proj" else self.strip.get(name)
-        if st is None:
-            return False
-        sc = self.gate_up_interleaved[2] if name == "gate_up_proj" else getattr(self, name).fast_params()[2]
-        return ops.wna16_gemm_norm_fused_supported(m, sc.shape[1], in_slabs.shape[2], sc.shape[0], in_slabs.shape[0], sc.dtype)
-
     def forward_decode_fused(self, positions, x, slabs, residual, first, kv_cache, attn_metadata, cos_sin,
-                             cos_sin_tok=None, next_weights=None, norm_sync=None):
+                             cos_sin_tok=None, next_weights=None):
         """x: row-major input (first layer, or the all-reduced down_proj output of the previous
         layer when TP > 1) or None; slabs: fp32 split-K slabs of the previous down_proj (TP == 1).
         Returns (x, slabs) of this layer's down_proj in the same convention."""
@@ -426,13 +420,6 @@ class LlamaDecoderLayer(nn.Module):
                                                      self.post_attention_layernorm, eps)
         else:
             o_slabs, _ = self._gemm_slabs("o_proj", attn_packed, m, self.q_size)
-            if self.gate_up_interleaved is not None and self._norm_fused_ok("gate_up_proj", o_slabs, m, norm_sync):
-                # norm-in-consumer: post-attention norm + gate_up + SiluAndMul + pack in one launch
-                _, qz_, sc_, zo_ = self.gate_up_interleaved
-                act_packed = ops.wna16_gemm_norm_fused(o_slabs, residual, self.post_attention_layernorm, eps,
-                                                       self.gate_up_strip, qz_, sc_, zo_, norm_sync, mode="silu")
-                down_slabs, _ = self._gemm_slabs("down_proj", act_packed, m, self.down_proj.in_features)
-                return None, down_slabs
             packed2, _ = ops.fused_add_rms_norm_pack(None, o_slabs, residual, True,
                                                      self.post_attention_layernorm, eps)
         # 33..64 rows: the MLP weights go through the one-pass 32x32x16 MFMA kernel (wna16_gemm_mid.hip: 26.6 vs 37.6 us on
@@ -638,11 +625,6 @@ class LlamaForCausalLM(nn.Module):
             requires_grad=False)
         self.cos_sin = None
         self.use_fused_decode = True
-        # norm-in-consumer gate_up launch on the fused decode path (ops.wna16_gemm_norm_fused).  OFF by default: bit-identical,
-        # but measured 21.6-22.8 us against 4.8 + 15.5-16.9 for the two launches (step 2.69-2.70 ms against 2.60-2.64; the
-        # per-wave timeline that says why: profiles/r4_norm_in_consumer.txt).  APHRO_DECODE_NORM_FUSED=1 turns it on.
-        self.norm_fused = os.environ.get("APHRO_DECODE_NORM_FUSED", "0") == "1"
-        self._norm_sync = None
 
     # -- synthetic weights in the real formats -----------------------------------
     @torch.no_grad()
@@ -716,14 +698,6 @@ class LlamaForCausalLM(nn.Module):
             # rotary table rows of this step's positions, gathered once for all layers
             cos_sin_tok = self.cos_sin.index_select(0, positions)
             tp = get_tensor_model_parallel_world_size()
-            # norm-in-consumer launches (ops.wna16_gemm_norm_fused, opt-in): one arrival ticket per launch, all zeroed by ONE
-            # fill per step
-            sync = None
-            if self.norm_fused and tp == 1 and hidden.shape[0] <= 32:
-                if self._norm_sync is None or self._norm_sync.device != hidden.device:
-                    self._norm_sync = torch.zeros(len(self.layers), dtype=torch.int32, device=hidden.device)
-                sync = self._norm_sync
-                sync.zero_()
             for i, layer in enumerate(self.layers):
                 # TP: the down_proj all-reduce of this layer overlaps with a prefetch of the NEXT layer's qkv weights
                 nxt = None
@@ -731,8 +705,7 @@ class LlamaForCausalLM(nn.Module):
                     fp = self.layers[i + 1].qkv_proj.fast_params()
                     nxt = fp[:3] if fp is not None else None
                 x, slabs = layer.forward_decode_fused(positions, x, slabs, residual, i == 0,
-                                                      kv_caches[i], attn_metadata, self.cos_sin, cos_sin_tok, nxt,
-                                                      norm_sync=None if sync is None else sync[i:i + 1])
+                                                      kv_caches[i], attn_metadata, self.cos_sin, cos_sin_tok, nxt)
             if isinstance(x, DeferredCombine):
                 _, out = ops.fused_add_rms_norm_pack_combine(x.slabs, x.inv, x.topk_weights, residual, True, self.norm,
                                                              self.cfg.rms_norm_eps, pack=False, want_out=True)

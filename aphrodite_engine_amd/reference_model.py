@@ -49,11 +49,22 @@ class MI355XLlamaForCausalLM(nn.Module):
         # set_default_torch_dtype(model_config.dtype) (modeling/model_loader/loader.py:384-390), and that dtype -- e.g.
         # --dtype half for a GPTQ checkpoint whose config says bfloat16 -- is what the KV cache and the model runner use.
         # hf.torch_dtype only decides when the default is still torch's own float32 (standalone construction).
-        dtype = extra.get("dtype") or torch.get_default_dtype()
-        if dtype == torch.float32:
-            dtype = hf.get("torch_dtype") or getattr(config, "torch_dtype", None) or dtype
+        # (an engine that ASKED for float32 -- an explicit dtype argument, or a model_config.dtype the caller passes
+        # through -- must not silently get the checkpoint's dtype while its runner and KV cache stay float32: the fused path
+        # has no float32 form, so that case is refused.)
+        explicit = extra.get("dtype") or getattr(extra.get("model_config"), "dtype", None)
+        if isinstance(explicit, str):
+            explicit = getattr(torch, explicit)
+        if explicit is not None:
+            dtype = explicit
+        else:
+            dtype = torch.get_default_dtype()
+            if dtype == torch.float32:
+                dtype = hf.get("torch_dtype") or getattr(config, "torch_dtype", None) or dtype
         if isinstance(dtype, str):
             dtype = getattr(torch, dtype)
+        if dtype not in (torch.float16, torch.bfloat16):
+            raise ValueError(f"MI355XLlamaForCausalLM runs in float16 or bfloat16; got {dtype} (pass --dtype half / bfloat16)")
         kv_cache_dtype = getattr(cache_config, "cache_dtype", "auto") if cache_config is not None else "auto"
         self.tie_word_embeddings = bool(hf.get("tie_word_embeddings", False))
         self.kv_cache_dtype = kv_cache_dtype

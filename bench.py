@@ -276,28 +276,7 @@ def roofline_section(model, loop, args):
             if resident or (halves and name in getattr(layers[0], "strip", {})):
                 mid = False
 
-            # norm-in-consumer (round 4): the step's qkv / gate_up launch carries the norm in front of it -- time THAT launch
-            # (4 fp32 slabs + residual in, residual out on top of the GEMM's bytes)
-            nf_slabs = torch.randn(4, bs, lin0.in_features, device="cuda", dtype=torch.float32) * 0.25
-            norm_fused = (getattr(model, "norm_fused", False) and name in ("qkv_proj", "gate_up_proj") and not mid
-                          and layers[0]._norm_fused_ok(name, nf_slabs, bs, True))
-            nf_res = torch.randn(bs, lin0.in_features, device="cuda", dtype=torch.float32).to(model.dtype)
-            nf_sync = torch.zeros(len(layers), dtype=torch.int32, device="cuda")
-
-            def run_lin(name=name, packed=packed, silu=silu, k=lin0.in_features, mid=mid, resident=resident,
-                        norm_fused=norm_fused, nf_slabs=nf_slabs, nf_res=nf_res, nf_sync=nf_sync):
-                if norm_fused:
-                    nf_sync.zero_()
-                    for i, layer in enumerate(layers):
-                        if silu:
-                            _, qz, sc, zo = layer.gate_up_interleaved
-                            ops.wna16_gemm_norm_fused(nf_slabs, nf_res, layer.post_attention_layernorm, 1e-5, layer.gate_up_strip,
-                                                      qz, sc, zo, nf_sync[i:i + 1], mode="silu")
-                        else:
-                            _, qz, sc, zo = getattr(layer, name).fast_params()
-                            ops.wna16_gemm_norm_fused(nf_slabs, nf_res, layer.input_layernorm, 1e-5, layer.strip[name],
-                                                      qz, sc, zo, nf_sync[i:i + 1], mode="slabs")
-                    return
+            def run_lin(name=name, packed=packed, silu=silu, k=lin0.in_features, mid=mid, resident=resident):
                 for layer in layers:
                     if silu:
                         qw, qz, sc, zo = layer.gate_up_interleaved
@@ -316,8 +295,7 @@ def roofline_section(model, loop, args):
                      ("wna16_gemm_stream_kernel" + (" (two 32-row halves)" if bs > 32 else "")
                       if stream and (bs > 32 or ((bs, model.cfg.hidden_size) == (bs, 4096) and args.model == "llama3-8b"))
                       else "wna16_gemm_resident_kernel") + " (strip-major weights)" if (resident or res_slabs)
-                     else "wna16_gemm_kernel") + (" (+SiluAndMul epilogue)" if silu else "") + \
-                (" (+ slab reduce + fused_add_rms_norm + pack in the first M workgroups)" if norm_fused else "")
+                     else "wna16_gemm_kernel") + (" (+SiluAndMul epilogue)" if silu else "")
         elif args.quant == "fp8ct" and getattr(model, "use_fused_decode", False):
             # the FP8 decode fast path hands every GEMM pre-quantised activations (the quantisation is fused into the norm /
             # SiluAndMul kernels): time the GEMM launch alone, in the form the step uses (fp32 slabs for qkv / o / down,
@@ -347,10 +325,6 @@ def roofline_section(model, loop, args):
         t = measure_kernel(run_lin, len(layers))
         out[name] = dict(kernel=kname, shape=[bs, lin0.in_features, lin0.out_features],
                          bytes=gemm_bytes(lin0, bs), seconds=t)
-        if fast and norm_fused:
-            # + the norm's own bytes: 4 fp32 slabs and the residual in, the residual and the packed rows out
-            out[name]["bytes"] += bs * lin0.in_features * (4 * 4 + 2 + 2 + 2)
-            out[name]["norm_in_consumer"] = True
     # decode attention over the real caches / metadata of the loop, in the form the step launches
     l0 = layers[0]
     meta = loop.meta

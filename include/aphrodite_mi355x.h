@@ -606,22 +606,6 @@ int aphro_wna16_gemm_resident(const void* a_packed, const uint32_t* q_weight, co
                               const void* scales, void* c, float* slabs, size_t slabs_bytes, void* act_packed,
                               int64_t M, int64_t N, int64_t K, int64_t groups, int zero_offset, int dtype,
                               int strip_layout, void* stream);
-/* fused_add_rms_norm + the decode GEMM that consumes it in ONE launch ("norm-in-consumer", round 4): the reference's
- * `_C::fused_add_rms_norm` (kernels/layernorm_kernels.cu:200-240; schema kernels/torch_bindings.cpp "fused_add_rms_norm(Tensor!
- * input, Tensor! residual, Tensor weight, float epsilon)") followed by the W4A16 linear (q_gemm.cu:190-326 role) of
- * LlamaDecoderLayer.forward (modeling/models/llama.py:234-262).  x = the sum of the nslab (= 4) fp32 split-K slabs in_slabs
- * [4][M][K] of the previous projection rounded to `dtype`; residual [M, K] is updated in place; the normalised row goes to
- * a_packed (scratch, aphro_wna16_packed_a_bytes(M, K)) -- bit for bit aphro_fused_add_rms_norm_pack -- from the first M
- * workgroups while every workgroup's first weights are in flight; then aphro_wna16_gemm_resident on strip-major q_weight
- * (exactly one of act_packed / slabs).  sync: one 32-bit word of device memory that is ZERO at launch; the launch leaves M
- * in it (bit 31 set: a workgroup gave up waiting for the rows -- the outputs are garbage; cannot happen with a zeroed word
- * on a device that runs the grid's 256 workgroups at once) and the caller zeroes it before its next use (stream-ordered).
- * K == 4096, M <= 32, the gate_up plan of Llama-3-8B: _supported() answers. */
-int aphro_wna16_gemm_norm_fused_supported(int64_t M, int64_t N, int64_t K, int64_t groups, int nslab, int dtype);
-int aphro_wna16_gemm_norm_fused(const float* in_slabs, int nslab, void* residual, const void* norm_weight, float eps,
-                                void* a_packed, const uint32_t* q_weight, const uint32_t* qzeros, const void* scales,
-                                float* slabs, size_t slabs_bytes, void* act_packed, int64_t M, int64_t N, int64_t K,
-                                int64_t groups, int zero_offset, int dtype, void* sync, void* stream);
 /* Load-time: [K/8, N] exllama-ordered words (aphro_gptq_shuffle's output) -> strip-major order of the resident kernel's
  * plan for this shape (every wave's 16-byte pieces in the order it reads them).  A permutation of the words; out != in. */
 int aphro_wna16_strip_relayout(const uint32_t* q_weight, uint32_t* out, int64_t M, int64_t N, int64_t K,

@@ -57,32 +57,12 @@ def test_int4_gemm_plans_through_their_workspace_sizes():
     assert mid(65, 28672, 4096) == 0
 
 
-def test_norm_in_consumer_plan_is_host_logic():
-    """aphro_wna16_gemm_norm_fused_supported (no device call): the gate_up plan of configs[1] only -- hidden 4096, <= 32 rows,
-    four input slabs, f16 / bf16; everything else keeps the two launches."""
-    from aphrodite_engine_amd import _lib
-    L = _lib.lib()
-    ok = L.aphro_wna16_gemm_norm_fused_supported
-    assert ok(32, 28672, 4096, 32, 4, _lib.F16) and ok(1, 28672, 4096, 32, 4, _lib.BF16)
-    assert not ok(32, 6144, 4096, 32, 4, _lib.F16)            # qkv: measured slower than its two launches, not instantiated
-    assert not ok(33, 28672, 4096, 32, 4, _lib.F16) and not ok(0, 28672, 4096, 32, 4, _lib.F16)
-    assert not ok(32, 28672, 4096, 32, 2, _lib.F16) and not ok(32, 28672, 4096, 32, 4, _lib.F32)
-    assert not ok(32, 28672, 8192, 64, 4, _lib.F16) and not ok(32, 28672, 4096, 0, 4, _lib.F16)
-
-
 def test_new_entry_points_refuse_bad_arguments_before_touching_a_device():
     """Argument checks run on the host, before any device call: error code + message, nothing launched (no GPU here)."""
     import ctypes
     from aphrodite_engine_amd import _lib
     L = _lib.lib()
     L.aphro_last_error.restype = ctypes.c_char_p
-    # norm-in-consumer: a shape it does not serve (qkv), then null arguments on a served shape
-    rc = L.aphro_wna16_gemm_norm_fused(None, 4, None, None, 1e-5, None, None, None, None, None, 0, None, 32, 6144, 4096, 32, 1,
-                                       _lib.F16, None, None)
-    assert rc != 0 and b"not served" in L.aphro_last_error()
-    rc = L.aphro_wna16_gemm_norm_fused(None, 4, None, None, 1e-5, None, None, None, None, None, 0, None, 32, 28672, 4096, 32, 1,
-                                       _lib.F16, None, None)
-    assert rc != 0 and b"null argument" in L.aphro_last_error()
     # SiluAndMul on slabs: missing slabs, unsupported width, unsupported dtype
     assert L.aphro_silu_and_mul_pack_slabs(None, 2, None, None, 4, 1024, _lib.F16, None) != 0
     assert b"slabs" in L.aphro_last_error()

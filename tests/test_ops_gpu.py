@@ -9,6 +9,8 @@ oracle on the same seeded inputs.  Bars:
   * paged attention: atol 1e-3 (fp8 KV 1e-2), tests/kernels/test_attention.py:318-326;
   * scaled_mm: rtol 1e-2 atol 5e-2 (tests/kernels/test_cutlass.py:78).
 """
+import zlib
+
 import numpy as np
 import pytest
 import torch
@@ -752,21 +754,23 @@ def test_gptq_marlin_gemm_role(ops, has_zp, M):
     np.testing.assert_allclose(got, ref, rtol=2e-3, atol=2e-3 * np.abs(ref).max())
 
 
-@pytest.mark.parametrize("kind", ["fp8", "fp8_e5m2"])
+@pytest.mark.parametrize("kind", ["fp8", "fp8_e5m2", "auto"])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_convert_fp8_round_trip(ops, kind, dtype):
+    """("auto" is accepted like the reference's dispatch does, cache_kernels.cu:373-388: the platform's fp8 format, e4m3.)"""
     rng = np.random.default_rng(12)
     src = t(((rng.random((4, 2, 8, 16, 8)) - 0.5) * 6).astype(np.float32), dtype)
     q = torch.empty(src.shape, dtype=torch.uint8, device=DEV)
     ops.convert_fp8(q, src, 0.5, kind)
+    okind = "fp8" if kind == "auto" else kind
     np.testing.assert_array_equal(q.cpu().numpy(),
-                                  of8.kv_quant(src.float().cpu().numpy(), 0.5, kind))
+                                  of8.kv_quant(src.float().cpu().numpy(), 0.5, okind))
     back = torch.empty_like(src)
     ops.convert_fp8(back, q, 0.5, kind)
-    ref = torch.from_numpy(of8.kv_dequant(q.cpu().numpy(), 0.5, kind)).to(dtype)
+    ref = torch.from_numpy(of8.kv_dequant(q.cpu().numpy(), 0.5, okind)).to(dtype)
     assert torch.equal(back.cpu(), ref)
     # the reference's own (loose) pin: tests/kernels/test_cache.py:408-433
-    torch.testing.assert_close(back.float(), src.float(), atol=1e-3 if kind == "fp8" else 1e-3, rtol=0.26)
+    torch.testing.assert_close(back.float(), src.float(), atol=1e-3, rtol=0.26)
 
 
 ATT_CASES = [
@@ -789,7 +793,8 @@ ATT_CASES = [
 @pytest.mark.parametrize("use_alibi", [False, True])
 def test_paged_attention(ops, case, version, kv_cache_dtype, dtype, use_alibi):
     num_seqs, Hq, Hkv, D, BS, max_len = case
-    rng = np.random.default_rng(hash((case, version)) % 2 ** 31)
+    # (stable across processes: hash() of a tuple holding a str is salted per interpreter -- VERDICT r4)
+    rng = np.random.default_rng(zlib.crc32(repr((case, version)).encode()))
     seq_lens = rng.integers(1, max_len + 1, size=num_seqs).astype(np.int32)
     seq_lens[-1] = max_len
     if num_seqs > 2:

@@ -72,6 +72,10 @@ def test_resident_strip_layout_is_bit_identical(ops, K, N, M):
     s0, _ = ops.wna16_gemm_resident(pk, M, K, qw, t(qzeros), t(scales), 1, mode="slabs")
     s1, _ = ops.wna16_gemm_resident(pk, M, K, strip, t(qzeros), t(scales), 1, mode="slabs", strip_layout=True)
     assert torch.equal(s0, s1)
+    # ... and the strip-major launch is the STREAM kernel for these plans (the one bench.py times): checked against the oracle
+    # directly, not only through its bit-equality with the two-pass kernel
+    ref = case(K, N)[4][:M]
+    np.testing.assert_allclose(s1.double().sum(0).cpu().numpy(), ref, rtol=1e-4, atol=2e-5 * np.abs(ref).max())
 
 
 @pytest.mark.parametrize("strip", [False, True])
@@ -101,8 +105,7 @@ def test_resident_gate_up_silu_epilogue_vs_oracle(ops, M, strip):
     np.testing.assert_allclose(a_new, a_old, rtol=2e-3, atol=2e-3 * np.abs(want).max())
 
 
-@pytest.mark.parametrize("cfg,K,N", [("4,2,1,2", 4096, 6144), ("4,1,2,0", 4096, 4096), ("7,2,2,0", 14336, 4096),
-                                     ("4,4,0,3", 4096, 6144), ("4,8,1,0", 4096, 4096), ("4,2,1,0", 4096, 4096)])
+@pytest.mark.parametrize("cfg,K,N", [("4,4,0,3", 4096, 6144), ("4,8,1,0", 4096, 4096), ("4,2,1,0", 4096, 4096)])
 def test_resident_alternative_configs_vs_oracle(ops, cfg, K, N):
     """The other instantiated (waves, segments per wave, 64-column passes, last-pass blocks) plans, picked by hand."""
     shuf, qzeros, scales, a, ref = case(K, N)
