@@ -1955,6 +1955,58 @@ def init_custom_ar(meta: torch.Tensor, rank_data: torch.Tensor, handles: List, o
     return fa.value
 
 
+def init_custom_ar_loopback(meta: torch.Tensor, rank_data: torch.Tensor, world: int) -> int:
+    """A LOOPBACK communicator (aphro_custom_ar_init_loopback): ``world`` ranks that all resolve to this process's
+    buffers -- the timing rig of ``bench.py --sim-tp`` (one rank of a TP group on a one-GPU box runs the real
+    all-reduce kernels on local memory).  ``meta`` as in init_custom_ar."""
+    import ctypes
+    _require_cuda(meta, rank_data)
+    ms = meta_size()
+    if meta.numel() * meta.element_size() <= ms:
+        raise ValueError("meta must hold the signal area and the two-shot scratch (meta_size() + max_size bytes)")
+    scratch_bytes = (meta.numel() * meta.element_size() - ms) // 16 * 16
+    fa = ctypes.c_void_p()
+    check(_lib.lib().aphro_custom_ar_init_loopback(
+        ctypes.byref(fa), meta.data_ptr(), meta.data_ptr() + ms, scratch_bytes, rank_data.data_ptr(),
+        rank_data.numel() * rank_data.element_size(), world), "init_custom_ar_loopback")
+    _custom_ar_live[fa.value] = (meta, rank_data)
+    return fa.value
+
+
+def should_one_shot(world: int, nbytes: int) -> bool:
+    """The peer-access all-reduce's one-shot (every rank sums all inputs) vs two-shot choice at this message size."""
+    return _lib.lib().aphro_custom_ar_should_one_shot(world, nbytes) != 0
+
+
+def custom_ar_fused_norm_one_shot(world: int, tokens: int, hidden: int, esz: int = 2) -> bool:
+    """True when custom_ar_fused_add_rms_norm runs its one-shot form at this size (every rank ends with the whole
+    residual); False = reduce-scatter by token row (see ``shard_residual`` there)."""
+    return _lib.lib().aphro_custom_ar_fused_norm_one_shot(world, tokens, hidden, esz) != 0
+
+
+def custom_ar_fused_add_rms_norm(fa: int, inp: torch.Tensor, residual: Optional[torch.Tensor], has_residual: bool,
+                                 weight: torch.Tensor, epsilon: float, pack: bool = True, want_out: bool = False,
+                                 shard_residual: bool = False, reg_buffer: Optional[torch.Tensor] = None):
+    """tensor_model_parallel_all_reduce(inp) -> fused_add_rms_norm(residual) [-> pack] in ONE launch
+    (modeling/layers/linear.py:1142-1143 followed by models/llama.py's layernorm call): the bits of all_reduce_reg /
+    all_reduce_unreg followed by fused_add_rms_norm_pack.  Returns (packed or None, out or None); ``residual`` is
+    updated in place.  ``inp`` [tokens <= 64, hidden] must be registered (or ``reg_buffer`` given, or the stream capturing)."""
+    _require_cuda(inp, weight)
+    if inp.dim() != 2 or not inp.is_contiguous() or inp.dtype != weight.dtype or inp.dtype not in (torch.float16, torch.bfloat16):
+        raise RuntimeError("custom_ar_fused_add_rms_norm: inp must be a contiguous [tokens, hidden] f16 / bf16 tensor of the weight's dtype")
+    tokens, hidden = inp.shape
+    lib = _lib.lib()
+    packed = torch.empty(lib.aphro_wna16_packed_a_bytes(tokens, hidden) // 2, dtype=torch.float16,
+                         device=inp.device) if pack else None
+    out = torch.empty((tokens, hidden), dtype=weight.dtype, device=inp.device) if want_out else None
+    check(lib.aphro_custom_ar_fused_add_rms_norm(
+        fa, inp.data_ptr(), _ptr(residual), 1 if has_residual else 0, weight.data_ptr(), float(epsilon), _ptr(packed),
+        _ptr(out), tokens, hidden, _dt(weight), 1 if shard_residual else 0, _ptr(reg_buffer),
+        reg_buffer.numel() * reg_buffer.element_size() if reg_buffer is not None else 0, _stream()),
+        "custom_ar_fused_add_rms_norm")
+    return packed, out
+
+
 def _ar_check_io(inp: torch.Tensor, out: torch.Tensor):
     _require_cuda(inp, out)
     if inp.dtype != out.dtype or inp.numel() != out.numel():

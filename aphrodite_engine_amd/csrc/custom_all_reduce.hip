@@ -22,7 +22,18 @@
 //    hold bit-identical results, which the greedy-decode parity tests rely on;
 //  * barriers spin a bounded number of times and then raise an error word the host can read
 //    (aphro_custom_ar_error) instead of hanging the GPU;
-//  * per-block call counters live on the device, so a captured launch replays correctly in a HIP graph.
+//  * per-block call counters live on the device, so a captured launch replays correctly in a HIP graph;
+//  * the sum is followed, in every decoder layer, by residual add + RMSNorm (+ the pack of the next GEMM's A operand):
+//    aphro_custom_ar_fused_add_rms_norm runs them in the all-reduce launch.  One-shot sizes:
+//    one workgroup per token reads the token's row from every rank and finishes the norm on it.  Two-shot sizes: the
+//    reduce-scatter is BY TOKEN ROW -- rank r sums, adds the residual to and normalises rows [r R, (r + 1) R), publishes
+//    the normalised rows, and everybody gathers the other ranks' rows: the norm is computed once per row instead of
+//    `world` times, the gather moves what the next GEMM reads, and the residual may stay sharded by row between the
+//    layers (nobody but the owner of a row ever reads its residual again).  Bits: those of all_reduce followed by
+//    aphro_fused_add_rms_norm_pack;
+//  * a LOOPBACK communicator (aphro_custom_ar_init_loopback) runs the same kernels with every "peer" pointing at this
+//    rank's own buffers: bench.py --sim-tp times one rank of a TP group on a one-GPU box with the real instruction
+//    stream, flags and scratch traffic (local memory instead of links), not a stream-holding stub.
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -59,6 +70,9 @@ struct ArParams {
   int64_t nvec;                         // 16-byte vectors
   int64_t timeout_ticks;                // a barrier waits this long for a peer, then raises `error`
   int rank, world;
+  int loopback;                         // every peer is this rank itself (one-GPU timing rig): flags go to the own columns
+  int use_inline;                       // loopback: the input table travels in the kernel arguments (capture-safe)
+  ArPeers in_inline;
 };
 
 __device__ __forceinline__ void st_sys(uint32_t* p, uint32_t v) {
@@ -90,7 +104,8 @@ __device__ __forceinline__ void ar_barrier(const ArParams& p, int which, uint32_
     const int r = threadIdx.x;
     ArSignal* peer = p.sig[r];
     ArSignal* self = p.sig[p.rank];
-    uint32_t* dst = which == 0 ? &peer->start[b][p.rank] : which == 1 ? &peer->mid[b][p.rank] : &peer->end[b][p.rank];
+    const int col = p.loopback ? r : p.rank;
+    uint32_t* dst = which == 0 ? &peer->start[b][col] : which == 1 ? &peer->mid[b][col] : &peer->end[b][col];
     const uint32_t* src = which == 0 ? &self->start[b][r] : which == 1 ? &self->mid[b][r] : &self->end[b][r];
     st_sys(dst, val);
     const int64_t t0 = (int64_t)wall_clock64();
@@ -184,7 +199,7 @@ __global__ __launch_bounds__(AR_THREADS) void ar_one_shot_kernel(ArParams p) {
   __syncthreads();
   const uint32_t val = ticket;
   ar_barrier(p, 0, val);                                  // every peer's input is in place
-  const ArPeers in = *p.in;
+  const ArPeers in = p.use_inline ? p.in_inline : *p.in;
   for (int64_t i = (int64_t)blockIdx.x * AR_THREADS + threadIdx.x; i < p.nvec; i += (int64_t)gridDim.x * AR_THREADS)
     ((u32x4*)p.out)[i] = reduce_vec<T, WORLD>(in, i);
   ar_barrier(p, 2, val);                                  // nobody still reads my input when I return
@@ -203,7 +218,7 @@ __global__ __launch_bounds__(AR_THREADS) void ar_two_shot_kernel(ArParams p) {
   const int64_t part = (p.nvec + WORLD - 1) / WORLD;
   const int64_t lo = part * p.rank, hi = lo + part < p.nvec ? lo + part : p.nvec;
   ar_barrier(p, 0, val);
-  const ArPeers in = *p.in;
+  const ArPeers in = p.use_inline ? p.in_inline : *p.in;
   u32x4* mine = (u32x4*)p.scratch.ptr[p.rank];
   for (int64_t i = lo + (int64_t)blockIdx.x * AR_THREADS + threadIdx.x; i < hi; i += (int64_t)gridDim.x * AR_THREADS) {
     const u32x4 s = reduce_vec<T, WORLD>(in, i);
@@ -218,6 +233,232 @@ __global__ __launch_bounds__(AR_THREADS) void ar_two_shot_kernel(ArParams p) {
     const u32x4* theirs = (const u32x4*)p.scratch.ptr[r];
     for (int64_t i = rlo + (int64_t)blockIdx.x * AR_THREADS + threadIdx.x; i < rhi; i += (int64_t)gridDim.x * AR_THREADS) {
       ((u32x4*)p.out)[i] = ld_peer(theirs + i);
+    }
+  }
+  ar_barrier(p, 2, val);
+}
+
+
+// ---------------------------------------------------------------------------------------------------
+// all-reduce + residual add + RMSNorm (+ pack) in one launch.  Arithmetic = ar_*_kernel followed by
+// add_rms_norm_pack_kernel (fused_decode.hip) on its `input` path: x = round_T(sum over ranks, fp32, rank order);
+// residual' = round_T(x + residual); y = round_T(round_T(residual' * rstd) * w); same thread -> element mapping, same
+// block size and the same reduction order as that kernel, so the bits agree.
+struct ArNormParams {
+  ArParams ar;
+  uint16_t* residual;                   // [tokens, hidden] T, updated in place (may be null when !has_residual)
+  const uint16_t* weight;               // [hidden] T
+  uint16_t* packed;                     // fragment-major f16 A operand of the next GEMM, or null
+  uint16_t* out;                        // row-major [tokens, hidden] T, or null
+  float eps;
+  int has_residual;
+  int tokens, hidden;
+  int rows_per_rank;                    // two-shot: ceil(tokens / world)
+  int replicate_residual;               // two-shot: every rank ends with the whole residual (else: owners' rows only)
+};
+
+__device__ __forceinline__ float ar_block_sum(float v, float* red) {      // == block_sum_f of fused_decode.hip
+  v = wave_sum(v);
+  const int nw = blockDim.x >> 6;
+  if (nw == 1) return v;
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int w = 0; w < nw; ++w) t += red[w];
+  __syncthreads();
+  return t;
+}
+__device__ __forceinline__ size_t ar_packed_chunk(int row, int k, int mtiles) {   // == packed_chunk of fused_decode.hip
+  const int seg = k >> 7, g = (k & 127) >> 5, u = (k & 31) >> 3;
+  const int mt = row >> 4;
+  return ((((size_t)seg * 4 + u) * mtiles + mt) * 64 + g * 16 + (row & 15)) * 8;
+}
+template <typename T>
+__device__ __forceinline__ uint16_t ar_to_f16_bits(uint16_t tbits) {
+  if constexpr (__is_same(T, Half)) return tbits;
+  else return bf16_bits_to_f16_bits_sat(tbits);
+}
+
+// One row of the norm on the block: xs[it] = the T-rounded sums of this thread's (up to) two 8-element chunks.  Returns
+// the normalised chunks in y[it]; writes residual' to `res_row` (if non-null) and, when `res_pub` is non-null, to that
+// second place too (the two-shot scratch).
+template <typename T>
+__device__ __forceinline__ void ar_norm_row(const u32x4 (&xs)[2], const uint16_t* __restrict__ res_in, uint16_t* res_row,
+                                            uint16_t* res_pub, const u16x8 (&wv)[2], int nv, int hidden, float eps,
+                                            float* red, u16x8 (&y)[2]) {
+  float v[2][8];
+  float ss = 0.f;
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int i = threadIdx.x + it * blockDim.x;
+    if (i < nv) {
+      const u16x8 a = __builtin_bit_cast(u16x8, xs[it]);
+      u16x8 rs;
+      if (res_in) {
+        const u16x8 r = *reinterpret_cast<const u16x8*>(res_in + 8 * i);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          rs[j] = T::from_f32(T::to_f32(a[j]) + T::to_f32(r[j]));
+          v[it][j] = T::to_f32(rs[j]);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          rs[j] = a[j];
+          v[it][j] = T::to_f32(a[j]);
+        }
+      }
+      if (res_row) *reinterpret_cast<u16x8*>(res_row + 8 * i) = rs;
+      if (res_pub) *reinterpret_cast<u16x8*>(res_pub + 8 * i) = rs;
+      {
+        // squares rounded, then added (what hipcc emits for add_rms_norm_pack_kernel's input path: v_pk_mul_f32 + adds)
+#pragma clang fp contract(off)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ss += v[it][j] * v[it][j];
+      }
+    }
+  }
+  ss = ar_block_sum(ss, red);
+  const float inv = __frsqrt_rn(ss / (float)hidden + eps);
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int i = threadIdx.x + it * blockDim.x;
+    if (i < nv) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        y[it][j] = T::from_f32(T::to_f32(from_f32_exact<T>(v[it][j] * inv)) * T::to_f32(wv[it][j]));
+    }
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ void ar_norm_emit(const ArNormParams& q, int row, int i, u16x8 y) {
+  if (q.out) *reinterpret_cast<u16x8*>(q.out + (size_t)row * q.hidden + 8 * i) = y;
+  if (q.packed) {
+    u16x8 yh;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) yh[j] = ar_to_f16_bits<T>(y[j]);
+    *reinterpret_cast<u16x8*>(q.packed + ar_packed_chunk(row, 8 * i, (q.tokens + 15) >> 4)) = yh;
+  }
+}
+
+template <typename T, int WORLD>
+__global__ __launch_bounds__(1024) void ar_norm_one_shot_kernel(ArNormParams q) {
+  __shared__ uint32_t ticket;
+  __shared__ float red[16];
+  const ArParams& p = q.ar;
+  if (threadIdx.x == 0) {
+    ArSignal* self = p.sig[p.rank];
+    ticket = self->counter[blockIdx.x] + 1;
+    self->counter[blockIdx.x] = ticket;
+  }
+  const int tok = blockIdx.x;
+  const int nv = q.hidden >> 3;
+  u16x8 wv[2];                                             // norm weights: in flight across the barrier
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int i = threadIdx.x + it * blockDim.x;
+    if (i < nv) wv[it] = *reinterpret_cast<const u16x8*>(q.weight + 8 * i);
+  }
+  __syncthreads();
+  const uint32_t val = ticket;
+  ar_barrier(p, 0, val);                                   // every peer's input is in place
+  const ArPeers in = p.use_inline ? p.in_inline : *p.in;
+  u32x4 xs[2];
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int i = threadIdx.x + it * blockDim.x;
+    if (i < nv) xs[it] = reduce_vec<T, WORLD>(in, (int64_t)tok * nv + i);
+  }
+  uint16_t* res_row = q.residual ? q.residual + (size_t)tok * q.hidden : nullptr;
+  u16x8 y[2];
+  ar_norm_row<T>(xs, q.has_residual ? res_row : nullptr, res_row, nullptr, wv, nv, q.hidden, q.eps, red, y);
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int i = threadIdx.x + it * blockDim.x;
+    if (i < nv) ar_norm_emit<T>(q, tok, i, y[it]);
+  }
+  ar_barrier(p, 2, val);                                   // nobody still reads my input when I return
+}
+
+// Two-shot by rows.  Scratch of a rank: y rows [tokens][hidden] T, then (replicate_residual) residual' rows.
+template <typename T, int WORLD>
+__global__ __launch_bounds__(1024) void ar_norm_two_shot_kernel(ArNormParams q) {
+  __shared__ uint32_t ticket;
+  __shared__ float red[16];
+  const ArParams& p = q.ar;
+  if (threadIdx.x == 0) {
+    ArSignal* self = p.sig[p.rank];
+    ticket = self->counter[blockIdx.x] + 1;
+    self->counter[blockIdx.x] = ticket;
+  }
+  const int nv = q.hidden >> 3;
+  const int row = p.rank * q.rows_per_rank + (int)blockIdx.x;          // the row this workgroup owns
+  const bool own = row < q.tokens;
+  const size_t plane = (size_t)q.tokens * q.hidden;
+  u16x8 wv[2];
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int i = threadIdx.x + it * blockDim.x;
+    if (i < nv) wv[it] = *reinterpret_cast<const u16x8*>(q.weight + 8 * i);
+  }
+  __syncthreads();
+  const uint32_t val = ticket;
+  ar_barrier(p, 0, val);
+  const ArPeers in = p.use_inline ? p.in_inline : *p.in;
+  if (own) {                                               // (block-uniform)
+    u32x4 xs[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int i = threadIdx.x + it * blockDim.x;
+      if (i < nv) xs[it] = reduce_vec<T, WORLD>(in, (int64_t)row * nv + i);
+    }
+    uint16_t* mine = (uint16_t*)p.scratch.ptr[p.rank];
+    uint16_t* res_row = q.residual ? q.residual + (size_t)row * q.hidden : nullptr;
+    u16x8 y[2];
+    ar_norm_row<T>(xs, q.has_residual ? res_row : nullptr, res_row,
+                   q.replicate_residual ? mine + plane + (size_t)row * q.hidden : nullptr, wv, nv, q.hidden, q.eps, red, y);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int i = threadIdx.x + it * blockDim.x;
+      if (i < nv) {
+        *reinterpret_cast<u16x8*>(mine + (size_t)row * q.hidden + 8 * i) = y[it];   // uncached: through to memory
+        ar_norm_emit<T>(q, row, i, y[it]);
+      }
+    }
+  }
+  ar_barrier(p, 1, val);                                   // (waits for the write-through stores first)
+  // gather: one vector from every other rank's published rows, all loads in flight together (one per xGMI link)
+  const uint16_t* mine_c = (const uint16_t*)p.scratch.ptr[p.rank];
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int i = threadIdx.x + it * blockDim.x;
+    if (i < nv) {
+      ArPeers gy, gr;
+#pragma unroll
+      for (int r = 0; r < WORLD; ++r) {
+        const int prow = r * q.rows_per_rank + (int)blockIdx.x;
+        const bool valid = r != p.rank && prow < q.tokens;
+        const uint16_t* base = valid ? (const uint16_t*)p.scratch.ptr[r] + (size_t)prow * q.hidden : mine_c;   // (own slot: a harmless local read)
+        gy.ptr[r] = base + 8 * i;
+        gr.ptr[r] = base + (valid ? plane : 0) + 8 * i;
+      }
+      u32x4 yv[WORLD];
+      ld_peers<WORLD>(yv, gy, 0);
+#pragma unroll
+      for (int r = 0; r < WORLD; ++r) {
+        const int prow = r * q.rows_per_rank + (int)blockIdx.x;
+        if (r != p.rank && prow < q.tokens) ar_norm_emit<T>(q, prow, i, __builtin_bit_cast(u16x8, yv[r]));
+      }
+      if (q.replicate_residual && q.residual) {
+        ld_peers<WORLD>(yv, gr, 0);
+#pragma unroll
+        for (int r = 0; r < WORLD; ++r) {
+          const int prow = r * q.rows_per_rank + (int)blockIdx.x;
+          if (r != p.rank && prow < q.tokens)
+            *reinterpret_cast<u32x4*>(q.residual + (size_t)prow * q.hidden + 8 * i) = yv[r];
+        }
+      }
     }
   }
   ar_barrier(p, 2, val);
@@ -242,6 +483,7 @@ struct CustomAr {
   void* own_signal = nullptr;
   void* own_scratch = nullptr;
   int64_t timeout_ticks = 10000 * AR_TICKS_PER_MS;   // APHRODITE_CUSTOM_AR_TIMEOUT_MS, default 10 s
+  bool loopback = false;                             // aphro_custom_ar_init_loopback: every peer is this rank
 
   void* open_peer(const char* handle) {
     IpcKey k;
@@ -273,6 +515,40 @@ static int fill_peers(CustomAr* fa, const void* local, const char* handles, cons
       out->ptr[r] = base + offsets[r];
     }
   }
+  return APHRO_OK;
+}
+
+
+// Resolve the registered-buffer slot of `src` (or reserve one while the stream is capturing) and fill the fields every
+// kernel of this file needs.
+static int ar_fill_params(CustomAr* fa, const void* src, hipStream_t st, ArParams* p) {
+  memset(p, 0, sizeof(*p));
+  for (int r = 0; r < AR_MAX_RANKS; ++r) p->sig[r] = fa->sig[r];
+  p->scratch = fa->scratch;
+  p->rank = fa->rank; p->world = fa->world;
+  p->timeout_ticks = fa->timeout_ticks;
+  if (fa->loopback) {
+    p->loopback = 1; p->use_inline = 1;
+    for (int r = 0; r < AR_MAX_RANKS; ++r) p->in_inline.ptr[r] = src;
+    p->in = fa->d_slots;
+    return APHRO_OK;
+  }
+  int slot = -1;
+  auto it = fa->registered.find(src);
+  if (it != fa->registered.end()) {
+    slot = it->second;
+  } else {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(st, &cs);
+    if (cs != hipStreamCaptureStatusActive) {
+      set_error("custom_ar: buffer address %p is not registered!", src);
+      return APHRO_ERR_INVALID;
+    }
+    APHRO_CHECK(fa->slot_used + (int)fa->graph_unreg.size() < fa->slot_cap, "custom_ar: rank_data is full");
+    slot = fa->slot_used + (int)fa->graph_unreg.size();    // filled by register_graph_buffers
+    fa->graph_unreg.push_back(src);
+  }
+  p->in = fa->d_slots + slot;
   return APHRO_OK;
 }
 
@@ -391,6 +667,10 @@ extern "C" int aphro_custom_ar_register_buffer(void* fa_, const void* local_ptr,
 
 extern "C" int aphro_custom_ar_should_one_shot(int world, size_t bytes) {
   // one link transfer of `bytes` vs two transfers of bytes / world plus a second flag round trip
+  // (APHRO_CUSTOM_AR_ONE_SHOT_MAX=<bytes>: override, any world size -- the tests use it to reach the two-shot forms with
+  //  two ranks; must be the same on every rank)
+  static const long forced = [] { const char* e = getenv("APHRO_CUSTOM_AR_ONE_SHOT_MAX"); return e ? atol(e) : -1L; }();
+  if (forced >= 0) return bytes <= (size_t)forced;
   if (world <= 2) return 1;
   return bytes <= (world <= 4 ? 512u * 1024u : 256u * 1024u);
 }
@@ -416,28 +696,13 @@ extern "C" int aphro_custom_ar_all_reduce(void* fa_, const void* inp, void* out,
                 "custom_ar: staging copy failed");
     src = reg_buffer;
   }
-  int slot = -1;
-  auto it = fa->registered.find(src);
-  if (it != fa->registered.end()) {
-    slot = it->second;
-  } else {
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    (void)hipStreamIsCapturing(st, &cs);
-    if (cs != hipStreamCaptureStatusActive) {
-      set_error("custom_ar: buffer address %p is not registered!", src);
-      return APHRO_ERR_INVALID;
-    }
-    APHRO_CHECK(fa->slot_used + (int)fa->graph_unreg.size() < fa->slot_cap, "custom_ar: rank_data is full");
-    slot = fa->slot_used + (int)fa->graph_unreg.size();    // filled by register_graph_buffers
-    fa->graph_unreg.push_back(src);
-  }
+  ArParams p;
+  int rc = ar_fill_params(fa, src, st, &p);
+  if (rc != APHRO_OK) return rc;
   const bool one_shot = aphro_custom_ar_should_one_shot(fa->world, bytes) != 0;
   APHRO_CHECK(one_shot || bytes <= fa->scratch_bytes, "custom_ar: %zu bytes exceed the two-shot scratch", bytes);
-  ArParams p;
-  for (int r = 0; r < AR_MAX_RANKS; ++r) p.sig[r] = fa->sig[r];
-  p.in = fa->d_slots + slot; p.scratch = fa->scratch; p.out = out;
-  p.nvec = (int64_t)(bytes / 16); p.rank = fa->rank; p.world = fa->world;
-  p.timeout_ticks = fa->timeout_ticks;
+  p.out = out;
+  p.nvec = (int64_t)(bytes / 16);
   int64_t work = one_shot ? p.nvec : (p.nvec + fa->world - 1) / fa->world;
   int blocks = (int)((work + AR_THREADS - 1) / AR_THREADS);
   blocks = blocks < 1 ? 1 : (blocks > AR_MAX_BLOCKS ? AR_MAX_BLOCKS : blocks);
@@ -517,4 +782,105 @@ extern "C" int aphro_custom_ar_error(void* fa_) {
     (void)hipMemcpy(&s->error, &z, sizeof(z), hipMemcpyHostToDevice);
   }
   return (int)e;
+}
+
+// Loopback communicator for one-GPU timing (bench.py --sim-tp): `world` ranks that are all this process -- every signal
+// area, scratch region and input resolves to the local buffers, so each kernel of this file runs its real instruction
+// stream (flag writes / polls through uncached memory, `world` input reads per element, scratch round trip) with local
+// memory in place of the xGMI links.  The RESULT is the sum of `world` copies of the local input: timing only.
+extern "C" int aphro_custom_ar_init_loopback(void** fa_out, void* signal, void* scratch, size_t scratch_bytes,
+                                             void* rank_data, size_t rank_data_bytes, int world) {
+  APHRO_CHECK(fa_out && signal && scratch && rank_data, "custom_ar_init_loopback: NULL argument");
+  APHRO_CHECK(world >= 2 && world <= AR_MAX_RANKS && world % 2 == 0, "custom_ar: world size %d not in {2,4,6,8}", world);
+  APHRO_CHECK(rank_data_bytes >= sizeof(ArPeers) && scratch_bytes % 16 == 0, "custom_ar: bad buffer sizes");
+  CustomAr* fa = new CustomAr();
+  fa->rank = 0; fa->world = world; fa->loopback = true;
+  fa->own_signal = signal; fa->own_scratch = scratch; fa->scratch_bytes = scratch_bytes;
+  fa->d_slots = (ArPeers*)rank_data;
+  fa->slot_cap = (int)(rank_data_bytes / sizeof(ArPeers));
+  for (int r = 0; r < world; ++r) {
+    fa->sig[r] = (ArSignal*)signal;
+    fa->scratch.ptr[r] = scratch;
+  }
+  *fa_out = fa;
+  return APHRO_OK;
+}
+
+// 1 when aphro_custom_ar_fused_add_rms_norm will run the one-shot form for `tokens` x `hidden` elements of `esz` bytes
+// (every rank ends with the whole residual), 0 for the two-shot-by-rows form.
+extern "C" int aphro_custom_ar_fused_norm_one_shot(int world, int64_t tokens, int hidden, int esz) {
+  return aphro_custom_ar_should_one_shot(world, (size_t)tokens * hidden * esz);
+}
+
+// all_reduce(inp) -> fused_add_rms_norm(residual) [-> pack] in ONE launch: x = sum over the ranks of inp [tokens, hidden]
+// (rounded to the dtype, as the all-reduce returns it), residual' = x + residual (in place; has_residual = 0: residual'
+// = x, written if `residual` is given), y = rms_norm(residual') * weight -> `packed` (the W4A16 / FP8 decode GEMMs'
+// fragment-major f16 A operand, aphro_wna16_packed_a_bytes) and / or row-major `out`.  Same bits as
+// aphro_custom_ar_all_reduce followed by aphro_fused_add_rms_norm_pack (reference call sites: the row-parallel linear's
+// all-reduce, modeling/layers/linear.py:1142-1143, then models/llama.py's fused_add_rms_norm).
+// reg_buffer as in aphro_custom_ar_all_reduce.  shard_residual (two-shot sizes only, see
+// aphro_custom_ar_fused_norm_one_shot): 1 = a rank updates only the residual rows it owns, rows
+// [rank R, (rank + 1) R), R = ceil(tokens / world) -- valid while every later reader of the residual is this function
+// with the same tokens / world; 0 = the owners publish their residual rows and every rank ends with all of them.
+extern "C" int aphro_custom_ar_fused_add_rms_norm(void* fa_, const void* inp, void* residual, int has_residual,
+                                                  const void* weight, float eps, void* packed, void* out,
+                                                  int64_t tokens, int hidden, int dtype, int shard_residual,
+                                                  void* reg_buffer, size_t reg_buffer_bytes, void* stream) {
+  CustomAr* fa = (CustomAr*)fa_;
+  hipStream_t st = (hipStream_t)stream;
+  APHRO_CHECK(fa && inp && weight, "custom_ar_fused_add_rms_norm: NULL argument");
+  APHRO_CHECK(dtype == APHRO_F16 || dtype == APHRO_BF16, "custom_ar_fused_add_rms_norm: dtype must be f16 or bf16");
+  APHRO_CHECK(hidden % 8 == 0 && hidden > 0 && hidden <= 16384, "custom_ar_fused_add_rms_norm: hidden=%d unsupported", hidden);
+  APHRO_CHECK(packed == nullptr || hidden % 128 == 0, "custom_ar_fused_add_rms_norm: packing needs hidden %% 128 == 0");
+  APHRO_CHECK(!has_residual || residual != nullptr, "custom_ar_fused_add_rms_norm: residual missing");
+  APHRO_CHECK(packed != nullptr || out != nullptr, "custom_ar_fused_add_rms_norm: no output requested");
+  APHRO_CHECK(tokens >= 0 && tokens <= (int64_t)AR_MAX_BLOCKS, "custom_ar_fused_add_rms_norm: %lld tokens (at most %d: decode batches)",
+              (long long)tokens, AR_MAX_BLOCKS);
+  APHRO_CHECK(((uintptr_t)inp % 16) == 0, "custom_ar_fused_add_rms_norm: input must be 16-byte aligned");
+  if (tokens == 0) return APHRO_OK;
+  const size_t bytes = (size_t)tokens * hidden * 2;
+  const void* src = inp;
+  if (reg_buffer != nullptr) {
+    APHRO_CHECK(bytes <= reg_buffer_bytes, "custom_ar: registered buffer is too small (%zu > %zu)", bytes, reg_buffer_bytes);
+    APHRO_CHECK(hipMemcpyAsync(reg_buffer, inp, bytes, hipMemcpyDeviceToDevice, st) == hipSuccess,
+                "custom_ar: staging copy failed");
+    src = reg_buffer;
+  }
+  ArNormParams q;
+  memset(&q, 0, sizeof(q));
+  int rc = ar_fill_params(fa, src, st, &q.ar);
+  if (rc != APHRO_OK) return rc;
+  const bool one_shot = aphro_custom_ar_should_one_shot(fa->world, bytes) != 0;
+  const bool replicate = !one_shot && !shard_residual && residual != nullptr;
+  APHRO_CHECK(one_shot || bytes * (replicate ? 2 : 1) <= fa->scratch_bytes,
+              "custom_ar_fused_add_rms_norm: %zu bytes exceed the two-shot scratch", bytes * (replicate ? 2 : 1));
+  q.residual = (uint16_t*)residual; q.weight = (const uint16_t*)weight;
+  q.packed = (uint16_t*)packed; q.out = (uint16_t*)out;
+  q.eps = eps; q.has_residual = has_residual ? 1 : 0;
+  q.tokens = (int)tokens; q.hidden = hidden;
+  q.rows_per_rank = (int)((tokens + fa->world - 1) / fa->world);
+  q.replicate_residual = replicate ? 1 : 0;
+  // the block size of aphro_fused_add_rms_norm_pack (same thread -> element mapping, same reduction order)
+  int nv = hidden / 8, t = nv <= 1024 ? nv : (nv + 1) / 2;
+  t = (t + 63) / 64 * 64;
+  t = t < 64 ? 64 : (t > 1024 ? 1024 : t);
+  const int blocks = one_shot ? (int)tokens : q.rows_per_rank;
+#define ARN_LAUNCH(TT, W)                                                                              \
+  {                                                                                                    \
+    if (one_shot) hipLaunchKernelGGL((ar_norm_one_shot_kernel<TT, W>), dim3(blocks), dim3(t), 0, st, q); \
+    else hipLaunchKernelGGL((ar_norm_two_shot_kernel<TT, W>), dim3(blocks), dim3(t), 0, st, q);         \
+  }
+#define ARN_WORLD(TT)                                                                 \
+  switch (fa->world) {                                                               \
+    case 2: ARN_LAUNCH(TT, 2) break;                                                  \
+    case 4: ARN_LAUNCH(TT, 4) break;                                                  \
+    case 6: ARN_LAUNCH(TT, 6) break;                                                  \
+    default: ARN_LAUNCH(TT, 8) break;                                                 \
+  }
+  if (dtype == APHRO_F16) ARN_WORLD(Half)
+  else ARN_WORLD(BFloat)
+#undef ARN_WORLD
+#undef ARN_LAUNCH
+  APHRO_LAUNCH_CHECK();
+  return APHRO_OK;
 }

@@ -53,6 +53,17 @@ def init_simulated_tensor_parallel(tp_size: int, all_reduce_us, rank: int = 0) -
     _SIM_AR_US = all_reduce_us if isinstance(all_reduce_us, dict) else {1 << 62: float(all_reduce_us)}
 
 
+def enable_loopback_all_reduce(device, max_size: int = 8192 * 1024):
+    """Simulated TP only: replace the stream-holding stub by the REAL peer-access kernels on a loopback communicator
+    (distributed/custom_all_reduce.py: LoopbackAllreduce) -- flags, scratch and ``tp_size`` reads per element against
+    local memory.  The stub stays the fallback for sizes the kernel does not take."""
+    global _CUSTOM_AR
+    assert _SIM_AR_US is not None and _TP_SIZE > 1, "enable_loopback_all_reduce follows init_simulated_tensor_parallel"
+    from .custom_all_reduce import LoopbackAllreduce
+    _CUSTOM_AR = LoopbackAllreduce(_TP_SIZE, device, max_size)
+    return _CUSTOM_AR
+
+
 def destroy_tensor_parallel() -> None:
     global _TP_GROUP, _TP_RANK, _TP_SIZE, _CUSTOM_AR, _OVERLAP, _SIM_AR_US
     if _CUSTOM_AR is not None:
@@ -140,6 +151,10 @@ def tensor_model_parallel_all_reduce(input_: torch.Tensor, prefetch=None) -> tor
         return input_
     if _SIM_AR_US is not None:
         from .. import _lib
+        if _CUSTOM_AR is not None and input_.is_cuda:          # loopback communicator: the real kernel on local memory
+            out = _CUSTOM_AR.custom_all_reduce(input_)
+            if out is not None:
+                return out
         nbytes = input_.numel() * input_.element_size()
         us = next(v for k, v in sorted(_SIM_AR_US.items()) if nbytes <= k)
         _lib.check(_lib.lib().aphro_spin_us(float(us), torch.cuda.current_stream(input_.device).cuda_stream), "spin_us")
@@ -147,6 +162,55 @@ def tensor_model_parallel_all_reduce(input_: torch.Tensor, prefetch=None) -> tor
     if _OVERLAP is not None and input_.is_cuda:
         return _OVERLAP.all_reduce(_all_reduce_serial, input_, prefetch)
     return _all_reduce_serial(input_)
+
+
+def tensor_model_parallel_all_reduce_norm(input_: torch.Tensor, residual: Optional[torch.Tensor], has_residual: bool,
+                                         weight: torch.Tensor, epsilon: float, pack: bool = True, want_out: bool = False,
+                                         shard_residual: bool = False):
+    """The row-parallel linear's all-reduce (linear.py:1142-1143) and the fused_add_rms_norm [+ pack] that follows it in
+    every decoder layer as ONE launch of the peer-access kernel (csrc/custom_all_reduce.hip) -- the bits of
+    tensor_model_parallel_all_reduce -> ops.fused_add_rms_norm_pack.  Returns (packed, out), or None when the fused
+    form does not apply (no peer-access communicator, overlap mode, ineligible size): the caller then issues the two
+    ops.  ``shard_residual``: see CustomAllreduce.fused_norm_shards_residual."""
+    if _TP_SIZE == 1 or _CUSTOM_AR is None or _OVERLAP is not None or not input_.is_cuda:
+        return None
+    return _CUSTOM_AR.fused_add_rms_norm(input_, residual, has_residual, weight, epsilon, pack=pack, want_out=want_out,
+                                         shard_residual=shard_residual)
+
+
+class DeferredAllReduce:
+    """A row-parallel projection's per-rank partial sums [tokens, hidden] whose all-reduce has NOT been issued: the norm
+    that consumes them runs it in its own launch (``finish``).  ``shard_residual``: the by-row form may leave the
+    residual rows of other ranks untouched (dense decoder layers, where every reader of the residual is such a launch)."""
+
+    def __init__(self, partial: torch.Tensor, shard_residual: bool):
+        self.partial, self.shard_residual = partial, shard_residual
+
+    def finish(self, residual, weight, epsilon, pack=True, want_out=False):
+        res = tensor_model_parallel_all_reduce_norm(self.partial, residual, True, weight, epsilon, pack=pack,
+                                                    want_out=want_out, shard_residual=self.shard_residual)
+        assert res is not None, "the fused all-reduce + norm stopped applying between defer and finish"
+        return res
+
+
+def defer_all_reduce(partial: torch.Tensor, allow_shard_residual: bool = False) -> Optional["DeferredAllReduce"]:
+    """A DeferredAllReduce for ``partial`` when the fused all-reduce + norm launch serves it (peer-access communicator
+    attached, decode-sized [tokens <= 64, hidden] f16 / bf16, no side-stream overlap; APHRO_NO_FUSED_AR_NORM=1 opts
+    out), else None: the caller all-reduces now."""
+    import os
+    if (_TP_SIZE == 1 or _CUSTOM_AR is None or _OVERLAP is not None or not partial.is_cuda
+            or os.environ.get("APHRO_NO_FUSED_AR_NORM") == "1" or _CUSTOM_AR.disabled
+            or not _CUSTOM_AR.fused_norm_eligible(partial)):
+        return None
+    return DeferredAllReduce(partial, allow_shard_residual and _CUSTOM_AR.fused_norm_shards_residual(partial))
+
+
+def fused_all_reduce_norm_shards_residual(input_: torch.Tensor) -> bool:
+    """True if tensor_model_parallel_all_reduce_norm would run its by-row form on ``input_`` (and so may be asked to
+    keep the residual sharded by row)."""
+    if _TP_SIZE == 1 or _CUSTOM_AR is None or _OVERLAP is not None or not input_.is_cuda:
+        return False
+    return _CUSTOM_AR.fused_norm_eligible(input_) and _CUSTOM_AR.fused_norm_shards_residual(input_)
 
 
 def tensor_model_parallel_all_gather(input_: torch.Tensor, dim: int = -1) -> torch.Tensor:

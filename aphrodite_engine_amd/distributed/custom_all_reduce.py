@@ -181,6 +181,38 @@ class CustomAllreduce:
             self.check()                            # a timed-out barrier must not return garbage silently for long
         return out
 
+    # -- all-reduce + residual add + RMSNorm (+ pack) in one launch -------------------------------------
+    def fused_norm_eligible(self, inp: torch.Tensor) -> bool:
+        return (self.should_custom_ar(inp) and inp.dim() == 2 and inp.shape[0] <= 64 and inp.shape[1] % 8 == 0
+                and inp.shape[1] <= 16384 and inp.dtype in (torch.float16, torch.bfloat16) and inp.is_contiguous()
+                and 2 * inp.numel() * inp.element_size() <= self.max_size)
+
+    def fused_norm_shards_residual(self, inp: torch.Tensor) -> bool:
+        """True when the fused form at this size is the reduce-scatter by token row (a rank then owns rows
+        [rank R, (rank + 1) R), R = ceil(tokens / world), and ``shard_residual=True`` leaves the other rows alone)."""
+        return not self._ops.custom_ar_fused_norm_one_shot(self.world_size, inp.shape[0], inp.shape[1], inp.element_size())
+
+    def fused_add_rms_norm(self, inp: torch.Tensor, residual: Optional[torch.Tensor], has_residual: bool,
+                           weight: torch.Tensor, epsilon: float, pack: bool = True, want_out: bool = False,
+                           shard_residual: bool = False):
+        """custom_all_reduce(inp) followed by ops.fused_add_rms_norm_pack(out, None, residual, ...) in ONE launch, same
+        bits (csrc/custom_all_reduce.hip).  None = not eligible: the caller runs the two ops.  Returns (packed, out)."""
+        if self.disabled or not self.fused_norm_eligible(inp):
+            return None
+        kw = dict(pack=pack, want_out=want_out, shard_residual=shard_residual)
+        if self._IS_CAPTURING:
+            if torch.cuda.is_current_stream_capturing():
+                return self._ops.custom_ar_fused_add_rms_norm(self._ptr, inp, residual, has_residual, weight, epsilon, **kw)
+            # warm-up run before the capture: shapes only (as custom_all_reduce does)
+            return self._ops.fused_add_rms_norm_pack(torch.zeros_like(inp), None, None, False, weight, epsilon, pack=pack,
+                                                     want_out=want_out)
+        res = self._ops.custom_ar_fused_add_rms_norm(self._ptr, inp, residual, has_residual, weight, epsilon,
+                                                     reg_buffer=self.buffer, **kw)
+        self._calls += 1
+        if self._check_every > 0 and self._calls % self._check_every == 0:
+            self.check()
+        return res
+
     def check(self) -> None:
         """Raise if one of this rank's barriers timed out since the last call."""
         if not self.disabled and self._ops.custom_ar_error(self._ptr):
@@ -199,3 +231,57 @@ class CustomAllreduce:
             self.close()
         except Exception:
             pass
+
+
+class LoopbackAllreduce:
+    """ONE rank of a ``world_size`` TP group on a one-GPU box (bench.py --sim-tp): the CustomAllreduce surface over a
+    loopback communicator (ops.init_custom_ar_loopback) -- the all-reduce and fused all-reduce + norm kernels run their
+    real instruction stream, flag protocol and scratch traffic against this process's own buffers, so the launch costs
+    what the peer-access kernel costs with zero link time.  The sums are over ``world_size`` copies of the local partial:
+    timing only.  No process group, nothing to register, capturable as is."""
+
+    def __init__(self, world_size: int, device, max_size: int = 8192 * 1024) -> None:
+        from .. import _custom_ops as ops
+        self._ops = ops
+        self.device = torch.device(device)
+        self.rank, self.world_size, self.max_size = 0, world_size, max_size
+        self.disabled = False
+        self._IS_CAPTURING = False
+        with torch.cuda.device(self.device):
+            self.meta = ops.custom_ar_alloc_meta(ops.meta_size() + max_size, self.device)
+            self.rank_data = torch.empty(64 * 1024, dtype=torch.uint8, device=self.device)
+            self._ptr = ops.init_custom_ar_loopback(self.meta, self.rank_data, world_size)
+
+    should_custom_ar = CustomAllreduce.should_custom_ar
+    fused_norm_eligible = CustomAllreduce.fused_norm_eligible
+    fused_norm_shards_residual = CustomAllreduce.fused_norm_shards_residual
+
+    @contextmanager
+    def capture(self):
+        yield
+
+    def custom_all_reduce(self, input: torch.Tensor) -> Optional[torch.Tensor]:
+        if not self.should_custom_ar(input):
+            return None
+        out = torch.empty_like(input)
+        self._ops.all_reduce_reg(self._ptr, input, out)
+        return out
+
+    def fused_add_rms_norm(self, inp, residual, has_residual, weight, epsilon, pack=True, want_out=False,
+                           shard_residual=False):
+        if not self.fused_norm_eligible(inp):
+            return None
+        return self._ops.custom_ar_fused_add_rms_norm(self._ptr, inp, residual, has_residual, weight, epsilon, pack=pack,
+                                                      want_out=want_out, shard_residual=shard_residual)
+
+    def check(self) -> None:
+        if self._ptr and self._ops.custom_ar_error(self._ptr):
+            raise RuntimeError("loopback all-reduce: a barrier timed out")
+
+    def close(self) -> None:
+        if self._ptr:
+            torch.cuda.synchronize(self.device)
+            self._ops.dispose(self._ptr)
+            self._ptr = None
+            self.meta = None
+            self.disabled = True

@@ -21,7 +21,8 @@ from torch import nn
 from . import _custom_ops as ops
 from .attention.backend import MI355XAttentionImpl, MI355XAttentionMetadata
 from .moe import DeferredCombine
-from .distributed import (get_tensor_model_parallel_rank,
+from .distributed import (DeferredAllReduce, defer_all_reduce,
+                          get_tensor_model_parallel_rank,
                           get_tensor_model_parallel_world_size,
                           tensor_model_parallel_all_reduce)
 from .quantization.awq import AWQConfig
@@ -342,12 +343,13 @@ class LlamaDecoderLayer(nn.Module):
             (self.qkv_proj, self.o_proj, self.gate_up_proj, self.down_proj)
 
     def moe_block(self, normed: torch.Tensor, router_logits: Optional[torch.Tensor] = None,
-                  defer_combine: bool = False):
+                  defer_combine: bool = False, defer_all_reduce: bool = False):
         """router (fp16 library GEMM, [M, E], unless the norm kernel already produced the logits) + fused experts
         (+ TP all-reduce inside FusedMoE)."""
         if router_logits is None:
             router_logits = torch.matmul(normed, self.moe_gate.t())
-        return self.experts(normed, router_logits, defer_combine=defer_combine)
+        return self.experts(normed, router_logits, defer_combine=defer_combine,
+                            defer_all_reduce=defer_all_reduce and self.tp > 1)
 
     def forward_decode_fused(self, positions, x, slabs, residual, first, kv_cache, attn_metadata, cos_sin,
                              cos_sin_tok=None, next_weights=None):
@@ -360,6 +362,9 @@ class LlamaDecoderLayer(nn.Module):
         if isinstance(x, DeferredCombine):        # the previous layer's sparse MLP: combine inside this norm launch
             packed, _ = ops.fused_add_rms_norm_pack_combine(x.slabs, x.inv, x.topk_weights, residual, not first,
                                                             self.input_layernorm, eps)
+            qkv_slabs, _ = self._gemm_slabs("qkv_proj", packed, m, h)
+        elif isinstance(x, DeferredAllReduce):    # TP: the previous layer's last all-reduce runs inside this norm launch
+            packed, _ = x.finish(residual, self.input_layernorm, eps)
             qkv_slabs, _ = self._gemm_slabs("qkv_proj", packed, m, h)
         else:
             packed, _ = ops.fused_add_rms_norm_pack(x if slabs is None else None, slabs, residual,
@@ -395,7 +400,7 @@ class LlamaDecoderLayer(nn.Module):
                 if self.moe_gate.shape[0] <= 16 and not os.environ.get("APHRO_MOE_NO_NORM_ROUTER"):
                     normed, logits = ops.fused_add_rms_norm_router(o, None, residual, True,
                                                                    self.post_attention_layernorm, eps, self.moe_gate)
-                    return self.moe_block(normed, logits), None
+                    return self.moe_block(normed, logits, defer_all_reduce=True), None
                 _, normed = ops.fused_add_rms_norm_pack(o, None, residual, True, self.post_attention_layernorm,
                                                         eps, pack=False, want_out=True)
             else:
@@ -409,15 +414,21 @@ class LlamaDecoderLayer(nn.Module):
                 _, normed = ops.fused_add_rms_norm_pack(None, o_slabs, residual, True,
                                                         self.post_attention_layernorm, eps, pack=False,
                                                         want_out=True)
-            return self.moe_block(normed), None
+            return self.moe_block(normed, defer_all_reduce=True), None
         if self.tp > 1:   # row-parallel: local reduce, all-reduce over the TP group, then the norm
             o = ops.wna16_gemm_packed(attn_packed, m, self.q_size, qw, qz, sc, zo, partials=False)
             # (with enable_all_reduce_overlap: the all-reduce runs on a side stream while this stream pulls the
             #  gate_up weights through the Infinity Cache -- distributed/overlap.py)
             gu = self.gate_up_interleaved if self.gate_up_interleaved is not None else self.gate_up_proj.fast_params()
-            o = tensor_model_parallel_all_reduce(o, prefetch=gu[:3])
-            packed2, _ = ops.fused_add_rms_norm_pack(o, None, residual, True,
-                                                     self.post_attention_layernorm, eps)
+            # all-reduce + residual add + RMSNorm + pack as ONE launch of the peer-access kernel where it applies
+            # (csrc/custom_all_reduce.hip; same bits); by rows at two-shot sizes, the residual then stays sharded by row
+            dar = defer_all_reduce(o, allow_shard_residual=True)
+            if dar is not None:
+                packed2, _ = dar.finish(residual, self.post_attention_layernorm, eps)
+            else:
+                o = tensor_model_parallel_all_reduce(o, prefetch=gu[:3])
+                packed2, _ = ops.fused_add_rms_norm_pack(o, None, residual, True,
+                                                         self.post_attention_layernorm, eps)
         else:
             o_slabs, _ = self._gemm_slabs("o_proj", attn_packed, m, self.q_size)
             packed2, _ = ops.fused_add_rms_norm_pack(None, o_slabs, residual, True,
@@ -456,6 +467,9 @@ class LlamaDecoderLayer(nn.Module):
         qw, qz, sc, zo = self.down_proj.fast_params()
         if self.tp > 1:
             d = ops.wna16_gemm_packed(act_packed, m, self.down_proj.in_features, qw, qz, sc, zo, partials=False)
+            dar = defer_all_reduce(d, allow_shard_residual=True)      # the next norm launch (next layer / final norm) runs it
+            if dar is not None:
+                return dar, None
             return tensor_model_parallel_all_reduce(d, prefetch=next_weights), None
         kd = self.down_proj.in_features
         if mid and not (halves and "down_proj" in self.strip) and qw.shape[1] * kd >= 2 ** 25 \
@@ -709,6 +723,9 @@ class LlamaForCausalLM(nn.Module):
             if isinstance(x, DeferredCombine):
                 _, out = ops.fused_add_rms_norm_pack_combine(x.slabs, x.inv, x.topk_weights, residual, True, self.norm,
                                                              self.cfg.rms_norm_eps, pack=False, want_out=True)
+                return out
+            if isinstance(x, DeferredAllReduce):
+                _, out = x.finish(residual, self.norm, self.cfg.rms_norm_eps, pack=False, want_out=True)
                 return out
             _, out = ops.fused_add_rms_norm_pack(x if slabs is None else None, slabs, residual, True, self.norm,
                                                  self.cfg.rms_norm_eps, pack=False, want_out=True)

@@ -54,6 +54,9 @@ def parse_args():
     ap.add_argument("--sim-ar-us", type=float, default=0.0,
                     help="latency of the stubbed all-reduce (default: the one-GPU lower bound of the peer-access kernel for "
                          "the message size, profiles/r1_custom_ar_one_gpu.txt)")
+    ap.add_argument("--sim-ar-stub", action="store_true",
+                    help="with --sim-tp: every all-reduce is a launch holding the stream for --sim-ar-us (the round-3/4 stub) "
+                         "instead of the real peer-access kernels on a loopback communicator")
     ap.add_argument("--model", default="llama3-8b", choices=["llama3-8b", "llama3-70b", "mixtral-8x7b"],
                     help="mixtral-8x7b: BASELINE configs[4] (int4 experts through the grouped GEMM); gptq / awq only")
     ap.add_argument("--quant", default="gptq", choices=["gptq", "fp8", "awq", "fp8ct"],
@@ -652,6 +655,11 @@ def main():
         msg = args.batch * {"llama3-8b": 4096, "llama3-70b": 8192, "mixtral-8x7b": 4096}[args.model] * 2
         sim_ar_us = args.sim_ar_us if args.sim_ar_us > 0 else (6.7 if msg <= 256 * 1024 else 11.4)
         D.init_simulated_tensor_parallel(args.sim_tp, sim_ar_us)
+        if not args.sim_ar_stub:
+            # the REAL peer-access kernels (all-reduce, and all-reduce + residual add + RMSNorm + pack in one launch) on a
+            # loopback communicator: flags, scratch and sim_tp reads per element against local memory, zero link time.
+            # The stream-holding stub stays the fallback for sizes the kernels do not take (and --sim-ar-stub forces it).
+            D.enable_loopback_all_reduce(device)
     ca = None
     if tp > 1 and not os.environ.get("APHRO_NO_CUSTOM_AR"):
         # xGMI peer-access all-reduce for the [M, hidden] sums (RCCL stays the fallback for ineligible sizes)
@@ -859,11 +867,15 @@ def main():
             line["config"]["INVALID"] = "debug run with fewer layers"
         if args.sim_tp > 1:
             line["config"]["parallelism"] = f"ONE rank of tp{args.sim_tp}, simulated on one GPU"
-            line["config"]["simulated_all_reduce_us"] = sim_ar_us
-            line["config"]["NOTE"] = ("per-GPU shard timing: real shard shapes and kernels of one rank; every all-reduce replaced by a "
-                                      "launch holding the stream for simulated_all_reduce_us (one-GPU lower bound of the peer-access "
-                                      "kernel, no link time); tokens/s is what the TP group would deliver at that all-reduce latency; "
-                                      "outputs are not meaningful (partial sums are not reduced)")
+            line["config"]["simulated_all_reduce_us"] = sim_ar_us if args.sim_ar_stub else None
+            line["config"]["all_reduce"] = ("stub: a launch holding the stream for simulated_all_reduce_us" if args.sim_ar_stub else
+                                            "the peer-access kernels on a LOOPBACK communicator (csrc/custom_all_reduce.hip: "
+                                            "all-reduce + residual add + RMSNorm + pack in one launch where the layer allows, "
+                                            f"fused={'off' if os.environ.get('APHRO_NO_FUSED_AR_NORM') == '1' else 'on'})")
+            line["config"]["NOTE"] = ("per-GPU shard timing: real shard shapes and kernels of one rank; the all-reduces run the real "
+                                      "kernel instruction stream, flag protocol and scratch traffic with every peer resolved to this "
+                                      "GPU's own memory (no link time: a lower bound); tokens/s is what the TP group would deliver "
+                                      "at that all-reduce latency; outputs are not meaningful (the sums are over copies of one partial)")
 
     def emit_line(tp_result=None):
         if tp_result is not None:
@@ -966,6 +978,8 @@ def extra_legs(args):
                          "roofline": {"kernel": roof.get("kernel"), "frac": roof.get("frac"), "step_frac": roof.get("step_frac"),
                                       "avg_launch_us": roof.get("avg_launch_us")},
                          "per_kernel_us": {k: round(v["avg_us"], 2) for k, v in rec.get("roofline_all", {}).items()}}
+            if rec["config"].get("all_reduce"):
+                out[name]["all_reduce"] = rec["config"]["all_reduce"]
             if "simulated_all_reduce_us" in rec["config"]:
                 out[name]["simulated_all_reduce_us"] = rec["config"]["simulated_all_reduce_us"]
         except Exception as e:

@@ -555,6 +555,26 @@ int aphro_custom_ar_register_graph_buffers(void* fa, const char* handles, const 
 /* 1 if one of this rank's barriers timed out since the last query (bounded spin: a lost peer raises
  * this instead of hanging the GPU) */
 int aphro_custom_ar_error(void* fa);
+/* The row-parallel linear's all-reduce (modeling/layers/linear.py:1142-1143) fused with the residual add + RMSNorm that
+ * follows it in every decoder layer (models/llama.py: post_attention_layernorm / the next layer's input_layernorm;
+ * kernels/layernorm_kernels.cu:200-240), ONE launch, the bits of aphro_custom_ar_all_reduce -> aphro_fused_add_rms_norm_pack:
+ * x = sum over the ranks of inp [tokens, hidden] (tokens <= 64), residual' = x + residual (in place), y = rms_norm(residual')
+ * * weight -> `packed` (aphro_wna16_packed_a_bytes; f16) and / or row-major `out`.  One-shot sizes
+ * (aphro_custom_ar_fused_norm_one_shot == 1): one workgroup per token row on every rank.  Larger: reduce-scatter BY ROW --
+ * rank r owns rows [r R, (r + 1) R), R = ceil(tokens / world), normalises them once and publishes them; everybody gathers
+ * the rest.  shard_residual (that form only): 1 = only the owner updates a row of `residual` (valid while every later
+ * reader is this function with the same tokens and world), 0 = every rank ends with the whole residual.  reg_buffer as in
+ * aphro_custom_ar_all_reduce.  csrc/custom_all_reduce.hip. */
+int aphro_custom_ar_fused_norm_one_shot(int world, int64_t tokens, int hidden, int esz);
+int aphro_custom_ar_fused_add_rms_norm(void* fa, const void* inp, void* residual, int has_residual,
+                                       const void* weight, float eps, void* packed, void* out,
+                                       int64_t tokens, int hidden, int dtype, int shard_residual,
+                                       void* reg_buffer, size_t reg_buffer_bytes, void* stream);
+/* Loopback communicator (timing rig for ONE rank of a TP group on a one-GPU box, bench.py --sim-tp): `world` ranks that
+ * all resolve to this process's buffers; the kernels above run unchanged (flags and scratch through uncached memory,
+ * `world` reads per element) with local memory in place of the xGMI links.  Results are not a sum over real ranks. */
+int aphro_custom_ar_init_loopback(void** fa_out, void* signal, void* scratch, size_t scratch_bytes,
+                                  void* rank_data, size_t rank_data_bytes, int world);
 
 /* W4A16 GEMM for prefill-sized M (M > 64) -- the role of `_C::gptq_marlin_gemm` at large M
  * (kernels/torch_bindings.cpp:195-201, kernels/quantization/gptq_marlin/gptq_marlin.cu:544,2247) and of the reference's

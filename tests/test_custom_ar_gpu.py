@@ -119,6 +119,228 @@ def test_custom_all_reduce_ranks_on_one_gpu(world):
     _spawn(_ar_worker, world)
 
 
+# ---- all-reduce + residual add + RMSNorm (+ pack) in one launch ---------------------------------
+def _ar_norm_worker(rank, world, port, one_shot_max):
+    """ca.fused_add_rms_norm(x, residual, ...) == ca.custom_all_reduce(x) -> ops.fused_add_rms_norm_pack(...) bit for bit:
+    packed f16 fragments, row-major out, and the residual (every row in the one-shot / replicate forms, the rows a rank
+    owns in the sharded by-row form), eagerly and from a captured graph."""
+    import os
+    if one_shot_max is not None:
+        os.environ["APHRO_CUSTOM_AR_ONE_SHOT_MAX"] = str(one_shot_max)      # before the library is loaded
+    import torch.distributed as dist
+    from aphrodite_engine_amd import _custom_ops as ops
+    from aphrodite_engine_amd.distributed.custom_all_reduce import CustomAllreduce
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    ca = CustomAllreduce(dist.group.WORLD, dev, max_size=4 * 1024 * 1024)
+    assert not ca.disabled
+    gen = torch.Generator(device="cpu")
+    try:
+        cases = [(torch.float16, 32, 4096), (torch.bfloat16, 64, 8192), (torch.float16, 1, 1024), (torch.float16, 7, 5120),
+                 (torch.bfloat16, 33, 8192), (torch.float16, 17, 16384), (torch.float16, 3, 4096), (torch.float16, 64, 2048)]
+        for dtype, tokens, hidden in cases:
+            gen.manual_seed(31 * tokens + hidden)
+            parts = [(torch.randn(tokens, hidden, generator=gen) * 2).to(dtype) for _ in range(world)]
+            res0 = (torch.randn(tokens, hidden, generator=gen) * 3).to(dtype).to(dev)
+            w = (torch.rand(hidden, generator=gen) + 0.5).to(dtype).to(dev)
+            x = parts[rank].to(dev)
+            one_shot = ops.custom_ar_fused_norm_one_shot(world, tokens, hidden, 2)
+            assert ca.fused_norm_shards_residual(x) == (not one_shot)
+            rpr = (tokens + world - 1) // world
+            own = slice(rank * rpr, min(tokens, (rank + 1) * rpr))
+            for has_res in (True, False):
+                for shard in (False, True):
+                    for pack, want_out in ((True, False), (False, True), (True, True)):
+                        # the two-op sequence
+                        r_ref = res0.clone()
+                        summed = ca.custom_all_reduce(x)
+                        p_ref, o_ref = ops.fused_add_rms_norm_pack(summed, None, r_ref, has_res, w, 1e-5, pack=pack, want_out=want_out)
+                        # one launch
+                        r_got = res0.clone()
+                        got = ca.fused_add_rms_norm(x, r_got, has_res, w, 1e-5, pack=pack, want_out=want_out, shard_residual=shard)
+                        assert got is not None
+                        torch.cuda.synchronize()
+                        ca.check()
+                        tag = f"{dtype} {tokens}x{hidden} world {world} one_shot={one_shot} res={has_res} shard={shard} pack={pack} out={want_out}"
+                        if pack:
+                            assert torch.equal(got[0], p_ref), tag
+                        if want_out:
+                            assert torch.equal(got[1], o_ref), tag
+                        if shard and not one_shot:
+                            assert torch.equal(r_got[own], r_ref[own]), tag
+                            other = torch.ones(tokens, dtype=torch.bool)
+                            other[own] = False
+                            assert torch.equal(r_got[other.to(dev)], res0[other.to(dev)]), tag      # left alone
+                        else:
+                            assert torch.equal(r_got, r_ref), tag
+                        assert torch.equal(x.cpu(), parts[rank])
+        # captured: the partial sums live in a graph-private buffer that is registered after the capture
+        tokens, hidden = 32, 4096
+        a = torch.empty(tokens, hidden, dtype=torch.float16, device=dev)
+        res = torch.zeros(tokens, hidden, dtype=torch.float16, device=dev)
+        w = torch.ones(hidden, dtype=torch.float16, device=dev)
+        g = torch.cuda.CUDAGraph()
+        with ca.capture():
+            assert ca.fused_add_rms_norm(a, res, True, w, 1e-5, pack=True, want_out=True) is not None     # warm-up: shapes only
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s), torch.cuda.graph(g, stream=s):
+                pk, out = ca.fused_add_rms_norm(a * 1.0, res, True, w, 1e-5, pack=True, want_out=True)
+        for it in range(4):
+            gen.manual_seed(5 + it)
+            parts = [torch.randn(tokens, hidden, generator=gen).half() for _ in range(world)]
+            a.copy_(parts[rank])
+            res.fill_(0.25 * it)
+            r_ref = res.clone()
+            torch.cuda.synchronize()
+            dist.barrier()
+            g.replay()
+            torch.cuda.synchronize()
+            ca.check()
+            p_ref, o_ref = ops.fused_add_rms_norm_pack(_expected(parts, torch.float16).to(dev), None, r_ref, True, w, 1e-5,
+                                                       pack=True, want_out=True)
+            assert torch.equal(out, o_ref) and torch.equal(pk, p_ref) and torch.equal(res, r_ref)
+            dist.barrier()
+        # not eligible -> None (the caller issues the two ops)
+        assert ca.fused_add_rms_norm(torch.zeros(65, 4096, dtype=torch.float16, device=dev), None, False, w, 1e-5) is None
+        assert ca.fused_add_rms_norm(torch.zeros(8, 4096, dtype=torch.float32, device=dev), None, False, w.float(), 1e-5) is None
+    finally:
+        ca.close()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,one_shot_max", [(2, None), (4, None), (2, 65536), (4, 0)])
+def test_fused_all_reduce_norm_ranks_on_one_gpu(world, one_shot_max):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    _spawn(_ar_norm_worker, world, one_shot_max, timeout=240)
+
+
+def test_loopback_all_reduce_runs_the_real_kernels():
+    """bench.py --sim-tp: a loopback communicator of 8 "ranks" sums 8 copies of the local partial (exact in f16: x 8) with
+    the real one-/two-shot kernels and the fused all-reduce + norm, eagerly and inside a graph, no registration."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from aphrodite_engine_amd import _custom_ops as ops
+    from aphrodite_engine_amd.distributed.custom_all_reduce import LoopbackAllreduce
+    dev = torch.device("cuda:0")
+    ca = LoopbackAllreduce(8, dev)
+    try:
+        g = torch.Generator(device=dev).manual_seed(3)
+        for tokens, hidden in ((32, 4096), (64, 8192)):       # one-shot, two-shot at 8 ranks
+            x = torch.randn(tokens, hidden, device=dev, dtype=torch.float16, generator=g)
+            out = ca.custom_all_reduce(x)
+            torch.cuda.synchronize()
+            ca.check()
+            # (two-shot: "rank 0" reduces the first eighth; the slices it gathers from its own scratch were never written)
+            n_ok = x.numel() if ops.should_one_shot(8, x.numel() * 2) else x.numel() // 8
+            assert torch.equal(out.flatten()[:n_ok], (x * 8).flatten()[:n_ok])
+            w = torch.rand(hidden, device=dev, dtype=torch.float16, generator=g) + 0.5
+            res = torch.randn(tokens, hidden, device=dev, dtype=torch.float16, generator=g)
+            one_shot = ops.custom_ar_fused_norm_one_shot(8, tokens, hidden, 2)
+            r_ref, r_got = res.clone(), res.clone()
+            p_ref, o_ref = ops.fused_add_rms_norm_pack(x * 8, None, r_ref, True, w, 1e-5, pack=True, want_out=True)
+            pk, o = ca.fused_add_rms_norm(x, r_got, True, w, 1e-5, pack=True, want_out=True)
+            torch.cuda.synchronize()
+            ca.check()
+            rows = slice(0, tokens) if one_shot else slice(0, (tokens + 7) // 8)      # by rows: "rank 0" owns the first R rows
+            assert torch.equal(o[rows], o_ref[rows]) and torch.equal(r_got[rows], r_ref[rows])
+            if one_shot:
+                assert torch.equal(pk, p_ref)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                o2 = ca.custom_all_reduce(x)
+                pk2, _ = ca.fused_add_rms_norm(x, r_got, True, w, 1e-5)
+            graph.replay()
+            torch.cuda.synchronize()
+            ca.check()
+            assert torch.equal(o2.flatten()[:n_ok], (x * 8).flatten()[:n_ok])
+    finally:
+        ca.close()
+
+
+def _tp_fused_norm_model_worker(rank, world, port, one_shot_max, moe):
+    """TP decode with every row-parallel all-reduce folded into the norm launch that follows it == the same step with
+    all-reduce and norm as two launches, bit for bit (one-shot, and the by-row form with the residual sharded by row
+    across the layers); the fused form really ran (2 per layer + the final norm - 1 for the first layer's plain norm)."""
+    import os
+    if one_shot_max is not None:
+        os.environ["APHRO_CUSTOM_AR_ONE_SHOT_MAX"] = str(one_shot_max)
+    import torch.distributed as dist
+    from aphrodite_engine_amd import distributed as D
+    from aphrodite_engine_amd import model as M
+    from aphrodite_engine_amd.quantization.gptq import GPTQConfig
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    D.init_tensor_parallel(world, backend="gloo")
+    kw = dict(num_local_experts=4, num_experts_per_tok=2) if moe else {}
+    cfg = M.LlamaConfig(hidden_size=1024, intermediate_size=4096, num_hidden_layers=3, num_attention_heads=8,
+                        num_key_value_heads=4, vocab_size=512, max_position_embeddings=1024, **kw)
+    try:
+        with torch.no_grad():
+            m = M.LlamaForCausalLM(cfg, GPTQConfig(4, 128, False), torch.float16).init_synthetic(dev)
+            lens = [3, 17, 64, 200, 129, 5, 77, 31, 1, 250]
+            meta, pos, nblocks = M.make_decode_metadata(len(lens), lens, 16, "cuda:0")
+            ids = torch.randint(0, cfg.vocab_size, (len(lens), ), device=dev, generator=torch.Generator(device=dev).manual_seed(1))
+            ca = D.enable_custom_all_reduce(dev)
+            assert ca is not None and not ca.disabled
+            calls = {"n": 0}
+            orig = ca.fused_add_rms_norm
+
+            def counted(*a, **k):
+                calls["n"] += 1
+                return orig(*a, **k)
+            ca.fused_add_rms_norm = counted
+
+            def step():
+                caches = M.make_kv_caches(cfg, nblocks, 16, torch.float16, "auto", "cuda:0", seed=3)
+                out = m(ids, pos, caches, meta)
+                torch.cuda.synchronize()
+                ca.check()
+                return out.clone()
+            os.environ["APHRO_NO_FUSED_AR_NORM"] = "1"
+            two_launch = step()
+            assert calls["n"] == 0
+            del os.environ["APHRO_NO_FUSED_AR_NORM"]
+            fused = step()
+            # dense: o_proj + down_proj of every layer; sparse MLP: the expert output's all-reduce only (the attention
+            # block's goes to the router norm)
+            assert calls["n"] == (cfg.num_hidden_layers if moe else 2 * cfg.num_hidden_layers), calls
+            assert torch.equal(two_launch, fused)
+            # captured
+            caches = M.make_kv_caches(cfg, nblocks, 16, torch.float16, "auto", "cuda:0", seed=3)
+            g = torch.cuda.CUDAGraph()
+            with ca.capture():
+                m(ids, pos, caches, meta)
+                s = torch.cuda.Stream()
+                s.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(s), torch.cuda.graph(g, stream=s):
+                    out_g = m(ids, pos, caches, meta)
+            for _ in range(2):
+                fresh = M.make_kv_caches(cfg, nblocks, 16, torch.float16, "auto", "cuda:0", seed=3)
+                for c, f in zip(caches, fresh):
+                    c.copy_(f)
+                torch.cuda.synchronize()
+                dist.barrier()
+                g.replay()
+                torch.cuda.synchronize()
+                ca.check()
+                assert torch.equal(out_g, fused)
+                dist.barrier()
+    finally:
+        D.destroy_tensor_parallel()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("one_shot_max,moe", [(None, False), (0, False), (None, True)])
+def test_tp2_decode_fused_all_reduce_norm_is_bit_identical(one_shot_max, moe):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    _spawn(_tp_fused_norm_model_worker, 2, one_shot_max, moe, timeout=240)
+
+
 def _schema_worker(rank, world, port):
     """The `_C_custom_ar::*` ops as torch.library ops (kernels/torch_bindings.cpp:506-536), driven the way the
     reference's CustomAllreduce drives them (custom_all_reduce.py:101-120, 206-289); IPC handles travel as hex str."""
