@@ -80,6 +80,8 @@ def parse_args():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prefill-info", action="store_true", help="skip the MFMA-bound prefill kernels' info section")
+    ap.add_argument("--no-prefill-e2e", action="store_true",
+                    help="skip the end-to-end 8192-token prefill legs (int4 and FP8, ours and the library arm)")
     ap.add_argument("--no-ops-path", action="store_true", help="skip the second measurement on the op-by-op (drop-in) path")
     ap.add_argument("--ragged", action="store_true",
                     help="ragged context lengths randint(1, ctx) (seed 0; SURVEY 8d, the reference's "
@@ -447,6 +449,108 @@ def prefill_section(cfg):
     ob = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
     t = timeit(lambda: ops.cutlass_scaled_mm(a8, w8.t(), sa, sb, torch.bfloat16, out=ob), 3)
     out[f"cutlass_scaled_mm W8A8 fp8 {M}x{K}x{N}"] = dict(ms=t * 1e3, TFLOPs=fl / t / 1e12, frac=fl / t / 5.0e15, bound="mfma fp8")
+    return out
+
+
+
+def prefill_e2e_section(T=8192):
+    """End-to-end prefill (time to first token) of ONE 8192-token prompt -- BASELINE configs[2]'s sequence length -- through
+    this package's Llama-3-8B, GPTQ int4 g128 (configs[1]'s model) and compressed-tensors FP8 W8A8 + FP8 KV (configs[2]):
+    embedding gather, 32 x (norm, qkv GEMM, rotary, cache write, causal attention, o GEMM, norm, gate_up GEMM, SiluAndMul,
+    down GEMM), final norm, lm_head of the last token, argmax -- everything on the clock, no graph.  Harness shape:
+    the reference's tests/benchmarks/engine/throughput.py:353-363 (--input-len).
+    Next to it, timed in the same process on the same weights, the SAME model with the hand-written MFMA kernels switched
+    off in favour of what the reference already calls on ROCm: gptq dequantise + hipBLASLt (torch.matmul) for W4A16
+    (q_gemm.cu:1529-1544's reconstruct + hipBLAS path), torch._scaled_mm (hipBLASLt) for W8A8
+    (quantization/utils/w8a8_utils.py:130,165), torch SDPA (flash / CK) for the causal attention -- a stated baseline,
+    never the target.  frac = time at the dense MFMA peaks (GEMMs at 2.5 PF f16 / 5 PF fp8, attention at 2.5 PF) / time."""
+    import dataclasses
+    import torch.nn.functional as F
+    from aphrodite_engine_amd import _custom_ops as ops
+    from aphrodite_engine_amd import model as M
+    from aphrodite_engine_amd.attention.backend import MI355XAttentionMetadata
+    from aphrodite_engine_amd.quantization.fp8 import CompressedTensorsW8A8Fp8Config
+    from aphrodite_engine_amd.quantization.gptq import GPTQConfig
+    dev = torch.device("cuda", torch.cuda.current_device())
+    BS = 16
+    out = {}
+
+    def sdpa_varlen(q, k, v, cu_seqlens, max_seqlen, softmax_scale, causal=True, alibi_slopes=None):
+        # one sequence (this section's prompt): [T, H, D] -> [1, H, T, D]; GQA inside SDPA
+        assert cu_seqlens.numel() == 2 and alibi_slopes is None
+        o = F.scaled_dot_product_attention(q.transpose(0, 1).unsqueeze(0), k.transpose(0, 1).unsqueeze(0),
+                                           v.transpose(0, 1).unsqueeze(0), is_causal=causal, scale=softmax_scale,
+                                           enable_gqa=True)
+        return o.squeeze(0).transpose(0, 1).contiguous()
+
+    def one(name, qc, kv, gemm_peak):
+        cfg = dataclasses.replace(M.LLAMA3_8B, max_position_embeddings=max(8192, T))
+        model = M.LlamaForCausalLM(cfg, qc, torch.float16, kv)
+        model.init_synthetic(dev, seed=0)
+        nblk = (T + BS - 1) // BS
+        caches = M.make_kv_caches(cfg, nblk, BS, torch.float16, kv, dev, fill=False)
+        bt = torch.randperm(nblk, device=dev).to(torch.int32).view(1, nblk)
+        pos = torch.arange(T, device=dev, dtype=torch.int64)
+        slots = (bt[0, (pos // BS)].long() * BS + pos % BS)
+        i32 = lambda *a: torch.tensor(a, dtype=torch.int32, device=dev)
+        meta = MI355XAttentionMetadata(
+            num_prefills=1, num_prefill_tokens=T, num_decode_tokens=0, slot_mapping=slots, seq_lens=[T],
+            seq_lens_tensor=i32(T), max_query_len=T, max_prefill_seq_len=T, max_decode_seq_len=0,
+            query_start_loc=i32(0, T), seq_start_loc=i32(0, T), context_lens_tensor=i32(0), block_tables=bt,
+            use_cuda_graph=False, max_context_len=0)      # (a fresh prompt: the builder's max_context_len = 0 -> flash_attn_varlen)
+        ids = torch.randint(0, cfg.vocab_size, (T, ), device=dev)
+
+        def step():
+            h = model(ids, pos, caches, meta)
+            return model.sample_greedy(model.compute_logits(h[-1:]))
+
+        def timed(n=3):
+            step()
+            step()                      # (the first ~50 ms of MFMA-heavy work run below the clocks the chip then holds)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                tok = step()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / n, tok
+
+        h, i = cfg.hidden_size, cfg.intermediate_size
+        qkv = h * (cfg.num_attention_heads + 2 * cfg.num_key_value_heads) * cfg.head_dim
+        gemm = 2.0 * T * (qkv + h * h + 3 * h * i) * cfg.num_hidden_layers
+        attn = 4.0 * T * T * cfg.head_dim * cfg.num_attention_heads / 2 * cfg.num_hidden_layers
+        t_peak = gemm / gemm_peak + attn / 2.5e15
+        dt, tok = timed()
+        rec = {"ms": dt * 1e3, "tokens_per_s": T / dt, "TFLOPs": (gemm + attn) / dt / 1e12, "frac": t_peak / dt,
+               "flops": {"gemm": gemm, "attention": attn}, "kv_cache": kv, "tokens": T}
+        # the library arm: same weights, same process
+        saved_env = {k: os.environ.get(k) for k in ("APHRO_WNA16_NO_LARGE", "APHRO_FP8_NO_LARGE")}
+        saved_fa = ops.flash_attn_varlen
+        try:
+            os.environ["APHRO_WNA16_NO_LARGE"] = "1"
+            os.environ["APHRO_FP8_NO_LARGE"] = "1"
+            ops.flash_attn_varlen = sdpa_varlen
+            try:
+                dt_l, tok_l = timed()
+                rec["library"] = {"ms": dt_l * 1e3, "TFLOPs": (gemm + attn) / dt_l / 1e12,
+                                  "what": "dequantise + torch.matmul / torch._scaled_mm (hipBLASLt), torch SDPA attention",
+                                  "same_first_token": bool(torch.equal(tok, tok_l))}
+                rec["vs_library"] = dt_l / dt
+            except Exception as e:
+                rec["library"] = {"error": repr(e)[:200]}
+        finally:
+            ops.flash_attn_varlen = saved_fa
+            for k, v_ in saved_env.items():
+                if v_ is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v_
+        out[name] = rec
+        del model, caches
+        torch.cuda.empty_cache()
+
+    with torch.no_grad():
+        one("int4_gptq_g128", GPTQConfig(4, 128, False), "auto", 2.5e15)
+        one("fp8_w8a8_fp8kv", CompressedTensorsW8A8Fp8Config(strategy="channel", is_static_input_scheme=False), "fp8", 5.0e15)
     return out
 
 
@@ -919,6 +1023,12 @@ def main():
             line["prefill_kernels"] = prefill_section(cfg)
         except Exception as e:
             line["prefill_kernels"] = {"error": repr(e)}
+        if not args.no_prefill_e2e:
+            try:
+                torch.cuda.empty_cache()
+                line["prefill_e2e"] = prefill_e2e_section()
+            except Exception as e:
+                line["prefill_e2e"] = {"error": repr(e)[:300]}
     if world == 1 and not args.no_cpu_baseline and args.model == "llama3-8b":
         try:
             line["cpu_baseline"] = cpu_baseline(args, cfg)
@@ -962,7 +1072,7 @@ def extra_legs(args):
     budget_s = float(os.environ.get("APHRO_BENCH_LEG_TIMEOUT_S", "150"))
     for name, extra in LEGS.items():
         cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(args.steps), "--warmup", str(args.warmup),
-               "--no-cpu-baseline", "--no-prefill-info", "--no-ops-path"] + extra
+               "--no-cpu-baseline", "--no-prefill-info", "--no-ops-path", "--no-prefill-e2e"] + extra
         try:
             r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=budget_s)
             rec = None
