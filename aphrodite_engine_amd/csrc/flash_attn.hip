@@ -15,26 +15,10 @@
 // fp32 accumulation.  MFMA-bound regime; this first version is single-buffered
 // (two barriers per K/V tile) -- see DESIGN.md for the planned pipeline.
 #include "common.h"
+#include "flash_attn_common.h"
 
 namespace aphro {
 
-struct FAParams {
-  void* out;
-  const void* q;
-  const void* k;
-  const void* v;
-  const int32_t* cu_seqlens;
-  const float* alibi;
-  int num_heads, num_kv_heads;
-  int64_t q_stride, k_stride, v_stride;
-  float scale;
-  int causal;
-  int debug;
-  int nqt_max, xcd_remap;   // third-generation kernel: query tiles per sequence in the grid; kv-head -> XCD placement
-  const int32_t* cu_seqlens_k;   // third-generation kernel: key rows per sequence when they differ from the query rows
-  int64_t o_stride;              // ... and the output row stride (elements)
-  int window;                    // first / second generation kernels: sliding window (keys > query position - window), 0 = off
-};
 
 template <typename T>
 __device__ __forceinline__ f32x4 fa_mfma(u32x4 a, u32x4 b, f32x4 c) {
@@ -478,8 +462,6 @@ __global__ __launch_bounds__(NWV * 64) void flash_attn_varlen_v2_kernel(FAParams
 //   * O leaves through a wave-private LDS transpose as full 256-byte rows.
 // Keys beyond the sequence are fetched as zeros by the buffer descriptor's bounds check.
 // ---------------------------------------------------------------------------
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __attribute__((address_space(3))) void* fa_lds_ptr;
 #ifndef FA_QK_SCHED
 #define FA_QK_SCHED 1
 #endif
@@ -490,13 +472,6 @@ typedef __attribute__((address_space(3))) void* fa_lds_ptr;
 __device__ unsigned long long fa_dbg[8 * 64];
 #define FA_STAMP(slot) if ((p.debug & 1) && blockIdx.x == 0 && lane == 0) fa_dbg[wave * 64 + (slot)] = __builtin_amdgcn_s_memtime();
 
-template <typename T>
-__device__ __forceinline__ f32x16 fa_mfma32(u32x4 a, u32x4 b, f32x16 c) {
-  if constexpr (__is_same(T, Half))
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
-  else
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-}
 
 template <typename T>
 __global__ __launch_bounds__(512) void flash_attn_varlen_v3_kernel(FAParams p) {
@@ -1176,6 +1151,11 @@ static int fa_dispatch(FAParams p, int head_size, int dtype, int batch, int max_
   if (head_size == 128 && max_key_len >= 1024 && p.window <= 0 && !getenv("APHRO_FA_NO_V3")) {
     p.nqt_max = (max_query_len + 255) / 256;
     p.xcd_remap = (batch * p.num_kv_heads) % 8 == 0 && !getenv("APHRO_FA_NO_XCD");
+    // fourth generation (one wave per SIMD, two 32-row blocks per wave: flash_attn_v4.hip) from 4096 keys on (measured on
+    // T = 8192 / 4096 / 2048 / 1111 causal, Hq 32 / Hkv 8: 0.583 / 0.174 / 0.081 / 0.046 ms against 0.62 / 0.182 / 0.078 /
+    // 0.044 ms of the third generation); APHRO_FA_NO_V4=1: third generation always; APHRO_FA_V4_MIN_KEYS=<n>: threshold
+    const int v4_min = getenv("APHRO_FA_V4_MIN_KEYS") ? atoi(getenv("APHRO_FA_V4_MIN_KEYS")) : 4096;
+    if (!getenv("APHRO_FA_NO_V4") && max_key_len >= v4_min) return fa_v4_launch(p, dtype, batch, st);
     dim3 grid3((unsigned)(p.nqt_max * p.num_heads * batch));
     static bool attr_set_dev[APHRO_MAX_DEVICES] = {}; bool& attr_set = attr_set_dev[device_slot()];
     if (!attr_set) {

@@ -636,6 +636,14 @@ def test_context_attention_fwd_long(ops, kv_cache_dtype, dtype, variant):
     tol = 2e-3 if dtype == torch.float16 else 1.6e-2
     np.testing.assert_allclose(out.float().cpu().numpy(), ref, atol=tol, rtol=tol)
     np.testing.assert_allclose(out_old.float().cpu().numpy(), ref, atol=tol, rtol=tol)
+    # the fourth-generation tile machine over the gathered context (query rows offset by the context length)
+    os.environ["APHRO_FA_V4_MIN_KEYS"] = "1024"
+    try:
+        out4 = torch.empty_like(out)
+        ops.context_attention_fwd(q, k, v, out4, *args)
+    finally:
+        del os.environ["APHRO_FA_V4_MIN_KEYS"]
+    np.testing.assert_allclose(out4.float().cpu().numpy(), ref, atol=tol, rtol=tol)
 
 
 def test_backend_prefix_prefill_matches_full_prefill(ops):
@@ -951,6 +959,68 @@ def test_flash_attn_varlen_v3_kv_head_placement(ops, dtype, causal):
     ref = oa.varlen_causal_attention(q, k, v, cu, scale, causal=causal)
     tol = 2e-3 if dtype == torch.float16 else 1.6e-2
     np.testing.assert_allclose(got.float().cpu().numpy(), ref, atol=tol, rtol=tol)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("causal,alibi", [(True, False), (False, False), (True, True)])
+@pytest.mark.parametrize("Hq,Hkv", [(16, 8), (8, 2)])
+def test_flash_attn_varlen_v4(ops, dtype, causal, alibi, Hq, Hkv):
+    """Fourth-generation prefill kernel (one wave per SIMD, two 32-row query blocks per wave, defer-max; flash_attn_v4.hip),
+    forced on from 1024 keys: ragged lengths around the 256-row / 64-key tile edges, sequences of one to five tiles next to
+    long ones, GQA, ALiBi (every tile masked), non-causal -- vs the fp64 oracle and vs the third-generation kernel."""
+    import os
+    rng = np.random.default_rng(11 + Hq)
+    D = 128
+    lens = [1300, 257, 1024, 65, 1, 640, 2049]
+    cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    T = int(cu[-1])
+    qkv = t(rng.standard_normal((T, (Hq + 2 * Hkv) * D)).astype(np.float32) * 0.7, dtype)
+    q, k, v = qkv.split([Hq * D, Hkv * D, Hkv * D], dim=-1)
+    q, k, v = q.view(T, Hq, D), k.view(T, Hkv, D), v.view(T, Hkv, D)
+    scale = float(D ** -0.5)
+    slopes = (rng.random(Hq).astype(np.float32) * 0.05) if alibi else None
+    kw = dict(causal=causal, alibi_slopes=t(slopes) if alibi else None)
+    os.environ["APHRO_FA_V4_MIN_KEYS"] = "1024"
+    try:
+        got = ops.flash_attn_varlen(q, k, v, t(cu), max(lens), scale, **kw)
+        os.environ["APHRO_FA_NO_V4"] = "1"
+        third = ops.flash_attn_varlen(q, k, v, t(cu), max(lens), scale, **kw)
+    finally:
+        os.environ.pop("APHRO_FA_V4_MIN_KEYS", None)
+        os.environ.pop("APHRO_FA_NO_V4", None)
+    ref = oa.varlen_causal_attention(q, k, v, cu, scale, causal=causal, alibi_slopes=slopes)
+    tol = 2e-3 if dtype == torch.float16 else 1.6e-2
+    np.testing.assert_allclose(got.float().cpu().numpy(), ref, atol=tol, rtol=tol)
+    np.testing.assert_allclose(got.float().cpu().numpy(), third.float().cpu().numpy(), atol=tol, rtol=tol)
+
+
+def test_flash_attn_varlen_v4_defer_max_rescale(ops):
+    """The running maximum of the fourth-generation kernel moves only when a row's new maximum exceeds it by more than 2^8:
+    keys whose scores jump far above everything before them (at a tile in the middle, at the diagonal tile, twice in a
+    row) force that rescale of the output accumulators; rows that never trigger it sit next to rows that do."""
+    import os
+    rng = np.random.default_rng(3)
+    Hq, Hkv, D = 8, 2, 128
+    lens = [1536, 2600]
+    cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    T = int(cu[-1])
+    q = rng.standard_normal((T, Hq, D)).astype(np.float32) * 0.5
+    k = rng.standard_normal((T, Hkv, D)).astype(np.float32) * 0.5
+    v = rng.standard_normal((T, Hkv, D)).astype(np.float32)
+    # spike keys: aligned with the mean query direction of a head group -> raw scores 20-60 above the rest for most rows
+    for pos, gain in ((700, 6.0), (1100, 12.0), (1536 + 130, 5.0), (1536 + 2000, 9.0), (1536 + 2001, 14.0), (1536 + 2500, 20.0)):
+        for h in range(Hkv):
+            k[pos, h] = q[cu[0 if pos < 1536 else 1]:, h * (Hq // Hkv)].mean(0) * gain + k[pos, h] * 0.1
+    q, k, v = t(q, torch.float16), t(k, torch.float16), t(v, torch.float16)
+    scale = 1.0
+    os.environ["APHRO_FA_V4_MIN_KEYS"] = "1024"
+    try:
+        got = ops.flash_attn_varlen(q, k, v, t(cu), max(lens), scale, causal=True)
+    finally:
+        os.environ.pop("APHRO_FA_V4_MIN_KEYS", None)
+    ref = oa.varlen_causal_attention(q, k, v, cu, scale, causal=True)
+    assert torch.isfinite(got).all()
+    np.testing.assert_allclose(got.float().cpu().numpy(), ref, atol=4e-3, rtol=4e-3)
 
 
 def test_attention_backend_prefill_then_decode(ops):
