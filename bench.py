@@ -453,7 +453,7 @@ def prefill_section(cfg):
 
 
 
-def prefill_e2e_section(T=8192):
+def prefill_e2e_section(T=8192, library=True, which=("int4", "fp8")):
     """End-to-end prefill (time to first token) of ONE 8192-token prompt -- BASELINE configs[2]'s sequence length -- through
     this package's Llama-3-8B, GPTQ int4 g128 (configs[1]'s model) and compressed-tensors FP8 W8A8 + FP8 KV (configs[2]):
     embedding gather, 32 x (norm, qkv GEMM, rotary, cache write, causal attention, o GEMM, norm, gate_up GEMM, SiluAndMul,
@@ -522,6 +522,11 @@ def prefill_e2e_section(T=8192):
         dt, tok = timed()
         rec = {"ms": dt * 1e3, "tokens_per_s": T / dt, "TFLOPs": (gemm + attn) / dt / 1e12, "frac": t_peak / dt,
                "flops": {"gemm": gemm, "attention": attn}, "kv_cache": kv, "tokens": T}
+        if not library:
+            out[name] = rec
+            del model, caches
+            torch.cuda.empty_cache()
+            return
         # the library arm: same weights, same process
         saved_env = {k: os.environ.get(k) for k in ("APHRO_WNA16_NO_LARGE", "APHRO_FP8_NO_LARGE")}
         saved_fa = ops.flash_attn_varlen
@@ -549,8 +554,10 @@ def prefill_e2e_section(T=8192):
         torch.cuda.empty_cache()
 
     with torch.no_grad():
-        one("int4_gptq_g128", GPTQConfig(4, 128, False), "auto", 2.5e15)
-        one("fp8_w8a8_fp8kv", CompressedTensorsW8A8Fp8Config(strategy="channel", is_static_input_scheme=False), "fp8", 5.0e15)
+        if "int4" in which:
+            one("int4_gptq_g128", GPTQConfig(4, 128, False), "auto", 2.5e15)
+        if "fp8" in which:
+            one("fp8_w8a8_fp8kv", CompressedTensorsW8A8Fp8Config(strategy="channel", is_static_input_scheme=False), "fp8", 5.0e15)
     return out
 
 
