@@ -583,6 +583,60 @@ class LlamaDecoderLayer(nn.Module):
             return tensor_model_parallel_all_reduce(d), None
         return None, (self._fp8_slabs("down_proj", qd), sd, self.down_proj.weight_scale)
 
+    # -- FP8 W8A8 prefill: the activation quantisations ride in the kernels that produce the activations ---------------
+    def fused_prefill_fp8_ok(self) -> bool:
+        """Prompt-sized batches of an FP8 W8A8 layer (compressed-tensors per-token / static, or Fp8Config static): the
+        decode fast path's fused kernels at M = prompt tokens -- fused_add_rms_norm + quant and SiluAndMul + quant in one
+        launch each instead of norm, quant, SiluAndMul, quant (profiles/r5_prefill_e2e_kernels.txt: the four per-token
+        quantisation passes were 9.2 of 82 ms of an 8192-token prompt).  Same bits as the op-by-op path."""
+        from .quantization.fp8 import CompressedTensorsW8A8Fp8Method, CDNA4Fp8LinearMethod
+        if self.is_moe or os.environ.get("APHRO_PREFILL_NO_FUSED_FP8"):
+            return False
+        lins = self.linears()
+        static = [getattr(lin, "input_scale", None) is not None for lin in lins]
+        if any(static) != all(static):
+            return False
+        for lin in lins:
+            qm = lin.quant_method
+            if isinstance(qm, CDNA4Fp8LinearMethod):
+                if qm.use_marlin or lin.input_scale is None or lin.weight.dtype != torch.float8_e4m3fn \
+                        or lin.weight_scale.numel() != 1:
+                    return False
+            elif not isinstance(qm, CompressedTensorsW8A8Fp8Method):
+                return False
+            if lin.input_scale is not None and (lin.input_scale.numel() != 1 or lin.input_scale.dtype != torch.float32):
+                return False
+            if getattr(lin, "bias", None) is not None:
+                return False
+        return True
+
+    def forward_prefill_fp8(self, positions, hidden, residual, first, kv_cache, attn_metadata, cos_sin):
+        """One decoder layer on a prompt-sized batch, FP8 W8A8: returns the down_proj output (the next norm adds it to
+        ``residual``, updated in place)."""
+        eps = self.cfg.rms_norm_eps
+        act_dtype = hidden.dtype
+        s_qkv, s_o = self.qkv_proj.input_scale, self.o_proj.input_scale
+        s_gu, s_dn = self.gate_up_proj.input_scale, self.down_proj.input_scale
+        mm = lambda a, sa, lin: ops.cutlass_scaled_mm(a, lin.weight, out_dtype=act_dtype, scale_a=sa, scale_b=lin.weight_scale)
+        qx, sx, _ = ops.fused_add_rms_norm_quant_fp8(hidden, None, None, None, residual, not first, self.input_layernorm,
+                                                     eps, static_scale=s_qkv)
+        qkv = mm(qx, sx, self.qkv_proj)
+        q, k, v = qkv.split([self.q_size, self.kv_size, self.kv_size], dim=-1)
+        ops.rotary_embedding(positions, q, k, self.head_dim, cos_sin, True)
+        attn_out = self.attn.forward(q, k, v, kv_cache, attn_metadata, self.k_scale, self.v_scale)
+        qa, sa = ops.scaled_fp8_quant(attn_out.view(attn_out.shape[0], self.q_size), s_o, use_per_token_if_dynamic=True)
+        o = mm(qa, sa, self.o_proj)
+        if self.tp > 1:
+            o = tensor_model_parallel_all_reduce(o)
+        qh, sh, _ = ops.fused_add_rms_norm_quant_fp8(o, None, None, None, residual, True, self.post_attention_layernorm,
+                                                     eps, static_scale=s_gu)
+        gate_up = mm(qh, sh, self.gate_up_proj)
+        qd, sd, _ = ops.silu_and_mul_quant_fp8(gate_up, static_scale=s_dn)
+        d = mm(qd, sd, self.down_proj)
+        if self.tp > 1:
+            d = tensor_model_parallel_all_reduce(d)
+        return d
+
     def forward(self, positions, hidden, residual, kv_cache, attn_metadata, cos_sin):
         eps = self.cfg.rms_norm_eps
         if residual is None:
@@ -746,6 +800,15 @@ class LlamaForCausalLM(nn.Module):
                 _, _, out = ops.fused_add_rms_norm_quant_fp8(None, prev[0], prev[1], prev[2], residual, True,
                                                              self.norm, self.cfg.rms_norm_eps, want_out=True)
             return out
+        if (attn_metadata.num_prefill_tokens > 0 and attn_metadata.num_decode_tokens == 0 and hidden.shape[0] > 64
+                and all(l.fused_prefill_fp8_ok() for l in self.layers)):
+            # prompt-sized FP8 W8A8 batches: norm + quant and SiluAndMul + quant fused (forward_prefill_fp8)
+            residual = torch.empty_like(hidden)
+            for i, layer in enumerate(self.layers):
+                hidden = layer.forward_prefill_fp8(positions, hidden, residual, i == 0, kv_caches[i], attn_metadata,
+                                                   self.cos_sin)
+            ops.fused_add_rms_norm(hidden, residual, self.norm, self.cfg.rms_norm_eps)
+            return hidden
         residual = None
         for i, layer in enumerate(self.layers):
             hidden, residual = layer(positions, hidden, residual, kv_caches[i],

@@ -1023,6 +1023,55 @@ def test_flash_attn_varlen_v4_defer_max_rescale(ops):
     np.testing.assert_allclose(got.float().cpu().numpy(), ref, atol=4e-3, rtol=4e-3)
 
 
+@pytest.mark.parametrize("scheme", ["dynamic", "static"])
+@pytest.mark.parametrize("kv", ["auto", "fp8"])
+def test_fp8_prefill_fused_matches_op_by_op(ops, scheme, kv):
+    """Prompt-sized FP8 W8A8 batches: norm + quant and SiluAndMul + quant in one launch each (LlamaDecoderLayer.forward_prefill_fp8)
+    give the bits of the op-by-op layer (norm, quant, GEMM, ..., SiluAndMul, quant, GEMM) -- two ragged prompts, fresh cache."""
+    import os
+    from aphrodite_engine_amd import model as M
+    from aphrodite_engine_amd.attention.backend import MI355XAttentionMetadata
+    from aphrodite_engine_amd.quantization.fp8 import CompressedTensorsW8A8Fp8Config
+    cfg = M.LlamaConfig(hidden_size=1024, intermediate_size=2816, num_hidden_layers=2, num_attention_heads=8,
+                        num_key_value_heads=4, vocab_size=512, max_position_embeddings=2048)
+    qc = CompressedTensorsW8A8Fp8Config(strategy="channel", is_static_input_scheme=scheme == "static")
+    with torch.no_grad():
+        m = M.LlamaForCausalLM(cfg, qc, torch.float16, kv).init_synthetic(torch.device(DEV), seed=2)
+        lens = [130, 77]
+        T, BS = sum(lens), 16
+        nblk = sum((n + BS - 1) // BS for n in lens)
+        bt = torch.arange(nblk, device=DEV, dtype=torch.int32)
+        tables = torch.zeros(2, (max(lens) + BS - 1) // BS, dtype=torch.int32, device=DEV)
+        tables[0, :(lens[0] + BS - 1) // BS] = bt[:(lens[0] + BS - 1) // BS]
+        tables[1, :(lens[1] + BS - 1) // BS] = bt[(lens[0] + BS - 1) // BS:]
+        pos = torch.cat([torch.arange(n, device=DEV) for n in lens]).long()
+        slots = torch.cat([tables[i, torch.arange(n, device=DEV) // BS].long() * BS + torch.arange(n, device=DEV) % BS
+                           for i, n in enumerate(lens)])
+        i32 = lambda *a: torch.tensor(a, dtype=torch.int32, device=DEV)
+        meta = MI355XAttentionMetadata(
+            num_prefills=2, num_prefill_tokens=T, num_decode_tokens=0, slot_mapping=slots, seq_lens=lens,
+            seq_lens_tensor=i32(*lens), max_query_len=max(lens), max_prefill_seq_len=max(lens), max_decode_seq_len=0,
+            query_start_loc=i32(0, lens[0], T), seq_start_loc=i32(0, lens[0], T), context_lens_tensor=i32(0, 0),
+            block_tables=tables, use_cuda_graph=False, max_context_len=0)
+        ids = torch.randint(0, cfg.vocab_size, (T, ), device=DEV, generator=torch.Generator(device=DEV).manual_seed(5))
+        assert all(l.fused_prefill_fp8_ok() for l in m.layers)
+
+        def run():
+            caches = M.make_kv_caches(cfg, nblk, BS, torch.float16, kv, DEV, fill=False)
+            out = m(ids, pos, caches, meta)
+            torch.cuda.synchronize()
+            return out.clone()
+        fused = run()
+        os.environ["APHRO_PREFILL_NO_FUSED_FP8"] = "1"
+        try:
+            assert not m.layers[0].fused_prefill_fp8_ok()
+            plain = run()
+        finally:
+            del os.environ["APHRO_PREFILL_NO_FUSED_FP8"]
+    assert torch.isfinite(fused.float()).all()
+    assert torch.equal(fused, plain)
+
+
 def test_attention_backend_prefill_then_decode(ops):
     """AttentionImpl.forward on a mixed (chunked-prefill style) batch: prefill
     tokens attend causally within their sequence and are written to the paged
