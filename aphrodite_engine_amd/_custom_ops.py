@@ -1986,11 +1986,14 @@ def custom_ar_fused_norm_one_shot(world: int, tokens: int, hidden: int, esz: int
 
 def custom_ar_fused_add_rms_norm(fa: int, inp: torch.Tensor, residual: Optional[torch.Tensor], has_residual: bool,
                                  weight: torch.Tensor, epsilon: float, pack: bool = True, want_out: bool = False,
-                                 shard_residual: bool = False, reg_buffer: Optional[torch.Tensor] = None):
+                                 shard_residual: bool = False, reg_buffer: Optional[torch.Tensor] = None,
+                                 prefetch: Optional[torch.Tensor] = None):
     """tensor_model_parallel_all_reduce(inp) -> fused_add_rms_norm(residual) [-> pack] in ONE launch
     (modeling/layers/linear.py:1142-1143 followed by models/llama.py's layernorm call): the bits of all_reduce_reg /
     all_reduce_unreg followed by fused_add_rms_norm_pack.  Returns (packed or None, out or None); ``residual`` is
-    updated in place.  ``inp`` [tokens <= 64, hidden] must be registered (or ``reg_buffer`` given, or the stream capturing)."""
+    updated in place.  ``inp`` [tokens <= 64, hidden] must be registered (or ``reg_buffer`` given, or the stream capturing).
+    ``prefetch``: the packed weights of the GEMM that follows -- extra workgroups of the launch stream them through the
+    Infinity Cache while the sum waits on flags and links."""
     _require_cuda(inp, weight)
     if inp.dim() != 2 or not inp.is_contiguous() or inp.dtype != weight.dtype or inp.dtype not in (torch.float16, torch.bfloat16):
         raise RuntimeError("custom_ar_fused_add_rms_norm: inp must be a contiguous [tokens, hidden] f16 / bf16 tensor of the weight's dtype")
@@ -2001,7 +2004,8 @@ def custom_ar_fused_add_rms_norm(fa: int, inp: torch.Tensor, residual: Optional[
     out = torch.empty((tokens, hidden), dtype=weight.dtype, device=inp.device) if want_out else None
     check(lib.aphro_custom_ar_fused_add_rms_norm(
         fa, inp.data_ptr(), _ptr(residual), 1 if has_residual else 0, weight.data_ptr(), float(epsilon), _ptr(packed),
-        _ptr(out), tokens, hidden, _dt(weight), 1 if shard_residual else 0, _ptr(reg_buffer),
+        _ptr(out), tokens, hidden, _dt(weight), 1 if shard_residual else 0, _ptr(prefetch),
+        prefetch.numel() * prefetch.element_size() if prefetch is not None else 0, _ptr(reg_buffer),
         reg_buffer.numel() * reg_buffer.element_size() if reg_buffer is not None else 0, _stream()),
         "custom_ar_fused_add_rms_norm")
     return packed, out

@@ -255,7 +255,27 @@ struct ArNormParams {
   int tokens, hidden;
   int rows_per_rank;                    // two-shot: ceil(tokens / world)
   int replicate_residual;               // two-shot: every rank ends with the whole residual (else: owners' rows only)
+  // Workgroups nb .. gridDim.x - 1 take no part in the sum: they pull `pf_n16` 16-byte vectors at `pf` -- the packed weights
+  // of the GEMM that follows the norm -- through the memory-side Infinity Cache while the nb reducing workgroups wait on
+  // flags and xGMI round trips (the sum moves a few hundred KiB and is latency bound: HBM is idle).  The all-reduce
+  // overlapped with the next GEMM's weight stream inside ONE launch, no stream fork / join (BASELINE north_star; the
+  // side-stream form of round 3, distributed/overlap.py, measured 38-61 % SLOWER under a graph).
+  const u32x4* pf;
+  size_t pf_n16;
+  int nb;
 };
+
+__device__ __forceinline__ void ar_prefetch_role(const ArNormParams& q) {
+  u32x4 acc = {0, 0, 0, 0};
+  const size_t stride = (size_t)(gridDim.x - q.nb) * blockDim.x;
+  size_t i = (size_t)(blockIdx.x - q.nb) * blockDim.x + threadIdx.x;
+  for (; i + 3 * stride < q.pf_n16; i += 4 * stride) {
+    const u32x4 a = q.pf[i], b = q.pf[i + stride], c = q.pf[i + 2 * stride], d = q.pf[i + 3 * stride];
+    acc ^= a ^ b ^ c ^ d;
+  }
+  for (; i < q.pf_n16; i += stride) acc ^= q.pf[i];
+  if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x9e3779b9u && q.out == (uint16_t*)1) *q.out = 1;   // keeps the loads alive
+}
 
 __device__ __forceinline__ float ar_block_sum(float v, float* red) {      // == block_sum_f of fused_decode.hip
   v = wave_sum(v);
@@ -346,6 +366,7 @@ template <typename T, int WORLD>
 __global__ __launch_bounds__(1024) void ar_norm_one_shot_kernel(ArNormParams q) {
   __shared__ uint32_t ticket;
   __shared__ float red[16];
+  if ((int)blockIdx.x >= q.nb) { ar_prefetch_role(q); return; }      // (block-uniform)
   const ArParams& p = q.ar;
   if (threadIdx.x == 0) {
     ArSignal* self = p.sig[p.rank];
@@ -386,6 +407,7 @@ template <typename T, int WORLD>
 __global__ __launch_bounds__(1024) void ar_norm_two_shot_kernel(ArNormParams q) {
   __shared__ uint32_t ticket;
   __shared__ float red[16];
+  if ((int)blockIdx.x >= q.nb) { ar_prefetch_role(q); return; }      // (block-uniform)
   const ArParams& p = q.ar;
   if (threadIdx.x == 0) {
     ArSignal* self = p.sig[p.rank];
@@ -825,6 +847,7 @@ extern "C" int aphro_custom_ar_fused_norm_one_shot(int world, int64_t tokens, in
 extern "C" int aphro_custom_ar_fused_add_rms_norm(void* fa_, const void* inp, void* residual, int has_residual,
                                                   const void* weight, float eps, void* packed, void* out,
                                                   int64_t tokens, int hidden, int dtype, int shard_residual,
+                                                  const void* prefetch, size_t prefetch_bytes,
                                                   void* reg_buffer, size_t reg_buffer_bytes, void* stream) {
   CustomAr* fa = (CustomAr*)fa_;
   hipStream_t st = (hipStream_t)stream;
@@ -864,7 +887,20 @@ extern "C" int aphro_custom_ar_fused_add_rms_norm(void* fa_, const void* inp, vo
   int nv = hidden / 8, t = nv <= 1024 ? nv : (nv + 1) / 2;
   t = (t + 63) / 64 * 64;
   t = t < 64 ? 64 : (t > 1024 ? 1024 : t);
-  const int blocks = one_shot ? (int)tokens : q.rows_per_rank;
+  int blocks = one_shot ? (int)tokens : q.rows_per_rank;
+  q.nb = blocks;
+  if (prefetch != nullptr && prefetch_bytes >= 16) {
+    // (a hint: an unaligned pointer is rounded up; a modest number of extra workgroups streams at the HBM rate)
+    const uintptr_t a = ((uintptr_t)prefetch + 15) & ~(uintptr_t)15;
+    const size_t skip = (size_t)(a - (uintptr_t)prefetch);
+    if (prefetch_bytes > skip + 16) {
+      q.pf = (const u32x4*)a;
+      q.pf_n16 = (prefetch_bytes - skip) / 16;
+      static const int max_pf = [] { const char* e = getenv("APHRO_AR_PREFETCH_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 192; }();
+      size_t want = (q.pf_n16 + (size_t)t * 4 - 1) / ((size_t)t * 4);
+      blocks += (int)(want > (size_t)max_pf ? (size_t)max_pf : want);
+    }
+  }
 #define ARN_LAUNCH(TT, W)                                                                              \
   {                                                                                                    \
     if (one_shot) hipLaunchKernelGGL((ar_norm_one_shot_kernel<TT, W>), dim3(blocks), dim3(t), 0, st, q); \

@@ -166,7 +166,7 @@ def tensor_model_parallel_all_reduce(input_: torch.Tensor, prefetch=None) -> tor
 
 def tensor_model_parallel_all_reduce_norm(input_: torch.Tensor, residual: Optional[torch.Tensor], has_residual: bool,
                                          weight: torch.Tensor, epsilon: float, pack: bool = True, want_out: bool = False,
-                                         shard_residual: bool = False):
+                                         shard_residual: bool = False, prefetch: Optional[torch.Tensor] = None):
     """The row-parallel linear's all-reduce (linear.py:1142-1143) and the fused_add_rms_norm [+ pack] that follows it in
     every decoder layer as ONE launch of the peer-access kernel (csrc/custom_all_reduce.hip) -- the bits of
     tensor_model_parallel_all_reduce -> ops.fused_add_rms_norm_pack.  Returns (packed, out), or None when the fused
@@ -175,7 +175,7 @@ def tensor_model_parallel_all_reduce_norm(input_: torch.Tensor, residual: Option
     if _TP_SIZE == 1 or _CUSTOM_AR is None or _OVERLAP is not None or not input_.is_cuda:
         return None
     return _CUSTOM_AR.fused_add_rms_norm(input_, residual, has_residual, weight, epsilon, pack=pack, want_out=want_out,
-                                         shard_residual=shard_residual)
+                                         shard_residual=shard_residual, prefetch=prefetch)
 
 
 class DeferredAllReduce:
@@ -186,9 +186,15 @@ class DeferredAllReduce:
     def __init__(self, partial: torch.Tensor, shard_residual: bool):
         self.partial, self.shard_residual = partial, shard_residual
 
-    def finish(self, residual, weight, epsilon, pack=True, want_out=False):
+    def finish(self, residual, weight, epsilon, pack=True, want_out=False, prefetch=None):
+        """``prefetch``: the packed weights of the GEMM that consumes the norm -- streamed through the Infinity Cache by
+        extra workgroups of the same launch (APHRO_AR_PREFETCH=0 turns it off)."""
+        import os
+        if os.environ.get("APHRO_AR_PREFETCH") == "0":
+            prefetch = None
         res = tensor_model_parallel_all_reduce_norm(self.partial, residual, True, weight, epsilon, pack=pack,
-                                                    want_out=want_out, shard_residual=self.shard_residual)
+                                                    want_out=want_out, shard_residual=self.shard_residual,
+                                                    prefetch=prefetch)
         assert res is not None, "the fused all-reduce + norm stopped applying between defer and finish"
         return res
 

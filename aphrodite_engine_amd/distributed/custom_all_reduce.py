@@ -194,12 +194,12 @@ class CustomAllreduce:
 
     def fused_add_rms_norm(self, inp: torch.Tensor, residual: Optional[torch.Tensor], has_residual: bool,
                            weight: torch.Tensor, epsilon: float, pack: bool = True, want_out: bool = False,
-                           shard_residual: bool = False):
+                           shard_residual: bool = False, prefetch: Optional[torch.Tensor] = None):
         """custom_all_reduce(inp) followed by ops.fused_add_rms_norm_pack(out, None, residual, ...) in ONE launch, same
         bits (csrc/custom_all_reduce.hip).  None = not eligible: the caller runs the two ops.  Returns (packed, out)."""
         if self.disabled or not self.fused_norm_eligible(inp):
             return None
-        kw = dict(pack=pack, want_out=want_out, shard_residual=shard_residual)
+        kw = dict(pack=pack, want_out=want_out, shard_residual=shard_residual, prefetch=prefetch)
         if self._IS_CAPTURING:
             if torch.cuda.is_current_stream_capturing():
                 return self._ops.custom_ar_fused_add_rms_norm(self._ptr, inp, residual, has_residual, weight, epsilon, **kw)
@@ -268,11 +268,11 @@ class LoopbackAllreduce:
         return out
 
     def fused_add_rms_norm(self, inp, residual, has_residual, weight, epsilon, pack=True, want_out=False,
-                           shard_residual=False):
+                           shard_residual=False, prefetch=None):
         if not self.fused_norm_eligible(inp):
             return None
         return self._ops.custom_ar_fused_add_rms_norm(self._ptr, inp, residual, has_residual, weight, epsilon, pack=pack,
-                                                      want_out=want_out, shard_residual=shard_residual)
+                                                      want_out=want_out, shard_residual=shard_residual, prefetch=prefetch)
 
     def check(self) -> None:
         if self._ptr and self._ops.custom_ar_error(self._ptr):

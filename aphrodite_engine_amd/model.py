@@ -324,6 +324,20 @@ class LlamaDecoderLayer(nn.Module):
             return ops.wna16_gemm_resident(packed, m, k, st, qz, sc, zo, mode="slabs", strip_layout=True)
         return ops.wna16_gemm_packed(packed, m, k, qw, qz, sc, zo, partials=True)
 
+    def _packed_weights(self, name: str) -> Optional[torch.Tensor]:
+        """The int4 weight tensor the decode GEMM of projection ``name`` streams (the strip-major copy where the layer has
+        one, the interleaved gate_up where enabled): what an all-reduce + norm launch in front of it prefetches."""
+        if name == "gate_up_proj":
+            if self.gate_up_strip is not None:
+                return self.gate_up_strip
+            if self.gate_up_interleaved is not None:
+                return self.gate_up_interleaved[0]
+        st = self.strip.get(name)
+        if st is not None:
+            return st
+        fp = getattr(self, name).fast_params()
+        return fp[0] if fp is not None else None
+
     def fused_decode_ok(self, m: int) -> bool:
         """Decode fast path (7 launches per layer instead of 17): W4A16 linears in the
         K-packed layout, shapes (per TP shard) served by the packed-activation kernel.  With
@@ -364,7 +378,7 @@ class LlamaDecoderLayer(nn.Module):
                                                             self.input_layernorm, eps)
             qkv_slabs, _ = self._gemm_slabs("qkv_proj", packed, m, h)
         elif isinstance(x, DeferredAllReduce):    # TP: the previous layer's last all-reduce runs inside this norm launch
-            packed, _ = x.finish(residual, self.input_layernorm, eps)
+            packed, _ = x.finish(residual, self.input_layernorm, eps, prefetch=self._packed_weights("qkv_proj"))
             qkv_slabs, _ = self._gemm_slabs("qkv_proj", packed, m, h)
         else:
             packed, _ = ops.fused_add_rms_norm_pack(x if slabs is None else None, slabs, residual,
@@ -424,7 +438,8 @@ class LlamaDecoderLayer(nn.Module):
             # (csrc/custom_all_reduce.hip; same bits); by rows at two-shot sizes, the residual then stays sharded by row
             dar = defer_all_reduce(o, allow_shard_residual=True)
             if dar is not None:
-                packed2, _ = dar.finish(residual, self.post_attention_layernorm, eps)
+                packed2, _ = dar.finish(residual, self.post_attention_layernorm, eps,
+                                        prefetch=None if self.is_moe else self._packed_weights("gate_up_proj"))
             else:
                 o = tensor_model_parallel_all_reduce(o, prefetch=gu[:3])
                 packed2, _ = ops.fused_add_rms_norm_pack(o, None, residual, True,

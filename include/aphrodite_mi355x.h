@@ -563,12 +563,16 @@ int aphro_custom_ar_error(void* fa);
  * (aphro_custom_ar_fused_norm_one_shot == 1): one workgroup per token row on every rank.  Larger: reduce-scatter BY ROW --
  * rank r owns rows [r R, (r + 1) R), R = ceil(tokens / world), normalises them once and publishes them; everybody gathers
  * the rest.  shard_residual (that form only): 1 = only the owner updates a row of `residual` (valid while every later
- * reader is this function with the same tokens and world), 0 = every rank ends with the whole residual.  reg_buffer as in
- * aphro_custom_ar_all_reduce.  csrc/custom_all_reduce.hip. */
+ * reader is this function with the same tokens and world), 0 = every rank ends with the whole residual.  prefetch /
+ * prefetch_bytes (optional): the packed weights of the GEMM that consumes the norm's output -- extra workgroups of the same
+ * launch pull them through the Infinity Cache while the reducing workgroups wait on flags and links (the all-reduce
+ * overlapped with the GEMM's weight stream, BASELINE north_star).  reg_buffer as in aphro_custom_ar_all_reduce.
+ * csrc/custom_all_reduce.hip. */
 int aphro_custom_ar_fused_norm_one_shot(int world, int64_t tokens, int hidden, int esz);
 int aphro_custom_ar_fused_add_rms_norm(void* fa, const void* inp, void* residual, int has_residual,
                                        const void* weight, float eps, void* packed, void* out,
                                        int64_t tokens, int hidden, int dtype, int shard_residual,
+                                       const void* prefetch, size_t prefetch_bytes,
                                        void* reg_buffer, size_t reg_buffer_bytes, void* stream);
 /* Loopback communicator (timing rig for ONE rank of a TP group on a one-GPU box, bench.py --sim-tp): `world` ranks that
  * all resolve to this process's buffers; the kernels above run unchanged (flags and scratch through uncached memory,

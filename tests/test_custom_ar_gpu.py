@@ -150,6 +150,7 @@ def _ar_norm_worker(rank, world, port, one_shot_max):
     try:
         cases = [(torch.float16, 32, 4096), (torch.bfloat16, 64, 8192), (torch.float16, 1, 1024), (torch.float16, 7, 5120),
                  (torch.bfloat16, 33, 8192), (torch.float16, 17, 16384), (torch.float16, 3, 4096), (torch.float16, 64, 2048)]
+        pf_weights = torch.randint(0, 2 ** 31 - 1, (3 * 1024 * 1024 + 5, ), dtype=torch.int32, device=dev)[1:]    # 12 MiB, unaligned start
         for dtype, tokens, hidden in cases:
             gen.manual_seed(31 * tokens + hidden)
             parts = [(torch.randn(tokens, hidden, generator=gen) * 2).to(dtype) for _ in range(world)]
@@ -169,7 +170,9 @@ def _ar_norm_worker(rank, world, port, one_shot_max):
                         p_ref, o_ref = ops.fused_add_rms_norm_pack(summed, None, r_ref, has_res, w, 1e-5, pack=pack, want_out=want_out)
                         # one launch
                         r_got = res0.clone()
-                        got = ca.fused_add_rms_norm(x, r_got, has_res, w, 1e-5, pack=pack, want_out=want_out, shard_residual=shard)
+                        # (with and without the in-launch weight prefetch role: extra workgroups, same results)
+                        got = ca.fused_add_rms_norm(x, r_got, has_res, w, 1e-5, pack=pack, want_out=want_out, shard_residual=shard,
+                                                    prefetch=pf_weights if (pack and want_out) else None)
                         assert got is not None
                         torch.cuda.synchronize()
                         ca.check()
