@@ -1979,15 +1979,13 @@ def should_one_shot(world: int, nbytes: int) -> bool:
 
 
 def custom_ar_fused_norm_one_shot(world: int, tokens: int, hidden: int, esz: int = 2) -> bool:
-    """True when custom_ar_fused_add_rms_norm runs its one-shot form at this size (every rank ends with the whole
-    residual); False = reduce-scatter by token row (see ``shard_residual`` there)."""
+    """True when custom_ar_fused_add_rms_norm runs its one-shot form at this size; False = the two-shot (column-slice) form."""
     return _lib.lib().aphro_custom_ar_fused_norm_one_shot(world, tokens, hidden, esz) != 0
 
 
 def custom_ar_fused_add_rms_norm(fa: int, inp: torch.Tensor, residual: Optional[torch.Tensor], has_residual: bool,
                                  weight: torch.Tensor, epsilon: float, pack: bool = True, want_out: bool = False,
-                                 shard_residual: bool = False, reg_buffer: Optional[torch.Tensor] = None,
-                                 prefetch: Optional[torch.Tensor] = None):
+                                 reg_buffer: Optional[torch.Tensor] = None, prefetch: Optional[torch.Tensor] = None):
     """tensor_model_parallel_all_reduce(inp) -> fused_add_rms_norm(residual) [-> pack] in ONE launch
     (modeling/layers/linear.py:1142-1143 followed by models/llama.py's layernorm call): the bits of all_reduce_reg /
     all_reduce_unreg followed by fused_add_rms_norm_pack.  Returns (packed or None, out or None); ``residual`` is
@@ -2004,7 +2002,7 @@ def custom_ar_fused_add_rms_norm(fa: int, inp: torch.Tensor, residual: Optional[
     out = torch.empty((tokens, hidden), dtype=weight.dtype, device=inp.device) if want_out else None
     check(lib.aphro_custom_ar_fused_add_rms_norm(
         fa, inp.data_ptr(), _ptr(residual), 1 if has_residual else 0, weight.data_ptr(), float(epsilon), _ptr(packed),
-        _ptr(out), tokens, hidden, _dt(weight), 1 if shard_residual else 0, _ptr(prefetch),
+        _ptr(out), tokens, hidden, _dt(weight), _ptr(prefetch),
         prefetch.numel() * prefetch.element_size() if prefetch is not None else 0, _ptr(reg_buffer),
         reg_buffer.numel() * reg_buffer.element_size() if reg_buffer is not None else 0, _stream()),
         "custom_ar_fused_add_rms_norm")

@@ -26,11 +26,8 @@
 //  * the sum is followed, in every decoder layer, by residual add + RMSNorm (+ the pack of the next GEMM's A operand):
 //    aphro_custom_ar_fused_add_rms_norm runs them in the all-reduce launch.  One-shot sizes:
 //    one workgroup per token reads the token's row from every rank and finishes the norm on it.  Two-shot sizes: the
-//    reduce-scatter is BY TOKEN ROW -- rank r sums, adds the residual to and normalises rows [r R, (r + 1) R), publishes
-//    the normalised rows, and everybody gathers the other ranks' rows: the norm is computed once per row instead of
-//    `world` times, the gather moves what the next GEMM reads, and the residual may stay sharded by row between the
-//    layers (nobody but the owner of a row ever reads its residual again).  Bits: those of all_reduce followed by
-//    aphro_fused_add_rms_norm_pack;
+//    reduce-scatter is by COLUMN SLICE of every row, and the workgroup of a row gathers the slices and normalises it.
+//    Bits: those of all_reduce followed by aphro_fused_add_rms_norm_pack;
 //  * a LOOPBACK communicator (aphro_custom_ar_init_loopback) runs the same kernels with every "peer" pointing at this
 //    rank's own buffers: bench.py --sim-tp times one rank of a TP group on a one-GPU box with the real instruction
 //    stream, flags and scratch traffic (local memory instead of links), not a stream-holding stub.
@@ -253,8 +250,8 @@ struct ArNormParams {
   float eps;
   int has_residual;
   int tokens, hidden;
-  int rows_per_rank;                    // two-shot: ceil(tokens / world)
-  int replicate_residual;               // two-shot: every rank ends with the whole residual (else: owners' rows only)
+  int rows_per_rank;                    // two-shot: vectors per column slice, ceil(hidden / 8 / world)
+  int replicate_residual;               // (unused)
   // Workgroups nb .. gridDim.x - 1 take no part in the sum: they pull `pf_n16` 16-byte vectors at `pf` -- the packed weights
   // of the GEMM that follows the norm -- through the memory-side Infinity Cache while the nb reducing workgroups wait on
   // flags and xGMI round trips (the sum moves a few hundred KiB and is latency bound: HBM is idle).  The all-reduce
@@ -402,7 +399,14 @@ __global__ __launch_bounds__(1024) void ar_norm_one_shot_kernel(ArNormParams q) 
   ar_barrier(p, 2, val);                                   // nobody still reads my input when I return
 }
 
-// Two-shot by rows.  Scratch of a rank: y rows [tokens][hidden] T, then (replicate_residual) residual' rows.
+// Two-shot sizes: reduce-scatter by COLUMN SLICE, norm after the gather.  Rank r sums vectors [r S, (r + 1) S), S =
+// ceil(hidden / 8 / world), of every row (workgroup b = row b, S threads busy: the same one-round-trip reduce as
+// ar_two_shot_kernel, spread over `tokens` workgroups) and publishes them in its uncached scratch; after the flag round
+// every workgroup gathers ITS row -- one 16-byte load per thread from the slice's owner -- and finishes residual add +
+// norm + pack on it.  Every rank ends with every row (residual included), the data crossed the links twice per element
+// instead of `world` times.  (Round-5 lab, loopback communicator, [64, 8192] f16 at 8 ranks: all-reduce 8.0 us + norm 4.4 us
+// as two launches 12.6 us; a reduce-scatter BY ROW with the norm before the gather -- 8 workgroups of 1024 threads doing
+// all of it -- 15.3 us; this form see profiles/r5_ar_norm_fused.txt.)
 template <typename T, int WORLD>
 __global__ __launch_bounds__(1024) void ar_norm_two_shot_kernel(ArNormParams q) {
   __shared__ uint32_t ticket;
@@ -414,10 +418,9 @@ __global__ __launch_bounds__(1024) void ar_norm_two_shot_kernel(ArNormParams q) 
     ticket = self->counter[blockIdx.x] + 1;
     self->counter[blockIdx.x] = ticket;
   }
+  const int row = blockIdx.x;
   const int nv = q.hidden >> 3;
-  const int row = p.rank * q.rows_per_rank + (int)blockIdx.x;          // the row this workgroup owns
-  const bool own = row < q.tokens;
-  const size_t plane = (size_t)q.tokens * q.hidden;
+  const int nvs = q.rows_per_rank;                          // (reused field: vectors per column slice)
   u16x8 wv[2];
 #pragma unroll
   for (int it = 0; it < 2; ++it) {
@@ -428,60 +431,25 @@ __global__ __launch_bounds__(1024) void ar_norm_two_shot_kernel(ArNormParams q) 
   const uint32_t val = ticket;
   ar_barrier(p, 0, val);
   const ArPeers in = p.use_inline ? p.in_inline : *p.in;
-  if (own) {                                               // (block-uniform)
-    u32x4 xs[2];
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      const int i = threadIdx.x + it * blockDim.x;
-      if (i < nv) xs[it] = reduce_vec<T, WORLD>(in, (int64_t)row * nv + i);
-    }
-    uint16_t* mine = (uint16_t*)p.scratch.ptr[p.rank];
-    uint16_t* res_row = q.residual ? q.residual + (size_t)row * q.hidden : nullptr;
-    u16x8 y[2];
-    ar_norm_row<T>(xs, q.has_residual ? res_row : nullptr, res_row,
-                   q.replicate_residual ? mine + plane + (size_t)row * q.hidden : nullptr, wv, nv, q.hidden, q.eps, red, y);
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      const int i = threadIdx.x + it * blockDim.x;
-      if (i < nv) {
-        *reinterpret_cast<u16x8*>(mine + (size_t)row * q.hidden + 8 * i) = y[it];   // uncached: through to memory
-        ar_norm_emit<T>(q, row, i, y[it]);
-      }
-    }
+  u32x4* mine = (u32x4*)p.scratch.ptr[p.rank];
+  for (int i = threadIdx.x; i < nvs; i += blockDim.x) {
+    const int col = p.rank * nvs + i;
+    if (col < nv) mine[(size_t)row * nv + col] = reduce_vec<T, WORLD>(in, (int64_t)row * nv + col);   // uncached: through to memory
   }
   ar_barrier(p, 1, val);                                   // (waits for the write-through stores first)
-  // gather: one vector from every other rank's published rows, all loads in flight together (one per xGMI link)
-  const uint16_t* mine_c = (const uint16_t*)p.scratch.ptr[p.rank];
+  u32x4 xs[2];
 #pragma unroll
   for (int it = 0; it < 2; ++it) {
     const int i = threadIdx.x + it * blockDim.x;
-    if (i < nv) {
-      ArPeers gy, gr;
+    if (i < nv) xs[it] = ld_peer((const u32x4*)p.scratch.ptr[i / nvs] + (size_t)row * nv + i);
+  }
+  uint16_t* res_row = q.residual ? q.residual + (size_t)row * q.hidden : nullptr;
+  u16x8 y[2];
+  ar_norm_row<T>(xs, q.has_residual ? res_row : nullptr, res_row, nullptr, wv, nv, q.hidden, q.eps, red, y);
 #pragma unroll
-      for (int r = 0; r < WORLD; ++r) {
-        const int prow = r * q.rows_per_rank + (int)blockIdx.x;
-        const bool valid = r != p.rank && prow < q.tokens;
-        const uint16_t* base = valid ? (const uint16_t*)p.scratch.ptr[r] + (size_t)prow * q.hidden : mine_c;   // (own slot: a harmless local read)
-        gy.ptr[r] = base + 8 * i;
-        gr.ptr[r] = base + (valid ? plane : 0) + 8 * i;
-      }
-      u32x4 yv[WORLD];
-      ld_peers<WORLD>(yv, gy, 0);
-#pragma unroll
-      for (int r = 0; r < WORLD; ++r) {
-        const int prow = r * q.rows_per_rank + (int)blockIdx.x;
-        if (r != p.rank && prow < q.tokens) ar_norm_emit<T>(q, prow, i, __builtin_bit_cast(u16x8, yv[r]));
-      }
-      if (q.replicate_residual && q.residual) {
-        ld_peers<WORLD>(yv, gr, 0);
-#pragma unroll
-        for (int r = 0; r < WORLD; ++r) {
-          const int prow = r * q.rows_per_rank + (int)blockIdx.x;
-          if (r != p.rank && prow < q.tokens)
-            *reinterpret_cast<u32x4*>(q.residual + (size_t)prow * q.hidden + 8 * i) = yv[r];
-        }
-      }
-    }
+  for (int it = 0; it < 2; ++it) {
+    const int i = threadIdx.x + it * blockDim.x;
+    if (i < nv) ar_norm_emit<T>(q, row, i, y[it]);
   }
   ar_barrier(p, 2, val);
 }
@@ -828,8 +796,8 @@ extern "C" int aphro_custom_ar_init_loopback(void** fa_out, void* signal, void* 
   return APHRO_OK;
 }
 
-// 1 when aphro_custom_ar_fused_add_rms_norm will run the one-shot form for `tokens` x `hidden` elements of `esz` bytes
-// (every rank ends with the whole residual), 0 for the two-shot-by-rows form.
+// 1 when aphro_custom_ar_fused_add_rms_norm will run the one-shot form for `tokens` x `hidden` elements of `esz` bytes,
+// 0 for the two-shot (column-slice) form.
 extern "C" int aphro_custom_ar_fused_norm_one_shot(int world, int64_t tokens, int hidden, int esz) {
   return aphro_custom_ar_should_one_shot(world, (size_t)tokens * hidden * esz);
 }
@@ -839,14 +807,11 @@ extern "C" int aphro_custom_ar_fused_norm_one_shot(int world, int64_t tokens, in
 // = x, written if `residual` is given), y = rms_norm(residual') * weight -> `packed` (the W4A16 / FP8 decode GEMMs'
 // fragment-major f16 A operand, aphro_wna16_packed_a_bytes) and / or row-major `out`.  Same bits as
 // aphro_custom_ar_all_reduce followed by aphro_fused_add_rms_norm_pack (reference call sites: the row-parallel linear's
-// all-reduce, modeling/layers/linear.py:1142-1143, then models/llama.py's fused_add_rms_norm).
-// reg_buffer as in aphro_custom_ar_all_reduce.  shard_residual (two-shot sizes only, see
-// aphro_custom_ar_fused_norm_one_shot): 1 = a rank updates only the residual rows it owns, rows
-// [rank R, (rank + 1) R), R = ceil(tokens / world) -- valid while every later reader of the residual is this function
-// with the same tokens / world; 0 = the owners publish their residual rows and every rank ends with all of them.
+// all-reduce, modeling/layers/linear.py:1142-1143, then models/llama.py's fused_add_rms_norm).  Every rank ends with every
+// row.  prefetch: see ArNormParams.  reg_buffer as in aphro_custom_ar_all_reduce.
 extern "C" int aphro_custom_ar_fused_add_rms_norm(void* fa_, const void* inp, void* residual, int has_residual,
                                                   const void* weight, float eps, void* packed, void* out,
-                                                  int64_t tokens, int hidden, int dtype, int shard_residual,
+                                                  int64_t tokens, int hidden, int dtype,
                                                   const void* prefetch, size_t prefetch_bytes,
                                                   void* reg_buffer, size_t reg_buffer_bytes, void* stream) {
   CustomAr* fa = (CustomAr*)fa_;
@@ -874,20 +839,19 @@ extern "C" int aphro_custom_ar_fused_add_rms_norm(void* fa_, const void* inp, vo
   int rc = ar_fill_params(fa, src, st, &q.ar);
   if (rc != APHRO_OK) return rc;
   const bool one_shot = aphro_custom_ar_should_one_shot(fa->world, bytes) != 0;
-  const bool replicate = !one_shot && !shard_residual && residual != nullptr;
-  APHRO_CHECK(one_shot || bytes * (replicate ? 2 : 1) <= fa->scratch_bytes,
-              "custom_ar_fused_add_rms_norm: %zu bytes exceed the two-shot scratch", bytes * (replicate ? 2 : 1));
+  APHRO_CHECK(one_shot || bytes <= fa->scratch_bytes,
+              "custom_ar_fused_add_rms_norm: %zu bytes exceed the two-shot scratch", bytes);
   q.residual = (uint16_t*)residual; q.weight = (const uint16_t*)weight;
   q.packed = (uint16_t*)packed; q.out = (uint16_t*)out;
   q.eps = eps; q.has_residual = has_residual ? 1 : 0;
   q.tokens = (int)tokens; q.hidden = hidden;
-  q.rows_per_rank = (int)((tokens + fa->world - 1) / fa->world);
-  q.replicate_residual = replicate ? 1 : 0;
+  q.rows_per_rank = (hidden / 8 + fa->world - 1) / fa->world;
+  q.replicate_residual = 0;
   // the block size of aphro_fused_add_rms_norm_pack (same thread -> element mapping, same reduction order)
   int nv = hidden / 8, t = nv <= 1024 ? nv : (nv + 1) / 2;
   t = (t + 63) / 64 * 64;
   t = t < 64 ? 64 : (t > 1024 ? 1024 : t);
-  int blocks = one_shot ? (int)tokens : q.rows_per_rank;
+  int blocks = (int)tokens;
   q.nb = blocks;
   if (prefetch != nullptr && prefetch_bytes >= 16) {
     // (a hint: an unaligned pointer is rounded up; a modest number of extra workgroups streams at the HBM rate)

@@ -166,40 +166,38 @@ def tensor_model_parallel_all_reduce(input_: torch.Tensor, prefetch=None) -> tor
 
 def tensor_model_parallel_all_reduce_norm(input_: torch.Tensor, residual: Optional[torch.Tensor], has_residual: bool,
                                          weight: torch.Tensor, epsilon: float, pack: bool = True, want_out: bool = False,
-                                         shard_residual: bool = False, prefetch: Optional[torch.Tensor] = None):
+                                         prefetch: Optional[torch.Tensor] = None):
     """The row-parallel linear's all-reduce (linear.py:1142-1143) and the fused_add_rms_norm [+ pack] that follows it in
     every decoder layer as ONE launch of the peer-access kernel (csrc/custom_all_reduce.hip) -- the bits of
     tensor_model_parallel_all_reduce -> ops.fused_add_rms_norm_pack.  Returns (packed, out), or None when the fused
-    form does not apply (no peer-access communicator, overlap mode, ineligible size): the caller then issues the two
-    ops.  ``shard_residual``: see CustomAllreduce.fused_norm_shards_residual."""
+    form does not apply (no peer-access communicator, overlap mode, ineligible size): the caller then issues the two ops."""
     if _TP_SIZE == 1 or _CUSTOM_AR is None or _OVERLAP is not None or not input_.is_cuda:
         return None
     return _CUSTOM_AR.fused_add_rms_norm(input_, residual, has_residual, weight, epsilon, pack=pack, want_out=want_out,
-                                         shard_residual=shard_residual, prefetch=prefetch)
+                                         prefetch=prefetch)
 
 
 class DeferredAllReduce:
     """A row-parallel projection's per-rank partial sums [tokens, hidden] whose all-reduce has NOT been issued: the norm
-    that consumes them runs it in its own launch (``finish``).  ``shard_residual``: the by-row form may leave the
-    residual rows of other ranks untouched (dense decoder layers, where every reader of the residual is such a launch)."""
+    that consumes them runs it in its own launch (``finish``)."""
 
-    def __init__(self, partial: torch.Tensor, shard_residual: bool):
-        self.partial, self.shard_residual = partial, shard_residual
+    def __init__(self, partial: torch.Tensor):
+        self.partial = partial
 
     def finish(self, residual, weight, epsilon, pack=True, want_out=False, prefetch=None):
-        """``prefetch``: the packed weights of the GEMM that consumes the norm -- streamed through the Infinity Cache by
-        extra workgroups of the same launch (APHRO_AR_PREFETCH=0 turns it off)."""
+        """``prefetch`` (opt-in, APHRO_AR_PREFETCH=1): the packed weights of the GEMM that consumes the norm -- streamed
+        through the Infinity Cache by extra workgroups of the same launch.  Off by default: on the one-GPU loopback rig
+        the longer launch cost more than the warmer weights returned (profiles/r5_ar_norm_fused.txt)."""
         import os
-        if os.environ.get("APHRO_AR_PREFETCH") == "0":
+        if os.environ.get("APHRO_AR_PREFETCH") != "1":
             prefetch = None
         res = tensor_model_parallel_all_reduce_norm(self.partial, residual, True, weight, epsilon, pack=pack,
-                                                    want_out=want_out, shard_residual=self.shard_residual,
-                                                    prefetch=prefetch)
+                                                    want_out=want_out, prefetch=prefetch)
         assert res is not None, "the fused all-reduce + norm stopped applying between defer and finish"
         return res
 
 
-def defer_all_reduce(partial: torch.Tensor, allow_shard_residual: bool = False) -> Optional["DeferredAllReduce"]:
+def defer_all_reduce(partial: torch.Tensor) -> Optional["DeferredAllReduce"]:
     """A DeferredAllReduce for ``partial`` when the fused all-reduce + norm launch serves it (peer-access communicator
     attached, decode-sized [tokens <= 64, hidden] f16 / bf16, no side-stream overlap; APHRO_NO_FUSED_AR_NORM=1 opts
     out), else None: the caller all-reduces now."""
@@ -208,15 +206,7 @@ def defer_all_reduce(partial: torch.Tensor, allow_shard_residual: bool = False) 
             or os.environ.get("APHRO_NO_FUSED_AR_NORM") == "1" or _CUSTOM_AR.disabled
             or not _CUSTOM_AR.fused_norm_eligible(partial)):
         return None
-    return DeferredAllReduce(partial, allow_shard_residual and _CUSTOM_AR.fused_norm_shards_residual(partial))
-
-
-def fused_all_reduce_norm_shards_residual(input_: torch.Tensor) -> bool:
-    """True if tensor_model_parallel_all_reduce_norm would run its by-row form on ``input_`` (and so may be asked to
-    keep the residual sharded by row)."""
-    if _TP_SIZE == 1 or _CUSTOM_AR is None or _OVERLAP is not None or not input_.is_cuda:
-        return False
-    return _CUSTOM_AR.fused_norm_eligible(input_) and _CUSTOM_AR.fused_norm_shards_residual(input_)
+    return DeferredAllReduce(partial)
 
 
 def tensor_model_parallel_all_gather(input_: torch.Tensor, dim: int = -1) -> torch.Tensor:

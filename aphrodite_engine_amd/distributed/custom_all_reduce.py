@@ -185,21 +185,16 @@ class CustomAllreduce:
     def fused_norm_eligible(self, inp: torch.Tensor) -> bool:
         return (self.should_custom_ar(inp) and inp.dim() == 2 and inp.shape[0] <= 64 and inp.shape[1] % 8 == 0
                 and inp.shape[1] <= 16384 and inp.dtype in (torch.float16, torch.bfloat16) and inp.is_contiguous()
-                and 2 * inp.numel() * inp.element_size() <= self.max_size)
-
-    def fused_norm_shards_residual(self, inp: torch.Tensor) -> bool:
-        """True when the fused form at this size is the reduce-scatter by token row (a rank then owns rows
-        [rank R, (rank + 1) R), R = ceil(tokens / world), and ``shard_residual=True`` leaves the other rows alone)."""
-        return not self._ops.custom_ar_fused_norm_one_shot(self.world_size, inp.shape[0], inp.shape[1], inp.element_size())
+                and inp.numel() * inp.element_size() <= self.max_size)
 
     def fused_add_rms_norm(self, inp: torch.Tensor, residual: Optional[torch.Tensor], has_residual: bool,
                            weight: torch.Tensor, epsilon: float, pack: bool = True, want_out: bool = False,
-                           shard_residual: bool = False, prefetch: Optional[torch.Tensor] = None):
+                           prefetch: Optional[torch.Tensor] = None):
         """custom_all_reduce(inp) followed by ops.fused_add_rms_norm_pack(out, None, residual, ...) in ONE launch, same
         bits (csrc/custom_all_reduce.hip).  None = not eligible: the caller runs the two ops.  Returns (packed, out)."""
         if self.disabled or not self.fused_norm_eligible(inp):
             return None
-        kw = dict(pack=pack, want_out=want_out, shard_residual=shard_residual, prefetch=prefetch)
+        kw = dict(pack=pack, want_out=want_out, prefetch=prefetch)
         if self._IS_CAPTURING:
             if torch.cuda.is_current_stream_capturing():
                 return self._ops.custom_ar_fused_add_rms_norm(self._ptr, inp, residual, has_residual, weight, epsilon, **kw)
@@ -254,7 +249,6 @@ class LoopbackAllreduce:
 
     should_custom_ar = CustomAllreduce.should_custom_ar
     fused_norm_eligible = CustomAllreduce.fused_norm_eligible
-    fused_norm_shards_residual = CustomAllreduce.fused_norm_shards_residual
 
     @contextmanager
     def capture(self):
@@ -267,12 +261,11 @@ class LoopbackAllreduce:
         self._ops.all_reduce_reg(self._ptr, input, out)
         return out
 
-    def fused_add_rms_norm(self, inp, residual, has_residual, weight, epsilon, pack=True, want_out=False,
-                           shard_residual=False, prefetch=None):
+    def fused_add_rms_norm(self, inp, residual, has_residual, weight, epsilon, pack=True, want_out=False, prefetch=None):
         if not self.fused_norm_eligible(inp):
             return None
         return self._ops.custom_ar_fused_add_rms_norm(self._ptr, inp, residual, has_residual, weight, epsilon, pack=pack,
-                                                      want_out=want_out, shard_residual=shard_residual, prefetch=prefetch)
+                                                      want_out=want_out, prefetch=prefetch)
 
     def check(self) -> None:
         if self._ptr and self._ops.custom_ar_error(self._ptr):

@@ -435,8 +435,8 @@ class LlamaDecoderLayer(nn.Module):
             #  gate_up weights through the Infinity Cache -- distributed/overlap.py)
             gu = self.gate_up_interleaved if self.gate_up_interleaved is not None else self.gate_up_proj.fast_params()
             # all-reduce + residual add + RMSNorm + pack as ONE launch of the peer-access kernel where it applies
-            # (csrc/custom_all_reduce.hip; same bits); by rows at two-shot sizes, the residual then stays sharded by row
-            dar = defer_all_reduce(o, allow_shard_residual=True)
+            # (csrc/custom_all_reduce.hip; same bits)
+            dar = defer_all_reduce(o)
             if dar is not None:
                 packed2, _ = dar.finish(residual, self.post_attention_layernorm, eps,
                                         prefetch=None if self.is_moe else self._packed_weights("gate_up_proj"))
@@ -482,7 +482,7 @@ class LlamaDecoderLayer(nn.Module):
         qw, qz, sc, zo = self.down_proj.fast_params()
         if self.tp > 1:
             d = ops.wna16_gemm_packed(act_packed, m, self.down_proj.in_features, qw, qz, sc, zo, partials=False)
-            dar = defer_all_reduce(d, allow_shard_residual=True)      # the next norm launch (next layer / final norm) runs it
+            dar = defer_all_reduce(d)      # the next norm launch (next layer / final norm) runs it
             if dar is not None:
                 return dar, None
             return tensor_model_parallel_all_reduce(d, prefetch=next_weights), None

@@ -581,8 +581,7 @@ class FusedMoE(nn.Module):
                 defer_all_reduce: bool = False):
         """defer_combine: return a DeferredCombine for the next norm launch to consume (int4 experts on one rank only).
         defer_all_reduce (TP > 1): return a distributed.DeferredAllReduce where the fused all-reduce + norm launch serves
-        the size -- the next norm runs the sum (the residual stays replicated: the attention block's router norm reads
-        every row)."""
+        the size -- the next norm runs the sum."""
         if defer_combine and isinstance(self.quant_method, Wna16MoEMethod) and not (self.reduce_results and self.tp_size > 1):
             return self.quant_method.apply(self, hidden_states, router_logits, self.top_k, self.renormalize,
                                            defer_combine=True)
@@ -590,7 +589,7 @@ class FusedMoE(nn.Module):
         if self.reduce_results and self.tp_size > 1:
             from .distributed import defer_all_reduce as _defer, tensor_model_parallel_all_reduce
             if defer_all_reduce and out.dim() == 2:
-                dar = _defer(out if out.is_contiguous() else out.contiguous(), allow_shard_residual=False)
+                dar = _defer(out if out.is_contiguous() else out.contiguous())
                 if dar is not None:
                     return dar
             out = tensor_model_parallel_all_reduce(out)

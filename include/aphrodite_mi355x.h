@@ -559,11 +559,9 @@ int aphro_custom_ar_error(void* fa);
  * follows it in every decoder layer (models/llama.py: post_attention_layernorm / the next layer's input_layernorm;
  * kernels/layernorm_kernels.cu:200-240), ONE launch, the bits of aphro_custom_ar_all_reduce -> aphro_fused_add_rms_norm_pack:
  * x = sum over the ranks of inp [tokens, hidden] (tokens <= 64), residual' = x + residual (in place), y = rms_norm(residual')
- * * weight -> `packed` (aphro_wna16_packed_a_bytes; f16) and / or row-major `out`.  One-shot sizes
- * (aphro_custom_ar_fused_norm_one_shot == 1): one workgroup per token row on every rank.  Larger: reduce-scatter BY ROW --
- * rank r owns rows [r R, (r + 1) R), R = ceil(tokens / world), normalises them once and publishes them; everybody gathers
- * the rest.  shard_residual (that form only): 1 = only the owner updates a row of `residual` (valid while every later
- * reader is this function with the same tokens and world), 0 = every rank ends with the whole residual.  prefetch /
+ * * weight -> `packed` (aphro_wna16_packed_a_bytes; f16) and / or row-major `out`; every rank ends with every row.  One-shot
+ * sizes (aphro_custom_ar_fused_norm_one_shot == 1): one workgroup per token row reads the row from every rank.  Larger:
+ * reduce-scatter by column slice of every row, the row's workgroup gathers the slices and normalises.  prefetch /
  * prefetch_bytes (optional): the packed weights of the GEMM that consumes the norm's output -- extra workgroups of the same
  * launch pull them through the Infinity Cache while the reducing workgroups wait on flags and links (the all-reduce
  * overlapped with the GEMM's weight stream, BASELINE north_star).  reg_buffer as in aphro_custom_ar_all_reduce.
@@ -571,7 +569,7 @@ int aphro_custom_ar_error(void* fa);
 int aphro_custom_ar_fused_norm_one_shot(int world, int64_t tokens, int hidden, int esz);
 int aphro_custom_ar_fused_add_rms_norm(void* fa, const void* inp, void* residual, int has_residual,
                                        const void* weight, float eps, void* packed, void* out,
-                                       int64_t tokens, int hidden, int dtype, int shard_residual,
+                                       int64_t tokens, int hidden, int dtype,
                                        const void* prefetch, size_t prefetch_bytes,
                                        void* reg_buffer, size_t reg_buffer_bytes, void* stream);
 /* Loopback communicator (timing rig for ONE rank of a TP group on a one-GPU box, bench.py --sim-tp): `world` ranks that
