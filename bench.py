@@ -91,6 +91,7 @@ def parse_args():
                          "process of this script, summarised under `legs` in the line)")
     ap.add_argument("--no-tp-section", action="store_true",
                     help="N > 1, replicas: skip the tensor-parallel section (TP = N timing, overlap A/B, all-reduce latencies)")
+    ap.add_argument("--tp-child", action="store_true", help="(internal) the tensor-parallel section of an N > 1 run, in its own processes")
     ap.add_argument("--layers", type=int, default=0, help="debug only: fewer layers (marks the line invalid)")
     return ap.parse_args()
 
@@ -618,11 +619,25 @@ def all_reduce_section(args, model, device, ca):
         return start.elapsed_time(end) * 1e3 / (iters * n)
     for nbytes in sizes:
         x = torch.zeros(nbytes // 2, dtype=torch.float16, device=device)
-        row = {"algo": None, "custom_us": None, "rccl_us": None}
+        row = {"algo": None, "custom_us": None, "rccl_us": None,
+               # which implementation tensor_model_parallel_all_reduce hands a decode-step tensor of this size to
+               "served_by": "RCCL"}
         if ca is not None and not ca.disabled and ca.should_custom_ar(x):
             row["algo"] = "one-shot" if lib.aphro_custom_ar_should_one_shot(world, nbytes) else "two-shot"
-            row["custom_us"] = timed(lambda t_: ca.custom_all_reduce(t_), x)
-            ca.check()
+            row["served_by"] = "peer-access kernel (" + row["algo"] + ")"
+            try:
+                row["custom_us"] = timed(lambda t_: ca.custom_all_reduce(t_), x)
+                ca.check()
+                if nbytes == sizes[0]:
+                    # the [M, hidden] sum of the decode layer as it really runs: fused with residual add + RMSNorm + pack
+                    xm = x.view(args.batch, -1)
+                    res = torch.zeros_like(xm)
+                    wn = torch.ones(xm.shape[1], dtype=xm.dtype, device=device)
+                    if ca.fused_norm_eligible(xm):
+                        row["fused_norm_us"] = timed(lambda t_: (ca.fused_add_rms_norm(t_, res, True, wn, 1e-5, pack=False, want_out=True)[1]), xm)
+                        ca.check()
+            except Exception as e:       # report, do not fail the section
+                row["custom_error"] = repr(e)[:160]
 
         def rccl(t_):
             dist.all_reduce(t_, group=D._TP_GROUP)
@@ -731,8 +746,179 @@ def tp_section(args, device, world, rank, one_gpu):
     return out
 
 
+
+# ---- multi-rank control flow (first contact with a multi-GPU node happens in the driver's own run: every step below is
+# ---- written so that the replica ("dp") line survives whatever the tensor-parallel side does) -------------------------------
+def init_process_group_safe(world, rank, device, want_nccl):
+    """RCCL ("nccl") for the replicas' barriers and the max over ranks; if it cannot be brought up the run continues on gloo
+    (the replicas exchange no data) and says so in the line.  Returns {"backend", "world", "note"}."""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    info = {"note": None}
+    if want_nccl:
+        try:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+            t = torch.ones(1, device=device)
+            dist.all_reduce(t)                      # first collective: communicator really up, every rank present
+            torch.cuda.synchronize()
+            if int(t.item()) != world:
+                raise RuntimeError(f"first all-reduce saw {int(t.item())} of {world} ranks")
+        except Exception as e:                      # noqa: BLE001 -- anything: the DP line must not depend on RCCL
+            info["note"] = f"nccl process group failed ({e!r}"[:200] + "): replicas synchronise over gloo"
+            try:
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+            except Exception:
+                pass
+            # a different rendezvous port: the failed attempt may still hold the first one
+            os.environ["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 17)
+            os.environ.pop("TORCHELASTIC_USE_AGENT_STORE", None)
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    info["backend"] = dist.get_backend()
+    info["world"] = dist.get_world_size()
+    return info
+
+
+def timed_region(run, steps, world, sync, max_device):
+    """EXACTLY `steps` calls of run() bracketed by barrier + device synchronize on both sides; max over ranks."""
+    import torch.distributed as dist
+    sync()
+    if world > 1:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        run()
+    sync()
+    if world > 1:
+        dist.barrier()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=max_device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    return elapsed
+
+
+def run_tp_children(argv, world, rank):
+    """The tensor-parallel section of an N > 1 run in CHILD processes (one per rank, own process group on its own
+    rendezvous port): a collective that hangs, an IPC mapping that faults or an RCCL abort ends a child, not the process
+    that holds the replica numbers.  Every rank spawns its child and waits (APHRO_BENCH_TP_TIMEOUT_S, default 200 s);
+    rank 0 returns the child's result dict (or {"error": ...})."""
+    import signal
+    import subprocess
+    import torch.distributed as dist
+    port = [0]
+    if rank == 0:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port[0] = sk.getsockname()[1]
+    dist.broadcast_object_list(port, src=0)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port[0]), APHRO_BENCH_TP_CHILD="1")
+    env.pop("TORCHELASTIC_USE_AGENT_STORE", None)          # the child's rank 0 hosts its own store on the new port
+    cmd = [sys.executable, os.path.abspath(__file__), "--tp-child"] + [a for a in argv if a != "--tp-child"]
+    budget = float(os.environ.get("APHRO_BENCH_TP_TIMEOUT_S", "200"))
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+    result = None
+    try:
+        out, err = p.communicate(timeout=budget)
+        if p.returncode != 0:
+            result = {"error": f"tensor-parallel child exited with {p.returncode}: {(err or out)[-300:]}"}
+        else:
+            for ln in out.splitlines():
+                if ln.startswith("TP_RESULT "):
+                    result = json.loads(ln[len("TP_RESULT "):])
+            if result is None and rank == 0:
+                result = {"error": "tensor-parallel child printed no result: " + (err or out)[-200:]}
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(p.pid, signal.SIGKILL)               # the session we started, nothing else
+        except ProcessLookupError:
+            pass
+        p.communicate()
+        result = {"error": f"tensor-parallel child timed out after {budget:.0f} s (killed): replica numbers are unaffected"}
+    return result
+
+
+def tp_child_main(args):
+    """`bench.py --tp-child ...` (spawned by run_tp_children): own process group, the tensor-parallel section, one
+    TP_RESULT line on rank 0."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    dry = os.environ.get("APHRO_BENCH_DRY_CPU") == "1"
+    one_gpu = os.environ.get("APHRO_BENCH_ONE_GPU") == "1"
+    import torch.distributed as dist
+    if dry:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        fail = os.environ.get("APHRO_BENCH_DRY_TP_FAIL", "")
+        if fail == "crash" and rank == world - 1:
+            os.abort()
+        if fail == "hang":
+            time.sleep(3600)
+        if fail == "raise":
+            raise RuntimeError("dry-run tensor-parallel failure")
+        t = torch.ones(1)
+        dist.all_reduce(t)
+        out = {"tp": world, "backend": dist.get_backend(), "ranks_seen_by_collective": int(t.item()), "dry_run": True}
+    else:
+        local_rank = 0 if one_gpu else int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
+        info = init_process_group_safe(world, rank, device, want_nccl=not one_gpu)
+        from aphrodite_engine_amd import _lib
+        _lib.lib()
+        out = tp_section(args, device, world, rank, one_gpu)
+        out["process_group"] = info
+    if rank == 0:
+        print("TP_RESULT " + json.dumps(out), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def main_dry_cpu(args):
+    """APHRO_BENCH_DRY_CPU=1 (tests/test_host_cpu.py): the multi-rank control flow of main() -- process group, barriers,
+    max over ranks, the tensor-parallel children and their failure containment, the ONE line of rank 0 -- with a stub in
+    place of the model, on CPU over gloo.  The numbers mean nothing."""
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    pg = {"backend": None, "world": 1, "note": None}
+    if world > 1:
+        pg = init_process_group_safe(world, rank, torch.device("cpu"), want_nccl=False)
+    x = torch.zeros(64, 64)
+
+    def step():
+        x.add_(1.0)
+    for _ in range(args.warmup):
+        step()
+    elapsed = timed_region(step, args.steps, world, lambda: None, "cpu")
+    line = None
+    if rank == 0:
+        line = {"metric": "output tokens/sec + HBM-roofline %, Llama-3-8B int4/fp8 @ 1/2/4/8 MI355X", "value": args.batch * args.steps * world / elapsed,
+                "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "dry run", "data": "none",
+                "config": {"workload": "DRY RUN on CPU (control flow only)", "INVALID": "dry run"}, "process_group": pg}
+    if world > 1 and not args.no_tp_section:
+        tp = run_tp_children(sys.argv[1:], world, rank)
+        if rank == 0:
+            line["tp_section"] = tp
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse_args()
+    if args.tp_child:
+        return tp_child_main(args)
+    if os.environ.get("APHRO_BENCH_DRY_CPU") == "1":
+        return main_dry_cpu(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -747,12 +933,9 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     import torch.distributed as dist
+    pg_info = {"backend": None, "world": 1, "note": None}
     if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if one_gpu:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        pg_info = init_process_group_safe(world, rank, device, want_nccl=not one_gpu)
     from aphrodite_engine_amd import _lib
     from aphrodite_engine_amd import distributed as D
     _lib.lib()  # fail loudly if the HIP library is missing
@@ -805,22 +988,8 @@ def main():
         run = graph.replay if graph is not None else loop.step
         for _ in range(args.warmup):
             run()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            run()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-        if world > 1:
-            tmax = torch.tensor([elapsed], device="cpu" if one_gpu else device, dtype=torch.float64)
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            elapsed = float(tmax.item())
+        max_dev = "cpu" if (one_gpu or pg_info["backend"] == "gloo") else device
+        elapsed = timed_region(run, args.steps, world, torch.cuda.synchronize, max_dev)
         if ca is not None:
             ca.check()      # a timed-out barrier would have produced garbage: fail loudly
         ctx_end = int(loop.meta.seq_lens_tensor[0].item())
@@ -953,6 +1122,7 @@ def main():
                 "all_reduce": ("xGMI peer-access kernel" if ca is not None and not ca.disabled else "RCCL") if tp > 1 else None,
                 "all_reduce_overlap": (overlap is not None) if tp > 1 else None,
                 "layers": cfg.num_hidden_layers,
+                "process_group": {"backend": pg_info["backend"], "ranks": pg_info["world"], "note": pg_info["note"]},
             },
             "step_hbm": {"active_expert_fraction": active_frac, "algorithmic_bytes": step_bytes, "achieved_GBps": step_bytes / (elapsed / args.steps) / 1e9,
                          "frac_of_peak": step_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS},
@@ -988,36 +1158,17 @@ def main():
                                       "GPU's own memory (no link time: a lower bound); tokens/s is what the TP group would deliver "
                                       "at that all-reduce latency; outputs are not meaningful (the sums are over copies of one partial)")
 
-    def emit_line(tp_result=None):
-        if tp_result is not None:
-            line["tp_section"] = tp_result
-        print(json.dumps(line), flush=True)
-
-    tp_info = None
     if world > 1 and tp == 1 and not args.no_tp_section and args.model == "llama3-8b":
-        # free the replica first, then run the sharded model under a watchdog: a hung collective must not cost the line
+        # free the replica first; the sharded model runs in CHILD processes (run_tp_children): whatever happens there, the
+        # replica numbers above are already measured and the line below is printed
         loop = model = None
         torch.cuda.empty_cache()
-        import threading
-        done = threading.Event()
-        result = {}
-
-        def guard():
-            if not done.wait(float(os.environ.get("APHRO_BENCH_TP_TIMEOUT_S", "240"))):
-                result["tp"] = {"error": "tensor-parallel section timed out (watchdog): replica numbers above are unaffected"}
-                result["timeout"] = True
-                if rank == 0:
-                    emit_line(result["tp"])
-                os._exit(0)
-        threading.Thread(target=guard, daemon=True).start()
         try:
-            tp_info = tp_section(args, device, world, rank, one_gpu)
-        except Exception as e:
+            tp_info = run_tp_children(sys.argv[1:], world, rank)
+        except Exception as e:                      # noqa: BLE001
             tp_info = {"error": repr(e)[:300]}
-        done.set()
         if rank == 0:
             line["tp_section"] = tp_info
-
     if rank != 0:
         if world > 1:
             dist.barrier()

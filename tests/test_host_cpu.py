@@ -553,3 +553,44 @@ def test_int4_expert_methods_refuse_group_sizes_the_grouped_kernel_does_not_serv
     for bad in (32, 64, 192, 0):
         with pytest.raises(NotImplementedError):
             Wna16MoEMethod("gptq", bad)
+
+
+# ---- bench.py --gpus 2: the driver's launch form, control flow only -----------------------------
+def _run_bench_dry(extra_env, timeout=180):
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, APHRO_BENCH_DRY_CPU="1", **extra_env)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout, cwd=root)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(lines) == 1, (r.stdout[-1000:], r.stderr[-1000:])            # ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_control_flow_over_gloo():
+    """`python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 ...` exactly as the driver launches it, with a stub
+    in place of the model (APHRO_BENCH_DRY_CPU): process group, barrier + max-over-ranks timing, the tensor-parallel section in
+    child processes on their own rendezvous, one line from rank 0 with whole-job throughput."""
+    line = _run_bench_dry({})
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["warmup"] == 1 and line["value"] > 0
+    assert line["process_group"]["backend"] == "gloo" and line["process_group"]["world"] == 2
+    assert line["tp_section"] == {"tp": 2, "backend": "gloo", "ranks_seen_by_collective": 2, "dry_run": True}
+
+
+@pytest.mark.parametrize("failure", ["crash", "raise", "hang"])
+def test_bench_replica_line_survives_a_failing_tensor_parallel_section(failure):
+    """A tensor-parallel child that aborts, raises or hangs (killed at the budget) costs the tp_section, not the line."""
+    line = _run_bench_dry({"APHRO_BENCH_DRY_TP_FAIL": failure, "APHRO_BENCH_TP_TIMEOUT_S": "8"})
+    assert line["n_gpus"] == 2 and line["value"] > 0
+    assert "error" in line["tp_section"], line["tp_section"]
+    if failure == "hang":
+        assert "timed out" in line["tp_section"]["error"]
