@@ -1822,13 +1822,15 @@ def fused_add_rms_norm(input: torch.Tensor, residual: torch.Tensor,
         "fused_add_rms_norm")
 
 
-def silu_and_mul(out: torch.Tensor, x: torch.Tensor) -> None:
+def silu_and_mul(out: torch.Tensor, x: torch.Tensor, interleaved: bool = False) -> None:
+    """``interleaved``: the columns of x are (gate_j, up_j) pairs (a gate_up GEMM on ops.interleave_gate_up weights)
+    instead of [gate | up] halves -- same result."""
     _require_cuda(out, x)
     d = x.shape[-1] // 2
     assert x.is_contiguous() and out.is_contiguous()
-    check(_lib.lib().aphro_silu_and_mul(out.data_ptr(), x.data_ptr(),
-                                        x.numel() // (2 * d), d, _dt(x), _stream()),
-          "silu_and_mul")
+    lib = _lib.lib()
+    fn = lib.aphro_silu_and_mul_interleaved if interleaved else lib.aphro_silu_and_mul
+    check(fn(out.data_ptr(), x.data_ptr(), x.numel() // (2 * d), d, _dt(x), _stream()), "silu_and_mul")
 
 
 def rotary_embedding(positions: torch.Tensor, query: torch.Tensor,

@@ -129,6 +129,7 @@ SIGNATURES = {
     "aphro_rms_norm": (I, [P, P, P, F, L, I, L, I, P]),
     "aphro_fused_add_rms_norm": (I, [P, P, P, F, L, I, I, P]),
     "aphro_silu_and_mul": (I, [P, P, L, I, I, P]),
+    "aphro_silu_and_mul_interleaved": (I, [P, P, L, I, I, P]),
     "aphro_rotary_embedding": (I, [P, P, P, L, I, I, I, I, P, L, L, I, I, P]),
     "aphro_flash_attn_varlen": (I, [P, P, P, P, P, I, I, I, I, I, L, L, L, F, I, P, I, P]),
     "aphro_context_attention": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, L, L, L, L,

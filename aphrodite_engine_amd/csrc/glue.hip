@@ -95,6 +95,30 @@ __global__ void silu_and_mul_kernel(uint16_t* __restrict__ out, const uint16_t* 
   }
 }
 
+// The same arithmetic on a gate_up GEMM output whose columns are interleaved, (gate_j, up_j) pairs -- what the layer's
+// weights look like once SiluAndMul rides in the decode GEMM's epilogue (ops.interleave_gate_up): the prompt-sized GEMMs run
+// on the SAME copy of the weights and this kernel pairs the columns back up, so that no second [gate | up] copy of the
+// matrix has to stay in HBM.  Same bits as silu_and_mul_kernel on the de-interleaved input.
+template <typename T>
+__global__ void silu_and_mul_interleaved_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict__ in, int d) {
+  const int64_t tok = blockIdx.x;
+  const uint16_t* a = in + tok * 2 * (int64_t)d;
+  uint16_t* o = out + tok * (int64_t)d;
+  for (int i = threadIdx.x; i < (d >> 3); i += blockDim.x) {
+    const u16x8 lo = *reinterpret_cast<const u16x8*>(a + 16 * i);
+    const u16x8 hi = *reinterpret_cast<const u16x8*>(a + 16 * i + 8);
+    u16x8 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const uint16_t g = j < 4 ? lo[2 * j] : hi[2 * j - 8], u = j < 4 ? lo[2 * j + 1] : hi[2 * j - 7];
+      const float xf = T::to_f32(g);
+      const float s = T::to_f32(T::from_f32(xf / (1.0f + __expf(-xf))));
+      r[j] = T::from_f32(s * T::to_f32(u));
+    }
+    *reinterpret_cast<u16x8*>(o + 8 * i) = r;
+  }
+}
+
 template <typename T, bool NEOX>
 __global__ void rotary_kernel(const int64_t* __restrict__ positions, uint16_t* __restrict__ query,
                               uint16_t* __restrict__ key, const uint16_t* __restrict__ cache, int rot_dim,
@@ -184,6 +208,24 @@ extern "C" int aphro_silu_and_mul(void* out, const void* input, int64_t num_toke
                        (const uint16_t*)input, d);
   else
     hipLaunchKernelGGL((silu_and_mul_kernel<BFloat>), grid, block, 0, (hipStream_t)stream, (uint16_t*)out,
+                       (const uint16_t*)input, d);
+  APHRO_LAUNCH_CHECK();
+  return APHRO_OK;
+}
+
+// out [tokens, d] = SiluAndMul of in [tokens, 2 d] with interleaved (gate_j, up_j) columns.
+extern "C" int aphro_silu_and_mul_interleaved(void* out, const void* input, int64_t num_tokens, int d, int dtype,
+                                  void* stream) {
+  APHRO_CHECK(dtype == APHRO_F16 || dtype == APHRO_BF16, "silu_and_mul_interleaved: dtype must be f16 or bf16");
+  APHRO_CHECK(d % 8 == 0, "silu_and_mul_interleaved: d=%d must be a multiple of 8", d);
+  if (num_tokens == 0) return APHRO_OK;
+  int threads = d / 8 >= 1024 ? 1024 : ((d / 8 + 63) / 64 * 64);
+  dim3 grid((unsigned)num_tokens), block(threads);
+  if (dtype == APHRO_F16)
+    hipLaunchKernelGGL((silu_and_mul_interleaved_kernel<Half>), grid, block, 0, (hipStream_t)stream, (uint16_t*)out,
+                       (const uint16_t*)input, d);
+  else
+    hipLaunchKernelGGL((silu_and_mul_interleaved_kernel<BFloat>), grid, block, 0, (hipStream_t)stream, (uint16_t*)out,
                        (const uint16_t*)input, d);
   APHRO_LAUNCH_CHECK();
   return APHRO_OK;

@@ -207,8 +207,9 @@ class LlamaDecoderLayer(nn.Module):
     def enable_fused_silu(self, m: int = 32, keep_original: bool = True) -> bool:
         """Re-lay the gate_up weights with interleaved (gate_j, up_j) columns so that the
         decode fast path runs SiluAndMul inside the GEMM epilogue.  With
-        keep_original=False the [gate | up] copy is dropped (the unfused forward then
-        de-interleaves the GEMM output instead)."""
+        keep_original=False the [gate | up] copy is dropped: the parameters themselves take the interleaved
+        order and the op-by-op / prompt-sized forward pairs the columns in its SiluAndMul
+        (ops.silu_and_mul(..., interleaved=True)) -- one copy of the matrix in HBM."""
         self.enable_resident_layouts(m)       # (also where SiluAndMul cannot ride in the epilogue: TP shards, sparse layers)
         if self.is_moe:
             return False
@@ -673,11 +674,11 @@ class LlamaDecoderLayer(nn.Module):
         if self.is_moe:
             return self.moe_block(hidden), residual
         gate_up = self.gate_up_proj(hidden)
-        if self.gate_up_interleaved is not None and not self.gate_up_keep_original:
-            gate_up = gate_up.view(gate_up.shape[0], -1, 2).transpose(1, 2).reshape(gate_up.shape[0], -1)
         act = torch.empty(gate_up.shape[0], gate_up.shape[1] // 2, dtype=gate_up.dtype,
                           device=gate_up.device)
-        ops.silu_and_mul(act, gate_up)
+        # ONE copy of the gate_up weights: once SiluAndMul rides in the decode GEMM's epilogue the parameters hold the
+        # interleaved (gate_j, up_j) column order, and the op-by-op / prompt-sized path pairs the columns in the activation
+        ops.silu_and_mul(act, gate_up, interleaved=self.gate_up_interleaved is not None and not self.gate_up_keep_original)
         hidden = self.down_proj(act)
         if self.tp > 1:
             hidden = tensor_model_parallel_all_reduce(hidden)

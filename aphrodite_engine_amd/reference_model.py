@@ -91,7 +91,9 @@ class MI355XLlamaForCausalLM(nn.Module):
                                         cfg.rope_scaling)
         inner.process_weights_after_loading()       # no-op for the layers the loader's own pass has already processed
         for layer in inner.layers:
-            layer.enable_fused_silu(32, keep_original=True)                    # SiluAndMul in the gate_up epilogue
+            # SiluAndMul in the gate_up epilogue; ONE copy of the matrix (prompt-sized batches pair the interleaved columns in
+            # their SiluAndMul): the footprint bench.py measures
+            layer.enable_fused_silu(32, keep_original=False)
             layer.enable_fp8_strips(32)                                        # FP8 checkpoints: strip-major decode copies
         inner.use_fused_decode = True
         self._ready = True

@@ -122,6 +122,8 @@ def build(args, device):
     else:
         qc = Fp8Config(is_checkpoint_fp8_serialized=True, activation_scheme=args.act_scheme)
     dtype = torch.float16
+    torch.cuda.synchronize()
+    mem0 = torch.cuda.memory_allocated(device)
     model = M.LlamaForCausalLM(cfg, qc, dtype, args.kv_cache_dtype)
     model.init_synthetic(device, seed=0)
     if os.environ.get("APHRO_NO_FUSED_ROPE"):
@@ -134,6 +136,11 @@ def build(args, device):
     if args.quant.startswith("fp8") and args.batch <= 32:
         for layer in model.layers:
             layer.enable_fp8_strips(args.batch)     # load-time relayout for the resident W8A8 decode GEMM
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    # everything the model keeps in HBM (every layout copy of every matrix, embedding, lm_head, rotary table): the footprint
+    # a serving engine pays, next to the one-copy algorithmic bytes of the roofline
+    model.weight_bytes_resident = int(torch.cuda.memory_allocated(device) - mem0)
     return model, cfg, dtype
 
 
@@ -1054,6 +1061,7 @@ def main():
         tokens = args.batch * args.steps * replicas
         ms_per_step = elapsed / args.steps * 1e3
         # step-level algorithmic bytes
+        weight_bytes_resident = getattr(model, "weight_bytes_resident", None)
         w_bytes = model.weight_bytes_per_layer(active_frac) * cfg.num_hidden_layers
         lm_head = model.lm_head.numel() * 2
         esz = 1 if args.kv_cache_dtype != "auto" else 2
@@ -1124,7 +1132,9 @@ def main():
                 "layers": cfg.num_hidden_layers,
                 "process_group": {"backend": pg_info["backend"], "ranks": pg_info["world"], "note": pg_info["note"]},
             },
-            "step_hbm": {"active_expert_fraction": active_frac, "algorithmic_bytes": step_bytes, "achieved_GBps": step_bytes / (elapsed / args.steps) / 1e9,
+            "step_hbm": {"active_expert_fraction": active_frac, "algorithmic_bytes": step_bytes,
+                         "weight_bytes_one_copy": w_bytes + lm_head + model.embed_tokens.numel() * 2,
+                         "weight_bytes_resident": weight_bytes_resident, "achieved_GBps": step_bytes / (elapsed / args.steps) / 1e9,
                          "frac_of_peak": step_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS},
             "roofline": {"bound": "hbm", "kernel": dom_name, "members": dom["members"], "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,

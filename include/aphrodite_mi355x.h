@@ -338,6 +338,11 @@ int aphro_fused_add_rms_norm(void* input, void* residual, const void* weight,
 /* _C::silu_and_mul  kernels/activation_kernels.cu:55-75 : out[T,d] from in[T,2d] */
 int aphro_silu_and_mul(void* out, const void* input, int64_t num_tokens, int d,
                        int dtype, void* stream);
+/* SiluAndMul over a gate_up output with INTERLEAVED (gate_j, up_j) columns -- the column order a layer's weights have once
+ * SiluAndMul rides in the decode GEMM's epilogue: prompt-sized batches run on the same single copy of the weights.  Same
+ * bits as aphro_silu_and_mul on the de-interleaved input (kernels/activation_kernels.cu:12-75).  csrc/glue.hip. */
+int aphro_silu_and_mul_interleaved(void* out, const void* input, int64_t num_tokens, int d,
+                       int dtype, void* stream);
 /* _C::rotary_embedding  kernels/pos_encoding_kernels.cu:120-160 (in place) */
 int aphro_rotary_embedding(const int64_t* positions, void* query, void* key,
                            int64_t num_tokens, int num_heads, int num_kv_heads,

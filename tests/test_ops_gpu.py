@@ -1183,6 +1183,11 @@ def test_silu_and_mul_and_rope(ops, dtype):
     ops.silu_and_mul(out, x)
     tol = 4e-3 if dtype == torch.float16 else 3e-2
     np.testing.assert_allclose(out.float().cpu().numpy(), oa.silu_and_mul(x), atol=tol, rtol=tol)
+    # interleaved (gate_j, up_j) columns -- the order of a gate_up GEMM on ops.interleave_gate_up weights: same bits
+    x_il = x.view(T, 2, d).transpose(1, 2).reshape(T, 2 * d).contiguous()
+    out_il = torch.empty_like(out)
+    ops.silu_and_mul(out_il, x_il, interleaved=True)
+    assert torch.equal(out, out_il)
     Hq, Hkv, hd = 8, 2, 128
     qkv = t(rng.standard_normal((T, (Hq + 2 * Hkv) * hd)).astype(np.float32), dtype)
     q, k, _ = qkv.split([Hq * hd, Hkv * hd, Hkv * hd], dim=-1)
