@@ -13,9 +13,12 @@ then ``compute_logits`` / ``sample`` (llama.py:433-450).  Inside, it is this pac
 op by op (prefill kernels), decode batches of <= 64 rows take the fused path, both under the reference's own HIP-graph
 capture (everything is launched on the current stream).
 
-Opt in:  ``APHRODITE_MI355X_FUSED_MODEL=1`` makes ``plugin.register()`` register it for ``LlamaForCausalLM`` (and
-``MistralForCausalLM``: same decoder, llama.py:548).  What this class cannot do is listed where it raises: LoRA, pipeline
-parallelism, sliding-window / biased projections / non-llama3 rope scaling (``loader.llama_config_from_hf``).
+``plugin.register()`` registers it for ``LlamaForCausalLM`` and ``MistralForCausalLM`` (same decoder, llama.py:548) BY
+DEFAULT since round 5 (``APHRODITE_MI355X_FUSED_MODEL=0`` opts out): one number for a maintainer, the fused one.  What this
+class does not serve -- LoRA, sliding-window / biased projections / non-llama3 rope scaling
+(``loader.llama_config_from_hf``), a quantization config that is not this package's, float32 -- falls back to the
+reference's own class of the architecture (``unsupported_reason`` / ``__new__``), i.e. to the op-by-op path on the same
+kernels; pipeline parallelism raises where it is asked for.
 
 The attention metadata it receives is the reference's ``ROCmFlashAttentionMetadata`` (or ``MI355XAttentionMetadata``): the
 fields read -- ``num_prefill_tokens``, ``num_decode_tokens``, ``slot_mapping``, ``prefill_metadata`` /
@@ -37,6 +40,55 @@ class MI355XLlamaForCausalLM(nn.Module):
     supported_lora_modules: List[str] = []
     embedding_modules = {}
     embedding_padding_modules: List[str] = []
+
+    # the architecture this class was registered for and the reference's registry (set per registration by
+    # register_with_reference): a configuration the fused step does not serve falls back to the registry's BUILT-IN class
+    # of that architecture, resolved lazily (importing the reference's llama module while plugins load would be circular)
+    _fallback_arch = None
+    _fallback_registry = None
+
+    @classmethod
+    def unsupported_reason(cls, config, cache_config=None, quant_config=None, lora_config=None, **extra) -> Optional[str]:
+        """None when the fused step serves this model; else why not (the engine then gets the reference's own model class on
+        top of this package's ops and quant methods -- the op-by-op path -- instead of an exception)."""
+        if lora_config is not None:
+            return "LoRA adapters"
+        hf = config.to_dict() if hasattr(config, "to_dict") else dict(vars(config))
+        try:
+            L.llama_config_from_hf(hf)
+        except (NotImplementedError, ValueError, KeyError) as e:
+            return str(e)
+        from .quantization.base_config import QuantizationConfig as OurBase
+        if quant_config is not None and not isinstance(quant_config, OurBase):
+            return f"quantization config {type(quant_config).__name__} is not one of this package's"
+        explicit = extra.get("dtype") or getattr(extra.get("model_config"), "dtype", None)
+        if isinstance(explicit, str):
+            explicit = getattr(torch, explicit, None)
+        if explicit is None and torch.get_default_dtype() != torch.float32:
+            explicit = torch.get_default_dtype()
+        if explicit is not None and explicit not in (torch.float16, torch.bfloat16):
+            return f"dtype {explicit}"
+        return None
+
+    def __new__(cls, *args, **kwargs):
+        # registered by default for the dense Llama-family architectures (plugin.register): a checkpoint the fused step does
+        # not serve must still load -- hand it to the reference's own class (an object that is not an instance of `cls`, so
+        # this class's __init__ does not run)
+        if cls._fallback_arch is not None and cls._fallback_registry is not None:
+            config = kwargs.get("config", args[0] if args else None)
+            rest = {k: v for k, v in kwargs.items() if k != "config"}
+            try:
+                reason = cls.unsupported_reason(config, **rest) if config is not None else None
+            except Exception as e:      # noqa: BLE001 -- a probe must never be the reason a model does not load
+                reason = f"probe failed: {e!r}"
+            if reason is not None:
+                fb = cls._fallback_registry._get_model(cls._fallback_arch)      # the built-in table, not the OOT one
+                if fb is not None:
+                    import logging
+                    logging.getLogger(__name__).warning("MI355X fused model not used (%s): the reference's %s runs on the "
+                                                        "MI355X ops instead", reason, getattr(fb, "__name__", fb))
+                    return fb(*args, **kwargs)
+        return super().__new__(cls)
 
     def __init__(self, config, cache_config=None, quant_config=None, lora_config=None, **extra) -> None:
         super().__init__()
@@ -128,6 +180,11 @@ class MI355XLlamaForCausalLM(nn.Module):
 
 
 def register_with_reference(model_registry, archs=("LlamaForCausalLM", "MistralForCausalLM")) -> None:
-    """ModelRegistry.register_model for the dense Llama-family architectures (idempotent: a dict assignment)."""
+    """ModelRegistry.register_model for the dense Llama-family architectures (idempotent: a dict assignment).  Each
+    architecture gets its own subclass carrying the reference's built-in class as the fallback for configurations the
+    fused step does not serve (sliding window, projection biases, LoRA, foreign quantization configs, float32)."""
     for arch in archs:
-        model_registry.register_model(arch, MI355XLlamaForCausalLM)
+        has_builtin = callable(getattr(model_registry, "_get_model", None))
+        cls = type(f"MI355X{arch}", (MI355XLlamaForCausalLM, ),
+                   {"_fallback_arch": arch if has_builtin else None, "_fallback_registry": model_registry if has_builtin else None})
+        model_registry.register_model(arch, cls)

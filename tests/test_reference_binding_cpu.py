@@ -257,7 +257,7 @@ if __name__ == "__main__":   # regenerate the committed call list (build contain
 
 @needs_ref
 def test_fused_model_registers_through_the_reference_model_registry(monkeypatch):
-    """APHRODITE_MI355X_FUSED_MODEL=1: plugin.register() hands MI355XLlamaForCausalLM to the reference's OWN ModelRegistry
+    """plugin.register() (default; APHRODITE_MI355X_FUSED_MODEL=0 opts out) hands MI355XLlamaForCausalLM to the reference's OWN ModelRegistry
     (modeling/models/__init__.py loaded by path), whose lookup then resolves the Llama architectures to it; the class is
     constructed with the keyword arguments ``build_model`` passes (model_loader/loader.py:144-157) and exposes the methods
     the model runner calls."""
@@ -279,12 +279,20 @@ def test_fused_model_registers_through_the_reference_model_registry(monkeypatch)
         reg = _load("aphrodite.modeling.models", "aphrodite/modeling/models/__init__.py")
         from aphrodite_engine_amd import plugin
         from aphrodite_engine_amd.reference_model import MI355XLlamaForCausalLM
-        monkeypatch.setenv("APHRODITE_MI355X_FUSED_MODEL", "1")
         builtin = reg._MODELS["LlamaForCausalLM"]
+        monkeypatch.setenv("APHRODITE_MI355X_FUSED_MODEL", "0")
+        plugin.register()                                                   # opted out: the registry keeps its own
+        assert "LlamaForCausalLM" not in reg._OOT_MODELS
+        monkeypatch.delenv("APHRODITE_MI355X_FUSED_MODEL")
+        # a stand-in for the reference's built-in class (its real module needs the whole engine): the fallback target
+        class RefLlama:
+            def __init__(self, *a, **k):
+                self.args, self.kwargs = a, k
+        monkeypatch.setattr(reg.ModelRegistry, "_get_model", staticmethod(lambda arch: RefLlama), raising=False)
         plugin.register()
         plugin.register()
-        assert reg.ModelRegistry._try_load_model_cls("LlamaForCausalLM") is MI355XLlamaForCausalLM
-        assert reg.ModelRegistry._try_load_model_cls("MistralForCausalLM") is MI355XLlamaForCausalLM
+        cls = reg.ModelRegistry._try_load_model_cls("LlamaForCausalLM")
+        assert issubclass(cls, MI355XLlamaForCausalLM) and issubclass(reg.ModelRegistry._try_load_model_cls("MistralForCausalLM"), MI355XLlamaForCausalLM)
         assert reg._MODELS["LlamaForCausalLM"] == builtin                   # the built-in table is untouched
         assert "LlamaForCausalLM" in reg.ModelRegistry.get_supported_archs()
         # constructed the way build_model does, from a HF-style config object
@@ -299,6 +307,16 @@ def test_fused_model_registers_through_the_reference_model_registry(monkeypatch)
         assert m.inner.layers[0].qkv_proj.qweight.shape == (512 // 8, (4 + 2 * 2) * 128)
         with pytest.raises(NotImplementedError):
             MI355XLlamaForCausalLM(config=hf, cache_config=cache, quant_config=None, lora_config=object())
+        # ... while the REGISTERED class hands what the fused step does not serve to the reference's built-in class
+        assert isinstance(cls(config=hf, cache_config=cache, quant_config=GPTQConfig(4, 128, False)), MI355XLlamaForCausalLM)
+        for bad_kw, bad_hf in ((dict(lora_config=object()), hf),
+                               ({}, types.SimpleNamespace(**{**vars(hf), "sliding_window": 4096})),
+                               ({}, types.SimpleNamespace(**{**vars(hf), "attention_bias": True})),
+                               (dict(quant_config=object()), hf)):
+            kw = dict(cache_config=cache, quant_config=GPTQConfig(4, 128, False))
+            kw.update(bad_kw)
+            ref = cls(config=bad_hf, **kw)
+            assert isinstance(ref, RefLlama) and ref.kwargs["config"] is bad_hf
     finally:
         for k in [k for k in sys.modules if k == "aphrodite" or k.startswith("aphrodite.") or k == "loguru"]:
             del sys.modules[k]
