@@ -6,6 +6,7 @@
 // The namespace is a build-time macro (APHRO_TORCH_NS, default `_C_mi355x`): built with -DAPHRO_TORCH_NS=_C it takes the
 // place of the reference's extension; the default lets both be loaded side by side (A/B runs, the tests here).
 // Schemas are the reference's, verbatim (kernels/torch_bindings.cpp line numbers on each def).
+#include <c10/hip/HIPGuard.h>
 #include <c10/hip/HIPStream.h>
 #include <torch/all.h>
 #include <torch/library.h>
@@ -314,6 +315,82 @@ void convert_fp8(torch::Tensor dst_cache, torch::Tensor src_cache, double scale,
      "convert_fp8");
 }
 
+// dynamic_scaled_fp8_quant (fp8/common.cu:133-186): ONE scale over the whole tensor.  `scale` is zeroed here, as the
+// reference's Python wrapper does before the call (_custom_ops.py:676), so that the atomic-max form needs no scratch.
+void dynamic_scaled_fp8_quant(torch::Tensor out, torch::Tensor input, torch::Tensor scale) {
+  TORCH_CHECK(input.is_contiguous() && out.is_contiguous() && scale.scalar_type() == torch::kFloat && scale.numel() >= 1,
+              "dynamic_scaled_fp8_quant: contiguous tensors and an fp32 scale expected");
+  scale.zero_();
+  ok(aphro_dynamic_scaled_fp8_quant(out.data_ptr(), input.data_ptr(), scale.data_ptr<float>(), rows_of(input), input.size(-1),
+                                    quant_in_dtype(input), cur_stream()),
+     "dynamic_scaled_fp8_quant");
+}
+
+// moe_align_block_size (moe_align_block_size_kernels.cu)
+void moe_align_block_size(torch::Tensor topk_ids, int64_t num_experts, int64_t block_size, torch::Tensor sorted_token_ids,
+                          torch::Tensor experts_ids, torch::Tensor num_tokens_post_pad) {
+  TORCH_CHECK(topk_ids.scalar_type() == torch::kInt && topk_ids.is_contiguous(), "moe_align_block_size: topk_ids must be contiguous int32");
+  const int64_t numel = topk_ids.numel(), need = numel + num_experts * (block_size - 1);
+  TORCH_CHECK(sorted_token_ids.numel() >= need && experts_ids.numel() >= (need + block_size - 1) / block_size,
+              "moe_align_block_size: output tensors too small");
+  ok(aphro_moe_align_block_size(topk_ids.data_ptr<int32_t>(), (int)num_experts, (int)block_size, sorted_token_ids.data_ptr<int32_t>(),
+                                experts_ids.data_ptr<int32_t>(), num_tokens_post_pad.data_ptr<int32_t>(), nullptr, numel, cur_stream()),
+     "moe_align_block_size");
+}
+
+// _moe_C::topk_softmax (kernels/moe/topk_softmax_kernels.cu)
+void topk_softmax(torch::Tensor topk_weights, torch::Tensor topk_indices, torch::Tensor token_expert_indices, torch::Tensor gating_output) {
+  TORCH_CHECK(gating_output.scalar_type() == torch::kFloat && gating_output.is_contiguous() && gating_output.dim() == 2,
+              "topk_softmax: gating_output must be contiguous float32 [tokens, experts]");
+  TORCH_CHECK(topk_indices.scalar_type() == torch::kInt && topk_weights.scalar_type() == torch::kFloat,
+              "topk_softmax: topk_weights must be float32 and topk_ids int32");
+  ok(aphro_topk_softmax(topk_weights.data_ptr<float>(), topk_indices.data_ptr<int32_t>(),
+                        token_expert_indices.defined() && token_expert_indices.numel() ? token_expert_indices.data_ptr<int32_t>() : nullptr,
+                        gating_output.data_ptr<float>(), gating_output.size(0), (int)gating_output.size(1), (int)topk_indices.size(1),
+                        cur_stream()),
+     "topk_softmax");
+}
+
+// swap_blocks (cache_kernels.cu:24-63): block_mapping is a CPU int64 [pairs, 2] tensor
+void swap_blocks(torch::Tensor src, torch::Tensor dst, const torch::Tensor& block_mapping) {
+  TORCH_CHECK(block_mapping.device().is_cpu(), "block_mapping must be on CPU");
+  int kind;
+  if (src.is_cuda() && dst.is_cuda()) {
+    TORCH_CHECK(src.device().index() == dst.device().index(), "src and dst must be on the same GPU");
+    kind = 0;
+  } else if (src.is_cuda() && dst.device().is_cpu()) {
+    kind = 1;
+  } else if (src.device().is_cpu() && dst.is_cuda()) {
+    kind = 2;
+  } else {
+    TORCH_CHECK(false, "Invalid device combination");
+  }
+  const torch::Tensor bm = block_mapping.to(torch::kLong).contiguous();
+  if (bm.numel() == 0) return;
+  const int64_t block_bytes = src[0].numel() * src.element_size();
+  const c10::hip::HIPGuard guard(src.is_cuda() ? src.device() : dst.device());
+  ok(aphro_swap_blocks(src.data_ptr(), dst.data_ptr(), bm.data_ptr<int64_t>(), bm.size(0), block_bytes, kind, cur_stream()), "swap_blocks");
+}
+
+// copy_blocks (cache_kernels.cu:103-148): block_mapping int64 [pairs, 2] on the device
+void copy_blocks(std::vector<torch::Tensor> const& key_caches, std::vector<torch::Tensor> const& value_caches,
+                 const torch::Tensor& block_mapping) {
+  const int64_t num_layers = (int64_t)key_caches.size();
+  TORCH_CHECK(num_layers == (int64_t)value_caches.size(), "copy_blocks: key_caches and value_caches differ in length");
+  if (num_layers == 0 || block_mapping.numel() == 0) return;
+  TORCH_CHECK(key_caches[0].is_cuda() && block_mapping.is_cuda(), "copy_blocks: device tensors expected");
+  std::vector<int64_t> kp(num_layers), vp(num_layers);
+  for (int64_t i = 0; i < num_layers; ++i) { kp[i] = (int64_t)key_caches[i].data_ptr(); vp[i] = (int64_t)value_caches[i].data_ptr(); }
+  const auto opts = torch::TensorOptions().dtype(torch::kLong);
+  const torch::Tensor kpt = torch::from_blob(kp.data(), {num_layers}, opts).to(key_caches[0].device());
+  const torch::Tensor vpt = torch::from_blob(vp.data(), {num_layers}, opts).to(key_caches[0].device());
+  const torch::Tensor bm = block_mapping.to(torch::kLong).contiguous();
+  const int64_t block_bytes = key_caches[0][0].numel() * key_caches[0].element_size();
+  ok(aphro_copy_blocks(kpt.data_ptr<int64_t>(), vpt.data_ptr<int64_t>(), (int)num_layers, bm.data_ptr<int64_t>(), bm.size(0),
+                       block_bytes, cur_stream()),
+     "copy_blocks");
+}
+
 }  // namespace
 
 TORCH_LIBRARY_FRAGMENT(APHRO_TORCH_NS, m) {
@@ -372,4 +449,26 @@ TORCH_LIBRARY_FRAGMENT(APHRO_CONCAT(APHRO_TORCH_NS, _cache_ops), m) {
   m.def("reshape_and_cache(Tensor key, Tensor value, Tensor! key_cache, Tensor! value_cache, Tensor slot_mapping, "
         "str kv_cache_dtype, float k_scale, float v_scale) -> ()");                                     // :467-473
   m.impl("reshape_and_cache", torch::kCUDA, &reshape_and_cache);
+}
+
+// round 5: the whole-tensor quantiser, the MoE routing ops, block copies / swaps
+TORCH_LIBRARY_FRAGMENT(APHRO_TORCH_NS, m) {
+  m.def("dynamic_scaled_fp8_quant(Tensor! out, Tensor input, Tensor! scale) -> ()");                    // :379-382
+  m.impl("dynamic_scaled_fp8_quant", torch::kCUDA, &dynamic_scaled_fp8_quant);
+  m.def("moe_align_block_size(Tensor topk_ids, int num_experts, int block_size, Tensor! sorted_token_ids, "
+        "Tensor! experts_ids, Tensor! num_tokens_post_pad) -> ()");                                     // :394-399
+  m.impl("moe_align_block_size", torch::kCUDA, &moe_align_block_size);
+}
+
+TORCH_LIBRARY_FRAGMENT(APHRO_CONCAT(APHRO_TORCH_NS, _moe), m) {
+  m.def("topk_softmax(Tensor! topk_weights, Tensor! topk_indices, Tensor! token_expert_indices, "
+        "Tensor gating_output) -> ()");                                                 // kernels/moe/torch_bindings.cpp:11-14
+  m.impl("topk_softmax", torch::kCUDA, &topk_softmax);
+}
+
+TORCH_LIBRARY_FRAGMENT(APHRO_CONCAT(APHRO_TORCH_NS, _cache_ops), m) {
+  m.def("swap_blocks(Tensor src, Tensor! dst, Tensor block_mapping) -> ()");                            // :456-458
+  m.impl("swap_blocks", torch::kCUDA, &swap_blocks);
+  m.def("copy_blocks(Tensor(a!)[] key_caches, Tensor[](b!) value_caches, Tensor block_mapping) -> ()"); // :461-464
+  m.impl("copy_blocks", torch::kCUDA, &copy_blocks);
 }

@@ -300,7 +300,12 @@ def test_cpp_torch_library_registration():
     assert "reshape_and_cache(Tensor key, Tensor value" in str(torch.ops._C_mi355x_cache_ops.reshape_and_cache.default._schema)
     cache_ns = [ns for ns in ("_aphro_t_cache", "_aphro_g_cache", "_C_cache_ops") if hasattr(torch.ops, ns)
                 and hasattr(getattr(torch.ops, ns), "convert_fp8")]
-    for name in ("reshape_and_cache", "reshape_and_cache_flash", "convert_fp8"):
+    # round 5: block copies / swaps, the whole-tensor quantiser, the MoE routing ops
+    for name in ("dynamic_scaled_fp8_quant", "moe_align_block_size"):
+        assert strip(getattr(torch.ops._C_mi355x, name).default._schema) == strip(getattr(getattr(torch.ops, py_ns[0]), name).default._schema), name
+    moe_ns = [ns for ns in ("_aphro_t_moe", "_aphro_g_moe", "_moe_C") if hasattr(torch.ops, ns) and hasattr(getattr(torch.ops, ns), "topk_softmax")]
+    assert moe_ns and strip(torch.ops._C_mi355x_moe.topk_softmax.default._schema) == strip(getattr(torch.ops, moe_ns[0]).topk_softmax.default._schema)
+    for name in ("reshape_and_cache", "reshape_and_cache_flash", "convert_fp8", "swap_blocks", "copy_blocks"):
         cpp = getattr(torch.ops._C_mi355x_cache_ops, name).default._schema
         assert cache_ns and strip(cpp) == strip(getattr(getattr(torch.ops, cache_ns[0]), name).default._schema), name
     with pytest.raises((RuntimeError, NotImplementedError)):

@@ -411,3 +411,58 @@ def test_reference_wrapper_call_list_resolves_on_the_device_box(T):
             packet = getattr(getattr(torch.ops, ns_map[ns]), op)        # AttributeError = the reference's hint_on_error case
             schema = packet.default._schema
             assert len(schema.arguments) == nargs, (wrapper, op, str(schema))
+
+
+def test_cpp_registered_round5_ops_match_the_python_registration(T):
+    """Round 5: dynamic_scaled_fp8_quant, moe_align_block_size, _moe::topk_softmax, swap_blocks, copy_blocks from C++ -- the
+    same C ABI underneath, the same results as the Python-registered ops."""
+    from aphrodite_engine_amd import torch_cpp
+    torch_cpp.load()
+    C, cache, moe = torch.ops._C_mi355x, torch.ops._C_mi355x_cache_ops, torch.ops._C_mi355x_moe
+    rng = np.random.default_rng(3)
+    x = t(rng.standard_normal((9, 512)).astype(np.float32), torch.float16)
+    a, b = (torch.empty(9, 512, dtype=torch.float8_e4m3fn, device=DEV) for _ in range(2))
+    sa, sb = torch.zeros(1, device=DEV), torch.full((1, ), 123.0, device=DEV)      # (C++ zeroes the scale itself)
+    T.C.dynamic_scaled_fp8_quant(a, x, sa)
+    C.dynamic_scaled_fp8_quant(b, x, sb)
+    assert torch.equal(a.view(torch.uint8), b.view(torch.uint8)) and torch.equal(sa, sb)
+    # routing
+    gating = t(rng.standard_normal((33, 8)).astype(np.float32))
+    outs = []
+    for ns in (T.moe, moe):
+        w = torch.empty(33, 2, device=DEV)
+        ids = torch.empty(33, 2, dtype=torch.int32, device=DEV)
+        src = torch.empty(33, 2, dtype=torch.int32, device=DEV)
+        ns.topk_softmax(w, ids, src, gating)
+        outs.append((w, ids, src))
+    assert all(torch.equal(p, q) for p, q in zip(*outs))
+    ids = outs[0][1]
+    res = []
+    for ns in (T.C, C):
+        cap = ids.numel() + 8 * 15
+        sorted_ids = torch.full((cap, ), -1, dtype=torch.int32, device=DEV)
+        experts = torch.full(((cap + 15) // 16, ), -1, dtype=torch.int32, device=DEV)
+        post = torch.zeros(1, dtype=torch.int32, device=DEV)
+        ns.moe_align_block_size(ids, 8, 16, sorted_ids, experts, post)
+        res.append((sorted_ids, experts, post))
+    n = int(res[0][2].item())
+    assert int(res[1][2].item()) == n and torch.equal(res[0][0][:n], res[1][0][:n]) and torch.equal(res[0][1][:n // 16], res[1][1][:n // 16])
+    # block copies: two layers, pairs (0 -> 3), (2 -> 1)
+    kc = [t(rng.standard_normal((4, 2, 16, 16, 8)).astype(np.float32), torch.float16) for _ in range(2)]
+    vc = [t(rng.standard_normal((4, 2, 128, 16)).astype(np.float32), torch.float16) for _ in range(2)]
+    kc2, vc2 = [c.clone() for c in kc], [c.clone() for c in vc]
+    bm = torch.tensor([[0, 3], [2, 1]], dtype=torch.int64, device=DEV)
+    T.cache.copy_blocks(kc, vc, bm)
+    cache.copy_blocks(kc2, vc2, bm)
+    assert all(torch.equal(p, q) for p, q in zip(kc + vc, kc2 + vc2)) and torch.equal(kc2[1][3], kc2[1][0])
+    src_cache = t(rng.standard_normal((4, 2, 128, 16)).astype(np.float32), torch.float16)
+    d1, d2 = torch.zeros_like(src_cache), torch.zeros_like(src_cache)
+    bmh = torch.tensor([[1, 0], [3, 2]], dtype=torch.int64)
+    T.cache.swap_blocks(src_cache, d1, bmh)
+    cache.swap_blocks(src_cache, d2, bmh)
+    torch.cuda.synchronize()
+    assert torch.equal(d1, d2) and torch.equal(d2[0], src_cache[1]) and torch.equal(d2[2], src_cache[3])
+    host = torch.zeros(4, 2, 128, 16, dtype=torch.float16).pin_memory()
+    cache.swap_blocks(src_cache, host, bmh)                  # device -> host
+    torch.cuda.synchronize()
+    assert torch.equal(host[0], src_cache[1].cpu())
