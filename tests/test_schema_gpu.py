@@ -27,6 +27,7 @@ def T():
         C = torch.ops._aphro_g_C
         cache = torch.ops._aphro_g_cache
         rocm = torch.ops._aphro_g_rocm
+        moe = torch.ops._aphro_g_moe
     return NS
 
 
