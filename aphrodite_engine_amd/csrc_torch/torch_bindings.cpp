@@ -6,7 +6,7 @@
 // The namespace is a build-time macro (APHRO_TORCH_NS, default `_C_mi355x`): built with -DAPHRO_TORCH_NS=_C it takes the
 // place of the reference's extension; the default lets both be loaded side by side (A/B runs, the tests here).
 // Schemas are the reference's, verbatim (kernels/torch_bindings.cpp line numbers on each def).
-#include <c10/hip/HIPGuard.h>
+#include <c10/core/DeviceGuard.h>
 #include <c10/hip/HIPStream.h>
 #include <torch/all.h>
 #include <torch/library.h>
@@ -368,7 +368,7 @@ void swap_blocks(torch::Tensor src, torch::Tensor dst, const torch::Tensor& bloc
   const torch::Tensor bm = block_mapping.to(torch::kLong).contiguous();
   if (bm.numel() == 0) return;
   const int64_t block_bytes = src[0].numel() * src.element_size();
-  const c10::hip::HIPGuard guard(src.is_cuda() ? src.device() : dst.device());
+  const c10::DeviceGuard guard(src.is_cuda() ? src.device() : dst.device());
   ok(aphro_swap_blocks(src.data_ptr(), dst.data_ptr(), bm.data_ptr<int64_t>(), bm.size(0), block_bytes, kind, cur_stream()), "swap_blocks");
 }
 
