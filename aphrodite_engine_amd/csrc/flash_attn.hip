@@ -462,6 +462,9 @@ __global__ __launch_bounds__(NWV * 64) void flash_attn_varlen_v2_kernel(FAParams
 //   * O leaves through a wave-private LDS transpose as full 256-byte rows.
 // Keys beyond the sequence are fetched as zeros by the buffer descriptor's bounds check.
 // ---------------------------------------------------------------------------
+#ifndef FA3_ASM_DMA
+#define FA3_ASM_DMA 0
+#endif
 #ifndef FA_QK_SCHED
 #define FA_QK_SCHED 1
 #endif
@@ -534,10 +537,18 @@ __global__ __launch_bounds__(512) void flash_attn_varlen_v3_kernel(FAParams p) {
   // ---- K / V staging: buffer descriptors over this sequence's rows of this kv head (reads past the end return 0) -------
   const uint16_t* kbase = (const uint16_t*)p.k + (size_t)s0 * p.k_stride + (size_t)kvh * HD;
   const uint16_t* vbase = (const uint16_t*)p.v + (size_t)s0 * p.v_stride + (size_t)kvh * HD;
+#if FA3_ASM_DMA
+  // (round 5: the LDS-DMA pieces as inline asm, see fa_dma16 -- behind a DMA it can see hipcc drains vmcnt to 0 in front of
+  //  the next LDS read, i.e. right after the pieces of tile it + 2 are issued)
+  const u32x4 rk = fa_make_rsrc(kbase, (uint32_t)(((size_t)(len - 1) * p.k_stride + HD) * 2));
+  const u32x4 rv = fa_make_rsrc(vbase, (uint32_t)(((size_t)(len - 1) * p.v_stride + HD) * 2));
+  const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)fa_smem;
+#else
   const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(kbase), 0,
       (uint32_t)(((size_t)(len - 1) * p.k_stride + HD) * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(vbase), 0,
       (uint32_t)(((size_t)(len - 1) * p.v_stride + HD) * 2), 0x00020000);
+#endif
   // a wave stages pieces 2 wave, 2 wave + 1 (4 keys = 1 KiB each) of both tiles.
   // K piece: lane L -> key 4 c + (L >> 4), LDS slot L & 15 holds d-chunk slot ^ (key & 15)
   // V piece: lane L -> key 4 c + (L & 3), d-chunk L >> 2  (image [d-chunk][key] inside the piece)
@@ -555,8 +566,13 @@ __global__ __launch_bounds__(512) void flash_attn_varlen_v3_kernel(FAParams p) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int kv = k_voff[j], vv = v_voff[j];     // (local copies: see wna16_gemm_large.hip on the hipcc host-stub bug)
+#if FA3_ASM_DMA
+      fa_dma16(rk, lds0 + buf * STAGE + (2 * wave + j) * 1024, kv, __builtin_amdgcn_readfirstlane((int)(t0 * p.k_stride * 2)));
+      fa_dma16(rv, lds0 + buf * STAGE + KT + (2 * wave + j) * 1024, vv, __builtin_amdgcn_readfirstlane((int)(t0 * p.v_stride * 2)));
+#else
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (fa_lds_ptr)(sk + (2 * wave + j) * 1024), 16, kv, (int)(t0 * p.k_stride * 2), 0, 0);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (fa_lds_ptr)(sk + KT + (2 * wave + j) * 1024), 16, vv, (int)(t0 * p.v_stride * 2), 0, 0);
+#endif
     }
   };
   // fragment read addresses (lane-invariant parts)

@@ -53,16 +53,6 @@ typedef short fa4_s16x4 __attribute__((ext_vector_type(4)));
 #define FA4_THR 8.0f        // defer-max threshold, log2 units
 #endif
 
-// One LDS-DMA instruction (64 lanes x 16 bytes -> 1 KiB at LDS byte address `lds`), hidden from hipcc: behind a DMA it can
-// see, hipcc drains vmcnt to 0 in front of the next LDS read of the kernel (it cannot tell the slots apart) -- every piece
-// was waited for, the full memory latency exposed, 4 times per phase (SQ_WAIT_ANY 48 % of the wave cycles).  The pieces are
-// counted by hand instead (vmcnt before the barrier at the top of a body).  s_nop 4: SGPR operands may be fresh SALU results.
-__device__ __forceinline__ void fa4_dma16(u32x4 rsrc, uint32_t lds, int voff, int soff) {
-  uint32_t keep;
-  asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "s"(lds), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
-}
-
 // S += K . Q^T with the register classes chosen by hand: the scores accumulate in VGPRs, the Q fragment is read straight
 // from the accumulator file.  hipcc picks ONE form per kernel -- with 512 registers every MFMA result goes to the
 // accumulator file, so the 64 scores of a tile came back through 64 v_accvgpr_read (measured: 22 cycles each beside
@@ -137,13 +127,8 @@ void flash_attn_varlen_v4_kernel(FAParams p) {
   const uint16_t* kbase = (const uint16_t*)p.k + (size_t)k_row0 * p.k_stride + (size_t)kvh * HD;
   const uint16_t* vbase = (const uint16_t*)p.v + (size_t)k_row0 * p.v_stride + (size_t)kvh * HD;
   // buffer descriptors over this sequence's rows of this kv head (reads past the end return 0): base, no stride, bytes, raw dword format
-  auto make_rsrc = [](const void* base, uint32_t bytes) __attribute__((always_inline)) {
-    const uint64_t a = (uint64_t)base;
-    return u32x4{(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)a), (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(a >> 32) & 0xffffu),
-                 (uint32_t)__builtin_amdgcn_readfirstlane(bytes), 0x00020000u};
-  };
-  const u32x4 rk = make_rsrc(kbase, (uint32_t)(((size_t)(len - 1) * p.k_stride + HD) * 2));
-  const u32x4 rv = make_rsrc(vbase, (uint32_t)(((size_t)(len - 1) * p.v_stride + HD) * 2));
+  const u32x4 rk = fa_make_rsrc(kbase, (uint32_t)(((size_t)(len - 1) * p.k_stride + HD) * 2));
+  const u32x4 rv = fa_make_rsrc(vbase, (uint32_t)(((size_t)(len - 1) * p.v_stride + HD) * 2));
   const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)fa_smem;
   // K piece: lane L -> key 4 c + (L >> 4), LDS slot L & 15 holds d-chunk slot ^ (key & 15)
   // V piece: lane L -> key 4 c + (L & 3), d-chunk L >> 2  (image [d-chunk][key] inside the piece)
@@ -158,10 +143,10 @@ void flash_attn_varlen_v4_kernel(FAParams p) {
   }
   // one 1-KiB piece (j of this wave's 4) of the K / V tile t into ring slot t & 3
   auto stage_k1 = [&](int t, int j) __attribute__((always_inline)) {
-    fa4_dma16(rk, lds0 + (t & 3) * KT + (4 * wave + j) * 1024, k_voff[j], __builtin_amdgcn_readfirstlane((int)(t * BN * p.k_stride * 2)));
+    fa_dma16(rk, lds0 + (t & 3) * KT + (4 * wave + j) * 1024, k_voff[j], __builtin_amdgcn_readfirstlane((int)(t * BN * p.k_stride * 2)));
   };
   auto stage_v1 = [&](int t, int j) __attribute__((always_inline)) {
-    fa4_dma16(rv, lds0 + 4 * KT + (t & 3) * KT + (4 * wave + j) * 1024, v_voff[j], __builtin_amdgcn_readfirstlane((int)(t * BN * p.v_stride * 2)));
+    fa_dma16(rv, lds0 + 4 * KT + (t & 3) * KT + (4 * wave + j) * 1024, v_voff[j], __builtin_amdgcn_readfirstlane((int)(t * BN * p.v_stride * 2)));
   };
   auto stage_k = [&](int t) __attribute__((always_inline)) {
 #pragma unroll
