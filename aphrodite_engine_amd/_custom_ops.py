@@ -483,6 +483,30 @@ def _wna16_large(a, qweight, qzeros, scales, perm, zero_offset):
     return out
 
 
+def wna16_gemm_large_silu_supported(m: int, n: int, k: int, groups: int) -> bool:
+    return bool(_lib.lib().aphro_wna16_gemm_large_silu_supported(m, n, k, groups)) and m * k * 2 < 2 ** 32
+
+
+def wna16_gemm_large_silu(a: torch.Tensor, qweight: torch.Tensor, qzeros: torch.Tensor, scales: torch.Tensor,
+                          zero_offset: int) -> torch.Tensor:
+    """Prompt-sized gate_up GEMM on INTERLEAVED (gate_j, up_j) columns (ops.interleave_gate_up) with SiluAndMul in the
+    epilogue: act [M, N / 2] -- the bits of the GEMM followed by silu_and_mul(..., interleaved=True), without the [M, N]
+    round trip through HBM.  K-packed exllama weights, no act-order (csrc/wna16_gemm_large.hip)."""
+    _require_cuda(a, qweight, qzeros, scales)
+    m, k = a.shape
+    n = qweight.shape[1]
+    lib = _lib.lib()
+    if a.stride(1) != 1 or a.stride(0) % 8 != 0 or a.data_ptr() % 16 != 0:
+        a = a.contiguous()
+    out = torch.empty((m, n // 2), dtype=a.dtype, device=a.device)
+    nbytes = lib.aphro_wna16_gemm_large_workspace_bytes(m, n, k, scales.shape[0], _dt(a))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=a.device) if nbytes else None
+    check(lib.aphro_wna16_gemm_large_silu(a.data_ptr(), qweight.data_ptr(), qzeros.data_ptr(), scales.data_ptr(),
+                                          out.data_ptr(), _ptr(ws), nbytes, m, n, k, scales.shape[0], a.stride(0),
+                                          zero_offset, _dt(a), _stream()), "wna16_gemm_large_silu")
+    return out
+
+
 def wna16_mid_ok(m: int, n: int, k: int, groups: int) -> bool:
     return bool(_lib.lib().aphro_wna16_gemm_mid_supported(m, n, k, groups)) and m * k * 2 < 2 ** 32
 

@@ -85,6 +85,8 @@ SIGNATURES = {
     "aphro_spin_us": (I, [ctypes.c_double, P]),
     "aphro_wna16_gemm_large_workspace_bytes": (Z, [L, L, L, L, I]),
     "aphro_wna16_gemm_large": (I, [P, P, P, P, P, P, Z, L, L, L, L, L, I, I, P]),
+    "aphro_wna16_gemm_large_silu_supported": (I, [L, L, L, L]),
+    "aphro_wna16_gemm_large_silu": (I, [P, P, P, P, P, P, Z, L, L, L, L, L, I, I, P]),
     "aphro_wna16_gemm_mid_supported": (I, [L, L, L, L]),
     "aphro_wna16_gemm_mid_workspace_bytes": (Z, [L, L, L, L]),
     "aphro_wna16_gemm_mid": (I, [P, P, P, P, P, P, Z, L, L, L, L, L, I, I, P]),

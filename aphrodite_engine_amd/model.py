@@ -673,6 +673,17 @@ class LlamaDecoderLayer(nn.Module):
         ops.fused_add_rms_norm(hidden, residual, self.post_attention_layernorm, eps)
         if self.is_moe:
             return self.moe_block(hidden), residual
+        il = self.gate_up_interleaved is not None and not self.gate_up_keep_original
+        if il and hidden.shape[0] > 64 and not os.environ.get("APHRO_PREFILL_NO_SILU_EPILOGUE"):
+            # prompt-sized batches on the interleaved copy: SiluAndMul in the GEMM's epilogue (same bits, no [M, 2 I] round trip)
+            qw, qz, sc, zo = self.gate_up_interleaved
+            if ops.wna16_gemm_large_silu_supported(hidden.shape[0], qw.shape[1], hidden.shape[1], sc.shape[0]) \
+                    and hidden.dtype == sc.dtype:
+                act = ops.wna16_gemm_large_silu(hidden, qw, qz, sc, zo)
+                hidden = self.down_proj(act)
+                if self.tp > 1:
+                    hidden = tensor_model_parallel_all_reduce(hidden)
+                return hidden, residual
         gate_up = self.gate_up_proj(hidden)
         act = torch.empty(gate_up.shape[0], gate_up.shape[1] // 2, dtype=gate_up.dtype,
                           device=gate_up.device)

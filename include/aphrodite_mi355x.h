@@ -595,6 +595,15 @@ size_t aphro_wna16_gemm_large_workspace_bytes(int64_t M, int64_t N, int64_t K, i
 int aphro_wna16_gemm_large(const void* a, const uint32_t* q_weight, const uint32_t* qzeros, const void* scales,
                            void* c, void* workspace, size_t workspace_bytes, int64_t M, int64_t N, int64_t K,
                            int64_t groups, int64_t lda, int zero_offset, int dtype, void* stream);
+/* The same GEMM on a gate_up matrix whose columns are interleaved (gate_j, up_j) pairs, SiluAndMul in the epilogue:
+ * act [M, N / 2] = silu_and_mul(a . dequant(W)), the GEMM result rounded to the dtype first -- the bits of
+ * aphro_wna16_gemm_large followed by aphro_silu_and_mul_interleaved (gptq_gemm / awq_gemm + kernels/activation_kernels.cu:12-75
+ * in the reference's LlamaMLP, modeling/models/llama.py:88-93) without the [M, N] round trip.  Shapes the plan cuts into
+ * K slices are not served (aphro_wna16_gemm_large_silu_supported == 0).  csrc/wna16_gemm_large.hip. */
+int aphro_wna16_gemm_large_silu_supported(int64_t M, int64_t N, int64_t K, int64_t groups);
+int aphro_wna16_gemm_large_silu(const void* a, const uint32_t* q_weight, const uint32_t* qzeros, const void* scales,
+                                void* act, void* workspace, size_t workspace_bytes, int64_t M, int64_t N, int64_t K,
+                                int64_t groups, int64_t lda, int zero_offset, int dtype, void* stream);
 
 /* W4A16 GEMM for decode batches of 33..64 rows (any M in 1..64 is accepted) -- the reference runs its exllama kernel
  * up to 50 rows and reconstruct + hipBLAS above (kernels/quantization/gptq/q_gemm.cu:1529-1544); Marlin covers the range

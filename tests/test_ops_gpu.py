@@ -1520,6 +1520,34 @@ def test_fused_silu_model_matches_unfused(ops, keep_original):
         torch.testing.assert_close(outs[1], ref, atol=2e-2, rtol=2e-2)
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M_,K,N", [(8192, 4096, 28672), (300, 1024, 2048), (1000, 2048, 4096), (129, 512, 1024)])
+def test_wna16_gemm_large_silu_epilogue_matches_gemm_then_silu(ops, dtype, M_, K, N):
+    """Prompt-sized gate_up GEMM on interleaved (gate_j, up_j) columns with SiluAndMul in its epilogue == the same GEMM followed
+    by silu_and_mul(interleaved=True), bit for bit (stream-K tiles cut between workgroups, ragged last row tile, bf16), and ==
+    silu_and_mul of the [gate | up] GEMM on the original column order."""
+    rng = np.random.default_rng(K + N)
+    G = 128
+    g = torch.Generator(device=DEV).manual_seed(K + M_)
+    qw = torch.randint(-2 ** 31, 2 ** 31 - 1, (K // 8, N), generator=g, device=DEV, dtype=torch.int64).to(torch.int32)
+    qz = torch.randint(-2 ** 31, 2 ** 31 - 1, (K // G, N // 8), generator=g, device=DEV, dtype=torch.int64).to(torch.int32)
+    sc = (torch.rand(K // G, N, generator=g, device=DEV) * 0.01 + 0.005).to(dtype)
+    a = (torch.randn(M_, K, generator=g, device=DEV) * 0.5).to(dtype)
+    if not ops.wna16_gemm_large_silu_supported(M_, N, K, K // G):
+        pytest.skip("shape is K-sliced by the plan")
+    qw_il, qz_il, sc_il = ops.interleave_gate_up(qw, qz, sc)
+    full = ops._wna16_large(a, qw_il, qz_il, sc_il, None, 1)                  # the same tile machine: [M, N], interleaved columns
+    want = torch.empty(M_, N // 2, dtype=dtype, device=DEV)
+    ops.silu_and_mul(want, full, interleaved=True)
+    got = ops.wna16_gemm_large_silu(a, qw_il, qz_il, sc_il, 1)
+    assert got.shape == want.shape and torch.equal(got, want)
+    if M_ <= 1000:
+        plain = ops._wna16_large(a, qw, qz, sc, None, 1)                       # [gate | up]
+        want2 = torch.empty_like(want)
+        ops.silu_and_mul(want2, plain)
+        assert torch.equal(got, want2)
+
+
 def test_fused_decode_model_matches_unfused(ops):
     """Whole decode step: fused fast path vs the op-by-op path of the same model."""
     from aphrodite_engine_amd import model as M
