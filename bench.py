@@ -495,6 +495,8 @@ def prefill_e2e_section(T=8192, library=True, which=("int4", "fp8")):
         cfg = dataclasses.replace(M.LLAMA3_8B, max_position_embeddings=max(8192, T))
         model = M.LlamaForCausalLM(cfg, qc, torch.float16, kv)
         model.init_synthetic(dev, seed=0)
+        for layer in model.layers:      # the layouts the engine adapter leaves behind (reference_model._finish): ONE interleaved
+            layer.enable_fused_silu(32, keep_original=False)      # gate_up copy -> SiluAndMul rides in the prefill GEMM's epilogue
         nblk = (T + BS - 1) // BS
         caches = M.make_kv_caches(cfg, nblk, BS, torch.float16, kv, dev, fill=False)
         bt = torch.randperm(nblk, device=dev).to(torch.int32).view(1, nblk)
