@@ -674,7 +674,8 @@ class LlamaDecoderLayer(nn.Module):
         if self.is_moe:
             return self.moe_block(hidden), residual
         il = self.gate_up_interleaved is not None and not self.gate_up_keep_original
-        if il and hidden.shape[0] > 64 and not os.environ.get("APHRO_PREFILL_NO_SILU_EPILOGUE"):
+        if il and hidden.shape[0] > 64 and not os.environ.get("APHRO_PREFILL_NO_SILU_EPILOGUE") \
+                and not os.environ.get("APHRO_WNA16_NO_LARGE"):
             # prompt-sized batches on the interleaved copy: SiluAndMul in the GEMM's epilogue (same bits, no [M, 2 I] round trip)
             qw, qz, sc, zo = self.gate_up_interleaved
             if ops.wna16_gemm_large_silu_supported(hidden.shape[0], qw.shape[1], hidden.shape[1], sc.shape[0]) \
