@@ -1724,7 +1724,8 @@ def cutlass_scaled_mm(a: torch.Tensor, b: torch.Tensor, scale_a: torch.Tensor,
         # shapes the hand-written kernel does not tile (N or K not a multiple of 128): library GEMM: a plain library GEMM (hipBLASLt through torch._scaled_mm --
         # what the reference itself calls on ROCm, w8a8_utils.py:130,165; measured 1.9 PFLOP/s fp8 at
         # M = 8192).  Row-wise scaling needs both scale vectors; a scalar one is broadcast.
-        _library_fallback("cutlass_scaled_mm", f"M={m} N={n} K={k}: N or K not a multiple of 128 (torch._scaled_mm)")
+        why = "APHRO_FP8_NO_LARGE is set" if (n % 128 == 0 and k % 128 == 0) else "N or K not a multiple of 128"
+        _library_fallback("cutlass_scaled_mm", f"M={m} N={n} K={k}: {why} (torch._scaled_mm)")
         sa_, sb_ = scale_a.reshape(-1).float(), scale_b.reshape(-1).float()
         if sa_.numel() > 1 or sb_.numel() > 1:
             sa_ = (sa_ if sa_.numel() > 1 else sa_.expand(m)).reshape(m, 1).contiguous()

@@ -149,7 +149,7 @@ def _ar_norm_worker(rank, world, port, one_shot_max):
     gen = torch.Generator(device="cpu")
     try:
         cases = [(torch.float16, 32, 4096), (torch.bfloat16, 64, 8192), (torch.float16, 1, 1024), (torch.float16, 7, 5120),
-                 (torch.bfloat16, 33, 8192), (torch.float16, 17, 16384), (torch.float16, 3, 4096), (torch.float16, 64, 2048)]
+                 (torch.float16, 17, 16384), (torch.bfloat16, 3, 4096)]
         pf_weights = torch.randint(0, 2 ** 31 - 1, (3 * 1024 * 1024 + 5, ), dtype=torch.int32, device=dev)[1:]    # 12 MiB, unaligned start
         for dtype, tokens, hidden in cases:
             gen.manual_seed(31 * tokens + hidden)
@@ -159,7 +159,7 @@ def _ar_norm_worker(rank, world, port, one_shot_max):
             x = parts[rank].to(dev)
             one_shot = ops.custom_ar_fused_norm_one_shot(world, tokens, hidden, 2)
             for has_res in (True, False):
-                for shard in (False, ):
+                if True:
                     for pack, want_out in ((True, False), (False, True), (True, True)):
                         # the two-op sequence
                         r_ref = res0.clone()
@@ -216,7 +216,7 @@ def _ar_norm_worker(rank, world, port, one_shot_max):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,one_shot_max", [(2, None), (4, None), (2, 65536), (4, 0)])
+@pytest.mark.parametrize("world,one_shot_max", [(4, None), (2, 65536), (4, 0)])
 def test_fused_all_reduce_norm_ranks_on_one_gpu(world, one_shot_max):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
