@@ -963,7 +963,7 @@ def test_flash_attn_varlen_v3_kv_head_placement(ops, dtype, causal):
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("causal,alibi", [(True, False), (False, False), (True, True)])
-@pytest.mark.parametrize("Hq,Hkv", [(16, 8), (8, 2)])
+@pytest.mark.parametrize("Hq,Hkv", [(16, 8)])
 def test_flash_attn_varlen_v4(ops, dtype, causal, alibi, Hq, Hkv):
     """Fourth-generation prefill kernel (one wave per SIMD, two 32-row query blocks per wave, defer-max; flash_attn_v4.hip),
     forced on from 1024 keys: ragged lengths around the 256-row / 64-key tile edges, sequences of one to five tiles next to
@@ -971,7 +971,7 @@ def test_flash_attn_varlen_v4(ops, dtype, causal, alibi, Hq, Hkv):
     import os
     rng = np.random.default_rng(11 + Hq)
     D = 128
-    lens = [1300, 257, 1024, 65, 1, 640, 2049]
+    lens = [1300, 257, 1024, 65, 1, 640]        # (GQA 4:1 and > 2048 keys: the defer-max test below)
     cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
     T = int(cu[-1])
     qkv = t(rng.standard_normal((T, (Hq + 2 * Hkv) * D)).astype(np.float32) * 0.7, dtype)
