@@ -183,7 +183,7 @@ class CustomAllreduce:
 
     # -- all-reduce + residual add + RMSNorm (+ pack) in one launch -------------------------------------
     def fused_norm_eligible(self, inp: torch.Tensor) -> bool:
-        return (self.should_custom_ar(inp) and inp.dim() == 2 and inp.shape[0] <= 64 and inp.shape[1] % 8 == 0
+        return (self.should_custom_ar(inp) and inp.dim() == 2 and inp.shape[0] <= 64 and inp.shape[1] % 128 == 0
                 and inp.shape[1] <= 16384 and inp.dtype in (torch.float16, torch.bfloat16) and inp.is_contiguous()
                 and inp.numel() * inp.element_size() <= self.max_size)
 
