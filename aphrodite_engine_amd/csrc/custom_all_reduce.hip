@@ -824,7 +824,8 @@ extern "C" int aphro_custom_ar_fused_add_rms_norm(void* fa_, const void* inp, vo
   APHRO_CHECK(packed != nullptr || out != nullptr, "custom_ar_fused_add_rms_norm: no output requested");
   APHRO_CHECK(tokens >= 0 && tokens <= (int64_t)AR_MAX_BLOCKS, "custom_ar_fused_add_rms_norm: %lld tokens (at most %d: decode batches)",
               (long long)tokens, AR_MAX_BLOCKS);
-  APHRO_CHECK(((uintptr_t)inp % 16) == 0, "custom_ar_fused_add_rms_norm: input must be 16-byte aligned");
+  APHRO_CHECK((((uintptr_t)inp | (uintptr_t)residual | (uintptr_t)weight | (uintptr_t)packed | (uintptr_t)out) % 16) == 0,
+              "custom_ar_fused_add_rms_norm: input, residual, weight and outputs must be 16-byte aligned");
   if (tokens == 0) return APHRO_OK;
   const size_t bytes = (size_t)tokens * hidden * 2;
   const void* src = inp;

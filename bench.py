@@ -457,6 +457,58 @@ def prefill_section(cfg):
     ob = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
     t = timeit(lambda: ops.cutlass_scaled_mm(a8, w8.t(), sa, sb, torch.bfloat16, out=ob), 3)
     out[f"cutlass_scaled_mm W8A8 fp8 {M}x{K}x{N}"] = dict(ms=t * 1e3, TFLOPs=fl / t / 1e12, frac=fl / t / 5.0e15, bound="mfma fp8")
+    del w8, a8, sa, sb, ob
+    # ---- every prompt-sized GEMM shape of the model, ours next to what the reference already calls on ROCm, same run: gptq
+    # dequantise + hipBLASLt (q_gemm.cu:1529-1544's reconstruct + hipBLAS) and torch._scaled_mm (w8a8_utils.py:130,165); causal
+    # attention next to torch SDPA.  A stated baseline: ratio > 1 = the hand-written kernel is faster.
+    vs = {}
+    import torch.nn.functional as F
+    try:
+        qs = q.transpose(0, 1).unsqueeze(0)
+        ks, vs_ = k.transpose(0, 1).unsqueeze(0), v.transpose(0, 1).unsqueeze(0)
+        t_lib = timeit(lambda: F.scaled_dot_product_attention(qs, ks, vs_, is_causal=True, scale=D ** -0.5, enable_gqa=True))
+        t_our = out["flash_attn_varlen causal T=8192"]["ms"] * 1e-3
+        vs["attention causal T=8192"] = dict(ours_ms=t_our * 1e3, library_ms=t_lib * 1e3, ratio=t_lib / t_our, library="torch SDPA")
+    except Exception as e:
+        vs["attention causal T=8192"] = {"error": repr(e)[:120]}
+    h, inter = cfg.hidden_size, cfg.intermediate_size
+    shapes = {"qkv": (h, (Hq + 2 * Hkv) * D), "o": (Hq * D, h), "gate_up": (h, 2 * inter), "down": (inter, h)}
+
+    def with_env(name, fn):
+        old = os.environ.get(name)
+        os.environ[name] = "1"
+        try:
+            return timeit(fn, 3)
+        finally:
+            if old is None:
+                os.environ.pop(name, None)
+            else:
+                os.environ[name] = old
+    for name, (K2, N2) in shapes.items():
+        try:
+            qw = torch.randint(-2 ** 31, 2 ** 31 - 1, (K2 // 8, N2), generator=g, device=dev, dtype=torch.int64).to(torch.int32)
+            qz = torch.randint(-2 ** 31, 2 ** 31 - 1, (K2 // 128, N2 // 8), generator=g, device=dev, dtype=torch.int64).to(torch.int32)
+            sc = (torch.rand(K2 // 128, N2, generator=g, device=dev) * 0.01 + 0.005).half()
+            a2 = torch.randn(M, K2, device=dev, dtype=torch.float16, generator=g)
+            fn = lambda: ops.gptq_gemm(a2, qw, qz, sc, empty, True, 4)
+            t_our, t_lib = timeit(fn, 3), with_env("APHRO_WNA16_NO_LARGE", fn)
+            fl2 = 2.0 * M * N2 * K2
+            vs[f"W4A16 {name} {M}x{K2}x{N2}"] = dict(ours_ms=t_our * 1e3, ours_TFLOPs=fl2 / t_our / 1e12, library_ms=t_lib * 1e3,
+                                                    ratio=t_lib / t_our, library="gptq dequantise + torch.matmul (hipBLASLt)")
+            del qw, qz, sc
+            w8 = (torch.randn(N2, K2, device=dev, generator=g) * 0.5).to(torch.float8_e4m3fn)
+            a8 = a2.to(torch.float8_e4m3fn)
+            sa = torch.rand(M, 1, device=dev, generator=g) * 0.1 + 0.05
+            sb = torch.rand(N2, device=dev, generator=g) * 0.01 + 0.005
+            ob = torch.empty(M, N2, device=dev, dtype=torch.bfloat16)
+            fn8 = lambda: ops.cutlass_scaled_mm(a8, w8.t(), sa, sb, torch.bfloat16, out=ob)
+            t_our, t_lib = timeit(fn8, 3), with_env("APHRO_FP8_NO_LARGE", fn8)
+            vs[f"W8A8 {name} {M}x{K2}x{N2}"] = dict(ours_ms=t_our * 1e3, ours_TFLOPs=fl2 / t_our / 1e12, library_ms=t_lib * 1e3,
+                                                   ratio=t_lib / t_our, library="torch._scaled_mm (hipBLASLt)")
+            del w8, a8, sa, sb, ob, a2
+        except Exception as e:
+            vs[f"{name} {M}x{K2}x{N2}"] = {"error": repr(e)[:120]}
+    out["vs_library"] = vs
     return out
 
 
