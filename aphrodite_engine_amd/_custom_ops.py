@@ -588,7 +588,9 @@ def gptq_gemm(a: torch.Tensor, b_q_weight: torch.Tensor,
         if use_exllama and b_g_idx is not None and b_g_idx.numel() > 0:
             a = a[:, b_g_idx.long()]
         _library_fallback("gptq_gemm", "not exllama-shuffled" if not use_exllama else
-                          f"M={m} N={b_q_weight.shape[1]} K={a.shape[1]}: shape not tiled by wna16_gemm_large (gptq_dequant + matmul)")
+                          f"M={m} N={b_q_weight.shape[1]} K={a.shape[1]}: " +
+                          ("APHRO_WNA16_NO_LARGE is set" if os.environ.get("APHRO_WNA16_NO_LARGE") else
+                           "shape not tiled by wna16_gemm_large") + " (gptq_dequant + matmul)")
         return torch.matmul(a, w)
     perm = None
     if b_g_idx is not None and b_g_idx.numel() > 0:

@@ -37,6 +37,7 @@ struct Fp8ResParams {
   int M, N, K, lda;
   int a_per_token, b_per_channel;
   int ksplit;
+  int strips, xcd_shift, strips_per_xcd;   // workgroup placement, worked out by the host (see the launcher)
 };
 
 template <int B, int E, typename F>
@@ -51,8 +52,15 @@ __device__ __forceinline__ long f8r_lo(u32x4 v) { return (long)(((uint64_t)v[1] 
 __device__ __forceinline__ long f8r_hi(u32x4 v) { return (long)(((uint64_t)v[3] << 32) | v[2]); }
 
 // MT: 16-token tiles.  NSEG: 128-k segments per wave (2 k-pairs each).  NT: 16-column tiles per strip.  D: k-pairs in flight.
+// Kernel arguments as in wna16_gemm_stream_kernel: what the first loads need comes first and as scalars (preloaded into
+// SGPRs, Makefile: -amdgpu-kernarg-preload-count); p_in carries the rest.
 template <typename T, int MT, int NSEG, int NT, int D>
-__global__ __launch_bounds__(256, 1) void fp8_gemm_resident_kernel(Fp8ResParams p) {
+__global__ __launch_bounds__(256, 1) void fp8_gemm_resident_kernel(const uint8_t* w, const uint8_t* a, int strips, int xcd_shift,
+                                                                   int strips_per_xcd, int ksplit, int M, int N, int K, int lda,
+                                                                   Fp8ResParams p_in) {
+  Fp8ResParams p = p_in;
+  p.w = w; p.a = a; p.strips = strips; p.xcd_shift = xcd_shift; p.strips_per_xcd = strips_per_xcd; p.ksplit = ksplit;
+  p.M = M; p.N = N; p.K = K; p.lda = lda;
   constexpr int NWV = 4;
   constexpr int NKP = 2 * NSEG;
   constexpr int CW = 16 * NT;
@@ -65,12 +73,14 @@ __global__ __launch_bounds__(256, 1) void fp8_gemm_resident_kernel(Fp8ResParams 
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, c = lane & 15;
   // workgroup -> (strip, K slice): the placement rules of wna16_gemm_resident.hip (a K slice's strips on 8 / ksplit XCDs)
-  const int S = gridDim.x;
+  // (the divisions by 8 / ksplit are the host's: in the kernel they were ~120 instructions in front of the first address,
+  // profiles/r5_decode_experiments.txt (2))
+  const int S = p.strips;
   int strip, ky;
-  if (gridDim.y > 1 && 8 % gridDim.y == 0 && S % (8 / gridDim.y) == 0) {
-    const int L = blockIdx.y * S + blockIdx.x, xcd = L & 7, idx = L >> 3, per = 8 / gridDim.y;
-    ky = xcd / per;
-    strip = (xcd % per) * (S / per) + idx;
+  if (p.xcd_shift >= 0) {
+    const int L = blockIdx.y * S + blockIdx.x, xcd = L & 7, idx = L >> 3;
+    ky = xcd >> p.xcd_shift;
+    strip = (xcd & ((1 << p.xcd_shift) - 1)) * p.strips_per_xcd + idx;
   } else {
     strip = (S & 7) == 0 ? (int)(blockIdx.x & 7) * (S >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
     ky = blockIdx.y;
@@ -253,6 +263,12 @@ extern "C" int aphro_fp8_gemm_resident(const void* a, int64_t lda, const void* w
   p.a_per_token = a_scale_per_token; p.b_per_channel = b_scale_per_channel; p.ksplit = cf.ksplit;
   const int mt = M > 16 ? 2 : 1;
   const dim3 grid((unsigned)(N / (16 * cf.nt)), (unsigned)cf.ksplit);
+  p.strips = (int)grid.x; p.xcd_shift = -1; p.strips_per_xcd = 0;
+  if (cf.ksplit > 1 && 8 % cf.ksplit == 0 && p.strips % (8 / cf.ksplit) == 0) {
+    const int per = 8 / cf.ksplit;         // XCDs per K slice: 4, 2, 1
+    p.xcd_shift = per == 4 ? 2 : per == 2 ? 1 : 0;
+    p.strips_per_xcd = p.strips / per;
+  }
   // k-pairs in flight per wave (bench.py --quant fp8ct, per-kernel, depth 4 / 6 / 8: gate_up 22.8 / 23.3 / 23.8 us, down 12.6 /
   // 12.5 / 12.4, qkv 7.3 / 7.1 / 6.8, o 5.6 / 5.6 / 5.7): 4 for the wide strips, 8 for the narrow ones
 #ifndef F8R_DEPTH
@@ -267,7 +283,8 @@ extern "C" int aphro_fp8_gemm_resident(const void* a, int64_t lda, const void* w
       set_error("fp8_gemm_resident: cannot raise the dynamic LDS limit to %zu", lds);                                   \
       return APHRO_ERR_LAUNCH;                                                                                          \
     }                                                                                                                   \
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, (hipStream_t)stream, p);                                             \
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, (hipStream_t)stream, p.w, p.a, p.strips, p.xcd_shift, p.strips_per_xcd,  \
+                       p.ksplit, p.M, p.N, p.K, p.lda, p);                                                             \
   }
 #define X(a_, b_)                                                  \
   if (cf.nseg == a_ && cf.nt == b_) {                              \

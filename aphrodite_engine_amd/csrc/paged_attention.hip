@@ -148,8 +148,18 @@ __device__ __forceinline__ u32x2 fp8x4_to_T(uint32_t w) {
 // KV: 0 = cache holds T, 1 = e4m3, 2 = e5m2.   HD: head size.  BS: block size.
 // ROPE: the fused rotary + cache-write form (a separate instantiation: the plain kernel must not
 // pay for the extra live state -- measured +1.4 us per launch when it was a runtime branch)
+// Kernel arguments: the head of the dependent chain (sequence length -> block table -> K/V addresses) and the sizes every
+// address needs come first and as scalars, so that they are preloaded into SGPRs (Makefile: -amdgpu-kernarg-preload-count);
+// p_in carries the rest, its copies of the leading fields are not read.
 template <typename T, int KV, int HD, int BS, int NW, int ROPE, bool SPLIT = false>
-__global__ __launch_bounds__(NW * 64) void paged_attention_kernel(PAParams p) {
+__global__ __launch_bounds__(NW * 64) void paged_attention_kernel(const int32_t* seq_lens, const int32_t* block_tables,
+                                                                  const void* kc_, const void* vc_, const float* qkv_slabs,
+                                                                  int num_heads, int num_kv_heads, int max_blocks_per_seq,
+                                                                  int partition_size, PAParams p_in) {
+  PAParams p = p_in;
+  p.seq_lens = seq_lens; p.block_tables = block_tables; p.kc = kc_; p.vc = vc_; p.qkv_slabs = qkv_slabs;
+  p.num_heads = num_heads; p.num_kv_heads = num_kv_heads; p.max_blocks_per_seq = max_blocks_per_seq;
+  p.partition_size = partition_size;
   constexpr bool FP8 = KV != 0;
   constexpr bool E5M2 = KV == 2;
   constexpr int XB = 16;                        // bytes per K chunk
@@ -846,7 +856,8 @@ static int launch_pa(const PAParams& p, int num_seqs, int parts, int nw, hipStre
     auto kern = paged_attention_kernel<T, KV, HD, BS, NWV, ROPE, SPL>;                              \
     if (lds > 64 * 1024)                                                                            \
       (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-    hipLaunchKernelGGL(kern, grid, dim3(NWV * 64), lds, st, p);                                      \
+    hipLaunchKernelGGL(kern, grid, dim3(NWV * 64), lds, st, p.seq_lens, p.block_tables, p.kc, p.vc, p.qkv_slabs,        \
+                       p.num_heads, p.num_kv_heads, p.max_blocks_per_seq, p.partition_size, p);                  \
   }
   if constexpr (HD == 128 && (BS == 16 || BS == 32)) {   // the split form is instantiated for the serving geometry only
     if (p.nsplit > 1) {

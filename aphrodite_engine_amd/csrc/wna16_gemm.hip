@@ -84,7 +84,8 @@ struct Wna16Params {
   uint16_t* act_packed;   // != NULL (ksplit == 1 only): columns are (gate_j, up_j) pairs; the epilogue
                           // writes silu(gate) * up as fragment-major f16 [M, N/2] for the next GEMM
   // ---- grouped (mixture-of-experts) form: every 16-row m-tile uses the weights of ONE expert ----
-  int xcd_remap;          // fast kernel, ksplit in {2, 4, 8}: K slice y runs on 8 / ksplit XCDs (see the kernel)
+  int xcd_remap;          // fast kernel, ksplit in {2, 4, 8}: K slice y runs on 8 / ksplit XCDs (see the kernel); 0 = off, else
+  int xcd_tiles;          // 1 + log2(8 / ksplit), and grid.x / (8 / ksplit)
   const int32_t* expert_ids;     // [M / 16] expert of each m-tile (moe_align_block_size), < 0: skip; NULL: dense
   const int32_t* num_post_pad;   // device scalar: rows >= *num_post_pad are not computed
   int64_t w_estride, z_estride, s_estride;  // per-expert strides of qw / qz (words) and sc (elements)
@@ -240,11 +241,10 @@ __global__ __launch_bounds__(FNW * 64, (VEC * MT >= 8) ? 2 : 3) void wna16_gemm_
   // activations: 8 x M x K x 2 bytes through the fabric (PMC: 38.8 MB read for the 31.4 MB down projection, profiles/
   // r3_pmc_traffic.txt).  xcd_remap gives slice y to 8 / ksplit XCDs only.
   int bx = blockIdx.x, by = blockIdx.y;
-  if (p.xcd_remap) {
-    const int L = blockIdx.y * gridDim.x + blockIdx.x, xcd = L & 7, idx = L >> 3;
-    const int per = 8 / gridDim.y;                  // XCDs per K slice (host: 8 % ksplit == 0, grid.x % per == 0)
-    by = xcd / per;
-    bx = (xcd % per) * (gridDim.x / per) + idx;
+  if (p.xcd_remap) {                                // 1 + log2(XCDs per K slice); xcd_tiles = grid.x / that count (host:
+    const int L = blockIdx.y * gridDim.x + blockIdx.x, xcd = L & 7, idx = L >> 3, sh = p.xcd_remap - 1;   // no division here)
+    by = xcd >> sh;
+    bx = (xcd & ((1 << sh) - 1)) * p.xcd_tiles + idx;
   }
   const int n0 = bx * (16 * VEC);
   const int m0 = blockIdx.z * (16 * MT);
@@ -745,7 +745,9 @@ static void launch_wna16(const Wna16Params& p_in, const Wna16Plan& pl, hipStream
     if constexpr (VEC >= 2) {
       Wna16Params p = p_in;
       const unsigned per = pl.ksplit > 1 && 8 % pl.ksplit == 0 ? 8u / (unsigned)pl.ksplit : 0u;
-      p.xcd_remap = (per > 0 && grid.z == 1 && p.expert_ids == nullptr && grid.x % per == 0 && !env_int("APHRO_WNA16_NO_XCD_REMAP", 0)) ? 1 : 0;
+      const bool remap = per > 0 && grid.z == 1 && p.expert_ids == nullptr && grid.x % per == 0 && !env_int("APHRO_WNA16_NO_XCD_REMAP", 0);
+      p.xcd_remap = remap ? (per == 4 ? 3 : per == 2 ? 2 : 1) : 0;
+      p.xcd_tiles = remap ? (int)(grid.x / per) : 0;
       size_t lds = (size_t)FNW * MT * VEC * 64 * 4 * sizeof(float);
 #define APHRO_FAST(NS) hipLaunchKernelGGL((wna16_gemm_kernel<T, VEC, MT, NS>), grid, dim3(FNW * 64), lds, st, p)
       switch (pl.nseg) {

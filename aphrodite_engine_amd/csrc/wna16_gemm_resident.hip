@@ -50,7 +50,35 @@ struct Wna16ResParams {
   const uint16_t* a;      // AROW instantiations: row-major f16 activations [M, lda] read in place (no pack launch)
   int lda;
   unsigned* counter;      // one launch for [M, N] with K slices: tickets per strip (zero between launches), see the epilogue
+  int strips, xcd_shift, strips_per_xcd;   // res_set_placement
 };
+
+// Workgroup -> (strip, K slice).  Workgroups are dealt round-robin to the 8 XCDs; the host (res_set_placement) works the
+// divisions out once per launch -- done here they were ~120 instructions of v_rcp / readfirstlane chains in front of the
+// first weight load of every K-sliced launch (profiles/r5_decode_experiments.txt (2)).
+__device__ __forceinline__ void res_place(const Wna16ResParams& p, int& strip, int& ky) {
+  const int S = p.strips;
+  if (p.xcd_shift >= 0) {                 // K slices: slice y owns 8 / ksplit XCDs (each L2 fetches only its slice of A)
+    const int L = blockIdx.y * S + blockIdx.x, xcd = L & 7, idx = L >> 3;
+    ky = xcd >> p.xcd_shift;
+    strip = (xcd & ((1 << p.xcd_shift) - 1)) * p.strips_per_xcd + idx;
+  } else {                                // every XCD one contiguous run of strips
+    strip = (S & 7) == 0 ? (int)(blockIdx.x & 7) * (S >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    ky = blockIdx.y;
+  }
+}
+
+static void res_set_placement(Wna16ResParams& p, int strips) {
+  p.strips = strips;
+  p.xcd_shift = -1;
+  p.strips_per_xcd = 0;
+  const int ks = p.ksplit;
+  if (ks > 1 && 8 % ks == 0 && strips % (8 / ks) == 0) {
+    const int per = 8 / ks;               // 4, 2, 1
+    p.xcd_shift = per == 4 ? 2 : per == 2 ? 1 : 0;
+    p.strips_per_xcd = strips / per;
+  }
+}
 
 template <int B, int E, typename F>
 __device__ __forceinline__ void res_static_for(F&& f) {
@@ -143,16 +171,9 @@ __global__ __launch_bounds__(NWV * 64, NWV <= 4 ? 1 : 2) void wna16_gemm_residen
   // share cache lines at their edges when a strip's row piece is not a multiple of 128 bytes)
   // With K slices (grid.y > 1) all strips of slice y read the same activation rows: slice y goes to 8 / grid.y XCDs, so
   // that each XCD's L2 fetches only its slice of A (same placement as wna16_gemm.hip's xcd_remap).
-  const int S = gridDim.x;
+  const int S = p.strips;
   int strip, ky;
-  if (gridDim.y > 1 && 8 % gridDim.y == 0 && S % (8 / gridDim.y) == 0) {
-    const int L = blockIdx.y * S + blockIdx.x, xcd = L & 7, idx = L >> 3, per = 8 / gridDim.y;
-    ky = xcd / per;
-    strip = (xcd % per) * (S / per) + idx;
-  } else {
-    strip = (S & 7) == 0 ? (int)(blockIdx.x & 7) * (S >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-    ky = blockIdx.y;
-  }
+  res_place(p, strip, ky);
   const int seg0 = (ky * NWV + wave) * NSEG;
   const int cb = strip * CW;
   const int mtiles = (p.M + 15) >> 4;
@@ -589,8 +610,18 @@ __device__ __forceinline__ void res_reduce_store(const Wna16ResParams& p, float*
 // Strip-major weights and packed activations only.  (The round-4 norm-in-consumer and LDS-ring forms of this kernel were lab
 // material -- measured slower, profiles/r4_norm_in_consumer.txt, r4_gemm_lab.txt -- and left the tree in round 5; git
 // history: commit 9b85643.)
+// Kernel arguments: what the first loads need (weight / activation pointers, placement, sizes) comes FIRST and as scalars, so
+// that -amdgpu-kernarg-preload-count (Makefile) has the dispatcher deliver it in SGPRs -- a by-value struct is fetched by
+// s_load at entry, one scalar-cache miss in front of every address (profiles/r5_decode_experiments.txt (2)).  p_in carries the rest;
+// its copies of the leading fields are not read.
 template <int MT, int NWV, int NSEG, int NP4, int REM, int D>
-__global__ __launch_bounds__(NWV * 64, 1) void wna16_gemm_stream_kernel(Wna16ResParams p) {
+__global__ __launch_bounds__(NWV * 64, 1) void wna16_gemm_stream_kernel(const uint32_t* qw, const uint16_t* apk, int strips,
+                                                                        int xcd_shift, int strips_per_xcd, int ksplit, int M,
+                                                                        int N, int K, int gshift, const uint16_t* sc,
+                                                                        const uint32_t* qz, Wna16ResParams p_in) {
+  Wna16ResParams p = p_in;
+  p.qw = qw; p.apk = apk; p.strips = strips; p.xcd_shift = xcd_shift; p.strips_per_xcd = strips_per_xcd; p.ksplit = ksplit;
+  p.M = M; p.N = N; p.K = K; p.gshift = gshift; p.sc = sc; p.qz = qz;
   constexpr int NST = NSEG * 4;
   constexpr int CW = 64 * NP4 + 16 * REM;
   constexpr int CWP = CW + 4;
@@ -604,16 +635,9 @@ __global__ __launch_bounds__(NWV * 64, 1) void wna16_gemm_stream_kernel(Wna16Res
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4;
   const int c = lane & 15;
-  const int S = gridDim.x;
+  const int S = p.strips;
   int strip, ky;
-  if (gridDim.y > 1 && 8 % gridDim.y == 0 && S % (8 / gridDim.y) == 0) {
-    const int L = blockIdx.y * S + blockIdx.x, xcd = L & 7, idx = L >> 3, per = 8 / gridDim.y;
-    ky = xcd / per;
-    strip = (xcd % per) * (S / per) + idx;
-  } else {
-    strip = (S & 7) == 0 ? (int)(blockIdx.x & 7) * (S >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-    ky = blockIdx.y;
-  }
+  res_place(p, strip, ky);
   const int seg0 = (ky * NWV + wave) * NSEG;
   const int cb = strip * CW;
   const int mtiles = (p.M + 15) >> 4;
@@ -886,7 +910,9 @@ static int res_launch(const Wna16ResParams& p, hipStream_t st) {
     }
   }
   const dim3 grid((unsigned)(p.N / CW), (unsigned)p.ksplit);
-  hipLaunchKernelGGL(kern, grid, dim3(NWV * 64), lds, st, p);
+  Wna16ResParams q = p;
+  res_set_placement(q, (int)grid.x);
+  hipLaunchKernelGGL(kern, grid, dim3(NWV * 64), lds, st, q);
   APHRO_LAUNCH_CHECK();
   return APHRO_OK;
 }
@@ -902,7 +928,10 @@ static int res_launch_stream(const Wna16ResParams& p, hipStream_t st) {
     return APHRO_ERR_LAUNCH;
   }
   const dim3 grid((unsigned)(p.N / CW), (unsigned)p.ksplit, (unsigned)(p.M > 32 ? 2 : 1));
-  hipLaunchKernelGGL(kern, grid, dim3(NWV * 64), LDS, st, p);
+  Wna16ResParams q = p;
+  res_set_placement(q, (int)grid.x);
+  hipLaunchKernelGGL(kern, grid, dim3(NWV * 64), LDS, st, q.qw, q.apk, q.strips, q.xcd_shift, q.strips_per_xcd, q.ksplit, q.M, q.N,
+                     q.K, q.gshift, q.sc, q.qz, q);
   APHRO_LAUNCH_CHECK();
   return APHRO_OK;
 }
