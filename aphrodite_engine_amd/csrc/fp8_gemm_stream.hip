@@ -55,7 +55,11 @@ __device__ __forceinline__ void f8s_lds_barrier() { asm volatile("s_waitcnt lgkm
 
 // KS: 128-k segments per wave and K slice (K = gridDim.y x 8 waves x KS x 128).  MT: 16-token tiles.
 template <typename T, int MT, int KS, bool SILU = false>
-__global__ __launch_bounds__(512, 1) void fp8_gemm_stream_kernel(Fp8StreamParams p) {
+__global__ __launch_bounds__(512, 1) void fp8_gemm_stream_kernel(const uint8_t* w, const uint8_t* a, int M, int N, int K,
+                                                                 int lda, int tiles, Fp8StreamParams p_in) {
+  // (leading scalars: preloaded into SGPRs, Makefile -amdgpu-kernarg-preload-count; p_in carries the rest)
+  Fp8StreamParams p = p_in;
+  p.w = w; p.a = a; p.M = M; p.N = N; p.K = K; p.lda = lda; p.tiles = tiles;
   constexpr int NWV = 8;
   constexpr int SEGB = 16 * 128;                    // one staged segment: [16 rows][8 chunks of 16 k]
   constexpr int R = 8;                              // ring slots per wave
@@ -255,7 +259,7 @@ extern "C" int aphro_fp8_gemm_stream(const void* a, int64_t lda, const void* w, 
       set_error("fp8_gemm_stream: cannot raise the dynamic LDS limit to %zu", lds);                                \
       return APHRO_ERR_LAUNCH;                                                                                     \
     }                                                                                                              \
-    hipLaunchKernelGGL(kern, grid, dim3(512), lds, (hipStream_t)stream, p);                                        \
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, (hipStream_t)stream, p.w, p.a, p.M, p.N, p.K, p.lda, p.tiles, p); \
   }
 #define LK(TT, MTV)                                   \
   switch (ks) {                                       \
@@ -310,7 +314,7 @@ extern "C" int aphro_fp8_gemm_stream_silu_quant(const void* a, int64_t lda, cons
       set_error("fp8_gemm_stream_silu_quant: cannot raise the dynamic LDS limit to %zu", lds);                     \
       return APHRO_ERR_LAUNCH;                                                                                     \
     }                                                                                                              \
-    hipLaunchKernelGGL(kern, grid, dim3(512), lds, (hipStream_t)stream, p);                                        \
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, (hipStream_t)stream, p.w, p.a, p.M, p.N, p.K, p.lda, p.tiles, p); \
   }
 #define LK(TT, MTV)                                   \
   switch (ks) {                                       \
