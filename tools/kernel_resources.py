@@ -12,8 +12,10 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "aphrodite_engine_amd", "csrc")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-function", "-Wno-unused-variable", "-Wno-pass-failed"]
-EXTRA = {"paged_attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"], "flash_attn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-function", "-Wno-unused-variable", "-Wno-pass-failed",
+         "-mllvm", "-amdgpu-kernarg-preload-count=14"]
+EXTRA = {"paged_attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"], "flash_attn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
+         "wna16_gemm_resident.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
 def demangle(names):
