@@ -391,6 +391,109 @@ void copy_blocks(std::vector<torch::Tensor> const& key_caches, std::vector<torch
      "copy_blocks");
 }
 
+// awq_gemm (awq/gemm_kernels.cu:784-858): [M, N] in the activations' dtype.  Checkpoint-layout AWQ tensors; from 256 rows
+// the nibbles are transposed once per call and the prefill-sized MFMA kernel runs (the Python op's rule, _custom_ops.awq_gemm)
+torch::Tensor awq_gemm(torch::Tensor in_feats, torch::Tensor kernel, torch::Tensor scaling_factors, torch::Tensor zeros,
+                       int64_t split_k_iters) {
+  TORCH_CHECK(in_feats.is_cuda() && kernel.is_cuda() && scaling_factors.is_cuda() && zeros.is_cuda() && in_feats.dim() == 2,
+              "awq_gemm: device tensors and a 2-D activation matrix expected");
+  torch::Tensor a = in_feats.stride(1) == 1 ? in_feats : in_feats.contiguous();
+  const int64_t m = a.size(0), k = a.size(1), n = kernel.size(1) * 8, groups = scaling_factors.size(0);
+  TORCH_CHECK(groups > 0 && k % groups == 0, "awq_gemm: scales [groups, N] with groups dividing K");
+  const int dt = act_dtype(a);
+  auto out = torch::empty({m, n}, a.options());
+  const int64_t gs = k / groups;
+  const bool large = m >= 256 && n % 128 == 0 && k % 64 == 0 && gs % 64 == 0 && (k / 8) * n * 4 < (int64_t(1) << 32) &&
+                     m * k * 2 < (int64_t(1) << 32) && getenv("APHRO_WNA16_NO_LARGE") == nullptr;
+  if (large) {
+    auto qw = torch::empty({k / 8, n}, kernel.options());
+    auto qz = torch::empty_like(zeros);
+    ok(aphro_awq_repack((const uint32_t*)kernel.data_ptr(), (uint32_t*)qw.data_ptr(), k, n, cur_stream()), "awq_gemm");
+    ok(aphro_awq_repack_zeros((const uint32_t*)zeros.data_ptr(), (uint32_t*)qz.data_ptr(), zeros.size(0), n, cur_stream()), "awq_gemm");
+    if (a.stride(0) % 8 != 0 || ((uintptr_t)a.data_ptr() % 16) != 0) a = a.contiguous();
+    const size_t nb = aphro_wna16_gemm_large_workspace_bytes(m, n, k, groups, dt);
+    auto ws = torch::empty({(int64_t)nb}, a.options().dtype(torch::kUInt8));
+    ok(aphro_wna16_gemm_large(a.data_ptr(), (const uint32_t*)qw.data_ptr(), (const uint32_t*)qz.data_ptr(),
+                              scaling_factors.data_ptr(), out.data_ptr(), nb ? ws.data_ptr() : nullptr, nb, m, n, k, groups,
+                              a.stride(0), 0, dt, cur_stream()),
+       "awq_gemm");
+    return out;
+  }
+  const size_t nb = aphro_awq_gemm_workspace_bytes(m < 64 ? m : 64, n, k, groups);
+  auto ws = torch::empty({(int64_t)nb}, a.options().dtype(torch::kUInt8));
+  const int64_t esz = a.element_size();
+  for (int64_t m0 = 0; m0 < m; m0 += 64) {
+    const int64_t rows = m - m0 < 64 ? m - m0 : 64;
+    ok(aphro_awq_gemm((const char*)a.data_ptr() + m0 * a.stride(0) * esz, (const uint32_t*)kernel.data_ptr(),
+                      scaling_factors.data_ptr(), (const uint32_t*)zeros.data_ptr(), (char*)out.data_ptr() + m0 * n * esz,
+                      ws.data_ptr(), nb, rows, n, k, groups, a.stride(0), dt, cur_stream()),
+       "awq_gemm");
+  }
+  return out;
+}
+
+// cutlass_scaled_mm_supports_fp8 (scaled_mm_entry.cu:30-50): gfx950 has native OCP fp8 MFMA
+bool cutlass_scaled_mm_supports_fp8(int64_t cuda_device_capability) { return true; }
+
+// _rocm_C::paged_attention (kernels/rocm/attention.cu:903-1000; schema kernels/rocm/torch_bindings.cpp:17-28): scratch
+// sized for 512-token partitions; one launch over whole sequences where that is the faster form (the rule of the Python
+// op, _custom_ops.paged_attention_rocm -- the reference's own v1 / v2 rule, paged_attn.py:112-121)
+void paged_attention_rocm(torch::Tensor out, torch::Tensor exp_sums, torch::Tensor max_logits, torch::Tensor tmp_out,
+                          torch::Tensor query, torch::Tensor key_cache, torch::Tensor value_cache, int64_t num_kv_heads,
+                          double scale, torch::Tensor block_tables, torch::Tensor context_lens, int64_t block_size,
+                          int64_t max_context_len, const c10::optional<torch::Tensor>& alibi_slopes, std::string kv_cache_dtype,
+                          double k_scale, double v_scale) {
+  int64_t part = 512;
+  const int64_t need = (max_context_len + part - 1) / part;
+  TORCH_CHECK(tmp_out.is_contiguous() && tmp_out.size(2) >= need, "tmp_out has ", tmp_out.size(2), " partitions, need ", need,
+              " for max_seq_len=", max_context_len);
+  const int64_t num_seqs = query.size(0), num_heads = query.size(1), head_size = query.size(2);
+  TORCH_CHECK(query.stride(2) == 1 && query.stride(1) == head_size && out.is_contiguous(),
+              "paged_attention: contiguous query heads and out expected");
+  const bool whole = max_context_len <= 8192 && (need == 1 || num_seqs * num_heads > 512) &&
+                     getenv("APHRO_PA_ROCM_PARTITIONED") == nullptr;
+  if (whole) part = 0;
+  ok(aphro_paged_attention(out.data_ptr(), whole ? nullptr : exp_sums.data_ptr<float>(),
+                           whole ? nullptr : max_logits.data_ptr<float>(), whole ? nullptr : tmp_out.data_ptr(), query.data_ptr(),
+                           key_cache.data_ptr(), value_cache.data_ptr(), (int)num_seqs, (int)num_heads, (int)num_kv_heads,
+                           (int)head_size, (float)scale, block_tables.data_ptr<int>(), context_lens.data_ptr<int>(),
+                           (int)block_tables.stride(0), (int)block_size, (int)max_context_len,
+                           alibi_slopes ? alibi_slopes->data_ptr<float>() : nullptr, query.stride(0), key_cache.stride(0),
+                           key_cache.stride(1), act_dtype(query), kv_dtype(kv_cache_dtype), (float)k_scale, (float)v_scale,
+                           (int)part, cur_stream()),
+     "paged_attention");
+}
+
+// _C_custom_ar (custom_all_reduce.cu): the ops whose arguments cross the dispatcher unchanged.  init_custom_ar,
+// register_buffer and the graph-buffer pair carry IPC handles as `str[]`; their callers hold raw bytes and go through
+// aphrodite_engine_amd._custom_ops (torch_ops.py says why) -- not registered here.
+int ar_dtype(const torch::Tensor& t) {
+  if (t.scalar_type() == torch::kFloat) return APHRO_F32;
+  TORCH_CHECK(t.scalar_type() == torch::kHalf || t.scalar_type() == torch::kBFloat16,
+              "custom allreduce only supports float32, float16 and bfloat16");
+  return act_dtype(t);
+}
+void ar_check_io(const torch::Tensor& inp, const torch::Tensor& out) {
+  TORCH_CHECK(inp.is_cuda() && out.is_cuda() && inp.scalar_type() == out.scalar_type() && inp.numel() == out.numel(),
+              "all_reduce: inp and out must be device tensors of the same dtype and number of elements");
+}
+// custom_all_reduce.cu:84-92
+void all_reduce_reg(int64_t fa, torch::Tensor inp, torch::Tensor out) {
+  ar_check_io(inp, out);
+  ok(aphro_custom_ar_all_reduce((void*)fa, inp.data_ptr(), out.data_ptr(), inp.numel(), ar_dtype(inp), nullptr, 0, cur_stream()),
+     "all_reduce_reg");
+}
+// custom_all_reduce.cu:94-109
+void all_reduce_unreg(int64_t fa, torch::Tensor inp, torch::Tensor reg_buffer, torch::Tensor out) {
+  ar_check_io(inp, out);
+  const size_t nbytes = (size_t)inp.numel() * inp.element_size(), cap = (size_t)reg_buffer.numel() * reg_buffer.element_size();
+  TORCH_CHECK(nbytes <= cap, "registered buffer is too small to contain the input");
+  ok(aphro_custom_ar_all_reduce((void*)fa, inp.data_ptr(), out.data_ptr(), inp.numel(), ar_dtype(inp), reg_buffer.data_ptr(), cap,
+                                cur_stream()),
+     "all_reduce_unreg");
+}
+int64_t meta_size() { return aphro_custom_ar_meta_size(); }   // custom_all_reduce.cu:111-113
+
 }  // namespace
 
 TORCH_LIBRARY_FRAGMENT(APHRO_TORCH_NS, m) {
@@ -471,4 +574,32 @@ TORCH_LIBRARY_FRAGMENT(APHRO_CONCAT(APHRO_TORCH_NS, _cache_ops), m) {
   m.impl("swap_blocks", torch::kCUDA, &swap_blocks);
   m.def("copy_blocks(Tensor(a!)[] key_caches, Tensor[](b!) value_caches, Tensor block_mapping) -> ()"); // :461-464
   m.impl("copy_blocks", torch::kCUDA, &copy_blocks);
+}
+
+// round 5, second batch
+#ifndef APHRO_TORCH_ROCM_NS
+#define APHRO_TORCH_ROCM_NS _rocm_C_mi355x      // (-DAPHRO_TORCH_ROCM_NS=_rocm_C next to -DAPHRO_TORCH_NS=_C takes the reference's place)
+#endif
+TORCH_LIBRARY_FRAGMENT(APHRO_TORCH_NS, m) {
+  m.def("awq_gemm(Tensor _in_feats, Tensor _kernel, Tensor _scaling_factors, Tensor _zeros, int split_k_iters) -> Tensor");  // :133-135
+  m.impl("awq_gemm", torch::kCUDA, &awq_gemm);
+  m.def("cutlass_scaled_mm_supports_fp8(int cuda_device_capability) -> bool");                          // :250-252
+  m.impl("cutlass_scaled_mm_supports_fp8", &cutlass_scaled_mm_supports_fp8);
+}
+
+TORCH_LIBRARY_FRAGMENT(APHRO_TORCH_ROCM_NS, m) {
+  m.def("paged_attention(Tensor! out, Tensor exp_sums, Tensor max_logits, Tensor tmp_out, Tensor query, "
+        "Tensor key_cache, Tensor value_cache, int num_kv_heads, float scale, Tensor block_tables, "
+        "Tensor context_lens, int block_size, int max_context_len, Tensor? alibi_slopes, str kv_cache_dtype, "
+        "float k_scale, float v_scale) -> ()");                                                         // kernels/rocm/torch_bindings.cpp:17-28
+  m.impl("paged_attention", torch::kCUDA, &paged_attention_rocm);
+}
+
+TORCH_LIBRARY_FRAGMENT(APHRO_CONCAT(APHRO_TORCH_NS, _custom_ar), m) {
+  m.def("all_reduce_reg(int fa, Tensor inp, Tensor! out) -> ()");                                       // :516-517
+  m.impl("all_reduce_reg", torch::kCUDA, &all_reduce_reg);
+  m.def("all_reduce_unreg(int fa, Tensor inp, Tensor reg_buffer, Tensor! out) -> ()");                  // :519-522
+  m.impl("all_reduce_unreg", torch::kCUDA, &all_reduce_unreg);
+  m.def("meta_size() -> int");                                                                          // :526
+  m.impl("meta_size", &meta_size);
 }

@@ -308,6 +308,20 @@ def test_cpp_torch_library_registration():
     for name in ("reshape_and_cache", "reshape_and_cache_flash", "convert_fp8", "swap_blocks", "copy_blocks"):
         cpp = getattr(torch.ops._C_mi355x_cache_ops, name).default._schema
         assert cache_ns and strip(cpp) == strip(getattr(getattr(torch.ops, cache_ns[0]), name).default._schema), name
+    # round 5, second batch: the AWQ GEMM, the fp8 capability query, _rocm_C::paged_attention, the _C_custom_ar ops whose
+    # arguments cross the dispatcher unchanged
+    for name in ("awq_gemm", "cutlass_scaled_mm_supports_fp8"):
+        assert strip(getattr(torch.ops._C_mi355x, name).default._schema) == strip(getattr(getattr(torch.ops, py_ns[0]), name).default._schema), name
+    assert torch.ops._C_mi355x.cutlass_scaled_mm_supports_fp8(94) is True           # no tensor arguments: runs without a GPU
+    rocm_ns = [ns for ns in ("_aphro_t_rocm", "_aphro_g_rocm", "_rocm_C") if hasattr(torch.ops, ns) and hasattr(getattr(torch.ops, ns), "paged_attention")]
+    assert rocm_ns and strip(torch.ops._rocm_C_mi355x.paged_attention.default._schema) == strip(getattr(torch.ops, rocm_ns[0]).paged_attention.default._schema)
+    from aphrodite_engine_amd import _custom_ops as ops
+    assert torch.ops._C_mi355x_custom_ar.meta_size() == ops.meta_size() > 0
+    ar_ns = [ns for ns in ("_aphro_t_C_custom_ar", "_aphro_g_C_custom_ar", "_C_custom_ar") if hasattr(torch.ops, ns)
+             and hasattr(getattr(torch.ops, ns), "all_reduce_reg")]
+    for name in ("all_reduce_reg", "all_reduce_unreg", "meta_size"):
+        assert ar_ns and strip(getattr(torch.ops._C_mi355x_custom_ar, name).default._schema) == \
+            strip(getattr(getattr(torch.ops, ar_ns[0]), name).default._schema), name
     with pytest.raises((RuntimeError, NotImplementedError)):
         torch.ops._C_mi355x.gptq_gemm(torch.zeros(1, 64, dtype=torch.half), torch.zeros(8, 16, dtype=torch.int32),
                                       torch.zeros(1, 2, dtype=torch.int32), torch.zeros(1, 16, dtype=torch.half),

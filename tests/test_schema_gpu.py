@@ -467,3 +467,67 @@ def test_cpp_registered_round5_ops_match_the_python_registration(T):
     cache.swap_blocks(src_cache, host, bmh)                  # device -> host
     torch.cuda.synchronize()
     assert torch.equal(host[0], src_cache[1].cpu())
+
+
+def test_cpp_registered_round5_second_batch_matches_the_python_registration(T):
+    """Round 5, second batch from C++: awq_gemm (decode-sized and prompt-sized M), cutlass_scaled_mm_supports_fp8,
+    _rocm_C::paged_attention (whole-sequence and partitioned forms), _C_custom_ar::all_reduce_reg / all_reduce_unreg /
+    meta_size (on a loopback communicator: the kernel sums `world` copies of the local buffer) -- the same C ABI underneath,
+    the same bits as the Python-registered ops."""
+    from aphrodite_engine_amd import _custom_ops as ops, torch_cpp
+    from aphrodite_engine_amd.distributed.custom_all_reduce import LoopbackAllreduce
+    torch_cpp.load()
+    C, rocm, car = torch.ops._C_mi355x, torch.ops._rocm_C_mi355x, torch.ops._C_mi355x_custom_ar
+    assert C.cutlass_scaled_mm_supports_fp8(94) is True
+    rng = np.random.default_rng(11)
+    K, N, G = 512, 256, 128
+    w = (rng.standard_normal((K, N)) * 0.02).astype(np.float16)
+    _, q, s, zp = oq.quantize_weights(w, 4, G, zero_points=True)
+    qw, qz, sc = t(oq.awq_pack(q)), t(oq.awq_pack(zp)), t(s.astype(np.float16))
+    for M in (1, 33, 70, 300):                       # one pass, two 64-row passes, the repack + tile-machine path
+        a = t(rng.standard_normal((M, K)).astype(np.float16))
+        assert torch.equal(C.awq_gemm(a, qw, sc, qz, 8), T.C.awq_gemm(a, qw, sc, qz, 8)), M
+    a = t(rng.standard_normal((16, 2 * K)).astype(np.float16))[:, ::2]       # non-unit column stride: made contiguous
+    assert torch.equal(C.awq_gemm(a, qw, sc, qz, 8), T.C.awq_gemm(a, qw, sc, qz, 8))
+    # paged attention through the ROCm schema
+    S, Hq, Hkv, D, BS = 5, 8, 2, 128, 16
+    for seq_lens in (np.array([1, 40, 300, 511, 77], np.int32), np.array([5, 600, 1300, 33, 2], np.int32)):
+        max_len = int(seq_lens.max())
+        bps = (max_len + BS - 1) // BS
+        NB = S * bps + 1
+        kc = t((rng.standard_normal((NB, Hkv, D // 8, BS, 8)) * 0.3).astype(np.float16))
+        vc = t((rng.standard_normal((NB, Hkv, D, BS)) * 0.3).astype(np.float16))
+        bt = t(rng.permutation(NB)[:S * bps].reshape(S, bps).astype(np.int32))
+        qq = t(rng.standard_normal((S, Hq, D)).astype(np.float16))
+        P = (max_len + 511) // 512
+        outs = []
+        for ns in (T.rocm, rocm):
+            es, ml = torch.zeros(S, Hq, P, device=DEV), torch.zeros(S, Hq, P, device=DEV)
+            tmp = torch.zeros(S, Hq, P, D, dtype=torch.float16, device=DEV)
+            out = torch.empty(S, Hq, D, dtype=torch.float16, device=DEV)
+            ns.paged_attention(out, es, ml, tmp, qq, kc, vc, Hkv, float(D ** -0.5), bt, t(seq_lens), BS, max_len, None, "auto", 1.0, 1.0)
+            outs.append((out, es, ml, tmp))
+        assert all(torch.equal(p, q2) for p, q2 in zip(*outs)), seq_lens
+    # the peer-access all-reduce on a loopback communicator of 4 "ranks"
+    assert car.meta_size() == ops.meta_size()
+    lb = LoopbackAllreduce(4, torch.device(DEV), max_size=1 << 20)
+    try:
+        for dtype, numel in ((torch.float16, 32 * 4096), (torch.bfloat16, 64 * 4096), (torch.float32, 8 * 1024)):
+            x = t(rng.standard_normal(numel).astype(np.float32), dtype)
+            want = torch.empty_like(x)
+            ops.all_reduce_reg(lb._ptr, x, want)
+            got = torch.empty_like(x)
+            car.all_reduce_reg(lb._ptr, x, got)
+            torch.cuda.synchronize()
+            assert torch.equal(got, want)
+            reg = torch.empty(1 << 20, dtype=torch.uint8, device=DEV)
+            got2 = torch.empty_like(x)
+            car.all_reduce_unreg(lb._ptr, x, reg, got2)
+            torch.cuda.synchronize()
+            assert torch.equal(got2, want)
+        assert not ops.custom_ar_error(lb._ptr)
+        with pytest.raises(RuntimeError):
+            car.all_reduce_unreg(lb._ptr, torch.zeros(1 << 20, dtype=torch.float16, device=DEV),
+                                 torch.empty(16, dtype=torch.uint8, device=DEV), torch.zeros(1 << 20, dtype=torch.float16, device=DEV))
+    finally:
+        lb.close()
