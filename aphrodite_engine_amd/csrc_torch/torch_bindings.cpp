@@ -464,9 +464,9 @@ void paged_attention_rocm(torch::Tensor out, torch::Tensor exp_sums, torch::Tens
      "paged_attention");
 }
 
-// _C_custom_ar (custom_all_reduce.cu): the ops whose arguments cross the dispatcher unchanged.  init_custom_ar,
-// register_buffer and the graph-buffer pair carry IPC handles as `str[]`; their callers hold raw bytes and go through
-// aphrodite_engine_amd._custom_ops (torch_ops.py says why) -- not registered here.
+// _C_custom_ar (custom_all_reduce.cu).  IPC handles are `str[]` in the schema: through a C++-registered op a Python `bytes`
+// object arrives as the raw std::string the reference's C++ expects (the Python-registered ops only see decoded text,
+// torch_ops.py) -- see ipc_raw below.
 int ar_dtype(const torch::Tensor& t) {
   if (t.scalar_type() == torch::kFloat) return APHRO_F32;
   TORCH_CHECK(t.scalar_type() == torch::kHalf || t.scalar_type() == torch::kBFloat16,
@@ -493,6 +493,104 @@ void all_reduce_unreg(int64_t fa, torch::Tensor inp, torch::Tensor reg_buffer, t
      "all_reduce_unreg");
 }
 int64_t meta_size() { return aphro_custom_ar_meta_size(); }   // custom_all_reduce.cu:111-113
+
+// IPC handles arrive as `str` = std::string: raw bytes when the caller passes Python `bytes` (what the reference's
+// CustomAllreduce holds, custom_all_reduce.py:210-214), or the 128 hex digits / latin-1 text the Python-registered ops take
+std::string ipc_raw(const std::string& h) {
+  const size_t n = (size_t)aphro_ipc_handle_bytes();
+  if (h.size() == n) return h;
+  if (h.size() == 2 * n) {
+    std::string out(n, '\0');
+    for (size_t i = 0; i < n; ++i) {
+      auto nib = [&](char ch) -> int {
+        if (ch >= '0' && ch <= '9') return ch - '0';
+        if (ch >= 'a' && ch <= 'f') return ch - 'a' + 10;
+        if (ch >= 'A' && ch <= 'F') return ch - 'A' + 10;
+        TORCH_CHECK(false, "IPC handle: not a hex string");
+      };
+      out[i] = (char)((nib(h[2 * i]) << 4) | nib(h[2 * i + 1]));
+    }
+    return out;
+  }
+  // latin-1 text that the dispatcher UTF-8 encoded on the way in: code points 0x80..0xff became two bytes
+  std::string out;
+  for (size_t i = 0; i < h.size(); ++i) {
+    const unsigned char c0 = (unsigned char)h[i];
+    if (c0 < 0x80) { out.push_back((char)c0); continue; }
+    TORCH_CHECK((c0 == 0xc2 || c0 == 0xc3) && i + 1 < h.size(), "IPC handle has ", h.size(), " bytes, expected ", n);
+    out.push_back((char)(((c0 & 0x03) << 6) | ((unsigned char)h[++i] & 0x3f)));
+  }
+  TORCH_CHECK(out.size() == n, "IPC handle has ", out.size(), " bytes, expected ", n);
+  return out;
+}
+std::string ipc_pack(const std::vector<std::string>& handles) {
+  std::string raw;
+  for (const auto& h : handles) raw += ipc_raw(h);
+  return raw;
+}
+
+// init_custom_ar (custom_all_reduce.cu:13-41): meta = this rank's signal area followed by the two-shot scratch
+int64_t init_custom_ar(torch::Tensor meta, torch::Tensor rank_data, std::vector<std::string> handles, std::vector<int64_t> offsets,
+                       int64_t rank, bool full_nvlink) {
+  TORCH_CHECK(meta.is_cuda() && rank_data.is_cuda(), "init_custom_ar: device tensors expected");
+  const int64_t world = (int64_t)handles.size();
+  TORCH_CHECK((int64_t)offsets.size() == world, "handles length should equal to offsets length");
+  TORCH_CHECK(rank >= 0 && rank < world, "invalid rank passed in");
+  const int64_t ms = aphro_custom_ar_meta_size(), total = meta.numel() * meta.element_size();
+  TORCH_CHECK(total > ms, "meta must hold the signal area and the two-shot scratch (meta_size() + max_size bytes)");
+  const size_t scratch_bytes = (size_t)((total - ms) / 16 * 16);
+  const std::string raw = ipc_pack(handles);
+  std::vector<int64_t> soff(offsets);
+  for (auto& o : soff) o += ms;
+  void* fa = nullptr;
+  ok(aphro_custom_ar_init(&fa, meta.data_ptr(), raw.data(), offsets.data(), (char*)meta.data_ptr() + ms, scratch_bytes, raw.data(),
+                          soff.data(), rank_data.data_ptr(), (size_t)(rank_data.numel() * rank_data.element_size()), (int)rank,
+                          (int)world),
+     "init_custom_ar");
+  return (int64_t)fa;
+}
+void dispose(int64_t fa) { aphro_custom_ar_dispose((void*)fa); }   // custom_all_reduce.cu:111
+// custom_all_reduce.cu:114-118
+void register_buffer(int64_t fa, torch::Tensor t, std::vector<std::string> handles, std::vector<int64_t> offsets) {
+  TORCH_CHECK(handles.size() == offsets.size(), "register_buffer: one offset per handle");
+  const std::string raw = ipc_pack(handles);
+  ok(aphro_custom_ar_register_buffer((void*)fa, t.data_ptr(), raw.data(), offsets.data()), "register_buffer");
+}
+// custom_all_reduce.cu:120-128: (handle bytes as int[], offsets)
+std::tuple<std::vector<int64_t>, std::vector<int64_t>> get_graph_buffer_ipc_meta(int64_t fa) {
+  int count = 0;
+  ok(aphro_custom_ar_get_graph_buffer_ipc_meta((void*)fa, nullptr, nullptr, 0, &count), "get_graph_buffer_ipc_meta");
+  const size_t hb = (size_t)aphro_ipc_handle_bytes();
+  std::string raw((size_t)count * hb, '\0');
+  std::vector<int64_t> offs((size_t)count);
+  if (count > 0)
+    ok(aphro_custom_ar_get_graph_buffer_ipc_meta((void*)fa, &raw[0], offs.data(), count, &count), "get_graph_buffer_ipc_meta");
+  std::vector<int64_t> bytes(raw.size());
+  for (size_t i = 0; i < raw.size(); ++i) bytes[i] = (unsigned char)raw[i];
+  return {bytes, offs};
+}
+// custom_all_reduce.cu:130-137: handles[r] = rank r's blob (count handles back to back), offsets[r] its offsets
+void register_graph_buffers(int64_t fa, std::vector<std::string> handles, std::vector<std::vector<int64_t>> offsets) {
+  TORCH_CHECK(handles.size() == offsets.size(), "register_graph_buffers: handles and offsets must have one entry per rank");
+  const size_t hb = (size_t)aphro_ipc_handle_bytes(), count = offsets.empty() ? 0 : offsets[0].size();
+  std::string raw;
+  std::vector<int64_t> flat;
+  for (size_t r = 0; r < handles.size(); ++r) {
+    std::string blob = handles[r];
+    if (blob.size() == 2 * hb * count && count > 0) {          // hex text
+      std::string dec;
+      for (size_t i = 0; i < count; ++i) dec += ipc_raw(blob.substr(2 * hb * i, 2 * hb));
+      blob = dec;
+    }
+    TORCH_CHECK(offsets[r].size() == count && blob.size() == count * hb,
+                "register_graph_buffers: every rank must contribute the same number of buffers");
+    raw += blob;
+    flat.insert(flat.end(), offsets[r].begin(), offsets[r].end());
+  }
+  if (raw.empty()) raw.push_back('\0');
+  if (flat.empty()) flat.push_back(0);
+  ok(aphro_custom_ar_register_graph_buffers((void*)fa, raw.data(), flat.data(), (int)count), "register_graph_buffers");
+}
 
 }  // namespace
 
@@ -602,4 +700,14 @@ TORCH_LIBRARY_FRAGMENT(APHRO_CONCAT(APHRO_TORCH_NS, _custom_ar), m) {
   m.impl("all_reduce_unreg", torch::kCUDA, &all_reduce_unreg);
   m.def("meta_size() -> int");                                                                          // :526
   m.impl("meta_size", &meta_size);
+  m.def("init_custom_ar(Tensor meta, Tensor rank_data, str[] handles, int[] offsets, int rank, bool full_nvlink) -> int");  // :510-514
+  m.impl("init_custom_ar", torch::kCUDA, &init_custom_ar);
+  m.def("dispose(int fa) -> ()");                                                                       // :524
+  m.impl("dispose", &dispose);
+  m.def("register_buffer(int fa, Tensor t, str[] handles, int[] offsets) -> ()");                       // :528-531
+  m.impl("register_buffer", torch::kCUDA, &register_buffer);
+  m.def("get_graph_buffer_ipc_meta(int fa) -> (int[], int[])");                                         // :533
+  m.impl("get_graph_buffer_ipc_meta", &get_graph_buffer_ipc_meta);
+  m.def("register_graph_buffers(int fa, str[] handles, int[][] offsets) -> ()");                        // :535
+  m.impl("register_graph_buffers", &register_graph_buffers);
 }

@@ -44,7 +44,9 @@ class CustomAllreduce:
     _SUPPORTED_WORLD_SIZES = [2, 4, 6, 8]
 
     def __init__(self, group: dist.ProcessGroup, device: Union[int, str, torch.device],
-                 max_size: int = 8192 * 1024) -> None:
+                 max_size: int = 8192 * 1024, ops=None) -> None:
+        """``ops``: the provider of the ``_C_custom_ar`` op surface (default: ``aphrodite_engine_amd._custom_ops``; the tests
+        pass a view whose schema ops go through the C++ registration, ``torch.ops._C_mi355x_custom_ar``)."""
         self._IS_CAPTURING = False
         self.disabled = True
         self._ptr = None
@@ -70,7 +72,8 @@ class CustomAllreduce:
                 import warnings
                 warnings.warn(f"custom all-reduce is disabled ({why}); tensor parallelism falls back to RCCL")
             return
-        from .. import _custom_ops as ops
+        if ops is None:
+            from .. import _custom_ops as ops
         self._ops = ops
         with torch.cuda.device(device):
             # custom_all_reduce.py:101-120: meta = signal area + two-shot scratch, a staging buffer for unregistered

@@ -319,7 +319,8 @@ def test_cpp_torch_library_registration():
     assert torch.ops._C_mi355x_custom_ar.meta_size() == ops.meta_size() > 0
     ar_ns = [ns for ns in ("_aphro_t_C_custom_ar", "_aphro_g_C_custom_ar", "_C_custom_ar") if hasattr(torch.ops, ns)
              and hasattr(getattr(torch.ops, ns), "all_reduce_reg")]
-    for name in ("all_reduce_reg", "all_reduce_unreg", "meta_size"):
+    for name in ("all_reduce_reg", "all_reduce_unreg", "meta_size", "init_custom_ar", "dispose", "register_buffer",
+                 "get_graph_buffer_ipc_meta", "register_graph_buffers"):
         assert ar_ns and strip(getattr(torch.ops._C_mi355x_custom_ar, name).default._schema) == \
             strip(getattr(getattr(torch.ops, ar_ns[0]), name).default._schema), name
     with pytest.raises((RuntimeError, NotImplementedError)):
