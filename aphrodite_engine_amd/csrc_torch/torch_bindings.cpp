@@ -432,6 +432,138 @@ torch::Tensor awq_gemm(torch::Tensor in_feats, torch::Tensor kernel, torch::Tens
   return out;
 }
 
+// gptq_marlin_repack (gptq_marlin_repack.cu:257-340): the Marlin-role load-time prepack into the CDNA4 K-packed layout
+// ([K/8, N], same shape as the input); perm = argsort(g_idx) or empty
+torch::Tensor gptq_marlin_repack(torch::Tensor b_q_weight, torch::Tensor perm, c10::SymInt size_k, c10::SymInt size_n, int64_t num_bits) {
+  TORCH_CHECK(b_q_weight.is_cuda(), "gptq_marlin_repack: device tensor expected");
+  auto out = torch::empty_like(b_q_weight);
+  const bool has_perm = perm.defined() && perm.numel() > 0;
+  torch::Tensor p32 = has_perm ? perm.to(torch::kInt) : perm;
+  ok(aphro_gptq_repack((const uint32_t*)b_q_weight.data_ptr(), has_perm ? (const int32_t*)p32.data_ptr() : nullptr,
+                       (uint32_t*)out.data_ptr(), size_k.expect_int(), size_n.expect_int(), (int)num_bits, cur_stream()),
+     "gptq_marlin_repack");
+  return out;
+}
+
+// awq_marlin_repack (awq_marlin_repack.cu:199-267): AWQ [K, N/8] -> CDNA4 K-packed [K/8, N]
+torch::Tensor awq_marlin_repack(torch::Tensor b_q_weight, c10::SymInt size_k, c10::SymInt size_n, int64_t num_bits) {
+  TORCH_CHECK(b_q_weight.is_cuda(), "awq_marlin_repack: device tensor expected");
+  TORCH_CHECK(num_bits == 4, "only 4-bit AWQ is implemented");
+  const int64_t k = size_k.expect_int(), n = size_n.expect_int();
+  auto out = torch::empty({k / 8, n}, b_q_weight.options().dtype(torch::kInt));
+  ok(aphro_awq_repack((const uint32_t*)b_q_weight.data_ptr(), (uint32_t*)out.data_ptr(), k, n, cur_stream()), "awq_marlin_repack");
+  return out;
+}
+
+// The W4A16 dispatch of the Python op surface (_custom_ops._wna16): prompt-sized tile machine, the one-pass 33..64-row kernel
+// where it wins, else the decode kernel 64 rows at a time.  K-packed exllama-order weights; perm = act-order gather or undefined.
+torch::Tensor wna16_dispatch(torch::Tensor a, const torch::Tensor& qweight, const torch::Tensor& qzeros, const torch::Tensor& scales,
+                             const torch::Tensor& perm, int zero_offset, const char* op) {
+  const int64_t m = a.size(0), k = a.size(1), n = qweight.size(1), groups = scales.size(0);
+  const int dt = act_dtype(a);
+  const bool has_perm = perm.defined() && perm.numel() > 0;
+  const int64_t gs = groups > 0 ? k / groups : 0;
+  const bool large_ok = m > 64 && n % 128 == 0 && k % 64 == 0 && groups > 0 && k % groups == 0 && gs % 64 == 0 &&
+                        (k / 8) * n * 4 < (int64_t(1) << 32) && m * k * 2 < (int64_t(1) << 32);
+  const bool prefers_large = m > 128 || n * k >= (int64_t(1) << 25);
+  auto out = torch::empty({m, n}, a.options());
+  auto gathered = [&]() {
+    torch::Tensor x = has_perm ? a.index_select(1, perm.to(torch::kLong)) : a;
+    if (x.stride(1) != 1 || x.stride(0) % 8 != 0 || ((uintptr_t)x.data_ptr() % 16) != 0) x = x.contiguous();
+    return x;
+  };
+  if (large_ok && prefers_large && getenv("APHRO_WNA16_NO_LARGE") == nullptr) {
+    torch::Tensor x = gathered();
+    const size_t nb = aphro_wna16_gemm_large_workspace_bytes(m, n, k, groups, dt);
+    auto ws = torch::empty({(int64_t)nb}, a.options().dtype(torch::kUInt8));
+    ok(aphro_wna16_gemm_large(x.data_ptr(), (const uint32_t*)qweight.data_ptr(), (const uint32_t*)qzeros.data_ptr(), scales.data_ptr(),
+                              out.data_ptr(), nb ? ws.data_ptr() : nullptr, nb, m, n, k, groups, x.stride(0), zero_offset, dt, cur_stream()),
+       op);
+    return out;
+  }
+  if (m > 32 && m <= 64 && n * k >= (int64_t(1) << 25) && m * k * 2 < (int64_t(1) << 32) &&
+      aphro_wna16_gemm_mid_supported(m, n, k, groups) && getenv("APHRO_WNA16_NO_MID") == nullptr) {
+    torch::Tensor x = gathered();
+    const size_t nb = aphro_wna16_gemm_mid_workspace_bytes(m, n, k, groups);
+    auto ws = torch::empty({(int64_t)nb}, a.options().dtype(torch::kUInt8));
+    ok(aphro_wna16_gemm_mid(x.data_ptr(), (const uint32_t*)qweight.data_ptr(), (const uint32_t*)qzeros.data_ptr(), scales.data_ptr(),
+                            out.data_ptr(), ws.data_ptr(), nb, m, n, k, groups, x.stride(0), zero_offset, dt, cur_stream()),
+       op);
+    return out;
+  }
+  if (a.stride(1) != 1) a = a.contiguous();
+  auto ws = torch::empty({(int64_t)aphro_wna16_workspace_bytes(m < 64 ? m : 64, n, k)}, a.options().dtype(torch::kUInt8));
+  torch::Tensor tmp, p32;
+  if (has_perm) {
+    tmp = torch::empty({m < 64 ? m : 64, k}, a.options());
+    p32 = perm.to(torch::kInt);
+  }
+  for (int64_t m0 = 0; m0 < m; m0 += 64) {
+    const int64_t rows = m - m0 < 64 ? m - m0 : 64;
+    ok(aphro_gptq_gemm((const char*)a.data_ptr() + m0 * a.stride(0) * a.element_size(), (const uint32_t*)qweight.data_ptr(),
+                       (const uint32_t*)qzeros.data_ptr(), scales.data_ptr(), has_perm ? (const int32_t*)p32.data_ptr() : nullptr,
+                       has_perm ? tmp.data_ptr() : nullptr, (char*)out.data_ptr() + m0 * n * out.element_size(), ws.data_ptr(),
+                       (size_t)ws.numel(), rows, n, k, groups, a.stride(0), zero_offset, dt, cur_stream()),
+       op);
+  }
+  return out;
+}
+
+// gptq_marlin_gemm (gptq_marlin.cu:2136-2330; schema :195-201 with the type as its size in bits -- the verbatim schema names
+// the torchbind class _core_C.ScalarType, which only exists inside the reference: torch_ops.py).  b_q_weight = the
+// gptq_marlin_repack / awq_marlin_repack output; b_zeros plain-order int32 [G, N/8] when has_zp, else the uint4b8 zero point 8.
+torch::Tensor gptq_marlin_gemm(torch::Tensor a, torch::Tensor b_q_weight, torch::Tensor b_scales, torch::Tensor b_zeros,
+                               torch::Tensor g_idx, torch::Tensor perm, torch::Tensor workspace, int64_t b_q_type, int64_t size_m,
+                               int64_t size_n, int64_t size_k, bool is_k_full, bool has_zp, bool use_fp32_reduce, bool is_zp_float) {
+  TORCH_CHECK(!is_zp_float, "gptq_marlin_gemm: float zero points are not supported");
+  TORCH_CHECK(b_q_type == 4, "gptq_marlin_gemm on MI355X serves 4-bit weights only");
+  torch::Tensor x = a.reshape({-1, a.size(-1)});
+  TORCH_CHECK(x.size(0) == size_m && x.size(1) == size_k && b_q_weight.dim() == 2 && b_q_weight.size(0) == size_k / 8 &&
+              b_q_weight.size(1) == size_n, "gptq_marlin_gemm: shape mismatch");
+  torch::Tensor zp = b_zeros;
+  if (!has_zp)
+    zp = torch::full({b_scales.size(0), size_n / 8}, (int64_t)0x88888888 - ((int64_t)1 << 32), b_q_weight.options().dtype(torch::kInt));
+  return wna16_dispatch(x, b_q_weight, zp, b_scales, perm, 0, "gptq_marlin_gemm");
+}
+
+// fp8_marlin_gemm (fp8_marlin.cu:1212; :218-222): W8A16 on the checkpoint layout, e4m3 [N, K] row-major, scales fp32 [1] or [N]
+torch::Tensor fp8_marlin_gemm(torch::Tensor a, torch::Tensor b_q_weight, torch::Tensor b_scales, torch::Tensor workspace,
+                              int64_t num_bits, int64_t size_m, int64_t size_n, int64_t size_k) {
+  TORCH_CHECK(num_bits == 8 && a.is_cuda() && b_q_weight.is_cuda() && b_scales.is_cuda(), "fp8_marlin_gemm: 8-bit device tensors expected");
+  if (a.stride(1) != 1) a = a.contiguous();
+  const int dt = act_dtype(a);
+  torch::Tensor sb = b_scales.reshape({-1}).to(torch::kFloat);
+  const int per_channel = sb.numel() > 1 ? 1 : 0;
+  if (size_m > 64 && size_n % 128 == 0 && size_k % 64 == 0 && getenv("APHRO_WNA16_NO_LARGE") == nullptr) {
+    torch::Tensor x = a.narrow(0, 0, size_m);
+    if (x.stride(0) % 8 != 0 || ((uintptr_t)x.data_ptr() % 16) != 0) x = x.contiguous();
+    auto out = torch::empty({size_m, size_n}, a.options());
+    const size_t nb = aphro_fp8_w8a16_gemm_large_workspace_bytes(size_m, size_n, size_k, dt);
+    auto ws = torch::empty({(int64_t)nb}, a.options().dtype(torch::kUInt8));
+    ok(aphro_fp8_w8a16_gemm_large(out.data_ptr(), x.data_ptr(), b_q_weight.data_ptr(), sb.data_ptr<float>(), nullptr,
+                                  nb ? ws.data_ptr() : nullptr, nb, size_m, size_n, size_k, x.stride(0), per_channel, dt, cur_stream()),
+       "fp8_marlin_gemm");
+    return out;
+  }
+  if (size_m >= 256) {     // shapes the hand-written kernel does not tile: widen the weight once (exact) + a library GEMM
+    torch::Tensor w = b_q_weight.to(a.scalar_type());
+    torch::Tensor s = b_scales.reshape({-1}).to(a.scalar_type());
+    w = per_channel ? w * s.reshape({-1, 1}) : w * s;
+    return torch::matmul(a.narrow(0, 0, size_m), w.t());
+  }
+  auto out = torch::empty({size_m, size_n}, a.options());
+  const size_t nb = aphro_fp8_gemm_workspace_bytes(size_m < 64 ? size_m : 64, size_n, size_k);
+  auto ws = torch::empty({(int64_t)nb}, a.options().dtype(torch::kUInt8));
+  for (int64_t m0 = 0; m0 < size_m; m0 += 64) {
+    const int64_t rows = size_m - m0 < 64 ? size_m - m0 : 64;
+    ok(aphro_fp8_w8a16_gemm((char*)out.data_ptr() + m0 * size_n * out.element_size(),
+                            (const char*)a.data_ptr() + m0 * a.stride(0) * a.element_size(), b_q_weight.data_ptr(), sb.data_ptr<float>(),
+                            nullptr, ws.data_ptr(), nb, rows, size_n, size_k, a.stride(0), per_channel, dt, cur_stream()),
+       "fp8_marlin_gemm");
+  }
+  return out;
+}
+
 // cutlass_scaled_mm_supports_fp8 (scaled_mm_entry.cu:30-50): gfx950 has native OCP fp8 MFMA
 bool cutlass_scaled_mm_supports_fp8(int64_t cuda_device_capability) { return true; }
 
@@ -683,6 +815,17 @@ TORCH_LIBRARY_FRAGMENT(APHRO_TORCH_NS, m) {
   m.impl("awq_gemm", torch::kCUDA, &awq_gemm);
   m.def("cutlass_scaled_mm_supports_fp8(int cuda_device_capability) -> bool");                          // :250-252
   m.impl("cutlass_scaled_mm_supports_fp8", &cutlass_scaled_mm_supports_fp8);
+  m.def("gptq_marlin_repack(Tensor b_q_weight, Tensor perm, SymInt size_k, SymInt size_n, int num_bits) -> Tensor");  // :204-208
+  m.impl("gptq_marlin_repack", torch::kCUDA, &gptq_marlin_repack);
+  m.def("awq_marlin_repack(Tensor b_q_weight, SymInt size_k, SymInt size_n, int num_bits) -> Tensor");  // :211-215
+  m.impl("awq_marlin_repack", torch::kCUDA, &awq_marlin_repack);
+  m.def("gptq_marlin_gemm(Tensor a, Tensor b_q_weight, Tensor b_scales, Tensor b_zeros, Tensor g_idx, Tensor perm, "
+        "Tensor workspace, int b_q_type, int size_m, int size_n, int size_k, bool is_k_full, bool has_zp, "
+        "bool use_fp32_reduce, bool is_zp_float) -> Tensor");                                           // :195-201
+  m.impl("gptq_marlin_gemm", torch::kCUDA, &gptq_marlin_gemm);
+  m.def("fp8_marlin_gemm(Tensor a, Tensor b_q_weight, Tensor b_scales, Tensor! workspace, int num_bits, "
+        "int size_m, int size_n, int size_k) -> Tensor");                                               // :218-222
+  m.impl("fp8_marlin_gemm", torch::kCUDA, &fp8_marlin_gemm);
 }
 
 TORCH_LIBRARY_FRAGMENT(APHRO_TORCH_ROCM_NS, m) {

@@ -310,7 +310,8 @@ def test_cpp_torch_library_registration():
         assert cache_ns and strip(cpp) == strip(getattr(getattr(torch.ops, cache_ns[0]), name).default._schema), name
     # round 5, second batch: the AWQ GEMM, the fp8 capability query, _rocm_C::paged_attention, the _C_custom_ar ops whose
     # arguments cross the dispatcher unchanged
-    for name in ("awq_gemm", "cutlass_scaled_mm_supports_fp8"):
+    for name in ("awq_gemm", "cutlass_scaled_mm_supports_fp8", "gptq_marlin_repack", "awq_marlin_repack", "gptq_marlin_gemm",
+                 "fp8_marlin_gemm"):
         assert strip(getattr(torch.ops._C_mi355x, name).default._schema) == strip(getattr(getattr(torch.ops, py_ns[0]), name).default._schema), name
     assert torch.ops._C_mi355x.cutlass_scaled_mm_supports_fp8(94) is True           # no tensor arguments: runs without a GPU
     rocm_ns = [ns for ns in ("_aphro_t_rocm", "_aphro_g_rocm", "_rocm_C") if hasattr(torch.ops, ns) and hasattr(getattr(torch.ops, ns), "paged_attention")]

@@ -487,6 +487,31 @@ def test_cpp_registered_round5_second_batch_matches_the_python_registration(T):
     for M in (1, 33, 70, 300):                       # one pass, two 64-row passes, the repack + tile-machine path
         a = t(rng.standard_normal((M, K)).astype(np.float16))
         assert torch.equal(C.awq_gemm(a, qw, sc, qz, 8), T.C.awq_gemm(a, qw, sc, qz, 8)), M
+    # the Marlin-role prepacks (load time)
+    assert torch.equal(C.awq_marlin_repack(qw, K, N, 4), T.C.awq_marlin_repack(qw, K, N, 4))
+    gq = t(oq.gptq_pack(q))
+    perm = t(rng.permutation(K).astype(np.int32))
+    for pm in (torch.empty(0, dtype=torch.int32, device=DEV), perm):
+        assert torch.equal(C.gptq_marlin_repack(gq, pm, K, N, 4), T.C.gptq_marlin_repack(gq, pm, K, N, 4))
+    # the Marlin-role GEMMs: symmetric uint4b8 and zero-point weights, decode-sized / one-pass 33..64-row / prompt-sized rows
+    K2, N2 = 4096, 8192                               # n k = 2^25: the size from which the one-pass kernel is preferred
+    w2 = (rng.standard_normal((K2, N2)) * 0.02).astype(np.float16)
+    _, q2, s2, zp2 = oq.quantize_weights(w2, 4, G, zero_points=True)
+    empty = torch.empty(0, dtype=torch.int32, device=DEV)
+    mq = T.C.gptq_marlin_repack(t(oq.gptq_pack(q2)), empty, K2, N2, 4)
+    msc, mzp = t(s2.astype(np.float16)), t(oq.gptq_pack_zeros(zp2 + 1))        # plain zero points (no GPTQ "- 1")
+    ws_m = torch.zeros(N2 // 64 * 16, dtype=torch.int32, device=DEV)
+    for M in (7, 48, 130):
+        a2 = t(rng.standard_normal((M, K2)).astype(np.float16))
+        for has_zp, zt in ((False, empty), (True, mzp)):
+            args = (a2, mq, msc, zt, empty, empty, ws_m, 4, M, N2, K2, True, has_zp, True, False)
+            assert torch.equal(C.gptq_marlin_gemm(*args), T.C.gptq_marlin_gemm(*args)), (M, has_zp)
+    w8 = t((rng.standard_normal((256, 512)) * 0.5).astype(np.float32)).to(torch.float8_e4m3fn)     # [N, K]
+    for sb8 in (t(np.array([0.02], np.float32)), t((rng.random(256) * 0.02 + 0.01).astype(np.float32))):
+        for M in (5, 70, 200):
+            a8 = t(rng.standard_normal((M, 512)).astype(np.float16))
+            args = (a8, w8, sb8, ws_m, 8, M, 256, 512)
+            assert torch.equal(C.fp8_marlin_gemm(*args), T.C.fp8_marlin_gemm(*args)), M
     a = t(rng.standard_normal((16, 2 * K)).astype(np.float16))[:, ::2]       # non-unit column stride: made contiguous
     assert torch.equal(C.awq_gemm(a, qw, sc, qz, 8), T.C.awq_gemm(a, qw, sc, qz, 8))
     # paged attention through the ROCm schema
