@@ -1139,13 +1139,15 @@ def main():
         achieved = dom["bytes"] / dom["seconds"] / 1e9
         n_members = len(dom["members"])
         # HBM bytes per launch: PMC counters cannot be collected from inside this process (rocprofv3 wraps it).  The
-        # committed same-round passes (profiles/r4_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE,
+        # committed passes of the newest round (profiles/r5_pmc_traffic.json, else r4_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE,
         # separate runs of tools/prof_step_kernels.py at THESE shapes, gfx950 x2 correction on FETCH_SIZE) are attached
         # with their provenance; null when the file has no entry for the dominant template.
         traffic = None
         traffic_src = None
         try:
-            pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r4_pmc_traffic.json")))
+            pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+            pmc_file = next(f for f in ("r5_pmc_traffic.json", "r4_pmc_traffic.json") if os.path.exists(os.path.join(pdir, f)))
+            pmc = json.load(open(os.path.join(pdir, pmc_file)))
             pref = "fp8_" if args.quant.startswith("fp8") else ""     # (the FP8 resident kernels have their own entries)
             ent = [pmc["kernels"][pref + m] for m in dom["members"] if pref + m in pmc.get("kernels", {})]
             if len(ent) == n_members and args.quant in ("gptq", "awq", "fp8ct", "fp8") and args.batch == 32 \

@@ -3,8 +3,8 @@
 never together: 3 + 2 TCC slots of 4, MI355X_MICROARCH.md "rocprofv3 PMC slots") into HBM bytes per launch of every
 decode-step kernel, next to the algorithmic bytes of bench.py's roofline section.
 
-    python tools/pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> > profiles/r4_pmc_traffic.txt
-    (also writes profiles/r4_pmc_traffic.json, which bench.py attaches as roofline.traffic with its provenance)
+    PMC_TAG=r5 python tools/pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> > profiles/r5_pmc_traffic.txt
+    (also writes profiles/<PMC_TAG>_pmc_traffic.json; bench.py attaches the newest round's file as roofline.traffic with its provenance)
 
 Units / corrections (guide, HBM section): FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports one half of
 the bytes of wide coalesced streaming reads (128-byte requests tallied at 64): bytes = FETCH_SIZE * 1024 * 2.  WRITE_SIZE
@@ -73,14 +73,15 @@ def main():
     wd = find(write, r"wna16_gemm_kernel<aphro::Half, 4, 2, 7>")
     if wd:
         wcal = (4 * M * 4096 * 4) / (wd[0] * 1024)
-    print("HBM traffic per launch of the decode-step kernels (round 4; rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes of")
+    print("HBM traffic per launch of the decode-step kernels (round " + os.environ.get("PMC_TAG", "r4")[1:] + "; rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes of")
     print("tools/prof_step_kernels.py: bs 32, ctx 1100, configs[1] shapes; no trace domains in the same run)")
     print("bytes read = FETCH_SIZE [KiB] x 1024 x 2 (gfx950: wide coalesced reads are tallied at half their size -- MI355X_MICROARCH.md, HBM);")
     print(f"bytes written = WRITE_SIZE [KiB] x 1024 x {wcal:.3f} (calibrated on the down projection's 4 x 32 x 4096 fp32 slabs = 2 097 152 B)" if wcal else "WRITE_SIZE uncalibrated")
     print()
     print(f"{'role':34s} {'launches':>8s} {'read MB':>9s} {'alg read MB':>11s} {'ratio':>6s} {'write MB':>9s} {'alg write MB':>12s}")
-    out = {"source": "profiles/r4_pmc_traffic.txt: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of tools/prof_step_kernels.py "
-                     "(round 4, bs 32, ctx 1100); read bytes = FETCH_SIZE KiB x 1024 x 2 (gfx950 correction), write bytes calibrated on "
+    tag = os.environ.get("PMC_TAG", "r4")            # which round's files: profiles/<tag>_pmc_traffic.{txt,json}
+    out = {"source": f"profiles/{tag}_pmc_traffic.txt: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of tools/prof_step_kernels.py "
+                     f"(round {tag[1:]}, bs 32, ctx 1100); read bytes = FETCH_SIZE KiB x 1024 x 2 (gfx950 correction), write bytes calibrated on "
                      "the down projection's slabs", "kernels": {}}
     for role, pat, alg_r, alg_w in table:
         f, w = find(fetch, pat), find(write, pat)
@@ -99,7 +100,7 @@ def main():
     for k, v in sorted(fetch.items(), key=lambda kv: -kv[1][0]):
         if "aphro::" in k:
             print(f"  {short(k):70s} {v[0]:12.1f} {v[1]:4d}")
-    json.dump(out, open(os.path.join(ROOT, "profiles", "r4_pmc_traffic.json"), "w"), indent=1)
+    json.dump(out, open(os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json"), "w"), indent=1)
 
 
 if __name__ == "__main__":
