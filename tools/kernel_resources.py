@@ -12,10 +12,10 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "aphrodite_engine_amd", "csrc")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-function", "-Wno-unused-variable", "-Wno-pass-failed",
-         "-mllvm", "-amdgpu-kernarg-preload-count=14"]
-EXTRA = {"paged_attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"], "flash_attn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
-         "wna16_gemm_resident.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-function", "-Wno-unused-variable", "-Wno-pass-failed"]
+_VF, _KP = ["-mllvm", "-amdgpu-mfma-vgpr-form=1"], ["-mllvm", "-amdgpu-kernarg-preload-count=14"]
+EXTRA = {"paged_attention.hip": _VF + _KP, "flash_attn.hip": _VF, "wna16_gemm_resident.hip": _VF + _KP,
+         "fp8_gemm_resident.hip": _KP, "fp8_gemm_stream.hip": _KP, "wna16_gemm.hip": _KP}      # (the Makefile's per-file EXTRA)
 
 
 def demangle(names):
