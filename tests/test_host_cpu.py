@@ -615,3 +615,26 @@ def test_bench_replica_line_survives_a_failing_tensor_parallel_section(failure):
     assert "error" in line["tp_section"], line["tp_section"]
     if failure == "hang":
         assert "timed out" in line["tp_section"]["error"]
+
+
+def test_per_file_compile_flags_have_one_source_of_truth():
+    """The Makefile's per-file EXTRA flags (VGPR-form MFMA results, kernel-argument preload) are what the GPU suite validated;
+    tools/kernel_resources.py recompiles every file to report registers / spills and must use the same ones."""
+    import importlib.util
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    mk = open(os.path.join(root, "aphrodite_engine_amd", "csrc", "Makefile")).read()
+    var = {"VGPR_FORM": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"], "KERNARG_PRELOAD": ["-mllvm", "-amdgpu-kernarg-preload-count=14"],
+           "PA_EXTRA": []}
+    for name, flags in var.items():
+        if flags:
+            assert re.search(rf"^{name}\s*:=\s*{re.escape(' '.join(flags))}\s*$", mk, re.M), name
+    want = {}
+    for m in re.finditer(r"^build/(\w+)\.o: EXTRA := (.*)$", mk, re.M):
+        want[m.group(1) + ".hip"] = sum((var[v] for v in re.findall(r"\$\((\w+)\)", m.group(2))), [])
+    assert set(want) >= {"paged_attention.hip", "wna16_gemm_resident.hip", "fp8_gemm_resident.hip", "fp8_gemm_stream.hip", "wna16_gemm.hip"}
+    assert "kernarg-preload" not in re.search(r"^FLAGS\s*:=.*(?:\n\s+.*)*", mk, re.M).group(0)      # per file, not global
+    spec = importlib.util.spec_from_file_location("kernel_resources", os.path.join(root, "tools", "kernel_resources.py"))
+    kr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kr)
+    assert {k: v for k, v in kr.EXTRA.items()} == want
