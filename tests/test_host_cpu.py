@@ -638,3 +638,24 @@ def test_per_file_compile_flags_have_one_source_of_truth():
     kr = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(kr)
     assert {k: v for k, v in kr.EXTRA.items()} == want
+
+
+def test_deferred_all_reduce_falls_back_to_the_two_launches(monkeypatch):
+    """DeferredAllReduce.finish when the fused all-reduce + norm launch stopped applying between defer and finish (communicator
+    disabled after a peer timeout): the all-reduce, then ops.fused_add_rms_norm_pack -- the two launches the fused one stands
+    for, same arguments -- instead of an assertion."""
+    from aphrodite_engine_amd import _custom_ops as ops, distributed as d
+    calls = []
+    monkeypatch.setattr(d, "tensor_model_parallel_all_reduce_norm", lambda *a, **k: None)
+    monkeypatch.setattr(d, "tensor_model_parallel_all_reduce", lambda x, *a, **k: calls.append(("ar", x)) or x + 1)
+
+    def norm(x, slabs, residual, has_residual, weight, eps, pack=True, want_out=False):
+        calls.append(("norm", x, slabs, residual, has_residual, weight, eps, pack, want_out))
+        return "packed", "out"
+    monkeypatch.setattr(ops, "fused_add_rms_norm_pack", norm)
+    partial, res, w = torch.zeros(2, 8), torch.ones(2, 8), torch.ones(8)
+    assert d.DeferredAllReduce(partial).finish(res, w, 1e-5, pack=False, want_out=True) == ("packed", "out")
+    assert calls[0][0] == "ar" and calls[0][1] is partial
+    kind, x, slabs, residual, has_residual, weight, eps, pack, want_out = calls[1]
+    assert kind == "norm" and torch.equal(x, partial + 1) and slabs is None and residual is res and has_residual is True
+    assert weight is w and eps == 1e-5 and pack is False and want_out is True
