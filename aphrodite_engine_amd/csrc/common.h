@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/aphrodite_mi355x.h"
 
@@ -58,6 +59,14 @@ inline int device_cu_count() {
     n[d] = v;
   }
   return n[d];
+}
+// Persistent grids whose workgroups WAIT on one another (the stream-K owners of the prompt-sized GEMMs spin on flags
+// of higher-index workgroups) are only correct when the whole grid is co-resident.  One workgroup per reported CU is,
+// unless the process runs under a CU mask (the runtime still reports every CU): then those plans are not used at all
+// and the shape takes the one-workgroup-per-tile + split-K plan, which has no cross-workgroup wait.
+inline int device_coresident_cu_count() {
+  static const bool masked = getenv("HSA_CU_MASK") || getenv("ROC_GLOBAL_CU_MASK") || getenv("HSA_CU_MASK_SKIP_INIT");
+  return masked ? 0 : device_cu_count();
 }
 
 // ---- scalar conversions -----------------------------------------------------

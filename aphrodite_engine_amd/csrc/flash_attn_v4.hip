@@ -435,6 +435,10 @@ void flash_attn_varlen_v4_kernel(FAParams p) {
     if (t == L)                            // this wave's last PV (block 1 of tile L - 1)
       phase(false, 0, sc1, qf[1], true, t - 1, o[1], pf1, false, false, 0, 0, sc0, pf0, st0, 0, 0);
   }
+  // The tail bodies above still issued K(t + 3) / V(t + 2) pieces by LDS-DMA from inline asm hipcc cannot count, and
+  // __syncthreads() does not wait on vmcnt: a piece of a causal non-final q tile (real rows below `len`) could land in the
+  // K ring AFTER a wave has written its O rows there.  Drain this wave's pieces before the barrier that frees the rings.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();                                         // every wave is done with the K / V buffers
 
   // ---- normalise, transpose through LDS (wave-private 16 KiB: 64 rows x 256 B), store whole rows -------------------------------

@@ -719,7 +719,7 @@ static Fp8LargePlan fp8_large_plan(int64_t M, int64_t N, int64_t K) {
   const int64_t rows = (M + 128 * pl.wm - 1) / (128 * pl.wm);
   static const int mode = getenv("APHRO_FP8_LARGE_STREAMK") ? atoi(getenv("APHRO_FP8_LARGE_STREAMK")) : -1;
   const int64_t big_tiles = N % 256 == 0 ? rows * (N / 256) : rows * (N / 128);
-  pl.streamk = mode >= 0 ? mode : (big_tiles >= 128);
+  pl.streamk = (mode >= 0 ? mode : (big_tiles >= 128)) && device_coresident_cu_count() > 0;
   pl.ksplit = 1;
   if (pl.streamk) {
     pl.wn = N % 256 == 0 ? 4 : 2;

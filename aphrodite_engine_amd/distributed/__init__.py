@@ -18,6 +18,7 @@ _TP_RANK = 0
 _TP_SIZE = 1
 _CUSTOM_AR = None      # CustomAllreduce of the TP group (enable_custom_all_reduce)
 _OVERLAP = None        # AllReduceOverlap (enable_all_reduce_overlap): all-reduce on a side stream + weight prefetch
+_ADOPTED = False       # TP state taken from the reference engine's GroupCoordinator (adopt_reference_parallel_state)
 _SIM_AR_US = None      # simulated TP (init_simulated_tensor_parallel): {bytes threshold: microseconds} of the stubbed all-reduce
 
 
@@ -64,11 +65,64 @@ def enable_loopback_all_reduce(device, max_size: int = 8192 * 1024):
     return _CUSTOM_AR
 
 
+def reference_parallel_sizes():
+    """(tensor-parallel size, pipeline-parallel size) of the REFERENCE engine this process runs inside
+    (aphrodite/distributed/parallel_state.py:875-889, 1104-1111), or None when the reference is not importable or its
+    groups are not initialised (standalone use of this package)."""
+    try:
+        from aphrodite.distributed import parallel_state as ps
+    except Exception:
+        return None
+    try:
+        tp = int(ps.get_tp_group().world_size)
+    except Exception:
+        return None
+    try:
+        pp = int(ps.get_pp_group().world_size)
+    except Exception:
+        pp = 1
+    return tp, pp
+
+
+def adopt_reference_parallel_state() -> bool:
+    """Inside the reference engine the TP group is the reference's ``GroupCoordinator`` (parallel_state.py:131-231), built
+    by ``initialize_model_parallel`` before any model class is constructed (worker/worker.py ``init_worker_distributed_
+    environment`` -> ``load_model``).  This package's layers shard by ITS OWN ``_TP_*`` state, so a fused model built
+    under a TP > 1 engine must take group, rank and size from there -- otherwise every rank builds the unsharded model
+    while the worker allocates KV caches for ``num_kv_heads / tp`` heads.  Adopts ``device_group``
+    (the RCCL group the reference's own all-reduce uses), ``rank_in_group``, ``world_size`` and -- when the plugin has
+    swapped this package's ``CustomAllreduce`` in and it is enabled -- the group's ``ca_comm``.  Returns True when this
+    package's TP state now equals the reference's (also when both are 1 or it already matched)."""
+    global _TP_GROUP, _TP_RANK, _TP_SIZE, _CUSTOM_AR, _ADOPTED
+    try:
+        from aphrodite.distributed import parallel_state as ps
+        grp = ps.get_tp_group()
+    except Exception:
+        return False
+    size = int(grp.world_size)
+    if size == 1:
+        return _TP_SIZE == 1
+    rank = int(grp.rank_in_group)
+    device_group = getattr(grp, "device_group", None)
+    if device_group is None:
+        return False
+    if _TP_SIZE == size and _TP_RANK == rank and _TP_GROUP is device_group:
+        return True
+    if _TP_SIZE != 1 or _SIM_AR_US is not None:
+        return False            # this package's TP state was initialised to something else: do not overwrite it
+    _TP_GROUP, _TP_RANK, _TP_SIZE, _ADOPTED = device_group, rank, size, True
+    ca = getattr(grp, "ca_comm", None)
+    from .custom_all_reduce import CustomAllreduce
+    if isinstance(ca, CustomAllreduce) and not getattr(ca, "disabled", True):
+        _CUSTOM_AR = ca
+    return True
+
+
 def destroy_tensor_parallel() -> None:
-    global _TP_GROUP, _TP_RANK, _TP_SIZE, _CUSTOM_AR, _OVERLAP, _SIM_AR_US
-    if _CUSTOM_AR is not None:
+    global _TP_GROUP, _TP_RANK, _TP_SIZE, _CUSTOM_AR, _OVERLAP, _SIM_AR_US, _ADOPTED
+    if _CUSTOM_AR is not None and not _ADOPTED:     # an adopted communicator belongs to the reference's GroupCoordinator
         _CUSTOM_AR.close()
-    _TP_GROUP, _TP_RANK, _TP_SIZE, _CUSTOM_AR, _OVERLAP, _SIM_AR_US = None, 0, 1, None, None, None
+    _TP_GROUP, _TP_RANK, _TP_SIZE, _CUSTOM_AR, _OVERLAP, _SIM_AR_US, _ADOPTED = None, 0, 1, None, None, None, False
 
 
 def enable_custom_all_reduce(device, cpu_group: Optional[dist.ProcessGroup] = None, max_size: int = 8192 * 1024):

@@ -40,6 +40,11 @@ class MI355XLlamaForCausalLM(nn.Module):
     supported_lora_modules: List[str] = []
     embedding_modules = {}
     embedding_padding_modules: List[str] = []
+    # ``build_model`` asks ``supports_lora(model_class)`` BEFORE it constructs anything (model_loader/loader.py:115-131,
+    # interfaces.py:136-142: the flag plus the four attributes above) and raises "does not support LoRA" for a class
+    # without it -- so the REGISTERED subclasses carry the flag (register_with_reference) and ``lora_config`` reaches
+    # ``__new__``, which hands a LoRA-enabled engine to the reference's own class.  The base class, constructed directly,
+    # refuses LoRA and does not DEFINE the flag (the protocol check is hasattr, not truth).
 
     # the architecture this class was registered for and the reference's registry (set per registration by
     # register_with_reference): a configuration the fused step does not serve falls back to the registry's BUILT-IN class
@@ -53,6 +58,17 @@ class MI355XLlamaForCausalLM(nn.Module):
         top of this package's ops and quant methods -- the op-by-op path -- instead of an exception)."""
         if lora_config is not None:
             return "LoRA adapters"
+        # the engine's parallel layout (ADVICE r5): this package's layers shard by its own TP state, which must BE the
+        # reference's before a fused model is built under TP > 1; pipeline stages are not served at all
+        from . import distributed as D
+        sizes = D.reference_parallel_sizes()
+        if sizes is not None:
+            tp, pp = sizes
+            if pp > 1:
+                return f"pipeline parallel size {pp}"
+            if tp != D.get_tensor_model_parallel_world_size() and not D.adopt_reference_parallel_state():
+                return (f"tensor parallel size {tp}: this package's TP state ({D.get_tensor_model_parallel_world_size()}) "
+                        "could not be matched to the engine's")
         hf = config.to_dict() if hasattr(config, "to_dict") else dict(vars(config))
         try:
             L.llama_config_from_hf(hf)
@@ -66,6 +82,12 @@ class MI355XLlamaForCausalLM(nn.Module):
             explicit = getattr(torch, explicit, None)
         if explicit is None and torch.get_default_dtype() != torch.float32:
             explicit = torch.get_default_dtype()
+        if explicit is None and cls._fallback_registry is not None:
+            # constructed THROUGH the registry = by the reference's loader, which builds every model under
+            # set_default_torch_dtype(model_config.dtype) (model_loader/loader.py:384-390) and passes neither dtype nor
+            # model_config: a float32 default there is the engine's choice (--dtype float32: its runner and KV cache are
+            # float32), not "unset" -- the fused path has no float32 form
+            explicit = torch.float32
         if explicit is not None and explicit not in (torch.float16, torch.bfloat16):
             return f"dtype {explicit}"
         return None
@@ -186,5 +208,7 @@ def register_with_reference(model_registry, archs=("LlamaForCausalLM", "MistralF
     for arch in archs:
         has_builtin = callable(getattr(model_registry, "_get_model", None))
         cls = type(f"MI355X{arch}", (MI355XLlamaForCausalLM, ),
-                   {"_fallback_arch": arch if has_builtin else None, "_fallback_registry": model_registry if has_builtin else None})
+                   {"_fallback_arch": arch if has_builtin else None, "_fallback_registry": model_registry if has_builtin else None,
+                    # only a class that CAN fall back advertises LoRA to the loader's pre-construction check
+                    **({"supports_lora": True} if has_builtin else {})})
         model_registry.register_model(arch, cls)

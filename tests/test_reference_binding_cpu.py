@@ -307,7 +307,10 @@ def test_fused_model_registers_through_the_reference_model_registry(monkeypatch)
         assert m.inner.layers[0].qkv_proj.qweight.shape == (512 // 8, (4 + 2 * 2) * 128)
         with pytest.raises(NotImplementedError):
             MI355XLlamaForCausalLM(config=hf, cache_config=cache, quant_config=None, lora_config=object())
-        # ... while the REGISTERED class hands what the fused step does not serve to the reference's built-in class
+        # ... while the REGISTERED class hands what the fused step does not serve to the reference's built-in class.
+        # The reference's loader constructs every model under set_default_torch_dtype(model_config.dtype)
+        # (model_loader/loader.py:384-390): --dtype half here
+        torch.set_default_dtype(torch.float16)
         assert isinstance(cls(config=hf, cache_config=cache, quant_config=GPTQConfig(4, 128, False)), MI355XLlamaForCausalLM)
         for bad_kw, bad_hf in ((dict(lora_config=object()), hf),
                                ({}, types.SimpleNamespace(**{**vars(hf), "sliding_window": 4096})),
@@ -317,7 +320,46 @@ def test_fused_model_registers_through_the_reference_model_registry(monkeypatch)
             kw.update(bad_kw)
             ref = cls(config=bad_hf, **kw)
             assert isinstance(ref, RefLlama) and ref.kwargs["config"] is bad_hf
+        # an engine run with --dtype float32 builds the model under a float32 default and passes no dtype:
+        # through the registry that is the engine's choice, not "unset" -- the reference's class gets it
+        torch.set_default_dtype(torch.float32)
+        assert isinstance(cls(config=hf, cache_config=cache, quant_config=GPTQConfig(4, 128, False)), RefLlama)
+        torch.set_default_dtype(torch.float16)
+        # build_model asks supports_lora(model_class) BEFORE constructing (loader.py:115-131) -- with the
+        # reference's own interfaces.py: the registered class passes the check, so lora_config reaches __new__ and falls back
+        _stub("aphrodite.common.config", LoRAConfig=type("LoRAConfig", (), {}), MultiModalConfig=type("MultiModalConfig", (), {}),
+              SchedulerConfig=type("SchedulerConfig", (), {}))
+        itf = _load("aphrodite.modeling.models.interfaces", "aphrodite/modeling/models/interfaces.py")
+        assert itf.supports_lora(cls) and not itf.supports_lora(MI355XLlamaForCausalLM)
+        lora = sys.modules["aphrodite.common.config"].LoRAConfig()
+        assert isinstance(cls(config=hf, cache_config=cache, quant_config=GPTQConfig(4, 128, False), lora_config=lora), RefLlama)
+        assert isinstance(cls(config=hf, cache_config=cache, quant_config=GPTQConfig(4, 128, False), lora_config=None),
+                          MI355XLlamaForCausalLM)
+        # under a TP > 1 engine the fused model takes group, rank and size from the reference's
+        # GroupCoordinator (parallel_state.py:875-889) -- every rank builds ITS shard; pipeline stages fall back
+        from aphrodite_engine_amd import distributed as D
+        grp = types.SimpleNamespace(world_size=2, rank_in_group=1, device_group=object(), ca_comm=None)
+        pp = types.SimpleNamespace(world_size=1)
+        _stub("aphrodite.distributed")
+        ps = _stub("aphrodite.distributed.parallel_state", get_tp_group=lambda: grp, get_pp_group=lambda: pp)
+        sys.modules["aphrodite.distributed"].parallel_state = ps
+        try:
+            assert D.reference_parallel_sizes() == (2, 1)
+            m2 = cls(config=hf, cache_config=cache, quant_config=GPTQConfig(4, 128, False))
+            assert isinstance(m2, MI355XLlamaForCausalLM)
+            assert (D.get_tensor_model_parallel_world_size(), D.get_tensor_model_parallel_rank()) == (2, 1)
+            assert m2.inner.layers[0].qkv_proj.qweight.shape == (512 // 8, (4 + 2 * 2) * 128 // 2)      # this rank's heads
+            assert m2.inner.layers[0].num_kv_heads == 1
+            pp.world_size = 2
+            assert isinstance(cls(config=hf, cache_config=cache, quant_config=GPTQConfig(4, 128, False)), RefLlama)
+            # a TP state of this package that is something ELSE is never overwritten: fall back instead
+            pp.world_size, grp.world_size = 1, 4
+            assert isinstance(cls(config=hf, cache_config=cache, quant_config=GPTQConfig(4, 128, False)), RefLlama)
+            assert D.get_tensor_model_parallel_world_size() == 2
+        finally:
+            D.destroy_tensor_parallel()
     finally:
+        torch.set_default_dtype(torch.float32)
         for k in [k for k in sys.modules if k == "aphrodite" or k.startswith("aphrodite.") or k == "loguru"]:
             del sys.modules[k]
         sys.modules.update(saved)
