@@ -51,6 +51,10 @@ struct PAParams {
   // static_scaled_fp8_quant (fp8/common.cu:187-199) produces from `out`
   uint8_t* out_q8;
   const float* out_q8_scale;
+  // optional, DYNAMIC per-token scheme: absmax over this workgroup's slice of `out` ((sequence, kv-head): gqa x hd values)
+  // -> out_absmax[seq][kv_head].  The row's absmax is the max over its num_kv_heads partials (max is order-free), so the
+  // o_proj GEMM that reads `out` works out dynamic_per_token_scaled_fp8_quant's scale itself (fp8_gemm_resident.hip, AQ).
+  float* out_absmax;
   float scale;         // softmax scale * k_scale
   float v_scale;
   int64_t q_stride, kv_block_stride, kv_head_stride;
@@ -681,6 +685,7 @@ __global__ __launch_bounds__(NW * 64) void paged_attention_kernel(const int32_t*
       if (threadIdx.x == 0)   // everybody has arrived: ready for the next launch
         __hip_atomic_store(p.split_counter + (size_t)seq * p.num_kv_heads + kvh, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    float out_amax = 0.f;
     for (int idx = threadIdx.x; idx < nh * HD; idx += NW * 64) {
       const int h = idx / HD, d = idx - h * HD;
       float M = -1e30f, L = 0.f, acc = 0.f;
@@ -744,6 +749,7 @@ __global__ __launch_bounds__(NW * 64) void paged_attention_kernel(const int32_t*
           ((uint16_t*)p.out_packed)[chunk + (k & 7)] = h16;
         }
         if constexpr (ROPE == 2) {
+          out_amax = __builtin_fmaxf(out_amax, __builtin_fabsf(T::to_f32(r16)));
           if (p.out_q8) {
             const float qv = __builtin_fmaxf(-448.f, __builtin_fminf(T::to_f32(r16) * q8_inv, 448.f));
             p.out_q8[((size_t)seq * p.num_heads + qh) * HD + d] = (uint8_t)(__builtin_amdgcn_cvt_pk_fp8_f32(qv, qv, 0, false) & 0xff);
@@ -755,6 +761,20 @@ __global__ __launch_bounds__(NW * 64) void paged_attention_kernel(const int32_t*
         if (d == 0) {
           p.exp_sums[pi] = L;
           p.max_logits[pi] = M;
+        }
+      }
+    }
+    if constexpr (ROPE == 2) {
+      if (p.out_absmax) {                      // (uniform) one partial per (sequence, kv-head)
+        __shared__ float amax_red[NW];
+        out_amax = wave_max(out_amax);
+        if (lane == 0) amax_red[wave] = out_amax;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+          float m = amax_red[0];
+#pragma unroll
+          for (int w = 1; w < NW; ++w) m = __builtin_fmaxf(m, amax_red[w]);
+          p.out_absmax[(size_t)seq * p.num_kv_heads + kvh] = m;
         }
       }
     }
@@ -966,7 +986,7 @@ static int paged_attention_impl(void* out, void* out_packed, float* exp_sums, fl
                                      const int64_t* positions = nullptr, const void* cos_sin = nullptr,
                                      const int64_t* slot_mapping = nullptr, const float* slab_row_scale = nullptr,
                                      const float* slab_col_scale = nullptr, void* out_q8 = nullptr,
-                                     const float* out_q8_scale = nullptr) {
+                                     const float* out_q8_scale = nullptr, float* out_absmax = nullptr) {
   hipStream_t st = (hipStream_t)stream;
   APHRO_CHECK(dtype == APHRO_F16 || dtype == APHRO_BF16, "paged_attention: query dtype must be f16 or bf16");
   APHRO_CHECK(kv_dtype >= APHRO_KV_AUTO && kv_dtype <= APHRO_KV_FP8_E5M2, "Unsupported data type of kv cache: %d", kv_dtype);
@@ -991,6 +1011,10 @@ static int paged_attention_impl(void* out, void* out_packed, float* exp_sums, fl
   APHRO_CHECK(out_packed == nullptr || (partition_size == 0 && ((int64_t)num_heads * head_size) % 128 == 0),
               "paged_attention: packed output needs the single-kernel (v1) form and Hq*hd %% 128 == 0");
   p.out_q8 = (uint8_t*)out_q8; p.out_q8_scale = out_q8_scale;
+  p.out_absmax = out_absmax;
+  APHRO_CHECK(out_absmax == nullptr || (partition_size == 0 && qkv_slabs != nullptr && slab_col_scale != nullptr && out != nullptr &&
+                                        num_heads / num_kv_heads <= 16),
+              "paged_attention: the absmax partials need the fused scaled-slab form, its 16-bit output and GQA <= 16");
   APHRO_CHECK(out_q8 == nullptr || (partition_size == 0 && out_q8_scale != nullptr && qkv_slabs != nullptr && slab_col_scale != nullptr),
               "paged_attention: the fp8 output needs the fused scaled-slab form and its scale");
   p.out = out; p.exp_sums = exp_sums; p.max_logits = max_logits; p.tmp_out = tmp_out;
@@ -1164,6 +1188,28 @@ extern "C" int aphro_paged_attention_rope_scaled_q8(void* out, void* out_q8, con
                               max_num_blocks_per_seq, block_size, max_seq_len, alibi_slopes, 0, kv_block_stride,
                               kv_head_stride, dtype, kv_dtype, k_scale, v_scale, 0, stream, qkv_slabs, nslab, positions,
                               cos_sin_cache, slot_mapping, slab_row_scale, slab_col_scale, out_q8, out_q8_scale);
+}
+
+// ... and, for an FP8 o_proj with DYNAMIC per-token activation scales, the absmax of every (sequence, kv-head) slice of `out`
+// (out_absmax [num_seqs][num_kv_heads]): the GEMM that reads `out` reduces the partials to the row scale and quantises on load
+// (aphro_fp8_gemm_resident_aq) -- dynamic_per_token_scaled_fp8_quant (fp8/common.cu:201-256) without its launch.
+extern "C" int aphro_paged_attention_rope_scaled_absmax(void* out, float* out_absmax, const float* qkv_slabs, int nslab,
+                                                        const float* slab_row_scale, const float* slab_col_scale,
+                                                        const int64_t* positions, const void* cos_sin_cache,
+                                                        const int64_t* slot_mapping, void* key_cache, void* value_cache,
+                                                        int num_seqs, int num_heads, int num_kv_heads, int head_size,
+                                                        float scale, const int32_t* block_tables, const int32_t* seq_lens,
+                                                        int max_num_blocks_per_seq, int block_size, int max_seq_len,
+                                                        const float* alibi_slopes, int64_t kv_block_stride,
+                                                        int64_t kv_head_stride, int dtype, int kv_dtype, float k_scale,
+                                                        float v_scale, void* stream) {
+  APHRO_CHECK(qkv_slabs != nullptr && slab_col_scale != nullptr && out != nullptr && out_absmax != nullptr,
+              "paged_attention_rope_scaled_absmax: NULL slabs / scales / outputs");
+  return paged_attention_impl(out, nullptr, nullptr, nullptr, nullptr, nullptr, key_cache, value_cache, num_seqs,
+                              num_heads, num_kv_heads, head_size, scale, block_tables, seq_lens,
+                              max_num_blocks_per_seq, block_size, max_seq_len, alibi_slopes, 0, kv_block_stride,
+                              kv_head_stride, dtype, kv_dtype, k_scale, v_scale, 0, stream, qkv_slabs, nslab, positions,
+                              cos_sin_cache, slot_mapping, slab_row_scale, slab_col_scale, nullptr, nullptr, out_absmax);
 }
 
 extern "C" int aphro_reshape_and_cache(const void* key, const void* value, void* key_cache,
