@@ -1275,6 +1275,134 @@ def fp8_gemm_resident(a: torch.Tensor, w_strip: torch.Tensor, scale_a: Optional[
     return out
 
 
+def fp8_strip_relayout_interleaved(weight: torch.Tensor, m: int = 32) -> torch.Tensor:
+    """fp8_strip_relayout for a [gate; up] matrix whose SiluAndMul runs in the GEMM epilogue (ops.fp8_gemm_resident_silu):
+    strip column 2 j = gate row j, 2 j + 1 = up row N / 2 + j."""
+    check_fp8_buffer(weight, "fp8_strip_relayout_interleaved")
+    if weight.dim() != 2 or not weight.is_contiguous():
+        raise RuntimeError("fp8_strip_relayout_interleaved: weight must be a contiguous [N, K] tensor")
+    n, k = weight.shape
+    out = torch.empty_like(weight)
+    check(_lib.lib().aphro_fp8_strip_relayout_interleaved(weight.data_ptr(), out.data_ptr(), m, n, k, _stream()),
+          "fp8_strip_relayout_interleaved")
+    return out
+
+
+def fp8_gemm_resident_strips(m: int, n: int, k: int) -> int:
+    """Column strips of the resident plan for (M, N, K) = absmax partials per row of ops.fp8_gemm_resident_silu; 0: not served."""
+    return int(_lib.lib().aphro_fp8_gemm_resident_strips(m, n, k))
+
+
+def fp8_gemm_resident_silu_supported(m: int, n: int, k: int) -> bool:
+    return n % 2 == 0 and _lib.lib().aphro_fp8_gemm_resident_ksplit(m, n, k) == 1
+
+
+def aq_pairs_numel(m: int, k: int) -> int:
+    """16-bit elements of the pair-major activation buffer for [m, k] (k % 64 == 0): [k / 64][ceil(m / 16)][2][64 lanes][8]."""
+    return (k // 64) * ((m + 15) // 16) * 1024
+
+
+def aq_pairs_index(m: int, k: int, device) -> torch.Tensor:
+    """int64 [m, k]: the offset of element (row, column) in the pair-major buffer (csrc/common.h aq_pair_offset) -- the layout
+    the fused producers write for ops.fp8_gemm_resident_aq (every 16-byte load of the GEMM lane-linear).  Tests / debugging."""
+    row = torch.arange(m, device=device).view(-1, 1)
+    col = torch.arange(k, device=device).view(1, -1)
+    mtiles = (m + 15) // 16
+    return ((((col >> 6) * mtiles + (row >> 4)) * 2 + ((col & 15) >> 3)) * 64 + ((col & 63) >> 4) * 16 + (row & 15)) * 8 + (col & 7)
+
+
+def fp8_gemm_resident_silu(a: torch.Tensor, w_strip_il: torch.Tensor, scale_a: torch.Tensor, scale_b: torch.Tensor,
+                           out_dtype: torch.dtype, static_out_scale: Optional[torch.Tensor] = None, act_pairs: bool = False):
+    """gate_up W8A8 GEMM + SiluAndMul in one launch on the interleaved strip-major copy (<= 32 rows).  Dynamic scheme:
+    returns (act [M, N / 2] in ``out_dtype``, absmax partials fp32 [M, strips]) -- the consumer
+    (ops.fp8_gemm_resident_aq) turns the partials into dynamic_per_token_scaled_fp8_quant's scale and quantises on load.
+    ``static_out_scale`` (fp32 [1], the down projection's input_scale): returns the e4m3 [M, N / 2]
+    static_scaled_fp8_quant would produce from act.  Bits of cutlass_scaled_mm -> silu_and_mul [-> the quantiser]."""
+    m, k = a.shape
+    n = w_strip_il.shape[0]
+    if w_strip_il.shape[1] != k or not a.is_contiguous() or not w_strip_il.is_contiguous():
+        raise RuntimeError("fp8_gemm_resident_silu: a [M, K] and the interleaved strip-major copy of a [N, K] weight expected")
+    check_fp8_buffer(a, "fp8_gemm_resident_silu")
+    check_fp8_buffer(w_strip_il, "fp8_gemm_resident_silu")
+    lib = _lib.lib()
+    strips = lib.aphro_fp8_gemm_resident_strips(m, n, k)
+    if strips <= 0 or lib.aphro_fp8_gemm_resident_ksplit(m, n, k) != 1:
+        raise RuntimeError(f"fp8_gemm_resident_silu: shape M={m} N={n} K={k} not served with one K slice")
+    sa = scale_a.to(torch.float32).contiguous()
+    sb = scale_b.to(torch.float32).contiguous()
+    if static_out_scale is not None:
+        _check_static_scale(static_out_scale, a.device)
+        q8 = torch.empty((m, n // 2), dtype=FP8_DTYPE, device=a.device)
+        check(lib.aphro_fp8_gemm_resident_silu(a.data_ptr(), k, w_strip_il.data_ptr(), sa.data_ptr(), sb.data_ptr(), None, 0, None,
+                                               q8.data_ptr(), static_out_scale.data_ptr(), m, n, k, 1 if sa.numel() > 1 else 0,
+                                               1 if sb.numel() > 1 else 0, _dt_of(out_dtype), _stream()), "fp8_gemm_resident_silu")
+        return q8
+    # act_pairs: the activation in the pair-major layout (a flat buffer, aq_pairs_index) for ops.fp8_gemm_resident_aq(a_pairs=...)
+    if act_pairs and (n // 2) % 64 != 0:
+        raise RuntimeError("fp8_gemm_resident_silu: the pair-major activation needs N / 2 % 64 == 0")
+    act = torch.empty((aq_pairs_numel(m, n // 2), ) if act_pairs else (m, n // 2), dtype=out_dtype, device=a.device)
+    absmax = torch.empty((m, strips), dtype=torch.float32, device=a.device)
+    check(lib.aphro_fp8_gemm_resident_silu(a.data_ptr(), k, w_strip_il.data_ptr(), sa.data_ptr(), sb.data_ptr(), act.data_ptr(),
+                                           1 if act_pairs else 0, absmax.data_ptr(), None, None, m, n, k, 1 if sa.numel() > 1 else 0,
+                                           1 if sb.numel() > 1 else 0, _dt_of(out_dtype), _stream()), "fp8_gemm_resident_silu")
+    return act, absmax
+
+
+def fp8_gemm_resident_aq_supported(m: int, n: int, k: int, np_: int) -> bool:
+    return 4 <= np_ <= 256 and np_ % 4 == 0 and _lib.lib().aphro_fp8_gemm_resident_ksplit(m, n, k) > 0
+
+
+def fp8_gemm_resident_aq(a16: torch.Tensor, absmax: torch.Tensor, w_strip: torch.Tensor, slabs: bool = True,
+                         scale_b: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None,
+                         a_pairs: bool = False):
+    """The resident W8A8 GEMM fed with the PRODUCER's 16-bit activations ``a16`` [M, K] and its absmax partials
+    ``absmax`` fp32 [M, np]: per-token scales and e4m3 operands are made inside the launch -- the bits of
+    ops.scaled_fp8_quant(a16, None, use_per_token_if_dynamic=True) -> ops.fp8_gemm_resident.  ``a_pairs``: a16 is the flat
+    pair-major buffer a fused producer wrote (aq_pairs_index).  Returns (slabs fp32 [ksplit, M, N] or out [M, N] in a16's
+    dtype, scales fp32 [M, 1])."""
+    n, k = w_strip.shape
+    if absmax.dtype != torch.float32 or absmax.dim() != 2 or not absmax.is_contiguous():
+        raise RuntimeError("fp8_gemm_resident_aq: absmax partials must be a contiguous fp32 [M, np] tensor")
+    m = absmax.shape[0]
+    if a16.dtype not in (torch.float16, torch.bfloat16) or not a16.is_contiguous() or not w_strip.is_contiguous() or \
+            (a16.numel() != aq_pairs_numel(m, k) if a_pairs else tuple(a16.shape) != (m, k)):
+        raise RuntimeError("fp8_gemm_resident_aq: a16 [M, K] f16 / bf16 (or its pair-major buffer) and the strip-major copy of a [N, K] weight expected")
+    check_fp8_buffer(w_strip, "fp8_gemm_resident_aq")
+    lib = _lib.lib()
+    ks = lib.aphro_fp8_gemm_resident_ksplit(m, n, k)
+    if ks <= 0:
+        raise RuntimeError(f"fp8_gemm_resident_aq: shape M={m} N={n} K={k} not served")
+    sc = torch.empty((m, 1), dtype=torch.float32, device=a16.device)
+    ap = 1 if a_pairs else 0
+    if slabs:
+        out = torch.empty((ks, m, n), dtype=torch.float32, device=a16.device)
+        check(lib.aphro_fp8_gemm_resident_aq(a16.data_ptr(), k, ap, absmax.data_ptr(), absmax.shape[1], w_strip.data_ptr(),
+                                             sc.data_ptr(), None, None, None, out.data_ptr(), out.numel() * 4, m, n, k, 0,
+                                             _dt(a16), _stream()), "fp8_gemm_resident_aq")
+        return out, sc
+    if ks != 1:
+        raise RuntimeError(f"fp8_gemm_resident_aq: M={m} N={n} K={k} is K-sliced ({ks}): slabs only")
+    sb = scale_b.to(torch.float32).contiguous()
+    out = torch.empty((m, n), dtype=a16.dtype, device=a16.device)
+    check(lib.aphro_fp8_gemm_resident_aq(a16.data_ptr(), k, ap, absmax.data_ptr(), absmax.shape[1], w_strip.data_ptr(),
+                                         sc.data_ptr(), sb.data_ptr(), _ptr(bias), out.data_ptr(), None, 0, m, n, k,
+                                         1 if sb.numel() > 1 else 0, _dt(a16), _stream()), "fp8_gemm_resident_aq")
+    return out, sc
+
+
+def fp8_quant_rows_aq(x: torch.Tensor, absmax: torch.Tensor):
+    """The quantiser of ops.fp8_gemm_resident_aq on its own (same device code): (q e4m3 [M, K], scales fp32 [M, 1]) from the
+    16-bit rows x [M, K] and absmax partials fp32 [M, np] -- for the parity tests against x / scale."""
+    m, k = x.shape
+    if not x.is_contiguous() or absmax.dtype != torch.float32 or not absmax.is_contiguous() or absmax.shape[0] != m:
+        raise RuntimeError("fp8_quant_rows_aq: contiguous x [M, K] and fp32 absmax [M, np] expected")
+    q = torch.empty((m, k), dtype=FP8_DTYPE, device=x.device)
+    sc = torch.empty((m, 1), dtype=torch.float32, device=x.device)
+    check(_lib.lib().aphro_fp8_quant_rows_aq(x.data_ptr(), absmax.data_ptr(), absmax.shape[1], q.data_ptr(), sc.data_ptr(), m, k,
+                                             _dt(x), _stream()), "fp8_quant_rows_aq")
+    return q, sc
+
+
 def fp8_gemm_silu_quant_supported(m: int, n: int, k: int) -> bool:
     return bool(_lib.lib().aphro_fp8_gemm_stream_silu_supported(m, n, k))
 
@@ -1360,7 +1488,8 @@ def paged_attention_rope_scaled(qkv_slabs: torch.Tensor, slab_row_scale: Optiona
                                 block_tables: torch.Tensor, seq_lens: torch.Tensor, block_size: int,
                                 max_seq_len: int, alibi_slopes: Optional[torch.Tensor], kv_cache_dtype: str,
                                 k_scale: float, v_scale: float,
-                                out_q8_scale: Optional[torch.Tensor] = None, want_out: bool = True):
+                                out_q8_scale: Optional[torch.Tensor] = None, want_out: bool = True,
+                                want_absmax: bool = False, out_pairs: bool = False):
     """paged_attention_rope_packed over the raw slabs of an FP8 qkv projection (dequantised on the
     fly); returns the attention output [S, Hq, hd] row-major in the activation dtype.
     ``out_q8_scale`` (fp32 [1]: the static input_scale of an FP8 o_proj): returns (out or None, out_q8) with out_q8 the
@@ -1383,6 +1512,24 @@ def paged_attention_rope_scaled(qkv_slabs: torch.Tensor, slab_row_scale: Optiona
             _ptr(alibi_slopes), key_cache.stride(0), key_cache.stride(1), _dt(cos_sin_cache), _kv(kv_cache_dtype),
             float(k_scale), float(v_scale), _stream()), "paged_attention_rope_scaled_q8")
         return out, out_q8
+    if want_absmax:
+        # dynamic per-token scheme: (out, absmax partials [S, Hkv]) -- the o_proj GEMM (ops.fp8_gemm_resident_aq) makes the
+        # per-token scale from the partials and quantises `out` on load; out_pairs: `out` is the flat pair-major buffer of
+        # [S, Hq * hd] that GEMM reads lane-linearly (aq_pairs_index) instead of the row-major [S, Hq, hd]
+        if out_pairs:
+            out = torch.empty((aq_pairs_numel(num_seqs, num_heads * head_size), ), dtype=cos_sin_cache.dtype, device=qkv_slabs.device)
+        else:
+            out = torch.empty((num_seqs, num_heads, head_size), dtype=cos_sin_cache.dtype, device=qkv_slabs.device)
+        absmax = torch.empty((num_seqs, num_kv_heads), dtype=torch.float32, device=qkv_slabs.device)
+        check(lib.aphro_paged_attention_rope_scaled_absmax(
+            None if out_pairs else out.data_ptr(), out.data_ptr() if out_pairs else None, absmax.data_ptr(), qkv_slabs.data_ptr(),
+            nslab, _ptr(slab_row_scale),
+            slab_col_scale.data_ptr(), _ptr(positions), cos_sin_cache.data_ptr(), slot_mapping.data_ptr(),
+            key_cache.data_ptr(), value_cache.data_ptr(), num_seqs, num_heads, num_kv_heads, head_size, float(scale),
+            block_tables.data_ptr(), seq_lens.data_ptr(), block_tables.stride(0), block_size, int(max_seq_len),
+            _ptr(alibi_slopes), key_cache.stride(0), key_cache.stride(1), _dt(cos_sin_cache), _kv(kv_cache_dtype),
+            float(k_scale), float(v_scale), _stream()), "paged_attention_rope_scaled_absmax")
+        return out, absmax
     out = torch.empty((num_seqs, num_heads, head_size), dtype=cos_sin_cache.dtype, device=qkv_slabs.device)
     check(lib.aphro_paged_attention_rope_packed_scaled(
         out.data_ptr(), None, qkv_slabs.data_ptr(), nslab, _ptr(slab_row_scale), slab_col_scale.data_ptr(),

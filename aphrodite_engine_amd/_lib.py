@@ -42,6 +42,8 @@ SIGNATURES = {
                                                      I, I, I, P, L, L, I, I, F, F, P]),
     "aphro_paged_attention_rope_scaled_q8": (I, [P, P, P, P, I, P, P, P, P, P, P, P, I, I, I, I, F, P, P,
                                                  I, I, I, P, L, L, I, I, F, F, P]),
+    "aphro_paged_attention_rope_scaled_absmax": (I, [P, P, P, P, I, P, P, P, P, P, P, P, I, I, I, I, F, P, P,
+                                                     I, I, I, P, L, L, I, I, F, F, P]),
     "aphro_sample_top_k_top_p": (I, [P, P, L, P, P, P, P, P, L, P, P, L, L, I, P]),
     "aphro_custom_ar_meta_size": (L, []),
     "aphro_ipc_handle_bytes": (I, []),
@@ -107,6 +109,11 @@ SIGNATURES = {
     "aphro_fp8_gemm_resident_ksplit": (I, [L, L, L]),
     "aphro_fp8_strip_relayout": (I, [P, P, L, L, L, P]),
     "aphro_fp8_gemm_resident": (I, [P, L, P, P, P, P, P, P, Z, L, L, L, I, I, I, P]),
+    "aphro_fp8_gemm_resident_strips": (I, [L, L, L]),
+    "aphro_fp8_strip_relayout_interleaved": (I, [P, P, L, L, L, P]),
+    "aphro_fp8_gemm_resident_aq": (I, [P, L, I, P, I, P, P, P, P, P, P, Z, L, L, L, I, I, P]),
+    "aphro_fp8_gemm_resident_silu": (I, [P, L, P, P, P, P, I, P, P, P, L, L, L, I, I, I, P]),
+    "aphro_fp8_quant_rows_aq": (I, [P, P, I, P, P, L, L, I, P]),
     "aphro_fp8_gemm_stream_silu_quant": (I, [P, L, P, P, P, P, P, P, L, L, L, I, I, I, P]),
     "aphro_gptq_dequant_bits": (I, [P, P, P, P, P, L, L, L, I, I, P]),
     "aphro_gptq_gemm_bits_supported": (I, [L, L, L, L, I]),

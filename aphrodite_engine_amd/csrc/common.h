@@ -69,6 +69,15 @@ inline int device_coresident_cu_count() {
   return masked ? 0 : device_cu_count();
 }
 
+// Pair-major 16-bit activations between a fused producer and the AQ GEMM: element (row m, column k) of [M, K] sits at
+//   ((((k / 64) * mtiles + m / 16) * 2 + (k % 16) / 8) * 64 + ((k % 64) / 16) * 16 + m % 16) * 8 + k % 8      (16-bit elements)
+// i.e. for every (k-pair, 16-row tile, half) the 64 lanes' 16-byte pieces are one contiguous KiB in lane order: the consumer's
+// A loads are lane-linear like its weight loads (a row-major gather touches 16 cache lines per instruction, twice per
+// fragment for 16-bit data).  mtiles = ceil(M / 16); rows >= M of the last tile are never written and never read back.
+__host__ __device__ __forceinline__ size_t aq_pair_offset(int m, int k, int mtiles) {
+  return ((((size_t)(k >> 6) * mtiles + (m >> 4)) * 2 + ((k & 15) >> 3)) * 64 + ((k & 63) >> 4) * 16 + (m & 15)) * 8 + (k & 7);
+}
+
 // ---- scalar conversions -----------------------------------------------------
 __device__ __forceinline__ float bf16_bits_to_f32(uint16_t b) {
   return __builtin_bit_cast(float, (uint32_t)b << 16);

@@ -28,8 +28,9 @@
 //     [M][np] (one per producing workgroup: max is order-free, so max over partials == the row's absmax, bit for bit).  The
 //     prologue reduces them to the row scale max(absmax / 448, 1 / (448 * 512)) (common.cu:205,233-240) and every k-pair's
 //     A fragment is quantised in registers in front of its MFMAs: fp8(x / scale) with the IEEE quotient.  The quotient is
-//     hipcc's own fp32 division sequence (v_rcp, one Newton step on the reciprocal, q = n r, two residual corrections) with
-//     the per-ROW part -- reciprocal + its refinement -- hoisted: 5 VALU per element, packed two at a time (v_pk_mul_f32 /
+//     hipcc's own fp32 division sequence (v_rcp, one Newton step on the reciprocal, q = n r, residual corrections) with
+//     the per-ROW part -- reciprocal + its refinement -- hoisted and ONE residual correction (proven sufficient for every
+//     (input, scale) pair that can occur, see F8R_DIV_STEPS): 3 VALU per element, packed two at a time (v_pk_mul_f32 /
 //     v_pk_fma_f32), on |x| with the sign put back on the packed bytes (-0 stays -0 as v_div_fixup_f32 would leave it).
 //     v_div_scale_f32 is the identity for every finite 16-bit x and scale in [1 / (448 * 512), 65504 / 448]; the clamp to
 //     +-448 is a no-op when |x| <= absmax.  tests: aphro_fp8_quant_rows_aq runs the same device function over all 65 536
@@ -62,8 +63,11 @@ struct Fp8ResParams {
   const float* absmax_in;
   int np;
   float* scale_out;
+  // AQ: A in the PAIR-MAJOR layout the fused producers write (a_pairs), see aq_pair_offset; else row-major [M, lda]
+  int a_pairs;
   // SILU epilogue (ksplit == 1): act T [M, N / 2] + absmax partials [M][strips], or e4m3 [M, N / 2] with *static_out_scale
   int silu;
+  int act_pairs;          // act_out in the pair-major layout (for an AQ consumer) instead of row-major [M, N / 2]
   void* act_out;
   float* absmax_out;
   uint8_t* q8_out;
@@ -71,6 +75,16 @@ struct Fp8ResParams {
 };
 
 // ---- fp8(x / scale) with the IEEE fp32 quotient, per-row part hoisted -------------------------------------------------------
+// Residual corrections after q0 = n r.  hipcc's own fp32 division is r = refine(rcp(s)); q0 = n r; q1 = q0 + r (n - s q0);
+// q = q1 + r (n - s q1) (+ v_div_scale / v_div_fixup for exponent extremes and specials).  ONE correction already lands
+// on the same fp8 byte for EVERY input this kernel can meet: the scale of a row is fl(a / 448) (floored at 1 / (448 * 512))
+// for a 16-bit magnitude a that occurs in the row, and the row holds 16-bit values |x| <= a -- a finite domain of
+// 32 768 x 65 536 pairs per dtype, all of which tests/test_fp8_diet_gpu.py::test_quantise_on_load_every_input_absmax_pair
+// runs against fp8(x / scale) (itself pinned to the CPU oracle).  -DF8R_DIV_STEPS=2 builds the full sequence (the same test
+// passes with it; it costs 1 more VALU per element: o_proj 6.6 -> 6.9 us, down 14.7 -> 15.4, tools/fp8_aq_lab.py).
+#ifndef F8R_DIV_STEPS
+#define F8R_DIV_STEPS 1
+#endif
 struct F8Rcp { float s, r; };
 __device__ __forceinline__ F8Rcp f8r_make_rcp(float s) {
   const float r0 = __builtin_amdgcn_rcpf(s);
@@ -96,8 +110,12 @@ __device__ __forceinline__ void f8r_quant8(const u32x4 h, const F8Rcp rc, uint32
     const f32x2 q0 = n * rr;
     const f32x2 e1 = __builtin_elementwise_fma(nd, q0, n);
     const f32x2 q1 = __builtin_elementwise_fma(e1, rr, q0);
+#if F8R_DIV_STEPS >= 2
     const f32x2 e2 = __builtin_elementwise_fma(nd, q1, n);
     q[j] = __builtin_elementwise_fma(e2, rr, q1);
+#else
+    q[j] = q1;
+#endif
   }
   int w0 = __builtin_amdgcn_cvt_pk_fp8_f32(q[0][0], q[0][1], 0, false);
   w0 = __builtin_amdgcn_cvt_pk_fp8_f32(q[1][0], q[1][1], w0, true);
@@ -193,76 +211,140 @@ __global__ __launch_bounds__(256, 1) void fp8_gemm_resident_kernel(const uint8_t
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(p.w), 0,
       (uint32_t)((size_t)p.N * p.K), 0x00020000);
   const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(p.a), 0,
-      (uint32_t)(((size_t)(p.M - 1) * p.lda + p.K) * AB), 0x00020000);
+      (AQ && p.a_pairs) ? (uint32_t)((size_t)(p.K >> 6) * ((p.M + 15) >> 4) * 2048)
+                        : (uint32_t)(((size_t)(p.M - 1) * p.lda + p.K) * AB), 0x00020000);
   constexpr int WAVE_BYTES = NKP * NT * 1024;
   const int sbase = ((ky * S + strip) * NWV + wave) * WAVE_BYTES;
   const int voff_w = lane * 16;
 
   // AQ: the absmax partials are the first bytes asked for (they gate the first MFMA, the rings do not wait for them)
   F8AbsmaxLoads aml;
-  if constexpr (AQ) aml = f8r_absmax_issue(p.absmax_in, p.M, p.np);
+  f32x4 amd[MT][4];         // np <= 16: the partials of this lane's own rows
+  if constexpr (AQ) {
+    if (p.np <= 16) {
+      const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.absmax_in), 0,
+          (uint32_t)((size_t)p.M * p.np * sizeof(float)), 0x00020000);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int row = min(16 * i + c, p.M - 1);
+          const int off = 4 * j < p.np ? (row * p.np + 4 * j) * 4 : 0x7ffffff0;      // out of range reads as 0
+          amd[i][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, off, 0, 0));
+        }
+    } else {
+      aml = f8r_absmax_issue(p.absmax_in, p.M, p.np);
+    }
+  }
 
   // ---- one stream per wave: the activations of k-pair kp (lane (g, c) = token 16 i + c, elements k + 16 g .. + 16: used ONCE,
   // every k-pair covers all the strip's columns) ride in the same register ring as its weights, DD k-pairs ahead.  (First version:
   // all of A loaded up front -- 32 gathers of 16 x 64 bytes in front of the first weight byte of every wave.)
+  // A addressing: row-major -- lane (g, c) of tile i reads row 16 i + c at element k0 + 16 g (+ 8 for the second half);
+  // pair-major (AQ only) -- the lane's piece of block (k-pair, tile i, half)
+  const bool pairs = AQ && p.a_pairs;
+  const int mtiles_a = (p.M + 15) >> 4;
+  const int kp_stride = pairs ? mtiles_a * 2048 : 64 * AB, h_stride = pairs ? 1024 : 16;
   int voff_a[MT];
 #pragma unroll
-  for (int i = 0; i < MT; ++i) voff_a[i] = (min(16 * i + c, p.M - 1) * p.lda + 16 * g) * AB;
+  for (int i = 0; i < MT; ++i)
+    voff_a[i] = pairs ? min(i, mtiles_a - 1) * 2048 + lane * 16 : (min(16 * i + c, p.M - 1) * p.lda + 16 * g) * AB;
   f32x4 acc[MT][NT];
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  u32x4 wr[RING][NT], ar[RING][MT][AB];
-  auto load_kp = [&](auto KP_) {
+  // AQ: the activations run AHEAD of the weights (DA = DD + 2 k-pairs in flight against DD): loads return in order, so when a
+  // wave waits for the weights of k-pair kp the 16-bit activations of kp + 1 (L2 hits, issued two iterations earlier than
+  // those weights) have long landed -- their quantisation (VALU) is done in the shadow of the wait for W(kp) from HBM instead
+  // of between that wait and the MFMAs (measured, tools/fp8_aq_lab.py: down 15.6 -> see profiles/r6_fp8_diet_lab.txt).
+  constexpr int DA = AQ ? (DD + 2 < NKP ? DD + 2 : NKP) : DD;
+  constexpr int RA = DA + 1;
+  u32x4 wr[RING][NT], ar[RA][MT][AB];
+  auto load_a = [&](auto KP_) {
     constexpr int kp = decltype(KP_)::value;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       const int vo = voff_a[i];
 #pragma unroll
       for (int h = 0; h < AB; ++h)
-        ar[kp % RING][i][h] = __builtin_amdgcn_raw_buffer_load_b128(ra, vo, (kp0 + kp) * 64 * AB + 16 * h, 0);
+        ar[kp % RA][i][h] = __builtin_amdgcn_raw_buffer_load_b128(ra, vo, (kp0 + kp) * kp_stride + h * h_stride, 0);
     }
+  };
+  auto load_w = [&](auto KP_) {
+    constexpr int kp = decltype(KP_)::value;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
       wr[kp % RING][t] = __builtin_amdgcn_raw_buffer_load_b128(rw, voff_w, sbase + (kp * NT + t) * 1024, 2);
   };
-  f8r_static_for<0, DD>([&](auto KP_) { load_kp(KP_); });
+  if constexpr (AQ) {       // every A load of the prologue in front of the first weight load
+    f8r_static_for<0, DA>([&](auto KP_) { load_a(KP_); });
+    f8r_static_for<0, DD>([&](auto KP_) { load_w(KP_); });
+  } else {
+    f8r_static_for<0, DD>([&](auto KP_) { load_a(KP_); load_w(KP_); });
+  }
   __builtin_amdgcn_sched_barrier(0);
 
   F8Rcp rc[MT];
-  if constexpr (AQ) {
-    f8r_absmax_finish(aml, sscale);
-    __syncthreads();
+  u32x4 af[2][MT];          // AQ: the e4m3 fragments of k-pair kp (slot kp & 1), made one iteration ahead
+  auto quant_kp = [&](auto KP_) {
+    constexpr int kp = decltype(KP_)::value;
 #pragma unroll
-    for (int i = 0; i < MT; ++i) rc[i] = f8r_make_rcp(sscale[min(16 * i + c, p.M - 1)]);
-    if (p.scale_out && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < p.M) p.scale_out[threadIdx.x] = sscale[threadIdx.x];
+    for (int i = 0; i < MT; ++i) {
+      uint32_t q0, q1, q2, q3;
+      f8r_quant8<T>(ar[kp % RA][i][0], rc[i], q0, q1);
+      f8r_quant8<T>(ar[kp % RA][i][AB - 1], rc[i], q2, q3);
+      af[kp & 1][i] = u32x4{q0, q1, q2, q3};
+    }
+  };
+  if constexpr (AQ) {
+    if (p.np <= 16) {
+      // few partials per row (attention: one per kv-head): every lane reduces the rows it quantises by itself -- no LDS
+      // round trip, no workgroup barrier in front of the first MFMA
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        float am = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) am = __builtin_fmaxf(am, amd[i][j][e]);
+        const float sc_row = __builtin_fmaxf(am / 448.f, 1.0f / (448.f * 512.f));
+        rc[i] = f8r_make_rcp(sc_row);
+        if (p.scale_out && blockIdx.x == 0 && blockIdx.y == 0 && wave == 0 && g == 0 && 16 * i + c < p.M) p.scale_out[16 * i + c] = sc_row;
+        if (!p.slab && wave == 0 && g == 0) sscale[16 * i + c] = sc_row;       // the scaled epilogue reads the row scales from LDS
+      }
+    } else {
+      f8r_absmax_finish(aml, sscale);
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < MT; ++i) rc[i] = f8r_make_rcp(sscale[min(16 * i + c, p.M - 1)]);
+      if (p.scale_out && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < p.M) p.scale_out[threadIdx.x] = sscale[threadIdx.x];
+    }
+    quant_kp(std::integral_constant<int, 0>{});
     __builtin_amdgcn_sched_barrier(0);
   }
 
   f8r_static_for<0, NKP>([&](auto KP_) {
     constexpr int kp = decltype(KP_)::value;
-    if constexpr (kp + DD < NKP) load_kp(std::integral_constant<int, (kp + DD < NKP ? kp + DD : 0)>{});
+    if constexpr (kp + DA < NKP) load_a(std::integral_constant<int, (kp + DA < NKP ? kp + DA : 0)>{});
+    if constexpr (kp + DD < NKP) load_w(std::integral_constant<int, (kp + DD < NKP ? kp + DD : 0)>{});
     __builtin_amdgcn_sched_barrier(0);
-    u32x4 af[MT];
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      if constexpr (AQ) {
-        uint32_t q0, q1, q2, q3;
-        f8r_quant8<T>(ar[kp % RING][i][0], rc[i], q0, q1);
-        f8r_quant8<T>(ar[kp % RING][i][AB - 1], rc[i], q2, q3);
-        af[i] = u32x4{q0, q1, q2, q3};
-      } else {
-        af[i] = ar[kp % RING][i][0];
+    if constexpr (AQ) {
+      if constexpr (kp + 1 < NKP) {
+        quant_kp(std::integral_constant<int, (kp + 1 < NKP ? kp + 1 : 0)>{});
+        __builtin_amdgcn_sched_barrier(0);         // the quantisation is issued BEFORE the wait for this k-pair's weights
       }
+    } else {
+#pragma unroll
+      for (int i = 0; i < MT; ++i) af[kp & 1][i] = ar[kp % RA][i][0];
     }
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const u32x4 b = wr[kp % RING][t];
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
-        acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(f8r_lo(af[i]), f8r_lo(b), acc[i][t], 0, 0, 0);
-        acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(f8r_hi(af[i]), f8r_hi(b), acc[i][t], 0, 0, 0);
+        acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(f8r_lo(af[kp & 1][i]), f8r_lo(b), acc[i][t], 0, 0, 0);
+        acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(f8r_hi(af[kp & 1][i]), f8r_hi(b), acc[i][t], 0, 0, 0);
       }
     }
   });
@@ -309,7 +391,8 @@ __global__ __launch_bounds__(256, 1) void fp8_gemm_resident_kernel(const uint8_t
           *reinterpret_cast<uint16_t*>(p.q8_out + (size_t)row * I + j0) =
               (uint16_t)(__builtin_amdgcn_cvt_pk_fp8_f32(q0, q1, 0, false) & 0xffff);
         } else {
-          *reinterpret_cast<uint32_t*>((uint16_t*)p.act_out + (size_t)row * I + j0) = (uint32_t)a0 | ((uint32_t)a1 << 16);
+          uint16_t* dst = (uint16_t*)p.act_out + (p.act_pairs ? aq_pair_offset(row, j0, (p.M + 15) >> 4) : (size_t)row * I + j0);
+          *reinterpret_cast<uint32_t*>(dst) = (uint32_t)a0 | ((uint32_t)a1 << 16);
           const float am = __builtin_fmaxf(__builtin_fabsf(T::to_f32(a0)), __builtin_fabsf(T::to_f32(a1)));
           atomicMax(reinterpret_cast<unsigned*>(&sscale[row]), __builtin_bit_cast(unsigned, am));   // magnitudes: uint order
         }
@@ -516,10 +599,11 @@ extern "C" int aphro_fp8_gemm_resident(const void* a, int64_t lda, const void* w
   return f8r_launch(p, cf, 0, dtype, stream);
 }
 
-// The AQ form: a16 = the producer's 16-bit activations [M, lda] (lda in elements), absmax = its partials [M][np]; the row
+// The AQ form: a16 = the producer's 16-bit activations -- row-major [M, lda] (lda in elements) or, a_pairs, the pair-major
+// layout of aq_pair_offset ([K / 64][ceil(M / 16)][2][64 lanes][8]) --, absmax = its partials [M][np]; the row
 // scales max(max_p absmax[m][p] / 448, 1 / (448 * 512)) are worked out in the launch, left in scale_out[M] (for the consumer
 // of the slabs) and the A fragments quantised on load: the bits of dynamic_per_token_scaled_fp8_quant -> the plain kernel.
-extern "C" int aphro_fp8_gemm_resident_aq(const void* a16, int64_t lda, const float* absmax, int np, const void* w_strip,
+extern "C" int aphro_fp8_gemm_resident_aq(const void* a16, int64_t lda, int a_pairs, const float* absmax, int np, const void* w_strip,
                                           float* scale_out, const float* b_scales, const void* bias, void* out, float* slabs,
                                           size_t slabs_bytes, int64_t M, int64_t N, int64_t K, int b_scale_per_channel,
                                           int dtype, void* stream) {
@@ -531,15 +615,16 @@ extern "C" int aphro_fp8_gemm_resident_aq(const void* a16, int64_t lda, const fl
   APHRO_CHECK(slabs == nullptr || slabs_bytes >= (size_t)cf.ksplit * M * N * sizeof(float), "fp8_gemm_resident_aq: slabs too small");
   APHRO_CHECK(absmax != nullptr && np >= 4 && np <= 256 && np % 4 == 0 && ((uintptr_t)absmax % 16) == 0,
               "fp8_gemm_resident_aq: absmax partials [M][np] with np %% 4 == 0, 4 <= np <= 256, 16-byte aligned (np=%d)", np);
-  APHRO_CHECK(((uintptr_t)a16 % 16) == 0 && ((uintptr_t)w_strip % 16) == 0 && lda % 8 == 0 && lda >= K &&
-              (size_t)M * lda * 2 < 0x7fffffffull &&
+  APHRO_CHECK(a_pairs == 0 || K % 64 == 0, "fp8_gemm_resident_aq: the pair-major layout needs K %% 64 == 0");
+  APHRO_CHECK(((uintptr_t)a16 % 16) == 0 && ((uintptr_t)w_strip % 16) == 0 && (a_pairs || (lda % 8 == 0 && lda >= K)) &&
+              (size_t)(M + 15) * (a_pairs ? K : lda) * 2 < 0x7fffffffull &&
               (out == nullptr || ((uintptr_t)out % 8) == 0) && (slabs == nullptr || ((uintptr_t)slabs % 16) == 0),
               "fp8_gemm_resident_aq: alignment (16-byte rows of a, lda %% 8 == 0)");
   Fp8ResParams p = f8r_params();
   p.a = (const uint8_t*)a16; p.w = (const uint8_t*)w_strip; p.b_scales = b_scales; p.bias = bias;
   p.c = out; p.slab = slabs; p.M = (int)M; p.N = (int)N; p.K = (int)K; p.lda = (int)lda;
   p.a_per_token = 1; p.b_per_channel = b_scale_per_channel;
-  p.absmax_in = absmax; p.np = np; p.scale_out = scale_out;
+  p.absmax_in = absmax; p.np = np; p.scale_out = scale_out; p.a_pairs = a_pairs;
   return f8r_launch(p, cf, 1, dtype, stream);
 }
 
@@ -547,7 +632,7 @@ extern "C" int aphro_fp8_gemm_resident_aq(const void* a16, int64_t lda, const fl
 // act_out T [M, N / 2] + absmax_out [M][strips] (strips: aphro_fp8_gemm_resident_strips); static scheme -- q8_out e4m3
 // [M, N / 2] = fp8(act * (1 / *static_out_scale)).  The bits of the plain kernel -> silu_and_mul[_quant_fp8].
 extern "C" int aphro_fp8_gemm_resident_silu(const void* a, int64_t lda, const void* w_strip_il, const float* a_scales,
-                                            const float* b_scales, void* act_out, float* absmax_out, void* q8_out,
+                                            const float* b_scales, void* act_out, int act_pairs, float* absmax_out, void* q8_out,
                                             const float* static_out_scale, int64_t M, int64_t N, int64_t K,
                                             int a_scale_per_token, int b_scale_per_channel, int dtype, void* stream) {
   const Fp8ResConfig cf = f8r_plan(M, N, K);
@@ -563,7 +648,7 @@ extern "C" int aphro_fp8_gemm_resident_silu(const void* a, int64_t lda, const vo
   p.a = (const uint8_t*)a; p.w = (const uint8_t*)w_strip_il; p.a_scales = a_scales; p.b_scales = b_scales;
   p.M = (int)M; p.N = (int)N; p.K = (int)K; p.lda = (int)lda;
   p.a_per_token = a_scale_per_token; p.b_per_channel = b_scale_per_channel;
-  p.silu = 1; p.act_out = act_out; p.absmax_out = absmax_out; p.q8_out = (uint8_t*)q8_out; p.static_out_scale = static_out_scale;
+  p.silu = 1; p.act_out = act_out; p.act_pairs = act_pairs; p.absmax_out = absmax_out; p.q8_out = (uint8_t*)q8_out; p.static_out_scale = static_out_scale;
   return f8r_launch(p, cf, 0, dtype, stream);
 }
 

@@ -55,6 +55,7 @@ struct PAParams {
   // -> out_absmax[seq][kv_head].  The row's absmax is the max over its num_kv_heads partials (max is order-free), so the
   // o_proj GEMM that reads `out` works out dynamic_per_token_scaled_fp8_quant's scale itself (fp8_gemm_resident.hip, AQ).
   float* out_absmax;
+  void* out_pairs;     // ... and `out` in the pair-major layout that GEMM reads lane-linearly (common.h aq_pair_offset; out may be NULL)
   float scale;         // softmax scale * k_scale
   float v_scale;
   int64_t q_stride, kv_block_stride, kv_head_stride;
@@ -750,6 +751,7 @@ __global__ __launch_bounds__(NW * 64) void paged_attention_kernel(const int32_t*
         }
         if constexpr (ROPE == 2) {
           out_amax = __builtin_fmaxf(out_amax, __builtin_fabsf(T::to_f32(r16)));
+          if (p.out_pairs) ((typename T::storage*)p.out_pairs)[aq_pair_offset(seq, qh * HD + d, p.pack_mtiles)] = r16;
           if (p.out_q8) {
             const float qv = __builtin_fmaxf(-448.f, __builtin_fminf(T::to_f32(r16) * q8_inv, 448.f));
             p.out_q8[((size_t)seq * p.num_heads + qh) * HD + d] = (uint8_t)(__builtin_amdgcn_cvt_pk_fp8_f32(qv, qv, 0, false) & 0xff);
@@ -986,7 +988,8 @@ static int paged_attention_impl(void* out, void* out_packed, float* exp_sums, fl
                                      const int64_t* positions = nullptr, const void* cos_sin = nullptr,
                                      const int64_t* slot_mapping = nullptr, const float* slab_row_scale = nullptr,
                                      const float* slab_col_scale = nullptr, void* out_q8 = nullptr,
-                                     const float* out_q8_scale = nullptr, float* out_absmax = nullptr) {
+                                     const float* out_q8_scale = nullptr, float* out_absmax = nullptr,
+                                     void* out_pairs = nullptr) {
   hipStream_t st = (hipStream_t)stream;
   APHRO_CHECK(dtype == APHRO_F16 || dtype == APHRO_BF16, "paged_attention: query dtype must be f16 or bf16");
   APHRO_CHECK(kv_dtype >= APHRO_KV_AUTO && kv_dtype <= APHRO_KV_FP8_E5M2, "Unsupported data type of kv cache: %d", kv_dtype);
@@ -1011,10 +1014,12 @@ static int paged_attention_impl(void* out, void* out_packed, float* exp_sums, fl
   APHRO_CHECK(out_packed == nullptr || (partition_size == 0 && ((int64_t)num_heads * head_size) % 128 == 0),
               "paged_attention: packed output needs the single-kernel (v1) form and Hq*hd %% 128 == 0");
   p.out_q8 = (uint8_t*)out_q8; p.out_q8_scale = out_q8_scale;
-  p.out_absmax = out_absmax;
-  APHRO_CHECK(out_absmax == nullptr || (partition_size == 0 && qkv_slabs != nullptr && slab_col_scale != nullptr && out != nullptr &&
-                                        num_heads / num_kv_heads <= 16),
-              "paged_attention: the absmax partials need the fused scaled-slab form, its 16-bit output and GQA <= 16");
+  p.out_absmax = out_absmax; p.out_pairs = out_pairs;
+  APHRO_CHECK(out_absmax == nullptr || (partition_size == 0 && qkv_slabs != nullptr && slab_col_scale != nullptr &&
+                                        (out != nullptr || out_pairs != nullptr) && num_heads / num_kv_heads <= 16),
+              "paged_attention: the absmax partials need the fused scaled-slab form, a 16-bit output and GQA <= 16");
+  APHRO_CHECK(out_pairs == nullptr || (out_absmax != nullptr && ((int64_t)num_heads * head_size) % 64 == 0),
+              "paged_attention: the pair-major output goes with the absmax partials (Hq * hd %% 64 == 0)");
   APHRO_CHECK(out_q8 == nullptr || (partition_size == 0 && out_q8_scale != nullptr && qkv_slabs != nullptr && slab_col_scale != nullptr),
               "paged_attention: the fp8 output needs the fused scaled-slab form and its scale");
   p.out = out; p.exp_sums = exp_sums; p.max_logits = max_logits; p.tmp_out = tmp_out;
@@ -1191,9 +1196,10 @@ extern "C" int aphro_paged_attention_rope_scaled_q8(void* out, void* out_q8, con
 }
 
 // ... and, for an FP8 o_proj with DYNAMIC per-token activation scales, the absmax of every (sequence, kv-head) slice of `out`
-// (out_absmax [num_seqs][num_kv_heads]): the GEMM that reads `out` reduces the partials to the row scale and quantises on load
+// (out_absmax [num_seqs][num_kv_heads]; `out` row-major and / or out_pairs in the pair-major layout of common.h
+// aq_pair_offset over [num_seqs, Hq * hd]): the GEMM that reads it reduces the partials to the row scale and quantises on load
 // (aphro_fp8_gemm_resident_aq) -- dynamic_per_token_scaled_fp8_quant (fp8/common.cu:201-256) without its launch.
-extern "C" int aphro_paged_attention_rope_scaled_absmax(void* out, float* out_absmax, const float* qkv_slabs, int nslab,
+extern "C" int aphro_paged_attention_rope_scaled_absmax(void* out, void* out_pairs, float* out_absmax, const float* qkv_slabs, int nslab,
                                                         const float* slab_row_scale, const float* slab_col_scale,
                                                         const int64_t* positions, const void* cos_sin_cache,
                                                         const int64_t* slot_mapping, void* key_cache, void* value_cache,
@@ -1203,13 +1209,13 @@ extern "C" int aphro_paged_attention_rope_scaled_absmax(void* out, float* out_ab
                                                         const float* alibi_slopes, int64_t kv_block_stride,
                                                         int64_t kv_head_stride, int dtype, int kv_dtype, float k_scale,
                                                         float v_scale, void* stream) {
-  APHRO_CHECK(qkv_slabs != nullptr && slab_col_scale != nullptr && out != nullptr && out_absmax != nullptr,
+  APHRO_CHECK(qkv_slabs != nullptr && slab_col_scale != nullptr && (out != nullptr || out_pairs != nullptr) && out_absmax != nullptr,
               "paged_attention_rope_scaled_absmax: NULL slabs / scales / outputs");
   return paged_attention_impl(out, nullptr, nullptr, nullptr, nullptr, nullptr, key_cache, value_cache, num_seqs,
                               num_heads, num_kv_heads, head_size, scale, block_tables, seq_lens,
                               max_num_blocks_per_seq, block_size, max_seq_len, alibi_slopes, 0, kv_block_stride,
                               kv_head_stride, dtype, kv_dtype, k_scale, v_scale, 0, stream, qkv_slabs, nslab, positions,
-                              cos_sin_cache, slot_mapping, slab_row_scale, slab_col_scale, nullptr, nullptr, out_absmax);
+                              cos_sin_cache, slot_mapping, slab_row_scale, slab_col_scale, nullptr, nullptr, out_absmax, out_pairs);
 }
 
 extern "C" int aphro_reshape_and_cache(const void* key, const void* value, void* key_cache,

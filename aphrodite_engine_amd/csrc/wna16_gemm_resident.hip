@@ -887,6 +887,8 @@ static ResConfig res_plan32(int64_t M, int64_t N, int64_t K, int64_t gs) {
   // candidates in order of preference per shape class; the first that fits and fills >= 3/4 of the CUs wins
   // ({4, 4, 1, 3}: round 4, the 8192 x 7168 gate_up of a 70B TP-8 shard -- 64 strips of 112 columns x 4 K slices)
   static const int cand[][4] = {{4, 8, 1, 3}, {4, 4, 1, 3}, {4, 7, 1, 0}, {4, 8, 1, 0}, {4, 4, 1, 0}, {4, 2, 1, 0}, {4, 4, 0, 3}};
+  // (round 6: 48-column strips for qkv -- 128 x 2 = 256 workgroups instead of 96 x 2 = 192 -- measured null in the step:
+  // 2.5415 / 2.5557 against 2.5513 / 2.5460 ms, profiles/r6_decode_experiments.txt; the plan stays at 64 columns)
   for (const auto& cd : cand) {
     const int ks = fits(cd[0], cd[1], cd[2], cd[3]);
     if (ks <= 0 || ks > 8) continue;

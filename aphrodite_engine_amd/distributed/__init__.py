@@ -165,6 +165,104 @@ def get_all_reduce_overlap():
     return _OVERLAP
 
 
+def choose_all_reduce_overlap(device, timed_run, margin: float = 0.03) -> dict:
+    """The side-stream overlap (distributed/overlap.py: all-reduce on its own stream + a prefetch of the next projection's
+    weights) is kept ONLY behind a measured win on the group it runs on: ``timed_run()`` -> seconds of a representative
+    decode run under the CURRENT setting is called with the overlap off, then on; the overlap stays enabled iff it is
+    faster by more than ``margin``.  On one GPU it measured 38-61 % slower, so nothing enables it unmeasured.
+    Every rank must take the same decision: the two times are max-reduced over the TP group first.  Returns the record."""
+    rec = {"margin": margin}
+    times = {}
+    for name, on in (("serial", False), ("overlap", True)):
+        enable_all_reduce_overlap(device, enabled=on)
+        try:
+            times[name] = float(timed_run())
+        except Exception as e:      # noqa: BLE001 -- a failed arm loses, it does not take the caller down
+            rec[name + "_error"] = repr(e)[:200]
+            times[name] = float("inf")
+    if _TP_GROUP is not None and dist.is_initialized():
+        t = torch.tensor([times["serial"], times["overlap"]], dtype=torch.float64,
+                         device=device if dist.get_backend(_TP_GROUP) == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=_TP_GROUP)
+        times = {"serial": float(t[0]), "overlap": float(t[1])}
+    keep = times["overlap"] < times["serial"] * (1.0 - margin)
+    enable_all_reduce_overlap(device, enabled=keep)
+    rec.update(serial_s=times["serial"], overlap_s=times["overlap"], enabled=bool(keep))
+    return rec
+
+
+def all_reduce_self_check(device, sizes=(32 * 4096 * 2, 256 * 1024, 1024 * 1024, 4 * 1024 * 1024)) -> dict:
+    """First contact with a real TP group, BEFORE anything is timed or captured: for every message size the decode path can
+    issue, run the peer-access kernel (one- / two-shot as it would choose) on data whose sum is exact in f16 and compare
+    with ``dist.all_reduce`` on the same group; the same for the fused all-reduce + residual add + RMSNorm against the
+    two-op sequence.  A size that does not verify DISABLES the peer-access communicator (every all-reduce then goes to
+    RCCL): the report says "peer path verified" / "fell back to RCCL" per size instead of a hang or a silently wrong sum
+    (the kernels' waits are bounded, custom_all_reduce.hip).  Collective: every rank of the group calls it."""
+    out = {}
+    ca = _CUSTOM_AR
+    if _TP_SIZE == 1 or _TP_GROUP is None:
+        return {"skipped": "no tensor-parallel group"}
+    from .. import _custom_ops as ops
+    ok_all = True
+    for nbytes in sizes:
+        n = nbytes // 2
+        # small integers, different on every rank: the sum over <= 8 ranks is exact in f16 whatever the order
+        base = (torch.arange(n, device=device, dtype=torch.int32) * 7 + _TP_RANK * 13) % 31 - 15
+        x = base.to(torch.float16)
+        want = x.clone()
+        dist.all_reduce(want, group=_TP_GROUP)
+        row = {"rccl": "ok"}
+        if ca is None or getattr(ca, "disabled", True):
+            row["peer"] = "off (" + str(getattr(ca, "disabled_reason", "no communicator")) + ")"
+        elif not ca.should_custom_ar(x):
+            row["peer"] = "not eligible at this size: RCCL serves it"
+        else:
+            try:
+                got = ca.custom_all_reduce(x)
+                torch.cuda.synchronize(device)
+                ca.check()
+                same = got is not None and torch.equal(got, want)
+                algo = "one-shot" if ops.should_one_shot(_TP_SIZE, nbytes) else "two-shot"
+                row["peer"] = f"verified ({algo})" if same else f"MISMATCH ({algo})"
+                ok_all = ok_all and same
+            except Exception as e:      # noqa: BLE001
+                row["peer"] = "error: " + repr(e)[:160]
+                ok_all = False
+        out[str(nbytes)] = row
+    # the fused all-reduce + norm on the decode layer's own [32, 4096] sum
+    if ok_all and ca is not None and not getattr(ca, "disabled", True):
+        try:
+            tokens, hidden = 32, 4096
+            xm = (((torch.arange(tokens * hidden, device=device, dtype=torch.int32) * 5 + _TP_RANK * 11) % 29 - 14)
+                  .to(torch.float16).view(tokens, hidden))
+            res = torch.ones(tokens, hidden, dtype=torch.float16, device=device)
+            w = torch.full((hidden, ), 0.5, dtype=torch.float16, device=device)
+            if ca.fused_norm_eligible(xm):
+                r1, r2 = res.clone(), res.clone()
+                summed = xm.clone()
+                dist.all_reduce(summed, group=_TP_GROUP)
+                _, o_ref = ops.fused_add_rms_norm_pack(summed, None, r1, True, w, 1e-5, pack=False, want_out=True)
+                got = ca.fused_add_rms_norm(xm, r2, True, w, 1e-5, pack=False, want_out=True)
+                torch.cuda.synchronize(device)
+                ca.check()
+                same = got is not None and torch.equal(got[1], o_ref) and torch.equal(r1, r2)
+                out["fused_all_reduce_norm"] = "verified" if same else "MISMATCH"
+                ok_all = ok_all and same
+        except Exception as e:      # noqa: BLE001
+            out["fused_all_reduce_norm"] = "error: " + repr(e)[:160]
+            ok_all = False
+    # one decision for the whole group
+    flag = torch.tensor([1 if ok_all else 0], dtype=torch.int32, device=device if dist.get_backend(_TP_GROUP) == "nccl" else "cpu")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=_TP_GROUP)
+    if int(flag.item()) == 0 and ca is not None and not getattr(ca, "disabled", True):
+        ca.disabled = True
+        ca.disabled_reason = "self-check failed on at least one rank"
+        out["decision"] = "fell back to RCCL for every size"
+    else:
+        out["decision"] = "peer path verified" if (ca is not None and not getattr(ca, "disabled", True)) else "RCCL (no peer-access communicator)"
+    return out
+
+
 @contextlib.contextmanager
 def simulated_tensor_parallel(rank: int, size: int):
     """Pretend to be TP rank ``rank`` of ``size`` with no process group: for building one rank's

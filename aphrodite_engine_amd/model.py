@@ -202,6 +202,7 @@ class LlamaDecoderLayer(nn.Module):
         self.gate_up_strip = None
         self.strip = {}
         self.fp8_strip = {}
+        self.fp8_gate_up_il = None
         self.fuse_rope_attention = True
 
     def enable_fused_silu(self, m: int = 32, keep_original: bool = True) -> bool:
@@ -263,15 +264,23 @@ class LlamaDecoderLayer(nn.Module):
         A second copy of every matrix it serves (7 GB on Llama-3-8B: the [N, K] originals keep serving > 32 rows and
         prefill); APHRO_DECODE_NO_FP8_RESIDENT=1 keeps the round-3 kernels."""
         self.fp8_strip = {}
+        self.fp8_gate_up_il = None      # round 6: the gate_up strip copy with (gate_j, up_j) adjacent -- SiluAndMul in the epilogue
         if os.environ.get("APHRO_DECODE_NO_FP8_RESIDENT") or self.is_moe:
             return
         for name in ("qkv_proj", "o_proj", "gate_up_proj", "down_proj"):
-            w = getattr(getattr(self, name), "weight", None)
+            lin = getattr(self, name)
+            w = getattr(lin, "weight", None)
             if w is None or w.dtype != torch.float8_e4m3fn or w.dim() != 2:
                 continue
             wt = w.t()                                   # the [N, K] checkpoint tensor behind the column-major [K, N] view
             if wt.is_contiguous() and ops.fp8_gemm_resident_ksplit(m, wt.shape[0], wt.shape[1]) > 0:
-                self.fp8_strip[name] = ops.fp8_strip_relayout(wt, m)
+                # (a TP rank under the dynamic scheme keeps the plain copy: its down projection is not on the quantise-on-load form)
+                if name == "gate_up_proj" and getattr(lin, "bias", None) is None and not os.environ.get("APHRO_FP8_NO_LAUNCH_DIET") \
+                        and (self.tp == 1 or getattr(lin, "input_scale", None) is not None) \
+                        and ops.fp8_gemm_resident_silu_supported(m, wt.shape[0], wt.shape[1]):
+                    self.fp8_gate_up_il = ops.fp8_strip_relayout_interleaved(wt, m)     # instead of, not beside, the plain strip copy
+                else:
+                    self.fp8_strip[name] = ops.fp8_strip_relayout(wt, m)
 
     def _fp8_slabs(self, name: str, qx: torch.Tensor) -> torch.Tensor:
         """Raw fp32 split-K slabs of FP8 projection ``name``: the resident kernel on its strip-major copy at <= 32 rows."""
@@ -556,6 +565,13 @@ class LlamaDecoderLayer(nn.Module):
         # static scheme: the attention launch writes the o_proj input as e4m3 itself, and gate_up + SiluAndMul + the
         # down_proj input quantisation are one launch where the streaming kernel tiles the shape (7 launches per layer)
         fuse_static = s_o is not None and not os.environ.get("APHRO_FP8_NO_STATIC_FUSION")
+        # round 6, dynamic per-token scheme at <= 32 rows (TP 1): the attention launch leaves its 16-bit output plus one absmax
+        # partial per (token, kv-head), and the o_proj GEMM makes the per-token scale from the partials and quantises its A
+        # fragments on load (ops.fp8_gemm_resident_aq) -- scaled_fp8_quant's launch is gone, its bits are not
+        o_st = self.fp8_strip.get("o_proj") if m <= 32 else None
+        aq_o = s_o is None and self.tp == 1 and o_st is not None and self.num_heads // self.num_kv_heads <= 16 and self.q_size % 64 == 0 \
+            and ops.fp8_gemm_resident_aq_supported(m, self.o_proj.out_features, self.q_size, self.num_kv_heads) \
+            and not os.environ.get("APHRO_FP8_NO_LAUNCH_DIET")
         attn_res = ops.paged_attention_rope_scaled(
             qkv_slabs, sx, self._channel_scale(self.qkv_proj),
             None if cos_sin_tok is not None else positions,
@@ -563,10 +579,15 @@ class LlamaDecoderLayer(nn.Module):
             key_cache, value_cache, self.num_heads, self.num_kv_heads, self.attn.scale,
             attn_metadata.block_tables, attn_metadata.seq_lens_tensor, value_cache.shape[3],
             attn_metadata.max_decode_seq_len, None, self.attn.kv_cache_dtype, self.k_scale, self.v_scale,
-            out_q8_scale=s_o if fuse_static else None, want_out=False)
+            out_q8_scale=s_o if fuse_static else None, want_out=False, want_absmax=aq_o, out_pairs=aq_o)
+        o_slabs = None
         if fuse_static:
             qa, sa = attn_res[1], s_o
             act_dtype = cos_sin.dtype if cos_sin_tok is None else cos_sin_tok.dtype
+        elif aq_o:
+            attn_out, attn_absmax = attn_res            # (pair-major: every A load of the GEMM is lane-linear)
+            act_dtype = attn_out.dtype
+            o_slabs, sa = ops.fp8_gemm_resident_aq(attn_out, attn_absmax, o_st, a_pairs=True)
         else:
             attn_out = attn_res
             act_dtype = attn_out.dtype
@@ -578,11 +599,26 @@ class LlamaDecoderLayer(nn.Module):
             qh, sh, _ = ops.fused_add_rms_norm_quant_fp8(o, None, None, None, residual, True,
                                                          self.post_attention_layernorm, eps, static_scale=s_gu)
         else:
-            o_slabs = self._fp8_slabs("o_proj", qa)
+            if o_slabs is None:
+                o_slabs = self._fp8_slabs("o_proj", qa)
             qh, sh, _ = ops.fused_add_rms_norm_quant_fp8(None, o_slabs, sa, self.o_proj.weight_scale, residual,
                                                          True, self.post_attention_layernorm, eps, static_scale=s_gu)
-        if fuse_static and ops.fp8_gemm_silu_quant_supported(m, self.gate_up_proj.out_features,
-                                                             self.gate_up_proj.in_features):
+        # gate_up: SiluAndMul in the resident kernel's epilogue on the interleaved strip copy (round 6).  Static scheme: the
+        # epilogue writes the down projection's e4m3 input itself; dynamic scheme: 16-bit activation + one absmax partial per
+        # (token, column strip), and the down GEMM quantises on load like o_proj above -- silu_and_mul_quant's launch is gone
+        gu_il = self.fp8_gate_up_il if m <= 32 else None
+        d_st = self.fp8_strip.get("down_proj") if m <= 32 else None
+        down_slabs = None
+        if gu_il is not None and s_dn is not None and fuse_static:
+            qd = ops.fp8_gemm_resident_silu(qh, gu_il, sh, self.gate_up_proj.weight_scale, act_dtype, static_out_scale=s_dn)
+            sd = s_dn
+        elif gu_il is not None and s_dn is None and self.tp == 1 and d_st is not None and self.down_proj.in_features % 64 == 0 \
+                and ops.fp8_gemm_resident_aq_supported(
+                m, self.down_proj.out_features, self.down_proj.in_features, ops.fp8_gemm_resident_strips(m, gu_il.shape[0], gu_il.shape[1])):
+            act, act_absmax = ops.fp8_gemm_resident_silu(qh, gu_il, sh, self.gate_up_proj.weight_scale, act_dtype, act_pairs=True)
+            down_slabs, sd = ops.fp8_gemm_resident_aq(act, act_absmax, d_st, a_pairs=True)
+        elif fuse_static and ops.fp8_gemm_silu_quant_supported(m, self.gate_up_proj.out_features,
+                                                               self.gate_up_proj.in_features):
             qd = ops.fp8_gemm_silu_quant(qh, self.gate_up_proj.weight, sh, self.gate_up_proj.weight_scale, s_dn, act_dtype)
             sd = s_dn
         else:
@@ -597,7 +633,9 @@ class LlamaDecoderLayer(nn.Module):
             d = ops.cutlass_scaled_mm(qd, self.down_proj.weight, out_dtype=act_dtype, scale_a=sd,
                                       scale_b=self.down_proj.weight_scale)
             return tensor_model_parallel_all_reduce(d), None
-        return None, (self._fp8_slabs("down_proj", qd), sd, self.down_proj.weight_scale)
+        if down_slabs is None:
+            down_slabs = self._fp8_slabs("down_proj", qd)
+        return None, (down_slabs, sd, self.down_proj.weight_scale)
 
     # -- FP8 W8A8 prefill: the activation quantisations ride in the kernels that produce the activations ---------------
     def fused_prefill_fp8_ok(self) -> bool:

@@ -319,17 +319,37 @@ def roofline_section(model, loop, args):
             res8 = bs <= 32 and name in getattr(layers[0], "fp8_strip", {}) and (
                 slab_form or ops.fp8_gemm_resident_ksplit(bs, lin0.out_features, lin0.in_features) == 1)
 
-            def run_lin(name=name, qx=qx, sx=sx, slab_form=slab_form, res8=res8):
+            # round 6 (dynamic scheme, <= 32 rows): gate_up runs SiluAndMul in its epilogue on the interleaved strip copy, and
+            # o / down take the producer's 16-bit activations + absmax partials and quantise on load (the step's forms)
+            l0_ = layers[0]
+            il = getattr(l0_, "fp8_gate_up_il", None) is not None and bs <= 32
+            dyn = getattr(lin0, "input_scale", None) is None
+            np_aq = {"o_proj": l0_.num_kv_heads,
+                     "down_proj": ops.fp8_gemm_resident_strips(bs, l0_.gate_up_proj.out_features, l0_.gate_up_proj.in_features)}.get(name, 0)
+            aq = il and dyn and name in ("o_proj", "down_proj") and res8 and l0_.tp == 1 and \
+                ops.fp8_gemm_resident_aq_supported(bs, lin0.out_features, lin0.in_features, np_aq)
+            absmax = xin.float().abs().view(bs, np_aq, -1).amax(dim=2).contiguous() if aq else None
+            if aq:          # the producers leave the activation pair-major (every A load of the GEMM lane-linear)
+                xp = torch.zeros(ops.aq_pairs_numel(bs, xin.shape[1]), dtype=xin.dtype, device=xin.device)
+                xp[ops.aq_pairs_index(bs, xin.shape[1], xin.device).flatten()] = xin.flatten()
+                xin = xp
+
+            def run_lin(name=name, qx=qx, sx=sx, slab_form=slab_form, res8=res8, il=il, aq=aq, absmax=absmax, xin=xin):
                 for layer in layers:
                     lin = getattr(layer, name)
-                    if slab_form:
+                    if aq:
+                        ops.fp8_gemm_resident_aq(xin, absmax, layer.fp8_strip[name], a_pairs=True)
+                    elif slab_form:
                         layer._fp8_slabs(name, qx)              # the resident kernel on the strip-major copy where the layer has one
+                    elif il:
+                        ops.fp8_gemm_resident_silu(qx, layer.fp8_gate_up_il, sx, lin.weight_scale, model.dtype, act_pairs=dyn)
                     elif res8:
                         ops.fp8_gemm_resident(qx, layer.fp8_strip[name], sx, lin.weight_scale, out_dtype=model.dtype)
                     else:
                         ops.cutlass_scaled_mm(qx, lin.weight, out_dtype=model.dtype, scale_a=sx, scale_b=lin.weight_scale)
-            kname = ("fp8_gemm_resident_kernel (strip-major weights)" if res8 else "fp8_gemm_fast_kernel") + \
-                (" (fp32 slabs)" if slab_form else " (scaled epilogue)")
+            kname = ("fp8_gemm_resident_kernel (strip-major weights)" if (res8 or il) else "fp8_gemm_fast_kernel") + \
+                (" (16-bit A quantised on load, fp32 slabs)" if aq else " (fp32 slabs)" if slab_form
+                 else " (+SiluAndMul epilogue, absmax partials)" if il else " (scaled epilogue)")
         else:
             def run_lin(name=name, xin=xin):
                 for layer in layers:
@@ -789,14 +809,24 @@ def tp_section(args, device, world, rank, one_gpu):
     model, cfg, dtype = build(args, device)
     total = 2 * (args.warmup + args.steps + 8)
     loop = DecodeLoop(model, cfg, dtype, args, device, total)
+    # first contact with the real group: verify the peer-access kernels against RCCL per message size before anything is
+    # captured or timed (a size that does not verify sends every all-reduce to RCCL: a report, not a hang or a wrong sum)
+    try:
+        out["self_check"] = D.all_reduce_self_check(device)
+    except Exception as e:
+        out["self_check"] = {"error": repr(e)[:200]}
     with torch.no_grad():
-        for name, on in (("no_overlap", False), ("overlap", True)):     # (the default arm first: it is the one that counts)
-            D.enable_all_reduce_overlap(device, enabled=on)
-            try:
-                el = timed_decode(loop, args, world, one_gpu, device, ca)
-                out[name] = {"tokens_per_s": args.batch * args.steps / el, "ms_per_step": el / args.steps * 1e3}
-            except Exception as e:
-                out[name] = {"error": repr(e)[:200]}
+        # the side-stream overlap stays on only behind a measured win on THIS group (distributed.choose_all_reduce_overlap):
+        # both arms are timed, the record says which one the step then runs
+        def arm():
+            el = timed_decode(loop, args, world, one_gpu, device, ca)
+            name = "overlap" if D.get_all_reduce_overlap() is not None else "no_overlap"
+            out[name] = {"tokens_per_s": args.batch * args.steps / el, "ms_per_step": el / args.steps * 1e3}
+            return el
+        try:
+            out["overlap_decision"] = D.choose_all_reduce_overlap(device, arm)
+        except Exception as e:
+            out["overlap_decision"] = {"error": repr(e)[:200]}
         D.enable_all_reduce_overlap(device, enabled=False)
         try:
             out["all_reduce_info"] = all_reduce_section(args, model, device, ca)

@@ -501,6 +501,21 @@ int aphro_paged_attention_rope_scaled_q8(void* out, void* out_q8, const float* o
                                          int64_t kv_head_stride, int dtype, int kv_dtype, float k_scale,
                                          float v_scale, void* stream);
 
+/* ... with, for an FP8 o_proj under DYNAMIC per-token activation scales, the absmax of every (sequence, kv-head) slice of
+ * `out` in out_absmax [num_seqs][num_kv_heads] (`out` row-major [S, Hq, hd] and / or out_pairs: the same values in the
+ * pair-major layout of aphro_fp8_gemm_resident_aq over [S, Hq * hd]; either may be NULL): aphro_fp8_gemm_resident_aq reduces the partials to the row scale and
+ * quantises on load -- dynamic_per_token_scaled_fp8_quant (fp8/common.cu:201-256) without its launch. */
+int aphro_paged_attention_rope_scaled_absmax(void* out, void* out_pairs, float* out_absmax, const float* qkv_slabs, int nslab,
+                                             const float* slab_row_scale, const float* slab_col_scale,
+                                             const int64_t* positions, const void* cos_sin_cache,
+                                             const int64_t* slot_mapping, void* key_cache, void* value_cache,
+                                             int num_seqs, int num_heads, int num_kv_heads, int head_size, float scale,
+                                             const int32_t* block_tables, const int32_t* seq_lens,
+                                             int max_num_blocks_per_seq, int block_size, int max_seq_len,
+                                             const float* alibi_slopes, int64_t kv_block_stride,
+                                             int64_t kv_head_stride, int dtype, int kv_dtype, float k_scale,
+                                             float v_scale, void* stream);
+
 /* ------------------------------------------------------------------------
  * Random sampling inside the decode graph: temperature -> top-k -> top-p -> softmax
  * -> multinomial in one launch.  Semantics of modeling/layers/sampler.py: logits / t (:256-262, t <
@@ -796,6 +811,35 @@ int aphro_fp8_strip_relayout(const void* w, void* out, int64_t M, int64_t N, int
 int aphro_fp8_gemm_resident(const void* a, int64_t lda, const void* w_strip, const float* a_scales,
                             const float* b_scales, const void* bias, void* out, float* slabs, size_t slabs_bytes,
                             int64_t M, int64_t N, int64_t K, int a_scale_per_token, int b_scale_per_channel,
+                            int dtype, void* stream);
+
+/* Round 6 -- the dynamic per-token scheme without its quantising launches (what llm-compressor checkpoints select,
+ * quantization/compressed_tensors/schemes/compressed_tensors_w8a8_fp8.py:133-141; quantiser
+ * kernels/quantization/fp8/common.cu:187-256, called from quantization/utils/w8a8_utils.py:83-183 through
+ * _custom_ops.scaled_fp8_quant :632-685).
+ * aphro_fp8_gemm_resident_aq: the resident GEMM with `a16` = the PRODUCER's 16-bit activations [M, lda] (lda in elements,
+ * lda % 8 == 0; or, a_pairs / act_pairs != 0, the PAIR-MAJOR layout the fused producers write for it: element (m, k) at
+ * ((((k / 64) * ceil(M / 16) + m / 16) * 2 + (k % 16) / 8) * 64 + ((k % 64) / 16) * 16 + m % 16) * 8 + k % 8, every
+ * 16-byte load of the GEMM lane-linear) and `absmax` = the producer's absmax partials [M][np] (np % 4 == 0, 4 <= np <= 256): the launch reduces the
+ * partials to the row scale max(absmax / 448, 1 / (448 * 512)) -> scale_out[M] (may be NULL) and quantises every A fragment
+ * on load as fp8(x / scale) with the IEEE quotient -- the bits of dynamic_per_token_scaled_fp8_quant followed by
+ * aphro_fp8_gemm_resident.  aphro_fp8_quant_rows_aq: that quantiser alone (same device code) for parity tests.
+ * aphro_fp8_strip_relayout_interleaved / aphro_fp8_gemm_resident_silu: gate_up with SiluAndMul in the epilogue (plans with
+ * one K slice): the strip-major copy pairs (gate row j, up row N / 2 + j) as adjacent columns; dynamic scheme: act_out
+ * `dtype` [M, N / 2] + absmax_out [M][strips] (strips = aphro_fp8_gemm_resident_strips(M, N, K)); static scheme: q8_out e4m3
+ * [M, N / 2] = fp8(act * (1 / *static_out_scale)) (static_scaled_fp8_quant, common.cu:187-199) -- the bits of
+ * aphro_fp8_gemm_resident -> silu_and_mul (kernels/activation_kernels.cu:12-75) [-> the quantiser]. */
+int aphro_fp8_gemm_resident_strips(int64_t M, int64_t N, int64_t K);
+int aphro_fp8_strip_relayout_interleaved(const void* w, void* out, int64_t M, int64_t N, int64_t K, void* stream);
+int aphro_fp8_gemm_resident_aq(const void* a16, int64_t lda, int a_pairs, const float* absmax, int np, const void* w_strip,
+                               float* scale_out, const float* b_scales, const void* bias, void* out, float* slabs,
+                               size_t slabs_bytes, int64_t M, int64_t N, int64_t K, int b_scale_per_channel, int dtype,
+                               void* stream);
+int aphro_fp8_gemm_resident_silu(const void* a, int64_t lda, const void* w_strip_il, const float* a_scales,
+                                 const float* b_scales, void* act_out, int act_pairs, float* absmax_out, void* q8_out,
+                                 const float* static_out_scale, int64_t M, int64_t N, int64_t K, int a_scale_per_token,
+                                 int b_scale_per_channel, int dtype, void* stream);
+int aphro_fp8_quant_rows_aq(const void* x, const float* absmax, int np, void* q, float* scale_out, int64_t M, int64_t K,
                             int dtype, void* stream);
 
 /* FP8 W8A8 decode GEMM for M <= 32 on the LDS-DMA streaming structure (round 3, csrc/fp8_gemm_stream.hip): same role and

@@ -6,6 +6,7 @@ HIP-graph capture + replay with buffers registered after the capture, and the de
 Every wait in the kernel is bounded, every process is spawned with a join timeout."""
 import socket
 
+import numpy as np
 import pytest
 import torch
 
@@ -226,6 +227,23 @@ def _ar_norm_worker(rank, world, port, one_shot_max):
                             assert got[0].shape == p_ref.shape and torch.equal(got[0][pos], p_ref[pos]), tag
                         if want_out:
                             assert torch.equal(got[1], o_ref), tag
+                            # ... and DIRECTLY against the oracle, not only against this package's two launches:
+                            # the rank-ordered fp32 sum rounded to the storage dtype (custom_all_reduce.cuh:445-449 packed_assign
+                            # of the upcast sum), then fused_add_rms_norm (layernorm_kernels.cu:200-240) with its roundings
+                            from oracle import attention as oa
+                            acc = parts[0].float()
+                            for q_ in parts[1:]:
+                                acc = acc + q_.float()
+                            summed_o = acc.to(dtype).float().numpy()
+                            if has_res:
+                                _, r_o = oa.fused_add_rms_norm(summed_o, res0.float().cpu().numpy(), w.float().cpu().numpy(), 1e-5)
+                                r_o = torch.from_numpy(np.asarray(r_o, np.float32)).to(dtype)
+                                assert torch.equal(r_got.cpu(), r_o), tag
+                            else:
+                                r_o = torch.from_numpy(summed_o).to(dtype)
+                            want_o = oa.rms_norm(r_o.float().numpy(), w.float().cpu().numpy(), 1e-5)
+                            tol = 1e-2 if dtype == torch.bfloat16 else 2e-3           # tests/kernels/test_layernorm.py: atol = rtol = 1e-2
+                            np.testing.assert_allclose(got[1].float().cpu().numpy(), want_o, atol=tol, rtol=tol, err_msg=tag)
                         assert torch.equal(r_got, r_ref), tag
                         assert torch.equal(x.cpu(), parts[rank])
         # captured: the partial sums live in a graph-private buffer that is registered after the capture

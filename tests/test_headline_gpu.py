@@ -518,9 +518,10 @@ def test_config3_batch64_fused_decode_layers_vs_oracle(ops):
     assert np.abs(got - want).mean() / np.abs(want).mean() < 4e-3
 
 
+@pytest.mark.parametrize("strips", [False, True])
 @pytest.mark.parametrize("scheme", ["dynamic", "static"])
 @pytest.mark.parametrize("kv_cache_dtype", ["fp8", "auto"])
-def test_config2_fused_fp8_decode_layers_vs_oracle(ops, kv_cache_dtype, scheme):
+def test_config2_fused_fp8_decode_layers_vs_oracle(ops, kv_cache_dtype, scheme, strips):
     """configs[2] (compressed-tensors FP8 W8A8, per-token dynamic activations x per-channel weights, FP8-E4M3 KV cache)
     through TWO decoder layers of Llama-3-8B geometry on forward_decode_fused_fp8 -- every activation quantisation fused
     into its producer, raw fp32 slabs between the GEMMs and their consumers, rotary + cache write inside the attention
@@ -530,8 +531,11 @@ def test_config2_fused_fp8_decode_layers_vs_oracle(ops, kv_cache_dtype, scheme):
     K-long dot products only average out -- hence a bound on the MEAN error, calibrated in the test itself against the
     oracle's own sensitivity to one omitted bf16 rounding, plus a loose element-wise one.
     scheme "static": the checkpoint carries one input_scale per projection (compressed_tensors_w8a8_fp8.py:98-113) and
-    every quantisation is static_scaled_fp8_quant (x * (1 / scale)) -- the same fused launches with the scale handed in."""
-    _config2_fused_fp8_layers_vs_oracle(kv_cache_dtype, scheme, [5, 17, 33, 64], 2, 512)
+    every quantisation is static_scaled_fp8_quant (x * (1 / scale)) -- the same fused launches with the scale handed in.
+    strips: the strip-major decode copies of the benched path (``enable_fp8_strips``: the resident W8A8 kernel; round 6: 7
+    launches per layer -- the o_proj / down GEMMs quantise the producers' 16-bit activations on load, SiluAndMul rides in the
+    gate_up epilogue)."""
+    _config2_fused_fp8_layers_vs_oracle(kv_cache_dtype, scheme, [5, 17, 33, 64], 2, 512, strips)
 
 
 def test_config2_bs32_ctx8192_fused_fp8_decode_layer_vs_oracle(ops):
@@ -542,10 +546,10 @@ def test_config2_bs32_ctx8192_fused_fp8_decode_layer_vs_oracle(ops):
     rng = np.random.default_rng(8192)
     lens = [8192, 8191, 4096, 4097, 1, 16] + [int(x) for x in rng.integers(1, 8193, size=10)] + \
         [int(x) for x in rng.integers(1, 1025, size=16)]
-    _config2_fused_fp8_layers_vs_oracle("fp8", "dynamic", lens, 1, 8448)
+    _config2_fused_fp8_layers_vs_oracle("fp8", "dynamic", lens, 1, 8448, True)
 
 
-def _config2_fused_fp8_layers_vs_oracle(kv_cache_dtype, scheme, lens, nlayers, max_pos):
+def _config2_fused_fp8_layers_vs_oracle(kv_cache_dtype, scheme, lens, nlayers, max_pos, strips=False):
     from oracle import fp8 as of8
     from aphrodite_engine_amd import model as M
     from aphrodite_engine_amd.quantization.fp8 import CompressedTensorsW8A8Fp8Config
@@ -569,6 +573,10 @@ def _config2_fused_fp8_layers_vs_oracle(kv_cache_dtype, scheme, lens, nlayers, m
                    for c in caches]
         m.use_fused_decode = True
         assert all(l.fused_decode_fp8_ok(bs) for l in m.layers)
+        if strips:
+            for l in m.layers:
+                l.enable_fp8_strips(bs)
+            assert m.layers[0].fp8_gate_up_il is not None and "down_proj" in m.layers[0].fp8_strip
         got = m(ids, pos, caches, meta).float().cpu().numpy()
 
         def linear(lin_, x):

@@ -241,6 +241,42 @@ def _tp_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _tp_selfcheck_worker(rank, world, port, q):
+    """the first-contact self-check and the measured overlap gate, on a real (gloo) group of two."""
+    import torch.distributed as dist
+    from aphrodite_engine_amd import distributed as d
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    d.init_tensor_parallel(world, backend="gloo")
+    chk = d.all_reduce_self_check(torch.device("cpu"), sizes=(4096, 65536))
+    # the overlap arm needs HIP streams: stand in for it, the DECISION logic is what runs here (both ranks must agree: rank 1
+    # measures the overlap arm slower than rank 0 does -- the max over the group decides)
+    state = {"on": False}
+    d.enable_all_reduce_overlap = lambda device, enabled=True: state.__setitem__("on", bool(enabled))
+    times = iter([1.0, 0.90 if rank == 0 else 0.99])
+    rec = d.choose_all_reduce_overlap(torch.device("cpu"), lambda: next(times))
+    times2 = iter([1.0, 0.80])
+    rec2 = d.choose_all_reduce_overlap(torch.device("cpu"), lambda: next(times2))
+    q.put((rank, chk, rec, rec2, state["on"]))
+    dist.destroy_process_group()
+
+
+def test_all_reduce_self_check_and_measured_overlap_gate_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_tp_selfcheck_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+    for rank, chk, rec, rec2, on in res:
+        assert chk["decision"] == "RCCL (no peer-access communicator)"                 # no GPU here: the report says who serves
+        assert chk["4096"]["rccl"] == "ok" and chk["4096"]["peer"].startswith("off")
+        assert rec["enabled"] is False and rec["overlap_s"] == 0.99 and rec["serial_s"] == 1.0     # max over ranks: inside the margin
+        assert rec2["enabled"] is True and on is True
+
+
 def test_tensor_parallel_collectives_gloo():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
