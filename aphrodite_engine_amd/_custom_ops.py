@@ -13,11 +13,13 @@ tensors are allocated here on the input's device.  Every launch goes to
 ``torch.cuda.current_stream()`` and nothing synchronises, so the ops can be
 captured into a HIP graph exactly like the reference's.
 """
+import contextlib
 import os
 from typing import List, Optional, Tuple
 
 import torch
 
+from .switches import switch
 from . import _lib
 from ._lib import check
 
@@ -33,6 +35,32 @@ _workspaces = {}
 
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
+
+
+def reload_env() -> None:
+    """Have the library re-read its environment switches (csrc/common.h ``Knobs``): they are read once at load and never on
+    a launch path, so a process that changes one afterwards says so."""
+    _lib.lib().aphro_reload_env()
+
+
+@contextlib.contextmanager
+def knob(name: str, value):
+    """``with ops.knob("APHRO_PA_SPLITS", 4): ...`` -- set (``None``: unset) one of the library's environment switches for the
+    block: the variable is changed in this process, the library told to re-read, and both undone on exit."""
+    old = os.environ.get(name)
+    try:
+        if value is None:
+            os.environ.pop(name, None)
+        else:
+            os.environ[name] = str(value)
+        reload_env()
+        yield
+    finally:
+        if old is None:
+            os.environ.pop(name, None)
+        else:
+            os.environ[name] = old
+        reload_env()
 
 
 def _dt(t: torch.Tensor) -> int:
@@ -182,7 +210,7 @@ def paged_attention_rocm(out, exp_sum, max_logits, tmp_out, query, key_cache,
     part = _partition_size(tmp_out, max_seq_len)
     num_seqs, num_heads = query.shape[0], query.shape[1]
     if (max_seq_len <= 8192 and ((max_seq_len + part - 1) // part == 1 or num_seqs * num_heads > 512)
-            and not os.environ.get("APHRO_PA_ROCM_PARTITIONED")):
+            and not switch("APHRO_PA_ROCM_PARTITIONED")):
         part, exp_sum, max_logits, tmp_out = 0, None, None, None
     _paged_attention(out, exp_sum, max_logits, tmp_out, query, key_cache,
                      value_cache, num_kv_heads, scale, block_tables, seq_lens,
@@ -265,7 +293,7 @@ def context_attention_fwd(q, k, v, o, kv_cache_dtype: str, k_cache, v_cache, b_l
         slopes = alibi_slopes.to(device=q.device, dtype=torch.float32).contiguous()
     win = int(sliding_window) if sliding_window is not None and sliding_window > 0 else 0
     lib = _lib.lib()
-    if head_size in (64, 96, 128, 256) and not os.environ.get("APHRO_CA_NO_GATHER"):
+    if head_size in (64, 96, 128, 256) and not switch("APHRO_CA_NO_GATHER"):
         # gather the cached context once, then the prefill tile machines over context + new tokens (every head size, ALiBi,
         # sliding window: round 3).  The caller passes the host-side maxima when it has them (the attention metadata does);
         # without them a host-side bound -- new tokens + block-table capacity per sequence -- sizes the workspace when that
@@ -541,9 +569,9 @@ def _wna16(a, qweight, qzeros, scales, perm, zero_offset):
     m, k = a.shape
     n = qweight.shape[1]
     if wna16_large_ok(m, n, k, scales.shape[0]) and wna16_prefers_large(m, n, k) \
-            and not os.environ.get("APHRO_WNA16_NO_LARGE"):
+            and not switch("APHRO_WNA16_NO_LARGE"):
         return _wna16_large(a, qweight, qzeros, scales, perm, zero_offset)
-    if wna16_prefers_mid(m, n, k) and wna16_mid_ok(m, n, k, scales.shape[0]) and not os.environ.get("APHRO_WNA16_NO_MID"):
+    if wna16_prefers_mid(m, n, k) and wna16_mid_ok(m, n, k, scales.shape[0]) and not switch("APHRO_WNA16_NO_MID"):
         return _wna16_mid(a, qweight, qzeros, scales, perm, zero_offset)
     lib = _lib.lib()
     out = torch.empty((m, n), dtype=a.dtype, device=a.device)
@@ -581,7 +609,7 @@ def gptq_gemm(a: torch.Tensor, b_q_weight: torch.Tensor,
         raise RuntimeError(f"gptq_gemm: weight width {bit} is not one of 2, 3, 4, 8")
     m = a.shape[0]
     large = use_exllama and wna16_large_ok(m, b_q_weight.shape[1], a.shape[1], b_gptq_scales.shape[0]) \
-        and wna16_prefers_large(m, b_q_weight.shape[1], a.shape[1]) and not os.environ.get("APHRO_WNA16_NO_LARGE")
+        and wna16_prefers_large(m, b_q_weight.shape[1], a.shape[1]) and not switch("APHRO_WNA16_NO_LARGE")
     if not use_exllama or (m >= GPTQ_DEQUANT_MIN_M and not large):
         w = gptq_dequant(b_q_weight, b_gptq_qzeros, b_gptq_scales, b_g_idx,
                          use_exllama, bit)
@@ -589,7 +617,7 @@ def gptq_gemm(a: torch.Tensor, b_q_weight: torch.Tensor,
             a = a[:, b_g_idx.long()]
         _library_fallback("gptq_gemm", "not exllama-shuffled" if not use_exllama else
                           f"M={m} N={b_q_weight.shape[1]} K={a.shape[1]}: " +
-                          ("APHRO_WNA16_NO_LARGE is set" if os.environ.get("APHRO_WNA16_NO_LARGE") else
+                          ("APHRO_WNA16_NO_LARGE is set" if switch("APHRO_WNA16_NO_LARGE") else
                            "shape not tiled by wna16_gemm_large") + " (gptq_dequant + matmul)")
         return torch.matmul(a, w)
     perm = None
@@ -713,7 +741,7 @@ def awq_gemm(input: torch.Tensor, qweight: torch.Tensor, qzeros: torch.Tensor,
     groups = scaling_factors.shape[0]
     if input.stride(1) != 1:
         input = input.contiguous()
-    if m >= AWQ_REPACK_MIN_M and wna16_large_ok(m, n, k, groups) and not os.environ.get("APHRO_WNA16_NO_LARGE"):
+    if m >= AWQ_REPACK_MIN_M and wna16_large_ok(m, n, k, groups) and not switch("APHRO_WNA16_NO_LARGE"):
         # prefill-sized M on checkpoint-layout AWQ tensors: transpose the nibbles once per call (2 x the weight bytes,
         # a few % of the GEMM at this M) and run the MFMA-bound kernel -- the reference dequantises + matmuls above 256
         # tokens (awq.py:160-164).  Load-time repack (AWQConfig(prepack=True)) skips this step entirely.
@@ -969,7 +997,7 @@ def wna16_decode_strip_copy(qweight: torch.Tensor, scales: torch.Tensor) -> Opti
     matrix at 32 rows (two column passes per workgroup), nothing on the one-pass shapes (down / qkv / o) -- so only
     matrices of >= 32 MiB get one (it doubles their footprint: the [K/8, N] original still serves M > 32).
     APHRODITE_MI355X_NO_STRIP_COPY=1 turns it off."""
-    if os.environ.get("APHRODITE_MI355X_NO_STRIP_COPY") == "1" or scales.dtype != torch.float16:
+    if switch("APHRODITE_MI355X_NO_STRIP_COPY") == "1" or scales.dtype != torch.float16:
         return None
     k, n, groups = qweight.shape[0] * 8, qweight.shape[1], scales.shape[0]
     if qweight.numel() * 4 < STRIP_COPY_MIN_BYTES or not wna16_gemm_rowmajor_supported(32, n, k, groups, torch.float16):
@@ -1852,7 +1880,7 @@ def cutlass_scaled_mm(a: torch.Tensor, b: torch.Tensor, scale_a: torch.Tensor,
         raise RuntimeError("b must be column-major [K,N] (weight.t())")
     if not a.is_contiguous():
         a = a.contiguous()
-    if m > SCALED_MM_LIBRARY_MIN_M and n % 128 == 0 and k % 128 == 0 and not os.environ.get("APHRO_FP8_NO_LARGE"):
+    if m > SCALED_MM_LIBRARY_MIN_M and n % 128 == 0 and k % 128 == 0 and not switch("APHRO_FP8_NO_LARGE"):
         # prefill-sized M: the MFMA-bound kernel of fp8_gemm_large.hip (scales + bias in its epilogue, f16 or bf16)
         lib = _lib.lib()
         if out is None:
@@ -1935,7 +1963,7 @@ def fp8_marlin_gemm(a: torch.Tensor, b_q_weight: torch.Tensor,
     lib = _lib.lib()
     if a.stride(1) != 1:
         a = a.contiguous()
-    if size_m > WNA16_LARGE_MIN_M and size_n % 128 == 0 and size_k % 64 == 0 and not os.environ.get("APHRO_WNA16_NO_LARGE"):
+    if size_m > WNA16_LARGE_MIN_M and size_n % 128 == 0 and size_k % 64 == 0 and not switch("APHRO_WNA16_NO_LARGE"):
         # prefill-sized M: the int4 kernel's tile machine with e4m3 weights widened in registers (wna16_gemm_large.hip)
         a_ = a[:size_m]
         if a_.stride(0) % 8 != 0 or a_.data_ptr() % 16 != 0:

@@ -109,6 +109,7 @@ SIGNATURES = {
     "aphro_fp8_gemm_resident_ksplit": (I, [L, L, L]),
     "aphro_fp8_strip_relayout": (I, [P, P, L, L, L, P]),
     "aphro_fp8_gemm_resident": (I, [P, L, P, P, P, P, P, P, Z, L, L, L, I, I, I, P]),
+    "aphro_reload_env": (None, []),
     "aphro_fp8_gemm_resident_strips": (I, [L, L, L]),
     "aphro_fp8_strip_relayout_interleaved": (I, [P, P, L, L, L, P]),
     "aphro_fp8_gemm_resident_aq": (I, [P, L, I, P, I, P, P, P, P, P, P, Z, L, L, L, I, I, P]),

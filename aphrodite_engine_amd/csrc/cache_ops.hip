@@ -154,8 +154,7 @@ extern "C" int aphro_prefetch(const void* ptr, size_t bytes, void* stream) {
   if (bytes <= skip) return APHRO_OK;
   const size_t n16 = (bytes - skip) / 16;
   if (n16 == 0) return APHRO_OK;
-  int max_blocks = 512;                  // (read per call: calls happen at capture time only, replays never get here)
-  if (const char* e = getenv("APHRO_PREFETCH_BLOCKS")) { const int v = atoi(e); if (v >= 1) max_blocks = v; }
+  const int max_blocks = APHRO_LAB_ENV_INT("APHRO_PREFETCH_BLOCKS", 512);
   unsigned blocks = (unsigned)((n16 + 256 * 4 - 1) / (256 * 4));
   if (blocks > (unsigned)max_blocks) blocks = (unsigned)max_blocks;
   hipLaunchKernelGGL(aphro::prefetch_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const u32x4*)a, n16,

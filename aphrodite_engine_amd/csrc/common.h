@@ -60,14 +60,40 @@ inline int device_cu_count() {
   }
   return n[d];
 }
+// ---- the environment, read ONCE --------------------------------------------------------------------------------------
+// Every switch the library honours is a field of Knobs, filled from the environment the first time knobs() is called and
+// again by aphro_reload_env() (tests flip a switch inside one process: ops.knob(...)); nothing on a launch path calls
+// getenv.  These are the switches INTEGRATION.md documents.  Plan-forcing / ablation overrides of the kernel labs are NOT
+// product switches: APHRO_LAB_ENV_INT(name, default) reads them only in a -DAPHRO_LAB build (make LAB=1 -> the library the
+// tools/ scripts load through APHRODITE_MI355X_LIB) and is the constant `default` in the product.
+struct Knobs {
+  int pa_splits;              // APHRO_PA_SPLITS=<n>: force the in-launch KV split count of decode attention (0: planned)
+  int fa_v4_min_keys;         // APHRO_FA_V4_MIN_KEYS=<n>: prefill attention, fourth generation from n keys (default 4096)
+  int fa_no_xcd;              // APHRO_FA_NO_XCD=1: prefill attention without the kv-head -> XCD placement (same bits)
+  int fp8_stream_all;         // APHRO_FP8_STREAM_ALL=1: the LDS-DMA FP8 decode kernel on every shape it tiles
+  int wna16_stream;           // APHRO_WNA16_STREAM=0: the two-pass resident kernel instead of the single-pass stream kernel
+  int wna16_op_no_resident;   // APHRO_WNA16_OP_NO_RESIDENT=1: op-level gptq_gemm as pack + GEMM + reduce (three launches)
+  int wna16_large_8phase;     // APHRO_WNA16_LARGE_8PHASE=0/1: prefill W4A16 schedule (-1: by K)
+  int wna16_mid_waves;        // APHRO_WNA16_MID_WAVES=4/8: K waves of the 33..64-row kernel (0: planned)
+  int res_cfg[4];             // APHRO_WNA16_RES_CFG="nwv,nseg,np4,rem": force a resident-kernel plan (tests)
+  int res_cfg_set;
+  long ar_one_shot_max;       // APHRO_CUSTOM_AR_ONE_SHOT_MAX=<bytes>: one- / two-shot crossover of the peer-access all-reduce (-1: planned)
+  long ar_timeout_ms;         // APHRODITE_CUSTOM_AR_TIMEOUT_MS=<ms>: bound on a peer wait (0: the built-in default)
+  int cu_masked;              // HSA_CU_MASK / ROC_GLOBAL_CU_MASK present: not every reported CU is usable
+};
+const Knobs& knobs();
+#ifdef APHRO_LAB
+inline int aphro_lab_env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+#define APHRO_LAB_ENV_INT(name, dflt) ([]() -> int { static const int v_ = aphro::aphro_lab_env_int(name, dflt); return v_; }())
+#else
+#define APHRO_LAB_ENV_INT(name, dflt) (dflt)
+#endif
+
 // Persistent grids whose workgroups WAIT on one another (the stream-K owners of the prompt-sized GEMMs spin on flags
 // of higher-index workgroups) are only correct when the whole grid is co-resident.  One workgroup per reported CU is,
 // unless the process runs under a CU mask (the runtime still reports every CU): then those plans are not used at all
 // and the shape takes the one-workgroup-per-tile + split-K plan, which has no cross-workgroup wait.
-inline int device_coresident_cu_count() {
-  static const bool masked = getenv("HSA_CU_MASK") || getenv("ROC_GLOBAL_CU_MASK") || getenv("HSA_CU_MASK_SKIP_INIT");
-  return masked ? 0 : device_cu_count();
-}
+inline int device_coresident_cu_count() { return knobs().cu_masked ? 0 : device_cu_count(); }
 
 // Pair-major 16-bit activations between a fused producer and the AQ GEMM: element (row m, column k) of [M, K] sits at
 //   ((((k / 64) * mtiles + m / 16) * 2 + (k % 16) / 8) * 64 + ((k % 64) / 16) * 16 + m % 16) * 8 + k % 8      (16-bit elements)

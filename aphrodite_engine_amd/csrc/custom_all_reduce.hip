@@ -614,10 +614,7 @@ extern "C" int aphro_custom_ar_init(void** fa_out, void* signal, const char* sig
   CustomAr* fa = new CustomAr();
   fa->rank = rank; fa->world = world;
   fa->own_signal = signal; fa->own_scratch = scratch; fa->scratch_bytes = scratch_bytes;
-  if (const char* ms = getenv("APHRODITE_CUSTOM_AR_TIMEOUT_MS")) {
-    long v = atol(ms);
-    if (v > 0) fa->timeout_ticks = (int64_t)v * AR_TICKS_PER_MS;
-  }
+  if (knobs().ar_timeout_ms > 0) fa->timeout_ticks = (int64_t)knobs().ar_timeout_ms * AR_TICKS_PER_MS;
   fa->d_slots = (ArPeers*)rank_data;
   fa->slot_cap = (int)(rank_data_bytes / sizeof(ArPeers));
   ArPeers sp;
@@ -659,7 +656,7 @@ extern "C" int aphro_custom_ar_should_one_shot(int world, size_t bytes) {
   // one link transfer of `bytes` vs two transfers of bytes / world plus a second flag round trip
   // (APHRO_CUSTOM_AR_ONE_SHOT_MAX=<bytes>: override, any world size -- the tests use it to reach the two-shot forms with
   //  two ranks; must be the same on every rank)
-  static const long forced = [] { const char* e = getenv("APHRO_CUSTOM_AR_ONE_SHOT_MAX"); return e ? atol(e) : -1L; }();
+  const long forced = knobs().ar_one_shot_max;
   if (forced >= 0) return bytes <= (size_t)forced;
   if (world <= 2) return 1;
   return bytes <= (world <= 4 ? 512u * 1024u : 256u * 1024u);
@@ -861,7 +858,7 @@ extern "C" int aphro_custom_ar_fused_add_rms_norm(void* fa_, const void* inp, vo
     if (prefetch_bytes > skip + 16) {
       q.pf = (const u32x4*)a;
       q.pf_n16 = (prefetch_bytes - skip) / 16;
-      static const int max_pf = [] { const char* e = getenv("APHRO_AR_PREFETCH_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 192; }();
+      const int max_pf = APHRO_LAB_ENV_INT("APHRO_AR_PREFETCH_BLOCKS", 192);
       size_t want = (q.pf_n16 + (size_t)t * 4 - 1) / ((size_t)t * 4);
       blocks += (int)(want > (size_t)max_pf ? (size_t)max_pf : want);
     }

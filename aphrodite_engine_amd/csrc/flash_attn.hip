@@ -462,18 +462,6 @@ __global__ __launch_bounds__(NWV * 64) void flash_attn_varlen_v2_kernel(FAParams
 //   * O leaves through a wave-private LDS transpose as full 256-byte rows.
 // Keys beyond the sequence are fetched as zeros by the buffer descriptor's bounds check.
 // ---------------------------------------------------------------------------
-#ifndef FA3_ASM_DMA
-#define FA3_ASM_DMA 0
-#endif
-#ifndef FA_QK_SCHED
-#define FA_QK_SCHED 1
-#endif
-#ifndef FA_FUSED_QKSM
-#define FA_FUSED_QKSM 1
-#endif
-// lab (APHRO_FA_DEBUG=1): s_memtime stamps of the heaviest workgroup's waves, read back with aphro_fa_debug_dump
-__device__ unsigned long long fa_dbg[8 * 64];
-#define FA_STAMP(slot) if ((p.debug & 1) && blockIdx.x == 0 && lane == 0) fa_dbg[wave * 64 + (slot)] = __builtin_amdgcn_s_memtime();
 
 
 template <typename T>
@@ -537,18 +525,10 @@ __global__ __launch_bounds__(512) void flash_attn_varlen_v3_kernel(FAParams p) {
   // ---- K / V staging: buffer descriptors over this sequence's rows of this kv head (reads past the end return 0) -------
   const uint16_t* kbase = (const uint16_t*)p.k + (size_t)s0 * p.k_stride + (size_t)kvh * HD;
   const uint16_t* vbase = (const uint16_t*)p.v + (size_t)s0 * p.v_stride + (size_t)kvh * HD;
-#if FA3_ASM_DMA
-  // (round 5: the LDS-DMA pieces as inline asm, see fa_dma16 -- behind a DMA it can see hipcc drains vmcnt to 0 in front of
-  //  the next LDS read, i.e. right after the pieces of tile it + 2 are issued)
-  const u32x4 rk = fa_make_rsrc(kbase, (uint32_t)(((size_t)(len - 1) * p.k_stride + HD) * 2));
-  const u32x4 rv = fa_make_rsrc(vbase, (uint32_t)(((size_t)(len - 1) * p.v_stride + HD) * 2));
-  const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)fa_smem;
-#else
   const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(kbase), 0,
       (uint32_t)(((size_t)(len - 1) * p.k_stride + HD) * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(vbase), 0,
       (uint32_t)(((size_t)(len - 1) * p.v_stride + HD) * 2), 0x00020000);
-#endif
   // a wave stages pieces 2 wave, 2 wave + 1 (4 keys = 1 KiB each) of both tiles.
   // K piece: lane L -> key 4 c + (L >> 4), LDS slot L & 15 holds d-chunk slot ^ (key & 15)
   // V piece: lane L -> key 4 c + (L & 3), d-chunk L >> 2  (image [d-chunk][key] inside the piece)
@@ -566,13 +546,8 @@ __global__ __launch_bounds__(512) void flash_attn_varlen_v3_kernel(FAParams p) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int kv = k_voff[j], vv = v_voff[j];     // (local copies: see wna16_gemm_large.hip on the hipcc host-stub bug)
-#if FA3_ASM_DMA
-      fa_dma16(rk, lds0 + buf * STAGE + (2 * wave + j) * 1024, kv, __builtin_amdgcn_readfirstlane((int)(t0 * p.k_stride * 2)));
-      fa_dma16(rv, lds0 + buf * STAGE + KT + (2 * wave + j) * 1024, vv, __builtin_amdgcn_readfirstlane((int)(t0 * p.v_stride * 2)));
-#else
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (fa_lds_ptr)(sk + (2 * wave + j) * 1024), 16, kv, (int)(t0 * p.k_stride * 2), 0, 0);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (fa_lds_ptr)(sk + KT + (2 * wave + j) * 1024), 16, vv, (int)(t0 * p.v_stride * 2), 0, 0);
-#endif
     }
   };
   // fragment read addresses (lane-invariant parts)
@@ -617,9 +592,7 @@ __global__ __launch_bounds__(512) void flash_attn_varlen_v3_kernel(FAParams p) {
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
       if (ks < 7) rd(ks + 1, fr[(ks + 1) & 1]);
-#if FA_QK_SCHED == 1
       __builtin_amdgcn_sched_barrier(0);
-#endif
       dst[0] = fa_mfma32<T>(fr[ks & 1][1], fr[ks & 1][0], ks == 0 ? zero : dst[0]);
       dst[1] = fa_mfma32<T>(fr[ks & 1][2], fr[ks & 1][0], ks == 0 ? zero : dst[1]);
     }
@@ -778,60 +751,31 @@ __global__ __launch_bounds__(512) void flash_attn_varlen_v3_kernel(FAParams p) {
   // QK^T 1280 + softmax 1224 + PV 1032 cycles per tile with NOTHING overlapping, whatever the pairing of waves).
   // Ring of 3 tile buffers: at the top of iteration it every wave has finished tile it - 1 (the barrier), tiles it and
   // it + 1 are being read, tile it + 2 is written.
-  // Lab knob (FA_TRAIL = 1 / 2): the two waves of a SIMD rotate the three phases of a tile against each other (waves 0-3
-  // QK^T(next) | softmax | PV, the others softmax | PV | QK^T(next)) so that one wave's softmax VALU runs beside the
-  // other's MFMAs.  Measured at T = 8192: 0.794 ms unrotated, 0.852 (w >= 4) / 0.837 (odd waves) rotated -- no gain, like
-  // the half-tile stagger of the first version; off.
-#ifndef FA_TRAIL
-#define FA_TRAIL 0
-#endif
-  const bool trail = FA_TRAIL == 1 ? wave >= 4 : FA_TRAIL == 2 ? (wave & 1) : false;
+  // (Rotating the three phases of a tile between the two waves of a SIMD -- one wave's softmax VALU beside the other's MFMAs --
+  // measured 0.852 / 0.837 ms against 0.794 unrotated at T = 8192 and is not in the tree: tools/lab_patches/flash_attn.hip.patch.)
   f32x16 s_a[2], s_b[2];
   stage(0, 0);
   if (ntile > 1) stage(1, BN);
   if (ntile > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  FA_STAMP(0)
-  if ((p.debug & 1) && blockIdx.x == 0 && lane == 0) fa_dbg[wave * 64 + 12] = wall_clock64();
   if (L > 0) do_qk(0, s_a);
   auto step = [&](int it, f32x16 (&s_cur)[2], f32x16 (&s_nxt)[2]) __attribute__((always_inline)) {
-    if (it == 32) { FA_STAMP(1) }
-    if (it == 64) { FA_STAMP(2) }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of tile it + 1 (issued one iteration ago)
     __builtin_amdgcn_s_barrier();
-#if defined(FA_LAB) && (FA_LAB & 64)
-    if (it + 2 < ntile && it < 2) stage((it + 2) % 3, (it + 2) * BN);
-#else
     if (it + 2 < ntile) stage((it + 2) % 3, (it + 2) * BN);
-#endif
     if (it >= L) return;                                   // causal: this wave's rows are done (it still stages its pieces)
     u32x4 pf[4];
     float alpha;
-#ifdef FA_LAB     // tools/fa_lab.hip: timing floors with pieces compiled out (results are garbage)
-    {
-      if (!(FA_LAB & 16) && it + 1 < L) do_qk(it + 1, s_nxt);
-      if (!(FA_LAB & 8)) alpha = softmax_fast(s_cur, pf);
-      else { alpha = 1.f; make_pf(s_cur, pf); }
-      if (!(FA_LAB & 32)) do_pv(it, pf);
-      else { o[0][0] += __builtin_bit_cast(float, pf[0][0] ^ pf[1][1] ^ pf[2][2] ^ pf[3][3]); }
-      return;
-    }
-#endif
     // QK^T of the NEXT tile is issued ahead of this tile's softmax: its MFMAs are independent of the softmax VALU
     // (unconditional: past this wave's last tile it multiplies stale ring data into a buffer nobody reads -- keeping the
     //  branch out puts these MFMAs and the softmax VALU in ONE scheduling region)
-#if FA_FUSED_QKSM
-    if (it < F && !trail) {
+    if (it < F) {
       alpha = qk_softmax_fast(it + 1, s_nxt, s_cur, pf);
     } else {
-      if (!trail) do_qk(it + 1, s_nxt);
-      alpha = it < F ? softmax_fast(s_cur, pf) : softmax_edge(it, s_cur, pf);
+      do_qk(it + 1, s_nxt);
+      alpha = softmax_edge(it, s_cur, pf);
     }
-#else
-    if (!trail) do_qk(it + 1, s_nxt);
-    alpha = it < F ? softmax_fast(s_cur, pf) : softmax_edge(it, s_cur, pf);
-#endif
     if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
 #pragma unroll
       for (int db = 0; db < 4; ++db)
@@ -839,14 +783,11 @@ __global__ __launch_bounds__(512) void flash_attn_varlen_v3_kernel(FAParams p) {
         for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
     }
     do_pv(it, pf);
-    if (trail) do_qk(it + 1, s_nxt);
   };
   for (int it = 0; it < ntile; it += 2) {
     step(it, s_a, s_b);
     if (it + 1 < ntile) step(it + 1, s_b, s_a);
   }
-  FA_STAMP(7)
-  if ((p.debug & 1) && blockIdx.x == 0 && lane == 0) fa_dbg[wave * 64 + 13] = wall_clock64();
   __syncthreads();                                         // every wave is done with the K / V buffers
 
   // ---- normalise, transpose through LDS (wave-private 8 KiB: 32 rows x 256 B), store whole rows -----------------------------
@@ -1164,14 +1105,13 @@ extern "C" int aphro_context_attention(void* out, const void* q, const void* k, 
 // for head 128, sequences >= 1024, no sliding window; second for head 64 / 128 (always when the keys carry a context
 // offset: its 64-key tiles are what the gathered-context path wants); first generation for the rest.
 static int fa_dispatch(FAParams p, int head_size, int dtype, int batch, int max_query_len, int max_key_len, hipStream_t st) {
-  if (head_size == 128 && max_key_len >= 1024 && p.window <= 0 && !getenv("APHRO_FA_NO_V3")) {
+  if (head_size == 128 && max_key_len >= 1024 && p.window <= 0 && !APHRO_LAB_ENV_INT("APHRO_FA_NO_V3", 0)) {
     p.nqt_max = (max_query_len + 255) / 256;
-    p.xcd_remap = (batch * p.num_kv_heads) % 8 == 0 && !getenv("APHRO_FA_NO_XCD");
+    p.xcd_remap = (batch * p.num_kv_heads) % 8 == 0 && !knobs().fa_no_xcd;
     // fourth generation (one wave per SIMD, two 32-row blocks per wave: flash_attn_v4.hip) from 4096 keys on (measured on
     // T = 8192 / 4096 / 2048 / 1111 causal, Hq 32 / Hkv 8: 0.583 / 0.174 / 0.081 / 0.046 ms against 0.62 / 0.182 / 0.078 /
-    // 0.044 ms of the third generation); APHRO_FA_NO_V4=1: third generation always; APHRO_FA_V4_MIN_KEYS=<n>: threshold
-    const int v4_min = getenv("APHRO_FA_V4_MIN_KEYS") ? atoi(getenv("APHRO_FA_V4_MIN_KEYS")) : 4096;
-    if (!getenv("APHRO_FA_NO_V4") && max_key_len >= v4_min) return fa_v4_launch(p, dtype, batch, st);
+    // 0.044 ms of the third generation); APHRO_FA_V4_MIN_KEYS=<n>: threshold (a huge n: third generation always)
+    if (max_key_len >= knobs().fa_v4_min_keys) return fa_v4_launch(p, dtype, batch, st);
     dim3 grid3((unsigned)(p.nqt_max * p.num_heads * batch));
     static bool attr_set_dev[APHRO_MAX_DEVICES] = {}; bool& attr_set = attr_set_dev[device_slot()];
     if (!attr_set) {
@@ -1191,11 +1131,11 @@ static int fa_dispatch(FAParams p, int head_size, int dtype, int batch, int max_
   // two 16-row query tiles per wave (128-row workgroups) once the sequences are long enough to
   // fill the chip with them; head 256 keeps one tile (registers)
   const bool offset_keys = p.cu_seqlens_k != nullptr;
-  const int qt = ((max_query_len >= 512 || (offset_keys && max_query_len >= 128)) && head_size <= 128 && !getenv("APHRO_FA_QT1")) ? 2 : 1;
+  const int qt = ((max_query_len >= 512 || (offset_keys && max_query_len >= 128)) && head_size <= 128 && !APHRO_LAB_ENV_INT("APHRO_FA_QT1", 0)) ? 2 : 1;
   dim3 grid((unsigned)((max_query_len + 64 * qt - 1) / (64 * qt)), (unsigned)p.num_heads, (unsigned)batch);
-  const bool v2 = qt == 2 && (head_size == 64 || head_size == 128) && !getenv("APHRO_FA_V1");
+  const bool v2 = qt == 2 && (head_size == 64 || head_size == 128) && !APHRO_LAB_ENV_INT("APHRO_FA_V1", 0);
   // 256-row (8-wave) workgroups measured slower at T = 8192 (376 vs 413 TFLOP/s): opt-in only
-  const bool v2w8 = v2 && head_size == 128 && getenv("APHRO_FA_W8") != nullptr;
+  const bool v2w8 = v2 && head_size == 128 && APHRO_LAB_ENV_INT("APHRO_FA_W8", 0) != 0;
   if (v2w8) grid.x = (unsigned)((max_query_len + 255) / 256);
 #define FA_L(TT, HDV) { if (v2w8) hipLaunchKernelGGL((flash_attn_varlen_v2_kernel<TT, 128, 2, 8>), grid, dim3(512), 0, st, p); \
                         else if (v2) hipLaunchKernelGGL((flash_attn_varlen_v2_kernel<TT, (HDV == 64 ? 64 : 128), 2, 4>), grid, dim3(256), 0, st, p); \
@@ -1274,7 +1214,7 @@ extern "C" int aphro_context_attention_gathered(void* out, const void* q, const 
   p.out = out; p.q = q; p.k = kc; p.v = vc; p.cu_seqlens = q_start_loc; p.cu_seqlens_k = cu_k; p.alibi = alibi_slopes;
   p.num_heads = num_heads; p.num_kv_heads = num_kv_heads;
   p.q_stride = q_stride; p.k_stride = (int64_t)num_kv_heads * head_size; p.v_stride = p.k_stride; p.o_stride = o_stride;
-  p.scale = scale; p.causal = 1; p.debug = 0; p.window = sliding_window > 0 ? sliding_window : 0;
+  p.scale = scale; p.causal = 1; p.window = sliding_window > 0 ? sliding_window : 0;
   return fa_dispatch(p, head_size, dtype, batch, max_query_len, max_seq_len, st);
 }
 
@@ -1293,13 +1233,8 @@ extern "C" int aphro_flash_attn_varlen(void* out, const void* q, const void* k, 
   p.out = out; p.q = q; p.k = k; p.v = v; p.cu_seqlens = cu_seqlens; p.alibi = alibi_slopes;
   p.num_heads = num_heads; p.num_kv_heads = num_kv_heads;
   p.q_stride = q_stride; p.k_stride = k_stride; p.v_stride = v_stride;
-  p.scale = scale; p.causal = causal; p.debug = getenv("APHRO_FA_DEBUG") ? atoi(getenv("APHRO_FA_DEBUG")) : 0;
+  p.scale = scale; p.causal = causal;
   p.cu_seqlens_k = nullptr; p.o_stride = (int64_t)num_heads * head_size; p.nqt_max = 0; p.xcd_remap = 0; p.window = 0;
   return fa_dispatch(p, head_size, dtype, batch, max_seqlen, max_seqlen, (hipStream_t)stream);
 }
 
-// lab: copy the stamp buffer of the third-generation prefill kernel to the host
-extern "C" int aphro_fa_debug_dump(unsigned long long* host_out, int n) {
-  if (n > 8 * 64) n = 8 * 64;
-  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(aphro::fa_dbg), (size_t)n * 8) == hipSuccess ? APHRO_OK : APHRO_ERR_LAUNCH;
-}

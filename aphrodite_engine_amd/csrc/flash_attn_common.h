@@ -15,7 +15,6 @@ struct FAParams {
   int64_t q_stride, k_stride, v_stride;
   float scale;
   int causal;
-  int debug;
   int nqt_max, xcd_remap;   // third-generation kernel: query tiles per sequence in the grid; kv-head -> XCD placement
   const int32_t* cu_seqlens_k;   // third-generation kernel: key rows per sequence when they differ from the query rows
   int64_t o_stride;              // ... and the output row stride (elements)

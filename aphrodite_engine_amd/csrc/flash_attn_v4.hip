@@ -27,28 +27,9 @@ namespace aphro {
 
 typedef short fa4_s16x4 __attribute__((ext_vector_type(4)));
 
-// lab (tools/fa_lab.hip, -DFA4_LAB=<bits>; results are garbage, timing only): 1 no softmax slices, 2 no QK^T MFMAs, 4 no PV MFMAs,
-// 8 no K / V staging after the prologue, 16 no rescale branches, 32 no LDS fragment reads
-#ifndef FA4_LAB
-#define FA4_LAB 0
-#endif
-#ifndef FA4_ASM_QK
-#define FA4_ASM_QK 1
-#endif
-#ifndef FA4_QV
-#define FA4_QV 0
-#endif
-#if FA4_QV
-#define FA4_QC "v"
-#else
-#define FA4_QC "a"
-#endif
-#ifndef FA4_PF
-#define FA4_PF 1
-#endif
-#ifndef FA4_SCHED
-#define FA4_SCHED 1
-#endif
+// (the timing-only ablations of tools/fa_lab.hip -- no softmax slices / MFMAs / staging / rescales / fragment reads, the Q
+// register class, fragment lead, sched_barriers -- live in tools/lab_patches/flash_attn_v4.hip.patch, not here)
+#define FA4_QC "a"          // Q fragments are read from the accumulator file
 #ifndef FA4_THR
 #define FA4_THR 8.0f        // defer-max threshold, log2 units
 #endif
@@ -213,9 +194,6 @@ void flash_attn_varlen_v4_kernel(FAParams p) {
           const float x = s[b][r] * c2 + slope2 * (float)(key - qpos);
           s[b][r] = key <= lim ? x : -1e30f;          // in place: the scores are VGPRs
         }
-      } else if (FA4_LAB & 64) {      // lab: no reads of the scores
-#pragma unroll
-        for (int r = r0; r < r0 + 4; ++r) s[b][r] = c2 * (float)r;
       }
       float mx = (sl == 0 && h == 0) ? s[0][0] : st.mx;
 #pragma unroll
@@ -229,11 +207,6 @@ void flash_attn_varlen_v4_kernel(FAParams p) {
         st.alpha = new_max(qb, st.mx);
         st.m_new = m_run[qb];
         st.lsum = 0.f;
-      }
-    } else if (sl < 13 && (FA4_LAB & 128)) {      // lab: no exponentials / packing
-      if (sl == 5 && h == 0) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) pf[i] = u32x4{__builtin_bit_cast(uint32_t, s[0][i]), __builtin_bit_cast(uint32_t, s[1][i]), __builtin_bit_cast(uint32_t, s[0][4 + i]), __builtin_bit_cast(uint32_t, s[1][8 + i])};
       }
     } else if (sl < 13) {
       const int e = sl - 5;                         // 8 slices x 4 values: block e >> 2, accumulator quad e & 3
@@ -275,17 +248,15 @@ void flash_attn_varlen_v4_kernel(FAParams p) {
     const unsigned char* sk = fa_smem + (tq & 3) * KT;
     int ka = kaddr, va = vaddr + ((tv + 4) & 3) * KT;
     asm volatile("" : "+v"(ka), "+v"(va));      // (opaque per phase: hipcc would hoist the XOR-ed addresses x 4 ring slots and spill them)
-    // the LDS fragments of a step are requested FA4_PF same-kind steps (2 FA4_PF steps) ahead of their MFMAs: one wave per
+    // the LDS fragments of a step are requested one same-kind step (two steps) ahead of their MFMAs: one wave per
     // SIMD has nobody to hide an LDS round trip behind (left alone hipcc reads them right in front of the MFMA)
-    constexpr int D = FA4_PF;
+    constexpr int D = 1;
     u32x4 kf[D + 1][2], vf[D + 1][2];
     auto rdk = [&](int ks) __attribute__((always_inline)) {
-      if (FA4_LAB & 32) return;
       kf[ks % (D + 1)][0] = *reinterpret_cast<const u32x4*>(sk + (ka ^ (ks << 5)));
       kf[ks % (D + 1)][1] = *reinterpret_cast<const u32x4*>(sk + 8192 + (ka ^ (ks << 5)));
     };
     auto rdv = [&](int e) __attribute__((always_inline)) {
-      if (FA4_LAB & 32) return;
       const int ks = e >> 1;
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
@@ -297,11 +268,6 @@ void flash_attn_varlen_v4_kernel(FAParams p) {
         vf[e % (D + 1)][h] = u32x4{l2[0], l2[1], h2[0], h2[1]};
       }
     };
-    if (FA4_LAB & 1) SM = false;
-    if (FA4_LAB & 32) {
-#pragma unroll
-      for (int d = 0; d <= D; ++d) kf[d][0] = kf[d][1] = vf[d][0] = vf[d][1] = u32x4{(uint32_t)ka, (uint32_t)va, 0u, 0u};
-    }
 #pragma unroll
     for (int d = 0; d < D; ++d) {
       if (QK) rdk(d);
@@ -315,51 +281,32 @@ void flash_attn_varlen_v4_kernel(FAParams p) {
       if (pv_step && i + D < 8) rdv(i + D);
       // first MFMA
       if (qk_step) {
-        if (!(FA4_LAB & 2)) {
-#if FA4_ASM_QK
-          if (i == 0) fa4_qk_mfma<T, true>(sq[0], kf[0][0], qq[0]);
-          else fa4_qk_mfma<T, false>(sq[0], kf[i % (D + 1)][0], qq[i]);
-#else
-          sq[0] = fa_mfma32<T>(kf[i % (D + 1)][0], qq[i], i == 0 ? zero16 : sq[0]);
-#endif
-        } else if (i == 0) { sq[0] = zero16; sq[1] = zero16; sq[0][0] = __builtin_bit_cast(float, kf[0][0][0] ^ kf[0][1][1] ^ qq[i][2]); }
+        if (i == 0) fa4_qk_mfma<T, true>(sq[0], kf[0][0], qq[0]);
+        else fa4_qk_mfma<T, false>(sq[0], kf[i % (D + 1)][0], qq[i]);
       }
       if (pv_step) {
-        if (!(FA4_LAB & 4)) ov[2 * (i & 1)] = fa_mfma32<T>(vf[i % (D + 1)][0], pv[i >> 1], ov[2 * (i & 1)]);
-        else if (i == 0) { ov[0][0] += __builtin_bit_cast(float, vf[0][0][0] ^ vf[0][1][1] ^ pv[0][2] ^ pv[3][3]); }
+        ov[2 * (i & 1)] = fa_mfma32<T>(vf[i % (D + 1)][0], pv[i >> 1], ov[2 * (i & 1)]);
       }
-      if ((g & 3) == 2 && !(FA4_LAB & 8)) {
+      if ((g & 3) == 2) {
         if (dma == 1) stage_k1(tdma, g >> 2);
         if (dma == 2) stage_v1(tdma, g >> 2);
       }
-#if FA4_SCHED
       __builtin_amdgcn_sched_barrier(0);
-#endif
       if (SM) softmax_slice(MASK, tsm, qb_sm, ssm, pfsm, st, g, 0);
-#if FA4_SCHED
       __builtin_amdgcn_sched_barrier(0);
-#endif
       // second MFMA
-      if (qk_step && !(FA4_LAB & 2)) {
-#if FA4_ASM_QK
+      if (qk_step) {
         if (i == 0) fa4_qk_mfma<T, true>(sq[1], kf[0][1], qq[0]);
         else fa4_qk_mfma<T, false>(sq[1], kf[i % (D + 1)][1], qq[i]);
-#else
-        sq[1] = fa_mfma32<T>(kf[i % (D + 1)][1], qq[i], i == 0 ? zero16 : sq[1]);
-#endif
       }
-      if (pv_step && !(FA4_LAB & 4)) ov[2 * (i & 1) + 1] = fa_mfma32<T>(vf[i % (D + 1)][1], pv[i >> 1], ov[2 * (i & 1) + 1]);
-#if FA4_SCHED
+      if (pv_step) ov[2 * (i & 1) + 1] = fa_mfma32<T>(vf[i % (D + 1)][1], pv[i >> 1], ov[2 * (i & 1) + 1]);
       __builtin_amdgcn_sched_barrier(0);
-#endif
       if (SM) softmax_slice(MASK, tsm, qb_sm, ssm, pfsm, st, g, 1);
-#if FA4_SCHED
       __builtin_amdgcn_sched_barrier(0);
-#endif
     }
   };
   auto rescale = [&](f32x16 (&ov)[4], float a) __attribute__((always_inline)) {
-    if (__builtin_expect((FA4_LAB & 16) == 0 && __builtin_amdgcn_ballot_w64(a != 1.0f) != 0, 0)) {      // (cold: spill weights)
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(a != 1.0f) != 0, 0)) {      // (cold: spill weights)
       // (a quarter of a block at a time: done in one batch hipcc reserves 64 VGPRs for it, which evicts Q to the accumulator
       //  file for the whole loop -- 64 v_accvgpr_read per tile in the hot path)
 #pragma unroll
@@ -428,10 +375,8 @@ void flash_attn_varlen_v4_kernel(FAParams p) {
   }
   for (; t <= ntile; ++t) {
     top(t);
-    if (!(FA4_LAB & 8)) {
-      stage_k(t + 3);
-      stage_v(t + 2);
-    }
+    stage_k(t + 3);
+    stage_v(t + 2);
     if (t == L)                            // this wave's last PV (block 1 of tile L - 1)
       phase(false, 0, sc1, qf[1], true, t - 1, o[1], pf1, false, false, 0, 0, sc0, pf0, st0, 0, 0);
   }

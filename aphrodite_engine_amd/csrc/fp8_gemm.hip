@@ -319,7 +319,7 @@ struct Fp8Plan { int nt, mt, ksplit, msteps_per_split, nseg; };
 static Fp8Plan make_fp8_plan(int64_t M, int64_t N, int64_t K, bool a8) {
   Fp8Plan pl;
   pl.nseg = 0;
-  if (a8 && N % 64 == 0 && K % 128 == 0 && N * K < (int64_t)0xffffffff && !getenv("APHRO_FP8_GENERIC")) {
+  if (a8 && N % 64 == 0 && K % 128 == 0 && N * K < (int64_t)0xffffffff && !APHRO_LAB_ENV_INT("APHRO_FP8_GENERIC", 0)) {
     // fast W8A8 kernel: every wave owns exactly NSEG macro steps; split across workgroups only
     // while the grid leaves CUs idle
     const int total = (int)(K / 128);
@@ -339,16 +339,14 @@ static Fp8Plan make_fp8_plan(int64_t M, int64_t N, int64_t K, bool a8) {
     }
   }
   pl.nt = (N % 64 == 0 && N / 64 >= 192) ? 4 : (N % 32 == 0 ? 2 : 1);
-  const char* e = getenv("APHRO_FP8_NT");
-  if (e) { int v = atoi(e); if ((v == 1 || v == 2 || v == 4) && N % (16 * v) == 0) pl.nt = v; }
+  { const int v = APHRO_LAB_ENV_INT("APHRO_FP8_NT", 0); if ((v == 1 || v == 2 || v == 4) && N % (16 * v) == 0) pl.nt = v; }
   pl.mt = M > 16 ? 2 : 1;
   const int64_t tiles = N / (16 * pl.nt) * ((M + 16 * pl.mt - 1) / (16 * pl.mt));
   const int total = (int)(K / 128);
   int target = (int)((256 + tiles / 2) / tiles);
   if (target < 1) target = 1;
   if (target > 8) target = 8;
-  e = getenv("APHRO_FP8_KSPLIT");
-  if (e && atoi(e) > 0) target = atoi(e);
+  if (APHRO_LAB_ENV_INT("APHRO_FP8_KSPLIT", 0) > 0) target = APHRO_LAB_ENV_INT("APHRO_FP8_KSPLIT", 0);
   // prefer splits that keep whole macro steps per wave
   int best = 1;
   for (int ks = 1; ks <= target; ++ks)

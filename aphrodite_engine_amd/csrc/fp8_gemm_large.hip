@@ -444,18 +444,8 @@ __global__ __launch_bounds__(512) void fp8_gemm_large8_kernel(Fp8LargeParams p) 
     if (p.debug == 2) k1 = k0 + 1;
     const int tm = tile / p.tiles_n, tn = tile % p.tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
-#ifdef F8_LAB
-    // lab (debug == 4): workgroups 0..3, waves 0 and 4 stamp s_memtime at six points of their first four segments:
-    // flags[512 ...] as u64 [w][wave >> 2][seg][point]; point 6/7 of seg 0 = s_memrealtime at kernel start / end of seg
-    ++seg_no;
-    unsigned long long* stamp = (p.debug == 4 && w < 4 && (wave & 3) == 0 && lane == 0 && seg_no < 4)
-                                    ? reinterpret_cast<unsigned long long*>(p.flags + 512) + ((w * 2 + (wave >> 2)) * 4 + seg_no) * 8 : nullptr;
-#define F8_STAMP(i) if (stamp) stamp[i] = __builtin_amdgcn_s_memtime();
-    if (stamp) stamp[6] = __builtin_amdgcn_s_memrealtime();
-#else
     unsigned long long* stamp = nullptr;
 #define F8_STAMP(i)
-#endif
     if (!first_segment) {                           // the previous segment's epilogue is done with the LDS
       if constexpr (RAWSYNC) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
       else __syncthreads();
@@ -717,7 +707,7 @@ static Fp8LargePlan fp8_large_plan(int64_t M, int64_t N, int64_t K) {
   Fp8LargePlan pl;
   pl.wm = M > 128 ? 2 : 1;
   const int64_t rows = (M + 128 * pl.wm - 1) / (128 * pl.wm);
-  static const int mode = getenv("APHRO_FP8_LARGE_STREAMK") ? atoi(getenv("APHRO_FP8_LARGE_STREAMK")) : -1;
+  const int mode = APHRO_LAB_ENV_INT("APHRO_FP8_LARGE_STREAMK", -1);
   const int64_t big_tiles = N % 256 == 0 ? rows * (N / 256) : rows * (N / 128);
   pl.streamk = (mode >= 0 ? mode : (big_tiles >= 128)) && device_coresident_cu_count() > 0;
   pl.ksplit = 1;
@@ -731,7 +721,7 @@ static Fp8LargePlan fp8_large_plan(int64_t M, int64_t N, int64_t K) {
       if (tiles * pl.ksplit >= 200) break;
       if (K % (s * 128) == 0 && K / s >= 1024) pl.ksplit = s;
     }
-    if (const char* e = getenv("APHRO_FP8_LARGE_KSPLIT")) { const int s = atoi(e); if (s >= 1 && K % (s * 128) == 0) pl.ksplit = s; }
+    { const int s = APHRO_LAB_ENV_INT("APHRO_FP8_LARGE_KSPLIT", 0); if (s >= 1 && K % (s * 128) == 0) pl.ksplit = s; }
     pl.grid = (int)tiles;
   }
   pl.tiles_m = (int)rows;
@@ -774,7 +764,7 @@ extern "C" int aphro_scaled_mm_fp8_large(void* out, const void* a, const void* b
   p.a_per_token = a_scale_per_token; p.b_per_channel = b_scale_per_channel; p.out_bf16 = out_dtype == APHRO_BF16;
   p.tiles_m = pl.tiles_m; p.tiles_n = pl.tiles_n; p.streamk = pl.streamk; p.ksplit = pl.ksplit;
   p.flags = nullptr; p.partial = (float*)workspace;
-  p.debug = getenv("APHRO_FP8_LARGE_DEBUG") ? atoi(getenv("APHRO_FP8_LARGE_DEBUG")) : 0;
+  p.debug = APHRO_LAB_ENV_INT("APHRO_FP8_LARGE_DEBUG", 0);
   if (pl.streamk) {
     p.flags = (unsigned*)workspace;
     p.partial = (float*)((char*)workspace + FP8_LARGE_FLAG_BYTES);
@@ -786,14 +776,12 @@ extern "C" int aphro_scaled_mm_fp8_large(void* out, const void* a, const void* b
   int rc;
   // eight-phase schedule from 16 K tiles per output tile up: below that the longer prologue (seven half-tiles, the stagger
   // barriers) costs more than the K loop gains (K = 512 / 1024: 29.6 / 47.4 us against 25.8 / 43.6 for the two-stage kernel)
-  const int eight = getenv("APHRO_FP8_LARGE_8PHASE") ? atoi(getenv("APHRO_FP8_LARGE_8PHASE")) : (K >= 2048 ? 2 : 0);
+  const int eight_lab = APHRO_LAB_ENV_INT("APHRO_FP8_LARGE_8PHASE", -1);
+  const int eight = eight_lab >= 0 ? eight_lab : (K >= 2048 ? 2 : 0);
   if (pl.wm == 2 && pl.wn == 4 && pl.streamk && eight) {
     switch (eight) {
 #define F8_V(v) case v: rc = p.out_bf16 ? launch_fp8_large8_t<true, v>(p, pl.grid, st) : launch_fp8_large8_t<false, v>(p, pl.grid, st); break;
       F8_V(2)
-#ifdef F8_LAB
-      F8_V(1) F8_V(3) F8_V(4) F8_V(5) F8_V(6) F8_V(7)
-#endif
 #undef F8_V
       default: set_error("scaled_mm_fp8_large: unknown schedule variant %d", eight); return APHRO_ERR_INVALID;
     }

@@ -482,7 +482,6 @@ struct Fp8ResConfig { int nseg, nt, ksplit; };
 static Fp8ResConfig f8r_plan(int64_t M, int64_t N, int64_t K) {
   const Fp8ResConfig none = {0, 0, 0};
   if (M < 1 || M > 32 || K % 128 != 0 || N % 16 != 0 || (size_t)N * K >= 0x7fffffffull) return none;
-  if (getenv("APHRO_FP8_NO_RESIDENT")) return none;
   const int segs = (int)(K / 128);
   static const int cand[][2] = {{8, 7}, {7, 4}, {4, 3}, {2, 4}, {4, 4}, {8, 4}, {4, 2}, {8, 2}};
   for (const auto& cd : cand) {

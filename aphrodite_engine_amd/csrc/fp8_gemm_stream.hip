@@ -214,7 +214,7 @@ using namespace aphro;
 // K slices the streaming kernel needs for (M, N, K): 0 = not served.  K = slices x 8 waves x KS x 128 with KS <= 8.
 extern "C" int aphro_fp8_gemm_stream_ksplit(int64_t M, int64_t N, int64_t K) {
   if (M < 1 || M > 32 || N % 16 != 0 || N < 16 || K % 1024 != 0 || (size_t)N * K >= 0x7fffffffull) return 0;
-  if (getenv("APHRO_FP8_NO_STREAM")) return 0;
+  if (APHRO_LAB_ENV_INT("APHRO_FP8_NO_STREAM", 0)) return 0;
   // Measured in the decode step (bench.py --quant fp8ct, same box, against fp8_gemm_fast_kernel): gate_up [28672, 4096]
   // 31.8 -> 29.9 us, but down [4096, 14336] 16.4 -> 22.9 (two K slices), qkv 9.7 -> 13.4, o 6.7 -> 11.3: a workgroup needs
   // several 16-row tiles to amortise its prologue (the resident A gather) -- so only wide matrices whose K fits one
@@ -224,7 +224,7 @@ extern "C" int aphro_fp8_gemm_stream_ksplit(int64_t M, int64_t N, int64_t K) {
     if (segs % ks == 0) {
       const int split = segs / ks;
       if (split > 8) return 0;
-      if (!getenv("APHRO_FP8_STREAM_ALL") && (split != 1 || N / 16 < 4 * (int64_t)device_cu_count())) return 0;
+      if (!knobs().fp8_stream_all && (split != 1 || N / 16 < 4 * (int64_t)device_cu_count())) return 0;
       return split;
     }
   return 0;

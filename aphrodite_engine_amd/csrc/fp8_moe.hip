@@ -144,8 +144,8 @@ extern "C" int aphro_fp8_moe_gemm(const void* a, const void* w, const float* a_s
   if (num_valid == 0 || max_blocks == 0) return APHRO_OK;
   int nt = (N % 64 == 0) ? 4 : (N % 32 == 0) ? 2 : 1;
   int nw = 4;
-  if (const char* e = getenv("APHRO_FP8_MOE_NT")) { const int v = atoi(e); if ((v == 1 || v == 2 || v == 4) && N % (16 * v) == 0) nt = v; }
-  if (const char* e = getenv("APHRO_FP8_MOE_NW")) { const int v = atoi(e); if (v == 4 || v == 8) nw = v; }
+  { const int v = APHRO_LAB_ENV_INT("APHRO_FP8_MOE_NT", 0); if ((v == 1 || v == 2 || v == 4) && N % (16 * v) == 0) nt = v; }
+  { const int v = APHRO_LAB_ENV_INT("APHRO_FP8_MOE_NW", 0); if (v == 4 || v == 8) nw = v; }
   Fp8MoeParams p;
   p.a = (const uint8_t*)a; p.w = (const uint8_t*)w; p.a_scale = a_scale; p.b_scales = b_scales; p.topk_weights = topk_weights;
   p.sorted_ids = sorted_ids; p.expert_ids = expert_ids; p.num_post_pad = num_post_pad; p.c = c;

@@ -492,9 +492,9 @@ extern "C" int aphro_fused_add_rms_norm_pack(const void* input, const float* sla
                      slabs, nslab, (uint16_t*)residual, has_residual, (const uint16_t*)weight, eps,                         \
                      (uint16_t*)packed, (uint16_t*)out, (int)tokens, hidden)
 #define LS(NSV) do { if (dtype == APHRO_F16) L(Half, NSV); else L(BFloat, NSV); } while (0)
-  if (slabs != nullptr && nslab == 4 && !getenv("APHRO_NORM_GENERIC")) LS(4);
-  else if (slabs != nullptr && nslab == 2 && !getenv("APHRO_NORM_GENERIC")) LS(2);
-  else if (slabs != nullptr && nslab == 8 && !getenv("APHRO_NORM_GENERIC")) LS(8);
+  if (slabs != nullptr && nslab == 4 && !APHRO_LAB_ENV_INT("APHRO_NORM_GENERIC", 0)) LS(4);
+  else if (slabs != nullptr && nslab == 2 && !APHRO_LAB_ENV_INT("APHRO_NORM_GENERIC", 0)) LS(2);
+  else if (slabs != nullptr && nslab == 8 && !APHRO_LAB_ENV_INT("APHRO_NORM_GENERIC", 0)) LS(8);
   else LS(0);
 #undef LS
 #undef L

@@ -78,21 +78,10 @@ __global__ __launch_bounds__(512, 1) void lm_head_argmax_kernel(LmHeadParams p) 
 
   // this workgroup's vocabulary tiles: blockIdx.x, + G, + 2 G, ... (LMH_CONTIG: a contiguous run instead)
   const int G = gridDim.x;
-#ifdef LMH_CONTIG
-  const int per = p.tiles / G, extra = p.tiles % G;
-  const int t0 = blockIdx.x * per + min((int)blockIdx.x, extra);
-  const int t1 = t0 + per + ((int)blockIdx.x < extra ? 1 : 0);
-  const int tstep = 1;
-#else
   const int t0 = blockIdx.x, t1 = p.tiles, tstep = G;
-#endif
   // this wave's K slice: segments wave, wave + 8, ... (LMH_KBLOCK: KS consecutive segments) -- the eight waves' requests
   // for their s-th segment then cover 2 KiB of each row together
-#ifdef LMH_KBLOCK
-  auto kseg = [&](int s) { return (wave * KS + s) * 128; };
-#else
   auto kseg = [&](int s) { return (s * NWV + wave) * 128; };
-#endif
 
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.w), 0,
       (uint32_t)(((size_t)(p.V - 1) * p.ldw + p.K) * 2), 0x00020000);

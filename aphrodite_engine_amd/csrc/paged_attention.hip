@@ -84,16 +84,8 @@ struct PAParams {
   int nsplit;                    // 0 / 1: off
   float* split_scratch;          // [num_seqs * Hkv][nsplit][16 * HD + 32]
   unsigned* split_counter;       // [num_seqs * Hkv], zero between launches (the merging workgroup resets it)
-  unsigned long long* trace;     // PA_LAB builds (tools/attn_trace.py): [workgroup][wave][16] timeline stamps, or NULL
 };
 
-#ifdef PA_LAB
-#define PA_STAMP(i) do { if (p.trace) { __builtin_amdgcn_sched_barrier(0); stamp[i] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } } while (0)
-#define PA_WAIT_DATA() do { if (p.trace) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); } while (0)
-#else
-#define PA_STAMP(i) do { } while (0)
-#define PA_WAIT_DATA() do { } while (0)
-#endif
 
 // write-through (system-scope) store / coherent loads: partial results cross XCDs (separate L2s) inside one launch.  No
 // release / acquire FENCES: at agent scope those write back / invalidate the whole L2 (+16 us per launch).
@@ -184,12 +176,6 @@ __global__ __launch_bounds__(NW * 64) void paged_attention_kernel(const int32_t*
   const int wave = threadIdx.x >> 6;
   const int g = lane >> 4;
   const int c = lane & 15;
-#ifdef PA_LAB
-  unsigned long long stamp[16] = {};
-  const unsigned long long wall0 = __builtin_amdgcn_s_memrealtime();
-  int it_count = 0;
-#endif
-  PA_STAMP(0);
   const int kvh = blockIdx.x;
   const int seq = blockIdx.y;
   const int part = blockIdx.z;
@@ -516,9 +502,6 @@ __global__ __launch_bounds__(NW * 64) void paged_attention_kernel(const int32_t*
         }
       }
     }
-#ifdef PA_LAB
-    if constexpr (fused_rope) PA_STAMP(11);             // fused: q slab / cos-sin loads issued
-#endif
     // ---- Q fragments (B operand: lane (g, head) holds 8 consecutive d) --------
     // fused form: rotated from the qkv slabs INSIDE the first loop iteration, after that
     // iteration's K/V loads have been issued (their HBM latency covers the slab round trip)
@@ -542,16 +525,7 @@ __global__ __launch_bounds__(NW * 64) void paged_attention_kernel(const int32_t*
       for (; pr < pair_end; pr += NW) {
         load_pair(pr, ids, kfa, vra);
         if (pr + NW < pair_end) load_ids(pr + NW, ids_next);
-#ifdef PA_LAB
-        if (it_count == 0) PA_STAMP(1);                 // first pair's loads issued
-        PA_WAIT_DATA();
-        if (it_count < 6) PA_STAMP(2 + 2 * it_count);   // pair i: data has arrived
-#endif
         compute_pair(pr, kfa, vra);
-#ifdef PA_LAB
-        if (it_count < 6) PA_STAMP(3 + 2 * it_count);   // pair i: compute issued
-        ++it_count;
-#endif
 #pragma unroll
         for (int e = 0; e < 4; ++e) ids[e] = ids_next[e];
       }
@@ -561,9 +535,6 @@ __global__ __launch_bounds__(NW * 64) void paged_attention_kernel(const int32_t*
     const bool defer_first = kv_owner && have && pr + NW >= pair_end;
     if (have && !defer_first) load_pair(pr, ids, kfa, vra);
     if (have && pr + NW < pair_end) load_ids(pr + NW, ids_next);
-#ifdef PA_LAB
-    if constexpr (fused_rope) PA_STAMP(12);             // fused: first pair's K/V loads issued
-#endif
     if constexpr (fused_rope) {
       // ---- q of the new token: slab reduce + rotary, ONCE per workgroup, one (d, d + hd/2) pair per
       // thread, through LDS.  The slab / cos-sin loads were issued above (before the K/V loads: the
@@ -582,9 +553,6 @@ __global__ __launch_bounds__(NW * 64) void paged_attention_kernel(const int32_t*
           }
         }
       }
-#ifdef PA_LAB
-      PA_STAMP(13);                                     // fused: this wave's share of q rotated and in LDS (slab data arrived)
-#endif
       __syncthreads();
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks) {
@@ -605,16 +573,7 @@ __global__ __launch_bounds__(NW * 64) void paged_attention_kernel(const int32_t*
       }
     }
     while (have) {
-#ifdef PA_LAB
-      if (it_count == 0) PA_STAMP(1);                   // (fused form: q phase done, first pair's loads long issued)
-      PA_WAIT_DATA();
-      if (it_count < 4) PA_STAMP(2 + 2 * it_count);     // (stamps 11..13 belong to the fused prologue)
-#endif
       compute_pair(pr, kfa, vra);
-#ifdef PA_LAB
-      if (it_count < 4) PA_STAMP(3 + 2 * it_count);
-      ++it_count;
-#endif
       pr += NW;
       have = pr < pair_end;
       if (have) {
@@ -633,7 +592,6 @@ __global__ __launch_bounds__(NW * 64) void paged_attention_kernel(const int32_t*
 
     // ---- merge the NW waves through LDS ---------------------------------------------
     // layout: ml[NW][16][2] then ov[NW][16 heads][HD]
-    PA_STAMP(14);
     l_run += __shfl_xor(l_run, 16, 64);
     l_run += __shfl_xor(l_run, 32, 64);
     float* ml = lds;
@@ -780,20 +738,6 @@ __global__ __launch_bounds__(NW * 64) void paged_attention_kernel(const int32_t*
         }
       }
     }
-#ifdef PA_LAB
-    if (p.trace && hb == 0) {
-      PA_STAMP(15);
-      if (lane == 0) {
-        unsigned long long* t = p.trace + ((((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * NW + wave) * 20;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) t[i] = stamp[i];
-        t[16] = wall0;
-        t[17] = __builtin_amdgcn_s_memrealtime();
-        t[18] = __builtin_amdgcn_s_getreg(((32 - 1) << 11) | 20);    // HW_REG_XCC_ID
-        t[19] = (unsigned long long)it_count;
-      }
-    }
-#endif
   }
 }
 
@@ -972,10 +916,6 @@ static bool split_workspace(size_t groups, size_t floats, hipStream_t st, SplitW
   return true;
 }
 
-static unsigned long long* g_pa_trace = nullptr;
-// PA_LAB builds: device buffer of [workgroups][waves][20] u64 the next launches stamp their timeline into (NULL: off).
-extern "C" void aphro_paged_attention_set_trace(void* buf) { g_pa_trace = (unsigned long long*)buf; }
-
 static int paged_attention_impl(void* out, void* out_packed, float* exp_sums, float* max_logits, void* tmp_out,
                                      const void* query, const void* key_cache, const void* value_cache,
                                      int num_seqs, int num_heads, int num_kv_heads, int head_size,
@@ -1034,7 +974,6 @@ static int paged_attention_impl(void* out, void* out_packed, float* exp_sums, fl
   p.nh_lds = gqa < 16 ? gqa : 16;
   int parts = 1, nw;
   p.nsplit = 0; p.split_scratch = nullptr; p.split_counter = nullptr;
-  p.trace = g_pa_trace;
   if (partition_size == 0) {
     p.partition_size = 0; p.max_parts = 0; p.write_direct = 1;
     // v1 form: one workgroup per (seq, kv head) walks the whole sequence
@@ -1048,7 +987,7 @@ static int paged_attention_impl(void* out, void* out_packed, float* exp_sums, fl
       int want = groups >= cus ? 1 : (int)((2 * cus + groups - 1) / groups);
       const int max_pairs = (max_seq_len + 31) / 32;
       if (want > max_pairs / 8) want = max_pairs / 8;
-      if (const char* e = getenv("APHRO_PA_SPLITS")) want = atoi(e);
+      if (knobs().pa_splits > 0) want = knobs().pa_splits;
       want = want > 8 ? 8 : want;
       if (want > 1) {
         SplitWs* ws = nullptr;

@@ -14,6 +14,35 @@ void set_error(const char* fmt, ...) {
 }
 }  // namespace aphro
 
+// ---- the environment (common.h: Knobs) ------------------------------------------------------------------------------------
+namespace aphro {
+static int env_i(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+static long env_l(const char* name, long dflt) { const char* e = getenv(name); return e ? atol(e) : dflt; }
+static Knobs read_knobs() {
+  Knobs k;
+  k.pa_splits = env_i("APHRO_PA_SPLITS", 0);
+  k.fa_v4_min_keys = env_i("APHRO_FA_V4_MIN_KEYS", 4096);
+  k.fa_no_xcd = env_i("APHRO_FA_NO_XCD", 0);
+  k.fp8_stream_all = env_i("APHRO_FP8_STREAM_ALL", 0);
+  k.wna16_stream = env_i("APHRO_WNA16_STREAM", 1);
+  k.wna16_op_no_resident = env_i("APHRO_WNA16_OP_NO_RESIDENT", 0);
+  k.wna16_large_8phase = env_i("APHRO_WNA16_LARGE_8PHASE", -1);
+  k.wna16_mid_waves = env_i("APHRO_WNA16_MID_WAVES", 0);
+  k.res_cfg_set = 0;
+  k.res_cfg[0] = k.res_cfg[1] = k.res_cfg[2] = k.res_cfg[3] = 0;
+  if (const char* e = getenv("APHRO_WNA16_RES_CFG"))
+    k.res_cfg_set = sscanf(e, "%d,%d,%d,%d", &k.res_cfg[0], &k.res_cfg[1], &k.res_cfg[2], &k.res_cfg[3]) == 4 ? 1 : -1;
+  k.ar_one_shot_max = env_l("APHRO_CUSTOM_AR_ONE_SHOT_MAX", -1);
+  k.ar_timeout_ms = env_l("APHRODITE_CUSTOM_AR_TIMEOUT_MS", 0);
+  k.cu_masked = (getenv("HSA_CU_MASK") || getenv("ROC_GLOBAL_CU_MASK")) ? 1 : 0;
+  return k;
+}
+static Knobs g_knobs = read_knobs();
+const Knobs& knobs() { return g_knobs; }
+}  // namespace aphro
+// Re-read the environment switches (a test or a tool that changed one inside the process; never needed on a serving path).
+extern "C" void aphro_reload_env(void) { aphro::g_knobs = aphro::read_knobs(); }
+
 extern "C" const char* aphro_last_error(void) { return aphro::g_err; }
 extern "C" int aphro_abi_version(void) { return 1; }
 

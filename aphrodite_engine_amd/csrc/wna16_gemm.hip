@@ -214,23 +214,11 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, ui
 
 template <typename T, int VEC, int MT, int NSEG>
 __global__ __launch_bounds__(FNW * 64, (VEC * MT >= 8) ? 2 : 3) void wna16_gemm_kernel(Wna16Params p) {
-#ifdef ABL_DEPTH
-  constexpr int DEPTH = NSEG < ABL_DEPTH ? NSEG : ABL_DEPTH;
-#else
   constexpr int DEPTH = NSEG < 2 ? NSEG : 2;  // weight segments in flight ahead of the consumer
-#endif
   constexpr int NBUF = DEPTH + 1;
-#ifdef ABL_ADEPTH
-  constexpr int ADEPTH = NSEG < ABL_ADEPTH ? NSEG : ABL_ADEPTH;   // experiment: A fragments this many segments ahead
-#else
   constexpr int ADEPTH = 1;
-#endif
   constexpr int NA = ADEPTH + 1;
-#ifdef ABL_WAUX
-  constexpr int AUX_NT = ABL_WAUX;
-#else
   constexpr int AUX_NT = 2;  // nontemporal: weights are read exactly once
-#endif
   extern __shared__ __attribute__((aligned(16))) float red[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -324,11 +312,7 @@ __global__ __launch_bounds__(FNW * 64, (VEC * MT >= 8) ? 2 : 3) void wna16_gemm_
     for (int u = 0; u < 4; ++u)
 #pragma unroll
       for (int i = 0; i < MT; ++i)
-#ifdef ABL_AAUX
-        ad[u][i] = __builtin_amdgcn_raw_buffer_load_b128(ra, voff_a[i], ((seg0 + s) * 4 + u) * abytes, ABL_AAUX);
-#else
         ad[u][i] = __builtin_amdgcn_raw_buffer_load_b128(ra, voff_a[i], ((seg0 + s) * 4 + u) * abytes, 0);
-#endif
   };
 
   // ---- prologue: meta(0), A(0), W(0..DEPTH-1) ---------------------------------------
@@ -344,9 +328,7 @@ __global__ __launch_bounds__(FNW * 64, (VEC * MT >= 8) ? 2 : 3) void wna16_gemm_
     // straight-line code (NSEG is a template constant): hipcc's waitcnt insertion degrades to
     // vmcnt(0) around runtime-conditional loads, and the issue points are pinned with
     // sched_barrier (the scheduler otherwise sinks loads next to their first use).
-#ifndef ABL_NO_A
     if (s + ADEPTH < NSEG) load_a(af[(s + ADEPTH) % NA], s + ADEPTH);
-#endif
     if (s + DEPTH < NSEG) load_w(w[(s + DEPTH) % NBUF], s + DEPTH);
     if (s + 1 < NSEG) load_meta(meta[(s + 1) & 1], s + 1);
     __builtin_amdgcn_sched_barrier(0);
@@ -361,16 +343,10 @@ __global__ __launch_bounds__(FNW * 64, (VEC * MT >= 8) ? 2 : 3) void wna16_gemm_
         // they weigh 16x, so those four k of the A fragment are scaled by 1/16
         // (inline asm on the integer lanes: hipcc miscompiles a bitcast of one vector element)
         u32x4 av = af[s % NA][u][i];
-#ifndef ABL_NO_PKMUL   // (timing experiments only: tools/gemm_ablate.hip)
         asm("v_pk_mul_f16 %0, %1, %2" : "=v"(av[1]) : "v"(av[1]), "s"(0x2c002c00u));
         asm("v_pk_mul_f16 %0, %1, %2" : "=v"(av[3]) : "v"(av[3]), "s"(0x2c002c00u));
-#endif
         a[i] = __builtin_bit_cast(f16x8, av);
-#ifndef ABL_NO_RS
         rs[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], ones, u == 0 ? zero4 : rs[i], 0, 0, 0);
-#else
-        rs[i] = zero4;
-#endif
       }
 #pragma unroll
       for (int t = 0; t < VEC; ++t) {
@@ -683,16 +659,11 @@ struct Wna16Plan {
   bool fast;
 };
 
-static int env_int(const char* name, int dflt) {
-  const char* v = getenv(name);
-  return v ? atoi(v) : dflt;
-}
-
 static Wna16Plan make_plan(int64_t M, int64_t N, int64_t K, int64_t gs, int64_t ztiles = 0) {
   Wna16Plan pl;
   pl.nseg = 0;
   pl.vec = (N % 64 == 0) ? 4 : (N % 32 == 0) ? 2 : 1;
-  int fv = env_int("APHRO_WNA16_VEC", 0);
+  int fv = APHRO_LAB_ENV_INT("APHRO_WNA16_VEC", 0);
   if (fv == 1 || fv == 2 || fv == 4) {
     if (N % (16 * fv) == 0) pl.vec = fv;
   }
@@ -704,10 +675,10 @@ static Wna16Plan make_plan(int64_t M, int64_t N, int64_t K, int64_t gs, int64_t 
   const int total_segs = (int)((K + 127) / 128);
   const int64_t gq = gs >> 7;
   pl.fast = (K % 128 == 0 && gs % 128 == 0 && (gq & (gq - 1)) == 0 && pl.vec >= 2 &&
-             (K / 8) * N * 4 < (int64_t)0xffffffff) && !env_int("APHRO_WNA16_GENERIC", 0);
+             (K / 8) * N * 4 < (int64_t)0xffffffff) && !APHRO_LAB_ENV_INT("APHRO_WNA16_GENERIC", 0);
   if (pl.fast) {
     // every wave owns exactly NSEG segments; ksplit = total_segs / (FNW * NSEG) fp32 slabs.
-    const int fk = env_int("APHRO_WNA16_KSPLIT", 0);
+    const int fk = APHRO_LAB_ENV_INT("APHRO_WNA16_KSPLIT", 0);
     int best_ns = 0, best_split = 0;
     for (int split = 1; split <= 8; ++split) {
       if (total_segs % (split * FNW) != 0) continue;
@@ -728,7 +699,7 @@ static Wna16Plan make_plan(int64_t M, int64_t N, int64_t K, int64_t gs, int64_t 
   }
   int target = (int)((256 + tiles / 2) / tiles);
   target = target < 1 ? 1 : (target > 8 ? 8 : target);
-  int fk = env_int("APHRO_WNA16_KSPLIT", 0);
+  int fk = APHRO_LAB_ENV_INT("APHRO_WNA16_KSPLIT", 0);
   if (fk > 0) target = fk;
   while (target > 1 && total_segs / target < 1) --target;
   int segs = (total_segs + target - 1) / target;
@@ -745,7 +716,7 @@ static void launch_wna16(const Wna16Params& p_in, const Wna16Plan& pl, hipStream
     if constexpr (VEC >= 2) {
       Wna16Params p = p_in;
       const unsigned per = pl.ksplit > 1 && 8 % pl.ksplit == 0 ? 8u / (unsigned)pl.ksplit : 0u;
-      const bool remap = per > 0 && grid.z == 1 && p.expert_ids == nullptr && grid.x % per == 0 && !env_int("APHRO_WNA16_NO_XCD_REMAP", 0);
+      const bool remap = per > 0 && grid.z == 1 && p.expert_ids == nullptr && grid.x % per == 0 && !APHRO_LAB_ENV_INT("APHRO_WNA16_NO_XCD_REMAP", 0);
       p.xcd_remap = remap ? (per == 4 ? 3 : per == 2 ? 2 : 1) : 0;
       p.xcd_tiles = remap ? (int)(grid.x / per) : 0;
       size_t lds = (size_t)FNW * MT * VEC * 64 * 4 * sizeof(float);

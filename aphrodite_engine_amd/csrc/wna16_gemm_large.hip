@@ -820,7 +820,7 @@ static int launch_large(const Wna16LargeParams& p, hipStream_t st) {
   constexpr int BM = 128 * WM, BN = 64 * WN;
   const int G = WFP8 ? 0 : (p.streamk ? p.K / p.group_size : p.K / p.ksplit / p.group_size);
   const size_t lds3 = 3 * ((size_t)BM * 64 * 2 + (WFP8 ? (size_t)BN * 64 : (size_t)8 * BN * 4)) + (size_t)G * BN * 2 + (size_t)G * (BN / 8) * 4;
-  static const int force = getenv("APHRO_WNA16_LARGE_STAGES") ? atoi(getenv("APHRO_WNA16_LARGE_STAGES")) : 0;
+  const int force = APHRO_LAB_ENV_INT("APHRO_WNA16_LARGE_STAGES", 0);
   if ((lds3 <= 160 * 1024 && force != 2) || force == 3) return launch_large_s<WM, WN, 3, WFP8>(p, st);
   return launch_large_s<WM, WN, 2, WFP8>(p, st);
 }
@@ -842,7 +842,7 @@ static LargePlan large_plan(int64_t M, int64_t N, int64_t K, int64_t gs) {
   LargePlan pl;
   pl.wm = M > 128 ? 2 : 1;
   const int64_t rows = (M + 128 * pl.wm - 1) / (128 * pl.wm);
-  static const int mode = getenv("APHRO_WNA16_LARGE_STREAMK") ? atoi(getenv("APHRO_WNA16_LARGE_STREAMK")) : -1;
+  const int mode = APHRO_LAB_ENV_INT("APHRO_WNA16_LARGE_STREAMK", -1);
   const int64_t big_tiles = N % 256 == 0 ? rows * (N / 256) : rows * (N / 128);
   pl.streamk = (mode >= 0 ? mode : (big_tiles >= 128)) && device_coresident_cu_count() > 0;
   pl.ksplit = 1;
@@ -853,7 +853,7 @@ static LargePlan large_plan(int64_t M, int64_t N, int64_t K, int64_t gs) {
     return pl;
   }
   pl.wn = (N % 256 == 0 && rows * (N / 256) >= 200) ? 4 : 2;
-  if (const char* e = getenv("APHRO_WNA16_LARGE_WN")) { const int v = atoi(e); if (v == 2 || (v == 4 && N % 256 == 0)) pl.wn = v; }
+  { const int v = APHRO_LAB_ENV_INT("APHRO_WNA16_LARGE_WN", 0); if (v == 2 || (v == 4 && N % 256 == 0)) pl.wn = v; }
   const int64_t tiles = rows * (N / (64 * pl.wn));
   const int64_t unit = gs > 64 ? gs : 64;           // a K range holds whole groups and whole K tiles
   // K slices until ~800 waves exist (a 2-wave workgroup fills half a CU's SIMDs: 400 of those), as long as the fp32
@@ -865,7 +865,7 @@ static LargePlan large_plan(int64_t M, int64_t N, int64_t K, int64_t gs) {
     if (tiles * pl.ksplit >= want) break;
     if (K % (s * unit) == 0 && K / s >= 512 && s * slab <= (36ll << 20)) pl.ksplit = s;
   }
-  if (const char* e = getenv("APHRO_WNA16_LARGE_KSPLIT")) { const int s = atoi(e); if (s >= 1 && K % (s * unit) == 0) pl.ksplit = s; }
+  { const int s = APHRO_LAB_ENV_INT("APHRO_WNA16_LARGE_KSPLIT", 0); if (s >= 1 && K % (s * unit) == 0) pl.ksplit = s; }
   return pl;
 }
 
@@ -938,8 +938,8 @@ static int wna16_gemm_large_impl(const void* a, const uint32_t* q_weight, const 
   p.w8 = nullptr; p.w_scales = nullptr; p.w_per_channel = 0; p.bias = nullptr;
   if (int rcb = large_bind_scratch(p, pl, ws, st)) return rcb;
   int rc;
-  // eight-phase schedule on the 256 x 256 stream-K tile from 32 K tiles per output tile up (lab switch: read per call)
-  const int eight = getenv("APHRO_WNA16_LARGE_8PHASE") ? atoi(getenv("APHRO_WNA16_LARGE_8PHASE")) : (K >= 2048 ? 1 : 0);
+  // eight-phase schedule on the 256 x 256 stream-K tile from 32 K tiles per output tile up (APHRO_WNA16_LARGE_8PHASE=0/1 forces)
+  const int eight = knobs().wna16_large_8phase >= 0 ? knobs().wna16_large_8phase : (K >= 2048 ? 1 : 0);
   if (pl.wm == 2 && pl.wn == 4 && pl.streamk && eight) rc = launch_large8(p, st);
   else if (pl.wm == 2) rc = pl.wn == 4 ? launch_large<2, 4>(p, st) : launch_large<2, 2>(p, st);
   else rc = pl.wn == 4 ? launch_large<1, 4>(p, st) : launch_large<1, 2>(p, st);

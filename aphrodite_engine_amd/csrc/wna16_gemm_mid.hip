@@ -401,13 +401,13 @@ static MidPlan mid_plan(int64_t M, int64_t N, int64_t K, int64_t gs) {
   pl.ksplit = 1;
   const int64_t tiles = N / 128;
   pl.nwk = (tiles >= 200 && K % (8 * gs) == 0) ? 8 : 4;
-  if (const char* e = getenv("APHRO_WNA16_MID_WAVES")) { const int v = atoi(e); if (v == 4 || (v == 8 && K % (8 * gs) == 0)) pl.nwk = v; }
+  { const int v = knobs().wna16_mid_waves; if (v == 4 || (v == 8 && K % (8 * gs) == 0)) pl.nwk = v; }
   if (pl.nwk == 4)
     for (int s = 2; s <= 32; ++s) {
       if (tiles * pl.ksplit >= 200) break;      // (down_proj at M = 64: 7 slices 23.7 us, 14 slices 28.9 us)
       if (K % (4 * s * gs) == 0 && K / (4 * s) >= 128) pl.ksplit = s;
     }
-  if (const char* e = getenv("APHRO_WNA16_MID_KSPLIT")) { const int s = atoi(e); if (s >= 1 && K % (pl.nwk * s * gs) == 0) pl.ksplit = s; }
+  { const int s = APHRO_LAB_ENV_INT("APHRO_WNA16_MID_KSPLIT", 0); if (s >= 1 && K % (pl.nwk * s * gs) == 0) pl.ksplit = s; }
   return pl;
 }
 

@@ -861,7 +861,7 @@ static ResConfig res_plan32(int64_t M, int64_t N, int64_t K, int64_t gs);
 static ResConfig res_plan(int64_t M, int64_t N, int64_t K, int64_t gs) {
   if (M <= 32) return res_plan32(M, N, K, gs);
   ResConfig none = {0, 0, 0, 0, 0};
-  if (M > 64 || getenv("APHRO_WNA16_NO_ROW_HALVES")) return none;
+  if (M > 64 || APHRO_LAB_ENV_INT("APHRO_WNA16_NO_ROW_HALVES", 0)) return none;
   const ResConfig cf = res_plan32(32, N, K, gs);
   return cf.nwv != 0 && res_stream_instantiated(cf.nwv, cf.nseg, cf.np4, cf.rem) ? cf : none;
 }
@@ -876,11 +876,11 @@ static ResConfig res_plan32(int64_t M, int64_t N, int64_t K, int64_t gs) {
     if (!res_instantiated(nwv, nseg, np4, rem) || N % cw != 0 || segs % (nwv * nseg) != 0) return 0;
     return segs / (nwv * nseg);
   };
-  if (const char* e = getenv("APHRO_WNA16_RES_CFG")) {
-    int a = 0, b = 0, c2 = 0, d = 0;
-    if (sscanf(e, "%d,%d,%d,%d", &a, &b, &c2, &d) == 4) {
-      const int ks = fits(a, b, c2, d);
-      if (ks > 0 && ks <= 16) return ResConfig{a, b, c2, d, ks};
+  if (knobs().res_cfg_set != 0) {
+    if (knobs().res_cfg_set > 0) {
+      const int* rc4 = knobs().res_cfg;
+      const int ks = fits(rc4[0], rc4[1], rc4[2], rc4[3]);
+      if (ks > 0 && ks <= 16) return ResConfig{rc4[0], rc4[1], rc4[2], rc4[3], ks};
     }
     return none;
   }
@@ -998,7 +998,7 @@ static int res_dispatch(const Wna16ResParams& p, const ResConfig& cf, hipStream_
   if (p.a == nullptr && p.strip_layout) {
     // packed activations on strip-major weights: the single-pass stream kernel where it is instantiated
     // (APHRO_WNA16_STREAM=0: the two-pass resident kernel, 32 rows at most)
-    static const bool stream = [] { const char* e = getenv("APHRO_WNA16_STREAM"); return !e || atoi(e) != 0; }();
+    const bool stream = knobs().wna16_stream != 0;
 #define X(a, b, c, d, r)                                                                 \
     if (stream && cf.nwv == a && cf.nseg == b && cf.np4 == c && cf.rem == d)             \
       return mt == 2 ? res_launch_stream<2, a, b, c, d, r>(p, st) : res_launch_stream<1, a, b, c, d, r>(p, st);
@@ -1095,7 +1095,7 @@ static unsigned* res_counters(hipStream_t st) {
 
 // 1: aphro_wna16_gemm_rowmajor serves this call (f16 activations, M <= 32, a shape the resident kernel tiles).
 extern "C" int aphro_wna16_gemm_rowmajor_supported(int64_t M, int64_t N, int64_t K, int64_t groups, int dtype) {
-  if (dtype != APHRO_F16 || M > 32 || groups <= 0 || K % groups != 0 || getenv("APHRO_WNA16_OP_NO_RESIDENT")) return 0;
+  if (dtype != APHRO_F16 || M > 32 || groups <= 0 || K % groups != 0 || knobs().wna16_op_no_resident) return 0;
   const ResConfig cf = res_plan(M, N, K, K / groups);
   if (cf.nwv == 0 || N / (64 * cf.np4 + 16 * cf.rem) > RES_COUNTERS) return 0;
 #define X(a, b, c, d) if (cf.nwv == a && cf.nseg == b && cf.np4 == c && cf.rem == d) return 1;

@@ -11,6 +11,7 @@ import contextlib
 from typing import Optional
 
 import torch
+from ..switches import switch
 import torch.distributed as dist
 
 _TP_GROUP: Optional[dist.ProcessGroup] = None
@@ -341,7 +342,7 @@ class DeferredAllReduce:
         through the Infinity Cache by extra workgroups of the same launch.  Off by default: on the one-GPU loopback rig
         the longer launch cost more than the warmer weights returned (profiles/r5_ar_norm_fused.txt)."""
         import os
-        if os.environ.get("APHRO_AR_PREFETCH") != "1":
+        if switch("APHRO_AR_PREFETCH") != "1":
             prefetch = None
         res = tensor_model_parallel_all_reduce_norm(self.partial, residual, True, weight, epsilon, pack=pack,
                                                     want_out=want_out, prefetch=prefetch)
@@ -360,7 +361,7 @@ def defer_all_reduce(partial: torch.Tensor) -> Optional["DeferredAllReduce"]:
     out), else None: the caller all-reduces now."""
     import os
     if (_TP_SIZE == 1 or _CUSTOM_AR is None or _OVERLAP is not None or not partial.is_cuda
-            or os.environ.get("APHRO_NO_FUSED_AR_NORM") == "1" or _CUSTOM_AR.disabled
+            or switch("APHRO_NO_FUSED_AR_NORM") == "1" or _CUSTOM_AR.disabled
             or not _CUSTOM_AR.fused_norm_eligible(partial)):
         return None
     return DeferredAllReduce(partial)

@@ -28,6 +28,7 @@ from typing import List, Optional, Tuple, Union
 import torch
 import torch.distributed as dist
 
+from ..switches import switch
 from .. import _lib
 from .._lib import check
 
@@ -64,7 +65,7 @@ class CustomAllreduce:
         self.device = device
         self.rank, self.world_size, self.max_size = rank, world_size, max_size
         self._calls = 0
-        self._check_every = int(os.environ.get("APHRODITE_CUSTOM_AR_CHECK_EVERY", "256"))
+        self._check_every = int((switch("APHRODITE_CUSTOM_AR_CHECK_EVERY") or "256"))
         ok, why = self._peers_eligible(device)
         self.full_nvlink = ok              # one xGMI hop between any two GPUs of the node
         if not ok:

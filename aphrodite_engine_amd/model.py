@@ -18,6 +18,7 @@ from typing import List, Optional
 import torch
 from torch import nn
 
+from .switches import switch
 from . import _custom_ops as ops
 from .attention.backend import MI355XAttentionImpl, MI355XAttentionMetadata
 from .moe import DeferredCombine
@@ -229,7 +230,7 @@ class LlamaDecoderLayer(nn.Module):
         #  the 33..64-row kernel on the one-GPU shapes: gate_up 29.6-30.7 us against 26.8, down 17.3 against 14.2 at batch 64,
         #  a CU takes in both halves' activations AND the weights twice; APHRO_DECODE_ROW_HALVES=1 builds the copies anyway)
         self.gate_up_strip = None
-        if m <= (64 if os.environ.get("APHRO_DECODE_ROW_HALVES") == "1" else 32) and not os.environ.get("APHRO_DECODE_NO_RESIDENT") \
+        if m <= (64 if switch("APHRO_DECODE_ROW_HALVES") == "1" else 32) and not switch("APHRO_DECODE_NO_RESIDENT") \
                 and ops.wna16_resident_ksplit(m, lin.out_features, lin.in_features, sc.shape[0]) == 1:
             self.gate_up_strip = ops.wna16_strip_relayout(qw, m, sc.shape[0])
         # The op-level strip-major copy the quant method made at load time (gptq.py / awq.py process_weights_after_loading,
@@ -265,7 +266,7 @@ class LlamaDecoderLayer(nn.Module):
         prefill); APHRO_DECODE_NO_FP8_RESIDENT=1 keeps the round-3 kernels."""
         self.fp8_strip = {}
         self.fp8_gate_up_il = None      # round 6: the gate_up strip copy with (gate_j, up_j) adjacent -- SiluAndMul in the epilogue
-        if os.environ.get("APHRO_DECODE_NO_FP8_RESIDENT") or self.is_moe:
+        if switch("APHRO_DECODE_NO_FP8_RESIDENT") or self.is_moe:
             return
         for name in ("qkv_proj", "o_proj", "gate_up_proj", "down_proj"):
             lin = getattr(self, name)
@@ -275,7 +276,7 @@ class LlamaDecoderLayer(nn.Module):
             wt = w.t()                                   # the [N, K] checkpoint tensor behind the column-major [K, N] view
             if wt.is_contiguous() and ops.fp8_gemm_resident_ksplit(m, wt.shape[0], wt.shape[1]) > 0:
                 # (a TP rank under the dynamic scheme keeps the plain copy: its down projection is not on the quantise-on-load form)
-                if name == "gate_up_proj" and getattr(lin, "bias", None) is None and not os.environ.get("APHRO_FP8_NO_LAUNCH_DIET") \
+                if name == "gate_up_proj" and getattr(lin, "bias", None) is None and not switch("APHRO_FP8_NO_LAUNCH_DIET") \
                         and (self.tp == 1 or getattr(lin, "input_scale", None) is not None) \
                         and ops.fp8_gemm_resident_silu_supported(m, wt.shape[0], wt.shape[1]):
                     self.fp8_gate_up_il = ops.fp8_strip_relayout_interleaved(wt, m)     # instead of, not beside, the plain strip copy
@@ -295,7 +296,7 @@ class LlamaDecoderLayer(nn.Module):
         8.2 -> 7.1 us and 11.4 -> 10.5 us, profiles/r3_resident_bench.txt; round 4, single-pass stream kernel: qkv 6.65,
         down 9.84, o_proj 5.58 -> 4.98 us, profiles/r4_gemm_lab.txt)."""
         self.strip = {}
-        if m > 64 or os.environ.get("APHRO_DECODE_NO_RESIDENT"):
+        if m > 64 or switch("APHRO_DECODE_NO_RESIDENT"):
             return
         # gate_up_proj: the NON-interleaved [gate | up] matrix, for layers whose SiluAndMul does not ride in the GEMM epilogue
         # (K-sliced gate_up of a TP shard: slabs -> silu_and_mul_pack(slabs=...))
@@ -313,7 +314,7 @@ class LlamaDecoderLayer(nn.Module):
                 continue
             # <= 32 rows: only where the resident plan keeps the round-2 kernel's K slices (the consumers were tuned to those
             # slab counts); 33..64 rows (two 32-row halves): opt-in, see enable_fused_silu
-            if m > 32 and os.environ.get("APHRO_DECODE_ROW_HALVES") != "1":
+            if m > 32 and switch("APHRO_DECODE_ROW_HALVES") != "1":
                 continue
             if rks > 0 and (m > 32 or rks == ops.wna16_ksplit(m, n, k, g)) and (k // 8) * n * 4 >= 2 ** 23:
                 self.strip[name] = ops.wna16_strip_relayout(qw, m, g)
@@ -327,7 +328,7 @@ class LlamaDecoderLayer(nn.Module):
         #  the strip-major copy serves <= 32 rows; 33..64 rows only with the opt-in row halves AND a plan the
         # stream kernel is instantiated for (an 8192 x 8192 o_proj plans to {4, 8, 1, 0}: no stream form) -- otherwise the
         # round-2 kernel on the [K/8, N] layout, as before round 4
-        if st is not None and m > 32 and not (m <= 64 and os.environ.get("APHRO_DECODE_ROW_HALVES") == "1"
+        if st is not None and m > 32 and not (m <= 64 and switch("APHRO_DECODE_ROW_HALVES") == "1"
                                               and ops.wna16_resident_ksplit(m, lin.out_features, lin.in_features, sc.shape[0]) > 0):
             st = None
         if st is not None:
@@ -421,7 +422,7 @@ class LlamaDecoderLayer(nn.Module):
             if self.tp > 1:
                 o = ops.wna16_gemm_packed(attn_packed, m, self.q_size, qw, qz, sc, zo, partials=False)
                 o = tensor_model_parallel_all_reduce(o)
-                if self.moe_gate.shape[0] <= 16 and not os.environ.get("APHRO_MOE_NO_NORM_ROUTER"):
+                if self.moe_gate.shape[0] <= 16 and not switch("APHRO_MOE_NO_NORM_ROUTER"):
                     normed, logits = ops.fused_add_rms_norm_router(o, None, residual, True,
                                                                    self.post_attention_layernorm, eps, self.moe_gate)
                     return self.moe_block(normed, logits, defer_all_reduce=True), None
@@ -429,12 +430,12 @@ class LlamaDecoderLayer(nn.Module):
                                                         eps, pack=False, want_out=True)
             else:
                 o_slabs, _ = ops.wna16_gemm_packed(attn_packed, m, self.q_size, qw, qz, sc, zo, partials=True)
-                if self.moe_gate.shape[0] <= 16 and not os.environ.get("APHRO_MOE_NO_NORM_ROUTER"):
+                if self.moe_gate.shape[0] <= 16 and not switch("APHRO_MOE_NO_NORM_ROUTER"):
                     # the router's logits come out of the norm launch (no [M, E] library GEMM launch)
                     normed, logits = ops.fused_add_rms_norm_router(None, o_slabs, residual, True,
                                                                    self.post_attention_layernorm, eps, self.moe_gate)
                     return self.moe_block(normed, logits,
-                                          defer_combine=not os.environ.get("APHRO_MOE_NO_DEFERRED_COMBINE")), None
+                                          defer_combine=not switch("APHRO_MOE_NO_DEFERRED_COMBINE")), None
                 _, normed = ops.fused_add_rms_norm_pack(None, o_slabs, residual, True,
                                                         self.post_attention_layernorm, eps, pack=False,
                                                         want_out=True)
@@ -460,10 +461,10 @@ class LlamaDecoderLayer(nn.Module):
                                                      self.post_attention_layernorm, eps)
         # 33..64 rows: the MLP weights go through the one-pass 32x32x16 MFMA kernel (wna16_gemm_mid.hip: 26.6 vs 37.6 us on
         # gate_up at 64 rows) -- same packed activations in, same packed activations / fp32 slabs out
-        mid = 32 < m <= 64 and not os.environ.get("APHRO_DECODE_NO_MID")
+        mid = 32 < m <= 64 and not switch("APHRO_DECODE_NO_MID")
         # 33..64 rows: the one-pass 32x32x16 MFMA kernel; APHRO_DECODE_ROW_HALVES=1: the stream kernel on two 32-row halves
         # where the layer has the strip-major copies (measured slower on the one-GPU shapes, see enable_fused_silu)
-        halves = 32 < m <= 64 and os.environ.get("APHRO_DECODE_ROW_HALVES") == "1"
+        halves = 32 < m <= 64 and switch("APHRO_DECODE_ROW_HALVES") == "1"
         if self.gate_up_interleaved is not None:
             # SiluAndMul + pack run in the GEMM epilogue (interleaved gate/up columns)
             qw, qz, sc, zo = self.gate_up_interleaved
@@ -480,7 +481,7 @@ class LlamaDecoderLayer(nn.Module):
         else:
             qw, qz, sc, zo = self.gate_up_proj.fast_params()
             if (ops.wna16_ksplit(m, qw.shape[1], h, sc.shape[0]) > 1 or "gate_up_proj" in self.strip) \
-                    and not os.environ.get("APHRO_DECODE_NO_SILU_SLABS"):
+                    and not switch("APHRO_DECODE_NO_SILU_SLABS"):
                 # K-sliced gate_up (TP shards: 8192 x 7168 at 64 rows): the slab reduce rides in the SiluAndMul + pack launch
                 # (GEMM + splitk_reduce + silu_and_mul_pack -> GEMM + one consumer, same bits); the GEMM is the stream kernel
                 # on a strip-major copy where the layer has one
@@ -564,14 +565,14 @@ class LlamaDecoderLayer(nn.Module):
         key_cache, value_cache = PagedAttention.split_kv_cache(kv_cache, self.num_kv_heads, self.head_dim)
         # static scheme: the attention launch writes the o_proj input as e4m3 itself, and gate_up + SiluAndMul + the
         # down_proj input quantisation are one launch where the streaming kernel tiles the shape (7 launches per layer)
-        fuse_static = s_o is not None and not os.environ.get("APHRO_FP8_NO_STATIC_FUSION")
+        fuse_static = s_o is not None and not switch("APHRO_FP8_NO_STATIC_FUSION")
         # round 6, dynamic per-token scheme at <= 32 rows (TP 1): the attention launch leaves its 16-bit output plus one absmax
         # partial per (token, kv-head), and the o_proj GEMM makes the per-token scale from the partials and quantises its A
         # fragments on load (ops.fp8_gemm_resident_aq) -- scaled_fp8_quant's launch is gone, its bits are not
         o_st = self.fp8_strip.get("o_proj") if m <= 32 else None
         aq_o = s_o is None and self.tp == 1 and o_st is not None and self.num_heads // self.num_kv_heads <= 16 and self.q_size % 64 == 0 \
             and ops.fp8_gemm_resident_aq_supported(m, self.o_proj.out_features, self.q_size, self.num_kv_heads) \
-            and not os.environ.get("APHRO_FP8_NO_LAUNCH_DIET")
+            and not switch("APHRO_FP8_NO_LAUNCH_DIET")
         attn_res = ops.paged_attention_rope_scaled(
             qkv_slabs, sx, self._channel_scale(self.qkv_proj),
             None if cos_sin_tok is not None else positions,
@@ -644,7 +645,7 @@ class LlamaDecoderLayer(nn.Module):
         launch each instead of norm, quant, SiluAndMul, quant (profiles/r5_prefill_e2e_kernels.txt: the four per-token
         quantisation passes were 9.2 of 82 ms of an 8192-token prompt).  Same bits as the op-by-op path."""
         from .quantization.fp8 import CompressedTensorsW8A8Fp8Method, CDNA4Fp8LinearMethod
-        if self.is_moe or os.environ.get("APHRO_PREFILL_NO_FUSED_FP8"):
+        if self.is_moe or switch("APHRO_PREFILL_NO_FUSED_FP8"):
             return False
         lins = self.linears()
         static = [getattr(lin, "input_scale", None) is not None for lin in lins]
@@ -712,8 +713,8 @@ class LlamaDecoderLayer(nn.Module):
         if self.is_moe:
             return self.moe_block(hidden), residual
         il = self.gate_up_interleaved is not None and not self.gate_up_keep_original
-        if il and hidden.shape[0] > 64 and not os.environ.get("APHRO_PREFILL_NO_SILU_EPILOGUE") \
-                and not os.environ.get("APHRO_WNA16_NO_LARGE"):
+        if il and hidden.shape[0] > 64 and not switch("APHRO_PREFILL_NO_SILU_EPILOGUE") \
+                and not switch("APHRO_WNA16_NO_LARGE"):
             # prompt-sized batches on the interleaved copy: SiluAndMul in the GEMM's epilogue (same bits, no [M, 2 I] round trip)
             qw, qz, sc, zo = self.gate_up_interleaved
             if ops.wna16_gemm_large_silu_supported(hidden.shape[0], qw.shape[1], hidden.shape[1], sc.shape[0]) \
@@ -897,7 +898,7 @@ class LlamaForCausalLM(nn.Module):
         APHRO_NO_LM_HEAD_ARGMAX=1 keeps the two-step path."""
         import os
         if (hidden.is_cuda and hidden.dim() == 2 and get_tensor_model_parallel_world_size() == 1
-                and not os.environ.get("APHRO_NO_LM_HEAD_ARGMAX") and hidden.stride(1) == 1
+                and not switch("APHRO_NO_LM_HEAD_ARGMAX") and hidden.stride(1) == 1
                 and ops.lm_head_argmax_supported(hidden.shape[0], hidden.shape[1], self.cfg.vocab_size,
                                                  self.lm_head.stride(0), hidden.dtype)):
             return ops.lm_head_argmax(hidden, self.lm_head, self.cfg.vocab_size, out)

@@ -18,6 +18,7 @@ from typing import Callable, List, Optional, Tuple
 import torch
 from torch import nn
 
+from .switches import switch
 from . import _custom_ops as ops
 from .quantization.base_config import QuantizeMethodBase, _param
 
@@ -85,7 +86,7 @@ def route_and_align(hidden_states: torch.Tensor, gating_output: torch.Tensor, to
             and (t_ * topk + 66 * num_experts + 1) * 4 <= 64 * 1024
             and gating_output.stride(1) == 1
             and gating_output.dtype in (torch.float16, torch.bfloat16, torch.float32)
-            and not os.environ.get("APHRO_MOE_NO_ROUTE_ALIGN")):
+            and not switch("APHRO_MOE_NO_ROUTE_ALIGN")):
         return ops.moe_route_align(gating_output, topk, renormalize, num_experts, MOE_BLOCK_M, want_inverse)
     topk_weights, topk_ids = fused_topk(hidden_states, gating_output, topk, renormalize)
     out = moe_align_block_size(topk_ids, MOE_BLOCK_M, num_experts, want_inverse=want_inverse)

@@ -23,6 +23,7 @@ own class).
 
 def register() -> None:
     from . import torch_ops
+    from .switches import switch
     torch_ops.register()
     try:
         import aphrodite.quantization as ref_q
@@ -34,7 +35,7 @@ def register() -> None:
     reg_methods(ref_q.QUANTIZATION_METHODS)
     reg_kernels(ref_k._POSSIBLE_KERNELS)
     import os
-    if os.environ.get("APHRODITE_MI355X_FUSED_MODEL", "1") != "0":
+    if (switch("APHRODITE_MI355X_FUSED_MODEL") or "1") != "0":
         # model-level adoption of the fused decode step through the reference's out-of-tree model hook (reference_model.py):
         # ON by default since round 5 -- what the fused step does not serve falls back to the reference's own class
         try:

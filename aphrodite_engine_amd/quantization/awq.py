@@ -10,6 +10,7 @@ from typing import Any, Dict, List, Optional
 import torch
 from torch import nn
 
+from ..switches import switch
 from .. import _custom_ops as ops
 from .base_config import LinearMethodBase, QuantizationConfig, _param
 from .utils import layer_kind
@@ -53,7 +54,7 @@ class AWQConfig(QuantizationConfig):
         # checkpoints are re-laid into the CDNA4 K-packed order at load time (the decode fast path
         # needs it); APHRODITE_AWQ_NO_PREPACK=1 keeps the on-disk layout and the awq_gemm op
         return cls(weight_bits, group_size, zero_point,
-                   prepack=os.environ.get("APHRODITE_AWQ_NO_PREPACK", "0") != "1")
+                   prepack=(switch("APHRODITE_AWQ_NO_PREPACK") or "0") != "1")
 
     def get_quant_method(self, layer: nn.Module, prefix: str):
         kind = layer_kind(layer)

@@ -4,6 +4,7 @@ slot Machete/Marlin occupy on NVIDIA."""
 import os
 from typing import List, Optional, Type
 
+from ...switches import switch
 from .MPLinearKernel import MPLinearKernel, MPLinearLayerConfig
 from .cdna4 import CDNA4LinearKernel
 
@@ -17,7 +18,7 @@ def choose_mp_linear_kernel(config: MPLinearLayerConfig,
         compute_capability = 95  # gfx950 reports (9, 5)
     failure_reasons = []
     for kernel in _POSSIBLE_KERNELS:
-        if kernel.__name__ in os.environ.get("APHRODITE_DISABLED_KERNELS", "").split(","):
+        if kernel.__name__ in (switch("APHRODITE_DISABLED_KERNELS") or "").split(","):
             failure_reasons.append(f" {kernel.__name__} disabled by environment variable")
             continue
         if kernel.get_min_capability() > compute_capability:

@@ -1169,14 +1169,14 @@ def main():
         achieved = dom["bytes"] / dom["seconds"] / 1e9
         n_members = len(dom["members"])
         # HBM bytes per launch: PMC counters cannot be collected from inside this process (rocprofv3 wraps it).  The
-        # committed passes of the newest round (profiles/r5_pmc_traffic.json, else r4_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE,
+        # committed passes of the newest round (profiles/r6_pmc_traffic.json, else r5 / r4: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE,
         # separate runs of tools/prof_step_kernels.py at THESE shapes, gfx950 x2 correction on FETCH_SIZE) are attached
         # with their provenance; null when the file has no entry for the dominant template.
         traffic = None
         traffic_src = None
         try:
             pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-            pmc_file = next(f for f in ("r5_pmc_traffic.json", "r4_pmc_traffic.json") if os.path.exists(os.path.join(pdir, f)))
+            pmc_file = next(f for f in ("r6_pmc_traffic.json", "r5_pmc_traffic.json", "r4_pmc_traffic.json") if os.path.exists(os.path.join(pdir, f)))
             pmc = json.load(open(os.path.join(pdir, pmc_file)))
             pref = "fp8_" if args.quant.startswith("fp8") else ""     # (the FP8 resident kernels have their own entries)
             ent = [pmc["kernels"][pref + m] for m in dom["members"] if pref + m in pmc.get("kernels", {})]
@@ -1275,6 +1275,19 @@ def main():
             del loop, model               # the decode state is no longer needed: give its memory back first
             torch.cuda.empty_cache()
             line["prefill_kernels"] = prefill_section(cfg)
+            # counter evidence for the MFMA-bound kernels, attached the way the decode `traffic` is: the committed
+            # rocprofv3 --pmc passes of tools/prof_prefill_r6.py (FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES ... GRBM_GUI_ACTIVE),
+            # reduced by tools/pmc_prefill.py -- HBM-side bytes per launch against the algorithmic ones, MFMA-pipe utilisation
+            try:
+                pm = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r6_pmc_prefill.json")))
+                line["prefill_kernels"]["pmc"] = {
+                    "source": pm["source"],
+                    "rows": [{k: r[k] for k in ("kernel", "case", "read_bytes", "alg_read_bytes", "read_ratio", "write_bytes",
+                                                "alg_write_bytes", "mfma_util", "clock_ghz_under_pmc", "wait_any_frac",
+                                                "wait_inst_any_frac", "active_inst_any_frac", "active_inst_valu_frac")}
+                             for r in pm["rows"]]}
+            except Exception as e:
+                line["prefill_kernels"]["pmc"] = {"error": repr(e)[:120]}
         except Exception as e:
             line["prefill_kernels"] = {"error": repr(e)}
         if not args.no_prefill_e2e:

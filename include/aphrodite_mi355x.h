@@ -38,6 +38,9 @@ extern "C" {
 
 const char* aphro_last_error(void);
 int aphro_abi_version(void);
+/* The library reads its environment switches ONCE (at load; the list is csrc/common.h `Knobs` = INTEGRATION.md "Switches") and
+ * never on a launch path.  A process that changes one afterwards -- the tests do -- calls this to have them read again. */
+void aphro_reload_env(void);
 
 /* ------------------------------------------------------------------------
  * GPTQ 4-bit

@@ -666,7 +666,7 @@ def test_per_file_compile_flags_have_one_source_of_truth():
         if flags:
             assert re.search(rf"^{name}\s*:=\s*{re.escape(' '.join(flags))}\s*$", mk, re.M), name
     want = {}
-    for m in re.finditer(r"^build/(\w+)\.o: EXTRA := (.*)$", mk, re.M):
+    for m in re.finditer(r"^\$\(BUILD\)/(\w+)\.o: EXTRA := (.*)$", mk, re.M):      # (BUILD = build, or build_lab under LAB=1)
         want[m.group(1) + ".hip"] = sum((var[v] for v in re.findall(r"\$\((\w+)\)", m.group(2))), [])
     assert set(want) >= {"paged_attention.hip", "wna16_gemm_resident.hip", "fp8_gemm_resident.hip", "fp8_gemm_stream.hip", "wna16_gemm.hip"}
     assert "kernarg-preload" not in re.search(r"^FLAGS\s*:=.*(?:\n\s+.*)*", mk, re.M).group(0)      # per file, not global

@@ -150,9 +150,9 @@ def test_wna16_large_eight_phase(ops, monkeypatch, M, N, K, G, dtype):
     ta, ts = t(a).to(dtype), t(s, torch.float16).to(dtype)
     got_t = ops._wna16_large(ta, t(shuf), t(qzeros), ts, None, 1)
     assert got_t.shape == (M, N) and got_t.dtype == dtype
-    monkeypatch.setenv("APHRO_WNA16_LARGE_8PHASE", "0")
+    monkeypatch.setenv("APHRO_WNA16_LARGE_8PHASE", "0"); ops.reload_env()
     old_t = ops._wna16_large(ta, t(shuf), t(qzeros), ts, None, 1)
-    monkeypatch.delenv("APHRO_WNA16_LARGE_8PHASE")
+    monkeypatch.delenv("APHRO_WNA16_LARGE_8PHASE"); ops.reload_env()
     assert torch.equal(got_t, old_t)
     got = got_t.float().cpu().numpy()
     a16 = ta.float().cpu().numpy().astype(np.float16)
@@ -177,7 +177,7 @@ def test_wna16_gemm_mid_vs_oracle(ops, monkeypatch, K, N, G, M, dtype, waves):
     in an LDS butterfly, fp32 slabs for more K slices) against the oracle's gptq_gemm, every row and column; and
     bit-equal to itself run twice (fixed summation order).  waves: K-splitting waves per workgroup (8 = the form
     gate_up-sized weights run, one more butterfly round; shapes whose K does not hold 8 groups fall back to 4)."""
-    monkeypatch.setenv("APHRO_WNA16_MID_WAVES", str(waves))
+    monkeypatch.setenv("APHRO_WNA16_MID_WAVES", str(waves)); ops.reload_env()
     rng = np.random.default_rng(100 + M + K)
     qweight, qzeros, s, _ = make_gptq(rng, K, N, G)
     a = rng.standard_normal((M, K)).astype(np.float16)
@@ -637,12 +637,12 @@ def test_context_attention_fwd_long(ops, kv_cache_dtype, dtype, variant):
     np.testing.assert_allclose(out.float().cpu().numpy(), ref, atol=tol, rtol=tol)
     np.testing.assert_allclose(out_old.float().cpu().numpy(), ref, atol=tol, rtol=tol)
     # the fourth-generation tile machine over the gathered context (query rows offset by the context length)
-    os.environ["APHRO_FA_V4_MIN_KEYS"] = "1024"
+    os.environ["APHRO_FA_V4_MIN_KEYS"] = "1024"; ops.reload_env()
     try:
         out4 = torch.empty_like(out)
         ops.context_attention_fwd(q, k, v, out4, *args)
     finally:
-        del os.environ["APHRO_FA_V4_MIN_KEYS"]
+        del os.environ["APHRO_FA_V4_MIN_KEYS"]; ops.reload_env()
     np.testing.assert_allclose(out4.float().cpu().numpy(), ref, atol=tol, rtol=tol)
 
 
@@ -950,11 +950,11 @@ def test_flash_attn_varlen_v3_kv_head_placement(ops, dtype, causal):
     q, k, v = q.view(T, Hq, D), k.view(T, Hkv, D), v.view(T, Hkv, D)
     scale = float(D ** -0.5)
     got = ops.flash_attn_varlen(q, k, v, t(cu), max(lens), scale, causal=causal)
-    os.environ["APHRO_FA_NO_XCD"] = "1"
+    os.environ["APHRO_FA_NO_XCD"] = "1"; ops.reload_env()
     try:
         plain = ops.flash_attn_varlen(q, k, v, t(cu), max(lens), scale, causal=causal)
     finally:
-        del os.environ["APHRO_FA_NO_XCD"]
+        del os.environ["APHRO_FA_NO_XCD"]; ops.reload_env()
     assert torch.equal(got, plain)
     ref = oa.varlen_causal_attention(q, k, v, cu, scale, causal=causal)
     tol = 2e-3 if dtype == torch.float16 else 1.6e-2
@@ -963,7 +963,7 @@ def test_flash_attn_varlen_v3_kv_head_placement(ops, dtype, causal):
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("causal,alibi", [(True, False), (False, False), (True, True)])
-@pytest.mark.parametrize("Hq,Hkv", [(16, 8)])
+@pytest.mark.parametrize("Hq,Hkv", [(16, 8), (32, 8), (4, 4)])     # 2:1, the benched Llama-3-8B geometry (4:1), no grouping (GQA 1)
 def test_flash_attn_varlen_v4(ops, dtype, causal, alibi, Hq, Hkv):
     """Fourth-generation prefill kernel (one wave per SIMD, two 32-row query blocks per wave, defer-max; flash_attn_v4.hip),
     forced on from 1024 keys: ragged lengths around the 256-row / 64-key tile edges, sequences of one to five tiles next to
@@ -980,14 +980,13 @@ def test_flash_attn_varlen_v4(ops, dtype, causal, alibi, Hq, Hkv):
     scale = float(D ** -0.5)
     slopes = (rng.random(Hq).astype(np.float32) * 0.05) if alibi else None
     kw = dict(causal=causal, alibi_slopes=t(slopes) if alibi else None)
-    os.environ["APHRO_FA_V4_MIN_KEYS"] = "1024"
+    os.environ["APHRO_FA_V4_MIN_KEYS"] = "1024"; ops.reload_env()
     try:
         got = ops.flash_attn_varlen(q, k, v, t(cu), max(lens), scale, **kw)
-        os.environ["APHRO_FA_NO_V4"] = "1"
+        os.environ["APHRO_FA_V4_MIN_KEYS"] = str(1 << 30); ops.reload_env()       # third generation always
         third = ops.flash_attn_varlen(q, k, v, t(cu), max(lens), scale, **kw)
     finally:
-        os.environ.pop("APHRO_FA_V4_MIN_KEYS", None)
-        os.environ.pop("APHRO_FA_NO_V4", None)
+        os.environ.pop("APHRO_FA_V4_MIN_KEYS", None); ops.reload_env()
     ref = oa.varlen_causal_attention(q, k, v, cu, scale, causal=causal, alibi_slopes=slopes)
     tol = 2e-3 if dtype == torch.float16 else 1.6e-2
     np.testing.assert_allclose(got.float().cpu().numpy(), ref, atol=tol, rtol=tol)
@@ -1013,11 +1012,11 @@ def test_flash_attn_varlen_v4_defer_max_rescale(ops):
             k[pos, h] = q[cu[0 if pos < 1536 else 1]:, h * (Hq // Hkv)].mean(0) * gain + k[pos, h] * 0.1
     q, k, v = t(q, torch.float16), t(k, torch.float16), t(v, torch.float16)
     scale = 1.0
-    os.environ["APHRO_FA_V4_MIN_KEYS"] = "1024"
+    os.environ["APHRO_FA_V4_MIN_KEYS"] = "1024"; ops.reload_env()
     try:
         got = ops.flash_attn_varlen(q, k, v, t(cu), max(lens), scale, causal=True)
     finally:
-        os.environ.pop("APHRO_FA_V4_MIN_KEYS", None)
+        os.environ.pop("APHRO_FA_V4_MIN_KEYS", None); ops.reload_env()
     ref = oa.varlen_causal_attention(q, k, v, cu, scale, causal=True)
     assert torch.isfinite(got).all()
     np.testing.assert_allclose(got.float().cpu().numpy(), ref, atol=4e-3, rtol=4e-3)
@@ -1991,10 +1990,10 @@ def test_paged_attention_split_kv_inside_the_launch(ops, splits, dtype, kv_cache
     args = (q, kc, vc, Hkv, D ** -0.5, t(bt), t(seq_lens), BS, max_len, None, kv_cache_dtype, ks, vs)
     old = os.environ.get("APHRO_PA_SPLITS")
     try:
-        os.environ["APHRO_PA_SPLITS"] = "1"
+        os.environ["APHRO_PA_SPLITS"] = "1"; ops.reload_env()
         plain = torch.empty_like(q)
         ops.paged_attention_v1(plain, *args)
-        os.environ["APHRO_PA_SPLITS"] = str(splits)
+        os.environ["APHRO_PA_SPLITS"] = str(splits); ops.reload_env()
         out = torch.full_like(q, float("nan"))
         ops.paged_attention_v1(out, *args)
         np.testing.assert_allclose(out.float().cpu().numpy(), ref, atol=atol, rtol=1e-5)
@@ -2025,9 +2024,9 @@ def test_paged_attention_split_kv_inside_the_launch(ops, splits, dtype, kv_cache
             assert torch.equal(g_out, out)
     finally:
         if old is None:
-            os.environ.pop("APHRO_PA_SPLITS", None)
+            os.environ.pop("APHRO_PA_SPLITS", None); ops.reload_env()
         else:
-            os.environ["APHRO_PA_SPLITS"] = old
+            os.environ["APHRO_PA_SPLITS"] = old; ops.reload_env()
 
 
 def test_paged_attention_split_workspace_growth_keeps_captured_graphs_valid(ops):
@@ -2049,7 +2048,7 @@ def test_paged_attention_split_workspace_growth_keeps_captured_graphs_valid(ops)
         q = t(rng.standard_normal((S, Hq, D)).astype(np.float32), torch.float16)
         return q, (q, kc, vc, Hkv, D ** -0.5, t(bt), t(seq_lens), BS, L, None, "auto", 1.0, 1.0)
     try:
-        os.environ["APHRO_PA_SPLITS"] = "4"
+        os.environ["APHRO_PA_SPLITS"] = "4"; ops.reload_env()
         q, args = problem(3, 1024)
         want = torch.empty_like(q)
         ops.paged_attention_v1(want, *args)            # (allocates the workspace outside any capture)
@@ -2066,7 +2065,7 @@ def test_paged_attention_split_workspace_growth_keeps_captured_graphs_valid(ops)
         torch.cuda.synchronize()
         assert torch.equal(g_out, want)
         # growth: far more (sequence, kv-head) groups x splits than any plan the launcher makes by itself
-        os.environ["APHRO_PA_SPLITS"] = "8"
+        os.environ["APHRO_PA_SPLITS"] = "8"; ops.reload_env()
         q2, args2 = problem(1400, 256)
         big = torch.empty_like(q2)
         ops.paged_attention_v1(big, *args2)
@@ -2081,9 +2080,9 @@ def test_paged_attention_split_workspace_growth_keeps_captured_graphs_valid(ops)
         del junk
     finally:
         if old is None:
-            os.environ.pop("APHRO_PA_SPLITS", None)
+            os.environ.pop("APHRO_PA_SPLITS", None); ops.reload_env()
         else:
-            os.environ["APHRO_PA_SPLITS"] = old
+            os.environ["APHRO_PA_SPLITS"] = old; ops.reload_env()
 
 
 def test_paged_attention_rope_packed_split_matches_unsplit(ops):
@@ -2106,16 +2105,16 @@ def test_paged_attention_rope_packed_split_matches_unsplit(ops):
     old = os.environ.get("APHRO_PA_SPLITS")
     try:
         for sp in (1, 4):
-            os.environ["APHRO_PA_SPLITS"] = str(sp)
+            os.environ["APHRO_PA_SPLITS"] = str(sp); ops.reload_env()
             kc, vc = kc0.clone(), vc0.clone()
             packed, out = ops.paged_attention_rope_packed(slabs, pos, cos_sin, t(slots), kc, vc, Hq, Hkv, 0.09, t(bt),
                                                           t(seq_lens), BS, int(seq_lens.max()), None, "auto", 1.0, 1.0, want_out=True)
             res[sp] = (kc, vc, out)
     finally:
         if old is None:
-            os.environ.pop("APHRO_PA_SPLITS", None)
+            os.environ.pop("APHRO_PA_SPLITS", None); ops.reload_env()
         else:
-            os.environ["APHRO_PA_SPLITS"] = old
+            os.environ["APHRO_PA_SPLITS"] = old; ops.reload_env()
     assert torch.equal(res[1][0], res[4][0]) and torch.equal(res[1][1], res[4][1])
     np.testing.assert_allclose(res[4][2].float().cpu().numpy(), res[1][2].float().cpu().numpy(), atol=1e-3, rtol=1e-5)
 
@@ -2430,7 +2429,7 @@ def test_fp8_gemm_stream_vs_oracle(ops, M, N, K, dtype):
     from oracle import fp8 as ofp8
     lib = _lib.lib()
     rng = np.random.default_rng(M + N + K)
-    os.environ["APHRO_FP8_STREAM_ALL"] = "1"
+    os.environ["APHRO_FP8_STREAM_ALL"] = "1"; ops.reload_env()
     try:
         split = lib.aphro_fp8_gemm_stream_ksplit(M, N, K)
         assert split >= 1
@@ -2458,7 +2457,7 @@ def test_fp8_gemm_stream_vs_oracle(ops, M, N, K, dtype):
             eps = 2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7
             np.testing.assert_allclose(out.float().cpu().numpy(), ref, rtol=2 * eps, atol=2 * eps * np.abs(ref).max())
     finally:
-        os.environ.pop("APHRO_FP8_STREAM_ALL")
+        os.environ.pop("APHRO_FP8_STREAM_ALL"); ops.reload_env()
 
 
 # ---- FP8 W8A8 decode GEMM, one workgroup per CU on a strip-major weight copy (csrc/fp8_gemm_resident.hip, round 4) -----
@@ -2537,7 +2536,7 @@ def test_fp8_gemm_silu_quant_matches_op_sequence(ops, M, N, K, dtype, per_token)
     from oracle import fp8 as ofp8
     from oracle import attention as oa
     rng = np.random.default_rng(M + N + K)
-    os.environ["APHRO_FP8_STREAM_ALL"] = "1"
+    os.environ["APHRO_FP8_STREAM_ALL"] = "1"; ops.reload_env()
     try:
         assert ops.fp8_gemm_silu_quant_supported(M, N, K)
         a = ofp8.fp8_encode((rng.standard_normal((M, K)) * 1.5).astype(np.float32), "e4m3")
@@ -2563,7 +2562,7 @@ def test_fp8_gemm_silu_quant_matches_op_sequence(ops, M, N, K, dtype, per_token)
         assert diff.mean() < 0.02, diff.mean()
         np.testing.assert_allclose(got, want, rtol=0.13, atol=2.0 ** -6)             # one e4m3 step (mantissa 3 bits)
     finally:
-        os.environ.pop("APHRO_FP8_STREAM_ALL")
+        os.environ.pop("APHRO_FP8_STREAM_ALL"); ops.reload_env()
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32])

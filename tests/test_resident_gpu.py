@@ -27,10 +27,10 @@ def ops():
 
 
 @pytest.fixture(autouse=True)
-def _no_cfg_env():
-    os.environ.pop("APHRO_WNA16_RES_CFG", None)
+def _no_cfg_env(ops):
+    os.environ.pop("APHRO_WNA16_RES_CFG", None); ops.reload_env()
     yield
-    os.environ.pop("APHRO_WNA16_RES_CFG", None)
+    os.environ.pop("APHRO_WNA16_RES_CFG", None); ops.reload_env()
 
 
 @pytest.mark.parametrize("M", [1, 8, 16, 17, 32])
@@ -109,7 +109,7 @@ def test_resident_gate_up_silu_epilogue_vs_oracle(ops, M, strip):
 def test_resident_alternative_configs_vs_oracle(ops, cfg, K, N):
     """The other instantiated (waves, segments per wave, 64-column passes, last-pass blocks) plans, picked by hand."""
     shuf, qzeros, scales, a, ref = case(K, N)
-    os.environ["APHRO_WNA16_RES_CFG"] = cfg
+    os.environ["APHRO_WNA16_RES_CFG"] = cfg; ops.reload_env()
     for M in (5, 32):
         ks = ops.wna16_resident_ksplit(M, N, K, K // 128)
         assert ks >= 1
@@ -170,11 +170,11 @@ def test_rowmajor_one_launch_vs_oracle(ops, K, N, M):
     g_idx = torch.empty(0, dtype=torch.int32, device=DEV)
     assert torch.equal(ops.gptq_gemm(x, t(shuf), t(qzeros), t(scales), g_idx, True, 4), y)
     # ... and agrees with the three-launch path it replaces (another K partition: fp32 rounding apart)
-    os.environ["APHRO_WNA16_OP_NO_RESIDENT"] = "1"
+    os.environ["APHRO_WNA16_OP_NO_RESIDENT"] = "1"; ops.reload_env()
     try:
         old = ops.gptq_gemm(x, t(shuf), t(qzeros), t(scales), g_idx, True, 4)
     finally:
-        os.environ.pop("APHRO_WNA16_OP_NO_RESIDENT")
+        os.environ.pop("APHRO_WNA16_OP_NO_RESIDENT"); ops.reload_env()
     torch.testing.assert_close(y.float(), old.float(), rtol=2e-3, atol=2e-3 * float(np.abs(ref).max()))
 
 

@@ -53,10 +53,14 @@ def main():
         ("qkv_proj (round-2 kernel)", r"wna16_gemm_kernel<aphro::Half, 4, 2, 4>", *gemm_alg(4096, 6144, out_bytes=2 * M * 6144 * 4)),
         ("o_proj", r"wna16_gemm_stream_kernel<2, 4, 2, 1, 0", *gemm_alg(4096, 4096, out_bytes=4 * M * 4096 * 4)),
         ("o_proj (round-2 kernel)", r"wna16_gemm_kernel<aphro::Half, 4, 2, 2>", *gemm_alg(4096, 4096, out_bytes=4 * M * 4096 * 4)),
-        ("fp8_gate_up_proj", r"fp8_gemm_resident_kernel<aphro::Half, 2, 8, 7", 4096 * 28672 + M * 4096, M * 28672 * 4),
-        ("fp8_down_proj", r"fp8_gemm_resident_kernel<aphro::Half, 2, 7, 4", 14336 * 4096 + M * 14336, 4 * M * 4096 * 4),
+        # round 6: the step's forms -- gate_up + SiluAndMul epilogue (16-bit activation [M, I] + partials out; mean over the plain
+        # slab-form launches of the same template and the epilogue form), o / down quantising 16-bit pair-major A on load (<..., 1>)
+        ("fp8_gate_up_proj", r"fp8_gemm_resident_kernel<aphro::Half, 2, 8, 7, 4, 0>", 4096 * 28672 + M * 4096, M * 14336 * 2 + M * 256 * 4),
+        ("fp8_down_proj", r"fp8_gemm_resident_kernel<aphro::Half, 2, 7, 4, 6, 1>", 14336 * 4096 + M * 14336 * 2 + M * 256 * 4, 4 * M * 4096 * 4),
+        ("fp8_down_proj (pre-quantised A, round 5)", r"fp8_gemm_resident_kernel<aphro::Half, 2, 7, 4, 8, 0>", 14336 * 4096 + M * 14336, 4 * M * 4096 * 4),
         ("fp8_qkv_proj", r"fp8_gemm_resident_kernel<aphro::Half, 2, 4, 3", 4096 * 6144 + M * 4096, 2 * M * 6144 * 4),
-        ("fp8_o_proj", r"fp8_gemm_resident_kernel<aphro::Half, 2, 2, 4", 4096 * 4096 + M * 4096, 4 * M * 4096 * 4),
+        ("fp8_o_proj", r"fp8_gemm_resident_kernel<aphro::Half, 2, 2, 4, 6, 1>", 4096 * 4096 + M * 4096 * 2 + M * 8 * 4, 4 * M * 4096 * 4),
+        ("fp8_o_proj (pre-quantised A, round 5)", r"fp8_gemm_resident_kernel<aphro::Half, 2, 2, 4, 8, 0>", 4096 * 4096 + M * 4096, 4 * M * 4096 * 4),
         ("paged_attention", r"paged_attention_kernel<aphro::Half, 0, 128, 16, 8, 1", kv + 2 * bs * 6144 * 4, bs * 4096 * 2 + bs * 2 * 8 * 128 * 2),
         ("add_rms_norm_pack", r"add_rms_norm_pack_kernel", 4 * M * 4096 * 4 + M * 4096 * 2, 2 * M * 4096 * 2),
         ("gate_up_proj bs64 (mid kernel)", r"wna16_gemm_mid_kernel<2, 8, true>", *gemm_alg(4096, 28672, m=64, out_bytes=64 * 14336 * 2)),

@@ -79,3 +79,23 @@ for name, (k, n) in shapes.items():
         st8 = ops.fp8_strip_relayout(w8, bs)
         ops.fp8_gemm_resident(qa, st8, slabs=True)
 torch.cuda.synchronize()
+
+# round 6: the step's forms of the dynamic per-token scheme -- gate_up with SiluAndMul + absmax partials in the epilogue on the
+# interleaved strip copy (same kernel template as the plain form: only this form is launched for it now), o_proj / down fed with
+# pair-major 16-bit activations + partials and quantising on load (template <..., 1>)
+for name, (k, n) in shapes.items():
+    x16 = torch.randn(bs, k, device=dev, dtype=torch.float16, generator=g)
+    if name in ("o", "down"):
+        np_ = 8 if name == "o" else 256
+        part = x16.float().abs().view(bs, np_, -1).amax(2).contiguous()
+        xp = torch.zeros(ops.aq_pairs_numel(bs, k), dtype=x16.dtype, device=dev)
+        xp[ops.aq_pairs_index(bs, k, dev).flatten()] = x16.flatten()
+    for _ in range(4):
+        w8 = torch.randint(0, 0x48, (n, k), generator=g, device=dev, dtype=torch.int16).to(torch.uint8).view(torch.float8_e4m3fn)
+        if name == "gate_up":
+            qa, sa = ops.scaled_fp8_quant(x16, None, use_per_token_if_dynamic=True)
+            ops.fp8_gemm_resident_silu(qa, ops.fp8_strip_relayout_interleaved(w8, bs), sa, torch.full((n, 1), 0.01, device=dev), torch.float16,
+                                       act_pairs=True)
+        elif name in ("o", "down"):
+            ops.fp8_gemm_resident_aq(xp, part, ops.fp8_strip_relayout(w8, bs), a_pairs=True)
+torch.cuda.synchronize()
