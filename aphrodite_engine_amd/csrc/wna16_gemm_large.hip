@@ -528,7 +528,6 @@ __global__ __launch_bounds__(512) void wna16_gemm_large8_kernel(Wna16LargeParams
   const int zshift = (lane & 1) * 16;               // this thread's four zero-point nibbles inside its qzeros dword
 
   bool first_segment = true;
-  int seg_no = -1;
   while (u < u_end) {
     const int tile = u / ktiles_total;
     const int k0 = u - tile * ktiles_total;
@@ -539,18 +538,6 @@ __global__ __launch_bounds__(512) void wna16_gemm_large8_kernel(Wna16LargeParams
     const int m0 = tm * BM, n0 = tn * BN;
     if (!first_segment) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
     first_segment = false;
-#ifdef LG_LAB
-    // lab: workgroups 0..3, waves 0 and 4 stamp s_memtime at four points of their first four segments:
-    // flags[512 ...] as u64 [w][wave >> 2][seg][point]; points 6 / 7 = s_memrealtime at segment start / end
-    ++seg_no;
-    unsigned long long* stamp = (w < 4 && (wave & 3) == 0 && lane == 0 && seg_no < 4)
-                                    ? reinterpret_cast<unsigned long long*>(p.flags + 512) + ((w * 2 + (wave >> 2)) * 4 + seg_no) * 8 : nullptr;
-#define LG_STAMP(i) if (stamp) stamp[i] = __builtin_amdgcn_s_memtime();
-    if (stamp) stamp[6] = __builtin_amdgcn_s_memrealtime();
-#else
-#define LG_STAMP(i)
-#endif
-    LG_STAMP(0)
 
     // ---- activations: this wave's two LDS-DMA instructions (8 rows x 128 B each) of the half-tiles Ah(h): rows
     // (i >> 3) * 128 + h * 64 + (i & 7) * 8 .. + 8 for instruction i = 2 wave + t ----------------------------------------
@@ -626,7 +613,6 @@ __global__ __launch_bounds__(512) void wna16_gemm_large8_kernel(Wna16LargeParams
     __builtin_amdgcn_s_barrier();
     if (wm == 1) __builtin_amdgcn_s_barrier();       // group 1 runs one barrier behind
     __builtin_amdgcn_sched_barrier(0);
-    LG_STAMP(1)
 
     u32x4 wf[2][4], af[2][4];                        // [n block][k step] / [m block of the current half][k step]
     auto read_w = [&](auto NB) {
@@ -723,13 +709,7 @@ __global__ __launch_bounds__(512) void wna16_gemm_large8_kernel(Wna16LargeParams
     }
 #undef LG_BAR
 #undef LG_LGKM0
-    LG_STAMP(2)
     wna16_large_finish<NWAVE, false>(p, acc, smem, rp, head, tail, w, GW, U, tile, ktiles_total, m0, n0, wave, wm, wn, lane);
-    LG_STAMP(4)
-#ifdef LG_LAB
-    if (stamp) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp[5] = __builtin_amdgcn_s_memtime(); stamp[7] = __builtin_amdgcn_s_memrealtime(); }
-#endif
-#undef LG_STAMP
   }
 }
 

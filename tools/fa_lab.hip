@@ -3,9 +3,9 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/fa_lab.hip -o tools/bin/fa_lab     (tools/run_fa_lab.sh)
 // Without FA_LAB: times the third-generation (APHRO_FA_NO_V4=1) and the fourth-generation kernel on the same random
 // input (T tokens, Hq 32 / Hkv 8 / hd 128, causal) and compares their outputs element by element.
-#include "../aphrodite_engine_amd/csrc/flash_attn.hip"
-#include "../aphrodite_engine_amd/csrc/flash_attn_v4.hip"
-#include "../aphrodite_engine_amd/csrc/runtime.hip"
+#include "bin/csrc_lab/flash_attn.hip"
+#include "bin/csrc_lab/flash_attn_v4.hip"
+#include "bin/csrc_lab/runtime.hip"
 #include <cmath>
 #include <cstring>
 #include <vector>

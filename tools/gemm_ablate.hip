@@ -2,7 +2,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DABL_NO_A ...] tools/gemm_ablate.hip -o /tmp/abl && /tmp/abl K N M
 // Includes the kernel translation unit directly and launches the fast kernel
 // on random data, cycling over enough weight copies to defeat the Infinity Cache.
-#include "../aphrodite_engine_amd/csrc/wna16_gemm.hip"
+#include "bin/csrc_lab/wna16_gemm.hip"
 #include <vector>
 namespace aphro { void set_error(const char*, ...) {} }
 #include <stdio.h>

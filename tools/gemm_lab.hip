@@ -9,7 +9,7 @@
 //     different segment, MODE_ILV gives the four waves adjacent segments, MODE_AREP reads one of 8
 //     staggered copies of A.  probe_a isolates the A stream, probe_l2 measures the interleave itself.
 //   * how far do the small shapes (qkv / o) move with every load issued up front and 8-16 waves.
-#include "../aphrodite_engine_amd/csrc/wna16_gemm.hip"
+#include "bin/csrc_lab/wna16_gemm.hip"
 #include <vector>
 #include <string>
 #include <algorithm>

@@ -3,6 +3,7 @@
 # library per variant under tools/bin/, the other objects are the shipped ones.   tools/mid_ablate.sh 0 1 2 4 8 3 12 15
 set -e
 cd "$(dirname "$0")/.."
+bash tools/apply_lab_patches.sh > /dev/null      # the kernel sources WITH their lab branches: tools/bin/csrc_lab
 mkdir -p tools/bin
 C=aphrodite_engine_amd/csrc
 OTHERS=$(ls $C/build/*.o | grep -v wna16_gemm_mid.o)

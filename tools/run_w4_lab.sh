@@ -2,7 +2,8 @@
 # builds tools/bin/w4_lab (here, cross-compiled); run it on the GPU box: tools/bin/w4_lab
 set -e
 cd "$(dirname "$0")/.."
+bash tools/apply_lab_patches.sh > /dev/null      # the kernel sources WITH their lab branches: tools/bin/csrc_lab
 mkdir -p tools/bin
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-unused-function -Wno-unused-variable -Wno-pass-failed $LAB_FLAGS \
-  tools/w4_lab.hip aphrodite_engine_amd/csrc/wna16_gemm_large.hip aphrodite_engine_amd/csrc/runtime.hip -o tools/bin/w4_lab
+  tools/w4_lab.hip tools/bin/csrc_lab/wna16_gemm_large.hip tools/bin/csrc_lab/runtime.hip -o tools/bin/w4_lab
 echo built tools/bin/w4_lab

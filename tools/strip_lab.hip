@@ -7,7 +7,7 @@
 // into an LDS ring ONCE per CU with direct-to-LDS loads, NS consumer waves read them from LDS, stream their own
 // weight strip straight into registers (dword loads, DW segments ahead) and keep full-K sums in registers -- no
 // cross-wave reduction, A through the texture path once per CU instead of once per 64 columns.
-#include "../aphrodite_engine_amd/csrc/wna16_gemm.hip"
+#include "bin/csrc_lab/wna16_gemm.hip"
 #include <vector>
 #include <string>
 #include <algorithm>

@@ -20,6 +20,7 @@ extern "C" int aphro_wna16_gemm_large(const void* a, const uint32_t* q_weight, c
                                       void* workspace, size_t workspace_bytes, int64_t M, int64_t N, int64_t K, int64_t groups,
                                       int64_t lda, int zero_offset, int dtype, void* stream);
 extern "C" const char* aphro_last_error(void);
+extern "C" void aphro_reload_env(void);
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 
@@ -54,6 +55,7 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(dq, hq.data(), hq.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dz, hz.data(), hz.size() * 4, hipMemcpyHostToDevice));
     auto run = [&](uint16_t* out, int eight) {
       setenv("APHRO_WNA16_LARGE_8PHASE", eight ? "1" : "0", 1);
+      aphro_reload_env();
       const int rc = aphro_wna16_gemm_large(da, dq, dz, ds, out, ws, wsb, M, N, K, G, K, 1, APHRO_F16, st);
       if (rc != 0) { printf("launch rc=%d: %s\n", rc, aphro_last_error()); exit(1); }
     };
