@@ -74,6 +74,7 @@ struct Knobs {
   int wna16_stream;           // APHRO_WNA16_STREAM=0: the two-pass resident kernel instead of the single-pass stream kernel
   int wna16_op_no_resident;   // APHRO_WNA16_OP_NO_RESIDENT=1: op-level gptq_gemm as pack + GEMM + reduce (three launches)
   int wna16_large_8phase;     // APHRO_WNA16_LARGE_8PHASE=0/1: prefill W4A16 schedule (-1: by K)
+  int wna16_large_two_pass;   // APHRO_WNA16_LARGE_TWO_PASS=0/1: prefill W4A16 dequantise-once form off / wherever it applies (-1: from 4096 rows)
   int wna16_mid_waves;        // APHRO_WNA16_MID_WAVES=4/8: K waves of the 33..64-row kernel (0: planned)
   int res_cfg[4];             // APHRO_WNA16_RES_CFG="nwv,nseg,np4,rem": force a resident-kernel plan (tests)
   int res_cfg_set;

@@ -27,6 +27,7 @@ static Knobs read_knobs() {
   k.wna16_stream = env_i("APHRO_WNA16_STREAM", 1);
   k.wna16_op_no_resident = env_i("APHRO_WNA16_OP_NO_RESIDENT", 0);
   k.wna16_large_8phase = env_i("APHRO_WNA16_LARGE_8PHASE", -1);
+  k.wna16_large_two_pass = env_i("APHRO_WNA16_LARGE_TWO_PASS", -1);
   k.wna16_mid_waves = env_i("APHRO_WNA16_MID_WAVES", 0);
   k.res_cfg_set = 0;
   k.res_cfg[0] = k.res_cfg[1] = k.res_cfg[2] = k.res_cfg[3] = 0;

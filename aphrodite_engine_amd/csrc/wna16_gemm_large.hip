@@ -56,6 +56,11 @@ struct Wna16LargeParams {
   // followed by silu_and_mul on its rounded output, without the [M, N] round trip through HBM (0.9 GB per layer of an
   // 8192-token Llama-3-8B prompt)
   int silu;
+  // two-pass form (round 6, template WDMA of the eight-phase kernel): the weights dequantised ONCE per call into wt = f16
+  // W^T [N, K] (k contiguous; wna16_dequant_t_kernel) and staged by LDS-DMA like the activations.  At M = 8192 every weight is
+  // otherwise dequantised by 32 row-tile workgroups: the in-loop dequantisation costs 15 % of the K loop
+  // (profiles/r6_w4_two_pass.txt).
+  const uint16_t* wt;
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t lg_rsrc(const void* base, uint32_t bytes) {
@@ -481,7 +486,7 @@ __device__ __forceinline__ void lg_lds_write128(uint32_t addr, const u32x4& v) {
 }
 __device__ __forceinline__ void lg_touch(u32x4& x) { asm volatile("" : "+v"(x)); }
 
-template <bool BF16OUT>
+template <bool BF16OUT, bool WDMA = false>
 __global__ __launch_bounds__(512) void wna16_gemm_large8_kernel(Wna16LargeParams p) {
   constexpr int NWAVE = 8, BM = 256, BN = 256, BK = 64;
   constexpr int A_REGION = BM * BK * 2;             // 32 KiB
@@ -506,7 +511,8 @@ __global__ __launch_bounds__(512) void wna16_gemm_large8_kernel(Wna16LargeParams
   const int u_end = (int)((w + 1) * U / GW);
 
   const __amdgpu_buffer_rsrc_t ra = lg_rsrc(p.a, (uint32_t)((size_t)p.M * p.lda * 2));
-  const __amdgpu_buffer_rsrc_t rb = lg_rsrc(p.qw, (uint32_t)((size_t)(p.K >> 3) * p.N * 4));
+  const __amdgpu_buffer_rsrc_t rb = WDMA ? lg_rsrc(p.wt, (uint32_t)((size_t)p.N * p.K * 2))
+                                         : lg_rsrc(p.qw, (uint32_t)((size_t)(p.K >> 3) * p.N * 4));
   const __amdgpu_buffer_rsrc_t rs = lg_rsrc(p.sc, (uint32_t)((size_t)(p.K / p.group_size) * p.N * 2));
   const __amdgpu_buffer_rsrc_t rz = lg_rsrc(p.qz, (uint32_t)((size_t)(p.K / p.group_size) * (p.N >> 3) * 4));
   const __amdgpu_buffer_rsrc_t rp = lg_rsrc(p.partial, (uint32_t)((size_t)GW * IMAGE));
@@ -554,6 +560,20 @@ __global__ __launch_bounds__(512) void wna16_gemm_large8_kernel(Wna16LargeParams
     auto stage_a1 = [&](int h, int t, int buf, int kt) {
       const int voff = a_voff[h][t];                // (local copy: see the kernel above on the hipcc host-stub bug)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_ptr)(smem + buf * BUF + a_row0[h][t] * 128), 16, voff, kt * (BK * 2), 0, 0);
+    };
+    // WDMA: the f16 weight rows n0 + (the same row pattern) of W^T [N, K], same swizzle: the weight region of a buffer is filled
+    // by 4 LDS-DMA instructions per wave exactly like the activation region
+    int w_dvoff[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int wr_ = a_row0[h][t] + (lane >> 3);
+        w_dvoff[h][t] = min(n0 + wr_, p.N - 1) * p.K * 2 + (((lane & 7) ^ ((wr_ >> 1) & 7)) << 4);
+      }
+    auto stage_w1 = [&](int h, int t, int buf, int kt) {
+      const int voff = w_dvoff[h][t];
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void_ptr)(smem + buf * BUF + A_REGION + a_row0[h][t] * 128), 16, voff, kt * (BK * 2), 0, 0);
     };
     // ---- weights: one packed row piece, its scales and zero points per thread and K tile (inline asm: counted by hand) ---
     const uint32_t w_voff = (uint32_t)((wave * p.N + n0 + 4 * lane) * 4);
@@ -603,6 +623,14 @@ __global__ __launch_bounds__(512) void wna16_gemm_large8_kernel(Wna16LargeParams
     // ---- prologue: K tile 0 complete in buffer 0 (activations by DMA, weights dequantised), Ah0(1) and the packed weights of
     // tile 1 in flight.  Past the segment's last K tile every slot keeps loading a clamped tile nobody reads (one basic
     // block, one vmcnt count: see fp8_gemm_large8_kernel) ---------------------------------------------------------------------
+    if constexpr (WDMA) {
+      // tile 0 whole in buffer 0 (4 + 4 DMAs), then -- as the steady state leaves them -- Ah0 and the weights of tile 1 in flight
+      stage_a1(0, 0, 0, k0); stage_a1(0, 1, 0, k0); stage_a1(1, 0, 0, k0); stage_a1(1, 1, 0, k0);
+      stage_w1(0, 0, 0, k0); stage_w1(0, 1, 0, k0); stage_w1(1, 0, 0, k0); stage_w1(1, 1, 0, k0);
+      { const int kt1 = min(k0 + 1, klast); stage_a1(0, 0, 1, kt1); stage_a1(0, 1, 1, kt1);
+        stage_w1(0, 0, 1, kt1); stage_w1(0, 1, 1, kt1); stage_w1(1, 0, 1, kt1); stage_w1(1, 1, 1, kt1); }
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
     load_w(k0);
     stage_a1(0, 0, 0, k0); stage_a1(0, 1, 0, k0); stage_a1(1, 0, 0, k0); stage_a1(1, 1, 0, k0);
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -610,6 +638,7 @@ __global__ __launch_bounds__(512) void wna16_gemm_large8_kernel(Wna16LargeParams
     dequant_write1(Q0{}, 0); dequant_write1(Q1{}, 0); dequant_write1(Q2{}, 0); dequant_write1(Q3{}, 0);
     { const int kt1 = min(k0 + 1, klast); load_w(kt1); stage_a1(0, 0, 1, kt1); stage_a1(0, 1, 1, kt1); }
     asm volatile("s_waitcnt vmcnt(5)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();
     if (wm == 1) __builtin_amdgcn_s_barrier();       // group 1 runs one barrier behind
     __builtin_amdgcn_sched_barrier(0);
@@ -671,29 +700,40 @@ __global__ __launch_bounds__(512) void wna16_gemm_large8_kernel(Wna16LargeParams
       // built in the read blocks of P2 (1 dword), P3 (1) and P4 (2, no fragment reads there) while the SIMD's other wave is
       // in its MFMA cluster ------------------------------------------------------------------------------------------------
       read_w(std::integral_constant<int, 1>{});
-      asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-      landed_wq();
-      dequant_write1(Q0{}, cur ^ 1);
+      if constexpr (!WDMA) {
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        landed_wq();
+        dequant_write1(Q0{}, cur ^ 1);
+      }
       LG_BAR();
       LG_LGKM0(); landed_w(1);
       mma(1, 0, [&](int) {});
       LG_BAR();
       // ---- P3 -------------------------------------------------------------------------------------------------------
+      // (WDMA: from here on every wave -- group 1 runs one barrier behind -- has finished its LDS reads of this tile's weight
+      //  region (P1: nb 0, P2: nb 1): the weights of tile t + 2 go into the same buffer, 1 piece here, 3 behind P4's MFMAs)
       read_a(std::integral_constant<int, 1>{});
-      dequant_write1(Q1{}, cur ^ 1);
+      if constexpr (!WDMA) dequant_write1(Q1{}, cur ^ 1);
       LG_BAR();
       LG_LGKM0(); landed_a();
-      mma(1, 1, [&](int i) { if (i < 2) stage_a1(0, i, cur, kt2); });
+      mma(1, 1, [&](int i) { if (i < 2) stage_a1(0, i, cur, kt2); else if (WDMA) stage_w1(0, 0, cur, kt2); });
       LG_BAR();
       // ---- P4 -------------------------------------------------------------------------------------------------------
       // everything older than P3's two DMAs has landed (the activations of tile t + 1 are whole); this wave's weight rows of
       // tile t + 1 are in the LDS before the barrier: the first reader is P1 of tile t + 1.  The request for tile t + 2's
       // packed weights follows in the MFMA shadow (wq is free again).
+      if constexpr (WDMA) {
+        // all but P3's three DMAs (Ah0 x 2, one weight piece of tile t + 2) have landed: tile t + 1 is whole
+        asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        LG_BAR();
+        mma(0, 1, [&](int i) { if (i == 0) stage_w1(0, 1, cur, kt2); else if (i == 1) stage_w1(1, 0, cur, kt2); else stage_w1(1, 1, cur, kt2); });
+      } else {
       dequant_write1(Q2{}, cur ^ 1);
       dequant_write1(Q3{}, cur ^ 1);
       asm volatile("s_waitcnt vmcnt(2)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
       LG_BAR();
       mma(0, 1, [&](int i) { if (i == 0) load_w(kt2); });
+      }
       LG_BAR();
 #pragma unroll
       for (int j = 0; j < 4; ++j) { a_addr[j] += cur ? -BUF : BUF; w_addr[j] += cur ? -BUF : BUF; }
@@ -710,6 +750,43 @@ __global__ __launch_bounds__(512) void wna16_gemm_large8_kernel(Wna16LargeParams
 #undef LG_BAR
 #undef LG_LGKM0
     wna16_large_finish<NWAVE, false>(p, acc, smem, rp, head, tail, w, GW, U, tile, ktiles_total, m0, n0, wave, wm, wn, lane);
+  }
+}
+
+// Two-pass form, pass 1: q_weight [K/8, N] (exllama order) -> f16 W^T [N, K] with the numerics of the in-loop dequantisation
+// (dq8_scaled: (q - z) * s in f16, q_gemm.cu:1394-1434) -- the reference's own large-M path reconstructs the matrix once per
+// call too (q_gemm.cu:1529-1544).  One workgroup = 256 columns x 64 k, the load pattern of the eight-phase kernel: thread
+// (lane: columns 4 lane .. + 3, wave: packed row) reads ONE 16-byte piece, dequantises its 4 x 8 weights into an LDS tile
+// [column][64 k], and the tile leaves as whole 128-byte lines of W^T (8 lanes per line).  (First version: every thread wrote
+// its own column's 16-byte pieces straight to W^T -- 64 partial lines per store instruction: 2.1 TB/s, 139 us on gate_up.)
+__global__ __launch_bounds__(512) void wna16_dequant_t_kernel(const uint32_t* __restrict__ qw, const uint32_t* __restrict__ qz,
+                                                             const uint16_t* __restrict__ sc, uint16_t* __restrict__ wt, int N, int K,
+                                                             int group_size, int zero_offset, int scale_bf16) {
+  constexpr int PITCH = 128 + 16;                       // bytes per LDS row (64 k of one column), padded
+  __shared__ __attribute__((aligned(16))) unsigned char tile[256 * PITCH];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n0 = blockIdx.x * 256, kt = blockIdx.y;
+  const int nq = n0 + 4 * lane;
+  const int g = (kt * 64) / group_size;
+  const u32x4 wq = *reinterpret_cast<const u32x4*>(qw + (size_t)(kt * 8 + wave) * N + nq);
+  const u32x2 sq = *reinterpret_cast<const u32x2*>(sc + (size_t)g * N + nq);
+  const uint32_t zq = qz[(size_t)g * (N >> 3) + (nq >> 3)] >> ((lane & 1) * 16);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const uint16_t sb = (uint16_t)(sq[q >> 1] >> ((q & 1) * 16));
+    const float sf = scale_bf16 ? bf16_bits_to_f32(sb) : f16_bits_to_f32(sb);
+    const int z = (int)((zq >> (4 * q)) & 0xf) + zero_offset;
+    const f16 s16 = (f16)sf;
+    const f16 a16 = __builtin_bit_cast(f16, (uint16_t)(0x6400 | z));   // 1024 + z
+    const f16 b16 = (f16)(float)(-64 - z);
+    *reinterpret_cast<u32x4*>(tile + (4 * lane + q) * PITCH + wave * 16) =
+        __builtin_bit_cast(u32x4, dq8_scaled(wq[q], f16x2{a16, a16}, f16x2{b16, b16}, f16x2{s16, s16}));
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int idx = it * 512 + threadIdx.x, row = idx >> 3, ch = idx & 7;
+    *reinterpret_cast<u32x4*>(wt + (size_t)(n0 + row) * K + kt * 64 + ch * 8) = *reinterpret_cast<const u32x4*>(tile + row * PITCH + ch * 16);
   }
 }
 
@@ -773,14 +850,15 @@ static int launch_large_s(const Wna16LargeParams& p, hipStream_t st) {
   return APHRO_OK;
 }
 
-static int launch_large8(const Wna16LargeParams& p, hipStream_t st) {
+template <bool WDMA>
+static int launch_large8_t(const Wna16LargeParams& p, hipStream_t st) {
   Wna16LargeParams q = p;
   q.tiles_m = (p.M + 255) / 256;
   q.tiles_n = p.N / 256;
   constexpr size_t lds = 128 * 1024;
   static bool attr_set_dev[APHRO_MAX_DEVICES][2] = {};
   bool& attr_set = attr_set_dev[device_slot()][p.out_bf16 ? 1 : 0];
-  const void* fn = p.out_bf16 ? (const void*)wna16_gemm_large8_kernel<true> : (const void*)wna16_gemm_large8_kernel<false>;
+  const void* fn = p.out_bf16 ? (const void*)wna16_gemm_large8_kernel<true, WDMA> : (const void*)wna16_gemm_large8_kernel<false, WDMA>;
   if (!attr_set) {
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
       set_error("wna16_gemm_large: cannot raise the dynamic LDS limit");
@@ -788,10 +866,13 @@ static int launch_large8(const Wna16LargeParams& p, hipStream_t st) {
     }
     attr_set = true;
   }
-  if (p.out_bf16) hipLaunchKernelGGL((wna16_gemm_large8_kernel<true>), dim3(p.grid), dim3(512), lds, st, q);
-  else hipLaunchKernelGGL((wna16_gemm_large8_kernel<false>), dim3(p.grid), dim3(512), lds, st, q);
+  if (p.out_bf16) hipLaunchKernelGGL((wna16_gemm_large8_kernel<true, WDMA>), dim3(p.grid), dim3(512), lds, st, q);
+  else hipLaunchKernelGGL((wna16_gemm_large8_kernel<false, WDMA>), dim3(p.grid), dim3(512), lds, st, q);
   APHRO_LAUNCH_CHECK();
   return APHRO_OK;
+}
+static int launch_large8(const Wna16LargeParams& p, hipStream_t st) {
+  return p.wt != nullptr ? launch_large8_t<true>(p, st) : launch_large8_t<false>(p, st);
 }
 
 // three LDS stages (loads two K tiles ahead, one raw barrier per tile) when the group metadata leaves room for them
@@ -849,6 +930,19 @@ static LargePlan large_plan(int64_t M, int64_t N, int64_t K, int64_t gs) {
   return pl;
 }
 
+// Two-pass form (dequantise-transpose once per call, then the eight-phase schedule with the weights by LDS-DMA): where every
+// weight would otherwise be dequantised by >= TWO_PASS_ROW_TILES row-tile workgroups and the shape runs the eight-phase
+// stream-K plan.  Costs K x N f16 of workspace per call.  APHRO_WNA16_LARGE_TWO_PASS=0/1 forces (tests compare the two forms' bits).
+constexpr int64_t TWO_PASS_MIN_M = 6144;      // (M = 4096: the fused form is 2-4 % faster on all four Llama-3-8B shapes; 8192: 4-14 % slower)
+static bool large_two_pass(const LargePlan& pl, int64_t M, int64_t N, int64_t K, int64_t gs) {
+  const int force = knobs().wna16_large_two_pass;
+  const int eight = knobs().wna16_large_8phase >= 0 ? knobs().wna16_large_8phase : (K >= 2048 ? 1 : 0);
+  const bool can = pl.wm == 2 && pl.wn == 4 && pl.streamk && eight && K % 64 == 0 && N % 256 == 0 && gs % 64 == 0 &&
+                   (size_t)N * K * 2 < 0xffffffffull;
+  if (force >= 0) return can && force != 0;
+  return can && M >= TWO_PASS_MIN_M;
+}
+
 static size_t large_scratch_bytes(const LargePlan& pl, int64_t M, int64_t N) {
   if (pl.streamk) return LARGE_FLAG_BYTES + (size_t)pl.grid * pl.wm * pl.wn * 32 * 1024;
   return pl.ksplit > 1 ? (size_t)pl.ksplit * M * N * sizeof(float) : 0;
@@ -873,6 +967,7 @@ extern "C" size_t aphro_wna16_gemm_large_workspace_bytes(int64_t M, int64_t N, i
   if (groups <= 0 || K % groups != 0) return 0;
   const LargePlan pl = large_plan(M, N, K, K / groups);
   size_t b = dtype == APHRO_BF16 ? ((size_t)M * K * 2 + 255) / 256 * 256 : 0;
+  if (large_two_pass(pl, M, N, K, K / groups)) b += ((size_t)N * K * 2 + 255) / 256 * 256;      // f16 W^T of the two-pass form
   return b + large_scratch_bytes(pl, M, N);
 }
 
@@ -916,6 +1011,15 @@ static int wna16_gemm_large_impl(const void* a, const uint32_t* q_weight, const 
   p.out_bf16 = dtype == APHRO_BF16; p.scale_bf16 = dtype == APHRO_BF16;
   p.tiles_m = p.tiles_n = 0;
   p.w8 = nullptr; p.w_scales = nullptr; p.w_per_channel = 0; p.bias = nullptr;
+  p.wt = nullptr;
+  if (large_two_pass(pl, M, N, K, gs)) {
+    // pass 1: the weights dequantised once into f16 W^T [N, K] (same numerics as the in-loop dequantisation: same bits out)
+    hipLaunchKernelGGL(wna16_dequant_t_kernel, dim3((unsigned)(N / 256), (unsigned)(K / 64)), dim3(512), 0, st, q_weight, qzeros,
+                       (const uint16_t*)scales, (uint16_t*)ws, (int)N, (int)K, (int)gs, zero_offset, p.scale_bf16);
+    APHRO_LAUNCH_CHECK();
+    p.wt = (const uint16_t*)ws;
+    ws += ((size_t)N * K * 2 + 255) / 256 * 256;
+  }
   if (int rcb = large_bind_scratch(p, pl, ws, st)) return rcb;
   int rc;
   // eight-phase schedule on the 256 x 256 stream-K tile from 32 K tiles per output tile up (APHRO_WNA16_LARGE_8PHASE=0/1 forces)
@@ -987,7 +1091,7 @@ extern "C" int aphro_fp8_w8a16_gemm_large(void* out, const void* a, const void* 
     APHRO_LAUNCH_CHECK();
     p.a = (const uint16_t*)workspace; p.lda = (int)K;
   }
-  p.silu = 0;
+  p.silu = 0; p.wt = nullptr;
   p.qw = nullptr; p.qz = nullptr; p.sc = nullptr; p.c = (uint16_t*)out;
   p.M = (int)M; p.N = (int)N; p.K = (int)K; p.group_size = 64; p.zero_offset = 0;
   p.out_bf16 = dtype == APHRO_BF16; p.scale_bf16 = 0;

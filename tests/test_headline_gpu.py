@@ -149,6 +149,34 @@ def test_config1_prefill_sized_gemm_vs_oracle(ops, K, N, M):
     assert torch.equal(got, ops.gptq_gemm(t(a), t(shuf), t(qzeros), t(scales), empty, True, 4))
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("K,N", SHAPES)
+def test_config1_prefill_two_pass_form_is_the_fused_form_bit_for_bit(ops, K, N, dtype):
+    """Round 6: from 6144 rows the W4A16 prefill GEMM dequantises the weights ONCE per call (f16 W^T, the numerics of the in-loop
+    dequantisation) and runs the eight-phase schedule with the weights by LDS-DMA (csrc/wna16_gemm_large.hip, WDMA) -- same tile
+    order, same MFMA order, same operands: the bits of the fused kernel (which the test above holds against the oracle), at
+    8192 rows (default dispatch) and, forced, at a ragged 1000 rows; also the SiluAndMul-epilogue entry point on gate_up."""
+    g = torch.Generator(device=DEV).manual_seed(K * 7 + N)
+    qw = torch.randint(-2 ** 31, 2 ** 31 - 1, (K // 8, N), generator=g, device=DEV, dtype=torch.int64).to(torch.int32)
+    qz = torch.randint(-2 ** 31, 2 ** 31 - 1, (K // 128, N // 8), generator=g, device=DEV, dtype=torch.int64).to(torch.int32)
+    sc = (torch.rand(K // 128, N, generator=g, device=DEV) * 0.01 + 0.005).to(dtype)
+    for M in (8192, 1000):
+        a = torch.randn(M, K, device=DEV, dtype=dtype, generator=g)
+        with ops.knob("APHRO_WNA16_LARGE_TWO_PASS", 0):
+            fused = ops._wna16_large(a, qw, qz, sc, None, 1)
+        with ops.knob("APHRO_WNA16_LARGE_TWO_PASS", 1):
+            two = ops._wna16_large(a, qw, qz, sc, None, 1)
+        assert torch.equal(fused.view(torch.int16), two.view(torch.int16)), (M, K, N)
+        if M == 8192:
+            assert torch.equal(ops._wna16_large(a, qw, qz, sc, None, 1).view(torch.int16), two.view(torch.int16))      # default dispatch
+        if N == 28672 and ops.wna16_gemm_large_silu_supported(M, N, K, K // 128):
+            with ops.knob("APHRO_WNA16_LARGE_TWO_PASS", 0):
+                act_f = ops.wna16_gemm_large_silu(a, qw, qz, sc, 1)
+            with ops.knob("APHRO_WNA16_LARGE_TWO_PASS", 1):
+                act_t = ops.wna16_gemm_large_silu(a, qw, qz, sc, 1)
+            assert torch.equal(act_f.view(torch.int16), act_t.view(torch.int16))
+
+
 def test_prefill_sized_gemm_bf16_act_order_and_odd_rows(ops):
     """bf16 activations / scales (widened to f16 with saturation), act-order gather, M not a multiple of any tile,
     group size 64, against the oracle."""
