@@ -380,6 +380,26 @@ def roofline_section(model, loop, args):
                                                 args.kv_cache_dtype, 1.0, 1.0)
         kname = "paged_attention_kernel<ROPE> (qkv slab reduce + rotary + cache write + attention)"
         ab += slabs.numel() * 4
+    elif args.quant == "fp8ct" and getattr(model, "use_fused_decode", False) and l0.head_dim == 128 and l0.fuse_rope_attention:
+        # the FP8 fused step launches the SCALED-slab form (raw fp32 slabs of the W8A8 qkv GEMM dequantised on the fly, rotary,
+        # cache write; round 6: + absmax partials and the pair-major output for the o_proj GEMM that quantises on load).  Until
+        # round 6 this entry timed the plain kernel (24.9 us at ctx 1024 where the step's form takes 33 us in the trace).
+        slabs = torch.randn(2, bs, ntot, device="cuda", dtype=torch.float32) * 0.1
+        cs_tok = model.cos_sin.index_select(0, loop.positions if hasattr(loop, "positions")
+                                            else (meta.seq_lens_tensor.long() - 1))
+        row_sc = torch.rand(bs, 1, device="cuda") + 0.5
+        col_sc = l0._channel_scale(l0.qkv_proj)
+        dyn_o = getattr(l0.o_proj, "input_scale", None) is None and getattr(l0, "fp8_gate_up_il", None) is not None and bs <= 32
+
+        def run_attn():
+            for kc, vc in caches:
+                ops.paged_attention_rope_scaled(slabs, row_sc, col_sc, None, cs_tok, meta.slot_mapping, kc, vc, l0.num_heads,
+                                                l0.num_kv_heads, l0.attn.scale, meta.block_tables, meta.seq_lens_tensor, 16,
+                                                meta.max_decode_seq_len, None, args.kv_cache_dtype, 1.0, 1.0,
+                                                want_absmax=dyn_o, out_pairs=dyn_o)
+        kname = "paged_attention_kernel<ROPE = scaled slabs> (slab reduce + dequant + rotary + cache write + attention" + \
+            (" + absmax partials, pair-major output)" if dyn_o else ")")
+        ab += slabs.numel() * 4
     else:
         q = torch.randn(bs, ntot, device="cuda", dtype=model.dtype)[:, :l0.q_size]
 

@@ -45,7 +45,9 @@ def test_int4_gemm_plans_through_their_workspace_sizes():
     assert large(256, 6144, 4096) == 4 * slab(256, 6144)          # 8 slices would be 50 MB of slabs: capped
     assert large(1024, 6144, 4096) == 0                           # one slab pair already 50 MB: no split
     assert large(96, 4096, 14336) == 14 * slab(96, 4096)
-    assert large(8192, 28672, 4096) == 4096 + 256 * 8 * 32 * 1024  # stream-K: flags + one image per workgroup
+    assert large(4096, 28672, 4096) == 4096 + 256 * 8 * 32 * 1024  # stream-K: flags + one image per workgroup
+    # round 6, from 6144 rows: + the f16 W^T [N, K] of the two-pass form (dequantised once per call instead of once per row tile)
+    assert large(8192, 28672, 4096) == 28672 * 4096 * 2 + 4096 + 256 * 8 * 32 * 1024
     assert large(256, 28672, 4096, ) % 256 == 0
     mid_ok = lambda m, n, k: L.aphro_wna16_gemm_mid_supported(m, n, k, k // 128)
     mid = lambda m, n, k: L.aphro_wna16_gemm_mid_workspace_bytes(m, n, k, k // 128)
