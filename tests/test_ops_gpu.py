@@ -1520,7 +1520,9 @@ def test_fused_silu_model_matches_unfused(ops, keep_original):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("M_,K,N", [(8192, 4096, 28672), (300, 1024, 2048), (1000, 2048, 4096), (129, 512, 1024)])
+# (the unsliced one-workgroup-per-tile plans need >= 200 tiles: ragged 300 / 129 rows on wide N; round 5's 2048- and 1024-column
+#  cases were K-sliced by the plan and skipped)
+@pytest.mark.parametrize("M_,K,N", [(8192, 4096, 28672), (300, 1024, 14336), (1000, 2048, 4096), (129, 512, 28672)])
 def test_wna16_gemm_large_silu_epilogue_matches_gemm_then_silu(ops, dtype, M_, K, N):
     """Prompt-sized gate_up GEMM on interleaved (gate_j, up_j) columns with SiluAndMul in its epilogue == the same GEMM followed
     by silu_and_mul(interleaved=True), bit for bit (stream-K tiles cut between workgroups, ragged last row tile, bf16), and ==
