@@ -303,7 +303,12 @@ __global__ __launch_bounds__(NW * 64) void paged_attention_kernel(const int32_t*
     }
   };
 
-  for (int hb = 0; hb < gqa; hb += 16) {  // >16 query heads per kv head: extra passes
+  // (the fused forms serve GQA <= 16 only -- checked by the launcher -- : ONE pass, said at compile time, so that hipcc does not
+  //  hoist the pass-invariant address arithmetic of the cache write and the epilogue out of a loop that never repeats: that
+  //  hoisting cost the scaled-slab instantiation 60 bytes of scratch per lane and with it ~4 us per launch -- round 6,
+  //  tools/attn_forms_bench.py: 34.0 us against 28.1 for the plain fused form, whose allocation fits)
+  const int hb_end = fused_rope ? 1 : gqa;
+  for (int hb = 0; hb < hb_end; hb += 16) {  // >16 query heads per kv head: extra passes
     const int nh = min(16, gqa - hb);
     const int head = kvh * gqa + hb + c;  // this lane's query head (valid if c < nh)
     const float slope = (p.alibi != nullptr && c < nh) ? p.alibi[head] : 0.f;
