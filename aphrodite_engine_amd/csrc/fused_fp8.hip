@@ -50,7 +50,10 @@ __device__ __forceinline__ uint32_t fq_pack4_inv(const float (&v)[4], float inv)
 // x = input (T) or T(sa[tok] * (sb[col] * sum_k slabs[k])); residual' = T(x + residual) (or x);
 // y = T(T(residual' * rstd) * w); q = fp8(y / scale), scale = max(absmax(y) / 448, 1/(448*512)).
 // Same thread -> element mapping and reduction order as rms_norm_kernel / add_rms_norm_pack_kernel.
-template <typename T>
+// NS > 0 (round 6, as add_rms_norm_pack_kernel got in round 4): x = the sum of exactly NS slabs with every slab piece of a
+// thread requested before the first one is waited for -- the run-time loop `for (s = 1; s < nslab; ++s) a += slab[s]`
+// compiles to one dependent memory round trip per K slice.  Same summation order, same bits.
+template <typename T, int NS = 0>
 __global__ void add_rms_norm_quant_kernel(const uint16_t* __restrict__ input, const float* __restrict__ slabs,
                                           int nslab, const float* __restrict__ sa, const float* __restrict__ sb,
                                           int sa_per_token, int sb_per_channel, uint16_t* __restrict__ residual,
@@ -73,11 +76,24 @@ __global__ void add_rms_norm_quant_kernel(const uint16_t* __restrict__ input, co
       wv[it] = *reinterpret_cast<const u16x8*>(weight + 8 * i);
       float x[8];
       if (slabs) {
-        f32x4 a = *reinterpret_cast<const f32x4*>(slabs + off);
-        f32x4 b = *reinterpret_cast<const f32x4*>(slabs + off + 4);
-        for (int s = 1; s < nslab; ++s) {
-          a += *reinterpret_cast<const f32x4*>(slabs + s * slab_stride + off);
-          b += *reinterpret_cast<const f32x4*>(slabs + s * slab_stride + off + 4);
+        f32x4 a, b;
+        if constexpr (NS > 0) {
+          f32x4 sa4[NS], sb4[NS];
+#pragma unroll
+          for (int s = 0; s < NS; ++s) {
+            sa4[s] = *reinterpret_cast<const f32x4*>(slabs + s * slab_stride + off);
+            sb4[s] = *reinterpret_cast<const f32x4*>(slabs + s * slab_stride + off + 4);
+          }
+          a = sa4[0]; b = sb4[0];
+#pragma unroll
+          for (int s = 1; s < NS; ++s) { a += sa4[s]; b += sb4[s]; }
+        } else {
+          a = *reinterpret_cast<const f32x4*>(slabs + off);
+          b = *reinterpret_cast<const f32x4*>(slabs + off + 4);
+          for (int s = 1; s < nslab; ++s) {
+            a += *reinterpret_cast<const f32x4*>(slabs + s * slab_stride + off);
+            b += *reinterpret_cast<const f32x4*>(slabs + s * slab_stride + off + 4);
+          }
         }
         const float sav = sa ? sa[sa_per_token ? tok : 0] : 1.f;
         f32x4 sb0, sb1;                                   // the 8 column scales: two 16-byte loads, not 8 conditional ones
@@ -231,12 +247,16 @@ extern "C" int aphro_fused_add_rms_norm_quant_fp8_static(const void* input, cons
   int nv = hidden / 8, t = nv <= 1024 ? nv : (nv + 1) / 2;   // same mapping as the norm kernels (glue.hip)
   t = (t + 63) / 64 * 64;
   t = t < 64 ? 64 : (t > 1024 ? 1024 : t);
-#define L(TT)                                                                                                    \
-  hipLaunchKernelGGL((add_rms_norm_quant_kernel<TT>), dim3((unsigned)tokens), dim3(t), 0, (hipStream_t)stream,    \
+#define L(TT, NSV)                                                                                               \
+  hipLaunchKernelGGL((add_rms_norm_quant_kernel<TT, NSV>), dim3((unsigned)tokens), dim3(t), 0, (hipStream_t)stream, \
                      (const uint16_t*)input, slabs, nslab, slab_a_scales, slab_b_scales, a_scale_per_token,      \
                      b_scale_per_channel, (uint16_t*)residual, has_residual, (const uint16_t*)weight, eps,       \
                      (uint8_t*)q_out, scale_out, (uint16_t*)out, (int)tokens, hidden, static_scale)
-  if (dtype == APHRO_F16) L(Half); else L(BFloat);
+#define LS(NSV) do { if (dtype == APHRO_F16) L(Half, NSV); else L(BFloat, NSV); } while (0)
+  if (slabs != nullptr && nslab == 4) LS(4);
+  else if (slabs != nullptr && nslab == 2) LS(2);
+  else LS(0);
+#undef LS
 #undef L
   APHRO_LAUNCH_CHECK();
   return APHRO_OK;
