@@ -697,3 +697,40 @@ def test_deferred_all_reduce_falls_back_to_the_two_launches(monkeypatch):
     kind, x, slabs, residual, has_residual, weight, eps, pack, want_out = calls[1]
     assert kind == "norm" and torch.equal(x, partial + 1) and slabs is None and residual is res and has_residual is True
     assert weight is w and eps == 1e-5 and pack is False and want_out is True
+
+
+
+def test_environment_surface_is_one_table_read_once():
+    """the C library's environment switches are read in ONE place (csrc/runtime.hip: read_knobs), never
+    on a launch path; every other override is a lab override behind APHRO_LAB_ENV_INT (compiled in by `make LAB=1` only); no lab
+    #ifdef branches in the product kernels; every switch -- C and Python side -- is documented in INTEGRATION.md."""
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "aphrodite_engine_amd", "csrc")
+    names = set()
+    for f in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h"))):
+        src = open(f).read()
+        code = re.sub(r"//[^\n]*", "", src)
+        if os.path.basename(f) == "runtime.hip":
+            names |= set(re.findall(r'(?:env_i|env_l|getenv)\("([A-Z_0-9]+)"', code))
+            continue
+        if os.path.basename(f) == "common.h":
+            code = code.replace("const char* e = getenv(name);", "")          # the one getenv of the LAB-only helper
+        assert "getenv(" not in code, f"{os.path.basename(f)} reads the environment outside runtime.hip"
+        for lab in ("PA_LAB", "FA_LAB", "FA4_LAB", "F8_LAB", "LG_LAB", "ABL_", "LMH_CONTIG", "LMH_KBLOCK", "FA_TRAIL"):
+            assert not re.search(rf"#\s*if[a-z]*\s+.*{lab}", code), f"{os.path.basename(f)} still carries {lab} branches"
+    assert 10 <= len(names) <= 15, sorted(names)
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    for n in names:
+        assert n in doc, f"{n} is read by the library but not documented in INTEGRATION.md"
+    from aphrodite_engine_amd import switches
+    with pytest.raises(KeyError):
+        switches.switch("APHRO_NOT_A_SWITCH")
+    pysrc = ""
+    for f in glob.glob(os.path.join(root, "aphrodite_engine_amd", "**", "*.py"), recursive=True):
+        if os.path.basename(f) not in ("switches.py", "_lib.py"):
+            pysrc += open(f).read()
+    used = set(re.findall(r'switch\("([A-Z_0-9]+)"\)', pysrc))
+    assert used <= set(switches.SWITCHES), used - set(switches.SWITCHES)
+    assert not re.findall(r'os\.environ\.get\("APHRO', pysrc)            # the package reads its switches through the registry only
