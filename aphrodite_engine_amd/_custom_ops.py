@@ -2213,6 +2213,30 @@ def custom_ar_fused_add_rms_norm(fa: int, inp: torch.Tensor, residual: Optional[
     return packed, out
 
 
+def custom_ar_fused_add_rms_norm_quant_fp8(fa: int, inp: torch.Tensor, residual: Optional[torch.Tensor], has_residual: bool,
+                                           weight: torch.Tensor, epsilon: float, want_out: bool = False,
+                                           static_scale: Optional[torch.Tensor] = None,
+                                           reg_buffer: Optional[torch.Tensor] = None):
+    """tensor_model_parallel_all_reduce(inp) -> fused_add_rms_norm(residual) -> scaled_fp8_quant in ONE launch (an FP8
+    W8A8 layer under TP: linear.py:1142-1143, models/llama.py's layernorm, quantization/fp8.py's activation quantisation):
+    the bits of all_reduce_reg / all_reduce_unreg followed by fused_add_rms_norm_quant_fp8(inp, ...).  Returns
+    (q e4m3 [tokens, hidden], scales fp32 [tokens, 1], out or None); ``residual`` is updated in place."""
+    _require_cuda(inp, weight)
+    if inp.dim() != 2 or not inp.is_contiguous() or inp.dtype != weight.dtype or inp.dtype not in (torch.float16, torch.bfloat16):
+        raise RuntimeError("custom_ar_fused_add_rms_norm_quant_fp8: inp must be a contiguous [tokens, hidden] f16 / bf16 tensor of the weight's dtype")
+    tokens, hidden = inp.shape
+    q = torch.empty((tokens, hidden), dtype=FP8_DTYPE, device=inp.device)
+    sc = torch.empty((tokens, 1), dtype=torch.float32, device=inp.device)
+    out = torch.empty((tokens, hidden), dtype=weight.dtype, device=inp.device) if want_out else None
+    _check_static_scale(static_scale, inp.device)
+    check(_lib.lib().aphro_custom_ar_fused_add_rms_norm_quant_fp8(
+        fa, inp.data_ptr(), _ptr(residual), 1 if has_residual else 0, weight.data_ptr(), float(epsilon), q.data_ptr(),
+        sc.data_ptr(), _ptr(static_scale), _ptr(out), tokens, hidden, _dt(weight), _ptr(reg_buffer),
+        reg_buffer.numel() * reg_buffer.element_size() if reg_buffer is not None else 0, _stream()),
+        "custom_ar_fused_add_rms_norm_quant_fp8")
+    return q, sc, out
+
+
 def _ar_check_io(inp: torch.Tensor, out: torch.Tensor):
     _require_cuda(inp, out)
     if inp.dtype != out.dtype or inp.numel() != out.numel():

@@ -260,6 +260,12 @@ struct ArNormParams {
   const u32x4* pf;
   size_t pf_n16;
   int nb;
+  // Q8 kernels (FP8 W8A8 layers under TP): the normalised row also leaves as e4m3 with its per-token scale -- the bits of
+  // add_rms_norm_quant_kernel (fused_fp8.hip) on the all-reduced input: scale = max(absmax(y) / 448, 1 / (448 * 512)),
+  // q = fp8(y / scale); with q8_static: q = fp8(y * (1 / *q8_static)), scale_out = *q8_static.
+  uint8_t* q8_out;                      // [tokens, hidden] e4m3
+  float* q8_scale_out;                  // [tokens]
+  const float* q8_static;               // [1] or null
 };
 
 __device__ __forceinline__ void ar_prefetch_role(const ArNormParams& q) {
@@ -359,7 +365,60 @@ __device__ __forceinline__ void ar_norm_emit(const ArNormParams& q, int row, int
   }
 }
 
-template <typename T, int WORLD>
+// The FP8 epilogue of a Q8 launch: y[it] = this thread's normalised chunks of row `row` (ar_norm_row).
+template <typename T>
+__device__ __forceinline__ void ar_norm_quant(const ArNormParams& q, int row, const u16x8 (&y)[2], int nv, float* red) {
+  constexpr float Q8_MAX = 448.f;
+  float v[2][8];
+  float amax = 0.f;
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int i = threadIdx.x + it * blockDim.x;
+    if (i < nv) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        v[it][j] = T::to_f32(y[it][j]);
+        amax = __builtin_fmaxf(amax, __builtin_fabsf(v[it][j]));
+      }
+    }
+  }
+  float scale, inv_static = 0.f;
+  if (q.q8_static) {
+    scale = *q.q8_static;
+    inv_static = 1.0f / scale;
+  } else {
+    amax = wave_max(amax);
+    const int nw = blockDim.x >> 6;
+    if (nw > 1) {                                          // (red[] is free: ar_block_sum ended on a barrier)
+      if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = amax;
+      __syncthreads();
+      float t = red[0];
+      for (int w = 1; w < nw; ++w) t = __builtin_fmaxf(t, red[w]);
+      amax = t;
+    }
+    scale = __builtin_fmaxf(amax / Q8_MAX, 1.0f / (Q8_MAX * 512.f));
+  }
+  if (threadIdx.x == 0) q.q8_scale_out[row] = scale;
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int i = threadIdx.x + it * blockDim.x;
+    if (i < nv) {
+      float a[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float s = q.q8_static ? v[it][j] * inv_static : v[it][j] / scale;
+        a[j] = __builtin_fmaxf(-Q8_MAX, __builtin_fminf(s, Q8_MAX));
+      }
+      int lo = __builtin_amdgcn_cvt_pk_fp8_f32(a[0], a[1], 0, false);
+      lo = __builtin_amdgcn_cvt_pk_fp8_f32(a[2], a[3], lo, true);
+      int hi = __builtin_amdgcn_cvt_pk_fp8_f32(a[4], a[5], 0, false);
+      hi = __builtin_amdgcn_cvt_pk_fp8_f32(a[6], a[7], hi, true);
+      *reinterpret_cast<u32x2*>(q.q8_out + (size_t)row * q.hidden + 8 * i) = u32x2{(uint32_t)lo, (uint32_t)hi};
+    }
+  }
+}
+
+template <typename T, int WORLD, bool Q8>
 __global__ __launch_bounds__(1024) void ar_norm_one_shot_kernel(ArNormParams q) {
   __shared__ uint32_t ticket;
   __shared__ float red[16];
@@ -396,6 +455,7 @@ __global__ __launch_bounds__(1024) void ar_norm_one_shot_kernel(ArNormParams q) 
     const int i = threadIdx.x + it * blockDim.x;
     if (i < nv) ar_norm_emit<T>(q, tok, i, y[it]);
   }
+  if constexpr (Q8) ar_norm_quant<T>(q, tok, y, nv, red);
   ar_barrier(p, 2, val);                                   // nobody still reads my input when I return
 }
 
@@ -407,7 +467,7 @@ __global__ __launch_bounds__(1024) void ar_norm_one_shot_kernel(ArNormParams q) 
 // instead of `world` times.  (Round-5 lab, loopback communicator, [64, 8192] f16 at 8 ranks: all-reduce 8.0 us + norm 4.4 us
 // as two launches 12.6 us; a reduce-scatter BY ROW with the norm before the gather -- 8 workgroups of 1024 threads doing
 // all of it -- 15.3 us; this form see profiles/r5_ar_norm_fused.txt.)
-template <typename T, int WORLD>
+template <typename T, int WORLD, bool Q8>
 __global__ __launch_bounds__(1024) void ar_norm_two_shot_kernel(ArNormParams q) {
   __shared__ uint32_t ticket;
   __shared__ float red[16];
@@ -451,6 +511,7 @@ __global__ __launch_bounds__(1024) void ar_norm_two_shot_kernel(ArNormParams q) 
     const int i = threadIdx.x + it * blockDim.x;
     if (i < nv) ar_norm_emit<T>(q, row, i, y[it]);
   }
+  if constexpr (Q8) ar_norm_quant<T>(q, row, y, nv, red);
   ar_barrier(p, 2, val);
 }
 
@@ -806,11 +867,12 @@ extern "C" int aphro_custom_ar_fused_norm_one_shot(int world, int64_t tokens, in
 // aphro_custom_ar_all_reduce followed by aphro_fused_add_rms_norm_pack (reference call sites: the row-parallel linear's
 // all-reduce, modeling/layers/linear.py:1142-1143, then models/llama.py's fused_add_rms_norm).  Every rank ends with every
 // row.  prefetch: see ArNormParams.  reg_buffer as in aphro_custom_ar_all_reduce.
-extern "C" int aphro_custom_ar_fused_add_rms_norm(void* fa_, const void* inp, void* residual, int has_residual,
-                                                  const void* weight, float eps, void* packed, void* out,
-                                                  int64_t tokens, int hidden, int dtype,
-                                                  const void* prefetch, size_t prefetch_bytes,
-                                                  void* reg_buffer, size_t reg_buffer_bytes, void* stream) {
+static int ar_fused_norm_launch(void* fa_, const void* inp, void* residual, int has_residual,
+                                const void* weight, float eps, void* packed, void* out,
+                                void* q8_out, float* q8_scale_out, const float* q8_static,
+                                int64_t tokens, int hidden, int dtype,
+                                const void* prefetch, size_t prefetch_bytes,
+                                void* reg_buffer, size_t reg_buffer_bytes, void* stream) {
   CustomAr* fa = (CustomAr*)fa_;
   hipStream_t st = (hipStream_t)stream;
   APHRO_CHECK(fa && inp && weight, "custom_ar_fused_add_rms_norm: NULL argument");
@@ -818,7 +880,9 @@ extern "C" int aphro_custom_ar_fused_add_rms_norm(void* fa_, const void* inp, vo
   APHRO_CHECK(hidden % 8 == 0 && hidden > 0 && hidden <= 16384, "custom_ar_fused_add_rms_norm: hidden=%d unsupported", hidden);
   APHRO_CHECK(packed == nullptr || hidden % 128 == 0, "custom_ar_fused_add_rms_norm: packing needs hidden %% 128 == 0");
   APHRO_CHECK(!has_residual || residual != nullptr, "custom_ar_fused_add_rms_norm: residual missing");
-  APHRO_CHECK(packed != nullptr || out != nullptr, "custom_ar_fused_add_rms_norm: no output requested");
+  APHRO_CHECK(packed != nullptr || out != nullptr || q8_out != nullptr, "custom_ar_fused_add_rms_norm: no output requested");
+  APHRO_CHECK(q8_out == nullptr || q8_scale_out != nullptr, "custom_ar_fused_add_rms_norm: e4m3 output without a scale output");
+  APHRO_CHECK(((uintptr_t)q8_out % 8) == 0, "custom_ar_fused_add_rms_norm: the e4m3 output must be 8-byte aligned");
   APHRO_CHECK(tokens >= 0 && tokens <= (int64_t)AR_MAX_BLOCKS, "custom_ar_fused_add_rms_norm: %lld tokens (at most %d: decode batches)",
               (long long)tokens, AR_MAX_BLOCKS);
   APHRO_CHECK((((uintptr_t)inp | (uintptr_t)residual | (uintptr_t)weight | (uintptr_t)packed | (uintptr_t)out) % 16) == 0,
@@ -845,7 +909,8 @@ extern "C" int aphro_custom_ar_fused_add_rms_norm(void* fa_, const void* inp, vo
   q.tokens = (int)tokens; q.hidden = hidden;
   q.rows_per_rank = (hidden / 8 + fa->world - 1) / fa->world;
   q.replicate_residual = 0;
-  // the block size of aphro_fused_add_rms_norm_pack (same thread -> element mapping, same reduction order)
+  q.q8_out = (uint8_t*)q8_out; q.q8_scale_out = q8_scale_out; q.q8_static = q8_static;
+  // the block size of aphro_fused_add_rms_norm_pack / aphro_fused_add_rms_norm_quant_fp8 (same thread -> element mapping, same reduction order)
   int nv = hidden / 8, t = nv <= 1024 ? nv : (nv + 1) / 2;
   t = (t + 63) / 64 * 64;
   t = t < 64 ? 64 : (t > 1024 ? 1024 : t);
@@ -863,22 +928,52 @@ extern "C" int aphro_custom_ar_fused_add_rms_norm(void* fa_, const void* inp, vo
       blocks += (int)(want > (size_t)max_pf ? (size_t)max_pf : want);
     }
   }
-#define ARN_LAUNCH(TT, W)                                                                              \
-  {                                                                                                    \
-    if (one_shot) hipLaunchKernelGGL((ar_norm_one_shot_kernel<TT, W>), dim3(blocks), dim3(t), 0, st, q); \
-    else hipLaunchKernelGGL((ar_norm_two_shot_kernel<TT, W>), dim3(blocks), dim3(t), 0, st, q);         \
+#define ARN_LAUNCH(TT, W, Q)                                                                              \
+  {                                                                                                       \
+    if (one_shot) hipLaunchKernelGGL((ar_norm_one_shot_kernel<TT, W, Q>), dim3(blocks), dim3(t), 0, st, q); \
+    else hipLaunchKernelGGL((ar_norm_two_shot_kernel<TT, W, Q>), dim3(blocks), dim3(t), 0, st, q);         \
   }
-#define ARN_WORLD(TT)                                                                 \
+#define ARN_WORLD(TT, Q)                                                              \
   switch (fa->world) {                                                               \
-    case 2: ARN_LAUNCH(TT, 2) break;                                                  \
-    case 4: ARN_LAUNCH(TT, 4) break;                                                  \
-    case 6: ARN_LAUNCH(TT, 6) break;                                                  \
-    default: ARN_LAUNCH(TT, 8) break;                                                 \
+    case 2: ARN_LAUNCH(TT, 2, Q) break;                                               \
+    case 4: ARN_LAUNCH(TT, 4, Q) break;                                               \
+    case 6: ARN_LAUNCH(TT, 6, Q) break;                                               \
+    default: ARN_LAUNCH(TT, 8, Q) break;                                              \
   }
-  if (dtype == APHRO_F16) ARN_WORLD(Half)
-  else ARN_WORLD(BFloat)
+  if (q8_out) {
+    if (dtype == APHRO_F16) ARN_WORLD(Half, true)
+    else ARN_WORLD(BFloat, true)
+  } else {
+    if (dtype == APHRO_F16) ARN_WORLD(Half, false)
+    else ARN_WORLD(BFloat, false)
+  }
 #undef ARN_WORLD
 #undef ARN_LAUNCH
   APHRO_LAUNCH_CHECK();
   return APHRO_OK;
+}
+
+extern "C" int aphro_custom_ar_fused_add_rms_norm(void* fa_, const void* inp, void* residual, int has_residual,
+                                                  const void* weight, float eps, void* packed, void* out,
+                                                  int64_t tokens, int hidden, int dtype,
+                                                  const void* prefetch, size_t prefetch_bytes,
+                                                  void* reg_buffer, size_t reg_buffer_bytes, void* stream) {
+  return ar_fused_norm_launch(fa_, inp, residual, has_residual, weight, eps, packed, out, nullptr, nullptr, nullptr, tokens,
+                              hidden, dtype, prefetch, prefetch_bytes, reg_buffer, reg_buffer_bytes, stream);
+}
+
+// The FP8 W8A8 form: all_reduce(inp) -> fused_add_rms_norm(residual) -> per-token (or static) FP8
+// quantisation of the normalised row in ONE launch -- the bits of aphro_custom_ar_all_reduce followed by
+// aphro_fused_add_rms_norm_quant_fp8 on its `input` path (reference call sites: linear.py:1142-1143, models/llama.py's
+// layernorm, then the scaled_fp8_quant at the head of Fp8LinearMethod.apply, quantization/fp8.py).  q_out [tokens, hidden]
+// e4m3, scale_out [tokens] (static_scale [1]: q = fp8(y * (1 / s)) and every scale_out entry = s); `out`: optional
+// row-major T copy of the normalised rows (the last norm of the model).
+extern "C" int aphro_custom_ar_fused_add_rms_norm_quant_fp8(void* fa_, const void* inp, void* residual, int has_residual,
+                                                            const void* weight, float eps, void* q_out, float* scale_out,
+                                                            const float* static_scale, void* out, int64_t tokens,
+                                                            int hidden, int dtype, void* reg_buffer,
+                                                            size_t reg_buffer_bytes, void* stream) {
+  APHRO_CHECK(q_out && scale_out, "custom_ar_fused_add_rms_norm_quant_fp8: NULL output");
+  return ar_fused_norm_launch(fa_, inp, residual, has_residual, weight, eps, nullptr, out, q_out, scale_out, static_scale,
+                              tokens, hidden, dtype, nullptr, 0, reg_buffer, reg_buffer_bytes, stream);
 }

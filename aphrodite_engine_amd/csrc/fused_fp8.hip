@@ -132,8 +132,13 @@ __global__ void add_rms_norm_quant_kernel(const uint16_t* __restrict__ input, co
         }
       }
       if (residual) *reinterpret_cast<u16x8*>(residual + off) = rs;
+      {
+        // squares rounded, then added -- pinned as in add_rms_norm_pack_kernel: the all-reduce + norm + quant launch
+        // (custom_all_reduce.hip, Q8 kernels) reproduces this row bit for bit; left alone hipcc contracted two of the eight
+#pragma clang fp contract(off)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) ss += v[it][j] * v[it][j];
+        for (int j = 0; j < 8; ++j) ss += v[it][j] * v[it][j];
+      }
     }
   }
   ss = fq_block_reduce(ss, red, false);

@@ -330,6 +330,18 @@ def tensor_model_parallel_all_reduce_norm(input_: torch.Tensor, residual: Option
                                          prefetch=prefetch)
 
 
+def tensor_model_parallel_all_reduce_norm_quant_fp8(input_: torch.Tensor, residual: Optional[torch.Tensor],
+                                                   has_residual: bool, weight: torch.Tensor, epsilon: float,
+                                                   want_out: bool = False, static_scale: Optional[torch.Tensor] = None):
+    """tensor_model_parallel_all_reduce_norm for an FP8 W8A8 layer: the all-reduce, fused_add_rms_norm and the next
+    linear's activation quantisation (quantization/fp8.py -> ops.scaled_fp8_quant) as ONE launch -- the bits of
+    tensor_model_parallel_all_reduce -> ops.fused_add_rms_norm_quant_fp8.  Returns (q, scales, out) or None."""
+    if _TP_SIZE == 1 or _CUSTOM_AR is None or _OVERLAP is not None or not input_.is_cuda:
+        return None
+    return _CUSTOM_AR.fused_add_rms_norm_quant_fp8(input_, residual, has_residual, weight, epsilon, want_out=want_out,
+                                                   static_scale=static_scale)
+
+
 class DeferredAllReduce:
     """A row-parallel projection's per-rank partial sums [tokens, hidden] whose all-reduce has NOT been issued: the norm
     that consumes them runs it in its own launch (``finish``)."""
@@ -352,6 +364,18 @@ class DeferredAllReduce:
             from .. import _custom_ops as ops
             x = tensor_model_parallel_all_reduce(self.partial)
             res = ops.fused_add_rms_norm_pack(x, None, residual, True, weight, epsilon, pack=pack, want_out=want_out)
+        return res
+
+    def finish_quant_fp8(self, residual, weight, epsilon, want_out=False, static_scale=None):
+        """finish() for a consumer that is an FP8 W8A8 linear: (q, scales, out) of ops.fused_add_rms_norm_quant_fp8 on the
+        all-reduced partial, one launch."""
+        res = tensor_model_parallel_all_reduce_norm_quant_fp8(self.partial, residual, True, weight, epsilon,
+                                                              want_out=want_out, static_scale=static_scale)
+        if res is None:     # (as in finish: the two launches the fused one stands for -- same bits)
+            from .. import _custom_ops as ops
+            x = tensor_model_parallel_all_reduce(self.partial)
+            res = ops.fused_add_rms_norm_quant_fp8(x, None, None, None, residual, True, weight, epsilon, want_out=want_out,
+                                                   static_scale=static_scale)
         return res
 
 

@@ -212,6 +212,28 @@ class CustomAllreduce:
             self.check()
         return res
 
+    def fused_add_rms_norm_quant_fp8(self, inp: torch.Tensor, residual: Optional[torch.Tensor], has_residual: bool,
+                                     weight: torch.Tensor, epsilon: float, want_out: bool = False,
+                                     static_scale: Optional[torch.Tensor] = None):
+        """custom_all_reduce(inp) followed by ops.fused_add_rms_norm_quant_fp8(out, None, None, None, residual, ...) in
+        ONE launch, same bits.  None = not eligible.  Returns (q, scales, out)."""
+        if self.disabled or not self.fused_norm_eligible(inp):
+            return None
+        kw = dict(want_out=want_out, static_scale=static_scale)
+        if self._IS_CAPTURING:
+            if torch.cuda.is_current_stream_capturing():
+                return self._ops.custom_ar_fused_add_rms_norm_quant_fp8(self._ptr, inp, residual, has_residual, weight,
+                                                                        epsilon, **kw)
+            # warm-up run before the capture: shapes only (the residual is left alone)
+            return self._ops.fused_add_rms_norm_quant_fp8(torch.zeros_like(inp), None, None, None, torch.empty_like(inp),
+                                                          False, weight, epsilon, **kw)
+        res = self._ops.custom_ar_fused_add_rms_norm_quant_fp8(self._ptr, inp, residual, has_residual, weight, epsilon,
+                                                               reg_buffer=self.buffer, **kw)
+        self._calls += 1
+        if self._check_every > 0 and self._calls % self._check_every == 0:
+            self.check()
+        return res
+
     def check(self) -> None:
         """Raise if one of this rank's barriers timed out since the last call."""
         if not self.disabled and self._ops.custom_ar_error(self._ptr):
@@ -270,6 +292,12 @@ class LoopbackAllreduce:
             return None
         return self._ops.custom_ar_fused_add_rms_norm(self._ptr, inp, residual, has_residual, weight, epsilon, pack=pack,
                                                       want_out=want_out, prefetch=prefetch)
+
+    def fused_add_rms_norm_quant_fp8(self, inp, residual, has_residual, weight, epsilon, want_out=False, static_scale=None):
+        if not self.fused_norm_eligible(inp):
+            return None
+        return self._ops.custom_ar_fused_add_rms_norm_quant_fp8(self._ptr, inp, residual, has_residual, weight, epsilon,
+                                                                want_out=want_out, static_scale=static_scale)
 
     def check(self) -> None:
         if self._ptr and self._ops.custom_ar_error(self._ptr):

@@ -554,7 +554,9 @@ class LlamaDecoderLayer(nn.Module):
         # static scheme: each projection's input_scale ([1]) goes to the kernel that quantises its input
         s_qkv, s_o = self.qkv_proj.input_scale, self.o_proj.input_scale
         s_gu, s_dn = self.gate_up_proj.input_scale, self.down_proj.input_scale
-        if prev is None:
+        if isinstance(x, DeferredAllReduce):      # TP: the previous layer's down_proj all-reduce runs inside this norm + quant launch
+            qx, sx, _ = x.finish_quant_fp8(residual, self.input_layernorm, eps, static_scale=s_qkv)
+        elif prev is None:
             qx, sx, _ = ops.fused_add_rms_norm_quant_fp8(x, None, None, None, residual, not first,
                                                          self.input_layernorm, eps, static_scale=s_qkv)
         else:
@@ -596,9 +598,15 @@ class LlamaDecoderLayer(nn.Module):
         if self.tp > 1:
             o = ops.cutlass_scaled_mm(qa, self.o_proj.weight, out_dtype=act_dtype, scale_a=sa,
                                       scale_b=self.o_proj.weight_scale)
-            o = tensor_model_parallel_all_reduce(o)
-            qh, sh, _ = ops.fused_add_rms_norm_quant_fp8(o, None, None, None, residual, True,
-                                                         self.post_attention_layernorm, eps, static_scale=s_gu)
+            # all-reduce + residual add + norm + the gate_up input quantisation: one launch of the peer-access kernel
+            # (csrc/custom_all_reduce.hip, Q8 form) where the communicator serves the shape, else the two launches
+            deferred = defer_all_reduce(o)
+            if deferred is not None:
+                qh, sh, _ = deferred.finish_quant_fp8(residual, self.post_attention_layernorm, eps, static_scale=s_gu)
+            else:
+                o = tensor_model_parallel_all_reduce(o)
+                qh, sh, _ = ops.fused_add_rms_norm_quant_fp8(o, None, None, None, residual, True,
+                                                             self.post_attention_layernorm, eps, static_scale=s_gu)
         else:
             if o_slabs is None:
                 o_slabs = self._fp8_slabs("o_proj", qa)
@@ -633,7 +641,8 @@ class LlamaDecoderLayer(nn.Module):
         if self.tp > 1:
             d = ops.cutlass_scaled_mm(qd, self.down_proj.weight, out_dtype=act_dtype, scale_a=sd,
                                       scale_b=self.down_proj.weight_scale)
-            return tensor_model_parallel_all_reduce(d), None
+            deferred = defer_all_reduce(d)          # (the next layer's input norm, or the model's last norm, finishes it)
+            return (deferred if deferred is not None else tensor_model_parallel_all_reduce(d)), None
         if down_slabs is None:
             down_slabs = self._fp8_slabs("down_proj", qd)
         return None, (down_slabs, sd, self.down_proj.weight_scale)
@@ -860,7 +869,9 @@ class LlamaForCausalLM(nn.Module):
             for i, layer in enumerate(self.layers):
                 x, prev = layer.forward_decode_fused_fp8(positions, x, prev, residual, i == 0, kv_caches[i],
                                                          attn_metadata, self.cos_sin, cos_sin_tok)
-            if prev is None:
+            if isinstance(x, DeferredAllReduce):
+                _, _, out = x.finish_quant_fp8(residual, self.norm, self.cfg.rms_norm_eps, want_out=True)
+            elif prev is None:
                 _, _, out = ops.fused_add_rms_norm_quant_fp8(x, None, None, None, residual, True, self.norm,
                                                              self.cfg.rms_norm_eps, want_out=True)
             else:

@@ -595,6 +595,17 @@ int aphro_custom_ar_fused_add_rms_norm(void* fa, const void* inp, void* residual
                                        int64_t tokens, int hidden, int dtype,
                                        const void* prefetch, size_t prefetch_bytes,
                                        void* reg_buffer, size_t reg_buffer_bytes, void* stream);
+/* The same launch for an FP8 W8A8 layer under tensor parallelism: the all-reduce of the row-parallel linear
+ * (modeling/layers/linear.py:1142-1143), the residual add + RMSNorm (kernels/layernorm_kernels.cu:200-240) and the
+ * activation quantisation at the head of the next FP8 linear (quantization/fp8.py Fp8LinearMethod.apply ->
+ * ops.scaled_fp8_quant, kernels/quantization/fp8/common.cu:187-256) -- the bits of aphro_custom_ar_all_reduce ->
+ * aphro_fused_add_rms_norm_quant_fp8(input = the sum).  q_out [tokens, hidden] e4m3; scale_out [tokens] f32 (dynamic
+ * per-token: max(absmax / 448, 1 / (448 * 512)); static_scale [1] given: q = fp8(y * (1 / s)), every entry = s);
+ * `out` (optional): the normalised rows in the activation dtype.  tokens <= 64. */
+int aphro_custom_ar_fused_add_rms_norm_quant_fp8(void* fa, const void* inp, void* residual, int has_residual,
+                                                 const void* weight, float eps, void* q_out, float* scale_out,
+                                                 const float* static_scale, void* out, int64_t tokens, int hidden,
+                                                 int dtype, void* reg_buffer, size_t reg_buffer_bytes, void* stream);
 /* Loopback communicator (timing rig for ONE rank of a TP group on a one-GPU box, bench.py --sim-tp): `world` ranks that
  * all resolve to this process's buffers; the kernels above run unchanged (flags and scratch through uncached memory,
  * `world` reads per element) with local memory in place of the xGMI links.  Results are not a sum over real ranks. */

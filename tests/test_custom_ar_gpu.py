@@ -281,6 +281,106 @@ def _ar_norm_worker(rank, world, port, one_shot_max):
         dist.destroy_process_group()
 
 
+def _ar_norm_quant_worker(rank, world, port, one_shot_max):
+    """ca.fused_add_rms_norm_quant_fp8(x, residual, ...) == ca.custom_all_reduce(x) -> ops.fused_add_rms_norm_quant_fp8(...)
+    bit for bit -- e4m3 bytes, per-token scales, the row-major copy and the residual -- dynamic per-token and static scheme,
+    one-shot and two-shot form, eagerly and from a captured graph; the bytes are also the oracle's quantisation
+    (fp8/common.cu:187-256) of the normalised rows the launch returned."""
+    import os
+    if one_shot_max is not None:
+        os.environ["APHRO_CUSTOM_AR_ONE_SHOT_MAX"] = str(one_shot_max)
+    import torch.distributed as dist
+    from aphrodite_engine_amd import _custom_ops as ops
+    from aphrodite_engine_amd.distributed.custom_all_reduce import CustomAllreduce
+    from oracle import fp8 as ofp8
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    ca = CustomAllreduce(dist.group.WORLD, dev, max_size=4 * 1024 * 1024)
+    assert not ca.disabled
+    gen = torch.Generator(device="cpu")
+    try:
+        cases = [(torch.float16, 32, 4096), (torch.bfloat16, 64, 8192), (torch.float16, 1, 1024), (torch.float16, 7, 5120),
+                 (torch.float16, 17, 16384), (torch.bfloat16, 3, 4096)]
+        for dtype, tokens, hidden in cases:
+            gen.manual_seed(17 * tokens + hidden)
+            parts = [(torch.randn(tokens, hidden, generator=gen) * 2).to(dtype) for _ in range(world)]
+            if tokens > 2:
+                for q_ in parts:
+                    q_[2].zero_()              # an all-zero row: the scale floor 1 / (448 * 512)
+            res0 = (torch.randn(tokens, hidden, generator=gen) * 3).to(dtype).to(dev)
+            w = (torch.rand(hidden, generator=gen) + 0.5).to(dtype).to(dev)
+            x = parts[rank].to(dev)
+            one_shot = ops.custom_ar_fused_norm_one_shot(world, tokens, hidden, 2)
+            for has_res in (True, False):
+                for static in (None, torch.tensor([0.037], dtype=torch.float32, device=dev)):
+                    for want_out in (False, True):
+                        r_ref = res0.clone()
+                        summed = ca.custom_all_reduce(x)
+                        q_ref, s_ref, o_ref = ops.fused_add_rms_norm_quant_fp8(summed, None, None, None, r_ref, has_res, w, 1e-5,
+                                                                               want_out=want_out, static_scale=static)
+                        r_got = res0.clone()
+                        got = ca.fused_add_rms_norm_quant_fp8(x, r_got, has_res, w, 1e-5, want_out=want_out, static_scale=static)
+                        assert got is not None
+                        torch.cuda.synchronize()
+                        ca.check()
+                        tag = f"{dtype} {tokens}x{hidden} world {world} one_shot={one_shot} res={has_res} static={static is not None} out={want_out}"
+                        assert torch.equal(got[0].view(torch.uint8), q_ref.view(torch.uint8)), tag
+                        assert torch.equal(got[1], s_ref), tag
+                        assert torch.equal(r_got, r_ref), tag
+                        if want_out:
+                            assert torch.equal(got[2], o_ref), tag
+                            # the oracle on the rows the launch returned: same bytes, same scales
+                            y = got[2].float().cpu().numpy()
+                            if static is None:
+                                q_o, s_o = ofp8.dynamic_per_token_scaled_fp8_quant(y)
+                                assert np.array_equal(np.asarray(s_o, np.float32).reshape(-1), got[1].cpu().numpy().reshape(-1)), tag
+                            else:
+                                q_o = ofp8.static_scaled_fp8_quant(y, np.float32(0.037))
+                                assert (got[1].cpu().numpy() == np.float32(0.037)).all(), tag
+                            assert np.array_equal(np.asarray(q_o, np.uint8), got[0].view(torch.uint8).cpu().numpy()), tag
+                        assert torch.equal(x.cpu(), parts[rank])
+        # captured
+        tokens, hidden = 32, 4096
+        a = torch.empty(tokens, hidden, dtype=torch.float16, device=dev)
+        res = torch.zeros(tokens, hidden, dtype=torch.float16, device=dev)
+        w = torch.ones(hidden, dtype=torch.float16, device=dev)
+        g = torch.cuda.CUDAGraph()
+        with ca.capture():
+            assert ca.fused_add_rms_norm_quant_fp8(a, res, True, w, 1e-5, want_out=True) is not None     # warm-up: shapes only
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s), torch.cuda.graph(g, stream=s):
+                q8, sc, out = ca.fused_add_rms_norm_quant_fp8(a * 1.0, res, True, w, 1e-5, want_out=True)
+        for it in range(4):
+            gen.manual_seed(9 + it)
+            parts = [torch.randn(tokens, hidden, generator=gen).half() for _ in range(world)]
+            a.copy_(parts[rank])
+            res.fill_(0.25 * it)
+            r_ref = res.clone()
+            torch.cuda.synchronize()
+            dist.barrier()
+            g.replay()
+            torch.cuda.synchronize()
+            ca.check()
+            q_ref, s_ref, o_ref = ops.fused_add_rms_norm_quant_fp8(_expected(parts, torch.float16).to(dev), None, None, None, r_ref,
+                                                                   True, w, 1e-5, want_out=True)
+            assert torch.equal(out, o_ref) and torch.equal(q8.view(torch.uint8), q_ref.view(torch.uint8))
+            assert torch.equal(sc, s_ref) and torch.equal(res, r_ref)
+            dist.barrier()
+        assert ca.fused_add_rms_norm_quant_fp8(torch.zeros(65, 4096, dtype=torch.float16, device=dev), None, False, w, 1e-5) is None
+    finally:
+        ca.close()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,one_shot_max", [(4, None), (2, 65536), (4, 0)])
+def test_fused_all_reduce_norm_quant_fp8_ranks_on_one_gpu(world, one_shot_max):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    _spawn(_ar_norm_quant_worker, world, one_shot_max, timeout=240)
+
+
 @pytest.mark.parametrize("world,one_shot_max", [(4, None), (2, 65536), (4, 0)])
 def test_fused_all_reduce_norm_ranks_on_one_gpu(world, one_shot_max):
     if not torch.cuda.is_available():
@@ -320,6 +420,14 @@ def test_loopback_all_reduce_runs_the_real_kernels():
                 assert torch.equal(o, o_ref) and torch.equal(r_got, r_ref) and torch.equal(pk[pos], p_ref[pos])
             else:      # column slices: "rank 0" sums the first eighth of every row; the slices it gathers from itself were never written
                 assert o.shape == o_ref.shape and torch.isfinite(o.float()).all()
+            # the FP8 W8A8 form of the launch (norm + per-token quantisation of the next GEMM's input)
+            r_ref, r_got = res.clone(), res.clone()
+            q_ref, s_ref, _ = ops.fused_add_rms_norm_quant_fp8(x * 8, None, None, None, r_ref, True, w, 1e-5)
+            q8, s8, _ = ca.fused_add_rms_norm_quant_fp8(x, r_got, True, w, 1e-5)
+            torch.cuda.synchronize()
+            ca.check()
+            if one_shot:
+                assert torch.equal(q8.view(torch.uint8), q_ref.view(torch.uint8)) and torch.equal(s8, s_ref) and torch.equal(r_got, r_ref)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 o2 = ca.custom_all_reduce(x)
@@ -332,7 +440,7 @@ def test_loopback_all_reduce_runs_the_real_kernels():
         ca.close()
 
 
-def _tp_fused_norm_model_worker(rank, world, port, one_shot_max, moe):
+def _tp_fused_norm_model_worker(rank, world, port, one_shot_max, moe, quant="gptq"):
     """TP decode with every row-parallel all-reduce folded into the norm launch that follows it == the same step with
     all-reduce and norm as two launches, bit for bit (one-shot, and the two-shot column-slice form); the fused form really ran (2 per layer + the final norm - 1 for the first layer's plain norm)."""
     import os
@@ -351,19 +459,27 @@ def _tp_fused_norm_model_worker(rank, world, port, one_shot_max, moe):
                         num_key_value_heads=4, vocab_size=512, max_position_embeddings=1024, **kw)
     try:
         with torch.no_grad():
-            m = M.LlamaForCausalLM(cfg, GPTQConfig(4, 128, False), torch.float16).init_synthetic(dev)
+            if quant == "gptq":
+                qc = GPTQConfig(4, 128, False)
+            else:       # FP8 W8A8: the norm launch that finishes the all-reduce also quantises the next GEMM's input
+                from aphrodite_engine_amd.quantization.fp8 import CompressedTensorsW8A8Fp8Config
+                qc = CompressedTensorsW8A8Fp8Config("channel", is_static_input_scheme=quant == "fp8_static")
+            m = M.LlamaForCausalLM(cfg, qc, torch.float16).init_synthetic(dev)
             lens = [3, 17, 64, 200, 129, 5, 77, 31, 1, 250]
             meta, pos, nblocks = M.make_decode_metadata(len(lens), lens, 16, "cuda:0")
             ids = torch.randint(0, cfg.vocab_size, (len(lens), ), device=dev, generator=torch.Generator(device=dev).manual_seed(1))
             ca = D.enable_custom_all_reduce(dev)
             assert ca is not None and not ca.disabled
             calls = {"n": 0}
-            orig = ca.fused_add_rms_norm
+            fused_name = "fused_add_rms_norm" if quant == "gptq" else "fused_add_rms_norm_quant_fp8"
+            orig = getattr(ca, fused_name)
 
             def counted(*a, **k):
                 calls["n"] += 1
-                return orig(*a, **k)
-            ca.fused_add_rms_norm = counted
+                res = orig(*a, **k)
+                assert res is not None
+                return res
+            setattr(ca, fused_name, counted)
 
             def step():
                 caches = M.make_kv_caches(cfg, nblocks, 16, torch.float16, "auto", "cuda:0", seed=3)
@@ -405,11 +521,12 @@ def _tp_fused_norm_model_worker(rank, world, port, one_shot_max, moe):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("one_shot_max,moe", [(None, False), (0, False), (None, True)])
-def test_tp2_decode_fused_all_reduce_norm_is_bit_identical(one_shot_max, moe):
+@pytest.mark.parametrize("one_shot_max,moe,quant", [(None, False, "gptq"), (0, False, "gptq"), (None, True, "gptq"),
+                                                    (None, False, "fp8"), (0, False, "fp8"), (None, False, "fp8_static")])
+def test_tp2_decode_fused_all_reduce_norm_is_bit_identical(one_shot_max, moe, quant):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
-    _spawn(_tp_fused_norm_model_worker, 2, one_shot_max, moe, timeout=240)
+    _spawn(_tp_fused_norm_model_worker, 2, one_shot_max, moe, quant, timeout=240)
 
 
 def _schema_worker(rank, world, port):
