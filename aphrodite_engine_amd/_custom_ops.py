@@ -235,11 +235,13 @@ def _partition_size(tmp_out: torch.Tensor, max_seq_len: int) -> int:
 def flash_attn_varlen(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor,
                       cu_seqlens: torch.Tensor, max_seqlen: int, softmax_scale: float,
                       causal: bool = True,
-                      alibi_slopes: Optional[torch.Tensor] = None) -> torch.Tensor:
+                      alibi_slopes: Optional[torch.Tensor] = None,
+                      window_size: Optional[tuple] = None) -> torch.Tensor:
     """Prefill self-attention over packed sequences: the role of
     triton_attention / flash_attn_varlen_func in ROCmFlashAttentionImpl
     (rocm_flash_attn.py:455-508).  q [T,Hq,hd], k/v [T,Hkv,hd] (token-strided
-    views allowed), cu_seqlens int32 [B+1]; returns [T,Hq,hd]."""
+    views allowed), cu_seqlens int32 [B+1]; returns [T,Hq,hd].  ``window_size`` = flash_attn_varlen_func's (left, right)
+    (rocm_flash_attn.py:506; (-1, -1) / None = off): under causal attention query i sees keys i - left .. i."""
     _require_cuda(q, k, v, cu_seqlens)
     t, hq, hd = q.shape
     hkv = k.shape[1]
@@ -251,6 +253,17 @@ def flash_attn_varlen(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor,
     out = torch.empty((t, hq, hd), dtype=q.dtype, device=q.device)
     if alibi_slopes is not None and alibi_slopes.dtype != torch.float32:
         alibi_slopes = alibi_slopes.float()
+    left = int(window_size[0]) if window_size is not None else -1
+    if left >= 0:
+        if not causal:
+            raise RuntimeError("flash_attn_varlen: a sliding window needs causal attention")
+        check(_lib.lib().aphro_flash_attn_varlen_window(
+            out.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(),
+            cu_seqlens.data_ptr(), cu_seqlens.numel() - 1, int(max_seqlen), hq, hkv, hd,
+            q.stride(0), k.stride(0), v.stride(0), float(softmax_scale),
+            1, _ptr(alibi_slopes), left + 1, _dt(q), _stream()),
+            "flash_attn_varlen")
+        return out
     check(_lib.lib().aphro_flash_attn_varlen(
         out.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(),
         cu_seqlens.data_ptr(), cu_seqlens.numel() - 1, int(max_seqlen), hq, hkv, hd,

@@ -143,6 +143,7 @@ SIGNATURES = {
     "aphro_silu_and_mul_interleaved": (I, [P, P, L, I, I, P]),
     "aphro_rotary_embedding": (I, [P, P, P, L, I, I, I, I, P, L, L, I, I, P]),
     "aphro_flash_attn_varlen": (I, [P, P, P, P, P, I, I, I, I, I, L, L, L, F, I, P, I, P]),
+    "aphro_flash_attn_varlen_window": (I, [P, P, P, P, P, I, I, I, I, I, L, L, L, F, I, P, I, I, P]),
     "aphro_context_attention": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, L, L, L, L,
                                     F, F, F, P, I, I, I, P]),
     "aphro_context_attention_workspace_bytes": (Z, [L, I, I, I]),

@@ -157,8 +157,6 @@ class MI355XAttentionImpl:
             raise ValueError("MI355X backend does not support blocksparse attention.")
         if logits_soft_cap is not None:
             raise ValueError("MI355X backend does not support attention logits soft capping.")
-        if sliding_window is not None:
-            raise ValueError("MI355X backend does not support sliding window yet.")
         self.num_heads = num_heads
         self.head_size = head_size
         self.scale = float(scale)
@@ -166,7 +164,10 @@ class MI355XAttentionImpl:
         self.alibi_slopes = (torch.tensor(alibi_slopes, dtype=torch.float32)
                              if alibi_slopes is not None else None)
         self.kv_cache_dtype = kv_cache_dtype
-        self.sliding_window = None
+        # rocm_flash_attn.py:321-322: the window reaches the prompt kernels (flash_attn_varlen_func's window_size, the
+        # cached-context kernel's sliding_window); decode sees it through the metadata builder's trimmed block tables and
+        # clipped sequence lengths (attention/backends/utils.py:150-185), not through the paged-attention kernel
+        self.sliding_window = ((sliding_window, sliding_window) if sliding_window is not None else (-1, -1))
         assert self.num_heads % self.num_kv_heads == 0
         self.num_queries_per_kv = self.num_heads // self.num_kv_heads
         supported = PagedAttention.get_supported_head_sizes()
@@ -222,7 +223,7 @@ class MI355XAttentionImpl:
                     query, key, value, self.kv_cache_dtype, key_cache, value_cache,
                     prefill_meta.block_tables, prefill_meta.query_start_loc,
                     prefill_meta.seq_lens_tensor, prefill_meta.context_lens_tensor,
-                    prefill_meta.max_query_len, self.alibi_slopes, self.sliding_window,
+                    prefill_meta.max_query_len, self.alibi_slopes, self.sliding_window[0],
                     k_scale, v_scale,
                     # host-side maxima of the prefill sequences (seq_lens is a Python list): no .item() per layer
                     max_seq_len=max(prefill_meta.seq_lens), total_kv_tokens=sum(prefill_meta.seq_lens))
@@ -230,7 +231,7 @@ class MI355XAttentionImpl:
                 out = ops.flash_attn_varlen(
                     query, key, value, prefill_meta.seq_start_loc,
                     prefill_meta.max_prefill_seq_len, self.scale, causal=True,
-                    alibi_slopes=self.alibi_slopes)
+                    alibi_slopes=self.alibi_slopes, window_size=self.sliding_window)
                 output[:num_prefill_tokens] = out
 
         if decode_meta := attn_metadata.decode_metadata:

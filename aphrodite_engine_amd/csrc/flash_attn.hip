@@ -1219,11 +1219,15 @@ extern "C" int aphro_context_attention_gathered(void* out, const void* q, const 
 }
 
 
-extern "C" int aphro_flash_attn_varlen(void* out, const void* q, const void* k, const void* v,
-                                       const int32_t* cu_seqlens, int batch, int max_seqlen, int num_heads,
-                                       int num_kv_heads, int head_size, int64_t q_stride, int64_t k_stride,
-                                       int64_t v_stride, float scale, int causal, const float* alibi_slopes,
-                                       int dtype, void* stream) {
+// window > 0 (causal only): query i sees keys j with i - j < window -- flash_attn_varlen_func's window_size = (left, *) under
+// causal = True is window = left + 1 (rocm_flash_attn.py:497-507).  The windowed form runs on the first / second generation
+// tile machines (their key loops start at the first visible key tile).
+static int fa_varlen_entry(void* out, const void* q, const void* k, const void* v,
+                           const int32_t* cu_seqlens, int batch, int max_seqlen, int num_heads,
+                           int num_kv_heads, int head_size, int64_t q_stride, int64_t k_stride,
+                           int64_t v_stride, float scale, int causal, const float* alibi_slopes, int window,
+                           int dtype, void* stream) {
+  APHRO_CHECK(window <= 0 || causal, "flash_attn_varlen: a sliding window needs causal attention");
   APHRO_CHECK(dtype == APHRO_F16 || dtype == APHRO_BF16, "flash_attn_varlen: dtype must be f16 or bf16");
   APHRO_CHECK(num_kv_heads > 0 && num_heads % num_kv_heads == 0, "flash_attn_varlen: bad head counts");
   APHRO_CHECK(q_stride % 8 == 0 && k_stride % 8 == 0 && v_stride % 8 == 0, "flash_attn_varlen: strides must be multiples of 8");
@@ -1234,7 +1238,26 @@ extern "C" int aphro_flash_attn_varlen(void* out, const void* q, const void* k, 
   p.num_heads = num_heads; p.num_kv_heads = num_kv_heads;
   p.q_stride = q_stride; p.k_stride = k_stride; p.v_stride = v_stride;
   p.scale = scale; p.causal = causal;
-  p.cu_seqlens_k = nullptr; p.o_stride = (int64_t)num_heads * head_size; p.nqt_max = 0; p.xcd_remap = 0; p.window = 0;
+  p.cu_seqlens_k = nullptr; p.o_stride = (int64_t)num_heads * head_size; p.nqt_max = 0; p.xcd_remap = 0;
+  p.window = window > 0 ? window : 0;
   return fa_dispatch(p, head_size, dtype, batch, max_seqlen, max_seqlen, (hipStream_t)stream);
+}
+
+extern "C" int aphro_flash_attn_varlen(void* out, const void* q, const void* k, const void* v,
+                                       const int32_t* cu_seqlens, int batch, int max_seqlen, int num_heads,
+                                       int num_kv_heads, int head_size, int64_t q_stride, int64_t k_stride,
+                                       int64_t v_stride, float scale, int causal, const float* alibi_slopes,
+                                       int dtype, void* stream) {
+  return fa_varlen_entry(out, q, k, v, cu_seqlens, batch, max_seqlen, num_heads, num_kv_heads, head_size, q_stride, k_stride,
+                         v_stride, scale, causal, alibi_slopes, 0, dtype, stream);
+}
+
+extern "C" int aphro_flash_attn_varlen_window(void* out, const void* q, const void* k, const void* v,
+                                              const int32_t* cu_seqlens, int batch, int max_seqlen, int num_heads,
+                                              int num_kv_heads, int head_size, int64_t q_stride, int64_t k_stride,
+                                              int64_t v_stride, float scale, int causal, const float* alibi_slopes,
+                                              int window, int dtype, void* stream) {
+  return fa_varlen_entry(out, q, k, v, cu_seqlens, batch, max_seqlen, num_heads, num_kv_heads, head_size, q_stride, k_stride,
+                         v_stride, scale, causal, alibi_slopes, window, dtype, stream);
 }
 

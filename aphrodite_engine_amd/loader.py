@@ -210,8 +210,10 @@ def llama_config_from_hf(hf: Dict[str, Any]):
     from .model import LlamaConfig
     # what this skeleton does not model is refused, never loaded approximately
     rs = hf.get("rope_scaling")
-    if rs and rs.get("rope_type", rs.get("type")) != "llama3":
-        raise NotImplementedError(f"rope_scaling={rs!r}: only the llama3 scheme is implemented")
+    if rs and rs.get("rope_type", rs.get("type")) not in ("llama3", "linear", "dynamic", "yarn"):
+        raise NotImplementedError(f"rope_scaling={rs!r}: the llama3, linear, dynamic and yarn schemes are implemented")
+    if rs and hf.get("original_max_position_embeddings"):       # models/llama.py:196-200
+        rs = dict(rs, original_max_position_embeddings=hf["original_max_position_embeddings"])
     if hf.get("sliding_window"):
         raise NotImplementedError("sliding-window attention in decode is not implemented")
     if hf.get("attention_bias") or hf.get("mlp_bias"):

@@ -129,27 +129,75 @@ class QuantLinear(nn.Module):
         return None
 
 
+def _yarn_inv_freq(head_dim: int, theta: float, factor: float, orig_max: int, beta_fast, beta_slow,
+                   extrapolation_factor: float, device):
+    """YaRN frequencies (rotary_embedding.py:332-364, 400-417): interpolated (1 / (factor * theta^(2i/d))) and extrapolated
+    (1 / theta^(2i/d)) frequencies blended by a linear ramp over the rotary dimensions between the two correction bounds
+    -- the dimensions that turn ``beta_fast`` / ``beta_slow`` times over the original context."""
+    pos_freqs = theta ** (torch.arange(0, head_dim, 2, dtype=torch.float, device=device) / head_dim)
+    extra = 1.0 / pos_freqs
+    inter = 1.0 / (factor * pos_freqs)
+
+    def correction_dim(rotations):
+        return (head_dim * math.log(orig_max / (rotations * 2 * math.pi))) / (2 * math.log(theta))
+    low = max(math.floor(correction_dim(beta_fast)), 0)
+    high = min(math.ceil(correction_dim(beta_slow)), head_dim - 1)
+    if low == high:
+        high += 0.001
+    ramp = torch.clamp((torch.arange(head_dim // 2, dtype=torch.float, device=device) - low) / (high - low), 0, 1)
+    mask = (1 - ramp) * extrapolation_factor
+    return inter * (1 - mask) + extra * mask
+
+
 def _rope_cache(head_dim: int, max_pos: int, theta: float, dtype, device, rope_scaling: Optional[dict] = None):
-    """cos | sin table [max_pos, head_dim] (modeling/layers/rotary_embedding.py:101-120).  ``rope_scaling``
-    of type "llama3" (Llama-3.1 checkpoints) stretches the long wavelengths: a frequency whose wavelength
-    exceeds orig_max / low_freq_factor is divided by ``factor``, one below orig_max / high_freq_factor is
-    kept, and the band in between is blended linearly in orig_max / wavelength (:680-723)."""
-    inv_freq = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.float,
-                                             device=device) / head_dim))
+    """cos | sin table [rows, head_dim] (modeling/layers/rotary_embedding.py:101-120) -- what the rotary kernels index by
+    position.  ``rope_scaling`` selects the reference's scaled tables (get_rope, :902-1017):
+      "llama3"  (Llama-3.1; :680-723) long wavelengths stretched: a frequency whose wavelength exceeds orig_max /
+                low_freq_factor is divided by ``factor``, one below orig_max / high_freq_factor is kept, the band in between
+                blended linearly in orig_max / wavelength; max_pos rows;
+      "linear"  (:205-287) positions divided by ``factor``; max_pos * factor rows;
+      "dynamic" (NTK; :291-329) theta grown by (factor * L / max_pos - (factor - 1))^(d / (d - 2)), L = max_pos * factor rows;
+      "yarn"    (:372-430) _yarn_inv_freq, cos / sin scaled by (0.1 ln(factor) + 1) * attn_factor;
+                original_max_position_embeddings * factor rows."""
+    def plain_inv(base):
+        return 1.0 / (base ** (torch.arange(0, head_dim, 2, dtype=torch.float, device=device) / head_dim))
+    inv_freq = plain_inv(theta)
+    rows, t_div, mscale = max_pos, None, None
     if rope_scaling:
         kind = rope_scaling.get("rope_type", rope_scaling.get("type"))
-        if kind != "llama3":
-            raise NotImplementedError(f"rope_scaling type {kind!r} is not implemented (llama3 only)")
-        factor = float(rope_scaling["factor"])
-        lo, hi = float(rope_scaling["low_freq_factor"]), float(rope_scaling["high_freq_factor"])
-        orig = float(rope_scaling["original_max_position_embeddings"])
-        wavelen = 2 * math.pi / inv_freq
-        blend = (orig / wavelen - lo) / (hi - lo) if lo != hi else torch.zeros_like(inv_freq)
-        mid = (1 - blend) * inv_freq / factor + blend * inv_freq
-        inv_freq = torch.where(wavelen < orig / hi, inv_freq, torch.where(wavelen > orig / lo, inv_freq / factor, mid))
-    t = torch.arange(max_pos, dtype=torch.float, device=device)
+        if kind == "llama3":
+            factor = float(rope_scaling["factor"])
+            lo, hi = float(rope_scaling["low_freq_factor"]), float(rope_scaling["high_freq_factor"])
+            orig = float(rope_scaling["original_max_position_embeddings"])
+            wavelen = 2 * math.pi / inv_freq
+            blend = (orig / wavelen - lo) / (hi - lo) if lo != hi else torch.zeros_like(inv_freq)
+            mid = (1 - blend) * inv_freq / factor + blend * inv_freq
+            inv_freq = torch.where(wavelen < orig / hi, inv_freq, torch.where(wavelen > orig / lo, inv_freq / factor, mid))
+        elif kind == "linear":
+            factor = rope_scaling["factor"]
+            rows, t_div = max_pos * factor, factor
+        elif kind == "dynamic":
+            factor = rope_scaling["factor"]
+            rows = max_pos * factor
+            inv_freq = plain_inv(theta * ((factor * rows / max_pos) - (factor - 1)) ** (head_dim / (head_dim - 2)))
+        elif kind == "yarn":
+            factor = rope_scaling["factor"]
+            orig = rope_scaling["original_max_position_embeddings"]
+            inv_freq = _yarn_inv_freq(head_dim, theta, factor, orig, rope_scaling.get("beta_fast", 32),
+                                      rope_scaling.get("beta_slow", 1), rope_scaling.get("extrapolation_factor", 1), device)
+            rows = orig * factor
+            mscale = float((0.1 * math.log(factor) + 1.0 if factor > 1 else 1.0) * rope_scaling.get("attn_factor", 1))
+        else:
+            # deepseek_yarn / longrope / mrope belong to model families outside the Llama / Mixtral decoder of this path
+            raise NotImplementedError(f"rope_scaling type {kind!r} is not implemented (llama3, linear, dynamic, yarn)")
+    t = torch.arange(rows, dtype=torch.float, device=device)
+    if t_div is not None:
+        t = t / t_div
     freqs = torch.einsum("i,j->ij", t, inv_freq)
-    return torch.cat((freqs.cos(), freqs.sin()), dim=-1).to(dtype)
+    cos, sin = freqs.cos(), freqs.sin()
+    if mscale is not None:
+        cos, sin = cos * mscale, sin * mscale
+    return torch.cat((cos, sin), dim=-1).to(dtype)
 
 
 class LlamaDecoderLayer(nn.Module):

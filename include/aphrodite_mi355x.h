@@ -393,6 +393,16 @@ int aphro_flash_attn_varlen(void* out, const void* q, const void* k, const void*
                             int64_t q_stride, int64_t k_stride, int64_t v_stride,
                             float scale, int causal, const float* alibi_slopes,
                             int dtype, void* stream);
+/* The same op with a sliding window (Mistral-style checkpoints): window > 0, causal only -- query i sees keys j with
+ * i - j < window.  The reference hands its window to flash_attn_varlen_func as window_size = (sliding_window,
+ * sliding_window) under causal = True (backends/rocm_flash_attn.py:321-322, 497-507): keys i - sliding_window .. i, i.e.
+ * window = sliding_window + 1 here.  window <= 0: aphro_flash_attn_varlen. */
+int aphro_flash_attn_varlen_window(void* out, const void* q, const void* k, const void* v,
+                                   const int32_t* cu_seqlens, int batch, int max_seqlen,
+                                   int num_heads, int num_kv_heads, int head_size,
+                                   int64_t q_stride, int64_t k_stride, int64_t v_stride,
+                                   float scale, int causal, const float* alibi_slopes,
+                                   int window, int dtype, void* stream);
 
 /* Prefill with cached context -- the context_attention_fwd role
  *   attention/ops/prefix_prefill.py:696-858 (kernel :58-255), called through

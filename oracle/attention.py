@@ -199,10 +199,14 @@ def paged_attention_v2_partials(query, key_cache, value_cache, block_tables,
     return out, mx, es, tmp
 
 
-def varlen_causal_attention(q, k, v, cu_seqlens, scale, causal=True, alibi_slopes=None):
+def varlen_causal_attention(q, k, v, cu_seqlens, scale, causal=True, alibi_slopes=None, window_left=None):
     """Prefill self-attention over packed sequences (rocm_flash_attn.py:598-630).
     q [T,Hq,hd], k/v [T,Hkv,hd]; float64 math.  alibi bias = slope_h * (key_pos - query_pos)
-    (_make_alibi_bias, rocm_flash_attn.py:238-263)."""
+    (_make_alibi_bias, rocm_flash_attn.py:238-263).  window_left: the `left` of flash_attn_varlen_func's window_size --
+    the call at rocm_flash_attn.py:497-507 passes (sliding_window, sliding_window) with causal=True.  flash_attn is a
+    third-party dependency that is not vendored in the reference (requirements-rocm: the ROCm CK fork, unpinned); its
+    published mask: query i (aligned to the end of the keys) sees keys j with i - left <= j <= i + right, right = 0 under
+    causal -- keys i - left .. i."""
     q = _f32(q).astype(np.float64)
     k = _f32(k).astype(np.float64)
     v = _f32(v).astype(np.float64)
@@ -224,6 +228,9 @@ def varlen_causal_attention(q, k, v, cu_seqlens, scale, causal=True, alibi_slope
         if causal:
             mask = np.triu(np.ones((n, n), dtype=bool), 1)
             lg = np.where(mask[None], -np.inf, lg)
+        if window_left is not None and window_left >= 0:
+            far = (np.arange(n)[:, None] - np.arange(n)[None, :]) > window_left      # query_pos - key_pos > left
+            lg = np.where(far[None], -np.inf, lg)
         lg -= lg.max(axis=2, keepdims=True)
         p = np.exp(lg)
         p /= p.sum(axis=2, keepdims=True)

@@ -934,6 +934,33 @@ def test_flash_attn_varlen_long(ops, dtype, Hq, Hkv, D, causal, alibi):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("Hq,Hkv,D", [(8, 2, 128), (4, 4, 64), (6, 2, 96), (32, 8, 128)])
+@pytest.mark.parametrize("left", [0, 1, 31, 64, 300, 4096])
+def test_flash_attn_varlen_sliding_window(ops, dtype, Hq, Hkv, D, left):
+    """Prefill with a sliding window, as ROCmFlashAttentionImpl hands it to flash_attn_varlen_func (window_size = (left, left),
+    causal; rocm_flash_attn.py:321-322, 497-507): query i sees keys i - left .. i.  Short and long sequences (both tile
+    machines that take a window, and the head-128 / >= 1024-key shape that would otherwise go to the window-less third
+    generation), windows of one key, around the 64-key tile edge, and wider than every sequence (= plain causal)."""
+    rng = np.random.default_rng(Hq * 5 + D + left)
+    lens = [1, 63, 64, 65, 200, 33, 700, 1100]
+    cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    T = int(cu[-1])
+    qkv = t(rng.standard_normal((T, (Hq + 2 * Hkv) * D)).astype(np.float32) * 0.7, dtype)
+    q, k, v = qkv.split([Hq * D, Hkv * D, Hkv * D], dim=-1)
+    q, k, v = q.view(T, Hq, D), k.view(T, Hkv, D), v.view(T, Hkv, D)
+    scale = float(D ** -0.5)
+    got = ops.flash_attn_varlen(q, k, v, t(cu), max(lens), scale, causal=True, window_size=(left, left))
+    ref = oa.varlen_causal_attention(q, k, v, cu, scale, causal=True, window_left=left)
+    tol = 2e-3 if dtype == torch.float16 else 1.6e-2
+    np.testing.assert_allclose(got.float().cpu().numpy(), ref, atol=tol, rtol=tol)
+    if left >= max(lens):
+        plain = oa.varlen_causal_attention(q, k, v, cu, scale, causal=True)
+        np.testing.assert_allclose(got.float().cpu().numpy(), plain, atol=tol, rtol=tol)
+    with pytest.raises(RuntimeError):
+        ops.flash_attn_varlen(q, k, v, t(cu), max(lens), scale, causal=False, window_size=(left, left))
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("causal", [True, False])
 def test_flash_attn_varlen_v3_kv_head_placement(ops, dtype, causal):
     """Third-generation prefill kernel with (sequences x kv heads) a multiple of 8: the kv-head -> XCD placement of the

@@ -406,7 +406,22 @@ def test_rotary_tables_golden(golden_dir):
     np.testing.assert_array_equal(scaled.numpy(), g["llama3"])
     assert not np.array_equal(g["plain"], g["llama3"])
     with pytest.raises(NotImplementedError):
-        _rope_cache(128, 16, 10000.0, torch.float32, "cpu", {"rope_type": "yarn", "factor": 4.0})
+        _rope_cache(128, 16, 10000.0, torch.float32, "cpu", {"rope_type": "longrope", "factor": 4.0})
+
+
+def test_scaled_rotary_tables_golden(golden_dir):
+    """Host logic: the linear, dynamic-NTK and YaRN tables (rows, frequencies, mscale) vs the reference's
+    LinearScaling / DynamicNTKScaling / YaRNScalingRotaryEmbedding (tests/golden/make_golden_rope_scaling.py), bit for bit."""
+    import json
+    from aphrodite_engine_amd.model import _rope_cache
+    g = np.load(os.path.join(golden_dir, "rope_scaling.npz"))
+    cases = json.load(open(os.path.join(golden_dir, "rope_scaling_cases.json")))
+    assert set(cases) == set(g.files) == {"linear", "dynamic", "yarn", "yarn_kw"}
+    for tag, c in cases.items():
+        got = _rope_cache(c["head_dim"], c["max_pos"], c["theta"], torch.float32, "cpu", c["rope_scaling"])
+        assert got.shape == g[tag].shape, tag
+        np.testing.assert_array_equal(got.numpy(), g[tag], err_msg=tag)
+    assert not np.array_equal(g["yarn"], g["yarn_kw"])
 
 
 def test_compressed_tensors_scheme_selection_golden(golden_dir):
