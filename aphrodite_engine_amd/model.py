@@ -46,6 +46,8 @@ class LlamaConfig:
     rope_scaling: Optional[dict] = None   # {"rope_type": "llama3", factor, low_freq_factor, high_freq_factor, original_max_position_embeddings}
     num_local_experts: int = 0        # > 0: Mixtral-style sparse MLP (block_sparse_moe), SURVEY 8f row 2
     num_experts_per_tok: int = 2
+    attention_bias: bool = False      # q / k / v / o projection biases (models/llama.py:109, 135-150: config.attention_bias or config.bias)
+    mlp_bias: bool = False            # gate / up / down projection biases (models/llama.py:62-82: config.mlp_bias)
 
     @property
     def head_dim(self) -> int:
@@ -84,7 +86,7 @@ class QuantLinear(nn.Module):
     def __init__(self, in_features: int, out_partition_sizes: List[int],
                  quant_config: Optional[QuantizationConfig], dtype: torch.dtype,
                  full_in_features: Optional[int] = None, prefix: str = "", plan=None,
-                 full_out_features: Optional[int] = None):
+                 full_out_features: Optional[int] = None, bias: bool = False):
         super().__init__()
         from .loader import make_weight_loader, merged_plan
         self.in_features = in_features
@@ -105,11 +107,22 @@ class QuantLinear(nn.Module):
                 self, in_features, out_partition_sizes,
                 full_in_features or in_features, full_out_features or self.out_features, dtype,
                 weight_loader=self.weight_loader)
+        if bias:
+            # ColumnParallelLinear / RowParallelLinear.bias (linear.py:283-291, 1074-1084): cut along the output like the
+            # weight's rows in a column-parallel layer, whole in a row-parallel one (added after the all-reduce)
+            from .quantization.base_config import _param
+            self.register_parameter("bias", _param(torch.zeros(self.out_features, dtype=dtype), output_dim=0,
+                                                   weight_loader=self.weight_loader))
+        else:
+            self.bias = None
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, add_bias: bool = True) -> torch.Tensor:
+        """``add_bias=False``: a row-parallel layer under TP -- the caller adds ``self.bias`` once, after the all-reduce
+        (RowParallelLinear.forward, linear.py:1136-1150)."""
+        bias = self.bias if add_bias else None
         if self.quant_method is None:
-            return torch.nn.functional.linear(x, self.weight)
-        return self.quant_method.apply(self, x)
+            return torch.nn.functional.linear(x, self.weight, bias)
+        return self.quant_method.apply(self, x, bias)
 
     def fast_params(self):
         """(qweight, qzeros, scales, zero_offset) if this layer's weights are in the
@@ -220,10 +233,13 @@ class LlamaDecoderLayer(nn.Module):
                                     quant_config, dtype, prefix=pfx + "self_attn.qkv_proj",
                                     plan=qkv_plan(cfg.num_attention_heads, cfg.num_key_value_heads, self.head_dim),
                                     full_out_features=(cfg.num_attention_heads + 2 * cfg.num_key_value_heads)
-                                    * self.head_dim)
+                                    * self.head_dim, bias=cfg.attention_bias)
         self.o_proj = QuantLinear(self.q_size, [h], quant_config, dtype,
                                   full_in_features=cfg.num_attention_heads * self.head_dim,
-                                  prefix=pfx + "self_attn.o_proj", plan=row_plan())
+                                  prefix=pfx + "self_attn.o_proj", plan=row_plan(), bias=cfg.attention_bias)
+        # projection biases: served by the op-by-op path (the quant methods' apply(layer, x, bias)); the fused steps hand raw
+        # split-K slabs from GEMM to consumer and have no place for them -- they stay off for such a layer
+        self.has_bias = bool(cfg.attention_bias or (cfg.mlp_bias and cfg.num_local_experts == 0))
         inter = cfg.intermediate_size // tp
         self.is_moe = cfg.num_local_experts > 0
         if self.is_moe:
@@ -237,10 +253,10 @@ class LlamaDecoderLayer(nn.Module):
         else:
             self.gate_up_proj = QuantLinear(h, [inter, inter], quant_config, dtype, prefix=pfx + "mlp.gate_up_proj",
                                             plan=merged_plan([cfg.intermediate_size] * 2),
-                                            full_out_features=2 * cfg.intermediate_size)
+                                            full_out_features=2 * cfg.intermediate_size, bias=cfg.mlp_bias)
             self.down_proj = QuantLinear(inter, [h], quant_config, dtype,
                                          full_in_features=cfg.intermediate_size, prefix=pfx + "mlp.down_proj",
-                                         plan=row_plan())
+                                         plan=row_plan(), bias=cfg.mlp_bias)
         self.attn = MI355XAttentionImpl(self.num_heads, self.head_dim,
                                         self.head_dim ** -0.5, self.num_kv_heads,
                                         kv_cache_dtype=kv_cache_dtype)
@@ -260,6 +276,8 @@ class LlamaDecoderLayer(nn.Module):
         keep_original=False the [gate | up] copy is dropped: the parameters themselves take the interleaved
         order and the op-by-op / prompt-sized forward pairs the columns in its SiluAndMul
         (ops.silu_and_mul(..., interleaved=True)) -- one copy of the matrix in HBM."""
+        if self.has_bias:                     # (op-by-op path only: no decode copies, no column interleave under the bias)
+            return False
         self.enable_resident_layouts(m)       # (also where SiluAndMul cannot ride in the epilogue: TP shards, sparse layers)
         if self.is_moe:
             return False
@@ -314,7 +332,7 @@ class LlamaDecoderLayer(nn.Module):
         prefill); APHRO_DECODE_NO_FP8_RESIDENT=1 keeps the round-3 kernels."""
         self.fp8_strip = {}
         self.fp8_gate_up_il = None      # round 6: the gate_up strip copy with (gate_j, up_j) adjacent -- SiluAndMul in the epilogue
-        if switch("APHRO_DECODE_NO_FP8_RESIDENT") or self.is_moe:
+        if switch("APHRO_DECODE_NO_FP8_RESIDENT") or self.is_moe or self.has_bias:
             return
         for name in ("qkv_proj", "o_proj", "gate_up_proj", "down_proj"):
             lin = getattr(self, name)
@@ -344,7 +362,7 @@ class LlamaDecoderLayer(nn.Module):
         8.2 -> 7.1 us and 11.4 -> 10.5 us, profiles/r3_resident_bench.txt; round 4, single-pass stream kernel: qkv 6.65,
         down 9.84, o_proj 5.58 -> 4.98 us, profiles/r4_gemm_lab.txt)."""
         self.strip = {}
-        if m > 64 or switch("APHRO_DECODE_NO_RESIDENT"):
+        if m > 64 or self.has_bias or switch("APHRO_DECODE_NO_RESIDENT"):
             return
         # gate_up_proj: the NON-interleaved [gate | up] matrix, for layers whose SiluAndMul does not ride in the GEMM epilogue
         # (K-sliced gate_up of a TP shard: slabs -> silu_and_mul_pack(slabs=...))
@@ -402,7 +420,7 @@ class LlamaDecoderLayer(nn.Module):
         K-packed layout, shapes (per TP shard) served by the packed-activation kernel.  With
         TP > 1 the two row-parallel projections reduce their split-K slabs locally, all-reduce
         the [M, hidden] result over the TP group and hand it to the fused norm as a tensor."""
-        if m > 64:
+        if m > 64 or self.has_bias:
             return False
         for lin in self.linears():
             fp = lin.fast_params()
@@ -561,7 +579,7 @@ class LlamaDecoderLayer(nn.Module):
         inside the attention kernel.  The activation scheme -- dynamic per token, or the checkpoint's
         static per-tensor input_scale -- must be the same for the four projections of the layer."""
         from .quantization.fp8 import CompressedTensorsW8A8Fp8Method, CDNA4Fp8LinearMethod
-        if m > 64 or self.head_dim != 128 or not self.fuse_rope_attention or self.is_moe:
+        if m > 64 or self.head_dim != 128 or not self.fuse_rope_attention or self.is_moe or self.has_bias:
             return False
         lins = self.linears()
         static = [getattr(lin, "input_scale", None) is not None for lin in lins]
@@ -702,7 +720,7 @@ class LlamaDecoderLayer(nn.Module):
         launch each instead of norm, quant, SiluAndMul, quant (profiles/r5_prefill_e2e_kernels.txt: the four per-token
         quantisation passes were 9.2 of 82 ms of an 8192-token prompt).  Same bits as the op-by-op path."""
         from .quantization.fp8 import CompressedTensorsW8A8Fp8Method, CDNA4Fp8LinearMethod
-        if self.is_moe or switch("APHRO_PREFILL_NO_FUSED_FP8"):
+        if self.is_moe or self.has_bias or switch("APHRO_PREFILL_NO_FUSED_FP8"):
             return False
         lins = self.linears()
         static = [getattr(lin, "input_scale", None) is not None for lin in lins]
@@ -763,14 +781,12 @@ class LlamaDecoderLayer(nn.Module):
         ops.rotary_embedding(positions, q, k, self.head_dim, cos_sin, True)
         attn_out = self.attn.forward(q, k, v, kv_cache, attn_metadata,
                                      self.k_scale, self.v_scale)
-        hidden = self.o_proj(attn_out)
-        if self.tp > 1:
-            hidden = tensor_model_parallel_all_reduce(hidden)
+        hidden = self._row_parallel(self.o_proj, attn_out)
         ops.fused_add_rms_norm(hidden, residual, self.post_attention_layernorm, eps)
         if self.is_moe:
             return self.moe_block(hidden), residual
         il = self.gate_up_interleaved is not None and not self.gate_up_keep_original
-        if il and hidden.shape[0] > 64 and not switch("APHRO_PREFILL_NO_SILU_EPILOGUE") \
+        if il and hidden.shape[0] > 64 and not self.has_bias and not switch("APHRO_PREFILL_NO_SILU_EPILOGUE") \
                 and not switch("APHRO_WNA16_NO_LARGE"):
             # prompt-sized batches on the interleaved copy: SiluAndMul in the GEMM's epilogue (same bits, no [M, 2 I] round trip)
             qw, qz, sc, zo = self.gate_up_interleaved
@@ -787,10 +803,15 @@ class LlamaDecoderLayer(nn.Module):
         # ONE copy of the gate_up weights: once SiluAndMul rides in the decode GEMM's epilogue the parameters hold the
         # interleaved (gate_j, up_j) column order, and the op-by-op / prompt-sized path pairs the columns in the activation
         ops.silu_and_mul(act, gate_up, interleaved=self.gate_up_interleaved is not None and not self.gate_up_keep_original)
-        hidden = self.down_proj(act)
-        if self.tp > 1:
-            hidden = tensor_model_parallel_all_reduce(hidden)
-        return hidden, residual
+        return self._row_parallel(self.down_proj, act), residual
+
+    def _row_parallel(self, lin: QuantLinear, x: torch.Tensor) -> torch.Tensor:
+        """RowParallelLinear.forward (linear.py:1136-1150): this rank's partial product, the all-reduce over the TP group,
+        then the bias -- once, not per rank."""
+        if self.tp == 1:
+            return lin(x)
+        out = tensor_model_parallel_all_reduce(lin(x, add_bias=False))
+        return out if lin.bias is None else out + lin.bias
 
 
 class LlamaForCausalLM(nn.Module):

@@ -48,9 +48,11 @@ def fp8_quant(w, per_channel):
 
 
 def write_checkpoint(path, cfg, fmt, seed=0, group_size=128, kv_scales=None, fp8_static=False,
-                     embedded_config=True, fused_on_disk=False, extra_bias=True, bits=4):
+                     embedded_config=True, fused_on_disk=False, extra_bias=True, bits=4, proj_bias=None):
     """fmt: fp16 | gptq | awq | fp8 | ct-fp8-channel | ct-fp8-tensor | ct-w8a16 | ct-w4a16 | ct-w8a16i (int8 pack-quantized).
     kv_scales: None | "kv" (per-layer k_scale + v_scale) | "legacy" (kv_scale) | "ct" ({k,v}_proj.output_scale).
+    proj_bias: None | "attn" | "mlp" | "both" -- real projection biases (config.attention_bias / mlp_bias), also in
+    logical[name]["bias"].
     Returns {"tensors": {hf name: tensor}, "logical": {hf module name: dict of logical matrices}}."""
     os.makedirs(path, exist_ok=True)
     rng = np.random.default_rng(seed)
@@ -122,6 +124,10 @@ def write_checkpoint(path, cfg, fmt, seed=0, group_size=128, kv_scales=None, fp8
                 tensors[name + ".weight_shape"] = torch.tensor([N, K], dtype=torch.int64)
             else:
                 raise ValueError(fmt)
+            if proj_bias in ("both", "attn" if proj.startswith("self_attn") else "mlp") and "experts" not in proj:
+                b = (rng.standard_normal(N) * 0.5).astype(np.float16)
+                tensors[name + ".bias"] = torch.from_numpy(b)
+                logical[name]["bias"] = b
         if kv_scales == "kv":
             tensors[base + "self_attn.k_scale"] = torch.tensor(0.02 + 0.001 * li, dtype=torch.float32)
             tensors[base + "self_attn.v_scale"] = torch.tensor(0.03 + 0.001 * li, dtype=torch.float32)
@@ -169,6 +175,10 @@ def write_checkpoint(path, cfg, fmt, seed=0, group_size=128, kv_scales=None, fp8
                                               "input_activations": acts}},
                 "ignore": ["lm_head"]}
     hf = hf_config(cfg, {"quantization_config": qcfg} if (qcfg and embedded_config) else None)
+    if proj_bias in ("attn", "both"):
+        hf["attention_bias"] = True
+    if proj_bias in ("mlp", "both"):
+        hf["mlp_bias"] = True
     with open(os.path.join(path, "config.json"), "w") as f:
         json.dump(hf, f)
     for fname, doc in extra_files.items():

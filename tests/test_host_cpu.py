@@ -578,6 +578,8 @@ def test_attention_impl_and_metadata_take_the_reference_layers_calls(monkeypatch
     assert "attn_type" in inspect.signature(B.MI355XAttentionImpl.forward).parameters
     AttentionType = enum.Enum("AttentionType", ["DECODER", "ENCODER", "ENCODER_DECODER"])
     impl = B.MI355XAttentionImpl(4, 128, 0.1, 2)
+    # the window as ROCmFlashAttentionImpl keeps it (rocm_flash_attn.py:321-322): a (left, right) pair for the prompt kernels
+    assert impl.sliding_window == (-1, -1) and B.MI355XAttentionImpl(4, 128, 0.1, 2, sliding_window=4096).sliding_window == (4096, 4096)
     with pytest.raises(NotImplementedError):
         impl.forward(torch.zeros(1, 512), torch.zeros(1, 256), torch.zeros(1, 256), None, None, attn_type=AttentionType.ENCODER)
     calls = {}

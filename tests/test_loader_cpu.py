@@ -411,13 +411,42 @@ def test_unsupported_architectures_are_refused(tmp_path):
     CU.write_checkpoint(str(tmp_path), CFG, "fp16", seed=13)
     cfg_path = tmp_path / "config.json"
     base = _json.loads(cfg_path.read_text())
-    for extra in ({"rope_scaling": {"rope_type": "yarn", "factor": 8.0}}, {"sliding_window": 4096},
-                  {"attention_bias": True}, {"hidden_act": "gelu"}):
+    for extra in ({"rope_scaling": {"rope_type": "longrope", "short_factor": [1.0], "long_factor": [2.0]}}, {"sliding_window": 4096},
+                  {"hidden_act": "gelu"}):
         cfg_path.write_text(_json.dumps({**base, **extra}))
         with pytest.raises(NotImplementedError):
             build(tmp_path, "fp16", 0, 1)
     cfg_path.write_text(_json.dumps({**base, "sliding_window": None, "rope_scaling": None}))
     build(tmp_path, "fp16", 0, 1)
+    # the scaled tables the reference's get_rope builds for Llama-architecture checkpoints load (rotary_embedding.py:940-973)
+    for rs in ({"rope_type": "yarn", "factor": 4.0, "original_max_position_embeddings": 64}, {"type": "linear", "factor": 2.0},
+               {"type": "dynamic", "factor": 2.0}):
+        cfg_path.write_text(_json.dumps({**base, "rope_scaling": rs}))
+        assert build(tmp_path, "fp16", 0, 1).cfg.rope_scaling == rs
+
+
+@pytest.mark.parametrize("fmt", ["fp16", "gptq"])
+@pytest.mark.parametrize("rank,world", WORLDS)
+def test_projection_biases_are_sharded_like_their_layers(tmp_path, fmt, rank, world):
+    """config.attention_bias / mlp_bias (models/llama.py:62-82, 135-150, 206-211): q / k / v and gate / up biases are cut along
+    the output with their heads / columns (ColumnParallelLinear, linear.py:283-291), o / down biases are whole on every rank
+    (RowParallelLinear adds them after the all-reduce, linear.py:1136-1150); such a layer stays off the fused steps."""
+    truth = CU.write_checkpoint(str(tmp_path), CFG, fmt, seed=23, proj_bias="both")
+    m = build(tmp_path, fmt, rank, world)
+    hd = CFG.hidden_size // CFG.num_attention_heads
+    hq, hkv, inter = CFG.num_attention_heads // world, max(1, CFG.num_key_value_heads // world), CFG.intermediate_size // world
+    kv_rank = rank * CFG.num_key_value_heads // world if CFG.num_key_value_heads >= world else rank // (world // CFG.num_key_value_heads)
+    for li, layer in enumerate(m.layers):
+        lg = lambda p: torch.from_numpy(truth["logical"][f"model.layers.{li}.{p}"]["bias"])
+        assert layer.has_bias and not layer.fused_decode_ok(4)
+        want_qkv = torch.cat([lg("self_attn.q_proj")[rank * hq * hd:(rank + 1) * hq * hd],
+                              lg("self_attn.k_proj")[kv_rank * hd:(kv_rank + hkv) * hd],
+                              lg("self_attn.v_proj")[kv_rank * hd:(kv_rank + hkv) * hd]])
+        assert torch.equal(layer.qkv_proj.bias.data, want_qkv)
+        assert torch.equal(layer.gate_up_proj.bias.data, torch.cat([lg("mlp.gate_proj")[rank * inter:(rank + 1) * inter],
+                                                                    lg("mlp.up_proj")[rank * inter:(rank + 1) * inter]]))
+        assert torch.equal(layer.o_proj.bias.data, lg("self_attn.o_proj"))
+        assert torch.equal(layer.down_proj.bias.data, lg("mlp.down_proj"))
 
 
 def test_gptq_act_order_checkpoint(tmp_path):

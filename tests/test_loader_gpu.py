@@ -81,6 +81,42 @@ def test_loaded_checkpoint_linears_and_decode(ops, tmp_path, fmt):
         assert logits.shape == (5, CFG.vocab_size) and torch.isfinite(logits.float()).all()
 
 
+@pytest.mark.parametrize("fmt", ["fp16", "gptq", "ct-fp8-channel"])
+def test_loaded_checkpoint_with_projection_biases(ops, tmp_path, fmt):
+    """config.attention_bias / mlp_bias (models/llama.py:62-82, 135-150): every projection = x W + b through the quant method's
+    apply(layer, x, bias); the layers stay off the fused steps (which have no place for a bias), a decode step runs op by op
+    and differs from the same checkpoint with its biases zeroed."""
+    truth = CU.write_checkpoint(str(tmp_path), CFG, fmt, seed=12, proj_bias="both")
+    with torch.no_grad():
+        m = L.load_model(str(tmp_path), dtype=torch.float16, device=DEV)
+        rng = np.random.default_rng(6)
+        for li, layer in enumerate(m.layers):
+            assert layer.has_bias and not layer.fused_decode_ok(5) and not layer.fused_decode_fp8_ok(5)
+            for mod, projs in PROJ_OF.items():
+                lin = getattr(layer, mod)
+                w = np.concatenate([dense_weight(fmt, truth["logical"][f"model.layers.{li}.{p}"]) for p in projs], 1)
+                b = np.concatenate([truth["logical"][f"model.layers.{li}.{p}"]["bias"].astype(np.float32) for p in projs])
+                x = torch.from_numpy(rng.standard_normal((7, w.shape[0])).astype(np.float32)).half().to(DEV)
+                got = lin(x).float().cpu().numpy()
+                ref = x.float().cpu().numpy() @ w + b
+                err = np.abs(got - ref).mean() / np.abs(ref).mean()
+                assert err < (0.04 if fmt == "ct-fp8-channel" else 4e-3), (fmt, mod, err)
+                nob = lin(x, add_bias=False).float().cpu().numpy()
+                np.testing.assert_allclose(got - nob, np.broadcast_to(b, got.shape), atol=2e-2)
+        meta, pos, nblocks = M.make_decode_metadata(5, [3, 17, 64, 200, 129], 16, DEV)
+        ids = torch.randint(0, CFG.vocab_size, (5, ), device=DEV)
+
+        def step():
+            caches = M.make_kv_caches(CFG, nblocks, 16, torch.float16, "auto", DEV, seed=3)
+            return m(ids, pos, caches, meta).float()
+        with_bias = step()
+        assert torch.isfinite(with_bias).all()
+        for layer in m.layers:
+            for lin in layer.linears():
+                lin.bias.data.zero_()
+        assert not torch.equal(with_bias, step())
+
+
 def test_loaded_gptq_matches_directly_built_model(ops, tmp_path):
     """The loader path and direct parameter assignment give the same model, bit for bit."""
     from aphrodite_engine_amd.quantization.gptq import GPTQConfig

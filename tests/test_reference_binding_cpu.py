@@ -314,12 +314,17 @@ def test_fused_model_registers_through_the_reference_model_registry(monkeypatch)
         assert isinstance(cls(config=hf, cache_config=cache, quant_config=GPTQConfig(4, 128, False)), MI355XLlamaForCausalLM)
         for bad_kw, bad_hf in ((dict(lora_config=object()), hf),
                                ({}, types.SimpleNamespace(**{**vars(hf), "sliding_window": 4096})),
-                               ({}, types.SimpleNamespace(**{**vars(hf), "attention_bias": True})),
+                               ({}, types.SimpleNamespace(**{**vars(hf), "hidden_act": "gelu"})),
                                (dict(quant_config=object()), hf)):
             kw = dict(cache_config=cache, quant_config=GPTQConfig(4, 128, False))
             kw.update(bad_kw)
             ref = cls(config=bad_hf, **kw)
             assert isinstance(ref, RefLlama) and ref.kwargs["config"] is bad_hf
+        # projection biases (config.attention_bias, models/llama.py:206-211) are served by this class (op-by-op layers)
+        biased = cls(config=types.SimpleNamespace(**{**vars(hf), "attention_bias": True}), cache_config=cache,
+                     quant_config=GPTQConfig(4, 128, False))
+        assert isinstance(biased, MI355XLlamaForCausalLM) and biased.inner.layers[0].qkv_proj.bias is not None
+        assert biased.inner.layers[0].has_bias and biased.inner.layers[0].down_proj.bias is None
         # an engine run with --dtype float32 builds the model under a float32 default and passes no dtype:
         # through the registry that is the engine's choice, not "unset" -- the reference's class gets it
         torch.set_default_dtype(torch.float32)
