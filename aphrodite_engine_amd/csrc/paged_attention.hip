@@ -166,6 +166,17 @@ __global__ __launch_bounds__(NW * 64) void paged_attention_kernel(const int32_t*
   constexpr int NKS = FP8 ? 2 * NLD : (HD + 31) / 32;  // QK MFMAs per tile
   constexpr int NDT = (HD + 15) / 16;           // PV d-tiles
   constexpr int ESZ = FP8 ? 1 : 2;              // cache element bytes
+  // Token <-> MFMA slot of a 32-token tile pair.  16-bit KV: row 4g + r of score tile jj is token 16jj + 4g + r (a tile =
+  // 16 consecutive tokens: whole 128-byte lines per K load).  fp8 KV (TOK8, round 6): token 8g + 4jj + r, so that the eight
+  // k-slots a lane feeds to the PV MFMA -- (jj, r) -- are EIGHT CONSECUTIVE tokens of one cache block and the lane's V bytes
+  // of a d-row come with ONE 8-byte load instead of two 4-byte ones (the V side of a pair: 8 vector-memory instructions
+  // instead of 16; configs[2] attention 94.6 -> 90.6 us).  With 16-bit KV the same map measured +2.4 us per launch at ctx
+  // 1024 and +-0 at 8192 (profiles/r6_decode_experiments.txt (5)): not used there.
+  constexpr bool TOK8 = FP8;
+  using VRaw = u32x2;                           // TOK8: a lane's 8 fp8 tokens of one V row; else 4 tokens (fp8: in [0])
+  constexpr int NVJ = TOK8 ? 1 : 2;             // V loads per d-tile
+  auto tok_of_k_row = [](int jj, int c) { return TOK8 ? 8 * (c >> 2) + 4 * jj + (c & 3) : 16 * jj + c; };
+  auto tok_of_s_row = [](int jj, int g, int r) { return TOK8 ? 8 * g + 4 * jj + r : 16 * jj + 4 * g + r; };
   static_assert(HD % XE == 0, "head size must be a multiple of the K chunk");
 
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -316,12 +327,12 @@ __global__ __launch_bounds__(NW * 64) void paged_attention_kernel(const int32_t*
 #pragma unroll
     for (int i = 0; i < NDT; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     float m_run = -1e30f;
-    float l_run = 0.f;  // this lane's share (its 4g..4g+3 tokens); summed over g at the end
+    float l_run = 0.f;  // this lane's share (its 8 tokens of every pair); summed over g at the end
     u32x4 qf[NKS];
     const int pair0 = pstart >> 5;
     const int pair_end = (pend + 31) >> 5;
     // K/V registers of one 32-token tile pair: kf = K fragments, vraw = 4 tokens x 16 d-rows per
-    // lane (16-bit KV: 8 B, fp8: 4 B in [0]).  ONE set: a pair is loaded, then computed; the other 7 waves hide the
+    // lane (16-bit KV: 8 B, fp8: 8 tokens in one 8-byte load, see TOK8).  ONE set: a pair is loaded, then computed; the other 7 waves hide the
     // latency.  (A second set -- the next pair's loads issued before this pair's compute -- was measured in round 2:
     // 256 VGPRs with 74 spills in the fused-rope form, 44 us instead of 29.7; fp8 KV 26.6 instead of 20 us.  An L2
     // warm-up of the next pair instead -- one dword per 128-byte line, issued when this pair's compute starts -- also
@@ -332,22 +343,25 @@ __global__ __launch_bounds__(NW * 64) void paged_attention_kernel(const int32_t*
       const int tb = pr << 5;
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj) {
-        ids[jj] = bt[min(tb + 16 * jj + c, seq_len - 1) / BS];
-        ids[2 + jj] = bt[min(tb + 16 * jj + 4 * g, alloc_tokens - 4) / BS];
+        ids[jj] = bt[min(tb + tok_of_k_row(jj, c), seq_len - 1) / BS];
+        if constexpr (TOK8) ids[2 + jj] = bt[min(tb + 8 * g, alloc_tokens - 8) / BS];
+        else ids[2 + jj] = bt[min(tb + 16 * jj + 4 * g, alloc_tokens - 4) / BS];
       }
     };
-    auto load_pair = [&](int pr, const int (&ids)[4], u32x4 (&kf)[2][NLD], u32x2 (&vraw)[NDT][2])
+    auto load_pair = [&](int pr, const int (&ids)[4], u32x4 (&kf)[2][NLD], VRaw (&vraw)[NDT][NVJ])
         __attribute__((always_inline)) {
       const int tb = pr << 5;
       // ---- addresses -----------------------------------------------------------
       const char* kptr[2];
-      const char* vptr[2];
+      const char* vptr[NVJ];
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj) {
-        int tk = min(tb + 16 * jj + c, seq_len - 1);
+        int tk = min(tb + tok_of_k_row(jj, c), seq_len - 1);
         kptr[jj] = kc + ((size_t)ids[jj] * p.kv_block_stride + (size_t)(tk % BS) * XE) * ESZ;
-        int tv = min(tb + 16 * jj + 4 * g, alloc_tokens - 4);
-        vptr[jj] = vc + ((size_t)ids[2 + jj] * p.kv_block_stride + (size_t)c * BS + (tv % BS)) * ESZ;
+        if (jj < NVJ) {
+          int tv = TOK8 ? min(tb + 8 * g, alloc_tokens - 8) : min(tb + 16 * jj + 4 * g, alloc_tokens - 4);
+          vptr[jj] = vc + ((size_t)ids[2 + jj] * p.kv_block_stride + (size_t)c * BS + (tv % BS)) * ESZ;
+        }
       }
       // ---- issue all K and V loads of the pair ----------------------------------
 #pragma unroll
@@ -364,10 +378,10 @@ __global__ __launch_bounds__(NW * 64) void paged_attention_kernel(const int32_t*
 #pragma unroll
       for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {
+        for (int jj = 0; jj < NVJ; ++jj) {
           const char* vp = vptr[jj] + (size_t)dt * 16 * BS * ESZ;
           if (16 * dt + c < HD) {
-            if constexpr (FP8) {
+            if constexpr (FP8 && !TOK8) {
               vraw[dt][jj][0] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(vp));
               vraw[dt][jj][1] = 0;
             } else {
@@ -378,7 +392,7 @@ __global__ __launch_bounds__(NW * 64) void paged_attention_kernel(const int32_t*
           }
         }
     };
-    auto compute_pair = [&](int pr, u32x4 (&kf)[2][NLD], u32x2 (&vraw)[NDT][2]) __attribute__((always_inline)) {
+    auto compute_pair = [&](int pr, u32x4 (&kf)[2][NLD], VRaw (&vraw)[NDT][NVJ]) __attribute__((always_inline)) {
       const int tb = pr << 5;
       // ---- S^T = K . Q^T -----------------------------------------------------------
       f32x4 s[2];
@@ -409,7 +423,7 @@ __global__ __launch_bounds__(NW * 64) void paged_attention_kernel(const int32_t*
       for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          int tok = tb + 16 * jj + 4 * g + r;
+          int tok = tb + tok_of_s_row(jj, g, r);
           float x = s[jj][r] * p.scale + slope * (float)(tok - seq_len + 1);
           bool ok = tok >= pstart && tok < pend;
           x = ok ? x : -1e30f;
@@ -443,20 +457,24 @@ __global__ __launch_bounds__(NW * 64) void paged_attention_kernel(const int32_t*
 #pragma unroll
       for (int dt = 0; dt < NDT; ++dt) {
         u32x4 vf;
-        if constexpr (FP8) {
+        if constexpr (TOK8) {
           u32x2 c0 = fp8x4_to_T<T, E5M2>(vraw[dt][0][0]);
-          u32x2 c1 = fp8x4_to_T<T, E5M2>(vraw[dt][1][0]);
+          u32x2 c1 = fp8x4_to_T<T, E5M2>(vraw[dt][0][1]);
+          vf = u32x4{c0[0], c0[1], c1[0], c1[1]};
+        } else if constexpr (FP8) {
+          u32x2 c0 = fp8x4_to_T<T, E5M2>(vraw[dt][0][0]);
+          u32x2 c1 = fp8x4_to_T<T, E5M2>(vraw[dt][NVJ - 1][0]);
           vf = u32x4{c0[0], c0[1], c1[0], c1[1]};
         } else {
           vf[0] = vraw[dt][0][0]; vf[1] = vraw[dt][0][1];
-          vf[2] = vraw[dt][1][0]; vf[3] = vraw[dt][1][1];
+          vf[2] = vraw[dt][NVJ - 1][0]; vf[3] = vraw[dt][NVJ - 1][1];
         }
         if (ragged) {  // zero V of tokens outside [pstart, pend): 0 * NaN must not poison O
 #pragma unroll
           for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
             for (int h2 = 0; h2 < 2; ++h2) {
-              int tok = tb + 16 * jj + 4 * g + 2 * h2;
+              int tok = tb + tok_of_s_row(jj, g, 2 * h2);
               uint32_t msk = (tok < pend ? 0x0000ffffu : 0u) | (tok + 1 < pend ? 0xffff0000u : 0u);
               vf[2 * jj + h2] &= msk;
             }
@@ -465,7 +483,7 @@ __global__ __launch_bounds__(NW * 64) void paged_attention_kernel(const int32_t*
       }
     };
     u32x4 kfa[2][NLD];
-    u32x2 vra[NDT][2];
+    VRaw vra[NDT][NVJ];
     int pr = pair0 + wave;
     // Fused form: the wave AFTER the owner of the last tile pair (the one with the fewest pairs in
     // the round-robin) writes the new token's K/V and raises an LDS flag; the owner polls the flag
