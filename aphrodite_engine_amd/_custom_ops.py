@@ -668,8 +668,15 @@ def _gptq_gemm_bits(a, qweight, qzeros, scales, g_idx, use_exllama: bool, bit: i
 def gptq_marlin_repack(b_q_weight: torch.Tensor, perm: torch.Tensor, size_k: int,
                        size_n: int, num_bits: int) -> torch.Tensor:
     """Marlin-role load-time prepack into the CDNA4 K-packed layout (same
-    shape as the input, [K/8, N]); perm = argsort(g_idx) or empty."""
+    shape as the input, [K/8, N]); perm = argsort(g_idx) or empty.  num_bits = 8 (uint8b128, marlin_utils.py:28-45): the
+    checkpoint's sequential [K/4, N] words are what the 8-bit kernels read (csrc/wnx_gemm.hip) -- act-order rows made
+    sequential, nothing else moves."""
     _require_cuda(b_q_weight)
+    if num_bits == 8:
+        out = b_q_weight.clone()
+        if perm is not None and perm.numel() > 0:
+            gptq_shuffle(out, perm, 8)
+        return out
     out = torch.empty_like(b_q_weight)
     p = perm.to(torch.int32) if (perm is not None and perm.numel() > 0) else None
     check(_lib.lib().aphro_gptq_repack(b_q_weight.data_ptr(), _ptr(p),
@@ -710,8 +717,24 @@ def gptq_marlin_gemm(a: torch.Tensor, b_q_weight: torch.Tensor, b_scales: torch.
     if is_zp_float:
         raise RuntimeError("gptq_marlin_gemm: float zero points are not supported")
     bits = getattr(b_q_type, "size_bits", 4)
+    if bits == 8:
+        # uint8b128 (quantization/utils/marlin_utils.py:28-45): b_q_weight = gptq_marlin_repack(..., 8) -- sequential [K/4, N]
+        # words; the symmetric zero point 128 in GPTQ's stored-minus-one convention is 127 per byte; perm gathers the
+        # activation columns (gptq_gemm's exllama form)
+        if has_zp or getattr(b_q_type, "bias", 128) != 128:
+            raise RuntimeError("gptq_marlin_gemm: the 8-bit type served is uint8b128 (symmetric, no zero points)")
+        x = a.reshape(-1, a.shape[-1])
+        if x.shape[0] != size_m or x.shape[1] != size_k or b_q_weight.shape != (size_k // 4, size_n):
+            raise RuntimeError("gptq_marlin_gemm: shape mismatch")
+        key = (a.device.type, a.device.index, b_scales.shape[0], size_n, 8)
+        zp = _ZP8.get(key)
+        if zp is None:
+            zp = torch.full((b_scales.shape[0], size_n // 4), 0x7f7f7f7f, dtype=torch.int32, device=a.device)
+            _ZP8[key] = zp
+        p = perm if perm is not None and perm.numel() > 0 else torch.empty(0, dtype=torch.int32, device=a.device)
+        return gptq_gemm(x, b_q_weight, zp, b_scales, p, True, 8)
     if bits != 4:
-        raise RuntimeError("gptq_marlin_gemm on MI355X serves 4-bit weights only")
+        raise RuntimeError("gptq_marlin_gemm on MI355X serves uint4 / uint4b8 and uint8b128 weights")
     x = a.reshape(-1, a.shape[-1])
     if x.shape[0] != size_m or x.shape[1] != size_k or b_q_weight.shape != (size_k // 8, size_n):
         raise RuntimeError("gptq_marlin_gemm: shape mismatch")

@@ -436,9 +436,17 @@ torch::Tensor awq_gemm(torch::Tensor in_feats, torch::Tensor kernel, torch::Tens
 // ([K/8, N], same shape as the input); perm = argsort(g_idx) or empty
 torch::Tensor gptq_marlin_repack(torch::Tensor b_q_weight, torch::Tensor perm, c10::SymInt size_k, c10::SymInt size_n, int64_t num_bits) {
   TORCH_CHECK(b_q_weight.is_cuda(), "gptq_marlin_repack: device tensor expected");
-  auto out = torch::empty_like(b_q_weight);
   const bool has_perm = perm.defined() && perm.numel() > 0;
   torch::Tensor p32 = has_perm ? perm.to(torch::kInt) : perm;
+  if (num_bits == 8) {   // uint8b128: the sequential [K/4, N] words stay; act-order rows are made sequential (gptq_shuffle's 8-bit form)
+    if (!has_perm) return b_q_weight.clone();
+    auto seq = torch::empty_like(b_q_weight);
+    ok(aphro_gptq_make_sequential_bits((const uint32_t*)b_q_weight.data_ptr(), (uint32_t*)seq.data_ptr(), (const int32_t*)p32.data_ptr(),
+                                       size_k.expect_int(), size_n.expect_int(), 8, cur_stream()),
+       "gptq_marlin_repack");
+    return seq;
+  }
+  auto out = torch::empty_like(b_q_weight);
   ok(aphro_gptq_repack((const uint32_t*)b_q_weight.data_ptr(), has_perm ? (const int32_t*)p32.data_ptr() : nullptr,
                        (uint32_t*)out.data_ptr(), size_k.expect_int(), size_n.expect_int(), (int)num_bits, cur_stream()),
      "gptq_marlin_repack");
@@ -516,8 +524,16 @@ torch::Tensor gptq_marlin_gemm(torch::Tensor a, torch::Tensor b_q_weight, torch:
                                torch::Tensor g_idx, torch::Tensor perm, torch::Tensor workspace, int64_t b_q_type, int64_t size_m,
                                int64_t size_n, int64_t size_k, bool is_k_full, bool has_zp, bool use_fp32_reduce, bool is_zp_float) {
   TORCH_CHECK(!is_zp_float, "gptq_marlin_gemm: float zero points are not supported");
-  TORCH_CHECK(b_q_type == 4, "gptq_marlin_gemm on MI355X serves 4-bit weights only");
+  TORCH_CHECK(b_q_type == 4 || b_q_type == 8, "gptq_marlin_gemm on MI355X serves uint4 / uint4b8 and uint8b128 weights");
   torch::Tensor x = a.reshape({-1, a.size(-1)});
+  if (b_q_type == 8) {   // uint8b128 (marlin_utils.py:28-45): sequential [K/4, N] words, zero point 128 = 127 per byte stored-minus-one
+    TORCH_CHECK(!has_zp, "gptq_marlin_gemm: the 8-bit type served is uint8b128 (symmetric, no zero points)");
+    TORCH_CHECK(x.size(0) == size_m && x.size(1) == size_k && b_q_weight.dim() == 2 && b_q_weight.size(0) == size_k / 4 &&
+                b_q_weight.size(1) == size_n, "gptq_marlin_gemm: shape mismatch");
+    auto zp8 = torch::full({b_scales.size(0), size_n / 4}, (int64_t)0x7f7f7f7f, b_q_weight.options().dtype(torch::kInt));
+    torch::Tensor g = perm.defined() && perm.numel() > 0 ? perm : torch::empty({0}, b_q_weight.options().dtype(torch::kInt));
+    return gptq_gemm(x.stride(1) == 1 ? x : x.contiguous(), b_q_weight, zp8, b_scales, g, true, 8);
+  }
   TORCH_CHECK(x.size(0) == size_m && x.size(1) == size_k && b_q_weight.dim() == 2 && b_q_weight.size(0) == size_k / 8 &&
               b_q_weight.size(1) == size_n, "gptq_marlin_gemm: shape mismatch");
   torch::Tensor zp = b_zeros;

@@ -762,6 +762,39 @@ def test_gptq_marlin_gemm_role(ops, has_zp, M):
     np.testing.assert_allclose(got, ref, rtol=2e-3, atol=2e-3 * np.abs(ref).max())
 
 
+@pytest.mark.parametrize("act_order", [False, True])
+@pytest.mark.parametrize("M", [1, 32, 48, 200])
+def test_gptq_marlin_gemm_role_uint8b128(ops, act_order, M):
+    """The Marlin role's second weight type (quantization/utils/marlin_utils.py:28-45: uint4b8 and uint8b128): symmetric 8-bit
+    weights, zero point 128, group scales; gptq_marlin_repack(..., 8) makes act-order rows sequential, gptq_marlin_gemm takes
+    perm = argsort(g_idx).  Against the dequantised reference (tests/kernels/test_marlin_gemm.py:30-32: relative error < 0.04);
+    a type the op does not serve is refused."""
+    from aphrodite_engine_amd.scalar_type import ScalarType, scalar_types
+    rng = np.random.default_rng(M + 3 * act_order)
+    K, N, G = 512, 256, 128
+    w = (rng.standard_normal((K, N)) * 0.05).astype(np.float32)
+    _, q, s, _ = oq.quantize_weights(w, 8, G, zero_points=False)          # q in [0, 255], value = (q - 128) * s[group]
+    g_idx = (np.arange(K) // G).astype(np.int32)
+    if act_order:
+        g_idx = g_idx[rng.permutation(K)]
+    w_ref = ((q.astype(np.float32) - 128.0) * s.astype(np.float16).astype(np.float32)[g_idx]).astype(np.float16).astype(np.float32)
+    qweight = t(oq.gptq_pack(q, 8).astype(np.int32))                      # checkpoint rows, [K/4, N]
+    perm = t(np.argsort(g_idx, kind="stable").astype(np.int32)) if act_order else torch.empty(0, dtype=torch.int32, device=DEV)
+    b = ops.gptq_marlin_repack(qweight, perm, K, N, 8)
+    assert b.shape == qweight.shape and (act_order or torch.equal(b, qweight))
+    a = t(rng.standard_normal((M, K)).astype(np.float16))
+    empty = torch.empty(0, dtype=torch.int32, device=DEV)
+    got = ops.gptq_marlin_gemm(a, b, t(s, torch.float16), empty, t(g_idx) if act_order else empty, perm, None,
+                               scalar_types.uint8b128, M, N, K, True, False, True, False).float().cpu().numpy()
+    ref = a.float().cpu().numpy() @ w_ref
+    assert rel_mean_err(got, ref) < 0.04
+    np.testing.assert_allclose(got, ref, rtol=4e-3, atol=4e-3 * np.abs(ref).max())
+    with pytest.raises(RuntimeError):
+        ops.gptq_marlin_gemm(a, b, t(s, torch.float16), empty, empty, perm, None, scalar_types.uint8, M, N, K, True, True, True, False)
+    with pytest.raises(RuntimeError):
+        ops.gptq_marlin_gemm(a, b, t(s, torch.float16), empty, empty, perm, None, ScalarType.uint(2, 0), M, N, K, True, False, True, False)
+
+
 @pytest.mark.parametrize("kind", ["fp8", "fp8_e5m2", "auto"])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_convert_fp8_round_trip(ops, kind, dtype):

@@ -506,6 +506,17 @@ def test_cpp_registered_round5_second_batch_matches_the_python_registration(T):
         for has_zp, zt in ((False, empty), (True, mzp)):
             args = (a2, mq, msc, zt, empty, empty, ws_m, 4, M, N2, K2, True, has_zp, True, False)
             assert torch.equal(C.gptq_marlin_gemm(*args), T.C.gptq_marlin_gemm(*args)), (M, has_zp)
+    # ... and the role's 8-bit type (uint8b128): repack (act-order rows made sequential) and GEMM, C++ == Python registration
+    _, q8, s8, _ = oq.quantize_weights((rng.standard_normal((512, 256)) * 0.05).astype(np.float32), 8, G, zero_points=False)
+    gq8 = t(oq.gptq_pack(q8, 8).astype(np.int32))
+    perm8 = t(rng.permutation(512).astype(np.int32))
+    for pm in (empty, perm8):
+        r8 = C.gptq_marlin_repack(gq8, pm, 512, 256, 8)
+        assert torch.equal(r8, T.C.gptq_marlin_repack(gq8, pm, 512, 256, 8))
+        for M in (7, 48, 130):
+            a8b = t(rng.standard_normal((M, 512)).astype(np.float16))
+            args = (a8b, r8, t(s8.astype(np.float16)), empty, empty, pm, ws_m, 8, M, 256, 512, True, False, True, False)
+            assert torch.equal(C.gptq_marlin_gemm(*args), T.C.gptq_marlin_gemm(*args)), (M, pm.numel())
     w8 = t((rng.standard_normal((256, 512)) * 0.5).astype(np.float32)).to(torch.float8_e4m3fn)     # [N, K]
     for sb8 in (t(np.array([0.02], np.float32)), t((rng.random(256) * 0.02 + 0.01).astype(np.float32))):
         for M in (5, 70, 200):
