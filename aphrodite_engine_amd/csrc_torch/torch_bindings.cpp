@@ -51,11 +51,15 @@ torch::Tensor gptq_gemm(torch::Tensor a, torch::Tensor b_q_weight, torch::Tensor
   if (bit != 4) {   // csrc/wnx_gemm.hip: MFMA small-M kernel on the sequential layout, else reconstruct + library GEMM
     torch::Tensor ag = act_order ? a.index_select(1, b_g_idx.to(torch::kLong)) : a;
     if (ag.stride(1) != 1 || ag.stride(0) % 8 != 0) ag = ag.contiguous();
-    if (m >= 1 && m <= 32 && aphro_gptq_gemm_bits_supported(m, n, k, groups, (int)bit)) {
-      ok(aphro_gptq_gemm_bits(ag.data_ptr(), ag.stride(0), (const uint32_t*)b_q_weight.data_ptr(),
-                              (const uint32_t*)b_gptq_qzeros.data_ptr(), b_gptq_scales.data_ptr(), out.data_ptr(), m, n, k,
-                              groups, (int)bit, act_dtype(a), cur_stream()),
-         "gptq_gemm");
+    if (m >= 1 && m <= 64 && aphro_gptq_gemm_bits_supported(m < 32 ? m : 32, n, k, groups, (int)bit)) {
+      for (int64_t m0 = 0; m0 < m; m0 += 32) {          // (as the Python op: up to 64 rows in two passes of the 32-row kernel)
+        const int64_t rows = m - m0 < 32 ? m - m0 : 32;
+        ok(aphro_gptq_gemm_bits((const char*)ag.data_ptr() + m0 * ag.stride(0) * ag.element_size(), ag.stride(0),
+                                (const uint32_t*)b_q_weight.data_ptr(), (const uint32_t*)b_gptq_qzeros.data_ptr(),
+                                b_gptq_scales.data_ptr(), (char*)out.data_ptr() + m0 * n * out.element_size(), rows, n, k,
+                                groups, (int)bit, act_dtype(a), cur_stream()),
+           "gptq_gemm");
+      }
       return out;
     }
     auto w = torch::empty({k, n}, a.options());
@@ -835,10 +839,8 @@ TORCH_LIBRARY_FRAGMENT(APHRO_TORCH_NS, m) {
   m.impl("gptq_marlin_repack", torch::kCUDA, &gptq_marlin_repack);
   m.def("awq_marlin_repack(Tensor b_q_weight, SymInt size_k, SymInt size_n, int num_bits) -> Tensor");  // :211-215
   m.impl("awq_marlin_repack", torch::kCUDA, &awq_marlin_repack);
-  m.def("gptq_marlin_gemm(Tensor a, Tensor b_q_weight, Tensor b_scales, Tensor b_zeros, Tensor g_idx, Tensor perm, "
-        "Tensor workspace, int b_q_type, int size_m, int size_n, int size_k, bool is_k_full, bool has_zp, "
-        "bool use_fp32_reduce, bool is_zp_float) -> Tensor");                                           // :195-201
-  m.impl("gptq_marlin_gemm", torch::kCUDA, &gptq_marlin_gemm);
+  // (gptq_marlin_gemm: registered by aphro_torch_register_marlin below -- its schema depends on whether the process has the
+  //  torchbind class _core_C.ScalarType)
   m.def("fp8_marlin_gemm(Tensor a, Tensor b_q_weight, Tensor b_scales, Tensor! workspace, int num_bits, "
         "int size_m, int size_n, int size_k) -> Tensor");                                               // :218-222
   m.impl("fp8_marlin_gemm", torch::kCUDA, &fp8_marlin_gemm);
@@ -869,4 +871,61 @@ TORCH_LIBRARY_FRAGMENT(APHRO_CONCAT(APHRO_TORCH_NS, _custom_ar), m) {
   m.impl("get_graph_buffer_ipc_meta", &get_graph_buffer_ipc_meta);
   m.def("register_graph_buffers(int fa, str[] handles, int[][] offsets) -> ()");                        // :535
   m.impl("register_graph_buffers", &register_graph_buffers);
+}
+
+
+// gptq_marlin_gemm, kernels/torch_bindings.cpp:195-201: the verbatim schema names the torchbind class _core_C.ScalarType
+// (kernels/core/torch_bindings.cpp:10-13).  with_class != 0: the class resolves in this process (the reference's own _core_C, or
+// csrc_torch/core_scalar_type.cpp loaded by torch_cpp.load()) -- the op is defined with the verbatim schema and a BOXED kernel
+// that reads the type through its `size_bits` / `bias` properties, so it does not matter whose C++ class sits behind the name;
+// with_class == 0: the type travels as its size in bits (`int b_q_type`).  Called once, after the library is loaded.
+static int64_t scalar_type_property(const c10::IValue& v, const char* name) {
+  auto obj = v.toObject();
+  auto prop = obj->type()->getProperty(name);
+  TORCH_CHECK(prop.has_value() && prop->getter != nullptr, "gptq_marlin_gemm: b_q_type has no property ", name);
+  return (*prop->getter)({v}).toInt();
+}
+
+static void gptq_marlin_gemm_boxed(const c10::OperatorHandle&, c10::DispatchKeySet, torch::jit::Stack* stack) {
+  constexpr size_t NARGS = 15;
+  auto args = torch::jit::last(*stack, NARGS);
+  const c10::IValue qt = args[7];
+  const bool has_zp = args[12].toBool();
+  int64_t bits;
+  if (qt.isInt()) {
+    bits = qt.toInt();
+  } else {
+    bits = scalar_type_property(qt, "size_bits");
+    const int64_t bias = scalar_type_property(qt, "bias");
+    // the types the Marlin role takes (quantization/utils/marlin_utils.py:28-45; awq_marlin: uint4 with zero points)
+    TORCH_CHECK((bits == 4 && (bias == 8 || (bias == 0 && has_zp))) || (bits == 8 && bias == 128),
+                "gptq_marlin_gemm: weight type with ", bits, " bits and bias ", bias, " is not one of uint4 (zero points), uint4b8, uint8b128");
+  }
+  torch::Tensor out = gptq_marlin_gemm(args[0].toTensor(), args[1].toTensor(), args[2].toTensor(), args[3].toTensor(), args[4].toTensor(),
+                                       args[5].toTensor(), args[6].toTensor(), bits, args[8].toInt(), args[9].toInt(), args[10].toInt(),
+                                       args[11].toBool(), has_zp, args[13].toBool(), args[14].toBool());
+  torch::jit::drop(*stack, NARGS);
+  torch::jit::push(*stack, std::move(out));
+}
+
+#define APHRO_STR2(x) #x
+#define APHRO_STR(x) APHRO_STR2(x)
+extern "C" int aphro_torch_register_marlin(int with_class) {
+  static torch::Library* lib = nullptr;
+  if (lib != nullptr) return 1;                      // once per process
+  try {
+    lib = new torch::Library(torch::Library::FRAGMENT, APHRO_STR(APHRO_TORCH_NS), c10::nullopt, __FILE__, __LINE__);
+    const std::string head = "gptq_marlin_gemm(Tensor a, Tensor b_q_weight, Tensor b_scales, Tensor b_zeros, Tensor g_idx, Tensor perm, "
+                             "Tensor workspace, ";
+    const std::string tail = " b_q_type, int size_m, int size_n, int size_k, bool is_k_full, bool has_zp, bool use_fp32_reduce, "
+                             "bool is_zp_float) -> Tensor";
+    lib->def((head + (with_class ? "__torch__.torch.classes._core_C.ScalarType" : "int") + tail).c_str());
+    lib->impl("gptq_marlin_gemm", torch::kCUDA, torch::CppFunction::makeFromBoxedFunction<&gptq_marlin_gemm_boxed>());
+  } catch (const std::exception& e) {
+    fprintf(stderr, "aphro_torch_register_marlin: %s\n", e.what());
+    delete lib;
+    lib = nullptr;
+    return -1;
+  }
+  return 0;
 }

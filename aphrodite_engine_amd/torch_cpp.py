@@ -19,6 +19,29 @@ def library_path() -> str:
     return os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libaphrodite_mi355x_torch.so")
 
 
+def core_library_path() -> str:
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libaphrodite_mi355x_core.so")
+
+
+def scalar_type_class():
+    """``torch.classes._core_C.ScalarType`` or None when no library of the process has registered it."""
+    try:
+        return torch.classes._core_C.ScalarType
+    except Exception:
+        return None
+
+
+def ensure_scalar_type_class():
+    """The torchbind class the quantised GEMM schemas name (kernels/core/torch_bindings.cpp:10-13).  Inside the reference its own
+    ``_core_C`` extension registers it (aphrodite/_core_ext.py imports that before any plugin runs); standalone this package's
+    csrc_torch/core_scalar_type.cpp does -- loaded only when the name does not resolve: a class can be registered once."""
+    cls = scalar_type_class()
+    if cls is None and os.path.exists(core_library_path()):
+        torch.ops.load_library(core_library_path())
+        cls = scalar_type_class()
+    return cls
+
+
 def load() -> str:
     """Idempotent; raises if the library has not been built (``__graft_entry__.build()``)."""
     global _LOADED
@@ -26,6 +49,12 @@ def load() -> str:
     if not _LOADED:
         if not os.path.exists(path):
             raise RuntimeError(f"{path} is missing: run `make -C aphrodite_engine_amd/csrc_torch` (or __graft_entry__.build())")
+        have_class = ensure_scalar_type_class() is not None
         torch.ops.load_library(path)
+        # gptq_marlin_gemm: the verbatim schema (ScalarType b_q_type) when the class exists, else `int b_q_type`
+        import ctypes
+        rc = ctypes.CDLL(path).aphro_torch_register_marlin(1 if have_class else 0)
+        if rc < 0:
+            raise RuntimeError("torch_cpp.load: registering gptq_marlin_gemm failed (see stderr)")
         _LOADED = True
     return path

@@ -85,9 +85,10 @@ def _gptq_marlin_gemm(a, b_q_weight, b_scales, b_zeros, g_idx, perm, workspace, 
 
 
 # torch_bindings.cpp:195-201.  The verbatim schema names the torchbind class ``_core_C.ScalarType``
-# (kernels/core/torch_bindings.cpp:13), which exists once the reference's ``_core_C`` extension is loaded -- inside
-# the reference that is always the case.  Standalone (tests, bench) the class is absent and the schema cannot be
-# parsed: the same op is then defined with ``int b_q_type`` (size in bits) in that position.
+# (kernels/core/torch_bindings.cpp:13), which exists once the reference's ``_core_C`` extension is loaded, or -- standalone
+# (tests, bench) -- once this package's own registration of it is (csrc_torch/core_scalar_type.cpp,
+# torch_cpp.ensure_scalar_type_class).  Only when neither library is there is the op defined with ``int b_q_type``
+# (size in bits) in that position.
 _MARLIN_GEMM_TAIL = ("int size_m, int size_n, int size_k, bool is_k_full, bool has_zp, bool use_fp32_reduce, "
                      "bool is_zp_float) -> Tensor")
 _MARLIN_GEMM_HEAD = ("gptq_marlin_gemm(Tensor a, Tensor b_q_weight, Tensor b_scales, Tensor b_zeros, Tensor g_idx, "
@@ -188,6 +189,8 @@ def register(ns_c: str = "_C", ns_cache: str = "_C_cache_ops", ns_rocm: str = "_
             else:
                 lib.impl(name, fn, "CUDA")
         if ns == ns_c:
+            from . import torch_cpp
+            torch_cpp.ensure_scalar_type_class()      # standalone: this package's own registration of _core_C.ScalarType
             try:
                 lib.define(GPTQ_MARLIN_GEMM_SCHEMAS[0])
             except Exception:          # _core_C.ScalarType is not registered: standalone form

@@ -203,9 +203,46 @@ def test_schema_cutlass_scaled_mm(T, M):
     assert T.C.cutlass_scaled_mm_supports_fp8(95) is True
 
 
+def _qtype(bits, bias):
+    """The b_q_type argument: the torchbind class _core_C.ScalarType (kernels/core/torch_bindings.cpp:10-13; standalone this
+    package registers it, csrc_torch/core_scalar_type.cpp) -- or the size in bits where no library has the class."""
+    from aphrodite_engine_amd import torch_cpp
+    cls = torch_cpp.ensure_scalar_type_class()
+    return bits if cls is None else cls.uint(bits, bias)
+
+
+def test_core_scalar_type_class():
+    """_core_C.ScalarType as this package registers it: the reference class's Python surface (kernels/core/scalar_type.hpp;
+    the typing mock of aphrodite/_core_ext.py:28-171 lists it) and its values for the types the hot path and the reference's
+    scalar_types table name (aphrodite/scalar_type.py)."""
+    from aphrodite_engine_amd import torch_cpp
+    S = torch_cpp.ensure_scalar_type_class()
+    assert S is not None
+    u4b8, u4, i4, u8b128 = S.uint(4, 8), S.uint(4, None), S.int_(4, None), S.uint(8, 128)
+    assert (str(u4b8), str(u4), str(i4), str(u8b128)) == ("uint4b8", "uint4", "int4", "uint8b128")
+    assert repr(i4) == "ScalarType.int4"
+    assert (u4b8.size_bits, u4b8.bias, u4b8.mantissa, u4b8.exponent, u4b8.signed) == (4, 8, 4, 0, False)
+    assert (u4b8.min(), u4b8.max(), u4.min(), u4.max(), i4.min(), i4.max(), u8b128.min(), u8b128.max()) == (-8, 7, 0, 15, -8, 7, -128, 127)
+    assert u4b8.is_integer() and not u4b8.is_floating_point() and u4b8.has_bias() and not u4.has_bias() and i4.is_signed()
+    assert u4b8 == S.uint(4, 8) and not (u4b8 == u4) and S(0, 4, 8, False) == u4b8
+    e4m3fn, e5m2, f16, bf16, e3m2f = S.float_(4, 3, True, 2), S.float_IEEE754(5, 2), S.float_IEEE754(5, 10), S.float_IEEE754(8, 7), S.float_(3, 2, True, 0)
+    assert [str(x) for x in (e4m3fn, e5m2, f16, bf16, e3m2f)] == ["float8_e4m3fn", "float8_e5m2", "float16_e5m10", "float16_e8m7", "float6_e3m2f"]
+    assert (e4m3fn.max(), e4m3fn.min(), e5m2.max(), f16.max(), e3m2f.max()) == (448.0, -448.0, 57344.0, 65504.0, 28.0)
+    assert bf16.max() == float(torch.finfo(torch.bfloat16).max)
+    assert e4m3fn.has_nans() and not e4m3fn.has_infs() and not e4m3fn.is_ieee_754() and f16.is_ieee_754() and f16.has_infs()
+    assert not e3m2f.has_nans() and e4m3fn.is_floating_point() and e4m3fn.is_signed()
+    for x in (u4b8, u8b128, i4, e4m3fn, bf16):                       # torch.compile's flatten / unflatten round trip
+        assert S.__obj_unflatten__(x.__obj_flatten__()) == x
+    with pytest.raises(TypeError):
+        len(u4b8)
+    with pytest.raises(RuntimeError):
+        S.float_(4, 3, False, 1)                                       # IEEE types go through float_IEEE754
+
+
 def test_schema_gptq_marlin_gemm(T):
-    """_C::gptq_marlin_gemm (torch_bindings.cpp:195-201).  Standalone the ScalarType argument travels as its size in
-    bits (torch_ops.GPTQ_MARLIN_GEMM_SCHEMAS); symmetric uint4b8 weights, no per-call allocation under capture."""
+    """_C::gptq_marlin_gemm (torch_bindings.cpp:195-201) with the verbatim schema -- b_q_type is the torchbind class
+    _core_C.ScalarType; symmetric uint4b8 weights, no per-call allocation under capture; a type outside the Marlin role's
+    table is refused."""
     rng = np.random.default_rng(5)
     K, N, G, M = 1024, 256, 128, 16
     w = (rng.standard_normal((K, N)) * 0.02).astype(np.float16)
@@ -214,7 +251,8 @@ def test_schema_gptq_marlin_gemm(T):
     a = rng.standard_normal((M, K)).astype(np.float16)
     empty = torch.empty(0, dtype=torch.int32, device=DEV)
     ws = torch.zeros(N // 64 * 16, dtype=torch.int32, device=DEV)
-    args = (t(a), qw, t(s.astype(np.float16)), empty, empty, empty, ws, 4, M, N, K, True, False, True, False)
+    args = (t(a), qw, t(s.astype(np.float16)), empty, empty, empty, ws, _qtype(4, 8), M, N, K, True, False, True, False)
+    assert "ScalarType b_q_type" in str(T.C.gptq_marlin_gemm.default._schema)
     _, out = captured(lambda: T.C.gptq_marlin_gemm(*args))
     ref = a.astype(np.float64) @ w_ref.astype(np.float64)
     got = out.float().cpu().numpy()
@@ -504,8 +542,11 @@ def test_cpp_registered_round5_second_batch_matches_the_python_registration(T):
     for M in (7, 48, 130):
         a2 = t(rng.standard_normal((M, K2)).astype(np.float16))
         for has_zp, zt in ((False, empty), (True, mzp)):
-            args = (a2, mq, msc, zt, empty, empty, ws_m, 4, M, N2, K2, True, has_zp, True, False)
+            args = (a2, mq, msc, zt, empty, empty, ws_m, _qtype(4, 0 if has_zp else 8), M, N2, K2, True, has_zp, True, False)
             assert torch.equal(C.gptq_marlin_gemm(*args), T.C.gptq_marlin_gemm(*args)), (M, has_zp)
+    assert "ScalarType b_q_type" in str(C.gptq_marlin_gemm.default._schema)        # the C++ registration: verbatim schema, boxed kernel
+    with pytest.raises(RuntimeError):                                              # int3 is not in the role's table
+        C.gptq_marlin_gemm(a2, mq, msc, empty, empty, empty, ws_m, _qtype(3, 4), 130, N2, K2, True, False, True, False)
     # ... and the role's 8-bit type (uint8b128): repack (act-order rows made sequential) and GEMM, C++ == Python registration
     _, q8, s8, _ = oq.quantize_weights((rng.standard_normal((512, 256)) * 0.05).astype(np.float32), 8, G, zero_points=False)
     gq8 = t(oq.gptq_pack(q8, 8).astype(np.int32))
@@ -515,7 +556,7 @@ def test_cpp_registered_round5_second_batch_matches_the_python_registration(T):
         assert torch.equal(r8, T.C.gptq_marlin_repack(gq8, pm, 512, 256, 8))
         for M in (7, 48, 130):
             a8b = t(rng.standard_normal((M, 512)).astype(np.float16))
-            args = (a8b, r8, t(s8.astype(np.float16)), empty, empty, pm, ws_m, 8, M, 256, 512, True, False, True, False)
+            args = (a8b, r8, t(s8.astype(np.float16)), empty, empty, pm, ws_m, _qtype(8, 128), M, 256, 512, True, False, True, False)
             assert torch.equal(C.gptq_marlin_gemm(*args), T.C.gptq_marlin_gemm(*args)), (M, pm.numel())
     w8 = t((rng.standard_normal((256, 512)) * 0.5).astype(np.float32)).to(torch.float8_e4m3fn)     # [N, K]
     for sb8 in (t(np.array([0.02], np.float32)), t((rng.random(256) * 0.02 + 0.01).astype(np.float32))):
