@@ -575,9 +575,9 @@ def prefill_e2e_section(T=8192, library=True, which=("int4", "fp8")):
     BS = 16
     out = {}
 
-    def sdpa_varlen(q, k, v, cu_seqlens, max_seqlen, softmax_scale, causal=True, alibi_slopes=None):
+    def sdpa_varlen(q, k, v, cu_seqlens, max_seqlen, softmax_scale, causal=True, alibi_slopes=None, window_size=None):
         # one sequence (this section's prompt): [T, H, D] -> [1, H, T, D]; GQA inside SDPA
-        assert cu_seqlens.numel() == 2 and alibi_slopes is None
+        assert cu_seqlens.numel() == 2 and alibi_slopes is None and (window_size is None or window_size[0] < 0)
         o = F.scaled_dot_product_attention(q.transpose(0, 1).unsqueeze(0), k.transpose(0, 1).unsqueeze(0),
                                            v.transpose(0, 1).unsqueeze(0), is_causal=causal, scale=softmax_scale,
                                            enable_gqa=True)
