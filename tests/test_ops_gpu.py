@@ -1186,6 +1186,44 @@ def test_attention_backend_prefill_then_decode(ops):
         np.testing.assert_allclose(out[npf + j].reshape(Hq, D), ref_d, atol=2e-3, rtol=2e-3)
 
 
+def test_attention_backend_sliding_window_prefill(ops):
+    """MI355XAttentionImpl(sliding_window=w) on a fresh prompt batch (no cached context): the window goes to the prompt kernel
+    as ROCmFlashAttentionImpl hands it to flash_attn_varlen_func (window_size = (w, w), causal: keys i - w .. i;
+    rocm_flash_attn.py:321-322, 497-507); the new K / V still land in the paged cache."""
+    from aphrodite_engine_amd.attention import MI355XAttentionImpl, MI355XAttentionMetadata
+    rng = np.random.default_rng(33)
+    Hq, Hkv, D, BS, W = 8, 2, 128, 16, 24
+    plens = [70, 9, 300]
+    NB = 32
+    kv_cache = torch.zeros(2, NB, BS * Hkv * D, dtype=torch.float16, device=DEV)
+    impl = MI355XAttentionImpl(Hq, D, D ** -0.5, Hkv, sliding_window=W)
+    assert impl.sliding_window == (W, W)
+    T = sum(plens)
+    q = rng.standard_normal((T, Hq * D)).astype(np.float16)
+    k = rng.standard_normal((T, Hkv * D)).astype(np.float16)
+    v = rng.standard_normal((T, Hkv * D)).astype(np.float16)
+    perm = np.random.default_rng(4).permutation(NB).astype(np.int32)         # disjoint block sets: 5, 1 and 19 blocks
+    tabs = [perm[:5], perm[5:6], perm[6:25]]
+    slots = []
+    for tab, L in zip(tabs, plens):
+        slots += [int(tab[p // BS]) * BS + p % BS for p in range(L)]
+    cu = np.concatenate([[0], np.cumsum(plens)]).astype(np.int32)
+    meta = MI355XAttentionMetadata(
+        num_prefills=3, num_prefill_tokens=T, num_decode_tokens=0, slot_mapping=t(np.array(slots, np.int64)), seq_lens=plens,
+        seq_lens_tensor=t(np.array(plens, np.int32)), max_query_len=max(plens), max_prefill_seq_len=max(plens),
+        max_decode_seq_len=0, query_start_loc=t(cu), seq_start_loc=t(cu), context_lens_tensor=t(np.zeros(3, np.int32)),
+        block_tables=None)
+    out = impl.forward(t(q), t(k), t(v), kv_cache, meta).float().cpu().numpy()
+    ref = oa.varlen_causal_attention(q.reshape(T, Hq, D), k.reshape(T, Hkv, D), v.reshape(T, Hkv, D), cu, D ** -0.5, window_left=W)
+    np.testing.assert_allclose(out.reshape(T, Hq, D), ref, atol=2e-3, rtol=2e-3)
+    full = oa.varlen_causal_attention(q.reshape(T, Hq, D), k.reshape(T, Hkv, D), v.reshape(T, Hkv, D), cu, D ** -0.5)
+    assert np.abs(full - ref).max() > 1e-2                       # the window matters for these lengths
+    kc, _ = ops_split(kv_cache, Hkv, D)                          # token 5 of the first prompt, kv head 1: written to its slot
+    blk, off = slots[5] // BS, slots[5] % BS
+    got_k = kc[blk, 1, :, off, :].reshape(-1).float().cpu().numpy()
+    np.testing.assert_array_equal(got_k, k[5].reshape(Hkv, D)[1].astype(np.float32))
+
+
 def ops_split(kv_cache, Hkv, D):
     from aphrodite_engine_amd.attention import PagedAttention
     return PagedAttention.split_kv_cache(kv_cache, Hkv, D)

@@ -661,3 +661,11 @@ def test_reference_attention_layer_over_our_backend_and_kv_method(reference_modu
     q = torch.zeros(1, 32 * 128)
     assert layer.forward(q, q[:, :1024], q[:, :1024], None, None) == "out"
     assert got["a"][5:] == (layer._k_scale, layer._v_scale) and got["k"] == {"attn_type": AttentionType.DECODER}
+    # a Mistral-style engine config: cache_config.sliding_window reaches our impl the way ROCmFlashAttentionImpl keeps it
+    # (attention/layer.py:44-47 -> rocm_flash_attn.py:321-322)
+    windowed = ref_attn.Attention(32, 128, 128 ** -0.5, num_kv_heads=8,
+                                  cache_config=types.SimpleNamespace(cache_dtype=kv_cache_dtype, block_size=16, sliding_window=4096,
+                                                                     is_attention_free=False),
+                                  quant_config=None, prefix="model.layers.1.self_attn.attn")
+    assert isinstance(windowed.impl, MI355XAttentionImpl) and windowed.impl.sliding_window == (4096, 4096)
+    assert layer.impl.sliding_window == (-1, -1)
