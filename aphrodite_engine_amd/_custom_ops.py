@@ -2273,6 +2273,30 @@ def custom_ar_fused_add_rms_norm_quant_fp8(fa: int, inp: torch.Tensor, residual:
     return q, sc, out
 
 
+def custom_ar_fused_add_rms_norm_router(fa: int, inp: torch.Tensor, residual: Optional[torch.Tensor], has_residual: bool,
+                                        weight: torch.Tensor, epsilon: float, router_weight: torch.Tensor,
+                                        reg_buffer: Optional[torch.Tensor] = None):
+    """tensor_model_parallel_all_reduce(inp) -> fused_add_rms_norm(residual) -> the router's logits of a sparse-MLP layer in
+    ONE launch (linear.py:1142-1143, models/mixtral.py's post_attention_layernorm and MixtralMoE.gate, mixtral.py:60-110):
+    the bits of all_reduce_reg / all_reduce_unreg followed by fused_add_rms_norm_router(inp, ...).  Returns
+    (out [tokens, hidden], router_logits [tokens, E]), E <= 16; ``residual`` is updated in place."""
+    _require_cuda(inp, weight, router_weight)
+    if inp.dim() != 2 or not inp.is_contiguous() or inp.dtype != weight.dtype or inp.dtype not in (torch.float16, torch.bfloat16):
+        raise RuntimeError("custom_ar_fused_add_rms_norm_router: inp must be a contiguous [tokens, hidden] f16 / bf16 tensor of the weight's dtype")
+    tokens, hidden = inp.shape
+    e = router_weight.shape[0]
+    if router_weight.shape[1] != hidden or not router_weight.is_contiguous() or router_weight.dtype != weight.dtype:
+        raise RuntimeError("custom_ar_fused_add_rms_norm_router: router_weight must be a contiguous [E, hidden] tensor of the norm's dtype")
+    out = torch.empty((tokens, hidden), dtype=weight.dtype, device=inp.device)
+    logits = torch.empty((tokens, e), dtype=weight.dtype, device=inp.device)
+    check(_lib.lib().aphro_custom_ar_fused_add_rms_norm_router(
+        fa, inp.data_ptr(), _ptr(residual), 1 if has_residual else 0, weight.data_ptr(), float(epsilon), out.data_ptr(),
+        router_weight.data_ptr(), logits.data_ptr(), e, tokens, hidden, _dt(weight), _ptr(reg_buffer),
+        reg_buffer.numel() * reg_buffer.element_size() if reg_buffer is not None else 0, _stream()),
+        "custom_ar_fused_add_rms_norm_router")
+    return out, logits
+
+
 def _ar_check_io(inp: torch.Tensor, out: torch.Tensor):
     _require_cuda(inp, out)
     if inp.dtype != out.dtype or inp.numel() != out.numel():

@@ -61,6 +61,7 @@ SIGNATURES = {
     "aphro_custom_ar_fused_norm_one_shot": (I, [I, L, I, I]),
     "aphro_custom_ar_fused_add_rms_norm": (I, [P, P, P, I, P, F, P, P, L, I, I, P, Z, P, Z, P]),
     "aphro_custom_ar_fused_add_rms_norm_quant_fp8": (I, [P, P, P, I, P, F, P, P, P, P, L, I, I, P, Z, P]),
+    "aphro_custom_ar_fused_add_rms_norm_router": (I, [P, P, P, I, P, F, P, P, P, I, L, I, I, P, Z, P]),
     "aphro_custom_ar_init_loopback": (I, [P, P, P, Z, P, Z, I]),
     "aphro_advance_step_flashattn": (I, [I, I, I, P, P, P, P, P, P, L, P]),
     "aphro_argmax_rows": (I, [P, P, L, L, L, I, P]),

@@ -266,7 +266,15 @@ struct ArNormParams {
   uint8_t* q8_out;                      // [tokens, hidden] e4m3
   float* q8_scale_out;                  // [tokens]
   const float* q8_static;               // [1] or null
+  // ROUTER kernels (sparse-MLP layers under TP: the attention block's all-reduce in front of the router norm): the router's
+  // logits of the row, round_T(y . router_w[e]) for e < num_experts <= 16 -- the bits of add_rms_norm_pack_kernel<T, ROUTER>
+  // (fused_decode.hip) on the all-reduced input; the normalised row leaves row-major through `out`.
+  const uint16_t* router_w;             // [num_experts, hidden] T
+  uint16_t* router_out;                 // [tokens, num_experts] T
+  int num_experts;
 };
+
+constexpr int AR_EPI_NONE = 0, AR_EPI_Q8 = 1, AR_EPI_ROUTER = 2;
 
 __device__ __forceinline__ void ar_prefetch_role(const ArNormParams& q) {
   u32x4 acc = {0, 0, 0, 0};
@@ -418,10 +426,83 @@ __device__ __forceinline__ void ar_norm_quant(const ArNormParams& q, int row, co
   }
 }
 
-template <typename T, int WORLD, bool Q8>
+// The router epilogue of a ROUTER launch: same thread -> element mapping, accumulation order, reduce-scatter butterfly and
+// cross-wave sum as add_rms_norm_pack_kernel<T, ROUTER = true> (fused_decode.hip).
+// The first eight router rows of a thread's chunks: requested with the norm weights, in flight across the first barrier (a
+// serial L2 round trip behind the norm otherwise: 8.1 -> 7.4 us per launch at 4 ranks, [32, 4096]).
+template <bool ON>
+__device__ __forceinline__ void ar_router_prefetch(const ArNormParams& q, int nv, u16x8 (&g8v)[2][8]) {
+  if constexpr (ON) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int i = threadIdx.x + it * blockDim.x;
+      if (i < nv) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (e < q.num_experts) g8v[it][e] = *reinterpret_cast<const u16x8*>(q.router_w + (size_t)e * q.hidden + 8 * i);
+      }
+    }
+  }
+}
+
+// PRE: g8v holds the prefetched rows (one-shot kernel).  The two-shot kernel (1024-thread workgroups at hidden 8192: 128
+// VGPRs) loads them here -- with the prefetch it measured 13.2 us against 10.6 at 8 ranks, [64, 8192].
+template <typename T, bool PRE>
+__device__ __forceinline__ void ar_norm_router(const ArNormParams& q, int row, const u16x8 (&y)[2], int nv, float* rred,
+                                               const u16x8 (&g8v)[PRE ? 2 : 1][8]) {
+  float rpart[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) rpart[e] = 0.f;
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int i = threadIdx.x + it * blockDim.x;
+    if (i < nv) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        if (e < q.num_experts) {
+          u16x8 g8;
+          if (PRE && e < 8) g8 = g8v[PRE ? it : 0][e < 8 ? e : 0];
+          else g8 = *reinterpret_cast<const u16x8*>(q.router_w + (size_t)e * q.hidden + 8 * i);
+          {
+#pragma clang fp contract(off)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) rpart[e] += T::to_f32(y[it][j]) * T::to_f32(g8[j]);
+          }
+        }
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = (blockDim.x + 63) >> 6;
+#define AR_RS_STEP(O, HALF)                                           \
+  {                                                                   \
+    const bool up = (lane & O) != 0;                                  \
+    _Pragma("unroll") for (int j = 0; j < HALF; ++j) {                \
+      const float send = up ? rpart[j] : rpart[j + HALF];             \
+      const float keep = up ? rpart[j + HALF] : rpart[j];             \
+      rpart[j] = keep + __shfl_xor(send, O, 64);                      \
+    }                                                                 \
+  }
+  AR_RS_STEP(32, 8)
+  AR_RS_STEP(16, 4)
+  AR_RS_STEP(8, 2)
+  AR_RS_STEP(4, 1)
+#undef AR_RS_STEP
+  float v2 = rpart[0];
+  v2 += __shfl_xor(v2, 2, 64);
+  v2 += __shfl_xor(v2, 1, 64);
+  if ((lane & 3) == 0) rred[wave * 16 + ((lane >> 2) & 15)] = v2;
+  __syncthreads();
+  if ((int)threadIdx.x < q.num_experts) {
+    float sum = 0.f;
+    for (int w2 = 0; w2 < nwave; ++w2) sum += rred[w2 * 16 + threadIdx.x];
+    q.router_out[(size_t)row * q.num_experts + threadIdx.x] = T::from_f32(sum);
+  }
+}
+
+template <typename T, int WORLD, int EPI>
 __global__ __launch_bounds__(1024) void ar_norm_one_shot_kernel(ArNormParams q) {
   __shared__ uint32_t ticket;
   __shared__ float red[16];
+  __shared__ float rred[EPI == AR_EPI_ROUTER ? 16 * 16 : 1];
   if ((int)blockIdx.x >= q.nb) { ar_prefetch_role(q); return; }      // (block-uniform)
   const ArParams& p = q.ar;
   if (threadIdx.x == 0) {
@@ -437,6 +518,8 @@ __global__ __launch_bounds__(1024) void ar_norm_one_shot_kernel(ArNormParams q) 
     const int i = threadIdx.x + it * blockDim.x;
     if (i < nv) wv[it] = *reinterpret_cast<const u16x8*>(q.weight + 8 * i);
   }
+  u16x8 g8v[EPI == AR_EPI_ROUTER ? 2 : 1][8];
+  if constexpr (EPI == AR_EPI_ROUTER) ar_router_prefetch<true>(q, nv, g8v);
   __syncthreads();
   const uint32_t val = ticket;
   ar_barrier(p, 0, val);                                   // every peer's input is in place
@@ -455,7 +538,8 @@ __global__ __launch_bounds__(1024) void ar_norm_one_shot_kernel(ArNormParams q) 
     const int i = threadIdx.x + it * blockDim.x;
     if (i < nv) ar_norm_emit<T>(q, tok, i, y[it]);
   }
-  if constexpr (Q8) ar_norm_quant<T>(q, tok, y, nv, red);
+  if constexpr (EPI == AR_EPI_Q8) ar_norm_quant<T>(q, tok, y, nv, red);
+  if constexpr (EPI == AR_EPI_ROUTER) ar_norm_router<T, true>(q, tok, y, nv, rred, g8v);
   ar_barrier(p, 2, val);                                   // nobody still reads my input when I return
 }
 
@@ -467,10 +551,11 @@ __global__ __launch_bounds__(1024) void ar_norm_one_shot_kernel(ArNormParams q) 
 // instead of `world` times.  (Round-5 lab, loopback communicator, [64, 8192] f16 at 8 ranks: all-reduce 8.0 us + norm 4.4 us
 // as two launches 12.6 us; a reduce-scatter BY ROW with the norm before the gather -- 8 workgroups of 1024 threads doing
 // all of it -- 15.3 us; this form see profiles/r5_ar_norm_fused.txt.)
-template <typename T, int WORLD, bool Q8>
+template <typename T, int WORLD, int EPI>
 __global__ __launch_bounds__(1024) void ar_norm_two_shot_kernel(ArNormParams q) {
   __shared__ uint32_t ticket;
   __shared__ float red[16];
+  __shared__ float rred[EPI == AR_EPI_ROUTER ? 16 * 16 : 1];
   if ((int)blockIdx.x >= q.nb) { ar_prefetch_role(q); return; }      // (block-uniform)
   const ArParams& p = q.ar;
   if (threadIdx.x == 0) {
@@ -487,6 +572,7 @@ __global__ __launch_bounds__(1024) void ar_norm_two_shot_kernel(ArNormParams q) 
     const int i = threadIdx.x + it * blockDim.x;
     if (i < nv) wv[it] = *reinterpret_cast<const u16x8*>(q.weight + 8 * i);
   }
+  u16x8 g8v[1][8];                                          // (not prefetched in this form: see ar_norm_router)
   __syncthreads();
   const uint32_t val = ticket;
   ar_barrier(p, 0, val);
@@ -511,7 +597,8 @@ __global__ __launch_bounds__(1024) void ar_norm_two_shot_kernel(ArNormParams q) 
     const int i = threadIdx.x + it * blockDim.x;
     if (i < nv) ar_norm_emit<T>(q, row, i, y[it]);
   }
-  if constexpr (Q8) ar_norm_quant<T>(q, row, y, nv, red);
+  if constexpr (EPI == AR_EPI_Q8) ar_norm_quant<T>(q, row, y, nv, red);
+  if constexpr (EPI == AR_EPI_ROUTER) ar_norm_router<T, false>(q, row, y, nv, rred, g8v);
   ar_barrier(p, 2, val);
 }
 
@@ -870,6 +957,7 @@ extern "C" int aphro_custom_ar_fused_norm_one_shot(int world, int64_t tokens, in
 static int ar_fused_norm_launch(void* fa_, const void* inp, void* residual, int has_residual,
                                 const void* weight, float eps, void* packed, void* out,
                                 void* q8_out, float* q8_scale_out, const float* q8_static,
+                                const void* router_w, void* router_out, int num_experts,
                                 int64_t tokens, int hidden, int dtype,
                                 const void* prefetch, size_t prefetch_bytes,
                                 void* reg_buffer, size_t reg_buffer_bytes, void* stream) {
@@ -910,6 +998,7 @@ static int ar_fused_norm_launch(void* fa_, const void* inp, void* residual, int 
   q.rows_per_rank = (hidden / 8 + fa->world - 1) / fa->world;
   q.replicate_residual = 0;
   q.q8_out = (uint8_t*)q8_out; q.q8_scale_out = q8_scale_out; q.q8_static = q8_static;
+  q.router_w = (const uint16_t*)router_w; q.router_out = (uint16_t*)router_out; q.num_experts = num_experts;
   // the block size of aphro_fused_add_rms_norm_pack / aphro_fused_add_rms_norm_quant_fp8 (same thread -> element mapping, same reduction order)
   int nv = hidden / 8, t = nv <= 1024 ? nv : (nv + 1) / 2;
   t = (t + 63) / 64 * 64;
@@ -941,11 +1030,14 @@ static int ar_fused_norm_launch(void* fa_, const void* inp, void* residual, int 
     default: ARN_LAUNCH(TT, 8, Q) break;                                              \
   }
   if (q8_out) {
-    if (dtype == APHRO_F16) ARN_WORLD(Half, true)
-    else ARN_WORLD(BFloat, true)
+    if (dtype == APHRO_F16) ARN_WORLD(Half, AR_EPI_Q8)
+    else ARN_WORLD(BFloat, AR_EPI_Q8)
+  } else if (router_out) {
+    if (dtype == APHRO_F16) ARN_WORLD(Half, AR_EPI_ROUTER)
+    else ARN_WORLD(BFloat, AR_EPI_ROUTER)
   } else {
-    if (dtype == APHRO_F16) ARN_WORLD(Half, false)
-    else ARN_WORLD(BFloat, false)
+    if (dtype == APHRO_F16) ARN_WORLD(Half, AR_EPI_NONE)
+    else ARN_WORLD(BFloat, AR_EPI_NONE)
   }
 #undef ARN_WORLD
 #undef ARN_LAUNCH
@@ -958,8 +1050,8 @@ extern "C" int aphro_custom_ar_fused_add_rms_norm(void* fa_, const void* inp, vo
                                                   int64_t tokens, int hidden, int dtype,
                                                   const void* prefetch, size_t prefetch_bytes,
                                                   void* reg_buffer, size_t reg_buffer_bytes, void* stream) {
-  return ar_fused_norm_launch(fa_, inp, residual, has_residual, weight, eps, packed, out, nullptr, nullptr, nullptr, tokens,
-                              hidden, dtype, prefetch, prefetch_bytes, reg_buffer, reg_buffer_bytes, stream);
+  return ar_fused_norm_launch(fa_, inp, residual, has_residual, weight, eps, packed, out, nullptr, nullptr, nullptr, nullptr,
+                              nullptr, 0, tokens, hidden, dtype, prefetch, prefetch_bytes, reg_buffer, reg_buffer_bytes, stream);
 }
 
 // The FP8 W8A8 form: all_reduce(inp) -> fused_add_rms_norm(residual) -> per-token (or static) FP8
@@ -975,5 +1067,22 @@ extern "C" int aphro_custom_ar_fused_add_rms_norm_quant_fp8(void* fa_, const voi
                                                             size_t reg_buffer_bytes, void* stream) {
   APHRO_CHECK(q_out && scale_out, "custom_ar_fused_add_rms_norm_quant_fp8: NULL output");
   return ar_fused_norm_launch(fa_, inp, residual, has_residual, weight, eps, nullptr, out, q_out, scale_out, static_scale,
-                              tokens, hidden, dtype, nullptr, 0, reg_buffer, reg_buffer_bytes, stream);
+                              nullptr, nullptr, 0, tokens, hidden, dtype, nullptr, 0, reg_buffer, reg_buffer_bytes, stream);
+}
+
+// The sparse-MLP form: all_reduce(inp) -> fused_add_rms_norm(residual) -> the router's logits in ONE launch -- the bits of
+// aphro_custom_ar_all_reduce followed by aphro_fused_add_rms_norm_router on its `input` path (reference call sites: the
+// attention block's row-parallel all-reduce, linear.py:1142-1143; models/mixtral.py's post_attention_layernorm; the
+// replicated gate linear of MixtralMoE, mixtral.py:60-110).  out [tokens, hidden] T (the experts' input), router_out
+// [tokens, num_experts] T, num_experts <= 16.
+extern "C" int aphro_custom_ar_fused_add_rms_norm_router(void* fa_, const void* inp, void* residual, int has_residual,
+                                                         const void* weight, float eps, void* out, const void* router_w,
+                                                         void* router_out, int num_experts, int64_t tokens, int hidden,
+                                                         int dtype, void* reg_buffer, size_t reg_buffer_bytes,
+                                                         void* stream) {
+  APHRO_CHECK(out && router_w && router_out, "custom_ar_fused_add_rms_norm_router: NULL argument");
+  APHRO_CHECK(num_experts >= 1 && num_experts <= 16, "custom_ar_fused_add_rms_norm_router: 1..16 experts (got %d)", num_experts);
+  APHRO_CHECK((((uintptr_t)router_w) % 16) == 0, "custom_ar_fused_add_rms_norm_router: router weights must be 16-byte aligned");
+  return ar_fused_norm_launch(fa_, inp, residual, has_residual, weight, eps, nullptr, out, nullptr, nullptr, nullptr, router_w,
+                              router_out, num_experts, tokens, hidden, dtype, nullptr, 0, reg_buffer, reg_buffer_bytes, stream);
 }

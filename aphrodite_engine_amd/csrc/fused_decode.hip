@@ -214,8 +214,13 @@ __global__ void add_rms_norm_pack_kernel(const uint16_t* __restrict__ input, con
             u16x8 g8;
             if (e < 8) g8 = g8v[it][e < 8 ? e : 0];
             else g8 = *reinterpret_cast<const u16x8*>(router_w + (size_t)e * hidden + 8 * i);
+            {
+              // products rounded, then added -- pinned (what hipcc emits for the f16 instantiation: v_pk_mul_f32 + adds): the
+              // all-reduce + norm + router launch (custom_all_reduce.hip, ROUTER epilogue) reproduces these logits bit for bit
+#pragma clang fp contract(off)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) rpart[e] += T::to_f32(y[j]) * T::to_f32(g8[j]);
+              for (int j = 0; j < 8; ++j) rpart[e] += T::to_f32(y[j]) * T::to_f32(g8[j]);
+            }
           }
       }
     }

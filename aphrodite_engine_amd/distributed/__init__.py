@@ -342,6 +342,16 @@ def tensor_model_parallel_all_reduce_norm_quant_fp8(input_: torch.Tensor, residu
                                                    static_scale=static_scale)
 
 
+def tensor_model_parallel_all_reduce_norm_router(input_: torch.Tensor, residual: Optional[torch.Tensor], has_residual: bool,
+                                                weight: torch.Tensor, epsilon: float, router_weight: torch.Tensor):
+    """tensor_model_parallel_all_reduce_norm for a sparse-MLP layer: the attention block's all-reduce, fused_add_rms_norm and
+    the router's logits (MixtralMoE.gate, mixtral.py:60-110) as ONE launch -- the bits of tensor_model_parallel_all_reduce ->
+    ops.fused_add_rms_norm_router.  Returns (normed, router_logits) or None."""
+    if _TP_SIZE == 1 or _CUSTOM_AR is None or _OVERLAP is not None or not input_.is_cuda:
+        return None
+    return _CUSTOM_AR.fused_add_rms_norm_router(input_, residual, has_residual, weight, epsilon, router_weight)
+
+
 class DeferredAllReduce:
     """A row-parallel projection's per-rank partial sums [tokens, hidden] whose all-reduce has NOT been issued: the norm
     that consumes them runs it in its own launch (``finish``)."""
@@ -364,6 +374,16 @@ class DeferredAllReduce:
             from .. import _custom_ops as ops
             x = tensor_model_parallel_all_reduce(self.partial)
             res = ops.fused_add_rms_norm_pack(x, None, residual, True, weight, epsilon, pack=pack, want_out=want_out)
+        return res
+
+    def finish_router(self, residual, weight, epsilon, router_weight):
+        """finish() for the norm in front of a sparse MLP: (normed rows, router logits) of ops.fused_add_rms_norm_router on the
+        all-reduced partial, one launch."""
+        res = tensor_model_parallel_all_reduce_norm_router(self.partial, residual, True, weight, epsilon, router_weight)
+        if res is None:     # (as in finish: the two launches the fused one stands for -- same bits)
+            from .. import _custom_ops as ops
+            x = tensor_model_parallel_all_reduce(self.partial)
+            res = ops.fused_add_rms_norm_router(x, None, residual, True, weight, epsilon, router_weight)
         return res
 
     def finish_quant_fp8(self, residual, weight, epsilon, want_out=False, static_scale=None):

@@ -234,6 +234,34 @@ class CustomAllreduce:
             self.check()
         return res
 
+    def _router_form_pays(self, inp: torch.Tensor) -> bool:
+        """The one-launch all-reduce + norm + router form against its two launches on the loopback rig (tools/ar_router_bench.py,
+        us): 4 ranks [32, 4096] 7.4 / 8.5, 8 ranks [64, 8192] (two-shot) 10.4 / 14.0 -- but 8 ranks [32, 4096] in the one-shot
+        form 9.6 / 8.9: every workgroup reads the row from eight peers AND the router rows.  Not used there."""
+        one_shot = self._ops.custom_ar_fused_norm_one_shot(self.world_size, inp.shape[0], inp.shape[1], inp.element_size())
+        return not (one_shot and self.world_size > 4)
+
+    def fused_add_rms_norm_router(self, inp: torch.Tensor, residual: Optional[torch.Tensor], has_residual: bool,
+                                  weight: torch.Tensor, epsilon: float, router_weight: torch.Tensor):
+        """custom_all_reduce(inp) followed by ops.fused_add_rms_norm_router(out, None, residual, ...) in ONE launch, same
+        bits.  None = not eligible.  Returns (normed [tokens, hidden], router_logits [tokens, E])."""
+        if self.disabled or not self.fused_norm_eligible(inp) or router_weight.shape[0] > 16 \
+                or not self._router_form_pays(inp):
+            return None
+        if self._IS_CAPTURING:
+            if torch.cuda.is_current_stream_capturing():
+                return self._ops.custom_ar_fused_add_rms_norm_router(self._ptr, inp, residual, has_residual, weight, epsilon,
+                                                                     router_weight)
+            # warm-up run before the capture: shapes only (the residual is left alone)
+            return self._ops.fused_add_rms_norm_router(torch.zeros_like(inp), None, torch.empty_like(inp), False, weight,
+                                                       epsilon, router_weight)
+        res = self._ops.custom_ar_fused_add_rms_norm_router(self._ptr, inp, residual, has_residual, weight, epsilon,
+                                                            router_weight, reg_buffer=self.buffer)
+        self._calls += 1
+        if self._check_every > 0 and self._calls % self._check_every == 0:
+            self.check()
+        return res
+
     def check(self) -> None:
         """Raise if one of this rank's barriers timed out since the last call."""
         if not self.disabled and self._ops.custom_ar_error(self._ptr):
@@ -298,6 +326,13 @@ class LoopbackAllreduce:
             return None
         return self._ops.custom_ar_fused_add_rms_norm_quant_fp8(self._ptr, inp, residual, has_residual, weight, epsilon,
                                                                 want_out=want_out, static_scale=static_scale)
+
+    def fused_add_rms_norm_router(self, inp, residual, has_residual, weight, epsilon, router_weight):
+        if not self.fused_norm_eligible(inp) or router_weight.shape[0] > 16 \
+                or not CustomAllreduce._router_form_pays(self, inp):
+            return None
+        return self._ops.custom_ar_fused_add_rms_norm_router(self._ptr, inp, residual, has_residual, weight, epsilon,
+                                                             router_weight)
 
     def check(self) -> None:
         if self._ptr and self._ops.custom_ar_error(self._ptr):

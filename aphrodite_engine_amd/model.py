@@ -487,11 +487,18 @@ class LlamaDecoderLayer(nn.Module):
             # sparse MLP: the norm hands row-major activations to the router and the expert gather
             if self.tp > 1:
                 o = ops.wna16_gemm_packed(attn_packed, m, self.q_size, qw, qz, sc, zo, partials=False)
-                o = tensor_model_parallel_all_reduce(o)
                 if self.moe_gate.shape[0] <= 16 and not switch("APHRO_MOE_NO_NORM_ROUTER"):
-                    normed, logits = ops.fused_add_rms_norm_router(o, None, residual, True,
-                                                                   self.post_attention_layernorm, eps, self.moe_gate)
+                    # all-reduce + residual add + norm + the router's logits: one launch of the peer-access kernel where the
+                    # communicator serves the shape (csrc/custom_all_reduce.hip, ROUTER form), else all-reduce, then norm + router
+                    dar = defer_all_reduce(o)
+                    if dar is not None:
+                        normed, logits = dar.finish_router(residual, self.post_attention_layernorm, eps, self.moe_gate)
+                    else:
+                        o = tensor_model_parallel_all_reduce(o)
+                        normed, logits = ops.fused_add_rms_norm_router(o, None, residual, True,
+                                                                       self.post_attention_layernorm, eps, self.moe_gate)
                     return self.moe_block(normed, logits, defer_all_reduce=True), None
+                o = tensor_model_parallel_all_reduce(o)
                 _, normed = ops.fused_add_rms_norm_pack(o, None, residual, True, self.post_attention_layernorm,
                                                         eps, pack=False, want_out=True)
             else:

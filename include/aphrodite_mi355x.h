@@ -616,6 +616,14 @@ int aphro_custom_ar_fused_add_rms_norm_quant_fp8(void* fa, const void* inp, void
                                                  const void* weight, float eps, void* q_out, float* scale_out,
                                                  const float* static_scale, void* out, int64_t tokens, int hidden,
                                                  int dtype, void* reg_buffer, size_t reg_buffer_bytes, void* stream);
+/* ... and for a sparse-MLP (Mixtral) layer under tensor parallelism: the attention block's all-reduce (linear.py:1142-1143),
+ * post_attention_layernorm and the replicated router linear of MixtralMoE (models/mixtral.py:60-110) in one launch -- the
+ * bits of aphro_custom_ar_all_reduce -> aphro_fused_add_rms_norm_router(input = the sum).  out [tokens, hidden] (the
+ * experts' input), router_out [tokens, num_experts] in the activation dtype, num_experts <= 16, tokens <= 64. */
+int aphro_custom_ar_fused_add_rms_norm_router(void* fa, const void* inp, void* residual, int has_residual,
+                                              const void* weight, float eps, void* out, const void* router_w,
+                                              void* router_out, int num_experts, int64_t tokens, int hidden, int dtype,
+                                              void* reg_buffer, size_t reg_buffer_bytes, void* stream);
 /* Loopback communicator (timing rig for ONE rank of a TP group on a one-GPU box, bench.py --sim-tp): `world` ranks that
  * all resolve to this process's buffers; the kernels above run unchanged (flags and scratch through uncached memory,
  * `world` reads per element) with local memory in place of the xGMI links.  Results are not a sum over real ranks. */

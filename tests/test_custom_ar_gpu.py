@@ -374,6 +374,92 @@ def _ar_norm_quant_worker(rank, world, port, one_shot_max):
         dist.destroy_process_group()
 
 
+def _ar_norm_router_worker(rank, world, port, one_shot_max):
+    """ca.fused_add_rms_norm_router(x, residual, ..., gate) == ca.custom_all_reduce(x) -> ops.fused_add_rms_norm_router(...) bit
+    for bit -- normalised rows, router logits, residual -- one-shot and two-shot form, 8 and 16 experts, eagerly and from a
+    captured graph; the logits are also the oracle's rms_norm followed by the gate matmul (mixtral.py:60-110) within the
+    rounding of the activation dtype."""
+    import os
+    if one_shot_max is not None:
+        os.environ["APHRO_CUSTOM_AR_ONE_SHOT_MAX"] = str(one_shot_max)
+    import torch.distributed as dist
+    from aphrodite_engine_amd import _custom_ops as ops
+    from aphrodite_engine_amd.distributed.custom_all_reduce import CustomAllreduce
+    from oracle import attention as oa
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    ca = CustomAllreduce(dist.group.WORLD, dev, max_size=4 * 1024 * 1024)
+    assert not ca.disabled
+    gen = torch.Generator(device="cpu")
+    try:
+        cases = [(torch.float16, 32, 4096, 8), (torch.bfloat16, 64, 8192, 16), (torch.float16, 7, 5120, 8), (torch.float16, 1, 1024, 3),
+                 (torch.bfloat16, 3, 4096, 8)]
+        for dtype, tokens, hidden, E in cases:
+            gen.manual_seed(13 * tokens + hidden + E)
+            parts = [(torch.randn(tokens, hidden, generator=gen) * 2).to(dtype) for _ in range(world)]
+            res0 = (torch.randn(tokens, hidden, generator=gen) * 3).to(dtype).to(dev)
+            w = (torch.rand(hidden, generator=gen) + 0.5).to(dtype).to(dev)
+            gate = (torch.randn(E, hidden, generator=gen) * 0.05).to(dtype).to(dev)
+            x = parts[rank].to(dev)
+            one_shot = ops.custom_ar_fused_norm_one_shot(world, tokens, hidden, 2)
+            for has_res in (True, False):
+                r_ref = res0.clone()
+                summed = ca.custom_all_reduce(x)
+                o_ref, l_ref = ops.fused_add_rms_norm_router(summed, None, r_ref, has_res, w, 1e-5, gate)
+                r_got = res0.clone()
+                got = ca.fused_add_rms_norm_router(x, r_got, has_res, w, 1e-5, gate)
+                assert got is not None
+                torch.cuda.synchronize()
+                ca.check()
+                tag = f"{dtype} {tokens}x{hidden} E={E} world {world} one_shot={one_shot} res={has_res}"
+                assert torch.equal(got[0], o_ref) and torch.equal(got[1], l_ref) and torch.equal(r_got, r_ref), tag
+                assert got[1].shape == (tokens, E)
+                want = got[0].float().cpu().numpy() @ gate.float().cpu().numpy().T          # the gate linear on the rows it returned
+                tol = 2e-2 if dtype == torch.bfloat16 else 4e-3
+                np.testing.assert_allclose(got[1].float().cpu().numpy(), want, atol=tol * max(1.0, float(np.abs(want).max())), rtol=tol, err_msg=tag)
+                assert torch.equal(x.cpu(), parts[rank])
+        # captured
+        tokens, hidden, E = 32, 4096, 8
+        a = torch.empty(tokens, hidden, dtype=torch.float16, device=dev)
+        res = torch.zeros(tokens, hidden, dtype=torch.float16, device=dev)
+        w = torch.ones(hidden, dtype=torch.float16, device=dev)
+        gate = (torch.randn(E, hidden, generator=gen) * 0.05).half().to(dev)
+        g = torch.cuda.CUDAGraph()
+        with ca.capture():
+            assert ca.fused_add_rms_norm_router(a, res, True, w, 1e-5, gate) is not None          # warm-up: shapes only
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s), torch.cuda.graph(g, stream=s):
+                out, logits = ca.fused_add_rms_norm_router(a * 1.0, res, True, w, 1e-5, gate)
+        for it in range(3):
+            gen.manual_seed(21 + it)
+            parts = [torch.randn(tokens, hidden, generator=gen).half() for _ in range(world)]
+            a.copy_(parts[rank])
+            res.fill_(0.25 * it)
+            r_ref = res.clone()
+            torch.cuda.synchronize()
+            dist.barrier()
+            g.replay()
+            torch.cuda.synchronize()
+            ca.check()
+            o_ref, l_ref = ops.fused_add_rms_norm_router(_expected(parts, torch.float16).to(dev), None, r_ref, True, w, 1e-5, gate)
+            assert torch.equal(out, o_ref) and torch.equal(logits, l_ref) and torch.equal(res, r_ref)
+            dist.barrier()
+        many = torch.zeros(17, hidden, dtype=torch.float16, device=dev)
+        assert ca.fused_add_rms_norm_router(a, res, True, w, 1e-5, many) is None          # > 16 experts: the caller issues the two ops
+    finally:
+        ca.close()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,one_shot_max", [(4, None), (2, 0)])
+def test_fused_all_reduce_norm_router_ranks_on_one_gpu(world, one_shot_max):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    _spawn(_ar_norm_router_worker, world, one_shot_max, timeout=240)
+
+
 @pytest.mark.parametrize("world,one_shot_max", [(4, None), (2, 65536), (4, 0)])
 def test_fused_all_reduce_norm_quant_fp8_ranks_on_one_gpu(world, one_shot_max):
     if not torch.cuda.is_available():
@@ -480,6 +566,15 @@ def _tp_fused_norm_model_worker(rank, world, port, one_shot_max, moe, quant="gpt
                 assert res is not None
                 return res
             setattr(ca, fused_name, counted)
+            router_calls = {"n": 0}
+            orig_router = ca.fused_add_rms_norm_router
+
+            def counted_router(*a, **k):
+                router_calls["n"] += 1
+                res = orig_router(*a, **k)
+                assert res is not None
+                return res
+            ca.fused_add_rms_norm_router = counted_router
 
             def step():
                 caches = M.make_kv_caches(cfg, nblocks, 16, torch.float16, "auto", "cuda:0", seed=3)
@@ -489,12 +584,14 @@ def _tp_fused_norm_model_worker(rank, world, port, one_shot_max, moe, quant="gpt
                 return out.clone()
             os.environ["APHRO_NO_FUSED_AR_NORM"] = "1"
             two_launch = step()
-            assert calls["n"] == 0
+            assert calls["n"] == 0 and router_calls["n"] == 0
             del os.environ["APHRO_NO_FUSED_AR_NORM"]
             fused = step()
             # dense: o_proj + down_proj of every layer; sparse MLP: the expert output's all-reduce only (the attention
             # block's goes to the router norm)
             assert calls["n"] == (cfg.num_hidden_layers if moe else 2 * cfg.num_hidden_layers), calls
+            # sparse MLP (round 6): the attention block's all-reduce runs inside the norm + router launch
+            assert router_calls["n"] == (cfg.num_hidden_layers if moe else 0), router_calls
             assert torch.equal(two_launch, fused)
             # captured
             caches = M.make_kv_caches(cfg, nblocks, 16, torch.float16, "auto", "cuda:0", seed=3)
