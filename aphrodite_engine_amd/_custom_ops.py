@@ -1755,6 +1755,41 @@ def moe_route_align(gating_output: torch.Tensor, topk: int, renormalize: bool, n
 MOE_ROUTE_ALIGN_MAX_SLOTS = 8192
 
 
+def moe_route_gather_supported(num_tokens: int, num_experts: int, topk: int, block_size: int, k: int) -> bool:
+    return bool(_lib.lib().aphro_moe_route_gather_supported(num_tokens, num_experts, topk, block_size, k))
+
+
+def moe_route_gather(hidden_states: torch.Tensor, gating_output: torch.Tensor, topk: int, renormalize: bool, num_experts: int,
+                     block_size: int):
+    """moe_route_align + moe_gather_pack in ONE launch (csrc/moe.hip moe_route_gather_kernel; decode-sized batches, <= 16
+    experts): returns (topk_weights, topk_ids, sorted_ids, expert_ids, num_tokens_post_pad, inv, packed, m_pad) -- bit for bit
+    what the two ops return."""
+    _require_cuda(hidden_states, gating_output)
+    t_, e = gating_output.shape
+    if e != num_experts or gating_output.stride(1) != 1 or gating_output.dtype != hidden_states.dtype \
+            or hidden_states.stride(1) != 1 or hidden_states.shape[0] != t_:
+        raise RuntimeError("moe_route_gather: [tokens, E] logits and [tokens, K] activations of one 16-bit dtype, contiguous rows")
+    dev = gating_output.device
+    k = hidden_states.shape[1]
+    numel = t_ * topk
+    max_padded = numel + num_experts * (block_size - 1)
+    m_pad = (max_padded + 15) // 16 * 16
+    topk_weights = torch.empty((t_, topk), dtype=torch.float32, device=dev)
+    topk_ids = torch.empty((t_, topk), dtype=torch.int32, device=dev)
+    sorted_ids = torch.empty((max_padded, ), dtype=torch.int32, device=dev)
+    expert_ids = torch.empty(((max_padded + block_size - 1) // block_size, ), dtype=torch.int32, device=dev)
+    post_pad = torch.empty((1, ), dtype=torch.int32, device=dev)
+    inv = torch.empty(numel, dtype=torch.int32, device=dev)
+    lib = _lib.lib()
+    packed = torch.empty(lib.aphro_wna16_packed_a_bytes(m_pad, k) // 2, dtype=torch.float16, device=dev)
+    check(lib.aphro_moe_route_gather(topk_weights.data_ptr(), topk_ids.data_ptr(), gating_output.data_ptr(),
+                                     gating_output.stride(0), sorted_ids.data_ptr(), expert_ids.data_ptr(), post_pad.data_ptr(),
+                                     inv.data_ptr(), t_, num_experts, topk, 1 if renormalize else 0, block_size,
+                                     hidden_states.data_ptr(), hidden_states.stride(0), packed.data_ptr(), m_pad, k,
+                                     _dt(hidden_states), _stream()), "moe_route_gather")
+    return topk_weights, topk_ids, sorted_ids, expert_ids, post_pad, inv, packed, m_pad
+
+
 def moe_gather_pack(a: torch.Tensor, sorted_token_ids: torch.Tensor, num_tokens_post_pad: torch.Tensor,
                     m_pad: int, topk: int) -> torch.Tensor:
     """Packed (fragment-major f16) activations of the expert GEMMs: row r = a[sorted[r] // topk]."""

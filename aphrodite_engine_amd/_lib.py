@@ -103,6 +103,8 @@ SIGNATURES = {
     "aphro_lm_head_argmax_supported": (I, [L, L, L, L, I]),
     "aphro_fp8_moe_gemm": (I, [P, P, P, P, P, P, P, P, P, L, L, L, L, I, I, P]),
     "aphro_moe_route_align": (I, [P, P, P, L, P, P, P, P, L, I, I, I, I, I, P]),
+    "aphro_moe_route_gather_supported": (I, [L, I, I, I, L]),
+    "aphro_moe_route_gather": (I, [P, P, P, L, P, P, P, P, L, I, I, I, I, P, L, P, L, L, I, P]),
     "aphro_fused_add_rms_norm_router": (I, [P, P, I, P, I, P, F, P, P, P, I, L, I, I, P]),
     "aphro_fused_add_rms_norm_pack_combine": (I, [P, I, L, P, P, I, P, I, P, F, P, P, L, I, I, P]),
     "aphro_fp8_gemm_stream_ksplit": (I, [L, L, L]),

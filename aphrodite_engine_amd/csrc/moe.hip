@@ -101,6 +101,104 @@ __global__ void moe_align_kernel(const int32_t* __restrict__ topk_ids, int32_t* 
   }
 }
 
+// One token's routing with <= 16 experts, the whole row in ONE thread (no cross-lane step).  Bit-identical to the wave form of
+// topk_softmax_kernel: max is exact in any order; the sum of exps replays wave_sum's butterfly (offsets 8, 4, 2, 1 over 16
+// slots, the idle lanes' zeros left out: x + 0 = x); arg-max scans ascending, so ties keep the lower expert.
+template <typename T>
+__device__ __forceinline__ void moe_route_row16(const typename T::storage* __restrict__ row, int num_experts, int k,
+                                                float (&wk)[8], int (&we)[8], float& wsum) {
+  float ex[16];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    ex[j] = j < num_experts ? T::to_f32(row[j]) : 0.f;
+    if (j < num_experts) mx = __builtin_fmaxf(mx, ex[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < 16; ++j) ex[j] = j < num_experts ? expf(ex[j] - mx) : 0.f;
+  float a[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) a[j] = ex[j];
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) {
+    float nx[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) nx[j] = a[j] + a[j ^ o];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) a[j] = nx[j];
+  }
+  const float norm = 1.f / a[0];
+  float prob[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) prob[j] = j < num_experts ? ex[j] * norm : -1.f;
+  wsum = 0.f;
+#pragma unroll
+  for (int kk = 0; kk < 8; ++kk) {
+    wk[kk] = 0.f;
+    we[kk] = 0;
+    if (kk < k) {
+      float best = -1.f;
+      int best_e = 0;
+#pragma unroll
+      for (int j = 0; j < 16; ++j)
+        if (prob[j] > best) { best = prob[j]; best_e = j; }
+      wk[kk] = best;
+      we[kk] = best_e;
+      wsum += best;
+#pragma unroll
+      for (int j = 0; j < 16; ++j)
+        if (j == best_e) prob[j] = -1.f;
+    }
+  }
+}
+
+// moe_align_kernel's result by wave-wide ranking (a few dozen slots, <= 64 experts; ONE wave, lane e owns expert e).  Within an
+// expert the slots stay in ascending order, as the counting sort leaves them (its shards are ascending slot ranges).  The
+// output pointers may be global memory or LDS.
+__device__ __forceinline__ void moe_align_rank64(const int32_t* ids, int numel, int num_experts, int block_size, int max_padded,
+                                                 int max_blocks, int t, int32_t* sorted_token_ids, int32_t* expert_ids,
+                                                 int32_t* num_tokens_post_pad, int32_t* inv_pos) {
+  int my_cnt = 0;
+  for (int c0 = 0; c0 < numel; c0 += 64) {
+    const int my_e = c0 + t < numel ? ids[c0 + t] : -1;
+    for (int e = 0; e < num_experts; ++e) {
+      const unsigned long long mask = __ballot(my_e == e);
+      if (t == e) my_cnt += __popcll(mask);
+    }
+  }
+  const int padded = t < num_experts ? (my_cnt + block_size - 1) / block_size * block_size : 0;
+  int incl = padded;                                // inclusive scan over the lanes
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int up = __shfl_up(incl, o, 64);
+    if (t >= o) incl += up;
+  }
+  const int start = incl - padded;                  // cumsum[e]
+  const int total = __shfl(incl, 63, 64);
+  if (t == 0) *num_tokens_post_pad = total;
+  for (int i = t; i < max_padded; i += 64) sorted_token_ids[i] = numel;
+  for (int i = t; i < max_blocks; i += 64) expert_ids[i] = -1;
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // the fills above come from other lanes than the real entries below
+  if (t < num_experts)
+    for (int i = start; i < start + padded; i += block_size) expert_ids[i / block_size] = t;
+  int base = start;                                 // lane e: next free position of expert e
+  for (int c0 = 0; c0 < numel; c0 += 64) {
+    const int i = c0 + t;
+    const int my_e = i < numel ? ids[i] : -1;
+    int pos = -1;
+    for (int e = 0; e < num_experts; ++e) {
+      const unsigned long long mask = __ballot(my_e == e);
+      const int b = __shfl(base, e, 64);
+      if (my_e == e) pos = b + __popcll(mask & ((1ull << t) - 1ull));
+      if (t == e) base += __popcll(mask);
+    }
+    if (pos >= 0) {
+      sorted_token_ids[pos] = i;
+      if (inv_pos) inv_pos[i] = pos;
+    }
+  }
+}
+
 // fused_topk (fused_moe.py:369-402: gating.float() -> topk_softmax -> optional renormalise) + moe_align_block_size
 // (:174-228) in ONE launch for decode-sized batches: the two ops, the fp32 cast and the renormalisation (sum + divide) are
 // five launches of a few microseconds each in front of every sparse MLP -- at ~5 us of fixed cost per launch that is a
@@ -126,50 +224,10 @@ __global__ __launch_bounds__(1024) void moe_route_align_kernel(
     // the wave form below: max is exact in any order; the sum of exps replays wave_sum's butterfly (offsets 8, 4, 2, 1 over
     // 16 slots, the idle lanes' zeros left out: x + 0 = x); arg-max scans ascending, so ties keep the lower expert.
     for (int tok = threadIdx.x; tok < num_tokens; tok += blockDim.x) {
-      const typename T::storage* row = gating + (size_t)tok * gating_stride;
-      float ex[16];
-      float mx = -INFINITY;
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        ex[j] = j < num_experts ? T::to_f32(row[j]) : 0.f;
-        if (j < num_experts) mx = __builtin_fmaxf(mx, ex[j]);
-      }
-#pragma unroll
-      for (int j = 0; j < 16; ++j) ex[j] = j < num_experts ? expf(ex[j] - mx) : 0.f;
-      float a[16];
-#pragma unroll
-      for (int j = 0; j < 16; ++j) a[j] = ex[j];
-#pragma unroll
-      for (int o = 8; o > 0; o >>= 1) {
-        float nx[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) nx[j] = a[j] + a[j ^ o];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) a[j] = nx[j];
-      }
-      const float norm = 1.f / a[0];
-      float prob[16];
-#pragma unroll
-      for (int j = 0; j < 16; ++j) prob[j] = j < num_experts ? ex[j] * norm : -1.f;
-      float wsum = 0.f;
       float wk[8];
       int we[8];
-#pragma unroll
-      for (int kk = 0; kk < 8; ++kk) {
-        if (kk < k) {
-          float best = -1.f;
-          int best_e = 0;
-#pragma unroll
-          for (int j = 0; j < 16; ++j)
-            if (prob[j] > best) { best = prob[j]; best_e = j; }
-          wk[kk] = best;
-          we[kk] = best_e;
-          wsum += best;
-#pragma unroll
-          for (int j = 0; j < 16; ++j)
-            if (j == best_e) prob[j] = -1.f;
-        }
-      }
+      float wsum;
+      moe_route_row16<T>(gating + (size_t)tok * gating_stride, num_experts, k, wk, we, wsum);
 #pragma unroll
       for (int kk = 0; kk < 8; ++kk) {
         if (kk < k) {
@@ -234,49 +292,10 @@ __global__ __launch_bounds__(1024) void moe_route_align_kernel(
   __syncthreads();
   if (wave != 0) return;
   if (num_experts <= 64) {
-    // ---- moe_align_kernel's result by wave-wide ranking (the decode case: a few dozen slots, <= 64 experts): lane e owns
-    // expert e.  Within an expert the slots stay in ascending order, as the counting sort below leaves them (its shards are
-    // ascending slot ranges) -- the 65-deep serial prefix of that sort was 2/3 of this launch's 12 us.
-    const int t = lane;
-    int my_cnt = 0;
-    for (int c0 = 0; c0 < numel; c0 += 64) {
-      const int my_e = c0 + t < numel ? ids[c0 + t] : -1;
-      for (int e = 0; e < num_experts; ++e) {
-        const unsigned long long mask = __ballot(my_e == e);
-        if (t == e) my_cnt += __popcll(mask);
-      }
-    }
-    const int padded = t < num_experts ? (my_cnt + block_size - 1) / block_size * block_size : 0;
-    int incl = padded;                                // inclusive scan over the lanes
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int up = __shfl_up(incl, o, 64);
-      if (t >= o) incl += up;
-    }
-    const int start = incl - padded;                  // cumsum[e]
-    const int total = __shfl(incl, 63, 64);
-    if (t == 0) *num_tokens_post_pad = total;
-    for (int i = t; i < max_padded; i += 64) sorted_token_ids[i] = numel;
-    for (int i = t; i < max_blocks; i += 64) expert_ids[i] = -1;
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // the fills above come from other lanes than the real entries below
-    if (t < num_experts)
-      for (int i = start; i < start + padded; i += block_size) expert_ids[i / block_size] = t;
-    int base = start;                                 // lane e: next free position of expert e
-    for (int c0 = 0; c0 < numel; c0 += 64) {
-      const int i = c0 + t;
-      const int my_e = i < numel ? ids[i] : -1;
-      int pos = -1;
-      for (int e = 0; e < num_experts; ++e) {
-        const unsigned long long mask = __ballot(my_e == e);
-        const int b = __shfl(base, e, 64);
-        if (my_e == e) pos = b + __popcll(mask & ((1ull << t) - 1ull));
-        if (t == e) base += __popcll(mask);
-      }
-      if (pos >= 0) {
-        sorted_token_ids[pos] = i;
-        if (inv_pos) inv_pos[i] = pos;
-      }
-    }
+    // ---- the decode case: a few dozen slots, <= 64 experts -- by wave-wide ranking (the 65-deep serial prefix of the counting
+    // sort below was 2/3 of this launch's 12 us)
+    moe_align_rank64(ids, numel, num_experts, block_size, max_padded, max_blocks, lane, sorted_token_ids, expert_ids,
+                     num_tokens_post_pad, inv_pos);
     return;
   }
   // ---- moe_align_kernel on the ids in LDS (same shards, same order) -------------------------------------------------
@@ -341,6 +360,81 @@ __global__ void moe_gather_pack_kernel(const uint16_t* __restrict__ a, const int
     const int slot = sorted_token_ids[row];
     if (slot < numel) {
       v = *reinterpret_cast<const u16x8*>(a + (size_t)(slot / topk) * lda + k0);
+      if constexpr (!__is_same(T, Half)) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = bf16_bits_to_f16_bits_sat(v[j]);
+      }
+    }
+  }
+  *reinterpret_cast<u16x8*>(out + idx * 8) = v;
+}
+
+// moe_route_align_kernel + moe_gather_pack_kernel in ONE launch for decode-sized batches with <= 16 experts (round 6): the
+// routing of a few dozen tokens is a few hundred instructions, so EVERY workgroup of the gather redoes it in its own LDS
+// (thread per token, then wave 0 ranks the slots) instead of waiting for a one-workgroup launch to publish it -- a launch
+// boundary and a dependent round trip less in front of every sparse MLP (6.7 + 4.9 us -> one launch).  Workgroup 0 also writes
+// the routing to global memory for the grouped GEMMs and the combine.  Same arithmetic as the two kernels: bit-identical
+// weights, ids, slot order and packed rows.
+template <typename T>
+__global__ __launch_bounds__(256) void moe_route_gather_kernel(
+    float* __restrict__ topk_weights, int32_t* __restrict__ topk_ids_out, const typename T::storage* __restrict__ gating,
+    int64_t gating_stride, int32_t* __restrict__ sorted_token_ids, int32_t* __restrict__ expert_ids,
+    int32_t* __restrict__ num_tokens_post_pad, int32_t* __restrict__ inv_pos, int num_tokens, int num_experts, int k,
+    int renormalize, int block_size, int max_padded, int max_blocks, const uint16_t* __restrict__ a,
+    uint16_t* __restrict__ out, int m_pad, int K, int lda) {
+  extern __shared__ int32_t sm[];
+  const int numel = num_tokens * k;
+  int32_t* ids = sm;                                  // [numel]
+  int32_t* sorted_l = ids + numel;                    // [max_padded]
+  int32_t* expert_l = sorted_l + max_padded;          // [max_blocks]
+  int32_t* inv_l = expert_l + max_blocks;             // [numel]
+  int32_t* post_l = inv_l + numel;                    // [1]
+  const bool publish = blockIdx.x == 0;
+  for (int tok = threadIdx.x; tok < num_tokens; tok += blockDim.x) {
+    float wk[8];
+    int we[8];
+    float wsum;
+    moe_route_row16<T>(gating + (size_t)tok * gating_stride, num_experts, k, wk, we, wsum);
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      if (kk < k) {
+        ids[tok * k + kk] = we[kk];
+        if (publish) {
+          topk_ids_out[(size_t)tok * k + kk] = we[kk];
+          topk_weights[(size_t)tok * k + kk] = renormalize ? wk[kk] / wsum : wk[kk];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 64)
+    moe_align_rank64(ids, numel, num_experts, block_size, max_padded, max_blocks, (int)threadIdx.x, sorted_l, expert_l, post_l,
+                     inv_l);
+  __syncthreads();
+  if (publish) {
+    for (int i = threadIdx.x; i < max_padded; i += blockDim.x) sorted_token_ids[i] = sorted_l[i];
+    for (int i = threadIdx.x; i < max_blocks; i += blockDim.x) expert_ids[i] = expert_l[i];
+    if (inv_pos)
+      for (int i = threadIdx.x; i < numel; i += blockDim.x) inv_pos[i] = inv_l[i];
+    if (threadIdx.x == 0) *num_tokens_post_pad = *post_l;
+  }
+  // ---- the gather (moe_gather_pack_kernel on the routing in LDS) ---------------------------------------------------------
+  const int mtiles = m_pad >> 4;
+  const int64_t total = (int64_t)(K >> 7) * 4 * mtiles * 64;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int lane = (int)(idx & 63);
+  int64_t blk = idx >> 6;
+  const int mt = (int)(blk % mtiles); blk /= mtiles;
+  const int u = (int)(blk & 3);
+  const int seg = (int)(blk >> 2);
+  const int row = 16 * mt + (lane & 15);
+  const int k0 = 128 * seg + 32 * (lane >> 4) + 8 * u;
+  u16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (row < *post_l) {
+    const int slot = row < max_padded ? sorted_l[row] : numel;
+    if (slot < numel) {
+      v = *reinterpret_cast<const u16x8*>(a + (size_t)(slot / k) * lda + k0);
       if constexpr (!__is_same(T, Half)) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = bf16_bits_to_f16_bits_sat(v[j]);
@@ -430,6 +524,43 @@ extern "C" int aphro_moe_route_align(float* topk_weights, int32_t* topk_ids, con
                      (const typename TT::storage*)gating, gating_stride, sorted_token_ids, expert_ids, num_tokens_post_pad, \
                      inv_pos, (int)num_tokens, num_experts, topk, renormalize, block_size, max_padded, max_blocks)
   if (dtype == APHRO_F16) L(Half); else if (dtype == APHRO_BF16) L(BFloat); else L(Float);
+#undef L
+  APHRO_LAUNCH_CHECK();
+  return APHRO_OK;
+}
+
+// 1 when aphro_moe_route_gather serves the call: <= 16 experts, <= 256 tokens, top-k <= 8, f16 / bf16 logits AND activations.
+extern "C" int aphro_moe_route_gather_supported(int64_t num_tokens, int num_experts, int topk, int block_size, int64_t K) {
+  if (num_tokens < 1 || num_tokens > 256 || num_experts < 1 || num_experts > 16 || topk < 1 || topk > 8 || topk > num_experts)
+    return 0;
+  if (block_size != 16 || K % 128 != 0) return 0;
+  return 1;
+}
+
+// aphro_moe_route_align followed by aphro_moe_gather_pack (m_pad = the padded bound rounded up to 16 rows) in one launch.
+// gating [num_tokens, gating_stride] and a [num_tokens, lda] in `dtype` (f16 / bf16); packed as aphro_moe_gather_pack.
+extern "C" int aphro_moe_route_gather(float* topk_weights, int32_t* topk_ids, const void* gating, int64_t gating_stride,
+                                      int32_t* sorted_token_ids, int32_t* expert_ids, int32_t* num_tokens_post_pad,
+                                      int32_t* inv_pos, int64_t num_tokens, int num_experts, int topk, int renormalize,
+                                      int block_size, const void* a, int64_t lda, void* packed, int64_t m_pad, int64_t K,
+                                      int dtype, void* stream) {
+  APHRO_CHECK(dtype == APHRO_F16 || dtype == APHRO_BF16, "moe_route_gather: dtype must be f16 or bf16");
+  APHRO_CHECK(aphro_moe_route_gather_supported(num_tokens, num_experts, topk, block_size, K),
+              "moe_route_gather: %ld tokens, %d experts, top-%d, block %d, K=%ld is not served", (long)num_tokens, num_experts,
+              topk, block_size, (long)K);
+  const int numel = (int)num_tokens * topk;
+  const int max_padded = numel + num_experts * (block_size - 1);
+  const int max_blocks = (max_padded + block_size - 1) / block_size;
+  APHRO_CHECK(m_pad % 16 == 0 && m_pad >= max_padded && lda % 8 == 0 && lda >= K, "moe_route_gather: bad shape");
+  const size_t lds = (size_t)(2 * numel + max_padded + max_blocks + 1) * sizeof(int32_t);
+  const int64_t total = (K / 128) * 4 * (m_pad / 16) * 64;
+  dim3 grid((unsigned)((total + 255) / 256));
+#define L(TT)                                                                                                              \
+  hipLaunchKernelGGL((moe_route_gather_kernel<TT>), grid, dim3(256), lds, (hipStream_t)stream, topk_weights, topk_ids,     \
+                     (const typename TT::storage*)gating, gating_stride, sorted_token_ids, expert_ids, num_tokens_post_pad, \
+                     inv_pos, (int)num_tokens, num_experts, topk, renormalize, block_size, max_padded, max_blocks,         \
+                     (const uint16_t*)a, (uint16_t*)packed, (int)m_pad, (int)K, (int)lda)
+  if (dtype == APHRO_F16) L(Half); else L(BFloat);
 #undef L
   APHRO_LAUNCH_CHECK();
   return APHRO_OK;

@@ -137,15 +137,25 @@ def fused_wna16_moe(hidden_states: torch.Tensor, experts: Wna16Experts, gating_o
     assert gating_output.shape[1] == experts.num_experts, "Number of experts mismatch"
     m = hidden_states.shape[0]
     e = experts.num_experts
+    packed = None
     if aligned is not None:
         sorted_ids, expert_ids, post_pad, inv = aligned
     elif topk_ids is None:
-        topk_weights, topk_ids, sorted_ids, expert_ids, post_pad, inv = route_and_align(
-            hidden_states, gating_output, topk, renormalize, e, want_inverse=True)
+        if (gating_output.dtype == hidden_states.dtype and gating_output.dtype in (torch.float16, torch.bfloat16)
+                and gating_output.stride(1) == 1 and hidden_states.stride(1) == 1
+                and ops.moe_route_gather_supported(m, e, topk, MOE_BLOCK_M, experts.hidden)
+                and not switch("APHRO_MOE_NO_ROUTE_ALIGN")):
+            # decode-sized batch, <= 16 experts: routing, alignment and the packed gather in ONE launch (round 6)
+            topk_weights, topk_ids, sorted_ids, expert_ids, post_pad, inv, packed, m_pad = ops.moe_route_gather(
+                hidden_states, gating_output, topk, renormalize, e, MOE_BLOCK_M)
+        else:
+            topk_weights, topk_ids, sorted_ids, expert_ids, post_pad, inv = route_and_align(
+                hidden_states, gating_output, topk, renormalize, e, want_inverse=True)
     else:
         sorted_ids, expert_ids, post_pad, inv = moe_align_block_size(topk_ids, MOE_BLOCK_M, e, want_inverse=True)
-    m_pad = (sorted_ids.numel() + MOE_BLOCK_M - 1) // MOE_BLOCK_M * MOE_BLOCK_M
-    packed = ops.moe_gather_pack(hidden_states, sorted_ids, post_pad, m_pad, topk)
+    if packed is None:
+        m_pad = (sorted_ids.numel() + MOE_BLOCK_M - 1) // MOE_BLOCK_M * MOE_BLOCK_M
+        packed = ops.moe_gather_pack(hidden_states, sorted_ids, post_pad, m_pad, topk)
     qw, qz, sc = experts.w13
     n13 = qw.shape[2]
     if ops.wna16_grouped_ksplit(m_pad, n13, experts.hidden, sc.shape[1]) == 1 and n13 % 256 == 0:
@@ -269,6 +279,9 @@ class Wna16MoEMethod(FusedMoEMethodBase):
             raise NotImplementedError("grouped top-k routing (DeepSeek-V2) is outside the hot path")
         if layer.experts_packed is None:
             raise RuntimeError("FusedMoE: process_weights_after_loading has not run")
+        if custom_routing_function is None and not getattr(layer, "record_routing", False):
+            # (routing, alignment and the packed gather are one launch where csrc/moe.hip serves the shape: fused_wna16_moe)
+            return fused_wna16_moe(x, layer.experts_packed, router_logits, top_k, renormalize, defer_combine=defer_combine)
         topk_weights, topk_ids, sorted_ids, expert_ids, post_pad, inv = route_and_align(
             x, router_logits, top_k, renormalize, layer.experts_packed.num_experts, want_inverse=True,
             custom_routing_function=custom_routing_function)

@@ -770,6 +770,17 @@ int aphro_moe_route_align(float* topk_weights, int32_t* topk_ids, const void* ga
                           int64_t num_tokens, int num_experts, int topk, int renormalize, int block_size, int dtype,
                           void* stream);
 
+/* aphro_moe_route_align + aphro_moe_gather_pack in ONE launch (decode-sized batches, <= 16 experts, <= 256 tokens, block 16,
+ * f16 / bf16 logits and activations: aphro_moe_route_gather_supported): every workgroup of the gather redoes the routing of
+ * the few dozen tokens in its own LDS, workgroup 0 publishes it.  Same outputs, bit for bit, as the two calls
+ * (fused_topk + moe_align_block_size, fused_moe.py:223-268, 405-436; the sorted_ids addressing of marlin_gemm_moe).
+ * m_pad: a multiple of 16 >= num_tokens * topk + num_experts * (block_size - 1). */
+int aphro_moe_route_gather_supported(int64_t num_tokens, int num_experts, int topk, int block_size, int64_t K);
+int aphro_moe_route_gather(float* topk_weights, int32_t* topk_ids, const void* gating, int64_t gating_stride,
+                           int32_t* sorted_token_ids, int32_t* expert_ids, int32_t* num_tokens_post_pad, int32_t* inv_pos,
+                           int64_t num_tokens, int num_experts, int topk, int renormalize, int block_size, const void* a,
+                           int64_t lda, void* packed, int64_t m_pad, int64_t K, int dtype, void* stream);
+
 /* Fragment-major activation pack of the rows a[sorted_token_ids[r] / topk] (zero rows for
  * padding) -- the sorted_ids / replicate_input addressing of marlin_gemm_moe
  * (kernels/moe/marlin_moe_ops.cu) done once, ahead of the GEMM. */

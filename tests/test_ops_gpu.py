@@ -2704,6 +2704,42 @@ def test_moe_route_align_matches_the_separate_ops(ops, T, E, k, renorm, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("T,E,k,renorm,K", [(1, 8, 2, True, 4096), (32, 8, 2, True, 4096), (64, 8, 2, False, 1024), (33, 16, 4, True, 2048),
+                                            (40, 12, 3, True, 1024), (7, 4, 1, False, 512), (256, 8, 2, True, 256)])
+def test_moe_route_gather_matches_the_two_launches(ops, T, E, k, renorm, K, dtype):
+    """Routing + alignment + the packed gather of the expert GEMM's A operand in ONE launch (round 6: every workgroup of the
+    gather redoes the routing in LDS, workgroup 0 publishes it) == ops.moe_route_align followed by ops.moe_gather_pack, every
+    output bit for bit; ties in the logits (equal rows) keep the lower expert in both; capturable.  Shapes the launch does not
+    serve are reported as such."""
+    rng = np.random.default_rng(T * 17 + E + k)
+    gating = t((rng.standard_normal((T, E)) * 2).astype(np.float32)).to(dtype)
+    if T > 2:
+        gating[2] = gating[2, 0]                     # a row of equal logits: the ascending arg-max keeps experts 0 .. k-1
+    x = t(rng.standard_normal((T, K)).astype(np.float32)).to(dtype)
+    assert ops.moe_route_gather_supported(T, E, k, 16, K)
+    tw0, ids0, s0, e0, p0, inv0 = ops.moe_route_align(gating, k, renorm, E, 16, want_inverse=True)
+    m_pad = (s0.numel() + 15) // 16 * 16
+    pk0 = ops.moe_gather_pack(x, s0, p0, m_pad, k)
+    tw1, ids1, s1, e1, p1, inv1, pk1, m_pad1 = ops.moe_route_gather(x, gating, k, renorm, E, 16)
+    torch.cuda.synchronize()
+    assert m_pad1 == m_pad and torch.equal(ids1, ids0) and torch.equal(tw1, tw0)
+    assert torch.equal(s1, s0) and torch.equal(e1, e0) and torch.equal(p1, p0) and torch.equal(inv1, inv0)
+    assert pk1.shape == pk0.shape and torch.equal(pk1, pk0)
+    if T > 2:
+        assert ids1[2].tolist() == list(range(k))
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = ops.moe_route_gather(x, gating, k, renorm, E, 16)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out[6], pk0) and torch.equal(out[2], s0) and torch.equal(out[0], tw0)
+    assert not ops.moe_route_gather_supported(257, E, k, 16, K) and not ops.moe_route_gather_supported(T, 17, k, 16, K)
+    assert not ops.moe_route_gather_supported(T, E, k, 16, K + 64)
+    with pytest.raises(RuntimeError):
+        ops.moe_route_gather(x, gating.float(), k, renorm, E, 16)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("tokens,hidden,E,nslab", [(32, 4096, 8, 4), (1, 4096, 8, 2), (5, 1024, 16, 0), (64, 2048, 3, 1)])
 def test_fused_add_rms_norm_router(ops, tokens, hidden, E, nslab, dtype):
     """The norm launch of a sparse-MLP layer that also emits the router logits: `out` and the residual are bit-identical
