@@ -548,6 +548,60 @@ def wna16_gemm_large_silu(a: torch.Tensor, qweight: torch.Tensor, qzeros: torch.
     return out
 
 
+def wna16_strip_unrelayout(strip: torch.Tensor, m: int, groups: int) -> torch.Tensor:
+    """wna16_strip_relayout backwards: the strip-major copy (laid out for the M class ``m``) -> [K/8, N] exllama-ordered words.
+    For the kernels that do not read the strip-major order when it is the only resident copy of the matrix."""
+    _require_cuda(strip)
+    out = torch.empty_like(strip)
+    check(_lib.lib().aphro_wna16_strip_unrelayout(strip.data_ptr(), out.data_ptr(), m, strip.shape[1], strip.shape[0] * 8,
+                                                  groups, _stream()), "wna16_strip_unrelayout")
+    return out
+
+
+def wna16_gemm_large_strip(a: torch.Tensor, strip: torch.Tensor, qzeros: torch.Tensor, scales: torch.Tensor,
+                           zero_offset: int, silu: bool = False, strip_m: int = 32) -> torch.Tensor:
+    """_wna16_large / wna16_gemm_large_silu on the STRIP-MAJOR copy of the weights (wna16_strip_relayout(qweight, strip_m,
+    groups)): the eight-phase plans address its 16-byte pieces in place, the other plans rebuild [K/8, N] in the workspace.
+    Same bits as the [K/8, N] entries (csrc/wna16_gemm_large.hip, Wna16LargeParams::strip)."""
+    _require_cuda(a, strip, qzeros, scales)
+    m, k = a.shape
+    n = strip.shape[1]
+    lib = _lib.lib()
+    if a.stride(1) != 1 or a.stride(0) % 8 != 0 or a.data_ptr() % 16 != 0:
+        a = a.contiguous()
+    out = torch.empty((m, n // 2 if silu else n), dtype=a.dtype, device=a.device)
+    nbytes = lib.aphro_wna16_gemm_large_strip_workspace_bytes(m, n, k, scales.shape[0], _dt(a), strip_m)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=a.device) if nbytes else None
+    check(lib.aphro_wna16_gemm_large_strip(a.data_ptr(), strip.data_ptr(), qzeros.data_ptr(), scales.data_ptr(),
+                                           out.data_ptr(), _ptr(ws), nbytes, m, n, k, scales.shape[0], a.stride(0),
+                                           zero_offset, _dt(a), 1 if silu else 0, strip_m, _stream()), "wna16_gemm_large_strip")
+    return out
+
+
+def wna16_linear_strip(a: torch.Tensor, strip: torch.Tensor, qzeros: torch.Tensor, scales: torch.Tensor,
+                       zero_offset: int, strip_m: int = 32) -> torch.Tensor:
+    """[M, N] = a . dequant(W) for ANY M when the strip-major copy is the only resident copy of W (model.enable_one_copy):
+    <= 32 rows the one-launch decode GEMM; prompt-sized M the tile machine reading the strip-major order in place; in
+    between 32-row passes of the decode GEMM (f16) -- and where none of these serves the call, the [K/8, N] order rebuilt
+    into a transient (one more pass over the packed weights) for the generic kernels."""
+    _require_cuda(a, strip, qzeros, scales)
+    m, k = a.shape
+    n, groups = scales.shape[1], scales.shape[0]
+    if m == 0:
+        return torch.empty((0, n), dtype=a.dtype, device=a.device)
+    large = wna16_large_ok(m, n, k, groups) and not switch("APHRO_WNA16_NO_LARGE")
+    if large and wna16_prefers_large(m, n, k):
+        return wna16_gemm_large_strip(a, strip, qzeros, scales, zero_offset, strip_m=strip_m)
+    if m <= 128 and a.dtype == torch.float16 and wna16_gemm_rowmajor_supported(min(m, 32), n, k, groups, a.dtype):
+        if m <= 32:
+            return wna16_gemm_rowmajor(a, strip, qzeros, scales, zero_offset, strip_layout=True)
+        return torch.cat([wna16_gemm_rowmajor(a[m0:m0 + 32], strip, qzeros, scales, zero_offset, strip_layout=True)
+                          for m0 in range(0, m, 32)], 0)
+    if large:
+        return wna16_gemm_large_strip(a, strip, qzeros, scales, zero_offset, strip_m=strip_m)
+    return _wna16(a, wna16_strip_unrelayout(strip, strip_m, groups), qzeros, scales, None, zero_offset)
+
+
 def wna16_mid_ok(m: int, n: int, k: int, groups: int) -> bool:
     return bool(_lib.lib().aphro_wna16_gemm_mid_supported(m, n, k, groups)) and m * k * 2 < 2 ** 32
 

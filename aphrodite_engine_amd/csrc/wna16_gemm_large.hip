@@ -61,7 +61,31 @@ struct Wna16LargeParams {
   // otherwise dequantised by 32 row-tile workgroups: the in-loop dequantisation costs 15 % of the K loop
   // (profiles/r6_w4_two_pass.txt).
   const uint16_t* wt;
+  // strip-major weights (round 6, template STRIP of the eight-phase kernel / of the dequantise-transpose pass): qw is the
+  // strip-major copy the <= 32-row decode kernels stream (aphro_wna16_strip_relayout, wna16_gemm_resident.hip) -- the ONLY
+  // resident copy of the matrix.  Every 16-byte piece (one packed row, four 4-aligned columns) of the [K/8, N] order is 16
+  // contiguous bytes there too; its dword offset is
+  //   ((ky * S + strip) * nwv + wv) * wave_dw + colbase(col) + mult(col) * (256 s + 64 u + 16 g)
+  // with row = 16 * ((ky * nwv + wv) * nseg + s) + 4 g + u and (colbase, mult) = (pass * nseg * 1024 + col % 64, 4) in the
+  // 64-column passes, (np4 * nseg * 1024 + col - 64 np4, rem) in the remainder pass (columns inside the strip).
+  int strip;
+  int st_nwv, st_nseg, st_np4, st_rem, st_S;
+  uint32_t st_wave_dw;
+  uint32_t st_inv_nseg, st_inv_nwv;       // ceil(2^16 / d): (x * inv) >> 16 == x / d for every x the kernel divides (host-checked)
 };
+
+// The strip-major dword offset of the piece at packed row `row`, column `col` (4-aligned) -- see Wna16LargeParams::strip.
+__device__ __forceinline__ uint32_t lg_strip_dw(const Wna16LargeParams& p, int row, int col) {
+  const int cw = 64 * p.st_np4 + 16 * p.st_rem;
+  const int strip = col / cw, cin = col - strip * cw;
+  const int seg = row >> 4, g = (row >> 2) & 3, u = row & 3;
+  const int kw = seg / p.st_nseg, s = seg - kw * p.st_nseg;
+  const int ky = kw / p.st_nwv, wv = kw - ky * p.st_nwv;
+  const uint32_t chunk = (uint32_t)((ky * p.st_S + strip) * p.st_nwv + wv) * p.st_wave_dw;
+  const uint32_t R = 256u * s + 64u * u + 16u * g;
+  if (cin < 64 * p.st_np4) return chunk + (uint32_t)(cin >> 6) * p.st_nseg * 1024u + (cin & 63) + 4u * R;
+  return chunk + (uint32_t)p.st_np4 * p.st_nseg * 1024u + (cin - 64 * p.st_np4) + (uint32_t)p.st_rem * R;
+}
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t lg_rsrc(const void* base, uint32_t bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
@@ -486,8 +510,9 @@ __device__ __forceinline__ void lg_lds_write128(uint32_t addr, const u32x4& v) {
 }
 __device__ __forceinline__ void lg_touch(u32x4& x) { asm volatile("" : "+v"(x)); }
 
-template <bool BF16OUT, bool WDMA = false>
+template <bool BF16OUT, bool WDMA = false, bool STRIP = false>
 __global__ __launch_bounds__(512) void wna16_gemm_large8_kernel(Wna16LargeParams p) {
+  static_assert(!(WDMA && STRIP), "the two-pass form reads f16 W^T: the strip-major order is pass 1's business");
   constexpr int NWAVE = 8, BM = 256, BN = 256, BK = 64;
   constexpr int A_REGION = BM * BK * 2;             // 32 KiB
   constexpr int BUF = 2 * A_REGION;                 // 64 KiB per K tile: [activations | f16 weights]
@@ -576,21 +601,43 @@ __global__ __launch_bounds__(512) void wna16_gemm_large8_kernel(Wna16LargeParams
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void_ptr)(smem + buf * BUF + A_REGION + a_row0[h][t] * 128), 16, voff, kt * (BK * 2), 0, 0);
     };
     // ---- weights: one packed row piece, its scales and zero points per thread and K tile (inline asm: counted by hand) ---
-    const uint32_t w_voff = (uint32_t)((wave * p.N + n0 + 4 * lane) * 4);
+    // STRIP: the lane's column part of the strip-major address (fixed per segment) and its row multiplier -- the row part is
+    // wave-uniform and comes per K tile as one scalar offset + one v_mad (load_w)
+    uint32_t w_voff = (uint32_t)((wave * p.N + n0 + 4 * lane) * 4);
+    uint32_t w_mult4 = 0;
+    if constexpr (STRIP) {
+      const int cw = 64 * p.st_np4 + 16 * p.st_rem;
+      const int col = n0 + 4 * lane, strip = col / cw, cin = col - strip * cw;
+      const bool p4 = cin < 64 * p.st_np4;
+      const uint32_t colbase = p4 ? (uint32_t)(cin >> 6) * p.st_nseg * 1024u + (cin & 63)
+                                  : (uint32_t)p.st_np4 * p.st_nseg * 1024u + (cin - 64 * p.st_np4);
+      w_voff = ((uint32_t)(strip * p.st_nwv) * p.st_wave_dw + colbase) * 4u;
+      w_mult4 = p4 ? 16u : 4u * (uint32_t)p.st_rem;
+    }
     const uint32_t s_voff = (uint32_t)((n0 + 4 * lane) * 2);
     const uint32_t z_voff = (uint32_t)(((n0 + 4 * lane) >> 3) * 4);
     u32x4 wq = {0, 0, 0, 0};                         // (read-write asm operands: one register set across the loop's back edge)
     u32x2 sq = {0, 0};
     uint32_t zq = 0;
     auto load_w = [&](int kt) {
-      const uint32_t so_w = (uint32_t)kt * 8u * (uint32_t)p.N * 4u;
+      uint32_t so_w = (uint32_t)kt * 8u * (uint32_t)p.N * 4u;
+      uint32_t voff_w = w_voff;
+      if constexpr (STRIP) {
+        // packed row kt * 8 + wave = 16 seg + 4 g + u (all wave-uniform: scalar arithmetic, divisions by multiply-shift)
+        const uint32_t row = (uint32_t)kt * 8u + (uint32_t)wave, seg = row >> 4;
+        const uint32_t kw = (seg * p.st_inv_nseg) >> 16, sg = seg - kw * (uint32_t)p.st_nseg;
+        const uint32_t ky = (kw * p.st_inv_nwv) >> 16, wv = kw - ky * (uint32_t)p.st_nwv;
+        so_w = (ky * (uint32_t)(p.st_S * p.st_nwv) + wv) * p.st_wave_dw * 4u;
+        const uint32_t R = 256u * sg + 64u * (row & 3u) + 16u * ((row >> 2) & 3u);
+        voff_w = __builtin_amdgcn_readfirstlane(R) * w_mult4 + w_voff;
+      }
       const uint32_t g = (uint32_t)(kt * BK) / (uint32_t)p.group_size;
       const uint32_t so_s = g * (uint32_t)p.N * 2u, so_z = g * (uint32_t)(p.N >> 3) * 4u;
       asm volatile("buffer_load_dwordx4 %0, %3, %4, %7 offen\n\t"
                    "buffer_load_dwordx2 %1, %5, %6, %8 offen\n\t"
                    "buffer_load_dword %2, %9, %10, %11 offen"
                    : "+v"(wq), "+v"(sq), "+v"(zq)
-                   : "v"(w_voff), "s"(rb), "v"(s_voff), "s"(rs), "s"(so_w), "s"(so_s), "v"(z_voff), "s"(rz), "s"(so_z)
+                   : "v"(voff_w), "s"(rb), "v"(s_voff), "s"(rs), "s"(so_w), "s"(so_s), "v"(z_voff), "s"(rz), "s"(so_z)
                    : "memory");
     };
     // (q - z) * s of dword q (0..3) of the thread's packed row piece -> f16 -> row 4 lane + q of the weight region of buffer
@@ -759,16 +806,18 @@ __global__ __launch_bounds__(512) void wna16_gemm_large8_kernel(Wna16LargeParams
 // (lane: columns 4 lane .. + 3, wave: packed row) reads ONE 16-byte piece, dequantises its 4 x 8 weights into an LDS tile
 // [column][64 k], and the tile leaves as whole 128-byte lines of W^T (8 lanes per line).  (First version: every thread wrote
 // its own column's 16-byte pieces straight to W^T -- 64 partial lines per store instruction: 2.1 TB/s, 139 us on gate_up.)
+// STRIP: qw is the strip-major copy (Wna16LargeParams::strip) -- the same 16-byte piece from its strip-major address.
+template <bool STRIP>
 __global__ __launch_bounds__(512) void wna16_dequant_t_kernel(const uint32_t* __restrict__ qw, const uint32_t* __restrict__ qz,
                                                              const uint16_t* __restrict__ sc, uint16_t* __restrict__ wt, int N, int K,
-                                                             int group_size, int zero_offset, int scale_bf16) {
+                                                             int group_size, int zero_offset, int scale_bf16, Wna16LargeParams sp) {
   constexpr int PITCH = 128 + 16;                       // bytes per LDS row (64 k of one column), padded
   __shared__ __attribute__((aligned(16))) unsigned char tile[256 * PITCH];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n0 = blockIdx.x * 256, kt = blockIdx.y;
   const int nq = n0 + 4 * lane;
   const int g = (kt * 64) / group_size;
-  const u32x4 wq = *reinterpret_cast<const u32x4*>(qw + (size_t)(kt * 8 + wave) * N + nq);
+  const u32x4 wq = *reinterpret_cast<const u32x4*>(qw + (STRIP ? (size_t)lg_strip_dw(sp, kt * 8 + wave, nq) : (size_t)(kt * 8 + wave) * N + nq));
   const u32x2 sq = *reinterpret_cast<const u32x2*>(sc + (size_t)g * N + nq);
   const uint32_t zq = qz[(size_t)g * (N >> 3) + (nq >> 3)] >> ((lane & 1) * 16);
 #pragma unroll
@@ -850,15 +899,15 @@ static int launch_large_s(const Wna16LargeParams& p, hipStream_t st) {
   return APHRO_OK;
 }
 
-template <bool WDMA>
+template <bool WDMA, bool STRIP = false>
 static int launch_large8_t(const Wna16LargeParams& p, hipStream_t st) {
   Wna16LargeParams q = p;
   q.tiles_m = (p.M + 255) / 256;
   q.tiles_n = p.N / 256;
   constexpr size_t lds = 128 * 1024;
-  static bool attr_set_dev[APHRO_MAX_DEVICES][2] = {};
+  static bool attr_set_dev[APHRO_MAX_DEVICES][2] = {};      // (one array per template instance)
   bool& attr_set = attr_set_dev[device_slot()][p.out_bf16 ? 1 : 0];
-  const void* fn = p.out_bf16 ? (const void*)wna16_gemm_large8_kernel<true, WDMA> : (const void*)wna16_gemm_large8_kernel<false, WDMA>;
+  const void* fn = p.out_bf16 ? (const void*)wna16_gemm_large8_kernel<true, WDMA, STRIP> : (const void*)wna16_gemm_large8_kernel<false, WDMA, STRIP>;
   if (!attr_set) {
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
       set_error("wna16_gemm_large: cannot raise the dynamic LDS limit");
@@ -866,13 +915,14 @@ static int launch_large8_t(const Wna16LargeParams& p, hipStream_t st) {
     }
     attr_set = true;
   }
-  if (p.out_bf16) hipLaunchKernelGGL((wna16_gemm_large8_kernel<true, WDMA>), dim3(p.grid), dim3(512), lds, st, q);
-  else hipLaunchKernelGGL((wna16_gemm_large8_kernel<false, WDMA>), dim3(p.grid), dim3(512), lds, st, q);
+  if (p.out_bf16) hipLaunchKernelGGL((wna16_gemm_large8_kernel<true, WDMA, STRIP>), dim3(p.grid), dim3(512), lds, st, q);
+  else hipLaunchKernelGGL((wna16_gemm_large8_kernel<false, WDMA, STRIP>), dim3(p.grid), dim3(512), lds, st, q);
   APHRO_LAUNCH_CHECK();
   return APHRO_OK;
 }
 static int launch_large8(const Wna16LargeParams& p, hipStream_t st) {
-  return p.wt != nullptr ? launch_large8_t<true>(p, st) : launch_large8_t<false>(p, st);
+  if (p.wt != nullptr) return launch_large8_t<true>(p, st);
+  return p.strip ? launch_large8_t<false, true>(p, st) : launch_large8_t<false>(p, st);
 }
 
 // three LDS stages (loads two K tiles ahead, one raw barrier per tile) when the group metadata leaves room for them
@@ -962,13 +1012,33 @@ static int large_bind_scratch(Wna16LargeParams& p, const LargePlan& pl, char* ws
   return APHRO_OK;
 }
 
-// Bytes of scratch aphro_wna16_gemm_large needs: the f16 copy of bf16 activations + the fp32 split-K slabs.
-extern "C" size_t aphro_wna16_gemm_large_workspace_bytes(int64_t M, int64_t N, int64_t K, int64_t groups, int dtype) {
+extern "C" int aphro_wna16_strip_geometry(int64_t M, int64_t N, int64_t K, int64_t groups, int* geom);      // wna16_gemm_resident.hip
+extern "C" int aphro_wna16_strip_unrelayout(const uint32_t* strip, uint32_t* out, int64_t M, int64_t N, int64_t K, int64_t groups, void* stream);
+
+// Plans that read the strip-major copy in place: the eight-phase kernel (fused and two-pass form).  The others get the
+// [K/8, N] order back in the workspace first (aphro_wna16_strip_unrelayout: one more pass over the packed weights).
+static bool large_eight(const LargePlan& pl, int64_t K) {
+  const int eight = knobs().wna16_large_8phase >= 0 ? knobs().wna16_large_8phase : (K >= 2048 ? 1 : 0);
+  return pl.wm == 2 && pl.wn == 4 && pl.streamk && eight;
+}
+
+static size_t large_workspace_bytes(int64_t M, int64_t N, int64_t K, int64_t groups, int dtype, int strip_m) {
   if (groups <= 0 || K % groups != 0) return 0;
   const LargePlan pl = large_plan(M, N, K, K / groups);
   size_t b = dtype == APHRO_BF16 ? ((size_t)M * K * 2 + 255) / 256 * 256 : 0;
   if (large_two_pass(pl, M, N, K, K / groups)) b += ((size_t)N * K * 2 + 255) / 256 * 256;      // f16 W^T of the two-pass form
+  if (strip_m > 0 && !large_eight(pl, K)) b += ((size_t)(K / 8) * N * 4 + 255) / 256 * 256;    // the [K/8, N] order, rebuilt
   return b + large_scratch_bytes(pl, M, N);
+}
+
+// Bytes of scratch aphro_wna16_gemm_large needs: the f16 copy of bf16 activations + the fp32 split-K slabs.
+extern "C" size_t aphro_wna16_gemm_large_workspace_bytes(int64_t M, int64_t N, int64_t K, int64_t groups, int dtype) {
+  return large_workspace_bytes(M, N, K, groups, dtype, 0);
+}
+// ... aphro_wna16_gemm_large_strip needs (strip_m: the M class the strip-major copy was laid out for, as given to
+// aphro_wna16_strip_relayout).
+extern "C" size_t aphro_wna16_gemm_large_strip_workspace_bytes(int64_t M, int64_t N, int64_t K, int64_t groups, int dtype, int64_t strip_m) {
+  return large_workspace_bytes(M, N, K, groups, dtype, (int)strip_m);
 }
 
 // c[M, N] = a[M, K] . dequant(q_weight[K/8, N] exllama order, qzeros[G, N/8], scales[G, N]); any M, meant for M > 64.
@@ -976,7 +1046,7 @@ extern "C" size_t aphro_wna16_gemm_large_workspace_bytes(int64_t M, int64_t N, i
 // with saturation, scales and output stay bf16).  Act-order: pass the activations already gathered (a[:, perm]).
 static int wna16_gemm_large_impl(const void* a, const uint32_t* q_weight, const uint32_t* qzeros, const void* scales,
                                  void* c, void* workspace, size_t workspace_bytes, int64_t M, int64_t N, int64_t K,
-                                 int64_t groups, int64_t lda, int zero_offset, int dtype, int silu, void* stream) {
+                                 int64_t groups, int64_t lda, int zero_offset, int dtype, int silu, void* stream, int strip_m = 0) {
   hipStream_t st = (hipStream_t)stream;
   APHRO_CHECK(dtype == APHRO_F16 || dtype == APHRO_BF16, "wna16_gemm_large: dtype must be f16 or bf16");
   APHRO_CHECK(groups > 0 && K % groups == 0, "wna16_gemm_large: K=%ld not divisible by groups=%ld", (long)K, (long)groups);
@@ -989,7 +1059,7 @@ static int wna16_gemm_large_impl(const void* a, const uint32_t* q_weight, const 
   const LargePlan pl = large_plan(M, N, K, gs);
   APHRO_CHECK(!silu || pl.streamk || pl.ksplit == 1, "wna16_gemm_large_silu: shape M=%ld N=%ld K=%ld is K-sliced (no SiluAndMul epilogue)",
               (long)M, (long)N, (long)K);
-  const size_t need = aphro_wna16_gemm_large_workspace_bytes(M, N, K, groups, dtype);
+  const size_t need = large_workspace_bytes(M, N, K, groups, dtype, strip_m);
   if (need > 0 && (workspace == nullptr || workspace_bytes < need)) {
     set_error("wna16_gemm_large: workspace %zu < %zu bytes", workspace_bytes, need);
     return APHRO_ERR_WORKSPACE;
@@ -1012,19 +1082,51 @@ static int wna16_gemm_large_impl(const void* a, const uint32_t* q_weight, const 
   p.tiles_m = p.tiles_n = 0;
   p.w8 = nullptr; p.w_scales = nullptr; p.w_per_channel = 0; p.bias = nullptr;
   p.wt = nullptr;
+  p.strip = 0;
+  p.st_nwv = p.st_nseg = p.st_np4 = p.st_rem = p.st_S = 0; p.st_wave_dw = p.st_inv_nseg = p.st_inv_nwv = 0;
+  if (strip_m > 0) {
+    // q_weight is the strip-major copy of the <= 32-row decode kernels (the only resident one)
+    int geom[5];
+    APHRO_CHECK(aphro_wna16_strip_geometry(strip_m, N, K, groups, geom) == 1,
+                "wna16_gemm_large_strip: no strip-major form for M class %d, N=%ld, K=%ld, groups=%ld", strip_m, (long)N, (long)K, (long)groups);
+    if (large_eight(pl, K)) {
+      p.strip = 1;
+      p.st_nwv = geom[0]; p.st_nseg = geom[1]; p.st_np4 = geom[2]; p.st_rem = geom[3];
+      const int cw = 64 * p.st_np4 + 16 * p.st_rem;
+      p.st_S = (int)(N / cw);
+      p.st_wave_dw = (uint32_t)(p.st_nseg * 256 * (4 * p.st_np4 + p.st_rem));
+      p.st_inv_nseg = (65536u + p.st_nseg - 1) / p.st_nseg;
+      p.st_inv_nwv = (65536u + p.st_nwv - 1) / p.st_nwv;
+      const uint32_t segs = (uint32_t)(K / 128) + 1;       // (+ 1: a clamped tile past the range is never formed, the bound is slack)
+      for (uint32_t x = 0; x < segs; ++x)
+        APHRO_CHECK(((x * p.st_inv_nseg) >> 16) == x / p.st_nseg && ((x * p.st_inv_nwv) >> 16) == x / p.st_nwv,
+                    "wna16_gemm_large_strip: multiply-shift division fails at %u (nseg %d, nwv %d)", x, p.st_nseg, p.st_nwv);
+    } else {
+      // a plan that reads [K/8, N]: the permutation backwards into the workspace, then as ever
+      uint32_t* qw_rm = (uint32_t*)ws;
+      if (int rcu = aphro_wna16_strip_unrelayout(q_weight, qw_rm, strip_m, N, K, groups, stream)) return rcu;
+      p.qw = q_weight = qw_rm;
+      ws += ((size_t)(K / 8) * N * 4 + 255) / 256 * 256;
+    }
+  }
   if (large_two_pass(pl, M, N, K, gs)) {
     // pass 1: the weights dequantised once into f16 W^T [N, K] (same numerics as the in-loop dequantisation: same bits out)
-    hipLaunchKernelGGL(wna16_dequant_t_kernel, dim3((unsigned)(N / 256), (unsigned)(K / 64)), dim3(512), 0, st, q_weight, qzeros,
-                       (const uint16_t*)scales, (uint16_t*)ws, (int)N, (int)K, (int)gs, zero_offset, p.scale_bf16);
+    const dim3 dgrid((unsigned)(N / 256), (unsigned)(K / 64));
+    if (p.strip)
+      hipLaunchKernelGGL(wna16_dequant_t_kernel<true>, dgrid, dim3(512), 0, st, q_weight, qzeros,
+                         (const uint16_t*)scales, (uint16_t*)ws, (int)N, (int)K, (int)gs, zero_offset, p.scale_bf16, p);
+    else
+      hipLaunchKernelGGL(wna16_dequant_t_kernel<false>, dgrid, dim3(512), 0, st, q_weight, qzeros,
+                         (const uint16_t*)scales, (uint16_t*)ws, (int)N, (int)K, (int)gs, zero_offset, p.scale_bf16, p);
     APHRO_LAUNCH_CHECK();
+    p.strip = 0;                                    // (pass 2 reads W^T)
     p.wt = (const uint16_t*)ws;
     ws += ((size_t)N * K * 2 + 255) / 256 * 256;
   }
   if (int rcb = large_bind_scratch(p, pl, ws, st)) return rcb;
   int rc;
   // eight-phase schedule on the 256 x 256 stream-K tile from 32 K tiles per output tile up (APHRO_WNA16_LARGE_8PHASE=0/1 forces)
-  const int eight = knobs().wna16_large_8phase >= 0 ? knobs().wna16_large_8phase : (K >= 2048 ? 1 : 0);
-  if (pl.wm == 2 && pl.wn == 4 && pl.streamk && eight) rc = launch_large8(p, st);
+  if (large_eight(pl, K)) rc = launch_large8(p, st);
   else if (pl.wm == 2) rc = pl.wn == 4 ? launch_large<2, 4>(p, st) : launch_large<2, 2>(p, st);
   else rc = pl.wn == 4 ? launch_large<1, 4>(p, st) : launch_large<1, 2>(p, st);
   if (rc != APHRO_OK) return rc;
@@ -1046,6 +1148,19 @@ extern "C" int aphro_wna16_gemm_large(const void* a, const uint32_t* q_weight, c
 // The same GEMM on a gate_up matrix with interleaved (gate_j, up_j) columns, SiluAndMul in the epilogue: act [M, N / 2] =
 // silu_and_mul(a . dequant(W)) with the GEMM result rounded to the dtype first (the bits of aphro_wna16_gemm_large followed by
 // aphro_silu_and_mul_interleaved).  1 if the shape is served (not K-sliced), else 0: aphro_wna16_gemm_large_silu_supported.
+// aphro_wna16_gemm_large / aphro_wna16_gemm_large_silu (silu != 0) on the STRIP-MAJOR copy of the weights
+// (aphro_wna16_strip_relayout for the M class strip_m, normally 32): the eight-phase plans read it in place -- same loads,
+// other addresses, same bits -- the others rebuild the [K/8, N] order in the workspace first.  For a model that keeps one
+// copy of each matrix resident (the one its decode kernels stream).
+extern "C" int aphro_wna16_gemm_large_strip(const void* a, const uint32_t* q_weight_strip, const uint32_t* qzeros, const void* scales,
+                                            void* c, void* workspace, size_t workspace_bytes, int64_t M, int64_t N, int64_t K,
+                                            int64_t groups, int64_t lda, int zero_offset, int dtype, int silu, int64_t strip_m,
+                                            void* stream) {
+  APHRO_CHECK(strip_m >= 1 && strip_m <= 64, "wna16_gemm_large_strip: strip_m=%ld", (long)strip_m);
+  return wna16_gemm_large_impl(a, q_weight_strip, qzeros, scales, c, workspace, workspace_bytes, M, N, K, groups, lda, zero_offset, dtype,
+                               silu ? 1 : 0, stream, (int)strip_m);
+}
+
 extern "C" int aphro_wna16_gemm_large_silu_supported(int64_t M, int64_t N, int64_t K, int64_t groups) {
   if (groups <= 0 || K % groups != 0 || K % 64 != 0 || (K / groups) % 64 != 0 || N % 128 != 0 || M <= 0) return 0;
   const LargePlan pl = large_plan(M, N, K, K / groups);
@@ -1091,7 +1206,7 @@ extern "C" int aphro_fp8_w8a16_gemm_large(void* out, const void* a, const void* 
     APHRO_LAUNCH_CHECK();
     p.a = (const uint16_t*)workspace; p.lda = (int)K;
   }
-  p.silu = 0; p.wt = nullptr;
+  p.silu = 0; p.wt = nullptr; p.strip = 0;
   p.qw = nullptr; p.qz = nullptr; p.sc = nullptr; p.c = (uint16_t*)out;
   p.M = (int)M; p.N = (int)N; p.K = (int)K; p.group_size = 64; p.zero_offset = 0;
   p.out_bf16 = dtype == APHRO_BF16; p.scale_bf16 = 0;

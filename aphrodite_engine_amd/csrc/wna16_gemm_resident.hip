@@ -809,7 +809,9 @@ __global__ __launch_bounds__(NWV * 64, 1) void wna16_gemm_stream_kernel(const ui
 }
 
 // [K/8, N] exllama order -> strip-major: the 16-byte (last pass: 4 REM-byte) pieces in the order the waves read them.
-// One thread per destination dword.
+// One thread per strip-major dword.  INVERSE: the same permutation backwards (strip-major -> [K/8, N]): what a caller that
+// keeps ONLY the strip-major copy runs for the kernels that do not read it (aphro_wna16_strip_unrelayout).
+template <bool INVERSE>
 __global__ void wna16_strip_relayout_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, int N, int K,
                                             int nwv, int nseg, int np4, int rem, int ksplit) {
   const int64_t total = (int64_t)(K >> 3) * N;
@@ -842,7 +844,8 @@ __global__ void wna16_strip_relayout_kernel(const uint32_t* __restrict__ in, uin
   const int seg = (ky * nwv + wave) * nseg + s;
   const int row = seg * 16 + 4 * g + u;
   const int col = strip * cw + (pass < np4 ? 64 * pass + 4 * c + t : 64 * np4 + rem * c + t);
-  out[d] = in[(size_t)row * N + col];
+  if constexpr (INVERSE) out[(size_t)row * N + col] = in[d];
+  else out[d] = in[(size_t)row * N + col];
 }
 
 }  // namespace aphro
@@ -1146,14 +1149,39 @@ extern "C" int aphro_wna16_gemm_rowmajor(const void* a, int64_t lda, const uint3
 
 // Load-time relayout of a [K/8, N] exllama-ordered int4 matrix into the strip-major order of the configuration
 // res_plan picks for (M, N, K, groups).  out != in.
-extern "C" int aphro_wna16_strip_relayout(const uint32_t* q_weight, uint32_t* out, int64_t M, int64_t N, int64_t K,
-                                          int64_t groups, void* stream) {
-  APHRO_CHECK(groups > 0 && K % groups == 0 && q_weight != out, "wna16_strip_relayout: bad arguments");
+static int strip_relayout_impl(const uint32_t* in, uint32_t* out, int64_t M, int64_t N, int64_t K, int64_t groups, bool inverse,
+                               void* stream) {
+  APHRO_CHECK(groups > 0 && K % groups == 0 && in != out && in && out, "wna16_strip_relayout: bad arguments");
   const ResConfig cf = res_plan(M, N, K, K / groups);
   APHRO_CHECK(cf.nwv != 0, "wna16_strip_relayout: shape M=%ld N=%ld K=%ld is not served by the resident kernel", (long)M, (long)N, (long)K);
   const int64_t total = (K / 8) * N;
-  hipLaunchKernelGGL(wna16_strip_relayout_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     q_weight, out, (int)N, (int)K, cf.nwv, cf.nseg, cf.np4, cf.rem, cf.ksplit);
+  const dim3 grid((unsigned)((total + 255) / 256));
+  if (inverse)
+    hipLaunchKernelGGL(wna16_strip_relayout_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, in, out, (int)N, (int)K,
+                       cf.nwv, cf.nseg, cf.np4, cf.rem, cf.ksplit);
+  else
+    hipLaunchKernelGGL(wna16_strip_relayout_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, in, out, (int)N, (int)K,
+                       cf.nwv, cf.nseg, cf.np4, cf.rem, cf.ksplit);
   APHRO_LAUNCH_CHECK();
   return APHRO_OK;
+}
+extern "C" int aphro_wna16_strip_relayout(const uint32_t* q_weight, uint32_t* out, int64_t M, int64_t N, int64_t K,
+                                          int64_t groups, void* stream) {
+  return strip_relayout_impl(q_weight, out, M, N, K, groups, false, stream);
+}
+// The permutation backwards: strip-major (as aphro_wna16_strip_relayout wrote it for the same M class, N, K, groups) ->
+// [K/8, N] exllama order.  out != strip.  For a caller that keeps only the strip-major copy resident.
+extern "C" int aphro_wna16_strip_unrelayout(const uint32_t* strip, uint32_t* out, int64_t M, int64_t N, int64_t K,
+                                            int64_t groups, void* stream) {
+  return strip_relayout_impl(strip, out, M, N, K, groups, true, stream);
+}
+// The strip-major geometry of (M class, N, K, groups): geom[5] = {waves, 128-k segments per wave, 64-column passes,
+// 16-column remainder units, K slices}.  1: served, 0: no strip-major form for the shape (geom untouched).  What the
+// prompt-sized kernels (wna16_gemm_large.hip) address the strip-major copy with.
+extern "C" int aphro_wna16_strip_geometry(int64_t M, int64_t N, int64_t K, int64_t groups, int* geom) {
+  if (groups <= 0 || K % groups != 0) return 0;
+  const ResConfig cf = res_plan(M, N, K, K / groups);
+  if (cf.nwv == 0) return 0;
+  if (geom) { geom[0] = cf.nwv; geom[1] = cf.nseg; geom[2] = cf.np4; geom[3] = cf.rem; geom[4] = cf.ksplit; }
+  return 1;
 }

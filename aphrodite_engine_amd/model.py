@@ -122,6 +122,14 @@ class QuantLinear(nn.Module):
         bias = self.bias if add_bias else None
         if self.quant_method is None:
             return torch.nn.functional.linear(x, self.weight, bias)
+        if getattr(self, "qweight_strip_major", False):
+            # DecoderLayer.enable_one_copy: ``qweight`` holds the strip-major order of the decode kernels, the only resident
+            # copy -- any M through the kernels that read it (ops.wna16_linear_strip), never through the quant method's op
+            fp = self.fast_params()
+            out = ops.wna16_linear_strip(x.reshape(-1, x.shape[-1]), fp[0], fp[1], fp[2], fp[3])
+            if bias is not None:
+                out.add_(bias)
+            return out.reshape(x.shape[:-1] + (self.out_features,))
         return self.quant_method.apply(self, x, bias)
 
     def fast_params(self):
@@ -269,6 +277,59 @@ class LlamaDecoderLayer(nn.Module):
         self.fp8_strip = {}
         self.fp8_gate_up_il = None
         self.fuse_rope_attention = True
+        self.one_copy = False
+
+    def enable_one_copy(self) -> int:
+        """Release the [K/8, N] originals of every int4 matrix this layer holds a strip-major decode copy of: ONE resident copy
+        per matrix (what the reference keeps: its exllama / Marlin kernels serve every M from the one repacked tensor,
+        quantization/gptq.py:214-228; spare HBM is KV blocks, worker/cache_engine.py:66-86).  Call after enable_fused_silu(m <=
+        32, keep_original=False).  The linear's ``qweight`` parameter then HOLDS the strip-major words (same shape, flag
+        ``qweight_strip_major``) and
+          * <= 32 rows: the fused decode step as before (it only ever read the strip-major copies);
+          * 33..64 rows: the fused step on two 32-row halves of the stream kernels (what APHRO_DECODE_ROW_HALVES=1 selects)
+            where every projection has a stream plan, else op by op;
+          * prompt-sized M: the eight-phase kernel / the dequantise-transpose pass address the strip-major pieces in place
+            (ops.wna16_gemm_large_strip: same loads, same bits); any other plan rebuilds [K/8, N] in its workspace.
+        TP 1, dense, bias-free layers only (the TP / sparse steps run the round-2 kernels on [K/8, N]).  Returns the bytes
+        released; restore_op_level_layouts undoes it."""
+        if self.one_copy or self.tp != 1 or self.is_moe or self.has_bias or switch("APHRO_WEIGHTS_TWO_COPIES"):
+            return 0
+        freed = 0
+        for name in ("qkv_proj", "o_proj", "down_proj"):
+            lin, st = getattr(self, name), self.strip.get(name)
+            if st is None or lin.fast_params() is None or getattr(lin, "qweight_strip_major", False):
+                continue
+            freed += lin.qweight.numel() * 4
+            lin.qweight.data = st
+            lin.qweight_strip_major = True
+            if getattr(lin, "qweight_strip", None) is not None:
+                lin.qweight_strip = None
+        lin = self.gate_up_proj
+        if self.gate_up_strip is not None and self.gate_up_interleaved is not None and not self.gate_up_keep_original:
+            _, qz, sc, zo = self.gate_up_interleaved
+            freed += lin.qweight.numel() * 4
+            lin.qweight.data = self.gate_up_strip
+            lin.qweight_strip_major = True
+            self.gate_up_interleaved = (self.gate_up_strip, qz, sc, zo)     # ([0]: shape only -- the words are strip-major)
+        self.one_copy = freed > 0
+        return freed
+
+    def _undo_one_copy(self) -> None:
+        if not self.one_copy:
+            return
+        for name in ("qkv_proj", "o_proj", "down_proj", "gate_up_proj"):
+            lin = getattr(self, name)
+            if getattr(lin, "qweight_strip_major", False):
+                lin.qweight.data = ops.wna16_strip_unrelayout(lin.qweight.data, 32, lin.scales.shape[0])
+                lin.qweight_strip_major = False
+        if self.gate_up_interleaved is not None:
+            self.gate_up_interleaved = (self.gate_up_proj.qweight.data,) + tuple(self.gate_up_interleaved[1:])
+        self.one_copy = False
+
+    def _row_halves(self, m: int) -> bool:
+        """33..64 rows on two 32-row halves of the stream kernels: opt-in (measured slower than the one-pass kernel on
+        [K/8, N], see enable_fused_silu) -- and the form of a layer that keeps only the strip-major copies."""
+        return 32 < m <= 64 and (self.one_copy or switch("APHRO_DECODE_ROW_HALVES") == "1")
 
     def enable_fused_silu(self, m: int = 32, keep_original: bool = True) -> bool:
         """Re-lay the gate_up weights with interleaved (gate_j, up_j) columns so that the
@@ -278,6 +339,7 @@ class LlamaDecoderLayer(nn.Module):
         (ops.silu_and_mul(..., interleaved=True)) -- one copy of the matrix in HBM."""
         if self.has_bias:                     # (op-by-op path only: no decode copies, no column interleave under the bias)
             return False
+        self._undo_one_copy()
         self.enable_resident_layouts(m)       # (also where SiluAndMul cannot ride in the epilogue: TP shards, sparse layers)
         if self.is_moe:
             return False
@@ -314,6 +376,7 @@ class LlamaDecoderLayer(nn.Module):
         """Undo enable_fused_silu / enable_resident_layouts: the parameters and the op-level strip-major copy as the quant
         method's process_weights_after_loading leaves them (what the reference's own LlamaDecoderLayer runs on through the
         plugin).  bench.py measures its op-by-op leg on this state."""
+        self._undo_one_copy()
         self.strip = {}
         self.gate_up_strip = None
         if self.gate_up_interleaved is not None:
@@ -391,14 +454,16 @@ class LlamaDecoderLayer(nn.Module):
         lin = getattr(self, name)
         qw, qz, sc, zo = lin.fast_params()
         st = self.strip.get(name)
-        #  the strip-major copy serves <= 32 rows; 33..64 rows only with the opt-in row halves AND a plan the
-        # stream kernel is instantiated for (an 8192 x 8192 o_proj plans to {4, 8, 1, 0}: no stream form) -- otherwise the
-        # round-2 kernel on the [K/8, N] layout, as before round 4
-        if st is not None and m > 32 and not (m <= 64 and switch("APHRO_DECODE_ROW_HALVES") == "1"
+        #  the strip-major copy serves <= 32 rows; 33..64 rows only with the row halves (opt-in, or a layer that
+        # keeps one copy) AND a plan the stream kernel is instantiated for (an 8192 x 8192 o_proj plans to {4, 8, 1, 0}: no
+        # stream form) -- otherwise the round-2 kernel on the [K/8, N] layout, as before round 4
+        if st is not None and m > 32 and not (self._row_halves(m)
                                               and ops.wna16_resident_ksplit(m, lin.out_features, lin.in_features, sc.shape[0]) > 0):
             st = None
         if st is not None:
             return ops.wna16_gemm_resident(packed, m, k, st, qz, sc, zo, mode="slabs", strip_layout=True)
+        if getattr(lin, "qweight_strip_major", False):     # (one copy, no stream plan for this M: fused_decode_ok says no --
+            qw = ops.wna16_strip_unrelayout(qw, 32, sc.shape[0])    #  kept correct for a direct caller: [K/8, N] rebuilt)
         return ops.wna16_gemm_packed(packed, m, k, qw, qz, sc, zo, partials=True)
 
     def _packed_weights(self, name: str) -> Optional[torch.Tensor]:
@@ -425,6 +490,10 @@ class LlamaDecoderLayer(nn.Module):
         for lin in self.linears():
             fp = lin.fast_params()
             if fp is None or ops.wna16_ksplit(m, lin.out_features, lin.in_features, fp[2].shape[0]) <= 0:
+                return False
+            # one resident copy (enable_one_copy): 33..64 rows need the stream kernel's row-halves plan on that copy
+            if m > 32 and getattr(lin, "qweight_strip_major", False) \
+                    and ops.wna16_resident_ksplit(m, lin.out_features, lin.in_features, fp[2].shape[0]) <= 0:
                 return False
         return True
 
@@ -537,19 +606,22 @@ class LlamaDecoderLayer(nn.Module):
         mid = 32 < m <= 64 and not switch("APHRO_DECODE_NO_MID")
         # 33..64 rows: the one-pass 32x32x16 MFMA kernel; APHRO_DECODE_ROW_HALVES=1: the stream kernel on two 32-row halves
         # where the layer has the strip-major copies (measured slower on the one-GPU shapes, see enable_fused_silu)
-        halves = 32 < m <= 64 and switch("APHRO_DECODE_ROW_HALVES") == "1"
+        halves = self._row_halves(m)
+        gu_one = self.one_copy and getattr(self.gate_up_proj, "qweight_strip_major", False)
         if self.gate_up_interleaved is not None:
             # SiluAndMul + pack run in the GEMM epilogue (interleaved gate/up columns)
             qw, qz, sc, zo = self.gate_up_interleaved
             if halves and self.gate_up_strip is not None and ops.wna16_resident_ksplit(m, qw.shape[1], h, sc.shape[0]) == 1:
                 act_packed = ops.wna16_gemm_resident(packed2, m, h, self.gate_up_strip, qz, sc, zo, mode="silu",
                                                      strip_layout=True)
-            elif mid and ops.wna16_gemm_mid_ksplit(m, qw.shape[1], h, sc.shape[0]) == 1 and qw.shape[1] % 256 == 0:
+            elif mid and not gu_one and ops.wna16_gemm_mid_ksplit(m, qw.shape[1], h, sc.shape[0]) == 1 and qw.shape[1] % 256 == 0:
                 act_packed = ops.wna16_gemm_mid_silu_pack(packed2, m, h, qw, qz, sc, zo)
             elif self.gate_up_strip is not None and m <= 32 and ops.wna16_resident_ksplit(m, qw.shape[1], h, sc.shape[0]) == 1:
                 act_packed = ops.wna16_gemm_resident(packed2, m, h, self.gate_up_strip, qz, sc, zo, mode="silu",
                                                      strip_layout=True)
             else:
+                if gu_one:                                         # (not reached through fused_decode_ok; kept correct)
+                    qw = ops.wna16_strip_unrelayout(qw, 32, sc.shape[0])
                 act_packed = ops.wna16_gemm_silu_pack(packed2, m, h, qw, qz, sc, zo)
         else:
             qw, qz, sc, zo = self.gate_up_proj.fast_params()
@@ -571,7 +643,8 @@ class LlamaDecoderLayer(nn.Module):
                 return dar, None
             return tensor_model_parallel_all_reduce(d, prefetch=next_weights), None
         kd = self.down_proj.in_features
-        if mid and not (halves and "down_proj" in self.strip) and qw.shape[1] * kd >= 2 ** 25 \
+        if mid and not (halves and "down_proj" in self.strip) and not getattr(self.down_proj, "qweight_strip_major", False) \
+                and qw.shape[1] * kd >= 2 ** 25 \
                 and ops.wna16_gemm_mid_ksplit(m, qw.shape[1], kd, sc.shape[0]) > 0:
             down_slabs, _ = ops.wna16_gemm_mid_packed(act_packed, m, kd, qw, qz, sc, zo, partials=True)
         else:
@@ -799,7 +872,10 @@ class LlamaDecoderLayer(nn.Module):
             qw, qz, sc, zo = self.gate_up_interleaved
             if ops.wna16_gemm_large_silu_supported(hidden.shape[0], qw.shape[1], hidden.shape[1], sc.shape[0]) \
                     and hidden.dtype == sc.dtype:
-                act = ops.wna16_gemm_large_silu(hidden, qw, qz, sc, zo)
+                if getattr(self.gate_up_proj, "qweight_strip_major", False):      # one resident copy: the strip-major words
+                    act = ops.wna16_gemm_large_strip(hidden, qw, qz, sc, zo, silu=True)
+                else:
+                    act = ops.wna16_gemm_large_silu(hidden, qw, qz, sc, zo)
                 hidden = self.down_proj(act)
                 if self.tp > 1:
                     hidden = tensor_model_parallel_all_reduce(hidden)

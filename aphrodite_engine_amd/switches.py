@@ -13,6 +13,7 @@ SWITCHES = {
     "APHRODITE_AWQ_NO_PREPACK": "1: AWQ weights stay in the checkpoint's nibble order (transposed per call)",
     "APHRODITE_DISABLED_KERNELS": "the reference's own list of MPLinearKernel names to skip (kernels/__init__.py:37-56)",
     "APHRODITE_CUSTOM_AR_CHECK_EVERY": "host-side error-word poll period of the peer-access all-reduce (calls)",
+    "APHRO_WEIGHTS_TWO_COPIES": "1: DecoderLayer.enable_one_copy keeps the [K/8, N] originals beside the strip-major decode copies",
     "APHRO_AR_PREFETCH": "1: extra workgroups of the fused all-reduce + norm launch prefetch the next GEMM's weights",
     # A/B routing: the previous generation of a kernel / an unfused form (same bits unless stated)
     "APHRO_PA_ROCM_PARTITIONED": "_rocm_C::paged_attention always in its partitioned two-launch form",

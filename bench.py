@@ -78,6 +78,8 @@ def parse_args():
                          "the all-reduce side of the trade; the TP section of a multi-GPU run still reports both arms")
     ap.add_argument("--no-overlap", action="store_true", help="(accepted for older command lines: overlap is off by default)")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--two-copies", action="store_true",
+                    help="keep the [K/8, N] originals of the int4 matrices beside the strip-major decode copies (the layout of rounds 3-5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prefill-info", action="store_true", help="skip the MFMA-bound prefill kernels' info section")
     ap.add_argument("--no-prefill-e2e", action="store_true",
@@ -133,6 +135,10 @@ def build(args, device):
         # load-time relayout: SiluAndMul + pack run in the gate_up GEMM epilogue
         for layer in model.layers:
             layer.enable_fused_silu(args.batch, keep_original=False)
+            if not getattr(args, "two_copies", False):
+                # ONE resident copy of each int4 matrix: the strip-major order the decode kernels stream (the prompt-sized
+                # kernels address it in place) -- TP 1 dense layers; a no-op elsewhere (model.DecoderLayer.enable_one_copy)
+                layer.enable_one_copy()
     if args.quant.startswith("fp8") and args.batch <= 32:
         for layer in model.layers:
             layer.enable_fp8_strips(args.batch)     # load-time relayout for the resident W8A8 decode GEMM
@@ -283,7 +289,7 @@ def roofline_section(model, loop, args):
                  and ops.wna16_gemm_mid_ksplit(bs, n_out, lin0.in_features, groups) > 0))
 
             # 33..64 rows (round 4): the stream kernel on two 32-row halves where the layer has its strip-major copies
-            halves = 32 < bs <= 64 and os.environ.get("APHRO_DECODE_ROW_HALVES") == "1"
+            halves = layers[0]._row_halves(bs)
             resident = silu and layers[0].gate_up_strip is not None and (bs <= 32 or halves) \
                 and ops.wna16_resident_ksplit(bs, n_out, lin0.in_features, groups) == 1
             if resident or (halves and name in getattr(layers[0], "strip", {})):
@@ -589,6 +595,7 @@ def prefill_e2e_section(T=8192, library=True, which=("int4", "fp8")):
         model.init_synthetic(dev, seed=0)
         for layer in model.layers:      # the layouts the engine adapter leaves behind (reference_model._finish): ONE interleaved
             layer.enable_fused_silu(32, keep_original=False)      # gate_up copy -> SiluAndMul rides in the prefill GEMM's epilogue
+            layer.enable_one_copy()         # ... and only the strip-major copy of every int4 matrix resident, as in the headline
         nblk = (T + BS - 1) // BS
         caches = M.make_kv_caches(cfg, nblk, BS, torch.float16, kv, dev, fill=False)
         bt = torch.randperm(nblk, device=dev).to(torch.int32).view(1, nblk)
@@ -1138,6 +1145,8 @@ def main():
             if not os.environ.get("APHRO_NO_FUSED_SILU"):
                 for layer in model.layers:
                     layer.enable_fused_silu(args.batch, keep_original=False)
+                    if not getattr(args, "two_copies", False):
+                        layer.enable_one_copy()
         active_frac = 1.0
         if cfg.num_local_experts:
             # experts the decode step really routes to (one more eager step with the routing recorded)

@@ -693,6 +693,26 @@ int aphro_wna16_gemm_resident(const void* a_packed, const uint32_t* q_weight, co
  * plan for this shape (every wave's 16-byte pieces in the order it reads them).  A permutation of the words; out != in. */
 int aphro_wna16_strip_relayout(const uint32_t* q_weight, uint32_t* out, int64_t M, int64_t N, int64_t K,
                                int64_t groups, void* stream);
+/* ONE resident copy of a decode matrix (round 6; the reference keeps one too: its exllama / Marlin kernels serve every M from
+ * the same repacked tensor, quantization/gptq.py:214-228, gptq_marlin.py:296-330 -- spare HBM is KV blocks,
+ * worker/cache_engine.py:66-86).  The strip-major copy stays, the [K/8, N] original goes:
+ *   aphro_wna16_strip_unrelayout   the permutation backwards (strip-major -> [K/8, N]; out != strip), for kernels that do not
+ *                                  read the strip-major order;
+ *   aphro_wna16_strip_geometry     geom[5] = {waves, 128-k segments per wave, 64-column passes, 16-column remainder units,
+ *                                  K slices} of the strip-major order for (M class, N, K, groups); 1 = served, 0 = none;
+ *   aphro_wna16_gemm_large_strip   aphro_wna16_gemm_large (silu == 0) / aphro_wna16_gemm_large_silu (silu != 0) with
+ *                                  q_weight_strip = aphro_wna16_strip_relayout's output for the M class strip_m (32): the
+ *                                  eight-phase plans address the pieces in place (same loads, same bits), the others rebuild
+ *                                  [K/8, N] in the workspace (aphro_wna16_gemm_large_strip_workspace_bytes).
+ * csrc/wna16_gemm_resident.hip, csrc/wna16_gemm_large.hip. */
+int aphro_wna16_strip_unrelayout(const uint32_t* strip, uint32_t* out, int64_t M, int64_t N, int64_t K,
+                                 int64_t groups, void* stream);
+int aphro_wna16_strip_geometry(int64_t M, int64_t N, int64_t K, int64_t groups, int* geom);
+size_t aphro_wna16_gemm_large_strip_workspace_bytes(int64_t M, int64_t N, int64_t K, int64_t groups, int dtype, int64_t strip_m);
+int aphro_wna16_gemm_large_strip(const void* a, const uint32_t* q_weight_strip, const uint32_t* qzeros, const void* scales,
+                                 void* c, void* workspace, size_t workspace_bytes, int64_t M, int64_t N, int64_t K,
+                                 int64_t groups, int64_t lda, int zero_offset, int dtype, int silu, int64_t strip_m,
+                                 void* stream);
 
 /* The op-level decode GEMM (`_C::gptq_gemm` / `_C::awq_gemm` at M <= 32, torch_bindings.cpp:229-243; the role of
  * gemm_half_q_half_gptq_4bit_kernel, q_gemm.cu:190-326, which also reads row-major `a` and writes [M, N] in one launch) in
