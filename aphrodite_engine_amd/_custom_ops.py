@@ -561,7 +561,7 @@ def wna16_strip_unrelayout(strip: torch.Tensor, m: int, groups: int) -> torch.Te
 def wna16_gemm_large_strip(a: torch.Tensor, strip: torch.Tensor, qzeros: torch.Tensor, scales: torch.Tensor,
                            zero_offset: int, silu: bool = False, strip_m: int = 32) -> torch.Tensor:
     """_wna16_large / wna16_gemm_large_silu on the STRIP-MAJOR copy of the weights (wna16_strip_relayout(qweight, strip_m,
-    groups)): the eight-phase plans address its 16-byte pieces in place, the other plans rebuild [K/8, N] in the workspace.
+    groups)): every plan of the tile machine addresses its 16-byte pieces in place.
     Same bits as the [K/8, N] entries (csrc/wna16_gemm_large.hip, Wna16LargeParams::strip)."""
     _require_cuda(a, strip, qzeros, scales)
     m, k = a.shape

@@ -343,6 +343,17 @@ __global__ __launch_bounds__(WM * WN * 64) void wna16_gemm_large_kernel(Wna16Lar
   // B tile: 8 packed rows x BN dwords = BN * 32 bytes; one DMA instruction = 1 KiB = 256 dwords
   constexpr int B_INSTR = B_STAGE / 1024;
   const int b_row_bytes = p.N * 4;
+  // strip-major weights (Wna16LargeParams::strip): the lane's column is the same in every instruction of the tile (256 % BN
+  // == 0) -- its column part of the address and its row multiplier once per segment, the row part per instruction
+  uint32_t st_colbase = 0, st_mult = 0;
+  if (!WFP8 && p.strip) {
+    const int cw = 64 * p.st_np4 + 16 * p.st_rem;
+    const int col = n0 + (lane * 4) % BN, strip = col / cw, cin = col - strip * cw;
+    const bool p4 = cin < 64 * p.st_np4;
+    st_colbase = (uint32_t)(strip * p.st_nwv) * p.st_wave_dw +
+                 (p4 ? (uint32_t)(cin >> 6) * p.st_nseg * 1024u + (cin & 63) : (uint32_t)p.st_np4 * p.st_nseg * 1024u + (cin - 64 * p.st_np4));
+    st_mult = p4 ? 4u : (uint32_t)p.st_rem;
+  }
   auto stage = [&](int st, int kt) {
     unsigned char* sa = smem + st * STAGE;
 #pragma unroll
@@ -366,6 +377,14 @@ __global__ __launch_bounds__(WM * WN * 64) void wna16_gemm_large_kernel(Wna16Lar
         // dword index d = i * 256 + 4 * lane .. +3 of the [8][BN] tile
         const int d = i * 256 + lane * 4;
         const int row = d / BN, col = d % BN;
+        if (p.strip) {
+          const uint32_t ra_ = (uint32_t)(k_begin / 8 + kt * 8 + row), seg = ra_ >> 4;
+          const uint32_t kw = (seg * p.st_inv_nseg) >> 16, sg = seg - kw * (uint32_t)p.st_nseg;
+          const uint32_t ky = (kw * p.st_inv_nwv) >> 16, wv = kw - ky * (uint32_t)p.st_nwv;
+          const uint32_t off = (ky * (uint32_t)(p.st_S * p.st_nwv) + wv) * p.st_wave_dw + st_colbase +
+                               st_mult * (256u * sg + 64u * (ra_ & 3u) + 16u * ((ra_ >> 2) & 3u));
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void_ptr)(sa + A_STAGE + i * 1024), 16, (int)(off * 4u), 0, 0, 0);
+        } else
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void_ptr)(sa + A_STAGE + i * 1024), 16,
                                                  (n0 + col) * 4 + row * b_row_bytes, (k_begin / 8 + kt * 8) * b_row_bytes, 0, 0);
       }
@@ -1013,10 +1032,8 @@ static int large_bind_scratch(Wna16LargeParams& p, const LargePlan& pl, char* ws
 }
 
 extern "C" int aphro_wna16_strip_geometry(int64_t M, int64_t N, int64_t K, int64_t groups, int* geom);      // wna16_gemm_resident.hip
-extern "C" int aphro_wna16_strip_unrelayout(const uint32_t* strip, uint32_t* out, int64_t M, int64_t N, int64_t K, int64_t groups, void* stream);
 
-// Plans that read the strip-major copy in place: the eight-phase kernel (fused and two-pass form).  The others get the
-// [K/8, N] order back in the workspace first (aphro_wna16_strip_unrelayout: one more pass over the packed weights).
+// (the eight-phase schedule on the 256 x 256 stream-K tile from 32 K tiles per output tile up; APHRO_WNA16_LARGE_8PHASE=0/1 forces)
 static bool large_eight(const LargePlan& pl, int64_t K) {
   const int eight = knobs().wna16_large_8phase >= 0 ? knobs().wna16_large_8phase : (K >= 2048 ? 1 : 0);
   return pl.wm == 2 && pl.wn == 4 && pl.streamk && eight;
@@ -1027,7 +1044,7 @@ static size_t large_workspace_bytes(int64_t M, int64_t N, int64_t K, int64_t gro
   const LargePlan pl = large_plan(M, N, K, K / groups);
   size_t b = dtype == APHRO_BF16 ? ((size_t)M * K * 2 + 255) / 256 * 256 : 0;
   if (large_two_pass(pl, M, N, K, K / groups)) b += ((size_t)N * K * 2 + 255) / 256 * 256;      // f16 W^T of the two-pass form
-  if (strip_m > 0 && !large_eight(pl, K)) b += ((size_t)(K / 8) * N * 4 + 255) / 256 * 256;    // the [K/8, N] order, rebuilt
+  (void)strip_m;              // (every plan addresses the strip-major copy in place: nothing is rebuilt)
   return b + large_scratch_bytes(pl, M, N);
 }
 
@@ -1089,25 +1106,17 @@ static int wna16_gemm_large_impl(const void* a, const uint32_t* q_weight, const 
     int geom[5];
     APHRO_CHECK(aphro_wna16_strip_geometry(strip_m, N, K, groups, geom) == 1,
                 "wna16_gemm_large_strip: no strip-major form for M class %d, N=%ld, K=%ld, groups=%ld", strip_m, (long)N, (long)K, (long)groups);
-    if (large_eight(pl, K)) {
-      p.strip = 1;
-      p.st_nwv = geom[0]; p.st_nseg = geom[1]; p.st_np4 = geom[2]; p.st_rem = geom[3];
-      const int cw = 64 * p.st_np4 + 16 * p.st_rem;
-      p.st_S = (int)(N / cw);
-      p.st_wave_dw = (uint32_t)(p.st_nseg * 256 * (4 * p.st_np4 + p.st_rem));
-      p.st_inv_nseg = (65536u + p.st_nseg - 1) / p.st_nseg;
-      p.st_inv_nwv = (65536u + p.st_nwv - 1) / p.st_nwv;
-      const uint32_t segs = (uint32_t)(K / 128) + 1;       // (+ 1: a clamped tile past the range is never formed, the bound is slack)
-      for (uint32_t x = 0; x < segs; ++x)
-        APHRO_CHECK(((x * p.st_inv_nseg) >> 16) == x / p.st_nseg && ((x * p.st_inv_nwv) >> 16) == x / p.st_nwv,
-                    "wna16_gemm_large_strip: multiply-shift division fails at %u (nseg %d, nwv %d)", x, p.st_nseg, p.st_nwv);
-    } else {
-      // a plan that reads [K/8, N]: the permutation backwards into the workspace, then as ever
-      uint32_t* qw_rm = (uint32_t*)ws;
-      if (int rcu = aphro_wna16_strip_unrelayout(q_weight, qw_rm, strip_m, N, K, groups, stream)) return rcu;
-      p.qw = q_weight = qw_rm;
-      ws += ((size_t)(K / 8) * N * 4 + 255) / 256 * 256;
-    }
+    p.strip = 1;
+    p.st_nwv = geom[0]; p.st_nseg = geom[1]; p.st_np4 = geom[2]; p.st_rem = geom[3];
+    const int cw = 64 * p.st_np4 + 16 * p.st_rem;
+    p.st_S = (int)(N / cw);
+    p.st_wave_dw = (uint32_t)(p.st_nseg * 256 * (4 * p.st_np4 + p.st_rem));
+    p.st_inv_nseg = (65536u + p.st_nseg - 1) / p.st_nseg;
+    p.st_inv_nwv = (65536u + p.st_nwv - 1) / p.st_nwv;
+    const uint32_t segs = (uint32_t)(K / 128) + 1;       // (+ 1: a clamped tile past the range is never formed, the bound is slack)
+    for (uint32_t x = 0; x < segs; ++x)
+      APHRO_CHECK(((x * p.st_inv_nseg) >> 16) == x / p.st_nseg && ((x * p.st_inv_nwv) >> 16) == x / p.st_nwv,
+                  "wna16_gemm_large_strip: multiply-shift division fails at %u (nseg %d, nwv %d)", x, p.st_nseg, p.st_nwv);
   }
   if (large_two_pass(pl, M, N, K, gs)) {
     // pass 1: the weights dequantised once into f16 W^T [N, K] (same numerics as the in-loop dequantisation: same bits out)
@@ -1149,8 +1158,8 @@ extern "C" int aphro_wna16_gemm_large(const void* a, const uint32_t* q_weight, c
 // silu_and_mul(a . dequant(W)) with the GEMM result rounded to the dtype first (the bits of aphro_wna16_gemm_large followed by
 // aphro_silu_and_mul_interleaved).  1 if the shape is served (not K-sliced), else 0: aphro_wna16_gemm_large_silu_supported.
 // aphro_wna16_gemm_large / aphro_wna16_gemm_large_silu (silu != 0) on the STRIP-MAJOR copy of the weights
-// (aphro_wna16_strip_relayout for the M class strip_m, normally 32): the eight-phase plans read it in place -- same loads,
-// other addresses, same bits -- the others rebuild the [K/8, N] order in the workspace first.  For a model that keeps one
+// (aphro_wna16_strip_relayout for the M class strip_m, normally 32): every plan reads it in place -- same loads, other
+// addresses, same bits.  For a model that keeps one
 // copy of each matrix resident (the one its decode kernels stream).
 extern "C" int aphro_wna16_gemm_large_strip(const void* a, const uint32_t* q_weight_strip, const uint32_t* qzeros, const void* scales,
                                             void* c, void* workspace, size_t workspace_bytes, int64_t M, int64_t N, int64_t K,

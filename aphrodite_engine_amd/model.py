@@ -288,8 +288,8 @@ class LlamaDecoderLayer(nn.Module):
           * <= 32 rows: the fused decode step as before (it only ever read the strip-major copies);
           * 33..64 rows: the fused step on two 32-row halves of the stream kernels (what APHRO_DECODE_ROW_HALVES=1 selects)
             where every projection has a stream plan, else op by op;
-          * prompt-sized M: the eight-phase kernel / the dequantise-transpose pass address the strip-major pieces in place
-            (ops.wna16_gemm_large_strip: same loads, same bits); any other plan rebuilds [K/8, N] in its workspace.
+          * prompt-sized M: the tile machines / the dequantise-transpose pass address the strip-major pieces in place
+            (ops.wna16_gemm_large_strip: same loads, same bits).
         TP 1, dense, bias-free layers only (the TP / sparse steps run the round-2 kernels on [K/8, N]).  Returns the bytes
         released; restore_op_level_layouts undoes it."""
         if self.one_copy or self.tp != 1 or self.is_moe or self.has_bias or switch("APHRO_WEIGHTS_TWO_COPIES"):

@@ -701,9 +701,9 @@ int aphro_wna16_strip_relayout(const uint32_t* q_weight, uint32_t* out, int64_t 
  *   aphro_wna16_strip_geometry     geom[5] = {waves, 128-k segments per wave, 64-column passes, 16-column remainder units,
  *                                  K slices} of the strip-major order for (M class, N, K, groups); 1 = served, 0 = none;
  *   aphro_wna16_gemm_large_strip   aphro_wna16_gemm_large (silu == 0) / aphro_wna16_gemm_large_silu (silu != 0) with
- *                                  q_weight_strip = aphro_wna16_strip_relayout's output for the M class strip_m (32): the
- *                                  eight-phase plans address the pieces in place (same loads, same bits), the others rebuild
- *                                  [K/8, N] in the workspace (aphro_wna16_gemm_large_strip_workspace_bytes).
+ *                                  q_weight_strip = aphro_wna16_strip_relayout's output for the M class strip_m (32): every
+ *                                  plan addresses the 16-byte pieces in place (same loads, same bits; workspace:
+ *                                  aphro_wna16_gemm_large_strip_workspace_bytes = the [K/8, N] entry's).
  * csrc/wna16_gemm_resident.hip, csrc/wna16_gemm_large.hip. */
 int aphro_wna16_strip_unrelayout(const uint32_t* strip, uint32_t* out, int64_t M, int64_t N, int64_t K,
                                  int64_t groups, void* stream);
