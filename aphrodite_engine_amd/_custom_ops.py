@@ -599,7 +599,12 @@ def wna16_linear_strip(a: torch.Tensor, strip: torch.Tensor, qzeros: torch.Tenso
                           for m0 in range(0, m, 32)], 0)
     if large:
         return wna16_gemm_large_strip(a, strip, qzeros, scales, zero_offset, strip_m=strip_m)
-    return _wna16(a, wna16_strip_unrelayout(strip, strip_m, groups), qzeros, scales, None, zero_offset)
+    qweight = wna16_strip_unrelayout(strip, strip_m, groups)
+    if m >= GPTQ_DEQUANT_MIN_M:         # gptq_gemm's own rule where the tile machine does not take the call
+        _library_fallback("wna16_linear_strip", f"M={m} N={n} K={k}: " + ("APHRO_WNA16_NO_LARGE is set" if switch("APHRO_WNA16_NO_LARGE")
+                          else "shape not tiled by wna16_gemm_large") + " (strip_unrelayout + gptq_dequant + matmul)")
+        return torch.matmul(a, gptq_dequant(qweight, qzeros, scales, None, True, 4, zero_offset))
+    return _wna16(a, qweight, qzeros, scales, None, zero_offset)
 
 
 def wna16_mid_ok(m: int, n: int, k: int, groups: int) -> bool:

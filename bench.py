@@ -135,9 +135,12 @@ def build(args, device):
         # load-time relayout: SiluAndMul + pack run in the gate_up GEMM epilogue
         for layer in model.layers:
             layer.enable_fused_silu(args.batch, keep_original=False)
-            if not getattr(args, "two_copies", False):
-                # ONE resident copy of each int4 matrix: the strip-major order the decode kernels stream (the prompt-sized
-                # kernels address it in place) -- TP 1 dense layers; a no-op elsewhere (model.DecoderLayer.enable_one_copy)
+        if not getattr(args, "two_copies", False):
+            # ONE resident copy of each int4 matrix: the strip-major order the decode kernels stream (the prompt-sized
+            # kernels address it in place) -- TP 1 dense layers; a no-op elsewhere (model.DecoderLayer.enable_one_copy).
+            # (after ALL layers have their decode copies: released layer by layer, the allocator hands layer i's [K/8, N]
+            #  blocks to layer i + 1's strip-major copies)
+            for layer in model.layers:
                 layer.enable_one_copy()
     if args.quant.startswith("fp8") and args.batch <= 32:
         for layer in model.layers:
@@ -595,6 +598,7 @@ def prefill_e2e_section(T=8192, library=True, which=("int4", "fp8")):
         model.init_synthetic(dev, seed=0)
         for layer in model.layers:      # the layouts the engine adapter leaves behind (reference_model._finish): ONE interleaved
             layer.enable_fused_silu(32, keep_original=False)      # gate_up copy -> SiluAndMul rides in the prefill GEMM's epilogue
+        for layer in model.layers:
             layer.enable_one_copy()         # ... and only the strip-major copy of every int4 matrix resident, as in the headline
         nblk = (T + BS - 1) // BS
         caches = M.make_kv_caches(cfg, nblk, BS, torch.float16, kv, dev, fill=False)
@@ -1145,7 +1149,8 @@ def main():
             if not os.environ.get("APHRO_NO_FUSED_SILU"):
                 for layer in model.layers:
                     layer.enable_fused_silu(args.batch, keep_original=False)
-                    if not getattr(args, "two_copies", False):
+                if not getattr(args, "two_copies", False):
+                    for layer in model.layers:
                         layer.enable_one_copy()
         active_frac = 1.0
         if cfg.num_local_experts:
