@@ -294,18 +294,13 @@ class LlamaDecoderLayer(nn.Module):
         released; restore_op_level_layouts undoes it."""
         if self.one_copy or self.tp != 1 or self.is_moe or self.has_bias or switch("APHRO_WEIGHTS_TWO_COPIES"):
             return 0
-        # The strip-major words are COPIED INTO the parameter's own storage and the later-allocated strip tensor is what goes:
-        # the parameters keep the addresses the loader gave them, and what returns to the allocator is the tail of the
-        # load-time allocations, not 4 holes per layer in the middle of them (measured, profiles/r6_one_copy.txt: with the
-        # [K/8, N] blocks released instead, kernels launched on memory allocated afterwards ran 3-15 % slower)
         freed = 0
         for name in ("qkv_proj", "o_proj", "down_proj"):
             lin, st = getattr(self, name), self.strip.get(name)
             if st is None or lin.fast_params() is None or getattr(lin, "qweight_strip_major", False):
                 continue
             freed += lin.qweight.numel() * 4
-            lin.qweight.data.copy_(st)
-            self.strip[name] = lin.qweight.data
+            lin.qweight.data = st
             lin.qweight_strip_major = True
             if getattr(lin, "qweight_strip", None) is not None:
                 lin.qweight_strip = None
@@ -313,10 +308,9 @@ class LlamaDecoderLayer(nn.Module):
         if self.gate_up_strip is not None and self.gate_up_interleaved is not None and not self.gate_up_keep_original:
             _, qz, sc, zo = self.gate_up_interleaved
             freed += lin.qweight.numel() * 4
-            lin.qweight.data.copy_(self.gate_up_strip)
+            lin.qweight.data = self.gate_up_strip
             lin.qweight_strip_major = True
-            self.gate_up_strip = lin.qweight.data
-            self.gate_up_interleaved = (lin.qweight.data, qz, sc, zo)       # ([0]: shape only -- the words are strip-major)
+            self.gate_up_interleaved = (self.gate_up_strip, qz, sc, zo)     # ([0]: shape only -- the words are strip-major)
         self.one_copy = freed > 0
         return freed
 

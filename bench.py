@@ -146,7 +146,8 @@ def build(args, device):
         for layer in model.layers:
             layer.enable_fp8_strips(args.batch)     # load-time relayout for the resident W8A8 decode GEMM
     torch.cuda.synchronize()
-    torch.cuda.empty_cache()
+    torch.cuda.empty_cache()        # (also: no big cached free blocks for the step's small hot buffers to scatter into,
+                                    #  profiles/r6_one_copy.txt)
     # everything the model keeps in HBM (every layout copy of every matrix, embedding, lm_head, rotary table): the footprint
     # a serving engine pays, next to the one-copy algorithmic bytes of the roofline
     model.weight_bytes_resident = int(torch.cuda.memory_allocated(device) - mem0)
@@ -1117,6 +1118,28 @@ def main():
         ctx_end = int(loop.meta.seq_lens_tensor[0].item())
         ctx_mean_end = float(loop.meta.seq_lens_tensor.float().mean().item())
         ctx_mean_start = loop.ctx_sum0 / args.batch
+        active_frac = 1.0
+        if cfg.num_local_experts:
+            # experts the decode step really routes to (one more eager step with the routing recorded)
+            for layer in model.layers:
+                layer.experts.record_routing = True
+            loop.step()
+            torch.cuda.synchronize()
+            active_frac = sum(int(torch.unique(l.experts.last_topk_ids).numel()) for l in model.layers) \
+                / (len(model.layers) * cfg.num_local_experts)
+            for layer in model.layers:
+                layer.experts.record_routing = False
+        ar_info = None
+        if tp > 1:
+            if overlap is not None:
+                D.enable_all_reduce_overlap(device, enabled=False)     # measure the bare collective
+            try:
+                ar_info = all_reduce_section(args, model, device, ca)
+            except Exception as e:
+                ar_info = {"error": repr(e)[:200]}
+        roof = roofline_section(model, loop, args) if rank == 0 else None
+        # (the per-kernel section above runs on the allocations the timed step ran on; the op-by-op leg below releases and
+        #  rebuilds every decode layout, which moves them -- round 6, profiles/r6_one_copy.txt)
         # ---- the same workload on the OP-BY-OP path: what a reference LlamaDecoderLayer (modeling/models/llama.py:234,
         # quant_method.apply -> ops.gptq_gemm, quantization/gptq.py:230-243; Attention.forward -> ops.reshape_and_cache +
         # ops.paged_attention_*) gets through the plugin without adopting forward_decode_fused: one launch per reference op
@@ -1152,26 +1175,8 @@ def main():
                 if not getattr(args, "two_copies", False):
                     for layer in model.layers:
                         layer.enable_one_copy()
-        active_frac = 1.0
-        if cfg.num_local_experts:
-            # experts the decode step really routes to (one more eager step with the routing recorded)
-            for layer in model.layers:
-                layer.experts.record_routing = True
-            loop.step()
-            torch.cuda.synchronize()
-            active_frac = sum(int(torch.unique(l.experts.last_topk_ids).numel()) for l in model.layers) \
-                / (len(model.layers) * cfg.num_local_experts)
-            for layer in model.layers:
-                layer.experts.record_routing = False
-        ar_info = None
-        if tp > 1:
-            if overlap is not None:
-                D.enable_all_reduce_overlap(device, enabled=False)     # measure the bare collective
-            try:
-                ar_info = all_reduce_section(args, model, device, ca)
-            except Exception as e:
-                ar_info = {"error": repr(e)[:200]}
-        roof = roofline_section(model, loop, args) if rank == 0 else None
+                torch.cuda.synchronize()
+                torch.cuda.empty_cache()    # (the [K/8, N] blocks of the op-by-op leg go back to the driver, as after build_model)
 
     line = None
     if rank == 0:
