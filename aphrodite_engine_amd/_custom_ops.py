@@ -978,10 +978,18 @@ def wna16_gemm_mid_ksplit(m: int, n: int, k: int, groups: int) -> int:
     return int(_lib.lib().aphro_wna16_gemm_mid_ksplit(m, n, k, groups))
 
 
+def _mid_packed_call(lib, strip_m: int, *args):
+    """aphro_wna16_gemm_mid_packed, or its strip-major form when ``strip_m`` > 0 (args: ..., dtype, stream)."""
+    if strip_m:
+        return lib.aphro_wna16_gemm_mid_packed_strip(*args[:-1], strip_m, args[-1])
+    return lib.aphro_wna16_gemm_mid_packed(*args)
+
+
 def wna16_gemm_mid_packed(a_packed: torch.Tensor, m: int, k: int, qweight: torch.Tensor, qzeros: torch.Tensor,
-                          scales: torch.Tensor, zero_offset: int, partials: bool = False):
+                          scales: torch.Tensor, zero_offset: int, partials: bool = False, strip_m: int = 0):
     """wna16_gemm_packed for 33..64 rows on the one-pass MFMA kernel (csrc/wna16_gemm_mid.hip) -- same packed
-    activations in, same conventions out: partials=True -> (fp32 slabs [S, M, N], S) for a fused consumer."""
+    activations in, same conventions out: partials=True -> (fp32 slabs [S, M, N], S) for a fused consumer.
+    ``strip_m`` > 0: ``qweight`` is the strip-major copy laid out for that M class (the only resident one)."""
     lib = _lib.lib()
     n = qweight.shape[1]
     groups = scales.shape[0]
@@ -990,29 +998,29 @@ def wna16_gemm_mid_packed(a_packed: torch.Tensor, m: int, k: int, qweight: torch
         raise RuntimeError(f"wna16_gemm_mid_packed: shape M={m} N={n} K={k} not served")
     if partials:
         slabs = torch.empty((ks, m, n), dtype=torch.float32, device=qweight.device)
-        check(lib.aphro_wna16_gemm_mid_packed(a_packed.data_ptr(), qweight.data_ptr(), qzeros.data_ptr(), scales.data_ptr(),
-                                              None, slabs.data_ptr(), slabs.numel() * 4, None, m, n, k, groups,
-                                              zero_offset, _dt(scales), _stream()), "wna16_gemm_mid_packed")
+        check(_mid_packed_call(lib, strip_m, a_packed.data_ptr(), qweight.data_ptr(), qzeros.data_ptr(), scales.data_ptr(),
+                               None, slabs.data_ptr(), slabs.numel() * 4, None, m, n, k, groups,
+                               zero_offset, _dt(scales), _stream()), "wna16_gemm_mid_packed")
         return slabs, ks
     if ks > 1:
-        slabs, _ = wna16_gemm_mid_packed(a_packed, m, k, qweight, qzeros, scales, zero_offset, partials=True)
+        slabs, _ = wna16_gemm_mid_packed(a_packed, m, k, qweight, qzeros, scales, zero_offset, partials=True, strip_m=strip_m)
         return slabs.sum(0).to(scales.dtype)
     out = torch.empty((m, n), dtype=scales.dtype, device=qweight.device)
-    check(lib.aphro_wna16_gemm_mid_packed(a_packed.data_ptr(), qweight.data_ptr(), qzeros.data_ptr(), scales.data_ptr(),
-                                          out.data_ptr(), None, 0, None, m, n, k, groups, zero_offset, _dt(scales),
-                                          _stream()), "wna16_gemm_mid_packed")
+    check(_mid_packed_call(lib, strip_m, a_packed.data_ptr(), qweight.data_ptr(), qzeros.data_ptr(), scales.data_ptr(),
+                           out.data_ptr(), None, 0, None, m, n, k, groups, zero_offset, _dt(scales),
+                           _stream()), "wna16_gemm_mid_packed")
     return out
 
 
 def wna16_gemm_mid_silu_pack(a_packed: torch.Tensor, m: int, k: int, qweight: torch.Tensor, qzeros: torch.Tensor,
-                             scales: torch.Tensor, zero_offset: int) -> torch.Tensor:
+                             scales: torch.Tensor, zero_offset: int, strip_m: int = 0) -> torch.Tensor:
     """wna16_gemm_silu_pack for 33..64 rows: gate_up GEMM (interleaved columns) + SiluAndMul + pack in one launch."""
     lib = _lib.lib()
     n = qweight.shape[1]
     out = torch.empty(lib.aphro_wna16_packed_a_bytes(m, n // 2) // 2, dtype=torch.float16, device=qweight.device)
-    check(lib.aphro_wna16_gemm_mid_packed(a_packed.data_ptr(), qweight.data_ptr(), qzeros.data_ptr(), scales.data_ptr(),
-                                          None, None, 0, out.data_ptr(), m, n, k, scales.shape[0], zero_offset,
-                                          _dt(scales), _stream()), "wna16_gemm_mid_silu_pack")
+    check(_mid_packed_call(lib, strip_m, a_packed.data_ptr(), qweight.data_ptr(), qzeros.data_ptr(), scales.data_ptr(),
+                           None, None, 0, out.data_ptr(), m, n, k, scales.shape[0], zero_offset,
+                           _dt(scales), _stream()), "wna16_gemm_mid_silu_pack")
     return out
 
 

@@ -101,6 +101,7 @@ SIGNATURES = {
     "aphro_wna16_strip_relayout": (I, [P, P, L, L, L, L, P]),
     "aphro_wna16_strip_unrelayout": (I, [P, P, L, L, L, L, P]),
     "aphro_wna16_strip_geometry": (I, [L, L, L, L, P]),
+    "aphro_wna16_gemm_mid_packed_strip": (I, [P, P, P, P, P, P, Z, P, L, L, L, L, I, I, L, P]),
     "aphro_wna16_gemm_large_strip_workspace_bytes": (Z, [L, L, L, L, I, L]),
     "aphro_wna16_gemm_large_strip": (I, [P, P, P, P, P, P, Z, L, L, L, L, L, I, I, I, L, P]),
     "aphro_wna16_gemm_rowmajor_supported": (I, [L, L, L, L, I]),

@@ -18,6 +18,7 @@
 //   * int4 -> f16 in registers with the reference's numerics (q_gemm.cu:1394-1434): (q - z) exact through the 1024 + q
 //     trick, one rounding in the multiply by the group scale.
 #include "common.h"
+#include "wna16_strip.h"
 
 #ifndef MID_ABL      // timing experiments only (tools/mid_ablate.sh): 1 no A loads, 2 no W loads, 4 no MFMA, 8 no dequant,
                      // 16 no K reduction / store (one dword per lane instead), 32 no K loop at all, 64 no prologue loads
@@ -45,6 +46,7 @@ struct Wna16MidParams {
   int mtiles;             // 16-row m-tiles of that buffer = ceil(M / 16)
   int force_partial;      // write the fp32 slab(s) even with one K slice (the consumer kernel sums them)
   uint16_t* act_packed;   // != NULL: SiluAndMul + pack epilogue (interleaved gate / up columns) into the same format
+  Wna16StripGeom strip;   // .on: qw is the strip-major copy of the <= 32-row kernels, the only resident one (wna16_strip.h)
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t mid_rsrc(const void* base, uint32_t bytes) {
@@ -188,8 +190,15 @@ __global__ __launch_bounds__(64 * NWK, 2) void wna16_gemm_mid_kernel(Wna16MidPar
   const int ngroups = p.K / p.group_size;
   const __amdgpu_buffer_rsrc_t rs = mid_rsrc(p.sc, (uint32_t)((size_t)ngroups * p.N * 2));
   const __amdgpu_buffer_rsrc_t rz = mid_rsrc(p.qz, (uint32_t)((size_t)ngroups * (p.N >> 3) * 4));
-  const int voff_w = (kh * p.N + n0 + 4 * l31) * 4;     // packed row 2 s + kh, this lane's 4 columns
+  int voff_w = (kh * p.N + n0 + 4 * l31) * 4;           // packed row 2 s + kh, this lane's 4 columns
   const int wstep = 2 * p.N * 4;
+  uint32_t st_mult4 = 0;                                // strip-major weights: the lane's column part + the u bit of its row (kh)
+  if (p.strip.on) {
+    uint32_t mult;
+    const uint32_t cb = wna16_strip_col(p.strip, n0 + 4 * l31, mult);
+    voff_w = (int)((cb + mult * 64u * (uint32_t)kh) * 4u);
+    st_mult4 = mult * 4u;
+  }
   // ADEC: chunk (m, k8 = 2 s + kh) sits in block ((s / 8) * 4 + 2 (s % 2) + kh, m / 16), lane ((s % 8) / 2, m % 16)
   const int voff_a = ADEC ? (kh * p.mtiles + (l31 >> 4)) * 1024 + (l31 & 15) * 16 : lane * 16;
   constexpr int astep = MB * 1024;
@@ -214,7 +223,14 @@ __global__ __launch_bounds__(64 * NWK, 2) void wna16_gemm_mid_kernel(Wna16MidPar
     sraw = __builtin_amdgcn_raw_buffer_load_b64(rs, voff_s, grp * p.N * 2, 0);
     zraw = __builtin_amdgcn_raw_buffer_load_b32(rz, voff_z, grp * (p.N >> 3) * 4, 0);
   };
-  auto load_w = [&](int s) { return __builtin_amdgcn_raw_buffer_load_b128(rw, voff_w, s * wstep, 2); };
+  auto load_w = [&](int s) {
+    if (p.strip.on) {      // packed row 2 s (+ kh in the lane part): chunk and row term are wave-uniform, one v_mad per load
+      uint32_t chunk, R;
+      wna16_strip_row(p.strip, 2u * (uint32_t)s, chunk, R);
+      return __builtin_amdgcn_raw_buffer_load_b128(rw, (int)(st_mult4 * R) + voff_w, (int)(chunk * 4u), 2);
+    }
+    return __builtin_amdgcn_raw_buffer_load_b128(rw, voff_w, s * wstep, 2);
+  };
   auto load_a = [&](int s, int mb) {
     if constexpr (ADEC)
       return __builtin_amdgcn_raw_buffer_load_b128(ra, voff_a + mb * 2048, (((s >> 3) * 4 + 2 * (s & 1)) * p.mtiles) * 1024 + ((s & 7) >> 1) * 256, 0);
@@ -476,7 +492,7 @@ extern "C" int aphro_wna16_gemm_mid(const void* a, const uint32_t* q_weight, con
   p.partial = (float*)((char*)workspace + apk_bytes);
   p.M = (int)M; p.N = (int)N; p.K = (int)K; p.group_size = (int)gs; p.zero_offset = zero_offset;
   p.out_bf16 = dtype == APHRO_BF16; p.scale_bf16 = dtype == APHRO_BF16; p.ksplit = pl.ksplit;
-  p.mtiles = 0; p.force_partial = 0; p.act_packed = nullptr;
+  p.mtiles = 0; p.force_partial = 0; p.act_packed = nullptr; p.strip = Wna16StripGeom{};
   const dim3 grid((unsigned)(N / 128), (unsigned)pl.ksplit);
   int rc;
   if (pl.mb == 1) rc = pl.nwk == 8 ? mid_launch<1, 8>(p, grid, st) : mid_launch<1, 4>(p, grid, st);
@@ -503,10 +519,10 @@ extern "C" int aphro_wna16_gemm_mid_ksplit(int64_t M, int64_t N, int64_t K, int6
   return mid_plan(M, N, K, K / groups).ksplit;
 }
 
-extern "C" int aphro_wna16_gemm_mid_packed(const void* a_packed, const uint32_t* q_weight, const uint32_t* qzeros,
-                                           const void* scales, void* c, void* slabs, size_t slabs_bytes, void* act_packed,
-                                           int64_t M, int64_t N, int64_t K, int64_t groups, int zero_offset, int dtype,
-                                           void* stream) {
+static int mid_packed_impl(const void* a_packed, const uint32_t* q_weight, const uint32_t* qzeros,
+                           const void* scales, void* c, void* slabs, size_t slabs_bytes, void* act_packed,
+                           int64_t M, int64_t N, int64_t K, int64_t groups, int zero_offset, int dtype, int64_t strip_m,
+                           void* stream) {
   hipStream_t st = (hipStream_t)stream;
   APHRO_CHECK(dtype == APHRO_F16 || dtype == APHRO_BF16, "wna16_gemm_mid_packed: dtype must be f16 or bf16");
   APHRO_CHECK(M > 32 && aphro_wna16_gemm_mid_supported(M, N, K, groups), "wna16_gemm_mid_packed: unsupported shape M=%ld N=%ld K=%ld groups=%ld",
@@ -520,6 +536,9 @@ extern "C" int aphro_wna16_gemm_mid_packed(const void* a_packed, const uint32_t*
   p.M = (int)M; p.N = (int)N; p.K = (int)K; p.group_size = (int)gs; p.zero_offset = zero_offset;
   p.out_bf16 = dtype == APHRO_BF16; p.scale_bf16 = dtype == APHRO_BF16; p.ksplit = pl.ksplit;
   p.mtiles = (int)((M + 15) / 16); p.force_partial = 0; p.act_packed = nullptr;
+  p.strip = Wna16StripGeom{};
+  APHRO_CHECK(strip_m == 0 || wna16_strip_fill(p.strip, strip_m, N, K, groups),
+              "wna16_gemm_mid_packed_strip: no strip-major form for M class %ld, N=%ld, K=%ld, groups=%ld", (long)strip_m, (long)N, (long)K, (long)groups);
   if (act_packed != nullptr) {
     APHRO_CHECK(pl.ksplit == 1 && N % 256 == 0, "wna16_gemm_mid_packed: the SiluAndMul form needs one K slice and N/2 %% 128 == 0 (N=%ld)", (long)N);
     p.act_packed = (uint16_t*)act_packed;
@@ -531,4 +550,21 @@ extern "C" int aphro_wna16_gemm_mid_packed(const void* a_packed, const uint32_t*
   }
   const dim3 grid((unsigned)(N / 128), (unsigned)pl.ksplit);
   return pl.nwk == 8 ? mid_launch<2, 8, true>(p, grid, st) : mid_launch<2, 4, true>(p, grid, st);
+}
+extern "C" int aphro_wna16_gemm_mid_packed(const void* a_packed, const uint32_t* q_weight, const uint32_t* qzeros,
+                                           const void* scales, void* c, void* slabs, size_t slabs_bytes, void* act_packed,
+                                           int64_t M, int64_t N, int64_t K, int64_t groups, int zero_offset, int dtype,
+                                           void* stream) {
+  return mid_packed_impl(a_packed, q_weight, qzeros, scales, c, slabs, slabs_bytes, act_packed, M, N, K, groups, zero_offset, dtype, 0, stream);
+}
+// The same launch on the STRIP-MAJOR copy of the weights (aphro_wna16_strip_relayout for the M class strip_m, normally 32):
+// every 16-byte weight load takes its strip-major address (wna16_strip.h) -- same loads, same bits.  For a layer that keeps
+// one resident copy of each matrix (model.DecoderLayer.enable_one_copy).
+extern "C" int aphro_wna16_gemm_mid_packed_strip(const void* a_packed, const uint32_t* q_weight_strip, const uint32_t* qzeros,
+                                                 const void* scales, void* c, void* slabs, size_t slabs_bytes, void* act_packed,
+                                                 int64_t M, int64_t N, int64_t K, int64_t groups, int zero_offset, int dtype,
+                                                 int64_t strip_m, void* stream) {
+  APHRO_CHECK(strip_m >= 1 && strip_m <= 64, "wna16_gemm_mid_packed_strip: strip_m=%ld", (long)strip_m);
+  return mid_packed_impl(a_packed, q_weight_strip, qzeros, scales, c, slabs, slabs_bytes, act_packed, M, N, K, groups, zero_offset, dtype,
+                         strip_m, stream);
 }

@@ -286,8 +286,9 @@ class LlamaDecoderLayer(nn.Module):
         32, keep_original=False).  The linear's ``qweight`` parameter then HOLDS the strip-major words (same shape, flag
         ``qweight_strip_major``) and
           * <= 32 rows: the fused decode step as before (it only ever read the strip-major copies);
-          * 33..64 rows: the fused step on two 32-row halves of the stream kernels (what APHRO_DECODE_ROW_HALVES=1 selects)
-            where every projection has a stream plan, else op by op;
+          * 33..64 rows: the MLP weights stay on the one-pass kernel, which takes the strip-major addresses
+            (ops.wna16_gemm_mid_packed(strip_m=32): same bits); qkv / o run two 32-row halves of the stream kernels (what
+            APHRO_DECODE_ROW_HALVES=1 selects) where they have a stream plan, else the layer goes op by op;
           * prompt-sized M: the tile machines / the dequantise-transpose pass address the strip-major pieces in place
             (ops.wna16_gemm_large_strip: same loads, same bits).
         TP 1, dense, bias-free layers only (the TP / sparse steps run the round-2 kernels on [K/8, N]).  Returns the bytes
@@ -607,15 +608,21 @@ class LlamaDecoderLayer(nn.Module):
         # 33..64 rows: the one-pass 32x32x16 MFMA kernel; APHRO_DECODE_ROW_HALVES=1: the stream kernel on two 32-row halves
         # where the layer has the strip-major copies (measured slower on the one-GPU shapes, see enable_fused_silu)
         halves = self._row_halves(m)
+        # one resident copy: the one-pass kernel reads the strip-major words in place (strip_m), so the MLP weights keep it and
+        # only an explicit APHRO_DECODE_ROW_HALVES=1 moves them to the stream kernel's halves
         gu_one = self.one_copy and getattr(self.gate_up_proj, "qweight_strip_major", False)
+        dn_one = self.one_copy and getattr(self.down_proj, "qweight_strip_major", False)
+        asked_halves = halves and switch("APHRO_DECODE_ROW_HALVES") == "1"
         if self.gate_up_interleaved is not None:
             # SiluAndMul + pack run in the GEMM epilogue (interleaved gate/up columns)
             qw, qz, sc, zo = self.gate_up_interleaved
-            if halves and self.gate_up_strip is not None and ops.wna16_resident_ksplit(m, qw.shape[1], h, sc.shape[0]) == 1:
+            gu_mid = mid and ops.wna16_gemm_mid_ksplit(m, qw.shape[1], h, sc.shape[0]) == 1 and qw.shape[1] % 256 == 0
+            if halves and self.gate_up_strip is not None and ops.wna16_resident_ksplit(m, qw.shape[1], h, sc.shape[0]) == 1 \
+                    and not (gu_one and gu_mid and not asked_halves):
                 act_packed = ops.wna16_gemm_resident(packed2, m, h, self.gate_up_strip, qz, sc, zo, mode="silu",
                                                      strip_layout=True)
-            elif mid and not gu_one and ops.wna16_gemm_mid_ksplit(m, qw.shape[1], h, sc.shape[0]) == 1 and qw.shape[1] % 256 == 0:
-                act_packed = ops.wna16_gemm_mid_silu_pack(packed2, m, h, qw, qz, sc, zo)
+            elif gu_mid:
+                act_packed = ops.wna16_gemm_mid_silu_pack(packed2, m, h, qw, qz, sc, zo, strip_m=32 if gu_one else 0)
             elif self.gate_up_strip is not None and m <= 32 and ops.wna16_resident_ksplit(m, qw.shape[1], h, sc.shape[0]) == 1:
                 act_packed = ops.wna16_gemm_resident(packed2, m, h, self.gate_up_strip, qz, sc, zo, mode="silu",
                                                      strip_layout=True)
@@ -643,10 +650,10 @@ class LlamaDecoderLayer(nn.Module):
                 return dar, None
             return tensor_model_parallel_all_reduce(d, prefetch=next_weights), None
         kd = self.down_proj.in_features
-        if mid and not (halves and "down_proj" in self.strip) and not getattr(self.down_proj, "qweight_strip_major", False) \
+        if mid and not ((asked_halves if dn_one else halves) and "down_proj" in self.strip) \
                 and qw.shape[1] * kd >= 2 ** 25 \
                 and ops.wna16_gemm_mid_ksplit(m, qw.shape[1], kd, sc.shape[0]) > 0:
-            down_slabs, _ = ops.wna16_gemm_mid_packed(act_packed, m, kd, qw, qz, sc, zo, partials=True)
+            down_slabs, _ = ops.wna16_gemm_mid_packed(act_packed, m, kd, qw, qz, sc, zo, partials=True, strip_m=32 if dn_one else 0)
         else:
             down_slabs, _ = self._gemm_slabs("down_proj", act_packed, m, kd)
         return None, down_slabs

@@ -293,23 +293,30 @@ def roofline_section(model, loop, args):
                  and ops.wna16_gemm_mid_ksplit(bs, n_out, lin0.in_features, groups) > 0))
 
             # 33..64 rows (round 4): the stream kernel on two 32-row halves where the layer has its strip-major copies
+            # (a layer with ONE resident copy keeps its MLP weights on the one-pass kernel, which reads the strip-major words in
+            #  place; only qkv / o go to the halves -- model.forward_decode_fused)
             halves = layers[0]._row_halves(bs)
-            resident = silu and layers[0].gate_up_strip is not None and (bs <= 32 or halves) \
+            strip_m = 32 if getattr(lin0, "qweight_strip_major", False) else 0
+            mlp_halves = halves and (not strip_m or os.environ.get("APHRO_DECODE_ROW_HALVES") == "1")
+            use_halves = mlp_halves if name in ("gate_up_proj", "down_proj") else halves
+            resident = silu and layers[0].gate_up_strip is not None and (bs <= 32 or use_halves) \
                 and ops.wna16_resident_ksplit(bs, n_out, lin0.in_features, groups) == 1
-            if resident or (halves and name in getattr(layers[0], "strip", {})):
+            if resident or (use_halves and name in getattr(layers[0], "strip", {})):
                 mid = False
 
-            def run_lin(name=name, packed=packed, silu=silu, k=lin0.in_features, mid=mid, resident=resident):
+            def run_lin(name=name, packed=packed, silu=silu, k=lin0.in_features, mid=mid, resident=resident, strip_m=strip_m):
                 for layer in layers:
                     if silu:
                         qw, qz, sc, zo = layer.gate_up_interleaved
                         if resident:      # what forward_decode_fused launches at <= 32 rows
                             ops.wna16_gemm_resident(packed, bs, k, layer.gate_up_strip, qz, sc, zo, mode="silu", strip_layout=True)
+                        elif mid:
+                            ops.wna16_gemm_mid_silu_pack(packed, bs, k, qw, qz, sc, zo, strip_m=strip_m)
                         else:
-                            (ops.wna16_gemm_mid_silu_pack if mid else ops.wna16_gemm_silu_pack)(packed, bs, k, qw, qz, sc, zo)
+                            ops.wna16_gemm_silu_pack(packed, bs, k, qw, qz, sc, zo)
                     elif mid:
                         qw, qz, sc, zo = getattr(layer, name).fast_params()
-                        ops.wna16_gemm_mid_packed(packed, bs, k, qw, qz, sc, zo, partials=True)
+                        ops.wna16_gemm_mid_packed(packed, bs, k, qw, qz, sc, zo, partials=True, strip_m=strip_m)
                     else:
                         layer._gemm_slabs(name, packed, bs, k)      # resident kernel on the strip-major copy where the layer has one
             res_slabs = (not silu) and (not mid) and bs <= 64 and name in getattr(layers[0], "strip", {})

@@ -707,6 +707,13 @@ int aphro_wna16_strip_relayout(const uint32_t* q_weight, uint32_t* out, int64_t 
  * csrc/wna16_gemm_resident.hip, csrc/wna16_gemm_large.hip. */
 int aphro_wna16_strip_unrelayout(const uint32_t* strip, uint32_t* out, int64_t M, int64_t N, int64_t K,
                                  int64_t groups, void* stream);
+/*   aphro_wna16_gemm_mid_packed_strip   aphro_wna16_gemm_mid_packed (33..64 rows, one pass over the weights) with q_weight_strip
+ *                                  = the strip-major copy for the M class strip_m: same loads at strip-major addresses
+ *                                  (csrc/wna16_strip.h), same bits.  csrc/wna16_gemm_mid.hip. */
+int aphro_wna16_gemm_mid_packed_strip(const void* a_packed, const uint32_t* q_weight_strip, const uint32_t* qzeros,
+                                      const void* scales, void* c, void* slabs, size_t slabs_bytes, void* act_packed,
+                                      int64_t M, int64_t N, int64_t K, int64_t groups, int zero_offset, int dtype,
+                                      int64_t strip_m, void* stream);
 int aphro_wna16_strip_geometry(int64_t M, int64_t N, int64_t K, int64_t groups, int* geom);
 size_t aphro_wna16_gemm_large_strip_workspace_bytes(int64_t M, int64_t N, int64_t K, int64_t groups, int dtype, int64_t strip_m);
 int aphro_wna16_gemm_large_strip(const void* a, const uint32_t* q_weight_strip, const uint32_t* qzeros, const void* scales,

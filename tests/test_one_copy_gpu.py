@@ -122,6 +122,25 @@ def test_linear_on_the_strip_major_copy_any_m(ops, M_, K, N):
         assert torch.equal(got, ref)
 
 
+@pytest.mark.parametrize("M_", [33, 48, 64])
+@pytest.mark.parametrize("K,N", [(4096, 28672), (14336, 4096), (4096, 6144), (8192, 7168)])
+def test_one_pass_kernel_on_the_strip_major_copy(ops, M_, K, N):
+    """33..64 rows: wna16_gemm_mid_packed(strip_m=32) == the same launch on [K/8, N], bit for bit -- fp32 slabs, and the
+    SiluAndMul + pack epilogue where the plan has one K slice (4 and 8 K-waves, K-sliced plans)."""
+    qw, qz, sc, g = _weights(K, N, 128, torch.float16, K + N + M_)
+    if ops.wna16_gemm_mid_ksplit(M_, N, K, K // 128) <= 0 or ops.wna16_resident_ksplit(32, N, K, K // 128) <= 0:
+        pytest.skip("shape not served")
+    a = (torch.randn(M_, K, generator=g, device=DEV) * 0.5).to(torch.float16)
+    packed = ops.wna16_pack_a(a)
+    st = ops.wna16_strip_relayout(qw, 32, K // 128)
+    want, ks = ops.wna16_gemm_mid_packed(packed, M_, K, qw, qz, sc, 1, partials=True)
+    got, ks2 = ops.wna16_gemm_mid_packed(packed, M_, K, st, qz, sc, 1, partials=True, strip_m=32)
+    assert ks == ks2 and torch.equal(got, want)
+    if ks == 1 and N % 256 == 0:
+        assert torch.equal(ops.wna16_gemm_mid_silu_pack(packed, M_, K, st, qz, sc, 1, strip_m=32),
+                           ops.wna16_gemm_mid_silu_pack(packed, M_, K, qw, qz, sc, 1))
+
+
 def _tiny_llama3(layers=2, seed=2):
     from aphrodite_engine_amd import model as Mo
     from aphrodite_engine_amd.quantization.gptq import GPTQConfig
