@@ -736,3 +736,22 @@ def test_environment_surface_is_one_table_read_once():
     used = set(re.findall(r'switch\("([A-Z_0-9]+)"\)', pysrc))
     assert used <= set(switches.SWITCHES), used - set(switches.SWITCHES)
     assert not re.findall(r'os\.environ\.get\("APHRO', pysrc)            # the package reads its switches through the registry only
+
+
+def test_lab_patches_apply_to_the_product_sources():
+    """tools/lab_patches/*.patch (the kernels' stamp / ablation branches, kept out of the product sources) still apply to the
+    files they instrument -- a kernel edit that moves a hunk's context is caught here, not when a lab build is next needed."""
+    import glob
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if shutil.which("patch") is None:
+        pytest.skip("no patch(1) in this image")
+    patches = sorted(glob.glob(os.path.join(root, "tools", "lab_patches", "*.patch")))
+    assert patches
+    for pf in patches:
+        target = os.path.join(root, "aphrodite_engine_amd", "csrc", os.path.basename(pf)[:-len(".patch")])
+        assert os.path.exists(target), target
+        with open(pf) as f:
+            r = subprocess.run(["patch", "--dry-run", "-s", "-p0", target], stdin=f, capture_output=True, text=True)
+        assert r.returncode == 0, (os.path.basename(pf), r.stdout[-400:], r.stderr[-400:])
