@@ -581,9 +581,10 @@ def wna16_gemm_large_strip(a: torch.Tensor, strip: torch.Tensor, qzeros: torch.T
 def wna16_linear_strip(a: torch.Tensor, strip: torch.Tensor, qzeros: torch.Tensor, scales: torch.Tensor,
                        zero_offset: int, strip_m: int = 32) -> torch.Tensor:
     """[M, N] = a . dequant(W) for ANY M when the strip-major copy is the only resident copy of W (model.enable_one_copy):
-    <= 32 rows the one-launch decode GEMM; prompt-sized M the tile machine reading the strip-major order in place; in
-    between 32-row passes of the decode GEMM (f16) -- and where none of these serves the call, the [K/8, N] order rebuilt
-    into a transient (one more pass over the packed weights) for the generic kernels."""
+    <= 32 rows the one-launch decode GEMM; prompt-sized M the tile machine reading the strip-major order in place; 33..64 rows
+    on the big matrices the one-pass kernel at strip-major addresses; else 32-row passes of the decode GEMM (f16) -- and where
+    none of these serves the call, the [K/8, N] order rebuilt into a transient (one more pass over the packed weights) for
+    the generic kernels."""
     _require_cuda(a, strip, qzeros, scales)
     m, k = a.shape
     n, groups = scales.shape[1], scales.shape[0]
@@ -592,6 +593,9 @@ def wna16_linear_strip(a: torch.Tensor, strip: torch.Tensor, qzeros: torch.Tenso
     large = wna16_large_ok(m, n, k, groups) and not switch("APHRO_WNA16_NO_LARGE")
     if large and wna16_prefers_large(m, n, k):
         return wna16_gemm_large_strip(a, strip, qzeros, scales, zero_offset, strip_m=strip_m)
+    if wna16_prefers_mid(m, n, k) and wna16_mid_ok(m, n, k, groups) and a.dtype == scales.dtype and not switch("APHRO_WNA16_NO_MID"):
+        # 33..64 rows on the big matrices: ONE pass of the 32x32x16 kernel over the strip-major words (the generic op's own rule)
+        return wna16_gemm_mid_packed(wna16_pack_a(a), m, k, strip, qzeros, scales, zero_offset, strip_m=strip_m)
     if m <= 128 and a.dtype == torch.float16 and wna16_gemm_rowmajor_supported(min(m, 32), n, k, groups, a.dtype):
         if m <= 32:
             return wna16_gemm_rowmajor(a, strip, qzeros, scales, zero_offset, strip_layout=True)

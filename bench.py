@@ -648,7 +648,10 @@ def prefill_e2e_section(T=8192, library=True, which=("int4", "fp8")):
             del model, caches
             torch.cuda.empty_cache()
             return
-        # the library arm: same weights, same process
+        # the library arm: same weights, same process -- on the layouts the loader leaves behind (the [K/8, N] words back in the
+        # parameters: its dequantise kernel reads them directly, no strip-major detour is charged to the library)
+        for layer in model.layers:
+            layer.restore_op_level_layouts()
         saved_env = {k: os.environ.get(k) for k in ("APHRO_WNA16_NO_LARGE", "APHRO_FP8_NO_LARGE")}
         saved_fa = ops.flash_attn_varlen
         try:
