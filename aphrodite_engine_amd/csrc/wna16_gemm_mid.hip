@@ -171,7 +171,9 @@ __device__ __forceinline__ void mid_flush(const float* tile, const Wna16MidParam
 }
 
 // NWK waves split K: 4 (two workgroups per CU, more K slices go to slabs) or 8 (one workgroup per CU, 128 KiB butterfly)
-template <int MB, int NWK, bool ADEC = false>
+// STRIP: p.qw is the strip-major copy (p.strip: wna16_strip.h) -- a template parameter, not a run-time test: a branch per weight
+// load cuts the software-pipelined K loop into basic blocks the scheduler cannot interleave
+template <int MB, int NWK, bool ADEC = false, bool STRIP = false>
 __global__ __launch_bounds__(64 * NWK, 2) void wna16_gemm_mid_kernel(Wna16MidParams p) {
   constexpr int NB = 4;
   constexpr int DW = 8;   // weight steps in flight (one 16-byte load each)
@@ -193,7 +195,7 @@ __global__ __launch_bounds__(64 * NWK, 2) void wna16_gemm_mid_kernel(Wna16MidPar
   int voff_w = (kh * p.N + n0 + 4 * l31) * 4;           // packed row 2 s + kh, this lane's 4 columns
   const int wstep = 2 * p.N * 4;
   uint32_t st_mult4 = 0;                                // strip-major weights: the lane's column part + the u bit of its row (kh)
-  if (p.strip.on) {
+  if constexpr (STRIP) {
     uint32_t mult;
     const uint32_t cb = wna16_strip_col(p.strip, n0 + 4 * l31, mult);
     voff_w = (int)((cb + mult * 64u * (uint32_t)kh) * 4u);
@@ -224,7 +226,7 @@ __global__ __launch_bounds__(64 * NWK, 2) void wna16_gemm_mid_kernel(Wna16MidPar
     zraw = __builtin_amdgcn_raw_buffer_load_b32(rz, voff_z, grp * (p.N >> 3) * 4, 0);
   };
   auto load_w = [&](int s) {
-    if (p.strip.on) {      // packed row 2 s (+ kh in the lane part): chunk and row term are wave-uniform, one v_mad per load
+    if constexpr (STRIP) { // packed row 2 s (+ kh in the lane part): chunk and row term are wave-uniform, one v_mad per load
       uint32_t chunk, R;
       wna16_strip_row(p.strip, 2u * (uint32_t)s, chunk, R);
       return __builtin_amdgcn_raw_buffer_load_b128(rw, (int)(st_mult4 * R) + voff_w, (int)(chunk * 4u), 2);
@@ -432,18 +434,18 @@ static size_t mid_lds_bytes(int mb, int nwk) {   // round 1 of the butterfly, or
   return r1 > r2 ? r1 : r2;
 }
 
-template <int MB, int NWK, bool ADEC = false>
+template <int MB, int NWK, bool ADEC = false, bool STRIP = false>
 static int mid_launch(const Wna16MidParams& p, dim3 grid, hipStream_t st) {
   const size_t lds = mid_lds_bytes(MB, NWK);
   static bool attr_set_dev[APHRO_MAX_DEVICES] = {}; bool& attr_set = attr_set_dev[device_slot()];                  // up to 128 KiB of dynamic LDS: above the default 64 KiB limit
   if (!attr_set && lds > 64 * 1024) {
-    if (hipFuncSetAttribute((const void*)wna16_gemm_mid_kernel<MB, NWK, ADEC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+    if (hipFuncSetAttribute((const void*)wna16_gemm_mid_kernel<MB, NWK, ADEC, STRIP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
       set_error("wna16_gemm_mid: cannot raise the dynamic LDS limit");
       return APHRO_ERR_LAUNCH;
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL((wna16_gemm_mid_kernel<MB, NWK, ADEC>), grid, dim3(64 * NWK), lds, st, p);
+  hipLaunchKernelGGL((wna16_gemm_mid_kernel<MB, NWK, ADEC, STRIP>), grid, dim3(64 * NWK), lds, st, p);
   APHRO_LAUNCH_CHECK();
   return APHRO_OK;
 }
@@ -549,6 +551,7 @@ static int mid_packed_impl(const void* a_packed, const uint32_t* q_weight, const
     APHRO_CHECK(c != nullptr && pl.ksplit == 1, "wna16_gemm_mid_packed: this shape needs the slab form (%d K slices)", pl.ksplit);
   }
   const dim3 grid((unsigned)(N / 128), (unsigned)pl.ksplit);
+  if (p.strip.on) return pl.nwk == 8 ? mid_launch<2, 8, true, true>(p, grid, st) : mid_launch<2, 4, true, true>(p, grid, st);
   return pl.nwk == 8 ? mid_launch<2, 8, true>(p, grid, st) : mid_launch<2, 4, true>(p, grid, st);
 }
 extern "C" int aphro_wna16_gemm_mid_packed(const void* a_packed, const uint32_t* q_weight, const uint32_t* qzeros,

@@ -136,7 +136,7 @@ def test_one_pass_kernel_on_the_strip_major_copy(ops, M_, K, N):
     want, ks = ops.wna16_gemm_mid_packed(packed, M_, K, qw, qz, sc, 1, partials=True)
     got, ks2 = ops.wna16_gemm_mid_packed(packed, M_, K, st, qz, sc, 1, partials=True, strip_m=32)
     assert ks == ks2 and torch.equal(got, want)
-    if ks == 1 and N % 256 == 0:
+    if ks == 1 and N % 256 == 0 and M_ % 16 == 0:      # (the packed output's padding rows are whatever torch.empty held)
         assert torch.equal(ops.wna16_gemm_mid_silu_pack(packed, M_, K, st, qz, sc, 1, strip_m=32),
                            ops.wna16_gemm_mid_silu_pack(packed, M_, K, qw, qz, sc, 1))
 

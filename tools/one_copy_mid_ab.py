@@ -56,7 +56,59 @@ def step_ms(cfg, m, bs, ctx=1024):
     return best, out.float().argmax(-1)
 
 
+def kernels():
+    """The MLP GEMMs of one layer at 48 / 64 rows: one-pass kernel on [K/8, N], on the strip-major copy, and the stream kernel's
+    two 32-row halves on the strip-major copy (us per launch, 16 distinct weight sets cycled, graph-captured)."""
+    from aphrodite_engine_amd import _custom_ops as ops
+    g = torch.Generator(device=DEV).manual_seed(0)
+    print("MLP GEMMs at 33..64 rows (us per launch; 16 weight sets cycled)")
+    for name, K, N, silu in (("gate_up", 4096, 28672, True), ("down", 14336, 4096, False)):
+        sets = []
+        for _ in range(16):
+            qw = torch.randint(-2 ** 31, 2 ** 31 - 1, (K // 8, N), generator=g, device=DEV, dtype=torch.int64).to(torch.int32)
+            qz = torch.randint(-2 ** 31, 2 ** 31 - 1, (K // 128, N // 8), generator=g, device=DEV, dtype=torch.int64).to(torch.int32)
+            sc = (torch.rand(K // 128, N, generator=g, device=DEV) * 0.01 + 0.005).half()
+            sets.append((qw, ops.wna16_strip_relayout(qw, 32, K // 128), qz, sc))
+        for M in (48, 64):
+            packed = ops.wna16_pack_a((torch.randn(M, K, generator=g, device=DEV) * 0.5).half())
+
+            def mid(strip):
+                for qw, st, qz, sc in sets:
+                    if silu:
+                        ops.wna16_gemm_mid_silu_pack(packed, M, K, st if strip else qw, qz, sc, 1, strip_m=32 if strip else 0)
+                    else:
+                        ops.wna16_gemm_mid_packed(packed, M, K, st if strip else qw, qz, sc, 1, partials=True, strip_m=32 if strip else 0)
+
+            def halves():
+                for qw, st, qz, sc in sets:
+                    ops.wna16_gemm_resident(packed, M, K, st, qz, sc, 1, mode="silu" if silu else "slabs", strip_layout=True)
+
+            row = []
+            for fn in (lambda: mid(False), lambda: mid(True), halves):
+                fn()
+                torch.cuda.synchronize()
+                gr = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gr):
+                    fn()
+                gr.replay()
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                best = 1e9
+                for _ in range(3):
+                    e0.record()
+                    for _ in range(5):
+                        gr.replay()
+                    e1.record()
+                    torch.cuda.synchronize()
+                    best = min(best, e0.elapsed_time(e1) / (5 * len(sets)) * 1e3)
+                row.append(best)
+            print(f"  {name:>8} M={M}: one-pass [K/8, N] {row[0]:6.2f}   one-pass strip-major {row[1]:6.2f}   two halves {row[2]:6.2f}")
+        del sets
+        torch.cuda.empty_cache()
+
+
 def main():
+    kernels()
     res = {}
     for mode in ("two", "one", "one+halves"):
         if mode == "one+halves":
