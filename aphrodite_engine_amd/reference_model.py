@@ -169,8 +169,8 @@ class MI355XLlamaForCausalLM(nn.Module):
             # their SiluAndMul): the footprint bench.py measures
             layer.enable_fused_silu(32, keep_original=False)
             # ... of EVERY int4 matrix: the strip-major decode copy stays, the [K/8, N] words go (TP 1 dense layers; prompt-sized
-            # GEMMs address the strip-major pieces in place, 33..64-row decode runs two 32-row halves of the stream kernels --
-            # 5 % of such a step for 3.5 GB of KV blocks on Llama-3-8B; APHRO_WEIGHTS_TWO_COPIES=1 keeps both): below
+            # GEMMs and the one-pass 33..64-row kernel address the strip-major pieces in place -- 1.5-2 % of a 33..64-row step
+            # for 3.5 GB of KV blocks on Llama-3-8B; APHRO_WEIGHTS_TWO_COPIES=1 keeps both): below
             layer.enable_fp8_strips(32)                                        # FP8 checkpoints: strip-major decode copies
         for layer in inner.layers:          # (after every layer has its decode copies: see bench.build_model)
             layer.enable_one_copy()
