@@ -596,11 +596,26 @@ def wna16_linear_strip(a: torch.Tensor, strip: torch.Tensor, qzeros: torch.Tenso
     if wna16_prefers_mid(m, n, k) and wna16_mid_ok(m, n, k, groups) and a.dtype == scales.dtype and not switch("APHRO_WNA16_NO_MID"):
         # 33..64 rows on the big matrices: ONE pass of the 32x32x16 kernel over the strip-major words (the generic op's own rule)
         return wna16_gemm_mid_packed(wna16_pack_a(a), m, k, strip, qzeros, scales, zero_offset, strip_m=strip_m)
-    if m <= 128 and a.dtype == torch.float16 and wna16_gemm_rowmajor_supported(min(m, 32), n, k, groups, a.dtype):
-        if m <= 32:
-            return wna16_gemm_rowmajor(a, strip, qzeros, scales, zero_offset, strip_layout=True)
-        return torch.cat([wna16_gemm_rowmajor(a[m0:m0 + 32], strip, qzeros, scales, zero_offset, strip_layout=True)
-                          for m0 in range(0, m, 32)], 0)
+    if m <= 128:
+        def rows32(x):          # <= 32 rows: the one-launch row-major GEMM (f16), else pack + the resident kernel (bf16 too)
+            if x.dtype == torch.float16 and wna16_gemm_rowmajor_supported(x.shape[0], n, k, groups, x.dtype):
+                return wna16_gemm_rowmajor(x, strip, qzeros, scales, zero_offset, strip_layout=True)
+            ks = wna16_resident_ksplit(x.shape[0], n, k, groups) if x.dtype == scales.dtype else 0
+            if ks <= 0:
+                return None
+            packed = wna16_pack_a(x)
+            if ks == 1:
+                return wna16_gemm_resident(packed, x.shape[0], k, strip, qzeros, scales, zero_offset, mode="out", strip_layout=True)
+            slabs, _ = wna16_gemm_resident(packed, x.shape[0], k, strip, qzeros, scales, zero_offset, mode="slabs", strip_layout=True)
+            return slabs.sum(0).to(x.dtype)
+        parts = []
+        for m0 in range(0, m, 32):
+            part = rows32(a[m0:m0 + 32])
+            if part is None:
+                break
+            parts.append(part)
+        else:
+            return parts[0] if len(parts) == 1 else torch.cat(parts, 0)
     if large:
         return wna16_gemm_large_strip(a, strip, qzeros, scales, zero_offset, strip_m=strip_m)
     qweight = wna16_strip_unrelayout(strip, strip_m, groups)

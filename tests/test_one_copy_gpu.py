@@ -105,19 +105,29 @@ def test_plans_outside_the_eight_phase_kernel_read_it_in_place_too(ops, M_, K, N
     assert torch.equal(ops.wna16_gemm_large_strip(a, st, qz, sc, 1), ops._wna16_large(a, qw, qz, sc, None, 1))
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("M_", [1, 17, 32, 33, 64, 100, 129, 700])
 @pytest.mark.parametrize("K,N", [(4096, 6144), (14336, 4096)])
-def test_linear_on_the_strip_major_copy_any_m(ops, M_, K, N):
+def test_linear_on_the_strip_major_copy_any_m(ops, M_, K, N, dtype):
     """ops.wna16_linear_strip (what a one-copy QuantLinear.forward runs) against gptq_gemm on the original: the same kernels
-    where the same kernel serves both (bit-equal), the GEMMs' own rounding where the K partition differs."""
-    qw, qz, sc, g = _weights(K, N, 128, torch.float16, K + M_)
-    a = (torch.randn(M_, K, generator=g, device=DEV) * 0.5).to(torch.float16)
+    where the same kernel serves both (bit-equal), the GEMMs' own rounding where the K partition differs.  bf16: no row-major
+    one-launch form -- pack + the resident kernel; never the [K/8, N] rebuild on these shapes."""
+    qw, qz, sc, g = _weights(K, N, 128, dtype, K + M_)
+    a = (torch.randn(M_, K, generator=g, device=DEV) * 0.5).to(dtype)
     st = ops.wna16_strip_relayout(qw, 32, K // 128)
-    got = ops.wna16_linear_strip(a, st, qz, sc, 1)
+    calls = []
+    real = ops.wna16_strip_unrelayout
+    ops.wna16_strip_unrelayout = lambda *a_, **k_: (calls.append(1), real(*a_, **k_))[1]
+    try:
+        got = ops.wna16_linear_strip(a, st, qz, sc, 1)
+    finally:
+        ops.wna16_strip_unrelayout = real
+    assert not calls
     want = ops.gptq_gemm(a, qw, qz, sc, torch.empty(0, dtype=torch.int32, device=DEV), True, 4)
-    assert got.shape == want.shape
-    torch.testing.assert_close(got.float(), want.float(), atol=2e-2, rtol=2e-2)
-    if M_ > 128 or M_ <= 32:
+    assert got.shape == want.shape and got.dtype == dtype
+    tol = 2e-2 if dtype == torch.float16 else 6e-2
+    torch.testing.assert_close(got.float(), want.float(), atol=tol, rtol=tol)
+    if dtype == torch.float16 and (M_ > 128 or M_ <= 32):
         ref = ops._wna16_large(a, qw, qz, sc, None, 1) if M_ > 128 else ops.wna16_gemm_rowmajor(a, st, qz, sc, 1, strip_layout=True)
         assert torch.equal(got, ref)
 
