@@ -292,7 +292,8 @@ class LlamaDecoderLayer(nn.Module):
           * prompt-sized M: the tile machines / the dequantise-transpose pass address the strip-major pieces in place
             (ops.wna16_gemm_large_strip: same loads, same bits).
         TP 1, dense, bias-free layers only (the TP / sparse steps run the round-2 kernels on [K/8, N]).  Returns the bytes
-        released; restore_op_level_layouts undoes it."""
+        released; restore_op_level_layouts undoes it (the permutation backwards) -- call it before exporting the parameters:
+        a state_dict taken in between holds the strip-major words."""
         if self.one_copy or self.tp != 1 or self.is_moe or self.has_bias or switch("APHRO_WEIGHTS_TWO_COPIES"):
             return 0
         freed = 0
