@@ -443,6 +443,11 @@ class LlamaDecoderLayer(nn.Module):
                 if self.tp > 1 and rks > 1:
                     self.strip[name] = ops.wna16_strip_relayout(qw, m, g)
                 continue
+            # (round 6) no copy the step never reads: under TP the row-parallel projections run the round-2 kernel on
+            # [K/8, N] (their output is all-reduced, not handed on as slabs), and so does o_proj in front of a sparse MLP --
+            # 14.7 MB per layer of a 70B TP-8 shard (down_proj) that used to sit in HBM unread
+            if (name in ("o_proj", "down_proj") and self.tp > 1) or (name == "o_proj" and self.is_moe):
+                continue
             # <= 32 rows: only where the resident plan keeps the round-2 kernel's K slices (the consumers were tuned to those
             # slab counts); 33..64 rows (two 32-row halves): opt-in, see enable_fused_silu
             if m > 32 and switch("APHRO_DECODE_ROW_HALVES") != "1":

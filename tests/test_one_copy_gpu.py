@@ -227,3 +227,36 @@ def test_one_copy_is_refused_where_the_step_reads_the_row_order(ops):
     assert layer.enable_one_copy() > 0
     assert layer.enable_fused_silu(32, keep_original=False)         # (rebuilding the layouts undoes it first)
     assert not layer.one_copy and not getattr(layer.qkv_proj, "qweight_strip_major", False)
+
+
+def test_tp_shard_keeps_no_copy_its_step_never_reads(ops):
+    """ONE rank of Llama-3-70B at TP 8, layouts for 32 rows: the row-parallel projections (o_proj, down_proj) run the round-2
+    kernel on [K/8, N] under TP -- no strip-major copy is built for them (14.7 MB per layer that used to sit unread); the
+    column-parallel ones keep theirs; the fused decode step still agrees with the op-by-op path."""
+    import dataclasses
+    from aphrodite_engine_amd import distributed as D
+    from aphrodite_engine_amd import model as Mo
+    from aphrodite_engine_amd.quantization.gptq import GPTQConfig
+    D.init_simulated_tensor_parallel(8, 1.0)
+    try:
+        cfg = dataclasses.replace(Mo.LLAMA3_70B, num_hidden_layers=1, vocab_size=1024, max_position_embeddings=2048)
+        with torch.no_grad():
+            m = Mo.LlamaForCausalLM(cfg, GPTQConfig(4, 128, False), torch.float16, "auto").init_synthetic(DEV, seed=4)
+            bs, ctx = 32, 70
+            layer = m.layers[0]
+            layer.enable_fused_silu(bs)
+            assert layer.tp == 8 and not ({"o_proj", "down_proj"} & set(layer.strip))
+            assert layer.enable_one_copy() == 0 and not layer.one_copy            # (TP: [K/8, N] stays)
+            meta, pos, nblocks = Mo.make_decode_metadata(bs, ctx, 16, DEV)
+            ids = torch.arange(bs, device=DEV) % cfg.vocab_size
+            outs = []
+            for fused in (False, True):
+                kv = Mo.make_kv_caches(cfg, nblocks, 16, torch.float16, "auto", DEV, seed=3)
+                m.use_fused_decode = fused
+                if fused:
+                    assert layer.fused_decode_ok(bs)
+                outs.append(m(ids, pos, kv, meta).float())
+        assert torch.isfinite(outs[1]).all()
+        torch.testing.assert_close(outs[0], outs[1], atol=2e-2, rtol=2e-2)
+    finally:
+        D.destroy_tensor_parallel()
