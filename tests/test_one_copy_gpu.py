@@ -260,3 +260,19 @@ def test_tp_shard_keeps_no_copy_its_step_never_reads(ops):
         torch.testing.assert_close(outs[0], outs[1], atol=2e-2, rtol=2e-2)
     finally:
         D.destroy_tensor_parallel()
+
+
+@pytest.mark.parametrize("K,N", [(4096, 28672), (14336, 4096)])
+def test_awq_prepacked_words_zero_offset_0(ops, K, N):
+    """The AWQ-prepacked form of the same layout (zero points without GPTQ's + 1): every strip-major entry against its
+    [K/8, N] twin, bit for bit -- prompt-sized, 33..64 rows, <= 32 rows."""
+    qw, qz, sc, g = _weights(K, N, 128, torch.float16, K + 3)
+    st = ops.wna16_strip_relayout(qw, 32, K // 128)
+    a = (torch.randn(700, K, generator=g, device=DEV) * 0.5).to(torch.float16)
+    assert torch.equal(ops.wna16_gemm_large_strip(a, st, qz, sc, 0), ops._wna16_large(a, qw, qz, sc, None, 0))
+    assert not torch.equal(ops.wna16_gemm_large_strip(a, st, qz, sc, 0), ops.wna16_gemm_large_strip(a, st, qz, sc, 1))
+    p48 = ops.wna16_pack_a(a[:48])
+    want, _ = ops.wna16_gemm_mid_packed(p48, 48, K, qw, qz, sc, 0, partials=True)
+    got, _ = ops.wna16_gemm_mid_packed(p48, 48, K, st, qz, sc, 0, partials=True, strip_m=32)
+    assert torch.equal(got, want)
+    assert torch.equal(ops.wna16_linear_strip(a[:17], st, qz, sc, 0), ops.wna16_gemm_rowmajor(a[:17], qw, qz, sc, 0))
