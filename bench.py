@@ -1235,6 +1235,25 @@ def main():
                 traffic_src = pmc.get("source")
         except Exception:
             pass
+        # The same fraction from the COMMITTED kernel trace of this command (profiles/r6_bench_one_copy_kernel_stats.csv, rocprofv3
+        # --kernel-trace --stats): averages over every launch of the run -- mostly the step's own, back to back in the graph, where
+        # a launch starts under the previous one's tail -- next to the live figure, which times each kernel on its own.  Only for
+        # the workload that trace was taken on (the default int4 line); null otherwise.
+        traced = None
+        try:
+            if dom_name == "wna16_gemm_stream_kernel" and args.model == "llama3-8b" and args.quant == "gptq" and args.batch == 32 \
+                    and tp == 1 and not args.ragged and args.ctx == 1024:
+                import csv as _csv
+                tf = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r6_bench_one_copy_kernel_stats.csv")
+                avg = [float(r["AverageNs"]) for r in _csv.DictReader(open(tf)) if "wna16_gemm_stream_kernel" in r["Name"]]
+                if len(avg) == n_members:
+                    t_us = sum(avg) / 1e3
+                    traced = {"total_us_per_layer": t_us, "avg_launch_us": t_us / n_members,
+                              "frac": dom["bytes"] / (t_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                              "source": "profiles/r6_bench_one_copy_kernel_stats.csv (committed rocprofv3 --kernel-trace --stats run of this "
+                                        "command on the round's last tree; NOT measured in this process)"}
+        except Exception:
+            traced = None
         line = {
             "metric": "output tokens/sec + HBM-roofline %, Llama-3-8B int4/fp8 @ 1/2/4/8 MI355X",
             "value": tokens / elapsed,
@@ -1274,7 +1293,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom_name, "members": dom["members"], "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "bytes_per_launch": dom["bytes"] / n_members, "avg_launch_us": dom["seconds"] / n_members * 1e6,
-                         "total_us_per_layer": dom["seconds"] * 1e6,
+                         "total_us_per_layer": dom["seconds"] * 1e6, "traced": traced,
                          # the whole step against the same peak (the headline fraction; `frac` is the dominant kernel's)
                          "step_frac": step_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS},
             "roofline_all": {k: {"GBps": v["bytes"] / v["seconds"] / 1e9, "frac": v["bytes"] / v["seconds"] / 1e9 / HBM_PEAK_GBS,
