@@ -820,6 +820,114 @@ __global__ void reshape_and_cache_kernel(const typename T::storage* __restrict__
   }
 }
 
+// Prompt-sized form (round 6): one workgroup per (16 consecutive tokens, KV head).  The per-token kernel above stores every
+// VALUE element on its own -- the V layout [blocks, Hkv, hd, block] puts a token's 128 values of a head into 128 different
+// 32-byte rows: 8.4 M two-byte stores for an 8192-token Llama-3-8B prompt, 55 us per layer (profiles/r6_prefill_e2e_trace.txt).
+// Here the 16 tokens' K and V rows of one head are staged through LDS (16-byte loads, 256 B per token and head) and, when the
+// 16 slots are 16 consecutive places of ONE block -- what a prompt's slot mapping is, block after block -- leave as whole
+// 16-byte pieces: K [hd/x][block][x]: piece (d/x, token) -> 256 contiguous bytes per d/x over the 16 tokens; V [hd][block]:
+// a row's 16 tokens are 32 (fp8: 16) contiguous bytes.  Any other window (a sequence boundary, padding, a shuffled mapping)
+// takes the element-wise stores of the kernel above for its tokens.  Same conversions, same bits.  2-byte inputs only.
+template <typename T, int KV>
+__global__ __launch_bounds__(256) void reshape_and_cache_window_kernel(
+    const typename T::storage* __restrict__ key, const typename T::storage* __restrict__ value, void* __restrict__ key_cache,
+    void* __restrict__ value_cache, const int64_t* __restrict__ slot_mapping, int64_t num_tokens, int num_kv_heads, int head_size,
+    int block_size, int64_t key_stride, int64_t value_stride, float k_scale, float v_scale) {
+  static_assert(sizeof(typename T::storage) == 2, "2-byte activations");
+  using S = typename T::storage;
+  constexpr int W = 16;                               // tokens per window
+  constexpr int X = KV == 0 ? 8 : 16;                 // elements per 16-byte cache piece
+  extern __shared__ __attribute__((aligned(16))) unsigned char rc_smem[];
+  const int D = head_size, P = D + 8;                 // LDS row pitch in elements (+ 16 B: the column reads spread over the banks)
+  S* sk = reinterpret_cast<S*>(rc_smem);
+  S* sv = sk + W * P;
+  __shared__ int64_t s_slot[W];
+  __shared__ int s_fast;
+  const int64_t t0 = (int64_t)blockIdx.x * W;
+  const int h = blockIdx.y;
+  const int nt = (int)(num_tokens - t0 < W ? num_tokens - t0 : W);
+  if (threadIdx.x < W) s_slot[threadIdx.x] = threadIdx.x < nt ? slot_mapping[t0 + threadIdx.x] : -1;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    bool f = nt == W && s_slot[0] >= 0 && (s_slot[0] % block_size) + W <= block_size;
+    for (int j = 1; j < W && f; ++j) f = s_slot[j] == s_slot[0] + j;
+    s_fast = f ? 1 : 0;
+  }
+  // stage: 16-byte pieces of the tokens' K / V rows of this head
+  const int pieces = D / 8;
+  for (int i = threadIdx.x; i < nt * pieces; i += blockDim.x) {
+    const int j = i / pieces, pc = i % pieces;
+    *reinterpret_cast<u32x4*>(sk + j * P + pc * 8) = *reinterpret_cast<const u32x4*>(key + (t0 + j) * key_stride + h * D + pc * 8);
+    *reinterpret_cast<u32x4*>(sv + j * P + pc * 8) = *reinterpret_cast<const u32x4*>(value + (t0 + j) * value_stride + h * D + pc * 8);
+  }
+  __syncthreads();
+  auto cvt = [](S e, float scale) -> uint8_t {        // cache_kernels.cu:198-201 (the division, not a reciprocal)
+    return (uint8_t)f32x2_to_fp8<KV == 2>(T::to_f32(e) / scale, 0.f);
+  };
+  if (s_fast) {
+    const int64_t blk = s_slot[0] / block_size;
+    const int off0 = (int)(s_slot[0] % block_size);
+    // K: piece (px = d / X, token j) -> ((blk * H + h) * (D / X) + px) * block + off0 + j, X elements each
+    for (int i = threadIdx.x; i < (D / X) * W; i += blockDim.x) {
+      const int px = i / W, j = i % W;
+      const int64_t dst = (((blk * num_kv_heads + h) * (D / X) + px) * block_size + off0 + j) * X;
+      if constexpr (KV == 0) {
+        *reinterpret_cast<u32x4*>((S*)key_cache + dst) = *reinterpret_cast<const u32x4*>(sk + j * P + px * 8);
+      } else {
+        uint32_t w[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          uint32_t v = 0;
+#pragma unroll
+          for (int b = 0; b < 4; ++b) v |= (uint32_t)cvt(sk[j * P + px * 16 + 4 * q + b], k_scale) << (8 * b);
+          w[q] = v;
+        }
+        *reinterpret_cast<u32x4*>((uint8_t*)key_cache + dst) = u32x4{w[0], w[1], w[2], w[3]};
+      }
+    }
+    // V: row d -> ((blk * H + h) * D + d) * block + off0 .. + 15: 16 tokens = 32 B (two 16-byte pieces) / fp8: 16 B (one)
+    constexpr int VP = KV == 0 ? 2 : 1;               // 16-byte pieces per row
+    for (int i = threadIdx.x; i < D * VP; i += blockDim.x) {
+      const int d = i / VP, half = i % VP;
+      const int64_t dst = ((blk * num_kv_heads + h) * D + d) * block_size + off0;
+      if constexpr (KV == 0) {
+        uint32_t w[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          w[q] = (uint32_t)sv[(half * 8 + 2 * q) * P + d] | ((uint32_t)sv[(half * 8 + 2 * q + 1) * P + d] << 16);
+        *reinterpret_cast<u32x4*>((S*)value_cache + dst + half * 8) = u32x4{w[0], w[1], w[2], w[3]};
+      } else {
+        uint32_t w[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          uint32_t v = 0;
+#pragma unroll
+          for (int b = 0; b < 4; ++b) v |= (uint32_t)cvt(sv[(4 * q + b) * P + d], v_scale) << (8 * b);
+          w[q] = v;
+        }
+        *reinterpret_cast<u32x4*>((uint8_t*)value_cache + dst) = u32x4{w[0], w[1], w[2], w[3]};
+      }
+    }
+    return;
+  }
+  // any other window: the per-token kernel's stores for this head
+  for (int i = threadIdx.x; i < nt * D; i += blockDim.x) {
+    const int j = i / D, d = i % D;
+    const int64_t slot = s_slot[j];
+    if (slot < 0) continue;                           // padding (cache_kernels.cu:163-166)
+    const int64_t blk = slot / block_size, off = slot % block_size;
+    const int64_t kdst = (((blk * num_kv_heads + h) * (D / X) + d / X) * block_size + off) * X + d % X;
+    const int64_t vdst = ((blk * num_kv_heads + h) * D + d) * block_size + off;
+    if constexpr (KV == 0) {
+      ((S*)key_cache)[kdst] = sk[j * P + d];
+      ((S*)value_cache)[vdst] = sv[j * P + d];
+    } else {
+      ((uint8_t*)key_cache)[kdst] = cvt(sk[j * P + d], k_scale);
+      ((uint8_t*)value_cache)[vdst] = cvt(sv[j * P + d], v_scale);
+    }
+  }
+}
+
 template <typename T, int KV, bool TO_FP8>
 __global__ void convert_fp8_kernel(void* __restrict__ dst, const void* __restrict__ src, int64_t n,
                                    float scale) {
@@ -1191,6 +1299,26 @@ extern "C" int aphro_reshape_and_cache(const void* key, const void* value, void*
   APHRO_CHECK(x > 0 && head_size % x == 0, "reshape_and_cache: head_size %% x != 0");
   if (num_tokens == 0) return APHRO_OK;
   int n = num_kv_heads * head_size;
+  // prompt-sized calls on 2-byte activations: the 16-token window form (whole 16-byte stores where the slots run through a block)
+  const int xe = kv_dtype == APHRO_KV_AUTO ? 8 : 16;
+  if (num_tokens >= 64 && (dtype == APHRO_F16 || dtype == APHRO_BF16) && x == xe && head_size % 16 == 0 && head_size <= 512 &&
+      block_size % 16 == 0 && key_stride % 8 == 0 && value_stride % 8 == 0 && ((uintptr_t)key % 16) == 0 && ((uintptr_t)value % 16) == 0 &&
+      ((uintptr_t)key_cache % 16) == 0 && ((uintptr_t)value_cache % 16) == 0) {
+    const dim3 wgrid((unsigned)((num_tokens + 15) / 16), (unsigned)num_kv_heads);
+    const size_t lds = (size_t)2 * 16 * (head_size + 8) * 2;
+#define APHRO_RCW(TT, KVV)                                                                             \
+    hipLaunchKernelGGL((reshape_and_cache_window_kernel<TT, KVV>), wgrid, dim3(256), lds, st,          \
+                       (const typename TT::storage*)key, (const typename TT::storage*)value, key_cache, \
+                       value_cache, slot_mapping, num_tokens, num_kv_heads, head_size, block_size, key_stride, value_stride, k_scale, v_scale)
+#define APHRO_RCW_T(KVV) if (dtype == APHRO_F16) APHRO_RCW(Half, KVV); else APHRO_RCW(BFloat, KVV);
+    if (kv_dtype == APHRO_KV_AUTO) { APHRO_RCW_T(0) }
+    else if (kv_dtype == APHRO_KV_FP8_E4M3) { APHRO_RCW_T(1) }
+    else { APHRO_RCW_T(2) }
+#undef APHRO_RCW_T
+#undef APHRO_RCW
+    APHRO_LAUNCH_CHECK();
+    return APHRO_OK;
+  }
   dim3 grid((unsigned)num_tokens), block((unsigned)(n < 512 ? (n + 63) / 64 * 64 : 512));
 #define APHRO_RC(TT, KVV)                                                                           \
   hipLaunchKernelGGL((reshape_and_cache_kernel<TT, KVV>), grid, block, 0, st,                        \

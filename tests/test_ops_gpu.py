@@ -509,6 +509,49 @@ def test_reshape_and_cache(ops, kv_cache_dtype, dtype):
 
 @pytest.mark.parametrize("kv_cache_dtype", ["auto", "fp8", "fp8_e5m2"])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("Hkv,D,BS", [(8, 128, 16), (2, 64, 32), (3, 96, 16)])
+def test_reshape_and_cache_prompt_sized(ops, kv_cache_dtype, dtype, Hkv, D, BS):
+    """>= 64 tokens: the 16-token window form (whole 16-byte stores where a window's slots run through one block) against the
+    oracle, bit for bit -- three prompts through a shuffled block table (one continuing at position 5 of a block: every window
+    of it straddles two blocks), a padded token inside a run, a window that crosses a sequence boundary, a ragged tail."""
+    rng = np.random.default_rng(Hkv * 100 + D + BS)
+    lens, starts = [150, 37, 83], [0, 5, 0]              # tokens per prompt, first position (a chunked-prefill continuation)
+    nblk = [(st + ln + BS - 1) // BS for ln, st in zip(lens, starts)]
+    NB = sum(nblk) + 3
+    table = rng.permutation(NB)[:sum(nblk)]
+    slots, b0 = [], 0
+    for ln, st, nb in zip(lens, starts, nblk):
+        pos = np.arange(st, st + ln)
+        slots.append(table[b0 + pos // BS].astype(np.int64) * BS + pos % BS)
+        b0 += nb
+    slots = np.concatenate(slots)
+    slots[40] = -1                                        # padding inside an otherwise whole window
+    T = len(slots)
+    cdt = dtype if kv_cache_dtype == "auto" else torch.uint8
+    x = 16 // torch.tensor([], dtype=cdt).element_size()
+    kc = torch.zeros(NB, Hkv, D // x, BS, x, dtype=cdt, device=DEV)
+    vc = torch.zeros(NB, Hkv, D, BS, dtype=cdt, device=DEV)
+    qkv = t(rng.standard_normal((T, 3 * Hkv * D)).astype(np.float32), dtype)
+    key = qkv[:, Hkv * D:2 * Hkv * D].view(T, Hkv, D)      # strided views like the model's
+    val = qkv[:, 2 * Hkv * D:].view(T, Hkv, D)
+    ks, vs = (1.0, 1.0) if kv_cache_dtype == "auto" else (0.37, 0.5)
+    ops.reshape_and_cache(key, val, kc, vc, t(slots), kv_cache_dtype, ks, vs)
+    kc_ref = np.zeros(kc.shape, dtype=np.float32 if kv_cache_dtype == "auto" else np.uint8)
+    vc_ref = np.zeros(vc.shape, dtype=kc_ref.dtype)
+    oa.reshape_and_cache(key.float().cpu().numpy(), val.float().cpu().numpy(), kc_ref, vc_ref, slots, kv_cache_dtype, ks, vs)
+    got_k = kc.float().cpu().numpy() if kv_cache_dtype == "auto" else kc.cpu().numpy()
+    got_v = vc.float().cpu().numpy() if kv_cache_dtype == "auto" else vc.cpu().numpy()
+    np.testing.assert_array_equal(got_k, kc_ref)
+    np.testing.assert_array_equal(got_v, vc_ref)
+    # and the same bits as the per-token form (what a call of < 64 tokens runs), chunk by chunk
+    kc2, vc2 = torch.zeros_like(kc), torch.zeros_like(vc)
+    for c0 in range(0, T, 50):
+        ops.reshape_and_cache(key[c0:c0 + 50], val[c0:c0 + 50], kc2, vc2, t(slots[c0:c0 + 50]), kv_cache_dtype, ks, vs)
+    assert torch.equal(kc2, kc) and torch.equal(vc2, vc)
+
+
+@pytest.mark.parametrize("kv_cache_dtype", ["auto", "fp8", "fp8_e5m2"])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_reshape_and_cache_flash(ops, kv_cache_dtype, dtype):
     rng = np.random.default_rng(21)
     T, H, D, BS, NB = 11, 3, 64, 16, 4
