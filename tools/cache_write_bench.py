@@ -41,4 +41,5 @@ for kv in ("auto", "fp8"):
             ops.reshape_and_cache(k[c0:c0 + 63], v[c0:c0 + 63], kc, vc, slots[c0:c0 + 63], kv, 0.5, 0.5)
     t_old = timed(g.replay)
     mb = T * H * D * 2 * (2 + (2 if kv == "auto" else 1)) / 1e6
-    print(f"kv_cache={kv}: window form {t_new:.1f} us ({mb / t_new * 1e-3 * 1e3:.0f} GB/s)   per-token form in 63-token calls (graph) {t_old:.1f} us")
+    print(f"kv_cache={kv}: window form {t_new:.1f} us ({mb / t_new:.2f} TB/s of K/V read + cache written)   the per-token form, same tokens in 131 calls of 63 "
+          f"(graph; launch-bound -- the one-call figure of the per-token form is the trace's 55.3 us, profiles/r6_prefill_e2e_trace.txt) {t_old:.1f} us")

@@ -17,4 +17,6 @@ if __name__ == "__main__":
             print(f"  {n:<70} calls {int(r['Calls']):>5}  {float(r['TotalDurationNs']) / 5 / 1e6:7.2f} ms/pass  {float(r['AverageNs']) / 1e3:8.1f} us avg")
     else:
         import bench
-        print(bench.prefill_e2e_section(which=("int4",), library=False))
+        which = tuple(sys.argv[1].split(",")) if len(sys.argv) > 1 else ("int4",)
+        out = bench.prefill_e2e_section(which=which, library=False)
+        print({k: round(v["ms"], 2) for k, v in out.items()})
