@@ -181,6 +181,43 @@ __global__ void per_token_quant_kernel(uint8_t* __restrict__ out, float* __restr
   }
 }
 
+// Prompt-sized form (round 6): one WAVE per token, the row held in registers between the absmax and the quantisation -- one read
+// of the row, no workgroup barrier (the form above reads it twice around two __syncthreads: 1.9 TB/s at 8192 x 4096,
+// profiles/r6_prefill_e2e_trace.txt).  Same loads (load4), same max (order-free), same division (pack4_e4m3): same bits.
+// hidden % 4 == 0, hidden <= 256 * NQ.
+template <typename T, int NQ>
+__global__ __launch_bounds__(256) void per_token_quant_wave_kernel(uint8_t* __restrict__ out, float* __restrict__ scales,
+                                                                   const typename T::storage* __restrict__ in,
+                                                                   const float* __restrict__ scale_ub, int hidden, int64_t tokens) {
+  const int lane = threadIdx.x & 63;
+  const int64_t tok = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tok >= tokens) return;
+  const typename T::storage* x = in + tok * hidden;
+  const int quads = hidden >> 2;
+  float v[NQ][4];
+  float m = 0.f;
+#pragma unroll
+  for (int j = 0; j < NQ; ++j) {
+    const int q = j * 64 + lane;
+    if (q < quads) {
+      load4<T>(x + 4 * q, v[j]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) m = __builtin_fmaxf(m, __builtin_fabsf(v[j][e]));
+    }
+  }
+  m = wave_max(m);
+  if (scale_ub) m = __builtin_fminf(m, *scale_ub);
+  const float min_sf = 1.0f / (FP8_MAX * 512.f);
+  const float s = __builtin_fmaxf(m / FP8_MAX, min_sf);
+  if (lane == 0) scales[tok] = s;
+  uint32_t* o = reinterpret_cast<uint32_t*>(out + tok * hidden);
+#pragma unroll
+  for (int j = 0; j < NQ; ++j) {
+    const int q = j * 64 + lane;
+    if (q < quads) o[q] = pack4_e4m3(v[j], s, false);   // division: matches FBGemm (common.cu:243)
+  }
+}
+
 }  // namespace aphro
 
 using namespace aphro;
@@ -252,6 +289,23 @@ extern "C" int aphro_dynamic_per_token_scaled_fp8_quant(void* out, const void* i
                                                         int dtype, void* stream) {
   APHRO_CHECK(dtype >= APHRO_F16 && dtype <= APHRO_F32, "scaled_fp8_quant: unsupported dtype %d", dtype);
   if (M == 0 || K == 0) return APHRO_OK;
+  // prompt-sized calls: one wave per token, the row in registers (decode-sized calls keep a whole workgroup per row: latency)
+  if (M >= 256 && dtype != APHRO_F32 && K % 4 == 0 && K <= 8192 && ((uintptr_t)input % 8) == 0 && ((uintptr_t)out % 4) == 0) {
+    const dim3 wgrid((unsigned)((M + 3) / 4));
+#define CALLW(TT)                                                                                                  \
+    if (K <= 1024) hipLaunchKernelGGL((per_token_quant_wave_kernel<TT, 4>), wgrid, dim3(256), 0, (hipStream_t)stream,  \
+                                      (uint8_t*)out, scales, (const typename TT::storage*)input, scale_ub, (int)K, M); \
+    else if (K <= 2048) hipLaunchKernelGGL((per_token_quant_wave_kernel<TT, 8>), wgrid, dim3(256), 0, (hipStream_t)stream, \
+                                      (uint8_t*)out, scales, (const typename TT::storage*)input, scale_ub, (int)K, M); \
+    else if (K <= 4096) hipLaunchKernelGGL((per_token_quant_wave_kernel<TT, 16>), wgrid, dim3(256), 0, (hipStream_t)stream, \
+                                      (uint8_t*)out, scales, (const typename TT::storage*)input, scale_ub, (int)K, M); \
+    else hipLaunchKernelGGL((per_token_quant_wave_kernel<TT, 32>), wgrid, dim3(256), 0, (hipStream_t)stream,           \
+                            (uint8_t*)out, scales, (const typename TT::storage*)input, scale_ub, (int)K, M)
+    if (dtype == APHRO_F16) { CALLW(Half); } else { CALLW(BFloat); }
+#undef CALLW
+    APHRO_LAUNCH_CHECK();
+    return APHRO_OK;
+  }
   int threads = K >= 4096 ? 1024 : (K >= 1024 ? 256 : 64);
 #define CALL(TT)                                                                                          \
   hipLaunchKernelGGL((per_token_quant_kernel<TT>), dim3((unsigned)M), dim3(threads), 0, (hipStream_t)stream, \

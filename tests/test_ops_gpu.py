@@ -384,6 +384,29 @@ def test_scaled_fp8_quant_bit_exact(ops, dtype, M, K):
     assert q.shape == (M + 5, K)
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,K", [(256, 64), (301, 1028), (1000, 4096), (257, 2052), (300, 8192), (512, 6144)])
+def test_per_token_fp8_quant_prompt_sized(ops, dtype, M, K):
+    """From 256 rows the per-token quantisation runs one wave per row with the row in registers: against the oracle, bit for
+    bit (scales and bytes), with and without the upper bound, on widths that leave lanes idle and a ragged last workgroup; an
+    all-zero row takes the floor scale; and == the workgroup-per-row form on the same rows (a call of < 256 rows)."""
+    rng = np.random.default_rng(M + K)
+    x = ((rng.random((M, K)) - 0.5) * 60).astype(np.float32)
+    x[0] *= 1e-4
+    x[5] = 0.0
+    x[7, 3] = 3e4
+    xt = t(x, dtype)
+    xr = xt.float().cpu().numpy()
+    for ub in (None, 3.0):
+        q, s = ops.scaled_fp8_quant(xt, scale_ub=None if ub is None else torch.tensor([ub], device=DEV), use_per_token_if_dynamic=True)
+        rq, rs = of8.dynamic_per_token_scaled_fp8_quant(xr) if ub is None else of8.dynamic_per_token_scaled_fp8_quant(xr, ub)
+        np.testing.assert_array_equal(s.cpu().numpy(), rs)
+        np.testing.assert_array_equal(q.view(torch.uint8).cpu().numpy(), rq)
+    q2 = torch.cat([ops.scaled_fp8_quant(xt[r0:r0 + 200], use_per_token_if_dynamic=True)[0].view(torch.uint8) for r0 in range(0, M, 200)], 0)
+    q, _ = ops.scaled_fp8_quant(xt, use_per_token_if_dynamic=True)
+    assert torch.equal(q.view(torch.uint8), q2)
+
+
 @pytest.mark.parametrize("M", [1, 16, 33, 64, 90])
 @pytest.mark.parametrize("K,N", [(256, 64), (1024, 256), (4096, 32)])
 @pytest.mark.parametrize("per_token,per_channel", [(False, False), (True, True)])
